@@ -1,0 +1,559 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz by running the REFERENCE's own code (imported
+read-only from /root/reference through tests/ref_shim.py) on seeded inputs.
+
+The reference ships no tests or golden vectors, so these
+fixtures are what pins the oracle (oracle/) and, through it, the HIP path.
+Re-run:  python tests/golden/make_golden.py        (needs /root/reference)
+"""
+import os
+import random
+import zlib
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import ref_shim  # noqa: E402
+import fake_envs  # noqa: E402
+
+ref = ref_shim.load()
+torch.set_num_threads(1)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+# --------------------------------------------------------------------------- replay
+from golden.make_golden_cases import UNIFORM_CASES, PER_CASES, stream as _stream  # noqa: E402
+
+
+def gen_uniform():
+    out = {}
+    for name, mem, b, h, n, disc, shape, kind, t_len, cps in UNIFORM_CASES:
+        rs = np.random.RandomState(1000 + ord(name))
+        states, actions, rewards, masks = _stream(rs, t_len, shape, kind, 4, 0.1)
+        replay = ref.UniformReplay(memory_size=mem, batch_size=b, n_step=n, discount=disc, history_length=h)
+        accepted = []
+        orig = replay.construct_transition
+
+        def logged(index, _orig=orig, _acc=accepted):
+            tr = _orig(index)
+            if tr is not None:
+                _acc.append(index)
+            return tr
+
+        replay.construct_transition = logged
+        np.random.seed(2000 + ord(name))
+        for t in range(t_len):
+            replay.feed(dict(state=states[t][None], action=actions[t:t + 1], reward=[rewards[t]],
+                             mask=masks[t:t + 1]))
+            if t in cps:
+                del accepted[:]
+                tr = replay.sample()
+                k = "%s_t%d_" % (name, t)
+                out[k + "idx"] = np.asarray(accepted, dtype=np.int64)
+                out[k + "state"], out[k + "action"] = tr.state, tr.action
+                out[k + "reward"], out[k + "next_state"], out[k + "mask"] = tr.reward, tr.next_state, tr.mask
+                out[k + "pos_size"] = np.asarray([replay.pos, replay.size()], dtype=np.int64)
+        out[name + "_rng_tail"] = np.random.randint(0, 1 << 30, size=4)  # RNG stream position check
+    save("uniform_replay", **out)
+
+
+def gen_prioritized():
+    out = {}
+    for name, mem, b, h, n, disc, shape, kind, t_len, every in PER_CASES:
+        rs = np.random.RandomState(3000 + ord(name))
+        states, actions, rewards, masks = _stream(rs, t_len, shape, kind, 4, 0.1)
+        replay = ref.PrioritizedReplay(memory_size=mem, batch_size=b, n_step=n, discount=disc, history_length=h)
+        random.seed(4000 + ord(name))
+        np.random.seed(4000 + ord(name))
+        k_samples = 0
+        for t in range(t_len):
+            replay.feed(dict(state=states[t][None], action=actions[t:t + 1], reward=[rewards[t]],
+                             mask=masks[t:t + 1]))
+            if t >= h + n + 6 and t % every == 0:
+                tr = replay.sample()
+                k = "%s_s%d_" % (name, k_samples)
+                out[k + "t"] = np.asarray(t)
+                for f in ("state", "action", "reward", "next_state", "mask", "sampling_prob", "idx"):
+                    out[k + f] = getattr(tr, f)
+                # agent side (DQN_agent.py:121-123): fp32 priorities, zip(idx, prio)
+                loss = torch.from_numpy(rs.standard_normal(b).astype(np.float32)) * 2
+                prio = loss.abs().add(0.01).pow(0.5)
+                idxs = ref.tensor(tr.idx).long()
+                out[k + "prio"] = ref.to_np(prio)
+                replay.update_priorities(zip(ref.to_np(idxs), ref.to_np(prio)))
+                out[k + "tree"] = replay.tree.tree.copy()
+                out[k + "max_priority"] = np.asarray(float(replay.max_priority))
+                k_samples += 1
+        out[name + "_n_samples"] = np.asarray(k_samples)
+        out[name + "_tree_final"] = replay.tree.tree.copy()
+        out[name + "_rng_tail"] = np.asarray([random.random() for _ in range(3)])
+    save("prioritized_replay", **out)
+
+
+def gen_sumtree():
+    """Raw SumTree ops incl. the pending-idx gating and duplicate handling."""
+    out = {}
+    for cap in (8, 13, 50):
+        rs = np.random.RandomState(cap)
+        tree = ref.SumTree(cap)
+        log = []
+        for step in range(4 * cap):
+            op = rs.randint(0, 3)
+            if op == 0 or tree.n_entries < 2:
+                p = np.float32(rs.uniform(0.1, 4.0))
+                tree.add(p, None)
+                log.append((0, float(p), 0.0, -1))
+            elif op == 1:
+                s = rs.uniform(0, tree.total())
+                idx, p, didx = tree.get(s)
+                log.append((1, float(s), float(p), idx))
+            else:
+                idx = int(rs.randint(cap - 1, 2 * cap - 1))
+                p = np.float32(rs.uniform(0.1, 4.0))
+                tree.update(idx, p)
+                log.append((2, float(p), 0.0, idx))
+        out["cap%d_log" % cap] = np.asarray(log, dtype=np.float64)
+        out["cap%d_tree" % cap] = tree.tree.copy()
+        out["cap%d_pending" % cap] = np.asarray(sorted(tree.pending_idx), dtype=np.int64)
+    save("sumtree", **out)
+
+
+# --------------------------------------------------------------------------- losses
+class _Obj:
+    pass
+
+
+class _FakeNet:
+    """Returns fixed (leaf) tensors per call, in order -- lets the reference's
+    compute_loss run on hand-made network outputs so grads w.r.t. them are golden."""
+
+    def __init__(self, outs):
+        self.outs = list(outs)
+        self.k = 0
+
+    def __call__(self, x):
+        o = self.outs[self.k % len(self.outs)]
+        self.k += 1
+        return o
+
+
+def _cfg(**kw):
+    c = ref.Config()
+    c.state_normalizer = ref.RescaleNormalizer()
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _transitions(rs, b, a, per=False):
+    state = rs.standard_normal((b, 3)).astype(np.float32)
+    tr = dict(state=state, action=rs.randint(0, a, size=b).astype(np.int64),
+              reward=np.sign(rs.standard_normal(b)), next_state=state + 1,
+              mask=(rs.rand(b) > 0.2).astype(np.int32))
+    if per:
+        p = rs.uniform(0.001, 0.2, size=b)
+        return ref.PrioritizedTransition(sampling_prob=p, idx=rs.randint(40, 90, size=b).astype(np.int64), **tr)
+    return ref.Transition(**tr)
+
+
+def gen_dqn_loss():
+    out = {}
+    for tag, b, a, n_step, double_q in (("b32a4", 32, 4, 1, False), ("b10a2n3", 10, 2, 3, False),
+                                         ("b32a4dq", 32, 4, 1, True), ("b7a18", 7, 18, 1, True)):
+        rs = np.random.RandomState(zlib.crc32(tag.encode()) % 10000)
+        tr = _transitions(rs, b, a, per=True)
+        q = torch.tensor(rs.standard_normal((b, a)).astype(np.float32), requires_grad=True)
+        q_next_t = torch.tensor(rs.standard_normal((b, a)).astype(np.float32))
+        q_next_o = torch.tensor(rs.standard_normal((b, a)).astype(np.float32))
+        agent = _Obj()
+        agent.config = _cfg(discount=0.99, n_step=n_step, double_q=double_q)
+        agent.target_network = _FakeNet([dict(q=q_next_t)])
+        # online net is called for next_states first (double_q) then for states
+        agent.network = _FakeNet([dict(q=q_next_o), dict(q=q)] if double_q else [dict(q=q)])
+        loss_vec = ref.DQNAgent.compute_loss(agent, tr)
+        # PER branch exactly as DQN_agent.py:120-127
+        eps, alpha, beta = 0.01, 0.5, 0.6
+        prio = loss_vec.abs().add(eps).pow(alpha)
+        sp = ref.tensor(tr.sampling_prob)
+        w = sp.mul(sp.size(0)).add(1e-6).pow(-beta)
+        w = w / w.max()
+        loss_plain = ref.DQNAgent.reduce_loss(agent, loss_vec)
+        loss_per = ref.DQNAgent.reduce_loss(agent, loss_vec.mul(w))
+        g_plain, = torch.autograd.grad(loss_plain, q, retain_graph=True)
+        g_per, = torch.autograd.grad(loss_per, q)
+        k = tag + "_"
+        out.update({k + "q": q.detach().numpy(), k + "q_next_t": q_next_t.numpy(), k + "q_next_o": q_next_o.numpy(),
+                    k + "action": tr.action, k + "reward": tr.reward, k + "mask": tr.mask,
+                    k + "sampling_prob": tr.sampling_prob, k + "cfg": np.asarray([0.99, n_step, double_q, eps, alpha, beta]),
+                    k + "loss_vec": loss_vec.detach().numpy(), k + "loss": loss_plain.detach().numpy(),
+                    k + "grad_q": g_plain.numpy(), k + "prio": prio.detach().numpy(), k + "w": w.numpy(),
+                    k + "loss_per": loss_per.detach().numpy(), k + "grad_q_per": g_per.numpy()})
+    save("dqn_loss", **out)
+
+
+def gen_c51_loss():
+    out = {}
+    for tag, b, a, n_atoms, n_step, double_q in (("b32a4", 32, 4, 51, 1, False), ("b8a3n3dq", 8, 3, 51, 3, True),
+                                                 ("b5a6at21", 5, 6, 21, 1, False)):
+        rs = np.random.RandomState(zlib.crc32(tag.encode()) % 10000)
+        tr = _transitions(rs, b, a)
+        logits = torch.tensor(rs.standard_normal((b, a, n_atoms)).astype(np.float32), requires_grad=True)
+        lt = torch.tensor(rs.standard_normal((b, a, n_atoms)).astype(np.float32) * 2)
+        lo = torch.tensor(rs.standard_normal((b, a, n_atoms)).astype(np.float32) * 2)
+        import torch.nn.functional as F
+        mk = lambda z: dict(prob=F.softmax(z, dim=-1), log_prob=F.log_softmax(z, dim=-1))
+        agent = _Obj()
+        vmin, vmax = -10.0, 10.0
+        agent.config = _cfg(discount=0.99, n_step=n_step, double_q=double_q, categorical_v_min=vmin,
+                            categorical_v_max=vmax, categorical_n_atoms=n_atoms)
+        agent.atoms = ref.tensor(np.linspace(vmin, vmax, n_atoms))
+        agent.delta_atom = (vmax - vmin) / float(n_atoms - 1)
+        agent.batch_indices = ref.range_tensor(b)
+        agent.target_network = _FakeNet([mk(lt)])
+        agent.network = _FakeNet([mk(lo), mk(logits)] if double_q else [mk(logits)])
+        kl = ref.CategoricalDQNAgent.compute_loss(agent, tr)
+        loss = ref.CategoricalDQNAgent.reduce_loss(agent, kl)
+        g, = torch.autograd.grad(loss, logits)
+        k = tag + "_"
+        out.update({k + "logits": logits.detach().numpy(), k + "logits_next_t": lt.numpy(), k + "logits_next_o": lo.numpy(),
+                    k + "action": tr.action, k + "reward": tr.reward, k + "mask": tr.mask,
+                    k + "cfg": np.asarray([0.99, n_step, double_q, vmin, vmax, n_atoms]),
+                    k + "kl": kl.detach().numpy(), k + "loss": loss.detach().numpy(), k + "grad_logits": g.numpy()})
+    save("c51_loss", **out)
+
+
+def gen_qr_loss():
+    out = {}
+    for tag, b, a, nq, n_step in (("b32a4", 32, 4, 200, 1), ("b6a3q17n3", 6, 3, 17, 3)):
+        rs = np.random.RandomState(zlib.crc32(tag.encode()) % 10000)
+        tr = _transitions(rs, b, a)
+        theta = torch.tensor(rs.standard_normal((b, a, nq)).astype(np.float32), requires_grad=True)
+        theta_t = torch.tensor(rs.standard_normal((b, a, nq)).astype(np.float32) * 1.5)
+        agent = _Obj()
+        agent.config = _cfg(discount=0.99, n_step=n_step, num_quantiles=nq)
+        agent.batch_indices = ref.range_tensor(b)
+        agent.cumulative_density = ref.tensor((2 * np.arange(nq) + 1) / (2.0 * nq)).view(1, -1)
+        agent.target_network = _FakeNet([dict(quantile=theta_t)])
+        agent.network = _FakeNet([dict(quantile=theta)])
+        lv = ref.QuantileRegressionDQNAgent.compute_loss(agent, tr)
+        loss = ref.QuantileRegressionDQNAgent.reduce_loss(agent, lv)
+        g, = torch.autograd.grad(loss, theta)
+        k = tag + "_"
+        out.update({k + "theta": theta.detach().numpy(), k + "theta_next_t": theta_t.numpy(),
+                    k + "action": tr.action, k + "reward": tr.reward, k + "mask": tr.mask,
+                    k + "cfg": np.asarray([0.99, n_step, nq]),
+                    k + "loss_vec": lv.detach().numpy(), k + "loss": loss.detach().numpy(), k + "grad_theta": g.numpy()})
+    save("qr_loss", **out)
+
+
+# --------------------------------------------------------------------------- full DQN update on NatureConv
+def _load_numpy_params(module, shapes, seed):
+    p = fake_envs.numpy_params(shapes, seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    return p
+
+
+def gen_dqn_nature_update():
+    """One full reference DQN update (DQN_agent.py:114-134) on VanillaNet(NatureConvBody):
+    forward q, loss, every gradient, clip, centered RMSprop (examples.py:67-68).
+    Weights come from fake_envs.numpy_params so only seeds are stored."""
+    out = {}
+    b, a = 8, 4
+    rs = np.random.RandomState(77)
+    net = ref.VanillaNet(a, ref.NatureConvBody())
+    tgt = ref.VanillaNet(a, ref.NatureConvBody())
+    _load_numpy_params(net, fake_envs.nature_vanilla_shapes(a), seed=11)
+    _load_numpy_params(tgt, fake_envs.nature_vanilla_shapes(a), seed=12)
+    state = rs.randint(0, 256, size=(b, 4, 84, 84)).astype(np.uint8)
+    next_state = rs.randint(0, 256, size=(b, 4, 84, 84)).astype(np.uint8)
+    tr = ref.Transition(state=state, action=rs.randint(0, a, size=b).astype(np.int64),
+                        reward=np.sign(rs.standard_normal(b)), next_state=next_state,
+                        mask=(rs.rand(b) > 0.2).astype(np.int32))
+    agent = _Obj()
+    agent.config = _cfg(discount=0.99, n_step=1, double_q=False)
+    agent.config.state_normalizer = ref.ImageNormalizer()
+    agent.network, agent.target_network = net, tgt
+    opt = torch.optim.RMSprop(net.parameters(), lr=0.00025, alpha=0.95, eps=0.01, centered=True)
+    q0 = net(agent.config.state_normalizer(state))["q"].detach().numpy()
+    traj = []
+    for it in range(3):
+        lv = ref.DQNAgent.compute_loss(agent, tr)
+        loss = ref.DQNAgent.reduce_loss(agent, lv)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            grads = {k: p.grad.detach().numpy().copy() for k, p in net.named_parameters()}
+        gn = torch.nn.utils.clip_grad_norm_(net.parameters(), 5)
+        opt.step()
+        traj.append([float(loss.detach()), float(gn)])
+    out["state_seed"] = np.asarray(77)
+    out["q0"] = q0
+    out["action"], out["reward"], out["mask"] = tr.action, tr.reward, tr.mask
+    out["loss_gradnorm_traj"] = np.asarray(traj)
+    for k, g in grads.items():
+        if k == "body.fc4.weight":
+            out["grad_" + k + "_rows"] = g[::37].copy()  # 14 of 512 rows, all 3136 columns
+            out["grad_" + k + "_norm"] = np.asarray(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        else:
+            out["grad_" + k] = g
+    fin = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    for k, v in fin.items():
+        if k == "body.fc4.weight":
+            out["final_" + k + "_rows"] = v[::37].copy()
+        else:
+            out["final_" + k] = v
+    out["q_final"] = net(agent.config.state_normalizer(state))["q"].detach().numpy()
+    save("dqn_nature_update", **out)
+
+
+# --------------------------------------------------------------------------- optimisers
+def gen_optim():
+    out = {}
+    rs = np.random.RandomState(5)
+    shapes = [(7, 5), (5,), (3, 2, 2, 2), (130,)]
+    p0 = [rs.standard_normal(s).astype(np.float32) for s in shapes]
+    grads = [[(rs.standard_normal(s) * (3.0 if i % 2 else 0.3)).astype(np.float32) for s in shapes] for i in range(5)]
+    for j, p in enumerate(p0):
+        out["p0_%d" % j] = p
+    for i, gs in enumerate(grads):
+        for j, g in enumerate(gs):
+            out["g%d_%d" % (i, j)] = g
+    specs = {
+        "rmsprop_centered": lambda ps: torch.optim.RMSprop(ps, lr=0.00025, alpha=0.95, eps=0.01, centered=True),
+        "rmsprop_plain": lambda ps: torch.optim.RMSprop(ps, lr=1e-4, alpha=0.99, eps=1e-5),
+        "adam": lambda ps: torch.optim.Adam(ps, lr=2.5e-4, eps=0.01 / 32),
+        "adam_default": lambda ps: torch.optim.Adam(ps, 3e-4),
+    }
+    for name, mk in specs.items():
+        for clip in (5.0, 0.5):
+            ps = [torch.nn.Parameter(torch.from_numpy(p.copy())) for p in p0]
+            opt = mk(ps)
+            norms = []
+            for gs in grads:
+                opt.zero_grad()
+                for p, g in zip(ps, gs):
+                    p.grad = torch.from_numpy(g.copy())
+                norms.append(float(torch.nn.utils.clip_grad_norm_(ps, clip)))
+                opt.step()
+            for j, p in enumerate(ps):
+                out["%s_clip%g_p%d" % (name, clip, j)] = p.detach().numpy()
+            out["%s_clip%g_norms" % (name, clip)] = np.asarray(norms)
+    save("optim", **out)
+
+
+# --------------------------------------------------------------------------- on-policy: GAE, PPO, A2C
+class _Logger:
+    def info(self, *a, **k):
+        pass
+
+    def add_scalar(self, *a, **k):
+        pass
+
+    def add_histogram(self, *a, **k):
+        pass
+
+
+def _capture_storage(module_name):
+    mod = sys.modules[module_name]
+    captured = []
+    base = ref.Storage
+
+    class CapturingStorage(base):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            captured.append(self)
+
+        def extract(self, keys):
+            e = super().extract(keys)
+            self.entries = e
+            return e
+
+    mod.Storage = CapturingStorage
+    return captured, lambda: setattr(mod, "Storage", base)
+
+
+def _stack(lst, t_len):
+    return np.stack([x.detach().numpy() for x in lst[:t_len]])
+
+
+def gen_a2c():
+    out = {}
+    for tag, t_len, n_env, use_gae in (("t5n16", 5, 16, False), ("t5n16gae", 5, 16, True), ("t20n3gae", 20, 3, True)):
+        captured, restore = _capture_storage("deep_rl.agent.A2C_agent")
+        try:
+            cfg = _cfg(discount=0.99, use_gae=use_gae, gae_tau=0.95, entropy_weight=0.01, rollout_length=t_len,
+                       gradient_clip=5, num_workers=n_env, value_loss_weight=1.0)
+            cfg.reward_normalizer = ref.RescaleNormalizer()
+            agent = _Obj()
+            agent.config = cfg
+            agent.task = fake_envs.VectorTask(seed=5, state_dim=6, action_dim=3, horizon=7, num_envs=n_env)
+            torch.manual_seed(3)
+            agent.network = ref.CategoricalActorCriticNet(6, 3, ref.FCBody(6, hidden_units=(32,)))
+            p_init = {k: v.detach().numpy().copy() for k, v in agent.network.state_dict().items()}
+            agent.optimizer = torch.optim.RMSprop(agent.network.parameters(), lr=1e-3, alpha=0.99, eps=1e-5)
+            agent.total_steps = 0
+            agent.states = agent.task.reset()
+            agent.record_online_return = lambda *a, **k: None
+            ref.A2CAgent.step(agent)
+            st = captured[0]
+            k = tag + "_"
+            out[k + "cfg"] = np.asarray([0.99, 0.95, use_gae, 0.01, 1.0, 5, t_len, n_env])
+            out[k + "reward"], out[k + "mask"] = _stack(st.reward, t_len), _stack(st.mask, t_len)
+            out[k + "v"] = _stack(st.v, t_len + 1)
+            out[k + "log_pi_a"], out[k + "entropy"] = _stack(st.log_pi_a, t_len), _stack(st.entropy, t_len)
+            out[k + "action"] = _stack(st.action, t_len)
+            out[k + "adv"], out[k + "ret"] = _stack(st.advantage, t_len), _stack(st.ret, t_len)
+            for n, v in p_init.items():
+                out[k + "init_" + n] = v
+            for n, v in agent.network.state_dict().items():
+                out[k + "final_" + n] = v.detach().numpy()
+        finally:
+            restore()
+    save("a2c_step", **out)
+
+
+def gen_ppo():
+    out = {}
+    for tag, t_len, n_env, shared in (("t64n2", 64, 2, False), ("t32n4", 32, 4, False)):
+        captured, restore = _capture_storage("deep_rl.agent.PPO_agent")
+        try:
+            cfg = _cfg(discount=0.99, use_gae=True, gae_tau=0.95, entropy_weight=0.01, rollout_length=t_len,
+                       gradient_clip=0.5, num_workers=n_env, optimization_epochs=3, mini_batch_size=32,
+                       ppo_ratio_clip=0.2, target_kl=0.01, shared_repr=shared, max_steps=1e6)
+            cfg.reward_normalizer = ref.RescaleNormalizer()
+            cfg.state_normalizer = ref.RescaleNormalizer()
+            agent = _Obj()
+            agent.config = cfg
+            agent.task = fake_envs.ContinuousTask(seed=9, state_dim=5, action_dim=2, horizon=25, num_envs=n_env)
+            torch.manual_seed(4)
+            agent.network = ref.GaussianActorCriticNet(
+                5, 2, actor_body=ref.FCBody(5, hidden_units=(16, 16), gate=torch.tanh),
+                critic_body=ref.FCBody(5, hidden_units=(16, 16), gate=torch.tanh))
+            p_init = {k: v.detach().numpy().copy() for k, v in agent.network.state_dict().items()}
+            agent.actor_opt = torch.optim.Adam(agent.network.actor_params, 3e-4)
+            agent.critic_opt = torch.optim.Adam(agent.network.critic_params, 1e-3)
+            agent.total_steps = 0
+            agent.states = cfg.state_normalizer(agent.task.reset())
+            agent.record_online_return = lambda *a, **k: None
+            np.random.seed(21)
+            torch.manual_seed(22)  # action sampling stream
+            ref.PPOAgent.step(agent)
+            st = captured[0]
+            k = tag + "_"
+            out[k + "cfg"] = np.asarray([0.99, 0.95, 0.01, 0.2, 0.01, 3, 32, t_len, n_env])
+            out[k + "reward"], out[k + "mask"] = _stack(st.reward, t_len), _stack(st.mask, t_len)
+            out[k + "v"] = _stack(st.v, t_len + 1)
+            out[k + "adv"], out[k + "ret"] = _stack(st.advantage, t_len), _stack(st.ret, t_len)
+            e = st.entries
+            out[k + "ent_state"], out[k + "ent_action"] = e.state.detach().numpy(), e.action.detach().numpy()
+            out[k + "ent_log_pi_a"], out[k + "ent_ret"] = e.log_pi_a.detach().numpy(), e.ret.detach().numpy()
+            out[k + "ent_adv_normalized"] = e.advantage.detach().numpy()
+            for n, v in p_init.items():
+                out[k + "init_" + n] = v
+            for n, v in agent.network.state_dict().items():
+                out[k + "final_" + n] = v.detach().numpy()
+        finally:
+            restore()
+    save("ppo_step", **out)
+
+
+def gen_ppo_loss():
+    """PPO / A2C loss values + grads on hand-made network outputs."""
+    out = {}
+    rs = np.random.RandomState(31)
+    for tag, m in (("m64", 64), ("m256", 256), ("m5", 5)):
+        lp = torch.tensor(rs.standard_normal((m, 1)).astype(np.float32) * 0.3 - 1, requires_grad=True)
+        ent = torch.tensor(rs.uniform(0.5, 1.5, (m, 1)).astype(np.float32), requires_grad=True)
+        v = torch.tensor(rs.standard_normal((m, 1)).astype(np.float32), requires_grad=True)
+        old_lp = torch.tensor(lp.detach().numpy() + rs.standard_normal((m, 1)).astype(np.float32) * 0.3)
+        adv = torch.tensor(rs.standard_normal((m, 1)).astype(np.float32))
+        ret = torch.tensor(rs.standard_normal((m, 1)).astype(np.float32))
+        clip, ew = 0.2, 0.01
+        ratio = (lp - old_lp).exp()
+        obj = ratio * adv
+        obj_clipped = ratio.clamp(1.0 - clip, 1.0 + clip) * adv
+        policy_loss = -torch.min(obj, obj_clipped).mean() - ew * ent.mean()
+        value_loss = 0.5 * (ret - v).pow(2).mean()
+        approx_kl = (old_lp - lp).mean()
+        g = torch.autograd.grad(policy_loss + value_loss, [lp, ent, v])
+        k = tag + "_"
+        out.update({k + "lp": lp.detach().numpy(), k + "ent": ent.detach().numpy(), k + "v": v.detach().numpy(),
+                    k + "old_lp": old_lp.numpy(), k + "adv": adv.numpy(), k + "ret": ret.numpy(),
+                    k + "out": np.asarray([float(policy_loss), float(value_loss), float(approx_kl)]),
+                    k + "g_lp": g[0].numpy(), k + "g_ent": g[1].numpy(), k + "g_v": g[2].numpy()})
+    save("ppo_loss", **out)
+
+
+# --------------------------------------------------------------------------- end-to-end DQN agent, config 1
+def gen_dqn_agent_cartpole():
+    """BASELINE config 1 (examples.py:11-52, dqn_feature) on the reference's own
+    DQNAgent/DQNActor/ReplayWrapper classes, sync replay + sync actor, fake CartPole."""
+    base_mod = sys.modules["deep_rl.agent.BaseAgent"]
+    orig_logger = base_mod.get_logger
+    base_mod.get_logger = lambda *a, **k: _Logger()
+    try:
+        out = {}
+        for tag, replay_cls, n_step, n_steps in (("uniform", ref.UniformReplay, 1, 60),
+                                                 ("per_n3", ref.PrioritizedReplay, 3, 60)):
+            cfg = ref.Config()
+            cfg.merge(dict(game="fake", n_step=n_step, replay_cls=replay_cls, async_replay=False, log_level=0, tag=tag))
+            cfg.task_fn = lambda: fake_envs.VectorTask(seed=1, state_dim=4, action_dim=2, horizon=20)
+            cfg.eval_env = cfg.task_fn()
+            cfg.optimizer_fn = lambda params: torch.optim.RMSprop(params, 0.001)
+            cfg.network_fn = lambda: ref.VanillaNet(cfg.action_dim, ref.FCBody(cfg.state_dim))
+            cfg.history_length = 1
+            cfg.batch_size = 10
+            cfg.discount = 0.99
+            cfg.max_steps = 1e5
+            kw = dict(memory_size=int(1e4), batch_size=cfg.batch_size, n_step=cfg.n_step, discount=cfg.discount,
+                      history_length=cfg.history_length)
+            cfg.replay_fn = lambda: ref.ReplayWrapper(cfg.replay_cls, kw, cfg.async_replay)
+            cfg.replay_eps, cfg.replay_alpha = 0.01, 0.5
+            cfg.replay_beta = ref.LinearSchedule(0.4, 1.0, cfg.max_steps)
+            cfg.random_action_prob = ref.LinearSchedule(1.0, 0.1, 100)
+            cfg.target_network_update_freq = 5
+            cfg.exploration_steps = 40
+            cfg.double_q = False
+            cfg.sgd_update_frequency = 4
+            cfg.gradient_clip = 5
+            cfg.async_actor = False
+            ref.random_seed(0)
+            random.seed(0)
+            agent = ref.DQNAgent(cfg)
+            init = {k: v.detach().numpy().copy() for k, v in agent.network.state_dict().items()}
+            for _ in range(n_steps):
+                agent.step()
+            k = tag + "_"
+            for n, v in init.items():
+                out[k + "init_" + n] = v
+            for n, v in agent.network.state_dict().items():
+                out[k + "final_" + n] = v.detach().numpy()
+            for n, v in agent.target_network.state_dict().items():
+                out[k + "target_" + n] = v.detach().numpy()
+            out[k + "total_steps"] = np.asarray(agent.total_steps)
+            rp = agent.replay.replay
+            out[k + "replay_action"] = np.asarray(rp.action).reshape(-1)
+            out[k + "replay_state"] = np.asarray(rp.state)
+            out[k + "rng_tail"] = np.random.randint(0, 1 << 30, size=4)
+    finally:
+        base_mod.get_logger = orig_logger
+    save("dqn_agent_cartpole", **out)
+
+
+GENERATORS = [gen_uniform, gen_prioritized, gen_sumtree, gen_dqn_loss, gen_c51_loss, gen_qr_loss,
+              gen_dqn_nature_update, gen_optim, gen_a2c, gen_ppo, gen_ppo_loss, gen_dqn_agent_cartpole]
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for g in GENERATORS:
+        if only and g.__name__ not in only:
+            continue
+        g()

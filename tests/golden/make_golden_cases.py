@@ -1,0 +1,30 @@
+"""Case tables + input streams shared by the golden generator and the tests
+(kept free of any reference import so it loads on the GPU box)."""
+import numpy as np
+
+
+def stream(rs, t_len, state_shape, state_kind, action_dim, done_p):
+    if state_kind == "u8":
+        states = rs.randint(0, 256, size=(t_len,) + state_shape).astype(np.uint8)
+    else:
+        states = rs.uniform(-1, 1, size=(t_len,) + state_shape)
+    actions = rs.randint(0, action_dim, size=t_len).astype(np.int64)
+    rewards = np.sign(rs.choice([-2.0, 0.0, 3.0], size=t_len, p=[0.2, 0.6, 0.2]))
+    masks = (1 - (rs.rand(t_len) < done_p)).astype(np.int32)
+    return states, actions, rewards, masks
+
+
+UNIFORM_CASES = [
+    # name, memory, batch, H, n, discount, state_shape, kind, T, checkpoints
+    ("a", 37, 8, 4, 1, 0.99, (6, 6), "u8", 100, [12, 36, 37, 41, 60, 74, 99]),
+    ("b", 32, 6, 2, 3, 0.5, (3, 5), "u8", 90, [9, 31, 33, 40, 64, 89]),
+    ("c", 20, 5, 1, 1, 0.99, (4,), "f64", 55, [3, 19, 20, 27, 54]),
+    ("d", 64, 16, 4, 3, 0.99, (4, 4), "u8", 200, [20, 63, 64, 70, 128, 199]),
+]
+
+PER_CASES = [
+    # name, memory, batch, H, n, discount, state_shape, kind, T, sample_every
+    ("p", 50, 8, 4, 1, 0.99, (4, 4), "u8", 180, 7),
+    ("q", 64, 16, 1, 3, 0.9, (4,), "f64", 200, 5),
+    ("r", 33, 4, 2, 1, 0.99, (2, 2), "u8", 120, 3),
+]

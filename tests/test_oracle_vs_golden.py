@@ -1,0 +1,285 @@
+"""Pins the CPU oracle (oracle/) against fixtures generated from the reference's
+own code (tests/golden/make_golden.py).  Integer / byte / index / fp64 work is
+compared bit-exactly; fp32 losses and gradients at 1e-5 (north_star tolerance)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from golden.make_golden_cases import UNIFORM_CASES, PER_CASES, stream
+from oracle import loss_oracle as L
+from oracle import net_oracle as N
+from oracle import numerics_oracle as NUM
+from oracle.replay_oracle import PrioritizedReplayOracle, UniformReplayOracle
+from oracle.sumtree_oracle import SumTreeOracle
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def _feed(rep, states, actions, rewards, masks, t):
+    rep.feed_one(states[t], actions[t], rewards[t], masks[t])
+
+
+@pytest.mark.parametrize("case", UNIFORM_CASES, ids=[c[0] for c in UNIFORM_CASES])
+def test_uniform_replay(golden, case):
+    g = golden("uniform_replay")
+    name, mem, b, h, n, disc, shape, kind, t_len, cps = case
+    states, actions, rewards, masks = stream(np.random.RandomState(1000 + ord(name)), t_len, shape, kind, 4, 0.1)
+    rep = UniformReplayOracle(mem, b, n, disc, h)
+    np.random.seed(2000 + ord(name))
+    for t in range(t_len):
+        _feed(rep, states, actions, rewards, masks, t)
+        if t in cps:
+            st, ac, rw, ns, mk, idx = rep.sample()
+            k = "%s_t%d_" % (name, t)
+            assert np.array_equal(idx, g[k + "idx"])
+            assert np.array_equal(g[k + "pos_size"], [rep.pos, rep.size()])
+            for got, key in ((st, "state"), (ac, "action"), (rw, "reward"), (ns, "next_state"), (mk, "mask")):
+                want = g[k + key]
+                assert got.shape == want.shape and got.dtype == want.dtype, key
+                assert np.array_equal(got, want), key
+    assert np.array_equal(np.random.randint(0, 1 << 30, size=4), g[name + "_rng_tail"])
+
+
+@pytest.mark.parametrize("case", PER_CASES, ids=[c[0] for c in PER_CASES])
+def test_prioritized_replay(golden, case):
+    g = golden("prioritized_replay")
+    name, mem, b, h, n, disc, shape, kind, t_len, every = case
+    rs = np.random.RandomState(3000 + ord(name))
+    states, actions, rewards, masks = stream(rs, t_len, shape, kind, 4, 0.1)
+    rep = PrioritizedReplayOracle(mem, b, n, disc, h)
+    random.seed(4000 + ord(name))
+    np.random.seed(4000 + ord(name))
+    ks = 0
+    for t in range(t_len):
+        _feed(rep, states, actions, rewards, masks, t)
+        if t >= h + n + 6 and t % every == 0:
+            st, ac, rw, ns, mk, prob, tidx = rep.sample()
+            k = "%s_s%d_" % (name, ks)
+            assert int(g[k + "t"]) == t
+            for got, key in ((st, "state"), (ac, "action"), (rw, "reward"), (ns, "next_state"), (mk, "mask"),
+                             (prob, "sampling_prob"), (tidx, "idx")):
+                assert np.array_equal(got, g[k + key]), (key, ks)
+            rs.standard_normal(b)  # the generator drew the fake loss here
+            prio = g[k + "prio"]
+            assert prio.dtype == np.float32
+            rep.update_priorities(zip(tidx, prio))
+            assert np.array_equal(rep.tree.tree, g[k + "tree"]), ks
+            assert float(rep.max_priority) == float(g[k + "max_priority"])
+            ks += 1
+    assert ks == int(g[name + "_n_samples"])
+    assert np.array_equal(rep.tree.tree, g[name + "_tree_final"])
+    assert np.array_equal([random.random() for _ in range(3)], g[name + "_rng_tail"])
+    # exactness regime: incremental tree == bottom-up rebuild
+    assert np.array_equal(rep.tree.tree, rep.tree.rebuilt())
+
+
+@pytest.mark.parametrize("cap", [8, 13, 50])
+def test_sumtree_ops(golden, cap):
+    g = golden("sumtree")
+    tree = SumTreeOracle(cap)
+    for op, x, p_out, idx in g["cap%d_log" % cap]:
+        op, idx = int(op), int(idx)
+        if op == 0:
+            tree.add(np.float32(x))
+        elif op == 1:
+            i, p, d = tree.get(x)
+            assert i == idx and float(p) == p_out and d == i - cap + 1
+        else:
+            tree.update(idx, np.float32(x))
+    assert np.array_equal(tree.tree, g["cap%d_tree" % cap])
+    assert np.array_equal(sorted(tree.pending), g["cap%d_pending" % cap])
+
+
+def _t(x, grad=False):
+    t = torch.tensor(np.asarray(x, dtype=np.float32))
+    t.requires_grad_(grad)
+    return t
+
+
+@pytest.mark.parametrize("tag", ["b32a4", "b10a2n3", "b32a4dq", "b7a18"])
+def test_dqn_loss(golden, tag):
+    g = golden("dqn_loss")
+    k = tag + "_"
+    gamma, n_step, double_q, eps, alpha, beta = g[k + "cfg"]
+    q = _t(g[k + "q"], True)
+    delta = L.dqn_td_error(q, _t(g[k + "q_next_t"]), torch.tensor(g[k + "action"]), _t(g[k + "reward"]),
+                           _t(g[k + "mask"]), gamma ** int(n_step),
+                           _t(g[k + "q_next_o"]) if double_q else None)
+    np.testing.assert_allclose(delta.detach().numpy(), g[k + "loss_vec"], **TOL)
+    loss = L.dqn_reduce(delta)
+    np.testing.assert_allclose(loss.item(), g[k + "loss"], **TOL)
+    gq, = torch.autograd.grad(loss, q, retain_graph=True)
+    np.testing.assert_allclose(gq.numpy(), g[k + "grad_q"], **TOL)
+    prio, w, wl = L.per_priorities_and_weights(delta, _t(g[k + "sampling_prob"]), eps, alpha, beta)
+    np.testing.assert_allclose(prio.detach().numpy(), g[k + "prio"], **TOL)
+    np.testing.assert_allclose(w.numpy(), g[k + "w"], **TOL)
+    lp = L.dqn_reduce(wl)
+    np.testing.assert_allclose(lp.item(), g[k + "loss_per"], **TOL)
+    gq, = torch.autograd.grad(lp, q)
+    np.testing.assert_allclose(gq.numpy(), g[k + "grad_q_per"], **TOL)
+
+
+@pytest.mark.parametrize("tag", ["b32a4", "b8a3n3dq", "b5a6at21"])
+def test_c51_loss(golden, tag):
+    g = golden("c51_loss")
+    k = tag + "_"
+    gamma, n_step, double_q, vmin, vmax, n_atoms = g[k + "cfg"]
+    n_atoms = int(n_atoms)
+    atoms = _t(np.linspace(vmin, vmax, n_atoms))
+    logits = _t(g[k + "logits"], True)
+    sm = lambda z: torch.softmax(z, dim=-1)
+    kl = L.c51_kl(torch.log_softmax(logits, dim=-1), sm(_t(g[k + "logits_next_t"])), torch.tensor(g[k + "action"]),
+                  _t(g[k + "reward"]), _t(g[k + "mask"]), gamma ** int(n_step), atoms, vmin, vmax,
+                  sm(_t(g[k + "logits_next_o"])) if double_q else None)
+    np.testing.assert_allclose(kl.detach().numpy(), g[k + "kl"], **TOL)
+    loss = kl.mean()
+    np.testing.assert_allclose(loss.item(), g[k + "loss"], **TOL)
+    gl, = torch.autograd.grad(loss, logits)
+    np.testing.assert_allclose(gl.numpy(), g[k + "grad_logits"], **TOL)
+
+
+@pytest.mark.parametrize("tag", ["b32a4", "b6a3q17n3"])
+def test_qr_loss(golden, tag):
+    g = golden("qr_loss")
+    k = tag + "_"
+    gamma, n_step, nq = g[k + "cfg"]
+    theta = _t(g[k + "theta"], True)
+    lv = L.qr_loss(theta, _t(g[k + "theta_next_t"]), torch.tensor(g[k + "action"]), _t(g[k + "reward"]),
+                   _t(g[k + "mask"]), gamma ** int(n_step))
+    np.testing.assert_allclose(lv.detach().numpy(), g[k + "loss_vec"], rtol=1e-5, atol=1e-5)
+    loss = lv.mean()
+    np.testing.assert_allclose(loss.item(), g[k + "loss"], **TOL)
+    gt, = torch.autograd.grad(loss, theta)
+    np.testing.assert_allclose(gt.numpy(), g[k + "grad_theta"], **TOL)
+
+
+@pytest.mark.parametrize("tag", ["m64", "m256", "m5"])
+def test_ppo_loss(golden, tag):
+    g = golden("ppo_loss")
+    k = tag + "_"
+    lp, ent, v = _t(g[k + "lp"], True), _t(g[k + "ent"], True), _t(g[k + "v"], True)
+    pl, vl, kl = L.ppo_losses(lp, ent, v, _t(g[k + "old_lp"]), _t(g[k + "adv"]), _t(g[k + "ret"]), 0.2, 0.01)
+    np.testing.assert_allclose([pl.item(), vl.item(), kl.item()], g[k + "out"], **TOL)
+    gs = torch.autograd.grad(pl + vl, [lp, ent, v])
+    for got, key in zip(gs, ("g_lp", "g_ent", "g_v")):
+        np.testing.assert_allclose(got.numpy(), g[k + key], **TOL)
+
+
+@pytest.mark.parametrize("tag", ["t5n16", "t5n16gae", "t20n3gae"])
+def test_a2c_gae_and_step(golden, tag):
+    g = golden("a2c_step")
+    k = tag + "_"
+    gamma, tau, use_gae, ew, vw, clip, t_len, n_env = g[k + "cfg"]
+    adv, ret = L.gae_reverse(_t(g[k + "reward"]), _t(g[k + "mask"]), _t(g[k + "v"]), gamma, tau, bool(use_gae))
+    np.testing.assert_allclose(adv.numpy(), g[k + "adv"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ret.numpy(), g[k + "ret"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["t64n2", "t32n4"])
+def test_ppo_gae_and_normalize(golden, tag):
+    g = golden("ppo_step")
+    k = tag + "_"
+    gamma, tau = g[k + "cfg"][:2]
+    adv, ret = L.gae_reverse(_t(g[k + "reward"]), _t(g[k + "mask"]), _t(g[k + "v"]), gamma, tau, True)
+    np.testing.assert_allclose(adv.numpy(), g[k + "adv"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ret.numpy(), g[k + "ret"], rtol=1e-6, atol=1e-6)
+    flat = adv.reshape(-1, 1)
+    np.testing.assert_allclose(L.normalize_advantage(flat).numpy(), g[k + "ent_adv_normalized"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ret.reshape(-1, 1).numpy(), g[k + "ent_ret"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["rmsprop_centered", "rmsprop_plain", "adam", "adam_default"])
+@pytest.mark.parametrize("clip", [5.0, 0.5])
+def test_optim(golden, name, clip):
+    g = golden("optim")
+    n_t = 4
+    ps = [_t(g["p0_%d" % j]) for j in range(n_t)]
+    s1 = [torch.zeros_like(p) for p in ps]
+    s2 = [torch.zeros_like(p) for p in ps]
+    hp = {"rmsprop_centered": dict(lr=0.00025, alpha=0.95, eps=0.01, centered=True),
+          "rmsprop_plain": dict(lr=1e-4, alpha=0.99, eps=1e-5, centered=False),
+          "adam": dict(lr=2.5e-4, beta1=0.9, beta2=0.999, eps=0.01 / 32),
+          "adam_default": dict(lr=3e-4, beta1=0.9, beta2=0.999, eps=1e-8)}[name]
+    norms = []
+    for i in range(5):
+        gs = [_t(g["g%d_%d" % (i, j)]) for j in range(n_t)]
+        norm, gs = N.clip_grad_norm(gs, clip)
+        norms.append(float(norm))
+        for j in range(n_t):
+            if name.startswith("rmsprop"):
+                ps[j], s1[j], s2[j] = N.rmsprop_step(ps[j], gs[j], s1[j], s2[j], **hp)
+            else:
+                ps[j], s1[j], s2[j] = N.adam_step(ps[j], gs[j], s1[j], s2[j], i + 1, **hp)
+    np.testing.assert_allclose(norms, g["%s_clip%g_norms" % (name, clip)], rtol=1e-6)
+    for j in range(n_t):
+        np.testing.assert_allclose(ps[j].numpy(), g["%s_clip%g_p%d" % (name, clip, j)], rtol=1e-5, atol=1e-6)
+
+
+def test_dqn_nature_update(golden):
+    """Full reference DQN update on VanillaNet(NatureConvBody): oracle forward/backward
+    (F.conv2d chain) + clip + centered RMSprop reproduce the reference trajectory."""
+    import fake_envs
+    g = golden("dqn_nature_update")
+    b, a = 8, 4
+    rs = np.random.RandomState(int(g["state_seed"]))
+    p = {k: torch.tensor(v, requires_grad=True) for k, v in fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(a), 11).items()}
+    pt = {k: torch.tensor(v) for k, v in fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(a), 12).items()}
+    state = rs.randint(0, 256, size=(b, 4, 84, 84)).astype(np.uint8)
+    next_state = rs.randint(0, 256, size=(b, 4, 84, 84)).astype(np.uint8)
+    action = rs.randint(0, a, size=b).astype(np.int64)
+    reward = np.sign(rs.standard_normal(b))
+    mask = (rs.rand(b) > 0.2).astype(np.int32)
+    assert np.array_equal(action, g["action"]) and np.array_equal(reward, g["reward"]) and np.array_equal(mask, g["mask"])
+    x = torch.from_numpy(NUM.image_normalize_sync(state))
+    xn = torch.from_numpy(NUM.image_normalize_sync(next_state))
+    q0 = N.vanilla_head(p, N.nature_conv_body(p, x))
+    np.testing.assert_allclose(q0.detach().numpy(), g["q0"], **TOL)
+    names = list(p.keys())
+    sq = {k: torch.zeros_like(v) for k, v in p.items()}
+    ga = {k: torch.zeros_like(v) for k, v in p.items()}
+    for it in range(3):
+        q = N.vanilla_head(p, N.nature_conv_body(p, x))
+        with torch.no_grad():
+            qn = N.vanilla_head(pt, N.nature_conv_body(pt, xn))
+        delta = L.dqn_td_error(q, qn, torch.tensor(action), _t(reward), _t(mask), 0.99)
+        loss = L.dqn_reduce(delta)
+        grads = torch.autograd.grad(loss, [p[k] for k in names])
+        if it == 0:
+            for k, gr in zip(names, grads):
+                if k == "body.fc4.weight":
+                    np.testing.assert_allclose(gr.numpy()[::37], g["grad_" + k + "_rows"], rtol=1e-4, atol=1e-6)
+                    np.testing.assert_allclose(np.sqrt((gr.numpy().astype(np.float64) ** 2).sum()), g["grad_" + k + "_norm"], rtol=1e-5)
+                else:
+                    np.testing.assert_allclose(gr.numpy(), g["grad_" + k], rtol=1e-4, atol=1e-6)
+        norm, grads = N.clip_grad_norm(list(grads), 5)
+        np.testing.assert_allclose([loss.item(), float(norm)], g["loss_gradnorm_traj"][it], rtol=5e-5)
+        with torch.no_grad():
+            for k, gr in zip(names, grads):
+                newp, sq[k], ga[k] = N.rmsprop_step(p[k], gr, sq[k], ga[k], 0.00025, 0.95, 0.01, True)
+                p[k].copy_(newp)
+    for k in names:
+        want = g["final_" + k + "_rows"] if k == "body.fc4.weight" else g["final_" + k]
+        got = p[k].detach().numpy()[::37] if k == "body.fc4.weight" else p[k].detach().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_image_lut_matches_reference_numerics():
+    lut = NUM.image_lut()
+    assert lut.dtype == np.float32 and lut.shape == (256,)
+    # f64 multiply then round-to-f32 (sync path), NOT f32*f32 (async path): differs in 126 code points
+    async_path = np.arange(256, dtype=np.float32) * np.float32(1.0 / 255)
+    assert int((lut != async_path).sum()) == 126
+
+
+def test_running_mean_std_two_pass():
+    rs = np.random.RandomState(0)
+    rms = NUM.RunningMeanStdOracle(shape=(1, 3))
+    chunks = [rs.randn(5, 3) * 2 + 1 for _ in range(20)]
+    for c in chunks:
+        rms.update(c)
+    allx = np.concatenate(chunks)
+    # prior pseudo-count 1e-4 of (mean 0, var 1) is below 1e-5 relative here
+    np.testing.assert_allclose(rms.mean[0], allx.mean(0), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rms.var[0], allx.var(0), rtol=1e-4, atol=1e-5)
