@@ -1,0 +1,433 @@
+// Fused per-batch loss kernels, forward + backward in one launch each.
+//   K4  dra_td_loss   deep_rl/agent/DQN_agent.py:78-99 (+ PER branch :120-127)
+//   K5  dra_c51_loss  deep_rl/agent/CategoricalDQN_agent.py:60-89
+//   K6  dra_qr_loss   deep_rl/agent/QuantileRegressionDQN_agent.py:55-77 (+ utils/torch_utils.py:47-48)
+//   K10 dra_ppo_loss  deep_rl/agent/PPO_agent.py:77-86 ; dra_a2c_loss deep_rl/agent/A2C_agent.py:55-62
+// All are bandwidth/latency-bound on a few KB; each is one launch (two for QR) instead of the
+// reference's 15-30 ATen ops, and never materialises the [B,N,N] / [N,B,N] intermediates.
+// Actions arrive as the ring's raw int64 records or as f32 (what `tensor()` makes of them).
+#include "common.h"
+
+__device__ __forceinline__ int64_t load_action(const void* a, int is_i64, int b) {
+  return is_i64 ? reinterpret_cast<const int64_t*>(a)[b] : (int64_t)reinterpret_cast<const float*>(a)[b];
+}
+
+// block-wide reductions for blockDim <= 1024 (<=16 waves); every thread gets the result
+__device__ __forceinline__ float block_sum(float v, float* s_red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += s_red[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* s_red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[w] = v;
+  __syncthreads();
+  float t = s_red[0];
+  for (int i = 1; i < nw; ++i) t = fmaxf(t, s_red[i]);
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------ K4
+// One workgroup, one thread per sample (B <= 1024).
+__global__ void __launch_bounds__(1024)
+td_loss_kernel(const float* __restrict__ q, const float* __restrict__ qn_t, const float* __restrict__ qn_o,
+               const void* __restrict__ action, int action_i64, const float* __restrict__ reward,
+               const float* __restrict__ mask, int B, int A, float gamma_n, const float* __restrict__ samp_prob,
+               float beta, float eps, float alpha, float* __restrict__ out_loss, float* __restrict__ out_dq,
+               float* __restrict__ out_delta, float* __restrict__ out_prio, float* __restrict__ out_w) {
+  __shared__ float s_red[16];
+  const int b = threadIdx.x;
+  const bool on = b < B;
+  float delta = 0.f, w = 1.f;
+  int64_t a = 0;
+  if (on) {
+    const float* t = qn_t + (int64_t)b * A;
+    float qn;
+    if (qn_o) {  // double-Q: target value at the online argmax (first max wins, as torch.argmax)
+      const float* o = qn_o + (int64_t)b * A;
+      int best = 0;
+      float bv = o[0];
+      for (int k = 1; k < A; ++k) if (o[k] > bv) { bv = o[k]; best = k; }
+      qn = t[best];
+    } else {
+      qn = t[0];
+      for (int k = 1; k < A; ++k) qn = fmaxf(qn, t[k]);
+    }
+    a = load_action(action, action_i64, b);
+    // rewards + gamma^n * q_next * masks  ->  r + ((g*qn)*m), unfused
+    const float target = __fadd_rn(reward[b], __fmul_rn(__fmul_rn(gamma_n, qn), mask[b]));
+    delta = __fsub_rn(target, q[(int64_t)b * A + a]);
+    if (out_delta) out_delta[b] = delta;
+  }
+  if (samp_prob) {  // PER: priorities from the PRE-weight vector; weights use the batch size
+    float wraw = 0.f;
+    if (on) {
+      const float ad = fabsf(delta) + eps;
+      if (out_prio) out_prio[b] = (alpha == 0.5f) ? sqrtf(ad) : powf(ad, alpha);
+      wraw = powf(samp_prob[b] * (float)B + 1e-6f, -beta);
+    }
+    const float wmax = block_max(on ? wraw : -INFINITY, s_red);
+    w = wraw / wmax;
+    if (on && out_w) out_w[b] = w;
+  }
+  const float lw = delta * w;
+  const float tot = block_sum(on ? 0.5f * lw * lw : 0.f, s_red);
+  if (b == 0) *out_loss = tot / (float)B;
+  if (on && out_dq) {
+    float* g = out_dq + (int64_t)b * A;
+    for (int k = 0; k < A; ++k) g[k] = 0.f;
+    g[a] = -(lw * w) / (float)B;
+  }
+}
+
+DRA_API int dra_td_loss(const float* q, const float* q_next_target, const float* q_next_online, const void* action,
+                        int action_is_i64, const float* reward, const float* mask, int batch, int n_actions,
+                        float gamma_n, const float* sampling_prob, float beta, float replay_eps, float replay_alpha,
+                        float* out_loss, float* out_dq, float* out_delta, float* out_prio, float* out_weights,
+                        void* stream) {
+  if (!q || !q_next_target || !action || !reward || !mask || !out_loss || batch < 1 || batch > 1024 || n_actions < 1)
+    return DRA_EINVAL;
+  const int threads = ((batch + 63) / 64) * 64;
+  hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(threads), 0, dra_stream(stream), q, q_next_target, q_next_online,
+                     action, action_is_i64, reward, mask, batch, n_actions, gamma_n, sampling_prob, beta, replay_eps,
+                     replay_alpha, out_loss, out_dq, out_delta, out_prio, out_weights);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ K5
+// One workgroup per sample, one thread per atom (N <= 256).  Inputs are LOGITS [B,A,N]; the
+// softmax / log-softmax of CategoricalNet (network_heads.py:51-53) is folded in, and the gradient
+// comes out w.r.t. the online logits:  d/dlogit_i = (softmax_i * sum_j m_j - m_i) / B  on row a.
+__global__ void __launch_bounds__(256)
+c51_loss_kernel(const float* __restrict__ logits, const float* __restrict__ logits_t, const float* __restrict__ logits_o,
+                const void* __restrict__ action, int action_i64, const float* __restrict__ reward,
+                const float* __restrict__ mask, int B, int A, int N, float gamma_n, float v_min, float v_max,
+                const float* __restrict__ atoms, float* __restrict__ out_kl, float* __restrict__ out_dlogits,
+                const float* __restrict__ weights) {
+  extern __shared__ float smem[];  // [N] p_next | [N] atoms
+  __shared__ float s_red[16];
+  __shared__ int s_anext;
+  float* s_p = smem;
+  float* s_z = smem + N;
+  const int b = blockIdx.x, j = threadIdx.x;
+  const bool on = j < N;
+  // delta_atom is a python float in the reference (CategoricalDQN_agent.py:49), divided into an f32 tensor
+  const float delta_atom = (float)(((double)v_max - (double)v_min) / (double)(N - 1));
+  // atoms = tensor(np.linspace(v_min, v_max, N)) is passed in as f32[N]
+  const float zj = on ? atoms[j] : 0.f;
+  if (on) s_z[j] = zj;
+
+  // greedy next action under the selector net (online for double-Q, else target)
+  const float* sel = (logits_o ? logits_o : logits_t) + (int64_t)b * A * N;
+  float best_q = -INFINITY;
+  int best_a = 0;
+  for (int a = 0; a < A; ++a) {
+    const float x = on ? sel[a * N + j] : -INFINITY;
+    const float mx = block_max(x, s_red);
+    const float e = on ? expf(x - mx) : 0.f;
+    const float den = block_sum(e, s_red);
+    const float qa = block_sum(on ? (e / den) * zj : 0.f, s_red);
+    if (qa > best_q) { best_q = qa; best_a = a; }
+  }
+  if (j == 0) s_anext = best_a;
+  __syncthreads();
+  const int a_next = s_anext;
+  {  // p_next = softmax(target logits[b, a_next, :])
+    const float x = on ? logits_t[((int64_t)b * A + a_next) * N + j] : -INFINITY;
+    const float mx = block_max(x, s_red);
+    const float e = on ? expf(x - mx) : 0.f;
+    const float den = block_sum(e, s_red);
+    if (on) s_p[j] = e / den;
+  }
+  __syncthreads();
+  // projected target m_j = sum_i clamp(1 - |Tz_i - z_j| / dz, 0, 1) * p_i
+  const float r = reward[b], gm = __fmul_rn(gamma_n, mask[b]);
+  float m = 0.f;
+  if (on) {
+    for (int i = 0; i < N; ++i) {
+      const float zi = s_z[i];
+      float tz = __fadd_rn(r, __fmul_rn(gm, zi));
+      tz = fminf(fmaxf(tz, v_min), v_max);
+      float c = 1.f - fabsf(tz - zj) / delta_atom;
+      c = fminf(fmaxf(c, 0.f), 1.f);
+      m += c * s_p[i];
+    }
+  }
+  // online log-softmax on row a
+  const int64_t a = load_action(action, action_i64, b);
+  const float x = on ? logits[((int64_t)b * A + a) * N + j] : -INFINITY;
+  const float mx = block_max(x, s_red);
+  const float e = on ? expf(x - mx) : 0.f;
+  const float den = block_sum(e, s_red);
+  const float lp = on ? (x - mx) - logf(den) : 0.f;
+  const float kl = block_sum(on ? m * logf(m + 1e-5f) - m * lp : 0.f, s_red);
+  const float msum = block_sum(m, s_red);
+  const float wb = weights ? weights[b] : 1.f;
+  if (j == 0) out_kl[b] = kl;
+  if (out_dlogits) {
+    float* g = out_dlogits + (int64_t)b * A * N;
+    for (int k = j; k < A * N; k += blockDim.x) g[k] = 0.f;
+    __syncthreads();
+    if (on) g[a * N + j] = wb * ((e / den) * msum - m) / (float)B;
+  }
+}
+
+DRA_API int dra_c51_loss(const float* logits, const float* logits_next_target, const float* logits_next_online,
+                         const void* action, int action_is_i64, const float* reward, const float* mask, int batch,
+                         int n_actions, int n_atoms, float gamma_n, float v_min, float v_max, const float* atoms,
+                         float* out_kl, float* out_dlogits, const float* weights, void* stream) {
+  if (!logits || !logits_next_target || !action || !reward || !mask || !atoms || !out_kl || batch < 1 || n_actions < 1 ||
+      n_atoms < 2 || n_atoms > 256)
+    return DRA_EINVAL;
+  const int threads = ((n_atoms + 63) / 64) * 64;
+  hipLaunchKernelGGL(c51_loss_kernel, dim3(batch), dim3(threads), 2 * n_atoms * sizeof(float), dra_stream(stream), logits,
+                     logits_next_target, logits_next_online, action, action_is_i64, reward, mask, batch, n_actions, n_atoms,
+                     gamma_n, v_min, v_max, atoms, out_kl, out_dlogits, weights);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ K6
+// One workgroup per sample, one thread per quantile (N <= 1024).  Pass 1 (thread = online
+// quantile i) accumulates d loss / d theta_i over all target quantiles j; pass 2 (thread = target
+// quantile j) accumulates the per-j loss over i.  The [N,B,N] tensor (5 MB at N=200) never exists.
+__device__ __forceinline__ float huber1(float d) {
+  const float ad = fabsf(d);
+  return ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+}
+__device__ __forceinline__ float huber1_grad(float d) { return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)); }
+
+__global__ void __launch_bounds__(1024)
+qr_loss_kernel(const float* __restrict__ theta, const float* __restrict__ theta_t, const void* __restrict__ action,
+               int action_i64, const float* __restrict__ reward, const float* __restrict__ mask, int B, int A, int N,
+               float gamma_n, float* __restrict__ out_partial /*[B][N]*/, float* __restrict__ out_dtheta) {
+  extern __shared__ float smem[];  // [N] T theta | [N] theta_a
+  __shared__ float s_red[16];
+  __shared__ int s_anext;
+  float* s_t = smem;
+  float* s_th = smem + N;
+  const int b = blockIdx.x, i = threadIdx.x;
+  const bool on = i < N;
+  const float* tt = theta_t + (int64_t)b * A * N;
+  float best = -INFINITY;
+  int best_a = 0;
+  for (int a = 0; a < A; ++a) {  // a* = argmax_a sum_q theta_target
+    const float s = block_sum(on ? tt[a * N + i] : 0.f, s_red);
+    if (s > best) { best = s; best_a = a; }
+  }
+  if (i == 0) s_anext = best_a;
+  __syncthreads();
+  const int64_t a = load_action(action, action_i64, b);
+  if (on) {
+    // rewards + gamma^n * masks * quantiles_next -> r + ((g*m)*theta')
+    s_t[i] = __fadd_rn(reward[b], __fmul_rn(__fmul_rn(gamma_n, mask[b]), tt[s_anext * N + i]));
+    s_th[i] = theta[((int64_t)b * A + a) * N + i];
+  }
+  __syncthreads();
+  if (out_dtheta) {
+    float* g = out_dtheta + (int64_t)b * A * N;
+    for (int k = i; k < A * N; k += blockDim.x) g[k] = 0.f;
+    __syncthreads();
+    if (on) {
+      const float tau = (float)((2.0 * (double)i + 1.0) / (2.0 * (double)N));
+      const float th = s_th[i];
+      float acc = 0.f;
+      for (int j = 0; j < N; ++j) {
+        const float d = s_t[j] - th;
+        acc += huber1_grad(d) * fabsf(tau - (d < 0.f ? 1.f : 0.f));
+      }
+      g[a * N + i] = -acc / ((float)N * (float)B);  // loss = mean_j mean_b sum_i rho ; d(d)/d(theta) = -1
+    }
+  }
+  if (on) {
+    const float tj = s_t[i];  // thread plays target quantile j = i
+    float l = 0.f;
+    for (int k = 0; k < N; ++k) {
+      const float d = tj - s_th[k];
+      const float tau = (float)((2.0 * (double)k + 1.0) / (2.0 * (double)N));
+      l += huber1(d) * fabsf(tau - (d < 0.f ? 1.f : 0.f));
+    }
+    out_partial[(int64_t)b * N + i] = l;
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+qr_finalize_kernel(const float* __restrict__ partial, int B, int N, float* __restrict__ out_loss_vec,
+                   float* __restrict__ out_loss) {
+  __shared__ float s_red[16];
+  const int j = threadIdx.x;
+  float l = 0.f;
+  if (j < N) {
+    for (int b = 0; b < B; ++b) l += partial[(int64_t)b * N + j];
+    l /= (float)B;
+    if (out_loss_vec) out_loss_vec[j] = l;
+  }
+  const float tot = block_sum(j < N ? l : 0.f, s_red);
+  if (j == 0) *out_loss = tot / (float)N;
+}
+
+DRA_API int dra_qr_loss(const float* theta, const float* theta_next_target, const void* action, int action_is_i64,
+                        const float* reward, const float* mask, int batch, int n_actions, int n_quantiles, float gamma_n,
+                        float* workspace /*[B*N]*/, float* out_loss_vec, float* out_loss, float* out_dtheta, void* stream) {
+  if (!theta || !theta_next_target || !action || !reward || !mask || !workspace || !out_loss || batch < 1 ||
+      n_actions < 1 || n_quantiles < 1 || n_quantiles > 1024)
+    return DRA_EINVAL;
+  const int threads = ((n_quantiles + 63) / 64) * 64;
+  hipLaunchKernelGGL(qr_loss_kernel, dim3(batch), dim3(threads), 2 * n_quantiles * sizeof(float), dra_stream(stream),
+                     theta, theta_next_target, action, action_is_i64, reward, mask, batch, n_actions, n_quantiles, gamma_n,
+                     workspace, out_dtheta);
+  DRA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(qr_finalize_kernel, dim3(1), dim3(threads), 0, dra_stream(stream), (const float*)workspace, batch,
+                     n_quantiles, out_loss_vec, out_loss);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// ------------------------------------------------------------------------------------------ K10
+// out[0..2] = policy_loss, value_loss, approx_kl.  Gradients are of (policy_loss + value_loss);
+// the three inputs are disjoint so they also serve the separate actor / critic backward passes.
+__global__ void __launch_bounds__(1024)
+ppo_loss_kernel(const float* __restrict__ lp, const float* __restrict__ ent, const float* __restrict__ v,
+                const float* __restrict__ old_lp, const float* __restrict__ adv, const float* __restrict__ ret, int M,
+                float clip, float entropy_weight, float* __restrict__ out, float* __restrict__ g_lp,
+                float* __restrict__ g_ent, float* __restrict__ g_v) {
+  __shared__ float s_red[16];
+  float s_obj = 0.f, s_ent = 0.f, s_v = 0.f, s_kl = 0.f;
+  const float inv_m = 1.f / (float)M;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    const float ratio = expf(lp[i] - old_lp[i]);
+    const float a = adv[i];
+    const float obj = ratio * a;
+    const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+    const float objc = rc * a;
+    s_obj += fminf(obj, objc);
+    s_ent += ent[i];
+    const float dv = ret[i] - v[i];
+    s_v += dv * dv;
+    s_kl += old_lp[i] - lp[i];
+    // torch.min splits ties evenly and clamp passes gradient inside [1-c, 1+c] (inclusive):
+    // inside the range both branches carry ratio*adv; outside only `obj` does, when it is the min.
+    const bool inside = (ratio >= 1.f - clip) && (ratio <= 1.f + clip);
+    const float gate = inside ? 1.f : (obj < objc ? 1.f : (obj == objc ? 0.5f : 0.f));
+    if (g_lp) g_lp[i] = -gate * obj * inv_m;
+    if (g_ent) g_ent[i] = -entropy_weight * inv_m;
+    if (g_v) g_v[i] = -dv * inv_m;
+  }
+  s_obj = block_sum(s_obj, s_red);
+  s_ent = block_sum(s_ent, s_red);
+  s_v = block_sum(s_v, s_red);
+  s_kl = block_sum(s_kl, s_red);
+  if (threadIdx.x == 0) {
+    out[0] = -s_obj * inv_m - entropy_weight * (s_ent * inv_m);
+    out[1] = 0.5f * (s_v * inv_m);
+    out[2] = s_kl * inv_m;
+  }
+}
+
+DRA_API int dra_ppo_loss(const float* log_pi_a, const float* entropy, const float* v, const float* old_log_pi_a,
+                         const float* adv, const float* ret, int m, float ratio_clip, float entropy_weight, float* out3,
+                         float* g_log_pi_a, float* g_entropy, float* g_v, void* stream) {
+  if (!log_pi_a || !entropy || !v || !old_log_pi_a || !adv || !ret || !out3 || m < 1) return DRA_EINVAL;
+  int threads = ((m + 63) / 64) * 64;
+  if (threads > 1024) threads = 1024;
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(threads), 0, dra_stream(stream), log_pi_a, entropy, v, old_log_pi_a,
+                     adv, ret, m, ratio_clip, entropy_weight, out3, g_log_pi_a, g_entropy, g_v);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+__global__ void __launch_bounds__(1024)
+a2c_loss_kernel(const float* __restrict__ lp, const float* __restrict__ ent, const float* __restrict__ v,
+                const float* __restrict__ adv, const float* __restrict__ ret, int M, float entropy_weight,
+                float value_weight, float* __restrict__ out, float* __restrict__ g_lp, float* __restrict__ g_ent,
+                float* __restrict__ g_v) {
+  __shared__ float s_red[16];
+  float s_pg = 0.f, s_ent = 0.f, s_v = 0.f;
+  const float inv_m = 1.f / (float)M;
+  for (int i = threadIdx.x; i < M; i += blockDim.x) {
+    s_pg += lp[i] * adv[i];
+    s_ent += ent[i];
+    const float dv = ret[i] - v[i];
+    s_v += dv * dv;
+    if (g_lp) g_lp[i] = -adv[i] * inv_m;
+    if (g_ent) g_ent[i] = -entropy_weight * inv_m;
+    if (g_v) g_v[i] = -value_weight * dv * inv_m;
+  }
+  s_pg = block_sum(s_pg, s_red);
+  s_ent = block_sum(s_ent, s_red);
+  s_v = block_sum(s_v, s_red);
+  if (threadIdx.x == 0) {
+    const float policy = -s_pg * inv_m, value = 0.5f * (s_v * inv_m), entropy = s_ent * inv_m;
+    out[0] = policy - entropy_weight * entropy + value_weight * value;
+    out[1] = policy; out[2] = value; out[3] = entropy;
+  }
+}
+
+DRA_API int dra_a2c_loss(const float* log_pi_a, const float* entropy, const float* v, const float* adv, const float* ret,
+                         int m, float entropy_weight, float value_loss_weight, float* out4, float* g_log_pi_a,
+                         float* g_entropy, float* g_v, void* stream) {
+  if (!log_pi_a || !entropy || !v || !adv || !ret || !out4 || m < 1) return DRA_EINVAL;
+  int threads = ((m + 63) / 64) * 64;
+  if (threads > 1024) threads = 1024;
+  hipLaunchKernelGGL(a2c_loss_kernel, dim3(1), dim3(threads), 0, dra_stream(stream), log_pi_a, entropy, v, adv, ret, m,
+                     entropy_weight, value_loss_weight, out4, g_log_pi_a, g_entropy, g_v);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// PER helpers for the distributional agents (DQN_agent.py:121-127 applied to a KL / QR vector):
+// priorities from a loss vector, importance weights from the sampling probabilities, and the
+// weighted mean used by reduce_loss.
+__global__ void __launch_bounds__(1024)
+per_kernel(const float* __restrict__ loss_vec, const float* __restrict__ samp_prob, int B, float beta, float eps,
+           float alpha, float* __restrict__ out_prio, float* __restrict__ out_w) {
+  __shared__ float s_red[16];
+  const int b = threadIdx.x;
+  const bool on = b < B;
+  if (on && loss_vec && out_prio) {
+    const float ad = fabsf(loss_vec[b]) + eps;
+    out_prio[b] = (alpha == 0.5f) ? sqrtf(ad) : powf(ad, alpha);
+  }
+  if (samp_prob && out_w) {
+    const float wraw = on ? powf(samp_prob[b] * (float)B + 1e-6f, -beta) : -INFINITY;
+    const float wmax = block_max(wraw, s_red);
+    if (on) out_w[b] = wraw / wmax;
+  }
+}
+
+DRA_API int dra_per_weights(const float* loss_vec, const float* sampling_prob, int batch, float beta, float replay_eps,
+                            float replay_alpha, float* out_prio, float* out_weights, void* stream) {
+  if (batch < 1 || batch > 1024) return DRA_EINVAL;
+  const int threads = ((batch + 63) / 64) * 64;
+  hipLaunchKernelGGL(per_kernel, dim3(1), dim3(threads), 0, dra_stream(stream), loss_vec, sampling_prob, batch, beta,
+                     replay_eps, replay_alpha, out_prio, out_weights);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+__global__ void __launch_bounds__(1024)
+weighted_mean_kernel(const float* __restrict__ x, const float* __restrict__ w, int n, float* __restrict__ out) {
+  __shared__ float s_red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += w ? x[i] * w[i] : x[i];
+  s = block_sum(s, s_red);
+  if (threadIdx.x == 0) *out = s / (float)n;
+}
+
+DRA_API int dra_weighted_mean(const float* x, const float* w, int n, float* out, void* stream) {
+  if (!x || !out || n < 1) return DRA_EINVAL;
+  int threads = ((n + 63) / 64) * 64;
+  if (threads > 1024) threads = 1024;
+  hipLaunchKernelGGL(weighted_mean_kernel, dim3(1), dim3(threads), 0, dra_stream(stream), x, w, n, out);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}

@@ -1,0 +1,196 @@
+// K11: global-norm gradient clipping fused with the optimiser step over ONE flat fp32 buffer.
+// Replaces nn.utils.clip_grad_norm_ + torch.optim.{RMSprop,Adam}.step() at
+// deep_rl/agent/DQN_agent.py:130-134 (optimisers configured at examples.py:67-68,139,204,370,
+// 508-509,534): ~100 tiny ATen ops over 10 tensors become two launches.
+//
+//   launch 1  dra_grad_sqnorm : per-workgroup partial sums of g^2 (fp32 per lane, fp64 across
+//                               lanes) -> partials[nblocks]; optionally folds split-K slabs of
+//                               the weight-gradient GEMMs into the final gradient on the way.
+//   launch 2  dra_*_step      : every workgroup re-reduces the partials in a fixed order (so
+//                               the result is run-to-run deterministic), forms
+//                               coef = max_norm / (norm + 1e-6), and applies the update.
+// HBM-bound: centered RMSprop reads p,g,sq,ga and writes p,sq,ga (+ the norm read) = 32 B/param.
+#include "common.h"
+
+constexpr int kNormBlocks = 512;  // fixed so graphs replay the same reduction tree
+
+__global__ void __launch_bounds__(256)
+grad_sqnorm_kernel(float* __restrict__ grad, int64_t n, const float* __restrict__ slabs, int n_slabs,
+                   int64_t slab_stride, double* __restrict__ partials) {
+  __shared__ double s_red[4];
+  float acc = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n >> 2;
+  float4* g4 = reinterpret_cast<float4*>(grad);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 g = g4[i];
+    if (n_slabs > 0) {  // fold split-K slabs: grad = sum_s slab[s]  (fixed order)
+      g = reinterpret_cast<const float4*>(slabs)[i];
+      for (int s = 1; s < n_slabs; ++s) {
+        const float4 t = reinterpret_cast<const float4*>(slabs + (int64_t)s * slab_stride)[i];
+        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+      }
+      g4[i] = g;
+    }
+    acc += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float g = grad[i];
+    if (n_slabs > 0) {
+      g = slabs[i];
+      for (int s = 1; s < n_slabs; ++s) g += slabs[(int64_t)s * slab_stride + i];
+      grad[i] = g;
+    }
+    acc += g * g;
+  }
+  double d = wave_sum((double)acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// Each dra_grad_sqnorm call writes dra_norm_partials() doubles.  Several gradient segments ->
+// one global norm: give each call its own run of partials and pass the total count to the step.
+DRA_API int dra_norm_partials(void) { return kNormBlocks; }
+
+DRA_API int dra_grad_sqnorm(float* grad, int64_t n, const float* slabs, int n_slabs, int64_t slab_stride,
+                            double* partials, void* stream) {
+  if (!grad || !partials || n < 1 || n_slabs < 0 || (n_slabs > 0 && !slabs)) return DRA_EINVAL;
+  if ((((uintptr_t)grad) & 15) || (slabs && ((((uintptr_t)slabs) & 15) || (slab_stride & 3)))) return DRA_EINVAL;
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(kNormBlocks), dim3(256), 0, dra_stream(stream), grad, n, slabs, n_slabs,
+                     slab_stride, partials);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// Fixed-order reduction of the partials by every workgroup; returns the clip coefficient.
+__device__ __forceinline__ float clip_coef_from_partials(const double* __restrict__ partials, int n_partials,
+                                                         float max_norm, float* __restrict__ out_norm) {
+  __shared__ double s_part[4];
+  __shared__ float s_coef;
+  double d = 0.0;
+  for (int i = threadIdx.x; i < n_partials; i += blockDim.x) d += partials[i];
+  d = wave_sum(d);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+    if (out_norm && blockIdx.x == 0) *out_norm = norm;
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+      coef = max_norm / (norm + 1e-6f);
+      if (coef > 1.f) coef = 1.f;
+    }
+    s_coef = coef;
+  }
+  __syncthreads();
+  return s_coef;
+}
+
+// torch.optim.RMSprop:  sq = a*sq + (1-a)*g*g ; centered: ga = a*ga + (1-a)*g,
+// avg = sqrt(sq - ga*ga) + eps  else  avg = sqrt(sq) + eps ;  p -= lr * g / avg.
+__global__ void __launch_bounds__(256)
+rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, float* __restrict__ ga,
+                    int64_t n, const double* __restrict__ partials, int n_partials, float max_norm, float lr,
+                    float alpha, float eps, int centered, float* __restrict__ out_norm) {
+  const float coef = partials ? clip_coef_from_partials(partials, n_partials, max_norm, out_norm) : 1.f;
+  const float oma = 1.f - alpha;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 P = reinterpret_cast<float4*>(p)[i];
+    const float4 G0 = reinterpret_cast<const float4*>(g)[i];
+    float4 S = reinterpret_cast<float4*>(sq)[i];
+    float4 A = centered ? reinterpret_cast<float4*>(ga)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* pp = &P.x; const float* gg = &G0.x; float* ss = &S.x; float* aa = &A.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = gg[k] * coef;
+      ss[k] = ss[k] * alpha + oma * gk * gk;
+      float avg;
+      if (centered) {
+        aa[k] = aa[k] * alpha + oma * gk;
+        avg = sqrtf(ss[k] - aa[k] * aa[k]) + eps;
+      } else {
+        avg = sqrtf(ss[k]) + eps;
+      }
+      pp[k] = pp[k] - lr * (gk / avg);
+    }
+    reinterpret_cast<float4*>(p)[i] = P;
+    reinterpret_cast<float4*>(sq)[i] = S;
+    if (centered) reinterpret_cast<float4*>(ga)[i] = A;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gk = g[i] * coef;
+    float s = sq[i] * alpha + oma * gk * gk;
+    float avg;
+    if (centered) {
+      const float a = ga[i] * alpha + oma * gk;
+      ga[i] = a;
+      avg = sqrtf(s - a * a) + eps;
+    } else {
+      avg = sqrtf(s) + eps;
+    }
+    sq[i] = s;
+    p[i] = p[i] - lr * (gk / avg);
+  }
+}
+
+static inline int step_blocks(int64_t n) {
+  int64_t b = ((n >> 2) + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+DRA_API int dra_rmsprop_step(float* param, const float* grad, float* square_avg, float* grad_avg, int64_t n,
+                             const double* partials, int n_partials, float max_norm, float lr, float alpha, float eps,
+                             int centered, float* out_norm, void* stream) {
+  if (!param || !grad || !square_avg || (centered && !grad_avg) || n < 1) return DRA_EINVAL;
+  if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)square_avg) | ((uintptr_t)grad_avg)) & 15) return DRA_EINVAL;
+  hipLaunchKernelGGL(rmsprop_step_kernel, dim3(step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad, square_avg,
+                     grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps, centered, out_norm);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// torch.optim.Adam (no amsgrad / weight decay): m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
+// p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  `step` is the 1-based count.
+__global__ void __launch_bounds__(256)
+adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                 int64_t n, const double* __restrict__ partials, int n_partials, float max_norm, float step_size,
+                 float beta1, float beta2, float inv_sqrt_bc2, float eps, float* __restrict__ out_norm) {
+  const float coef = partials ? clip_coef_from_partials(partials, n_partials, max_norm, out_norm) : 1.f;
+  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gk = g[i] * coef;
+    const float mk = m[i] * beta1 + omb1 * gk;
+    const float vk = v[i] * beta2 + omb2 * gk * gk;
+    m[i] = mk;
+    v[i] = vk;
+    p[i] = p[i] - step_size * (mk / (sqrtf(vk) * inv_sqrt_bc2 + eps));
+  }
+}
+
+DRA_API int dra_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          const double* partials, int n_partials, float max_norm, float lr, float beta1, float beta2,
+                          float eps, int64_t step, float* out_norm, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return DRA_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  int64_t b = (n + 255) / 256;
+  if (b > 2048) b = 2048;
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)b), dim3(256), 0, dra_stream(stream), param, grad, exp_avg,
+                     exp_avg_sq, n, partials, n_partials, max_norm, (float)((double)lr / bc1), beta1, beta2,
+                     (float)(1.0 / sqrt(bc2)), eps, out_norm);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// Device-to-device parameter copy for the target-network sync (DQN_agent.py:136-138).
+DRA_API int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream) {
+  if (!dst || !src || n < 0) return DRA_EINVAL;
+  DRA_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, dra_stream(stream)));
+  return DRA_OK;
+}

@@ -1,0 +1,203 @@
+// fp64 binary-heap sum tree in HBM (K7 sample / K8 update).
+// Replaces deep_rl/utils/sum_tree.py:6-66 as used by deep_rl/component/replay.py:152-196.
+//
+// Storage is the reference's own heap array: f64[2*cap-1], root 0, children 2i+1 / 2i+2,
+// leaves cap-1 .. 2cap-2 (two depths when cap is not a power of two), so the tree is
+// inspectable and comparable node by node with the reference's numpy array.
+//
+// Update modes:
+//   parallel  (default) one lane per updated leaf; leaves are written, then every affected
+//             ancestor is recomputed as left+right, one level per barrier.  In the regime the
+//             reference runs in (fp32-valued priorities summed in fp64) every
+//             node sum is exact, hence identical to the reference's incremental `+= change`.
+//   ordered   one lane replays the reference's `tree[parent] += change` walk update by update;
+//             bit-identical for ANY fp64 priorities, ~50x slower (dependent L2 round trips).
+// pending_idx gating, first-writer-wins de-duplication and max_priority live on the host
+// mirror (deeprl_amd/component/replay.py), which passes only the effective updates.
+#include "common.h"
+#include <new>
+
+struct dra_sumtree {
+  int64_t capacity;
+  int64_t n_nodes;
+  int levels;  // depth of the deepest leaf (root = 0)
+  double* tree;
+};
+
+DRA_API int dra_sumtree_create(dra_sumtree** out, int64_t capacity) {
+  if (!out || capacity < 1) return DRA_EINVAL;
+  dra_sumtree* t = new (std::nothrow) dra_sumtree();
+  if (!t) return DRA_ENOMEM;
+  t->capacity = capacity;
+  t->n_nodes = 2 * capacity - 1;
+  int lv = 0;
+  for (int64_t node = t->n_nodes - 1; node > 0; node = (node - 1) / 2) ++lv;
+  t->levels = lv;
+  hipError_t e = hipMalloc(&t->tree, (size_t)t->n_nodes * sizeof(double));
+  if (e != hipSuccess) { delete t; return (int)e; }
+  e = hipMemset(t->tree, 0, (size_t)t->n_nodes * sizeof(double));
+  if (e != hipSuccess) { (void)hipFree(t->tree); delete t; return (int)e; }
+  *out = t;
+  return DRA_OK;
+}
+
+DRA_API int dra_sumtree_destroy(dra_sumtree* t) {
+  if (!t) return DRA_OK;
+  (void)hipFree(t->tree);
+  delete t;
+  return DRA_OK;
+}
+
+DRA_API int dra_sumtree_pointer(dra_sumtree* t, void** tree_dev, int64_t* n_nodes) {
+  if (!t) return DRA_EINVAL;
+  if (tree_dev) *tree_dev = t->tree;
+  if (n_nodes) *n_nodes = t->n_nodes;
+  return DRA_OK;
+}
+
+// L1-bypassing accessors: nodes written by one lane are read by other lanes of the same
+// workgroup a barrier later; sc1 loads/stores are served by L2, never a stale L1 line.
+__device__ __forceinline__ double node_load(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void node_store(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One workgroup, one lane per update (n <= 1024).  Leaves must be unique.
+__global__ void __launch_bounds__(1024)
+sumtree_update_parallel_kernel(double* __restrict__ tree, int levels, const int64_t* __restrict__ leaf,
+                               const double* __restrict__ prio, int n) {
+  int64_t node = -1;
+  if ((int)threadIdx.x < n) {
+    node = leaf[threadIdx.x];
+    node_store(tree + node, prio[threadIdx.x]);
+  }
+  for (int lv = 0; lv < levels; ++lv) {
+    __syncthreads();  // previous level's stores are in L2 before anyone reads them
+    if (node > 0) {
+      const int64_t parent = (node - 1) >> 1;
+      const double s = __dadd_rn(node_load(tree + 2 * parent + 1), node_load(tree + 2 * parent + 2));
+      node_store(tree + parent, s);
+      node = parent;
+    }
+  }
+}
+
+// Reference-order replay: sum_tree.py:54-60 + _propagate :16-20, one update after another.
+__global__ void sumtree_update_ordered_kernel(double* __restrict__ tree, const int64_t* __restrict__ leaf,
+                                              const double* __restrict__ prio, int n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int k = 0; k < n; ++k) {
+    int64_t node = leaf[k];
+    const double p = prio[k];
+    const double change = __dsub_rn(p, tree[node]);
+    tree[node] = p;
+    while (node > 0) {
+      node = (node - 1) >> 1;
+      tree[node] = __dadd_rn(tree[node], change);
+    }
+  }
+}
+
+DRA_API int dra_sumtree_update(dra_sumtree* t, const int64_t* leaf_idx_dev, const double* prio_dev, int n, int ordered,
+                               void* stream) {
+  if (!t || !leaf_idx_dev || !prio_dev || n < 0 || n > 1024) return DRA_EINVAL;
+  if (n == 0) return DRA_OK;
+  if (ordered)
+    hipLaunchKernelGGL(sumtree_update_ordered_kernel, dim3(1), dim3(64), 0, dra_stream(stream), t->tree, leaf_idx_dev,
+                       prio_dev, n);
+  else {
+    const int threads = ((n + 63) / 64) * 64;
+    hipLaunchKernelGGL(sumtree_update_parallel_kernel, dim3(1), dim3(threads), 0, dra_stream(stream), t->tree, t->levels,
+                       leaf_idx_dev, prio_dev, n);
+  }
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// Single-leaf variant with by-value arguments (PrioritizedReplay.feed -> SumTree.add, sum_tree.py:39-51):
+// one wave walks leaf -> root recomputing each ancestor from its children.
+__global__ void sumtree_set_kernel(double* __restrict__ tree, int64_t leaf, double prio) {
+  if (threadIdx.x != 0) return;
+  int64_t node = leaf;
+  tree[node] = prio;
+  double below = prio;
+  while (node > 0) {
+    const int64_t parent = (node - 1) >> 1;
+    const int64_t sib = (node & 1) ? node + 1 : node - 1;  // odd index = left child
+    const double s = (node & 1) ? __dadd_rn(below, tree[sib]) : __dadd_rn(tree[sib], below);
+    tree[parent] = s;
+    below = s;
+    node = parent;
+  }
+}
+
+DRA_API int dra_sumtree_set(dra_sumtree* t, int64_t leaf_idx, double prio, void* stream) {
+  if (!t || leaf_idx < t->capacity - 1 || leaf_idx >= t->n_nodes) return DRA_EINVAL;
+  hipLaunchKernelGGL(sumtree_set_kernel, dim3(1), dim3(64), 0, dra_stream(stream), t->tree, leaf_idx, prio);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// Stratified sample (replay.py:168-175 + sum_tree.py:23-33): lane i draws
+//   s = a + (b - a) * u_i,  a = seg*i, b = seg*(i+1), seg = total / B      (python random.uniform)
+// and descends `s <= left ? left : (right, s - left)` until 2i+1 >= n_nodes.  All fp64, no
+// contraction, same association as the reference.
+__global__ void __launch_bounds__(1024)
+sumtree_sample_kernel(const double* __restrict__ tree, int64_t n_nodes, const double* __restrict__ u, int batch,
+                      int64_t* __restrict__ out_idx, double* __restrict__ out_p, double* __restrict__ out_total) {
+  const int i = threadIdx.x;
+  const double total = tree[0];
+  if (i == 0 && out_total) *out_total = total;
+  if (i >= batch) return;
+  const double seg = __ddiv_rn(total, (double)batch);
+  const double a = __dmul_rn(seg, (double)i);
+  const double b = __dmul_rn(seg, (double)(i + 1));
+  double s = __dadd_rn(a, __dmul_rn(__dsub_rn(b, a), u[i]));
+  int64_t idx = 0;
+  while (true) {
+    const int64_t left = 2 * idx + 1;
+    if (left >= n_nodes) break;
+    const double lv = tree[left];
+    if (s <= lv) idx = left;
+    else { idx = left + 1; s = __dsub_rn(s, lv); }
+  }
+  out_idx[i] = idx;
+  out_p[i] = tree[idx];
+}
+
+DRA_API int dra_sumtree_sample(dra_sumtree* t, const double* u_dev, int batch, int64_t* out_tree_idx, double* out_p,
+                               double* out_total, void* stream) {
+  if (!t || !u_dev || !out_tree_idx || !out_p || batch < 1 || batch > 1024) return DRA_EINVAL;
+  const int threads = ((batch + 63) / 64) * 64;
+  hipLaunchKernelGGL(sumtree_sample_kernel, dim3(1), dim3(threads), 0, dra_stream(stream), (const double*)t->tree,
+                     t->n_nodes, u_dev, batch, out_tree_idx, out_p, out_total);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// Bottom-up rebuild of every internal node from the leaves (state restore / tests): one launch
+// per heap level, deepest first.  Level L holds nodes [2^L - 1, 2^(L+1) - 2].
+__global__ void __launch_bounds__(256)
+sumtree_rebuild_level_kernel(double* __restrict__ tree, int64_t first, int64_t last, int64_t n_nodes) {
+  const int64_t node = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (node > last) return;
+  const int64_t l = 2 * node + 1;
+  if (l >= n_nodes) return;  // a leaf living on this level
+  tree[node] = __dadd_rn(tree[l], tree[l + 1]);
+}
+
+DRA_API int dra_sumtree_rebuild(dra_sumtree* t, void* stream) {
+  if (!t) return DRA_EINVAL;
+  for (int lv = t->levels - 1; lv >= 0; --lv) {
+    const int64_t first = ((int64_t)1 << lv) - 1;
+    int64_t last = ((int64_t)1 << (lv + 1)) - 2;
+    if (last > t->n_nodes - 1) last = t->n_nodes - 1;
+    const int64_t cnt = last - first + 1;
+    hipLaunchKernelGGL(sumtree_rebuild_level_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, dra_stream(stream),
+                       t->tree, first, last, t->n_nodes);
+    DRA_LAUNCH_CHECK();
+  }
+  return DRA_OK;
+}

@@ -1,0 +1,104 @@
+"""State / reward normalisers (deep_rl/utils/normalizer.py:11-71).
+
+numpy inputs (what environments hand over) are processed on the host exactly as the reference
+does; a uint8 DEVICE tensor (what the HBM replay returns) goes through the HIP table kernel
+whose 256 entries are f32(f64(v) * coef) -- the reference's sync-replay numerics
+(normalizer.py:58-61 then torch_utils.py:23), bit for bit.
+"""
+import numpy as np
+import torch
+
+
+class BaseNormalizer:
+    def __init__(self, read_only=False):
+        self.read_only = read_only
+
+    def set_read_only(self):
+        self.read_only = True
+
+    def unset_read_only(self):
+        self.read_only = False
+
+    def state_dict(self):
+        return None
+
+    def load_state_dict(self, _):
+        return
+
+
+class RunningMeanStd:
+    """Count-weighted running mean / variance (the algorithm of baselines.common.running_mean_std
+    @ 8e56dd, which the reference imports at normalizer.py:8; restated, that package is absent)."""
+
+    def __init__(self, epsilon=1e-4, shape=()):
+        self.mean = np.zeros(shape, 'float64')
+        self.var = np.ones(shape, 'float64')
+        self.count = epsilon
+
+    def update(self, x):
+        x = np.asarray(x)
+        b_mean, b_var, b_count = np.mean(x, axis=0), np.var(x, axis=0), x.shape[0]
+        delta = b_mean - self.mean
+        total = self.count + b_count
+        m2 = self.var * self.count + b_var * b_count + np.square(delta) * self.count * b_count / total
+        self.mean = self.mean + delta * b_count / total
+        self.var = m2 / total
+        self.count = total
+
+
+class MeanStdNormalizer(BaseNormalizer):
+    def __init__(self, read_only=False, clip=10.0, epsilon=1e-8):
+        BaseNormalizer.__init__(self, read_only)
+        self.rms = None
+        self.clip = clip
+        self.epsilon = epsilon
+
+    def __call__(self, x):
+        x = np.asarray(x)
+        if self.rms is None:
+            self.rms = RunningMeanStd(shape=(1,) + x.shape[1:])
+        if not self.read_only:
+            self.rms.update(x)
+        return np.clip((x - self.rms.mean) / np.sqrt(self.rms.var + self.epsilon), -self.clip, self.clip)
+
+    def state_dict(self):
+        return {'mean': self.rms.mean, 'var': self.rms.var}
+
+    def load_state_dict(self, saved):
+        self.rms.mean = saved['mean']
+        self.rms.var = saved['var']
+
+
+class RescaleNormalizer(BaseNormalizer):
+    def __init__(self, coef=1.0):
+        BaseNormalizer.__init__(self)
+        self.coef = coef
+        self._lut = {}
+
+    def lut(self, device):
+        """f32(f64(v) * coef) for v in 0..255, resident on `device`."""
+        key = str(device)
+        if key not in self._lut:
+            table = np.asarray(self.coef * np.arange(256, dtype=np.uint8), dtype=np.float32)
+            self._lut[key] = torch.from_numpy(table).to(device)
+        return self._lut[key]
+
+    def __call__(self, x):
+        if isinstance(x, torch.Tensor):
+            if x.dtype == torch.uint8 and x.is_cuda:
+                from . import ops
+                return ops.u8_to_f32(x, self.lut(x.device))
+            if self.coef == 1.0:
+                return x
+            return self.coef * x
+        return self.coef * np.asarray(x)
+
+
+class ImageNormalizer(RescaleNormalizer):
+    def __init__(self):
+        RescaleNormalizer.__init__(self, 1.0 / 255)
+
+
+class SignNormalizer(BaseNormalizer):
+    def __call__(self, x):
+        return np.sign(x)

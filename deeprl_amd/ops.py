@@ -1,0 +1,430 @@
+"""Thin torch-tensor wrappers over the C-ABI (one function per exported kernel group).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every bit of
+arithmetic on the hot path is a hand-written HIP kernel in deeprl_amd/csrc reached through
+deeprl_amd._lib.  All tensors must be CUDA(ROCm) tensors; there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import DraError, lib, ptr, ptr_array, stream_ptr
+
+ACT = {None: 0, "none": 0, "relu": 1, "tanh": 2}
+_f32 = torch.float32
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise DraError("deeprl_amd ops need device tensors (got %s); there is no CPU fallback" % t.device)
+    return t
+
+
+def _c(t, dtype=None):
+    _dev(t)
+    if dtype is not None and t.dtype != dtype:
+        raise DraError("expected dtype %s, got %s" % (dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------ ring
+class Ring:
+    """HBM ring handle (dra_ring_*).  Host bookkeeping (pos/size) lives in component/replay.py."""
+
+    def __init__(self, capacity, frame_bytes, action_bytes, history, n_step, discount):
+        h = ctypes.c_void_p()
+        lib.dra_ring_create(ctypes.byref(h), int(capacity), int(frame_bytes), int(action_bytes), int(history),
+                            int(n_step), float(discount))
+        self.h = h
+        self.capacity, self.frame_bytes, self.action_bytes = int(capacity), int(frame_bytes), int(action_bytes)
+        self.history, self.n_step = int(history), int(n_step)
+
+    def close(self):
+        if self.h:
+            lib.dra_ring_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def put_host(self, slot, frame, action, reward, mask):
+        frame = np.ascontiguousarray(frame)
+        action = np.ascontiguousarray(action)
+        if frame.nbytes != self.frame_bytes or action.nbytes != self.action_bytes:
+            raise DraError("put_host: frame/action byte size mismatch (%d/%d vs %d/%d)" %
+                           (frame.nbytes, action.nbytes, self.frame_bytes, self.action_bytes))
+        lib.dra_ring_put_host(self.h, int(slot), frame.ctypes.data_as(ctypes.c_void_p),
+                              action.ctypes.data_as(ctypes.c_void_p), float(reward), int(mask), stream_ptr())
+
+    def put_device(self, slot0, frames, actions=None, rewards=None, masks=None, action_val=0, reward_val=0.0,
+                   mask_val=1, count=1):
+        lib.dra_ring_put(self.h, int(slot0), int(count), ptr(_c(frames)), ptr(actions), int(action_val), ptr(rewards),
+                         float(reward_val), ptr(masks), int(mask_val), stream_ptr())
+
+    def fill_synthetic(self, slot0, count, counter0, seed, n_actions=4, done_period=800):
+        lib.dra_ring_fill_synthetic(self.h, int(slot0), int(count), int(counter0), int(seed), int(n_actions),
+                                    int(done_period), stream_ptr())
+
+    def gather(self, idx, state_shape, state_dtype, action_dtype=torch.int64, want_f32=False, out=None):
+        """idx: int64 device tensor [B].  Returns dict of device tensors shaped like the reference's sample()."""
+        idx = _c(idx, torch.int64)
+        b = idx.numel()
+        dev = idx.device
+        if out is None:
+            stack = (b, self.history) + tuple(state_shape) if self.history > 1 else (b,) + tuple(state_shape)
+            esize = torch.empty(0, dtype=action_dtype).element_size()
+            ashape = (b,) if self.action_bytes == esize else (b, self.action_bytes // esize)
+            out = dict(state=torch.empty(stack, dtype=state_dtype, device=dev),
+                       next_state=torch.empty(stack, dtype=state_dtype, device=dev),
+                       action=torch.empty(ashape, dtype=action_dtype, device=dev),
+                       reward=torch.empty(b, dtype=torch.float64, device=dev),
+                       mask=torch.empty(b, dtype=torch.int32, device=dev))
+            if want_f32:
+                out["reward_f32"] = torch.empty(b, dtype=_f32, device=dev)
+                out["mask_f32"] = torch.empty(b, dtype=_f32, device=dev)
+        lib.dra_ring_gather(self.h, ptr(idx), b, ptr(out["state"]), ptr(out["next_state"]), ptr(out["action"]),
+                            ptr(out["reward"]), ptr(out["mask"]), ptr(out.get("reward_f32")), ptr(out.get("mask_f32")),
+                            stream_ptr())
+        return out
+
+    def pointers(self):
+        ps = [ctypes.c_void_p() for _ in range(4)]
+        lib.dra_ring_pointers(self.h, *[ctypes.byref(p) for p in ps])
+        return [p.value for p in ps]
+
+
+def u8_to_f32(x_u8, lut):
+    x = _c(x_u8, torch.uint8)
+    out = torch.empty(x.shape, dtype=_f32, device=x.device)
+    lib.dra_u8_to_f32_lut(ptr(x), ptr(out), x.numel(), ptr(_c(lut, _f32)), stream_ptr())
+    return out
+
+
+# ------------------------------------------------------------------------------------------ sum tree
+class SumTree:
+    def __init__(self, capacity):
+        h = ctypes.c_void_p()
+        lib.dra_sumtree_create(ctypes.byref(h), int(capacity))
+        self.h = h
+        self.capacity = int(capacity)
+        self.n_nodes = 2 * self.capacity - 1
+
+    def close(self):
+        if self.h:
+            lib.dra_sumtree_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, leaf_idx, prio, ordered=False):
+        leaf_idx, prio = _c(leaf_idx, torch.int64), _c(prio, torch.float64)
+        lib.dra_sumtree_update(self.h, ptr(leaf_idx), ptr(prio), leaf_idx.numel(), int(bool(ordered)), stream_ptr())
+
+    def set(self, leaf_idx, prio):
+        lib.dra_sumtree_set(self.h, int(leaf_idx), float(prio), stream_ptr())
+
+    def sample(self, u):
+        u = _c(u, torch.float64)
+        b = u.numel()
+        idx = torch.empty(b, dtype=torch.int64, device=u.device)
+        p = torch.empty(b, dtype=torch.float64, device=u.device)
+        total = torch.empty(1, dtype=torch.float64, device=u.device)
+        lib.dra_sumtree_sample(self.h, ptr(u), b, ptr(idx), ptr(p), ptr(total), stream_ptr())
+        return idx, p, total
+
+    def rebuild(self):
+        lib.dra_sumtree_rebuild(self.h, stream_ptr())
+
+    def as_tensor(self):
+        """Zero-copy f64 view of the heap array (for tests / checkpoints)."""
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        lib.dra_sumtree_pointer(self.h, ctypes.byref(p), ctypes.byref(n))
+        return _wrap_device_pointer(p.value, n.value, torch.float64)
+
+
+def _wrap_device_pointer(addr, numel, dtype):
+    """torch view over library-owned HBM via __cuda_array_interface__ (no copy)."""
+    typestr = {torch.float64: "<f8", torch.float32: "<f4", torch.uint8: "|u1", torch.int64: "<i8",
+               torch.int32: "<i4"}[dtype]
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = dict(shape=(int(numel),), typestr=typestr, data=(int(addr), False), version=2)
+    return torch.as_tensor(h, device="cuda")
+
+
+# ------------------------------------------------------------------------------------------ losses
+def _action_args(action):
+    if action.dtype == torch.int64:
+        return ptr(_c(action)), 1
+    if action.dtype == _f32:
+        return ptr(_c(action)), 0
+    raise DraError("action must be int64 or float32, got %s" % action.dtype)
+
+
+def td_loss(q, q_next_target, action, reward, mask, gamma_n, q_next_online=None, sampling_prob=None, beta=0.0,
+            replay_eps=0.01, replay_alpha=0.5):
+    q, qt = _c(q, _f32), _c(q_next_target, _f32)
+    b, a = q.shape
+    dev = q.device
+    out = dict(loss=torch.empty((), dtype=_f32, device=dev), dq=torch.empty_like(q),
+               delta=torch.empty(b, dtype=_f32, device=dev))
+    if sampling_prob is not None:
+        out["prio"] = torch.empty(b, dtype=_f32, device=dev)
+        out["weights"] = torch.empty(b, dtype=_f32, device=dev)
+    ap, ai = _action_args(action)
+    lib.dra_td_loss(ptr(q), ptr(qt), ptr(None if q_next_online is None else _c(q_next_online, _f32)), ap, ai,
+                    ptr(_c(reward, _f32)), ptr(_c(mask, _f32)), b, a, float(gamma_n),
+                    ptr(None if sampling_prob is None else _c(sampling_prob, _f32)), float(beta), float(replay_eps),
+                    float(replay_alpha), ptr(out["loss"]), ptr(out["dq"]), ptr(out["delta"]), ptr(out.get("prio")),
+                    ptr(out.get("weights")), stream_ptr())
+    return out
+
+
+def c51_loss(logits, logits_next_target, action, reward, mask, gamma_n, atoms, v_min, v_max,
+             logits_next_online=None, weights=None):
+    lg, lt = _c(logits, _f32), _c(logits_next_target, _f32)
+    b, a, n = lg.shape
+    out = dict(kl=torch.empty(b, dtype=_f32, device=lg.device), dlogits=torch.empty_like(lg))
+    ap, ai = _action_args(action)
+    lib.dra_c51_loss(ptr(lg), ptr(lt), ptr(None if logits_next_online is None else _c(logits_next_online, _f32)), ap,
+                     ai, ptr(_c(reward, _f32)), ptr(_c(mask, _f32)), b, a, n, float(gamma_n), float(v_min),
+                     float(v_max), ptr(_c(atoms, _f32)), ptr(out["kl"]), ptr(out["dlogits"]),
+                     ptr(None if weights is None else _c(weights, _f32)), stream_ptr())
+    out["loss"] = weighted_mean(out["kl"], weights)
+    return out
+
+
+def qr_loss(theta, theta_next_target, action, reward, mask, gamma_n):
+    th, tt = _c(theta, _f32), _c(theta_next_target, _f32)
+    b, a, n = th.shape
+    dev = th.device
+    ws = torch.empty(b * n, dtype=_f32, device=dev)
+    out = dict(loss_vec=torch.empty(n, dtype=_f32, device=dev), loss=torch.empty((), dtype=_f32, device=dev),
+               dtheta=torch.empty_like(th))
+    ap, ai = _action_args(action)
+    lib.dra_qr_loss(ptr(th), ptr(tt), ap, ai, ptr(_c(reward, _f32)), ptr(_c(mask, _f32)), b, a, n, float(gamma_n),
+                    ptr(ws), ptr(out["loss_vec"]), ptr(out["loss"]), ptr(out["dtheta"]), stream_ptr())
+    return out
+
+
+def per_weights(loss_vec, sampling_prob, beta, replay_eps, replay_alpha):
+    sp = _c(sampling_prob, _f32)
+    b = sp.numel()
+    prio = torch.empty(b, dtype=_f32, device=sp.device) if loss_vec is not None else None
+    w = torch.empty(b, dtype=_f32, device=sp.device)
+    lib.dra_per_weights(ptr(None if loss_vec is None else _c(loss_vec, _f32)), ptr(sp), b, float(beta),
+                        float(replay_eps), float(replay_alpha), ptr(prio), ptr(w), stream_ptr())
+    return prio, w
+
+
+def weighted_mean(x, w=None):
+    x = _c(x, _f32)
+    out = torch.empty((), dtype=_f32, device=x.device)
+    lib.dra_weighted_mean(ptr(x), ptr(None if w is None else _c(w, _f32)), x.numel(), ptr(out), stream_ptr())
+    return out
+
+
+def ppo_loss(log_pi_a, entropy, v, old_log_pi_a, adv, ret, ratio_clip, entropy_weight):
+    lp = _c(log_pi_a, _f32)
+    m = lp.numel()
+    out3 = torch.empty(3, dtype=_f32, device=lp.device)
+    g = [torch.empty(lp.shape, dtype=_f32, device=lp.device) for _ in range(3)]
+    lib.dra_ppo_loss(ptr(lp), ptr(_c(entropy, _f32)), ptr(_c(v, _f32)), ptr(_c(old_log_pi_a, _f32)), ptr(_c(adv, _f32)),
+                     ptr(_c(ret, _f32)), m, float(ratio_clip), float(entropy_weight), ptr(out3), ptr(g[0]), ptr(g[1]),
+                     ptr(g[2]), stream_ptr())
+    return out3, g
+
+
+def a2c_loss(log_pi_a, entropy, v, adv, ret, entropy_weight, value_loss_weight):
+    lp = _c(log_pi_a, _f32)
+    m = lp.numel()
+    out4 = torch.empty(4, dtype=_f32, device=lp.device)
+    g = [torch.empty(lp.shape, dtype=_f32, device=lp.device) for _ in range(3)]
+    lib.dra_a2c_loss(ptr(lp), ptr(_c(entropy, _f32)), ptr(_c(v, _f32)), ptr(_c(adv, _f32)), ptr(_c(ret, _f32)), m,
+                     float(entropy_weight), float(value_loss_weight), ptr(out4), ptr(g[0]), ptr(g[1]), ptr(g[2]),
+                     stream_ptr())
+    return out4, g
+
+
+# ------------------------------------------------------------------------------------------ scan
+def gae(reward, mask, value, gamma, tau, use_gae):
+    """reward, mask: [T,N(,1)] f32; value: [T+1,N(,1)] f32 -> (adv, ret) shaped like reward."""
+    r, m, v = _c(reward, _f32), _c(mask, _f32), _c(value, _f32)
+    t_len = r.shape[0]
+    n_env = r.numel() // t_len
+    if v.numel() != (t_len + 1) * n_env or m.numel() != r.numel():
+        raise DraError("gae: shape mismatch")
+    adv, ret = torch.empty_like(r), torch.empty_like(r)
+    lib.dra_gae(ptr(r), ptr(m), ptr(v), t_len, n_env, float(gamma), float(tau), int(bool(use_gae)), ptr(adv), ptr(ret),
+                stream_ptr())
+    return adv, ret
+
+
+def adv_normalize_(adv):
+    a = _dev(adv)
+    if not a.is_contiguous() or a.dtype != _f32:
+        raise DraError("adv_normalize_ needs a contiguous f32 tensor")
+    lib.dra_adv_normalize(ptr(a), a.numel(), stream_ptr())
+    return adv
+
+
+# ------------------------------------------------------------------------------------------ contractions
+_CONV_GEOM = {1: (4, 84, 32, 8, 4), 2: (32, 20, 64, 4, 2), 3: (64, 9, 64, 3, 1)}  # C, H, OC, K, S
+
+
+def conv_layer_for(weight_shape, stride, in_hw):
+    """Which NatureConvBody layer (1..3) a Conv2d is, or None."""
+    for layer, (c, h, oc, k, s) in _CONV_GEOM.items():
+        if tuple(weight_shape) == (oc, c, k, k) and stride == s and in_hw == h:
+            return layer
+    return None
+
+
+def conv_out_shape(layer, batch):
+    c, h, oc, k, s = _CONV_GEOM[layer]
+    o = (h - k) // s + 1
+    return (batch, oc, o, o)
+
+
+def conv_fwd(layer, xs, ws, bs, act="relu", u8_coef=None):
+    """Batched forward: lists of nz inputs / weights / biases -> list of nz outputs (one launch)."""
+    nz = len(xs)
+    c, h, oc, k, s = _CONV_GEOM[layer]
+    batch = xs[0].shape[0]
+    is_u8 = xs[0].dtype == torch.uint8
+    if is_u8 and u8_coef is None:
+        raise DraError("uint8 input needs u8_coef")
+    xs = [_c(x, torch.uint8 if is_u8 else _f32) for x in xs]
+    for x in xs:
+        if tuple(x.shape) != (batch, c, h, h):
+            raise DraError("conv_fwd layer %d expects [B,%d,%d,%d], got %s" % (layer, c, h, h, tuple(x.shape)))
+    ws = [_c(w, _f32) for w in ws]
+    bs = [_c(b, _f32) for b in bs]
+    ys = [torch.empty(conv_out_shape(layer, batch), dtype=_f32, device=xs[0].device) for _ in range(nz)]
+    lib.dra_conv_fwd(layer, nz, ptr_array(xs), ptr_array(ws), ptr_array(bs), ptr_array(ys), batch, int(is_u8),
+                     float(u8_coef if is_u8 else 1.0), ACT[act], stream_ptr())
+    return ys
+
+
+def conv_bwd_w(layer, dy, x, ksplit=16, u8_coef=None, slabs=None):
+    """Returns (dw_slabs [ksplit, OC*K], db_slabs [ksplit, OC]) views of one slab buffer."""
+    c, h, oc, k, s = _CONV_GEOM[layer]
+    kk = c * k * k
+    batch = x.shape[0]
+    is_u8 = x.dtype == torch.uint8
+    stride = oc * kk + oc
+    stride = (stride + 3) // 4 * 4
+    if slabs is None:
+        slabs = torch.empty(ksplit * stride, dtype=_f32, device=x.device)
+    dw0 = slabs
+    lib.dra_conv_bwd_w(layer, ptr(_c(dy, _f32)), ptr(_c(x)), ptr(slabs), ctypes.c_void_p(slabs.data_ptr() + 4 * oc * kk),
+                       stride, ksplit, batch, int(is_u8), float(u8_coef if is_u8 else 1.0), stream_ptr())
+    v = dw0.view(ksplit, stride)
+    return v[:, :oc * kk], v[:, oc * kk:oc * kk + oc]
+
+
+def conv_bwd_x(layer, dy, w, xact=None, act="relu"):
+    """Gradient w.r.t. the layer's input; with `xact` (the layer-below's activated output) the
+    activation derivative of that layer is folded in (gradient w.r.t. its PRE-activation)."""
+    c, h, oc, k, s = _CONV_GEOM[layer]
+    batch = dy.shape[0]
+    dx = torch.empty((batch, c, h, h), dtype=_f32, device=dy.device)
+    lib.dra_conv_bwd_x(layer, ptr(_c(dy, _f32)), ptr(_c(w, _f32)), ptr(None if xact is None else _c(xact, _f32)), ptr(dx),
+                       batch, ACT[act], stream_ptr())
+    return dx
+
+
+def act_bwd(dy, y, act):
+    """dpre = dy * act'(y) (activation derivative through its output)."""
+    dy, y = _c(dy, _f32), _c(y, _f32)
+    out = torch.empty_like(dy)
+    lib.dra_act_bwd(ptr(dy), ptr(y), ptr(out), dy.numel(), ACT[act], stream_ptr())
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(device, floats):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < floats:
+        t = torch.empty(max(floats, 1 << 20), dtype=_f32, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def linear_fwd(xs, ws, bs, act=None):
+    nz = len(xs)
+    xs = [_c(x, _f32) for x in xs]
+    batch, fin = xs[0].shape
+    fout = ws[0].shape[0]
+    ws = [_c(w, _f32) for w in ws]
+    bs = [None if b is None else _c(b, _f32) for b in bs]
+    ys = [torch.empty((batch, fout), dtype=_f32, device=xs[0].device) for _ in range(nz)]
+    need = nz * 32 * batch * fout
+    wsb = _workspace(xs[0].device, need)
+    lib.dra_linear_fwd(nz, ptr_array(xs), ptr_array(ws), ptr_array(bs), ptr_array(ys), batch, fin, fout, ACT[act],
+                       ptr(wsb), wsb.numel(), stream_ptr())
+    return ys
+
+
+def linear_bwd_w(dy, x, dw=None, db=None, want_bias=True):
+    dy, x = _c(dy, _f32), _c(x, _f32)
+    batch, fout = dy.shape
+    fin = x.shape[1]
+    if dw is None:
+        dw = torch.empty((fout, fin), dtype=_f32, device=x.device)
+    if db is None and want_bias:
+        db = torch.empty(fout, dtype=_f32, device=x.device)
+    lib.dra_linear_bwd_w(ptr(dy), ptr(x), ptr(dw), ptr(db), batch, fin, fout, stream_ptr())
+    return dw, db
+
+
+def linear_bwd_x(dy, w, xact=None, act=None, dx=None):
+    dy, w = _c(dy, _f32), _c(w, _f32)
+    batch, fout = dy.shape
+    fin = w.shape[1]
+    if dx is None:
+        dx = torch.empty((batch, fin), dtype=_f32, device=dy.device)
+    lib.dra_linear_bwd_x(ptr(dy), ptr(w), ptr(None if xact is None else _c(xact, _f32)), ptr(dx), batch, fin, fout,
+                         ACT[act], stream_ptr())
+    return dx
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def norm_partials():
+    return lib.dra_norm_partials.raw()
+
+
+def grad_sqnorm(grad, partials, slabs=None, n_slabs=0, slab_stride=0):
+    lib.dra_grad_sqnorm(ptr(grad), grad.numel(), ptr(slabs), int(n_slabs), int(slab_stride), ptr(partials), stream_ptr())
+
+
+def rmsprop_step(param, grad, square_avg, grad_avg, partials, n_partials, max_norm, lr, alpha, eps, centered,
+                 out_norm=None):
+    lib.dra_rmsprop_step(ptr(param), ptr(grad), ptr(square_avg), ptr(grad_avg), param.numel(), ptr(partials),
+                         int(n_partials), float(max_norm if max_norm else 0.0), float(lr), float(alpha), float(eps),
+                         int(bool(centered)), ptr(out_norm), stream_ptr())
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, partials, n_partials, max_norm, lr, beta1, beta2, eps, step,
+              out_norm=None):
+    lib.dra_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), ptr(partials),
+                      int(n_partials), float(max_norm if max_norm else 0.0), float(lr), float(beta1), float(beta2),
+                      float(eps), int(step), ptr(out_norm), stream_ptr())
+
+
+def copy_f32(dst, src):
+    lib.dra_copy_f32(ptr(dst), ptr(src), src.numel(), stream_ptr())

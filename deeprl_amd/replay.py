@@ -1,0 +1,338 @@
+"""Host mirror of the reference replay interface over the HBM ring + HIP kernels.
+
+Same names, constructor signatures, method names and error behaviour as
+deep_rl/component/replay.py (Storage :20-54, UniformReplay :57-149, PrioritizedReplay
+:152-196, ReplayWrapper :199-278); data lives in HBM and `sample()` returns DEVICE tensors
+(the reference's `tensor()` / normalisers pass torch tensors through unchanged, torch_utils.py:20-22,
+normalizer.py:58-61, so agents need no change).
+
+What stays on the host, on purpose: `pos` / `size` bookkeeping, `valid_index`, and every RNG
+draw (numpy legacy global RandomState for uniform sampling, python `random` for prioritized
+sampling) -- the index stream is therefore the reference's own, draw for draw.
+"""
+import random
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import DraError
+from .support import Config
+
+Transition = namedtuple('Transition', ['state', 'action', 'reward', 'next_state', 'mask'])
+PrioritizedTransition = namedtuple('Transition',
+                                   ['state', 'action', 'reward', 'next_state', 'mask', 'sampling_prob', 'idx'])
+
+_DEFAULT_KEYS = ['state', 'action', 'reward', 'mask', 'v', 'q', 'pi', 'log_pi', 'entropy', 'advantage', 'ret', 'q_a',
+                 'log_pi_a', 'mean', 'next_state']
+
+_NP2TORCH = {np.dtype(np.uint8): torch.uint8, np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+             np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32}
+
+
+class Storage:
+    """On-policy rollout buffer: per-key python lists of [N, ...] device tensors, time-major
+    `extract` (replay.py:20-54).  Used by the A2C / PPO / n-step agents."""
+
+    def __init__(self, memory_size, keys=None):
+        self.keys = list(keys or []) + _DEFAULT_KEYS
+        self.memory_size = memory_size
+        self.reset()
+
+    def feed(self, data):
+        for k, v in data.items():
+            if k not in self.keys:
+                raise RuntimeError('Undefined key')
+            getattr(self, k).append(v)
+
+    def placeholder(self):
+        for k in self.keys:
+            if len(getattr(self, k)) == 0:
+                setattr(self, k, [None] * self.memory_size)
+
+    def reset(self):
+        for k in self.keys:
+            setattr(self, k, [])
+        self.pos = 0
+        self._size = 0
+
+    def extract(self, keys):
+        entry = namedtuple('Entry', keys)
+        return entry(*[torch.cat(getattr(self, k)[:self.memory_size], dim=0) for k in keys])
+
+
+class _PinnedUploader:
+    """Rotating pinned staging buffers for the few hundred bytes of indices / uniforms that cross
+    the host->device boundary per sample; an event per slot guards reuse."""
+
+    def __init__(self, dtype, numel, device, slots=8):
+        self.bufs = [torch.empty(numel, dtype=dtype).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.device = device
+        self.k = 0
+
+    def upload(self, array):
+        k = self.k
+        self.k = (k + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        n = len(array)
+        self.bufs[k][:n].copy_(torch.from_numpy(np.ascontiguousarray(array)))
+        out = self.bufs[k][:n].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return out
+
+
+class UniformReplay(Storage):
+    TransitionCLS = Transition
+
+    def __init__(self, memory_size, batch_size, n_step=1, discount=1, history_length=1, keys=None):
+        super(UniformReplay, self).__init__(memory_size, keys)
+        self.batch_size = batch_size
+        self.n_step = n_step
+        self.discount = discount
+        self.history_length = history_length
+        self.pos = 0
+        self._size = 0
+        self._ring = None
+        self._state_shape = self._state_dtype = self._action_dtype = None
+        self._idx_up = None
+
+    # -- host bookkeeping (replay.py:69-73, 105-110, 142-146) ---------------------------------
+    def size(self):
+        return self._size
+
+    def full(self):
+        return self._size == self.memory_size
+
+    def valid_index(self, index):
+        if index - self.history_length + 1 >= 0 and index + self.n_step < self.pos:
+            return True
+        if index - self.history_length + 1 >= self.pos and index + self.n_step < self.size():
+            return True
+        return False
+
+    def compute_valid_indices(self):
+        lo = list(range(self.history_length - 1, self.pos - self.n_step))
+        hi = list(range(self.pos + self.history_length - 1, self.size() - self.n_step))
+        return np.asarray(lo + hi)
+
+    # -- feed (replay.py:75-90) ----------------------------------------------------------------
+    def _device(self):
+        dev = Config.DEVICE
+        if dev.type != 'cuda':
+            raise DraError("deeprl_amd replay lives in HBM: call select_device(gpu_id >= 0) first (no CPU path)")
+        return dev
+
+    def _lazy_ring(self, state, action):
+        if self._ring is not None:
+            return
+        dev = self._device()
+        if isinstance(state, torch.Tensor):
+            self._state_shape, self._state_dtype = tuple(state.shape), state.dtype
+            fbytes = state.numel() * state.element_size()
+        else:
+            self._state_shape, self._state_dtype = tuple(state.shape), _NP2TORCH[state.dtype]
+            fbytes = state.nbytes
+        if isinstance(action, torch.Tensor):
+            self._action_dtype, abytes = action.dtype, action.numel() * action.element_size()
+        else:
+            self._action_dtype, abytes = _NP2TORCH[action.dtype], action.nbytes
+        with torch.cuda.device(dev):
+            self._ring = ops.Ring(self.memory_size, fbytes, abytes, self.history_length, self.n_step, self.discount)
+        self._idx_up = _PinnedUploader(torch.int64, 4096, dev)
+
+    def feed(self, data):
+        for k in data.keys():
+            if k not in self.keys:
+                raise RuntimeError('Undefined key')
+        states, actions = data['state'], data['action']
+        rewards, masks = data['reward'], data['mask']
+        n_env = len(states)
+        if n_env != 1:
+            # replay.py:87 writes every env of a multi-env feed to storage[self.pos]: only 1-env
+            # feeds are well defined in the reference; refuse the rest loudly.
+            raise DraError("UniformReplay.feed: one environment per feed (got %d)" % n_env)
+        state, action = states[0], actions[0]
+        if not isinstance(state, torch.Tensor):
+            state = np.asarray(state)
+        if not isinstance(action, torch.Tensor):
+            action = np.asarray(action)
+        self._lazy_ring(state, action)
+        reward = rewards[0]
+        mask = masks[0]
+        slot = self.pos
+        with torch.cuda.device(self._device()):
+            if isinstance(state, torch.Tensor):
+                a_t = action if isinstance(action, torch.Tensor) else None
+                self._ring.put_device(slot, state, actions=a_t, action_val=0 if a_t is not None else int(action),
+                                      reward_val=float(reward), mask_val=int(mask))
+            else:
+                self._ring.put_host(slot, state, action, float(reward), int(mask))
+        if slot >= self._size:
+            self._size += 1
+        self.pos = (slot + 1) % self.memory_size
+
+    # -- sample (replay.py:92-103, 112-140) ----------------------------------------------------
+    def draw_indices(self, batch_size=None):
+        """The reference's rejection loop, draw for draw: one np.random.randint(0, size) per attempt."""
+        if batch_size is None:
+            batch_size = self.batch_size
+        out = []
+        size = self.size()
+        while len(out) < batch_size:
+            i = int(np.random.randint(0, size))
+            if self.valid_index(i):
+                out.append(i)
+        return np.asarray(out, dtype=np.int64)
+
+    def gather(self, idx, want_f32=False):
+        """Device gather of validated indices (numpy int64 or device tensor) -> dict of device tensors."""
+        with torch.cuda.device(self._device()):
+            if not isinstance(idx, torch.Tensor):
+                idx = self._idx_up.upload(idx)
+            return self._ring.gather(idx, self._state_shape, self._state_dtype, self._action_dtype, want_f32=want_f32)
+
+    def sample(self, batch_size=None):
+        g = self.gather(self.draw_indices(batch_size))
+        return Transition(state=g['state'], action=g['action'], reward=g['reward'], next_state=g['next_state'],
+                          mask=g['mask'])
+
+    def construct_transition(self, index):
+        if not self.valid_index(index):
+            return None
+        g = self.gather(np.asarray([index], dtype=np.int64))
+        return Transition(state=g['state'][0], action=g['action'][0], reward=g['reward'][0],
+                          next_state=g['next_state'][0], mask=g['mask'][0])
+
+    def update_priorities(self, info):
+        raise NotImplementedError
+
+    def close(self):
+        if self._ring is not None:
+            self._ring.close()
+            self._ring = None
+
+
+class PrioritizedReplay(UniformReplay):
+    TransitionCLS = PrioritizedTransition
+
+    def __init__(self, memory_size, batch_size, n_step=1, discount=1, history_length=1, keys=None):
+        super(PrioritizedReplay, self).__init__(memory_size, batch_size, n_step, discount, history_length, keys)
+        self.tree = None
+        self.max_priority = 1
+        self._pending = set()   # sum_tree.py:13 pending_idx
+        self._write = 0         # sum_tree.py:7 write cursor
+        self.ordered_updates = False
+        self._u_up = self._leaf_up = self._prio_up = None
+
+    def _lazy_tree(self):
+        if self.tree is None:
+            dev = self._device()
+            with torch.cuda.device(dev):
+                self.tree = ops.SumTree(self.memory_size)
+            self._u_up = _PinnedUploader(torch.float64, 1024, dev)
+            self._leaf_up = _PinnedUploader(torch.int64, 1024, dev)
+            self._prio_up = _PinnedUploader(torch.float64, 1024, dev)
+
+    def feed(self, data):
+        super().feed(data)
+        self._lazy_tree()
+        # SumTree.add (sum_tree.py:39-51): the new leaf is self-marked pending then set
+        leaf = self._write + self.memory_size - 1
+        with torch.cuda.device(self._device()):
+            self.tree.set(leaf, float(self.max_priority))
+        self._write += 1
+        if self._write >= self.memory_size:
+            self._write = 0
+
+    def draw(self, batch_size=None):
+        """replay.py:164-186.  Returns (tree_idx, sampling_prob, data_idx) as numpy arrays; consumes
+        python `random` exactly as the reference: B uniforms, then one random.choice per padded slot."""
+        if batch_size is None:
+            batch_size = self.batch_size
+        self._lazy_tree()
+        u = np.asarray([random.random() for _ in range(batch_size)], dtype=np.float64)
+        with torch.cuda.device(self._device()):
+            idx_d, p_d, total_d = self.tree.sample(self._u_up.upload(u))
+            packed = torch.cat([idx_d.to(torch.float64), p_d, total_d]).cpu().numpy()  # one D2H, syncs
+        tree_idx = packed[:batch_size].astype(np.int64)
+        p = packed[batch_size:2 * batch_size]
+        total = packed[-1]
+        picked = []
+        for i in range(batch_size):
+            ti = int(tree_idx[i])
+            self._pending.add(ti)  # sum_tree.py:66 (before the validity check)
+            di = ti - self.memory_size + 1
+            if not self.valid_index(di):
+                continue
+            picked.append((ti, p[i] / total, di))
+        while len(picked) < batch_size:
+            picked.append(random.choice(picked))  # "This should rarely happen" (replay.py:184-186)
+        return (np.asarray([t[0] for t in picked], dtype=np.int64), np.asarray([t[1] for t in picked], dtype=np.float64),
+                np.asarray([t[2] for t in picked], dtype=np.int64))
+
+    def sample(self, batch_size=None):
+        tree_idx, prob, data_idx = self.draw(batch_size)
+        g = self.gather(data_idx)
+        dev = g['state'].device
+        return PrioritizedTransition(state=g['state'], action=g['action'], reward=g['reward'],
+                                     next_state=g['next_state'], mask=g['mask'],
+                                     sampling_prob=torch.from_numpy(prob).to(dev),
+                                     idx=torch.from_numpy(tree_idx).to(dev))
+
+    def update_priorities(self, info):
+        """replay.py:193-196 + sum_tree.py:54-60: max_priority tracks every offered priority; a tree
+        update happens only for pending leaves, first occurrence wins."""
+        leaves, prios = [], []
+        for idx, priority in info:
+            self.max_priority = max(self.max_priority, priority)
+            idx = int(idx)
+            if idx in self._pending:
+                self._pending.remove(idx)
+                leaves.append(idx)
+                prios.append(float(priority))
+        if leaves:
+            with torch.cuda.device(self._device()):
+                self.tree.update(self._leaf_up.upload(np.asarray(leaves, dtype=np.int64)),
+                                 self._prio_up.upload(np.asarray(prios, dtype=np.float64)), ordered=self.ordered_updates)
+
+    def close(self):
+        super().close()
+        if self.tree is not None:
+            self.tree.close()
+            self.tree = None
+
+
+class ReplayWrapper:
+    """Same surface as replay.py:199-278.  The reference runs the replay in a separate process so
+    that sampling and the host->GPU copy overlap the learner; with the ring resident in HBM there
+    is nothing left to hide, so the wrapper is a thin in-process delegate for both values of the
+    `async` flag (third positional argument, or `async_=` / `**{'async': ...}`)."""
+    FEED = 0
+    SAMPLE = 1
+    EXIT = 2
+    UPDATE_PRIORITIES = 3
+
+    def __init__(self, replay_cls, replay_kwargs, async_=True, **kw):
+        if 'async' in kw:
+            async_ = kw.pop('async')
+        if kw:
+            raise TypeError('unexpected arguments %s' % sorted(kw))
+        self.replay_kwargs = replay_kwargs
+        self.replay_cls = replay_cls
+        self.async_ = async_
+        self.cache_len = 2
+        self.replay = replay_cls(**replay_kwargs)
+        self.sample = self.replay.sample
+        self.feed = self.replay.feed
+        self.update_priorities = self.replay.update_priorities
+
+    def size(self):
+        return self.replay.size()
+
+    def close(self):
+        self.replay.close()

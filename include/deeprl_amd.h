@@ -1,0 +1,142 @@
+/* deeprl_amd.h -- C ABI of libdeeprl_amd.so: the MI355X (gfx950) replacement for the
+ * rollout -> replay -> update hot path of ShangtongZhang/DeepRL.
+ *
+ * The reference has no FFI of its own (it is pure Python over ATen); the boundary below is what a
+ * binding for this path would call, one group per reference component (file:line into the
+ * reference tree).  Conventions:
+ *   - plain `extern "C"`, raw pointers + sizes, no torch / C++ types;
+ *   - every pointer named *_dev or documented "device" is a DEVICE pointer (HBM), outputs are
+ *     CALLER-allocated; handles own only their own HBM;
+ *   - the last argument is a hipStream_t (as void*); every call is asynchronous on it, never
+ *     synchronises the device, allocates nothing (except *_create) and is hipGraph-capturable;
+ *   - return 0 on success, a positive hipError_t or a negative errno-style code otherwise;
+ *     nothing throws or aborts across the boundary;
+ *   - host RNG (numpy legacy RandomState / python `random`) stays with the caller so that index
+ *     streams are the reference's own; only indices / uniforms cross the boundary.
+ */
+#ifndef DEEPRL_AMD_H
+#define DEEPRL_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRA_ACT_NONE 0
+#define DRA_ACT_RELU 1
+#define DRA_ACT_TANH 2
+#define DRA_MAX_Z 4 /* independent (input, weights) sets per batched forward launch */
+
+/* ---- replay ring: deep_rl/component/replay.py:57-149 (UniformReplay storage + construct_transition) */
+typedef struct dra_ring dra_ring;
+/* replay.py:60-67.  frame_bytes = bytes of ONE stored observation (84*84 for Atari), action_bytes = bytes of one
+ * action record (8 for int64). */
+int dra_ring_create(dra_ring** out, int64_t capacity, int64_t frame_bytes, int64_t action_bytes, int history,
+                    int n_step, double discount);
+int dra_ring_destroy(dra_ring* ring);
+int dra_ring_pointers(dra_ring* ring, void** frames, void** actions, void** rewards, void** masks);
+/* replay.py:75-90 (feed): write `count` consecutive slots from DEVICE-ACCESSIBLE sources (device or pinned host).
+ * NULL action/reward/mask sources take the by-value scalars (count == 1 use). */
+int dra_ring_put(dra_ring* ring, int64_t slot0, int64_t count, const void* frame_src, const void* action_src,
+                 int64_t action_val, const double* reward_src, double reward_val, const int32_t* mask_src,
+                 int32_t mask_val, void* stream);
+/* replay.py:75-90 from pageable HOST memory (staged through the handle's pinned buffer). */
+int dra_ring_put_host(dra_ring* ring, int64_t slot, const void* frame_host, const void* action_host, double reward,
+                      int32_t mask, void* stream);
+/* synthetic transitions: frame k = splitmix64(seed, counter) bytes, action/reward/mask hashed. */
+int dra_ring_fill_synthetic(dra_ring* ring, int64_t slot0, int64_t count, int64_t counter0, uint64_t seed,
+                            int n_actions, int done_period, void* stream);
+/* replay.py:112-140 (construct_transition) for a batch of validated indices idx_dev[batch] (int64, device):
+ * out_state / out_next_state [batch][history][frame_bytes], out_action [batch][action_bytes], out_reward f64[batch]
+ * (n-step return, fp64, reference association), out_mask i32[batch]; optional f32 copies of reward / mask
+ * (what torch_utils.py:20-25 `tensor()` would produce).  Any output may be NULL. */
+int dra_ring_gather(dra_ring* ring, const int64_t* idx_dev, int batch, void* out_state, void* out_next_state,
+                    void* out_action, double* out_reward, int32_t* out_mask, float* out_reward_f32,
+                    float* out_mask_f32, void* stream);
+/* deep_rl/utils/normalizer.py:58-66 + torch_utils.py:23: out[i] = lut[in[i]], lut = f32(f64(v) * coef). */
+int dra_u8_to_f32_lut(const void* in_u8, float* out, int64_t n, const float* lut256_dev, void* stream);
+
+/* ---- sum tree: deep_rl/utils/sum_tree.py:6-66 as driven by replay.py:152-196 (PrioritizedReplay) */
+typedef struct dra_sumtree dra_sumtree;
+int dra_sumtree_create(dra_sumtree** out, int64_t capacity);            /* sum_tree.py:8-13 */
+int dra_sumtree_destroy(dra_sumtree* tree);
+int dra_sumtree_pointer(dra_sumtree* tree, void** tree_dev, int64_t* n_nodes);
+/* sum_tree.py:54-60 + 16-20 for n (<= 1024) UNIQUE leaves (tree indices, int64 device) and fp64 priorities.
+ * ordered != 0 replays the reference's incremental `+= change` walk update by update (slow, bit-exact always);
+ * otherwise affected ancestors are recomputed level by level (bit-identical for fp32-valued priorities). */
+int dra_sumtree_update(dra_sumtree* tree, const int64_t* leaf_idx_dev, const double* prio_dev, int n, int ordered,
+                       void* stream);
+int dra_sumtree_set(dra_sumtree* tree, int64_t leaf_idx, double prio, void* stream); /* sum_tree.py:39-51 (add) */
+/* replay.py:168-175 + sum_tree.py:23-33,63-66: u_dev[batch] are raw python random.random() draws; lane i samples
+ * s = a + (b-a)*u_i on segment i of total/batch and descends; outputs tree index, leaf priority, and the total. */
+int dra_sumtree_sample(dra_sumtree* tree, const double* u_dev, int batch, int64_t* out_tree_idx, double* out_p,
+                       double* out_total, void* stream);
+int dra_sumtree_rebuild(dra_sumtree* tree, void* stream);
+
+/* ---- fused losses (forward + backward) */
+/* deep_rl/agent/DQN_agent.py:78-99 (+ PER :120-127).  q, q_next_* [batch][n_actions] f32; action int64[batch] or
+ * f32[batch]; reward/mask f32[batch].  sampling_prob NULL = uniform replay.  out_dq = d(reduced loss)/dq. */
+int dra_td_loss(const float* q, const float* q_next_target, const float* q_next_online, const void* action,
+                int action_is_i64, const float* reward, const float* mask, int batch, int n_actions, float gamma_n,
+                const float* sampling_prob, float beta, float replay_eps, float replay_alpha, float* out_loss,
+                float* out_dq, float* out_delta, float* out_prio, float* out_weights, void* stream);
+/* deep_rl/agent/CategoricalDQN_agent.py:60-89 on LOGITS [batch][n_actions][n_atoms] (softmax folded in). */
+int dra_c51_loss(const float* logits, const float* logits_next_target, const float* logits_next_online,
+                 const void* action, int action_is_i64, const float* reward, const float* mask, int batch,
+                 int n_actions, int n_atoms, float gamma_n, float v_min, float v_max, const float* atoms,
+                 float* out_kl, float* out_dlogits, const float* weights, void* stream);
+/* deep_rl/agent/QuantileRegressionDQN_agent.py:55-77 + utils/torch_utils.py:47-48; workspace f32[batch*n_q]. */
+int dra_qr_loss(const float* theta, const float* theta_next_target, const void* action, int action_is_i64,
+                const float* reward, const float* mask, int batch, int n_actions, int n_quantiles, float gamma_n,
+                float* workspace, float* out_loss_vec, float* out_loss, float* out_dtheta, void* stream);
+/* DQN_agent.py:121-127 applied to any loss vector. */
+int dra_per_weights(const float* loss_vec, const float* sampling_prob, int batch, float beta, float replay_eps,
+                    float replay_alpha, float* out_prio, float* out_weights, void* stream);
+int dra_weighted_mean(const float* x, const float* w, int n, float* out, void* stream);
+/* deep_rl/agent/PPO_agent.py:77-86: out3 = {policy_loss, value_loss, approx_kl}. */
+int dra_ppo_loss(const float* log_pi_a, const float* entropy, const float* v, const float* old_log_pi_a,
+                 const float* adv, const float* ret, int m, float ratio_clip, float entropy_weight, float* out3,
+                 float* g_log_pi_a, float* g_entropy, float* g_v, void* stream);
+/* deep_rl/agent/A2C_agent.py:55-62: out4 = {total, policy, value, entropy}. */
+int dra_a2c_loss(const float* log_pi_a, const float* entropy, const float* v, const float* adv, const float* ret,
+                 int m, float entropy_weight, float value_loss_weight, float* out4, float* g_log_pi_a,
+                 float* g_entropy, float* g_v, void* stream);
+
+/* ---- return / advantage recurrences: PPO_agent.py:51-61, A2C_agent.py:43-53, NStepDQN_agent.py:56-60 */
+/* reward, mask [t_len][n_env]; value [t_len+1][n_env]; outputs [t_len][n_env]. */
+int dra_gae(const float* reward, const float* mask, const float* value, int t_len, int n_env, float gamma, float tau,
+            int use_gae, float* out_adv, float* out_ret, void* stream);
+int dra_adv_normalize(float* adv, int64_t n, void* stream); /* PPO_agent.py:66 */
+
+/* ---- network contractions: deep_rl/network/network_bodies.py:10-33,50-73 + network_heads.py heads */
+/* layer 1..3 of NatureConvBody; nz batched (input, weights) sets per launch. */
+int dra_conv_fwd(int layer, int nz, const void* const* x, const float* const* w, const float* const* bias,
+                 float* const* y, int batch, int x_is_u8, double u8_coef, int act, void* stream);
+int dra_conv_bwd_w(int layer, const float* dy, const void* x, float* dw, float* db, int64_t slab_stride, int ksplit,
+                   int batch, int x_is_u8, double u8_coef, void* stream);
+int dra_conv_bwd_x(int layer, const float* dy, const float* w, const float* xact, float* dx, int batch, int act,
+                   void* stream);
+int dra_act_bwd(const float* dy, const float* y, float* dpre, int64_t n, int act, void* stream);
+int dra_linear_fwd(int nz, const float* const* x, const float* const* w, const float* const* bias, float* const* y,
+                   int batch, int in_features, int out_features, int act, float* workspace, int64_t workspace_floats,
+                   void* stream);
+int dra_linear_bwd_w(const float* dy, const float* x, float* dw, float* db, int batch, int in_features,
+                     int out_features, void* stream);
+int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* dx, int batch, int in_features,
+                     int out_features, int act, void* stream);
+
+/* ---- clip + optimiser: DQN_agent.py:130-134 with the optimisers of examples.py:67-68,139,204,370,508-509,534 */
+int dra_norm_partials(void); /* doubles needed per dra_grad_sqnorm call */
+int dra_grad_sqnorm(float* grad, int64_t n, const float* slabs, int n_slabs, int64_t slab_stride, double* partials,
+                    void* stream);
+int dra_rmsprop_step(float* param, const float* grad, float* square_avg, float* grad_avg, int64_t n,
+                     const double* partials, int n_partials, float max_norm, float lr, float alpha, float eps,
+                     int centered, float* out_norm, void* stream);
+int dra_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  const double* partials, int n_partials, float max_norm, float lr, float beta1, float beta2, float eps,
+                  int64_t step, float* out_norm, void* stream);
+int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream); /* DQN_agent.py:136-138 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
