@@ -1,0 +1,623 @@
+"""Agents with the reference's `Agent(config).step()` surface and control flow, whose per-step
+arithmetic runs on the HIP kernels.
+
+Reference: deep_rl/agent/BaseAgent.py:15-182 (BaseAgent, BaseActor), DQN_agent.py:14-138,
+CategoricalDQN_agent.py:14-89, QuantileRegressionDQN_agent.py:14-77, A2C_agent.py:12-64,
+PPO_agent.py:12-100, NStepDQN_agent.py:12-67.
+
+Differences that are the point of the rewrite (results unchanged):
+  * actor / replay "processes" are in-process objects: the replay is an HBM ring, so the
+    pickle-over-pipe hops of BaseAgent.py:142-172 / replay.py:219-278 have nothing left to hide;
+    `config.async_actor` / `async_replay` are accepted and ignored;
+  * TD / C51 / QR / PPO / A2C losses are single fused kernels that emit the gradient w.r.t. the
+    network output, which is pushed through the HIP contractions by autograd;
+  * clip_grad_norm_ + optimizer.step() are two launches over one flat buffer (optim.py);
+  * GAE / n-step returns are one chunked-scan launch instead of T python iterations.
+"""
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .envs import LazyFrames
+from .optim import FlatParams, FusedOptimizer
+from .replay import PrioritizedTransition, Storage
+from .support import close_obj, epsilon_greedy, get_logger, random_sample, range_tensor, tensor, to_np
+
+
+class _NullLock:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class BaseAgent:
+    """BaseAgent.py:15-105."""
+
+    def __init__(self, config):
+        self.config = config
+        self.logger = get_logger(tag=config.tag, log_level=config.log_level)
+        self.task_ind = 0
+
+    def close(self):
+        close_obj(self.task)
+
+    def save(self, filename):
+        torch.save(self.network.state_dict(), '%s.model' % (filename))
+        with open('%s.stats' % (filename), 'wb') as f:
+            pickle.dump(self.config.state_normalizer.state_dict(), f)
+
+    def load(self, filename):
+        state_dict = torch.load('%s.model' % filename, map_location=lambda storage, loc: storage)
+        self.network.load_state_dict(state_dict)
+        with open('%s.stats' % (filename), 'rb') as f:
+            self.config.state_normalizer.load_state_dict(pickle.load(f))
+
+    def eval_step(self, state):
+        raise NotImplementedError
+
+    def eval_episode(self):
+        env = self.config.eval_env
+        state = env.reset()
+        while True:
+            action = self.eval_step(state)
+            state, reward, done, info = env.step(action)
+            ret = info[0]['episodic_return']
+            if ret is not None:
+                break
+        return ret
+
+    def eval_episodes(self):
+        episodic_returns = []
+        for ep in range(self.config.eval_episodes):
+            episodic_returns.append(np.sum(self.eval_episode()))
+        self.logger.info('steps %d, episodic_return_test %.2f(%.2f)' % (
+            self.total_steps, np.mean(episodic_returns), np.std(episodic_returns) / np.sqrt(len(episodic_returns))))
+        self.logger.add_scalar('episodic_return_test', np.mean(episodic_returns), self.total_steps)
+        return {'episodic_return_test': np.mean(episodic_returns)}
+
+    def record_online_return(self, info, offset=0):
+        if isinstance(info, dict):
+            ret = info['episodic_return']
+            if ret is not None:
+                self.logger.add_scalar('episodic_return_train', ret, self.total_steps + offset)
+                self.logger.info('steps %d, episodic_return_train %s' % (self.total_steps + offset, ret))
+        elif isinstance(info, tuple):
+            for i, info_ in enumerate(info):
+                self.record_online_return(info_, i)
+        else:
+            raise NotImplementedError
+
+    def switch_task(self):
+        config = self.config
+        if not config.tasks:
+            return
+        segs = np.linspace(0, config.max_steps, len(config.tasks) + 1)
+        if self.total_steps > segs[self.task_ind + 1]:
+            self.task_ind += 1
+            self.task = config.tasks[self.task_ind]
+            self.states = self.task.reset()
+            self.states = config.state_normalizer(self.states)
+
+
+class BaseActor:
+    """BaseAgent.py:108-182 without the process: `step()` returns `sgd_update_frequency`
+    transitions, in the order the reference's sync path (`async_actor=False`) produces them."""
+    STEP, RESET, EXIT, SPECS, NETWORK, CACHE = range(6)
+
+    def __init__(self, config):
+        self.config = config
+        self._state = None
+        self._task = None
+        self._network = None
+        self._total_steps = 0
+        self._set_up()
+        self._task = config.task_fn()
+
+    def start(self):
+        return None
+
+    def _sample(self):
+        transitions = []
+        for _ in range(self.config.sgd_update_frequency):
+            transition = self._transition()
+            if transition is not None:
+                transitions.append(transition)
+        return transitions
+
+    def step(self):
+        return self._sample()
+
+    def _transition(self):
+        raise NotImplementedError
+
+    def _set_up(self):
+        pass
+
+    def close(self):
+        close_obj(self._task)
+
+    def set_network(self, net):
+        self._network = net
+
+
+# ==================================================================================================== DQN family
+class DQNActor(BaseActor):
+    """DQN_agent.py:14-45."""
+
+    def __init__(self, config):
+        BaseActor.__init__(self, config)
+        self.config = config
+        self.start()
+
+    def compute_q(self, prediction):
+        return to_np(prediction['q'])
+
+    def _transition(self):
+        if self._state is None:
+            self._state = self._task.reset()
+        config = self.config
+        if config.noisy_linear:
+            self._network.reset_noise()
+        with config.lock:
+            with torch.no_grad():
+                prediction = self._network(config.state_normalizer(self._state))
+        q_values = self.compute_q(prediction)
+        if config.noisy_linear:
+            epsilon = 0
+        elif self._total_steps < config.exploration_steps:
+            epsilon = 1
+        else:
+            epsilon = config.random_action_prob()
+        action = epsilon_greedy(epsilon, q_values)
+        next_state, reward, done, info = self._task.step(action)
+        entry = [self._state, action, reward, next_state, done, info]
+        self._total_steps += 1
+        self._state = next_state
+        return entry
+
+
+class DQNAgent(BaseAgent):
+    """DQN_agent.py:48-138."""
+    ActorCLS = DQNActor
+
+    def __init__(self, config):
+        BaseAgent.__init__(self, config)
+        self.config = config
+        config.lock = _NullLock()
+        self._pre_init()
+        self.replay = config.replay_fn()
+        self.actor = self.ActorCLS(config)
+        self.network = config.network_fn()
+        self.target_network = config.network_fn()
+        self.target_network.load_state_dict(self.network.state_dict())
+        self.optimizer = config.optimizer_fn(self.network.parameters())
+        self._fused = FusedOptimizer.adopt(self.optimizer)           # re-homes network params in one flat buffer
+        self._target_flat = FlatParams(self.target_network.parameters())
+        self.actor.set_network(self.network)
+        self.total_steps = 0
+        self._post_init()
+
+    def _pre_init(self):
+        pass
+
+    def _post_init(self):
+        pass
+
+    def close(self):
+        close_obj(self.replay)
+        close_obj(self.actor)
+
+    def eval_step(self, state):
+        self.config.state_normalizer.set_read_only()
+        state = self.config.state_normalizer(state)
+        with torch.no_grad():
+            q = self.network(state)['q']
+        action = to_np(q.argmax(-1))
+        self.config.state_normalizer.unset_read_only()
+        return action
+
+    # -- reference-shaped hooks, kept for callers that use them directly -------------------------------
+    def reduce_loss(self, loss):
+        return ops.weighted_mean(loss.pow(2).mul(0.5).contiguous())
+
+    def compute_loss(self, transitions):
+        """DQN_agent.py:81-99: returns the TD-error vector (no autograd graph; step() uses _loss_grad)."""
+        out, _ = self._loss_grad(transitions, per=None)
+        return out['delta']
+
+    @staticmethod
+    def _f32(x):
+        return x if (isinstance(x, torch.Tensor) and x.dtype == torch.float32) else tensor(to_np(x) if isinstance(x, torch.Tensor) else x)
+
+    def _batch_scalars(self, transitions):
+        reward = transitions.reward
+        mask = transitions.mask
+        reward = reward.float() if isinstance(reward, torch.Tensor) else tensor(reward)
+        mask = mask.float() if isinstance(mask, torch.Tensor) else tensor(mask)
+        action = transitions.action
+        if not isinstance(action, torch.Tensor):
+            action = torch.from_numpy(np.asarray(action, dtype=np.int64)).to(reward.device)
+        elif action.dtype not in (torch.int64, torch.float32):
+            action = action.long()
+        return action.contiguous(), reward.contiguous(), mask.contiguous()
+
+    def _per_args(self, transitions):
+        config = self.config
+        sp = transitions.sampling_prob
+        sp = sp.float() if isinstance(sp, torch.Tensor) else tensor(sp)
+        return dict(sampling_prob=sp.contiguous(), beta=config.replay_beta(), replay_eps=config.replay_eps,
+                    replay_alpha=config.replay_alpha)
+
+    def _loss_grad(self, transitions, per):
+        """Forward passes + the fused TD kernel.  Returns (kernel outputs, (net_output, grad))."""
+        config = self.config
+        states = config.state_normalizer(transitions.state)
+        next_states = config.state_normalizer(transitions.next_state)
+        with torch.no_grad():
+            q_next = self.target_network(next_states)['q']
+            q_next_online = self.network(next_states)['q'] if config.double_q else None
+        action, reward, mask = self._batch_scalars(transitions)
+        q = self.network(states)['q']
+        out = ops.td_loss(q.detach(), q_next, action, reward, mask, config.discount ** config.n_step,
+                          q_next_online=q_next_online, **(per or {}))
+        return out, (q, out['dq'])
+
+    def _learn(self, transitions):
+        config = self.config
+        is_per = isinstance(transitions, PrioritizedTransition)
+        out, (net_out, grad) = self._loss_grad(transitions, self._per_args(transitions) if is_per else None)
+        if is_per:
+            idxs = transitions.idx
+            idxs = to_np(idxs.long()) if isinstance(idxs, torch.Tensor) else np.asarray(idxs, dtype=np.int64)
+            self.replay.update_priorities(zip(idxs, to_np(out['prio'])))
+        self._fused.zero_grad()
+        net_out.backward(grad)
+        with config.lock:
+            self._fused.step(config.gradient_clip)
+        return out
+
+    def step(self):
+        config = self.config
+        transitions = self.actor.step()
+        for states, actions, rewards, next_states, dones, info in transitions:
+            self.record_online_return(info)
+            self.total_steps += 1
+            self.replay.feed(dict(
+                state=np.array([s[-1] if isinstance(s, LazyFrames) else s for s in states]),
+                action=actions,
+                reward=[config.reward_normalizer(r) for r in rewards],
+                mask=1 - np.asarray(dones, dtype=np.int32),
+            ))
+        if self.total_steps > config.exploration_steps:
+            transitions = self.replay.sample()
+            if config.noisy_linear:
+                self.target_network.reset_noise()
+                self.network.reset_noise()
+            self._learn(transitions)
+        if self.total_steps / config.sgd_update_frequency % config.target_network_update_freq == 0:
+            self.sync_target()
+
+    def sync_target(self):
+        """DQN_agent.py:136-138 as one device-to-device copy of the flat parameter buffer."""
+        ops.copy_f32(self._target_flat.flat, self._fused.flat.flat)
+        for tb, b in zip(self.target_network.buffers(), self.network.buffers()):
+            tb.copy_(b)
+
+
+class CategoricalDQNActor(DQNActor):
+    """CategoricalDQN_agent.py:14-24."""
+
+    def _set_up(self):
+        self.config.atoms = tensor(self.config.atoms)
+
+    def compute_q(self, prediction):
+        return to_np((prediction['prob'] * self.config.atoms).sum(-1))
+
+
+class CategoricalDQNAgent(DQNAgent):
+    """CategoricalDQN_agent.py:27-89."""
+    ActorCLS = CategoricalDQNActor
+
+    def _pre_init(self):
+        config = self.config
+        config.atoms = np.linspace(config.categorical_v_min, config.categorical_v_max, config.categorical_n_atoms)
+
+    def _post_init(self):
+        config = self.config
+        self.batch_indices = range_tensor(config.batch_size)
+        self.atoms = tensor(config.atoms)
+        self.delta_atom = (config.categorical_v_max - config.categorical_v_min) / float(config.categorical_n_atoms - 1)
+
+    def eval_step(self, state):
+        self.config.state_normalizer.set_read_only()
+        state = self.config.state_normalizer(state)
+        with torch.no_grad():
+            prediction = self.network(state)
+        action = to_np((prediction['prob'] * self.atoms).sum(-1).argmax(-1))
+        self.config.state_normalizer.unset_read_only()
+        return action
+
+    def compute_loss(self, transitions):
+        return self._loss_grad(transitions, per=None)[0]['kl']
+
+    def reduce_loss(self, loss):
+        return ops.weighted_mean(loss.contiguous())
+
+    def _loss_grad(self, transitions, per):
+        config = self.config
+        states = config.state_normalizer(transitions.state)
+        next_states = config.state_normalizer(transitions.next_state)
+        with torch.no_grad():
+            logits_t = self.target_network(next_states)['logits']
+            logits_o = self.network(next_states)['logits'] if config.double_q else None
+        action, reward, mask = self._batch_scalars(transitions)
+        logits = self.network(states)['logits']
+        weights = prio_w = None
+        if per is not None:
+            _, weights = ops.per_weights(None, per['sampling_prob'], per['beta'], per['replay_eps'], per['replay_alpha'])
+        out = ops.c51_loss(logits.detach().contiguous(), logits_t.contiguous(), action, reward, mask,
+                           config.discount ** config.n_step, self.atoms, config.categorical_v_min,
+                           config.categorical_v_max, logits_next_online=logits_o, weights=weights)
+        if per is not None:
+            out['prio'], _ = ops.per_weights(out['kl'], per['sampling_prob'], per['beta'], per['replay_eps'],
+                                             per['replay_alpha'])
+            out['weights'] = weights
+        return out, (logits, out['dlogits'])
+
+
+class QuantileRegressionDQNActor(DQNActor):
+    """QuantileRegressionDQN_agent.py:13-20."""
+
+    def compute_q(self, prediction):
+        return to_np(prediction['quantile'].mean(-1))
+
+
+class QuantileRegressionDQNAgent(DQNAgent):
+    """QuantileRegressionDQN_agent.py:23-77 (UniformReplay only: the PER branch mis-shapes in the
+    reference)."""
+    ActorCLS = QuantileRegressionDQNActor
+
+    def _post_init(self):
+        config = self.config
+        self.batch_indices = range_tensor(config.batch_size)
+        self.quantile_weight = 1.0 / config.num_quantiles
+        self.cumulative_density = tensor((2 * np.arange(config.num_quantiles) + 1) / (2.0 * config.num_quantiles)).view(1, -1)
+
+    def eval_step(self, state):
+        self.config.state_normalizer.set_read_only()
+        state = self.config.state_normalizer(state)
+        with torch.no_grad():
+            q = self.network(state)['quantile'].mean(-1)
+        action = np.argmax(to_np(q).flatten())
+        self.config.state_normalizer.unset_read_only()
+        return [action]
+
+    def compute_loss(self, transitions):
+        return self._loss_grad(transitions, per=None)[0]['loss_vec']
+
+    def reduce_loss(self, loss):
+        return ops.weighted_mean(loss.contiguous())
+
+    def _loss_grad(self, transitions, per):
+        if per is not None:
+            raise NotImplementedError("QR-DQN with PrioritizedReplay is not a valid reference configuration")
+        config = self.config
+        states = config.state_normalizer(transitions.state)
+        next_states = config.state_normalizer(transitions.next_state)
+        with torch.no_grad():
+            theta_t = self.target_network(next_states)['quantile']
+        action, reward, mask = self._batch_scalars(transitions)
+        theta = self.network(states)['quantile']
+        out = ops.qr_loss(theta.detach().contiguous(), theta_t.contiguous(), action, reward, mask,
+                          config.discount ** config.n_step)
+        return out, (theta, out['dtheta'])
+
+
+# ==================================================================================================== on-policy
+def _rollout_scan(storage, config, bootstrap_v):
+    """PPO_agent.py:51-61 / A2C_agent.py:43-53 as one dra_gae launch.  Fills storage.advantage / .ret
+    with per-step [N,1] tensors (views of the [T,N,1] results)."""
+    t_len = config.rollout_length
+    reward = torch.stack(storage.reward[:t_len]).contiguous()
+    mask = torch.stack(storage.mask[:t_len]).contiguous()
+    value = torch.stack([v.detach() for v in storage.v[:t_len]] + [bootstrap_v.detach()]).contiguous()
+    adv, ret = ops.gae(reward, mask, value, config.discount, config.gae_tau, config.use_gae)
+    for i in range(t_len):
+        storage.advantage[i] = adv[i]
+        storage.ret[i] = ret[i]
+    return adv, ret
+
+
+class A2CAgent(BaseAgent):
+    """A2C_agent.py:12-64."""
+
+    def __init__(self, config):
+        BaseAgent.__init__(self, config)
+        self.config = config
+        self.task = config.task_fn()
+        self.network = config.network_fn()
+        self.optimizer = config.optimizer_fn(self.network.parameters())
+        self._fused = FusedOptimizer.adopt(self.optimizer)
+        self.total_steps = 0
+        self.states = self.task.reset()
+        self.grad_hook = None  # multi-GPU: called with the flat gradient before the optimiser step
+
+    def step(self):
+        config = self.config
+        storage = Storage(config.rollout_length)
+        states = self.states
+        for _ in range(config.rollout_length):
+            prediction = self.network(config.state_normalizer(states))
+            next_states, rewards, terminals, info = self.task.step(to_np(prediction['action']))
+            self.record_online_return(info)
+            rewards = config.reward_normalizer(rewards)
+            storage.feed(prediction)
+            storage.feed({'reward': tensor(rewards).unsqueeze(-1), 'mask': tensor(1 - terminals).unsqueeze(-1)})
+            states = next_states
+            self.total_steps += config.num_workers
+        self.states = states
+        prediction = self.network(config.state_normalizer(states))
+        storage.feed(prediction)
+        storage.placeholder()
+        _rollout_scan(storage, config, prediction['v'])
+
+        entries = storage.extract(['log_pi_a', 'v', 'ret', 'advantage', 'entropy'])
+        out4, (g_lp, g_ent, g_v) = ops.a2c_loss(entries.log_pi_a.detach(), entries.entropy.detach(), entries.v.detach(),
+                                                entries.advantage, entries.ret, config.entropy_weight,
+                                                config.value_loss_weight)
+        self._fused.zero_grad()
+        torch.autograd.backward([entries.log_pi_a, entries.entropy, entries.v], [g_lp, g_ent, g_v])
+        if self.grad_hook is not None:
+            self.grad_hook(self._fused.flat.grad)
+        self._fused.step(config.gradient_clip)
+        self.last_loss = out4
+
+
+class NStepDQNAgent(BaseAgent):
+    """NStepDQN_agent.py:12-67: on-policy n-step Q-learning; returns via the scan kernel (use_gae off)."""
+
+    def __init__(self, config):
+        BaseAgent.__init__(self, config)
+        self.config = config
+        self.task = config.task_fn()
+        self.network = config.network_fn()
+        self.target_network = config.network_fn()
+        self.optimizer = config.optimizer_fn(self.network.parameters())
+        self._fused = FusedOptimizer.adopt(self.optimizer)
+        self._target_flat = FlatParams(self.target_network.parameters())
+        ops.copy_f32(self._target_flat.flat, self._fused.flat.flat)
+        self.total_steps = 0
+        self.states = self.task.reset()
+
+    def step(self):
+        config = self.config
+        storage = Storage(config.rollout_length)
+        states = self.states
+        for _ in range(config.rollout_length):
+            q = self.network(config.state_normalizer(states))['q']
+            epsilon = config.random_action_prob(config.num_workers)
+            actions = epsilon_greedy(epsilon, to_np(q))
+            next_states, rewards, terminals, info = self.task.step(actions)
+            self.record_online_return(info)
+            rewards = config.reward_normalizer(rewards)
+            storage.feed({'q': q, 'action': tensor(actions).unsqueeze(-1).long(),
+                          'reward': tensor(rewards).unsqueeze(-1), 'mask': tensor(1 - terminals).unsqueeze(-1)})
+            states = next_states
+            self.total_steps += config.num_workers
+            if self.total_steps // config.num_workers % config.target_network_update_freq == 0:
+                ops.copy_f32(self._target_flat.flat, self._fused.flat.flat)
+        self.states = states
+        storage.placeholder()
+        with torch.no_grad():
+            ret = self.target_network(config.state_normalizer(states))['q']
+            ret = torch.max(ret, dim=1, keepdim=True)[0]
+        t_len = config.rollout_length
+        reward = torch.stack(storage.reward[:t_len]).contiguous()
+        mask = torch.stack(storage.mask[:t_len]).contiguous()
+        zeros = torch.zeros((t_len + 1,) + tuple(ret.shape), device=ret.device)
+        zeros[t_len] = ret
+        _, rets = ops.gae(reward, mask, zeros, config.discount, 1.0, False)
+        for i in range(t_len):
+            storage.ret[i] = rets[i]
+        entries = storage.extract(['q', 'action', 'ret'])
+        q_a = entries.q.gather(1, entries.action)
+        n = q_a.numel()
+        grad = (q_a.detach() - entries.ret) / n  # d/dq of 0.5 * mean((q - ret)^2)
+        self._fused.zero_grad()
+        q_a.backward(grad)
+        self._fused.step(config.gradient_clip)
+
+
+class PPOAgent(BaseAgent):
+    """PPO_agent.py:12-100."""
+
+    def __init__(self, config):
+        BaseAgent.__init__(self, config)
+        self.config = config
+        self.task = config.task_fn()
+        self.network = config.network_fn()
+        if config.shared_repr:
+            self.opt = config.optimizer_fn(self.network.parameters())
+            self._fused = FusedOptimizer.adopt(self.opt)
+        else:
+            self.actor_opt = config.actor_opt_fn(self.network.actor_params)
+            self.critic_opt = config.critic_opt_fn(self.network.critic_params)
+            actor_ids = {id(p) for p in self.network.actor_params}
+            if any(id(p) in actor_ids for p in self.network.critic_params):
+                raise NotImplementedError("PPO with a shared phi_body and separate optimisers: use shared_repr=True")
+            self._fused_actor = FusedOptimizer.adopt(self.actor_opt)
+            self._fused_critic = FusedOptimizer.adopt(self.critic_opt)
+        self.total_steps = 0
+        self.states = self.task.reset()
+        self.states = config.state_normalizer(self.states)
+        if config.shared_repr:
+            self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda step: 1 - step / config.max_steps)
+        self.grad_hook = None
+
+    def step(self):
+        config = self.config
+        storage = Storage(config.rollout_length)
+        states = self.states
+        for _ in range(config.rollout_length):
+            with torch.no_grad():
+                prediction = self.network(states)
+            next_states, rewards, terminals, info = self.task.step(to_np(prediction['action']))
+            self.record_online_return(info)
+            rewards = config.reward_normalizer(rewards)
+            next_states = config.state_normalizer(next_states)
+            storage.feed(prediction)
+            storage.feed({'reward': tensor(rewards).unsqueeze(-1), 'mask': tensor(1 - terminals).unsqueeze(-1),
+                          'state': tensor(states)})
+            states = next_states
+            self.total_steps += config.num_workers
+        self.states = states
+        with torch.no_grad():
+            prediction = self.network(states)
+        storage.feed(prediction)
+        storage.placeholder()
+        _rollout_scan(storage, config, prediction['v'])
+
+        entries = storage.extract(['state', 'action', 'log_pi_a', 'ret', 'advantage'])
+        entry_cls = entries.__class__
+        entries = entry_cls(*[x.detach() for x in entries])
+        ops.adv_normalize_(entries.advantage)  # PPO_agent.py:66 in place
+
+        if config.shared_repr:
+            self.lr_scheduler.step(self.total_steps)
+        self.optimize(entries)
+
+    def optimize(self, entries):
+        """PPO_agent.py:71-99: epochs of shuffled minibatches over the (detached) rollout entries."""
+        config = self.config
+        entry_cls = entries.__class__
+        for _ in range(config.optimization_epochs):
+            sampler = random_sample(np.arange(entries.state.size(0)), config.mini_batch_size)
+            for batch_indices in sampler:
+                batch_indices = tensor(batch_indices).long()
+                entry = entry_cls(*[x[batch_indices] for x in entries])
+                prediction = self.network(entry.state, entry.action)
+                out3, (g_lp, g_ent, g_v) = ops.ppo_loss(
+                    prediction['log_pi_a'].detach(), prediction['entropy'].detach(), prediction['v'].detach(),
+                    entry.log_pi_a, entry.advantage, entry.ret, config.ppo_ratio_clip, config.entropy_weight)
+                if config.shared_repr:
+                    self._fused.zero_grad()
+                    torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']],
+                                            [g_lp, g_ent, g_v])
+                    if self.grad_hook is not None:
+                        self.grad_hook(self._fused.flat.grad)
+                    self._fused.step(config.gradient_clip)
+                else:
+                    approx_kl = out3[2].item()
+                    if approx_kl <= 1.5 * config.target_kl:
+                        self._fused_actor.zero_grad()
+                        torch.autograd.backward([prediction['log_pi_a'], prediction['entropy']], [g_lp, g_ent])
+                        self._fused_actor.step(None)
+                    self._fused_critic.zero_grad()
+                    prediction['v'].backward(g_v)
+                    self._fused_critic.step(None)
+        self.last_loss = out3

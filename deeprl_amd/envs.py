@@ -1,0 +1,186 @@
+"""Environment surface (deep_rl/component/envs.py:92-189): `LazyFrames`, the auto-resetting
+vector env contract and `Task`.
+
+The emulators themselves (gym 0.10.8 / baselines / atari-py / mujoco, envs.py:8-16,27-55) are
+third-party CPU code outside the hot path and absent from this image, so `Task`
+builds SYNTHETIC environments with the same surface -- reset() / step(actions) -> (obs, reward,
+done, info tuple with 'episodic_return'), state_dim, action_dim, name, action_space -- and the
+same observation shapes / dtypes: Atari-like names give uint8 [4,84,84] frame stacks, everything
+else float64 vectors.  Frames are a counter hash (identical to dra_ring_fill_synthetic), so runs
+are reproducible without an emulator.
+"""
+import numpy as np
+
+
+class LazyFrames(object):
+    """envs.py:92-113: frame stack that materialises on demand; `s[-1]` is the newest frame."""
+
+    def __init__(self, frames):
+        self._frames = frames
+
+    def __array__(self, dtype=None, copy=None):
+        out = np.concatenate(self._frames, axis=0)
+        if dtype is not None:
+            out = out.astype(dtype)
+        return out
+
+    def __len__(self):
+        return len(self.__array__())
+
+    def __getitem__(self, i):
+        return self.__array__()[i]
+
+
+class Discrete:
+    def __init__(self, n):
+        self.n = n
+
+
+class Box:
+    def __init__(self, low, high, shape):
+        self.low, self.high, self.shape = low, high, shape
+
+
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _mix64(z):
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def synthetic_frame(counter, seed, frame_bytes=7056):
+    """Frame `counter` of stream `seed`: the same bytes dra_ring_fill_synthetic writes."""
+    words = frame_bytes // 8
+    with np.errstate(over="ignore"):
+        base = np.uint64(seed) * _GOLD + np.uint64(counter) * np.uint64(words)
+        w = _mix64(base + np.arange(words, dtype=np.uint64))
+    return w.astype("<u8").view(np.uint8)
+
+
+class SyntheticAtari:
+    """uint8 [history,84,84] observations as LazyFrames of (1,84,84) frames, `n_actions` discrete
+    actions, reward in {-1,0,1}, episode ends w.p. 1/800 per step."""
+
+    def __init__(self, seed=0, history=4, n_actions=4, done_period=800):
+        self.seed, self.history, self.n_actions, self.done_period = seed, history, n_actions, done_period
+        self.counter = 0
+        self.frames = None
+        self.ret = 0.0
+
+    def _next_frame(self):
+        f = synthetic_frame(self.counter, self.seed).reshape(1, 84, 84)
+        self.counter += 1
+        return f
+
+    def reset(self):
+        f = self._next_frame()
+        self.frames = [f] * self.history
+        self.ret = 0.0
+        return LazyFrames(list(self.frames))
+
+    def step(self, action):
+        h = int(_mix64(np.uint64(self.seed + 1) * _GOLD + np.uint64(self.counter)))
+        u = (h >> 32) % 10
+        reward = -1.0 if u == 0 else (1.0 if u == 9 else 0.0)
+        done = int(_mix64(np.uint64(self.seed + 2) * _GOLD + np.uint64(self.counter))) % self.done_period == 0
+        self.frames = self.frames[1:] + [self._next_frame()]
+        self.ret += reward
+        info = {'episodic_return': self.ret if done else None}
+        return LazyFrames(list(self.frames)), reward, done, info
+
+
+class SyntheticVector:
+    def __init__(self, seed=0, state_dim=4, n_actions=2, continuous=False, horizon=200):
+        self.rs = np.random.RandomState(seed)
+        self.state_dim, self.n_actions, self.continuous, self.horizon = state_dim, n_actions, continuous, horizon
+        self.s = None
+        self.ret = 0.0
+
+    def reset(self):
+        self.s = self.rs.uniform(-0.05, 0.05, size=self.state_dim)
+        self.ret = 0.0
+        return self.s.copy()
+
+    def step(self, action):
+        a = np.asarray(action, dtype=np.float64).reshape(-1)
+        self.s = self.s + 0.01 * (a.mean() - (0.0 if self.continuous else (self.n_actions - 1) / 2.0)) + \
+            self.rs.uniform(-0.02, 0.02, size=self.state_dim)
+        reward = float(self.rs.randn()) if self.continuous else 1.0
+        done = bool(self.rs.rand() < 1.0 / self.horizon)
+        self.ret += reward
+        info = {'episodic_return': self.ret if done else None}
+        return self.s.copy(), reward, done, info
+
+
+class DummyVecEnv:
+    """envs.py:126-150: serial vector env with auto-reset on done."""
+
+    def __init__(self, envs):
+        self.envs = envs
+        self.num_envs = len(envs)
+        self.actions = None
+
+    def step_async(self, actions):
+        self.actions = actions
+
+    def step_wait(self):
+        data = []
+        for i in range(self.num_envs):
+            obs, rew, done, info = self.envs[i].step(self.actions[i])
+            if done:
+                obs = self.envs[i].reset()
+            data.append([obs, rew, done, info])
+        obs, rew, done, info = zip(*data)
+        return obs, np.asarray(rew), np.asarray(done), info
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def reset(self):
+        return [env.reset() for env in self.envs]
+
+    def close(self):
+        return
+
+
+class Task:
+    """envs.py:153-189 surface over synthetic environments (see module docstring)."""
+
+    def __init__(self, name, num_envs=1, single_process=True, log_dir=None, episode_life=True, seed=None):
+        if seed is None:
+            seed = np.random.randint(int(1e9))
+        self.name = name
+        atari = 'NoFrameskip' in name or name.startswith('synthetic-atari')
+        continuous = any(k in name for k in ('HalfCheetah', 'Walker', 'Hopper', 'Reacher', 'Swimmer', 'Ant', 'Humanoid',
+                                             'dm-', 'synthetic-continuous'))
+        if atari:
+            envs = [SyntheticAtari(seed + i) for i in range(num_envs)]
+            self.observation_space = Box(0, 255, (4, 84, 84))
+            self.action_space = Discrete(4)
+        elif continuous:
+            envs = [SyntheticVector(seed + i, 17, 6, continuous=True, horizon=1000) for i in range(num_envs)]
+            self.observation_space = Box(-np.inf, np.inf, (17,))
+            self.action_space = Box(-1.0, 1.0, (6,))
+        else:
+            envs = [SyntheticVector(seed + i, 4, 2) for i in range(num_envs)]
+            self.observation_space = Box(-np.inf, np.inf, (4,))
+            self.action_space = Discrete(2)
+        self.env = DummyVecEnv(envs)
+        self.state_dim = int(np.prod(self.observation_space.shape))
+        if isinstance(self.action_space, Discrete):
+            self.action_dim = self.action_space.n
+        else:
+            self.action_dim = self.action_space.shape[0]
+
+    def reset(self):
+        return self.env.reset()
+
+    def step(self, actions):
+        if isinstance(self.action_space, Box):
+            actions = np.clip(actions, self.action_space.low, self.action_space.high)
+        return self.env.step(actions)

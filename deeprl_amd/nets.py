@@ -1,0 +1,484 @@
+"""Network bodies and heads with the reference's module / parameter names (so state_dicts
+interchange with deep_rl/network/*), whose contractions run on the hand-written fp32-MFMA HIP
+kernels through autograd Functions.
+
+Reference: deep_rl/network/network_utils.py:23-83 (layer_init, NoisyLinear),
+network_bodies.py:10-82 (NatureConvBody, DDPGConvBody, FCBody, DummyBody), network_heads.py:11-293
+(the `forward -> dict` heads).  Softmax / distribution glue in the heads stays PyTorch
+(element-wise, bandwidth-trivial); every conv / linear forward, input-gradient and
+weight-gradient is a HIP kernel, and the fused learner (deeprl_amd/learner.py) bypasses autograd
+altogether for the DQN family.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .support import Config, tensor
+
+
+class BaseNet:
+    def __init__(self):
+        pass
+
+    def reset_noise(self):
+        pass
+
+
+def layer_init(layer, w_scale=1.0):
+    """network_utils.py:23-27: orthogonal weights (scaled), zero bias -- drawn on the CPU generator
+    before the module moves to the device, so seeds reproduce the reference's initial weights."""
+    nn.init.orthogonal_(layer.weight.data)
+    layer.weight.data.mul_(w_scale)
+    nn.init.constant_(layer.bias.data, 0)
+    return layer
+
+
+# ----------------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        y = ops.linear_fwd([x], [w], [b], act=act)[0]
+        ctx.save_for_backward(x, w, y)
+        ctx.act = act
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        dpre = ops.act_bwd(dy, y, ctx.act) if ctx.act else dy
+        dw, db = ops.linear_bwd_w(dpre, x, want_bias=ctx.has_bias)
+        dx = ops.linear_bwd_x(dpre, w) if ctx.needs_input_grad[0] else None
+        return dx, dw, db, None
+
+
+def linear(x, w, b, act=None):
+    x = x.float() if x.dtype != torch.float32 else x
+    lead = x.shape[:-1]
+    y = _LinearFn.apply(x.reshape(-1, x.shape[-1]).contiguous(), w, b, act)
+    return y.reshape(lead + (w.shape[0],))
+
+
+class _ConvFn(torch.autograd.Function):
+    KSPLIT = 16
+
+    @staticmethod
+    def forward(ctx, x, w, b, layer, u8_coef):
+        y = ops.conv_fwd(layer, [x], [w], [b], act="relu", u8_coef=u8_coef)[0]
+        ctx.save_for_backward(x, w, y)
+        ctx.layer, ctx.u8_coef = layer, u8_coef
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dpre = ops.act_bwd(dy.contiguous(), y, "relu")
+        n_w, n_b = w.numel(), w.shape[0]
+        dw_s, db_s = ops.conv_bwd_w(ctx.layer, dpre, x, ksplit=_ConvFn.KSPLIT, u8_coef=ctx.u8_coef)
+        stride = dw_s.stride(0)
+        flat = torch.empty(stride, dtype=torch.float32, device=w.device)
+        partials = torch.empty(ops.norm_partials(), dtype=torch.float64, device=w.device)
+        ops.grad_sqnorm(flat, partials, slabs=dw_s, n_slabs=_ConvFn.KSPLIT, slab_stride=stride)  # fold split-K slabs
+        dw = flat[:n_w].view_as(w)
+        db = flat[n_w:n_w + n_b]
+        dx = None
+        if ctx.needs_input_grad[0] and ctx.layer > 1:
+            dx = ops.conv_bwd_x(ctx.layer, dpre, w)
+        return dx, dw, db, None, None
+
+
+class Linear(nn.Linear):
+    """nn.Linear whose forward / backward are the HIP contractions; `fused_act` folds the body's
+    gate into the GEMM epilogue."""
+    fused_act = None
+
+    def forward(self, x):
+        return linear(x, self.weight, self.bias, self.fused_act)
+
+
+class Conv2d(nn.Conv2d):
+    """One of the three NatureConvBody convolutions (+ fused ReLU).  Other geometries have no HIP
+    kernel in this build and raise rather than fall back."""
+
+    def forward(self, x):
+        layer = ops.conv_layer_for(self.weight.shape, self.stride[0], x.shape[-1])
+        if layer is None or self.padding != (0, 0) or self.stride[0] != self.stride[1]:
+            raise NotImplementedError("deeprl_amd has HIP kernels for the NatureConvBody convolutions only; got "
+                                      "weight %s stride %s input %s" % (tuple(self.weight.shape), self.stride,
+                                                                        tuple(x.shape)))
+        u8_coef = getattr(x, "dra_u8_coef", None) if x.dtype == torch.uint8 else None
+        if x.dtype == torch.uint8 and u8_coef is None:
+            raise TypeError("uint8 input to a convolution needs a normaliser (RescaleNormalizer marks it)")
+        return _ConvFn.apply(x.contiguous(), self.weight, self.bias, layer, u8_coef)
+
+
+# ---------------------------------------------------------------------------------------------------- NoisyLinear
+class NoisyLinear(nn.Module):
+    """network_utils.py:31-83 (Rainbow): factorised Gaussian noise; the mixed weight feeds the HIP GEMM."""
+
+    def __init__(self, in_features, out_features, std_init=0.4):
+        super(NoisyLinear, self).__init__()
+        self.in_features, self.out_features, self.std_init = in_features, out_features, std_init
+        self.weight_mu = nn.Parameter(torch.zeros((out_features, in_features)), requires_grad=True)
+        self.weight_sigma = nn.Parameter(torch.zeros((out_features, in_features)), requires_grad=True)
+        self.register_buffer('weight_epsilon', torch.zeros((out_features, in_features)))
+        self.bias_mu = nn.Parameter(torch.zeros(out_features), requires_grad=True)
+        self.bias_sigma = nn.Parameter(torch.zeros(out_features), requires_grad=True)
+        self.register_buffer('bias_epsilon', torch.zeros(out_features))
+        self.register_buffer('noise_in', torch.zeros(in_features))
+        self.register_buffer('noise_out_weight', torch.zeros(out_features))
+        self.register_buffer('noise_out_bias', torch.zeros(out_features))
+        self.fused_act = None
+        self.reset_parameters()
+        self.reset_noise()
+
+    def forward(self, x):
+        if self.training:
+            weight = self.weight_mu + self.weight_sigma.mul(self.weight_epsilon)
+            bias = self.bias_mu + self.bias_sigma.mul(self.bias_epsilon)
+        else:
+            weight, bias = self.weight_mu, self.bias_mu
+        return linear(x, weight, bias, self.fused_act)
+
+    def reset_parameters(self):
+        mu_range = 1 / math.sqrt(self.weight_mu.size(1))
+        self.weight_mu.data.uniform_(-mu_range, mu_range)
+        self.weight_sigma.data.fill_(self.std_init / math.sqrt(self.weight_sigma.size(1)))
+        self.bias_mu.data.uniform_(-mu_range, mu_range)
+        self.bias_sigma.data.fill_(self.std_init / math.sqrt(self.bias_sigma.size(0)))
+
+    def reset_noise(self):
+        self.noise_in.normal_(std=Config.NOISY_LAYER_STD)
+        self.noise_out_weight.normal_(std=Config.NOISY_LAYER_STD)
+        self.noise_out_bias.normal_(std=Config.NOISY_LAYER_STD)
+        self.weight_epsilon.copy_(self.transform_noise(self.noise_out_weight).ger(self.transform_noise(self.noise_in)))
+        self.bias_epsilon.copy_(self.transform_noise(self.noise_out_bias))
+
+    def transform_noise(self, x):
+        return x.sign().mul(x.abs().sqrt())
+
+
+# ---------------------------------------------------------------------------------------------------- bodies
+class NatureConvBody(nn.Module):
+    """network_bodies.py:10-33."""
+
+    def __init__(self, in_channels=4, noisy_linear=False):
+        super(NatureConvBody, self).__init__()
+        self.feature_dim = 512
+        self.conv1 = layer_init(Conv2d(in_channels, 32, kernel_size=8, stride=4))
+        self.conv2 = layer_init(Conv2d(32, 64, kernel_size=4, stride=2))
+        self.conv3 = layer_init(Conv2d(64, 64, kernel_size=3, stride=1))
+        if noisy_linear:
+            self.fc4 = NoisyLinear(7 * 7 * 64, self.feature_dim)
+        else:
+            self.fc4 = layer_init(Linear(7 * 7 * 64, self.feature_dim))
+        self.fc4.fused_act = "relu"
+        self.noisy_linear = noisy_linear
+
+    def reset_noise(self):
+        if self.noisy_linear:
+            self.fc4.reset_noise()
+
+    def forward(self, x):
+        y = self.conv1(x)  # ReLU fused into every layer's epilogue
+        y = self.conv2(y)
+        y = self.conv3(y)
+        y = y.view(y.size(0), -1)
+        return self.fc4(y)
+
+
+class DDPGConvBody(nn.Module):
+    """network_bodies.py:36-47 -- unused by every example; kept for name compatibility only."""
+
+    def __init__(self, in_channels=4):
+        super(DDPGConvBody, self).__init__()
+        raise NotImplementedError("DDPGConvBody is outside the hot path (SURVEY.md section 2 #7): no HIP kernel")
+
+
+_GATES = {F.relu: "relu", torch.relu: "relu", torch.tanh: "tanh", F.tanh: "tanh"}
+
+
+class FCBody(nn.Module):
+    """network_bodies.py:50-73: Linear + gate stack; relu / tanh gates fold into the GEMM epilogue."""
+
+    def __init__(self, state_dim, hidden_units=(64, 64), gate=F.relu, noisy_linear=False):
+        super(FCBody, self).__init__()
+        dims = (state_dim,) + tuple(hidden_units)
+        if noisy_linear:
+            self.layers = nn.ModuleList([NoisyLinear(i, o) for i, o in zip(dims[:-1], dims[1:])])
+        else:
+            self.layers = nn.ModuleList([layer_init(Linear(i, o)) for i, o in zip(dims[:-1], dims[1:])])
+        self.gate = gate
+        self._fused = _GATES.get(gate)
+        for layer in self.layers:
+            layer.fused_act = self._fused
+        self.feature_dim = dims[-1]
+        self.noisy_linear = noisy_linear
+
+    def reset_noise(self):
+        if self.noisy_linear:
+            for layer in self.layers:
+                layer.reset_noise()
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+            if self._fused is None:
+                x = self.gate(x)
+        return x
+
+
+class DummyBody(nn.Module):
+    def __init__(self, state_dim):
+        super(DummyBody, self).__init__()
+        self.feature_dim = state_dim
+
+    def forward(self, x):
+        return x
+
+
+# ---------------------------------------------------------------------------------------------------- heads
+class VanillaNet(nn.Module, BaseNet):
+    """network_heads.py:11-21."""
+
+    def __init__(self, output_dim, body):
+        super(VanillaNet, self).__init__()
+        self.fc_head = layer_init(Linear(body.feature_dim, output_dim))
+        self.body = body
+        self.to(Config.DEVICE)
+
+    def forward(self, x):
+        phi = self.body(tensor(x))
+        return dict(q=self.fc_head(phi))
+
+
+class DuelingNet(nn.Module, BaseNet):
+    """network_heads.py:24-37."""
+
+    def __init__(self, action_dim, body):
+        super(DuelingNet, self).__init__()
+        self.fc_value = layer_init(Linear(body.feature_dim, 1))
+        self.fc_advantage = layer_init(Linear(body.feature_dim, action_dim))
+        self.body = body
+        self.to(Config.DEVICE)
+
+    def forward(self, x, to_numpy=False):
+        phi = self.body(tensor(x))
+        value = self.fc_value(phi)
+        adv = self.fc_advantage(phi)
+        q = value.expand_as(adv) + (adv - adv.mean(1, keepdim=True).expand_as(adv))
+        return dict(q=q)
+
+
+class CategoricalNet(nn.Module, BaseNet):
+    """network_heads.py:40-54; also returns the pre-softmax `logits` the fused C51 loss consumes."""
+
+    def __init__(self, action_dim, num_atoms, body):
+        super(CategoricalNet, self).__init__()
+        self.fc_categorical = layer_init(Linear(body.feature_dim, action_dim * num_atoms))
+        self.action_dim = action_dim
+        self.num_atoms = num_atoms
+        self.body = body
+        self.to(Config.DEVICE)
+
+    def forward(self, x):
+        phi = self.body(tensor(x))
+        pre_prob = self.fc_categorical(phi).view((-1, self.action_dim, self.num_atoms))
+        return dict(prob=F.softmax(pre_prob, dim=-1), log_prob=F.log_softmax(pre_prob, dim=-1), logits=pre_prob)
+
+
+class RainbowNet(nn.Module, BaseNet):
+    """network_heads.py:57-86."""
+
+    def __init__(self, action_dim, num_atoms, body, noisy_linear):
+        super(RainbowNet, self).__init__()
+        if noisy_linear:
+            self.fc_value = NoisyLinear(body.feature_dim, num_atoms)
+            self.fc_advantage = NoisyLinear(body.feature_dim, action_dim * num_atoms)
+        else:
+            self.fc_value = layer_init(Linear(body.feature_dim, num_atoms))
+            self.fc_advantage = layer_init(Linear(body.feature_dim, action_dim * num_atoms))
+        self.action_dim = action_dim
+        self.num_atoms = num_atoms
+        self.body = body
+        self.noisy_linear = noisy_linear
+        self.to(Config.DEVICE)
+
+    def reset_noise(self):
+        if self.noisy_linear:
+            self.fc_value.reset_noise()
+            self.fc_advantage.reset_noise()
+            self.body.reset_noise()
+
+    def forward(self, x):
+        phi = self.body(tensor(x))
+        value = self.fc_value(phi).view((-1, 1, self.num_atoms))
+        advantage = self.fc_advantage(phi).view(-1, self.action_dim, self.num_atoms)
+        q = value + (advantage - advantage.mean(1, keepdim=True))
+        return dict(prob=F.softmax(q, dim=-1), log_prob=F.log_softmax(q, dim=-1), logits=q)
+
+
+class QuantileNet(nn.Module, BaseNet):
+    """network_heads.py:89-102."""
+
+    def __init__(self, action_dim, num_quantiles, body):
+        super(QuantileNet, self).__init__()
+        self.fc_quantiles = layer_init(Linear(body.feature_dim, action_dim * num_quantiles))
+        self.action_dim = action_dim
+        self.num_quantiles = num_quantiles
+        self.body = body
+        self.to(Config.DEVICE)
+
+    def forward(self, x):
+        phi = self.body(tensor(x))
+        quantiles = self.fc_quantiles(phi).view((-1, self.action_dim, self.num_quantiles))
+        return dict(quantile=quantiles)
+
+
+class OptionCriticNet(nn.Module, BaseNet):
+    """network_heads.py:105-127."""
+
+    def __init__(self, body, action_dim, num_options):
+        super(OptionCriticNet, self).__init__()
+        self.fc_q = layer_init(Linear(body.feature_dim, num_options))
+        self.fc_pi = layer_init(Linear(body.feature_dim, num_options * action_dim))
+        self.fc_beta = layer_init(Linear(body.feature_dim, num_options))
+        self.num_options = num_options
+        self.action_dim = action_dim
+        self.body = body
+        self.to(Config.DEVICE)
+
+    def forward(self, x):
+        phi = self.body(tensor(x))
+        q = self.fc_q(phi)
+        beta = torch.sigmoid(self.fc_beta(phi))
+        pi = self.fc_pi(phi).view(-1, self.num_options, self.action_dim)
+        return {'q': q, 'beta': beta, 'log_pi': F.log_softmax(pi, dim=-1), 'pi': F.softmax(pi, dim=-1)}
+
+
+def _ac_bodies(state_dim, phi_body, actor_body, critic_body):
+    if phi_body is None:
+        phi_body = DummyBody(state_dim)
+    if actor_body is None:
+        actor_body = DummyBody(phi_body.feature_dim)
+    if critic_body is None:
+        critic_body = DummyBody(phi_body.feature_dim)
+    return phi_body, actor_body, critic_body
+
+
+class DeterministicActorCriticNet(nn.Module, BaseNet):
+    """network_heads.py:130-170 (DDPG)."""
+
+    def __init__(self, state_dim, action_dim, actor_opt_fn, critic_opt_fn, phi_body=None, actor_body=None,
+                 critic_body=None):
+        super(DeterministicActorCriticNet, self).__init__()
+        self.phi_body, self.actor_body, self.critic_body = _ac_bodies(state_dim, phi_body, actor_body, critic_body)
+        self.fc_action = layer_init(Linear(self.actor_body.feature_dim, action_dim), 1e-3)
+        self.fc_critic = layer_init(Linear(self.critic_body.feature_dim, 1), 1e-3)
+        self.actor_params = list(self.actor_body.parameters()) + list(self.fc_action.parameters())
+        self.critic_params = list(self.critic_body.parameters()) + list(self.fc_critic.parameters())
+        self.phi_params = list(self.phi_body.parameters())
+        self.actor_opt = actor_opt_fn(self.actor_params + self.phi_params)
+        self.critic_opt = critic_opt_fn(self.critic_params + self.phi_params)
+        self.to(Config.DEVICE)
+
+    def forward(self, obs):
+        return self.actor(self.feature(obs))
+
+    def feature(self, obs):
+        return self.phi_body(tensor(obs))
+
+    def actor(self, phi):
+        return torch.tanh(self.fc_action(self.actor_body(phi)))
+
+    def critic(self, phi, a):
+        return self.fc_critic(self.critic_body(torch.cat([phi, a], dim=1)))
+
+
+class GaussianActorCriticNet(nn.Module, BaseNet):
+    """network_heads.py:173-214 (PPO / A2C continuous)."""
+
+    def __init__(self, state_dim, action_dim, phi_body=None, actor_body=None, critic_body=None):
+        super(GaussianActorCriticNet, self).__init__()
+        self.phi_body, self.actor_body, self.critic_body = _ac_bodies(state_dim, phi_body, actor_body, critic_body)
+        self.fc_action = layer_init(Linear(self.actor_body.feature_dim, action_dim), 1e-3)
+        self.fc_critic = layer_init(Linear(self.critic_body.feature_dim, 1), 1e-3)
+        self.std = nn.Parameter(torch.zeros(action_dim))
+        self.phi_params = list(self.phi_body.parameters())
+        self.actor_params = list(self.actor_body.parameters()) + list(self.fc_action.parameters()) + self.phi_params
+        self.actor_params.append(self.std)
+        self.critic_params = list(self.critic_body.parameters()) + list(self.fc_critic.parameters()) + self.phi_params
+        self.to(Config.DEVICE)
+
+    def forward(self, obs, action=None):
+        obs = tensor(obs)
+        phi = self.phi_body(obs)
+        phi_a = self.actor_body(phi)
+        phi_v = self.critic_body(phi)
+        mean = torch.tanh(self.fc_action(phi_a))
+        v = self.fc_critic(phi_v)
+        dist = torch.distributions.Normal(mean, F.softplus(self.std))
+        if action is None:
+            action = dist.sample()
+        log_prob = dist.log_prob(action).sum(-1).unsqueeze(-1)
+        entropy = dist.entropy().sum(-1).unsqueeze(-1)
+        return {'action': action, 'log_pi_a': log_prob, 'entropy': entropy, 'mean': mean, 'v': v}
+
+
+class CategoricalActorCriticNet(nn.Module, BaseNet):
+    """network_heads.py:217-255 (A2C / PPO Atari)."""
+
+    def __init__(self, state_dim, action_dim, phi_body=None, actor_body=None, critic_body=None):
+        super(CategoricalActorCriticNet, self).__init__()
+        self.phi_body, self.actor_body, self.critic_body = _ac_bodies(state_dim, phi_body, actor_body, critic_body)
+        self.fc_action = layer_init(Linear(self.actor_body.feature_dim, action_dim), 1e-3)
+        self.fc_critic = layer_init(Linear(self.critic_body.feature_dim, 1), 1e-3)
+        self.actor_params = list(self.actor_body.parameters()) + list(self.fc_action.parameters())
+        self.critic_params = list(self.critic_body.parameters()) + list(self.fc_critic.parameters())
+        self.phi_params = list(self.phi_body.parameters())
+        self.to(Config.DEVICE)
+
+    def forward(self, obs, action=None):
+        obs = tensor(obs)
+        phi = self.phi_body(obs)
+        phi_a = self.actor_body(phi)
+        phi_v = self.critic_body(phi)
+        logits = self.fc_action(phi_a)
+        v = self.fc_critic(phi_v)
+        dist = torch.distributions.Categorical(logits=logits)
+        if action is None:
+            action = dist.sample()
+        log_prob = dist.log_prob(action).unsqueeze(-1)
+        entropy = dist.entropy().unsqueeze(-1)
+        return {'action': action, 'log_pi_a': log_prob, 'entropy': entropy, 'v': v}
+
+
+class TD3Net(nn.Module, BaseNet):
+    """network_heads.py:258-293."""
+
+    def __init__(self, action_dim, actor_body_fn, critic_body_fn, actor_opt_fn, critic_opt_fn):
+        super(TD3Net, self).__init__()
+        self.actor_body = actor_body_fn()
+        self.critic_body_1 = critic_body_fn()
+        self.critic_body_2 = critic_body_fn()
+        self.fc_action = layer_init(Linear(self.actor_body.feature_dim, action_dim), 1e-3)
+        self.fc_critic_1 = layer_init(Linear(self.critic_body_1.feature_dim, 1), 1e-3)
+        self.fc_critic_2 = layer_init(Linear(self.critic_body_2.feature_dim, 1), 1e-3)
+        self.actor_params = list(self.actor_body.parameters()) + list(self.fc_action.parameters())
+        self.critic_params = list(self.critic_body_1.parameters()) + list(self.fc_critic_1.parameters()) + \
+            list(self.critic_body_2.parameters()) + list(self.fc_critic_2.parameters())
+        self.actor_opt = actor_opt_fn(self.actor_params)
+        self.critic_opt = critic_opt_fn(self.critic_params)
+        self.to(Config.DEVICE)
+
+    def forward(self, obs):
+        return torch.tanh(self.fc_action(self.actor_body(tensor(obs))))
+
+    def q(self, obs, a):
+        x = torch.cat([tensor(obs), tensor(a)], dim=1)
+        return self.fc_critic_1(self.critic_body_1(x)), self.fc_critic_2(self.critic_body_2(x))

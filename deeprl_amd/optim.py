@@ -1,0 +1,112 @@
+"""Flat parameter storage + the fused clip/optimiser step (K11).
+
+`config.optimizer_fn(params)` in examples.py builds a torch.optim.RMSprop / Adam
+(examples.py:67-68,139,204,370,508-509,534).  `FusedOptimizer.adopt` keeps that object as the
+carrier of hyper-parameters (lr schedules keep working) but replaces its ~100 tiny ATen kernels
+per step (deep_rl/agent/DQN_agent.py:130-134) with two HIP launches over ONE flat fp32 buffer that
+all parameters (and their .grad views) alias.
+"""
+import torch
+
+from . import ops
+from ._lib import DraError
+
+
+class FlatParams:
+    """Re-homes parameters into one contiguous fp32 buffer (each tensor 16-byte aligned) and gives
+    every parameter a .grad view into a matching flat gradient buffer."""
+
+    def __init__(self, params, align=4):
+        self.params = []
+        seen = set()
+        for p in params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                self.params.append(p)
+        if not self.params:
+            raise DraError("no parameters")
+        dev = self.params[0].device
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise DraError("FlatParams supports float32 parameters")
+            self.offsets.append(off)
+            off += (p.numel() + align - 1) // align * align
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view(p.shape)
+            p.grad = self.grad[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def offset_of(self, p):
+        for q, o in zip(self.params, self.offsets):
+            if q is p:
+                return o
+        raise KeyError("parameter not in this flat buffer")
+
+    def view(self, buf, p):
+        o = self.offset_of(p)
+        return buf[o:o + p.numel()].view(p.shape)
+
+
+class FusedOptimizer:
+    """clip_grad_norm_ + optimizer.step() as two launches (dra_grad_sqnorm, dra_*_step)."""
+
+    def __init__(self, flat, kind, hyper, torch_optimizer=None):
+        self.flat = flat
+        self.kind = kind
+        self.hyper = hyper
+        self.torch_optimizer = torch_optimizer
+        dev = flat.flat.device
+        self.state1 = torch.zeros_like(flat.flat)
+        self.state2 = torch.zeros_like(flat.flat)
+        self.n_partials = ops.norm_partials()
+        self.partials = torch.zeros(self.n_partials, dtype=torch.float64, device=dev)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.steps = 0
+
+    @classmethod
+    def adopt(cls, torch_optimizer, flat=None):
+        groups = torch_optimizer.param_groups
+        if len(groups) != 1:
+            raise DraError("FusedOptimizer supports a single param group")
+        g = groups[0]
+        if flat is None:
+            flat = FlatParams(g['params'])
+        if isinstance(torch_optimizer, torch.optim.RMSprop):
+            if g.get('momentum', 0) != 0 or g.get('weight_decay', 0) != 0:
+                raise DraError("RMSprop momentum / weight_decay have no HIP kernel")
+            kind = 'rmsprop'
+        elif isinstance(torch_optimizer, torch.optim.Adam):
+            if g.get('weight_decay', 0) != 0 or g.get('amsgrad', False):
+                raise DraError("Adam weight_decay / amsgrad have no HIP kernel")
+            kind = 'adam'
+        else:
+            raise DraError("no HIP kernel for optimizer %s" % type(torch_optimizer).__name__)
+        return cls(flat, kind, g, torch_optimizer)
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+    def step(self, max_norm=None):
+        """max_norm None / 0 = no clipping (then the norm pass is skipped)."""
+        f, h = self.flat, self.hyper
+        clip = bool(max_norm)
+        if clip:
+            ops.grad_sqnorm(f.grad, self.partials)
+        partials = self.partials if clip else None
+        self.steps += 1
+        if self.kind == 'rmsprop':
+            ops.rmsprop_step(f.flat, f.grad, self.state1, self.state2, partials, self.n_partials, max_norm or 0.0,
+                             h['lr'], h['alpha'], h['eps'], h['centered'], self.norm if clip else None)
+        else:
+            b1, b2 = h['betas']
+            ops.adam_step(f.flat, f.grad, self.state1, self.state2, partials, self.n_partials, max_norm or 0.0, h['lr'],
+                          b1, b2, h['eps'], self.steps, self.norm if clip else None)

@@ -402,6 +402,16 @@ def gen_a2c():
             agent.total_steps = 0
             agent.states = agent.task.reset()
             agent.record_online_return = lambda *a, **k: None
+            seen_states = [np.asarray(agent.states).copy()]
+            raw_step = agent.task.step
+
+            def logging_step(actions, _raw=raw_step, _log=seen_states):
+                o = _raw(actions)
+                _log.append(np.asarray(o[0]).copy())
+                return o
+
+            agent.task.step = logging_step
+            torch.manual_seed(33)  # action sampling stream
             ref.A2CAgent.step(agent)
             st = captured[0]
             k = tag + "_"
@@ -411,6 +421,7 @@ def gen_a2c():
             out[k + "log_pi_a"], out[k + "entropy"] = _stack(st.log_pi_a, t_len), _stack(st.entropy, t_len)
             out[k + "action"] = _stack(st.action, t_len)
             out[k + "adv"], out[k + "ret"] = _stack(st.advantage, t_len), _stack(st.ret, t_len)
+            out[k + "states"] = np.stack(seen_states)  # [T+1, N, state_dim]
             for n, v in p_init.items():
                 out[k + "init_" + n] = v
             for n, v in agent.network.state_dict().items():

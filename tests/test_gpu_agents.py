@@ -1,0 +1,223 @@
+"""GPU parity tests at the agent level: the drop-in surface (Config / Agent.step()) on the HIP
+kernels against fixtures produced by the reference's own agents (tests/golden/make_golden.py)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import fake_envs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dra():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import deeprl_amd as d
+    d.select_device(0)
+    return d
+
+
+class _Quiet:
+    def info(self, *a, **k):
+        pass
+
+    def add_scalar(self, *a, **k):
+        pass
+
+    def add_histogram(self, *a, **k):
+        pass
+
+
+def _load(module, arrays, prefix):
+    sd = {k: torch.from_numpy(arrays[prefix + k]) for k in module.state_dict().keys()}
+    module.load_state_dict(sd)
+
+
+def _cmp_params(module, g, prefix, rtol, atol):
+    for k, v in module.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), g[prefix + k], rtol=rtol, atol=atol, err_msg=k)
+
+
+@pytest.mark.parametrize("tag,per,n_step", [("uniform", False, 1), ("per_n3", True, 3)])
+def test_dqn_agent_config1_matches_reference_run(golden, dra, tag, per, n_step, monkeypatch):
+    """BASELINE config 1 (examples.py dqn_feature on a CartPole-shaped env, sync replay / actor):
+    60 agent.step() calls reproduce the reference's action stream, RNG consumption and weights."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    g = golden("dqn_agent_cartpole")
+    cfg = d.Config()
+    replay_cls = d.PrioritizedReplay if per else d.UniformReplay
+    cfg.merge(dict(game="fake", n_step=n_step, replay_cls=replay_cls, async_replay=False, log_level=0, tag=tag))
+    cfg.task_fn = lambda: fake_envs.VectorTask(seed=1, state_dim=4, action_dim=2, horizon=20)
+    cfg.eval_env = cfg.task_fn()
+    cfg.optimizer_fn = lambda params: torch.optim.RMSprop(params, 0.001)
+    cfg.network_fn = lambda: d.VanillaNet(cfg.action_dim, d.FCBody(cfg.state_dim))
+    cfg.history_length = 1
+    cfg.batch_size = 10
+    cfg.discount = 0.99
+    cfg.max_steps = 1e5
+    kw = dict(memory_size=int(1e4), batch_size=cfg.batch_size, n_step=cfg.n_step, discount=cfg.discount,
+              history_length=cfg.history_length)
+    cfg.replay_fn = lambda: d.ReplayWrapper(cfg.replay_cls, kw, cfg.async_replay)
+    cfg.replay_eps, cfg.replay_alpha = 0.01, 0.5
+    cfg.replay_beta = d.LinearSchedule(0.4, 1.0, cfg.max_steps)
+    cfg.random_action_prob = d.LinearSchedule(1.0, 0.1, 100)
+    cfg.target_network_update_freq = 5
+    cfg.exploration_steps = 40
+    cfg.double_q = False
+    cfg.sgd_update_frequency = 4
+    cfg.gradient_clip = 5
+    cfg.async_actor = False
+    d.random_seed(0)
+    random.seed(0)
+    agent = d.DQNAgent(cfg)
+    k = tag + "_"
+    _cmp_params(agent.network, g, k + "init_", 0, 0)  # same seeds -> bit-identical orthogonal init
+    for _ in range(60):
+        agent.step()
+    assert agent.total_steps == int(g[k + "total_steps"])
+    rp = agent.replay.replay
+    n = rp.size()
+    # the replay ring holds the whole action / state history of the run (size < capacity)
+    ring_actions = d.ops._wrap_device_pointer(rp._ring.pointers()[1], n, torch.int64).cpu().numpy()
+    assert np.array_equal(ring_actions, g[k + "replay_action"])
+    ring_states = d.ops._wrap_device_pointer(rp._ring.pointers()[0], n * 4, torch.float64).cpu().numpy().reshape(n, 4)
+    assert np.array_equal(ring_states, g[k + "replay_state"])
+    assert np.array_equal(np.random.randint(0, 1 << 30, size=4), g[k + "rng_tail"])
+    _cmp_params(agent.network, g, k + "final_", 2e-4, 2e-5)
+    _cmp_params(agent.target_network, g, k + "target_", 2e-4, 2e-5)
+    agent.close()
+
+
+def test_dqn_nature_update_matches_reference(golden, dra):
+    """Three full DQN updates on VanillaNet(NatureConvBody) (BASELINE config 2 shapes, B=8): q values,
+    every gradient, the clipped norm, and the weights after centered RMSprop."""
+    d = dra
+    g = golden("dqn_nature_update")
+    b, a = 8, 4
+    rs = np.random.RandomState(int(g["state_seed"]))
+    net = d.VanillaNet(a, d.NatureConvBody())
+    tgt = d.VanillaNet(a, d.NatureConvBody())
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(a), 11).items()})
+    tgt.load_state_dict({k: torch.from_numpy(v) for k, v in fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(a), 12).items()})
+    dev = d.Config.DEVICE
+    state = rs.randint(0, 256, size=(b, 4, 84, 84)).astype(np.uint8)
+    next_state = rs.randint(0, 256, size=(b, 4, 84, 84)).astype(np.uint8)
+    tr = d.Transition(state=torch.from_numpy(state).to(dev), action=torch.from_numpy(rs.randint(0, a, size=b).astype(np.int64)).to(dev),
+                      reward=torch.from_numpy(np.sign(rs.standard_normal(b))).to(dev), next_state=torch.from_numpy(next_state).to(dev),
+                      mask=torch.from_numpy((rs.rand(b) > 0.2).astype(np.int32)).to(dev))
+
+    class Agent(d.DQNAgent):
+        def __init__(self):  # bypass env / replay construction: only the learner is under test
+            cfg = d.Config()
+            cfg.discount, cfg.n_step, cfg.double_q, cfg.gradient_clip = 0.99, 1, False, 5
+            cfg.state_normalizer = d.ImageNormalizer()
+            cfg.lock = agents_lock()
+            self.config = cfg
+            self.network, self.target_network = net, tgt
+            self.optimizer = torch.optim.RMSprop(net.parameters(), lr=0.00025, alpha=0.95, eps=0.01, centered=True)
+            self._fused = d.optim.FusedOptimizer.adopt(self.optimizer)
+
+    from deeprl_amd.agents import _NullLock as agents_lock
+    import deeprl_amd.optim  # noqa: F401
+    agent = Agent()
+    with torch.no_grad():
+        q0 = net(agent.config.state_normalizer(tr.state))["q"]
+    np.testing.assert_allclose(q0.cpu().numpy(), g["q0"], rtol=1e-5, atol=1e-5)
+    for it in range(3):
+        out = agent._learn(tr)
+        want_loss, want_norm = g["loss_gradnorm_traj"][it]
+        np.testing.assert_allclose(out["loss"].item(), want_loss, rtol=2e-5)
+        np.testing.assert_allclose(agent._fused.norm.item(), want_norm, rtol=5e-5)
+        if it == 0:
+            for name, p in net.named_parameters():
+                got = p.grad.cpu().numpy()
+                if name == "body.fc4.weight":
+                    np.testing.assert_allclose(got[::37], g["grad_" + name + "_rows"], rtol=1e-4, atol=2e-6)
+                else:
+                    np.testing.assert_allclose(got, g["grad_" + name], rtol=1e-4, atol=2e-6, err_msg=name)
+    for name, v in net.state_dict().items():
+        got = v.cpu().numpy()
+        want = g["final_" + name + "_rows"] if name == "body.fc4.weight" else g["final_" + name]
+        got = got[::37] if name == "body.fc4.weight" else got
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6, err_msg=name)
+    with torch.no_grad():
+        qf = net(agent.config.state_normalizer(tr.state))["q"]
+    np.testing.assert_allclose(qf.cpu().numpy(), g["q_final"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["t5n16", "t5n16gae", "t20n3gae"])
+def test_a2c_update_matches_reference(golden, dra, tag):
+    """A2C_agent.py:22-64 on the reference's own rollout: states / actions replayed, then the scan,
+    the fused loss, backward through the HIP GEMMs, clip and RMSprop must land on the same weights."""
+    d = dra
+    g = golden("a2c_step")
+    k = tag + "_"
+    gamma, tau, use_gae, ew, vw, clip, t_len, n_env = g[k + "cfg"]
+    t_len, n_env = int(t_len), int(n_env)
+    net = d.CategoricalActorCriticNet(6, 3, d.FCBody(6, hidden_units=(32,)))
+    _load(net, g, k + "init_")
+    opt = torch.optim.RMSprop(net.parameters(), lr=1e-3, alpha=0.99, eps=1e-5)
+    fused = d.optim.FusedOptimizer.adopt(opt)
+    dev = d.Config.DEVICE
+    storage = d.Storage(t_len)
+    for t in range(t_len):
+        pred = net(g[k + "states"][t], torch.from_numpy(g[k + "action"][t]).to(dev))
+        np.testing.assert_allclose(pred["log_pi_a"].detach().cpu().numpy(), g[k + "log_pi_a"][t], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(pred["v"].detach().cpu().numpy(), g[k + "v"][t], rtol=1e-5, atol=1e-5)
+        storage.feed(pred)
+        storage.feed({"reward": torch.from_numpy(g[k + "reward"][t]).to(dev), "mask": torch.from_numpy(g[k + "mask"][t]).to(dev)})
+    boot = net(g[k + "states"][t_len])
+    storage.feed(boot)
+    storage.placeholder()
+    cfg = d.Config()
+    cfg.rollout_length, cfg.discount, cfg.gae_tau, cfg.use_gae = t_len, gamma, tau, bool(use_gae)
+    from deeprl_amd.agents import _rollout_scan
+    adv, ret = _rollout_scan(storage, cfg, boot["v"])
+    np.testing.assert_allclose(adv.cpu().numpy(), g[k + "adv"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ret.cpu().numpy(), g[k + "ret"], rtol=1e-5, atol=1e-5)
+    entries = storage.extract(["log_pi_a", "v", "ret", "advantage", "entropy"])
+    out4, (g_lp, g_ent, g_v) = d.ops.a2c_loss(entries.log_pi_a.detach(), entries.entropy.detach(), entries.v.detach(),
+                                             entries.advantage, entries.ret, ew, vw)
+    fused.zero_grad()
+    torch.autograd.backward([entries.log_pi_a, entries.entropy, entries.v], [g_lp, g_ent, g_v])
+    fused.step(clip)
+    _cmp_params(net, g, k + "final_", 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("tag", ["t64n2", "t32n4"])
+def test_ppo_optimize_matches_reference(golden, dra, tag, monkeypatch):
+    """PPO_agent.py:63-99 on the reference's own rollout entries: advantage normalisation, the
+    np.random minibatch permutations, the fused clip loss, the approx-KL gate and both Adam steps."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    g = golden("ppo_step")
+    k = tag + "_"
+    gamma, tau, ew, clip, target_kl, epochs, mb, t_len, n_env = g[k + "cfg"]
+    cfg = d.Config()
+    cfg.merge(dict(discount=gamma, use_gae=True, gae_tau=tau, entropy_weight=ew, rollout_length=int(t_len),
+                   num_workers=int(n_env), optimization_epochs=int(epochs), mini_batch_size=int(mb),
+                   ppo_ratio_clip=clip, target_kl=target_kl, shared_repr=False, max_steps=1e6, gradient_clip=0.5))
+    cfg.task_fn = lambda: fake_envs.ContinuousTask(seed=9, state_dim=5, action_dim=2, horizon=25, num_envs=int(n_env))
+    cfg.network_fn = lambda: d.GaussianActorCriticNet(
+        5, 2, actor_body=d.FCBody(5, hidden_units=(16, 16), gate=torch.tanh),
+        critic_body=d.FCBody(5, hidden_units=(16, 16), gate=torch.tanh))
+    cfg.actor_opt_fn = lambda params: torch.optim.Adam(params, 3e-4)
+    cfg.critic_opt_fn = lambda params: torch.optim.Adam(params, 1e-3)
+    agent = d.PPOAgent(cfg)
+    _load(agent.network, g, k + "init_")
+    dev = d.Config.DEVICE
+    from collections import namedtuple
+    entry_cls = namedtuple("Entry", ["state", "action", "log_pi_a", "ret", "advantage"])
+    raw_adv = torch.from_numpy(g[k + "adv"].reshape(-1, 1)).to(dev).contiguous()
+    d.ops.adv_normalize_(raw_adv)
+    np.testing.assert_allclose(raw_adv.cpu().numpy(), g[k + "ent_adv_normalized"], rtol=1e-5, atol=1e-5)
+    entries = entry_cls(*[torch.from_numpy(g[k + n]).to(dev) for n in ("ent_state", "ent_action", "ent_log_pi_a", "ent_ret")],
+                        raw_adv)
+    np.random.seed(21)
+    agent.optimize(entries)
+    _cmp_params(agent.network, g, k + "final_", 2e-5, 2e-6)

@@ -1,0 +1,468 @@
+"""GPU parity tests: every HIP kernel (called through the C-ABI) against the CPU oracle and the
+golden fixtures generated from the reference.  Integer / byte / index / fp64 work is compared
+bit-exactly; fp32 losses / gradients at 1e-5 (north_star); contractions at 1e-4 relative to the
+output scale (different fp32 summation order than the CPU oracle)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden.make_golden_cases import PER_CASES, UNIFORM_CASES, stream  # noqa: E402
+from oracle import loss_oracle as L  # noqa: E402
+from oracle import net_oracle as NO  # noqa: E402
+from oracle import numerics_oracle as NUM  # noqa: E402
+from oracle.replay_oracle import UniformReplayOracle  # noqa: E402
+from oracle.synth_oracle import synth_transitions  # noqa: E402
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from deeprl_amd.support import select_device, Config
+    select_device(0)
+    return Config.DEVICE
+
+
+def cu(x, dev, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev)
+
+
+def f32(x, dev):
+    return cu(np.asarray(x, dtype=np.float32), dev)
+
+
+# --------------------------------------------------------------------------------------------- replay
+@pytest.mark.parametrize("case", UNIFORM_CASES, ids=[c[0] for c in UNIFORM_CASES])
+def test_uniform_replay_golden(golden, dev, case):
+    from deeprl_amd.replay import UniformReplay
+    g = golden("uniform_replay")
+    name, mem, b, h, n, disc, shape, kind, t_len, cps = case
+    states, actions, rewards, masks = stream(np.random.RandomState(1000 + ord(name)), t_len, shape, kind, 4, 0.1)
+    rep = UniformReplay(memory_size=mem, batch_size=b, n_step=n, discount=disc, history_length=h)
+    np.random.seed(2000 + ord(name))
+    for t in range(t_len):
+        rep.feed(dict(state=states[t][None], action=actions[t:t + 1], reward=[rewards[t]], mask=masks[t:t + 1]))
+        if t in cps:
+            tr = rep.sample()
+            k = "%s_t%d_" % (name, t)
+            assert np.array_equal(g[k + "pos_size"], [rep.pos, rep.size()])
+            for key in ("state", "action", "reward", "next_state", "mask"):
+                got, want = getattr(tr, key).cpu().numpy(), g[k + key]
+                assert got.shape == want.shape and got.dtype == want.dtype, (key, got.dtype, want.dtype, got.shape)
+                assert np.array_equal(got, want), key
+    assert np.array_equal(np.random.randint(0, 1 << 30, size=4), g[name + "_rng_tail"])
+    rep.close()
+
+
+@pytest.mark.parametrize("case", PER_CASES, ids=[c[0] for c in PER_CASES])
+@pytest.mark.parametrize("ordered", [False, True])
+def test_prioritized_replay_golden(golden, dev, case, ordered):
+    from deeprl_amd.replay import PrioritizedReplay
+    g = golden("prioritized_replay")
+    name, mem, b, h, n, disc, shape, kind, t_len, every = case
+    rs = np.random.RandomState(3000 + ord(name))
+    states, actions, rewards, masks = stream(rs, t_len, shape, kind, 4, 0.1)
+    rep = PrioritizedReplay(memory_size=mem, batch_size=b, n_step=n, discount=disc, history_length=h)
+    rep.ordered_updates = ordered
+    random.seed(4000 + ord(name))
+    np.random.seed(4000 + ord(name))
+    ks = 0
+    for t in range(t_len):
+        rep.feed(dict(state=states[t][None], action=actions[t:t + 1], reward=[rewards[t]], mask=masks[t:t + 1]))
+        if t >= h + n + 6 and t % every == 0:
+            tr = rep.sample()
+            k = "%s_s%d_" % (name, ks)
+            for key in ("state", "action", "reward", "next_state", "mask", "sampling_prob", "idx"):
+                got, want = getattr(tr, key).cpu().numpy(), g[k + key]
+                assert got.dtype == want.dtype, (key, got.dtype, want.dtype)
+                assert np.array_equal(got, want), (key, ks)
+            rs.standard_normal(b)
+            prio = g[k + "prio"]
+            rep.update_priorities(zip(tr.idx.cpu().numpy(), prio))
+            assert np.array_equal(rep.tree.as_tensor().cpu().numpy(), g[k + "tree"]), ks
+            assert float(rep.max_priority) == float(g[k + "max_priority"])
+            ks += 1
+    assert ks == int(g[name + "_n_samples"])
+    assert np.array_equal([random.random() for _ in range(3)], g[name + "_rng_tail"])
+    rep.close()
+
+
+def test_ring_vs_oracle_atari_shapes(dev):
+    """84x84 frames (16-byte vector path), H=4, n=3, wrap-around, device-side synthetic fill."""
+    from deeprl_amd import ops
+    cap, h, n, gamma, fb = 5000, 4, 3, 0.99, 7056
+    ring = ops.Ring(cap, fb, 8, h, n, gamma)
+    orc = UniformReplayOracle(cap, 32, n, gamma, h)
+    total = 7300  # wraps
+    frames, act, rew, msk = synth_transitions(0, total, fb, seed=3, n_actions=4, done_period=50)
+    pos = 0
+    done = 0
+    while done < total:  # device fill in runs that do not wrap
+        run = min(total - done, cap - pos)
+        ring.fill_synthetic(pos, run, done, 3, n_actions=4, done_period=50)
+        pos = (pos + run) % cap
+        done += run
+    for t in range(total):
+        orc.feed_one(frames[t].reshape(84, 84), act[t], rew[t], msk[t])
+    np.random.seed(5)
+    idx = orc.draw_indices(256)
+    want = orc.gather(idx)
+    got = ring.gather(cu(idx, dev), (84, 84), torch.uint8, torch.int64, want_f32=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(got["state"].cpu().numpy(), want[0])
+    assert np.array_equal(got["action"].cpu().numpy(), want[1])
+    assert np.array_equal(got["reward"].cpu().numpy(), want[2])
+    assert np.array_equal(got["next_state"].cpu().numpy(), want[3])
+    assert np.array_equal(got["mask"].cpu().numpy(), want[4])
+    assert np.array_equal(got["reward_f32"].cpu().numpy(), want[2].astype(np.float32))
+    assert np.array_equal(got["mask_f32"].cpu().numpy(), want[4].astype(np.float32))
+    ring.close()
+
+
+def test_image_lut_bit_exact(dev):
+    from deeprl_amd.normalizers import ImageNormalizer
+    rs = np.random.RandomState(0)
+    x = rs.randint(0, 256, size=(5, 4, 84, 84)).astype(np.uint8)
+    x.reshape(-1)[:256] = np.arange(256)
+    got = ImageNormalizer()(cu(x, dev)).cpu().numpy()
+    want = NUM.image_normalize_sync(x)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    odd = x.reshape(-1)[:1003].copy()  # tail path (n % 16 != 0)
+    got = ImageNormalizer()(cu(odd, dev)).cpu().numpy()
+    assert np.array_equal(got, NUM.image_normalize_sync(odd))
+
+
+@pytest.mark.parametrize("cap", [8, 13, 50])
+def test_sumtree_ops_golden(golden, dev, cap):
+    """Replays the reference SumTree's op log (add / get / update with pending gating on the host,
+    as deeprl_amd.replay does) and compares the device heap array node by node."""
+    from deeprl_amd import ops
+    g = golden("sumtree")
+    tree = ops.SumTree(cap)
+    pending, write = set(), 0
+    for op, x, p_out, idx in g["cap%d_log" % cap]:
+        op, idx = int(op), int(idx)
+        if op == 0:  # add: self-mark pending, update, advance the write cursor
+            leaf = write + cap - 1
+            tree.set(leaf, float(np.float32(x)))
+            pending.discard(leaf)
+            write = (write + 1) % cap
+        elif op == 1:  # get(s): arbitrary-s descents are covered by the PrioritizedReplay goldens
+            pending.add(idx)
+        elif idx in pending:  # update: only pending leaves
+            pending.remove(idx)
+            tree.update(cu([idx], dev), cu(np.asarray([np.float32(x)], dtype=np.float64), dev))
+    assert np.array_equal(tree.as_tensor().cpu().numpy(), g["cap%d_tree" % cap])
+    assert np.array_equal(sorted(pending), g["cap%d_pending" % cap])
+    tree.close()
+
+
+@pytest.mark.gpu
+def test_sumtree_large_parallel_equals_ordered(dev):
+    """1M-leaf tree: parallel level-by-level update == reference-order incremental update ==
+    bottom-up rebuild, for fp32-valued priorities (the exactness regime of SURVEY.md section 7)."""
+    from deeprl_amd import ops
+    cap = 1_000_003
+    rs = np.random.RandomState(1)
+    ta, tb = ops.SumTree(cap), ops.SumTree(cap)
+    leaves0 = cu(np.arange(cap - 1, 2 * cap - 1, dtype=np.int64), dev)
+    view_a, view_b = ta.as_tensor(), tb.as_tensor()
+    init = torch.ones(cap, dtype=torch.float64, device=dev)
+    view_a[cap - 1:] = init
+    view_b[cap - 1:] = init
+    ta.rebuild()
+    tb.rebuild()
+    for _ in range(20):
+        leaf = rs.choice(cap, size=32, replace=False).astype(np.int64) + cap - 1
+        prio = np.sqrt(np.abs(rs.standard_normal(32)).astype(np.float32) + np.float32(0.01)).astype(np.float64)
+        ta.update(cu(leaf, dev), cu(prio, dev), ordered=False)
+        tb.update(cu(leaf, dev), cu(prio, dev), ordered=True)
+    torch.cuda.synchronize()
+    a, b = view_a.cpu().numpy(), view_b.cpu().numpy()
+    assert np.array_equal(a, b)
+    tb.rebuild()
+    assert np.array_equal(view_b.cpu().numpy(), a)
+    # stratified sampling agrees with the oracle descent on the same tree
+    from oracle.sumtree_oracle import SumTreeOracle
+    o = SumTreeOracle(cap)
+    o.tree = a.copy()
+    u = rs.rand(32)
+    idx, p, total = ta.sample(cu(u, dev))
+    seg = o.total() / 32
+    for i in range(32):
+        s = seg * i + (seg * (i + 1) - seg * i) * u[i]
+        oi, op_, _ = o.get(s)
+        assert oi == int(idx[i]) and op_ == float(p[i])
+    assert float(total) == o.total()
+    ta.close()
+    tb.close()
+    del leaves0
+
+
+# --------------------------------------------------------------------------------------------- losses
+@pytest.mark.parametrize("tag", ["b32a4", "b10a2n3", "b32a4dq", "b7a18"])
+@pytest.mark.parametrize("act_i64", [True, False])
+def test_td_loss_golden(golden, dev, tag, act_i64):
+    from deeprl_amd import ops
+    g = golden("dqn_loss")
+    k = tag + "_"
+    gamma, n_step, double_q, eps, alpha, beta = g[k + "cfg"]
+    action = cu(g[k + "action"], dev) if act_i64 else f32(g[k + "action"], dev)
+    common = dict(q=f32(g[k + "q"], dev), q_next_target=f32(g[k + "q_next_t"], dev), action=action,
+                  reward=f32(g[k + "reward"], dev), mask=f32(g[k + "mask"], dev), gamma_n=gamma ** int(n_step),
+                  q_next_online=f32(g[k + "q_next_o"], dev) if double_q else None)
+    out = ops.td_loss(**common)
+    np.testing.assert_allclose(out["delta"].cpu().numpy(), g[k + "loss_vec"], **TOL)
+    np.testing.assert_allclose(out["loss"].item(), g[k + "loss"], **TOL)
+    np.testing.assert_allclose(out["dq"].cpu().numpy(), g[k + "grad_q"], **TOL)
+    out = ops.td_loss(sampling_prob=f32(g[k + "sampling_prob"], dev), beta=beta, replay_eps=eps, replay_alpha=alpha,
+                      **common)
+    np.testing.assert_allclose(out["prio"].cpu().numpy(), g[k + "prio"], **TOL)
+    np.testing.assert_allclose(out["weights"].cpu().numpy(), g[k + "w"], **TOL)
+    np.testing.assert_allclose(out["loss"].item(), g[k + "loss_per"], **TOL)
+    np.testing.assert_allclose(out["dq"].cpu().numpy(), g[k + "grad_q_per"], **TOL)
+
+
+@pytest.mark.parametrize("tag", ["b32a4", "b8a3n3dq", "b5a6at21"])
+def test_c51_loss_golden(golden, dev, tag):
+    from deeprl_amd import ops
+    g = golden("c51_loss")
+    k = tag + "_"
+    gamma, n_step, double_q, vmin, vmax, n_atoms = g[k + "cfg"]
+    atoms = f32(np.linspace(vmin, vmax, int(n_atoms)), dev)
+    out = ops.c51_loss(f32(g[k + "logits"], dev), f32(g[k + "logits_next_t"], dev), cu(g[k + "action"], dev),
+                       f32(g[k + "reward"], dev), f32(g[k + "mask"], dev), gamma ** int(n_step), atoms, vmin, vmax,
+                       logits_next_online=f32(g[k + "logits_next_o"], dev) if double_q else None)
+    np.testing.assert_allclose(out["kl"].cpu().numpy(), g[k + "kl"], **TOL)
+    np.testing.assert_allclose(out["loss"].item(), g[k + "loss"], **TOL)
+    np.testing.assert_allclose(out["dlogits"].cpu().numpy(), g[k + "grad_logits"], **TOL)
+
+
+@pytest.mark.parametrize("tag", ["b32a4", "b6a3q17n3"])
+def test_qr_loss_golden(golden, dev, tag):
+    from deeprl_amd import ops
+    g = golden("qr_loss")
+    k = tag + "_"
+    gamma, n_step, nq = g[k + "cfg"]
+    out = ops.qr_loss(f32(g[k + "theta"], dev), f32(g[k + "theta_next_t"], dev), cu(g[k + "action"], dev),
+                      f32(g[k + "reward"], dev), f32(g[k + "mask"], dev), gamma ** int(n_step))
+    np.testing.assert_allclose(out["loss_vec"].cpu().numpy(), g[k + "loss_vec"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(out["loss"].item(), g[k + "loss"], **TOL)
+    np.testing.assert_allclose(out["dtheta"].cpu().numpy(), g[k + "grad_theta"], **TOL)
+
+
+@pytest.mark.parametrize("tag", ["m64", "m256", "m5"])
+def test_ppo_loss_golden(golden, dev, tag):
+    from deeprl_amd import ops
+    g = golden("ppo_loss")
+    k = tag + "_"
+    out3, gs = ops.ppo_loss(f32(g[k + "lp"], dev), f32(g[k + "ent"], dev), f32(g[k + "v"], dev), f32(g[k + "old_lp"], dev),
+                            f32(g[k + "adv"], dev), f32(g[k + "ret"], dev), 0.2, 0.01)
+    np.testing.assert_allclose(out3.cpu().numpy(), g[k + "out"], **TOL)
+    for got, key in zip(gs, ("g_lp", "g_ent", "g_v")):
+        np.testing.assert_allclose(got.cpu().numpy(), g[k + key], **TOL)
+
+
+def test_a2c_loss_vs_oracle(dev):
+    from deeprl_amd import ops
+    rs = np.random.RandomState(0)
+    m = 80
+    arr = [rs.standard_normal((m, 1)).astype(np.float32) for _ in range(5)]
+    lp, ent, v = [torch.tensor(a, requires_grad=True) for a in arr[:3]]
+    loss = L.a2c_loss(lp, ent, v, torch.tensor(arr[3]), torch.tensor(arr[4]), 0.01, 1.0)
+    gs = torch.autograd.grad(loss, [lp, ent, v])
+    out4, gg = ops.a2c_loss(*[f32(a, dev) for a in arr], 0.01, 1.0)
+    np.testing.assert_allclose(out4[0].item(), loss.item(), **TOL)
+    for got, want in zip(gg, gs):
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), **TOL)
+
+
+# --------------------------------------------------------------------------------------------- scan
+@pytest.mark.parametrize("name,tag", [("a2c_step", "t5n16"), ("a2c_step", "t5n16gae"), ("a2c_step", "t20n3gae"),
+                                      ("ppo_step", "t64n2"), ("ppo_step", "t32n4")])
+def test_gae_golden(golden, dev, name, tag):
+    from deeprl_amd import ops
+    g = golden(name)
+    k = tag + "_"
+    cfg = g[k + "cfg"]
+    gamma, tau = cfg[0], cfg[1]
+    use_gae = bool(cfg[2]) if name == "a2c_step" else True
+    adv, ret = ops.gae(f32(g[k + "reward"], dev), f32(g[k + "mask"], dev), f32(g[k + "v"], dev), gamma, tau, use_gae)
+    np.testing.assert_allclose(adv.cpu().numpy(), g[k + "adv"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ret.cpu().numpy(), g[k + "ret"], rtol=1e-5, atol=1e-5)
+    if name == "ppo_step":
+        flat = adv.reshape(-1, 1).clone()
+        ops.adv_normalize_(flat)
+        np.testing.assert_allclose(flat.cpu().numpy(), g[k + "ent_adv_normalized"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("t_len,n_env,use_gae", [(2048, 16, True), (2048, 1, True), (128, 8, True), (5, 16, False),
+                                                 (700, 5, True)])
+def test_gae_vs_oracle_baseline_sizes(dev, t_len, n_env, use_gae):
+    from deeprl_amd import ops
+    rs = np.random.RandomState(t_len + n_env)
+    r = rs.standard_normal((t_len, n_env, 1)).astype(np.float32)
+    m = (rs.rand(t_len, n_env, 1) > 0.01).astype(np.float32)
+    v = rs.standard_normal((t_len + 1, n_env, 1)).astype(np.float32)
+    wa, wr = L.gae_reverse(torch.tensor(r), torch.tensor(m), torch.tensor(v), 0.99, 0.95, use_gae)
+    adv, ret = ops.gae(f32(r, dev), f32(m, dev), f32(v, dev), 0.99, 0.95, use_gae)
+    np.testing.assert_allclose(adv.cpu().numpy(), wa.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ret.cpu().numpy(), wr.numpy(), rtol=1e-5, atol=1e-5)
+
+
+# --------------------------------------------------------------------------------------------- optimiser
+@pytest.mark.parametrize("name", ["rmsprop_centered", "rmsprop_plain", "adam", "adam_default"])
+@pytest.mark.parametrize("clip", [5.0, 0.5])
+def test_optim_golden(golden, dev, name, clip):
+    from deeprl_amd import ops
+    g = golden("optim")
+    shapes = [g["p0_%d" % j].shape for j in range(4)]
+    sizes = [int(np.prod(s)) for s in shapes]
+    n = sum(sizes)
+    flat = lambda arrs: np.concatenate([np.asarray(a, dtype=np.float32).reshape(-1) for a in arrs])
+    p = f32(flat([g["p0_%d" % j] for j in range(4)]), dev)
+    s1, s2 = torch.zeros_like(p), torch.zeros_like(p)
+    npart = ops.norm_partials()
+    partials = torch.zeros(npart, dtype=torch.float64, device=dev)
+    norm = torch.zeros(1, dtype=torch.float32, device=dev)
+    norms = []
+    for i in range(5):
+        gr = f32(flat([g["g%d_%d" % (i, j)] for j in range(4)]), dev)
+        ops.grad_sqnorm(gr, partials)
+        if name == "rmsprop_centered":
+            ops.rmsprop_step(p, gr, s1, s2, partials, npart, clip, 0.00025, 0.95, 0.01, True, norm)
+        elif name == "rmsprop_plain":
+            ops.rmsprop_step(p, gr, s1, s2, partials, npart, clip, 1e-4, 0.99, 1e-5, False, norm)
+        elif name == "adam":
+            ops.adam_step(p, gr, s1, s2, partials, npart, clip, 2.5e-4, 0.9, 0.999, 0.01 / 32, i + 1, norm)
+        else:
+            ops.adam_step(p, gr, s1, s2, partials, npart, clip, 3e-4, 0.9, 0.999, 1e-8, i + 1, norm)
+        norms.append(norm.item())
+    np.testing.assert_allclose(norms, g["%s_clip%g_norms" % (name, clip)], rtol=1e-6)
+    got = p.cpu().numpy()
+    off = 0
+    for j in range(4):
+        np.testing.assert_allclose(got[off:off + sizes[j]].reshape(shapes[j]), g["%s_clip%g_p%d" % (name, clip, j)],
+                                   rtol=1e-5, atol=1e-6)
+        off += sizes[j]
+    assert off == n
+
+
+def test_grad_sqnorm_folds_slabs(dev):
+    from deeprl_amd import ops
+    rs = np.random.RandomState(2)
+    n, s = 78_563, 7
+    stride = (n + 3) // 4 * 4
+    slabs = rs.standard_normal((s, stride)).astype(np.float32)
+    grad = torch.zeros(n, dtype=torch.float32, device=dev)
+    partials = torch.zeros(ops.norm_partials(), dtype=torch.float64, device=dev)
+    ops.grad_sqnorm(grad, partials, slabs=f32(slabs, dev), n_slabs=s, slab_stride=stride)
+    want = slabs[0, :n].copy()
+    for k in range(1, s):
+        want = want + slabs[k, :n]
+    assert np.array_equal(grad.cpu().numpy(), want)
+    np.testing.assert_allclose(partials.sum().item(), (want.astype(np.float64) ** 2).sum(), rtol=1e-6)
+
+
+# --------------------------------------------------------------------------------------------- contractions
+def _scale_close(got, want, rel=1e-4):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    scale = np.abs(want).max() + 1e-12
+    err = np.abs(got - want).max()
+    assert err <= rel * scale, "max abs err %.3e vs scale %.3e" % (err, scale)
+
+
+CONV = {1: (4, 84, 32, 8, 4), 2: (32, 20, 64, 4, 2), 3: (64, 9, 64, 3, 1)}
+
+
+@pytest.mark.parametrize("layer", [1, 2, 3])
+@pytest.mark.parametrize("batch", [32, 1, 5])
+def test_conv_fwd_bwd_vs_oracle(dev, layer, batch):
+    """Forward (two weight sets in one launch), weight/bias gradient (split-K slabs folded by
+    dra_grad_sqnorm) and input gradient against F.conv2d autograd on the CPU."""
+    import torch.nn.functional as F
+    from deeprl_amd import ops
+    c, h, oc, k, s = CONV[layer]
+    rs = np.random.RandomState(10 * layer + batch)
+    ws = [(rs.standard_normal((oc, c, k, k)) / np.sqrt(c * k * k)).astype(np.float32) for _ in range(2)]
+    bs = [(rs.standard_normal(oc) * 0.1).astype(np.float32) for _ in range(2)]
+    if layer == 1:
+        xs_u8 = [rs.randint(0, 256, size=(batch, c, h, h)).astype(np.uint8) for _ in range(2)]
+        xs = [NUM.image_normalize_sync(x) for x in xs_u8]
+        ys = ops.conv_fwd(1, [cu(x, dev) for x in xs_u8], [f32(w, dev) for w in ws], [f32(b, dev) for b in bs],
+                          act="relu", u8_coef=1.0 / 255)
+    else:
+        xs = [np.maximum(rs.standard_normal((batch, c, h, h)), 0).astype(np.float32) for _ in range(2)]
+        ys = ops.conv_fwd(layer, [f32(x, dev) for x in xs], [f32(w, dev) for w in ws], [f32(b, dev) for b in bs],
+                          act="relu")
+    refs = []
+    for z in range(2):
+        xt = torch.tensor(xs[z], requires_grad=True)
+        wt, bt = torch.tensor(ws[z], requires_grad=True), torch.tensor(bs[z], requires_grad=True)
+        yt = F.relu(F.conv2d(xt, wt, bt, stride=s))
+        refs.append((xt, wt, bt, yt))
+        _scale_close(ys[z].cpu().numpy(), yt.detach().numpy())
+    # backward of set 0 with a random upstream gradient (w.r.t. the post-ReLU output)
+    xt, wt, bt, yt = refs[0]
+    dy = rs.standard_normal(tuple(yt.shape)).astype(np.float32)
+    yt.backward(torch.tensor(dy))
+    dpre = ops.act_bwd(f32(dy, dev), ys[0], "relu")
+    x_dev = cu(xs_u8[0], dev) if layer == 1 else f32(xs[0], dev)
+    ksplit = 16
+    dw_s, db_s = ops.conv_bwd_w(layer, dpre, x_dev, ksplit=ksplit, u8_coef=1.0 / 255 if layer == 1 else None)
+    _scale_close(dw_s.sum(0).cpu().numpy().reshape(wt.shape), wt.grad.numpy())
+    _scale_close(db_s.sum(0).cpu().numpy(), bt.grad.numpy())
+    if layer > 1:
+        dx = ops.conv_bwd_x(layer, dpre, f32(ws[0], dev))
+        _scale_close(dx.cpu().numpy(), xt.grad.numpy())
+        # fused activation-derivative mask of the layer below (xact = this layer's input, post-ReLU)
+        dxm = ops.conv_bwd_x(layer, dpre, f32(ws[0], dev), xact=f32(xs[0], dev), act="relu")
+        _scale_close(dxm.cpu().numpy(), xt.grad.numpy() * (xs[0] > 0))
+
+
+@pytest.mark.parametrize("batch,fin,fout,act", [(32, 3136, 512, "relu"), (32, 512, 4, None), (32, 512, 204, None),
+                                                (10, 4, 64, "relu"), (64, 17, 64, "tanh"), (1, 3136, 512, "relu"),
+                                                (256, 64, 1, None), (32, 512, 800, None)])
+def test_linear_fwd_bwd_vs_oracle(dev, batch, fin, fout, act):
+    import torch.nn.functional as F
+    from deeprl_amd import ops
+    rs = np.random.RandomState(batch + fin + fout)
+    xs = [rs.standard_normal((batch, fin)).astype(np.float32) for _ in range(2)]
+    ws = [(rs.standard_normal((fout, fin)) / np.sqrt(fin)).astype(np.float32) for _ in range(2)]
+    bs = [(rs.standard_normal(fout) * 0.1).astype(np.float32) for _ in range(2)]
+    ys = ops.linear_fwd([f32(x, dev) for x in xs], [f32(w, dev) for w in ws], [f32(b, dev) for b in bs], act=act)
+    fn = {None: lambda t: t, "relu": F.relu, "tanh": torch.tanh}[act]
+    refs = []
+    for z in range(2):
+        xt = torch.tensor(xs[z], requires_grad=True)
+        wt, bt = torch.tensor(ws[z], requires_grad=True), torch.tensor(bs[z], requires_grad=True)
+        yt = fn(F.linear(xt, wt, bt))
+        refs.append((xt, wt, bt, yt))
+        _scale_close(ys[z].cpu().numpy(), yt.detach().numpy())
+    xt, wt, bt, yt = refs[1]
+    dy = rs.standard_normal((batch, fout)).astype(np.float32)
+    yt.backward(torch.tensor(dy))
+    dpre = ops.act_bwd(f32(dy, dev), ys[1], act) if act else f32(dy, dev)
+    dw, db = ops.linear_bwd_w(dpre, f32(xs[1], dev))
+    _scale_close(dw.cpu().numpy(), wt.grad.numpy())
+    _scale_close(db.cpu().numpy(), bt.grad.numpy())
+    dx = ops.linear_bwd_x(dpre, f32(ws[1], dev))
+    _scale_close(dx.cpu().numpy(), xt.grad.numpy())
+
+
+def test_mfma_layout_transpose_detecting(dev):
+    """A = I with an ASYMMETRIC B: catches a row<->column swap in the MFMA C/D write-out."""
+    from deeprl_amd import ops
+    n = 64
+    x = np.eye(n, dtype=np.float32)
+    w = (np.arange(n * n, dtype=np.float32).reshape(n, n) / 7.0)  # w[o][i] asymmetric
+    y = ops.linear_fwd([f32(x, dev)], [f32(w, dev)], [None], act=None)[0]
+    assert np.array_equal(y.cpu().numpy(), w.T)
