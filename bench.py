@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""bench.py -- gradient-updates/sec (+ env-steps/sec) of the DQN Breakout hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE JSON line on rank 0.
+  * workload = BASELINE.json configs[1]: DQN, NatureConvBody, 84x84x4 uint8 frames, batch 32,
+    1M-frame HBM replay ring, centered RMSprop, clip 5 (examples.py:55-97), synthetic frames
+    (counter hash, data: "synthetic"), random-init weights.
+  * a "step" = one full agent step of that config: 4 environment transitions (synthetic frame
+    source + batch-1 greedy/epsilon action selection on device) fed to the ring, one uniform
+    minibatch draw (host np.random, reference-exact), gather, target + online forward, TD loss,
+    backward, global-norm clip, RMSprop.  Inputs are resident in HBM before the timed region.
+  * N > 1: one process per GPU, independent replicas (the reference's only multi-GPU mode for
+    off-policy agents, docker_batch.sh:2-8) -> "scaling": "weak", no data-path
+    collective; a barrier + max-over-ranks brackets the timed region.
+  * roofline: the dominant kernel of the update, timed live with HIP events on the launch stream.
+  * cpu_baseline: the CPU oracle (port of the reference path on torch-CPU fp32) on a bounded
+    sample, rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B, H, A, F = 32, 4, 4, 84 * 84
+CONV_FLOPS_FWD = 209_715_200 + 169_869_312 + 115_605_504
+UPDATE_FLOPS = 2_182_600_000
+FP32_MFMA_PEAK = 157.3e12
+HBM_PEAK = 8.0e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--ring", type=int, default=1_000_000, help="replay capacity in frames")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-actor", action="store_true", help="skip actor inference (then env_steps is null)")
+    ap.add_argument("--path", default="fused", choices=["fused", "generic"])
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds=15.0, ring=20_000):
+    """The CPU oracle of the same update (port of the reference path): numpy ring gather ->
+    f64*(1/255)->f32 -> target fwd, online fwd, TD loss, backward, clip, centered RMSprop on
+    torch-CPU fp32, single thread like the reference's set_one_thread() (examples.py:623)."""
+    from oracle import loss_oracle as L, net_oracle as N, numerics_oracle as NUM
+    from oracle.replay_oracle import UniformReplayOracle
+    from oracle.synth_oracle import synth_transitions
+    torch.set_num_threads(1)
+    rs = np.random.RandomState(0)
+    shapes = [("body.conv1.weight", (32, 4, 8, 8)), ("body.conv1.bias", (32,)), ("body.conv2.weight", (64, 32, 4, 4)),
+              ("body.conv2.bias", (64,)), ("body.conv3.weight", (64, 64, 3, 3)), ("body.conv3.bias", (64,)),
+              ("body.fc4.weight", (512, 3136)), ("body.fc4.bias", (512,)), ("fc_head.weight", (A, 512)),
+              ("fc_head.bias", (A,))]
+    p = {k: torch.tensor((rs.standard_normal(s) / np.sqrt(max(1, int(np.prod(s[1:]))))).astype(np.float32), requires_grad=True)
+         for k, s in shapes}
+    pt = {k: v.detach().clone() for k, v in p.items()}
+    rep = UniformReplayOracle(ring, B, 1, 0.99, H)
+    frames, act, rew, msk = synth_transitions(0, ring, F, seed=0)
+    for t in range(ring):
+        rep.feed_one(frames[t].reshape(84, 84), act[t], rew[t], msk[t])
+    names = list(p)
+    sq = {k: torch.zeros_like(v) for k, v in p.items()}
+    ga = {k: torch.zeros_like(v) for k, v in p.items()}
+    np.random.seed(0)
+
+    def one():
+        st, ac, rw, ns, mk, _ = rep.sample()
+        x = torch.from_numpy(NUM.image_normalize_sync(st))
+        xn = torch.from_numpy(NUM.image_normalize_sync(ns))
+        with torch.no_grad():
+            qn = N.vanilla_head(pt, N.nature_conv_body(pt, xn))
+        q = N.vanilla_head(p, N.nature_conv_body(p, x))
+        delta = L.dqn_td_error(q, qn, torch.from_numpy(ac), torch.from_numpy(rw.astype(np.float32)),
+                               torch.from_numpy(mk.astype(np.float32)), 0.99)
+        loss = L.dqn_reduce(delta)
+        grads = torch.autograd.grad(loss, [p[k] for k in names])
+        _, grads = N.clip_grad_norm(list(grads), 5)
+        with torch.no_grad():
+            for k, g in zip(names, grads):
+                newp, sq[k], ga[k] = N.rmsprop_step(p[k], g, sq[k], ga[k], 0.00025, 0.95, 0.01, True)
+                p[k].copy_(newp)
+
+    for _ in range(3):
+        one()
+    n, t0 = 0, time.time()
+    while time.time() - t0 < seconds:
+        one()
+        n += 1
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "gradient-updates/sec", "cores": 1, "kind": "port",
+            "sample": "%d DQN updates (B=32, 84x84x4, %d-frame ring) in %.1f s, torch-CPU fp32 oracle, 1 thread" % (n, ring, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import deeprl_amd as d
+    from deeprl_amd.learner import DQNLearnerBench
+    d.select_device(local_rank)
+    torch.manual_seed(1234 + rank)
+    np.random.seed(rank)
+    bench = DQNLearnerBench(ring_capacity=args.ring, batch=B, seed=rank, actor=not args.no_actor, path=args.path)
+    for _ in range(args.warmup):
+        bench.step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bench.step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    roof = bench.roofline(args.steps if args.steps < 500 else 500)
+    extra = bench.report()
+    if rank == 0:
+        ups = world * args.steps / dt
+        out = {
+            "metric": "gradient-updates/sec", "value": ups, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DQN Breakout 84x84x4 uint8, NatureConvBody, batch 32, %d-frame HBM replay ring, "
+                                   "centered RMSprop, clip 5 (BASELINE configs[1])" % args.ring,
+                       "global_batch": B * world, "parallelism": "replicas x%d" % world, "path": args.path,
+                       "actor_in_step": not args.no_actor},
+            "env_steps_per_sec": (4 * ups) if not args.no_actor else None,
+            "roofline": roof,
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

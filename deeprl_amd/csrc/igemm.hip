@@ -418,7 +418,7 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
   const int tiles = ((out_features + 31) / 32) * ((batch + 31) / 32) * nz;
   const int chunks = (in_features + 63) / 64;
   int ksplit = 1;
-  if (tiles < 128 && chunks >= 4) {
+  if (tiles < 128 && chunks >= 16) {  // K >= 1024: heads (K = 512) stay single-launch
     ksplit = (256 + tiles - 1) / tiles;
     if (ksplit > chunks / 2) ksplit = chunks / 2;
     if (ksplit > 32) ksplit = 32;

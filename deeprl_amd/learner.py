@@ -1,0 +1,245 @@
+"""Python host of the fused DQN learner (deeprl_amd/csrc/learner.hip).
+
+`DQNLearner` binds a VanillaNet(NatureConvBody) pair (online / target), the optimiser
+hyper-parameters and an HBM replay ring to the C-ABI learner: after that, one gradient update
+(DQN_agent.py:114-134) is ONE ctypes call that replays a captured hipGraph, and one actor step
+(DQN_agent.py:24-45) is one call that never synchronises.  All RNG stays on the host in the
+reference's draw order.
+
+`DQNLearnerBench` is the synthetic-workload driver bench.py times (BASELINE configs[1]).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import DraError, lib
+from .optim import FlatParams
+from .support import Config
+
+_ORDER = ["body.conv1.weight", "body.conv1.bias", "body.conv2.weight", "body.conv2.bias", "body.conv3.weight",
+          "body.conv3.bias", "body.fc4.weight", "body.fc4.bias", "fc_head.weight", "fc_head.bias"]
+
+
+class _DqnConfig(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_int32), ("n_actions", ctypes.c_int32), ("double_q", ctypes.c_int32),
+                ("ksplit", ctypes.c_int32), ("centered", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("gamma_n", ctypes.c_float), ("gradient_clip", ctypes.c_float), ("lr", ctypes.c_float),
+                ("alpha", ctypes.c_float), ("eps", ctypes.c_float), ("replay_eps", ctypes.c_float),
+                ("replay_alpha", ctypes.c_float), ("reserved1", ctypes.c_float), ("u8_coef", ctypes.c_double),
+                ("n_params", ctypes.c_int64), ("conv_end", ctypes.c_int64), ("ring_capacity", ctypes.c_int64),
+                ("offset", ctypes.c_int64 * 10)]
+
+
+def _ordered_params(net):
+    named = dict(net.named_parameters())
+    missing = [k for k in _ORDER if k not in named]
+    if missing or len(named) != len(_ORDER):
+        raise DraError("the fused learner supports VanillaNet(NatureConvBody); parameters found: %s" % sorted(named))
+    return [named[k] for k in _ORDER]
+
+
+class DQNLearner:
+    def __init__(self, network, target_network, ring, batch, n_actions, gamma_n, gradient_clip, lr, alpha, eps,
+                 centered=True, double_q=False, u8_coef=1.0 / 255, replay_eps=0.01, replay_alpha=0.5, ksplit=16):
+        self.network, self.target_network, self.ring = network, target_network, ring
+        self.flat = FlatParams(_ordered_params(network))           # conv segment first
+        self.target_flat = FlatParams(_ordered_params(target_network))
+        self.state1 = torch.zeros_like(self.flat.flat)
+        self.state2 = torch.zeros_like(self.flat.flat)
+        cfg = _DqnConfig()
+        cfg.batch, cfg.n_actions, cfg.double_q, cfg.ksplit, cfg.centered = batch, n_actions, int(double_q), ksplit, int(centered)
+        cfg.gamma_n, cfg.gradient_clip, cfg.lr, cfg.alpha, cfg.eps = gamma_n, gradient_clip or 0.0, lr, alpha, eps
+        cfg.replay_eps, cfg.replay_alpha, cfg.u8_coef = replay_eps, replay_alpha, u8_coef
+        cfg.n_params = self.flat.numel
+        cfg.conv_end = self.flat.offsets[6]                          # start of fc4.weight
+        cfg.ring_capacity = ring.capacity
+        for i, o in enumerate(self.flat.offsets):
+            cfg.offset[i] = o
+        self.cfg = cfg
+        self.batch, self.n_actions = batch, n_actions
+        h = ctypes.c_void_p()
+        lib.dra_dqn_learner_create(ctypes.byref(h), ring.h, ctypes.byref(cfg), ctypes.c_void_p(self.flat.flat.data_ptr()),
+                                   ctypes.c_void_p(self.target_flat.flat.data_ptr()),
+                                   ctypes.c_void_p(self.flat.grad.data_ptr()), ctypes.c_void_p(self.state1.data_ptr()),
+                                   ctypes.c_void_p(self.state2.data_ptr()))
+        self.h = h
+        ps = [ctypes.c_void_p() for _ in range(8)]
+        lib.dra_dqn_learner_buffers(h, *[ctypes.byref(p) for p in ps])
+        w = ops._wrap_device_pointer
+        self.idx = w(ps[0].value, batch, torch.int64)
+        self.sampling_prob = w(ps[1].value, batch, torch.float32)
+        self.loss = w(ps[2].value, 1, torch.float32)
+        self.norm = w(ps[3].value, 1, torch.float32)
+        self.q = w(ps[4].value, batch * n_actions, torch.float32).view(batch, n_actions)
+        self.delta = w(ps[5].value, batch, torch.float32)
+        self.prio = w(ps[6].value, batch, torch.float32)
+        self.actor_q = w(ps[7].value, n_actions, torch.float32)
+        self.stream = torch.cuda.Stream()                            # graphs cannot capture on the NULL stream
+        self._idx_pinned = [torch.empty(batch, dtype=torch.int64).pin_memory() for _ in range(8)]
+        self._idx_events = [None] * 8
+        self._k = 0
+
+    def close(self):
+        if self.h:
+            lib.dra_dqn_learner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _sp(self):
+        return ctypes.c_void_p(self.stream.cuda_stream)
+
+    def upload_indices(self, idx):
+        """numpy int64[batch] -> the learner's device idx buffer (async, pinned staging)."""
+        k = self._k
+        self._k = (k + 1) % len(self._idx_pinned)
+        if self._idx_events[k] is not None:
+            self._idx_events[k].synchronize()
+        self._idx_pinned[k].numpy()[:] = idx
+        with torch.cuda.stream(self.stream):
+            self.idx.copy_(self._idx_pinned[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._idx_events[k] = ev
+
+    def update(self, idx=None, use_graph=True, sampling_prob=None, beta=0.0):
+        if idx is not None:
+            self.upload_indices(idx)
+        per = sampling_prob is not None
+        if per:
+            with torch.cuda.stream(self.stream):
+                self.sampling_prob.copy_(sampling_prob, non_blocking=True)
+        lib.dra_dqn_learner_update(self.h, int(use_graph), int(per), float(beta), self._sp())
+
+    def act(self, newest_slot, epsilon, random_action, dice, store_slot, out_action=None):
+        lib.dra_dqn_learner_act(self.h, int(newest_slot), float(epsilon), int(random_action), float(dice), int(store_slot),
+                                None if out_action is None else ctypes.c_void_p(out_action.data_ptr()), self._sp())
+
+    def sync_target(self):
+        lib.dra_dqn_learner_sync_target(self.h, self._sp())
+
+    def profile(self):
+        """Per-kernel-group milliseconds of one eager update (HIP events on the launch stream)."""
+        n = 17
+        out = (ctypes.c_float * n)()
+        lib.dra_dqn_learner_profile(self.h, out, n, self._sp())
+        names = []
+        for k in range(n):
+            buf = ctypes.create_string_buffer(32)
+            lib.dra_dqn_learner_kernel_name(k, buf, 32)
+            names.append(buf.value.decode())
+        return dict(zip(names, [float(v) for v in out]))
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+
+def draw_uniform_indices(size, pos, batch, history, n_step):
+    """UniformReplay.sample's rejection loop (replay.py:92-110), vectorised without changing the
+    np.random stream: randint(0, size, size=k) yields the same values as k scalar draws, and each
+    block asks for exactly the number still missing, which the scalar loop would also draw."""
+    out = np.empty(batch, dtype=np.int64)
+    have = 0
+    while have < batch:
+        cand = np.random.randint(0, size, size=batch - have)
+        lo = cand - history + 1
+        hi = cand + n_step
+        ok = ((lo >= 0) & (hi < pos)) | ((lo >= pos) & (hi < size))
+        good = cand[ok]
+        out[have:have + len(good)] = good
+        have += len(good)
+    return out
+
+
+class DQNLearnerBench:
+    """BASELINE configs[1] on synthetic data: per step 4 env transitions (device frame source +
+    device actor), one reference-exact uniform minibatch draw, one fused update; target sync every
+    10 000 updates (examples.py:90)."""
+
+    def __init__(self, ring_capacity=1_000_000, batch=32, seed=0, actor=True, path="fused", n_actions=4,
+                 prefill=None):
+        from .nets import NatureConvBody, VanillaNet
+        dev = Config.DEVICE
+        if dev.type != "cuda":
+            raise DraError("DQNLearnerBench needs select_device(gpu_id >= 0)")
+        self.batch, self.capacity, self.seed, self.actor, self.path = batch, ring_capacity, seed, actor, path
+        self.history, self.n_step, self.n_actions = 4, 1, n_actions
+        self.ring = ops.Ring(ring_capacity, 7056, 8, self.history, self.n_step, 0.99)
+        self.network = VanillaNet(n_actions, NatureConvBody())
+        self.target_network = VanillaNet(n_actions, NatureConvBody())
+        self.target_network.load_state_dict(self.network.state_dict())
+        self.learner = DQNLearner(self.network, self.target_network, self.ring, batch, n_actions, 0.99, 5.0, 0.00025, 0.95,
+                                  0.01, centered=True)
+        # resident replay before the timed region: fill the whole ring (exploration phase done)
+        prefill = ring_capacity if prefill is None else prefill
+        with torch.cuda.stream(self.learner.stream):
+            self.ring.fill_synthetic(0, prefill, 0, seed, n_actions=n_actions, done_period=800)
+        self.counter = prefill
+        self.size = prefill
+        self.pos = prefill % ring_capacity
+        self.updates = 0
+        self.epsilon = 0.01
+        self.learner.synchronize()
+
+    def env_steps(self, n=4):
+        """n transitions: the synthetic env writes frame / reward / mask of slot `pos`; the actor
+        picks the action from the 4-frame stack ending there (host RNG order of epsilon_greedy)."""
+        L = self.learner
+        for _ in range(n):
+            slot = self.pos
+            with torch.cuda.stream(L.stream):
+                self.ring.fill_synthetic(slot, 1, self.counter, self.seed, n_actions=self.n_actions, done_period=800)
+            if self.actor:
+                random_action = int(np.random.randint(self.n_actions, size=1)[0])
+                dice = float(np.random.rand(1)[0])
+                L.act(slot, self.epsilon, random_action, dice, slot)
+            self.counter += 1
+            if self.size < self.capacity:
+                self.size += 1
+            self.pos = (slot + 1) % self.capacity
+
+    def step(self):
+        self.env_steps(4)
+        idx = draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step)
+        self.learner.update(idx, use_graph=True)
+        self.updates += 1
+        if self.updates % 10000 == 0:
+            self.learner.sync_target()
+
+    def roofline(self, n=200):
+        """Dominant kernel of the update, timed with HIP events on the learner's stream."""
+        L = self.learner
+        L.synchronize()
+        acc = {}
+        for _ in range(n):
+            L.upload_indices(draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step))
+            for k, v in L.profile().items():
+                acc[k] = acc.get(k, 0.0) + v
+        ms = {k: v / n for k, v in acc.items()}
+        self.kernel_ms = ms
+        b = self.batch
+        flops = {"conv1_fwd": 2 * 2 * b * 400 * 32 * 256, "conv2_fwd": 2 * 2 * b * 81 * 64 * 512,
+                 "conv3_fwd": 2 * 2 * b * 49 * 64 * 576, "fc4_fwd": 2 * 2 * b * 512 * 3136,
+                 "conv3_bwd_w": 2 * b * 49 * 64 * 576, "conv3_bwd_x": 2 * b * 49 * 64 * 576,
+                 "conv2_bwd_w": 2 * b * 81 * 64 * 512, "conv2_bwd_x": 2 * b * 81 * 64 * 512,
+                 "conv1_bwd_w": 2 * b * 400 * 32 * 256, "fc4_bwd_w": 2 * b * 512 * 3136, "fc4_bwd_x": 2 * b * 512 * 3136}
+        bytes_ = {"gather": b * (5 * 7056) + 2 * b * 4 * 7056, "rmsprop_step": 32 * L.flat.numel}
+        dom = max(ms, key=ms.get)
+        if dom in flops:
+            ach = flops[dom] / (ms[dom] * 1e-3) / 1e12
+            return {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
+                    "frac": ach / 157.3, "traffic": None, "avg_ms": ms[dom]}
+        byt = bytes_.get(dom, 0)
+        ach = byt / (ms[dom] * 1e-3) / 1e9
+        return {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                "traffic": None, "avg_ms": ms[dom]}
+
+    def report(self):
+        ms = getattr(self, "kernel_ms", {})
+        return {"kernel_ms": {k: round(v, 5) for k, v in ms.items()}, "update_kernel_ms_sum": round(sum(ms.values()), 5)}

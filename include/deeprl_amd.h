@@ -136,6 +136,34 @@ int dra_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   int64_t step, float* out_norm, void* stream);
 int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream); /* DQN_agent.py:136-138 */
 
+/* ---- fused DQN learner + device-resident actor: DQN_agent.py:24-45 (actor step), :114-138 (update) for
+ * VanillaNet(NatureConvBody).  All five flat buffers are caller-owned f32[n_params] with the tensor order
+ * conv1.w, conv1.b, conv2.w, conv2.b, conv3.w, conv3.b, fc4.w, fc4.b, head.w, head.b at `offset[]` (16-byte
+ * aligned); [0, conv_end) is the conv segment whose split-K slabs are folded in the norm pass. */
+typedef struct dra_dqn_config {
+  int32_t batch, n_actions, double_q, ksplit, centered, reserved0;
+  float gamma_n, gradient_clip, lr, alpha, eps, replay_eps, replay_alpha, reserved1;
+  double u8_coef;
+  int64_t n_params, conv_end, ring_capacity;
+  int64_t offset[10];
+} dra_dqn_config;
+typedef struct dra_dqn_learner dra_dqn_learner;
+int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const dra_dqn_config* cfg, float* params,
+                           float* target, float* grad, float* state1, float* state2);
+int dra_dqn_learner_destroy(dra_dqn_learner* learner);
+int dra_dqn_learner_buffers(dra_dqn_learner* learner, void** idx, void** sampling_prob, void** loss, void** norm,
+                            void** q, void** delta, void** prio, void** actor_q);
+/* one gradient update on the int64[batch] indices in the learner's idx buffer; use_graph replays a captured
+ * hipGraph (stream must not be the NULL stream); per != 0 adds the PER branch (DQN_agent.py:120-127). */
+int dra_dqn_learner_update(dra_dqn_learner* learner, int use_graph, int per, float beta, void* stream);
+int dra_dqn_learner_profile(dra_dqn_learner* learner, float* out_ms, int n_out, void* stream);
+int dra_dqn_learner_kernel_name(int k, char* out, int n);
+int dra_dqn_learner_sync_target(dra_dqn_learner* learner, void* stream); /* DQN_agent.py:136-138 */
+/* DQNActor._transition on device: stack the 4 frames ending at newest_slot, batch-1 forward, epsilon-greedy with
+ * host-drawn (random_action, dice) (torch_utils.py:51-58), action -> ring action record of store_slot. */
+int dra_dqn_learner_act(dra_dqn_learner* learner, int64_t newest_slot, float epsilon, int random_action, float dice,
+                        int64_t store_slot, int64_t* out_action_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

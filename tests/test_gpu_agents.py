@@ -225,3 +225,79 @@ def test_ppo_optimize_matches_reference(golden, dra, tag, monkeypatch):
     np.random.seed(21)
     agent.optimize(entries)
     _cmp_params(agent.network, g, k + "final_", 2e-5, 2e-6)
+
+
+@pytest.mark.parametrize("double_q", [False])
+def test_fused_learner_matches_oracle(dra, double_q):
+    """The captured-graph DQN learner (one C-ABI call per update, zero host round trips) against
+    the CPU oracle's full update on identical ring contents, indices and weights: 4 consecutive
+    updates (graph capture + 3 replays), B=32, then the device actor step."""
+    d = dra
+    from deeprl_amd.learner import DQNLearner, draw_uniform_indices
+    from oracle import loss_oracle as L, net_oracle as N, numerics_oracle as NUM
+    from oracle.replay_oracle import UniformReplayOracle
+    from oracle.synth_oracle import synth_transitions
+    cap, b, a = 6000, 32, 4
+    ring = d.ops.Ring(cap, 7056, 8, 4, 1, 0.99)
+    ring.fill_synthetic(0, cap, 0, 9, n_actions=a, done_period=40)
+    torch.cuda.synchronize()
+    frames, act, rew, msk = synth_transitions(0, cap, 7056, seed=9, n_actions=a, done_period=40)
+    orc = UniformReplayOracle(cap, b, 1, 0.99, 4)
+    for t in range(cap):
+        orc.feed_one(frames[t].reshape(84, 84), act[t], rew[t], msk[t])
+    net = d.VanillaNet(a, d.NatureConvBody())
+    tgt = d.VanillaNet(a, d.NatureConvBody())
+    p_np = fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(a), 21)
+    t_np = fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(a), 22)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
+    tgt.load_state_dict({k: torch.from_numpy(v) for k, v in t_np.items()})
+    learner = DQNLearner(net, tgt, ring, b, a, 0.99, 5.0, 0.00025, 0.95, 0.01, centered=True, double_q=double_q)
+    p = {k: torch.tensor(v, requires_grad=True) for k, v in p_np.items()}
+    pt = {k: torch.tensor(v) for k, v in t_np.items()}
+    names = list(p.keys())
+    sq = {k: torch.zeros_like(v) for k, v in p.items()}
+    ga = {k: torch.zeros_like(v) for k, v in p.items()}
+    np.random.seed(77)
+    for it in range(4):
+        idx = draw_uniform_indices(orc.size(), orc.pos, b, 4, 1)
+        st, ac, rw, ns, mk = orc.gather(idx)
+        x, xn = torch.from_numpy(NUM.image_normalize_sync(st)), torch.from_numpy(NUM.image_normalize_sync(ns))
+        q = N.vanilla_head(p, N.nature_conv_body(p, x))
+        with torch.no_grad():
+            qn = N.vanilla_head(pt, N.nature_conv_body(pt, xn))
+        delta = L.dqn_td_error(q, qn, torch.from_numpy(ac), torch.from_numpy(rw.astype(np.float32)),
+                               torch.from_numpy(mk.astype(np.float32)), 0.99)
+        loss = L.dqn_reduce(delta)
+        grads = torch.autograd.grad(loss, [p[k] for k in names])
+        norm, grads = N.clip_grad_norm(list(grads), 5)
+        learner.update(idx, use_graph=True)
+        learner.synchronize()
+        np.testing.assert_allclose(learner.q.cpu().numpy(), q.detach().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(learner.delta.cpu().numpy(), delta.detach().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(learner.loss.item(), loss.item(), rtol=2e-5)
+        np.testing.assert_allclose(learner.norm.item(), float(norm), rtol=5e-5)
+        with torch.no_grad():
+            for k, g in zip(names, grads):
+                newp, sq[k], ga[k] = N.rmsprop_step(p[k], g, sq[k], ga[k], 0.00025, 0.95, 0.01, True)
+                p[k].copy_(newp)
+    for k, v in net.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), p[k].detach().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    # eager (non-graph) path gives the same numbers as the replayed graph
+    learner.update(idx, use_graph=False)
+    learner.synchronize()
+    # device actor: stack ending at a slot that wraps the ring end, greedy and random branches
+    for newest, eps, rnd, dice in ((1, 0.5, 3, 0.9), (cap - 1, 0.5, 2, 0.1), (100, 0.0, 1, 0.0)):
+        out = torch.zeros(1, dtype=torch.int64, device=d.Config.DEVICE)
+        learner.act(newest, eps, rnd, dice, newest, out)
+        learner.synchronize()
+        slots = [(newest - 3 + j) % cap for j in range(4)]
+        xs = torch.from_numpy(NUM.image_normalize_sync(frames[slots].reshape(1, 4, 84, 84)))
+        pp = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        q1 = N.vanilla_head(pp, N.nature_conv_body(pp, xs)).numpy()[0]
+        np.testing.assert_allclose(learner.actor_q.cpu().numpy(), q1, rtol=1e-4, atol=1e-5)
+        want = rnd if dice < eps else int(np.argmax(q1))
+        assert int(out.item()) == want
+        stored = d.ops._wrap_device_pointer(ring.pointers()[1], cap, torch.int64)[newest].item()
+        assert stored == want
+    learner.close()
+    ring.close()
