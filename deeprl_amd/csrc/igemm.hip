@@ -69,15 +69,28 @@ __global__ void __launch_bounds__(256) igemm_kernel(const P p) {
   const int k_begin = blockIdx.y * cper * BK;
   const int k_end = min(K, k_begin + cper * BK);
 
+  // Operand fetch is split in two so that ALL global loads of a chunk issue back to back and stay
+  // in flight under the previous chunk's MFMAs:
+  //   fetch(): unconditional loads from clamped (always valid) addresses + a 2-bit code per
+  //            element (0 -> 0.0, 1 -> loaded value, 2 -> 1.0) kept in a bit mask;
+  //   stash(): the select happens here, behind an empty `asm volatile` that makes the loaded value
+  //            opaque -- otherwise LLVM sinks each load under its bounds condition and emits a
+  //            branch + s_waitcnt vmcnt(0) per element (serialised L2 round trips, 10x slower).
   float ra[RA], rb[RB];
+  unsigned ca = 0, cb = 0;
+  static_assert(RA <= 16 && RB <= 16, "2-bit codes live in one 32-bit mask per operand");
   auto fetch = [&](int k0) {
+    ca = 0; cb = 0;
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int e = tid + 256 * r;
       const int kk = P::A_KFAST ? (e % BK) : (e / BM);
       const int mm = P::A_KFAST ? (e / BK) : (e % BM);
       const int m = m0 + mm, k = k0 + kk;
-      ra[r] = (m < M && k < k_end) ? p.a(z, m, k) : 0.f;
+      int code = 1;
+      ra[r] = p.a(z, min(m, M - 1), min(k, K - 1), code);
+      code = (m < M && k < k_end) ? code : 0;
+      ca |= (unsigned)code << (2 * r);
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -85,7 +98,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(const P p) {
       const int kk = P::B_KFAST ? (e % BK) : (e / BN);
       const int nn = P::B_KFAST ? (e / BK) : (e % BN);
       const int n = n0 + nn, k = k0 + kk;
-      rb[r] = (n < N && k < k_end) ? p.b(z, k, n) : 0.f;
+      int code = 1;
+      rb[r] = p.b(z, min(k, K - 1), min(n, N - 1), code);
+      code = (n < N && k < k_end) ? code : 0;
+      cb |= (unsigned)code << (2 * r);
     }
   };
   auto stash = [&]() {
@@ -94,14 +110,21 @@ __global__ void __launch_bounds__(256) igemm_kernel(const P p) {
       const int e = tid + 256 * r;
       const int kk = P::A_KFAST ? (e % BK) : (e / BM);
       const int mm = P::A_KFAST ? (e / BK) : (e % BM);
-      As[kk * LDA + mm] = ra[r];
+      float v = ra[r];
+      asm volatile("" : "+v"(v));
+      const unsigned code = (ca >> (2 * r)) & 3u;
+      As[kk * LDA + mm] = code == 1u ? v : (code == 2u ? 1.f : 0.f);
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       const int e = tid + 256 * r;
       const int kk = P::B_KFAST ? (e % BK) : (e / BN);
       const int nn = P::B_KFAST ? (e / BK) : (e % BN);
-      Bs[kk * LDB + nn] = rb[r];
+      float v = rb[r];
+      asm volatile("" : "+v"(v));
+      v = p.fin_b(v);
+      const unsigned code = (cb >> (2 * r)) & 3u;
+      Bs[kk * LDB + nn] = code == 1u ? v : (code == 2u ? 1.f : 0.f);
     }
   };
 
@@ -156,10 +179,21 @@ __global__ void __launch_bounds__(256) igemm_kernel(const P p) {
       const int tile = tile0 + t;
       const int tm = tile / TN, tn = tile - tm * TN;
       const int n = n0 + tn * 32 + li;
+      // per-output side inputs (bias / activation-derivative source) are loaded for all 16 rows
+      // first, unconditionally from clamped addresses, so they overlap instead of serialising
+      // behind the bounds checks of the stores
+      float aux[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;  // 32x32 MFMA C/D row map
-        if (m < M && n < N) p.store(z, (int)blockIdx.y, m, n, acc[t][r]);
+        aux[r] = p.aux(z, min(m, M - 1), min(n, N - 1));
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(aux[r]));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m < M && n < N) p.store(z, (int)blockIdx.y, m, n, acc[t][r], aux[r]);
       }
     }
   }
@@ -191,37 +225,45 @@ struct ConvPtrs {
   float* y[kMaxZ];
 };
 
-template <class G>
-__device__ __forceinline__ float conv_in(const void* x, int u8, double coef, int bi, int c, int ih, int iw) {
+// Raw element fetch: f32 value, or (U8) the byte's integer bits parked in a float register so that
+// the f64 normalisation runs at LDS-stash time, off the load's critical path (see conv_fin).
+template <class G, bool U8>
+__device__ __forceinline__ float conv_in(const void* x, int bi, int c, int ih, int iw) {
   const int off = ((bi * G::C + c) * G::H + ih) * G::H + iw;
-  if (u8) return (float)((double)reinterpret_cast<const uint8_t*>(x)[off] * coef);
+  if (U8) return __uint_as_float((unsigned)reinterpret_cast<const uint8_t*>(x)[off]);
   return reinterpret_cast<const float*>(x)[off];
+}
+template <bool U8>
+__device__ __forceinline__ float conv_fin(float raw, double coef) {
+  return U8 ? (float)((double)__float_as_uint(raw) * coef) : raw;
 }
 
 // forward: Y[b][oc][p] = act(bias[oc] + sum_k W[oc][k] * Xcol[k][(b,p)])   M=OC, N=B*P, K=C*KH*KH
-template <class G, int BM_, int BN_, int BK_>
+template <class G, int BM_, int BN_, int BK_, bool U8>
 struct ConvFwd {
   static constexpr int BM = BM_, BN = BN_, BK = BK_;
   static constexpr bool A_KFAST = true, B_KFAST = false;
   int M, N, K;
   ConvPtrs q;
-  int u8, act;
+  int act;
   double coef;
-  __device__ __forceinline__ float a(int z, int m, int k) const { return q.w[z][m * G::K + k]; }
-  __device__ __forceinline__ float b(int z, int k, int n) const {
+  __device__ __forceinline__ float fin_b(float raw) const { return conv_fin<U8>(raw, coef); }
+  __device__ __forceinline__ float a(int z, int m, int k, int&) const { return q.w[z][m * G::K + k]; }
+  __device__ __forceinline__ float b(int z, int k, int n, int&) const {
     const int bi = n / G::P, pp = n - bi * G::P, oh = pp / G::OH, ow = pp - oh * G::OH;
     const int c = k / G::KK, kr = k - c * G::KK, kh = kr / G::KH, kw = kr - kh * G::KH;
-    return conv_in<G>(q.x[z], u8, coef, bi, c, oh * G::S + kh, ow * G::S + kw);
+    return conv_in<G, U8>(q.x[z], bi, c, oh * G::S + kh, ow * G::S + kw);
   }
-  __device__ __forceinline__ void store(int z, int, int m, int n, float v) const {
+  __device__ __forceinline__ float aux(int z, int m, int) const { return q.bias[z][m]; }
+  __device__ __forceinline__ void store(int z, int, int m, int n, float v, float bias) const {
     const int bi = n / G::P, pp = n - bi * G::P;
-    q.y[z][(bi * G::OC + m) * G::P + pp] = act_apply(v + q.bias[z][m], act);
+    q.y[z][(bi * G::OC + m) * G::P + pp] = act_apply(v + bias, act);
   }
 };
 
 // weight gradient: dW[oc][k] = sum_(b,p) dY[b][oc][p] * Xcol[k][(b,p)]; column k == K carries the
 // bias gradient (Xcol := 1).  M=OC, N=K+1, Kdim=B*P, split over gridDim.y into slabs.
-template <class G, int BM_, int BN_, int BK_>
+template <class G, int BM_, int BN_, int BK_, bool U8>
 struct ConvWgrad {
   static constexpr int BM = BM_, BN = BN_, BK = BK_;
   static constexpr bool A_KFAST = true, B_KFAST = false;
@@ -231,19 +273,21 @@ struct ConvWgrad {
   float* dw;         // slab 0 of the weight gradient  [OC][K]
   float* db;         // slab 0 of the bias gradient    [OC]
   int64_t slab_stride;
-  int u8;
   double coef;
-  __device__ __forceinline__ float a(int, int m, int k) const {
+  __device__ __forceinline__ float fin_b(float raw) const { return conv_fin<U8>(raw, coef); }
+  __device__ __forceinline__ float a(int, int m, int k, int&) const {
     const int bi = k / G::P, pp = k - bi * G::P;
     return dy[(bi * G::OC + m) * G::P + pp];
   }
-  __device__ __forceinline__ float b(int, int k, int n) const {
-    if (n == G::K) return 1.f;
+  __device__ __forceinline__ float b(int, int k, int n, int& code) const {
+    const int nc = min(n, G::K - 1);
     const int bi = k / G::P, pp = k - bi * G::P, oh = pp / G::OH, ow = pp - oh * G::OH;
-    const int c = n / G::KK, kr = n - c * G::KK, kh = kr / G::KH, kw = kr - kh * G::KH;
-    return conv_in<G>(x, u8, coef, bi, c, oh * G::S + kh, ow * G::S + kw);
+    const int c = nc / G::KK, kr = nc - c * G::KK, kh = kr / G::KH, kw = kr - kh * G::KH;
+    code = (n == G::K) ? 2 : 1;  // bias column: Xcol := 1
+    return conv_in<G, U8>(x, bi, c, oh * G::S + kh, ow * G::S + kw);
   }
-  __device__ __forceinline__ void store(int, int ks, int m, int n, float v) const {
+  __device__ __forceinline__ float aux(int, int, int) const { return 0.f; }
+  __device__ __forceinline__ void store(int, int ks, int m, int n, float v, float) const {
     if (n == G::K) db[ks * slab_stride + m] = v;
     else dw[ks * slab_stride + m * G::K + n] = v;
   }
@@ -256,6 +300,7 @@ struct ConvWgrad {
 // M=C, N=B*HP*HP (HP = ceil(H/S) positions per phase axis), Kdim=OC*KP*KP (KP = ceil(KH/S)).
 template <class G, int BM_, int BN_, int BK_>
 struct ConvDgrad {
+  __device__ __forceinline__ float fin_b(float raw) const { return raw; }
   static constexpr int BM = BM_, BN = BN_, BK = BK_;
   static constexpr bool A_KFAST = true, B_KFAST = false;
   static constexpr int HP = (G::H + G::S - 1) / G::S, KP = (G::KH + G::S - 1) / G::S, PP = HP * HP, KPP = KP * KP;
@@ -265,27 +310,40 @@ struct ConvDgrad {
   const float* xact;  // this layer's INPUT activations (post-activation output of the layer below)
   float* dx;          // [B][C][H][H] gradient w.r.t. the pre-activation of the layer below
   int act;
-  __device__ __forceinline__ float a(int z, int m, int k) const {
+  __device__ __forceinline__ float a(int z, int m, int k, int& code) const {
     const int ph = z / G::S, pw = z - ph * G::S;
     const int oc = k / KPP, kr = k - oc * KPP, kh2 = kr / KP, kw2 = kr - kh2 * KP;
     const int kh = kh2 * G::S + ph, kw = kw2 * G::S + pw;
-    if (kh >= G::KH || kw >= G::KH) return 0.f;
-    return w[((oc * G::C + m) * G::KH + kh) * G::KH + kw];
+    code = (kh >= G::KH || kw >= G::KH) ? 0 : 1;
+    return w[((oc * G::C + m) * G::KH + min(kh, G::KH - 1)) * G::KH + min(kw, G::KH - 1)];
   }
-  __device__ __forceinline__ float b(int z, int k, int n) const {
+  __device__ __forceinline__ float b(int z, int k, int n, int& code) const {
     const int bi = n / PP, pp = n - bi * PP, ih2 = pp / HP, iw2 = pp - ih2 * HP;
     const int oc = k / KPP, kr = k - oc * KPP, kh2 = kr / KP, kw2 = kr - kh2 * KP;
     const int oh = ih2 - kh2, ow = iw2 - kw2;
-    if (oh < 0 || ow < 0 || oh >= G::OH || ow >= G::OH) return 0.f;
-    return dy[((bi * G::OC + oc) * G::OH + oh) * G::OH + ow];
+    const int ohc = min(max(oh, 0), G::OH - 1), owc = min(max(ow, 0), G::OH - 1);
+    code = (oh < 0 || ow < 0 || oh >= G::OH || ow >= G::OH) ? 0 : 1;  // taps that fall outside the output
+    return dy[((bi * G::OC + oc) * G::OH + ohc) * G::OH + owc];
   }
-  __device__ __forceinline__ void store(int z, int, int m, int n, float v) const {
+  __device__ __forceinline__ int out_off(int z, int m, int n, bool& inside) const {
     const int ph = z / G::S, pw = z - ph * G::S;
     const int bi = n / PP, pp = n - bi * PP, ih2 = pp / HP, iw2 = pp - ih2 * HP;
     const int ih = ih2 * G::S + ph, iw = iw2 * G::S + pw;
-    if (ih >= G::H || iw >= G::H) return;
-    const int off = ((bi * G::C + m) * G::H + ih) * G::H + iw;
-    dx[off] = xact ? v * act_grad(xact[off], act) : v;
+    inside = ih < G::H && iw < G::H;
+    return ((bi * G::C + m) * G::H + min(ih, G::H - 1)) * G::H + min(iw, G::H - 1);
+  }
+  // raw activation value; a null xact reads dx instead (always mapped, value ignored) so the load
+  // stays branch-free -- the derivative itself is pure ALU work in store()
+  __device__ __forceinline__ float aux(int z, int m, int n) const {
+    bool inside;
+    const int off = out_off(z, m, n, inside);
+    const float* src = xact ? xact : dx;
+    return src[off];
+  }
+  __device__ __forceinline__ void store(int z, int, int m, int n, float v, float y) const {
+    bool inside;
+    const int off = out_off(z, m, n, inside);
+    if (inside) dx[off] = xact ? v * act_grad(y, act) : v;
   }
 };
 
@@ -293,13 +351,13 @@ using G1 = ConvGeom<4, 84, 32, 8, 4>;   // 84x84x4  -> 20x20x32
 using G2 = ConvGeom<32, 20, 64, 4, 2>;  // 20x20x32 -> 9x9x64
 using G3 = ConvGeom<64, 9, 64, 3, 1>;   // 9x9x64   -> 7x7x64
 
-template <class G, int BM, int BN, int BK>
+template <class G, int BM, int BN, int BK, bool U8>
 static int conv_fwd_t(int nz, const void* const* x, const float* const* w, const float* const* bias, float* const* y,
-                      int batch, int u8, double coef, int act, hipStream_t st) {
-  ConvFwd<G, BM, BN, BK> p;
+                      int batch, double coef, int act, hipStream_t st) {
+  ConvFwd<G, BM, BN, BK, U8> p;
   p.M = G::OC; p.N = batch * G::P; p.K = G::K;
   for (int z = 0; z < nz; ++z) { p.q.x[z] = x[z]; p.q.w[z] = w[z]; p.q.bias[z] = bias[z]; p.q.y[z] = y[z]; }
-  p.u8 = u8; p.act = act; p.coef = coef;
+  p.act = act; p.coef = coef;
   return launch_igemm(p, nz, 1, st);
 }
 
@@ -312,19 +370,21 @@ DRA_API int dra_conv_fwd(int layer, int nz, const void* const* x, const float* c
   for (int z = 0; z < nz; ++z) if (!x[z] || !w[z] || !bias[z] || !y[z]) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
   switch (layer) {
-    case 1: return conv_fwd_t<G1, 32, 64, 32>(nz, x, w, bias, y, batch, x_is_u8, u8_coef, act, st);
-    case 2: return x_is_u8 ? DRA_EINVAL : conv_fwd_t<G2, 32, 32, 64>(nz, x, w, bias, y, batch, 0, 1.0, act, st);
-    case 3: return x_is_u8 ? DRA_EINVAL : conv_fwd_t<G3, 32, 32, 64>(nz, x, w, bias, y, batch, 0, 1.0, act, st);
+    case 1:
+      return x_is_u8 ? conv_fwd_t<G1, 32, 64, 32, true>(nz, x, w, bias, y, batch, u8_coef, act, st)
+                     : conv_fwd_t<G1, 32, 64, 32, false>(nz, x, w, bias, y, batch, 1.0, act, st);
+    case 2: return x_is_u8 ? DRA_EINVAL : conv_fwd_t<G2, 32, 32, 64, false>(nz, x, w, bias, y, batch, 1.0, act, st);
+    case 3: return x_is_u8 ? DRA_EINVAL : conv_fwd_t<G3, 32, 32, 64, false>(nz, x, w, bias, y, batch, 1.0, act, st);
   }
   return DRA_EINVAL;
 }
 
-template <class G, int BM, int BN, int BK>
+template <class G, int BM, int BN, int BK, bool U8>
 static int conv_wgrad_t(const float* dy, const void* x, float* dw, float* db, int64_t slab_stride, int ksplit, int batch,
-                        int u8, double coef, hipStream_t st) {
-  ConvWgrad<G, BM, BN, BK> p;
+                        double coef, hipStream_t st) {
+  ConvWgrad<G, BM, BN, BK, U8> p;
   p.M = G::OC; p.N = G::K + 1; p.K = batch * G::P;
-  p.dy = dy; p.x = x; p.dw = dw; p.db = db; p.slab_stride = slab_stride; p.u8 = u8; p.coef = coef;
+  p.dy = dy; p.x = x; p.dw = dw; p.db = db; p.slab_stride = slab_stride; p.coef = coef;
   return launch_igemm(p, 1, ksplit, st);
 }
 
@@ -335,9 +395,11 @@ DRA_API int dra_conv_bwd_w(int layer, const float* dy, const void* x, float* dw,
   if (!dy || !x || !dw || !db || batch < 1 || ksplit < 1) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
   switch (layer) {
-    case 1: return conv_wgrad_t<G1, 32, 32, 64>(dy, x, dw, db, slab_stride, ksplit, batch, x_is_u8, u8_coef, st);
-    case 2: return x_is_u8 ? DRA_EINVAL : conv_wgrad_t<G2, 32, 32, 64>(dy, x, dw, db, slab_stride, ksplit, batch, 0, 1.0, st);
-    case 3: return x_is_u8 ? DRA_EINVAL : conv_wgrad_t<G3, 32, 32, 64>(dy, x, dw, db, slab_stride, ksplit, batch, 0, 1.0, st);
+    case 1:
+      return x_is_u8 ? conv_wgrad_t<G1, 32, 32, 64, true>(dy, x, dw, db, slab_stride, ksplit, batch, u8_coef, st)
+                     : conv_wgrad_t<G1, 32, 32, 64, false>(dy, x, dw, db, slab_stride, ksplit, batch, 1.0, st);
+    case 2: return x_is_u8 ? DRA_EINVAL : conv_wgrad_t<G2, 32, 32, 64, false>(dy, x, dw, db, slab_stride, ksplit, batch, 1.0, st);
+    case 3: return x_is_u8 ? DRA_EINVAL : conv_wgrad_t<G3, 32, 32, 64, false>(dy, x, dw, db, slab_stride, ksplit, batch, 1.0, st);
   }
   return DRA_EINVAL;
 }
@@ -377,17 +439,22 @@ struct LinPtrs {
 // partial sums go to slabs [z][ks][B][O] and dra_linear_fwd finishes with linear_finish_kernel.
 template <int BM_, int BN_, int BK_>
 struct LinFwd {
+  __device__ __forceinline__ float fin_b(float raw) const { return raw; }
   static constexpr int BM = BM_, BN = BN_, BK = BK_;
   static constexpr bool A_KFAST = true, B_KFAST = true;
   int M, N, K;
   LinPtrs q;
   float* slabs;
   int ksplit, act;
-  __device__ __forceinline__ float a(int z, int m, int k) const { return q.w[z][(int64_t)m * K + k]; }
-  __device__ __forceinline__ float b(int z, int k, int n) const { return q.x[z][(int64_t)n * K + k]; }
-  __device__ __forceinline__ void store(int z, int ks, int m, int n, float v) const {
+  __device__ __forceinline__ float a(int z, int m, int k, int&) const { return q.w[z][(int64_t)m * K + k]; }
+  __device__ __forceinline__ float b(int z, int k, int n, int&) const { return q.x[z][(int64_t)n * K + k]; }
+  __device__ __forceinline__ float aux(int z, int m, int) const {
+    const float* src = q.bias[z] ? q.bias[z] : q.w[z];  // null bias: any mapped address, value ignored
+    return src[m];
+  }
+  __device__ __forceinline__ void store(int z, int ks, int m, int n, float v, float bias) const {
     if (ksplit > 1) slabs[((int64_t)(z * ksplit + ks) * N + n) * M + m] = v;
-    else q.y[z][(int64_t)n * M + m] = act_apply(v + (q.bias[z] ? q.bias[z][m] : 0.f), act);
+    else q.y[z][(int64_t)n * M + m] = act_apply(q.bias[z] ? v + bias : v, act);
   }
 };
 
@@ -441,6 +508,7 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
 // weight gradient: dW[o][i] = sum_b dy[b][o] * x[b][i]; column i == I carries db.  M=O, N=I+1, K=B.
 template <int BM_, int BN_, int BK_>
 struct LinWgrad {
+  __device__ __forceinline__ float fin_b(float raw) const { return raw; }
   static constexpr int BM = BM_, BN = BN_, BK = BK_;
   static constexpr bool A_KFAST = false, B_KFAST = false;
   int M, N, K;
@@ -449,9 +517,13 @@ struct LinWgrad {
   const float* x;
   float* dw;
   float* db;
-  __device__ __forceinline__ float a(int, int m, int k) const { return dy[(int64_t)k * M + m]; }
-  __device__ __forceinline__ float b(int, int k, int n) const { return n == I ? 1.f : x[(int64_t)k * I + n]; }
-  __device__ __forceinline__ void store(int, int, int m, int n, float v) const {
+  __device__ __forceinline__ float a(int, int m, int k, int&) const { return dy[(int64_t)k * M + m]; }
+  __device__ __forceinline__ float b(int, int k, int n, int& code) const {
+    code = (n == I) ? 2 : 1;  // bias column
+    return x[(int64_t)k * I + min(n, I - 1)];
+  }
+  __device__ __forceinline__ float aux(int, int, int) const { return 0.f; }
+  __device__ __forceinline__ void store(int, int, int m, int n, float v, float) const {
     if (n == I) { if (db) db[m] = v; }
     else dw[(int64_t)m * I + n] = v;
   }
@@ -474,6 +546,7 @@ DRA_API int dra_linear_bwd_w(const float* dy, const float* x, float* dw, float* 
 // input gradient: dxpre[b][i] = act'(xact[b][i]) * sum_o dy[b][o] * W[o][i].  M=B, N=I, K=O.
 template <int BM_, int BN_, int BK_>
 struct LinDgrad {
+  __device__ __forceinline__ float fin_b(float raw) const { return raw; }
   static constexpr int BM = BM_, BN = BN_, BK = BK_;
   static constexpr bool A_KFAST = true, B_KFAST = false;
   int M, N, K;
@@ -482,11 +555,14 @@ struct LinDgrad {
   const float* xact;
   float* dx;
   int act;
-  __device__ __forceinline__ float a(int, int m, int k) const { return dy[(int64_t)m * K + k]; }
-  __device__ __forceinline__ float b(int, int k, int n) const { return w[(int64_t)k * N + n]; }
-  __device__ __forceinline__ void store(int, int, int m, int n, float v) const {
-    const int64_t off = (int64_t)m * N + n;
-    dx[off] = xact ? v * act_grad(xact[off], act) : v;
+  __device__ __forceinline__ float a(int, int m, int k, int&) const { return dy[(int64_t)m * K + k]; }
+  __device__ __forceinline__ float b(int, int k, int n, int&) const { return w[(int64_t)k * N + n]; }
+  __device__ __forceinline__ float aux(int, int m, int n) const {
+    const float* src = xact ? xact : dx;
+    return src[(int64_t)m * N + n];
+  }
+  __device__ __forceinline__ void store(int, int, int m, int n, float v, float y) const {
+    dx[(int64_t)m * N + n] = xact ? v * act_grad(y, act) : v;
   }
 };
 
