@@ -426,6 +426,136 @@ DRA_API int dra_conv_bwd_x(int layer, const float* dy, const float* w, const flo
   return DRA_EINVAL;
 }
 
+
+// ---- KOC weight layout ([K=(c,kh,kw)][OC], see conv_v2.hip): gradients and input gradients for the
+// fused learner, whose flat parameter buffer keeps the conv weights in that layout.
+// weight gradient, KOC: dWt[k][oc] = sum_(b,p) Xcol[k][(b,p)] * dY[b][oc][p]; row k == K carries db.
+// M = K+1, N = OC, Kdim = B*P: the 32 MFMA lanes run along oc, so slab stores are coalesced.
+template <class G, int BM_, int BN_, int BK_, bool U8>
+struct ConvWgradKoc {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_;
+  static constexpr bool A_KFAST = true, B_KFAST = true;
+  int M, N, K;
+  const float* dy;
+  const void* x;
+  float* dw;
+  float* db;
+  int64_t slab_stride;
+  double coef;
+  __device__ __forceinline__ float fin_b(float raw) const { return raw; }
+  __device__ __forceinline__ float a(int, int m, int k, int& code) const {
+    const int mc = min(m, G::K - 1);
+    const int bi = k / G::P, pp = k - bi * G::P, oh = pp / G::OH, ow = pp - oh * G::OH;
+    const int c = mc / G::KK, kr = mc - c * G::KK, kh = kr / G::KH, kw = kr - kh * G::KH;
+    code = (m == G::K) ? 2 : 1;
+    // the uint8 normalisation is applied here (A operand has no stash-time hook): still one load
+    const float raw = conv_in<G, U8>(x, bi, c, oh * G::S + kh, ow * G::S + kw);
+    return conv_fin<U8>(raw, coef);
+  }
+  __device__ __forceinline__ float b(int, int k, int n, int&) const {
+    const int bi = k / G::P, pp = k - bi * G::P;
+    return dy[(bi * G::OC + n) * G::P + pp];
+  }
+  __device__ __forceinline__ float aux(int, int, int) const { return 0.f; }
+  __device__ __forceinline__ void store(int, int ks, int m, int n, float v, float) const {
+    if (m == G::K) db[ks * slab_stride + n] = v;
+    else dw[ks * slab_stride + m * G::OC + n] = v;
+  }
+};
+
+// input gradient, KOC weights: the reduction index is ordered (kh2, kw2, oc) with oc fastest so that
+// consecutive k read consecutive weights.
+template <class G, int BM_, int BN_, int BK_>
+struct ConvDgradKoc {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_;
+  static constexpr bool A_KFAST = true, B_KFAST = false;
+  static constexpr int HP = (G::H + G::S - 1) / G::S, KP = (G::KH + G::S - 1) / G::S, PP = HP * HP, KPP = KP * KP;
+  int M, N, K;
+  const float* dy;
+  const float* wt;    // [K][OC]
+  const float* xact;
+  float* dx;
+  int act;
+  __device__ __forceinline__ float fin_b(float raw) const { return raw; }
+  __device__ __forceinline__ float a(int z, int m, int k, int& code) const {
+    const int ph = z / G::S, pw = z - ph * G::S;
+    const int tap = k / G::OC, oc = k - tap * G::OC, kh2 = tap / KP, kw2 = tap - kh2 * KP;
+    const int kh = kh2 * G::S + ph, kw = kw2 * G::S + pw;
+    code = (kh >= G::KH || kw >= G::KH) ? 0 : 1;
+    return wt[((m * G::KH + min(kh, G::KH - 1)) * G::KH + min(kw, G::KH - 1)) * G::OC + oc];
+  }
+  __device__ __forceinline__ float b(int z, int k, int n, int& code) const {
+    const int bi = n / PP, pp = n - bi * PP, ih2 = pp / HP, iw2 = pp - ih2 * HP;
+    const int tap = k / G::OC, oc = k - tap * G::OC, kh2 = tap / KP, kw2 = tap - kh2 * KP;
+    const int oh = ih2 - kh2, ow = iw2 - kw2;
+    const int ohc = min(max(oh, 0), G::OH - 1), owc = min(max(ow, 0), G::OH - 1);
+    code = (oh < 0 || ow < 0 || oh >= G::OH || ow >= G::OH) ? 0 : 1;
+    return dy[((bi * G::OC + oc) * G::OH + ohc) * G::OH + owc];
+  }
+  __device__ __forceinline__ int out_off(int z, int m, int n, bool& inside) const {
+    const int ph = z / G::S, pw = z - ph * G::S;
+    const int bi = n / PP, pp = n - bi * PP, ih2 = pp / HP, iw2 = pp - ih2 * HP;
+    const int ih = ih2 * G::S + ph, iw = iw2 * G::S + pw;
+    inside = ih < G::H && iw < G::H;
+    return ((bi * G::C + m) * G::H + min(ih, G::H - 1)) * G::H + min(iw, G::H - 1);
+  }
+  __device__ __forceinline__ float aux(int z, int m, int n) const {
+    bool inside;
+    const int off = out_off(z, m, n, inside);
+    const float* src = xact ? xact : dx;
+    return src[off];
+  }
+  __device__ __forceinline__ void store(int z, int, int m, int n, float v, float y) const {
+    bool inside;
+    const int off = out_off(z, m, n, inside);
+    if (inside) dx[off] = xact ? v * act_grad(y, act) : v;
+  }
+};
+
+template <class G, int BM, int BN, int BK, bool U8>
+static int conv_wgrad_koc_t(const float* dy, const void* x, float* dw, float* db, int64_t slab_stride, int ksplit,
+                            int batch, double coef, hipStream_t st) {
+  ConvWgradKoc<G, BM, BN, BK, U8> p;
+  p.M = G::K + 1; p.N = G::OC; p.K = batch * G::P;
+  p.dy = dy; p.x = x; p.dw = dw; p.db = db; p.slab_stride = slab_stride; p.coef = coef;
+  return launch_igemm(p, 1, ksplit, st);
+}
+
+DRA_API int dra_conv_bwd_w_koc(int layer, const float* dy, const void* x, float* dw, float* db, int64_t slab_stride,
+                               int ksplit, int batch, int x_is_u8, double u8_coef, void* stream) {
+  if (!dy || !x || !dw || !db || batch < 1 || ksplit < 1) return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  switch (layer) {
+    case 1:
+      return x_is_u8 ? conv_wgrad_koc_t<G1, 32, 32, 64, true>(dy, x, dw, db, slab_stride, ksplit, batch, u8_coef, st)
+                     : conv_wgrad_koc_t<G1, 32, 32, 64, false>(dy, x, dw, db, slab_stride, ksplit, batch, 1.0, st);
+    case 2: return x_is_u8 ? DRA_EINVAL : conv_wgrad_koc_t<G2, 32, 32, 64, false>(dy, x, dw, db, slab_stride, ksplit, batch, 1.0, st);
+    case 3: return x_is_u8 ? DRA_EINVAL : conv_wgrad_koc_t<G3, 32, 32, 64, false>(dy, x, dw, db, slab_stride, ksplit, batch, 1.0, st);
+  }
+  return DRA_EINVAL;
+}
+
+template <class G, int BM, int BN, int BK>
+static int conv_dgrad_koc_t(const float* dy, const float* wt, const float* xact, float* dx, int batch, int act,
+                            hipStream_t st) {
+  using PT = ConvDgradKoc<G, BM, BN, BK>;
+  PT p;
+  p.M = G::C; p.N = batch * PT::PP; p.K = G::OC * PT::KPP;
+  p.dy = dy; p.wt = wt; p.xact = xact; p.dx = dx; p.act = act;
+  return launch_igemm(p, G::S * G::S, 1, st);
+}
+
+DRA_API int dra_conv_bwd_x_koc(int layer, const float* dy, const float* wt, const float* xact, float* dx, int batch,
+                               int act, void* stream) {
+  if (!dy || !wt || !dx || batch < 1) return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  switch (layer) {
+    case 2: return conv_dgrad_koc_t<G2, 32, 32, 64>(dy, wt, xact, dx, batch, act, st);
+    case 3: return conv_dgrad_koc_t<G3, 32, 32, 64>(dy, wt, xact, dx, batch, act, st);
+  }
+  return DRA_EINVAL;
+}
+
 // =============================================================================================
 // Linear layers  y[b][o] = act(bias[o] + sum_i x[b][i] * W[o][i])   (runtime sizes)
 struct LinPtrs {

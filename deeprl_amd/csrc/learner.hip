@@ -20,7 +20,8 @@ static const char* kKernelNames[K_COUNT] = {
   "gather", "conv1_fwd", "conv2_fwd", "conv3_fwd", "fc4_fwd", "head_fwd", "td_loss", "head_bwd", "fc4_bwd_w", "fc4_bwd_x",
   "conv3_bwd_w", "conv3_bwd_x", "conv2_bwd_w", "conv2_bwd_x", "conv1_bwd_w", "grad_norm", "rmsprop_step"};
 
-// parameter tensor order inside the flat buffers (conv segment first, 16-byte aligned offsets)
+// parameter tensor order inside the flat buffers (conv segment first, 16-byte aligned offsets);
+// the three conv weights are stored in the KOC layout [(c,kh,kw)][oc] (conv_v2.hip)
 enum { P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WH, P_BH, P_COUNT };
 
 struct dra_dqn_learner {
@@ -146,15 +147,15 @@ static int run_update(dra_dqn_learner* l, hipStream_t st, int per, float beta) {
   const void* x1[3] = {l->state, l->next_state, l->next_state};
   const float* w1[3] = {P + o[P_W1], T + o[P_W1], P + o[P_W1]};
   const float* b1[3] = {P + o[P_B1], T + o[P_B1], P + o[P_B1]};
-  STEP(K_CONV1_F, dra_conv_fwd(1, nz, x1, w1, b1, l->y1, B, 1, c.u8_coef, DRA_ACT_RELU, s));
+  STEP(K_CONV1_F, dra_conv_fwd_koc(1, nz, x1, w1, b1, l->y1, B, 1, c.u8_coef, DRA_ACT_RELU, s));
   const void* x2[3] = {l->y1[0], l->y1[1], l->y1[2]};
   const float* w2[3] = {P + o[P_W2], T + o[P_W2], P + o[P_W2]};
   const float* b2[3] = {P + o[P_B2], T + o[P_B2], P + o[P_B2]};
-  STEP(K_CONV2_F, dra_conv_fwd(2, nz, x2, w2, b2, l->y2, B, 0, 1.0, DRA_ACT_RELU, s));
+  STEP(K_CONV2_F, dra_conv_fwd_koc(2, nz, x2, w2, b2, l->y2, B, 0, 1.0, DRA_ACT_RELU, s));
   const void* x3[3] = {l->y2[0], l->y2[1], l->y2[2]};
   const float* w3[3] = {P + o[P_W3], T + o[P_W3], P + o[P_W3]};
   const float* b3[3] = {P + o[P_B3], T + o[P_B3], P + o[P_B3]};
-  STEP(K_CONV3_F, dra_conv_fwd(3, nz, x3, w3, b3, l->y3, B, 0, 1.0, DRA_ACT_RELU, s));
+  STEP(K_CONV3_F, dra_conv_fwd_koc(3, nz, x3, w3, b3, l->y3, B, 0, 1.0, DRA_ACT_RELU, s));
   const float* x4[3] = {l->y3[0], l->y3[1], l->y3[2]};
   const float* w4[3] = {P + o[P_W4], T + o[P_W4], P + o[P_W4]};
   const float* b4[3] = {P + o[P_B4], T + o[P_B4], P + o[P_B4]};
@@ -172,11 +173,11 @@ static int run_update(dra_dqn_learner* l, hipStream_t st, int per, float beta) {
   STEP(K_FC4_BW, dra_linear_bwd_w(l->dh4, l->y3[0], G + o[P_W4], G + o[P_B4], B, 3136, 512, s));
   STEP(K_FC4_BX, dra_linear_bwd_x(l->dh4, P + o[P_W4], l->y3[0], l->dy3, B, 3136, 512, DRA_ACT_RELU, s));
   float* S = l->slabs;
-  STEP(K_CONV3_BW, dra_conv_bwd_w(3, l->dy3, l->y2[0], S + o[P_W3], S + o[P_B3], l->slab_stride, c.ksplit, B, 0, 1.0, s));
-  STEP(K_CONV3_BX, dra_conv_bwd_x(3, l->dy3, P + o[P_W3], l->y2[0], l->dy2, B, DRA_ACT_RELU, s));
-  STEP(K_CONV2_BW, dra_conv_bwd_w(2, l->dy2, l->y1[0], S + o[P_W2], S + o[P_B2], l->slab_stride, c.ksplit, B, 0, 1.0, s));
-  STEP(K_CONV2_BX, dra_conv_bwd_x(2, l->dy2, P + o[P_W2], l->y1[0], l->dy1, B, DRA_ACT_RELU, s));
-  STEP(K_CONV1_BW, dra_conv_bwd_w(1, l->dy1, l->state, S + o[P_W1], S + o[P_B1], l->slab_stride, c.ksplit, B, 1, c.u8_coef, s));
+  STEP(K_CONV3_BW, dra_conv_bwd_w_koc(3, l->dy3, l->y2[0], S + o[P_W3], S + o[P_B3], l->slab_stride, c.ksplit, B, 0, 1.0, s));
+  STEP(K_CONV3_BX, dra_conv_bwd_x_koc(3, l->dy3, P + o[P_W3], l->y2[0], l->dy2, B, DRA_ACT_RELU, s));
+  STEP(K_CONV2_BW, dra_conv_bwd_w_koc(2, l->dy2, l->y1[0], S + o[P_W2], S + o[P_B2], l->slab_stride, c.ksplit, B, 0, 1.0, s));
+  STEP(K_CONV2_BX, dra_conv_bwd_x_koc(2, l->dy2, P + o[P_W2], l->y1[0], l->dy1, B, DRA_ACT_RELU, s));
+  STEP(K_CONV1_BW, dra_conv_bwd_w_koc(1, l->dy1, l->state, S + o[P_W1], S + o[P_B1], l->slab_stride, c.ksplit, B, 1, c.u8_coef, s));
   const int np = dra_norm_partials();
   STEP(K_NORM, dra_grad_sqnorm(G, c.conv_end, S, c.ksplit, l->slab_stride, l->partials, s));  // folds the conv slabs
   STEP(K_NORM, dra_grad_sqnorm(G + c.conv_end, c.n_params - c.conv_end, nullptr, 0, 0, l->partials + np, s));
@@ -288,13 +289,13 @@ DRA_API int dra_dqn_learner_act(dra_dqn_learner* l, int64_t newest_slot, float e
   void* s = (void*)st;
   const void* x1[1] = {l->act_state}; const float* w1[1] = {P + o[P_W1]}; const float* b1[1] = {P + o[P_B1]};
   float* y1[1] = {l->ay1};
-  if ((rc = dra_conv_fwd(1, 1, x1, w1, b1, y1, 1, 1, c.u8_coef, DRA_ACT_RELU, s))) return rc;
+  if ((rc = dra_conv_fwd_koc(1, 1, x1, w1, b1, y1, 1, 1, c.u8_coef, DRA_ACT_RELU, s))) return rc;
   const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
   float* y2[1] = {l->ay2};
-  if ((rc = dra_conv_fwd(2, 1, x2, w2, b2, y2, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+  if ((rc = dra_conv_fwd_koc(2, 1, x2, w2, b2, y2, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
   const void* x3[1] = {l->ay2}; const float* w3[1] = {P + o[P_W3]}; const float* b3[1] = {P + o[P_B3]};
   float* y3[1] = {l->ay3};
-  if ((rc = dra_conv_fwd(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+  if ((rc = dra_conv_fwd_koc(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
   const float* x4[1] = {l->ay3}; const float* w4[1] = {P + o[P_W4]}; const float* b4[1] = {P + o[P_B4]};
   float* h4[1] = {l->ah4};
   if ((rc = dra_linear_fwd(1, x4, w4, b4, h4, 1, 3136, 512, DRA_ACT_RELU, l->lin_ws, l->lin_ws_floats, s))) return rc;

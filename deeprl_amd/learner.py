@@ -44,8 +44,9 @@ class DQNLearner:
     def __init__(self, network, target_network, ring, batch, n_actions, gamma_n, gradient_clip, lr, alpha, eps,
                  centered=True, double_q=False, u8_coef=1.0 / 255, replay_eps=0.01, replay_alpha=0.5, ksplit=16):
         self.network, self.target_network, self.ring = network, target_network, ring
-        self.flat = FlatParams(_ordered_params(network))           # conv segment first
-        self.target_flat = FlatParams(_ordered_params(target_network))
+        po, pt = _ordered_params(network), _ordered_params(target_network)
+        self.flat = FlatParams(po, koc=(po[0], po[2], po[4]))        # conv segment first, conv weights in KOC
+        self.target_flat = FlatParams(pt, koc=(pt[0], pt[2], pt[4]))
         self.state1 = torch.zeros_like(self.flat.flat)
         self.state2 = torch.zeros_like(self.flat.flat)
         cfg = _DqnConfig()

@@ -334,6 +334,52 @@ def conv_bwd_w(layer, dy, x, ksplit=16, u8_coef=None, slabs=None):
     return v[:, :oc * kk], v[:, oc * kk:oc * kk + oc]
 
 
+def to_koc(w):
+    """[OC,C,KH,KW] -> the [K=(c,kh,kw)][OC] layout of conv_v2.hip (a torch copy; test / glue helper)."""
+    return w.permute(1, 2, 3, 0).contiguous().view(-1, w.shape[0])
+
+
+def from_koc(wt, shape):
+    oc, c, kh, kw = shape
+    return wt.view(c, kh, kw, oc).permute(3, 0, 1, 2).contiguous()
+
+
+def conv_fwd_koc(layer, xs, wts, bs, act="relu", u8_coef=None):
+    nz = len(xs)
+    c, h, oc, k, s = _CONV_GEOM[layer]
+    batch = xs[0].shape[0]
+    is_u8 = xs[0].dtype == torch.uint8
+    xs = [_c(x, torch.uint8 if is_u8 else _f32) for x in xs]
+    wts = [_c(w, _f32) for w in wts]
+    bs = [_c(b, _f32) for b in bs]
+    ys = [torch.empty(conv_out_shape(layer, batch), dtype=_f32, device=xs[0].device) for _ in range(nz)]
+    lib.dra_conv_fwd_koc(layer, nz, ptr_array(xs), ptr_array(wts), ptr_array(bs), ptr_array(ys), batch, int(is_u8),
+                         float(u8_coef if is_u8 else 1.0), ACT[act], stream_ptr())
+    return ys
+
+
+def conv_bwd_w_koc(layer, dy, x, ksplit=16, u8_coef=None):
+    """Returns (dwt_slabs [ksplit, K*OC] in KOC layout, db_slabs [ksplit, OC])."""
+    c, h, oc, k, s = _CONV_GEOM[layer]
+    kk = c * k * k
+    is_u8 = x.dtype == torch.uint8
+    stride = (oc * kk + oc + 3) // 4 * 4
+    slabs = torch.empty(ksplit * stride, dtype=_f32, device=x.device)
+    lib.dra_conv_bwd_w_koc(layer, ptr(_c(dy, _f32)), ptr(_c(x)), ptr(slabs), ctypes.c_void_p(slabs.data_ptr() + 4 * oc * kk),
+                           stride, ksplit, x.shape[0], int(is_u8), float(u8_coef if is_u8 else 1.0), stream_ptr())
+    v = slabs.view(ksplit, stride)
+    return v[:, :oc * kk], v[:, oc * kk:oc * kk + oc]
+
+
+def conv_bwd_x_koc(layer, dy, wt, xact=None, act="relu"):
+    c, h, oc, k, s = _CONV_GEOM[layer]
+    batch = dy.shape[0]
+    dx = torch.empty((batch, c, h, h), dtype=_f32, device=dy.device)
+    lib.dra_conv_bwd_x_koc(layer, ptr(_c(dy, _f32)), ptr(_c(wt, _f32)), ptr(None if xact is None else _c(xact, _f32)),
+                           ptr(dx), batch, ACT[act], stream_ptr())
+    return dx
+
+
 def conv_bwd_x(layer, dy, w, xact=None, act="relu"):
     """Gradient w.r.t. the layer's input; with `xact` (the layer-below's activated output) the
     activation derivative of that layer is folded in (gradient w.r.t. its PRE-activation)."""

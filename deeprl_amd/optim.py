@@ -16,7 +16,10 @@ class FlatParams:
     """Re-homes parameters into one contiguous fp32 buffer (each tensor 16-byte aligned) and gives
     every parameter a .grad view into a matching flat gradient buffer."""
 
-    def __init__(self, params, align=4):
+    def __init__(self, params, align=4, koc=()):
+        """`koc`: parameters (4-D conv weights [OC,C,KH,KW]) to store in the [(c,kh,kw)][oc] layout
+        the one-round-trip conv kernels read; the module keeps seeing a [OC,C,KH,KW] (strided) view."""
+        koc_ids = {id(p) for p in koc}
         self.params = []
         seen = set()
         for p in params:
@@ -38,9 +41,15 @@ class FlatParams:
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         for p, o in zip(self.params, self.offsets):
             n = p.numel()
-            self.flat[o:o + n].copy_(p.data.reshape(-1))
-            p.data = self.flat[o:o + n].view(p.shape)
-            p.grad = self.grad[o:o + n].view(p.shape)
+            if id(p) in koc_ids:
+                oc, c, kh, kw = p.shape
+                self.flat[o:o + n].copy_(p.data.permute(1, 2, 3, 0).reshape(-1))
+                p.data = self.flat[o:o + n].view(c, kh, kw, oc).permute(3, 0, 1, 2)
+                p.grad = self.grad[o:o + n].view(c, kh, kw, oc).permute(3, 0, 1, 2)
+            else:
+                self.flat[o:o + n].copy_(p.data.reshape(-1))
+                p.data = self.flat[o:o + n].view(p.shape)
+                p.grad = self.grad[o:o + n].view(p.shape)
 
     def zero_grad(self):
         self.grad.zero_()

@@ -115,6 +115,14 @@ int dra_conv_bwd_w(int layer, const float* dy, const void* x, float* dw, float* 
                    int batch, int x_is_u8, double u8_coef, void* stream);
 int dra_conv_bwd_x(int layer, const float* dy, const float* w, const float* xact, float* dx, int batch, int act,
                    void* stream);
+/* KOC weight layout ([K=(c,kh,kw)][OC]; conv_v2.hip): one-round-trip forward, and the matching gradients. */
+int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const float* const* wt, const float* const* bias,
+                     float* const* y, int batch, int x_is_u8, double u8_coef, int act, void* stream);
+int dra_conv_bwd_w_koc(int layer, const float* dy, const void* x, float* dw, float* db, int64_t slab_stride, int ksplit,
+                       int batch, int x_is_u8, double u8_coef, void* stream);
+int dra_conv_bwd_x_koc(int layer, const float* dy, const float* wt, const float* xact, float* dx, int batch, int act,
+                       void* stream);
+int dra_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 int dra_act_bwd(const float* dy, const float* y, float* dpre, int64_t n, int act, void* stream);
 int dra_linear_fwd(int nz, const float* const* x, const float* const* w, const float* const* bias, float* const* y,
                    int batch, int in_features, int out_features, int act, float* workspace, int64_t workspace_floats,

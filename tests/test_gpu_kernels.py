@@ -466,3 +466,47 @@ def test_mfma_layout_transpose_detecting(dev):
     w = (np.arange(n * n, dtype=np.float32).reshape(n, n) / 7.0)  # w[o][i] asymmetric
     y = ops.linear_fwd([f32(x, dev)], [f32(w, dev)], [None], act=None)[0]
     assert np.array_equal(y.cpu().numpy(), w.T)
+
+
+@pytest.mark.parametrize("layer", [1, 2, 3])
+@pytest.mark.parametrize("batch", [32, 1, 5])
+def test_conv_koc_fwd_bwd_vs_oracle(dev, layer, batch):
+    """One-round-trip forward (conv_v2.hip) and the KOC-layout weight / input gradients."""
+    import torch.nn.functional as F
+    from deeprl_amd import ops
+    c, h, oc, k, s = CONV[layer]
+    rs = np.random.RandomState(100 * layer + batch)
+    ws = [(rs.standard_normal((oc, c, k, k)) / np.sqrt(c * k * k)).astype(np.float32) for _ in range(3)]
+    bs = [(rs.standard_normal(oc) * 0.1).astype(np.float32) for _ in range(3)]
+    wts = [ops.to_koc(f32(w, dev)) for w in ws]
+    if layer == 1:
+        xs_u8 = [rs.randint(0, 256, size=(batch, c, h, h)).astype(np.uint8) for _ in range(3)]
+        xs = [NUM.image_normalize_sync(x) for x in xs_u8]
+        ys = ops.conv_fwd_koc(1, [cu(x, dev) for x in xs_u8], wts, [f32(b, dev) for b in bs], u8_coef=1.0 / 255)
+        ys_f = ops.conv_fwd_koc(1, [f32(x, dev) for x in xs], wts, [f32(b, dev) for b in bs])
+        for a_, b_ in zip(ys, ys_f):
+            assert torch.equal(a_, b_)  # u8 path normalises bit-exactly, so both inputs agree to the bit
+    else:
+        xs = [np.maximum(rs.standard_normal((batch, c, h, h)), 0).astype(np.float32) for _ in range(3)]
+        ys = ops.conv_fwd_koc(layer, [f32(x, dev) for x in xs], wts, [f32(b, dev) for b in bs])
+    refs = []
+    for z in range(3):
+        xt = torch.tensor(xs[z], requires_grad=True)
+        wt, bt = torch.tensor(ws[z], requires_grad=True), torch.tensor(bs[z], requires_grad=True)
+        yt = F.relu(F.conv2d(xt, wt, bt, stride=s))
+        refs.append((xt, wt, bt, yt))
+        _scale_close(ys[z].cpu().numpy(), yt.detach().numpy())
+    xt, wt, bt, yt = refs[2]
+    dy = rs.standard_normal(tuple(yt.shape)).astype(np.float32)
+    yt.backward(torch.tensor(dy))
+    dpre = ops.act_bwd(f32(dy, dev), ys[2], "relu")
+    x_dev = cu(xs_u8[2], dev) if layer == 1 else f32(xs[2], dev)
+    dw_s, db_s = ops.conv_bwd_w_koc(layer, dpre, x_dev, ksplit=16, u8_coef=1.0 / 255 if layer == 1 else None)
+    dw = ops.from_koc(dw_s.sum(0).contiguous(), (oc, c, k, k))
+    _scale_close(dw.cpu().numpy(), wt.grad.numpy())
+    _scale_close(db_s.sum(0).cpu().numpy(), bt.grad.numpy())
+    if layer > 1:
+        dx = ops.conv_bwd_x_koc(layer, dpre, wts[2])
+        _scale_close(dx.cpu().numpy(), xt.grad.numpy())
+        dxm = ops.conv_bwd_x_koc(layer, dpre, wts[2], xact=f32(xs[2], dev), act="relu")
+        _scale_close(dxm.cpu().numpy(), xt.grad.numpy() * (xs[2] > 0))
