@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--ring", type=int, default=1_000_000, help="replay capacity in frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-actor", action="store_true", help="skip actor inference (then env_steps is null)")
-    ap.add_argument("--path", default="fused", choices=["fused", "generic"])
+    ap.add_argument("--sync-actor", action="store_true",
+                    help="in-order actor (async_actor=False); default is the reference's dqn_pixel setting async_actor=True")
     return ap.parse_args()
 
 
@@ -116,7 +117,8 @@ def main():
     d.select_device(local_rank)
     torch.manual_seed(1234 + rank)
     np.random.seed(rank)
-    bench = DQNLearnerBench(ring_capacity=args.ring, batch=B, seed=rank, actor=not args.no_actor, path=args.path)
+    bench = DQNLearnerBench(ring_capacity=args.ring, batch=B, seed=rank, actor=not args.no_actor,
+                            async_actor=not args.sync_actor)
     for _ in range(args.warmup):
         bench.step()
     torch.cuda.synchronize()
@@ -145,8 +147,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DQN Breakout 84x84x4 uint8, NatureConvBody, batch 32, %d-frame HBM replay ring, "
                                    "centered RMSprop, clip 5 (BASELINE configs[1])" % args.ring,
-                       "global_batch": B * world, "parallelism": "replicas x%d" % world, "path": args.path,
-                       "actor_in_step": not args.no_actor},
+                       "global_batch": B * world, "parallelism": "replicas x%d" % world,
+                       "actor_in_step": not args.no_actor, "async_actor": not args.sync_actor},
             "env_steps_per_sec": (4 * ups) if not args.no_actor else None,
             "roofline": roof,
         }

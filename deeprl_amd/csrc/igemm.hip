@@ -635,6 +635,20 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
   return DRA_OK;
 }
 
+DRA_API int dra_linear_fwd_slabs(int nz, const float* const* x, const float* const* w, int batch, int in_features,
+                                 int out_features, int ksplit, float* slabs, void* stream) {
+  if (nz < 1 || nz > kMaxZ || batch < 1 || in_features < 1 || out_features < 1 || ksplit < 2 || !x || !w || !slabs)
+    return DRA_EINVAL;
+  LinFwd<32, 32, 64> p;
+  p.M = out_features; p.N = batch; p.K = in_features;
+  for (int z = 0; z < nz; ++z) {
+    if (!x[z] || !w[z]) return DRA_EINVAL;
+    p.q.x[z] = x[z]; p.q.w[z] = w[z]; p.q.bias[z] = nullptr; p.q.y[z] = nullptr;
+  }
+  p.slabs = slabs; p.ksplit = ksplit; p.act = ACT_NONE;
+  return launch_igemm(p, nz, ksplit, dra_stream(stream));
+}
+
 // weight gradient: dW[o][i] = sum_b dy[b][o] * x[b][i]; column i == I carries db.  M=O, N=I+1, K=B.
 template <int BM_, int BN_, int BK_>
 struct LinWgrad {

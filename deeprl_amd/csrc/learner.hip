@@ -1,28 +1,43 @@
-// Fused DQN learner: one C-ABI call per gradient update / per environment step.
-// Replaces the body of deep_rl/agent/DQN_agent.py:114-138 (sample -> compute_loss -> backward ->
-// clip -> optimizer.step -> target sync) and the per-step inference of DQNActor._transition
+// Fused DQN learner + device-resident actor: one C-ABI call per agent step.
+// Replaces deep_rl/agent/DQN_agent.py:101-138 (DQNAgent.step: actor transitions, replay feed,
+// sample, compute_loss, backward, clip, optimizer.step, target sync) and DQNActor._transition
 // (DQN_agent.py:24-45) for VanillaNet(NatureConvBody).
 //
-// MI355X design: the reference issues ~640 ATen ops per update; here the update is a fixed chain
-// of ~20 hand-written kernels over persistent HBM workspaces, captured ONCE into a hipGraph and
-// replayed -- launch-bound inner loops belong in graphs (no tracing compiler involved).  Online
-// (states) and target (next_states) forwards share launches (blockIdx.z), split-K slabs of the
-// conv weight gradients are folded inside the gradient-norm pass, and nothing returns to the host:
-// the only per-update host->device traffic is the 256-byte index vector.
+// MI355X design (the reference issues ~640 ATen ops per update plus 4 batch-1 forwards with a
+// device->host sync each, spread over three processes):
+//   * the update is a fixed chain of hand-written kernels over persistent HBM workspaces, captured
+//     ONCE into a hipGraph and replayed; online(states) / target(next_states) forwards share
+//     launches (blockIdx.z); weight- and input-gradient kernels of a layer run on forked graph
+//     branches; split-K slabs of the conv weight gradients are folded inside the norm pass;
+//   * fc4's split-K reduction, bias, ReLU, both heads, the TD error, dL/dq and dL/dh4 are ONE kernel;
+//   * the actor's env steps are a second captured graph whose kernels read their per-step
+//     arguments (slot, epsilon, host-drawn random action / dice) from a device parameter block,
+//     so a whole agent step costs two small async memcpys and three graph/kernel launches and
+//     never synchronises with the host;
+//   * async mode runs the actor graph of step t+1 on its own stream under the update of step t.
+//     The reference's process-level overlap (BaseActor, async_actor=True) and its config.lock
+//     around optimizer.step() / the actor's forward (DQN_agent.py:30,133) become HIP events: the
+//     optimizer kernel is the only section exclusive with the actor's weight reads, and the
+//     actor's ring writes wait for the update's gather.
 #include "common.h"
 #include <new>
+#include <stddef.h>
 #include <string.h>
 
-enum { K_GATHER, K_CONV1_F, K_CONV2_F, K_CONV3_F, K_FC4_F, K_HEAD_F, K_LOSS, K_HEAD_B, K_FC4_BW, K_FC4_BX, K_CONV3_BW,
-       K_CONV3_BX, K_CONV2_BW, K_CONV2_BX, K_CONV1_BW, K_NORM, K_STEP, K_COUNT };
+enum { K_GATHER, K_CONV1_F, K_CONV2_F, K_CONV3_F, K_FC4_F, K_HEAD, K_HEAD_BW, K_FC4_BW, K_FC4_BX, K_CONV3_BW, K_CONV3_BX,
+       K_CONV2_BW, K_CONV2_BX, K_CONV1_BW, K_NORM, K_STEP, K_COUNT };
 
 static const char* kKernelNames[K_COUNT] = {
-  "gather", "conv1_fwd", "conv2_fwd", "conv3_fwd", "fc4_fwd", "head_fwd", "td_loss", "head_bwd", "fc4_bwd_w", "fc4_bwd_x",
+  "gather", "conv1_fwd", "conv2_fwd", "conv3_fwd", "fc4_fwd", "head_loss", "head_bwd_w", "fc4_bwd_w", "fc4_bwd_x",
   "conv3_bwd_w", "conv3_bwd_x", "conv2_bwd_w", "conv2_bwd_x", "conv1_bwd_w", "grad_norm", "rmsprop_step"};
 
 // parameter tensor order inside the flat buffers (conv segment first, 16-byte aligned offsets);
 // the three conv weights are stored in the KOC layout [(c,kh,kw)][oc] (conv_v2.hip)
 enum { P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WH, P_BH, P_COUNT };
+
+constexpr int kFc4Split = 8;     // split-K of the 3136 -> 512 layer (slabs reduced inside head_fused_kernel)
+constexpr int kMaxEnvSteps = 8;  // env transitions per agent step (sgd_update_frequency)
+constexpr size_t kPrmHeadBytes = offsetof(dra_dqn_step_params, idx);  // the part the actor kernels read
 
 struct dra_dqn_learner {
   dra_dqn_config c;
@@ -32,15 +47,26 @@ struct dra_dqn_learner {
   uint8_t *state, *next_state, *act_state;
   int64_t *action, *idx;
   float *reward, *mask;
-  float *y1[3], *y2[3], *y3[3], *h4[3], *q[3];
-  float *ay1, *ay2, *ay3, *ah4, *aq;  // actor (batch 1)
+  float *y1[3], *y2[3], *y3[3], *h4, *q[3];
+  float *ay1, *ay2, *ay3, *aq;  // actor (batch 1)
   float *dq, *dh4, *dy3, *dy2, *dy1, *delta, *prio, *weights, *samp_prob;
-  float *slabs, *lin_ws;
+  float *slabs, *fc4_slabs, *afc4_slabs, *lin_ws;
   int64_t lin_ws_floats, slab_stride;
   double* partials;
   float *loss, *norm;
-  hipGraphExec_t graph;
-  bool graph_ready;
+  dra_dqn_step_params* prm_dev;     // device copy read by the actor kernels
+  dra_dqn_step_params* prm_stage;   // pinned staging ring
+  int64_t* idx_stage;               // pinned staging ring for the minibatch indices
+  int stage_k;
+  hipEvent_t stage_ev[8];
+  bool stage_used[8];
+  hipGraphExec_t g_update, g_actor;
+  bool g_update_ready, g_actor_ready;
+  int g_actor_n;
+  hipStream_t side;                 // fork stream for graph branches
+  hipEvent_t ev_fork, ev_join[4];
+  hipEvent_t ev_actor_done, ev_gather_done, ev_step_done;
+  bool actor_pending;               // async mode: an actor graph has been issued and not yet consumed
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
 };
@@ -50,7 +76,9 @@ static int alloc_f(float** p, int64_t n) { return (int)hipMalloc(p, (size_t)n * 
 DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const dra_dqn_config* cfg, float* params,
                                    float* target, float* grad, float* state1, float* state2) {
   if (!out || !ring || !cfg || !params || !target || !grad || !state1 || !state2) return DRA_EINVAL;
-  if (cfg->batch < 1 || cfg->batch > 1024 || cfg->n_actions < 1 || cfg->ksplit < 1 || cfg->ksplit > 64) return DRA_EINVAL;
+  if (cfg->batch < 1 || cfg->batch > 1024 || cfg->n_actions < 1 || cfg->n_actions > 64 || cfg->ksplit < 1 ||
+      cfg->ksplit > 64)
+    return DRA_EINVAL;
   dra_dqn_learner* l = new (std::nothrow) dra_dqn_learner();
   if (!l) return DRA_ENOMEM;
   memset(l, 0, sizeof(*l));
@@ -66,26 +94,39 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= alloc_f(&l->reward, B); rc |= alloc_f(&l->mask, B);
   for (int z = 0; z < nz; ++z) {
     rc |= alloc_f(&l->y1[z], (int64_t)B * 32 * 400); rc |= alloc_f(&l->y2[z], (int64_t)B * 64 * 81);
-    rc |= alloc_f(&l->y3[z], (int64_t)B * 64 * 49); rc |= alloc_f(&l->h4[z], (int64_t)B * 512);
-    rc |= alloc_f(&l->q[z], (int64_t)B * A);
+    rc |= alloc_f(&l->y3[z], (int64_t)B * 64 * 49); rc |= alloc_f(&l->q[z], (int64_t)B * A);
   }
+  rc |= alloc_f(&l->h4, (int64_t)B * 512);
   rc |= alloc_f(&l->ay1, 32 * 400); rc |= alloc_f(&l->ay2, 64 * 81); rc |= alloc_f(&l->ay3, 64 * 49);
-  rc |= alloc_f(&l->ah4, 512); rc |= alloc_f(&l->aq, A);
+  rc |= alloc_f(&l->aq, A);
   rc |= alloc_f(&l->dq, (int64_t)B * A); rc |= alloc_f(&l->dh4, (int64_t)B * 512);
   rc |= alloc_f(&l->dy3, (int64_t)B * 64 * 49); rc |= alloc_f(&l->dy2, (int64_t)B * 64 * 81);
   rc |= alloc_f(&l->dy1, (int64_t)B * 32 * 400);
   rc |= alloc_f(&l->delta, B); rc |= alloc_f(&l->prio, B); rc |= alloc_f(&l->weights, B); rc |= alloc_f(&l->samp_prob, B);
   l->slab_stride = cfg->conv_end;  // conv segment occupies [0, conv_end) of the flat layout
   rc |= alloc_f(&l->slabs, (int64_t)cfg->ksplit * l->slab_stride);
+  rc |= alloc_f(&l->fc4_slabs, (int64_t)3 * kFc4Split * B * 512);
+  rc |= alloc_f(&l->afc4_slabs, (int64_t)kFc4Split * 512);
   l->lin_ws_floats = (int64_t)3 * 32 * B * 512;
   rc |= alloc_f(&l->lin_ws, l->lin_ws_floats);
   rc |= (int)hipMalloc(&l->partials, (size_t)2 * dra_norm_partials() * sizeof(double));
   rc |= alloc_f(&l->loss, 1); rc |= alloc_f(&l->norm, 1);
+  rc |= (int)hipMalloc(&l->prm_dev, sizeof(dra_dqn_step_params));
+  rc |= (int)hipHostMalloc(&l->prm_stage, 8 * sizeof(dra_dqn_step_params), hipHostMallocDefault);
+  rc |= (int)hipHostMalloc(&l->idx_stage, (size_t)8 * 1024 * sizeof(int64_t), hipHostMallocDefault);
   if (rc) { delete l; return rc; }
   // slab gaps (alignment padding between tensors) are never written: keep them zero
   rc |= (int)hipMemset(l->slabs, 0, (size_t)cfg->ksplit * l->slab_stride * sizeof(float));
   rc |= (int)hipMemset(l->partials, 0, (size_t)2 * dra_norm_partials() * sizeof(double));
+  rc |= (int)hipMemset(l->prm_dev, 0, sizeof(dra_dqn_step_params));
   for (int k = 0; k <= K_COUNT; ++k) rc |= (int)hipEventCreate(&l->ev[k]);
+  for (int k = 0; k < 8; ++k) rc |= (int)hipEventCreateWithFlags(&l->stage_ev[k], hipEventDisableTiming);
+  rc |= (int)hipStreamCreateWithFlags(&l->side, hipStreamNonBlocking);
+  rc |= (int)hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming);
+  for (int k = 0; k < 4; ++k) rc |= (int)hipEventCreateWithFlags(&l->ev_join[k], hipEventDisableTiming);
+  rc |= (int)hipEventCreateWithFlags(&l->ev_actor_done, hipEventDisableTiming);
+  rc |= (int)hipEventCreateWithFlags(&l->ev_gather_done, hipEventDisableTiming);
+  rc |= (int)hipEventCreateWithFlags(&l->ev_step_done, hipEventDisableTiming);
   if (rc) { delete l; return rc; }
   *out = l;
   return DRA_OK;
@@ -93,19 +134,27 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
 
 DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (!l) return DRA_OK;
-  if (l->graph_ready) (void)hipGraphExecDestroy(l->graph);
-  void* bufs[] = {l->state, l->next_state, l->act_state, l->action, l->idx, l->reward, l->mask, l->ay1, l->ay2, l->ay3,
-                  l->ah4, l->aq, l->dq, l->dh4, l->dy3, l->dy2, l->dy1, l->delta, l->prio, l->weights, l->samp_prob,
-                  l->slabs, l->lin_ws, l->partials, l->loss, l->norm};
+  (void)hipDeviceSynchronize();
+  if (l->g_update_ready) (void)hipGraphExecDestroy(l->g_update);
+  if (l->g_actor_ready) (void)hipGraphExecDestroy(l->g_actor);
+  void* bufs[] = {l->state, l->next_state, l->act_state, l->action, l->idx, l->reward, l->mask, l->h4, l->ay1, l->ay2,
+                  l->ay3, l->aq, l->dq, l->dh4, l->dy3, l->dy2, l->dy1, l->delta, l->prio, l->weights, l->samp_prob,
+                  l->slabs, l->fc4_slabs, l->afc4_slabs, l->lin_ws, l->partials, l->loss, l->norm, l->prm_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (int z = 0; z < 3; ++z) {
     if (l->y1[z]) (void)hipFree(l->y1[z]);
     if (l->y2[z]) (void)hipFree(l->y2[z]);
     if (l->y3[z]) (void)hipFree(l->y3[z]);
-    if (l->h4[z]) (void)hipFree(l->h4[z]);
     if (l->q[z]) (void)hipFree(l->q[z]);
   }
+  (void)hipHostFree(l->prm_stage);
+  (void)hipHostFree(l->idx_stage);
   for (int k = 0; k <= K_COUNT; ++k) (void)hipEventDestroy(l->ev[k]);
+  for (int k = 0; k < 8; ++k) (void)hipEventDestroy(l->stage_ev[k]);
+  (void)hipStreamDestroy(l->side);
+  (void)hipEventDestroy(l->ev_fork);
+  for (int k = 0; k < 4; ++k) (void)hipEventDestroy(l->ev_join[k]);
+  (void)hipEventDestroy(l->ev_actor_done); (void)hipEventDestroy(l->ev_gather_done); (void)hipEventDestroy(l->ev_step_done);
   delete l;
   return DRA_OK;
 }
@@ -126,6 +175,99 @@ DRA_API int dra_dqn_learner_buffers(dra_dqn_learner* l, void** idx, void** sampl
   return DRA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// head_fused_kernel: one workgroup per sample.
+//   h4[z][b][:] = relu(b4_z + sum_s fc4_slab[z][s][b][:])          (split-K reduction of fc4, all nets)
+//   q[z][b][a]  = bh_z[a] + <h4[z][b], Wh_z[a]>                     (VanillaNet head, network_heads.py:18-21)
+//   delta_b     = (r + (g*qnext)*m) - q[0][b][a_b]                  (DQN_agent.py:85-99; uniform replay)
+//   dq[b][:]    = -delta_b / B at a_b, 0 elsewhere                  (d mean(0.5 delta^2) / dq)
+//   dh4[b][k]   = dq[b][a_b] * Wh_0[a_b][k] * (h4[0][b][k] > 0)     (gradient w.r.t. fc4's pre-activation)
+// Per-sample work only: the batch-mean loss is recovered from `delta` on demand, and the PER
+// variant (needs max over the batch) keeps the separate td_loss kernel.
+__global__ void __launch_bounds__(256)
+head_fused_kernel(const float* __restrict__ slabs, int nz, int ks, int B, int A, const float* __restrict__ b4_on,
+                  const float* __restrict__ b4_tg, const float* __restrict__ wh_on, const float* __restrict__ wh_tg,
+                  const float* __restrict__ bh_on, const float* __restrict__ bh_tg, const int64_t* __restrict__ action,
+                  const float* __restrict__ reward, const float* __restrict__ mask, float gamma_n, int double_q,
+                  float* __restrict__ h4_out, float* __restrict__ q_on, float* __restrict__ q_tg, float* __restrict__ q_on2,
+                  float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dh4) {
+  __shared__ float s_h[3][512];
+  __shared__ float s_q[3][64];
+  __shared__ float s_red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int z = 0; z < nz; ++z) {
+    const float* bias = (z == 1) ? b4_tg : b4_on;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int k = tid + 256 * rep;
+      const float* s = slabs + ((int64_t)z * ks * B + b) * 512 + k;
+      float v = s[0];
+      for (int i = 1; i < ks; ++i) v += s[(int64_t)i * B * 512];
+      v += bias[k];
+      v = v > 0.f ? v : 0.f;
+      s_h[z][k] = v;
+      if (z == 0) h4_out[(int64_t)b * 512 + k] = v;
+    }
+  }
+  __syncthreads();
+  for (int z = 0; z < nz; ++z) {
+    const float* wh = (z == 1) ? wh_tg : wh_on;
+    const float* bh = (z == 1) ? bh_tg : bh_on;
+    for (int a = 0; a < A; ++a) {
+      float part = s_h[z][tid] * wh[a * 512 + tid] + s_h[z][tid + 256] * wh[a * 512 + tid + 256];
+      part = wave_sum(part);
+      if ((tid & 63) == 0) s_red[tid >> 6] = part;
+      __syncthreads();
+      if (tid == 0) s_q[z][a] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + bh[a];
+      __syncthreads();
+    }
+  }
+  const int64_t ab = action[b];
+  float dqa;
+  {
+    float qn;
+    if (double_q) {
+      int best = 0;
+      float bv = s_q[2][0];
+      for (int k = 1; k < A; ++k) if (s_q[2][k] > bv) { bv = s_q[2][k]; best = k; }
+      qn = s_q[1][best];
+    } else {
+      qn = s_q[1][0];
+      for (int k = 1; k < A; ++k) qn = fmaxf(qn, s_q[1][k]);
+    }
+    const float target = reward[b] + (gamma_n * qn) * mask[b];
+    const float d = target - s_q[0][ab];
+    dqa = -d / (float)B;
+    if (tid == 0) delta[b] = d;
+  }
+  if (tid < A) {
+    q_on[(int64_t)b * A + tid] = s_q[0][tid];
+    q_tg[(int64_t)b * A + tid] = s_q[1][tid];
+    if (nz > 2) q_on2[(int64_t)b * A + tid] = s_q[2][tid];
+    dq[(int64_t)b * A + tid] = (tid == ab) ? dqa : 0.f;
+  }
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int k = tid + 256 * rep;
+    dh4[(int64_t)b * 512 + k] = s_h[0][k] > 0.f ? dqa * wh_on[ab * 512 + k] : 0.f;
+  }
+}
+
+// dWh[a][k] = sum_b dq[b][a] * h4[b][k] ;  dbh[a] = sum_b dq[b][a]      (grid = A, 512 threads)
+__global__ void __launch_bounds__(512)
+head_wgrad_kernel(const float* __restrict__ dq, const float* __restrict__ h4, int B, int A, float* __restrict__ dwh,
+                  float* __restrict__ dbh) {
+  const int a = blockIdx.x, k = threadIdx.x;
+  float acc = 0.f, accb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float d = dq[(int64_t)b * A + a];
+    acc += d * h4[(int64_t)b * 512 + k];
+    accb += d;
+  }
+  dwh[a * 512 + k] = acc;
+  if (k == 0) dbh[a] = accb;
+}
+
 #define STEP(kid, expr)                                                        \
   do {                                                                         \
     if (l->profiling) DRA_HIP(hipEventRecord(l->ev[kid], st));                 \
@@ -133,7 +275,21 @@ DRA_API int dra_dqn_learner_buffers(dra_dqn_learner* l, void** idx, void** sampl
     if (_rc != DRA_OK) return _rc;                                             \
   } while (0)
 
-static int run_update(dra_dqn_learner* l, hipStream_t st, int per, float beta) {
+static int launch_gather(dra_dqn_learner* l, hipStream_t st) {
+  return dra_ring_gather(l->ring, l->idx, l->c.batch, l->state, l->next_state, l->action, nullptr, nullptr, l->reward,
+                         l->mask, (void*)st);
+}
+
+static int launch_optimizer(dra_dqn_learner* l, hipStream_t st) {
+  const dra_dqn_config& c = l->c;
+  return dra_rmsprop_step(l->p, l->g, l->s1, l->s2, c.n_params, l->partials, 2 * dra_norm_partials(), c.gradient_clip,
+                          c.lr, c.alpha, c.eps, c.centered, l->norm, (void*)st);
+}
+
+// forward + loss + backward + gradient norm (everything between the gather and the optimizer).
+// `fork` != 0 places each layer's weight-gradient kernel on the side stream (captured as a parallel
+// graph branch) while the input-gradient chain continues on `st`.
+static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int fork) {
   const dra_dqn_config& c = l->c;
   const int B = c.batch, A = c.n_actions;
   const int nz = c.double_q ? 3 : 2;
@@ -141,8 +297,6 @@ static int run_update(dra_dqn_learner* l, hipStream_t st, int per, float beta) {
   const float* P = l->p;
   const float* T = l->pt;
   const int64_t* o = c.offset;
-  STEP(K_GATHER, dra_ring_gather(l->ring, l->idx, B, l->state, l->next_state, l->action, nullptr, nullptr, l->reward,
-                                 l->mask, s));
   // z = 0: online(states)   z = 1: target(next_states)   z = 2: online(next_states) [double-Q]
   const void* x1[3] = {l->state, l->next_state, l->next_state};
   const float* w1[3] = {P + o[P_W1], T + o[P_W1], P + o[P_W1]};
@@ -158,56 +312,75 @@ static int run_update(dra_dqn_learner* l, hipStream_t st, int per, float beta) {
   STEP(K_CONV3_F, dra_conv_fwd_koc(3, nz, x3, w3, b3, l->y3, B, 0, 1.0, DRA_ACT_RELU, s));
   const float* x4[3] = {l->y3[0], l->y3[1], l->y3[2]};
   const float* w4[3] = {P + o[P_W4], T + o[P_W4], P + o[P_W4]};
-  const float* b4[3] = {P + o[P_B4], T + o[P_B4], P + o[P_B4]};
-  STEP(K_FC4_F, dra_linear_fwd(nz, x4, w4, b4, l->h4, B, 3136, 512, DRA_ACT_RELU, l->lin_ws, l->lin_ws_floats, s));
-  const float* xh[3] = {l->h4[0], l->h4[1], l->h4[2]};
-  const float* wh[3] = {P + o[P_WH], T + o[P_WH], P + o[P_WH]};
-  const float* bh[3] = {P + o[P_BH], T + o[P_BH], P + o[P_BH]};
-  STEP(K_HEAD_F, dra_linear_fwd(nz, xh, wh, bh, l->q, B, 512, A, DRA_ACT_NONE, l->lin_ws, l->lin_ws_floats, s));
-  STEP(K_LOSS, dra_td_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action, 1, l->reward, l->mask, B, A,
-                           c.gamma_n, per ? l->samp_prob : nullptr, beta, c.replay_eps, c.replay_alpha, l->loss, l->dq,
-                           l->delta, per ? l->prio : nullptr, per ? l->weights : nullptr, s));
+  STEP(K_FC4_F, dra_linear_fwd_slabs(nz, x4, w4, B, 3136, 512, kFc4Split, l->fc4_slabs, s));
+  if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_HEAD], st));
+  hipLaunchKernelGGL(head_fused_kernel, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, kFc4Split, B, A,
+                     P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
+                     (const int64_t*)l->action, (const float*)l->reward, (const float*)l->mask, c.gamma_n, c.double_q,
+                     l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4);
+  DRA_LAUNCH_CHECK();
+  if (per) {  // PER needs the batch-wide max of the importance weights: separate kernel recomputes dq, then dh4
+    int rc = dra_td_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action, 1, l->reward, l->mask, B, A, c.gamma_n,
+                         l->samp_prob, beta, c.replay_eps, c.replay_alpha, l->loss, l->dq, l->delta, l->prio, l->weights, s);
+    if (rc) return rc;
+    rc = dra_linear_bwd_x(l->dq, P + o[P_WH], l->h4, l->dh4, B, 512, A, DRA_ACT_RELU, s);
+    if (rc) return rc;
+  }
   float* G = l->g;
-  STEP(K_HEAD_B, dra_linear_bwd_w(l->dq, l->h4[0], G + o[P_WH], G + o[P_BH], B, 512, A, s));
-  STEP(K_HEAD_B, dra_linear_bwd_x(l->dq, P + o[P_WH], l->h4[0], l->dh4, B, 512, A, DRA_ACT_RELU, s));
-  STEP(K_FC4_BW, dra_linear_bwd_w(l->dh4, l->y3[0], G + o[P_W4], G + o[P_B4], B, 3136, 512, s));
-  STEP(K_FC4_BX, dra_linear_bwd_x(l->dh4, P + o[P_W4], l->y3[0], l->dy3, B, 3136, 512, DRA_ACT_RELU, s));
   float* S = l->slabs;
-  STEP(K_CONV3_BW, dra_conv_bwd_w_koc(3, l->dy3, l->y2[0], S + o[P_W3], S + o[P_B3], l->slab_stride, c.ksplit, B, 0, 1.0, s));
+  hipStream_t sd = fork ? l->side : st;
+  void* sds = (void*)sd;
+  if (fork) { DRA_HIP(hipEventRecord(l->ev_fork, st)); DRA_HIP(hipStreamWaitEvent(sd, l->ev_fork, 0)); }
+  // side branch: head and fc4 weight gradients need only dq / dh4 / stored activations
+  if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_HEAD_BW], st));
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(A), dim3(512), 0, sd, (const float*)l->dq, (const float*)l->h4, B, A,
+                     G + o[P_WH], G + o[P_BH]);
+  DRA_LAUNCH_CHECK();
+  STEP(K_FC4_BW, dra_linear_bwd_w(l->dh4, l->y3[0], G + o[P_W4], G + o[P_B4], B, 3136, 512, sds));
+  STEP(K_FC4_BX, dra_linear_bwd_x(l->dh4, P + o[P_W4], l->y3[0], l->dy3, B, 3136, 512, DRA_ACT_RELU, s));
+  if (fork) { DRA_HIP(hipEventRecord(l->ev_join[0], st)); DRA_HIP(hipStreamWaitEvent(sd, l->ev_join[0], 0)); }
+  STEP(K_CONV3_BW, dra_conv_bwd_w_koc(3, l->dy3, l->y2[0], S + o[P_W3], S + o[P_B3], l->slab_stride, c.ksplit, B, 0, 1.0, sds));
   STEP(K_CONV3_BX, dra_conv_bwd_x_koc(3, l->dy3, P + o[P_W3], l->y2[0], l->dy2, B, DRA_ACT_RELU, s));
-  STEP(K_CONV2_BW, dra_conv_bwd_w_koc(2, l->dy2, l->y1[0], S + o[P_W2], S + o[P_B2], l->slab_stride, c.ksplit, B, 0, 1.0, s));
+  if (fork) { DRA_HIP(hipEventRecord(l->ev_join[1], st)); DRA_HIP(hipStreamWaitEvent(sd, l->ev_join[1], 0)); }
+  STEP(K_CONV2_BW, dra_conv_bwd_w_koc(2, l->dy2, l->y1[0], S + o[P_W2], S + o[P_B2], l->slab_stride, c.ksplit, B, 0, 1.0, sds));
   STEP(K_CONV2_BX, dra_conv_bwd_x_koc(2, l->dy2, P + o[P_W2], l->y1[0], l->dy1, B, DRA_ACT_RELU, s));
   STEP(K_CONV1_BW, dra_conv_bwd_w_koc(1, l->dy1, l->state, S + o[P_W1], S + o[P_B1], l->slab_stride, c.ksplit, B, 1, c.u8_coef, s));
+  if (fork) { DRA_HIP(hipEventRecord(l->ev_join[2], sd)); DRA_HIP(hipStreamWaitEvent(st, l->ev_join[2], 0)); }
   const int np = dra_norm_partials();
   STEP(K_NORM, dra_grad_sqnorm(G, c.conv_end, S, c.ksplit, l->slab_stride, l->partials, s));  // folds the conv slabs
-  STEP(K_NORM, dra_grad_sqnorm(G + c.conv_end, c.n_params - c.conv_end, nullptr, 0, 0, l->partials + np, s));
-  STEP(K_STEP, dra_rmsprop_step(l->p, G, l->s1, l->s2, c.n_params, l->partials, 2 * np, c.gradient_clip, c.lr, c.alpha,
-                                c.eps, c.centered, l->norm, s));
-  if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_COUNT], st));
+  if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_STEP], st));  // second norm launch is charged to the norm group
+  int rc = dra_grad_sqnorm(G + c.conv_end, c.n_params - c.conv_end, nullptr, 0, 0, l->partials + np, s);
+  return rc;
+}
+
+static int body_graph(dra_dqn_learner* l, hipStream_t st) {
+  if (!l->g_update_ready) {
+    hipGraph_t graph;
+    DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = run_body(l, st, 0, 0.f, 1);
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc != DRA_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    DRA_HIP(hipGraphInstantiate(&l->g_update, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    l->g_update_ready = true;
+  }
+  DRA_HIP(hipGraphLaunch(l->g_update, st));
   return DRA_OK;
 }
 
-// One gradient update on the indices currently in the learner's idx buffer.  use_graph != 0
-// captures the chain on first use and replays it afterwards (uniform replay only: the PER beta is
-// a kernel argument that changes per update).
+// One gradient update on the indices currently in the learner's idx buffer (all on `stream`).
+// use_graph != 0 replays the captured forward/backward graph (uniform replay only: the PER beta
+// is a kernel argument that changes per update); the stream must not be the NULL stream.
 DRA_API int dra_dqn_learner_update(dra_dqn_learner* l, int use_graph, int per, float beta, void* stream) {
   if (!l) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
   l->profiling = false;
-  if (!use_graph || per) return run_update(l, st, per, beta);
-  if (!l->graph_ready) {
-    hipGraph_t graph;
-    DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = run_update(l, st, 0, 0.f);
-    hipError_t e = hipStreamEndCapture(st, &graph);
-    if (rc != DRA_OK) return rc;
-    if (e != hipSuccess) return (int)e;
-    DRA_HIP(hipGraphInstantiate(&l->graph, graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
-    l->graph_ready = true;
-  }
-  DRA_HIP(hipGraphLaunch(l->graph, st));
-  return DRA_OK;
+  int rc = launch_gather(l, st);
+  if (rc) return rc;
+  rc = (use_graph && !per) ? body_graph(l, st) : run_body(l, st, per, beta, 0);
+  if (rc) return rc;
+  return launch_optimizer(l, st);
 }
 
 // Eager update with a HIP event before every kernel group (on the launch stream); returns the
@@ -216,13 +389,16 @@ DRA_API int dra_dqn_learner_profile(dra_dqn_learner* l, float* out_ms, int n_out
   if (!l || !out_ms || n_out < K_COUNT) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
   l->profiling = true;
-  int rc = run_update(l, st, 0, 0.f);
+  DRA_HIP(hipEventRecord(l->ev[K_GATHER], st));
+  int rc = launch_gather(l, st);
+  if (!rc) rc = run_body(l, st, 0, 0.f, 0);
+  // run_body recorded ev[K_STEP] before the second norm launch; re-record it right before the optimizer
+  if (!rc) rc = (int)hipEventRecord(l->ev[K_STEP], st);
+  if (!rc) rc = launch_optimizer(l, st);
+  if (!rc) rc = (int)hipEventRecord(l->ev[K_COUNT], st);
   l->profiling = false;
   if (rc != DRA_OK) return rc;
   DRA_HIP(hipEventSynchronize(l->ev[K_COUNT]));
-  // groups with two launches record their event twice; the later record wins, so a group's time
-  // is measured from its last record to the next group's record -- use single-launch groups for
-  // roofline figures (conv / fc / gather all are).
   for (int k = 0; k < K_COUNT; ++k) {
     float ms = 0.f;
     DRA_HIP(hipEventElapsedTime(&ms, l->ev[k], l->ev[k + 1]));
@@ -238,72 +414,227 @@ DRA_API int dra_dqn_learner_kernel_name(int k, char* out, int n) {
   return DRA_OK;
 }
 
+DRA_API int dra_dqn_learner_kernel_count(void) { return K_COUNT; }
+
 DRA_API int dra_dqn_learner_sync_target(dra_dqn_learner* l, void* stream) {
   if (!l) return DRA_EINVAL;
   return dra_copy_f32(l->pt, l->p, l->c.n_params, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Actor step (DQN_agent.py:24-45 + torch_utils.py:51-58) entirely on device: stack the last H
-// frames ending at `newest_slot` (modular, so the stack may wrap the ring end), batch-1 forward
-// of the ONLINE net, epsilon-greedy with HOST-drawn randomness (so the np.random stream is the
-// reference's: randint(A) then rand()), action written into the ring's action record of
-// `store_slot` and to out_action (device int64, may be NULL).  No device->host sync.
+// Actor step (DQN_agent.py:24-45 + torch_utils.py:51-58) on device.  Per-step arguments come from
+// the device parameter block `prm` (entry e), so the kernels can live in a captured graph.
+//   env_stack_kernel : 4 workgroups.  Workgroup j < 3 copies ring frame (slot-3+j, modular) into the
+//                      actor's stack; workgroup 3 produces the NEW observation frame of `slot` --
+//                      synthetic counter-hash frame (counter >= 0) written to the ring together with
+//                      its hashed reward / mask, or the frame already in the ring (counter < 0) --
+//                      and copies it to the stack.
+//   actor_head_kernel: fc4 split-K reduction + bias + ReLU + head + epsilon-greedy with the
+//                      HOST-drawn (random_action, dice) -> action record of `slot`.
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
 __global__ void __launch_bounds__(256)
-actor_stack_kernel(const uint8_t* __restrict__ frames, int64_t capacity, int64_t frame_bytes, int64_t newest, int H,
-                   uint8_t* __restrict__ out) {
-  const int j = blockIdx.x;  // 0 = oldest
-  int64_t slot = newest - (H - 1) + j;
+env_stack_kernel(const dra_dqn_step_params* __restrict__ prm, int e, uint8_t* __restrict__ frames,
+                 double* __restrict__ rewards, int32_t* __restrict__ masks, int64_t capacity, uint64_t seed,
+                 int done_period, uint8_t* __restrict__ stack) {
+  const int j = blockIdx.x;  // 0 = oldest of the 4-frame stack
+  const int64_t newest = prm->slot[e];
+  const int64_t counter = prm->counter[e];
+  int64_t slot = newest - 3 + j;
   if (slot < 0) slot += capacity;
-  const uint4* s = reinterpret_cast<const uint4*>(frames + slot * frame_bytes);
-  uint4* d = reinterpret_cast<uint4*>(out + (int64_t)j * frame_bytes);
-  for (int64_t t = threadIdx.x; t < (frame_bytes >> 4); t += blockDim.x) d[t] = s[t];
+  uint64_t* dst = reinterpret_cast<uint64_t*>(stack + (int64_t)j * 7056);
+  uint64_t* src = reinterpret_cast<uint64_t*>(frames + slot * 7056);
+  if (j == 3 && counter >= 0) {
+    const uint64_t base = seed * 0x9E3779B97F4A7C15ull + (uint64_t)counter * 882ull;
+    for (int w = threadIdx.x; w < 882; w += blockDim.x) {
+      const uint64_t v = mix64(base + (uint64_t)w);
+      src[w] = v;
+      dst[w] = v;
+    }
+    if (threadIdx.x == 0) {
+      const uint64_t hh = mix64((seed + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
+      const uint32_t u = (uint32_t)(hh >> 32) % 10u;
+      rewards[newest] = (u == 0) ? -1.0 : ((u == 9) ? 1.0 : 0.0);
+      const uint64_t h2 = mix64((seed + 2) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
+      masks[newest] = ((h2 % (uint64_t)done_period) == 0) ? 0 : 1;
+    }
+  } else {
+    for (int w = threadIdx.x; w < 882; w += blockDim.x) dst[w] = src[w];
+  }
 }
 
-__global__ void eps_greedy_kernel(const float* __restrict__ q, int A, float epsilon, int random_action, float dice,
-                                  uint8_t* __restrict__ ring_actions, int64_t store_slot, int64_t action_bytes,
-                                  int64_t* __restrict__ out_action) {
-  if (threadIdx.x != 0) return;
-  int best = 0;
-  float bv = q[0];
-  for (int k = 1; k < A; ++k) if (q[k] > bv) { bv = q[k]; best = k; }  // np.argmax: first max
-  const int64_t a = (dice < epsilon) ? random_action : best;
-  if (ring_actions) *reinterpret_cast<int64_t*>(ring_actions + store_slot * action_bytes) = a;
-  if (out_action) *out_action = a;
+__global__ void __launch_bounds__(512)
+actor_head_kernel(const dra_dqn_step_params* __restrict__ prm, int e, const float* __restrict__ slabs, int ks,
+                  const float* __restrict__ b4, const float* __restrict__ wh, const float* __restrict__ bh, int A,
+                  uint8_t* __restrict__ ring_actions, float* __restrict__ q_out, int64_t* __restrict__ out_action) {
+  __shared__ float s_h[512];
+  __shared__ float s_red[8];
+  __shared__ float s_q[64];
+  const int k = threadIdx.x;
+  float v = slabs[k];
+  for (int i = 1; i < ks; ++i) v += slabs[i * 512 + k];
+  v += b4[k];
+  s_h[k] = v > 0.f ? v : 0.f;
+  __syncthreads();
+  for (int a = 0; a < A; ++a) {
+    float part = wave_sum(s_h[k] * wh[a * 512 + k]);
+    if ((k & 63) == 0) s_red[k >> 6] = part;
+    __syncthreads();
+    if (k == 0) {
+      float t = 0.f;
+      for (int i = 0; i < 8; ++i) t += s_red[i];
+      s_q[a] = t + bh[a];
+    }
+    __syncthreads();
+  }
+  if (k < A && q_out) q_out[k] = s_q[k];
+  if (k == 0) {
+    int best = 0;
+    float bv = s_q[0];
+    for (int a = 1; a < A; ++a) if (s_q[a] > bv) { bv = s_q[a]; best = a; }  // np.argmax: first max
+    const int64_t act = (prm->dice[e] < prm->epsilon[e]) ? (int64_t)prm->random_action[e] : (int64_t)best;
+    const int64_t slot = prm->slot[e];
+    if (prm->store_action[e]) *reinterpret_cast<int64_t*>(ring_actions + slot * 8) = act;
+    if (out_action) out_action[e] = act;
+  }
 }
 
-DRA_API int dra_dqn_learner_act(dra_dqn_learner* l, int64_t newest_slot, float epsilon, int random_action, float dice,
-                                int64_t store_slot, int64_t* out_action_dev, void* stream) {
-  if (!l) return DRA_EINVAL;
-  hipStream_t st = dra_stream(stream);
-  void *frames, *actions;
-  int rc = dra_ring_pointers(l->ring, &frames, &actions, nullptr, nullptr);
-  if (rc) return rc;
+static int run_actor_steps(dra_dqn_learner* l, int n_env, hipStream_t st) {
   const dra_dqn_config& c = l->c;
-  if (newest_slot < 0 || newest_slot >= c.ring_capacity || store_slot >= c.ring_capacity) return DRA_EINVAL;
-  hipLaunchKernelGGL(actor_stack_kernel, dim3(4), dim3(256), 0, st, (const uint8_t*)frames, c.ring_capacity,
-                     (int64_t)7056, newest_slot, 4, l->act_state);
-  DRA_LAUNCH_CHECK();
+  void *frames, *actions, *rewards, *masks;
+  int rc = dra_ring_pointers(l->ring, &frames, &actions, &rewards, &masks);
+  if (rc) return rc;
   const float* P = l->p;
   const int64_t* o = c.offset;
   void* s = (void*)st;
-  const void* x1[1] = {l->act_state}; const float* w1[1] = {P + o[P_W1]}; const float* b1[1] = {P + o[P_B1]};
-  float* y1[1] = {l->ay1};
-  if ((rc = dra_conv_fwd_koc(1, 1, x1, w1, b1, y1, 1, 1, c.u8_coef, DRA_ACT_RELU, s))) return rc;
-  const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
-  float* y2[1] = {l->ay2};
-  if ((rc = dra_conv_fwd_koc(2, 1, x2, w2, b2, y2, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
-  const void* x3[1] = {l->ay2}; const float* w3[1] = {P + o[P_W3]}; const float* b3[1] = {P + o[P_B3]};
-  float* y3[1] = {l->ay3};
-  if ((rc = dra_conv_fwd_koc(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
-  const float* x4[1] = {l->ay3}; const float* w4[1] = {P + o[P_W4]}; const float* b4[1] = {P + o[P_B4]};
-  float* h4[1] = {l->ah4};
-  if ((rc = dra_linear_fwd(1, x4, w4, b4, h4, 1, 3136, 512, DRA_ACT_RELU, l->lin_ws, l->lin_ws_floats, s))) return rc;
-  const float* xh[1] = {l->ah4}; const float* wh[1] = {P + o[P_WH]}; const float* bh[1] = {P + o[P_BH]};
-  float* q[1] = {l->aq};
-  if ((rc = dra_linear_fwd(1, xh, wh, bh, q, 1, 512, c.n_actions, DRA_ACT_NONE, l->lin_ws, l->lin_ws_floats, s))) return rc;
-  hipLaunchKernelGGL(eps_greedy_kernel, dim3(1), dim3(64), 0, st, (const float*)l->aq, c.n_actions, epsilon, random_action,
-                     dice, store_slot >= 0 ? (uint8_t*)actions : nullptr, store_slot, (int64_t)8, out_action_dev);
-  DRA_LAUNCH_CHECK();
+  for (int e = 0; e < n_env; ++e) {
+    hipLaunchKernelGGL(env_stack_kernel, dim3(4), dim3(256), 0, st, (const dra_dqn_step_params*)l->prm_dev, e,
+                       (uint8_t*)frames, (double*)rewards, (int32_t*)masks, c.ring_capacity, (uint64_t)c.env_seed,
+                       (int)c.env_done_period, l->act_state);
+    DRA_LAUNCH_CHECK();
+    const void* x1[1] = {l->act_state}; const float* w1[1] = {P + o[P_W1]}; const float* b1[1] = {P + o[P_B1]};
+    float* y1[1] = {l->ay1};
+    if ((rc = dra_conv_fwd_koc(1, 1, x1, w1, b1, y1, 1, 1, c.u8_coef, DRA_ACT_RELU, s))) return rc;
+    const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
+    float* y2[1] = {l->ay2};
+    if ((rc = dra_conv_fwd_koc(2, 1, x2, w2, b2, y2, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+    const void* x3[1] = {l->ay2}; const float* w3[1] = {P + o[P_W3]}; const float* b3[1] = {P + o[P_B3]};
+    float* y3[1] = {l->ay3};
+    if ((rc = dra_conv_fwd_koc(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+    const float* x4[1] = {l->ay3}; const float* w4[1] = {P + o[P_W4]};
+    if ((rc = dra_linear_fwd_slabs(1, x4, w4, 1, 3136, 512, kFc4Split, l->afc4_slabs, s))) return rc;
+    hipLaunchKernelGGL(actor_head_kernel, dim3(1), dim3(512), 0, st, (const dra_dqn_step_params*)l->prm_dev, e,
+                       (const float*)l->afc4_slabs, kFc4Split, P + o[P_B4], P + o[P_WH], P + o[P_BH], c.n_actions,
+                       (uint8_t*)actions, l->aq, (int64_t*)nullptr);
+    DRA_LAUNCH_CHECK();
+  }
+  return DRA_OK;
+}
+
+static int actor_graph(dra_dqn_learner* l, int n_env, hipStream_t st) {
+  if (l->g_actor_ready && l->g_actor_n != n_env) {
+    (void)hipGraphExecDestroy(l->g_actor);
+    l->g_actor_ready = false;
+  }
+  if (!l->g_actor_ready) {
+    hipGraph_t graph;
+    DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = run_actor_steps(l, n_env, st);
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc != DRA_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    DRA_HIP(hipGraphInstantiate(&l->g_actor, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    l->g_actor_ready = true;
+    l->g_actor_n = n_env;
+  }
+  DRA_HIP(hipGraphLaunch(l->g_actor, st));
+  return DRA_OK;
+}
+
+// pinned staging slot k is free again once the copies issued from it have completed
+static int stage_acquire(dra_dqn_learner* l, int* k_out) {
+  const int k = l->stage_k;
+  l->stage_k = (k + 1) % 8;
+  if (l->stage_used[k]) DRA_HIP(hipEventSynchronize(l->stage_ev[k]));
+  l->stage_used[k] = true;
+  *k_out = k;
+  return DRA_OK;
+}
+
+// Actor only: runs prm->n_env environment transitions on `stream` (graph replay).
+DRA_API int dra_dqn_learner_act(dra_dqn_learner* l, const dra_dqn_step_params* prm, int use_graph, void* stream) {
+  if (!l || !prm || prm->n_env < 1 || prm->n_env > kMaxEnvSteps) return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  int k;
+  int rc = stage_acquire(l, &k);
+  if (rc) return rc;
+  memcpy(&l->prm_stage[k], prm, kPrmHeadBytes);
+  DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, st));
+  DRA_HIP(hipEventRecord(l->stage_ev[k], st));
+  return use_graph ? actor_graph(l, prm->n_env, st) : run_actor_steps(l, prm->n_env, st);
+}
+
+// One whole agent step (DQN_agent.py:101-138 minus logging): prm->n_env actor transitions, then one
+// gradient update on prm->idx.
+//   sync mode  (stream_actor == NULL): actor then update, in order, on stream_update -- the
+//              reference's async_actor=False ordering; this is the parity mode.
+//   async mode (stream_actor != NULL): the transitions issued by THIS call are those of the NEXT
+//              step; they run on stream_actor under this step's update (which consumes the
+//              transitions issued by the previous call).  Call dra_dqn_learner_act once before
+//              the first step.  Exclusions, as HIP events: actor ring writes wait for this
+//              update's gather; the optimizer kernel waits for the actor's forwards; the next
+//              actor waits for the optimizer.
+DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, void* stream_update,
+                                 void* stream_actor) {
+  if (!l || !prm || prm->n_env < 0 || prm->n_env > kMaxEnvSteps) return DRA_EINVAL;
+  hipStream_t su = dra_stream(stream_update);
+  hipStream_t sa = dra_stream(stream_actor);
+  const int B = l->c.batch;
+  l->profiling = false;
+  int k, rc;
+  if ((rc = stage_acquire(l, &k))) return rc;
+  memcpy(&l->prm_stage[k], prm, kPrmHeadBytes);
+  memcpy(l->idx_stage + (size_t)k * 1024, prm->idx, (size_t)B * sizeof(int64_t));
+  if (!stream_actor) {  // ---- sync mode
+    if (prm->n_env > 0) {
+      DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, su));
+      if ((rc = actor_graph(l, prm->n_env, su))) return rc;
+    }
+    if (do_update) {
+      DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
+      if ((rc = launch_gather(l, su))) return rc;
+      if ((rc = body_graph(l, su))) return rc;
+      if ((rc = launch_optimizer(l, su))) return rc;
+    }
+    DRA_HIP(hipEventRecord(l->stage_ev[k], su));
+    return DRA_OK;
+  }
+  // ---- async mode
+  if (do_update) {
+    if (l->actor_pending) DRA_HIP(hipStreamWaitEvent(su, l->ev_actor_done, 0));  // transitions of this step are in the ring
+    DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
+    if ((rc = launch_gather(l, su))) return rc;
+    DRA_HIP(hipEventRecord(l->ev_gather_done, su));
+    if ((rc = body_graph(l, su))) return rc;
+  }
+  if (prm->n_env > 0) {
+    if (do_update) DRA_HIP(hipStreamWaitEvent(sa, l->ev_gather_done, 0));  // do not overwrite slots the gather reads
+    DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, sa));
+    if ((rc = actor_graph(l, prm->n_env, sa))) return rc;
+    DRA_HIP(hipEventRecord(l->ev_actor_done, sa));
+    l->actor_pending = true;
+  }
+  if (do_update) {
+    if (prm->n_env > 0) DRA_HIP(hipStreamWaitEvent(su, l->ev_actor_done, 0));  // config.lock: optimizer excludes actor reads
+    if ((rc = launch_optimizer(l, su))) return rc;
+    DRA_HIP(hipEventRecord(l->ev_step_done, su));
+    DRA_HIP(hipStreamWaitEvent(sa, l->ev_step_done, 0));  // the next actor sees whole optimizer steps only
+  }
+  DRA_HIP(hipEventRecord(l->stage_ev[k], do_update ? su : sa));
   return DRA_OK;
 }

@@ -1,9 +1,9 @@
 """Python host of the fused DQN learner (deeprl_amd/csrc/learner.hip).
 
 `DQNLearner` binds a VanillaNet(NatureConvBody) pair (online / target), the optimiser
-hyper-parameters and an HBM replay ring to the C-ABI learner: after that, one gradient update
-(DQN_agent.py:114-134) is ONE ctypes call that replays a captured hipGraph, and one actor step
-(DQN_agent.py:24-45) is one call that never synchronises.  All RNG stays on the host in the
+hyper-parameters and an HBM replay ring to the C-ABI learner: after that, one whole agent step
+(DQN_agent.py:101-138: 4 actor transitions + sample + update) is ONE ctypes call that replays
+captured hipGraphs and never synchronises with the host.  All RNG stays on the host in the
 reference's draw order.
 
 `DQNLearnerBench` is the synthetic-workload driver bench.py times (BASELINE configs[1]).
@@ -22,14 +22,22 @@ _ORDER = ["body.conv1.weight", "body.conv1.bias", "body.conv2.weight", "body.con
           "body.conv3.bias", "body.fc4.weight", "body.fc4.bias", "fc_head.weight", "fc_head.bias"]
 
 
-class _DqnConfig(ctypes.Structure):
+class DqnConfig(ctypes.Structure):
+    """Mirror of dra_dqn_config (include/deeprl_amd.h)."""
     _fields_ = [("batch", ctypes.c_int32), ("n_actions", ctypes.c_int32), ("double_q", ctypes.c_int32),
-                ("ksplit", ctypes.c_int32), ("centered", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("ksplit", ctypes.c_int32), ("centered", ctypes.c_int32), ("env_done_period", ctypes.c_int32),
                 ("gamma_n", ctypes.c_float), ("gradient_clip", ctypes.c_float), ("lr", ctypes.c_float),
                 ("alpha", ctypes.c_float), ("eps", ctypes.c_float), ("replay_eps", ctypes.c_float),
                 ("replay_alpha", ctypes.c_float), ("reserved1", ctypes.c_float), ("u8_coef", ctypes.c_double),
                 ("n_params", ctypes.c_int64), ("conv_end", ctypes.c_int64), ("ring_capacity", ctypes.c_int64),
-                ("offset", ctypes.c_int64 * 10)]
+                ("env_seed", ctypes.c_uint64), ("offset", ctypes.c_int64 * 10)]
+
+
+class StepParams(ctypes.Structure):
+    """Mirror of dra_dqn_step_params (include/deeprl_amd.h)."""
+    _fields_ = [("slot", ctypes.c_int64 * 8), ("counter", ctypes.c_int64 * 8), ("random_action", ctypes.c_int32 * 8),
+                ("store_action", ctypes.c_int32 * 8), ("dice", ctypes.c_float * 8), ("epsilon", ctypes.c_float * 8),
+                ("n_env", ctypes.c_int32), ("reserved", ctypes.c_int32), ("idx", ctypes.c_int64 * 1024)]
 
 
 def _ordered_params(net):
@@ -42,17 +50,19 @@ def _ordered_params(net):
 
 class DQNLearner:
     def __init__(self, network, target_network, ring, batch, n_actions, gamma_n, gradient_clip, lr, alpha, eps,
-                 centered=True, double_q=False, u8_coef=1.0 / 255, replay_eps=0.01, replay_alpha=0.5, ksplit=16):
+                 centered=True, double_q=False, u8_coef=1.0 / 255, replay_eps=0.01, replay_alpha=0.5, ksplit=16,
+                 env_seed=0, env_done_period=800):
         self.network, self.target_network, self.ring = network, target_network, ring
         po, pt = _ordered_params(network), _ordered_params(target_network)
         self.flat = FlatParams(po, koc=(po[0], po[2], po[4]))        # conv segment first, conv weights in KOC
         self.target_flat = FlatParams(pt, koc=(pt[0], pt[2], pt[4]))
         self.state1 = torch.zeros_like(self.flat.flat)
         self.state2 = torch.zeros_like(self.flat.flat)
-        cfg = _DqnConfig()
+        cfg = DqnConfig()
         cfg.batch, cfg.n_actions, cfg.double_q, cfg.ksplit, cfg.centered = batch, n_actions, int(double_q), ksplit, int(centered)
         cfg.gamma_n, cfg.gradient_clip, cfg.lr, cfg.alpha, cfg.eps = gamma_n, gradient_clip or 0.0, lr, alpha, eps
         cfg.replay_eps, cfg.replay_alpha, cfg.u8_coef = replay_eps, replay_alpha, u8_coef
+        cfg.env_seed, cfg.env_done_period = env_seed, env_done_period
         cfg.n_params = self.flat.numel
         cfg.conv_end = self.flat.offsets[6]                          # start of fc4.weight
         cfg.ring_capacity = ring.capacity
@@ -71,13 +81,16 @@ class DQNLearner:
         w = ops._wrap_device_pointer
         self.idx = w(ps[0].value, batch, torch.int64)
         self.sampling_prob = w(ps[1].value, batch, torch.float32)
-        self.loss = w(ps[2].value, 1, torch.float32)
+        self._loss_per = w(ps[2].value, 1, torch.float32)
         self.norm = w(ps[3].value, 1, torch.float32)
         self.q = w(ps[4].value, batch * n_actions, torch.float32).view(batch, n_actions)
         self.delta = w(ps[5].value, batch, torch.float32)
         self.prio = w(ps[6].value, batch, torch.float32)
         self.actor_q = w(ps[7].value, n_actions, torch.float32)
         self.stream = torch.cuda.Stream()                            # graphs cannot capture on the NULL stream
+        self.actor_stream = torch.cuda.Stream()
+        self.params = StepParams()
+        self._idx_view = np.ctypeslib.as_array(self.params.idx)[:batch]
         self._idx_pinned = [torch.empty(batch, dtype=torch.int64).pin_memory() for _ in range(8)]
         self._idx_events = [None] * 8
         self._k = 0
@@ -93,8 +106,13 @@ class DQNLearner:
         except Exception:
             pass
 
-    def _sp(self):
-        return ctypes.c_void_p(self.stream.cuda_stream)
+    def _sp(self, stream=None):
+        return ctypes.c_void_p((stream or self.stream).cuda_stream)
+
+    @property
+    def loss(self):
+        """mean(0.5 * delta^2) of the last update (DQN_agent.py:78-79), recovered from the TD errors."""
+        return self.delta.pow(2).mul(0.5).mean()
 
     def upload_indices(self, idx):
         """numpy int64[batch] -> the learner's device idx buffer (async, pinned staging)."""
@@ -110,6 +128,7 @@ class DQNLearner:
         self._idx_events[k] = ev
 
     def update(self, idx=None, use_graph=True, sampling_prob=None, beta=0.0):
+        """One gradient update (gather + forward/backward graph + optimizer) on the update stream."""
         if idx is not None:
             self.upload_indices(idx)
         per = sampling_prob is not None
@@ -118,16 +137,32 @@ class DQNLearner:
                 self.sampling_prob.copy_(sampling_prob, non_blocking=True)
         lib.dra_dqn_learner_update(self.h, int(use_graph), int(per), float(beta), self._sp())
 
-    def act(self, newest_slot, epsilon, random_action, dice, store_slot, out_action=None):
-        lib.dra_dqn_learner_act(self.h, int(newest_slot), float(epsilon), int(random_action), float(dice), int(store_slot),
-                                None if out_action is None else ctypes.c_void_p(out_action.data_ptr()), self._sp())
+    def set_env_steps(self, slots, counters, random_actions, dices, epsilons, store=True):
+        p = self.params
+        n = len(slots)
+        p.n_env = n
+        for e in range(n):
+            p.slot[e], p.counter[e] = int(slots[e]), int(counters[e])
+            p.random_action[e], p.dice[e], p.epsilon[e] = int(random_actions[e]), float(dices[e]), float(epsilons[e])
+            p.store_action[e] = int(store)
+
+    def act(self, use_graph=True, stream=None):
+        """Runs the env transitions currently described by self.params (set_env_steps)."""
+        lib.dra_dqn_learner_act(self.h, ctypes.byref(self.params), int(use_graph), self._sp(stream))
+
+    def step(self, idx, do_update=True, async_actor=False):
+        """One agent step: the env transitions in self.params + one update on `idx`."""
+        if idx is not None:
+            self._idx_view[:] = idx
+        lib.dra_dqn_learner_step(self.h, ctypes.byref(self.params), int(do_update), self._sp(),
+                                 self._sp(self.actor_stream) if async_actor else None)
 
     def sync_target(self):
         lib.dra_dqn_learner_sync_target(self.h, self._sp())
 
     def profile(self):
         """Per-kernel-group milliseconds of one eager update (HIP events on the launch stream)."""
-        n = 17
+        n = lib.dra_dqn_learner_kernel_count.raw()
         out = (ctypes.c_float * n)()
         lib.dra_dqn_learner_profile(self.h, out, n, self._sp())
         names = []
@@ -139,6 +174,7 @@ class DQNLearner:
 
     def synchronize(self):
         self.stream.synchronize()
+        self.actor_stream.synchronize()
 
 
 def draw_uniform_indices(size, pos, batch, history, n_step):
@@ -159,62 +195,81 @@ def draw_uniform_indices(size, pos, batch, history, n_step):
 
 
 class DQNLearnerBench:
-    """BASELINE configs[1] on synthetic data: per step 4 env transitions (device frame source +
-    device actor), one reference-exact uniform minibatch draw, one fused update; target sync every
-    10 000 updates (examples.py:90)."""
+    """BASELINE configs[1] on synthetic data.  Per step: 4 env transitions (device frame source +
+    device actor, epsilon-greedy with host-drawn randomness), one reference-exact uniform minibatch
+    draw, one fused update; target sync every 10 000 updates (examples.py:90).
 
-    def __init__(self, ring_capacity=1_000_000, batch=32, seed=0, actor=True, path="fused", n_actions=4,
+    async_actor=True is the reference's dqn_pixel setting (examples.py:96): the actor works one
+    agent step ahead of the learner on its own stream; async_actor=False is the in-order mode the
+    parity tests use."""
+
+    def __init__(self, ring_capacity=1_000_000, batch=32, seed=0, actor=True, async_actor=True, n_actions=4,
                  prefill=None):
         from .nets import NatureConvBody, VanillaNet
         dev = Config.DEVICE
         if dev.type != "cuda":
             raise DraError("DQNLearnerBench needs select_device(gpu_id >= 0)")
-        self.batch, self.capacity, self.seed, self.actor, self.path = batch, ring_capacity, seed, actor, path
+        self.batch, self.capacity, self.seed, self.actor, self.async_actor = batch, ring_capacity, seed, actor, async_actor
         self.history, self.n_step, self.n_actions = 4, 1, n_actions
         self.ring = ops.Ring(ring_capacity, 7056, 8, self.history, self.n_step, 0.99)
         self.network = VanillaNet(n_actions, NatureConvBody())
         self.target_network = VanillaNet(n_actions, NatureConvBody())
         self.target_network.load_state_dict(self.network.state_dict())
         self.learner = DQNLearner(self.network, self.target_network, self.ring, batch, n_actions, 0.99, 5.0, 0.00025, 0.95,
-                                  0.01, centered=True)
+                                  0.01, centered=True, env_seed=seed, env_done_period=800)
         # resident replay before the timed region: fill the whole ring (exploration phase done)
         prefill = ring_capacity if prefill is None else prefill
         with torch.cuda.stream(self.learner.stream):
             self.ring.fill_synthetic(0, prefill, 0, seed, n_actions=n_actions, done_period=800)
-        self.counter = prefill
+        self.counter = prefill        # next synthetic frame
         self.size = prefill
         self.pos = prefill % ring_capacity
         self.updates = 0
         self.epsilon = 0.01
         self.learner.synchronize()
+        self._primed = False
 
-    def env_steps(self, n=4):
-        """n transitions: the synthetic env writes frame / reward / mask of slot `pos`; the actor
-        picks the action from the 4-frame stack ending there (host RNG order of epsilon_greedy)."""
-        L = self.learner
+    def _queue_env_steps(self, n=4):
+        """Host side of n env transitions: slots / frame counters and the epsilon-greedy randomness in
+        the reference's draw order (torch_utils.py:51-58).  Returns (pos, size) after feeding them."""
+        slots, counters, ras, dices = [], [], [], []
+        pos, size = self.pos, self.size
         for _ in range(n):
-            slot = self.pos
-            with torch.cuda.stream(L.stream):
-                self.ring.fill_synthetic(slot, 1, self.counter, self.seed, n_actions=self.n_actions, done_period=800)
-            if self.actor:
-                random_action = int(np.random.randint(self.n_actions, size=1)[0])
-                dice = float(np.random.rand(1)[0])
-                L.act(slot, self.epsilon, random_action, dice, slot)
+            slots.append(pos)
+            counters.append(self.counter)
+            ras.append(int(np.random.randint(self.n_actions, size=1)[0]))
+            dices.append(float(np.random.rand(1)[0]))
             self.counter += 1
-            if self.size < self.capacity:
-                self.size += 1
-            self.pos = (slot + 1) % self.capacity
+            size = min(size + 1, self.capacity)
+            pos = (pos + 1) % self.capacity
+        self.learner.set_env_steps(slots, counters, ras, dices, [self.epsilon] * n)
+        return pos, size
 
     def step(self):
-        self.env_steps(4)
-        idx = draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step)
-        self.learner.update(idx, use_graph=True)
+        L = self.learner
+        if not self.actor:
+            L.params.n_env = 0
+            L.step(draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step), True, False)
+        elif not self.async_actor:
+            self.pos, self.size = self._queue_env_steps(4)
+            L.step(draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step), True, False)
+        else:
+            if not self._primed:  # the actor runs one agent step ahead
+                self._next = self._queue_env_steps(4)
+                L.act(use_graph=True, stream=L.actor_stream)
+                L.actor_stream.synchronize()
+                self._primed = True
+            self.pos, self.size = self._next                      # transitions of this step are in the ring
+            idx = draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step)
+            self._next = self._queue_env_steps(4)                 # next step's transitions, overlapped with the update
+            L.step(idx, True, True)
         self.updates += 1
         if self.updates % 10000 == 0:
-            self.learner.sync_target()
+            L.sync_target()
 
     def roofline(self, n=200):
-        """Dominant kernel of the update, timed with HIP events on the learner's stream."""
+        """Per-kernel-group times of the update with HIP events on the learner's stream, and the
+        roofline position of the dominant one."""
         L = self.learner
         L.synchronize()
         acc = {}

@@ -127,6 +127,9 @@ int dra_act_bwd(const float* dy, const float* y, float* dpre, int64_t n, int act
 int dra_linear_fwd(int nz, const float* const* x, const float* const* w, const float* const* bias, float* const* y,
                    int batch, int in_features, int out_features, int act, float* workspace, int64_t workspace_floats,
                    void* stream);
+/* raw split-K partial sums [nz][ksplit][batch][out] (no bias / activation): the consumer reduces them. */
+int dra_linear_fwd_slabs(int nz, const float* const* x, const float* const* w, int batch, int in_features,
+                         int out_features, int ksplit, float* slabs, void* stream);
 int dra_linear_bwd_w(const float* dy, const float* x, float* dw, float* db, int batch, int in_features,
                      int out_features, void* stream);
 int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* dx, int batch, int in_features,
@@ -149,12 +152,26 @@ int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream); /* DQN_
  * conv1.w, conv1.b, conv2.w, conv2.b, conv3.w, conv3.b, fc4.w, fc4.b, head.w, head.b at `offset[]` (16-byte
  * aligned); [0, conv_end) is the conv segment whose split-K slabs are folded in the norm pass. */
 typedef struct dra_dqn_config {
-  int32_t batch, n_actions, double_q, ksplit, centered, reserved0;
+  int32_t batch, n_actions, double_q, ksplit, centered, env_done_period;
   float gamma_n, gradient_clip, lr, alpha, eps, replay_eps, replay_alpha, reserved1;
   double u8_coef;
   int64_t n_params, conv_end, ring_capacity;
+  uint64_t env_seed;        /* synthetic frame source (dra_ring_fill_synthetic stream) used by the device actor */
   int64_t offset[10];
 } dra_dqn_config;
+/* per-agent-step arguments: the device actor's kernels read them from a device copy, so the 4 env steps of a
+ * DQN agent step replay as one captured graph.  All randomness is drawn by the HOST in the reference's order
+ * (torch_utils.py:51-58: randint(A) then rand()), so the np.random stream is the reference's. */
+typedef struct dra_dqn_step_params {
+  int64_t slot[8];           /* ring slot of each env transition (frame / action / reward / mask live there) */
+  int64_t counter[8];        /* >= 0: synthesise frame `counter` (+ hashed reward / mask) into the slot; < 0: frame already there */
+  int32_t random_action[8];  /* np.random.randint(A) drawn by the host */
+  int32_t store_action[8];   /* write the chosen action into the slot's action record */
+  float dice[8];             /* np.random.rand() drawn by the host */
+  float epsilon[8];
+  int32_t n_env, reserved;
+  int64_t idx[1024];         /* minibatch indices of this step's update (first `batch` used) */
+} dra_dqn_step_params;
 typedef struct dra_dqn_learner dra_dqn_learner;
 int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const dra_dqn_config* cfg, float* params,
                            float* target, float* grad, float* state1, float* state2);
@@ -166,11 +183,15 @@ int dra_dqn_learner_buffers(dra_dqn_learner* learner, void** idx, void** samplin
 int dra_dqn_learner_update(dra_dqn_learner* learner, int use_graph, int per, float beta, void* stream);
 int dra_dqn_learner_profile(dra_dqn_learner* learner, float* out_ms, int n_out, void* stream);
 int dra_dqn_learner_kernel_name(int k, char* out, int n);
+int dra_dqn_learner_kernel_count(void);
 int dra_dqn_learner_sync_target(dra_dqn_learner* learner, void* stream); /* DQN_agent.py:136-138 */
-/* DQNActor._transition on device: stack the 4 frames ending at newest_slot, batch-1 forward, epsilon-greedy with
- * host-drawn (random_action, dice) (torch_utils.py:51-58), action -> ring action record of store_slot. */
-int dra_dqn_learner_act(dra_dqn_learner* learner, int64_t newest_slot, float epsilon, int random_action, float dice,
-                        int64_t store_slot, int64_t* out_action_dev, void* stream);
+/* DQNActor._transition on device for prm->n_env transitions (graph replay when use_graph). */
+int dra_dqn_learner_act(dra_dqn_learner* learner, const dra_dqn_step_params* prm, int use_graph, void* stream);
+/* DQNAgent.step: prm->n_env actor transitions + one update on prm->idx.  stream_actor == NULL: in-order on
+ * stream_update (async_actor=False semantics).  stream_actor != NULL: this call's transitions belong to the NEXT
+ * step and overlap this step's update (async_actor=True; config.lock becomes HIP events). */
+int dra_dqn_learner_step(dra_dqn_learner* learner, const dra_dqn_step_params* prm, int do_update, void* stream_update,
+                         void* stream_actor);
 
 #ifdef __cplusplus
 }

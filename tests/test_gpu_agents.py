@@ -286,18 +286,63 @@ def test_fused_learner_matches_oracle(dra, double_q):
     learner.update(idx, use_graph=False)
     learner.synchronize()
     # device actor: stack ending at a slot that wraps the ring end, greedy and random branches
-    for newest, eps, rnd, dice in ((1, 0.5, 3, 0.9), (cap - 1, 0.5, 2, 0.1), (100, 0.0, 1, 0.0)):
-        out = torch.zeros(1, dtype=torch.int64, device=d.Config.DEVICE)
-        learner.act(newest, eps, rnd, dice, newest, out)
+    for newest, eps, rnd, dice, graph in ((1, 0.5, 3, 0.9, False), (cap - 1, 0.5, 2, 0.1, True), (100, 0.0, 1, 0.0, True)):
+        learner.set_env_steps([newest], [-1], [rnd], [dice], [eps])  # counter < 0: frame already in the ring
+        learner.act(use_graph=graph)
         learner.synchronize()
         slots = [(newest - 3 + j) % cap for j in range(4)]
         xs = torch.from_numpy(NUM.image_normalize_sync(frames[slots].reshape(1, 4, 84, 84)))
-        pp = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        pp = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()}
         q1 = N.vanilla_head(pp, N.nature_conv_body(pp, xs)).numpy()[0]
         np.testing.assert_allclose(learner.actor_q.cpu().numpy(), q1, rtol=1e-4, atol=1e-5)
         want = rnd if dice < eps else int(np.argmax(q1))
-        assert int(out.item()) == want
         stored = d.ops._wrap_device_pointer(ring.pointers()[1], cap, torch.int64)[newest].item()
         assert stored == want
     learner.close()
     ring.close()
+
+
+def test_fused_step_sync_equals_act_then_update(dra):
+    """dra_dqn_learner_step in in-order mode == explicit actor transitions followed by an update:
+    the synthetic frame source, the device epsilon-greedy and the captured graphs change nothing."""
+    d = dra
+    from deeprl_amd.learner import DQNLearner, draw_uniform_indices
+    from oracle.synth_oracle import synth_transitions
+    cap, b, a, seed = 3000, 32, 4, 5
+    outs = []
+    for mode in ("step", "manual"):
+        ring = d.ops.Ring(cap, 7056, 8, 4, 1, 0.99)
+        ring.fill_synthetic(0, cap, 0, seed, n_actions=a, done_period=800)
+        torch.cuda.synchronize()
+        net, tgt = d.VanillaNet(a, d.NatureConvBody()), d.VanillaNet(a, d.NatureConvBody())
+        p_np = fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(a), 31)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
+        tgt.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
+        L = DQNLearner(net, tgt, ring, b, a, 0.99, 5.0, 0.00025, 0.95, 0.01, centered=True, env_seed=seed)
+        np.random.seed(3)
+        pos, size, counter = 0, cap, cap
+        for it in range(6):
+            slots = [(pos + e) % cap for e in range(4)]
+            ras = [int(np.random.randint(a, size=1)[0]) for _ in range(4)]
+            dices = [float(np.random.rand(1)[0]) for _ in range(4)]
+            L.set_env_steps(slots, [counter + e for e in range(4)], ras, dices, [0.3] * 4)
+            counter += 4
+            pos = (pos + 4) % cap
+            idx = draw_uniform_indices(size, pos, b, 4, 1)
+            if mode == "step":
+                L.step(idx, True, False)
+            else:
+                L.act(use_graph=False)
+                L.update(idx, use_graph=False)
+        L.synchronize()
+        acts = d.ops._wrap_device_pointer(ring.pointers()[1], cap, torch.int64)[:24].cpu().numpy().copy()
+        frames24 = d.ops._wrap_device_pointer(ring.pointers()[0], 24 * 7056, torch.uint8).cpu().numpy().copy()
+        outs.append((L.flat.flat.cpu().numpy().copy(), acts, frames24))
+        L.close()
+        ring.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    # the device frame source is the documented counter hash
+    want_frames, _, _, _ = synth_transitions(cap, 24, 7056, seed=seed)
+    assert np.array_equal(outs[0][2].reshape(24, 7056), want_frames)
