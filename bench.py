@@ -139,6 +139,8 @@ def main():
         dt = float(t.item())
     roof = bench.roofline(args.steps if args.steps < 500 else 500)
     extra = bench.report()
+    if not args.no_actor:
+        extra["host_us_per_step"] = bench.host_profile(100)
     if rank == 0:
         ups = world * args.steps / dt
         out = {

@@ -184,8 +184,9 @@ DRA_API int dra_dqn_learner_buffers(dra_dqn_learner* l, void** idx, void** sampl
 //   dh4[b][k]   = dq[b][a_b] * Wh_0[a_b][k] * (h4[0][b][k] > 0)     (gradient w.r.t. fc4's pre-activation)
 // Per-sample work only: the batch-mean loss is recovered from `delta` on demand, and the PER
 // variant (needs max over the batch) keeps the separate td_loss kernel.
+template <int KS>
 __global__ void __launch_bounds__(256)
-head_fused_kernel(const float* __restrict__ slabs, int nz, int ks, int B, int A, const float* __restrict__ b4_on,
+head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const float* __restrict__ b4_on,
                   const float* __restrict__ b4_tg, const float* __restrict__ wh_on, const float* __restrict__ wh_tg,
                   const float* __restrict__ bh_on, const float* __restrict__ bh_tg, const int64_t* __restrict__ action,
                   const float* __restrict__ reward, const float* __restrict__ mask, float gamma_n, int double_q,
@@ -193,16 +194,19 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int ks, int B, int A,
                   float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dh4) {
   __shared__ float s_h[3][512];
   __shared__ float s_q[3][64];
-  __shared__ float s_red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int z = 0; z < nz; ++z) {
     const float* bias = (z == 1) ? b4_tg : b4_on;
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
       const int k = tid + 256 * rep;
-      const float* s = slabs + ((int64_t)z * ks * B + b) * 512 + k;
-      float v = s[0];
-      for (int i = 1; i < ks; ++i) v += s[(int64_t)i * B * 512];
+      const float* s = slabs + ((int64_t)z * KS * B + b) * 512 + k;
+      float part[KS];
+#pragma unroll
+      for (int i = 0; i < KS; ++i) part[i] = s[(int64_t)i * B * 512];  // all split-K partials in flight at once
+      float v = part[0];
+#pragma unroll
+      for (int i = 1; i < KS; ++i) v += part[i];
       v += bias[k];
       v = v > 0.f ? v : 0.f;
       s_h[z][k] = v;
@@ -210,18 +214,21 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int ks, int B, int A,
     }
   }
   __syncthreads();
-  for (int z = 0; z < nz; ++z) {
-    const float* wh = (z == 1) ? wh_tg : wh_on;
-    const float* bh = (z == 1) ? bh_tg : bh_on;
-    for (int a = 0; a < A; ++a) {
-      float part = s_h[z][tid] * wh[a * 512 + tid] + s_h[z][tid + 256] * wh[a * 512 + tid + 256];
+  // heads: wave w owns the (net, action) pairs w, w+4, ... -- one wave-level dot product each, no
+  // workgroup barrier per output
+  {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int pair = wave; pair < nz * A; pair += 4) {
+      const int z = pair / A, a = pair - z * A;
+      const float* wh = ((z == 1) ? wh_tg : wh_on) + a * 512;
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) part += s_h[z][lane + 64 * i] * wh[lane + 64 * i];
       part = wave_sum(part);
-      if ((tid & 63) == 0) s_red[tid >> 6] = part;
-      __syncthreads();
-      if (tid == 0) s_q[z][a] = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + bh[a];
-      __syncthreads();
+      if (lane == 0) s_q[z][a] = part + ((z == 1) ? bh_tg : bh_on)[a];
     }
   }
+  __syncthreads();
   const int64_t ab = action[b];
   float dqa;
   {
@@ -254,12 +261,20 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int ks, int B, int A,
 }
 
 // dWh[a][k] = sum_b dq[b][a] * h4[b][k] ;  dbh[a] = sum_b dq[b][a]      (grid = A, 512 threads)
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(64)
 head_wgrad_kernel(const float* __restrict__ dq, const float* __restrict__ h4, int B, int A, float* __restrict__ dwh,
                   float* __restrict__ dbh) {
-  const int a = blockIdx.x, k = threadIdx.x;
+  const int a = blockIdx.x, k = blockIdx.y * 64 + threadIdx.x;  // grid (A, 8) x 64 threads
   float acc = 0.f, accb = 0.f;
-  for (int b = 0; b < B; ++b) {
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {
+    float d[8], h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { d[i] = dq[(int64_t)(b + i) * A + a]; h[i] = h4[(int64_t)(b + i) * 512 + k]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc += d[i] * h[i]; accb += d[i]; }
+  }
+  for (; b < B; ++b) {
     const float d = dq[(int64_t)b * A + a];
     acc += d * h4[(int64_t)b * 512 + k];
     accb += d;
@@ -314,7 +329,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   const float* w4[3] = {P + o[P_W4], T + o[P_W4], P + o[P_W4]};
   STEP(K_FC4_F, dra_linear_fwd_slabs(nz, x4, w4, B, 3136, 512, kFc4Split, l->fc4_slabs, s));
   if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_HEAD], st));
-  hipLaunchKernelGGL(head_fused_kernel, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, kFc4Split, B, A,
+  hipLaunchKernelGGL(head_fused_kernel<kFc4Split>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                      P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
                      (const int64_t*)l->action, (const float*)l->reward, (const float*)l->mask, c.gamma_n, c.double_q,
                      l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4);
@@ -333,7 +348,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   if (fork) { DRA_HIP(hipEventRecord(l->ev_fork, st)); DRA_HIP(hipStreamWaitEvent(sd, l->ev_fork, 0)); }
   // side branch: head and fc4 weight gradients need only dq / dh4 / stored activations
   if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_HEAD_BW], st));
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3(A), dim3(512), 0, sd, (const float*)l->dq, (const float*)l->h4, B, A,
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(A, 8), dim3(64), 0, sd, (const float*)l->dq, (const float*)l->h4, B, A,
                      G + o[P_WH], G + o[P_BH]);
   DRA_LAUNCH_CHECK();
   STEP(K_FC4_BW, dra_linear_bwd_w(l->dh4, l->y3[0], G + o[P_W4], G + o[P_B4], B, 3136, 512, sds));
@@ -357,7 +372,9 @@ static int body_graph(dra_dqn_learner* l, hipStream_t st) {
   if (!l->g_update_ready) {
     hipGraph_t graph;
     DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = run_body(l, st, 0, 0.f, 1);
+    // single-queue chain: forked branches end up on other HW queues and every cross-queue join was
+    // measured at 10-13 us of idle gap (profiles/r01_timeline_async_forked.txt); same-queue gaps are 0
+    int rc = run_body(l, st, 0, 0.f, 0);
     hipError_t e = hipStreamEndCapture(st, &graph);
     if (rc != DRA_OK) return rc;
     if (e != hipSuccess) return (int)e;
@@ -475,8 +492,12 @@ actor_head_kernel(const dra_dqn_step_params* __restrict__ prm, int e, const floa
   __shared__ float s_red[8];
   __shared__ float s_q[64];
   const int k = threadIdx.x;
-  float v = slabs[k];
-  for (int i = 1; i < ks; ++i) v += slabs[i * 512 + k];
+  float part[kFc4Split];
+#pragma unroll
+  for (int i = 0; i < kFc4Split; ++i) part[i] = slabs[i * 512 + k];
+  float v = part[0];
+#pragma unroll
+  for (int i = 1; i < kFc4Split; ++i) v += part[i];
   v += b4[k];
   s_h[k] = v > 0.f ? v : 0.f;
   __syncthreads();
@@ -620,9 +641,8 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
     DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
     if ((rc = launch_gather(l, su))) return rc;
     DRA_HIP(hipEventRecord(l->ev_gather_done, su));
-    if ((rc = body_graph(l, su))) return rc;
   }
-  if (prm->n_env > 0) {
+  if (prm->n_env > 0) {  // issued before the update body so that it starts as soon as the gather is done
     if (do_update) DRA_HIP(hipStreamWaitEvent(sa, l->ev_gather_done, 0));  // do not overwrite slots the gather reads
     DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, sa));
     if ((rc = actor_graph(l, prm->n_env, sa))) return rc;
@@ -630,6 +650,7 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
     l->actor_pending = true;
   }
   if (do_update) {
+    if ((rc = body_graph(l, su))) return rc;
     if (prm->n_env > 0) DRA_HIP(hipStreamWaitEvent(su, l->ev_actor_done, 0));  // config.lock: optimizer excludes actor reads
     if ((rc = launch_optimizer(l, su))) return rc;
     DRA_HIP(hipEventRecord(l->ev_step_done, su));

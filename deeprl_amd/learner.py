@@ -267,6 +267,31 @@ class DQNLearnerBench:
         if self.updates % 10000 == 0:
             L.sync_target()
 
+    def host_profile(self, n=200):
+        """Host-side cost of one agent step with the GPU idle (synchronise before every call): python
+        bookkeeping + RNG vs the C call that enqueues the step.  Microseconds."""
+        import time
+        L = self.learner
+        py = call = 0.0
+        for _ in range(n):
+            L.synchronize()
+            t0 = time.perf_counter()
+            self.pos, self.size = self._next if self.async_actor and self._primed else (self.pos, self.size)
+            idx = draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step)
+            nxt = self._queue_env_steps(4)
+            t1 = time.perf_counter()
+            if self.async_actor:
+                self._next = nxt
+                L.step(idx, True, True)
+            else:
+                self.pos, self.size = nxt
+                L.step(idx, True, False)
+            t2 = time.perf_counter()
+            py += t1 - t0
+            call += t2 - t1
+        L.synchronize()
+        return {"python_us": 1e6 * py / n, "enqueue_call_us": 1e6 * call / n}
+
     def roofline(self, n=200):
         """Per-kernel-group times of the update with HIP events on the learner's stream, and the
         roofline position of the dominant one."""
