@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--ring", type=int, default=1_000_000, help="replay capacity in frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-actor", action="store_true", help="skip actor inference (then env_steps is null)")
+    ap.add_argument("--variant", type=int, default=-1, help="DRA_VAR_* kernel-variant mask (-1: library default)")
     ap.add_argument("--sync-actor", action="store_true",
                     help="in-order actor (async_actor=False); default is the reference's dqn_pixel setting async_actor=True")
     return ap.parse_args()
@@ -101,6 +102,25 @@ def cpu_baseline(seconds=15.0, ring=20_000):
             "sample": "%d DQN updates (B=32, 84x84x4, %d-frame ring) in %.1f s, torch-CPU fp32 oracle, 1 thread" % (n, ring, dt)}
 
 
+def pmc_traffic(kernel_group):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/rNN_pmc_traffic.json, made by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of
+    tools/pmc_workload.py, calibrated on the gather launch whose byte count is known); null when the
+    kernel was not profiled.  Counters cannot be collected inside this process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        table = json.load(open(files[-1]))["kernels"]
+    except Exception:
+        return None
+    alias = {"conv3_bwd_x": "conv3_bwd", "conv3_bwd_w": "conv3_bwd", "conv2_bwd_x": "conv2_bwd", "conv2_bwd_w": "conv2_bwd",
+             "fc4_bwd_x": "fc4_bwd"}
+    rec = table.get(alias.get(kernel_group, kernel_group))
+    return None if rec is None else rec.get("hbm_bytes")
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -118,7 +138,7 @@ def main():
     torch.manual_seed(1234 + rank)
     np.random.seed(rank)
     bench = DQNLearnerBench(ring_capacity=args.ring, batch=B, seed=rank, actor=not args.no_actor,
-                            async_actor=not args.sync_actor)
+                            async_actor=not args.sync_actor, variant=args.variant)
     for _ in range(args.warmup):
         bench.step()
     torch.cuda.synchronize()
@@ -138,6 +158,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     roof = bench.roofline(args.steps if args.steps < 500 else 500)
+    roof["traffic"] = pmc_traffic(roof["kernel"])
     extra = bench.report()
     if not args.no_actor:
         extra["host_us_per_step"] = bench.host_profile(100)
@@ -150,7 +171,8 @@ def main():
             "config": {"workload": "DQN Breakout 84x84x4 uint8, NatureConvBody, batch 32, %d-frame HBM replay ring, "
                                    "centered RMSprop, clip 5 (BASELINE configs[1])" % args.ring,
                        "global_batch": B * world, "parallelism": "replicas x%d" % world,
-                       "actor_in_step": not args.no_actor, "async_actor": not args.sync_actor},
+                       "actor_in_step": not args.no_actor, "async_actor": not args.sync_actor,
+                       "kernel_variant": bench.learner.variant},
             "env_steps_per_sec": (4 * ups) if not args.no_actor else None,
             "roofline": roof,
         }

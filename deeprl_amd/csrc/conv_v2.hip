@@ -52,6 +52,10 @@ struct ConvV2Args {
   float* y[DRA_MAX_Z];
   int batch, act;
   double coef;
+  // ring-direct input (batch 1, uint8 frames): channel c of the stack is ring frame
+  // (*ring_slot - (C-1) + c) mod ring_cap of the slot-major frame array x[0]; null = plain NCHW input
+  const int64_t* ring_slot;
+  int64_t ring_cap;
 };
 
 __device__ __forceinline__ float v2_act(float v, int act) {
@@ -98,10 +102,16 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
     unsigned raw[CPT * LPT];
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x[z]);
     const int nw = nrows * WPR;
+    const int64_t newest = a.ring_slot ? *a.ring_slot : 0;
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
       const int c = wave + 4 * ci;
-      const unsigned* src = reinterpret_cast<const unsigned*>(xb + ((int64_t)(bi * G::C + min(c, G::C - 1)) * G::H + ir0) * G::H);
+      int64_t img = (int64_t)bi * G::C + min(c, G::C - 1);       // image index in a plain NCHW batch
+      if (a.ring_slot) {
+        img = newest - (G::C - 1) + min(c, G::C - 1);
+        if (img < 0) img += a.ring_cap;
+      }
+      const unsigned* src = reinterpret_cast<const unsigned*>(xb + (img * G::H + ir0) * G::H);
 #pragma unroll
       for (int q = 0; q < LPT; ++q) {
         const int e = lane + 64 * q;
@@ -222,7 +232,7 @@ DRA_API int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const floa
     if (!x[z] || !wt[z] || !bias[z] || !y[z]) return DRA_EINVAL;
     a.x[z] = x[z]; a.wt[z] = wt[z]; a.bias[z] = bias[z]; a.y[z] = y[z];
   }
-  a.batch = batch; a.act = act; a.coef = u8_coef;
+  a.batch = batch; a.act = act; a.coef = u8_coef; a.ring_slot = nullptr; a.ring_cap = 0;
   hipStream_t st = dra_stream(stream);
   switch (layer) {
     case 1: return x_is_u8 ? launch_conv_v2<VG1, true>(a, nz, st) : launch_conv_v2<VG1, false>(a, nz, st);
@@ -230,6 +240,18 @@ DRA_API int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const floa
     case 3: return x_is_u8 ? DRA_EINVAL : launch_conv_v2<VG3, false>(a, nz, st);
   }
   return DRA_EINVAL;
+}
+
+// conv1 of the actor's batch-1 forward reading its 4-frame stack straight from the replay ring
+// (DQN_agent.py:24-33: the state the actor acts on IS the newest `history` frames of the ring):
+// frames = slot-major u8 ring, *newest_slot_dev = slot of the newest frame (device int64).
+DRA_API int dra_conv1_fwd_koc_ring(const void* frames, const int64_t* newest_slot_dev, int64_t capacity, const float* wt,
+                                   const float* bias, float* y, double u8_coef, int act, void* stream) {
+  if (!frames || !newest_slot_dev || capacity < VG1::C || !wt || !bias || !y) return DRA_EINVAL;
+  ConvV2Args a;
+  a.x[0] = frames; a.wt[0] = wt; a.bias[0] = bias; a.y[0] = y;
+  a.batch = 1; a.act = act; a.coef = u8_coef; a.ring_slot = newest_slot_dev; a.ring_cap = capacity;
+  return launch_conv_v2<VG1, true>(a, 1, dra_stream(stream));
 }
 
 // Layout conversion [OC][K] <-> [K][OC] for one layer's weight tensor (tests, generic path, and

@@ -1,0 +1,178 @@
+// Horizontally fused backward launches and the one-pass contractions of the DQN update (oneshot.h).
+// Replaces the autograd backward of deep_rl/network/network_bodies.py:27-33 + network_heads.py:18-21
+// as driven by DQN_agent.py:129 (loss.backward()) for VanillaNet(NatureConvBody).
+//
+// A layer's weight gradient and input gradient are independent given the incoming gradient, so they
+// share ONE launch (multi_kernel): one dependent-launch cost instead of two or three, and the two
+// half-empty grids fill the chip together.  `variant` selects the kernels behind each role:
+//   DRA_VAR_ONESHOT_DGRAD  one-pass input gradients (ConvDgradOne / LinDgradOne) instead of the
+//                          K-chunked implicit GEMM;
+//   DRA_VAR_ONESHOT_WGRAD  one-pass conv weight gradients (ConvWgradOne): one slab per (sample, row
+//                          chunk) -- dra_conv_wgrad_slabs() slabs instead of `ksplit`.
+#include "oneshot.h"
+
+static int g_tuning = 0;
+
+DRA_API int dra_set_tuning(int mask) {
+  if (mask < 0) return DRA_EINVAL;
+  g_tuning = mask;
+  return DRA_OK;
+}
+DRA_API int dra_get_tuning(int* mask) {
+  if (!mask) return DRA_EINVAL;
+  *mask = g_tuning;
+  return DRA_OK;
+}
+
+// conv1: 4 output rows per chunk, all 8 k tiles per workgroup; conv2 / conv3: whole sample per chunk
+using WG1u = ConvWgradOne<G1, 4, 4, 88, 0, true>;
+using WG1f = ConvWgradOne<G1, 4, 4, 88, 0, false>;
+using WG2 = ConvWgradOne<G2, 9, 4, 24, 4, false>;
+using WG3 = ConvWgradOne<G3, 7, 3, 10, 1, false>;
+
+DRA_API int dra_conv_wgrad_slabs(int layer, int batch, int ksplit, int variant, int* n_slabs) {
+  if (!n_slabs || batch < 1 || ksplit < 1) return DRA_EINVAL;
+  if (!(variant & DRA_VAR_ONESHOT_WGRAD)) { *n_slabs = ksplit; return DRA_OK; }
+  switch (layer) {
+    case 1: *n_slabs = WG1u::n_slabs(batch); return DRA_OK;
+    case 2: *n_slabs = WG2::n_slabs(batch); return DRA_OK;
+    case 3: *n_slabs = WG3::n_slabs(batch); return DRA_OK;
+  }
+  return DRA_EINVAL;
+}
+
+template <class W>
+static W make_wgrad_one(const float* dy, const void* x, float* dw, float* db, int64_t slab_stride, int batch, double coef) {
+  W r;
+  r.dy = dy; r.x = x; r.dw = dw; r.db = db; r.slab_stride = slab_stride; r.B = batch; r.coef = coef;
+  return r;
+}
+
+template <class G>
+static ConvDgradOne<G> make_dgrad_one(const float* dy, const float* wt, const float* xact, float* dx, int batch, int act) {
+  ConvDgradOne<G> r;
+  r.dy = dy; r.wt = wt; r.xact = xact; r.dx = dx; r.B = batch; r.act = act;
+  return r;
+}
+
+template <class G, bool U8>
+static IgemmRole<ConvWgradKoc<G, 32, 32, 64, U8>> make_wgrad_igemm(const float* dy, const void* x, float* dw, float* db,
+                                                                 int64_t slab_stride, int ksplit, int batch, double coef) {
+  ConvWgradKoc<G, 32, 32, 64, U8> p;
+  p.M = G::K + 1; p.N = G::OC; p.K = batch * G::P;
+  p.dy = dy; p.x = x; p.dw = dw; p.db = db; p.slab_stride = slab_stride; p.coef = coef;
+  return make_igemm_role(p, ksplit);
+}
+
+template <class G>
+static IgemmRole<ConvDgradKoc<G, 32, 32, 64>> make_dgrad_igemm(const float* dy, const float* wt, const float* xact,
+                                                               float* dx, int batch, int act) {
+  using PT = ConvDgradKoc<G, 32, 32, 64>;
+  PT p;
+  p.M = G::C; p.N = batch * PT::PP; p.K = G::OC * PT::KPP;
+  p.dy = dy; p.wt = wt; p.xact = xact; p.dx = dx; p.act = act;
+  IgemmRole<PT> r = make_igemm_role(p, 1);
+  return r;
+}
+
+template <class R>
+static int igemm_blocks(const R& r, int nz) { return r.tiles * r.ksplit * nz; }
+
+// layers 2 / 3: weight gradient + input gradient in one launch
+template <class G, class WOne>
+static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
+                            int64_t slab_stride, int ksplit, float* dx, int batch, int act, int variant, hipStream_t st) {
+  const bool ow = variant & DRA_VAR_ONESHOT_WGRAD, od = variant & DRA_VAR_ONESHOT_DGRAD;
+  NoRole none;
+  if (od && ow) {
+    auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
+    auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
+    return launch_multi(rd, rd.blocks(), rw, rw.blocks(), none, 0, st);
+  }
+  if (od) {
+    auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
+    auto rw = make_wgrad_igemm<G, false>(dy, x, dw, db, slab_stride, ksplit, batch, 1.0);
+    return launch_multi(rd, rd.blocks(), rw, igemm_blocks(rw, 1), none, 0, st);
+  }
+  auto rd = make_dgrad_igemm<G>(dy, wt, xact, dx, batch, act);
+  const int nd = igemm_blocks(rd, G::S * G::S);
+  if (ow) {
+    auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
+    return launch_multi(rd, nd, rw, rw.blocks(), none, 0, st);
+  }
+  auto rw = make_wgrad_igemm<G, false>(dy, x, dw, db, slab_stride, ksplit, batch, 1.0);
+  return launch_multi(rd, nd, rw, igemm_blocks(rw, 1), none, 0, st);
+}
+
+// One launch for a conv layer's backward (KOC weights): dWt / db slabs [n_slabs][..] and, for layers 2 and 3,
+// dx = gradient w.r.t. the pre-activation of the layer below (xact = that layer's output).  layer 1 has no
+// input gradient (dx / wt / xact ignored).  n_slabs = dra_conv_wgrad_slabs(layer, batch, ksplit, variant).
+DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const float* wt, const float* xact, float* dw,
+                               float* db, int64_t slab_stride, int ksplit, float* dx, int batch, int x_is_u8,
+                               double u8_coef, int act, int variant, void* stream) {
+  if (!dy || !x || !dw || !db || batch < 1 || ksplit < 1) return DRA_EINVAL;
+  if (layer != 1 && (!wt || !dx || x_is_u8)) return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  NoRole none;
+  switch (layer) {
+    case 1:
+      if (variant & DRA_VAR_ONESHOT_WGRAD) {
+        if (x_is_u8) {
+          auto rw = make_wgrad_one<WG1u>(dy, x, dw, db, slab_stride, batch, u8_coef);
+          return launch_multi(rw, rw.blocks(), none, 0, none, 0, st);
+        }
+        auto rw = make_wgrad_one<WG1f>(dy, x, dw, db, slab_stride, batch, 1.0);
+        return launch_multi(rw, rw.blocks(), none, 0, none, 0, st);
+      }
+      return dra_conv_bwd_w_koc(1, dy, x, dw, db, slab_stride, ksplit, batch, x_is_u8, u8_coef, stream);
+    case 2: return conv_bwd_fused_t<G2, WG2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+    case 3: return conv_bwd_fused_t<G3, WG3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+  }
+  return DRA_EINVAL;
+}
+
+// Backward of head + fc4 in one launch (VanillaNet over NatureConvBody, hidden = 512):
+//   dWh / dbh (HeadWgradRole), dW4 / db4 (LinWgrad), dx3 = relu'(x3) * (dh4 . W4) (LinDgrad / LinDgradOne).
+// dq [B][A], h4 [B][512] (post-ReLU), dh4 [B][512] (gradient w.r.t. fc4's pre-activation), x3 [B][I].
+DRA_API int dra_fc_bwd_fused(const float* dq, const float* h4, const float* dh4, const float* x3, const float* w4,
+                             float* dwh, float* dbh, float* dw4, float* db4, float* dx3, int batch, int n_actions,
+                             int in_features, int act, int variant, void* stream) {
+  if (!dq || !h4 || !dh4 || !x3 || !w4 || !dwh || !dbh || !dw4 || !db4 || !dx3 || batch < 1 || n_actions < 1 ||
+      in_features < 1)
+    return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  constexpr int O = 512;
+  HeadWgradRole rh;
+  rh.dq = dq; rh.h4 = h4; rh.dwh = dwh; rh.dbh = dbh; rh.B = batch; rh.A = n_actions;
+  LinWgrad<64, 64, 32> pw;
+  pw.M = O; pw.N = in_features + 1; pw.K = batch; pw.I = in_features; pw.dy = dh4; pw.x = x3; pw.dw = dw4; pw.db = db4;
+  auto rw = make_igemm_role(pw, 1);
+  if (variant & DRA_VAR_ONESHOT_DGRAD) {
+    LinDgradOne<O> rd;
+    rd.dy = dh4; rd.w = w4; rd.xact = x3; rd.dx = dx3; rd.B = batch; rd.I = in_features; rd.act = act;
+    rd.tiles_n = (in_features + 31) / 32;
+    return launch_multi(rd, rd.tiles_n * ((batch + 31) / 32), rw, igemm_blocks(rw, 1), rh, 2 * n_actions, st);
+  }
+  LinDgrad<32, 32, 64> pd;
+  pd.M = batch; pd.N = in_features; pd.K = O; pd.dy = dh4; pd.w = w4; pd.xact = x3; pd.dx = dx3; pd.act = act;
+  auto rd = make_igemm_role(pd, 1);
+  return launch_multi(rd, igemm_blocks(rd, 1), rw, igemm_blocks(rw, 1), rh, 2 * n_actions, st);
+}
+
+// fc4 forward partial sums in one pass per K split (in_features = 3136, ksplit = 8): same contract as
+// dra_linear_fwd_slabs.
+DRA_API int dra_linear_fwd_slabs_one(int nz, const float* const* x, const float* const* w, int batch, int in_features,
+                                     int out_features, int ksplit, float* slabs, void* stream) {
+  if (nz < 1 || nz > kMaxZ || batch < 1 || !x || !w || !slabs) return DRA_EINVAL;
+  if (in_features != 3136 || ksplit != 8 || out_features < 1) return DRA_EINVAL;
+  LinFwdSlabsOne<3136, 8> r;
+  for (int z = 0; z < nz; ++z) {
+    if (!x[z] || !w[z]) return DRA_EINVAL;
+    if ((((uintptr_t)x[z]) | ((uintptr_t)w[z])) & 15) return DRA_EINVAL;
+    r.x[z] = x[z]; r.w[z] = w[z];
+  }
+  r.slabs = slabs; r.B = batch; r.O = out_features;
+  r.tiles_n = (out_features + 31) / 32; r.tiles_m = (batch + 31) / 32;
+  NoRole none;
+  return launch_multi(r, r.tiles_n * r.tiles_m * 8 * nz, none, 0, none, 0, dra_stream(stream));
+}

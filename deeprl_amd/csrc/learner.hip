@@ -52,6 +52,11 @@ struct dra_dqn_learner {
   float *dq, *dh4, *dy3, *dy2, *dy1, *delta, *prio, *weights, *samp_prob;
   float *slabs, *fc4_slabs, *afc4_slabs, *lin_ws;
   int64_t lin_ws_floats, slab_stride;
+  int variant;                      // DRA_VAR_* mask fixed at creation
+  float* lslabs[3];                 // per-layer slab buffers (one-pass weight gradients): [n_slabs][w | b]
+  int64_t lstride[3];
+  int lnslabs[3];
+  int n_partials;                   // doubles the norm pass of this configuration writes
   double* partials;
   float *loss, *norm;
   dra_dqn_step_params* prm_dev;     // device copy read by the actor kernels
@@ -60,9 +65,15 @@ struct dra_dqn_learner {
   int stage_k;
   hipEvent_t stage_ev[8];
   bool stage_used[8];
-  hipGraphExec_t g_update, g_actor;
-  bool g_update_ready, g_actor_ready;
-  int g_actor_n;
+  hipGraphExec_t g_update;
+  bool g_update_ready;
+  // actor graphs are keyed by (n_env, parameter block they read): online params in in-order mode, one of the
+  // two actor copies in async mode (DRA_VAR_ACTOR_PARAMS)
+  struct { hipGraphExec_t exec; const float* params; int n_env; bool ready; } g_actor[3];
+  float* pa[2];                     // double-buffered parameter copies the async actor reads
+  int pa_cur;                       // pa[pa_cur] holds the newest completed parameters
+  bool pa_valid;
+  float* ah4;                       // actor fc4 output (v2)
   hipStream_t side;                 // fork stream for graph branches
   hipEvent_t ev_fork, ev_join[4];
   hipEvent_t ev_actor_done, ev_gather_done, ev_step_done;
@@ -105,11 +116,28 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= alloc_f(&l->delta, B); rc |= alloc_f(&l->prio, B); rc |= alloc_f(&l->weights, B); rc |= alloc_f(&l->samp_prob, B);
   l->slab_stride = cfg->conv_end;  // conv segment occupies [0, conv_end) of the flat layout
   rc |= alloc_f(&l->slabs, (int64_t)cfg->ksplit * l->slab_stride);
+  if (cfg->variant >= 0) l->variant = cfg->variant;
+  else rc |= dra_get_tuning(&l->variant);
+  if (l->variant & DRA_VAR_ONESHOT_WGRAD) {
+    // layer L's segment of the flat gradient is [offset(W_L), offset(b_L) + OC): weight then bias, contiguous
+    const int wi[3] = {P_W1, P_W2, P_W3};
+    const int64_t seg_end[3] = {cfg->offset[P_W2], cfg->offset[P_W3], cfg->conv_end};
+    for (int k = 0; k < 3; ++k) {
+      l->lstride[k] = seg_end[k] - cfg->offset[wi[k]];
+      rc |= dra_conv_wgrad_slabs(k + 1, B, cfg->ksplit, l->variant, &l->lnslabs[k]);
+      if (rc) break;
+      rc |= alloc_f(&l->lslabs[k], (int64_t)l->lnslabs[k] * l->lstride[k]);
+      if (!rc) rc |= (int)hipMemset(l->lslabs[k], 0, (size_t)l->lnslabs[k] * l->lstride[k] * sizeof(float));
+    }
+  }
+  l->n_partials = 2 * dra_norm_partials();
+  rc |= alloc_f(&l->ah4, 512);
+  if (l->variant & DRA_VAR_ACTOR_PARAMS) { rc |= alloc_f(&l->pa[0], cfg->n_params); rc |= alloc_f(&l->pa[1], cfg->n_params); }
   rc |= alloc_f(&l->fc4_slabs, (int64_t)3 * kFc4Split * B * 512);
   rc |= alloc_f(&l->afc4_slabs, (int64_t)kFc4Split * 512);
   l->lin_ws_floats = (int64_t)3 * 32 * B * 512;
   rc |= alloc_f(&l->lin_ws, l->lin_ws_floats);
-  rc |= (int)hipMalloc(&l->partials, (size_t)2 * dra_norm_partials() * sizeof(double));
+  rc |= (int)hipMalloc(&l->partials, (size_t)dra_norm_partials_max() * sizeof(double));
   rc |= alloc_f(&l->loss, 1); rc |= alloc_f(&l->norm, 1);
   rc |= (int)hipMalloc(&l->prm_dev, sizeof(dra_dqn_step_params));
   rc |= (int)hipHostMalloc(&l->prm_stage, 8 * sizeof(dra_dqn_step_params), hipHostMallocDefault);
@@ -117,7 +145,7 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   if (rc) { delete l; return rc; }
   // slab gaps (alignment padding between tensors) are never written: keep them zero
   rc |= (int)hipMemset(l->slabs, 0, (size_t)cfg->ksplit * l->slab_stride * sizeof(float));
-  rc |= (int)hipMemset(l->partials, 0, (size_t)2 * dra_norm_partials() * sizeof(double));
+  rc |= (int)hipMemset(l->partials, 0, (size_t)dra_norm_partials_max() * sizeof(double));
   rc |= (int)hipMemset(l->prm_dev, 0, sizeof(dra_dqn_step_params));
   for (int k = 0; k <= K_COUNT; ++k) rc |= (int)hipEventCreate(&l->ev[k]);
   for (int k = 0; k < 8; ++k) rc |= (int)hipEventCreateWithFlags(&l->stage_ev[k], hipEventDisableTiming);
@@ -136,11 +164,14 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (!l) return DRA_OK;
   (void)hipDeviceSynchronize();
   if (l->g_update_ready) (void)hipGraphExecDestroy(l->g_update);
-  if (l->g_actor_ready) (void)hipGraphExecDestroy(l->g_actor);
+  for (auto& ga : l->g_actor) if (ga.ready) (void)hipGraphExecDestroy(ga.exec);
+  for (int k = 0; k < 2; ++k) if (l->pa[k]) (void)hipFree(l->pa[k]);
+  if (l->ah4) (void)hipFree(l->ah4);
   void* bufs[] = {l->state, l->next_state, l->act_state, l->action, l->idx, l->reward, l->mask, l->h4, l->ay1, l->ay2,
                   l->ay3, l->aq, l->dq, l->dh4, l->dy3, l->dy2, l->dy1, l->delta, l->prio, l->weights, l->samp_prob,
                   l->slabs, l->fc4_slabs, l->afc4_slabs, l->lin_ws, l->partials, l->loss, l->norm, l->prm_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
+  for (int k = 0; k < 3; ++k) if (l->lslabs[k]) (void)hipFree(l->lslabs[k]);
   for (int z = 0; z < 3; ++z) {
     if (l->y1[z]) (void)hipFree(l->y1[z]);
     if (l->y2[z]) (void)hipFree(l->y2[z]);
@@ -290,15 +321,18 @@ head_wgrad_kernel(const float* __restrict__ dq, const float* __restrict__ h4, in
     if (_rc != DRA_OK) return _rc;                                             \
   } while (0)
 
-static int launch_gather(dra_dqn_learner* l, hipStream_t st) {
-  return dra_ring_gather(l->ring, l->idx, l->c.batch, l->state, l->next_state, l->action, nullptr, nullptr, l->reward,
+// `idx`: device buffer, or (DRA_VAR_PINNED_IDX) the pinned staging slot itself -- the 160 gather workgroups
+// read their 8-byte index over the host link (~1-2 us, inside the kernel) instead of waiting for a
+// separate 4-5 us copy command on the update's critical path.
+static int launch_gather(dra_dqn_learner* l, hipStream_t st, const int64_t* idx = nullptr) {
+  return dra_ring_gather(l->ring, idx ? idx : l->idx, l->c.batch, l->state, l->next_state, l->action, nullptr, nullptr, l->reward,
                          l->mask, (void*)st);
 }
 
-static int launch_optimizer(dra_dqn_learner* l, hipStream_t st) {
+static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = nullptr) {
   const dra_dqn_config& c = l->c;
-  return dra_rmsprop_step(l->p, l->g, l->s1, l->s2, c.n_params, l->partials, 2 * dra_norm_partials(), c.gradient_clip,
-                          c.lr, c.alpha, c.eps, c.centered, l->norm, (void*)st);
+  return dra_rmsprop_step_copy(l->p, l->g, l->s1, l->s2, c.n_params, l->partials, l->n_partials, c.gradient_clip,
+                               c.lr, c.alpha, c.eps, c.centered, l->norm, p_copy, (void*)st);
 }
 
 // forward + loss + backward + gradient norm (everything between the gather and the optimizer).
@@ -327,7 +361,8 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   STEP(K_CONV3_F, dra_conv_fwd_koc(3, nz, x3, w3, b3, l->y3, B, 0, 1.0, DRA_ACT_RELU, s));
   const float* x4[3] = {l->y3[0], l->y3[1], l->y3[2]};
   const float* w4[3] = {P + o[P_W4], T + o[P_W4], P + o[P_W4]};
-  STEP(K_FC4_F, dra_linear_fwd_slabs(nz, x4, w4, B, 3136, 512, kFc4Split, l->fc4_slabs, s));
+  if (l->variant & DRA_VAR_ONESHOT_FWD) STEP(K_FC4_F, dra_linear_fwd_slabs_one(nz, x4, w4, B, 3136, 512, kFc4Split, l->fc4_slabs, s));
+  else STEP(K_FC4_F, dra_linear_fwd_slabs(nz, x4, w4, B, 3136, 512, kFc4Split, l->fc4_slabs, s));
   if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_HEAD], st));
   hipLaunchKernelGGL(head_fused_kernel<kFc4Split>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                      P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
@@ -343,6 +378,46 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   }
   float* G = l->g;
   float* S = l->slabs;
+  if (l->variant & (DRA_VAR_FUSED_BWD | DRA_VAR_ONESHOT_WGRAD)) {
+    // one launch per layer: {head wgrad, fc4 wgrad, fc4 dgrad} {conv3 wgrad, dgrad} {conv2 wgrad, dgrad} {conv1 wgrad};
+    // the profile charges each launch to its input-gradient group (the sibling groups read ~0)
+    const int var = l->variant;
+    const bool own = var & DRA_VAR_ONESHOT_WGRAD;  // per-layer slab buffers
+    float* dw[3]; float* dbs[3]; int64_t stride[3];
+    const int wi[3] = {P_W1, P_W2, P_W3}, bi_[3] = {P_B1, P_B2, P_B3};
+    for (int k = 0; k < 3; ++k) {
+      dw[k] = own ? l->lslabs[k] : S + o[wi[k]];
+      dbs[k] = own ? l->lslabs[k] + (o[bi_[k]] - o[wi[k]]) : S + o[bi_[k]];
+      stride[k] = own ? l->lstride[k] : l->slab_stride;
+    }
+    if (l->profiling) { DRA_HIP(hipEventRecord(l->ev[K_HEAD_BW], st)); DRA_HIP(hipEventRecord(l->ev[K_FC4_BW], st)); }
+    STEP(K_FC4_BX, dra_fc_bwd_fused(l->dq, l->h4, l->dh4, l->y3[0], P + o[P_W4], G + o[P_WH], G + o[P_BH], G + o[P_W4],
+                                    G + o[P_B4], l->dy3, B, A, 3136, DRA_ACT_RELU, var, s));
+    if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV3_BW], st));
+    STEP(K_CONV3_BX, dra_conv_bwd_fused(3, l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], c.ksplit,
+                                        l->dy2, B, 0, 1.0, DRA_ACT_RELU, var, s));
+    if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV2_BW], st));
+    STEP(K_CONV2_BX, dra_conv_bwd_fused(2, l->dy2, l->y1[0], P + o[P_W2], l->y1[0], dw[1], dbs[1], stride[1], c.ksplit,
+                                        l->dy1, B, 0, 1.0, DRA_ACT_RELU, var, s));
+    STEP(K_CONV1_BW, dra_conv_bwd_fused(1, l->dy1, l->state, nullptr, nullptr, dw[0], dbs[0], stride[0], c.ksplit, nullptr,
+                                        B, 1, c.u8_coef, DRA_ACT_RELU, var, s));
+    if (own) {
+      dra_fold_seg segs[3];
+      for (int k = 0; k < 3; ++k) {
+        segs[k].begin = o[wi[k]]; segs[k].count = l->lstride[k]; segs[k].slabs = l->lslabs[k];
+        segs[k].slab_stride = l->lstride[k]; segs[k].n_slabs = l->lnslabs[k]; segs[k].reserved = 0;
+      }
+      int np_out = 0;
+      STEP(K_NORM, dra_grad_sqnorm_segs(G, c.n_params, segs, 3, l->partials, &np_out, s));
+      l->n_partials = np_out;
+      if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_STEP], st));
+      return DRA_OK;
+    }
+    const int np = dra_norm_partials();
+    STEP(K_NORM, dra_grad_sqnorm(G, c.conv_end, S, c.ksplit, l->slab_stride, l->partials, s));
+    if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_STEP], st));
+    return dra_grad_sqnorm(G + c.conv_end, c.n_params - c.conv_end, nullptr, 0, 0, l->partials + np, s);
+  }
   hipStream_t sd = fork ? l->side : st;
   void* sds = (void*)sd;
   if (fork) { DRA_HIP(hipEventRecord(l->ev_fork, st)); DRA_HIP(hipStreamWaitEvent(sd, l->ev_fork, 0)); }
@@ -393,11 +468,14 @@ DRA_API int dra_dqn_learner_update(dra_dqn_learner* l, int use_graph, int per, f
   if (!l) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
   l->profiling = false;
+  l->pa_valid = false;
   int rc = launch_gather(l, st);
   if (rc) return rc;
   rc = (use_graph && !per) ? body_graph(l, st) : run_body(l, st, per, beta, 0);
   if (rc) return rc;
-  return launch_optimizer(l, st);
+  if ((rc = launch_optimizer(l, st))) return rc;
+  DRA_HIP(hipEventRecord(l->ev_step_done, st));
+  return DRA_OK;
 }
 
 // Eager update with a HIP event before every kernel group (on the launch stream); returns the
@@ -524,12 +602,131 @@ actor_head_kernel(const dra_dqn_step_params* __restrict__ prm, int e, const floa
   }
 }
 
-static int run_actor_steps(dra_dqn_learner* l, int n_env, hipStream_t st) {
+// ---- actor v2 (DRA_VAR_ACTOR_V2): 5 kernels per env step instead of 6, none of them K-chunked:
+//   conv1 reads its 4-frame stack straight from the ring (dra_conv1_fwd_koc_ring), conv2, conv3,
+//   actor_fc4_kernel  : batch-1 fc4 as a GEMV -- one wave per output row, the 12.5 KB row and the input as
+//                       float4 loads all in flight, wave reduction, bias + ReLU;
+//   actor_head_env_kernel: head + epsilon-greedy + action record of env step e, then the ENVIRONMENT step:
+//                       the synthetic frame / reward / mask of transition e+1 (what env.step(action)
+//                       returns, envs.py:140-141).  env_frame_kernel produces the frame of e = 0.
+__device__ __forceinline__ void synth_transition(const dra_dqn_step_params* __restrict__ prm, int e,
+                                                 uint8_t* __restrict__ frames, double* __restrict__ rewards,
+                                                 int32_t* __restrict__ masks, uint64_t seed, int done_period) {
+  const int64_t counter = prm->counter[e];
+  if (counter < 0) return;  // frame already in the ring
+  const int64_t slot = prm->slot[e];
+  uint64_t* dst = reinterpret_cast<uint64_t*>(frames + slot * 7056);
+  const uint64_t base = seed * 0x9E3779B97F4A7C15ull + (uint64_t)counter * 882ull;
+  for (int w = threadIdx.x; w < 882; w += blockDim.x) dst[w] = mix64(base + (uint64_t)w);
+  if (threadIdx.x == 0) {
+    const uint64_t hh = mix64((seed + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
+    const uint32_t u = (uint32_t)(hh >> 32) % 10u;
+    rewards[slot] = (u == 0) ? -1.0 : ((u == 9) ? 1.0 : 0.0);
+    const uint64_t h2 = mix64((seed + 2) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
+    masks[slot] = ((h2 % (uint64_t)done_period) == 0) ? 0 : 1;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+env_frame_kernel(const dra_dqn_step_params* __restrict__ prm, int e, uint8_t* __restrict__ frames,
+                 double* __restrict__ rewards, int32_t* __restrict__ masks, uint64_t seed, int done_period) {
+  synth_transition(prm, e, frames, rewards, masks, seed, done_period);
+}
+
+__global__ void __launch_bounds__(256)
+actor_fc4_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                 float* __restrict__ h4, int in_features) {
+  constexpr int R = 13;  // float4 per lane: 3136 / 4 / 64 = 12.25
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  const int nv = in_features >> 2;
+  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w + (int64_t)row * in_features);
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+  float4 wv[R], xv[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int i = min(lane + 64 * q, nv - 1);
+    wv[q] = w4[i];
+    xv[q] = x4[i];
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    float4 a = wv[q], b = xv[q];
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));  // loads stay unconditional and batched
+    if (lane + 64 * q < nv) acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const float v = acc + bias[row];
+    h4[row] = v > 0.f ? v : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+actor_head_env_kernel(const dra_dqn_step_params* __restrict__ prm, int e, const float* __restrict__ h4,
+                      const float* __restrict__ wh, const float* __restrict__ bh, int A,
+                      uint8_t* __restrict__ ring_actions, float* __restrict__ q_out, uint8_t* __restrict__ frames,
+                      double* __restrict__ rewards, int32_t* __restrict__ masks, uint64_t seed, int done_period) {
+  __shared__ float s_q[64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int a = wave; a < A; a += 4) {
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part += h4[lane + 64 * i] * wh[a * 512 + lane + 64 * i];
+    part = wave_sum(part);
+    if (lane == 0) s_q[a] = part + bh[a];
+  }
+  __syncthreads();
+  if (threadIdx.x < A && q_out) q_out[threadIdx.x] = s_q[threadIdx.x];
+  if (threadIdx.x == 0) {
+    int best = 0;
+    float bv = s_q[0];
+    for (int a = 1; a < A; ++a) if (s_q[a] > bv) { bv = s_q[a]; best = a; }  // np.argmax: first max
+    const int64_t act = (prm->dice[e] < prm->epsilon[e]) ? (int64_t)prm->random_action[e] : (int64_t)best;
+    if (prm->store_action[e]) *reinterpret_cast<int64_t*>(ring_actions + prm->slot[e] * 8) = act;
+  }
+  // env.step(action): the next observation (synthetic source: independent of the action taken)
+  if (e + 1 < prm->n_env) synth_transition(prm, e + 1, frames, rewards, masks, seed, done_period);
+}
+
+static int run_actor_steps_v2(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
   const dra_dqn_config& c = l->c;
   void *frames, *actions, *rewards, *masks;
   int rc = dra_ring_pointers(l->ring, &frames, &actions, &rewards, &masks);
   if (rc) return rc;
-  const float* P = l->p;
+  const int64_t* o = c.offset;
+  void* s = (void*)st;
+  hipLaunchKernelGGL(env_frame_kernel, dim3(1), dim3(256), 0, st, (const dra_dqn_step_params*)l->prm_dev, 0,
+                     (uint8_t*)frames, (double*)rewards, (int32_t*)masks, (uint64_t)c.env_seed, (int)c.env_done_period);
+  DRA_LAUNCH_CHECK();
+  for (int e = 0; e < n_env; ++e) {
+    if ((rc = dra_conv1_fwd_koc_ring(frames, &l->prm_dev->slot[e], c.ring_capacity, P + o[P_W1], P + o[P_B1], l->ay1,
+                                     c.u8_coef, DRA_ACT_RELU, s)))
+      return rc;
+    const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
+    float* y2[1] = {l->ay2};
+    if ((rc = dra_conv_fwd_koc(2, 1, x2, w2, b2, y2, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+    const void* x3[1] = {l->ay2}; const float* w3[1] = {P + o[P_W3]}; const float* b3[1] = {P + o[P_B3]};
+    float* y3[1] = {l->ay3};
+    if ((rc = dra_conv_fwd_koc(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+    hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
+                       l->ah4, 3136);
+    DRA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(actor_head_env_kernel, dim3(1), dim3(256), 0, st, (const dra_dqn_step_params*)l->prm_dev, e,
+                       (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq,
+                       (uint8_t*)frames, (double*)rewards, (int32_t*)masks, (uint64_t)c.env_seed, (int)c.env_done_period);
+    DRA_LAUNCH_CHECK();
+  }
+  return DRA_OK;
+}
+
+static int run_actor_steps(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
+  if (l->variant & DRA_VAR_ACTOR_V2) return run_actor_steps_v2(l, n_env, P, st);
+  const dra_dqn_config& c = l->c;
+  void *frames, *actions, *rewards, *masks;
+  int rc = dra_ring_pointers(l->ring, &frames, &actions, &rewards, &masks);
+  if (rc) return rc;
   const int64_t* o = c.offset;
   void* s = (void*)st;
   for (int e = 0; e < n_env; ++e) {
@@ -556,24 +753,30 @@ static int run_actor_steps(dra_dqn_learner* l, int n_env, hipStream_t st) {
   return DRA_OK;
 }
 
-static int actor_graph(dra_dqn_learner* l, int n_env, hipStream_t st) {
-  if (l->g_actor_ready && l->g_actor_n != n_env) {
-    (void)hipGraphExecDestroy(l->g_actor);
-    l->g_actor_ready = false;
-  }
-  if (!l->g_actor_ready) {
+static int actor_graph(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
+  int slot = -1;
+  for (int k = 0; k < 3; ++k) if (l->g_actor[k].ready && l->g_actor[k].params == P && l->g_actor[k].n_env == n_env) slot = k;
+  if (slot < 0) {
+    for (int k = 0; k < 3 && slot < 0; ++k) if (!l->g_actor[k].ready) slot = k;
+    if (slot < 0) {  // evict an entry of the same parameter block (n_env changed), else entry 0
+      slot = 0;
+      for (int k = 0; k < 3; ++k) if (l->g_actor[k].params == P) slot = k;
+      (void)hipGraphExecDestroy(l->g_actor[slot].exec);
+      l->g_actor[slot].ready = false;
+    }
     hipGraph_t graph;
     DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = run_actor_steps(l, n_env, st);
+    int rc = run_actor_steps(l, n_env, P, st);
     hipError_t e = hipStreamEndCapture(st, &graph);
     if (rc != DRA_OK) return rc;
     if (e != hipSuccess) return (int)e;
-    DRA_HIP(hipGraphInstantiate(&l->g_actor, graph, nullptr, nullptr, 0));
+    DRA_HIP(hipGraphInstantiate(&l->g_actor[slot].exec, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);
-    l->g_actor_ready = true;
-    l->g_actor_n = n_env;
+    l->g_actor[slot].ready = true;
+    l->g_actor[slot].params = P;
+    l->g_actor[slot].n_env = n_env;
   }
-  DRA_HIP(hipGraphLaunch(l->g_actor, st));
+  DRA_HIP(hipGraphLaunch(l->g_actor[slot].exec, st));
   return DRA_OK;
 }
 
@@ -597,7 +800,7 @@ DRA_API int dra_dqn_learner_act(dra_dqn_learner* l, const dra_dqn_step_params* p
   memcpy(&l->prm_stage[k], prm, kPrmHeadBytes);
   DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, st));
   DRA_HIP(hipEventRecord(l->stage_ev[k], st));
-  return use_graph ? actor_graph(l, prm->n_env, st) : run_actor_steps(l, prm->n_env, st);
+  return use_graph ? actor_graph(l, prm->n_env, l->p, st) : run_actor_steps(l, prm->n_env, l->p, st);
 }
 
 // One whole agent step (DQN_agent.py:101-138 minus logging): prm->n_env actor transitions, then one
@@ -624,13 +827,17 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
   if (!stream_actor) {  // ---- sync mode
     if (prm->n_env > 0) {
       DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, su));
-      if ((rc = actor_graph(l, prm->n_env, su))) return rc;
+      if ((rc = actor_graph(l, prm->n_env, l->p, su))) return rc;
     }
+    if (do_update) l->pa_valid = false;
     if (do_update) {
-      DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
-      if ((rc = launch_gather(l, su))) return rc;
+      const int64_t* pinned = (l->variant & DRA_VAR_PINNED_IDX) ? l->idx_stage + (size_t)k * 1024 : nullptr;
+      if (!pinned)
+        DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
+      if ((rc = launch_gather(l, su, pinned))) return rc;
       if ((rc = body_graph(l, su))) return rc;
       if ((rc = launch_optimizer(l, su))) return rc;
+      DRA_HIP(hipEventRecord(l->ev_step_done, su));
     }
     DRA_HIP(hipEventRecord(l->stage_ev[k], su));
     return DRA_OK;
@@ -638,23 +845,47 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
   // ---- async mode
   if (do_update) {
     if (l->actor_pending) DRA_HIP(hipStreamWaitEvent(su, l->ev_actor_done, 0));  // transitions of this step are in the ring
-    DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
-    if ((rc = launch_gather(l, su))) return rc;
+    const int64_t* pinned = (l->variant & DRA_VAR_PINNED_IDX) ? l->idx_stage + (size_t)k * 1024 : nullptr;
+    if (!pinned)
+      DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
+    if ((rc = launch_gather(l, su, pinned))) return rc;
     DRA_HIP(hipEventRecord(l->ev_gather_done, su));
   }
+  const bool dbuf = l->variant & DRA_VAR_ACTOR_PARAMS;
+  bool seeded = false;
   if (prm->n_env > 0) {  // issued before the update body so that it starts as soon as the gather is done
     if (do_update) DRA_HIP(hipStreamWaitEvent(sa, l->ev_gather_done, 0));  // do not overwrite slots the gather reads
     DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, sa));
-    if ((rc = actor_graph(l, prm->n_env, sa))) return rc;
+    const float* pact = l->p;
+    if (dbuf) {
+      if (!l->pa_valid) {  // (re)seed the actor copy: first async step, or the parameters changed behind it
+        DRA_HIP(hipStreamWaitEvent(sa, l->ev_step_done, 0));   // after the last optimiser step ...
+        DRA_HIP(hipMemcpyAsync(l->pa[l->pa_cur], l->p, (size_t)l->c.n_params * sizeof(float), hipMemcpyDeviceToDevice, sa));
+        DRA_HIP(hipEventRecord(l->ev_join[0], sa));            // ... and before this step's (see below)
+        l->pa_valid = true;
+        seeded = true;
+      }
+      pact = l->pa[l->pa_cur];
+    }
+    if ((rc = actor_graph(l, prm->n_env, pact, sa))) return rc;
     DRA_HIP(hipEventRecord(l->ev_actor_done, sa));
     l->actor_pending = true;
   }
   if (do_update) {
     if ((rc = body_graph(l, su))) return rc;
-    if (prm->n_env > 0) DRA_HIP(hipStreamWaitEvent(su, l->ev_actor_done, 0));  // config.lock: optimizer excludes actor reads
-    if ((rc = launch_optimizer(l, su))) return rc;
-    DRA_HIP(hipEventRecord(l->ev_step_done, su));
-    DRA_HIP(hipStreamWaitEvent(sa, l->ev_step_done, 0));  // the next actor sees whole optimizer steps only
+    if (dbuf && l->pa_valid) {
+      // the optimiser writes the parameters twice: in place, and into the actor copy the NEXT actor graph will
+      // read; the copy the current actor reads is untouched, so neither side waits for the other
+      if (seeded) DRA_HIP(hipStreamWaitEvent(su, l->ev_join[0], 0));  // the seed copy read the old parameters
+      if ((rc = launch_optimizer(l, su, l->pa[l->pa_cur ^ 1]))) return rc;
+      l->pa_cur ^= 1;
+      DRA_HIP(hipEventRecord(l->ev_step_done, su));
+    } else {
+      if (prm->n_env > 0) DRA_HIP(hipStreamWaitEvent(su, l->ev_actor_done, 0));  // config.lock: optimizer excludes actor reads
+      if ((rc = launch_optimizer(l, su))) return rc;
+      DRA_HIP(hipEventRecord(l->ev_step_done, su));
+      DRA_HIP(hipStreamWaitEvent(sa, l->ev_step_done, 0));  // the next actor sees whole optimizer steps only
+    }
   }
   DRA_HIP(hipEventRecord(l->stage_ev[k], do_update ? su : sa));
   return DRA_OK;

@@ -1,0 +1,541 @@
+// One-memory-round-trip contractions of the DQN update at batch 32, written as "roles" that can share
+// a launch (multi_kernel).
+//
+// Why: at batch 32 every contraction of the update is 0.1-0.2 GFLOP on <= 400 workgroups; the K-chunked
+// implicit GEMM (igemm.h) pays one dependent global-memory round trip (~2 us) per 64-wide chunk and
+// 10-20 integer div/mods per fetched element, so the backward kernels run 11-29 us each at 5-8 % of the
+// fp32 MFMA rate (profiles/r01_*).  The kernels below follow conv_v2.hip's recipe instead:
+//   * a workgroup owns a 32x32 (or a few 32x32) output tile and ALL of its reduction;
+//   * every global load of the workgroup is issued up front (one exposed memory latency);
+//   * the operand whose MFMA lane axis is contiguous in memory goes straight to registers (128-byte
+//     coalesced rows); the other is staged through LDS once, in a layout where the 32 lanes of an
+//     operand read hit 32 different banks and the per-MFMA address is `base + immediate`;
+//   * the reduction is split over the 4 waves and folded through LDS in a fixed order
+//     ((w0+w1)+(w2+w3)), so results are run-to-run deterministic.
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere: an exact fmaf chain, as the 1e-5 parity bar needs.
+#pragma once
+#include "igemm.h"
+
+// 32x32 MFMA C/D row of accumulator register r for half-wave h
+__device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 a;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+  return a;
+}
+
+// Fold the 4 waves' partial accumulators of ONE 32x32 tile through `red` (4096 floats): wave w gets
+// the sums of accumulator registers 4w .. 4w+3.  Caller guarantees `red` is no longer read as operands.
+__device__ __forceinline__ void reduce4(float* __restrict__ red, const f32x16& acc, int wave, int lane, float out[4]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = wave * 4 + q;
+    out[q] = (red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) +
+             (red[(2 * 16 + r) * 64 + lane] + red[(3 * 16 + r) * 64 + lane]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Roles: a role is a POD with  LDS_FLOATS,  run(block, lds)  and a host-side block count; multi_kernel
+// runs up to three independent roles in one launch (block ranges [0,n1) [n1,n1+n2) [n1+n2, ...)).
+struct NoRole {
+  static constexpr int LDS_FLOATS = 0;
+  __device__ __forceinline__ void run(int, float*) const {}
+};
+
+template <class P>
+struct IgemmRole {
+  static constexpr int LDS_FLOATS = igemm_lds_floats<P>();
+  P p;
+  int tiles, ksplit;
+  __device__ __forceinline__ void run(int bid, float* lds) const {
+    const int bx = bid % tiles, r = bid / tiles;
+    const int by = r % ksplit, bz = r / ksplit;
+    igemm_body<P>(p, bx, by, bz, ksplit, lds);
+  }
+};
+
+template <class P>
+static IgemmRole<P> make_igemm_role(const P& p, int ksplit) {
+  IgemmRole<P> r;
+  r.p = p;
+  r.tiles = ((p.M + P::BM - 1) / P::BM) * ((p.N + P::BN - 1) / P::BN);
+  r.ksplit = ksplit;
+  return r;
+}
+
+// amdgpu_waves_per_eu(1, 2): these kernels want registers (every load of a workgroup in flight at once),
+// not occupancy; without it the scheduler throttles loads to stay under 64 VGPRs.
+template <class R1, class R2, class R3>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) multi_kernel(const R1 r1, const R2 r2, const R3 r3, const int n1, const int n2) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  const int b = blockIdx.x;
+  if (b < n1) r1.run(b, dyn_lds);
+  else if (b < n1 + n2) r2.run(b - n1, dyn_lds);
+  else r3.run(b - n1 - n2, dyn_lds);
+}
+
+template <class R1, class R2, class R3>
+static int launch_multi(const R1& r1, int n1, const R2& r2, int n2, const R3& r3, int n3, hipStream_t st) {
+  constexpr int f12 = R1::LDS_FLOATS > R2::LDS_FLOATS ? R1::LDS_FLOATS : R2::LDS_FLOATS;
+  constexpr int fl = f12 > R3::LDS_FLOATS ? f12 : R3::LDS_FLOATS;
+  constexpr size_t bytes = (size_t)fl * sizeof(float);
+  static_assert(bytes <= 160 * 1024, "LDS per workgroup");
+  if (n1 < 0 || n2 < 0 || n3 < 0 || n1 + n2 + n3 < 1) return DRA_EINVAL;
+  static bool attr_set = false;  // one flag per instantiation
+  if (bytes > 64 * 1024 && !attr_set) {
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&multi_kernel<R1, R2, R3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((multi_kernel<R1, R2, R3>), dim3(n1 + n2 + n3), dim3(256), bytes, st, r1, r2, r3, n1, n2);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// VanillaNet head weight gradient (network_heads.py:18-21 backward):
+//   dWh[a][k] = sum_b dq[b][a] * h4[b][k] ;  dbh[a] = sum_b dq[b][a].   blocks = A * 2 (256 k each)
+struct HeadWgradRole {
+  static constexpr int LDS_FLOATS = 0;
+  const float* dq;   // [B][A]
+  const float* h4;   // [B][512]
+  float* dwh;        // [A][512]
+  float* dbh;        // [A]
+  int B, A;
+  __device__ __forceinline__ void run(int bid, float*) const {
+    const int a = bid >> 1, k = (bid & 1) * 256 + threadIdx.x;
+    float acc = 0.f, accb = 0.f;
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {
+      float d[8], h[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { d[i] = dq[(int64_t)(b + i) * A + a]; h[i] = h4[(int64_t)(b + i) * 512 + k]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { acc += d[i] * h[i]; accb += d[i]; }
+    }
+    for (; b < B; ++b) {
+      const float d = dq[(int64_t)b * A + a];
+      acc += d * h4[(int64_t)b * 512 + k];
+      accb += d;
+    }
+    dwh[a * 512 + k] = acc;
+    if (k == 0) dbh[a] = accb;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Linear input gradient, whole reduction in one pass (fc4: O = 512):
+//   dx[b][i] = act'(xact[b][i]) * sum_o dy[b][o] * W[o][i]          M = b (32 rows), N = i, K = o
+// A = dy rows -> LDS [32][O+1] (coalesced loads, conflict-free lane=row reads);  B = W[o][i0..i0+31]
+// straight to registers (128-byte rows).  MFMA slot (j, h) of wave w <-> o = w*O/4 + h*O/8 + j.
+template <int O>
+struct LinDgradOne {
+  static constexpr int KW = O / 4, NJ = KW / 2, LDA = O + 1, RA = 32 * O / 256;
+  static constexpr int LDS_FLOATS = 32 * LDA > 4096 ? 32 * LDA : 4096;
+  static_assert(O % 8 == 0 && (32 * O) % 256 == 0, "reduction split over 4 waves x 2 half-waves");
+  const float* dy;    // [B][O]
+  const float* w;     // [O][I]
+  const float* xact;  // [B][I] or null
+  float* dx;          // [B][I]
+  int B, I, act, tiles_n;
+  __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int bm = bid / tiles_n, bn = bid - bm * tiles_n;
+    const int m0 = bm * 32, n0 = bn * 32;
+    const int ncol = min(n0 + li, I - 1);
+    const int kb = wave * KW + h * NJ;
+    float breg[NJ];
+    {
+      const float* wp = w + (int64_t)kb * I + ncol;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) breg[j] = wp[(int64_t)j * I];
+    }
+    float araw[RA];
+#pragma unroll
+    for (int q = 0; q < RA; ++q) {
+      const int e = tid + 256 * q, row = e / O, col = e - row * O;
+      araw[q] = dy[(int64_t)min(m0 + row, B - 1) * O + col];
+    }
+    float aux[4];
+    {
+      const float* src = xact ? xact : dx;  // null xact: any mapped address, value ignored
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = min(m0 + mfma_row(wave * 4 + q, h), B - 1);
+        aux[q] = src[(int64_t)m * I + ncol];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first LDS write below
+#pragma unroll
+    for (int q = 0; q < RA; ++q) {
+      const int e = tid + 256 * q, row = e / O, col = e - row * O;
+      lds[row * LDA + col] = araw[q];
+    }
+    __syncthreads();
+    f32x16 acc = zero16();
+    const float* ap = lds + li * LDA + kb;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[j], breg[j], acc, 0, 0, 0);
+    __syncthreads();
+    float s[4];
+    reduce4(lds, acc, wave, lane, s);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + mfma_row(wave * 4 + q, h);
+      if (m < B && n0 + li < I) dx[(int64_t)m * I + n0 + li] = xact ? s[q] * act_grad(aux[q], act) : s[q];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Linear forward partial sums, one K-split per workgroup, whole split in one pass (fc4: I = 3136, KS = 8):
+//   slabs[z][s][b][o] = sum_{k in split s} x_z[b][k] * W_z[o][k]      M = b, N = o, K = I / KS
+// Both operands are k-contiguous in memory: float4 loads -> LDS [32][KPS+1] each; lane = row reads are
+// conflict-free (odd row stride).  The consumer (head_fused_kernel) reduces the KS slabs.
+template <int I, int KS>
+struct LinFwdSlabsOne {
+  static constexpr int KPS = I / KS, KW = KPS / 4, NJ = KW / 2, LD = KPS + 1;
+  static constexpr int V = KPS / 4, NV = 32 * V, RV = (NV + 255) / 256;
+  static constexpr int LDS_FLOATS = 2 * 32 * LD > 4096 ? 2 * 32 * LD : 4096;
+  static_assert(I % KS == 0 && KPS % 8 == 0, "K split: float4 rows, even k per half-wave");
+  const float* x[kMaxZ];  // [B][I]
+  const float* w[kMaxZ];  // [O][I]
+  float* slabs;           // [nz][KS][B][O]
+  int B, O, tiles_n, tiles_m;
+  __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int bn = bid % tiles_n;
+    int r = bid / tiles_n;
+    const int bm = r % tiles_m;
+    r /= tiles_m;
+    const int s = r % KS, z = r / KS;
+    const int m0 = bm * 32, n0 = bn * 32, k0 = s * KPS;
+    const float* __restrict__ xz = x[z];
+    const float* __restrict__ wz = w[z];
+    float4 xa[RV], wa[RV];
+#pragma unroll
+    for (int q = 0; q < RV; ++q) {
+      const int e = min(tid + 256 * q, NV - 1), row = e / V, c4 = e - row * V;
+      xa[q] = *reinterpret_cast<const float4*>(xz + (int64_t)min(m0 + row, B - 1) * I + k0 + 4 * c4);
+      wa[q] = *reinterpret_cast<const float4*>(wz + (int64_t)min(n0 + row, O - 1) * I + k0 + 4 * c4);
+    }
+    float* xs = lds;
+    float* ws = lds + 32 * LD;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < RV; ++q) {
+      const int e = tid + 256 * q;
+      if (e < NV) {
+        const int row = e / V, c4 = e - row * V;
+        float* dx_ = xs + row * LD + 4 * c4;
+        float* dw_ = ws + row * LD + 4 * c4;
+        dx_[0] = xa[q].x; dx_[1] = xa[q].y; dx_[2] = xa[q].z; dx_[3] = xa[q].w;
+        dw_[0] = wa[q].x; dw_[1] = wa[q].y; dw_[2] = wa[q].z; dw_[3] = wa[q].w;
+      }
+    }
+    __syncthreads();
+    f32x16 acc = zero16();
+    const float* ap = xs + li * LD + wave * KW + h * NJ;
+    const float* bp = ws + li * LD + wave * KW + h * NJ;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[j], bp[j], acc, 0, 0, 0);
+    __syncthreads();
+    float sum[4];
+    reduce4(lds, acc, wave, lane, sum);
+    float* out = slabs + ((int64_t)(z * KS + s) * B) * O;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + mfma_row(wave * 4 + q, h);
+      if (m < B && n0 + li < O) out[(int64_t)m * O + n0 + li] = sum[q];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Convolution input gradient with KOC weights, one pass (layers 2 and 3 of NatureConvBody).
+// Stride-phase decomposition as in ConvDgradKoc: phase (ph, pw) covers input pixels ih = ih2*S + ph,
+// iw = iw2*S + pw and only taps kh = kh2*S + ph, kw = kw2*S + pw reach them, so each phase is a dense
+// KPxKP correlation over the zero-padded output gradient:
+//   dXpre[b][c][ih][iw] = act'(X[b][c][ih][iw]) * sum_(oc,kh2,kw2) dYpad[b][oc][ih2-kh2+PAD][iw2-kw2+PAD] * Wt[(c,kh,kw)][oc]
+// Workgroup = (sample, phase, 32 positions of the phase, 32 input channels).  dY[b] goes to LDS once,
+// zero-padded ([OC][DH][RW]); MFMA lane li of the B operand is a position, so every B read is
+// `base(position) + immediate(oc, tap)`.  The A operand (weights, lane li = input channel c) is read
+// straight from the KOC tensor: slot (jj, h) of wave w <-> oc = 16w + 8h + jj, i.e. two float4 per tap.
+template <class G>
+struct ConvDgradOne {
+  static constexpr int S = G::S, KP = (G::KH + S - 1) / S, NPH = S * S, HP = (G::H + S - 1) / S, PP = HP * HP;
+  static constexpr int PAD = KP - 1, DH = G::OH + 2 * PAD, RW = DH, CS = DH * RW;
+  static constexpr int TPP = (PP + 31) / 32;
+  static constexpr int OCW = G::OC / 4, OCH = OCW / 2, NT = KP * KP, NJ = NT * OCH;
+  static constexpr int MT = G::C / 32;
+  static constexpr int NCELL = G::OC * CS, RQ = (NCELL + 255) / 256;
+  static constexpr int LDS_FLOATS = NCELL > 4096 ? NCELL : 4096;
+  static_assert(G::KH % S == 0, "every stride phase has KP x KP taps");
+  static_assert(HP + PAD == DH, "padded gradient covers every shifted read");
+  static_assert(G::OC % 32 == 0 && OCH % 4 == 0 && G::C % 32 == 0, "float4 weight runs per half-wave");
+  const float* dy;    // [B][OC][OH][OH] pre-activation gradient of this layer's output
+  const float* wt;    // [(c,kh,kw)][OC]
+  const float* xact;  // [B][C][H][H] this layer's input (post-activation) or null
+  float* dx;          // [B][C][H][H]
+  int B, act;
+  __host__ int blocks() const { return B * NPH * TPP * MT; }
+  __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int mt = bid % MT;
+    int r = bid / MT;
+    const int tile = r % TPP;
+    r /= TPP;
+    const int phi = r % NPH, bi = r / NPH;
+    const int ph = phi / S, pw = phi - ph * S;
+    const int c0 = mt * 32, p0 = tile * 32;
+    const int np = min(32, PP - p0);
+    // ---- weights: lane li <-> input channel c0 + li
+    float4 areg[NT][OCH / 4];
+    {
+      const float* wl = wt + (int64_t)(c0 + li) * G::KK * G::OC + wave * OCW + h * OCH;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int kh = (t / KP) * S + ph, kw = (t % KP) * S + pw;
+#pragma unroll
+        for (int v = 0; v < OCH / 4; ++v)
+          areg[t][v] = *reinterpret_cast<const float4*>(wl + (kh * G::KH + kw) * G::OC + 4 * v);
+      }
+    }
+    // ---- zero-padded dY[bi] -> LDS
+    float raw[RQ];
+    const float* dyb = dy + (int64_t)bi * G::OC * G::P;
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int e = min(tid + 256 * q, NCELL - 1);
+      const int oc = e / CS, rem = e - oc * CS, rr = rem / RW, cc = rem - rr * RW;
+      const int oh = min(max(rr - PAD, 0), G::OH - 1), ow = min(max(cc - PAD, 0), G::OH - 1);
+      raw[q] = dyb[(oc * G::OH + oh) * G::OH + ow];
+    }
+    // ---- epilogue side input (activation-derivative source), loaded with everything else
+    const int pj = min(li, np - 1);
+    const int ih2 = (p0 + pj) / HP, iw2 = (p0 + pj) - ih2 * HP;
+    const int ih = ih2 * S + ph, iw = iw2 * S + pw;
+    const bool inside = ih < G::H && iw < G::H;
+    const int pix = min(ih, G::H - 1) * G::H + min(iw, G::H - 1);
+    float aux[4];
+    {
+      const float* src = xact ? xact : dx;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + mfma_row(wave * 4 + q, h);
+        aux[q] = src[((int64_t)bi * G::C + c) * G::HW + pix];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      const int e = tid + 256 * q;
+      float v = raw[q];
+      asm volatile("" : "+v"(v));  // keep the loads unconditional and batched (see igemm.h)
+      if (e < NCELL) {
+        const int oc = e / CS, rem = e - oc * CS, rr = rem / RW, cc = rem - rr * RW;
+        const bool in = rr >= PAD && rr < PAD + G::OH && cc >= PAD && cc < PAD + G::OH;
+        lds[e] = in ? v : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: B operand of lane li = padded gradient at (ih2 - kh2 + PAD, iw2 - kw2 + PAD)
+    f32x16 acc = zero16();
+    const float* bptr = lds + (wave * OCW + h * OCH) * CS + ih2 * RW + iw2;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int kh2 = t / KP, kw2 = t % KP;
+#pragma unroll
+      for (int jj = 0; jj < OCH; ++jj) {
+        const float4 av = areg[t][jj / 4];
+        const float a = (jj % 4 == 0) ? av.x : ((jj % 4 == 1) ? av.y : ((jj % 4 == 2) ? av.z : av.w));
+        const float b = bptr[jj * CS + (PAD - kh2) * RW + (PAD - kw2)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    float s[4];
+    reduce4(lds, acc, wave, lane, s);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + mfma_row(wave * 4 + q, h);
+      if (li < np && inside) dx[((int64_t)bi * G::C + c) * G::HW + pix] = xact ? s[q] * act_grad(aux[q], act) : s[q];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Convolution weight gradient in the KOC layout, one pass:
+//   dWt[k][oc] = sum_(b,p) Xcol[k][(b,p)] * dY[b][oc][p],  k = (c,kh,kw);   db[oc] = sum_(b,p) dY[b][oc][p]
+// Workgroup = (sample b, chunk of ROWS output rows, group of MTG 32-row k tiles): M = k (lane li = tap),
+// N = oc (lane li = output channel), reduction over the chunk's positions.  The input rows the chunk
+// touches are staged to LDS once ([channel][row][RW], uint8 frames normalised f32(f64(v)*coef) on the
+// way in); dY of the chunk is staged transposed ([oh][ow][OC+1]) so the B operand is a conflict-free
+// lane = oc read.  The two k-slices of an MFMA are the even / odd output columns of the same row, so
+// both operand addresses are `lane base + immediate`.  Every (sample, chunk) writes its own slab:
+// slab index = b * (OH/ROWS) + chunk; the fold happens in the gradient-norm pass (dra_grad_sqnorm_segs).
+template <class G, int ROWS, int MTG, int RW_, int CSPAD, bool U8>
+struct ConvWgradOne {
+  static constexpr int S = G::S, OH = G::OH, OWP = (OH + 1) & ~1, NPAIR = OWP / 2, NJ = ROWS * NPAIR;
+  static constexpr int NCHUNK = OH / ROWS;
+  static constexpr int MTILES = G::K / 32, NGRP = MTILES / MTG, NTL = G::OC / 32, TILES = MTG * NTL;
+  static constexpr int TPW = (TILES + 3) / 4;
+  static constexpr int NR = (ROWS - 1) * S + G::KH;            // input rows a chunk touches
+  static constexpr int RW = RW_, CS = NR * RW + CSPAD;          // LDS row / channel strides of the image
+  // channels a group of MTG*32 consecutive k can touch (exact when groups start on channel boundaries)
+  static constexpr int NCHMAX = ((MTG * 32) % G::KK == 0) ? (MTG * 32) / G::KK : (MTG * 32 + G::KK - 2) / G::KK + 1;
+  static constexpr int NCH = NCHMAX < G::C ? NCHMAX : G::C;
+  static constexpr int IMG = NCH * CS + RW;                     // + zeroed tail for the odd-column pad slot
+  static constexpr int LDB = G::OC + 1, NPOS = ROWS * OWP, DYF = NPOS * LDB;
+  static constexpr int LDS_FLOATS = IMG + DYF;
+  static_assert(G::K % 32 == 0 && MTILES % MTG == 0 && OH % ROWS == 0, "tiling");
+  static_assert(RW >= (OWP - 1) * S + G::KH, "LDS row holds the pad column's taps");
+  const float* dy;   // [B][OC][OH][OH]
+  const void* x;     // [B][C][H][H] f32 or u8
+  float* dw;         // slab 0 of dWt [K][OC]
+  float* db;         // slab 0 of db [OC]
+  int64_t slab_stride;
+  int B;
+  double coef;
+  __host__ int blocks() const { return B * NCHUNK * NGRP; }
+  __host__ static int n_slabs(int batch) { return batch * NCHUNK; }
+  __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int grp = bid % NGRP;
+    int r = bid / NGRP;
+    const int chunk = r % NCHUNK, bi = r / NCHUNK;
+    const int k0 = grp * MTG * 32;
+    const int c_lo = k0 / G::KK;
+    const int c_hi = min((k0 + MTG * 32 - 1) / G::KK, G::C - 1);
+    const int nch = c_hi - c_lo + 1;                       // <= NCH
+    const int ir0 = chunk * ROWS * S;                      // first input row
+    float* img = lds;
+    float* dyl = lds + IMG;
+    // ---- issue all loads: dY chunk, then the image rows
+    constexpr int NDY = G::OC * NPOS, RD = (NDY + 255) / 256;
+    float draw[RD];
+    const float* dyb = dy + (int64_t)bi * G::OC * G::P + chunk * ROWS * OH;
+#pragma unroll
+    for (int q = 0; q < RD; ++q) {
+      const int e = min(tid + 256 * q, NDY - 1);
+      const int oc = e / NPOS, pos = e - oc * NPOS, ohl = pos / OWP, ow = pos - ohl * OWP;
+      draw[q] = dyb[oc * G::P + ohl * OH + min(ow, OH - 1)];
+    }
+    if (U8) {
+      constexpr int WPR = G::H / 4;                         // u32 words per 84-byte row
+      constexpr int NW = NCH * NR * WPR, RI = (NW + 255) / 256;
+      unsigned iraw[RI];
+      const uint8_t* xb = reinterpret_cast<const uint8_t*>(x) + ((int64_t)bi * G::C + c_lo) * G::HW;
+#pragma unroll
+      for (int q = 0; q < RI; ++q) {
+        const int e = min(tid + 256 * q, NW - 1);
+        const int cl = e / (NR * WPR), rem = e - cl * (NR * WPR), rr = rem / WPR, wd = rem - rr * WPR;
+        iraw[q] = *reinterpret_cast<const unsigned*>(xb + ((int64_t)min(cl, nch - 1) * G::H + ir0 + rr) * G::H + 4 * wd);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < RI; ++q) {
+        const int e = tid + 256 * q;
+        unsigned v = iraw[q];
+        asm volatile("" : "+v"(v));
+        if (e < NW) {
+          const int cl = e / (NR * WPR), rem = e - cl * (NR * WPR), rr = rem / WPR, wd = rem - rr * WPR;
+          float* d = img + cl * CS + rr * RW + 4 * wd;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) d[b] = (float)((double)((v >> (8 * b)) & 0xffu) * coef);
+        }
+      }
+      // pad columns [H, RW) of every row and the tail: zero (finite values for the pad slot's A operand)
+      constexpr int PADW = RW - G::H;
+      if (PADW > 0) {
+        for (int e = tid; e < NCH * NR * PADW; e += 256) {
+          const int rowi = e / PADW, pc = e - rowi * PADW, cl = rowi / NR, rr = rowi - cl * NR;
+          img[cl * CS + rr * RW + G::H + pc] = 0.f;
+        }
+      }
+      if (CSPAD > 0) for (int e = tid; e < NCH * CSPAD; e += 256) img[(e / CSPAD) * CS + NR * RW + e % CSPAD] = 0.f;
+      for (int e = tid; e < RW; e += 256) img[NCH * CS + e] = 0.f;
+    } else {
+      constexpr int NE = NCH * CS + RW, RI = (NE + 255) / 256;   // loop over every LDS cell: loaded or zero
+      float iraw[RI];
+      const float* xf = reinterpret_cast<const float*>(x) + ((int64_t)bi * G::C + c_lo) * G::HW;
+#pragma unroll
+      for (int q = 0; q < RI; ++q) {
+        const int e = min(tid + 256 * q, NE - 1);
+        const int cl = min(e / CS, nch - 1), rem = e % CS, rr = min(rem / RW, NR - 1), cc = min(rem % RW, G::H - 1);
+        iraw[q] = xf[((int64_t)cl * G::H + ir0 + rr) * G::H + cc];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < RI; ++q) {
+        const int e = tid + 256 * q;
+        float v = iraw[q];
+        asm volatile("" : "+v"(v));
+        if (e < NE) {
+          const int cl = e / CS, rem = e - cl * CS, rr = rem / RW, cc = rem - rr * RW;
+          const bool in = cl < nch && rr < NR && cc < G::H;
+          img[e] = in ? v : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RD; ++q) {
+      const int e = tid + 256 * q;
+      float v = draw[q];
+      asm volatile("" : "+v"(v));
+      if (e < NDY) {
+        const int oc = e / NPOS, pos = e - oc * NPOS, ow = pos % OWP;
+        dyl[pos * LDB + oc] = ow < OH ? v : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: wave w owns tiles w, w+4, ...; tile t = (mt, nt), mt = t / NTL
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = zero16();
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < TILES) {
+        const int mt = tile / NTL, nt = tile - mt * NTL;
+        const int k = k0 + mt * 32 + li;
+        const int c = k / G::KK, kr = k - c * G::KK, kh = kr / G::KH, kw = kr - kh * G::KH;
+        const float* ap = img + (c - c_lo) * CS + kh * RW + kw + h * S;
+        const float* bp = dyl + h * LDB + nt * 32 + li;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int ohl = j / NPAIR, jw = j - ohl * NPAIR;
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ohl * S * RW + 2 * jw * S], bp[(ohl * OWP + 2 * jw) * LDB],
+                                                       acc[t], 0, 0, 0);
+        }
+      }
+    }
+    // ---- slab stores (rows = k, 32 lanes along oc: 128-byte rows)
+    const int64_t slab = (int64_t)bi * NCHUNK + chunk;
+    float* dws = dw + slab * slab_stride;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < TILES) {
+        const int mt = tile / NTL, nt = tile - mt * NTL;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int k = k0 + mt * 32 + mfma_row(rr, h);
+          dws[(int64_t)k * G::OC + nt * 32 + li] = acc[t][rr];
+        }
+      }
+    }
+    if (grp == 0 && tid < G::OC) {  // bias gradient of this (sample, chunk): fixed-order column sum
+      float sb = 0.f;
+#pragma unroll 8
+      for (int pos = 0; pos < NPOS; ++pos) sb += dyl[pos * LDB + tid];
+      db[slab * slab_stride + tid] = sb;
+    }
+  }
+};

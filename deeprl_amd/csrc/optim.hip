@@ -11,6 +11,7 @@
 //                               coef = max_norm / (norm + 1e-6), and applies the update.
 // HBM-bound: centered RMSprop reads p,g,sq,ga and writes p,sq,ga (+ the norm read) = 32 B/param.
 #include "common.h"
+#include <string.h>
 
 constexpr int kNormBlocks = 512;  // fixed so graphs replay the same reduction tree
 
@@ -63,6 +64,132 @@ DRA_API int dra_grad_sqnorm(float* grad, int64_t n, const float* slabs, int n_sl
   return DRA_OK;
 }
 
+// ---- segmented variant: ONE launch for the whole flat gradient when the conv layers keep a different
+// number of split-K slabs each (one-pass weight gradients write one slab per (sample, row chunk):
+// 32-160 slabs).  Folding 160 slabs serially per element would be 160 dependent-ish loads, so a fold
+// workgroup is 16 slab groups x 16 float4 elements: thread (g, el) sums slabs g, g+16, ... (all loads
+// in flight), the 16 group partials meet in LDS and are added in group order -> the result is
+// deterministic and the fold costs one memory round trip.  Block ranges: [fold blocks of segment 0]
+// [segment 1] ... [plain blocks over the rest of the gradient]; every block writes one partial.
+struct FoldSegs {
+  int64_t begin[DRA_MAX_FOLD_SEGS];     // first float of the segment in `grad` (multiple of 4)
+  int64_t count[DRA_MAX_FOLD_SEGS];     // floats (multiple of 4)
+  const float* slabs[DRA_MAX_FOLD_SEGS];
+  int64_t stride[DRA_MAX_FOLD_SEGS];
+  int32_t n_slabs[DRA_MAX_FOLD_SEGS];
+  int32_t first_block[DRA_MAX_FOLD_SEGS + 1];  // block range of each segment; [n_segs] = first plain block
+  int32_t n_segs, plain_blocks;
+  int64_t plain_begin, plain_count;     // [plain_begin, plain_begin + plain_count): no slabs
+};
+
+__global__ void __launch_bounds__(256)
+grad_fold_norm_kernel(float* __restrict__ grad, const FoldSegs fs, double* __restrict__ partials) {
+  __shared__ float4 s_part[16][17];
+  __shared__ double s_red[4];
+  const int tid = threadIdx.x, bid = blockIdx.x;
+  float acc = 0.f;
+  if (bid < fs.first_block[fs.n_segs]) {
+    int sg = 0;
+    while (sg + 1 < fs.n_segs && bid >= fs.first_block[sg + 1]) ++sg;
+    const int nb = fs.first_block[sg + 1] - fs.first_block[sg], b = bid - fs.first_block[sg];
+    const int64_t n4 = fs.count[sg] >> 2;
+    const float4* __restrict__ sl = reinterpret_cast<const float4*>(fs.slabs[sg]);
+    const int64_t st4 = fs.stride[sg] >> 2;
+    const int ns = fs.n_slabs[sg];
+    float4* g4 = reinterpret_cast<float4*>(grad + fs.begin[sg]);
+    const int g = tid >> 4, el = tid & 15;
+    for (int64_t base = (int64_t)b * 16; base < n4; base += (int64_t)nb * 16) {
+      const int64_t i = base + el;
+      const int64_t ic = i < n4 ? i : n4 - 1;
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s0 = g; s0 < ns; s0 += 16 * 8) {  // up to 8 slabs of this group in flight per pass
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int s = s0 + 16 * u;
+          t[u] = sl[(int64_t)(s < ns ? s : g) * st4 + ic];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (s0 + 16 * u < ns) { p.x += t[u].x; p.y += t[u].y; p.z += t[u].z; p.w += t[u].w; }
+        }
+      }
+      s_part[g][el] = p;
+      __syncthreads();
+      if (g == 0) {
+        float4 r = s_part[0][el];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+          const float4 t = s_part[q][el];
+          r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+        if (i < n4) {
+          g4[i] = r;
+          acc += r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    const int b = bid - fs.first_block[fs.n_segs];
+    const int64_t n4 = fs.plain_count >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(grad + fs.plain_begin);
+    const int64_t stride = (int64_t)fs.plain_blocks * 256;
+    for (int64_t i = (int64_t)b * 256 + tid; i < n4; i += stride) {
+      const float4 v = g4[i];
+      acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+  }
+  double d = wave_sum((double)acc);
+  if ((tid & 63) == 0) s_red[tid >> 6] = d;
+  __syncthreads();
+  if (tid == 0) partials[bid] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// grad[0, n): segments (contiguous from 0, 4-float aligned) are folded from their slabs
+// (grad[seg] = sum_s slabs[s*stride + i], fixed order) and everything after the last segment is read as
+// is; *n_partials doubles are written (<= dra_norm_partials_max()) -- pass that count to dra_*_step.
+DRA_API int dra_norm_partials_max(void) { return 2048; }
+
+DRA_API int dra_grad_sqnorm_segs(float* grad, int64_t n, const dra_fold_seg* segs, int n_segs, double* partials,
+                                 int* n_partials, void* stream) {
+  if (!grad || !partials || !n_partials || n < 4 || (n & 3) || n_segs < 0 || n_segs > DRA_MAX_FOLD_SEGS || (n_segs && !segs))
+    return DRA_EINVAL;
+  if (((uintptr_t)grad) & 15) return DRA_EINVAL;
+  FoldSegs fs;
+  memset(&fs, 0, sizeof(fs));
+  int64_t end = 0;
+  int blocks = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    const dra_fold_seg& sg = segs[i];
+    if (sg.begin != end || (sg.begin & 3) || (sg.count & 3) || sg.count < 4 || sg.begin + sg.count > n || !sg.slabs ||
+        sg.n_slabs < 1 || (sg.slab_stride & 3) || (((uintptr_t)sg.slabs) & 15))
+      return DRA_EINVAL;
+    fs.begin[i] = sg.begin; fs.count[i] = sg.count; fs.slabs[i] = sg.slabs; fs.stride[i] = sg.slab_stride;
+    fs.n_slabs[i] = sg.n_slabs;
+    fs.first_block[i] = blocks;
+    int64_t nb = ((sg.count >> 2) + 15) / 16;  // one 16-element group per block, capped
+    if (nb > 320) nb = 320;
+    blocks += (int)nb;
+    end = sg.begin + sg.count;
+  }
+  fs.first_block[n_segs] = blocks;
+  fs.n_segs = n_segs;
+  fs.plain_begin = end; fs.plain_count = n - end;
+  int pb = 0;
+  if (fs.plain_count > 0) {
+    int64_t want = ((fs.plain_count >> 2) + 767) / 768;  // ~3 float4 per thread
+    pb = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  }
+  fs.plain_blocks = pb;
+  blocks += pb;
+  if (blocks < 1 || blocks > dra_norm_partials_max()) return DRA_EINVAL;
+  hipLaunchKernelGGL(grad_fold_norm_kernel, dim3(blocks), dim3(256), 0, dra_stream(stream), grad, fs, partials);
+  DRA_LAUNCH_CHECK();
+  *n_partials = blocks;
+  return DRA_OK;
+}
+
 // Fixed-order reduction of the partials by every workgroup; returns the clip coefficient.
 __device__ __forceinline__ float clip_coef_from_partials(const double* __restrict__ partials, int n_partials,
                                                          float max_norm, float* __restrict__ out_norm) {
@@ -92,7 +219,7 @@ __device__ __forceinline__ float clip_coef_from_partials(const double* __restric
 __global__ void __launch_bounds__(256)
 rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, float* __restrict__ ga,
                     int64_t n, const double* __restrict__ partials, int n_partials, float max_norm, float lr,
-                    float alpha, float eps, int centered, float* __restrict__ out_norm) {
+                    float alpha, float eps, int centered, float* __restrict__ out_norm, float* __restrict__ p_copy) {
   const float coef = partials ? clip_coef_from_partials(partials, n_partials, max_norm, out_norm) : 1.f;
   const float oma = 1.f - alpha;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -117,6 +244,7 @@ rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* _
       pp[k] = pp[k] - lr * (gk / avg);
     }
     reinterpret_cast<float4*>(p)[i] = P;
+    if (p_copy) reinterpret_cast<float4*>(p_copy)[i] = P;
     reinterpret_cast<float4*>(sq)[i] = S;
     if (centered) reinterpret_cast<float4*>(ga)[i] = A;
   }
@@ -132,7 +260,9 @@ rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* _
       avg = sqrtf(s) + eps;
     }
     sq[i] = s;
-    p[i] = p[i] - lr * (gk / avg);
+    const float pn = p[i] - lr * (gk / avg);
+    p[i] = pn;
+    if (p_copy) p_copy[i] = pn;
   }
 }
 
@@ -143,15 +273,26 @@ static inline int step_blocks(int64_t n) {
   return (int)b;
 }
 
+// param_copy (optional): the updated parameters are ALSO written there -- the async actor of the fused DQN
+// learner reads a double-buffered copy so that the optimiser never has to wait for its forwards
+// (DQN_agent.py:30,133: config.lock) -- +4 B/param of write traffic instead of a cross-queue join.
+DRA_API int dra_rmsprop_step_copy(float* param, const float* grad, float* square_avg, float* grad_avg, int64_t n,
+                                  const double* partials, int n_partials, float max_norm, float lr, float alpha,
+                                  float eps, int centered, float* out_norm, float* param_copy, void* stream) {
+  if (!param || !grad || !square_avg || (centered && !grad_avg) || n < 1) return DRA_EINVAL;
+  if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)square_avg) | ((uintptr_t)grad_avg) | ((uintptr_t)param_copy)) & 15)
+    return DRA_EINVAL;
+  hipLaunchKernelGGL(rmsprop_step_kernel, dim3(step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad, square_avg,
+                     grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps, centered, out_norm, param_copy);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 DRA_API int dra_rmsprop_step(float* param, const float* grad, float* square_avg, float* grad_avg, int64_t n,
                              const double* partials, int n_partials, float max_norm, float lr, float alpha, float eps,
                              int centered, float* out_norm, void* stream) {
-  if (!param || !grad || !square_avg || (centered && !grad_avg) || n < 1) return DRA_EINVAL;
-  if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)square_avg) | ((uintptr_t)grad_avg)) & 15) return DRA_EINVAL;
-  hipLaunchKernelGGL(rmsprop_step_kernel, dim3(step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad, square_avg,
-                     grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps, centered, out_norm);
-  DRA_LAUNCH_CHECK();
-  return DRA_OK;
+  return dra_rmsprop_step_copy(param, grad, square_avg, grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps,
+                               centered, out_norm, nullptr, stream);
 }
 
 // torch.optim.Adam (no amsgrad / weight decay): m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;

@@ -28,7 +28,7 @@ class DqnConfig(ctypes.Structure):
                 ("ksplit", ctypes.c_int32), ("centered", ctypes.c_int32), ("env_done_period", ctypes.c_int32),
                 ("gamma_n", ctypes.c_float), ("gradient_clip", ctypes.c_float), ("lr", ctypes.c_float),
                 ("alpha", ctypes.c_float), ("eps", ctypes.c_float), ("replay_eps", ctypes.c_float),
-                ("replay_alpha", ctypes.c_float), ("reserved1", ctypes.c_float), ("u8_coef", ctypes.c_double),
+                ("replay_alpha", ctypes.c_float), ("variant", ctypes.c_int32), ("u8_coef", ctypes.c_double),
                 ("n_params", ctypes.c_int64), ("conv_end", ctypes.c_int64), ("ring_capacity", ctypes.c_int64),
                 ("env_seed", ctypes.c_uint64), ("offset", ctypes.c_int64 * 10)]
 
@@ -51,7 +51,8 @@ def _ordered_params(net):
 class DQNLearner:
     def __init__(self, network, target_network, ring, batch, n_actions, gamma_n, gradient_clip, lr, alpha, eps,
                  centered=True, double_q=False, u8_coef=1.0 / 255, replay_eps=0.01, replay_alpha=0.5, ksplit=16,
-                 env_seed=0, env_done_period=800):
+                 env_seed=0, env_done_period=800, variant=-1):
+        """`variant`: DRA_VAR_* kernel-selection mask (ops.VAR_*); -1 = the process default (ops.set_tuning)."""
         self.network, self.target_network, self.ring = network, target_network, ring
         po, pt = _ordered_params(network), _ordered_params(target_network)
         self.flat = FlatParams(po, koc=(po[0], po[2], po[4]))        # conv segment first, conv weights in KOC
@@ -63,12 +64,14 @@ class DQNLearner:
         cfg.gamma_n, cfg.gradient_clip, cfg.lr, cfg.alpha, cfg.eps = gamma_n, gradient_clip or 0.0, lr, alpha, eps
         cfg.replay_eps, cfg.replay_alpha, cfg.u8_coef = replay_eps, replay_alpha, u8_coef
         cfg.env_seed, cfg.env_done_period = env_seed, env_done_period
+        cfg.variant = int(variant)
         cfg.n_params = self.flat.numel
         cfg.conv_end = self.flat.offsets[6]                          # start of fc4.weight
         cfg.ring_capacity = ring.capacity
         for i, o in enumerate(self.flat.offsets):
             cfg.offset[i] = o
         self.cfg = cfg
+        self.variant = int(variant) if int(variant) >= 0 else ops.get_tuning()
         self.batch, self.n_actions = batch, n_actions
         h = ctypes.c_void_p()
         lib.dra_dqn_learner_create(ctypes.byref(h), ring.h, ctypes.byref(cfg), ctypes.c_void_p(self.flat.flat.data_ptr()),
@@ -204,7 +207,7 @@ class DQNLearnerBench:
     parity tests use."""
 
     def __init__(self, ring_capacity=1_000_000, batch=32, seed=0, actor=True, async_actor=True, n_actions=4,
-                 prefill=None):
+                 prefill=None, variant=-1):
         from .nets import NatureConvBody, VanillaNet
         dev = Config.DEVICE
         if dev.type != "cuda":
@@ -216,7 +219,7 @@ class DQNLearnerBench:
         self.target_network = VanillaNet(n_actions, NatureConvBody())
         self.target_network.load_state_dict(self.network.state_dict())
         self.learner = DQNLearner(self.network, self.target_network, self.ring, batch, n_actions, 0.99, 5.0, 0.00025, 0.95,
-                                  0.01, centered=True, env_seed=seed, env_done_period=800)
+                                  0.01, centered=True, env_seed=seed, env_done_period=800, variant=variant)
         # resident replay before the timed region: fill the whole ring (exploration phase done)
         prefill = ring_capacity if prefill is None else prefill
         with torch.cuda.stream(self.learner.stream):
@@ -310,16 +313,21 @@ class DQNLearnerBench:
                  "conv3_bwd_w": 2 * b * 49 * 64 * 576, "conv3_bwd_x": 2 * b * 49 * 64 * 576,
                  "conv2_bwd_w": 2 * b * 81 * 64 * 512, "conv2_bwd_x": 2 * b * 81 * 64 * 512,
                  "conv1_bwd_w": 2 * b * 400 * 32 * 256, "fc4_bwd_w": 2 * b * 512 * 3136, "fc4_bwd_x": 2 * b * 512 * 3136}
+        variant = L.cfg.variant if L.cfg.variant >= 0 else ops.get_tuning()
+        if variant & (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_WGRAD):
+            # a layer's weight- and input-gradient kernels share one launch, charged to the *_bwd_x group
+            for lay in ("fc4", "conv3", "conv2"):
+                flops[lay + "_bwd_x"] += flops.pop(lay + "_bwd_w")
         bytes_ = {"gather": b * (5 * 7056) + 2 * b * 4 * 7056, "rmsprop_step": 32 * L.flat.numel}
         dom = max(ms, key=ms.get)
         if dom in flops:
             ach = flops[dom] / (ms[dom] * 1e-3) / 1e12
             return {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
-                    "frac": ach / 157.3, "traffic": None, "avg_ms": ms[dom]}
+                    "frac": ach / 157.3, "traffic": None, "avg_ms": ms[dom], "algorithmic_flops": flops[dom]}
         byt = bytes_.get(dom, 0)
         ach = byt / (ms[dom] * 1e-3) / 1e9
         return {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                "traffic": None, "avg_ms": ms[dom]}
+                "traffic": None, "avg_ms": ms[dom], "algorithmic_bytes": byt}
 
     def report(self):
         ms = getattr(self, "kernel_ms", {})

@@ -380,6 +380,98 @@ def conv_bwd_x_koc(layer, dy, wt, xact=None, act="relu"):
     return dx
 
 
+# variant bits of the fused / one-pass kernels (include/deeprl_amd.h DRA_VAR_*)
+VAR_FUSED_BWD, VAR_ONESHOT_DGRAD, VAR_ONESHOT_FWD, VAR_ONESHOT_WGRAD = 1, 2, 4, 8
+VAR_PINNED_IDX, VAR_ACTOR_V2, VAR_ACTOR_PARAMS = 16, 32, 64
+VAR_ALL = 127
+
+
+def set_tuning(mask):
+    """Process-wide default variant mask for learners created afterwards (dra_set_tuning)."""
+    lib.dra_set_tuning(int(mask))
+
+
+def get_tuning():
+    m = ctypes.c_int(0)
+    lib.dra_get_tuning(ctypes.byref(m))
+    return m.value
+
+
+def conv_wgrad_slabs(layer, batch, ksplit, variant):
+    n = ctypes.c_int(0)
+    lib.dra_conv_wgrad_slabs(int(layer), int(batch), int(ksplit), int(variant), ctypes.byref(n))
+    return n.value
+
+
+def conv_bwd_fused(layer, dy, x, wt=None, xact=None, ksplit=16, u8_coef=None, act="relu", variant=0):
+    """One launch: KOC weight / bias gradient slabs (+ the input gradient for layers 2, 3).
+    Returns (dwt_slabs [n_slabs, K*OC], db_slabs [n_slabs, OC], dx or None, the flat slab buffer)."""
+    c, h, oc, k, s = _CONV_GEOM[layer]
+    kk = c * k * k
+    batch = x.shape[0]
+    is_u8 = x.dtype == torch.uint8
+    stride = (oc * kk + oc + 3) // 4 * 4
+    n_slabs = conv_wgrad_slabs(layer, batch, ksplit, variant)
+    slabs = torch.full((n_slabs * stride,), float("nan"), dtype=_f32, device=x.device)
+    dx = torch.full((batch, c, h, h), float("nan"), dtype=_f32, device=x.device) if layer > 1 else None
+    lib.dra_conv_bwd_fused(layer, ptr(_c(dy, _f32)), ptr(_c(x)), ptr(None if wt is None else _c(wt, _f32)),
+                           ptr(None if xact is None else _c(xact, _f32)), ptr(slabs),
+                           ctypes.c_void_p(slabs.data_ptr() + 4 * oc * kk), stride, ksplit, ptr(dx), batch, int(is_u8),
+                           float(u8_coef if is_u8 else 1.0), ACT[act], int(variant), stream_ptr())
+    v = slabs.view(n_slabs, stride)
+    return v[:, :oc * kk], v[:, oc * kk:oc * kk + oc], dx, slabs
+
+
+def fc_bwd_fused(dq, h4, dh4, x3, w4, act="relu", variant=0):
+    """One launch: head weight gradient, fc4 weight gradient, fc4 input gradient (hidden = 512)."""
+    dq, h4, dh4, x3, w4 = [_c(t, _f32) for t in (dq, h4, dh4, x3, w4)]
+    batch, a = dq.shape
+    fin = x3.shape[1]
+    dev = dq.device
+    nan = float("nan")
+    dwh = torch.full((a, 512), nan, dtype=_f32, device=dev)
+    dbh = torch.full((a,), nan, dtype=_f32, device=dev)
+    dw4 = torch.full((512, fin), nan, dtype=_f32, device=dev)
+    db4 = torch.full((512,), nan, dtype=_f32, device=dev)
+    dx3 = torch.full((batch, fin), nan, dtype=_f32, device=dev)
+    lib.dra_fc_bwd_fused(ptr(dq), ptr(h4), ptr(dh4), ptr(x3), ptr(w4), ptr(dwh), ptr(dbh), ptr(dw4), ptr(db4), ptr(dx3),
+                         batch, a, fin, ACT[act], int(variant), stream_ptr())
+    return dwh, dbh, dw4, db4, dx3
+
+
+def linear_fwd_slabs(xs, ws, ksplit=8, one_pass=False):
+    """Raw split-K partial sums [nz][ksplit][B][O] of the fc4-shaped forward."""
+    nz = len(xs)
+    xs = [_c(x, _f32) for x in xs]
+    ws = [_c(w, _f32) for w in ws]
+    batch, fin = xs[0].shape
+    fout = ws[0].shape[0]
+    slabs = torch.full((nz, ksplit, batch, fout), float("nan"), dtype=_f32, device=xs[0].device)
+    fn = lib.dra_linear_fwd_slabs_one if one_pass else lib.dra_linear_fwd_slabs
+    fn(nz, ptr_array(xs), ptr_array(ws), batch, fin, fout, ksplit, ptr(slabs), stream_ptr())
+    return slabs
+
+
+class FoldSeg(ctypes.Structure):
+    """Mirror of dra_fold_seg."""
+    _fields_ = [("begin", ctypes.c_int64), ("count", ctypes.c_int64), ("slabs", ctypes.c_void_p),
+                ("slab_stride", ctypes.c_int64), ("n_slabs", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+def grad_sqnorm_segs(grad, segs, partials):
+    """segs: list of (begin, count, slabs_tensor, slab_stride, n_slabs).  Returns the number of partials written."""
+    arr = (FoldSeg * max(1, len(segs)))()
+    for i, (b, c, t, st, ns) in enumerate(segs):
+        arr[i].begin, arr[i].count, arr[i].slabs, arr[i].slab_stride, arr[i].n_slabs = b, c, t.data_ptr(), st, ns
+    n = ctypes.c_int(0)
+    lib.dra_grad_sqnorm_segs(ptr(grad), grad.numel(), arr, len(segs), ptr(partials), ctypes.byref(n), stream_ptr())
+    return n.value
+
+
+def norm_partials_max():
+    return lib.dra_norm_partials_max.raw()
+
+
 def conv_bwd_x(layer, dy, w, xact=None, act="relu"):
     """Gradient w.r.t. the layer's input; with `xact` (the layer-below's activated output) the
     activation derivative of that layer is folded in (gradient w.r.t. its PRE-activation)."""

@@ -118,6 +118,9 @@ int dra_conv_bwd_x(int layer, const float* dy, const float* w, const float* xact
 /* KOC weight layout ([K=(c,kh,kw)][OC]; conv_v2.hip): one-round-trip forward, and the matching gradients. */
 int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const float* const* wt, const float* const* bias,
                      float* const* y, int batch, int x_is_u8, double u8_coef, int act, void* stream);
+/* conv1 of a batch-1 forward whose 4-frame uint8 stack is read straight from the ring (newest slot on device) */
+int dra_conv1_fwd_koc_ring(const void* frames, const int64_t* newest_slot_dev, int64_t capacity, const float* wt,
+                           const float* bias, float* y, double u8_coef, int act, void* stream);
 int dra_conv_bwd_w_koc(int layer, const float* dy, const void* x, float* dw, float* db, int64_t slab_stride, int ksplit,
                        int batch, int x_is_u8, double u8_coef, void* stream);
 int dra_conv_bwd_x_koc(int layer, const float* dy, const float* wt, const float* xact, float* dx, int batch, int act,
@@ -135,13 +138,50 @@ int dra_linear_bwd_w(const float* dy, const float* x, float* dw, float* db, int 
 int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* dx, int batch, int in_features,
                      int out_features, int act, void* stream);
 
+/* ---- horizontally fused backward launches + one-pass contractions (csrc/fused.hip, csrc/oneshot.h): the autograd
+ * backward behind DQN_agent.py:129 for VanillaNet(NatureConvBody).  `variant` / tuning bits: */
+#define DRA_VAR_FUSED_BWD 1      /* learner: a layer's weight- and input-gradient kernels share one launch */
+#define DRA_VAR_ONESHOT_DGRAD 2  /* one-pass input gradients (conv2, conv3, fc4) */
+#define DRA_VAR_ONESHOT_FWD 4    /* one-pass fc4 forward partial sums */
+#define DRA_VAR_ONESHOT_WGRAD 8  /* one-pass conv weight gradients, one slab per (sample, row chunk) */
+#define DRA_VAR_PINNED_IDX 16    /* learner: the gather reads minibatch indices from pinned host memory */
+#define DRA_VAR_ACTOR_V2 32      /* learner: 5-kernel actor step (ring-direct conv1, GEMV fc4, head + env) */
+#define DRA_VAR_ACTOR_PARAMS 64  /* learner: async actor reads a double-buffered parameter copy */
+/* process-wide default variant mask used by learners created afterwards */
+int dra_set_tuning(int mask);
+int dra_get_tuning(int* mask);
+int dra_conv_wgrad_slabs(int layer, int batch, int ksplit, int variant, int* n_slabs);
+int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const float* wt, const float* xact, float* dw,
+                       float* db, int64_t slab_stride, int ksplit, float* dx, int batch, int x_is_u8, double u8_coef,
+                       int act, int variant, void* stream);
+int dra_fc_bwd_fused(const float* dq, const float* h4, const float* dh4, const float* x3, const float* w4, float* dwh,
+                     float* dbh, float* dw4, float* db4, float* dx3, int batch, int n_actions, int in_features, int act,
+                     int variant, void* stream);
+int dra_linear_fwd_slabs_one(int nz, const float* const* x, const float* const* w, int batch, int in_features,
+                             int out_features, int ksplit, float* slabs, void* stream);
+
 /* ---- clip + optimiser: DQN_agent.py:130-134 with the optimisers of examples.py:67-68,139,204,370,508-509,534 */
 int dra_norm_partials(void); /* doubles needed per dra_grad_sqnorm call */
 int dra_grad_sqnorm(float* grad, int64_t n, const float* slabs, int n_slabs, int64_t slab_stride, double* partials,
                     void* stream);
+/* segmented norm + fold (one launch): each segment of the flat gradient is the fixed-order sum of its own
+ * n_slabs split-K slabs (slab s of element i at slabs[s*slab_stride + (i - begin)]); the rest of grad is read as is. */
+#define DRA_MAX_FOLD_SEGS 4
+typedef struct dra_fold_seg {
+  int64_t begin, count;     /* floats, multiples of 4 */
+  const float* slabs;       /* 16-byte aligned */
+  int64_t slab_stride;      /* floats, multiple of 4 */
+  int32_t n_slabs, reserved;
+} dra_fold_seg;
+int dra_norm_partials_max(void);
+int dra_grad_sqnorm_segs(float* grad, int64_t n, const dra_fold_seg* segs, int n_segs, double* partials,
+                         int* n_partials, void* stream);
 int dra_rmsprop_step(float* param, const float* grad, float* square_avg, float* grad_avg, int64_t n,
                      const double* partials, int n_partials, float max_norm, float lr, float alpha, float eps,
                      int centered, float* out_norm, void* stream);
+int dra_rmsprop_step_copy(float* param, const float* grad, float* square_avg, float* grad_avg, int64_t n,
+                          const double* partials, int n_partials, float max_norm, float lr, float alpha, float eps,
+                          int centered, float* out_norm, float* param_copy, void* stream);
 int dra_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   const double* partials, int n_partials, float max_norm, float lr, float beta1, float beta2, float eps,
                   int64_t step, float* out_norm, void* stream);
@@ -153,7 +193,8 @@ int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream); /* DQN_
  * aligned); [0, conv_end) is the conv segment whose split-K slabs are folded in the norm pass. */
 typedef struct dra_dqn_config {
   int32_t batch, n_actions, double_q, ksplit, centered, env_done_period;
-  float gamma_n, gradient_clip, lr, alpha, eps, replay_eps, replay_alpha, reserved1;
+  float gamma_n, gradient_clip, lr, alpha, eps, replay_eps, replay_alpha;
+  int32_t variant;          /* DRA_VAR_* mask, or < 0 = the process default (dra_set_tuning) */
   double u8_coef;
   int64_t n_params, conv_end, ring_capacity;
   uint64_t env_seed;        /* synthetic frame source (dra_ring_fill_synthetic stream) used by the device actor */

@@ -227,8 +227,8 @@ def test_ppo_optimize_matches_reference(golden, dra, tag, monkeypatch):
     _cmp_params(agent.network, g, k + "final_", 2e-5, 2e-6)
 
 
-@pytest.mark.parametrize("double_q", [False])
-def test_fused_learner_matches_oracle(dra, double_q):
+@pytest.mark.parametrize("double_q,variant", [(False, 0), (False, 1), (False, 7), (False, 127)])
+def test_fused_learner_matches_oracle(dra, double_q, variant):
     """The captured-graph DQN learner (one C-ABI call per update, zero host round trips) against
     the CPU oracle's full update on identical ring contents, indices and weights: 4 consecutive
     updates (graph capture + 3 replays), B=32, then the device actor step."""
@@ -251,7 +251,8 @@ def test_fused_learner_matches_oracle(dra, double_q):
     t_np = fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(a), 22)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
     tgt.load_state_dict({k: torch.from_numpy(v) for k, v in t_np.items()})
-    learner = DQNLearner(net, tgt, ring, b, a, 0.99, 5.0, 0.00025, 0.95, 0.01, centered=True, double_q=double_q)
+    learner = DQNLearner(net, tgt, ring, b, a, 0.99, 5.0, 0.00025, 0.95, 0.01, centered=True, double_q=double_q,
+                         variant=variant)
     p = {k: torch.tensor(v, requires_grad=True) for k, v in p_np.items()}
     pt = {k: torch.tensor(v) for k, v in t_np.items()}
     names = list(p.keys())
@@ -302,7 +303,8 @@ def test_fused_learner_matches_oracle(dra, double_q):
     ring.close()
 
 
-def test_fused_step_sync_equals_act_then_update(dra):
+@pytest.mark.parametrize("variant", [0, 127])
+def test_fused_step_sync_equals_act_then_update(dra, variant):
     """dra_dqn_learner_step in in-order mode == explicit actor transitions followed by an update:
     the synthetic frame source, the device epsilon-greedy and the captured graphs change nothing."""
     d = dra
@@ -318,7 +320,8 @@ def test_fused_step_sync_equals_act_then_update(dra):
         p_np = fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(a), 31)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
         tgt.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
-        L = DQNLearner(net, tgt, ring, b, a, 0.99, 5.0, 0.00025, 0.95, 0.01, centered=True, env_seed=seed)
+        L = DQNLearner(net, tgt, ring, b, a, 0.99, 5.0, 0.00025, 0.95, 0.01, centered=True, env_seed=seed,
+                       variant=variant)
         np.random.seed(3)
         pos, size, counter = 0, cap, cap
         for it in range(6):
@@ -346,3 +349,35 @@ def test_fused_step_sync_equals_act_then_update(dra):
     # the device frame source is the documented counter hash
     want_frames, _, _, _ = synth_transitions(cap, 24, 7056, seed=seed)
     assert np.array_equal(outs[0][2].reshape(24, 7056), want_frames)
+
+
+@pytest.mark.parametrize("variant", [0, 127])
+def test_fused_step_async_pipeline(dra, variant):
+    """async_actor=True pipeline (actor one agent step ahead on its own stream, double-buffered actor
+    parameters when variant has DRA_VAR_ACTOR_PARAMS): the transitions it feeds are the documented counter-hash
+    frames, every stored action is a valid action, the TD errors stay finite, and the run is reproducible
+    (two identical runs give bit-identical parameters: no race between the optimiser and the actor's reads)."""
+    d = dra
+    from deeprl_amd.learner import DQNLearnerBench
+    from oracle.synth_oracle import synth_transitions
+    outs = []
+    for rep in range(2):
+        d.random_seed(11)
+        torch.manual_seed(5)
+        np.random.seed(5)
+        bench = DQNLearnerBench(ring_capacity=4000, batch=32, seed=3, actor=True, async_actor=True, variant=variant)
+        for _ in range(25):
+            bench.step()
+        bench.learner.synchronize()
+        L = bench.learner
+        assert torch.isfinite(L.delta).all() and torch.isfinite(L.flat.flat).all()
+        frames = d.ops._wrap_device_pointer(bench.ring.pointers()[0], 100 * 7056, torch.uint8).cpu().numpy().copy()
+        acts = d.ops._wrap_device_pointer(bench.ring.pointers()[1], 100, torch.int64).cpu().numpy().copy()
+        outs.append((L.flat.flat.cpu().numpy().copy(), frames, acts))
+        L.close()
+        bench.ring.close()
+    # 25 agent steps wrote 100 transitions into slots 0..99 (ring was full: pos started at 0), counters 4000..4099
+    want_frames, _, _, _ = synth_transitions(4000, 100, 7056, seed=3)
+    assert np.array_equal(outs[0][1].reshape(100, 7056), want_frames)
+    assert ((outs[0][2] >= 0) & (outs[0][2] < 4)).all()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][2], outs[1][2])

@@ -510,3 +510,140 @@ def test_conv_koc_fwd_bwd_vs_oracle(dev, layer, batch):
         _scale_close(dx.cpu().numpy(), xt.grad.numpy())
         dxm = ops.conv_bwd_x_koc(layer, dpre, wts[2], xact=f32(xs[2], dev), act="relu")
         _scale_close(dxm.cpu().numpy(), xt.grad.numpy() * (xs[2] > 0))
+
+
+# ---------------------------------------------------------------- fused launches + one-pass kernels (fused.hip)
+@pytest.mark.parametrize("layer", [1, 2, 3])
+@pytest.mark.parametrize("batch", [32, 1, 5])
+@pytest.mark.parametrize("variant", [1, 3, 9, 11])
+def test_conv_bwd_fused_vs_autograd(dev, layer, batch, variant):
+    """dra_conv_bwd_fused: weight/bias gradient slabs and the masked input gradient of one layer in ONE launch,
+    for the K-chunked (1), one-pass dgrad (3), one-pass wgrad (9) and all-one-pass (11) variants, against
+    F.conv2d autograd; the slab fold goes through dra_grad_sqnorm_segs."""
+    import torch.nn.functional as F
+    from deeprl_amd import ops
+    c, h, oc, k, s = CONV[layer]
+    rs = np.random.RandomState(1000 * layer + 10 * batch + variant)
+    w = (rs.standard_normal((oc, c, k, k)) / np.sqrt(c * k * k)).astype(np.float32)
+    wt_dev = ops.to_koc(f32(w, dev))
+    if layer == 1:
+        x_u8 = rs.randint(0, 256, size=(batch, c, h, h)).astype(np.uint8)
+        x = NUM.image_normalize_sync(x_u8)
+        x_dev = cu(x_u8, dev)
+    else:
+        x = np.maximum(rs.standard_normal((batch, c, h, h)), 0).astype(np.float32)
+        x_dev = f32(x, dev)
+    xt, wt = torch.tensor(x, requires_grad=True), torch.tensor(w, requires_grad=True)
+    bt = torch.zeros(oc, requires_grad=True)
+    yt = F.conv2d(xt, wt, bt, stride=s)
+    dy = rs.standard_normal(tuple(yt.shape)).astype(np.float32)
+    yt.backward(torch.tensor(dy))
+    dw_s, db_s, dx, slab_buf = ops.conv_bwd_fused(layer, f32(dy, dev), x_dev, wt=wt_dev if layer > 1 else None,
+                                                  xact=x_dev if layer > 1 else None, ksplit=16,
+                                                  u8_coef=1.0 / 255 if layer == 1 else None, variant=variant)
+    assert not torch.isnan(dw_s).any() and not torch.isnan(db_s).any()      # every slab element is written
+    # fold the slabs with the segmented norm kernel: grad segment = [w | b]
+    kk = c * k * k
+    stride = dw_s.stride(0)
+    n_slabs = dw_s.shape[0]
+    seg = oc * kk + oc
+    grad = torch.zeros(seg + 1000, dtype=torch.float32, device=dev)
+    tail = rs.standard_normal(1000).astype(np.float32)
+    grad[seg:] = f32(tail, dev)
+    partials = torch.zeros(ops.norm_partials_max(), dtype=torch.float64, device=dev)
+    n_part = ops.grad_sqnorm_segs(grad, [(0, seg, slab_buf, stride, n_slabs)], partials)
+    g = grad.cpu().numpy()
+    dw = ops.from_koc(grad[:oc * kk].contiguous(), (oc, c, k, k)).cpu().numpy()
+    _scale_close(dw, wt.grad.numpy())
+    _scale_close(g[oc * kk:seg], bt.grad.numpy())
+    assert np.array_equal(g[seg:], tail)
+    np.testing.assert_allclose(partials[:n_part].sum().item(), (g.astype(np.float64) ** 2).sum(), rtol=1e-6)
+    if layer > 1:
+        assert not torch.isnan(dx).any()
+        _scale_close(dx.cpu().numpy(), xt.grad.numpy() * (x > 0))
+
+
+@pytest.mark.parametrize("batch", [32, 5, 1, 64])
+@pytest.mark.parametrize("variant", [0, 2])
+def test_fc_bwd_fused_vs_autograd(dev, batch, variant):
+    import torch.nn.functional as F
+    from deeprl_amd import ops
+    rs = np.random.RandomState(batch + variant)
+    a, fin = 4, 3136
+    x3 = np.maximum(rs.standard_normal((batch, fin)), 0).astype(np.float32)
+    w4 = (rs.standard_normal((512, fin)) / np.sqrt(fin)).astype(np.float32)
+    b4 = (rs.standard_normal(512) * 0.1).astype(np.float32)
+    wh = (rs.standard_normal((a, 512)) / np.sqrt(512)).astype(np.float32)
+    dq = rs.standard_normal((batch, a)).astype(np.float32)
+    x3t, w4t, b4t = torch.tensor(x3, requires_grad=True), torch.tensor(w4, requires_grad=True), torch.tensor(b4, requires_grad=True)
+    wht, bht = torch.tensor(wh, requires_grad=True), torch.zeros(a, requires_grad=True)
+    h4 = F.relu(F.linear(x3t, w4t, b4t))
+    q = F.linear(h4, wht, bht)
+    q.backward(torch.tensor(dq))
+    h4n = h4.detach().numpy()
+    dh4 = (dq @ wh) * (h4n > 0)
+    dwh, dbh, dw4, db4, dx3 = ops.fc_bwd_fused(f32(dq, dev), f32(h4n, dev), f32(dh4.astype(np.float32), dev), f32(x3, dev),
+                                               f32(w4, dev), variant=variant)
+    for t in (dwh, dbh, dw4, db4, dx3):
+        assert not torch.isnan(t).any()
+    _scale_close(dwh.cpu().numpy(), wht.grad.numpy())
+    _scale_close(dbh.cpu().numpy(), bht.grad.numpy())
+    _scale_close(dw4.cpu().numpy(), w4t.grad.numpy())
+    _scale_close(db4.cpu().numpy(), b4t.grad.numpy())
+    _scale_close(dx3.cpu().numpy(), x3t.grad.numpy() * (x3 > 0))
+
+
+@pytest.mark.parametrize("batch", [32, 1, 7])
+def test_linear_fwd_slabs_one_pass(dev, batch):
+    from deeprl_amd import ops
+    rs = np.random.RandomState(batch)
+    xs = [np.maximum(rs.standard_normal((batch, 3136)), 0).astype(np.float32) for _ in range(2)]
+    ws = [(rs.standard_normal((512, 3136)) / 56.0).astype(np.float32) for _ in range(2)]
+    one = ops.linear_fwd_slabs([f32(x, dev) for x in xs], [f32(w, dev) for w in ws], 8, one_pass=True)
+    old = ops.linear_fwd_slabs([f32(x, dev) for x in xs], [f32(w, dev) for w in ws], 8, one_pass=False)
+    assert not torch.isnan(one).any()
+    for z in range(2):
+        want = xs[z].astype(np.float64) @ ws[z].astype(np.float64).T
+        _scale_close(one[z].sum(0).cpu().numpy(), want)
+        _scale_close(old[z].sum(0).cpu().numpy(), want)
+        # same K split boundaries: each slab is the same partial sum up to summation order
+        _scale_close(one[z].cpu().numpy(), old[z].cpu().numpy())
+
+
+def test_grad_sqnorm_segs_many_slabs(dev):
+    """Three contiguous segments with 160 / 32 / 5 slabs and a plain tail, against a numpy fold in the kernel's
+    order (16 slab groups of stride 16, then group order)."""
+    from deeprl_amd import ops
+    rs = np.random.RandomState(4)
+    counts, nsl = [8224, 32832, 36928], [160, 32, 5]
+    tail = 50_000
+    n = sum(counts) + tail
+    grad = f32(rs.standard_normal(n).astype(np.float32), dev)
+    tail_np = grad[sum(counts):].cpu().numpy().copy()
+    segs, want, off = [], [], 0
+    for cnt, ns in zip(counts, nsl):
+        sl = rs.standard_normal((ns, cnt)).astype(np.float32)
+        t = f32(sl.reshape(-1), dev)
+        segs.append((off, cnt, t, cnt, ns))
+        groups = []
+        for g in range(min(16, ns)):
+            acc = np.zeros(cnt, dtype=np.float32)
+            for s_ in range(g, ns, 16):
+                acc = acc + sl[s_]
+            groups.append(acc)
+        while len(groups) < 16:
+            groups.append(np.zeros(cnt, dtype=np.float32))
+        r = groups[0].copy()
+        for g in range(1, 16):
+            r = r + groups[g]
+        want.append(r)
+        off += cnt
+    partials = torch.zeros(ops.norm_partials_max(), dtype=torch.float64, device=dev)
+    n_part = ops.grad_sqnorm_segs(grad, segs, partials)
+    got = grad.cpu().numpy()
+    off = 0
+    for cnt, w_ in zip(counts, want):
+        assert np.array_equal(got[off:off + cnt], w_)
+        off += cnt
+    assert np.array_equal(got[off:], tail_np)
+    np.testing.assert_allclose(partials[:n_part].sum().item(), (got.astype(np.float64) ** 2).sum(), rtol=1e-6)

@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+"""CPU emulation of the lane / slot / LDS index maps of deeprl_amd/csrc/oneshot.h.
+
+There is no GPU in the authoring container, so every one-pass kernel's addressing is transcribed
+here lane by lane (numpy, one workgroup at a time: staging -> "LDS" array -> per-wave MFMA operand
+fetch -> 4-wave fold -> guarded store) and compared with torch's autograd on random inputs.  This
+checks the mathematics of the maps (slot <-> reduction index bijections, padding, phase decomposition,
+slab layout); the real parity tests run on the GPU (tests/test_gpu_kernels.py).
+
+    python tools/emulate_oneshot.py
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def mfma_row(r, h):
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def mfma_acc(acc, a, b):
+    """acc[32][32] += sum_h a[(i,h)] * b[(j,h)]; a, b indexed [h][lane32]."""
+    acc += np.outer(a[0], b[0]) + np.outer(a[1], b[1])
+
+
+class Geom:
+    def __init__(self, C, H, OC, KH, S):
+        self.C, self.H, self.OC, self.KH, self.S = C, H, OC, KH, S
+        self.OH = (H - KH) // S + 1
+        self.P = self.OH * self.OH
+        self.KK = KH * KH
+        self.K = C * self.KK
+        self.HW = H * H
+
+
+G1 = Geom(4, 84, 32, 8, 4)
+G2 = Geom(32, 20, 64, 4, 2)
+G3 = Geom(64, 9, 64, 3, 1)
+
+
+def emu_conv_dgrad(G, dy, wt, xact, B):
+    """ConvDgradOne<G>::run for every block.  dy [B][OC][OH][OH], wt [K][OC], xact [B][C][H][H] -> dx."""
+    S, KH, OC, C, H, OH = G.S, G.KH, G.OC, G.C, G.H, G.OH
+    KP = (KH + S - 1) // S
+    NPH, HP = S * S, (H + S - 1) // S
+    PP, PAD = HP * HP, KP - 1
+    DH = OH + 2 * PAD
+    RW, CS = DH, DH * DH
+    TPP = (PP + 31) // 32
+    OCW, OCH, NT, MT = OC // 4, OC // 8, KP * KP, C // 32
+    NCELL = OC * CS
+    dx = np.full((B, C, H, H), np.nan, dtype=np.float64)
+    dyf, wtf = dy.reshape(-1), wt.reshape(-1)
+    for bid in range(B * NPH * TPP * MT):
+        mt = bid % MT
+        r = bid // MT
+        tile = r % TPP
+        r //= TPP
+        phi, bi = r % NPH, r // NPH
+        ph, pw = phi // S, phi % S
+        c0, p0 = mt * 32, tile * 32
+        np_ = min(32, PP - p0)
+        lds = np.zeros(NCELL)
+        for e in range(NCELL):
+            oc, rem = divmod(e, CS)
+            rr, cc = divmod(rem, RW)
+            inside = PAD <= rr < PAD + OH and PAD <= cc < PAD + OH
+            oh, ow = min(max(rr - PAD, 0), OH - 1), min(max(cc - PAD, 0), OH - 1)
+            v = dyf[bi * OC * G.P + (oc * OH + oh) * OH + ow]
+            lds[e] = v if inside else 0.0
+        acc = np.zeros((32, 32))
+        li = np.arange(32)
+        pj = np.minimum(li, np_ - 1)
+        ih2, iw2 = (p0 + pj) // HP, (p0 + pj) % HP
+        for wave in range(4):
+            for t in range(NT):
+                kh2, kw2 = t // KP, t % KP
+                kh, kw = kh2 * S + ph, kw2 * S + pw
+                for jj in range(OCH):
+                    a = np.zeros((2, 32))
+                    b = np.zeros((2, 32))
+                    for h in range(2):
+                        oc = wave * OCW + h * OCH + jj
+                        a[h] = wtf[((c0 + li) * G.KK + kh * KH + kw) * OC + oc]
+                        b[h] = lds[oc * CS + ih2 * RW + iw2 + (PAD - kh2) * RW + (PAD - kw2)]
+                    mfma_acc(acc, a, b)
+        ih, iw = ih2 * S + ph, iw2 * S + pw
+        for l in range(32):
+            if l < np_ and ih[l] < H and iw[l] < H:
+                for m in range(32):
+                    c = c0 + m
+                    v = acc[m][l]
+                    dx[bi, c, ih[l], iw[l]] = v * (1.0 if xact[bi, c, ih[l], iw[l]] > 0 else 0.0)
+    return dx
+
+
+def emu_conv_wgrad(G, ROWS, MTG, RW, CSPAD, dy, x, B):
+    """ConvWgradOne<G, ROWS, MTG, RW, CSPAD>::run for every block -> (dw slabs [n_slabs][K][OC], db slabs)."""
+    S, KH, OC, C, H, OH = G.S, G.KH, G.OC, G.C, G.H, G.OH
+    OWP = (OH + 1) & ~1
+    NPAIR = OWP // 2
+    NJ, NCHUNK = ROWS * NPAIR, OH // ROWS
+    MTILES = G.K // 32
+    NGRP, NTL = MTILES // MTG, OC // 32
+    TILES = MTG * NTL
+    NR = (ROWS - 1) * S + KH
+    CS = NR * RW + CSPAD
+    NCHMAX = (MTG * 32) // G.KK if (MTG * 32) % G.KK == 0 else (MTG * 32 + G.KK - 2) // G.KK + 1
+    NCH = min(NCHMAX, C)
+    IMG = NCH * CS + RW
+    LDB, NPOS = OC + 1, ROWS * OWP
+    n_slabs = B * NCHUNK
+    dw = np.full((n_slabs, G.K, OC), np.nan)
+    db = np.full((n_slabs, OC), np.nan)
+    assert RW >= (OWP - 1) * S + KH
+    for bid in range(B * NCHUNK * NGRP):
+        grp = bid % NGRP
+        r = bid // NGRP
+        chunk, bi = r % NCHUNK, r // NCHUNK
+        k0 = grp * MTG * 32
+        c_lo = k0 // G.KK
+        c_hi = min((k0 + MTG * 32 - 1) // G.KK, C - 1)
+        nch = c_hi - c_lo + 1
+        assert nch <= NCH
+        ir0 = chunk * ROWS * S
+        img = np.full(IMG, np.nan)
+        for e in range(NCH * CS + RW):
+            cl, rem = divmod(e, CS)
+            rr, cc = divmod(rem, RW)
+            inside = cl < nch and rr < NR and cc < H
+            img[e] = x[bi, c_lo + cl, ir0 + rr, cc] if inside else 0.0
+        dyl = np.full(NPOS * LDB, np.nan)
+        for e in range(OC * NPOS):
+            oc, pos = divmod(e, NPOS)
+            ohl, ow = divmod(pos, OWP)
+            dyl[pos * LDB + oc] = dy[bi, oc, chunk * ROWS + ohl, ow] if ow < OH else 0.0
+        li = np.arange(32)
+        slab = bi * NCHUNK + chunk
+        for wave in range(4):
+            for t in range((TILES + 3) // 4):
+                tile = wave + 4 * t
+                if tile >= TILES:
+                    continue
+                mt, nt = tile // NTL, tile % NTL
+                k = k0 + mt * 32 + li
+                c, kr = k // G.KK, k % G.KK
+                kh, kw = kr // KH, kr % KH
+                acc = np.zeros((32, 32))
+                for j in range(NJ):
+                    ohl, jw = j // NPAIR, j % NPAIR
+                    a = np.zeros((2, 32))
+                    b = np.zeros((2, 32))
+                    for h in range(2):
+                        a[h] = img[(c - c_lo) * CS + kh * RW + kw + h * S + ohl * S * RW + 2 * jw * S]
+                        b[h] = dyl[h * LDB + nt * 32 + li + (ohl * OWP + 2 * jw) * LDB]
+                    mfma_acc(acc, a, b)
+                assert not np.isnan(acc).any()
+                dw[slab, k0 + mt * 32:k0 + mt * 32 + 32, nt * 32:nt * 32 + 32] = acc
+        if grp == 0:
+            for oc in range(OC):
+                db[slab, oc] = sum(dyl[pos * LDB + oc] for pos in range(NPOS))
+    return dw, db
+
+
+def emu_lin_dgrad(O, dy, w, xact, B, I):
+    """LinDgradOne<O>: dx[b][i] = relu'(xact) * sum_o dy[b][o] w[o][i]."""
+    KW, NJ, LDA = O // 4, O // 8, O + 1
+    tiles_n = (I + 31) // 32
+    dx = np.full((B, I), np.nan)
+    li = np.arange(32)
+    for bid in range(tiles_n * ((B + 31) // 32)):
+        bm, bn = bid // tiles_n, bid % tiles_n
+        m0, n0 = bm * 32, bn * 32
+        ncol = np.minimum(n0 + li, I - 1)
+        lds = np.zeros(32 * LDA)
+        for e in range(32 * O):
+            row, col = divmod(e, O)
+            lds[row * LDA + col] = dy[min(m0 + row, B - 1), col]
+        acc = np.zeros((32, 32))
+        for wave in range(4):
+            for j in range(NJ):
+                a = np.zeros((2, 32))
+                b = np.zeros((2, 32))
+                for h in range(2):
+                    kb = wave * KW + h * NJ
+                    a[h] = lds[li * LDA + kb + j]
+                    b[h] = w[kb + j, ncol]
+                mfma_acc(acc, a, b)
+        for m in range(32):
+            for l in range(32):
+                if m0 + m < B and n0 + l < I:
+                    dx[m0 + m, n0 + l] = acc[m][l] * (1.0 if xact[m0 + m, n0 + l] > 0 else 0.0)
+    return dx
+
+
+def emu_lin_fwd_slabs(I, KS, x, w, B, O):
+    KPS = I // KS
+    KW, NJ, LD = KPS // 4, KPS // 8, KPS + 1
+    tiles_n, tiles_m = (O + 31) // 32, (B + 31) // 32
+    slabs = np.full((KS, B, O), np.nan)
+    li = np.arange(32)
+    for bid in range(tiles_n * tiles_m * KS):
+        bn = bid % tiles_n
+        r = bid // tiles_n
+        bm = r % tiles_m
+        s = (r // tiles_m) % KS
+        m0, n0, k0 = bm * 32, bn * 32, s * KPS
+        xs, ws = np.zeros(32 * LD), np.zeros(32 * LD)
+        for row in range(32):
+            xs[row * LD:row * LD + KPS] = x[min(m0 + row, B - 1), k0:k0 + KPS]
+            ws[row * LD:row * LD + KPS] = w[min(n0 + row, O - 1), k0:k0 + KPS]
+        acc = np.zeros((32, 32))
+        for wave in range(4):
+            for j in range(NJ):
+                a = np.zeros((2, 32))
+                b = np.zeros((2, 32))
+                for h in range(2):
+                    a[h] = xs[li * LD + wave * KW + h * NJ + j]
+                    b[h] = ws[li * LD + wave * KW + h * NJ + j]
+                mfma_acc(acc, a, b)
+        for m in range(32):
+            for l in range(32):
+                if m0 + m < B and n0 + l < O:
+                    slabs[s, m0 + m, n0 + l] = acc[m][l]
+    return slabs
+
+
+def check(name, got, want, tol=1e-9):
+    assert not np.isnan(got).any(), name + ": unwritten outputs"
+    err = np.abs(got - want).max() / max(1e-30, np.abs(want).max())
+    print("%-28s max rel err %.2e %s" % (name, err, "ok" if err < tol else "FAIL"))
+    assert err < tol, name
+
+
+def main():
+    torch.manual_seed(0)
+    rs = np.random.RandomState(0)
+    for name, G, wg in (("conv3", G3, (7, 3, 10, 1)), ("conv2", G2, (9, 4, 24, 4)), ("conv1", G1, (4, 4, 88, 0))):
+        B = 2
+        x = torch.randn(B, G.C, G.H, G.H, dtype=torch.float64)
+        x = x * (x > -0.3)  # some exact zeros / negatives for the relu mask
+        w = torch.randn(G.OC, G.C, G.KH, G.KH, dtype=torch.float64, requires_grad=True)
+        xr = x.clone().requires_grad_(True)
+        y = F.conv2d(xr, w, stride=G.S)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        wt = w.detach().permute(1, 2, 3, 0).reshape(G.K, G.OC).numpy()
+        if name != "conv1":
+            want_dx = xr.grad.numpy() * (x.numpy() > 0)
+            got = emu_conv_dgrad(G, dy.numpy(), wt, x.numpy(), B)
+            check(name + " dgrad one-pass", got, want_dx)
+        dw, db = emu_conv_wgrad(G, *wg, dy.numpy(), x.numpy(), B)
+        want_dw = w.grad.permute(1, 2, 3, 0).reshape(G.K, G.OC).numpy()
+        check(name + " wgrad one-pass", dw.sum(0), want_dw)
+        check(name + " bias  one-pass", db.sum(0), dy.sum((0, 2, 3)).numpy())
+    B, I, O = 5, 96, 64
+    dyl, wl = rs.randn(B, O), rs.randn(O, I)
+    xa = rs.randn(B, I)
+    check("linear dgrad one-pass", emu_lin_dgrad(O, dyl, wl, xa, B, I), (dyl @ wl) * (xa > 0))
+    B, I, O, KS = 3, 64, 40, 2
+    xl, wl = rs.randn(B, I), rs.randn(O, I)
+    check("linear fwd slabs one-pass", emu_lin_fwd_slabs(I, KS, xl, wl, B, O).sum(0), xl @ wl.T)
+    print("all index maps agree with autograd")
+
+
+if __name__ == "__main__":
+    main()
