@@ -11,7 +11,7 @@
 //                          chunk) -- dra_conv_wgrad_slabs() slabs instead of `ksplit`.
 #include "oneshot.h"
 
-static int g_tuning = 0;
+static int g_tuning = 127;  // DRA_VAR_ALL: every variant measured faster on MI355X (profiles/r01b_ab_variants.jsonl)
 
 DRA_API int dra_set_tuning(int mask) {
   if (mask < 0) return DRA_EINVAL;

@@ -606,8 +606,8 @@ def test_linear_fwd_slabs_one_pass(dev, batch):
         want = xs[z].astype(np.float64) @ ws[z].astype(np.float64).T
         _scale_close(one[z].sum(0).cpu().numpy(), want)
         _scale_close(old[z].sum(0).cpu().numpy(), want)
-        # same K split boundaries: each slab is the same partial sum up to summation order
-        _scale_close(one[z].cpu().numpy(), old[z].cpu().numpy())
+        # (the two kernels partition K differently -- contiguous eighths vs interleaved chunks -- so only the
+        #  slab SUM is comparable, which is what head_fused_kernel consumes)
 
 
 def test_grad_sqnorm_segs_many_slabs(dev):
