@@ -179,7 +179,7 @@ def main():
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
 

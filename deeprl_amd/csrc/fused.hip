@@ -11,7 +11,8 @@
 //                          chunk) -- dra_conv_wgrad_slabs() slabs instead of `ksplit`.
 #include "oneshot.h"
 
-static int g_tuning = 127;  // DRA_VAR_ALL: every variant measured faster on MI355X (profiles/r01b_ab_variants.jsonl)
+static int g_tuning = 511;  // every bit up to DRA_VAR_CU_PARTITION measured faster on MI355X (profiles/r01b_ab_variants.jsonl,
+                            // r01d_*); DRA_VAR_ACTOR_V3 (512) measured neutral and stays opt-in
 
 DRA_API int dra_set_tuning(int mask) {
   if (mask < 0) return DRA_EINVAL;

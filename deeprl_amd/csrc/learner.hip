@@ -23,6 +23,7 @@
 #include <new>
 #include <stddef.h>
 #include <string.h>
+#include <chrono>
 
 enum { K_GATHER, K_CONV1_F, K_CONV2_F, K_CONV3_F, K_FC4_F, K_HEAD, K_HEAD_BW, K_FC4_BW, K_FC4_BX, K_CONV3_BW, K_CONV3_BX,
        K_CONV2_BW, K_CONV2_BX, K_CONV1_BW, K_NORM, K_STEP, K_COUNT };
@@ -38,15 +39,21 @@ enum { P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WH, P_BH, P_COUNT };
 constexpr int kFc4Split = 8;     // split-K of the 3136 -> 512 layer (slabs reduced inside head_fused_kernel)
 constexpr int kMaxEnvSteps = 8;  // env transitions per agent step (sgd_update_frequency)
 constexpr size_t kPrmHeadBytes = offsetof(dra_dqn_step_params, idx);  // the part the actor kernels read
+constexpr int kAprmSlots = 16;
+constexpr size_t kAprmStride = 512;
+static_assert(kPrmHeadBytes <= kAprmStride && kPrmHeadBytes % 4 == 0, "pinned parameter ring entry");
 
 struct dra_dqn_learner {
   dra_dqn_config c;
   dra_ring* ring;
   float *p, *pt, *g, *s1, *s2;
   // workspaces
-  uint8_t *state, *next_state, *act_state;
-  int64_t *action, *idx;
-  float *reward, *mask;
+  // minibatch (gather outputs), double-buffered: buffer `gb` is the one the gather / update body kernels
+  // currently issued refer to (pipelined async mode alternates; every other path uses buffer 0)
+  uint8_t *state_[2], *next_state_[2], *act_state;
+  int64_t *action_[2], *idx;
+  float *reward_[2], *mask_[2];
+  int gb;
   float *y1[3], *y2[3], *y3[3], *h4, *q[3];
   float *ay1, *ay2, *ay3, *aq;  // actor (batch 1)
   float *dq, *dh4, *dy3, *dy2, *dy1, *delta, *prio, *weights, *samp_prob;
@@ -67,6 +74,18 @@ struct dra_dqn_learner {
   bool stage_used[8];
   hipGraphExec_t g_update;
   bool g_update_ready;
+  // pipelined async mode (DRA_VAR_PIPE_GATHER): per step parity, body + optimizer in one graph
+  hipGraphExec_t g_pipe[2];
+  bool g_pipe_ready[2];
+  hipEvent_t ev_mb_ready[2], ev_mb_free[2];   // gather of buffer b finished / update body done with buffer b
+  bool mb_used[2];
+  int64_t step_no;                  // async steps with an update issued so far
+  // optional timeline of the pipelined async step (measurement aid): per traced step 5 timing events --
+  // actor stream before gather / after gather / after the actor graph, update stream before / after the graph
+  hipEvent_t* tr_ev;
+  int tr_cap, tr_n;
+  double host_wait_s, host_call_s;  // dra_dqn_learner_step: seconds blocked on a staging slot / seconds in the call
+  int64_t host_calls;
   // actor graphs are keyed by (n_env, parameter block they read): online params in in-order mode, one of the
   // two actor copies in async mode (DRA_VAR_ACTOR_PARAMS)
   struct { hipGraphExec_t exec; const float* params; int n_env; bool ready; } g_actor[3];
@@ -74,6 +93,14 @@ struct dra_dqn_learner {
   int pa_cur;                       // pa[pa_cur] holds the newest completed parameters
   bool pa_valid;
   float* ah4;                       // actor fc4 output (v2)
+  // actor v3: parameter blocks are read by the graph's first kernel straight from a pinned ring (no copy
+  // command in front of the graph); the device counter selects the ring entry, in lockstep with aprm_seq
+  uint8_t* aprm_ring;               // pinned, kAprmSlots x kAprmStride bytes
+  unsigned* aprm_seq_dev;           // actor launches executed so far (device)
+  unsigned* fc4_ticket;             // last-workgroup ticket of the fused fc4 + head kernel
+  uint64_t aprm_seq;                // actor launches issued so far (host)
+  hipEvent_t aprm_ev[16];
+  bool aprm_used[16];
   hipStream_t side;                 // fork stream for graph branches
   hipEvent_t ev_fork, ev_join[4];
   hipEvent_t ev_actor_done, ev_gather_done, ev_step_done;
@@ -81,6 +108,40 @@ struct dra_dqn_learner {
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
 };
+
+// HIP stream restricted to a set of compute units (bit i of cu_mask = CU i enabled).  The async agent step runs
+// two latency-bound kernel chains concurrently; without a partition every small actor kernel queues behind
+// whatever workgroups of the update currently fill the chip (measured: actor chain 116 us alone, 165 us under
+// the update).  A disjoint CU partition gives each chain its own workgroup slots.
+DRA_API int dra_stream_create_masked(void** out, const uint32_t* cu_mask, int n_words) {
+  if (!out || !cu_mask || n_words < 1) return DRA_EINVAL;
+  hipStream_t s;
+  DRA_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
+  *out = (void*)s;
+  return DRA_OK;
+}
+
+// Where did a workgroup land?  out[2*wg] = XCC id, out[2*wg+1] = HW_ID (cu_id bits 11:8, sh 12, se 15:13).
+// Used by tools/probe_cu_mask.py to map CU-mask bits to XCDs.
+__global__ void hw_id_kernel(uint32_t* __restrict__ out) {
+  uint32_t xcc, hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = xcc; out[2 * blockIdx.x + 1] = hw; }
+}
+
+DRA_API int dra_probe_hw_id(uint32_t* out, int n_workgroups, void* stream) {
+  if (!out || n_workgroups < 1) return DRA_EINVAL;
+  hipLaunchKernelGGL(hw_id_kernel, dim3(n_workgroups), dim3(64), 0, dra_stream(stream), out);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+DRA_API int dra_stream_destroy(void* stream) {
+  if (!stream) return DRA_OK;
+  DRA_HIP(hipStreamDestroy(dra_stream(stream)));
+  return DRA_OK;
+}
 
 static int alloc_f(float** p, int64_t n) { return (int)hipMalloc(p, (size_t)n * sizeof(float)); }
 
@@ -97,12 +158,14 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   const int B = cfg->batch, A = cfg->n_actions;
   const int nz = cfg->double_q ? 3 : 2;
   int rc = 0;
-  rc |= (int)hipMalloc(&l->state, (size_t)B * 4 * 7056);
-  rc |= (int)hipMalloc(&l->next_state, (size_t)B * 4 * 7056);
+  for (int g = 0; g < 2; ++g) {
+    rc |= (int)hipMalloc(&l->state_[g], (size_t)B * 4 * 7056);
+    rc |= (int)hipMalloc(&l->next_state_[g], (size_t)B * 4 * 7056);
+    rc |= (int)hipMalloc(&l->action_[g], (size_t)B * 8);
+    rc |= alloc_f(&l->reward_[g], B); rc |= alloc_f(&l->mask_[g], B);
+  }
   rc |= (int)hipMalloc(&l->act_state, (size_t)4 * 7056);
-  rc |= (int)hipMalloc(&l->action, (size_t)B * 8);
   rc |= (int)hipMalloc(&l->idx, (size_t)B * 8);
-  rc |= alloc_f(&l->reward, B); rc |= alloc_f(&l->mask, B);
   for (int z = 0; z < nz; ++z) {
     rc |= alloc_f(&l->y1[z], (int64_t)B * 32 * 400); rc |= alloc_f(&l->y2[z], (int64_t)B * 64 * 81);
     rc |= alloc_f(&l->y3[z], (int64_t)B * 64 * 49); rc |= alloc_f(&l->q[z], (int64_t)B * A);
@@ -133,6 +196,14 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   l->n_partials = 2 * dra_norm_partials();
   rc |= alloc_f(&l->ah4, 512);
   if (l->variant & DRA_VAR_ACTOR_PARAMS) { rc |= alloc_f(&l->pa[0], cfg->n_params); rc |= alloc_f(&l->pa[1], cfg->n_params); }
+  if (l->variant & DRA_VAR_ACTOR_V3) {
+    rc |= (int)hipHostMalloc(&l->aprm_ring, kAprmSlots * kAprmStride, hipHostMallocDefault);
+    rc |= (int)hipMalloc(&l->aprm_seq_dev, sizeof(unsigned));
+    rc |= (int)hipMalloc(&l->fc4_ticket, sizeof(unsigned));
+    if (!rc) rc |= (int)hipMemset(l->aprm_seq_dev, 0, sizeof(unsigned));
+    if (!rc) rc |= (int)hipMemset(l->fc4_ticket, 0, sizeof(unsigned));
+    for (int k = 0; k < kAprmSlots; ++k) rc |= (int)hipEventCreateWithFlags(&l->aprm_ev[k], hipEventDisableTiming);
+  }
   rc |= alloc_f(&l->fc4_slabs, (int64_t)3 * kFc4Split * B * 512);
   rc |= alloc_f(&l->afc4_slabs, (int64_t)kFc4Split * 512);
   l->lin_ws_floats = (int64_t)3 * 32 * B * 512;
@@ -155,6 +226,10 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= (int)hipEventCreateWithFlags(&l->ev_actor_done, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_gather_done, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_step_done, hipEventDisableTiming);
+  for (int g = 0; g < 2; ++g) {
+    rc |= (int)hipEventCreateWithFlags(&l->ev_mb_ready[g], hipEventDisableTiming);
+    rc |= (int)hipEventCreateWithFlags(&l->ev_mb_free[g], hipEventDisableTiming);
+  }
   if (rc) { delete l; return rc; }
   *out = l;
   return DRA_OK;
@@ -164,10 +239,24 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (!l) return DRA_OK;
   (void)hipDeviceSynchronize();
   if (l->g_update_ready) (void)hipGraphExecDestroy(l->g_update);
+  if (l->tr_ev) {
+    for (int i = 0; i < l->tr_cap * 5; ++i) (void)hipEventDestroy(l->tr_ev[i]);
+    delete[] l->tr_ev;
+  }
+  for (int g = 0; g < 2; ++g) {
+    if (l->g_pipe_ready[g]) (void)hipGraphExecDestroy(l->g_pipe[g]);
+    (void)hipEventDestroy(l->ev_mb_ready[g]); (void)hipEventDestroy(l->ev_mb_free[g]);
+    void* mb[] = {l->state_[g], l->next_state_[g], l->action_[g], l->reward_[g], l->mask_[g]};
+    for (void* b : mb) if (b) (void)hipFree(b);
+  }
   for (auto& ga : l->g_actor) if (ga.ready) (void)hipGraphExecDestroy(ga.exec);
   for (int k = 0; k < 2; ++k) if (l->pa[k]) (void)hipFree(l->pa[k]);
   if (l->ah4) (void)hipFree(l->ah4);
-  void* bufs[] = {l->state, l->next_state, l->act_state, l->action, l->idx, l->reward, l->mask, l->h4, l->ay1, l->ay2,
+  if (l->aprm_ring) {
+    (void)hipHostFree(l->aprm_ring); (void)hipFree(l->aprm_seq_dev); (void)hipFree(l->fc4_ticket);
+    for (int k = 0; k < kAprmSlots; ++k) (void)hipEventDestroy(l->aprm_ev[k]);
+  }
+  void* bufs[] = {l->act_state, l->idx, l->h4, l->ay1, l->ay2,
                   l->ay3, l->aq, l->dq, l->dh4, l->dy3, l->dy2, l->dy1, l->delta, l->prio, l->weights, l->samp_prob,
                   l->slabs, l->fc4_slabs, l->afc4_slabs, l->lin_ws, l->partials, l->loss, l->norm, l->prm_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
@@ -325,8 +414,8 @@ head_wgrad_kernel(const float* __restrict__ dq, const float* __restrict__ h4, in
 // read their 8-byte index over the host link (~1-2 us, inside the kernel) instead of waiting for a
 // separate 4-5 us copy command on the update's critical path.
 static int launch_gather(dra_dqn_learner* l, hipStream_t st, const int64_t* idx = nullptr) {
-  return dra_ring_gather(l->ring, idx ? idx : l->idx, l->c.batch, l->state, l->next_state, l->action, nullptr, nullptr, l->reward,
-                         l->mask, (void*)st);
+  return dra_ring_gather(l->ring, idx ? idx : l->idx, l->c.batch, l->state_[l->gb], l->next_state_[l->gb], l->action_[l->gb], nullptr, nullptr,
+                         l->reward_[l->gb], l->mask_[l->gb], (void*)st);
 }
 
 static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = nullptr) {
@@ -347,7 +436,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   const float* T = l->pt;
   const int64_t* o = c.offset;
   // z = 0: online(states)   z = 1: target(next_states)   z = 2: online(next_states) [double-Q]
-  const void* x1[3] = {l->state, l->next_state, l->next_state};
+  const void* x1[3] = {l->state_[l->gb], l->next_state_[l->gb], l->next_state_[l->gb]};
   const float* w1[3] = {P + o[P_W1], T + o[P_W1], P + o[P_W1]};
   const float* b1[3] = {P + o[P_B1], T + o[P_B1], P + o[P_B1]};
   STEP(K_CONV1_F, dra_conv_fwd_koc(1, nz, x1, w1, b1, l->y1, B, 1, c.u8_coef, DRA_ACT_RELU, s));
@@ -366,11 +455,13 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_HEAD], st));
   hipLaunchKernelGGL(head_fused_kernel<kFc4Split>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                      P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
-                     (const int64_t*)l->action, (const float*)l->reward, (const float*)l->mask, c.gamma_n, c.double_q,
+                     (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
+                     c.double_q,
                      l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4);
   DRA_LAUNCH_CHECK();
   if (per) {  // PER needs the batch-wide max of the importance weights: separate kernel recomputes dq, then dh4
-    int rc = dra_td_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action, 1, l->reward, l->mask, B, A, c.gamma_n,
+    int rc = dra_td_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action_[l->gb], 1, l->reward_[l->gb],
+                         l->mask_[l->gb], B, A, c.gamma_n,
                          l->samp_prob, beta, c.replay_eps, c.replay_alpha, l->loss, l->dq, l->delta, l->prio, l->weights, s);
     if (rc) return rc;
     rc = dra_linear_bwd_x(l->dq, P + o[P_WH], l->h4, l->dh4, B, 512, A, DRA_ACT_RELU, s);
@@ -399,7 +490,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV2_BW], st));
     STEP(K_CONV2_BX, dra_conv_bwd_fused(2, l->dy2, l->y1[0], P + o[P_W2], l->y1[0], dw[1], dbs[1], stride[1], c.ksplit,
                                         l->dy1, B, 0, 1.0, DRA_ACT_RELU, var, s));
-    STEP(K_CONV1_BW, dra_conv_bwd_fused(1, l->dy1, l->state, nullptr, nullptr, dw[0], dbs[0], stride[0], c.ksplit, nullptr,
+    STEP(K_CONV1_BW, dra_conv_bwd_fused(1, l->dy1, l->state_[l->gb], nullptr, nullptr, dw[0], dbs[0], stride[0], c.ksplit, nullptr,
                                         B, 1, c.u8_coef, DRA_ACT_RELU, var, s));
     if (own) {
       dra_fold_seg segs[3];
@@ -434,7 +525,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   if (fork) { DRA_HIP(hipEventRecord(l->ev_join[1], st)); DRA_HIP(hipStreamWaitEvent(sd, l->ev_join[1], 0)); }
   STEP(K_CONV2_BW, dra_conv_bwd_w_koc(2, l->dy2, l->y1[0], S + o[P_W2], S + o[P_B2], l->slab_stride, c.ksplit, B, 0, 1.0, sds));
   STEP(K_CONV2_BX, dra_conv_bwd_x_koc(2, l->dy2, P + o[P_W2], l->y1[0], l->dy1, B, DRA_ACT_RELU, s));
-  STEP(K_CONV1_BW, dra_conv_bwd_w_koc(1, l->dy1, l->state, S + o[P_W1], S + o[P_B1], l->slab_stride, c.ksplit, B, 1, c.u8_coef, s));
+  STEP(K_CONV1_BW, dra_conv_bwd_w_koc(1, l->dy1, l->state_[l->gb], S + o[P_W1], S + o[P_B1], l->slab_stride, c.ksplit, B, 1, c.u8_coef, s));
   if (fork) { DRA_HIP(hipEventRecord(l->ev_join[2], sd)); DRA_HIP(hipStreamWaitEvent(st, l->ev_join[2], 0)); }
   const int np = dra_norm_partials();
   STEP(K_NORM, dra_grad_sqnorm(G, c.conv_end, S, c.ksplit, l->slab_stride, l->partials, s));  // folds the conv slabs
@@ -458,6 +549,28 @@ static int body_graph(dra_dqn_learner* l, hipStream_t st) {
     l->g_update_ready = true;
   }
   DRA_HIP(hipGraphLaunch(l->g_update, st));
+  return DRA_OK;
+}
+
+// Pipelined async mode: update body + optimizer of one step parity as ONE graph (no launch gap in front of
+// the optimizer).  The optimizer's second output is the actor parameter copy of the same parity.
+static int pipe_graph(dra_dqn_learner* l, hipStream_t st, int par) {
+  if (!l->g_pipe_ready[par]) {
+    hipGraph_t graph;
+    l->gb = par;
+    hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (b != hipSuccess) { l->gb = 0; return (int)b; }
+    int rc = run_body(l, st, 0, 0.f, 0);
+    if (rc == DRA_OK) rc = launch_optimizer(l, st, l->pa[par]);
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    l->gb = 0;
+    if (rc != DRA_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    DRA_HIP(hipGraphInstantiate(&l->g_pipe[par], graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    l->g_pipe_ready[par] = true;
+  }
+  DRA_HIP(hipGraphLaunch(l->g_pipe[par], st));
   return DRA_OK;
 }
 
@@ -690,6 +803,147 @@ actor_head_env_kernel(const dra_dqn_step_params* __restrict__ prm, int e, const 
   if (e + 1 < prm->n_env) synth_transition(prm, e + 1, frames, rewards, masks, seed, done_period);
 }
 
+// ---- actor v3 (DRA_VAR_ACTOR_V3): 4 kernels per env step and no copy command in front of the graph.
+//   env_frame_v3_kernel        : first kernel of the graph.  Copies this launch's parameter block from the pinned
+//                                ring entry (*seq mod kAprmSlots) to the device block the later kernels read, bumps
+//                                *seq, then produces the frame of env step 0.
+//   actor_fc4_head_env_kernel  : fc4 GEMV as in v2; every workgroup publishes its 4 rows of h4, fences and takes a
+//                                ticket; the LAST workgroup to arrive (all of h4 is then visible to it) computes the
+//                                head, the epsilon-greedy action and the environment step -- one dependent launch
+//                                less per env step.
+__global__ void __launch_bounds__(256)
+env_frame_v3_kernel(const uint8_t* __restrict__ ring_pinned, unsigned* __restrict__ seq, dra_dqn_step_params* __restrict__ prm_dev,
+                    uint8_t* __restrict__ frames, double* __restrict__ rewards, int32_t* __restrict__ masks, uint64_t seed,
+                    int done_period) {
+  __shared__ uint32_t s_prm[kAprmStride / 4];
+  constexpr int NW = (int)(kPrmHeadBytes / 4);
+  const unsigned n = *seq;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(ring_pinned + (size_t)(n % kAprmSlots) * kAprmStride);
+  if (threadIdx.x < NW) {
+    const uint32_t v = src[threadIdx.x];
+    s_prm[threadIdx.x] = v;
+    reinterpret_cast<uint32_t*>(prm_dev)[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *seq = n + 1;
+  synth_transition(reinterpret_cast<const dra_dqn_step_params*>(s_prm), 0, frames, rewards, masks, seed, done_period);
+}
+
+__global__ void __launch_bounds__(256)
+actor_fc4_head_env_kernel(const dra_dqn_step_params* __restrict__ prm, int e, const float* __restrict__ x,
+                          const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ h4,
+                          int in_features, unsigned* __restrict__ ticket, const float* __restrict__ wh,
+                          const float* __restrict__ bh, int A, uint8_t* __restrict__ ring_actions, float* __restrict__ q_out,
+                          uint8_t* __restrict__ frames, double* __restrict__ rewards, int32_t* __restrict__ masks,
+                          uint64_t seed, int done_period) {
+  constexpr int R = 13;  // float4 per lane: 3136 / 4 / 64 = 12.25
+  __shared__ float s_q[64];
+  __shared__ unsigned s_last;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  {
+    const int row = blockIdx.x * 4 + wave;
+    const int nv = in_features >> 2;
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w + (int64_t)row * in_features);
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    float4 wv[R], xv[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int i = min(lane + 64 * q, nv - 1);
+      wv[q] = w4[i];
+      xv[q] = x4[i];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      float4 a = wv[q], b = xv[q];
+      asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));  // loads stay unconditional and batched
+      if (lane + 64 * q < nv) acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float v = acc + bias[row];
+      // agent-scope store: written through to memory, no cache-wide writeback needed to publish it
+      __hip_atomic_store(h4 + row, v > 0.f ? v : 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // publish, then take a ticket: the workgroup that draws the last one sees every other workgroup's rows.
+  // (A __threadfence() here costs a full L2 writeback + invalidate per workgroup: measured +9 us per env step;
+  // the rows are published with agent-scope stores and completed with s_waitcnt before the ticket instead.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  asm volatile("" ::: "memory");
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch starts from zero
+  for (int a = wave; a < A; a += 4) {
+    float hv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hv[i] = __hip_atomic_load(h4 + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part += hv[i] * wh[a * 512 + lane + 64 * i];
+    part = wave_sum(part);
+    if (lane == 0) s_q[a] = part + bh[a];
+  }
+  __syncthreads();
+  if (threadIdx.x < A && q_out) q_out[threadIdx.x] = s_q[threadIdx.x];
+  if (threadIdx.x == 0) {
+    int best = 0;
+    float bv = s_q[0];
+    for (int a = 1; a < A; ++a) if (s_q[a] > bv) { bv = s_q[a]; best = a; }  // np.argmax: first max
+    const int64_t act = (prm->dice[e] < prm->epsilon[e]) ? (int64_t)prm->random_action[e] : (int64_t)best;
+    if (prm->store_action[e]) *reinterpret_cast<int64_t*>(ring_actions + prm->slot[e] * 8) = act;
+  }
+  if (e + 1 < prm->n_env) synth_transition(prm, e + 1, frames, rewards, masks, seed, done_period);
+}
+
+static int run_actor_steps_v3(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
+  const dra_dqn_config& c = l->c;
+  void *frames, *actions, *rewards, *masks;
+  int rc = dra_ring_pointers(l->ring, &frames, &actions, &rewards, &masks);
+  if (rc) return rc;
+  const int64_t* o = c.offset;
+  void* s = (void*)st;
+  hipLaunchKernelGGL(env_frame_v3_kernel, dim3(1), dim3(256), 0, st, (const uint8_t*)l->aprm_ring, l->aprm_seq_dev,
+                     l->prm_dev, (uint8_t*)frames, (double*)rewards, (int32_t*)masks, (uint64_t)c.env_seed,
+                     (int)c.env_done_period);
+  DRA_LAUNCH_CHECK();
+  for (int e = 0; e < n_env; ++e) {
+    if ((rc = dra_conv1_fwd_koc_ring(frames, &l->prm_dev->slot[e], c.ring_capacity, P + o[P_W1], P + o[P_B1], l->ay1,
+                                     c.u8_coef, DRA_ACT_RELU, s)))
+      return rc;
+    const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
+    float* y2[1] = {l->ay2};
+    if ((rc = dra_conv_fwd_koc(2, 1, x2, w2, b2, y2, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+    const void* x3[1] = {l->ay2}; const float* w3[1] = {P + o[P_W3]}; const float* b3[1] = {P + o[P_B3]};
+    float* y3[1] = {l->ay3};
+    if ((rc = dra_conv_fwd_koc(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+    hipLaunchKernelGGL(actor_fc4_head_env_kernel, dim3(128), dim3(256), 0, st, (const dra_dqn_step_params*)l->prm_dev, e,
+                       (const float*)l->ay3, P + o[P_W4], P + o[P_B4], l->ah4, 3136, l->fc4_ticket, P + o[P_WH],
+                       P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq, (uint8_t*)frames, (double*)rewards,
+                       (int32_t*)masks, (uint64_t)c.env_seed, (int)c.env_done_period);
+    DRA_LAUNCH_CHECK();
+  }
+  return DRA_OK;
+}
+
+// v3: the parameter block travels through the pinned ring (read by the graph's first kernel) instead of a copy
+// command; entry = launch sequence number mod kAprmSlots, free again once the launch that read it has finished.
+static int stage_actor_params(dra_dqn_learner* l, const dra_dqn_step_params* prm, hipStream_t st, bool before_launch) {
+  const int k = (int)(l->aprm_seq % kAprmSlots);
+  if (before_launch) {
+    if (l->aprm_used[k]) DRA_HIP(hipEventSynchronize(l->aprm_ev[k]));
+    memcpy(l->aprm_ring + (size_t)k * kAprmStride, prm, kPrmHeadBytes);
+  } else {
+    DRA_HIP(hipEventRecord(l->aprm_ev[k], st));
+    l->aprm_used[k] = true;
+    l->aprm_seq++;
+  }
+  return DRA_OK;
+}
+
 static int run_actor_steps_v2(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
   const dra_dqn_config& c = l->c;
   void *frames, *actions, *rewards, *masks;
@@ -722,6 +976,7 @@ static int run_actor_steps_v2(dra_dqn_learner* l, int n_env, const float* P, hip
 }
 
 static int run_actor_steps(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
+  if (l->variant & DRA_VAR_ACTOR_V3) return run_actor_steps_v3(l, n_env, P, st);
   if (l->variant & DRA_VAR_ACTOR_V2) return run_actor_steps_v2(l, n_env, P, st);
   const dra_dqn_config& c = l->c;
   void *frames, *actions, *rewards, *masks;
@@ -780,11 +1035,121 @@ static int actor_graph(dra_dqn_learner* l, int n_env, const float* P, hipStream_
   return DRA_OK;
 }
 
+static int actor_graph(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st);
+static int issue_actor(dra_dqn_learner* l, const dra_dqn_step_params* prm, int k, const float* P, hipStream_t st, bool use_graph);
+
+#define TRACE(slot, stream)                                                                        \
+  do {                                                                                             \
+    if (l->tr_ev && l->tr_n < l->tr_cap) DRA_HIP(hipEventRecord(l->tr_ev[l->tr_n * 5 + (slot)], (stream))); \
+  } while (0)
+
+// Arms the timeline for the next `n_steps` pipelined async steps (n_steps = 0 frees it).
+DRA_API int dra_dqn_learner_trace(dra_dqn_learner* l, int n_steps) {
+  if (!l || n_steps < 0 || n_steps > 4096) return DRA_EINVAL;
+  if (l->tr_ev) {
+    for (int i = 0; i < l->tr_cap * 5; ++i) (void)hipEventDestroy(l->tr_ev[i]);
+    delete[] l->tr_ev;
+    l->tr_ev = nullptr;
+  }
+  l->tr_cap = l->tr_n = 0;
+  if (n_steps == 0) return DRA_OK;
+  l->tr_ev = new (std::nothrow) hipEvent_t[(size_t)n_steps * 5];
+  if (!l->tr_ev) return DRA_ENOMEM;
+  for (int i = 0; i < n_steps * 5; ++i) DRA_HIP(hipEventCreate(&l->tr_ev[i]));
+  l->tr_cap = n_steps;
+  return DRA_OK;
+}
+
+// Milliseconds of every traced event relative to the first one: out[step * 5 + slot].  Synchronises.
+DRA_API int dra_dqn_learner_trace_read(dra_dqn_learner* l, float* out_ms, int max_steps, int* n_steps) {
+  if (!l || !out_ms || !n_steps) return DRA_EINVAL;
+  const int n = l->tr_n < max_steps ? l->tr_n : max_steps;
+  *n_steps = n;
+  if (n == 0) return DRA_OK;
+  DRA_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < n * 5; ++i) DRA_HIP(hipEventElapsedTime(&out_ms[i], l->tr_ev[0], l->tr_ev[i]));
+  return DRA_OK;
+}
+
+// async mode, DRA_VAR_PIPE_GATHER (needs DRA_VAR_ACTOR_PARAMS).  Two independent chains per agent step t:
+//   actor stream  : gather(t) -> minibatch buffer t%2 ; actor graph of step t+1 (reads parameter copy (t+1)%2)
+//   update stream : body(t) + optimizer(t) as one graph on minibatch buffer t%2 ; the optimizer also writes
+//                   parameter copy t%2 (read by the actor graph of step t+2)
+// The gather sits between the actor graph that wrote this step's transitions and the one that overwrites the
+// oldest ring slots, in stream order -- no event on either chain's critical path: the waits below (minibatch
+// buffer free again, optimizer of step t-1 done) refer to work issued a whole step earlier.
+static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, hipStream_t su,
+                          hipStream_t sa, int k) {
+  const int B = l->c.batch;
+  const int par = (int)(l->step_no & 1);
+  int rc;
+  if (do_update) {
+    if (l->mb_used[par]) DRA_HIP(hipStreamWaitEvent(sa, l->ev_mb_free[par], 0));
+    const int64_t* pinned = (l->variant & DRA_VAR_PINNED_IDX) ? l->idx_stage + (size_t)k * 1024 : nullptr;
+    if (!pinned)
+      DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, sa));
+    TRACE(0, sa);
+    l->gb = par;
+    rc = launch_gather(l, sa, pinned);
+    l->gb = 0;
+    if (rc) return rc;
+    DRA_HIP(hipEventRecord(l->ev_mb_ready[par], sa));
+    TRACE(1, sa);
+  }
+  bool seeded = false;
+  if (prm->n_env > 0) {
+    if (l->pa_valid && l->pa_cur != (par ^ 1)) l->pa_valid = false;   // copies out of phase with the step parity
+    DRA_HIP(hipStreamWaitEvent(sa, l->ev_step_done, 0));              // the optimizer that produced the copy read below
+    if (!l->pa_valid) {
+      l->pa_cur = par ^ 1;
+      DRA_HIP(hipMemcpyAsync(l->pa[l->pa_cur], l->p, (size_t)l->c.n_params * sizeof(float), hipMemcpyDeviceToDevice, sa));
+      DRA_HIP(hipEventRecord(l->ev_join[0], sa));
+      l->pa_valid = true;
+      seeded = true;
+    }
+    if ((rc = issue_actor(l, prm, k, l->pa[l->pa_cur], sa, true))) return rc;
+    DRA_HIP(hipEventRecord(l->ev_actor_done, sa));
+    l->actor_pending = true;
+    TRACE(2, sa);
+  }
+  DRA_HIP(hipEventRecord(l->stage_ev[k], sa));  // staging slot k: parameter block copy and the gather's pinned index reads
+  if (do_update) {
+    DRA_HIP(hipStreamWaitEvent(su, l->ev_mb_ready[par], 0));
+    if (seeded) DRA_HIP(hipStreamWaitEvent(su, l->ev_join[0], 0));    // the seed copy read the parameters this step overwrites
+    TRACE(3, su);
+    if ((rc = pipe_graph(l, su, par))) return rc;
+    TRACE(4, su);
+    if (l->tr_ev && l->tr_n < l->tr_cap) l->tr_n++;
+    DRA_HIP(hipEventRecord(l->ev_step_done, su));
+    DRA_HIP(hipEventRecord(l->ev_mb_free[par], su));
+    l->mb_used[par] = true;
+    if (l->pa_valid) l->pa_cur = par;   // the graph's optimizer wrote copy `par`
+    l->step_no++;
+  }
+  return DRA_OK;
+}
+
+// Actor transitions of `prm` on `st`: parameter block (copy command, or the pinned ring of actor v3) + the
+// captured graph (or the eager kernels).
+static int issue_actor(dra_dqn_learner* l, const dra_dqn_step_params* prm, int k, const float* P, hipStream_t st, bool use_graph) {
+  int rc;
+  const bool v3 = l->variant & DRA_VAR_ACTOR_V3;
+  if (v3) { if ((rc = stage_actor_params(l, prm, st, true))) return rc; }
+  else DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, st));
+  rc = use_graph ? actor_graph(l, prm->n_env, P, st) : run_actor_steps(l, prm->n_env, P, st);
+  if (rc) return rc;
+  return v3 ? stage_actor_params(l, prm, st, false) : DRA_OK;
+}
+
 // pinned staging slot k is free again once the copies issued from it have completed
 static int stage_acquire(dra_dqn_learner* l, int* k_out) {
   const int k = l->stage_k;
   l->stage_k = (k + 1) % 8;
-  if (l->stage_used[k]) DRA_HIP(hipEventSynchronize(l->stage_ev[k]));
+  if (l->stage_used[k]) {
+    const auto t0 = std::chrono::steady_clock::now();
+    DRA_HIP(hipEventSynchronize(l->stage_ev[k]));
+    l->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
   l->stage_used[k] = true;
   *k_out = k;
   return DRA_OK;
@@ -798,9 +1163,9 @@ DRA_API int dra_dqn_learner_act(dra_dqn_learner* l, const dra_dqn_step_params* p
   int rc = stage_acquire(l, &k);
   if (rc) return rc;
   memcpy(&l->prm_stage[k], prm, kPrmHeadBytes);
-  DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, st));
+  rc = issue_actor(l, prm, k, l->p, st, use_graph != 0);
   DRA_HIP(hipEventRecord(l->stage_ev[k], st));
-  return use_graph ? actor_graph(l, prm->n_env, l->p, st) : run_actor_steps(l, prm->n_env, l->p, st);
+  return rc;
 }
 
 // One whole agent step (DQN_agent.py:101-138 minus logging): prm->n_env actor transitions, then one
@@ -813,9 +1178,30 @@ DRA_API int dra_dqn_learner_act(dra_dqn_learner* l, const dra_dqn_step_params* p
 //              the first step.  Exclusions, as HIP events: actor ring writes wait for this
 //              update's gather; the optimizer kernel waits for the actor's forwards; the next
 //              actor waits for the optimizer.
+static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, void* stream_update,
+                             void* stream_actor);
+
 DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, void* stream_update,
                                  void* stream_actor) {
   if (!l || !prm || prm->n_env < 0 || prm->n_env > kMaxEnvSteps) return DRA_EINVAL;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = learner_step_impl(l, prm, do_update, stream_update, stream_actor);
+  l->host_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  l->host_calls++;
+  return rc;
+}
+
+// Host-side accounting of dra_dqn_learner_step since the last reset: out[0] = calls, out[1] = seconds inside
+// the call, out[2] = seconds of that blocked on a pinned staging slot (i.e. waiting for the GPU: back-pressure).
+DRA_API int dra_dqn_learner_host_stats(dra_dqn_learner* l, double* out, int reset) {
+  if (!l || !out) return DRA_EINVAL;
+  out[0] = (double)l->host_calls; out[1] = l->host_call_s; out[2] = l->host_wait_s;
+  if (reset) { l->host_calls = 0; l->host_call_s = 0; l->host_wait_s = 0; }
+  return DRA_OK;
+}
+
+static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, void* stream_update,
+                             void* stream_actor) {
   hipStream_t su = dra_stream(stream_update);
   hipStream_t sa = dra_stream(stream_actor);
   const int B = l->c.batch;
@@ -826,8 +1212,7 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
   memcpy(l->idx_stage + (size_t)k * 1024, prm->idx, (size_t)B * sizeof(int64_t));
   if (!stream_actor) {  // ---- sync mode
     if (prm->n_env > 0) {
-      DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, su));
-      if ((rc = actor_graph(l, prm->n_env, l->p, su))) return rc;
+      if ((rc = issue_actor(l, prm, k, l->p, su, true))) return rc;
     }
     if (do_update) l->pa_valid = false;
     if (do_update) {
@@ -843,6 +1228,7 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
     return DRA_OK;
   }
   // ---- async mode
+  if ((l->variant & DRA_VAR_PIPE_GATHER) && (l->variant & DRA_VAR_ACTOR_PARAMS)) return step_pipelined(l, prm, do_update, su, sa, k);
   if (do_update) {
     if (l->actor_pending) DRA_HIP(hipStreamWaitEvent(su, l->ev_actor_done, 0));  // transitions of this step are in the ring
     const int64_t* pinned = (l->variant & DRA_VAR_PINNED_IDX) ? l->idx_stage + (size_t)k * 1024 : nullptr;
@@ -855,7 +1241,6 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
   bool seeded = false;
   if (prm->n_env > 0) {  // issued before the update body so that it starts as soon as the gather is done
     if (do_update) DRA_HIP(hipStreamWaitEvent(sa, l->ev_gather_done, 0));  // do not overwrite slots the gather reads
-    DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, sa));
     const float* pact = l->p;
     if (dbuf) {
       if (!l->pa_valid) {  // (re)seed the actor copy: first async step, or the parameters changed behind it
@@ -867,7 +1252,7 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
       }
       pact = l->pa[l->pa_cur];
     }
-    if ((rc = actor_graph(l, prm->n_env, pact, sa))) return rc;
+    if ((rc = issue_actor(l, prm, k, pact, sa, true))) return rc;
     DRA_HIP(hipEventRecord(l->ev_actor_done, sa));
     l->actor_pending = true;
   }

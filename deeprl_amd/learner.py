@@ -22,6 +22,12 @@ _ORDER = ["body.conv1.weight", "body.conv1.bias", "body.conv2.weight", "body.con
           "body.conv3.bias", "body.fc4.weight", "body.fc4.bias", "fc_head.weight", "fc_head.bias"]
 
 
+# CU-partitioned stream pairs live for the whole process, one pair per (device, actor CUs): PyTorch's pinned-memory
+# allocator keeps events recorded on them (non_blocking copies), so destroying such a stream while the process
+# runs crashes later inside the HIP runtime; every learner on the device shares the pair.
+_PARTITIONED_STREAMS = {}
+
+
 class DqnConfig(ctypes.Structure):
     """Mirror of dra_dqn_config (include/deeprl_amd.h)."""
     _fields_ = [("batch", ctypes.c_int32), ("n_actions", ctypes.c_int32), ("double_q", ctypes.c_int32),
@@ -59,6 +65,7 @@ class DQNLearner:
         self.target_flat = FlatParams(pt, koc=(pt[0], pt[2], pt[4]))
         self.state1 = torch.zeros_like(self.flat.flat)
         self.state2 = torch.zeros_like(self.flat.flat)
+        self.variant = int(variant) if int(variant) >= 0 else ops.get_tuning()
         cfg = DqnConfig()
         cfg.batch, cfg.n_actions, cfg.double_q, cfg.ksplit, cfg.centered = batch, n_actions, int(double_q), ksplit, int(centered)
         cfg.gamma_n, cfg.gradient_clip, cfg.lr, cfg.alpha, cfg.eps = gamma_n, gradient_clip or 0.0, lr, alpha, eps
@@ -71,7 +78,6 @@ class DQNLearner:
         for i, o in enumerate(self.flat.offsets):
             cfg.offset[i] = o
         self.cfg = cfg
-        self.variant = int(variant) if int(variant) >= 0 else ops.get_tuning()
         self.batch, self.n_actions = batch, n_actions
         h = ctypes.c_void_p()
         lib.dra_dqn_learner_create(ctypes.byref(h), ring.h, ctypes.byref(cfg), ctypes.c_void_p(self.flat.flat.data_ptr()),
@@ -90,13 +96,40 @@ class DQNLearner:
         self.delta = w(ps[5].value, batch, torch.float32)
         self.prio = w(ps[6].value, batch, torch.float32)
         self.actor_q = w(ps[7].value, n_actions, torch.float32)
-        self.stream = torch.cuda.Stream()                            # graphs cannot capture on the NULL stream
-        self.actor_stream = torch.cuda.Stream()
+        if self.variant & ops.VAR_CU_PARTITION:
+            self.stream, self.actor_stream = self._partitioned_streams()
+        else:
+            self.stream = torch.cuda.Stream()                        # graphs cannot capture on the NULL stream
+            self.actor_stream = torch.cuda.Stream()
         self.params = StepParams()
         self._idx_view = np.ctypeslib.as_array(self.params.idx)[:batch]
         self._idx_pinned = [torch.empty(batch, dtype=torch.int64).pin_memory() for _ in range(8)]
         self._idx_events = [None] * 8
         self._k = 0
+
+    def _partitioned_streams(self):
+        """Update stream / actor stream on disjoint CU sets (DRA_VAR_CU_PARTITION).  On MI355X mask bit i is CU
+        (i // 32) of shader engine (i // 8) % 4 of XCD i % 8 (tools/probe_cu_mask.py), and a workgroup's XCD is
+        fixed by the dispatcher (round robin), so the first DRA_ACTOR_CUS (default 64) bits give the actor chain
+        the same 8 CUs (2 per shader engine) in every XCD and the update chain the other 24."""
+        import os
+        n_cu = torch.cuda.get_device_properties(Config.DEVICE).multi_processor_count
+        n_act = max(8, min(n_cu - 8, int(os.environ.get("DRA_ACTOR_CUS", "64"))))
+        key = (Config.DEVICE.index, n_act)
+        if key in _PARTITIONED_STREAMS:
+            return _PARTITIONED_STREAMS[key]
+        actor_bits = set(range(n_act))
+        words = (n_cu + 31) // 32
+        out = []
+        for bits in (set(range(n_cu)) - actor_bits, actor_bits):
+            mask = (ctypes.c_uint32 * words)()
+            for b in bits:
+                mask[b // 32] |= 1 << (b % 32)
+            h = ctypes.c_void_p()
+            lib.dra_stream_create_masked(ctypes.byref(h), mask, words)
+            out.append(torch.cuda.ExternalStream(h.value, device=Config.DEVICE))
+        _PARTITIONED_STREAMS[key] = out
+        return out
 
     def close(self):
         if self.h:

@@ -382,8 +382,8 @@ def conv_bwd_x_koc(layer, dy, wt, xact=None, act="relu"):
 
 # variant bits of the fused / one-pass kernels (include/deeprl_amd.h DRA_VAR_*)
 VAR_FUSED_BWD, VAR_ONESHOT_DGRAD, VAR_ONESHOT_FWD, VAR_ONESHOT_WGRAD = 1, 2, 4, 8
-VAR_PINNED_IDX, VAR_ACTOR_V2, VAR_ACTOR_PARAMS = 16, 32, 64
-VAR_ALL = 127
+VAR_PINNED_IDX, VAR_ACTOR_V2, VAR_ACTOR_PARAMS, VAR_PIPE_GATHER, VAR_CU_PARTITION, VAR_ACTOR_V3 = 16, 32, 64, 128, 256, 512
+VAR_ALL = 1023
 
 
 def set_tuning(mask):

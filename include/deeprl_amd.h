@@ -147,6 +147,11 @@ int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* 
 #define DRA_VAR_PINNED_IDX 16    /* learner: the gather reads minibatch indices from pinned host memory */
 #define DRA_VAR_ACTOR_V2 32      /* learner: 5-kernel actor step (ring-direct conv1, GEMV fc4, head + env) */
 #define DRA_VAR_ACTOR_PARAMS 64  /* learner: async actor reads a double-buffered parameter copy */
+#define DRA_VAR_ACTOR_V3 512     /* learner: 4-kernel actor step (fc4 + head + env fused through a last-workgroup ticket),
+                                    parameter block read from a pinned ring by the graph's first kernel */
+#define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
+#define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
+                                    body + optimizer as one graph -- no cross-stream wait on either chain */
 /* process-wide default variant mask used by learners created afterwards */
 int dra_set_tuning(int mask);
 int dra_get_tuning(int* mask);
@@ -233,6 +238,23 @@ int dra_dqn_learner_act(dra_dqn_learner* learner, const dra_dqn_step_params* prm
  * step and overlap this step's update (async_actor=True; config.lock becomes HIP events). */
 int dra_dqn_learner_step(dra_dqn_learner* learner, const dra_dqn_step_params* prm, int do_update, void* stream_update,
                          void* stream_actor);
+
+/* host-side accounting of dra_dqn_learner_step since the last reset: out[0] calls, out[1] seconds in the call,
+ * out[2] seconds of that blocked on a pinned staging slot (GPU back-pressure). */
+int dra_dqn_learner_host_stats(dra_dqn_learner* learner, double* out, int reset);
+
+/* HIP stream restricted to the compute units whose bit is set in cu_mask (n_words x 32 bits): the async agent step
+ * gives the actor chain and the update chain disjoint CU partitions (DRA_VAR_CU_PARTITION, host side). */
+int dra_stream_create_masked(void** out_stream, const uint32_t* cu_mask, int n_words);
+int dra_stream_destroy(void* stream);
+/* placement probe: out[2*wg] = XCC (XCD) id, out[2*wg+1] = HW_ID register of workgroup wg (device uint32[2*n]) */
+int dra_probe_hw_id(uint32_t* out, int n_workgroups, void* stream);
+
+/* timeline of the pipelined async step without a profiler: arms 5 timing events per step for the next n_steps
+ * steps (actor stream: before gather, after gather, after the actor graph; update stream: before / after the
+ * update graph); trace_read returns milliseconds relative to the first event, out[step*5 + slot]. */
+int dra_dqn_learner_trace(dra_dqn_learner* learner, int n_steps);
+int dra_dqn_learner_trace_read(dra_dqn_learner* learner, float* out_ms, int max_steps, int* n_steps);
 
 #ifdef __cplusplus
 }

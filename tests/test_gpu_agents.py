@@ -303,7 +303,7 @@ def test_fused_learner_matches_oracle(dra, double_q, variant):
     ring.close()
 
 
-@pytest.mark.parametrize("variant", [0, 127])
+@pytest.mark.parametrize("variant", [0, 127, 767])
 def test_fused_step_sync_equals_act_then_update(dra, variant):
     """dra_dqn_learner_step in in-order mode == explicit actor transitions followed by an update:
     the synthetic frame source, the device epsilon-greedy and the captured graphs change nothing."""
@@ -351,7 +351,10 @@ def test_fused_step_sync_equals_act_then_update(dra, variant):
     assert np.array_equal(outs[0][2].reshape(24, 7056), want_frames)
 
 
-@pytest.mark.parametrize("variant", [0, 127])
+_ASYNC_RESULTS = {}
+
+
+@pytest.mark.parametrize("variant", [0, 127, 255, 767, 1023])
 def test_fused_step_async_pipeline(dra, variant):
     """async_actor=True pipeline (actor one agent step ahead on its own stream, double-buffered actor
     parameters when variant has DRA_VAR_ACTOR_PARAMS): the transitions it feeds are the documented counter-hash
@@ -381,3 +384,12 @@ def test_fused_step_async_pipeline(dra, variant):
     assert np.array_equal(outs[0][1].reshape(100, 7056), want_frames)
     assert ((outs[0][2] >= 0) & (outs[0][2] < 4)).all()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][2], outs[1][2])
+    # DRA_VAR_PIPE_GATHER moves the gather to the actor stream and the optimizer into the graph: same
+    # ordering semantics as the event-based pipeline (gather(t) between actor graphs t and t+1, actor t+1 on
+    # the parameters of optimizer t-1) -> bit-identical parameters and actions
+    _ASYNC_RESULTS[variant] = outs[0]
+    # ... and so do the 4-kernel actor step (DRA_VAR_ACTOR_V3: same arithmetic, fused launches) and the CU partition
+    for other in (255, 767, 1023):
+        if 127 in _ASYNC_RESULTS and other in _ASYNC_RESULTS:
+            assert np.array_equal(_ASYNC_RESULTS[127][0], _ASYNC_RESULTS[other][0])
+            assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
