@@ -193,10 +193,22 @@ DRA_API int dra_grad_sqnorm_segs(float* grad, int64_t n, const dra_fold_seg* seg
 // Fixed-order reduction of the partials by every workgroup; returns the clip coefficient.
 __device__ __forceinline__ float clip_coef_from_partials(const double* __restrict__ partials, int n_partials,
                                                          float max_norm, float* __restrict__ out_norm) {
+  if (!partials) return 1.f;  // uniform: no clipping requested
   __shared__ double s_part[4];
   __shared__ float s_coef;
+  // n_partials <= dra_norm_partials_max() = 2048 = 8 per thread: straight-line loads (a loop here makes the
+  // compiler drain every outstanding load of the caller first); same per-thread summation order as a loop
   double d = 0.0;
-  for (int i = threadIdx.x; i < n_partials; i += blockDim.x) d += partials[i];
+  {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = (int)threadIdx.x + 256 * u;
+      v[u] = partials[i < n_partials ? i : n_partials - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) d += ((int)threadIdx.x + 256 * u < n_partials) ? v[u] : 0.0;
+  }
   d = wave_sum(d);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = d;
   __syncthreads();
@@ -220,15 +232,32 @@ __global__ void __launch_bounds__(256)
 rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, float* __restrict__ ga,
                     int64_t n, const double* __restrict__ partials, int n_partials, float max_norm, float lr,
                     float alpha, float eps, int centered, float* __restrict__ out_norm, float* __restrict__ p_copy) {
-  const float coef = partials ? clip_coef_from_partials(partials, n_partials, max_norm, out_norm) : 1.f;
   const float oma = 1.f - alpha;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t n4 = n >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 P = reinterpret_cast<float4*>(p)[i];
-    const float4 G0 = reinterpret_cast<const float4*>(g)[i];
-    float4 S = reinterpret_cast<float4*>(sq)[i];
-    float4 A = centered ? reinterpret_cast<float4*>(ga)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // The first (for the DQN learner: the only) float4 of every operand is requested BEFORE the clip coefficient
+  // is reduced from the partials -- the operands do not depend on it, so the kernel exposes one memory
+  // latency instead of two.
+  const int64_t ic = i0 < n4 ? i0 : (n4 > 0 ? n4 - 1 : 0);
+  // (unconditional loads, n >= 4 is checked by the launcher: a branch or a default value here turns the loaded
+  // registers into phi copies and the compiler waits for them on the spot)
+  const float4 P0 = reinterpret_cast<float4*>(p)[ic];
+  const float4 G00 = reinterpret_cast<const float4*>(g)[ic];
+  const float4 S0 = reinterpret_cast<float4*>(sq)[ic];
+  const float4 A0 = reinterpret_cast<float4*>(centered ? ga : sq)[ic];
+  __builtin_amdgcn_sched_barrier(0);
+  const float coef = clip_coef_from_partials(partials, n_partials, max_norm, out_norm);
+  for (int64_t i = i0; i < n4; i += stride) {
+    float4 P, G0, S, A;
+    if (i == i0) {
+      P = P0; G0 = G00; S = S0; A = A0;
+    } else {
+      P = reinterpret_cast<float4*>(p)[i];
+      G0 = reinterpret_cast<const float4*>(g)[i];
+      S = reinterpret_cast<float4*>(sq)[i];
+      A = centered ? reinterpret_cast<float4*>(ga)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     float* pp = &P.x; const float* gg = &G0.x; float* ss = &S.x; float* aa = &A.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -282,6 +311,8 @@ DRA_API int dra_rmsprop_step_copy(float* param, const float* grad, float* square
   if (!param || !grad || !square_avg || (centered && !grad_avg) || n < 1) return DRA_EINVAL;
   if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)square_avg) | ((uintptr_t)grad_avg) | ((uintptr_t)param_copy)) & 15)
     return DRA_EINVAL;
+  if (n < 4) return DRA_EINVAL;
+  if (partials && (n_partials < 1 || n_partials > dra_norm_partials_max())) return DRA_EINVAL;
   hipLaunchKernelGGL(rmsprop_step_kernel, dim3(step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad, square_avg,
                      grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps, centered, out_norm, param_copy);
   DRA_LAUNCH_CHECK();
@@ -318,6 +349,7 @@ DRA_API int dra_adam_step(float* param, const float* grad, float* exp_avg, float
                           const double* partials, int n_partials, float max_norm, float lr, float beta1, float beta2,
                           float eps, int64_t step, float* out_norm, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return DRA_EINVAL;
+  if (partials && (n_partials < 1 || n_partials > dra_norm_partials_max())) return DRA_EINVAL;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   int64_t b = (n + 255) / 256;
