@@ -12,7 +12,11 @@ Differences that are the point of the rewrite (results unchanged):
   * TD / C51 / QR / PPO / A2C losses are single fused kernels that emit the gradient w.r.t. the
     network output, which is pushed through the HIP contractions by autograd;
   * clip_grad_norm_ + optimizer.step() are two launches over one flat buffer (optim.py);
-  * GAE / n-step returns are one chunked-scan launch instead of T python iterations.
+  * GAE / n-step returns are one chunked-scan launch instead of T python iterations;
+  * DQNAgent on the dqn_pixel configuration (VanillaNet(NatureConvBody), RMSprop, UniformReplay of 84x84 uint8
+    frames, history 4 -- examples.py:55-97) switches to the fused learner of csrc/learner.hip: one C call per
+    update (gather + forward + TD loss + backward + clip + RMSprop as a captured hipGraph) and one C call per
+    actor forward; `config.fused_learner = False` keeps the generic autograd path.
 """
 import pickle
 
@@ -152,6 +156,7 @@ class DQNActor(BaseActor):
     def __init__(self, config):
         BaseActor.__init__(self, config)
         self.config = config
+        self._fast_q = None
         self.start()
 
     def compute_q(self, prediction):
@@ -163,10 +168,13 @@ class DQNActor(BaseActor):
         config = self.config
         if config.noisy_linear:
             self._network.reset_noise()
-        with config.lock:
-            with torch.no_grad():
-                prediction = self._network(config.state_normalizer(self._state))
-        q_values = self.compute_q(prediction)
+        if self._fast_q is not None:     # fused learner attached (DQNAgent._attach_fused_learner)
+            q_values = self._fast_q(self._state)
+        else:
+            with config.lock:
+                with torch.no_grad():
+                    prediction = self._network(config.state_normalizer(self._state))
+            q_values = self.compute_q(prediction)
         if config.noisy_linear:
             epsilon = 0
         elif self._total_steps < config.exploration_steps:
@@ -200,7 +208,51 @@ class DQNAgent(BaseAgent):
         self._target_flat = FlatParams(self.target_network.parameters())
         self.actor.set_network(self.network)
         self.total_steps = 0
+        self._learner = None            # fused learner (csrc/learner.hip), attached lazily when eligible
+        self._fused_checked = False
         self._post_init()
+
+    # -- fused fast path ---------------------------------------------------------------------------------
+    def _inner_replay(self):
+        return getattr(self.replay, 'replay', self.replay)
+
+    def _fused_eligible(self):
+        """The configuration csrc/learner.hip implements: examples.py:55-97 (dqn_pixel) with uniform replay."""
+        from .nets import NatureConvBody, VanillaNet
+        from .normalizers import ImageNormalizer
+        from .replay import UniformReplay
+        cfg = self.config
+        if type(self) is not DQNAgent or getattr(cfg, 'fused_learner', True) is False or cfg.noisy_linear:
+            return False
+        net = self.network
+        if type(net) is not VanillaNet or type(net.body) is not NatureConvBody or len(list(net.parameters())) != 10:
+            return False
+        rp = self._inner_replay()
+        if type(rp) is not UniformReplay or rp._ring is None or rp.history_length != 4:
+            return False
+        if rp._ring.frame_bytes != 7056 or rp._ring.action_bytes != 8 or rp._state_dtype != torch.uint8:
+            return False
+        if type(cfg.state_normalizer) is not ImageNormalizer or not isinstance(self.optimizer, torch.optim.RMSprop):
+            return False
+        g = self.optimizer.param_groups[0]
+        if g.get('momentum', 0) != 0 or g.get('weight_decay', 0) != 0 or len(self.optimizer.param_groups) != 1:
+            return False
+        return cfg.batch_size <= 1024 and cfg.action_dim <= 64 and net.body.conv1.weight.shape[1] == 4
+
+    def _attach_fused_learner(self):
+        from .learner import DQNLearner
+        cfg = self.config
+        g = self.optimizer.param_groups[0]
+        rp = self._inner_replay()
+        torch.cuda.synchronize()        # everything issued so far (feeds, initialisation) is on other streams
+        self._learner = DQNLearner(self.network, self.target_network, rp._ring, cfg.batch_size, cfg.action_dim,
+                                   cfg.discount ** cfg.n_step, cfg.gradient_clip or 0.0, g['lr'], g['alpha'], g['eps'],
+                                   centered=bool(g['centered']), double_q=bool(cfg.double_q),
+                                   u8_coef=cfg.state_normalizer.coef)
+        self._fused = None              # its flat buffer no longer backs the parameters
+        self._target_flat = None
+        learner = self._learner
+        self.actor._fast_q = lambda state: learner.q_host(np.asarray(state, dtype=np.uint8)).reshape(1, -1)
 
     def _pre_init(self):
         pass
@@ -209,12 +261,18 @@ class DQNAgent(BaseAgent):
         pass
 
     def close(self):
+        if getattr(self, '_learner', None) is not None:
+            self._learner.synchronize()
+            self._learner.close()
+            self._learner = None
         close_obj(self.replay)
         close_obj(self.actor)
 
     def eval_step(self, state):
         self.config.state_normalizer.set_read_only()
         state = self.config.state_normalizer(state)
+        if self._learner is not None:
+            self._learner.synchronize()
         with torch.no_grad():
             q = self.network(state)['q']
         action = to_np(q.argmax(-1))
@@ -282,6 +340,16 @@ class DQNAgent(BaseAgent):
         return out
 
     def step(self):
+        if self._learner is not None:   # ring feeds, actor forwards and updates share the learner's stream
+            with torch.cuda.stream(self._learner.stream):
+                return self._step()
+        self._step()
+        if not self._fused_checked and self._inner_replay().size() > 0:
+            self._fused_checked = True
+            if self._fused_eligible():
+                self._attach_fused_learner()
+
+    def _step(self):
         config = self.config
         transitions = self.actor.step()
         for states, actions, rewards, next_states, dones, info in transitions:
@@ -294,16 +362,23 @@ class DQNAgent(BaseAgent):
                 mask=1 - np.asarray(dones, dtype=np.int32),
             ))
         if self.total_steps > config.exploration_steps:
-            transitions = self.replay.sample()
-            if config.noisy_linear:
-                self.target_network.reset_noise()
-                self.network.reset_noise()
-            self._learn(transitions)
+            if self._learner is not None:
+                # same index draws as replay.sample() (replay.py:92-103); gather + update are one graph replay
+                self._learner.update(self._inner_replay().draw_indices(), use_graph=True)
+            else:
+                transitions = self.replay.sample()
+                if config.noisy_linear:
+                    self.target_network.reset_noise()
+                    self.network.reset_noise()
+                self._learn(transitions)
         if self.total_steps / config.sgd_update_frequency % config.target_network_update_freq == 0:
             self.sync_target()
 
     def sync_target(self):
         """DQN_agent.py:136-138 as one device-to-device copy of the flat parameter buffer."""
+        if self._learner is not None:
+            self._learner.sync_target()
+            return
         ops.copy_f32(self._target_flat.flat, self._fused.flat.flat)
         for tb, b in zip(self.target_network.buffers(), self.network.buffers()):
             tb.copy_(b)

@@ -93,6 +93,11 @@ struct dra_dqn_learner {
   int pa_cur;                       // pa[pa_cur] holds the newest completed parameters
   bool pa_valid;
   float* ah4;                       // actor fc4 output (v2)
+  // q(state) for a HOST environment (dra_dqn_learner_q_host): pinned staging + one captured graph
+  uint8_t* qs_stage;                // pinned [4 x 7056]
+  float* q_stage;                   // pinned [64]
+  hipGraphExec_t g_q;
+  bool g_q_ready;
   // actor v3: parameter blocks are read by the graph's first kernel straight from a pinned ring (no copy
   // command in front of the graph); the device counter selects the ring entry, in lockstep with aprm_seq
   uint8_t* aprm_ring;               // pinned, kAprmSlots x kAprmStride bytes
@@ -213,6 +218,8 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= (int)hipMalloc(&l->prm_dev, sizeof(dra_dqn_step_params));
   rc |= (int)hipHostMalloc(&l->prm_stage, 8 * sizeof(dra_dqn_step_params), hipHostMallocDefault);
   rc |= (int)hipHostMalloc(&l->idx_stage, (size_t)8 * 1024 * sizeof(int64_t), hipHostMallocDefault);
+  rc |= (int)hipHostMalloc(&l->qs_stage, (size_t)4 * 7056, hipHostMallocDefault);
+  rc |= (int)hipHostMalloc(&l->q_stage, 64 * sizeof(float), hipHostMallocDefault);
   if (rc) { delete l; return rc; }
   // slab gaps (alignment padding between tensors) are never written: keep them zero
   rc |= (int)hipMemset(l->slabs, 0, (size_t)cfg->ksplit * l->slab_stride * sizeof(float));
@@ -269,6 +276,9 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   }
   (void)hipHostFree(l->prm_stage);
   (void)hipHostFree(l->idx_stage);
+  if (l->qs_stage) (void)hipHostFree(l->qs_stage);
+  if (l->q_stage) (void)hipHostFree(l->q_stage);
+  if (l->g_q_ready) (void)hipGraphExecDestroy(l->g_q);
   for (int k = 0; k <= K_COUNT; ++k) (void)hipEventDestroy(l->ev[k]);
   for (int k = 0; k < 8; ++k) (void)hipEventDestroy(l->stage_ev[k]);
   (void)hipStreamDestroy(l->side);
@@ -941,6 +951,68 @@ static int stage_actor_params(dra_dqn_learner* l, const dra_dqn_step_params* prm
     l->aprm_used[k] = true;
     l->aprm_seq++;
   }
+  return DRA_OK;
+}
+
+// q[a] = bh[a] + <h4, Wh[a]>  (VanillaNet head, batch 1; one wave per action)
+__global__ void __launch_bounds__(256)
+head_q_kernel(const float* __restrict__ h4, const float* __restrict__ wh, const float* __restrict__ bh, int A,
+              float* __restrict__ q_out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int a = wave; a < A; a += 4) {
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part += h4[lane + 64 * i] * wh[a * 512 + lane + 64 * i];
+    part = wave_sum(part);
+    if (lane == 0) q_out[a] = part + bh[a];
+  }
+}
+
+// DQNActor._transition's forward (DQN_agent.py:29-33) for an environment that lives on the HOST: the caller's
+// uint8 [4][84][84] observation goes through pinned staging to the device, the batch-1 forward of the ONLINE
+// parameters runs as one captured graph (5 kernels), and q[0..A) comes back.  Synchronises `stream` (the
+// reference's to_np(q) does too): the action must reach the host emulator before it can step.
+DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host, float* q_host, void* stream) {
+  if (!l || !state_host || !q_host) return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  const dra_dqn_config& c = l->c;
+  memcpy(l->qs_stage, state_host, (size_t)4 * 7056);
+  DRA_HIP(hipMemcpyAsync(l->act_state, l->qs_stage, (size_t)4 * 7056, hipMemcpyHostToDevice, st));
+  if (!l->g_q_ready) {
+    const int64_t* o = c.offset;
+    const float* P = l->p;
+    void* s = (void*)st;
+    hipGraph_t graph;
+    DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = DRA_OK;
+    {
+      const void* x1[1] = {l->act_state}; const float* w1[1] = {P + o[P_W1]}; const float* b1[1] = {P + o[P_B1]};
+      float* y1[1] = {l->ay1};
+      rc = dra_conv_fwd_koc(1, 1, x1, w1, b1, y1, 1, 1, c.u8_coef, DRA_ACT_RELU, s);
+      const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
+      float* y2[1] = {l->ay2};
+      if (!rc) rc = dra_conv_fwd_koc(2, 1, x2, w2, b2, y2, 1, 0, 1.0, DRA_ACT_RELU, s);
+      const void* x3[1] = {l->ay2}; const float* w3[1] = {P + o[P_W3]}; const float* b3[1] = {P + o[P_B3]};
+      float* y3[1] = {l->ay3};
+      if (!rc) rc = dra_conv_fwd_koc(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s);
+      if (!rc) {
+        hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
+                           l->ah4, 3136);
+        hipLaunchKernelGGL(head_q_kernel, dim3(1), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH], P + o[P_BH],
+                           c.n_actions, l->aq);
+      }
+    }
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc != DRA_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    DRA_HIP(hipGraphInstantiate(&l->g_q, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    l->g_q_ready = true;
+  }
+  DRA_HIP(hipGraphLaunch(l->g_q, st));
+  DRA_HIP(hipMemcpyAsync(l->q_stage, l->aq, (size_t)c.n_actions * sizeof(float), hipMemcpyDeviceToHost, st));
+  DRA_HIP(hipStreamSynchronize(st));
+  memcpy(q_host, l->q_stage, (size_t)c.n_actions * sizeof(float));
   return DRA_OK;
 }
 

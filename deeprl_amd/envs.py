@@ -83,10 +83,12 @@ class SyntheticAtari:
         return LazyFrames(list(self.frames))
 
     def step(self, action):
-        h = int(_mix64(np.uint64(self.seed + 1) * _GOLD + np.uint64(self.counter)))
+        with np.errstate(over="ignore"):
+            h = int(_mix64(np.uint64(self.seed + 1) * _GOLD + np.uint64(self.counter)))
+            h2 = int(_mix64(np.uint64(self.seed + 2) * _GOLD + np.uint64(self.counter)))
         u = (h >> 32) % 10
         reward = -1.0 if u == 0 else (1.0 if u == 9 else 0.0)
-        done = int(_mix64(np.uint64(self.seed + 2) * _GOLD + np.uint64(self.counter))) % self.done_period == 0
+        done = h2 % self.done_period == 0
         self.frames = self.frames[1:] + [self._next_frame()]
         self.ret += reward
         info = {'episodic_return': self.ret if done else None}

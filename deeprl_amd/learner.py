@@ -196,6 +196,17 @@ class DQNLearner:
     def sync_target(self):
         lib.dra_dqn_learner_sync_target(self.h, self._sp())
 
+    def q_host(self, state):
+        """q(state) for a host environment: uint8 [4,84,84] observation (numpy) -> float32 [n_actions] numpy.
+        Batch-1 forward of the online parameters on the update stream, synchronous (DQN_agent.py:29-33)."""
+        state = np.ascontiguousarray(state, dtype=np.uint8)
+        if state.size != 4 * 7056:
+            raise DraError("q_host: expected a uint8 [4,84,84] observation, got shape %s" % (state.shape,))
+        q = np.empty(self.n_actions, dtype=np.float32)
+        lib.dra_dqn_learner_q_host(self.h, state.ctypes.data_as(ctypes.c_void_p), q.ctypes.data_as(ctypes.c_void_p),
+                                   self._sp())
+        return q
+
     def profile(self):
         """Per-kernel-group milliseconds of one eager update (HIP events on the launch stream)."""
         n = lib.dra_dqn_learner_kernel_count.raw()

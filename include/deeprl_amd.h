@@ -233,6 +233,10 @@ int dra_dqn_learner_kernel_count(void);
 int dra_dqn_learner_sync_target(dra_dqn_learner* learner, void* stream); /* DQN_agent.py:136-138 */
 /* DQNActor._transition on device for prm->n_env transitions (graph replay when use_graph). */
 int dra_dqn_learner_act(dra_dqn_learner* learner, const dra_dqn_step_params* prm, int use_graph, void* stream);
+/* DQNActor._transition's forward (DQN_agent.py:29-33) for a HOST environment: state_host = uint8 [4][84][84]
+ * observation, q_host = float[n_actions] out.  Pinned staging both ways, batch-1 forward of the online parameters
+ * as one captured graph; synchronises `stream` (like the reference's to_np(q)). */
+int dra_dqn_learner_q_host(dra_dqn_learner* learner, const uint8_t* state_host, float* q_host, void* stream);
 /* DQNAgent.step: prm->n_env actor transitions + one update on prm->idx.  stream_actor == NULL: in-order on
  * stream_update (async_actor=False semantics).  stream_actor != NULL: this call's transitions belong to the NEXT
  * step and overlap this step's update (async_actor=True; config.lock becomes HIP events). */

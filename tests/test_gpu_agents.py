@@ -393,3 +393,65 @@ def test_fused_step_async_pipeline(dra, variant):
         if 127 in _ASYNC_RESULTS and other in _ASYNC_RESULTS:
             assert np.array_equal(_ASYNC_RESULTS[127][0], _ASYNC_RESULTS[other][0])
             assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
+
+
+def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch):
+    """dqn_pixel configuration (examples.py:55-97 shapes): DQNAgent attaches the fused learner
+    (csrc/learner.hip) after the first feed.  20 agent steps give the same action stream and replay
+    contents and, to fp32 reassociation, the same parameters as the generic autograd path
+    (config.fused_learner = False), which the tests above pin to the reference's fixtures."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    outs = []
+    for fused in (True, False):
+        cfg = d.Config()
+        cfg.merge(dict(game="BreakoutNoFrameskip-v4", n_step=1, replay_cls=d.UniformReplay, async_replay=False, log_level=0,
+                       tag="fast%d" % fused, fused_learner=fused))
+        cfg.task_fn = lambda: d.Task(cfg.game, seed=7)
+        cfg.eval_env = cfg.task_fn()
+        cfg.optimizer_fn = lambda params: torch.optim.RMSprop(params, lr=0.00025, alpha=0.95, eps=0.01, centered=True)
+        cfg.network_fn = lambda: d.VanillaNet(cfg.action_dim, d.NatureConvBody(in_channels=4))
+        cfg.random_action_prob = d.LinearSchedule(1.0, 0.05, 60)
+        cfg.batch_size = 32
+        cfg.discount = 0.99
+        cfg.history_length = 4
+        kw = dict(memory_size=500, batch_size=32, n_step=1, discount=0.99, history_length=4)
+        cfg.replay_fn = lambda: d.ReplayWrapper(cfg.replay_cls, kw, cfg.async_replay)
+        cfg.state_normalizer = d.ImageNormalizer()
+        cfg.reward_normalizer = d.SignNormalizer()
+        cfg.target_network_update_freq = 3
+        cfg.exploration_steps = 40
+        cfg.sgd_update_frequency = 4
+        cfg.gradient_clip = 5
+        cfg.double_q = False
+        cfg.async_actor = False
+        cfg.max_steps = 1e5
+        d.random_seed(3)
+        random.seed(3)
+        agent = d.DQNAgent(cfg)
+        p_np = fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(cfg.action_dim), 17)
+        agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
+        agent.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
+        for _ in range(20):
+            agent.step()
+        assert (agent._learner is not None) == fused
+        if fused:
+            agent._learner.synchronize()
+        torch.cuda.synchronize()
+        rp = agent.replay.replay
+        n = rp.size()
+        acts = d.ops._wrap_device_pointer(rp._ring.pointers()[1], n, torch.int64).cpu().numpy().copy()
+        frames = d.ops._wrap_device_pointer(rp._ring.pointers()[0], n * 7056, torch.uint8).cpu().numpy().copy()
+        params = {k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()}
+        tparams = {k: v.detach().cpu().numpy().copy() for k, v in agent.target_network.state_dict().items()}
+        rng_tail = np.random.randint(0, 1 << 30, size=4)
+        outs.append((acts, frames, params, tparams, rng_tail, agent.total_steps))
+        agent.close()
+    assert outs[0][5] == outs[1][5] == 80
+    assert np.array_equal(outs[0][0], outs[1][0])          # action stream
+    assert np.array_equal(outs[0][1], outs[1][1])          # frames fed
+    assert np.array_equal(outs[0][4], outs[1][4])          # np.random consumption
+    for k in outs[0][2]:
+        np.testing.assert_allclose(outs[0][2][k], outs[1][2][k], rtol=2e-4, atol=2e-6, err_msg=k)
+        np.testing.assert_allclose(outs[0][3][k], outs[1][3][k], rtol=2e-4, atol=2e-6, err_msg="target " + k)
