@@ -15,8 +15,9 @@ Differences that are the point of the rewrite (results unchanged):
   * GAE / n-step returns are one chunked-scan launch instead of T python iterations;
   * DQNAgent on the dqn_pixel configuration (VanillaNet(NatureConvBody), RMSprop, UniformReplay of 84x84 uint8
     frames, history 4 -- examples.py:55-97) switches to the fused learner of csrc/learner.hip: one C call per
-    update (gather + forward + TD loss + backward + clip + RMSprop as a captured hipGraph) and one C call per
-    actor forward; `config.fused_learner = False` keeps the generic autograd path.
+    update (gather + forward + TD loss + backward + clip + RMSprop as a captured hipGraph; PrioritizedReplay adds
+    the IS-weight / priority kernel and runs the chain eagerly) and one C call per actor forward;
+    `config.fused_learner = False` keeps the generic autograd path.
 """
 import pickle
 
@@ -220,7 +221,7 @@ class DQNAgent(BaseAgent):
         """The configuration csrc/learner.hip implements: examples.py:55-97 (dqn_pixel) with uniform replay."""
         from .nets import NatureConvBody, VanillaNet
         from .normalizers import ImageNormalizer
-        from .replay import UniformReplay
+        from .replay import PrioritizedReplay, UniformReplay
         cfg = self.config
         if type(self) is not DQNAgent or getattr(cfg, 'fused_learner', True) is False or cfg.noisy_linear:
             return False
@@ -228,7 +229,7 @@ class DQNAgent(BaseAgent):
         if type(net) is not VanillaNet or type(net.body) is not NatureConvBody or len(list(net.parameters())) != 10:
             return False
         rp = self._inner_replay()
-        if type(rp) is not UniformReplay or rp._ring is None or rp.history_length != 4:
+        if type(rp) not in (UniformReplay, PrioritizedReplay) or rp._ring is None or rp.history_length != 4:
             return False
         if rp._ring.frame_bytes != 7056 or rp._ring.action_bytes != 8 or rp._state_dtype != torch.uint8:
             return False
@@ -363,8 +364,18 @@ class DQNAgent(BaseAgent):
             ))
         if self.total_steps > config.exploration_steps:
             if self._learner is not None:
-                # same index draws as replay.sample() (replay.py:92-103); gather + update are one graph replay
-                self._learner.update(self._inner_replay().draw_indices(), use_graph=True)
+                rp = self._inner_replay()
+                if hasattr(rp, 'draw'):
+                    # PER (DQN_agent.py:120-127): tree descent on device with host-drawn uniforms, one D2H of the
+                    # indices (validity / padding stay on the host, draw for draw); the update applies the IS
+                    # weights and emits the new priorities, which go back through update_priorities
+                    tree_idx, prob, data_idx = rp.draw()
+                    self._learner.update(data_idx, use_graph=False, sampling_prob=torch.from_numpy(prob.astype(np.float32)),
+                                         beta=config.replay_beta())
+                    rp.update_priorities(zip(tree_idx, to_np(self._learner.prio)))
+                else:
+                    # same index draws as replay.sample() (replay.py:92-103); gather + update are one graph replay
+                    self._learner.update(rp.draw_indices(), use_graph=True)
             else:
                 transitions = self.replay.sample()
                 if config.noisy_linear:

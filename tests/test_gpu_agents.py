@@ -395,7 +395,8 @@ def test_fused_step_async_pipeline(dra, variant):
             assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
 
 
-def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch):
+@pytest.mark.parametrize("per,n_step", [(False, 1), (True, 3)])
+def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch, per, n_step):
     """dqn_pixel configuration (examples.py:55-97 shapes): DQNAgent attaches the fused learner
     (csrc/learner.hip) after the first feed.  20 agent steps give the same action stream and replay
     contents and, to fp32 reassociation, the same parameters as the generic autograd path
@@ -406,8 +407,10 @@ def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch):
     outs = []
     for fused in (True, False):
         cfg = d.Config()
-        cfg.merge(dict(game="BreakoutNoFrameskip-v4", n_step=1, replay_cls=d.UniformReplay, async_replay=False, log_level=0,
-                       tag="fast%d" % fused, fused_learner=fused))
+        cfg.merge(dict(game="BreakoutNoFrameskip-v4", n_step=n_step, replay_cls=d.PrioritizedReplay if per else d.UniformReplay,
+                       async_replay=False, log_level=0, tag="fast%d" % fused, fused_learner=fused))
+        cfg.replay_eps, cfg.replay_alpha = 0.01, 0.5
+        cfg.replay_beta = d.LinearSchedule(0.4, 1.0, 1000)
         cfg.task_fn = lambda: d.Task(cfg.game, seed=7)
         cfg.eval_env = cfg.task_fn()
         cfg.optimizer_fn = lambda params: torch.optim.RMSprop(params, lr=0.00025, alpha=0.95, eps=0.01, centered=True)
@@ -416,7 +419,7 @@ def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch):
         cfg.batch_size = 32
         cfg.discount = 0.99
         cfg.history_length = 4
-        kw = dict(memory_size=500, batch_size=32, n_step=1, discount=0.99, history_length=4)
+        kw = dict(memory_size=500, batch_size=32, n_step=n_step, discount=0.99, history_length=4)
         cfg.replay_fn = lambda: d.ReplayWrapper(cfg.replay_cls, kw, cfg.async_replay)
         cfg.state_normalizer = d.ImageNormalizer()
         cfg.reward_normalizer = d.SignNormalizer()
@@ -445,7 +448,11 @@ def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch):
         frames = d.ops._wrap_device_pointer(rp._ring.pointers()[0], n * 7056, torch.uint8).cpu().numpy().copy()
         params = {k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()}
         tparams = {k: v.detach().cpu().numpy().copy() for k, v in agent.target_network.state_dict().items()}
-        rng_tail = np.random.randint(0, 1 << 30, size=4)
+        rng_tail = np.concatenate([np.random.randint(0, 1 << 30, size=4), [random.getrandbits(30)]])
+        if per:   # the priority tree after 10 updates: same leaves sampled, priorities to fp32 reassociation
+            tree = rp.tree.as_tensor().cpu().numpy().copy()
+            params["__tree__"] = tree
+            tparams["__tree__"] = tree
         outs.append((acts, frames, params, tparams, rng_tail, agent.total_steps))
         agent.close()
     assert outs[0][5] == outs[1][5] == 80
