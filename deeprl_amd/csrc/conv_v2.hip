@@ -19,6 +19,7 @@
 // Numerics: fp32 MFMA (exact fmaf chains), summation order differs from igemm.hip / the CPU
 // oracle only in the order of the four K-quarters.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -67,18 +68,35 @@ __device__ __forceinline__ float v2_act(float v, int act) {
 template <class G>
 __device__ __forceinline__ int lds_col(int iw) { return (iw % G::S) * G::WPH + iw / G::S; }
 
-template <class G, bool U8>
+// PT = consecutive 32-position tiles of ONE sample per workgroup.  PT = 1 is the latency shape (batch 32 and the
+// batch-1 actor: most workgroups, shortest dependent chain).  PT > 1 is the throughput shape for large batches
+// (A2C / PPO minibatches, the batch-1024 roofline measurement): the register-resident weights and the staged
+// rows (adjacent tiles share most of them) are reused by PT independent MFMA accumulation chains per wave --
+// rocprofv3 SQ counters at batch 1024, PT = 1: waves spend 71 % of their cycles stalled on MFMA issue behind the
+// other resident waves while the pipe itself is only ~45 % busy, because every workgroup pays the full
+// load / staging / reduction phases for 32 MFMAs per wave (profiles/r01e_pmc_conv_fwd_b1024_before.json).
+template <class G, int PT>
+struct V2Tile {
+  static constexpr int TPG = (G::TPS + PT - 1) / PT;                       // tile groups per sample
+  static constexpr int OROWS = (32 * PT - 1 + G::OH - 1) / G::OH + 1;      // output rows a group can touch
+  static constexpr int NR_RAW = (OROWS - 1) * G::S + G::KH;
+  static constexpr int NR = NR_RAW < G::H ? NR_RAW : G::H;
+  static constexpr int CS = NR * G::RW;                                    // LDS channel stride
+};
+
+template <class G, bool U8, int PT>
 __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
+  using T = V2Tile<G, PT>;
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [C][NR][RW] image, then reused for the reduction
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
   const int z = blockIdx.z;
-  const int bi = blockIdx.x / G::TPS, tile = blockIdx.x - bi * G::TPS;
+  const int bi = blockIdx.x / T::TPG, grp = blockIdx.x - bi * T::TPG;
   const int oc0 = blockIdx.y * 32;
-  const int p0 = tile * 32;
-  const int np = min(32, G::P - p0);
+  const int p0 = grp * PT * 32;
+  const int np = min(32 * PT, G::P - p0);
   const int oh0 = p0 / G::OH, oh1 = (p0 + np - 1) / G::OH;
   const int ir0 = oh0 * G::S;
-  const int nrows = (oh1 - oh0) * G::S + G::KH;  // <= G::NR
+  const int nrows = (oh1 - oh0) * G::S + G::KH;  // <= T::NR
 
   // ---- issue every global load of this workgroup: weight operands first, then the image rows
   const float* __restrict__ wt = a.wt[z];
@@ -93,15 +111,25 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
       areg[j] = wbase[(2 * cpl * G::KK + t) * G::OC];
     }
   }
+  // Staging maps lanes to (row, column) so that no per-element division is needed: LR lanes walk one image
+  // row (the surplus lanes of a row idle), 64 / LR rows per pass; row offsets are compile-time immediates and
+  // the de-interleaved LDS column is a per-lane constant.  (The flat "element e of the block" mapping this
+  // replaces cost ~40 integer multiplies and 70 shifts / adds per lane -- on CDNA the fp32 MFMA and the vector
+  // ALU issue from the same SIMD port, so every VALU cycle in a workgroup is an MFMA cycle lost: SQ counters in
+  // profiles/r01e_pmc_conv_fwd_b1024_*.json.)
   if (U8) {
-    // rows are 84 bytes: the [nrows x 84] block of a channel is contiguous and 4-byte aligned
+    // uint8 frames (conv1: S = 4, rows of 84 bytes = 21 u32 words): lane (rsub, wd) loads word wd of rows
+    // 2q + rsub; pixel b of word wd is column 4 wd + b = stride phase b, phase index wd.  The exact
+    // normalisation f32(f64(v) * coef) comes from a 256-entry LDS table built while the loads are in flight.
+    static_assert(!U8 || (G::S == 4 && G::H % 4 == 0 && G::H / 4 <= 32), "u8 staging: stride-4 layer, <= 32 words per row");
     constexpr int WPR = G::H / 4;                               // u32 words per row
-    constexpr int NWMAX = G::NR * WPR;
-    constexpr int LPT = (NWMAX + 63) / 64;                      // words per lane per channel
+    constexpr int LPT = (T::NR + 1) / 2;                        // rows per lane per channel
     constexpr int CPT = (G::C + 3) / 4;                         // channels per wave
+    __shared__ float s_lut[256];
     unsigned raw[CPT * LPT];
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x[z]);
-    const int nw = nrows * WPR;
+    const int rsub = lane >> 5, wd = lane & 31;
+    const int wdc = min(wd, WPR - 1);
     const int64_t newest = a.ring_slot ? *a.ring_slot : 0;
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
@@ -111,32 +139,30 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
         img = newest - (G::C - 1) + min(c, G::C - 1);
         if (img < 0) img += a.ring_cap;
       }
-      const unsigned* src = reinterpret_cast<const unsigned*>(xb + (img * G::H + ir0) * G::H);
+      const unsigned* src = reinterpret_cast<const unsigned*>(xb + (img * G::H + ir0) * G::H) + wdc;
 #pragma unroll
-      for (int q = 0; q < LPT; ++q) {
-        const int e = lane + 64 * q;
-        raw[ci * LPT + q] = src[min(e, nw - 1)];
-      }
+      for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = src[min(2 * q + rsub, nrows - 1) * WPR];
     }
+    s_lut[tid] = (float)((double)tid * a.coef);
+    __syncthreads();
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
       const int c = wave + 4 * ci;
+      float* dst = lds + c * T::CS + rsub * G::RW + wd;
 #pragma unroll
       for (int q = 0; q < LPT; ++q) {
-        const int e = lane + 64 * q;
         unsigned v = raw[ci * LPT + q];
         asm volatile("" : "+v"(v));  // keep the loads unconditional and batched (see igemm.hip)
-        if (e < nw && c < G::C) {
-          const int r = e / WPR, iw = (e - r * WPR) * 4;
-          float* dst = lds + c * G::CS + r * G::RW;
+        if (wd < WPR && 2 * q + rsub < nrows && c < G::C) {
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
-            dst[lds_col<G>(iw + b)] = (float)((double)((v >> (8 * b)) & 0xffu) * a.coef);
+          for (int b = 0; b < 4; ++b) dst[2 * q * G::RW + b * G::WPH] = s_lut[(v >> (8 * b)) & 0xffu];
         }
       }
     }
-  } else {
-    constexpr int NEMAX = G::NR * G::H;                          // floats per channel block
+  } else if constexpr (G::H > 32) {
+    // wide fp32 rows (conv1 fed with already-normalised floats: tests / generic callers, not a hot path):
+    // flat element mapping
+    constexpr int NEMAX = T::NR * G::H;                          // floats per channel block
     constexpr int LPT = (NEMAX + 63) / 64;
     constexpr int CPT = (G::C + 3) / 4;
     float raw[CPT * LPT];
@@ -162,44 +188,86 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
         asm volatile("" : "+v"(v));
         if (e < ne && c < G::C) {
           const int r = e / G::H, iw = e - r * G::H;
-          lds[c * G::CS + r * G::RW + lds_col<G>(iw)] = v;
+          lds[c * T::CS + r * G::RW + lds_col<G>(iw)] = v;
         }
+      }
+    }
+  } else {
+    constexpr int LR = G::H > 16 ? 32 : 16;                     // lanes per image row
+    constexpr int RP = 64 / LR;                                  // rows per pass
+    constexpr int LPT = (T::NR + RP - 1) / RP;
+    constexpr int CPT = (G::C + 3) / 4;
+    float raw[CPT * LPT];
+    const float* xf = reinterpret_cast<const float*>(a.x[z]);
+    const int rsub = lane / LR, iw = lane % LR;
+    const int iwc = min(iw, G::H - 1);
+    const int col = lds_col<G>(iwc);
+#pragma unroll
+    for (int ci = 0; ci < CPT; ++ci) {
+      const int c = wave + 4 * ci;
+      const float* src = xf + ((int64_t)(bi * G::C + min(c, G::C - 1)) * G::H + ir0) * G::H + iwc;
+#pragma unroll
+      for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = src[min(RP * q + rsub, nrows - 1) * G::H];
+    }
+#pragma unroll
+    for (int ci = 0; ci < CPT; ++ci) {
+      const int c = wave + 4 * ci;
+      float* dst = lds + c * T::CS + rsub * G::RW + col;
+#pragma unroll
+      for (int q = 0; q < LPT; ++q) {
+        float v = raw[ci * LPT + q];
+        asm volatile("" : "+v"(v));
+        if (iw < G::H && RP * q + rsub < nrows && c < G::C) dst[RP * q * G::RW] = v;
       }
     }
   }
   __syncthreads();
 
-  // ---- MFMA: lane li owns output position p0 + li (clamped), half-wave h the odd channel of a pair
-  const int pj = min(li, np - 1);
-  const int poh = (p0 + pj) / G::OH, pow_ = (p0 + pj) - poh * G::OH;
-  const float* bptr = lds + (2 * cp0 + h) * G::CS + ((poh - oh0) * G::S + t0 / G::KH) * G::RW + pow_;
-  f32x16 acc;
+  // ---- MFMA: lane li owns output positions p0 + 32 t + li (clamped), half-wave h the odd channel of a pair
+  const float* bptr[PT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int t = 0; t < PT; ++t) {
+    const int pj = min(32 * t + li, np - 1);
+    const int poh = (p0 + pj) / G::OH, pow_ = (p0 + pj) - poh * G::OH;
+    bptr[t] = lds + (2 * cp0 + h) * T::CS + ((poh - oh0) * G::S + t0 / G::KH) * G::RW + pow_;
+  }
+  f32x16 acc[PT];
+#pragma unroll
+  for (int t = 0; t < PT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
   for (int j = 0; j < G::NJ; ++j) {
-    const int cpl = j / G::TW, t = j - cpl * G::TW;  // tap relative to the wave's base tap t0 (folded into bptr)
-    const int kh = t / G::KH, kw = t - kh * G::KH;
-    const float b = bptr[2 * cpl * G::CS + kh * G::RW + (kw % G::S) * G::WPH + kw / G::S];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[j], b, acc, 0, 0, 0);
+    const int cpl = j / G::TW, tp = j - cpl * G::TW;  // tap relative to the wave's base tap t0 (folded into bptr)
+    const int kh = tp / G::KH, kw = tp - kh * G::KH;
+    const int off = 2 * cpl * T::CS + kh * G::RW + (kw % G::S) * G::WPH + kw / G::S;
+#pragma unroll
+    for (int t = 0; t < PT; ++t)  // PT independent accumulation chains share the A operand
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[j], bptr[t][off], acc[t], 0, 0, 0);
   }
   __syncthreads();  // every wave is done reading the image: reuse LDS for the 4-way reduction
 
-  float* red = lds;  // [4 waves][16][64]
+  float* red = lds;  // [PT][4 waves][16][64]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  for (int t = 0; t < PT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((t * 4 + wave) * 16 + r) * 64 + lane] = acc[t][r];
   __syncthreads();
   // wave w finalises accumulator registers 4w .. 4w+3 (MFMA C/D rows (r&3) + 8*(r>>2) + 4*h)
   float* __restrict__ y = a.y[z];
   const float* __restrict__ bias = a.bias[z];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = wave * 4 + q;
-    const float s = (red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) +
-                    (red[(2 * 16 + r) * 64 + lane] + red[(3 * 16 + r) * 64 + lane]);
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const float v = v2_act(s + bias[oc0 + row], a.act);
-    if (li < np) y[((int64_t)(bi * G::OC + oc0 + row)) * G::P + p0 + li] = v;
+  for (int t = 0; t < PT; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave * 4 + q;
+      const float* rt = red + (t * 4 * 16) * 64;
+      const float s = (rt[(0 * 16 + r) * 64 + lane] + rt[(1 * 16 + r) * 64 + lane]) +
+                      (rt[(2 * 16 + r) * 64 + lane] + rt[(3 * 16 + r) * 64 + lane]);
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float v = v2_act(s + bias[oc0 + row], a.act);
+      if (32 * t + li < np) y[((int64_t)(bi * G::OC + oc0 + row)) * G::P + p0 + 32 * t + li] = v;
+    }
   }
 }
 
@@ -207,20 +275,36 @@ using VG1 = V2Geom<4, 84, 32, 8, 4>;
 using VG2 = V2Geom<32, 20, 64, 4, 2>;
 using VG3 = V2Geom<64, 9, 64, 3, 1>;
 
-template <class G, bool U8>
-static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
-  constexpr size_t img = (size_t)G::C * G::CS * sizeof(float);
-  constexpr size_t red = (size_t)4 * 16 * 64 * sizeof(float);
+template <class G, bool U8, int PT>
+static int launch_conv_v2_pt(const ConvV2Args& a, int nz, hipStream_t st) {
+  using T = V2Tile<G, PT>;
+  constexpr size_t img = (size_t)G::C * T::CS * sizeof(float);
+  constexpr size_t red = (size_t)PT * 4 * 16 * 64 * sizeof(float);
   constexpr size_t bytes = img > red ? img : red;
+  static_assert(bytes <= 160 * 1024, "LDS per workgroup");
   static bool attr_set = false;
   if (bytes > 64 * 1024 && !attr_set) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_v2_kernel<G, U8>),
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_v2_kernel<G, U8, PT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_fwd_v2_kernel<G, U8>), dim3(G::TPS * a.batch, G::OC / 32, nz), dim3(256), bytes, st, a);
+  hipLaunchKernelGGL((conv_fwd_v2_kernel<G, U8, PT>), dim3(T::TPG * a.batch, G::OC / 32, nz), dim3(256), bytes, st, a);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
+}
+
+// Tile shape by problem size: one tile per workgroup (latency shape) until the launch has several workgroups
+// per CU slot anyway, then PTBIG tiles per workgroup (throughput shape).  DRA_CONV_PT=1 forces the latency shape.
+static int g_conv_pt_threshold = -1;
+template <class G, bool U8, int PTBIG>
+static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
+  if (g_conv_pt_threshold < 0) {
+    const char* e = getenv("DRA_CONV_PT_BATCH");   // batch from which the throughput shape is used (0 = never)
+    g_conv_pt_threshold = e ? atoi(e) : 128;
+  }
+  if (PTBIG > 1 && g_conv_pt_threshold > 0 && a.batch >= g_conv_pt_threshold && !a.ring_slot)
+    return launch_conv_v2_pt<G, U8, PTBIG>(a, nz, st);
+  return launch_conv_v2_pt<G, U8, 1>(a, nz, st);
 }
 
 // Same contract as dra_conv_fwd, but the weights are in the KOC layout: wt[(c*KH+kh)*KH+kw][oc].
@@ -235,9 +319,9 @@ DRA_API int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const floa
   a.batch = batch; a.act = act; a.coef = u8_coef; a.ring_slot = nullptr; a.ring_cap = 0;
   hipStream_t st = dra_stream(stream);
   switch (layer) {
-    case 1: return x_is_u8 ? launch_conv_v2<VG1, true>(a, nz, st) : launch_conv_v2<VG1, false>(a, nz, st);
-    case 2: return x_is_u8 ? DRA_EINVAL : launch_conv_v2<VG2, false>(a, nz, st);
-    case 3: return x_is_u8 ? DRA_EINVAL : launch_conv_v2<VG3, false>(a, nz, st);
+    case 1: return x_is_u8 ? launch_conv_v2<VG1, true, 2>(a, nz, st) : launch_conv_v2<VG1, false, 2>(a, nz, st);
+    case 2: return x_is_u8 ? DRA_EINVAL : launch_conv_v2<VG2, false, 3>(a, nz, st);
+    case 3: return x_is_u8 ? DRA_EINVAL : launch_conv_v2<VG3, false, 2>(a, nz, st);
   }
   return DRA_EINVAL;
 }
@@ -251,7 +335,7 @@ DRA_API int dra_conv1_fwd_koc_ring(const void* frames, const int64_t* newest_slo
   ConvV2Args a;
   a.x[0] = frames; a.wt[0] = wt; a.bias[0] = bias; a.y[0] = y;
   a.batch = 1; a.act = act; a.coef = u8_coef; a.ring_slot = newest_slot_dev; a.ring_cap = capacity;
-  return launch_conv_v2<VG1, true>(a, 1, dra_stream(stream));
+  return launch_conv_v2_pt<VG1, true, 1>(a, 1, dra_stream(stream));
 }
 
 // Layout conversion [OC][K] <-> [K][OC] for one layer's weight tensor (tests, generic path, and

@@ -512,6 +512,33 @@ def test_conv_koc_fwd_bwd_vs_oracle(dev, layer, batch):
         _scale_close(dxm.cpu().numpy(), xt.grad.numpy() * (xs[2] > 0))
 
 
+@pytest.mark.parametrize("layer", [1, 2, 3])
+def test_conv_koc_fwd_throughput_shape(dev, layer):
+    """conv_v2.hip picks the multi-tile (throughput) workgroup shape from batch 128 up: same arithmetic per
+    output position as the one-tile (latency) shape, so the two agree to the bit on a shared prefix of the
+    batch, and both match F.conv2d (incl. ragged last tile groups: 400 = 6x64+16, 81 = 96-15, 49 = 64-15)."""
+    import torch.nn.functional as F
+    from deeprl_amd import ops
+    c, h, oc, k, s = CONV[layer]
+    batch = 131
+    rs = np.random.RandomState(77 + layer)
+    w = (rs.standard_normal((oc, c, k, k)) / np.sqrt(c * k * k)).astype(np.float32)
+    b = (rs.standard_normal(oc) * 0.1).astype(np.float32)
+    wt = ops.to_koc(f32(w, dev))
+    if layer == 1:
+        x_u8 = rs.randint(0, 256, size=(batch, c, h, h)).astype(np.uint8)
+        x = NUM.image_normalize_sync(x_u8)
+        big = ops.conv_fwd_koc(1, [cu(x_u8, dev)], [wt], [f32(b, dev)], u8_coef=1.0 / 255)[0]
+        small = ops.conv_fwd_koc(1, [cu(x_u8[:40], dev)], [wt], [f32(b, dev)], u8_coef=1.0 / 255)[0]
+    else:
+        x = np.maximum(rs.standard_normal((batch, c, h, h)), 0).astype(np.float32)
+        big = ops.conv_fwd_koc(layer, [f32(x, dev)], [wt], [f32(b, dev)])[0]
+        small = ops.conv_fwd_koc(layer, [f32(x[:40], dev)], [wt], [f32(b, dev)])[0]
+    assert torch.equal(big[:40], small)
+    ref = F.relu(F.conv2d(torch.tensor(x), torch.tensor(w), torch.tensor(b), stride=s)).numpy()
+    _scale_close(big.cpu().numpy(), ref)
+
+
 # ---------------------------------------------------------------- fused launches + one-pass kernels (fused.hip)
 @pytest.mark.parametrize("layer", [1, 2, 3])
 @pytest.mark.parametrize("batch", [32, 1, 5])
