@@ -10,6 +10,7 @@
 //   DRA_VAR_ONESHOT_WGRAD  one-pass conv weight gradients (ConvWgradOne): one slab per (sample, row
 //                          chunk) -- dra_conv_wgrad_slabs() slabs instead of `ksplit`.
 #include "oneshot.h"
+#include <stdlib.h>
 
 static int g_tuning = 511;  // every bit up to DRA_VAR_CU_PARTITION measured faster on MI355X (profiles/r01b_ab_variants.jsonl,
                             // r01d_*); DRA_VAR_ACTOR_V3 (512) measured neutral and stays opt-in
@@ -49,9 +50,18 @@ static W make_wgrad_one(const float* dy, const void* x, float* dw, float* db, in
   return r;
 }
 
-template <class G>
-static ConvDgradOne<G> make_dgrad_one(const float* dy, const float* wt, const float* xact, float* dx, int batch, int act) {
-  ConvDgradOne<G> r;
+// tiles per workgroup of the one-pass input gradient: conv2 (4 stride phases x 4 tiles per sample) pairs tiles
+// (DRA_DGRAD_PT=1 in the environment keeps one tile per workgroup: A/B switch)
+template <class G> struct DgradTiles { static constexpr int PT = (G::S == 2) ? 2 : 1; };
+static int dgrad_pt_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_DGRAD_PT"); v = (e && atoi(e) == 1) ? 0 : 1; }
+  return v;
+}
+
+template <class G, int PT = DgradTiles<G>::PT>
+static ConvDgradOne<G, PT> make_dgrad_one(const float* dy, const float* wt, const float* xact, float* dx, int batch, int act) {
+  ConvDgradOne<G, PT> r;
   r.dy = dy; r.wt = wt; r.xact = xact; r.dx = dx; r.B = batch; r.act = act;
   return r;
 }
@@ -86,8 +96,12 @@ static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, con
   const bool ow = variant & DRA_VAR_ONESHOT_WGRAD, od = variant & DRA_VAR_ONESHOT_DGRAD;
   NoRole none;
   if (od && ow) {
-    auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
     auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
+    if (DgradTiles<G>::PT > 1 && !dgrad_pt_enabled()) {
+      auto rd1 = make_dgrad_one<G, 1>(dy, wt, xact, dx, batch, act);
+      return launch_multi(rd1, rd1.blocks(), rw, rw.blocks(), none, 0, st);
+    }
+    auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
     return launch_multi(rd, rd.blocks(), rw, rw.blocks(), none, 0, st);
   }
   if (od) {

@@ -267,15 +267,20 @@ struct LinFwdSlabsOne {
 // zero-padded ([OC][DH][RW]); MFMA lane li of the B operand is a position, so every B read is
 // `base(position) + immediate(oc, tap)`.  The A operand (weights, lane li = input channel c) is read
 // straight from the KOC tensor: slot (jj, h) of wave w <-> oc = 16w + 8h + jj, i.e. two float4 per tap.
-template <class G>
+// PT = consecutive 32-position tiles of one (sample, phase) per workgroup: the staged gradient image and the
+// register-resident weights are shared by PT independent accumulation chains.  conv2 at batch 32 uses PT = 2:
+// 256 instead of 512 workgroups, so that together with the 128 weight-gradient workgroups of the same launch the
+// grid fits the chip's workgroup slots in ONE round (two workgroups per CU at these register counts).
+template <class G, int PT = 1>
 struct ConvDgradOne {
   static constexpr int S = G::S, KP = (G::KH + S - 1) / S, NPH = S * S, HP = (G::H + S - 1) / S, PP = HP * HP;
   static constexpr int PAD = KP - 1, DH = G::OH + 2 * PAD, RW = DH, CS = DH * RW;
-  static constexpr int TPP = (PP + 31) / 32;
+  static constexpr int TPP = (PP + 31) / 32, TGP = (TPP + PT - 1) / PT;   // tiles / tile groups per phase
   static constexpr int OCW = G::OC / 4, OCH = OCW / 2, NT = KP * KP, NJ = NT * OCH;
   static constexpr int MT = G::C / 32;
   static constexpr int NCELL = G::OC * CS, RQ = (NCELL + 255) / 256;
-  static constexpr int LDS_FLOATS = NCELL > 4096 ? NCELL : 4096;
+  static constexpr int RED = PT * 4096;
+  static constexpr int LDS_FLOATS = NCELL > RED ? NCELL : RED;
   static_assert(G::KH % S == 0, "every stride phase has KP x KP taps");
   static_assert(HP + PAD == DH, "padded gradient covers every shifted read");
   static_assert(G::OC % 32 == 0 && OCH % 4 == 0 && G::C % 32 == 0, "float4 weight runs per half-wave");
@@ -284,17 +289,17 @@ struct ConvDgradOne {
   const float* xact;  // [B][C][H][H] this layer's input (post-activation) or null
   float* dx;          // [B][C][H][H]
   int B, act;
-  __host__ int blocks() const { return B * NPH * TPP * MT; }
+  __host__ int blocks() const { return B * NPH * TGP * MT; }
   __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int mt = bid % MT;
     int r = bid / MT;
-    const int tile = r % TPP;
-    r /= TPP;
+    const int grp = r % TGP;
+    r /= TGP;
     const int phi = r % NPH, bi = r / NPH;
     const int ph = phi / S, pw = phi - ph * S;
-    const int c0 = mt * 32, p0 = tile * 32;
-    const int np = min(32, PP - p0);
+    const int c0 = mt * 32, p0 = grp * PT * 32;
+    const int np = min(32 * PT, PP - p0);
     // ---- weights: lane li <-> input channel c0 + li
     float4 areg[NT][OCH / 4];
     {
@@ -318,18 +323,22 @@ struct ConvDgradOne {
       raw[q] = dyb[(oc * G::OH + oh) * G::OH + ow];
     }
     // ---- epilogue side input (activation-derivative source), loaded with everything else
-    const int pj = min(li, np - 1);
-    const int ih2 = (p0 + pj) / HP, iw2 = (p0 + pj) - ih2 * HP;
-    const int ih = ih2 * S + ph, iw = iw2 * S + pw;
-    const bool inside = ih < G::H && iw < G::H;
-    const int pix = min(ih, G::H - 1) * G::H + min(iw, G::H - 1);
-    float aux[4];
-    {
+    int ih2[PT], iw2[PT], pix[PT];
+    bool inside[PT];
+    float aux[PT][4];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int pj = min(32 * t + li, np - 1);
+      ih2[t] = (p0 + pj) / HP;
+      iw2[t] = (p0 + pj) - ih2[t] * HP;
+      const int ih = ih2[t] * S + ph, iw = iw2[t] * S + pw;
+      inside[t] = ih < G::H && iw < G::H;
+      pix[t] = min(ih, G::H - 1) * G::H + min(iw, G::H - 1);
       const float* src = xact ? xact : dx;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = c0 + mfma_row(wave * 4 + q, h);
-        aux[q] = src[((int64_t)bi * G::C + c) * G::HW + pix];
+        aux[t][q] = src[((int64_t)bi * G::C + c) * G::HW + pix[t]];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -346,8 +355,13 @@ struct ConvDgradOne {
     }
     __syncthreads();
     // ---- MFMA: B operand of lane li = padded gradient at (ih2 - kh2 + PAD, iw2 - kw2 + PAD)
-    f32x16 acc = zero16();
-    const float* bptr = lds + (wave * OCW + h * OCH) * CS + ih2 * RW + iw2;
+    f32x16 acc[PT];
+    const float* bptr[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      acc[t] = zero16();
+      bptr[t] = lds + (wave * OCW + h * OCH) * CS + ih2[t] * RW + iw2[t];
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int kh2 = t / KP, kw2 = t % KP;
@@ -355,17 +369,24 @@ struct ConvDgradOne {
       for (int jj = 0; jj < OCH; ++jj) {
         const float4 av = areg[t][jj / 4];
         const float a = (jj % 4 == 0) ? av.x : ((jj % 4 == 1) ? av.y : ((jj % 4 == 2) ? av.z : av.w));
-        const float b = bptr[jj * CS + (PAD - kh2) * RW + (PAD - kw2)];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          const float b = bptr[pt][jj * CS + (PAD - kh2) * RW + (PAD - kw2)];
+          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[pt], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
-    float s[4];
-    reduce4(lds, acc, wave, lane, s);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = c0 + mfma_row(wave * 4 + q, h);
-      if (li < np && inside) dx[((int64_t)bi * G::C + c) * G::HW + pix] = xact ? s[q] * act_grad(aux[q], act) : s[q];
+    for (int t = 0; t < PT; ++t) {
+      float s[4];
+      reduce4(lds + t * 4096, acc[t], wave, lane, s);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + mfma_row(wave * 4 + q, h);
+        if (32 * t + li < np && inside[t])
+          dx[((int64_t)bi * G::C + c) * G::HW + pix[t]] = xact ? s[q] * act_grad(aux[t][q], act) : s[q];
+      }
     }
   }
 };

@@ -14,8 +14,8 @@ echo "== rocprofv3 kernel trace" ; (cd /tmp && timeout 300 rocprofv3 --kernel-tr
 python tools/prof_summary.py $OUT/prof > $OUT/rocprofv3_kernel_stats.txt 2>&1; head -30 $OUT/rocprofv3_kernel_stats.txt
 python tools/prof_timeline.py $OUT/prof 200 2 > $OUT/timeline.txt 2>&1
 find $OUT/prof -name "*.db" -size +20M -delete
-echo "== pmc FETCH_SIZE" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -- python $R/tools/pmc_workload.py --steps 40 > $R/$OUT/pmc_fetch.log 2>&1); tail -2 $OUT/pmc_fetch.log
-echo "== pmc WRITE_SIZE" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write -- python $R/tools/pmc_workload.py --steps 40 > $R/$OUT/pmc_write.log 2>&1); tail -2 $OUT/pmc_write.log
+echo "== pmc FETCH_SIZE" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -- python $R/tools/pmc_workload.py --steps 40 --variant 255 > $R/$OUT/pmc_fetch.log 2>&1); tail -2 $OUT/pmc_fetch.log
+echo "== pmc WRITE_SIZE" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write -- python $R/tools/pmc_workload.py --steps 40 --variant 255 > $R/$OUT/pmc_write.log 2>&1); tail -2 $OUT/pmc_write.log
 python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; head -c 1500 $OUT/pmc_traffic.json; tail -3 $OUT/pmc_traffic.err
 find $OUT/pmc_fetch $OUT/pmc_write -name "*.db" -size +20M -delete
 find $OUT/pmc_fetch $OUT/pmc_write -name "*kernel_trace*" -size +20M -delete
