@@ -27,9 +27,9 @@ import torch.nn as nn
 
 from . import ops
 from .envs import LazyFrames
-from .optim import FlatParams, FusedOptimizer
+from .optim import FlatParams, FusedOptimizer, nature_conv_weights
 from .replay import PrioritizedTransition, Storage
-from .support import close_obj, epsilon_greedy, get_logger, random_sample, range_tensor, tensor, to_np
+from .support import Config, close_obj, epsilon_greedy, get_logger, random_sample, range_tensor, tensor, to_np
 
 
 class _NullLock:
@@ -158,10 +158,15 @@ class DQNActor(BaseActor):
         BaseActor.__init__(self, config)
         self.config = config
         self._fast_q = None
+        self._graphed_q = _GraphedQ(self) if Config.DEVICE.type == 'cuda' else None
         self.start()
 
     def compute_q(self, prediction):
         return to_np(prediction['q'])
+
+    def q_device(self, prediction):
+        """The action values compute_q() brings to the host, as a device tensor (graph-captured actor forward)."""
+        return prediction['q']
 
     def _transition(self):
         if self._state is None:
@@ -169,9 +174,12 @@ class DQNActor(BaseActor):
         config = self.config
         if config.noisy_linear:
             self._network.reset_noise()
+        q_values = None
         if self._fast_q is not None:     # fused learner attached (DQNAgent._attach_fused_learner)
             q_values = self._fast_q(self._state)
-        else:
+        elif self._graphed_q is not None and self._graphed_q.usable(self._state):
+            q_values = self._graphed_q(self._state)     # None during its warm-up calls
+        if q_values is None:
             with config.lock:
                 with torch.no_grad():
                     prediction = self._network(config.state_normalizer(self._state))
@@ -190,6 +198,138 @@ class DQNActor(BaseActor):
         return entry
 
 
+class _GraphedQ:
+    """DQNActor's forward (DQN_agent.py:29-33) as ONE hipGraph replay for image observations: the uint8
+    [1,C,H,W] observation goes through pinned staging into a static device buffer; normaliser table kernel,
+    network forward and the action-value reduction replay from a graph captured (torch.cuda.graphs) after four
+    eager calls (one agent step: by then a DQNAgent that qualifies for the fused learner has switched to it).
+    Same kernels, same arguments as the eager path -> bit-identical action values."""
+    WARMUP = 4
+
+    def __init__(self, actor):
+        self.actor = actor
+        self.calls = 0
+        self.graph = None
+        self.static_in = self.static_out = None
+        self.stage = []
+        self.events = []
+        self.k = 0
+        self.failed = False
+
+    def usable(self, state):
+        from .normalizers import RescaleNormalizer
+        cfg = self.actor.config
+        if self.failed or cfg.noisy_linear or getattr(cfg, 'graph_update', True) is False:
+            return False
+        if not isinstance(cfg.state_normalizer, RescaleNormalizer):
+            return False
+        first = state[0] if isinstance(state, (list, tuple)) else state
+        return isinstance(first, LazyFrames) or (isinstance(first, np.ndarray) and first.dtype == np.uint8)
+
+    def __call__(self, state):
+        a = self.actor
+        cfg = a.config
+        self.calls += 1
+        if self.calls <= self.WARMUP:
+            return None
+        x = np.ascontiguousarray(np.asarray(state, dtype=np.uint8))
+        dev = next(a._network.parameters()).device
+        if self.graph is None:
+            try:
+                self.static_in = torch.zeros(x.shape, dtype=torch.uint8, device=dev)
+                self.stage = [torch.empty(x.shape, dtype=torch.uint8).pin_memory() for _ in range(4)]
+                self.events = [None] * 4
+                with torch.no_grad():   # eager dry run of exactly what is captured: creates every lazily built
+                    a.q_device(a._network(cfg.state_normalizer(self.static_in)))   # object (normaliser table, ...)
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    with torch.no_grad():
+                        self.static_out = a.q_device(a._network(cfg.state_normalizer(self.static_in)))
+                self.graph = g
+            except Exception as e:      # e.g. a network with host-side control flow: stay on the eager path
+                import warnings
+                warnings.warn("actor forward could not be captured as a graph (%r); using the eager path" % (e,))
+                self.failed = True
+                self.graph = None
+                return None
+        k = self.k
+        self.k = (k + 1) % len(self.stage)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        self.stage[k].numpy()[...] = x
+        self.static_in.copy_(self.stage[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        self.graph.replay()
+        return to_np(self.static_out)
+
+
+class _GraphedUpdate:
+    """One DQN-family update (DQN_agent.py:114-134: normalise, target / online forwards, fused loss kernel,
+    backward, clip, optimizer) as ONE hipGraph replay over static minibatch buffers that the ring gather refills
+    in place.  Captured with torch.cuda.graphs after two eager updates (which also run every lazy one-time
+    initialisation); same kernels and arguments as the eager path -> bit-identical parameters.  Uniform replay
+    only: the PER importance exponent changes every update and is a kernel argument."""
+    WARMUP = 2
+
+    def __init__(self, agent):
+        self.agent = agent
+        self.updates = 0
+        self.graph = None
+        self.static = None
+        self.out = None
+        self.signature = None
+        self.failed = False
+
+    def usable(self, rp):
+        cfg = self.agent.config
+        return not (self.failed or cfg.noisy_linear or getattr(cfg, 'graph_update', True) is False or hasattr(rp, 'draw')
+                    or self.agent._fused is None)
+
+    def run(self, rp):
+        """Returns the loss-kernel outputs of the update it performed, or None (caller runs the eager update)."""
+        agent = self.agent
+        cfg = agent.config
+        self.updates += 1
+        if self.updates <= self.WARMUP:
+            return None
+        opt = agent._fused
+        if self.graph is not None and self.signature != opt.hyper_signature():
+            self.graph = None       # a hyper-parameter baked into the graph changed (lr schedule): re-capture
+        idx = rp.draw_indices()
+        if self.graph is None:
+            try:
+                self.static = rp.gather(idx)
+                tr = rp.TransitionCLS(state=self.static['state'], action=self.static['action'], reward=self.static['reward'],
+                                      next_state=self.static['next_state'], mask=self.static['mask'])
+                opt.enable_graph_mode()
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    out, (net_out, grad) = agent._loss_grad(tr, None)
+                    opt.zero_grad()
+                    net_out.backward(grad)
+                    opt.step(cfg.gradient_clip)
+                self.out = out
+                self.graph = g
+                self.signature = opt.hyper_signature()
+            except Exception as e:
+                import warnings
+                warnings.warn("update could not be captured as a graph (%r); using the eager path" % (e,))
+                self.failed = True
+                self.graph = None
+                opt.graph_mode = False
+                return agent._learn(rp.TransitionCLS(**{k: v for k, v in rp.gather(idx).items()
+                                                        if k in rp.TransitionCLS._fields}))
+        else:
+            rp.gather(idx, out=self.static)
+        opt.prepare_step()
+        self.graph.replay()
+        return self.out
+
+
 class DQNAgent(BaseAgent):
     """DQN_agent.py:48-138."""
     ActorCLS = DQNActor
@@ -206,11 +346,13 @@ class DQNAgent(BaseAgent):
         self.target_network.load_state_dict(self.network.state_dict())
         self.optimizer = config.optimizer_fn(self.network.parameters())
         self._fused = FusedOptimizer.adopt(self.optimizer)           # re-homes network params in one flat buffer
-        self._target_flat = FlatParams(self.target_network.parameters())
+        self._target_flat = FlatParams(list(self.target_network.parameters()),
+                                       koc=nature_conv_weights(list(self.target_network.parameters())))
         self.actor.set_network(self.network)
         self.total_steps = 0
         self._learner = None            # fused learner (csrc/learner.hip), attached lazily when eligible
         self._fused_checked = False
+        self._graphed = _GraphedUpdate(self)   # generic path: whole update as one graph replay (uniform replay)
         self._post_init()
 
     # -- fused fast path ---------------------------------------------------------------------------------
@@ -376,6 +518,8 @@ class DQNAgent(BaseAgent):
                 else:
                     # same index draws as replay.sample() (replay.py:92-103); gather + update are one graph replay
                     self._learner.update(rp.draw_indices(), use_graph=True)
+            elif self._graphed.usable(self._inner_replay()) and self._graphed.run(self._inner_replay()) is not None:
+                pass
             else:
                 transitions = self.replay.sample()
                 if config.noisy_linear:
@@ -403,6 +547,9 @@ class CategoricalDQNActor(DQNActor):
 
     def compute_q(self, prediction):
         return to_np((prediction['prob'] * self.config.atoms).sum(-1))
+
+    def q_device(self, prediction):
+        return (prediction['prob'] * self.config.atoms).sum(-1)
 
 
 class CategoricalDQNAgent(DQNAgent):
@@ -461,6 +608,9 @@ class QuantileRegressionDQNActor(DQNActor):
 
     def compute_q(self, prediction):
         return to_np(prediction['quantile'].mean(-1))
+
+    def q_device(self, prediction):
+        return prediction['quantile'].mean(-1)
 
 
 class QuantileRegressionDQNAgent(DQNAgent):
@@ -575,7 +725,8 @@ class NStepDQNAgent(BaseAgent):
         self.target_network = config.network_fn()
         self.optimizer = config.optimizer_fn(self.network.parameters())
         self._fused = FusedOptimizer.adopt(self.optimizer)
-        self._target_flat = FlatParams(self.target_network.parameters())
+        self._target_flat = FlatParams(list(self.target_network.parameters()),
+                                       koc=nature_conv_weights(list(self.target_network.parameters())))
         ops.copy_f32(self._target_flat.flat, self._fused.flat.flat)
         self.total_steps = 0
         self.states = self.task.reset()

@@ -930,10 +930,18 @@ static int run_actor_steps_v3(dra_dqn_learner* l, int n_env, const float* P, hip
     const void* x3[1] = {l->ay2}; const float* w3[1] = {P + o[P_W3]}; const float* b3[1] = {P + o[P_B3]};
     float* y3[1] = {l->ay3};
     if ((rc = dra_conv_fwd_koc(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
-    hipLaunchKernelGGL(actor_fc4_head_env_kernel, dim3(128), dim3(256), 0, st, (const dra_dqn_step_params*)l->prm_dev, e,
-                       (const float*)l->ay3, P + o[P_W4], P + o[P_B4], l->ah4, 3136, l->fc4_ticket, P + o[P_WH],
-                       P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq, (uint8_t*)frames, (double*)rewards,
-                       (int32_t*)masks, (uint64_t)c.env_seed, (int)c.env_done_period);
+    if (l->variant & DRA_VAR_ACTOR_FUSED_HEAD) {
+      hipLaunchKernelGGL(actor_fc4_head_env_kernel, dim3(128), dim3(256), 0, st, (const dra_dqn_step_params*)l->prm_dev, e,
+                         (const float*)l->ay3, P + o[P_W4], P + o[P_B4], l->ah4, 3136, l->fc4_ticket, P + o[P_WH],
+                         P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq, (uint8_t*)frames, (double*)rewards,
+                         (int32_t*)masks, (uint64_t)c.env_seed, (int)c.env_done_period);
+    } else {
+      hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
+                         l->ah4, 3136);
+      hipLaunchKernelGGL(actor_head_env_kernel, dim3(1), dim3(256), 0, st, (const dra_dqn_step_params*)l->prm_dev, e,
+                         (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq,
+                         (uint8_t*)frames, (double*)rewards, (int32_t*)masks, (uint64_t)c.env_seed, (int)c.env_done_period);
+    }
     DRA_LAUNCH_CHECK();
   }
   return DRA_OK;

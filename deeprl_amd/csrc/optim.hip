@@ -331,8 +331,13 @@ DRA_API int dra_rmsprop_step(float* param, const float* grad, float* square_avg,
 __global__ void __launch_bounds__(256)
 adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                  int64_t n, const double* __restrict__ partials, int n_partials, float max_norm, float step_size,
-                 float beta1, float beta2, float inv_sqrt_bc2, float eps, float* __restrict__ out_norm) {
-  const float coef = partials ? clip_coef_from_partials(partials, n_partials, max_norm, out_norm) : 1.f;
+                 float beta1, float beta2, float inv_sqrt_bc2, float eps, float* __restrict__ out_norm,
+                 const float* __restrict__ hyper) {
+  if (hyper) {  // bias-corrected step size / 1/sqrt(1-b2^t) from device memory: the launch is replayable in a graph
+    step_size = hyper[0];
+    inv_sqrt_bc2 = hyper[1];
+  }
+  const float coef = clip_coef_from_partials(partials, n_partials, max_norm, out_norm);
   const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -345,20 +350,48 @@ adam_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __re
   }
 }
 
-DRA_API int dra_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                          const double* partials, int n_partials, float max_norm, float lr, float beta1, float beta2,
-                          float eps, int64_t step, float* out_norm, void* stream) {
-  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1 || step < 1) return DRA_EINVAL;
-  if (partials && (n_partials < 1 || n_partials > dra_norm_partials_max())) return DRA_EINVAL;
+// host side of the bias corrections: step_size = lr / (1 - b1^t), inv_sqrt_bc2 = 1 / sqrt(1 - b2^t)
+DRA_API int dra_adam_hyper(float lr, float beta1, float beta2, int64_t step, float* out2) {
+  if (!out2 || step < 1) return DRA_EINVAL;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  out2[0] = (float)((double)lr / bc1);
+  out2[1] = (float)(1.0 / sqrt(bc2));
+  return DRA_OK;
+}
+
+static int launch_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const double* partials,
+                       int n_partials, float max_norm, float step_size, float beta1, float beta2, float inv_sqrt_bc2,
+                       float eps, float* out_norm, const float* hyper, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 1) return DRA_EINVAL;
+  if (partials && (n_partials < 1 || n_partials > dra_norm_partials_max())) return DRA_EINVAL;
   int64_t b = (n + 255) / 256;
   if (b > 2048) b = 2048;
   hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)b), dim3(256), 0, dra_stream(stream), param, grad, exp_avg,
-                     exp_avg_sq, n, partials, n_partials, max_norm, (float)((double)lr / bc1), beta1, beta2,
-                     (float)(1.0 / sqrt(bc2)), eps, out_norm);
+                     exp_avg_sq, n, partials, n_partials, max_norm, step_size, beta1, beta2, inv_sqrt_bc2, eps, out_norm,
+                     hyper);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
+}
+
+DRA_API int dra_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          const double* partials, int n_partials, float max_norm, float lr, float beta1, float beta2,
+                          float eps, int64_t step, float* out_norm, void* stream) {
+  float hp[2];
+  if (dra_adam_hyper(lr, beta1, beta2, step, hp)) return DRA_EINVAL;
+  return launch_adam(param, grad, exp_avg, exp_avg_sq, n, partials, n_partials, max_norm, hp[0], beta1, beta2, hp[1], eps,
+                     out_norm, nullptr, stream);
+}
+
+// Same step with the two step-dependent scalars read from DEVICE memory (hyper_dev = {step_size, inv_sqrt_bc2},
+// filled from dra_adam_hyper): every kernel argument is then constant across steps and the launch can be
+// replayed from a captured graph.
+DRA_API int dra_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              const double* partials, int n_partials, float max_norm, float beta1, float beta2,
+                              float eps, const float* hyper_dev, float* out_norm, void* stream) {
+  if (!hyper_dev) return DRA_EINVAL;
+  return launch_adam(param, grad, exp_avg, exp_avg_sq, n, partials, n_partials, max_norm, 0.f, beta1, beta2, 0.f, eps,
+                     out_norm, hyper_dev, stream);
 }
 
 // Device-to-device parameter copy for the target-network sync (DQN_agent.py:136-138).

@@ -92,6 +92,40 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _ConvKocFn(torch.autograd.Function):
+    """Same layer on the one-round-trip kernels (conv_v2.hip forward, oneshot.h backward: weight gradient and
+    input gradient in ONE launch).  Used when the weight Parameter is a [OC,C,KH,KW] view of [(c,kh,kw)][oc]
+    ("KOC") storage, which is how FlatParams stores the three NatureConvBody weights."""
+    KSPLIT = 16
+
+    @staticmethod
+    def forward(ctx, x, w, b, layer, u8_coef):
+        wt = w.permute(1, 2, 3, 0)                      # the contiguous KOC storage
+        y = ops.conv_fwd_koc(layer, [x], [wt], [b], act="relu", u8_coef=u8_coef)[0]
+        ctx.save_for_backward(x, w, y)
+        ctx.layer, ctx.u8_coef = layer, u8_coef
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        layer = ctx.layer
+        dpre = ops.act_bwd(dy.contiguous(), y, "relu")
+        oc, c, kh, kw = w.shape
+        n_w = w.numel()
+        # per-(sample, row chunk) slabs pay off at DQN batch sizes; large batches use the fixed split-K weight gradient
+        variant = (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD | ops.VAR_ONESHOT_WGRAD) if x.shape[0] <= 64 else \
+            (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD)
+        dx, slabs, n_slabs, stride = ops.conv_bwd_fused_koc(layer, dpre, x, w.permute(1, 2, 3, 0), ksplit=_ConvKocFn.KSPLIT,
+                                                            u8_coef=ctx.u8_coef, variant=variant)
+        flat = torch.empty(stride, dtype=torch.float32, device=w.device)
+        partials = torch.empty(ops.norm_partials(), dtype=torch.float64, device=w.device)
+        ops.grad_sqnorm(flat, partials, slabs=slabs, n_slabs=n_slabs, slab_stride=stride)      # fixed-order slab fold
+        dw = flat[:n_w].view(c, kh, kw, oc).permute(3, 0, 1, 2)
+        db = flat[n_w:n_w + oc]
+        return (dx if ctx.needs_input_grad[0] and layer > 1 else None), dw, db, None, None
+
+
 class Linear(nn.Linear):
     """nn.Linear whose forward / backward are the HIP contractions; `fused_act` folds the body's
     gate into the GEMM epilogue."""
@@ -114,6 +148,8 @@ class Conv2d(nn.Conv2d):
         u8_coef = getattr(x, "dra_u8_coef", None) if x.dtype == torch.uint8 else None
         if x.dtype == torch.uint8 and u8_coef is None:
             raise TypeError("uint8 input to a convolution needs a normaliser (RescaleNormalizer marks it)")
+        if self.weight.permute(1, 2, 3, 0).is_contiguous():     # KOC storage (FlatParams): one-round-trip kernels
+            return _ConvKocFn.apply(x.contiguous(), self.weight, self.bias, layer, u8_coef)
         return _ConvFn.apply(x.contiguous(), self.weight, self.bias, layer, u8_coef)
 
 

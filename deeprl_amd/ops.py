@@ -383,7 +383,8 @@ def conv_bwd_x_koc(layer, dy, wt, xact=None, act="relu"):
 # variant bits of the fused / one-pass kernels (include/deeprl_amd.h DRA_VAR_*)
 VAR_FUSED_BWD, VAR_ONESHOT_DGRAD, VAR_ONESHOT_FWD, VAR_ONESHOT_WGRAD = 1, 2, 4, 8
 VAR_PINNED_IDX, VAR_ACTOR_V2, VAR_ACTOR_PARAMS, VAR_PIPE_GATHER, VAR_CU_PARTITION, VAR_ACTOR_V3 = 16, 32, 64, 128, 256, 512
-VAR_ALL = 1023
+VAR_ACTOR_FUSED_HEAD = 1024
+VAR_ALL = 2047
 
 
 def set_tuning(mask):
@@ -420,6 +421,26 @@ def conv_bwd_fused(layer, dy, x, wt=None, xact=None, ksplit=16, u8_coef=None, ac
                            float(u8_coef if is_u8 else 1.0), ACT[act], int(variant), stream_ptr())
     v = slabs.view(n_slabs, stride)
     return v[:, :oc * kk], v[:, oc * kk:oc * kk + oc], dx, slabs
+
+
+def conv_bwd_fused_koc(layer, dy, x, wt, ksplit=16, u8_coef=None, variant=0):
+    """Production form of conv_bwd_fused (generic autograd path): dy = gradient w.r.t. this layer's pre-activation,
+    wt = KOC weights.  One launch -> (dx or None, slab buffer [n_slabs * stride], n_slabs, stride); slab s holds
+    dWt [K*OC] then db [OC]; the caller folds them (grad_sqnorm)."""
+    c, h, oc, k, s = _CONV_GEOM[layer]
+    kk = c * k * k
+    batch = x.shape[0]
+    is_u8 = x.dtype == torch.uint8
+    stride = (oc * kk + oc + 3) // 4 * 4
+    n_slabs = conv_wgrad_slabs(layer, batch, ksplit, variant)
+    slabs = torch.empty(n_slabs * stride, dtype=_f32, device=x.device)
+    if stride != oc * kk + oc:
+        slabs.view(n_slabs, stride)[:, oc * kk + oc:].zero_()      # alignment gap is folded too: keep it finite
+    dx = torch.empty((batch, c, h, h), dtype=_f32, device=x.device) if layer > 1 else None
+    lib.dra_conv_bwd_fused(layer, ptr(_c(dy, _f32)), ptr(_c(x)), ptr(_c(wt, _f32)), None, ptr(slabs),
+                           ctypes.c_void_p(slabs.data_ptr() + 4 * oc * kk), stride, ksplit, ptr(dx), batch, int(is_u8),
+                           float(u8_coef if is_u8 else 1.0), ACT["relu"], int(variant), stream_ptr())
+    return dx, slabs, n_slabs, stride
 
 
 def fc_bwd_fused(dq, h4, dh4, x3, w4, act="relu", variant=0):
@@ -562,6 +583,14 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, partials, n_partials, max_norm, 
     lib.dra_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), ptr(partials),
                       int(n_partials), float(max_norm if max_norm else 0.0), float(lr), float(beta1), float(beta2),
                       float(eps), int(step), ptr(out_norm), stream_ptr())
+
+
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, partials, n_partials, max_norm, beta1, beta2, eps, hyper_dev,
+                  out_norm=None):
+    """Adam with {lr/(1-b1^t), 1/sqrt(1-b2^t)} read from the device tensor `hyper_dev` (graph-replayable)."""
+    lib.dra_adam_step_dev(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), ptr(partials),
+                          int(n_partials), float(max_norm if max_norm else 0.0), float(beta1), float(beta2), float(eps),
+                          ptr(hyper_dev), ptr(out_norm), stream_ptr())
 
 
 def copy_f32(dst, src):

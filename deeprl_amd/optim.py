@@ -12,6 +12,15 @@ from . import ops
 from ._lib import DraError
 
 
+# the three NatureConvBody weights (network_bodies.py:14-20): stored [(c,kh,kw)][oc] so that the one-round-trip
+# convolution kernels read them without a per-step layout conversion
+NATURE_CONV_SHAPES = {(32, 4, 8, 8), (64, 32, 4, 4), (64, 64, 3, 3)}
+
+
+def nature_conv_weights(params):
+    return [p for p in params if p.dim() == 4 and tuple(p.shape) in NATURE_CONV_SHAPES]
+
+
 class FlatParams:
     """Re-homes parameters into one contiguous fp32 buffer (each tensor 16-byte aligned) and gives
     every parameter a .grad view into a matching flat gradient buffer."""
@@ -80,6 +89,11 @@ class FusedOptimizer:
         self.partials = torch.zeros(self.n_partials, dtype=torch.float64, device=dev)
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.steps = 0
+        # graph mode (agents capture the whole update into a hipGraph): every kernel argument must be constant
+        # across steps, so Adam's step-dependent scalars live in device memory and are refreshed by prepare_step()
+        self.graph_mode = False
+        self._hyper_dev = None
+        self._hyper_up = None
 
     @classmethod
     def adopt(cls, torch_optimizer, flat=None):
@@ -88,7 +102,7 @@ class FusedOptimizer:
             raise DraError("FusedOptimizer supports a single param group")
         g = groups[0]
         if flat is None:
-            flat = FlatParams(g['params'])
+            flat = FlatParams(g['params'], koc=nature_conv_weights(g['params']))
         if isinstance(torch_optimizer, torch.optim.RMSprop):
             if g.get('momentum', 0) != 0 or g.get('weight_decay', 0) != 0:
                 raise DraError("RMSprop momentum / weight_decay have no HIP kernel")
@@ -104,6 +118,31 @@ class FusedOptimizer:
     def zero_grad(self):
         self.flat.zero_grad()
 
+    def enable_graph_mode(self):
+        if not self.graph_mode:
+            dev = self.flat.flat.device
+            self._hyper_dev = torch.zeros(2, dtype=torch.float32, device=dev)
+            from .replay import _PinnedUploader
+            self._hyper_up = _PinnedUploader(torch.float32, 2, dev)
+            self.graph_mode = True
+
+    def hyper_signature(self):
+        """Hyper-parameters that are baked into a captured update (a change invalidates the graph)."""
+        h = self.hyper
+        return (self.kind, h['lr'], h.get('alpha'), h.get('eps'), h.get('centered'), tuple(h.get('betas', ())))
+
+    def prepare_step(self):
+        """Graph mode, OUTSIDE the captured region and before each replay: count the step and refresh Adam's
+        bias-corrected scalars in device memory (same host arithmetic as the eager path: dra_adam_hyper)."""
+        self.steps += 1
+        if self.kind == 'adam':
+            import ctypes
+            from ._lib import lib
+            b1, b2 = self.hyper['betas']
+            hp = (ctypes.c_float * 2)()
+            lib.dra_adam_hyper(float(self.hyper['lr']), float(b1), float(b2), int(self.steps), hp)
+            self._hyper_dev.copy_(self._hyper_up.upload([hp[0], hp[1]]), non_blocking=True)
+
     def step(self, max_norm=None):
         """max_norm None / 0 = no clipping (then the norm pass is skipped)."""
         f, h = self.flat, self.hyper
@@ -111,6 +150,15 @@ class FusedOptimizer:
         if clip:
             ops.grad_sqnorm(f.grad, self.partials)
         partials = self.partials if clip else None
+        if self.graph_mode:   # steps / Adam scalars were advanced by prepare_step()
+            if self.kind == 'rmsprop':
+                ops.rmsprop_step(f.flat, f.grad, self.state1, self.state2, partials, self.n_partials, max_norm or 0.0,
+                                 h['lr'], h['alpha'], h['eps'], h['centered'], self.norm if clip else None)
+            else:
+                b1, b2 = h['betas']
+                ops.adam_step_dev(f.flat, f.grad, self.state1, self.state2, partials, self.n_partials, max_norm or 0.0,
+                                  b1, b2, h['eps'], self._hyper_dev, self.norm if clip else None)
+            return
         self.steps += 1
         if self.kind == 'rmsprop':
             ops.rmsprop_step(f.flat, f.grad, self.state1, self.state2, partials, self.n_partials, max_norm or 0.0,

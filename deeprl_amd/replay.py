@@ -189,12 +189,14 @@ class UniformReplay(Storage):
                 out.append(i)
         return np.asarray(out, dtype=np.int64)
 
-    def gather(self, idx, want_f32=False):
-        """Device gather of validated indices (numpy int64 or device tensor) -> dict of device tensors."""
+    def gather(self, idx, want_f32=False, out=None):
+        """Device gather of validated indices (numpy int64 or device tensor) -> dict of device tensors
+        (`out`: a dict returned by an earlier call, refilled in place -- static buffers of a captured update)."""
         with torch.cuda.device(self._device()):
             if not isinstance(idx, torch.Tensor):
                 idx = self._idx_up.upload(idx)
-            return self._ring.gather(idx, self._state_shape, self._state_dtype, self._action_dtype, want_f32=want_f32)
+            return self._ring.gather(idx, self._state_shape, self._state_dtype, self._action_dtype, want_f32=want_f32,
+                                     out=out)
 
     def sample(self, batch_size=None):
         g = self.gather(self.draw_indices(batch_size))

@@ -147,8 +147,9 @@ int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* 
 #define DRA_VAR_PINNED_IDX 16    /* learner: the gather reads minibatch indices from pinned host memory */
 #define DRA_VAR_ACTOR_V2 32      /* learner: 5-kernel actor step (ring-direct conv1, GEMV fc4, head + env) */
 #define DRA_VAR_ACTOR_PARAMS 64  /* learner: async actor reads a double-buffered parameter copy */
-#define DRA_VAR_ACTOR_V3 512     /* learner: 4-kernel actor step (fc4 + head + env fused through a last-workgroup ticket),
-                                    parameter block read from a pinned ring by the graph's first kernel */
+#define DRA_VAR_ACTOR_V3 512     /* learner: the actor graph's first kernel reads its parameter block from a pinned ring
+                                    (no copy command in front of the graph) */
+#define DRA_VAR_ACTOR_FUSED_HEAD 1024 /* with ACTOR_V3: fc4 + head + env step as one kernel (last-workgroup ticket) */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
@@ -190,6 +191,12 @@ int dra_rmsprop_step_copy(float* param, const float* grad, float* square_avg, fl
 int dra_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   const double* partials, int n_partials, float max_norm, float lr, float beta1, float beta2, float eps,
                   int64_t step, float* out_norm, void* stream);
+/* graph-replayable Adam: the step-dependent scalars {lr/(1-b1^t), 1/sqrt(1-b2^t)} (dra_adam_hyper, host) are read
+ * from device memory, every kernel argument is constant across steps */
+int dra_adam_hyper(float lr, float beta1, float beta2, int64_t step, float* out2);
+int dra_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const double* partials, int n_partials, float max_norm, float beta1, float beta2, float eps,
+                      const float* hyper_dev, float* out_norm, void* stream);
 int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream); /* DQN_agent.py:136-138 */
 
 /* ---- fused DQN learner + device-resident actor: DQN_agent.py:24-45 (actor step), :114-138 (update) for

@@ -303,7 +303,7 @@ def test_fused_learner_matches_oracle(dra, double_q, variant):
     ring.close()
 
 
-@pytest.mark.parametrize("variant", [0, 127, 767])
+@pytest.mark.parametrize("variant", [0, 127, 1791])
 def test_fused_step_sync_equals_act_then_update(dra, variant):
     """dra_dqn_learner_step in in-order mode == explicit actor transitions followed by an update:
     the synthetic frame source, the device epsilon-greedy and the captured graphs change nothing."""
@@ -354,7 +354,7 @@ def test_fused_step_sync_equals_act_then_update(dra, variant):
 _ASYNC_RESULTS = {}
 
 
-@pytest.mark.parametrize("variant", [0, 127, 255, 767, 1023])
+@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047])
 def test_fused_step_async_pipeline(dra, variant):
     """async_actor=True pipeline (actor one agent step ahead on its own stream, double-buffered actor
     parameters when variant has DRA_VAR_ACTOR_PARAMS): the transitions it feeds are the documented counter-hash
@@ -389,7 +389,7 @@ def test_fused_step_async_pipeline(dra, variant):
     # the parameters of optimizer t-1) -> bit-identical parameters and actions
     _ASYNC_RESULTS[variant] = outs[0]
     # ... and so do the 4-kernel actor step (DRA_VAR_ACTOR_V3: same arithmetic, fused launches) and the CU partition
-    for other in (255, 767, 1023):
+    for other in (255, 1023, 2047):
         if 127 in _ASYNC_RESULTS and other in _ASYNC_RESULTS:
             assert np.array_equal(_ASYNC_RESULTS[127][0], _ASYNC_RESULTS[other][0])
             assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
@@ -462,3 +462,73 @@ def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch, per, n_step
     for k in outs[0][2]:
         np.testing.assert_allclose(outs[0][2][k], outs[1][2][k], rtol=2e-4, atol=2e-6, err_msg=k)
         np.testing.assert_allclose(outs[0][3][k], outs[1][3][k], rtol=2e-4, atol=2e-6, err_msg="target " + k)
+
+
+@pytest.mark.parametrize("kind", ["c51", "qr", "dqn_fc"])
+def test_graphed_generic_update_is_bit_identical(dra, monkeypatch, kind):
+    """The generic DQN-family path replays its update (and, for image observations, the actor forward) from a
+    captured hipGraph after two eager updates: same kernels and arguments, so 16 agent steps with
+    config.graph_update True / False end in bit-identical parameters, replay contents and RNG state
+    (C51 and QR-DQN use Adam: its step-dependent scalars come from device memory in graph mode)."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    outs = []
+    for graph in (True, False):
+        cfg = d.Config()
+        pixel = kind != "dqn_fc"
+        cfg.merge(dict(game="BreakoutNoFrameskip-v4" if pixel else "CartPole-v0", n_step=1, replay_cls=d.UniformReplay,
+                       async_replay=False, log_level=0, tag="g%d" % graph, graph_update=graph, fused_learner=False))
+        cfg.task_fn = lambda: d.Task(cfg.game, seed=5)
+        cfg.eval_env = cfg.task_fn()
+        if kind == "c51":
+            cfg.optimizer_fn = lambda p: torch.optim.Adam(p, lr=0.00025, eps=0.01 / 32)
+            cfg.categorical_v_max, cfg.categorical_v_min, cfg.categorical_n_atoms = 10, -10, 51
+            cfg.network_fn = lambda: d.CategoricalNet(cfg.action_dim, cfg.categorical_n_atoms, d.NatureConvBody())
+            cls = d.CategoricalDQNAgent
+        elif kind == "qr":
+            cfg.optimizer_fn = lambda p: torch.optim.Adam(p, lr=0.00005, eps=0.01 / 32)
+            cfg.num_quantiles = 50
+            cfg.network_fn = lambda: d.QuantileNet(cfg.action_dim, cfg.num_quantiles, d.NatureConvBody())
+            cls = d.QuantileRegressionDQNAgent
+        else:
+            cfg.optimizer_fn = lambda p: torch.optim.RMSprop(p, 0.001)
+            cfg.network_fn = lambda: d.VanillaNet(cfg.action_dim, d.FCBody(cfg.state_dim))
+            cls = d.DQNAgent
+        cfg.random_action_prob = d.LinearSchedule(1.0, 0.05, 60)
+        cfg.batch_size = 16
+        cfg.discount = 0.99
+        cfg.history_length = 4 if pixel else 1
+        kw = dict(memory_size=400, batch_size=16, n_step=1, discount=0.99, history_length=cfg.history_length)
+        cfg.replay_fn = lambda: d.ReplayWrapper(cfg.replay_cls, kw, cfg.async_replay)
+        if pixel:
+            cfg.state_normalizer = d.ImageNormalizer()
+            cfg.reward_normalizer = d.SignNormalizer()
+        cfg.target_network_update_freq = 3
+        cfg.exploration_steps = 24
+        cfg.sgd_update_frequency = 4
+        cfg.gradient_clip = 5
+        cfg.double_q = False
+        cfg.async_actor = False
+        cfg.max_steps = 1e5
+        d.random_seed(4)
+        random.seed(4)
+        torch.manual_seed(4)
+        agent = cls(cfg)
+        for _ in range(16):
+            agent.step()
+        torch.cuda.synchronize()
+        assert (agent._graphed.graph is not None) == graph
+        if pixel:
+            assert (agent.actor._graphed_q.graph is not None) == graph
+        rp = agent.replay.replay
+        n = rp.size()
+        acts = d.ops._wrap_device_pointer(rp._ring.pointers()[1], n, torch.int64).cpu().numpy().copy()
+        params = {k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()}
+        rng_tail = np.random.randint(0, 1 << 30, size=4)
+        outs.append((acts, params, rng_tail))
+        agent.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    for k in outs[0][1]:
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
