@@ -102,6 +102,54 @@ def cpu_baseline(seconds=15.0, ring=20_000):
             "sample": "%d DQN updates (B=32, 84x84x4, %d-frame ring) in %.1f s, torch-CPU fp32 oracle, 1 thread" % (n, ring, dt)}
 
 
+def agent_api(seconds=3.0, ring=100_000):
+    """The same configuration through the drop-in surface: DQNAgent(config).step() as run_steps drives it
+    (examples.py:55-97), with the synthetic emulator on the HOST -- every observation is uploaded and every action
+    crosses back to the host, as in the reference.  DQNAgent attaches the fused learner by itself.  Reported next
+    to `value`, never as `value`."""
+    import deeprl_amd as d
+    import deeprl_amd.agents as agents_mod
+
+    class _Quiet:
+        def info(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+        def add_histogram(self, *a, **k):
+            pass
+
+    agents_mod.get_logger = lambda *a, **k: _Quiet()
+    c = d.Config()
+    c.merge(dict(game="BreakoutNoFrameskip-v4", log_level=0, tag="bench", n_step=1, replay_cls=d.UniformReplay, async_replay=False))
+    c.task_fn = lambda: d.Task(c.game, seed=1)
+    c.eval_env = c.task_fn()
+    c.optimizer_fn = lambda p: torch.optim.RMSprop(p, lr=0.00025, alpha=0.95, eps=0.01, centered=True)
+    c.network_fn = lambda: d.VanillaNet(c.action_dim, d.NatureConvBody(in_channels=4))
+    c.random_action_prob = d.LinearSchedule(1.0, 0.01, 1e6)
+    c.batch_size, c.discount, c.history_length = B, 0.99, H
+    kw = dict(memory_size=ring, batch_size=B, n_step=1, discount=0.99, history_length=H)
+    c.replay_fn = lambda: d.ReplayWrapper(c.replay_cls, kw, c.async_replay)
+    c.state_normalizer, c.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
+    c.target_network_update_freq, c.exploration_steps, c.sgd_update_frequency = 10000, 200, 4
+    c.gradient_clip, c.double_q, c.async_actor, c.max_steps = 5, False, False, int(2e7)
+    agent = d.DQNAgent(c)
+    for _ in range(100):
+        agent.step()
+    torch.cuda.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        agent.step()
+        n += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fused = agent._learner is not None
+    agent.close()
+    return {"updates_per_s": n / dt, "env_steps_per_s": 4 * n / dt, "fused_learner_attached": fused,
+            "note": "DQNAgent.step() (run_steps path), host-side synthetic emulator, sync actor, %d agent steps" % n}
+
+
 def pmc_traffic(kernel_group):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_traffic.json, made by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of
@@ -178,6 +226,7 @@ def main():
         }
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
+            out["agent_api"] = agent_api()
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if distributed:

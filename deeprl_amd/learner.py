@@ -121,13 +121,14 @@ class DQNLearner:
         actor_bits = set(range(n_act))
         words = (n_cu + 31) // 32
         out = []
-        for bits in (set(range(n_cu)) - actor_bits, actor_bits):
-            mask = (ctypes.c_uint32 * words)()
-            for b in bits:
-                mask[b // 32] |= 1 << (b % 32)
-            h = ctypes.c_void_p()
-            lib.dra_stream_create_masked(ctypes.byref(h), mask, words)
-            out.append(torch.cuda.ExternalStream(h.value, device=Config.DEVICE))
+        with torch.cuda.device(Config.DEVICE):      # the stream is created on the current HIP device
+            for bits in (set(range(n_cu)) - actor_bits, actor_bits):
+                mask = (ctypes.c_uint32 * words)()
+                for b in bits:
+                    mask[b // 32] |= 1 << (b % 32)
+                h = ctypes.c_void_p()
+                lib.dra_stream_create_masked(ctypes.byref(h), mask, words)
+                out.append(torch.cuda.ExternalStream(h.value, device=Config.DEVICE))
         _PARTITIONED_STREAMS[key] = out
         return out
 
