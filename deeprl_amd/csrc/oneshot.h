@@ -198,16 +198,20 @@ struct LinDgradOne {
 //   slabs[z][s][b][o] = sum_{k in split s} x_z[b][k] * W_z[o][k]      M = b, N = o, K = I / KS
 // Both operands are k-contiguous in memory: float4 loads -> LDS [32][KPS+1] each; lane = row reads are
 // conflict-free (odd row stride).  The consumer (head_fused_kernel) reduces the KS slabs.
-template <int I, int KS>
+// NT = 32-wide output tiles per workgroup (sharing the staged x rows).  NT = 2 keeps fc4 at 128 workgroups for
+// two networks: one round even on the 192-CU partition the update chain owns (at 100-150 KB of LDS a CU holds
+// one of these workgroups; with NT = 1 the 256 workgroups ran in two rounds there: 12.4 us vs 8.4 us on 256 CUs).
+template <int I, int KS, int NT = 1>
 struct LinFwdSlabsOne {
   static constexpr int KPS = I / KS, KW = KPS / 4, NJ = KW / 2, LD = KPS + 1;
-  static constexpr int V = KPS / 4, NV = 32 * V, RV = (NV + 255) / 256;
-  static constexpr int LDS_FLOATS = 2 * 32 * LD > 4096 ? 2 * 32 * LD : 4096;
+  static constexpr int V = KPS / 4, NVX = 32 * V, NVW = 32 * NT * V, RX = (NVX + 255) / 256, RWV = (NVW + 255) / 256;
+  static constexpr int LDS_FLOATS = (1 + NT) * 32 * LD > NT * 4096 ? (1 + NT) * 32 * LD : NT * 4096;
   static_assert(I % KS == 0 && KPS % 8 == 0, "K split: float4 rows, even k per half-wave");
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS per workgroup");
   const float* x[kMaxZ];  // [B][I]
   const float* w[kMaxZ];  // [O][I]
   float* slabs;           // [nz][KS][B][O]
-  int B, O, tiles_n, tiles_m;
+  int B, O, tiles_n, tiles_m;   // tiles_n counts 32*NT-wide tile groups
   __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int bn = bid % tiles_n;
@@ -215,44 +219,65 @@ struct LinFwdSlabsOne {
     const int bm = r % tiles_m;
     r /= tiles_m;
     const int s = r % KS, z = r / KS;
-    const int m0 = bm * 32, n0 = bn * 32, k0 = s * KPS;
+    const int m0 = bm * 32, n0 = bn * 32 * NT, k0 = s * KPS;
     const float* __restrict__ xz = x[z];
     const float* __restrict__ wz = w[z];
-    float4 xa[RV], wa[RV];
+    float4 xa[RX], wa[RWV];
 #pragma unroll
-    for (int q = 0; q < RV; ++q) {
-      const int e = min(tid + 256 * q, NV - 1), row = e / V, c4 = e - row * V;
+    for (int q = 0; q < RX; ++q) {
+      const int e = min(tid + 256 * q, NVX - 1), row = e / V, c4 = e - row * V;
       xa[q] = *reinterpret_cast<const float4*>(xz + (int64_t)min(m0 + row, B - 1) * I + k0 + 4 * c4);
+    }
+#pragma unroll
+    for (int q = 0; q < RWV; ++q) {
+      const int e = min(tid + 256 * q, NVW - 1), row = e / V, c4 = e - row * V;
       wa[q] = *reinterpret_cast<const float4*>(wz + (int64_t)min(n0 + row, O - 1) * I + k0 + 4 * c4);
     }
     float* xs = lds;
     float* ws = lds + 32 * LD;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int q = 0; q < RV; ++q) {
+    for (int q = 0; q < RX; ++q) {
       const int e = tid + 256 * q;
-      if (e < NV) {
+      if (e < NVX) {
         const int row = e / V, c4 = e - row * V;
         float* dx_ = xs + row * LD + 4 * c4;
-        float* dw_ = ws + row * LD + 4 * c4;
         dx_[0] = xa[q].x; dx_[1] = xa[q].y; dx_[2] = xa[q].z; dx_[3] = xa[q].w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RWV; ++q) {
+      const int e = tid + 256 * q;
+      if (e < NVW) {
+        const int row = e / V, c4 = e - row * V;
+        float* dw_ = ws + row * LD + 4 * c4;
         dw_[0] = wa[q].x; dw_[1] = wa[q].y; dw_[2] = wa[q].z; dw_[3] = wa[q].w;
       }
     }
     __syncthreads();
-    f32x16 acc = zero16();
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = zero16();
     const float* ap = xs + li * LD + wave * KW + h * NJ;
     const float* bp = ws + li * LD + wave * KW + h * NJ;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[j], bp[j], acc, 0, 0, 0);
+    for (int j = 0; j < NJ; ++j) {
+      const float a = ap[j];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[t * 32 * LD + j], acc[t], 0, 0, 0);
+    }
     __syncthreads();
-    float sum[4];
-    reduce4(lds, acc, wave, lane, sum);
     float* out = slabs + ((int64_t)(z * KS + s) * B) * O;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int m = m0 + mfma_row(wave * 4 + q, h);
-      if (m < B && n0 + li < O) out[(int64_t)m * O + n0 + li] = sum[q];
+    for (int t = 0; t < NT; ++t) {
+      float sum[4];
+      reduce4(lds + t * 4096, acc[t], wave, lane, sum);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + mfma_row(wave * 4 + q, h);
+        const int n = n0 + 32 * t + li;
+        if (m < B && n < O) out[(int64_t)m * O + n] = sum[q];
+      }
     }
   }
 };

@@ -209,7 +209,7 @@ DRA_API int dra_ring_fill_synthetic(dra_ring* r, int64_t slot0, int64_t count, i
 // (H-n) frames shared by state and next_state are read once, so HBM reads are the compulsory
 // (H+n)*frame_bytes per sample.  Thread 0 of workgroup (b,0) folds the n-step return
 // (replay.py:135-139) in fp64 with the reference's association: cum = r + ((m*gamma)*cum).
-template <bool VEC16>
+template <bool VEC16, bool STREAM>
 __global__ void __launch_bounds__(256)
 ring_gather_kernel(const uint8_t* __restrict__ frames, const uint8_t* __restrict__ actions,
                    const double* __restrict__ rewards, const int32_t* __restrict__ masks,
@@ -225,12 +225,24 @@ ring_gather_kernel(const uint8_t* __restrict__ frames, const uint8_t* __restrict
   uint8_t* d0 = (j < H && out_state) ? out_state + ((int64_t)b * H + j) * frame_bytes : nullptr;
   uint8_t* d1 = (j >= n && out_next) ? out_next + ((int64_t)b * H + (j - n)) * frame_bytes : nullptr;
   if (VEC16) {
+    // two 16-byte loads per lane in flight before the first store (a 7056-byte frame is 441 vectors: one pass
+    // of this loop); STREAM (many-minibatch launches whose output does not fit the caches) also streams the stores
     const int64_t nv = frame_bytes >> 4;
     const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
-    for (int64_t t = threadIdx.x; t < nv; t += blockDim.x) {
+    u32x4* o0 = reinterpret_cast<u32x4*>(d0);
+    u32x4* o1 = reinterpret_cast<u32x4*>(d1);
+    for (int64_t t = threadIdx.x; t < nv; t += 2 * blockDim.x) {
+      const int64_t t2 = t + blockDim.x;
+      const bool second = t2 < nv;
       const u32x4 v = __builtin_nontemporal_load(s4 + t);  // ring frames are streamed once
-      if (d0) reinterpret_cast<u32x4*>(d0)[t] = v;
-      if (d1) reinterpret_cast<u32x4*>(d1)[t] = v;
+      const u32x4 w = __builtin_nontemporal_load(s4 + (second ? t2 : t));
+      if (STREAM) {
+        if (d0) { __builtin_nontemporal_store(v, o0 + t); if (second) __builtin_nontemporal_store(w, o0 + t2); }
+        if (d1) { __builtin_nontemporal_store(v, o1 + t); if (second) __builtin_nontemporal_store(w, o1 + t2); }
+      } else {
+        if (d0) { o0[t] = v; if (second) o0[t2] = w; }
+        if (d1) { o1[t] = v; if (second) o1[t2] = w; }
+      }
     }
   } else {
     for (int64_t t = threadIdx.x; t < frame_bytes; t += blockDim.x) {
@@ -267,16 +279,17 @@ DRA_API int dra_ring_gather(dra_ring* r, const int64_t* idx_dev, int batch, void
   const bool vec = (r->frame_bytes % 16 == 0) && aligned16(r->frames) && (!out_state || aligned16(out_state)) &&
                    (!out_next_state || aligned16(out_next_state));
   dim3 grid((unsigned)batch * span), block(256);
-  if (vec)
-    hipLaunchKernelGGL(ring_gather_kernel<true>, grid, block, 0, dra_stream(stream), r->frames, r->actions, r->rewards,
-                       r->masks, idx_dev, r->frame_bytes, r->action_bytes, r->history, r->n_step, r->discount,
-                       (uint8_t*)out_state, (uint8_t*)out_next_state, (uint8_t*)out_action, out_reward, out_mask,
-                       out_reward_f32, out_mask_f32);
-  else
-    hipLaunchKernelGGL(ring_gather_kernel<false>, grid, block, 0, dra_stream(stream), r->frames, r->actions, r->rewards,
-                       r->masks, idx_dev, r->frame_bytes, r->action_bytes, r->history, r->n_step, r->discount,
-                       (uint8_t*)out_state, (uint8_t*)out_next_state, (uint8_t*)out_action, out_reward, out_mask,
-                       out_reward_f32, out_mask_f32);
+  // an output larger than the 256 MB Infinity Cache cannot stay on die anyway: stream it past the caches
+  const bool stream_out = (int64_t)batch * 2 * r->history * r->frame_bytes >= ((int64_t)256 << 20);
+#define DRA_GATHER_LAUNCH(V, S)                                                                                        \
+  hipLaunchKernelGGL((ring_gather_kernel<V, S>), grid, block, 0, dra_stream(stream), r->frames, r->actions, r->rewards, \
+                     r->masks, idx_dev, r->frame_bytes, r->action_bytes, r->history, r->n_step, r->discount,          \
+                     (uint8_t*)out_state, (uint8_t*)out_next_state, (uint8_t*)out_action, out_reward, out_mask,       \
+                     out_reward_f32, out_mask_f32)
+  if (vec && stream_out) DRA_GATHER_LAUNCH(true, true);
+  else if (vec) DRA_GATHER_LAUNCH(true, false);
+  else DRA_GATHER_LAUNCH(false, false);
+#undef DRA_GATHER_LAUNCH
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
