@@ -80,6 +80,12 @@ struct dra_dqn_learner {
   hipEvent_t ev_mb_ready[2], ev_mb_free[2];   // gather of buffer b finished / update body done with buffer b
   bool mb_used[2];
   int64_t step_no;                  // async steps with an update issued so far
+  // DRA_VAR_GATHER_IN_GRAPH: actor transitions + the gather of the SAME step as one graph per step parity
+  hipGraphExec_t g_ag[2];
+  bool g_ag_ready[2];
+  int g_ag_nenv[2];
+  bool ag_have_prev;                // a gathered minibatch is waiting for its update
+  int ag_prev_par;
   // optional timeline of the pipelined async step (measurement aid): per traced step 5 timing events --
   // actor stream before gather / after gather / after the actor graph, update stream before / after the graph
   hipEvent_t* tr_ev;
@@ -251,6 +257,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
     delete[] l->tr_ev;
   }
   for (int g = 0; g < 2; ++g) {
+    if (l->g_ag_ready[g]) (void)hipGraphExecDestroy(l->g_ag[g]);
     if (l->g_pipe_ready[g]) (void)hipGraphExecDestroy(l->g_pipe[g]);
     (void)hipEventDestroy(l->ev_mb_ready[g]); (void)hipEventDestroy(l->ev_mb_free[g]);
     void* mb[] = {l->state_[g], l->next_state_[g], l->action_[g], l->reward_[g], l->mask_[g]};
@@ -1221,6 +1228,92 @@ static int issue_actor(dra_dqn_learner* l, const dra_dqn_step_params* prm, int k
   return v3 ? stage_actor_params(l, prm, st, false) : DRA_OK;
 }
 
+// async mode, DRA_VAR_GATHER_IN_GRAPH (on top of PIPE_GATHER + ACTOR_PARAMS).  Call k carries the transitions of
+// step k AND the minibatch indices of step k (the host draws them in the reference's order: actor randomness of a
+// step, then its sample).  Per call:
+//   actor stream  : ONE copy (parameter block + indices, contiguous in dra_dqn_step_params) and ONE graph
+//                   [actor transitions of step k ... gather of step k -> minibatch buffer k%2]
+//   update stream : body + optimizer of step k-1 (one graph) on the minibatch gathered by the previous call
+// Same dependencies as step_pipelined (gather(k) after actor(k), before actor(k+1); actor(k) on the parameters of
+// optimizer k-2; optimizer k-1 after actor(k-1)), hence bit-identical results; one launch boundary and one event
+// less per step on the actor chain.  A call with n_env == 0 flushes: it only issues the pending update.
+static int ag_graph(dra_dqn_learner* l, int n_env, int par, hipStream_t st) {
+  if (l->g_ag_ready[par] && l->g_ag_nenv[par] != n_env) {
+    (void)hipGraphExecDestroy(l->g_ag[par]);
+    l->g_ag_ready[par] = false;
+  }
+  if (!l->g_ag_ready[par]) {
+    hipGraph_t graph;
+    hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (b != hipSuccess) return (int)b;
+    int rc = run_actor_steps(l, n_env, l->pa[par], st);
+    if (rc == DRA_OK) {
+      l->gb = par;
+      rc = launch_gather(l, st, l->prm_dev->idx);
+      l->gb = 0;
+    }
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc != DRA_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    DRA_HIP(hipGraphInstantiate(&l->g_ag[par], graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    l->g_ag_ready[par] = true;
+    l->g_ag_nenv[par] = n_env;
+  }
+  DRA_HIP(hipGraphLaunch(l->g_ag[par], st));
+  return DRA_OK;
+}
+
+static int step_pipelined2(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, hipStream_t su,
+                           hipStream_t sa, int k) {
+  const int B = l->c.batch;
+  int rc;
+  bool seeded = false;
+  const int par = (int)(l->step_no & 1);
+  if (prm->n_env > 0) {
+    if (l->mb_used[par]) DRA_HIP(hipStreamWaitEvent(sa, l->ev_mb_free[par], 0));   // update k-2 is done with buffer par
+    memcpy(l->prm_stage[k].idx, prm->idx, (size_t)B * sizeof(int64_t));
+    DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes + (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, sa));
+    TRACE(0, sa);
+    if (l->pa_valid && l->pa_cur != par) l->pa_valid = false;
+    DRA_HIP(hipStreamWaitEvent(sa, l->ev_step_done, 0));   // optimizer k-2 produced the copy this graph reads
+    if (!l->pa_valid) {
+      l->pa_cur = par;
+      DRA_HIP(hipMemcpyAsync(l->pa[par], l->p, (size_t)l->c.n_params * sizeof(float), hipMemcpyDeviceToDevice, sa));
+      DRA_HIP(hipEventRecord(l->ev_join[0], sa));
+      l->pa_valid = true;
+      seeded = true;
+    }
+    if ((rc = ag_graph(l, prm->n_env, par, sa))) return rc;
+    DRA_HIP(hipEventRecord(l->ev_mb_ready[par], sa));
+    DRA_HIP(hipEventRecord(l->ev_actor_done, sa));
+    l->actor_pending = true;
+    TRACE(1, sa);
+    TRACE(2, sa);
+  }
+  DRA_HIP(hipEventRecord(l->stage_ev[k], sa));
+  if (do_update && l->ag_have_prev) {
+    const int q = l->ag_prev_par;
+    DRA_HIP(hipStreamWaitEvent(su, l->ev_mb_ready[q], 0));
+    if (seeded) DRA_HIP(hipStreamWaitEvent(su, l->ev_join[0], 0));
+    TRACE(3, su);
+    if ((rc = pipe_graph(l, su, q))) return rc;
+    TRACE(4, su);
+    if (l->tr_ev && l->tr_n < l->tr_cap) l->tr_n++;
+    DRA_HIP(hipEventRecord(l->ev_step_done, su));
+    DRA_HIP(hipEventRecord(l->ev_mb_free[q], su));
+    l->mb_used[q] = true;
+    if (l->pa_valid) l->pa_cur = q;     // the optimizer wrote copy q = the one the NEXT call's graph reads
+    l->ag_have_prev = false;
+  }
+  if (prm->n_env > 0) {
+    l->ag_have_prev = true;
+    l->ag_prev_par = par;
+    l->step_no++;
+  }
+  return DRA_OK;
+}
+
 // pinned staging slot k is free again once the copies issued from it have completed
 static int stage_acquire(dra_dqn_learner* l, int* k_out) {
   const int k = l->stage_k;
@@ -1308,7 +1401,10 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
     return DRA_OK;
   }
   // ---- async mode
-  if ((l->variant & DRA_VAR_PIPE_GATHER) && (l->variant & DRA_VAR_ACTOR_PARAMS)) return step_pipelined(l, prm, do_update, su, sa, k);
+  if ((l->variant & DRA_VAR_PIPE_GATHER) && (l->variant & DRA_VAR_ACTOR_PARAMS)) {
+    if ((l->variant & DRA_VAR_GATHER_IN_GRAPH) && !(l->variant & DRA_VAR_ACTOR_V3)) return step_pipelined2(l, prm, do_update, su, sa, k);
+    return step_pipelined(l, prm, do_update, su, sa, k);
+  }
   if (do_update) {
     if (l->actor_pending) DRA_HIP(hipStreamWaitEvent(su, l->ev_actor_done, 0));  // transitions of this step are in the ring
     const int64_t* pinned = (l->variant & DRA_VAR_PINNED_IDX) ? l->idx_stage + (size_t)k * 1024 : nullptr;

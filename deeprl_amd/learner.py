@@ -276,6 +276,9 @@ class DQNLearnerBench:
         self.epsilon = 0.01
         self.learner.synchronize()
         self._primed = False
+        v = self.learner.variant
+        need = ops.VAR_GATHER_IN_GRAPH | ops.VAR_PIPE_GATHER | ops.VAR_ACTOR_PARAMS
+        self._gather_in_graph = async_actor and (v & need) == need and not (v & ops.VAR_ACTOR_V3)
 
     def _queue_env_steps(self, n=4):
         """Host side of n env transitions: slots / frame counters and the epsilon-greedy randomness in
@@ -301,6 +304,11 @@ class DQNLearnerBench:
         elif not self.async_actor:
             self.pos, self.size = self._queue_env_steps(4)
             L.step(draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step), True, False)
+        elif self._gather_in_graph:
+            # one call = transitions of a step + the minibatch sampled after them (reference draw order: actor
+            # randomness, then the sample); the C side issues the update of the PREVIOUS call's minibatch
+            self.pos, self.size = self._queue_env_steps(4)
+            L.step(draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step), True, True)
         else:
             if not self._primed:  # the actor runs one agent step ahead
                 self._next = self._queue_env_steps(4)
@@ -324,6 +332,15 @@ class DQNLearnerBench:
         for _ in range(n):
             L.synchronize()
             t0 = time.perf_counter()
+            if self._gather_in_graph:
+                self.pos, self.size = self._queue_env_steps(4)
+                idx = draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step)
+                t1 = time.perf_counter()
+                L.step(idx, True, True)
+                t2 = time.perf_counter()
+                py += t1 - t0
+                call += t2 - t1
+                continue
             self.pos, self.size = self._next if self.async_actor and self._primed else (self.pos, self.size)
             idx = draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step)
             nxt = self._queue_env_steps(4)

@@ -384,7 +384,8 @@ def conv_bwd_x_koc(layer, dy, wt, xact=None, act="relu"):
 VAR_FUSED_BWD, VAR_ONESHOT_DGRAD, VAR_ONESHOT_FWD, VAR_ONESHOT_WGRAD = 1, 2, 4, 8
 VAR_PINNED_IDX, VAR_ACTOR_V2, VAR_ACTOR_PARAMS, VAR_PIPE_GATHER, VAR_CU_PARTITION, VAR_ACTOR_V3 = 16, 32, 64, 128, 256, 512
 VAR_ACTOR_FUSED_HEAD = 1024
-VAR_ALL = 2047
+VAR_GATHER_IN_GRAPH = 2048
+VAR_ALL = 4095
 
 
 def set_tuning(mask):

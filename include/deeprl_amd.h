@@ -150,6 +150,8 @@ int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* 
 #define DRA_VAR_ACTOR_V3 512     /* learner: the actor graph's first kernel reads its parameter block from a pinned ring
                                     (no copy command in front of the graph) */
 #define DRA_VAR_ACTOR_FUSED_HEAD 1024 /* with ACTOR_V3: fc4 + head + env step as one kernel (last-workgroup ticket) */
+#define DRA_VAR_GATHER_IN_GRAPH 2048 /* learner, async: a call carries transitions AND indices of the same step; actor
+                                    transitions + gather are one graph, the update issued is the previous step's */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */

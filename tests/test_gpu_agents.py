@@ -354,7 +354,7 @@ def test_fused_step_sync_equals_act_then_update(dra, variant):
 _ASYNC_RESULTS = {}
 
 
-@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047])
+@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559])
 def test_fused_step_async_pipeline(dra, variant):
     """async_actor=True pipeline (actor one agent step ahead on its own stream, double-buffered actor
     parameters when variant has DRA_VAR_ACTOR_PARAMS): the transitions it feeds are the documented counter-hash
@@ -369,7 +369,9 @@ def test_fused_step_async_pipeline(dra, variant):
         torch.manual_seed(5)
         np.random.seed(5)
         bench = DQNLearnerBench(ring_capacity=4000, batch=32, seed=3, actor=True, async_actor=True, variant=variant)
-        for _ in range(25):
+        # DRA_VAR_GATHER_IN_GRAPH (2048) issues the update of the previous call: 26 calls = 26 steps of transitions
+        # and 25 updates, what the primed pipelines reach after 25 calls
+        for _ in range(26 if variant & 2048 else 25):
             bench.step()
         bench.learner.synchronize()
         L = bench.learner
@@ -389,7 +391,7 @@ def test_fused_step_async_pipeline(dra, variant):
     # the parameters of optimizer t-1) -> bit-identical parameters and actions
     _ASYNC_RESULTS[variant] = outs[0]
     # ... and so do the 4-kernel actor step (DRA_VAR_ACTOR_V3: same arithmetic, fused launches) and the CU partition
-    for other in (255, 1023, 2047):
+    for other in (255, 1023, 2047, 2559):
         if 127 in _ASYNC_RESULTS and other in _ASYNC_RESULTS:
             assert np.array_equal(_ASYNC_RESULTS[127][0], _ASYNC_RESULTS[other][0])
             assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
