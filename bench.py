@@ -178,8 +178,22 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        n_dev = torch.cuda.device_count()
+        backend = "nccl"
+        if local_rank >= n_dev:
+            # more ranks than GPUs (only when exercising the launch contract on a 1-GPU box): share devices and use
+            # gloo for the barrier / max-reduce; the replicas themselves never communicate
+            local_rank, backend = local_rank % n_dev, "gloo"
+        if os.environ.get("DRA_BENCH_BACKEND"):
+            backend = os.environ["DRA_BENCH_BACKEND"]
+        import datetime
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        limit = datetime.timedelta(seconds=600)     # a rendezvous problem must fail, not hang the node
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
+        else:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # the container hostname may not resolve
+            dist.init_process_group(backend, timeout=limit)
     import deeprl_amd as d
     from deeprl_amd.learner import DQNLearnerBench
     d.select_device(local_rank)
@@ -202,15 +216,15 @@ def main():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    roof = bench.roofline(args.steps if args.steps < 500 else 500)
-    roof["traffic"] = pmc_traffic(roof["kernel"])
-    extra = bench.report()
-    if not args.no_actor:
-        extra["host_us_per_step"] = bench.host_profile(100)
     if rank == 0:
+        roof = bench.roofline(args.steps if args.steps < 500 else 500)
+        roof["traffic"] = pmc_traffic(roof["kernel"])
+        extra = bench.report()
+        if not args.no_actor:
+            extra["host_us_per_step"] = bench.host_profile(100)
         ups = world * args.steps / dt
         out = {
             "metric": "gradient-updates/sec", "value": ups, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
@@ -230,6 +244,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if distributed:
+        dist.barrier()          # rank 0 is still measuring the roofline / baselines: leave together
         dist.destroy_process_group()
 
 
