@@ -180,9 +180,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         n_dev = torch.cuda.device_count()
         backend = "nccl"
-        if local_rank >= n_dev:
-            # more ranks than GPUs (only when exercising the launch contract on a 1-GPU box): share devices and use
-            # gloo for the barrier / max-reduce; the replicas themselves never communicate
+        if world > n_dev:
+            # more ranks than GPUs (only when exercising the launch contract on a 1-GPU box): EVERY rank shares
+            # devices and uses gloo for the barrier / max-reduce; the replicas themselves never communicate
             local_rank, backend = local_rank % n_dev, "gloo"
         if os.environ.get("DRA_BENCH_BACKEND"):
             backend = os.environ["DRA_BENCH_BACKEND"]
