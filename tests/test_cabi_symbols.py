@@ -43,3 +43,43 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M) or "ref_shim" in src:
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_adam_hyper_matches_torch_bias_corrections():
+    """dra_adam_hyper (host arithmetic shared by the eager and the graph-replayable Adam step) reproduces
+    torch.optim.Adam's step_size = lr / (1 - b1^t) and 1 / sqrt(1 - b2^t) (examples.py:139,204 optimisers)."""
+    import math
+    from deeprl_amd._lib import lib
+    for lr, b1, b2 in ((0.00025, 0.9, 0.999), (5e-5, 0.9, 0.999), (3e-4, 0.5, 0.9)):
+        for step in (1, 2, 10, 1000, 123456):
+            out = (ctypes.c_float * 2)()
+            lib.dra_adam_hyper(lr, b1, b2, step, out)
+            f32 = lambda v: ctypes.c_float(v).value
+            bc1 = 1.0 - float(f32(b1)) ** step
+            bc2 = 1.0 - float(f32(b2)) ** step
+            assert out[0] == f32(float(f32(lr)) / bc1)
+            assert out[1] == f32(1.0 / math.sqrt(bc2))
+
+
+def test_vectorised_index_draw_consumes_the_reference_stream():
+    """learner.draw_uniform_indices == the scalar rejection loop of replay.py:92-110 (same indices, same
+    np.random state afterwards), including a write head in the middle of the ring and a ring that is not full."""
+    import numpy as np
+    from deeprl_amd.learner import draw_uniform_indices
+
+    def scalar(size, pos, batch, h, n):
+        out = []
+        while len(out) < batch:
+            i = int(np.random.randint(0, size))
+            if (i - h + 1 >= 0 and i + n < pos) or (i - h + 1 >= pos and i + n < size):
+                out.append(i)
+        return np.asarray(out, dtype=np.int64)
+
+    for size, pos, h, n in ((1000, 0, 4, 1), (1000, 517, 4, 3), (50, 50, 4, 1), (12, 7, 2, 2), (1_000_000, 123_456, 4, 1)):
+        np.random.seed(size + pos)
+        want = scalar(size, pos, 32, h, n)
+        tail_want = np.random.randint(0, 1 << 30, size=3)
+        np.random.seed(size + pos)
+        got = draw_uniform_indices(size, pos, 32, h, n)
+        tail_got = np.random.randint(0, 1 << 30, size=3)
+        assert np.array_equal(got, want) and np.array_equal(tail_got, tail_want)
