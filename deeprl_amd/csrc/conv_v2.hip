@@ -20,6 +20,7 @@
 // oracle only in the order of the four K-quarters.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -271,6 +272,182 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined forward for LARGE batches (the throughput regime: A2C / PPO minibatches, the
+// batch-1024 MFMA-rate measurement).  The one-shot kernel above pays, per 32*PT positions, a full exposed memory
+// latency plus staging and reduction around a short MFMA phase; at occupancy 3-6 that caps the fp32 MFMA pipe at
+// ~45 % (SQ counters, profiles/r01e_pmc_conv_fwd_b1024_before.json).  Here a workgroup loads its 32 output
+// channels' weights into registers ONCE and walks tile groups g = blockIdx.x, +gridDim.x, ...:
+//     global loads of group g+1 -> registers          (in flight during the MFMA phase)
+//     MFMA phase of group g from the LDS image
+//     barrier; accumulators -> LDS reduction area; registers of group g+1 -> LDS image; barrier
+//     4-way fold, bias, activation, store of group g  (overlaps the next group's loads)
+// Same per-position arithmetic and summation order as the one-shot kernel: bit-identical outputs.
+// Measured (batch 1024, fp32 MFMA fraction, one-shot multi-tile -> persistent): conv1 43.9 -> 43.3 %, conv2
+// 45.8 -> 45.0 %, conv3 43.8 -> 48.6 %.  A further variant that flattened (sample, position) into one M axis to
+// remove the per-sample tile padding (81 -> 96, 49 -> 64 positions) staged 2-3 whole samples per group at one
+// wave per SIMD and LOST (conv2 34 %, conv3 37 %): it was removed.  What remains between ~45 % and the pipe's
+// peak is the 16-23 % padding of conv2 / conv3 and the fp32 MFMA sharing its issue port with the staging VALU work.
+template <class G, class T, bool U8>
+struct V2Stage {
+  static constexpr int CPT = (G::C + 3) / 4;                       // channels per wave
+  static constexpr int LR = U8 ? 32 : (G::H > 16 ? 32 : 16);       // lanes per image row (u8: one u32 word per lane)
+  static constexpr int RP = 64 / LR;                               // rows per pass
+  static constexpr int LPT = (T::NR + RP - 1) / RP;
+  static constexpr int N = CPT * LPT;
+  static constexpr int COLS = U8 ? G::H / 4 : G::H;                // valid lanes per row
+  static_assert(COLS <= LR, "one image row per LR lanes");
+
+  template <class E>
+  __device__ static __forceinline__ void load(const ConvV2Args& a, int z, int bi, int ir0, int nrows, int wave, int lane,
+                                              E (&raw)[N]) {
+    const int rsub = lane / LR, col = min(lane % LR, COLS - 1);
+    const E* base = reinterpret_cast<const E*>(a.x[z]);
+    constexpr int ROW = U8 ? G::H / 4 : G::H;                      // elements of E per image row
+#pragma unroll
+    for (int ci = 0; ci < CPT; ++ci) {
+      const int c = min(wave + 4 * ci, G::C - 1);
+      const E* src = base + ((int64_t)(bi * G::C + c) * G::H + ir0) * ROW + col;
+#pragma unroll
+      for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = src[min(RP * q + rsub, nrows - 1) * ROW];
+    }
+  }
+
+  template <class E>
+  __device__ static __forceinline__ void store(E (&raw)[N], float* __restrict__ img, const float* __restrict__ lut, int nrows,
+                                               int wave, int lane) {
+    const int rsub = lane / LR, cl = lane % LR;
+#pragma unroll
+    for (int ci = 0; ci < CPT; ++ci) {
+      const int c = wave + 4 * ci;
+      if constexpr (U8) {
+        float* dst = img + c * T::CS + rsub * G::RW + cl;
+#pragma unroll
+        for (int q = 0; q < LPT; ++q) {
+          unsigned v = raw[ci * LPT + q];
+          asm volatile("" : "+v"(v));
+          if (cl < COLS && RP * q + rsub < nrows && c < G::C) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dst[RP * q * G::RW + b * G::WPH] = lut[(v >> (8 * b)) & 0xffu];
+          }
+        }
+      } else {
+        float* dst = img + c * T::CS + rsub * G::RW + lds_col<G>(min(cl, G::H - 1));
+#pragma unroll
+        for (int q = 0; q < LPT; ++q) {
+          float v = raw[ci * LPT + q];
+          asm volatile("" : "+v"(v));
+          if (cl < COLS && RP * q + rsub < nrows && c < G::C) dst[RP * q * G::RW] = v;
+        }
+      }
+    }
+  }
+};
+
+template <class G, bool U8, int PT>
+__global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Args a, const int n_groups) {
+  using T = V2Tile<G, PT>;
+  using ST = V2Stage<G, T, U8>;
+  using E = typename std::conditional<U8, unsigned, float>::type;
+  static_assert(!U8 || G::S == 4, "u8 staging: stride-4 layer");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float s_lut[256];
+  float* img = lds;                          // [C][NR][RW]
+  float* red = lds + G::C * T::CS;           // [PT][4 waves][16][64]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int z = blockIdx.z;
+  const int oc0 = blockIdx.y * 32;
+  const float* __restrict__ wt = a.wt[z];
+  const int cp0 = (G::CP >= 4) ? wave * G::CPW : (wave % G::CP);
+  const int t0 = (G::CP >= 4) ? 0 : (wave / G::CP) * G::TW;
+  float areg[G::NJ];
+  {
+    const float* wbase = wt + ((int64_t)(2 * cp0 + h) * G::KK + t0) * G::OC + oc0 + li;
+#pragma unroll
+    for (int j = 0; j < G::NJ; ++j) {
+      const int cpl = j / G::TW, t = j - cpl * G::TW;
+      areg[j] = wbase[(2 * cpl * G::KK + t) * G::OC];
+    }
+  }
+  float bias_r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = wave * 4 + q;
+    bias_r[q] = a.bias[z][oc0 + (r & 3) + 8 * (r >> 2) + 4 * h];
+  }
+  if (U8) s_lut[tid] = (float)((double)tid * a.coef);
+  float* __restrict__ y = a.y[z];
+
+  int g = blockIdx.x;
+  int bi = g / T::TPG, p0 = (g - bi * T::TPG) * PT * 32;
+  int np = min(32 * PT, G::P - p0);
+  int oh0 = p0 / G::OH;
+  int nrows = ((p0 + np - 1) / G::OH - oh0) * G::S + G::KH;
+  E raw[ST::N];
+  ST::load(a, z, bi, oh0 * G::S, nrows, wave, lane, raw);
+  __syncthreads();                                   // normalisation table visible
+  ST::store(raw, img, s_lut, nrows, wave, lane);
+  __syncthreads();
+  for (;;) {
+    // ---- next group's rows: requested now, consumed after the MFMA phase (always issued -- the last iteration
+    // re-reads its own group -- so that no branch sits between the loads and the MFMA loop)
+    const int gn = g + gridDim.x;
+    const bool more = gn < n_groups;
+    const int gl = more ? gn : g;
+    const int bi_n = gl / T::TPG, p0_n = (gl - bi_n * T::TPG) * PT * 32;
+    const int np_n = min(32 * PT, G::P - p0_n);
+    const int oh0_n = p0_n / G::OH;
+    const int nrows_n = ((p0_n + np_n - 1) / G::OH - oh0_n) * G::S + G::KH;
+    ST::load(a, z, bi_n, oh0_n * G::S, nrows_n, wave, lane, raw);
+    __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise sinks these loads to the end of the MFMA phase
+    // ---- MFMA phase of the current group
+    const float* bptr[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int pj = min(32 * t + li, np - 1);
+      const int poh = (p0 + pj) / G::OH, pow_ = (p0 + pj) - poh * G::OH;
+      bptr[t] = img + (2 * cp0 + h) * T::CS + ((poh - oh0) * G::S + t0 / G::KH) * G::RW + pow_;
+    }
+    f32x16 acc[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < G::NJ; ++j) {
+      const int cpl = j / G::TW, tp = j - cpl * G::TW;
+      const int kh = tp / G::KH, kw = tp - kh * G::KH;
+      const int off = 2 * cpl * T::CS + kh * G::RW + (kw % G::S) * G::WPH + kw / G::S;
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[j], bptr[t][off], acc[t], 0, 0, 0);
+    }
+    __syncthreads();   // image fully consumed
+#pragma unroll
+    for (int t = 0; t < PT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((t * 4 + wave) * 16 + r) * 64 + lane] = acc[t][r];
+    if (more) ST::store(raw, img, s_lut, nrows_n, wave, lane);
+    __syncthreads();
+    // ---- fold the four K-quarters, bias, activation, store (same order as the one-shot kernel)
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const float* rt = red + (t * 4 * 16) * 64;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = wave * 4 + q;
+        const float s = (rt[(0 * 16 + r) * 64 + lane] + rt[(1 * 16 + r) * 64 + lane]) +
+                        (rt[(2 * 16 + r) * 64 + lane] + rt[(3 * 16 + r) * 64 + lane]);
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = v2_act(s + bias_r[q], a.act);
+        if (32 * t + li < np) y[((int64_t)(bi * G::OC + oc0 + row)) * G::P + p0 + 32 * t + li] = v;
+      }
+    }
+    if (!more) break;
+    g = gn; bi = bi_n; p0 = p0_n; np = np_n; oh0 = oh0_n; nrows = nrows_n;
+  }
+}
+
 using VG1 = V2Geom<4, 84, 32, 8, 4>;
 using VG2 = V2Geom<32, 20, 64, 4, 2>;
 using VG3 = V2Geom<64, 9, 64, 3, 1>;
@@ -293,6 +470,41 @@ static int launch_conv_v2_pt(const ConvV2Args& a, int nz, hipStream_t st) {
   return DRA_OK;
 }
 
+template <class G, bool U8, int PT>
+static int launch_conv_v2_persist(const ConvV2Args& a, int nz, hipStream_t st) {
+  using T = V2Tile<G, PT>;
+  constexpr size_t bytes = ((size_t)G::C * T::CS + (size_t)PT * 4 * 16 * 64) * sizeof(float);
+  static_assert(bytes <= 159 * 1024, "LDS per workgroup (+1 KB normalisation table)");
+  static bool attr_set = false;
+  if (bytes > 64 * 1024 && !attr_set) {
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    attr_set = true;
+  }
+  const int n_groups = T::TPG * a.batch;
+  // exactly as many workgroups as the chip holds at this kernel's occupancy (registers / LDS: 1-3 per CU), each
+  // walking several groups, so that the weight loads and the pipeline prologue are amortised
+  static int resident = -1;
+  if (resident < 0) {
+    int per_cu = 0, dev = 0, n_cu = 0;
+    const char* e = getenv("DRA_CONV_PERSIST_WGS");
+    if (e) resident = atoi(e);
+    else {
+      DRA_HIP(hipGetDevice(&dev));
+      DRA_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+      DRA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT>),
+                                                           256, bytes));
+      resident = (per_cu > 0 ? per_cu : 1) * n_cu;
+    }
+  }
+  const int lanes = (G::OC / 32) * nz;
+  const int per = resident / lanes > 0 ? resident / lanes : 1;
+  const int nwg = n_groups < per ? n_groups : per;
+  hipLaunchKernelGGL((conv_fwd_v2_persist_kernel<G, U8, PT>), dim3(nwg, G::OC / 32, nz), dim3(256), bytes, st, a, n_groups);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 // Tile shape by problem size: one tile per workgroup (latency shape) until the launch has several workgroups
 // per CU slot anyway, then PTBIG tiles per workgroup (throughput shape).  DRA_CONV_PT=1 forces the latency shape.
 static int g_conv_pt_threshold = -1;
@@ -302,8 +514,14 @@ static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
     const char* e = getenv("DRA_CONV_PT_BATCH");   // batch from which the throughput shape is used (0 = never)
     g_conv_pt_threshold = e ? atoi(e) : 128;
   }
-  if (PTBIG > 1 && g_conv_pt_threshold > 0 && a.batch >= g_conv_pt_threshold && !a.ring_slot)
+  if (PTBIG > 1 && g_conv_pt_threshold > 0 && a.batch >= g_conv_pt_threshold && !a.ring_slot) {
+    if constexpr (U8 || G::H <= 32) {
+      static int persist = -1;
+      if (persist < 0) { const char* e = getenv("DRA_CONV_PERSIST"); persist = e ? atoi(e) : 1; }
+      if (persist) return launch_conv_v2_persist<G, U8, PTBIG>(a, nz, st);
+    }
     return launch_conv_v2_pt<G, U8, PTBIG>(a, nz, st);
+  }
   return launch_conv_v2_pt<G, U8, 1>(a, nz, st);
 }
 
