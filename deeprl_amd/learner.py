@@ -97,7 +97,12 @@ class DQNLearner:
         self.prio = w(ps[6].value, batch, torch.float32)
         self.actor_q = w(ps[7].value, n_actions, torch.float32)
         if self.variant & ops.VAR_CU_PARTITION:
-            self.stream, self.actor_stream = self._partitioned_streams()
+            try:
+                self.stream, self.actor_stream = self._partitioned_streams()
+            except DraError as e:           # e.g. a device mode without CU masking: plain streams, same results
+                import warnings
+                warnings.warn("CU-partitioned streams unavailable (%s); using plain streams" % (e,))
+                self.stream, self.actor_stream = torch.cuda.Stream(), torch.cuda.Stream()
         else:
             self.stream = torch.cuda.Stream()                        # graphs cannot capture on the NULL stream
             self.actor_stream = torch.cuda.Stream()
@@ -114,7 +119,7 @@ class DQNLearner:
         the same 8 CUs (2 per shader engine) in every XCD and the update chain the other 24."""
         import os
         n_cu = torch.cuda.get_device_properties(Config.DEVICE).multi_processor_count
-        n_act = max(8, min(n_cu - 8, int(os.environ.get("DRA_ACTOR_CUS", "64"))))
+        n_act = max(8, min(n_cu - 8, int(os.environ.get("DRA_ACTOR_CUS", str(n_cu // 4)))))   # 64 of 256
         key = (Config.DEVICE.index, n_act)
         if key in _PARTITIONED_STREAMS:
             return _PARTITIONED_STREAMS[key]
