@@ -58,6 +58,14 @@ struct ConvV2Args {
   // (*ring_slot - (C-1) + c) mod ring_cap of the slot-major frame array x[0]; null = plain NCHW input
   const int64_t* ring_slot;
   int64_t ring_cap;
+  // optional indirection for `ring_slot`: the slot lives in entry (*slot_seq mod slot_entries) of an array of
+  // parameter blocks slot_stride bytes apart (the learner's K-steps-ahead actor parameter ring)
+  const unsigned* slot_seq;
+  int slot_entries;
+  int64_t slot_stride;
+  // optional: the NEWEST channel of the ring stack comes from this frame instead of ring slot *ring_slot (an
+  // observation that has not been committed to the replay ring yet)
+  const uint8_t* newest_frame;
 };
 
 __device__ __forceinline__ float v2_act(float v, int act) {
@@ -131,7 +139,12 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x[z]);
     const int rsub = lane >> 5, wd = lane & 31;
     const int wdc = min(wd, WPR - 1);
-    const int64_t newest = a.ring_slot ? *a.ring_slot : 0;
+    int64_t newest = 0;
+    if (a.ring_slot) {
+      const char* sp = reinterpret_cast<const char*>(a.ring_slot);
+      if (a.slot_seq) sp += (int64_t)(*a.slot_seq % (unsigned)a.slot_entries) * a.slot_stride;
+      newest = *reinterpret_cast<const int64_t*>(sp);
+    }
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
       const int c = wave + 4 * ci;
@@ -141,6 +154,8 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
         if (img < 0) img += a.ring_cap;
       }
       const unsigned* src = reinterpret_cast<const unsigned*>(xb + (img * G::H + ir0) * G::H) + wdc;
+      if (a.ring_slot && a.newest_frame && c == G::C - 1)
+        src = reinterpret_cast<const unsigned*>(a.newest_frame + (int64_t)ir0 * G::H) + wdc;
 #pragma unroll
       for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = src[min(2 * q + rsub, nrows - 1) * WPR];
     }
@@ -535,6 +550,7 @@ DRA_API int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const floa
     a.x[z] = x[z]; a.wt[z] = wt[z]; a.bias[z] = bias[z]; a.y[z] = y[z];
   }
   a.batch = batch; a.act = act; a.coef = u8_coef; a.ring_slot = nullptr; a.ring_cap = 0;
+  a.slot_seq = nullptr; a.slot_entries = 0; a.slot_stride = 0; a.newest_frame = nullptr;
   hipStream_t st = dra_stream(stream);
   switch (layer) {
     case 1: return x_is_u8 ? launch_conv_v2<VG1, true, 2>(a, nz, st) : launch_conv_v2<VG1, false, 2>(a, nz, st);
@@ -553,6 +569,23 @@ DRA_API int dra_conv1_fwd_koc_ring(const void* frames, const int64_t* newest_slo
   ConvV2Args a;
   a.x[0] = frames; a.wt[0] = wt; a.bias[0] = bias; a.y[0] = y;
   a.batch = 1; a.act = act; a.coef = u8_coef; a.ring_slot = newest_slot_dev; a.ring_cap = capacity;
+  a.slot_seq = nullptr; a.slot_entries = 0; a.slot_stride = 0; a.newest_frame = nullptr;
+  return launch_conv_v2_pt<VG1, true, 1>(a, 1, dra_stream(stream));
+}
+
+// Same, with the slot read from entry (*seq_dev mod n_entries) of an array of parameter blocks: slot_field_dev points at
+// the slot field of entry 0, entries are stride_bytes apart (dra_dqn_learner's actor parameter ring).
+DRA_API int dra_conv1_fwd_koc_ring_seq(const void* frames, const int64_t* slot_field_dev, const unsigned* seq_dev,
+                                       int n_entries, int64_t stride_bytes, int64_t capacity, const void* newest_frame,
+                                       const float* wt, const float* bias, float* y, double u8_coef, int act,
+                                       void* stream) {
+  if (!frames || !slot_field_dev || !seq_dev || n_entries < 1 || stride_bytes < 8 || capacity < VG1::C || !wt || !bias || !y)
+    return DRA_EINVAL;
+  ConvV2Args a;
+  a.x[0] = frames; a.wt[0] = wt; a.bias[0] = bias; a.y[0] = y;
+  a.batch = 1; a.act = act; a.coef = u8_coef; a.ring_slot = slot_field_dev; a.ring_cap = capacity;
+  a.slot_seq = seq_dev; a.slot_entries = n_entries; a.slot_stride = stride_bytes;
+  a.newest_frame = reinterpret_cast<const uint8_t*>(newest_frame);
   return launch_conv_v2_pt<VG1, true, 1>(a, 1, dra_stream(stream));
 }
 

@@ -40,6 +40,7 @@ constexpr int kFc4Split = 8;     // split-K of the 3136 -> 512 layer (slabs redu
 constexpr int kMaxEnvSteps = 8;  // env transitions per agent step (sgd_update_frequency)
 constexpr size_t kPrmHeadBytes = offsetof(dra_dqn_step_params, idx);  // the part the actor kernels read
 constexpr int kAprmSlots = 16;
+constexpr int kAringSlots = 64;
 constexpr size_t kAprmStride = 512;
 static_assert(kPrmHeadBytes <= kAprmStride && kPrmHeadBytes % 4 == 0, "pinned parameter ring entry");
 
@@ -110,6 +111,21 @@ struct dra_dqn_learner {
   unsigned* aprm_seq_dev;           // actor launches executed so far (device)
   unsigned* fc4_ticket;             // last-workgroup ticket of the fused fc4 + head kernel
   uint64_t aprm_seq;                // actor launches issued so far (host)
+  // DRA_VAR_ACTOR_RING: parameter blocks of the next agent steps live in a DEVICE ring filled ahead of time
+  // (dra_dqn_learner_actor_ring_push); the actor kernels read entry (*aring_seq mod kAringSlots), the last kernel of
+  // an agent step produces the first frame of the NEXT step and advances the counter -- no per-step copy command
+  // and no separate frame kernel in front of the actor graph
+  uint8_t* aring_dev;               // kAringSlots x kAprmStride bytes
+  uint8_t* aring_stage;             // pinned mirror
+  unsigned* aring_seq;              // agent steps completed by the actor (device)
+  uint8_t* pend_frame;              // the observation the actor acts on next, not yet fed to the replay ring
+  double* pend_reward;              //   (DQN_agent.py:104-112 feeds a transition only after the env step)
+  int32_t* pend_mask;
+  uint64_t aring_pushed, aring_issued;
+  bool aring_primed;
+  hipGraphExec_t g_aring[2];
+  bool g_aring_ready[2];
+  int g_aring_nenv[2];
   hipEvent_t aprm_ev[16];
   bool aprm_used[16];
   hipStream_t side;                 // fork stream for graph branches
@@ -215,6 +231,16 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
     if (!rc) rc |= (int)hipMemset(l->fc4_ticket, 0, sizeof(unsigned));
     for (int k = 0; k < kAprmSlots; ++k) rc |= (int)hipEventCreateWithFlags(&l->aprm_ev[k], hipEventDisableTiming);
   }
+  if (l->variant & DRA_VAR_ACTOR_RING) {
+    rc |= (int)hipMalloc(&l->aring_dev, kAringSlots * kAprmStride);
+    rc |= (int)hipHostMalloc(&l->aring_stage, kAringSlots * kAprmStride, hipHostMallocDefault);
+    rc |= (int)hipMalloc(&l->aring_seq, sizeof(unsigned));
+    rc |= (int)hipMalloc(&l->pend_frame, 7056);
+    rc |= (int)hipMalloc(&l->pend_reward, sizeof(double));
+    rc |= (int)hipMalloc(&l->pend_mask, sizeof(int32_t));
+    if (!rc) rc |= (int)hipMemset(l->aring_seq, 0, sizeof(unsigned));
+    if (!rc) rc |= (int)hipMemset(l->aring_dev, 0, kAringSlots * kAprmStride);
+  }
   rc |= alloc_f(&l->fc4_slabs, (int64_t)3 * kFc4Split * B * 512);
   rc |= alloc_f(&l->afc4_slabs, (int64_t)kFc4Split * 512);
   l->lin_ws_floats = (int64_t)3 * 32 * B * 512;
@@ -266,6 +292,11 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   for (auto& ga : l->g_actor) if (ga.ready) (void)hipGraphExecDestroy(ga.exec);
   for (int k = 0; k < 2; ++k) if (l->pa[k]) (void)hipFree(l->pa[k]);
   if (l->ah4) (void)hipFree(l->ah4);
+  if (l->aring_dev) {
+    (void)hipFree(l->aring_dev); (void)hipHostFree(l->aring_stage); (void)hipFree(l->aring_seq);
+    (void)hipFree(l->pend_frame); (void)hipFree(l->pend_reward); (void)hipFree(l->pend_mask);
+  }
+  for (int g = 0; g < 2; ++g) if (l->g_aring_ready[g]) (void)hipGraphExecDestroy(l->g_aring[g]);
   if (l->aprm_ring) {
     (void)hipHostFree(l->aprm_ring); (void)hipFree(l->aprm_seq_dev); (void)hipFree(l->fc4_ticket);
     for (int k = 0; k < kAprmSlots; ++k) (void)hipEventDestroy(l->aprm_ev[k]);
@@ -1031,6 +1062,176 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
   return DRA_OK;
 }
 
+// ---- actor parameter ring (DRA_VAR_ACTOR_RING).  entry(seq) = ring + (seq mod kAringSlots) * kAprmStride holds the
+// head of a dra_dqn_step_params.  actor_head_env_ring_kernel = actor_head_env_kernel reading its block through the
+// device step counter; for the LAST env step of an agent step it also performs what the next agent step would
+// start with -- the first observation of the next block (env.step's return value, envs.py:140-141) -- and then
+// advances the counter.  env_frame_ring_kernel primes the very first block.
+__device__ __forceinline__ const dra_dqn_step_params* aring_entry(const uint8_t* ring, unsigned seq) {
+  return reinterpret_cast<const dra_dqn_step_params*>(ring + (size_t)(seq % kAringSlots) * kAprmStride);
+}
+
+// synthetic observation `e` of block `prm` into a PENDING buffer (frame, reward, mask of the transition it starts)
+__device__ __forceinline__ void synth_pending(const dra_dqn_step_params* __restrict__ prm, int e, uint8_t* __restrict__ frame,
+                                              double* __restrict__ reward, int32_t* __restrict__ mask, uint64_t seed,
+                                              int done_period) {
+  const int64_t counter = prm->counter[e];
+  if (counter < 0) return;
+  uint64_t* dst = reinterpret_cast<uint64_t*>(frame);
+  const uint64_t base = seed * 0x9E3779B97F4A7C15ull + (uint64_t)counter * 882ull;
+  for (int w = threadIdx.x; w < 882; w += blockDim.x) dst[w] = mix64(base + (uint64_t)w);
+  if (threadIdx.x == 0) {
+    const uint64_t hh = mix64((seed + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
+    const uint32_t u = (uint32_t)(hh >> 32) % 10u;
+    *reward = (u == 0) ? -1.0 : ((u == 9) ? 1.0 : 0.0);
+    const uint64_t h2 = mix64((seed + 2) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
+    *mask = ((h2 % (uint64_t)done_period) == 0) ? 0 : 1;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+env_frame_ring_kernel(const uint8_t* __restrict__ ring, const unsigned* __restrict__ seq, uint8_t* __restrict__ pend_frame,
+                      double* __restrict__ pend_reward, int32_t* __restrict__ pend_mask, uint64_t seed, int done_period) {
+  synth_pending(aring_entry(ring, *seq), 0, pend_frame, pend_reward, pend_mask, seed, done_period);
+}
+
+__global__ void __launch_bounds__(256)
+actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restrict__ seq, int e, int last,
+                           const float* __restrict__ h4, const float* __restrict__ wh, const float* __restrict__ bh, int A,
+                           uint8_t* __restrict__ ring_actions, float* __restrict__ q_out, uint8_t* __restrict__ frames,
+                           double* __restrict__ rewards, int32_t* __restrict__ masks, uint8_t* __restrict__ pend_frame,
+                           double* __restrict__ pend_reward, int32_t* __restrict__ pend_mask, uint64_t seed,
+                           int done_period) {
+  __shared__ float s_q[64];
+  const unsigned sq = *seq;
+  const dra_dqn_step_params* __restrict__ prm = aring_entry(ring, sq);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (e == 0 && prm->counter[0] >= 0) {
+    // feed: the observation this step started from becomes ring slot[0] now (not when it was produced: a
+    // minibatch gathered in between must still see the slot's previous contents)
+    const int64_t slot = prm->slot[0];
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(pend_frame);
+    uint64_t* dst = reinterpret_cast<uint64_t*>(frames + slot * 7056);
+    for (int w = threadIdx.x; w < 882; w += blockDim.x) dst[w] = src[w];
+    if (threadIdx.x == 0) { rewards[slot] = *pend_reward; masks[slot] = *pend_mask; }
+  }
+  for (int a = wave; a < A; a += 4) {
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part += h4[lane + 64 * i] * wh[a * 512 + lane + 64 * i];
+    part = wave_sum(part);
+    if (lane == 0) s_q[a] = part + bh[a];
+  }
+  __syncthreads();   // (also: every thread is done reading the pending frame)
+  if (threadIdx.x < A && q_out) q_out[threadIdx.x] = s_q[threadIdx.x];
+  if (threadIdx.x == 0) {
+    int best = 0;
+    float bv = s_q[0];
+    for (int a = 1; a < A; ++a) if (s_q[a] > bv) { bv = s_q[a]; best = a; }  // np.argmax: first max
+    const int64_t act = (prm->dice[e] < prm->epsilon[e]) ? (int64_t)prm->random_action[e] : (int64_t)best;
+    if (prm->store_action[e]) *reinterpret_cast<int64_t*>(ring_actions + prm->slot[e] * 8) = act;
+  }
+  if (!last) {
+    synth_transition(prm, e + 1, frames, rewards, masks, seed, done_period);
+  } else {
+    synth_pending(aring_entry(ring, sq + 1), 0, pend_frame, pend_reward, pend_mask, seed, done_period);
+    if (threadIdx.x == 0) *seq = sq + 1;   // every thread read *seq before the barrier above
+  }
+}
+
+static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
+  const dra_dqn_config& c = l->c;
+  void *frames, *actions, *rewards, *masks;
+  int rc = dra_ring_pointers(l->ring, &frames, &actions, &rewards, &masks);
+  if (rc) return rc;
+  const int64_t* o = c.offset;
+  void* s = (void*)st;
+  for (int e = 0; e < n_env; ++e) {
+    const int64_t* slot_field = reinterpret_cast<const int64_t*>(l->aring_dev + offsetof(dra_dqn_step_params, slot)) + e;
+    if ((rc = dra_conv1_fwd_koc_ring_seq(frames, slot_field, l->aring_seq, kAringSlots, (int64_t)kAprmStride, c.ring_capacity,
+                                         e == 0 ? l->pend_frame : nullptr, P + o[P_W1], P + o[P_B1], l->ay1, c.u8_coef,
+                                         DRA_ACT_RELU, s)))
+      return rc;
+    const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
+    float* y2[1] = {l->ay2};
+    if ((rc = dra_conv_fwd_koc(2, 1, x2, w2, b2, y2, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+    const void* x3[1] = {l->ay2}; const float* w3[1] = {P + o[P_W3]}; const float* b3[1] = {P + o[P_B3]};
+    float* y3[1] = {l->ay3};
+    if ((rc = dra_conv_fwd_koc(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+    hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
+                       l->ah4, 3136);
+    hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(256), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq, e,
+                       (int)(e == n_env - 1), (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions,
+                       l->aq, (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
+                       (uint64_t)c.env_seed, (int)c.env_done_period);
+    DRA_LAUNCH_CHECK();
+  }
+  return DRA_OK;
+}
+
+// Uploads `n` parameter blocks (agent steps pushed, pushed+1, ...) into the device ring on `stream` (the actor
+// stream: in order with the actor graphs).  At most kAringSlots / 2 blocks may be pending (pushed - issued).
+DRA_API int dra_dqn_learner_actor_ring_push(dra_dqn_learner* l, const dra_dqn_step_params* blocks, int n, void* stream) {
+  if (!l || !blocks || n < 1 || !l->aring_dev) return DRA_EINVAL;
+  if ((int64_t)(l->aring_pushed - l->aring_issued) + n > kAringSlots / 2) return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  for (int i = 0; i < n; ++i) {
+    if (blocks[i].n_env < 1 || blocks[i].n_env > kMaxEnvSteps) return DRA_EINVAL;
+    for (int e = 0; e < blocks[i].n_env; ++e)
+      if (blocks[i].counter[e] < 0) return DRA_EINVAL;   // the ring actor owns the (device-resident) environment
+    const size_t k = (size_t)((l->aring_pushed + i) % kAringSlots);
+    memcpy(l->aring_stage + k * kAprmStride, &blocks[i], kPrmHeadBytes);
+  }
+  const size_t k0 = (size_t)(l->aring_pushed % kAringSlots);
+  const size_t first = (k0 + n <= kAringSlots) ? (size_t)n : kAringSlots - k0;
+  DRA_HIP(hipMemcpyAsync(l->aring_dev + k0 * kAprmStride, l->aring_stage + k0 * kAprmStride, first * kAprmStride,
+                         hipMemcpyHostToDevice, st));
+  if (first < (size_t)n)
+    DRA_HIP(hipMemcpyAsync(l->aring_dev, l->aring_stage, ((size_t)n - first) * kAprmStride, hipMemcpyHostToDevice, st));
+  l->aring_pushed += n;
+  return DRA_OK;
+}
+
+// one agent step of actor transitions from the ring on `st` (graph per parameter-copy parity, or eager for P = online)
+static int issue_actor_ring(dra_dqn_learner* l, int n_env, const float* P, int par, hipStream_t st, bool use_graph) {
+  if (!l->aring_dev || l->aring_issued >= l->aring_pushed) return DRA_EINVAL;   // no block pushed for this step
+  if (!l->aring_primed) {     // very first step: its first observation has no previous step to come from
+    void *frames, *actions, *rewards, *masks;
+    int rc0 = dra_ring_pointers(l->ring, &frames, &actions, &rewards, &masks);
+    if (rc0) return rc0;
+    hipLaunchKernelGGL(env_frame_ring_kernel, dim3(1), dim3(256), 0, st, (const uint8_t*)l->aring_dev,
+                       (const unsigned*)l->aring_seq, l->pend_frame, l->pend_reward, l->pend_mask,
+                       (uint64_t)l->c.env_seed, (int)l->c.env_done_period);
+    DRA_LAUNCH_CHECK();
+    l->aring_primed = true;
+  }
+  int rc;
+  if (!use_graph) {
+    rc = run_actor_steps_ring(l, n_env, P, st);
+  } else {
+    if (l->g_aring_ready[par] && l->g_aring_nenv[par] != n_env) {
+      (void)hipGraphExecDestroy(l->g_aring[par]);
+      l->g_aring_ready[par] = false;
+    }
+    if (!l->g_aring_ready[par]) {
+      hipGraph_t graph;
+      DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      rc = run_actor_steps_ring(l, n_env, P, st);
+      hipError_t e = hipStreamEndCapture(st, &graph);
+      if (rc != DRA_OK) return rc;
+      if (e != hipSuccess) return (int)e;
+      DRA_HIP(hipGraphInstantiate(&l->g_aring[par], graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      l->g_aring_ready[par] = true;
+      l->g_aring_nenv[par] = n_env;
+    }
+    DRA_HIP(hipGraphLaunch(l->g_aring[par], st));
+    rc = DRA_OK;
+  }
+  if (rc == DRA_OK) l->aring_issued++;
+  return rc;
+}
+
 static int run_actor_steps_v2(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
   const dra_dqn_config& c = l->c;
   void *frames, *actions, *rewards, *masks;
@@ -1194,7 +1395,9 @@ static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, in
       l->pa_valid = true;
       seeded = true;
     }
-    if ((rc = issue_actor(l, prm, k, l->pa[l->pa_cur], sa, true))) return rc;
+    if (l->variant & DRA_VAR_ACTOR_RING) rc = issue_actor_ring(l, prm->n_env, l->pa[l->pa_cur], l->pa_cur, sa, true);
+    else rc = issue_actor(l, prm, k, l->pa[l->pa_cur], sa, true);
+    if (rc) return rc;
     DRA_HIP(hipEventRecord(l->ev_actor_done, sa));
     l->actor_pending = true;
     TRACE(2, sa);
@@ -1336,7 +1539,8 @@ DRA_API int dra_dqn_learner_act(dra_dqn_learner* l, const dra_dqn_step_params* p
   int rc = stage_acquire(l, &k);
   if (rc) return rc;
   memcpy(&l->prm_stage[k], prm, kPrmHeadBytes);
-  rc = issue_actor(l, prm, k, l->p, st, use_graph != 0);
+  if (l->variant & DRA_VAR_ACTOR_RING) rc = issue_actor_ring(l, prm->n_env, l->p, 0, st, false);
+  else rc = issue_actor(l, prm, k, l->p, st, use_graph != 0);
   DRA_HIP(hipEventRecord(l->stage_ev[k], st));
   return rc;
 }

@@ -284,6 +284,15 @@ class DQNLearnerBench:
         v = self.learner.variant
         need = ops.VAR_GATHER_IN_GRAPH | ops.VAR_PIPE_GATHER | ops.VAR_ACTOR_PARAMS
         self._gather_in_graph = async_actor and (v & need) == need and not (v & ops.VAR_ACTOR_V3)
+        need = ops.VAR_ACTOR_RING | ops.VAR_PIPE_GATHER | ops.VAR_ACTOR_PARAMS
+        self._actor_ring = (async_actor and (v & need) == need and not self._gather_in_graph and not (v & ops.VAR_ACTOR_V3))
+        # async_actor=True is a separate PROCESS in the reference (BaseAgent.py:108-182) with its own np.random
+        # state: the actor's epsilon-greedy randomness comes from its own stream here too (the in-order mode keeps
+        # the single global stream, draw for draw)
+        self.actor_rs = np.random.RandomState(seed + 977) if async_actor else None
+        self._ring_pushed = self._ring_issued = 0
+        self._fed_steps = 0
+        self._pos0, self._size0 = self.pos, self.size
 
     def _queue_env_steps(self, n=4):
         """Host side of n env transitions: slots / frame counters and the epsilon-greedy randomness in
@@ -293,8 +302,9 @@ class DQNLearnerBench:
         for _ in range(n):
             slots.append(pos)
             counters.append(self.counter)
-            ras.append(int(np.random.randint(self.n_actions, size=1)[0]))
-            dices.append(float(np.random.rand(1)[0]))
+            rs = self.actor_rs if self.actor_rs is not None else np.random
+            ras.append(int(rs.randint(self.n_actions, size=1)[0]))
+            dices.append(float(rs.rand(1)[0]))
             self.counter += 1
             size = min(size + 1, self.capacity)
             pos = (pos + 1) % self.capacity
@@ -309,6 +319,25 @@ class DQNLearnerBench:
         elif not self.async_actor:
             self.pos, self.size = self._queue_env_steps(4)
             L.step(draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step), True, False)
+        elif self._actor_ring:
+            # parameter blocks are generated and uploaded ahead of time (16 agent steps per upload); a call carries
+            # only the minibatch indices
+            if not self._primed:
+                self._push_blocks()
+                L.params.n_env = 4
+                L.act(use_graph=False, stream=L.actor_stream)      # transitions of step 0
+                self._ring_issued += 1
+                L.actor_stream.synchronize()
+                self._primed = True
+            self._fed_steps += 1                                   # transitions of this step are in the ring
+            n = 4 * self._fed_steps
+            pos, size = (self._pos0 + n) % self.capacity, min(self._size0 + n, self.capacity)
+            idx = draw_uniform_indices(size, pos, self.batch, self.history, self.n_step)
+            if self._ring_pushed - self._ring_issued < 8:
+                self._push_blocks()
+            L.params.n_env = 4
+            L.step(idx, True, True)                                # gather(t), actor(t+1) from the ring, update(t)
+            self._ring_issued += 1
         elif self._gather_in_graph:
             # one call = transitions of a step + the minibatch sampled after them (reference draw order: actor
             # randomness, then the sample); the C side issues the update of the PREVIOUS call's minibatch
@@ -328,6 +357,17 @@ class DQNLearnerBench:
         if self.updates % 10000 == 0:
             L.sync_target()
 
+    def _push_blocks(self, n=16):
+        """Generates the parameter blocks of the next n agent steps (slots / counters / actor randomness) and
+        uploads them into the learner's device ring on the actor stream."""
+        L = self.learner
+        blocks = (StepParams * n)()
+        for i in range(n):
+            self.pos, self.size = self._queue_env_steps(4)
+            ctypes.memmove(ctypes.byref(blocks[i]), ctypes.byref(L.params), StepParams.idx.offset)
+        lib.dra_dqn_learner_actor_ring_push(L.h, blocks, n, L._sp(L.actor_stream))
+        self._ring_pushed += n
+
     def host_profile(self, n=200):
         """Host-side cost of one agent step with the GPU idle (synchronise before every call): python
         bookkeeping + RNG vs the C call that enqueues the step.  Microseconds."""
@@ -337,6 +377,12 @@ class DQNLearnerBench:
         for _ in range(n):
             L.synchronize()
             t0 = time.perf_counter()
+            if self._actor_ring:
+                t0 = time.perf_counter()
+                self.step()
+                t2 = time.perf_counter()
+                call += t2 - t0
+                continue
             if self._gather_in_graph:
                 self.pos, self.size = self._queue_env_steps(4)
                 idx = draw_uniform_indices(self.size, self.pos, self.batch, self.history, self.n_step)

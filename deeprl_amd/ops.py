@@ -385,7 +385,8 @@ VAR_FUSED_BWD, VAR_ONESHOT_DGRAD, VAR_ONESHOT_FWD, VAR_ONESHOT_WGRAD = 1, 2, 4, 
 VAR_PINNED_IDX, VAR_ACTOR_V2, VAR_ACTOR_PARAMS, VAR_PIPE_GATHER, VAR_CU_PARTITION, VAR_ACTOR_V3 = 16, 32, 64, 128, 256, 512
 VAR_ACTOR_FUSED_HEAD = 1024
 VAR_GATHER_IN_GRAPH = 2048
-VAR_ALL = 4095
+VAR_ACTOR_RING = 4096
+VAR_ALL = 8191
 
 
 def set_tuning(mask):

@@ -121,6 +121,11 @@ int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const float* const
 /* conv1 of a batch-1 forward whose 4-frame uint8 stack is read straight from the ring (newest slot on device) */
 int dra_conv1_fwd_koc_ring(const void* frames, const int64_t* newest_slot_dev, int64_t capacity, const float* wt,
                            const float* bias, float* y, double u8_coef, int act, void* stream);
+/* same, the slot taken from entry (*seq_dev mod n_entries) of an array of parameter blocks stride_bytes apart;
+ * newest_frame (optional, device uint8[84*84]): the newest channel comes from this not-yet-committed observation */
+int dra_conv1_fwd_koc_ring_seq(const void* frames, const int64_t* slot_field_dev, const unsigned* seq_dev, int n_entries,
+                               int64_t stride_bytes, int64_t capacity, const void* newest_frame, const float* wt,
+                               const float* bias, float* y, double u8_coef, int act, void* stream);
 int dra_conv_bwd_w_koc(int layer, const float* dy, const void* x, float* dw, float* db, int64_t slab_stride, int ksplit,
                        int batch, int x_is_u8, double u8_coef, void* stream);
 int dra_conv_bwd_x_koc(int layer, const float* dy, const float* wt, const float* xact, float* dx, int batch, int act,
@@ -152,6 +157,9 @@ int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* 
 #define DRA_VAR_ACTOR_FUSED_HEAD 1024 /* with ACTOR_V3: fc4 + head + env step as one kernel (last-workgroup ticket) */
 #define DRA_VAR_GATHER_IN_GRAPH 2048 /* learner, async: a call carries transitions AND indices of the same step; actor
                                     transitions + gather are one graph, the update issued is the previous step's */
+#define DRA_VAR_ACTOR_RING 4096  /* learner, async pipelined: the actor's parameter blocks are pushed K steps ahead into a
+                                    device ring (dra_dqn_learner_actor_ring_push); no per-step copy command, the last actor
+                                    kernel of a step produces the next step's first frame */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
@@ -246,6 +254,10 @@ int dra_dqn_learner_act(dra_dqn_learner* learner, const dra_dqn_step_params* prm
  * observation, q_host = float[n_actions] out.  Pinned staging both ways, batch-1 forward of the online parameters
  * as one captured graph; synchronises `stream` (like the reference's to_np(q)). */
 int dra_dqn_learner_q_host(dra_dqn_learner* learner, const uint8_t* state_host, float* q_host, void* stream);
+/* DRA_VAR_ACTOR_RING: upload the parameter blocks of the next `n` agent steps (consumed in order, one per actor launch;
+ * at most 32 may be pending).  With the ring, dra_dqn_learner_step / _act take the transitions from it and use only
+ * n_env and idx of the block passed to them. */
+int dra_dqn_learner_actor_ring_push(dra_dqn_learner* learner, const dra_dqn_step_params* blocks, int n, void* stream);
 /* DQNAgent.step: prm->n_env actor transitions + one update on prm->idx.  stream_actor == NULL: in-order on
  * stream_update (async_actor=False semantics).  stream_actor != NULL: this call's transitions belong to the NEXT
  * step and overlap this step's update (async_actor=True; config.lock becomes HIP events). */

@@ -354,7 +354,7 @@ def test_fused_step_sync_equals_act_then_update(dra, variant):
 _ASYNC_RESULTS = {}
 
 
-@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559])
+@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559, 4607])
 def test_fused_step_async_pipeline(dra, variant):
     """async_actor=True pipeline (actor one agent step ahead on its own stream, double-buffered actor
     parameters when variant has DRA_VAR_ACTOR_PARAMS): the transitions it feeds are the documented counter-hash
@@ -391,7 +391,7 @@ def test_fused_step_async_pipeline(dra, variant):
     # the parameters of optimizer t-1) -> bit-identical parameters and actions
     _ASYNC_RESULTS[variant] = outs[0]
     # ... and so do the 4-kernel actor step (DRA_VAR_ACTOR_V3: same arithmetic, fused launches) and the CU partition
-    for other in (255, 1023, 2047, 2559):
+    for other in (255, 1023, 2047, 2559, 4607):
         if 127 in _ASYNC_RESULTS and other in _ASYNC_RESULTS:
             assert np.array_equal(_ASYNC_RESULTS[127][0], _ASYNC_RESULTS[other][0])
             assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
