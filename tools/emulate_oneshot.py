@@ -225,11 +225,89 @@ def emu_lin_fwd_slabs(I, KS, x, w, B, O):
     return slabs
 
 
+def emu_conv_fwd(G, PT, x, wt, U8=False):
+    """conv_fwd_v2_kernel / conv_fwd_v2_persist_kernel (conv_v2.hip): tile groups of PT 32-position tiles, the
+    division-free staging map (LR lanes per image row, 64/LR rows per pass, stride-phase de-interleaved LDS
+    columns), the 4-wave K split and the per-MFMA operand addresses `bptr + off`.  x [B][C][H][H], wt [K][OC]."""
+    B = x.shape[0]
+    S, KH, OH, P, KK, C, H, OC = G.S, G.KH, G.OH, G.P, G.KK, G.C, G.H, G.OC
+    TPS = (P + 31) // 32
+    WPH = (H + S - 1) // S
+    RW = S * WPH
+    CP = C // 2
+    CPW = CP // 4 if CP >= 4 else 1
+    TSPLIT = 1 if CP >= 4 else 4 // CP
+    TW = KK // TSPLIT
+    NJ = CPW * TW
+    TPG = (TPS + PT - 1) // PT
+    OROWS = (32 * PT - 1 + OH - 1) // OH + 1
+    NR = min((OROWS - 1) * S + KH, H)
+    CS = NR * RW
+    LR = 32 if (U8 or H > 16) else 16
+    RP = 64 // LR
+    LPT = (NR + RP - 1) // RP
+    CPT = (C + 3) // 4
+    COLS = H // 4 if U8 else H
+    lds_col = lambda iw: (iw % S) * WPH + iw // S
+    y = np.zeros((B, OC, P))
+    for bi in range(B):
+        for grp in range(TPG):
+            p0 = grp * PT * 32
+            npos = min(32 * PT, P - p0)
+            if npos <= 0:
+                continue
+            oh0, oh1 = p0 // OH, (p0 + npos - 1) // OH
+            ir0, nrows = oh0 * S, (oh1 - oh0) * S + KH
+            assert nrows <= NR
+            lds = np.full(C * CS, np.nan)
+            for wave in range(4):
+                for ci in range(CPT):
+                    c = wave + 4 * ci
+                    for lane in range(64):
+                        rsub, cl = lane // LR, lane % LR
+                        for q in range(LPT):
+                            r = RP * q + rsub
+                            if cl < COLS and r < nrows and c < C:
+                                if U8:   # one u32 word = 4 pixels: pixel b of word cl is stride phase b, index cl
+                                    for b in range(4):
+                                        lds[c * CS + r * RW + cl + b * WPH] = x[bi, c, ir0 + r, 4 * cl + b]
+                                else:
+                                    lds[c * CS + r * RW + lds_col(cl)] = x[bi, c, ir0 + r, cl]
+            for oc0 in range(0, OC, 32):
+                acc = np.zeros((PT, 32, 32))
+                for wave in range(4):
+                    cp0 = wave * CPW if CP >= 4 else wave % CP
+                    t0 = 0 if CP >= 4 else (wave // CP) * TW
+                    for j in range(NJ):
+                        cpl, tp = j // TW, j % TW
+                        kh, kw = tp // KH, tp % KH
+                        off = 2 * cpl * CS + kh * RW + (kw % S) * WPH + kw // S
+                        a = np.stack([wt[((2 * cp0 + h) * KK + t0) + (2 * cpl * KK + tp), oc0:oc0 + 32] for h in range(2)])
+                        for t in range(PT):
+                            b = np.empty((2, 32))
+                            for h in range(2):
+                                for li in range(32):
+                                    pj = min(32 * t + li, npos - 1)
+                                    poh, pw = (p0 + pj) // OH, (p0 + pj) % OH
+                                    bptr = (2 * cp0 + h) * CS + ((poh - oh0) * S + t0 // KH) * RW + pw
+                                    b[h, li] = lds[bptr + off]
+                            mfma_acc(acc[t], a, b)
+                for t in range(PT):
+                    for li in range(32):
+                        if 32 * t + li < npos:
+                            y[bi, oc0:oc0 + 32, p0 + 32 * t + li] = acc[t][:, li]
+    return y.reshape(B, OC, OH, OH)
+
+
 def check(name, got, want, tol=1e-9):
     assert not np.isnan(got).any(), name + ": unwritten outputs"
     err = np.abs(got - want).max() / max(1e-30, np.abs(want).max())
     print("%-28s max rel err %.2e %s" % (name, err, "ok" if err < tol else "FAIL"))
+    FAILED.extend([name] if not err < tol else [])
     assert err < tol, name
+
+
+FAILED = []
 
 
 def main():
@@ -260,6 +338,15 @@ def main():
     B, I, O, KS = 3, 64, 40, 2
     xl, wl = rs.randn(B, I), rs.randn(O, I)
     check("linear fwd slabs one-pass", emu_lin_fwd_slabs(I, KS, xl, wl, B, O).sum(0), xl @ wl.T)
+    for name, G, pts, u8 in (("conv1", G1, (1, 2), True), ("conv2", G2, (1, 3), False), ("conv3", G3, (1, 2), False)):
+        x = rs.randint(0, 256, size=(2, G.C, G.H, G.H)).astype(np.float64) if u8 else rs.randn(2, G.C, G.H, G.H)
+        w = rs.randn(G.OC, G.C, G.KH, G.KH)
+        want = F.conv2d(torch.tensor(x), torch.tensor(w), stride=G.S).numpy()
+        wt = np.transpose(w, (1, 2, 3, 0)).reshape(G.K, G.OC)
+        for pt in pts:
+            check("%s fwd PT=%d staging+operands" % (name, pt), emu_conv_fwd(G, pt, x, wt, U8=u8), want)
+    if FAILED:
+        raise AssertionError("index maps disagree with autograd: %s" % FAILED)
     print("all index maps agree with autograd")
 
 
