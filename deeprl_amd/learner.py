@@ -115,11 +115,12 @@ class DQNLearner:
     def _partitioned_streams(self):
         """Update stream / actor stream on disjoint CU sets (DRA_VAR_CU_PARTITION).  On MI355X mask bit i is CU
         (i // 32) of shader engine (i // 8) % 4 of XCD i % 8 (tools/probe_cu_mask.py), and a workgroup's XCD is
-        fixed by the dispatcher (round robin), so the first DRA_ACTOR_CUS (default 64) bits give the actor chain
-        the same 8 CUs (2 per shader engine) in every XCD and the update chain the other 24."""
+        fixed by the dispatcher (round robin), so the first DRA_ACTOR_CUS (default 3/8 of the device = 96) bits give
+        the actor chain the same 12 CUs (3 per shader engine) in every XCD and the update chain the other 20
+        (scan with the parameter ring: 64 -> 6372, 80 -> 6614, 96 -> 6705, 112 -> 5671 updates/s on one box)."""
         import os
         n_cu = torch.cuda.get_device_properties(Config.DEVICE).multi_processor_count
-        n_act = max(8, min(n_cu - 8, int(os.environ.get("DRA_ACTOR_CUS", str(n_cu // 4)))))   # 64 of 256
+        n_act = max(8, min(n_cu - 8, int(os.environ.get("DRA_ACTOR_CUS", str(3 * n_cu // 8)))))   # 96 of 256
         key = (Config.DEVICE.index, n_act)
         if key in _PARTITIONED_STREAMS:
             return _PARTITIONED_STREAMS[key]
