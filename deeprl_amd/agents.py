@@ -391,7 +391,7 @@ class DQNAgent(BaseAgent):
         self._learner = DQNLearner(self.network, self.target_network, rp._ring, cfg.batch_size, cfg.action_dim,
                                    cfg.discount ** cfg.n_step, cfg.gradient_clip or 0.0, g['lr'], g['alpha'], g['eps'],
                                    centered=bool(g['centered']), double_q=bool(cfg.double_q),
-                                   u8_coef=cfg.state_normalizer.coef)
+                                   u8_coef=cfg.state_normalizer.coef, cu_partition=False)
         self._fused = None              # its flat buffer no longer backs the parameters
         self._target_flat = None
         learner = self._learner

@@ -57,8 +57,10 @@ def _ordered_params(net):
 class DQNLearner:
     def __init__(self, network, target_network, ring, batch, n_actions, gamma_n, gradient_clip, lr, alpha, eps,
                  centered=True, double_q=False, u8_coef=1.0 / 255, replay_eps=0.01, replay_alpha=0.5, ksplit=16,
-                 env_seed=0, env_done_period=800, variant=-1):
-        """`variant`: DRA_VAR_* kernel-selection mask (ops.VAR_*); -1 = the process default (ops.set_tuning)."""
+                 env_seed=0, env_done_period=800, variant=-1, cu_partition=True):
+        """`variant`: DRA_VAR_* kernel-selection mask (ops.VAR_*); -1 = the process default (ops.set_tuning).
+        `cu_partition=False` drops DRA_VAR_CU_PARTITION from it: a caller that never runs the device actor
+        concurrently (in-order mode, host environments) wants every CU for the update chain."""
         self.network, self.target_network, self.ring = network, target_network, ring
         po, pt = _ordered_params(network), _ordered_params(target_network)
         self.flat = FlatParams(po, koc=(po[0], po[2], po[4]))        # conv segment first, conv weights in KOC
@@ -66,6 +68,9 @@ class DQNLearner:
         self.state1 = torch.zeros_like(self.flat.flat)
         self.state2 = torch.zeros_like(self.flat.flat)
         self.variant = int(variant) if int(variant) >= 0 else ops.get_tuning()
+        if not cu_partition:
+            self.variant &= ~ops.VAR_CU_PARTITION
+        variant = self.variant
         cfg = DqnConfig()
         cfg.batch, cfg.n_actions, cfg.double_q, cfg.ksplit, cfg.centered = batch, n_actions, int(double_q), ksplit, int(centered)
         cfg.gamma_n, cfg.gradient_clip, cfg.lr, cfg.alpha, cfg.eps = gamma_n, gradient_clip or 0.0, lr, alpha, eps
@@ -270,7 +275,8 @@ class DQNLearnerBench:
         self.target_network = VanillaNet(n_actions, NatureConvBody())
         self.target_network.load_state_dict(self.network.state_dict())
         self.learner = DQNLearner(self.network, self.target_network, self.ring, batch, n_actions, 0.99, 5.0, 0.00025, 0.95,
-                                  0.01, centered=True, env_seed=seed, env_done_period=800, variant=variant)
+                                  0.01, centered=True, env_seed=seed, env_done_period=800, variant=variant,
+                                  cu_partition=bool(actor and async_actor))
         # resident replay before the timed region: fill the whole ring (exploration phase done)
         prefill = ring_capacity if prefill is None else prefill
         with torch.cuda.stream(self.learner.stream):
