@@ -222,6 +222,9 @@ def main():
     if rank == 0:
         roof = bench.roofline(args.steps if args.steps < 500 else 500)
         roof["traffic"] = pmc_traffic(roof["kernel"])
+        # the update chain owns a CU partition while the device actor runs beside it (lever 5):
+        # the kernel is timed on that stream, i.e. on this many of the device's CUs
+        roof["stream_cus"] = bench.learner.update_cus or torch.cuda.get_device_properties(0).multi_processor_count
         extra = bench.report()
         if not args.no_actor:
             extra["host_us_per_step"] = bench.host_profile(100)

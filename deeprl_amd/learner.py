@@ -101,6 +101,7 @@ class DQNLearner:
         self.delta = w(ps[5].value, batch, torch.float32)
         self.prio = w(ps[6].value, batch, torch.float32)
         self.actor_q = w(ps[7].value, n_actions, torch.float32)
+        self.update_cus = self.actor_cus = None      # CUs of the two chains' streams (None: the whole device)
         if self.variant & ops.VAR_CU_PARTITION:
             try:
                 self.stream, self.actor_stream = self._partitioned_streams()
@@ -127,6 +128,7 @@ class DQNLearner:
         n_cu = torch.cuda.get_device_properties(Config.DEVICE).multi_processor_count
         n_act = max(8, min(n_cu - 8, int(os.environ.get("DRA_ACTOR_CUS", str(3 * n_cu // 8)))))   # 96 of 256
         key = (Config.DEVICE.index, n_act)
+        self.update_cus, self.actor_cus = n_cu - n_act, n_act
         if key in _PARTITIONED_STREAMS:
             return _PARTITIONED_STREAMS[key]
         actor_bits = set(range(n_act))
