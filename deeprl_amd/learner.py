@@ -109,6 +109,7 @@ class DQNLearner:
                 import warnings
                 warnings.warn("CU-partitioned streams unavailable (%s); using plain streams" % (e,))
                 self.stream, self.actor_stream = torch.cuda.Stream(), torch.cuda.Stream()
+                self.update_cus = self.actor_cus = None
         else:
             self.stream = torch.cuda.Stream()                        # graphs cannot capture on the NULL stream
             self.actor_stream = torch.cuda.Stream()
