@@ -283,3 +283,29 @@ def test_running_mean_std_two_pass():
     # prior pseudo-count 1e-4 of (mean 0, var 1) is below 1e-5 relative here
     np.testing.assert_allclose(rms.mean[0], allx.mean(0), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(rms.var[0], allx.var(0), rtol=1e-4, atol=1e-5)
+
+
+def test_product_normalizers_equal_oracle():
+    """Host-side normalisers of the product (deeprl_amd/normalizers.py, numpy fp64 like the reference's
+    normalizer.py:28-71) against the oracle restatement on a random observation stream: MeanStdNormalizer
+    (running statistics, clipping, read-only mode, state_dict round trip), RescaleNormalizer / ImageNormalizer on
+    numpy input, SignNormalizer."""
+    from deeprl_amd.normalizers import ImageNormalizer, MeanStdNormalizer, RescaleNormalizer, SignNormalizer
+    rs = np.random.RandomState(7)
+    prod, orc = MeanStdNormalizer(), NUM.MeanStdNormalizerOracle()
+    for t in range(50):
+        x = rs.standard_normal((16, 17)) * (1 + t % 5) + 0.3 * t
+        assert np.array_equal(prod(x), orc(x))
+    prod.set_read_only()
+    orc.read_only = True
+    x = rs.standard_normal((16, 17)) * 100
+    assert np.array_equal(prod(x), orc(x)) and np.abs(prod(x)).max() <= 10.0
+    clone = MeanStdNormalizer(read_only=True)
+    clone(x)                                    # creates its statistics object, read-only: no update
+    clone.load_state_dict(prod.state_dict())
+    assert np.array_equal(clone(x), prod(x))
+    img = rs.randint(0, 256, size=(2, 4, 84, 84)).astype(np.uint8)
+    assert np.array_equal(np.asarray(ImageNormalizer()(img), dtype=np.float32), NUM.image_normalize_sync(img))
+    assert np.array_equal(RescaleNormalizer(0.5)(img), 0.5 * img)
+    r = rs.standard_normal(9)
+    assert np.array_equal(SignNormalizer()(r), np.sign(r))
