@@ -32,6 +32,7 @@ using WG1u = ConvWgradOne<G1, 4, 4, 88, 0, true>;
 using WG1f = ConvWgradOne<G1, 4, 4, 88, 0, false>;
 using WG2 = ConvWgradOne<G2, 9, 4, 24, 4, false>;
 using WG3 = ConvWgradOne<G3, 7, 3, 10, 1, false>;
+using WG3b = ConvWgradOne<G3, 7, 6, 10, 1, false>;   // 6 k-tiles per workgroup: 96 instead of 192 workgroups
 
 DRA_API int dra_conv_wgrad_slabs(int layer, int batch, int ksplit, int variant, int* n_slabs) {
   if (!n_slabs || batch < 1 || ksplit < 1) return DRA_EINVAL;
@@ -39,7 +40,7 @@ DRA_API int dra_conv_wgrad_slabs(int layer, int batch, int ksplit, int variant, 
   switch (layer) {
     case 1: *n_slabs = WG1u::n_slabs(batch); return DRA_OK;
     case 2: *n_slabs = WG2::n_slabs(batch); return DRA_OK;
-    case 3: *n_slabs = WG3::n_slabs(batch); return DRA_OK;
+    case 3: *n_slabs = WG3::n_slabs(batch); return DRA_OK;   // (WG3b: same slab count, slabs are per (sample, chunk))
   }
   return DRA_EINVAL;
 }
@@ -54,9 +55,14 @@ static W make_wgrad_one(const float* dy, const void* x, float* dw, float* db, in
 // tiles per workgroup of the one-pass input gradient: conv2 (4 stride phases x 4 tiles per sample) pairs tiles
 // (DRA_DGRAD_PT=1 in the environment keeps one tile per workgroup: A/B switch)
 template <class G> struct DgradTiles { static constexpr int PT = (G::S == 2) ? 2 : 1; };
-static int dgrad_pt_enabled() {
+static int dgrad_pt_choice() {   // tiles per conv2 input-gradient workgroup: 1, 2 or 4 (all four tiles of a phase)
   static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_DGRAD_PT"); v = (e && atoi(e) == 1) ? 0 : 1; }
+  if (v < 0) { const char* e = getenv("DRA_DGRAD_PT"); v = e ? atoi(e) : 2; if (v != 1 && v != 2 && v != 4) v = 2; }
+  return v;
+}
+static int wg3_wide() {            // conv3 weight gradient: 6 k-tiles per workgroup (DRA_WG3_MTG=6) instead of 3
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_WG3_MTG"); v = (e && atoi(e) == 6) ? 1 : 0; }
   return v;
 }
 
@@ -98,9 +104,13 @@ static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, con
   NoRole none;
   if (od && ow) {
     auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
-    if (DgradTiles<G>::PT > 1 && !dgrad_pt_enabled()) {
+    if (DgradTiles<G>::PT > 1 && dgrad_pt_choice() == 1) {
       auto rd1 = make_dgrad_one<G, 1>(dy, wt, xact, dx, batch, act);
       return launch_multi(rd1, rd1.blocks(), rw, rw.blocks(), none, 0, st);
+    }
+    if (DgradTiles<G>::PT > 1 && dgrad_pt_choice() == 4) {
+      auto rd4 = make_dgrad_one<G, 4>(dy, wt, xact, dx, batch, act);
+      return launch_multi(rd4, rd4.blocks(), rw, rw.blocks(), none, 0, st);
     }
     auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
     return launch_multi(rd, rd.blocks(), rw, rw.blocks(), none, 0, st);
@@ -142,7 +152,9 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
       }
       return dra_conv_bwd_w_koc(1, dy, x, dw, db, slab_stride, ksplit, batch, x_is_u8, u8_coef, stream);
     case 2: return conv_bwd_fused_t<G2, WG2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
-    case 3: return conv_bwd_fused_t<G3, WG3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+    case 3:
+      if (wg3_wide()) return conv_bwd_fused_t<G3, WG3b>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+      return conv_bwd_fused_t<G3, WG3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
   }
   return DRA_EINVAL;
 }
