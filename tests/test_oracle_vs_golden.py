@@ -1,6 +1,7 @@
 """Pins the CPU oracle (oracle/) against fixtures generated from the reference's
 own code (tests/golden/make_golden.py).  Integer / byte / index / fp64 work is
 compared bit-exactly; fp32 losses and gradients at 1e-5 (north_star tolerance)."""
+import os
 import random
 
 import numpy as np
@@ -309,3 +310,29 @@ def test_product_normalizers_equal_oracle():
     assert np.array_equal(RescaleNormalizer(0.5)(img), 0.5 * img)
     r = rs.standard_normal(9)
     assert np.array_equal(SignNormalizer()(r), np.sign(r))
+
+
+@pytest.mark.skipif(not os.path.isdir(os.environ.get("DEEPRL_REFERENCE_ROOT", "/root/reference")),
+                    reason="the reference tree is only present in the authoring container")
+def test_committed_fixtures_are_the_reference_outputs(tmp_path):
+    """Pins tests/golden/*.npz to the reference LIVE: re-runs tests/golden/make_golden.py (which drives the
+    untouched /root/reference code through tests/ref_shim.py) into a scratch directory and compares every array
+    with the committed fixture bit for bit.  Skipped on the GPU box, where /root/reference does not exist."""
+    import glob
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, GOLDEN_OUT=str(tmp_path))
+    subprocess.check_call([sys.executable, os.path.join(here, "golden", "make_golden.py")], env=env,
+                          stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
+    committed = sorted(glob.glob(os.path.join(here, "golden", "*.npz")))
+    assert len(committed) >= 12
+    for f in committed:
+        a = np.load(f, allow_pickle=True)
+        b = np.load(os.path.join(str(tmp_path), os.path.basename(f)), allow_pickle=True)
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            if a[k].dtype == object:
+                assert str(a[k]) == str(b[k]), (f, k)
+            else:
+                assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (f, k)
