@@ -336,3 +336,54 @@ def test_committed_fixtures_are_the_reference_outputs(tmp_path):
                 assert str(a[k]) == str(b[k]), (f, k)
             else:
                 assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (f, k)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.environ.get("DEEPRL_REFERENCE_ROOT", "/root/reference")),
+                    reason="the reference tree is only present in the authoring container")
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_replay_oracle_equals_live_reference_on_random_streams(seed):
+    """Beyond the fixed fixtures: random feed / sample / update_priorities interleavings (random capacity,
+    history, n-step, discount; wrap-around; terminals) through the reference's own UniformReplay /
+    PrioritizedReplay (tests/ref_shim.py) and through the oracle -- identical samples, index streams, sampling
+    probabilities, tree contents and RNG positions."""
+    import ref_shim
+    ref = ref_shim.load()
+    rs = np.random.RandomState(100 + seed)
+    cap = int(rs.randint(40, 200))
+    h, n = int(rs.randint(1, 5)), int(rs.randint(1, 4))
+    gamma = float(rs.choice([1.0, 0.99, 0.5]))
+    b = 8
+    for cls_ref, cls_orc, per in ((ref.UniformReplay, UniformReplayOracle, False), (ref.PrioritizedReplay, PrioritizedReplayOracle, True)):
+        r = cls_ref(memory_size=cap, batch_size=b, n_step=n, discount=gamma, history_length=h)
+        o = cls_orc(cap, b, n, gamma, h)
+        np.random.seed(seed)
+        random.seed(seed)
+        st_np, st_py = np.random.get_state(), random.getstate()
+        fed = 0
+        for step in range(3 * cap):
+            frame = rs.randint(0, 256, size=(3, 3)).astype(np.uint8)
+            act, rew, msk = int(rs.randint(0, 4)), float(rs.randint(-1, 2)), int(rs.rand() > 0.2)
+            r.feed(dict(state=[frame], action=[act], reward=[rew], mask=[msk]))
+            o.feed_one(frame, np.int64(act), rew, msk)
+            fed += 1
+            if fed > h + n + 4 and step % 7 == 0:
+                # same RNG state into both samplers
+                np.random.set_state(st_np); random.setstate(st_py)
+                got = r.sample()
+                a_np, a_py = np.random.get_state(), random.getstate()
+                np.random.set_state(st_np); random.setstate(st_py)
+                want = o.sample()
+                b_np, b_py = np.random.get_state(), random.getstate()
+                assert a_py == b_py and all(np.array_equal(x, y) for x, y in zip(a_np[1:3], b_np[1:3]))
+                st_np, st_py = a_np, a_py
+                assert np.array_equal(np.asarray(got.state), want[0]) and np.array_equal(np.asarray(got.next_state), want[3])
+                assert np.array_equal(np.asarray(got.action).reshape(-1), np.asarray(want[1]).reshape(-1))
+                assert np.array_equal(np.asarray(got.reward, dtype=np.float64), want[2])
+                assert np.array_equal(np.asarray(got.mask), want[4])
+                if per:
+                    assert np.array_equal(np.asarray(got.sampling_prob), want[5]) and np.array_equal(np.asarray(got.idx), want[6])
+                    prio = (rs.rand(b).astype(np.float32) * 2 + 0.1)
+                    info = list(zip(np.asarray(got.idx).tolist(), prio.tolist()))
+                    r.update_priorities(info)
+                    o.update_priorities(info)
+                    assert np.array_equal(r.tree.tree, o.tree.tree) and r.max_priority == o.max_priority
