@@ -24,8 +24,9 @@ from .envs import LazyFrames, Task
 from .nets import (BaseNet, CategoricalActorCriticNet, CategoricalNet, DDPGConvBody, DeterministicActorCriticNet,
                    DuelingNet, DummyBody, FCBody, GaussianActorCriticNet, NatureConvBody, NoisyLinear, OptionCriticNet,
                    QuantileNet, RainbowNet, TD3Net, VanillaNet, layer_init)
-from .agents import (A2CAgent, BaseActor, BaseAgent, CategoricalDQNActor, CategoricalDQNAgent, DQNActor, DQNAgent,
-                     NStepDQNAgent, PPOAgent, QuantileRegressionDQNActor, QuantileRegressionDQNAgent)
+from .agents import (A2CAgent, BaseActor, BaseAgent, CategoricalDQNActor, CategoricalDQNAgent, DDPGAgent, DQNActor,
+                     DQNAgent, NStepDQNAgent, OptionCriticAgent, PPOAgent, QuantileRegressionDQNActor,
+                     QuantileRegressionDQNAgent, TD3Agent)
 from .random_process import GaussianProcess, OrnsteinUhlenbeckProcess, RandomProcess
 
 

@@ -858,3 +858,21 @@ class PPOAgent(BaseAgent):
                     prediction['v'].backward(g_v)
                     self._fused_critic.step(None)
         self.last_loss = out3
+
+
+# ==================================================================================================== out of scope
+def _out_of_scope(name, where):
+    class _Stub(BaseAgent):
+        __doc__ = "%s (%s): outside the rollout -> replay -> update hot path this package implements." % (name, where)
+
+        def __init__(self, config=None):
+            raise NotImplementedError("%s (%s) is outside the hot path deeprl_amd implements (DESIGN.md section 7); "
+                                      "use the reference's agent with deeprl_amd's replay / networks" % (name, where))
+    _Stub.__name__ = _Stub.__qualname__ = name
+    return _Stub
+
+
+# names examples.py refers to (examples.py:404-617); constructing one fails loudly instead of a NameError at call time
+OptionCriticAgent = _out_of_scope("OptionCriticAgent", "deep_rl/agent/OptionCritic_agent.py")
+DDPGAgent = _out_of_scope("DDPGAgent", "deep_rl/agent/DDPG_agent.py")
+TD3Agent = _out_of_scope("TD3Agent", "deep_rl/agent/TD3_agent.py")
