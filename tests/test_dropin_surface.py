@@ -31,8 +31,19 @@ def _global_names(fn):
 
 @pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "examples.py")), reason="reference tree not present")
 def test_reference_examples_resolve_against_the_package():
+    import sys
     import deeprl_amd
-    deeprl_amd.install_as_deep_rl()
+    saved = {k: v for k, v in sys.modules.items() if k == "deep_rl" or k.startswith("deep_rl.")}
+    try:
+        deeprl_amd.install_as_deep_rl()
+        _check_examples(deeprl_amd)
+    finally:                                   # other tests import the REAL reference under the same name
+        for k in [k for k in sys.modules if k == "deep_rl" or k.startswith("deep_rl.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def _check_examples(deeprl_amd):
     src = re.sub(r"\basync\b", "async_", open(os.path.join(REF, "examples.py")).read())
     mod = types.ModuleType("ref_examples_dropin")
     exec(compile(src, "examples.py", "exec"), mod.__dict__)     # star-imports deep_rl == deeprl_amd; defines the entry points
