@@ -795,6 +795,7 @@ class PPOAgent(BaseAgent):
         if config.shared_repr:
             self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda step: 1 - step / config.max_steps)
         self.grad_hook = None
+        self._graphed = _GraphedPPO(self)
 
     def step(self):
         config = self.config
@@ -828,36 +829,199 @@ class PPOAgent(BaseAgent):
             self.lr_scheduler.step(self.total_steps)
         self.optimize(entries)
 
+    def _minibatch(self, entry, prepared=False):
+        """One minibatch update (PPO_agent.py:77-99) on already-gathered rows.  `prepared`: the optimisers are in
+        graph mode and the caller has advanced their step scalars (FusedOptimizer.prepare_step)."""
+        config = self.config
+        prediction = self.network(entry.state, entry.action)
+        out3, (g_lp, g_ent, g_v) = ops.ppo_loss(
+            prediction['log_pi_a'].detach(), prediction['entropy'].detach(), prediction['v'].detach(),
+            entry.log_pi_a, entry.advantage, entry.ret, config.ppo_ratio_clip, config.entropy_weight)
+        if config.shared_repr:
+            self._fused.zero_grad()
+            torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']],
+                                    [g_lp, g_ent, g_v])
+            if self.grad_hook is not None:
+                self.grad_hook(self._fused.flat.grad)
+            self._fused.step(config.gradient_clip)
+        else:
+            approx_kl = out3[2].item()
+            if approx_kl <= 1.5 * config.target_kl:
+                self._fused_actor.zero_grad()
+                torch.autograd.backward([prediction['log_pi_a'], prediction['entropy']], [g_lp, g_ent])
+                self._fused_actor.step(None)
+            self._fused_critic.zero_grad()
+            prediction['v'].backward(g_v)
+            self._fused_critic.step(None)
+        return out3
+
     def optimize(self, entries):
         """PPO_agent.py:71-99: epochs of shuffled minibatches over the (detached) rollout entries."""
         config = self.config
+        if self._graphed.usable() and self._graphed.optimize(entries):
+            return
         entry_cls = entries.__class__
         for _ in range(config.optimization_epochs):
             sampler = random_sample(np.arange(entries.state.size(0)), config.mini_batch_size)
             for batch_indices in sampler:
                 batch_indices = tensor(batch_indices).long()
                 entry = entry_cls(*[x[batch_indices] for x in entries])
-                prediction = self.network(entry.state, entry.action)
-                out3, (g_lp, g_ent, g_v) = ops.ppo_loss(
-                    prediction['log_pi_a'].detach(), prediction['entropy'].detach(), prediction['v'].detach(),
-                    entry.log_pi_a, entry.advantage, entry.ret, config.ppo_ratio_clip, config.entropy_weight)
-                if config.shared_repr:
-                    self._fused.zero_grad()
-                    torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']],
-                                            [g_lp, g_ent, g_v])
-                    if self.grad_hook is not None:
-                        self.grad_hook(self._fused.flat.grad)
-                    self._fused.step(config.gradient_clip)
-                else:
-                    approx_kl = out3[2].item()
-                    if approx_kl <= 1.5 * config.target_kl:
-                        self._fused_actor.zero_grad()
-                        torch.autograd.backward([prediction['log_pi_a'], prediction['entropy']], [g_lp, g_ent])
-                        self._fused_actor.step(None)
-                    self._fused_critic.zero_grad()
-                    prediction['v'].backward(g_v)
-                    self._fused_critic.step(None)
+                out3 = self._minibatch(entry)
         self.last_loss = out3
+
+
+class _GraphedPPO:
+    """PPO's optimisation phase (PPO_agent.py:71-99: epochs x minibatches, each a forward, the clip loss, a
+    backward and one or two Adam steps -- 320 tiny updates per rollout at ppo_continuous's sizes) with every
+    full-size minibatch replayed from captured hipGraphs: the rollout's rows live in static buffers, a static
+    index tensor selects the minibatch inside the graph, Adam's step-dependent scalars (and a scheduled lr) reach
+    the kernels through device memory (FusedOptimizer.prepare_step).  shared_repr: one graph (forward, loss,
+    backward, clip, step).  Separate actor / critic optimisers: the KL gate of PPO_agent.py:88-93 needs the
+    forward's result on the host first, so a forward+loss graph runs, the host decides, and one of two update
+    graphs (actor+critic, critic only) -- each recomputing the same forward -- runs.  Same kernels and arguments
+    as the eager path: bit-identical parameters.  First rollout and odd-sized remainder minibatches run eagerly."""
+    WARMUP = 1
+
+    def __init__(self, agent):
+        self.agent = agent
+        self.rollouts = 0
+        self.static = None
+        self.idx = None
+        self.graphs = None
+        self.out3 = None
+        self.failed = False
+        self._up = None
+
+    def usable(self):
+        a = self.agent
+        cfg = a.config
+        if self.failed or getattr(cfg, 'graph_update', True) is False or a.grad_hook is not None:
+            return False
+        if Config.DEVICE.type != 'cuda':
+            return False
+        opts = [a._fused] if cfg.shared_repr else [a._fused_actor, a._fused_critic]
+        return all(o.kind == 'adam' for o in opts)      # scheduled / stepped scalars travel through device memory
+
+    def _capture(self, entry_cls):
+        a = self.agent
+        cfg = a.config
+        rows = lambda: entry_cls(*[x[self.idx] for x in self.static])
+        opts = [a._fused] if cfg.shared_repr else [a._fused_actor, a._fused_critic]
+        for o in opts:
+            o.enable_graph_mode()
+        validate = torch.distributions.Distribution._validate_args
+        torch.distributions.Distribution.set_default_validate_args(False)   # argument checks synchronise with the host
+        try:
+            torch.cuda.synchronize()
+            if cfg.shared_repr:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.out3 = a._minibatch(rows(), prepared=True)
+                self.graphs = dict(all=g)
+            else:
+                net = a.network
+                g_fwd, g_both, g_critic = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+
+                def forward_loss():
+                    e = rows()
+                    p = net(e.state, e.action)
+                    out3, grads = ops.ppo_loss(p['log_pi_a'].detach(), p['entropy'].detach(), p['v'].detach(), e.log_pi_a,
+                                               e.advantage, e.ret, cfg.ppo_ratio_clip, cfg.entropy_weight)
+                    return p, out3, grads
+
+                with torch.cuda.graph(g_fwd):
+                    with torch.no_grad():
+                        _, self.out3, _ = forward_loss()
+                with torch.cuda.graph(g_both):
+                    p, _, (g_lp, g_ent, g_v) = forward_loss()
+                    a._fused_actor.zero_grad()
+                    torch.autograd.backward([p['log_pi_a'], p['entropy']], [g_lp, g_ent])
+                    a._fused_actor.step(None)
+                    a._fused_critic.zero_grad()
+                    p['v'].backward(g_v)
+                    a._fused_critic.step(None)
+                with torch.cuda.graph(g_critic):
+                    p, _, (g_lp, g_ent, g_v) = forward_loss()
+                    a._fused_critic.zero_grad()
+                    p['v'].backward(g_v)
+                    a._fused_critic.step(None)
+                self.graphs = dict(fwd=g_fwd, both=g_both, critic=g_critic)
+        finally:
+            torch.distributions.Distribution.set_default_validate_args(validate)
+
+    def optimize(self, entries):
+        a = self.agent
+        cfg = a.config
+        self.rollouts += 1
+        if self.rollouts <= self.WARMUP:
+            return False
+        entry_cls = entries.__class__
+        mb = cfg.mini_batch_size
+        n = entries.state.size(0)
+        try:
+            if self.static is None or any(s.shape != x.shape for s, x in zip(self.static, entries)):
+                self.static = entry_cls(*[x.clone() for x in entries])
+                self.idx = torch.zeros(mb, dtype=torch.int64, device=entries.state.device)
+                self.graphs = None
+                from .replay import _PinnedUploader
+                self._up = _PinnedUploader(torch.int64, mb, entries.state.device)
+            else:
+                for st, x in zip(self.static, entries):
+                    st.copy_(x)
+            if self.graphs is None:
+                self._capture(entry_cls)
+        except Exception as e:
+            import warnings
+            warnings.warn("PPO minibatch update could not be captured as a graph (%r); using the eager path" % (e,))
+            self.failed = True
+            for o in ([a._fused] if cfg.shared_repr else [a._fused_actor, a._fused_critic]):
+                o.graph_mode = False
+            return False
+        opts = [a._fused] if cfg.shared_repr else None
+        for _ in range(cfg.optimization_epochs):
+            for batch_indices in random_sample(np.arange(n), mb):
+                if len(batch_indices) != mb:          # remainder minibatch: eager, optimisers stay in graph mode
+                    bi = tensor(batch_indices).long()
+                    if cfg.shared_repr:
+                        a._fused.prepare_step()
+                        out3 = a._minibatch(entry_cls(*[x[bi] for x in self.static]), prepared=True)
+                    else:
+                        out3 = self._eager_split(entry_cls(*[x[bi] for x in self.static]))
+                    continue
+                self.idx.copy_(self._up.upload(np.asarray(batch_indices, dtype=np.int64)), non_blocking=True)
+                if cfg.shared_repr:
+                    a._fused.prepare_step()
+                    self.graphs['all'].replay()
+                else:
+                    self.graphs['fwd'].replay()
+                    if self.out3[2].item() <= 1.5 * cfg.target_kl:
+                        a._fused_actor.prepare_step()
+                        a._fused_critic.prepare_step()
+                        self.graphs['both'].replay()
+                    else:
+                        a._fused_critic.prepare_step()
+                        self.graphs['critic'].replay()
+                out3 = self.out3
+        a.last_loss = out3
+        return True
+
+    def _eager_split(self, entry):
+        """remainder minibatch with separate optimisers in graph mode: same arithmetic as PPOAgent._minibatch."""
+        a = self.agent
+        cfg = a.config
+        p = a.network(entry.state, entry.action)
+        out3, (g_lp, g_ent, g_v) = ops.ppo_loss(p['log_pi_a'].detach(), p['entropy'].detach(), p['v'].detach(), entry.log_pi_a,
+                                                entry.advantage, entry.ret, cfg.ppo_ratio_clip, cfg.entropy_weight)
+        if out3[2].item() <= 1.5 * cfg.target_kl:
+            a._fused_actor.prepare_step()
+            a._fused_actor.zero_grad()
+            torch.autograd.backward([p['log_pi_a'], p['entropy']], [g_lp, g_ent])
+            a._fused_actor.step(None)
+        a._fused_critic.prepare_step()
+        a._fused_critic.zero_grad()
+        p['v'].backward(g_v)
+        a._fused_critic.step(None)
+        return out3
 
 
 # ==================================================================================================== out of scope

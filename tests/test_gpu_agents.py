@@ -534,3 +534,54 @@ def test_graphed_generic_update_is_bit_identical(dra, monkeypatch, kind):
     assert np.array_equal(outs[0][2], outs[1][2])
     for k in outs[0][1]:
         assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
+@pytest.mark.parametrize("kind", ["continuous", "continuous_remainder", "pixel"])
+def test_graphed_ppo_optimisation_is_bit_identical(dra, monkeypatch, kind):
+    """PPO's minibatch loop replayed from captured hipGraphs (config.graph_update, default on) against the eager
+    loop: 3 rollouts (the first is eager in both runs) end in bit-identical parameters.  `continuous`: separate
+    actor / critic Adam optimisers with the KL gate (examples.py:497-523 shapes); `continuous_remainder`: a
+    minibatch size that leaves a remainder batch; `pixel`: shared representation, clipped gradient, lr schedule
+    (examples.py:525-550 shapes, 2 workers)."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    outs = []
+    for graph in (True, False):
+        c = d.Config()
+        pixel = kind == "pixel"
+        c.merge(dict(game="BreakoutNoFrameskip-v4" if pixel else "HalfCheetah-v2", log_level=0, tag="ppo%d" % graph,
+                     graph_update=graph, skip=False))
+        c.num_workers = 2
+        c.task_fn = lambda: d.Task(c.game, num_envs=c.num_workers, seed=3)
+        c.eval_env = d.Task(c.game, seed=4)
+        if pixel:
+            c.optimizer_fn = lambda p: torch.optim.Adam(p, lr=2.5e-4)
+            c.network_fn = lambda: d.CategoricalActorCriticNet(c.state_dim, c.action_dim, d.NatureConvBody())
+            c.state_normalizer, c.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
+            c.entropy_weight, c.gradient_clip, c.rollout_length, c.optimization_epochs = 0.01, 0.5, 8, 2
+            c.mini_batch_size, c.ppo_ratio_clip, c.shared_repr, c.max_steps = 8, 0.1, True, 1000
+        else:
+            c.network_fn = lambda: d.GaussianActorCriticNet(c.state_dim, c.action_dim,
+                                                            actor_body=d.FCBody(c.state_dim, gate=torch.tanh),
+                                                            critic_body=d.FCBody(c.state_dim, gate=torch.tanh))
+            c.actor_opt_fn = lambda p: torch.optim.Adam(p, 3e-4)
+            c.critic_opt_fn = lambda p: torch.optim.Adam(p, 1e-3)
+            c.gradient_clip, c.rollout_length, c.optimization_epochs = 0.5, 32, 2
+            c.mini_batch_size = 24 if kind == "continuous_remainder" else 16
+            c.ppo_ratio_clip, c.max_steps, c.target_kl = 0.2, 3e6, 0.01
+            c.state_normalizer = d.MeanStdNormalizer()
+        c.discount, c.use_gae, c.gae_tau = 0.99, True, 0.95
+        c.log_interval = 10 ** 9
+        d.random_seed(9)
+        torch.manual_seed(9)
+        torch.cuda.manual_seed_all(9)
+        agent = d.PPOAgent(c)
+        for _ in range(3):
+            agent.step()
+        torch.cuda.synchronize()
+        assert (agent._graphed.graphs is not None) == graph
+        outs.append({k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()})
+        agent.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
