@@ -796,26 +796,25 @@ class PPOAgent(BaseAgent):
             self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda step: 1 - step / config.max_steps)
         self.grad_hook = None
         self._graphed = _GraphedPPO(self)
+        self._rollout_graph = dict(calls=0, graph=None, failed=False, k=0)
 
     def step(self):
         config = self.config
         storage = Storage(config.rollout_length)
         states = self.states
         for _ in range(config.rollout_length):
-            with torch.no_grad():
-                prediction = self.network(states)
+            prediction, state_t = self._act(states)
             next_states, rewards, terminals, info = self.task.step(to_np(prediction['action']))
             self.record_online_return(info)
             rewards = config.reward_normalizer(rewards)
             next_states = config.state_normalizer(next_states)
             storage.feed(prediction)
             storage.feed({'reward': tensor(rewards).unsqueeze(-1), 'mask': tensor(1 - terminals).unsqueeze(-1),
-                          'state': tensor(states)})
+                          'state': state_t})
             states = next_states
             self.total_steps += config.num_workers
         self.states = states
-        with torch.no_grad():
-            prediction = self.network(states)
+        prediction, _ = self._act(states)
         storage.feed(prediction)
         storage.placeholder()
         _rollout_scan(storage, config, prediction['v'])
@@ -828,6 +827,54 @@ class PPOAgent(BaseAgent):
         if config.shared_repr:
             self.lr_scheduler.step(self.total_steps)
         self.optimize(entries)
+
+    def _act(self, states):
+        """The rollout's no-grad forward (PPO_agent.py:35-36, incl. the action sample) -> (prediction dict, the
+        f32 device copy of `states` that PPO_agent.py:41 stores).  After two eager calls it is replayed from a
+        captured hipGraph over a static input buffer: same kernels, same arguments, and torch's graph-safe Philox
+        bookkeeping continues the generator's sequence exactly as the eager sampling kernels would."""
+        g = self._rollout_graph
+        cfg = self.config
+        usable = (g is not None and not g['failed'] and getattr(cfg, 'graph_rollout', getattr(cfg, 'graph_update', True))
+                  and Config.DEVICE.type == 'cuda' and not isinstance(states, torch.Tensor))
+        if usable:
+            x = np.ascontiguousarray(np.asarray(states, dtype=np.float32))    # what tensor() uploads (torch_utils.py:23)
+            g['calls'] += 1
+            if g['calls'] > 2:
+                if g['graph'] is None or g['in'].shape != x.shape:
+                    validate = torch.distributions.Distribution._validate_args
+                    try:
+                        g['in'] = torch.zeros(x.shape, dtype=torch.float32, device=Config.DEVICE)
+                        g['stage'] = [torch.empty(x.shape, dtype=torch.float32).pin_memory() for _ in range(4)]
+                        g['events'] = [None] * 4
+                        torch.distributions.Distribution.set_default_validate_args(False)
+                        graph = torch.cuda.CUDAGraph()
+                        torch.cuda.synchronize()
+                        with torch.cuda.graph(graph):
+                            with torch.no_grad():
+                                g['out'] = self.network(g['in'])
+                        g['graph'] = graph
+                    except Exception as e:
+                        import warnings
+                        warnings.warn("rollout forward could not be captured as a graph (%r); using the eager path" % (e,))
+                        g['failed'] = True
+                    finally:
+                        torch.distributions.Distribution.set_default_validate_args(validate)
+                if not g['failed']:
+                    k = g['k']
+                    g['k'] = (k + 1) % 4
+                    if g['events'][k] is not None:
+                        g['events'][k].synchronize()
+                    g['stage'][k].numpy()[...] = x
+                    g['in'].copy_(g['stage'][k], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    g['events'][k] = ev
+                    g['graph'].replay()
+                    return {key: v.clone() for key, v in g['out'].items()}, g['in'].clone()
+        with torch.no_grad():
+            prediction = self.network(states)
+        return prediction, tensor(states)
 
     def _minibatch(self, entry, prepared=False):
         """One minibatch update (PPO_agent.py:77-99) on already-gathered rows.  `prepared`: the optimisers are in

@@ -458,9 +458,13 @@ class GaussianActorCriticNet(nn.Module, BaseNet):
         phi_v = self.critic_body(phi)
         mean = torch.tanh(self.fc_action(phi_a))
         v = self.fc_critic(phi_v)
-        dist = torch.distributions.Normal(mean, F.softplus(self.std))
+        scale = F.softplus(self.std)
+        dist = torch.distributions.Normal(mean, scale)
         if action is None:
-            action = dist.sample()
+            # dist.sample() is torch.normal(mean, scale): standard normals, times scale, plus mean.  Written out
+            # because torch.normal checks `scale >= 0` on the HOST, which a captured rollout graph cannot do.
+            with torch.no_grad():
+                action = torch.randn_like(mean).mul_(scale).add_(mean)
         log_prob = dist.log_prob(action).sum(-1).unsqueeze(-1)
         entropy = dist.entropy().sum(-1).unsqueeze(-1)
         return {'action': action, 'log_pi_a': log_prob, 'entropy': entropy, 'mean': mean, 'v': v}
