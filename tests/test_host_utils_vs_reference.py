@@ -96,3 +96,88 @@ def test_config_defaults_merge_and_tag(ref):
     d.generate_tag(pa)
     ref.generate_tag(pb)
     assert pa["tag"] == pb["tag"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# loss oracles against the reference's own compute_loss on RANDOM shapes / seeds (the committed fixtures cover
+# fixed cases).  The reference agents are driven as unbound methods on a stand-in, as tests/golden/make_golden.py does.
+class _Obj:
+    pass
+
+
+class _FakeNet:
+    def __init__(self, outs):
+        self.outs, self.k = list(outs), 0
+
+    def __call__(self, x):
+        o = self.outs[self.k % len(self.outs)]
+        self.k += 1
+        return o
+
+
+def _cfg(ref, **kw):
+    c = ref.Config()
+    c.state_normalizer = ref.RescaleNormalizer()
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _tr(ref, rs, b, a):
+    state = rs.standard_normal((b, 3)).astype(np.float32)
+    return ref.Transition(state=state, action=rs.randint(0, a, size=b).astype(np.int64), reward=np.sign(rs.standard_normal(b)),
+                          next_state=state + 1, mask=(rs.rand(b) > 0.3).astype(np.int32))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_loss_oracles_equal_live_reference_on_random_cases(ref, seed):
+    import torch.nn.functional as F
+    from oracle import loss_oracle as L
+    rs = np.random.RandomState(500 + seed)
+    b, a = int(rs.randint(2, 40)), int(rs.randint(2, 19))
+    n_step, double_q = int(rs.randint(1, 4)), bool(rs.randint(0, 2))
+    gamma_n = 0.99 ** n_step
+    tr = _tr(ref, rs, b, a)
+    act, rew, msk = torch.tensor(tr.action), torch.tensor(tr.reward, dtype=torch.float32), torch.tensor(tr.mask, dtype=torch.float32)
+    t32 = lambda *s, scale=1.0: torch.tensor((rs.standard_normal(s) * scale).astype(np.float32))
+    # --- DQN
+    q, qt, qo = t32(b, a).requires_grad_(True), t32(b, a), t32(b, a)
+    ag = _Obj()
+    ag.config = _cfg(ref, discount=0.99, n_step=n_step, double_q=double_q)
+    ag.target_network = _FakeNet([dict(q=qt)])
+    ag.network = _FakeNet([dict(q=qo), dict(q=q)] if double_q else [dict(q=q)])
+    want = ref.DQNAgent.compute_loss(ag, tr)
+    got = L.dqn_td_error(q, qt, act, rew, msk, gamma_n, q_next_online=qo if double_q else None)
+    assert torch.equal(got, want)
+    gw, = torch.autograd.grad(ref.DQNAgent.reduce_loss(ag, want), q)
+    gg, = torch.autograd.grad(L.dqn_reduce(got), q)
+    assert torch.equal(gg, gw)
+    # --- C51
+    n_atoms = int(rs.choice([11, 21, 51]))
+    vmin, vmax = -10.0, 10.0
+    lg, lt, lo = t32(b, a, n_atoms).requires_grad_(True), t32(b, a, n_atoms, scale=2.0), t32(b, a, n_atoms, scale=2.0)
+    mk = lambda z: dict(prob=F.softmax(z, dim=-1), log_prob=F.log_softmax(z, dim=-1))
+    ag = _Obj()
+    ag.config = _cfg(ref, discount=0.99, n_step=n_step, double_q=double_q, categorical_v_min=vmin, categorical_v_max=vmax,
+                     categorical_n_atoms=n_atoms)
+    ag.atoms = ref.tensor(np.linspace(vmin, vmax, n_atoms))
+    ag.delta_atom = (vmax - vmin) / float(n_atoms - 1)
+    ag.batch_indices = ref.range_tensor(b)
+    ag.target_network = _FakeNet([mk(lt)])
+    ag.network = _FakeNet([mk(lo), mk(lg)] if double_q else [mk(lg)])
+    want = ref.CategoricalDQNAgent.compute_loss(ag, tr)
+    got = L.c51_kl(F.log_softmax(lg, dim=-1), F.softmax(lt, dim=-1), act, rew, msk, gamma_n, ag.atoms, vmin, vmax,
+                   prob_next_online=F.softmax(lo, dim=-1) if double_q else None)
+    np.testing.assert_allclose(got.detach().numpy(), want.detach().numpy(), rtol=1e-6, atol=1e-6)
+    # --- QR-DQN
+    nq = int(rs.choice([5, 17, 50]))
+    th, tt = t32(b, a, nq).requires_grad_(True), t32(b, a, nq, scale=1.5)
+    ag = _Obj()
+    ag.config = _cfg(ref, discount=0.99, n_step=n_step, num_quantiles=nq)
+    ag.batch_indices = ref.range_tensor(b)
+    ag.cumulative_density = ref.tensor((2 * np.arange(nq) + 1) / (2.0 * nq)).view(1, -1)
+    ag.target_network = _FakeNet([dict(quantile=tt)])
+    ag.network = _FakeNet([dict(quantile=th)])
+    want = ref.QuantileRegressionDQNAgent.compute_loss(ag, tr)
+    got = L.qr_loss(th, tt, act, rew, msk, gamma_n)
+    np.testing.assert_allclose(got.detach().numpy(), want.detach().numpy(), rtol=1e-6, atol=1e-6)
