@@ -12,9 +12,17 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
   * N > 1: one process per GPU, independent replicas (the reference's only multi-GPU mode for
     off-policy agents, docker_batch.sh:2-8) -> "scaling": "weak", no data-path
     collective; a barrier + max-over-ranks brackets the timed region.
-  * roofline: the dominant kernel of the update, timed live with HIP events on the launch stream.
+  * roofline: the dominant kernel of the update, timed live with HIP events on the launch stream
+    ("source": "hip_events"; the rocprofv3 summary of the same command is committed under profiles/).
   * cpu_baseline: the CPU oracle (port of the reference path on torch-CPU fp32) on a bounded
-    sample, rank 0 / N=1 only.
+    sample, rank 0 / N=1 only: `value` with ONE thread (the reference's set_one_thread(), examples.py:623),
+    `all_cores` with torch.set_num_threads(nproc).
+  * parity_check: after the timed region, ONE more agent step of the SAME pipelined configuration is replayed
+    through the CPU oracle (snapshot of parameters / optimizer state before, the minibatch the update consumed,
+    parameters after): loss and every parameter at 1e-5.  Outside the timing.
+  * `--gpus N` without a torchrun environment launches the N ranks itself (torch.distributed.run, 127.0.0.1).
+  * a run of fewer than 500 timed steps (the driver's default is 20) is a few milliseconds: `value` is still exactly
+    those K steps (the contract), and `long_run` carries the same measurement over 2000 steps.
 """
 import argparse
 import json
@@ -46,7 +54,22 @@ def parse():
     ap.add_argument("--variant", type=int, default=-1, help="DRA_VAR_* kernel-variant mask (-1: library default)")
     ap.add_argument("--sync-actor", action="store_true",
                     help="in-order actor (async_actor=False); default is the reference's dqn_pixel setting async_actor=True")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the post-run oracle replay of one agent step")
+    ap.add_argument("--no-long-run", action="store_true", help="short runs (< 500 steps): skip the extra 2000-step measurement")
+    ap.add_argument("--master-port", type=int, default=29517, help="rendezvous port when bench.py launches the ranks itself")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: launch N ranks of this script (one process per GPU, rendezvous on
+    127.0.0.1) and pass rank 0's JSON line through."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(seconds=15.0, ring=20_000):
@@ -56,6 +79,7 @@ def cpu_baseline(seconds=15.0, ring=20_000):
     from oracle import loss_oracle as L, net_oracle as N, numerics_oracle as NUM
     from oracle.replay_oracle import UniformReplayOracle
     from oracle.synth_oracle import synth_transitions
+    threads_before = torch.get_num_threads()
     torch.set_num_threads(1)
     rs = np.random.RandomState(0)
     shapes = [("body.conv1.weight", (32, 4, 8, 8)), ("body.conv1.bias", (32,)), ("body.conv2.weight", (64, 32, 4, 4)),
@@ -91,15 +115,25 @@ def cpu_baseline(seconds=15.0, ring=20_000):
                 newp, sq[k], ga[k] = N.rmsprop_step(p[k], g, sq[k], ga[k], 0.00025, 0.95, 0.01, True)
                 p[k].copy_(newp)
 
-    for _ in range(3):
-        one()
-    n, t0 = 0, time.time()
-    while time.time() - t0 < seconds:
-        one()
-        n += 1
-    dt = time.time() - t0
+    def timed(limit):
+        for _ in range(3):
+            one()
+        n, t0 = 0, time.time()
+        while time.time() - t0 < limit:
+            one()
+            n += 1
+        return n, time.time() - t0
+
+    n, dt = timed(seconds)
+    nproc = os.cpu_count() or 1
+    torch.set_num_threads(nproc)
+    n_all, dt_all = timed(max(4.0, seconds / 2))
+    torch.set_num_threads(threads_before)
     return {"value": n / dt, "unit": "gradient-updates/sec", "cores": 1, "kind": "port",
-            "sample": "%d DQN updates (B=32, 84x84x4, %d-frame ring) in %.1f s, torch-CPU fp32 oracle, 1 thread" % (n, ring, dt)}
+            "sample": "%d DQN updates (B=32, 84x84x4, %d-frame ring) in %.1f s, torch-CPU fp32 oracle, 1 thread "
+                      "(the reference's set_one_thread()); kind 'port': the reference tree is not on the GPU box" % (n, ring, dt),
+            "all_cores": {"value": n_all / dt_all, "cores": nproc,
+                          "sample": "%d updates in %.1f s with torch.set_num_threads(%d)" % (n_all, dt_all, nproc)}}
 
 
 def agent_api(seconds=3.0, ring=100_000):
@@ -150,6 +184,58 @@ def agent_api(seconds=3.0, ring=100_000):
             "note": "DQNAgent.step() (run_steps path), host-side synthetic emulator, sync actor, %d agent steps" % n}
 
 
+def parity_check(bench, max_tries=4, gate_margin=5e-7):
+    """One more agent step of the configuration that was just timed (same learner, same pipeline, same graphs), replayed
+    through the CPU oracle: parameters / RMSprop state are snapshotted first, the step runs, and the oracle redoes the
+    update (DQN_agent.py:114-134) on the minibatch the learner's own gather produced.  Bar: loss 1e-5 relative, every
+    parameter within atol 2e-6 + rtol 1e-5 (weights are O(0.05)).  A step in which some ReLU input of the differentiated
+    forward lies within fp32 summation noise of zero (|pre-activation| < gate_margin: two correct fp32 implementations
+    may gate it differently, which changes that unit's whole backward contribution; about one batch-32 update in three
+    with zero-initialised biases) says nothing either way, so the check moves on to the next step, at most max_tries."""
+    from oracle import loss_oracle as L, net_oracle as N, numerics_oracle as NUM
+    lr = bench.learner
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    out = None
+    for attempt in range(1, max_tries + 1):
+        snap = lr.export_state()          # parameters / target / RMSprop state before the step, module layout, CPU
+        before, target, sq, ga = snap["params"], snap["target"], snap["square_avg"], snap["grad_avg"]
+        names = list(before)
+        bench.step()
+        lr.synchronize()
+        torch.cuda.synchronize()
+        st, ns, ac, rw, mk = [t.cpu() for t in lr.last_minibatch()]
+        after = {k: v.detach().cpu().clone() for k, v in bench.network.state_dict().items()}
+        gpu_loss = float(lr.delta.double().pow(2).mul(0.5).mean().item())
+        p = {k: v.clone().requires_grad_(True) for k, v in before.items()}
+        x = torch.from_numpy(NUM.image_normalize_sync(st.numpy()))
+        xn = torch.from_numpy(NUM.image_normalize_sync(ns.numpy()))
+        with torch.no_grad():
+            qn = N.vanilla_head(target, N.nature_conv_body(target, xn))
+        phi, margin = N.nature_conv_body_margin(p, x)
+        q = N.vanilla_head(p, phi)
+        delta = L.dqn_td_error(q, qn, ac, rw, mk, 0.99)
+        loss = L.dqn_reduce(delta)
+        grads = torch.autograd.grad(loss, [p[k] for k in names])
+        _, grads = N.clip_grad_norm(list(grads), 5)
+        worst_abs, ok = 0.0, True
+        for k, g in zip(names, grads):
+            want, _, _ = N.rmsprop_step(p[k].detach(), g, sq[k], ga[k], 0.00025, 0.95, 0.01, True)
+            err = (after[k] - want).abs()
+            worst_abs = max(worst_abs, float(err.max()))
+            ok = ok and bool(torch.all(err <= 2e-6 + 1e-5 * want.abs()))
+        loss_f = float(loss.detach())
+        rel_loss = abs(gpu_loss - loss_f) / max(abs(loss_f), 1e-12)
+        ok = ok and rel_loss <= 1e-5
+        out = {"ok": bool(ok), "steps_checked": attempt, "loss_gpu": gpu_loss, "loss_oracle": loss_f, "rel_loss_err": rel_loss,
+               "max_abs_param_err": worst_abs, "min_relu_input_abs": margin, "gate_ambiguous": bool(margin < gate_margin),
+               "tolerance": "loss 1e-5 rel; params atol 2e-6 + rtol 1e-5; steps with a ReLU input within %g of zero are skipped" % gate_margin,
+               "what": "one more agent step of the timed configuration (same learner, pipeline and graphs) replayed through "
+                       "the CPU oracle on the minibatch its gather produced; outside the timed region"}
+        if ok or margin >= gate_margin:
+            break
+    return out
+
+
 def pmc_traffic(kernel_group):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_traffic.json, made by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of
@@ -171,6 +257,8 @@ def pmc_traffic(kernel_group):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -219,8 +307,34 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    long_run = None
+    if args.steps < 500 and not args.no_long_run:
+        # the contract's K steps are a few milliseconds; the same measurement over 2000 steps next to it (every rank runs
+        # it so that the replicas keep loading the node the same way; not part of `value`)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(2000):
+            bench.step()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        dt_long = time.perf_counter() - t1
+        if distributed:
+            t = torch.tensor([dt_long], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_long = float(t.item())
+        long_run = {"steps": 2000, "value": world * 2000 / dt_long, "ms_per_step": 1e3 * dt_long / 2000}
     if rank == 0:
-        roof = bench.roofline(args.steps if args.steps < 500 else 500)
+        parity = None
+        if not args.no_parity_check and not args.no_actor:   # first: the learner is still in exactly the timed state
+            try:
+                parity = parity_check(bench)
+            except Exception as e:      # the checker must never take the measurement down with it
+                parity = {"ok": False, "error": repr(e)}
+        roof = bench.roofline(200 if args.steps < 500 else 500)
+        roof["source"] = "hip_events"
         roof["traffic"] = pmc_traffic(roof["kernel"])
         # the update chain owns a CU partition while the device actor runs beside it (lever 5):
         # the kernel is timed on that stream, i.e. on this many of the device's CUs
@@ -242,6 +356,11 @@ def main():
             "roofline": roof,
         }
         out.update(extra)
+        if long_run is not None:
+            out["short_run"] = True
+            out["long_run"] = long_run
+        if parity is not None:
+            out["parity_check"] = parity
         if world == 1 and not args.no_cpu_baseline:
             out["agent_api"] = agent_api()
             out["cpu_baseline"] = cpu_baseline()

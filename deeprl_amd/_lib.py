@@ -10,7 +10,9 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "deeprl_amd.h")
-LIBRARY = os.path.join(_HERE, "lib", "libdeeprl_amd.so")
+# DEEPRL_AMD_LIB: measurement builds of the SAME sources (tools/phase_trace.py loads libdeeprl_amd_trace.so); still a HIP
+# library with the full C ABI -- there is no non-HIP implementation to point this at.
+LIBRARY = os.environ.get("DEEPRL_AMD_LIB") or os.path.join(_HERE, "lib", "libdeeprl_amd.so")
 
 _SCALARS = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,

@@ -1,0 +1,80 @@
+// Device-resident synthetic environment + the actor's parameter-block ring, shared by learner.hip (actor head /
+// environment kernels) and conv_v2.hip (conv1 of the actor with the previous step's head and the environment
+// step fused in front of it).
+//
+// The environment (SURVEY.md 8d "C2"): frame k of stream `seed` is a counter hash (the bytes
+// dra_ring_fill_synthetic writes), reward in {-1, 0, 1} with p = .1 / .8 / .1 and done w.p. 1/done_period are hashes of
+// the same counter.  obs_{t+1} = env_step(state_t, action_t): every frame generator below takes the action of the
+// transition that produced the frame, so that the kernels keep the data dependence a real environment has (forward ->
+// action -> environment step -> next observation -> next forward) even though THIS environment's observations do
+// not depend on it.
+#pragma once
+#include "common.h"
+#include <stddef.h>
+
+constexpr int kMaxEnvSteps = 8;  // env transitions per agent step (sgd_update_frequency)
+constexpr size_t kPrmHeadBytes = offsetof(dra_dqn_step_params, idx);  // the part the actor kernels read
+constexpr int kAringSlots = 64;
+constexpr size_t kAprmStride = 512;
+static_assert(kPrmHeadBytes <= kAprmStride && kPrmHeadBytes % 4 == 0, "parameter ring entry");
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// 8-byte word w (0..881) of the 84x84 frame with counter `counter`; `action` = the action whose environment step
+// produced this observation (unused by the synthetic source)
+__device__ __forceinline__ uint64_t synth_frame_word(uint64_t seed, int64_t counter, int64_t action, int w) {
+  (void)action;
+  return mix64(seed * 0x9E3779B97F4A7C15ull + (uint64_t)counter * 882ull + (uint64_t)w);
+}
+__device__ __forceinline__ double synth_reward(uint64_t seed, int64_t counter) {
+  const uint64_t hh = mix64((seed + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
+  const uint32_t u = (uint32_t)(hh >> 32) % 10u;
+  return (u == 0) ? -1.0 : ((u == 9) ? 1.0 : 0.0);
+}
+__device__ __forceinline__ int32_t synth_mask(uint64_t seed, int64_t counter, int done_period) {
+  const uint64_t h2 = mix64((seed + 2) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
+  return ((h2 % (uint64_t)done_period) == 0) ? 0 : 1;
+}
+
+// entry (seq mod kAringSlots) of the device parameter ring = the head of a dra_dqn_step_params
+__device__ __forceinline__ const dra_dqn_step_params* aring_entry(const uint8_t* ring, unsigned seq) {
+  return reinterpret_cast<const dra_dqn_step_params*>(ring + (size_t)(seq % kAringSlots) * kAprmStride);
+}
+
+// epsilon-greedy on q[0..A) with HOST-drawn randomness (torch_utils.py:51-58: np.argmax = first maximum)
+__device__ __forceinline__ int64_t eps_greedy_action(const float* q, int A, const dra_dqn_step_params* prm, int e) {
+  int best = 0;
+  float bv = q[0];
+  for (int a = 1; a < A; ++a) if (q[a] > bv) { bv = q[a]; best = a; }
+  return (prm->dice[e] < prm->epsilon[e]) ? (int64_t)prm->random_action[e] : (int64_t)best;
+}
+
+// What conv1 of env step e >= 1 of the ring actor needs to perform the head of step e-1 and the environment step
+// in front of its own work (launch = conv1's workgroups + ONE environment workgroup, the last one):
+//   every workgroup : q = head(h4) -> action of step e-1 -> the rows of observation e it convolves (generated, not read);
+//   environment wg  : stores that action into ring slot[e-1], writes observation e (frame / reward / mask) to ring slot[e].
+// mode 1 (env step 0): conv1 reads its newest frame from the pending buffer as before and the environment
+// workgroup commits the pending observation to ring slot[0] (the feed of DQN_agent.py:104-112 happens after the
+// minibatch of the previous agent step was gathered).
+struct ActorFuse {
+  int mode;                    // 0 = plain conv1, 1 = commit pending (env step 0), 2 = head(e-1) + env step -> e
+  int e, n_actions, done_period;
+  const float* h4;             // [512] fc4 output of env step e-1
+  const float* wh;             // [A][512]
+  const float* bh;             // [A]
+  const uint8_t* aring;        // device parameter ring
+  const unsigned* seq;         // agent steps completed by the actor
+  uint8_t* frames; uint8_t* actions; double* rewards; int32_t* masks;   // replay ring arrays
+  float* q_out;                // [A] or null
+  const uint8_t* pend_frame; const double* pend_reward; const int32_t* pend_mask;
+  uint64_t seed;
+};
+
+// conv_v2.hip (library-internal)
+int dra_conv1_fwd_actor_fused(const void* frames, const int64_t* slot_field_dev, const int32_t* stack_age_field_dev, const unsigned* seq_dev, int n_entries,
+                              int64_t stride_bytes, int64_t capacity, const void* newest_frame, const float* wt,
+                              const float* bias, float* y, double u8_coef, int act, const ActorFuse* f, void* stream);

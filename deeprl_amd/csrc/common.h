@@ -43,3 +43,46 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Phase trace (measurement aid, compiled only into libdeeprl_amd_trace.so: `make trace`, -DDRA_TRACE).
+// Thread 0 of every workgroup writes a constant-rate (s_memrealtime) time stamp at up to 8 phase
+// boundaries into a per-kernel-family region of a trace buffer; tools/phase_trace.py turns the
+// stamps into per-phase durations, workgroup start distributions (rounds) and the XCD / CU each
+// workgroup ran on.  The product library has no stamps at all (the macros expand to nothing).
+enum { TR_GATHER, TR_CONV1_F, TR_CONV2_F, TR_CONV3_F, TR_FC4_F, TR_HEAD, TR_FC_B, TR_CONV3_B, TR_CONV2_B,
+       TR_CONV1_B, TR_NORM, TR_STEP, TR_A_CONV1, TR_A_CONV2, TR_A_CONV3, TR_A_FC4, TR_A_HEAD, TR_REGIONS };
+constexpr int kTraceWgs = 4096;   // workgroups recorded per region
+#ifdef DRA_TRACE
+static __device__ unsigned long long* g_dra_trace = nullptr;   // one copy per translation unit
+__device__ __forceinline__ void dra_stamp(int region, int k) {
+  unsigned long long* p = g_dra_trace;
+  if (p && threadIdx.x == 0) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (wg < (unsigned)kTraceWgs) {
+      unsigned long long* rec = p + ((size_t)region * kTraceWgs + wg) * 8;
+      if (k == 7) {   // last slot also carries where the workgroup ran: [63:48] XCC id, [47:32] HW_ID low bits
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        rec[6] = ((unsigned long long)(xcc & 0xffffu) << 32) | (hw & 0xffffffffu);
+      }
+      rec[k == 7 ? 7 : k] = t;
+    }
+  }
+}
+// every pending vector-memory operation of the calling wave has completed
+__device__ __forceinline__ void dra_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+static int dra_trace_set_local(void* p) {
+  unsigned long long* v = reinterpret_cast<unsigned long long*>(p);
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_dra_trace), &v, sizeof(v));
+  return (int)e;
+}
+#define DRA_STAMP(region, k) dra_stamp((region), (k))
+#define DRA_STAMP_END(region) do { dra_drain(); dra_stamp((region), 7); } while (0)
+#else
+#define DRA_STAMP(region, k) ((void)0)
+#define DRA_STAMP_END(region) ((void)0)
+#endif

@@ -18,7 +18,7 @@
 //   * reduces the 4 partial accumulators through LDS, adds bias, applies ReLU, stores coalesced.
 // Numerics: fp32 MFMA (exact fmaf chains), summation order differs from igemm.hip / the CPU
 // oracle only in the order of the four K-quarters.
-#include "common.h"
+#include "actor_env.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -45,6 +45,18 @@ struct V2Geom {
   static_assert(C % 2 == 0 && (CP >= 4 ? CP % 4 == 0 : (4 % CP == 0 && KK % TSPLIT == 0)), "K split");
   static_assert(TW % KH == 0, "a wave's tap range starts on a kernel-row boundary");
   static_assert(OC % 32 == 0, "OC tiles");
+  // the same split over NW waves (NW = 4 gives the members above).  NW = 8 is the batch-1 (actor) shape: the launch
+  // has 4-13 workgroups, so a workgroup's latency IS the kernel's -- half the operand loads and half the MFMA chain
+  // per wave (conv3: 72 -> 36 dependent 64-cycle MFMAs, 1.9 -> 0.95 us)
+  template <int NW>
+  struct Split {
+    static constexpr int CPW = CP >= NW ? CP / NW : 1;
+    static constexpr int TSPLIT = CP >= NW ? 1 : NW / CP;
+    static constexpr int TW = KK / TSPLIT;
+    static constexpr int NJ = CPW * TW;
+    static_assert(CP >= NW ? CP % NW == 0 : (NW % CP == 0 && KK % TSPLIT == 0), "K split");
+    static_assert(TW % KH == 0, "a wave's tap range starts on a kernel-row boundary");
+  };
 };
 
 struct ConvV2Args {
@@ -58,6 +70,9 @@ struct ConvV2Args {
   // (*ring_slot - (C-1) + c) mod ring_cap of the slot-major frame array x[0]; null = plain NCHW input
   const int64_t* ring_slot;
   int64_t ring_cap;
+  // optional, with ring_slot (same indirection): frames of the same episode older than the newest one, capped at C-1;
+  // channel c reads slot newest - min(C-1-c, age).  null = C-1 (the last C ring frames)
+  const int32_t* stack_age;
   // optional indirection for `ring_slot`: the slot lives in entry (*slot_seq mod slot_entries) of an array of
   // parameter blocks slot_stride bytes apart (the learner's K-steps-ahead actor parameter ring)
   const unsigned* slot_seq;
@@ -93,10 +108,64 @@ struct V2Tile {
   static constexpr int CS = NR * G::RW;                                    // LDS channel stride
 };
 
-template <class G, bool U8, int PT>
-__global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
+// q[a] = bh[a] + <h4, Wh[a]> for the VanillaNet head at batch 1, one wave per action (same per-lane order and
+// butterfly as actor_head_env_ring_kernel: bit-identical action values), into s_q; caller synchronises.
+template <int NW>
+__device__ __forceinline__ void fused_head_q(const ActorFuse& f, int wave, int lane, float* __restrict__ s_q) {
+  for (int a = wave; a < f.n_actions; a += NW) {
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part += f.h4[lane + 64 * i] * f.wh[a * 512 + lane + 64 * i];
+    part = wave_sum(part);
+    if (lane == 0) s_q[a] = part + f.bh[a];
+  }
+}
+
+// The environment workgroup of a fused actor launch (ActorFuse, actor_env.h).
+template <int NW>
+__device__ __forceinline__ void fused_env_workgroup(const ActorFuse& f, float* __restrict__ s_q) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const dra_dqn_step_params* __restrict__ prm = aring_entry(f.aring, *f.seq);
+  if (f.mode == 1) {   // env step 0: feed the pending observation into ring slot[0]
+    if (prm->counter[0] < 0) return;
+    const int64_t slot = prm->slot[0];
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(f.pend_frame);
+    uint64_t* dst = reinterpret_cast<uint64_t*>(f.frames + slot * 7056);
+    for (int w = tid; w < 882; w += 64 * NW) dst[w] = src[w];
+    if (tid == 0) { f.rewards[slot] = *f.pend_reward; f.masks[slot] = *f.pend_mask; }
+    return;
+  }
+  const int e = f.e;   // head of env step e-1, then the environment step that produces observation e
+  fused_head_q<NW>(f, wave, lane, s_q);
+  __syncthreads();
+  if (tid < f.n_actions && f.q_out) f.q_out[tid] = s_q[tid];
+  const int64_t act = eps_greedy_action(s_q, f.n_actions, prm, e - 1);
+  if (tid == 0 && prm->store_action[e - 1]) *reinterpret_cast<int64_t*>(f.actions + prm->slot[e - 1] * 8) = act;
+  const int64_t counter = prm->counter[e];
+  if (counter < 0) return;
+  const int64_t slot = prm->slot[e];
+  uint64_t* dst = reinterpret_cast<uint64_t*>(f.frames + slot * 7056);
+  for (int w = tid; w < 882; w += 64 * NW) dst[w] = synth_frame_word(f.seed, counter, act, w);
+  if (tid == 0) {
+    f.rewards[slot] = synth_reward(f.seed, prm->rcounter[e]);
+    f.masks[slot] = synth_mask(f.seed, prm->rcounter[e], f.done_period);
+  }
+}
+
+template <class G, bool U8, int PT, int NW, bool FUSE>
+__device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const ActorFuse& f) {
   using T = V2Tile<G, PT>;
+  using KS = typename G::template Split<NW>;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  static_assert(!FUSE || (U8 && PT == 1 && G::C == 4), "the fused actor launch is conv1 on uint8 ring frames");
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [C][NR][RW] image, then reused for the reduction
+  __shared__ float s_q[FUSE ? 64 : 1];
+  if constexpr (FUSE) {
+    if (blockIdx.x == gridDim.x - 1) {   // the launch's extra workgroup: environment side
+      fused_env_workgroup<NW>(f, s_q);
+      return;
+    }
+  }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
   const int z = blockIdx.z;
   const int bi = blockIdx.x / T::TPG, grp = blockIdx.x - bi * T::TPG;
@@ -106,19 +175,39 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
   const int oh0 = p0 / G::OH, oh1 = (p0 + np - 1) / G::OH;
   const int ir0 = oh0 * G::S;
   const int nrows = (oh1 - oh0) * G::S + G::KH;  // <= T::NR
+  [[maybe_unused]] const int TRR = (a.batch == 1 ? TR_A_CONV1 : TR_CONV1_F) + (G::C == 4 ? 0 : (G::C == 32 ? 1 : 2));
+  DRA_STAMP(TRR, 0);
 
+  // ---- fused actor launch: the previous env step's head is requested FIRST (its loads complete first, so the action
+  // is known while the weight / frame loads below are still in flight)
+  [[maybe_unused]] const dra_dqn_step_params* prm = nullptr;
+  if constexpr (FUSE) {
+    if (f.mode == 2) {
+      prm = aring_entry(f.aring, *f.seq);
+      fused_head_q<NW>(f, wave, lane, s_q);
+    }
+  }
   // ---- issue every global load of this workgroup: weight operands first, then the image rows
   const float* __restrict__ wt = a.wt[z];
-  const int cp0 = (G::CP >= 4) ? wave * G::CPW : (wave % G::CP);
-  const int t0 = (G::CP >= 4) ? 0 : (wave / G::CP) * G::TW;
-  float areg[G::NJ];
+  const int cp0 = (G::CP >= NW) ? wave * KS::CPW : (wave % G::CP);
+  const int t0 = (G::CP >= NW) ? 0 : (wave / G::CP) * KS::TW;
+  float areg[KS::NJ];
   {
     const float* wbase = wt + ((int64_t)(2 * cp0 + h) * G::KK + t0) * G::OC + oc0 + li;
 #pragma unroll
-    for (int j = 0; j < G::NJ; ++j) {
-      const int cpl = j / G::TW, t = j - cpl * G::TW;
+    for (int j = 0; j < KS::NJ; ++j) {
+      const int cpl = j / KS::TW, t = j - cpl * KS::TW;
       areg[j] = wbase[(2 * cpl * G::KK + t) * G::OC];
     }
+  }
+  // bias of the 4 output rows this wave finalises: requested with the operands (a load in the epilogue exposes a
+  // second memory latency per workgroup: 0.5-0.7 us of the 1.2-2.0 us epilogue in the phase traces, profiles/r02a_*)
+  constexpr int RPW = 16 / NW;                                 // accumulator registers a wave finalises
+  float bias_r[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int r = wave * RPW + q;
+    bias_r[q] = a.bias[z][oc0 + (r & 3) + 8 * (r >> 2) + 4 * h];
   }
   // Staging maps lanes to (row, column) so that no per-element division is needed: LR lanes walk one image
   // row (the surplus lanes of a row idle), 64 / LR rows per pass; row offsets are compile-time immediates and
@@ -132,12 +221,16 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
     // normalisation f32(f64(v) * coef) comes from a 256-entry LDS table built while the loads are in flight.
     static_assert(!U8 || (G::S == 4 && G::H % 4 == 0 && G::H / 4 <= 32), "u8 staging: stride-4 layer, <= 32 words per row");
     constexpr int WPR = G::H / 4;                               // u32 words per row
-    constexpr int LPT = (T::NR + 1) / 2;                        // rows per lane per channel
-    constexpr int CPT = (G::C + 3) / 4;                         // channels per wave
+    // waves = (channel group, row part): RPARTS waves share a channel and interleave its row passes
+    constexpr int RPARTS = (NW > G::C) ? NW / G::C : 1;
+    constexpr int CW = NW / RPARTS;                             // waves along the channel axis
+    constexpr int LPT = ((T::NR + 1) / 2 + RPARTS - 1) / RPARTS; // row passes per lane per channel
+    constexpr int CPT = (G::C + CW - 1) / CW;                   // channels per wave
     __shared__ float s_lut[256];
     unsigned raw[CPT * LPT];
     const uint8_t* xb = reinterpret_cast<const uint8_t*>(a.x[z]);
-    const int rsub = lane >> 5, wd = lane & 31;
+    const int wc = wave % CW, rpart = wave / CW;
+    const int rsub = (lane >> 5) + 2 * rpart, wd = lane & 31;   // first row of this lane; passes advance by 2*RPARTS
     const int wdc = min(wd, WPR - 1);
     int64_t newest = 0;
     if (a.ring_slot) {
@@ -145,33 +238,62 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
       if (a.slot_seq) sp += (int64_t)(*a.slot_seq % (unsigned)a.slot_entries) * a.slot_stride;
       newest = *reinterpret_cast<const int64_t*>(sp);
     }
+    int age = G::C - 1;
+    if (a.ring_slot && a.stack_age) {
+      const char* ap = reinterpret_cast<const char*>(a.stack_age);
+      if (a.slot_seq) ap += (int64_t)(*a.slot_seq % (unsigned)a.slot_entries) * a.slot_stride;
+      age = *reinterpret_cast<const int32_t*>(ap);
+    }
+    bool generated = false;      // fused mode 2: the newest channel is produced by the environment step below
+    if constexpr (FUSE) generated = f.mode == 2;
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
-      const int c = wave + 4 * ci;
+      const int c = wc + CW * ci;
       int64_t img = (int64_t)bi * G::C + min(c, G::C - 1);       // image index in a plain NCHW batch
+      const int off = min(G::C - 1 - min(c, G::C - 1), age);      // ring stack: frames back from the newest one
       if (a.ring_slot) {
-        img = newest - (G::C - 1) + min(c, G::C - 1);
+        img = newest - off;
         if (img < 0) img += a.ring_cap;
+        if (generated && off == 0) img = newest >= 1 ? newest - 1 : newest + 1;   // any committed slot: value unused
       }
       const unsigned* src = reinterpret_cast<const unsigned*>(xb + (img * G::H + ir0) * G::H) + wdc;
-      if (a.ring_slot && a.newest_frame && c == G::C - 1)
+      if (a.ring_slot && a.newest_frame && off == 0)              // the newest observation is not in the ring yet
         src = reinterpret_cast<const unsigned*>(a.newest_frame + (int64_t)ir0 * G::H) + wdc;
 #pragma unroll
-      for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = src[min(2 * q + rsub, nrows - 1) * WPR];
+      for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = src[min(2 * RPARTS * q + rsub, nrows - 1) * WPR];
     }
-    s_lut[tid] = (float)((double)tid * a.coef);
+    if (tid < 256) s_lut[tid] = (float)((double)tid * a.coef);
     __syncthreads();
+    if constexpr (FUSE) {
+      if (f.mode == 2) {
+        // action of env step e-1 (every workgroup, redundantly), then THIS workgroup's rows of the observation that
+        // environment step returns: u32 word wd of row r is half ((21 r + wd) & 1) of 8-byte word (21 r + wd) >> 1
+        const int64_t act = eps_greedy_action(s_q, f.n_actions, prm, f.e - 1);
+        const int64_t counter = prm->counter[f.e];
+#pragma unroll
+        for (int ci = 0; ci < CPT; ++ci) {
+          if (min(G::C - 1 - min(wc + CW * ci, G::C - 1), age) == 0) {   // every channel that shows the newest frame
+#pragma unroll
+            for (int q = 0; q < LPT; ++q) {
+              const int w32 = (ir0 + min(2 * RPARTS * q + rsub, nrows - 1)) * WPR + wdc;
+              const uint64_t v = synth_frame_word(f.seed, counter, act, w32 >> 1);
+              raw[ci * LPT + q] = (unsigned)(v >> (32 * (w32 & 1)));
+            }
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
-      const int c = wave + 4 * ci;
+      const int c = wc + CW * ci;
       float* dst = lds + c * T::CS + rsub * G::RW + wd;
 #pragma unroll
       for (int q = 0; q < LPT; ++q) {
         unsigned v = raw[ci * LPT + q];
         asm volatile("" : "+v"(v));  // keep the loads unconditional and batched (see igemm.hip)
-        if (wd < WPR && 2 * q + rsub < nrows && c < G::C) {
+        if (wd < WPR && 2 * RPARTS * q + rsub < nrows && c < G::C) {
 #pragma unroll
-          for (int b = 0; b < 4; ++b) dst[2 * q * G::RW + b * G::WPH] = s_lut[(v >> (8 * b)) & 0xffu];
+          for (int b = 0; b < 4; ++b) dst[2 * RPARTS * q * G::RW + b * G::WPH] = s_lut[(v >> (8 * b)) & 0xffu];
         }
       }
     }
@@ -180,13 +302,13 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
     // flat element mapping
     constexpr int NEMAX = T::NR * G::H;                          // floats per channel block
     constexpr int LPT = (NEMAX + 63) / 64;
-    constexpr int CPT = (G::C + 3) / 4;
+    constexpr int CPT = (G::C + NW - 1) / NW;
     float raw[CPT * LPT];
     const float* xf = reinterpret_cast<const float*>(a.x[z]);
     const int ne = nrows * G::H;
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
-      const int c = wave + 4 * ci;
+      const int c = wave + NW * ci;
       const float* src = xf + ((int64_t)(bi * G::C + min(c, G::C - 1)) * G::H + ir0) * G::H;
 #pragma unroll
       for (int q = 0; q < LPT; ++q) {
@@ -196,7 +318,7 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
     }
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
-      const int c = wave + 4 * ci;
+      const int c = wave + NW * ci;
 #pragma unroll
       for (int q = 0; q < LPT; ++q) {
         const int e = lane + 64 * q;
@@ -212,7 +334,7 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
     constexpr int LR = G::H > 16 ? 32 : 16;                     // lanes per image row
     constexpr int RP = 64 / LR;                                  // rows per pass
     constexpr int LPT = (T::NR + RP - 1) / RP;
-    constexpr int CPT = (G::C + 3) / 4;
+    constexpr int CPT = (G::C + NW - 1) / NW;
     float raw[CPT * LPT];
     const float* xf = reinterpret_cast<const float*>(a.x[z]);
     const int rsub = lane / LR, iw = lane % LR;
@@ -220,14 +342,14 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
     const int col = lds_col<G>(iwc);
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
-      const int c = wave + 4 * ci;
+      const int c = wave + NW * ci;
       const float* src = xf + ((int64_t)(bi * G::C + min(c, G::C - 1)) * G::H + ir0) * G::H + iwc;
 #pragma unroll
       for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = src[min(RP * q + rsub, nrows - 1) * G::H];
     }
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
-      const int c = wave + 4 * ci;
+      const int c = wave + NW * ci;
       float* dst = lds + c * T::CS + rsub * G::RW + col;
 #pragma unroll
       for (int q = 0; q < LPT; ++q) {
@@ -237,7 +359,9 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
       }
     }
   }
+  DRA_STAMP(TRR, 1);   // loads consumed, LDS writes issued
   __syncthreads();
+  DRA_STAMP(TRR, 2);   // image staged
 
   // ---- MFMA: lane li owns output positions p0 + 32 t + li (clamped), half-wave h the odd channel of a pair
   const float* bptr[PT];
@@ -253,38 +377,59 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_kernel(const ConvV2Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
-  for (int j = 0; j < G::NJ; ++j) {
-    const int cpl = j / G::TW, tp = j - cpl * G::TW;  // tap relative to the wave's base tap t0 (folded into bptr)
+  for (int j = 0; j < KS::NJ; ++j) {
+    const int cpl = j / KS::TW, tp = j - cpl * KS::TW;  // tap relative to the wave's base tap t0 (folded into bptr)
     const int kh = tp / G::KH, kw = tp - kh * G::KH;
     const int off = 2 * cpl * T::CS + kh * G::RW + (kw % G::S) * G::WPH + kw / G::S;
 #pragma unroll
     for (int t = 0; t < PT; ++t)  // PT independent accumulation chains share the A operand
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[j], bptr[t][off], acc[t], 0, 0, 0);
   }
+  DRA_STAMP(TRR, 3);   // this wave's MFMAs issued
   __syncthreads();  // every wave is done reading the image: reuse LDS for the 4-way reduction
+  DRA_STAMP(TRR, 4);
 
-  float* red = lds;  // [PT][4 waves][16][64]
+  float* red = lds;  // [PT][NW waves][16][64]
 #pragma unroll
   for (int t = 0; t < PT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[((t * 4 + wave) * 16 + r) * 64 + lane] = acc[t][r];
+    for (int r = 0; r < 16; ++r) red[((t * NW + wave) * 16 + r) * 64 + lane] = acc[t][r];
   __syncthreads();
-  // wave w finalises accumulator registers 4w .. 4w+3 (MFMA C/D rows (r&3) + 8*(r>>2) + 4*h)
+  // wave w finalises accumulator registers RPW*w .. RPW*w+RPW-1 (MFMA C/D rows (r&3) + 8*(r>>2) + 4*h); the NW partials are
+  // added as a fixed balanced tree: run-to-run deterministic
   float* __restrict__ y = a.y[z];
-  const float* __restrict__ bias = a.bias[z];
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = wave * 4 + q;
-      const float* rt = red + (t * 4 * 16) * 64;
-      const float s = (rt[(0 * 16 + r) * 64 + lane] + rt[(1 * 16 + r) * 64 + lane]) +
-                      (rt[(2 * 16 + r) * 64 + lane] + rt[(3 * 16 + r) * 64 + lane]);
+    for (int q = 0; q < RPW; ++q) {
+      const int r = wave * RPW + q;
+      const float* rt = red + (t * NW * 16) * 64;
+      float s = (rt[(0 * 16 + r) * 64 + lane] + rt[(1 * 16 + r) * 64 + lane]) +
+                (rt[(2 * 16 + r) * 64 + lane] + rt[(3 * 16 + r) * 64 + lane]);
+      if constexpr (NW == 8)
+        s += (rt[(4 * 16 + r) * 64 + lane] + rt[(5 * 16 + r) * 64 + lane]) +
+             (rt[(6 * 16 + r) * 64 + lane] + rt[(7 * 16 + r) * 64 + lane]);
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float v = v2_act(s + bias[oc0 + row], a.act);
+      const float v = v2_act(s + bias_r[q], a.act);
       if (32 * t + li < np) y[((int64_t)(bi * G::OC + oc0 + row)) * G::P + p0 + 32 * t + li] = v;
     }
   }
+  DRA_STAMP(TRR, 5);   // reduction folded, stores issued
+  DRA_STAMP_END(TRR);
+}
+
+template <class G, bool U8, int PT, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) conv_fwd_v2_kernel(const ConvV2Args a) {
+  ActorFuse none;
+  none.mode = 0;
+  conv_fwd_v2_body<G, U8, PT, NW, false>(a, none);
+}
+
+// conv1 of the ring actor's env step e with the head of step e-1 and the environment step in front (ActorFuse):
+// grid = conv1's workgroups + 1 environment workgroup.
+template <class G, int NW>
+__global__ void __launch_bounds__(64 * NW) conv1_actor_fused_kernel(const ConvV2Args a, const ActorFuse f) {
+  conv_fwd_v2_body<G, true, 1, NW, true>(a, f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -375,6 +520,8 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Ar
   const float* __restrict__ wt = a.wt[z];
   const int cp0 = (G::CP >= 4) ? wave * G::CPW : (wave % G::CP);
   const int t0 = (G::CP >= 4) ? 0 : (wave / G::CP) * G::TW;
+  [[maybe_unused]] const int TRR = TR_CONV1_F + (G::C == 4 ? 0 : (G::C == 32 ? 1 : 2));
+  DRA_STAMP(TRR, 0);
   float areg[G::NJ];
   {
     const float* wbase = wt + ((int64_t)(2 * cp0 + h) * G::KK + t0) * G::OC + oc0 + li;
@@ -403,6 +550,7 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Ar
   __syncthreads();                                   // normalisation table visible
   ST::store(raw, img, s_lut, nrows, wave, lane);
   __syncthreads();
+  DRA_STAMP(TRR, 2);   // prologue done: weights + first group staged
   for (;;) {
     // ---- next group's rows: requested now, consumed after the MFMA phase (always issued -- the last iteration
     // re-reads its own group -- so that no branch sits between the loads and the MFMA loop)
@@ -461,28 +609,37 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Ar
     if (!more) break;
     g = gn; bi = bi_n; p0 = p0_n; np = np_n; oh0 = oh0_n; nrows = nrows_n;
   }
+  DRA_STAMP(TRR, 5);
+  DRA_STAMP_END(TRR);
 }
 
 using VG1 = V2Geom<4, 84, 32, 8, 4>;
 using VG2 = V2Geom<32, 20, 64, 4, 2>;
 using VG3 = V2Geom<64, 9, 64, 3, 1>;
 
-template <class G, bool U8, int PT>
+template <class G, bool U8, int PT, int NW = 4>
 static int launch_conv_v2_pt(const ConvV2Args& a, int nz, hipStream_t st) {
   using T = V2Tile<G, PT>;
   constexpr size_t img = (size_t)G::C * T::CS * sizeof(float);
-  constexpr size_t red = (size_t)PT * 4 * 16 * 64 * sizeof(float);
+  constexpr size_t red = (size_t)PT * NW * 16 * 64 * sizeof(float);
   constexpr size_t bytes = img > red ? img : red;
   static_assert(bytes <= 160 * 1024, "LDS per workgroup");
   static bool attr_set = false;
   if (bytes > 64 * 1024 && !attr_set) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_v2_kernel<G, U8, PT>),
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_v2_kernel<G, U8, PT, NW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_fwd_v2_kernel<G, U8, PT>), dim3(T::TPG * a.batch, G::OC / 32, nz), dim3(256), bytes, st, a);
+  hipLaunchKernelGGL((conv_fwd_v2_kernel<G, U8, PT, NW>), dim3(T::TPG * a.batch, G::OC / 32, nz), dim3(64 * NW), bytes, st, a);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
+}
+
+// batch-1 launches (the actor's forward) use 8 waves per workgroup unless DRA_CONV_B1_WAVES=4
+static int conv_b1_waves() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_CONV_B1_WAVES"); v = (e && atoi(e) == 4) ? 4 : 8; }
+  return v;
 }
 
 template <class G, bool U8, int PT>
@@ -537,6 +694,7 @@ static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
     }
     return launch_conv_v2_pt<G, U8, PTBIG>(a, nz, st);
   }
+  if (a.batch == 1 && conv_b1_waves() == 8) return launch_conv_v2_pt<G, U8, 1, 8>(a, nz, st);
   return launch_conv_v2_pt<G, U8, 1>(a, nz, st);
 }
 
@@ -549,7 +707,7 @@ DRA_API int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const floa
     if (!x[z] || !wt[z] || !bias[z] || !y[z]) return DRA_EINVAL;
     a.x[z] = x[z]; a.wt[z] = wt[z]; a.bias[z] = bias[z]; a.y[z] = y[z];
   }
-  a.batch = batch; a.act = act; a.coef = u8_coef; a.ring_slot = nullptr; a.ring_cap = 0;
+  a.batch = batch; a.act = act; a.coef = u8_coef; a.ring_slot = nullptr; a.ring_cap = 0; a.stack_age = nullptr;
   a.slot_seq = nullptr; a.slot_entries = 0; a.slot_stride = 0; a.newest_frame = nullptr;
   hipStream_t st = dra_stream(stream);
   switch (layer) {
@@ -563,19 +721,20 @@ DRA_API int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const floa
 // conv1 of the actor's batch-1 forward reading its 4-frame stack straight from the replay ring
 // (DQN_agent.py:24-33: the state the actor acts on IS the newest `history` frames of the ring):
 // frames = slot-major u8 ring, *newest_slot_dev = slot of the newest frame (device int64).
-DRA_API int dra_conv1_fwd_koc_ring(const void* frames, const int64_t* newest_slot_dev, int64_t capacity, const float* wt,
+DRA_API int dra_conv1_fwd_koc_ring(const void* frames, const int64_t* newest_slot_dev, const int32_t* stack_age_dev, int64_t capacity, const float* wt,
                                    const float* bias, float* y, double u8_coef, int act, void* stream) {
   if (!frames || !newest_slot_dev || capacity < VG1::C || !wt || !bias || !y) return DRA_EINVAL;
   ConvV2Args a;
   a.x[0] = frames; a.wt[0] = wt; a.bias[0] = bias; a.y[0] = y;
-  a.batch = 1; a.act = act; a.coef = u8_coef; a.ring_slot = newest_slot_dev; a.ring_cap = capacity;
+  a.batch = 1; a.act = act; a.coef = u8_coef; a.ring_slot = newest_slot_dev; a.ring_cap = capacity; a.stack_age = stack_age_dev;
   a.slot_seq = nullptr; a.slot_entries = 0; a.slot_stride = 0; a.newest_frame = nullptr;
+  if (conv_b1_waves() == 8) return launch_conv_v2_pt<VG1, true, 1, 8>(a, 1, dra_stream(stream));
   return launch_conv_v2_pt<VG1, true, 1>(a, 1, dra_stream(stream));
 }
 
 // Same, with the slot read from entry (*seq_dev mod n_entries) of an array of parameter blocks: slot_field_dev points at
 // the slot field of entry 0, entries are stride_bytes apart (dra_dqn_learner's actor parameter ring).
-DRA_API int dra_conv1_fwd_koc_ring_seq(const void* frames, const int64_t* slot_field_dev, const unsigned* seq_dev,
+DRA_API int dra_conv1_fwd_koc_ring_seq(const void* frames, const int64_t* slot_field_dev, const int32_t* stack_age_field_dev, const unsigned* seq_dev,
                                        int n_entries, int64_t stride_bytes, int64_t capacity, const void* newest_frame,
                                        const float* wt, const float* bias, float* y, double u8_coef, int act,
                                        void* stream) {
@@ -583,10 +742,42 @@ DRA_API int dra_conv1_fwd_koc_ring_seq(const void* frames, const int64_t* slot_f
     return DRA_EINVAL;
   ConvV2Args a;
   a.x[0] = frames; a.wt[0] = wt; a.bias[0] = bias; a.y[0] = y;
-  a.batch = 1; a.act = act; a.coef = u8_coef; a.ring_slot = slot_field_dev; a.ring_cap = capacity;
+  a.batch = 1; a.act = act; a.coef = u8_coef; a.ring_slot = slot_field_dev; a.ring_cap = capacity; a.stack_age = stack_age_field_dev;
   a.slot_seq = seq_dev; a.slot_entries = n_entries; a.slot_stride = stride_bytes;
   a.newest_frame = reinterpret_cast<const uint8_t*>(newest_frame);
+  if (conv_b1_waves() == 8) return launch_conv_v2_pt<VG1, true, 1, 8>(a, 1, dra_stream(stream));
   return launch_conv_v2_pt<VG1, true, 1>(a, 1, dra_stream(stream));
+}
+
+// conv1 of the ring actor's env step with the previous step's head and the environment step fused in (ActorFuse in
+// actor_env.h).  Internal to the library (called by learner.hip): not part of the C ABI.
+template <int NW>
+static int launch_conv1_actor_fused(const ConvV2Args& a, const ActorFuse& f, hipStream_t st) {
+  using T = V2Tile<VG1, 1>;
+  constexpr size_t img = (size_t)VG1::C * T::CS * sizeof(float);
+  constexpr size_t red = (size_t)NW * 16 * 64 * sizeof(float);
+  constexpr size_t bytes = img > red ? img : red;
+  static_assert(bytes <= 64 * 1024, "default dynamic LDS limit");
+  hipLaunchKernelGGL((conv1_actor_fused_kernel<VG1, NW>), dim3(T::TPG + 1, 1, 1), dim3(64 * NW), bytes, st, a, f);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+int dra_conv1_fwd_actor_fused(const void* frames, const int64_t* slot_field_dev, const int32_t* stack_age_field_dev, const unsigned* seq_dev, int n_entries,
+                              int64_t stride_bytes, int64_t capacity, const void* newest_frame, const float* wt,
+                              const float* bias, float* y, double u8_coef, int act, const ActorFuse* f, void* stream) {
+  if (!frames || !slot_field_dev || !seq_dev || n_entries < 1 || stride_bytes < 8 || capacity < VG1::C || !wt || !bias || !y || !f)
+    return DRA_EINVAL;
+  if (f->mode != 1 && f->mode != 2) return DRA_EINVAL;
+  if (f->mode == 2 && (f->e < 1 || f->e >= kMaxEnvSteps || f->n_actions < 1 || f->n_actions > 64 || !f->h4 || !f->wh || !f->bh))
+    return DRA_EINVAL;
+  ConvV2Args a;
+  a.x[0] = frames; a.wt[0] = wt; a.bias[0] = bias; a.y[0] = y;
+  a.batch = 1; a.act = act; a.coef = u8_coef; a.ring_slot = slot_field_dev; a.ring_cap = capacity; a.stack_age = stack_age_field_dev;
+  a.slot_seq = seq_dev; a.slot_entries = n_entries; a.slot_stride = stride_bytes;
+  a.newest_frame = f->mode == 1 ? reinterpret_cast<const uint8_t*>(newest_frame) : nullptr;
+  if (conv_b1_waves() == 8) return launch_conv1_actor_fused<8>(a, *f, dra_stream(stream));
+  return launch_conv1_actor_fused<4>(a, *f, dra_stream(stream));
 }
 
 // Layout conversion [OC][K] <-> [K][OC] for one layer's weight tensor (tests, generic path, and
@@ -607,3 +798,7 @@ DRA_API int dra_transpose_f32(const float* in, float* out, int rows, int cols, v
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
+
+#ifdef DRA_TRACE
+extern "C" int dra_trace_set_conv_v2(void* p) { return dra_trace_set_local(p); }
+#endif

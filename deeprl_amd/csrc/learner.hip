@@ -19,9 +19,10 @@
 //     around optimizer.step() / the actor's forward (DQN_agent.py:30,133) become HIP events: the
 //     optimizer kernel is the only section exclusive with the actor's weight reads, and the
 //     actor's ring writes wait for the update's gather.
-#include "common.h"
+#include "actor_env.h"
 #include <new>
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 #include <chrono>
 
@@ -37,12 +38,7 @@ static const char* kKernelNames[K_COUNT] = {
 enum { P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WH, P_BH, P_COUNT };
 
 constexpr int kFc4Split = 8;     // split-K of the 3136 -> 512 layer (slabs reduced inside head_fused_kernel)
-constexpr int kMaxEnvSteps = 8;  // env transitions per agent step (sgd_update_frequency)
-constexpr size_t kPrmHeadBytes = offsetof(dra_dqn_step_params, idx);  // the part the actor kernels read
 constexpr int kAprmSlots = 16;
-constexpr int kAringSlots = 64;
-constexpr size_t kAprmStride = 512;
-static_assert(kPrmHeadBytes <= kAprmStride && kPrmHeadBytes % 4 == 0, "pinned parameter ring entry");
 
 struct dra_dqn_learner {
   dra_dqn_config c;
@@ -55,6 +51,7 @@ struct dra_dqn_learner {
   int64_t *action_[2], *idx;
   float *reward_[2], *mask_[2];
   int gb;
+  int last_gb;                      // buffer the most recently issued gather filled
   float *y1[3], *y2[3], *y3[3], *h4, *q[3];
   float *ay1, *ay2, *ay3, *aq;  // actor (batch 1)
   float *dq, *dh4, *dy3, *dy2, *dy1, *delta, *prio, *weights, *samp_prob;
@@ -131,6 +128,8 @@ struct dra_dqn_learner {
   hipStream_t side;                 // fork stream for graph branches
   hipEvent_t ev_fork, ev_join[4];
   hipEvent_t ev_actor_done, ev_gather_done, ev_step_done;
+  hipEvent_t last_done;             // the event recorded after the most recent optimizer launch (ev_step_done, or the
+                                    // pipelined step's per-parity event: ONE record per step on the update stream)
   bool actor_pending;               // async mode: an actor graph has been issued and not yet consumed
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
@@ -363,6 +362,7 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
   __shared__ float s_h[3][512];
   __shared__ float s_q[3][64];
   const int b = blockIdx.x, tid = threadIdx.x;
+  DRA_STAMP(TR_HEAD, 0);
   for (int z = 0; z < nz; ++z) {
     const float* bias = (z == 1) ? b4_tg : b4_on;
 #pragma unroll
@@ -382,6 +382,7 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
     }
   }
   __syncthreads();
+  DRA_STAMP(TR_HEAD, 2);
   // heads: wave w owns the (net, action) pairs w, w+4, ... -- one wave-level dot product each, no
   // workgroup barrier per output
   {
@@ -397,6 +398,7 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
     }
   }
   __syncthreads();
+  DRA_STAMP(TR_HEAD, 4);
   const int64_t ab = action[b];
   float dqa;
   {
@@ -426,6 +428,8 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
     const int k = tid + 256 * rep;
     dh4[(int64_t)b * 512 + k] = s_h[0][k] > 0.f ? dqa * wh_on[ab * 512 + k] : 0.f;
   }
+  DRA_STAMP(TR_HEAD, 5);
+  DRA_STAMP_END(TR_HEAD);
 }
 
 // dWh[a][k] = sum_b dq[b][a] * h4[b][k] ;  dbh[a] = sum_b dq[b][a]      (grid = A, 512 threads)
@@ -462,6 +466,7 @@ head_wgrad_kernel(const float* __restrict__ dq, const float* __restrict__ h4, in
 // read their 8-byte index over the host link (~1-2 us, inside the kernel) instead of waiting for a
 // separate 4-5 us copy command on the update's critical path.
 static int launch_gather(dra_dqn_learner* l, hipStream_t st, const int64_t* idx = nullptr) {
+  l->last_gb = l->gb;
   return dra_ring_gather(l->ring, idx ? idx : l->idx, l->c.batch, l->state_[l->gb], l->next_state_[l->gb], l->action_[l->gb], nullptr, nullptr,
                          l->reward_[l->gb], l->mask_[l->gb], (void*)st);
 }
@@ -636,6 +641,7 @@ DRA_API int dra_dqn_learner_update(dra_dqn_learner* l, int use_graph, int per, f
   if (rc) return rc;
   if ((rc = launch_optimizer(l, st))) return rc;
   DRA_HIP(hipEventRecord(l->ev_step_done, st));
+  l->last_done = l->ev_step_done;
   return DRA_OK;
 }
 
@@ -645,6 +651,7 @@ DRA_API int dra_dqn_learner_profile(dra_dqn_learner* l, float* out_ms, int n_out
   if (!l || !out_ms || n_out < K_COUNT) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
   l->profiling = true;
+  l->pa_valid = false;   // the parameters change behind the async actor's copies
   DRA_HIP(hipEventRecord(l->ev[K_GATHER], st));
   int rc = launch_gather(l, st);
   if (!rc) rc = run_body(l, st, 0, 0.f, 0);
@@ -660,6 +667,22 @@ DRA_API int dra_dqn_learner_profile(dra_dqn_learner* l, float* out_ms, int n_out
     DRA_HIP(hipEventElapsedTime(&ms, l->ev[k], l->ev[k + 1]));
     out_ms[k] = ms;
   }
+  return DRA_OK;
+}
+
+// The minibatch the most recently issued update consumed (device pointers into the learner's own buffers: uint8
+// [B][4][84][84] states / next states, int64 [B] actions, f32 [B] n-step rewards and masks).  Valid until two more
+// updates have been issued; callers synchronise first.  For checkers (bench.py's parity_check replays the update on
+// the CPU oracle), not for the hot path.
+DRA_API int dra_dqn_learner_last_minibatch(dra_dqn_learner* l, void** state, void** next_state, void** action, void** reward,
+                                           void** mask) {
+  if (!l) return DRA_EINVAL;
+  const int g = l->last_gb;
+  if (state) *state = l->state_[g];
+  if (next_state) *next_state = l->next_state_[g];
+  if (action) *action = l->action_[g];
+  if (reward) *reward = l->reward_[g];
+  if (mask) *mask = l->mask_[g];
   return DRA_OK;
 }
 
@@ -687,12 +710,6 @@ DRA_API int dra_dqn_learner_sync_target(dra_dqn_learner* l, void* stream) {
 //                      and copies it to the stack.
 //   actor_head_kernel: fc4 split-K reduction + bias + ReLU + head + epsilon-greedy with the
 //                      HOST-drawn (random_action, dice) -> action record of `slot`.
-__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
 __global__ void __launch_bounds__(256)
 env_stack_kernel(const dra_dqn_step_params* __restrict__ prm, int e, uint8_t* __restrict__ frames,
                  double* __restrict__ rewards, int32_t* __restrict__ masks, int64_t capacity, uint64_t seed,
@@ -712,11 +729,8 @@ env_stack_kernel(const dra_dqn_step_params* __restrict__ prm, int e, uint8_t* __
       dst[w] = v;
     }
     if (threadIdx.x == 0) {
-      const uint64_t hh = mix64((seed + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
-      const uint32_t u = (uint32_t)(hh >> 32) % 10u;
-      rewards[newest] = (u == 0) ? -1.0 : ((u == 9) ? 1.0 : 0.0);
-      const uint64_t h2 = mix64((seed + 2) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
-      masks[newest] = ((h2 % (uint64_t)done_period) == 0) ? 0 : 1;
+      rewards[newest] = synth_reward(seed, prm->rcounter[e]);
+      masks[newest] = synth_mask(seed, prm->rcounter[e], done_period);
     }
   } else {
     for (int w = threadIdx.x; w < 882; w += blockDim.x) dst[w] = src[w];
@@ -780,11 +794,8 @@ __device__ __forceinline__ void synth_transition(const dra_dqn_step_params* __re
   const uint64_t base = seed * 0x9E3779B97F4A7C15ull + (uint64_t)counter * 882ull;
   for (int w = threadIdx.x; w < 882; w += blockDim.x) dst[w] = mix64(base + (uint64_t)w);
   if (threadIdx.x == 0) {
-    const uint64_t hh = mix64((seed + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
-    const uint32_t u = (uint32_t)(hh >> 32) % 10u;
-    rewards[slot] = (u == 0) ? -1.0 : ((u == 9) ? 1.0 : 0.0);
-    const uint64_t h2 = mix64((seed + 2) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
-    masks[slot] = ((h2 % (uint64_t)done_period) == 0) ? 0 : 1;
+    rewards[slot] = synth_reward(seed, prm->rcounter[e]);
+    masks[slot] = synth_mask(seed, prm->rcounter[e], done_period);
   }
 }
 
@@ -803,6 +814,7 @@ actor_fc4_kernel(const float* __restrict__ x, const float* __restrict__ w, const
   const int nv = in_features >> 2;
   const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w + (int64_t)row * in_features);
   const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+  DRA_STAMP(TR_A_FC4, 0);
   float4 wv[R], xv[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) {
@@ -822,6 +834,8 @@ actor_fc4_kernel(const float* __restrict__ x, const float* __restrict__ w, const
     const float v = acc + bias[row];
     h4[row] = v > 0.f ? v : 0.f;
   }
+  DRA_STAMP(TR_A_FC4, 5);
+  DRA_STAMP_END(TR_A_FC4);
 }
 
 __global__ void __launch_bounds__(256)
@@ -959,7 +973,7 @@ static int run_actor_steps_v3(dra_dqn_learner* l, int n_env, const float* P, hip
                      (int)c.env_done_period);
   DRA_LAUNCH_CHECK();
   for (int e = 0; e < n_env; ++e) {
-    if ((rc = dra_conv1_fwd_koc_ring(frames, &l->prm_dev->slot[e], c.ring_capacity, P + o[P_W1], P + o[P_B1], l->ay1,
+    if ((rc = dra_conv1_fwd_koc_ring(frames, &l->prm_dev->slot[e], &l->prm_dev->stack_age[e], c.ring_capacity, P + o[P_W1], P + o[P_B1], l->ay1,
                                      c.u8_coef, DRA_ACT_RELU, s)))
       return rc;
     const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
@@ -1067,10 +1081,6 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
 // device step counter; for the LAST env step of an agent step it also performs what the next agent step would
 // start with -- the first observation of the next block (env.step's return value, envs.py:140-141) -- and then
 // advances the counter.  env_frame_ring_kernel primes the very first block.
-__device__ __forceinline__ const dra_dqn_step_params* aring_entry(const uint8_t* ring, unsigned seq) {
-  return reinterpret_cast<const dra_dqn_step_params*>(ring + (size_t)(seq % kAringSlots) * kAprmStride);
-}
-
 // synthetic observation `e` of block `prm` into a PENDING buffer (frame, reward, mask of the transition it starts)
 __device__ __forceinline__ void synth_pending(const dra_dqn_step_params* __restrict__ prm, int e, uint8_t* __restrict__ frame,
                                               double* __restrict__ reward, int32_t* __restrict__ mask, uint64_t seed,
@@ -1081,11 +1091,8 @@ __device__ __forceinline__ void synth_pending(const dra_dqn_step_params* __restr
   const uint64_t base = seed * 0x9E3779B97F4A7C15ull + (uint64_t)counter * 882ull;
   for (int w = threadIdx.x; w < 882; w += blockDim.x) dst[w] = mix64(base + (uint64_t)w);
   if (threadIdx.x == 0) {
-    const uint64_t hh = mix64((seed + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
-    const uint32_t u = (uint32_t)(hh >> 32) % 10u;
-    *reward = (u == 0) ? -1.0 : ((u == 9) ? 1.0 : 0.0);
-    const uint64_t h2 = mix64((seed + 2) * 0x9E3779B97F4A7C15ull + (uint64_t)counter);
-    *mask = ((h2 % (uint64_t)done_period) == 0) ? 0 : 1;
+    *reward = synth_reward(seed, prm->rcounter[e]);
+    *mask = synth_mask(seed, prm->rcounter[e], done_period);
   }
 }
 
@@ -1096,17 +1103,18 @@ env_frame_ring_kernel(const uint8_t* __restrict__ ring, const unsigned* __restri
 }
 
 __global__ void __launch_bounds__(256)
-actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restrict__ seq, int e, int last,
+actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restrict__ seq, int e, int last, int commit,
                            const float* __restrict__ h4, const float* __restrict__ wh, const float* __restrict__ bh, int A,
                            uint8_t* __restrict__ ring_actions, float* __restrict__ q_out, uint8_t* __restrict__ frames,
                            double* __restrict__ rewards, int32_t* __restrict__ masks, uint8_t* __restrict__ pend_frame,
                            double* __restrict__ pend_reward, int32_t* __restrict__ pend_mask, uint64_t seed,
                            int done_period) {
   __shared__ float s_q[64];
+  DRA_STAMP(TR_A_HEAD, 0);
   const unsigned sq = *seq;
   const dra_dqn_step_params* __restrict__ prm = aring_entry(ring, sq);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (e == 0 && prm->counter[0] >= 0) {
+  if (commit && e == 0 && prm->counter[0] >= 0) {
     // feed: the observation this step started from becomes ring slot[0] now (not when it was produced: a
     // minibatch gathered in between must still see the slot's previous contents)
     const int64_t slot = prm->slot[0];
@@ -1123,6 +1131,7 @@ actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restric
     if (lane == 0) s_q[a] = part + bh[a];
   }
   __syncthreads();   // (also: every thread is done reading the pending frame)
+  DRA_STAMP(TR_A_HEAD, 2);
   if (threadIdx.x < A && q_out) q_out[threadIdx.x] = s_q[threadIdx.x];
   if (threadIdx.x == 0) {
     int best = 0;
@@ -1137,9 +1146,59 @@ actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restric
     synth_pending(aring_entry(ring, sq + 1), 0, pend_frame, pend_reward, pend_mask, seed, done_period);
     if (threadIdx.x == 0) *seq = sq + 1;   // every thread read *seq before the barrier above
   }
+  DRA_STAMP(TR_A_HEAD, 5);
+  DRA_STAMP_END(TR_A_HEAD);
+}
+
+// DRA_VAR_ACTOR_FUSED_CONV1: 4 launches per env step instead of 5.  The head of env step e-1 (action values,
+// epsilon-greedy, action record) and the environment step that produces observation e run in front of conv1 of step e
+// inside ONE launch (conv_v2.hip, ActorFuse): every conv1 workgroup derives the action and generates the rows of the new
+// observation it convolves, one extra workgroup writes the action and the whole observation to the replay ring.  Env
+// step 0's launch commits the pending observation instead; the head of the LAST env step keeps its own kernel (it also
+// produces the next agent step's first observation and advances the step counter).  Same arithmetic, same order:
+// bit-identical action values, actions and ring contents.
+static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
+  const dra_dqn_config& c = l->c;
+  void *frames, *actions, *rewards, *masks;
+  int rc = dra_ring_pointers(l->ring, &frames, &actions, &rewards, &masks);
+  if (rc) return rc;
+  const int64_t* o = c.offset;
+  void* s = (void*)st;
+  ActorFuse f;
+  memset(&f, 0, sizeof(f));
+  f.n_actions = c.n_actions; f.done_period = (int)c.env_done_period; f.h4 = l->ah4; f.wh = P + o[P_WH]; f.bh = P + o[P_BH];
+  f.aring = l->aring_dev; f.seq = l->aring_seq; f.frames = (uint8_t*)frames; f.actions = (uint8_t*)actions;
+  f.rewards = (double*)rewards; f.masks = (int32_t*)masks; f.q_out = l->aq; f.pend_frame = l->pend_frame;
+  f.pend_reward = l->pend_reward; f.pend_mask = l->pend_mask; f.seed = (uint64_t)c.env_seed;
+  for (int e = 0; e < n_env; ++e) {
+    const int64_t* slot_field = reinterpret_cast<const int64_t*>(l->aring_dev + offsetof(dra_dqn_step_params, slot)) + e;
+    const int32_t* age_field = reinterpret_cast<const int32_t*>(l->aring_dev + offsetof(dra_dqn_step_params, stack_age)) + e;
+    f.mode = e == 0 ? 1 : 2;
+    f.e = e;
+    if ((rc = dra_conv1_fwd_actor_fused(frames, slot_field, age_field, l->aring_seq, kAringSlots, (int64_t)kAprmStride, c.ring_capacity,
+                                        e == 0 ? l->pend_frame : nullptr, P + o[P_W1], P + o[P_B1], l->ay1, c.u8_coef,
+                                        DRA_ACT_RELU, &f, s)))
+      return rc;
+    const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
+    float* y2[1] = {l->ay2};
+    if ((rc = dra_conv_fwd_koc(2, 1, x2, w2, b2, y2, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+    const void* x3[1] = {l->ay2}; const float* w3[1] = {P + o[P_W3]}; const float* b3[1] = {P + o[P_B3]};
+    float* y3[1] = {l->ay3};
+    if ((rc = dra_conv_fwd_koc(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
+    hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
+                       l->ah4, 3136);
+    DRA_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(256), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq,
+                     n_env - 1, 1, 0, (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq,
+                     (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
+                     (uint64_t)c.env_seed, (int)c.env_done_period);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
 }
 
 static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
+  if (l->variant & DRA_VAR_ACTOR_FUSED_CONV1) return run_actor_steps_ring_fused(l, n_env, P, st);
   const dra_dqn_config& c = l->c;
   void *frames, *actions, *rewards, *masks;
   int rc = dra_ring_pointers(l->ring, &frames, &actions, &rewards, &masks);
@@ -1148,7 +1207,8 @@ static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, h
   void* s = (void*)st;
   for (int e = 0; e < n_env; ++e) {
     const int64_t* slot_field = reinterpret_cast<const int64_t*>(l->aring_dev + offsetof(dra_dqn_step_params, slot)) + e;
-    if ((rc = dra_conv1_fwd_koc_ring_seq(frames, slot_field, l->aring_seq, kAringSlots, (int64_t)kAprmStride, c.ring_capacity,
+    const int32_t* age_field = reinterpret_cast<const int32_t*>(l->aring_dev + offsetof(dra_dqn_step_params, stack_age)) + e;
+    if ((rc = dra_conv1_fwd_koc_ring_seq(frames, slot_field, age_field, l->aring_seq, kAringSlots, (int64_t)kAprmStride, c.ring_capacity,
                                          e == 0 ? l->pend_frame : nullptr, P + o[P_W1], P + o[P_B1], l->ay1, c.u8_coef,
                                          DRA_ACT_RELU, s)))
       return rc;
@@ -1161,7 +1221,7 @@ static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, h
     hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
                        l->ah4, 3136);
     hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(256), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq, e,
-                       (int)(e == n_env - 1), (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions,
+                       (int)(e == n_env - 1), 1, (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions,
                        l->aq, (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
                        (uint64_t)c.env_seed, (int)c.env_done_period);
     DRA_LAUNCH_CHECK();
@@ -1243,7 +1303,7 @@ static int run_actor_steps_v2(dra_dqn_learner* l, int n_env, const float* P, hip
                      (uint8_t*)frames, (double*)rewards, (int32_t*)masks, (uint64_t)c.env_seed, (int)c.env_done_period);
   DRA_LAUNCH_CHECK();
   for (int e = 0; e < n_env; ++e) {
-    if ((rc = dra_conv1_fwd_koc_ring(frames, &l->prm_dev->slot[e], c.ring_capacity, P + o[P_W1], P + o[P_B1], l->ay1,
+    if ((rc = dra_conv1_fwd_koc_ring(frames, &l->prm_dev->slot[e], &l->prm_dev->stack_age[e], c.ring_capacity, P + o[P_W1], P + o[P_B1], l->ay1,
                                      c.u8_coef, DRA_ACT_RELU, s)))
       return rc;
     const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
@@ -1366,13 +1426,20 @@ DRA_API int dra_dqn_learner_trace_read(dra_dqn_learner* l, float* out_ms, int ma
 // The gather sits between the actor graph that wrote this step's transitions and the one that overwrites the
 // oldest ring slots, in stream order -- no event on either chain's critical path: the waits below (minibatch
 // buffer free again, optimizer of step t-1 done) refer to work issued a whole step earlier.
+static int debug_nosync() {   // TIMING EXPERIMENTS ONLY (results are then wrong): bit 0 drops the update stream's wait for the
+  static int v = -1;          // gather, bit 1 the minibatch-free event, bit 2 the actor stream's waits
+  if (v < 0) { const char* e = getenv("DRA_DEBUG_NOSYNC"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, hipStream_t su,
                           hipStream_t sa, int k) {
   const int B = l->c.batch;
   const int par = (int)(l->step_no & 1);
+  const int dbg = debug_nosync();
   int rc;
   if (do_update) {
-    if (l->mb_used[par]) DRA_HIP(hipStreamWaitEvent(sa, l->ev_mb_free[par], 0));
+    if (l->mb_used[par] && !(dbg & 4)) DRA_HIP(hipStreamWaitEvent(sa, l->ev_mb_free[par], 0));
     const int64_t* pinned = (l->variant & DRA_VAR_PINNED_IDX) ? l->idx_stage + (size_t)k * 1024 : nullptr;
     if (!pinned)
       DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, sa));
@@ -1387,7 +1454,7 @@ static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, in
   bool seeded = false;
   if (prm->n_env > 0) {
     if (l->pa_valid && l->pa_cur != (par ^ 1)) l->pa_valid = false;   // copies out of phase with the step parity
-    DRA_HIP(hipStreamWaitEvent(sa, l->ev_step_done, 0));              // the optimizer that produced the copy read below
+    if (!(dbg & 4) && l->last_done) DRA_HIP(hipStreamWaitEvent(sa, l->last_done, 0));   // the optimizer that produced the copy read below
     if (!l->pa_valid) {
       l->pa_cur = par ^ 1;
       DRA_HIP(hipMemcpyAsync(l->pa[l->pa_cur], l->p, (size_t)l->c.n_params * sizeof(float), hipMemcpyDeviceToDevice, sa));
@@ -1404,14 +1471,16 @@ static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, in
   }
   DRA_HIP(hipEventRecord(l->stage_ev[k], sa));  // staging slot k: parameter block copy and the gather's pinned index reads
   if (do_update) {
-    DRA_HIP(hipStreamWaitEvent(su, l->ev_mb_ready[par], 0));
+    if (!(dbg & 1)) DRA_HIP(hipStreamWaitEvent(su, l->ev_mb_ready[par], 0));
     if (seeded) DRA_HIP(hipStreamWaitEvent(su, l->ev_join[0], 0));    // the seed copy read the parameters this step overwrites
     TRACE(3, su);
     if ((rc = pipe_graph(l, su, par))) return rc;
     TRACE(4, su);
     if (l->tr_ev && l->tr_n < l->tr_cap) l->tr_n++;
-    DRA_HIP(hipEventRecord(l->ev_step_done, su));
+    // ONE event per step on the update stream (each stream-level event costs ~3.5 us of queue time between two graph
+    // launches: profiles/r02d_*): it means both 'minibatch buffer par is free' and 'optimizer of this step is done'
     DRA_HIP(hipEventRecord(l->ev_mb_free[par], su));
+    l->last_done = l->ev_mb_free[par];
     l->mb_used[par] = true;
     if (l->pa_valid) l->pa_cur = par;   // the graph's optimizer wrote copy `par`
     l->step_no++;
@@ -1423,6 +1492,8 @@ static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, in
 // captured graph (or the eager kernels).
 static int issue_actor(dra_dqn_learner* l, const dra_dqn_step_params* prm, int k, const float* P, hipStream_t st, bool use_graph) {
   int rc;
+  if (!(l->variant & (DRA_VAR_ACTOR_V2 | DRA_VAR_ACTOR_V3)))     // the first-generation actor copies the last 4 ring frames
+    for (int e = 0; e < prm->n_env; ++e) if (prm->stack_age[e] != 3) return DRA_EINVAL;
   const bool v3 = l->variant & DRA_VAR_ACTOR_V3;
   if (v3) { if ((rc = stage_actor_params(l, prm, st, true))) return rc; }
   else DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes, hipMemcpyHostToDevice, st));
@@ -1479,7 +1550,7 @@ static int step_pipelined2(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
     DRA_HIP(hipMemcpyAsync(l->prm_dev, &l->prm_stage[k], kPrmHeadBytes + (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, sa));
     TRACE(0, sa);
     if (l->pa_valid && l->pa_cur != par) l->pa_valid = false;
-    DRA_HIP(hipStreamWaitEvent(sa, l->ev_step_done, 0));   // optimizer k-2 produced the copy this graph reads
+    if (l->last_done) DRA_HIP(hipStreamWaitEvent(sa, l->last_done, 0));   // optimizer k-2 produced the copy this graph reads
     if (!l->pa_valid) {
       l->pa_cur = par;
       DRA_HIP(hipMemcpyAsync(l->pa[par], l->p, (size_t)l->c.n_params * sizeof(float), hipMemcpyDeviceToDevice, sa));
@@ -1503,8 +1574,8 @@ static int step_pipelined2(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
     if ((rc = pipe_graph(l, su, q))) return rc;
     TRACE(4, su);
     if (l->tr_ev && l->tr_n < l->tr_cap) l->tr_n++;
-    DRA_HIP(hipEventRecord(l->ev_step_done, su));
-    DRA_HIP(hipEventRecord(l->ev_mb_free[q], su));
+    DRA_HIP(hipEventRecord(l->ev_mb_free[q], su));   // one record: minibatch buffer q free AND optimizer done
+    l->last_done = l->ev_mb_free[q];
     l->mb_used[q] = true;
     if (l->pa_valid) l->pa_cur = q;     // the optimizer wrote copy q = the one the NEXT call's graph reads
     l->ag_have_prev = false;
@@ -1600,6 +1671,7 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
       if ((rc = body_graph(l, su))) return rc;
       if ((rc = launch_optimizer(l, su))) return rc;
       DRA_HIP(hipEventRecord(l->ev_step_done, su));
+      l->last_done = l->ev_step_done;
     }
     DRA_HIP(hipEventRecord(l->stage_ev[k], su));
     return DRA_OK;
@@ -1624,7 +1696,7 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
     const float* pact = l->p;
     if (dbuf) {
       if (!l->pa_valid) {  // (re)seed the actor copy: first async step, or the parameters changed behind it
-        DRA_HIP(hipStreamWaitEvent(sa, l->ev_step_done, 0));   // after the last optimiser step ...
+        if (l->last_done) DRA_HIP(hipStreamWaitEvent(sa, l->last_done, 0));   // after the last optimiser step ...
         DRA_HIP(hipMemcpyAsync(l->pa[l->pa_cur], l->p, (size_t)l->c.n_params * sizeof(float), hipMemcpyDeviceToDevice, sa));
         DRA_HIP(hipEventRecord(l->ev_join[0], sa));            // ... and before this step's (see below)
         l->pa_valid = true;
@@ -1645,13 +1717,30 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
       if ((rc = launch_optimizer(l, su, l->pa[l->pa_cur ^ 1]))) return rc;
       l->pa_cur ^= 1;
       DRA_HIP(hipEventRecord(l->ev_step_done, su));
+      l->last_done = l->ev_step_done;
     } else {
       if (prm->n_env > 0) DRA_HIP(hipStreamWaitEvent(su, l->ev_actor_done, 0));  // config.lock: optimizer excludes actor reads
       if ((rc = launch_optimizer(l, su))) return rc;
       DRA_HIP(hipEventRecord(l->ev_step_done, su));
+      l->last_done = l->ev_step_done;
       DRA_HIP(hipStreamWaitEvent(sa, l->ev_step_done, 0));  // the next actor sees whole optimizer steps only
     }
   }
   DRA_HIP(hipEventRecord(l->stage_ev[k], do_update ? su : sa));
   return DRA_OK;
 }
+
+#ifdef DRA_TRACE
+// Measurement build only (libdeeprl_amd_trace.so): points every translation unit's phase-trace pointer at `buf`
+// (TR_REGIONS x kTraceWgs x 8 u64, device memory; null switches the stamps off).  tools/phase_trace.py.
+extern "C" int dra_trace_set_conv_v2(void*);
+extern "C" int dra_trace_set_ring(void*);
+extern "C" int dra_trace_set_optim(void*);
+extern "C" int dra_trace_set_fused(void*);
+DRA_API int dra_trace_set(void* buf) {
+  int rc = dra_trace_set_local(buf);
+  rc |= dra_trace_set_conv_v2(buf); rc |= dra_trace_set_ring(buf); rc |= dra_trace_set_optim(buf); rc |= dra_trace_set_fused(buf);
+  return rc;
+}
+DRA_API int dra_trace_layout(int* regions, int* wgs) { *regions = TR_REGIONS; *wgs = kTraceWgs; return DRA_OK; }
+#endif

@@ -149,6 +149,7 @@ struct LinDgradOne {
     const int bm = bid / tiles_n, bn = bid - bm * tiles_n;
     const int m0 = bm * 32, n0 = bn * 32;
     const int ncol = min(n0 + li, I - 1);
+    DRA_STAMP(TR_FC_B, 0);
     const int kb = wave * KW + h * NJ;
     float breg[NJ];
     {
@@ -177,12 +178,16 @@ struct LinDgradOne {
       const int e = tid + 256 * q, row = e / O, col = e - row * O;
       lds[row * LDA + col] = araw[q];
     }
+    DRA_STAMP(TR_FC_B, 1);
     __syncthreads();
+    DRA_STAMP(TR_FC_B, 2);
     f32x16 acc = zero16();
     const float* ap = lds + li * LDA + kb;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[j], breg[j], acc, 0, 0, 0);
+    DRA_STAMP(TR_FC_B, 3);
     __syncthreads();
+    DRA_STAMP(TR_FC_B, 4);
     float s[4];
     reduce4(lds, acc, wave, lane, s);
 #pragma unroll
@@ -190,6 +195,8 @@ struct LinDgradOne {
       const int m = m0 + mfma_row(wave * 4 + q, h);
       if (m < B && n0 + li < I) dx[(int64_t)m * I + n0 + li] = xact ? s[q] * act_grad(aux[q], act) : s[q];
     }
+    DRA_STAMP(TR_FC_B, 5);
+    DRA_STAMP_END(TR_FC_B);
   }
 };
 
@@ -222,6 +229,7 @@ struct LinFwdSlabsOne {
     const int m0 = bm * 32, n0 = bn * 32 * NT, k0 = s * KPS;
     const float* __restrict__ xz = x[z];
     const float* __restrict__ wz = w[z];
+    DRA_STAMP(TR_FC4_F, 0);
     float4 xa[RX], wa[RWV];
 #pragma unroll
     for (int q = 0; q < RX; ++q) {
@@ -254,7 +262,9 @@ struct LinFwdSlabsOne {
         dw_[0] = wa[q].x; dw_[1] = wa[q].y; dw_[2] = wa[q].z; dw_[3] = wa[q].w;
       }
     }
+    DRA_STAMP(TR_FC4_F, 1);
     __syncthreads();
+    DRA_STAMP(TR_FC4_F, 2);
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = zero16();
@@ -266,7 +276,9 @@ struct LinFwdSlabsOne {
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[t * 32 * LD + j], acc[t], 0, 0, 0);
     }
+    DRA_STAMP(TR_FC4_F, 3);
     __syncthreads();
+    DRA_STAMP(TR_FC4_F, 4);
     float* out = slabs + ((int64_t)(z * KS + s) * B) * O;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -279,6 +291,8 @@ struct LinFwdSlabsOne {
         if (m < B && n < O) out[(int64_t)m * O + n] = sum[q];
       }
     }
+    DRA_STAMP(TR_FC4_F, 5);
+    DRA_STAMP_END(TR_FC4_F);
   }
 };
 
@@ -325,6 +339,8 @@ struct ConvDgradOne {
     const int ph = phi / S, pw = phi - ph * S;
     const int c0 = mt * 32, p0 = grp * PT * 32;
     const int np = min(32 * PT, PP - p0);
+    [[maybe_unused]] constexpr int TRR = (G::C == 32) ? TR_CONV2_B : TR_CONV3_B;
+    DRA_STAMP(TRR, 0);
     // ---- weights: lane li <-> input channel c0 + li
     float4 areg[NT][OCH / 4];
     {
@@ -378,7 +394,9 @@ struct ConvDgradOne {
         lds[e] = in ? v : 0.f;
       }
     }
+    DRA_STAMP(TRR, 1);
     __syncthreads();
+    DRA_STAMP(TRR, 2);
     // ---- MFMA: B operand of lane li = padded gradient at (ih2 - kh2 + PAD, iw2 - kw2 + PAD)
     f32x16 acc[PT];
     const float* bptr[PT];
@@ -401,7 +419,9 @@ struct ConvDgradOne {
         }
       }
     }
+    DRA_STAMP(TRR, 3);
     __syncthreads();
+    DRA_STAMP(TRR, 4);
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       float s[4];
@@ -413,6 +433,8 @@ struct ConvDgradOne {
           dx[((int64_t)bi * G::C + c) * G::HW + pix[t]] = xact ? s[q] * act_grad(aux[t][q], act) : s[q];
       }
     }
+    DRA_STAMP(TRR, 5);
+    DRA_STAMP_END(TRR);
   }
 };
 
@@ -463,6 +485,8 @@ struct ConvWgradOne {
     const int ir0 = chunk * ROWS * S;                      // first input row
     float* img = lds;
     float* dyl = lds + IMG;
+    [[maybe_unused]] constexpr int TRR = (G::C == 4) ? TR_CONV1_B : ((G::C == 32) ? TR_CONV2_B : TR_CONV3_B);
+    DRA_STAMP(TRR, 0);
     // ---- issue all loads: dY chunk, then the image rows
     constexpr int NDY = G::OC * NPOS, RD = (NDY + 255) / 256;
     float draw[RD];
@@ -540,7 +564,9 @@ struct ConvWgradOne {
         dyl[pos * LDB + oc] = ow < OH ? v : 0.f;
       }
     }
+    DRA_STAMP(TRR, 1);
     __syncthreads();
+    DRA_STAMP(TRR, 2);
     // ---- MFMA: wave w owns tiles w, w+4, ...; tile t = (mt, nt), mt = t / NTL
     f32x16 acc[TPW];
 #pragma unroll
@@ -562,6 +588,7 @@ struct ConvWgradOne {
         }
       }
     }
+    DRA_STAMP(TRR, 3);
     // ---- slab stores (rows = k, 32 lanes along oc: 128-byte rows)
     const int64_t slab = (int64_t)bi * NCHUNK + chunk;
     float* dws = dw + slab * slab_stride;
@@ -583,5 +610,7 @@ struct ConvWgradOne {
       for (int pos = 0; pos < NPOS; ++pos) sb += dyl[pos * LDB + tid];
       db[slab * slab_stride + tid] = sb;
     }
+    DRA_STAMP(TRR, 5);
+    DRA_STAMP_END(TRR);
   }
 };

@@ -88,6 +88,7 @@ grad_fold_norm_kernel(float* __restrict__ grad, const FoldSegs fs, double* __res
   __shared__ double s_red[4];
   const int tid = threadIdx.x, bid = blockIdx.x;
   float acc = 0.f;
+  DRA_STAMP(TR_NORM, 0);
   if (bid < fs.first_block[fs.n_segs]) {
     int sg = 0;
     while (sg + 1 < fs.n_segs && bid >= fs.first_block[sg + 1]) ++sg;
@@ -140,10 +141,13 @@ grad_fold_norm_kernel(float* __restrict__ grad, const FoldSegs fs, double* __res
       acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
   }
+  DRA_STAMP(TR_NORM, 4);
   double d = wave_sum((double)acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = d;
   __syncthreads();
   if (tid == 0) partials[bid] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  DRA_STAMP(TR_NORM, 5);
+  DRA_STAMP_END(TR_NORM);
 }
 
 // grad[0, n): segments (contiguous from 0, 4-float aligned) are folded from their slabs
@@ -228,78 +232,79 @@ __device__ __forceinline__ float clip_coef_from_partials(const double* __restric
 
 // torch.optim.RMSprop:  sq = a*sq + (1-a)*g*g ; centered: ga = a*ga + (1-a)*g,
 // avg = sqrt(sq - ga*ga) + eps  else  avg = sqrt(sq) + eps ;  p -= lr * g / avg.
+// NV float4 per thread, every operand of both requested before the clip coefficient is reduced from the partials
+// (the operands do not depend on it): one exposed memory latency, and the grid (n / (4 * 256 * NV) workgroups = 824 for
+// the DQN learner) fits the update chain's CU partition in ONE round -- with one float4 per thread the 1647 workgroups
+// ran as 1280 + 367 on 160 CUs (phase trace, profiles/r02a_phase_async.json: span 11.0 us for 6.0 us workgroups).
+constexpr int kStepNV = 2;
+
+__device__ __forceinline__ void rmsprop_elem(float& p, float g, float& s, float& a, float coef, float alpha, float oma,
+                                             float lr, float eps, int centered) {
+  const float gk = g * coef;
+  s = s * alpha + oma * gk * gk;
+  float avg;
+  if (centered) {
+    a = a * alpha + oma * gk;
+    avg = sqrtf(s - a * a) + eps;
+  } else {
+    avg = sqrtf(s) + eps;
+  }
+  p = p - lr * (gk / avg);
+}
+
 __global__ void __launch_bounds__(256)
 rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, float* __restrict__ ga,
                     int64_t n, const double* __restrict__ partials, int n_partials, float max_norm, float lr,
                     float alpha, float eps, int centered, float* __restrict__ out_norm, float* __restrict__ p_copy) {
   const float oma = 1.f - alpha;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t n4 = n >> 2;
-  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // The first (for the DQN learner: the only) float4 of every operand is requested BEFORE the clip coefficient
-  // is reduced from the partials -- the operands do not depend on it, so the kernel exposes one memory
-  // latency instead of two.
-  const int64_t ic = i0 < n4 ? i0 : (n4 > 0 ? n4 - 1 : 0);
-  // (unconditional loads, n >= 4 is checked by the launcher: a branch or a default value here turns the loaded
-  // registers into phi copies and the compiler waits for them on the spot)
-  const float4 P0 = reinterpret_cast<float4*>(p)[ic];
-  const float4 G00 = reinterpret_cast<const float4*>(g)[ic];
-  const float4 S0 = reinterpret_cast<float4*>(sq)[ic];
-  const float4 A0 = reinterpret_cast<float4*>(centered ? ga : sq)[ic];
+  const int64_t i0 = (int64_t)blockIdx.x * (256 * kStepNV) + threadIdx.x;
+  DRA_STAMP(TR_STEP, 0);
+  // (unconditional loads of a clamped index, n >= 4 is checked by the launcher: a branch or a default value here turns
+  // the loaded registers into phi copies and the compiler waits for them on the spot)
+  float4 P[kStepNV], G[kStepNV], S[kStepNV], A[kStepNV];
+#pragma unroll
+  for (int v = 0; v < kStepNV; ++v) {
+    const int64_t i = i0 + 256 * v;
+    const int64_t ic = i < n4 ? i : n4 - 1;
+    P[v] = reinterpret_cast<float4*>(p)[ic];
+    G[v] = reinterpret_cast<const float4*>(g)[ic];
+    S[v] = reinterpret_cast<float4*>(sq)[ic];
+    A[v] = reinterpret_cast<float4*>(centered ? ga : sq)[ic];
+  }
   __builtin_amdgcn_sched_barrier(0);
   const float coef = clip_coef_from_partials(partials, n_partials, max_norm, out_norm);
-  for (int64_t i = i0; i < n4; i += stride) {
-    float4 P, G0, S, A;
-    if (i == i0) {
-      P = P0; G0 = G00; S = S0; A = A0;
-    } else {
-      P = reinterpret_cast<float4*>(p)[i];
-      G0 = reinterpret_cast<const float4*>(g)[i];
-      S = reinterpret_cast<float4*>(sq)[i];
-      A = centered ? reinterpret_cast<float4*>(ga)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float* pp = &P.x; const float* gg = &G0.x; float* ss = &S.x; float* aa = &A.x;
+  DRA_STAMP(TR_STEP, 2);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gk = gg[k] * coef;
-      ss[k] = ss[k] * alpha + oma * gk * gk;
-      float avg;
-      if (centered) {
-        aa[k] = aa[k] * alpha + oma * gk;
-        avg = sqrtf(ss[k] - aa[k] * aa[k]) + eps;
-      } else {
-        avg = sqrtf(ss[k]) + eps;
-      }
-      pp[k] = pp[k] - lr * (gk / avg);
+  for (int v = 0; v < kStepNV; ++v) {
+    const int64_t i = i0 + 256 * v;
+    if (i < n4) {
+      float* pp = &P[v].x; const float* gg = &G[v].x; float* ss = &S[v].x; float* aa = &A[v].x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rmsprop_elem(pp[k], gg[k], ss[k], aa[k], coef, alpha, oma, lr, eps, centered);
+      reinterpret_cast<float4*>(p)[i] = P[v];
+      if (p_copy) reinterpret_cast<float4*>(p_copy)[i] = P[v];
+      reinterpret_cast<float4*>(sq)[i] = S[v];
+      if (centered) reinterpret_cast<float4*>(ga)[i] = A[v];
     }
-    reinterpret_cast<float4*>(p)[i] = P;
-    if (p_copy) reinterpret_cast<float4*>(p_copy)[i] = P;
-    reinterpret_cast<float4*>(sq)[i] = S;
-    if (centered) reinterpret_cast<float4*>(ga)[i] = A;
   }
-  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float gk = g[i] * coef;
-    float s = sq[i] * alpha + oma * gk * gk;
-    float avg;
-    if (centered) {
-      const float a = ga[i] * alpha + oma * gk;
-      ga[i] = a;
-      avg = sqrtf(s - a * a) + eps;
-    } else {
-      avg = sqrtf(s) + eps;
-    }
-    sq[i] = s;
-    const float pn = p[i] - lr * (gk / avg);
-    p[i] = pn;
-    if (p_copy) p_copy[i] = pn;
+  // tail (n not a multiple of 4): the last few floats, by the first threads of workgroup 0
+  const int64_t t = (n4 << 2) + threadIdx.x;
+  if (blockIdx.x == 0 && t < n) {
+    float pv = p[t], sv = sq[t], av = centered ? ga[t] : 0.f;
+    rmsprop_elem(pv, g[t], sv, av, coef, alpha, oma, lr, eps, centered);
+    p[t] = pv;
+    if (p_copy) p_copy[t] = pv;
+    sq[t] = sv;
+    if (centered) ga[t] = av;
   }
+  DRA_STAMP(TR_STEP, 5);
+  DRA_STAMP_END(TR_STEP);
 }
 
-static inline int step_blocks(int64_t n) {
-  int64_t b = ((n >> 2) + 255) / 256;
-  if (b < 1) b = 1;
-  if (b > 2048) b = 2048;
-  return (int)b;
+static inline int64_t step_blocks(int64_t n) {   // every float4 has its own thread slot: no grid-stride loop
+  int64_t b = ((n >> 2) + 256 * kStepNV - 1) / (256 * kStepNV);
+  return b < 1 ? 1 : b;
 }
 
 // param_copy (optional): the updated parameters are ALSO written there -- the async actor of the fused DQN
@@ -313,7 +318,8 @@ DRA_API int dra_rmsprop_step_copy(float* param, const float* grad, float* square
     return DRA_EINVAL;
   if (n < 4) return DRA_EINVAL;
   if (partials && (n_partials < 1 || n_partials > dra_norm_partials_max())) return DRA_EINVAL;
-  hipLaunchKernelGGL(rmsprop_step_kernel, dim3(step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad, square_avg,
+  if (step_blocks(n) > 0x7fffffff) return DRA_EINVAL;
+  hipLaunchKernelGGL(rmsprop_step_kernel, dim3((unsigned)step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad, square_avg,
                      grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps, centered, out_norm, param_copy);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
@@ -400,3 +406,7 @@ DRA_API int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream) 
   DRA_HIP(hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, dra_stream(stream)));
   return DRA_OK;
 }
+
+#ifdef DRA_TRACE
+extern "C" int dra_trace_set_optim(void* p) { return dra_trace_set_local(p); }
+#endif

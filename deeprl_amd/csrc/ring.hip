@@ -220,6 +220,7 @@ ring_gather_kernel(const uint8_t* __restrict__ frames, const uint8_t* __restrict
   const int span = H + n;
   const int b = blockIdx.x / span;
   const int j = blockIdx.x - b * span;
+  DRA_STAMP(TR_GATHER, 0);
   const int64_t i = idx[b];
   const uint8_t* src = frames + (i - H + 1 + j) * frame_bytes;
   uint8_t* d0 = (j < H && out_state) ? out_state + ((int64_t)b * H + j) * frame_bytes : nullptr;
@@ -269,6 +270,8 @@ ring_gather_kernel(const uint8_t* __restrict__ frames, const uint8_t* __restrict
       if (out_mask_f32) out_mask_f32[b] = (float)cum_m;
     }
   }
+  DRA_STAMP(TR_GATHER, 5);
+  DRA_STAMP_END(TR_GATHER);
 }
 
 DRA_API int dra_ring_gather(dra_ring* r, const int64_t* idx_dev, int batch, void* out_state, void* out_next_state,
@@ -332,3 +335,7 @@ DRA_API int dra_u8_to_f32_lut(const void* in_u8, float* out, int64_t n, const fl
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
+
+#ifdef DRA_TRACE
+extern "C" int dra_trace_set_ring(void* p) { return dra_trace_set_local(p); }
+#endif

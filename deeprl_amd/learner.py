@@ -41,9 +41,10 @@ class DqnConfig(ctypes.Structure):
 
 class StepParams(ctypes.Structure):
     """Mirror of dra_dqn_step_params (include/deeprl_amd.h)."""
-    _fields_ = [("slot", ctypes.c_int64 * 8), ("counter", ctypes.c_int64 * 8), ("random_action", ctypes.c_int32 * 8),
-                ("store_action", ctypes.c_int32 * 8), ("dice", ctypes.c_float * 8), ("epsilon", ctypes.c_float * 8),
-                ("n_env", ctypes.c_int32), ("reserved", ctypes.c_int32), ("idx", ctypes.c_int64 * 1024)]
+    _fields_ = [("slot", ctypes.c_int64 * 8), ("counter", ctypes.c_int64 * 8), ("rcounter", ctypes.c_int64 * 8),
+                ("random_action", ctypes.c_int32 * 8), ("store_action", ctypes.c_int32 * 8), ("dice", ctypes.c_float * 8),
+                ("epsilon", ctypes.c_float * 8), ("stack_age", ctypes.c_int32 * 8), ("n_env", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("idx", ctypes.c_int64 * 1024)]
 
 
 def _ordered_params(net):
@@ -188,14 +189,19 @@ class DQNLearner:
                 self.sampling_prob.copy_(sampling_prob, non_blocking=True)
         lib.dra_dqn_learner_update(self.h, int(use_graph), int(per), float(beta), self._sp())
 
-    def set_env_steps(self, slots, counters, random_actions, dices, epsilons, store=True):
+    def set_env_steps(self, slots, counters, random_actions, dices, epsilons, store=True, rcounters=None, ages=None):
+        """Describes the next env transitions.  rcounters: counter whose hashes give the reward / mask stored with each
+        slot (default: the frame's own counter); ages: observations of the same episode before each one, capped at 3
+        (default 3 = the actor's stack is the last 4 ring frames)."""
         p = self.params
         n = len(slots)
         p.n_env = n
         for e in range(n):
             p.slot[e], p.counter[e] = int(slots[e]), int(counters[e])
+            p.rcounter[e] = int(counters[e] if rcounters is None else rcounters[e])
             p.random_action[e], p.dice[e], p.epsilon[e] = int(random_actions[e]), float(dices[e]), float(epsilons[e])
             p.store_action[e] = int(store)
+            p.stack_age[e] = 3 if ages is None else int(ages[e])
 
     def act(self, use_graph=True, stream=None):
         """Runs the env transitions currently described by self.params (set_env_steps)."""
@@ -237,6 +243,41 @@ class DQNLearner:
     def synchronize(self):
         self.stream.synchronize()
         self.actor_stream.synchronize()
+
+    def export_state(self):
+        """CPU copies, in the MODULE's layout and keyed like state_dict(), of everything an update reads and writes:
+        {'params', 'target', 'square_avg', 'grad_avg'} -> {name: tensor}.  (The flat buffers keep the conv weights
+        as [(c,kh,kw)][oc]; this undoes that.)  Used by checkpointing and by the parity checkers; synchronises."""
+        self.synchronize()
+        torch.cuda.synchronize()
+        names = list(_ORDER)
+        net_p = dict(self.network.named_parameters())
+
+        def per_tensor(buf):
+            out = {}
+            for k in names:
+                p = net_p[k]
+                o = self.flat.offset_of(p)
+                v = buf[o:o + p.numel()]
+                if p.dim() == 4 and not p.is_contiguous():      # KOC storage -> [oc, c, kh, kw]
+                    oc, c, kh, kw = p.shape
+                    v = v.view(c, kh, kw, oc).permute(3, 0, 1, 2)
+                else:
+                    v = v.view(p.shape)
+                out[k] = v.detach().cpu().contiguous().clone()
+            return out
+
+        return {"params": per_tensor(self.flat.flat), "target": per_tensor(self.target_flat.flat),
+                "square_avg": per_tensor(self.state1), "grad_avg": per_tensor(self.state2)}
+
+    def last_minibatch(self):
+        """(state, next_state, action, reward, mask) device tensors of the most recently issued update (views of the
+        learner's own gather buffers; synchronize() first).  For checkers."""
+        ps = [ctypes.c_void_p() for _ in range(5)]
+        lib.dra_dqn_learner_last_minibatch(self.h, *[ctypes.byref(p) for p in ps])
+        w, b = ops._wrap_device_pointer, self.batch
+        return (w(ps[0].value, b * 4 * 7056, torch.uint8).view(b, 4, 84, 84), w(ps[1].value, b * 4 * 7056, torch.uint8).view(b, 4, 84, 84),
+                w(ps[2].value, b, torch.int64), w(ps[3].value, b, torch.float32), w(ps[4].value, b, torch.float32))
 
 
 def draw_uniform_indices(size, pos, batch, history, n_step):

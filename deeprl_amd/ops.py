@@ -386,7 +386,8 @@ VAR_PINNED_IDX, VAR_ACTOR_V2, VAR_ACTOR_PARAMS, VAR_PIPE_GATHER, VAR_CU_PARTITIO
 VAR_ACTOR_FUSED_HEAD = 1024
 VAR_GATHER_IN_GRAPH = 2048
 VAR_ACTOR_RING = 4096
-VAR_ALL = 8191
+VAR_ACTOR_FUSED_CONV1 = 8192
+VAR_ALL = 16383
 
 
 def set_tuning(mask):

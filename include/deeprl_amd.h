@@ -118,12 +118,14 @@ int dra_conv_bwd_x(int layer, const float* dy, const float* w, const float* xact
 /* KOC weight layout ([K=(c,kh,kw)][OC]; conv_v2.hip): one-round-trip forward, and the matching gradients. */
 int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const float* const* wt, const float* const* bias,
                      float* const* y, int batch, int x_is_u8, double u8_coef, int act, void* stream);
-/* conv1 of a batch-1 forward whose 4-frame uint8 stack is read straight from the ring (newest slot on device) */
-int dra_conv1_fwd_koc_ring(const void* frames, const int64_t* newest_slot_dev, int64_t capacity, const float* wt,
+/* conv1 of a batch-1 forward whose 4-frame uint8 stack is read straight from the ring (newest slot on device);
+ * stack_age_dev (optional, device int32): channel c reads slot newest - min(3 - c, *stack_age_dev) (episode start:
+ * the first frame repeated, dra_dqn_step_params.stack_age); null = the last 4 ring frames */
+int dra_conv1_fwd_koc_ring(const void* frames, const int64_t* newest_slot_dev, const int32_t* stack_age_dev, int64_t capacity, const float* wt,
                            const float* bias, float* y, double u8_coef, int act, void* stream);
 /* same, the slot taken from entry (*seq_dev mod n_entries) of an array of parameter blocks stride_bytes apart;
  * newest_frame (optional, device uint8[84*84]): the newest channel comes from this not-yet-committed observation */
-int dra_conv1_fwd_koc_ring_seq(const void* frames, const int64_t* slot_field_dev, const unsigned* seq_dev, int n_entries,
+int dra_conv1_fwd_koc_ring_seq(const void* frames, const int64_t* slot_field_dev, const int32_t* stack_age_field_dev, const unsigned* seq_dev, int n_entries,
                                int64_t stride_bytes, int64_t capacity, const void* newest_frame, const float* wt,
                                const float* bias, float* y, double u8_coef, int act, void* stream);
 int dra_conv_bwd_w_koc(int layer, const float* dy, const void* x, float* dw, float* db, int64_t slab_stride, int ksplit,
@@ -160,6 +162,8 @@ int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* 
 #define DRA_VAR_ACTOR_RING 4096  /* learner, async pipelined: the actor's parameter blocks are pushed K steps ahead into a
                                     device ring (dra_dqn_learner_actor_ring_push); no per-step copy command, the last actor
                                     kernel of a step produces the next step's first frame */
+#define DRA_VAR_ACTOR_FUSED_CONV1 8192 /* with ACTOR_RING: the head of env step e-1 and the environment step run in front of
+                                          conv1 of step e in one launch (4 launches per env step instead of 5) */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
@@ -228,10 +232,15 @@ typedef struct dra_dqn_config {
 typedef struct dra_dqn_step_params {
   int64_t slot[8];           /* ring slot of each env transition (frame / action / reward / mask live there) */
   int64_t counter[8];        /* >= 0: synthesise frame `counter` (+ hashed reward / mask) into the slot; < 0: frame already there */
+  int64_t rcounter[8];       /* counter whose hashes give the reward / mask stored WITH the slot: the transition that leaves
+                                this observation (envs.py:140-141: the counter of the NEXT frame); = counter for a plain stream */
   int32_t random_action[8];  /* np.random.randint(A) drawn by the host */
   int32_t store_action[8];   /* write the chosen action into the slot's action record */
   float dice[8];             /* np.random.rand() drawn by the host */
   float epsilon[8];
+  int32_t stack_age[8];      /* observations of the same episode before this one, capped at history-1: channel c of the
+                                actor's frame stack is ring slot  slot - min(history-1-c, stack_age)  (after a reset the
+                                first frame is repeated, envs.py FrameStack.reset); history-1 = plain "last 4 ring frames" */
   int32_t n_env, reserved;
   int64_t idx[1024];         /* minibatch indices of this step's update (first `batch` used) */
 } dra_dqn_step_params;
@@ -245,6 +254,10 @@ int dra_dqn_learner_buffers(dra_dqn_learner* learner, void** idx, void** samplin
  * hipGraph (stream must not be the NULL stream); per != 0 adds the PER branch (DQN_agent.py:120-127). */
 int dra_dqn_learner_update(dra_dqn_learner* learner, int use_graph, int per, float beta, void* stream);
 int dra_dqn_learner_profile(dra_dqn_learner* learner, float* out_ms, int n_out, void* stream);
+/* the minibatch the most recently issued update consumed (device pointers into the learner's buffers: u8 states /
+ * next states [B][4][84][84], int64 actions [B], f32 rewards / masks [B]); for checkers, after a synchronise */
+int dra_dqn_learner_last_minibatch(dra_dqn_learner* learner, void** state, void** next_state, void** action, void** reward,
+                                   void** mask);
 int dra_dqn_learner_kernel_name(int k, char* out, int n);
 int dra_dqn_learner_kernel_count(void);
 int dra_dqn_learner_sync_target(dra_dqn_learner* learner, void* stream); /* DQN_agent.py:136-138 */

@@ -1,0 +1,132 @@
+"""Oracle: the deterministic schedule of the pipelined async DQN agent step.  TEST INFRASTRUCTURE ONLY.
+
+The reference's async_actor=True (deep_rl/agent/BaseAgent.py:108-182, DQN_agent.py:24-45,101-138) runs the actor in
+its own process, two agent steps ahead at most, on whatever parameters the shared-memory network holds at the
+time -- a race the reference does not resolve.  deeprl_amd's two-stream pipeline (csrc/learner.hip step_pipelined,
+DQNLearnerBench with the actor parameter ring) fixes ONE legal interleaving of that race, and this module restates
+it on the CPU with the oracle's own update / forward arithmetic:
+
+    prefill      ring <- synthetic transitions 0 .. cap-1 (counter hash), pos = 0
+    actor(0)     4 transitions on theta_0
+    for k = 0, 1, ...:
+        idx_k  = UniformReplay.sample's rejection loop on the GLOBAL np.random stream, ring state after actor(k)
+        batch_k = gather(idx_k)                       # BEFORE actor(k+1) overwrites the oldest slots
+        actor(k+1) on theta_k                          # = parameters after updates 0 .. k-1
+        theta_{k+1} = dqn_update(theta_k, batch_k)     # DQN_agent.py:114-134, centered RMSprop, clip 5
+    actor randomness (torch_utils.py:51-58 order: randint(A) then rand()) comes from its OWN RandomState(seed + 977),
+    like the reference's actor process has its own np.random state.
+
+A transition of the synthetic environment: observation = counter-hash frame, reward / mask = hashes of the same
+counter (synth_oracle.py); the action does not influence the next observation.
+"""
+import numpy as np
+import torch
+
+from . import loss_oracle as L, net_oracle as N, numerics_oracle as NUM
+from .replay_oracle import UniformReplayOracle
+from .synth_oracle import synth_transitions
+
+
+def draw_uniform_indices(size, pos, batch, history, n_step):
+    """replay.py:92-110 on the global np.random stream (block draws = the same stream as scalar draws)."""
+    out = np.empty(batch, dtype=np.int64)
+    have = 0
+    while have < batch:
+        cand = np.random.randint(0, size, size=batch - have)
+        lo, hi = cand - history + 1, cand + n_step
+        ok = ((lo >= 0) & (hi < pos)) | ((lo >= pos) & (hi < size))
+        good = cand[ok]
+        out[have:have + len(good)] = good
+        have += len(good)
+    return out
+
+
+class AsyncDqnScheduleOracle:
+    def __init__(self, params, target_params, cap, batch, seed, n_actions=4, epsilon=0.01, done_period=800, gamma=0.99,
+                 clip=5.0, lr=0.00025, alpha=0.95, eps=0.01, double_q=False):
+        torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+        self.p = {k: torch.tensor(v, requires_grad=True) for k, v in params.items()}
+        self.pt = {k: torch.tensor(v) for k, v in target_params.items()}
+        self.names = list(self.p)
+        self.sq = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.ga = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.cap, self.batch, self.seed, self.A = cap, batch, seed, n_actions
+        self.epsilon, self.done_period, self.gamma = epsilon, done_period, gamma
+        self.clip, self.lr, self.alpha, self.eps, self.double_q = clip, lr, alpha, eps, double_q
+        frames, act, rew, msk = synth_transitions(0, cap, 7056, seed=seed, n_actions=n_actions, done_period=done_period)
+        self.rep = UniformReplayOracle(cap, batch, 1, gamma, 4)
+        for t in range(cap):
+            self.rep.feed_one(frames[t].reshape(84, 84), act[t], rew[t], msk[t])
+        self.counter = cap
+        self.actor_rs = np.random.RandomState(seed + 977)
+        self.actions = []          # every action the actor stored, in order
+        self.q_gaps = []           # top-2 gap of the actor's q per greedy decision (tie diagnostics)
+        self.losses = []
+
+    def load_state(self, state):
+        """Adopts {'params', 'square_avg', 'grad_avg'} (per-tensor CPU tensors, module layout): the checker restarts
+        from the implementation's own state after a step whose ReLU gates were ambiguous (net_oracle.nature_conv_body_margin)."""
+        with torch.no_grad():
+            for k in self.names:
+                self.p[k].copy_(state["params"][k])
+                self.sq[k] = state["square_avg"][k].clone()
+                self.ga[k] = state["grad_avg"][k].clone()
+
+    def _snapshot(self):
+        return {k: v.detach().clone() for k, v in self.p.items()}
+
+    def actor_step(self, theta, override_actions=None):
+        """4 env transitions on parameters `theta` (DQN_agent.py:24-45).  override_actions: actions to STORE instead of
+        the oracle's own (keeps the two ring histories aligned after a numerical near-tie)."""
+        rep = self.rep
+        out = []
+        for e in range(4):
+            ra = int(self.actor_rs.randint(self.A, size=1)[0])
+            dice = float(self.actor_rs.rand(1)[0])
+            frame, _, rew, msk = synth_transitions(self.counter, 1, 7056, seed=self.seed, n_actions=self.A,
+                                                   done_period=self.done_period)
+            slot = rep.pos
+            # the observation the actor acts on: the 3 newest ring frames + the new frame
+            stack = np.stack([rep.state[(slot - 3 + j) % self.cap] for j in range(3)] + [frame[0].reshape(84, 84)])
+            x = torch.from_numpy(NUM.image_normalize_sync(stack[None]))
+            with torch.no_grad():
+                q = N.vanilla_head(theta, N.nature_conv_body(theta, x)).numpy()[0]
+            greedy = int(np.argmax(q))
+            srt = np.sort(q)
+            action = ra if dice < self.epsilon else greedy
+            if not (dice < self.epsilon):
+                self.q_gaps.append(float(srt[-1] - srt[-2]))
+            stored = action if override_actions is None else int(override_actions[e])
+            rep.feed_one(frame[0].reshape(84, 84), np.int64(stored), rew[0], msk[0])
+            self.counter += 1
+            out.append((action, float(srt[-1] - srt[-2]), dice < self.epsilon))
+            self.actions.append(action)
+        return out
+
+    def sample(self):
+        idx = draw_uniform_indices(self.rep.size(), self.rep.pos, self.batch, 4, 1)
+        return idx, self.rep.gather(idx)
+
+    def update(self, batch):
+        st, ac, rw, ns, mk = batch
+        p, pt = self.p, self.pt
+        x = torch.from_numpy(NUM.image_normalize_sync(st))
+        xn = torch.from_numpy(NUM.image_normalize_sync(ns))
+        with torch.no_grad():
+            qn = N.vanilla_head(pt, N.nature_conv_body(pt, xn))
+            qno = N.vanilla_head(p, N.nature_conv_body(p, xn)) if self.double_q else None
+        phi, self.relu_margin = N.nature_conv_body_margin(p, x)    # smallest |ReLU input| of the differentiated forward
+        q = N.vanilla_head(p, phi)
+        delta = L.dqn_td_error(q, qn, torch.from_numpy(ac), torch.from_numpy(rw.astype(np.float32)),
+                               torch.from_numpy(mk.astype(np.float32)), self.gamma, q_next_online=qno)
+        loss = L.dqn_reduce(delta)
+        grads = torch.autograd.grad(loss, [p[k] for k in self.names])
+        norm, grads = N.clip_grad_norm(list(grads), self.clip)
+        with torch.no_grad():
+            for k, g in zip(self.names, grads):
+                newp, self.sq[k], self.ga[k] = N.rmsprop_step(p[k], g, self.sq[k], self.ga[k], self.lr, self.alpha,
+                                                              self.eps, True)
+                p[k].copy_(newp)
+        loss = float(loss.detach())
+        self.losses.append(loss)
+        return loss, delta.detach().numpy(), q.detach().numpy(), float(norm)

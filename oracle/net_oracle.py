@@ -26,6 +26,23 @@ def nature_conv_body(p, x, prefix="body."):
     return F.relu(F.linear(y, p[prefix + "fc4.weight"], p[prefix + "fc4.bias"]))
 
 
+def nature_conv_body_margin(p, x, prefix="body."):
+    """nature_conv_body plus the smallest |pre-activation| over its four ReLU layers.  A ReLU whose input lies within
+    fp32 summation noise of zero (~1e-7 of the operand scale) can be gated differently by two correct fp32
+    implementations; its whole backward contribution then differs.  Parity tests use the margin to tell such a step
+    (expected about once per 3-4 batch-32 updates: 7e5 gates, density ~2 per unit at zero) from a real mismatch."""
+    margin = float("inf")
+    y = x
+    for name, stride in (("conv1", 4), ("conv2", 2), ("conv3", 1)):
+        pre = F.conv2d(y, p[prefix + name + ".weight"], p[prefix + name + ".bias"], stride=stride)
+        margin = min(margin, float(pre.detach().abs().min()))
+        y = F.relu(pre)
+    y = y.reshape(y.size(0), -1)
+    pre = F.linear(y, p[prefix + "fc4.weight"], p[prefix + "fc4.bias"])
+    margin = min(margin, float(pre.detach().abs().min()))
+    return F.relu(pre), margin
+
+
 def fc_body(p, x, n_layers, gate=F.relu, prefix="body."):
     """deep_rl/network/network_bodies.py:70-73."""
     for i in range(n_layers):

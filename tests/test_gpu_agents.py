@@ -227,7 +227,7 @@ def test_ppo_optimize_matches_reference(golden, dra, tag, monkeypatch):
     _cmp_params(agent.network, g, k + "final_", 2e-5, 2e-6)
 
 
-@pytest.mark.parametrize("double_q,variant", [(False, 0), (False, 1), (False, 7), (False, 127)])
+@pytest.mark.parametrize("double_q,variant", [(False, 0), (False, 1), (False, 7), (False, 127), (True, 127), (True, 511)])
 def test_fused_learner_matches_oracle(dra, double_q, variant):
     """The captured-graph DQN learner (one C-ABI call per update, zero host round trips) against
     the CPU oracle's full update on identical ring contents, indices and weights: 4 consecutive
@@ -266,8 +266,9 @@ def test_fused_learner_matches_oracle(dra, double_q, variant):
         q = N.vanilla_head(p, N.nature_conv_body(p, x))
         with torch.no_grad():
             qn = N.vanilla_head(pt, N.nature_conv_body(pt, xn))
+            qno = N.vanilla_head(p, N.nature_conv_body(p, xn)) if double_q else None   # DQN_agent.py:87-89
         delta = L.dqn_td_error(q, qn, torch.from_numpy(ac), torch.from_numpy(rw.astype(np.float32)),
-                               torch.from_numpy(mk.astype(np.float32)), 0.99)
+                               torch.from_numpy(mk.astype(np.float32)), 0.99, q_next_online=qno)
         loss = L.dqn_reduce(delta)
         grads = torch.autograd.grad(loss, [p[k] for k in names])
         norm, grads = N.clip_grad_norm(list(grads), 5)
@@ -354,7 +355,7 @@ def test_fused_step_sync_equals_act_then_update(dra, variant):
 _ASYNC_RESULTS = {}
 
 
-@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559, 4607])
+@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559, 4607, 12799])
 def test_fused_step_async_pipeline(dra, variant):
     """async_actor=True pipeline (actor one agent step ahead on its own stream, double-buffered actor
     parameters when variant has DRA_VAR_ACTOR_PARAMS): the transitions it feeds are the documented counter-hash
@@ -391,10 +392,100 @@ def test_fused_step_async_pipeline(dra, variant):
     # the parameters of optimizer t-1) -> bit-identical parameters and actions
     _ASYNC_RESULTS[variant] = outs[0]
     # ... and so do the 4-kernel actor step (DRA_VAR_ACTOR_V3: same arithmetic, fused launches) and the CU partition
-    for other in (255, 1023, 2047, 2559, 4607):
+    for other in (255, 1023, 2047, 2559, 4607, 12799):
         if 127 in _ASYNC_RESULTS and other in _ASYNC_RESULTS:
             assert np.array_equal(_ASYNC_RESULTS[127][0], _ASYNC_RESULTS[other][0])
             assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
+
+
+@pytest.mark.parametrize("variant,init", [(-1, "bench"), (-1, "normal"), (4607, "normal")])
+def test_async_pipeline_matches_schedule_oracle(dra, variant, init):
+    """THE BENCHMARKED CONFIGURATION against the oracle: DQNLearnerBench(async_actor=True) with the default kernel
+    variant (bench.py's: CU partition, pipelined gather, actor parameter ring, fused actor conv1) for 14 agent steps vs
+    oracle/async_schedule_oracle.py, the CPU restatement of the pipeline's schedule (actor step t+1 on the parameters
+    after update t-1, minibatch t gathered between actor steps t and t+1, the actor's own RandomState).
+
+    Per step: TD errors (rtol 1e-4, atol 1e-5 x max|q|: a TD error is a difference of action values of that scale),
+    loss at 2e-5 relative, parameters after the step at rtol 1e-5 / atol 2e-6 (weights are O(0.05)).  Every stored
+    action must equal the oracle's (a mismatch is tolerated only where the oracle's own top-2 action values are within
+    1e-5: an fp32 near-tie) and the ring frames are compared bit for bit.
+
+    ReLU gates: when some pre-activation of the differentiated forward lies within fp32 summation noise of zero
+    (oracle margin < 5e-7), two correct fp32 implementations may gate that unit differently and its whole backward
+    contribution differs (measured: parameter errors of 1e-6 .. 5e-5 from ONE such unit, tests/diag_schedule.py).
+    Such a step is checked at 100x the tolerances and the oracle then adopts the implementation's state, so that every
+    later step starts from a common state again.  init="bench": bench.py's own initialisation (layer_init: orthogonal
+    weights, zero biases -- small margins, so the oracle resynchronises after EVERY step and each step is an independent
+    check); init="normal": random-normal weights and O(1) biases (tests/fake_envs.numpy_params, as in the in-order
+    learner test): no resynchronisation unless a gate is ambiguous -- 14 CHAINED steps at the strict tolerances."""
+    d = dra
+    from deeprl_amd.learner import DQNLearnerBench
+    from oracle.async_schedule_oracle import AsyncDqnScheduleOracle
+    cap, b, a, seed, steps = 4000, 32, 4, 3, 14
+    d.random_seed(11)
+    torch.manual_seed(5)
+    bench = DQNLearnerBench(ring_capacity=cap, batch=b, seed=seed, actor=True, async_actor=True, variant=variant)
+    if variant < 0:
+        assert bench._actor_ring and bench.learner.variant & d.ops.VAR_ACTOR_FUSED_CONV1, "default variant = bench.py's"
+    if init == "normal":
+        p0 = fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(a), 21)
+        bench.network.load_state_dict({k: torch.from_numpy(v) for k, v in p0.items()})
+        bench.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in p0.items()})
+    p_np = {k: v.detach().cpu().numpy().copy() for k, v in bench.network.state_dict().items()}
+    t_np = {k: v.detach().cpu().numpy().copy() for k, v in bench.target_network.state_dict().items()}
+    orc = AsyncDqnScheduleOracle(p_np, t_np, cap, b, seed, n_actions=a, epsilon=bench.epsilon)
+    rng_state = np.random.get_state()
+    L = bench.learner
+    # ---- GPU run: 14 pipelined steps; TD errors and the learner's state read back after each (synchronising changes no result)
+    np.random.seed(5)
+    gpu_delta, gpu_state = [], []
+    for _ in range(steps):
+        bench.step()
+        L.synchronize()
+        gpu_delta.append(L.delta.cpu().numpy().copy())
+        gpu_state.append(L.export_state())
+    n_tr = 4 * (steps + 1)                       # the actor ran one agent step ahead
+    gpu_actions = d.ops._wrap_device_pointer(bench.ring.pointers()[1], n_tr, torch.int64).cpu().numpy().copy()
+    gpu_frames = d.ops._wrap_device_pointer(bench.ring.pointers()[0], n_tr * 7056, torch.uint8).cpu().numpy().copy()
+    # ---- oracle run of the same schedule (same global np.random stream for the minibatch draws)
+    np.random.seed(5)
+    near_ties, strict_steps, diag = 0, 0, []
+
+    def check_actions(res, first, who):
+        nonlocal near_ties
+        for e, (act, gap, rnd) in enumerate(res):
+            got = gpu_actions[first + e]
+            if act != got:
+                assert (not rnd) and gap < 1e-5, "%s env step %d: action %d vs %d, top-2 gap %g" % (who, e, act, got, gap)
+                near_ties += 1
+
+    check_actions(orc.actor_step(orc._snapshot(), override_actions=gpu_actions[0:4]), 0, "actor(0)")
+    for k in range(steps):
+        idx, batch = orc.sample()
+        theta = orc._snapshot()                                  # theta_k: what actor(k+1) acts on
+        check_actions(orc.actor_step(theta, override_actions=gpu_actions[4 * (k + 1):4 * (k + 2)]), 4 * (k + 1), "actor(%d)" % (k + 1))
+        loss, delta, q, norm = orc.update(batch)
+        ambiguous = orc.relu_margin < 5e-7
+        f = 100.0 if ambiguous else 1.0
+        strict_steps += not ambiguous
+        scale = max(1.0, float(np.abs(q).max()))
+        perr = max(float(np.abs(gpu_state[k]["params"][n].numpy() - orc.p[n].detach().numpy()).max()) for n in orc.names)
+        diag.append((k, "%.1e" % orc.relu_margin, "%.1e" % float(np.abs(gpu_delta[k] - delta).max()), "%.1e" % perr))
+        msg = "step %d (step, relu margin, max TD err, max param err): %s" % (k, diag)
+        np.testing.assert_allclose(gpu_delta[k], delta, rtol=1e-4 * f, atol=1e-5 * scale * f, err_msg="TD errors, " + msg)
+        np.testing.assert_allclose(0.5 * float(np.mean(gpu_delta[k].astype(np.float64) ** 2)), loss, rtol=2e-5 * f,
+                                   err_msg="loss, " + msg)
+        for n in orc.names:
+            np.testing.assert_allclose(gpu_state[k]["params"][n].numpy(), orc.p[n].detach().numpy(), rtol=1e-5 * f,
+                                       atol=2e-6 * f, err_msg=n + ", " + msg)
+        if ambiguous or init == "bench":
+            orc.load_state(gpu_state[k])
+    assert near_ties <= 1, "more than one fp32 near-tie in %d greedy decisions is not plausible" % len(orc.q_gaps)
+    assert strict_steps >= (steps // 2 if init == "normal" else 3), "too few unambiguous steps to mean anything: %s" % diag
+    assert np.array_equal(gpu_frames, orc.rep.state[:n_tr].reshape(n_tr * 7056))
+    np.random.set_state(rng_state)
+    L.close()
+    bench.ring.close()
 
 
 @pytest.mark.parametrize("per,n_step", [(False, 1), (True, 3)])

@@ -23,16 +23,18 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--ring", type=int, default=400_000)
+    ap.add_argument("--no-calibration", action="store_true", help="skip the 1024-minibatch gather launches")
     args = ap.parse_args()
     d.select_device(0)
     dev = d.Config.DEVICE
     bench = DQNLearnerBench(ring_capacity=args.ring, batch=32, seed=0, actor=True, async_actor=False, variant=args.variant)
-    rs = np.random.RandomState(0)
-    idx = torch.from_numpy(rs.randint(3, args.ring - 2, size=32 * 1024).astype(np.int64)).to(dev)
-    bufs = bench.ring.gather(idx, (84, 84), torch.uint8, torch.int64, want_f32=True)
-    for _ in range(3):
-        bench.ring.gather(idx, (84, 84), torch.uint8, torch.int64, want_f32=True, out=bufs)
-    torch.cuda.synchronize()
+    if not args.no_calibration:
+        rs = np.random.RandomState(0)
+        idx = torch.from_numpy(rs.randint(3, args.ring - 2, size=32 * 1024).astype(np.int64)).to(dev)
+        bufs = bench.ring.gather(idx, (84, 84), torch.uint8, torch.int64, want_f32=True)
+        for _ in range(3):
+            bench.ring.gather(idx, (84, 84), torch.uint8, torch.int64, want_f32=True, out=bufs)
+        torch.cuda.synchronize()
     for _ in range(args.steps):
         bench.step()
     torch.cuda.synchronize()
