@@ -351,9 +351,14 @@ class DQNAgent(BaseAgent):
         self.actor.set_network(self.network)
         self.total_steps = 0
         self._learner = None            # fused learner (csrc/learner.hip), attached lazily when eligible
+        self._learner_lr = None
+        self._pipe = None               # device-resident actor / environment pipeline
         self._fused_checked = False
         self._graphed = _GraphedUpdate(self)   # generic path: whole update as one graph replay (uniform replay)
         self._post_init()
+        env = self._device_env()
+        if env is not None:
+            self._attach_device_pipeline(env)
 
     # -- fused fast path ---------------------------------------------------------------------------------
     def _inner_replay(self):
@@ -391,17 +396,107 @@ class DQNAgent(BaseAgent):
         self._learner = DQNLearner(self.network, self.target_network, rp._ring, cfg.batch_size, cfg.action_dim,
                                    cfg.discount ** cfg.n_step, cfg.gradient_clip or 0.0, g['lr'], g['alpha'], g['eps'],
                                    centered=bool(g['centered']), double_q=bool(cfg.double_q),
-                                   u8_coef=cfg.state_normalizer.coef, cu_partition=False)
+                                   u8_coef=cfg.state_normalizer.coef, cu_partition=False,
+                                   replay_eps=getattr(cfg, 'replay_eps', 0.01), replay_alpha=getattr(cfg, 'replay_alpha', 0.5))
+        self._learner_lr = g['lr']
         self._fused = None              # its flat buffer no longer backs the parameters
         self._target_flat = None
         learner = self._learner
         self.actor._fast_q = lambda state: learner.q_host(np.asarray(state, dtype=np.uint8)).reshape(1, -1)
+
+    # -- device-resident environment + actor (BaseAgent.py:108-182 for async_actor) -----------
+    def _device_env(self):
+        """The synthetic Atari environment of this agent's actor if the whole rollout -> replay -> update loop can live on
+        the device: the dqn_pixel configuration (see _fused_eligible), UniformReplay, ONE SyntheticAtari environment,
+        sign / identity reward normaliser.  `config.device_env = False` keeps the environment on the host."""
+        from .envs import SyntheticAtari
+        from .normalizers import RescaleNormalizer, SignNormalizer
+        from .replay import UniformReplay
+        cfg = self.config
+        if Config.DEVICE.type != 'cuda' or getattr(cfg, 'device_env', True) is False:
+            return None
+        task = getattr(self.actor, '_task', None)
+        envs = getattr(getattr(task, 'env', None), 'envs', None)
+        if not envs or len(envs) != 1 or type(envs[0]) is not SyntheticAtari:
+            return None
+        env = envs[0]
+        rn = cfg.reward_normalizer
+        if not (type(rn) is SignNormalizer or (type(rn) is RescaleNormalizer and rn.coef == 1.0)):
+            return None
+        rp = self._inner_replay()
+        if type(rp) is not UniformReplay or rp.history_length != 4 or env.history != 4 or env.n_actions != cfg.action_dim:
+            return None
+        if env.frames is not None:        # somebody already stepped it on the host: leave it there
+            return None
+        rp.device_ring()                  # the ring feed() would create from the first transition
+        return env if self._fused_eligible() else None
+
+    def _attach_device_pipeline(self, env):
+        """config.async_actor (BaseAgent.py:142-162) is honoured as the two-stream pipeline of csrc/learner.hip: the actor
+        (forward, epsilon-greedy, environment step, replay feed) runs one agent step ahead of the learner on its own
+        stream and CU partition; async_actor=False runs the same kernels in order."""
+        from .learner import DeviceActorPipeline, DQNLearner, SyntheticEpisodeStream
+        cfg = self.config
+        g = self.optimizer.param_groups[0]
+        rp = self._inner_replay()
+        torch.cuda.synchronize()
+        async_actor = bool(cfg.async_actor)
+        self._learner = DQNLearner(self.network, self.target_network, rp._ring, cfg.batch_size, cfg.action_dim,
+                                   cfg.discount ** cfg.n_step, cfg.gradient_clip or 0.0, g['lr'], g['alpha'], g['eps'],
+                                   centered=bool(g['centered']), double_q=bool(cfg.double_q),
+                                   u8_coef=cfg.state_normalizer.coef, cu_partition=async_actor,
+                                   replay_eps=getattr(cfg, 'replay_eps', 0.01), replay_alpha=getattr(cfg, 'replay_alpha', 0.5),
+                                   env_seed=env.seed, env_done_period=env.done_period)
+        self._learner_lr = g['lr']
+        self._fused = None
+        self._target_flat = None
+        self._fused_checked = True
+        actor = self.actor
+
+        def epsilon():                     # DQN_agent.py:34-39, the actor's own step counter
+            if actor._total_steps < cfg.exploration_steps:
+                eps = 1
+            else:
+                eps = cfg.random_action_prob()
+            actor._total_steps += 1
+            return eps
+
+        stream = SyntheticEpisodeStream(env.seed, env.counter, env.done_period, env.history)
+        self._pipe = DeviceActorPipeline(self._learner, rp, stream, cfg.action_dim, cfg.sgd_update_frequency, epsilon,
+                                         async_actor, actor_seed=int(np.random.randint(1 << 31)) if async_actor else None)
+
+    def _step_device(self):
+        cfg = self.config
+
+        def account(infos):               # DQN_agent.py:103-113 for transitions that never leave the device
+            for reward, done, info in infos:
+                self.record_online_return((info,))
+                self.total_steps += 1
+            return self.total_steps > cfg.exploration_steps
+
+        with torch.cuda.stream(self._learner.stream):
+            self._pipe.step(account)
+            if self.total_steps / cfg.sgd_update_frequency % cfg.target_network_update_freq == 0:
+                self.sync_target()
 
     def _pre_init(self):
         pass
 
     def _post_init(self):
         pass
+
+    def save(self, filename):
+        if self._learner is not None:     # updates run asynchronously on the learner's streams
+            self._learner.synchronize()
+        BaseAgent.save(self, filename)
+
+    def load(self, filename):
+        if self._learner is not None:
+            self._learner.synchronize()
+        BaseAgent.load(self, filename)
+        if self._learner is not None:     # parameters changed behind the learner: actor copies are stale
+            torch.cuda.synchronize()
+            self._learner.invalidate_actor_copy()
 
     def close(self):
         if getattr(self, '_learner', None) is not None:
@@ -483,6 +578,11 @@ class DQNAgent(BaseAgent):
         return out
 
     def step(self):
+        if self._learner is not None and self.optimizer.param_groups[0]['lr'] != self._learner_lr:
+            raise NotImplementedError("the fused DQN learner bakes the learning rate into its captured graphs; a scheduled "
+                                      "lr needs config.fused_learner = False (generic path)")
+        if self._pipe is not None:
+            return self._step_device()
         if self._learner is not None:   # ring feeds, actor forwards and updates share the learner's stream
             with torch.cuda.stream(self._learner.stream):
                 return self._step()
@@ -669,19 +769,43 @@ def _rollout_scan(storage, config, bootstrap_v):
     return adv, ret
 
 
+def _install_sampler(agent):
+    """Data-parallel agents (and config.dp_invariant_sampling) sample actions from per-step noise that is the same
+    however the environments are spread over ranks (dist.DataParallel.uniforms); everything else keeps the reference's
+    dist.sample() on torch's global generator."""
+    dp = agent.dp
+    net = agent.network
+    if not dp.invariant_sampling or not hasattr(net, 'fc_action') or not hasattr(agent.task, 'action_space'):
+        return
+    from .dist import gumbel_argmax
+    from .envs import Discrete
+    if not isinstance(agent.task.action_space, Discrete):
+        raise NotImplementedError("data-parallel sampling is implemented for categorical policies (BASELINE config 5)")
+    net.sampler = lambda logits: gumbel_argmax(logits, dp.uniforms(agent._rollout_step, dp.global_workers, logits.shape[-1],
+                                                                   logits.device))
+
+
 class A2CAgent(BaseAgent):
     """A2C_agent.py:12-64."""
 
     def __init__(self, config):
         BaseAgent.__init__(self, config)
         self.config = config
+        from .dist import DataParallel
+        self.dp = DataParallel(config)           # shards config.num_workers over the ranks BEFORE task_fn builds the envs
         self.task = config.task_fn()
         self.network = config.network_fn()
         self.optimizer = config.optimizer_fn(self.network.parameters())
         self._fused = FusedOptimizer.adopt(self.optimizer)
         self.total_steps = 0
         self.states = self.task.reset()
-        self.grad_hook = None  # multi-GPU: called with the flat gradient before the optimiser step
+        self.grad_hook = None  # optional extra hook on the flat gradient before the optimiser step
+        self._rollout_step = 0
+        _install_sampler(self)
+
+    def close(self):
+        close_obj(self.task)
+        self.dp.close()
 
     def step(self):
         config = self.config
@@ -689,13 +813,14 @@ class A2CAgent(BaseAgent):
         states = self.states
         for _ in range(config.rollout_length):
             prediction = self.network(config.state_normalizer(states))
+            self._rollout_step += 1
             next_states, rewards, terminals, info = self.task.step(to_np(prediction['action']))
             self.record_online_return(info)
             rewards = config.reward_normalizer(rewards)
             storage.feed(prediction)
             storage.feed({'reward': tensor(rewards).unsqueeze(-1), 'mask': tensor(1 - terminals).unsqueeze(-1)})
             states = next_states
-            self.total_steps += config.num_workers
+            self.total_steps += self.dp.global_workers
         self.states = states
         prediction = self.network(config.state_normalizer(states))
         storage.feed(prediction)
@@ -708,6 +833,9 @@ class A2CAgent(BaseAgent):
                                                 config.value_loss_weight)
         self._fused.zero_grad()
         torch.autograd.backward([entries.log_pi_a, entries.entropy, entries.v], [g_lp, g_ent, g_v])
+        # data parallel: the loss above is the mean over this rank's T x N/G rows; equal shards -> the mean of the G
+        # gradients is the gradient of the global mean loss.  ONE all-reduce, then clip + step identically everywhere.
+        self.dp.sum_grads(self._fused.flat.grad, 1.0 / self.dp.world if self.dp.active else 1.0)
         if self.grad_hook is not None:
             self.grad_hook(self._fused.flat.grad)
         self._fused.step(config.gradient_clip)
@@ -776,6 +904,8 @@ class PPOAgent(BaseAgent):
     def __init__(self, config):
         BaseAgent.__init__(self, config)
         self.config = config
+        from .dist import DataParallel
+        self.dp = DataParallel(config)
         self.task = config.task_fn()
         self.network = config.network_fn()
         if config.shared_repr:
@@ -797,6 +927,14 @@ class PPOAgent(BaseAgent):
         self.grad_hook = None
         self._graphed = _GraphedPPO(self)
         self._rollout_graph = dict(calls=0, graph=None, failed=False, k=0)
+        self._rollout_step = 0
+        _install_sampler(self)
+        if self.dp.invariant_sampling:
+            self._rollout_graph = None      # the sampler reseeds a generator per step: not capturable
+
+    def close(self):
+        close_obj(self.task)
+        self.dp.close()
 
     def step(self):
         config = self.config
@@ -804,6 +942,7 @@ class PPOAgent(BaseAgent):
         states = self.states
         for _ in range(config.rollout_length):
             prediction, state_t = self._act(states)
+            self._rollout_step += 1
             next_states, rewards, terminals, info = self.task.step(to_np(prediction['action']))
             self.record_online_return(info)
             rewards = config.reward_normalizer(rewards)
@@ -812,9 +951,10 @@ class PPOAgent(BaseAgent):
             storage.feed({'reward': tensor(rewards).unsqueeze(-1), 'mask': tensor(1 - terminals).unsqueeze(-1),
                           'state': state_t})
             states = next_states
-            self.total_steps += config.num_workers
+            self.total_steps += self.dp.global_workers
         self.states = states
         prediction, _ = self._act(states)
+        self._rollout_step += 1
         storage.feed(prediction)
         storage.placeholder()
         _rollout_scan(storage, config, prediction['v'])
@@ -822,7 +962,11 @@ class PPOAgent(BaseAgent):
         entries = storage.extract(['state', 'action', 'log_pi_a', 'ret', 'advantage'])
         entry_cls = entries.__class__
         entries = entry_cls(*[x.detach() for x in entries])
-        ops.adv_normalize_(entries.advantage)  # PPO_agent.py:66 in place
+        if self.dp.active:      # PPO_agent.py:66 over the GLOBAL rollout: three scalars all-reduced
+            from .dist import global_advantage_normalize_
+            global_advantage_normalize_(entries.advantage)
+        else:
+            ops.adv_normalize_(entries.advantage)  # PPO_agent.py:66 in place
 
         if config.shared_repr:
             self.lr_scheduler.step(self.total_steps)
@@ -876,35 +1020,53 @@ class PPOAgent(BaseAgent):
             prediction = self.network(states)
         return prediction, tensor(states)
 
-    def _minibatch(self, entry, prepared=False):
+    def _minibatch(self, entry, prepared=False, weight=1.0):
         """One minibatch update (PPO_agent.py:77-99) on already-gathered rows.  `prepared`: the optimisers are in
-        graph mode and the caller has advanced their step scalars (FusedOptimizer.prepare_step)."""
+        graph mode and the caller has advanced their step scalars (FusedOptimizer.prepare_step).  `weight` (data
+        parallel): rows here / rows of the GLOBAL minibatch -- the kernels' means are over the local rows, so
+        weight * local gradient summed over ranks is the gradient of the global mean."""
         config = self.config
-        prediction = self.network(entry.state, entry.action)
-        out3, (g_lp, g_ent, g_v) = ops.ppo_loss(
-            prediction['log_pi_a'].detach(), prediction['entropy'].detach(), prediction['v'].detach(),
-            entry.log_pi_a, entry.advantage, entry.ret, config.ppo_ratio_clip, config.entropy_weight)
+        dp = self.dp
+        n_local = entry.state.size(0)
+        if n_local > 0:
+            prediction = self.network(entry.state, entry.action)
+            out3, (g_lp, g_ent, g_v) = ops.ppo_loss(
+                prediction['log_pi_a'].detach(), prediction['entropy'].detach(), prediction['v'].detach(),
+                entry.log_pi_a, entry.advantage, entry.ret, config.ppo_ratio_clip, config.entropy_weight)
+        else:       # this rank holds no row of the global minibatch: it still takes part in the exchange
+            prediction, out3, g_lp, g_ent, g_v = None, torch.zeros(3, device=Config.DEVICE), None, None, None
         if config.shared_repr:
             self._fused.zero_grad()
-            torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']],
-                                    [g_lp, g_ent, g_v])
+            if prediction is not None:
+                torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']],
+                                        [g_lp, g_ent, g_v])
+            dp.sum_grads(self._fused.flat.grad, weight)
             if self.grad_hook is not None:
                 self.grad_hook(self._fused.flat.grad)
             self._fused.step(config.gradient_clip)
         else:
             approx_kl = out3[2].item()
+            if dp.active:   # the KL gate (PPO_agent.py:88) must fall the same way on every rank: global mean KL
+                approx_kl = dp.sum_scalars([approx_kl * weight])[0]
             if approx_kl <= 1.5 * config.target_kl:
                 self._fused_actor.zero_grad()
-                torch.autograd.backward([prediction['log_pi_a'], prediction['entropy']], [g_lp, g_ent])
+                if prediction is not None:
+                    torch.autograd.backward([prediction['log_pi_a'], prediction['entropy']], [g_lp, g_ent], retain_graph=True)
+                dp.sum_grads(self._fused_actor.flat.grad, weight)
                 self._fused_actor.step(None)
             self._fused_critic.zero_grad()
-            prediction['v'].backward(g_v)
+            if prediction is not None:
+                prediction['v'].backward(g_v)
+            dp.sum_grads(self._fused_critic.flat.grad, weight)
             self._fused_critic.step(None)
         return out3
 
     def optimize(self, entries):
         """PPO_agent.py:71-99: epochs of shuffled minibatches over the (detached) rollout entries."""
         config = self.config
+        dp = self.dp
+        if dp.active:
+            return self._optimize_data_parallel(entries)
         if self._graphed.usable() and self._graphed.optimize(entries):
             return
         entry_cls = entries.__class__
@@ -914,6 +1076,29 @@ class PPOAgent(BaseAgent):
                 batch_indices = tensor(batch_indices).long()
                 entry = entry_cls(*[x[batch_indices] for x in entries])
                 out3 = self._minibatch(entry)
+        self.last_loss = out3
+
+    def _optimize_data_parallel(self, entries):
+        """The same epochs x minibatches over the GLOBAL rollout (T x N rows, time-major like Storage.extract): every rank
+        draws the same permutation (dist.DataParallel.permutation), forms the same global minibatches as a single
+        process would, and contributes the rows that belong to its environments [lo, hi)."""
+        config, dp = self.config, self.dp
+        entry_cls = entries.__class__
+        n_glob, n_loc = dp.global_workers, dp.hi - dp.lo
+        t_len = entries.state.size(0) // n_loc
+        total = t_len * n_glob
+        mb = config.mini_batch_size
+        for _ in range(config.optimization_epochs):
+            perm = np.asarray(dp.permutation(total))
+            full = total // mb * mb
+            batches = list(perm[:full].reshape(-1, mb)) + ([perm[full:]] if total % mb else [])
+            for g_idx in batches:
+                t, n = g_idx // n_glob, g_idx % n_glob
+                mine = (n >= dp.lo) & (n < dp.hi)
+                local = t[mine] * n_loc + (n[mine] - dp.lo)
+                rows = tensor(local).long()
+                entry = entry_cls(*[x[rows] for x in entries])
+                out3 = self._minibatch(entry, weight=float(len(local)) / float(len(g_idx)))
         self.last_loss = out3
 
 
@@ -942,7 +1127,7 @@ class _GraphedPPO:
     def usable(self):
         a = self.agent
         cfg = a.config
-        if self.failed or getattr(cfg, 'graph_update', True) is False or a.grad_hook is not None:
+        if self.failed or getattr(cfg, 'graph_update', True) is False or a.grad_hook is not None or a.dp.active:
             return False
         if Config.DEVICE.type != 'cuda':
             return False

@@ -686,6 +686,14 @@ DRA_API int dra_dqn_learner_last_minibatch(dra_dqn_learner* l, void** state, voi
   return DRA_OK;
 }
 
+// The parameters were written from outside the learner (checkpoint load): the async actor's double-buffered copies
+// are reseeded from them by the next step.
+DRA_API int dra_dqn_learner_invalidate_actor_copy(dra_dqn_learner* l) {
+  if (!l) return DRA_EINVAL;
+  l->pa_valid = false;
+  return DRA_OK;
+}
+
 DRA_API int dra_dqn_learner_kernel_name(int k, char* out, int n) {
   if (k < 0 || k >= K_COUNT || !out || n < 1) return DRA_EINVAL;
   strncpy(out, kKernelNames[k], (size_t)n - 1);

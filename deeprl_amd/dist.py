@@ -11,8 +11,14 @@ The reference has no collective anywhere; what shards nat
     fused clip + optimizer kernels run identically on every rank.  PPO additionally needs the
     advantage mean / std over the GLOBAL rollout (PPO_agent.py:66): three scalars all-reduced.
 
-`GradAllReduce` plugs into A2CAgent / PPOAgent through their `grad_hook`.
+`DataParallel` is what A2CAgent / PPOAgent consult; it is active whenever torch.distributed is initialised with more
+than one rank (config.data_parallel = False opts out).  The gradient exchange itself is the C ABI's
+dra_allreduce_grads (csrc/comm.hip: one ncclAllReduce over RCCL on the agent's stream) when every rank owns its own
+GPU; ranks that share a device (tests on a one-GPU box) and CPU tensors go through torch.distributed (gloo).
 """
+import ctypes
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -74,3 +80,123 @@ def global_advantage_normalize_(adv, group=None):
     var = (ss - n * mean * mean) / (n - 1)
     adv.sub_(mean.to(adv.dtype)).div_(var.sqrt().to(adv.dtype))
     return adv
+
+
+class RcclComm:
+    """dra_comm (include/deeprl_amd.h "comm"): an RCCL communicator over the ranks of the default process group; the
+    unique id travels through torch.distributed's own broadcast (any backend)."""
+
+    def __init__(self):
+        from ._lib import lib
+        self.lib = lib
+        self.world, self.rank = world(), rank()
+        buf = (ctypes.c_ubyte * 256)()
+        if self.rank == 0:
+            lib.dra_comm_unique_id(buf)
+        if self.world > 1:
+            on_gpu = dist.get_backend() == "nccl"
+            t = torch.tensor(list(buf), dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
+            dist.broadcast(t, 0)
+            for i, v in enumerate(t.cpu().tolist()):
+                buf[i] = v
+        self.h = ctypes.c_void_p()
+        lib.dra_comm_init_rank(ctypes.byref(self.h), self.world, self.rank, buf)
+
+    def allreduce_grads(self, flat, scale):
+        from ._lib import stream_ptr
+        self.lib.dra_allreduce_grads(ctypes.c_void_p(flat.data_ptr()), flat.numel(), float(scale), self.h, stream_ptr())
+        return flat
+
+    def close(self):
+        if self.h:
+            self.lib.dra_comm_destroy(self.h)
+            self.h = None
+
+
+def _distinct_gpus():
+    """True when every rank of the default group drives a different GPU (the production layout: one process per GPU)."""
+    if not torch.cuda.is_available():
+        return False
+    mine = torch.tensor([torch.cuda.current_device(), torch.cuda.device_count()], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        return True
+    allv = [torch.zeros_like(mine) for _ in range(world())]
+    dist.all_gather(allv, mine)
+    return len({int(v[0]) for v in allv}) == world() and world() <= int(mine[1])
+
+
+class DataParallel:
+    """Data-parallel state of one on-policy agent.  Rank g owns environments [lo, hi) of the
+    config.num_workers GLOBAL environments; the agent builds only its shard (config.num_workers is rewritten to the shard
+    size before task_fn runs; config.env_shard = (lo, hi) for task factories that seed per environment), counts GLOBAL
+    environment steps, and calls
+
+        sum_grads(flat, weight)        one all-reduce per optimizer step: flat <- sum over ranks of weight * flat
+        sum_scalars([...])             fp64 scalars summed over ranks (advantage statistics, KL gate)
+        permutation(n)                 the SAME permutation on every rank (one RandomState seeded by rank 0)
+        uniforms(step, n_global, k)    per-step U(0,1) noise of shape [n_global, k], identical on every rank: actions are
+                                       sampled by the Gumbel trick from the shard's rows, so that G ranks x N/G
+                                       environments act exactly like 1 rank x N
+    """
+
+    def __init__(self, config):
+        self.world, self.rank = world(), rank()
+        self.active = self.world > 1 and getattr(config, "data_parallel", True) is not False
+        self.invariant_sampling = self.active or bool(getattr(config, "dp_invariant_sampling", False))
+        self.global_workers = config.num_workers
+        self.lo, self.hi = 0, config.num_workers
+        self.comm = None
+        self.rs = None
+        self.noise_seed = int(getattr(config, "dp_noise_seed", 0))
+        if self.active:
+            self.lo, self.hi = shard_envs(config.num_workers)
+            config.num_workers = self.hi - self.lo
+            seed = torch.tensor([np.random.randint(1 << 30)], dtype=torch.int64)
+            if dist.get_backend() == "nccl":
+                seed = seed.cuda()
+            dist.broadcast(seed, 0)
+            self.rs = np.random.RandomState(int(seed.item()))
+            if _distinct_gpus():
+                self.comm = RcclComm()
+        config.env_shard = (self.lo, self.hi)
+        self._gen = None
+
+    def permutation(self, n):
+        return self.rs.permutation(n) if self.active else np.random.permutation(n)
+
+    def uniforms(self, step, n_global, k, device):
+        if self._gen is None:
+            self._gen = torch.Generator(device=device)
+        self._gen.manual_seed(self.noise_seed * 1000003 + int(step))
+        return torch.rand(n_global, k, generator=self._gen, device=device)[self.lo:self.hi]
+
+    def sum_grads(self, flat, weight=1.0):
+        if not self.active:
+            if weight != 1.0:
+                flat.mul_(weight)
+            return flat
+        if self.comm is not None and flat.is_cuda:
+            return self.comm.allreduce_grads(flat, weight)
+        if weight != 1.0:
+            flat.mul_(weight)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
+
+    def sum_scalars(self, values):
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        if self.active:
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.cpu()]
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
+
+
+def gumbel_argmax(logits, u):
+    """A categorical sample from `logits` [N, A] driven by uniforms u [N, A]: argmax(logits - log(-log u))."""
+    g = -torch.log(-torch.log(u.clamp(1e-20, 1.0 - 1e-7)))
+    return torch.argmax(logits + g, dim=-1)

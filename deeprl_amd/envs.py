@@ -61,6 +61,16 @@ def synthetic_frame(counter, seed, frame_bytes=7056):
     return w.astype("<u8").view(np.uint8)
 
 
+def synthetic_reward_done(counter, seed, done_period):
+    """(reward, done) hashed from `counter`: what SyntheticAtari.step returns when its frame counter is `counter`, and what
+    the device environment stores for dra_dqn_step_params.rcounter (csrc/actor_env.h synth_reward / synth_mask)."""
+    with np.errstate(over="ignore"):
+        h = int(_mix64(np.uint64(seed + 1) * _GOLD + np.uint64(counter)))
+        h2 = int(_mix64(np.uint64(seed + 2) * _GOLD + np.uint64(counter)))
+    u = (h >> 32) % 10
+    return (-1.0 if u == 0 else (1.0 if u == 9 else 0.0)), (h2 % done_period == 0)
+
+
 class SyntheticAtari:
     """uint8 [history,84,84] observations as LazyFrames of (1,84,84) frames, `n_actions` discrete
     actions, reward in {-1,0,1}, episode ends w.p. 1/800 per step."""
@@ -83,12 +93,7 @@ class SyntheticAtari:
         return LazyFrames(list(self.frames))
 
     def step(self, action):
-        with np.errstate(over="ignore"):
-            h = int(_mix64(np.uint64(self.seed + 1) * _GOLD + np.uint64(self.counter)))
-            h2 = int(_mix64(np.uint64(self.seed + 2) * _GOLD + np.uint64(self.counter)))
-        u = (h >> 32) % 10
-        reward = -1.0 if u == 0 else (1.0 if u == 9 else 0.0)
-        done = h2 % self.done_period == 0
+        reward, done = synthetic_reward_done(self.counter, self.seed, self.done_period)
         self.frames = self.frames[1:] + [self._next_frame()]
         self.ret += reward
         info = {'episodic_return': self.ret if done else None}
@@ -150,26 +155,102 @@ class DummyVecEnv:
         return
 
 
-class Task:
-    """envs.py:153-189 surface over synthetic environments (see module docstring)."""
+_WARNED = set()
 
-    def __init__(self, name, num_envs=1, single_process=True, log_dir=None, episode_life=True, seed=None):
+
+def _real_task_envs(name, num_envs, seed, episode_life):
+    """The reference's path (envs.py:27-55: gym.make + baselines' Atari wrappers) when those third-party packages are
+    installed; None when they are not (this image: no gym, no baselines, no emulators)."""
+    try:
+        import gym
+    except ImportError:
+        return None
+    if not getattr(gym, "__file__", None) or not hasattr(gym, "make"):   # a placeholder module, not an installation
+        return None
+    try:
+        from baselines.common.atari_wrappers import FrameStack, make_atari, wrap_deepmind
+    except ImportError:
+        make_atari = None
+    envs = []
+    for i in range(num_envs):
+        if 'NoFrameskip' in name:
+            if make_atari is None:
+                raise ImportError("gym is installed but baselines.common.atari_wrappers is not: %s needs the reference's "
+                                  "Atari preprocessing (envs.py:39-47)" % name)
+            env = make_atari(name)
+            env.seed(seed + i)
+            env = wrap_deepmind(env, episode_life=episode_life, clip_rewards=False, frame_stack=False, scale=False)
+            env = FrameStack(env, 4)
+        else:
+            import gym
+            env = gym.make(name)
+            env.seed(seed + i)
+        envs.append(_GymAdapter(env))
+    return envs
+
+
+class _GymAdapter:
+    """reset() / step() -> (obs, reward, done, {'episodic_return': ...}) over a gym environment (envs.py:58-89)."""
+
+    def __init__(self, env):
+        self.env = env
+        self.ret = 0.0
+        self.observation_space, self.action_space = env.observation_space, env.action_space
+
+    def reset(self):
+        self.ret = 0.0
+        return self.env.reset()
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        self.ret += reward
+        info = dict(info or {})
+        info['episodic_return'] = self.ret if done else None
+        return obs, reward, done, info
+
+
+class Task:
+    """envs.py:153-189.  Real environments when gym (+ baselines for Atari) is installed -- the reference's own path.
+    Otherwise, and for explicit `synthetic-*` names, a SYNTHETIC stand-in with the same surface and observation shapes
+    (module docstring); falling back for a real environment name warns loudly once per name (DEEPRL_AMD_STRICT_ENVS=1
+    makes it an error): the numbers such a run produces are throughput numbers, not learning curves."""
+
+    def __init__(self, name, num_envs=1, single_process=True, log_dir=None, episode_life=True, seed=None,
+                 synthetic_done_period=None):
         if seed is None:
             seed = np.random.randint(int(1e9))
         self.name = name
+        explicit = name.startswith('synthetic-')
+        real = None if explicit else _real_task_envs(name, num_envs, seed, episode_life)
+        if real is not None:
+            self.env = DummyVecEnv(real)
+            self.observation_space, self.action_space = real[0].observation_space, real[0].action_space
+            self.state_dim = int(np.prod(self.observation_space.shape))
+            self.action_dim = self.action_space.n if hasattr(self.action_space, 'n') else self.action_space.shape[0]
+            return
+        if not explicit and name not in _WARNED:
+            import os
+            import warnings
+            msg = ("Task(%r): gym / the emulator for this environment is not installed; using a SYNTHETIC environment with "
+                   "the same observation and action shapes (counter-hash frames / random-walk vectors).  Throughput is "
+                   "meaningful, returns are not.  Use a 'synthetic-*' name to silence this." % name)
+            if os.environ.get("DEEPRL_AMD_STRICT_ENVS") == "1":
+                raise ImportError(msg)
+            warnings.warn(msg, stacklevel=2)
+            _WARNED.add(name)
         atari = 'NoFrameskip' in name or name.startswith('synthetic-atari')
         continuous = any(k in name for k in ('HalfCheetah', 'Walker', 'Hopper', 'Reacher', 'Swimmer', 'Ant', 'Humanoid',
                                              'dm-', 'synthetic-continuous'))
         if atari:
-            envs = [SyntheticAtari(seed + i) for i in range(num_envs)]
+            envs = [SyntheticAtari(seed + i, done_period=synthetic_done_period or 800) for i in range(num_envs)]
             self.observation_space = Box(0, 255, (4, 84, 84))
             self.action_space = Discrete(4)
         elif continuous:
-            envs = [SyntheticVector(seed + i, 17, 6, continuous=True, horizon=1000) for i in range(num_envs)]
+            envs = [SyntheticVector(seed + i, 17, 6, continuous=True, horizon=synthetic_done_period or 1000) for i in range(num_envs)]
             self.observation_space = Box(-np.inf, np.inf, (17,))
             self.action_space = Box(-1.0, 1.0, (6,))
         else:
-            envs = [SyntheticVector(seed + i, 4, 2) for i in range(num_envs)]
+            envs = [SyntheticVector(seed + i, 4, 2, horizon=synthetic_done_period or 200) for i in range(num_envs)]
             self.observation_space = Box(-np.inf, np.inf, (4,))
             self.action_space = Discrete(2)
         self.env = DummyVecEnv(envs)

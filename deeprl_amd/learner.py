@@ -244,6 +244,10 @@ class DQNLearner:
         self.stream.synchronize()
         self.actor_stream.synchronize()
 
+    def invalidate_actor_copy(self):
+        """The parameters were changed from outside (checkpoint load): the async actor's copies are reseeded on the next step."""
+        lib.dra_dqn_learner_invalidate_actor_copy(self.h)
+
     def export_state(self):
         """CPU copies, in the MODULE's layout and keyed like state_dict(), of everything an update reads and writes:
         {'params', 'target', 'square_avg', 'grad_avg'} -> {name: tensor}.  (The flat buffers keep the conv weights
@@ -295,6 +299,127 @@ def draw_uniform_indices(size, pos, batch, history, n_step):
         out[have:have + len(good)] = good
         have += len(good)
     return out
+
+
+class SyntheticEpisodeStream:
+    """Host-side shadow of ONE device-resident synthetic Atari environment: the counters, episode boundaries, rewards
+    and returns envs.SyntheticAtari + DummyVecEnv's auto-reset (envs.py:126-150 of the reference) would produce, computed
+    from the same counter hashes -- no device round trip.  For each transition it yields what the device kernels need
+    (dra_dqn_step_params): counter of the observation acted on, counter whose hash gives the reward / done of leaving it,
+    and the number of earlier observations of the same episode (the frame stack repeats the first frame after a reset)."""
+
+    def __init__(self, seed, counter0=0, done_period=800, history=4):
+        self.seed, self.done_period, self.history = int(seed), int(done_period), int(history)
+        self.next_counter = int(counter0)
+        self.c = None
+        self.age = 0
+        self.ret = 0.0
+
+    def _reset(self):
+        self.c = self.next_counter          # SyntheticAtari.reset(): one new frame, repeated `history` times
+        self.next_counter += 1
+        self.age = 0
+        self.ret = 0.0
+
+    def transition(self):
+        """-> (counter, rcounter, stack_age, reward, done, info) of the next transition (SyntheticAtari.step)."""
+        from .envs import synthetic_reward_done
+        if self.c is None:
+            self._reset()
+        counter, age = self.c, self.age
+        rc = self.next_counter              # step(): reward / done hashed from the counter of the frame it generates
+        reward, done = synthetic_reward_done(rc, self.seed, self.done_period)
+        self.next_counter += 1
+        self.ret += reward
+        info = {'episodic_return': self.ret if done else None}
+        if done:
+            self._reset()                   # DummyVecEnv: the post-step frame is dropped, the stack restarts
+        else:
+            self.c = rc
+            self.age = min(age + 1, self.history - 1)
+        return counter, rc, age, reward, done, info
+
+
+class DeviceActorPipeline:
+    """DQNAgent.step() for a device-resident environment (DQN_agent.py:101-138): per call `n_env` actor transitions
+    (forward, epsilon-greedy, environment step, replay feed) and one update, as ONE C call.
+
+    async_actor=False: transitions then update, in order, every random draw from the GLOBAL np.random stream in the
+    reference's order (torch_utils.py:51-58 per transition, then replay.py:92-103) -- the parity mode.
+    async_actor=True (the reference's dqn_pixel setting, BaseAgent.py:108-182): the two-stream pipeline of
+    csrc/learner.hip; the actor runs one agent step ahead on its own CU partition, its randomness comes from its own
+    RandomState (the reference's actor process has its own np.random state too), parameter blocks are generated 16
+    agent steps ahead."""
+    AHEAD = 16
+
+    def __init__(self, learner, replay, stream, n_actions, n_env, epsilon_fn, async_actor, actor_seed=None):
+        self.L, self.rp, self.stream = learner, replay, stream
+        self.A, self.n_env, self.epsilon_fn, self.async_actor = int(n_actions), int(n_env), epsilon_fn, bool(async_actor)
+        self.rs = np.random.RandomState(actor_seed) if async_actor else np.random
+        self.capacity = replay.memory_size
+        self.slot = replay.pos               # slot the next generated transition goes to
+        self.pending = []                    # per issued-but-unreported agent step: list of (reward, done, info)
+        self.pushed = self.issued = 0
+        self.primed = False
+        v = learner.variant
+        need = ops.VAR_ACTOR_RING | ops.VAR_PIPE_GATHER | ops.VAR_ACTOR_PARAMS
+        self.ring_mode = async_actor and (v & need) == need and not (v & (ops.VAR_ACTOR_V3 | ops.VAR_GATHER_IN_GRAPH))
+        if async_actor and not self.ring_mode:
+            raise DraError("the async device pipeline needs the default kernel variant (actor parameter ring)")
+
+    def _block(self):
+        """Host side of one agent step's transitions -> (StepParams head filled in learner.params, infos)."""
+        slots, counters, rcs, ages, ras, dices, epss, infos = [], [], [], [], [], [], [], []
+        for _ in range(self.n_env):
+            c, rc, age, reward, done, info = self.stream.transition()
+            eps = self.epsilon_fn()                                  # DQN_agent.py:34-39, once per transition
+            ras.append(int(self.rs.randint(self.A, size=1)[0]))      # epsilon_greedy, 2-D branch: randint, (argmax), rand
+            dices.append(float(self.rs.rand(1)[0]))
+            slots.append(self.slot)
+            counters.append(c); rcs.append(rc); ages.append(age); epss.append(eps)
+            infos.append((reward, done, info))
+            self.slot = (self.slot + 1) % self.capacity
+        self.L.set_env_steps(slots, counters, ras, dices, epss, rcounters=rcs, ages=ages)
+        return infos
+
+    def _push(self):
+        L = self.L
+        blocks = (StepParams * self.AHEAD)()
+        for i in range(self.AHEAD):
+            self.pending.append(self._block())
+            ctypes.memmove(ctypes.byref(blocks[i]), ctypes.byref(L.params), StepParams.idx.offset)
+        lib.dra_dqn_learner_actor_ring_push(L.h, blocks, self.AHEAD, L._sp(L.actor_stream))
+        self.pushed += self.AHEAD
+
+    def step(self, account):
+        """One agent step.  account(infos) is called with the (reward, done, info) of the transitions this call reports
+        (async mode: the ones the actor produced one call earlier) and returns whether this step updates
+        (DQN_agent.py:114: total_steps > exploration_steps)."""
+        L, rp = self.L, self.rp
+        if not self.async_actor:
+            infos = self._block()
+            rp.advance(self.n_env)
+            do_update = bool(account(infos))
+            idx = rp.draw_indices() if do_update else None
+            L.step(idx, do_update, False)
+            return infos
+        if not self.primed:
+            self._push()
+            L.params.n_env = self.n_env
+            L.act(use_graph=False, stream=L.actor_stream)          # transitions of agent step 0
+            self.issued += 1
+            L.actor_stream.synchronize()
+            self.primed = True
+        infos = self.pending.pop(0)                                  # produced by the actor launch issued last call
+        rp.advance(self.n_env)
+        do_update = bool(account(infos))
+        idx = rp.draw_indices() if do_update else None
+        if self.pushed - self.issued < 8:
+            self._push()
+        L.params.n_env = self.n_env
+        L.step(idx, do_update, True)                                 # gather(t), actor(t+1), update(t)
+        self.issued += 1
+        return infos
 
 
 class DQNLearnerBench:

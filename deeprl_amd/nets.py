@@ -492,7 +492,9 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         v = self.fc_critic(phi_v)
         dist = torch.distributions.Categorical(logits=logits)
         if action is None:
-            action = dist.sample()
+            # `sampler` (set by a data-parallel agent, dist.py): draws that do not depend on how the environments are
+            # spread over ranks; default = the reference's dist.sample() on torch's global generator
+            action = self.sampler(logits) if getattr(self, "sampler", None) is not None else dist.sample()
         log_prob = dist.log_prob(action).unsqueeze(-1)
         entropy = dist.entropy().unsqueeze(-1)
         return {'action': action, 'log_pi_a': log_prob, 'entropy': entropy, 'v': v}

@@ -176,6 +176,21 @@ class UniformReplay(Storage):
             self._size += 1
         self.pos = (slot + 1) % self.memory_size
 
+    def advance(self, n=1):
+        """`n` transitions were written into ring slots pos, pos+1, ... by a DEVICE producer (the device-resident
+        actor / environment of csrc/learner.hip): the host part of feed() -- replay.py:84-90's pos / size bookkeeping."""
+        if self._ring is None:
+            raise DraError("advance(): no ring yet")
+        for _ in range(int(n)):
+            if self.pos >= self._size:
+                self._size += 1
+            self.pos = (self.pos + 1) % self.memory_size
+
+    def device_ring(self, state_shape=(1, 84, 84), state_dtype=np.uint8, action_dtype=np.int64):
+        """The HBM ring, created now (feed() creates it lazily from the first transition's shapes)."""
+        self._lazy_ring(np.zeros(state_shape, dtype=state_dtype), np.zeros((), dtype=action_dtype))
+        return self._ring
+
     # -- sample (replay.py:92-103, 112-140) ----------------------------------------------------
     def draw_indices(self, batch_size=None):
         """The reference's rejection loop, draw for draw: one np.random.randint(0, size) per attempt."""

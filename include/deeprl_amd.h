@@ -261,6 +261,8 @@ int dra_dqn_learner_last_minibatch(dra_dqn_learner* learner, void** state, void*
 int dra_dqn_learner_kernel_name(int k, char* out, int n);
 int dra_dqn_learner_kernel_count(void);
 int dra_dqn_learner_sync_target(dra_dqn_learner* learner, void* stream); /* DQN_agent.py:136-138 */
+/* the parameters were written from outside (checkpoint load, BaseAgent.py:29-33): reseed the async actor's copies */
+int dra_dqn_learner_invalidate_actor_copy(dra_dqn_learner* learner);
 /* DQNActor._transition on device for prm->n_env transitions (graph replay when use_graph). */
 int dra_dqn_learner_act(dra_dqn_learner* learner, const dra_dqn_step_params* prm, int use_graph, void* stream);
 /* DQNActor._transition's forward (DQN_agent.py:29-33) for a HOST environment: state_host = uint8 [4][84][84]
@@ -293,6 +295,20 @@ int dra_probe_hw_id(uint32_t* out, int n_workgroups, void* stream);
  * update graph); trace_read returns milliseconds relative to the first event, out[step*5 + slot]. */
 int dra_dqn_learner_trace(dra_dqn_learner* learner, int n_steps);
 int dra_dqn_learner_trace_read(dra_dqn_learner* learner, float* out_ms, int max_steps, int* n_steps);
+
+/* ---- comm: RCCL gradient all-reduce for the data-parallel on-policy agents (SURVEY.md 8b "comm", 8e).  The reference
+ * has no collective; A2C / PPO (A2C_agent.py:55-64, PPO_agent.py:77-99) shard their environments over the GPUs of a node
+ * and exchange ONE flat fp32 gradient per optimizer step.  One process per GPU; rank 0 creates the id, the host ships
+ * its DRA_COMM_ID_BYTES to the other ranks, every rank calls init_rank (collective). */
+#define DRA_COMM_ID_BYTES 256
+typedef struct dra_comm dra_comm;
+int dra_comm_unique_id(void* id_bytes);
+int dra_comm_init_rank(dra_comm** out, int n_ranks, int rank, const void* id_bytes);
+int dra_comm_destroy(dra_comm* comm);
+/* flat_grad <- (sum over ranks) * scale, in place, asynchronous on stream (scale = 1/n_ranks: gradient of the global mean) */
+int dra_allreduce_grads(float* flat_grad, int64_t count, float scale, dra_comm* comm, void* stream);
+/* a few fp64 scalars summed over ranks (PPO's global advantage statistics, PPO_agent.py:66) */
+int dra_allreduce_f64(double* values, int count, dra_comm* comm, void* stream);
 
 #ifdef __cplusplus
 }

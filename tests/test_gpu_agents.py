@@ -488,23 +488,28 @@ def test_async_pipeline_matches_schedule_oracle(dra, variant, init):
     bench.ring.close()
 
 
-@pytest.mark.parametrize("per,n_step", [(False, 1), (True, 3)])
-def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch, per, n_step):
+@pytest.mark.parametrize("per,n_step,device_env,done_period", [(False, 1, False, 800), (True, 3, False, 800), (False, 1, True, 800),
+                                                             (False, 1, True, 7), (False, 3, True, 11)])
+def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch, per, n_step, device_env, done_period):
     """dqn_pixel configuration (examples.py:55-97 shapes): DQNAgent attaches the fused learner
     (csrc/learner.hip) after the first feed.  20 agent steps give the same action stream and replay
     contents and, to fp32 reassociation, the same parameters as the generic autograd path
-    (config.fused_learner = False), which the tests above pin to the reference's fixtures."""
+    (config.fused_learner = False), which the tests above pin to the reference's fixtures.
+    device_env=True: the environment itself is device-resident (DeviceActorPipeline, in-order mode): forward,
+    epsilon-greedy, environment step and replay feed never leave the GPU, and the run still equals the generic
+    host-emulator path transition for transition -- including episode ends (done_period 7 / 11: frame stacks restart
+    with the first frame repeated, the discarded post-terminal frame, rewards / masks of the LEAVING transition)."""
     d = dra
     import deeprl_amd.agents as agents_mod
     monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
     outs = []
     for fused in (True, False):
         cfg = d.Config()
-        cfg.merge(dict(game="BreakoutNoFrameskip-v4", n_step=n_step, replay_cls=d.PrioritizedReplay if per else d.UniformReplay,
-                       async_replay=False, log_level=0, tag="fast%d" % fused, fused_learner=fused))
+        cfg.merge(dict(game="synthetic-atari", n_step=n_step, replay_cls=d.PrioritizedReplay if per else d.UniformReplay,
+                       async_replay=False, log_level=0, tag="fast%d" % fused, fused_learner=fused, device_env=device_env))
         cfg.replay_eps, cfg.replay_alpha = 0.01, 0.5
         cfg.replay_beta = d.LinearSchedule(0.4, 1.0, 1000)
-        cfg.task_fn = lambda: d.Task(cfg.game, seed=7)
+        cfg.task_fn = lambda: d.Task(cfg.game, seed=7, synthetic_done_period=done_period)
         cfg.eval_env = cfg.task_fn()
         cfg.optimizer_fn = lambda params: torch.optim.RMSprop(params, lr=0.00025, alpha=0.95, eps=0.01, centered=True)
         cfg.network_fn = lambda: d.VanillaNet(cfg.action_dim, d.NatureConvBody(in_channels=4))
@@ -532,6 +537,7 @@ def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch, per, n_step
         for _ in range(20):
             agent.step()
         assert (agent._learner is not None) == fused
+        assert (agent._pipe is not None) == (fused and device_env and not per)
         if fused:
             agent._learner.synchronize()
         torch.cuda.synchronize()
