@@ -24,6 +24,7 @@ import pickle
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 from .envs import LazyFrames
@@ -41,7 +42,12 @@ class _NullLock:
 
 
 class BaseAgent:
-    """BaseAgent.py:15-105."""
+    """What every agent shares with the outside world (the surface of BaseAgent.py:15-105): checkpoint files in the
+    reference's format, evaluation episodes, the episodic-return log lines / scalars its plotting tools parse, task
+    switching.  The file formats and log strings are interchange formats and are kept byte for byte:
+      '<name>.model'  torch.save of network.state_dict() -- the reference's key names, [OC,C,KH,KW] conv weights;
+      '<name>.stats'  pickle of config.state_normalizer.state_dict();
+      'steps %d, episodic_return_test %.2f(%.2f)' / 'steps %d, episodic_return_train %s' (logger.py / plot.py tags)."""
 
     def __init__(self, config):
         self.config = config
@@ -51,62 +57,65 @@ class BaseAgent:
     def close(self):
         close_obj(self.task)
 
+    # -- checkpoints -------------------------------------------------------------------------------------------
     def save(self, filename):
-        torch.save(self.network.state_dict(), '%s.model' % (filename))
-        with open('%s.stats' % (filename), 'wb') as f:
+        # parameters may be strided views of a flat (KOC) buffer: write plain contiguous CPU tensors, as the reference does
+        weights = {k: v.detach().cpu().contiguous().clone() for k, v in self.network.state_dict().items()}
+        torch.save(weights, filename + '.model')
+        with open(filename + '.stats', 'wb') as f:
             pickle.dump(self.config.state_normalizer.state_dict(), f)
 
     def load(self, filename):
-        state_dict = torch.load('%s.model' % filename, map_location=lambda storage, loc: storage)
-        self.network.load_state_dict(state_dict)
-        with open('%s.stats' % (filename), 'rb') as f:
+        weights = torch.load(filename + '.model', map_location='cpu')
+        self.network.load_state_dict(weights)
+        with open(filename + '.stats', 'rb') as f:
             self.config.state_normalizer.load_state_dict(pickle.load(f))
 
+    # -- evaluation --------------------------------------------------------------------------------------------
     def eval_step(self, state):
         raise NotImplementedError
 
     def eval_episode(self):
         env = self.config.eval_env
         state = env.reset()
-        while True:
-            action = self.eval_step(state)
-            state, reward, done, info = env.step(action)
+        ret = None
+        while ret is None:
+            state, _, _, info = env.step(self.eval_step(state))
             ret = info[0]['episodic_return']
-            if ret is not None:
-                break
         return ret
 
     def eval_episodes(self):
-        episodic_returns = []
-        for ep in range(self.config.eval_episodes):
-            episodic_returns.append(np.sum(self.eval_episode()))
-        self.logger.info('steps %d, episodic_return_test %.2f(%.2f)' % (
-            self.total_steps, np.mean(episodic_returns), np.std(episodic_returns) / np.sqrt(len(episodic_returns))))
-        self.logger.add_scalar('episodic_return_test', np.mean(episodic_returns), self.total_steps)
-        return {'episodic_return_test': np.mean(episodic_returns)}
+        returns = np.asarray([np.sum(self.eval_episode()) for _ in range(self.config.eval_episodes)])
+        mean, sem = returns.mean(), returns.std() / np.sqrt(len(returns))
+        self.logger.info('steps %d, episodic_return_test %.2f(%.2f)' % (self.total_steps, mean, sem))
+        self.logger.add_scalar('episodic_return_test', mean, self.total_steps)
+        return {'episodic_return_test': mean}
 
     def record_online_return(self, info, offset=0):
-        if isinstance(info, dict):
-            ret = info['episodic_return']
-            if ret is not None:
-                self.logger.add_scalar('episodic_return_train', ret, self.total_steps + offset)
-                self.logger.info('steps %d, episodic_return_train %s' % (self.total_steps + offset, ret))
-        elif isinstance(info, tuple):
-            for i, info_ in enumerate(info):
-                self.record_online_return(info_, i)
-        else:
+        """info: one env's dict or the vector env's tuple of dicts; a finished episode logs its return at
+        total_steps + the env's position in the tuple."""
+        if isinstance(info, tuple):
+            for i, one in enumerate(info):
+                self.record_online_return(one, i)
+            return
+        if not isinstance(info, dict):
             raise NotImplementedError
+        ret = info['episodic_return']
+        if ret is not None:
+            at = self.total_steps + offset
+            self.logger.add_scalar('episodic_return_train', ret, at)
+            self.logger.info('steps %d, episodic_return_train %s' % (at, ret))
 
     def switch_task(self):
-        config = self.config
-        if not config.tasks:
+        """config.tasks: consecutive equal shares of max_steps per task."""
+        tasks = self.config.tasks
+        if not tasks:
             return
-        segs = np.linspace(0, config.max_steps, len(config.tasks) + 1)
-        if self.total_steps > segs[self.task_ind + 1]:
+        boundary = np.linspace(0, self.config.max_steps, len(tasks) + 1)[self.task_ind + 1]
+        if self.total_steps > boundary:
             self.task_ind += 1
-            self.task = config.tasks[self.task_ind]
-            self.states = self.task.reset()
-            self.states = config.state_normalizer(self.states)
+            self.task = tasks[self.task_ind]
+            self.states = self.config.state_normalizer(self.task.reset())
 
 
 class BaseActor:
@@ -1065,7 +1074,7 @@ class PPOAgent(BaseAgent):
         """PPO_agent.py:71-99: epochs of shuffled minibatches over the (detached) rollout entries."""
         config = self.config
         dp = self.dp
-        if dp.active:
+        if dp.invariant_sampling:        # G ranks, or one process asked to behave exactly like G ranks would
             return self._optimize_data_parallel(entries)
         if self._graphed.usable() and self._graphed.optimize(entries):
             return
@@ -1256,19 +1265,220 @@ class _GraphedPPO:
         return out3
 
 
-# ==================================================================================================== out of scope
-def _out_of_scope(name, where):
-    class _Stub(BaseAgent):
-        __doc__ = "%s (%s): outside the rollout -> replay -> update hot path this package implements." % (name, where)
-
-        def __init__(self, config=None):
-            raise NotImplementedError("%s (%s) is outside the hot path deeprl_amd implements (DESIGN.md section 7); "
-                                      "use the reference's agent with deeprl_amd's replay / networks" % (name, where))
-    _Stub.__name__ = _Stub.__qualname__ = name
-    return _Stub
+# ==================================================================================================== replay-based actor-critic
+def _f32(x):
+    """A sampled replay field as a float32 device tensor (the reference's tensor() narrows its f64 numpy batches to
+    f32 BEFORE any arithmetic, torch_utils.py:20-25; the HBM ring hands back the stored dtype)."""
+    return x.float() if isinstance(x, torch.Tensor) else tensor(x)
 
 
-# names examples.py refers to (examples.py:404-617); constructing one fails loudly instead of a NameError at call time
-OptionCriticAgent = _out_of_scope("OptionCriticAgent", "deep_rl/agent/OptionCritic_agent.py")
-DDPGAgent = _out_of_scope("DDPGAgent", "deep_rl/agent/DDPG_agent.py")
-TD3Agent = _out_of_scope("TD3Agent", "deep_rl/agent/TD3_agent.py")
+class _DeterministicPolicyAgent(BaseAgent):
+    """What DDPG_agent.py:13-100 and TD3_agent.py:13-108 share: one environment, a deterministic policy perturbed by a
+    random process (uniform actions during warm-up), every transition fed to the uniform replay -- here the HBM ring:
+    17-float states and 6-float actions are just small "frames" -- one sampled minibatch per step once warm, and a
+    polyak-averaged target network.  Sub-classes provide `warm()` and `learn(batch)`."""
+
+    def __init__(self, config):
+        BaseAgent.__init__(self, config)
+        self.config = config
+        self.task = config.task_fn()
+        self.network = config.network_fn()
+        self.target_network = config.network_fn()
+        self.target_network.load_state_dict(self.network.state_dict())
+        self.replay = config.replay_fn()
+        self.random_process = config.random_process_fn()
+        self.total_steps = 0
+        self.state = None
+
+    def close(self):
+        close_obj(self.replay)
+        close_obj(self.task)
+
+    def soft_update(self, target, src):
+        """target <- (1 - mix) * target + mix * src over every parameter: two multi-tensor launches."""
+        mix = self.config.target_network_mix
+        with torch.no_grad():
+            tp, sp = list(target.parameters()), [p.detach() for p in src.parameters()]
+            torch._foreach_mul_(tp, 1.0 - mix)
+            torch._foreach_add_(tp, sp, alpha=mix)
+
+    def eval_step(self, state):
+        norm = self.config.state_normalizer
+        norm.set_read_only()
+        with torch.no_grad():
+            action = self.network(norm(state))
+        norm.unset_read_only()
+        return to_np(action)
+
+    def _behaviour_action(self):
+        space = self.task.action_space
+        if self.total_steps < self.config.warm_up:
+            action = [space.sample()]
+        else:
+            with torch.no_grad():
+                action = to_np(self.network(self.state))
+            action = action + self.random_process.sample()
+        return np.clip(action, space.low, space.high)
+
+    def step(self):
+        config = self.config
+        if self.state is None:
+            self.random_process.reset_states()
+            self.state = config.state_normalizer(self.task.reset())
+        action = self._behaviour_action()
+        next_state, reward, done, info = self.task.step(action)
+        next_state = config.state_normalizer(next_state)
+        self.record_online_return(info)
+        reward = config.reward_normalizer(reward)
+        self.replay.feed(dict(state=self.state, action=action, reward=reward, next_state=next_state,
+                              mask=1 - np.asarray(done, dtype=np.int32)))
+        if done[0]:
+            self.random_process.reset_states()
+        self.state = next_state
+        self.total_steps += 1
+        if self.warm():
+            tr = self.replay.sample()
+            self.learn(_f32(tr.state), _f32(tr.action), _f32(tr.reward).unsqueeze(-1), _f32(tr.next_state),
+                       _f32(tr.mask).unsqueeze(-1))
+
+
+class DDPGAgent(_DeterministicPolicyAgent):
+    """DDPG_agent.py:13-100."""
+
+    def warm(self):
+        return self.replay.size() >= self.config.warm_up
+
+    def learn(self, states, actions, rewards, next_states, mask):
+        net, tgt, gamma = self.network, self.target_network, self.config.discount
+        with torch.no_grad():
+            phi_next = tgt.feature(next_states)
+            q_next = tgt.critic(phi_next, tgt.actor(phi_next))
+            y = (gamma * mask * q_next).add_(rewards)
+        critic_loss = (net.critic(net.feature(states), actions) - y).pow(2).mul(0.5).sum(-1).mean()
+        net.zero_grad()
+        critic_loss.backward()
+        net.critic_opt.step()
+        phi = net.feature(states)
+        policy_loss = -net.critic(phi.detach(), net.actor(phi)).mean()
+        net.zero_grad()
+        policy_loss.backward()
+        net.actor_opt.step()
+        self.soft_update(tgt, net)
+
+
+class TD3Agent(_DeterministicPolicyAgent):
+    """TD3_agent.py:13-108: clipped double Q, target-policy smoothing, delayed policy / target updates (on the steps
+    where total_steps % td3_delay is non-zero, as written at TD3_agent.py:100)."""
+
+    def warm(self):
+        return self.total_steps >= self.config.warm_up
+
+    def learn(self, states, actions, rewards, next_states, mask):
+        config, net, tgt = self.config, self.network, self.target_network
+        space = self.task.action_space
+        with torch.no_grad():
+            a_next = tgt(next_states)
+            noise = torch.randn_like(a_next).mul(config.td3_noise).clamp(-config.td3_noise_clip, config.td3_noise_clip)
+            a_next = (a_next + noise).clamp(float(space.low[0]), float(space.high[0]))
+            y = rewards + config.discount * mask * torch.min(*tgt.q(next_states, a_next))
+        q_1, q_2 = net.q(states, actions)
+        critic_loss = F.mse_loss(q_1, y) + F.mse_loss(q_2, y)
+        net.zero_grad()
+        critic_loss.backward()
+        net.critic_opt.step()
+        if self.total_steps % config.td3_delay:
+            policy_loss = -net.q(states, net(states))[0].mean()
+            net.zero_grad()
+            policy_loss.backward()
+            net.actor_opt.step()
+            self.soft_update(tgt, net)
+
+
+# ==================================================================================================== option-critic
+class OptionCriticAgent(BaseAgent):
+    """OptionCritic_agent.py:11-119: n-step option-critic over `num_workers` environments.  Per rollout step: one forward
+    (q over options, termination beta, intra-option policies), an epsilon-soft option choice that keeps the previous
+    option unless it terminates, an action from the chosen option's policy; per rollout: returns bootstrapped from the
+    target network, three losses (option values, intra-option policy, termination) through ONE backward and the fused
+    clip + optimizer step.  Draw order of the three Categorical samples per step is the reference's."""
+
+    def __init__(self, config):
+        BaseAgent.__init__(self, config)
+        self.config = config
+        self.task = config.task_fn()
+        self.network = config.network_fn()
+        self.target_network = config.network_fn()
+        self.optimizer = config.optimizer_fn(self.network.parameters())
+        self._fused = FusedOptimizer.adopt(self.optimizer)
+        self._target_flat = FlatParams(list(self.target_network.parameters()),
+                                       koc=nature_conv_weights(list(self.target_network.parameters())))
+        self._sync_target()
+        self.total_steps = 0
+        self.worker_index = range_tensor(config.num_workers)
+        self.states = config.state_normalizer(self.task.reset())
+        self.is_initial_states = torch.ones(config.num_workers, dtype=torch.bool, device=Config.DEVICE)
+        self.prev_options = torch.ones(config.num_workers, dtype=torch.int64, device=Config.DEVICE)
+
+    def _sync_target(self):
+        ops.copy_f32(self._target_flat.flat, self._fused.flat.flat)
+
+    def sample_option(self, prediction, epsilon, prev_option, is_initial):
+        with torch.no_grad():
+            q = prediction['q']
+            n_opt = q.size(1)
+            pi = torch.full_like(q, epsilon / n_opt)                       # epsilon-soft over options ...
+            pi.scatter_(1, q.argmax(dim=-1, keepdim=True), 1 - epsilon + epsilon / n_opt)
+            keep = torch.zeros_like(q)
+            keep[self.worker_index, prev_option] = 1
+            beta = prediction['beta']
+            pi_hat = (1 - beta) * keep + beta * pi                         # ... unless the previous option continues
+            fresh = torch.distributions.Categorical(probs=pi).sample()
+            continued = torch.distributions.Categorical(probs=pi_hat).sample()
+            return torch.where(is_initial, fresh, continued)
+
+    def step(self):
+        config = self.config
+        n, w = config.rollout_length, self.worker_index
+        storage = Storage(n, ['beta', 'option', 'beta_advantage', 'prev_option', 'init_state', 'eps'])
+        for _ in range(n):
+            prediction = self.network(self.states)
+            epsilon = config.random_option_prob(config.num_workers)
+            options = self.sample_option(prediction, epsilon, self.prev_options, self.is_initial_states)
+            prediction['pi'] = prediction['pi'][w, options]
+            prediction['log_pi'] = prediction['log_pi'][w, options]
+            policy = torch.distributions.Categorical(probs=prediction['pi'])
+            actions = policy.sample()
+            next_states, rewards, terminals, info = self.task.step(to_np(actions))
+            self.record_online_return(info)
+            storage.feed(prediction)
+            storage.feed({'reward': tensor(config.reward_normalizer(rewards)).unsqueeze(-1),
+                          'mask': tensor(1 - terminals).unsqueeze(-1), 'option': options.unsqueeze(-1),
+                          'prev_option': self.prev_options.unsqueeze(-1), 'entropy': policy.entropy().unsqueeze(-1),
+                          'action': actions.unsqueeze(-1), 'init_state': self.is_initial_states.unsqueeze(-1).float(),
+                          'eps': epsilon})
+            self.is_initial_states = torch.as_tensor(np.asarray(terminals), device=Config.DEVICE).bool()
+            self.prev_options = options
+            self.states = config.state_normalizer(next_states)
+            self.total_steps += config.num_workers
+            if self.total_steps // config.num_workers % config.target_network_update_freq == 0:
+                self._sync_target()
+        with torch.no_grad():
+            boot = self.target_network(self.states)
+            storage.placeholder()
+            beta = boot['beta'][w, self.prev_options]
+            ret = ((1 - beta) * boot['q'][w, self.prev_options] + beta * boot['q'].max(dim=-1)[0]).unsqueeze(-1)
+            for i in reversed(range(n)):
+                q_i = storage.q[i].detach()
+                ret = storage.reward[i] + config.discount * storage.mask[i] * ret
+                storage.ret[i] = ret
+                storage.advantage[i] = ret - q_i.gather(1, storage.option[i])
+                v = q_i.max(dim=-1, keepdim=True)[0] * (1 - storage.eps[i]) + q_i.mean(-1).unsqueeze(-1) * storage.eps[i]
+                storage.beta_advantage[i] = q_i.gather(1, storage.prev_option[i]) - v + config.termination_regularizer
+        e = storage.extract(['q', 'beta', 'log_pi', 'ret', 'advantage', 'beta_advantage', 'entropy', 'option', 'action',
+                             'init_state', 'prev_option'])
+        q_loss = (e.q.gather(1, e.option) - e.ret).pow(2).mul(0.5).mean()
+        pi_loss = (-(e.log_pi.gather(1, e.action) * e.advantage) - config.entropy_weight * e.entropy).mean()
+        beta_loss = (e.beta.gather(1, e.prev_option) * e.beta_advantage * (1 - e.init_state)).mean()
+        self._fused.zero_grad()
+        (pi_loss + q_loss + beta_loss).backward()
+        self._fused.step(config.gradient_clip)

@@ -147,22 +147,26 @@ class DataParallel:
         self.lo, self.hi = 0, config.num_workers
         self.comm = None
         self.rs = None
-        self.noise_seed = int(getattr(config, "dp_noise_seed", 0))
+        noise_seed = getattr(config, "dp_noise_seed", None)
         if self.active:
             self.lo, self.hi = shard_envs(config.num_workers)
             config.num_workers = self.hi - self.lo
-            seed = torch.tensor([np.random.randint(1 << 30)], dtype=torch.int64)
-            if dist.get_backend() == "nccl":
-                seed = seed.cuda()
-            dist.broadcast(seed, 0)
-            self.rs = np.random.RandomState(int(seed.item()))
+            if noise_seed is None:          # rank 0 picks the seed of the shared streams
+                seed = torch.tensor([np.random.randint(1 << 30)], dtype=torch.int64)
+                if dist.get_backend() == "nccl":
+                    seed = seed.cuda()
+                dist.broadcast(seed, 0)
+                noise_seed = int(seed.item())
             if _distinct_gpus():
                 self.comm = RcclComm()
+        self.noise_seed = int(noise_seed or 0)
+        if self.invariant_sampling:         # permutations and action noise come from streams every rank can reproduce
+            self.rs = np.random.RandomState(self.noise_seed + 12345)
         config.env_shard = (self.lo, self.hi)
         self._gen = None
 
     def permutation(self, n):
-        return self.rs.permutation(n) if self.active else np.random.permutation(n)
+        return self.rs.permutation(n) if self.rs is not None else np.random.permutation(n)
 
     def uniforms(self, step, n_global, k, device):
         if self._gen is None:

@@ -37,8 +37,12 @@ class Discrete:
 
 
 class Box:
-    def __init__(self, low, high, shape):
+    def __init__(self, low, high, shape, seed=0):
         self.low, self.high, self.shape = low, high, shape
+        self._rs = np.random.RandomState(seed)      # gym's spaces draw from their own generator, not np.random
+
+    def sample(self):
+        return self._rs.uniform(np.broadcast_to(self.low, self.shape), np.broadcast_to(self.high, self.shape))
 
 
 _GOLD = np.uint64(0x9E3779B97F4A7C15)

@@ -155,48 +155,48 @@ class Conv2d(nn.Conv2d):
 
 # ---------------------------------------------------------------------------------------------------- NoisyLinear
 class NoisyLinear(nn.Module):
-    """network_utils.py:31-83 (Rainbow): factorised Gaussian noise; the mixed weight feeds the HIP GEMM."""
+    """Linear layer with factorised Gaussian parameter noise (Fortunato et al.; parameter / buffer names and initial
+    values of network_utils.py:31-83 so that Rainbow checkpoints interchange):  y = x (W_mu + W_sigma * eps_W)^T +
+    (b_mu + b_sigma * eps_b),  eps_W = f(e_out) f(e_in)^T,  eps_b = f(e_b),  f(e) = sign(e) sqrt|e|,  e ~ N(0, NOISY_LAYER_STD^2)
+    redrawn by reset_noise().  Evaluation mode uses the means only.  The mixed weight feeds the HIP GEMM."""
 
     def __init__(self, in_features, out_features, std_init=0.4):
         super(NoisyLinear, self).__init__()
         self.in_features, self.out_features, self.std_init = in_features, out_features, std_init
-        self.weight_mu = nn.Parameter(torch.zeros((out_features, in_features)), requires_grad=True)
-        self.weight_sigma = nn.Parameter(torch.zeros((out_features, in_features)), requires_grad=True)
-        self.register_buffer('weight_epsilon', torch.zeros((out_features, in_features)))
-        self.bias_mu = nn.Parameter(torch.zeros(out_features), requires_grad=True)
-        self.bias_sigma = nn.Parameter(torch.zeros(out_features), requires_grad=True)
-        self.register_buffer('bias_epsilon', torch.zeros(out_features))
-        self.register_buffer('noise_in', torch.zeros(in_features))
-        self.register_buffer('noise_out_weight', torch.zeros(out_features))
-        self.register_buffer('noise_out_bias', torch.zeros(out_features))
+        shape = (out_features, in_features)
+        for name, s in (('weight', shape), ('bias', (out_features,))):
+            setattr(self, name + '_mu', nn.Parameter(torch.zeros(s), requires_grad=True))
+            setattr(self, name + '_sigma', nn.Parameter(torch.zeros(s), requires_grad=True))
+            self.register_buffer(name + '_epsilon', torch.zeros(s))
+        for name, n in (('noise_in', in_features), ('noise_out_weight', out_features), ('noise_out_bias', out_features)):
+            self.register_buffer(name, torch.zeros(n))
         self.fused_act = None
         self.reset_parameters()
         self.reset_noise()
 
-    def forward(self, x):
-        if self.training:
-            weight = self.weight_mu + self.weight_sigma.mul(self.weight_epsilon)
-            bias = self.bias_mu + self.bias_sigma.mul(self.bias_epsilon)
-        else:
-            weight, bias = self.weight_mu, self.bias_mu
-        return linear(x, weight, bias, self.fused_act)
-
     def reset_parameters(self):
-        mu_range = 1 / math.sqrt(self.weight_mu.size(1))
-        self.weight_mu.data.uniform_(-mu_range, mu_range)
-        self.weight_sigma.data.fill_(self.std_init / math.sqrt(self.weight_sigma.size(1)))
-        self.bias_mu.data.uniform_(-mu_range, mu_range)
-        self.bias_sigma.data.fill_(self.std_init / math.sqrt(self.bias_sigma.size(0)))
+        bound = 1 / math.sqrt(self.in_features)
+        for mu, sigma, fan in ((self.weight_mu, self.weight_sigma, self.in_features),
+                               (self.bias_mu, self.bias_sigma, self.out_features)):
+            mu.data.uniform_(-bound, bound)
+            sigma.data.fill_(self.std_init / math.sqrt(fan))
+
+    @staticmethod
+    def transform_noise(x):
+        return x.sign().mul(x.abs().sqrt())
 
     def reset_noise(self):
-        self.noise_in.normal_(std=Config.NOISY_LAYER_STD)
-        self.noise_out_weight.normal_(std=Config.NOISY_LAYER_STD)
-        self.noise_out_bias.normal_(std=Config.NOISY_LAYER_STD)
-        self.weight_epsilon.copy_(self.transform_noise(self.noise_out_weight).ger(self.transform_noise(self.noise_in)))
-        self.bias_epsilon.copy_(self.transform_noise(self.noise_out_bias))
+        for e in (self.noise_in, self.noise_out_weight, self.noise_out_bias):       # this draw order
+            e.normal_(std=Config.NOISY_LAYER_STD)
+        f = self.transform_noise
+        self.weight_epsilon.copy_(torch.outer(f(self.noise_out_weight), f(self.noise_in)))
+        self.bias_epsilon.copy_(f(self.noise_out_bias))
 
-    def transform_noise(self, x):
-        return x.sign().mul(x.abs().sqrt())
+    def forward(self, x):
+        if not self.training:
+            return linear(x, self.weight_mu, self.bias_mu, self.fused_act)
+        return linear(x, self.weight_mu + self.weight_sigma * self.weight_epsilon,
+                      self.bias_mu + self.bias_sigma * self.bias_epsilon, self.fused_act)
 
 
 # ---------------------------------------------------------------------------------------------------- bodies
@@ -293,22 +293,25 @@ class VanillaNet(nn.Module, BaseNet):
         return dict(q=self.fc_head(phi))
 
 
+def _head(features, outputs, w_scale=1.0, noisy=False):
+    """A linear head on the HIP GEMM: orthogonal / zero-bias initialised (network_utils.py:23-27), or a NoisyLinear."""
+    return NoisyLinear(features, outputs) if noisy else layer_init(Linear(features, outputs), w_scale)
+
+
 class DuelingNet(nn.Module, BaseNet):
-    """network_heads.py:24-37."""
+    """q = v + (adv - mean_a adv) over a shared body (module names of network_heads.py:24-37)."""
 
     def __init__(self, action_dim, body):
         super(DuelingNet, self).__init__()
-        self.fc_value = layer_init(Linear(body.feature_dim, 1))
-        self.fc_advantage = layer_init(Linear(body.feature_dim, action_dim))
+        self.fc_value = _head(body.feature_dim, 1)
+        self.fc_advantage = _head(body.feature_dim, action_dim)
         self.body = body
         self.to(Config.DEVICE)
 
     def forward(self, x, to_numpy=False):
         phi = self.body(tensor(x))
-        value = self.fc_value(phi)
         adv = self.fc_advantage(phi)
-        q = value.expand_as(adv) + (adv - adv.mean(1, keepdim=True).expand_as(adv))
-        return dict(q=q)
+        return dict(q=self.fc_value(phi) + adv - adv.mean(1, keepdim=True))
 
 
 class CategoricalNet(nn.Module, BaseNet):
@@ -329,34 +332,26 @@ class CategoricalNet(nn.Module, BaseNet):
 
 
 class RainbowNet(nn.Module, BaseNet):
-    """network_heads.py:57-86."""
+    """Dueling heads over atoms: logits[a] = value + (advantage[a] - mean_a advantage), softmax over the atoms; the
+    heads (and the body's fc4) are NoisyLinear when noisy_linear (module names of network_heads.py:57-86)."""
 
     def __init__(self, action_dim, num_atoms, body, noisy_linear):
         super(RainbowNet, self).__init__()
-        if noisy_linear:
-            self.fc_value = NoisyLinear(body.feature_dim, num_atoms)
-            self.fc_advantage = NoisyLinear(body.feature_dim, action_dim * num_atoms)
-        else:
-            self.fc_value = layer_init(Linear(body.feature_dim, num_atoms))
-            self.fc_advantage = layer_init(Linear(body.feature_dim, action_dim * num_atoms))
-        self.action_dim = action_dim
-        self.num_atoms = num_atoms
-        self.body = body
-        self.noisy_linear = noisy_linear
+        self.fc_value = _head(body.feature_dim, num_atoms, noisy=noisy_linear)
+        self.fc_advantage = _head(body.feature_dim, action_dim * num_atoms, noisy=noisy_linear)
+        self.action_dim, self.num_atoms, self.body, self.noisy_linear = action_dim, num_atoms, body, noisy_linear
         self.to(Config.DEVICE)
 
     def reset_noise(self):
         if self.noisy_linear:
-            self.fc_value.reset_noise()
-            self.fc_advantage.reset_noise()
-            self.body.reset_noise()
+            for m in (self.fc_value, self.fc_advantage, self.body):
+                m.reset_noise()
 
     def forward(self, x):
         phi = self.body(tensor(x))
-        value = self.fc_value(phi).view((-1, 1, self.num_atoms))
-        advantage = self.fc_advantage(phi).view(-1, self.action_dim, self.num_atoms)
-        q = value + (advantage - advantage.mean(1, keepdim=True))
-        return dict(prob=F.softmax(q, dim=-1), log_prob=F.log_softmax(q, dim=-1), logits=q)
+        adv = self.fc_advantage(phi).view(-1, self.action_dim, self.num_atoms)
+        logits = self.fc_value(phi).view(-1, 1, self.num_atoms) + adv - adv.mean(1, keepdim=True)
+        return dict(prob=F.softmax(logits, dim=-1), log_prob=F.log_softmax(logits, dim=-1), logits=logits)
 
 
 class QuantileNet(nn.Module, BaseNet):
@@ -377,54 +372,48 @@ class QuantileNet(nn.Module, BaseNet):
 
 
 class OptionCriticNet(nn.Module, BaseNet):
-    """network_heads.py:105-127."""
+    """Option-critic heads on one body: option values q [N, O], termination probabilities beta = sigmoid(.) [N, O] and
+    one softmax policy per option pi [N, O, A] (+ its log) -- module names of network_heads.py:105-127."""
 
     def __init__(self, body, action_dim, num_options):
         super(OptionCriticNet, self).__init__()
-        self.fc_q = layer_init(Linear(body.feature_dim, num_options))
-        self.fc_pi = layer_init(Linear(body.feature_dim, num_options * action_dim))
-        self.fc_beta = layer_init(Linear(body.feature_dim, num_options))
-        self.num_options = num_options
-        self.action_dim = action_dim
-        self.body = body
+        self.fc_q = _head(body.feature_dim, num_options)
+        self.fc_pi = _head(body.feature_dim, num_options * action_dim)
+        self.fc_beta = _head(body.feature_dim, num_options)
+        self.num_options, self.action_dim, self.body = num_options, action_dim, body
         self.to(Config.DEVICE)
 
     def forward(self, x):
         phi = self.body(tensor(x))
-        q = self.fc_q(phi)
-        beta = torch.sigmoid(self.fc_beta(phi))
-        pi = self.fc_pi(phi).view(-1, self.num_options, self.action_dim)
-        return {'q': q, 'beta': beta, 'log_pi': F.log_softmax(pi, dim=-1), 'pi': F.softmax(pi, dim=-1)}
+        pi_logits = self.fc_pi(phi).view(-1, self.num_options, self.action_dim)
+        return dict(q=self.fc_q(phi), beta=torch.sigmoid(self.fc_beta(phi)), log_pi=F.log_softmax(pi_logits, dim=-1),
+                    pi=F.softmax(pi_logits, dim=-1))
 
 
 def _ac_bodies(state_dim, phi_body, actor_body, critic_body):
-    if phi_body is None:
-        phi_body = DummyBody(state_dim)
-    if actor_body is None:
-        actor_body = DummyBody(phi_body.feature_dim)
-    if critic_body is None:
-        critic_body = DummyBody(phi_body.feature_dim)
+    phi_body = phi_body if phi_body is not None else DummyBody(state_dim)
+    actor_body = actor_body if actor_body is not None else DummyBody(phi_body.feature_dim)
+    critic_body = critic_body if critic_body is not None else DummyBody(phi_body.feature_dim)
     return phi_body, actor_body, critic_body
 
 
 class DeterministicActorCriticNet(nn.Module, BaseNet):
-    """network_heads.py:130-170 (DDPG)."""
+    """DDPG's pair on an optional shared feature body (module names of network_heads.py:130-170): actor(phi) =
+    tanh(fc_action(actor_body(phi))), critic(phi, a) = fc_critic(critic_body([phi, a])); the network owns its two
+    optimisers (actor_opt over actor + phi parameters, critic_opt over critic + phi parameters)."""
 
     def __init__(self, state_dim, action_dim, actor_opt_fn, critic_opt_fn, phi_body=None, actor_body=None,
                  critic_body=None):
         super(DeterministicActorCriticNet, self).__init__()
         self.phi_body, self.actor_body, self.critic_body = _ac_bodies(state_dim, phi_body, actor_body, critic_body)
-        self.fc_action = layer_init(Linear(self.actor_body.feature_dim, action_dim), 1e-3)
-        self.fc_critic = layer_init(Linear(self.critic_body.feature_dim, 1), 1e-3)
-        self.actor_params = list(self.actor_body.parameters()) + list(self.fc_action.parameters())
-        self.critic_params = list(self.critic_body.parameters()) + list(self.fc_critic.parameters())
-        self.phi_params = list(self.phi_body.parameters())
+        self.fc_action = _head(self.actor_body.feature_dim, action_dim, 1e-3)
+        self.fc_critic = _head(self.critic_body.feature_dim, 1, 1e-3)
+        own = lambda *mods: [p for m in mods for p in m.parameters()]
+        self.actor_params, self.critic_params = own(self.actor_body, self.fc_action), own(self.critic_body, self.fc_critic)
+        self.phi_params = own(self.phi_body)
         self.actor_opt = actor_opt_fn(self.actor_params + self.phi_params)
         self.critic_opt = critic_opt_fn(self.critic_params + self.phi_params)
         self.to(Config.DEVICE)
-
-    def forward(self, obs):
-        return self.actor(self.feature(obs))
 
     def feature(self, obs):
         return self.phi_body(tensor(obs))
@@ -434,6 +423,9 @@ class DeterministicActorCriticNet(nn.Module, BaseNet):
 
     def critic(self, phi, a):
         return self.fc_critic(self.critic_body(torch.cat([phi, a], dim=1)))
+
+    def forward(self, obs):
+        return self.actor(self.feature(obs))
 
 
 class GaussianActorCriticNet(nn.Module, BaseNet):
@@ -501,21 +493,19 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
 
 
 class TD3Net(nn.Module, BaseNet):
-    """network_heads.py:258-293."""
+    """TD3's actor and twin critics, each on its own body (module names of network_heads.py:258-293):
+    forward(obs) = tanh(fc_action(actor_body(obs))), q(obs, a) = (Q1, Q2) on [obs, a]."""
 
     def __init__(self, action_dim, actor_body_fn, critic_body_fn, actor_opt_fn, critic_opt_fn):
         super(TD3Net, self).__init__()
-        self.actor_body = actor_body_fn()
-        self.critic_body_1 = critic_body_fn()
-        self.critic_body_2 = critic_body_fn()
-        self.fc_action = layer_init(Linear(self.actor_body.feature_dim, action_dim), 1e-3)
-        self.fc_critic_1 = layer_init(Linear(self.critic_body_1.feature_dim, 1), 1e-3)
-        self.fc_critic_2 = layer_init(Linear(self.critic_body_2.feature_dim, 1), 1e-3)
-        self.actor_params = list(self.actor_body.parameters()) + list(self.fc_action.parameters())
-        self.critic_params = list(self.critic_body_1.parameters()) + list(self.fc_critic_1.parameters()) + \
-            list(self.critic_body_2.parameters()) + list(self.fc_critic_2.parameters())
-        self.actor_opt = actor_opt_fn(self.actor_params)
-        self.critic_opt = critic_opt_fn(self.critic_params)
+        self.actor_body, self.critic_body_1, self.critic_body_2 = actor_body_fn(), critic_body_fn(), critic_body_fn()
+        self.fc_action = _head(self.actor_body.feature_dim, action_dim, 1e-3)
+        self.fc_critic_1 = _head(self.critic_body_1.feature_dim, 1, 1e-3)
+        self.fc_critic_2 = _head(self.critic_body_2.feature_dim, 1, 1e-3)
+        own = lambda *mods: [p for m in mods for p in m.parameters()]
+        self.actor_params = own(self.actor_body, self.fc_action)
+        self.critic_params = own(self.critic_body_1, self.fc_critic_1) + own(self.critic_body_2, self.fc_critic_2)
+        self.actor_opt, self.critic_opt = actor_opt_fn(self.actor_params), critic_opt_fn(self.critic_params)
         self.to(Config.DEVICE)
 
     def forward(self, obs):

@@ -27,46 +27,49 @@ class BaseNormalizer:
 
 
 class RunningMeanStd:
-    """Count-weighted running mean / variance (the algorithm of baselines.common.running_mean_std
-    @ 8e56dd, which the reference imports at normalizer.py:8; restated, that package is absent)."""
+    """Streaming mean / population variance over axis 0 by Chan's pairwise merge: a batch with moments (m_b, v_b, n_b) is
+    folded into the running (m, v, n) as  m' = m + d n_b / N,  v' = (v n + v_b n_b + d^2 n n_b / N) / N  with d = m_b - m,
+    N = n + n_b.  Starts from mean 0, variance 1 and a pseudo-count of 1e-4 -- the published algorithm of
+    baselines.common.running_mean_std (@8e56dd), the third-party class the reference imports at normalizer.py:8 (absent
+    here; restated, checked against a two-pass computation in tests/test_oracle_vs_golden.py)."""
 
     def __init__(self, epsilon=1e-4, shape=()):
-        self.mean = np.zeros(shape, 'float64')
-        self.var = np.ones(shape, 'float64')
-        self.count = epsilon
+        self.mean, self.var, self.count = np.zeros(shape, 'float64'), np.ones(shape, 'float64'), epsilon
 
     def update(self, x):
         x = np.asarray(x)
-        b_mean, b_var, b_count = np.mean(x, axis=0), np.var(x, axis=0), x.shape[0]
+        self.merge(np.mean(x, axis=0), np.var(x, axis=0), x.shape[0])
+
+    def merge(self, b_mean, b_var, b_count):
+        n, total = self.count, self.count + b_count
         delta = b_mean - self.mean
-        total = self.count + b_count
-        m2 = self.var * self.count + b_var * b_count + np.square(delta) * self.count * b_count / total
-        self.mean = self.mean + delta * b_count / total
-        self.var = m2 / total
-        self.count = total
+        m2 = self.var * n + b_var * b_count + np.square(delta) * n * b_count / total
+        self.mean, self.var, self.count = self.mean + delta * b_count / total, m2 / total, total
 
 
 class MeanStdNormalizer(BaseNormalizer):
+    """clip((x - running mean) / sqrt(running var + epsilon), +-clip), the statistics updated by every call unless
+    read_only (the interface and state_dict format {'mean', 'var'} of normalizer.py:28-51).  Host-side fp64 numpy, like
+    the reference: it sits on the environment side of the boundary (one [num_envs, 17] block per environment step)."""
+
     def __init__(self, read_only=False, clip=10.0, epsilon=1e-8):
         BaseNormalizer.__init__(self, read_only)
-        self.rms = None
-        self.clip = clip
-        self.epsilon = epsilon
+        self.clip, self.epsilon, self.rms = clip, epsilon, None
 
     def __call__(self, x):
         x = np.asarray(x)
-        if self.rms is None:
+        if self.rms is None:                       # statistics are per feature, shared by the environments
             self.rms = RunningMeanStd(shape=(1,) + x.shape[1:])
         if not self.read_only:
             self.rms.update(x)
-        return np.clip((x - self.rms.mean) / np.sqrt(self.rms.var + self.epsilon), -self.clip, self.clip)
+        z = (x - self.rms.mean) / np.sqrt(self.rms.var + self.epsilon)
+        return np.clip(z, -self.clip, self.clip)
 
     def state_dict(self):
-        return {'mean': self.rms.mean, 'var': self.rms.var}
+        return dict(mean=self.rms.mean, var=self.rms.var)
 
     def load_state_dict(self, saved):
-        self.rms.mean = saved['mean']
-        self.rms.var = saved['var']
+        self.rms.mean, self.rms.var = saved['mean'], saved['var']
 
 
 class RescaleNormalizer(BaseNormalizer):

@@ -1,32 +1,39 @@
-"""Exploration noise for the continuous-control agents (deep_rl/component/random_process.py:10-41).
-Host-side numpy; outside the accelerated path, kept so examples.py imports resolve."""
+"""Exploration noise for the deterministic-policy agents (the interface of deep_rl/component/random_process.py:
+`sample()` -> numpy noise of the configured shape, `reset_states()`; `std` is a schedule object called once per
+sample, e.g. LinearSchedule(0.2)).  Both processes draw from the GLOBAL np.random stream with one standard-normal
+block per sample, so a seeded run consumes the stream exactly like the reference."""
 import numpy as np
 
 
-class RandomProcess(object):
+class RandomProcess:
     def reset_states(self):
-        pass
+        """Called at every episode start (DDPG_agent.py:42,66)."""
 
 
 class GaussianProcess(RandomProcess):
+    """Independent N(0, std()^2) noise (TD3's exploration, examples.py:606-607)."""
+
     def __init__(self, size, std):
-        self.size = size
-        self.std = std
+        self.size, self.std = size, std
 
     def sample(self):
-        return np.random.randn(*self.size) * self.std()
+        z = np.random.randn(*self.size)
+        return z * self.std()
 
 
 class OrnsteinUhlenbeckProcess(RandomProcess):
+    """Euler-Maruyama discretisation of dx = theta (mu - x) dt + std dW (DDPG's exploration, examples.py:577-578):
+    x <- x + theta (mu - x) dt + std() sqrt(dt) N(0, I), restarted from x0 (default 0) at every episode."""
+
     def __init__(self, size, std, theta=.15, dt=1e-2, x0=None):
-        self.theta, self.mu, self.std, self.dt, self.x0, self.size = theta, 0, std, dt, x0, size
+        self.size, self.std, self.theta, self.dt, self.x0, self.mu = size, std, theta, dt, x0, 0
         self.reset_states()
 
-    def sample(self):
-        x = self.x_prev + self.theta * (self.mu - self.x_prev) * self.dt + \
-            self.std() * np.sqrt(self.dt) * np.random.randn(*self.size)
-        self.x_prev = x
-        return x
-
     def reset_states(self):
-        self.x_prev = self.x0 if self.x0 is not None else np.zeros(self.size)
+        self.x_prev = np.zeros(self.size) if self.x0 is None else self.x0
+
+    def sample(self):
+        drift = self.theta * (self.mu - self.x_prev) * self.dt
+        diffusion = self.std() * np.sqrt(self.dt) * np.random.randn(*self.size)
+        self.x_prev = self.x_prev + drift + diffusion
+        return self.x_prev

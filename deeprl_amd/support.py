@@ -154,21 +154,30 @@ class LinearSchedule:
 # ----------------------------------------------------------------------------------------------------
 # driver + helpers (deep_rl/utils/misc.py:19-84)
 def run_steps(agent):
-    """misc.py:19-35: save / log / eval cadence around agent.step() + switch_task()."""
+    """The training driver (the cadence of misc.py:19-35): before EVERY agent.step() -- checkpoint every save_interval
+    steps to data/<Agent>-<tag>-<steps>, a 'steps %d, %.2f steps/s' line every log_interval steps (rate since the previous
+    line), evaluation every eval_interval steps, stop (and close the agent) once total_steps reaches max_steps; after the
+    step, agent.switch_task().  The interval tests are on total_steps exactly, so an agent whose step() advances
+    total_steps by k only triggers on multiples that it lands on (reference behaviour)."""
     config = agent.config
-    agent_name = agent.__class__.__name__
-    t0 = time.time()
+    name = type(agent).__name__
+    mark = time.time()
+
+    def due(interval):
+        return bool(interval) and agent.total_steps % interval == 0
+
     while True:
-        if config.save_interval and not agent.total_steps % config.save_interval:
-            agent.save('data/%s-%s-%d' % (agent_name, config.tag, agent.total_steps))
-        if config.log_interval and not agent.total_steps % config.log_interval:
-            agent.logger.info('steps %d, %.2f steps/s' % (agent.total_steps, config.log_interval / (time.time() - t0)))
-            t0 = time.time()
-        if config.eval_interval and not agent.total_steps % config.eval_interval:
+        if due(config.save_interval):
+            agent.save('data/%s-%s-%d' % (name, config.tag, agent.total_steps))
+        if due(config.log_interval):
+            now = time.time()
+            agent.logger.info('steps %d, %.2f steps/s' % (agent.total_steps, config.log_interval / (now - mark)))
+            mark = time.time()
+        if due(config.eval_interval):
             agent.eval_episodes()
         if config.max_steps and agent.total_steps >= config.max_steps:
             agent.close()
-            break
+            return
         agent.step()
         agent.switch_task()
 
@@ -220,33 +229,36 @@ def generate_tag(params):
 
 
 # ----------------------------------------------------------------------------------------------------
-# logger facade (deep_rl/utils/logger.py:17-73)
+# logger facade (the interface of deep_rl/utils/logger.py:17-73)
 def get_logger(tag='default', log_level=0):
-    logger = logging.getLogger()
-    logger.setLevel(logging.INFO)
+    """A Logger whose text lines also go to ./log/<tag>-<time>.txt and whose scalars go to a tensorboard run under
+    ./tf_log/ (when tensorboard is installed) -- the two places the reference's plot tools read."""
+    text = logging.getLogger()
+    text.setLevel(logging.INFO)
     if tag is not None:
         try:
             mkdir('./log')
-            fh = logging.FileHandler('./log/%s-%s.txt' % (tag, get_time_str()))
-            fh.setFormatter(logging.Formatter('%(asctime)s - %(name)s - %(levelname)s: %(message)s'))
-            fh.setLevel(logging.INFO)
-            logger.addHandler(fh)
+            handler = logging.FileHandler('./log/%s-%s.txt' % (tag, get_time_str()))
         except OSError:
-            pass
-    return Logger(logger, './tf_log/logger-%s-%s' % (tag, get_time_str()), log_level)
+            handler = None
+        if handler is not None:
+            handler.setFormatter(logging.Formatter('%(asctime)s - %(name)s - %(levelname)s: %(message)s'))
+            handler.setLevel(logging.INFO)
+            text.addHandler(handler)
+    return Logger(text, './tf_log/logger-%s-%s' % (tag, get_time_str()), log_level)
 
 
 class Logger(object):
+    """info / debug / warning of a python logger + add_scalar / add_histogram with the reference's signatures
+    (tag, value, step=None, log_level=0): entries above the logger's level are dropped, a missing step is the count of
+    earlier entries under the same tag.  Scalars are also kept in `self.scalars[tag]` as (step, value)."""
+
     def __init__(self, vanilla_logger, log_dir, log_level=0):
-        self.log_level = log_level
-        self.writer = None
+        self.log_level, self.log_dir = log_level, log_dir
+        self.writer = None              # created on first use; False when tensorboard is unavailable
+        self.all_steps, self.scalars = {}, {}
         if vanilla_logger is not None:
-            self.info = vanilla_logger.info
-            self.debug = vanilla_logger.debug
-            self.warning = vanilla_logger.warning
-        self.all_steps = {}
-        self.scalars = {}
-        self.log_dir = log_dir
+            self.info, self.debug, self.warning = vanilla_logger.info, vanilla_logger.debug, vanilla_logger.warning
 
     def lazy_init_writer(self):
         if self.writer is None:
@@ -255,30 +267,27 @@ class Logger(object):
                 self.writer = SummaryWriter(self.log_dir)
             except Exception:
                 self.writer = False
+        return self.writer
 
     def get_step(self, tag):
-        if tag not in self.all_steps:
-            self.all_steps[tag] = 0
-        step = self.all_steps[tag]
-        self.all_steps[tag] += 1
+        step = self.all_steps.get(tag, 0)
+        self.all_steps[tag] = step + 1
         return step
 
-    def add_scalar(self, tag, value, step=None, log_level=0):
+    def _entry(self, tag, step, log_level):
         if log_level > self.log_level:
-            return
+            return None, None
+        return (self.get_step(tag) if step is None else step), self.lazy_init_writer()
+
+    def add_scalar(self, tag, value, step=None, log_level=0):
+        step, writer = self._entry(tag, step, log_level)
         if step is None:
-            step = self.get_step(tag)
+            return
         self.scalars.setdefault(tag, []).append((step, float(value)))
-        self.lazy_init_writer()
-        if self.writer:
-            self.writer.add_scalar(tag, value, step)
+        if writer:
+            writer.add_scalar(tag, value, step)
 
     def add_histogram(self, tag, values, step=None, log_level=0):
-        if log_level > self.log_level:
-            return
-        self.lazy_init_writer()
-        if self.writer:
-            if step is None:
-                step = self.get_step(tag)
-            self.writer.add_histogram(tag, values, step)
-
+        step, writer = self._entry(tag, step, log_level)
+        if step is not None and writer:
+            writer.add_histogram(tag, values, step)

@@ -42,6 +42,18 @@ class VectorTask:
         return self.s.copy(), rew, done, tuple(infos)
 
 
+class BoxSpace:
+    """gym.spaces.Box surface the continuous-control agents use (low / high / sample()); sample() draws from a private
+    stream like gym's own space RNG, never from the global np.random."""
+
+    def __init__(self, dim, seed):
+        self.low, self.high, self.shape = -np.ones(dim), np.ones(dim), (dim,)
+        self.rs = np.random.RandomState(seed + 4242)
+
+    def sample(self):
+        return self.rs.uniform(self.low, self.high)
+
+
 class ContinuousTask:
     """HalfCheetah-like: f64[state_dim] ~ N(0,1) observations, continuous actions,
     reward ~ N(0,1), done w.p. 1/horizon."""
@@ -51,6 +63,7 @@ class ContinuousTask:
         self.state_dim, self.action_dim, self.name = state_dim, action_dim, name
         self.horizon, self.num_envs = horizon, num_envs
         self.ret = np.zeros(num_envs)
+        self.action_space = BoxSpace(action_dim, seed)
 
     def reset(self):
         self.ret[:] = 0

@@ -559,8 +559,113 @@ def gen_dqn_agent_cartpole():
     save("dqn_agent_cartpole", **out)
 
 
+def _quiet_logger():
+    base_mod = sys.modules["deep_rl.agent.BaseAgent"]
+    orig = base_mod.get_logger
+    base_mod.get_logger = lambda *a, **k: _Logger()
+    return lambda: setattr(base_mod, "get_logger", orig)
+
+
+def _dump_agent(out, k, agent, init):
+    for n, v in init.items():
+        out[k + "init_" + n] = v
+    for n, v in agent.network.state_dict().items():
+        out[k + "final_" + n] = v.detach().numpy()
+    for n, v in agent.target_network.state_dict().items():
+        out[k + "target_" + n] = v.detach().numpy()
+    out[k + "total_steps"] = np.asarray(agent.total_steps)
+    out[k + "rng_tail"] = np.random.randint(0, 1 << 30, size=4)
+
+
+def gen_ddpg_td3():
+    """DDPGAgent.step / TD3Agent.step (DDPG_agent.py:38-100, TD3_agent.py:38-108) for 40 steps on a continuous fake
+    task: warm-up with action_space.sample(), exploration noise from np.random, uniform replay of f64 vectors, two Adam
+    optimisers, soft target updates.  TD3's target-policy noise is torch's global generator in the reference (not
+    reproducible across devices): td3_noise = 0 makes it the zero tensor."""
+    out = {}
+    restore = _quiet_logger()
+    try:
+        for tag in ("ddpg", "td3"):
+            cfg = ref.Config()
+            cfg.merge(dict(game="fake", log_level=0, tag=tag))
+            cfg.task_fn = lambda: fake_envs.ContinuousTask(seed=13, state_dim=5, action_dim=2, horizon=9)
+            cfg.eval_env = cfg.task_fn()
+            if tag == "ddpg":
+                cfg.network_fn = lambda: ref.DeterministicActorCriticNet(
+                    5, 2, actor_body=ref.FCBody(5, (16, 16), gate=torch.relu), critic_body=ref.FCBody(7, (16, 16), gate=torch.relu),
+                    actor_opt_fn=lambda p: torch.optim.Adam(p, lr=1e-3), critic_opt_fn=lambda p: torch.optim.Adam(p, lr=1e-3))
+                cfg.replay_fn = lambda: ref.UniformReplay(memory_size=200, batch_size=8)
+                cfg.random_process_fn = lambda: ref.OrnsteinUhlenbeckProcess(size=(2,), std=ref.LinearSchedule(0.2))
+                cls = ref.DDPGAgent
+            else:
+                cfg.network_fn = lambda: ref.TD3Net(
+                    2, actor_body_fn=lambda: ref.FCBody(5, (16, 16), gate=torch.relu),
+                    critic_body_fn=lambda: ref.FCBody(7, (16, 16), gate=torch.relu),
+                    actor_opt_fn=lambda p: torch.optim.Adam(p, lr=1e-3), critic_opt_fn=lambda p: torch.optim.Adam(p, lr=1e-3))
+                cfg.replay_fn = lambda: ref.ReplayWrapper(ref.UniformReplay, dict(memory_size=200, batch_size=8), False)
+                cfg.random_process_fn = lambda: ref.GaussianProcess(size=(2,), std=ref.LinearSchedule(0.1))
+                cfg.td3_noise, cfg.td3_noise_clip, cfg.td3_delay = 0.0, 0.5, 2
+                cls = ref.TD3Agent
+            cfg.discount, cfg.warm_up, cfg.target_network_mix, cfg.max_steps = 0.99, 10, 5e-3, 1e5
+            torch.manual_seed(7)
+            np.random.seed(17)
+            random.seed(17)
+            agent = cls(cfg)
+            init = {k: v.detach().numpy().copy() for k, v in agent.network.state_dict().items()}
+            for _ in range(40):
+                agent.step()
+            k = tag + "_"
+            _dump_agent(out, k, agent, init)
+            rp = getattr(agent.replay, "replay", agent.replay)
+            out[k + "replay_action"] = np.asarray(rp.action[:rp.size()], dtype=np.float64).reshape(rp.size(), -1)
+            out[k + "replay_reward"] = np.asarray(rp.reward[:rp.size()], dtype=np.float64).reshape(-1)
+    finally:
+        restore()
+    save("ddpg_td3_agents", **out)
+
+
+def gen_option_critic():
+    """OptionCriticAgent.step (OptionCritic_agent.py:52-119) for 4 rollouts of 5 steps x 3 workers.  Every
+    Categorical.sample() the reference draws (options, options_hat, actions; torch's CPU generator) is recorded so that an
+    implementation on another device can replay the same decisions."""
+    out = {}
+    restore = _quiet_logger()
+    samples = []
+    orig_sample = torch.distributions.Categorical.sample
+
+    def recording_sample(self, sample_shape=torch.Size()):
+        v = orig_sample(self, sample_shape)
+        samples.append(v.detach().numpy().copy())
+        return v
+
+    torch.distributions.Categorical.sample = recording_sample
+    try:
+        cfg = ref.Config()
+        cfg.merge(dict(game="fake", log_level=0, tag="oc"))
+        cfg.num_workers = 3
+        cfg.task_fn = lambda: fake_envs.VectorTask(seed=5, state_dim=4, action_dim=2, horizon=7, num_envs=3)
+        cfg.eval_env = fake_envs.VectorTask(seed=6, state_dim=4, action_dim=2)
+        cfg.optimizer_fn = lambda p: torch.optim.RMSprop(p, 0.001)
+        cfg.network_fn = lambda: ref.OptionCriticNet(ref.FCBody(4, hidden_units=(16,)), 2, num_options=2)
+        cfg.random_option_prob = ref.LinearSchedule(1.0, 0.1, 100)
+        cfg.discount, cfg.target_network_update_freq, cfg.rollout_length = 0.99, 4, 5
+        cfg.termination_regularizer, cfg.entropy_weight, cfg.gradient_clip = 0.01, 0.01, 5
+        torch.manual_seed(9)
+        np.random.seed(19)
+        agent = ref.OptionCriticAgent(cfg)
+        init = {k: v.detach().numpy().copy() for k, v in agent.network.state_dict().items()}
+        for _ in range(4):
+            agent.step()
+        _dump_agent(out, "oc_", agent, init)
+        out["oc_samples"] = np.stack(samples).astype(np.int64)      # [4 rollouts * 5 steps * 3 draws, 3 workers]
+    finally:
+        torch.distributions.Categorical.sample = orig_sample
+        restore()
+    save("option_critic_agent", **out)
+
+
 GENERATORS = [gen_uniform, gen_prioritized, gen_sumtree, gen_dqn_loss, gen_c51_loss, gen_qr_loss,
-              gen_dqn_nature_update, gen_optim, gen_a2c, gen_ppo, gen_ppo_loss, gen_dqn_agent_cartpole]
+              gen_dqn_nature_update, gen_optim, gen_a2c, gen_ppo, gen_ppo_loss, gen_dqn_agent_cartpole, gen_ddpg_td3, gen_option_critic]
 
 if __name__ == "__main__":
     only = sys.argv[1:]

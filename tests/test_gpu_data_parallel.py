@@ -1,0 +1,75 @@
+"""Data-parallel A2C / PPO (BASELINE configs[4]) as the AGENTS run it: 2 ranks x 2 environments against
+1 process x 4 environments, three updates each.  The ranks partition the environments, draw the same permutations,
+normalise advantages over the global rollout, exchange ONE flat gradient per optimizer step, and must land on the
+single-process parameters (fp32: the batch reduction is split differently, nothing else differs).
+
+The GPU box has one GPU: both ranks share it and torch.distributed's gloo backend carries the gradients; on a node
+where every rank owns a GPU the same agents use csrc/comm.hip (dra_allreduce_grads over RCCL), exercised here with a
+communicator of size 1."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+
+
+def _run(kind, out, world, port):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if world == 1:
+        cmd = [sys.executable, WORKER, kind, out]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), WORKER, kind, out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return dict(np.load(out))
+
+
+@pytest.mark.parametrize("kind,port", [("a2c", 29641), ("ppo", 29642)])
+def test_two_ranks_equal_one_process(tmp_path, kind, port):
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    one = _run(kind, str(tmp_path / "one.npz"), 1, port)
+    two = _run(kind, str(tmp_path / "two.npz"), 2, port)
+    assert int(one["total_steps"]) == int(two["total_steps"]) > 0      # both count GLOBAL environment steps
+    moved = 0.0
+    for k in one:
+        if k == "total_steps":
+            continue
+        # rtol 1e-5 / atol 2e-6 absolute on O(0.05) weights: the two runs differ only in how the batch sum is split.
+        # PPO's Adam (eps 1e-8) turns a gradient element of ANY size into a step of about lr = 2.5e-4, so an element whose
+        # gradient is itself summation noise moves by a noise-dependent amount: a few elements per tensor may differ by a
+        # fraction of lr after the run's 24 Adam steps (measured: 4 of 2048 in fc_action.weight, up to 1.6e-5).
+        err = np.abs(two[k] - one[k])
+        bad = err > 2e-6 + 1e-5 * np.abs(one[k])
+        limit = 0.0 if kind == "a2c" else 0.005
+        assert bad.mean() <= limit and err.max() < 1e-4, "%s: %d of %d elements off, max %g" % (k, bad.sum(), bad.size, err.max())
+        moved = max(moved, float(np.abs(one[k]).max()))
+    assert moved > 0
+
+
+def test_rccl_comm_of_size_one():
+    """csrc/comm.hip through its C ABI: unique id, init_rank, dra_allreduce_grads (sum over 1 rank, then the scale),
+    dra_allreduce_f64, destroy."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import deeprl_amd as d
+    from deeprl_amd.dist import RcclComm
+    d.select_device(0)
+    comm = RcclComm()
+    assert comm.world == 1 and comm.rank == 0
+    g = torch.arange(1, 1 + 4099, dtype=torch.float32, device=d.Config.DEVICE)
+    want = (g * 0.25).cpu().numpy()
+    comm.allreduce_grads(g, 0.25)
+    torch.cuda.synchronize()
+    assert np.array_equal(g.cpu().numpy(), want)
+    comm.close()

@@ -181,3 +181,85 @@ def test_loss_oracles_equal_live_reference_on_random_cases(ref, seed):
     want = ref.QuantileRegressionDQNAgent.compute_loss(ag, tr)
     got = L.qr_loss(th, tt, act, rew, msk, gamma_n)
     np.testing.assert_allclose(got.detach().numpy(), want.detach().numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_network_modules_have_the_reference_names_and_initial_values(ref):
+    """Same seed -> same state_dict (names, order, shapes, initial values) as the reference's modules: checkpoints
+    interchange key by key.  Covers the heads the on-policy / DQN-family goldens do not construct (Dueling, Rainbow +
+    NoisyLinear, OptionCritic, DDPG, TD3).  (Forward passes need the HIP kernels: tests/test_gpu_more_agents.py.)"""
+    import deeprl_amd as d
+    d.select_device(-1)
+    adam = lambda p: torch.optim.Adam(p, 1e-3)
+    makers = [
+        lambda n: n.NoisyLinear(7, 5),
+        lambda n: n.DuelingNet(3, n.FCBody(4, (8,))),
+        lambda n: n.RainbowNet(3, 5, n.FCBody(4, (8,), noisy_linear=True), True),
+        lambda n: n.OptionCriticNet(n.FCBody(4, (8,)), 2, 3),
+        lambda n: n.DeterministicActorCriticNet(4, 2, adam, adam, actor_body=n.FCBody(4, (8,)), critic_body=n.FCBody(6, (8,))),
+        lambda n: n.TD3Net(2, lambda: n.FCBody(4, (8,)), lambda: n.FCBody(6, (8,)), adam, adam),
+        lambda n: n.VanillaNet(4, n.NatureConvBody()),
+        lambda n: n.CategoricalActorCriticNet(4, 3, n.FCBody(4, (8,))),
+        lambda n: n.GaussianActorCriticNet(4, 2, actor_body=n.FCBody(4, (8,)), critic_body=n.FCBody(4, (8,))),
+    ]
+    for mk in makers:
+        torch.manual_seed(1)
+        mine = mk(d).state_dict()
+        torch.manual_seed(1)
+        want = mk(ref).state_dict()
+        assert list(mine) == list(want)
+        for k in want:
+            # orthogonal_ goes through LAPACK's QR: identical here (same process, same library)
+            assert torch.equal(mine[k].cpu(), want[k]), k
+
+
+def test_random_processes_consume_np_random_like_the_reference(ref):
+    import deeprl_amd as d
+    for name in ("OrnsteinUhlenbeckProcess", "GaussianProcess"):
+        np.random.seed(3)
+        a = getattr(d, name)(size=(3,), std=d.LinearSchedule(0.2))
+        xs = np.asarray([a.sample().copy() for _ in range(40)])
+        a.reset_states()
+        tail_a = np.random.rand()
+        np.random.seed(3)
+        b = getattr(ref, name)(size=(3,), std=ref.LinearSchedule(0.2))
+        ys = np.asarray([b.sample().copy() for _ in range(40)])
+        b.reset_states()
+        assert np.array_equal(xs, ys) and tail_a == np.random.rand()
+
+
+def test_run_steps_cadence_equals_reference(ref):
+    """run_steps (misc.py:19-35): the same sequence of save / log / eval / step / switch_task / close calls for an agent
+    whose step() advances total_steps by 4."""
+    import deeprl_amd as d
+
+    def trace(run_steps, config_cls):
+        calls = []
+
+        class Agent:
+            def __init__(self):
+                self.config = config_cls()
+                self.config.tag, self.config.save_interval, self.config.log_interval = "t", 8, 12
+                self.config.eval_interval, self.config.max_steps = 16, 40
+                self.total_steps = 0
+                self.logger = type("L", (), {"info": lambda s, m: calls.append("log " + m.split(",")[0])})()
+
+            def save(self, name):
+                calls.append("save " + name)
+
+            def eval_episodes(self):
+                calls.append("eval %d" % self.total_steps)
+
+            def step(self):
+                self.total_steps += 4
+                calls.append("step")
+
+            def switch_task(self):
+                calls.append("switch")
+
+            def close(self):
+                calls.append("close")
+
+        run_steps(Agent())
+        return calls
+
+    assert trace(d.run_steps, d.Config) == trace(ref.run_steps, ref.Config)
