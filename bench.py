@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-parity-check", action="store_true", help="skip the post-run oracle replay of one agent step")
     ap.add_argument("--no-long-run", action="store_true", help="short runs (< 500 steps): skip the extra 2000-step measurement")
     ap.add_argument("--master-port", type=int, default=29517, help="rendezvous port when bench.py launches the ranks itself")
+    ap.add_argument("--workload", default="dqn_pixel", choices=["dqn_pixel", "a2c_pixel", "ppo_pixel"],
+                    help="dqn_pixel = BASELINE configs[1] (the headline); a2c_pixel / ppo_pixel = configs[4]: the on-policy agents, "
+                         "environments sharded over the ranks, one gradient all-reduce per optimizer step (SURVEY.md 8e)")
     return ap.parse_args()
 
 
@@ -127,7 +130,12 @@ def cpu_baseline(seconds=15.0, ring=20_000):
     n, dt = timed(seconds)
     nproc = os.cpu_count() or 1
     torch.set_num_threads(nproc)
-    n_all, dt_all = timed(max(4.0, seconds / 2))
+    one()                                   # one warm-up only: with hundreds of threads a single update can take seconds
+    n_all, t1 = 0, time.time()
+    while n_all < 1 or time.time() - t1 < 4.0:
+        one()
+        n_all += 1
+    dt_all = time.time() - t1
     torch.set_num_threads(threads_before)
     return {"value": n / dt, "unit": "gradient-updates/sec", "cores": 1, "kind": "port",
             "sample": "%d DQN updates (B=32, 84x84x4, %d-frame ring) in %.1f s, torch-CPU fp32 oracle, 1 thread "
@@ -136,52 +144,44 @@ def cpu_baseline(seconds=15.0, ring=20_000):
                           "sample": "%d updates in %.1f s with torch.set_num_threads(%d)" % (n_all, dt_all, nproc)}}
 
 
-def agent_api(seconds=3.0, ring=100_000):
-    """The same configuration through the drop-in surface: DQNAgent(config).step() as run_steps drives it
-    (examples.py:55-97), with the synthetic emulator on the HOST -- every observation is uploaded and every action
-    crosses back to the host, as in the reference.  DQNAgent attaches the fused learner by itself.  Reported next
-    to `value`, never as `value`."""
+def agent_api(seconds=2.0):
+    """The same configuration through the drop-in surface: zoo.agent('dqn_pixel') = the reference's examples.py::dqn_pixel
+    (1M-frame replay, async_actor=True; examples.py:55-97) stepped exactly as run_steps does (agent.step() in a loop).
+    Three variants: the reference's own setting (async_actor=True: device-resident environment + two-stream pipeline),
+    async_actor=False (same kernels in order) and device_env=False (HOST emulator: every observation uploaded, every action
+    crossing back, as in the reference).  Reported next to `value`, never as `value`."""
     import deeprl_amd as d
     import deeprl_amd.agents as agents_mod
+    from deeprl_amd import zoo
 
     class _Quiet:
         def info(self, *a, **k):
             pass
-
-        def add_scalar(self, *a, **k):
-            pass
-
-        def add_histogram(self, *a, **k):
-            pass
+        add_scalar = add_histogram = info
 
     agents_mod.get_logger = lambda *a, **k: _Quiet()
-    c = d.Config()
-    c.merge(dict(game="BreakoutNoFrameskip-v4", log_level=0, tag="bench", n_step=1, replay_cls=d.UniformReplay, async_replay=False))
-    c.task_fn = lambda: d.Task(c.game, seed=1)
-    c.eval_env = c.task_fn()
-    c.optimizer_fn = lambda p: torch.optim.RMSprop(p, lr=0.00025, alpha=0.95, eps=0.01, centered=True)
-    c.network_fn = lambda: d.VanillaNet(c.action_dim, d.NatureConvBody(in_channels=4))
-    c.random_action_prob = d.LinearSchedule(1.0, 0.01, 1e6)
-    c.batch_size, c.discount, c.history_length = B, 0.99, H
-    kw = dict(memory_size=ring, batch_size=B, n_step=1, discount=0.99, history_length=H)
-    c.replay_fn = lambda: d.ReplayWrapper(c.replay_cls, kw, c.async_replay)
-    c.state_normalizer, c.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
-    c.target_network_update_freq, c.exploration_steps, c.sgd_update_frequency = 10000, 200, 4
-    c.gradient_clip, c.double_q, c.async_actor, c.max_steps = 5, False, False, int(2e7)
-    agent = d.DQNAgent(c)
-    for _ in range(100):
-        agent.step()
-    torch.cuda.synchronize()
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        agent.step()
-        n += 1
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    fused = agent._learner is not None
-    agent.close()
-    return {"updates_per_s": n / dt, "env_steps_per_s": 4 * n / dt, "fused_learner_attached": fused,
-            "note": "DQNAgent.step() (run_steps path), host-side synthetic emulator, sync actor, %d agent steps" % n}
+    out = {}
+    for name, over in (("async_actor", dict(async_actor=True)), ("sync_actor", dict(async_actor=False)),
+                       ("host_emulator", dict(async_actor=False, device_env=False))):
+        d.random_seed(1)
+        over.update(exploration_steps=200, save_interval=0)
+        agent = zoo.agent("dqn_pixel", game="synthetic-atari", overrides=over)
+        for _ in range(300):
+            agent.step()
+        torch.cuda.synchronize()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            agent.step()
+            n += 1
+        if agent._learner is not None:
+            agent._learner.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {"updates_per_s": n / dt, "env_steps_per_s": 4 * n / dt, "device_pipeline": agent._pipe is not None,
+                     "fused_learner": agent._learner is not None}
+        agent.close()
+    out["note"] = "DQNAgent.step() of zoo dqn_pixel (= examples.py::dqn_pixel, 1M-frame ring) as run_steps drives it"
+    return out
 
 
 def parity_check(bench, max_tries=4, gate_margin=5e-7):
@@ -255,10 +255,74 @@ def pmc_traffic(kernel_group):
     return None if rec is None else rec.get("hbm_bytes")
 
 
+def on_policy_main(args):
+    """BASELINE configs[4]: A2C / PPO on Atari shapes, config.num_workers environments PER GPU (weak scaling: 16 resp. 8,
+    examples.py:361-381,525-550), sharded over the ranks with one gradient all-reduce per optimizer step.  A step = one
+    agent.step() = one rollout (+ its optimisation phase); value = environment steps per second over all ranks."""
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    import deeprl_amd as d
+    import deeprl_amd.agents as agents_mod
+    import deeprl_amd.dist as dd
+    from deeprl_amd import zoo
+    n_dev = torch.cuda.device_count()
+    if world > 1:
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        torch.cuda.set_device(local_rank % n_dev)
+        dd.init("nccl" if world <= n_dev else "gloo")
+    d.select_device(local_rank % n_dev)
+
+    class Quiet:
+        def info(self, *a, **k):
+            pass
+        add_scalar = add_histogram = info
+
+    agents_mod.get_logger = lambda *a, **k: Quiet()
+    per_gpu = 16 if args.workload == "a2c_pixel" else 8
+    torch.manual_seed(0)
+    np.random.seed(0)
+    agent = zoo.agent(args.workload, game="synthetic-atari", overrides=dict(num_workers=per_gpu * world, save_interval=0))
+    steps_per_call = agent.config.rollout_length * per_gpu * world
+    for _ in range(max(1, args.warmup // 20)):
+        agent.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    k = max(1, args.steps // 20)
+    t0 = time.perf_counter()
+    for _ in range(k):
+        agent.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "env-steps/sec", "value": k * steps_per_call / dt, "unit": "env-steps/s", "n_gpus": world, "steps": k,
+            "warmup": max(1, args.warmup // 20), "ms_per_step": 1e3 * dt / k, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s (BASELINE configs[4]): %d environments per GPU, rollout %d, host-side synthetic emulators, "
+                                   "gradient all-reduce per optimizer step" % (args.workload, per_gpu, agent.config.rollout_length),
+                       "parallelism": "dp%d" % world, "collective": "dra_allreduce_grads (RCCL)" if agent.dp.comm else
+                       ("torch.distributed " + (dist.get_backend() if world > 1 else "none"))},
+            "updates_per_sec": k * (1 if args.workload == "a2c_pixel" else 16) / dt}), flush=True)
+    agent.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    if args.workload != "dqn_pixel":
+        return on_policy_main(args)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -295,14 +359,18 @@ def main():
     if distributed:
         dist.barrier()
         torch.cuda.synchronize()
+    bench.learner.host_stats(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         bench.step()
+    t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    host = bench.learner.host_stats(reset=True)
+    host["python_loop_us_per_step"] = 1e6 * t_host / args.steps
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -356,6 +424,7 @@ def main():
             "roofline": roof,
         }
         out.update(extra)
+        out["host"] = host      # per step: time in the enqueueing C call, of which blocked on the GPU; whole python loop
         if long_run is not None:
             out["short_run"] = True
             out["long_run"] = long_run

@@ -317,7 +317,7 @@ struct ConvDgradOne {
   static constexpr int TPP = (PP + 31) / 32, TGP = (TPP + PT - 1) / PT;   // tiles / tile groups per phase
   static constexpr int OCW = G::OC / 4, OCH = OCW / 2, NT = KP * KP, NJ = NT * OCH;
   static constexpr int MT = G::C / 32;
-  static constexpr int NCELL = G::OC * CS, RQ = (NCELL + 255) / 256;
+  static constexpr int NCELL = G::OC * CS;
   static constexpr int RED = PT * 4096;
   static constexpr int LDS_FLOATS = NCELL > RED ? NCELL : RED;
   static_assert(G::KH % S == 0, "every stride phase has KP x KP taps");
@@ -353,16 +353,15 @@ struct ConvDgradOne {
           areg[t][v] = *reinterpret_cast<const float4*>(wl + (kh * G::KH + kw) * G::OC + 4 * v);
       }
     }
-    // ---- zero-padded dY[bi] -> LDS
-    float raw[RQ];
-    const float* dyb = dy + (int64_t)bi * G::OC * G::P;
+    // ---- dY[bi] ([OC][OH][OH], contiguous, 16-byte aligned) -> registers as float4: NV loads per workgroup instead of
+    // one dword per padded LDS cell (conv2: 6 float4 per lane instead of 31 dwords, and one constant division per
+    // float4 instead of two per cell: SQ counters showed 1300 VALU instructions per wave for 72 MFMAs, profiles/r02a_*)
+    constexpr int NSRC = G::OC * G::P, NV = NSRC / 4, RV = (NV + 255) / 256;
+    static_assert(NSRC % 4 == 0 && NCELL % 4 == 0, "float4 staging");
+    float4 rawv[RV];
+    const float4* dyb4 = reinterpret_cast<const float4*>(dy + (int64_t)bi * NSRC);
 #pragma unroll
-    for (int q = 0; q < RQ; ++q) {
-      const int e = min(tid + 256 * q, NCELL - 1);
-      const int oc = e / CS, rem = e - oc * CS, rr = rem / RW, cc = rem - rr * RW;
-      const int oh = min(max(rr - PAD, 0), G::OH - 1), ow = min(max(cc - PAD, 0), G::OH - 1);
-      raw[q] = dyb[(oc * G::OH + oh) * G::OH + ow];
-    }
+    for (int q = 0; q < RV; ++q) rawv[q] = dyb4[min(tid + 256 * q, NV - 1)];
     // ---- epilogue side input (activation-derivative source), loaded with everything else
     int ih2[PT], iw2[PT], pix[PT];
     bool inside[PT];
@@ -383,15 +382,25 @@ struct ConvDgradOne {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    // zero the padded image while the loads are in flight, then drop the interior in (cell of source element (oc, oh, ow)
+    // is oc*CS + (oh+PAD)*RW + ow+PAD; a float4 may straddle two output channels)
+    for (int i = tid; i < NCELL / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
 #pragma unroll
-    for (int q = 0; q < RQ; ++q) {
-      const int e = tid + 256 * q;
-      float v = raw[q];
-      asm volatile("" : "+v"(v));  // keep the loads unconditional and batched (see igemm.h)
-      if (e < NCELL) {
-        const int oc = e / CS, rem = e - oc * CS, rr = rem / RW, cc = rem - rr * RW;
-        const bool in = rr >= PAD && rr < PAD + G::OH && cc >= PAD && cc < PAD + G::OH;
-        lds[e] = in ? v : 0.f;
+    for (int q = 0; q < RV; ++q) {
+      const int f = tid + 256 * q;
+      float4 v4 = rawv[q];
+      asm volatile("" : "+v"(v4.x), "+v"(v4.y), "+v"(v4.z), "+v"(v4.w));  // keep the loads unconditional and batched
+      if (f < NV) {
+        const int j0 = 4 * f, oc0 = j0 / G::P, pos0 = j0 - oc0 * G::P;
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int p = pos0 + i, oc = oc0;
+          if (p >= G::P) { p -= G::P; ++oc; }
+          const int oh = p / G::OH, ow = p - oh * G::OH;
+          lds[oc * CS + (oh + PAD) * RW + ow + PAD] = vv[i];
+        }
       }
     }
     DRA_STAMP(TRR, 1);
@@ -461,7 +470,7 @@ struct ConvWgradOne {
   static constexpr int NCH = NCHMAX < G::C ? NCHMAX : G::C;
   static constexpr int IMG = NCH * CS + RW;                     // + zeroed tail for the odd-column pad slot
   static constexpr int LDB = G::OC + 1, NPOS = ROWS * OWP, DYF = NPOS * LDB;
-  static constexpr int LDS_FLOATS = IMG + DYF;
+  static constexpr int LDS_FLOATS = (IMG + DYF + 3) & ~3;       // whole float4s: the zero fill writes 16 bytes at a time
   static_assert(G::K % 32 == 0 && MTILES % MTG == 0 && OH % ROWS == 0, "tiling");
   static_assert(RW >= (OWP - 1) * S + G::KH, "LDS row holds the pad column's taps");
   const float* dy;   // [B][OC][OH][OH]
@@ -487,17 +496,28 @@ struct ConvWgradOne {
     float* dyl = lds + IMG;
     [[maybe_unused]] constexpr int TRR = (G::C == 4) ? TR_CONV1_B : ((G::C == 32) ? TR_CONV2_B : TR_CONV3_B);
     DRA_STAMP(TRR, 0);
-    // ---- issue all loads: dY chunk, then the image rows
-    constexpr int NDY = G::OC * NPOS, RD = (NDY + 255) / 256;
-    float draw[RD];
+    // ---- issue all loads: dY chunk, then the image rows.  Loads walk the SOURCE as float4 (a few per lane, one constant
+    // division each) instead of one dword per padded LDS cell with two or three divisions (SQ counters: ~1300 VALU
+    // instructions per wave around 90 MFMAs, profiles/r02a_sq_learner_b32.json); padding is zero-filled up front.
+    // dY: per output channel the chunk's ROWS*OH gradients are one contiguous run; a whole-sample chunk (ROWS == OH)
+    // makes all OC runs one block.
+    constexpr bool WHOLE = (ROWS == OH);
+    constexpr int RUN = ROWS * OH;                                   // floats per output channel in this chunk
+    static_assert(WHOLE ? (G::OC * G::P) % 4 == 0 : RUN % 4 == 0, "float4 dY staging");
+    constexpr int NVD = WHOLE ? (G::OC * G::P) / 4 : G::OC * (RUN / 4), RD = (NVD + 255) / 256;
+    float4 draw[RD];
     const float* dyb = dy + (int64_t)bi * G::OC * G::P + chunk * ROWS * OH;
 #pragma unroll
     for (int q = 0; q < RD; ++q) {
-      const int e = min(tid + 256 * q, NDY - 1);
-      const int oc = e / NPOS, pos = e - oc * NPOS, ohl = pos / OWP, ow = pos - ohl * OWP;
-      draw[q] = dyb[oc * G::P + ohl * OH + min(ow, OH - 1)];
+      const int f = min(tid + 256 * q, NVD - 1);
+      if constexpr (WHOLE) {
+        draw[q] = reinterpret_cast<const float4*>(dyb)[f];
+      } else {
+        const int oc = f / (RUN / 4), v = f - oc * (RUN / 4);
+        draw[q] = *reinterpret_cast<const float4*>(dyb + oc * G::P + 4 * v);
+      }
     }
-    if (U8) {
+    if constexpr (U8) {
       constexpr int WPR = G::H / 4;                         // u32 words per 84-byte row
       constexpr int NW = NCH * NR * WPR, RI = (NW + 255) / 256;
       unsigned iraw[RI];
@@ -509,6 +529,7 @@ struct ConvWgradOne {
         iraw[q] = *reinterpret_cast<const unsigned*>(xb + ((int64_t)min(cl, nch - 1) * G::H + ir0 + rr) * G::H + 4 * wd);
       }
       __builtin_amdgcn_sched_barrier(0);
+      for (int i = tid; i < DYF; i += 256) dyl[i] = 0.f;        // pad columns of the transposed gradient
 #pragma unroll
       for (int q = 0; q < RI; ++q) {
         const int e = tid + 256 * q;
@@ -529,39 +550,65 @@ struct ConvWgradOne {
           img[cl * CS + rr * RW + G::H + pc] = 0.f;
         }
       }
-      if (CSPAD > 0) for (int e = tid; e < NCH * CSPAD; e += 256) img[(e / CSPAD) * CS + NR * RW + e % CSPAD] = 0.f;
+      if constexpr (CSPAD > 0) for (int e = tid; e < NCH * CSPAD; e += 256) img[(e / CSPAD) * CS + NR * RW + e % CSPAD] = 0.f;
       for (int e = tid; e < RW; e += 256) img[NCH * CS + e] = 0.f;
+      __syncthreads();                                           // zero fill of dyl complete before the gradient lands
     } else {
-      constexpr int NE = NCH * CS + RW, RI = (NE + 255) / 256;   // loop over every LDS cell: loaded or zero
-      float iraw[RI];
-      const float* xf = reinterpret_cast<const float*>(x) + ((int64_t)bi * G::C + c_lo) * G::HW;
+      // image: per channel the chunk's NR input rows are one contiguous run of NR*H floats (the whole image for conv2 /
+      // conv3, where a chunk is a whole sample)
+      constexpr int RUNI = NR * G::H;
+      constexpr bool V4 = (RUNI % 4 == 0) && (G::HW % 4 == 0) && (G::H % 4 == 0);   // conv3 (9x9 images): dwords
+      constexpr int VPC = V4 ? RUNI / 4 : RUNI;                   // loads per channel
+      constexpr int NVI = NCH * VPC, RI = (NVI + 255) / 256;
+      const float* xf = reinterpret_cast<const float*>(x) + ((int64_t)bi * G::C + c_lo) * G::HW + (int64_t)ir0 * G::H;
+      float4 iraw4[V4 ? RI : 1];
+      float iraw1[V4 ? 1 : RI];
 #pragma unroll
       for (int q = 0; q < RI; ++q) {
-        const int e = min(tid + 256 * q, NE - 1);
-        const int cl = min(e / CS, nch - 1), rem = e % CS, rr = min(rem / RW, NR - 1), cc = min(rem % RW, G::H - 1);
-        iraw[q] = xf[((int64_t)cl * G::H + ir0 + rr) * G::H + cc];
+        const int f = min(tid + 256 * q, nch * VPC - 1);
+        const int cl = f / VPC, v = f - cl * VPC;
+        if constexpr (V4) iraw4[q] = *reinterpret_cast<const float4*>(xf + (int64_t)cl * G::HW + 4 * v);
+        else iraw1[q] = xf[(int64_t)cl * G::HW + v];
       }
       __builtin_amdgcn_sched_barrier(0);
+      // zero everything (image padding + transposed-gradient pad columns) while the loads are in flight
+      for (int i = tid; i < (IMG + DYF + 3) / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();
 #pragma unroll
       for (int q = 0; q < RI; ++q) {
-        const int e = tid + 256 * q;
-        float v = iraw[q];
-        asm volatile("" : "+v"(v));
-        if (e < NE) {
-          const int cl = e / CS, rem = e - cl * CS, rr = rem / RW, cc = rem - rr * RW;
-          const bool in = cl < nch && rr < NR && cc < G::H;
-          img[e] = in ? v : 0.f;
+        const int f = tid + 256 * q;
+        if (f < nch * VPC) {
+          const int cl = f / VPC, v = f - cl * VPC;
+          if constexpr (V4) {
+            float4 v4 = iraw4[q];
+            const int r0 = 4 * v, rr = r0 / G::H, cc = r0 - rr * G::H;   // H % 4 == 0: a float4 never leaves its image row
+            float* d = img + cl * CS + rr * RW + cc;
+            d[0] = v4.x; d[1] = v4.y; d[2] = v4.z; d[3] = v4.w;
+          } else {
+            const int rr = v / G::H, cc = v - rr * G::H;
+            img[cl * CS + rr * RW + cc] = iraw1[q];
+          }
         }
       }
     }
+    // transposed gradient: element (oc, ohl, ow) -> dyl[(ohl*OWP + ow)*LDB + oc]
 #pragma unroll
     for (int q = 0; q < RD; ++q) {
-      const int e = tid + 256 * q;
-      float v = draw[q];
-      asm volatile("" : "+v"(v));
-      if (e < NDY) {
-        const int oc = e / NPOS, pos = e - oc * NPOS, ow = pos % OWP;
-        dyl[pos * LDB + oc] = ow < OH ? v : 0.f;
+      const int f = tid + 256 * q;
+      float4 v4 = draw[q];
+      asm volatile("" : "+v"(v4.x), "+v"(v4.y), "+v"(v4.z), "+v"(v4.w));
+      if (f < NVD) {
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        int oc0, pos0;
+        if constexpr (WHOLE) { oc0 = (4 * f) / G::P; pos0 = 4 * f - oc0 * G::P; }
+        else { oc0 = f / (RUN / 4); pos0 = 4 * (f - oc0 * (RUN / 4)); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int p = pos0 + i, oc = oc0;
+          if (WHOLE && p >= G::P) { p -= G::P; ++oc; }
+          const int ohl = p / OH, ow = p - ohl * OH;
+          dyl[(ohl * OWP + ow) * LDB + oc] = vv[i];
+        }
       }
     }
     DRA_STAMP(TRR, 1);

@@ -11,6 +11,7 @@
 //                               coef = max_norm / (norm + 1e-6), and applies the update.
 // HBM-bound: centered RMSprop reads p,g,sq,ga and writes p,sq,ga (+ the norm read) = 32 B/param.
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 constexpr int kNormBlocks = 512;  // fixed so graphs replay the same reduction tree
@@ -252,6 +253,25 @@ __device__ __forceinline__ void rmsprop_elem(float& p, float g, float& s, float&
   p = p - lr * (gk / avg);
 }
 
+// NT: the optimizer state (sq, ga) and the gradient are touched once per update -- stream them past the caches
+// (non-temporal) so that the update does not evict what the concurrently running actor re-reads from L2 / MALL
+// (its parameter copy: 4 forwards per agent step)
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float4* p) {
+  if (!NT) return *p;
+  const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool NT>
+__device__ __forceinline__ void st4(float4* p, const float4& v) {
+  if (!NT) { *p = v; return; }
+  f32x4_nt w;
+  w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<f32x4_nt*>(p));
+}
+
+template <bool NT>
 __global__ void __launch_bounds__(256)
 rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, float* __restrict__ ga,
                     int64_t n, const double* __restrict__ partials, int n_partials, float max_norm, float lr,
@@ -268,9 +288,9 @@ rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* _
     const int64_t i = i0 + 256 * v;
     const int64_t ic = i < n4 ? i : n4 - 1;
     P[v] = reinterpret_cast<float4*>(p)[ic];
-    G[v] = reinterpret_cast<const float4*>(g)[ic];
-    S[v] = reinterpret_cast<float4*>(sq)[ic];
-    A[v] = reinterpret_cast<float4*>(centered ? ga : sq)[ic];
+    G[v] = ld4<NT>(reinterpret_cast<const float4*>(g) + ic);
+    S[v] = ld4<NT>(reinterpret_cast<const float4*>(sq) + ic);
+    A[v] = ld4<NT>(reinterpret_cast<const float4*>(centered ? ga : sq) + ic);
   }
   __builtin_amdgcn_sched_barrier(0);
   const float coef = clip_coef_from_partials(partials, n_partials, max_norm, out_norm);
@@ -284,8 +304,8 @@ rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* _
       for (int k = 0; k < 4; ++k) rmsprop_elem(pp[k], gg[k], ss[k], aa[k], coef, alpha, oma, lr, eps, centered);
       reinterpret_cast<float4*>(p)[i] = P[v];
       if (p_copy) reinterpret_cast<float4*>(p_copy)[i] = P[v];
-      reinterpret_cast<float4*>(sq)[i] = S[v];
-      if (centered) reinterpret_cast<float4*>(ga)[i] = A[v];
+      st4<NT>(reinterpret_cast<float4*>(sq) + i, S[v]);
+      if (centered) st4<NT>(reinterpret_cast<float4*>(ga) + i, A[v]);
     }
   }
   // tail (n not a multiple of 4): the last few floats, by the first threads of workgroup 0
@@ -319,8 +339,14 @@ DRA_API int dra_rmsprop_step_copy(float* param, const float* grad, float* square
   if (n < 4) return DRA_EINVAL;
   if (partials && (n_partials < 1 || n_partials > dra_norm_partials_max())) return DRA_EINVAL;
   if (step_blocks(n) > 0x7fffffff) return DRA_EINVAL;
-  hipLaunchKernelGGL(rmsprop_step_kernel, dim3((unsigned)step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad, square_avg,
-                     grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps, centered, out_norm, param_copy);
+  static int nt = -1;
+  if (nt < 0) { const char* e = getenv("DRA_NT_OPT"); nt = e ? atoi(e) : 0; }
+  if (nt & 1)
+    hipLaunchKernelGGL(rmsprop_step_kernel<true>, dim3((unsigned)step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad,
+                       square_avg, grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps, centered, out_norm, param_copy);
+  else
+    hipLaunchKernelGGL(rmsprop_step_kernel<false>, dim3((unsigned)step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad,
+                       square_avg, grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps, centered, out_norm, param_copy);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

@@ -13,6 +13,7 @@
 // the index stream is the reference's own np.random stream.
 #include "common.h"
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -274,6 +275,9 @@ ring_gather_kernel(const uint8_t* __restrict__ frames, const uint8_t* __restrict
   DRA_STAMP_END(TR_GATHER);
 }
 
+// (A workgroup-per-SAMPLE shape -- one workgroup walking the whole 5-frame run, 3 loads per lane in flight -- was measured
+// for many-minibatch launches and LOST to the workgroup-per-frame shape below: 4.90 vs 5.81 TB/s at 1024 minibatches on the
+// same box, profiles/r02w_kernel_microbench_gather_ab.json; fewer, longer workgroups leave fewer loads in flight per CU.)
 DRA_API int dra_ring_gather(dra_ring* r, const int64_t* idx_dev, int batch, void* out_state, void* out_next_state,
                             void* out_action, double* out_reward, int32_t* out_mask, float* out_reward_f32,
                             float* out_mask_f32, void* stream) {

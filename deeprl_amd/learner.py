@@ -123,12 +123,14 @@ class DQNLearner:
     def _partitioned_streams(self):
         """Update stream / actor stream on disjoint CU sets (DRA_VAR_CU_PARTITION).  On MI355X mask bit i is CU
         (i // 32) of shader engine (i // 8) % 4 of XCD i % 8 (tools/probe_cu_mask.py), and a workgroup's XCD is
-        fixed by the dispatcher (round robin), so the first DRA_ACTOR_CUS (default 3/8 of the device = 96) bits give
-        the actor chain the same 12 CUs (3 per shader engine) in every XCD and the update chain the other 20
-        (scan with the parameter ring: 64 -> 6372, 80 -> 6614, 96 -> 6705, 112 -> 5671 updates/s on one box)."""
+        fixed by the dispatcher (round robin), so the first DRA_ACTOR_CUS (default 1/4 of the device = 64) bits give
+        the actor chain the same 8 CUs (2 per shader engine) in every XCD and the update chain the other 24.
+        Round 2 (4-launch env step, 8-wave batch-1 convolutions): 96 -> 6876, 64 -> 7438, 56 -> 7082, 48 -> 6379 updates/s on
+        one box (profiles/r02f_*): at 192 CUs conv2 / conv3 backward (384 workgroups at 2 per CU) and the optimizer fit
+        ONE round of workgroups, at 160 they do not (phase traces, profiles/r02b_*)."""
         import os
         n_cu = torch.cuda.get_device_properties(Config.DEVICE).multi_processor_count
-        n_act = max(8, min(n_cu - 8, int(os.environ.get("DRA_ACTOR_CUS", str(3 * n_cu // 8)))))   # 96 of 256
+        n_act = max(8, min(n_cu - 8, int(os.environ.get("DRA_ACTOR_CUS", str(n_cu // 4)))))   # 64 of 256
         key = (Config.DEVICE.index, n_act)
         self.update_cus, self.actor_cus = n_cu - n_act, n_act
         if key in _PARTITIONED_STREAMS:
@@ -243,6 +245,15 @@ class DQNLearner:
     def synchronize(self):
         self.stream.synchronize()
         self.actor_stream.synchronize()
+
+    def host_stats(self, reset=True):
+        """Host-side accounting of dra_dqn_learner_step since the last reset: number of calls, mean microseconds inside the
+        C call, and of those the microseconds BLOCKED on a pinned staging slot, i.e. waiting for the GPU (back-pressure: a
+        loop whose calls never block is host-bound)."""
+        out = (ctypes.c_double * 3)()
+        lib.dra_dqn_learner_host_stats(self.h, out, int(reset))
+        n = max(1.0, out[0])
+        return {"calls": int(out[0]), "call_us": 1e6 * out[1] / n, "blocked_on_gpu_us": 1e6 * out[2] / n}
 
     def invalidate_actor_copy(self):
         """The parameters were changed from outside (checkpoint load): the async actor's copies are reseeded on the next step."""

@@ -260,6 +260,9 @@ class PrioritizedReplay(UniformReplay):
         self._lazy_tree()
         # SumTree.add (sum_tree.py:39-51): the new leaf is self-marked pending then set
         leaf = self._write + self.memory_size - 1
+        # SumTree.add marks the leaf pending and update() clears it (sum_tree.py:39-51,54-60): a leaf that was sampled
+        # and is overwritten before its priority came back is NOT pending any more -- the late update is dropped
+        self._pending.discard(leaf)
         with torch.cuda.device(self._device()):
             self.tree.set(leaf, float(self.max_priority))
         self._write += 1
