@@ -1141,7 +1141,8 @@ env_frame_ring_kernel(const uint8_t* __restrict__ ring, const unsigned* __restri
   synth_pending(aring_entry(ring, *seq), 0, pend_frame, pend_reward, pend_mask, seed, done_period);
 }
 
-__global__ void __launch_bounds__(256)
+// (launched with 1024 threads: the 882-word frame generation is the long pole of this one-workgroup kernel)
+__global__ void __launch_bounds__(1024)
 actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restrict__ seq, int e, int last, int commit,
                            const float* __restrict__ h4, const float* __restrict__ wh, const float* __restrict__ bh, int A,
                            uint8_t* __restrict__ ring_actions, float* __restrict__ q_out, uint8_t* __restrict__ frames,
@@ -1162,7 +1163,7 @@ actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restric
     for (int w = threadIdx.x; w < 882; w += blockDim.x) dst[w] = src[w];
     if (threadIdx.x == 0) { rewards[slot] = *pend_reward; masks[slot] = *pend_mask; }
   }
-  for (int a = wave; a < A; a += 4) {
+  for (int a = wave; a < A; a += (int)(blockDim.x >> 6)) {
     float part = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) part += h4[lane + 64 * i] * wh[a * 512 + lane + 64 * i];
@@ -1228,7 +1229,7 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
                        l->ah4, 3136);
     DRA_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(256), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq,
+  hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq,
                      n_env - 1, 1, 0, (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq,
                      (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
                      (uint64_t)c.env_seed, (int)c.env_done_period);
@@ -1259,7 +1260,7 @@ static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, h
     if ((rc = dra_conv_fwd_koc(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
     hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
                        l->ah4, 3136);
-    hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(256), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq, e,
+    hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq, e,
                        (int)(e == n_env - 1), 1, (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions,
                        l->aq, (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
                        (uint64_t)c.env_seed, (int)c.env_done_period);

@@ -38,8 +38,8 @@ class _Quiet:
 
 def dqn_family(kind, replay_cls, ring=200_000, fused=True):
     c = d.Config()
-    c.merge(dict(game="BreakoutNoFrameskip-v4", log_level=0, tag="bench", n_step=1, replay_cls=replay_cls, async_replay=False,
-                 fused_learner=fused))
+    c.merge(dict(game="synthetic-atari", log_level=0, tag="bench", n_step=1, replay_cls=replay_cls, async_replay=False,
+                 fused_learner=fused, device_env=False))      # HOST emulator (bench.py's agent_api reports the device-resident one)
     c.task_fn = lambda: d.Task(c.game, seed=1)
     c.eval_env = c.task_fn()
     if kind == "dqn":

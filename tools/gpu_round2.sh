@@ -1,0 +1,27 @@
+#!/bin/bash
+# One gpurun call: bench, rocprofv3 kernel stats of the same command, the two --pmc traffic passes (FETCH_SIZE / WRITE_SIZE,
+# separate runs, kernel-trace only), SQ counters at batch 32, phase traces.  Everything under gpurun_out/<tag>/.
+TAG=${1:-r02x}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+nproc > $OUT/nproc.txt
+echo "== bench" ; timeout 500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; head -c 400 $OUT/bench.json; echo
+echo "== bench (driver command)" ; timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err; head -c 300 $OUT/bench_driver_cmd.json; echo
+echo "== rocprofv3 kernel trace" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -- python $R/bench.py --steps 600 --warmup 100 --no-cpu-baseline --no-parity-check > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_bench.err)
+python tools/prof_summary.py $OUT/prof > $OUT/rocprofv3_kernel_stats.txt 2>&1; head -32 $OUT/rocprofv3_kernel_stats.txt
+python tools/prof_timeline.py $OUT/prof 200 2 > $OUT/timeline.txt 2>&1
+find $OUT/prof -name "*.db" -size +20M -delete
+echo "== pmc FETCH_SIZE" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -- python $R/tools/pmc_workload.py --steps 40 --variant 255 > $R/$OUT/pmc_fetch.log 2>&1); tail -2 $OUT/pmc_fetch.log
+echo "== pmc WRITE_SIZE" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write -- python $R/tools/pmc_workload.py --steps 40 --variant 255 > $R/$OUT/pmc_write.log 2>&1); tail -2 $OUT/pmc_write.log
+python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; head -c 1200 $OUT/pmc_traffic.json; tail -3 $OUT/pmc_traffic.err
+find $OUT/pmc_fetch $OUT/pmc_write -name "*.db" -size +20M -delete
+find $OUT/pmc_fetch $OUT/pmc_write -name "*kernel_trace*" -size +20M -delete
+echo "== SQ counters at batch 32"; bash tools/pmc_sq_learner.sh $TAG > $OUT/sq.log 2>&1; tail -3 $OUT/sq.log
+export DEEPRL_AMD_LIB=$R/deeprl_amd/lib/libdeeprl_amd_trace.so
+echo "== phase traces"; timeout 200 python tools/phase_trace.py > $OUT/phase_async.json 2> $OUT/phase.err; python tools/phase_summary.py $OUT/phase_async.json | grep -E "chain|env step"
+timeout 200 python tools/phase_trace.py --sync > $OUT/phase_sync.json 2>> $OUT/phase.err; python tools/phase_summary.py $OUT/phase_sync.json | grep -E "chain|env step"
+unset DEEPRL_AMD_LIB
+echo "== agents bench"; timeout 400 python tools/bench_agents.py > $OUT/bench_agents.jsonl 2> $OUT/bench_agents.err; cat $OUT/bench_agents.jsonl | cut -c1-300
+echo "== done"
