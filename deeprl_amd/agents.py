@@ -8,7 +8,9 @@ PPO_agent.py:12-100, NStepDQN_agent.py:12-67.
 Differences that are the point of the rewrite (results unchanged):
   * actor / replay "processes" are in-process objects: the replay is an HBM ring, so the
     pickle-over-pipe hops of BaseAgent.py:142-172 / replay.py:219-278 have nothing left to hide;
-    `config.async_actor` / `async_replay` are accepted and ignored;
+    `async_replay` is accepted and has no effect; `config.async_actor` selects, for DQNAgent on the dqn_pixel
+    configuration with a device-resident environment, the two-stream actor / learner pipeline of csrc/learner.hip
+    (DQNAgent._attach_device_pipeline) and is otherwise a no-op;
   * TD / C51 / QR / PPO / A2C losses are single fused kernels that emit the gradient w.r.t. the
     network output, which is pushed through the HIP contractions by autograd;
   * clip_grad_norm_ + optimizer.step() are two launches over one flat buffer (optim.py);

@@ -64,10 +64,21 @@ def main(argv=None):
     ap.add_argument("--max-steps", type=float, default=None)
     ap.add_argument("--seed", type=int, default=None)
     args = ap.parse_args(argv)
+    import os
     import deeprl_amd as d
     d.mkdir("log")
     d.mkdir("tf_log")
     d.set_one_thread()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:       # launched by torch.distributed.run: one rank per GPU, A2C / PPO become data-parallel (dist.py)
+        import torch
+        from . import dist as dp
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        args.gpu = local % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(args.gpu)
+        dp.init("nccl" if torch.cuda.device_count() >= world else "gloo")
+        if args.seed is None:
+            args.seed = 1 + int(os.environ.get("RANK", "0"))     # distinct exploration per rank unless asked otherwise
     d.random_seed(args.seed)
     d.select_device(args.gpu)
     mod = load_examples(args.file)

@@ -34,10 +34,9 @@ def _frames_of(slots, seed):
 
 @pytest.mark.parametrize("n_step,b", [(1, 256), (3, 256), (1, 4096), (3, 2048)])
 def test_full_size_ring_gather_properties(dev, n_step, b):
-    """BASELINE configs[1]/[3]: 1 000 000-frame ring of 84x84 uint8 frames, H = 4, batch 32 x 8 minibatches (the
-    workgroup-per-frame latency shape) and 32 x 128 / 32 x 64 (>= 2048 samples: the workgroup-per-sample throughput
-    shape, ring.hip ring_gather_sample_kernel), indices that include the first / last valid slots on both sides of the
-    write head."""
+    """BASELINE configs[1]/[3]: 1 000 000-frame ring of 84x84 uint8 frames, H = 4, batch 32 x 8 minibatches and
+    32 x 128 / 32 x 64 (the many-minibatch launches the gather roofline is quoted on), indices that include the first /
+    last valid slots on both sides of the write head."""
     from deeprl_amd import ops
     cap, h, gamma, seed = 1_000_000, 4, 0.99, 11
     ring = ops.Ring(cap, 7056, 8, h, n_step, gamma)
