@@ -12,7 +12,7 @@
 #include "oneshot.h"
 #include <stdlib.h>
 
-static int g_tuning = 511 | 4096 | 8192;  // every bit up to DRA_VAR_CU_PARTITION plus DRA_VAR_ACTOR_RING measured faster on MI355X
+static int g_tuning = 511 | 4096 | 8192 | 16384;  // every bit up to DRA_VAR_CU_PARTITION plus DRA_VAR_ACTOR_RING measured faster on MI355X
                                    // (profiles/r01b_ab_variants.jsonl, r01d_*, r01f_*); ACTOR_V3 (512), ACTOR_FUSED_HEAD (1024)
                                    // and GATHER_IN_GRAPH (2048) measured neutral or slower and stay opt-in
 

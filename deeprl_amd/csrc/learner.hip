@@ -131,6 +131,7 @@ struct dra_dqn_learner {
   hipEvent_t last_done;             // the event recorded after the most recent optimizer launch (ev_step_done, or the
                                     // pipelined step's per-parity event: ONE record per step on the update stream)
   bool actor_pending;               // async mode: an actor graph has been issued and not yet consumed
+  hipEvent_t actor_last = nullptr;  // GATHER_ON_UPDATE: recorded after the most recent actor launch (a staging-slot event)
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
 };
@@ -1505,11 +1506,11 @@ static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, in
     if (l->variant & DRA_VAR_ACTOR_RING) rc = issue_actor_ring(l, prm->n_env, l->pa[l->pa_cur], l->pa_cur, sa, true);
     else rc = issue_actor(l, prm, k, l->pa[l->pa_cur], sa, true);
     if (rc) return rc;
-    DRA_HIP(hipEventRecord(l->ev_actor_done, sa));
-    l->actor_pending = true;
+    l->actor_pending = true;     // (nothing waits for an 'actor done' event on this path: stream order + stage_ev[k] below)
     TRACE(2, sa);
   }
   DRA_HIP(hipEventRecord(l->stage_ev[k], sa));  // staging slot k: parameter block copy and the gather's pinned index reads
+  if (prm->n_env > 0) l->actor_last = l->stage_ev[k];
   if (do_update) {
     if (!(dbg & 1)) DRA_HIP(hipStreamWaitEvent(su, l->ev_mb_ready[par], 0));
     if (seeded) DRA_HIP(hipStreamWaitEvent(su, l->ev_join[0], 0));    // the seed copy read the parameters this step overwrites
@@ -1522,6 +1523,85 @@ static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, in
     DRA_HIP(hipEventRecord(l->ev_mb_free[par], su));
     l->last_done = l->ev_mb_free[par];
     l->mb_used[par] = true;
+    if (l->pa_valid) l->pa_cur = par;   // the graph's optimizer wrote copy `par`
+    l->step_no++;
+  }
+  return DRA_OK;
+}
+
+// async mode, DRA_VAR_GATHER_ON_UPDATE (on top of PIPE_GATHER + ACTOR_PARAMS): the gather moves to the UPDATE stream.
+// The phase traces (profiles/r02x_phase_async.json) show the actor chain -- 4 env steps of 4 launches + tail + gather and
+// three stream-level event records -- is the longer one (update stream idle ~18 us per step); here the actor stream
+// carries only [wait optimizer t-1] [actor graph t+1] [one record], the update stream
+// [wait actor graph t] [gather t] [update graph t] [one record].
+// The write-after-read hazard the actor-stream gather excluded by stream order (actor graph t+1 overwrites the OLDEST
+// ring slots, which minibatch t may still sample once the ring is full) is decided on the host, which knows both the
+// indices and the slots: in that (rare: ~1e-4 of the steps at 10^6 slots) case the actor graph also waits for this
+// step's update.  Results are bit-identical to step_pipelined.
+static bool gather_reads_slots(const dra_dqn_learner* l, const dra_dqn_step_params* prm) {
+  int hh = 4, nn = 1;
+  (void)dra_ring_shape(l->ring, &hh, &nn);
+  const int64_t h = hh, n = nn;
+  for (int e = 0; e < prm->n_env; ++e) {
+    const int64_t s = prm->slot[e];
+    for (int b = 0; b < l->c.batch; ++b)
+      if (s >= prm->idx[b] - h + 1 && s <= prm->idx[b] + n) return true;
+  }
+  return false;
+}
+
+static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, hipStream_t su,
+                           hipStream_t sa, int k) {
+  const int B = l->c.batch;
+  const int par = (int)(l->step_no & 1);
+  int rc;
+  hipEvent_t opt_prev = l->last_done;          // optimizer of step t-1: produced the copy the actor graph below reads
+  const bool hazard = do_update && prm->n_env > 0 && gather_reads_slots(l, prm);
+  bool seed = false;
+  if (prm->n_env > 0) {
+    if (l->pa_valid && l->pa_cur != (par ^ 1)) l->pa_valid = false;   // copies out of phase with the step parity
+    seed = !l->pa_valid;
+  }
+  if (seed) {   // (re)seed the actor copy from the online parameters BEFORE this step's optimizer overwrites them
+    if (opt_prev) DRA_HIP(hipStreamWaitEvent(sa, opt_prev, 0));
+    l->pa_cur = par ^ 1;
+    DRA_HIP(hipMemcpyAsync(l->pa[l->pa_cur], l->p, (size_t)l->c.n_params * sizeof(float), hipMemcpyDeviceToDevice, sa));
+    DRA_HIP(hipEventRecord(l->ev_join[0], sa));
+    l->pa_valid = true;
+  }
+  if (do_update) {
+    if (l->actor_last) DRA_HIP(hipStreamWaitEvent(su, l->actor_last, 0));   // transitions of step t are in the ring
+    if (seed) DRA_HIP(hipStreamWaitEvent(su, l->ev_join[0], 0));
+    const int64_t* pinned = (l->variant & DRA_VAR_PINNED_IDX) ? l->idx_stage + (size_t)k * 1024 : nullptr;
+    if (!pinned)
+      DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
+    TRACE(0, su);
+    l->gb = par;
+    rc = launch_gather(l, su, pinned);
+    l->gb = 0;
+    if (rc) return rc;
+    TRACE(1, su);
+    TRACE(3, su);
+    if ((rc = pipe_graph(l, su, par))) return rc;
+    TRACE(4, su);
+    DRA_HIP(hipEventRecord(l->ev_mb_free[par], su));   // the ONE record of the update stream: optimizer t done
+    l->last_done = l->ev_mb_free[par];
+    l->mb_used[par] = true;
+  }
+  if (prm->n_env > 0) {
+    if (!seed && opt_prev) DRA_HIP(hipStreamWaitEvent(sa, opt_prev, 0));
+    if (hazard) DRA_HIP(hipStreamWaitEvent(sa, l->last_done, 0));      // the gather reads slots this graph overwrites
+    const int cur = l->pa_cur;
+    if (l->variant & DRA_VAR_ACTOR_RING) rc = issue_actor_ring(l, prm->n_env, l->pa[cur], cur, sa, true);
+    else rc = issue_actor(l, prm, k, l->pa[cur], sa, true);
+    if (rc) return rc;
+    l->actor_pending = true;
+    TRACE(2, sa);
+  }
+  DRA_HIP(hipEventRecord(l->stage_ev[k], sa));   // the ONE record of the actor stream: graph done, staging slot k free
+  if (prm->n_env > 0) l->actor_last = l->stage_ev[k];
+  if (do_update) {
+    if (l->tr_ev && l->tr_n < l->tr_cap) l->tr_n++;
     if (l->pa_valid) l->pa_cur = par;   // the graph's optimizer wrote copy `par`
     l->step_no++;
   }
@@ -1635,6 +1715,9 @@ static int stage_acquire(dra_dqn_learner* l, int* k_out) {
   if (l->stage_used[k]) {
     const auto t0 = std::chrono::steady_clock::now();
     DRA_HIP(hipEventSynchronize(l->stage_ev[k]));
+    // GATHER_ON_UPDATE: the gather of that call read its indices from slot k on the UPDATE stream; the actor graph of the
+    // call after it waited for that update, so its event (7 calls old) implies the gather is done
+    if ((l->variant & DRA_VAR_GATHER_ON_UPDATE) && l->stage_used[(k + 1) % 8]) DRA_HIP(hipEventSynchronize(l->stage_ev[(k + 1) % 8]));
     l->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
   l->stage_used[k] = true;
@@ -1653,6 +1736,7 @@ DRA_API int dra_dqn_learner_act(dra_dqn_learner* l, const dra_dqn_step_params* p
   if (l->variant & DRA_VAR_ACTOR_RING) rc = issue_actor_ring(l, prm->n_env, l->p, 0, st, false);
   else rc = issue_actor(l, prm, k, l->p, st, use_graph != 0);
   DRA_HIP(hipEventRecord(l->stage_ev[k], st));
+  l->actor_last = l->stage_ev[k];
   return rc;
 }
 
@@ -1719,6 +1803,7 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
   // ---- async mode
   if ((l->variant & DRA_VAR_PIPE_GATHER) && (l->variant & DRA_VAR_ACTOR_PARAMS)) {
     if ((l->variant & DRA_VAR_GATHER_IN_GRAPH) && !(l->variant & DRA_VAR_ACTOR_V3)) return step_pipelined2(l, prm, do_update, su, sa, k);
+    if (l->variant & DRA_VAR_GATHER_ON_UPDATE) return step_pipelined3(l, prm, do_update, su, sa, k);
     return step_pipelined(l, prm, do_update, su, sa, k);
   }
   if (do_update) {

@@ -70,6 +70,13 @@ DRA_API int dra_ring_destroy(dra_ring* r) {
 }
 
 // Raw device pointers, for zero-copy consumers (fused learner) and tests.
+DRA_API int dra_ring_shape(dra_ring* r, int* history, int* n_step) {
+  if (!r || !history || !n_step) return DRA_EINVAL;
+  *history = r->history;
+  *n_step = r->n_step;
+  return DRA_OK;
+}
+
 DRA_API int dra_ring_pointers(dra_ring* r, void** frames, void** actions, void** rewards, void** masks) {
   if (!r) return DRA_EINVAL;
   if (frames) *frames = r->frames;

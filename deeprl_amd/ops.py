@@ -387,7 +387,8 @@ VAR_ACTOR_FUSED_HEAD = 1024
 VAR_GATHER_IN_GRAPH = 2048
 VAR_ACTOR_RING = 4096
 VAR_ACTOR_FUSED_CONV1 = 8192
-VAR_ALL = 16383
+VAR_GATHER_ON_UPDATE = 16384
+VAR_ALL = 32767
 
 
 def set_tuning(mask):

@@ -32,6 +32,7 @@ typedef struct dra_ring dra_ring;
  * action record (8 for int64). */
 int dra_ring_create(dra_ring** out, int64_t capacity, int64_t frame_bytes, int64_t action_bytes, int history,
                     int n_step, double discount);
+int dra_ring_shape(dra_ring* ring, int* history, int* n_step);   /* the history_length / n_step it was created with */
 int dra_ring_destroy(dra_ring* ring);
 int dra_ring_pointers(dra_ring* ring, void** frames, void** actions, void** rewards, void** masks);
 /* replay.py:75-90 (feed): write `count` consecutive slots from DEVICE-ACCESSIBLE sources (device or pinned host).
@@ -164,6 +165,9 @@ int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* 
                                     kernel of a step produces the next step's first frame */
 #define DRA_VAR_ACTOR_FUSED_CONV1 8192 /* with ACTOR_RING: the head of env step e-1 and the environment step run in front of
                                           conv1 of step e in one launch (4 launches per env step instead of 5) */
+#define DRA_VAR_GATHER_ON_UPDATE 16384 /* learner, async pipelined: the gather runs on the UPDATE stream (the actor chain is the
+                                       * longer one); the rare step whose minibatch touches the ring slots the next actor
+                                       * graph overwrites makes that graph wait for the update (decided on the host) */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
