@@ -375,41 +375,80 @@ class DQNAgent(BaseAgent):
     def _inner_replay(self):
         return getattr(self.replay, 'replay', self.replay)
 
+    def _fused_head(self):
+        """(head_kind, n_atoms, v_min, v_max) when this agent class / network pair is one csrc/learner.hip implements:
+        DQNAgent + VanillaNet, CategoricalDQNAgent + CategoricalNet, QuantileRegressionDQNAgent + QuantileNet, all over
+        NatureConvBody (examples.py:55-97, 127-158, 192-222)."""
+        from . import learner as L
+        from .nets import CategoricalNet, NatureConvBody, QuantileNet, VanillaNet
+        cfg, net = self.config, self.network
+        if type(getattr(net, 'body', None)) is not NatureConvBody or len(list(net.parameters())) != 10:
+            return None
+        if type(self) is DQNAgent and type(net) is VanillaNet:
+            return (L.HEAD_VANILLA, 0, 0.0, 0.0)
+        if type(self) is CategoricalDQNAgent and type(net) is CategoricalNet:
+            return (L.HEAD_CATEGORICAL, int(cfg.categorical_n_atoms), float(cfg.categorical_v_min), float(cfg.categorical_v_max))
+        if type(self) is QuantileRegressionDQNAgent and type(net) is QuantileNet:
+            return (L.HEAD_QUANTILE, int(cfg.num_quantiles), 0.0, 0.0)
+        return None
+
+    def _fused_optimizer(self):
+        """Keyword arguments of DQNLearner for this agent's torch optimizer (RMSprop or Adam, plain: no momentum, weight
+        decay, amsgrad), or None."""
+        from . import learner as L
+        opt = self.optimizer
+        if len(opt.param_groups) != 1:
+            return None
+        g = opt.param_groups[0]
+        if g.get('weight_decay', 0) != 0:
+            return None
+        if isinstance(opt, torch.optim.RMSprop) and g.get('momentum', 0) == 0:
+            return dict(lr=g['lr'], alpha=g['alpha'], eps=g['eps'], centered=bool(g['centered']), optimizer=L.OPT_RMSPROP)
+        if type(opt) is torch.optim.Adam and not g.get('amsgrad', False) and not g.get('maximize', False):
+            return dict(lr=g['lr'], alpha=0.0, eps=g['eps'], centered=False, optimizer=L.OPT_ADAM, betas=tuple(g['betas']))
+        return None
+
     def _fused_eligible(self):
-        """The configuration csrc/learner.hip implements: examples.py:55-97 (dqn_pixel) with uniform replay."""
-        from .nets import NatureConvBody, VanillaNet
+        """The configurations csrc/learner.hip implements: examples.py:55-97 (dqn_pixel), :127-158 (categorical_dqn_pixel),
+        :192-222 (quantile_regression_dqn_pixel) with uniform replay, the first two also with PrioritizedReplay."""
         from .normalizers import ImageNormalizer
         from .replay import PrioritizedReplay, UniformReplay
         cfg = self.config
-        if type(self) is not DQNAgent or getattr(cfg, 'fused_learner', True) is False or cfg.noisy_linear:
+        if getattr(cfg, 'fused_learner', True) is False or cfg.noisy_linear:
+            return False
+        head = self._fused_head()
+        if head is None or self._fused_optimizer() is None:
             return False
         net = self.network
-        if type(net) is not VanillaNet or type(net.body) is not NatureConvBody or len(list(net.parameters())) != 10:
-            return False
         rp = self._inner_replay()
         if type(rp) not in (UniformReplay, PrioritizedReplay) or rp._ring is None or rp.history_length != 4:
             return False
+        if head[0] == 2 and type(rp) is not UniformReplay:     # QR-DQN + PER is not a valid reference configuration
+            return False
         if rp._ring.frame_bytes != 7056 or rp._ring.action_bytes != 8 or rp._state_dtype != torch.uint8:
             return False
-        if type(cfg.state_normalizer) is not ImageNormalizer or not isinstance(self.optimizer, torch.optim.RMSprop):
+        if type(cfg.state_normalizer) is not ImageNormalizer:
             return False
-        g = self.optimizer.param_groups[0]
-        if g.get('momentum', 0) != 0 or g.get('weight_decay', 0) != 0 or len(self.optimizer.param_groups) != 1:
-            return False
-        return cfg.batch_size <= 1024 and cfg.action_dim <= 64 and net.body.conv1.weight.shape[1] == 4
+        n_out = cfg.action_dim * max(1, head[1])
+        return cfg.batch_size <= 1024 and cfg.action_dim <= 64 and n_out <= 4096 and net.body.conv1.weight.shape[1] == 4
 
-    def _attach_fused_learner(self):
+    def _make_learner(self, rp, cu_partition, **extra):
         from .learner import DQNLearner
         cfg = self.config
-        g = self.optimizer.param_groups[0]
+        head_kind, n_atoms, v_min, v_max = self._fused_head()
+        o = self._fused_optimizer()
+        self._learner_lr = o['lr']
+        return DQNLearner(self.network, self.target_network, rp._ring, cfg.batch_size, cfg.action_dim,
+                          cfg.discount ** cfg.n_step, cfg.gradient_clip or 0.0, o['lr'], o['alpha'], o['eps'],
+                          centered=o['centered'], double_q=bool(cfg.double_q), u8_coef=cfg.state_normalizer.coef,
+                          cu_partition=cu_partition, replay_eps=getattr(cfg, 'replay_eps', 0.01),
+                          replay_alpha=getattr(cfg, 'replay_alpha', 0.5), head_kind=head_kind, n_atoms=n_atoms, v_min=v_min,
+                          v_max=v_max, optimizer=o['optimizer'], betas=o.get('betas', (0.9, 0.999)), **extra)
+
+    def _attach_fused_learner(self):
         rp = self._inner_replay()
         torch.cuda.synchronize()        # everything issued so far (feeds, initialisation) is on other streams
-        self._learner = DQNLearner(self.network, self.target_network, rp._ring, cfg.batch_size, cfg.action_dim,
-                                   cfg.discount ** cfg.n_step, cfg.gradient_clip or 0.0, g['lr'], g['alpha'], g['eps'],
-                                   centered=bool(g['centered']), double_q=bool(cfg.double_q),
-                                   u8_coef=cfg.state_normalizer.coef, cu_partition=False,
-                                   replay_eps=getattr(cfg, 'replay_eps', 0.01), replay_alpha=getattr(cfg, 'replay_alpha', 0.5))
-        self._learner_lr = g['lr']
+        self._learner = self._make_learner(rp, cu_partition=False)
         self._fused = None              # its flat buffer no longer backs the parameters
         self._target_flat = None
         learner = self._learner
@@ -422,7 +461,7 @@ class DQNAgent(BaseAgent):
         sign / identity reward normaliser.  `config.device_env = False` keeps the environment on the host."""
         from .envs import SyntheticAtari
         from .normalizers import RescaleNormalizer, SignNormalizer
-        from .replay import UniformReplay
+        from .replay import PrioritizedReplay, UniformReplay
         cfg = self.config
         if Config.DEVICE.type != 'cuda' or getattr(cfg, 'device_env', True) is False:
             return None
@@ -435,7 +474,7 @@ class DQNAgent(BaseAgent):
         if not (type(rn) is SignNormalizer or (type(rn) is RescaleNormalizer and rn.coef == 1.0)):
             return None
         rp = self._inner_replay()
-        if type(rp) is not UniformReplay or rp.history_length != 4 or env.history != 4 or env.n_actions != cfg.action_dim:
+        if type(rp) not in (UniformReplay, PrioritizedReplay) or rp.history_length != 4 or env.history != 4 or env.n_actions != cfg.action_dim:
             return None
         if env.frames is not None:        # somebody already stepped it on the host: leave it there
             return None
@@ -446,19 +485,14 @@ class DQNAgent(BaseAgent):
         """config.async_actor (BaseAgent.py:142-162) is honoured as the two-stream pipeline of csrc/learner.hip: the actor
         (forward, epsilon-greedy, environment step, replay feed) runs one agent step ahead of the learner on its own
         stream and CU partition; async_actor=False runs the same kernels in order."""
-        from .learner import DeviceActorPipeline, DQNLearner, SyntheticEpisodeStream
+        from .learner import DeviceActorPipeline, SyntheticEpisodeStream
+        from .replay import PrioritizedReplay
         cfg = self.config
-        g = self.optimizer.param_groups[0]
         rp = self._inner_replay()
         torch.cuda.synchronize()
-        async_actor = bool(cfg.async_actor)
-        self._learner = DQNLearner(self.network, self.target_network, rp._ring, cfg.batch_size, cfg.action_dim,
-                                   cfg.discount ** cfg.n_step, cfg.gradient_clip or 0.0, g['lr'], g['alpha'], g['eps'],
-                                   centered=bool(g['centered']), double_q=bool(cfg.double_q),
-                                   u8_coef=cfg.state_normalizer.coef, cu_partition=async_actor,
-                                   replay_eps=getattr(cfg, 'replay_eps', 0.01), replay_alpha=getattr(cfg, 'replay_alpha', 0.5),
-                                   env_seed=env.seed, env_done_period=env.done_period)
-        self._learner_lr = g['lr']
+        # a prioritized draw needs the priorities the previous update wrote back: in order only
+        async_actor = bool(cfg.async_actor) and type(rp) is not PrioritizedReplay
+        self._learner = self._make_learner(rp, cu_partition=async_actor, env_seed=env.seed, env_done_period=env.done_period)
         self._fused = None
         self._target_flat = None
         self._fused_checked = True
@@ -474,7 +508,8 @@ class DQNAgent(BaseAgent):
 
         stream = SyntheticEpisodeStream(env.seed, env.counter, env.done_period, env.history)
         self._pipe = DeviceActorPipeline(self._learner, rp, stream, cfg.action_dim, cfg.sgd_update_frequency, epsilon,
-                                         async_actor, actor_seed=int(np.random.randint(1 << 31)) if async_actor else None)
+                                         async_actor, actor_seed=int(np.random.randint(1 << 31)) if async_actor else None,
+                                         beta_fn=getattr(cfg, 'replay_beta', None))
 
     def _step_device(self):
         cfg = self.config
@@ -621,11 +656,11 @@ class DQNAgent(BaseAgent):
                 if hasattr(rp, 'draw'):
                     # PER (DQN_agent.py:120-127): tree descent on device with host-drawn uniforms, one D2H of the
                     # indices (validity / padding stay on the host, draw for draw); the update applies the IS
-                    # weights and emits the new priorities, which go back through update_priorities
+                    # weights and emits the new priorities, which the tree takes without a second host round trip
                     tree_idx, prob, data_idx = rp.draw()
                     self._learner.update(data_idx, use_graph=False, sampling_prob=torch.from_numpy(prob.astype(np.float32)),
                                          beta=config.replay_beta())
-                    rp.update_priorities(zip(tree_idx, to_np(self._learner.prio)))
+                    rp.commit_device(tree_idx, self._learner.prio)      # replay.py:193-196, priorities stay on the device
                 else:
                     # same index draws as replay.sample() (replay.py:92-103); gather + update are one graph replay
                     self._learner.update(rp.draw_indices(), use_graph=True)
@@ -680,6 +715,8 @@ class CategoricalDQNAgent(DQNAgent):
     def eval_step(self, state):
         self.config.state_normalizer.set_read_only()
         state = self.config.state_normalizer(state)
+        if self._learner is not None:
+            self._learner.synchronize()
         with torch.no_grad():
             prediction = self.network(state)
         action = to_np((prediction['prob'] * self.atoms).sum(-1).argmax(-1))
@@ -738,6 +775,8 @@ class QuantileRegressionDQNAgent(DQNAgent):
     def eval_step(self, state):
         self.config.state_normalizer.set_read_only()
         state = self.config.state_normalizer(state)
+        if self._learner is not None:
+            self._learner.synchronize()
         with torch.no_grad():
             q = self.network(state)['quantile'].mean(-1)
         action = np.argmax(to_np(q).flatten())

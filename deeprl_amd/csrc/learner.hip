@@ -55,6 +55,11 @@ struct dra_dqn_learner {
   float *y1[3], *y2[3], *y3[3], *h4, *q[3];
   float *ay1, *ay2, *ay3, *aq;  // actor (batch 1)
   float *dq, *dh4, *dy3, *dy2, *dy1, *delta, *prio, *weights, *samp_prob;
+  // distributional heads (c.head_kind != 0): h4 holds the features of every net ([3][B][512], z = 0 first), q[z] the
+  // head outputs [B][n_out] (logits / quantiles), delta the per-sample loss vector (KL / quantile-Huber)
+  int n_out;                        // head outputs per sample: A, or A * n_atoms
+  float *atoms, *qr_ws, *alog;      // linspace(v_min, v_max, n_atoms); [B * n_atoms] workspace; actor head outputs [n_out]
+  int64_t* opt_step;                // device: optimizer steps issued (1-based after the bump; Adam's bias corrections)
   float *slabs, *fc4_slabs, *afc4_slabs, *lin_ws;
   int64_t lin_ws_floats, slab_stride;
   int variant;                      // DRA_VAR_* mask fixed at creation
@@ -131,10 +136,15 @@ struct dra_dqn_learner {
   hipEvent_t last_done;             // the event recorded after the most recent optimizer launch (ev_step_done, or the
                                     // pipelined step's per-parity event: ONE record per step on the update stream)
   bool actor_pending;               // async mode: an actor graph has been issued and not yet consumed
+  int step_per;                     // dra_dqn_learner_set_per: the in-order agent step applies PER importance weights
+  float step_beta;
   hipEvent_t actor_last = nullptr;  // GATHER_ON_UPDATE: recorded after the most recent actor launch (a staging-slot event)
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
 };
+
+struct HeadSpec;
+static HeadSpec head_spec(const dra_dqn_learner* l);
 
 // HIP stream restricted to a set of compute units (bit i of cu_mask = CU i enabled).  The async agent step runs
 // two latency-bound kernel chains concurrently; without a partition every small actor kernel queues behind
@@ -170,6 +180,8 @@ DRA_API int dra_stream_destroy(void* stream) {
   return DRA_OK;
 }
 
+constexpr int kMaxHeadOut = 4096;   // n_actions * n_atoms the batch-1 actor head keeps in LDS
+
 static int alloc_f(float** p, int64_t n) { return (int)hipMalloc(p, (size_t)n * sizeof(float)); }
 
 DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const dra_dqn_config* cfg, float* params,
@@ -178,12 +190,22 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   if (cfg->batch < 1 || cfg->batch > 1024 || cfg->n_actions < 1 || cfg->n_actions > 64 || cfg->ksplit < 1 ||
       cfg->ksplit > 64)
     return DRA_EINVAL;
+  if (cfg->head_kind < DRA_HEAD_VANILLA || cfg->head_kind > DRA_HEAD_QUANTILE || cfg->optimizer < DRA_OPT_RMSPROP ||
+      cfg->optimizer > DRA_OPT_ADAM)
+    return DRA_EINVAL;
+  if (cfg->head_kind != DRA_HEAD_VANILLA &&
+      (cfg->n_atoms < 2 || cfg->n_atoms > 1024 || (int64_t)cfg->n_actions * cfg->n_atoms > kMaxHeadOut ||
+       (cfg->head_kind == DRA_HEAD_CATEGORICAL && !(cfg->v_max > cfg->v_min))))
+    return DRA_EINVAL;
   dra_dqn_learner* l = new (std::nothrow) dra_dqn_learner();
   if (!l) return DRA_ENOMEM;
   memset(l, 0, sizeof(*l));
   l->c = *cfg; l->ring = ring; l->p = params; l->pt = target; l->g = grad; l->s1 = state1; l->s2 = state2;
+  if (cfg->head_kind == DRA_HEAD_QUANTILE) l->c.double_q = 0;   // QuantileRegressionDQN_agent.py:58-60: target network only
   const int B = cfg->batch, A = cfg->n_actions;
-  const int nz = cfg->double_q ? 3 : 2;
+  const int nz = l->c.double_q ? 3 : 2;
+  const int NO = cfg->head_kind == DRA_HEAD_VANILLA ? A : A * cfg->n_atoms;
+  l->n_out = NO;
   int rc = 0;
   for (int g = 0; g < 2; ++g) {
     rc |= (int)hipMalloc(&l->state_[g], (size_t)B * 4 * 7056);
@@ -195,12 +217,25 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= (int)hipMalloc(&l->idx, (size_t)B * 8);
   for (int z = 0; z < nz; ++z) {
     rc |= alloc_f(&l->y1[z], (int64_t)B * 32 * 400); rc |= alloc_f(&l->y2[z], (int64_t)B * 64 * 81);
-    rc |= alloc_f(&l->y3[z], (int64_t)B * 64 * 49); rc |= alloc_f(&l->q[z], (int64_t)B * A);
+    rc |= alloc_f(&l->y3[z], (int64_t)B * 64 * 49); rc |= alloc_f(&l->q[z], (int64_t)B * NO);
   }
-  rc |= alloc_f(&l->h4, (int64_t)B * 512);
+  rc |= alloc_f(&l->h4, (int64_t)3 * B * 512);
+  rc |= (int)hipMalloc(&l->opt_step, sizeof(int64_t));
+  if (!rc) rc |= (int)hipMemset(l->opt_step, 0, sizeof(int64_t));
+  if (cfg->head_kind != DRA_HEAD_VANILLA) {
+    const int N = cfg->n_atoms;
+    rc |= alloc_f(&l->atoms, N); rc |= alloc_f(&l->qr_ws, (int64_t)B * N); rc |= alloc_f(&l->alog, NO);
+    if (!rc) {   // np.linspace(v_min, v_max, N) in fp64 (start + i * step, the end point exact), then fp32 (tensor())
+      float host_atoms[1024];
+      const double step = ((double)cfg->v_max - (double)cfg->v_min) / (double)(N - 1);
+      for (int i = 0; i < N; ++i) host_atoms[i] = (float)((double)cfg->v_min + (double)i * step);
+      host_atoms[N - 1] = cfg->v_max;
+      rc |= (int)hipMemcpy(l->atoms, host_atoms, (size_t)N * sizeof(float), hipMemcpyHostToDevice);
+    }
+  }
   rc |= alloc_f(&l->ay1, 32 * 400); rc |= alloc_f(&l->ay2, 64 * 81); rc |= alloc_f(&l->ay3, 64 * 49);
   rc |= alloc_f(&l->aq, A);
-  rc |= alloc_f(&l->dq, (int64_t)B * A); rc |= alloc_f(&l->dh4, (int64_t)B * 512);
+  rc |= alloc_f(&l->dq, (int64_t)B * NO); rc |= alloc_f(&l->dh4, (int64_t)B * 512);
   rc |= alloc_f(&l->dy3, (int64_t)B * 64 * 49); rc |= alloc_f(&l->dy2, (int64_t)B * 64 * 81);
   rc |= alloc_f(&l->dy1, (int64_t)B * 32 * 400);
   rc |= alloc_f(&l->delta, B); rc |= alloc_f(&l->prio, B); rc |= alloc_f(&l->weights, B); rc |= alloc_f(&l->samp_prob, B);
@@ -208,6 +243,12 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= alloc_f(&l->slabs, (int64_t)cfg->ksplit * l->slab_stride);
   if (cfg->variant >= 0) l->variant = cfg->variant;
   else rc |= dra_get_tuning(&l->variant);
+  if (cfg->head_kind != DRA_HEAD_VANILLA) {
+    // the distributional heads exist in the second-generation actor (own head kernel per env step, in order or from the
+    // parameter ring); the launches that fold the VanillaNet head into a neighbouring kernel do not apply
+    l->variant |= DRA_VAR_ACTOR_V2;
+    l->variant &= ~(DRA_VAR_ACTOR_V3 | DRA_VAR_ACTOR_FUSED_HEAD | DRA_VAR_ACTOR_FUSED_CONV1 | DRA_VAR_GATHER_IN_GRAPH);
+  }
   if (l->variant & DRA_VAR_ONESHOT_WGRAD) {
     // layer L's segment of the flat gradient is [offset(W_L), offset(b_L) + OC): weight then bias, contiguous
     const int wi[3] = {P_W1, P_W2, P_W3};
@@ -305,6 +346,8 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
                   l->ay3, l->aq, l->dq, l->dh4, l->dy3, l->dy2, l->dy1, l->delta, l->prio, l->weights, l->samp_prob,
                   l->slabs, l->fc4_slabs, l->afc4_slabs, l->lin_ws, l->partials, l->loss, l->norm, l->prm_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
+  void* hb[] = {l->atoms, l->qr_ws, l->alog, l->opt_step};
+  for (void* b : hb) if (b) (void)hipFree(b);
   for (int k = 0; k < 3; ++k) if (l->lslabs[k]) (void)hipFree(l->lslabs[k]);
   for (int z = 0; z < 3; ++z) {
     if (l->y1[z]) (void)hipFree(l->y1[z]);
@@ -344,6 +387,98 @@ DRA_API int dra_dqn_learner_buffers(dra_dqn_learner* l, void** idx, void** sampl
 }
 
 // ------------------------------------------------------------------------------------------------
+// Batch-1 action values of the distributional heads (the actor side of CategoricalDQN_agent.py:21-24 and
+// QuantileRegressionDQN_agent.py:17-20).  out[o] = bh[o] + <h4, Wh[o]> for the A*N head outputs, one wave per output
+// (a 2 KB weight row is one coalesced read per lane group; 4 outputs in flight per wave), kept in LDS; then one wave
+// per action:  categorical  q[a] = sum_n softmax(out[a])_n * atoms[n],   quantile  q[a] = mean_n out[a][n].
+struct HeadSpec {
+  int kind, n_atoms;
+  const float* atoms;
+  float* out;          // optional global copy of the A*N head outputs (tests)
+};
+
+static HeadSpec head_spec(const dra_dqn_learner* l) {
+  HeadSpec hs;
+  hs.kind = l->c.head_kind; hs.n_atoms = l->c.n_atoms; hs.atoms = l->atoms; hs.out = l->alog;
+  return hs;
+}
+
+__device__ __forceinline__ void dist_head_q(const float* __restrict__ h4, const float* __restrict__ wh,
+                                            const float* __restrict__ bh, int A, const HeadSpec hs,
+                                            float* __restrict__ s_out, float* __restrict__ s_q) {
+  const int nw = (int)(blockDim.x >> 6), wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int N = hs.n_atoms, NO = A * N;
+  float hv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hv[i] = h4[lane + 64 * i];
+  for (int o0 = wave * 4; o0 < NO; o0 += nw * 4) {
+    float wv[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* row = wh + (int64_t)min(o0 + u, NO - 1) * 512;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wv[u][i] = row[lane + 64 * i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float part = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) part += hv[i] * wv[u][i];
+      part = wave_sum(part);
+      if (lane == 0 && o0 + u < NO) s_out[o0 + u] = part + bh[o0 + u];
+    }
+  }
+  __syncthreads();
+  if (hs.out) for (int o = threadIdx.x; o < NO; o += blockDim.x) hs.out[o] = s_out[o];
+  for (int a = wave; a < A; a += nw) {
+    const float* x = s_out + a * N;
+    float q;
+    if (hs.kind == DRA_HEAD_CATEGORICAL) {
+      float m = -INFINITY;
+      for (int n = lane; n < N; n += 64) m = fmaxf(m, x[n]);
+      m = wave_max(m);
+      float se = 0.f;
+      for (int n = lane; n < N; n += 64) se += expf(x[n] - m);
+      se = wave_sum(se);
+      float acc = 0.f;
+      for (int n = lane; n < N; n += 64) acc += (expf(x[n] - m) / se) * hs.atoms[n];
+      q = wave_sum(acc);
+    } else {
+      float acc = 0.f;
+      for (int n = lane; n < N; n += 64) acc += x[n];
+      q = wave_sum(acc) / (float)N;
+    }
+    if (lane == 0) s_q[a] = q;
+  }
+  __syncthreads();
+}
+
+// h4[z][b][:] = relu(b4_z + sum_s fc4_slab[z][s][b][:]) for every net of the update (z = 0 online(states), 1 target(next),
+// 2 online(next)): the split-K reduction head_fused_kernel performs for the VanillaNet head, on its own for the
+// distributional heads (their outputs are a [B,512] x [512, A*N] contraction -> linear kernel).  grid (B, nz).
+template <int KS>
+__global__ void __launch_bounds__(256)
+fc4_reduce_kernel(const float* __restrict__ slabs, int B, const float* __restrict__ b4_on, const float* __restrict__ b4_tg,
+                  float* __restrict__ h4, int64_t* __restrict__ opt_step) {
+  const int b = blockIdx.x, z = blockIdx.y, tid = threadIdx.x;
+  const float* bias = (z == 1) ? b4_tg : b4_on;
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int k = tid + 256 * rep;
+    const float* s = slabs + ((int64_t)z * KS * B + b) * 512 + k;
+    float part[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) part[i] = s[(int64_t)i * B * 512];
+    float v = part[0];
+#pragma unroll
+    for (int i = 1; i < KS; ++i) v += part[i];
+    v += bias[k];
+    h4[((int64_t)z * B + b) * 512 + k] = v > 0.f ? v : 0.f;
+  }
+  if (opt_step && b == 0 && z == 0 && tid == 0) *opt_step += 1;   // one optimizer step per update (Adam's t)
+}
+
+// ------------------------------------------------------------------------------------------------
 // head_fused_kernel: one workgroup per sample.
 //   h4[z][b][:] = relu(b4_z + sum_s fc4_slab[z][s][b][:])          (split-K reduction of fc4, all nets)
 //   q[z][b][a]  = bh_z[a] + <h4[z][b], Wh_z[a]>                     (VanillaNet head, network_heads.py:18-21)
@@ -359,7 +494,7 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
                   const float* __restrict__ bh_on, const float* __restrict__ bh_tg, const int64_t* __restrict__ action,
                   const float* __restrict__ reward, const float* __restrict__ mask, float gamma_n, int double_q,
                   float* __restrict__ h4_out, float* __restrict__ q_on, float* __restrict__ q_tg, float* __restrict__ q_on2,
-                  float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dh4) {
+                  float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dh4, int64_t* __restrict__ opt_step) {
   __shared__ float s_h[3][512];
   __shared__ float s_q[3][64];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -460,6 +595,7 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
     const int k = tid + 256 * rep;
     dh4[(int64_t)b * 512 + k] = s_h[0][k] > 0.f ? dqa * dwh[rep] : 0.f;
   }
+  if (opt_step && b == 0 && tid == 0) *opt_step += 1;   // one optimizer step per update (Adam's t)
   DRA_STAMP(TR_HEAD, 5);
   DRA_STAMP_END(TR_HEAD);
 }
@@ -505,8 +641,49 @@ static int launch_gather(dra_dqn_learner* l, hipStream_t st, const int64_t* idx 
 
 static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = nullptr) {
   const dra_dqn_config& c = l->c;
+  if (c.optimizer == DRA_OPT_ADAM)
+    return dra_adam_step_counter(l->p, l->g, l->s1, l->s2, c.n_params, l->partials, l->n_partials, c.gradient_clip, c.lr,
+                                 c.beta1, c.beta2, c.eps, l->opt_step, l->norm, p_copy, (void*)st);
   return dra_rmsprop_step_copy(l->p, l->g, l->s1, l->s2, c.n_params, l->partials, l->n_partials, c.gradient_clip,
                                c.lr, c.alpha, c.eps, c.centered, l->norm, p_copy, (void*)st);
+}
+
+// Head + loss + head input-gradient for the distributional heads (everything head_fused_kernel does for VanillaNet):
+//   h4[z] <- fc4 partial sums ; out[z] = h4[z] Wh_z^T + bh_z (q[z], [B][A*N]) ; fused loss kernel -> per-sample loss
+//   vector (delta) and d(reduced loss)/d out (dq) ; dh4 = (dq Wh) * relu'(h4[0]).
+static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta) {
+  const dra_dqn_config& c = l->c;
+  const int B = c.batch, A = c.n_actions, N = c.n_atoms, NO = l->n_out;
+  const int nz = c.double_q ? 3 : 2;
+  void* s = (void*)st;
+  const float* P = l->p;
+  const float* T = l->pt;
+  const int64_t* o = c.offset;
+  hipLaunchKernelGGL(fc4_reduce_kernel<kFc4Split>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
+                     T + o[P_B4], l->h4, l->opt_step);
+  DRA_LAUNCH_CHECK();
+  const float* hx[3] = {l->h4, l->h4 + (int64_t)B * 512, l->h4 + (int64_t)2 * B * 512};
+  const float* hw[3] = {P + o[P_WH], T + o[P_WH], P + o[P_WH]};
+  const float* hb[3] = {P + o[P_BH], T + o[P_BH], P + o[P_BH]};
+  int rc = dra_linear_fwd(nz, hx, hw, hb, l->q, B, 512, NO, DRA_ACT_NONE, l->lin_ws, l->lin_ws_floats, s);
+  if (rc) return rc;
+  if (c.head_kind == DRA_HEAD_CATEGORICAL) {
+    const float* weights = nullptr;
+    if (per) {   // DQN_agent.py:124-126: importance weights scale the per-sample loss before the mean
+      if ((rc = dra_per_weights(nullptr, l->samp_prob, B, beta, c.replay_eps, c.replay_alpha, nullptr, l->weights, s))) return rc;
+      weights = l->weights;
+    }
+    rc = dra_c51_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action_[l->gb], 1, l->reward_[l->gb], l->mask_[l->gb],
+                      B, A, N, c.gamma_n, c.v_min, c.v_max, l->atoms, l->delta, l->dq, weights, s);
+    if (rc) return rc;
+    if (per && (rc = dra_per_weights(l->delta, l->samp_prob, B, beta, c.replay_eps, c.replay_alpha, l->prio, nullptr, s))) return rc;
+  } else {
+    if (per) return DRA_EINVAL;   // not a valid reference configuration (QuantileRegressionDQN_agent.py: uniform replay only)
+    rc = dra_qr_loss(l->q[0], l->q[1], l->action_[l->gb], 1, l->reward_[l->gb], l->mask_[l->gb], B, A, N, c.gamma_n, l->qr_ws,
+                     l->delta, l->loss, l->dq, s);
+    if (rc) return rc;
+  }
+  return dra_linear_bwd_x(l->dq, P + o[P_WH], l->h4, l->dh4, B, 512, NO, DRA_ACT_RELU, s);
 }
 
 // forward + loss + backward + gradient norm (everything between the gather and the optimizer).
@@ -538,20 +715,26 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   if (l->variant & DRA_VAR_ONESHOT_FWD) STEP(K_FC4_F, dra_linear_fwd_slabs_one(nz, x4, w4, B, 3136, 512, kFc4Split, l->fc4_slabs, s));
   else STEP(K_FC4_F, dra_linear_fwd_slabs(nz, x4, w4, B, 3136, 512, kFc4Split, l->fc4_slabs, s));
   if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_HEAD], st));
-  hipLaunchKernelGGL(head_fused_kernel<kFc4Split>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
-                     P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
-                     (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
-                     c.double_q,
-                     l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4);
-  DRA_LAUNCH_CHECK();
-  if (per) {  // PER needs the batch-wide max of the importance weights: separate kernel recomputes dq, then dh4
-    int rc = dra_td_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action_[l->gb], 1, l->reward_[l->gb],
-                         l->mask_[l->gb], B, A, c.gamma_n,
-                         l->samp_prob, beta, c.replay_eps, c.replay_alpha, l->loss, l->dq, l->delta, l->prio, l->weights, s);
+  if (c.head_kind != DRA_HEAD_VANILLA) {
+    int rc = run_dist_head(l, st, per, beta);
     if (rc) return rc;
-    rc = dra_linear_bwd_x(l->dq, P + o[P_WH], l->h4, l->dh4, B, 512, A, DRA_ACT_RELU, s);
-    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(head_fused_kernel<kFc4Split>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
+                       P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
+                       (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
+                       c.double_q,
+                       l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step);
+    DRA_LAUNCH_CHECK();
+    if (per) {  // PER needs the batch-wide max of the importance weights: separate kernel recomputes dq, then dh4
+      int rc = dra_td_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action_[l->gb], 1, l->reward_[l->gb],
+                           l->mask_[l->gb], B, A, c.gamma_n,
+                           l->samp_prob, beta, c.replay_eps, c.replay_alpha, l->loss, l->dq, l->delta, l->prio, l->weights, s);
+      if (rc) return rc;
+      rc = dra_linear_bwd_x(l->dq, P + o[P_WH], l->h4, l->dh4, B, 512, A, DRA_ACT_RELU, s);
+      if (rc) return rc;
+    }
   }
+  const int NO = l->n_out;      // head outputs the backward sees: A, or A * n_atoms
   float* G = l->g;
   float* S = l->slabs;
   if (l->variant & (DRA_VAR_FUSED_BWD | DRA_VAR_ONESHOT_WGRAD)) {
@@ -568,7 +751,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     }
     if (l->profiling) { DRA_HIP(hipEventRecord(l->ev[K_HEAD_BW], st)); DRA_HIP(hipEventRecord(l->ev[K_FC4_BW], st)); }
     STEP(K_FC4_BX, dra_fc_bwd_fused(l->dq, l->h4, l->dh4, l->y3[0], P + o[P_W4], G + o[P_WH], G + o[P_BH], G + o[P_W4],
-                                    G + o[P_B4], l->dy3, B, A, 3136, DRA_ACT_RELU, var, s));
+                                    G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, s));
     if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV3_BW], st));
     STEP(K_CONV3_BX, dra_conv_bwd_fused(3, l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], c.ksplit,
                                         l->dy2, B, 0, 1.0, DRA_ACT_RELU, var, s));
@@ -599,7 +782,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   if (fork) { DRA_HIP(hipEventRecord(l->ev_fork, st)); DRA_HIP(hipStreamWaitEvent(sd, l->ev_fork, 0)); }
   // side branch: head and fc4 weight gradients need only dq / dh4 / stored activations
   if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_HEAD_BW], st));
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3(A, 8), dim3(64), 0, sd, (const float*)l->dq, (const float*)l->h4, B, A,
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(NO, 8), dim3(64), 0, sd, (const float*)l->dq, (const float*)l->h4, B, NO,
                      G + o[P_WH], G + o[P_BH]);
   DRA_LAUNCH_CHECK();
   STEP(K_FC4_BW, dra_linear_bwd_w(l->dh4, l->y3[0], G + o[P_W4], G + o[P_B4], B, 3136, 512, sds));
@@ -878,21 +1061,27 @@ actor_fc4_kernel(const float* __restrict__ x, const float* __restrict__ w, const
   DRA_STAMP_END(TR_A_FC4);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 actor_head_env_kernel(const dra_dqn_step_params* __restrict__ prm, int e, const float* __restrict__ h4,
                       const float* __restrict__ wh, const float* __restrict__ bh, int A,
                       uint8_t* __restrict__ ring_actions, float* __restrict__ q_out, uint8_t* __restrict__ frames,
-                      double* __restrict__ rewards, int32_t* __restrict__ masks, uint64_t seed, int done_period) {
+                      double* __restrict__ rewards, int32_t* __restrict__ masks, uint64_t seed, int done_period,
+                      const HeadSpec hs) {
   __shared__ float s_q[64];
+  __shared__ float s_out[kMaxHeadOut];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int a = wave; a < A; a += 4) {
-    float part = 0.f;
+  if (hs.kind != DRA_HEAD_VANILLA) {
+    dist_head_q(h4, wh, bh, A, hs, s_out, s_q);
+  } else {
+    for (int a = wave; a < A; a += (int)(blockDim.x >> 6)) {
+      float part = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) part += h4[lane + 64 * i] * wh[a * 512 + lane + 64 * i];
-    part = wave_sum(part);
-    if (lane == 0) s_q[a] = part + bh[a];
+      for (int i = 0; i < 8; ++i) part += h4[lane + 64 * i] * wh[a * 512 + lane + 64 * i];
+      part = wave_sum(part);
+      if (lane == 0) s_q[a] = part + bh[a];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (threadIdx.x < A && q_out) q_out[threadIdx.x] = s_q[threadIdx.x];
   if (threadIdx.x == 0) {
     int best = 0;
@@ -1030,9 +1219,10 @@ static int run_actor_steps_v3(dra_dqn_learner* l, int n_env, const float* P, hip
     } else {
       hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
                          l->ah4, 3136);
-      hipLaunchKernelGGL(actor_head_env_kernel, dim3(1), dim3(256), 0, st, (const dra_dqn_step_params*)l->prm_dev, e,
+      hipLaunchKernelGGL(actor_head_env_kernel, dim3(1), dim3(c.head_kind != DRA_HEAD_VANILLA ? 1024 : 256), 0, st, (const dra_dqn_step_params*)l->prm_dev, e,
                          (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq,
-                         (uint8_t*)frames, (double*)rewards, (int32_t*)masks, (uint64_t)c.env_seed, (int)c.env_done_period);
+                         (uint8_t*)frames, (double*)rewards, (int32_t*)masks, (uint64_t)c.env_seed, (int)c.env_done_period,
+                         head_spec(l));
     }
     DRA_LAUNCH_CHECK();
   }
@@ -1054,12 +1244,19 @@ static int stage_actor_params(dra_dqn_learner* l, const dra_dqn_step_params* prm
   return DRA_OK;
 }
 
-// q[a] = bh[a] + <h4, Wh[a]>  (VanillaNet head, batch 1; one wave per action)
-__global__ void __launch_bounds__(256)
+// q[a] of the head at batch 1 (one wave per action for VanillaNet; dist_head_q for the distributional heads)
+__global__ void __launch_bounds__(1024)
 head_q_kernel(const float* __restrict__ h4, const float* __restrict__ wh, const float* __restrict__ bh, int A,
-              float* __restrict__ q_out) {
+              float* __restrict__ q_out, const HeadSpec hs) {
+  __shared__ float s_out[kMaxHeadOut];
+  __shared__ float s_q[64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int a = wave; a < A; a += 4) {
+  if (hs.kind != DRA_HEAD_VANILLA) {
+    dist_head_q(h4, wh, bh, A, hs, s_out, s_q);
+    if (threadIdx.x < A) q_out[threadIdx.x] = s_q[threadIdx.x];
+    return;
+  }
+  for (int a = wave; a < A; a += (int)(blockDim.x >> 6)) {
     float part = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) part += h4[lane + 64 * i] * wh[a * 512 + lane + 64 * i];
@@ -1098,8 +1295,8 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
       if (!rc) {
         hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
                            l->ah4, 3136);
-        hipLaunchKernelGGL(head_q_kernel, dim3(1), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH], P + o[P_BH],
-                           c.n_actions, l->aq);
+        hipLaunchKernelGGL(head_q_kernel, dim3(1), dim3(c.head_kind != DRA_HEAD_VANILLA ? 1024 : 256), 0, st, (const float*)l->ah4,
+                           P + o[P_WH], P + o[P_BH], c.n_actions, l->aq, head_spec(l));
       }
     }
     hipError_t e = hipStreamEndCapture(st, &graph);
@@ -1149,8 +1346,9 @@ actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restric
                            uint8_t* __restrict__ ring_actions, float* __restrict__ q_out, uint8_t* __restrict__ frames,
                            double* __restrict__ rewards, int32_t* __restrict__ masks, uint8_t* __restrict__ pend_frame,
                            double* __restrict__ pend_reward, int32_t* __restrict__ pend_mask, uint64_t seed,
-                           int done_period) {
+                           int done_period, const HeadSpec hs) {
   __shared__ float s_q[64];
+  __shared__ float s_out[kMaxHeadOut];
   DRA_STAMP(TR_A_HEAD, 0);
   const unsigned sq = *seq;
   const dra_dqn_step_params* __restrict__ prm = aring_entry(ring, sq);
@@ -1164,12 +1362,16 @@ actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restric
     for (int w = threadIdx.x; w < 882; w += blockDim.x) dst[w] = src[w];
     if (threadIdx.x == 0) { rewards[slot] = *pend_reward; masks[slot] = *pend_mask; }
   }
-  for (int a = wave; a < A; a += (int)(blockDim.x >> 6)) {
-    float part = 0.f;
+  if (hs.kind != DRA_HEAD_VANILLA) {
+    dist_head_q(h4, wh, bh, A, hs, s_out, s_q);
+  } else {
+    for (int a = wave; a < A; a += (int)(blockDim.x >> 6)) {
+      float part = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) part += h4[lane + 64 * i] * wh[a * 512 + lane + 64 * i];
-    part = wave_sum(part);
-    if (lane == 0) s_q[a] = part + bh[a];
+      for (int i = 0; i < 8; ++i) part += h4[lane + 64 * i] * wh[a * 512 + lane + 64 * i];
+      part = wave_sum(part);
+      if (lane == 0) s_q[a] = part + bh[a];
+    }
   }
   __syncthreads();   // (also: every thread is done reading the pending frame)
   DRA_STAMP(TR_A_HEAD, 2);
@@ -1233,7 +1435,7 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq,
                      n_env - 1, 1, 0, (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq,
                      (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
-                     (uint64_t)c.env_seed, (int)c.env_done_period);
+                     (uint64_t)c.env_seed, (int)c.env_done_period, head_spec(l));
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -1264,7 +1466,7 @@ static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, h
     hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq, e,
                        (int)(e == n_env - 1), 1, (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions,
                        l->aq, (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
-                       (uint64_t)c.env_seed, (int)c.env_done_period);
+                       (uint64_t)c.env_seed, (int)c.env_done_period, head_spec(l));
     DRA_LAUNCH_CHECK();
   }
   return DRA_OK;
@@ -1356,9 +1558,10 @@ static int run_actor_steps_v2(dra_dqn_learner* l, int n_env, const float* P, hip
     hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
                        l->ah4, 3136);
     DRA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(actor_head_env_kernel, dim3(1), dim3(256), 0, st, (const dra_dqn_step_params*)l->prm_dev, e,
+    hipLaunchKernelGGL(actor_head_env_kernel, dim3(1), dim3(c.head_kind != DRA_HEAD_VANILLA ? 1024 : 256), 0, st, (const dra_dqn_step_params*)l->prm_dev, e,
                        (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq,
-                       (uint8_t*)frames, (double*)rewards, (int32_t*)masks, (uint64_t)c.env_seed, (int)c.env_done_period);
+                       (uint8_t*)frames, (double*)rewards, (int32_t*)masks, (uint64_t)c.env_seed, (int)c.env_done_period,
+                       head_spec(l));
     DRA_LAUNCH_CHECK();
   }
   return DRA_OK;
@@ -1763,6 +1966,16 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
   return rc;
 }
 
+// PER for the in-order agent step (dra_dqn_learner_step with stream_actor == NULL): per != 0 makes its update apply the
+// importance weights of the sampling probabilities currently in the learner's sampling_prob buffer with exponent beta
+// and emit the new priorities (DQN_agent.py:120-127); the pipelined step is uniform-replay only.
+DRA_API int dra_dqn_learner_set_per(dra_dqn_learner* l, int per, float beta) {
+  if (!l) return DRA_EINVAL;
+  l->step_per = per != 0;
+  l->step_beta = beta;
+  return DRA_OK;
+}
+
 // Host-side accounting of dra_dqn_learner_step since the last reset: out[0] = calls, out[1] = seconds inside
 // the call, out[2] = seconds of that blocked on a pinned staging slot (i.e. waiting for the GPU: back-pressure).
 DRA_API int dra_dqn_learner_host_stats(dra_dqn_learner* l, double* out, int reset) {
@@ -1792,7 +2005,8 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
       if (!pinned)
         DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
       if ((rc = launch_gather(l, su, pinned))) return rc;
-      if ((rc = body_graph(l, su))) return rc;
+      // PER: the importance exponent is a kernel argument that changes every update -> the chain runs eagerly
+      if ((rc = l->step_per ? run_body(l, su, 1, l->step_beta, 0) : body_graph(l, su))) return rc;
       if ((rc = launch_optimizer(l, su))) return rc;
       DRA_HIP(hipEventRecord(l->ev_step_done, su));
       l->last_done = l->ev_step_done;
@@ -1801,6 +2015,7 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
     return DRA_OK;
   }
   // ---- async mode
+  if (l->step_per && do_update) return DRA_EINVAL;   // prioritized draws depend on the previous update: in-order only
   if ((l->variant & DRA_VAR_PIPE_GATHER) && (l->variant & DRA_VAR_ACTOR_PARAMS)) {
     if ((l->variant & DRA_VAR_GATHER_IN_GRAPH) && !(l->variant & DRA_VAR_ACTOR_V3)) return step_pipelined2(l, prm, do_update, su, sa, k);
     if (l->variant & DRA_VAR_GATHER_ON_UPDATE) return step_pipelined3(l, prm, do_update, su, sa, k);

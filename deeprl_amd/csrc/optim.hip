@@ -426,6 +426,83 @@ DRA_API int dra_adam_step_dev(float* param, const float* grad, float* exp_avg, f
                      out_norm, hyper_dev, stream);
 }
 
+// Adam for a captured learner graph: the 1-based step count lives in DEVICE memory (*step_dev, bumped by an earlier
+// kernel of the same graph), the bias corrections are formed from it exactly as dra_adam_hyper does on the host, and
+// the updated parameters are optionally mirrored into param_copy (the async actor's double-buffered copy).  Same
+// element formula and load shape as rmsprop_step_kernel: 2 float4 per thread, every operand requested before the clip
+// coefficient is reduced from the partials.
+__global__ void __launch_bounds__(256)
+adam_step_ctr_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                     int64_t n, const double* __restrict__ partials, int n_partials, float max_norm, float lr, float beta1,
+                     float beta2, float eps, const int64_t* __restrict__ step_dev, float* __restrict__ out_norm,
+                     float* __restrict__ p_copy) {
+  __shared__ float s_hyper[2];
+  const int64_t n4 = n >> 2;
+  const int64_t i0 = (int64_t)blockIdx.x * (256 * kStepNV) + threadIdx.x;
+  float4 P[kStepNV], G[kStepNV], M[kStepNV], V[kStepNV];
+#pragma unroll
+  for (int q = 0; q < kStepNV; ++q) {
+    const int64_t i = i0 + 256 * q;
+    const int64_t ic = i < n4 ? i : n4 - 1;
+    P[q] = reinterpret_cast<float4*>(p)[ic];
+    G[q] = reinterpret_cast<const float4*>(g)[ic];
+    M[q] = reinterpret_cast<float4*>(m)[ic];
+    V[q] = reinterpret_cast<float4*>(v)[ic];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (threadIdx.x == 0) {
+    const double t = (double)*step_dev;
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    s_hyper[0] = (float)((double)lr / bc1);
+    s_hyper[1] = (float)(1.0 / sqrt(bc2));
+  }
+  const float coef = clip_coef_from_partials(partials, n_partials, max_norm, out_norm);   // (synchronises the workgroup)
+  const float step_size = s_hyper[0], inv_sqrt_bc2 = s_hyper[1];
+  const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+  auto elem = [&](float& pp, float gg, float& mm, float& vv) {
+    const float gk = gg * coef;
+    mm = mm * beta1 + omb1 * gk;
+    vv = vv * beta2 + omb2 * gk * gk;
+    pp = pp - step_size * (mm / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+  };
+#pragma unroll
+  for (int q = 0; q < kStepNV; ++q) {
+    const int64_t i = i0 + 256 * q;
+    if (i < n4) {
+      float* pp = &P[q].x; const float* gg = &G[q].x; float* mm = &M[q].x; float* vv = &V[q].x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) elem(pp[k], gg[k], mm[k], vv[k]);
+      reinterpret_cast<float4*>(p)[i] = P[q];
+      if (p_copy) reinterpret_cast<float4*>(p_copy)[i] = P[q];
+      reinterpret_cast<float4*>(m)[i] = M[q];
+      reinterpret_cast<float4*>(v)[i] = V[q];
+    }
+  }
+  const int64_t t = (n4 << 2) + threadIdx.x;
+  if (blockIdx.x == 0 && t < n) {
+    float pv = p[t], mv = m[t], vv = v[t];
+    elem(pv, g[t], mv, vv);
+    p[t] = pv;
+    if (p_copy) p_copy[t] = pv;
+    m[t] = mv;
+    v[t] = vv;
+  }
+}
+
+DRA_API int dra_adam_step_counter(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  const double* partials, int n_partials, float max_norm, float lr, float beta1, float beta2,
+                                  float eps, const int64_t* step_dev, float* out_norm, float* param_copy, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || n < 4) return DRA_EINVAL;
+  if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)exp_avg) | ((uintptr_t)exp_avg_sq) | ((uintptr_t)param_copy)) & 15)
+    return DRA_EINVAL;
+  if (partials && (n_partials < 1 || n_partials > dra_norm_partials_max())) return DRA_EINVAL;
+  if (step_blocks(n) > 0x7fffffff) return DRA_EINVAL;
+  hipLaunchKernelGGL(adam_step_ctr_kernel, dim3((unsigned)step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad, exp_avg,
+                     exp_avg_sq, n, partials, n_partials, max_norm, lr, beta1, beta2, eps, step_dev, out_norm, param_copy);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 // Device-to-device parameter copy for the target-network sync (DQN_agent.py:136-138).
 DRA_API int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream) {
   if (!dst || !src || n < 0) return DRA_EINVAL;

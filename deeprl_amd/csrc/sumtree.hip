@@ -140,6 +140,113 @@ DRA_API int dra_sumtree_set(dra_sumtree* t, int64_t leaf_idx, double prio, void*
   return DRA_OK;
 }
 
+// feed with the priority taken from DEVICE memory (PrioritizedReplay.feed adds new transitions at max_priority,
+// replay.py:161; the running maximum lives in stat_dev[0] once the priorities are written back on device)
+__global__ void sumtree_set_from_kernel(double* __restrict__ tree, int64_t leaf, const double* __restrict__ prio) {
+  if (threadIdx.x != 0) return;
+  int64_t node = leaf;
+  const double p = *prio;
+  tree[node] = p;
+  double below = p;
+  while (node > 0) {
+    const int64_t parent = (node - 1) >> 1;
+    const int64_t sib = (node & 1) ? node + 1 : node - 1;
+    const double s = (node & 1) ? __dadd_rn(below, tree[sib]) : __dadd_rn(tree[sib], below);
+    tree[parent] = s;
+    below = s;
+    node = parent;
+  }
+}
+
+DRA_API int dra_sumtree_set_from(dra_sumtree* t, int64_t leaf_idx, const double* prio_dev, void* stream) {
+  if (!t || !prio_dev || leaf_idx < t->capacity - 1 || leaf_idx >= t->n_nodes) return DRA_EINVAL;
+  hipLaunchKernelGGL(sumtree_set_from_kernel, dim3(1), dim3(64), 0, dra_stream(stream), t->tree, leaf_idx, prio_dev);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// Priority write-back of one minibatch without a host round trip (replay.py:193-196 + sum_tree.py:54-60).  The HOST
+// decides WHICH leaves are written (pending_idx gating and first-writer-wins need no priority value): leaf[i] gets
+// f64(prio_f32[pos[i]]), i < n.  stat[0] = max(stat[0], every offered priority) (replay.py:195: max_priority tracks all
+// of them, gated or not), stat[1] = the smallest priority ever offered.  The level-parallel update is exact -- hence
+// identical to the reference's incremental `+= change` -- as long as every leaf is a multiple of u = ulp_f32(stat[1])
+// and capacity * stat[0] / u <= 2^53; the kernel checks that bound and replays the reference's walk in order otherwise.
+__global__ void __launch_bounds__(1024)
+sumtree_commit_kernel(double* __restrict__ tree, int levels, int64_t capacity, const int64_t* __restrict__ leaf,
+                      const int32_t* __restrict__ pos, int n, const float* __restrict__ prio, int batch,
+                      double* __restrict__ stat, int force_ordered) {
+  __shared__ double s_hi[16], s_lo[16];
+  __shared__ int s_ordered;
+  const int tid = threadIdx.x;
+  double hi = -INFINITY, lo = INFINITY;
+  for (int b = tid; b < batch; b += blockDim.x) {
+    const double v = (double)prio[b];
+    hi = fmax(hi, v);
+    lo = fmin(lo, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    hi = fmax(hi, __shfl_xor(hi, off));
+    lo = fmin(lo, __shfl_xor(lo, off));
+  }
+  if ((tid & 63) == 0) { s_hi[tid >> 6] = hi; s_lo[tid >> 6] = lo; }
+  __syncthreads();
+  if (tid == 0) {
+    const int nw = (int)(blockDim.x >> 6);
+    for (int w = 1; w < nw; ++w) { hi = fmax(hi, s_hi[w]); lo = fmin(lo, s_lo[w]); }
+    hi = fmax(hi, stat[0]);
+    lo = fmin(lo, stat[1]);
+    stat[0] = hi;
+    stat[1] = lo;
+    int ordered = force_ordered;
+    if (!(lo > 0.0) || !(hi < INFINITY)) ordered = 1;
+    else if ((double)capacity * hi > ldexp(1.0, 53 + ilogb(lo) - 23)) ordered = 1;
+    s_ordered = ordered;
+  }
+  __syncthreads();
+  if (n <= 0) return;
+  if (s_ordered) {
+    if (tid != 0) return;
+    for (int k = 0; k < n; ++k) {
+      int64_t node = leaf[k];
+      const double p = (double)prio[pos[k]];
+      const double change = __dsub_rn(p, tree[node]);
+      tree[node] = p;
+      while (node > 0) {
+        node = (node - 1) >> 1;
+        tree[node] = __dadd_rn(tree[node], change);
+      }
+    }
+    return;
+  }
+  int64_t node = -1;
+  if (tid < n) {
+    node = leaf[tid];
+    node_store(tree + node, (double)prio[pos[tid]]);
+  }
+  for (int lv = 0; lv < levels; ++lv) {
+    __syncthreads();
+    if (node > 0) {
+      const int64_t parent = (node - 1) >> 1;
+      const double s = __dadd_rn(node_load(tree + 2 * parent + 1), node_load(tree + 2 * parent + 2));
+      node_store(tree + parent, s);
+      node = parent;
+    }
+  }
+}
+
+DRA_API int dra_sumtree_commit_f32(dra_sumtree* t, const int64_t* leaf_idx_dev, const int32_t* pos_dev, int n,
+                                   const float* prio_f32_dev, int batch, double* stat_dev, int force_ordered, void* stream) {
+  if (!t || !prio_f32_dev || !stat_dev || n < 0 || n > 1024 || batch < 1 || batch > 1024 || (n > 0 && (!leaf_idx_dev || !pos_dev)))
+    return DRA_EINVAL;
+  const int m = n > batch ? n : batch;
+  const int threads = ((m + 63) / 64) * 64;
+  hipLaunchKernelGGL(sumtree_commit_kernel, dim3(1), dim3(threads), 0, dra_stream(stream), t->tree, t->levels, t->capacity,
+                     leaf_idx_dev, pos_dev, n, prio_f32_dev, batch, stat_dev, force_ordered);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 // Stratified sample (replay.py:168-175 + sum_tree.py:23-33): lane i draws
 //   s = a + (b - a) * u_i,  a = seg*i, b = seg*(i+1), seg = total / B      (python random.uniform)
 // and descends `s <= left ? left : (right, s - left)` until 2i+1 >= n_nodes.  All fp64, no

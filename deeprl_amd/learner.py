@@ -36,7 +36,15 @@ class DqnConfig(ctypes.Structure):
                 ("alpha", ctypes.c_float), ("eps", ctypes.c_float), ("replay_eps", ctypes.c_float),
                 ("replay_alpha", ctypes.c_float), ("variant", ctypes.c_int32), ("u8_coef", ctypes.c_double),
                 ("n_params", ctypes.c_int64), ("conv_end", ctypes.c_int64), ("ring_capacity", ctypes.c_int64),
-                ("env_seed", ctypes.c_uint64), ("offset", ctypes.c_int64 * 10)]
+                ("env_seed", ctypes.c_uint64), ("offset", ctypes.c_int64 * 10),
+                ("head_kind", ctypes.c_int32), ("n_atoms", ctypes.c_int32), ("v_min", ctypes.c_float),
+                ("v_max", ctypes.c_float), ("optimizer", ctypes.c_int32), ("beta1", ctypes.c_float),
+                ("beta2", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
+
+HEAD_VANILLA, HEAD_CATEGORICAL, HEAD_QUANTILE = 0, 1, 2        # DRA_HEAD_*
+OPT_RMSPROP, OPT_ADAM = 0, 1                                     # DRA_OPT_*
+_HEAD_PARAM = {HEAD_VANILLA: "fc_head", HEAD_CATEGORICAL: "fc_categorical", HEAD_QUANTILE: "fc_quantiles"}
 
 
 class StepParams(ctypes.Structure):
@@ -47,23 +55,31 @@ class StepParams(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("idx", ctypes.c_int64 * 1024)]
 
 
-def _ordered_params(net):
+def _param_order(head_kind=HEAD_VANILLA):
+    return _ORDER[:8] + [_HEAD_PARAM[head_kind] + ".weight", _HEAD_PARAM[head_kind] + ".bias"]
+
+
+def _ordered_params(net, head_kind=HEAD_VANILLA):
     named = dict(net.named_parameters())
-    missing = [k for k in _ORDER if k not in named]
-    if missing or len(named) != len(_ORDER):
-        raise DraError("the fused learner supports VanillaNet(NatureConvBody); parameters found: %s" % sorted(named))
-    return [named[k] for k in _ORDER]
+    order = _param_order(head_kind)
+    missing = [k for k in order if k not in named]
+    if missing or len(named) != len(order):
+        raise DraError("the fused learner supports VanillaNet / CategoricalNet / QuantileNet over NatureConvBody; "
+                       "parameters found: %s" % sorted(named))
+    return [named[k] for k in order]
 
 
 class DQNLearner:
     def __init__(self, network, target_network, ring, batch, n_actions, gamma_n, gradient_clip, lr, alpha, eps,
                  centered=True, double_q=False, u8_coef=1.0 / 255, replay_eps=0.01, replay_alpha=0.5, ksplit=16,
-                 env_seed=0, env_done_period=800, variant=-1, cu_partition=True):
+                 env_seed=0, env_done_period=800, variant=-1, cu_partition=True, head_kind=HEAD_VANILLA, n_atoms=0,
+                 v_min=0.0, v_max=0.0, optimizer=OPT_RMSPROP, betas=(0.9, 0.999)):
         """`variant`: DRA_VAR_* kernel-selection mask (ops.VAR_*); -1 = the process default (ops.set_tuning).
         `cu_partition=False` drops DRA_VAR_CU_PARTITION from it: a caller that never runs the device actor
         concurrently (in-order mode, host environments) wants every CU for the update chain."""
         self.network, self.target_network, self.ring = network, target_network, ring
-        po, pt = _ordered_params(network), _ordered_params(target_network)
+        self.head_kind = int(head_kind)
+        po, pt = _ordered_params(network, self.head_kind), _ordered_params(target_network, self.head_kind)
         self.flat = FlatParams(po, koc=(po[0], po[2], po[4]))        # conv segment first, conv weights in KOC
         self.target_flat = FlatParams(pt, koc=(pt[0], pt[2], pt[4]))
         self.state1 = torch.zeros_like(self.flat.flat)
@@ -71,12 +87,18 @@ class DQNLearner:
         self.variant = int(variant) if int(variant) >= 0 else ops.get_tuning()
         if not cu_partition:
             self.variant &= ~ops.VAR_CU_PARTITION
+        if self.head_kind != HEAD_VANILLA:   # (dra_dqn_learner_create does the same: the launches that fold the VanillaNet
+            # head into a neighbouring kernel do not exist for the distributional heads)
+            self.variant = (self.variant | ops.VAR_ACTOR_V2) & ~(ops.VAR_ACTOR_V3 | ops.VAR_ACTOR_FUSED_HEAD |
+                                                                 ops.VAR_ACTOR_FUSED_CONV1 | ops.VAR_GATHER_IN_GRAPH)
         variant = self.variant
         cfg = DqnConfig()
         cfg.batch, cfg.n_actions, cfg.double_q, cfg.ksplit, cfg.centered = batch, n_actions, int(double_q), ksplit, int(centered)
         cfg.gamma_n, cfg.gradient_clip, cfg.lr, cfg.alpha, cfg.eps = gamma_n, gradient_clip or 0.0, lr, alpha, eps
         cfg.replay_eps, cfg.replay_alpha, cfg.u8_coef = replay_eps, replay_alpha, u8_coef
         cfg.env_seed, cfg.env_done_period = env_seed, env_done_period
+        cfg.head_kind, cfg.n_atoms, cfg.v_min, cfg.v_max = self.head_kind, int(n_atoms), float(v_min), float(v_max)
+        cfg.optimizer, cfg.beta1, cfg.beta2 = int(optimizer), float(betas[0]), float(betas[1])
         cfg.variant = int(variant)
         cfg.n_params = self.flat.numel
         cfg.conv_end = self.flat.offsets[6]                          # start of fc4.weight
@@ -98,7 +120,10 @@ class DQNLearner:
         self.sampling_prob = w(ps[1].value, batch, torch.float32)
         self._loss_per = w(ps[2].value, 1, torch.float32)
         self.norm = w(ps[3].value, 1, torch.float32)
-        self.q = w(ps[4].value, batch * n_actions, torch.float32).view(batch, n_actions)
+        # head outputs of the online net on the sampled states: q [B, A], or logits / quantiles [B, A, N]
+        self.n_out = n_actions * (int(n_atoms) if self.head_kind != HEAD_VANILLA else 1)
+        self.q = w(ps[4].value, batch * self.n_out, torch.float32)
+        self.q = self.q.view(batch, n_actions) if self.head_kind == HEAD_VANILLA else self.q.view(batch, n_actions, int(n_atoms))
         self.delta = w(ps[5].value, batch, torch.float32)
         self.prio = w(ps[6].value, batch, torch.float32)
         self.actor_q = w(ps[7].value, n_actions, torch.float32)
@@ -165,7 +190,10 @@ class DQNLearner:
 
     @property
     def loss(self):
-        """mean(0.5 * delta^2) of the last update (DQN_agent.py:78-79), recovered from the TD errors."""
+        """Reduced loss of the last update: mean(0.5 * delta^2) recovered from the TD errors (DQN_agent.py:78-79); for the
+        distributional heads `delta` holds the per-sample KL / quantile-Huber loss and this is its mean."""
+        if self.head_kind != HEAD_VANILLA:
+            return self.delta.mean()
         return self.delta.pow(2).mul(0.5).mean()
 
     def upload_indices(self, idx):
@@ -216,6 +244,11 @@ class DQNLearner:
         lib.dra_dqn_learner_step(self.h, ctypes.byref(self.params), int(do_update), self._sp(),
                                  self._sp(self.actor_stream) if async_actor else None)
 
+    def set_per(self, per, beta):
+        """The next in-order step() applies PER importance weights (exponent beta) from self.sampling_prob and leaves the
+        new priorities in self.prio."""
+        lib.dra_dqn_learner_set_per(self.h, int(bool(per)), float(beta))
+
     def sync_target(self):
         lib.dra_dqn_learner_sync_target(self.h, self._sp())
 
@@ -265,7 +298,7 @@ class DQNLearner:
         as [(c,kh,kw)][oc]; this undoes that.)  Used by checkpointing and by the parity checkers; synchronises."""
         self.synchronize()
         torch.cuda.synchronize()
-        names = list(_ORDER)
+        names = _param_order(self.head_kind)
         net_p = dict(self.network.named_parameters())
 
         def per_tensor(buf):
@@ -283,7 +316,8 @@ class DQNLearner:
             return out
 
         return {"params": per_tensor(self.flat.flat), "target": per_tensor(self.target_flat.flat),
-                "square_avg": per_tensor(self.state1), "grad_avg": per_tensor(self.state2)}
+                "square_avg": per_tensor(self.state1), "grad_avg": per_tensor(self.state2),   # RMSprop's names
+                "state1": per_tensor(self.state1), "state2": per_tensor(self.state2)}         # Adam: exp_avg, exp_avg_sq
 
     def last_minibatch(self):
         """(state, next_state, action, reward, mask) device tensors of the most recently issued update (views of the
@@ -363,8 +397,12 @@ class DeviceActorPipeline:
     agent steps ahead."""
     AHEAD = 16
 
-    def __init__(self, learner, replay, stream, n_actions, n_env, epsilon_fn, async_actor, actor_seed=None):
+    def __init__(self, learner, replay, stream, n_actions, n_env, epsilon_fn, async_actor, actor_seed=None, beta_fn=None):
         self.L, self.rp, self.stream = learner, replay, stream
+        self.per = hasattr(replay, 'draw')          # PrioritizedReplay: in-order only (a draw needs the previous write-back)
+        self.beta_fn = beta_fn
+        if self.per and async_actor:
+            raise DraError("the async device pipeline is uniform-replay only")
         self.A, self.n_env, self.epsilon_fn, self.async_actor = int(n_actions), int(n_env), epsilon_fn, bool(async_actor)
         self.rs = np.random.RandomState(actor_seed) if async_actor else np.random
         self.capacity = replay.memory_size
@@ -411,7 +449,19 @@ class DeviceActorPipeline:
             infos = self._block()
             rp.advance(self.n_env)
             do_update = bool(account(infos))
+            if self.per and do_update:
+                # DQN_agent.py:114-127 with PrioritizedReplay: tree descent on device from host-drawn uniforms, ONE D2H of
+                # the leaves (validity / padding stay on the host, draw for draw), importance weights applied inside the
+                # update, new priorities written back to the tree without leaving the device
+                tree_idx, prob, data_idx = rp.draw()
+                L.sampling_prob.copy_(torch.from_numpy(prob.astype(np.float32)), non_blocking=True)
+                L.set_per(True, self.beta_fn())
+                L.step(data_idx, True, False)
+                rp.commit_device(tree_idx, L.prio)
+                return infos
             idx = rp.draw_indices() if do_update else None
+            if self.per:
+                L.set_per(False, 0.0)
             L.step(idx, do_update, False)
             return infos
         if not self.primed:

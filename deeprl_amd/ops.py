@@ -131,6 +131,17 @@ class SumTree:
     def set(self, leaf_idx, prio):
         lib.dra_sumtree_set(self.h, int(leaf_idx), float(prio), stream_ptr())
 
+    def set_from(self, leaf_idx, prio_dev):
+        """set() with the priority read from device memory (f64 tensor, first element)."""
+        lib.dra_sumtree_set_from(self.h, int(leaf_idx), ptr(prio_dev), stream_ptr())
+
+    def commit_f32(self, leaf_idx, pos, prio_f32, stat, force_ordered=False):
+        """Priority write-back with the values still on the device: leaf_idx[i] <- f64(prio_f32[pos[i]]); stat (f64[2] device
+        tensor) = {running max, running min} over ALL of prio_f32 (dra_sumtree_commit_f32)."""
+        n = 0 if leaf_idx is None else leaf_idx.numel()
+        lib.dra_sumtree_commit_f32(self.h, ptr(leaf_idx) if n else None, ptr(pos) if n else None, n, ptr(prio_f32),
+                                   prio_f32.numel(), ptr(stat), int(bool(force_ordered)), stream_ptr())
+
     def sample(self, u):
         u = _c(u, torch.float64)
         b = u.numel()
@@ -595,6 +606,15 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, partials, n_partials, max_no
     lib.dra_adam_step_dev(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), ptr(partials),
                           int(n_partials), float(max_norm if max_norm else 0.0), float(beta1), float(beta2), float(eps),
                           ptr(hyper_dev), ptr(out_norm), stream_ptr())
+
+
+def adam_step_counter(param, grad, exp_avg, exp_avg_sq, partials, n_partials, max_norm, lr, beta1, beta2, eps, step_dev,
+                      out_norm=None, param_copy=None):
+    """Adam whose 1-based step count is the int64 device tensor `step_dev` (bumped by the caller's graph); optional
+    mirror of the updated parameters."""
+    lib.dra_adam_step_counter(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), ptr(partials),
+                              int(n_partials), float(max_norm if max_norm else 0.0), float(lr), float(beta1), float(beta2),
+                              float(eps), ptr(step_dev), ptr(out_norm), ptr(param_copy), stream_ptr())
 
 
 def copy_f32(dst, src):

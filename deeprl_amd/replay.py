@@ -240,11 +240,16 @@ class PrioritizedReplay(UniformReplay):
     def __init__(self, memory_size, batch_size, n_step=1, discount=1, history_length=1, keys=None):
         super(PrioritizedReplay, self).__init__(memory_size, batch_size, n_step, discount, history_length, keys)
         self.tree = None
-        self.max_priority = 1
+        self._max_priority = 1
+        self._min_priority = 1.0  # smallest priority ever offered (the exactness bound of the parallel tree update)
         self._pending = set()   # sum_tree.py:13 pending_idx
         self._write = 0         # sum_tree.py:7 write cursor
-        self.ordered_updates = False
-        self._u_up = self._leaf_up = self._prio_up = None
+        self.ordered_updates = False   # True: always replay the reference's incremental walk (slow, exact for any values)
+        self._u_up = self._leaf_up = self._prio_up = self._pos_up = None
+        # {max_priority, min priority offered} on the DEVICE once the fused learner writes priorities back without a
+        # host round trip (commit_device); the host attributes are then refreshed on demand
+        self._stat = None
+        self._stat_on_device = False
 
     def _lazy_tree(self):
         if self.tree is None:
@@ -254,20 +259,55 @@ class PrioritizedReplay(UniformReplay):
             self._u_up = _PinnedUploader(torch.float64, 1024, dev)
             self._leaf_up = _PinnedUploader(torch.int64, 1024, dev)
             self._prio_up = _PinnedUploader(torch.float64, 1024, dev)
+            self._pos_up = _PinnedUploader(torch.int32, 1024, dev)
+            self._stat = torch.tensor([float(self._max_priority), float(self._min_priority)], dtype=torch.float64, device=dev)
+
+    @property
+    def max_priority(self):
+        """replay.py:159,195.  Lives on the device while the fused learner commits priorities there (one D2H to read it)."""
+        if self._stat_on_device:
+            self._max_priority, self._min_priority = self._stat.cpu().tolist()
+        return self._max_priority
+
+    @max_priority.setter
+    def max_priority(self, value):
+        self._max_priority = value
+        if self._stat_on_device:
+            self._stat[0] = float(value)
+
+    def _exact_parallel(self):
+        """The level-parallel tree update recomputes ancestors as left + right; that equals the reference's incremental
+        `+= change` (sum_tree.py:16-20) exactly when every partial sum is representable: all leaves are multiples of
+        u = ulp_f32(smallest priority) and capacity * max_priority / u <= 2^53."""
+        lo, hi = float(self._min_priority), float(self._max_priority)
+        if not (lo > 0.0) or not np.isfinite(hi):
+            return False
+        return self.memory_size * hi <= np.ldexp(1.0, 53 + int(np.floor(np.log2(lo))) - 23)
 
     def feed(self, data):
         super().feed(data)
+        self._add_leaf()
+
+    def _add_leaf(self):
+        """SumTree.add (sum_tree.py:39-51) for the transition just written: the leaf at the write cursor gets max_priority;
+        a leaf that was sampled and is overwritten before its priority came back is no longer pending."""
         self._lazy_tree()
-        # SumTree.add (sum_tree.py:39-51): the new leaf is self-marked pending then set
         leaf = self._write + self.memory_size - 1
-        # SumTree.add marks the leaf pending and update() clears it (sum_tree.py:39-51,54-60): a leaf that was sampled
-        # and is overwritten before its priority came back is NOT pending any more -- the late update is dropped
         self._pending.discard(leaf)
         with torch.cuda.device(self._device()):
-            self.tree.set(leaf, float(self.max_priority))
+            if self._stat_on_device:
+                self.tree.set_from(leaf, self._stat)
+            else:
+                self.tree.set(leaf, float(self._max_priority))
         self._write += 1
         if self._write >= self.memory_size:
             self._write = 0
+
+    def advance(self, n=1):
+        """UniformReplay.advance + the tree side of feed() for transitions a DEVICE producer wrote into the ring."""
+        for _ in range(int(n)):
+            super().advance(1)
+            self._add_leaf()
 
     def draw(self, batch_size=None):
         """replay.py:164-186.  Returns (tree_idx, sampling_prob, data_idx) as numpy arrays; consumes
@@ -307,9 +347,13 @@ class PrioritizedReplay(UniformReplay):
     def update_priorities(self, info):
         """replay.py:193-196 + sum_tree.py:54-60: max_priority tracks every offered priority; a tree
         update happens only for pending leaves, first occurrence wins."""
+        if self._stat_on_device:        # back to host bookkeeping: fetch what the device accumulated
+            _ = self.max_priority
+            self._stat_on_device = False
         leaves, prios = [], []
         for idx, priority in info:
-            self.max_priority = max(self.max_priority, priority)
+            self._max_priority = max(self._max_priority, priority)
+            self._min_priority = min(self._min_priority, float(priority))
             idx = int(idx)
             if idx in self._pending:
                 self._pending.remove(idx)
@@ -318,7 +362,32 @@ class PrioritizedReplay(UniformReplay):
         if leaves:
             with torch.cuda.device(self._device()):
                 self.tree.update(self._leaf_up.upload(np.asarray(leaves, dtype=np.int64)),
-                                 self._prio_up.upload(np.asarray(prios, dtype=np.float64)), ordered=self.ordered_updates)
+                                 self._prio_up.upload(np.asarray(prios, dtype=np.float64)),
+                                 ordered=self.ordered_updates or not self._exact_parallel())
+
+    def commit_device(self, tree_idx, prio_f32):
+        """update_priorities(zip(tree_idx, prio)) with the priorities still on the device (f32 tensor, one per sampled
+        transition, in sample order): the host applies pending_idx gating / first-writer-wins (which need no priority
+        value) and the kernel writes the chosen leaves, keeps max_priority and falls back to the ordered walk by itself
+        when the parallel update would not be exact.  No host synchronisation."""
+        self._lazy_tree()
+        if not self._stat_on_device:
+            self._stat.copy_(torch.tensor([float(self._max_priority), float(self._min_priority)], dtype=torch.float64))
+            self._stat_on_device = True
+        leaves, pos = [], []
+        for j, idx in enumerate(tree_idx):
+            idx = int(idx)
+            if idx in self._pending:
+                self._pending.remove(idx)
+                leaves.append(idx)
+                pos.append(j)
+        with torch.cuda.device(self._device()):
+            if leaves:
+                self.tree.commit_f32(self._leaf_up.upload(np.asarray(leaves, dtype=np.int64)),
+                                     self._pos_up.upload(np.asarray(pos, dtype=np.int32)), prio_f32, self._stat,
+                                     force_ordered=self.ordered_updates)
+            else:
+                self.tree.commit_f32(None, None, prio_f32, self._stat, force_ordered=self.ordered_updates)
 
     def close(self):
         super().close()

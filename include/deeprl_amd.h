@@ -67,6 +67,13 @@ int dra_sumtree_pointer(dra_sumtree* tree, void** tree_dev, int64_t* n_nodes);
 int dra_sumtree_update(dra_sumtree* tree, const int64_t* leaf_idx_dev, const double* prio_dev, int n, int ordered,
                        void* stream);
 int dra_sumtree_set(dra_sumtree* tree, int64_t leaf_idx, double prio, void* stream); /* sum_tree.py:39-51 (add) */
+int dra_sumtree_set_from(dra_sumtree* tree, int64_t leaf_idx, const double* prio_dev, void* stream); /* same, *prio_dev */
+/* replay.py:193-196 with the new priorities still on the device: leaf_idx_dev[i] <- f64(prio_f32_dev[pos_dev[i]]), i < n
+ * (the host picks the pending, first-occurrence entries); stat_dev = {max_priority, smallest priority offered} is kept
+ * over all `batch` offered values.  Falls back by itself to the reference's ordered walk when the level-parallel update
+ * would not be exact in fp64 (capacity * max / ulp_f32(min) > 2^53), or when force_ordered != 0. */
+int dra_sumtree_commit_f32(dra_sumtree* tree, const int64_t* leaf_idx_dev, const int32_t* pos_dev, int n,
+                           const float* prio_f32_dev, int batch, double* stat_dev, int force_ordered, void* stream);
 /* replay.py:168-175 + sum_tree.py:23-33,63-66: u_dev[batch] are raw python random.random() draws; lane i samples
  * s = a + (b-a)*u_i on segment i of total/batch and descends; outputs tree index, leaf priority, and the total. */
 int dra_sumtree_sample(dra_sumtree* tree, const double* u_dev, int batch, int64_t* out_tree_idx, double* out_p,
@@ -215,6 +222,11 @@ int dra_adam_hyper(float lr, float beta1, float beta2, int64_t step, float* out2
 int dra_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                       const double* partials, int n_partials, float max_norm, float beta1, float beta2, float eps,
                       const float* hyper_dev, float* out_norm, void* stream);
+/* Adam whose 1-based step count is read from DEVICE memory (a learner graph bumps it), with an optional mirror of the
+ * updated parameters (the async actor's copy) */
+int dra_adam_step_counter(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                          const double* partials, int n_partials, float max_norm, float lr, float beta1, float beta2,
+                          float eps, const int64_t* step_dev, float* out_norm, float* param_copy, void* stream);
 int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream); /* DQN_agent.py:136-138 */
 
 /* ---- fused DQN learner + device-resident actor: DQN_agent.py:24-45 (actor step), :114-138 (update) for
@@ -229,7 +241,23 @@ typedef struct dra_dqn_config {
   int64_t n_params, conv_end, ring_capacity;
   uint64_t env_seed;        /* synthetic frame source (dra_ring_fill_synthetic stream) used by the device actor */
   int64_t offset[10];
+  /* head on top of NatureConvBody's 512 features (network_heads.py): DRA_HEAD_VANILLA = VanillaNet (n_actions outputs,
+   * MSE TD loss, DQN_agent.py:81-99); DRA_HEAD_CATEGORICAL = CategoricalNet (n_actions x n_atoms logits over
+   * linspace(v_min, v_max, n_atoms), CategoricalDQN_agent.py:60-89); DRA_HEAD_QUANTILE = QuantileNet (n_actions x n_atoms
+   * quantiles, QuantileRegressionDQN_agent.py:55-77).  head.w is [n_actions * n_atoms][512], action-major. */
+  int32_t head_kind, n_atoms;
+  float v_min, v_max;
+  /* DRA_OPT_RMSPROP (lr, alpha, eps, centered above) or DRA_OPT_ADAM (lr, beta1, beta2, eps; state1 = exp_avg,
+   * state2 = exp_avg_sq; examples.py:139,204) */
+  int32_t optimizer;
+  float beta1, beta2;
+  int32_t reserved;
 } dra_dqn_config;
+#define DRA_HEAD_VANILLA 0
+#define DRA_HEAD_CATEGORICAL 1
+#define DRA_HEAD_QUANTILE 2
+#define DRA_OPT_RMSPROP 0
+#define DRA_OPT_ADAM 1
 /* per-agent-step arguments: the device actor's kernels read them from a device copy, so the 4 env steps of a
  * DQN agent step replay as one captured graph.  All randomness is drawn by the HOST in the reference's order
  * (torch_utils.py:51-58: randint(A) then rand()), so the np.random stream is the reference's. */
@@ -257,6 +285,9 @@ int dra_dqn_learner_buffers(dra_dqn_learner* learner, void** idx, void** samplin
 /* one gradient update on the int64[batch] indices in the learner's idx buffer; use_graph replays a captured
  * hipGraph (stream must not be the NULL stream); per != 0 adds the PER branch (DQN_agent.py:120-127). */
 int dra_dqn_learner_update(dra_dqn_learner* learner, int use_graph, int per, float beta, void* stream);
+/* PER for the in-order dra_dqn_learner_step (stream_actor == NULL): importance weights from the learner's sampling_prob
+ * buffer with exponent beta, new priorities into its prio buffer (DQN_agent.py:120-127) */
+int dra_dqn_learner_set_per(dra_dqn_learner* learner, int per, float beta);
 int dra_dqn_learner_profile(dra_dqn_learner* learner, float* out_ms, int n_out, void* stream);
 /* the minibatch the most recently issued update consumed (device pointers into the learner's buffers: u8 states /
  * next states [B][4][84][84], int64 actions [B], f32 rewards / masks [B]); for checkers, after a synchronise */

@@ -491,9 +491,12 @@ def test_async_pipeline_matches_schedule_oracle(dra, variant, init):
     bench.ring.close()
 
 
-@pytest.mark.parametrize("per,n_step,device_env,done_period", [(False, 1, False, 800), (True, 3, False, 800), (False, 1, True, 800),
-                                                             (False, 1, True, 7), (False, 3, True, 11)])
-def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch, per, n_step, device_env, done_period):
+@pytest.mark.parametrize("kind,per,n_step,device_env,done_period",
+                         [("dqn", False, 1, False, 800), ("dqn", True, 3, False, 800), ("dqn", False, 1, True, 800),
+                          ("dqn", False, 1, True, 7), ("dqn", False, 3, True, 11), ("dqn", True, 3, True, 7),
+                          ("c51", False, 1, False, 800), ("c51", True, 1, False, 800), ("c51", True, 3, True, 9),
+                          ("c51", False, 1, True, 7), ("qr", False, 1, False, 800), ("qr", False, 3, True, 11)])
+def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch, kind, per, n_step, device_env, done_period):
     """dqn_pixel configuration (examples.py:55-97 shapes): DQNAgent attaches the fused learner
     (csrc/learner.hip) after the first feed.  20 agent steps give the same action stream and replay
     contents and, to fp32 reassociation, the same parameters as the generic autograd path
@@ -501,7 +504,11 @@ def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch, per, n_step
     device_env=True: the environment itself is device-resident (DeviceActorPipeline, in-order mode): forward,
     epsilon-greedy, environment step and replay feed never leave the GPU, and the run still equals the generic
     host-emulator path transition for transition -- including episode ends (done_period 7 / 11: frame stacks restart
-    with the first frame repeated, the discarded post-terminal frame, rewards / masks of the LEAVING transition)."""
+    with the first frame repeated, the discarded post-terminal frame, rewards / masks of the LEAVING transition).
+    kind = c51 / qr: CategoricalDQNAgent / QuantileRegressionDQNAgent with Adam (examples.py:127-158, 192-222: BASELINE
+    configs[3]) through the same learner -- distributional head + fused loss kernel + Adam in the update, the
+    distributional action values in the device actor; per=True: prioritized draws with the priorities written back to the
+    tree on the device (device_env=True then runs the in-order device pipeline)."""
     d = dra
     import deeprl_amd.agents as agents_mod
     monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
@@ -514,8 +521,23 @@ def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch, per, n_step
         cfg.replay_beta = d.LinearSchedule(0.4, 1.0, 1000)
         cfg.task_fn = lambda: d.Task(cfg.game, seed=7, synthetic_done_period=done_period)
         cfg.eval_env = cfg.task_fn()
-        cfg.optimizer_fn = lambda params: torch.optim.RMSprop(params, lr=0.00025, alpha=0.95, eps=0.01, centered=True)
-        cfg.network_fn = lambda: d.VanillaNet(cfg.action_dim, d.NatureConvBody(in_channels=4))
+        head = [("fc_head.weight", (cfg.action_dim, 512)), ("fc_head.bias", (cfg.action_dim,))]
+        cls = d.DQNAgent
+        if kind == "dqn":
+            cfg.optimizer_fn = lambda params: torch.optim.RMSprop(params, lr=0.00025, alpha=0.95, eps=0.01, centered=True)
+            cfg.network_fn = lambda: d.VanillaNet(cfg.action_dim, d.NatureConvBody(in_channels=4))
+        elif kind == "c51":
+            cfg.optimizer_fn = lambda params: torch.optim.Adam(params, lr=0.00025, eps=0.01 / 32)
+            cfg.categorical_v_max, cfg.categorical_v_min, cfg.categorical_n_atoms = 10, -10, 51
+            cfg.network_fn = lambda: d.CategoricalNet(cfg.action_dim, cfg.categorical_n_atoms, d.NatureConvBody())
+            cls = d.CategoricalDQNAgent
+            head = [("fc_categorical.weight", (cfg.action_dim * 51, 512)), ("fc_categorical.bias", (cfg.action_dim * 51,))]
+        else:
+            cfg.optimizer_fn = lambda params: torch.optim.Adam(params, lr=0.00005, eps=0.01 / 32)
+            cfg.num_quantiles = 200
+            cfg.network_fn = lambda: d.QuantileNet(cfg.action_dim, cfg.num_quantiles, d.NatureConvBody())
+            cls = d.QuantileRegressionDQNAgent
+            head = [("fc_quantiles.weight", (cfg.action_dim * 200, 512)), ("fc_quantiles.bias", (cfg.action_dim * 200,))]
         cfg.random_action_prob = d.LinearSchedule(1.0, 0.05, 60)
         cfg.batch_size = 32
         cfg.discount = 0.99
@@ -533,14 +555,14 @@ def test_dqn_agent_fused_fast_path_matches_generic(dra, monkeypatch, per, n_step
         cfg.max_steps = 1e5
         d.random_seed(3)
         random.seed(3)
-        agent = d.DQNAgent(cfg)
-        p_np = fake_envs.numpy_params(fake_envs.nature_vanilla_shapes(cfg.action_dim), 17)
+        agent = cls(cfg)
+        p_np = fake_envs.numpy_params(fake_envs.NATURE_SHAPES + head, 17)
         agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
         agent.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
         for _ in range(20):
             agent.step()
         assert (agent._learner is not None) == fused
-        assert (agent._pipe is not None) == (fused and device_env and not per)
+        assert (agent._pipe is not None) == (fused and device_env)
         if fused:
             agent._learner.synchronize()
         torch.cuda.synchronize()

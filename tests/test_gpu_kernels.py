@@ -96,6 +96,105 @@ def test_prioritized_replay_golden(golden, dev, case, ordered):
     rep.close()
 
 
+@pytest.mark.parametrize("case", PER_CASES, ids=[c[0] for c in PER_CASES])
+@pytest.mark.parametrize("ordered", [False, True])
+def test_prioritized_replay_device_commit_golden(golden, dev, case, ordered):
+    """The same reference op log with the priorities handed over as a DEVICE fp32 tensor (what the fused learner's loss
+    kernel leaves behind): commit_device applies pending gating / first-writer-wins on the host and writes the leaves,
+    max_priority included, without a host round trip (dra_sumtree_commit_f32); new transitions are then fed at the
+    device-resident max_priority (dra_sumtree_set_from).  Tree, samples and RNG stream equal the reference's."""
+    from deeprl_amd.replay import PrioritizedReplay
+    g = golden("prioritized_replay")
+    name, mem, b, h, n, disc, shape, kind, t_len, every = case
+    rs = np.random.RandomState(3000 + ord(name))
+    states, actions, rewards, masks = stream(rs, t_len, shape, kind, 4, 0.1)
+    rep = PrioritizedReplay(memory_size=mem, batch_size=b, n_step=n, discount=disc, history_length=h)
+    rep.ordered_updates = ordered
+    random.seed(4000 + ord(name))
+    np.random.seed(4000 + ord(name))
+    ks = 0
+    for t in range(t_len):
+        rep.feed(dict(state=states[t][None], action=actions[t:t + 1], reward=[rewards[t]], mask=masks[t:t + 1]))
+        if t >= h + n + 6 and t % every == 0:
+            tr = rep.sample()
+            k = "%s_s%d_" % (name, ks)
+            for key in ("state", "action", "reward", "next_state", "mask", "sampling_prob", "idx"):
+                assert np.array_equal(getattr(tr, key).cpu().numpy(), g[k + key]), (key, ks)
+            rs.standard_normal(b)
+            prio = np.asarray(g[k + "prio"])
+            assert prio.dtype == np.float32
+            rep.commit_device(tr.idx.cpu().numpy(), torch.from_numpy(prio).to(dev))
+            assert np.array_equal(rep.tree.as_tensor().cpu().numpy(), g[k + "tree"]), ks
+            assert float(rep.max_priority) == float(g[k + "max_priority"])
+            ks += 1
+    assert ks == int(g[name + "_n_samples"])
+    assert np.array_equal([random.random() for _ in range(3)], g[name + "_rng_tail"])
+    rep.close()
+
+
+def test_sumtree_commit_falls_back_to_ordered_walk(dev):
+    """Priorities spanning 2^-40 .. 2^20 on a 4096-leaf tree violate the fp64 exactness bound of the level-parallel
+    update (capacity * max / ulp_f32(min) > 2^53): dra_sumtree_commit_f32 notices on the device and replays the
+    reference's incremental walk, so the heap equals the numpy restatement of sum_tree.py bit for bit; the host-side
+    update_priorities takes the same decision (PrioritizedReplay._exact_parallel)."""
+    from deeprl_amd import ops
+    from oracle.sumtree_oracle import SumTreeOracle
+    cap = 4096
+    rs = np.random.RandomState(5)
+    tree, orc = ops.SumTree(cap), SumTreeOracle(cap)
+    stat = torch.tensor([1.0, 1.0], dtype=torch.float64, device=dev)
+    for i in range(cap):
+        tree.set(i + cap - 1, 1.0)
+        orc.pending.add(i + cap - 1)
+        orc.update(i + cap - 1, 1.0)
+    for r in range(12):
+        li = rs.choice(cap, 32, replace=False).astype(np.int64) + cap - 1
+        pr = (np.ldexp(1.0 + rs.rand(32), rs.randint(-40, 21, size=32))).astype(np.float32)
+        pos = rs.permutation(32).astype(np.int32)
+        tree.commit_f32(cu(li, dev), torch.from_numpy(pos).to(dev), torch.from_numpy(pr).to(dev), stat)
+        for k in range(32):
+            orc.pending.add(int(li[k]))
+            orc.update(int(li[k]), float(pr[pos[k]]))
+    torch.cuda.synchronize()
+    assert np.array_equal(tree.as_tensor().cpu().numpy(), orc.tree)
+    hi, lo = stat.cpu().tolist()
+    assert hi >= 2.0 ** 19 and lo < 2.0 ** -38
+    tree.close()
+
+
+def test_adam_step_counter_golden(golden, dev):
+    """dra_adam_step_counter (step count in device memory, bias corrections formed in the kernel, mirrored parameter copy)
+    against the same torch.optim.Adam trajectory as dra_adam_step."""
+    from deeprl_amd import ops
+    g = golden("optim")
+    shapes = [g["p0_%d" % j].shape for j in range(4)]
+    sizes = [int(np.prod(s)) for s in shapes]
+    flat = lambda arrs: np.concatenate([np.asarray(a, dtype=np.float32).reshape(-1) for a in arrs])
+    for name, clip, lr, eps in (("adam", 5.0, 2.5e-4, 0.01 / 32), ("adam", 0.5, 2.5e-4, 0.01 / 32), ("adam_default", 5.0, 3e-4, 1e-8)):
+        p = f32(flat([g["p0_%d" % j] for j in range(4)]), dev)
+        n_pad = (p.numel() + 3) // 4 * 4
+        buf = torch.zeros(4, n_pad, dtype=torch.float32, device=dev)      # 16-byte aligned rows
+        buf[0, :p.numel()] = p
+        pp, s1, s2, cp = buf[0, :p.numel()], buf[1, :p.numel()], buf[2, :p.numel()], buf[3, :p.numel()]
+        npart = ops.norm_partials()
+        partials = torch.zeros(npart, dtype=torch.float64, device=dev)
+        norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        step = torch.zeros(1, dtype=torch.int64, device=dev)
+        for i in range(5):
+            gr = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+            gr[:p.numel()] = f32(flat([g["g%d_%d" % (i, j)] for j in range(4)]), dev)
+            ops.grad_sqnorm(gr[:p.numel()], partials)
+            step += 1
+            ops.adam_step_counter(pp, gr[:p.numel()], s1, s2, partials, npart, clip, lr, 0.9, 0.999, eps, step, norm, cp)
+        got = pp.cpu().numpy()
+        assert np.array_equal(got, cp.cpu().numpy())
+        off = 0
+        for j in range(4):
+            np.testing.assert_allclose(got[off:off + sizes[j]].reshape(shapes[j]), g["%s_clip%g_p%d" % (name, clip, j)],
+                                       rtol=1e-5, atol=1e-6)
+            off += sizes[j]
+
+
 def test_ring_vs_oracle_atari_shapes(dev):
     """84x84 frames (16-byte vector path), H=4, n=3, wrap-around, device-side synthetic fill."""
     from deeprl_amd import ops
