@@ -658,8 +658,7 @@ class DQNAgent(BaseAgent):
                     # indices (validity / padding stay on the host, draw for draw); the update applies the IS
                     # weights and emits the new priorities, which the tree takes without a second host round trip
                     tree_idx, prob, data_idx = rp.draw()
-                    self._learner.update(data_idx, use_graph=False, sampling_prob=torch.from_numpy(prob.astype(np.float32)),
-                                         beta=config.replay_beta())
+                    self._learner.update(data_idx, use_graph=True, sampling_prob=prob, beta=config.replay_beta())
                     rp.commit_device(tree_idx, self._learner.prio)      # replay.py:193-196, priorities stay on the device
                 else:
                     # same index draws as replay.sample() (replay.py:92-103); gather + update are one graph replay

@@ -77,6 +77,8 @@ struct dra_dqn_learner {
   bool stage_used[8];
   hipGraphExec_t g_update;
   bool g_update_ready;
+  hipGraphExec_t g_update_per;      // the same chain with PER importance weights (beta from sampling_prob[B])
+  bool g_update_per_ready;
   // pipelined async mode (DRA_VAR_PIPE_GATHER): per step parity, body + optimizer in one graph
   hipGraphExec_t g_pipe[2];
   bool g_pipe_ready[2];
@@ -238,7 +240,8 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= alloc_f(&l->dq, (int64_t)B * NO); rc |= alloc_f(&l->dh4, (int64_t)B * 512);
   rc |= alloc_f(&l->dy3, (int64_t)B * 64 * 49); rc |= alloc_f(&l->dy2, (int64_t)B * 64 * 81);
   rc |= alloc_f(&l->dy1, (int64_t)B * 32 * 400);
-  rc |= alloc_f(&l->delta, B); rc |= alloc_f(&l->prio, B); rc |= alloc_f(&l->weights, B); rc |= alloc_f(&l->samp_prob, B);
+  rc |= alloc_f(&l->delta, B); rc |= alloc_f(&l->prio, B); rc |= alloc_f(&l->weights, B);
+  rc |= alloc_f(&l->samp_prob, B + 1);   // [B] = the PER exponent beta of the update (graph-replayable PER launches)
   l->slab_stride = cfg->conv_end;  // conv segment occupies [0, conv_end) of the flat layout
   rc |= alloc_f(&l->slabs, (int64_t)cfg->ksplit * l->slab_stride);
   if (cfg->variant >= 0) l->variant = cfg->variant;
@@ -319,6 +322,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (!l) return DRA_OK;
   (void)hipDeviceSynchronize();
   if (l->g_update_ready) (void)hipGraphExecDestroy(l->g_update);
+  if (l->g_update_per_ready) (void)hipGraphExecDestroy(l->g_update_per);
   if (l->tr_ev) {
     for (int i = 0; i < l->tr_cap * 5; ++i) (void)hipEventDestroy(l->tr_ev[i]);
     delete[] l->tr_ev;
@@ -648,6 +652,42 @@ static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = 
                                c.lr, c.alpha, c.eps, c.centered, l->norm, p_copy, (void*)st);
 }
 
+// Head contraction of the distributional heads at the update's batch: out[z][b][o] = bh_z[o] + <h4[z][b], Wh_z[o]>,
+// [B,512] x [512, A*N] per net (6.7 MFLOP for C51, 26 for QR at 200 quantiles).  Too small for the K-chunked implicit
+// GEMM to pay (16 us: 8 dependent 64-wide chunks on 14 workgroups): a workgroup stages 32 samples of h4 in LDS once (64 KB)
+// and each of its 4 waves owns one output row -- the 2 KB weight row sits in registers (8 floats per lane), 32 wave-level
+// dot products against the LDS rows.  grid (ceil(A*N / 4), nets, ceil(B / 32)).
+__global__ void __launch_bounds__(256)
+head_fwd_gemv_kernel(const float* __restrict__ h4, int B, int NO, const float* __restrict__ wh_on, const float* __restrict__ wh_tg,
+                     const float* __restrict__ bh_on, const float* __restrict__ bh_tg, float* __restrict__ out0,
+                     float* __restrict__ out1, float* __restrict__ out2) {
+  __shared__ __attribute__((aligned(16))) float s_h[32 * 512];
+  const int z = blockIdx.y, b0 = blockIdx.z * 32, nb = min(32, B - b0);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + wave;
+  const float* __restrict__ wh = (z == 1) ? wh_tg : wh_on;
+  float w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = wh[(int64_t)min(o, NO - 1) * 512 + lane + 64 * i];
+  const float bias = ((z == 1) ? bh_tg : bh_on)[min(o, NO - 1)];
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(h4 + ((int64_t)z * B + b0) * 512);
+  float4 v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = src[min((int)threadIdx.x + 256 * q, nb * 128 - 1)];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) reinterpret_cast<float4*>(s_h)[threadIdx.x + 256 * q] = v[q];
+  __syncthreads();
+  if (o >= NO) return;
+  float* __restrict__ out = (z == 0) ? out0 : (z == 1 ? out1 : out2);
+  for (int b = 0; b < nb; ++b) {
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part += s_h[b * 512 + lane + 64 * i] * w[i];
+    part = wave_sum(part);
+    if (lane == 0) out[(int64_t)(b0 + b) * NO + o] = part + bias;
+  }
+}
+
 // Head + loss + head input-gradient for the distributional heads (everything head_fused_kernel does for VanillaNet):
 //   h4[z] <- fc4 partial sums ; out[z] = h4[z] Wh_z^T + bh_z (q[z], [B][A*N]) ; fused loss kernel -> per-sample loss
 //   vector (delta) and d(reduced loss)/d out (dq) ; dh4 = (dq Wh) * relu'(h4[0]).
@@ -662,11 +702,19 @@ static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta
   hipLaunchKernelGGL(fc4_reduce_kernel<kFc4Split>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
                      T + o[P_B4], l->h4, l->opt_step);
   DRA_LAUNCH_CHECK();
-  const float* hx[3] = {l->h4, l->h4 + (int64_t)B * 512, l->h4 + (int64_t)2 * B * 512};
-  const float* hw[3] = {P + o[P_WH], T + o[P_WH], P + o[P_WH]};
-  const float* hb[3] = {P + o[P_BH], T + o[P_BH], P + o[P_BH]};
-  int rc = dra_linear_fwd(nz, hx, hw, hb, l->q, B, 512, NO, DRA_ACT_NONE, l->lin_ws, l->lin_ws_floats, s);
-  if (rc) return rc;
+  static int gemv = -1;
+  if (gemv < 0) { const char* e = getenv("DRA_HEAD_GEMV"); gemv = e ? atoi(e) : 1; }
+  int rc = DRA_OK;
+  if (gemv) {
+    hipLaunchKernelGGL(head_fwd_gemv_kernel, dim3((NO + 3) / 4, nz, (B + 31) / 32), dim3(256), 0, st, (const float*)l->h4, B, NO,
+                       P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH], l->q[0], l->q[1], l->q[2]);
+    DRA_LAUNCH_CHECK();
+  } else {
+    const float* hx[3] = {l->h4, l->h4 + (int64_t)B * 512, l->h4 + (int64_t)2 * B * 512};
+    const float* hw[3] = {P + o[P_WH], T + o[P_WH], P + o[P_WH]};
+    const float* hb[3] = {P + o[P_BH], T + o[P_BH], P + o[P_BH]};
+    if ((rc = dra_linear_fwd(nz, hx, hw, hb, l->q, B, 512, NO, DRA_ACT_NONE, l->lin_ws, l->lin_ws_floats, s))) return rc;
+  }
   if (c.head_kind == DRA_HEAD_CATEGORICAL) {
     const float* weights = nullptr;
     if (per) {   // DQN_agent.py:124-126: importance weights scale the per-sample loss before the mean
@@ -802,6 +850,24 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   return rc;
 }
 
+// PER variant of body_graph: the importance exponent comes from device memory (sampling_prob[B], uploaded with the
+// probabilities), so the captured chain has no per-update argument.
+static int body_graph_per(dra_dqn_learner* l, hipStream_t st) {
+  if (!l->g_update_per_ready) {
+    hipGraph_t graph;
+    DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = run_body(l, st, 1, -1.f, 0);
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc != DRA_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    DRA_HIP(hipGraphInstantiate(&l->g_update_per, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    l->g_update_per_ready = true;
+  }
+  DRA_HIP(hipGraphLaunch(l->g_update_per, st));
+  return DRA_OK;
+}
+
 static int body_graph(dra_dqn_learner* l, hipStream_t st) {
   if (!l->g_update_ready) {
     hipGraph_t graph;
@@ -852,7 +918,7 @@ DRA_API int dra_dqn_learner_update(dra_dqn_learner* l, int use_graph, int per, f
   l->pa_valid = false;
   int rc = launch_gather(l, st);
   if (rc) return rc;
-  rc = (use_graph && !per) ? body_graph(l, st) : run_body(l, st, per, beta, 0);
+  rc = (use_graph && !per) ? body_graph(l, st) : ((use_graph && per && beta < 0.f) ? body_graph_per(l, st) : run_body(l, st, per, beta, 0));
   if (rc) return rc;
   if ((rc = launch_optimizer(l, st))) return rc;
   DRA_HIP(hipEventRecord(l->ev_step_done, st));
@@ -2005,8 +2071,10 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
       if (!pinned)
         DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
       if ((rc = launch_gather(l, su, pinned))) return rc;
-      // PER: the importance exponent is a kernel argument that changes every update -> the chain runs eagerly
-      if ((rc = l->step_per ? run_body(l, su, 1, l->step_beta, 0) : body_graph(l, su))) return rc;
+      // PER: beta >= 0 is a kernel argument that changes every update (eager chain); beta < 0 = read it from
+      // sampling_prob[B] on the device (captured graph)
+      if ((rc = l->step_per ? (l->step_beta < 0.f ? body_graph_per(l, su) : run_body(l, su, 1, l->step_beta, 0)) : body_graph(l, su)))
+        return rc;
       if ((rc = launch_optimizer(l, su))) return rc;
       DRA_HIP(hipEventRecord(l->ev_step_done, su));
       l->last_done = l->ev_step_done;

@@ -71,7 +71,9 @@ td_loss_kernel(const float* __restrict__ q, const float* __restrict__ qn_t, cons
     if (on) {
       const float ad = fabsf(delta) + eps;
       if (out_prio) out_prio[b] = (alpha == 0.5f) ? sqrtf(ad) : powf(ad, alpha);
-      wraw = powf(samp_prob[b] * (float)B + 1e-6f, -beta);
+      // beta < 0: the exponent is the float behind the probabilities (sampling_prob[B]) -- every kernel argument is then
+      // constant across updates and the launch can be replayed from a captured graph
+      wraw = powf(samp_prob[b] * (float)B + 1e-6f, -(beta < 0.f ? samp_prob[B] : beta));
     }
     const float wmax = block_max(on ? wraw : -INFINITY, s_red);
     w = wraw / wmax;
@@ -398,7 +400,7 @@ per_kernel(const float* __restrict__ loss_vec, const float* __restrict__ samp_pr
     out_prio[b] = (alpha == 0.5f) ? sqrtf(ad) : powf(ad, alpha);
   }
   if (samp_prob && out_w) {
-    const float wraw = on ? powf(samp_prob[b] * (float)B + 1e-6f, -beta) : -INFINITY;
+    const float wraw = on ? powf(samp_prob[b] * (float)B + 1e-6f, -(beta < 0.f ? samp_prob[B] : beta)) : -INFINITY;
     const float wmax = block_max(wraw, s_red);
     if (on) out_w[b] = wraw / wmax;
   }

@@ -165,6 +165,37 @@ DRA_API int dra_sumtree_set_from(dra_sumtree* t, int64_t leaf_idx, const double*
   return DRA_OK;
 }
 
+// n consecutive adds (write cursor write0, write0+1, ... mod capacity) at the SAME device-resident priority: what
+// PrioritizedReplay.feed does for the n transitions a device producer wrote in one agent step.  One lane per leaf,
+// ancestors recomputed level by level as in sumtree_update_parallel_kernel (one walk of `levels` barriers instead of n
+// dependent leaf-to-root walks of ~20 L2 round trips each).
+__global__ void __launch_bounds__(64)
+sumtree_set_many_from_kernel(double* __restrict__ tree, int levels, int64_t capacity, int64_t write0, int n,
+                             const double* __restrict__ prio) {
+  int64_t node = -1;
+  if ((int)threadIdx.x < n) {
+    node = (write0 + threadIdx.x) % capacity + capacity - 1;
+    node_store(tree + node, *prio);
+  }
+  for (int lv = 0; lv < levels; ++lv) {
+    __syncthreads();
+    if (node > 0) {
+      const int64_t parent = (node - 1) >> 1;
+      const double s = __dadd_rn(node_load(tree + 2 * parent + 1), node_load(tree + 2 * parent + 2));
+      node_store(tree + parent, s);
+      node = parent;
+    }
+  }
+}
+
+DRA_API int dra_sumtree_set_many_from(dra_sumtree* t, int64_t write0, int n, const double* prio_dev, void* stream) {
+  if (!t || !prio_dev || write0 < 0 || write0 >= t->capacity || n < 1 || n > 64 || n > t->capacity) return DRA_EINVAL;
+  hipLaunchKernelGGL(sumtree_set_many_from_kernel, dim3(1), dim3(64), 0, dra_stream(stream), t->tree, t->levels, t->capacity,
+                     write0, n, prio_dev);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 // Priority write-back of one minibatch without a host round trip (replay.py:193-196 + sum_tree.py:54-60).  The HOST
 // decides WHICH leaves are written (pending_idx gating and first-writer-wins need no priority value): leaf[i] gets
 // f64(prio_f32[pos[i]]), i < n.  stat[0] = max(stat[0], every offered priority) (replay.py:195: max_priority tracks all

@@ -117,7 +117,7 @@ class DQNLearner:
         lib.dra_dqn_learner_buffers(h, *[ctypes.byref(p) for p in ps])
         w = ops._wrap_device_pointer
         self.idx = w(ps[0].value, batch, torch.int64)
-        self.sampling_prob = w(ps[1].value, batch, torch.float32)
+        self.sampling_prob = w(ps[1].value, batch + 1, torch.float32)    # [batch] = the PER exponent beta of the update
         self._loss_per = w(ps[2].value, 1, torch.float32)
         self.norm = w(ps[3].value, 1, torch.float32)
         # head outputs of the online net on the sampled states: q [B, A], or logits / quantiles [B, A, N]
@@ -144,6 +144,9 @@ class DQNLearner:
         self._idx_pinned = [torch.empty(batch, dtype=torch.int64).pin_memory() for _ in range(8)]
         self._idx_events = [None] * 8
         self._k = 0
+        self._sp_pinned = [torch.empty(batch + 1, dtype=torch.float32).pin_memory() for _ in range(8)]
+        self._sp_events = [None] * 8
+        self._sp_k = 0
 
     def _partitioned_streams(self):
         """Update stream / actor stream on disjoint CU sets (DRA_VAR_CU_PARTITION).  On MI355X mask bit i is CU
@@ -209,15 +212,31 @@ class DQNLearner:
             ev.record(self.stream)
         self._idx_events[k] = ev
 
+    def upload_sampling_prob(self, prob, beta):
+        """PER: numpy sampling probabilities [batch] + the importance exponent -> the learner's device buffer (async,
+        pinned staging).  The kernels read beta from device memory, so the PER update replays from a captured graph."""
+        k = self._sp_k
+        self._sp_k = (k + 1) % len(self._sp_pinned)
+        if self._sp_events[k] is not None:
+            self._sp_events[k].synchronize()
+        buf = self._sp_pinned[k].numpy()
+        buf[:self.batch] = prob                      # f64 -> f32, as tensor(transitions.sampling_prob) does
+        buf[self.batch] = beta
+        with torch.cuda.stream(self.stream):
+            self.sampling_prob.copy_(self._sp_pinned[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._sp_events[k] = ev
+
     def update(self, idx=None, use_graph=True, sampling_prob=None, beta=0.0):
-        """One gradient update (gather + forward/backward graph + optimizer) on the update stream."""
+        """One gradient update (gather + forward/backward graph + optimizer) on the update stream.  sampling_prob (numpy
+        [batch]) makes it a PER update with importance exponent beta (DQN_agent.py:120-127)."""
         if idx is not None:
             self.upload_indices(idx)
         per = sampling_prob is not None
         if per:
-            with torch.cuda.stream(self.stream):
-                self.sampling_prob.copy_(sampling_prob, non_blocking=True)
-        lib.dra_dqn_learner_update(self.h, int(use_graph), int(per), float(beta), self._sp())
+            self.upload_sampling_prob(np.asarray(sampling_prob), beta)
+        lib.dra_dqn_learner_update(self.h, int(use_graph), int(per), -1.0 if per else 0.0, self._sp())
 
     def set_env_steps(self, slots, counters, random_actions, dices, epsilons, store=True, rcounters=None, ages=None):
         """Describes the next env transitions.  rcounters: counter whose hashes give the reward / mask stored with each
@@ -450,13 +469,16 @@ class DeviceActorPipeline:
             rp.advance(self.n_env)
             do_update = bool(account(infos))
             if self.per and do_update:
-                # DQN_agent.py:114-127 with PrioritizedReplay: tree descent on device from host-drawn uniforms, ONE D2H of
-                # the leaves (validity / padding stay on the host, draw for draw), importance weights applied inside the
-                # update, new priorities written back to the tree without leaving the device
-                tree_idx, prob, data_idx = rp.draw()
-                L.sampling_prob.copy_(torch.from_numpy(prob.astype(np.float32)), non_blocking=True)
-                L.set_per(True, self.beta_fn())
-                L.step(data_idx, True, False)
+                # DQN_agent.py:114-127 with PrioritizedReplay: the tree descent (host-drawn uniforms) is enqueued BEFORE
+                # the actor's transitions and its leaves land in pinned memory, so the one host round trip of the draw
+                # (validity / padding stay on the host, draw for draw) hides under the actor's forward passes; importance
+                # weights are applied inside the update (captured graph, exponent from device memory) and the new priorities
+                # go back to the tree without leaving the device
+                pending_draw = rp.draw_begin()
+                L.set_per(False, 0.0)
+                L.step(None, False, False)            # actor transitions only (in order, on the update stream)
+                tree_idx, prob, data_idx = rp.draw_end(pending_draw)
+                L.update(data_idx, use_graph=True, sampling_prob=prob, beta=self.beta_fn())
                 rp.commit_device(tree_idx, L.prio)
                 return infos
             idx = rp.draw_indices() if do_update else None

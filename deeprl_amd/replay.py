@@ -250,6 +250,7 @@ class PrioritizedReplay(UniformReplay):
         # host round trip (commit_device); the host attributes are then refreshed on demand
         self._stat = None
         self._stat_on_device = False
+        self._draw_out = None   # pinned (leaf, priority, total) the sample kernel writes directly
 
     def _lazy_tree(self):
         if self.tree is None:
@@ -305,23 +306,49 @@ class PrioritizedReplay(UniformReplay):
 
     def advance(self, n=1):
         """UniformReplay.advance + the tree side of feed() for transitions a DEVICE producer wrote into the ring."""
-        for _ in range(int(n)):
-            super().advance(1)
-            self._add_leaf()
+        n = int(n)
+        super().advance(n)
+        self._lazy_tree()
+        if not self._stat_on_device or n > 64 or n > self.memory_size:
+            for _ in range(n):
+                self._add_leaf()
+            return
+        for i in range(n):
+            self._pending.discard((self._write + i) % self.memory_size + self.memory_size - 1)
+        with torch.cuda.device(self._device()):
+            self.tree.set_many_from(self._write, n, self._stat)      # one launch for the whole agent step's adds
+        self._write = (self._write + n) % self.memory_size
 
-    def draw(self, batch_size=None):
-        """replay.py:164-186.  Returns (tree_idx, sampling_prob, data_idx) as numpy arrays; consumes
-        python `random` exactly as the reference: B uniforms, then one random.choice per padded slot."""
+    def draw_begin(self, batch_size=None):
+        """First half of draw(): B uniforms from python `random` (replay.py:169-172) and the tree descent enqueued on the
+        current stream, its results going straight into pinned host memory.  draw_end() waits for them; anything enqueued
+        in between (the device actor's forward passes) overlaps the host round trip."""
         if batch_size is None:
             batch_size = self.batch_size
         self._lazy_tree()
         u = np.asarray([random.random() for _ in range(batch_size)], dtype=np.float64)
         with torch.cuda.device(self._device()):
-            idx_d, p_d, total_d = self.tree.sample(self._u_up.upload(u))
-            packed = torch.cat([idx_d.to(torch.float64), p_d, total_d]).cpu().numpy()  # one D2H, syncs
-        tree_idx = packed[:batch_size].astype(np.int64)
-        p = packed[batch_size:2 * batch_size]
-        total = packed[-1]
+            if self._draw_out is None or self._draw_out[0].numel() < batch_size:
+                self._draw_out = (torch.empty(batch_size, dtype=torch.int64).pin_memory(),
+                                  torch.empty(batch_size, dtype=torch.float64).pin_memory(),
+                                  torch.empty(1, dtype=torch.float64).pin_memory())
+            oi, op, ot = self._draw_out
+            # the descent kernel writes leaves / priorities / total into pinned host memory: no packing kernels, no copy
+            # command -- one event wait is the whole host round trip of a prioritized draw
+            self.tree.sample_into(self._u_up.upload(u), oi, op, ot)
+            ev = torch.cuda.Event()
+            ev.record()
+        return batch_size, ev
+
+    def draw_end(self, pending_draw):
+        """Second half of draw(): validity check, pending marks and padding on the host (replay.py:173-186), consuming python
+        `random` exactly as the reference: one random.choice per padded slot.  Returns (tree_idx, sampling_prob, data_idx)."""
+        batch_size, ev = pending_draw
+        ev.synchronize()
+        oi, op, ot = self._draw_out
+        tree_idx = oi.numpy()[:batch_size].copy()
+        p = op.numpy()[:batch_size].copy()
+        total = float(ot.numpy()[0])
         picked = []
         for i in range(batch_size):
             ti = int(tree_idx[i])
@@ -334,6 +361,10 @@ class PrioritizedReplay(UniformReplay):
             picked.append(random.choice(picked))  # "This should rarely happen" (replay.py:184-186)
         return (np.asarray([t[0] for t in picked], dtype=np.int64), np.asarray([t[1] for t in picked], dtype=np.float64),
                 np.asarray([t[2] for t in picked], dtype=np.int64))
+
+    def draw(self, batch_size=None):
+        """replay.py:164-186.  Returns (tree_idx, sampling_prob, data_idx) as numpy arrays."""
+        return self.draw_end(self.draw_begin(batch_size))
 
     def sample(self, batch_size=None):
         tree_idx, prob, data_idx = self.draw(batch_size)

@@ -68,6 +68,8 @@ int dra_sumtree_update(dra_sumtree* tree, const int64_t* leaf_idx_dev, const dou
                        void* stream);
 int dra_sumtree_set(dra_sumtree* tree, int64_t leaf_idx, double prio, void* stream); /* sum_tree.py:39-51 (add) */
 int dra_sumtree_set_from(dra_sumtree* tree, int64_t leaf_idx, const double* prio_dev, void* stream); /* same, *prio_dev */
+/* n (<= 64) consecutive adds at write cursor write0, write0+1, ... (mod capacity), all at *prio_dev */
+int dra_sumtree_set_many_from(dra_sumtree* tree, int64_t write0, int n, const double* prio_dev, void* stream);
 /* replay.py:193-196 with the new priorities still on the device: leaf_idx_dev[i] <- f64(prio_f32_dev[pos_dev[i]]), i < n
  * (the host picks the pending, first-occurrence entries); stat_dev = {max_priority, smallest priority offered} is kept
  * over all `batch` offered values.  Falls back by itself to the reference's ordered walk when the level-parallel update
@@ -82,7 +84,9 @@ int dra_sumtree_rebuild(dra_sumtree* tree, void* stream);
 
 /* ---- fused losses (forward + backward) */
 /* deep_rl/agent/DQN_agent.py:78-99 (+ PER :120-127).  q, q_next_* [batch][n_actions] f32; action int64[batch] or
- * f32[batch]; reward/mask f32[batch].  sampling_prob NULL = uniform replay.  out_dq = d(reduced loss)/dq. */
+ * f32[batch]; reward/mask f32[batch].  sampling_prob NULL = uniform replay.  out_dq = d(reduced loss)/dq.
+ * beta < 0 (here and in dra_per_weights): the importance exponent is read from sampling_prob[batch] on the device, so that
+ * the launch has no per-update argument and can be replayed from a captured graph. */
 int dra_td_loss(const float* q, const float* q_next_target, const float* q_next_online, const void* action,
                 int action_is_i64, const float* reward, const float* mask, int batch, int n_actions, float gamma_n,
                 const float* sampling_prob, float beta, float replay_eps, float replay_alpha, float* out_loss,

@@ -42,6 +42,30 @@ class VectorTask:
         return self.s.copy(), rew, done, tuple(infos)
 
 
+class PixelVectorTask:
+    """`num_envs` synthetic Atari emulators (counter-hash 84x84 uint8 frames, history 4; deeprl_amd.envs.SyntheticAtari is a
+    pure numpy host emulator) behind the Task surface with DummyVecEnv's auto-reset: states uint8 [N,4,84,84]."""
+
+    def __init__(self, seed=0, num_envs=4, done_period=9, n_actions=4, name="FakePixels"):
+        from deeprl_amd.envs import SyntheticAtari
+        self.envs = [SyntheticAtari(seed=seed + 1000 * e, history=4, n_actions=n_actions, done_period=done_period)
+                     for e in range(num_envs)]
+        self.state_dim, self.action_dim, self.name, self.num_envs = (4, 84, 84), n_actions, name, num_envs
+
+    def reset(self):
+        return np.stack([np.asarray(e.reset()) for e in self.envs])
+
+    def step(self, actions):
+        actions = np.asarray(actions).reshape(self.num_envs)
+        obs, rew, done, infos = [], [], [], []
+        for e, a in zip(self.envs, actions):
+            o, r, d, i = e.step(int(a))
+            if d:
+                o = e.reset()
+            obs.append(np.asarray(o)); rew.append(r); done.append(d); infos.append(i)
+        return np.stack(obs), np.asarray(rew, dtype=np.float64), np.asarray(done), tuple(infos)
+
+
 class BoxSpace:
     """gym.spaces.Box surface the continuous-control agents use (low / high / sample()); sample() draws from a private
     stream like gym's own space RNG, never from the global np.random."""
@@ -142,6 +166,11 @@ NATURE_SHAPES = [
     ("body.conv3.weight", (64, 64, 3, 3)), ("body.conv3.bias", (64,)),
     ("body.fc4.weight", (512, 3136)), ("body.fc4.bias", (512,)),
 ]
+
+
+def NATURE_SHAPES_PREFIXED(prefix):
+    """NatureConvBody's tensors under another module path (e.g. 'network.phi_body.' of the actor-critic nets)."""
+    return [(prefix + name[len("body."):], shape) for name, shape in NATURE_SHAPES]
 
 
 def nature_vanilla_shapes(action_dim):

@@ -28,3 +28,15 @@ PER_CASES = [
     ("q", 64, 16, 1, 3, 0.9, (4,), "f64", 200, 5),
     ("r", 33, 4, 2, 1, 0.99, (2, 2), "u8", 120, 3),
 ]
+
+PIXEL_AGENT_CASES = [   # tag, agent, replay, n_step, done_period, agent steps
+    ("dqn_b32", "dqn", "uniform", 1, 9, 24),
+    ("c51_per", "c51", "per", 1, 7, 24),
+    ("qr_n3", "qr", "uniform", 3, 11, 22),
+]
+
+
+def digest(t, stride=1009):
+    """Small stand-in for a multi-megabyte tensor: {fp64 sum, fp64 sum of squares} + every `stride`-th element."""
+    a = np.asarray(t, dtype=np.float32).reshape(-1)
+    return np.concatenate([[a.astype(np.float64).sum(), np.square(a.astype(np.float64)).sum()], a[::stride].astype(np.float64)])

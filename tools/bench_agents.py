@@ -36,10 +36,10 @@ class _Quiet:
         pass
 
 
-def dqn_family(kind, replay_cls, ring=200_000, fused=True):
+def dqn_family(kind, replay_cls, ring=200_000, fused=True, device=False):
     c = d.Config()
     c.merge(dict(game="synthetic-atari", log_level=0, tag="bench", n_step=1, replay_cls=replay_cls, async_replay=False,
-                 fused_learner=fused, device_env=False))      # HOST emulator (bench.py's agent_api reports the device-resident one)
+                 fused_learner=fused, device_env=device))     # device=False: HOST emulator; True: device-resident environment
     c.task_fn = lambda: d.Task(c.game, seed=1)
     c.eval_env = c.task_fn()
     if kind == "dqn":
@@ -73,7 +73,7 @@ def dqn_family(kind, replay_cls, ring=200_000, fused=True):
     c.exploration_steps = 300          # the update phase is what is timed
     c.sgd_update_frequency = 4
     c.double_q = False
-    c.async_actor = False
+    c.async_actor = bool(device)       # the reference's default for the pixel DQN family (PrioritizedReplay: in order anyway)
     c.max_steps = int(2e7)
     return agent_cls(c), dict(env_per_step=4, updates_per_step=1)
 
@@ -136,6 +136,10 @@ CASES = {
     "c51_pixel_uniform": lambda: dqn_family("c51", d.UniformReplay),
     "c51_pixel_per": lambda: dqn_family("c51", d.PrioritizedReplay),
     "qr_dqn_pixel_uniform": lambda: dqn_family("qr", d.UniformReplay),
+    "dqn_pixel_per_device": lambda: dqn_family("dqn", d.PrioritizedReplay, device=True),
+    "c51_pixel_uniform_device": lambda: dqn_family("c51", d.UniformReplay, device=True),
+    "c51_pixel_per_device": lambda: dqn_family("c51", d.PrioritizedReplay, device=True),
+    "qr_dqn_pixel_uniform_device": lambda: dqn_family("qr", d.UniformReplay, device=True),
     "a2c_pixel_16": lambda: a2c_pixel(16),
     "ppo_pixel_8": lambda: ppo_pixel(8),
     "ppo_continuous_1": lambda: ppo_continuous(1),
@@ -154,7 +158,7 @@ def main():
     for name in a.cases.split(","):
         try:
             agent, meta = CASES[name]()
-            warm = 80 if "dqn" in name or "c51" in name else 2      # DQN family: past exploration_steps
+            warm = 120 if "dqn" in name or "c51" in name else 2      # DQN family: past exploration_steps
             for _ in range(warm):
                 agent.step()
             torch.cuda.synchronize()
