@@ -306,8 +306,11 @@ def on_policy_main(args):
             "metric": "env-steps/sec", "value": k * steps_per_call / dt, "unit": "env-steps/s", "n_gpus": world, "steps": k,
             "warmup": max(1, args.warmup // 20), "ms_per_step": 1e3 * dt / k, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s (BASELINE configs[4]): %d environments per GPU, rollout %d, host-side synthetic emulators, "
-                                   "gradient all-reduce per optimizer step" % (args.workload, per_gpu, agent.config.rollout_length),
+            "config": {"workload": "%s (BASELINE configs[4]): %d environments per GPU, rollout %d, %s, "
+                                   "gradient all-reduce per optimizer step" % (
+                                       args.workload, per_gpu, agent.config.rollout_length,
+                                       "device-resident synthetic environments" if getattr(agent.task, "on_device", False)
+                                       else "host-side synthetic emulators"),
                        "parallelism": "dp%d" % world, "collective": "dra_allreduce_grads (RCCL)" if agent.dp.comm else
                        ("torch.distributed " + (dist.get_backend() if world > 1 else "none"))},
             "updates_per_sec": k * (1 if args.workload == "a2c_pixel" else 16) / dt}), flush=True)

@@ -209,6 +209,17 @@ class DQNActor(BaseActor):
         return entry
 
 
+def _capture_failed(config, what, error):
+    """A hipGraph capture failed.  Falling back to the eager kernels silently would turn a broken capture into nothing but a
+    slower number, so it is an error unless the configuration opts into the fallback (config.allow_eager_fallback = True:
+    e.g. a user network with host-side control flow)."""
+    if not getattr(config, 'allow_eager_fallback', False):
+        raise RuntimeError("%s could not be captured as a hipGraph (%r); set config.allow_eager_fallback = True to run it "
+                           "eagerly, or config.graph_update = False to skip capturing" % (what, error)) from error
+    import warnings
+    warnings.warn("%s could not be captured as a graph (%r); using the eager path" % (what, error))
+
+
 class _GraphedQ:
     """DQNActor's forward (DQN_agent.py:29-33) as ONE hipGraph replay for image observations: the uint8
     [1,C,H,W] observation goes through pinned staging into a static device buffer; normaliser table kernel,
@@ -259,8 +270,7 @@ class _GraphedQ:
                         self.static_out = a.q_device(a._network(cfg.state_normalizer(self.static_in)))
                 self.graph = g
             except Exception as e:      # e.g. a network with host-side control flow: stay on the eager path
-                import warnings
-                warnings.warn("actor forward could not be captured as a graph (%r); using the eager path" % (e,))
+                _capture_failed(cfg, "the actor forward", e)
                 self.failed = True
                 self.graph = None
                 return None
@@ -327,8 +337,7 @@ class _GraphedUpdate:
                 self.graph = g
                 self.signature = opt.hyper_signature()
             except Exception as e:
-                import warnings
-                warnings.warn("update could not be captured as a graph (%r); using the eager path" % (e,))
+                _capture_failed(cfg, "the update", e)
                 self.failed = True
                 self.graph = None
                 opt.graph_mode = False
@@ -834,6 +843,67 @@ def _install_sampler(agent):
                                                                    logits.device))
 
 
+class _OnPolicyGraph:
+    """Replays an on-policy agent's device-side work of one rollout (A2CAgent._rollout_compute: T forwards with action
+    sampling, the return scan, loss, backward, clip, optimizer) from ONE captured hipGraph after two eager rollouts.  The
+    rollout plan lives in persistent device buffers (DeviceAtariVec.plan), so every kernel argument is constant across
+    rollouts; torch's graph-safe Philox bookkeeping continues the sampling generator exactly as the eager kernels would.
+    Not used when the gradient leaves the device stream (data-parallel exchange, grad hooks) or config.graph_update is off."""
+    WARMUP = 2
+
+    def __init__(self, agent, optimizer_inside=True):
+        self.agent = agent
+        self.optimizer_inside = optimizer_inside      # the captured region ends with agent._fused.step()
+        self.calls = 0
+        self.graph = None
+        self.out = None
+        self.key = None
+        self.failed = False
+
+    def usable(self):
+        a = self.agent
+        cfg = a.config
+        return not (self.failed or getattr(cfg, 'graph_update', True) is False or a.grad_hook is not None or a.dp.active
+                    or a.dp.invariant_sampling)
+
+    def run(self, plan, compute):
+        a = self.agent
+        self.calls += 1
+        if not self.usable() or self.calls <= self.WARMUP:
+            return compute(plan)
+        opt = a._fused if self.optimizer_inside else None
+        key = (plan.counters.data_ptr(), plan.t_len, opt.hyper_signature() if opt is not None else None)
+        if self.graph is not None and key != self.key:
+            self.graph = None
+        if self.graph is None:
+            validate = torch.distributions.Distribution._validate_args
+            try:
+                torch.distributions.Distribution.set_default_validate_args(False)   # its checks synchronise with the host
+                if opt is not None:
+                    opt.enable_graph_mode()
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                steps = a._rollout_step
+                with torch.cuda.graph(g):
+                    self.out = compute(plan)
+                a._rollout_step = steps       # the capture pass only recorded the work
+                self.graph, self.key = g, key
+            except Exception as e:
+                _capture_failed(a.config, "the rollout", e)
+                self.failed = True
+                self.graph = None
+                if opt is not None:
+                    opt.graph_mode = False
+                return compute(plan)
+            finally:
+                torch.distributions.Distribution.set_default_validate_args(validate)
+        if opt is not None:
+            opt.prepare_step()
+        self.graph.replay()
+        a._rollout_step += plan.t_len + (1 if hasattr(a, '_act') else 0)
+        return self.out
+
+
 class A2CAgent(BaseAgent):
     """A2C_agent.py:12-64."""
 
@@ -847,16 +917,59 @@ class A2CAgent(BaseAgent):
         self.optimizer = config.optimizer_fn(self.network.parameters())
         self._fused = FusedOptimizer.adopt(self.optimizer)
         self.total_steps = 0
+        from .device_env import DeviceAtariVec
+        if DeviceAtariVec.eligible(self.task, config):      # synthetic Atari emulators: the environments live on the device
+            self.task = DeviceAtariVec(self.task)
         self.states = self.task.reset()
         self.grad_hook = None  # optional extra hook on the flat gradient before the optimiser step
         self._rollout_step = 0
+        self._dev_graph = _OnPolicyGraph(self)
         _install_sampler(self)
 
     def close(self):
         close_obj(self.task)
         self.dp.close()
 
+    def _step_device(self):
+        """step() over device-resident environments: the host lays the rollout out (counters, rewards, terminals of every
+        environment: the synthetic environment is a pure function of its frame counter), uploads it with one copy, and
+        everything else -- T x [observations, forward, action sample], bootstrap forward, return scan, loss, backward, clip,
+        optimizer -- is enqueued without a host round trip and, after two eager rollouts, replayed as ONE captured graph."""
+        config = self.config
+        plan = self.task.plan(config.rollout_length, config.reward_normalizer)
+        for t in range(config.rollout_length):
+            self.record_online_return(plan.infos[t])
+            self.total_steps += self.dp.global_workers
+        out4 = self._dev_graph.run(plan, self._rollout_compute)
+        self.last_loss = out4
+
+    def _rollout_compute(self, plan):
+        config = self.config
+        storage = Storage(config.rollout_length)
+        for t in range(config.rollout_length):
+            prediction = self.network(config.state_normalizer(self.task.states(plan, t)))
+            self._rollout_step += 1
+            storage.feed(prediction)
+            storage.feed({'reward': plan.reward[t], 'mask': plan.mask[t]})
+        prediction = self.network(config.state_normalizer(self.task.states(plan, config.rollout_length)))
+        storage.feed(prediction)
+        storage.placeholder()
+        _rollout_scan(storage, config, prediction['v'])
+        entries = storage.extract(['log_pi_a', 'v', 'ret', 'advantage', 'entropy'])
+        out4, (g_lp, g_ent, g_v) = ops.a2c_loss(entries.log_pi_a.detach(), entries.entropy.detach(), entries.v.detach(),
+                                                entries.advantage, entries.ret, config.entropy_weight,
+                                                config.value_loss_weight)
+        self._fused.zero_grad()
+        torch.autograd.backward([entries.log_pi_a, entries.entropy, entries.v], [g_lp, g_ent, g_v])
+        self.dp.sum_grads(self._fused.flat.grad, 1.0 / self.dp.world if self.dp.active else 1.0)
+        if self.grad_hook is not None:
+            self.grad_hook(self._fused.flat.grad)
+        self._fused.step(config.gradient_clip)
+        return out4
+
     def step(self):
+        if getattr(self.task, 'on_device', False):
+            return self._step_device()
         config = self.config
         storage = Storage(config.rollout_length)
         states = self.states
@@ -969,8 +1082,14 @@ class PPOAgent(BaseAgent):
             self._fused_actor = FusedOptimizer.adopt(self.actor_opt)
             self._fused_critic = FusedOptimizer.adopt(self.critic_opt)
         self.total_steps = 0
-        self.states = self.task.reset()
-        self.states = config.state_normalizer(self.states)
+        from .device_env import DeviceAtariVec
+        if DeviceAtariVec.eligible(self.task, config):      # synthetic Atari emulators: the environments live on the device
+            self.task = DeviceAtariVec(self.task)
+            self.states = None
+        else:
+            self.states = self.task.reset()
+            self.states = config.state_normalizer(self.states)
+        self._dev_graph = _OnPolicyGraph(self, optimizer_inside=False)
         if config.shared_repr:
             self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda step: 1 - step / config.max_steps)
         self.grad_hook = None
@@ -985,7 +1104,48 @@ class PPOAgent(BaseAgent):
         close_obj(self.task)
         self.dp.close()
 
+    def _step_device(self):
+        """step() over device-resident environments (see A2CAgent._step_device): the rollout -- T x [observations, image
+        normalisation, no-grad forward, action sample], bootstrap forward, GAE scan, advantage normalisation -- is one
+        captured graph whose outputs are the rollout entries; the optimisation phase is unchanged."""
+        config = self.config
+        plan = self.task.plan(config.rollout_length, config.reward_normalizer)
+        for t in range(config.rollout_length):
+            self.record_online_return(plan.infos[t])
+            self.total_steps += self.dp.global_workers
+        entries = self._dev_graph.run(plan, self._rollout_compute)
+        if config.shared_repr:
+            self.lr_scheduler.step(self.total_steps)
+        self.optimize(entries)
+
+    def _rollout_compute(self, plan):
+        config = self.config
+        storage = Storage(config.rollout_length)
+        with torch.no_grad():
+            for t in range(config.rollout_length):
+                state_t = config.state_normalizer(self.task.states(plan, t))
+                prediction = self.network(state_t)
+                self._rollout_step += 1
+                storage.feed(prediction)
+                storage.feed({'reward': plan.reward[t], 'mask': plan.mask[t], 'state': state_t})
+            prediction = self.network(config.state_normalizer(self.task.states(plan, config.rollout_length)))
+            self._rollout_step += 1
+        storage.feed(prediction)
+        storage.placeholder()
+        _rollout_scan(storage, config, prediction['v'])
+        entries = storage.extract(['state', 'action', 'log_pi_a', 'ret', 'advantage'])
+        entry_cls = entries.__class__
+        entries = entry_cls(*[x.detach() for x in entries])
+        if self.dp.active:
+            from .dist import global_advantage_normalize_
+            global_advantage_normalize_(entries.advantage)
+        else:
+            ops.adv_normalize_(entries.advantage)
+        return entries
+
     def step(self):
+        if getattr(self.task, 'on_device', False):
+            return self._step_device()
         config = self.config
         storage = Storage(config.rollout_length)
         states = self.states
@@ -1048,8 +1208,7 @@ class PPOAgent(BaseAgent):
                                 g['out'] = self.network(g['in'])
                         g['graph'] = graph
                     except Exception as e:
-                        import warnings
-                        warnings.warn("rollout forward could not be captured as a graph (%r); using the eager path" % (e,))
+                        _capture_failed(cfg, "the rollout forward", e)
                         g['failed'] = True
                     finally:
                         torch.distributions.Distribution.set_default_validate_args(validate)
@@ -1252,8 +1411,7 @@ class _GraphedPPO:
             if self.graphs is None:
                 self._capture(entry_cls)
         except Exception as e:
-            import warnings
-            warnings.warn("PPO minibatch update could not be captured as a graph (%r); using the eager path" % (e,))
+            _capture_failed(cfg, "the PPO minibatch update", e)
             self.failed = True
             for o in ([a._fused] if cfg.shared_repr else [a._fused_actor, a._fused_critic]):
                 o.graph_mode = False

@@ -2138,6 +2138,34 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
   return DRA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Observations of N device-resident synthetic Atari environments (the vectorised environments of the on-policy agents,
+// A2C_agent.py:26-34 / PPO_agent.py:33-47: `states` of one rollout step).  The environment is a pure function of its frame
+// counter, so an observation needs no state on the device: frame j of env e's stack is counter[e] - min(H-1-j, age[e])
+// of stream seed[e] (age = earlier observations of the same episode, capped at H-1: after a reset the first frame is
+// repeated, envs.py FrameStack.reset); the host shadow (SyntheticEpisodeStream) supplies counters / ages for a whole
+// rollout ahead of time together with the rewards and terminals.  grid (N, H) x 256 threads, out u8 [N][H][84*84].
+__global__ void __launch_bounds__(256)
+synth_stacks_kernel(const int64_t* __restrict__ counter, const int32_t* __restrict__ age, const int64_t* __restrict__ seed,
+                    int history, uint8_t* __restrict__ out) {
+  const int e = blockIdx.x, j = blockIdx.y;
+  const int back = min(history - 1 - j, (int)age[e]);
+  const int64_t c = counter[e] - back;
+  uint64_t* dst = reinterpret_cast<uint64_t*>(out + ((int64_t)e * history + j) * 7056);
+  const uint64_t sd = (uint64_t)seed[e];
+  for (int w = threadIdx.x; w < 882; w += 256) dst[w] = synth_frame_word(sd, c, 0, w);
+}
+
+DRA_API int dra_synth_stacks(const int64_t* counter_dev, const int32_t* age_dev, const int64_t* seed_dev, int n_env, int history,
+                             void* out_u8, void* stream) {
+  if (!counter_dev || !age_dev || !seed_dev || !out_u8 || n_env < 1 || history < 1 || history > 16) return DRA_EINVAL;
+  if (((uintptr_t)out_u8) & 7) return DRA_EINVAL;
+  hipLaunchKernelGGL(synth_stacks_kernel, dim3(n_env, history), dim3(256), 0, dra_stream(stream), counter_dev, age_dev, seed_dev,
+                     history, (uint8_t*)out_u8);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 #ifdef DRA_TRACE
 // Measurement build only (libdeeprl_amd_trace.so): points every translation unit's phase-trace pointer at `buf`
 // (TR_REGIONS x kTraceWgs x 8 u64, device memory; null switches the stamps off).  tools/phase_trace.py.

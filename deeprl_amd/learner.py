@@ -422,6 +422,10 @@ class DeviceActorPipeline:
         self.beta_fn = beta_fn
         if self.per and async_actor:
             raise DraError("the async device pipeline is uniform-replay only")
+        # the priority tree's kernels (adds of the new transitions, stratified descent, write-back) are single-workgroup
+        # latency chains of ~20 dependent levels each; they depend on the previous UPDATE only, so they run on their own
+        # stream underneath the actor's forward passes
+        self.tree_stream = torch.cuda.Stream() if self.per else None
         self.A, self.n_env, self.epsilon_fn, self.async_actor = int(n_actions), int(n_env), epsilon_fn, bool(async_actor)
         self.rs = np.random.RandomState(actor_seed) if async_actor else np.random
         self.capacity = replay.memory_size
@@ -466,7 +470,11 @@ class DeviceActorPipeline:
         L, rp = self.L, self.rp
         if not self.async_actor:
             infos = self._block()
-            rp.advance(self.n_env)
+            if self.per:
+                with torch.cuda.stream(self.tree_stream):
+                    rp.advance(self.n_env)
+            else:
+                rp.advance(self.n_env)
             do_update = bool(account(infos))
             if self.per and do_update:
                 # DQN_agent.py:114-127 with PrioritizedReplay: the tree descent (host-drawn uniforms) is enqueued BEFORE
@@ -474,12 +482,15 @@ class DeviceActorPipeline:
                 # (validity / padding stay on the host, draw for draw) hides under the actor's forward passes; importance
                 # weights are applied inside the update (captured graph, exponent from device memory) and the new priorities
                 # go back to the tree without leaving the device
-                pending_draw = rp.draw_begin()
+                with torch.cuda.stream(self.tree_stream):
+                    pending_draw = rp.draw_begin()
                 L.set_per(False, 0.0)
                 L.step(None, False, False)            # actor transitions only (in order, on the update stream)
                 tree_idx, prob, data_idx = rp.draw_end(pending_draw)
                 L.update(data_idx, use_graph=True, sampling_prob=prob, beta=self.beta_fn())
-                rp.commit_device(tree_idx, L.prio)
+                self.tree_stream.wait_stream(L.stream)                # the write-back reads this update's priorities
+                with torch.cuda.stream(self.tree_stream):
+                    rp.commit_device(tree_idx, L.prio)
                 return infos
             idx = rp.draw_indices() if do_update else None
             if self.per:

@@ -233,6 +233,12 @@ int dra_adam_step_counter(float* param, const float* grad, float* exp_avg, float
                           float eps, const int64_t* step_dev, float* out_norm, float* param_copy, void* stream);
 int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream); /* DQN_agent.py:136-138 */
 
+/* ---- device-resident synthetic vector environment (on-policy agents; A2C_agent.py:26-34, PPO_agent.py:33-47): the uint8
+ * [n_env][history][84*84] observations of one rollout step from per-environment frame counters / episode ages / stream
+ * seeds (device arrays of n_env).  Frames are the counter-hash frames of dra_ring_fill_synthetic. */
+int dra_synth_stacks(const int64_t* counter_dev, const int32_t* age_dev, const int64_t* seed_dev, int n_env, int history,
+                     void* out_u8, void* stream);
+
 /* ---- fused DQN learner + device-resident actor: DQN_agent.py:24-45 (actor step), :114-138 (update) for
  * VanillaNet(NatureConvBody).  All five flat buffers are caller-owned f32[n_params] with the tensor order
  * conv1.w, conv1.b, conv2.w, conv2.b, conv3.w, conv3.b, fc4.w, fc4.b, head.w, head.b at `offset[]` (16-byte

@@ -707,3 +707,50 @@ def test_graphed_ppo_optimisation_is_bit_identical(dra, monkeypatch, kind):
         agent.close()
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("kind", ["a2c", "ppo"])
+def test_onpolicy_device_env_equals_host_emulators(dra, monkeypatch, kind):
+    """A2C / PPO on pixels (BASELINE configs[4] shapes): with device-resident environments (device_env.DeviceAtariVec: the
+    host lays a rollout out, observations are generated on the device, the whole rollout -- and for A2C the update too --
+    replays from one captured graph) the agents end on the SAME parameters, bit for bit, as with the host emulators: same
+    frames, same normaliser arithmetic, same kernels, same generator sequence for the action samples."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    outs = []
+    for device_env in (True, False):
+        cfg = d.Config()
+        cfg.merge(dict(game="synthetic-atari", log_level=0, tag="dv%d" % device_env, device_env=device_env))
+        cfg.num_workers = 4
+        cfg.task_fn = lambda: d.Task(cfg.game, num_envs=cfg.num_workers, seed=11, synthetic_done_period=13)
+        cfg.eval_env = d.Task(cfg.game, seed=12)
+        cfg.network_fn = lambda: d.CategoricalActorCriticNet(cfg.state_dim, cfg.action_dim, d.NatureConvBody())
+        cfg.state_normalizer, cfg.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
+        cfg.discount, cfg.use_gae, cfg.entropy_weight = 0.99, True, 0.01
+        if kind == "a2c":
+            cfg.optimizer_fn = lambda p: torch.optim.RMSprop(p, lr=1e-4, alpha=0.99, eps=1e-5)
+            cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 1.0, 5, 5
+            cls, n = d.A2CAgent, 6
+        else:
+            cfg.optimizer_fn = lambda p: torch.optim.Adam(p, lr=2.5e-4)
+            cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 0.95, 16, 0.5
+            cfg.optimization_epochs, cfg.mini_batch_size, cfg.ppo_ratio_clip, cfg.shared_repr = 2, 16, 0.1, True
+            cfg.max_steps, cfg.log_interval, cfg.target_kl = 1e6, 10 ** 9, 0.01
+            cls, n = d.PPOAgent, 5
+        d.random_seed(21)
+        torch.manual_seed(22)
+        agent = cls(cfg)
+        assert getattr(agent.task, "on_device", False) == device_env
+        for _ in range(n):
+            agent.step()
+        torch.cuda.synchronize()
+        if device_env:
+            assert agent._dev_graph.graph is not None, "the rollout must be replayed from the captured graph"
+        outs.append(({k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()}, agent.total_steps,
+                     np.random.randint(0, 1 << 30, size=2)))
+        agent.close()
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][2], outs[1][2])
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k

@@ -78,9 +78,9 @@ def dqn_family(kind, replay_cls, ring=200_000, fused=True, device=False):
     return agent_cls(c), dict(env_per_step=4, updates_per_step=1)
 
 
-def a2c_pixel(workers=16):
+def a2c_pixel(workers=16, device=True):
     c = d.Config()
-    c.merge(dict(game="BreakoutNoFrameskip-v4", log_level=0, tag="bench"))
+    c.merge(dict(game="BreakoutNoFrameskip-v4", log_level=0, tag="bench", device_env=device))
     c.num_workers = workers
     c.task_fn = lambda: d.Task(c.game, num_envs=c.num_workers, seed=1)
     c.eval_env = d.Task(c.game, seed=2)
@@ -111,9 +111,9 @@ def ppo_continuous(workers=1):
     return d.PPOAgent(c), dict(env_per_step=2048 * workers, updates_per_step=n_mb)
 
 
-def ppo_pixel(workers=8):
+def ppo_pixel(workers=8, device=True):
     c = d.Config()
-    c.merge(dict(game="BreakoutNoFrameskip-v4", log_level=0, tag="bench", skip=False))
+    c.merge(dict(game="BreakoutNoFrameskip-v4", log_level=0, tag="bench", skip=False, device_env=device))
     c.num_workers = workers
     c.task_fn = lambda: d.Task(c.game, num_envs=c.num_workers, seed=1)
     c.eval_env = d.Task(c.game, seed=2)
@@ -140,8 +140,10 @@ CASES = {
     "c51_pixel_uniform_device": lambda: dqn_family("c51", d.UniformReplay, device=True),
     "c51_pixel_per_device": lambda: dqn_family("c51", d.PrioritizedReplay, device=True),
     "qr_dqn_pixel_uniform_device": lambda: dqn_family("qr", d.UniformReplay, device=True),
-    "a2c_pixel_16": lambda: a2c_pixel(16),
+    "a2c_pixel_16": lambda: a2c_pixel(16),                      # device-resident environments (the default)
+    "a2c_pixel_16_host": lambda: a2c_pixel(16, device=False),   # host emulators
     "ppo_pixel_8": lambda: ppo_pixel(8),
+    "ppo_pixel_8_host": lambda: ppo_pixel(8, device=False),
     "ppo_continuous_1": lambda: ppo_continuous(1),
     "ppo_continuous_16": lambda: ppo_continuous(16),
 }
@@ -158,7 +160,7 @@ def main():
     for name in a.cases.split(","):
         try:
             agent, meta = CASES[name]()
-            warm = 120 if "dqn" in name or "c51" in name else 2      # DQN family: past exploration_steps
+            warm = 120 if "dqn" in name or "c51" in name else 4      # DQN family: past exploration_steps; on-policy: past graph capture
             for _ in range(warm):
                 agent.step()
             torch.cuda.synchronize()
