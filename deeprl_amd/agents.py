@@ -945,22 +945,38 @@ class A2CAgent(BaseAgent):
 
     def _rollout_compute(self, plan):
         config = self.config
-        storage = Storage(config.rollout_length)
-        for t in range(config.rollout_length):
-            prediction = self.network(config.state_normalizer(self.task.states(plan, t)))
-            self._rollout_step += 1
-            storage.feed(prediction)
-            storage.feed({'reward': plan.reward[t], 'mask': plan.mask[t]})
-        prediction = self.network(config.state_normalizer(self.task.states(plan, config.rollout_length)))
-        storage.feed(prediction)
-        storage.placeholder()
-        _rollout_scan(storage, config, prediction['v'])
-        entries = storage.extract(['log_pi_a', 'v', 'ret', 'advantage', 'entropy'])
-        out4, (g_lp, g_ent, g_v) = ops.a2c_loss(entries.log_pi_a.detach(), entries.entropy.detach(), entries.v.detach(),
-                                                entries.advantage, entries.ret, config.entropy_weight,
-                                                config.value_loss_weight)
+        states, actions, values = [], [], []
+        with torch.no_grad():
+            for t in range(config.rollout_length):
+                state_t = config.state_normalizer(self.task.states(plan, t))
+                prediction = self.network(state_t)
+                self._rollout_step += 1
+                states.append(state_t)
+                actions.append(prediction['action'])
+                values.append(prediction['v'])
+            values.append(self.network(config.state_normalizer(self.task.states(plan, config.rollout_length)))['v'])
+        return self._learn(states, actions, values, [plan.reward[t] for t in range(config.rollout_length)],
+                           [plan.mask[t] for t in range(config.rollout_length)])
+
+    def _learn(self, states, actions, values, rewards, masks):
+        """A2C_agent.py:43-64 on a finished rollout.  The reference keeps the autograd graph of every rollout forward and
+        backpropagates through all T of them; the parameters do not change inside a rollout, so ONE forward over the T x N
+        stored observations with the stored actions gives the same log-probabilities, entropies and values and ONE
+        backward the same gradient (up to fp32 summation order) -- T-fold fewer backward launches and no gradient
+        accumulation passes (rocprofv3, profiles/r02z9_*: 490 launches per A2C step, 86 of them `grad += ...`)."""
+        config = self.config
+        t_len = config.rollout_length
+        value = torch.stack(values).contiguous()
+        adv, ret = ops.gae(torch.stack(rewards).contiguous(), torch.stack(masks).contiguous(), value, config.discount,
+                           config.gae_tau, config.use_gae)
+        prediction = self.network(torch.cat(states, dim=0), torch.cat([a.reshape(-1) for a in actions], dim=0))
+        out4, (g_lp, g_ent, g_v) = ops.a2c_loss(prediction['log_pi_a'].detach(), prediction['entropy'].detach(),
+                                                prediction['v'].detach(), adv.reshape(-1, 1), ret.reshape(-1, 1),
+                                                config.entropy_weight, config.value_loss_weight)
         self._fused.zero_grad()
-        torch.autograd.backward([entries.log_pi_a, entries.entropy, entries.v], [g_lp, g_ent, g_v])
+        torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']], [g_lp, g_ent, g_v])
+        # data parallel: the loss above is the mean over this rank's T x N/G rows; equal shards -> the mean of the G
+        # gradients is the gradient of the global mean loss.  ONE all-reduce, then clip + step identically everywhere.
         self.dp.sum_grads(self._fused.flat.grad, 1.0 / self.dp.world if self.dp.active else 1.0)
         if self.grad_hook is not None:
             self.grad_hook(self._fused.flat.grad)
@@ -971,37 +987,27 @@ class A2CAgent(BaseAgent):
         if getattr(self.task, 'on_device', False):
             return self._step_device()
         config = self.config
-        storage = Storage(config.rollout_length)
         states = self.states
+        seen, actions, values, rewards_l, masks_l = [], [], [], [], []
         for _ in range(config.rollout_length):
-            prediction = self.network(config.state_normalizer(states))
+            with torch.no_grad():
+                state_t = tensor(config.state_normalizer(states))
+                prediction = self.network(state_t)
             self._rollout_step += 1
             next_states, rewards, terminals, info = self.task.step(to_np(prediction['action']))
             self.record_online_return(info)
             rewards = config.reward_normalizer(rewards)
-            storage.feed(prediction)
-            storage.feed({'reward': tensor(rewards).unsqueeze(-1), 'mask': tensor(1 - terminals).unsqueeze(-1)})
+            seen.append(state_t)
+            actions.append(prediction['action'])
+            values.append(prediction['v'])
+            rewards_l.append(tensor(rewards).unsqueeze(-1))
+            masks_l.append(tensor(1 - terminals).unsqueeze(-1))
             states = next_states
             self.total_steps += self.dp.global_workers
         self.states = states
-        prediction = self.network(config.state_normalizer(states))
-        storage.feed(prediction)
-        storage.placeholder()
-        _rollout_scan(storage, config, prediction['v'])
-
-        entries = storage.extract(['log_pi_a', 'v', 'ret', 'advantage', 'entropy'])
-        out4, (g_lp, g_ent, g_v) = ops.a2c_loss(entries.log_pi_a.detach(), entries.entropy.detach(), entries.v.detach(),
-                                                entries.advantage, entries.ret, config.entropy_weight,
-                                                config.value_loss_weight)
-        self._fused.zero_grad()
-        torch.autograd.backward([entries.log_pi_a, entries.entropy, entries.v], [g_lp, g_ent, g_v])
-        # data parallel: the loss above is the mean over this rank's T x N/G rows; equal shards -> the mean of the G
-        # gradients is the gradient of the global mean loss.  ONE all-reduce, then clip + step identically everywhere.
-        self.dp.sum_grads(self._fused.flat.grad, 1.0 / self.dp.world if self.dp.active else 1.0)
-        if self.grad_hook is not None:
-            self.grad_hook(self._fused.flat.grad)
-        self._fused.step(config.gradient_clip)
-        self.last_loss = out4
+        with torch.no_grad():
+            values.append(self.network(config.state_normalizer(states))['v'])
+        self.last_loss = self._learn(seen, actions, values, rewards_l, masks_l)
 
 
 class NStepDQNAgent(BaseAgent):

@@ -1,5 +1,6 @@
 // K2/K3 exports: NatureConvBody / FCBody / head contractions (templates in igemm.h).
 #include "igemm.h"
+#include <stdlib.h>
 
 template <class G, int BM, int BN, int BK, bool U8>
 static int conv_fwd_t(int nz, const void* const* x, const float* const* w, const float* const* bias, float* const* y,
@@ -135,11 +136,65 @@ linear_finish_kernel(LinPtrs q, const float* __restrict__ slabs, int ksplit, int
   q.y[z][i] = act_apply(v + (q.bias[z] ? q.bias[z][o] : 0.f), act);
 }
 
+// Small layers (in_features <= 512: the actor-critic / Q heads on 512 features, every layer of the FCBody nets):
+// the K-chunked implicit GEMM pays ~2 us per dependent 64-wide chunk and lands at 8-16 us for a few MFLOP.  Here a
+// workgroup stages up to 32 input rows in LDS once (<= 64 KB) and each of its 4 waves owns one output: the weight row
+// sits in registers (<= 8 floats per lane, coalesced 2 KB reads), one wave-level dot product per input row.
+// grid (ceil(O / 4), nz, ceil(B / 32)).  Summation order per output: lane-strided partial sums, then the wave butterfly.
+template <int KV>   // float per lane: ceil(K / 64)
+__global__ void __launch_bounds__(256)
+linear_gemv_kernel(LinPtrs q, int B, int K, int O, int act) {
+  extern __shared__ __attribute__((aligned(16))) float s_x[];   // [rows][K]
+  const int z = blockIdx.y, b0 = blockIdx.z * 32, nb = min(32, B - b0);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + wave;
+  const float* __restrict__ wrow = q.w[z] + (int64_t)min(o, O - 1) * K;
+  float w[KV];
+#pragma unroll
+  for (int i = 0; i < KV; ++i) w[i] = (lane + 64 * i < K) ? wrow[lane + 64 * i] : 0.f;
+  const float bias = q.bias[z] ? q.bias[z][min(o, O - 1)] : 0.f;
+  const float* __restrict__ src = q.x[z] + (int64_t)b0 * K;
+  for (int i = threadIdx.x; i < nb * K; i += 256) s_x[i] = src[i];
+  __syncthreads();
+  if (o >= O) return;
+  float* __restrict__ out = q.y[z];
+  for (int b = 0; b < nb; ++b) {
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < KV; ++i) part += (lane + 64 * i < K) ? s_x[b * K + lane + 64 * i] * w[i] : 0.f;
+    part = wave_sum(part);
+    if (lane == 0) out[(int64_t)(b0 + b) * O + o] = act_apply(part + bias, act);
+  }
+}
+
+static int gemv_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_LINEAR_GEMV"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w, const float* const* bias,
                            float* const* y, int batch, int in_features, int out_features, int act, float* workspace,
                            int64_t workspace_floats, void* stream) {
   if (nz < 1 || nz > kMaxZ || batch < 1 || in_features < 1 || out_features < 1 || !x || !w || !y) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
+  // latency regime: few rows and a reduction that fits a wave's registers; large batches amortise the GEMM's chunks
+  if (in_features <= 512 && batch <= 128 && (int64_t)batch * out_features <= 65536 && gemv_enabled()) {
+    LinPtrs q;
+    for (int z = 0; z < nz; ++z) {
+      if (!x[z] || !w[z] || !y[z]) return DRA_EINVAL;
+      q.x[z] = x[z]; q.w[z] = w[z]; q.bias[z] = bias ? bias[z] : nullptr; q.y[z] = y[z];
+    }
+    const dim3 grid((out_features + 3) / 4, nz, (batch + 31) / 32);
+    const size_t lds = (size_t)(batch < 32 ? batch : 32) * in_features * sizeof(float);
+    const int kv = (in_features + 63) / 64;
+    if (kv <= 1) hipLaunchKernelGGL(linear_gemv_kernel<1>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
+    else if (kv <= 2) hipLaunchKernelGGL(linear_gemv_kernel<2>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
+    else if (kv <= 4) hipLaunchKernelGGL(linear_gemv_kernel<4>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
+    else hipLaunchKernelGGL(linear_gemv_kernel<8>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
+    DRA_LAUNCH_CHECK();
+    return DRA_OK;
+  }
   LinFwd<32, 32, 64> p;
   p.M = out_features; p.N = batch; p.K = in_features;
   for (int z = 0; z < nz; ++z) {

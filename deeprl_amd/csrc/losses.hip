@@ -386,6 +386,85 @@ DRA_API int dra_a2c_loss(const float* log_pi_a, const float* entropy, const floa
 }
 
 // ------------------------------------------------------------------------------------------
+// K12: categorical policy head of the actor-critic nets (network_heads.py:240-255: Categorical(logits), sample,
+// log_prob, entropy) as ONE kernel per direction instead of ~16 / ~10 elementwise, reduction and indexing kernels --
+// at Atari action counts (4..18) each of those is a launch for a few hundred bytes, and a rollout forward is
+// latency-bound on exactly these launches (rocprofv3: 60 % of the kernels of an A2C step, profiles/r02z9_*).
+//   logp[a] = x[a] - m - log sum exp(x - m)          (logits normalised as torch.distributions.Categorical does)
+//   action  = given, or sampled by inverse CDF from the uniform u[b] (first a with cumsum(p)[a] > u; the last action
+//             absorbs rounding), log_pi_a = logp[action], entropy = -sum p logp
+//   backward: dlogits[a] = g_lp (1[a == action] - p[a]) - g_ent p[a] (logp[a] + entropy)
+// One thread per sample (A <= 64).
+__global__ void __launch_bounds__(256)
+categorical_fwd_kernel(const float* __restrict__ logits, int B, int A, const int64_t* __restrict__ action_in,
+                       const float* __restrict__ u, int64_t* __restrict__ action_out, float* __restrict__ log_pi_a,
+                       float* __restrict__ entropy) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* x = logits + (int64_t)b * A;
+  float m = x[0];
+  for (int a = 1; a < A; ++a) m = fmaxf(m, x[a]);
+  float se = 0.f;
+  for (int a = 0; a < A; ++a) se += expf(x[a] - m);
+  const float lse = m + logf(se);
+  int64_t act = action_in ? action_in[b] : (int64_t)(A - 1);
+  float ent = 0.f, cum = 0.f;
+  bool found = action_in != nullptr;
+  const float ub = u ? u[b] : 0.f;
+  for (int a = 0; a < A; ++a) {
+    const float lp = x[a] - lse, p = expf(lp);
+    ent -= p * lp;
+    cum += p;
+    if (!found && cum > ub) { act = a; found = true; }
+  }
+  if (act < 0) act = 0;
+  if (act >= A) act = A - 1;
+  if (action_out) action_out[b] = act;
+  log_pi_a[b] = x[act] - lse;
+  entropy[b] = ent;
+}
+
+__global__ void __launch_bounds__(256)
+categorical_bwd_kernel(const float* __restrict__ logits, int B, int A, const int64_t* __restrict__ action,
+                       const float* __restrict__ g_lp, const float* __restrict__ g_ent, float* __restrict__ dlogits) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* x = logits + (int64_t)b * A;
+  float m = x[0];
+  for (int a = 1; a < A; ++a) m = fmaxf(m, x[a]);
+  float se = 0.f;
+  for (int a = 0; a < A; ++a) se += expf(x[a] - m);
+  const float lse = m + logf(se);
+  float ent = 0.f;
+  for (int a = 0; a < A; ++a) { const float lp = x[a] - lse; ent -= expf(lp) * lp; }
+  const float gl = g_lp ? g_lp[b] : 0.f, ge = g_ent ? g_ent[b] : 0.f;
+  const int64_t act = action[b];
+  for (int a = 0; a < A; ++a) {
+    const float lp = x[a] - lse, p = expf(lp);
+    dlogits[(int64_t)b * A + a] = gl * ((a == act ? 1.f : 0.f) - p) - ge * p * (lp + ent);
+  }
+}
+
+DRA_API int dra_categorical_fwd(const float* logits, int batch, int n_actions, const int64_t* action_in, const float* uniform,
+                                int64_t* action_out, float* log_pi_a, float* entropy, void* stream) {
+  if (!logits || !log_pi_a || !entropy || batch < 1 || n_actions < 1 || n_actions > 64) return DRA_EINVAL;
+  if (!action_in && (!uniform || !action_out)) return DRA_EINVAL;
+  hipLaunchKernelGGL(categorical_fwd_kernel, dim3((batch + 255) / 256), dim3(256), 0, dra_stream(stream), logits, batch, n_actions,
+                     action_in, uniform, action_out, log_pi_a, entropy);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+DRA_API int dra_categorical_bwd(const float* logits, int batch, int n_actions, const int64_t* action, const float* g_log_pi_a,
+                                const float* g_entropy, float* out_dlogits, void* stream) {
+  if (!logits || !action || !out_dlogits || batch < 1 || n_actions < 1 || n_actions > 64) return DRA_EINVAL;
+  hipLaunchKernelGGL(categorical_bwd_kernel, dim3((batch + 255) / 256), dim3(256), 0, dra_stream(stream), logits, batch, n_actions,
+                     action, g_log_pi_a, g_entropy, out_dlogits);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // PER helpers for the distributional agents (DQN_agent.py:121-127 applied to a KL / QR vector):
 // priorities from a loss vector, importance weights from the sampling probabilities, and the
 // weighted mean used by reduce_loss.

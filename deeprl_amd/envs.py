@@ -75,6 +75,18 @@ def synthetic_reward_done(counter, seed, done_period):
     return (-1.0 if u == 0 else (1.0 if u == 9 else 0.0)), (h2 % done_period == 0)
 
 
+def synthetic_reward_done_vec(counters, seeds, done_periods):
+    """synthetic_reward_done for arrays (one environment per element): (rewards f64[N], dones bool[N])."""
+    with np.errstate(over="ignore"):
+        c = np.asarray(counters).astype(np.uint64)
+        sd = np.asarray(seeds).astype(np.uint64)
+        h = _mix64((sd + np.uint64(1)) * _GOLD + c)
+        h2 = _mix64((sd + np.uint64(2)) * _GOLD + c)
+    u = (h >> np.uint64(32)) % np.uint64(10)
+    reward = np.where(u == 0, -1.0, np.where(u == 9, 1.0, 0.0))
+    return reward, (h2 % np.asarray(done_periods).astype(np.uint64)) == 0
+
+
 class SyntheticAtari:
     """uint8 [history,84,84] observations as LazyFrames of (1,84,84) frames, `n_actions` discrete
     actions, reward in {-1,0,1}, episode ends w.p. 1/800 per step."""

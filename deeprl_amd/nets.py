@@ -57,6 +57,37 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _CategoricalFn(torch.autograd.Function):
+    """Categorical(logits) -> (log_pi_a, entropy) for given actions as one kernel each way (losses.hip K12)."""
+
+    @staticmethod
+    def forward(ctx, logits, action):
+        _, lp, ent = ops.categorical_fwd(logits, action=action)
+        ctx.save_for_backward(logits, action)
+        return lp, ent
+
+    @staticmethod
+    def backward(ctx, g_lp, g_ent):
+        logits, action = ctx.saved_tensors
+        return ops.categorical_bwd(logits, action, g_lp, g_ent), None
+
+
+def categorical_policy(logits, action=None, sampler=None):
+    """network_heads.py:249-254: (action, log_pi_a [B,1], entropy [B,1]) of Categorical(logits=logits).  action None: drawn
+    by `sampler(logits)` when given, else by inverse CDF from one torch.rand(B) on torch's global device generator."""
+    logits = logits.float().contiguous()
+    if action is None:
+        if sampler is not None:
+            action = sampler(logits)
+        else:
+            with torch.no_grad():
+                u = torch.rand(logits.shape[0], dtype=torch.float32, device=logits.device)
+                action, _, _ = ops.categorical_fwd(logits.detach(), uniform=u)
+    action = action.long().reshape(-1).contiguous()
+    lp, ent = _CategoricalFn.apply(logits, action)
+    return action, lp.unsqueeze(-1), ent.unsqueeze(-1)
+
+
 def linear(x, w, b, act=None):
     x = x.float() if x.dtype != torch.float32 else x
     lead = x.shape[:-1]
@@ -482,10 +513,15 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         phi_v = self.critic_body(phi)
         logits = self.fc_action(phi_a)
         v = self.fc_critic(phi_v)
+        # `sampler` (set by a data-parallel agent, dist.py): draws that do not depend on how the environments are spread
+        # over ranks; default = one uniform per sample from torch's global generator, inverse CDF inside the fused kernel
+        # (the reference's dist.sample() is torch.multinomial on ITS generator: the action stream of a GPU run is not the
+        # reference's CPU stream either way)
+        if logits.is_cuda and logits.shape[-1] <= 64:
+            action, log_prob, entropy = categorical_policy(logits, action, getattr(self, "sampler", None))
+            return {'action': action, 'log_pi_a': log_prob, 'entropy': entropy, 'v': v}
         dist = torch.distributions.Categorical(logits=logits)
         if action is None:
-            # `sampler` (set by a data-parallel agent, dist.py): draws that do not depend on how the environments are
-            # spread over ranks; default = the reference's dist.sample() on torch's global generator
             action = self.sampler(logits) if getattr(self, "sampler", None) is not None else dist.sample()
         log_prob = dist.log_prob(action).unsqueeze(-1)
         entropy = dist.entropy().unsqueeze(-1)

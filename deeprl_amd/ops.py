@@ -616,6 +616,30 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, partials, n_partials, max_no
                           ptr(hyper_dev), ptr(out_norm), stream_ptr())
 
 
+def categorical_fwd(logits, action=None, uniform=None):
+    """Categorical(logits): (action, log_pi_a [B], entropy [B]); action None -> sampled by inverse CDF from `uniform` [B]."""
+    logits = _c(logits, _f32)
+    b, a = logits.shape
+    lp = torch.empty(b, dtype=_f32, device=logits.device)
+    ent = torch.empty(b, dtype=_f32, device=logits.device)
+    if action is None:
+        out_a = torch.empty(b, dtype=torch.int64, device=logits.device)
+        lib.dra_categorical_fwd(ptr(logits), b, a, None, ptr(_c(uniform, _f32)), ptr(out_a), ptr(lp), ptr(ent), stream_ptr())
+        return out_a, lp, ent
+    action = _c(action, torch.int64)
+    lib.dra_categorical_fwd(ptr(logits), b, a, ptr(action), None, None, ptr(lp), ptr(ent), stream_ptr())
+    return action, lp, ent
+
+
+def categorical_bwd(logits, action, g_lp, g_ent):
+    logits = _c(logits, _f32)
+    b, a = logits.shape
+    out = torch.empty_like(logits)
+    lib.dra_categorical_bwd(ptr(logits), b, a, ptr(_c(action, torch.int64)), ptr(None if g_lp is None else _c(g_lp, _f32)),
+                            ptr(None if g_ent is None else _c(g_ent, _f32)), ptr(out), stream_ptr())
+    return out
+
+
 def adam_step_counter(param, grad, exp_avg, exp_avg_sq, partials, n_partials, max_norm, lr, beta1, beta2, eps, step_dev,
                       out_norm=None, param_copy=None):
     """Adam whose 1-based step count is the int64 device tensor `step_dev` (bumped by the caller's graph); optional

@@ -104,6 +104,12 @@ int dra_qr_loss(const float* theta, const float* theta_next_target, const void* 
 int dra_per_weights(const float* loss_vec, const float* sampling_prob, int batch, float beta, float replay_eps,
                     float replay_alpha, float* out_prio, float* out_weights, void* stream);
 int dra_weighted_mean(const float* x, const float* w, int n, float* out, void* stream);
+/* deep_rl/network/network_heads.py:240-255 (CategoricalActorCriticNet: Categorical(logits) -> sample / log_prob / entropy).
+ * action_in NULL: actions are sampled by inverse CDF from uniform[batch] into action_out.  n_actions <= 64. */
+int dra_categorical_fwd(const float* logits, int batch, int n_actions, const int64_t* action_in, const float* uniform,
+                        int64_t* action_out, float* log_pi_a, float* entropy, void* stream);
+int dra_categorical_bwd(const float* logits, int batch, int n_actions, const int64_t* action, const float* g_log_pi_a,
+                        const float* g_entropy, float* out_dlogits, void* stream);
 /* deep_rl/agent/PPO_agent.py:77-86: out3 = {policy_loss, value_loss, approx_kl}. */
 int dra_ppo_loss(const float* log_pi_a, const float* entropy, const float* v, const float* old_log_pi_a,
                  const float* adv, const float* ret, int m, float ratio_clip, float entropy_weight, float* out3,

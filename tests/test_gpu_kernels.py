@@ -774,3 +774,56 @@ def test_grad_sqnorm_segs_many_slabs(dev):
         off += cnt
     assert np.array_equal(got[off:], tail_np)
     np.testing.assert_allclose(partials[:n_part].sum().item(), (got.astype(np.float64) ** 2).sum(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("b,a", [(1, 2), (16, 4), (80, 18), (1024, 6), (300, 64)])
+def test_categorical_policy_kernels_vs_torch(dev, b, a):
+    """K12 (network_heads.py:249-254): log_prob / entropy of Categorical(logits) and their gradient w.r.t. the logits against
+    torch.distributions on the CPU in fp32 (absolute 2e-6 on values of magnitude <= log(A)); sampled actions are the inverse
+    CDF of the given uniforms."""
+    from deeprl_amd import nets, ops
+    rs = np.random.RandomState(b * 131 + a)
+    logits = (rs.standard_normal((b, a)) * 3).astype(np.float32)
+    action = rs.randint(0, a, size=b).astype(np.int64)
+    g_lp, g_ent = rs.standard_normal(b).astype(np.float32), rs.standard_normal(b).astype(np.float32)
+    x = torch.from_numpy(logits).requires_grad_(True)
+    dist = torch.distributions.Categorical(logits=x)
+    lp_ref, ent_ref = dist.log_prob(torch.from_numpy(action)), dist.entropy()
+    torch.autograd.backward([lp_ref, ent_ref], [torch.from_numpy(g_lp), torch.from_numpy(g_ent)])
+    xd = torch.from_numpy(logits).to(dev).requires_grad_(True)
+    act_out, lp, ent = nets.categorical_policy(xd, torch.from_numpy(action).to(dev))
+    torch.autograd.backward([lp, ent], [torch.from_numpy(g_lp).to(dev).unsqueeze(-1), torch.from_numpy(g_ent).to(dev).unsqueeze(-1)])
+    assert np.array_equal(act_out.cpu().numpy(), action)
+    np.testing.assert_allclose(lp.detach().cpu().numpy()[:, 0], lp_ref.detach().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(ent.detach().cpu().numpy()[:, 0], ent_ref.detach().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), x.grad.numpy(), rtol=1e-5, atol=2e-6)
+    # sampling: action = first index whose cumulative probability exceeds u
+    u = rs.rand(b).astype(np.float32)
+    got, lp_s, _ = ops.categorical_fwd(torch.from_numpy(logits).to(dev), uniform=torch.from_numpy(u).to(dev))
+    p = torch.softmax(torch.from_numpy(logits).double(), dim=-1).numpy()
+    cum = np.cumsum(p, axis=1)
+    got = got.cpu().numpy()
+    for i in range(b):
+        lo = cum[i, got[i] - 1] if got[i] > 0 else 0.0
+        assert lo - 1e-6 <= u[i] <= cum[i, got[i]] + 1e-6 or got[i] == a - 1, (i, got[i], u[i])
+    np.testing.assert_allclose(lp_s.cpu().numpy(), np.log(p[np.arange(b), got]), rtol=1e-5, atol=3e-6)
+
+
+@pytest.mark.parametrize("b,k,o,act", [(16, 512, 4, None), (16, 512, 1, None), (80, 512, 18, None), (1, 17, 64, "tanh"),
+                                      (64, 64, 64, "relu"), (33, 400, 300, "relu"), (128, 512, 204, None), (5, 3, 2, None)])
+def test_linear_small_layers_vs_torch(dev, b, k, o, act):
+    """The one-pass small-layer forward behind dra_linear_fwd (in_features <= 512, batch <= 128: heads and FCBody layers)
+    against F.linear in fp32 on the CPU: 1e-5 relative to the operand scale sum|x||w|."""
+    from deeprl_amd import ops
+    rs = np.random.RandomState(b + 7 * k + 13 * o)
+    x = rs.standard_normal((b, k)).astype(np.float32)
+    w = (rs.standard_normal((o, k)) / np.sqrt(k)).astype(np.float32)
+    bias = rs.standard_normal(o).astype(np.float32)
+    want = torch.nn.functional.linear(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(bias))
+    if act == "relu":
+        want = torch.relu(want)
+    elif act == "tanh":
+        want = torch.tanh(want)
+    got = ops.linear_fwd([torch.from_numpy(x).to(dev)], [torch.from_numpy(w).to(dev)], [torch.from_numpy(bias).to(dev)], act=act)[0]
+    scale = float((np.abs(x) @ np.abs(w).T).max())
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5 * scale + 1e-6)
