@@ -78,3 +78,8 @@ struct ActorFuse {
 int dra_conv1_fwd_actor_fused(const void* frames, const int64_t* slot_field_dev, const int32_t* stack_age_field_dev, const unsigned* seq_dev, int n_entries,
                               int64_t stride_bytes, int64_t capacity, const void* newest_frame, const float* wt,
                               const float* bias, float* y, double u8_coef, int act, const ActorFuse* f, void* stream);
+
+// conv_v2.hip (library-internal): batch-1 conv2 / conv3 with the reduction split over two workgroups per output tile;
+// the two partial planes y[2][OC][P] are summed (+ bias, ReLU) by the consumer's staging
+int dra_conv_b1_split(int layer, const float* x0, const float* x1, const float* xbias, const float* wt, float* y_planes,
+                      void* stream);

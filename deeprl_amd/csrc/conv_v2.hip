@@ -613,9 +613,161 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Ar
   DRA_STAMP_END(TRR);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batch-1 conv2 / conv3 of the device actor with the reduction split over KZO workgroups per output tile.
+// At batch 1 these layers are 6 resp. 4 workgroups of 8 waves whose latency IS the kernel's: 32 / 36 dependent 64-cycle
+// MFMAs per wave with two waves sharing each SIMD's pipe (phase traces, profiles/r02x_phase_async.json: 1.9 - 2.1 us of
+// MFMA per kernel, 4 x 2 kernels per agent step on the actor chain, which is as long as the update chain).  With the
+// channel pairs halved over two workgroups (on different CUs) each wave issues 16 / 18 MFMAs and stages half the image;
+// the halves are NOT reduced here: each workgroup stores its partial sums (no bias, no activation) to its own plane and
+// the CONSUMER adds the planes, the bias and the ReLU while it stages its input (KZI = 2) -- the next conv, or the fc4
+// GEMV.  Fixed order (plane 0 + plane 1) + bias: deterministic.  grid (position tiles, (OC / 32) * KZO), 512 threads.
+template <class G, int KZI, int KZO>
+__global__ void __launch_bounds__(512)
+conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ xbias,
+                     const float* __restrict__ wt, const float* __restrict__ bias, float* __restrict__ y, int act) {
+  using T = V2Tile<G, 1>;
+  constexpr int NW = 8;
+  constexpr int CPK = G::CP / KZO;            // channel pairs of this workgroup
+  constexpr int CPW = CPK / NW;               // ... of a wave
+  constexpr int NJ = CPW * G::KK;
+  constexpr int CL = G::C / KZO;              // channels staged by this workgroup
+  static_assert(CPK % NW == 0 && CL % NW == 0 && G::H <= 32, "channel split");
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [CL][NR][RW] image, then the 8-way reduction
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int kz = blockIdx.y / (G::OC / 32);
+  const int oc0 = (blockIdx.y - kz * (G::OC / 32)) * 32;
+  const int p0 = blockIdx.x * 32;
+  const int np = min(32, G::P - p0);
+  const int oh0 = p0 / G::OH, oh1 = (p0 + np - 1) / G::OH;
+  const int ir0 = oh0 * G::S;
+  const int nrows = (oh1 - oh0) * G::S + G::KH;
+  [[maybe_unused]] const int TRR = TR_A_CONV1 + (G::C == 32 ? 1 : 2);
+  DRA_STAMP(TRR, 0);
+  // weights of this wave's channel pairs, then the image rows: every load of the workgroup in flight at once
+  const int cp0 = kz * CPK + wave * CPW;
+  float areg[NJ];
+  {
+    const float* wbase = wt + ((int64_t)(2 * cp0 + h) * G::KK) * G::OC + oc0 + li;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int cpl = j / G::KK, t = j - cpl * G::KK;
+      areg[j] = wbase[(2 * cpl * G::KK + t) * G::OC];
+    }
+  }
+  constexpr int RPW = 16 / NW;
+  float bias_r[RPW];
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int r = wave * RPW + q;
+    bias_r[q] = (KZO == 1) ? bias[oc0 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+  }
+  constexpr int LR = G::H > 16 ? 32 : 16;
+  constexpr int RP = 64 / LR;
+  constexpr int LPT = (T::NR + RP - 1) / RP;
+  constexpr int CPT = CL / NW;
+  float raw0[CPT * LPT];
+  [[maybe_unused]] float raw1[CPT * LPT];
+  [[maybe_unused]] float xb[CPT];
+  const int rsub = lane / LR, iw = lane % LR;
+  const int iwc = min(iw, G::H - 1);
+  const int col = lds_col<G>(iwc);
+#pragma unroll
+  for (int ci = 0; ci < CPT; ++ci) {
+    const int c = kz * CL + wave + NW * ci;
+    const int64_t o = ((int64_t)c * G::H + ir0) * G::H + iwc;
+    if constexpr (KZI == 2) xb[ci] = xbias[c];
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) {
+      const int64_t oo = o + (int64_t)min(RP * q + rsub, nrows - 1) * G::H;
+      raw0[ci * LPT + q] = x0[oo];
+      if constexpr (KZI == 2) raw1[ci * LPT + q] = x1[oo];
+    }
+  }
+#pragma unroll
+  for (int ci = 0; ci < CPT; ++ci) {
+    float* dst = lds + (wave + NW * ci) * T::CS + rsub * G::RW + col;
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) {
+      float v = raw0[ci * LPT + q];
+      if constexpr (KZI == 2) {
+        v = (v + raw1[ci * LPT + q]) + xb[ci];
+        v = v > 0.f ? v : 0.f;
+      }
+      asm volatile("" : "+v"(v));
+      if (iw < G::H && RP * q + rsub < nrows) dst[RP * q * G::RW] = v;
+    }
+  }
+  DRA_STAMP(TRR, 1);
+  __syncthreads();
+  DRA_STAMP(TRR, 2);
+  const int pj = min(li, np - 1);
+  const int poh = (p0 + pj) / G::OH, pow_ = (p0 + pj) - poh * G::OH;
+  const float* bptr = lds + (2 * (wave * CPW) + h) * T::CS + ((poh - oh0) * G::S) * G::RW + pow_;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int cpl = j / G::KK, tp = j - cpl * G::KK;
+    const int kh = tp / G::KH, kw = tp - kh * G::KH;
+    const int off = 2 * cpl * T::CS + kh * G::RW + (kw % G::S) * G::WPH + kw / G::S;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[j], bptr[off], acc, 0, 0, 0);
+  }
+  DRA_STAMP(TRR, 3);
+  __syncthreads();
+  DRA_STAMP(TRR, 4);
+  float* red = lds;   // [8 waves][16][64]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  float* __restrict__ yo = y + (int64_t)kz * G::OC * G::P;
+#pragma unroll
+  for (int q = 0; q < RPW; ++q) {
+    const int r = wave * RPW + q;
+    float s = (red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) +
+              (red[(2 * 16 + r) * 64 + lane] + red[(3 * 16 + r) * 64 + lane]);
+    s += (red[(4 * 16 + r) * 64 + lane] + red[(5 * 16 + r) * 64 + lane]) +
+         (red[(6 * 16 + r) * 64 + lane] + red[(7 * 16 + r) * 64 + lane]);
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    const float v = (KZO == 1) ? v2_act(s + bias_r[q], act) : s;
+    if (li < np) yo[(int64_t)(oc0 + row) * G::P + p0 + li] = v;
+  }
+  DRA_STAMP(TRR, 5);
+  DRA_STAMP_END(TRR);
+}
+
 using VG1 = V2Geom<4, 84, 32, 8, 4>;
 using VG2 = V2Geom<32, 20, 64, 4, 2>;
 using VG3 = V2Geom<64, 9, 64, 3, 1>;
+
+template <class G, int KZI, int KZO>
+static int launch_conv_b1_split(const float* x0, const float* x1, const float* xbias, const float* wt, const float* bias,
+                                float* y, int act, hipStream_t st) {
+  using T = V2Tile<G, 1>;
+  constexpr size_t img = (size_t)(G::C / KZO) * T::CS * sizeof(float);
+  constexpr size_t red = (size_t)8 * 16 * 64 * sizeof(float);
+  constexpr size_t bytes = img > red ? img : red;
+  static_assert(bytes <= 64 * 1024, "LDS per workgroup");
+  hipLaunchKernelGGL((conv_b1_split_kernel<G, KZI, KZO>), dim3(G::TPS, (G::OC / 32) * KZO), dim3(512), bytes, st, x0, x1, xbias, wt,
+                     bias, y, act);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// Library-internal (actor_env.h): batch-1 conv2 (layer 2) / conv3 (layer 3) writing KZO = 2 partial planes
+// y[2][OC][P]; layer 3 reads conv2's two planes (x0, x1) + conv2's bias and applies the ReLU while staging.
+int dra_conv_b1_split(int layer, const float* x0, const float* x1, const float* xbias, const float* wt, float* y_planes,
+                      void* stream) {
+  if (!x0 || !wt || !y_planes) return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  if (layer == 2) return launch_conv_b1_split<VG2, 1, 2>(x0, nullptr, nullptr, wt, nullptr, y_planes, DRA_ACT_NONE, st);
+  if (layer == 3) {
+    if (!x1 || !xbias) return DRA_EINVAL;
+    return launch_conv_b1_split<VG3, 2, 2>(x0, x1, xbias, wt, nullptr, y_planes, DRA_ACT_NONE, st);
+  }
+  return DRA_EINVAL;
+}
 
 template <class G, bool U8, int PT, int NW = 4>
 static int launch_conv_v2_pt(const ConvV2Args& a, int nz, hipStream_t st) {

@@ -54,6 +54,7 @@ struct dra_dqn_learner {
   int last_gb;                      // buffer the most recently issued gather filled
   float *y1[3], *y2[3], *y3[3], *h4, *q[3];
   float *ay1, *ay2, *ay3, *aq;  // actor (batch 1)
+  float *ay2p, *ay3p;           // actor conv2 / conv3 as two partial planes each (dra_conv_b1_split)
   float *dq, *dh4, *dy3, *dy2, *dy1, *delta, *prio, *weights, *samp_prob;
   // distributional heads (c.head_kind != 0): h4 holds the features of every net ([3][B][512], z = 0 first), q[z] the
   // head outputs [B][n_out] (logits / quantiles), delta the per-sample loss vector (KL / quantile-Huber)
@@ -140,6 +141,8 @@ struct dra_dqn_learner {
   bool actor_pending;               // async mode: an actor graph has been issued and not yet consumed
   int step_per;                     // dra_dqn_learner_set_per: the in-order agent step applies PER importance weights
   float step_beta;
+  int64_t prev_slots[8];            // ring slots the most recently issued actor launch writes (-1 entries: unknown)
+  int prev_n_slots;
   hipEvent_t actor_last = nullptr;  // GATHER_ON_UPDATE: recorded after the most recent actor launch (a staging-slot event)
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
@@ -203,6 +206,7 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   if (!l) return DRA_ENOMEM;
   memset(l, 0, sizeof(*l));
   l->c = *cfg; l->ring = ring; l->p = params; l->pt = target; l->g = grad; l->s1 = state1; l->s2 = state2;
+  l->prev_n_slots = -1;
   if (cfg->head_kind == DRA_HEAD_QUANTILE) l->c.double_q = 0;   // QuantileRegressionDQN_agent.py:58-60: target network only
   const int B = cfg->batch, A = cfg->n_actions;
   const int nz = l->c.double_q ? 3 : 2;
@@ -237,6 +241,7 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   }
   rc |= alloc_f(&l->ay1, 32 * 400); rc |= alloc_f(&l->ay2, 64 * 81); rc |= alloc_f(&l->ay3, 64 * 49);
   rc |= alloc_f(&l->aq, A);
+  rc |= alloc_f(&l->ay2p, 2 * 64 * 81); rc |= alloc_f(&l->ay3p, 2 * 64 * 49);
   rc |= alloc_f(&l->dq, (int64_t)B * NO); rc |= alloc_f(&l->dh4, (int64_t)B * 512);
   rc |= alloc_f(&l->dy3, (int64_t)B * 64 * 49); rc |= alloc_f(&l->dy2, (int64_t)B * 64 * 81);
   rc |= alloc_f(&l->dy1, (int64_t)B * 32 * 400);
@@ -350,7 +355,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
                   l->ay3, l->aq, l->dq, l->dh4, l->dy3, l->dy2, l->dy1, l->delta, l->prio, l->weights, l->samp_prob,
                   l->slabs, l->fc4_slabs, l->afc4_slabs, l->lin_ws, l->partials, l->loss, l->norm, l->prm_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
-  void* hb[] = {l->atoms, l->qr_ws, l->alog, l->opt_step};
+  void* hb[] = {l->atoms, l->qr_ws, l->alog, l->opt_step, l->ay2p, l->ay3p};
   for (void* b : hb) if (b) (void)hipFree(b);
   for (int k = 0; k < 3; ++k) if (l->lslabs[k]) (void)hipFree(l->lslabs[k]);
   for (int z = 0; z < 3; ++z) {
@@ -1127,6 +1132,47 @@ actor_fc4_kernel(const float* __restrict__ x, const float* __restrict__ w, const
   DRA_STAMP_END(TR_A_FC4);
 }
 
+// actor_fc4_kernel whose input is conv3's two partial planes (dra_conv_b1_split): x = relu(x0 + x1 + b3[channel]), formed
+// while the operands are loaded (channel = element / 49)
+__global__ void __launch_bounds__(256)
+actor_fc4_planes_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ b3,
+                        const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ h4, int in_features) {
+  constexpr int R = 13;  // float4 per lane: 3136 / 4 / 64 = 12.25
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  const int nv = in_features >> 2;
+  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w + (int64_t)row * in_features);
+  const float4* __restrict__ a4 = reinterpret_cast<const float4*>(x0);
+  const float4* __restrict__ c4 = reinterpret_cast<const float4*>(x1);
+  DRA_STAMP(TR_A_FC4, 0);
+  float4 wv[R], av[R], cv[R], bv[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int i = min(lane + 64 * q, nv - 1);
+    wv[q] = w4[i];
+    av[q] = a4[i];
+    cv[q] = c4[i];
+    bv[q] = make_float4(b3[(4 * i) / 49], b3[(4 * i + 1) / 49], b3[(4 * i + 2) / 49], b3[(4 * i + 3) / 49]);
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    float4 a = wv[q];
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));  // loads stay unconditional and batched
+    float4 b;
+    b.x = fmaxf((av[q].x + cv[q].x) + bv[q].x, 0.f); b.y = fmaxf((av[q].y + cv[q].y) + bv[q].y, 0.f);
+    b.z = fmaxf((av[q].z + cv[q].z) + bv[q].z, 0.f); b.w = fmaxf((av[q].w + cv[q].w) + bv[q].w, 0.f);
+    if (lane + 64 * q < nv) acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const float v = acc + bias[row];
+    h4[row] = v > 0.f ? v : 0.f;
+  }
+  DRA_STAMP(TR_A_FC4, 5);
+  DRA_STAMP_END(TR_A_FC4);
+}
+
 __global__ void __launch_bounds__(1024)
 actor_head_env_kernel(const dra_dqn_step_params* __restrict__ prm, int e, const float* __restrict__ h4,
                       const float* __restrict__ wh, const float* __restrict__ bh, int A,
@@ -1466,6 +1512,12 @@ actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restric
 // step 0's launch commits the pending observation instead; the head of the LAST env step keeps its own kernel (it also
 // produces the next agent step's first observation and advances the step counter).  Same arithmetic, same order:
 // bit-identical action values, actions and ring contents.
+static int actor_ksplit() {   // DRA_ACTOR_KSPLIT=0: conv2 / conv3 of the ring actor as single-workgroup-per-tile launches
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_ACTOR_KSPLIT"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
   const dra_dqn_config& c = l->c;
   void *frames, *actions, *rewards, *masks;
@@ -1488,6 +1540,16 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
                                         e == 0 ? l->pend_frame : nullptr, P + o[P_W1], P + o[P_B1], l->ay1, c.u8_coef,
                                         DRA_ACT_RELU, &f, s)))
       return rc;
+    if (actor_ksplit()) {
+      // conv2 / conv3 with their reduction halved over two workgroups per output tile; the partial planes are summed (+ bias,
+      // ReLU) by the consumer's staging (conv_v2.hip conv_b1_split_kernel)
+      if ((rc = dra_conv_b1_split(2, l->ay1, nullptr, nullptr, P + o[P_W2], l->ay2p, s))) return rc;
+      if ((rc = dra_conv_b1_split(3, l->ay2p, l->ay2p + 64 * 81, P + o[P_B2], P + o[P_W3], l->ay3p, s))) return rc;
+      hipLaunchKernelGGL(actor_fc4_planes_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3p, (const float*)(l->ay3p + 64 * 49),
+                         P + o[P_B3], P + o[P_W4], P + o[P_B4], l->ah4, 3136);
+      DRA_LAUNCH_CHECK();
+      continue;
+    }
     const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
     float* y2[1] = {l->ay2};
     if ((rc = dra_conv_fwd_koc(2, 1, x2, w2, b2, y2, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
@@ -1807,14 +1869,14 @@ static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, in
 // ring slots, which minibatch t may still sample once the ring is full) is decided on the host, which knows both the
 // indices and the slots: in that (rare: ~1e-4 of the steps at 10^6 slots) case the actor graph also waits for this
 // step's update.  Results are bit-identical to step_pipelined.
-static bool gather_reads_slots(const dra_dqn_learner* l, const dra_dqn_step_params* prm) {
+static bool gather_reads_slots(const dra_dqn_learner* l, const int64_t* idx, const int64_t* slots, int n_slots) {
   int hh = 4, nn = 1;
   (void)dra_ring_shape(l->ring, &hh, &nn);
   const int64_t h = hh, n = nn;
-  for (int e = 0; e < prm->n_env; ++e) {
-    const int64_t s = prm->slot[e];
+  for (int e = 0; e < n_slots; ++e) {
+    const int64_t s = slots[e];
     for (int b = 0; b < l->c.batch; ++b)
-      if (s >= prm->idx[b] - h + 1 && s <= prm->idx[b] + n) return true;
+      if (s >= idx[b] - h + 1 && s <= idx[b] + n) return true;
   }
   return false;
 }
@@ -1825,7 +1887,17 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
   const int par = (int)(l->step_no & 1);
   int rc;
   hipEvent_t opt_prev = l->last_done;          // optimizer of step t-1: produced the copy the actor graph below reads
-  const bool hazard = do_update && prm->n_env > 0 && gather_reads_slots(l, prm);
+  // the block the actor graph issued by THIS call consumes: with the parameter ring that is the next un-issued ring entry
+  // (pushed up to 16 agent steps ahead; `prm` then only carries n_env and the minibatch indices)
+  const dra_dqn_step_params* ablk = prm;
+  if ((l->variant & DRA_VAR_ACTOR_RING) && prm->n_env > 0) {
+    if (!l->aring_stage || l->aring_issued >= l->aring_pushed) return DRA_EINVAL;
+    ablk = reinterpret_cast<const dra_dqn_step_params*>(l->aring_stage + (size_t)(l->aring_issued % kAringSlots) * kAprmStride);
+  }
+  const bool hazard = do_update && prm->n_env > 0 && gather_reads_slots(l, prm->idx, ablk->slot, prm->n_env);
+  // ... and the other direction: the gather needs the transitions the PREVIOUS call's actor graph is writing only if the
+  // minibatch touches those slots (same order of probability); otherwise the two chains do not meet in this step at all
+  const bool needs_actor = do_update && (l->prev_n_slots < 0 || gather_reads_slots(l, prm->idx, l->prev_slots, l->prev_n_slots));
   bool seed = false;
   if (prm->n_env > 0) {
     if (l->pa_valid && l->pa_cur != (par ^ 1)) l->pa_valid = false;   // copies out of phase with the step parity
@@ -1839,7 +1911,7 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
     l->pa_valid = true;
   }
   if (do_update) {
-    if (l->actor_last) DRA_HIP(hipStreamWaitEvent(su, l->actor_last, 0));   // transitions of step t are in the ring
+    if (l->actor_last && needs_actor) DRA_HIP(hipStreamWaitEvent(su, l->actor_last, 0));   // transitions of step t are in the ring
     if (seed) DRA_HIP(hipStreamWaitEvent(su, l->ev_join[0], 0));
     const int64_t* pinned = (l->variant & DRA_VAR_PINNED_IDX) ? l->idx_stage + (size_t)k * 1024 : nullptr;
     if (!pinned)
@@ -1868,7 +1940,11 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
     TRACE(2, sa);
   }
   DRA_HIP(hipEventRecord(l->stage_ev[k], sa));   // the ONE record of the actor stream: graph done, staging slot k free
-  if (prm->n_env > 0) l->actor_last = l->stage_ev[k];
+  if (prm->n_env > 0) {
+    l->actor_last = l->stage_ev[k];
+    l->prev_n_slots = prm->n_env;
+    for (int e = 0; e < prm->n_env; ++e) l->prev_slots[e] = ablk->slot[e];
+  }
   if (do_update) {
     if (l->tr_ev && l->tr_n < l->tr_cap) l->tr_n++;
     if (l->pa_valid) l->pa_cur = par;   // the graph's optimizer wrote copy `par`
@@ -2006,6 +2082,7 @@ DRA_API int dra_dqn_learner_act(dra_dqn_learner* l, const dra_dqn_step_params* p
   else rc = issue_actor(l, prm, k, l->p, st, use_graph != 0);
   DRA_HIP(hipEventRecord(l->stage_ev[k], st));
   l->actor_last = l->stage_ev[k];
+  l->prev_n_slots = -1;      // (the slots this launch writes are not tracked: the next update waits for it unconditionally)
   return rc;
 }
 

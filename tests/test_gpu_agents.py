@@ -401,8 +401,9 @@ def test_fused_step_async_pipeline(dra, variant):
             assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
 
 
-@pytest.mark.parametrize("variant,init", [(-1, "bench"), (-1, "normal"), (4607, "normal"), (12799, "normal"), (29183, "normal")])
-def test_async_pipeline_matches_schedule_oracle(dra, variant, init):
+@pytest.mark.parametrize("variant,init,cap", [(-1, "bench", 4000), (-1, "normal", 4000), (4607, "normal", 4000), (12799, "normal", 4000),
+                                              (29183, "normal", 4000), (-1, "normal", 160), (12799, "normal", 160)])
+def test_async_pipeline_matches_schedule_oracle(dra, variant, init, cap):
     """THE BENCHMARKED CONFIGURATION against the oracle: DQNLearnerBench(async_actor=True) with the default kernel
     variant (bench.py's: CU partition, pipelined gather, actor parameter ring, fused actor conv1) for 14 agent steps vs
     oracle/async_schedule_oracle.py, the CPU restatement of the pipeline's schedule (actor step t+1 on the parameters
@@ -424,7 +425,10 @@ def test_async_pipeline_matches_schedule_oracle(dra, variant, init):
     d = dra
     from deeprl_amd.learner import DQNLearnerBench
     from oracle.async_schedule_oracle import AsyncDqnScheduleOracle
-    cap, b, a, seed, steps = 4000, 32, 4, 3, 14
+    # cap = 160: nearly every minibatch touches the 4 slots the actor graph of the same call overwrites, and the 4 the previous
+    # one wrote -- the host-decided cross-stream waits of the gather-on-update pipeline (csrc/learner.hip step_pipelined3)
+    # are then what keeps the schedule
+    b, a, seed, steps = 32, 4, 3, 14
     d.random_seed(11)
     torch.manual_seed(5)
     bench = DQNLearnerBench(ring_capacity=cap, batch=b, seed=seed, actor=True, async_actor=True, variant=variant)
