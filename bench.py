@@ -196,6 +196,7 @@ def parity_check(bench, max_tries=4, gate_margin=5e-7):
     lr = bench.learner
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     out = None
+    lr.keep_minibatch(True)     # ring-direct update: also gather what it reads, for the oracle (the update keeps reading the ring)
     for attempt in range(1, max_tries + 1):
         snap = lr.export_state()          # parameters / target / RMSprop state before the step, module layout, CPU
         before, target, sq, ga = snap["params"], snap["target"], snap["square_avg"], snap["grad_avg"]
@@ -233,6 +234,7 @@ def parity_check(bench, max_tries=4, gate_margin=5e-7):
                        "the CPU oracle on the minibatch its gather produced; outside the timed region"}
         if ok or margin >= gate_margin:
             break
+    lr.keep_minibatch(False)
     return out
 
 

@@ -80,6 +80,15 @@ int dra_conv1_fwd_actor_fused(const void* frames, const int64_t* slot_field_dev,
                               const float* bias, float* y, double u8_coef, int act, const ActorFuse* f, void* stream);
 
 // conv_v2.hip (library-internal): batch-1 conv2 / conv3 with the reduction split over two workgroups per output tile;
-// the two partial planes y[2][OC][P] are summed (+ bias, ReLU) by the consumer's staging
-int dra_conv_b1_split(int layer, const float* x0, const float* x1, const float* xbias, const float* wt, float* y_planes,
+// the two partial planes y[2][OC][P] (plane 0 includes the bias) are summed and passed through the ReLU by the consumer
+int dra_conv_b1_split(int layer, const float* x0, const float* x1, const float* wt, const float* bias, float* y_planes,
                       void* stream);
+
+// conv_v2.hip / fused.hip (library-internal): conv1 of the update reading its uint8 minibatch straight from the replay ring
+// (sample b = the 4 frames ending at slot idx[b] + newest_off): forward for nz nets, and the weight gradient
+// (idx may be pinned host memory; idx_copy, optional: device copy of it written on the way, for the update's later kernels)
+int dra_conv1_fwd_koc_ringbatch(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* newest_off, int nz,
+                                const float* const* wt, const float* const* bias, float* const* y, int batch, double u8_coef, int act,
+                                void* stream);
+int dra_conv1_wgrad_ringbatch(const float* dy, const void* frames, const int64_t* idx, float* dw_slabs, float* db_slabs,
+                              int64_t slab_stride, int batch, double u8_coef, int variant, void* stream);

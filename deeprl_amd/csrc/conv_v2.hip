@@ -81,6 +81,15 @@ struct ConvV2Args {
   // optional: the NEWEST channel of the ring stack comes from this frame instead of ring slot *ring_slot (an
   // observation that has not been committed to the replay ring yet)
   const uint8_t* newest_frame;
+  // optional (uint8 BATCHED input, the update's conv1 straight from the replay ring): sample bi of net z is the C
+  // consecutive ring frames starting at slot sample_idx[bi] + idx_bias[z] of the slot-major frame array x[z] (a sample's
+  // frames never wrap: replay.py:105-110), instead of image bi * C of a plain NCHW batch -- no gathered copy of the
+  // minibatch is written or re-read
+  const int64_t* sample_idx = nullptr;
+  int64_t idx_bias[DRA_MAX_Z] = {};
+  // optional: sample_idx may live in pinned HOST memory (one PCIe read per workgroup, ~1 us inside the operand phase); the
+  // first workgroup of every sample leaves a copy here (device memory) for the later kernels of the same update
+  int64_t* sample_idx_copy = nullptr;
 };
 
 __device__ __forceinline__ float v2_act(float v, int act) {
@@ -250,6 +259,11 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
     for (int ci = 0; ci < CPT; ++ci) {
       const int c = wc + CW * ci;
       int64_t img = (int64_t)bi * G::C + min(c, G::C - 1);       // image index in a plain NCHW batch
+      if (a.sample_idx) {                                        // ... or a run of ring slots
+        const int64_t si = a.sample_idx[bi];
+        img = si + a.idx_bias[z] + min(c, G::C - 1);
+        if (a.sample_idx_copy && ci == 0 && tid == 0 && grp == 0 && z == 0 && blockIdx.y == 0) a.sample_idx_copy[bi] = si;
+      }
       const int off = min(G::C - 1 - min(c, G::C - 1), age);      // ring stack: frames back from the newest one
       if (a.ring_slot) {
         img = newest - off;
@@ -619,13 +633,14 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Ar
 // MFMAs per wave with two waves sharing each SIMD's pipe (phase traces, profiles/r02x_phase_async.json: 1.9 - 2.1 us of
 // MFMA per kernel, 4 x 2 kernels per agent step on the actor chain, which is as long as the update chain).  With the
 // channel pairs halved over two workgroups (on different CUs) each wave issues 16 / 18 MFMAs and stages half the image;
-// the halves are NOT reduced here: each workgroup stores its partial sums (no bias, no activation) to its own plane and
-// the CONSUMER adds the planes, the bias and the ReLU while it stages its input (KZI = 2) -- the next conv, or the fc4
-// GEMV.  Fixed order (plane 0 + plane 1) + bias: deterministic.  grid (position tiles, (OC / 32) * KZO), 512 threads.
+// the halves are NOT reduced here: each workgroup stores its partial sums to its own plane (plane 0 carries the bias, no
+// activation) and the CONSUMER adds the planes and applies the ReLU while it stages its input (KZI = 2) -- the next
+// conv, or the fc4 GEMV.  Fixed order (plane 0 + bias) + plane 1: deterministic.
+// grid (position tiles, (OC / 32) * KZO), 512 threads.
 template <class G, int KZI, int KZO>
 __global__ void __launch_bounds__(512)
-conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ xbias,
-                     const float* __restrict__ wt, const float* __restrict__ bias, float* __restrict__ y, int act) {
+conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ wt,
+                     const float* __restrict__ bias, float* __restrict__ y, int act) {
   using T = V2Tile<G, 1>;
   constexpr int NW = 8;
   constexpr int CPK = G::CP / KZO;            // channel pairs of this workgroup
@@ -660,7 +675,7 @@ conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
 #pragma unroll
   for (int q = 0; q < RPW; ++q) {
     const int r = wave * RPW + q;
-    bias_r[q] = (KZO == 1) ? bias[oc0 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
+    bias_r[q] = (kz == 0) ? bias[oc0 + (r & 3) + 8 * (r >> 2) + 4 * h] : 0.f;
   }
   constexpr int LR = G::H > 16 ? 32 : 16;
   constexpr int RP = 64 / LR;
@@ -668,7 +683,6 @@ conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
   constexpr int CPT = CL / NW;
   float raw0[CPT * LPT];
   [[maybe_unused]] float raw1[CPT * LPT];
-  [[maybe_unused]] float xb[CPT];
   const int rsub = lane / LR, iw = lane % LR;
   const int iwc = min(iw, G::H - 1);
   const int col = lds_col<G>(iwc);
@@ -676,7 +690,6 @@ conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
   for (int ci = 0; ci < CPT; ++ci) {
     const int c = kz * CL + wave + NW * ci;
     const int64_t o = ((int64_t)c * G::H + ir0) * G::H + iwc;
-    if constexpr (KZI == 2) xb[ci] = xbias[c];
 #pragma unroll
     for (int q = 0; q < LPT; ++q) {
       const int64_t oo = o + (int64_t)min(RP * q + rsub, nrows - 1) * G::H;
@@ -691,7 +704,7 @@ conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
     for (int q = 0; q < LPT; ++q) {
       float v = raw0[ci * LPT + q];
       if constexpr (KZI == 2) {
-        v = (v + raw1[ci * LPT + q]) + xb[ci];
+        v = v + raw1[ci * LPT + q];
         v = v > 0.f ? v : 0.f;
       }
       asm volatile("" : "+v"(v));
@@ -730,7 +743,7 @@ conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
     s += (red[(4 * 16 + r) * 64 + lane] + red[(5 * 16 + r) * 64 + lane]) +
          (red[(6 * 16 + r) * 64 + lane] + red[(7 * 16 + r) * 64 + lane]);
     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-    const float v = (KZO == 1) ? v2_act(s + bias_r[q], act) : s;
+    const float v = (KZO == 1) ? v2_act(s + bias_r[q], act) : s + bias_r[q];
     if (li < np) yo[(int64_t)(oc0 + row) * G::P + p0 + li] = v;
   }
   DRA_STAMP(TRR, 5);
@@ -742,29 +755,28 @@ using VG2 = V2Geom<32, 20, 64, 4, 2>;
 using VG3 = V2Geom<64, 9, 64, 3, 1>;
 
 template <class G, int KZI, int KZO>
-static int launch_conv_b1_split(const float* x0, const float* x1, const float* xbias, const float* wt, const float* bias,
-                                float* y, int act, hipStream_t st) {
+static int launch_conv_b1_split(const float* x0, const float* x1, const float* wt, const float* bias, float* y, int act,
+                                hipStream_t st) {
   using T = V2Tile<G, 1>;
   constexpr size_t img = (size_t)(G::C / KZO) * T::CS * sizeof(float);
   constexpr size_t red = (size_t)8 * 16 * 64 * sizeof(float);
   constexpr size_t bytes = img > red ? img : red;
   static_assert(bytes <= 64 * 1024, "LDS per workgroup");
-  hipLaunchKernelGGL((conv_b1_split_kernel<G, KZI, KZO>), dim3(G::TPS, (G::OC / 32) * KZO), dim3(512), bytes, st, x0, x1, xbias, wt,
-                     bias, y, act);
+  hipLaunchKernelGGL((conv_b1_split_kernel<G, KZI, KZO>), dim3(G::TPS, (G::OC / 32) * KZO), dim3(512), bytes, st, x0, x1, wt, bias, y, act);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
 
 // Library-internal (actor_env.h): batch-1 conv2 (layer 2) / conv3 (layer 3) writing KZO = 2 partial planes
-// y[2][OC][P]; layer 3 reads conv2's two planes (x0, x1) + conv2's bias and applies the ReLU while staging.
-int dra_conv_b1_split(int layer, const float* x0, const float* x1, const float* xbias, const float* wt, float* y_planes,
+// y[2][OC][P] (plane 0 includes the bias); layer 3 reads conv2's two planes (x0, x1) and applies the ReLU while staging.
+int dra_conv_b1_split(int layer, const float* x0, const float* x1, const float* wt, const float* bias, float* y_planes,
                       void* stream) {
-  if (!x0 || !wt || !y_planes) return DRA_EINVAL;
+  if (!x0 || !wt || !bias || !y_planes) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
-  if (layer == 2) return launch_conv_b1_split<VG2, 1, 2>(x0, nullptr, nullptr, wt, nullptr, y_planes, DRA_ACT_NONE, st);
+  if (layer == 2) return launch_conv_b1_split<VG2, 1, 2>(x0, nullptr, wt, bias, y_planes, DRA_ACT_NONE, st);
   if (layer == 3) {
-    if (!x1 || !xbias) return DRA_EINVAL;
-    return launch_conv_b1_split<VG3, 2, 2>(x0, x1, xbias, wt, nullptr, y_planes, DRA_ACT_NONE, st);
+    if (!x1) return DRA_EINVAL;
+    return launch_conv_b1_split<VG3, 2, 2>(x0, x1, wt, bias, y_planes, DRA_ACT_NONE, st);
   }
   return DRA_EINVAL;
 }
@@ -868,6 +880,25 @@ DRA_API int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const floa
     case 3: return x_is_u8 ? DRA_EINVAL : launch_conv_v2<VG3, false, 2>(a, nz, st);
   }
   return DRA_EINVAL;
+}
+
+// conv1 of the UPDATE straight from the replay ring (library-internal, actor_env.h): net z of sample b convolves the 4 ring
+// frames ending at slot idx[b] + newest_off[z] (online(states): 0, target / online(next_states): n_step).
+int dra_conv1_fwd_koc_ringbatch(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* newest_off, int nz,
+                                const float* const* wt, const float* const* bias, float* const* y, int batch, double u8_coef, int act,
+                                void* stream) {
+  if (!frames || !idx || !newest_off || nz < 1 || nz > DRA_MAX_Z || batch < 1 || !wt || !bias || !y) return DRA_EINVAL;
+  ConvV2Args a;
+  for (int z = 0; z < nz; ++z) {
+    if (!wt[z] || !bias[z] || !y[z]) return DRA_EINVAL;
+    a.x[z] = frames; a.wt[z] = wt[z]; a.bias[z] = bias[z]; a.y[z] = y[z];
+    a.idx_bias[z] = newest_off[z] - (VG1::C - 1);
+  }
+  a.sample_idx = idx;
+  a.sample_idx_copy = idx_copy;
+  a.batch = batch; a.act = act; a.coef = u8_coef; a.ring_slot = nullptr; a.ring_cap = 0; a.stack_age = nullptr;
+  a.slot_seq = nullptr; a.slot_entries = 0; a.slot_stride = 0; a.newest_frame = nullptr;
+  return launch_conv_v2_pt<VG1, true, 1>(a, nz, dra_stream(stream));
 }
 
 // conv1 of the actor's batch-1 forward reading its 4-frame stack straight from the replay ring

@@ -10,11 +10,13 @@
 //   DRA_VAR_ONESHOT_WGRAD  one-pass conv weight gradients (ConvWgradOne): one slab per (sample, row
 //                          chunk) -- dra_conv_wgrad_slabs() slabs instead of `ksplit`.
 #include "oneshot.h"
+#include "actor_env.h"
 #include <stdlib.h>
 
-static int g_tuning = 511 | 4096 | 8192 | 16384;  // every bit up to DRA_VAR_CU_PARTITION plus DRA_VAR_ACTOR_RING measured faster on MI355X
-                                   // (profiles/r01b_ab_variants.jsonl, r01d_*, r01f_*); ACTOR_V3 (512), ACTOR_FUSED_HEAD (1024)
-                                   // and GATHER_IN_GRAPH (2048) measured neutral or slower and stay opt-in
+static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768;
+// every bit up to DRA_VAR_CU_PARTITION plus ACTOR_RING, ACTOR_FUSED_CONV1, GATHER_ON_UPDATE and RING_DIRECT measured faster
+// on MI355X in same-box A/Bs (profiles/r01b_ab_variants.jsonl, r01d_*, r01f_*, r02y_ab_*, r02zf_ab_*); ACTOR_V3 (512),
+// ACTOR_FUSED_HEAD (1024) and GATHER_IN_GRAPH (2048) measured neutral or slower and stay opt-in
 
 DRA_API int dra_set_tuning(int mask) {
   if (mask < 0) return DRA_EINVAL;
@@ -157,6 +159,17 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
       return conv_bwd_fused_t<G3, WG3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
   }
   return DRA_EINVAL;
+}
+
+// conv1's weight gradient with the uint8 minibatch read straight from the replay ring (library-internal, actor_env.h):
+// sample b = the 4 frames ending at ring slot idx[b].  One-pass kernel only (the learner's variant).
+int dra_conv1_wgrad_ringbatch(const float* dy, const void* frames, const int64_t* idx, float* dw_slabs, float* db_slabs,
+                              int64_t slab_stride, int batch, double u8_coef, int variant, void* stream) {
+  if (!dy || !frames || !idx || !dw_slabs || !db_slabs || batch < 1 || !(variant & DRA_VAR_ONESHOT_WGRAD)) return DRA_EINVAL;
+  auto rw = make_wgrad_one<WG1u>(dy, frames, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
+  rw.sample_idx = idx;
+  NoRole none;
+  return launch_multi(rw, rw.blocks(), none, 0, none, 0, dra_stream(stream));
 }
 
 // Backward of head + fc4 in one launch (VanillaNet over NatureConvBody, hidden = 512):

@@ -141,6 +141,15 @@ struct dra_dqn_learner {
   bool actor_pending;               // async mode: an actor graph has been issued and not yet consumed
   int step_per;                     // dra_dqn_learner_set_per: the in-order agent step applies PER importance weights
   float step_beta;
+  // DRA_VAR_RING_DIRECT: minibatch indices in four fixed pinned buffers (captured graphs bake the address; the host may
+  // run up to four steps ahead), the graph / event of the same rotation, and the flag for an additional gather (checkers)
+  int64_t* idx_pin[4];
+  hipGraphExec_t g_rd[4];
+  bool g_rd_ready[4];
+  hipEvent_t ev_upd[4];
+  bool upd_used[4];
+  int rd_slot;                      // >= 0 while run_body is being captured / run for the ring-direct pipeline
+  int keep_minibatch;
   int64_t prev_slots[8];            // ring slots the most recently issued actor launch writes (-1 entries: unknown)
   int prev_n_slots;
   hipEvent_t actor_last = nullptr;  // GATHER_ON_UPDATE: recorded after the most recent actor launch (a staging-slot event)
@@ -207,6 +216,7 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   memset(l, 0, sizeof(*l));
   l->c = *cfg; l->ring = ring; l->p = params; l->pt = target; l->g = grad; l->s1 = state1; l->s2 = state2;
   l->prev_n_slots = -1;
+  l->rd_slot = -1;
   if (cfg->head_kind == DRA_HEAD_QUANTILE) l->c.double_q = 0;   // QuantileRegressionDQN_agent.py:58-60: target network only
   const int B = cfg->batch, A = cfg->n_actions;
   const int nz = l->c.double_q ? 3 : 2;
@@ -251,6 +261,12 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= alloc_f(&l->slabs, (int64_t)cfg->ksplit * l->slab_stride);
   if (cfg->variant >= 0) l->variant = cfg->variant;
   else rc |= dra_get_tuning(&l->variant);
+  // ring-direct needs the one-launch-per-layer backward (its conv1 weight gradient) and the host-decided cross-stream waits
+  // of the gather-on-update pipeline; the distributional heads take their transition scalars from the gathered minibatch
+  if ((l->variant & DRA_VAR_RING_DIRECT) &&
+      (cfg->head_kind != DRA_HEAD_VANILLA || !(l->variant & DRA_VAR_ONESHOT_WGRAD) || !(l->variant & DRA_VAR_GATHER_ON_UPDATE) ||
+       !(l->variant & DRA_VAR_PINNED_IDX)))
+    l->variant &= ~DRA_VAR_RING_DIRECT;
   if (cfg->head_kind != DRA_HEAD_VANILLA) {
     // the distributional heads exist in the second-generation actor (own head kernel per env step, in order or from the
     // parameter ring); the launches that fold the VanillaNet head into a neighbouring kernel do not apply
@@ -299,6 +315,10 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= (int)hipMalloc(&l->prm_dev, sizeof(dra_dqn_step_params));
   rc |= (int)hipHostMalloc(&l->prm_stage, 8 * sizeof(dra_dqn_step_params), hipHostMallocDefault);
   rc |= (int)hipHostMalloc(&l->idx_stage, (size_t)8 * 1024 * sizeof(int64_t), hipHostMallocDefault);
+  for (int k = 0; k < 4; ++k) {
+    rc |= (int)hipHostMalloc(&l->idx_pin[k], (size_t)1024 * sizeof(int64_t), hipHostMallocDefault);
+    rc |= (int)hipEventCreateWithFlags(&l->ev_upd[k], hipEventDisableTiming);
+  }
   rc |= (int)hipHostMalloc(&l->qs_stage, (size_t)4 * 7056, hipHostMallocDefault);
   rc |= (int)hipHostMalloc(&l->q_stage, 64 * sizeof(float), hipHostMallocDefault);
   if (rc) { delete l; return rc; }
@@ -366,6 +386,11 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   }
   (void)hipHostFree(l->prm_stage);
   (void)hipHostFree(l->idx_stage);
+  for (int k = 0; k < 4; ++k) {
+    if (l->idx_pin[k]) (void)hipHostFree(l->idx_pin[k]);
+    if (l->g_rd_ready[k]) (void)hipGraphExecDestroy(l->g_rd[k]);
+    (void)hipEventDestroy(l->ev_upd[k]);
+  }
   if (l->qs_stage) (void)hipHostFree(l->qs_stage);
   if (l->q_stage) (void)hipHostFree(l->q_stage);
   if (l->g_q_ready) (void)hipGraphExecDestroy(l->g_q);
@@ -400,6 +425,18 @@ DRA_API int dra_dqn_learner_buffers(dra_dqn_learner* l, void** idx, void** sampl
 // QuantileRegressionDQN_agent.py:17-20).  out[o] = bh[o] + <h4, Wh[o]> for the A*N head outputs, one wave per output
 // (a 2 KB weight row is one coalesced read per lane group; 4 outputs in flight per wave), kept in LDS; then one wave
 // per action:  categorical  q[a] = sum_n softmax(out[a])_n * atoms[n],   quantile  q[a] = mean_n out[a][n].
+// where head_fused_kernel finds the transition scalars when the update reads the replay ring directly (idx == null:
+// from the gathered minibatch)
+struct RingScalars {
+  const int64_t* idx;          // [B] sampled slots (device-visible)
+  const uint8_t* actions;      // ring arrays
+  const double* rewards;
+  const int32_t* masks;
+  int n_step;
+  double discount;
+  int64_t* out_action; float* out_reward; float* out_mask;   // the learner's minibatch scalar buffers, filled on the way
+};
+
 struct HeadSpec {
   int kind, n_atoms;
   const float* atoms;
@@ -503,7 +540,8 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
                   const float* __restrict__ bh_on, const float* __restrict__ bh_tg, const int64_t* __restrict__ action,
                   const float* __restrict__ reward, const float* __restrict__ mask, float gamma_n, int double_q,
                   float* __restrict__ h4_out, float* __restrict__ q_on, float* __restrict__ q_tg, float* __restrict__ q_on2,
-                  float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dh4, int64_t* __restrict__ opt_step) {
+                  float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dh4, int64_t* __restrict__ opt_step,
+                  const RingScalars rs) {
   __shared__ float s_h[3][512];
   __shared__ float s_q[3][64];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -523,8 +561,28 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
     for (int i = 0; i < 8; ++i) whr[u][i] = wh[lane + 64 * i];
     bhr[u] = ((z == 1) ? bh_tg : bh_on)[a];
   }
-  const int64_t ab = action[b];
-  const float rew_b = reward[b], mask_b = mask[b];
+  int64_t ab;
+  float rew_b, mask_b;
+  if (rs.idx) {
+    // DRA_VAR_RING_DIRECT: action / n-step reward / mask of the sampled transition straight from the replay ring, folded as
+    // ring_gather_kernel does (replay.py:133-139, fp64, the reference's association), then f32 as tensor() would
+    const int64_t i = rs.idx[b];
+    ab = *reinterpret_cast<const int64_t*>(rs.actions + i * 8);
+    double cum_r = 0.0;
+    int32_t cum_m = 1;
+    for (int k = rs.n_step - 1; k >= 0; --k) {
+      const int32_t m = rs.masks[i + k];
+      cum_r = __dadd_rn(rs.rewards[i + k], __dmul_rn(__dmul_rn((double)m, rs.discount), cum_r));
+      cum_m = cum_m ? m : cum_m;
+    }
+    rew_b = (float)cum_r;
+    mask_b = (float)cum_m;
+    if (tid == 0) { rs.out_action[b] = ab; rs.out_reward[b] = rew_b; rs.out_mask[b] = mask_b; }   // (checkers, PER loss kernel)
+  } else {
+    ab = action[b];
+    rew_b = reward[b];
+    mask_b = mask[b];
+  }
   float dwh[2];                                             // wh_on[ab][k] for this thread's two k (dL/dh4 below)
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) dwh[rep] = wh_on[(int)min(max(ab, (int64_t)0), (int64_t)(A - 1)) * 512 + tid + 256 * rep];
@@ -754,7 +812,26 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   const void* x1[3] = {l->state_[l->gb], l->next_state_[l->gb], l->next_state_[l->gb]};
   const float* w1[3] = {P + o[P_W1], T + o[P_W1], P + o[P_W1]};
   const float* b1[3] = {P + o[P_B1], T + o[P_B1], P + o[P_B1]};
-  STEP(K_CONV1_F, dra_conv_fwd_koc(1, nz, x1, w1, b1, l->y1, B, 1, c.u8_coef, DRA_ACT_RELU, s));
+  // DRA_VAR_RING_DIRECT (l->rd_slot >= 0): the uint8 frames come straight from the replay ring, sample b of net z = the 4
+  // slots ending at idx[b] (+ n_step for the next-state nets); no gathered copy exists
+  const bool rd = l->rd_slot >= 0;
+  void *ring_frames = nullptr, *ring_actions = nullptr, *ring_rewards = nullptr, *ring_masks = nullptr;
+  int ring_h = 4, ring_n = 1;
+  double ring_discount = 1.0;
+  if (rd) {
+    int rc0 = dra_ring_pointers(l->ring, &ring_frames, &ring_actions, &ring_rewards, &ring_masks);
+    if (!rc0) rc0 = dra_ring_shape(l->ring, &ring_h, &ring_n);
+    if (!rc0) rc0 = dra_ring_discount(l->ring, &ring_discount);
+    if (rc0) return rc0;
+    if (ring_h != 4) return DRA_EINVAL;
+    const int64_t off[3] = {0, ring_n, ring_n};
+    // (the indices sit in pinned host memory: conv1's workgroups pay the one PCIe read and leave a device copy in l->idx
+    // for the head and the weight-gradient kernels of this update)
+    STEP(K_CONV1_F, dra_conv1_fwd_koc_ringbatch(ring_frames, l->idx_pin[l->rd_slot], l->idx, off, nz, w1, b1, l->y1, B, c.u8_coef,
+                                                DRA_ACT_RELU, s));
+  } else {
+    STEP(K_CONV1_F, dra_conv_fwd_koc(1, nz, x1, w1, b1, l->y1, B, 1, c.u8_coef, DRA_ACT_RELU, s));
+  }
   const void* x2[3] = {l->y1[0], l->y1[1], l->y1[2]};
   const float* w2[3] = {P + o[P_W2], T + o[P_W2], P + o[P_W2]};
   const float* b2[3] = {P + o[P_B2], T + o[P_B2], P + o[P_B2]};
@@ -772,11 +849,18 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     int rc = run_dist_head(l, st, per, beta);
     if (rc) return rc;
   } else {
+    RingScalars rs;
+    memset(&rs, 0, sizeof(rs));
+    if (rd) {
+      rs.idx = l->idx; rs.actions = (const uint8_t*)ring_actions; rs.rewards = (const double*)ring_rewards;
+      rs.masks = (const int32_t*)ring_masks; rs.n_step = ring_n; rs.discount = ring_discount;
+      rs.out_action = l->action_[l->gb]; rs.out_reward = l->reward_[l->gb]; rs.out_mask = l->mask_[l->gb];
+    }
     hipLaunchKernelGGL(head_fused_kernel<kFc4Split>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                        P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
                        (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
                        c.double_q,
-                       l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step);
+                       l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs);
     DRA_LAUNCH_CHECK();
     if (per) {  // PER needs the batch-wide max of the importance weights: separate kernel recomputes dq, then dh4
       int rc = dra_td_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action_[l->gb], 1, l->reward_[l->gb],
@@ -811,8 +895,12 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV2_BW], st));
     STEP(K_CONV2_BX, dra_conv_bwd_fused(2, l->dy2, l->y1[0], P + o[P_W2], l->y1[0], dw[1], dbs[1], stride[1], c.ksplit,
                                         l->dy1, B, 0, 1.0, DRA_ACT_RELU, var, s));
-    STEP(K_CONV1_BW, dra_conv_bwd_fused(1, l->dy1, l->state_[l->gb], nullptr, nullptr, dw[0], dbs[0], stride[0], c.ksplit, nullptr,
-                                        B, 1, c.u8_coef, DRA_ACT_RELU, var, s));
+    if (rd) {
+      STEP(K_CONV1_BW, dra_conv1_wgrad_ringbatch(l->dy1, ring_frames, l->idx, dw[0], dbs[0], stride[0], B, c.u8_coef, var, s));
+    } else {
+      STEP(K_CONV1_BW, dra_conv_bwd_fused(1, l->dy1, l->state_[l->gb], nullptr, nullptr, dw[0], dbs[0], stride[0], c.ksplit, nullptr,
+                                          B, 1, c.u8_coef, DRA_ACT_RELU, var, s));
+    }
     if (own) {
       dra_fold_seg segs[3];
       for (int k = 0; k < 3; ++k) {
@@ -910,6 +998,39 @@ static int pipe_graph(dra_dqn_learner* l, hipStream_t st, int par) {
     l->g_pipe_ready[par] = true;
   }
   DRA_HIP(hipGraphLaunch(l->g_pipe[par], st));
+  return DRA_OK;
+}
+
+// DRA_VAR_RING_DIRECT: update body + optimizer for rotation slot q (index buffer idx_pin[q], minibatch scalar buffers and
+// actor parameter copy of parity q & 1) as one graph.
+static int rd_graph(dra_dqn_learner* l, hipStream_t st, int q) {
+  if (!l->g_rd_ready[q]) {
+    hipGraph_t graph;
+    l->gb = q & 1;
+    l->rd_slot = q;
+    hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (b != hipSuccess) { l->gb = 0; l->rd_slot = -1; return (int)b; }
+    int rc = run_body(l, st, 0, 0.f, 0);
+    if (rc == DRA_OK) rc = launch_optimizer(l, st, l->pa[q & 1]);
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    l->gb = 0;
+    l->rd_slot = -1;
+    if (rc != DRA_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    DRA_HIP(hipGraphInstantiate(&l->g_rd[q], graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    l->g_rd_ready[q] = true;
+  }
+  DRA_HIP(hipGraphLaunch(l->g_rd[q], st));
+  return DRA_OK;
+}
+
+// Checkers (bench.py's parity check, tests): with DRA_VAR_RING_DIRECT no gathered minibatch exists; keep != 0 makes the
+// pipelined step ALSO run the gather into the learner's minibatch buffers (dra_dqn_learner_last_minibatch) -- the update
+// itself still reads the ring.
+DRA_API int dra_dqn_learner_keep_minibatch(dra_dqn_learner* l, int keep) {
+  if (!l) return DRA_EINVAL;
+  l->keep_minibatch = keep != 0;
   return DRA_OK;
 }
 
@@ -1132,11 +1253,10 @@ actor_fc4_kernel(const float* __restrict__ x, const float* __restrict__ w, const
   DRA_STAMP_END(TR_A_FC4);
 }
 
-// actor_fc4_kernel whose input is conv3's two partial planes (dra_conv_b1_split): x = relu(x0 + x1 + b3[channel]), formed
-// while the operands are loaded (channel = element / 49)
+// actor_fc4_kernel whose input is conv3's two partial planes (dra_conv_b1_split; plane 0 carries the bias): x = relu(x0 + x1),
+// formed while the operands are loaded
 __global__ void __launch_bounds__(256)
-actor_fc4_planes_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ b3,
-                        const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ h4, int in_features) {
+actor_fc4_planes_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ h4, int in_features) {
   constexpr int R = 13;  // float4 per lane: 3136 / 4 / 64 = 12.25
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wave;
@@ -1145,14 +1265,13 @@ actor_fc4_planes_kernel(const float* __restrict__ x0, const float* __restrict__ 
   const float4* __restrict__ a4 = reinterpret_cast<const float4*>(x0);
   const float4* __restrict__ c4 = reinterpret_cast<const float4*>(x1);
   DRA_STAMP(TR_A_FC4, 0);
-  float4 wv[R], av[R], cv[R], bv[R];
+  float4 wv[R], av[R], cv[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) {
     const int i = min(lane + 64 * q, nv - 1);
     wv[q] = w4[i];
     av[q] = a4[i];
     cv[q] = c4[i];
-    bv[q] = make_float4(b3[(4 * i) / 49], b3[(4 * i + 1) / 49], b3[(4 * i + 2) / 49], b3[(4 * i + 3) / 49]);
   }
   float acc = 0.f;
 #pragma unroll
@@ -1160,8 +1279,8 @@ actor_fc4_planes_kernel(const float* __restrict__ x0, const float* __restrict__ 
     float4 a = wv[q];
     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));  // loads stay unconditional and batched
     float4 b;
-    b.x = fmaxf((av[q].x + cv[q].x) + bv[q].x, 0.f); b.y = fmaxf((av[q].y + cv[q].y) + bv[q].y, 0.f);
-    b.z = fmaxf((av[q].z + cv[q].z) + bv[q].z, 0.f); b.w = fmaxf((av[q].w + cv[q].w) + bv[q].w, 0.f);
+    b.x = fmaxf(av[q].x + cv[q].x, 0.f); b.y = fmaxf(av[q].y + cv[q].y, 0.f);
+    b.z = fmaxf(av[q].z + cv[q].z, 0.f); b.w = fmaxf(av[q].w + cv[q].w, 0.f);
     if (lane + 64 * q < nv) acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
   }
   acc = wave_sum(acc);
@@ -1543,10 +1662,10 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
     if (actor_ksplit()) {
       // conv2 / conv3 with their reduction halved over two workgroups per output tile; the partial planes are summed (+ bias,
       // ReLU) by the consumer's staging (conv_v2.hip conv_b1_split_kernel)
-      if ((rc = dra_conv_b1_split(2, l->ay1, nullptr, nullptr, P + o[P_W2], l->ay2p, s))) return rc;
-      if ((rc = dra_conv_b1_split(3, l->ay2p, l->ay2p + 64 * 81, P + o[P_B2], P + o[P_W3], l->ay3p, s))) return rc;
+      if ((rc = dra_conv_b1_split(2, l->ay1, nullptr, P + o[P_W2], P + o[P_B2], l->ay2p, s))) return rc;
+      if ((rc = dra_conv_b1_split(3, l->ay2p, l->ay2p + 64 * 81, P + o[P_W3], P + o[P_B3], l->ay3p, s))) return rc;
       hipLaunchKernelGGL(actor_fc4_planes_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3p, (const float*)(l->ay3p + 64 * 49),
-                         P + o[P_B3], P + o[P_W4], P + o[P_B4], l->ah4, 3136);
+                         P + o[P_W4], P + o[P_B4], l->ah4, 3136);
       DRA_LAUNCH_CHECK();
       continue;
     }
@@ -1913,21 +2032,49 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
   if (do_update) {
     if (l->actor_last && needs_actor) DRA_HIP(hipStreamWaitEvent(su, l->actor_last, 0));   // transitions of step t are in the ring
     if (seed) DRA_HIP(hipStreamWaitEvent(su, l->ev_join[0], 0));
-    const int64_t* pinned = (l->variant & DRA_VAR_PINNED_IDX) ? l->idx_stage + (size_t)k * 1024 : nullptr;
-    if (!pinned)
-      DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
-    TRACE(0, su);
-    l->gb = par;
-    rc = launch_gather(l, su, pinned);
-    l->gb = 0;
-    if (rc) return rc;
-    TRACE(1, su);
-    TRACE(3, su);
-    if ((rc = pipe_graph(l, su, par))) return rc;
-    TRACE(4, su);
-    DRA_HIP(hipEventRecord(l->ev_mb_free[par], su));   // the ONE record of the update stream: optimizer t done
-    l->last_done = l->ev_mb_free[par];
-    l->mb_used[par] = true;
+    if (l->variant & DRA_VAR_RING_DIRECT) {
+      // no gather: the update's own kernels read the ring through idx_pin[q] (four rotating pinned buffers: a captured graph
+      // bakes the address; buffer q is free again once update t-4 is done)
+      const int q = (int)(l->step_no & 3);
+      if (l->upd_used[q]) {
+        const auto t0 = std::chrono::steady_clock::now();
+        DRA_HIP(hipEventSynchronize(l->ev_upd[q]));
+        l->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      }
+      memcpy(l->idx_pin[q], prm->idx, (size_t)B * sizeof(int64_t));
+      TRACE(0, su);
+      if (l->keep_minibatch) {
+        l->gb = par;
+        rc = launch_gather(l, su, l->idx_pin[q]);
+        l->gb = 0;
+        if (rc) return rc;
+      } else {
+        l->last_gb = par;
+      }
+      TRACE(1, su);
+      TRACE(3, su);
+      if ((rc = rd_graph(l, su, q))) return rc;
+      TRACE(4, su);
+      DRA_HIP(hipEventRecord(l->ev_upd[q], su));         // the ONE record of the update stream: optimizer t done
+      l->last_done = l->ev_upd[q];
+      l->upd_used[q] = true;
+    } else {
+      const int64_t* pinned = (l->variant & DRA_VAR_PINNED_IDX) ? l->idx_stage + (size_t)k * 1024 : nullptr;
+      if (!pinned)
+        DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, su));
+      TRACE(0, su);
+      l->gb = par;
+      rc = launch_gather(l, su, pinned);
+      l->gb = 0;
+      if (rc) return rc;
+      TRACE(1, su);
+      TRACE(3, su);
+      if ((rc = pipe_graph(l, su, par))) return rc;
+      TRACE(4, su);
+      DRA_HIP(hipEventRecord(l->ev_mb_free[par], su));   // the ONE record of the update stream: optimizer t done
+      l->last_done = l->ev_mb_free[par];
+      l->mb_used[par] = true;
+    }
   }
   if (prm->n_env > 0) {
     if (!seed && opt_prev) DRA_HIP(hipStreamWaitEvent(sa, opt_prev, 0));

@@ -480,6 +480,9 @@ struct ConvWgradOne {
   int64_t slab_stride;
   int B;
   double coef;
+  // optional (U8): sample bi is the C consecutive ring frames ending at slot sample_idx[bi] of the slot-major frame array x
+  // (conv1's weight gradient straight from the replay ring); null = image bi of a plain [B][C][H][H] batch
+  const int64_t* sample_idx = nullptr;
   __host__ int blocks() const { return B * NCHUNK * NGRP; }
   __host__ static int n_slabs(int batch) { return batch * NCHUNK; }
   __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
@@ -521,7 +524,8 @@ struct ConvWgradOne {
       constexpr int WPR = G::H / 4;                         // u32 words per 84-byte row
       constexpr int NW = NCH * NR * WPR, RI = (NW + 255) / 256;
       unsigned iraw[RI];
-      const uint8_t* xb = reinterpret_cast<const uint8_t*>(x) + ((int64_t)bi * G::C + c_lo) * G::HW;
+      const int64_t first = sample_idx ? sample_idx[bi] - (G::C - 1) : (int64_t)bi * G::C;   // first frame of the sample
+      const uint8_t* xb = reinterpret_cast<const uint8_t*>(x) + (first + c_lo) * G::HW;
 #pragma unroll
       for (int q = 0; q < RI; ++q) {
         const int e = min(tid + 256 * q, NW - 1);

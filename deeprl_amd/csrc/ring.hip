@@ -77,6 +77,12 @@ DRA_API int dra_ring_shape(dra_ring* r, int* history, int* n_step) {
   return DRA_OK;
 }
 
+DRA_API int dra_ring_discount(dra_ring* r, double* discount) {
+  if (!r || !discount) return DRA_EINVAL;
+  *discount = r->discount;
+  return DRA_OK;
+}
+
 DRA_API int dra_ring_pointers(dra_ring* r, void** frames, void** actions, void** rewards, void** masks) {
   if (!r) return DRA_EINVAL;
   if (frames) *frames = r->frames;

@@ -268,6 +268,11 @@ class DQNLearner:
         new priorities in self.prio."""
         lib.dra_dqn_learner_set_per(self.h, int(bool(per)), float(beta))
 
+    def keep_minibatch(self, keep):
+        """Checkers: with the ring-direct update (VAR_RING_DIRECT) no gathered minibatch exists; keep=True makes the pipelined
+        step also gather it into the buffers last_minibatch() returns."""
+        lib.dra_dqn_learner_keep_minibatch(self.h, int(bool(keep)))
+
     def sync_target(self):
         lib.dra_dqn_learner_sync_target(self.h, self._sp())
 

@@ -123,6 +123,10 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+import os as _os
+_ONESHOT_WGRAD_MAX_BATCH = int(_os.environ.get("DRA_ONESHOT_WGRAD_MAX_BATCH", "64"))
+
+
 class _ConvKocFn(torch.autograd.Function):
     """Same layer on the one-round-trip kernels (conv_v2.hip forward, oneshot.h backward: weight gradient and
     input gradient in ONE launch).  Used when the weight Parameter is a [OC,C,KH,KW] view of [(c,kh,kw)][oc]
@@ -145,7 +149,7 @@ class _ConvKocFn(torch.autograd.Function):
         oc, c, kh, kw = w.shape
         n_w = w.numel()
         # per-(sample, row chunk) slabs pay off at DQN batch sizes; large batches use the fixed split-K weight gradient
-        variant = (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD | ops.VAR_ONESHOT_WGRAD) if x.shape[0] <= 64 else \
+        variant = (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD | ops.VAR_ONESHOT_WGRAD) if x.shape[0] <= _ONESHOT_WGRAD_MAX_BATCH else \
             (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD)
         dx, slabs, n_slabs, stride = ops.conv_bwd_fused_koc(layer, dpre, x, w.permute(1, 2, 3, 0), ksplit=_ConvKocFn.KSPLIT,
                                                             u8_coef=ctx.u8_coef, variant=variant)

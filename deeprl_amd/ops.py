@@ -407,7 +407,8 @@ VAR_GATHER_IN_GRAPH = 2048
 VAR_ACTOR_RING = 4096
 VAR_ACTOR_FUSED_CONV1 = 8192
 VAR_GATHER_ON_UPDATE = 16384
-VAR_ALL = 32767
+VAR_RING_DIRECT = 32768
+VAR_ALL = 65535
 
 
 def set_tuning(mask):

@@ -33,6 +33,7 @@ typedef struct dra_ring dra_ring;
 int dra_ring_create(dra_ring** out, int64_t capacity, int64_t frame_bytes, int64_t action_bytes, int history,
                     int n_step, double discount);
 int dra_ring_shape(dra_ring* ring, int* history, int* n_step);   /* the history_length / n_step it was created with */
+int dra_ring_discount(dra_ring* ring, double* discount);           /* ... and the discount of its n-step fold */
 int dra_ring_destroy(dra_ring* ring);
 int dra_ring_pointers(dra_ring* ring, void** frames, void** actions, void** rewards, void** masks);
 /* replay.py:75-90 (feed): write `count` consecutive slots from DEVICE-ACCESSIBLE sources (device or pinned host).
@@ -185,6 +186,10 @@ int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* 
 #define DRA_VAR_GATHER_ON_UPDATE 16384 /* learner, async pipelined: the gather runs on the UPDATE stream (the actor chain is the
                                        * longer one); the rare step whose minibatch touches the ring slots the next actor
                                        * graph overwrites makes that graph wait for the update (decided on the host) */
+#define DRA_VAR_RING_DIRECT 32768  /* learner, async pipelined (with GATHER_ON_UPDATE's host-decided waits): NO gather -- conv1
+                                    * (forward of every net, weight gradient) reads the uint8 frames of the sampled
+                                    * transitions straight from the replay ring and the head kernel their action / n-step
+                                    * reward / mask: one launch, 1.8 MB of writes and 1.8 MB of re-reads less per update */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
@@ -304,6 +309,9 @@ int dra_dqn_learner_update(dra_dqn_learner* learner, int use_graph, int per, flo
 /* PER for the in-order dra_dqn_learner_step (stream_actor == NULL): importance weights from the learner's sampling_prob
  * buffer with exponent beta, new priorities into its prio buffer (DQN_agent.py:120-127) */
 int dra_dqn_learner_set_per(dra_dqn_learner* learner, int per, float beta);
+/* DRA_VAR_RING_DIRECT: also gather the minibatch into the learner's buffers (dra_dqn_learner_last_minibatch) -- for
+ * checkers; the update itself keeps reading the ring */
+int dra_dqn_learner_keep_minibatch(dra_dqn_learner* learner, int keep);
 int dra_dqn_learner_profile(dra_dqn_learner* learner, float* out_ms, int n_out, void* stream);
 /* the minibatch the most recently issued update consumed (device pointers into the learner's buffers: u8 states /
  * next states [B][4][84][84], int64 actions [B], f32 rewards / masks [B]); for checkers, after a synchronise */

@@ -356,7 +356,7 @@ def test_fused_step_sync_equals_act_then_update(dra, variant):
 _ASYNC_RESULTS = {}
 
 
-@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559, 4607, 12799, 29183])
+@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559, 4607, 12799, 29183, 61951])
 def test_fused_step_async_pipeline(dra, variant):
     """async_actor=True pipeline (actor one agent step ahead on its own stream, double-buffered actor
     parameters when variant has DRA_VAR_ACTOR_PARAMS): the transitions it feeds are the documented counter-hash
@@ -395,14 +395,16 @@ def test_fused_step_async_pipeline(dra, variant):
     # ... and so do the 4-kernel actor step (DRA_VAR_ACTOR_V3: same arithmetic, fused launches) and the CU partition
     # ... and the gather on the update stream (DRA_VAR_GATHER_ON_UPDATE = 16384; ring capacity 4000 with 32 samples per
     # step: the host-decided 'minibatch touches the slots the next actor graph overwrites' wait fires here)
-    for other in (255, 1023, 2047, 2559, 4607, 12799, 29183):
+    # ... and the ring-direct update (DRA_VAR_RING_DIRECT = 32768: conv1 and the head read the replay ring, no gather)
+    for other in (255, 1023, 2047, 2559, 4607, 12799, 29183, 61951):
         if 127 in _ASYNC_RESULTS and other in _ASYNC_RESULTS:
             assert np.array_equal(_ASYNC_RESULTS[127][0], _ASYNC_RESULTS[other][0])
             assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
 
 
 @pytest.mark.parametrize("variant,init,cap", [(-1, "bench", 4000), (-1, "normal", 4000), (4607, "normal", 4000), (12799, "normal", 4000),
-                                              (29183, "normal", 4000), (-1, "normal", 160), (12799, "normal", 160)])
+                                              (29183, "normal", 4000), (-1, "normal", 160), (12799, "normal", 160),
+                                              (61951, "normal", 4000), (61951, "normal", 160), (61951, "bench", 4000)])
 def test_async_pipeline_matches_schedule_oracle(dra, variant, init, cap):
     """THE BENCHMARKED CONFIGURATION against the oracle: DQNLearnerBench(async_actor=True) with the default kernel
     variant (bench.py's: CU partition, pipelined gather, actor parameter ring, fused actor conv1) for 14 agent steps vs
