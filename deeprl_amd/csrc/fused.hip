@@ -205,17 +205,25 @@ DRA_API int dra_fc_bwd_fused(const float* dq, const float* h4, const float* dh4,
 DRA_API int dra_linear_fwd_slabs_one(int nz, const float* const* x, const float* const* w, int batch, int in_features,
                                      int out_features, int ksplit, float* slabs, void* stream) {
   if (nz < 1 || nz > kMaxZ || batch < 1 || !x || !w || !slabs) return DRA_EINVAL;
-  if (in_features != 3136 || ksplit != 8 || out_features < 1) return DRA_EINVAL;
-  constexpr int NT = 2;
-  LinFwdSlabsOne<3136, 8, NT> r;
+  if (in_features != 3136 || (ksplit != 8 && ksplit != 28) || out_features < 1) return DRA_EINVAL;
   for (int z = 0; z < nz; ++z) {
     if (!x[z] || !w[z]) return DRA_EINVAL;
     if ((((uintptr_t)x[z]) | ((uintptr_t)w[z])) & 15) return DRA_EINVAL;
-    r.x[z] = x[z]; r.w[z] = w[z];
   }
-  r.slabs = slabs; r.B = batch; r.O = out_features;
-  r.tiles_n = (out_features + 32 * NT - 1) / (32 * NT); r.tiles_m = (batch + 31) / 32;
+  constexpr int NT = 2;
   NoRole none;
+  auto fill = [&](auto& r) {
+    for (int z = 0; z < nz; ++z) { r.x[z] = x[z]; r.w[z] = w[z]; }
+    r.slabs = slabs; r.B = batch; r.O = out_features;
+    r.tiles_n = (out_features + 32 * NT - 1) / (32 * NT); r.tiles_m = (batch + 31) / 32;
+  };
+  if (ksplit == 28) {   // 112-wide K slices: 3.5x the workgroups (448 at batch 32, two nets), 43 KB of LDS each
+    LinFwdSlabsOne<3136, 28, NT> r;
+    fill(r);
+    return launch_multi(r, r.tiles_n * r.tiles_m * 28 * nz, none, 0, none, 0, dra_stream(stream));
+  }
+  LinFwdSlabsOne<3136, 8, NT> r;
+  fill(r);
   return launch_multi(r, r.tiles_n * r.tiles_m * 8 * nz, none, 0, none, 0, dra_stream(stream));
 }
 

@@ -38,6 +38,9 @@ static const char* kKernelNames[K_COUNT] = {
 enum { P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WH, P_BH, P_COUNT };
 
 constexpr int kFc4Split = 8;     // split-K of the 3136 -> 512 layer (slabs reduced inside head_fused_kernel)
+constexpr int kFc4SplitWide = 28; // ... of the one-pass forward when DRA_FC4_KS=28: 448 workgroups of 112-wide K slices
+                                  // instead of 128 of 392 (the layer streams 12.8 MB of weights: more CUs pulling)
+static int fc4_ks(const struct dra_dqn_learner* l);
 constexpr int kAprmSlots = 16;
 
 struct dra_dqn_learner {
@@ -159,6 +162,12 @@ struct dra_dqn_learner {
 
 struct HeadSpec;
 static HeadSpec head_spec(const dra_dqn_learner* l);
+
+static int fc4_ks(const dra_dqn_learner* l) {   // K slices of the update's fc4 forward (one-pass kernel only)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_FC4_KS"); v = (e && atoi(e) == kFc4SplitWide) ? kFc4SplitWide : kFc4Split; }
+  return (l->variant & DRA_VAR_ONESHOT_FWD) ? v : kFc4Split;
+}
 
 // HIP stream restricted to a set of compute units (bit i of cu_mask = CU i enabled).  The async agent step runs
 // two latency-bound kernel chains concurrently; without a partition every small actor kernel queues behind
@@ -306,7 +315,7 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
     if (!rc) rc |= (int)hipMemset(l->aring_seq, 0, sizeof(unsigned));
     if (!rc) rc |= (int)hipMemset(l->aring_dev, 0, kAringSlots * kAprmStride);
   }
-  rc |= alloc_f(&l->fc4_slabs, (int64_t)3 * kFc4Split * B * 512);
+  rc |= alloc_f(&l->fc4_slabs, (int64_t)3 * kFc4SplitWide * B * 512);
   rc |= alloc_f(&l->afc4_slabs, (int64_t)kFc4Split * 512);
   l->lin_ws_floats = (int64_t)3 * 32 * B * 512;
   rc |= alloc_f(&l->lin_ws, l->lin_ws_floats);
@@ -762,8 +771,12 @@ static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta
   const float* P = l->p;
   const float* T = l->pt;
   const int64_t* o = c.offset;
-  hipLaunchKernelGGL(fc4_reduce_kernel<kFc4Split>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
-                     T + o[P_B4], l->h4, l->opt_step);
+  if (fc4_ks(l) == kFc4SplitWide)
+    hipLaunchKernelGGL(fc4_reduce_kernel<kFc4SplitWide>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
+                       T + o[P_B4], l->h4, l->opt_step);
+  else
+    hipLaunchKernelGGL(fc4_reduce_kernel<kFc4Split>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
+                       T + o[P_B4], l->h4, l->opt_step);
   DRA_LAUNCH_CHECK();
   static int gemv = -1;
   if (gemv < 0) { const char* e = getenv("DRA_HEAD_GEMV"); gemv = e ? atoi(e) : 1; }
@@ -842,7 +855,8 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   STEP(K_CONV3_F, dra_conv_fwd_koc(3, nz, x3, w3, b3, l->y3, B, 0, 1.0, DRA_ACT_RELU, s));
   const float* x4[3] = {l->y3[0], l->y3[1], l->y3[2]};
   const float* w4[3] = {P + o[P_W4], T + o[P_W4], P + o[P_W4]};
-  if (l->variant & DRA_VAR_ONESHOT_FWD) STEP(K_FC4_F, dra_linear_fwd_slabs_one(nz, x4, w4, B, 3136, 512, kFc4Split, l->fc4_slabs, s));
+  const int ks4 = fc4_ks(l);
+  if (l->variant & DRA_VAR_ONESHOT_FWD) STEP(K_FC4_F, dra_linear_fwd_slabs_one(nz, x4, w4, B, 3136, 512, ks4, l->fc4_slabs, s));
   else STEP(K_FC4_F, dra_linear_fwd_slabs(nz, x4, w4, B, 3136, 512, kFc4Split, l->fc4_slabs, s));
   if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_HEAD], st));
   if (c.head_kind != DRA_HEAD_VANILLA) {
@@ -856,11 +870,18 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       rs.masks = (const int32_t*)ring_masks; rs.n_step = ring_n; rs.discount = ring_discount;
       rs.out_action = l->action_[l->gb]; rs.out_reward = l->reward_[l->gb]; rs.out_mask = l->mask_[l->gb];
     }
-    hipLaunchKernelGGL(head_fused_kernel<kFc4Split>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
-                       P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
-                       (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
-                       c.double_q,
-                       l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs);
+    if (ks4 == kFc4SplitWide)
+      hipLaunchKernelGGL(head_fused_kernel<kFc4SplitWide>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
+                         P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
+                         (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
+                         c.double_q,
+                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs);
+    else
+      hipLaunchKernelGGL(head_fused_kernel<kFc4Split>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
+                         P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
+                         (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
+                         c.double_q,
+                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs);
     DRA_LAUNCH_CHECK();
     if (per) {  // PER needs the batch-wide max of the importance weights: separate kernel recomputes dq, then dh4
       int rc = dra_td_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action_[l->gb], 1, l->reward_[l->gb],
