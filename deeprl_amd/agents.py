@@ -499,8 +499,7 @@ class DQNAgent(BaseAgent):
         cfg = self.config
         rp = self._inner_replay()
         torch.cuda.synchronize()
-        # a prioritized draw needs the priorities the previous update wrote back: in order only
-        async_actor = bool(cfg.async_actor) and type(rp) is not PrioritizedReplay
+        async_actor = bool(cfg.async_actor)
         self._learner = self._make_learner(rp, cu_partition=async_actor, env_seed=env.seed, env_done_period=env.done_period)
         self._fused = None
         self._target_flat = None

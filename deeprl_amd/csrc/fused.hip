@@ -25,6 +25,12 @@ DRA_API int dra_set_tuning(int mask) {
 }
 DRA_API int dra_get_tuning(int* mask) {
   if (!mask) return DRA_EINVAL;
+  static bool env_read = false;
+  if (!env_read) {     // DRA_TUNING=<mask>: process default for A/B runs of whole agents (tools/gpu_ab_agents.sh)
+    env_read = true;
+    const char* e = getenv("DRA_TUNING");
+    if (e && atoi(e) >= 0) g_tuning = atoi(e);
+  }
   *mask = g_tuning;
   return DRA_OK;
 }

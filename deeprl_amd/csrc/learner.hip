@@ -84,8 +84,12 @@ struct dra_dqn_learner {
   hipGraphExec_t g_update_per;      // the same chain with PER importance weights (beta from sampling_prob[B])
   bool g_update_per_ready;
   // pipelined async mode (DRA_VAR_PIPE_GATHER): per step parity, body + optimizer in one graph
-  hipGraphExec_t g_pipe[2];
-  bool g_pipe_ready[2];
+  hipGraphExec_t g_pipe[4];         // (indexed by parity in the two-copy pipelines, by step mod 4 in step_pipelined3)
+  bool g_pipe_ready[4];
+  hipGraphExec_t g_pipe_per[4];     // ... with PER importance weights (exponent from sampling_prob[B]): forward + loss ...
+  bool g_pipe_per_ready[4];
+  hipGraphExec_t g_pipe_per_b[4];   // ... and backward + optimizer, with ev_loss recorded in between
+  hipEvent_t ev_loss;               // PER pipeline: the update's TD errors / new priorities exist
   hipEvent_t ev_mb_ready[2], ev_mb_free[2];   // gather of buffer b finished / update body done with buffer b
   bool mb_used[2];
   int64_t step_no;                  // async steps with an update issued so far
@@ -103,8 +107,10 @@ struct dra_dqn_learner {
   int64_t host_calls;
   // actor graphs are keyed by (n_env, parameter block they read): online params in in-order mode, one of the
   // two actor copies in async mode (DRA_VAR_ACTOR_PARAMS)
-  struct { hipGraphExec_t exec; const float* params; int n_env; bool ready; } g_actor[3];
-  float* pa[2];                     // double-buffered parameter copies the async actor reads
+  struct { hipGraphExec_t exec; const float* params; int n_env; bool ready; } g_actor[5];
+  float* pa[4];                     // parameter copies the async actor reads: two in the pipelines whose update waits for
+                                    // the previous actor graph every step, four (rotating) in step_pipelined3, which does not
+  hipEvent_t pa_reader[4];          // step_pipelined3: recorded after the last actor launch that reads copy i
   int pa_cur;                       // pa[pa_cur] holds the newest completed parameters
   bool pa_valid;
   float* ah4;                       // actor fc4 output (v2)
@@ -131,9 +137,9 @@ struct dra_dqn_learner {
   int32_t* pend_mask;
   uint64_t aring_pushed, aring_issued;
   bool aring_primed;
-  hipGraphExec_t g_aring[2];
-  bool g_aring_ready[2];
-  int g_aring_nenv[2];
+  hipGraphExec_t g_aring[4];
+  bool g_aring_ready[4];
+  int g_aring_nenv[4];
   hipEvent_t aprm_ev[16];
   bool aprm_used[16];
   hipStream_t side;                 // fork stream for graph branches
@@ -147,14 +153,16 @@ struct dra_dqn_learner {
   // DRA_VAR_RING_DIRECT: minibatch indices in four fixed pinned buffers (captured graphs bake the address; the host may
   // run up to four steps ahead), the graph / event of the same rotation, and the flag for an additional gather (checkers)
   int64_t* idx_pin[4];
-  hipGraphExec_t g_rd[4];
-  bool g_rd_ready[4];
+  hipGraphExec_t g_rd[4], g_rd_per[4], g_rd_per_b[4];
+  bool g_rd_ready[4], g_rd_per_ready[4];
   hipEvent_t ev_upd[4];
   bool upd_used[4];
   int rd_slot;                      // >= 0 while run_body is being captured / run for the ring-direct pipeline
   int keep_minibatch;
-  int64_t prev_slots[8];            // ring slots the most recently issued actor launch writes (-1 entries: unknown)
-  int prev_n_slots;
+  // actor launches issued and not yet known to be complete (oldest first; at most 8: a staging slot is reused only after
+  // its event was synchronised): the event recorded behind each and the ring slots it writes (n < 0: unknown = all)
+  struct { hipEvent_t ev; int n; int64_t slots[8]; } arec[8];
+  int arec_count;
   hipEvent_t actor_last = nullptr;  // GATHER_ON_UPDATE: recorded after the most recent actor launch (a staging-slot event)
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
@@ -224,7 +232,6 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   if (!l) return DRA_ENOMEM;
   memset(l, 0, sizeof(*l));
   l->c = *cfg; l->ring = ring; l->p = params; l->pt = target; l->g = grad; l->s1 = state1; l->s2 = state2;
-  l->prev_n_slots = -1;
   l->rd_slot = -1;
   if (cfg->head_kind == DRA_HEAD_QUANTILE) l->c.double_q = 0;   // QuantileRegressionDQN_agent.py:58-60: target network only
   const int B = cfg->batch, A = cfg->n_actions;
@@ -297,6 +304,9 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   l->n_partials = 2 * dra_norm_partials();
   rc |= alloc_f(&l->ah4, 512);
   if (l->variant & DRA_VAR_ACTOR_PARAMS) { rc |= alloc_f(&l->pa[0], cfg->n_params); rc |= alloc_f(&l->pa[1], cfg->n_params); }
+  if ((l->variant & DRA_VAR_ACTOR_PARAMS) && (l->variant & DRA_VAR_GATHER_ON_UPDATE)) {
+    rc |= alloc_f(&l->pa[2], cfg->n_params); rc |= alloc_f(&l->pa[3], cfg->n_params);
+  }
   if (l->variant & DRA_VAR_ACTOR_V3) {
     rc |= (int)hipHostMalloc(&l->aprm_ring, kAprmSlots * kAprmStride, hipHostMallocDefault);
     rc |= (int)hipMalloc(&l->aprm_seq_dev, sizeof(unsigned));
@@ -341,6 +351,7 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= (int)hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming);
   for (int k = 0; k < 4; ++k) rc |= (int)hipEventCreateWithFlags(&l->ev_join[k], hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_actor_done, hipEventDisableTiming);
+  rc |= (int)hipEventCreateWithFlags(&l->ev_loss, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_gather_done, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_step_done, hipEventDisableTiming);
   for (int g = 0; g < 2; ++g) {
@@ -363,19 +374,22 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   }
   for (int g = 0; g < 2; ++g) {
     if (l->g_ag_ready[g]) (void)hipGraphExecDestroy(l->g_ag[g]);
-    if (l->g_pipe_ready[g]) (void)hipGraphExecDestroy(l->g_pipe[g]);
+    for (int h = g; h < 4; h += 2) {
+      if (l->g_pipe_ready[h]) (void)hipGraphExecDestroy(l->g_pipe[h]);
+      if (l->g_pipe_per_ready[h]) { (void)hipGraphExecDestroy(l->g_pipe_per[h]); (void)hipGraphExecDestroy(l->g_pipe_per_b[h]); }
+    }
     (void)hipEventDestroy(l->ev_mb_ready[g]); (void)hipEventDestroy(l->ev_mb_free[g]);
     void* mb[] = {l->state_[g], l->next_state_[g], l->action_[g], l->reward_[g], l->mask_[g]};
     for (void* b : mb) if (b) (void)hipFree(b);
   }
   for (auto& ga : l->g_actor) if (ga.ready) (void)hipGraphExecDestroy(ga.exec);
-  for (int k = 0; k < 2; ++k) if (l->pa[k]) (void)hipFree(l->pa[k]);
+  for (int k = 0; k < 4; ++k) if (l->pa[k]) (void)hipFree(l->pa[k]);
   if (l->ah4) (void)hipFree(l->ah4);
   if (l->aring_dev) {
     (void)hipFree(l->aring_dev); (void)hipHostFree(l->aring_stage); (void)hipFree(l->aring_seq);
     (void)hipFree(l->pend_frame); (void)hipFree(l->pend_reward); (void)hipFree(l->pend_mask);
   }
-  for (int g = 0; g < 2; ++g) if (l->g_aring_ready[g]) (void)hipGraphExecDestroy(l->g_aring[g]);
+  for (int g = 0; g < 4; ++g) if (l->g_aring_ready[g]) (void)hipGraphExecDestroy(l->g_aring[g]);
   if (l->aprm_ring) {
     (void)hipHostFree(l->aprm_ring); (void)hipFree(l->aprm_seq_dev); (void)hipFree(l->fc4_ticket);
     for (int k = 0; k < kAprmSlots; ++k) (void)hipEventDestroy(l->aprm_ev[k]);
@@ -398,6 +412,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   for (int k = 0; k < 4; ++k) {
     if (l->idx_pin[k]) (void)hipHostFree(l->idx_pin[k]);
     if (l->g_rd_ready[k]) (void)hipGraphExecDestroy(l->g_rd[k]);
+    if (l->g_rd_per_ready[k]) { (void)hipGraphExecDestroy(l->g_rd_per[k]); (void)hipGraphExecDestroy(l->g_rd_per_b[k]); }
     (void)hipEventDestroy(l->ev_upd[k]);
   }
   if (l->qs_stage) (void)hipHostFree(l->qs_stage);
@@ -409,6 +424,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   (void)hipEventDestroy(l->ev_fork);
   for (int k = 0; k < 4; ++k) (void)hipEventDestroy(l->ev_join[k]);
   (void)hipEventDestroy(l->ev_actor_done); (void)hipEventDestroy(l->ev_gather_done); (void)hipEventDestroy(l->ev_step_done);
+  (void)hipEventDestroy(l->ev_loss);
   delete l;
   return DRA_OK;
 }
@@ -813,7 +829,10 @@ static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta
 // forward + loss + backward + gradient norm (everything between the gather and the optimizer).
 // `fork` != 0 places each layer's weight-gradient kernel on the side stream (captured as a parallel
 // graph branch) while the input-gradient chain continues on `st`.
-static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int fork) {
+// `part`: 0 = everything; 1 = forward passes + loss only (ends when the TD errors / priorities exist); 2 = the rest
+// (backward, gradient norm).  The PER pipeline captures the two halves as separate graphs with an event in between, so
+// that the priority write-back and the next prioritized draw start under the backward pass.
+static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int fork, int part = 0) {
   const dra_dqn_config& c = l->c;
   const int B = c.batch, A = c.n_actions;
   const int nz = c.double_q ? 3 : 2;
@@ -821,10 +840,6 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   const float* P = l->p;
   const float* T = l->pt;
   const int64_t* o = c.offset;
-  // z = 0: online(states)   z = 1: target(next_states)   z = 2: online(next_states) [double-Q]
-  const void* x1[3] = {l->state_[l->gb], l->next_state_[l->gb], l->next_state_[l->gb]};
-  const float* w1[3] = {P + o[P_W1], T + o[P_W1], P + o[P_W1]};
-  const float* b1[3] = {P + o[P_B1], T + o[P_B1], P + o[P_B1]};
   // DRA_VAR_RING_DIRECT (l->rd_slot >= 0): the uint8 frames come straight from the replay ring, sample b of net z = the 4
   // slots ending at idx[b] (+ n_step for the next-state nets); no gathered copy exists
   const bool rd = l->rd_slot >= 0;
@@ -837,6 +852,13 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     if (!rc0) rc0 = dra_ring_discount(l->ring, &ring_discount);
     if (rc0) return rc0;
     if (ring_h != 4) return DRA_EINVAL;
+  }
+  if (part != 2) {
+  // z = 0: online(states)   z = 1: target(next_states)   z = 2: online(next_states) [double-Q]
+  const void* x1[3] = {l->state_[l->gb], l->next_state_[l->gb], l->next_state_[l->gb]};
+  const float* w1[3] = {P + o[P_W1], T + o[P_W1], P + o[P_W1]};
+  const float* b1[3] = {P + o[P_B1], T + o[P_B1], P + o[P_B1]};
+  if (rd) {
     const int64_t off[3] = {0, ring_n, ring_n};
     // (the indices sit in pinned host memory: conv1's workgroups pay the one PCIe read and leave a device copy in l->idx
     // for the head and the weight-gradient kernels of this update)
@@ -892,6 +914,8 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       if (rc) return rc;
     }
   }
+  }   // part != 2
+  if (part == 1) return DRA_OK;
   const int NO = l->n_out;      // head outputs the backward sees: A, or A * n_atoms
   float* G = l->g;
   float* S = l->slabs;
@@ -1002,47 +1026,62 @@ static int body_graph(dra_dqn_learner* l, hipStream_t st) {
 
 // Pipelined async mode: update body + optimizer of one step parity as ONE graph (no launch gap in front of
 // the optimizer).  The optimizer's second output is the actor parameter copy of the same parity.
-static int pipe_graph(dra_dqn_learner* l, hipStream_t st, int par) {
-  if (!l->g_pipe_ready[par]) {
-    hipGraph_t graph;
-    l->gb = par;
-    hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-    if (b != hipSuccess) { l->gb = 0; return (int)b; }
-    int rc = run_body(l, st, 0, 0.f, 0);
-    if (rc == DRA_OK) rc = launch_optimizer(l, st, l->pa[par]);
-    hipError_t e = hipStreamEndCapture(st, &graph);
-    l->gb = 0;
-    if (rc != DRA_OK) return rc;
-    if (e != hipSuccess) return (int)e;
-    DRA_HIP(hipGraphInstantiate(&l->g_pipe[par], graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
-    l->g_pipe_ready[par] = true;
-  }
-  DRA_HIP(hipGraphLaunch(l->g_pipe[par], st));
+// Captures (once) and launches the update of rotation slot q as a graph: uniform replay = ONE graph (body + optimizer);
+// PER = two graphs, [forward passes + loss] and [backward + norm + optimizer], with ev_loss recorded between them -- the
+// priority write-back and the next prioritized draw (tree stream + one host round trip) then run under the backward pass.
+// rd: the ring-direct body (idx_pin[q]); otherwise the gathered minibatch of parity q & 1.
+static int capture_part(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int per, int part, bool with_optimizer,
+                        hipGraphExec_t* exec) {
+  hipGraph_t graph;
+  l->gb = q & 1;
+  l->rd_slot = rd ? q : -1;
+  hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  if (b != hipSuccess) { l->gb = 0; l->rd_slot = -1; return (int)b; }
+  int rc = run_body(l, st, per, per ? -1.f : 0.f, 0, part);     // PER: the exponent is read from sampling_prob[B]
+  if (rc == DRA_OK && with_optimizer) rc = launch_optimizer(l, st, l->pa[q]);
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  l->gb = 0;
+  l->rd_slot = -1;
+  if (rc != DRA_OK) return rc;
+  if (e != hipSuccess) return (int)e;
+  DRA_HIP(hipGraphInstantiate(exec, graph, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(graph);
   return DRA_OK;
 }
 
-// DRA_VAR_RING_DIRECT: update body + optimizer for rotation slot q (index buffer idx_pin[q], minibatch scalar buffers and
-// actor parameter copy of parity q & 1) as one graph.
-static int rd_graph(dra_dqn_learner* l, hipStream_t st, int q) {
-  if (!l->g_rd_ready[q]) {
-    hipGraph_t graph;
-    l->gb = q & 1;
-    l->rd_slot = q;
-    hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-    if (b != hipSuccess) { l->gb = 0; l->rd_slot = -1; return (int)b; }
-    int rc = run_body(l, st, 0, 0.f, 0);
-    if (rc == DRA_OK) rc = launch_optimizer(l, st, l->pa[q & 1]);
-    hipError_t e = hipStreamEndCapture(st, &graph);
-    l->gb = 0;
-    l->rd_slot = -1;
-    if (rc != DRA_OK) return rc;
-    if (e != hipSuccess) return (int)e;
-    DRA_HIP(hipGraphInstantiate(&l->g_rd[q], graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
-    l->g_rd_ready[q] = true;
+static int update_graph(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int per) {
+  hipGraphExec_t* exec = rd ? (per ? &l->g_rd_per[q] : &l->g_rd[q]) : (per ? &l->g_pipe_per[q] : &l->g_pipe[q]);
+  hipGraphExec_t* exec_b = rd ? &l->g_rd_per_b[q] : &l->g_pipe_per_b[q];
+  bool* ready = rd ? (per ? &l->g_rd_per_ready[q] : &l->g_rd_ready[q]) : (per ? &l->g_pipe_per_ready[q] : &l->g_pipe_ready[q]);
+  if (!*ready) {
+    int rc;
+    if (per) {
+      if ((rc = capture_part(l, st, q, rd, 1, 1, false, exec))) return rc;
+      if ((rc = capture_part(l, st, q, rd, 1, 2, true, exec_b))) return rc;
+    } else if ((rc = capture_part(l, st, q, rd, 0, 0, true, exec))) {
+      return rc;
+    }
+    *ready = true;
   }
-  DRA_HIP(hipGraphLaunch(l->g_rd[q], st));
+  DRA_HIP(hipGraphLaunch(*exec, st));
+  if (per) {
+    DRA_HIP(hipEventRecord(l->ev_loss, st));
+    DRA_HIP(hipGraphLaunch(*exec_b, st));
+  }
+  return DRA_OK;
+}
+
+static int pipe_graph(dra_dqn_learner* l, hipStream_t st, int par, int per = 0) {   // par: 0 / 1, or step mod 4
+  return update_graph(l, st, par, false, per);
+}
+
+static int rd_graph(dra_dqn_learner* l, hipStream_t st, int q, int per = 0) { return update_graph(l, st, q, true, per); }
+
+// The tree stream of a PER pipeline waits here for the TD errors / new priorities of the update issued last (they exist
+// after the loss kernel: the backward pass and the optimizer are still to run).
+DRA_API int dra_dqn_learner_wait_loss(dra_dqn_learner* l, void* stream) {
+  if (!l || !stream) return DRA_EINVAL;
+  DRA_HIP(hipStreamWaitEvent(dra_stream(stream), l->ev_loss, 0));
   return DRA_OK;
 }
 
@@ -1870,12 +1909,13 @@ static int run_actor_steps(dra_dqn_learner* l, int n_env, const float* P, hipStr
 
 static int actor_graph(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
   int slot = -1;
-  for (int k = 0; k < 3; ++k) if (l->g_actor[k].ready && l->g_actor[k].params == P && l->g_actor[k].n_env == n_env) slot = k;
+  constexpr int NS = 5;
+  for (int k = 0; k < NS; ++k) if (l->g_actor[k].ready && l->g_actor[k].params == P && l->g_actor[k].n_env == n_env) slot = k;
   if (slot < 0) {
-    for (int k = 0; k < 3 && slot < 0; ++k) if (!l->g_actor[k].ready) slot = k;
+    for (int k = 0; k < NS && slot < 0; ++k) if (!l->g_actor[k].ready) slot = k;
     if (slot < 0) {  // evict an entry of the same parameter block (n_env changed), else entry 0
       slot = 0;
-      for (int k = 0; k < 3; ++k) if (l->g_actor[k].params == P) slot = k;
+      for (int k = 0; k < NS; ++k) if (l->g_actor[k].params == P) slot = k;
       (void)hipGraphExecDestroy(l->g_actor[slot].exec);
       l->g_actor[slot].ready = false;
     }
@@ -2021,10 +2061,48 @@ static bool gather_reads_slots(const dra_dqn_learner* l, const int64_t* idx, con
   return false;
 }
 
+// Bookkeeping of the actor launches an update may have to wait for.  The update stream no longer waits for "the previous
+// actor graph" every step, so the host must know, for every actor launch that may still be running, which ring slots it
+// writes: a minibatch that touches the slots of launch i waits for launch i (which, the actor stream being in order,
+// covers every older one).  During the exploration phase the host issues actor-only calls far ahead of the device; the
+// first updates then meet several unfinished launches, not just the last one.
+static void arec_push(dra_dqn_learner* l, hipEvent_t ev, const int64_t* slots, int n) {
+  int w = 0;
+  for (int i = 0; i < l->arec_count; ++i)        // the staging slot's previous user is complete (stage_acquire synchronised it)
+    if (l->arec[i].ev != ev) l->arec[w++] = l->arec[i];
+  l->arec_count = w;
+  if (l->arec_count == 8) {                       // (cannot happen with 8 staging slots; keep the newest 7)
+    for (int i = 1; i < 8; ++i) l->arec[i - 1] = l->arec[i];
+    l->arec_count = 7;
+  }
+  auto& r = l->arec[l->arec_count++];
+  r.ev = ev;
+  r.n = n;
+  for (int e = 0; e < n && e < 8; ++e) r.slots[e] = slots[e];
+}
+
+// the newest unfinished actor launch whose slots the minibatch `idx` touches (null: none)
+static hipEvent_t arec_needed(dra_dqn_learner* l, const int64_t* idx) {
+  int first = 0;
+  while (first < l->arec_count && hipEventQuery(l->arec[first].ev) == hipSuccess) ++first;   // finished launches, oldest first
+  if (first > 0) {
+    for (int i = first; i < l->arec_count; ++i) l->arec[i - first] = l->arec[i];
+    l->arec_count -= first;
+  }
+  for (int i = l->arec_count - 1; i >= 0; --i)
+    if (l->arec[i].n < 0 || gather_reads_slots(l, idx, l->arec[i].slots, l->arec[i].n)) return l->arec[i].ev;
+  return nullptr;
+}
+
 static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, hipStream_t su,
                            hipStream_t sa, int k) {
   const int B = l->c.batch;
-  const int par = (int)(l->step_no & 1);
+  // Parameter copies rotate by FOUR here: update t writes copy t mod 4, the actor graph of step t+1 (issued with update t)
+  // reads the copy update t-1 wrote.  The copy update t overwrites was last read by the actor graph issued three calls ago;
+  // nothing on the device orders the update after that graph any more (the per-step wait is gone), so the HOST makes sure it
+  // is done before issuing the update (pa_reader: normally long complete -- the host runs at most four steps ahead).
+  const int q = (int)(l->step_no & 3), qr = (q + 3) & 3;
+  const int par = q & 1;           // minibatch buffers alternate
   int rc;
   hipEvent_t opt_prev = l->last_done;          // optimizer of step t-1: produced the copy the actor graph below reads
   // the block the actor graph issued by THIS call consumes: with the parameter ring that is the next un-issued ring entry
@@ -2035,28 +2113,33 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
     ablk = reinterpret_cast<const dra_dqn_step_params*>(l->aring_stage + (size_t)(l->aring_issued % kAringSlots) * kAprmStride);
   }
   const bool hazard = do_update && prm->n_env > 0 && gather_reads_slots(l, prm->idx, ablk->slot, prm->n_env);
-  // ... and the other direction: the gather needs the transitions the PREVIOUS call's actor graph is writing only if the
-  // minibatch touches those slots (same order of probability); otherwise the two chains do not meet in this step at all
-  const bool needs_actor = do_update && (l->prev_n_slots < 0 || gather_reads_slots(l, prm->idx, l->prev_slots, l->prev_n_slots));
+  // ... and the other direction: the update reads the transitions an unfinished actor launch is writing only if the
+  // minibatch touches its slots (same order of probability); otherwise the two chains do not meet in this step at all
+  const hipEvent_t needs_actor = do_update ? arec_needed(l, prm->idx) : nullptr;
   bool seed = false;
   if (prm->n_env > 0) {
-    if (l->pa_valid && l->pa_cur != (par ^ 1)) l->pa_valid = false;   // copies out of phase with the step parity
+    if (l->pa_valid && l->pa_cur != qr) l->pa_valid = false;   // copies out of phase with the step rotation
     seed = !l->pa_valid;
   }
   if (seed) {   // (re)seed the actor copy from the online parameters BEFORE this step's optimizer overwrites them
     if (opt_prev) DRA_HIP(hipStreamWaitEvent(sa, opt_prev, 0));
-    l->pa_cur = par ^ 1;
+    l->pa_cur = qr;
     DRA_HIP(hipMemcpyAsync(l->pa[l->pa_cur], l->p, (size_t)l->c.n_params * sizeof(float), hipMemcpyDeviceToDevice, sa));
     DRA_HIP(hipEventRecord(l->ev_join[0], sa));
     l->pa_valid = true;
   }
   if (do_update) {
-    if (l->actor_last && needs_actor) DRA_HIP(hipStreamWaitEvent(su, l->actor_last, 0));   // transitions of step t are in the ring
+    if (l->pa_reader[q]) {           // the optimizer of this update overwrites copy q: its last reader must be done
+      const auto t0 = std::chrono::steady_clock::now();
+      DRA_HIP(hipEventSynchronize(l->pa_reader[q]));
+      l->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      l->pa_reader[q] = nullptr;
+    }
+    if (needs_actor) DRA_HIP(hipStreamWaitEvent(su, needs_actor, 0));   // the sampled transitions are in the ring
     if (seed) DRA_HIP(hipStreamWaitEvent(su, l->ev_join[0], 0));
     if (l->variant & DRA_VAR_RING_DIRECT) {
       // no gather: the update's own kernels read the ring through idx_pin[q] (four rotating pinned buffers: a captured graph
       // bakes the address; buffer q is free again once update t-4 is done)
-      const int q = (int)(l->step_no & 3);
       if (l->upd_used[q]) {
         const auto t0 = std::chrono::steady_clock::now();
         DRA_HIP(hipEventSynchronize(l->ev_upd[q]));
@@ -2074,7 +2157,7 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
       }
       TRACE(1, su);
       TRACE(3, su);
-      if ((rc = rd_graph(l, su, q))) return rc;
+      if ((rc = rd_graph(l, su, q, l->step_per))) return rc;
       TRACE(4, su);
       DRA_HIP(hipEventRecord(l->ev_upd[q], su));         // the ONE record of the update stream: optimizer t done
       l->last_done = l->ev_upd[q];
@@ -2090,7 +2173,7 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
       if (rc) return rc;
       TRACE(1, su);
       TRACE(3, su);
-      if ((rc = pipe_graph(l, su, par))) return rc;
+      if ((rc = pipe_graph(l, su, q, l->step_per))) return rc;
       TRACE(4, su);
       DRA_HIP(hipEventRecord(l->ev_mb_free[par], su));   // the ONE record of the update stream: optimizer t done
       l->last_done = l->ev_mb_free[par];
@@ -2109,13 +2192,13 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
   }
   DRA_HIP(hipEventRecord(l->stage_ev[k], sa));   // the ONE record of the actor stream: graph done, staging slot k free
   if (prm->n_env > 0) {
+    l->pa_reader[l->pa_cur] = l->stage_ev[k];
     l->actor_last = l->stage_ev[k];
-    l->prev_n_slots = prm->n_env;
-    for (int e = 0; e < prm->n_env; ++e) l->prev_slots[e] = ablk->slot[e];
+    arec_push(l, l->stage_ev[k], ablk->slot, prm->n_env);
   }
   if (do_update) {
     if (l->tr_ev && l->tr_n < l->tr_cap) l->tr_n++;
-    if (l->pa_valid) l->pa_cur = par;   // the graph's optimizer wrote copy `par`
+    if (l->pa_valid) l->pa_cur = q;   // the graph's optimizer wrote copy q
     l->step_no++;
   }
   return DRA_OK;
@@ -2250,7 +2333,7 @@ DRA_API int dra_dqn_learner_act(dra_dqn_learner* l, const dra_dqn_step_params* p
   else rc = issue_actor(l, prm, k, l->p, st, use_graph != 0);
   DRA_HIP(hipEventRecord(l->stage_ev[k], st));
   l->actor_last = l->stage_ev[k];
-  l->prev_n_slots = -1;      // (the slots this launch writes are not tracked: the next update waits for it unconditionally)
+  arec_push(l, l->stage_ev[k], nullptr, -1);   // (slots not tracked: an update issued while it runs waits unconditionally)
   return rc;
 }
 
@@ -2328,7 +2411,9 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
     return DRA_OK;
   }
   // ---- async mode
-  if (l->step_per && do_update) return DRA_EINVAL;   // prioritized draws depend on the previous update: in-order only
+  // PER in the pipelined step: the gather-on-update pipeline only (its update graphs have a PER variant; the host performs the
+  // prioritized draw of step t after the write-back of update t-1, so the two chains still overlap inside a step)
+  if (l->step_per && do_update && (!(l->variant & DRA_VAR_GATHER_ON_UPDATE) || l->step_beta >= 0.f)) return DRA_EINVAL;
   if ((l->variant & DRA_VAR_PIPE_GATHER) && (l->variant & DRA_VAR_ACTOR_PARAMS)) {
     if ((l->variant & DRA_VAR_GATHER_IN_GRAPH) && !(l->variant & DRA_VAR_ACTOR_V3)) return step_pipelined2(l, prm, do_update, su, sa, k);
     if (l->variant & DRA_VAR_GATHER_ON_UPDATE) return step_pipelined3(l, prm, do_update, su, sa, k);

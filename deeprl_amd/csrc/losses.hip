@@ -8,8 +8,11 @@
 // Actions arrive as the ring's raw int64 records or as f32 (what `tensor()` makes of them).
 #include "common.h"
 
-__device__ __forceinline__ int64_t load_action(const void* a, int is_i64, int b) {
-  return is_i64 ? reinterpret_cast<const int64_t*>(a)[b] : (int64_t)reinterpret_cast<const float*>(a)[b];
+// (clamped to [0, n_actions): an action record that was never written -- a sampling bug upstream -- must show up as a wrong
+// number, not turn into a wild pointer and a GPU fault)
+__device__ __forceinline__ int64_t load_action(const void* a, int is_i64, int b, int n_actions) {
+  const int64_t v = is_i64 ? reinterpret_cast<const int64_t*>(a)[b] : (int64_t)reinterpret_cast<const float*>(a)[b];
+  return v < 0 ? 0 : (v >= n_actions ? (int64_t)n_actions - 1 : v);
 }
 
 // block-wide reductions for blockDim <= 1024 (<=16 waves); every thread gets the result
@@ -60,7 +63,7 @@ td_loss_kernel(const float* __restrict__ q, const float* __restrict__ qn_t, cons
       qn = t[0];
       for (int k = 1; k < A; ++k) qn = fmaxf(qn, t[k]);
     }
-    a = load_action(action, action_i64, b);
+    a = load_action(action, action_i64, b, A);
     // rewards + gamma^n * q_next * masks  ->  r + ((g*qn)*m), unfused
     const float target = __fadd_rn(reward[b], __fmul_rn(__fmul_rn(gamma_n, qn), mask[b]));
     delta = __fsub_rn(target, q[(int64_t)b * A + a]);
@@ -164,7 +167,7 @@ c51_loss_kernel(const float* __restrict__ logits, const float* __restrict__ logi
     }
   }
   // online log-softmax on row a
-  const int64_t a = load_action(action, action_i64, b);
+  const int64_t a = load_action(action, action_i64, b, A);
   const float x = on ? logits[((int64_t)b * A + a) * N + j] : -INFINITY;
   const float mx = block_max(x, s_red);
   const float e = on ? expf(x - mx) : 0.f;
@@ -227,7 +230,7 @@ qr_loss_kernel(const float* __restrict__ theta, const float* __restrict__ theta_
   }
   if (i == 0) s_anext = best_a;
   __syncthreads();
-  const int64_t a = load_action(action, action_i64, b);
+  const int64_t a = load_action(action, action_i64, b, A);
   if (on) {
     // rewards + gamma^n * masks * quantiles_next -> r + ((g*m)*theta')
     s_t[i] = __fadd_rn(reward[b], __fmul_rn(__fmul_rn(gamma_n, mask[b]), tt[s_anext * N + i]));

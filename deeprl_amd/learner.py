@@ -152,14 +152,16 @@ class DQNLearner:
     def _partitioned_streams(self):
         """Update stream / actor stream on disjoint CU sets (DRA_VAR_CU_PARTITION).  On MI355X mask bit i is CU
         (i // 32) of shader engine (i // 8) % 4 of XCD i % 8 (tools/probe_cu_mask.py), and a workgroup's XCD is
-        fixed by the dispatcher (round robin), so the first DRA_ACTOR_CUS (default 1/4 of the device = 64) bits give
-        the actor chain the same 8 CUs (2 per shader engine) in every XCD and the update chain the other 24.
+        fixed by the dispatcher (round robin), so the first DRA_ACTOR_CUS (default 1/8 of the device = 32) bits give
+        the actor chain the same 4 CUs (1 per shader engine) in every XCD and the update chain the other 28.
+        End of round 2 (actor conv2 / conv3 split over two workgroups, ring-direct update: the update chain is the longer one):
+        64 -> 8 347, 40 -> 8 383, 32 -> 8 490, 24 -> 7 709 updates/s on one box (profiles/r02zj_ab_actor_cus.json).
         Round 2 (4-launch env step, 8-wave batch-1 convolutions): 96 -> 6876, 64 -> 7438, 56 -> 7082, 48 -> 6379 updates/s on
         one box (profiles/r02f_*): at 192 CUs conv2 / conv3 backward (384 workgroups at 2 per CU) and the optimizer fit
         ONE round of workgroups, at 160 they do not (phase traces, profiles/r02b_*)."""
         import os
         n_cu = torch.cuda.get_device_properties(Config.DEVICE).multi_processor_count
-        n_act = max(8, min(n_cu - 8, int(os.environ.get("DRA_ACTOR_CUS", str(n_cu // 4)))))   # 64 of 256
+        n_act = max(8, min(n_cu - 8, int(os.environ.get("DRA_ACTOR_CUS", str(n_cu // 8)))))   # 32 of 256
         key = (Config.DEVICE.index, n_act)
         self.update_cus, self.actor_cus = n_cu - n_act, n_act
         if key in _PARTITIONED_STREAMS:
@@ -268,6 +270,11 @@ class DQNLearner:
         """The next in-order step() applies PER importance weights (exponent beta) from self.sampling_prob and leaves the
         new priorities in self.prio."""
         lib.dra_dqn_learner_set_per(self.h, int(bool(per)), float(beta))
+
+    def wait_loss(self, stream):
+        """`stream` waits until the TD errors / new priorities of the PER update issued last exist (its backward pass and
+        optimizer are still running then)."""
+        lib.dra_dqn_learner_wait_loss(self.h, self._sp(stream))
 
     def keep_minibatch(self, keep):
         """Checkers: with the ring-direct update (VAR_RING_DIRECT) no gathered minibatch exists; keep=True makes the pipelined
@@ -436,10 +443,8 @@ class DeviceActorPipeline:
 
     def __init__(self, learner, replay, stream, n_actions, n_env, epsilon_fn, async_actor, actor_seed=None, beta_fn=None):
         self.L, self.rp, self.stream = learner, replay, stream
-        self.per = hasattr(replay, 'draw')          # PrioritizedReplay: in-order only (a draw needs the previous write-back)
+        self.per = hasattr(replay, 'draw')          # PrioritizedReplay: one host round trip per step (the draw)
         self.beta_fn = beta_fn
-        if self.per and async_actor:
-            raise DraError("the async device pipeline is uniform-replay only")
         # the priority tree's kernels (adds of the new transitions, stratified descent, write-back) are single-workgroup
         # latency chains of ~20 dependent levels each; they depend on the previous UPDATE only, so they run on their own
         # stream underneath the actor's forward passes
@@ -523,12 +528,33 @@ class DeviceActorPipeline:
             L.actor_stream.synchronize()
             self.primed = True
         infos = self.pending.pop(0)                                  # produced by the actor launch issued last call
-        rp.advance(self.n_env)
+        if self.per:
+            with torch.cuda.stream(self.tree_stream):
+                rp.advance(self.n_env)
+        else:
+            rp.advance(self.n_env)
         do_update = bool(account(infos))
-        idx = rp.draw_indices() if do_update else None
         if self.pushed - self.issued < 8:
             self._push()
         L.params.n_env = self.n_env
+        if self.per and do_update:
+            # PrioritizedReplay inside the two-stream pipeline: the draw of step t needs the priorities update t-1 wrote
+            # back, so the host does wait once per step (tree stream: write-back t-1, adds t, descent t -> pinned memory);
+            # the actor transitions of step t+1 still run underneath update t on their own stream and CU partition
+            with torch.cuda.stream(self.tree_stream):
+                pending_draw = rp.draw_begin()
+            tree_idx, prob, data_idx = rp.draw_end(pending_draw)
+            L.upload_sampling_prob(prob, self.beta_fn())
+            L.set_per(True, -1.0)
+            L.step(data_idx, True, True)                             # update(t) with importance weights, actor(t+1)
+            L.wait_loss(self.tree_stream)                            # the write-back starts under the backward pass
+            with torch.cuda.stream(self.tree_stream):
+                rp.commit_device(tree_idx, L.prio)
+            self.issued += 1
+            return infos
+        if self.per:
+            L.set_per(False, 0.0)
+        idx = rp.draw_indices() if do_update else None
         L.step(idx, do_update, True)                                 # gather(t), actor(t+1), update(t)
         self.issued += 1
         return infos

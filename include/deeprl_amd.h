@@ -312,6 +312,10 @@ int dra_dqn_learner_set_per(dra_dqn_learner* learner, int per, float beta);
 /* DRA_VAR_RING_DIRECT: also gather the minibatch into the learner's buffers (dra_dqn_learner_last_minibatch) -- for
  * checkers; the update itself keeps reading the ring */
 int dra_dqn_learner_keep_minibatch(dra_dqn_learner* learner, int keep);
+/* PER in the pipelined step: the update is issued as [forward passes + loss] [backward + optimizer]; `stream` waits for the
+ * first half of the update issued last, i.e. until its TD errors / new priorities exist (the write-back to the sum tree and
+ * the next prioritized draw then run under the backward pass) */
+int dra_dqn_learner_wait_loss(dra_dqn_learner* learner, void* stream);
 int dra_dqn_learner_profile(dra_dqn_learner* learner, float* out_ms, int n_out, void* stream);
 /* the minibatch the most recently issued update consumed (device pointers into the learner's buffers: u8 states /
  * next states [B][4][84][84], int64 actions [B], f32 rewards / masks [B]); for checkers, after a synchronise */

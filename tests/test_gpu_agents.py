@@ -760,3 +760,83 @@ def test_onpolicy_device_env_equals_host_emulators(dra, monkeypatch, kind):
     assert np.array_equal(outs[0][2], outs[1][2])
     for k in outs[0][0]:
         assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+
+
+@pytest.mark.parametrize("kind,per", [("dqn", True), ("c51", True), ("dqn", False), ("c51", False)])
+def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch, kind, per):
+    """PrioritizedReplay inside the two-stream pipeline (config.async_actor=True: actor transitions of step t+1 on their own
+    stream under update t; the prioritized draw of step t after the device-side write-back of update t-1; ring-direct update
+    for DQN, gathered minibatch for C51).  With epsilon == 1 the actions do not depend on the (one update staler)
+    parameters the async actor sees, so the run must equal the in-order pipeline EXACTLY: same transitions, same draws,
+    same priority tree, bit-identical parameters -- on a 300-slot ring, where most minibatches touch the slots the
+    concurrently running actor overwrites (the host-decided cross-stream waits are what keeps the schedule).
+    per=False: the same equality for uniform replay.  The run starts with an exploration phase of actor-only calls, which the
+    host issues far ahead of the device: the first updates must wait for every unfinished actor launch whose slots they
+    sample, not just the latest one (csrc/learner.hip arec_needed)."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    outs = []
+    for async_actor in (True, False):
+        cfg = d.Config()
+        cfg.merge(dict(game="synthetic-atari", n_step=1, replay_cls=d.PrioritizedReplay if per else d.UniformReplay,
+                       async_replay=False, log_level=0, tag="pa%d" % async_actor, device_env=True))
+        cfg.replay_eps, cfg.replay_alpha = 0.01, 0.5
+        cfg.replay_beta = d.LinearSchedule(0.4, 1.0, 1000)
+        cfg.task_fn = lambda: d.Task(cfg.game, seed=9, synthetic_done_period=13)
+        cfg.eval_env = cfg.task_fn()
+        if kind == "dqn":
+            cfg.optimizer_fn = lambda params: torch.optim.RMSprop(params, lr=0.00025, alpha=0.95, eps=0.01, centered=True)
+            cfg.network_fn = lambda: d.VanillaNet(cfg.action_dim, d.NatureConvBody(in_channels=4))
+            cls, head = d.DQNAgent, [("fc_head.weight", (4, 512)), ("fc_head.bias", (4,))]
+        else:
+            cfg.optimizer_fn = lambda params: torch.optim.Adam(params, lr=0.00025, eps=0.01 / 32)
+            cfg.categorical_v_max, cfg.categorical_v_min, cfg.categorical_n_atoms = 10, -10, 51
+            cfg.network_fn = lambda: d.CategoricalNet(cfg.action_dim, cfg.categorical_n_atoms, d.NatureConvBody())
+            cls, head = d.CategoricalDQNAgent, [("fc_categorical.weight", (4 * 51, 512)), ("fc_categorical.bias", (4 * 51,))]
+        cfg.random_action_prob = d.LinearSchedule(1.0, 1.0, 10)          # epsilon == 1 throughout
+        cfg.batch_size, cfg.discount, cfg.history_length = 32, 0.99, 4
+        kw = dict(memory_size=300, batch_size=32, n_step=1, discount=0.99, history_length=4)
+        cfg.replay_fn = lambda: d.ReplayWrapper(cfg.replay_cls, kw, cfg.async_replay)
+        cfg.state_normalizer, cfg.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
+        cfg.target_network_update_freq, cfg.exploration_steps, cfg.sgd_update_frequency = 5, 40, 4
+        cfg.gradient_clip, cfg.double_q, cfg.async_actor, cfg.max_steps = 5, False, async_actor, 1e5
+        d.random_seed(3)
+        random.seed(3)
+        agent = cls(cfg)
+        assert agent._pipe is not None and agent._pipe.async_actor == async_actor and agent._pipe.per == per
+        agent._pipe.rs = np.random.RandomState(77)          # the actor's randint / rand stream, identical in both modes
+        np.random.seed(5)                                   # uniform index draws (the async constructor drew its actor seed)
+        p_np = fake_envs.numpy_params(fake_envs.NATURE_SHAPES + head, 17)
+        agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
+        agent.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
+        agent._learner.invalidate_actor_copy()
+        n_steps = 100
+        for _ in range(n_steps):
+            agent.step()
+        agent._learner.synchronize()
+        torch.cuda.synchronize()
+        rp = agent.replay.replay
+        # the async actor is one agent step ahead: compare the transitions both runs have REPORTED (ring slots of the first
+        # n_steps * 4 transitions; with a 300-slot ring that is the whole ring minus the 4 newest slots of the async run)
+        total = agent.total_steps
+        frames, actions, rewards, masks = rp._ring.pointers()
+        w = d.ops._wrap_device_pointer
+        outs.append(dict(total=total, pos=rp.pos, size=rp.size(),
+                         act=w(actions, 300, torch.int64).cpu().numpy().copy(), rew=w(rewards, 300, torch.float64).cpu().numpy().copy(),
+                         tree=rp.tree.as_tensor().cpu().numpy().copy() if per else np.zeros(1),
+                         maxp=float(rp.max_priority) if per else 0.0, np_rng=np.random.randint(0, 1 << 30, size=2),
+                         params={k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()},
+                         py_rng=[random.getrandbits(30) for _ in range(2)]))
+        agent.close()
+    a, b = outs
+    assert a["total"] == b["total"] and a["pos"] == b["pos"] and a["size"] == b["size"]
+    assert a["py_rng"] == b["py_rng"]                       # same number of prioritized draws / paddings
+    assert np.array_equal(a["np_rng"], b["np_rng"])         # ... and of uniform index draws
+    newest = [(a["pos"] + k) % 300 for k in range(4)]        # slots the async run's extra actor step has already rewritten
+    keep = np.ones(300, dtype=bool)
+    keep[newest] = False
+    assert np.array_equal(a["act"][keep], b["act"][keep]) and np.array_equal(a["rew"][keep], b["rew"][keep])
+    assert np.array_equal(a["tree"], b["tree"]) and a["maxp"] == b["maxp"]
+    for k in a["params"]:
+        assert np.array_equal(a["params"][k], b["params"][k]), k

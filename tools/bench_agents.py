@@ -36,7 +36,7 @@ class _Quiet:
         pass
 
 
-def dqn_family(kind, replay_cls, ring=200_000, fused=True, device=False):
+def dqn_family(kind, replay_cls, ring=200_000, fused=True, device=False, async_actor=None):
     c = d.Config()
     c.merge(dict(game="synthetic-atari", log_level=0, tag="bench", n_step=1, replay_cls=replay_cls, async_replay=False,
                  fused_learner=fused, device_env=device))     # device=False: HOST emulator; True: device-resident environment
@@ -73,7 +73,7 @@ def dqn_family(kind, replay_cls, ring=200_000, fused=True, device=False):
     c.exploration_steps = 300          # the update phase is what is timed
     c.sgd_update_frequency = 4
     c.double_q = False
-    c.async_actor = bool(device)       # the reference's default for the pixel DQN family (PrioritizedReplay: in order anyway)
+    c.async_actor = bool(device) if async_actor is None else bool(async_actor)   # the reference's default for the pixel DQN family
     c.max_steps = int(2e7)
     return agent_cls(c), dict(env_per_step=4, updates_per_step=1)
 
@@ -137,6 +137,8 @@ CASES = {
     "c51_pixel_per": lambda: dqn_family("c51", d.PrioritizedReplay),
     "qr_dqn_pixel_uniform": lambda: dqn_family("qr", d.UniformReplay),
     "dqn_pixel_per_device": lambda: dqn_family("dqn", d.PrioritizedReplay, device=True),
+    "dqn_pixel_per_device_sync": lambda: dqn_family("dqn", d.PrioritizedReplay, device=True, async_actor=False),
+    "dqn_pixel_uniform_device": lambda: dqn_family("dqn", d.UniformReplay, device=True),
     "c51_pixel_uniform_device": lambda: dqn_family("c51", d.UniformReplay, device=True),
     "c51_pixel_per_device": lambda: dqn_family("c51", d.PrioritizedReplay, device=True),
     "qr_dqn_pixel_uniform_device": lambda: dqn_family("qr", d.UniformReplay, device=True),
@@ -175,6 +177,12 @@ def main():
                               "updates_per_s": round(n * meta["updates_per_step"] / dt, 1)}), flush=True)
             if hasattr(agent, "close"):
                 agent.close()
+            if os.environ.get("BENCH_AGENTS_SETTLE"):
+                del agent
+                import gc
+                gc.collect()
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
         except Exception as e:
             import traceback
             print(json.dumps({"case": name, "error": repr(e), "trace": traceback.format_exc()[-600:]}), flush=True)
