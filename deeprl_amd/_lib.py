@@ -90,6 +90,8 @@ def _describe(rc):
         return " (invalid argument)"
     if rc == -12:
         return " (out of host memory)"
+    if rc == -110:
+        return " (a device-side grid barrier timed out: the cooperative optimizer's workgroups were not co-resident)"
     if rc == 100:
         return " (hipErrorNoDevice: deeprl_amd needs an MI355X; there is no CPU path)"
     if rc == 2:

@@ -86,8 +86,10 @@ int dra_conv_b1_split(int layer, const float* x0, const float* x1, const float* 
 
 // conv_v2.hip / fused.hip (library-internal): conv1 of the update reading its uint8 minibatch straight from the replay ring
 // (sample b = the 4 frames ending at slot idx[b] + newest_off): forward for nz nets, and the weight gradient
-// (idx may be pinned host memory; idx_copy, optional: device copy of it written on the way, for the update's later kernels)
-int dra_conv1_fwd_koc_ringbatch(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* newest_off, int nz,
+// (idx may be pinned host memory; idx_copy, optional: device copy of it written on the way, for the update's later kernels;
+// idx_tagged + update_seq, optional: the step-tagged device copy a previous update prefetched, ConvV2Args::sample_idx_tagged)
+int dra_conv1_fwd_koc_ringbatch(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* idx_tagged,
+                                const unsigned long long* update_seq, const int64_t* newest_off, int nz,
                                 const float* const* wt, const float* const* bias, float* const* y, int batch, double u8_coef, int act,
                                 void* stream);
 int dra_conv1_wgrad_ringbatch(const float* dy, const void* frames, const int64_t* idx, float* dw_slabs, float* db_slabs,

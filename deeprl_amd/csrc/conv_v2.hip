@@ -90,6 +90,12 @@ struct ConvV2Args {
   // optional: sample_idx may live in pinned HOST memory (one PCIe read per workgroup, ~1 us inside the operand phase); the
   // first workgroup of every sample leaves a copy here (device memory) for the later kernels of the same update
   int64_t* sample_idx_copy = nullptr;
+  // optional (DRA_VAR_IDX_PREFETCH): a device copy of sample_idx left by the PREVIOUS update's head kernel, every element
+  // tagged in its bits 63:40 with (number of the update it belongs to + 1) mod 2^24; *sample_seq = updates completed so far.
+  // An element whose tag matches is used as is (a device load instead of the PCIe read in front of the frame loads);
+  // otherwise (the host had not written the indices yet when the prefetch ran) sample_idx is read as before
+  const int64_t* sample_idx_tagged = nullptr;
+  const unsigned long long* sample_seq = nullptr;
 };
 
 __device__ __forceinline__ float v2_act(float v, int act) {
@@ -255,12 +261,22 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
     }
     bool generated = false;      // fused mode 2: the newest channel is produced by the environment step below
     if constexpr (FUSE) generated = f.mode == 2;
+    int64_t si = 0;              // ring-direct minibatch: the sampled slot of this workgroup's transition
+    if (a.sample_idx) {
+      if (a.sample_idx_tagged) {
+        const int64_t tv = a.sample_idx_tagged[bi];
+        const unsigned long long want = (*a.sample_seq + 1ull) & 0xffffffull;
+        if ((unsigned long long)tv >> 40 == want) si = tv & ((1ll << 40) - 1);
+        else si = a.sample_idx[bi];
+      } else {
+        si = a.sample_idx[bi];
+      }
+    }
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
       const int c = wc + CW * ci;
       int64_t img = (int64_t)bi * G::C + min(c, G::C - 1);       // image index in a plain NCHW batch
       if (a.sample_idx) {                                        // ... or a run of ring slots
-        const int64_t si = a.sample_idx[bi];
         img = si + a.idx_bias[z] + min(c, G::C - 1);
         if (a.sample_idx_copy && ci == 0 && tid == 0 && grp == 0 && z == 0 && blockIdx.y == 0) a.sample_idx_copy[bi] = si;
       }
@@ -884,10 +900,12 @@ DRA_API int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const floa
 
 // conv1 of the UPDATE straight from the replay ring (library-internal, actor_env.h): net z of sample b convolves the 4 ring
 // frames ending at slot idx[b] + newest_off[z] (online(states): 0, target / online(next_states): n_step).
-int dra_conv1_fwd_koc_ringbatch(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* newest_off, int nz,
+int dra_conv1_fwd_koc_ringbatch(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* idx_tagged,
+                                const unsigned long long* update_seq, const int64_t* newest_off, int nz,
                                 const float* const* wt, const float* const* bias, float* const* y, int batch, double u8_coef, int act,
                                 void* stream) {
   if (!frames || !idx || !newest_off || nz < 1 || nz > DRA_MAX_Z || batch < 1 || !wt || !bias || !y) return DRA_EINVAL;
+  if ((idx_tagged != nullptr) != (update_seq != nullptr)) return DRA_EINVAL;
   ConvV2Args a;
   for (int z = 0; z < nz; ++z) {
     if (!wt[z] || !bias[z] || !y[z]) return DRA_EINVAL;
@@ -896,6 +914,8 @@ int dra_conv1_fwd_koc_ringbatch(const void* frames, const int64_t* idx, int64_t*
   }
   a.sample_idx = idx;
   a.sample_idx_copy = idx_copy;
+  a.sample_idx_tagged = idx_tagged;
+  a.sample_seq = update_seq;
   a.batch = batch; a.act = act; a.coef = u8_coef; a.ring_slot = nullptr; a.ring_cap = 0; a.stack_age = nullptr;
   a.slot_seq = nullptr; a.slot_entries = 0; a.slot_stride = 0; a.newest_frame = nullptr;
   return launch_conv_v2_pt<VG1, true, 1>(a, nz, dra_stream(stream));

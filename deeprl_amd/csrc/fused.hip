@@ -211,7 +211,7 @@ DRA_API int dra_fc_bwd_fused(const float* dq, const float* h4, const float* dh4,
 DRA_API int dra_linear_fwd_slabs_one(int nz, const float* const* x, const float* const* w, int batch, int in_features,
                                      int out_features, int ksplit, float* slabs, void* stream) {
   if (nz < 1 || nz > kMaxZ || batch < 1 || !x || !w || !slabs) return DRA_EINVAL;
-  if (in_features != 3136 || (ksplit != 8 && ksplit != 28) || out_features < 1) return DRA_EINVAL;
+  if (in_features != 3136 || (ksplit != 8 && ksplit != 14 && ksplit != 28) || out_features < 1) return DRA_EINVAL;
   for (int z = 0; z < nz; ++z) {
     if (!x[z] || !w[z]) return DRA_EINVAL;
     if ((((uintptr_t)x[z]) | ((uintptr_t)w[z])) & 15) return DRA_EINVAL;
@@ -227,6 +227,11 @@ DRA_API int dra_linear_fwd_slabs_one(int nz, const float* const* x, const float*
     LinFwdSlabsOne<3136, 28, NT> r;
     fill(r);
     return launch_multi(r, r.tiles_n * r.tiles_m * 28 * nz, none, 0, none, 0, dra_stream(stream));
+  }
+  if (ksplit == 14) {   // 224-wide K slices: 224 workgroups at batch 32 and two nets, 86 KB of LDS each (one per CU)
+    LinFwdSlabsOne<3136, 14, NT> r;
+    fill(r);
+    return launch_multi(r, r.tiles_n * r.tiles_m * 14 * nz, none, 0, none, 0, dra_stream(stream));
   }
   LinFwdSlabsOne<3136, 8, NT> r;
   fill(r);

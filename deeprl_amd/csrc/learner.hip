@@ -40,6 +40,8 @@ enum { P_W1, P_B1, P_W2, P_B2, P_W3, P_B3, P_W4, P_B4, P_WH, P_BH, P_COUNT };
 constexpr int kFc4Split = 8;     // split-K of the 3136 -> 512 layer (slabs reduced inside head_fused_kernel)
 constexpr int kFc4SplitWide = 28; // ... of the one-pass forward when DRA_FC4_KS=28: 448 workgroups of 112-wide K slices
                                   // instead of 128 of 392 (the layer streams 12.8 MB of weights: more CUs pulling)
+constexpr int kFc4SplitMid = 14;  // ... DRA_FC4_KS=14: 224 workgroups of 224-wide slices for two nets -- one per CU of the 224-CU
+                                  // update partition (a CU's share of HBM is ~32 GB/s: 128 workgroups leave 96 CUs idle)
 static int fc4_ks(const struct dra_dqn_learner* l);
 constexpr int kAprmSlots = 16;
 
@@ -166,6 +168,19 @@ struct dra_dqn_learner {
   hipEvent_t actor_last = nullptr;  // GATHER_ON_UPDATE: recorded after the most recent actor launch (a staging-slot event)
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
+  // DRA_VAR_COOP_OPT: slab fold + gradient norm + optimiser as one launch behind a grid barrier (optim.hip clip_step_kernel).
+  // Used only when the launch's grid fits the workgroup slots of the update stream's CUs (dra_dqn_learner_set_update_cus).
+  unsigned long long* coop_ctr;     // device: the barrier's ever-growing ticket counter
+  int* coop_flag;                   // pinned host: set by a workgroup whose barrier wait timed out
+  int coop_limit;                   // co-resident workgroups assumed available (0: unknown -> two-launch form)
+  // DRA_VAR_IDX_PREFETCH (ring-direct pipeline): step-tagged copies of the minibatch indices -- pinned (written by the host
+  // with the indices), device (copied by the head kernel of the PREVIOUS update), and the device count of completed updates
+  int64_t* idx_tag_pin[4];
+  int64_t* idx_tag_dev;             // [4][1024]
+  unsigned long long* rd_seq_dev;   // ring-direct updates completed (bumped by each one's head kernel)
+  uint64_t rd_issued;               // ring-direct updates issued (host)
+  bool coop;                        // decided once, before the first graph capture
+  bool captured;                    // some graph has been captured (the decision above is baked into it)
 };
 
 struct HeadSpec;
@@ -173,7 +188,11 @@ static HeadSpec head_spec(const dra_dqn_learner* l);
 
 static int fc4_ks(const dra_dqn_learner* l) {   // K slices of the update's fc4 forward (one-pass kernel only)
   static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_FC4_KS"); v = (e && atoi(e) == kFc4SplitWide) ? kFc4SplitWide : kFc4Split; }
+  if (v < 0) {
+    const char* e = getenv("DRA_FC4_KS");
+    const int want = e ? atoi(e) : kFc4Split;
+    v = (want == kFc4SplitWide || want == kFc4SplitMid) ? want : kFc4Split;
+  }
   return (l->variant & DRA_VAR_ONESHOT_FWD) ? v : kFc4Split;
 }
 
@@ -331,6 +350,23 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= alloc_f(&l->lin_ws, l->lin_ws_floats);
   rc |= (int)hipMalloc(&l->partials, (size_t)dra_norm_partials_max() * sizeof(double));
   rc |= alloc_f(&l->loss, 1); rc |= alloc_f(&l->norm, 1);
+  if (l->variant & DRA_VAR_IDX_PREFETCH) {
+    if (!(l->variant & DRA_VAR_RING_DIRECT) || cfg->ring_capacity >= (1ll << 40)) l->variant &= ~DRA_VAR_IDX_PREFETCH;
+  }
+  if (l->variant & DRA_VAR_IDX_PREFETCH) {
+    for (int k = 0; k < 4; ++k) {
+      rc |= (int)hipHostMalloc(&l->idx_tag_pin[k], (size_t)1024 * sizeof(int64_t), hipHostMallocDefault);
+      if (!rc) memset(l->idx_tag_pin[k], 0, (size_t)1024 * sizeof(int64_t));
+    }
+    rc |= (int)hipMalloc(&l->idx_tag_dev, (size_t)4 * 1024 * sizeof(int64_t));
+    if (!rc) rc |= (int)hipMemset(l->idx_tag_dev, 0, (size_t)4 * 1024 * sizeof(int64_t));
+    rc |= (int)hipMalloc(&l->rd_seq_dev, sizeof(unsigned long long));
+    if (!rc) rc |= (int)hipMemset(l->rd_seq_dev, 0, sizeof(unsigned long long));
+  }
+  rc |= (int)hipMalloc(&l->coop_ctr, sizeof(unsigned long long));
+  if (!rc) rc |= (int)hipMemset(l->coop_ctr, 0, sizeof(unsigned long long));
+  rc |= (int)hipHostMalloc(&l->coop_flag, sizeof(int), hipHostMallocDefault);
+  if (!rc) *l->coop_flag = 0;
   rc |= (int)hipMalloc(&l->prm_dev, sizeof(dra_dqn_step_params));
   rc |= (int)hipHostMalloc(&l->prm_stage, 8 * sizeof(dra_dqn_step_params), hipHostMallocDefault);
   rc |= (int)hipHostMalloc(&l->idx_stage, (size_t)8 * 1024 * sizeof(int64_t), hipHostMallocDefault);
@@ -415,6 +451,11 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
     if (l->g_rd_per_ready[k]) { (void)hipGraphExecDestroy(l->g_rd_per[k]); (void)hipGraphExecDestroy(l->g_rd_per_b[k]); }
     (void)hipEventDestroy(l->ev_upd[k]);
   }
+  for (int k = 0; k < 4; ++k) if (l->idx_tag_pin[k]) (void)hipHostFree(l->idx_tag_pin[k]);
+  if (l->idx_tag_dev) (void)hipFree(l->idx_tag_dev);
+  if (l->rd_seq_dev) (void)hipFree(l->rd_seq_dev);
+  if (l->coop_ctr) (void)hipFree(l->coop_ctr);
+  if (l->coop_flag) (void)hipHostFree(l->coop_flag);
   if (l->qs_stage) (void)hipHostFree(l->qs_stage);
   if (l->q_stage) (void)hipHostFree(l->q_stage);
   if (l->g_q_ready) (void)hipGraphExecDestroy(l->g_q);
@@ -460,6 +501,9 @@ struct RingScalars {
   int n_step;
   double discount;
   int64_t* out_action; float* out_reward; float* out_mask;   // the learner's minibatch scalar buffers, filled on the way
+  // DRA_VAR_IDX_PREFETCH: workgroup b copies element b of the NEXT update's tagged indices (pinned host) to the device and
+  // workgroup 0 counts this update as done (conv1 of the next update compares tags with the count: ConvV2Args)
+  const int64_t* pf_src; int64_t* pf_dst; unsigned long long* seq;
 };
 
 struct HeadSpec {
@@ -588,6 +632,8 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
   }
   int64_t ab;
   float rew_b, mask_b;
+  int64_t pf = 0;
+  if (rs.pf_src && tid == 0) pf = rs.pf_src[b];   // (PCIe read: requested first, stored at the very end)
   if (rs.idx) {
     // DRA_VAR_RING_DIRECT: action / n-step reward / mask of the sampled transition straight from the replay ring, folded as
     // ring_gather_kernel does (replay.py:133-139, fp64, the reference's association), then f32 as tensor() would
@@ -688,6 +734,10 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
     dh4[(int64_t)b * 512 + k] = s_h[0][k] > 0.f ? dqa * dwh[rep] : 0.f;
   }
   if (opt_step && b == 0 && tid == 0) *opt_step += 1;   // one optimizer step per update (Adam's t)
+  if (rs.pf_src && tid == 0) {
+    rs.pf_dst[b] = pf;
+    if (b == 0) *rs.seq += 1ull;
+  }
   DRA_STAMP(TR_HEAD, 5);
   DRA_STAMP_END(TR_HEAD);
 }
@@ -731,8 +781,62 @@ static int launch_gather(dra_dqn_learner* l, hipStream_t st, const int64_t* idx 
                          l->reward_[l->gb], l->mask_[l->gb], (void*)st);
 }
 
+// the three conv layers' slab segments of the flat gradient (one-pass weight gradients)
+static void conv_fold_segs(const dra_dqn_learner* l, dra_fold_seg segs[3]) {
+  const int wi[3] = {P_W1, P_W2, P_W3};
+  for (int k = 0; k < 3; ++k) {
+    segs[k].begin = l->c.offset[wi[k]]; segs[k].count = l->lstride[k]; segs[k].slabs = l->lslabs[k];
+    segs[k].slab_stride = l->lstride[k]; segs[k].n_slabs = l->lnslabs[k]; segs[k].reserved = 0;
+  }
+}
+
+// The CUs the update stream may use (the host created it, possibly CU-masked).  With DRA_VAR_COOP_OPT this decides whether
+// fold + norm + optimiser run as ONE cooperative launch: its grid must fit the workgroup slots of those CUs (a grid
+// barrier needs every workgroup resident).  Call before the first update; later calls are refused (graphs bake the choice).
+DRA_API int dra_dqn_learner_set_update_cus(dra_dqn_learner* l, int n_cus) {
+  if (!l || n_cus < 1) return DRA_EINVAL;
+  if (l->captured) return DRA_EINVAL;
+  l->coop = false;
+  l->coop_limit = 0;
+  if (!(l->variant & DRA_VAR_COOP_OPT) || !(l->variant & DRA_VAR_ONESHOT_WGRAD)) return DRA_OK;
+  int per_cu = 0, blocks = 0;
+  int rc = dra_clip_step_coop_occupancy(l->c.optimizer, &per_cu);
+  if (rc) return rc;
+  dra_fold_seg segs[3];
+  conv_fold_segs(l, segs);
+  if (dra_clip_step_coop_blocks(l->c.n_params, segs, 3, &blocks) != DRA_OK) return DRA_OK;   // layout not supported: two launches
+  l->coop_limit = per_cu * n_cus;
+  l->coop = blocks <= l->coop_limit;
+  return DRA_OK;
+}
+
+// 1 = the cooperative optimizer launch is in use, 0 = the two-launch form
+DRA_API int dra_dqn_learner_coop_state(dra_dqn_learner* l, int* coop, int* blocks, int* resident_limit) {
+  if (!l) return DRA_EINVAL;
+  if (coop) *coop = l->coop ? 1 : 0;
+  if (resident_limit) *resident_limit = l->coop_limit;
+  if (blocks) {
+    *blocks = 0;
+    if (l->variant & DRA_VAR_ONESHOT_WGRAD) {
+      dra_fold_seg segs[3];
+      conv_fold_segs(l, segs);
+      (void)dra_clip_step_coop_blocks(l->c.n_params, segs, 3, blocks);
+    }
+  }
+  return DRA_OK;
+}
+
 static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = nullptr) {
   const dra_dqn_config& c = l->c;
+  if (l->coop) {
+    dra_fold_seg segs[3];
+    conv_fold_segs(l, segs);
+    const bool adam = c.optimizer == DRA_OPT_ADAM;
+    const float hyper[4] = {c.lr, adam ? c.beta1 : c.alpha, c.eps, adam ? c.beta2 : 0.f};
+    return dra_clip_step_coop(l->p, l->g, l->s1, l->s2, c.n_params, segs, 3, l->partials, l->coop_ctr, l->coop_flag,
+                              l->coop_limit, c.optimizer, c.gradient_clip, hyper, c.centered, l->opt_step, l->norm, p_copy,
+                              (void*)st);
+  }
   if (c.optimizer == DRA_OPT_ADAM)
     return dra_adam_step_counter(l->p, l->g, l->s1, l->s2, c.n_params, l->partials, l->n_partials, c.gradient_clip, c.lr,
                                  c.beta1, c.beta2, c.eps, l->opt_step, l->norm, p_copy, (void*)st);
@@ -790,6 +894,9 @@ static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta
   if (fc4_ks(l) == kFc4SplitWide)
     hipLaunchKernelGGL(fc4_reduce_kernel<kFc4SplitWide>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
                        T + o[P_B4], l->h4, l->opt_step);
+  else if (fc4_ks(l) == kFc4SplitMid)
+    hipLaunchKernelGGL(fc4_reduce_kernel<kFc4SplitMid>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
+                       T + o[P_B4], l->h4, l->opt_step);
   else
     hipLaunchKernelGGL(fc4_reduce_kernel<kFc4Split>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
                        T + o[P_B4], l->h4, l->opt_step);
@@ -834,6 +941,7 @@ static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta
 // that the priority write-back and the next prioritized draw start under the backward pass.
 static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int fork, int part = 0) {
   const dra_dqn_config& c = l->c;
+  l->captured = true;   // (the optimizer form is now fixed: dra_dqn_learner_set_update_cus)
   const int B = c.batch, A = c.n_actions;
   const int nz = c.double_q ? 3 : 2;
   void* s = (void*)st;
@@ -862,8 +970,10 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     const int64_t off[3] = {0, ring_n, ring_n};
     // (the indices sit in pinned host memory: conv1's workgroups pay the one PCIe read and leave a device copy in l->idx
     // for the head and the weight-gradient kernels of this update)
-    STEP(K_CONV1_F, dra_conv1_fwd_koc_ringbatch(ring_frames, l->idx_pin[l->rd_slot], l->idx, off, nz, w1, b1, l->y1, B, c.u8_coef,
-                                                DRA_ACT_RELU, s));
+    const bool pf = l->variant & DRA_VAR_IDX_PREFETCH;
+    STEP(K_CONV1_F, dra_conv1_fwd_koc_ringbatch(ring_frames, l->idx_pin[l->rd_slot], l->idx,
+                                                pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr,
+                                                off, nz, w1, b1, l->y1, B, c.u8_coef, DRA_ACT_RELU, s));
   } else {
     STEP(K_CONV1_F, dra_conv_fwd_koc(1, nz, x1, w1, b1, l->y1, B, 1, c.u8_coef, DRA_ACT_RELU, s));
   }
@@ -891,9 +1001,19 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       rs.idx = l->idx; rs.actions = (const uint8_t*)ring_actions; rs.rewards = (const double*)ring_rewards;
       rs.masks = (const int32_t*)ring_masks; rs.n_step = ring_n; rs.discount = ring_discount;
       rs.out_action = l->action_[l->gb]; rs.out_reward = l->reward_[l->gb]; rs.out_mask = l->mask_[l->gb];
+      if (l->variant & DRA_VAR_IDX_PREFETCH) {
+        const int qn = (l->rd_slot + 1) & 3;
+        rs.pf_src = l->idx_tag_pin[qn]; rs.pf_dst = l->idx_tag_dev + (size_t)qn * 1024; rs.seq = l->rd_seq_dev;
+      }
     }
     if (ks4 == kFc4SplitWide)
       hipLaunchKernelGGL(head_fused_kernel<kFc4SplitWide>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
+                         P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
+                         (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
+                         c.double_q,
+                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs);
+    else if (ks4 == kFc4SplitMid)
+      hipLaunchKernelGGL(head_fused_kernel<kFc4SplitMid>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                          P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
                          (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
                          c.double_q,
@@ -947,11 +1067,12 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
                                           B, 1, c.u8_coef, DRA_ACT_RELU, var, s));
     }
     if (own) {
-      dra_fold_seg segs[3];
-      for (int k = 0; k < 3; ++k) {
-        segs[k].begin = o[wi[k]]; segs[k].count = l->lstride[k]; segs[k].slabs = l->lslabs[k];
-        segs[k].slab_stride = l->lstride[k]; segs[k].n_slabs = l->lnslabs[k]; segs[k].reserved = 0;
+      if (l->coop) {   // fold + norm happen inside the optimizer launch (launch_optimizer)
+        if (l->profiling) { DRA_HIP(hipEventRecord(l->ev[K_NORM], st)); DRA_HIP(hipEventRecord(l->ev[K_STEP], st)); }
+        return DRA_OK;
       }
+      dra_fold_seg segs[3];
+      conv_fold_segs(l, segs);
       int np_out = 0;
       STEP(K_NORM, dra_grad_sqnorm_segs(G, c.n_params, segs, 3, l->partials, &np_out, s));
       l->n_partials = np_out;
@@ -1099,6 +1220,7 @@ DRA_API int dra_dqn_learner_keep_minibatch(dra_dqn_learner* l, int keep) {
 // is a kernel argument that changes per update); the stream must not be the NULL stream.
 DRA_API int dra_dqn_learner_update(dra_dqn_learner* l, int use_graph, int per, float beta, void* stream) {
   if (!l) return DRA_EINVAL;
+  if (*l->coop_flag) return DRA_ETIMEDOUT;
   hipStream_t st = dra_stream(stream);
   l->profiling = false;
   l->pa_valid = false;
@@ -1341,6 +1463,60 @@ actor_fc4_planes_kernel(const float* __restrict__ x0, const float* __restrict__ 
     float4 b;
     b.x = fmaxf(av[q].x + cv[q].x, 0.f); b.y = fmaxf(av[q].y + cv[q].y, 0.f);
     b.z = fmaxf(av[q].z + cv[q].z, 0.f); b.w = fmaxf(av[q].w + cv[q].w, 0.f);
+    if (lane + 64 * q < nv) acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const float v = acc + bias[row];
+    h4[row] = v > 0.f ? v : 0.f;
+  }
+  DRA_STAMP(TR_A_FC4, 5);
+  DRA_STAMP_END(TR_A_FC4);
+}
+
+// The same GEMV with x = relu(x0 + x1) formed ONCE per workgroup and staged in LDS (12.5 KB) instead of both planes in every
+// lane's registers: 13 float4 of weights + a few transient registers per lane, so that a CU keeps >= 4 of these workgroups
+// resident -- the 128 workgroups are ONE round on the actor's 32 CUs (the register-resident form ran 64 + 32 + 32: phase
+// trace profiles/r02zj_phase_async_acu32.json, 7.7 us per env step for 3.3 us workgroups).  Same products, same order.
+__global__ void __launch_bounds__(256)
+actor_fc4_planes_lds_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ w,
+                            const float* __restrict__ bias, float* __restrict__ h4, int in_features) {
+  constexpr int R = 13, NVMAX = 784;  // 3136 / 4 float4; per lane 3136 / 4 / 64 = 12.25
+  __shared__ float4 s_x[NVMAX];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  const int nv = in_features >> 2;
+  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w + (int64_t)row * in_features);
+  const float4* __restrict__ a4 = reinterpret_cast<const float4*>(x0);
+  const float4* __restrict__ c4 = reinterpret_cast<const float4*>(x1);
+  DRA_STAMP(TR_A_FC4, 0);
+  float4 wv[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) wv[q] = w4[min(lane + 64 * q, nv - 1)];
+  constexpr int XQ = (NVMAX + 255) / 256;
+  float4 av[XQ], cv[XQ];
+#pragma unroll
+  for (int q = 0; q < XQ; ++q) {
+    const int i = min((int)threadIdx.x + 256 * q, nv - 1);
+    av[q] = a4[i];
+    cv[q] = c4[i];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < XQ; ++q) {
+    const int i = (int)threadIdx.x + 256 * q;
+    float4 b;
+    b.x = fmaxf(av[q].x + cv[q].x, 0.f); b.y = fmaxf(av[q].y + cv[q].y, 0.f);
+    b.z = fmaxf(av[q].z + cv[q].z, 0.f); b.w = fmaxf(av[q].w + cv[q].w, 0.f);
+    if (i < nv) s_x[i] = b;
+  }
+  __syncthreads();
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    float4 a = wv[q];
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));  // loads stay unconditional and batched
+    const float4 b = s_x[min(lane + 64 * q, nv - 1)];
     if (lane + 64 * q < nv) acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
   }
   acc = wave_sum(acc);
@@ -1724,8 +1900,14 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
       // ReLU) by the consumer's staging (conv_v2.hip conv_b1_split_kernel)
       if ((rc = dra_conv_b1_split(2, l->ay1, nullptr, P + o[P_W2], P + o[P_B2], l->ay2p, s))) return rc;
       if ((rc = dra_conv_b1_split(3, l->ay2p, l->ay2p + 64 * 81, P + o[P_W3], P + o[P_B3], l->ay3p, s))) return rc;
-      hipLaunchKernelGGL(actor_fc4_planes_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3p, (const float*)(l->ay3p + 64 * 49),
-                         P + o[P_W4], P + o[P_B4], l->ah4, 3136);
+      static int fc4_lds = -1;   // DRA_ACTOR_FC4_LDS=1: the input staged through LDS (one round of workgroups on the actor's CUs)
+      if (fc4_lds < 0) { const char* e = getenv("DRA_ACTOR_FC4_LDS"); fc4_lds = e ? atoi(e) : 0; }
+      if (fc4_lds)
+        hipLaunchKernelGGL(actor_fc4_planes_lds_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3p,
+                           (const float*)(l->ay3p + 64 * 49), P + o[P_W4], P + o[P_B4], l->ah4, 3136);
+      else
+        hipLaunchKernelGGL(actor_fc4_planes_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3p, (const float*)(l->ay3p + 64 * 49),
+                           P + o[P_W4], P + o[P_B4], l->ah4, 3136);
       DRA_LAUNCH_CHECK();
       continue;
     }
@@ -2146,6 +2328,12 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
         l->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
       memcpy(l->idx_pin[q], prm->idx, (size_t)B * sizeof(int64_t));
+      if (l->variant & DRA_VAR_IDX_PREFETCH) {   // element-wise 8-byte stores: the device may read the buffer at any time
+        const uint64_t tag = ((l->rd_issued + 1ull) & 0xffffffull) << 40;
+        volatile int64_t* dst = l->idx_tag_pin[q];
+        for (int b = 0; b < B; ++b) dst[b] = (int64_t)((uint64_t)prm->idx[b] | tag);
+      }
+      l->rd_issued++;
       TRACE(0, su);
       if (l->keep_minibatch) {
         l->gb = par;
@@ -2353,6 +2541,7 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
 DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, void* stream_update,
                                  void* stream_actor) {
   if (!l || !prm || prm->n_env < 0 || prm->n_env > kMaxEnvSteps) return DRA_EINVAL;
+  if (*l->coop_flag) return DRA_ETIMEDOUT;   // a grid barrier of the cooperative optimizer timed out: results are invalid
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = learner_step_impl(l, prm, do_update, stream_update, stream_actor);
   l->host_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

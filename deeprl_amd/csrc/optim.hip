@@ -65,139 +65,12 @@ DRA_API int dra_grad_sqnorm(float* grad, int64_t n, const float* slabs, int n_sl
   return DRA_OK;
 }
 
-// ---- segmented variant: ONE launch for the whole flat gradient when the conv layers keep a different
-// number of split-K slabs each (one-pass weight gradients write one slab per (sample, row chunk):
-// 32-160 slabs).  Folding 160 slabs serially per element would be 160 dependent-ish loads, so a fold
-// workgroup is 16 slab groups x 16 float4 elements: thread (g, el) sums slabs g, g+16, ... (all loads
-// in flight), the 16 group partials meet in LDS and are added in group order -> the result is
-// deterministic and the fold costs one memory round trip.  Block ranges: [fold blocks of segment 0]
-// [segment 1] ... [plain blocks over the rest of the gradient]; every block writes one partial.
-struct FoldSegs {
-  int64_t begin[DRA_MAX_FOLD_SEGS];     // first float of the segment in `grad` (multiple of 4)
-  int64_t count[DRA_MAX_FOLD_SEGS];     // floats (multiple of 4)
-  const float* slabs[DRA_MAX_FOLD_SEGS];
-  int64_t stride[DRA_MAX_FOLD_SEGS];
-  int32_t n_slabs[DRA_MAX_FOLD_SEGS];
-  int32_t first_block[DRA_MAX_FOLD_SEGS + 1];  // block range of each segment; [n_segs] = first plain block
-  int32_t n_segs, plain_blocks;
-  int64_t plain_begin, plain_count;     // [plain_begin, plain_begin + plain_count): no slabs
-};
-
-__global__ void __launch_bounds__(256)
-grad_fold_norm_kernel(float* __restrict__ grad, const FoldSegs fs, double* __restrict__ partials) {
-  __shared__ float4 s_part[16][17];
-  __shared__ double s_red[4];
-  const int tid = threadIdx.x, bid = blockIdx.x;
-  float acc = 0.f;
-  DRA_STAMP(TR_NORM, 0);
-  if (bid < fs.first_block[fs.n_segs]) {
-    int sg = 0;
-    while (sg + 1 < fs.n_segs && bid >= fs.first_block[sg + 1]) ++sg;
-    const int nb = fs.first_block[sg + 1] - fs.first_block[sg], b = bid - fs.first_block[sg];
-    const int64_t n4 = fs.count[sg] >> 2;
-    const float4* __restrict__ sl = reinterpret_cast<const float4*>(fs.slabs[sg]);
-    const int64_t st4 = fs.stride[sg] >> 2;
-    const int ns = fs.n_slabs[sg];
-    float4* g4 = reinterpret_cast<float4*>(grad + fs.begin[sg]);
-    const int g = tid >> 4, el = tid & 15;
-    for (int64_t base = (int64_t)b * 16; base < n4; base += (int64_t)nb * 16) {
-      const int64_t i = base + el;
-      const int64_t ic = i < n4 ? i : n4 - 1;
-      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s0 = g; s0 < ns; s0 += 16 * 8) {  // up to 8 slabs of this group in flight per pass
-        float4 t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int s = s0 + 16 * u;
-          t[u] = sl[(int64_t)(s < ns ? s : g) * st4 + ic];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (s0 + 16 * u < ns) { p.x += t[u].x; p.y += t[u].y; p.z += t[u].z; p.w += t[u].w; }
-        }
-      }
-      s_part[g][el] = p;
-      __syncthreads();
-      if (g == 0) {
-        float4 r = s_part[0][el];
-#pragma unroll
-        for (int q = 1; q < 16; ++q) {
-          const float4 t = s_part[q][el];
-          r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
-        }
-        if (i < n4) {
-          g4[i] = r;
-          acc += r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
-        }
-      }
-      __syncthreads();
-    }
-  } else {
-    const int b = bid - fs.first_block[fs.n_segs];
-    const int64_t n4 = fs.plain_count >> 2;
-    const float4* g4 = reinterpret_cast<const float4*>(grad + fs.plain_begin);
-    const int64_t stride = (int64_t)fs.plain_blocks * 256;
-    for (int64_t i = (int64_t)b * 256 + tid; i < n4; i += stride) {
-      const float4 v = g4[i];
-      acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
-  }
-  DRA_STAMP(TR_NORM, 4);
-  double d = wave_sum((double)acc);
-  if ((tid & 63) == 0) s_red[tid >> 6] = d;
-  __syncthreads();
-  if (tid == 0) partials[bid] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-  DRA_STAMP(TR_NORM, 5);
-  DRA_STAMP_END(TR_NORM);
-}
-
-// grad[0, n): segments (contiguous from 0, 4-float aligned) are folded from their slabs
-// (grad[seg] = sum_s slabs[s*stride + i], fixed order) and everything after the last segment is read as
-// is; *n_partials doubles are written (<= dra_norm_partials_max()) -- pass that count to dra_*_step.
-DRA_API int dra_norm_partials_max(void) { return 2048; }
-
-DRA_API int dra_grad_sqnorm_segs(float* grad, int64_t n, const dra_fold_seg* segs, int n_segs, double* partials,
-                                 int* n_partials, void* stream) {
-  if (!grad || !partials || !n_partials || n < 4 || (n & 3) || n_segs < 0 || n_segs > DRA_MAX_FOLD_SEGS || (n_segs && !segs))
-    return DRA_EINVAL;
-  if (((uintptr_t)grad) & 15) return DRA_EINVAL;
-  FoldSegs fs;
-  memset(&fs, 0, sizeof(fs));
-  int64_t end = 0;
-  int blocks = 0;
-  for (int i = 0; i < n_segs; ++i) {
-    const dra_fold_seg& sg = segs[i];
-    if (sg.begin != end || (sg.begin & 3) || (sg.count & 3) || sg.count < 4 || sg.begin + sg.count > n || !sg.slabs ||
-        sg.n_slabs < 1 || (sg.slab_stride & 3) || (((uintptr_t)sg.slabs) & 15))
-      return DRA_EINVAL;
-    fs.begin[i] = sg.begin; fs.count[i] = sg.count; fs.slabs[i] = sg.slabs; fs.stride[i] = sg.slab_stride;
-    fs.n_slabs[i] = sg.n_slabs;
-    fs.first_block[i] = blocks;
-    int64_t nb = ((sg.count >> 2) + 15) / 16;  // one 16-element group per block, capped
-    if (nb > 320) nb = 320;
-    blocks += (int)nb;
-    end = sg.begin + sg.count;
-  }
-  fs.first_block[n_segs] = blocks;
-  fs.n_segs = n_segs;
-  fs.plain_begin = end; fs.plain_count = n - end;
-  int pb = 0;
-  if (fs.plain_count > 0) {
-    int64_t want = ((fs.plain_count >> 2) + 767) / 768;  // ~3 float4 per thread
-    pb = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
-  }
-  fs.plain_blocks = pb;
-  blocks += pb;
-  if (blocks < 1 || blocks > dra_norm_partials_max()) return DRA_EINVAL;
-  hipLaunchKernelGGL(grad_fold_norm_kernel, dim3(blocks), dim3(256), 0, dra_stream(stream), grad, fs, partials);
-  DRA_LAUNCH_CHECK();
-  *n_partials = blocks;
-  return DRA_OK;
-}
-
 // Fixed-order reduction of the partials by every workgroup; returns the clip coefficient.
-__device__ __forceinline__ float clip_coef_from_partials(const double* __restrict__ partials, int n_partials,
-                                                         float max_norm, float* __restrict__ out_norm) {
+// COHERENT: the partials were published by the other workgroups of THIS launch (agent-scope stores before a grid barrier):
+// read them with agent-scope loads, past this XCD's L2.
+template <bool COHERENT>
+__device__ __forceinline__ float clip_coef_impl(const double* __restrict__ partials, int n_partials, float max_norm,
+                                                float* __restrict__ out_norm) {
   if (!partials) return 1.f;  // uniform: no clipping requested
   __shared__ double s_part[4];
   __shared__ float s_coef;
@@ -209,7 +82,8 @@ __device__ __forceinline__ float clip_coef_from_partials(const double* __restric
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = (int)threadIdx.x + 256 * u;
-      v[u] = partials[i < n_partials ? i : n_partials - 1];
+      const double* src = partials + (i < n_partials ? i : n_partials - 1);
+      v[u] = COHERENT ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) d += ((int)threadIdx.x + 256 * u < n_partials) ? v[u] : 0.0;
@@ -229,6 +103,14 @@ __device__ __forceinline__ float clip_coef_from_partials(const double* __restric
   }
   __syncthreads();
   return s_coef;
+}
+
+__device__ __forceinline__ float clip_coef_from_partials(const double* __restrict__ partials, int n_partials,
+                                                         float max_norm, float* __restrict__ out_norm) {
+  return clip_coef_impl<false>(partials, n_partials, max_norm, out_norm);
+}
+__device__ __forceinline__ float clip_coef_coherent(const double* partials, int n_partials, float max_norm, float* out_norm) {
+  return clip_coef_impl<true>(partials, n_partials, max_norm, out_norm);
 }
 
 // torch.optim.RMSprop:  sq = a*sq + (1-a)*g*g ; centered: ga = a*ga + (1-a)*g,
@@ -251,6 +133,355 @@ __device__ __forceinline__ void rmsprop_elem(float& p, float g, float& s, float&
     avg = sqrtf(s) + eps;
   }
   p = p - lr * (gk / avg);
+}
+
+// ---- segmented fold + norm, and the same pass with the optimiser behind a grid barrier ----------------------------
+// The one-pass conv weight gradients write one slab per (sample, row chunk): 32-160 slabs per layer.  ONE work
+// decomposition serves two launches:
+//   MODE 0  fold + per-workgroup sums of squares -> partials (the optimiser is a second launch, dra_*_step);
+//   MODE 1/2  the same, then every workgroup publishes its partial, meets the others at a GRID BARRIER, reduces the
+//           partials in the fixed order and applies RMSprop / Adam to the elements it already holds in registers --
+//           one launch less on the update's dependent chain, the gradient is not re-read, and the loads of the
+//           parameters / optimiser state (issued before the barrier) overlap the fold.  Needs every workgroup
+//           co-resident: the launcher refuses grids larger than the caller's resident-workgroup limit.
+// Workgroup kinds (block ranges [fold blocks of segment 0][segment 1]...[plain blocks]); a fold workgroup is 16 slab
+// groups x 16 float4 elements per unit, thread (g, el) sums slabs g, g+16, ... in increasing order, the 16 group
+// partials meet in LDS and are added in group order: deterministic, and ONE memory round trip per workgroup:
+//   narrow (n_slabs <= 32): 4 units per workgroup, 2 slabs per thread and unit (8 float4 in flight)
+//   wide   (n_slabs  > 32): 1 unit per workgroup, 10 slabs per thread and pass (160 slabs = one pass)
+//   plain  (no slabs)     : 4 float4 per thread
+constexpr int kPlainNV = 4;
+constexpr int kWideL = 10;
+constexpr int kNarrowU = 4;
+constexpr unsigned long long kBarrierTicks = 5000000ull;   // 50 ms of s_memrealtime (100 MHz): a barrier that cannot
+                                                           // complete reports through the timeout flag instead of hanging
+
+struct FoldPlan {
+  int64_t begin4[DRA_MAX_FOLD_SEGS];     // first float4 of the segment in `grad`
+  int64_t count4[DRA_MAX_FOLD_SEGS];     // float4s
+  const float4* slabs[DRA_MAX_FOLD_SEGS];
+  int64_t stride4[DRA_MAX_FOLD_SEGS];
+  int32_t n_slabs[DRA_MAX_FOLD_SEGS];
+  int32_t first_block[DRA_MAX_FOLD_SEGS + 1];  // block range of each segment; [n_segs] = first plain block
+  int32_t n_segs, plain_blocks, plain_iters;   // plain_iters > 1 (MODE 0 only): a plain workgroup walks that many strides
+  int64_t plain_begin4, plain_count4;    // [plain_begin4, plain_begin4 + plain_count4): no slabs
+};
+
+struct StepHyper {
+  float max_norm, lr, a, b2, eps;        // a = alpha (RMSprop) / beta1 (Adam); b2 = beta2 (Adam)
+  int centered;
+  const int64_t* step_dev;               // Adam: 1-based step count in device memory
+};
+
+__device__ __forceinline__ float sq4(const float4& v) { return v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+__device__ __forceinline__ void add4(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+template <int MODE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+clip_step_kernel(float* __restrict__ grad, const FoldPlan fp, double* __restrict__ partials, float* __restrict__ p,
+                 float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ p_copy, const StepHyper hp,
+                 float* __restrict__ out_norm, unsigned long long* __restrict__ barrier, int* __restrict__ timeout_flag) {
+  __shared__ float4 s_part[kNarrowU][16][17];
+  __shared__ double s_red[4];
+  __shared__ float s_hyper[2];
+  const int tid = threadIdx.x, bid = blockIdx.x;
+  constexpr bool STEP = MODE != 0;
+  float acc = 0.f;
+  // what this thread holds across the barrier: up to kPlainNV float4 elements (global float4 index gi, -1 = none)
+  int64_t gi[kPlainNV];
+  float4 G[kPlainNV], P[kPlainNV], S[kPlainNV], A[kPlainNV];
+#pragma unroll
+  for (int v = 0; v < kPlainNV; ++v) gi[v] = -1;
+  float4* __restrict__ g4 = reinterpret_cast<float4*>(grad);
+  [[maybe_unused]] const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+  [[maybe_unused]] const float4* __restrict__ s14 = reinterpret_cast<const float4*>(s1);
+  [[maybe_unused]] const float4* __restrict__ s24 = reinterpret_cast<const float4*>((MODE == 1 && !hp.centered) ? s1 : s2);
+  DRA_STAMP(TR_NORM, 0);
+  if (bid < fp.first_block[fp.n_segs]) {
+    int sg = 0;
+    while (sg + 1 < fp.n_segs && bid >= fp.first_block[sg + 1]) ++sg;
+    const int b = bid - fp.first_block[sg];
+    const int64_t n4 = fp.count4[sg];
+    const float4* __restrict__ sl = fp.slabs[sg];
+    const int64_t st4 = fp.stride4[sg];
+    const int ns = fp.n_slabs[sg];
+    const int g = tid >> 4, el = tid & 15;
+    if (ns <= 32) {
+      // ---- narrow: units b*4 .. b*4+3; the owner of element (u, el) is thread 16 u + el
+      const int64_t e0 = (int64_t)b * (16 * kNarrowU);
+      const int64_t io = e0 + tid;                               // owner's element (tid < 64)
+      if (STEP && tid < 16 * kNarrowU) {
+        const int64_t ic = fp.begin4[sg] + (io < n4 ? io : n4 - 1);
+        P[0] = p4[ic]; S[0] = s14[ic]; A[0] = s24[ic];
+      }
+      float4 t[kNarrowU][2];
+      const bool v0 = g < ns, v1 = g + 16 < ns;
+      const int64_t r0 = (int64_t)(v0 ? g : 0) * st4, r1 = (int64_t)(v1 ? g + 16 : 0) * st4;
+#pragma unroll
+      for (int u = 0; u < kNarrowU; ++u) {
+        const int64_t i = e0 + 16 * u + el;
+        const int64_t ic = i < n4 ? i : n4 - 1;
+        t[u][0] = sl[r0 + ic];
+        t[u][1] = sl[r1 + ic];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kNarrowU; ++u) {
+        float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v0) add4(pp, t[u][0]);
+        if (v1) add4(pp, t[u][1]);
+        s_part[u][g][el] = pp;
+      }
+      __syncthreads();
+      if (tid < 16 * kNarrowU) {
+        const int u = tid >> 4;
+        float4 r = s_part[u][0][el];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) add4(r, s_part[u][q][el]);
+        if (io < n4) {
+          g4[fp.begin4[sg] + io] = r;
+          acc += sq4(r);
+          G[0] = r;
+          gi[0] = fp.begin4[sg] + io;
+        }
+      }
+    } else {
+      // ---- wide: unit b; the owner of element el is thread el
+      const int64_t i = (int64_t)b * 16 + el;
+      const int64_t ic = i < n4 ? i : n4 - 1;
+      if (STEP && tid < 16) {
+        const int64_t ig = fp.begin4[sg] + ic;
+        P[0] = p4[ig]; S[0] = s14[ig]; A[0] = s24[ig];
+      }
+      float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s0 = g; s0 < ns; s0 += 16 * kWideL) {
+        float4 t[kWideL];
+#pragma unroll
+        for (int u = 0; u < kWideL; ++u) {
+          const int s = s0 + 16 * u;
+          t[u] = sl[(int64_t)(s < ns ? s : g) * st4 + ic];
+        }
+#pragma unroll
+        for (int u = 0; u < kWideL; ++u)
+          if (s0 + 16 * u < ns) add4(pp, t[u]);
+      }
+      s_part[0][g][el] = pp;
+      __syncthreads();
+      if (tid < 16) {
+        float4 r = s_part[0][0][el];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) add4(r, s_part[0][q][el]);
+        if (i < n4) {
+          g4[fp.begin4[sg] + i] = r;
+          acc += sq4(r);
+          G[0] = r;
+          gi[0] = fp.begin4[sg] + i;
+        }
+      }
+    }
+  } else {
+    // ---- plain: kPlainNV float4 per thread, every operand requested up front
+    const int b = bid - fp.first_block[fp.n_segs];
+    for (int it = 0; it < (STEP ? 1 : fp.plain_iters); ++it) {
+      const int64_t i0 = ((int64_t)it * fp.plain_blocks + b) * (256 * kPlainNV) + tid;
+#pragma unroll
+      for (int v = 0; v < kPlainNV; ++v) {
+        const int64_t i = i0 + 256 * v;
+        const int64_t ic = fp.plain_begin4 + (i < fp.plain_count4 ? i : fp.plain_count4 - 1);
+        G[v] = g4[ic];
+        if (STEP) { P[v] = p4[ic]; S[v] = s14[ic]; A[v] = s24[ic]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int v = 0; v < kPlainNV; ++v) {
+        const int64_t i = i0 + 256 * v;
+        if (i < fp.plain_count4) {
+          acc += sq4(G[v]);
+          gi[v] = fp.plain_begin4 + i;
+        }
+      }
+    }
+  }
+  DRA_STAMP(TR_NORM, 4);
+  double d = wave_sum((double)acc);
+  if ((tid & 63) == 0) s_red[tid >> 6] = d;
+  if (MODE == 2 && tid == 64) {   // Adam's bias corrections from the device step count, exactly as dra_adam_hyper forms them
+    const double t = (double)*hp.step_dev;
+    const double bc1 = 1.0 - pow((double)hp.a, t), bc2 = 1.0 - pow((double)hp.b2, t);
+    s_hyper[0] = (float)((double)hp.lr / bc1);
+    s_hyper[1] = (float)(1.0 / sqrt(bc2));
+  }
+  __syncthreads();
+  if (!STEP) {
+    if (tid == 0) partials[bid] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    DRA_STAMP(TR_NORM, 5);
+    DRA_STAMP_END(TR_NORM);
+    return;
+  }
+  // ---- grid barrier.  The partial is published with an agent-scope store (written through: the other XCDs' L2s are not
+  // coherent with this one), completed with s_waitcnt, and only then the ticket is taken; the counter only ever grows
+  // (generation = ticket / workgroups), so graph replays need no reset.  (Same publish / ticket pattern as
+  // actor_fc4_head_env_kernel in learner.hip.)
+  if (tid == 0) {
+    __hip_atomic_store(partials + bid, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long nb = gridDim.x;
+    const unsigned long long ticket = __hip_atomic_fetch_add(barrier, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long target = (ticket / nb + 1ull) * nb;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > kBarrierTicks) {
+        __hip_atomic_store(timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  DRA_STAMP(TR_NORM, 5);
+  const float coef = clip_coef_coherent(partials, (int)gridDim.x, hp.max_norm, out_norm);
+  [[maybe_unused]] const float oma = 1.f - hp.a, omb2 = 1.f - hp.b2;
+  [[maybe_unused]] const float step_size = s_hyper[0], inv_sqrt_bc2 = s_hyper[1];
+#pragma unroll
+  for (int v = 0; v < kPlainNV; ++v) {
+    if (gi[v] >= 0) {
+      float* pp = &P[v].x; const float* gg = &G[v].x; float* ss = &S[v].x; float* aa = &A[v].x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (MODE == 1) {
+          rmsprop_elem(pp[k], gg[k], ss[k], aa[k], coef, hp.a, oma, hp.lr, hp.eps, hp.centered);
+        } else {
+          const float gk = gg[k] * coef;
+          ss[k] = ss[k] * hp.a + oma * gk;                       // exp_avg
+          aa[k] = aa[k] * hp.b2 + omb2 * gk * gk;                // exp_avg_sq
+          pp[k] = pp[k] - step_size * (ss[k] / (sqrtf(aa[k]) * inv_sqrt_bc2 + hp.eps));
+        }
+      }
+      reinterpret_cast<float4*>(p)[gi[v]] = P[v];
+      if (p_copy) reinterpret_cast<float4*>(p_copy)[gi[v]] = P[v];
+      reinterpret_cast<float4*>(s1)[gi[v]] = S[v];
+      if (MODE == 2 || hp.centered) reinterpret_cast<float4*>(s2)[gi[v]] = A[v];
+    }
+  }
+  DRA_STAMP_END(TR_NORM);
+}
+
+DRA_API int dra_norm_partials_max(void) { return 2048; }
+
+static int make_fold_plan(int64_t n, const dra_fold_seg* segs, int n_segs, FoldPlan* out, int* blocks_out) {
+  if (n < 4 || (n & 3) || n_segs < 0 || n_segs > DRA_MAX_FOLD_SEGS || (n_segs && !segs)) return DRA_EINVAL;
+  FoldPlan fp;
+  memset(&fp, 0, sizeof(fp));
+  int64_t end = 0;
+  int64_t blocks = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    const dra_fold_seg& sg = segs[i];
+    if (sg.begin != end || (sg.begin & 3) || (sg.count & 3) || sg.count < 4 || sg.begin + sg.count > n || !sg.slabs ||
+        sg.n_slabs < 1 || (sg.slab_stride & 3) || (((uintptr_t)sg.slabs) & 15))
+      return DRA_EINVAL;
+    fp.begin4[i] = sg.begin >> 2; fp.count4[i] = sg.count >> 2;
+    fp.slabs[i] = reinterpret_cast<const float4*>(sg.slabs); fp.stride4[i] = sg.slab_stride >> 2;
+    fp.n_slabs[i] = sg.n_slabs;
+    fp.first_block[i] = (int32_t)blocks;
+    const int64_t per = sg.n_slabs <= 32 ? 16 * kNarrowU : 16;   // float4 elements per fold workgroup
+    blocks += (fp.count4[i] + per - 1) / per;
+    end = sg.begin + sg.count;
+    if (blocks > 0x7fffffff) return DRA_EINVAL;
+  }
+  fp.first_block[n_segs] = (int32_t)blocks;
+  fp.n_segs = n_segs;
+  fp.plain_begin4 = end >> 2; fp.plain_count4 = (n - end) >> 2;
+  int64_t pb = (fp.plain_count4 + 256 * kPlainNV - 1) / (256 * kPlainNV);
+  fp.plain_iters = 1;
+  const int64_t room = (int64_t)dra_norm_partials_max() - blocks;   // every workgroup writes one partial
+  if (pb > room) {
+    if (room < 1) return DRA_EINVAL;
+    fp.plain_iters = (int32_t)((pb + room - 1) / room);
+    pb = (pb + fp.plain_iters - 1) / fp.plain_iters;
+  }
+  fp.plain_blocks = (int32_t)pb;
+  blocks += pb;
+  if (blocks < 1) return DRA_EINVAL;
+  *out = fp;
+  *blocks_out = blocks > 0x7fffffff ? 0x7fffffff : (int)blocks;
+  return DRA_OK;
+}
+
+// grad[0, n): segments (contiguous from 0, 4-float aligned) are folded from their slabs
+// (grad[seg] = sum_s slabs[s*stride + i], fixed order) and everything after the last segment is read as
+// is; *n_partials doubles are written (<= dra_norm_partials_max()) -- pass that count to dra_*_step.
+
+DRA_API int dra_grad_sqnorm_segs(float* grad, int64_t n, const dra_fold_seg* segs, int n_segs, double* partials,
+                                 int* n_partials, void* stream) {
+  if (!grad || !partials || !n_partials || (((uintptr_t)grad) & 15)) return DRA_EINVAL;
+  FoldPlan fp;
+  int blocks = 0;
+  int rc = make_fold_plan(n, segs, n_segs, &fp, &blocks);
+  if (rc) return rc;
+  if (blocks > dra_norm_partials_max()) return DRA_EINVAL;
+  StepHyper hp;
+  memset(&hp, 0, sizeof(hp));
+  hipLaunchKernelGGL(clip_step_kernel<0>, dim3(blocks), dim3(256), 0, dra_stream(stream), grad, fp, partials, (float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, hp, (float*)nullptr, (unsigned long long*)nullptr,
+                     (int*)nullptr);
+  DRA_LAUNCH_CHECK();
+  *n_partials = blocks;
+  return DRA_OK;
+}
+
+// ---- cooperative form: fold + norm + optimiser as ONE launch (clip_step_kernel<1 / 2>) --------------------------------
+// Workgroups of the launch for this gradient layout (the same count dra_grad_sqnorm_segs writes partials for).
+DRA_API int dra_clip_step_coop_blocks(int64_t n, const dra_fold_seg* segs, int n_segs, int* blocks) {
+  if (!blocks) return DRA_EINVAL;
+  FoldPlan fp;
+  int rc = make_fold_plan(n, segs, n_segs, &fp, blocks);
+  if (rc) return rc;
+  if (fp.plain_iters != 1 || *blocks > dra_norm_partials_max()) return DRA_EINVAL;   // the barrier form holds every element in registers
+  return DRA_OK;
+}
+
+// Workgroups of the cooperative kernel one CU can hold at once (registers / LDS of the compiled kernel): the grid barrier
+// needs blocks <= n_cus_of_the_stream * this.  optimizer: DRA_OPT_RMSPROP / DRA_OPT_ADAM.
+DRA_API int dra_clip_step_coop_occupancy(int optimizer, int* blocks_per_cu) {
+  if (!blocks_per_cu) return DRA_EINVAL;
+  int nb = 0;
+  if (optimizer == DRA_OPT_ADAM) DRA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, clip_step_kernel<2>, 256, 0));
+  else DRA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, clip_step_kernel<1>, 256, 0));
+  *blocks_per_cu = nb;
+  return DRA_OK;
+}
+
+// barrier_ctr: one zero-initialised 64-bit counter in device memory per (stream, gradient layout) -- it only grows;
+// timeout_flag: int in PINNED HOST memory, zero-initialised: set to 1 by a workgroup whose barrier wait exceeded 50 ms
+// (the grid was not co-resident after all); results of that launch are then invalid and the caller must check the flag.
+// resident_limit: workgroups that can be co-resident on the CUs `stream` may use; a larger grid is refused (DRA_EINVAL)
+// and the caller uses the two-launch form.  hyper: {lr, alpha | beta1, eps, beta2}; step_dev: Adam's device step count.
+DRA_API int dra_clip_step_coop(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* segs,
+                               int n_segs, double* partials, unsigned long long* barrier_ctr, int* timeout_flag,
+                               int resident_limit, int optimizer, float max_norm, const float* hyper, int centered,
+                               const int64_t* step_dev, float* out_norm, float* param_copy, void* stream) {
+  if (!param || !grad || !state1 || !partials || !barrier_ctr || !timeout_flag || !hyper) return DRA_EINVAL;
+  if (optimizer != DRA_OPT_RMSPROP && optimizer != DRA_OPT_ADAM) return DRA_EINVAL;
+  if ((optimizer == DRA_OPT_ADAM && (!state2 || !step_dev)) || (optimizer == DRA_OPT_RMSPROP && centered && !state2)) return DRA_EINVAL;
+  if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)state1) | ((uintptr_t)state2) | ((uintptr_t)param_copy)) & 15)
+    return DRA_EINVAL;
+  FoldPlan fp;
+  int blocks = 0;
+  int rc = make_fold_plan(n, segs, n_segs, &fp, &blocks);
+  if (rc) return rc;
+  if (fp.plain_iters != 1 || blocks > dra_norm_partials_max() || blocks > resident_limit) return DRA_EINVAL;
+  StepHyper hp;
+  memset(&hp, 0, sizeof(hp));
+  hp.max_norm = max_norm; hp.lr = hyper[0]; hp.a = hyper[1]; hp.eps = hyper[2]; hp.b2 = hyper[3];
+  hp.centered = centered; hp.step_dev = step_dev;
+  if (optimizer == DRA_OPT_ADAM)
+    hipLaunchKernelGGL(clip_step_kernel<2>, dim3(blocks), dim3(256), 0, dra_stream(stream), grad, fp, partials, param, state1,
+                       state2, param_copy, hp, out_norm, barrier_ctr, timeout_flag);
+  else
+    hipLaunchKernelGGL(clip_step_kernel<1>, dim3(blocks), dim3(256), 0, dra_stream(stream), grad, fp, partials, param, state1,
+                       state2, param_copy, hp, out_norm, barrier_ctr, timeout_flag);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
 }
 
 // NT: the optimizer state (sq, ga) and the gradient are touched once per update -- stream them past the caches

@@ -140,6 +140,10 @@ class DQNLearner:
         else:
             self.stream = torch.cuda.Stream()                        # graphs cannot capture on the NULL stream
             self.actor_stream = torch.cuda.Stream()
+        # VAR_COOP_OPT: the cooperative optimizer launch needs its whole grid resident on the update stream's CUs -- the C
+        # side decides from their number (once, before the first update)
+        n_cu = torch.cuda.get_device_properties(Config.DEVICE).multi_processor_count
+        lib.dra_dqn_learner_set_update_cus(h, int(self.update_cus or n_cu))
         self.params = StepParams()
         self._idx_view = np.ctypeslib.as_array(self.params.idx)[:batch]
         self._idx_pinned = [torch.empty(batch, dtype=torch.int64).pin_memory() for _ in range(8)]
@@ -310,6 +314,12 @@ class DQNLearner:
     def synchronize(self):
         self.stream.synchronize()
         self.actor_stream.synchronize()
+
+    def coop_state(self):
+        """(cooperative optimizer launch in use, its grid, resident-workgroup limit it was compared with): VAR_COOP_OPT."""
+        c, b, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib.dra_dqn_learner_coop_state(self.h, ctypes.byref(c), ctypes.byref(b), ctypes.byref(r))
+        return bool(c.value), b.value, r.value
 
     def host_stats(self, reset=True):
         """Host-side accounting of dra_dqn_learner_step since the last reset: number of calls, mean microseconds inside the
@@ -761,4 +771,6 @@ class DQNLearnerBench:
 
     def report(self):
         ms = getattr(self, "kernel_ms", {})
-        return {"kernel_ms": {k: round(v, 5) for k, v in ms.items()}, "update_kernel_ms_sum": round(sum(ms.values()), 5)}
+        coop, blocks, limit = self.learner.coop_state()
+        return {"kernel_ms": {k: round(v, 5) for k, v in ms.items()}, "update_kernel_ms_sum": round(sum(ms.values()), 5),
+                "coop_optimizer": {"in_use": coop, "workgroups": blocks, "resident_limit": limit}}

@@ -408,7 +408,9 @@ VAR_ACTOR_RING = 4096
 VAR_ACTOR_FUSED_CONV1 = 8192
 VAR_GATHER_ON_UPDATE = 16384
 VAR_RING_DIRECT = 32768
-VAR_ALL = 65535
+VAR_COOP_OPT = 65536
+VAR_IDX_PREFETCH = 131072
+VAR_ALL = 262143
 
 
 def set_tuning(mask):
@@ -505,9 +507,7 @@ class FoldSeg(ctypes.Structure):
 
 def grad_sqnorm_segs(grad, segs, partials):
     """segs: list of (begin, count, slabs_tensor, slab_stride, n_slabs).  Returns the number of partials written."""
-    arr = (FoldSeg * max(1, len(segs)))()
-    for i, (b, c, t, st, ns) in enumerate(segs):
-        arr[i].begin, arr[i].count, arr[i].slabs, arr[i].slab_stride, arr[i].n_slabs = b, c, t.data_ptr(), st, ns
+    arr = _fold_seg_array(segs)
     n = ctypes.c_int(0)
     lib.dra_grad_sqnorm_segs(ptr(grad), grad.numel(), arr, len(segs), ptr(partials), ctypes.byref(n), stream_ptr())
     return n.value
@@ -515,6 +515,39 @@ def grad_sqnorm_segs(grad, segs, partials):
 
 def norm_partials_max():
     return lib.dra_norm_partials_max.raw()
+
+
+def _fold_seg_array(segs):
+    arr = (FoldSeg * max(1, len(segs)))()
+    for i, (b, c, t, st, ns) in enumerate(segs):
+        arr[i].begin, arr[i].count, arr[i].slabs, arr[i].slab_stride, arr[i].n_slabs = b, c, t.data_ptr(), st, ns
+    return arr
+
+
+def clip_step_coop_blocks(n, segs):
+    """Workgroups of the cooperative fold + norm + optimiser launch for this gradient layout."""
+    b = ctypes.c_int(0)
+    lib.dra_clip_step_coop_blocks(int(n), _fold_seg_array(segs), len(segs), ctypes.byref(b))
+    return b.value
+
+
+def clip_step_coop_occupancy(optimizer):
+    """Workgroups of that kernel one CU holds at once (0 = RMSprop, 1 = Adam)."""
+    b = ctypes.c_int(0)
+    lib.dra_clip_step_coop_occupancy(int(optimizer), ctypes.byref(b))
+    return b.value
+
+
+def clip_step_coop(param, grad, state1, state2, segs, partials, barrier_ctr, timeout_flag, resident_limit, optimizer,
+                   max_norm, hyper, centered=True, step_dev=None, out_norm=None, param_copy=None):
+    """dra_clip_step_coop: slab fold + gradient norm + RMSprop (optimizer 0, hyper = (lr, alpha, eps)) or Adam (1: (lr, beta1,
+    eps, beta2), step count in the int64 device tensor step_dev) as ONE launch behind a grid barrier.  barrier_ctr: zeroed
+    int64 device tensor kept across calls; timeout_flag: zeroed int32 PINNED host tensor (becomes 1 when a barrier gave up)."""
+    hp = (ctypes.c_float * 4)(*([float(v) for v in hyper] + [0.0] * (4 - len(hyper))))
+    lib.dra_clip_step_coop(ptr(param), ptr(grad), ptr(state1), ptr(state2), param.numel(), _fold_seg_array(segs), len(segs),
+                           ptr(partials), ptr(barrier_ctr), ptr(timeout_flag), int(resident_limit), int(optimizer),
+                           float(max_norm if max_norm else 0.0), hp, int(bool(centered)), ptr(step_dev), ptr(out_norm),
+                           ptr(param_copy), stream_ptr())
 
 
 def conv_bwd_x(layer, dy, w, xact=None, act="relu"):

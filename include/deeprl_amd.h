@@ -190,6 +190,12 @@ int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* 
                                     * (forward of every net, weight gradient) reads the uint8 frames of the sampled
                                     * transitions straight from the replay ring and the head kernel their action / n-step
                                     * reward / mask: one launch, 1.8 MB of writes and 1.8 MB of re-reads less per update */
+#define DRA_VAR_COOP_OPT 65536    /* learner (with ONESHOT_WGRAD): slab fold + gradient norm + optimiser as ONE launch behind a
+                                    * grid barrier (dra_clip_step_coop) when the grid fits the update stream's CUs
+                                    * (dra_dqn_learner_set_update_cus); otherwise the two-launch form */
+#define DRA_VAR_IDX_PREFETCH 131072 /* learner (with RING_DIRECT): the head kernel of update t copies the (step-tagged) minibatch
+                                    * indices of update t+1 from pinned host memory to the device; conv1 of update t+1 takes
+                                    * them from there when the tag matches (no PCIe read in front of its frame loads) */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
@@ -222,6 +228,18 @@ typedef struct dra_fold_seg {
 int dra_norm_partials_max(void);
 int dra_grad_sqnorm_segs(float* grad, int64_t n, const dra_fold_seg* segs, int n_segs, double* partials,
                          int* n_partials, void* stream);
+/* the same fold + norm with the optimiser behind a GRID BARRIER (one launch instead of two: clip_grad_norm_ +
+ * optimizer.step(), DQN_agent.py:130-134): every workgroup keeps its elements in registers, publishes its partial, waits
+ * for the others and applies RMSprop (optimizer 0: hyper = {lr, alpha, eps, -}) or Adam (1: {lr, beta1, eps, beta2}, step
+ * count read from step_dev).  All workgroups must be co-resident: _coop_blocks gives the grid, _coop_occupancy the
+ * workgroups one CU holds; a grid above resident_limit is refused.  barrier_ctr: zeroed uint64 in device memory (only
+ * grows); timeout_flag: zeroed int in pinned host memory, set to 1 if a barrier wait exceeded 50 ms. */
+int dra_clip_step_coop_blocks(int64_t n, const dra_fold_seg* segs, int n_segs, int* blocks);
+int dra_clip_step_coop_occupancy(int optimizer, int* blocks_per_cu);
+int dra_clip_step_coop(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* segs,
+                       int n_segs, double* partials, unsigned long long* barrier_ctr, int* timeout_flag,
+                       int resident_limit, int optimizer, float max_norm, const float* hyper, int centered,
+                       const int64_t* step_dev, float* out_norm, float* param_copy, void* stream);
 int dra_rmsprop_step(float* param, const float* grad, float* square_avg, float* grad_avg, int64_t n,
                      const double* partials, int n_partials, float max_norm, float lr, float alpha, float eps,
                      int centered, float* out_norm, void* stream);
@@ -309,6 +327,13 @@ int dra_dqn_learner_update(dra_dqn_learner* learner, int use_graph, int per, flo
 /* PER for the in-order dra_dqn_learner_step (stream_actor == NULL): importance weights from the learner's sampling_prob
  * buffer with exponent beta, new priorities into its prio buffer (DQN_agent.py:120-127) */
 int dra_dqn_learner_set_per(dra_dqn_learner* learner, int per, float beta);
+/* DRA_VAR_COOP_OPT: n_cus = compute units the update stream may use (its CU mask, or the whole device).  Decides, once and
+ * before the first update, whether slab fold + gradient norm + optimiser run as ONE cooperative launch
+ * (dra_clip_step_coop: needs its whole grid resident on those CUs) or as two launches.  _coop_state reports the decision,
+ * the grid and the resident-workgroup limit it was compared with.  A barrier that times out anyway makes every later
+ * dra_dqn_learner_step / _update return -110. */
+int dra_dqn_learner_set_update_cus(dra_dqn_learner* learner, int n_cus);
+int dra_dqn_learner_coop_state(dra_dqn_learner* learner, int* coop, int* blocks, int* resident_limit);
 /* DRA_VAR_RING_DIRECT: also gather the minibatch into the learner's buffers (dra_dqn_learner_last_minibatch) -- for
  * checkers; the update itself keeps reading the ring */
 int dra_dqn_learner_keep_minibatch(dra_dqn_learner* learner, int keep);

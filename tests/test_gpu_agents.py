@@ -228,7 +228,8 @@ def test_ppo_optimize_matches_reference(golden, dra, tag, monkeypatch):
     _cmp_params(agent.network, g, k + "final_", 2e-5, 2e-6)
 
 
-@pytest.mark.parametrize("double_q,variant", [(False, 0), (False, 1), (False, 7), (False, 127), (True, 127), (True, 511)])
+@pytest.mark.parametrize("double_q,variant", [(False, 0), (False, 1), (False, 7), (False, 127), (True, 127), (True, 511),
+                                              (False, 511 + 65536), (True, 511 + 65536)])   # + COOP_OPT: one-launch clip + optimizer
 def test_fused_learner_matches_oracle(dra, double_q, variant):
     """The captured-graph DQN learner (one C-ABI call per update, zero host round trips) against
     the CPU oracle's full update on identical ring contents, indices and weights: 4 consecutive
@@ -254,6 +255,8 @@ def test_fused_learner_matches_oracle(dra, double_q, variant):
     tgt.load_state_dict({k: torch.from_numpy(v) for k, v in t_np.items()})
     learner = DQNLearner(net, tgt, ring, b, a, 0.99, 5.0, 0.00025, 0.95, 0.01, centered=True, double_q=double_q,
                          variant=variant)
+    if variant & d.ops.VAR_COOP_OPT:
+        assert learner.coop_state()[0], "the cooperative optimizer launch must fit the update stream's CUs: %s" % (learner.coop_state(),)
     p = {k: torch.tensor(v, requires_grad=True) for k, v in p_np.items()}
     pt = {k: torch.tensor(v) for k, v in t_np.items()}
     names = list(p.keys())
@@ -356,7 +359,8 @@ def test_fused_step_sync_equals_act_then_update(dra, variant):
 _ASYNC_RESULTS = {}
 
 
-@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559, 4607, 12799, 29183, 61951])
+@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559, 4607, 12799, 29183, 61951, 61951 + 65536, 61951 + 131072,
+                                     61951 + 65536 + 131072])
 def test_fused_step_async_pipeline(dra, variant):
     """async_actor=True pipeline (actor one agent step ahead on its own stream, double-buffered actor
     parameters when variant has DRA_VAR_ACTOR_PARAMS): the transitions it feeds are the documented counter-hash
@@ -396,7 +400,9 @@ def test_fused_step_async_pipeline(dra, variant):
     # ... and the gather on the update stream (DRA_VAR_GATHER_ON_UPDATE = 16384; ring capacity 4000 with 32 samples per
     # step: the host-decided 'minibatch touches the slots the next actor graph overwrites' wait fires here)
     # ... and the ring-direct update (DRA_VAR_RING_DIRECT = 32768: conv1 and the head read the replay ring, no gather)
-    for other in (255, 1023, 2047, 2559, 4607, 12799, 29183, 61951):
+    # ... and the cooperative one-launch clip + optimizer (DRA_VAR_COOP_OPT = 65536: same decomposition and reduction order
+    # as the two launches) and the prefetched minibatch indices (DRA_VAR_IDX_PREFETCH = 131072: same indices, another route)
+    for other in (255, 1023, 2047, 2559, 4607, 12799, 29183, 61951, 61951 + 65536, 61951 + 131072, 61951 + 65536 + 131072):
         if 127 in _ASYNC_RESULTS and other in _ASYNC_RESULTS:
             assert np.array_equal(_ASYNC_RESULTS[127][0], _ASYNC_RESULTS[other][0])
             assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
@@ -404,7 +410,8 @@ def test_fused_step_async_pipeline(dra, variant):
 
 @pytest.mark.parametrize("variant,init,cap", [(-1, "bench", 4000), (-1, "normal", 4000), (4607, "normal", 4000), (12799, "normal", 4000),
                                               (29183, "normal", 4000), (-1, "normal", 160), (12799, "normal", 160),
-                                              (61951, "normal", 4000), (61951, "normal", 160), (61951, "bench", 4000)])
+                                              (61951, "normal", 4000), (61951, "normal", 160), (61951, "bench", 4000),
+                                              (258559, "normal", 4000), (258559, "normal", 160), (258559, "bench", 4000)])
 def test_async_pipeline_matches_schedule_oracle(dra, variant, init, cap):
     """THE BENCHMARKED CONFIGURATION against the oracle: DQNLearnerBench(async_actor=True) with the default kernel
     variant (bench.py's: CU partition, pipelined gather, actor parameter ring, fused actor conv1) for 14 agent steps vs
