@@ -174,7 +174,7 @@ struct dra_dqn_learner {
   int* coop_flag;                   // pinned host: set by a workgroup whose barrier wait timed out
   int coop_limit;                   // co-resident workgroups assumed available (0: unknown -> two-launch form)
   // DRA_VAR_IDX_PREFETCH (ring-direct pipeline): step-tagged copies of the minibatch indices -- pinned (written by the host
-  // with the indices), device (copied by the head kernel of the PREVIOUS update), and the device count of completed updates
+  // with the indices), device (an unordered async copy on the side stream), and the device count of completed updates
   int64_t* idx_tag_pin[4];
   int64_t* idx_tag_dev;             // [4][1024]
   unsigned long long* rd_seq_dev;   // ring-direct updates completed (bumped by each one's head kernel)
@@ -501,9 +501,9 @@ struct RingScalars {
   int n_step;
   double discount;
   int64_t* out_action; float* out_reward; float* out_mask;   // the learner's minibatch scalar buffers, filled on the way
-  // DRA_VAR_IDX_PREFETCH: workgroup b copies element b of the NEXT update's tagged indices (pinned host) to the device and
-  // workgroup 0 counts this update as done (conv1 of the next update compares tags with the count: ConvV2Args)
-  const int64_t* pf_src; int64_t* pf_dst; unsigned long long* seq;
+  // DRA_VAR_IDX_PREFETCH: workgroup 0 counts this update as done (conv1 of the next update compares the tags of its
+  // prefetched indices with the count: ConvV2Args::sample_idx_tagged)
+  unsigned long long* seq;
 };
 
 struct HeadSpec {
@@ -632,8 +632,6 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
   }
   int64_t ab;
   float rew_b, mask_b;
-  int64_t pf = 0;
-  if (rs.pf_src && tid == 0) pf = rs.pf_src[b];   // (PCIe read: requested first, stored at the very end)
   if (rs.idx) {
     // DRA_VAR_RING_DIRECT: action / n-step reward / mask of the sampled transition straight from the replay ring, folded as
     // ring_gather_kernel does (replay.py:133-139, fp64, the reference's association), then f32 as tensor() would
@@ -734,10 +732,7 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
     dh4[(int64_t)b * 512 + k] = s_h[0][k] > 0.f ? dqa * dwh[rep] : 0.f;
   }
   if (opt_step && b == 0 && tid == 0) *opt_step += 1;   // one optimizer step per update (Adam's t)
-  if (rs.pf_src && tid == 0) {
-    rs.pf_dst[b] = pf;
-    if (b == 0) *rs.seq += 1ull;
-  }
+  if (rs.seq && b == 0 && tid == 0) *rs.seq += 1ull;
   DRA_STAMP(TR_HEAD, 5);
   DRA_STAMP_END(TR_HEAD);
 }
@@ -1001,10 +996,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       rs.idx = l->idx; rs.actions = (const uint8_t*)ring_actions; rs.rewards = (const double*)ring_rewards;
       rs.masks = (const int32_t*)ring_masks; rs.n_step = ring_n; rs.discount = ring_discount;
       rs.out_action = l->action_[l->gb]; rs.out_reward = l->reward_[l->gb]; rs.out_mask = l->mask_[l->gb];
-      if (l->variant & DRA_VAR_IDX_PREFETCH) {
-        const int qn = (l->rd_slot + 1) & 3;
-        rs.pf_src = l->idx_tag_pin[qn]; rs.pf_dst = l->idx_tag_dev + (size_t)qn * 1024; rs.seq = l->rd_seq_dev;
-      }
+      if (l->variant & DRA_VAR_IDX_PREFETCH) rs.seq = l->rd_seq_dev;
     }
     if (ks4 == kFc4SplitWide)
       hipLaunchKernelGGL(head_fused_kernel<kFc4SplitWide>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
@@ -1900,8 +1892,10 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
       // ReLU) by the consumer's staging (conv_v2.hip conv_b1_split_kernel)
       if ((rc = dra_conv_b1_split(2, l->ay1, nullptr, P + o[P_W2], P + o[P_B2], l->ay2p, s))) return rc;
       if ((rc = dra_conv_b1_split(3, l->ay2p, l->ay2p + 64 * 81, P + o[P_W3], P + o[P_B3], l->ay3p, s))) return rc;
-      static int fc4_lds = -1;   // DRA_ACTOR_FC4_LDS=1: the input staged through LDS (one round of workgroups on the actor's CUs)
-      if (fc4_lds < 0) { const char* e = getenv("DRA_ACTOR_FC4_LDS"); fc4_lds = e ? atoi(e) : 0; }
+      // the input staged through LDS: one round of workgroups on the actor's CUs, same-box A/B 8 575 / 8 559 vs 8 409 / 8 242
+      // updates/s (profiles/r02zt_ab.json); DRA_ACTOR_FC4_LDS=0 = the register-resident form
+      static int fc4_lds = -1;
+      if (fc4_lds < 0) { const char* e = getenv("DRA_ACTOR_FC4_LDS"); fc4_lds = e ? atoi(e) : 1; }
       if (fc4_lds)
         hipLaunchKernelGGL(actor_fc4_planes_lds_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3p,
                            (const float*)(l->ay3p + 64 * 49), P + o[P_W4], P + o[P_B4], l->ah4, 3136);
@@ -2328,10 +2322,17 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
         l->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
       memcpy(l->idx_pin[q], prm->idx, (size_t)B * sizeof(int64_t));
-      if (l->variant & DRA_VAR_IDX_PREFETCH) {   // element-wise 8-byte stores: the device may read the buffer at any time
+      if (l->variant & DRA_VAR_IDX_PREFETCH) {
+        // a step-tagged copy of the indices travels to the device on the side stream, ordered with NOTHING: conv1 uses an
+        // element only if its tag is this update's (then the copy landed in time, the normal case -- the host runs ahead
+        // of the device), else it reads the pinned indices as before.  (A first version let the previous update's head
+        // kernel fetch them over PCIe: conv1 -1.2 us, but the in-order vmcnt made the head kernel wait for that read:
+        // +1.9 us, profiles/r02zt_*.)
         const uint64_t tag = ((l->rd_issued + 1ull) & 0xffffffull) << 40;
         volatile int64_t* dst = l->idx_tag_pin[q];
         for (int b = 0; b < B; ++b) dst[b] = (int64_t)((uint64_t)prm->idx[b] | tag);
+        DRA_HIP(hipMemcpyAsync(l->idx_tag_dev + (size_t)q * 1024, l->idx_tag_pin[q], (size_t)B * sizeof(int64_t),
+                               hipMemcpyHostToDevice, l->side));
       }
       l->rd_issued++;
       TRACE(0, su);

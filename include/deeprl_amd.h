@@ -193,9 +193,9 @@ int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* 
 #define DRA_VAR_COOP_OPT 65536    /* learner (with ONESHOT_WGRAD): slab fold + gradient norm + optimiser as ONE launch behind a
                                     * grid barrier (dra_clip_step_coop) when the grid fits the update stream's CUs
                                     * (dra_dqn_learner_set_update_cus); otherwise the two-launch form */
-#define DRA_VAR_IDX_PREFETCH 131072 /* learner (with RING_DIRECT): the head kernel of update t copies the (step-tagged) minibatch
-                                    * indices of update t+1 from pinned host memory to the device; conv1 of update t+1 takes
-                                    * them from there when the tag matches (no PCIe read in front of its frame loads) */
+#define DRA_VAR_IDX_PREFETCH 131072 /* learner (with RING_DIRECT): a step-tagged copy of the minibatch indices goes to the device by
+                                    * an unordered async copy when the step is enqueued; conv1 takes an element from there when
+                                    * its tag is this update's (no PCIe read in front of its frame loads), else from pinned memory */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
