@@ -13,10 +13,12 @@
 #include "actor_env.h"
 #include <stdlib.h>
 
-static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768;
+static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768 | 131072;
 // every bit up to DRA_VAR_CU_PARTITION plus ACTOR_RING, ACTOR_FUSED_CONV1, GATHER_ON_UPDATE and RING_DIRECT measured faster
 // on MI355X in same-box A/Bs (profiles/r01b_ab_variants.jsonl, r01d_*, r01f_*, r02y_ab_*, r02zf_ab_*); ACTOR_V3 (512),
-// ACTOR_FUSED_HEAD (1024) and GATHER_IN_GRAPH (2048) measured neutral or slower and stay opt-in
+// ACTOR_FUSED_HEAD (1024) and GATHER_IN_GRAPH (2048) measured neutral or slower and stay opt-in; IDX_PREFETCH (131072): conv1_fwd
+// 11.6 -> 10.3 us, +0.6 % (profiles/r02zu_*); COOP_OPT (65536) measured 14 % SLOWER -- a grid barrier of 796 workgroups on one
+// counter costs 24 us on this part (profiles/r02zt_*) -- and stays opt-in as a kept negative result
 
 DRA_API int dra_set_tuning(int mask) {
   if (mask < 0) return DRA_EINVAL;

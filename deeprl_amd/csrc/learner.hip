@@ -186,14 +186,19 @@ struct dra_dqn_learner {
 struct HeadSpec;
 static HeadSpec head_spec(const dra_dqn_learner* l);
 
-static int fc4_ks(const dra_dqn_learner* l) {   // K slices of the update's fc4 forward (one-pass kernel only)
+// K slices of the update's fc4 forward (one-pass kernel only).  Default: 14 for two nets (224 workgroups: one per CU of the
+// update partition; fc4_fwd 10.4 -> 8.2 us, +1.8 % updates/s same box, profiles/r02zu_*), 8 with the third net of double-Q
+// (192 workgroups; 336 would need a second round).  DRA_FC4_KS = 8 / 14 / 28 overrides.
+static int fc4_ks(const dra_dqn_learner* l) {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("DRA_FC4_KS");
-    const int want = e ? atoi(e) : kFc4Split;
-    v = (want == kFc4SplitWide || want == kFc4SplitMid) ? want : kFc4Split;
+    const int want = e ? atoi(e) : 0;
+    v = (want == kFc4SplitWide || want == kFc4SplitMid || want == kFc4Split) ? want : 0;
   }
-  return (l->variant & DRA_VAR_ONESHOT_FWD) ? v : kFc4Split;
+  if (!(l->variant & DRA_VAR_ONESHOT_FWD)) return kFc4Split;
+  if (v) return v;
+  return l->c.double_q ? kFc4Split : kFc4SplitMid;
 }
 
 // HIP stream restricted to a set of compute units (bit i of cu_mask = CU i enabled).  The async agent step runs
@@ -290,7 +295,9 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= alloc_f(&l->dq, (int64_t)B * NO); rc |= alloc_f(&l->dh4, (int64_t)B * 512);
   rc |= alloc_f(&l->dy3, (int64_t)B * 64 * 49); rc |= alloc_f(&l->dy2, (int64_t)B * 64 * 81);
   rc |= alloc_f(&l->dy1, (int64_t)B * 32 * 400);
-  rc |= alloc_f(&l->delta, B); rc |= alloc_f(&l->prio, B); rc |= alloc_f(&l->weights, B);
+  // (the quantile head's loss vector has one entry per target quantile: QuantileRegressionDQN_agent.py:75-77)
+  rc |= alloc_f(&l->delta, (cfg->head_kind == DRA_HEAD_QUANTILE && cfg->n_atoms > B) ? cfg->n_atoms : B);
+  rc |= alloc_f(&l->prio, B); rc |= alloc_f(&l->weights, B);
   rc |= alloc_f(&l->samp_prob, B + 1);   // [B] = the PER exponent beta of the update (graph-replayable PER launches)
   l->slab_stride = cfg->conv_end;  // conv segment occupies [0, conv_end) of the flat layout
   rc |= alloc_f(&l->slabs, (int64_t)cfg->ksplit * l->slab_stride);
@@ -510,23 +517,50 @@ struct HeadSpec {
   int kind, n_atoms;
   const float* atoms;
   float* out;          // optional global copy of the A*N head outputs (tests)
+  const float* pre;    // optional: the A*N head outputs, already computed (actor_dist_gemv_kernel)
 };
 
 static HeadSpec head_spec(const dra_dqn_learner* l) {
   HeadSpec hs;
-  hs.kind = l->c.head_kind; hs.n_atoms = l->c.n_atoms; hs.atoms = l->atoms; hs.out = l->alog;
+  hs.kind = l->c.head_kind; hs.n_atoms = l->c.n_atoms; hs.atoms = l->atoms; hs.out = l->alog; hs.pre = nullptr;
   return hs;
 }
 
+// out[o] = bh[o] + <h4, Wh[o]> for the A*N outputs of a distributional head at batch 1: one wave per output (its 2 KB weight
+// row = 8 floats per lane, all requested at once), same per-lane products and butterfly as dist_head_q: bit-identical.
+__global__ void __launch_bounds__(256)
+actor_dist_gemv_kernel(const float* __restrict__ h4, const float* __restrict__ wh, const float* __restrict__ bh, int NO,
+                       float* __restrict__ out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + wave;
+  const float* row = wh + (int64_t)min(o, NO - 1) * 512;
+  float hv[8], wv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { wv[i] = row[lane + 64 * i]; hv[i] = h4[lane + 64 * i]; }
+  const float bias = bh[min(o, NO - 1)];
+  float part = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) part += hv[i] * wv[i];
+  part = wave_sum(part);
+  if (lane == 0 && o < NO) out[o] = part + bias;
+}
+
+// hs.pre != null: the A*N head outputs were already formed by actor_dist_gemv_kernel (one wave per output over many CUs: the
+// in-workgroup loop below is 4 / 13 dependent passes for C51 / QR-DQN at 16 waves -- 12 / 34 us of the actor's env step,
+// profiles/r02zu_kernel_stats_*); they are only copied in.
 __device__ __forceinline__ void dist_head_q(const float* __restrict__ h4, const float* __restrict__ wh,
                                             const float* __restrict__ bh, int A, const HeadSpec hs,
                                             float* __restrict__ s_out, float* __restrict__ s_q) {
   const int nw = (int)(blockDim.x >> 6), wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int N = hs.n_atoms, NO = A * N;
+  if (hs.pre) {
+    for (int o = threadIdx.x; o < NO; o += blockDim.x) s_out[o] = hs.pre[o];
+    __syncthreads();
+  }
   float hv[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) hv[i] = h4[lane + 64 * i];
-  for (int o0 = wave * 4; o0 < NO; o0 += nw * 4) {
+  for (int o0 = wave * 4; o0 < NO && !hs.pre; o0 += nw * 4) {
     float wv[4][8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -1923,6 +1957,12 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   return DRA_OK;
 }
 
+static int actor_dist_gemv() {   // DRA_ACTOR_DIST_GEMV=0: the distributional head's outputs inside the one-workgroup head kernel
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_ACTOR_DIST_GEMV"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
   if (l->variant & DRA_VAR_ACTOR_FUSED_CONV1) return run_actor_steps_ring_fused(l, n_env, P, st);
   const dra_dqn_config& c = l->c;
@@ -1946,10 +1986,17 @@ static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, h
     if ((rc = dra_conv_fwd_koc(3, 1, x3, w3, b3, y3, 1, 0, 1.0, DRA_ACT_RELU, s))) return rc;
     hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
                        l->ah4, 3136);
+    HeadSpec hs = head_spec(l);
+    if (c.head_kind != DRA_HEAD_VANILLA && actor_dist_gemv()) {
+      hipLaunchKernelGGL(actor_dist_gemv_kernel, dim3((l->n_out + 3) / 4), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH],
+                         P + o[P_BH], l->n_out, l->alog);
+      hs.pre = l->alog;
+      hs.out = nullptr;
+    }
     hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq, e,
                        (int)(e == n_env - 1), 1, (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions,
                        l->aq, (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
-                       (uint64_t)c.env_seed, (int)c.env_done_period, head_spec(l));
+                       (uint64_t)c.env_seed, (int)c.env_done_period, hs);
     DRA_LAUNCH_CHECK();
   }
   return DRA_OK;

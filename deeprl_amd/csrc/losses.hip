@@ -130,31 +130,45 @@ c51_loss_kernel(const float* __restrict__ logits, const float* __restrict__ logi
   const float zj = on ? atoms[j] : 0.f;
   if (on) s_z[j] = zj;
 
+  // every load that does not depend on the greedy action is requested up front: stored action -> its online row, the
+  // transition scalars, and the selector rows four at a time (the first version paid one memory round trip per action,
+  // one for the target row and two for the online row: 12.6 us at B=32, profiles/r02zu_kernel_stats_c51_*)
+  const int64_t a = load_action(action, action_i64, b, A);
+  const float r = reward[b], gm = __fmul_rn(gamma_n, mask[b]);
+  const float x_on = on ? logits[((int64_t)b * A + a) * N + j] : -INFINITY;
   // greedy next action under the selector net (online for double-Q, else target)
   const float* sel = (logits_o ? logits_o : logits_t) + (int64_t)b * A * N;
-  float best_q = -INFINITY;
+  float best_q = -INFINITY, p_best = 0.f;   // p_best: softmax(selector row of the greedy action)_j
   int best_a = 0;
-  for (int a = 0; a < A; ++a) {
-    const float x = on ? sel[a * N + j] : -INFINITY;
-    const float mx = block_max(x, s_red);
-    const float e = on ? expf(x - mx) : 0.f;
-    const float den = block_sum(e, s_red);
-    const float qa = block_sum(on ? (e / den) * zj : 0.f, s_red);
-    if (qa > best_q) { best_q = qa; best_a = a; }
+  for (int a0 = 0; a0 < A; a0 += 4) {
+    float xs[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xs[u] = (on && a0 + u < A) ? sel[(a0 + u) * N + j] : -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (a0 + u < A) {
+        const float mx = block_max(xs[u], s_red);
+        const float e = on ? expf(xs[u] - mx) : 0.f;
+        const float den = block_sum(e, s_red);
+        const float qa = block_sum(on ? (e / den) * zj : 0.f, s_red);
+        if (qa > best_q) { best_q = qa; best_a = a0 + u; p_best = e / den; }
+      }
+    }
   }
-  if (j == 0) s_anext = best_a;
-  __syncthreads();
-  const int a_next = s_anext;
-  {  // p_next = softmax(target logits[b, a_next, :])
+  if (logits_o) {  // double-Q: p_next = softmax(TARGET logits[b, a_next, :]), the selector was the online net
+    if (j == 0) s_anext = best_a;
+    __syncthreads();
+    const int a_next = s_anext;
     const float x = on ? logits_t[((int64_t)b * A + a_next) * N + j] : -INFINITY;
     const float mx = block_max(x, s_red);
     const float e = on ? expf(x - mx) : 0.f;
     const float den = block_sum(e, s_red);
     if (on) s_p[j] = e / den;
+  } else if (on) {
+    s_p[j] = p_best;                       // the same exp / sum / divide the selection loop performed on that row
   }
   __syncthreads();
   // projected target m_j = sum_i clamp(1 - |Tz_i - z_j| / dz, 0, 1) * p_i
-  const float r = reward[b], gm = __fmul_rn(gamma_n, mask[b]);
   float m = 0.f;
   if (on) {
     for (int i = 0; i < N; ++i) {
@@ -167,8 +181,7 @@ c51_loss_kernel(const float* __restrict__ logits, const float* __restrict__ logi
     }
   }
   // online log-softmax on row a
-  const int64_t a = load_action(action, action_i64, b, A);
-  const float x = on ? logits[((int64_t)b * A + a) * N + j] : -INFINITY;
+  const float x = x_on;
   const float mx = block_max(x, s_red);
   const float e = on ? expf(x - mx) : 0.f;
   const float den = block_sum(e, s_red);
@@ -210,55 +223,70 @@ __device__ __forceinline__ float huber1(float d) {
 }
 __device__ __forceinline__ float huber1_grad(float d) { return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)); }
 
+// grid (B, 2): blockIdx.y = 0 computes the gradient (thread = online quantile i, sum over target quantiles j),
+// blockIdx.y = 1 the per-target-quantile loss (thread = target quantile j, sum over i) -- the two O(N^2) passes of a sample
+// run on different CUs.  Every global load of a workgroup is requested before the first reduction (the target rows of ALL
+// actions, the online row of the stored action as soon as the action is known); tau_i = (2i+1)/(2N) is formed once per
+// thread (fp64, then f32 as the reference's tensor() does) and kept in LDS -- the first version divided in fp64 inside
+// the inner loop and loaded the rows one action at a time: 34 us at B=32, N=200 (profiles/r02zu_kernel_stats_qr_*).
+// Same arithmetic, same summation order.
 __global__ void __launch_bounds__(1024)
 qr_loss_kernel(const float* __restrict__ theta, const float* __restrict__ theta_t, const void* __restrict__ action,
                int action_i64, const float* __restrict__ reward, const float* __restrict__ mask, int B, int A, int N,
                float gamma_n, float* __restrict__ out_partial /*[B][N]*/, float* __restrict__ out_dtheta) {
-  extern __shared__ float smem[];  // [N] T theta | [N] theta_a
+  extern __shared__ float smem[];  // [N] T theta | [N] theta_a | [N] tau
   __shared__ float s_red[16];
-  __shared__ int s_anext;
   float* s_t = smem;
   float* s_th = smem + N;
-  const int b = blockIdx.x, i = threadIdx.x;
+  float* s_tau = smem + 2 * N;
+  const int b = blockIdx.x, i = threadIdx.x, pass = blockIdx.y;
   const bool on = i < N;
+  if (pass == 0 && !out_dtheta) return;
   const float* tt = theta_t + (int64_t)b * A * N;
-  float best = -INFINITY;
-  int best_a = 0;
-  for (int a = 0; a < A; ++a) {  // a* = argmax_a sum_q theta_target
-    const float s = block_sum(on ? tt[a * N + i] : 0.f, s_red);
-    if (s > best) { best = s; best_a = a; }
-  }
-  if (i == 0) s_anext = best_a;
-  __syncthreads();
   const int64_t a = load_action(action, action_i64, b, A);
+  const float rb = reward[b], gm = __fmul_rn(gamma_n, mask[b]);
+  const float th_i = on ? theta[((int64_t)b * A + a) * N + i] : 0.f;
+  if (on) s_tau[i] = (float)((2.0 * (double)i + 1.0) / (2.0 * (double)N));
+  float best = -INFINITY, x_best = 0.f;   // x_best: this thread's element of the greedy action's target row
+  for (int a0 = 0; a0 < A; a0 += 4) {  // a* = argmax_a sum_q theta_target: four rows in flight
+    float x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = (on && a0 + u < A) ? tt[(a0 + u) * N + i] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (a0 + u < A) {
+        const float sm = block_sum(x[u], s_red);
+        if (sm > best) { best = sm; x_best = x[u]; }
+      }
+    }
+  }
   if (on) {
     // rewards + gamma^n * masks * quantiles_next -> r + ((g*m)*theta')
-    s_t[i] = __fadd_rn(reward[b], __fmul_rn(__fmul_rn(gamma_n, mask[b]), tt[s_anext * N + i]));
-    s_th[i] = theta[((int64_t)b * A + a) * N + i];
+    s_t[i] = __fadd_rn(rb, __fmul_rn(gm, x_best));
+    s_th[i] = th_i;
   }
   __syncthreads();
-  if (out_dtheta) {
+  if (pass == 0) {
     float* g = out_dtheta + (int64_t)b * A * N;
     for (int k = i; k < A * N; k += blockDim.x) g[k] = 0.f;
     __syncthreads();
     if (on) {
-      const float tau = (float)((2.0 * (double)i + 1.0) / (2.0 * (double)N));
-      const float th = s_th[i];
+      const float tau = s_tau[i];
       float acc = 0.f;
       for (int j = 0; j < N; ++j) {
-        const float d = s_t[j] - th;
+        const float d = s_t[j] - th_i;
         acc += huber1_grad(d) * fabsf(tau - (d < 0.f ? 1.f : 0.f));
       }
       g[a * N + i] = -acc / ((float)N * (float)B);  // loss = mean_j mean_b sum_i rho ; d(d)/d(theta) = -1
     }
+    return;
   }
   if (on) {
     const float tj = s_t[i];  // thread plays target quantile j = i
     float l = 0.f;
     for (int k = 0; k < N; ++k) {
       const float d = tj - s_th[k];
-      const float tau = (float)((2.0 * (double)k + 1.0) / (2.0 * (double)N));
-      l += huber1(d) * fabsf(tau - (d < 0.f ? 1.f : 0.f));
+      l += huber1(d) * fabsf(s_tau[k] - (d < 0.f ? 1.f : 0.f));
     }
     out_partial[(int64_t)b * N + i] = l;
   }
@@ -271,7 +299,15 @@ qr_finalize_kernel(const float* __restrict__ partial, int B, int N, float* __res
   const int j = threadIdx.x;
   float l = 0.f;
   if (j < N) {
-    for (int b = 0; b < B; ++b) l += partial[(int64_t)b * N + j];
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {   // eight samples in flight, added in sample order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + u) * N + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) l += v[u];
+    }
+    for (; b < B; ++b) l += partial[(int64_t)b * N + j];
     l /= (float)B;
     if (out_loss_vec) out_loss_vec[j] = l;
   }
@@ -286,7 +322,7 @@ DRA_API int dra_qr_loss(const float* theta, const float* theta_next_target, cons
       n_actions < 1 || n_quantiles < 1 || n_quantiles > 1024)
     return DRA_EINVAL;
   const int threads = ((n_quantiles + 63) / 64) * 64;
-  hipLaunchKernelGGL(qr_loss_kernel, dim3(batch), dim3(threads), 2 * n_quantiles * sizeof(float), dra_stream(stream),
+  hipLaunchKernelGGL(qr_loss_kernel, dim3(batch, 2), dim3(threads), 3 * n_quantiles * sizeof(float), dra_stream(stream),
                      theta, theta_next_target, action, action_is_i64, reward, mask, batch, n_actions, n_quantiles, gamma_n,
                      workspace, out_dtheta);
   DRA_LAUNCH_CHECK();

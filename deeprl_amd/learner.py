@@ -202,6 +202,8 @@ class DQNLearner:
     def loss(self):
         """Reduced loss of the last update: mean(0.5 * delta^2) recovered from the TD errors (DQN_agent.py:78-79); for the
         distributional heads `delta` holds the per-sample KL / quantile-Huber loss and this is its mean."""
+        if self.head_kind == HEAD_QUANTILE:
+            return self._loss_per[0]          # the quantile loss kernel reduces it itself (one entry per target quantile)
         if self.head_kind != HEAD_VANILLA:
             return self.delta.mean()
         return self.delta.pow(2).mul(0.5).mean()
