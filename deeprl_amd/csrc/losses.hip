@@ -273,6 +273,7 @@ qr_loss_kernel(const float* __restrict__ theta, const float* __restrict__ theta_
     if (on) {
       const float tau = s_tau[i];
       float acc = 0.f;
+#pragma unroll 8
       for (int j = 0; j < N; ++j) {
         const float d = s_t[j] - th_i;
         acc += huber1_grad(d) * fabsf(tau - (d < 0.f ? 1.f : 0.f));
@@ -284,6 +285,7 @@ qr_loss_kernel(const float* __restrict__ theta, const float* __restrict__ theta_
   if (on) {
     const float tj = s_t[i];  // thread plays target quantile j = i
     float l = 0.f;
+#pragma unroll 8
     for (int k = 0; k < N; ++k) {
       const float d = tj - s_th[k];
       l += huber1(d) * fabsf(s_tau[k] - (d < 0.f ? 1.f : 0.f));

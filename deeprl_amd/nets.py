@@ -154,8 +154,14 @@ class _ConvKocFn(torch.autograd.Function):
         dx, slabs, n_slabs, stride = ops.conv_bwd_fused_koc(layer, dpre, x, w.permute(1, 2, 3, 0), ksplit=_ConvKocFn.KSPLIT,
                                                             u8_coef=ctx.u8_coef, variant=variant)
         flat = torch.empty(stride, dtype=torch.float32, device=w.device)
-        partials = torch.empty(ops.norm_partials(), dtype=torch.float64, device=w.device)
-        ops.grad_sqnorm(flat, partials, slabs=slabs, n_slabs=n_slabs, slab_stride=stride)      # fixed-order slab fold
+        if n_slabs > 32 and stride % 4 == 0:
+            # one slab per (sample, row chunk): hundreds of slabs -- the segmented fold keeps 160 of them in flight per element
+            # (dra_grad_sqnorm's per-element serial walk is for the <= 64 slabs of the fixed split-K kernels)
+            partials = torch.empty(ops.norm_partials_max(), dtype=torch.float64, device=w.device)
+            ops.grad_sqnorm_segs(flat, [(0, stride, slabs, stride, n_slabs)], partials)
+        else:
+            partials = torch.empty(ops.norm_partials(), dtype=torch.float64, device=w.device)
+            ops.grad_sqnorm(flat, partials, slabs=slabs, n_slabs=n_slabs, slab_stride=stride)  # fixed-order slab fold
         dw = flat[:n_w].view(c, kh, kw, oc).permute(3, 0, 1, 2)
         db = flat[n_w:n_w + oc]
         return (dx if ctx.needs_input_grad[0] and layer > 1 else None), dw, db, None, None

@@ -43,8 +43,11 @@ def test_fc4_k_split_changes_results_only_at_rounding_level(tmp_path):
     agree to fp32 reassociation (parameters rtol 1e-4 / atol 1e-6 after 50 updates), not bit for bit."""
     a = _run("dqn", {"DRA_FC4_KS": "14"}, tmp_path, "ks14")
     b = _run("dqn", {"DRA_FC4_KS": "8"}, tmp_path, "ks8")
-    assert np.mean(a["act"][:200] == b["act"][:200]) > 0.9        # an fp32 near-tie may flip a greedy action
-    if np.array_equal(a["act"], b["act"]):
+    # the 40 exploration steps (160 transitions) run before the first update: the K split cannot have touched them
+    assert np.array_equal(a["act"][:160], b["act"][:160]) and np.array_equal(a["rew"][:240], b["rew"][:240])
+    if np.array_equal(a["act"], b["act"]):   # (an fp32 near-tie may flip a greedy action; the runs then part ways)
         for k in a:
             if k.startswith("p_"):
                 np.testing.assert_allclose(a[k], b[k], rtol=1e-4, atol=1e-6, err_msg=k)
+    for k in a:
+        assert np.isfinite(a[k]).all() and np.isfinite(b[k]).all()
