@@ -179,6 +179,10 @@ struct dra_dqn_learner {
   int64_t* idx_tag_dev;             // [4][1024]
   unsigned long long* rd_seq_dev;   // ring-direct updates completed (bumped by each one's head kernel)
   uint64_t rd_issued;               // ring-direct updates issued (host)
+  float* sp_stage;                  // pinned [8][1025]: staging of dra_dqn_learner_upload_sampling_prob
+  hipEvent_t sp_ev[8];
+  bool sp_used[8];
+  int sp_k;
   bool coop;                        // decided once, before the first graph capture
   bool captured;                    // some graph has been captured (the decision above is baked into it)
 };
@@ -370,6 +374,8 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
     rc |= (int)hipMalloc(&l->rd_seq_dev, sizeof(unsigned long long));
     if (!rc) rc |= (int)hipMemset(l->rd_seq_dev, 0, sizeof(unsigned long long));
   }
+  rc |= (int)hipHostMalloc(&l->sp_stage, (size_t)8 * 1025 * sizeof(float), hipHostMallocDefault);
+  for (int k = 0; k < 8; ++k) rc |= (int)hipEventCreateWithFlags(&l->sp_ev[k], hipEventDisableTiming);
   rc |= (int)hipMalloc(&l->coop_ctr, sizeof(unsigned long long));
   if (!rc) rc |= (int)hipMemset(l->coop_ctr, 0, sizeof(unsigned long long));
   rc |= (int)hipHostMalloc(&l->coop_flag, sizeof(int), hipHostMallocDefault);
@@ -461,6 +467,8 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   for (int k = 0; k < 4; ++k) if (l->idx_tag_pin[k]) (void)hipHostFree(l->idx_tag_pin[k]);
   if (l->idx_tag_dev) (void)hipFree(l->idx_tag_dev);
   if (l->rd_seq_dev) (void)hipFree(l->rd_seq_dev);
+  if (l->sp_stage) (void)hipHostFree(l->sp_stage);
+  for (int k = 0; k < 8; ++k) if (l->sp_ev[k]) (void)hipEventDestroy(l->sp_ev[k]);
   if (l->coop_ctr) (void)hipFree(l->coop_ctr);
   if (l->coop_flag) (void)hipHostFree(l->coop_flag);
   if (l->qs_stage) (void)hipHostFree(l->qs_stage);
@@ -2604,6 +2612,23 @@ DRA_API int dra_dqn_learner_set_per(dra_dqn_learner* l, int per, float beta) {
   if (!l) return DRA_EINVAL;
   l->step_per = per != 0;
   l->step_beta = beta;
+  return DRA_OK;
+}
+
+// PER: the sampling probabilities of the minibatch (f64 on the host, f32 as tensor() would make them) and the importance
+// exponent beta go to the learner's sampling_prob buffer ([batch] probabilities, then beta) on `stream`, through the
+// learner's own rotating pinned staging -- one call instead of a pinned tensor copy, a device copy and an event in python.
+DRA_API int dra_dqn_learner_upload_sampling_prob(dra_dqn_learner* l, const double* prob_host, int n, float beta, void* stream) {
+  if (!l || !prob_host || n != l->c.batch) return DRA_EINVAL;
+  const int k = l->sp_k;
+  l->sp_k = (k + 1) % 8;
+  if (l->sp_used[k]) DRA_HIP(hipEventSynchronize(l->sp_ev[k]));
+  float* dst = l->sp_stage + (size_t)k * 1025;
+  for (int i = 0; i < n; ++i) dst[i] = (float)prob_host[i];
+  dst[n] = beta;
+  DRA_HIP(hipMemcpyAsync(l->samp_prob, dst, (size_t)(n + 1) * sizeof(float), hipMemcpyHostToDevice, dra_stream(stream)));
+  DRA_HIP(hipEventRecord(l->sp_ev[k], dra_stream(stream)));
+  l->sp_used[k] = true;
   return DRA_OK;
 }
 

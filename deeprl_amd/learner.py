@@ -224,18 +224,9 @@ class DQNLearner:
     def upload_sampling_prob(self, prob, beta):
         """PER: numpy sampling probabilities [batch] + the importance exponent -> the learner's device buffer (async,
         pinned staging).  The kernels read beta from device memory, so the PER update replays from a captured graph."""
-        k = self._sp_k
-        self._sp_k = (k + 1) % len(self._sp_pinned)
-        if self._sp_events[k] is not None:
-            self._sp_events[k].synchronize()
-        buf = self._sp_pinned[k].numpy()
-        buf[:self.batch] = prob                      # f64 -> f32, as tensor(transitions.sampling_prob) does
-        buf[self.batch] = beta
-        with torch.cuda.stream(self.stream):
-            self.sampling_prob.copy_(self._sp_pinned[k], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        self._sp_events[k] = ev
+        prob = np.ascontiguousarray(prob, dtype=np.float64)   # (f64 -> f32 in the C call, as tensor(transitions.sampling_prob) does)
+        lib.dra_dqn_learner_upload_sampling_prob(self.h, prob.ctypes.data_as(ctypes.c_void_p), int(prob.shape[0]), float(beta),
+                                                 self._sp())
 
     def update(self, idx=None, use_graph=True, sampling_prob=None, beta=0.0):
         """One gradient update (gather + forward/backward graph + optimizer) on the update stream.  sampling_prob (numpy
@@ -506,8 +497,7 @@ class DeviceActorPipeline:
         if not self.async_actor:
             infos = self._block()
             if self.per:
-                with torch.cuda.stream(self.tree_stream):
-                    rp.advance(self.n_env)
+                rp.advance(self.n_env, stream=self.tree_stream)
             else:
                 rp.advance(self.n_env)
             do_update = bool(account(infos))
@@ -517,15 +507,13 @@ class DeviceActorPipeline:
                 # (validity / padding stay on the host, draw for draw) hides under the actor's forward passes; importance
                 # weights are applied inside the update (captured graph, exponent from device memory) and the new priorities
                 # go back to the tree without leaving the device
-                with torch.cuda.stream(self.tree_stream):
-                    pending_draw = rp.draw_begin()
+                pending_draw = rp.draw_begin(stream=self.tree_stream)
                 L.set_per(False, 0.0)
                 L.step(None, False, False)            # actor transitions only (in order, on the update stream)
                 tree_idx, prob, data_idx = rp.draw_end(pending_draw)
                 L.update(data_idx, use_graph=True, sampling_prob=prob, beta=self.beta_fn())
                 self.tree_stream.wait_stream(L.stream)                # the write-back reads this update's priorities
-                with torch.cuda.stream(self.tree_stream):
-                    rp.commit_device(tree_idx, L.prio)
+                rp.commit_device(tree_idx, L.prio, stream=self.tree_stream)
                 return infos
             idx = rp.draw_indices() if do_update else None
             if self.per:
@@ -541,8 +529,7 @@ class DeviceActorPipeline:
             self.primed = True
         infos = self.pending.pop(0)                                  # produced by the actor launch issued last call
         if self.per:
-            with torch.cuda.stream(self.tree_stream):
-                rp.advance(self.n_env)
+            rp.advance(self.n_env, stream=self.tree_stream)
         else:
             rp.advance(self.n_env)
         do_update = bool(account(infos))
@@ -553,15 +540,15 @@ class DeviceActorPipeline:
             # PrioritizedReplay inside the two-stream pipeline: the draw of step t needs the priorities update t-1 wrote
             # back, so the host does wait once per step (tree stream: write-back t-1, adds t, descent t -> pinned memory);
             # the actor transitions of step t+1 still run underneath update t on their own stream and CU partition
-            with torch.cuda.stream(self.tree_stream):
-                pending_draw = rp.draw_begin()
+            # (every tree-stream call takes the stream explicitly: torch's stream / device context managers and per-call Event
+            # objects were ~100 us of host time per step, and the host IS on this pipeline's critical path)
+            pending_draw = rp.draw_begin(stream=self.tree_stream)
             tree_idx, prob, data_idx = rp.draw_end(pending_draw)
             L.upload_sampling_prob(prob, self.beta_fn())
             L.set_per(True, -1.0)
             L.step(data_idx, True, True)                             # update(t) with importance weights, actor(t+1)
             L.wait_loss(self.tree_stream)                            # the write-back starts under the backward pass
-            with torch.cuda.stream(self.tree_stream):
-                rp.commit_device(tree_idx, L.prio)
+            rp.commit_device(tree_idx, L.prio, stream=self.tree_stream)
             self.issued += 1
             return infos
         if self.per:

@@ -135,20 +135,20 @@ class SumTree:
         """set() with the priority read from device memory (f64 tensor, first element)."""
         lib.dra_sumtree_set_from(self.h, int(leaf_idx), ptr(prio_dev), stream_ptr())
 
-    def set_many_from(self, write0, n, prio_dev):
+    def set_many_from(self, write0, n, prio_dev, stream=None):
         """n consecutive adds at write cursor write0.. (mod capacity), all at the device-resident priority prio_dev[0]."""
-        lib.dra_sumtree_set_many_from(self.h, int(write0), int(n), ptr(prio_dev), stream_ptr())
+        lib.dra_sumtree_set_many_from(self.h, int(write0), int(n), ptr(prio_dev), stream_ptr(stream))
 
-    def sample_into(self, u, out_idx, out_p, out_total):
-        """sample() into caller-provided buffers (e.g. pinned host memory the kernel writes directly)."""
-        lib.dra_sumtree_sample(self.h, ptr(u), u.numel(), ptr(out_idx), ptr(out_p), ptr(out_total), stream_ptr())
+    def sample_into(self, u, out_idx, out_p, out_total, stream=None):
+        """sample() into caller-provided buffers (e.g. pinned host memory the kernel writes directly; `u` may be pinned too)."""
+        lib.dra_sumtree_sample(self.h, ptr(u), u.numel(), ptr(out_idx), ptr(out_p), ptr(out_total), stream_ptr(stream))
 
-    def commit_f32(self, leaf_idx, pos, prio_f32, stat, force_ordered=False):
+    def commit_f32(self, leaf_idx, pos, prio_f32, stat, force_ordered=False, stream=None):
         """Priority write-back with the values still on the device: leaf_idx[i] <- f64(prio_f32[pos[i]]); stat (f64[2] device
         tensor) = {running max, running min} over ALL of prio_f32 (dra_sumtree_commit_f32)."""
         n = 0 if leaf_idx is None else leaf_idx.numel()
         lib.dra_sumtree_commit_f32(self.h, ptr(leaf_idx) if n else None, ptr(pos) if n else None, n, ptr(prio_f32),
-                                   prio_f32.numel(), ptr(stat), int(bool(force_ordered)), stream_ptr())
+                                   prio_f32.numel(), ptr(stat), int(bool(force_ordered)), stream_ptr(stream))
 
     def sample(self, u):
         u = _c(u, torch.float64)

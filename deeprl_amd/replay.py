@@ -10,6 +10,7 @@ What stays on the host, on purpose: `pos` / `size` bookkeeping, `valid_index`, a
 draw (numpy legacy global RandomState for uniform sampling, python `random` for prioritized
 sampling) -- the index stream is therefore the reference's own, draw for draw.
 """
+import contextlib
 import random
 from collections import namedtuple
 
@@ -64,25 +65,35 @@ class Storage:
 
 class _PinnedUploader:
     """Rotating pinned staging buffers for the few hundred bytes of indices / uniforms that cross
-    the host->device boundary per sample; an event per slot guards reuse."""
+    the host->device boundary per sample; an event per slot guards reuse.
+
+    device_copy=False hands the KERNEL the pinned buffer itself (pinned host memory is device-addressable: a
+    single-workgroup tree kernel reading 32 words over the host link pays ~1.5 us inside the kernel instead of a copy command
+    in front of it and ~15 us of host time for the tensor copy -- cProfile of the prioritized agent step,
+    profiles/r02zz1_host_profile_per.txt: the PER pipeline was bound by exactly this host path)."""
 
     def __init__(self, dtype, numel, device, slots=8):
         self.bufs = [torch.empty(numel, dtype=dtype).pin_memory() for _ in range(slots)]
+        self.views = [b.numpy() for b in self.bufs]
         self.events = [None] * slots
+        self.used = [False] * slots
         self.device = device
         self.k = 0
 
-    def upload(self, array):
+    def upload(self, array, device_copy=True, stream=None):
         k = self.k
         self.k = (k + 1) % len(self.bufs)
-        if self.events[k] is not None:
+        if self.used[k]:
             self.events[k].synchronize()
         n = len(array)
-        self.bufs[k][:n].copy_(torch.from_numpy(np.ascontiguousarray(array)))
-        out = self.bufs[k][:n].to(self.device, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.events[k] = ev
+        self.views[k][:n] = array                      # (numpy casts to the buffer's dtype)
+        out = self.bufs[k][:n]
+        if device_copy:
+            out = out.to(self.device, non_blocking=True)
+        if self.events[k] is None:
+            self.events[k] = torch.cuda.Event()
+        self.events[k].record(stream)
+        self.used[k] = True
         return out
 
 
@@ -304,40 +315,54 @@ class PrioritizedReplay(UniformReplay):
         if self._write >= self.memory_size:
             self._write = 0
 
-    def advance(self, n=1):
-        """UniformReplay.advance + the tree side of feed() for transitions a DEVICE producer wrote into the ring."""
+    def advance(self, n=1, stream=None):
+        """UniformReplay.advance + the tree side of feed() for transitions a DEVICE producer wrote into the ring.
+        stream: where the tree kernels go (default: torch's current stream)."""
         n = int(n)
         super().advance(n)
         self._lazy_tree()
         if not self._stat_on_device or n > 64 or n > self.memory_size:
-            for _ in range(n):
-                self._add_leaf()
+            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                for _ in range(n):
+                    self._add_leaf()
             return
         for i in range(n):
             self._pending.discard((self._write + i) % self.memory_size + self.memory_size - 1)
-        with torch.cuda.device(self._device()):
-            self.tree.set_many_from(self._write, n, self._stat)      # one launch for the whole agent step's adds
+        with self._on_device():
+            self.tree.set_many_from(self._write, n, self._stat, stream=stream)   # one launch for the whole agent step's adds
         self._write = (self._write + n) % self.memory_size
 
-    def draw_begin(self, batch_size=None):
-        """First half of draw(): B uniforms from python `random` (replay.py:169-172) and the tree descent enqueued on the
-        current stream, its results going straight into pinned host memory.  draw_end() waits for them; anything enqueued
-        in between (the device actor's forward passes) overlaps the host round trip."""
+    def _on_device(self):
+        """torch.cuda.device(ring's device) only when it is not already current (the context manager costs ~5 us, and a
+        prioritized agent step enters it four times)."""
+        dev = self._device()
+        if dev.index is None or torch.cuda.current_device() == dev.index:
+            return contextlib.nullcontext()
+        return torch.cuda.device(dev)
+
+    def draw_begin(self, batch_size=None, stream=None):
+        """First half of draw(): B uniforms from python `random` (replay.py:169-172) and the tree descent enqueued on
+        `stream` (default: the current one), its results going straight into pinned host memory.  draw_end() waits for them;
+        anything enqueued in between (the device actor's forward passes) overlaps the host round trip."""
         if batch_size is None:
             batch_size = self.batch_size
         self._lazy_tree()
-        u = np.asarray([random.random() for _ in range(batch_size)], dtype=np.float64)
-        with torch.cuda.device(self._device()):
+        u = [random.random() for _ in range(batch_size)]
+        with self._on_device():
             if self._draw_out is None or self._draw_out[0].numel() < batch_size:
                 self._draw_out = (torch.empty(batch_size, dtype=torch.int64).pin_memory(),
                                   torch.empty(batch_size, dtype=torch.float64).pin_memory(),
                                   torch.empty(1, dtype=torch.float64).pin_memory())
+                self._draw_np = tuple(t.numpy() for t in self._draw_out)
+                self._draw_ev = [torch.cuda.Event(), torch.cuda.Event()]
+                self._draw_k = 0
             oi, op, ot = self._draw_out
-            # the descent kernel writes leaves / priorities / total into pinned host memory: no packing kernels, no copy
-            # command -- one event wait is the whole host round trip of a prioritized draw
-            self.tree.sample_into(self._u_up.upload(u), oi, op, ot)
-            ev = torch.cuda.Event()
-            ev.record()
+            # the descent kernel READS its uniforms from pinned host memory and WRITES leaves / priorities / total into pinned
+            # host memory: no packing kernels, no copy command -- one event wait is the whole host round trip of a draw
+            self.tree.sample_into(self._u_up.upload(u, device_copy=False, stream=stream), oi, op, ot, stream=stream)
+            self._draw_k ^= 1
+            ev = self._draw_ev[self._draw_k]
+            ev.record(stream)
         return batch_size, ev
 
     def draw_end(self, pending_draw):
@@ -345,10 +370,16 @@ class PrioritizedReplay(UniformReplay):
         `random` exactly as the reference: one random.choice per padded slot.  Returns (tree_idx, sampling_prob, data_idx)."""
         batch_size, ev = pending_draw
         ev.synchronize()
-        oi, op, ot = self._draw_out
-        tree_idx = oi.numpy()[:batch_size].copy()
-        p = op.numpy()[:batch_size].copy()
-        total = float(ot.numpy()[0])
+        oi, op, ot = self._draw_np
+        tree_idx = oi[:batch_size].copy()
+        p = op[:batch_size].copy()
+        total = float(ot[0])
+        # the common case without the per-sample python loop: every drawn transition is valid -> nothing is skipped or padded
+        di_all = tree_idx - (self.memory_size - 1)
+        lo, hi = di_all - self.history_length + 1, di_all + self.n_step
+        if bool((((lo >= 0) & (hi < self.pos)) | ((lo >= self.pos) & (hi < self.size()))).all()):
+            self._pending.update(tree_idx.tolist())     # sum_tree.py:66
+            return tree_idx, p / total, di_all
         picked = []
         for i in range(batch_size):
             ti = int(tree_idx[i])
@@ -396,7 +427,7 @@ class PrioritizedReplay(UniformReplay):
                                  self._prio_up.upload(np.asarray(prios, dtype=np.float64)),
                                  ordered=self.ordered_updates or not self._exact_parallel())
 
-    def commit_device(self, tree_idx, prio_f32):
+    def commit_device(self, tree_idx, prio_f32, stream=None):
         """update_priorities(zip(tree_idx, prio)) with the priorities still on the device (f32 tensor, one per sampled
         transition, in sample order): the host applies pending_idx gating / first-writer-wins (which need no priority
         value) and the kernel writes the chosen leaves, keeps max_priority and falls back to the ordered walk by itself
@@ -412,13 +443,13 @@ class PrioritizedReplay(UniformReplay):
                 self._pending.remove(idx)
                 leaves.append(idx)
                 pos.append(j)
-        with torch.cuda.device(self._device()):
+        with self._on_device():
             if leaves:
-                self.tree.commit_f32(self._leaf_up.upload(np.asarray(leaves, dtype=np.int64)),
-                                     self._pos_up.upload(np.asarray(pos, dtype=np.int32)), prio_f32, self._stat,
-                                     force_ordered=self.ordered_updates)
+                self.tree.commit_f32(self._leaf_up.upload(leaves, device_copy=False, stream=stream),
+                                     self._pos_up.upload(pos, device_copy=False, stream=stream), prio_f32, self._stat,
+                                     force_ordered=self.ordered_updates, stream=stream)
             else:
-                self.tree.commit_f32(None, None, prio_f32, self._stat, force_ordered=self.ordered_updates)
+                self.tree.commit_f32(None, None, prio_f32, self._stat, force_ordered=self.ordered_updates, stream=stream)
 
     def close(self):
         super().close()

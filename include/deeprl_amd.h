@@ -327,6 +327,9 @@ int dra_dqn_learner_update(dra_dqn_learner* learner, int use_graph, int per, flo
 /* PER for the in-order dra_dqn_learner_step (stream_actor == NULL): importance weights from the learner's sampling_prob
  * buffer with exponent beta, new priorities into its prio buffer (DQN_agent.py:120-127) */
 int dra_dqn_learner_set_per(dra_dqn_learner* learner, int per, float beta);
+/* PER: sampling probabilities (host f64[batch], converted to f32) + importance exponent -> the learner's sampling_prob
+ * buffer on `stream`, through the learner's own pinned staging (DQN_agent.py:120-127's tensor(sampling_prob)) */
+int dra_dqn_learner_upload_sampling_prob(dra_dqn_learner* learner, const double* prob_host, int n, float beta, void* stream);
 /* DRA_VAR_COOP_OPT: n_cus = compute units the update stream may use (its CU mask, or the whole device).  Decides, once and
  * before the first update, whether slab fold + gradient norm + optimiser run as ONE cooperative launch
  * (dra_clip_step_coop: needs its whole grid resident on those CUs) or as two launches.  _coop_state reports the decision,
