@@ -407,7 +407,7 @@ def main():
             except Exception as e:      # the checker must never take the measurement down with it
                 parity = {"ok": False, "error": repr(e)}
         roof = bench.roofline(200 if args.steps < 500 else 500)
-        roof["source"] = "hip_events"
+        roof["source"] = "hip_events (pair around the kernel minus the pair's own cost, both measured live)"
         roof["traffic"] = pmc_traffic(roof["kernel"])
         # the update chain owns a CU partition while the device actor runs beside it (lever 5):
         # the kernel is timed on that stream, i.e. on this many of the device's CUs

@@ -1290,6 +1290,16 @@ DRA_API int dra_dqn_learner_profile(dra_dqn_learner* l, float* out_ms, int n_out
     DRA_HIP(hipEventElapsedTime(&ms, l->ev[k], l->ev[k + 1]));
     out_ms[k] = ms;
   }
+  if (n_out > K_COUNT) {
+    // the bracket itself: two event records with nothing in between, on the same stream.  A kernel's bracket reads
+    // (this) + (the kernel's duration); callers subtract it (rocprofv3's per-kernel durations have no such term)
+    DRA_HIP(hipEventRecord(l->ev[0], st));
+    DRA_HIP(hipEventRecord(l->ev[1], st));
+    DRA_HIP(hipEventSynchronize(l->ev[1]));
+    float ms = 0.f;
+    DRA_HIP(hipEventElapsedTime(&ms, l->ev[0], l->ev[1]));
+    out_ms[K_COUNT] = ms;
+  }
   return DRA_OK;
 }
 

@@ -344,6 +344,9 @@ int dra_dqn_learner_keep_minibatch(dra_dqn_learner* learner, int keep);
  * first half of the update issued last, i.e. until its TD errors / new priorities exist (the write-back to the sum tree and
  * the next prioritized draw then run under the backward pass) */
 int dra_dqn_learner_wait_loss(dra_dqn_learner* learner, void* stream);
+/* measurement aid: one eager update with a HIP event in front of every kernel group; out_ms[k] = milliseconds of group k
+ * (dra_dqn_learner_kernel_count groups, names from _kernel_name).  With n_out > count, out_ms[count] = the same event pair
+ * with NOTHING in between (the bracket's own cost, to be subtracted).  Synchronises. */
 int dra_dqn_learner_profile(dra_dqn_learner* learner, float* out_ms, int n_out, void* stream);
 /* the minibatch the most recently issued update consumed (device pointers into the learner's buffers: u8 states /
  * next states [B][4][84][84], int64 actions [B], f32 rewards / masks [B]); for checkers, after a synchronise */

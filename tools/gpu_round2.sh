@@ -25,3 +25,5 @@ timeout 200 python tools/phase_trace.py --sync > $OUT/phase_sync.json 2>> $OUT/p
 unset DEEPRL_AMD_LIB
 echo "== agents bench"; timeout 400 python tools/bench_agents.py > $OUT/bench_agents.jsonl 2> $OUT/bench_agents.err; cat $OUT/bench_agents.jsonl | cut -c1-300
 echo "== done"
+echo "== launch contract: 2 ranks on this box (gloo barrier, replicas share the GPU)"; timeout 300 python bench.py --gpus 2 --steps 200 --warmup 20 --no-cpu-baseline --no-parity-check > $OUT/bench_2rank_one_box.json 2> $OUT/bench_2rank_one_box.err; head -c 300 $OUT/bench_2rank_one_box.json; echo
+echo "== GPU tests"; timeout 600 python -m pytest tests -q -m gpu -x -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; grep -E "passed|failed" $OUT/pytest_gpu.log | tail -2
