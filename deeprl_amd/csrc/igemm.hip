@@ -167,6 +167,65 @@ linear_gemv_kernel(LinPtrs q, int B, int K, int O, int act) {
   }
 }
 
+// Wide layers at rollout batch sizes (fc4 of NatureConvBody, 3136 -> 512, for the 8 / 16 environments of one A2C / PPO rollout
+// step): the K-chunked GEMM + its split-K finish were 13.2 + 5.4 us per rollout step (profiles/r02zw_kernel_stats_ppo_pixel_8.txt)
+// for 6.4 MB of weights and 26 MFLOP.  Same shape as the device actor's fc4 GEMV: one wave per output row, the row in registers
+// as R float4 per lane (all requested up front), the input rows staged in LDS eight at a time (100 KB at K = 3136) and shared
+// by the workgroup's four rows.  grid (ceil(O / 4), nz).  K % 4 == 0.
+template <int R>
+__global__ void __launch_bounds__(256)
+linear_gemv_wide_kernel(LinPtrs q, int B, int K, int O, int act) {
+  extern __shared__ __attribute__((aligned(16))) float s_x[];   // [<= 8 rows][K]
+  float4* __restrict__ s_x4 = reinterpret_cast<float4*>(s_x);
+  const int z = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + wave;
+  const int nv = K >> 2;
+  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(q.w[z] + (int64_t)min(o, O - 1) * K);
+  float4 wv[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) wv[i] = w4[min(lane + 64 * i, nv - 1)];
+  const float bias = q.bias[z] ? q.bias[z][min(o, O - 1)] : 0.f;
+  float* __restrict__ out = q.y[z];
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    const int nb = min(8, B - b0);
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(q.x[z] + (int64_t)b0 * K);
+    const int n4 = nb * nv;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n4; i += 256) s_x4[i] = src[i];
+    __syncthreads();
+    if (o < O) {
+      for (int b = 0; b < nb; ++b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const float4 a = wv[i];
+          const float4 xv = s_x4[b * nv + min(lane + 64 * i, nv - 1)];
+          if (lane + 64 * i < nv) acc += (a.x * xv.x + a.y * xv.y) + (a.z * xv.z + a.w * xv.w);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[(int64_t)(b0 + b) * O + o] = act_apply(acc + bias, act);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int R>
+static int launch_gemv_wide(const LinPtrs& q, int nz, int batch, int in_features, int out_features, int act, hipStream_t st) {
+  const size_t lds = (size_t)(batch < 8 ? batch : 8) * in_features * sizeof(float);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_gemv_wide_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(linear_gemv_wide_kernel<R>, dim3((out_features + 3) / 4, nz), dim3(256), lds, st, q, batch, in_features,
+                     out_features, act);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 static int gemv_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("DRA_LINEAR_GEMV"); v = e ? atoi(e) : 1; }
@@ -194,6 +253,22 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
     else hipLaunchKernelGGL(linear_gemv_kernel<8>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
     DRA_LAUNCH_CHECK();
     return DRA_OK;
+  }
+  if (in_features > 512 && in_features <= 4096 && (in_features & 3) == 0 && batch <= 32 && gemv_enabled()) {
+    LinPtrs q;
+    bool aligned = true;
+    for (int z = 0; z < nz; ++z) {
+      if (!x[z] || !w[z] || !y[z]) return DRA_EINVAL;
+      q.x[z] = x[z]; q.w[z] = w[z]; q.bias[z] = bias ? bias[z] : nullptr; q.y[z] = y[z];
+      aligned = aligned && !((((uintptr_t)x[z]) | ((uintptr_t)w[z])) & 15);
+    }
+    if (aligned) {
+      const int r = ((in_features >> 2) + 63) / 64;
+      if (r <= 4) return launch_gemv_wide<4>(q, nz, batch, in_features, out_features, act, st);
+      if (r <= 8) return launch_gemv_wide<8>(q, nz, batch, in_features, out_features, act, st);
+      if (r <= 13) return launch_gemv_wide<13>(q, nz, batch, in_features, out_features, act, st);
+      return launch_gemv_wide<16>(q, nz, batch, in_features, out_features, act, st);
+    }
   }
   LinFwd<32, 32, 64> p;
   p.M = out_features; p.N = batch; p.K = in_features;

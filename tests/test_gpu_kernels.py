@@ -874,10 +874,13 @@ def test_categorical_policy_kernels_vs_torch(dev, b, a):
 
 
 @pytest.mark.parametrize("b,k,o,act", [(16, 512, 4, None), (16, 512, 1, None), (80, 512, 18, None), (1, 17, 64, "tanh"),
-                                      (64, 64, 64, "relu"), (33, 400, 300, "relu"), (128, 512, 204, None), (5, 3, 2, None)])
+                                      (64, 64, 64, "relu"), (33, 400, 300, "relu"), (128, 512, 204, None), (5, 3, 2, None),
+                                      (8, 3136, 512, "relu"), (16, 3136, 512, "relu"), (5, 1024, 37, None), (9, 4096, 16, "tanh"),
+                                      (32, 2052, 6, None)])
 def test_linear_small_layers_vs_torch(dev, b, k, o, act):
-    """The one-pass small-layer forward behind dra_linear_fwd (in_features <= 512, batch <= 128: heads and FCBody layers)
-    against F.linear in fp32 on the CPU: 1e-5 relative to the operand scale sum|x||w|."""
+    """The one-pass forwards behind dra_linear_fwd -- in_features <= 512, batch <= 128 (heads and FCBody layers), and the wide
+    GEMV for 512 < in_features <= 4096 at batch <= 32 (fc4 of NatureConvBody at rollout batch sizes) -- against F.linear in
+    fp32 on the CPU: 1e-5 relative to the operand scale sum|x||w|."""
     from deeprl_amd import ops
     rs = np.random.RandomState(b + 7 * k + 13 * o)
     x = rs.standard_normal((b, k)).astype(np.float32)
