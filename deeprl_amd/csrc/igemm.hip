@@ -171,43 +171,56 @@ linear_gemv_kernel(LinPtrs q, int B, int K, int O, int act) {
 // step): the K-chunked GEMM + its split-K finish were 13.2 + 5.4 us per rollout step (profiles/r02zw_kernel_stats_ppo_pixel_8.txt)
 // for 6.4 MB of weights and 26 MFLOP.  Same shape as the device actor's fc4 GEMV: one wave per output row, the row in registers
 // as R float4 per lane (all requested up front), the input rows staged in LDS eight at a time (100 KB at K = 3136) and shared
-// by the workgroup's four rows.  grid (ceil(O / 4), nz).  K % 4 == 0.
+// by the workgroup's four rows; every load of the workgroup (its weight rows, its eight input rows) is requested before the
+// first LDS write (a first version staged the input with a load -> store loop: six dependent round trips, slower than the
+// GEMM it replaced).  grid (ceil(O / 4), nz, ceil(B / 8)).  K % 4 == 0.
 template <int R>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))   // registers, not occupancy (100 KB of LDS: one workgroup per CU)
 linear_gemv_wide_kernel(LinPtrs q, int B, int K, int O, int act) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];   // [<= 8 rows][K]
   float4* __restrict__ s_x4 = reinterpret_cast<float4*>(s_x);
-  const int z = blockIdx.y;
+  const int z = blockIdx.y, b0 = blockIdx.z * 8;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int o = blockIdx.x * 4 + wave;
   const int nv = K >> 2;
+  const int nb = min(8, B - b0);
+  const int n4 = nb * nv;
   const float4* __restrict__ w4 = reinterpret_cast<const float4*>(q.w[z] + (int64_t)min(o, O - 1) * K);
-  float4 wv[R];
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(q.x[z] + (int64_t)b0 * K);
+  // 8 rows x nv float4 over 256 threads: nv / 32 <= 2 R per thread (two arrays of R: one array of 2 R float4 is left in
+  // scratch memory by the compiler's alloca promotion limit)
+  float4 wv[R], xa[R], xb[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) wv[i] = w4[min(lane + 64 * i, nv - 1)];
-  const float bias = q.bias[z] ? q.bias[z][min(o, O - 1)] : 0.f;
-  float* __restrict__ out = q.y[z];
-  for (int b0 = 0; b0 < B; b0 += 8) {
-    const int nb = min(8, B - b0);
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(q.x[z] + (int64_t)b0 * K);
-    const int n4 = nb * nv;
-#pragma unroll 4
-    for (int i = threadIdx.x; i < n4; i += 256) s_x4[i] = src[i];
-    __syncthreads();
-    if (o < O) {
-      for (int b = 0; b < nb; ++b) {
-        float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-          const float4 a = wv[i];
-          const float4 xv = s_x4[b * nv + min(lane + 64 * i, nv - 1)];
-          if (lane + 64 * i < nv) acc += (a.x * xv.x + a.y * xv.y) + (a.z * xv.z + a.w * xv.w);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) out[(int64_t)(b0 + b) * O + o] = act_apply(acc + bias, act);
-      }
+  for (int i = 0; i < R; ++i) {
+    xa[i] = src[min((int)threadIdx.x + 256 * i, n4 - 1)];
+    xb[i] = src[min((int)threadIdx.x + 256 * (R + i), n4 - 1)];
+  }
+  const float bias = q.bias[z] ? q.bias[z][min(o, O - 1)] : 0.f;
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < R; ++i) {   // (clamped like the loads: a surplus thread rewrites the last element with the value it holds)
+    const int e = (int)threadIdx.x + 256 * i;
+    float4 va = xa[i], vb = xb[i];
+    asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w));   // (member access: the arrays stay in registers)
+    asm volatile("" : "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
+    s_x4[min(e, n4 - 1)] = va;
+    s_x4[min(e + 256 * R, n4 - 1)] = vb;
+  }
+  __syncthreads();
+  if (o >= O) return;
+  float* __restrict__ out = q.y[z];
+  for (int b = 0; b < nb; ++b) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const float4 a = wv[i];
+      const float4 xv = s_x4[b * nv + min(lane + 64 * i, nv - 1)];
+      if (lane + 64 * i < nv) acc += (a.x * xv.x + a.y * xv.y) + (a.z * xv.z + a.w * xv.w);
     }
-    __syncthreads();
+    acc = wave_sum(acc);
+    if (lane == 0) out[(int64_t)(b0 + b) * O + o] = act_apply(acc + bias, act);
   }
 }
 
@@ -220,8 +233,8 @@ static int launch_gemv_wide(const LinPtrs& q, int nz, int batch, int in_features
                                 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(linear_gemv_wide_kernel<R>, dim3((out_features + 3) / 4, nz), dim3(256), lds, st, q, batch, in_features,
-                     out_features, act);
+  hipLaunchKernelGGL(linear_gemv_wide_kernel<R>, dim3((out_features + 3) / 4, nz, (batch + 7) / 8), dim3(256), lds, st, q, batch,
+                     in_features, out_features, act);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
