@@ -308,10 +308,10 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   if (cfg->variant >= 0) l->variant = cfg->variant;
   else rc |= dra_get_tuning(&l->variant);
   // ring-direct needs the one-launch-per-layer backward (its conv1 weight gradient) and the host-decided cross-stream waits
-  // of the gather-on-update pipeline; the distributional heads take their transition scalars from the gathered minibatch
+  // of the gather-on-update pipeline (the distributional heads get their transition scalars from fc4_reduce_kernel, which
+  // folds them from the ring as head_fused_kernel does for VanillaNet)
   if ((l->variant & DRA_VAR_RING_DIRECT) &&
-      (cfg->head_kind != DRA_HEAD_VANILLA || !(l->variant & DRA_VAR_ONESHOT_WGRAD) || !(l->variant & DRA_VAR_GATHER_ON_UPDATE) ||
-       !(l->variant & DRA_VAR_PINNED_IDX)))
+      (!(l->variant & DRA_VAR_ONESHOT_WGRAD) || !(l->variant & DRA_VAR_GATHER_ON_UPDATE) || !(l->variant & DRA_VAR_PINNED_IDX)))
     l->variant &= ~DRA_VAR_RING_DIRECT;
   if (cfg->head_kind != DRA_HEAD_VANILLA) {
     // the distributional heads exist in the second-generation actor (own head kernel per env step, in order or from the
@@ -521,6 +521,22 @@ struct RingScalars {
   unsigned long long* seq;
 };
 
+// action / n-step reward / mask of sampled transition b straight from the replay ring, folded as ring_gather_kernel does
+// (replay.py:133-139, fp64, the reference's association), then f32 as tensor() would
+__device__ __forceinline__ void ring_scalars_of(const RingScalars& rs, int b, int64_t* ab, float* rew_b, float* mask_b) {
+  const int64_t i = rs.idx[b];
+  *ab = *reinterpret_cast<const int64_t*>(rs.actions + i * 8);
+  double cum_r = 0.0;
+  int32_t cum_m = 1;
+  for (int k = rs.n_step - 1; k >= 0; --k) {
+    const int32_t m = rs.masks[i + k];
+    cum_r = __dadd_rn(rs.rewards[i + k], __dmul_rn(__dmul_rn((double)m, rs.discount), cum_r));
+    cum_m = cum_m ? m : cum_m;
+  }
+  *rew_b = (float)cum_r;
+  *mask_b = (float)cum_m;
+}
+
 struct HeadSpec {
   int kind, n_atoms;
   const float* atoms;
@@ -616,8 +632,17 @@ __device__ __forceinline__ void dist_head_q(const float* __restrict__ h4, const 
 template <int KS>
 __global__ void __launch_bounds__(256)
 fc4_reduce_kernel(const float* __restrict__ slabs, int B, const float* __restrict__ b4_on, const float* __restrict__ b4_tg,
-                  float* __restrict__ h4, int64_t* __restrict__ opt_step) {
+                  float* __restrict__ h4, int64_t* __restrict__ opt_step, const RingScalars rs) {
   const int b = blockIdx.x, z = blockIdx.y, tid = threadIdx.x;
+  if (rs.idx && z == 0 && tid == 0) {
+    // DRA_VAR_RING_DIRECT with a distributional head: the loss kernel (later in this stream) reads the minibatch's
+    // action / n-step reward / mask buffers -- filled here from the ring, as head_fused_kernel does for VanillaNet
+    int64_t ab;
+    float rew_b, mask_b;
+    ring_scalars_of(rs, b, &ab, &rew_b, &mask_b);
+    rs.out_action[b] = ab; rs.out_reward[b] = rew_b; rs.out_mask[b] = mask_b;
+    if (rs.seq && b == 0) *rs.seq += 1ull;
+  }
   const float* bias = (z == 1) ? b4_tg : b4_on;
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) {
@@ -675,19 +700,8 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
   int64_t ab;
   float rew_b, mask_b;
   if (rs.idx) {
-    // DRA_VAR_RING_DIRECT: action / n-step reward / mask of the sampled transition straight from the replay ring, folded as
-    // ring_gather_kernel does (replay.py:133-139, fp64, the reference's association), then f32 as tensor() would
-    const int64_t i = rs.idx[b];
-    ab = *reinterpret_cast<const int64_t*>(rs.actions + i * 8);
-    double cum_r = 0.0;
-    int32_t cum_m = 1;
-    for (int k = rs.n_step - 1; k >= 0; --k) {
-      const int32_t m = rs.masks[i + k];
-      cum_r = __dadd_rn(rs.rewards[i + k], __dmul_rn(__dmul_rn((double)m, rs.discount), cum_r));
-      cum_m = cum_m ? m : cum_m;
-    }
-    rew_b = (float)cum_r;
-    mask_b = (float)cum_m;
+    // DRA_VAR_RING_DIRECT: the transition scalars straight from the replay ring
+    ring_scalars_of(rs, b, &ab, &rew_b, &mask_b);
     if (tid == 0) { rs.out_action[b] = ab; rs.out_reward[b] = rew_b; rs.out_mask[b] = mask_b; }   // (checkers, PER loss kernel)
   } else {
     ab = action[b];
@@ -920,7 +934,7 @@ head_fwd_gemv_kernel(const float* __restrict__ h4, int B, int NO, const float* _
 // Head + loss + head input-gradient for the distributional heads (everything head_fused_kernel does for VanillaNet):
 //   h4[z] <- fc4 partial sums ; out[z] = h4[z] Wh_z^T + bh_z (q[z], [B][A*N]) ; fused loss kernel -> per-sample loss
 //   vector (delta) and d(reduced loss)/d out (dq) ; dh4 = (dq Wh) * relu'(h4[0]).
-static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta) {
+static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta, const RingScalars& rs) {
   const dra_dqn_config& c = l->c;
   const int B = c.batch, A = c.n_actions, N = c.n_atoms, NO = l->n_out;
   const int nz = c.double_q ? 3 : 2;
@@ -930,13 +944,13 @@ static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta
   const int64_t* o = c.offset;
   if (fc4_ks(l) == kFc4SplitWide)
     hipLaunchKernelGGL(fc4_reduce_kernel<kFc4SplitWide>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
-                       T + o[P_B4], l->h4, l->opt_step);
+                       T + o[P_B4], l->h4, l->opt_step, rs);
   else if (fc4_ks(l) == kFc4SplitMid)
     hipLaunchKernelGGL(fc4_reduce_kernel<kFc4SplitMid>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
-                       T + o[P_B4], l->h4, l->opt_step);
+                       T + o[P_B4], l->h4, l->opt_step, rs);
   else
     hipLaunchKernelGGL(fc4_reduce_kernel<kFc4Split>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
-                       T + o[P_B4], l->h4, l->opt_step);
+                       T + o[P_B4], l->h4, l->opt_step, rs);
   DRA_LAUNCH_CHECK();
   static int gemv = -1;
   if (gemv < 0) { const char* e = getenv("DRA_HEAD_GEMV"); gemv = e ? atoi(e) : 1; }
@@ -1028,18 +1042,18 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   if (l->variant & DRA_VAR_ONESHOT_FWD) STEP(K_FC4_F, dra_linear_fwd_slabs_one(nz, x4, w4, B, 3136, 512, ks4, l->fc4_slabs, s));
   else STEP(K_FC4_F, dra_linear_fwd_slabs(nz, x4, w4, B, 3136, 512, kFc4Split, l->fc4_slabs, s));
   if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_HEAD], st));
+  RingScalars rs;
+  memset(&rs, 0, sizeof(rs));
+  if (rd) {
+    rs.idx = l->idx; rs.actions = (const uint8_t*)ring_actions; rs.rewards = (const double*)ring_rewards;
+    rs.masks = (const int32_t*)ring_masks; rs.n_step = ring_n; rs.discount = ring_discount;
+    rs.out_action = l->action_[l->gb]; rs.out_reward = l->reward_[l->gb]; rs.out_mask = l->mask_[l->gb];
+    if (l->variant & DRA_VAR_IDX_PREFETCH) rs.seq = l->rd_seq_dev;
+  }
   if (c.head_kind != DRA_HEAD_VANILLA) {
-    int rc = run_dist_head(l, st, per, beta);
+    int rc = run_dist_head(l, st, per, beta, rs);
     if (rc) return rc;
   } else {
-    RingScalars rs;
-    memset(&rs, 0, sizeof(rs));
-    if (rd) {
-      rs.idx = l->idx; rs.actions = (const uint8_t*)ring_actions; rs.rewards = (const double*)ring_rewards;
-      rs.masks = (const int32_t*)ring_masks; rs.n_step = ring_n; rs.discount = ring_discount;
-      rs.out_action = l->action_[l->gb]; rs.out_reward = l->reward_[l->gb]; rs.out_mask = l->mask_[l->gb];
-      if (l->variant & DRA_VAR_IDX_PREFETCH) rs.seq = l->rd_seq_dev;
-    }
     if (ks4 == kFc4SplitWide)
       hipLaunchKernelGGL(head_fused_kernel<kFc4SplitWide>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                          P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
