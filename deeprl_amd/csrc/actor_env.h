@@ -53,6 +53,28 @@ __device__ __forceinline__ int64_t eps_greedy_action(const float* q, int A, cons
   return (prm->dice[e] < prm->epsilon[e]) ? (int64_t)prm->random_action[e] : (int64_t)best;
 }
 
+// Action value of ONE action from its N head outputs x[0..N) (a distributional head at batch 1), computed by one wave:
+// categorical (kind 1): sum_n softmax(x)_n * atoms[n] (CategoricalDQN_agent.py:21-24); quantile (kind 2): mean_n x[n]
+// (QuantileRegressionDQN_agent.py:17-20).  Every lane returns the value.  Shared by the actor's head kernels and the fused
+// conv1 launch: one summation order, bit-identical action values.
+__device__ __forceinline__ float dist_action_value(const float* __restrict__ x, int N, int kind, const float* __restrict__ atoms,
+                                                   int lane) {
+  if (kind == 1) {
+    float m = -INFINITY;
+    for (int n = lane; n < N; n += 64) m = fmaxf(m, x[n]);
+    m = wave_max(m);
+    float se = 0.f;
+    for (int n = lane; n < N; n += 64) se += expf(x[n] - m);
+    se = wave_sum(se);
+    float acc = 0.f;
+    for (int n = lane; n < N; n += 64) acc += (expf(x[n] - m) / se) * atoms[n];
+    return wave_sum(acc);
+  }
+  float acc = 0.f;
+  for (int n = lane; n < N; n += 64) acc += x[n];
+  return wave_sum(acc) / (float)N;
+}
+
 // What conv1 of env step e >= 1 of the ring actor needs to perform the head of step e-1 and the environment step
 // in front of its own work (launch = conv1's workgroups + ONE environment workgroup, the last one):
 //   every workgroup : q = head(h4) -> action of step e-1 -> the rows of observation e it convolves (generated, not read);
@@ -72,6 +94,11 @@ struct ActorFuse {
   float* q_out;                // [A] or null
   const uint8_t* pend_frame; const double* pend_reward; const int32_t* pend_mask;
   uint64_t seed;
+  // distributional heads (head_kind 1 = categorical, 2 = quantile; 0 = VanillaNet): the A * n_atoms head outputs of env
+  // step e-1 were formed by actor_dist_gemv_kernel (learner.hip) into `pre`; the workgroups reduce them to action values
+  int head_kind, n_atoms;
+  const float* atoms;
+  const float* pre;
 };
 
 // conv_v2.hip (library-internal)

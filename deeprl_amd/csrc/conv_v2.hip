@@ -127,6 +127,13 @@ struct V2Tile {
 // butterfly as actor_head_env_ring_kernel: bit-identical action values), into s_q; caller synchronises.
 template <int NW>
 __device__ __forceinline__ void fused_head_q(const ActorFuse& f, int wave, int lane, float* __restrict__ s_q) {
+  if (f.head_kind != 0) {   // distributional head: its outputs already exist, one wave reduces one action's
+    for (int a = wave; a < f.n_actions; a += NW) {
+      const float q = dist_action_value(f.pre + a * f.n_atoms, f.n_atoms, f.head_kind, f.atoms, lane);
+      if (lane == 0) s_q[a] = q;
+    }
+    return;
+  }
   for (int a = wave; a < f.n_actions; a += NW) {
     float part = 0.f;
 #pragma unroll

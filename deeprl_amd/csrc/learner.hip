@@ -241,6 +241,12 @@ DRA_API int dra_stream_destroy(void* stream) {
 
 constexpr int kMaxHeadOut = 4096;   // n_actions * n_atoms the batch-1 actor head keeps in LDS
 
+static int dist_actor_fused() {   // DRA_ACTOR_DIST_FUSED=0: distributional heads on the six-launch env step (own head kernel)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_ACTOR_DIST_FUSED"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 static int alloc_f(float** p, int64_t n) { return (int)hipMalloc(p, (size_t)n * sizeof(float)); }
 
 DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const dra_dqn_config* cfg, float* params,
@@ -317,7 +323,9 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
     // the distributional heads exist in the second-generation actor (own head kernel per env step, in order or from the
     // parameter ring); the launches that fold the VanillaNet head into a neighbouring kernel do not apply
     l->variant |= DRA_VAR_ACTOR_V2;
-    l->variant &= ~(DRA_VAR_ACTOR_V3 | DRA_VAR_ACTOR_FUSED_HEAD | DRA_VAR_ACTOR_FUSED_CONV1 | DRA_VAR_GATHER_IN_GRAPH);
+    l->variant &= ~(DRA_VAR_ACTOR_V3 | DRA_VAR_ACTOR_FUSED_HEAD | DRA_VAR_GATHER_IN_GRAPH);
+    if (!dist_actor_fused()) l->variant &= ~DRA_VAR_ACTOR_FUSED_CONV1;   // (the ring actor's fused conv1 launch reduces the
+                                                                        // head outputs of actor_dist_gemv_kernel to action values)
   }
   if (l->variant & DRA_VAR_ONESHOT_WGRAD) {
     // layer L's segment of the flat gradient is [offset(W_L), offset(b_L) + OC): weight then bias, contiguous
@@ -604,23 +612,7 @@ __device__ __forceinline__ void dist_head_q(const float* __restrict__ h4, const 
   __syncthreads();
   if (hs.out) for (int o = threadIdx.x; o < NO; o += blockDim.x) hs.out[o] = s_out[o];
   for (int a = wave; a < A; a += nw) {
-    const float* x = s_out + a * N;
-    float q;
-    if (hs.kind == DRA_HEAD_CATEGORICAL) {
-      float m = -INFINITY;
-      for (int n = lane; n < N; n += 64) m = fmaxf(m, x[n]);
-      m = wave_max(m);
-      float se = 0.f;
-      for (int n = lane; n < N; n += 64) se += expf(x[n] - m);
-      se = wave_sum(se);
-      float acc = 0.f;
-      for (int n = lane; n < N; n += 64) acc += (expf(x[n] - m) / se) * hs.atoms[n];
-      q = wave_sum(acc);
-    } else {
-      float acc = 0.f;
-      for (int n = lane; n < N; n += 64) acc += x[n];
-      q = wave_sum(acc) / (float)N;
-    }
+    const float q = dist_action_value(s_out + a * N, N, hs.kind, hs.atoms, lane);
     if (lane == 0) s_q[a] = q;
   }
   __syncthreads();
@@ -1944,6 +1936,8 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   f.aring = l->aring_dev; f.seq = l->aring_seq; f.frames = (uint8_t*)frames; f.actions = (uint8_t*)actions;
   f.rewards = (double*)rewards; f.masks = (int32_t*)masks; f.q_out = l->aq; f.pend_frame = l->pend_frame;
   f.pend_reward = l->pend_reward; f.pend_mask = l->pend_mask; f.seed = (uint64_t)c.env_seed;
+  const bool dist = c.head_kind != DRA_HEAD_VANILLA;
+  f.head_kind = c.head_kind; f.n_atoms = c.n_atoms; f.atoms = l->atoms; f.pre = l->alog;
   for (int e = 0; e < n_env; ++e) {
     const int64_t* slot_field = reinterpret_cast<const int64_t*>(l->aring_dev + offsetof(dra_dqn_step_params, slot)) + e;
     const int32_t* age_field = reinterpret_cast<const int32_t*>(l->aring_dev + offsetof(dra_dqn_step_params, stack_age)) + e;
@@ -1969,6 +1963,11 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
         hipLaunchKernelGGL(actor_fc4_planes_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3p, (const float*)(l->ay3p + 64 * 49),
                            P + o[P_W4], P + o[P_B4], l->ah4, 3136);
       DRA_LAUNCH_CHECK();
+      if (dist) {   // the head's A*N outputs of this env step (consumed by the next launch: fused conv1 of e+1, or the tail kernel)
+        hipLaunchKernelGGL(actor_dist_gemv_kernel, dim3((l->n_out + 3) / 4), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH],
+                           P + o[P_BH], l->n_out, l->alog);
+        DRA_LAUNCH_CHECK();
+      }
       continue;
     }
     const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
@@ -1980,11 +1979,18 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
     hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
                        l->ah4, 3136);
     DRA_LAUNCH_CHECK();
+    if (dist) {
+      hipLaunchKernelGGL(actor_dist_gemv_kernel, dim3((l->n_out + 3) / 4), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH],
+                         P + o[P_BH], l->n_out, l->alog);
+      DRA_LAUNCH_CHECK();
+    }
   }
+  HeadSpec hs_tail = head_spec(l);
+  if (dist) { hs_tail.pre = l->alog; hs_tail.out = nullptr; }
   hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq,
                      n_env - 1, 1, 0, (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq,
                      (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
-                     (uint64_t)c.env_seed, (int)c.env_done_period, head_spec(l));
+                     (uint64_t)c.env_seed, (int)c.env_done_period, hs_tail);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

@@ -9,6 +9,7 @@ reference's draw order.
 `DQNLearnerBench` is the synthetic-workload driver bench.py times (BASELINE configs[1]).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -90,7 +91,9 @@ class DQNLearner:
         if self.head_kind != HEAD_VANILLA:   # (dra_dqn_learner_create does the same: the launches that fold the VanillaNet
             # head into a neighbouring kernel do not exist for the distributional heads)
             self.variant = (self.variant | ops.VAR_ACTOR_V2) & ~(ops.VAR_ACTOR_V3 | ops.VAR_ACTOR_FUSED_HEAD |
-                                                                 ops.VAR_ACTOR_FUSED_CONV1 | ops.VAR_GATHER_IN_GRAPH)
+                                                                 ops.VAR_GATHER_IN_GRAPH)
+            if os.environ.get("DRA_ACTOR_DIST_FUSED", "1") == "0":
+                self.variant &= ~ops.VAR_ACTOR_FUSED_CONV1
         variant = self.variant
         cfg = DqnConfig()
         cfg.batch, cfg.n_actions, cfg.double_q, cfg.ksplit, cfg.centered = batch, n_actions, int(double_q), ksplit, int(centered)
