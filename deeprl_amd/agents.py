@@ -23,6 +23,9 @@ Differences that are the point of the rewrite (results unchanged):
 """
 import pickle
 
+import contextlib
+import gc
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -33,6 +36,25 @@ from .envs import LazyFrames
 from .optim import FlatParams, FusedOptimizer, nature_conv_weights
 from .replay import PrioritizedTransition, Storage
 from .support import Config, close_obj, epsilon_greedy, get_logger, random_sample, range_tensor, tensor, to_np
+
+
+
+@contextlib.contextmanager
+def _capture(graph):
+    """torch.cuda.graph(graph) with the cyclic garbage collector held off for the duration of the capture.  A collection that
+    runs INSIDE a capture may finalise objects of an earlier agent that own HIP resources (pinned host tensors, the fused
+    learner's library handle): their frees / device synchronisation are illegal while a stream captures and end the process
+    (std::terminate out of a deleter) -- seen as a sporadic abort of the test suite at the first captured update that followed a
+    closed device-pipeline agent.  Collect first, then capture without the collector."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class _NullLock:
@@ -265,7 +287,7 @@ class _GraphedQ:
                     a.q_device(a._network(cfg.state_normalizer(self.static_in)))   # object (normaliser table, ...)
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g):
+                with _capture(g):
                     with torch.no_grad():
                         self.static_out = a.q_device(a._network(cfg.state_normalizer(self.static_in)))
                 self.graph = g
@@ -328,7 +350,7 @@ class _GraphedUpdate:
                 opt.enable_graph_mode()
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g):
+                with _capture(g):
                     out, (net_out, grad) = agent._loss_grad(tr, None)
                     opt.zero_grad()
                     net_out.backward(grad)
@@ -883,7 +905,7 @@ class _OnPolicyGraph:
                 g = torch.cuda.CUDAGraph()
                 torch.cuda.synchronize()
                 steps = a._rollout_step
-                with torch.cuda.graph(g):
+                with _capture(g):
                     self.out = compute(plan)
                 a._rollout_step = steps       # the capture pass only recorded the work
                 self.graph, self.key = g, key
@@ -1208,7 +1230,7 @@ class PPOAgent(BaseAgent):
                         torch.distributions.Distribution.set_default_validate_args(False)
                         graph = torch.cuda.CUDAGraph()
                         torch.cuda.synchronize()
-                        with torch.cuda.graph(graph):
+                        with _capture(graph):
                             with torch.no_grad():
                                 g['out'] = self.network(g['in'])
                         g['graph'] = graph
@@ -1360,7 +1382,7 @@ class _GraphedPPO:
             torch.cuda.synchronize()
             if cfg.shared_repr:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _capture(g):
                     self.out3 = a._minibatch(rows(), prepared=True)
                 self.graphs = dict(all=g)
             else:
@@ -1374,10 +1396,10 @@ class _GraphedPPO:
                                                e.advantage, e.ret, cfg.ppo_ratio_clip, cfg.entropy_weight)
                     return p, out3, grads
 
-                with torch.cuda.graph(g_fwd):
+                with _capture(g_fwd):
                     with torch.no_grad():
                         _, self.out3, _ = forward_loss()
-                with torch.cuda.graph(g_both):
+                with _capture(g_both):
                     p, _, (g_lp, g_ent, g_v) = forward_loss()
                     a._fused_actor.zero_grad()
                     torch.autograd.backward([p['log_pi_a'], p['entropy']], [g_lp, g_ent])
@@ -1385,7 +1407,7 @@ class _GraphedPPO:
                     a._fused_critic.zero_grad()
                     p['v'].backward(g_v)
                     a._fused_critic.step(None)
-                with torch.cuda.graph(g_critic):
+                with _capture(g_critic):
                     p, _, (g_lp, g_ent, g_v) = forward_loss()
                     a._fused_critic.zero_grad()
                     p['v'].backward(g_v)
