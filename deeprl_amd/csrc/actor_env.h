@@ -119,5 +119,8 @@ int dra_conv1_fwd_koc_ringbatch(const void* frames, const int64_t* idx, int64_t*
                                 const unsigned long long* update_seq, const int64_t* newest_off, int nz,
                                 const float* const* wt, const float* const* bias, float* const* y, int batch, double u8_coef, int act,
                                 void* stream);
+// fused.hip (library-internal): y_z = x_z W_z^T + bias_z for in_features = 512 in one pass (the distributional heads' update)
+int dra_head_fwd_one(int nz, const float* const* x, const float* const* w, const float* const* bias, float* const* y, int batch,
+                     int out_features, void* stream);
 int dra_conv1_wgrad_ringbatch(const float* dy, const void* frames, const int64_t* idx, float* dw_slabs, float* db_slabs,
                               int64_t slab_stride, int batch, double u8_coef, int variant, void* stream);

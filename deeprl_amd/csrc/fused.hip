@@ -240,6 +240,24 @@ DRA_API int dra_linear_fwd_slabs_one(int nz, const float* const* x, const float*
   return launch_multi(r, r.tiles_n * r.tiles_m * 8 * nz, none, 0, none, 0, dra_stream(stream));
 }
 
+// Head contraction of the distributional update in one pass (library-internal, actor_env.h): y_z[b][o] = bias_z[o] +
+// <x_z[b], w_z[o]> for in_features = 512, whole reduction per workgroup (32 x 32 output tile, K = 512 over 4 waves x 2
+// half-waves of fp32 MFMA, both operands staged through LDS once).  Replaces head_fwd_gemv_kernel's 32 serial wave-level dot
+// products per output row (12 us at [32,512] x [512, 204 | 800], profiles/r02zv_kernel_stats_*_after.txt).
+int dra_head_fwd_one(int nz, const float* const* x, const float* const* w, const float* const* bias, float* const* y, int batch,
+                     int out_features, void* stream) {
+  if (nz < 1 || nz > kMaxZ || batch < 1 || out_features < 1 || !x || !w || !bias || !y) return DRA_EINVAL;
+  LinFwdSlabsOne<512, 1, 1> r;
+  for (int z = 0; z < nz; ++z) {
+    if (!x[z] || !w[z] || !bias[z] || !y[z] || ((((uintptr_t)x[z]) | ((uintptr_t)w[z])) & 15)) return DRA_EINVAL;
+    r.x[z] = x[z]; r.w[z] = w[z]; r.bias[z] = bias[z]; r.out[z] = y[z];
+  }
+  r.slabs = nullptr; r.B = batch; r.O = out_features;
+  r.tiles_n = (out_features + 31) / 32; r.tiles_m = (batch + 31) / 32;
+  NoRole none;
+  return launch_multi(r, r.tiles_n * r.tiles_m * nz, none, 0, none, 0, dra_stream(stream));
+}
+
 #ifdef DRA_TRACE
 extern "C" int dra_trace_set_fused(void* p) { return dra_trace_set_local(p); }
 #endif

@@ -944,10 +944,15 @@ static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta
     hipLaunchKernelGGL(fc4_reduce_kernel<kFc4Split>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
                        T + o[P_B4], l->h4, l->opt_step, rs);
   DRA_LAUNCH_CHECK();
-  static int gemv = -1;
-  if (gemv < 0) { const char* e = getenv("DRA_HEAD_GEMV"); gemv = e ? atoi(e) : 1; }
+  static int gemv = -1;   // DRA_HEAD_GEMV: 2 = one-pass MFMA contraction (default), 1 = wave-per-output GEMV, 0 = K-chunked GEMM
+  if (gemv < 0) { const char* e = getenv("DRA_HEAD_GEMV"); gemv = e ? atoi(e) : 2; }
   int rc = DRA_OK;
-  if (gemv) {
+  if (gemv == 2) {
+    const float* hx[3] = {l->h4, l->h4 + (int64_t)B * 512, l->h4 + (int64_t)2 * B * 512};
+    const float* hw[3] = {P + o[P_WH], T + o[P_WH], P + o[P_WH]};
+    const float* hb[3] = {P + o[P_BH], T + o[P_BH], P + o[P_BH]};
+    if ((rc = dra_head_fwd_one(nz, hx, hw, hb, l->q, B, NO, s))) return rc;
+  } else if (gemv) {
     hipLaunchKernelGGL(head_fwd_gemv_kernel, dim3((NO + 3) / 4, nz, (B + 31) / 32), dim3(256), 0, st, (const float*)l->h4, B, NO,
                        P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH], l->q[0], l->q[1], l->q[2]);
     DRA_LAUNCH_CHECK();

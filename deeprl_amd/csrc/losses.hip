@@ -15,9 +15,12 @@ __device__ __forceinline__ int64_t load_action(const void* a, int is_i64, int b,
   return v < 0 ? 0 : (v >= n_actions ? (int64_t)n_actions - 1 : v);
 }
 
-// block-wide reductions for blockDim <= 1024 (<=16 waves); every thread gets the result
+// block-wide reductions for blockDim <= 1024 (<=16 waves); every thread gets the result.  A single-wave workgroup (the C51
+// loss at 51 atoms: ~20 reductions per sample) needs neither LDS nor barriers: the butterfly already leaves the result in
+// every lane (and 0.f + v, what the general path computes for one wave, is v).
 __device__ __forceinline__ float block_sum(float v, float* s_red) {
   v = wave_sum(v);
+  if (blockDim.x <= 64) return v;
   const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) s_red[w] = v;
@@ -28,6 +31,7 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 }
 __device__ __forceinline__ float block_max(float v, float* s_red) {
   v = wave_max(v);
+  if (blockDim.x <= 64) return v;
   const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) s_red[w] = v;

@@ -219,6 +219,10 @@ struct LinFwdSlabsOne {
   const float* w[kMaxZ];  // [O][I]
   float* slabs;           // [nz][KS][B][O]
   int B, O, tiles_n, tiles_m;   // tiles_n counts 32*NT-wide tile groups
+  // optional (KS == 1: the whole reduction in one workgroup): finished outputs y_z[b][o] = bias_z[o] + sum instead of slabs
+  // (the distributional heads' [B,512] x [512, A*N] contraction of the update)
+  const float* bias[kMaxZ] = {};
+  float* out[kMaxZ] = {};
   __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int bn = bid % tiles_n;
@@ -230,6 +234,9 @@ struct LinFwdSlabsOne {
     const float* __restrict__ xz = x[z];
     const float* __restrict__ wz = w[z];
     DRA_STAMP(TR_FC4_F, 0);
+    float bias_r[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias_r[t] = (KS == 1 && out[z]) ? bias[z][min(n0 + 32 * t + li, O - 1)] : 0.f;
     float4 xa[RX], wa[RWV];
 #pragma unroll
     for (int q = 0; q < RX; ++q) {
@@ -279,7 +286,8 @@ struct LinFwdSlabsOne {
     DRA_STAMP(TR_FC4_F, 3);
     __syncthreads();
     DRA_STAMP(TR_FC4_F, 4);
-    float* out = slabs + ((int64_t)(z * KS + s) * B) * O;
+    const bool finished = KS == 1 && out[z] != nullptr;
+    float* outp = finished ? out[z] : slabs + ((int64_t)(z * KS + s) * B) * O;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float sum[4];
@@ -288,7 +296,7 @@ struct LinFwdSlabsOne {
       for (int q = 0; q < 4; ++q) {
         const int m = m0 + mfma_row(wave * 4 + q, h);
         const int n = n0 + 32 * t + li;
-        if (m < B && n < O) out[(int64_t)m * O + n] = sum[q];
+        if (m < B && n < O) outp[(int64_t)m * O + n] = finished ? sum[q] + bias_r[t] : sum[q];
       }
     }
     DRA_STAMP(TR_FC4_F, 5);
