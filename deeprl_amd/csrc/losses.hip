@@ -175,6 +175,7 @@ c51_loss_kernel(const float* __restrict__ logits, const float* __restrict__ logi
   // projected target m_j = sum_i clamp(1 - |Tz_i - z_j| / dz, 0, 1) * p_i
   float m = 0.f;
   if (on) {
+#pragma unroll 8
     for (int i = 0; i < N; ++i) {
       const float zi = s_z[i];
       float tz = __fadd_rn(r, __fmul_rn(gm, zi));
