@@ -257,6 +257,32 @@ def pmc_traffic(kernel_group):
     return None if rec is None else rec.get("hbm_bytes")
 
 
+def rocprof_kernel(kernel_group, flops):
+    """The same kernel in the committed `rocprofv3 --kernel-trace --stats -- python bench.py` summary (profiles/
+    rNN_rocprofv3_kernel_stats.txt, newest): its average duration without the event pair's launch boundary, and the roofline
+    fraction that gives.  A profiler cannot run inside this process; the live number above is the conservative one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats.txt")))
+    pat = {"conv2_bwd_x": "ConvDgradOne<ConvGeom<32, 20, 64, 4, 2>", "conv3_bwd_x": "ConvDgradOne<ConvGeom<64, 9, 64, 3, 1>",
+           "conv1_fwd": "conv_fwd_v2_kernel<V2Geom<4, 84, 32, 8, 4>, true, 1, 4>", "rmsprop_step": "rmsprop_step_kernel",
+           "grad_norm": "clip_step_kernel<0>"}.get(kernel_group)
+    if not files or not pat:
+        return None
+    try:
+        for line in open(files[-1]):
+            if pat in line:
+                cols = line.split()                      # ... calls avg_us min_us max_us share
+                calls, avg_us = int(cols[-5]), float(cols[-4])
+                out = {"avg_ms": avg_us * 1e-3, "calls": calls, "file": os.path.relpath(files[-1], ROOT)}
+                if flops:
+                    out["achieved"] = flops / (avg_us * 1e-6) / 1e12
+                    out["frac"] = out["achieved"] / 157.3
+                return out
+    except Exception:
+        return None
+    return None
+
+
 def on_policy_main(args):
     """BASELINE configs[4]: A2C / PPO on Atari shapes, config.num_workers environments PER GPU (weak scaling: 16 resp. 8,
     examples.py:361-381,525-550), sharded over the ranks with one gradient all-reduce per optimizer step.  A step = one
@@ -407,7 +433,8 @@ def main():
             except Exception as e:      # the checker must never take the measurement down with it
                 parity = {"ok": False, "error": repr(e)}
         roof = bench.roofline(200 if args.steps < 500 else 500)
-        roof["source"] = "hip_events (pair around the kernel minus the pair's own cost, both measured live)"
+        roof["source"] = "hip_events (a pair around the kernel on its launch stream, live: includes the launch boundary)"
+        roof["rocprofv3"] = rocprof_kernel(roof["kernel"], roof.get("algorithmic_flops"))
         roof["traffic"] = pmc_traffic(roof["kernel"])
         # the update chain owns a CU partition while the device actor runs beside it (lever 5):
         # the kernel is timed on that stream, i.e. on this many of the device's CUs
