@@ -83,3 +83,39 @@ def test_vectorised_index_draw_consumes_the_reference_stream():
         got = draw_uniform_indices(size, pos, 32, h, n)
         tail_got = np.random.randint(0, 1 << 30, size=3)
         assert np.array_equal(got, want) and np.array_equal(tail_got, tail_want)
+
+
+def test_clip_step_plan_host_arithmetic():
+    """dra_clip_step_coop_blocks (pure host code: the work decomposition shared by dra_grad_sqnorm_segs and the cooperative
+    clip + optimizer launch): one fold workgroup per 64 float4 for segments of <= 32 slabs, per 16 float4 above, one plain
+    workgroup per 1024 float4 -- 796 for the DQN learner's gradient (conv segments of 160 / 32 / 32 slabs, fc4 + head plain);
+    malformed layouts are refused."""
+    from deeprl_amd import ops
+    from deeprl_amd._lib import lib
+
+    class _T:                                    # a fake 16-byte aligned "tensor": the planner only validates pointers
+        def __init__(self, addr):
+            self._a = addr
+
+        def data_ptr(self):
+            return self._a
+
+    def blocks(n, segs):
+        b = ctypes.c_int(0)
+        rc = lib.dra_clip_step_coop_blocks.raw(int(n), ops._fold_seg_array(segs), len(segs), ctypes.byref(b))
+        return rc, b.value
+
+    counts, nsl = [8224, 32832, 36928], [160, 32, 32]
+    tail = 3136 * 512 + 512 + 4 * 512 + 4
+    segs, off = [], 0
+    for cnt, ns in zip(counts, nsl):
+        segs.append((off, cnt, _T(0x10000), cnt, ns))
+        off += cnt
+    rc, b = blocks(off + tail, segs)
+    want = -(-(8224 // 4) // 16) + -(-(32832 // 4) // 64) + -(-(36928 // 4) // 64) + -(-(tail // 4) // 1024)
+    assert rc == 0 and b == want == 796
+    assert blocks(off + tail, [])[0] == 0                                           # no slab segments: plain only
+    assert blocks(off + tail + 1, segs)[0] == -22                                   # n not a multiple of 4
+    assert blocks(off + tail, [(4, 8220, _T(0x10000), 8224, 160)])[0] == -22        # segments must start at 0, contiguously
+    assert blocks(off + tail, [(0, 8224, _T(0x10004), 8224, 160)])[0] == -22        # misaligned slab pointer
+    assert blocks(64 * 1024 * 1024, [])[0] == -22                                   # would need more than one pass per workgroup
