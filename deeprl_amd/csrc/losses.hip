@@ -239,11 +239,12 @@ __global__ void __launch_bounds__(1024)
 qr_loss_kernel(const float* __restrict__ theta, const float* __restrict__ theta_t, const void* __restrict__ action,
                int action_i64, const float* __restrict__ reward, const float* __restrict__ mask, int B, int A, int N,
                float gamma_n, float* __restrict__ out_partial /*[B][N]*/, float* __restrict__ out_dtheta) {
-  extern __shared__ float smem[];  // [N] T theta | [N] theta_a | [N] tau
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [NP] T theta | [NP] theta_a | [NP] tau, NP = N rounded up to 4
   __shared__ float s_red[16];
+  const int NP = (N + 3) & ~3;         // 16-byte aligned segments: the O(N^2) loops read them four elements per LDS access
   float* s_t = smem;
-  float* s_th = smem + N;
-  float* s_tau = smem + 2 * N;
+  float* s_th = smem + NP;
+  float* s_tau = smem + 2 * NP;
   const int b = blockIdx.x, i = threadIdx.x, pass = blockIdx.y;
   const bool on = i < N;
   if (pass == 0 && !out_dtheta) return;
@@ -278,8 +279,19 @@ qr_loss_kernel(const float* __restrict__ theta, const float* __restrict__ theta_
     if (on) {
       const float tau = s_tau[i];
       float acc = 0.f;
-#pragma unroll 8
-      for (int j = 0; j < N; ++j) {
+      const float4* s_t4 = reinterpret_cast<const float4*>(s_t);
+      const int n4 = N >> 2;
+#pragma unroll 4
+      for (int j4 = 0; j4 < n4; ++j4) {     // same terms in the same order, one ds_read_b128 per four of them
+        const float4 v = s_t4[j4];
+        const float tj[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float d = tj[u] - th_i;
+          acc += huber1_grad(d) * fabsf(tau - (d < 0.f ? 1.f : 0.f));
+        }
+      }
+      for (int j = n4 << 2; j < N; ++j) {
         const float d = s_t[j] - th_i;
         acc += huber1_grad(d) * fabsf(tau - (d < 0.f ? 1.f : 0.f));
       }
@@ -290,8 +302,20 @@ qr_loss_kernel(const float* __restrict__ theta, const float* __restrict__ theta_
   if (on) {
     const float tj = s_t[i];  // thread plays target quantile j = i
     float l = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < N; ++k) {
+    const float4* s_th4 = reinterpret_cast<const float4*>(s_th);
+    const float4* s_tau4 = reinterpret_cast<const float4*>(s_tau);
+    const int n4 = N >> 2;
+#pragma unroll 4
+    for (int k4 = 0; k4 < n4; ++k4) {
+      const float4 hv = s_th4[k4], tv = s_tau4[k4];
+      const float th[4] = {hv.x, hv.y, hv.z, hv.w}, ta[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d = tj - th[u];
+        l += huber1(d) * fabsf(ta[u] - (d < 0.f ? 1.f : 0.f));
+      }
+    }
+    for (int k = n4 << 2; k < N; ++k) {
       const float d = tj - s_th[k];
       l += huber1(d) * fabsf(s_tau[k] - (d < 0.f ? 1.f : 0.f));
     }
@@ -329,7 +353,7 @@ DRA_API int dra_qr_loss(const float* theta, const float* theta_next_target, cons
       n_actions < 1 || n_quantiles < 1 || n_quantiles > 1024)
     return DRA_EINVAL;
   const int threads = ((n_quantiles + 63) / 64) * 64;
-  hipLaunchKernelGGL(qr_loss_kernel, dim3(batch, 2), dim3(threads), 3 * n_quantiles * sizeof(float), dra_stream(stream),
+  hipLaunchKernelGGL(qr_loss_kernel, dim3(batch, 2), dim3(threads), 3 * ((n_quantiles + 3) & ~3) * sizeof(float), dra_stream(stream),
                      theta, theta_next_target, action, action_is_i64, reward, mask, batch, n_actions, n_quantiles, gamma_n,
                      workspace, out_dtheta);
   DRA_LAUNCH_CHECK();
