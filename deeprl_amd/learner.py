@@ -151,9 +151,6 @@ class DQNLearner:
         self._idx_pinned = [torch.empty(batch, dtype=torch.int64).pin_memory() for _ in range(8)]
         self._idx_events = [None] * 8
         self._k = 0
-        self._sp_pinned = [torch.empty(batch + 1, dtype=torch.float32).pin_memory() for _ in range(8)]
-        self._sp_events = [None] * 8
-        self._sp_k = 0
 
     def _partitioned_streams(self):
         """Update stream / actor stream on disjoint CU sets (DRA_VAR_CU_PARTITION).  On MI355X mask bit i is CU
