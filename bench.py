@@ -56,6 +56,8 @@ def parse():
                     help="in-order actor (async_actor=False); default is the reference's dqn_pixel setting async_actor=True")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the post-run oracle replay of one agent step")
     ap.add_argument("--no-long-run", action="store_true", help="short runs (< 500 steps): skip the extra 2000-step measurement")
+    ap.add_argument("--cpu-replica-worker", type=float, default=0.0,
+                    help="internal: run the single-thread CPU oracle loop for this many seconds and print its count")
     ap.add_argument("--master-port", type=int, default=29517, help="rendezvous port when bench.py launches the ranks itself")
     ap.add_argument("--workload", default="dqn_pixel", choices=["dqn_pixel", "a2c_pixel", "ppo_pixel"],
                     help="dqn_pixel = BASELINE configs[1] (the headline); a2c_pixel / ppo_pixel = configs[4]: the on-policy agents, "
@@ -75,7 +77,7 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(seconds=15.0, ring=20_000):
+def cpu_baseline(seconds=15.0, ring=20_000, worker=False):
     """The CPU oracle of the same update (port of the reference path): numpy ring gather ->
     f64*(1/255)->f32 -> target fwd, online fwd, TD loss, backward, clip, centered RMSprop on
     torch-CPU fp32, single thread like the reference's set_one_thread() (examples.py:623)."""
@@ -128,6 +130,9 @@ def cpu_baseline(seconds=15.0, ring=20_000):
         return n, time.time() - t0
 
     n, dt = timed(seconds)
+    if worker:
+        torch.set_num_threads(threads_before)
+        return {"updates": n, "seconds": dt}
     nproc = os.cpu_count() or 1
     torch.set_num_threads(nproc)
     one()                                   # one warm-up only: with hundreds of threads a single update can take seconds
@@ -141,7 +146,38 @@ def cpu_baseline(seconds=15.0, ring=20_000):
             "sample": "%d DQN updates (B=32, 84x84x4, %d-frame ring) in %.1f s, torch-CPU fp32 oracle, 1 thread "
                       "(the reference's set_one_thread()); kind 'port': the reference tree is not on the GPU box" % (n, ring, dt),
             "all_cores": {"value": n_all / dt_all, "cores": nproc,
-                          "sample": "%d updates in %.1f s with torch.set_num_threads(%d)" % (n_all, dt_all, nproc)}}
+                          "sample": "%d updates in %.1f s with torch.set_num_threads(%d)" % (n_all, dt_all, nproc)},
+            "all_cores_replicas": cpu_replicas(nproc)}
+
+
+def cpu_replicas(nproc, seconds=6.0, ring=5_000, limit=64):
+    """The CPU path as it scales on a host: R independent single-thread learners (own ring, own parameters: what the DQN
+    family is on several GPUs too), one process each, all running for the same few seconds; the
+    aggregate updates/s.  R = min(cores, 64).  None when the workers cannot be run (never takes the bench line down)."""
+    import subprocess
+    r = max(1, min(int(nproc), limit))
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""              # the workers are CPU-only: they must not open the GPU
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["OMP_NUM_THREADS"] = env["MKL_NUM_THREADS"] = "1"
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-replica-worker", str(seconds), "--ring", str(ring)]
+    try:
+        procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(r)]
+        total, done = 0.0, 0
+        for pr in procs:
+            try:
+                out, _ = pr.communicate(timeout=120 + 4 * seconds)
+                rec = json.loads(out.strip().splitlines()[-1])
+                total += rec["updates"] / rec["seconds"]
+                done += 1
+            except Exception:
+                pr.kill()
+        if done == 0:
+            return None
+        return {"value": total, "cores": done, "sample": "%d single-thread learners side by side, %.0f s each, %d-frame rings"
+                                                          % (done, seconds, ring)}
+    except Exception:
+        return None
 
 
 def agent_api(seconds=2.0):
@@ -350,6 +386,9 @@ def on_policy_main(args):
 
 def main():
     args = parse()
+    if args.cpu_replica_worker > 0:
+        print(json.dumps(cpu_baseline(args.cpu_replica_worker, min(args.ring, 20_000), worker=True)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     if args.workload != "dqn_pixel":
