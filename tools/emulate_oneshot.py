@@ -338,6 +338,12 @@ def main():
     B, I, O, KS = 3, 64, 40, 2
     xl, wl = rs.randn(B, I), rs.randn(O, I)
     check("linear fwd slabs one-pass", emu_lin_fwd_slabs(I, KS, xl, wl, B, O).sum(0), xl @ wl.T)
+    # the instantiations the learner launches: fc4 forward with 8 / 14 / 28 K slices (3136 inputs) and the distributional
+    # heads' one-pass contraction (512 inputs, the whole reduction in one workgroup)
+    for I, KS in ((3136, 8), (3136, 14), (3136, 28), (512, 1)):
+        B, O = 3, 40
+        xl, wl = rs.randn(B, I), rs.randn(O, I)
+        check("linear fwd slabs one-pass I=%d KS=%d" % (I, KS), emu_lin_fwd_slabs(I, KS, xl, wl, B, O).sum(0), xl @ wl.T)
     for name, G, pts, u8 in (("conv1", G1, (1, 2), True), ("conv2", G2, (1, 3), False), ("conv3", G3, (1, 2), False)):
         x = rs.randint(0, 256, size=(2, G.C, G.H, G.H)).astype(np.float64) if u8 else rs.randn(2, G.C, G.H, G.H)
         w = rs.randn(G.OC, G.C, G.KH, G.KH)
