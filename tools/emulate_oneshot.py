@@ -358,3 +358,106 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# clip_step_kernel (optim.hip): slab fold + sums of squares, transcribed workgroup by workgroup / thread by thread.
+# Returns (folded gradient, partials[blocks], owners[float4 index] = how many (block, thread) pairs hold that element
+# across the barrier -- the cooperative form applies the optimizer to exactly those).
+def emu_clip_step(grad, segs, plain_iters_cap=2048):
+    """grad: f32 [n]; segs: list of (begin, count, slabs [ns, stride], stride, ns) with begin / count multiples of 4."""
+    n = grad.size
+    n4_total = n // 4
+    g4 = grad.astype(np.float32).reshape(n4_total, 4).copy()
+    owners = np.zeros(n4_total, dtype=np.int64)
+    first_block, blocks = [], 0
+    for (begin, count, slabs, stride, ns) in segs:
+        first_block.append(blocks)
+        per = 64 if ns <= 32 else 16
+        blocks += (count // 4 + per - 1) // per
+    first_block.append(blocks)
+    end = segs[-1][0] + segs[-1][1] if segs else 0
+    plain_begin4, plain_count4 = end // 4, (n - end) // 4
+    pb = (plain_count4 + 1023) // 1024
+    room = plain_iters_cap - blocks
+    iters = 1
+    if pb > room:
+        iters = (pb + room - 1) // room
+        pb = (pb + iters - 1) // iters
+    total = blocks + pb
+    partials = np.zeros(total, dtype=np.float64)
+    f32 = np.float32
+    for bid in range(total):
+        acc = np.zeros(256, dtype=np.float32)                 # per-thread fp32 accumulators
+        if bid < first_block[len(segs)]:
+            sg = 0
+            while sg + 1 < len(segs) and bid >= first_block[sg + 1]:
+                sg += 1
+            begin, count, slabs, stride, ns = segs[sg]
+            b = bid - first_block[sg]
+            n4 = count // 4
+            sl4 = slabs.astype(np.float32).reshape(ns, stride // 4, 4)
+            begin4 = begin // 4
+            if ns <= 32:
+                e0 = b * 64
+                s_part = np.zeros((4, 16, 16, 4), dtype=np.float32)
+                for tid in range(256):
+                    g, el = tid >> 4, tid & 15
+                    v0, v1 = g < ns, g + 16 < ns
+                    for u in range(4):
+                        i = e0 + 16 * u + el
+                        ic = i if i < n4 else n4 - 1
+                        pp = np.zeros(4, dtype=np.float32)
+                        if v0:
+                            pp = pp + sl4[g, ic]
+                        if v1:
+                            pp = pp + sl4[g + 16, ic]
+                        s_part[u, g, el] = pp
+                for tid in range(64):
+                    u, el = tid >> 4, tid & 15
+                    r = s_part[u, 0, el].copy()
+                    for q in range(1, 16):
+                        r = r + s_part[u, q, el]
+                    io = e0 + tid
+                    if io < n4:
+                        g4[begin4 + io] = r
+                        acc[tid] = f32(acc[tid] + f32(f32(f32(r[0] * r[0]) + f32(r[1] * r[1])) + f32(r[2] * r[2])) + f32(r[3] * r[3]))
+                        owners[begin4 + io] += 1
+            else:
+                s_part = np.zeros((16, 16, 4), dtype=np.float32)
+                for tid in range(256):
+                    g, el = tid >> 4, tid & 15
+                    i = b * 16 + el
+                    ic = i if i < n4 else n4 - 1
+                    pp = np.zeros(4, dtype=np.float32)
+                    s0 = g
+                    while s0 < ns:
+                        for u in range(10):
+                            s_ = s0 + 16 * u
+                            if s_ < ns:
+                                pp = pp + sl4[s_, ic]
+                        s0 += 160
+                    s_part[g, el] = pp
+                for tid in range(16):
+                    el = tid
+                    r = s_part[0, el].copy()
+                    for q in range(1, 16):
+                        r = r + s_part[q, el]
+                    i = b * 16 + el
+                    if i < n4:
+                        g4[begin4 + i] = r
+                        acc[tid] = f32(acc[tid] + f32(f32(f32(r[0] * r[0]) + f32(r[1] * r[1])) + f32(r[2] * r[2])) + f32(r[3] * r[3]))
+                        owners[begin4 + i] += 1
+        else:
+            b = bid - first_block[len(segs)]
+            for it in range(iters):
+                for tid in range(256):
+                    i0 = (it * pb + b) * 1024 + tid
+                    for v in range(4):
+                        i = i0 + 256 * v
+                        if i < plain_count4:
+                            r = g4[plain_begin4 + i]
+                            acc[tid] = f32(acc[tid] + f32(f32(f32(r[0] * r[0]) + f32(r[1] * r[1])) + f32(r[2] * r[2])) + f32(r[3] * r[3]))
+                            owners[plain_begin4 + i] += 1
+        partials[bid] = float(acc.astype(np.float64).sum())
+    return g4.reshape(-1), partials, owners
