@@ -12,6 +12,7 @@
 #include "oneshot.h"
 #include "actor_env.h"
 #include <stdlib.h>
+#include <type_traits>
 
 static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768 | 131072;
 // every bit up to DRA_VAR_CU_PARTITION plus ACTOR_RING, ACTOR_FUSED_CONV1, GATHER_ON_UPDATE and RING_DIRECT measured faster
@@ -43,10 +44,25 @@ using WG1f = ConvWgradOne<G1, 4, 4, 88, 0, false>;
 using WG2 = ConvWgradOne<G2, 9, 4, 24, 4, false>;
 using WG3 = ConvWgradOne<G3, 7, 3, 10, 1, false>;
 using WG3b = ConvWgradOne<G3, 7, 6, 10, 1, false>;   // 6 k-tiles per workgroup: 96 instead of 192 workgroups
+// DRA_VAR_WGRAD_ACC: four (sample, chunk) units per workgroup, one slab per unit group (8 / 8 / 40 slabs at batch 32):
+// conv1 one k-tile per workgroup (320 workgroups x 40 MFMAs per wave), conv2 two k-tiles x one oc-tile (128 x 90),
+// conv3 two k-tiles x one oc-tile (144 x 56)
+using WA1u = ConvWgradAcc<G1, 4, 1, 1, 88, 0, true>;
+using WA1f = ConvWgradAcc<G1, 4, 1, 1, 88, 0, false>;
+using WA2 = ConvWgradAcc<G2, 9, 2, 1, 24, 4, false>;
+using WA3 = ConvWgradAcc<G3, 7, 2, 1, 10, 1, false>;
 
 DRA_API int dra_conv_wgrad_slabs(int layer, int batch, int ksplit, int variant, int* n_slabs) {
   if (!n_slabs || batch < 1 || ksplit < 1) return DRA_EINVAL;
   if (!(variant & DRA_VAR_ONESHOT_WGRAD)) { *n_slabs = ksplit; return DRA_OK; }
+  if (variant & DRA_VAR_WGRAD_ACC) {
+    switch (layer) {
+      case 1: *n_slabs = WA1u::n_slabs(batch); return DRA_OK;
+      case 2: *n_slabs = WA2::n_slabs(batch); return DRA_OK;
+      case 3: *n_slabs = WA3::n_slabs(batch); return DRA_OK;
+    }
+    return DRA_EINVAL;
+  }
   switch (layer) {
     case 1: *n_slabs = WG1u::n_slabs(batch); return DRA_OK;
     case 2: *n_slabs = WG2::n_slabs(batch); return DRA_OK;
@@ -107,24 +123,27 @@ template <class R>
 static int igemm_blocks(const R& r, int nz) { return r.tiles * r.ksplit * nz; }
 
 // layers 2 / 3: weight gradient + input gradient in one launch
-template <class G, class WOne>
+template <class G, class WOne, class R3 = NoRole>
 static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
-                            int64_t slab_stride, int ksplit, float* dx, int batch, int act, int variant, hipStream_t st) {
+                            int64_t slab_stride, int ksplit, float* dx, int batch, int act, int variant, hipStream_t st,
+                            const R3& none = R3(), int n3 = 0) {
   const bool ow = variant & DRA_VAR_ONESHOT_WGRAD, od = variant & DRA_VAR_ONESHOT_DGRAD;
-  NoRole none;
+  if (n3 > 0 && !(od && ow)) return DRA_EINVAL;   // a riding role exists for the one-pass pair only
   if (od && ow) {
     auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
     if (DgradTiles<G>::PT > 1 && dgrad_pt_choice() == 1) {
       auto rd1 = make_dgrad_one<G, 1>(dy, wt, xact, dx, batch, act);
-      return launch_multi(rd1, rd1.blocks(), rw, rw.blocks(), none, 0, st);
+      return launch_multi(rd1, rd1.blocks(), rw, rw.blocks(), none, n3, st);
     }
     if (DgradTiles<G>::PT > 1 && dgrad_pt_choice() == 4) {
       auto rd4 = make_dgrad_one<G, 4>(dy, wt, xact, dx, batch, act);
-      return launch_multi(rd4, rd4.blocks(), rw, rw.blocks(), none, 0, st);
+      return launch_multi(rd4, rd4.blocks(), rw, rw.blocks(), none, n3, st);
     }
     auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
-    return launch_multi(rd, rd.blocks(), rw, rw.blocks(), none, 0, st);
+    return launch_multi(rd, rd.blocks(), rw, rw.blocks(), none, n3, st);
   }
+  if constexpr (!std::is_same<R3, NoRole>::value) return DRA_EINVAL;
+  else {
   if (od) {
     auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
     auto rw = make_wgrad_igemm<G, false>(dy, x, dw, db, slab_stride, ksplit, batch, 1.0);
@@ -138,6 +157,7 @@ static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, con
   }
   auto rw = make_wgrad_igemm<G, false>(dy, x, dw, db, slab_stride, ksplit, batch, 1.0);
   return launch_multi(rd, nd, rw, igemm_blocks(rw, 1), none, 0, st);
+  }
 }
 
 // One launch for a conv layer's backward (KOC weights): dWt / db slabs [n_slabs][..] and, for layers 2 and 3,
@@ -152,6 +172,14 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
   NoRole none;
   switch (layer) {
     case 1:
+      if ((variant & DRA_VAR_ONESHOT_WGRAD) && (variant & DRA_VAR_WGRAD_ACC)) {
+        if (x_is_u8) {
+          auto rw = make_wgrad_one<WA1u>(dy, x, dw, db, slab_stride, batch, u8_coef);
+          return launch_multi(rw, rw.blocks(), none, 0, none, 0, st);
+        }
+        auto rw = make_wgrad_one<WA1f>(dy, x, dw, db, slab_stride, batch, 1.0);
+        return launch_multi(rw, rw.blocks(), none, 0, none, 0, st);
+      }
       if (variant & DRA_VAR_ONESHOT_WGRAD) {
         if (x_is_u8) {
           auto rw = make_wgrad_one<WG1u>(dy, x, dw, db, slab_stride, batch, u8_coef);
@@ -161,8 +189,11 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
         return launch_multi(rw, rw.blocks(), none, 0, none, 0, st);
       }
       return dra_conv_bwd_w_koc(1, dy, x, dw, db, slab_stride, ksplit, batch, x_is_u8, u8_coef, stream);
-    case 2: return conv_bwd_fused_t<G2, WG2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+    case 2:
+      if (variant & DRA_VAR_WGRAD_ACC) return conv_bwd_fused_t<G2, WA2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+      return conv_bwd_fused_t<G2, WG2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
     case 3:
+      if (variant & DRA_VAR_WGRAD_ACC) return conv_bwd_fused_t<G3, WA3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
       if (wg3_wide()) return conv_bwd_fused_t<G3, WG3b>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
       return conv_bwd_fused_t<G3, WG3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
   }
@@ -174,15 +205,99 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
 int dra_conv1_wgrad_ringbatch(const float* dy, const void* frames, const int64_t* idx, float* dw_slabs, float* db_slabs,
                               int64_t slab_stride, int batch, double u8_coef, int variant, void* stream) {
   if (!dy || !frames || !idx || !dw_slabs || !db_slabs || batch < 1 || !(variant & DRA_VAR_ONESHOT_WGRAD)) return DRA_EINVAL;
+  NoRole none;
+  if (variant & DRA_VAR_WGRAD_ACC) {
+    auto ra = make_wgrad_one<WA1u>(dy, frames, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
+    ra.sample_idx = idx;
+    return launch_multi(ra, ra.blocks(), none, 0, none, 0, dra_stream(stream));
+  }
   auto rw = make_wgrad_one<WG1u>(dy, frames, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
   rw.sample_idx = idx;
-  NoRole none;
   return launch_multi(rw, rw.blocks(), none, 0, none, 0, dra_stream(stream));
+}
+
+// DRA_VAR_LATE_FOLD (library-internal, actor_env.h): the same launches with a FoldRole riding along -- `fold` describes the
+// segment of the flat gradient `grad` whose slabs the PREVIOUS backward launch wrote; its workgroups' sums of squares go to
+// fold_partials[0, *n_fold_partials); zero_flag (optional) is reset by the fold's first workgroup.
+static FoldRole make_fold_role(const dra_fold_seg* fold, float* grad, double* partials, unsigned* zero_flag) {
+  FoldRole f;
+  f.grad = grad; f.slabs = fold->slabs; f.begin4 = fold->begin >> 2; f.count4 = fold->count >> 2;
+  f.stride4 = fold->slab_stride >> 2; f.n_slabs = fold->n_slabs; f.partials = partials; f.zero_flag = zero_flag;
+  return f;
+}
+static bool fold_ok(const dra_fold_seg* fold, const float* grad, const double* partials) {
+  return fold && grad && partials && fold->slabs && fold->n_slabs >= 1 && fold->count >= 4 && !(fold->begin & 3) &&
+         !(fold->count & 3) && !(fold->slab_stride & 3) && !((((uintptr_t)fold->slabs) | ((uintptr_t)grad)) & 15);
+}
+
+int dra_conv_bwd_fused_fold(int layer, const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
+                            int64_t slab_stride, float* dx, int batch, int act, int variant, const dra_fold_seg* fold,
+                            float* grad, double* fold_partials, int* n_fold_partials, unsigned* zero_flag, void* stream) {
+  if (!dy || !x || !wt || !dx || !dw || !db || batch < 1 || !n_fold_partials || !fold_ok(fold, grad, fold_partials)) return DRA_EINVAL;
+  if (!(variant & DRA_VAR_ONESHOT_WGRAD) || !(variant & DRA_VAR_ONESHOT_DGRAD)) return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  const FoldRole f = make_fold_role(fold, grad, fold_partials, zero_flag);
+  *n_fold_partials = f.blocks();
+  const bool acc = variant & DRA_VAR_WGRAD_ACC;
+  if (layer == 2) {
+    if (acc) return conv_bwd_fused_t<G2, WA2, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
+    return conv_bwd_fused_t<G2, WG2, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
+  }
+  if (layer == 3) {
+    if (acc) return conv_bwd_fused_t<G3, WA3, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
+    return conv_bwd_fused_t<G3, WG3, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
+  }
+  return DRA_EINVAL;
+}
+
+// conv1's weight gradient (uint8 input: a plain [B][4][84][84] batch, or with idx != null the replay ring's frame array read
+// through the sampled slots) with a FoldRole riding along
+int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, float* dw_slabs, float* db_slabs, int64_t slab_stride,
+                         int batch, double u8_coef, int variant, const dra_fold_seg* fold, float* grad, double* fold_partials,
+                         int* n_fold_partials, unsigned* zero_flag, void* stream) {
+  if (!dy || !x || !dw_slabs || !db_slabs || batch < 1 || !(variant & DRA_VAR_ONESHOT_WGRAD) || !n_fold_partials ||
+      !fold_ok(fold, grad, fold_partials))
+    return DRA_EINVAL;
+  const FoldRole f = make_fold_role(fold, grad, fold_partials, zero_flag);
+  *n_fold_partials = f.blocks();
+  NoRole none;
+  if (variant & DRA_VAR_WGRAD_ACC) {
+    auto ra = make_wgrad_one<WA1u>(dy, x, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
+    ra.sample_idx = idx;
+    return launch_multi(ra, ra.blocks(), f, f.blocks(), none, 0, dra_stream(stream));
+  }
+  auto rw = make_wgrad_one<WG1u>(dy, x, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
+  rw.sample_idx = idx;
+  return launch_multi(rw, rw.blocks(), f, f.blocks(), none, 0, dra_stream(stream));
 }
 
 // Backward of head + fc4 in one launch (VanillaNet over NatureConvBody, hidden = 512):
 //   dWh / dbh (HeadWgradRole), dW4 / db4 (LinWgrad), dx3 = relu'(x3) * (dh4 . W4) (LinDgrad / LinDgradOne).
 // dq [B][A], h4 [B][512] (post-ReLU), dh4 [B][512] (gradient w.r.t. fc4's pre-activation), x3 [B][I].
+// sq_partials (optional, DRA_VAR_LATE_FOLD; one-pass input gradient only): the workgroups that write dW4 / db4 and dWh / dbh
+// leave their sums of squares in sq_partials[0, *n_sq_partials): fc4's tiles first, then the head's 2 * n_actions
+int dra_fc_bwd_fused_sq(const float* dq, const float* h4, const float* dh4, const float* x3, const float* w4, float* dwh,
+                        float* dbh, float* dw4, float* db4, float* dx3, int batch, int n_actions, int in_features, int act,
+                        int variant, double* sq_partials, int* n_sq_partials, void* stream) {
+  if (!dq || !h4 || !dh4 || !x3 || !w4 || !dwh || !dbh || !dw4 || !db4 || !dx3 || batch < 1 || n_actions < 1 ||
+      in_features < 1 || !sq_partials || !n_sq_partials || !(variant & DRA_VAR_ONESHOT_DGRAD))
+    return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  constexpr int O = 512;
+  LinWgradSq<64, 64, 32> pw;
+  pw.M = O; pw.N = in_features + 1; pw.K = batch; pw.I = in_features; pw.dy = dh4; pw.x = x3; pw.dw = dw4; pw.db = db4;
+  pw.partials = sq_partials;
+  auto rw = make_igemm_role(pw, 1);
+  const int nw = igemm_blocks(rw, 1);
+  HeadWgradRole rh;
+  rh.dq = dq; rh.h4 = h4; rh.dwh = dwh; rh.dbh = dbh; rh.B = batch; rh.A = n_actions; rh.partials = sq_partials + nw;
+  *n_sq_partials = nw + 2 * n_actions;
+  LinDgradOne<O> rd;
+  rd.dy = dh4; rd.w = w4; rd.xact = x3; rd.dx = dx3; rd.B = batch; rd.I = in_features; rd.act = act;
+  rd.tiles_n = (in_features + 31) / 32;
+  return launch_multi(rd, rd.tiles_n * ((batch + 31) / 32), rw, nw, rh, 2 * n_actions, st);
+}
+
 DRA_API int dra_fc_bwd_fused(const float* dq, const float* h4, const float* dh4, const float* x3, const float* w4,
                              float* dwh, float* dbh, float* dw4, float* db4, float* dx3, int batch, int n_actions,
                              int in_features, int act, int variant, void* stream) {

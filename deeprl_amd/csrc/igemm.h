@@ -21,6 +21,7 @@
 // operand reads are conflict-free ds_read_b32 and the next chunk's loads fly under the MFMAs.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -49,6 +50,12 @@ constexpr int igemm_lds_floats() {
   constexpr int RED_FLOATS = (KS > 1) ? TILES * (KS - 1) * 1024 : 0;
   return TILE_FLOATS > RED_FLOATS ? TILE_FLOATS : RED_FLOATS;
 }
+
+// A problem with `static constexpr bool SUMSQ = true` and a `double* partials` member also leaves the sum of squares of
+// everything its workgroup stored in partials[bx + tiles * (by + gy * z)] (null = off): the gradient-norm pass of the
+// optimizer then has nothing to read for that tensor (DRA_VAR_LATE_FOLD).
+template <class P, class = void> struct igemm_sumsq : std::false_type {};
+template <class P> struct igemm_sumsq<P, std::void_t<decltype(P::SUMSQ)>> : std::bool_constant<P::SUMSQ> {};
 
 // The body is a device function of (tile, k-split, z) so that several independent problems can share
 // ONE launch (multi_kernel below): every dependent launch costs ~4.5 us on this chip regardless of
@@ -184,6 +191,7 @@ __device__ __forceinline__ void igemm_body(const P& p, const int bx, const int b
         for (int r = 0; r < 16; ++r) acc[0][r] += red[((tile0 * (KS - 1) + q) * 16 + r) * 64 + lane];
     }
   }
+  [[maybe_unused]] float sq = 0.f;
   if (kpart == 0) {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -204,7 +212,23 @@ __device__ __forceinline__ void igemm_body(const P& p, const int bx, const int b
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (m < M && n < N) p.store(z, by, m, n, acc[t][r], aux[r]);
+        if (m < M && n < N) {
+          p.store(z, by, m, n, acc[t][r], aux[r]);
+          if constexpr (igemm_sumsq<P>::value) sq += acc[t][r] * acc[t][r];
+        }
+      }
+    }
+  }
+  if constexpr (igemm_sumsq<P>::value) {
+    if (p.partials) {   // (uniform) fixed-order workgroup sum: lanes by butterfly, waves (w0 + w1) + (w2 + w3)
+      const double d = wave_sum((double)sq);
+      __syncthreads();
+      double* dl = reinterpret_cast<double*>(lds);
+      if (lane == 0) dl[wave] = d;
+      __syncthreads();
+      if (tid == 0) {
+        const int tiles = ((M + BM - 1) / BM) * tiles_n;
+        p.partials[bx + tiles * (by + gy * z)] = (dl[0] + dl[1]) + (dl[2] + dl[3]);
       }
     }
   }
@@ -508,6 +532,13 @@ struct LinWgrad {
     if (n == I) { if (db) db[m] = v; }
     else dw[(int64_t)m * I + n] = v;
   }
+};
+
+// the same problem, also leaving its workgroups' sums of squares (igemm_sumsq)
+template <int BM_, int BN_, int BK_>
+struct LinWgradSq : LinWgrad<BM_, BN_, BK_> {
+  static constexpr bool SUMSQ = true;
+  double* partials;
 };
 
 // input gradient: dxpre[b][i] = act'(xact[b][i]) * sum_o dy[b][o] * W[o][i].  M=B, N=I, K=O.

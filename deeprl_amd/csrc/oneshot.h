@@ -102,13 +102,14 @@ static int launch_multi(const R1& r1, int n1, const R2& r2, int n2, const R3& r3
 // VanillaNet head weight gradient (network_heads.py:18-21 backward):
 //   dWh[a][k] = sum_b dq[b][a] * h4[b][k] ;  dbh[a] = sum_b dq[b][a].   blocks = A * 2 (256 k each)
 struct HeadWgradRole {
-  static constexpr int LDS_FLOATS = 0;
+  static constexpr int LDS_FLOATS = 8;
   const float* dq;   // [B][A]
   const float* h4;   // [B][512]
   float* dwh;        // [A][512]
   float* dbh;        // [A]
   int B, A;
-  __device__ __forceinline__ void run(int bid, float*) const {
+  double* partials = nullptr;   // optional [2 * A]: sum of squares of what each workgroup stored (DRA_VAR_LATE_FOLD)
+  __device__ __forceinline__ void run(int bid, float* lds) const {
     const int a = bid >> 1, k = (bid & 1) * 256 + threadIdx.x;
     float acc = 0.f, accb = 0.f;
     int b = 0;
@@ -126,6 +127,55 @@ struct HeadWgradRole {
     }
     dwh[a * 512 + k] = acc;
     if (k == 0) dbh[a] = accb;
+    if (partials) {
+      const double d = wave_sum((double)(acc * acc + (k == 0 ? accb * accb : 0.f)));
+      double* dl = reinterpret_cast<double*>(lds);
+      if ((threadIdx.x & 63) == 0) dl[threadIdx.x >> 6] = d;
+      __syncthreads();
+      if (threadIdx.x == 0) partials[bid] = (dl[0] + dl[1]) + (dl[2] + dl[3]);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Slab fold as a ROLE (DRA_VAR_LATE_FOLD): grad[begin + i] = sum_s slabs[s * stride + i] in slab order, for a layer whose
+// weight-gradient slabs were written by the PREVIOUS launch, riding in the spare workgroup slots of the next layer's
+// backward launch instead of a norm pass on the update's dependent chain.  One float4 per thread (256 per workgroup),
+// all slabs of an element in flight at once (<= 8 per pass); the workgroup's sum of squares goes to partials[bid].
+struct FoldRole {
+  static constexpr int LDS_FLOATS = 8;
+  float* grad;            // flat gradient
+  const float* slabs;     // [n_slabs][stride]
+  int64_t begin4, count4, stride4;
+  int n_slabs;
+  double* partials;       // [blocks()]
+  unsigned* zero_flag = nullptr;   // optional: workgroup 0 resets this counter (the late-fold optimizer launch's arrival count)
+  __host__ int blocks() const { return (int)((count4 + 255) / 256); }
+  __device__ __forceinline__ void run(int bid, float* lds) const {
+    const int tid = threadIdx.x;
+    if (zero_flag && bid == 0 && tid == 0) __hip_atomic_store(zero_flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t i = (int64_t)bid * 256 + tid;
+    const int64_t ic = i < count4 ? i : count4 - 1;
+    const float4* __restrict__ sl = reinterpret_cast<const float4*>(slabs) + ic;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < n_slabs; s0 += 8) {
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = sl[(int64_t)(s0 + u < n_slabs ? s0 + u : s0) * stride4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < n_slabs) { r.x += t[u].x; r.y += t[u].y; r.z += t[u].z; r.w += t[u].w; }
+    }
+    float sq = 0.f;
+    if (i < count4) {
+      reinterpret_cast<float4*>(grad)[begin4 + i] = r;
+      sq = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+    }
+    const double d = wave_sum((double)sq);
+    double* dl = reinterpret_cast<double*>(lds);
+    if ((tid & 63) == 0) dl[tid >> 6] = d;
+    __syncthreads();
+    if (tid == 0) partials[bid] = (dl[0] + dl[1]) + (dl[2] + dl[3]);
   }
 };
 
@@ -668,6 +718,228 @@ struct ConvWgradOne {
 #pragma unroll 8
       for (int pos = 0; pos < NPOS; ++pos) sb += dyl[pos * LDB + tid];
       db[slab * slab_stride + tid] = sb;
+    }
+    DRA_STAMP(TRR, 5);
+    DRA_STAMP_END(TRR);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Convolution weight gradient, KOC layout, FOUR (sample, row chunk) units accumulated per workgroup (round 3).
+//
+// ConvWgradOne writes one slab per (sample, chunk): 32 / 32 / 160 slabs per layer at batch 32, 14 MB written by the
+// backward and re-read by the fold -- 21 MB of traffic for 4.2 MB of algorithmic bytes in conv2's launch
+// (profiles/r02zzz_pmc_traffic.json).  Here wave w of a workgroup owns unit 4*ug + w: it stages ITS unit's input rows and
+// output gradients into its own quarter of LDS (same layouts as ConvWgradOne: image [channel][row][RW], gradient
+// transposed [oh][ow][oc + 1]) and runs the SAME MFMA sequence over ALL tiles of the workgroup; the four waves'
+// accumulators are then added through LDS in the fixed order (u0 + u1) + (u2 + u3) and ONE slab per unit group is
+// stored: 8 / 8 / 40 slabs.  To keep the MFMA chain per wave (and the workgroup count) where it was, a workgroup owns
+// a quarter of the tiles ConvWgradOne's did: MTG k-tiles x NTG 32-wide output-channel tiles, and only those channels'
+// gradients are staged.  Workgroup = (unit group, k-tile group, oc-tile group).
+template <class G, int ROWS, int MTG, int NTG, int RW_, int CSPAD, bool U8>
+struct ConvWgradAcc {
+  static constexpr int SB = 4;                                  // units per workgroup = waves
+  static constexpr int S = G::S, OH = G::OH, OWP = (OH + 1) & ~1, NPAIR = OWP / 2, NJ = ROWS * NPAIR;
+  static constexpr int NCHUNK = OH / ROWS;
+  static constexpr int MTILES = G::K / 32, NGRP = MTILES / MTG, NTL = G::OC / 32, NNG = NTL / NTG, TILES = MTG * NTG;
+  static constexpr int NR = (ROWS - 1) * S + G::KH;
+  static constexpr int RW = RW_, CS = NR * RW + CSPAD;
+  // channels MTG*32 consecutive k (starting at a multiple of 32) can touch
+  static constexpr int NCHMAX = ((MTG * 32) % G::KK == 0) ? (MTG * 32) / G::KK
+                              : ((G::KK % (MTG * 32) == 0) ? 1 : (MTG * 32 + G::KK - 2) / G::KK + 1);
+  static constexpr int NCH = NCHMAX < G::C ? NCHMAX : G::C;
+  static constexpr int IMG = NCH * CS + RW;
+  static constexpr int OCW = 32 * NTG, LDB = OCW + 1, NPOS = ROWS * OWP, DYF = NPOS * LDB;
+  static constexpr int UNIT = (IMG + DYF + 3) & ~3;
+  static constexpr int REDF = TILES * 4096 + SB * OCW;
+  static constexpr int LDS_FLOATS = SB * UNIT > REDF ? SB * UNIT : REDF;
+  static_assert(G::K % 32 == 0 && MTILES % MTG == 0 && NTL % NTG == 0 && OH % ROWS == 0, "tiling");
+  static_assert(RW >= (OWP - 1) * S + G::KH, "LDS row holds the pad column's taps");
+  static_assert(OCW <= 64, "bias partials: one lane per staged output channel");
+  const float* dy;   // [B][OC][OH][OH]
+  const void* x;     // [B][C][H][H] f32 or u8
+  float* dw;         // slab 0 of dWt [K][OC]
+  float* db;         // slab 0 of db [OC]
+  int64_t slab_stride;
+  int B;
+  double coef;
+  const int64_t* sample_idx = nullptr;   // (U8) ring-direct minibatch, as in ConvWgradOne
+  __host__ static int n_slabs(int batch) { return (batch * NCHUNK + SB - 1) / SB; }
+  __host__ int blocks() const { return n_slabs(B) * NGRP * NNG; }
+  __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int ng = bid % NNG;
+    int r = bid / NNG;
+    const int grp = r % NGRP, ug = r / NGRP;
+    const int n_units = B * NCHUNK;
+    const int unit = ug * SB + wave;
+    const bool valid = unit < n_units;
+    const int uc = valid ? unit : n_units - 1;              // clamped: every address below is mapped
+    const int bi = uc / NCHUNK, chunk = uc - bi * NCHUNK;
+    const int k0 = grp * MTG * 32, oc0 = ng * OCW;
+    const int c_lo = k0 / G::KK;
+    const int c_hi = min((k0 + MTG * 32 - 1) / G::KK, G::C - 1);
+    const int nch = c_hi - c_lo + 1;                        // <= NCH
+    const int ir0 = chunk * ROWS * S;
+    float* img = lds + wave * UNIT;
+    float* dyl = img + IMG;
+    [[maybe_unused]] constexpr int TRR = (G::C == 4) ? TR_CONV1_B : ((G::C == 32) ? TR_CONV2_B : TR_CONV3_B);
+    DRA_STAMP(TRR, 0);
+    // ---- this wave's loads: its unit's gradients of channels [oc0, oc0 + OCW), then its input rows
+    constexpr bool WHOLE = (ROWS == OH);
+    constexpr int RUN = ROWS * OH;
+    static_assert(WHOLE ? (OCW * G::P) % 4 == 0 : RUN % 4 == 0, "float4 dY staging");
+    constexpr int NVD = WHOLE ? (OCW * G::P) / 4 : OCW * (RUN / 4), RD = (NVD + 63) / 64;
+    float4 draw[RD];
+    const float* dyb = dy + ((int64_t)bi * G::OC + oc0) * G::P + chunk * ROWS * OH;
+#pragma unroll
+    for (int q = 0; q < RD; ++q) {
+      const int f = min(lane + 64 * q, NVD - 1);
+      if constexpr (WHOLE) {
+        draw[q] = reinterpret_cast<const float4*>(dyb)[f];
+      } else {
+        const int oc = f / (RUN / 4), v = f - oc * (RUN / 4);
+        draw[q] = *reinterpret_cast<const float4*>(dyb + oc * G::P + 4 * v);
+      }
+    }
+    constexpr int WPR = G::H / 4;                                    // (U8) u32 words per image row
+    constexpr int RUNI = NR * G::H;
+    constexpr bool V4 = !U8 && (RUNI % 4 == 0) && (G::HW % 4 == 0) && (G::H % 4 == 0);
+    constexpr int VPC = U8 ? NR * WPR : (V4 ? RUNI / 4 : RUNI);      // loads per channel
+    constexpr int NVI = NCH * VPC, RI = (NVI + 63) / 64;
+    unsigned iraw_u[U8 ? RI : 1];
+    float4 iraw4[V4 ? RI : 1];
+    float iraw1[(!U8 && !V4) ? RI : 1];
+    if constexpr (U8) {
+      const int64_t first = sample_idx ? sample_idx[bi] - (G::C - 1) : (int64_t)bi * G::C;
+      const uint8_t* xb = reinterpret_cast<const uint8_t*>(x) + (first + c_lo) * G::HW;
+#pragma unroll
+      for (int q = 0; q < RI; ++q) {
+        const int e = min(lane + 64 * q, nch * VPC - 1);
+        const int cl = e / VPC, rem = e - cl * VPC, rr = rem / WPR, wd = rem - rr * WPR;
+        iraw_u[q] = *reinterpret_cast<const unsigned*>(xb + ((int64_t)cl * G::H + ir0 + rr) * G::H + 4 * wd);
+      }
+    } else {
+      const float* xf = reinterpret_cast<const float*>(x) + ((int64_t)bi * G::C + c_lo) * G::HW + (int64_t)ir0 * G::H;
+#pragma unroll
+      for (int q = 0; q < RI; ++q) {
+        const int f = min(lane + 64 * q, nch * VPC - 1);
+        const int cl = f / VPC, v = f - cl * VPC;
+        if constexpr (V4) iraw4[q] = *reinterpret_cast<const float4*>(xf + (int64_t)cl * G::HW + 4 * v);
+        else iraw1[q] = xf[(int64_t)cl * G::HW + v];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // zero this wave's quarter (image padding, pad columns of the transposed gradient) while the loads are in flight
+    for (int i = lane; i < UNIT / 4; i += 64) reinterpret_cast<float4*>(img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RI; ++q) {
+      const int e = lane + 64 * q;
+      if constexpr (U8) {
+        unsigned v = iraw_u[q];
+        asm volatile("" : "+v"(v));
+        if (e < nch * VPC) {
+          const int cl = e / VPC, rem = e - cl * VPC, rr = rem / WPR, wd = rem - rr * WPR;
+          float* d = img + cl * CS + rr * RW + 4 * wd;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) d[b] = (float)((double)((v >> (8 * b)) & 0xffu) * coef);
+        }
+      } else if constexpr (V4) {
+        float4 v4 = iraw4[q];
+        asm volatile("" : "+v"(v4.x), "+v"(v4.y), "+v"(v4.z), "+v"(v4.w));
+        if (e < nch * VPC) {
+          const int cl = e / VPC, v = e - cl * VPC;
+          const int r0 = 4 * v, rr = r0 / G::H, cc = r0 - rr * G::H;   // H % 4 == 0: a float4 never leaves its image row
+          float* d = img + cl * CS + rr * RW + cc;
+          d[0] = v4.x; d[1] = v4.y; d[2] = v4.z; d[3] = v4.w;
+        }
+      } else {
+        float v1 = iraw1[q];
+        asm volatile("" : "+v"(v1));
+        if (e < nch * VPC) {
+          const int cl = e / VPC, v = e - cl * VPC;
+          const int rr = v / G::H, cc = v - rr * G::H;
+          img[cl * CS + rr * RW + cc] = v1;
+        }
+      }
+    }
+    // transposed gradient: element (ocl, ohl, ow) -> dyl[(ohl*OWP + ow)*LDB + ocl]
+#pragma unroll
+    for (int q = 0; q < RD; ++q) {
+      const int f = lane + 64 * q;
+      float4 v4 = draw[q];
+      asm volatile("" : "+v"(v4.x), "+v"(v4.y), "+v"(v4.z), "+v"(v4.w));
+      if (f < NVD) {
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        int oc0l, pos0;
+        if constexpr (WHOLE) { oc0l = (4 * f) / G::P; pos0 = 4 * f - oc0l * G::P; }
+        else { oc0l = f / (RUN / 4); pos0 = 4 * (f - oc0l * (RUN / 4)); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int p = pos0 + i, oc = oc0l;
+          if (WHOLE && p >= G::P) { p -= G::P; ++oc; }
+          const int ohl = p / OH, ow = p - ohl * OH;
+          dyl[(ohl * OWP + ow) * LDB + oc] = vv[i];
+        }
+      }
+    }
+    DRA_STAMP(TRR, 1);
+    __syncthreads();
+    DRA_STAMP(TRR, 2);
+    // ---- MFMA: every wave runs all TILES tiles on its own unit
+    f32x16 acc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) acc[t] = zero16();
+    if (valid) {
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) {
+        const int mt = t / NTG, nt = t - mt * NTG;
+        const int k = k0 + mt * 32 + li;
+        const int c = k / G::KK, kr = k - c * G::KK, kh = kr / G::KH, kw = kr - kh * G::KH;
+        const float* ap = img + (c - c_lo) * CS + kh * RW + kw + h * S;
+        const float* bp = dyl + h * LDB + nt * 32 + li;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int ohl = j / NPAIR, jw = j - ohl * NPAIR;
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ohl * S * RW + 2 * jw * S], bp[(ohl * OWP + 2 * jw) * LDB],
+                                                       acc[t], 0, 0, 0);
+        }
+      }
+    }
+    // bias gradient of this unit (k-group 0 only): fixed-order column sums of the staged gradient
+    float sb = 0.f;
+    if (grp == 0 && valid && lane < OCW) {
+#pragma unroll 8
+      for (int pos = 0; pos < NPOS; ++pos) sb += dyl[pos * LDB + lane];
+    }
+    DRA_STAMP(TRR, 3);
+    __syncthreads();   // every wave is done reading its operands: LDS becomes the reduction scratch
+    DRA_STAMP(TRR, 4);
+    float* red = lds;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) red[t * 4096 + (wave * 16 + rr) * 64 + lane] = acc[t][rr];
+    if (grp == 0 && lane < OCW) red[TILES * 4096 + wave * OCW + lane] = sb;
+    __syncthreads();
+    float* dws = dw + (int64_t)ug * slab_stride;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const int mt = t / NTG, nt = t - mt * NTG;
+      const float* rt = red + t * 4096;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = wave * 4 + q;
+        const float s = (rt[(0 * 16 + rr) * 64 + lane] + rt[(1 * 16 + rr) * 64 + lane]) +
+                        (rt[(2 * 16 + rr) * 64 + lane] + rt[(3 * 16 + rr) * 64 + lane]);
+        const int k = k0 + mt * 32 + mfma_row(rr, h);
+        dws[(int64_t)k * G::OC + oc0 + nt * 32 + li] = s;
+      }
+    }
+    if (grp == 0 && tid < OCW) {
+      const float* rb = red + TILES * 4096;
+      db[(int64_t)ug * slab_stride + oc0 + tid] = (rb[tid] + rb[OCW + tid]) + (rb[2 * OCW + tid] + rb[3 * OCW + tid]);
     }
     DRA_STAMP(TRR, 5);
     DRA_STAMP_END(TRR);

@@ -74,19 +74,20 @@ __device__ __forceinline__ float clip_coef_impl(const double* __restrict__ parti
   if (!partials) return 1.f;  // uniform: no clipping requested
   __shared__ double s_part[4];
   __shared__ float s_coef;
-  // n_partials <= dra_norm_partials_max() = 2048 = 8 per thread: straight-line loads (a loop here makes the
+  // n_partials <= dra_norm_partials_max() = 4096 = 16 per thread: straight-line loads (a loop here makes the
   // compiler drain every outstanding load of the caller first); same per-thread summation order as a loop
   double d = 0.0;
   {
-    double v[8];
+    constexpr int NPT = 16;
+    double v[NPT];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NPT; ++u) {
       const int i = (int)threadIdx.x + 256 * u;
       const double* src = partials + (i < n_partials ? i : n_partials - 1);
       v[u] = COHERENT ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) d += ((int)threadIdx.x + 256 * u < n_partials) ? v[u] : 0.0;
+    for (int u = 0; u < NPT; ++u) d += ((int)threadIdx.x + 256 * u < n_partials) ? v[u] : 0.0;
   }
   d = wave_sum(d);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = d;
@@ -366,7 +367,7 @@ clip_step_kernel(float* __restrict__ grad, const FoldPlan fp, double* __restrict
   DRA_STAMP_END(TR_NORM);
 }
 
-DRA_API int dra_norm_partials_max(void) { return 2048; }
+DRA_API int dra_norm_partials_max(void) { return 4096; }
 
 static int make_fold_plan(int64_t n, const dra_fold_seg* segs, int n_segs, FoldPlan* out, int* blocks_out) {
   if (n < 4 || (n & 3) || n_segs < 0 || n_segs > DRA_MAX_FOLD_SEGS || (n_segs && !segs)) return DRA_EINVAL;
@@ -480,6 +481,208 @@ DRA_API int dra_clip_step_coop(float* param, float* grad, float* state1, float* 
   else
     hipLaunchKernelGGL(clip_step_kernel<1>, dim3(blocks), dim3(256), 0, dra_stream(stream), grad, fp, partials, param, state1,
                        state2, param_copy, hp, out_norm, barrier_ctr, timeout_flag);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+
+// ---- late-fold form (DRA_VAR_LATE_FOLD): the optimizer launch with only the LAST layer's fold in front --------------------
+// The gradient-norm pass was a launch of its own on the update's dependent chain (5.8 us + a 1.8 us boundary,
+// profiles/r02zzz_phase_async.json) because the conv weight-gradient slabs had to be folded before anything could be
+// clipped.  With this form every tensor's sum of squares already exists when the optimizer starts -- the linear layers'
+// from the kernels that wrote them (igemm_sumsq, HeadWgradRole), conv3 / conv2 from FoldRole workgroups riding in the next
+// layer's backward launch -- EXCEPT the first segment (conv1, whose weight gradient is the last kernel of the backward).
+// Its fold_blocks workgroups come first in the grid: they fold their 64 float4 each (4 slab groups x 64 elements, thread
+// (g, el) adds slabs g, g+4, ... in order, the groups meet in LDS as (g0 + g1) + (g2 + g3)), publish their partial with an
+// agent-scope store and count themselves on *flag.  EVERY workgroup requests its parameters / optimizer state / gradient
+// first, then waits until *flag == fold_blocks (one agent-scope load per poll by one thread; ~33 arrivals instead of the
+// cooperative form's 796 tickets, which serialised at ~30 ns each: profiles/r02zt_*), reduces all partials in the fixed
+// order and applies the step.  Progress: the fold workgroups have the lowest block indices, so they are resident before
+// any waiting workgroup; a wait is bounded (50 ms) and reports through the pinned timeout flag like the cooperative form.
+// *flag must be zero at launch (FoldRole::zero_flag resets it in the preceding launch).
+struct LatePlan {
+  int64_t n;             // floats in the flat buffers (a tail of n % 4 floats is stepped by the last workgroup)
+  int64_t n4;            // whole float4s
+  int64_t fold_count4;   // the folded segment is [0, fold_count4)
+  const float4* slabs;
+  int64_t stride4;
+  int32_t n_slabs, fold_blocks, n_prior;   // n_prior: partials already written by earlier launches ([0, n_prior))
+};
+constexpr int kLateSlabsPerThread = 16;    // n_slabs <= 64
+
+template <int OPT>   // 0 = RMSprop, 1 = Adam
+__global__ void __launch_bounds__(256)
+late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict__ partials, float* __restrict__ p,
+                 float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ p_copy, const StepHyper hp,
+                 float* __restrict__ out_norm, unsigned* __restrict__ flag, int* __restrict__ timeout_flag) {
+  __shared__ float4 s_part[4][64];
+  __shared__ double s_red[4];
+  __shared__ float s_hyper[2];
+  const int tid = threadIdx.x, bid = blockIdx.x;
+  float4* __restrict__ g4 = reinterpret_cast<float4*>(grad);
+  const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+  const float4* __restrict__ s14 = reinterpret_cast<const float4*>(s1);
+  const float4* __restrict__ s24 = reinterpret_cast<const float4*>((OPT == 0 && !hp.centered) ? s1 : s2);
+  int64_t gi[kStepNV];
+  float4 G[kStepNV], P[kStepNV], S[kStepNV], A[kStepNV];
+#pragma unroll
+  for (int v = 0; v < kStepNV; ++v) gi[v] = -1;
+  DRA_STAMP(TR_STEP, 0);
+  if (bid < lp.fold_blocks) {
+    const int g = tid >> 6, el = tid & 63;
+    const int64_t i = (int64_t)bid * 64 + el;
+    const int64_t ic = i < lp.fold_count4 ? i : lp.fold_count4 - 1;
+    if (tid < 64) { P[0] = p4[ic]; S[0] = s14[ic]; A[0] = s24[ic]; }
+    const int ns = lp.n_slabs;
+    float4 t[kLateSlabsPerThread];
+#pragma unroll
+    for (int u = 0; u < kLateSlabsPerThread; ++u) {
+      const int s = g + 4 * u;
+      t[u] = lp.slabs[(int64_t)(s < ns ? s : 0) * lp.stride4 + ic];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < kLateSlabsPerThread; ++u)
+      if (g + 4 * u < ns) add4(pp, t[u]);
+    s_part[g][el] = pp;
+    __syncthreads();
+    float acc = 0.f;
+    if (tid < 64) {
+      float4 a = s_part[0][el], b = s_part[2][el];
+      add4(a, s_part[1][el]);
+      add4(b, s_part[3][el]);
+      add4(a, b);
+      if (i < lp.fold_count4) {
+        g4[i] = a;
+        acc = sq4(a);
+        G[0] = a;
+        gi[0] = i;
+      }
+    }
+    const double d = wave_sum((double)acc);   // (waves 1-3 hold zeros)
+    if (tid == 0) {
+      __hip_atomic_store(partials + lp.n_prior + bid, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    const int64_t i0 = lp.fold_count4 + (int64_t)(bid - lp.fold_blocks) * (256 * kStepNV) + tid;
+#pragma unroll
+    for (int v = 0; v < kStepNV; ++v) {
+      const int64_t i = i0 + 256 * v;
+      const int64_t ic = i < lp.n4 ? i : lp.n4 - 1;
+      P[v] = p4[ic]; G[v] = g4[ic]; S[v] = s14[ic]; A[v] = s24[ic];
+      if (i < lp.n4) gi[v] = i;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (OPT == 1 && tid == 64) {   // Adam's bias corrections from the device step count, exactly as dra_adam_hyper forms them
+    const double t = (double)*hp.step_dev;
+    const double bc1 = 1.0 - pow((double)hp.a, t), bc2 = 1.0 - pow((double)hp.b2, t);
+    s_hyper[0] = (float)((double)hp.lr / bc1);
+    s_hyper[1] = (float)(1.0 / sqrt(bc2));
+  }
+  if (tid == 0) {
+    const unsigned target = (unsigned)lp.fold_blocks;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > kBarrierTicks) {
+        __hip_atomic_store(timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  DRA_STAMP(TR_STEP, 2);
+  const float coef = clip_coef_coherent(partials, lp.n_prior + lp.fold_blocks, hp.max_norm, out_norm);
+  [[maybe_unused]] const float oma = 1.f - hp.a, omb2 = 1.f - hp.b2;
+  [[maybe_unused]] const float step_size = s_hyper[0], inv_sqrt_bc2 = s_hyper[1];
+#pragma unroll
+  for (int v = 0; v < kStepNV; ++v) {
+    if (gi[v] >= 0) {
+      float* pp = &P[v].x; const float* gg = &G[v].x; float* ss = &S[v].x; float* aa = &A[v].x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (OPT == 0) {
+          rmsprop_elem(pp[k], gg[k], ss[k], aa[k], coef, hp.a, oma, hp.lr, hp.eps, hp.centered);
+        } else {
+          const float gk = gg[k] * coef;
+          ss[k] = ss[k] * hp.a + oma * gk;                       // exp_avg
+          aa[k] = aa[k] * hp.b2 + omb2 * gk * gk;                // exp_avg_sq
+          pp[k] = pp[k] - step_size * (ss[k] / (sqrtf(aa[k]) * inv_sqrt_bc2 + hp.eps));
+        }
+      }
+      reinterpret_cast<float4*>(p)[gi[v]] = P[v];
+      if (p_copy) reinterpret_cast<float4*>(p_copy)[gi[v]] = P[v];
+      reinterpret_cast<float4*>(s1)[gi[v]] = S[v];
+      if (OPT == 1 || hp.centered) reinterpret_cast<float4*>(s2)[gi[v]] = A[v];
+    }
+  }
+  // tail (n not a multiple of 4): the last few floats, by the first threads of the last workgroup
+  const int64_t tl = (lp.n4 << 2) + tid;
+  if (bid == (int)gridDim.x - 1 && tl < lp.n) {
+    float pv = p[tl], sv = s1[tl], av = (OPT == 1 || hp.centered) ? s2[tl] : 0.f;
+    if (OPT == 0) {
+      rmsprop_elem(pv, grad[tl], sv, av, coef, hp.a, oma, hp.lr, hp.eps, hp.centered);
+    } else {
+      const float gk = grad[tl] * coef;
+      sv = sv * hp.a + oma * gk;
+      av = av * hp.b2 + omb2 * gk * gk;
+      pv = pv - step_size * (sv / (sqrtf(av) * inv_sqrt_bc2 + hp.eps));
+    }
+    p[tl] = pv;
+    if (p_copy) p_copy[tl] = pv;
+    s1[tl] = sv;
+    if (OPT == 1 || hp.centered) s2[tl] = av;
+  }
+  DRA_STAMP(TR_STEP, 5);
+  DRA_STAMP_END(TR_STEP);
+}
+
+// Workgroups of the late-fold launch that fold (and publish a partial): ceil(seg->count / 256 floats).
+DRA_API int dra_clip_step_late_blocks(const dra_fold_seg* seg, int* fold_blocks) {
+  if (!seg || !fold_blocks || seg->count < 4 || (seg->count & 3)) return DRA_EINVAL;
+  *fold_blocks = (int)(((seg->count >> 2) + 63) / 64);
+  return DRA_OK;
+}
+
+// seg: the ONE segment still in slabs (must start at element 0 of the flat gradient, n_slabs <= 64); partials[0, n_prior)
+// were written by earlier launches, this launch adds dra_clip_step_late_blocks() more behind them; flag: zeroed uint32 in
+// device memory (reset before every launch); timeout_flag: pinned host int.  hyper / optimizer as dra_clip_step_coop.
+DRA_API int dra_clip_step_late(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* seg,
+                               double* partials, int n_prior, unsigned* flag, int* timeout_flag, int optimizer, float max_norm,
+                               const float* hyper, int centered, const int64_t* step_dev, float* out_norm, float* param_copy,
+                               void* stream) {
+  if (!param || !grad || !state1 || !seg || !partials || !flag || !timeout_flag || !hyper) return DRA_EINVAL;
+  if (optimizer != DRA_OPT_RMSPROP && optimizer != DRA_OPT_ADAM) return DRA_EINVAL;
+  if ((optimizer == DRA_OPT_ADAM && (!state2 || !step_dev)) || (optimizer == DRA_OPT_RMSPROP && centered && !state2)) return DRA_EINVAL;
+  if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)state1) | ((uintptr_t)state2) | ((uintptr_t)param_copy) |
+       ((uintptr_t)seg->slabs)) & 15)
+    return DRA_EINVAL;
+  if (n < 4 || seg->begin != 0 || seg->count < 4 || (seg->count & 3) || seg->count > n || !seg->slabs ||
+      seg->n_slabs < 1 || seg->n_slabs > 4 * kLateSlabsPerThread || (seg->slab_stride & 3) || n_prior < 0)
+    return DRA_EINVAL;
+  LatePlan lp;
+  memset(&lp, 0, sizeof(lp));
+  lp.n = n; lp.n4 = n >> 2; lp.fold_count4 = seg->count >> 2; lp.slabs = reinterpret_cast<const float4*>(seg->slabs);
+  lp.stride4 = seg->slab_stride >> 2; lp.n_slabs = seg->n_slabs; lp.n_prior = n_prior;
+  lp.fold_blocks = (int)((lp.fold_count4 + 63) / 64);
+  if (lp.n_prior + lp.fold_blocks > dra_norm_partials_max()) return DRA_EINVAL;
+  const int64_t plain = (lp.n4 - lp.fold_count4 + 256 * kStepNV - 1) / (256 * kStepNV);
+  const int64_t blocks = lp.fold_blocks + plain;
+  if (blocks > 0x7fffffff) return DRA_EINVAL;
+  StepHyper hp;
+  memset(&hp, 0, sizeof(hp));
+  hp.max_norm = max_norm; hp.lr = hyper[0]; hp.a = hyper[1]; hp.eps = hyper[2]; hp.b2 = hyper[3];
+  hp.centered = centered; hp.step_dev = step_dev;
+  if (optimizer == DRA_OPT_ADAM)
+    hipLaunchKernelGGL(late_step_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, dra_stream(stream), grad, lp, partials, param,
+                       state1, state2, param_copy, hp, out_norm, flag, timeout_flag);
+  else
+    hipLaunchKernelGGL(late_step_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, dra_stream(stream), grad, lp, partials, param,
+                       state1, state2, param_copy, hp, out_norm, flag, timeout_flag);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

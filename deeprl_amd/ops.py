@@ -410,7 +410,9 @@ VAR_GATHER_ON_UPDATE = 16384
 VAR_RING_DIRECT = 32768
 VAR_COOP_OPT = 65536
 VAR_IDX_PREFETCH = 131072
-VAR_ALL = 262143
+VAR_WGRAD_ACC = 262144
+VAR_LATE_FOLD = 524288
+VAR_ALL = 1048575
 
 
 def set_tuning(mask):

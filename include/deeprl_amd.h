@@ -196,6 +196,13 @@ int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* 
 #define DRA_VAR_IDX_PREFETCH 131072 /* learner (with RING_DIRECT): a step-tagged copy of the minibatch indices goes to the device by
                                     * an unordered async copy when the step is enqueued; conv1 takes an element from there when
                                     * its tag is this update's (no PCIe read in front of its frame loads), else from pinned memory */
+#define DRA_VAR_WGRAD_ACC 262144  /* with ONESHOT_WGRAD: four (sample, row chunk) units accumulated per workgroup (one per
+                                   * wave, added through LDS in a fixed order): 8 / 8 / 40 slabs per layer at batch 32 instead
+                                   * of 32 / 32 / 160 -- the backward's slab traffic drops from 14 MB to 3.5 MB */
+#define DRA_VAR_LATE_FOLD 524288  /* learner (with ONESHOT_WGRAD + FUSED_BWD): no gradient-norm launch -- sums of squares come
+                                   * from the kernels that write each gradient, conv3 / conv2 slabs are folded by spare
+                                   * workgroups of the NEXT layer's backward launch, conv1's by the first workgroups of the
+                                   * optimizer launch (dra_clip_step_late) */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
@@ -240,6 +247,17 @@ int dra_clip_step_coop(float* param, float* grad, float* state1, float* state2, 
                        int n_segs, double* partials, unsigned long long* barrier_ctr, int* timeout_flag,
                        int resident_limit, int optimizer, float max_norm, const float* hyper, int centered,
                        const int64_t* step_dev, float* out_norm, float* param_copy, void* stream);
+/* the late-fold form (DRA_VAR_LATE_FOLD): every tensor's sum of squares was left in partials[0, n_prior) by the kernels
+ * that produced its gradient, except ONE segment (starting at element 0, n_slabs <= 64: conv1, whose weight gradient is the
+ * last kernel of the backward) that is still in slabs.  The launch's first dra_clip_step_late_blocks() workgroups fold it,
+ * publish their partials behind the others and count themselves on *flag (zeroed uint32 in device memory, reset before
+ * every launch); every workgroup loads its operands, waits for that count (bounded: timeout_flag as above), reduces all
+ * partials in the fixed order and applies the step.  No gradient-norm launch, no grid-wide ticket barrier. */
+int dra_clip_step_late_blocks(const dra_fold_seg* seg, int* fold_blocks);
+int dra_clip_step_late(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* seg,
+                       double* partials, int n_prior, unsigned* flag, int* timeout_flag, int optimizer, float max_norm,
+                       const float* hyper, int centered, const int64_t* step_dev, float* out_norm, float* param_copy,
+                       void* stream);
 int dra_rmsprop_step(float* param, const float* grad, float* square_avg, float* grad_avg, int64_t n,
                      const double* partials, int n_partials, float max_norm, float lr, float alpha, float eps,
                      int centered, float* out_norm, void* stream);

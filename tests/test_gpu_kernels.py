@@ -642,10 +642,11 @@ def test_conv_koc_fwd_throughput_shape(dev, layer):
 # ---------------------------------------------------------------- fused launches + one-pass kernels (fused.hip)
 @pytest.mark.parametrize("layer", [1, 2, 3])
 @pytest.mark.parametrize("batch", [32, 1, 5])
-@pytest.mark.parametrize("variant", [1, 3, 9, 11])
+@pytest.mark.parametrize("variant", [1, 3, 9, 11, 9 + 262144, 11 + 262144])
 def test_conv_bwd_fused_vs_autograd(dev, layer, batch, variant):
     """dra_conv_bwd_fused: weight/bias gradient slabs and the masked input gradient of one layer in ONE launch,
-    for the K-chunked (1), one-pass dgrad (3), one-pass wgrad (9) and all-one-pass (11) variants, against
+    for the K-chunked (1), one-pass dgrad (3), one-pass wgrad (9) and all-one-pass (11) variants, and the one-pass weight
+    gradient that accumulates four (sample, chunk) units per workgroup (+ 262144 = DRA_VAR_WGRAD_ACC), against
     F.conv2d autograd; the slab fold goes through dra_grad_sqnorm_segs."""
     import torch.nn.functional as F
     from deeprl_amd import ops
@@ -673,6 +674,8 @@ def test_conv_bwd_fused_vs_autograd(dev, layer, batch, variant):
     kk = c * k * k
     stride = dw_s.stride(0)
     n_slabs = dw_s.shape[0]
+    if variant & 262144:   # one slab per group of four units (unit = sample x row chunk; conv1 has 5 chunks per sample)
+        assert n_slabs == (batch * (5 if layer == 1 else 1) + 3) // 4
     seg = oc * kk + oc
     grad = torch.zeros(seg + 1000, dtype=torch.float32, device=dev)
     tail = rs.standard_normal(1000).astype(np.float32)
