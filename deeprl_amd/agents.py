@@ -83,6 +83,9 @@ class BaseAgent:
 
     # -- checkpoints -------------------------------------------------------------------------------------------
     def save(self, filename):
+        dp = getattr(self, 'dp', None)
+        if dp is not None and not dp.is_main:
+            return     # data parallel: every rank holds the same parameters; rank 0 writes the one checkpoint file
         # parameters may be strided views of a flat (KOC) buffer: write plain contiguous CPU tensors, as the reference does
         weights = {k: v.detach().cpu().contiguous().clone() for k, v in self.network.state_dict().items()}
         torch.save(weights, filename + '.model')
@@ -925,6 +928,24 @@ class _OnPolicyGraph:
         return self.out
 
 
+def _dp_sync_start(dp, network, *fused):
+    """Data parallel: every rank starts from rank 0's parameters, module buffers and optimizer state (only gradients are
+    exchanged afterwards, so equal starts stay equal)."""
+    if not dp.active:
+        return
+    tensors = []
+    for f in fused:
+        tensors += [f.flat.flat, f.state1, f.state2]
+    seen = {t.data_ptr() for t in tensors}
+    for t in list(network.parameters()) + list(network.buffers()):
+        # parameters re-homed in a flat buffer are views of it; anything else (buffers, stray parameters) goes by itself
+        if not any(f.flat.flat.data_ptr() <= t.data_ptr() < f.flat.flat.data_ptr() + 4 * f.flat.flat.numel() for f in fused) \
+                and t.data_ptr() not in seen:
+            tensors.append(t)
+            seen.add(t.data_ptr())
+    dp.sync_state(*tensors)
+
+
 class A2CAgent(BaseAgent):
     """A2C_agent.py:12-64."""
 
@@ -937,6 +958,7 @@ class A2CAgent(BaseAgent):
         self.network = config.network_fn()
         self.optimizer = config.optimizer_fn(self.network.parameters())
         self._fused = FusedOptimizer.adopt(self.optimizer)
+        _dp_sync_start(self.dp, self.network, self._fused)
         self.total_steps = 0
         from .device_env import DeviceAtariVec
         if DeviceAtariVec.eligible(self.task, config):      # synthetic Atari emulators: the environments live on the device
@@ -990,7 +1012,9 @@ class A2CAgent(BaseAgent):
         value = torch.stack(values).contiguous()
         adv, ret = ops.gae(torch.stack(rewards).contiguous(), torch.stack(masks).contiguous(), value, config.discount,
                            config.gae_tau, config.use_gae)
-        prediction = self.network(torch.cat(states, dim=0), torch.cat([a.reshape(-1) for a in actions], dim=0))
+        # (stored actions: [N] per step for Categorical policies, [N, action_dim] for Gaussian ones -- a2c_continuous,
+        # examples.py:384-404 -- so the environment axis is concatenated and the action axis kept)
+        prediction = self.network(torch.cat(states, dim=0), torch.cat(actions, dim=0))
         out4, (g_lp, g_ent, g_v) = ops.a2c_loss(prediction['log_pi_a'].detach(), prediction['entropy'].detach(),
                                                 prediction['v'].detach(), adv.reshape(-1, 1), ret.reshape(-1, 1),
                                                 config.entropy_weight, config.value_loss_weight)
@@ -1108,6 +1132,7 @@ class PPOAgent(BaseAgent):
                 raise NotImplementedError("PPO with a shared phi_body and separate optimisers: use shared_repr=True")
             self._fused_actor = FusedOptimizer.adopt(self.actor_opt)
             self._fused_critic = FusedOptimizer.adopt(self.critic_opt)
+        _dp_sync_start(self.dp, self.network, *([self._fused] if config.shared_repr else [self._fused_actor, self._fused_critic]))
         self.total_steps = 0
         from .device_env import DeviceAtariVec
         if DeviceAtariVec.eligible(self.task, config):      # synthetic Atari emulators: the environments live on the device

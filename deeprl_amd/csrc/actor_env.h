@@ -127,13 +127,15 @@ int dra_conv1_wgrad_ringbatch(const float* dy, const void* frames, const int64_t
 
 // fused.hip (library-internal), DRA_VAR_LATE_FOLD: the backward launches with (a) the linear layers' workgroups leaving
 // the sums of squares of what they store, (b) a FoldRole riding along that folds the PREVIOUS launch's weight-gradient
-// slabs (`fold`) into the flat gradient `grad` and leaves its workgroups' sums of squares
+// slabs (`fold`, at most 32) into the flat gradient `grad` and leaves its workgroups' sums of squares; reset_slots[0, n_reset)
+// (optional) are set to -1.0 by the fold's first workgroup: the arrival slots of the late-fold optimizer launch
 int dra_fc_bwd_fused_sq(const float* dq, const float* h4, const float* dh4, const float* x3, const float* w4, float* dwh,
                         float* dbh, float* dw4, float* db4, float* dx3, int batch, int n_actions, int in_features, int act,
                         int variant, double* sq_partials, int* n_sq_partials, void* stream);
 int dra_conv_bwd_fused_fold(int layer, const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
                             int64_t slab_stride, float* dx, int batch, int act, int variant, const dra_fold_seg* fold,
-                            float* grad, double* fold_partials, int* n_fold_partials, unsigned* zero_flag, void* stream);
+                            float* grad, double* fold_partials, int* n_fold_partials, double* reset_slots, int n_reset,
+                            void* stream);
 int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, float* dw_slabs, float* db_slabs, int64_t slab_stride,
                          int batch, double u8_coef, int variant, const dra_fold_seg* fold, float* grad, double* fold_partials,
-                         int* n_fold_partials, unsigned* zero_flag, void* stream);
+                         int* n_fold_partials, double* reset_slots, int n_reset, void* stream);

@@ -52,10 +52,20 @@ using WA1f = ConvWgradAcc<G1, 4, 1, 1, 88, 0, false>;
 using WA2 = ConvWgradAcc<G2, 9, 2, 1, 24, 4, false>;
 using WA3 = ConvWgradAcc<G3, 7, 2, 1, 10, 1, false>;
 
+// layers DRA_VAR_WGRAD_ACC applies to (bit 0 = conv1 ... bit 2 = conv3; DRA_WGRAD_ACC_LAYERS in the environment, read once)
+static int wgrad_acc_layers() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_WGRAD_ACC_LAYERS"); v = e ? (atoi(e) & 7) : 7; }
+  return v;
+}
+static bool wgrad_acc(int variant, int layer) {
+  return (variant & DRA_VAR_WGRAD_ACC) && ((wgrad_acc_layers() >> (layer - 1)) & 1);
+}
+
 DRA_API int dra_conv_wgrad_slabs(int layer, int batch, int ksplit, int variant, int* n_slabs) {
-  if (!n_slabs || batch < 1 || ksplit < 1) return DRA_EINVAL;
+  if (!n_slabs || batch < 1 || ksplit < 1 || layer < 1 || layer > 3) return DRA_EINVAL;
   if (!(variant & DRA_VAR_ONESHOT_WGRAD)) { *n_slabs = ksplit; return DRA_OK; }
-  if (variant & DRA_VAR_WGRAD_ACC) {
+  if (wgrad_acc(variant, layer)) {
     switch (layer) {
       case 1: *n_slabs = WA1u::n_slabs(batch); return DRA_OK;
       case 2: *n_slabs = WA2::n_slabs(batch); return DRA_OK;
@@ -172,7 +182,7 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
   NoRole none;
   switch (layer) {
     case 1:
-      if ((variant & DRA_VAR_ONESHOT_WGRAD) && (variant & DRA_VAR_WGRAD_ACC)) {
+      if ((variant & DRA_VAR_ONESHOT_WGRAD) && wgrad_acc(variant, 1)) {
         if (x_is_u8) {
           auto rw = make_wgrad_one<WA1u>(dy, x, dw, db, slab_stride, batch, u8_coef);
           return launch_multi(rw, rw.blocks(), none, 0, none, 0, st);
@@ -190,10 +200,10 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
       }
       return dra_conv_bwd_w_koc(1, dy, x, dw, db, slab_stride, ksplit, batch, x_is_u8, u8_coef, stream);
     case 2:
-      if (variant & DRA_VAR_WGRAD_ACC) return conv_bwd_fused_t<G2, WA2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+      if (wgrad_acc(variant, 2)) return conv_bwd_fused_t<G2, WA2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
       return conv_bwd_fused_t<G2, WG2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
     case 3:
-      if (variant & DRA_VAR_WGRAD_ACC) return conv_bwd_fused_t<G3, WA3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+      if (wgrad_acc(variant, 3)) return conv_bwd_fused_t<G3, WA3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
       if (wg3_wide()) return conv_bwd_fused_t<G3, WG3b>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
       return conv_bwd_fused_t<G3, WG3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
   }
@@ -206,7 +216,7 @@ int dra_conv1_wgrad_ringbatch(const float* dy, const void* frames, const int64_t
                               int64_t slab_stride, int batch, double u8_coef, int variant, void* stream) {
   if (!dy || !frames || !idx || !dw_slabs || !db_slabs || batch < 1 || !(variant & DRA_VAR_ONESHOT_WGRAD)) return DRA_EINVAL;
   NoRole none;
-  if (variant & DRA_VAR_WGRAD_ACC) {
+  if (wgrad_acc(variant, 1)) {
     auto ra = make_wgrad_one<WA1u>(dy, frames, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
     ra.sample_idx = idx;
     return launch_multi(ra, ra.blocks(), none, 0, none, 0, dra_stream(stream));
@@ -218,27 +228,31 @@ int dra_conv1_wgrad_ringbatch(const float* dy, const void* frames, const int64_t
 
 // DRA_VAR_LATE_FOLD (library-internal, actor_env.h): the same launches with a FoldRole riding along -- `fold` describes the
 // segment of the flat gradient `grad` whose slabs the PREVIOUS backward launch wrote; its workgroups' sums of squares go to
-// fold_partials[0, *n_fold_partials); zero_flag (optional) is reset by the fold's first workgroup.
-static FoldRole make_fold_role(const dra_fold_seg* fold, float* grad, double* partials, unsigned* zero_flag) {
+// fold_partials[0, *n_fold_partials); reset_slots[0, n_reset) (optional) are set to -1.0 by the fold's first workgroup (the
+// arrival slots of the late-fold optimizer launch, dra_clip_step_late).  At most 32 slabs.
+static FoldRole make_fold_role(const dra_fold_seg* fold, float* grad, double* partials, double* reset_slots, int n_reset) {
   FoldRole f;
   f.grad = grad; f.slabs = fold->slabs; f.begin4 = fold->begin >> 2; f.count4 = fold->count >> 2;
-  f.stride4 = fold->slab_stride >> 2; f.n_slabs = fold->n_slabs; f.partials = partials; f.zero_flag = zero_flag;
+  f.stride4 = fold->slab_stride >> 2; f.n_slabs = fold->n_slabs; f.partials = partials;
+  f.reset_slots = reset_slots; f.n_reset = reset_slots ? n_reset : 0;
   return f;
 }
 static bool fold_ok(const dra_fold_seg* fold, const float* grad, const double* partials) {
-  return fold && grad && partials && fold->slabs && fold->n_slabs >= 1 && fold->count >= 4 && !(fold->begin & 3) &&
+  return fold && grad && partials && fold->slabs && fold->n_slabs >= 1 && fold->n_slabs <= FoldRole::NG * FoldRole::SPT &&
+         fold->count >= 4 && !(fold->begin & 3) &&
          !(fold->count & 3) && !(fold->slab_stride & 3) && !((((uintptr_t)fold->slabs) | ((uintptr_t)grad)) & 15);
 }
 
 int dra_conv_bwd_fused_fold(int layer, const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
                             int64_t slab_stride, float* dx, int batch, int act, int variant, const dra_fold_seg* fold,
-                            float* grad, double* fold_partials, int* n_fold_partials, unsigned* zero_flag, void* stream) {
+                            float* grad, double* fold_partials, int* n_fold_partials, double* reset_slots, int n_reset,
+                            void* stream) {
   if (!dy || !x || !wt || !dx || !dw || !db || batch < 1 || !n_fold_partials || !fold_ok(fold, grad, fold_partials)) return DRA_EINVAL;
   if (!(variant & DRA_VAR_ONESHOT_WGRAD) || !(variant & DRA_VAR_ONESHOT_DGRAD)) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
-  const FoldRole f = make_fold_role(fold, grad, fold_partials, zero_flag);
+  const FoldRole f = make_fold_role(fold, grad, fold_partials, reset_slots, n_reset);
   *n_fold_partials = f.blocks();
-  const bool acc = variant & DRA_VAR_WGRAD_ACC;
+  const bool acc = wgrad_acc(variant, layer);
   if (layer == 2) {
     if (acc) return conv_bwd_fused_t<G2, WA2, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
     return conv_bwd_fused_t<G2, WG2, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
@@ -254,14 +268,14 @@ int dra_conv_bwd_fused_fold(int layer, const float* dy, const void* x, const flo
 // through the sampled slots) with a FoldRole riding along
 int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, float* dw_slabs, float* db_slabs, int64_t slab_stride,
                          int batch, double u8_coef, int variant, const dra_fold_seg* fold, float* grad, double* fold_partials,
-                         int* n_fold_partials, unsigned* zero_flag, void* stream) {
+                         int* n_fold_partials, double* reset_slots, int n_reset, void* stream) {
   if (!dy || !x || !dw_slabs || !db_slabs || batch < 1 || !(variant & DRA_VAR_ONESHOT_WGRAD) || !n_fold_partials ||
       !fold_ok(fold, grad, fold_partials))
     return DRA_EINVAL;
-  const FoldRole f = make_fold_role(fold, grad, fold_partials, zero_flag);
+  const FoldRole f = make_fold_role(fold, grad, fold_partials, reset_slots, n_reset);
   *n_fold_partials = f.blocks();
   NoRole none;
-  if (variant & DRA_VAR_WGRAD_ACC) {
+  if (wgrad_acc(variant, 1)) {
     auto ra = make_wgrad_one<WA1u>(dy, x, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
     ra.sample_idx = idx;
     return launch_multi(ra, ra.blocks(), f, f.blocks(), none, 0, dra_stream(stream));

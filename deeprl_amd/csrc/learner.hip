@@ -186,8 +186,8 @@ struct dra_dqn_learner {
   // DRA_VAR_LATE_FOLD: no gradient-norm launch (optim.hip late_step_kernel): sums of squares from the producing kernels,
   // conv3 / conv2 folds riding in the next backward launch, conv1's fold in front of the optimizer launch
   bool late;
-  unsigned* late_flag;              // device: fold workgroups of the optimizer launch that have published (reset per update)
   int late_nprior;                  // partials written before the optimizer launch
+  int late_nfold;                   // fold workgroups of the optimizer launch (their partial slots double as arrival flags)
   bool coop;                        // decided once, before the first graph capture
   bool captured;                    // some graph has been captured (the decision above is baked into it)
 };
@@ -346,14 +346,17 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   }
   l->n_partials = 2 * dra_norm_partials();
   if ((l->variant & DRA_VAR_LATE_FOLD) && (l->variant & DRA_VAR_ONESHOT_WGRAD) && (l->variant & DRA_VAR_ONESHOT_DGRAD) &&
-      (l->variant & DRA_VAR_FUSED_BWD) && !rc && cfg->offset[P_W1] == 0 && l->lnslabs[0] <= 64) {
-    // partials: fc4 tiles (64 x 64 over [512][3137]) + head workgroups + one per 1024 folded floats of conv3 / conv2 + one per
-    // 256 of conv1
-    const int64_t np = 8 * 50 + 2 * NO + (l->lstride[2] / 4 + 255) / 256 + (l->lstride[1] / 4 + 255) / 256 + (l->lstride[0] / 4 + 63) / 64;
-    l->late = np <= dra_norm_partials_max();
+      (l->variant & DRA_VAR_FUSED_BWD) && !rc && cfg->offset[P_W1] == 0 && l->lnslabs[1] <= 32 && l->lnslabs[2] <= 32) {
+    // partials: fc4 tiles (64 x 64 over [512][3137]) + head workgroups + one per 256 folded floats of conv3 / conv2 + conv1's
+    // fold workgroups in the optimizer launch
+    dra_fold_seg s0;
+    memset(&s0, 0, sizeof(s0));
+    s0.begin = 0; s0.count = l->lstride[0]; s0.slabs = l->lslabs[0]; s0.slab_stride = l->lstride[0]; s0.n_slabs = l->lnslabs[0];
+    if (dra_clip_step_late_blocks(&s0, &l->late_nfold) == DRA_OK) {
+      const int64_t np = 8 * 50 + 2 * NO + (l->lstride[2] / 4 + 63) / 64 + (l->lstride[1] / 4 + 63) / 64 + l->late_nfold;
+      l->late = np <= dra_norm_partials_max();
+    }
   }
-  rc |= (int)hipMalloc(&l->late_flag, sizeof(unsigned));
-  if (!rc) rc |= (int)hipMemset(l->late_flag, 0, sizeof(unsigned));
   rc |= alloc_f(&l->ah4, 512);
   if (l->variant & DRA_VAR_ACTOR_PARAMS) { rc |= alloc_f(&l->pa[0], cfg->n_params); rc |= alloc_f(&l->pa[1], cfg->n_params); }
   if ((l->variant & DRA_VAR_ACTOR_PARAMS) && (l->variant & DRA_VAR_GATHER_ON_UPDATE)) {
@@ -491,7 +494,6 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (l->rd_seq_dev) (void)hipFree(l->rd_seq_dev);
   if (l->sp_stage) (void)hipHostFree(l->sp_stage);
   for (int k = 0; k < 8; ++k) if (l->sp_ev[k]) (void)hipEventDestroy(l->sp_ev[k]);
-  if (l->late_flag) (void)hipFree(l->late_flag);
   if (l->coop_ctr) (void)hipFree(l->coop_ctr);
   if (l->coop_flag) (void)hipHostFree(l->coop_flag);
   if (l->qs_stage) (void)hipHostFree(l->qs_stage);
@@ -891,7 +893,7 @@ static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = 
     conv_fold_segs(l, segs);
     const bool adam = c.optimizer == DRA_OPT_ADAM;
     const float hyper[4] = {c.lr, adam ? c.beta1 : c.alpha, c.eps, adam ? c.beta2 : 0.f};
-    return dra_clip_step_late(l->p, l->g, l->s1, l->s2, c.n_params, &segs[0], l->partials, l->late_nprior, l->late_flag,
+    return dra_clip_step_late(l->p, l->g, l->s1, l->s2, c.n_params, &segs[0], l->partials, l->late_nprior,
                               l->coop_flag, c.optimizer, c.gradient_clip, hyper, c.centered, l->opt_step, l->norm, p_copy,
                               (void*)st);
   }
@@ -1127,6 +1129,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       dra_fold_seg segs[3];
       conv_fold_segs(l, segs);
       int nfc = 0, n3 = 0, n2 = 0;
+      const int nfc_expect = 8 * 50 + 2 * NO, n3_expect = (int)((l->lstride[2] / 4 + 63) / 64), n2_expect = (int)((l->lstride[1] / 4 + 63) / 64);
       STEP(K_FC4_BX, dra_fc_bwd_fused_sq(l->dq, l->h4, l->dh4, l->y3[0], P + o[P_W4], G + o[P_WH], G + o[P_BH], G + o[P_W4],
                                          G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, l->partials, &nfc, s));
       if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV3_BW], st));
@@ -1134,10 +1137,12 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
                                           l->dy2, B, 0, 1.0, DRA_ACT_RELU, var, s));
       if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV2_BW], st));
       STEP(K_CONV2_BX, dra_conv_bwd_fused_fold(2, l->dy2, l->y1[0], P + o[P_W2], l->y1[0], dw[1], dbs[1], stride[1], l->dy1, B,
-                                               DRA_ACT_RELU, var, &segs[2], G, l->partials + nfc, &n3, nullptr, s));
+                                               DRA_ACT_RELU, var, &segs[2], G, l->partials + nfc, &n3, nullptr, 0, s));
+      // (the fold riding in conv1's launch also resets the arrival slots of the optimizer launch that follows)
       STEP(K_CONV1_BW, dra_conv1_wgrad_fold(l->dy1, rd ? ring_frames : (const void*)l->state_[l->gb], rd ? l->idx : nullptr, dw[0],
                                             dbs[0], stride[0], B, c.u8_coef, var, &segs[1], G, l->partials + nfc + n3, &n2,
-                                            l->late_flag, s));
+                                            l->partials + nfc_expect + n3_expect + n2_expect, l->late_nfold, s));
+      if (nfc != nfc_expect || n3 != n3_expect || n2 != n2_expect) return DRA_EINVAL;
       l->late_nprior = nfc + n3 + n2;
       if (l->profiling) { DRA_HIP(hipEventRecord(l->ev[K_NORM], st)); DRA_HIP(hipEventRecord(l->ev[K_STEP], st)); }
       return DRA_OK;

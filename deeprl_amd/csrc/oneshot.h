@@ -140,42 +140,57 @@ struct HeadWgradRole {
 // ------------------------------------------------------------------------------------------------
 // Slab fold as a ROLE (DRA_VAR_LATE_FOLD): grad[begin + i] = sum_s slabs[s * stride + i] in slab order, for a layer whose
 // weight-gradient slabs were written by the PREVIOUS launch, riding in the spare workgroup slots of the next layer's
-// backward launch instead of a norm pass on the update's dependent chain.  One float4 per thread (256 per workgroup),
-// all slabs of an element in flight at once (<= 8 per pass); the workgroup's sum of squares goes to partials[bid].
+// backward launch instead of a norm pass on the update's dependent chain.  64 float4 per workgroup: thread (g, el) adds
+// slabs g, g + 4, ... (<= 8 each: every load of the workgroup in flight at once, one memory round trip), the four group
+// sums meet in LDS and are added in group order; the workgroup's sum of squares goes to partials[bid].
 struct FoldRole {
-  static constexpr int LDS_FLOATS = 8;
+  static constexpr int NG = 4, EPB = 64, SPT = 8;      // n_slabs <= NG * SPT = 32
+  static constexpr int LDS_FLOATS = NG * (EPB + 1) * 4;
   float* grad;            // flat gradient
   const float* slabs;     // [n_slabs][stride]
   int64_t begin4, count4, stride4;
   int n_slabs;
   double* partials;       // [blocks()]
-  unsigned* zero_flag = nullptr;   // optional: workgroup 0 resets this counter (the late-fold optimizer launch's arrival count)
-  __host__ int blocks() const { return (int)((count4 + 255) / 256); }
+  // optional: workgroup 0 resets these slots to -1.0 (the arrival slots of the late-fold optimizer launch that follows)
+  double* reset_slots = nullptr;
+  int n_reset = 0;
+  __host__ int blocks() const { return (int)((count4 + EPB - 1) / EPB); }
   __device__ __forceinline__ void run(int bid, float* lds) const {
-    const int tid = threadIdx.x;
-    if (zero_flag && bid == 0 && tid == 0) __hip_atomic_store(zero_flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int64_t i = (int64_t)bid * 256 + tid;
+    const int tid = threadIdx.x, g = tid >> 6, el = tid & 63;
+    if (reset_slots && bid == 0)
+      for (int i = tid; i < n_reset; i += 256) __hip_atomic_store(reset_slots + i, -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t i = (int64_t)bid * EPB + el;
     const int64_t ic = i < count4 ? i : count4 - 1;
     const float4* __restrict__ sl = reinterpret_cast<const float4*>(slabs) + ic;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = 0; s0 < n_slabs; s0 += 8) {
-      float4 t[8];
+    float4 t[SPT];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = sl[(int64_t)(s0 + u < n_slabs ? s0 + u : s0) * stride4];
+    for (int u = 0; u < SPT; ++u) {
+      const int s = g + NG * u;
+      t[u] = sl[(int64_t)(s < n_slabs ? s : 0) * stride4];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (s0 + u < n_slabs) { r.x += t[u].x; r.y += t[u].y; r.z += t[u].z; r.w += t[u].w; }
-    }
-    float sq = 0.f;
-    if (i < count4) {
-      reinterpret_cast<float4*>(grad)[begin4 + i] = r;
-      sq = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
-    }
-    const double d = wave_sum((double)sq);
-    double* dl = reinterpret_cast<double*>(lds);
-    if ((tid & 63) == 0) dl[tid >> 6] = d;
+    for (int u = 0; u < SPT; ++u)
+      if (g + NG * u < n_slabs) { pp.x += t[u].x; pp.y += t[u].y; pp.z += t[u].z; pp.w += t[u].w; }
+    float4* sf = reinterpret_cast<float4*>(lds);
+    sf[g * (EPB + 1) + el] = pp;
     __syncthreads();
-    if (tid == 0) partials[bid] = (dl[0] + dl[1]) + (dl[2] + dl[3]);
+    float sq = 0.f;
+    if (tid < EPB) {
+      float4 r = sf[el];
+#pragma unroll
+      for (int q = 1; q < NG; ++q) {
+        const float4 o = sf[q * (EPB + 1) + el];
+        r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+      }
+      if (i < count4) {
+        reinterpret_cast<float4*>(grad)[begin4 + i] = r;
+        sq = r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w;
+      }
+    }
+    const double d = wave_sum((double)sq);     // the owners are wave 0
+    if (tid == 0) partials[bid] = d;
   }
 };
 

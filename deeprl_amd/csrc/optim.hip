@@ -492,14 +492,18 @@ DRA_API int dra_clip_step_coop(float* param, float* grad, float* state1, float* 
 // clipped.  With this form every tensor's sum of squares already exists when the optimizer starts -- the linear layers'
 // from the kernels that wrote them (igemm_sumsq, HeadWgradRole), conv3 / conv2 from FoldRole workgroups riding in the next
 // layer's backward launch -- EXCEPT the first segment (conv1, whose weight gradient is the last kernel of the backward).
-// Its fold_blocks workgroups come first in the grid: they fold their 64 float4 each (4 slab groups x 64 elements, thread
-// (g, el) adds slabs g, g+4, ... in order, the groups meet in LDS as (g0 + g1) + (g2 + g3)), publish their partial with an
-// agent-scope store and count themselves on *flag.  EVERY workgroup requests its parameters / optimizer state / gradient
-// first, then waits until *flag == fold_blocks (one agent-scope load per poll by one thread; ~33 arrivals instead of the
-// cooperative form's 796 tickets, which serialised at ~30 ns each: profiles/r02zt_*), reduces all partials in the fixed
-// order and applies the step.  Progress: the fold workgroups have the lowest block indices, so they are resident before
-// any waiting workgroup; a wait is bounded (50 ms) and reports through the pinned timeout flag like the cooperative form.
-// *flag must be zero at launch (FoldRole::zero_flag resets it in the preceding launch).
+// Its fold_blocks workgroups come first in the grid.  A fold workgroup owns EPB float4 elements: thread (g, el) adds slabs
+// g, g + NG, ... in order (every load in flight at once), the NG group sums meet in LDS and are added in group order;
+// (EPB, NG) = (64, 4) for <= 64 slabs, (16, 16) for <= 256.  Its sum of squares is PUBLISHED AS THE FLAG: slot
+// partials[n_prior + b] holds -1 until the workgroup's one agent-scope store of a (non-negative) sum lands -- no ticket
+// counter, no second round trip (the cooperative form's 796 tickets on one counter serialised at ~30 ns each,
+// profiles/r02zt_*; round 3's first attempt published + counted, and read ALL partials with agent-scope loads: 19.4 us
+// against RMSprop's 12.5, profiles/r03a_*).  EVERY workgroup requests its parameters / optimizer state / gradient and
+// the earlier launches' partials (plain cached loads) first; thread t < fold_blocks then polls slot t until it is
+// non-negative, the partials are reduced in the fixed order and the step is applied.  Progress: the fold workgroups have
+// the lowest block indices, so they are resident before any waiting workgroup; a wait is bounded (50 ms) and reports
+// through the pinned timeout flag like the cooperative form.  The slots must hold -1 at launch (FoldRole::reset_slots in
+// the preceding launch).
 struct LatePlan {
   int64_t n;             // floats in the flat buffers (a tail of n % 4 floats is stepped by the last workgroup)
   int64_t n4;            // whole float4s
@@ -508,15 +512,57 @@ struct LatePlan {
   int64_t stride4;
   int32_t n_slabs, fold_blocks, n_prior;   // n_prior: partials already written by earlier launches ([0, n_prior))
 };
-constexpr int kLateSlabsPerThread = 16;    // n_slabs <= 64
+constexpr int kLateSlabsPerThread = 16;    // n_slabs <= 64 (4 groups) / 256 (16 groups)
+constexpr int kLateMaxFoldBlocks = 256;    // one polling thread per fold workgroup
 
-template <int OPT>   // 0 = RMSprop, 1 = Adam
+// fixed-order reduction: thread t sums prior partials t, t + 256, ... (plain loads, requested by the caller BEFORE the wait:
+// `pre`), then the fold workgroups' published sums (thread t < fold_blocks waits for slot t); lanes by butterfly, waves
+// (w0 + w1) + (w2 + w3).
+__device__ __forceinline__ float late_clip_coef(double pre, double* __restrict__ partials, int n_prior, int fold_blocks,
+                                                float max_norm, float* __restrict__ out_norm, int* __restrict__ timeout_flag) {
+  __shared__ double s_part[4];
+  __shared__ float s_coef;
+  double d = pre;
+  if ((int)threadIdx.x < fold_blocks) {
+    const double* slot = partials + n_prior + threadIdx.x;
+    double v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v < 0.0) {
+      const unsigned long long t0 = wall_clock64();
+      do {
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wall_clock64() - t0 > kBarrierTicks) {
+          __hip_atomic_store(timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          v = 0.0;
+        }
+      } while (v < 0.0);
+    }
+    d += v;
+  }
+  d = wave_sum(d);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+    if (out_norm && blockIdx.x == 0) *out_norm = norm;
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+      coef = max_norm / (norm + 1e-6f);
+      if (coef > 1.f) coef = 1.f;
+    }
+    s_coef = coef;
+  }
+  __syncthreads();
+  return s_coef;
+}
+
+template <int OPT, int NG>   // OPT: 0 = RMSprop, 1 = Adam;  NG: slab groups of a fold workgroup (4 or 16)
 __global__ void __launch_bounds__(256)
 late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict__ partials, float* __restrict__ p,
                  float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ p_copy, const StepHyper hp,
-                 float* __restrict__ out_norm, unsigned* __restrict__ flag, int* __restrict__ timeout_flag) {
-  __shared__ float4 s_part[4][64];
-  __shared__ double s_red[4];
+                 float* __restrict__ out_norm, int* __restrict__ timeout_flag) {
+  constexpr int EPB = 256 / NG;            // float4 elements per fold workgroup
+  __shared__ float4 s_fold[NG][EPB + 1];
   __shared__ float s_hyper[2];
   const int tid = threadIdx.x, bid = blockIdx.x;
   float4* __restrict__ g4 = reinterpret_cast<float4*>(grad);
@@ -528,31 +574,37 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
 #pragma unroll
   for (int v = 0; v < kStepNV; ++v) gi[v] = -1;
   DRA_STAMP(TR_STEP, 0);
+  // the earlier launches' partials: plain loads, in flight with everything else (16 per thread covers dra_norm_partials_max)
+  double pv[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int i = tid + 256 * u;
+    pv[u] = partials[i < lp.n_prior ? i : (lp.n_prior > 0 ? lp.n_prior - 1 : 0)];
+  }
   if (bid < lp.fold_blocks) {
-    const int g = tid >> 6, el = tid & 63;
-    const int64_t i = (int64_t)bid * 64 + el;
+    const int g = tid / EPB, el = tid % EPB;
+    const int64_t i = (int64_t)bid * EPB + el;
     const int64_t ic = i < lp.fold_count4 ? i : lp.fold_count4 - 1;
-    if (tid < 64) { P[0] = p4[ic]; S[0] = s14[ic]; A[0] = s24[ic]; }
+    if (tid < EPB) { P[0] = p4[ic]; S[0] = s14[ic]; A[0] = s24[ic]; }
     const int ns = lp.n_slabs;
     float4 t[kLateSlabsPerThread];
 #pragma unroll
     for (int u = 0; u < kLateSlabsPerThread; ++u) {
-      const int s = g + 4 * u;
+      const int s = g + NG * u;
       t[u] = lp.slabs[(int64_t)(s < ns ? s : 0) * lp.stride4 + ic];
     }
     __builtin_amdgcn_sched_barrier(0);
     float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < kLateSlabsPerThread; ++u)
-      if (g + 4 * u < ns) add4(pp, t[u]);
-    s_part[g][el] = pp;
+      if (g + NG * u < ns) add4(pp, t[u]);
+    s_fold[g][el] = pp;
     __syncthreads();
     float acc = 0.f;
-    if (tid < 64) {
-      float4 a = s_part[0][el], b = s_part[2][el];
-      add4(a, s_part[1][el]);
-      add4(b, s_part[3][el]);
-      add4(a, b);
+    if (tid < EPB) {
+      float4 a = s_fold[0][el];
+#pragma unroll
+      for (int q = 1; q < NG; ++q) add4(a, s_fold[q][el]);
       if (i < lp.fold_count4) {
         g4[i] = a;
         acc = sq4(a);
@@ -560,12 +612,9 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
         gi[0] = i;
       }
     }
-    const double d = wave_sum((double)acc);   // (waves 1-3 hold zeros)
-    if (tid == 0) {
-      __hip_atomic_store(partials + lp.n_prior + bid, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // (EPB <= 64: the owners are lanes of wave 0; the other waves hold zeros)
+    const double d = wave_sum((double)acc);
+    if (tid == 0) __hip_atomic_store(partials + lp.n_prior + bid, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     const int64_t i0 = lp.fold_count4 + (int64_t)(bid - lp.fold_blocks) * (256 * kStepNV) + tid;
 #pragma unroll
@@ -583,20 +632,11 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
     s_hyper[0] = (float)((double)hp.lr / bc1);
     s_hyper[1] = (float)(1.0 / sqrt(bc2));
   }
-  if (tid == 0) {
-    const unsigned target = (unsigned)lp.fold_blocks;
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > kBarrierTicks) {
-        __hip_atomic_store(timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-    }
-  }
-  __syncthreads();
+  double pre = 0.0;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) pre += (tid + 256 * u < lp.n_prior) ? pv[u] : 0.0;
   DRA_STAMP(TR_STEP, 2);
-  const float coef = clip_coef_coherent(partials, lp.n_prior + lp.fold_blocks, hp.max_norm, out_norm);
+  const float coef = late_clip_coef(pre, partials, lp.n_prior, lp.fold_blocks, hp.max_norm, out_norm, timeout_flag);
   [[maybe_unused]] const float oma = 1.f - hp.a, omb2 = 1.f - hp.b2;
   [[maybe_unused]] const float step_size = s_hyper[0], inv_sqrt_bc2 = s_hyper[1];
 #pragma unroll
@@ -623,17 +663,17 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
   // tail (n not a multiple of 4): the last few floats, by the first threads of the last workgroup
   const int64_t tl = (lp.n4 << 2) + tid;
   if (bid == (int)gridDim.x - 1 && tl < lp.n) {
-    float pv = p[tl], sv = s1[tl], av = (OPT == 1 || hp.centered) ? s2[tl] : 0.f;
+    float pv1 = p[tl], sv = s1[tl], av = (OPT == 1 || hp.centered) ? s2[tl] : 0.f;
     if (OPT == 0) {
-      rmsprop_elem(pv, grad[tl], sv, av, coef, hp.a, oma, hp.lr, hp.eps, hp.centered);
+      rmsprop_elem(pv1, grad[tl], sv, av, coef, hp.a, oma, hp.lr, hp.eps, hp.centered);
     } else {
       const float gk = grad[tl] * coef;
       sv = sv * hp.a + oma * gk;
       av = av * hp.b2 + omb2 * gk * gk;
-      pv = pv - step_size * (sv / (sqrtf(av) * inv_sqrt_bc2 + hp.eps));
+      pv1 = pv1 - step_size * (sv / (sqrtf(av) * inv_sqrt_bc2 + hp.eps));
     }
-    p[tl] = pv;
-    if (p_copy) p_copy[tl] = pv;
+    p[tl] = pv1;
+    if (p_copy) p_copy[tl] = pv1;
     s1[tl] = sv;
     if (OPT == 1 || hp.centered) s2[tl] = av;
   }
@@ -641,34 +681,41 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
   DRA_STAMP_END(TR_STEP);
 }
 
-// Workgroups of the late-fold launch that fold (and publish a partial): ceil(seg->count / 256 floats).
+static int late_groups(int n_slabs) { return n_slabs <= 4 * kLateSlabsPerThread ? 4 : 16; }
+
+// Workgroups of the late-fold launch that fold (and publish a partial): 64 float4 each for <= 64 slabs, 16 for <= 256.
 DRA_API int dra_clip_step_late_blocks(const dra_fold_seg* seg, int* fold_blocks) {
-  if (!seg || !fold_blocks || seg->count < 4 || (seg->count & 3)) return DRA_EINVAL;
-  *fold_blocks = (int)(((seg->count >> 2) + 63) / 64);
+  if (!seg || !fold_blocks || seg->count < 4 || (seg->count & 3) || seg->n_slabs < 1 || seg->n_slabs > 16 * kLateSlabsPerThread)
+    return DRA_EINVAL;
+  const int epb = 256 / late_groups(seg->n_slabs);
+  const int64_t nb = ((seg->count >> 2) + epb - 1) / epb;
+  if (nb > kLateMaxFoldBlocks) return DRA_EINVAL;
+  *fold_blocks = (int)nb;
   return DRA_OK;
 }
 
-// seg: the ONE segment still in slabs (must start at element 0 of the flat gradient, n_slabs <= 64); partials[0, n_prior)
-// were written by earlier launches, this launch adds dra_clip_step_late_blocks() more behind them; flag: zeroed uint32 in
-// device memory (reset before every launch); timeout_flag: pinned host int.  hyper / optimizer as dra_clip_step_coop.
+// seg: the ONE segment still in slabs (must start at element 0 of the flat gradient, n_slabs <= 256, at most 256 fold
+// workgroups); partials[0, n_prior) were written by earlier launches, partials[n_prior, n_prior + fold_blocks) must hold -1.0
+// at launch and receive this launch's published sums; timeout_flag: pinned host int.  hyper / optimizer as dra_clip_step_coop.
 DRA_API int dra_clip_step_late(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* seg,
-                               double* partials, int n_prior, unsigned* flag, int* timeout_flag, int optimizer, float max_norm,
+                               double* partials, int n_prior, int* timeout_flag, int optimizer, float max_norm,
                                const float* hyper, int centered, const int64_t* step_dev, float* out_norm, float* param_copy,
                                void* stream) {
-  if (!param || !grad || !state1 || !seg || !partials || !flag || !timeout_flag || !hyper) return DRA_EINVAL;
+  if (!param || !grad || !state1 || !seg || !partials || !timeout_flag || !hyper) return DRA_EINVAL;
   if (optimizer != DRA_OPT_RMSPROP && optimizer != DRA_OPT_ADAM) return DRA_EINVAL;
   if ((optimizer == DRA_OPT_ADAM && (!state2 || !step_dev)) || (optimizer == DRA_OPT_RMSPROP && centered && !state2)) return DRA_EINVAL;
   if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)state1) | ((uintptr_t)state2) | ((uintptr_t)param_copy) |
        ((uintptr_t)seg->slabs)) & 15)
     return DRA_EINVAL;
-  if (n < 4 || seg->begin != 0 || seg->count < 4 || (seg->count & 3) || seg->count > n || !seg->slabs ||
-      seg->n_slabs < 1 || seg->n_slabs > 4 * kLateSlabsPerThread || (seg->slab_stride & 3) || n_prior < 0)
-    return DRA_EINVAL;
+  if (n < 4 || seg->begin != 0 || seg->count > n || !seg->slabs || (seg->slab_stride & 3) || n_prior < 0) return DRA_EINVAL;
+  int fold_blocks = 0;
+  int rc = dra_clip_step_late_blocks(seg, &fold_blocks);
+  if (rc) return rc;
   LatePlan lp;
   memset(&lp, 0, sizeof(lp));
   lp.n = n; lp.n4 = n >> 2; lp.fold_count4 = seg->count >> 2; lp.slabs = reinterpret_cast<const float4*>(seg->slabs);
   lp.stride4 = seg->slab_stride >> 2; lp.n_slabs = seg->n_slabs; lp.n_prior = n_prior;
-  lp.fold_blocks = (int)((lp.fold_count4 + 63) / 64);
+  lp.fold_blocks = fold_blocks;
   if (lp.n_prior + lp.fold_blocks > dra_norm_partials_max()) return DRA_EINVAL;
   const int64_t plain = (lp.n4 - lp.fold_count4 + 256 * kStepNV - 1) / (256 * kStepNV);
   const int64_t blocks = lp.fold_blocks + plain;
@@ -677,12 +724,13 @@ DRA_API int dra_clip_step_late(float* param, float* grad, float* state1, float* 
   memset(&hp, 0, sizeof(hp));
   hp.max_norm = max_norm; hp.lr = hyper[0]; hp.a = hyper[1]; hp.eps = hyper[2]; hp.b2 = hyper[3];
   hp.centered = centered; hp.step_dev = step_dev;
-  if (optimizer == DRA_OPT_ADAM)
-    hipLaunchKernelGGL(late_step_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, dra_stream(stream), grad, lp, partials, param,
-                       state1, state2, param_copy, hp, out_norm, flag, timeout_flag);
-  else
-    hipLaunchKernelGGL(late_step_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, dra_stream(stream), grad, lp, partials, param,
-                       state1, state2, param_copy, hp, out_norm, flag, timeout_flag);
+  const bool adam = optimizer == DRA_OPT_ADAM, wide = late_groups(seg->n_slabs) == 16;
+#define DRA_LATE_LAUNCH(OPT, NG)                                                                                          \
+  hipLaunchKernelGGL((late_step_kernel<OPT, NG>), dim3((unsigned)blocks), dim3(256), 0, dra_stream(stream), grad, lp, partials, \
+                     param, state1, state2, param_copy, hp, out_norm, timeout_flag)
+  if (adam) { if (wide) DRA_LATE_LAUNCH(1, 16); else DRA_LATE_LAUNCH(1, 4); }
+  else { if (wide) DRA_LATE_LAUNCH(0, 16); else DRA_LATE_LAUNCH(0, 4); }
+#undef DRA_LATE_LAUNCH
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

@@ -143,7 +143,13 @@ class DataParallel:
         self.world, self.rank = world(), rank()
         self.active = self.world > 1 and getattr(config, "data_parallel", True) is not False
         self.invariant_sampling = self.active or bool(getattr(config, "dp_invariant_sampling", False))
+        # the GLOBAL environment count survives in config.global_num_workers: a second agent built from the same Config (an
+        # evaluation agent, a restart) shards the global count again instead of the already-sharded one
+        if self.active and getattr(config, "global_num_workers", None):
+            config.num_workers = config.global_num_workers
         self.global_workers = config.num_workers
+        if self.active:
+            config.global_num_workers = config.num_workers
         self.lo, self.hi = 0, config.num_workers
         self.comm = None
         self.rs = None
@@ -164,6 +170,32 @@ class DataParallel:
             self.rs = np.random.RandomState(self.noise_seed + 12345)
         config.env_shard = (self.lo, self.hi)
         self._gen = None
+
+    @property
+    def is_main(self):
+        """Rank that writes checkpoints / evaluation logs (every rank holds the same parameters)."""
+        return not self.active or self.rank == 0
+
+    def sync_state(self, *tensors):
+        """Rank 0's values of `tensors` (flat parameter buffer, optimizer state, module buffers) on every rank, in place.
+        Ranks launched with different seeds (python -m deeprl_amd.launch under torchrun seeds 1 + RANK so that exploration
+        differs) would otherwise build different initial weights and train G different replicas on one averaged gradient."""
+        if not self.active:
+            return
+        nccl = dist.get_backend() == "nccl"
+        for t in tensors:
+            if t is None:
+                continue
+            if t.is_cuda and not nccl:
+                h = t.detach().cpu()
+                dist.broadcast(h, 0)
+                t.data.copy_(h)
+            elif not t.is_cuda and nccl:
+                h = t.detach().cuda()
+                dist.broadcast(h, 0)
+                t.data.copy_(h.cpu())
+            else:
+                dist.broadcast(t.data, 0)
 
     def permutation(self, n):
         return self.rs.permutation(n) if self.rs is not None else np.random.permutation(n)

@@ -174,9 +174,113 @@ class DummyVecEnv:
 _WARNED = set()
 
 
+class _PassThrough:
+    """Wrapper base that forwards everything it does not define to the wrapped environment (so that gym.Wrapper subclasses
+    such as baselines' wrap_deepmind stack can sit on top of it: they read action_space / unwrapped / metadata ...)."""
+
+    def __init__(self, env):
+        self.env = env
+
+    def __getattr__(self, name):
+        if name == 'env':
+            raise AttributeError(name)
+        return getattr(self.env, name)
+
+    def reset(self, **kw):
+        return self.env.reset(**kw)
+
+    def step(self, action):
+        return self.env.step(action)
+
+
+class OriginalReturnWrapper(_PassThrough):
+    """envs.py:58-76: the return of the WHOLE game.  It sits directly on the seeded environment, UNDER wrap_deepmind, so
+    that EpisodicLifeEnv's per-life resets do not reset it; reset() does not clear the sum (only a real `done` does)."""
+
+    def __init__(self, env):
+        _PassThrough.__init__(self, env)
+        self.total_rewards = 0
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        self.total_rewards += reward
+        info = dict(info or {})
+        if done:
+            info['episodic_return'] = self.total_rewards
+            self.total_rewards = 0
+        else:
+            info['episodic_return'] = None
+        return obs, reward, done, info
+
+
+class TransposeImage(_PassThrough):
+    """envs.py:79-91: HWC -> CHW observations (and the observation space's shape)."""
+
+    def __init__(self, env):
+        _PassThrough.__init__(self, env)
+        sp = env.observation_space
+        shp = tuple(sp.shape)
+        lo = np.asarray(sp.low).reshape(-1)[0] if hasattr(sp, 'low') else 0
+        hi = np.asarray(sp.high).reshape(-1)[0] if hasattr(sp, 'high') else 255
+        self.observation_space = Box(lo, hi, (shp[2], shp[1], shp[0]))
+
+    def reset(self, **kw):
+        return np.asarray(self.env.reset(**kw)).transpose(2, 0, 1)
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        return np.asarray(obs).transpose(2, 0, 1), reward, done, info
+
+
+class FrameStack(_PassThrough):
+    """envs.py:116-123 over baselines' FrameStack: the last k observations as LazyFrames concatenated on AXIS 0 (k frames of
+    [1, 84, 84] -> [4, 84, 84]); reset() repeats the first observation k times."""
+
+    def __init__(self, env, k):
+        _PassThrough.__init__(self, env)
+        from collections import deque
+        self.k = k
+        self.frames = deque([], maxlen=k)
+        shp = tuple(env.observation_space.shape)
+        sp = env.observation_space
+        lo = np.asarray(sp.low).reshape(-1)[0] if hasattr(sp, 'low') else 0
+        hi = np.asarray(sp.high).reshape(-1)[0] if hasattr(sp, 'high') else 255
+        self.observation_space = Box(lo, hi, (shp[0] * k,) + shp[1:])
+
+    def _get_ob(self):
+        assert len(self.frames) == self.k
+        return LazyFrames(list(self.frames))
+
+    def reset(self, **kw):
+        ob = self.env.reset(**kw)
+        for _ in range(self.k):
+            self.frames.append(ob)
+        return self._get_ob()
+
+    def step(self, action):
+        ob, reward, done, info = self.env.step(action)
+        self.frames.append(ob)
+        return self._get_ob(), reward, done, info
+
+
+def wrap_like_reference(env, seed, rank, is_atari, wrap_deepmind=None, episode_life=True):
+    """make_env's wrapper stack (envs.py:39-53) around an already-constructed environment, in the reference's ORDER:
+    seed -> OriginalReturnWrapper -> [wrap_deepmind(episode_life, clip_rewards=False, frame_stack=False, scale=False) ->
+    TransposeImage (3-D observations) -> FrameStack(4)]."""
+    env.seed(seed + rank)
+    env = OriginalReturnWrapper(env)
+    if is_atari:
+        env = wrap_deepmind(env, episode_life=episode_life, clip_rewards=False, frame_stack=False, scale=False)
+        if len(env.observation_space.shape) == 3:
+            env = TransposeImage(env)
+        env = FrameStack(env, 4)
+    return env
+
+
 def _real_task_envs(name, num_envs, seed, episode_life):
     """The reference's path (envs.py:27-55: gym.make + baselines' Atari wrappers) when those third-party packages are
-    installed; None when they are not (this image: no gym, no baselines, no emulators)."""
+    installed; None when they are not (this image: no gym, no baselines, no emulators).  The wrapper stack itself is
+    wrap_like_reference (tested here against a stand-in emulator: tests/test_dropin_surface.py)."""
     try:
         import gym
     except ImportError:
@@ -184,45 +288,25 @@ def _real_task_envs(name, num_envs, seed, episode_life):
     if not getattr(gym, "__file__", None) or not hasattr(gym, "make"):   # a placeholder module, not an installation
         return None
     try:
-        from baselines.common.atari_wrappers import FrameStack, make_atari, wrap_deepmind
+        from baselines.common.atari_wrappers import make_atari, wrap_deepmind
     except ImportError:
-        make_atari = None
+        make_atari = wrap_deepmind = None
     envs = []
     for i in range(num_envs):
-        if 'NoFrameskip' in name:
+        if name.startswith("dm"):
+            import dm_control2gym
+            _, domain, task = name.split('-')
+            env = dm_control2gym.make(domain_name=domain, task_name=task)
+        else:
+            env = gym.make(name)
+        is_atari = hasattr(gym.envs, 'atari') and isinstance(env.unwrapped, gym.envs.atari.atari_env.AtariEnv)
+        if is_atari:
             if make_atari is None:
                 raise ImportError("gym is installed but baselines.common.atari_wrappers is not: %s needs the reference's "
                                   "Atari preprocessing (envs.py:39-47)" % name)
             env = make_atari(name)
-            env.seed(seed + i)
-            env = wrap_deepmind(env, episode_life=episode_life, clip_rewards=False, frame_stack=False, scale=False)
-            env = FrameStack(env, 4)
-        else:
-            import gym
-            env = gym.make(name)
-            env.seed(seed + i)
-        envs.append(_GymAdapter(env))
+        envs.append(wrap_like_reference(env, seed, i, is_atari, wrap_deepmind, episode_life))
     return envs
-
-
-class _GymAdapter:
-    """reset() / step() -> (obs, reward, done, {'episodic_return': ...}) over a gym environment (envs.py:58-89)."""
-
-    def __init__(self, env):
-        self.env = env
-        self.ret = 0.0
-        self.observation_space, self.action_space = env.observation_space, env.action_space
-
-    def reset(self):
-        self.ret = 0.0
-        return self.env.reset()
-
-    def step(self, action):
-        obs, reward, done, info = self.env.step(action)
-        self.ret += reward
-        info = dict(info or {})
-        info['episodic_return'] = self.ret if done else None
-        return obs, reward, done, info
 
 
 class Task:
@@ -280,6 +364,7 @@ class Task:
         return self.env.reset()
 
     def step(self, actions):
-        if isinstance(self.action_space, Box):
-            actions = np.clip(actions, self.action_space.low, self.action_space.high)
+        sp = self.action_space      # envs.py:186-189: Box actions are clipped (gym's Box as well as this module's)
+        if isinstance(sp, Box) or (hasattr(sp, 'low') and hasattr(sp, 'high') and not hasattr(sp, 'n')):
+            actions = np.clip(actions, sp.low, sp.high)
         return self.env.step(actions)

@@ -248,16 +248,16 @@ int dra_clip_step_coop(float* param, float* grad, float* state1, float* state2, 
                        int resident_limit, int optimizer, float max_norm, const float* hyper, int centered,
                        const int64_t* step_dev, float* out_norm, float* param_copy, void* stream);
 /* the late-fold form (DRA_VAR_LATE_FOLD): every tensor's sum of squares was left in partials[0, n_prior) by the kernels
- * that produced its gradient, except ONE segment (starting at element 0, n_slabs <= 64: conv1, whose weight gradient is the
- * last kernel of the backward) that is still in slabs.  The launch's first dra_clip_step_late_blocks() workgroups fold it,
- * publish their partials behind the others and count themselves on *flag (zeroed uint32 in device memory, reset before
- * every launch); every workgroup loads its operands, waits for that count (bounded: timeout_flag as above), reduces all
- * partials in the fixed order and applies the step.  No gradient-norm launch, no grid-wide ticket barrier. */
+ * that produced its gradient, except ONE segment (starting at element 0, n_slabs <= 256: conv1, whose weight gradient is the
+ * last kernel of the backward) that is still in slabs.  The launch's first dra_clip_step_late_blocks() (<= 256) workgroups
+ * fold it and publish their sums of squares into partials[n_prior ...], which must hold -1.0 at launch: the value IS the
+ * arrival flag.  Every workgroup loads its operands and the earlier partials, waits for those slots to turn non-negative
+ * (bounded: timeout_flag as above), reduces all partials in the fixed order and applies the step.  No gradient-norm launch,
+ * no ticket counter. */
 int dra_clip_step_late_blocks(const dra_fold_seg* seg, int* fold_blocks);
 int dra_clip_step_late(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* seg,
-                       double* partials, int n_prior, unsigned* flag, int* timeout_flag, int optimizer, float max_norm,
-                       const float* hyper, int centered, const int64_t* step_dev, float* out_norm, float* param_copy,
-                       void* stream);
+                       double* partials, int n_prior, int* timeout_flag, int optimizer, float max_norm, const float* hyper,
+                       int centered, const int64_t* step_dev, float* out_norm, float* param_copy, void* stream);
 int dra_rmsprop_step(float* param, const float* grad, float* square_avg, float* grad_avg, int64_t n,
                      const double* partials, int n_partials, float max_norm, float lr, float alpha, float eps,
                      int centered, float* out_norm, void* stream);

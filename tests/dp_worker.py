@@ -30,7 +30,9 @@ def main():
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dd.init("gloo")                       # ranks share ONE GPU on the test box: gloo moves the bytes
     d.select_device(0)
-    torch.manual_seed(0)                      # identical initial weights on every rank
+    # identical initial weights on every rank -- or, with DP_WORKER_RANK_SEEDS=1, a different torch seed per rank (what
+    # `python -m deeprl_amd.launch` does under torchrun): the agents must then start from rank 0's parameters
+    torch.manual_seed(int(os.environ.get("RANK", "0")) if os.environ.get("DP_WORKER_RANK_SEEDS") else 0)
     np.random.seed(0)
     c = d.Config()
     c.merge(dict(game="synthetic-atari", log_level=0, tag="dp", dp_invariant_sampling=True, dp_noise_seed=7))
@@ -53,6 +55,8 @@ def main():
     for _ in range(updates):
         agent.step()
     torch.cuda.synchronize()
+    if world > 1 and os.environ.get("DP_WORKER_RANK_SEEDS"):
+        np.savez(out + ".rank%d.npz" % dd.rank(), **{k: v.detach().cpu().numpy() for k, v in agent.network.state_dict().items()})
     if dd.rank() == 0:
         np.savez(out, total_steps=agent.total_steps, **{k: v.detach().cpu().numpy() for k, v in agent.network.state_dict().items()})
     agent.close()

@@ -52,3 +52,39 @@ def test_grad_allreduce_and_global_adv_norm_world2(tmp_path):
         np.testing.assert_allclose(o["adv"].numpy(), o["adv_want"].numpy(), rtol=1e-5, atol=1e-6)
         assert o["calls"] == 1
     assert torch.equal(outs[0]["flat"], outs[1]["flat"])  # identical gradients -> identical optimizer steps
+
+
+def _sync_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from deeprl_amd import dist as ddist
+    ddist.init("gloo")
+
+    class Cfg:
+        num_workers = 8
+        dp_noise_seed = 3
+    cfg = Cfg()
+    dp = ddist.DataParallel(cfg)
+    assert dp.active and dp.global_workers == 8 and cfg.num_workers == 4 and cfg.global_num_workers == 8
+    assert dp.is_main == (rank == 0)
+    # a second agent from the SAME config (evaluation agent, restart) shards the global count again, not the shard
+    dp2 = ddist.DataParallel(cfg)
+    assert dp2.global_workers == 8 and cfg.num_workers == 4 and (dp2.lo, dp2.hi) == (dp.lo, dp.hi)
+    # ranks built from different seeds: after sync_state every rank holds rank 0's values
+    torch.manual_seed(100 + rank)
+    flat, state = torch.randn(1000), torch.randn(1000)
+    dp.sync_state(flat, None, state)
+    torch.save(dict(flat=flat, state=state), os.path.join(out_dir, "s%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_state_sync_and_idempotent_sharding_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_sync_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "s%d.pt" % r)) for r in range(world)]
+    torch.manual_seed(100)
+    want_flat, want_state = torch.randn(1000), torch.randn(1000)
+    for o in outs:
+        assert torch.equal(o["flat"], want_flat) and torch.equal(o["state"], want_state)

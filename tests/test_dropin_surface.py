@@ -75,3 +75,104 @@ def test_replay_wrapper_accepts_every_spelling_of_the_async_flag():
         assert isinstance(w.replay, UniformReplay) and w.size() == 0
     with pytest.raises(TypeError):
         ReplayWrapper(UniformReplay, kw, bogus=1)
+
+
+def test_real_env_wrapper_stack_mirrors_make_env():
+    """ADVICE r2 (envs.py real-environment path): deeprl_amd.envs.wrap_like_reference must reproduce the ORDER and the
+    observation layout of the reference's make_env (deep_rl/component/envs.py:27-55) -- checked here with a stand-in emulator
+    (gym is not installed in this image): whole-game returns survive per-life resets (the return wrapper sits UNDER
+    wrap_deepmind), observations are CHW LazyFrames of shape (4, 84, 84), Task.step clips gym-style Box actions."""
+    import numpy as np
+    from deeprl_amd import envs as E
+
+    class Emu:
+        """3 lives, one life lost every 5 steps, reward 1 per step, HWC uint8 frames."""
+        class Space:
+            shape, low, high = (84, 84, 1), np.zeros((84, 84, 1)), np.full((84, 84, 1), 255.0)
+        observation_space, action_space = Space(), E.Discrete(4)
+
+        def __init__(self):
+            self.seeded, self.t, self.lives = None, 0, 3
+            self.unwrapped = self
+
+        def seed(self, s):
+            self.seeded = s
+
+        def _obs(self):
+            return np.full((84, 84, 1), self.t % 256, dtype=np.uint8)
+
+        def reset(self):
+            self.t, self.lives = 0, 3
+            return self._obs()
+
+        def step(self, a):
+            self.t += 1
+            if self.t % 5 == 0:
+                self.lives -= 1
+            return self._obs(), 1.0, self.lives == 0, {}
+
+    class EpisodicLife(E._PassThrough):
+        """baselines' EpisodicLifeEnv in miniature: a lost life ends the episode for the agent; reset() only restarts the
+        game when it is really over."""
+        def __init__(self, env):
+            E._PassThrough.__init__(self, env)
+            self.lives, self.real_done = 0, True
+
+        def step(self, a):
+            obs, r, done, info = self.env.step(a)
+            self.real_done = done
+            lives = self.env.unwrapped.lives
+            if 0 < lives < self.lives:
+                done = True
+            self.lives = lives
+            return obs, r, done, info
+
+        def reset(self):
+            if self.real_done:
+                obs = self.env.reset()
+            else:
+                obs, _, _, _ = self.env.step(0)
+            self.lives = self.env.unwrapped.lives
+            return obs
+
+    calls = {}
+
+    def fake_wrap_deepmind(env, episode_life, clip_rewards, frame_stack, scale):
+        calls.update(episode_life=episode_life, clip_rewards=clip_rewards, frame_stack=frame_stack, scale=scale,
+                     under=type(env).__name__)
+        return EpisodicLife(env) if episode_life else env
+
+    emu = Emu()
+    env = E.wrap_like_reference(emu, seed=7, rank=2, is_atari=True, wrap_deepmind=fake_wrap_deepmind, episode_life=True)
+    assert emu.seeded == 9
+    assert calls == dict(episode_life=True, clip_rewards=False, frame_stack=False, scale=False, under="OriginalReturnWrapper")
+    assert tuple(env.observation_space.shape) == (4, 84, 84)
+    ob = env.reset()
+    assert isinstance(ob, E.LazyFrames) and np.asarray(ob).shape == (4, 84, 84)
+    returns, steps = [], 0
+    while len(returns) < 1 and steps < 100:
+        ob, r, done, info = env.step(1)
+        steps += 1
+        if info['episodic_return'] is not None:
+            returns.append(info['episodic_return'])
+        if done:
+            ob = env.reset()
+    # the game ends when the third life is lost: 15 emulator steps of reward 1 (+1 no-op step per life-reset) -- ONE return
+    # for the whole game, not one per life
+    assert returns and returns[0] >= 15
+    a = np.asarray(ob)
+    assert a.shape == (4, 84, 84) and a.dtype == np.uint8
+    # Task.step clips Box actions of a duck-typed (gym) space too
+    class GymBox:
+        low, high, shape = np.full(2, -1.0), np.full(2, 1.0), (2,)
+    t = E.Task.__new__(E.Task)
+    t.action_space = GymBox()
+    seen = {}
+
+    class Rec:
+        def step(self, actions):
+            seen['a'] = actions
+            return None
+    t.env = Rec()
+    t.step(np.array([[3.0, -2.0]]))
+    assert np.array_equal(seen['a'], np.array([[1.0, -1.0]]))

@@ -19,8 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
 
 
-def _run(kind, out, world, port):
+def _run(kind, out, world, port, extra_env=None):
     env = dict(os.environ)
+    env.update(extra_env or {})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -55,6 +56,24 @@ def test_two_ranks_equal_one_process(tmp_path, kind, port):
         assert bad.mean() <= limit and err.max() < 1e-4, "%s: %d of %d elements off, max %g" % (k, bad.sum(), bad.size, err.max())
         moved = max(moved, float(np.abs(one[k]).max()))
     assert moved > 0
+
+
+def test_ranks_seeded_differently_start_from_rank0_parameters(tmp_path):
+    """ADVICE r2 (launch.py seeds 1 + RANK under torchrun): ranks that build their networks from DIFFERENT torch seeds must
+    still train ONE model -- DataParallel broadcasts rank 0's flat parameters / optimizer state at agent construction.
+    Two ranks with seeds (0, 1) == one process with seed 0, and both ranks end on identical parameters."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    one = _run("a2c", str(tmp_path / "one.npz"), 1, 29643)
+    out2 = str(tmp_path / "two.npz")
+    two = _run("a2c", out2, 2, 29643, {"DP_WORKER_RANK_SEEDS": "1"})
+    r0, r1 = dict(np.load(out2 + ".rank0.npz")), dict(np.load(out2 + ".rank1.npz"))
+    for k in one:
+        if k == "total_steps":
+            continue
+        assert np.array_equal(r0[k], r1[k]), k                     # same bits on both ranks
+        err = np.abs(two[k] - one[k])
+        assert (err <= 2e-6 + 1e-5 * np.abs(one[k])).all(), (k, err.max())
 
 
 def test_rccl_comm_of_size_one():
