@@ -17,9 +17,10 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
   * cpu_baseline: the CPU oracle (port of the reference path on torch-CPU fp32) on a bounded
     sample, rank 0 / N=1 only: `value` with ONE thread (the reference's set_one_thread(), examples.py:623),
     `all_cores` with torch.set_num_threads(nproc).
-  * parity_check: after the timed region, ONE more agent step of the SAME pipelined configuration is replayed
-    through the CPU oracle (snapshot of parameters / optimizer state before, the minibatch the update consumed,
-    parameters after): loss and every parameter at 1e-5.  Outside the timing.
+  * parity_check: after the timed region, SIX more agent steps of the SAME pipelined configuration are replayed through
+    the CPU oracle, chained (the oracle carries its own parameters / optimizer state from step to step; the minibatch each
+    update consumed comes from the learner): loss and every parameter at 1e-5 per step, the worst is reported.  Outside the
+    timing.
   * `--gpus N` without a torchrun environment launches the N ranks itself (torch.distributed.run, 127.0.0.1).
   * a run of fewer than 500 timed steps (the driver's default is 20) is a few milliseconds: `value` is still exactly
     those K steps (the contract), and `long_run` carries the same measurement over 2000 steps.
@@ -220,58 +221,80 @@ def agent_api(seconds=2.0):
     return out
 
 
-def parity_check(bench, max_tries=4, gate_margin=5e-7):
-    """One more agent step of the configuration that was just timed (same learner, same pipeline, same graphs), replayed
-    through the CPU oracle: parameters / RMSprop state are snapshotted first, the step runs, and the oracle redoes the
-    update (DQN_agent.py:114-134) on the minibatch the learner's own gather produced.  Bar: loss 1e-5 relative, every
-    parameter within atol 2e-6 + rtol 1e-5 (weights are O(0.05)).  A step in which some ReLU input of the differentiated
-    forward lies within fp32 summation noise of zero (|pre-activation| < gate_margin: two correct fp32 implementations
-    may gate it differently, which changes that unit's whole backward contribution; about one batch-32 update in three
-    with zero-initialised biases) says nothing either way, so the check moves on to the next step, at most max_tries."""
+def parity_check(bench, n_steps=6, gate_margin=5e-7):
+    """n_steps more agent steps of the configuration that was just timed (same learner, same pipeline, same graphs), replayed
+    through the CPU oracle and CHAINED: the oracle starts from the learner's parameters / RMSprop state before the first of
+    them and then carries ITS OWN state from step to step, redoing every update (DQN_agent.py:114-134) on the minibatch
+    the learner's gather produced.  Bar per step: loss 1e-5 relative, every parameter within atol 2e-6 + rtol 1e-5 (weights
+    are O(0.05)) of the oracle's.  A step in which some ReLU input of the differentiated forward lies within fp32 summation
+    noise of zero (|pre-activation| < gate_margin: two correct fp32 implementations may gate it differently, which changes
+    that unit's whole backward contribution; about one batch-32 update in three with zero-initialised biases) is reported
+    but not judged, and the oracle re-adopts the learner's state after it, which starts a new chain.  Reports the worst
+    errors over the judged steps, the longest chain, and every step."""
     from oracle import loss_oracle as L, net_oracle as N, numerics_oracle as NUM
     lr = bench.learner
     torch.set_num_threads(min(8, os.cpu_count() or 1))
-    out = None
     lr.keep_minibatch(True)     # ring-direct update: also gather what it reads, for the oracle (the update keeps reading the ring)
-    for attempt in range(1, max_tries + 1):
-        snap = lr.export_state()          # parameters / target / RMSprop state before the step, module layout, CPU
-        before, target, sq, ga = snap["params"], snap["target"], snap["square_avg"], snap["grad_avg"]
-        names = list(before)
+    lr.synchronize()
+    snap = lr.export_state()          # parameters / target / RMSprop state before the first step, module layout, CPU
+    names = list(snap["params"])
+    p = {k: v.clone() for k, v in snap["params"].items()}
+    sq = {k: v.clone() for k, v in snap["square_avg"].items()}
+    ga = {k: v.clone() for k, v in snap["grad_avg"].items()}
+    steps, worst_loss, worst_param, judged, chain, best_chain, all_ok = [], 0.0, 0.0, 0, 0, 0, True
+    for it in range(n_steps):
         bench.step()
         lr.synchronize()
         torch.cuda.synchronize()
+        now = lr.export_state()
+        target = now["target"]
         st, ns, ac, rw, mk = [t.cpu() for t in lr.last_minibatch()]
-        after = {k: v.detach().cpu().clone() for k, v in bench.network.state_dict().items()}
         gpu_loss = float(lr.delta.double().pow(2).mul(0.5).mean().item())
-        p = {k: v.clone().requires_grad_(True) for k, v in before.items()}
+        pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
         x = torch.from_numpy(NUM.image_normalize_sync(st.numpy()))
         xn = torch.from_numpy(NUM.image_normalize_sync(ns.numpy()))
         with torch.no_grad():
             qn = N.vanilla_head(target, N.nature_conv_body(target, xn))
-        phi, margin = N.nature_conv_body_margin(p, x)
-        q = N.vanilla_head(p, phi)
+        phi, margin = N.nature_conv_body_margin(pr, x)
+        q = N.vanilla_head(pr, phi)
         delta = L.dqn_td_error(q, qn, ac, rw, mk, 0.99)
         loss = L.dqn_reduce(delta)
-        grads = torch.autograd.grad(loss, [p[k] for k in names])
+        grads = torch.autograd.grad(loss, [pr[k] for k in names])
         _, grads = N.clip_grad_norm(list(grads), 5)
-        worst_abs, ok = 0.0, True
+        step_abs, ok = 0.0, True
         for k, g in zip(names, grads):
-            want, _, _ = N.rmsprop_step(p[k].detach(), g, sq[k], ga[k], 0.00025, 0.95, 0.01, True)
-            err = (after[k] - want).abs()
-            worst_abs = max(worst_abs, float(err.max()))
+            want, sq[k], ga[k] = N.rmsprop_step(pr[k].detach(), g, sq[k], ga[k], 0.00025, 0.95, 0.01, True)
+            err = (now["params"][k] - want).abs()
+            step_abs = max(step_abs, float(err.max()))
             ok = ok and bool(torch.all(err <= 2e-6 + 1e-5 * want.abs()))
+            p[k] = want
         loss_f = float(loss.detach())
         rel_loss = abs(gpu_loss - loss_f) / max(abs(loss_f), 1e-12)
         ok = ok and rel_loss <= 1e-5
-        out = {"ok": bool(ok), "steps_checked": attempt, "loss_gpu": gpu_loss, "loss_oracle": loss_f, "rel_loss_err": rel_loss,
-               "max_abs_param_err": worst_abs, "min_relu_input_abs": margin, "gate_ambiguous": bool(margin < gate_margin),
-               "tolerance": "loss 1e-5 rel; params atol 2e-6 + rtol 1e-5; steps with a ReLU input within %g of zero are skipped" % gate_margin,
-               "what": "one more agent step of the timed configuration (same learner, pipeline and graphs) replayed through "
-                       "the CPU oracle on the minibatch its gather produced; outside the timed region"}
-        if ok or margin >= gate_margin:
-            break
+        ambiguous = bool(margin < gate_margin)
+        steps.append({"rel_loss_err": rel_loss, "max_abs_param_err": step_abs, "min_relu_input_abs": margin,
+                      "gate_ambiguous": ambiguous, "within_tolerance": bool(ok), "chained_from_step": it - chain})
+        if ambiguous or not ok:
+            if not ambiguous:
+                all_ok = False
+                judged += 1
+                worst_loss, worst_param = max(worst_loss, rel_loss), max(worst_param, step_abs)
+            chain = 0       # new chain from the learner's own state
+            p = {k: v.clone() for k, v in now["params"].items()}
+            sq = {k: v.clone() for k, v in now["square_avg"].items()}
+            ga = {k: v.clone() for k, v in now["grad_avg"].items()}
+        else:
+            judged += 1
+            chain += 1
+            best_chain = max(best_chain, chain)
+            worst_loss, worst_param = max(worst_loss, rel_loss), max(worst_param, step_abs)
     lr.keep_minibatch(False)
-    return out
+    return {"ok": bool(all_ok and judged > 0), "steps_checked": n_steps, "steps_judged": judged, "longest_chain": best_chain,
+            "worst_rel_loss_err": worst_loss, "worst_abs_param_err": worst_param, "steps": steps,
+            "tolerance": "per step: loss 1e-5 rel; params atol 2e-6 + rtol 1e-5 against the oracle's CHAINED state; steps with a "
+                         "ReLU input within %g of zero are reported, not judged, and restart the chain" % gate_margin,
+            "what": "%d more agent steps of the timed configuration (same learner, pipeline and graphs) replayed through the CPU "
+                    "oracle on the minibatches its gather produced; outside the timed region" % n_steps}
 
 
 def pmc_traffic(kernel_group):

@@ -174,8 +174,56 @@ __device__ __forceinline__ void fused_env_workgroup(const ActorFuse& f, float* _
   }
 }
 
-template <class G, bool U8, int PT, int NW, bool FUSE>
-__device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const ActorFuse& f) {
+// ---- the actor's env step as ONE launch (DRA_VAR_ACTOR_MEGA): cross-workgroup hand-over inside a kernel ------------------
+// A producer writes its outputs with agent-scope stores (written through: the XCDs' L2s are not coherent with each other),
+// completes them (s_waitcnt), and ONE thread counts the workgroup on the layer's arrival counter; a consumer requests
+// everything that does not depend on the producer (its weights) first, then one thread polls the counter (bounded: 50 ms,
+// then the pinned timeout flag is set and the wait gives up -- results of that launch are invalid and the host reports
+// DRA_ETIMEDOUT), and the activations are read with agent-scope loads.  Few arrivals per counter (13 / 12 / 8): the
+// ~30 ns an agent-scope atomic costs on this part does not add up (the 796-ticket grid barrier of round 2 did).
+struct MegaSync {
+  unsigned* done = nullptr;        // this role's arrival counter (producers), null = nothing to publish
+  const unsigned* wait = nullptr;  // the counter this role waits on (consumers), null = nothing to wait for
+  unsigned wait_target = 0;
+  int* timeout_flag = nullptr;     // pinned host int
+};
+constexpr unsigned long long kMegaWaitTicks = 5000000ull;   // 50 ms of s_memrealtime (100 MHz)
+
+__device__ __forceinline__ void mega_publish(const MegaSync& ms) {
+  if (!ms.done) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ms.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mega_wait(const MegaSync& ms) {
+  if (!ms.wait) return;
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(ms.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ms.wait_target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > kMegaWaitTicks) {
+        if (ms.timeout_flag) __hip_atomic_store(ms.timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+template <bool COH> __device__ __forceinline__ float mega_ld(const float* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH> __device__ __forceinline__ void mega_st(float* p, float v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+// (bx, by, bz) = the workgroup's position in the conv grid (blockIdx of a plain launch; a role offset inside the actor's
+// one-launch env step), env_wg = this workgroup is the fused launch's environment workgroup; COH = outputs are handed to
+// other workgroups of the SAME launch (agent-scope stores + mega_publish)
+template <class G, bool U8, int PT, int NW, bool FUSE, bool COH = false>
+__device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const ActorFuse& f, const int bx, const int by, const int bz,
+                                                 const bool env_wg, const MegaSync ms = MegaSync()) {
   using T = V2Tile<G, PT>;
   using KS = typename G::template Split<NW>;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -183,15 +231,15 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [C][NR][RW] image, then reused for the reduction
   __shared__ float s_q[FUSE ? 64 : 1];
   if constexpr (FUSE) {
-    if (blockIdx.x == gridDim.x - 1) {   // the launch's extra workgroup: environment side
+    if (env_wg) {   // the launch's extra workgroup: environment side
       fused_env_workgroup<NW>(f, s_q);
       return;
     }
   }
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
-  const int z = blockIdx.z;
-  const int bi = blockIdx.x / T::TPG, grp = blockIdx.x - bi * T::TPG;
-  const int oc0 = blockIdx.y * 32;
+  const int z = bz;
+  const int bi = bx / T::TPG, grp = bx - bi * T::TPG;
+  const int oc0 = by * 32;
   const int p0 = grp * PT * 32;
   const int np = min(32 * PT, G::P - p0);
   const int oh0 = p0 / G::OH, oh1 = (p0 + np - 1) / G::OH;
@@ -285,7 +333,7 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
       int64_t img = (int64_t)bi * G::C + min(c, G::C - 1);       // image index in a plain NCHW batch
       if (a.sample_idx) {                                        // ... or a run of ring slots
         img = si + a.idx_bias[z] + min(c, G::C - 1);
-        if (a.sample_idx_copy && ci == 0 && tid == 0 && grp == 0 && z == 0 && blockIdx.y == 0) a.sample_idx_copy[bi] = si;
+        if (a.sample_idx_copy && ci == 0 && tid == 0 && grp == 0 && z == 0 && by == 0) a.sample_idx_copy[bi] = si;
       }
       const int off = min(G::C - 1 - min(c, G::C - 1), age);      // ring stack: frames back from the newest one
       if (a.ring_slot) {
@@ -448,10 +496,11 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
              (rt[(6 * 16 + r) * 64 + lane] + rt[(7 * 16 + r) * 64 + lane]);
       const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
       const float v = v2_act(s + bias_r[q], a.act);
-      if (32 * t + li < np) y[((int64_t)(bi * G::OC + oc0 + row)) * G::P + p0 + 32 * t + li] = v;
+      if (32 * t + li < np) mega_st<COH>(&y[((int64_t)(bi * G::OC + oc0 + row)) * G::P + p0 + 32 * t + li], v);
     }
   }
   DRA_STAMP(TRR, 5);   // reduction folded, stores issued
+  if constexpr (COH) mega_publish(ms);
   DRA_STAMP_END(TRR);
 }
 
@@ -459,14 +508,14 @@ template <class G, bool U8, int PT, int NW = 4>
 __global__ void __launch_bounds__(64 * NW) conv_fwd_v2_kernel(const ConvV2Args a) {
   ActorFuse none;
   none.mode = 0;
-  conv_fwd_v2_body<G, U8, PT, NW, false>(a, none);
+  conv_fwd_v2_body<G, U8, PT, NW, false>(a, none, blockIdx.x, blockIdx.y, blockIdx.z, false);
 }
 
 // conv1 of the ring actor's env step e with the head of step e-1 and the environment step in front (ActorFuse):
 // grid = conv1's workgroups + 1 environment workgroup.
 template <class G, int NW>
 __global__ void __launch_bounds__(64 * NW) conv1_actor_fused_kernel(const ConvV2Args a, const ActorFuse f) {
-  conv_fwd_v2_body<G, true, 1, NW, true>(a, f);
+  conv_fwd_v2_body<G, true, 1, NW, true>(a, f, blockIdx.x, blockIdx.y, blockIdx.z, blockIdx.x == gridDim.x - 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -660,10 +709,12 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Ar
 // activation) and the CONSUMER adds the planes and applies the ReLU while it stages its input (KZI = 2) -- the next
 // conv, or the fc4 GEMV.  Fixed order (plane 0 + bias) + plane 1: deterministic.
 // grid (position tiles, (OC / 32) * KZO), 512 threads.
-template <class G, int KZI, int KZO>
-__global__ void __launch_bounds__(512)
-conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ wt,
-                     const float* __restrict__ bias, float* __restrict__ y, int act) {
+// (bx, by) = blockIdx of a plain launch; COH: the input planes come from, and the output planes go to, other workgroups of
+// the SAME launch (the actor's one-launch env step): weights first, then the wait, then agent-scope loads / stores
+template <class G, int KZI, int KZO, bool COH>
+__device__ __forceinline__ void conv_b1_split_body(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ wt,
+                                                   const float* __restrict__ bias, float* __restrict__ y, int act, const int bx,
+                                                   const int by, const MegaSync ms = MegaSync()) {
   using T = V2Tile<G, 1>;
   constexpr int NW = 8;
   constexpr int CPK = G::CP / KZO;            // channel pairs of this workgroup
@@ -673,9 +724,9 @@ conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
   static_assert(CPK % NW == 0 && CL % NW == 0 && G::H <= 32, "channel split");
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [CL][NR][RW] image, then the 8-way reduction
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
-  const int kz = blockIdx.y / (G::OC / 32);
-  const int oc0 = (blockIdx.y - kz * (G::OC / 32)) * 32;
-  const int p0 = blockIdx.x * 32;
+  const int kz = by / (G::OC / 32);
+  const int oc0 = (by - kz * (G::OC / 32)) * 32;
+  const int p0 = bx * 32;
   const int np = min(32, G::P - p0);
   const int oh0 = p0 / G::OH, oh1 = (p0 + np - 1) / G::OH;
   const int ir0 = oh0 * G::S;
@@ -709,6 +760,10 @@ conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
   const int rsub = lane / LR, iw = lane % LR;
   const int iwc = min(iw, G::H - 1);
   const int col = lds_col<G>(iwc);
+  if constexpr (COH) {
+    __builtin_amdgcn_sched_barrier(0);   // the weight / bias loads above are in flight while this workgroup waits
+    mega_wait(ms);
+  }
 #pragma unroll
   for (int ci = 0; ci < CPT; ++ci) {
     const int c = kz * CL + wave + NW * ci;
@@ -716,8 +771,8 @@ conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
 #pragma unroll
     for (int q = 0; q < LPT; ++q) {
       const int64_t oo = o + (int64_t)min(RP * q + rsub, nrows - 1) * G::H;
-      raw0[ci * LPT + q] = x0[oo];
-      if constexpr (KZI == 2) raw1[ci * LPT + q] = x1[oo];
+      raw0[ci * LPT + q] = mega_ld<COH>(x0 + oo);
+      if constexpr (KZI == 2) raw1[ci * LPT + q] = mega_ld<COH>(x1 + oo);
     }
   }
 #pragma unroll
@@ -767,10 +822,18 @@ conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
          (red[(6 * 16 + r) * 64 + lane] + red[(7 * 16 + r) * 64 + lane]);
     const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
     const float v = (KZO == 1) ? v2_act(s + bias_r[q], act) : s + bias_r[q];
-    if (li < np) yo[(int64_t)(oc0 + row) * G::P + p0 + li] = v;
+    if (li < np) mega_st<COH>(&yo[(int64_t)(oc0 + row) * G::P + p0 + li], v);
   }
   DRA_STAMP(TRR, 5);
+  if constexpr (COH) mega_publish(ms);
   DRA_STAMP_END(TRR);
+}
+
+template <class G, int KZI, int KZO>
+__global__ void __launch_bounds__(512)
+conv_b1_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ wt,
+                     const float* __restrict__ bias, float* __restrict__ y, int act) {
+  conv_b1_split_body<G, KZI, KZO, false>(x0, x1, wt, bias, y, act, blockIdx.x, blockIdx.y);
 }
 
 using VG1 = V2Geom<4, 84, 32, 8, 4>;
@@ -802,6 +865,136 @@ int dra_conv_b1_split(int layer, const float* x0, const float* x1, const float* 
     return launch_conv_b1_split<VG3, 2, 2>(x0, x1, wt, bias, y_planes, DRA_ACT_NONE, st);
   }
   return DRA_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DRA_VAR_ACTOR_MEGA: one env step of the ring actor (head of step e-1 + environment step + conv1, conv2, conv3, fc4) as ONE
+// launch of 98 workgroups x 512 threads instead of four dependent launches (DQN_agent.py:24-45: forward -> epsilon-greedy
+// -> env.step -> next forward).  The actor chain is as long as the update chain (4 x ~29 us per agent step against
+// ~113 us, profiles/r03b_phase_async_193023.json) and every one of its launches is a handful of workgroups waiting
+// 1.5-2.7 us for operands after a ~2 us boundary.  Here the roles are laid out in dependency order along blockIdx --
+//   [0, 13) conv1 tiles (ActorFuse: head + action + the rows of the new observation they convolve)   [13] environment
+//   [14, 26) conv2 (two partial planes)   [26, 34) conv3 (two partial planes)   [34, 98) fc4, 8 rows per workgroup --
+// and hand their outputs over through MegaSync counters: a consumer's weights (6.4 MB for fc4) are in registers before
+// its producer has finished, what remains after an arrival is one agent-scope read of the activations.  Workgroups are
+// dispatched in blockIdx order, so every producer is resident before a workgroup that waits for it (98 workgroups on
+// the actor's 32 CUs: two per CU at 512 threads, the 34 producers first).  Same arithmetic, same order as the four
+// launches: bit-identical action values, actions and ring contents (tests/test_gpu_env_switches.py).
+struct ActorMegaArgs {
+  ConvV2Args c1;
+  ActorFuse f;
+  const float *w2, *b2, *w3, *b3, *w4, *b4;
+  float *y1, *y2p, *y3p, *h4;
+  unsigned* flags;         // [3] arrivals of conv1 / conv2 / conv3 of THIS env step, zero at launch
+  int* timeout_flag;
+};
+constexpr int kMegaC1 = V2Tile<VG1, 1>::TPG, kMegaC2 = VG2::TPS * (VG2::OC / 32) * 2, kMegaC3 = VG3::TPS * (VG3::OC / 32) * 2;
+constexpr int kMegaFc = 512 / 8;
+constexpr int kMegaBlocks = kMegaC1 + 1 + kMegaC2 + kMegaC3 + kMegaFc;
+
+__global__ void __launch_bounds__(512) actor_mega_kernel(const ActorMegaArgs m) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int b = blockIdx.x;
+  if (b <= kMegaC1) {
+    MegaSync ms;
+    ms.done = m.flags;
+    conv_fwd_v2_body<VG1, true, 1, 8, true, true>(m.c1, m.f, b, 0, 0, b == kMegaC1, ms);
+    return;
+  }
+  b -= kMegaC1 + 1;
+  if (b < kMegaC2) {
+    MegaSync ms;
+    ms.wait = m.flags; ms.wait_target = kMegaC1; ms.done = m.flags + 1; ms.timeout_flag = m.timeout_flag;
+    conv_b1_split_body<VG2, 1, 2, true>(m.y1, nullptr, m.w2, m.b2, m.y2p, DRA_ACT_NONE, b % VG2::TPS, b / VG2::TPS, ms);
+    return;
+  }
+  b -= kMegaC2;
+  if (b < kMegaC3) {
+    MegaSync ms;
+    ms.wait = m.flags + 1; ms.wait_target = kMegaC2; ms.done = m.flags + 2; ms.timeout_flag = m.timeout_flag;
+    conv_b1_split_body<VG3, 2, 2, true>(m.y2p, m.y2p + VG2::OC * VG2::P, m.w3, m.b3, m.y3p, DRA_ACT_NONE, b % VG3::TPS, b / VG3::TPS, ms);
+    return;
+  }
+  b -= kMegaC3;
+  // ---- fc4: h4[row] = relu(b4[row] + <W4[row], relu(x0 + x1)>), one wave per row, the row's weights requested BEFORE the
+  // wait (same per-lane products and butterfly as actor_fc4_planes_lds_kernel)
+  constexpr int I = VG3::OC * VG3::P, NV = I / 4, R = (NV + 63) / 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = b * 8 + wave;
+  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(m.w4 + (int64_t)row * I);
+  float4 wv[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) wv[q] = w4[min(lane + 64 * q, NV - 1)];
+  const float bias = m.b4[row];
+  __builtin_amdgcn_sched_barrier(0);
+  MegaSync ms;
+  ms.wait = m.flags + 2; ms.wait_target = kMegaC3; ms.timeout_flag = m.timeout_flag;
+  mega_wait(ms);
+  constexpr int XQ = (I + 511) / 512;
+  const float* x0 = m.y3p;
+  const float* x1 = m.y3p + I;
+  float xa[XQ], xc[XQ];
+#pragma unroll
+  for (int q = 0; q < XQ; ++q) {
+    const int i = min((int)threadIdx.x + 512 * q, I - 1);
+    xa[q] = mega_ld<true>(x0 + i);
+    xc[q] = mega_ld<true>(x1 + i);
+  }
+#pragma unroll
+  for (int q = 0; q < XQ; ++q) {
+    const int i = (int)threadIdx.x + 512 * q;
+    if (i < I) lds[i] = fmaxf(xa[q] + xc[q], 0.f);
+  }
+  __syncthreads();
+  const float4* sx = reinterpret_cast<const float4*>(lds);
+  float acc = 0.f;
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    float4 a = wv[q];
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+    const float4 x = sx[min(lane + 64 * q, NV - 1)];
+    if (lane + 64 * q < NV) acc += (a.x * x.x + a.y * x.y) + (a.z * x.z + a.w * x.w);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    const float v = acc + bias;
+    m.h4[row] = v > 0.f ? v : 0.f;
+  }
+}
+
+// Library-internal (actor_env.h).  flags: 3 zeroed arrival counters owned by this env step (the agent step's tail kernel
+// zeroes them again); everything else as dra_conv1_fwd_actor_fused + dra_conv_b1_split x 2 + the fc4 GEMV.
+int dra_actor_env_step_mega(const void* frames, const int64_t* slot_field_dev, const int32_t* stack_age_field_dev,
+                            const unsigned* seq_dev, int n_entries, int64_t stride_bytes, int64_t capacity, const void* newest_frame,
+                            const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                            const float* w4, const float* b4, float* y1, float* y2_planes, float* y3_planes, float* h4,
+                            double u8_coef, const ActorFuse* f, unsigned* flags, int* timeout_flag, void* stream) {
+  if (!frames || !slot_field_dev || !seq_dev || n_entries < 1 || stride_bytes < 8 || capacity < VG1::C || !w1 || !b1 || !w2 ||
+      !b2 || !w3 || !b3 || !w4 || !b4 || !y1 || !y2_planes || !y3_planes || !h4 || !f || !flags || !timeout_flag)
+    return DRA_EINVAL;
+  if (f->mode != 1 && f->mode != 2) return DRA_EINVAL;
+  if (f->mode == 2 && (f->e < 1 || f->e >= kMaxEnvSteps || f->n_actions < 1 || f->n_actions > 64 || !f->h4 || !f->wh || !f->bh))
+    return DRA_EINVAL;
+  ActorMegaArgs m;
+  ConvV2Args& a = m.c1;
+  a.x[0] = frames; a.wt[0] = w1; a.bias[0] = b1; a.y[0] = y1;
+  a.batch = 1; a.act = DRA_ACT_RELU; a.coef = u8_coef; a.ring_slot = slot_field_dev; a.ring_cap = capacity;
+  a.stack_age = stack_age_field_dev; a.slot_seq = seq_dev; a.slot_entries = n_entries; a.slot_stride = stride_bytes;
+  a.newest_frame = f->mode == 1 ? reinterpret_cast<const uint8_t*>(newest_frame) : nullptr;
+  m.f = *f;
+  m.w2 = w2; m.b2 = b2; m.w3 = w3; m.b3 = b3; m.w4 = w4; m.b4 = b4;
+  m.y1 = y1; m.y2p = y2_planes; m.y3p = y3_planes; m.h4 = h4; m.flags = flags; m.timeout_flag = timeout_flag;
+  constexpr size_t img1 = (size_t)VG1::C * V2Tile<VG1, 1>::CS * sizeof(float);
+  constexpr size_t img2 = (size_t)(VG2::C / 2) * V2Tile<VG2, 1>::CS * sizeof(float);
+  constexpr size_t img3 = (size_t)(VG3::C / 2) * V2Tile<VG3, 1>::CS * sizeof(float);
+  constexpr size_t red = (size_t)8 * 16 * 64 * sizeof(float);
+  constexpr size_t xfc = (size_t)VG3::OC * VG3::P * sizeof(float);
+  constexpr size_t m1 = img1 > img2 ? img1 : img2, m2 = img3 > red ? img3 : red, m3 = m1 > m2 ? m1 : m2;
+  constexpr size_t bytes = m3 > xfc ? m3 : xfc;
+  static_assert(bytes <= 64 * 1024, "default dynamic LDS limit");
+  hipLaunchKernelGGL(actor_mega_kernel, dim3(kMegaBlocks), dim3(512), bytes, dra_stream(stream), m);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
 }
 
 template <class G, bool U8, int PT, int NW = 4>

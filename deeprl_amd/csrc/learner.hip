@@ -185,6 +185,8 @@ struct dra_dqn_learner {
   int sp_k;
   // DRA_VAR_LATE_FOLD: no gradient-norm launch (optim.hip late_step_kernel): sums of squares from the producing kernels,
   // conv3 / conv2 folds riding in the next backward launch, conv1's fold in front of the optimizer launch
+  unsigned* aflags;                 // DRA_VAR_ACTOR_MEGA: [kMaxEnvSteps][4] arrival counters of the one-launch env steps (zeroed by
+                                    // the agent step's tail kernel)
   bool late;
   int late_nprior;                  // partials written before the optimizer launch
   int late_nfold;                   // fold workgroups of the optimizer launch (their partial slots double as arrival flags)
@@ -358,6 +360,8 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
     }
   }
   rc |= alloc_f(&l->ah4, 512);
+  rc |= (int)hipMalloc(&l->aflags, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
+  if (!rc) rc |= (int)hipMemset(l->aflags, 0, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
   if (l->variant & DRA_VAR_ACTOR_PARAMS) { rc |= alloc_f(&l->pa[0], cfg->n_params); rc |= alloc_f(&l->pa[1], cfg->n_params); }
   if ((l->variant & DRA_VAR_ACTOR_PARAMS) && (l->variant & DRA_VAR_GATHER_ON_UPDATE)) {
     rc |= alloc_f(&l->pa[2], cfg->n_params); rc |= alloc_f(&l->pa[3], cfg->n_params);
@@ -459,6 +463,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   for (auto& ga : l->g_actor) if (ga.ready) (void)hipGraphExecDestroy(ga.exec);
   for (int k = 0; k < 4; ++k) if (l->pa[k]) (void)hipFree(l->pa[k]);
   if (l->ah4) (void)hipFree(l->ah4);
+  if (l->aflags) (void)hipFree(l->aflags);
   if (l->aring_dev) {
     (void)hipFree(l->aring_dev); (void)hipHostFree(l->aring_stage); (void)hipFree(l->aring_seq);
     (void)hipFree(l->pend_frame); (void)hipFree(l->pend_reward); (void)hipFree(l->pend_mask);
@@ -1918,10 +1923,13 @@ actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restric
                            uint8_t* __restrict__ ring_actions, float* __restrict__ q_out, uint8_t* __restrict__ frames,
                            double* __restrict__ rewards, int32_t* __restrict__ masks, uint8_t* __restrict__ pend_frame,
                            double* __restrict__ pend_reward, int32_t* __restrict__ pend_mask, uint64_t seed,
-                           int done_period, const HeadSpec hs) {
+                           int done_period, const HeadSpec hs, unsigned* __restrict__ flags_reset, int n_flags) {
   __shared__ float s_q[64];
   __shared__ float s_out[kMaxHeadOut];
   DRA_STAMP(TR_A_HEAD, 0);
+  // DRA_VAR_ACTOR_MEGA: the arrival counters of this agent step's one-launch env steps are done with; zero them for the next
+  if (flags_reset)
+    for (int i = threadIdx.x; i < n_flags; i += blockDim.x) __hip_atomic_store(flags_reset + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned sq = *seq;
   const dra_dqn_step_params* __restrict__ prm = aring_entry(ring, sq);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1993,11 +2001,26 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   f.pend_reward = l->pend_reward; f.pend_mask = l->pend_mask; f.seed = (uint64_t)c.env_seed;
   const bool dist = c.head_kind != DRA_HEAD_VANILLA;
   f.head_kind = c.head_kind; f.n_atoms = c.n_atoms; f.atoms = l->atoms; f.pre = l->alog;
+  // DRA_VAR_ACTOR_MEGA: conv1 (+ head / environment step), conv2, conv3 and fc4 of an env step as ONE launch (conv_v2.hip)
+  const bool mega = (l->variant & DRA_VAR_ACTOR_MEGA) && actor_ksplit() && l->aflags;
   for (int e = 0; e < n_env; ++e) {
     const int64_t* slot_field = reinterpret_cast<const int64_t*>(l->aring_dev + offsetof(dra_dqn_step_params, slot)) + e;
     const int32_t* age_field = reinterpret_cast<const int32_t*>(l->aring_dev + offsetof(dra_dqn_step_params, stack_age)) + e;
     f.mode = e == 0 ? 1 : 2;
     f.e = e;
+    if (mega) {
+      if ((rc = dra_actor_env_step_mega(frames, slot_field, age_field, l->aring_seq, kAringSlots, (int64_t)kAprmStride, c.ring_capacity,
+                                        e == 0 ? l->pend_frame : nullptr, P + o[P_W1], P + o[P_B1], P + o[P_W2], P + o[P_B2],
+                                        P + o[P_W3], P + o[P_B3], P + o[P_W4], P + o[P_B4], l->ay1, l->ay2p, l->ay3p, l->ah4,
+                                        c.u8_coef, &f, l->aflags + 4 * e, l->coop_flag, s)))
+        return rc;
+      if (dist) {
+        hipLaunchKernelGGL(actor_dist_gemv_kernel, dim3((l->n_out + 3) / 4), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH],
+                           P + o[P_BH], l->n_out, l->alog);
+        DRA_LAUNCH_CHECK();
+      }
+      continue;
+    }
     if ((rc = dra_conv1_fwd_actor_fused(frames, slot_field, age_field, l->aring_seq, kAringSlots, (int64_t)kAprmStride, c.ring_capacity,
                                         e == 0 ? l->pend_frame : nullptr, P + o[P_W1], P + o[P_B1], l->ay1, c.u8_coef,
                                         DRA_ACT_RELU, &f, s)))
@@ -2045,7 +2068,7 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq,
                      n_env - 1, 1, 0, (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq,
                      (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
-                     (uint64_t)c.env_seed, (int)c.env_done_period, hs_tail);
+                     (uint64_t)c.env_seed, (int)c.env_done_period, hs_tail, mega ? l->aflags : (unsigned*)nullptr, kMaxEnvSteps * 4);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -2089,7 +2112,7 @@ static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, h
     hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq, e,
                        (int)(e == n_env - 1), 1, (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions,
                        l->aq, (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
-                       (uint64_t)c.env_seed, (int)c.env_done_period, hs);
+                       (uint64_t)c.env_seed, (int)c.env_done_period, hs, (unsigned*)nullptr, 0);
     DRA_LAUNCH_CHECK();
   }
   return DRA_OK;

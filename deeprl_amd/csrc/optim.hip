@@ -512,8 +512,11 @@ struct LatePlan {
   int64_t stride4;
   int32_t n_slabs, fold_blocks, n_prior;   // n_prior: partials already written by earlier launches ([0, n_prior))
 };
-constexpr int kLateSlabsPerThread = 16;    // n_slabs <= 64 (4 groups) / 256 (16 groups)
 constexpr int kLateMaxFoldBlocks = 256;    // one polling thread per fold workgroup
+constexpr int kLateNV = 3;                 // float4 per thread of a plain workgroup: with the fold workgroups the grid stays
+                                           // under the 4-per-CU resident limit of the update's 224 CUs (r03b: 949 workgroups at
+                                           // 2 float4 ran 896 + 53 and took 17 us)
+template <int NG> struct LateFold { static constexpr int SPT = NG == 4 ? 16 : 10; };   // slabs per thread: <= 64 / <= 160 slabs
 
 // fixed-order reduction: thread t sums prior partials t, t + 256, ... (plain loads, requested by the caller BEFORE the wait:
 // `pre`), then the fold workgroups' published sums (thread t < fold_blocks waits for slot t); lanes by butterfly, waves
@@ -556,12 +559,15 @@ __device__ __forceinline__ float late_clip_coef(double pre, double* __restrict__
   return s_coef;
 }
 
-template <int OPT, int NG>   // OPT: 0 = RMSprop, 1 = Adam;  NG: slab groups of a fold workgroup (4 or 16)
+// OPT: 0 = RMSprop, 1 = Adam;  NG: slab groups of a fold workgroup (4 or 16);  NPT: earlier partials per thread (4: <= 1024)
+template <int OPT, int NG, int NPT>
 __global__ void __launch_bounds__(256)
 late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict__ partials, float* __restrict__ p,
                  float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ p_copy, const StepHyper hp,
                  float* __restrict__ out_norm, int* __restrict__ timeout_flag) {
   constexpr int EPB = 256 / NG;            // float4 elements per fold workgroup
+  constexpr int SPT = LateFold<NG>::SPT;
+  constexpr int kStepNV = kLateNV;         // (shadows the two-launch kernels' constant)
   __shared__ float4 s_fold[NG][EPB + 1];
   __shared__ float s_hyper[2];
   const int tid = threadIdx.x, bid = blockIdx.x;
@@ -574,10 +580,10 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
 #pragma unroll
   for (int v = 0; v < kStepNV; ++v) gi[v] = -1;
   DRA_STAMP(TR_STEP, 0);
-  // the earlier launches' partials: plain loads, in flight with everything else (16 per thread covers dra_norm_partials_max)
-  double pv[16];
+  // the earlier launches' partials: plain loads, in flight with everything else
+  double pv[NPT];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
+  for (int u = 0; u < NPT; ++u) {
     const int i = tid + 256 * u;
     pv[u] = partials[i < lp.n_prior ? i : (lp.n_prior > 0 ? lp.n_prior - 1 : 0)];
   }
@@ -587,16 +593,16 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
     const int64_t ic = i < lp.fold_count4 ? i : lp.fold_count4 - 1;
     if (tid < EPB) { P[0] = p4[ic]; S[0] = s14[ic]; A[0] = s24[ic]; }
     const int ns = lp.n_slabs;
-    float4 t[kLateSlabsPerThread];
+    float4 t[SPT];
 #pragma unroll
-    for (int u = 0; u < kLateSlabsPerThread; ++u) {
+    for (int u = 0; u < SPT; ++u) {
       const int s = g + NG * u;
       t[u] = lp.slabs[(int64_t)(s < ns ? s : 0) * lp.stride4 + ic];
     }
     __builtin_amdgcn_sched_barrier(0);
     float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 0; u < kLateSlabsPerThread; ++u)
+    for (int u = 0; u < SPT; ++u)
       if (g + NG * u < ns) add4(pp, t[u]);
     s_fold[g][el] = pp;
     __syncthreads();
@@ -634,7 +640,7 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
   }
   double pre = 0.0;
 #pragma unroll
-  for (int u = 0; u < 16; ++u) pre += (tid + 256 * u < lp.n_prior) ? pv[u] : 0.0;
+  for (int u = 0; u < NPT; ++u) pre += (tid + 256 * u < lp.n_prior) ? pv[u] : 0.0;
   DRA_STAMP(TR_STEP, 2);
   const float coef = late_clip_coef(pre, partials, lp.n_prior, lp.fold_blocks, hp.max_norm, out_norm, timeout_flag);
   [[maybe_unused]] const float oma = 1.f - hp.a, omb2 = 1.f - hp.b2;
@@ -681,11 +687,11 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
   DRA_STAMP_END(TR_STEP);
 }
 
-static int late_groups(int n_slabs) { return n_slabs <= 4 * kLateSlabsPerThread ? 4 : 16; }
+static int late_groups(int n_slabs) { return n_slabs <= 4 * LateFold<4>::SPT ? 4 : 16; }
 
-// Workgroups of the late-fold launch that fold (and publish a partial): 64 float4 each for <= 64 slabs, 16 for <= 256.
+// Workgroups of the late-fold launch that fold (and publish a partial): 64 float4 each for <= 64 slabs, 16 for <= 160.
 DRA_API int dra_clip_step_late_blocks(const dra_fold_seg* seg, int* fold_blocks) {
-  if (!seg || !fold_blocks || seg->count < 4 || (seg->count & 3) || seg->n_slabs < 1 || seg->n_slabs > 16 * kLateSlabsPerThread)
+  if (!seg || !fold_blocks || seg->count < 4 || (seg->count & 3) || seg->n_slabs < 1 || seg->n_slabs > 16 * LateFold<16>::SPT)
     return DRA_EINVAL;
   const int epb = 256 / late_groups(seg->n_slabs);
   const int64_t nb = ((seg->count >> 2) + epb - 1) / epb;
@@ -717,19 +723,21 @@ DRA_API int dra_clip_step_late(float* param, float* grad, float* state1, float* 
   lp.stride4 = seg->slab_stride >> 2; lp.n_slabs = seg->n_slabs; lp.n_prior = n_prior;
   lp.fold_blocks = fold_blocks;
   if (lp.n_prior + lp.fold_blocks > dra_norm_partials_max()) return DRA_EINVAL;
-  const int64_t plain = (lp.n4 - lp.fold_count4 + 256 * kStepNV - 1) / (256 * kStepNV);
+  const int64_t plain = (lp.n4 - lp.fold_count4 + 256 * kLateNV - 1) / (256 * kLateNV);
   const int64_t blocks = lp.fold_blocks + plain;
   if (blocks > 0x7fffffff) return DRA_EINVAL;
   StepHyper hp;
   memset(&hp, 0, sizeof(hp));
   hp.max_norm = max_norm; hp.lr = hyper[0]; hp.a = hyper[1]; hp.eps = hyper[2]; hp.b2 = hyper[3];
   hp.centered = centered; hp.step_dev = step_dev;
-  const bool adam = optimizer == DRA_OPT_ADAM, wide = late_groups(seg->n_slabs) == 16;
-#define DRA_LATE_LAUNCH(OPT, NG)                                                                                          \
-  hipLaunchKernelGGL((late_step_kernel<OPT, NG>), dim3((unsigned)blocks), dim3(256), 0, dra_stream(stream), grad, lp, partials, \
+  const bool adam = optimizer == DRA_OPT_ADAM, wide = late_groups(seg->n_slabs) == 16, many = n_prior > 1024;
+#define DRA_LATE_LAUNCH(OPT, NG, NPT)                                                                                          \
+  hipLaunchKernelGGL((late_step_kernel<OPT, NG, NPT>), dim3((unsigned)blocks), dim3(256), 0, dra_stream(stream), grad, lp, partials, \
                      param, state1, state2, param_copy, hp, out_norm, timeout_flag)
-  if (adam) { if (wide) DRA_LATE_LAUNCH(1, 16); else DRA_LATE_LAUNCH(1, 4); }
-  else { if (wide) DRA_LATE_LAUNCH(0, 16); else DRA_LATE_LAUNCH(0, 4); }
+#define DRA_LATE_NG(OPT, NPT) do { if (wide) DRA_LATE_LAUNCH(OPT, 16, NPT); else DRA_LATE_LAUNCH(OPT, 4, NPT); } while (0)
+  if (adam) { if (many) DRA_LATE_NG(1, 16); else DRA_LATE_NG(1, 4); }
+  else { if (many) DRA_LATE_NG(0, 16); else DRA_LATE_NG(0, 4); }
+#undef DRA_LATE_NG
 #undef DRA_LATE_LAUNCH
   DRA_LAUNCH_CHECK();
   return DRA_OK;

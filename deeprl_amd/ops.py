@@ -412,7 +412,8 @@ VAR_COOP_OPT = 65536
 VAR_IDX_PREFETCH = 131072
 VAR_WGRAD_ACC = 262144
 VAR_LATE_FOLD = 524288
-VAR_ALL = 1048575
+VAR_ACTOR_MEGA = 1048576
+VAR_ALL = 2097151
 
 
 def set_tuning(mask):

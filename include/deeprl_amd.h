@@ -203,6 +203,10 @@ int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* 
                                    * from the kernels that write each gradient, conv3 / conv2 slabs are folded by spare
                                    * workgroups of the NEXT layer's backward launch, conv1's by the first workgroups of the
                                    * optimizer launch (dra_clip_step_late) */
+#define DRA_VAR_ACTOR_MEGA 1048576 /* learner (with ACTOR_RING + ACTOR_FUSED_CONV1): an env step of the device actor -- head of the
+                                   * previous step, environment step, conv1, conv2, conv3, fc4 -- is ONE launch whose workgroups
+                                   * hand their outputs over through arrival counters (4 launches per agent step + the tail
+                                   * kernel instead of 17): weights are prefetched before a layer's input exists */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */

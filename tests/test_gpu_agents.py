@@ -1,5 +1,6 @@
 """GPU parity tests at the agent level: the drop-in surface (Config / Agent.step()) on the HIP
 kernels against fixtures produced by the reference's own agents (tests/golden/make_golden.py)."""
+import os
 import random
 
 import numpy as np
@@ -228,6 +229,25 @@ def test_ppo_optimize_matches_reference(golden, dra, tag, monkeypatch):
     _cmp_params(agent.network, g, k + "final_", 2e-5, 2e-6)
 
 
+def _record_parity(case, **errs):
+    """Appends the measured maxima of a parity check to gpurun_out/parity_errors.jsonl (merged back from the GPU box;
+    tools/parity_summary.py turns it into profiles/r03_parity_errors.json).  Never fails a test."""
+    try:
+        import json
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_errors.jsonl"), "a") as f:
+            f.write(json.dumps(dict(case=case, **{k: float(v) for k, v in errs.items()})) + "\n")
+    except Exception:
+        pass
+
+
+def _rel(a, b, floor):
+    """max |a - b| / max(|b|, floor): the relative error with an absolute floor for values near zero."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))) if a.size else 0.0
+
+
 @pytest.mark.parametrize("double_q,variant", [(False, 0), (False, 1), (False, 7), (False, 127), (True, 127), (True, 511),
                                               (False, 511 + 65536), (True, 511 + 65536),   # + COOP_OPT: one-launch clip + optimizer
                                               (False, 511 + 262144), (True, 511 + 262144),   # + WGRAD_ACC: 8 / 8 / 40 slabs
@@ -281,14 +301,23 @@ def test_fused_learner_matches_oracle(dra, double_q, variant):
         norm, grads = N.clip_grad_norm(list(grads), 5)
         learner.update(idx, use_graph=True)
         learner.synchronize()
-        np.testing.assert_allclose(learner.q.cpu().numpy(), q.detach().numpy(), rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(learner.delta.cpu().numpy(), delta.detach().numpy(), rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(learner.loss.item(), loss.item(), rtol=2e-5)
-        np.testing.assert_allclose(learner.norm.item(), float(norm), rtol=5e-5)
+        # north_star's bar (fp32 within 1e-5): action values and TD errors at rtol 1e-5 with an absolute floor of
+        # 1e-5 x max|q| (a TD error is a difference of action values of that scale), loss and gradient norm at 1e-5 relative
+        # (measured: ~1e-7, profiles/r03_parity_errors.json)
+        scale = max(1.0, float(q.detach().abs().max()))
+        _record_parity("fused_learner[%s-%d] update %d" % (double_q, variant, it),
+                       q=_rel(learner.q.cpu().numpy(), q.detach().numpy(), scale), td=_rel(learner.delta.cpu().numpy(), delta.detach().numpy(), scale),
+                       loss=abs(learner.loss.item() - loss.item()) / abs(loss.item()), norm=abs(learner.norm.item() - float(norm)) / float(norm))
+        np.testing.assert_allclose(learner.q.cpu().numpy(), q.detach().numpy(), rtol=1e-5, atol=1e-5 * scale)
+        np.testing.assert_allclose(learner.delta.cpu().numpy(), delta.detach().numpy(), rtol=1e-5, atol=1e-5 * scale)
+        np.testing.assert_allclose(learner.loss.item(), loss.item(), rtol=1e-5)
+        np.testing.assert_allclose(learner.norm.item(), float(norm), rtol=1e-5)
         with torch.no_grad():
             for k, g in zip(names, grads):
                 newp, sq[k], ga[k] = N.rmsprop_step(p[k], g, sq[k], ga[k], 0.00025, 0.95, 0.01, True)
                 p[k].copy_(newp)
+    _record_parity("fused_learner[%s-%d] params after 4 updates" % (double_q, variant),
+                   params_abs=max(float(np.abs(v.cpu().numpy() - p[k].detach().numpy()).max()) for k, v in net.state_dict().items()))
     for k, v in net.state_dict().items():
         np.testing.assert_allclose(v.cpu().numpy(), p[k].detach().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
     # eager (non-graph) path gives the same numbers as the replayed graph
@@ -303,7 +332,7 @@ def test_fused_learner_matches_oracle(dra, double_q, variant):
         xs = torch.from_numpy(NUM.image_normalize_sync(frames[slots].reshape(1, 4, 84, 84)))
         pp = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()}
         q1 = N.vanilla_head(pp, N.nature_conv_body(pp, xs)).numpy()[0]
-        np.testing.assert_allclose(learner.actor_q.cpu().numpy(), q1, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(learner.actor_q.cpu().numpy(), q1, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(q1).max())))
         want = rnd if dice < eps else int(np.argmax(q1))
         stored = d.ops._wrap_device_pointer(ring.pointers()[1], cap, torch.int64)[newest].item()
         assert stored == want
@@ -363,7 +392,7 @@ _ASYNC_RESULTS = {}
 
 
 @pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559, 4607, 12799, 29183, 61951, 61951 + 65536, 61951 + 131072,
-                                     61951 + 65536 + 131072])
+                                     61951 + 65536 + 131072, 61951 + 1048576, 61951 + 131072 + 1048576])   # + ACTOR_MEGA
 def test_fused_step_async_pipeline(dra, variant):
     """async_actor=True pipeline (actor one agent step ahead on its own stream, double-buffered actor
     parameters when variant has DRA_VAR_ACTOR_PARAMS): the transitions it feeds are the documented counter-hash
@@ -405,7 +434,10 @@ def test_fused_step_async_pipeline(dra, variant):
     # ... and the ring-direct update (DRA_VAR_RING_DIRECT = 32768: conv1 and the head read the replay ring, no gather)
     # ... and the cooperative one-launch clip + optimizer (DRA_VAR_COOP_OPT = 65536: same decomposition and reduction order
     # as the two launches) and the prefetched minibatch indices (DRA_VAR_IDX_PREFETCH = 131072: same indices, another route)
-    for other in (255, 1023, 2047, 2559, 4607, 12799, 29183, 61951, 61951 + 65536, 61951 + 131072, 61951 + 65536 + 131072):
+    # ... and the actor's env step as ONE launch (DRA_VAR_ACTOR_MEGA = 1048576: the four launches' arithmetic in the same order,
+    # outputs handed over through arrival counters inside the launch)
+    for other in (255, 1023, 2047, 2559, 4607, 12799, 29183, 61951, 61951 + 65536, 61951 + 131072, 61951 + 65536 + 131072,
+                  61951 + 1048576, 61951 + 131072 + 1048576):
         if 127 in _ASYNC_RESULTS and other in _ASYNC_RESULTS:
             assert np.array_equal(_ASYNC_RESULTS[127][0], _ASYNC_RESULTS[other][0])
             assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
@@ -417,15 +449,18 @@ def test_fused_step_async_pipeline(dra, variant):
                                               (258559, "normal", 4000), (258559, "normal", 160), (258559, "bench", 4000),
                                               # round 3: + WGRAD_ACC (262144), + LATE_FOLD (524288) on the round-2 default 193023
                                               (455167, "normal", 4000), (979455, "normal", 4000), (979455, "normal", 160),
-                                              (979455, "bench", 4000)])
+                                              (979455, "bench", 4000),
+                                              # + ACTOR_MEGA (1048576): one launch per env step of the actor
+                                              (1241599, "normal", 4000), (1241599, "normal", 160), (1241599, "bench", 4000),
+                                              (1765887, "normal", 4000), (1765887, "bench", 4000), (2028031, "normal", 4000)])
 def test_async_pipeline_matches_schedule_oracle(dra, variant, init, cap):
     """THE BENCHMARKED CONFIGURATION against the oracle: DQNLearnerBench(async_actor=True) with the default kernel
     variant (bench.py's: CU partition, pipelined gather, actor parameter ring, fused actor conv1) for 14 agent steps vs
     oracle/async_schedule_oracle.py, the CPU restatement of the pipeline's schedule (actor step t+1 on the parameters
     after update t-1, minibatch t gathered between actor steps t and t+1, the actor's own RandomState).
 
-    Per step: TD errors (rtol 1e-4, atol 1e-5 x max|q|: a TD error is a difference of action values of that scale),
-    loss at 2e-5 relative, parameters after the step at rtol 1e-5 / atol 2e-6 (weights are O(0.05)).  Every stored
+    Per step: TD errors (rtol 1e-5, atol 1e-5 x max|q|: a TD error is a difference of action values of that scale),
+    loss at 1e-5 relative, parameters after the step at rtol 1e-5 / atol 2e-6 (weights are O(0.05)).  Every stored
     action must equal the oracle's (a mismatch is tolerated only where the oracle's own top-2 action values are within
     1e-5: an fp32 near-tie) and the ring frames are compared bit for bit.
 
@@ -494,8 +529,11 @@ def test_async_pipeline_matches_schedule_oracle(dra, variant, init, cap):
         perr = max(float(np.abs(gpu_state[k]["params"][n].numpy() - orc.p[n].detach().numpy()).max()) for n in orc.names)
         diag.append((k, "%.1e" % orc.relu_margin, "%.1e" % float(np.abs(gpu_delta[k] - delta).max()), "%.1e" % perr))
         msg = "step %d (step, relu margin, max TD err, max param err): %s" % (k, diag)
-        np.testing.assert_allclose(gpu_delta[k], delta, rtol=1e-4 * f, atol=1e-5 * scale * f, err_msg="TD errors, " + msg)
-        np.testing.assert_allclose(0.5 * float(np.mean(gpu_delta[k].astype(np.float64) ** 2)), loss, rtol=2e-5 * f,
+        _record_parity("schedule_oracle[%d-%s-%d] step %d%s" % (variant, init, cap, k, " (ambiguous ReLU gate)" if ambiguous else ""),
+                       td=_rel(gpu_delta[k], delta, scale), loss=abs(0.5 * float(np.mean(gpu_delta[k].astype(np.float64) ** 2)) - loss) / abs(loss),
+                       params_abs=perr, relu_margin=orc.relu_margin)
+        np.testing.assert_allclose(gpu_delta[k], delta, rtol=1e-5 * f, atol=1e-5 * scale * f, err_msg="TD errors, " + msg)
+        np.testing.assert_allclose(0.5 * float(np.mean(gpu_delta[k].astype(np.float64) ** 2)), loss, rtol=1e-5 * f,
                                    err_msg="loss, " + msg)
         for n in orc.names:
             np.testing.assert_allclose(gpu_state[k]["params"][n].numpy(), orc.p[n].detach().numpy(), rtol=1e-5 * f,
