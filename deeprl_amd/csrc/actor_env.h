@@ -147,3 +147,7 @@ int dra_actor_env_step_mega(const void* frames, const int64_t* slot_field_dev, c
                             const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
                             const float* w4, const float* b4, float* y1, float* y2_planes, float* y3_planes, float* h4,
                             double u8_coef, const ActorFuse* f, unsigned* flags, int* timeout_flag, void* stream);
+// ... and its default form: conv1 (fused head / environment step) and conv2 keep their launches, conv3 + fc4 share one
+// (flags[2] = conv3's arrival counter)
+int dra_actor_c3fc4(const float* y2_planes, const float* w3, const float* b3, const float* w4, const float* b4, float* y3_planes,
+                    float* h4, unsigned* flags, int* timeout_flag, void* stream);

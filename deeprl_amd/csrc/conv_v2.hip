@@ -20,6 +20,7 @@
 // oracle only in the order of the four K-quarters.
 #include "actor_env.h"
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -711,7 +712,7 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Ar
 // grid (position tiles, (OC / 32) * KZO), 512 threads.
 // (bx, by) = blockIdx of a plain launch; COH: the input planes come from, and the output planes go to, other workgroups of
 // the SAME launch (the actor's one-launch env step): weights first, then the wait, then agent-scope loads / stores
-template <class G, int KZI, int KZO, bool COH>
+template <class G, int KZI, int KZO, bool COH, bool CIN = COH>
 __device__ __forceinline__ void conv_b1_split_body(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ wt,
                                                    const float* __restrict__ bias, float* __restrict__ y, int act, const int bx,
                                                    const int by, const MegaSync ms = MegaSync()) {
@@ -760,7 +761,7 @@ __device__ __forceinline__ void conv_b1_split_body(const float* __restrict__ x0,
   const int rsub = lane / LR, iw = lane % LR;
   const int iwc = min(iw, G::H - 1);
   const int col = lds_col<G>(iwc);
-  if constexpr (COH) {
+  if constexpr (CIN) {
     __builtin_amdgcn_sched_barrier(0);   // the weight / bias loads above are in flight while this workgroup waits
     mega_wait(ms);
   }
@@ -771,8 +772,8 @@ __device__ __forceinline__ void conv_b1_split_body(const float* __restrict__ x0,
 #pragma unroll
     for (int q = 0; q < LPT; ++q) {
       const int64_t oo = o + (int64_t)min(RP * q + rsub, nrows - 1) * G::H;
-      raw0[ci * LPT + q] = mega_ld<COH>(x0 + oo);
-      if constexpr (KZI == 2) raw1[ci * LPT + q] = mega_ld<COH>(x1 + oo);
+      raw0[ci * LPT + q] = mega_ld<CIN>(x0 + oo);
+      if constexpr (KZI == 2) raw1[ci * LPT + q] = mega_ld<CIN>(x1 + oo);
     }
   }
 #pragma unroll
@@ -892,32 +893,10 @@ constexpr int kMegaC1 = V2Tile<VG1, 1>::TPG, kMegaC2 = VG2::TPS * (VG2::OC / 32)
 constexpr int kMegaFc = 512 / 8;
 constexpr int kMegaBlocks = kMegaC1 + 1 + kMegaC2 + kMegaC3 + kMegaFc;
 
-__global__ void __launch_bounds__(512) actor_mega_kernel(const ActorMegaArgs m) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int b = blockIdx.x;
-  if (b <= kMegaC1) {
-    MegaSync ms;
-    ms.done = m.flags;
-    conv_fwd_v2_body<VG1, true, 1, 8, true, true>(m.c1, m.f, b, 0, 0, b == kMegaC1, ms);
-    return;
-  }
-  b -= kMegaC1 + 1;
-  if (b < kMegaC2) {
-    MegaSync ms;
-    ms.wait = m.flags; ms.wait_target = kMegaC1; ms.done = m.flags + 1; ms.timeout_flag = m.timeout_flag;
-    conv_b1_split_body<VG2, 1, 2, true>(m.y1, nullptr, m.w2, m.b2, m.y2p, DRA_ACT_NONE, b % VG2::TPS, b / VG2::TPS, ms);
-    return;
-  }
-  b -= kMegaC2;
-  if (b < kMegaC3) {
-    MegaSync ms;
-    ms.wait = m.flags + 1; ms.wait_target = kMegaC2; ms.done = m.flags + 2; ms.timeout_flag = m.timeout_flag;
-    conv_b1_split_body<VG3, 2, 2, true>(m.y2p, m.y2p + VG2::OC * VG2::P, m.w3, m.b3, m.y3p, DRA_ACT_NONE, b % VG3::TPS, b / VG3::TPS, ms);
-    return;
-  }
-  b -= kMegaC3;
-  // ---- fc4: h4[row] = relu(b4[row] + <W4[row], relu(x0 + x1)>), one wave per row, the row's weights requested BEFORE the
-  // wait (same per-lane products and butterfly as actor_fc4_planes_lds_kernel)
+// fc4 role of the actor's fused launches: h4[row] = relu(b4[row] + <W4[row], relu(x0 + x1)>), one wave per row, the row's
+// weights requested BEFORE the wait for conv3's two partial planes (same per-lane products and butterfly as
+// actor_fc4_planes_lds_kernel: bit-identical); b = workgroup index within the role (8 rows each)
+__device__ __forceinline__ void mega_fc4_role(const ActorMegaArgs& m, const int b, float* __restrict__ lds) {
   constexpr int I = VG3::OC * VG3::P, NV = I / 4, R = (NV + 63) / 64;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = b * 8 + wave;
@@ -962,6 +941,49 @@ __global__ void __launch_bounds__(512) actor_mega_kernel(const ActorMegaArgs m) 
   }
 }
 
+__global__ void __launch_bounds__(512) actor_mega_kernel(const ActorMegaArgs m) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int b = blockIdx.x;
+  if (b <= kMegaC1) {
+    MegaSync ms;
+    ms.done = m.flags;
+    conv_fwd_v2_body<VG1, true, 1, 8, true, true>(m.c1, m.f, b, 0, 0, b == kMegaC1, ms);
+    return;
+  }
+  b -= kMegaC1 + 1;
+  if (b < kMegaC2) {
+    MegaSync ms;
+    ms.wait = m.flags; ms.wait_target = kMegaC1; ms.done = m.flags + 1; ms.timeout_flag = m.timeout_flag;
+    conv_b1_split_body<VG2, 1, 2, true>(m.y1, nullptr, m.w2, m.b2, m.y2p, DRA_ACT_NONE, b % VG2::TPS, b / VG2::TPS, ms);
+    return;
+  }
+  b -= kMegaC2;
+  if (b < kMegaC3) {
+    MegaSync ms;
+    ms.wait = m.flags + 1; ms.wait_target = kMegaC2; ms.done = m.flags + 2; ms.timeout_flag = m.timeout_flag;
+    conv_b1_split_body<VG3, 2, 2, true>(m.y2p, m.y2p + VG2::OC * VG2::P, m.w3, m.b3, m.y3p, DRA_ACT_NONE, b % VG3::TPS, b / VG3::TPS, ms);
+    return;
+  }
+  b -= kMegaC3;
+  mega_fc4_role(m, b, lds);
+}
+
+// conv3 + fc4 only (DRA_ACTOR_MEGA_MODE=1, the default): conv1 and conv2 keep their own launches -- a hand-over through memory
+// costs about what a launch boundary does (stores acknowledged, the arrival count, the poll: ~2.4 us against ~2 us), so
+// fusing them gains nothing (measured: all four layers in one launch -1.6 %, profiles/r03c_ab.jsonl); what pays is fc4's
+// 6.4 MB of weights arriving while conv3 computes.  grid = 8 conv3 workgroups + 64 fc4 workgroups.
+__global__ void __launch_bounds__(512) actor_c3fc4_kernel(const ActorMegaArgs m) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int b = blockIdx.x;
+  if (b < kMegaC3) {
+    MegaSync ms;
+    ms.done = m.flags + 2;
+    conv_b1_split_body<VG3, 2, 2, true, false>(m.y2p, m.y2p + VG2::OC * VG2::P, m.w3, m.b3, m.y3p, DRA_ACT_NONE, b % VG3::TPS, b / VG3::TPS, ms);
+    return;
+  }
+  mega_fc4_role(m, b - kMegaC3, lds);
+}
+
 // Library-internal (actor_env.h).  flags: 3 zeroed arrival counters owned by this env step (the agent step's tail kernel
 // zeroes them again); everything else as dra_conv1_fwd_actor_fused + dra_conv_b1_split x 2 + the fc4 GEMV.
 int dra_actor_env_step_mega(const void* frames, const int64_t* slot_field_dev, const int32_t* stack_age_field_dev,
@@ -993,6 +1015,25 @@ int dra_actor_env_step_mega(const void* frames, const int64_t* slot_field_dev, c
   constexpr size_t bytes = m3 > xfc ? m3 : xfc;
   static_assert(bytes <= 64 * 1024, "default dynamic LDS limit");
   hipLaunchKernelGGL(actor_mega_kernel, dim3(kMegaBlocks), dim3(512), bytes, dra_stream(stream), m);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// Library-internal (actor_env.h): conv3 (from conv2's two partial planes, written by the previous launch) + the fc4 GEMV as
+// one launch; flags[2] = conv3's arrival counter, zero at launch.
+int dra_actor_c3fc4(const float* y2_planes, const float* w3, const float* b3, const float* w4, const float* b4, float* y3_planes,
+                    float* h4, unsigned* flags, int* timeout_flag, void* stream) {
+  if (!y2_planes || !w3 || !b3 || !w4 || !b4 || !y3_planes || !h4 || !flags || !timeout_flag) return DRA_EINVAL;
+  ActorMegaArgs m;
+  memset(&m, 0, sizeof(m));
+  m.w3 = w3; m.b3 = b3; m.w4 = w4; m.b4 = b4;
+  m.y2p = const_cast<float*>(y2_planes); m.y3p = y3_planes; m.h4 = h4; m.flags = flags; m.timeout_flag = timeout_flag;
+  constexpr size_t img3 = (size_t)(VG3::C / 2) * V2Tile<VG3, 1>::CS * sizeof(float);
+  constexpr size_t red = (size_t)8 * 16 * 64 * sizeof(float);
+  constexpr size_t xfc = (size_t)VG3::OC * VG3::P * sizeof(float);
+  constexpr size_t m2 = img3 > red ? img3 : red;
+  constexpr size_t bytes = m2 > xfc ? m2 : xfc;
+  hipLaunchKernelGGL(actor_c3fc4_kernel, dim3(kMegaC3 + kMegaFc), dim3(512), bytes, dra_stream(stream), m);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

@@ -2003,11 +2003,29 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   f.head_kind = c.head_kind; f.n_atoms = c.n_atoms; f.atoms = l->atoms; f.pre = l->alog;
   // DRA_VAR_ACTOR_MEGA: conv1 (+ head / environment step), conv2, conv3 and fc4 of an env step as ONE launch (conv_v2.hip)
   const bool mega = (l->variant & DRA_VAR_ACTOR_MEGA) && actor_ksplit() && l->aflags;
+  static int mega_mode = -1;   // DRA_ACTOR_MEGA_MODE: 1 (default) = [conv1] [conv2] [conv3 + fc4], 0 = all four layers in one launch
+  if (mega_mode < 0) { const char* ev = getenv("DRA_ACTOR_MEGA_MODE"); mega_mode = ev ? atoi(ev) : 1; }
   for (int e = 0; e < n_env; ++e) {
     const int64_t* slot_field = reinterpret_cast<const int64_t*>(l->aring_dev + offsetof(dra_dqn_step_params, slot)) + e;
     const int32_t* age_field = reinterpret_cast<const int32_t*>(l->aring_dev + offsetof(dra_dqn_step_params, stack_age)) + e;
     f.mode = e == 0 ? 1 : 2;
     f.e = e;
+    if (mega && mega_mode == 1) {
+      if ((rc = dra_conv1_fwd_actor_fused(frames, slot_field, age_field, l->aring_seq, kAringSlots, (int64_t)kAprmStride, c.ring_capacity,
+                                          e == 0 ? l->pend_frame : nullptr, P + o[P_W1], P + o[P_B1], l->ay1, c.u8_coef,
+                                          DRA_ACT_RELU, &f, s)))
+        return rc;
+      if ((rc = dra_conv_b1_split(2, l->ay1, nullptr, P + o[P_W2], P + o[P_B2], l->ay2p, s))) return rc;
+      if ((rc = dra_actor_c3fc4(l->ay2p, P + o[P_W3], P + o[P_B3], P + o[P_W4], P + o[P_B4], l->ay3p, l->ah4, l->aflags + 4 * e,
+                                l->coop_flag, s)))
+        return rc;
+      if (dist) {
+        hipLaunchKernelGGL(actor_dist_gemv_kernel, dim3((l->n_out + 3) / 4), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH],
+                           P + o[P_BH], l->n_out, l->alog);
+        DRA_LAUNCH_CHECK();
+      }
+      continue;
+    }
     if (mega) {
       if ((rc = dra_actor_env_step_mega(frames, slot_field, age_field, l->aring_seq, kAringSlots, (int64_t)kAprmStride, c.ring_capacity,
                                         e == 0 ? l->pend_frame : nullptr, P + o[P_W1], P + o[P_B1], P + o[P_W2], P + o[P_B2],

@@ -298,6 +298,10 @@ def test_fused_learner_matches_oracle(dra, double_q, variant):
                                torch.from_numpy(mk.astype(np.float32)), 0.99, q_next_online=qno)
         loss = L.dqn_reduce(delta)
         grads = torch.autograd.grad(loss, [p[k] for k in names])
+        # the gradient norm of the ORACLE's fp32 gradients, accumulated in fp64: torch's own fp32 norm of 1.7M elements
+        # (clip_grad_norm_, what N.clip_grad_norm restates) carries ~3e-5 of summation noise itself (measured,
+        # profiles/r03_parity_errors.json), the device accumulates across lanes in fp64
+        norm64 = float(np.sqrt(sum(float((g.double() ** 2).sum()) for g in grads)))
         norm, grads = N.clip_grad_norm(list(grads), 5)
         learner.update(idx, use_graph=True)
         learner.synchronize()
@@ -307,11 +311,13 @@ def test_fused_learner_matches_oracle(dra, double_q, variant):
         scale = max(1.0, float(q.detach().abs().max()))
         _record_parity("fused_learner[%s-%d] update %d" % (double_q, variant, it),
                        q=_rel(learner.q.cpu().numpy(), q.detach().numpy(), scale), td=_rel(learner.delta.cpu().numpy(), delta.detach().numpy(), scale),
-                       loss=abs(learner.loss.item() - loss.item()) / abs(loss.item()), norm=abs(learner.norm.item() - float(norm)) / float(norm))
+                       loss=abs(learner.loss.item() - loss.item()) / abs(loss.item()), norm_vs_fp64_sum=abs(learner.norm.item() - norm64) / norm64,
+                       norm_vs_torch_fp32=abs(learner.norm.item() - float(norm)) / float(norm), torch_fp32_vs_fp64_sum=abs(float(norm) - norm64) / norm64)
         np.testing.assert_allclose(learner.q.cpu().numpy(), q.detach().numpy(), rtol=1e-5, atol=1e-5 * scale)
         np.testing.assert_allclose(learner.delta.cpu().numpy(), delta.detach().numpy(), rtol=1e-5, atol=1e-5 * scale)
         np.testing.assert_allclose(learner.loss.item(), loss.item(), rtol=1e-5)
-        np.testing.assert_allclose(learner.norm.item(), float(norm), rtol=1e-5)
+        np.testing.assert_allclose(learner.norm.item(), norm64, rtol=1e-5)
+        np.testing.assert_allclose(learner.norm.item(), float(norm), rtol=5e-5)    # torch's fp32 summation of the same gradients
         with torch.no_grad():
             for k, g in zip(names, grads):
                 newp, sq[k], ga[k] = N.rmsprop_step(p[k], g, sq[k], ga[k], 0.00025, 0.95, 0.01, True)
