@@ -16,7 +16,8 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W   prints ONE J
     ("source": "hip_events"; the rocprofv3 summary of the same command is committed under profiles/).
   * cpu_baseline: the CPU oracle (port of the reference path on torch-CPU fp32) on a bounded
     sample, rank 0 / N=1 only: `value` with ONE thread (the reference's set_one_thread(), examples.py:623),
-    `all_cores` with torch.set_num_threads(nproc).
+    `multi_thread` = the best of an 8 / 16 / 32-thread sweep of the same learner, `all_cores_replicas` = 64 single-thread
+    learners side by side (how the CPU path scales on a host).
   * parity_check: after the timed region, SIX more agent steps of the SAME pipelined configuration are replayed through
     the CPU oracle, chained (the oracle carries its own parameters / optimizer state from step to step; the minibatch each
     update consumed comes from the learner): loss and every parameter at 1e-5 per step, the worst is reported.  Outside the
@@ -135,19 +136,29 @@ def cpu_baseline(seconds=15.0, ring=20_000, worker=False):
         torch.set_num_threads(threads_before)
         return {"updates": n, "seconds": dt}
     nproc = os.cpu_count() or 1
-    torch.set_num_threads(nproc)
-    one()                                   # one warm-up only: with hundreds of threads a single update can take seconds
-    n_all, t1 = 0, time.time()
-    while n_all < 1 or time.time() - t1 < 4.0:
+    # one learner on several threads: the best of a small sweep.  (torch.set_num_threads(nproc) on this host's 256 hardware
+    # threads is an oversubscription artefact, not a baseline: 0.08 updates/s in round 2 -- a batch-32 NatureConv update has no
+    # work for that many threads.)
+    sweep = {}
+    for nt in (8, 16, 32):
+        if nt > nproc:
+            continue
+        torch.set_num_threads(nt)
         one()
-        n_all += 1
-    dt_all = time.time() - t1
+        k, t1 = 0, time.time()
+        while k < 1 or time.time() - t1 < 2.0:
+            one()
+            k += 1
+        sweep[nt] = k / (time.time() - t1)
+    best_nt = max(sweep, key=sweep.get) if sweep else 1
+    n_all, dt_all = (sweep[best_nt], 1.0) if sweep else (n / dt, 1.0)
     torch.set_num_threads(threads_before)
     return {"value": n / dt, "unit": "gradient-updates/sec", "cores": 1, "kind": "port",
             "sample": "%d DQN updates (B=32, 84x84x4, %d-frame ring) in %.1f s, torch-CPU fp32 oracle, 1 thread "
                       "(the reference's set_one_thread()); kind 'port': the reference tree is not on the GPU box" % (n, ring, dt),
-            "all_cores": {"value": n_all / dt_all, "cores": nproc,
-                          "sample": "%d updates in %.1f s with torch.set_num_threads(%d)" % (n_all, dt_all, nproc)},
+            "multi_thread": {"value": n_all / dt_all, "cores": best_nt,
+                             "sample": "ONE learner, best of torch.set_num_threads(8 / 16 / 32), 2 s each: %s updates/s"
+                                       % {k: round(v, 1) for k, v in sweep.items()}},
             "all_cores_replicas": cpu_replicas(nproc)}
 
 
@@ -323,7 +334,7 @@ def rocprof_kernel(kernel_group, flops):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats.txt")))
     pat = {"conv2_bwd_x": "ConvDgradOne<ConvGeom<32, 20, 64, 4, 2>", "conv3_bwd_x": "ConvDgradOne<ConvGeom<64, 9, 64, 3, 1>",
-           "conv1_fwd": "conv_fwd_v2_kernel<V2Geom<4, 84, 32, 8, 4>, true, 1, 4>", "rmsprop_step": "rmsprop_step_kernel",
+           "conv1_fwd": "conv_fwd_v2_kernel<V2Geom<4, 84, 32, 8, 4>, true, 1, 4>", "rmsprop_step": "late_step_kernel",
            "grad_norm": "clip_step_kernel<0>"}.get(kernel_group)
     if not files or not pat:
         return None
@@ -496,8 +507,18 @@ def main():
                 parity = {"ok": False, "error": repr(e)}
         roof = bench.roofline(200 if args.steps < 500 else 500)
         roof["source"] = "hip_events (a pair around the kernel on its launch stream, live: includes the launch boundary)"
+        # NOT measured in this process (a profiler cannot run inside it): read from the newest committed summaries of the same
+        # command on a builder box, and labelled so
         roof["rocprofv3"] = rocprof_kernel(roof["kernel"], roof.get("algorithmic_flops"))
+        if roof["rocprofv3"] is not None:
+            roof["rocprofv3"]["source"] = "committed file %s (rocprofv3 --kernel-trace --stats of this command on a builder box)" % roof["rocprofv3"].get("file")
         roof["traffic"] = pmc_traffic(roof["kernel"])
+        roof["traffic_source"] = "committed profiles/r*_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on a builder box)"
+        # the same live measurement with the empty event pair's cost taken off the (kernel + boundary + record) reading:
+        # a LOWER bound of the kernel's duration, hence an upper bound of the fraction -- the truth lies between the two
+        if roof.get("algorithmic_flops") and roof.get("avg_ms") and roof.get("event_pair_empty_ms"):
+            t_low = max(roof["avg_ms"] - roof["event_pair_empty_ms"], 1e-6)
+            roof["frac_event_pair_corrected"] = roof["algorithmic_flops"] / (t_low * 1e-3) / 1e12 / 157.3
         # the update chain owns a CU partition while the device actor runs beside it (lever 5):
         # the kernel is timed on that stream, i.e. on this many of the device's CUs
         roof["stream_cus"] = bench.learner.update_cus or torch.cuda.get_device_properties(0).multi_processor_count

@@ -14,12 +14,16 @@
 #include <stdlib.h>
 #include <type_traits>
 
-static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768 | 131072;
+static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 262144 | 524288 | 1048576;
 // every bit up to DRA_VAR_CU_PARTITION plus ACTOR_RING, ACTOR_FUSED_CONV1, GATHER_ON_UPDATE and RING_DIRECT measured faster
 // on MI355X in same-box A/Bs (profiles/r01b_ab_variants.jsonl, r01d_*, r01f_*, r02y_ab_*, r02zf_ab_*); ACTOR_V3 (512),
 // ACTOR_FUSED_HEAD (1024) and GATHER_IN_GRAPH (2048) measured neutral or slower and stay opt-in; IDX_PREFETCH (131072): conv1_fwd
 // 11.6 -> 10.3 us, +0.6 % (profiles/r02zu_*); COOP_OPT (65536) measured 14 % SLOWER -- a grid barrier of 796 workgroups on one
-// counter costs 24 us on this part (profiles/r02zt_*) -- and stays opt-in as a kept negative result
+// counter costs 24 us on this part (profiles/r02zt_*) -- and stays opt-in as a kept negative result.
+// Round 3 (same-box A/Bs, profiles/r03*_ab*.jsonl): LATE_FOLD (524288: no gradient-norm launch) and ACTOR_MEGA (1048576: conv3 + fc4
+// of the actor's env step as one launch) together +0.5 %, 14 -> 12 launches on the update + actor chains per env step pair;
+// WGRAD_ACC (262144) on conv3 only by default (DRA_WGRAD_ACC_LAYERS = 4): neutral there and 3.5 MB less slab traffic; on conv2 it
+// costs 0.9 us (-1.2 % updates/s) for 6 MB less traffic, on conv1 2 us -- both stay opt-in (DRA_WGRAD_ACC_LAYERS = 6 / 7)
 
 DRA_API int dra_set_tuning(int mask) {
   if (mask < 0) return DRA_EINVAL;
@@ -55,7 +59,7 @@ using WA3 = ConvWgradAcc<G3, 7, 2, 1, 10, 1, false>;
 // layers DRA_VAR_WGRAD_ACC applies to (bit 0 = conv1 ... bit 2 = conv3; DRA_WGRAD_ACC_LAYERS in the environment, read once)
 static int wgrad_acc_layers() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_WGRAD_ACC_LAYERS"); v = e ? (atoi(e) & 7) : 7; }
+  if (v < 0) { const char* e = getenv("DRA_WGRAD_ACC_LAYERS"); v = e ? (atoi(e) & 7) : 4; }
   return v;
 }
 static bool wgrad_acc(int variant, int layer) {

@@ -515,6 +515,58 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   return DRA_OK;
 }
 
+// ---- true resume (BaseAgent.py:24-33 saves weights only): the learner-internal state a bit-exact
+// continuation needs on top of what the host owns (parameters, target, optimizer state, the replay ring).  Call with the
+// learner synchronised, at a step boundary.
+//   dra_dqn_learner_resume_buffer(i)   enumerates the device buffers: the optimizer step count, the actor's rotating
+//                                      parameter copies, the actor parameter-block ring + its device counter, the pending
+//                                      observation, the ring-direct update counter (DRA_EINVAL past the last one);
+//   dra_dqn_learner_resume_counters    the host-side counters of the pipelines (restore != 0: into a FRESH learner of the
+//                                      same configuration, before its first step; all of its events are then unrecorded,
+//                                      which is correct -- nothing is in flight after a load).
+static const struct { const char* name; } kResumeNames[] = {{"opt_step"}, {"pa0"}, {"pa1"}, {"pa2"}, {"pa3"}, {"aring_dev"}, {"aring_seq"},
+                                                            {"pend_frame"}, {"pend_reward"}, {"pend_mask"}, {"rd_seq_dev"}, {"prm_dev"}};
+DRA_API int dra_dqn_learner_resume_buffer(dra_dqn_learner* l, int index, void** ptr, int64_t* bytes, char* name, int name_len) {
+  if (!l || !ptr || !bytes || index < 0 || index >= (int)(sizeof(kResumeNames) / sizeof(kResumeNames[0]))) return DRA_EINVAL;
+  void* p = nullptr;
+  int64_t n = 0;
+  const int64_t pbytes = (int64_t)l->c.n_params * (int64_t)sizeof(float);
+  switch (index) {
+    case 0: p = l->opt_step; n = sizeof(int64_t); break;
+    case 1: case 2: case 3: case 4: p = l->pa[index - 1]; n = pbytes; break;
+    case 5: p = l->aring_dev; n = (int64_t)kAringSlots * (int64_t)kAprmStride; break;
+    case 6: p = l->aring_seq; n = sizeof(unsigned); break;
+    case 7: p = l->pend_frame; n = 7056; break;
+    case 8: p = l->pend_reward; n = sizeof(double); break;
+    case 9: p = l->pend_mask; n = sizeof(int32_t); break;
+    case 10: p = l->rd_seq_dev; n = sizeof(unsigned long long); break;
+    case 11: p = l->prm_dev; n = sizeof(dra_dqn_step_params); break;
+  }
+  *ptr = p;
+  *bytes = p ? n : 0;      // a buffer this configuration does not have: null / 0
+  if (name && name_len > 0) { strncpy(name, kResumeNames[index].name, (size_t)name_len - 1); name[name_len - 1] = 0; }
+  return DRA_OK;
+}
+
+DRA_API int dra_dqn_learner_resume_counters(dra_dqn_learner* l, int64_t* io, int n, int restore) {
+  if (!l || !io || n < 16) return DRA_EINVAL;
+  if (!restore) {
+    memset(io, 0, (size_t)n * sizeof(int64_t));
+    io[0] = l->step_no; io[1] = l->pa_cur; io[2] = l->pa_valid ? 1 : 0; io[3] = (int64_t)l->aring_pushed;
+    io[4] = (int64_t)l->aring_issued; io[5] = l->aring_primed ? 1 : 0; io[6] = (int64_t)l->rd_issued; io[7] = l->actor_pending ? 1 : 0;
+    io[8] = l->stage_k; io[9] = l->gb; io[10] = l->last_gb; io[11] = (int64_t)l->aprm_seq; io[12] = l->variant;
+    io[13] = l->c.n_params; io[14] = l->ag_have_prev ? 1 : 0; io[15] = l->ag_prev_par;
+    return DRA_OK;
+  }
+  if (io[12] != l->variant || io[13] != l->c.n_params) return DRA_EINVAL;   // another pipeline / another network
+  if (l->step_no != 0 || l->aring_pushed != 0 || l->captured) return DRA_EINVAL;   // only into a fresh learner
+  l->step_no = io[0]; l->pa_cur = (int)io[1]; l->pa_valid = io[2] != 0; l->aring_pushed = (uint64_t)io[3];
+  l->aring_issued = (uint64_t)io[4]; l->aring_primed = io[5] != 0; l->rd_issued = (uint64_t)io[6]; l->actor_pending = false;
+  l->stage_k = (int)io[8]; l->gb = (int)io[9]; l->last_gb = (int)io[10]; l->aprm_seq = (uint64_t)io[11];
+  l->ag_have_prev = io[14] != 0; l->ag_prev_par = (int)io[15];
+  return DRA_OK;
+}
+
 // Device pointers the host fills / reads: idx (int64[B], written before every update),
 // sampling_prob (f32[B], PER only), and read-only results.
 DRA_API int dra_dqn_learner_buffers(dra_dqn_learner* l, void** idx, void** sampling_prob, void** loss, void** norm,

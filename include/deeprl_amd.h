@@ -385,6 +385,13 @@ int dra_dqn_learner_act(dra_dqn_learner* learner, const dra_dqn_step_params* prm
  * observation, q_host = float[n_actions] out.  Pinned staging both ways, batch-1 forward of the online parameters
  * as one captured graph; synchronises `stream` (like the reference's to_np(q)). */
 int dra_dqn_learner_q_host(dra_dqn_learner* learner, const uint8_t* state_host, float* q_host, void* stream);
+/* True resume (optimizer + ring + RNG state; the reference's save() keeps weights only, BaseAgent.py:24-33):
+ * the learner-internal state a bit-exact continuation needs beyond what the host owns.  _resume_buffer enumerates device
+ * buffers (index 0, 1, ... until DRA_EINVAL; *ptr null when this configuration has no such buffer); _resume_counters reads
+ * (restore = 0) or installs (restore = 1, into a FRESH learner of the same configuration before its first step) the
+ * pipelines' host-side counters (n >= 16).  Call with the learner synchronised, between agent steps. */
+int dra_dqn_learner_resume_buffer(dra_dqn_learner* l, int index, void** ptr, int64_t* bytes, char* name, int name_len);
+int dra_dqn_learner_resume_counters(dra_dqn_learner* l, int64_t* io, int n, int restore);
 /* DRA_VAR_ACTOR_RING: upload the parameter blocks of the next `n` agent steps (consumed in order, one per actor launch;
  * at most 32 may be pending).  With the ring, dra_dqn_learner_step / _act take the transitions from it and use only
  * n_env and idx of the block passed to them. */

@@ -55,3 +55,19 @@ def test_fc4_k_split_is_another_association_of_the_same_sums(tmp_path):
         assert np.isfinite(a[k]).all() and np.isfinite(b[k]).all()
         if k.startswith("p_"):               # 50 updates at lr 2.5e-4: a gate flip is worth a few learning rates, not more
             assert float(np.abs(a[k] - b[k]).max()) < 2.5e-3, k
+
+
+@pytest.mark.parametrize("kind", ["dqn", "c51"])
+def test_actor_mega_is_bit_identical(tmp_path, kind):
+    """DRA_VAR_ACTOR_MEGA (round 3): conv3 + fc4 of the actor's env step as ONE launch handing conv3's planes over through an
+    arrival counter (DRA_ACTOR_MEGA_MODE=1, the default), or all four layers in one launch (=0), against the four separate
+    launches (the bit cleared in DRA_TUNING): the same products in the same order -- same stored actions, bit-identical
+    parameters after 60 agent steps of the async pipeline."""
+    default = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 262144 | 524288 | 1048576
+    a = _run(kind, {"DRA_TUNING": str(default)}, tmp_path, "mega1")
+    b = _run(kind, {"DRA_TUNING": str(default & ~1048576)}, tmp_path, "nomega")
+    c = _run(kind, {"DRA_TUNING": str(default), "DRA_ACTOR_MEGA_MODE": "0"}, tmp_path, "mega0")
+    assert sorted(a) == sorted(b) == sorted(c)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(a[k], c[k]), k

@@ -4,6 +4,8 @@ bit-exactly; fp32 losses / gradients at 1e-5 (north_star); contractions at 1e-4 
 output scale (different fp32 summation order than the CPU oracle)."""
 import random
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -674,7 +676,9 @@ def test_conv_bwd_fused_vs_autograd(dev, layer, batch, variant):
     kk = c * k * k
     stride = dw_s.stride(0)
     n_slabs = dw_s.shape[0]
-    if variant & 262144:   # one slab per group of four units (unit = sample x row chunk; conv1 has 5 chunks per sample)
+    if variant & 262144 and (int(os.environ.get("DRA_WGRAD_ACC_LAYERS", "4")) >> (layer - 1)) & 1:
+        # one slab per group of four units (unit = sample x row chunk; conv1 has 5 chunks per sample); the library applies the
+        # accumulating kernel to the layers of DRA_WGRAD_ACC_LAYERS (default: conv3 only)
         assert n_slabs == (batch * (5 if layer == 1 else 1) + 3) // 4
     seg = oc * kk + oc
     grad = torch.zeros(seg + 1000, dtype=torch.float32, device=dev)

@@ -1,24 +1,37 @@
 #!/bin/bash
-# One gpurun call: GPU parity tests, bench, rocprofv3 kernel stats, the two --pmc passes (FETCH_SIZE / WRITE_SIZE,
-# separate runs, kernel-trace only), kernel micro-bench.  Everything under gpurun_out/<tag>/.
-# usage: gpurun --timeout 400 -- 'timeout 380 bash tools/gpu_round.sh <tag>'   (rocprofv3 runs of bench.py end with a segfault inside the
-# profiler's finalizer when CU-masked streams exist; the result files are complete -- the PMC passes use --variant 255)
-TAG=${1:-r01c}
+# One gpurun call of a round: the full GPU suite, bench (default + the driver's command), rocprofv3 kernel stats + timeline of
+# the same command, the two --pmc traffic passes (FETCH_SIZE / WRITE_SIZE, separate runs, kernel-trace only) for the default
+# kernels and with the accumulating conv2 weight gradient, SQ counters at batch 32, phase traces, agent benches.
+# Everything under gpurun_out/<tag>/ (copy what should be judged into profiles/).   usage: gpurun -- 'bash tools/gpu_round.sh r03x'
+TAG=${1:-r03x}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+PV=${PMC_VARIANT:-787199}     # in-order learner: 255 + WGRAD_ACC + LATE_FOLD
 nproc > $OUT/nproc.txt
-echo "== all gpu tests" ; timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; tail -8 $OUT/pytest_gpu.log
-echo "== bench" ; timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json
-echo "== rocprofv3 kernel trace" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -- python $R/bench.py --steps 600 --warmup 100 --no-cpu-baseline > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_bench.err)
-python tools/prof_summary.py $OUT/prof > $OUT/rocprofv3_kernel_stats.txt 2>&1; head -30 $OUT/rocprofv3_kernel_stats.txt
+rm -f gpurun_out/parity_errors.jsonl
+echo "== GPU tests"; timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; grep -E "passed|failed" $OUT/pytest_gpu.log | tail -2; tail -5 $OUT/pytest_gpu.log > $OUT/pytest_gpu_tail.txt
+python tools/parity_summary.py gpurun_out/parity_errors.jsonl > $OUT/parity_errors.json 2>/dev/null; head -c 600 $OUT/parity_errors.json; echo
+echo "== bench" ; timeout 500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; head -c 400 $OUT/bench.json; echo
+echo "== bench (driver command)" ; timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err; head -c 300 $OUT/bench_driver_cmd.json; echo
+echo "== rocprofv3 kernel trace" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -- python $R/bench.py --steps 600 --warmup 100 --no-cpu-baseline --no-parity-check > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_bench.err)
+python tools/prof_summary.py $OUT/prof > $OUT/rocprofv3_kernel_stats.txt 2>&1; head -32 $OUT/rocprofv3_kernel_stats.txt
 python tools/prof_timeline.py $OUT/prof 200 2 > $OUT/timeline.txt 2>&1
 find $OUT/prof -name "*.db" -size +20M -delete
-echo "== pmc FETCH_SIZE" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -- python $R/tools/pmc_workload.py --steps 40 --variant 255 > $R/$OUT/pmc_fetch.log 2>&1); tail -2 $OUT/pmc_fetch.log
-echo "== pmc WRITE_SIZE" ; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write -- python $R/tools/pmc_workload.py --steps 40 --variant 255 > $R/$OUT/pmc_write.log 2>&1); tail -2 $OUT/pmc_write.log
-python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; head -c 1500 $OUT/pmc_traffic.json; tail -3 $OUT/pmc_traffic.err
-find $OUT/pmc_fetch $OUT/pmc_write -name "*.db" -size +20M -delete
-find $OUT/pmc_fetch $OUT/pmc_write -name "*kernel_trace*" -size +20M -delete
-echo "== kernel microbench" ; timeout 300 python tools/bench_kernels.py > $OUT/kernel_microbench.json 2> $OUT/kernel_microbench.err; cat $OUT/kernel_microbench.json | head -c 3000
+for L in 4 6; do
+  echo "== pmc passes, DRA_WGRAD_ACC_LAYERS=$L"
+  (cd /tmp && DRA_WGRAD_ACC_LAYERS=$L timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch$L -- python $R/tools/pmc_workload.py --steps 40 --variant $PV > $R/$OUT/pmc_fetch$L.log 2>&1); tail -1 $OUT/pmc_fetch$L.log
+  (cd /tmp && DRA_WGRAD_ACC_LAYERS=$L timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write$L -- python $R/tools/pmc_workload.py --steps 40 --variant $PV > $R/$OUT/pmc_write$L.log 2>&1); tail -1 $OUT/pmc_write$L.log
+  python tools/pmc_traffic.py $OUT/pmc_fetch$L $OUT/pmc_write$L > $OUT/pmc_traffic_layers$L.json 2> $OUT/pmc_traffic$L.err; head -c 900 $OUT/pmc_traffic_layers$L.json; tail -2 $OUT/pmc_traffic$L.err
+  find $OUT/pmc_fetch$L $OUT/pmc_write$L -name "*.db" -size +20M -delete
+  find $OUT/pmc_fetch$L $OUT/pmc_write$L -name "*kernel_trace*" -size +20M -delete
+done
+echo "== SQ counters at batch 32"; PMC_VARIANT=$PV bash tools/pmc_sq_learner.sh $TAG > $OUT/sq.log 2>&1; tail -3 $OUT/sq.log
+export DEEPRL_AMD_LIB=$R/deeprl_amd/lib/libdeeprl_amd_trace.so
+echo "== phase traces"; timeout 200 python tools/phase_trace.py > $OUT/phase_async.json 2> $OUT/phase.err; python tools/phase_summary.py $OUT/phase_async.json | grep -E "chain|env step"
+timeout 200 python tools/phase_trace.py --sync > $OUT/phase_sync.json 2>> $OUT/phase.err; python tools/phase_summary.py $OUT/phase_sync.json | grep -E "chain|env step"
+unset DEEPRL_AMD_LIB
+echo "== agents bench"; timeout 400 python tools/bench_agents.py > $OUT/bench_agents.jsonl 2> $OUT/bench_agents.err; cat $OUT/bench_agents.jsonl | cut -c1-300
+echo "== launch contract: 2 ranks on this box (gloo barrier, replicas share the GPU)"; timeout 300 python bench.py --gpus 2 --steps 200 --warmup 20 --no-cpu-baseline --no-parity-check > $OUT/bench_2rank_one_box.json 2> $OUT/bench_2rank_one_box.err; head -c 300 $OUT/bench_2rank_one_box.json; echo
 echo "== done"
