@@ -35,7 +35,8 @@ from . import ops
 from .envs import LazyFrames
 from .optim import FlatParams, FusedOptimizer, nature_conv_weights
 from .replay import PrioritizedTransition, Storage
-from .support import Config, close_obj, epsilon_greedy, get_logger, random_sample, range_tensor, tensor, to_np
+from ._lib import DraError
+from .support import Config, LinearSchedule, close_obj, epsilon_greedy, get_logger, random_sample, range_tensor, tensor, to_np
 
 
 
@@ -577,6 +578,58 @@ class DQNAgent(BaseAgent):
             torch.cuda.synchronize()
             self._learner.invalidate_actor_copy()
 
+    # -- true resume (the reference's save() keeps weights + normaliser only, BaseAgent.py:24-33) ------
+    def save_full(self, filename):
+        """Everything a bit-exact continuation needs, next to the unchanged `.model` / `.stats` files: parameters, target
+        and optimizer state in their device layout, the learner's pipeline state (actor parameter copies, blocks generated
+        ahead, the pending observation), the replay ring (sharded) and its cursor / priority tree, schedules, step counters
+        and every random stream (numpy global, python `random`, torch CPU / device, the async actor's own RandomState).
+        40 steps + save_full + a fresh process + load_full + 20 steps == 60 uninterrupted steps, bit for bit
+        (tests/test_gpu_resume.py).  Device-resident pipeline (the benchmarked dqn_pixel-family configurations) only."""
+        import pickle
+        import random as pyrandom
+        if self._pipe is None or self._learner is None:
+            raise NotImplementedError("save_full: this agent runs a host environment / the generic update path; only the "
+                                      "device-resident pipeline (config.device_env, synthetic Atari) has a full resume")
+        self.save(filename)
+        cfg = self.config
+        sched = {}
+        for name in ("random_action_prob", "replay_beta"):
+            sc = getattr(cfg, name, None)
+            if isinstance(sc, LinearSchedule):
+                sched[name] = dict(current=sc.current, inc=sc.inc, end=sc.end)
+        state = dict(learner=self._learner.resume_state(), pipe=self._pipe.state_dict(), total_steps=self.total_steps,
+                     actor_total_steps=self.actor._total_steps, schedules=sched, learner_lr=self._learner_lr,
+                     np_random=np.random.get_state(), py_random=pyrandom.getstate(), torch_cpu=torch.get_rng_state(),
+                     torch_cuda=torch.cuda.get_rng_state(Config.DEVICE), agent=type(self).__name__)
+        self._inner_replay().save_full(filename)
+        with open(filename + '.resume', 'wb') as f:
+            pickle.dump(state, f)
+
+    def load_full(self, filename):
+        """Into a freshly constructed agent of the same Config (same network / replay / pipeline shape), before its first step."""
+        import pickle
+        import random as pyrandom
+        if self._pipe is None or self._learner is None:
+            raise NotImplementedError("load_full needs the device-resident pipeline (see save_full)")
+        with open(filename + '.resume', 'rb') as f:
+            state = pickle.load(f)
+        if state["agent"] != type(self).__name__:
+            raise DraError("%s.resume was written by a %s" % (filename, state["agent"]))
+        with open(filename + '.stats', 'rb') as f:
+            self.config.state_normalizer.load_state_dict(pickle.load(f))
+        self._inner_replay().load_full(filename)
+        self._learner.load_resume_state(state["learner"])
+        self._pipe.load_state_dict(state["pipe"])
+        self.total_steps, self.actor._total_steps = state["total_steps"], state["actor_total_steps"]
+        for name, st in state["schedules"].items():
+            sc = getattr(self.config, name)
+            sc.current, sc.inc, sc.end = st["current"], st["inc"], st["end"]
+        np.random.set_state(state["np_random"])
+        pyrandom.setstate(state["py_random"])
+        torch.set_rng_state(state["torch_cpu"])
+        torch.cuda.set_rng_state(state["torch_cuda"], Config.DEVICE)
+
     def close(self):
         if getattr(self, '_learner', None) is not None:
             self._learner.synchronize()
@@ -859,12 +912,11 @@ def _install_sampler(agent):
     net = agent.network
     if not dp.invariant_sampling or not hasattr(net, 'fc_action') or not hasattr(agent.task, 'action_space'):
         return
-    from .dist import gumbel_argmax
     from .envs import Discrete
     if not isinstance(agent.task.action_space, Discrete):
         raise NotImplementedError("data-parallel sampling is implemented for categorical policies (BASELINE config 5)")
-    net.sampler = lambda logits: gumbel_argmax(logits, dp.uniforms(agent._rollout_step, dp.global_workers, logits.shape[-1],
-                                                                   logits.device))
+    # one kernel per sample; the noise stream's position is a device counter the kernel advances: graph-capturable
+    net.sampler = lambda logits: dp.sample(logits.detach())
 
 
 class _OnPolicyGraph:
@@ -872,7 +924,10 @@ class _OnPolicyGraph:
     sampling, the return scan, loss, backward, clip, optimizer) from ONE captured hipGraph after two eager rollouts.  The
     rollout plan lives in persistent device buffers (DeviceAtariVec.plan), so every kernel argument is constant across
     rollouts; torch's graph-safe Philox bookkeeping continues the sampling generator exactly as the eager kernels would.
-    Not used when the gradient leaves the device stream (data-parallel exchange, grad hooks) or config.graph_update is off."""
+    Data parallel (dist.DataParallel): the captured region ends BEFORE the gradient exchange -- run(plan, compute, tail)
+    replays [rollout + loss + backward] and then calls tail() eagerly (all-reduce of the flat gradient over RCCL / gloo,
+    clip + optimizer step: three launches), so that ranks x environments-per-rank runs at the single-process graph speed.
+    Not used with grad hooks or config.graph_update off."""
     WARMUP = 2
 
     def __init__(self, agent, optimizer_inside=True):
@@ -887,15 +942,17 @@ class _OnPolicyGraph:
     def usable(self):
         a = self.agent
         cfg = a.config
-        return not (self.failed or getattr(cfg, 'graph_update', True) is False or a.grad_hook is not None or a.dp.active
-                    or a.dp.invariant_sampling)
+        return not (self.failed or getattr(cfg, 'graph_update', True) is False or a.grad_hook is not None)
 
-    def run(self, plan, compute):
+    def run(self, plan, compute, tail=None):
+        """compute(plan): the capturable device work; tail(out) (optional): what must stay eager after it (the data-parallel
+        exchange and the optimizer step behind it) -- called after the eager compute as well as after a replay."""
         a = self.agent
         self.calls += 1
         if not self.usable() or self.calls <= self.WARMUP:
-            return compute(plan)
-        opt = a._fused if self.optimizer_inside else None
+            out = compute(plan)
+            return out if tail is None else tail(out)
+        opt = a._fused if (self.optimizer_inside and tail is None) else None
         key = (plan.counters.data_ptr(), plan.t_len, opt.hyper_signature() if opt is not None else None)
         if self.graph is not None and key != self.key:
             self.graph = None
@@ -918,14 +975,15 @@ class _OnPolicyGraph:
                 self.graph = None
                 if opt is not None:
                     opt.graph_mode = False
-                return compute(plan)
+                out = compute(plan)
+                return out if tail is None else tail(out)
             finally:
                 torch.distributions.Distribution.set_default_validate_args(validate)
         if opt is not None:
             opt.prepare_step()
         self.graph.replay()
         a._rollout_step += plan.t_len + (1 if hasattr(a, '_act') else 0)
-        return self.out
+        return self.out if tail is None else tail(self.out)
 
 
 def _dp_sync_start(dp, network, *fused):
@@ -983,10 +1041,13 @@ class A2CAgent(BaseAgent):
         for t in range(config.rollout_length):
             self.record_online_return(plan.infos[t])
             self.total_steps += self.dp.global_workers
-        out4 = self._dev_graph.run(plan, self._rollout_compute)
+        if self.dp.active:      # graph = [rollout + loss + backward]; the exchange and the step behind it stay eager
+            out4 = self._dev_graph.run(plan, lambda pl: self._rollout_compute(pl, apply=False), tail=self._learn_apply)
+        else:
+            out4 = self._dev_graph.run(plan, self._rollout_compute)
         self.last_loss = out4
 
-    def _rollout_compute(self, plan):
+    def _rollout_compute(self, plan, apply=True):
         config = self.config
         states, actions, values = [], [], []
         with torch.no_grad():
@@ -999,9 +1060,19 @@ class A2CAgent(BaseAgent):
                 values.append(prediction['v'])
             values.append(self.network(config.state_normalizer(self.task.states(plan, config.rollout_length)))['v'])
         return self._learn(states, actions, values, [plan.reward[t] for t in range(config.rollout_length)],
-                           [plan.mask[t] for t in range(config.rollout_length)])
+                           [plan.mask[t] for t in range(config.rollout_length)], apply=apply)
 
-    def _learn(self, states, actions, values, rewards, masks):
+    def _learn_apply(self, out4=None):
+        """The part of an update behind the backward pass: gradient exchange (data parallel: the loss is the mean over this
+        rank's T x N/G rows; equal shards -> the mean of the G gradients is the gradient of the global mean loss; ONE
+        all-reduce), optional hook, clip + optimizer step identically on every rank."""
+        self.dp.sum_grads(self._fused.flat.grad, 1.0 / self.dp.world if self.dp.active else 1.0)
+        if self.grad_hook is not None:
+            self.grad_hook(self._fused.flat.grad)
+        self._fused.step(self.config.gradient_clip)
+        return out4
+
+    def _learn(self, states, actions, values, rewards, masks, apply=True):
         """A2C_agent.py:43-64 on a finished rollout.  The reference keeps the autograd graph of every rollout forward and
         backpropagates through all T of them; the parameters do not change inside a rollout, so ONE forward over the T x N
         stored observations with the stored actions gives the same log-probabilities, entropies and values and ONE
@@ -1020,13 +1091,7 @@ class A2CAgent(BaseAgent):
                                                 config.entropy_weight, config.value_loss_weight)
         self._fused.zero_grad()
         torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']], [g_lp, g_ent, g_v])
-        # data parallel: the loss above is the mean over this rank's T x N/G rows; equal shards -> the mean of the G
-        # gradients is the gradient of the global mean loss.  ONE all-reduce, then clip + step identically everywhere.
-        self.dp.sum_grads(self._fused.flat.grad, 1.0 / self.dp.world if self.dp.active else 1.0)
-        if self.grad_hook is not None:
-            self.grad_hook(self._fused.flat.grad)
-        self._fused.step(config.gradient_clip)
-        return out4
+        return self._learn_apply(out4) if apply else out4
 
     def step(self):
         if getattr(self.task, 'on_device', False):
@@ -1149,8 +1214,6 @@ class PPOAgent(BaseAgent):
         self._rollout_graph = dict(calls=0, graph=None, failed=False, k=0)
         self._rollout_step = 0
         _install_sampler(self)
-        if self.dp.invariant_sampling:
-            self._rollout_graph = None      # the sampler reseeds a generator per step: not capturable
 
     def close(self):
         close_obj(self.task)
@@ -1165,12 +1228,20 @@ class PPOAgent(BaseAgent):
         for t in range(config.rollout_length):
             self.record_online_return(plan.infos[t])
             self.total_steps += self.dp.global_workers
-        entries = self._dev_graph.run(plan, self._rollout_compute)
+        if self.dp.active:      # PPO_agent.py:66 over the GLOBAL rollout: three all-reduced scalars, outside the captured region
+            from .dist import global_advantage_normalize_
+
+            def normalise(entries):
+                global_advantage_normalize_(entries.advantage)
+                return entries
+            entries = self._dev_graph.run(plan, lambda pl: self._rollout_compute(pl, normalise=False), tail=normalise)
+        else:
+            entries = self._dev_graph.run(plan, self._rollout_compute)
         if config.shared_repr:
             self.lr_scheduler.step(self.total_steps)
         self.optimize(entries)
 
-    def _rollout_compute(self, plan):
+    def _rollout_compute(self, plan, normalise=True):
         config = self.config
         storage = Storage(config.rollout_length)
         with torch.no_grad():
@@ -1188,6 +1259,8 @@ class PPOAgent(BaseAgent):
         entries = storage.extract(['state', 'action', 'log_pi_a', 'ret', 'advantage'])
         entry_cls = entries.__class__
         entries = entry_cls(*[x.detach() for x in entries])
+        if not normalise:
+            return entries
         if self.dp.active:
             from .dist import global_advantage_normalize_
             global_advantage_normalize_(entries.advantage)

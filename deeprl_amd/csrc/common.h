@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/deeprl_amd.h"  // exported signatures are checked against the public header
 
 #define DRA_OK 0
@@ -42,6 +43,30 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// XCD-aware workgroup order.  MI355X dispatches the workgroups of a launch round-robin over its 8 XCDs (blockIdx mod 8;
+// wgs_per_xcd in every phase trace under profiles/) and every XCD has its own L2: with the natural (sample-major) block
+// order the 8-13 workgroups that share one sample's operands land on 8 different XCDs and every L2 fetches that sample
+// from the fabric -- conv2's backward launch FETCHED 14.2 MB for 2.4 MB of distinct inputs (profiles/r03e_pmc_traffic_*).
+// xcd_order() renumbers the workgroups so that a whole sharing group (all workgroups of one sample / one K slice) runs
+// on ONE XCD: workgroup `bid` (first = index of the role's first workgroup in the launch) works on the returned
+// virtual index of the natural order.  n_groups groups of per_group workgroups; groups beyond a multiple of 8 keep the
+// natural order.  A bijection on [0, n_groups * per_group).
+constexpr int kXcds = 8;
+__device__ __forceinline__ int xcd_order(int bid, int first, int n_groups, int per_group) {
+  const int gpx = n_groups / kXcds;                 // whole groups per XCD
+  const int main = gpx * kXcds * per_group;
+  if (bid >= main) return bid;
+  const int xcd = (bid + first) & (kXcds - 1), j = bid >> 3;      // j < gpx * per_group
+  return (xcd * gpx + j / per_group) * per_group + (j % per_group);
+}
+// DRA_XCD_ORDER=0 keeps the natural order (A/B switch, read once per process)
+static inline int dra_xcd_order_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_XCD_ORDER"); v = e ? atoi(e) : 1; }
   return v;
 }
 

@@ -97,6 +97,8 @@ struct ConvV2Args {
   // otherwise (the host had not written the indices yet when the prefetch ran) sample_idx is read as before
   const int64_t* sample_idx_tagged = nullptr;
   const unsigned long long* sample_seq = nullptr;
+  // != 0: XCD-aware block order (common.h xcd_order): every workgroup of one (net, sample) runs on one XCD
+  int xcd_order = 0;
 };
 
 __device__ __forceinline__ float v2_act(float v, int act) {
@@ -509,7 +511,21 @@ template <class G, bool U8, int PT, int NW = 4>
 __global__ void __launch_bounds__(64 * NW) conv_fwd_v2_kernel(const ConvV2Args a) {
   ActorFuse none;
   none.mode = 0;
-  conv_fwd_v2_body<G, U8, PT, NW, false>(a, none, blockIdx.x, blockIdx.y, blockIdx.z, false);
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd_order) {
+    // natural order: x = sample * TPG + tile group (fastest), y = output-channel tile, z = net; the sharing group is one
+    // (net, sample): TPG * gridDim.y workgroups staging rows of the same input images
+    constexpr int TPG = V2Tile<G, PT>::TPG;
+    const int ny = gridDim.y, per = TPG * ny, groups = (int)gridDim.z * a.batch;
+    const int lin = bx + (int)gridDim.x * (by + ny * bz);
+    const int v = xcd_order(lin, 0, groups, per);
+    const int g = v / per, w = v - g * per;
+    bz = g / a.batch;
+    const int bi = g - bz * a.batch, grp = w / ny;
+    by = w - grp * ny;
+    bx = bi * TPG + grp;
+  }
+  conv_fwd_v2_body<G, U8, PT, NW, false>(a, none, bx, by, bz, false);
 }
 
 // conv1 of the ring actor's env step e with the head of step e-1 and the environment step in front (ActorFuse):
@@ -1051,7 +1067,9 @@ static int launch_conv_v2_pt(const ConvV2Args& a, int nz, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_fwd_v2_kernel<G, U8, PT, NW>), dim3(T::TPG * a.batch, G::OC / 32, nz), dim3(64 * NW), bytes, st, a);
+  ConvV2Args ax = a;
+  ax.xcd_order = dra_xcd_order_enabled();
+  hipLaunchKernelGGL((conv_fwd_v2_kernel<G, U8, PT, NW>), dim3(T::TPG * a.batch, G::OC / 32, nz), dim3(64 * NW), bytes, st, ax);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

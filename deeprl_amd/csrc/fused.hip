@@ -89,6 +89,7 @@ template <class W>
 static W make_wgrad_one(const float* dy, const void* x, float* dw, float* db, int64_t slab_stride, int batch, double coef) {
   W r;
   r.dy = dy; r.x = x; r.dw = dw; r.db = db; r.slab_stride = slab_stride; r.B = batch; r.coef = coef;
+  r.xcd = dra_xcd_order_enabled();
   return r;
 }
 
@@ -110,6 +111,7 @@ template <class G, int PT = DgradTiles<G>::PT>
 static ConvDgradOne<G, PT> make_dgrad_one(const float* dy, const float* wt, const float* xact, float* dx, int batch, int act) {
   ConvDgradOne<G, PT> r;
   r.dy = dy; r.wt = wt; r.xact = xact; r.dx = dx; r.B = batch; r.act = act;
+  r.xcd = dra_xcd_order_enabled();
   return r;
 }
 
@@ -357,6 +359,7 @@ DRA_API int dra_linear_fwd_slabs_one(int nz, const float* const* x, const float*
     for (int z = 0; z < nz; ++z) { r.x[z] = x[z]; r.w[z] = w[z]; }
     r.slabs = slabs; r.B = batch; r.O = out_features;
     r.tiles_n = (out_features + 32 * NT - 1) / (32 * NT); r.tiles_m = (batch + 31) / 32;
+    r.xcd = dra_xcd_order_enabled(); r.n_groups = r.tiles_m * ksplit * nz;
   };
   if (ksplit == 28) {   // 112-wide K slices: 3.5x the workgroups (448 at batch 32, two nets), 43 KB of LDS each
     LinFwdSlabsOne<3136, 28, NT> r;

@@ -526,6 +526,8 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
 //                                      which is correct -- nothing is in flight after a load).
 static const struct { const char* name; } kResumeNames[] = {{"opt_step"}, {"pa0"}, {"pa1"}, {"pa2"}, {"pa3"}, {"aring_dev"}, {"aring_seq"},
                                                             {"pend_frame"}, {"pend_reward"}, {"pend_mask"}, {"rd_seq_dev"}, {"prm_dev"}};
+DRA_API int dra_dqn_learner_resume_buffer_count(void) { return (int)(sizeof(kResumeNames) / sizeof(kResumeNames[0])); }
+
 DRA_API int dra_dqn_learner_resume_buffer(dra_dqn_learner* l, int index, void** ptr, int64_t* bytes, char* name, int name_len) {
   if (!l || !ptr || !bytes || index < 0 || index >= (int)(sizeof(kResumeNames) / sizeof(kResumeNames[0]))) return DRA_EINVAL;
   void* p = nullptr;

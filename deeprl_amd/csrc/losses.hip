@@ -582,3 +582,43 @@ DRA_API int dra_weighted_mean(const float* x, const float* w, int n, float* out,
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
+
+// ---- rank-invariant categorical sampling (data-parallel A2C / PPO, dist.py) -----------------------------------------------
+// action[i] = argmax_a (logits[i][a] + Gumbel noise), the noise a counter hash of (seed, rollout step, GLOBAL environment
+// index lo + i, a): G ranks x N/G environments draw exactly what 1 rank x N would (Categorical(logits).sample() of
+// network_heads.py:249-252 in distribution).  The rollout step lives in DEVICE memory and is advanced by the kernel itself,
+// so the launch has constant arguments and replays from a captured rollout graph (round 2 reseeded a host generator per
+// step, which kept every data-parallel rollout on the eager path).  One workgroup; rows strided over its threads.
+__device__ __forceinline__ uint64_t gs_mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256)
+gumbel_sample_kernel(const float* __restrict__ logits, int n_local, int n_actions, uint64_t seed, int64_t* __restrict__ step_dev,
+                     int64_t lo, int64_t* __restrict__ action_out) {
+  const int64_t step = *step_dev;
+  __syncthreads();                    // every thread has read the step before thread 0 advances it
+  const uint64_t base = gs_mix64(seed * 0x9E3779B97F4A7C15ull + (uint64_t)step);
+  for (int i = threadIdx.x; i < n_local; i += blockDim.x) {
+    float best = -INFINITY;
+    int arg = 0;
+    for (int a = 0; a < n_actions; ++a) {
+      const uint64_t h = gs_mix64(base + (uint64_t)(lo + i) * 64ull + (uint64_t)a);
+      const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1), 24 bits
+      const float v = logits[(int64_t)i * n_actions + a] - logf(-logf(u));
+      if (v > best) { best = v; arg = a; }
+    }
+    action_out[i] = arg;
+  }
+  if (threadIdx.x == 0) *step_dev = step + 1;
+}
+
+DRA_API int dra_gumbel_sample(const float* logits, int n_local, int n_actions, uint64_t seed, int64_t* step_dev, int64_t lo,
+                              int64_t* action_out, void* stream) {
+  if (!logits || !step_dev || !action_out || n_local < 1 || n_actions < 1 || n_actions > 64 || lo < 0) return DRA_EINVAL;
+  hipLaunchKernelGGL(gumbel_sample_kernel, dim3(1), dim3(256), 0, dra_stream(stream), logits, n_local, n_actions, seed, step_dev, lo,
+                     action_out);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}

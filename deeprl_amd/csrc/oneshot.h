@@ -45,7 +45,7 @@ __device__ __forceinline__ void reduce4(float* __restrict__ red, const f32x16& a
 // runs up to three independent roles in one launch (block ranges [0,n1) [n1,n1+n2) [n1+n2, ...)).
 struct NoRole {
   static constexpr int LDS_FLOATS = 0;
-  __device__ __forceinline__ void run(int, float*) const {}
+  __device__ __forceinline__ void run(int, float*, int = 0) const {}
 };
 
 template <class P>
@@ -53,7 +53,7 @@ struct IgemmRole {
   static constexpr int LDS_FLOATS = igemm_lds_floats<P>();
   P p;
   int tiles, ksplit;
-  __device__ __forceinline__ void run(int bid, float* lds) const {
+  __device__ __forceinline__ void run(int bid, float* lds, int = 0) const {
     const int bx = bid % tiles, r = bid / tiles;
     const int by = r % ksplit, bz = r / ksplit;
     igemm_body<P>(p, bx, by, bz, ksplit, lds);
@@ -75,9 +75,10 @@ template <class R1, class R2, class R3>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) multi_kernel(const R1 r1, const R2 r2, const R3 r3, const int n1, const int n2) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   const int b = blockIdx.x;
-  if (b < n1) r1.run(b, dyn_lds);
-  else if (b < n1 + n2) r2.run(b - n1, dyn_lds);
-  else r3.run(b - n1 - n2, dyn_lds);
+  // (third argument: index of the role's first workgroup in the launch -- the XCD a workgroup runs on is blockIdx mod 8)
+  if (b < n1) r1.run(b, dyn_lds, 0);
+  else if (b < n1 + n2) r2.run(b - n1, dyn_lds, n1);
+  else r3.run(b - n1 - n2, dyn_lds, n1 + n2);
 }
 
 template <class R1, class R2, class R3>
@@ -109,7 +110,7 @@ struct HeadWgradRole {
   float* dbh;        // [A]
   int B, A;
   double* partials = nullptr;   // optional [2 * A]: sum of squares of what each workgroup stored (DRA_VAR_LATE_FOLD)
-  __device__ __forceinline__ void run(int bid, float* lds) const {
+  __device__ __forceinline__ void run(int bid, float* lds, int = 0) const {
     const int a = bid >> 1, k = (bid & 1) * 256 + threadIdx.x;
     float acc = 0.f, accb = 0.f;
     int b = 0;
@@ -155,7 +156,7 @@ struct FoldRole {
   double* reset_slots = nullptr;
   int n_reset = 0;
   __host__ int blocks() const { return (int)((count4 + EPB - 1) / EPB); }
-  __device__ __forceinline__ void run(int bid, float* lds) const {
+  __device__ __forceinline__ void run(int bid, float* lds, int = 0) const {
     const int tid = threadIdx.x, g = tid >> 6, el = tid & 63;
     if (reset_slots && bid == 0)
       for (int i = tid; i < n_reset; i += 256) __hip_atomic_store(reset_slots + i, -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -209,7 +210,7 @@ struct LinDgradOne {
   const float* xact;  // [B][I] or null
   float* dx;          // [B][I]
   int B, I, act, tiles_n;
-  __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
+  __device__ __forceinline__ void run(int bid, float* __restrict__ lds, int = 0) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int bm = bid / tiles_n, bn = bid - bm * tiles_n;
     const int m0 = bm * 32, n0 = bn * 32;
@@ -288,8 +289,10 @@ struct LinFwdSlabsOne {
   // (the distributional heads' [B,512] x [512, A*N] contraction of the update)
   const float* bias[kMaxZ] = {};
   float* out[kMaxZ] = {};
-  __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
+  int xcd = 0, n_groups = 0;   // xcd != 0: the tiles_n workgroups that share one (net, K slice, row tile) of x run on one XCD
+  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int bid = xcd ? xcd_order(bid_, first, n_groups, tiles_n) : bid_;
     const int bn = bid % tiles_n;
     int r = bid / tiles_n;
     const int bm = r % tiles_m;
@@ -401,9 +404,11 @@ struct ConvDgradOne {
   const float* xact;  // [B][C][H][H] this layer's input (post-activation) or null
   float* dx;          // [B][C][H][H]
   int B, act;
+  int xcd = 0;        // != 0: all workgroups of a sample on one XCD (xcd_order)
   __host__ int blocks() const { return B * NPH * TGP * MT; }
-  __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
+  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int bid = xcd ? xcd_order(bid_, first, B, NPH * TGP * MT) : bid_;
     const int mt = bid % MT;
     int r = bid / MT;
     const int grp = r % TGP;
@@ -556,10 +561,12 @@ struct ConvWgradOne {
   // optional (U8): sample bi is the C consecutive ring frames ending at slot sample_idx[bi] of the slot-major frame array x
   // (conv1's weight gradient straight from the replay ring); null = image bi of a plain [B][C][H][H] batch
   const int64_t* sample_idx = nullptr;
+  int xcd = 0;        // != 0: all workgroups of a sample on one XCD (xcd_order)
   __host__ int blocks() const { return B * NCHUNK * NGRP; }
   __host__ static int n_slabs(int batch) { return batch * NCHUNK; }
-  __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
+  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int bid = xcd ? xcd_order(bid_, first, B, NCHUNK * NGRP) : bid_;
     const int grp = bid % NGRP;
     int r = bid / NGRP;
     const int chunk = r % NCHUNK, bi = r / NCHUNK;
@@ -779,10 +786,12 @@ struct ConvWgradAcc {
   int B;
   double coef;
   const int64_t* sample_idx = nullptr;   // (U8) ring-direct minibatch, as in ConvWgradOne
+  int xcd = 0;        // != 0: all workgroups of a unit group on one XCD (xcd_order)
   __host__ static int n_slabs(int batch) { return (batch * NCHUNK + SB - 1) / SB; }
   __host__ int blocks() const { return n_slabs(B) * NGRP * NNG; }
-  __device__ __forceinline__ void run(int bid, float* __restrict__ lds) const {
+  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int bid = xcd ? xcd_order(bid_, first, (B * NCHUNK + SB - 1) / SB, NGRP * NNG) : bid_;
     const int ng = bid % NNG;
     int r = bid / NNG;
     const int grp = r % NGRP, ug = r / NGRP;

@@ -134,9 +134,10 @@ class DataParallel:
         sum_grads(flat, weight)        one all-reduce per optimizer step: flat <- sum over ranks of weight * flat
         sum_scalars([...])             fp64 scalars summed over ranks (advantage statistics, KL gate)
         permutation(n)                 the SAME permutation on every rank (one RandomState seeded by rank 0)
-        uniforms(step, n_global, k)    per-step U(0,1) noise of shape [n_global, k], identical on every rank: actions are
-                                       sampled by the Gumbel trick from the shard's rows, so that G ranks x N/G
-                                       environments act exactly like 1 rank x N
+        sample(logits)                 categorical actions of the shard's rows by the Gumbel trick, the noise a counter hash of
+                                       (noise seed, rollout step, GLOBAL environment, action): G ranks x N/G environments act
+                                       exactly like 1 rank x N.  The rollout step is a device counter the kernel advances
+                                       (ops.gumbel_sample), so data-parallel rollouts replay from captured graphs
     """
 
     def __init__(self, config):
@@ -170,6 +171,7 @@ class DataParallel:
             self.rs = np.random.RandomState(self.noise_seed + 12345)
         config.env_shard = (self.lo, self.hi)
         self._gen = None
+        self.step_dev = None          # device int64: sampler calls so far (the noise stream's position)
 
     @property
     def is_main(self):
@@ -199,6 +201,13 @@ class DataParallel:
 
     def permutation(self, n):
         return self.rs.permutation(n) if self.rs is not None else np.random.permutation(n)
+
+    def sample(self, logits):
+        """Rank-invariant Categorical(logits).sample() for this rank's rows (module docstring)."""
+        from . import ops
+        if self.step_dev is None:
+            self.step_dev = torch.zeros(1, dtype=torch.int64, device=logits.device)
+        return ops.gumbel_sample(logits, self.noise_seed, self.step_dev, self.lo)
 
     def uniforms(self, step, n_global, k, device):
         if self._gen is None:

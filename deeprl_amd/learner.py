@@ -355,6 +355,52 @@ class DQNLearner:
                 "square_avg": per_tensor(self.state1), "grad_avg": per_tensor(self.state2),   # RMSprop's names
                 "state1": per_tensor(self.state1), "state2": per_tensor(self.state2)}         # Adam: exp_avg, exp_avg_sq
 
+    # -- true resume ---------------------------------------------------------------------------
+    def _resume_buffers(self):
+        n = lib.dra_dqn_learner_resume_buffer_count.raw()
+        out = []
+        for i in range(n):
+            p, nb = ctypes.c_void_p(), ctypes.c_int64()
+            name = ctypes.create_string_buffer(32)
+            lib.dra_dqn_learner_resume_buffer(self.h, i, ctypes.byref(p), ctypes.byref(nb), name, 32)
+            if p.value and nb.value:
+                out.append((name.value.decode(), ops._wrap_device_pointer(p.value, nb.value, torch.uint8)))
+        return out
+
+    def resume_state(self):
+        """Everything of the learner a bit-exact continuation in a FRESH process needs: the flat parameter / target /
+        optimizer-state buffers in their device layout (KOC conv weights: no conversion, no rounding), the learner-internal
+        device buffers (optimizer step count, the actor's rotating parameter copies, the actor parameter-block ring and its
+        counter, the pending observation, ...) and the host-side pipeline counters.  Synchronises first."""
+        self.synchronize()
+        torch.cuda.synchronize()
+        counters = (ctypes.c_int64 * 16)()
+        lib.dra_dqn_learner_resume_counters(self.h, counters, 16, 0)
+        return dict(flat=self.flat.flat.detach().cpu().clone(), target=self.target_flat.flat.detach().cpu().clone(),
+                    state1=self.state1.cpu().clone(), state2=self.state2.cpu().clone(),
+                    buffers={k: v.cpu().clone() for k, v in self._resume_buffers()}, counters=list(counters),
+                    variant=self.variant, n_params=self.flat.numel)
+
+    def load_resume_state(self, st):
+        """Into a fresh learner of the same configuration, before its first step."""
+        if st["variant"] != self.variant or st["n_params"] != self.flat.numel:
+            raise DraError("resume state of another learner configuration (variant %d / %d parameters, this one %d / %d)"
+                           % (st["variant"], st["n_params"], self.variant, self.flat.numel))
+        self.synchronize()
+        torch.cuda.synchronize()
+        self.flat.flat.copy_(st["flat"])
+        self.target_flat.flat.copy_(st["target"])
+        self.state1.copy_(st["state1"])
+        self.state2.copy_(st["state2"])
+        mine = dict(self._resume_buffers())
+        for k, v in st["buffers"].items():
+            if k not in mine or mine[k].numel() != v.numel():
+                raise DraError("resume buffer %r does not exist in this learner" % k)
+            mine[k].copy_(v)
+        counters = (ctypes.c_int64 * 16)(*st["counters"])
+        lib.dra_dqn_learner_resume_counters(self.h, counters, 16, 1)
+        torch.cuda.synchronize()
+
     def last_minibatch(self):
         """(state, next_state, action, reward, mask) device tensors of the most recently issued update (views of the
         learner's own gather buffers; synchronize() first).  For checkers."""
@@ -395,6 +441,13 @@ class SyntheticEpisodeStream:
         self.c = None
         self.age = 0
         self.ret = 0.0
+        self._cache_base = None
+
+    def state_dict(self):
+        return dict(next_counter=self.next_counter, c=self.c, age=self.age, ret=self.ret)
+
+    def load_state_dict(self, st):
+        self.next_counter, self.c, self.age, self.ret = st["next_counter"], st["c"], st["age"], st["ret"]
         self._cache_base = None
 
     def _reset(self):
@@ -465,6 +518,20 @@ class DeviceActorPipeline:
         self.ring_mode = async_actor and (v & need) == need and not (v & (ops.VAR_ACTOR_V3 | ops.VAR_GATHER_IN_GRAPH))
         if async_actor and not self.ring_mode:
             raise DraError("the async device pipeline needs the default kernel variant (actor parameter ring)")
+
+    def state_dict(self):
+        """Host side of the pipeline between two agent steps: where the next transition goes, the (reward, done, info) of
+        the agent steps issued ahead, how far ahead the parameter blocks have been generated / issued, and the actor's own
+        random stream."""
+        return dict(slot=self.slot, pending=[list(p) for p in self.pending], pushed=self.pushed, issued=self.issued,
+                    primed=self.primed, rs=(self.rs.get_state() if self.async_actor else None), stream=self.stream.state_dict())
+
+    def load_state_dict(self, st):
+        self.slot, self.pushed, self.issued, self.primed = st["slot"], st["pushed"], st["issued"], st["primed"]
+        self.pending = [[tuple(x) for x in p] for p in st["pending"]]
+        if self.async_actor:
+            self.rs.set_state(st["rs"])
+        self.stream.load_state_dict(st["stream"])
 
     def _block(self):
         """Host side of one agent step's transitions -> (StepParams head filled in learner.params, infos)."""

@@ -40,6 +40,14 @@ class Ring:
         self.capacity, self.frame_bytes, self.action_bytes = int(capacity), int(frame_bytes), int(action_bytes)
         self.history, self.n_step = int(history), int(n_step)
 
+    def arrays(self):
+        """(frames u8[capacity * frame_bytes], actions u8[capacity * action_bytes], rewards f64[capacity], masks i32[capacity])
+        as tensors over the ring's own device memory (true resume dumps / restores them)."""
+        f, a, r, m = self.pointers()
+        return (_wrap_device_pointer(f, self.capacity * self.frame_bytes, torch.uint8),
+                _wrap_device_pointer(a, self.capacity * self.action_bytes, torch.uint8),
+                _wrap_device_pointer(r, self.capacity, torch.float64), _wrap_device_pointer(m, self.capacity, torch.int32))
+
     def close(self):
         if self.h:
             lib.dra_ring_destroy(self.h)
@@ -666,6 +674,16 @@ def categorical_fwd(logits, action=None, uniform=None):
     action = _c(action, torch.int64)
     lib.dra_categorical_fwd(ptr(logits), b, a, ptr(action), None, None, ptr(lp), ptr(ent), stream_ptr())
     return action, lp, ent
+
+
+def gumbel_sample(logits, seed, step_dev, lo):
+    """Rank-invariant categorical sample (dra_gumbel_sample): noise hashed from (seed, *step_dev, global row lo + i, action);
+    advances the device step counter.  Graph-capturable (no host-side generator)."""
+    logits = _c(logits, _f32)
+    b, a = logits.shape
+    out = torch.empty(b, dtype=torch.int64, device=logits.device)
+    lib.dra_gumbel_sample(ptr(logits), b, a, int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(step_dev), int(lo), ptr(out), stream_ptr())
+    return out
 
 
 def categorical_bwd(logits, action, g_lp, g_ent):

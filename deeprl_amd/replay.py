@@ -239,6 +239,61 @@ class UniformReplay(Storage):
     def update_priorities(self, info):
         raise NotImplementedError
 
+    # -- true resume: the ring's contents and the cursor ---------------------------------------
+    _RING_SHARD = 1 << 28       # bytes of frames per shard file
+
+    def save_full(self, prefix):
+        """Writes <prefix>.replay (cursor, shapes, small arrays) and <prefix>.frames.<k> (the frame array in 256 MB shards:
+        7 GB at 10^6 slots -- only the filled part is written)."""
+        import pickle
+        torch.cuda.synchronize()
+        meta = dict(pos=self.pos, size=self._size, cls=type(self).__name__, memory_size=self.memory_size, shards=0,
+                    state_shape=self._state_shape, state_dtype=str(self._state_dtype), action_dtype=str(self._action_dtype))
+        if self._ring is not None:
+            frames, actions, rewards, masks = self._ring.arrays()
+            n = self._size
+            fb = self._ring.frame_bytes
+            meta.update(actions=actions[:n * self._ring.action_bytes].cpu().numpy(), rewards=rewards[:n].cpu().numpy(),
+                        masks=masks[:n].cpu().numpy(), frame_bytes=fb)
+            per = max(1, self._RING_SHARD // fb)
+            k = 0
+            for lo in range(0, n, per):
+                frames[lo * fb:min(n, lo + per) * fb].cpu().numpy().tofile("%s.frames.%d" % (prefix, k))
+                k += 1
+            meta["shards"], meta["slots_per_shard"] = k, per
+        meta.update(self._extra_state())
+        with open(prefix + ".replay", "wb") as f:
+            pickle.dump(meta, f)
+
+    def load_full(self, prefix):
+        import pickle
+        with open(prefix + ".replay", "rb") as f:
+            meta = pickle.load(f)
+        if meta["cls"] != type(self).__name__ or meta["memory_size"] != self.memory_size:
+            raise DraError("%s.replay holds a %s of %d slots" % (prefix, meta["cls"], meta["memory_size"]))
+        if meta["shards"] or meta["size"]:
+            if self._ring is None:
+                sd = meta["state_dtype"]
+                self.device_ring(meta["state_shape"], np.uint8 if "uint8" in sd else (np.float64 if "64" in sd else np.float32),
+                                 np.int64 if "int" in meta["action_dtype"] else np.float64)
+            frames, actions, rewards, masks = self._ring.arrays()
+            n, fb, per = meta["size"], meta["frame_bytes"], meta.get("slots_per_shard", 1)
+            for k in range(meta["shards"]):
+                part = torch.from_numpy(np.fromfile("%s.frames.%d" % (prefix, k), dtype=np.uint8))
+                frames[k * per * fb:k * per * fb + part.numel()].copy_(part)
+            actions[:n * self._ring.action_bytes].copy_(torch.from_numpy(meta["actions"]))
+            rewards[:n].copy_(torch.from_numpy(meta["rewards"]))
+            masks[:n].copy_(torch.from_numpy(meta["masks"]))
+        self.pos, self._size = meta["pos"], meta["size"]
+        self._load_extra_state(meta)
+        torch.cuda.synchronize()
+
+    def _extra_state(self):
+        return {}
+
+    def _load_extra_state(self, meta):
+        pass
+
     def close(self):
         if self._ring is not None:
             self._ring.close()
@@ -273,6 +328,20 @@ class PrioritizedReplay(UniformReplay):
             self._prio_up = _PinnedUploader(torch.float64, 1024, dev)
             self._pos_up = _PinnedUploader(torch.int32, 1024, dev)
             self._stat = torch.tensor([float(self._max_priority), float(self._min_priority)], dtype=torch.float64, device=dev)
+
+    def _extra_state(self):
+        self._lazy_tree()
+        mx = self.max_priority      # (refreshes the host attributes from the device pair when the learner owns them)
+        return dict(tree=self.tree.as_tensor().cpu().numpy().copy(), max_priority=mx, min_priority=self._min_priority,
+                    pending=sorted(self._pending), write=self._write, stat_on_device=self._stat_on_device)
+
+    def _load_extra_state(self, meta):
+        self._lazy_tree()
+        self.tree.as_tensor().copy_(torch.from_numpy(meta["tree"]))
+        self._max_priority, self._min_priority = meta["max_priority"], meta["min_priority"]
+        self._pending, self._write = set(meta["pending"]), meta["write"]
+        self._stat.copy_(torch.tensor([float(self._max_priority), float(self._min_priority)], dtype=torch.float64))
+        self._stat_on_device = meta["stat_on_device"]
 
     @property
     def max_priority(self):

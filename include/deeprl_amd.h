@@ -111,6 +111,11 @@ int dra_categorical_fwd(const float* logits, int batch, int n_actions, const int
                         int64_t* action_out, float* log_pi_a, float* entropy, void* stream);
 int dra_categorical_bwd(const float* logits, int batch, int n_actions, const int64_t* action, const float* g_log_pi_a,
                         const float* g_entropy, float* out_dlogits, void* stream);
+/* rank-invariant Categorical(logits).sample() for the data-parallel on-policy agents: action[i] = argmax_a
+ * (logits[i][a] + Gumbel noise hashed from (seed, *step_dev, lo + i, a)), lo = first GLOBAL environment of this rank; the
+ * kernel advances *step_dev (device int64), so the launch replays from a captured rollout graph.  n_actions <= 64. */
+int dra_gumbel_sample(const float* logits, int n_local, int n_actions, uint64_t seed, int64_t* step_dev, int64_t lo,
+                      int64_t* action_out, void* stream);
 /* deep_rl/agent/PPO_agent.py:77-86: out3 = {policy_loss, value_loss, approx_kl}. */
 int dra_ppo_loss(const float* log_pi_a, const float* entropy, const float* v, const float* old_log_pi_a,
                  const float* adv, const float* ret, int m, float ratio_clip, float entropy_weight, float* out3,
@@ -387,9 +392,10 @@ int dra_dqn_learner_act(dra_dqn_learner* learner, const dra_dqn_step_params* prm
 int dra_dqn_learner_q_host(dra_dqn_learner* learner, const uint8_t* state_host, float* q_host, void* stream);
 /* True resume (optimizer + ring + RNG state; the reference's save() keeps weights only, BaseAgent.py:24-33):
  * the learner-internal state a bit-exact continuation needs beyond what the host owns.  _resume_buffer enumerates device
- * buffers (index 0, 1, ... until DRA_EINVAL; *ptr null when this configuration has no such buffer); _resume_counters reads
+ * buffers (index 0 .. _resume_buffer_count() - 1; *ptr null when this configuration has no such buffer); _resume_counters reads
  * (restore = 0) or installs (restore = 1, into a FRESH learner of the same configuration before its first step) the
  * pipelines' host-side counters (n >= 16).  Call with the learner synchronised, between agent steps. */
+int dra_dqn_learner_resume_buffer_count(void);
 int dra_dqn_learner_resume_buffer(dra_dqn_learner* l, int index, void** ptr, int64_t* bytes, char* name, int name_len);
 int dra_dqn_learner_resume_counters(dra_dqn_learner* l, int64_t* io, int n, int restore);
 /* DRA_VAR_ACTOR_RING: upload the parameter blocks of the next `n` agent steps (consumed in order, one per actor launch;

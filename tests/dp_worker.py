@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    kind, out, updates = sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    kind, out, updates = sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 5
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import deeprl_amd as d
     import deeprl_amd.agents as agents_mod
@@ -26,10 +26,16 @@ def main():
         add_scalar = add_histogram = info
 
     agents_mod.get_logger = lambda *a, **k: Quiet()
+    gpu = 0
     if world > 1:
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        dd.init("gloo")                       # ranks share ONE GPU on the test box: gloo moves the bytes
-    d.select_device(0)
+        if os.environ.get("DP_WORKER_BACKEND") == "nccl":     # every rank owns a GPU: RCCL carries the gradients (comm.hip)
+            gpu = int(os.environ.get("LOCAL_RANK", "0"))
+            torch.cuda.set_device(gpu)
+            dd.init("nccl")
+        else:
+            dd.init("gloo")                   # ranks share ONE GPU on the test box: gloo moves the bytes
+    d.select_device(gpu)
     # identical initial weights on every rank -- or, with DP_WORKER_RANK_SEEDS=1, a different torch seed per rank (what
     # `python -m deeprl_amd.launch` does under torchrun): the agents must then start from rank 0's parameters
     torch.manual_seed(int(os.environ.get("RANK", "0")) if os.environ.get("DP_WORKER_RANK_SEEDS") else 0)

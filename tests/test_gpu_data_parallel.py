@@ -76,6 +76,19 @@ def test_ranks_seeded_differently_start_from_rank0_parameters(tmp_path):
         assert (err <= 2e-6 + 1e-5 * np.abs(one[k])).all(), (k, err.max())
 
 
+@pytest.mark.parametrize("kind,port", [("a2c", 29644), ("ppo", 29645)])
+def test_rccl_two_ranks_equal_gloo_two_ranks(tmp_path, kind, port):
+    """On a node where two ranks can each own a GPU: the same agents with RCCL carrying the gradient (comm.hip's
+    ncclAllReduce, n_ranks = 2: the branch a one-GPU box cannot execute) end on the same parameters, bit for bit, as with gloo
+    (a two-rank sum is one addition per element whichever library performs it)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs on one node (the round's test box has one)")
+    g = _run(kind, str(tmp_path / "gloo.npz"), 2, port)
+    n = _run(kind, str(tmp_path / "rccl.npz"), 2, port + 10, {"DP_WORKER_BACKEND": "nccl"})
+    for k in g:
+        assert np.array_equal(g[k], n[k]), k
+
+
 def test_rccl_comm_of_size_one():
     """csrc/comm.hip through its C ABI: unique id, init_rank, dra_allreduce_grads (sum over 1 rank, then the scale),
     dra_allreduce_f64, destroy."""
