@@ -519,6 +519,11 @@ def main():
         if roof.get("algorithmic_flops") and roof.get("avg_ms") and roof.get("event_pair_empty_ms"):
             t_low = max(roof["avg_ms"] - roof["event_pair_empty_ms"], 1e-6)
             roof["frac_event_pair_corrected"] = roof["algorithmic_flops"] / (t_low * 1e-3) / 1e12 / 157.3
+        mf = getattr(bench, "roofline_mfma", None)
+        if mf is not None:      # the longest MFMA-bound kernel, with the same committed-file cross references
+            mf["rocprofv3"] = rocprof_kernel(mf["kernel"], mf.get("algorithmic_flops"))
+            mf["traffic"] = pmc_traffic(mf["kernel"])
+            roof["mfma_kernel"] = mf
         # the update chain owns a CU partition while the device actor runs beside it (lever 5):
         # the kernel is timed on that stream, i.e. on this many of the device's CUs
         roof["stream_cus"] = bench.learner.update_cus or torch.cuda.get_device_properties(0).multi_processor_count

@@ -397,6 +397,8 @@ class DQNAgent(BaseAgent):
         self.actor.set_network(self.network)
         self.total_steps = 0
         self._learner = None            # fused learner (csrc/learner.hip), attached lazily when eligible
+        self._host_async = False        # host environment + config.async_actor: the two-stream schedule of _step_host_async
+        self._ahead = None
         self._learner_lr = None
         self._pipe = None               # device-resident actor / environment pipeline
         self._fused_checked = False
@@ -481,13 +483,25 @@ class DQNAgent(BaseAgent):
                           v_max=v_max, optimizer=o['optimizer'], betas=o.get('betas', (0.9, 0.999)), **extra)
 
     def _attach_fused_learner(self):
+        """Host environment (a real emulator, or device_env=False): the update runs in csrc/learner.hip, observations and
+        actions cross the host link.  config.async_actor (BaseAgent.py:142-162) is honoured as a two-stream schedule here too:
+        the transitions of agent step t+1 (batch-1 forwards on the actor stream + CU partition, from the parameters of
+        update t-1, and the emulator steps on the host) are produced while update t runs on the update stream
+        (_step_host_async); async_actor=False keeps everything in order on one stream."""
+        from . import ops as _ops
         rp = self._inner_replay()
         torch.cuda.synchronize()        # everything issued so far (feeds, initialisation) is on other streams
-        self._learner = self._make_learner(rp, cu_partition=False)
+        want_async = bool(self.config.async_actor) and not hasattr(rp, 'draw')      # (PER: its draw waits for the update anyway)
+        self._learner = self._make_learner(rp, cu_partition=want_async)
         self._fused = None              # its flat buffer no longer backs the parameters
         self._target_flat = None
         learner = self._learner
-        self.actor._fast_q = lambda state: learner.q_host(np.asarray(state, dtype=np.uint8)).reshape(1, -1)
+        self._host_async = want_async and bool(learner.variant & _ops.VAR_ACTOR_PARAMS)
+        if self._host_async:
+            self._ahead = None
+            self.actor._fast_q = lambda state: learner.q_host_async(np.asarray(state, dtype=np.uint8)).reshape(1, -1)
+        else:
+            self.actor._fast_q = lambda state: learner.q_host(np.asarray(state, dtype=np.uint8)).reshape(1, -1)
 
     # -- device-resident environment + actor (SURVEY.md 8f rank 1; BaseAgent.py:108-182 for async_actor) -----------
     def _device_env(self):
@@ -602,7 +616,7 @@ class DQNAgent(BaseAgent):
                      actor_total_steps=self.actor._total_steps, schedules=sched, learner_lr=self._learner_lr,
                      np_random=np.random.get_state(), py_random=pyrandom.getstate(), torch_cpu=torch.get_rng_state(),
                      torch_cuda=torch.cuda.get_rng_state(Config.DEVICE), agent=type(self).__name__)
-        self._inner_replay().save_full(filename)
+        self._inner_replay().save_full(filename, ahead=2 * self._pipe.n_env)   # the actor is one agent step ahead of the cursor
         with open(filename + '.resume', 'wb') as f:
             pickle.dump(state, f)
 
@@ -717,6 +731,8 @@ class DQNAgent(BaseAgent):
             return self._step_device()
         if self._learner is not None:   # ring feeds, actor forwards and updates share the learner's stream
             with torch.cuda.stream(self._learner.stream):
+                if self._host_async:
+                    return self._step_host_async()
                 return self._step()
         self._step()
         if not self._fused_checked and self._inner_replay().size() > 0:
@@ -759,6 +775,32 @@ class DQNAgent(BaseAgent):
                 self._learn(transitions)
         if self.total_steps / config.sgd_update_frequency % config.target_network_update_freq == 0:
             self.sync_target()
+
+    def _step_host_async(self):
+        """DQN_agent.py:101-138 with async_actor=True over a HOST environment.  The reference's actor process produces the
+        transitions of the next agent step while the learner trains (BaseAgent.py:142-162: step() returns the cached
+        transitions and immediately asks for the next ones).  Here: feed the transitions produced during the previous call,
+        enqueue update t (non-blocking, update stream), then produce the transitions of step t+1 -- forward passes on the
+        actor stream from the parameter copy of update t-1 (csrc/learner.hip dra_dqn_learner_q_host_async), emulator steps
+        on the host -- while the update runs."""
+        config = self.config
+        transitions = self._ahead if self._ahead is not None else self.actor.step()
+        self._ahead = None
+        rp = self._inner_replay()
+        for states, actions, rewards, next_states, dones, info in transitions:
+            self.record_online_return(info)
+            self.total_steps += 1
+            self.replay.feed(dict(
+                state=np.array([s[-1] if isinstance(s, LazyFrames) else s for s in states]),
+                action=actions,
+                reward=[config.reward_normalizer(r) for r in rewards],
+                mask=1 - np.asarray(dones, dtype=np.int32),
+            ))
+        if self.total_steps > config.exploration_steps:
+            self._learner.update_async(rp.draw_indices(), use_graph=True)
+        if self.total_steps / config.sgd_update_frequency % config.target_network_update_freq == 0:
+            self.sync_target()
+        self._ahead = self.actor.step()          # overlaps the update just enqueued
 
     def sync_target(self):
         """DQN_agent.py:136-138 as one device-to-device copy of the flat parameter buffer."""

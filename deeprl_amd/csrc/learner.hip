@@ -185,6 +185,13 @@ struct dra_dqn_learner {
   int sp_k;
   // DRA_VAR_LATE_FOLD: no gradient-norm launch (optim.hip late_step_kernel): sums of squares from the producing kernels,
   // conv3 / conv2 folds riding in the next backward launch, conv1's fold in front of the optimizer launch
+  // host-environment async actor (dra_dqn_learner_update_async / _q_host_async): update t mirrors its parameters into copy
+  // t mod 2, the batch-1 forwards of agent step t+1 read the copy update t-1 wrote, on the actor stream
+  hipGraphExec_t g_qa[2];
+  bool g_qa_ready[2];
+  hipEvent_t ev_hq[2];
+  int64_t hq_updates;               // async updates issued
+  bool hq_seeded;                   // copy (hq_updates - 1) mod 2 holds valid parameters
   unsigned* aflags;                 // DRA_VAR_ACTOR_MEGA: [kMaxEnvSteps][4] arrival counters of the one-launch env steps (zeroed by
                                     // the agent step's tail kernel)
   bool late;
@@ -425,6 +432,7 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= (int)hipMemset(l->prm_dev, 0, sizeof(dra_dqn_step_params));
   for (int k = 0; k <= K_COUNT; ++k) rc |= (int)hipEventCreate(&l->ev[k]);
   for (int k = 0; k < 8; ++k) rc |= (int)hipEventCreateWithFlags(&l->stage_ev[k], hipEventDisableTiming);
+  for (int k = 0; k < 2; ++k) rc |= (int)hipEventCreateWithFlags(&l->ev_hq[k], hipEventDisableTiming);
   rc |= (int)hipStreamCreateWithFlags(&l->side, hipStreamNonBlocking);
   rc |= (int)hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming);
   for (int k = 0; k < 4; ++k) rc |= (int)hipEventCreateWithFlags(&l->ev_join[k], hipEventDisableTiming);
@@ -504,6 +512,10 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (l->qs_stage) (void)hipHostFree(l->qs_stage);
   if (l->q_stage) (void)hipHostFree(l->q_stage);
   if (l->g_q_ready) (void)hipGraphExecDestroy(l->g_q);
+  for (int k = 0; k < 2; ++k) {
+    if (l->g_qa_ready[k]) (void)hipGraphExecDestroy(l->g_qa[k]);
+    if (l->ev_hq[k]) (void)hipEventDestroy(l->ev_hq[k]);
+  }
   for (int k = 0; k <= K_COUNT; ++k) (void)hipEventDestroy(l->ev[k]);
   for (int k = 0; k < 8; ++k) (void)hipEventDestroy(l->stage_ev[k]);
   (void)hipStreamDestroy(l->side);
@@ -1878,10 +1890,13 @@ static int stage_actor_params(dra_dqn_learner* l, const dra_dqn_step_params* prm
 // q[a] of the head at batch 1 (one wave per action for VanillaNet; dist_head_q for the distributional heads)
 __global__ void __launch_bounds__(1024)
 head_q_kernel(const float* __restrict__ h4, const float* __restrict__ wh, const float* __restrict__ bh, int A,
-              float* __restrict__ q_out, const HeadSpec hs) {
+              float* __restrict__ q_out, const HeadSpec hs, unsigned* __restrict__ flags_reset, int n_flags) {
   __shared__ float s_out[kMaxHeadOut];
   __shared__ float s_q[64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // (the arrival counters of the fused conv3 + fc4 launch in front of this kernel are done with: zero them for the next one)
+  if (flags_reset)
+    for (int i = threadIdx.x; i < n_flags; i += blockDim.x) __hip_atomic_store(flags_reset + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (hs.kind != DRA_HEAD_VANILLA) {
     dist_head_q(h4, wh, bh, A, hs, s_out, s_q);
     if (threadIdx.x < A) q_out[threadIdx.x] = s_q[threadIdx.x];
@@ -1927,7 +1942,7 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
         hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
                            l->ah4, 3136);
         hipLaunchKernelGGL(head_q_kernel, dim3(1), dim3(c.head_kind != DRA_HEAD_VANILLA ? 1024 : 256), 0, st, (const float*)l->ah4,
-                           P + o[P_WH], P + o[P_BH], c.n_actions, l->aq, head_spec(l));
+                           P + o[P_WH], P + o[P_BH], c.n_actions, l->aq, head_spec(l), (unsigned*)nullptr, 0);
       }
     }
     hipError_t e = hipStreamEndCapture(st, &graph);
@@ -1938,6 +1953,89 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
     l->g_q_ready = true;
   }
   DRA_HIP(hipGraphLaunch(l->g_q, st));
+  DRA_HIP(hipMemcpyAsync(l->q_stage, l->aq, (size_t)c.n_actions * sizeof(float), hipMemcpyDeviceToHost, st));
+  DRA_HIP(hipStreamSynchronize(st));
+  memcpy(q_host, l->q_stage, (size_t)c.n_actions * sizeof(float));
+  return DRA_OK;
+}
+
+// ---- async actor over a HOST environment (BaseAgent.py:142-162 with a real emulator: the actor's forward for agent step
+// t+1 runs while the learner trains on step t).  The update mirrors its new parameters into copy (t mod 2) of the actor's
+// parameter copies; dra_dqn_learner_q_host_async runs the batch-1 forward of the copy update t-1 wrote on `stream_actor`
+// (the actor's CU partition), so it neither waits for update t nor races with its optimizer.  Needs DRA_VAR_ACTOR_PARAMS.
+DRA_API int dra_dqn_learner_update_async(dra_dqn_learner* l, int use_graph, int per, float beta, void* stream_update) {
+  if (!l || !l->pa[0] || !l->pa[1]) return DRA_EINVAL;
+  if (*l->coop_flag) return DRA_ETIMEDOUT;
+  hipStream_t st = dra_stream(stream_update);
+  l->profiling = false;
+  l->pa_valid = false;
+  const int k = (int)(l->hq_updates & 1);
+  int rc = launch_gather(l, st);
+  if (rc) return rc;
+  rc = (use_graph && !per) ? body_graph(l, st) : ((use_graph && per && beta < 0.f) ? body_graph_per(l, st) : run_body(l, st, per, beta, 0));
+  if (rc) return rc;
+  if ((rc = launch_optimizer(l, st, l->pa[k]))) return rc;
+  DRA_HIP(hipEventRecord(l->ev_hq[k], st));
+  DRA_HIP(hipEventRecord(l->ev_step_done, st));
+  l->last_done = l->ev_step_done;
+  l->hq_updates++;
+  l->hq_seeded = true;
+  return DRA_OK;
+}
+
+DRA_API int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* state_host, float* q_host, void* stream_actor,
+                                         void* stream_update) {
+  if (!l || !state_host || !q_host || !l->pa[0] || !l->pa[1]) return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream_actor);
+  const dra_dqn_config& c = l->c;
+  // copy the newest COMPLETED-BY-ORDER update wrote: update (hq_updates - 2) while update (hq_updates - 1) may still run
+  int k;
+  if (l->hq_updates >= 2) {
+    k = (int)((l->hq_updates - 2) & 1);
+    DRA_HIP(hipStreamWaitEvent(st, l->ev_hq[k], 0));
+  } else {
+    // before the second update: the online parameters as of now (after update 0 if it was issued), copied once per call site
+    k = (int)(l->hq_updates & 1) ^ 1;     // the copy the NEXT update does not write
+    hipStream_t su = dra_stream(stream_update);
+    DRA_HIP(hipEventRecord(l->ev_join[3], su));
+    DRA_HIP(hipStreamWaitEvent(st, l->ev_join[3], 0));
+    if (l->hq_updates == 0) {
+      DRA_HIP(hipMemcpyAsync(l->pa[k], l->p, (size_t)c.n_params * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+      k = 0;                              // exactly one update issued: it wrote copy 0; wait for it (no older copy exists)
+      DRA_HIP(hipStreamWaitEvent(st, l->ev_hq[0], 0));
+    }
+  }
+  memcpy(l->qs_stage, state_host, (size_t)4 * 7056);
+  DRA_HIP(hipMemcpyAsync(l->act_state, l->qs_stage, (size_t)4 * 7056, hipMemcpyHostToDevice, st));
+  if (!l->g_qa_ready[k]) {
+    const int64_t* o = c.offset;
+    const float* P = l->pa[k];
+    void* s = (void*)st;
+    hipGraph_t graph;
+    DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = DRA_OK;
+    {
+      const void* x1[1] = {l->act_state}; const float* w1[1] = {P + o[P_W1]}; const float* b1[1] = {P + o[P_B1]};
+      float* y1[1] = {l->ay1};
+      rc = dra_conv_fwd_koc(1, 1, x1, w1, b1, y1, 1, 1, c.u8_coef, DRA_ACT_RELU, s);
+      // conv2 with its reduction split over two workgroups per tile, conv3 + fc4 as one launch (the device actor's kernels)
+      if (!rc) rc = dra_conv_b1_split(2, l->ay1, nullptr, P + o[P_W2], P + o[P_B2], l->ay2p, s);
+      if (!rc) rc = dra_actor_c3fc4(l->ay2p, P + o[P_W3], P + o[P_B3], P + o[P_W4], P + o[P_B4], l->ay3p, l->ah4,
+                                    l->aflags + 4 * (kMaxEnvSteps - 1), l->coop_flag, s);
+      if (!rc) {
+        hipLaunchKernelGGL(head_q_kernel, dim3(1), dim3(c.head_kind != DRA_HEAD_VANILLA ? 1024 : 256), 0, st, (const float*)l->ah4,
+                           P + o[P_WH], P + o[P_BH], c.n_actions, l->aq, head_spec(l), l->aflags + 4 * (kMaxEnvSteps - 1), 4);
+      }
+    }
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc != DRA_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    DRA_HIP(hipGraphInstantiate(&l->g_qa[k], graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    l->g_qa_ready[k] = true;
+  }
+  DRA_HIP(hipGraphLaunch(l->g_qa[k], st));
   DRA_HIP(hipMemcpyAsync(l->q_stage, l->aq, (size_t)c.n_actions * sizeof(float), hipMemcpyDeviceToHost, st));
   DRA_HIP(hipStreamSynchronize(st));
   memcpy(q_host, l->q_stage, (size_t)c.n_actions * sizeof(float));

@@ -676,6 +676,42 @@ def categorical_fwd(logits, action=None, uniform=None):
     return action, lp, ent
 
 
+class AtariPreprocess:
+    """envs.py:39-47 (baselines' MaxAndSkipEnv max + WarpFrame: RGB2GRAY, INTER_AREA resize to 84x84) as one kernel
+    (csrc/preproc.hip): raw [n_env][2][H][W][3] uint8 (the last two frames of each environment's frame skip; host array or
+    device tensor) -> device uint8 [n_env][84][84], what FrameStack / the replay ring take.  The two axis tables are built
+    once on the host by dra_resize_area_tab (OpenCV's computeResizeAreaTab)."""
+
+    def __init__(self, height=210, width=160, out_h=84, out_w=84, device=None):
+        from .support import Config
+        self.h, self.w, self.oh, self.ow = int(height), int(width), int(out_h), int(out_w)
+        self.device = device or Config.DEVICE
+        self.tabs = []
+        for ssize, dsize in ((self.w, self.ow), (self.h, self.oh)):
+            cap = 2 * ssize + dsize + 8
+            si, al, off = (ctypes.c_int * cap)(), (ctypes.c_float * cap)(), (ctypes.c_int * (dsize + 1))()
+            n = lib.dra_resize_area_tab.raw(ssize, dsize, si, al, off, cap)
+            if n <= 0:
+                raise DraError("dra_resize_area_tab(%d, %d) failed: %d" % (ssize, dsize, n))
+            self.tabs += [torch.tensor(list(si[:n]), dtype=torch.int32, device=self.device),
+                          torch.tensor(list(al[:n]), dtype=torch.float32, device=self.device),
+                          torch.tensor(list(off), dtype=torch.int32, device=self.device)]
+
+    def __call__(self, raw2, out=None):
+        if not isinstance(raw2, torch.Tensor):
+            raw2 = torch.from_numpy(np.ascontiguousarray(raw2, dtype=np.uint8)).to(self.device, non_blocking=True)
+        raw2 = _c(raw2, torch.uint8)
+        n = raw2.shape[0]
+        if tuple(raw2.shape[1:]) != (2, self.h, self.w, 3):
+            raise DraError("AtariPreprocess: raw frames must be [n_env, 2, %d, %d, 3] uint8" % (self.h, self.w))
+        if out is None:
+            out = torch.empty((n, self.oh, self.ow), dtype=torch.uint8, device=raw2.device)
+        t = self.tabs
+        lib.dra_atari_preprocess(ptr(raw2), n, self.h, self.w, self.oh, self.ow, ptr(t[0]), ptr(t[1]), ptr(t[2]), ptr(t[3]), ptr(t[4]),
+                                 ptr(t[5]), ptr(out), stream_ptr())
+        return out
+
+
 def gumbel_sample(logits, seed, step_dev, lo):
     """Rank-invariant categorical sample (dra_gumbel_sample): noise hashed from (seed, *step_dev, global row lo + i, action);
     advances the device step counter.  Graph-capturable (no host-side generator)."""

@@ -242,16 +242,18 @@ class UniformReplay(Storage):
     # -- true resume: the ring's contents and the cursor ---------------------------------------
     _RING_SHARD = 1 << 28       # bytes of frames per shard file
 
-    def save_full(self, prefix):
+    def save_full(self, prefix, ahead=0):
         """Writes <prefix>.replay (cursor, shapes, small arrays) and <prefix>.frames.<k> (the frame array in 256 MB shards:
-        7 GB at 10^6 slots -- only the filled part is written)."""
+        7 GB at 10^6 slots -- only the filled part is written).  ahead: slots beyond the logical size that already hold
+        data (the device actor runs one agent step ahead of the replay's cursor)."""
         import pickle
         torch.cuda.synchronize()
         meta = dict(pos=self.pos, size=self._size, cls=type(self).__name__, memory_size=self.memory_size, shards=0,
                     state_shape=self._state_shape, state_dtype=str(self._state_dtype), action_dtype=str(self._action_dtype))
         if self._ring is not None:
             frames, actions, rewards, masks = self._ring.arrays()
-            n = self._size
+            n = min(self.memory_size, self._size + int(ahead))
+            meta["slots"] = n
             fb = self._ring.frame_bytes
             meta.update(actions=actions[:n * self._ring.action_bytes].cpu().numpy(), rewards=rewards[:n].cpu().numpy(),
                         masks=masks[:n].cpu().numpy(), frame_bytes=fb)
@@ -277,7 +279,7 @@ class UniformReplay(Storage):
                 self.device_ring(meta["state_shape"], np.uint8 if "uint8" in sd else (np.float64 if "64" in sd else np.float32),
                                  np.int64 if "int" in meta["action_dtype"] else np.float64)
             frames, actions, rewards, masks = self._ring.arrays()
-            n, fb, per = meta["size"], meta["frame_bytes"], meta.get("slots_per_shard", 1)
+            n, fb, per = meta.get("slots", meta["size"]), meta["frame_bytes"], meta.get("slots_per_shard", 1)
             for k in range(meta["shards"]):
                 part = torch.from_numpy(np.fromfile("%s.frames.%d" % (prefix, k), dtype=np.uint8))
                 frames[k * per * fb:k * per * fb + part.numel()].copy_(part)

@@ -169,6 +169,16 @@ int dra_linear_bwd_w(const float* dy, const float* x, float* dw, float* db, int 
 int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* dx, int batch, int in_features,
                      int out_features, int act, void* stream);
 
+/* ---- Atari frame preprocessing (csrc/preproc.hip): deep_rl/component/envs.py:39-47 -> baselines' MaxAndSkipEnv (max of the
+ * last two raw frames) + WarpFrame (cv2 RGB2GRAY, cv2.resize INTER_AREA to 84x84), restated from OpenCV's published
+ * algorithms; parity unpinned by the reference (cv2 / baselines are not in the image).  dra_resize_area_tab builds one
+ * axis' (source index, weight) table on the HOST (offs has dsize + 1 entries; returns the entry count); the kernel takes
+ * device copies of the two tables.  raw: [n_env][2][height][width][3] uint8, out: [n_env][out_h][out_w] uint8. */
+int dra_resize_area_tab(int ssize, int dsize, int* si, float* alpha, int* offs, int max_entries);
+int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, int out_h, int out_w, const int* x_si,
+                         const float* x_alpha, const int* x_off, const int* y_si, const float* y_alpha, const int* y_off,
+                         uint8_t* out, void* stream);
+
 /* ---- horizontally fused backward launches + one-pass contractions (csrc/fused.hip, csrc/oneshot.h): the autograd
  * backward behind DQN_agent.py:129 for VanillaNet(NatureConvBody).  `variant` / tuning bits: */
 #define DRA_VAR_FUSED_BWD 1      /* learner: a layer's weight- and input-gradient kernels share one launch */
@@ -390,6 +400,13 @@ int dra_dqn_learner_act(dra_dqn_learner* learner, const dra_dqn_step_params* prm
  * observation, q_host = float[n_actions] out.  Pinned staging both ways, batch-1 forward of the online parameters
  * as one captured graph; synchronises `stream` (like the reference's to_np(q)). */
 int dra_dqn_learner_q_host(dra_dqn_learner* learner, const uint8_t* state_host, float* q_host, void* stream);
+/* Async actor over a HOST environment (BaseAgent.py:142-162 with a real emulator; needs DRA_VAR_ACTOR_PARAMS):
+ * _update_async = dra_dqn_learner_update whose optimizer also mirrors the new parameters into actor copy (t mod 2);
+ * _q_host_async = dra_dqn_learner_q_host on `stream_actor`, reading the copy the update BEFORE the most recent one wrote --
+ * the forward for agent step t+1 overlaps update t and never races with its optimizer. */
+int dra_dqn_learner_update_async(dra_dqn_learner* l, int use_graph, int per, float beta, void* stream_update);
+int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* state_host, float* q_host, void* stream_actor,
+                                 void* stream_update);
 /* True resume (optimizer + ring + RNG state; the reference's save() keeps weights only, BaseAgent.py:24-33):
  * the learner-internal state a bit-exact continuation needs beyond what the host owns.  _resume_buffer enumerates device
  * buffers (index 0 .. _resume_buffer_count() - 1; *ptr null when this configuration has no such buffer); _resume_counters reads

@@ -901,3 +901,24 @@ def test_linear_small_layers_vs_torch(dev, b, k, o, act):
     got = ops.linear_fwd([torch.from_numpy(x).to(dev)], [torch.from_numpy(w).to(dev)], [torch.from_numpy(bias).to(dev)], act=act)[0]
     scale = float((np.abs(x) @ np.abs(w).T).max())
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5 * scale + 1e-6)
+
+
+def test_atari_preprocess_kernel_equals_oracle(dev):
+    """csrc/preproc.hip (max of two raw frames, RGB2GRAY, INTER_AREA resize 210x160 -> 84x84; envs.py:39-47 via baselines'
+    MaxAndSkipEnv / WarpFrame) against oracle/preproc_oracle.py: BIT-EXACT (same fp32 operation order), including the axis
+    tables dra_resize_area_tab builds on the host.  Parity unpinned by the reference (cv2 / baselines are not installed)."""
+    from deeprl_amd import ops
+    from oracle import preproc_oracle as P
+    rs = np.random.RandomState(5)
+    raw = rs.randint(0, 256, size=(3, 2, 210, 160, 3)).astype(np.uint8)
+    raw[2, 0] = 0
+    raw[2, 1, ::2] = 255
+    pre = ops.AtariPreprocess()
+    for (si, al, off), (ssize, dsize) in zip((pre.tabs[0:3], pre.tabs[3:6]), ((160, 84), (210, 84))):
+        tab = P.resize_area_tab(ssize, dsize)
+        flat = [e for row in tab for e in row]
+        assert si.cpu().tolist() == [s for s, _ in flat]
+        assert np.array_equal(al.cpu().numpy(), np.asarray([a for _, a in flat], dtype=np.float32))
+        assert off.cpu().tolist() == list(np.cumsum([0] + [len(r) for r in tab]))
+    got = pre(raw).cpu().numpy()
+    assert np.array_equal(got, P.atari_preprocess(raw))

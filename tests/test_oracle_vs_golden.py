@@ -387,3 +387,38 @@ def test_replay_oracle_equals_live_reference_on_random_streams(seed):
                     r.update_priorities(info)
                     o.update_priorities(info)
                     assert np.array_equal(r.tree.tree, o.tree.tree) and r.max_priority == o.max_priority
+
+
+def test_atari_preprocess_oracle_vs_float64_area_average():
+    """oracle/preproc_oracle.py restates OpenCV's RGB2GRAY + INTER_AREA resize (parity unpinned by the reference: cv2 and
+    baselines are not installed).  Checked against an INDEPENDENT formulation: the exact area average of the luminance image
+    over each destination cell in float64 (overlap-weighted box filter) -- the fp32 table walk may differ from it by
+    rounding only: at most one grey level, and only where the exact average sits on a .5 boundary to ~1e-4."""
+    from oracle import preproc_oracle as P
+    rs = np.random.RandomState(0)
+    raw = rs.randint(0, 256, size=(2, 2, 210, 160, 3)).astype(np.uint8)
+    raw[1, :, 50:90] = 255                       # a saturated band and a black band: exact values survive the average
+    raw[1, :, 120:160] = 0
+    got = P.atari_preprocess(raw)
+    assert got.shape == (2, 84, 84) and got.dtype == np.uint8
+    mx = np.maximum(raw[:, 0], raw[:, 1]).astype(np.int64)
+    gray = ((mx[..., 0] * 4899 + mx[..., 1] * 9617 + mx[..., 2] * 1868 + 8192) >> 14).astype(np.float64)
+
+    def weights(ssize, dsize):
+        w = np.zeros((dsize, ssize))
+        scale = ssize / dsize
+        for d in range(dsize):
+            lo, hi = d * scale, (d + 1) * scale
+            for s in range(int(np.floor(lo)), min(ssize, int(np.ceil(hi)))):
+                w[d, s] = max(0.0, min(hi, s + 1) - max(lo, s))
+            w[d] /= w[d].sum()
+        return w
+    wy, wx = weights(210, 84), weights(160, 84)
+    exact = np.einsum("ys,nst,xt->nyx", wy, gray, wx)
+    diff = np.abs(got.astype(np.float64) - exact)
+    assert diff.max() <= 0.5 + 1e-3, diff.max()
+    assert (got[1, 22:34] == 255).all() and (got[1, 50:62] == 0).all()     # rows fully inside the saturated / black bands
+    # the table itself: weights of every destination index sum to 1 (fp32) and cover [d*scale, (d+1)*scale)
+    for ssize in (210, 160):
+        for row in P.resize_area_tab(ssize, 84):
+            assert abs(sum(float(a) for _, a in row) - 1.0) < 1e-6
