@@ -195,9 +195,10 @@ def cpu_replicas(nproc, seconds=6.0, ring=5_000, limit=64):
 def agent_api(seconds=2.0):
     """The same configuration through the drop-in surface: zoo.agent('dqn_pixel') = the reference's examples.py::dqn_pixel
     (1M-frame replay, async_actor=True; examples.py:55-97) stepped exactly as run_steps does (agent.step() in a loop).
-    Three variants: the reference's own setting (async_actor=True: device-resident environment + two-stream pipeline),
-    async_actor=False (same kernels in order) and device_env=False (HOST emulator: every observation uploaded, every action
-    crossing back, as in the reference).  Reported next to `value`, never as `value`."""
+    Four variants: the reference's own setting (async_actor=True: device-resident environment + two-stream pipeline),
+    async_actor=False (same kernels in order), device_env=False (HOST emulator: every observation uploaded, every action
+    crossing back, as in the reference) in order, and the host emulator with async_actor=True (the forward passes of agent
+    step t+1 on the actor stream while update t trains).  Reported next to `value`, never as `value`."""
     import deeprl_amd as d
     import deeprl_amd.agents as agents_mod
     from deeprl_amd import zoo
@@ -210,7 +211,8 @@ def agent_api(seconds=2.0):
     agents_mod.get_logger = lambda *a, **k: _Quiet()
     out = {}
     for name, over in (("async_actor", dict(async_actor=True)), ("sync_actor", dict(async_actor=False)),
-                       ("host_emulator", dict(async_actor=False, device_env=False))):
+                       ("host_emulator", dict(async_actor=False, device_env=False)),
+                       ("host_emulator_async_actor", dict(async_actor=True, device_env=False))):
         d.random_seed(1)
         over.update(exploration_steps=200, save_interval=0)
         agent = zoo.agent("dqn_pixel", game="synthetic-atari", overrides=over)
@@ -381,13 +383,16 @@ def on_policy_main(args):
     np.random.seed(0)
     agent = zoo.agent(args.workload, game="synthetic-atari", overrides=dict(num_workers=per_gpu * world, save_interval=0))
     steps_per_call = agent.config.rollout_length * per_gpu * world
-    for _ in range(max(1, args.warmup // 20)):
+    # a step = one agent.step() = one rollout (+ its optimisation phase); at least 4 warm-up steps: the rollout is captured
+    # as a graph after two eager calls (agents._OnPolicyGraph), the capture itself is the third
+    n_warm = max(4, args.warmup if args.warmup <= 50 else args.warmup // 20)
+    for _ in range(n_warm):
         agent.step()
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
-    k = max(1, args.steps // 20)
+    k = max(1, args.steps if args.steps <= 400 else args.steps // 20)
     t0 = time.perf_counter()
     for _ in range(k):
         agent.step()
@@ -402,7 +407,7 @@ def on_policy_main(args):
     if rank == 0:
         print(json.dumps({
             "metric": "env-steps/sec", "value": k * steps_per_call / dt, "unit": "env-steps/s", "n_gpus": world, "steps": k,
-            "warmup": max(1, args.warmup // 20), "ms_per_step": 1e3 * dt / k, "higher_is_better": True, "scaling": "weak",
+            "warmup": n_warm, "ms_per_step": 1e3 * dt / k, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s (BASELINE configs[4]): %d environments per GPU, rollout %d, %s, "
                                    "gradient all-reduce per optimizer step" % (

@@ -578,6 +578,10 @@ DRA_API int dra_dqn_learner_resume_counters(dra_dqn_learner* l, int64_t* io, int
   l->aring_issued = (uint64_t)io[4]; l->aring_primed = io[5] != 0; l->rd_issued = (uint64_t)io[6]; l->actor_pending = false;
   l->stage_k = (int)io[8]; l->gb = (int)io[9]; l->last_gb = (int)io[10]; l->aprm_seq = (uint64_t)io[11];
   l->ag_have_prev = io[14] != 0; l->ag_prev_par = (int)io[15];
+  // the host mirror of the actor parameter-block ring: the pipelined step reads the slots of the blocks it issues from it
+  // (which ring slots an actor launch writes decides the cross-stream waits); the device ring was restored by the caller
+  if (l->aring_dev && l->aring_stage)
+    DRA_HIP(hipMemcpy(l->aring_stage, l->aring_dev, (size_t)kAringSlots * kAprmStride, hipMemcpyDeviceToHost));
   return DRA_OK;
 }
 

@@ -3,7 +3,7 @@
     python tests/resume_worker.py <kind> <out.npz> run   <steps>                     uninterrupted
     python tests/resume_worker.py <kind> <out.npz> save  <steps> <checkpoint prefix>  steps, then save_full
     python tests/resume_worker.py <kind> <out.npz> load  <steps> <checkpoint prefix>  fresh agent, load_full, then steps
-kind: dqn_async | dqn_sync | c51_per_async.  Writes final parameters, ring contents (first 400 slots) and the step count."""
+kind: dqn_async | dqn_sync | c51_per_async | dqn_per_async | c51_async.  Writes final parameters, ring contents (first 400 slots) and the step count."""
 import os
 import sys
 
@@ -27,6 +27,8 @@ def build(kind):
     agents_mod.get_logger = lambda *a, **k: _Quiet()
     d.select_device(0)
     d.random_seed(3)
+    import random
+    random.seed(3)      # PrioritizedReplay draws from python `random` (replay.py:169-172), which random_seed() leaves unseeded
     cfg = d.Config()
     per = "per" in kind
     cfg.merge(dict(game="synthetic-atari", n_step=1, replay_cls=d.PrioritizedReplay if per else d.UniformReplay, async_replay=False,
