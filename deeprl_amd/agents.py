@@ -797,7 +797,11 @@ class DQNAgent(BaseAgent):
                 mask=1 - np.asarray(dones, dtype=np.int32),
             ))
         if self.total_steps > config.exploration_steps:
-            self._learner.update_async(rp.draw_indices(), use_graph=True)
+            # the reference's rejection loop (replay.py:92-103) drawn in blocks: same np.random stream, same indices
+            # (learner.draw_uniform_indices; tests/test_host_utils_vs_reference.py), a fifth of the host time
+            from .learner import draw_uniform_indices
+            idx = draw_uniform_indices(rp.size(), rp.pos, rp.batch_size, rp.history_length, rp.n_step)
+            self._learner.update_async(idx, use_graph=True)
         if self.total_steps / config.sgd_update_frequency % config.target_network_update_freq == 0:
             self.sync_target()
         self._ahead = self.actor.step()          # overlaps the update just enqueued

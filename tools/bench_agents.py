@@ -131,6 +131,7 @@ def ppo_pixel(workers=8, device=True):
 
 CASES = {
     "dqn_pixel_uniform": lambda: dqn_family("dqn", d.UniformReplay),                      # fused learner attached
+    "dqn_pixel_uniform_host_async": lambda: dqn_family("dqn", d.UniformReplay, async_actor=True),   # host emulator, async actor
     "dqn_pixel_uniform_generic": lambda: dqn_family("dqn", d.UniformReplay, fused=False),  # autograd path
     "dqn_pixel_per": lambda: dqn_family("dqn", d.PrioritizedReplay),
     "c51_pixel_uniform": lambda: dqn_family("c51", d.UniformReplay),
