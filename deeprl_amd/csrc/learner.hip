@@ -192,6 +192,11 @@ struct dra_dqn_learner {
   hipEvent_t ev_hq[2];
   int64_t hq_updates;               // async updates issued
   bool hq_seeded;                   // copy (hq_updates - 1) mod 2 holds valid parameters
+  // the prioritized draw inside the update chain (dra_dqn_learner_set_per_chain): the replay's tree, its {max, min} pair and one
+  // pinned io block per rotation slot; captured into the PER update's first graph behind the loss kernel
+  dra_sumtree* per_tree;
+  double* per_stat;
+  dra_per_chain_io* per_io[4];
   unsigned* aflags;                 // DRA_VAR_ACTOR_MEGA: [kMaxEnvSteps][4] arrival counters of the one-launch env steps (zeroed by
                                     // the agent step's tail kernel)
   bool late;
@@ -1329,6 +1334,10 @@ static int capture_part(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int 
   hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (b != hipSuccess) { l->gb = 0; l->rd_slot = -1; return (int)b; }
   int rc = run_body(l, st, per, per ? -1.f : 0.f, 0, part);     // PER: the exponent is read from sampling_prob[B]
+  // the prioritized draw inside the chain: write-back of THIS update's priorities, the next step's adds and the next
+  // draw's descent as one kernel right behind the loss (inputs / outputs in the slot's pinned block)
+  if (rc == DRA_OK && per && part == 1 && l->per_tree && l->per_io[q & 3])
+    rc = dra_sumtree_per_chain(l->per_tree, l->per_io[q & 3], l->prio, l->per_stat, (void*)st);
   if (rc == DRA_OK && with_optimizer) rc = launch_optimizer(l, st, l->pa[q]);
   hipError_t e = hipStreamEndCapture(st, &graph);
   l->gb = 0;
@@ -1367,6 +1376,31 @@ static int pipe_graph(dra_dqn_learner* l, hipStream_t st, int par, int per = 0) 
 }
 
 static int rd_graph(dra_dqn_learner* l, hipStream_t st, int q, int per = 0) { return update_graph(l, st, q, true, per); }
+
+// PrioritizedReplay inside the update chain (sumtree.hip dra_sumtree_per_chain): tree = the replay's sum tree, stat_dev = its
+// {max_priority, min priority} pair, io[4] = pinned blocks, one per rotation slot of the pipelined update (slot of the next
+// update: dra_dqn_learner_next_slot).  Must be set before the first prioritized update is captured; tree == null switches
+// it off (later captures).  dra_dqn_learner_sync_loss blocks the HOST until the loss kernel (and the chain kernel behind it)
+// of the update issued last have run: the next draw is then in that update's io block.
+DRA_API int dra_dqn_learner_set_per_chain(dra_dqn_learner* l, dra_sumtree* tree, double* stat_dev, dra_per_chain_io* io0,
+                                          dra_per_chain_io* io1, dra_per_chain_io* io2, dra_per_chain_io* io3) {
+  if (!l || (tree && (!stat_dev || !io0 || !io1 || !io2 || !io3))) return DRA_EINVAL;
+  for (int k = 0; k < 4; ++k)
+    if (l->g_rd_per_ready[k] || l->g_pipe_per_ready[k]) return DRA_EINVAL;     // the graphs bake the choice
+  l->per_tree = tree; l->per_stat = stat_dev;
+  l->per_io[0] = io0; l->per_io[1] = io1; l->per_io[2] = io2; l->per_io[3] = io3;
+  return DRA_OK;
+}
+DRA_API int dra_dqn_learner_next_slot(dra_dqn_learner* l, int* slot) {
+  if (!l || !slot) return DRA_EINVAL;
+  *slot = (int)(l->step_no & 3);
+  return DRA_OK;
+}
+DRA_API int dra_dqn_learner_sync_loss(dra_dqn_learner* l) {
+  if (!l) return DRA_EINVAL;
+  DRA_HIP(hipEventSynchronize(l->ev_loss));
+  return DRA_OK;
+}
 
 // The tree stream of a PER pipeline waits here for the TD errors / new priorities of the update issued last (they exist
 // after the loss kernel: the backward pass and the optimizer are still to run).

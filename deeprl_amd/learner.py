@@ -288,6 +288,20 @@ class DQNLearner:
         new priorities in self.prio."""
         lib.dra_dqn_learner_set_per(self.h, int(bool(per)), float(beta))
 
+    def set_per_chain(self, tree, stat, blocks):
+        """PrioritizedReplay inside the update chain: `tree` (ops.SumTree), `stat` (its device {max, min} pair) and four
+        pinned dra_per_chain_io blocks; before the first prioritized update."""
+        lib.dra_dqn_learner_set_per_chain(self.h, tree.h, ctypes.c_void_p(stat.data_ptr()),
+                                          *[ctypes.c_void_p(ctypes.addressof(b)) for b in blocks])
+
+    def next_slot(self):
+        q = ctypes.c_int()
+        lib.dra_dqn_learner_next_slot(self.h, ctypes.byref(q))
+        return q.value
+
+    def sync_loss(self):
+        lib.dra_dqn_learner_sync_loss(self.h)
+
     def wait_loss(self, stream):
         """`stream` waits until the TD errors / new priorities of the PER update issued last exist (its backward pass and
         optimizer are still running then)."""
@@ -527,6 +541,11 @@ class DeviceActorPipeline:
         # latency chains of ~20 dependent levels each; they depend on the previous UPDATE only, so they run on their own
         # stream underneath the actor's forward passes
         self.tree_stream = torch.cuda.Stream() if self.per else None
+        # PER + async: write-back, next step's adds and the next draw's descent run INSIDE the update graph behind the loss
+        # kernel (sumtree.hip dra_sumtree_per_chain): the host collects the next draw after the loss event instead of driving
+        # a tree stream (DRA_PER_CHAIN=0: the round-2 tree-stream form)
+        self.chain = bool(self.per and async_actor and os.environ.get("DRA_PER_CHAIN", "1") != "0")
+        self._chain_io = self._chain_prev = None
         self.A, self.n_env, self.epsilon_fn, self.async_actor = int(n_actions), int(n_env), epsilon_fn, bool(async_actor)
         self.rs = np.random.RandomState(actor_seed) if async_actor else np.random
         self.capacity = replay.memory_size
@@ -544,8 +563,14 @@ class DeviceActorPipeline:
         """Host side of the pipeline between two agent steps: where the next transition goes, the (reward, done, info) of
         the agent steps issued ahead, how far ahead the parameter blocks have been generated / issued, and the actor's own
         random stream."""
+        chain_prev = None
+        if self._chain_prev is not None:       # the next draw, produced by the last update's chain kernel
+            self.L.sync_loss()
+            b, io = self.rp.batch_size, self._chain_prev
+            chain_prev = (list(io.out_idx[:b]), list(io.out_p[:b]), float(io.out_total))
         return dict(slot=self.slot, pending=[list(p) for p in self.pending], pushed=self.pushed, issued=self.issued,
-                    primed=self.primed, rs=(self.rs.get_state() if self.async_actor else None), stream=self.stream.state_dict())
+                    primed=self.primed, rs=(self.rs.get_state() if self.async_actor else None), stream=self.stream.state_dict(),
+                    chain_prev=chain_prev)
 
     def load_state_dict(self, st):
         self.slot, self.pushed, self.issued, self.primed = st["slot"], st["pushed"], st["issued"], st["primed"]
@@ -553,6 +578,16 @@ class DeviceActorPipeline:
         if self.async_actor:
             self.rs.set_state(st["rs"])
         self.stream.load_state_dict(st["stream"])
+        if st.get("chain_prev") is not None:
+            if self._chain_io is None:
+                self._chain_io = self.rp.chain_blocks(4)
+                self.L.set_per_chain(self.rp.tree, self.rp._stat, [b for b, _ in self._chain_io])
+            io = self._chain_io[0][0]
+            idx, p, total = st["chain_prev"]
+            io.out_idx[:len(idx)] = idx
+            io.out_p[:len(p)] = p
+            io.out_total = total
+            self._chain_prev = io
 
     def _block(self):
         """Host side of one agent step's transitions -> (StepParams head filled in learner.params, infos)."""
@@ -618,13 +653,35 @@ class DeviceActorPipeline:
             self.primed = True
         infos = self.pending.pop(0)                                  # produced by the actor launch issued last call
         if self.per:
-            rp.advance(self.n_env, stream=self.tree_stream)
+            # (chain mode, once primed: the tree side of these adds ran inside the previous update's chain kernel)
+            rp.advance(self.n_env, stream=self.tree_stream, tree=not (self.chain and self._chain_prev is not None))
         else:
             rp.advance(self.n_env)
         do_update = bool(account(infos))
         if self.pushed - self.issued < 8:
             self._push()
         L.params.n_env = self.n_env
+        if self.per and do_update and self.chain:
+            B = rp.batch_size
+            if self._chain_io is None:
+                self._chain_io = rp.chain_blocks(4)
+                L.set_per_chain(rp.tree, rp._stat, [b for b, _ in self._chain_io])
+            if self._chain_prev is None:
+                # the first prioritized update: a classic draw (tree stream); the tree is then handed to the update stream
+                tree_idx, prob, data_idx = rp.draw_end(rp.draw_begin(stream=self.tree_stream))
+                self.tree_stream.synchronize()
+            else:
+                L.sync_loss()                                       # loss + chain kernel of the previous update have run
+                tree_idx, prob, data_idx = rp.chain_collect(self._chain_prev, B)
+            leaves, pos = rp.commit_select(tree_idx)               # gating needs no priority value: decided before the update
+            io = self._chain_io[L.next_slot()][0]
+            rp.chain_fill(io, leaves, pos, batch=B, add_n=self.n_env, next_batch=B)
+            L.upload_sampling_prob(prob, self.beta_fn())
+            L.set_per(True, -1.0)
+            L.step(data_idx, True, True)                             # [fwd + loss][commit, adds, next descent][bwd + optimizer]
+            self._chain_prev = io
+            self.issued += 1
+            return infos
         if self.per and do_update:
             # PrioritizedReplay inside the two-stream pipeline: the draw of step t needs the priorities update t-1 wrote
             # back, so the host does wait once per step (tree stream: write-back t-1, adds t, descent t -> pinned memory);

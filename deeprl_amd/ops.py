@@ -676,6 +676,14 @@ def categorical_fwd(logits, action=None, uniform=None):
     return action, lp, ent
 
 
+class PerChainIO(ctypes.Structure):
+    """include/deeprl_amd.h dra_per_chain_io (pinned host block of one dra_sumtree_per_chain launch)."""
+    _fields_ = [("n_commit", ctypes.c_int32), ("add_n", ctypes.c_int32), ("batch", ctypes.c_int32), ("next_batch", ctypes.c_int32),
+                ("force_ordered", ctypes.c_int32), ("reserved", ctypes.c_int32), ("add_write0", ctypes.c_int64),
+                ("leaves", ctypes.c_int64 * 1024), ("pos", ctypes.c_int32 * 1024), ("u", ctypes.c_double * 1024),
+                ("out_idx", ctypes.c_int64 * 1024), ("out_p", ctypes.c_double * 1024), ("out_total", ctypes.c_double)]
+
+
 class AtariPreprocess:
     """envs.py:39-47 (baselines' MaxAndSkipEnv max + WarpFrame: RGB2GRAY, INTER_AREA resize to 84x84) as one kernel
     (csrc/preproc.hip): raw [n_env][2][H][W][3] uint8 (the last two frames of each environment's frame skip; host array or

@@ -386,11 +386,14 @@ class PrioritizedReplay(UniformReplay):
         if self._write >= self.memory_size:
             self._write = 0
 
-    def advance(self, n=1, stream=None):
+    def advance(self, n=1, stream=None, tree=True):
         """UniformReplay.advance + the tree side of feed() for transitions a DEVICE producer wrote into the ring.
-        stream: where the tree kernels go (default: torch's current stream)."""
+        stream: where the tree kernels go (default: torch's current stream).  tree=False: cursor / size only -- the adds were
+        issued inside the previous update's chain kernel (chain_fill)."""
         n = int(n)
         super().advance(n)
+        if not tree:
+            return
         self._lazy_tree()
         if not self._stat_on_device or n > 64 or n > self.memory_size:
             with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
@@ -442,9 +445,9 @@ class PrioritizedReplay(UniformReplay):
         batch_size, ev = pending_draw
         ev.synchronize()
         oi, op, ot = self._draw_np
-        tree_idx = oi[:batch_size].copy()
-        p = op[:batch_size].copy()
-        total = float(ot[0])
+        return self._finish_draw(oi[:batch_size].copy(), op[:batch_size].copy(), float(ot[0]), batch_size)
+
+    def _finish_draw(self, tree_idx, p, total, batch_size):
         # the common case without the per-sample python loop: every drawn transition is valid -> nothing is skipped or padded
         di_all = tree_idx - (self.memory_size - 1)
         lo, hi = di_all - self.history_length + 1, di_all + self.n_step
@@ -497,6 +500,54 @@ class PrioritizedReplay(UniformReplay):
                 self.tree.update(self._leaf_up.upload(np.asarray(leaves, dtype=np.int64)),
                                  self._prio_up.upload(np.asarray(prios, dtype=np.float64)),
                                  ordered=self.ordered_updates or not self._exact_parallel())
+
+    # -- the prioritized draw inside the update chain (csrc/sumtree.hip dra_sumtree_per_chain; learner.DeviceActorPipeline) --
+    def chain_blocks(self, n=4):
+        """n pinned dra_per_chain_io blocks (one per rotation slot of the pipelined update) -> list of (ctypes struct, pinned
+        tensor); also moves {max_priority, min priority} to the device pair the chain kernel maintains."""
+        import ctypes
+        self._lazy_tree()
+        if not self._stat_on_device:
+            self._stat.copy_(torch.tensor([float(self._max_priority), float(self._min_priority)], dtype=torch.float64))
+            self._stat_on_device = True
+        out = []
+        for _ in range(n):
+            t = torch.zeros(ctypes.sizeof(ops.PerChainIO), dtype=torch.uint8).pin_memory()
+            out.append((ops.PerChainIO.from_address(t.data_ptr()), t))
+        return out
+
+    def commit_select(self, tree_idx):
+        """update_priorities' gating (sum_tree.py:54-60) without the priorities: which sampled leaves are written -- pending
+        ones, first occurrence wins -- and their positions in the minibatch."""
+        leaves, pos = [], []
+        pend = self._pending
+        for j, idx in enumerate(tree_idx.tolist()):
+            if idx in pend:
+                pend.remove(idx)
+                leaves.append(idx)
+                pos.append(j)
+        return leaves, pos
+
+    def chain_fill(self, io, leaves, pos, batch, add_n, next_batch):
+        """Inputs of one dra_sumtree_per_chain launch: this update's gated leaves, the NEXT agent step's add_n adds (host
+        side of those adds happens here: a leaf that is overwritten is no longer pending, the write cursor moves on --
+        _add_leaf / advance), and the next draw's uniforms from python `random` (replay.py:169-172)."""
+        n = len(leaves)
+        io.n_commit, io.add_n, io.batch, io.next_batch = n, int(add_n), int(batch), int(next_batch)
+        io.force_ordered, io.add_write0 = int(bool(self.ordered_updates)), int(self._write)
+        if n:
+            io.leaves[:n] = leaves
+            io.pos[:n] = pos
+        for i in range(int(add_n)):
+            self._pending.discard((self._write + i) % self.memory_size + self.memory_size - 1)
+        self._write = (self._write + int(add_n)) % self.memory_size
+        io.u[:next_batch] = [random.random() for _ in range(next_batch)]
+
+    def chain_collect(self, io, batch_size):
+        """draw_end() on the draw a chain kernel left in its pinned block."""
+        tree_idx = np.asarray(io.out_idx[:batch_size], dtype=np.int64)
+        p = np.asarray(io.out_p[:batch_size], dtype=np.float64)
+        return self._finish_draw(tree_idx, p, float(io.out_total), batch_size)
 
     def commit_device(self, tree_idx, prio_f32, stream=None):
         """update_priorities(zip(tree_idx, prio)) with the priorities still on the device (f32 tensor, one per sampled

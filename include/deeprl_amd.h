@@ -77,6 +77,25 @@ int dra_sumtree_set_many_from(dra_sumtree* tree, int64_t write0, int n, const do
  * would not be exact in fp64 (capacity * max / ulp_f32(min) > 2^53), or when force_ordered != 0. */
 int dra_sumtree_commit_f32(dra_sumtree* tree, const int64_t* leaf_idx_dev, const int32_t* pos_dev, int n,
                            const float* prio_f32_dev, int batch, double* stat_dev, int force_ordered, void* stream);
+/* The prioritized draw inside the update chain (round 3): ONE single-workgroup kernel = write-back of the update that just
+ * computed prio_f32_dev (as dra_sumtree_commit_f32, incl. its ordered-walk fallback) -> add_n adds at the write cursor at
+ * max_priority (as dra_sumtree_set_many_from) -> stratified descent of the NEXT draw (as dra_sumtree_sample).  Every
+ * per-step input is read from, and the next draw written to, one PINNED HOST block, so the launch has constant arguments and
+ * is captured into the learner's update graph right behind its loss kernel (dra_dqn_learner_set_per_chain): no tree
+ * stream, no cross-stream event; the host collects the draw after the loss event. */
+#define DRA_PER_CHAIN_MAX 1024
+typedef struct dra_per_chain_io {
+  int32_t n_commit, add_n, batch, next_batch, force_ordered, reserved;   /* inputs */
+  int64_t add_write0;
+  int64_t leaves[DRA_PER_CHAIN_MAX];    /* gated leaves of this update (first n_commit) */
+  int32_t pos[DRA_PER_CHAIN_MAX];       /* their positions in the minibatch */
+  double u[DRA_PER_CHAIN_MAX];          /* uniforms of the next draw (first next_batch) */
+  int64_t out_idx[DRA_PER_CHAIN_MAX];   /* outputs: leaves, priorities and the tree total of the next draw */
+  double out_p[DRA_PER_CHAIN_MAX];
+  double out_total;
+} dra_per_chain_io;
+int dra_sumtree_per_chain(dra_sumtree* tree, dra_per_chain_io* io_pinned, const float* prio_f32_dev, double* stat_dev,
+                          void* stream);
 /* replay.py:168-175 + sum_tree.py:23-33,63-66: u_dev[batch] are raw python random.random() draws; lane i samples
  * s = a + (b-a)*u_i on segment i of total/batch and descends; outputs tree index, leaf priority, and the total. */
 int dra_sumtree_sample(dra_sumtree* tree, const double* u_dev, int batch, int64_t* out_tree_idx, double* out_p,
@@ -400,6 +419,14 @@ int dra_dqn_learner_act(dra_dqn_learner* learner, const dra_dqn_step_params* prm
  * observation, q_host = float[n_actions] out.  Pinned staging both ways, batch-1 forward of the online parameters
  * as one captured graph; synchronises `stream` (like the reference's to_np(q)). */
 int dra_dqn_learner_q_host(dra_dqn_learner* learner, const uint8_t* state_host, float* q_host, void* stream);
+/* PrioritizedReplay inside the update chain (dra_sumtree_per_chain captured behind the loss kernel of the pipelined
+ * prioritized update): set once before the first prioritized update (tree NULL = off); io0..3 = pinned blocks of the four
+ * rotation slots; _next_slot = the slot the next update uses; _sync_loss blocks the host until the loss + chain kernels of the
+ * update issued last have run (its io block then holds the next draw). */
+int dra_dqn_learner_set_per_chain(dra_dqn_learner* l, dra_sumtree* tree, double* stat_dev, dra_per_chain_io* io0,
+                                  dra_per_chain_io* io1, dra_per_chain_io* io2, dra_per_chain_io* io3);
+int dra_dqn_learner_next_slot(dra_dqn_learner* l, int* slot);
+int dra_dqn_learner_sync_loss(dra_dqn_learner* l);
 /* Async actor over a HOST environment (BaseAgent.py:142-162 with a real emulator; needs DRA_VAR_ACTOR_PARAMS):
  * _update_async = dra_dqn_learner_update whose optimizer also mirrors the new parameters into actor copy (t mod 2);
  * _q_host_async = dra_dqn_learner_q_host on `stream_actor`, reading the copy the update BEFORE the most recent one wrote --

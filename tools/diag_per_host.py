@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Host time of every call of one PrioritizedReplay agent step in the async device pipeline (perf_counter around the
+calls DeviceActorPipeline.step makes), averaged over N steps."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deeprl_amd as d
+import deeprl_amd.agents as agents_mod
+import bench_agents as B
+
+agents_mod.get_logger = lambda *x, **k: B._Quiet()
+d.select_device(0)
+d.random_seed(0)
+agent, meta = B.CASES[sys.argv[1] if len(sys.argv) > 1 else "dqn_pixel_per_device"]()
+for _ in range(400):
+    agent.step()
+torch.cuda.synchronize()
+pipe, L, rp = agent._pipe, agent._learner, agent._inner_replay()
+acc = {}
+
+
+def timed(name, fn):
+    def w(*a, **k):
+        t0 = time.perf_counter()
+        r = fn(*a, **k)
+        acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+        return r
+    return w
+
+
+rp.advance = timed("rp.advance", rp.advance)
+rp.draw_begin = timed("rp.draw_begin", rp.draw_begin)
+rp.draw_end = timed("rp.draw_end (incl. the wait)", rp.draw_end)
+rp.commit_device = timed("rp.commit_device", rp.commit_device)
+rp.tree.commit_f32 = timed("  tree.commit_f32 (C call)", rp.tree.commit_f32)
+rp.tree.sample_into = timed("  tree.sample_into (C call)", rp.tree.sample_into)
+L.upload_sampling_prob = timed("L.upload_sampling_prob", L.upload_sampling_prob)
+L.step = timed("L.step (C call)", L.step)
+L.wait_loss = timed("L.wait_loss", L.wait_loss)
+n = 2000
+t0 = time.perf_counter()
+for _ in range(n):
+    agent.step()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("%.1f us per agent step (%.0f updates/s)" % (1e6 * dt / n, n / dt))
+for k, v in acc.items():
+    print("%-32s %7.1f us" % (k, 1e6 * v / n))
