@@ -2923,6 +2923,16 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
   if (*l->coop_flag) return DRA_ETIMEDOUT;   // a grid barrier of the cooperative optimizer timed out: results are invalid
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = learner_step_impl(l, prm, do_update, stream_update, stream_actor);
+  // PER inside the chain: the host comes back for this update's loss (dra_dqn_learner_sync_loss) only after generating
+  // the next parameter blocks -- make sure everything issued above is on its way to the device by then
+  if (rc == DRA_OK && l->per_tree && l->step_per) {
+    static int flush = -1;
+    if (flush < 0) { const char* e = getenv("DRA_PER_FLUSH"); flush = e ? atoi(e) : 1; }
+    if (flush) {
+      (void)hipStreamQuery(dra_stream(stream_update));
+      if (stream_actor) (void)hipStreamQuery(dra_stream(stream_actor));
+    }
+  }
   l->host_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   l->host_calls++;
   return rc;

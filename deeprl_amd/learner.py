@@ -566,8 +566,8 @@ class DeviceActorPipeline:
         chain_prev = None
         if self._chain_prev is not None:       # the next draw, produced by the last update's chain kernel
             self.L.sync_loss()
-            b, io = self.rp.batch_size, self._chain_prev
-            chain_prev = (list(io.out_idx[:b]), list(io.out_p[:b]), float(io.out_total))
+            b, v = self.rp.batch_size, self._chain_prev.v
+            chain_prev = (v["out_idx"][:b].tolist(), v["out_p"][:b].tolist(), float(v["out_total"][0]))
         return dict(slot=self.slot, pending=[list(p) for p in self.pending], pushed=self.pushed, issued=self.issued,
                     primed=self.primed, rs=(self.rs.get_state() if self.async_actor else None), stream=self.stream.state_dict(),
                     chain_prev=chain_prev)
@@ -584,9 +584,9 @@ class DeviceActorPipeline:
                 self.L.set_per_chain(self.rp.tree, self.rp._stat, [b for b, _ in self._chain_io])
             io = self._chain_io[0][0]
             idx, p, total = st["chain_prev"]
-            io.out_idx[:len(idx)] = idx
-            io.out_p[:len(p)] = p
-            io.out_total = total
+            io.v["out_idx"][:len(idx)] = idx
+            io.v["out_p"][:len(p)] = p
+            io.v["out_total"][0] = total
             self._chain_prev = io
 
     def _block(self):
@@ -604,14 +604,15 @@ class DeviceActorPipeline:
         self.L.set_env_steps(slots, counters, ras, dices, epss, rcounters=rcs, ages=ages)
         return infos
 
-    def _push(self):
+    def _push(self, n=None):
         L = self.L
-        blocks = (StepParams * self.AHEAD)()
-        for i in range(self.AHEAD):
+        n = self.AHEAD if n is None else int(n)
+        blocks = (StepParams * n)()
+        for i in range(n):
             self.pending.append(self._block())
             ctypes.memmove(ctypes.byref(blocks[i]), ctypes.byref(L.params), StepParams.idx.offset)
-        lib.dra_dqn_learner_actor_ring_push(L.h, blocks, self.AHEAD, L._sp(L.actor_stream))
-        self.pushed += self.AHEAD
+        lib.dra_dqn_learner_actor_ring_push(L.h, blocks, n, L._sp(L.actor_stream))
+        self.pushed += n
 
     def step(self, account):
         """One agent step.  account(infos) is called with the (reward, done, info) of the transitions this call reports
@@ -681,6 +682,10 @@ class DeviceActorPipeline:
             L.step(data_idx, True, True)                             # [fwd + loss][commit, adds, next descent][bwd + optimizer]
             self._chain_prev = io
             self.issued += 1
+            # the next parameter block, generated while this update's forward runs: ONE block per step (16 at a time is a
+            # ~1 ms burst every 16th step that nothing overlaps when the host waits for every update's loss)
+            if self.pushed - self.issued < 16:
+                self._push(1)
             return infos
         if self.per and do_update:
             # PrioritizedReplay inside the two-stream pipeline: the draw of step t needs the priorities update t-1 wrote
@@ -715,20 +720,36 @@ class DQNLearnerBench:
     parity tests use."""
 
     def __init__(self, ring_capacity=1_000_000, batch=32, seed=0, actor=True, async_actor=True, n_actions=4,
-                 prefill=None, variant=-1):
-        from .nets import NatureConvBody, VanillaNet
+                 prefill=None, variant=-1, head="vanilla"):
+        """head: "vanilla" (BASELINE configs[1]: VanillaNet, centered RMSprop, clip 5), "c51" (CategoricalNet 51 atoms on
+        [-10, 10], Adam lr 2.5e-4 eps 0.01/32, clip 0.5: examples.py:127-158) or "qr" (QuantileNet 200 quantiles, Adam lr 5e-5,
+        clip 5: examples.py:192-222) -- the same pipeline with config 4's heads, for the schedule oracle."""
+        from .nets import CategoricalNet, NatureConvBody, QuantileNet, VanillaNet
         dev = Config.DEVICE
         if dev.type != "cuda":
             raise DraError("DQNLearnerBench needs select_device(gpu_id >= 0)")
         self.batch, self.capacity, self.seed, self.actor, self.async_actor = batch, ring_capacity, seed, actor, async_actor
         self.history, self.n_step, self.n_actions = 4, 1, n_actions
         self.ring = ops.Ring(ring_capacity, 7056, 8, self.history, self.n_step, 0.99)
-        self.network = VanillaNet(n_actions, NatureConvBody())
-        self.target_network = VanillaNet(n_actions, NatureConvBody())
+        self.head = head
+        if head == "vanilla":
+            make, extra = (lambda: VanillaNet(n_actions, NatureConvBody())), dict(gradient_clip=5.0, lr=0.00025, alpha=0.95, eps=0.01)
+        elif head == "c51":
+            make = lambda: CategoricalNet(n_actions, 51, NatureConvBody())
+            extra = dict(gradient_clip=0.5, lr=0.00025, alpha=0.0, eps=0.01 / 32, head_kind=HEAD_CATEGORICAL, n_atoms=51,
+                         v_min=-10.0, v_max=10.0, optimizer=OPT_ADAM)
+        elif head == "qr":
+            make = lambda: QuantileNet(n_actions, 200, NatureConvBody())
+            extra = dict(gradient_clip=5.0, lr=0.00005, alpha=0.0, eps=0.01 / 32, head_kind=HEAD_QUANTILE, n_atoms=200,
+                         optimizer=OPT_ADAM)
+        else:
+            raise DraError("DQNLearnerBench: head must be vanilla / c51 / qr")
+        self.network, self.target_network = make(), make()
         self.target_network.load_state_dict(self.network.state_dict())
-        self.learner = DQNLearner(self.network, self.target_network, self.ring, batch, n_actions, 0.99, 5.0, 0.00025, 0.95,
-                                  0.01, centered=True, env_seed=seed, env_done_period=800, variant=variant,
-                                  cu_partition=bool(actor and async_actor))
+        clip, lr, alpha, eps = extra.pop("gradient_clip"), extra.pop("lr"), extra.pop("alpha"), extra.pop("eps")
+        self.learner = DQNLearner(self.network, self.target_network, self.ring, batch, n_actions, 0.99, clip, lr, alpha,
+                                  eps, centered=(head == "vanilla"), env_seed=seed, env_done_period=800, variant=variant,
+                                  cu_partition=bool(actor and async_actor), **extra)
         # resident replay before the timed region: fill the whole ring (exploration phase done)
         prefill = ring_capacity if prefill is None else prefill
         with torch.cuda.stream(self.learner.stream):

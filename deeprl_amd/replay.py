@@ -511,9 +511,20 @@ class PrioritizedReplay(UniformReplay):
             self._stat.copy_(torch.tensor([float(self._max_priority), float(self._min_priority)], dtype=torch.float64))
             self._stat_on_device = True
         out = []
+        C = ops.PerChainIO
         for _ in range(n):
-            t = torch.zeros(ctypes.sizeof(ops.PerChainIO), dtype=torch.uint8).pin_memory()
-            out.append((ops.PerChainIO.from_address(t.data_ptr()), t))
+            t = torch.zeros(ctypes.sizeof(C), dtype=torch.uint8).pin_memory()
+            io = C.from_address(t.data_ptr())
+            raw = t.numpy()
+
+            def view(field, dtype, count):
+                off = getattr(C, field).offset
+                return raw[off:off + count * np.dtype(dtype).itemsize].view(dtype)
+            # numpy views of the block's arrays (ctypes array slicing costs ~10 us per 32 elements; the host is on this loop)
+            io.v = dict(head=view("n_commit", np.int32, 6), write0=view("add_write0", np.int64, 1), leaves=view("leaves", np.int64, 1024),
+                        pos=view("pos", np.int32, 1024), u=view("u", np.float64, 1024), out_idx=view("out_idx", np.int64, 1024),
+                        out_p=view("out_p", np.float64, 1024), out_total=view("out_total", np.float64, 1))
+            out.append((io, t))
         return out
 
     def commit_select(self, tree_idx):
@@ -533,21 +544,21 @@ class PrioritizedReplay(UniformReplay):
         side of those adds happens here: a leaf that is overwritten is no longer pending, the write cursor moves on --
         _add_leaf / advance), and the next draw's uniforms from python `random` (replay.py:169-172)."""
         n = len(leaves)
-        io.n_commit, io.add_n, io.batch, io.next_batch = n, int(add_n), int(batch), int(next_batch)
-        io.force_ordered, io.add_write0 = int(bool(self.ordered_updates)), int(self._write)
+        v = io.v
+        v["head"][:5] = (n, int(add_n), int(batch), int(next_batch), int(bool(self.ordered_updates)))
+        v["write0"][0] = int(self._write)
         if n:
-            io.leaves[:n] = leaves
-            io.pos[:n] = pos
+            v["leaves"][:n] = leaves
+            v["pos"][:n] = pos
         for i in range(int(add_n)):
             self._pending.discard((self._write + i) % self.memory_size + self.memory_size - 1)
         self._write = (self._write + int(add_n)) % self.memory_size
-        io.u[:next_batch] = [random.random() for _ in range(next_batch)]
+        v["u"][:next_batch] = [random.random() for _ in range(next_batch)]
 
     def chain_collect(self, io, batch_size):
         """draw_end() on the draw a chain kernel left in its pinned block."""
-        tree_idx = np.asarray(io.out_idx[:batch_size], dtype=np.int64)
-        p = np.asarray(io.out_p[:batch_size], dtype=np.float64)
-        return self._finish_draw(tree_idx, p, float(io.out_total), batch_size)
+        v = io.v
+        return self._finish_draw(v["out_idx"][:batch_size].copy(), v["out_p"][:batch_size].copy(), float(v["out_total"][0]), batch_size)
 
     def commit_device(self, tree_idx, prio_f32, stream=None):
         """update_priorities(zip(tree_idx, prio)) with the priorities still on the device (f32 tensor, one per sampled

@@ -42,9 +42,18 @@ def draw_uniform_indices(size, pos, batch, history, n_step):
 
 
 class AsyncDqnScheduleOracle:
+    """head = "vanilla" (DQN_agent.py:81-99, centered RMSprop), "c51" (CategoricalDQN_agent.py:60-89, Adam) or "qr"
+    (QuantileRegressionDQN_agent.py:55-77, Adam): the same schedule with the head's own loss, action values and optimizer
+    (round 3: config 4's heads are pinned to the oracle in ASYNC mode too, not only through async == in-order)."""
+
     def __init__(self, params, target_params, cap, batch, seed, n_actions=4, epsilon=0.01, done_period=800, gamma=0.99,
-                 clip=5.0, lr=0.00025, alpha=0.95, eps=0.01, double_q=False):
+                 clip=5.0, lr=0.00025, alpha=0.95, eps=0.01, double_q=False, head="vanilla", n_atoms=51, v_min=-10.0,
+                 v_max=10.0, betas=(0.9, 0.999)):
         torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+        self.head, self.n_atoms, self.v_min, self.v_max, self.betas = head, int(n_atoms), float(v_min), float(v_max), betas
+        self.opt_step = 0
+        if head == "c51":     # np.linspace in fp64, then fp32 (CategoricalDQN_agent.py:33, tensor())
+            self.atoms = torch.tensor(np.linspace(v_min, v_max, n_atoms), dtype=torch.float32)
         self.p = {k: torch.tensor(v, requires_grad=True) for k, v in params.items()}
         self.pt = {k: torch.tensor(v) for k, v in target_params.items()}
         self.names = list(self.p)
@@ -69,7 +78,7 @@ class AsyncDqnScheduleOracle:
         with torch.no_grad():
             for k in self.names:
                 self.p[k].copy_(state["params"][k])
-                self.sq[k] = state["square_avg"][k].clone()
+                self.sq[k] = state["square_avg"][k].clone()      # (Adam heads: exp_avg / exp_avg_sq under the same keys)
                 self.ga[k] = state["grad_avg"][k].clone()
 
     def _snapshot(self):
@@ -90,7 +99,7 @@ class AsyncDqnScheduleOracle:
             stack = np.stack([rep.state[(slot - 3 + j) % self.cap] for j in range(3)] + [frame[0].reshape(84, 84)])
             x = torch.from_numpy(NUM.image_normalize_sync(stack[None]))
             with torch.no_grad():
-                q = N.vanilla_head(theta, N.nature_conv_body(theta, x)).numpy()[0]
+                q = self._action_values(theta, N.nature_conv_body(theta, x)).numpy()[0]
             greedy = int(np.argmax(q))
             srt = np.sort(q)
             action = ra if dice < self.epsilon else greedy
@@ -103,11 +112,57 @@ class AsyncDqnScheduleOracle:
             self.actions.append(action)
         return out
 
+    def _action_values(self, theta, phi):
+        """What the actor takes the argmax of: q (DQN_agent.py:29-33), sum_n prob * atoms (CategoricalDQN_agent.py:21-24),
+        mean_n quantile (QuantileRegressionDQN_agent.py:17-20)."""
+        if self.head == "c51":
+            prob, _ = N.categorical_head(theta, phi, self.A, self.n_atoms)
+            return (prob * self.atoms).sum(-1)
+        if self.head == "qr":
+            return N.quantile_head(theta, phi, self.A, self.n_atoms).mean(-1)
+        return N.vanilla_head(theta, phi)
+
     def sample(self):
         idx = draw_uniform_indices(self.rep.size(), self.rep.pos, self.batch, 4, 1)
         return idx, self.rep.gather(idx)
 
+    def _update_dist(self, batch):
+        """One update of a distributional head: per-sample loss vector, its mean, clipped gradients, Adam."""
+        st, ac, rw, ns, mk = batch
+        p, pt = self.p, self.pt
+        x = torch.from_numpy(NUM.image_normalize_sync(st))
+        xn = torch.from_numpy(NUM.image_normalize_sync(ns))
+        a_t, r_t, m_t = torch.from_numpy(ac), torch.from_numpy(rw.astype(np.float32)), torch.from_numpy(mk.astype(np.float32))
+        phi, self.relu_margin = N.nature_conv_body_margin(p, x)
+        if self.head == "c51":
+            with torch.no_grad():
+                prob_t, _ = N.categorical_head(pt, N.nature_conv_body(pt, xn), self.A, self.n_atoms)
+                prob_o = N.categorical_head(p, N.nature_conv_body(p, xn), self.A, self.n_atoms)[0] if self.double_q else None
+            prob, log_prob = N.categorical_head(p, phi, self.A, self.n_atoms)
+            vec = L.c51_kl(log_prob, prob_t, a_t, r_t, m_t, self.gamma, self.atoms, self.v_min, self.v_max, prob_next_online=prob_o)
+            out = (prob * self.atoms).sum(-1)
+        else:
+            with torch.no_grad():
+                qn = N.quantile_head(pt, N.nature_conv_body(pt, xn), self.A, self.n_atoms)
+            quant = N.quantile_head(p, phi, self.A, self.n_atoms)
+            vec = L.qr_loss(quant, qn, a_t, r_t, m_t, self.gamma)
+            out = quant.mean(-1)
+        loss = vec.mean()
+        grads = torch.autograd.grad(loss, [p[k] for k in self.names])
+        norm, grads = N.clip_grad_norm(list(grads), self.clip)
+        self.opt_step += 1
+        with torch.no_grad():
+            for k, g in zip(self.names, grads):      # sq / ga hold Adam's exp_avg / exp_avg_sq here
+                newp, self.sq[k], self.ga[k] = N.adam_step(p[k], g, self.sq[k], self.ga[k], self.opt_step, self.lr, self.betas[0],
+                                                           self.betas[1], self.eps)
+                p[k].copy_(newp)
+        loss = float(loss.detach())
+        self.losses.append(loss)
+        return loss, vec.detach().numpy(), out.detach().numpy(), float(norm)
+
     def update(self, batch):
+        if self.head != "vanilla":
+            return self._update_dist(batch)
         st, ac, rw, ns, mk = batch
         p, pt = self.p, self.pt
         x = torch.from_numpy(NUM.image_normalize_sync(st))

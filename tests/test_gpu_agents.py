@@ -874,12 +874,21 @@ def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch
         agent._learner.synchronize()
         torch.cuda.synchronize()
         rp = agent.replay.replay
+        if per and not async_actor and outs and outs[0]["chain"]:
+            # the async run ran the prioritized draw INSIDE its update chain (dra_sumtree_per_chain): its last update already
+            # performed the next agent step's four adds and the next draw (32 uniforms from python `random`).  Bring the
+            # in-order run to the same point before comparing tree / generator positions.
+            for _ in range(4):
+                rp._add_leaf()
+            for _ in range(32):
+                random.random()
+            torch.cuda.synchronize()
         # the async actor is one agent step ahead: compare the transitions both runs have REPORTED (ring slots of the first
         # n_steps * 4 transitions; with a 300-slot ring that is the whole ring minus the 4 newest slots of the async run)
         total = agent.total_steps
         frames, actions, rewards, masks = rp._ring.pointers()
         w = d.ops._wrap_device_pointer
-        outs.append(dict(total=total, pos=rp.pos, size=rp.size(),
+        outs.append(dict(total=total, pos=rp.pos, size=rp.size(), chain=bool(getattr(agent._pipe, "chain", False)),
                          act=w(actions, 300, torch.int64).cpu().numpy().copy(), rew=w(rewards, 300, torch.float64).cpu().numpy().copy(),
                          tree=rp.tree.as_tensor().cpu().numpy().copy() if per else np.zeros(1),
                          maxp=float(rp.max_priority) if per else 0.0, np_rng=np.random.randint(0, 1 << 30, size=2),
@@ -897,3 +906,83 @@ def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch
     assert np.array_equal(a["tree"], b["tree"]) and a["maxp"] == b["maxp"]
     for k in a["params"]:
         assert np.array_equal(a["params"][k], b["params"][k]), k
+
+
+@pytest.mark.parametrize("head,cap", [("c51", 4000), ("c51", 160), ("qr", 4000)])
+def test_async_pipeline_dist_heads_match_schedule_oracle(dra, head, cap):
+    """Config 4's heads in ASYNC mode against the oracle of the schedule (verdict r2 #4: until round 3 they were pinned
+    through async == in-order with random actions only): DQNLearnerBench(head="c51" | "qr") -- CategoricalNet / QuantileNet
+    over NatureConvBody, the fused learner's distributional head + fused loss kernel + Adam, the distributional action values
+    in the device actor -- for 10 pipelined agent steps vs AsyncDqnScheduleOracle(head=...): every stored action (a mismatch
+    only where the oracle's own top-2 action values are within 1e-5), ring frames bit for bit, per step the loss vector
+    (KL per sample / quantile loss per target quantile) at rtol 1e-5 with an absolute floor of 1e-5 x its largest entry, the
+    loss at 1e-5 and the parameters at rtol 1e-5 / atol 2e-6 (Adam: atol 5e-6 -- a gradient element that is summation noise
+    becomes a step of a fraction of lr through 1 / (sqrt(v) + eps)).  Steps with an ambiguous ReLU gate are judged at 100x
+    and the oracle re-adopts the implementation's state, as in the VanillaNet test."""
+    d = dra
+    from deeprl_amd.learner import DQNLearnerBench
+    from oracle.async_schedule_oracle import AsyncDqnScheduleOracle
+    b, a, seed, steps = 32, 4, 3, 10
+    n = 51 if head == "c51" else 200
+    hname = "fc_categorical" if head == "c51" else "fc_quantiles"
+    d.random_seed(11)
+    torch.manual_seed(5)
+    bench = DQNLearnerBench(ring_capacity=cap, batch=b, seed=seed, actor=True, async_actor=True, head=head)
+    p0 = fake_envs.numpy_params(fake_envs.NATURE_SHAPES + [(hname + ".weight", (a * n, 512)), (hname + ".bias", (a * n,))], 21)
+    bench.network.load_state_dict({k: torch.from_numpy(v) for k, v in p0.items()})
+    bench.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in p0.items()})
+    p_np = {k: v.detach().cpu().numpy().copy() for k, v in bench.network.state_dict().items()}
+    kw = dict(clip=0.5, lr=0.00025) if head == "c51" else dict(clip=5.0, lr=0.00005)
+    orc = AsyncDqnScheduleOracle(p_np, p_np, cap, b, seed, n_actions=a, epsilon=bench.epsilon, eps=0.01 / 32, head=head, n_atoms=n, **kw)
+    rng_state = np.random.get_state()
+    L = bench.learner
+    np.random.seed(5)
+    gpu_vec, gpu_state = [], []
+    n_vec = b if head == "c51" else n
+    for _ in range(steps):
+        bench.step()
+        L.synchronize()
+        gpu_vec.append(d.ops._wrap_device_pointer(L.delta.data_ptr(), n_vec, torch.float32).cpu().numpy().copy())
+        gpu_state.append(L.export_state())
+    n_tr = 4 * (steps + 1)
+    gpu_actions = d.ops._wrap_device_pointer(bench.ring.pointers()[1], n_tr, torch.int64).cpu().numpy().copy()
+    gpu_frames = d.ops._wrap_device_pointer(bench.ring.pointers()[0], n_tr * 7056, torch.uint8).cpu().numpy().copy()
+    np.random.seed(5)
+    near_ties, strict = 0, 0
+
+    def check_actions(res, first, who):
+        nonlocal near_ties
+        for e, (act, gap, rnd) in enumerate(res):
+            got = gpu_actions[first + e]
+            if act != got:
+                assert (not rnd) and gap < 1e-5, "%s env step %d: action %d vs %d, top-2 gap %g" % (who, e, act, got, gap)
+                near_ties += 1
+
+    check_actions(orc.actor_step(orc._snapshot(), override_actions=gpu_actions[0:4]), 0, "actor(0)")
+    for k in range(steps):
+        idx, batch = orc.sample()
+        theta = orc._snapshot()
+        check_actions(orc.actor_step(theta, override_actions=gpu_actions[4 * (k + 1):4 * (k + 2)]), 4 * (k + 1), "actor(%d)" % (k + 1))
+        loss, vec, out, norm = orc.update(batch)
+        ambiguous = orc.relu_margin < 5e-7
+        f = 100.0 if ambiguous else 1.0
+        strict += not ambiguous
+        scale = max(1e-3, float(np.abs(vec).max()))
+        perr = max(float(np.abs(gpu_state[k]["params"][nm].numpy() - orc.p[nm].detach().numpy()).max()) for nm in orc.names)
+        _record_parity("schedule_oracle_%s[%d] step %d%s" % (head, cap, k, " (ambiguous ReLU gate)" if ambiguous else ""),
+                       loss_vec=_rel(gpu_vec[k], vec, scale), loss=abs(float(np.mean(gpu_vec[k].astype(np.float64))) - loss) / abs(loss),
+                       params_abs=perr, relu_margin=orc.relu_margin)
+        msg = "step %d: relu margin %.1e, max param err %.1e" % (k, orc.relu_margin, perr)
+        np.testing.assert_allclose(gpu_vec[k], vec, rtol=1e-5 * f, atol=1e-5 * scale * f, err_msg="loss vector, " + msg)
+        np.testing.assert_allclose(float(np.mean(gpu_vec[k].astype(np.float64))), loss, rtol=1e-5 * f, err_msg="loss, " + msg)
+        for nm in orc.names:
+            np.testing.assert_allclose(gpu_state[k]["params"][nm].numpy(), orc.p[nm].detach().numpy(), rtol=1e-5 * f,
+                                       atol=5e-6 * f, err_msg=nm + ", " + msg)
+        if ambiguous:
+            orc.load_state(gpu_state[k])
+    assert near_ties <= 1
+    assert strict >= steps // 2, "too few unambiguous steps to mean anything"
+    assert np.array_equal(gpu_frames, orc.rep.state[:n_tr].reshape(n_tr * 7056))
+    np.random.set_state(rng_state)
+    L.close()
+    bench.ring.close()

@@ -43,6 +43,13 @@ rp.tree.sample_into = timed("  tree.sample_into (C call)", rp.tree.sample_into)
 L.upload_sampling_prob = timed("L.upload_sampling_prob", L.upload_sampling_prob)
 L.step = timed("L.step (C call)", L.step)
 L.wait_loss = timed("L.wait_loss", L.wait_loss)
+L.sync_loss = timed("L.sync_loss (host wait)", L.sync_loss)
+rp.chain_collect = timed("rp.chain_collect", rp.chain_collect)
+rp.commit_select = timed("rp.commit_select", rp.commit_select)
+rp.chain_fill = timed("rp.chain_fill", rp.chain_fill)
+L.next_slot = timed("L.next_slot", L.next_slot)
+L.set_per = timed("L.set_per", L.set_per)
+pipe._push = timed("pipe._push (amortised)", pipe._push)
 n = 2000
 t0 = time.perf_counter()
 for _ in range(n):
@@ -52,3 +59,21 @@ dt = time.perf_counter() - t0
 print("%.1f us per agent step (%.0f updates/s)" % (1e6 * dt / n, n / dt))
 for k, v in acc.items():
     print("%-32s %7.1f us" % (k, 1e6 * v / n))
+
+# ---- issue -> loss latency with an idle GPU: how long do [forward + loss + chain kernel] take by themselves?
+if getattr(pipe, "chain", False):
+    import ctypes
+    from deeprl_amd._lib import lib
+    lat = []
+    orig_step = L.step.__wrapped__ if hasattr(L.step, "__wrapped__") else None
+    real_sync = lib.dra_dqn_learner_sync_loss
+    for _ in range(200):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        agent.step()                      # begins with sync_loss of the previous update (complete: ~0), ends after issuing
+        t1 = time.perf_counter()
+        real_sync(L.h)
+        t2 = time.perf_counter()
+        lat.append((t1 - t0, t2 - t1))
+    a = np.asarray(lat[20:])
+    print("idle GPU: agent.step() host time %.1f us, then issue -> loss event %.1f us" % (1e6 * a[:, 0].mean(), 1e6 * a[:, 1].mean()))
