@@ -31,7 +31,7 @@ def save(name, **arrays):
 
 
 # --------------------------------------------------------------------------- replay
-from golden.make_golden_cases import UNIFORM_CASES, PER_CASES, stream as _stream  # noqa: E402
+from golden.make_golden_cases import UNIFORM_CASES, PER_CASES, stream as _stream, trajectory_digest  # noqa: E402
 
 
 def gen_uniform():
@@ -739,11 +739,20 @@ def gen_pixel_agents():
             p_np = fake_envs.numpy_params(shapes, 17)
             agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
             agent.target_network.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
-            for _ in range(steps):
+            traj_steps, traj = [], []
+            prev = trajectory_digest(agent.network.state_dict())
+            for t in range(steps):
                 agent.step()
+                cur = trajectory_digest(agent.network.state_dict())
+                if not np.array_equal(cur, prev):        # this agent step ran an update
+                    traj_steps.append(t)
+                    traj.append(cur)
+                prev = cur
             k = tag + "_"
             rp = agent.replay.replay
             n = rp.size()
+            out[k + "update_steps"] = np.asarray(traj_steps, dtype=np.int64)
+            out[k + "update_digests"] = np.stack(traj)      # [n_updates, ~420] float32: the parameters after every update
             out[k + "total_steps"] = np.asarray(agent.total_steps)
             out[k + "pos_size"] = np.asarray([rp.pos, n])
             out[k + "replay_action"] = np.asarray(rp.action[:n]).reshape(-1).astype(np.int64)

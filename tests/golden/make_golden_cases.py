@@ -36,6 +36,13 @@ PIXEL_AGENT_CASES = [   # tag, agent, replay, n_step, done_period, agent steps
 ]
 
 
+def trajectory_digest(state_dict, stride=4099):
+    """Every `stride`-th element of every tensor of a state dict (fp32, in state-dict order): small enough to keep per
+    update, so a run can be compared with the reference's after EVERY update and not only at the end."""
+    return np.concatenate([np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v, dtype=np.float32).reshape(-1)[::stride]
+                           for v in state_dict.values()])
+
+
 def digest(t, stride=1009):
     """Small stand-in for a multi-megabyte tensor: {fp64 sum, fp64 sum of squares} + every `stride`-th element."""
     a = np.asarray(t, dtype=np.float32).reshape(-1)
