@@ -644,8 +644,20 @@ class DQNAgent(BaseAgent):
         torch.set_rng_state(state["torch_cpu"])
         torch.cuda.set_rng_state(state["torch_cuda"], Config.DEVICE)
 
+    def sync_host(self):
+        """Between two step() calls: everything issued has been accounted for on the host and python's `random` stands where the
+        reference's would (with PrioritizedReplay drawn on the device the generator runs ahead of the kernels otherwise:
+        replay.DeviceDraw).  save_full(), eval_episodes() and close() call it."""
+        if getattr(self, '_pipe', None) is not None:
+            self._pipe.sync_host()
+
+    def eval_episodes(self):
+        self.sync_host()
+        return super().eval_episodes()
+
     def close(self):
         if getattr(self, '_learner', None) is not None:
+            self.sync_host()
             self._learner.synchronize()
             self._learner.close()
             self._learner = None

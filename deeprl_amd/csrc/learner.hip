@@ -197,6 +197,16 @@ struct dra_dqn_learner {
   dra_sumtree* per_tree;
   double* per_stat;
   dra_per_chain_io* per_io[4];
+  // second form (dra_dqn_learner_set_per_chain2): the whole draw on the device; the next update's minibatch indices arrive in
+  // per2_idx[slot] (device), the sampling probabilities in samp_prob, without the host in between
+  dra_per_chain2_io* per2_io[4];
+  void* per2_dev;                   // sumtree.hip PerChain2Dev
+  int64_t* per2_idx;                // [4][1024]
+  const uint32_t* per2_words;       // pinned ring of Mersenne-Twister words (host-generated ahead)
+  int split_q;                      // step_pipelined3 in two calls: state carried from the update half to the actor half
+  hipEvent_t split_opt_prev;
+  bool split_seed, split_open;
+  hipEvent_t ev_per_fork, ev_per_join;   // capture-time fork / join of the chain kernel's branch
   unsigned* aflags;                 // DRA_VAR_ACTOR_MEGA: [kMaxEnvSteps][4] arrival counters of the one-launch env steps (zeroed by
                                     // the agent step's tail kernel)
   bool late;
@@ -443,6 +453,8 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   for (int k = 0; k < 4; ++k) rc |= (int)hipEventCreateWithFlags(&l->ev_join[k], hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_actor_done, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_loss, hipEventDisableTiming);
+  rc |= (int)hipEventCreateWithFlags(&l->ev_per_fork, hipEventDisableTiming);
+  rc |= (int)hipEventCreateWithFlags(&l->ev_per_join, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_gather_done, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_step_done, hipEventDisableTiming);
   for (int g = 0; g < 2; ++g) {
@@ -467,7 +479,10 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
     if (l->g_ag_ready[g]) (void)hipGraphExecDestroy(l->g_ag[g]);
     for (int h = g; h < 4; h += 2) {
       if (l->g_pipe_ready[h]) (void)hipGraphExecDestroy(l->g_pipe[h]);
-      if (l->g_pipe_per_ready[h]) { (void)hipGraphExecDestroy(l->g_pipe_per[h]); (void)hipGraphExecDestroy(l->g_pipe_per_b[h]); }
+      if (l->g_pipe_per_ready[h]) {
+        (void)hipGraphExecDestroy(l->g_pipe_per[h]);
+        if (l->g_pipe_per_b[h]) (void)hipGraphExecDestroy(l->g_pipe_per_b[h]);
+      }
     }
     (void)hipEventDestroy(l->ev_mb_ready[g]); (void)hipEventDestroy(l->ev_mb_free[g]);
     void* mb[] = {l->state_[g], l->next_state_[g], l->action_[g], l->reward_[g], l->mask_[g]};
@@ -504,11 +519,16 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   for (int k = 0; k < 4; ++k) {
     if (l->idx_pin[k]) (void)hipHostFree(l->idx_pin[k]);
     if (l->g_rd_ready[k]) (void)hipGraphExecDestroy(l->g_rd[k]);
-    if (l->g_rd_per_ready[k]) { (void)hipGraphExecDestroy(l->g_rd_per[k]); (void)hipGraphExecDestroy(l->g_rd_per_b[k]); }
+    if (l->g_rd_per_ready[k]) {
+      (void)hipGraphExecDestroy(l->g_rd_per[k]);
+      if (l->g_rd_per_b[k]) (void)hipGraphExecDestroy(l->g_rd_per_b[k]);   // (null with the one-graph prioritized update)
+    }
     (void)hipEventDestroy(l->ev_upd[k]);
   }
   for (int k = 0; k < 4; ++k) if (l->idx_tag_pin[k]) (void)hipHostFree(l->idx_tag_pin[k]);
   if (l->idx_tag_dev) (void)hipFree(l->idx_tag_dev);
+  if (l->per2_dev) (void)hipFree(l->per2_dev);
+  if (l->per2_idx) (void)hipFree(l->per2_idx);
   if (l->rd_seq_dev) (void)hipFree(l->rd_seq_dev);
   if (l->sp_stage) (void)hipHostFree(l->sp_stage);
   for (int k = 0; k < 8; ++k) if (l->sp_ev[k]) (void)hipEventDestroy(l->sp_ev[k]);
@@ -528,6 +548,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   for (int k = 0; k < 4; ++k) (void)hipEventDestroy(l->ev_join[k]);
   (void)hipEventDestroy(l->ev_actor_done); (void)hipEventDestroy(l->ev_gather_done); (void)hipEventDestroy(l->ev_step_done);
   (void)hipEventDestroy(l->ev_loss);
+  (void)hipEventDestroy(l->ev_per_fork); (void)hipEventDestroy(l->ev_per_join);
   delete l;
   return DRA_OK;
 }
@@ -1124,8 +1145,10 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     const int64_t off[3] = {0, ring_n, ring_n};
     // (the indices sit in pinned host memory: conv1's workgroups pay the one PCIe read and leave a device copy in l->idx
     // for the head and the weight-gradient kernels of this update)
-    const bool pf = l->variant & DRA_VAR_IDX_PREFETCH;
-    STEP(K_CONV1_F, dra_conv1_fwd_koc_ringbatch(ring_frames, l->idx_pin[l->rd_slot], l->idx,
+    // (PER drawn on the device: the previous update's chain kernel left them in device memory)
+    const bool dev_idx = per && l->per2_dev;
+    const bool pf = (l->variant & DRA_VAR_IDX_PREFETCH) && !dev_idx;
+    STEP(K_CONV1_F, dra_conv1_fwd_koc_ringbatch(ring_frames, dev_idx ? l->per2_idx + (size_t)l->rd_slot * 1024 : l->idx_pin[l->rd_slot], l->idx,
                                                 pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr,
                                                 off, nz, w1, b1, l->y1, B, c.u8_coef, DRA_ACT_RELU, s));
   } else {
@@ -1349,13 +1372,54 @@ static int capture_part(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int 
   return DRA_OK;
 }
 
+// The prioritized update with the draw on the device (dra_sumtree_per_chain2) as ONE graph: [forward + loss], then two
+// branches -- the chain kernel (priorities -> tree, adds, next draw: a single-workgroup latency chain of ~40 us) on the side
+// stream, and [backward + norm + optimizer] -- joined at the end.  Nothing in the backward pass touches what the chain
+// kernel reads or writes (prio / tree / sampling_prob / the NEXT slot's indices), and the next update starts behind the join.
+static int capture_per2(dra_dqn_learner* l, hipStream_t st, int q, bool rd, hipGraphExec_t* exec) {
+  hipGraph_t graph;
+  l->gb = q & 1;
+  l->rd_slot = rd ? q : -1;
+  hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+  if (b != hipSuccess) { l->gb = 0; l->rd_slot = -1; return (int)b; }
+  int rc = run_body(l, st, 1, -1.f, 0, 1);
+  static int fork = -1;
+  // 1: the chain kernel as a parallel branch of the graph.  Measured (profiles/r03h): the branches do overlap, but the forked
+  // graph no longer overlaps with the ACTOR stream's graph (4.5 k vs 6.0 k updates/s) and its results differ -- in line it is
+  if (fork < 0) { const char* e = getenv("DRA_PER_FORK"); fork = e ? atoi(e) : 0; }
+  hipStream_t sd = fork ? l->side : st;
+  if (rc == DRA_OK && fork) {
+    rc = (int)hipEventRecord(l->ev_per_fork, st);
+    if (rc == DRA_OK) rc = (int)hipStreamWaitEvent(sd, l->ev_per_fork, 0);
+  }
+  if (rc == DRA_OK)
+    rc = dra_sumtree_per_chain2(l->per_tree, l->per2_io[q & 3], l->prio, l->per_stat, l->per2_dev, l->per2_words,
+                                l->per2_idx + (size_t)((q + 1) & 3) * 1024, l->samp_prob, l->c.batch, (void*)sd);
+  if (rc == DRA_OK) rc = run_body(l, st, 1, -1.f, 0, 2);
+  if (rc == DRA_OK) rc = launch_optimizer(l, st, l->pa[q]);
+  if (rc == DRA_OK && fork) {
+    rc = (int)hipEventRecord(l->ev_per_join, sd);
+    if (rc == DRA_OK) rc = (int)hipStreamWaitEvent(st, l->ev_per_join, 0);
+  }
+  hipError_t e = hipStreamEndCapture(st, &graph);
+  l->gb = 0;
+  l->rd_slot = -1;
+  if (rc != DRA_OK) return rc;
+  if (e != hipSuccess) return (int)e;
+  DRA_HIP(hipGraphInstantiate(exec, graph, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(graph);
+  return DRA_OK;
+}
+
 static int update_graph(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int per) {
   hipGraphExec_t* exec = rd ? (per ? &l->g_rd_per[q] : &l->g_rd[q]) : (per ? &l->g_pipe_per[q] : &l->g_pipe[q]);
   hipGraphExec_t* exec_b = rd ? &l->g_rd_per_b[q] : &l->g_pipe_per_b[q];
   bool* ready = rd ? (per ? &l->g_rd_per_ready[q] : &l->g_rd_ready[q]) : (per ? &l->g_pipe_per_ready[q] : &l->g_pipe_ready[q]);
   if (!*ready) {
     int rc;
-    if (per) {
+    if (per && l->per2_dev && l->per_tree) {
+      if ((rc = capture_per2(l, st, q, rd, exec))) return rc;
+    } else if (per) {
       if ((rc = capture_part(l, st, q, rd, 1, 1, false, exec))) return rc;
       if ((rc = capture_part(l, st, q, rd, 1, 2, true, exec_b))) return rc;
     } else if ((rc = capture_part(l, st, q, rd, 0, 0, true, exec))) {
@@ -1364,7 +1428,7 @@ static int update_graph(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int 
     *ready = true;
   }
   DRA_HIP(hipGraphLaunch(*exec, st));
-  if (per) {
+  if (per && !(l->per2_dev && l->per_tree)) {
     DRA_HIP(hipEventRecord(l->ev_loss, st));
     DRA_HIP(hipGraphLaunch(*exec_b, st));
   }
@@ -1390,6 +1454,67 @@ DRA_API int dra_dqn_learner_set_per_chain(dra_dqn_learner* l, dra_sumtree* tree,
   l->per_tree = tree; l->per_stat = stat_dev;
   l->per_io[0] = io0; l->per_io[1] = io1; l->per_io[2] = io2; l->per_io[3] = io3;
   return DRA_OK;
+}
+// Second form (sumtree.hip dra_sumtree_per_chain2): io0..3 = pinned dra_per_chain2_io blocks, rng_words = pinned ring of
+// DRA_PER_RNG_WORDS Mersenne-Twister outputs.  From then on every prioritized update of the ring-direct pipeline reads its
+// minibatch indices from device memory (slot step_no & 3) and its sampling probabilities / exponent from the learner's
+// sampling_prob buffer, both written by the PREVIOUS update's chain kernel -- or by _per_chain2_seed for the first one.
+DRA_API int dra_dqn_learner_set_per_chain2(dra_dqn_learner* l, dra_sumtree* tree, double* stat_dev, dra_per_chain2_io* io0,
+                                           dra_per_chain2_io* io1, dra_per_chain2_io* io2, dra_per_chain2_io* io3,
+                                           const uint32_t* rng_words_pinned) {
+  if (!l || !tree || !stat_dev || !io0 || !io1 || !io2 || !io3 || !rng_words_pinned) return DRA_EINVAL;
+  if (!(l->variant & DRA_VAR_RING_DIRECT) || !(l->variant & DRA_VAR_GATHER_ON_UPDATE)) return DRA_EINVAL;
+  if (l->c.batch > DRA_PER_CHAIN_MAX) return DRA_EINVAL;
+  for (int k = 0; k < 4; ++k)
+    if (l->g_rd_per_ready[k] || l->g_pipe_per_ready[k]) return DRA_EINVAL;     // the graphs bake the choice
+  if (!l->per2_dev) {
+    int64_t sb = 0;
+    (void)dra_sumtree_per_chain2_state_bytes(&sb);
+    DRA_HIP(hipMalloc(&l->per2_dev, (size_t)sb));
+    DRA_HIP(hipMemset(l->per2_dev, 0, (size_t)sb));
+    DRA_HIP(hipMalloc(&l->per2_idx, (size_t)4 * 1024 * sizeof(int64_t)));
+    DRA_HIP(hipMemset(l->per2_idx, 0, (size_t)4 * 1024 * sizeof(int64_t)));
+  }
+  l->per_tree = tree; l->per_stat = stat_dev;
+  l->per2_io[0] = io0; l->per2_io[1] = io1; l->per2_io[2] = io2; l->per2_io[3] = io3;
+  l->per2_words = rng_words_pinned;
+  return DRA_OK;
+}
+// The minibatch of the NEXT update, from the host (the first prioritized update's classic draw, or a resumed run): leaves,
+// ring indices, sampling probabilities (f64, cast as tensor() would), its importance exponent, and the word-ring cursor /
+// launch count the chain kernel continues from.  Ordered on `stream` (the update stream).
+DRA_API int dra_dqn_learner_per_chain2_seed(dra_dqn_learner* l, const int64_t* tree_idx, const int64_t* data_idx,
+                                            const double* prob, float beta, uint64_t rng_cursor, uint64_t seq, void* stream) {
+  if (!l || !l->per2_dev || !tree_idx || !data_idx || !prob) return DRA_EINVAL;
+  const int B = l->c.batch;
+  hipStream_t st = dra_stream(stream);
+  DRA_HIP(hipStreamSynchronize(st));
+  float sp[DRA_PER_CHAIN_MAX + 1];
+  for (int i = 0; i < B; ++i) sp[i] = (float)prob[i];
+  sp[B] = beta;
+  DRA_HIP(hipMemcpy(l->samp_prob, sp, (size_t)(B + 1) * sizeof(float), hipMemcpyHostToDevice));
+  int rc = dra_sumtree_per_chain2_state_set(l->per2_dev, rng_cursor, seq, tree_idx, B);
+  if (rc) return rc;
+  DRA_HIP(hipMemcpy(l->per2_idx + (size_t)(l->step_no & 3) * 1024, data_idx, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice));
+  return DRA_OK;
+}
+// Spins (no driver call) until the chain kernel of rotation slot `slot` has published launch number `seq`; DRA_ETIMEDOUT
+// after timeout_us.
+DRA_API int dra_dqn_learner_per_chain2_wait(dra_dqn_learner* l, int slot, uint64_t seq, int64_t timeout_us) {
+  if (!l || !l->per2_dev || slot < 0 || slot > 3) return DRA_EINVAL;
+  const volatile uint64_t* p = &l->per2_io[slot]->out_seq;
+  if (__atomic_load_n(p, __ATOMIC_ACQUIRE) >= seq) return DRA_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    for (int i = 0; i < 256; ++i) {
+      if (__atomic_load_n(p, __ATOMIC_ACQUIRE) >= seq) {
+        l->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return DRA_OK;
+      }
+      __builtin_ia32_pause();
+    }
+    if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > (double)timeout_us) return DRA_ETIMEDOUT;
+  }
 }
 DRA_API int dra_dqn_learner_next_slot(dra_dqn_learner* l, int* slot) {
   if (!l || !slot) return DRA_EINVAL;
@@ -2648,8 +2773,12 @@ static hipEvent_t arec_needed(dra_dqn_learner* l, const int64_t* idx) {
   return nullptr;
 }
 
+// phase 0: the whole step.  phase 1 / 2: the same step in two calls for the device-drawn prioritized minibatch
+// (dra_dqn_learner_step_update / _step_actor): 1 = everything of the update (its indices are in device memory, so the host
+// cannot test them: it waits for the newest actor launch unconditionally), 2 = the actor launch + the step's bookkeeping,
+// prm->idx = the indices of the update issued by phase 1 (known to the host by then) for the slot hazard check.
 static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, hipStream_t su,
-                           hipStream_t sa, int k) {
+                           hipStream_t sa, int k, int phase = 0) {
   const int B = l->c.batch;
   // Parameter copies rotate by FOUR here: update t writes copy t mod 4, the actor graph of step t+1 (issued with update t)
   // reads the copy update t-1 wrote.  The copy update t overwrites was last read by the actor graph issued three calls ago;
@@ -2658,7 +2787,7 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
   const int q = (int)(l->step_no & 3), qr = (q + 3) & 3;
   const int par = q & 1;           // minibatch buffers alternate
   int rc;
-  hipEvent_t opt_prev = l->last_done;          // optimizer of step t-1: produced the copy the actor graph below reads
+  hipEvent_t opt_prev = phase == 2 ? l->split_opt_prev : l->last_done;   // optimizer of step t-1: produced the copy the actor graph below reads
   // the block the actor graph issued by THIS call consumes: with the parameter ring that is the next un-issued ring entry
   // (pushed up to 16 agent steps ahead; `prm` then only carries n_env and the minibatch indices)
   const dra_dqn_step_params* ablk = prm;
@@ -2666,23 +2795,26 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
     if (!l->aring_stage || l->aring_issued >= l->aring_pushed) return DRA_EINVAL;
     ablk = reinterpret_cast<const dra_dqn_step_params*>(l->aring_stage + (size_t)(l->aring_issued % kAringSlots) * kAprmStride);
   }
-  const bool hazard = do_update && prm->n_env > 0 && gather_reads_slots(l, prm->idx, ablk->slot, prm->n_env);
+  const bool hazard = phase != 1 && do_update && prm->n_env > 0 && gather_reads_slots(l, prm->idx, ablk->slot, prm->n_env);
   // ... and the other direction: the update reads the transitions an unfinished actor launch is writing only if the
   // minibatch touches its slots (same order of probability); otherwise the two chains do not meet in this step at all
-  const hipEvent_t needs_actor = do_update ? arec_needed(l, prm->idx) : nullptr;
-  bool seed = false;
-  if (prm->n_env > 0) {
+  const hipEvent_t needs_actor = !do_update || phase == 2 ? nullptr : (phase == 1 ? (l->actor_pending ? l->actor_last : nullptr)
+                                                                                  : arec_needed(l, prm->idx));
+  bool seed = phase == 2 ? l->split_seed : false;
+  if (phase == 1) { l->split_opt_prev = opt_prev; l->split_q = q; }
+  if (phase != 2 && prm->n_env > 0) {
     if (l->pa_valid && l->pa_cur != qr) l->pa_valid = false;   // copies out of phase with the step rotation
     seed = !l->pa_valid;
   }
-  if (seed) {   // (re)seed the actor copy from the online parameters BEFORE this step's optimizer overwrites them
+  if (seed && phase != 2) {   // (re)seed the actor copy from the online parameters BEFORE this step's optimizer overwrites them
     if (opt_prev) DRA_HIP(hipStreamWaitEvent(sa, opt_prev, 0));
     l->pa_cur = qr;
     DRA_HIP(hipMemcpyAsync(l->pa[l->pa_cur], l->p, (size_t)l->c.n_params * sizeof(float), hipMemcpyDeviceToDevice, sa));
     DRA_HIP(hipEventRecord(l->ev_join[0], sa));
     l->pa_valid = true;
   }
-  if (do_update) {
+  if (phase == 1) l->split_seed = seed;
+  if (do_update && phase != 2) {
     if (l->pa_reader[q]) {           // the optimizer of this update overwrites copy q: its last reader must be done
       const auto t0 = std::chrono::steady_clock::now();
       DRA_HIP(hipEventSynchronize(l->pa_reader[q]));
@@ -2699,8 +2831,8 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
         DRA_HIP(hipEventSynchronize(l->ev_upd[q]));
         l->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
-      memcpy(l->idx_pin[q], prm->idx, (size_t)B * sizeof(int64_t));
-      if (l->variant & DRA_VAR_IDX_PREFETCH) {
+      if (phase == 0) memcpy(l->idx_pin[q], prm->idx, (size_t)B * sizeof(int64_t));
+      if (phase == 0 && (l->variant & DRA_VAR_IDX_PREFETCH)) {
         // a step-tagged copy of the indices travels to the device on the side stream, ordered with NOTHING: conv1 uses an
         // element only if its tag is this update's (then the copy landed in time, the normal case -- the host runs ahead
         // of the device), else it reads the pinned indices as before.  (A first version let the previous update's head
@@ -2716,7 +2848,7 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
       TRACE(0, su);
       if (l->keep_minibatch) {
         l->gb = par;
-        rc = launch_gather(l, su, l->idx_pin[q]);
+        rc = launch_gather(l, su, phase == 1 ? l->per2_idx + (size_t)q * 1024 : l->idx_pin[q]);
         l->gb = 0;
         if (rc) return rc;
       } else {
@@ -2747,6 +2879,7 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
       l->mb_used[par] = true;
     }
   }
+  if (phase == 1) return DRA_OK;
   if (prm->n_env > 0) {
     if (!seed && opt_prev) DRA_HIP(hipStreamWaitEvent(sa, opt_prev, 0));
     if (hazard) DRA_HIP(hipStreamWaitEvent(sa, l->last_done, 0));      // the gather reads slots this graph overwrites
@@ -2932,6 +3065,48 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
       (void)hipStreamQuery(dra_stream(stream_update));
       if (stream_actor) (void)hipStreamQuery(dra_stream(stream_actor));
     }
+  }
+  l->host_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  l->host_calls++;
+  return rc;
+}
+
+// dra_dqn_learner_step in two calls (device-drawn prioritized minibatch; include/deeprl_amd.h)
+static int step_split_check(dra_dqn_learner* l, const dra_dqn_step_params* prm, void* su, void* sa) {
+  if (!l || !prm || !su || !sa || prm->n_env < 1 || prm->n_env > kMaxEnvSteps || !l->per2_dev) return DRA_EINVAL;
+  if (!l->step_per || l->step_beta >= 0.f) return DRA_EINVAL;
+  const int need = DRA_VAR_PIPE_GATHER | DRA_VAR_ACTOR_PARAMS | DRA_VAR_GATHER_ON_UPDATE | DRA_VAR_RING_DIRECT | DRA_VAR_ACTOR_RING;
+  if ((l->variant & need) != need) return DRA_EINVAL;
+  if (*l->coop_flag) return DRA_ETIMEDOUT;
+  return DRA_OK;
+}
+DRA_API int dra_dqn_learner_step_update(dra_dqn_learner* l, const dra_dqn_step_params* prm, void* stream_update, void* stream_actor) {
+  int rc = step_split_check(l, prm, stream_update, stream_actor);
+  if (rc) return rc;
+  if (l->split_open) return DRA_EINVAL;
+  const auto t0 = std::chrono::steady_clock::now();
+  l->profiling = false;
+  rc = step_pipelined3(l, prm, 1, dra_stream(stream_update), dra_stream(stream_actor), -1, 1);
+  if (rc == DRA_OK) {
+    l->split_open = true;
+    (void)hipStreamQuery(dra_stream(stream_update));     // on its way to the device before the host turns to the chain block
+  }
+  l->host_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+DRA_API int dra_dqn_learner_step_actor(dra_dqn_learner* l, const dra_dqn_step_params* prm, void* stream_update, void* stream_actor) {
+  int rc = step_split_check(l, prm, stream_update, stream_actor);
+  if (rc) return rc;
+  if (!l->split_open) return DRA_EINVAL;
+  const auto t0 = std::chrono::steady_clock::now();
+  int k;
+  if ((rc = stage_acquire(l, &k))) return rc;
+  memcpy(&l->prm_stage[k], prm, kPrmHeadBytes);
+  memcpy(l->idx_stage + (size_t)k * 1024, prm->idx, (size_t)l->c.batch * sizeof(int64_t));
+  rc = step_pipelined3(l, prm, 1, dra_stream(stream_update), dra_stream(stream_actor), k, 2);
+  if (rc == DRA_OK) {
+    l->split_open = false;
+    (void)hipStreamQuery(dra_stream(stream_actor));
   }
   l->host_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   l->host_calls++;

@@ -294,6 +294,33 @@ class DQNLearner:
         lib.dra_dqn_learner_set_per_chain(self.h, tree.h, ctypes.c_void_p(stat.data_ptr()),
                                           *[ctypes.c_void_p(ctypes.addressof(b)) for b in blocks])
 
+    def set_per_chain2(self, tree, stat, blocks, rng_words):
+        """PrioritizedReplay.sample() on the device (dra_sumtree_per_chain2): four pinned dra_per_chain2_io blocks and the
+        pinned ring of Mersenne-Twister words; before the first prioritized update."""
+        lib.dra_dqn_learner_set_per_chain2(self.h, tree.h, ctypes.c_void_p(stat.data_ptr()),
+                                           *[ctypes.c_void_p(ctypes.addressof(b)) for b in blocks],
+                                           ctypes.c_void_p(rng_words.data_ptr()))
+
+    def per_chain2_seed(self, tree_idx, data_idx, prob, beta, rng_cursor, seq):
+        """The NEXT update's minibatch from the host (first prioritized update / resume)."""
+        t = np.ascontiguousarray(tree_idx, dtype=np.int64)
+        d = np.ascontiguousarray(data_idx, dtype=np.int64)
+        p = np.ascontiguousarray(prob, dtype=np.float64)
+        lib.dra_dqn_learner_per_chain2_seed(self.h, t.ctypes.data_as(ctypes.c_void_p), d.ctypes.data_as(ctypes.c_void_p),
+                                            p.ctypes.data_as(ctypes.c_void_p), float(beta), int(rng_cursor), int(seq), self._sp())
+
+    def per_chain2_wait(self, slot, seq, timeout_us=20_000_000):
+        lib.dra_dqn_learner_per_chain2_wait(self.h, int(slot), int(seq), int(timeout_us))
+
+    def step_update(self):
+        """First half of an async step() whose prioritized minibatch is already in device memory: the update."""
+        lib.dra_dqn_learner_step_update(self.h, ctypes.byref(self.params), self._sp(), self._sp(self.actor_stream))
+
+    def step_actor(self, idx):
+        """Second half: the next agent step's transitions; idx = the indices of the update just issued (hazard check)."""
+        self._idx_view[:] = idx
+        lib.dra_dqn_learner_step_actor(self.h, ctypes.byref(self.params), self._sp(), self._sp(self.actor_stream))
+
     def next_slot(self):
         q = ctypes.c_int()
         lib.dra_dqn_learner_next_slot(self.h, ctypes.byref(q))
@@ -544,8 +571,15 @@ class DeviceActorPipeline:
         # PER + async: write-back, next step's adds and the next draw's descent run INSIDE the update graph behind the loss
         # kernel (sumtree.hip dra_sumtree_per_chain): the host collects the next draw after the loss event instead of driving
         # a tree stream (DRA_PER_CHAIN=0: the round-2 tree-stream form)
-        self.chain = bool(self.per and async_actor and os.environ.get("DRA_PER_CHAIN", "1") != "0")
+        # DRA_PER_CHAIN=2 (default where the ring-direct pipeline runs): the kernel also filters / pads the draw and hands the
+        # minibatch to the next update in device memory (dra_sumtree_per_chain2, replay.DeviceDraw): no host wait at all
+        mode = int(os.environ.get("DRA_PER_CHAIN", "2")) if (self.per and async_actor) else 0
+        need2 = (ops.VAR_PIPE_GATHER | ops.VAR_ACTOR_PARAMS | ops.VAR_GATHER_ON_UPDATE | ops.VAR_RING_DIRECT | ops.VAR_ACTOR_RING)
+        if mode == 2 and ((learner.variant & need2) != need2 or replay.batch_size > 1024):
+            mode = 1
+        self.chain = mode
         self._chain_io = self._chain_prev = None
+        self._dd = None                       # replay.DeviceDraw (mode 2)
         self.A, self.n_env, self.epsilon_fn, self.async_actor = int(n_actions), int(n_env), epsilon_fn, bool(async_actor)
         self.rs = np.random.RandomState(actor_seed) if async_actor else np.random
         self.capacity = replay.memory_size
@@ -564,7 +598,11 @@ class DeviceActorPipeline:
         the agent steps issued ahead, how far ahead the parameter blocks have been generated / issued, and the actor's own
         random stream."""
         chain_prev = None
-        if self._chain_prev is not None:       # the next draw, produced by the last update's chain kernel
+        if self._dd is not None and self._dd.active:
+            dd = self._dd
+            dd.release()                       # python `random` is the reference's again; the newest draw is the next update's
+            chain_prev = (dd.next_tree_idx.tolist(), dd.next_p.tolist(), dd.next_total, dd.next_beta)
+        elif self._chain_prev is not None:       # the next draw, produced by the last update's chain kernel
             self.L.sync_loss()
             b, v = self.rp.batch_size, self._chain_prev.v
             chain_prev = (v["out_idx"][:b].tolist(), v["out_p"][:b].tolist(), float(v["out_total"][0]))
@@ -572,18 +610,29 @@ class DeviceActorPipeline:
                     primed=self.primed, rs=(self.rs.get_state() if self.async_actor else None), stream=self.stream.state_dict(),
                     chain_prev=chain_prev)
 
+    def sync_host(self):
+        """Host bookkeeping caught up with the device; python's `random` where the reference's would be (DeviceDraw.release)."""
+        if self._dd is not None and self._dd.active:
+            self._dd.release()
+
     def load_state_dict(self, st):
         self.slot, self.pushed, self.issued, self.primed = st["slot"], st["pushed"], st["issued"], st["primed"]
         self.pending = [[tuple(x) for x in p] for p in st["pending"]]
         if self.async_actor:
             self.rs.set_state(st["rs"])
         self.stream.load_state_dict(st["stream"])
-        if st.get("chain_prev") is not None:
+        if st.get("chain_prev") is not None and self.chain == 2:
+            from .replay import DeviceDraw
+            if self._dd is None:
+                self._dd = DeviceDraw(self.rp, self.L)
+            idx, p, total, beta = st["chain_prev"]
+            self._dd.start(idx, p, total, beta)
+        elif st.get("chain_prev") is not None:
             if self._chain_io is None:
                 self._chain_io = self.rp.chain_blocks(4)
                 self.L.set_per_chain(self.rp.tree, self.rp._stat, [b for b, _ in self._chain_io])
             io = self._chain_io[0][0]
-            idx, p, total = st["chain_prev"]
+            idx, p, total = st["chain_prev"][:3]
             io.v["out_idx"][:len(idx)] = idx
             io.v["out_p"][:len(p)] = p
             io.v["out_total"][0] = total
@@ -655,13 +704,32 @@ class DeviceActorPipeline:
         infos = self.pending.pop(0)                                  # produced by the actor launch issued last call
         if self.per:
             # (chain mode, once primed: the tree side of these adds ran inside the previous update's chain kernel)
-            rp.advance(self.n_env, stream=self.tree_stream, tree=not (self.chain and self._chain_prev is not None))
+            primed = self._chain_prev is not None or (self._dd is not None and self._dd.active)
+            rp.advance(self.n_env, stream=self.tree_stream, tree=not (self.chain and primed))
         else:
             rp.advance(self.n_env)
         do_update = bool(account(infos))
         if self.pushed - self.issued < 8:
             self._push()
         L.params.n_env = self.n_env
+        if self.per and do_update and self.chain == 2:
+            if self._dd is None:
+                from .replay import DeviceDraw
+                self._dd = DeviceDraw(rp, L)
+            dd = self._dd
+            if not dd.active:
+                # the first prioritized update: a classic draw (tree stream); the tree then belongs to the update stream
+                tree_idx, prob, _ = rp.draw_end(rp.draw_begin(stream=self.tree_stream))
+                self.tree_stream.synchronize()
+                dd.start(tree_idx, prob, 1.0, self.beta_fn())         # (sampling probabilities as they are: p / 1.0)
+            dd.fill(L.next_slot(), self.n_env, self.beta_fn())        # (the exponent of the update AFTER this one)
+            L.set_per(True, -1.0)
+            L.step_update()                                          # [fwd + loss][commit, adds, next draw][bwd + optimizer]
+            L.step_actor(dd.issued_idx())                            # actor(t+1); hazard check on the minibatch just issued
+            self.issued += 1
+            if self.pushed - self.issued < 16:
+                self._push(1)
+            return infos
         if self.per and do_update and self.chain:
             B = rp.batch_size
             if self._chain_io is None:

@@ -684,6 +684,20 @@ class PerChainIO(ctypes.Structure):
                 ("out_idx", ctypes.c_int64 * 1024), ("out_p", ctypes.c_double * 1024), ("out_total", ctypes.c_double)]
 
 
+class PerChain2IO(ctypes.Structure):
+    """include/deeprl_amd.h dra_per_chain2_io (pinned host block of one dra_sumtree_per_chain2 launch)."""
+    _fields_ = [("add_n", ctypes.c_int32), ("batch", ctypes.c_int32), ("next_batch", ctypes.c_int32), ("force_ordered", ctypes.c_int32),
+                ("history", ctypes.c_int32), ("n_step", ctypes.c_int32), ("add_write0", ctypes.c_int64),
+                ("memory_size", ctypes.c_int64), ("pos_after", ctypes.c_int64), ("size_after", ctypes.c_int64),
+                ("rng_produced", ctypes.c_uint64), ("beta_next", ctypes.c_float), ("reserved", ctypes.c_int32),
+                ("out_raw_idx", ctypes.c_int64 * 1024), ("out_idx", ctypes.c_int64 * 1024), ("out_p", ctypes.c_double * 1024),
+                ("out_total", ctypes.c_double), ("out_n_valid", ctypes.c_int32), ("out_flags", ctypes.c_int32),
+                ("out_rng_cursor", ctypes.c_uint64), ("out_seq", ctypes.c_uint64)]
+
+
+PER_RNG_WORDS = 65536     # include/deeprl_amd.h DRA_PER_RNG_WORDS
+
+
 class AtariPreprocess:
     """envs.py:39-47 (baselines' MaxAndSkipEnv max + WarpFrame: RGB2GRAY, INTER_AREA resize to 84x84) as one kernel
     (csrc/preproc.hip): raw [n_env][2][H][W][3] uint8 (the last two frames of each environment's frame skip; host array or

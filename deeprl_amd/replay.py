@@ -591,6 +591,155 @@ class PrioritizedReplay(UniformReplay):
             self.tree = None
 
 
+class DeviceDraw:
+    """Host side of PrioritizedReplay.sample() ON THE DEVICE (csrc/sumtree.hip dra_sumtree_per_chain2, captured into the
+    learner's prioritized update behind its loss kernel): priorities of update t -> tree, adds of agent step t+1, descent +
+    valid_index filter + random.choice padding of draw t+1, whose indices / sampling probabilities the NEXT update reads from
+    device memory.  The host never waits for an update's priorities any more.  What stays here:
+
+      * python's `random` stream.  The kernel consumes raw Mersenne-Twister words from a pinned ring in exactly the order
+        replay.py:169-186 would (two per random.uniform, k-bit rejection draws for random.choice); the host generates them
+        ahead with random.getrandbits and keeps (words produced, random.getstate()) checkpoints, so that release() can put
+        the module's generator at exactly the word the device stopped at;
+      * the bookkeeping of sum_tree.py's pending_idx and of the actor / update ring-slot hazard, ONE launch late: collect()
+        reads the pinned block of the previous launch (spinning on its launch number only if the device is behind)."""
+    REFILL = 4096
+
+    def __init__(self, replay, learner):
+        import collections
+        import ctypes
+        self.rp, self.L = replay, learner
+        rp = replay
+        rp._lazy_tree()
+        if not rp._stat_on_device:
+            rp._stat.copy_(torch.tensor([float(rp._max_priority), float(rp._min_priority)], dtype=torch.float64))
+            rp._stat_on_device = True
+        C = ops.PerChain2IO
+        self.blocks = []
+        for _ in range(4):
+            t = torch.zeros(ctypes.sizeof(C), dtype=torch.uint8).pin_memory()
+            io = C.from_address(t.data_ptr())
+            raw = t.numpy()
+
+            def view(field, dtype, count, raw=raw):
+                off = getattr(C, field).offset
+                return raw[off:off + count * np.dtype(dtype).itemsize].view(dtype)
+            v = dict(head=view("add_n", np.int32, 6), i64=view("add_write0", np.int64, 4), produced=view("rng_produced", np.uint64, 1),
+                     beta=view("beta_next", np.float32, 1), raw=view("out_raw_idx", np.int64, 1024), idx=view("out_idx", np.int64, 1024),
+                     p=view("out_p", np.float64, 1024), total=view("out_total", np.float64, 1), tail=view("out_n_valid", np.int32, 2),
+                     cursor=view("out_rng_cursor", np.uint64, 1), seq=view("out_seq", np.uint64, 1))
+            self.blocks.append((io, t, v))
+        self._words_t = torch.zeros(ops.PER_RNG_WORDS, dtype=torch.int32).pin_memory()
+        self.words = self._words_t.numpy().view(np.uint32)
+        self.produced = self.consumed = 0          # words generated / known to be consumed
+        self.ckpt = collections.deque()            # (words produced before this refill, random.getstate())
+        self.seq = 0                               # launches issued
+        self.fifo = collections.deque()            # issued, not collected: (slot, launch number, leaves its adds overwrite)
+        self.active = False
+        # the newest draw the host has seen: after issued_idx() the minibatch of the update issued last, after release() the one
+        # of the update to be issued next
+        self.next_tree_idx = self.next_p = self.next_total = self.next_beta = None
+        self._collect_leaves = []                  # leaves of the minibatch the next collected launch committed
+        learner.set_per_chain2(rp.tree, rp._stat, [b for b, _, _ in self.blocks], self._words_t)
+
+    # -- python `random`, generated ahead -------------------------------------------------------------------------------
+    def _ensure_words(self, need):
+        if self.produced - self.consumed >= need:
+            return
+        n = max(self.REFILL, int(need))
+        R = ops.PER_RNG_WORDS
+        if self.produced + n - self.consumed > R:
+            raise DraError("DeviceDraw: the word ring is too small for this batch size")
+        self.ckpt.append((self.produced, random.getstate()))
+        w = np.frombuffer(random.getrandbits(32 * n).to_bytes(4 * n, "little"), dtype="<u4")
+        pos = self.produced & (R - 1)
+        first = min(n, R - pos)
+        self.words[pos:pos + first] = w[:first]
+        if first < n:
+            self.words[:n - first] = w[first:]
+        self.produced += n
+        while len(self.ckpt) > 2 and self.ckpt[1][0] <= self.consumed:
+            self.ckpt.popleft()
+
+    def release(self):
+        """Everything issued is collected and the module-level generator stands exactly where the reference's would: after
+        the last word the device consumed.  The next fill() generates ahead again from there."""
+        while self.fifo:
+            self.collect()
+        if self.ckpt:
+            base, state = [c for c in self.ckpt if c[0] <= self.consumed][-1]
+            random.setstate(state)
+            if self.consumed > base:
+                random.getrandbits(32 * (self.consumed - base))
+            self.ckpt.clear()
+        self.produced = self.consumed
+
+    # -- one launch -----------------------------------------------------------------------------------------------------
+    def start(self, tree_idx, p, total, beta, seq=0, cursor=0):
+        """The first prioritized minibatch comes from the host (a classic draw, or a resumed run)."""
+        rp = self.rp
+        tree_idx = np.asarray(tree_idx, dtype=np.int64)
+        p = np.asarray(p, dtype=np.float64)
+        self.release()
+        self.seq = int(seq)
+        self.produced = self.consumed = int(cursor)
+        self.L.per_chain2_seed(tree_idx, tree_idx - (rp.memory_size - 1), p / total, beta, cursor, seq)
+        self.next_tree_idx, self.next_p, self.next_total, self.next_beta = tree_idx, p, float(total), float(beta)
+        self._collect_leaves = tree_idx.tolist()
+        self.active = True
+
+    def fill(self, slot, add_n, beta_next):
+        """Inputs of the launch inside the update about to be issued: the next agent step's adds and everything valid_index
+        needs once they are in.  Nothing here depends on a draw."""
+        rp = self.rp
+        B, mem = rp.batch_size, rp.memory_size
+        self._ensure_words(8 * B + 256)
+        v = self.blocks[slot][2]
+        pos, size = rp.pos, rp.size()
+        for _ in range(int(add_n)):
+            if pos >= size:
+                size += 1
+            pos = (pos + 1) % mem
+        v["head"][:] = (int(add_n), B, B, int(bool(rp.ordered_updates)), rp.history_length, rp.n_step)
+        v["i64"][:] = (int(rp._write), mem, pos, size)
+        v["produced"][0] = self.produced
+        v["beta"][0] = beta_next
+        adds = [(rp._write + i) % mem + mem - 1 for i in range(int(add_n))]
+        rp._write = (rp._write + int(add_n)) % mem
+        self.seq += 1
+        self.fifo.append((slot, self.seq, adds, float(beta_next)))
+
+    def issued_idx(self):
+        """Ring indices of the minibatch of the update issued last (fill() + learner.step_update()): the draw of the launch
+        BEFORE the one just issued -- normally long complete."""
+        while len(self.fifo) > 1:
+            self.collect()
+        return self.next_tree_idx - (self.rp.memory_size - 1)
+
+    def collect(self):
+        """The oldest uncollected launch: its draw becomes `next_*`; pending_idx in the order the device worked
+        (commit of the launch's own minibatch, the adds, every leaf of the new draw)."""
+        slot, seq, adds, beta = self.fifo.popleft()
+        self.L.per_chain2_wait(slot, seq)
+        v = self.blocks[slot][2]
+        B = self.rp.batch_size
+        flags = int(v["tail"][1])
+        if flags:
+            raise DraError("dra_sumtree_per_chain2: %s" % ("the word ring ran dry" if flags & 1 else "no valid transition in a draw"))
+        pend = self.rp._pending
+        pend.difference_update(self._collect_leaves)
+        for leaf in adds:
+            pend.discard(leaf)
+        idx = v["idx"][:B].copy()
+        if int(v["tail"][0]) == B:
+            pend.update(idx.tolist())
+        else:
+            pend.update(v["raw"][:B].tolist())
+        self._collect_leaves = idx.tolist()
+        self.consumed = int(v["cursor"][0])
+        self.next_tree_idx, self.next_p, self.next_total, self.next_beta = idx, v["p"][:B].copy(), float(v["total"][0]), beta
+
+
 class ReplayWrapper:
     """Same surface as replay.py:199-278.  The reference runs the replay in a separate process so
     that sampling and the host->GPU copy overlap the learner; with the ring resident in HBM there

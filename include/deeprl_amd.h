@@ -96,6 +96,43 @@ typedef struct dra_per_chain_io {
 } dra_per_chain_io;
 int dra_sumtree_per_chain(dra_sumtree* tree, dra_per_chain_io* io_pinned, const float* prio_f32_dev, double* stat_dev,
                           void* stream);
+/* Second form (round 3, DRA_PER_CHAIN=2): the whole of PrioritizedReplay.sample() runs on the device, so the HOST is no
+ * longer between an update's priorities and the next update.  On top of dra_sumtree_per_chain the kernel
+ *   - gates the commit itself (sum_tree.py:54-60: first occurrence of a leaf in the minibatch wins; every sampled leaf is
+ *     pending by construction, the sampled leaves are kept in `dev` from one launch to the next),
+ *   - draws its uniforms from python's `random` stream: `rng_words` is a pinned ring of DRA_PER_RNG_WORDS raw Mersenne-Twister
+ *     outputs the host generates ahead (random.getrandbits), `dev` keeps the cursor; random.random() = two words
+ *     ((w0 >> 5) * 2^26 + (w1 >> 6)) * 2^-53, random.uniform(a, b) = a + (b - a) * random(),
+ *   - applies replay.py:122-127's valid_index to every draw, drops the invalid ones and pads with random.choice of what
+ *     has been picked so far (replay.py:176-186; _randbelow: k = n.bit_length(), words >> (32 - k) until one is < n),
+ *   - writes the minibatch's ring indices to `idx_out_dev` (int64[next_batch], what the next update's kernels read) and
+ *     f32(p / total) + the importance exponent to `samp_prob_dev` (f32[next_batch + 1]),
+ *   - and leaves everything the host's (lagging) bookkeeping wants in the pinned block, out_seq last. */
+#define DRA_PER_RNG_WORDS 65536
+typedef struct dra_per_chain2_io {
+  int32_t add_n, batch, next_batch, force_ordered;      /* inputs (batch = next_batch = the launch's `batch` argument) */
+  int32_t history, n_step;
+  int64_t add_write0;                  /* tree write cursor before the adds */
+  int64_t memory_size;                 /* ring slots = leaves */
+  int64_t pos_after, size_after;       /* replay.pos / size() after those adds (valid_index of the next draw) */
+  uint64_t rng_produced;               /* words the host has generated so far: the cursor must not pass it */
+  float beta_next;                     /* importance exponent of the next update (DQN_agent.py:124) */
+  int32_t reserved;
+  int64_t out_raw_idx[DRA_PER_CHAIN_MAX];   /* outputs: the leaf of every descent, in segment order (all become pending) */
+  int64_t out_idx[DRA_PER_CHAIN_MAX];       /* the minibatch's leaves after the validity filter and the padding */
+  double out_p[DRA_PER_CHAIN_MAX];          /* their priorities */
+  double out_total;
+  int32_t out_n_valid;
+  int32_t out_flags;                   /* 1: the word ring ran dry, 2: no valid draw at all -- the results are invalid */
+  uint64_t out_rng_cursor;             /* words consumed so far */
+  uint64_t out_seq;                    /* launches completed, written LAST with system scope */
+} dra_per_chain2_io;
+/* dev: device state of *dra_sumtree_per_chain2_state_bytes bytes ({cursor, seq, leaves of the current minibatch}). */
+int dra_sumtree_per_chain2_state_bytes(int64_t* bytes);
+int dra_sumtree_per_chain2_state_set(void* dev_state, uint64_t rng_cursor, uint64_t seq, const int64_t* tree_idx_host, int n);
+int dra_sumtree_per_chain2(dra_sumtree* tree, dra_per_chain2_io* io_pinned, const float* prio_f32_dev, double* stat_dev,
+                           void* dev_state, const uint32_t* rng_words_pinned, int64_t* idx_out_dev, float* samp_prob_dev,
+                           int batch, void* stream);
 /* replay.py:168-175 + sum_tree.py:23-33,63-66: u_dev[batch] are raw python random.random() draws; lane i samples
  * s = a + (b-a)*u_i on segment i of total/batch and descends; outputs tree index, leaf priority, and the total. */
 int dra_sumtree_sample(dra_sumtree* tree, const double* u_dev, int batch, int64_t* out_tree_idx, double* out_p,
@@ -425,6 +462,20 @@ int dra_dqn_learner_q_host(dra_dqn_learner* learner, const uint8_t* state_host, 
  * update issued last have run (its io block then holds the next draw). */
 int dra_dqn_learner_set_per_chain(dra_dqn_learner* l, dra_sumtree* tree, double* stat_dev, dra_per_chain_io* io0,
                                   dra_per_chain_io* io1, dra_per_chain_io* io2, dra_per_chain_io* io3);
+/* PrioritizedReplay.sample() on the device (dra_sumtree_per_chain2; needs the ring-direct pipeline): _set_per_chain2 once
+ * before the first prioritized update; _per_chain2_seed hands the NEXT update's minibatch over from the host (first update,
+ * resume); _per_chain2_wait spins until rotation slot `slot`'s block shows launch number >= seq (DRA_ETIMEDOUT after
+ * timeout_us).  dra_dqn_learner_step_update / _step_actor are dra_dqn_learner_step (async mode) in two calls: the update of
+ * this agent step on device-resident indices (prm: n_env only), then the NEXT step's actor transitions, prm->idx = the
+ * indices of the update just issued (read back from the chain kernel's block) for the ring-slot hazard check. */
+int dra_dqn_learner_set_per_chain2(dra_dqn_learner* l, dra_sumtree* tree, double* stat_dev, dra_per_chain2_io* io0,
+                                   dra_per_chain2_io* io1, dra_per_chain2_io* io2, dra_per_chain2_io* io3,
+                                   const uint32_t* rng_words_pinned);
+int dra_dqn_learner_per_chain2_seed(dra_dqn_learner* l, const int64_t* tree_idx, const int64_t* data_idx, const double* prob,
+                                    float beta, uint64_t rng_cursor, uint64_t seq, void* stream);
+int dra_dqn_learner_per_chain2_wait(dra_dqn_learner* l, int slot, uint64_t seq, int64_t timeout_us);
+int dra_dqn_learner_step_update(dra_dqn_learner* learner, const dra_dqn_step_params* prm, void* stream_update, void* stream_actor);
+int dra_dqn_learner_step_actor(dra_dqn_learner* learner, const dra_dqn_step_params* prm, void* stream_update, void* stream_actor);
 int dra_dqn_learner_next_slot(dra_dqn_learner* l, int* slot);
 int dra_dqn_learner_sync_loss(dra_dqn_learner* l);
 /* Async actor over a HOST environment (BaseAgent.py:142-162 with a real emulator; needs DRA_VAR_ACTOR_PARAMS):

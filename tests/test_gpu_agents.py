@@ -809,8 +809,9 @@ def test_onpolicy_device_env_equals_host_emulators(dra, monkeypatch, kind):
         assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
 
 
-@pytest.mark.parametrize("kind,per", [("dqn", True), ("c51", True), ("dqn", False), ("c51", False)])
-def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch, kind, per):
+@pytest.mark.parametrize("kind,per,chain", [("dqn", True, 2), ("c51", True, 2), ("dqn", True, 1), ("c51", True, 1), ("dqn", True, 0),
+                                            ("dqn", False, 2), ("c51", False, 2)])
+def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch, kind, per, chain):
     """PrioritizedReplay inside the two-stream pipeline (config.async_actor=True: actor transitions of step t+1 on their own
     stream under update t; the prioritized draw of step t after the device-side write-back of update t-1; ring-direct update
     for DQN, gathered minibatch for C51).  With epsilon == 1 the actions do not depend on the (one update staler)
@@ -823,6 +824,9 @@ def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch
     d = dra
     import deeprl_amd.agents as agents_mod
     monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    # chain: where the prioritized draw runs in async mode -- 2 = entirely inside the update (device-side filter / padding,
+    # replay.DeviceDraw; the default), 1 = inside the update with the host between two updates, 0 = tree stream
+    monkeypatch.setenv("DRA_PER_CHAIN", str(chain))
     outs = []
     for async_actor in (True, False):
         cfg = d.Config()
@@ -852,6 +856,8 @@ def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch
         random.seed(3)
         agent = cls(cfg)
         assert agent._pipe is not None and agent._pipe.async_actor == async_actor and agent._pipe.per == per
+        if per and async_actor:
+            assert agent._pipe.chain == chain
         agent._pipe.rs = np.random.RandomState(77)          # the actor's randint / rand stream, identical in both modes
         np.random.seed(5)                                   # uniform index draws (the async constructor drew its actor seed)
         p_np = fake_envs.numpy_params(fake_envs.NATURE_SHAPES + head, 17)
@@ -861,10 +867,19 @@ def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch
         n_steps = 100
         for _ in range(n_steps):
             agent.step()
+        agent.sync_host()                                   # (PER drawn on the device: python `random` back on the host)
         agent._learner.synchronize()
         torch.cuda.synchronize()
         rp = agent.replay.replay
-        if per and not async_actor and outs and outs[0]["chain"]:
+        pos_size = (rp.pos, rp.size())
+        if per and not async_actor and outs and outs[0]["chain"] == 2:
+            # the async run drew INSIDE its update chain, filter and padding included (dra_sumtree_per_chain2): its last update
+            # already performed the next agent step's four adds and the whole next draw (valid_index as of those four feeds).
+            # Same point for the in-order run:
+            rp.advance(4)
+            rp.draw()
+            torch.cuda.synchronize()
+        elif per and not async_actor and outs and outs[0]["chain"]:
             # the async run ran the prioritized draw INSIDE its update chain (dra_sumtree_per_chain): its last update already
             # performed the next agent step's four adds and the next draw (32 uniforms from python `random`).  Bring the
             # in-order run to the same point before comparing tree / generator positions.
@@ -878,7 +893,7 @@ def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch
         total = agent.total_steps
         frames, actions, rewards, masks = rp._ring.pointers()
         w = d.ops._wrap_device_pointer
-        outs.append(dict(total=total, pos=rp.pos, size=rp.size(), chain=bool(getattr(agent._pipe, "chain", False)),
+        outs.append(dict(total=total, pos=pos_size[0], size=pos_size[1], chain=int(getattr(agent._pipe, "chain", 0)),
                          act=w(actions, 300, torch.int64).cpu().numpy().copy(), rew=w(rewards, 300, torch.float64).cpu().numpy().copy(),
                          tree=rp.tree.as_tensor().cpu().numpy().copy() if per else np.zeros(1),
                          maxp=float(rp.max_priority) if per else 0.0, np_rng=np.random.randint(0, 1 << 30, size=2),

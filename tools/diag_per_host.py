@@ -50,6 +50,15 @@ rp.chain_fill = timed("rp.chain_fill", rp.chain_fill)
 L.next_slot = timed("L.next_slot", L.next_slot)
 L.set_per = timed("L.set_per", L.set_per)
 pipe._push = timed("pipe._push (amortised)", pipe._push)
+L.step_update = timed("L.step_update (C call)", L.step_update)
+L.step_actor = timed("L.step_actor (C call)", L.step_actor)
+L.per_chain2_wait = timed("  L.per_chain2_wait (spin)", L.per_chain2_wait)
+if getattr(pipe, "_dd", None) is not None:
+    dd = pipe._dd
+    dd.fill = timed("dd.fill", dd.fill)
+    dd.issued_idx = timed("dd.issued_idx (incl. the wait)", dd.issued_idx)
+    dd._ensure_words = timed("  dd._ensure_words", dd._ensure_words)
+pipe._block = timed("  pipe._block", pipe._block)
 n = 2000
 t0 = time.perf_counter()
 for _ in range(n):
@@ -61,7 +70,7 @@ for k, v in acc.items():
     print("%-32s %7.1f us" % (k, 1e6 * v / n))
 
 # ---- issue -> loss latency with an idle GPU: how long do [forward + loss + chain kernel] take by themselves?
-if getattr(pipe, "chain", False):
+if getattr(pipe, "chain", 0) == 1:
     import ctypes
     from deeprl_amd._lib import lib
     lat = []

@@ -10,7 +10,8 @@ nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 dbs = glob.glob(path + "/**/*_results.db", recursive=True)
 cur = sqlite3.connect(dbs[0]).cursor()
 rows = cur.execute("select name, start, end, queue_id, stream_id, grid_x, grid_y, grid_z from kernels order by start").fetchall()
-steps = [i for i, r in enumerate(rows) if "rmsprop_step" in r[0]]
+marker = sys.argv[4].split("|") if len(sys.argv) > 4 else ["rmsprop_step", "late_step_kernel", "clip_step_kernel"]   # the update's last kernel
+steps = [i for i, r in enumerate(rows) if any(m in r[0] for m in marker)]
 i0, i1 = steps[skip] + 1, steps[skip + nsteps] + 1
 t0 = rows[i0][1]
 print("window: %d kernels, %.1f us" % (i1 - i0, (rows[i1 - 1][2] - t0) / 1e3))
