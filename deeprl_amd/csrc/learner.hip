@@ -206,6 +206,7 @@ struct dra_dqn_learner {
   int split_q;                      // step_pipelined3 in two calls: state carried from the update half to the actor half
   hipEvent_t split_opt_prev;
   bool split_seed, split_open;
+  bool per2_active;                 // capturing the one-graph prioritized update: weights precomputed, priorities by the chain kernel
   hipEvent_t ev_per_fork, ev_per_join;   // capture-time fork / join of the chain kernel's branch
   unsigned* aflags;                 // DRA_VAR_ACTOR_MEGA: [kMaxEnvSteps][4] arrival counters of the one-launch env steps (zeroed by
                                     // the agent step's tail kernel)
@@ -787,7 +788,7 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
                   const float* __restrict__ reward, const float* __restrict__ mask, float gamma_n, int double_q,
                   float* __restrict__ h4_out, float* __restrict__ q_on, float* __restrict__ q_tg, float* __restrict__ q_on2,
                   float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dh4, int64_t* __restrict__ opt_step,
-                  const RingScalars rs) {
+                  const RingScalars rs, const float* __restrict__ per_w) {
   __shared__ float s_h[3][512];
   __shared__ float s_q[3][64];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -883,7 +884,15 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
     }
     const float target = rew_b + (gamma_n * qn) * mask_b;
     const float d = target - s_q[0][ab];
-    dqa = -d / (float)B;
+    if (per_w) {
+      // PrioritizedReplay with the importance weights already known (the previous update's chain kernel normalised them:
+      // sumtree.hip dra_sumtree_per_chain2): d mean(0.5 (delta w)^2) / dq, in td_loss_kernel's order of operations
+      const float w = per_w[b];
+      const float lw = d * w;
+      dqa = -(lw * w) / (float)B;
+    } else {
+      dqa = -d / (float)B;
+    }
     if (tid == 0) delta[b] = d;
   }
   if (tid < A) {
@@ -1092,13 +1101,16 @@ static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta
   if (c.head_kind == DRA_HEAD_CATEGORICAL) {
     const float* weights = nullptr;
     if (per) {   // DQN_agent.py:124-126: importance weights scale the per-sample loss before the mean
-      if ((rc = dra_per_weights(nullptr, l->samp_prob, B, beta, c.replay_eps, c.replay_alpha, nullptr, l->weights, s))) return rc;
+      // (device-side prioritized draw: the previous update's chain kernel left them, and computes the priorities itself)
+      if (!l->per2_active &&
+          (rc = dra_per_weights(nullptr, l->samp_prob, B, beta, c.replay_eps, c.replay_alpha, nullptr, l->weights, s))) return rc;
       weights = l->weights;
     }
     rc = dra_c51_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action_[l->gb], 1, l->reward_[l->gb], l->mask_[l->gb],
                       B, A, N, c.gamma_n, c.v_min, c.v_max, l->atoms, l->delta, l->dq, weights, s);
     if (rc) return rc;
-    if (per && (rc = dra_per_weights(l->delta, l->samp_prob, B, beta, c.replay_eps, c.replay_alpha, l->prio, nullptr, s))) return rc;
+    if (per && !l->per2_active &&
+        (rc = dra_per_weights(l->delta, l->samp_prob, B, beta, c.replay_eps, c.replay_alpha, l->prio, nullptr, s))) return rc;
   } else {
     if (per) return DRA_EINVAL;   // not a valid reference configuration (QuantileRegressionDQN_agent.py: uniform replay only)
     rc = dra_qr_loss(l->q[0], l->q[1], l->action_[l->gb], 1, l->reward_[l->gb], l->mask_[l->gb], B, A, N, c.gamma_n, l->qr_ws,
@@ -1180,26 +1192,28 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     int rc = run_dist_head(l, st, per, beta, rs);
     if (rc) return rc;
   } else {
+    // weights known before the update (device-side prioritized draw): the fused head applies them, no batch-wide reduction
+    const float* per_w = (per && l->per2_active) ? l->weights : nullptr;
     if (ks4 == kFc4SplitWide)
       hipLaunchKernelGGL(head_fused_kernel<kFc4SplitWide>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                          P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
                          (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
                          c.double_q,
-                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs);
+                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs, per_w);
     else if (ks4 == kFc4SplitMid)
       hipLaunchKernelGGL(head_fused_kernel<kFc4SplitMid>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                          P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
                          (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
                          c.double_q,
-                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs);
+                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs, per_w);
     else
       hipLaunchKernelGGL(head_fused_kernel<kFc4Split>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                          P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
                          (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
                          c.double_q,
-                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs);
+                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs, per_w);
     DRA_LAUNCH_CHECK();
-    if (per) {  // PER needs the batch-wide max of the importance weights: separate kernel recomputes dq, then dh4
+    if (per && !per_w) {  // PER needs the batch-wide max of the importance weights: separate kernel recomputes dq, then dh4
       int rc = dra_td_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action_[l->gb], 1, l->reward_[l->gb],
                            l->mask_[l->gb], B, A, c.gamma_n,
                            l->samp_prob, beta, c.replay_eps, c.replay_alpha, l->loss, l->dq, l->delta, l->prio, l->weights, s);
@@ -1382,6 +1396,7 @@ static int capture_per2(dra_dqn_learner* l, hipStream_t st, int q, bool rd, hipG
   l->rd_slot = rd ? q : -1;
   hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (b != hipSuccess) { l->gb = 0; l->rd_slot = -1; return (int)b; }
+  l->per2_active = true;
   int rc = run_body(l, st, 1, -1.f, 0, 1);
   static int fork = -1;
   // 1: the chain kernel as a parallel branch of the graph.  Measured (profiles/r03h): the branches do overlap, but the forked
@@ -1393,9 +1408,11 @@ static int capture_per2(dra_dqn_learner* l, hipStream_t st, int q, bool rd, hipG
     if (rc == DRA_OK) rc = (int)hipStreamWaitEvent(sd, l->ev_per_fork, 0);
   }
   if (rc == DRA_OK)
-    rc = dra_sumtree_per_chain2(l->per_tree, l->per2_io[q & 3], l->prio, l->per_stat, l->per2_dev, l->per2_words,
-                                l->per2_idx + (size_t)((q + 1) & 3) * 1024, l->samp_prob, l->c.batch, (void*)sd);
+    rc = dra_sumtree_per_chain2(l->per_tree, l->per2_io[q & 3], l->delta, l->c.replay_eps, l->c.replay_alpha, l->prio, l->per_stat,
+                                l->per2_dev, l->per2_words, l->per2_idx + (size_t)((q + 1) & 3) * 1024, l->samp_prob, l->weights,
+                                l->c.batch, (void*)sd);
   if (rc == DRA_OK) rc = run_body(l, st, 1, -1.f, 0, 2);
+  l->per2_active = false;
   if (rc == DRA_OK) rc = launch_optimizer(l, st, l->pa[q]);
   if (rc == DRA_OK && fork) {
     rc = (int)hipEventRecord(l->ev_per_join, sd);
@@ -1495,6 +1512,9 @@ DRA_API int dra_dqn_learner_per_chain2_seed(dra_dqn_learner* l, const int64_t* t
   DRA_HIP(hipMemcpy(l->samp_prob, sp, (size_t)(B + 1) * sizeof(float), hipMemcpyHostToDevice));
   int rc = dra_sumtree_per_chain2_state_set(l->per2_dev, rng_cursor, seq, tree_idx, B);
   if (rc) return rc;
+  // the importance weights of that update, by the kernel every other path uses (exponent read from samp_prob[B])
+  if ((rc = dra_per_weights(nullptr, l->samp_prob, B, -1.f, l->c.replay_eps, l->c.replay_alpha, nullptr, l->weights, stream))) return rc;
+  DRA_HIP(hipStreamSynchronize(st));
   DRA_HIP(hipMemcpy(l->per2_idx + (size_t)(l->step_no & 3) * 1024, data_idx, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice));
   return DRA_OK;
 }

@@ -548,9 +548,11 @@ __device__ __forceinline__ int lds_find(const int64_t* arr, int n, int64_t key) 
 
 __global__ void __launch_bounds__(1024)
 sumtree_per_chain2_kernel(double* __restrict__ tree, int levels, int64_t capacity, int64_t n_nodes, dra_per_chain2_io* __restrict__ io,
-                          const float* __restrict__ prio, double* __restrict__ stat, PerChain2Dev* __restrict__ dev,
-                          const uint32_t* __restrict__ words, int64_t* __restrict__ idx_out, float* __restrict__ samp_prob, int nb) {
+                          const float* __restrict__ loss_vec, float eps, float alpha, float* __restrict__ prio_out,
+                          double* __restrict__ stat, PerChain2Dev* __restrict__ dev, const uint32_t* __restrict__ words,
+                          int64_t* __restrict__ idx_out, float* __restrict__ samp_prob, float* __restrict__ weights_out, int nb) {
   __shared__ double s_hi[16], s_lo[16];
+  __shared__ float s_wmax[16];
   __shared__ unsigned long long s_head[9];
   __shared__ int s_ordered, s_all_valid, s_nvalid, s_flags;
   __shared__ double s_max;
@@ -572,9 +574,15 @@ sumtree_per_chain2_kernel(double* __restrict__ tree, int levels, int64_t capacit
   if (tid == 0) { s_all_valid = 1; s_flags = 0; }
   const int batch = nb;            // (the learner's batch size: every update commits and draws `nb` transitions)
   // ---- commit: {max, min} over every offered priority; a leaf is written by its FIRST occurrence in the minibatch
+  // (DQN_agent.py:121-123: priorities = |loss| + eps to the power alpha, from the PRE-weight loss vector; float arithmetic
+  // exactly as losses.hip's td_loss_kernel / per_kernel)
   double hi = -INFINITY, lo = INFINITY;
+  float prio_f = 0.f;
   if (tid < batch) {
-    const double v = (double)prio[tid];
+    const float ad = fabsf(loss_vec[tid]) + eps;
+    prio_f = (alpha == 0.5f) ? sqrtf(ad) : powf(ad, alpha);
+    prio_out[tid] = prio_f;
+    const double v = (double)prio_f;
     hi = v;
     lo = v;
     s_idx[tid] = dev->tidx[tid];
@@ -618,7 +626,7 @@ sumtree_per_chain2_kernel(double* __restrict__ tree, int levels, int64_t capacit
     int64_t node = -1;
     double val = 0.0;
     if (tid < batch) {
-      if (s_first[tid]) { node = s_idx[tid]; val = (double)prio[tid]; }
+      if (s_first[tid]) { node = s_idx[tid]; val = (double)prio_f; }
     } else if (tid < n_items) {
       node = (write0 + (tid - batch)) % capacity + capacity - 1;
       val = s_max;
@@ -642,7 +650,7 @@ sumtree_per_chain2_kernel(double* __restrict__ tree, int levels, int64_t capacit
         for (int k = 0; k < batch; ++k) {
           if (!s_first[k]) continue;
           int64_t node = s_idx[k];
-          const double p = (double)prio[k];
+          const double p = (double)prio_out[k];
           const double change = __dsub_rn(p, node_load(tree + node));
           node_store(tree + node, p);
           while (node > 0) {
@@ -656,7 +664,7 @@ sumtree_per_chain2_kernel(double* __restrict__ tree, int levels, int64_t capacit
       int64_t node = -1;
       if (tid < batch && s_first[tid]) {
         node = s_idx[tid];
-        node_store(tree + node, (double)prio[tid]);
+        node_store(tree + node, (double)prio_f);
       }
       for (int lv = 0; lv < levels; ++lv) {
         __syncthreads();
@@ -752,21 +760,37 @@ sumtree_per_chain2_kernel(double* __restrict__ tree, int levels, int64_t capacit
   }
   __syncthreads();
   CHAIN2_STAMP(7);
-  // ---- hand-over: the next update reads idx_out / samp_prob, the next launch of this kernel reads dev->tidx
+  // ---- hand-over: the next update reads idx_out / samp_prob / weights_out, the next launch of this kernel reads dev->tidx
+  float beta;
+  {
+    const unsigned lo32 = (unsigned)(s_head[8] & 0xffffffffull);
+    __builtin_memcpy(&beta, &lo32, sizeof(beta));
+  }
+  // DQN_agent.py:124-126, as per_kernel: weights = (P * B + 1e-6)^-beta / their max
+  float wraw = -INFINITY, spf = 0.f;
   if (tid < nb) {
+    spf = (float)__ddiv_rn(s_p[tid], total);
+    wraw = powf(spf * (float)nb + 1e-6f, -beta);
+  }
+  {
+    const float wm = wave_max(wraw);
+    if ((tid & 63) == 0) s_wmax[tid >> 6] = wm;
+  }
+  __syncthreads();
+  if (tid < nb) {
+    float wmax = s_wmax[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) wmax = fmaxf(wmax, s_wmax[w]);
+    weights_out[tid] = wraw / wmax;
     const int64_t leaf = s_idx[tid];
     const double p = s_p[tid];
     dev->tidx[tid] = leaf;
     idx_out[tid] = leaf - (mem - 1);
-    samp_prob[tid] = (float)__ddiv_rn(p, total);
+    samp_prob[tid] = spf;
     st_sys(&io->out_idx[tid], leaf);
     st_sys(&io->out_p[tid], p);
     stores_acknowledged();
   }
   if (tid == 0) {
-    float beta;
-    const unsigned lo32 = (unsigned)(s_head[8] & 0xffffffffull);
-    __builtin_memcpy(&beta, &lo32, sizeof(beta));
     samp_prob[nb] = beta;
     dev->rng_cursor = s_cursor;
     st_sys(&io->out_total, total);
@@ -801,15 +825,16 @@ DRA_API int dra_sumtree_per_chain2_state_set(void* dev_state, uint64_t rng_curso
   return DRA_OK;
 }
 
-DRA_API int dra_sumtree_per_chain2(dra_sumtree* t, dra_per_chain2_io* io_pinned, const float* prio_f32_dev, double* stat_dev,
-                                   void* dev_state, const uint32_t* rng_words_pinned, int64_t* idx_out_dev, float* samp_prob_dev,
-                                   int batch, void* stream) {
-  if (!t || !io_pinned || !prio_f32_dev || !stat_dev || !dev_state || !rng_words_pinned || !idx_out_dev || !samp_prob_dev ||
-      batch < 1 || batch > DRA_PER_CHAIN_MAX)
+DRA_API int dra_sumtree_per_chain2(dra_sumtree* t, dra_per_chain2_io* io_pinned, const float* loss_vec_dev, float replay_eps,
+                                   float replay_alpha, float* prio_out_dev, double* stat_dev, void* dev_state,
+                                   const uint32_t* rng_words_pinned, int64_t* idx_out_dev, float* samp_prob_dev,
+                                   float* weights_out_dev, int batch, void* stream) {
+  if (!t || !io_pinned || !loss_vec_dev || !prio_out_dev || !stat_dev || !dev_state || !rng_words_pinned || !idx_out_dev ||
+      !samp_prob_dev || !weights_out_dev || batch < 1 || batch > DRA_PER_CHAIN_MAX)
     return DRA_EINVAL;
   hipLaunchKernelGGL(sumtree_per_chain2_kernel, dim3(1), dim3(1024), 0, dra_stream(stream), t->tree, t->levels, t->capacity,
-                     t->n_nodes, io_pinned, prio_f32_dev, stat_dev, reinterpret_cast<PerChain2Dev*>(dev_state), rng_words_pinned,
-                     idx_out_dev, samp_prob_dev, batch);
+                     t->n_nodes, io_pinned, loss_vec_dev, replay_eps, replay_alpha, prio_out_dev, stat_dev,
+                     reinterpret_cast<PerChain2Dev*>(dev_state), rng_words_pinned, idx_out_dev, samp_prob_dev, weights_out_dev, batch);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

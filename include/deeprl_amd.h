@@ -107,6 +107,9 @@ int dra_sumtree_per_chain(dra_sumtree* tree, dra_per_chain_io* io_pinned, const 
  *     has been picked so far (replay.py:176-186; _randbelow: k = n.bit_length(), words >> (32 - k) until one is < n),
  *   - writes the minibatch's ring indices to `idx_out_dev` (int64[next_batch], what the next update's kernels read) and
  *     f32(p / total) + the importance exponent to `samp_prob_dev` (f32[next_batch + 1]),
+ *   - computes the priorities itself from the update's per-sample loss vector ((|loss| + eps)^alpha, DQN_agent.py:121-123;
+ *     also left in prio_out_dev) and the NEXT update's importance weights ((P * B + 1e-6)^-beta / max, :124-126) into
+ *     weights_out_dev: the update needs no batch-wide reduction of its own any more,
  *   - and leaves everything the host's (lagging) bookkeeping wants in the pinned block, out_seq last. */
 #define DRA_PER_RNG_WORDS 65536
 typedef struct dra_per_chain2_io {
@@ -130,9 +133,10 @@ typedef struct dra_per_chain2_io {
 /* dev: device state of *dra_sumtree_per_chain2_state_bytes bytes ({cursor, seq, leaves of the current minibatch}). */
 int dra_sumtree_per_chain2_state_bytes(int64_t* bytes);
 int dra_sumtree_per_chain2_state_set(void* dev_state, uint64_t rng_cursor, uint64_t seq, const int64_t* tree_idx_host, int n);
-int dra_sumtree_per_chain2(dra_sumtree* tree, dra_per_chain2_io* io_pinned, const float* prio_f32_dev, double* stat_dev,
-                           void* dev_state, const uint32_t* rng_words_pinned, int64_t* idx_out_dev, float* samp_prob_dev,
-                           int batch, void* stream);
+int dra_sumtree_per_chain2(dra_sumtree* tree, dra_per_chain2_io* io_pinned, const float* loss_vec_dev, float replay_eps,
+                           float replay_alpha, float* prio_out_dev, double* stat_dev, void* dev_state,
+                           const uint32_t* rng_words_pinned, int64_t* idx_out_dev, float* samp_prob_dev,
+                           float* weights_out_dev, int batch, void* stream);
 /* replay.py:168-175 + sum_tree.py:23-33,63-66: u_dev[batch] are raw python random.random() draws; lane i samples
  * s = a + (b-a)*u_i on segment i of total/batch and descends; outputs tree index, leaf priority, and the total. */
 int dra_sumtree_sample(dra_sumtree* tree, const double* u_dev, int batch, int64_t* out_tree_idx, double* out_p,
