@@ -551,9 +551,9 @@ __global__ void __launch_bounds__(64 * NW) conv1_actor_fused_kernel(const ConvV2
 // remove the per-sample tile padding (81 -> 96, 49 -> 64 positions) staged 2-3 whole samples per group at one
 // wave per SIMD and LOST (conv2 34 %, conv3 37 %): it was removed.  What remains between ~45 % and the pipe's
 // peak is the 16-23 % padding of conv2 / conv3 and the fp32 MFMA sharing its issue port with the staging VALU work.
-template <class G, class T, bool U8>
+template <class G, class T, bool U8, int NW = 4>
 struct V2Stage {
-  static constexpr int CPT = (G::C + 3) / 4;                       // channels per wave
+  static constexpr int CPT = (G::C + NW - 1) / NW;                 // channels per wave
   static constexpr int LR = U8 ? 32 : (G::H > 16 ? 32 : 16);       // lanes per image row (u8: one u32 word per lane)
   static constexpr int RP = 64 / LR;                               // rows per pass
   static constexpr int LPT = (T::NR + RP - 1) / RP;
@@ -569,7 +569,7 @@ struct V2Stage {
     constexpr int ROW = U8 ? G::H / 4 : G::H;                      // elements of E per image row
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
-      const int c = min(wave + 4 * ci, G::C - 1);
+      const int c = min(wave + NW * ci, G::C - 1);
       const E* src = base + ((int64_t)(bi * G::C + c) * G::H + ir0) * ROW + col;
 #pragma unroll
       for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = src[min(RP * q + rsub, nrows - 1) * ROW];
@@ -582,7 +582,7 @@ struct V2Stage {
     const int rsub = lane / LR, cl = lane % LR;
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
-      const int c = wave + 4 * ci;
+      const int c = wave + NW * ci;
       if constexpr (U8) {
         float* dst = img + c * T::CS + rsub * G::RW + cl;
 #pragma unroll
@@ -607,40 +607,87 @@ struct V2Stage {
   }
 };
 
-template <class G, bool U8, int PT>
-__global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Args a, const int n_groups) {
+// Staging of a WHOLE fp32 image of a stride-2 layer (conv2's throughput shape: PT = 3 covers the sample) as 128-bit loads: the
+// sample is one contiguous block of C * H * H floats, 13 loads per thread instead of 80 row-shaped dword loads with 20 of 32
+// lanes active.  More than 64 loads per thread cannot even be in flight together (vmcnt), and the rest issue only as the
+// first ones return -- in front of the MFMA phase they are ordered before: 8.2 us instead of 5.9 us per group
+// (tools/phase_conv_big.py).  A float4 never straddles a row (H % 4 == 0); its elements 0 / 2 and 1 / 3 are neighbours in the
+// two stride phases of the de-interleaved LDS row: two 64-bit writes.
+template <class G, class T, int NT>
+struct V2StageWide {
+  // (instantiated for every layer, USED only where the kernel's WIDE condition holds: whole image, stride 2, H % 4 == 0)
+  static constexpr int TOTAL = G::C * G::H * G::H / 4;               // float4s per sample
+  static constexpr int N = (TOTAL + NT - 1) / NT;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+
+  __device__ static __forceinline__ void load(const ConvV2Args& a, int z, int bi, int tid, f4 (&raw)[N]) {
+    const f4* base = reinterpret_cast<const f4*>(reinterpret_cast<const float*>(a.x[z]) + (int64_t)bi * G::C * G::H * G::H);
+#pragma unroll
+    for (int i = 0; i < N; ++i) raw[i] = base[min(tid + NT * i, TOTAL - 1)];
+  }
+
+  __device__ static __forceinline__ void store(f4 (&raw)[N], float* __restrict__ img, int tid) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      f4 v = raw[i];
+      asm volatile("" : "+v"(v));
+      const int idx = tid + NT * i;
+      if (idx < TOTAL) {
+        const int e = 4 * idx, c = e / (G::H * G::H), rem = e - c * (G::H * G::H), row = rem / G::H, col = rem - row * G::H;
+        float* dst = img + c * T::CS + row * G::RW + col / 2;
+        *reinterpret_cast<f2*>(dst) = f2{v.x, v.z};
+        *reinterpret_cast<f2*>(dst + G::WPH) = f2{v.y, v.w};
+      }
+    }
+  }
+};
+
+// NW = waves per workgroup = K split.  4: two or three workgroups share a CU where LDS allows (conv1, conv3).  8: conv2, whose
+// 51 KB fp32 image + partial-sum exchange leave room for ONE workgroup per CU -- and one wave per SIMD issues a 32x32x2 MFMA
+// only every ~90 cycles (7.7 us for 192 MFMAs), two waves per SIMD keep the pipe dense (conv3's two workgroups: 288 MFMAs in
+// 7.8 us; tools/phase_conv_big.py, profiles/r03h_phase_conv_big_before.json).
+// SEQ: the partial sums of the PT tiles cross LDS one tile at a time through ONE tile's worth of exchange buffer (16 KB instead
+// of PT x 16 KB): conv2's 51 KB image + 48 KB of partial sums allowed one workgroup per CU; with 67 KB two fit -- two waves per
+// SIMD issue a 32x32x2 MFMA every 27 ns, one wave only every 39 ns (same sums in the same order: bit-identical results;
+// starting the second workgroup half a group late was tried and loses 3-6 %).  Batch 1024, same box: 45.1 -> 48.9 %.
+template <class G, bool U8, int PT, int NW = 4, bool SEQ = false>
+__global__ void __launch_bounds__(64 * NW) conv_fwd_v2_persist_kernel(const ConvV2Args a, const int n_groups) {
   using T = V2Tile<G, PT>;
-  using ST = V2Stage<G, T, U8>;
+  using ST = V2Stage<G, T, U8, NW>;
+  using KS = typename G::template Split<NW>;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  constexpr int RPW = 16 / NW;                // accumulator rows a wave finalises
   using E = typename std::conditional<U8, unsigned, float>::type;
   static_assert(!U8 || G::S == 4, "u8 staging: stride-4 layer");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float s_lut[256];
   float* img = lds;                          // [C][NR][RW]
-  float* red = lds + G::C * T::CS;           // [PT][4 waves][16][64]
+  float* red = lds + G::C * T::CS;           // [PT][NW waves][16][64]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
   const int z = blockIdx.z;
   const int oc0 = blockIdx.y * 32;
   const float* __restrict__ wt = a.wt[z];
-  const int cp0 = (G::CP >= 4) ? wave * G::CPW : (wave % G::CP);
-  const int t0 = (G::CP >= 4) ? 0 : (wave / G::CP) * G::TW;
+  const int cp0 = (G::CP >= NW) ? wave * KS::CPW : (wave % G::CP);
+  const int t0 = (G::CP >= NW) ? 0 : (wave / G::CP) * KS::TW;
   [[maybe_unused]] const int TRR = TR_CONV1_F + (G::C == 4 ? 0 : (G::C == 32 ? 1 : 2));
   DRA_STAMP(TRR, 0);
-  float areg[G::NJ];
+  float areg[KS::NJ];
   {
     const float* wbase = wt + ((int64_t)(2 * cp0 + h) * G::KK + t0) * G::OC + oc0 + li;
 #pragma unroll
-    for (int j = 0; j < G::NJ; ++j) {
-      const int cpl = j / G::TW, t = j - cpl * G::TW;
+    for (int j = 0; j < KS::NJ; ++j) {
+      const int cpl = j / KS::TW, t = j - cpl * KS::TW;
       areg[j] = wbase[(2 * cpl * G::KK + t) * G::OC];
     }
   }
-  float bias_r[4];
+  float bias_r[RPW];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = wave * 4 + q;
+  for (int q = 0; q < RPW; ++q) {
+    const int r = wave * RPW + q;
     bias_r[q] = a.bias[z][oc0 + (r & 3) + 8 * (r >> 2) + 4 * h];
   }
-  if (U8) s_lut[tid] = (float)((double)tid * a.coef);
+  if (U8 && tid < 256) s_lut[tid] = (float)((double)tid * a.coef);
   float* __restrict__ y = a.y[z];
 
   int g = blockIdx.x;
@@ -648,10 +695,15 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Ar
   int np = min(32 * PT, G::P - p0);
   int oh0 = p0 / G::OH;
   int nrows = ((p0 + np - 1) / G::OH - oh0) * G::S + G::KH;
-  E raw[ST::N];
-  ST::load(a, z, bi, oh0 * G::S, nrows, wave, lane, raw);
+  constexpr bool WIDE = !U8 && G::S == 2 && G::H % 4 == 0 && T::NR == G::H && G::WPH % 2 == 0 && T::CS % 2 == 0;
+  using SW = V2StageWide<G, T, 64 * NW>;
+  E raw[WIDE ? 1 : ST::N];
+  typename SW::f4 raw4[WIDE ? SW::N : 1];
+  if constexpr (WIDE) SW::load(a, z, bi, tid, raw4);
+  else ST::load(a, z, bi, oh0 * G::S, nrows, wave, lane, raw);
   __syncthreads();                                   // normalisation table visible
-  ST::store(raw, img, s_lut, nrows, wave, lane);
+  if constexpr (WIDE) SW::store(raw4, img, tid);
+  else ST::store(raw, img, s_lut, nrows, wave, lane);
   __syncthreads();
   DRA_STAMP(TRR, 2);   // prologue done: weights + first group staged
   for (;;) {
@@ -664,7 +716,8 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Ar
     const int np_n = min(32 * PT, G::P - p0_n);
     const int oh0_n = p0_n / G::OH;
     const int nrows_n = ((p0_n + np_n - 1) / G::OH - oh0_n) * G::S + G::KH;
-    ST::load(a, z, bi_n, oh0_n * G::S, nrows_n, wave, lane, raw);
+    if constexpr (WIDE) SW::load(a, z, bi_n, tid, raw4);
+    else ST::load(a, z, bi_n, oh0_n * G::S, nrows_n, wave, lane, raw);
     __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise sinks these loads to the end of the MFMA phase
     // ---- MFMA phase of the current group
     const float* bptr[PT];
@@ -680,30 +733,52 @@ __global__ void __launch_bounds__(256) conv_fwd_v2_persist_kernel(const ConvV2Ar
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
-    for (int j = 0; j < G::NJ; ++j) {
-      const int cpl = j / G::TW, tp = j - cpl * G::TW;
+    for (int j = 0; j < KS::NJ; ++j) {
+      const int cpl = j / KS::TW, tp = j - cpl * KS::TW;
       const int kh = tp / G::KH, kw = tp - kh * G::KH;
       const int off = 2 * cpl * T::CS + kh * G::RW + (kw % G::S) * G::WPH + kw / G::S;
 #pragma unroll
       for (int t = 0; t < PT; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[j], bptr[t][off], acc[t], 0, 0, 0);
     }
+    if (g == (int)blockIdx.x) DRA_STAMP(TRR, 1);   // (first group only) this wave's MFMAs issued
     __syncthreads();   // image fully consumed
+    if (g == (int)blockIdx.x) DRA_STAMP(TRR, 3);   // every wave's MFMAs issued, the next group's rows have arrived
+    if constexpr (!SEQ) {
 #pragma unroll
-    for (int t = 0; t < PT; ++t)
+      for (int t = 0; t < PT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) red[((t * 4 + wave) * 16 + r) * 64 + lane] = acc[t][r];
-    if (more) ST::store(raw, img, s_lut, nrows_n, wave, lane);
-    __syncthreads();
-    // ---- fold the four K-quarters, bias, activation, store (same order as the one-shot kernel)
+        for (int r = 0; r < 16; ++r) red[((t * NW + wave) * 16 + r) * 64 + lane] = acc[t][r];
+      if (more) {
+        if constexpr (WIDE) SW::store(raw4, img, tid);
+        else ST::store(raw, img, s_lut, nrows_n, wave, lane);
+      }
+      __syncthreads();
+      if (g == (int)blockIdx.x) DRA_STAMP(TRR, 4);   // next group staged
+    }
+    // ---- fold the K parts (four: same order as the one-shot kernel; eight: pairs, then pairs of pairs), bias, activation, store
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
-      const float* rt = red + (t * 4 * 16) * 64;
+      if constexpr (SEQ) {
+        if (t > 0) __syncthreads();                  // the previous tile's partial sums have been folded
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = wave * 4 + q;
-        const float s = (rt[(0 * 16 + r) * 64 + lane] + rt[(1 * 16 + r) * 64 + lane]) +
-                        (rt[(2 * 16 + r) * 64 + lane] + rt[(3 * 16 + r) * 64 + lane]);
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t][r];
+        if (t == 0 && more) {
+          if constexpr (WIDE) SW::store(raw4, img, tid);
+          else ST::store(raw, img, s_lut, nrows_n, wave, lane);
+        }
+        __syncthreads();
+        if (t == 0 && g == (int)blockIdx.x) DRA_STAMP(TRR, 4);
+      }
+      const float* rt = red + (SEQ ? 0 : t * NW * 16) * 64;
+#pragma unroll
+      for (int q = 0; q < RPW; ++q) {
+        const int r = wave * RPW + q;
+        float s = (rt[(0 * 16 + r) * 64 + lane] + rt[(1 * 16 + r) * 64 + lane]) +
+                  (rt[(2 * 16 + r) * 64 + lane] + rt[(3 * 16 + r) * 64 + lane]);
+        if constexpr (NW == 8)
+          s += (rt[(4 * 16 + r) * 64 + lane] + rt[(5 * 16 + r) * 64 + lane]) +
+               (rt[(6 * 16 + r) * 64 + lane] + rt[(7 * 16 + r) * 64 + lane]);
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = v2_act(s + bias_r[q], a.act);
         if (32 * t + li < np) y[((int64_t)(bi * G::OC + oc0 + row)) * G::P + p0 + 32 * t + li] = v;
@@ -1081,14 +1156,14 @@ static int conv_b1_waves() {
   return v;
 }
 
-template <class G, bool U8, int PT>
+template <class G, bool U8, int PT, int NW = 4, bool SEQ = false>
 static int launch_conv_v2_persist(const ConvV2Args& a, int nz, hipStream_t st) {
   using T = V2Tile<G, PT>;
-  constexpr size_t bytes = ((size_t)G::C * T::CS + (size_t)PT * 4 * 16 * 64) * sizeof(float);
+  constexpr size_t bytes = ((size_t)G::C * T::CS + (size_t)(SEQ ? 1 : PT) * NW * 16 * 64) * sizeof(float);
   static_assert(bytes <= 159 * 1024, "LDS per workgroup (+1 KB normalisation table)");
   static bool attr_set = false;
   if (bytes > 64 * 1024 && !attr_set) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT>),
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT, NW, SEQ>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     attr_set = true;
   }
@@ -1103,15 +1178,15 @@ static int launch_conv_v2_persist(const ConvV2Args& a, int nz, hipStream_t st) {
     else {
       DRA_HIP(hipGetDevice(&dev));
       DRA_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-      DRA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT>),
-                                                           256, bytes));
+      DRA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT, NW, SEQ>),
+                                                           64 * NW, bytes));
       resident = (per_cu > 0 ? per_cu : 1) * n_cu;
     }
   }
   const int lanes = (G::OC / 32) * nz;
   const int per = resident / lanes > 0 ? resident / lanes : 1;
   const int nwg = n_groups < per ? n_groups : per;
-  hipLaunchKernelGGL((conv_fwd_v2_persist_kernel<G, U8, PT>), dim3(nwg, G::OC / 32, nz), dim3(256), bytes, st, a, n_groups);
+  hipLaunchKernelGGL((conv_fwd_v2_persist_kernel<G, U8, PT, NW, SEQ>), dim3(nwg, G::OC / 32, nz), dim3(64 * NW), bytes, st, a, n_groups);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -1129,7 +1204,18 @@ static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
     if constexpr (U8 || G::H <= 32) {
       static int persist = -1;
       if (persist < 0) { const char* e = getenv("DRA_CONV_PERSIST"); persist = e ? atoi(e) : 1; }
-      if (persist) return launch_conv_v2_persist<G, U8, PTBIG>(a, nz, st);
+      if (persist) {
+        if constexpr (!U8 && G::C == 32) {
+          // conv2 (51 KB fp32 image per sample).  DRA_CONV2_MODE: 2 (default) = one tile's partial sums at a time, two
+          // workgroups per CU; 1 = eight waves, one workgroup per CU (a different summation tree: not bit-identical with
+          // the latency shape); 0 = the round-2 form (four waves, one workgroup per CU)
+          static int mode = -1;
+          if (mode < 0) { const char* e = getenv("DRA_CONV2_MODE"); mode = e ? atoi(e) : 2; }
+          if (mode == 2) return launch_conv_v2_persist<G, U8, PTBIG, 4, true>(a, nz, st);
+          if (mode == 1) return launch_conv_v2_persist<G, U8, PTBIG, 8>(a, nz, st);
+        }
+        return launch_conv_v2_persist<G, U8, PTBIG>(a, nz, st);
+      }
     }
     return launch_conv_v2_pt<G, U8, PTBIG>(a, nz, st);
   }
