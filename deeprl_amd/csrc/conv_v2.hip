@@ -634,10 +634,15 @@ struct V2StageWide {
       asm volatile("" : "+v"(v));
       const int idx = tid + NT * i;
       if (idx < TOTAL) {
-        const int e = 4 * idx, c = e / (G::H * G::H), rem = e - c * (G::H * G::H), row = rem / G::H, col = rem - row * G::H;
-        float* dst = img + c * T::CS + row * G::RW + col / 2;
-        *reinterpret_cast<f2*>(dst) = f2{v.x, v.z};
-        *reinterpret_cast<f2*>(dst + G::WPH) = f2{v.y, v.w};
+        if constexpr (G::S == 1) {
+          // stride 1 (conv3): [C][H][RW = H] in LDS IS the sample's layout in memory -- a straight 128-bit copy
+          *reinterpret_cast<f4*>(img + 4 * idx) = v;
+        } else {
+          const int e = 4 * idx, c = e / (G::H * G::H), rem = e - c * (G::H * G::H), row = rem / G::H, col = rem - row * G::H;
+          float* dst = img + c * T::CS + row * G::RW + col / 2;
+          *reinterpret_cast<f2*>(dst) = f2{v.x, v.z};
+          *reinterpret_cast<f2*>(dst + G::WPH) = f2{v.y, v.w};
+        }
       }
     }
   }
@@ -651,8 +656,9 @@ struct V2StageWide {
 // of PT x 16 KB): conv2's 51 KB image + 48 KB of partial sums allowed one workgroup per CU; with 67 KB two fit -- two waves per
 // SIMD issue a 32x32x2 MFMA every 27 ns, one wave only every 39 ns (same sums in the same order: bit-identical results;
 // starting the second workgroup half a group late was tried and loses 3-6 %).  Batch 1024, same box: 45.1 -> 48.9 %.
-template <class G, bool U8, int PT, int NW = 4, bool SEQ = false>
-__global__ void __launch_bounds__(64 * NW) conv_fwd_v2_persist_kernel(const ConvV2Args a, const int n_groups) {
+// WPE: waves per SIMD the register allocation must leave room for (conv3 with SEQ: 37 KB of LDS, three workgroups per CU).
+template <class G, bool U8, int PT, int NW = 4, bool SEQ = false, int WPE = 1>
+__global__ void __launch_bounds__(64 * NW, WPE) conv_fwd_v2_persist_kernel(const ConvV2Args a, const int n_groups) {
   using T = V2Tile<G, PT>;
   using ST = V2Stage<G, T, U8, NW>;
   using KS = typename G::template Split<NW>;
@@ -695,7 +701,9 @@ __global__ void __launch_bounds__(64 * NW) conv_fwd_v2_persist_kernel(const Conv
   int np = min(32 * PT, G::P - p0);
   int oh0 = p0 / G::OH;
   int nrows = ((p0 + np - 1) / G::OH - oh0) * G::S + G::KH;
-  constexpr bool WIDE = !U8 && G::S == 2 && G::H % 4 == 0 && T::NR == G::H && G::WPH % 2 == 0 && T::CS % 2 == 0;
+  constexpr bool WIDE = !U8 && T::NR == G::H &&
+                        ((G::S == 2 && G::H % 4 == 0 && G::WPH % 2 == 0 && T::CS % 2 == 0) ||
+                         (G::S == 1 && G::RW == G::H && T::CS == G::H * G::H && (G::C * G::H * G::H) % 4 == 0));
   using SW = V2StageWide<G, T, 64 * NW>;
   E raw[WIDE ? 1 : ST::N];
   typename SW::f4 raw4[WIDE ? SW::N : 1];
@@ -1156,14 +1164,14 @@ static int conv_b1_waves() {
   return v;
 }
 
-template <class G, bool U8, int PT, int NW = 4, bool SEQ = false>
+template <class G, bool U8, int PT, int NW = 4, bool SEQ = false, int WPE = 1>
 static int launch_conv_v2_persist(const ConvV2Args& a, int nz, hipStream_t st) {
   using T = V2Tile<G, PT>;
   constexpr size_t bytes = ((size_t)G::C * T::CS + (size_t)(SEQ ? 1 : PT) * NW * 16 * 64) * sizeof(float);
   static_assert(bytes <= 159 * 1024, "LDS per workgroup (+1 KB normalisation table)");
   static bool attr_set = false;
   if (bytes > 64 * 1024 && !attr_set) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT, NW, SEQ>),
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT, NW, SEQ, WPE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     attr_set = true;
   }
@@ -1178,7 +1186,7 @@ static int launch_conv_v2_persist(const ConvV2Args& a, int nz, hipStream_t st) {
     else {
       DRA_HIP(hipGetDevice(&dev));
       DRA_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-      DRA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT, NW, SEQ>),
+      DRA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT, NW, SEQ, WPE>),
                                                            64 * NW, bytes));
       resident = (per_cu > 0 ? per_cu : 1) * n_cu;
     }
@@ -1186,7 +1194,7 @@ static int launch_conv_v2_persist(const ConvV2Args& a, int nz, hipStream_t st) {
   const int lanes = (G::OC / 32) * nz;
   const int per = resident / lanes > 0 ? resident / lanes : 1;
   const int nwg = n_groups < per ? n_groups : per;
-  hipLaunchKernelGGL((conv_fwd_v2_persist_kernel<G, U8, PT, NW, SEQ>), dim3(nwg, G::OC / 32, nz), dim3(64 * NW), bytes, st, a, n_groups);
+  hipLaunchKernelGGL((conv_fwd_v2_persist_kernel<G, U8, PT, NW, SEQ, WPE>), dim3(nwg, G::OC / 32, nz), dim3(64 * NW), bytes, st, a, n_groups);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -1205,6 +1213,14 @@ static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
       static int persist = -1;
       if (persist < 0) { const char* e = getenv("DRA_CONV_PERSIST"); persist = e ? atoi(e) : 1; }
       if (persist) {
+        if constexpr (!U8 && G::C == 64) {
+          // conv3: the same one-tile exchange (37 KB of LDS; DRA_CONV3_SEQ=1: three workgroups per CU, 2: two) measured no
+          // different from the plain form (55.1 / 54.3 / 54.5 % at batch 1024): off
+          static int seq3 = -1;
+          if (seq3 < 0) { const char* e = getenv("DRA_CONV3_SEQ"); seq3 = e ? atoi(e) : 0; }
+          if (seq3 == 1) return launch_conv_v2_persist<G, U8, PTBIG, 4, true, 3>(a, nz, st);
+          if (seq3) return launch_conv_v2_persist<G, U8, PTBIG, 4, true>(a, nz, st);
+        }
         if constexpr (!U8 && G::C == 32) {
           // conv2 (51 KB fp32 image per sample).  DRA_CONV2_MODE: 2 (default) = one tile's partial sums at a time, two
           // workgroups per CU; 1 = eight waves, one workgroup per CU (a different summation tree: not bit-identical with

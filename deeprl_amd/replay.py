@@ -70,7 +70,9 @@ class _PinnedUploader:
     device_copy=False hands the KERNEL the pinned buffer itself (pinned host memory is device-addressable: a
     single-workgroup tree kernel reading 32 words over the host link pays ~1.5 us inside the kernel instead of a copy command
     in front of it and ~15 us of host time for the tensor copy -- cProfile of the prioritized agent step,
-    profiles/r02zz1_host_profile_per.txt: the PER pipeline was bound by exactly this host path)."""
+    profiles/r02zz1_host_profile_per.txt: the PER pipeline was bound by exactly this host path).  The kernel that reads the
+    buffer is enqueued AFTER upload() returns, so the slot's reuse guard is recorded by consumed(stream), which the caller
+    invokes right behind that launch; a slot that comes round again without it waits for the whole stream."""
 
     def __init__(self, dtype, numel, device, slots=8):
         self.bufs = [torch.empty(numel, dtype=dtype).pin_memory() for _ in range(slots)]
@@ -79,11 +81,21 @@ class _PinnedUploader:
         self.used = [False] * slots
         self.device = device
         self.k = 0
+        self.unguarded = []          # slots handed to a kernel that has not been enqueued yet
+
+    def consumed(self, stream=None):
+        """The kernel(s) reading the buffers handed out with device_copy=False have been enqueued on `stream`."""
+        for k in self.unguarded:
+            self.events[k].record(stream)
+        self.unguarded = []
 
     def upload(self, array, device_copy=True, stream=None):
         k = self.k
         self.k = (k + 1) % len(self.bufs)
-        if self.used[k]:
+        if k in self.unguarded:      # its reader was never reported: nothing finer than the stream to wait for
+            (stream or torch.cuda.current_stream()).synchronize()
+            self.unguarded.remove(k)
+        elif self.used[k]:
             self.events[k].synchronize()
         n = len(array)
         self.views[k][:n] = array                      # (numpy casts to the buffer's dtype)
@@ -92,7 +104,10 @@ class _PinnedUploader:
             out = out.to(self.device, non_blocking=True)
         if self.events[k] is None:
             self.events[k] = torch.cuda.Event()
-        self.events[k].record(stream)
+        if device_copy:
+            self.events[k].record(stream)
+        else:
+            self.unguarded.append(k)
         self.used[k] = True
         return out
 
@@ -434,6 +449,7 @@ class PrioritizedReplay(UniformReplay):
             # the descent kernel READS its uniforms from pinned host memory and WRITES leaves / priorities / total into pinned
             # host memory: no packing kernels, no copy command -- one event wait is the whole host round trip of a draw
             self.tree.sample_into(self._u_up.upload(u, device_copy=False, stream=stream), oi, op, ot, stream=stream)
+            self._u_up.consumed(stream)
             self._draw_k ^= 1
             ev = self._draw_ev[self._draw_k]
             ev.record(stream)
@@ -581,6 +597,8 @@ class PrioritizedReplay(UniformReplay):
                 self.tree.commit_f32(self._leaf_up.upload(leaves, device_copy=False, stream=stream),
                                      self._pos_up.upload(pos, device_copy=False, stream=stream), prio_f32, self._stat,
                                      force_ordered=self.ordered_updates, stream=stream)
+                self._leaf_up.consumed(stream)
+                self._pos_up.consumed(stream)
             else:
                 self.tree.commit_f32(None, None, prio_f32, self._stat, force_ordered=self.ordered_updates, stream=stream)
 
