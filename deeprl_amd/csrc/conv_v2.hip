@@ -1213,6 +1213,13 @@ static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
       static int persist = -1;
       if (persist < 0) { const char* e = getenv("DRA_CONV_PERSIST"); persist = e ? atoi(e) : 1; }
       if (persist) {
+        if constexpr (G::C == 4) {
+          // conv1: 64 MFMAs per wave and group against ~2.6 us of staging / exchange: with the one-tile exchange (49 KB of LDS)
+          // three workgroups share a CU.  DRA_CONV1_SEQ=0: the round-2 form (two)
+          static int seq1 = -1;
+          if (seq1 < 0) { const char* e = getenv("DRA_CONV1_SEQ"); seq1 = e ? atoi(e) : 1; }
+          if (seq1) return launch_conv_v2_persist<G, U8, PTBIG, 4, true, 3>(a, nz, st);
+        }
         if constexpr (!U8 && G::C == 64) {
           // conv3: the same one-tile exchange (37 KB of LDS; DRA_CONV3_SEQ=1: three workgroups per CU, 2: two) measured no
           // different from the plain form (55.1 / 54.3 / 54.5 % at batch 1024): off
