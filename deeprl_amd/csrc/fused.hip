@@ -11,6 +11,7 @@
 //                          chunk) -- dra_conv_wgrad_slabs() slabs instead of `ksplit`.
 #include "oneshot.h"
 #include "actor_env.h"
+#include "per_chain2.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -214,6 +215,28 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
       return conv_bwd_fused_t<G3, WG3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
   }
   return DRA_EINVAL;
+}
+
+// conv3's backward with the device-side prioritized draw riding along (library-internal, per_chain2.h / actor_env.h): the
+// draw is one workgroup's 16 us latency chain that needs the update's loss vector only; as a third role of this launch
+// (10-11 us of MFMA work on every other CU) it disappears from the update's critical path.  Minibatches up to 256
+// (the role has the launch's 256 threads), one-pass kernels only.
+struct ChainRole {
+  static constexpr int LDS_FLOATS = (per_chain2_lds_bytes<256>() + 3) / 4;
+  PerChain2Args a;
+  __device__ __forceinline__ void run(int, float* lds, int = 0) const { per_chain2_body<256>(a, reinterpret_cast<char*>(lds)); }
+};
+int dra_conv3_bwd_fused_chain(const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
+                              int64_t slab_stride, float* dx, int batch, int act, int variant, const PerChain2Args* chain,
+                              void* stream) {
+  if (!dy || !x || !wt || !dx || !dw || !db || batch < 1 || !chain || chain->nb > 256) return DRA_EINVAL;
+  if (!(variant & DRA_VAR_ONESHOT_WGRAD) || !(variant & DRA_VAR_ONESHOT_DGRAD)) return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  ChainRole r;
+  r.a = *chain;
+  if (wgrad_acc(variant, 3)) return conv_bwd_fused_t<G3, WA3, ChainRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
+  if (wg3_wide()) return conv_bwd_fused_t<G3, WG3b, ChainRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
+  return conv_bwd_fused_t<G3, WG3, ChainRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
 }
 
 // conv1's weight gradient with the uint8 minibatch read straight from the replay ring (library-internal, actor_env.h):

@@ -20,6 +20,7 @@
 //     optimizer kernel is the only section exclusive with the actor's weight reads, and the
 //     actor's ring writes wait for the update's gather.
 #include "actor_env.h"
+#include "per_chain2.h"
 #include <new>
 #include <stddef.h>
 #include <stdlib.h>
@@ -207,6 +208,8 @@ struct dra_dqn_learner {
   hipEvent_t split_opt_prev;
   bool split_seed, split_open;
   bool per2_active;                 // capturing the one-graph prioritized update: weights precomputed, priorities by the chain kernel
+  bool per2_ride;                   // ... and the chain kernel rides in conv3's backward launch (per2_args) instead of its own
+  PerChain2Args per2_args;
   hipEvent_t ev_per_fork, ev_per_join;   // capture-time fork / join of the chain kernel's branch
   unsigned* aflags;                 // DRA_VAR_ACTOR_MEGA: [kMaxEnvSteps][4] arrival counters of the one-launch env steps (zeroed by
                                     // the agent step's tail kernel)
@@ -1250,6 +1253,10 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       STEP(K_FC4_BX, dra_fc_bwd_fused_sq(l->dq, l->h4, l->dh4, l->y3[0], P + o[P_W4], G + o[P_WH], G + o[P_BH], G + o[P_W4],
                                          G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, l->partials, &nfc, s));
       if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV3_BW], st));
+      if (l->per2_active && l->per2_ride)
+        STEP(K_CONV3_BX, dra_conv3_bwd_fused_chain(l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], l->dy2, B,
+                                                   DRA_ACT_RELU, var, &l->per2_args, s));
+      else
       STEP(K_CONV3_BX, dra_conv_bwd_fused(3, l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], c.ksplit,
                                           l->dy2, B, 0, 1.0, DRA_ACT_RELU, var, s));
       if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV2_BW], st));
@@ -1267,6 +1274,10 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     STEP(K_FC4_BX, dra_fc_bwd_fused(l->dq, l->h4, l->dh4, l->y3[0], P + o[P_W4], G + o[P_WH], G + o[P_BH], G + o[P_W4],
                                     G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, s));
     if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV3_BW], st));
+    if (l->per2_active && l->per2_ride)
+      STEP(K_CONV3_BX, dra_conv3_bwd_fused_chain(l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], l->dy2, B,
+                                                 DRA_ACT_RELU, var, &l->per2_args, s));
+    else
     STEP(K_CONV3_BX, dra_conv_bwd_fused(3, l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], c.ksplit,
                                         l->dy2, B, 0, 1.0, DRA_ACT_RELU, var, s));
     if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV2_BW], st));
@@ -1407,12 +1418,23 @@ static int capture_per2(dra_dqn_learner* l, hipStream_t st, int q, bool rd, hipG
     rc = (int)hipEventRecord(l->ev_per_fork, st);
     if (rc == DRA_OK) rc = (int)hipStreamWaitEvent(sd, l->ev_per_fork, 0);
   }
-  if (rc == DRA_OK)
+  // DRA_PER_RIDE (default 1): the draw as a role of conv3's backward launch (minibatches up to 256, the one-pass backward);
+  // 0: its own launch between the loss and the backward pass
+  static int ride = -1;
+  if (ride < 0) { const char* e = getenv("DRA_PER_RIDE"); ride = e ? atoi(e) : 1; }
+  const int both = DRA_VAR_ONESHOT_WGRAD | DRA_VAR_ONESHOT_DGRAD;
+  l->per2_ride = ride && !fork && l->c.batch <= 256 && (l->variant & both) == both;
+  if (rc == DRA_OK && l->per2_ride)
+    rc = dra_sumtree_per_chain2_args(l->per_tree, l->per2_io[q & 3], l->delta, l->c.replay_eps, l->c.replay_alpha, l->prio,
+                                     l->per_stat, l->per2_dev, l->per2_words, l->per2_idx + (size_t)((q + 1) & 3) * 1024,
+                                     l->samp_prob, l->weights, l->c.batch, &l->per2_args);
+  else if (rc == DRA_OK)
     rc = dra_sumtree_per_chain2(l->per_tree, l->per2_io[q & 3], l->delta, l->c.replay_eps, l->c.replay_alpha, l->prio, l->per_stat,
                                 l->per2_dev, l->per2_words, l->per2_idx + (size_t)((q + 1) & 3) * 1024, l->samp_prob, l->weights,
                                 l->c.batch, (void*)sd);
   if (rc == DRA_OK) rc = run_body(l, st, 1, -1.f, 0, 2);
   l->per2_active = false;
+  l->per2_ride = false;
   if (rc == DRA_OK) rc = launch_optimizer(l, st, l->pa[q]);
   if (rc == DRA_OK && fork) {
     rc = (int)hipEventRecord(l->ev_per_join, sd);

@@ -15,6 +15,7 @@
 // pending_idx gating, first-writer-wins de-duplication and max_priority live on the host
 // mirror (deeprl_amd/component/replay.py), which passes only the effective updates.
 #include "common.h"
+#include "per_chain2.h"
 #include <new>
 
 struct dra_sumtree {
@@ -479,333 +480,24 @@ DRA_API int dra_sumtree_per_chain(dra_sumtree* t, dra_per_chain_io* io_pinned, c
 }
 
 // ---- second form: PrioritizedReplay.sample() entirely on the device (include/deeprl_amd.h dra_per_chain2_io) --------------
-// With the first form the host still sat between an update's priorities and the next update: sync on the loss event,
-// validity check, gating, sampling probabilities, indices -> 84 us of host work per step inside the loop, 4.7 k updates/s
-// against 8.6 k with uniform replay (tools/diag_per_host.py, profiles/r03h).  Here the kernel does all of it and hands the
-// next minibatch to the next update through device memory; the host only generates raw Mersenne-Twister words ahead and
-// reads the pinned block one step late (bookkeeping, actor / update hazard check).
-struct PerChain2Dev {
-  unsigned long long rng_cursor;       // words of the ring consumed so far
-  unsigned long long seq;              // launches completed
-  int64_t tidx[DRA_PER_CHAIN_MAX];     // leaves of the minibatch the NEXT commit belongs to
-};
-
-// Stores to the pinned block: system-scope RELAXED atomics (write-through, sc0 sc1) + an explicit wait for their
-// acknowledgement.  NOT __threadfence_system() / a system-scope release: on gfx950 those are `buffer_wbl2 sc0 sc1` +
-// `buffer_inv sc0 sc1` -- the whole L2 written back and invalidated in the middle of the update (the first form of this
-// kernel took 41-66 us that way and slowed the backward pass behind it: profiles/r03h_timeline_per_chain2*.txt).
-template <class T> __device__ __forceinline__ void st_sys(T* p, T v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ void stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// Latency is what this kernel costs (it sits between the loss and the backward pass of every prioritized update): 41 us in its
-// first form (three level-by-level walks through L2, 13 header reads and the uniforms over PCIe one after the other:
-// profiles/r03h_timeline_per_chain2.txt).  Now:
-//   * header (9 quadwords) and uniforms (2 words per lane) are read by parallel lanes up front: one PCIe round trip;
-//   * commits and adds are delta propagation with f64 atomics, all ancestors of all leaves in flight together (exact
-//     whenever the parallel commit is: `ordered` below; otherwise the level-by-level walks through memory remain).  A climb
-//     in registers / LDS with pairwise exchange where two paths meet was tried first: 1.3 us per level, 25 us;
-//   * the descent reads the top 11 levels from an LDS copy.
-#ifdef DRA_TRACE
-// measurement build: thread 0 leaves s_memrealtime stamps (100 MHz) in the unused tail of out_raw_idx (tools/diag_chain2.py)
-#define CHAIN2_STAMP(k)                                                                              \
-  do {                                                                                               \
-    if (threadIdx.x == 0) {                                                                          \
-      unsigned long long t_;                                                                         \
-      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");             \
-      st_sys(&io->out_raw_idx[DRA_PER_CHAIN_MAX - 16 + (k)], (int64_t)t_);                           \
-    }                                                                                                \
-  } while (0)
-#else
-#define CHAIN2_STAMP(k) ((void)0)
-#endif
-constexpr int kTopNodes = 2047;
-
-
-// smallest j < n with arr[j] == key, or -1.  arr: 16-byte aligned LDS, readable up to the next multiple of 8 entries.  Eight
-// entries per trip as four 128-bit reads in flight together: a one-entry-per-trip loop pays a full LDS round trip per entry
-// (2.5 us per tree level for 36 entries: tools/diag_chain2.py on the first form of the climb).
-__device__ __forceinline__ int lds_find(const int64_t* arr, int n, int64_t key) {
-  typedef long long ll2 __attribute__((ext_vector_type(2)));
-  int fj = -1;
-  for (int j0 = 0; j0 < n; j0 += 8) {
-    const ll2* q = reinterpret_cast<const ll2*>(arr + j0);
-    const ll2 a = q[0], b = q[1], c = q[2], d = q[3];
-    int m = -1;
-    m = (d.y == key && j0 + 7 < n) ? j0 + 7 : m;
-    m = (d.x == key && j0 + 6 < n) ? j0 + 6 : m;
-    m = (c.y == key && j0 + 5 < n) ? j0 + 5 : m;
-    m = (c.x == key && j0 + 4 < n) ? j0 + 4 : m;
-    m = (b.y == key && j0 + 3 < n) ? j0 + 3 : m;
-    m = (b.x == key && j0 + 2 < n) ? j0 + 2 : m;
-    m = (a.y == key && j0 + 1 < n) ? j0 + 1 : m;
-    m = (a.x == key) ? j0 : m;
-    fj = (fj < 0) ? m : fj;
-  }
-  return fj;
+// The body lives in per_chain2.h (it also rides in the update's conv3 backward launch as a role: fused.hip ChainRole).
+__global__ void __launch_bounds__(1024) sumtree_per_chain2_kernel(const PerChain2Args a) {
+  __shared__ __attribute__((aligned(16))) char smem[per_chain2_lds_bytes<1024>()];
+  per_chain2_body<1024>(a, smem);
 }
 
-__global__ void __launch_bounds__(1024)
-sumtree_per_chain2_kernel(double* __restrict__ tree, int levels, int64_t capacity, int64_t n_nodes, dra_per_chain2_io* __restrict__ io,
-                          const float* __restrict__ loss_vec, float eps, float alpha, float* __restrict__ prio_out,
-                          double* __restrict__ stat, PerChain2Dev* __restrict__ dev, const uint32_t* __restrict__ words,
-                          int64_t* __restrict__ idx_out, float* __restrict__ samp_prob, float* __restrict__ weights_out, int nb) {
-  __shared__ double s_hi[16], s_lo[16];
-  __shared__ float s_wmax[16];
-  __shared__ unsigned long long s_head[9];
-  __shared__ int s_ordered, s_all_valid, s_nvalid, s_flags;
-  __shared__ double s_max;
-  __shared__ unsigned long long s_cursor;
-  __shared__ __attribute__((aligned(16))) int64_t s_idx[DRA_PER_CHAIN_MAX + 8];
-  __shared__ double s_p[DRA_PER_CHAIN_MAX];
-  __shared__ __attribute__((aligned(16))) double s_top[kTopNodes + 1];
-  __shared__ unsigned char s_first[DRA_PER_CHAIN_MAX];
-  const int tid = threadIdx.x;
-  CHAIN2_STAMP(0);
-  // ---- everything that crosses PCIe, at once
-  const unsigned long long cur0 = dev->rng_cursor;
-  uint32_t w0 = 0, w1 = 0;
-  if (tid < nb) {
-    w0 = words[(cur0 + 2ull * tid) & (DRA_PER_RNG_WORDS - 1)];
-    w1 = words[(cur0 + 2ull * tid + 1) & (DRA_PER_RNG_WORDS - 1)];
-  }
-  if (tid < 9) s_head[tid] = reinterpret_cast<const unsigned long long*>(io)[tid];
-  if (tid == 0) { s_all_valid = 1; s_flags = 0; }
-  const int batch = nb;            // (the learner's batch size: every update commits and draws `nb` transitions)
-  // ---- commit: {max, min} over every offered priority; a leaf is written by its FIRST occurrence in the minibatch
-  // (DQN_agent.py:121-123: priorities = |loss| + eps to the power alpha, from the PRE-weight loss vector; float arithmetic
-  // exactly as losses.hip's td_loss_kernel / per_kernel)
-  double hi = -INFINITY, lo = INFINITY;
-  float prio_f = 0.f;
-  if (tid < batch) {
-    const float ad = fabsf(loss_vec[tid]) + eps;
-    prio_f = (alpha == 0.5f) ? sqrtf(ad) : powf(ad, alpha);
-    prio_out[tid] = prio_f;
-    const double v = (double)prio_f;
-    hi = v;
-    lo = v;
-    s_idx[tid] = dev->tidx[tid];
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    hi = fmax(hi, __shfl_xor(hi, off));
-    lo = fmin(lo, __shfl_xor(lo, off));
-  }
-  if ((tid & 63) == 0) { s_hi[tid >> 6] = hi; s_lo[tid >> 6] = lo; }
-  __syncthreads();
-  CHAIN2_STAMP(1);
-  const int add_n = (int)(s_head[0] & 0xffffffffull);
-  const int force = (int)(s_head[1] >> 32);
-  const int hist = (int)(s_head[2] & 0xffffffffull), nstep = (int)(s_head[2] >> 32);
-  const int64_t write0 = (int64_t)s_head[3], mem = (int64_t)s_head[4], pos = (int64_t)s_head[5], size = (int64_t)s_head[6];
-  const unsigned long long produced = s_head[7];
-  if (tid < batch) s_first[tid] = lds_find(s_idx, batch, s_idx[tid]) == tid;
-  if (tid == 0) {
-    const int nw = (int)(blockDim.x >> 6);
-    for (int w = 1; w < nw; ++w) { hi = fmax(hi, s_hi[w]); lo = fmin(lo, s_lo[w]); }
-    hi = fmax(hi, stat[0]);
-    lo = fmin(lo, stat[1]);
-    stat[0] = hi;
-    stat[1] = lo;
-    s_max = hi;
-    int ordered = force;
-    if (!(lo > 0.0) || !(hi < INFINITY)) ordered = 1;
-    else if ((double)capacity * hi > ldexp(1.0, 53 + ilogb(lo) - 23)) ordered = 1;
-    s_ordered = ordered;
-  }
-  __syncthreads();
-  CHAIN2_STAMP(2);
-  const int n_items = batch + add_n;
-  if (!s_ordered && n_items <= DRA_PER_CHAIN_MAX) {
-    // ---- commits and adds as the reference does them -- tree[ancestor] += (new - old) (sum_tree.py:46-60) -- but all at once:
-    // one lane per written leaf, one fire-and-forget f64 atomic per ancestor.  `ordered == 0` means every priority is a
-    // multiple of one quantum and the total stays below 2^53 quanta: every partial sum is exact, so the additions commute
-    // BIT FOR BIT and the result equals the sequential walk's.  (An add on a leaf this minibatch also commits: the add's
-    // value stands, as in the reference's order.)  One memory round trip instead of a level-by-level climb (25 us).
-    int64_t node = -1;
-    double val = 0.0;
-    if (tid < batch) {
-      if (s_first[tid]) { node = s_idx[tid]; val = (double)prio_f; }
-    } else if (tid < n_items) {
-      node = (write0 + (tid - batch)) % capacity + capacity - 1;
-      val = s_max;
-    }
-    int64_t* s_add = reinterpret_cast<int64_t*>(s_top);   // (the tree's top is staged later)
-    if (tid >= batch && tid < n_items) s_add[tid - batch] = node;
-    __syncthreads();
-    if (tid < batch && node >= 0 && lds_find(s_add, add_n, node) >= 0) node = -1;
-    if (node >= 0) {
-      const double delta = __dsub_rn(val, node_load(tree + node));
-      node_store(tree + node, val);
-      for (int64_t n = node; n > 0;) {
-        n = (n - 1) >> 1;
-        unsafeAtomicAdd(tree + n, delta);
-      }
-    }
-    CHAIN2_STAMP(3);
-  } else {
-    if (s_ordered) {
-      if (tid == 0) {
-        for (int k = 0; k < batch; ++k) {
-          if (!s_first[k]) continue;
-          int64_t node = s_idx[k];
-          const double p = (double)prio_out[k];
-          const double change = __dsub_rn(p, node_load(tree + node));
-          node_store(tree + node, p);
-          while (node > 0) {
-            node = (node - 1) >> 1;
-            node_store(tree + node, __dadd_rn(node_load(tree + node), change));
-          }
-        }
-      }
-      __threadfence_block();
-    } else {
-      int64_t node = -1;
-      if (tid < batch && s_first[tid]) {
-        node = s_idx[tid];
-        node_store(tree + node, (double)prio_f);
-      }
-      for (int lv = 0; lv < levels; ++lv) {
-        __syncthreads();
-        if (node > 0) {
-          const int64_t parent = (node - 1) >> 1;
-          const double s = __dadd_rn(node_load(tree + 2 * parent + 1), node_load(tree + 2 * parent + 2));
-          node_store(tree + parent, s);
-          node = parent;
-        }
-      }
-    }
-    __syncthreads();
-    // adds of the next agent step's transitions at max_priority
-    int64_t node = -1;
-    if (tid < add_n) {
-      node = (write0 + tid) % capacity + capacity - 1;
-      node_store(tree + node, s_max);
-    }
-    for (int lv = 0; lv < levels; ++lv) {
-      __syncthreads();
-      if (node > 0) {
-        const int64_t parent = (node - 1) >> 1;
-        const double s = __dadd_rn(node_load(tree + 2 * parent + 1), node_load(tree + 2 * parent + 2));
-        node_store(tree + parent, s);
-        node = parent;
-      }
-    }
-  }
-  __syncthreads();
-  CHAIN2_STAMP(4);
-  // ---- stratified descent of the next draw; the top of the tree from LDS
-  const int n_top = (int)(n_nodes < (int64_t)kTopNodes ? n_nodes : (int64_t)kTopNodes);
-  for (int i = tid; i < n_top; i += blockDim.x) s_top[i] = node_load(tree + i);
-  __syncthreads();
-  CHAIN2_STAMP(5);
-  const double total = s_top[0];
-  const bool dry = cur0 + 2ull * (unsigned long long)nb > produced;
-  if (tid < nb) {
-    double u = 0.0;
-    if (!dry) u = ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) * (1.0 / 9007199254740992.0);
-    const double seg = __ddiv_rn(total, (double)nb);
-    const double a = __dmul_rn(seg, (double)tid);
-    const double b = __dmul_rn(seg, (double)(tid + 1));
-    double s = __dadd_rn(a, __dmul_rn(__dsub_rn(b, a), u));
-    int64_t idx = 0;
-    while (true) {
-      const int64_t left = 2 * idx + 1;
-      if (left >= n_nodes) break;
-      const double lv = left < n_top ? s_top[left] : node_load(tree + left);
-      if (s <= lv) idx = left;
-      else { idx = left + 1; s = __dsub_rn(s, lv); }
-    }
-    s_idx[tid] = idx;
-    s_p[tid] = idx < n_top ? s_top[idx] : node_load(tree + idx);
-    st_sys(&io->out_raw_idx[tid], idx);
-    // replay.py:122-127
-    const int64_t di = idx - (mem - 1), flo = di - hist + 1, fhi = di + nstep;
-    const bool valid = (flo >= 0 && fhi < pos) || (flo >= pos && fhi < size);
-    s_first[tid] = valid;
-    if (!valid) s_all_valid = 0;
-  }
-  __syncthreads();
-  CHAIN2_STAMP(6);
-  if (tid == 0) {
-    unsigned long long cur = cur0 + 2ull * (unsigned long long)nb;
-    int flags = dry ? 1 : 0;
-    int n = nb;
-    if (!s_all_valid) {
-      // the rare path: drop the invalid draws (order kept), then random.choice over what has been picked so far
-      n = 0;
-      for (int i = 0; i < nb; ++i)
-        if (s_first[i]) { s_idx[n] = s_idx[i]; s_p[n] = s_p[i]; ++n; }
-      s_nvalid = n;
-      if (n == 0) flags |= 2;
-      while (n > 0 && n < nb) {
-        const int k = 32 - __clz(n);                 // n.bit_length()
-        uint32_t r;
-        do {
-          if (cur >= produced) { flags |= 1; r = 0; break; }
-          r = words[cur & (DRA_PER_RNG_WORDS - 1)] >> (32 - k);
-          ++cur;
-        } while (r >= (uint32_t)n);
-        s_idx[n] = s_idx[r];
-        s_p[n] = s_p[r];
-        ++n;
-      }
-      for (; n < nb; ++n) { s_idx[n] = mem - 1 + hist; s_p[n] = 0.0; }   // flags & 2: keep the indices in range
-    } else {
-      s_nvalid = nb;
-    }
-    s_cursor = cur;
-    s_flags = flags;
-  }
-  __syncthreads();
-  CHAIN2_STAMP(7);
-  // ---- hand-over: the next update reads idx_out / samp_prob / weights_out, the next launch of this kernel reads dev->tidx
-  float beta;
-  {
-    const unsigned lo32 = (unsigned)(s_head[8] & 0xffffffffull);
-    __builtin_memcpy(&beta, &lo32, sizeof(beta));
-  }
-  // DQN_agent.py:124-126, as per_kernel: weights = (P * B + 1e-6)^-beta / their max
-  float wraw = -INFINITY, spf = 0.f;
-  if (tid < nb) {
-    spf = (float)__ddiv_rn(s_p[tid], total);
-    wraw = powf(spf * (float)nb + 1e-6f, -beta);
-  }
-  {
-    const float wm = wave_max(wraw);
-    if ((tid & 63) == 0) s_wmax[tid >> 6] = wm;
-  }
-  __syncthreads();
-  if (tid < nb) {
-    float wmax = s_wmax[0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) wmax = fmaxf(wmax, s_wmax[w]);
-    weights_out[tid] = wraw / wmax;
-    const int64_t leaf = s_idx[tid];
-    const double p = s_p[tid];
-    dev->tidx[tid] = leaf;
-    idx_out[tid] = leaf - (mem - 1);
-    samp_prob[tid] = spf;
-    st_sys(&io->out_idx[tid], leaf);
-    st_sys(&io->out_p[tid], p);
-    stores_acknowledged();
-  }
-  if (tid == 0) {
-    samp_prob[nb] = beta;
-    dev->rng_cursor = s_cursor;
-    st_sys(&io->out_total, total);
-    st_sys(&io->out_n_valid, (int32_t)s_nvalid);
-    st_sys(&io->out_flags, (int32_t)s_flags);
-    st_sys(&io->out_rng_cursor, (uint64_t)s_cursor);
-    stores_acknowledged();
-  }
-  __syncthreads();
-  CHAIN2_STAMP(8);
-  if (tid == 0) {
-    const unsigned long long seq = dev->seq + 1;
-    dev->seq = seq;
-    st_sys(&io->out_seq, (uint64_t)seq);
-  }
+int dra_sumtree_per_chain2_args(dra_sumtree* t, dra_per_chain2_io* io_pinned, const float* loss_vec_dev, float replay_eps,
+                                float replay_alpha, float* prio_out_dev, double* stat_dev, void* dev_state,
+                                const uint32_t* rng_words_pinned, int64_t* idx_out_dev, float* samp_prob_dev,
+                                float* weights_out_dev, int batch, PerChain2Args* out) {
+  if (!t || !io_pinned || !loss_vec_dev || !prio_out_dev || !stat_dev || !dev_state || !rng_words_pinned || !idx_out_dev ||
+      !samp_prob_dev || !weights_out_dev || batch < 1 || batch > DRA_PER_CHAIN_MAX || !out)
+    return DRA_EINVAL;
+  out->tree = t->tree; out->levels = t->levels; out->nb = batch; out->capacity = t->capacity; out->n_nodes = t->n_nodes;
+  out->io = io_pinned; out->loss_vec = loss_vec_dev; out->eps = replay_eps; out->alpha = replay_alpha; out->prio_out = prio_out_dev;
+  out->stat = stat_dev; out->dev = reinterpret_cast<PerChain2Dev*>(dev_state); out->words = rng_words_pinned;
+  out->idx_out = idx_out_dev; out->samp_prob = samp_prob_dev; out->weights_out = weights_out_dev;
+  return DRA_OK;
 }
 
 DRA_API int dra_sumtree_per_chain2_state_bytes(int64_t* bytes) {
@@ -829,12 +521,11 @@ DRA_API int dra_sumtree_per_chain2(dra_sumtree* t, dra_per_chain2_io* io_pinned,
                                    float replay_alpha, float* prio_out_dev, double* stat_dev, void* dev_state,
                                    const uint32_t* rng_words_pinned, int64_t* idx_out_dev, float* samp_prob_dev,
                                    float* weights_out_dev, int batch, void* stream) {
-  if (!t || !io_pinned || !loss_vec_dev || !prio_out_dev || !stat_dev || !dev_state || !rng_words_pinned || !idx_out_dev ||
-      !samp_prob_dev || !weights_out_dev || batch < 1 || batch > DRA_PER_CHAIN_MAX)
-    return DRA_EINVAL;
-  hipLaunchKernelGGL(sumtree_per_chain2_kernel, dim3(1), dim3(1024), 0, dra_stream(stream), t->tree, t->levels, t->capacity,
-                     t->n_nodes, io_pinned, loss_vec_dev, replay_eps, replay_alpha, prio_out_dev, stat_dev,
-                     reinterpret_cast<PerChain2Dev*>(dev_state), rng_words_pinned, idx_out_dev, samp_prob_dev, weights_out_dev, batch);
+  PerChain2Args a;
+  const int rc = dra_sumtree_per_chain2_args(t, io_pinned, loss_vec_dev, replay_eps, replay_alpha, prio_out_dev, stat_dev, dev_state,
+                                             rng_words_pinned, idx_out_dev, samp_prob_dev, weights_out_dev, batch, &a);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sumtree_per_chain2_kernel, dim3(1), dim3(1024), 0, dra_stream(stream), a);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
