@@ -140,10 +140,10 @@ int dra_conv_bwd_fused_fold(int layer, const float* dy, const void* x, const flo
 struct PerChain2Args;
 int dra_conv3_bwd_fused_chain(const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
                               int64_t slab_stride, float* dx, int batch, int act, int variant, const PerChain2Args* chain,
-                              void* stream);
+                              int first_half_only, void* stream);
 int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, float* dw_slabs, float* db_slabs, int64_t slab_stride,
                          int batch, double u8_coef, int variant, const dra_fold_seg* fold, float* grad, double* fold_partials,
-                         int* n_fold_partials, double* reset_slots, int n_reset, void* stream);
+                         int* n_fold_partials, double* reset_slots, int n_reset, const PerChain2Args* chain, void* stream);
 
 // conv_v2.hip (library-internal), DRA_VAR_ACTOR_MEGA: one env step of the ring actor as ONE launch (conv1 with the fused head /
 // environment step, conv2, conv3, fc4 handing over through three arrival counters `flags`, zero at launch)

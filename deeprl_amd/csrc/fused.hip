@@ -221,22 +221,31 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
 // draw is one workgroup's 16 us latency chain that needs the update's loss vector only; as a third role of this launch
 // (10-11 us of MFMA work on every other CU) it disappears from the update's critical path.  Minibatches up to 256
 // (the role has the launch's 256 threads), one-pass kernels only.
+// PART 0: the whole draw here.  PART 1: its first half (priorities -> tree, adds); the second half (descent, filter, hand-over)
+// then rides in conv1's weight-gradient launch (dra_conv1_wgrad_fold): each half is shorter than the launch carrying it.
+template <int PART>
 struct ChainRole {
   static constexpr int LDS_FLOATS = (per_chain2_lds_bytes<256>() + 3) / 4;
   PerChain2Args a;
-  __device__ __forceinline__ void run(int, float* lds, int = 0) const { per_chain2_body<256>(a, reinterpret_cast<char*>(lds)); }
+  __device__ __forceinline__ void run(int, float* lds, int = 0) const { per_chain2_body<256, PART>(a, reinterpret_cast<char*>(lds)); }
 };
+template <int PART>
+static int conv3_bwd_chain_t(const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
+                             int64_t slab_stride, float* dx, int batch, int act, int variant, const PerChain2Args* chain, hipStream_t st) {
+  ChainRole<PART> r;
+  r.a = *chain;
+  if (wgrad_acc(variant, 3)) return conv_bwd_fused_t<G3, WA3, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
+  if (wg3_wide()) return conv_bwd_fused_t<G3, WG3b, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
+  return conv_bwd_fused_t<G3, WG3, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
+}
 int dra_conv3_bwd_fused_chain(const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
                               int64_t slab_stride, float* dx, int batch, int act, int variant, const PerChain2Args* chain,
-                              void* stream) {
+                              int first_half_only, void* stream) {
   if (!dy || !x || !wt || !dx || !dw || !db || batch < 1 || !chain || chain->nb > 256) return DRA_EINVAL;
   if (!(variant & DRA_VAR_ONESHOT_WGRAD) || !(variant & DRA_VAR_ONESHOT_DGRAD)) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
-  ChainRole r;
-  r.a = *chain;
-  if (wgrad_acc(variant, 3)) return conv_bwd_fused_t<G3, WA3, ChainRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
-  if (wg3_wide()) return conv_bwd_fused_t<G3, WG3b, ChainRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
-  return conv_bwd_fused_t<G3, WG3, ChainRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
+  if (first_half_only) return conv3_bwd_chain_t<1>(dy, x, wt, xact, dw, db, slab_stride, dx, batch, act, variant, chain, st);
+  return conv3_bwd_chain_t<0>(dy, x, wt, xact, dw, db, slab_stride, dx, batch, act, variant, chain, st);
 }
 
 // conv1's weight gradient with the uint8 minibatch read straight from the replay ring (library-internal, actor_env.h):
@@ -297,12 +306,25 @@ int dra_conv_bwd_fused_fold(int layer, const float* dy, const void* x, const flo
 // through the sampled slots) with a FoldRole riding along
 int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, float* dw_slabs, float* db_slabs, int64_t slab_stride,
                          int batch, double u8_coef, int variant, const dra_fold_seg* fold, float* grad, double* fold_partials,
-                         int* n_fold_partials, double* reset_slots, int n_reset, void* stream) {
+                         int* n_fold_partials, double* reset_slots, int n_reset, const PerChain2Args* chain, void* stream) {
   if (!dy || !x || !dw_slabs || !db_slabs || batch < 1 || !(variant & DRA_VAR_ONESHOT_WGRAD) || !n_fold_partials ||
       !fold_ok(fold, grad, fold_partials))
     return DRA_EINVAL;
   const FoldRole f = make_fold_role(fold, grad, fold_partials, reset_slots, n_reset);
   *n_fold_partials = f.blocks();
+  if (chain) {     // the second half of the device-side prioritized draw as third role (see ChainRole)
+    if (chain->nb > 256) return DRA_EINVAL;
+    ChainRole<2> cr;
+    cr.a = *chain;
+    if (wgrad_acc(variant, 1)) {
+      auto ra = make_wgrad_one<WA1u>(dy, x, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
+      ra.sample_idx = idx;
+      return launch_multi(ra, ra.blocks(), f, f.blocks(), cr, 1, dra_stream(stream));
+    }
+    auto rw = make_wgrad_one<WG1u>(dy, x, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
+    rw.sample_idx = idx;
+    return launch_multi(rw, rw.blocks(), f, f.blocks(), cr, 1, dra_stream(stream));
+  }
   NoRole none;
   if (wgrad_acc(variant, 1)) {
     auto ra = make_wgrad_one<WA1u>(dy, x, dw_slabs, db_slabs, slab_stride, batch, u8_coef);

@@ -209,6 +209,7 @@ struct dra_dqn_learner {
   bool split_seed, split_open;
   bool per2_active;                 // capturing the one-graph prioritized update: weights precomputed, priorities by the chain kernel
   bool per2_ride;                   // ... and the chain kernel rides in conv3's backward launch (per2_args) instead of its own
+  bool per2_split;                  // ... its second half in conv1's weight-gradient launch (late-fold backward only)
   PerChain2Args per2_args;
   hipEvent_t ev_per_fork, ev_per_join;   // capture-time fork / join of the chain kernel's branch
   unsigned* aflags;                 // DRA_VAR_ACTOR_MEGA: [kMaxEnvSteps][4] arrival counters of the one-launch env steps (zeroed by
@@ -1255,7 +1256,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV3_BW], st));
       if (l->per2_active && l->per2_ride)
         STEP(K_CONV3_BX, dra_conv3_bwd_fused_chain(l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], l->dy2, B,
-                                                   DRA_ACT_RELU, var, &l->per2_args, s));
+                                                   DRA_ACT_RELU, var, &l->per2_args, l->per2_split ? 1 : 0, s));
       else
       STEP(K_CONV3_BX, dra_conv_bwd_fused(3, l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], c.ksplit,
                                           l->dy2, B, 0, 1.0, DRA_ACT_RELU, var, s));
@@ -1265,7 +1266,8 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       // (the fold riding in conv1's launch also resets the arrival slots of the optimizer launch that follows)
       STEP(K_CONV1_BW, dra_conv1_wgrad_fold(l->dy1, rd ? ring_frames : (const void*)l->state_[l->gb], rd ? l->idx : nullptr, dw[0],
                                             dbs[0], stride[0], B, c.u8_coef, var, &segs[1], G, l->partials + nfc + n3, &n2,
-                                            l->partials + nfc_expect + n3_expect + n2_expect, l->late_nfold, s));
+                                            l->partials + nfc_expect + n3_expect + n2_expect, l->late_nfold,
+                                            (l->per2_active && l->per2_ride && l->per2_split) ? &l->per2_args : nullptr, s));
       if (nfc != nfc_expect || n3 != n3_expect || n2 != n2_expect) return DRA_EINVAL;
       l->late_nprior = nfc + n3 + n2;
       if (l->profiling) { DRA_HIP(hipEventRecord(l->ev[K_NORM], st)); DRA_HIP(hipEventRecord(l->ev[K_STEP], st)); }
@@ -1276,7 +1278,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV3_BW], st));
     if (l->per2_active && l->per2_ride)
       STEP(K_CONV3_BX, dra_conv3_bwd_fused_chain(l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], l->dy2, B,
-                                                 DRA_ACT_RELU, var, &l->per2_args, s));
+                                                 DRA_ACT_RELU, var, &l->per2_args, 0, s));
     else
     STEP(K_CONV3_BX, dra_conv_bwd_fused(3, l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], c.ksplit,
                                         l->dy2, B, 0, 1.0, DRA_ACT_RELU, var, s));
@@ -1418,12 +1420,15 @@ static int capture_per2(dra_dqn_learner* l, hipStream_t st, int q, bool rd, hipG
     rc = (int)hipEventRecord(l->ev_per_fork, st);
     if (rc == DRA_OK) rc = (int)hipStreamWaitEvent(sd, l->ev_per_fork, 0);
   }
-  // DRA_PER_RIDE (default 1): the draw as a role of conv3's backward launch (minibatches up to 256, the one-pass backward);
-  // 0: its own launch between the loss and the backward pass
+  // DRA_PER_RIDE: 2 (default) = the draw as riding roles of two backward launches -- priorities / commits / adds in conv3's,
+  // descent / filter / hand-over in conv1's weight gradient (late-fold backward) --, 1 = whole in conv3's (27 instead of 12 us
+  // for that launch: profiles/r03i_timeline_per_ride.txt), 0 = its own launch between the loss and the backward pass.
+  // Minibatches up to 256 (a role has the launch's 256 threads), one-pass backward kernels.
   static int ride = -1;
-  if (ride < 0) { const char* e = getenv("DRA_PER_RIDE"); ride = e ? atoi(e) : 1; }
+  if (ride < 0) { const char* e = getenv("DRA_PER_RIDE"); ride = e ? atoi(e) : 2; }
   const int both = DRA_VAR_ONESHOT_WGRAD | DRA_VAR_ONESHOT_DGRAD;
   l->per2_ride = ride && !fork && l->c.batch <= 256 && (l->variant & both) == both;
+  l->per2_split = l->per2_ride && ride == 2 && l->late;
   if (rc == DRA_OK && l->per2_ride)
     rc = dra_sumtree_per_chain2_args(l->per_tree, l->per2_io[q & 3], l->delta, l->c.replay_eps, l->c.replay_alpha, l->prio,
                                      l->per_stat, l->per2_dev, l->per2_words, l->per2_idx + (size_t)((q + 1) & 3) * 1024,
@@ -1434,7 +1439,7 @@ static int capture_per2(dra_dqn_learner* l, hipStream_t st, int q, bool rd, hipG
                                 l->c.batch, (void*)sd);
   if (rc == DRA_OK) rc = run_body(l, st, 1, -1.f, 0, 2);
   l->per2_active = false;
-  l->per2_ride = false;
+  l->per2_ride = l->per2_split = false;
   if (rc == DRA_OK) rc = launch_optimizer(l, st, l->pa[q]);
   if (rc == DRA_OK && fork) {
     rc = (int)hipEventRecord(l->ev_per_join, sd);

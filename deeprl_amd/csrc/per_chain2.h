@@ -15,6 +15,9 @@ struct PerChain2Dev {
   unsigned long long rng_cursor;       // words of the ring consumed so far
   unsigned long long seq;              // launches completed
   int64_t tidx[DRA_PER_CHAIN_MAX];     // leaves of the minibatch the NEXT commit belongs to
+  // the launch in two halves (PART 1 / 2 below): what the first half read over PCIe, for the second
+  unsigned long long head[9];
+  uint32_t w[2 * DRA_PER_CHAIN_MAX];
 };
 
 // Stores to the pinned block: system-scope RELAXED atomics (write-through, sc0 sc1) + an explicit wait for their
@@ -102,7 +105,11 @@ int dra_sumtree_per_chain2_args(dra_sumtree* tree, dra_per_chain2_io* io_pinned,
 template <int NT>
 constexpr int per_chain2_lds_bytes() { return (16 + 16 + 12) * 8 + (2 * NT + 8) * 8 + (kTopNodes + 1) * 8 + 16 * 4 + 4 * 4 + NT; }
 
-template <int NT>
+// PART 0: the whole launch.  PART 1 / 2: its two halves as roles of two DIFFERENT launches of the same update -- 1 = priorities,
+// {max, min}, commits and adds (rides in conv3's backward launch), 2 = descent, valid_index filter, padding, hand-over (rides in
+// conv1's weight-gradient launch): each half is shorter than the launch that carries it (8-9 us against 10-12), the whole
+// (16 us) was not.  The second half reads header and uniforms from the copy the first left in device memory.
+template <int NT, int PART = 0>
 __device__ __forceinline__ void per_chain2_body(const PerChain2Args& a, char* smem) {
   // ---- LDS carve-out (NT threads, at most NT transitions per minibatch)
   double* s_hi = reinterpret_cast<double*>(smem);
@@ -136,11 +143,16 @@ __device__ __forceinline__ void per_chain2_body(const PerChain2Args& a, char* sm
   // ---- everything that crosses PCIe, at once
   const unsigned long long cur0 = a.dev->rng_cursor;
   uint32_t w0 = 0, w1 = 0;
-  if (tid < nb) {
-    w0 = words[(cur0 + 2ull * tid) & (DRA_PER_RNG_WORDS - 1)];
-    w1 = words[(cur0 + 2ull * tid + 1) & (DRA_PER_RNG_WORDS - 1)];
+  if constexpr (PART == 2) {
+    if (tid < nb) { w0 = a.dev->w[2 * tid]; w1 = a.dev->w[2 * tid + 1]; }
+    if (tid < 9) s_head[tid] = a.dev->head[tid];
+  } else {
+    if (tid < nb) {
+      w0 = words[(cur0 + 2ull * tid) & (DRA_PER_RNG_WORDS - 1)];
+      w1 = words[(cur0 + 2ull * tid + 1) & (DRA_PER_RNG_WORDS - 1)];
+    }
+    if (tid < 9) s_head[tid] = reinterpret_cast<const unsigned long long*>(a.io)[tid];
   }
-  if (tid < 9) s_head[tid] = reinterpret_cast<const unsigned long long*>(a.io)[tid];
   if (tid == 0) { s_all_valid = 1; s_flags = 0; }
   const int batch = nb;            // (the learner's batch size: every update commits and draws `nb` transitions)
   // ---- commit: {max, min} over every offered priority; a leaf is written by its FIRST occurrence in the minibatch
@@ -148,6 +160,7 @@ __device__ __forceinline__ void per_chain2_body(const PerChain2Args& a, char* sm
   // exactly as losses.hip's td_loss_kernel / per_kernel)
   double hi = -INFINITY, lo = INFINITY;
   float prio_f = 0.f;
+  if constexpr (PART != 2) {
   if (tid < batch) {
     const float ad = fabsf(loss_vec[tid]) + eps;
     prio_f = (alpha == 0.5f) ? sqrtf(ad) : powf(ad, alpha);
@@ -163,6 +176,7 @@ __device__ __forceinline__ void per_chain2_body(const PerChain2Args& a, char* sm
     lo = fmin(lo, __shfl_xor(lo, off));
   }
   if ((tid & 63) == 0) { s_hi[tid >> 6] = hi; s_lo[tid >> 6] = lo; }
+  }   // PART != 2
   __syncthreads();
   CHAIN2_STAMP(1);
   const int add_n = (int)(s_head[0] & 0xffffffffull);
@@ -170,6 +184,7 @@ __device__ __forceinline__ void per_chain2_body(const PerChain2Args& a, char* sm
   const int hist = (int)(s_head[2] & 0xffffffffull), nstep = (int)(s_head[2] >> 32);
   const int64_t write0 = (int64_t)s_head[3], mem = (int64_t)s_head[4], pos = (int64_t)s_head[5], size = (int64_t)s_head[6];
   const unsigned long long produced = s_head[7];
+  if constexpr (PART != 2) {
   if (tid < batch) s_first[tid] = lds_find(s_idx, batch, s_idx[tid]) == tid;
   if (tid == 0) {
     const int nw = (int)(NT >> 6);
@@ -262,6 +277,13 @@ __device__ __forceinline__ void per_chain2_body(const PerChain2Args& a, char* sm
         node = parent;
       }
     }
+  }
+  }   // PART != 2
+  if constexpr (PART == 1) {
+    // hand the PCIe reads to the second half
+    if (tid < nb) { a.dev->w[2 * tid] = w0; a.dev->w[2 * tid + 1] = w1; }
+    if (tid < 9) a.dev->head[tid] = s_head[tid];
+    return;
   }
   __syncthreads();
   CHAIN2_STAMP(4);
