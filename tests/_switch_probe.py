@@ -30,9 +30,13 @@ class _Quiet:
 def main(kind, out):
     agents_mod.get_logger = lambda *a, **k: _Quiet()
     d.select_device(0)
+    per = kind.endswith("_per")          # "dqn_per" / "c51_per": PrioritizedReplay (the device-side draw and its switches)
+    kind = kind.replace("_per", "")
     cfg = d.Config()
-    cfg.merge(dict(game="synthetic-atari", n_step=1, replay_cls=d.UniformReplay, async_replay=False, log_level=0, tag="probe",
-                   device_env=True))
+    cfg.merge(dict(game="synthetic-atari", n_step=1, replay_cls=d.PrioritizedReplay if per else d.UniformReplay, async_replay=False,
+                   log_level=0, tag="probe", device_env=True))
+    cfg.replay_eps, cfg.replay_alpha = 0.01, 0.5
+    cfg.replay_beta = d.LinearSchedule(0.4, 1.0, 1000)
     cfg.task_fn = lambda: d.Task(cfg.game, seed=9, synthetic_done_period=13)
     cfg.eval_env = cfg.task_fn()
     if kind == "dqn":
@@ -68,6 +72,7 @@ def main(kind, out):
     agent._learner.invalidate_actor_copy()
     for _ in range(int(os.environ.get("PROBE_STEPS", "60"))):
         agent.step()
+    agent.sync_host()
     agent._learner.synchronize()
     torch.cuda.synchronize()
     rp = agent.replay.replay
@@ -76,6 +81,9 @@ def main(kind, out):
     res = {"act": w(actions, 300, torch.int64).cpu().numpy().copy(), "rew": w(rewards, 300, torch.float64).cpu().numpy().copy()}
     for k, v in agent.network.state_dict().items():
         res["p_" + k] = v.detach().cpu().numpy().copy()
+    if per:
+        res["tree"] = rp.tree.as_tensor().cpu().numpy().copy()
+        res["py_rng"] = np.asarray([random.getrandbits(30) for _ in range(2)], dtype=np.int64)
     np.savez(out, **res)
     agent.close()
 
