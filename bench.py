@@ -195,10 +195,11 @@ def cpu_replicas(nproc, seconds=6.0, ring=5_000, limit=64):
 def agent_api(seconds=2.0):
     """The same configuration through the drop-in surface: zoo.agent('dqn_pixel') = the reference's examples.py::dqn_pixel
     (1M-frame replay, async_actor=True; examples.py:55-97) stepped exactly as run_steps does (agent.step() in a loop).
-    Four variants: the reference's own setting (async_actor=True: device-resident environment + two-stream pipeline),
+    Five variants: the reference's own setting (async_actor=True: device-resident environment + two-stream pipeline),
     async_actor=False (same kernels in order), device_env=False (HOST emulator: every observation uploaded, every action
-    crossing back, as in the reference) in order, and the host emulator with async_actor=True (the forward passes of agent
-    step t+1 on the actor stream while update t trains).  Reported next to `value`, never as `value`."""
+    crossing back, as in the reference) in order, the host emulator with async_actor=True (the forward passes of agent
+    step t+1 on the actor stream while update t trains), and dqn_pixel(replay_cls=PrioritizedReplay) with the async actor
+    (PrioritizedReplay.sample() on the device).  Reported next to `value`, never as `value`."""
     import deeprl_amd as d
     import deeprl_amd.agents as agents_mod
     from deeprl_amd import zoo
@@ -210,12 +211,13 @@ def agent_api(seconds=2.0):
 
     agents_mod.get_logger = lambda *a, **k: _Quiet()
     out = {}
-    for name, over in (("async_actor", dict(async_actor=True)), ("sync_actor", dict(async_actor=False)),
-                       ("host_emulator", dict(async_actor=False, device_env=False)),
-                       ("host_emulator_async_actor", dict(async_actor=True, device_env=False))):
+    for name, over, kw in (("async_actor", dict(async_actor=True), {}), ("sync_actor", dict(async_actor=False), {}),
+                           ("host_emulator", dict(async_actor=False, device_env=False), {}),
+                           ("host_emulator_async_actor", dict(async_actor=True, device_env=False), {}),
+                           ("async_actor_prioritized_replay", dict(async_actor=True), dict(replay_cls=d.PrioritizedReplay))):
         d.random_seed(1)
         over.update(exploration_steps=200, save_interval=0)
-        agent = zoo.agent("dqn_pixel", game="synthetic-atari", overrides=over)
+        agent = zoo.agent("dqn_pixel", game="synthetic-atari", overrides=over, **kw)
         for _ in range(300):
             agent.step()
         torch.cuda.synchronize()
