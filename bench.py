@@ -318,7 +318,9 @@ def pmc_traffic(kernel_group):
     tools/pmc_workload.py, calibrated on the gather launch whose byte count is known); null when the
     kernel was not profiled.  Counters cannot be collected inside this process."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    # (newest round's table for the DEFAULT kernels: rNN_pmc_traffic.json, from round 3 on rNN_pmc_traffic_layers4.json)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")) +
+                   glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_layers4.json")), key=os.path.basename)
     if not files:
         return None
     try:
@@ -520,7 +522,7 @@ def main():
         if roof["rocprofv3"] is not None:
             roof["rocprofv3"]["source"] = "committed file %s (rocprofv3 --kernel-trace --stats of this command on a builder box)" % roof["rocprofv3"].get("file")
         roof["traffic"] = pmc_traffic(roof["kernel"])
-        roof["traffic_source"] = "committed profiles/r*_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on a builder box)"
+        roof["traffic_source"] = "newest committed profiles/r*_pmc_traffic*.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on a builder box)"
         # the same live measurement with the empty event pair's cost taken off the (kernel + boundary + record) reading:
         # a LOWER bound of the kernel's duration, hence an upper bound of the fraction -- the truth lies between the two
         if roof.get("algorithmic_flops") and roof.get("avg_ms") and roof.get("event_pair_empty_ms"):

@@ -4,6 +4,8 @@ kernel leaves s_memrealtime stamps (100 MHz) in the unused tail of out_raw_idx."
 import os
 import sys
 
+os.environ.setdefault("DRA_PER_RIDE", "0")     # the draw as its own launch: one set of stamps per launch (riding halves overwrite slot 1)
+
 import numpy as np
 import torch
 
