@@ -60,6 +60,8 @@ struct V2Geom {
   };
 };
 
+using VG1_ = V2Geom<4, 84, 32, 8, 4>;      // conv1 (also VG1 below)
+
 struct ConvV2Args {
   const void* x[DRA_MAX_Z];
   const float* wt[DRA_MAX_Z];    // [K][OC]
@@ -1199,6 +1201,166 @@ static int launch_conv_v2_persist(const ConvV2Args& a, int nz, hipStream_t st) {
   return DRA_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv1's own throughput shape (plain uint8 NCHW batches >= 128: A2C / PPO minibatches).  The K-split kernels above spend
+// 2.6 us of staging + partial-sum exchange per 1.7 us of MFMA work per group on this layer (tools/phase_conv_big.py: 44-48 %
+// of the fp32-MFMA peak at batch 1024).  conv1 is the one layer whose WHOLE K fits a wave's registers (K = 256: 128 operand
+// registers), so here
+//   * every wave keeps all of K and owns whole 32-position tiles: no cross-wave exchange, no reduction buffer, no barrier
+//     inside a group;
+//   * the four K quarters of the latency shape (channel pair x tap half) stay four separate accumulation chains per tile and
+//     are folded (q0 + q1) + (q2 + q3) in registers: the same sums in the same order -- bit-identical with every other
+//     shape -- and four independent MFMA chains per wave;
+//   * the frames stay UINT8 in LDS (28 KB per sample instead of 113 KB as fp32): one or two whole samples per workgroup
+//     iteration, staged by a straight 128-bit copy; an operand is a byte read (4 px = 1 dword per output column: consecutive
+//     lanes hit consecutive banks without any de-interleaving) + the exact-normalisation table (f32(f64(v) * coef));
+//   * 13 tiles per sample over 4 waves: two samples per iteration (26 tiles: 7 / 7 / 6 / 6) once the launch has two
+//     iterations' worth of samples per resident workgroup, else one (4 / 3 / 3 / 3: more workgroups).
+//   * small batches (fewer samples than resident workgroups): a sample's 13 tiles are split over `tp` = 2 or 4 workgroups (each
+//     stages the whole 28 KB sample), so that the launch still has two workgroups per CU.
+__global__ void __launch_bounds__(256, 2) conv1_fwd_u8_tp_kernel(const ConvV2Args a, const int n_groups, const int spg, const int tp) {
+  using G = VG1_;
+  constexpr int IMG = G::C * G::H * G::H;                    // bytes per sample
+  constexpr int TPSAMP = G::TPS;                             // 13 position tiles per sample
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+  const int z = blockIdx.z;
+  DRA_STAMP(TR_CONV1_F, 0);
+  const float* __restrict__ wt = a.wt[z];
+  float areg[4][32];
+  if ((reinterpret_cast<uintptr_t>(wt) & 15) == 0) {
+    // the 32 KB of weights once per workgroup through LDS (the frame region, before the first frames): every wave loading
+    // all of K by itself is 4 x 32 KB of L2 reads per workgroup -- 7 us of prologue at batch 256 (512 workgroups)
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* wsrc = reinterpret_cast<const f4*>(wt);
+    f4* wl = reinterpret_cast<f4*>(smem);
+    f4 wr[G::K * G::OC / 4 / 256];
+#pragma unroll
+    for (int i = 0; i < G::K * G::OC / 4 / 256; ++i) wr[i] = wsrc[tid + 256 * i];
+#pragma unroll
+    for (int i = 0; i < G::K * G::OC / 4 / 256; ++i) wl[tid + 256 * i] = wr[i];
+    __syncthreads();
+    const float* wls = reinterpret_cast<const float*>(smem);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 32; ++j) areg[q][j] = wls[((2 * (q & 1) + h) * G::KK + (q >> 1) * 32 + j) * G::OC + li];
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* wbase = wt + ((int64_t)(2 * (q & 1) + h) * G::KK + (q >> 1) * 32) * G::OC + li;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) areg[q][j] = wbase[j * G::OC];
+    }
+  }
+  __shared__ float s_bias[G::OC];
+  // (one copy of the normalisation table: eight copies spread over the banks by lane measured 86 against 81 us at batch 1024)
+  __shared__ float s_lut[256];
+  if (tid < G::OC) s_bias[tid] = a.bias[z][tid];
+  s_lut[tid] = (float)((double)tid * a.coef);
+  const unsigned char* __restrict__ x = reinterpret_cast<const unsigned char*>(a.x[z]);
+  float* __restrict__ y = a.y[z];
+  DRA_STAMP(TR_CONV1_F, 2);
+  for (int g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    const int b0 = (g / tp) * spg, ns = min(spg, a.batch - b0), part = g - (g / tp) * tp;
+    // tiles of this workgroup: all ns * 13 of them, or (tp > 1, ns == 1) the part-th share of the sample's 13
+    const int t_lo = tp > 1 ? part * TPSAMP / tp : 0, t_hi = tp > 1 ? (part + 1) * TPSAMP / tp : ns * TPSAMP;
+    {
+      // straight copy of ns whole samples (16-byte aligned: 28 224 = 16 x 1764)
+      const uint4* src = reinterpret_cast<const uint4*>(x + (int64_t)b0 * IMG);
+      uint4* dst = reinterpret_cast<uint4*>(smem);
+      const int n16 = ns * (IMG / 16);
+      uint4 raw[2 * (IMG / 16 + 255) / 256];
+#pragma unroll
+      for (int i = 0; i < 2 * (IMG / 16 + 255) / 256; ++i) raw[i] = src[min(tid + 256 * i, n16 - 1)];
+#pragma unroll
+      for (int i = 0; i < 2 * (IMG / 16 + 255) / 256; ++i)
+        if (tid + 256 * i < n16) dst[tid + 256 * i] = raw[i];
+    }
+    __syncthreads();
+    for (int tile = t_lo + wave; tile < t_hi; tile += 4) {
+      const int s = tile / TPSAMP, p0 = (tile - s * TPSAMP) * 32;
+      const int p = min(p0 + li, G::P - 1), oh = p / G::OH, ow = p - oh * G::OH;
+      const unsigned char* bp = smem + s * IMG + h * (G::H * G::H) + (oh * G::S) * G::H + ow * G::S;
+      f32x16 acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+      // operand o = 4 j + q (j-th k-step of quarter q): byte read two chunks ahead, table read one chunk ahead of its MFMA --
+      // left alone the scheduler issues [byte read, wait, table read, wait, MFMA] per operand (two exposed LDS latencies each)
+      constexpr int CH = 8, NCHK = 128 / CH;
+      auto boff = [](int o) {
+        const int j = o >> 2, q = o & 3, t = (q >> 1) * 32 + j, kh = t / G::KH, kw = t - kh * G::KH;
+        return (q & 1) * 2 * (G::H * G::H) + kh * G::H + kw;
+      };
+      unsigned u[2][CH];
+      float bv[2][CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) { u[0][i] = bp[boff(i)]; u[1][i] = bp[boff(CH + i)]; }
+      // (the table, not the vector ALU: v_cvt_f64_u32 + v_mul_f64 + v_cvt_f32_f64 per operand compete with the MFMAs for the
+      // SIMD's issue port -- measured 87 against 81 us at batch 1024)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) bv[0][i] = s_lut[u[0][i]];
+#pragma unroll
+      for (int c = 0; c < NCHK; ++c) {
+        if (c + 1 < NCHK) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) bv[(c + 1) & 1][i] = s_lut[u[(c + 1) & 1][i]];
+        }
+        if (c + 2 < NCHK) {
+#pragma unroll
+          for (int i = 0; i < CH; ++i) u[c & 1][i] = bp[boff((c + 2) * CH + i)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          const int o = c * CH + i;
+          acc[o & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[o & 3][o >> 2], bv[c & 1][i], acc[o & 3], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const int bi = b0 + s;
+      if (p0 + li < G::P) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float sum = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          y[((int64_t)bi * G::OC + row) * G::P + p0 + li] = v2_act(sum + s_bias[row], a.act);
+        }
+      }
+    }
+    __syncthreads();     // every wave is done with the frames before the next group is staged
+  }
+  DRA_STAMP(TR_CONV1_F, 5);
+  DRA_STAMP_END(TR_CONV1_F);
+}
+
+static int launch_conv1_u8_tp(const ConvV2Args& a, int nz, hipStream_t st) {
+  using G = VG1_;
+  constexpr int IMG = G::C * G::H * G::H;
+  static int resident = -1;
+  if (resident < 0) {
+    int dev = 0, n_cu = 0;
+    DRA_HIP(hipGetDevice(&dev));
+    DRA_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    resident = 2 * n_cu;
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_fwd_u8_tp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * IMG));
+    static_assert(2 * IMG >= G::K * G::OC * 4, "the weights pass through the frame region");
+  }
+  const int per = resident / nz > 0 ? resident / nz : 1;
+  const int spg = a.batch >= 2 * per ? 2 : 1;
+  const int tp = spg == 2 || a.batch >= per ? 1 : (2 * a.batch >= per ? 2 : 4);
+  const int n_groups = ((a.batch + spg - 1) / spg) * tp;
+  const int nwg = n_groups < per ? n_groups : per;
+  const size_t lds_bytes = spg == 2 ? (size_t)2 * IMG : (size_t)(IMG > G::K * G::OC * 4 ? IMG : G::K * G::OC * 4);
+  hipLaunchKernelGGL(conv1_fwd_u8_tp_kernel, dim3(nwg, 1, nz), dim3(256), lds_bytes, st, a, n_groups, spg, tp);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 // Tile shape by problem size: one tile per workgroup (latency shape) until the launch has several workgroups
 // per CU slot anyway, then PTBIG tiles per workgroup (throughput shape).  DRA_CONV_PT=1 forces the latency shape.
 static int g_conv_pt_threshold = -1;
@@ -1213,6 +1375,14 @@ static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
       static int persist = -1;
       if (persist < 0) { const char* e = getenv("DRA_CONV_PERSIST"); persist = e ? atoi(e) : 1; }
       if (persist) {
+        if constexpr (U8 && G::C == 4) {
+          // conv1 on uint8 frames: its own throughput kernel (all of K in registers).  DRA_CONV1_TP=0: the K-split form below
+          static int tp1 = -1;
+          if (tp1 < 0) { const char* e = getenv("DRA_CONV1_TP"); tp1 = e ? atoi(e) : 1; }
+          // (from 384 samples per net on: below, the K-split form's smaller work units fill the chip better -- batch 256: 26.5 against
+          // 27.2 us; batch 512: 48.0 against 44.2; 1024: 91 against 81; 2048: 149 us = 57 % of the fp32-MFMA peak)
+          if (tp1 && a.batch >= 384 && !a.sample_idx && !a.newest_frame) return launch_conv1_u8_tp(a, nz, st);
+        }
         if constexpr (G::C == 4) {
           // conv1: 64 MFMAs per wave and group against ~2.6 us of staging / exchange: with the one-tile exchange (49 KB of LDS)
           // three workgroups share a CU.  DRA_CONV1_SEQ=0: the round-2 form (two)

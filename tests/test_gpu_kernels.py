@@ -641,6 +641,30 @@ def test_conv_koc_fwd_throughput_shape(dev, layer):
     _scale_close(big.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("batch", [389, 1025])
+def test_conv1_full_k_throughput_kernel(dev, batch):
+    """conv1's own throughput kernel (conv_v2.hip conv1_fwd_u8_tp_kernel, uint8 batches >= 384): all of K in a wave's
+    registers, the latency shape's four K quarters as four accumulation chains folded (q0 + q1) + (q2 + q3) -- bit-identical
+    with the latency shape on a shared prefix, and F.conv2d within the contraction tolerance.  389: one sample per workgroup
+    iteration, an odd batch; 1025: two samples per iteration, a second iteration, a last group of one sample."""
+    import torch.nn.functional as F
+    from deeprl_amd import ops
+    c, h, oc, k, s = CONV[1]
+    rs = np.random.RandomState(batch)
+    w = (rs.standard_normal((oc, c, k, k)) / np.sqrt(c * k * k)).astype(np.float32)
+    b = (rs.standard_normal(oc) * 0.1).astype(np.float32)
+    wt = ops.to_koc(f32(w, dev))
+    x_u8 = rs.randint(0, 256, size=(batch, c, h, h)).astype(np.uint8)
+    big = ops.conv_fwd_koc(1, [cu(x_u8, dev)], [wt], [f32(b, dev)], u8_coef=1.0 / 255)[0]
+    small = ops.conv_fwd_koc(1, [cu(x_u8[:33], dev)], [wt], [f32(b, dev)], u8_coef=1.0 / 255)[0]
+    tail = ops.conv_fwd_koc(1, [cu(x_u8[-7:], dev)], [wt], [f32(b, dev)], u8_coef=1.0 / 255)[0]
+    assert torch.equal(big[:33], small) and torch.equal(big[-7:], tail)
+    keep = np.r_[0:40, batch - 40:batch]
+    x = NUM.image_normalize_sync(x_u8[keep])
+    ref = F.relu(F.conv2d(torch.tensor(x), torch.tensor(w), torch.tensor(b), stride=s)).numpy()
+    _scale_close(big.cpu().numpy()[keep], ref)
+
+
 # ---------------------------------------------------------------- fused launches + one-pass kernels (fused.hip)
 @pytest.mark.parametrize("layer", [1, 2, 3])
 @pytest.mark.parametrize("batch", [32, 1, 5])
