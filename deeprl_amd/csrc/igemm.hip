@@ -154,7 +154,22 @@ linear_gemv_kernel(LinPtrs q, int B, int K, int O, int act) {
   for (int i = 0; i < KV; ++i) w[i] = (lane + 64 * i < K) ? wrow[lane + 64 * i] : 0.f;
   const float bias = q.bias[z] ? q.bias[z][min(o, O - 1)] : 0.f;
   const float* __restrict__ src = q.x[z] + (int64_t)b0 * K;
-  for (int i = threadIdx.x; i < nb * K; i += 256) s_x[i] = src[i];
+  if ((K & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+    // every load of the staging requested before the first LDS write: the plain load -> store loop below is one memory round
+    // trip per trip (32 of them for 16 rows of 512: the A2C / PPO heads took 12 us per launch, profiles/r03k_kernel_stats_*)
+    constexpr int NV = KV * 64 * 32 / 4 / 256;               // float4 per thread at 32 rows of KV * 64
+    const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src);
+    float4* s_x4 = reinterpret_cast<float4*>(s_x);
+    const int n4 = nb * K / 4;
+    float4 r[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = src4[min((int)threadIdx.x + 256 * i, n4 - 1)];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if ((int)threadIdx.x + 256 * i < n4) s_x4[threadIdx.x + 256 * i] = r[i];
+  } else {
+    for (int i = threadIdx.x; i < nb * K; i += 256) s_x[i] = src[i];
+  }
   __syncthreads();
   if (o >= O) return;
   float* __restrict__ out = q.y[z];

@@ -82,7 +82,10 @@ def categorical_policy(logits, action=None, sampler=None):
         else:
             with torch.no_grad():
                 u = torch.rand(logits.shape[0], dtype=torch.float32, device=logits.device)
-                action, _, _ = ops.categorical_fwd(logits.detach(), uniform=u)
+                action, lp, ent = ops.categorical_fwd(logits.detach(), uniform=u)
+            if not (torch.is_grad_enabled() and logits.requires_grad):
+                # a rollout step (no_grad): the sampling launch already produced log_pi_a / entropy of its own draw
+                return action.long().reshape(-1).contiguous(), lp.unsqueeze(-1), ent.unsqueeze(-1)
     action = action.long().reshape(-1).contiguous()
     lp, ent = _CategoricalFn.apply(logits, action)
     return action, lp.unsqueeze(-1), ent.unsqueeze(-1)
