@@ -58,6 +58,13 @@ for layer, (c, h, oc, kh, s) in GEOM.items():
     st = raw[used].astype(np.float64) / 100.0        # us
     t0 = st[:, 0].min()
     flops = 2.0 * B * oh * oh * oc * c * kh * kh
+    if layer == 1 and B >= 384:
+        # conv1's own throughput kernel (all of K in registers): entry, prologue (weights through LDS), end
+        out["conv1"] = {"batch": B, "us_per_call": us, "TFLOPs": flops / us / 1e6, "frac_mfma_f32": flops / us / 1e6 / 157.3,
+                        "kernel": "conv1_fwd_u8_tp_kernel", "workgroups": int(used.sum()),
+                        "kernel_span_us": float(st[:, 5].max() - t0), "prologue_us": float((st[:, 2] - st[:, 0]).mean()),
+                        "whole_workgroup_us": float((st[:, 5] - st[:, 0]).mean()), "start_spread_us": float(st[:, 0].max() - t0)}
+        continue
     rec = {"batch": B, "us_per_call": us, "TFLOPs": flops / us / 1e6, "frac_mfma_f32": flops / us / 1e6 / 157.3,
            "workgroups": int(used.sum()), "kernel_span_us": float(st[:, 5].max() - t0),
            "prologue_us": float((st[:, 2] - st[:, 0]).mean()),
