@@ -86,3 +86,75 @@ def test_release_rewinds_the_generator_to_the_consumed_word():
             random.setstate(state)
     dd.release()
     assert random.getrandbits(32) == int(ref[consumed])
+
+
+def test_collect_keeps_pending_idx_in_the_devices_order():
+    """DeviceDraw.collect() mirrors sum_tree.py's pending_idx one launch late, in the order the kernel worked: commit of the
+    launch's own minibatch (every distinct sampled leaf), the next agent step's adds, then every leaf of the new draw (the
+    filtered-out ones included).  Driven here with a stub learner and hand-made launch blocks against the oracle's own
+    bookkeeping (oracle/sumtree_oracle.py: get() adds, update() / add() remove)."""
+    from oracle.sumtree_oracle import SumTreeOracle
+    cap, B, n_env, h, n_step = 64, 8, 2, 4, 1
+    rs = np.random.RandomState(3)
+    orc = SumTreeOracle(cap)
+    for _ in range(40):
+        orc.add(1.0)
+    pos, size = 40, 40
+
+    class _Rp:
+        pass
+
+    rp = _Rp()
+    rp._pending, rp.batch_size, rp.memory_size = set(), B, cap
+
+    class _L:
+        def per_chain2_wait(self, slot, seq):
+            pass
+
+    dd = _bare_draw()
+    dd.rp, dd.L = rp, _L()
+    dd.blocks = [(None, None, dict(raw=np.zeros(1024, np.int64), idx=np.zeros(1024, np.int64), p=np.zeros(1024), total=np.zeros(1),
+                                   tail=np.zeros(2, np.int32), cursor=np.zeros(1, np.uint64))) for _ in range(4)]
+
+    def draw():          # replay.py:164-186 on the oracle: every descent is pending, invalid ones are dropped, then padding
+        raw, picked = [], []
+        for _ in range(B):
+            idx, p, di = orc.get(rs.uniform(0, orc.total()))
+            raw.append(idx)
+            if (di - h + 1 >= 0 and di + n_step < pos) or (di - h + 1 >= pos and di + n_step < size):
+                picked.append(idx)
+        n_valid = len(picked)
+        while len(picked) < B:
+            picked.append(picked[rs.randint(len(picked))])
+        return raw, picked, n_valid
+
+    raw, cur, _ = draw()                      # the first minibatch: drawn on the host (DeviceDraw.start)
+    rp._pending = set(orc.pending)
+    dd._collect_leaves = list(cur)
+    dd.next_tree_idx = np.asarray(cur)
+    write = orc.write
+    some_invalid = False
+    for t in range(60):
+        # what launch t does on the device, replayed on the oracle
+        for leaf in cur:
+            orc.update(leaf, float(rs.uniform(0.1, 2.0)))
+        adds = [(write + i) % cap + cap - 1 for i in range(n_env)]
+        for _ in range(n_env):
+            orc.add(2.0)
+            if pos >= size:
+                size += 1
+            pos = (pos + 1) % cap
+        write = (write + n_env) % cap
+        raw, nxt, n_valid = draw()
+        some_invalid = some_invalid or n_valid < B
+        # its pinned block, then the host's (lagging) collect
+        slot = t & 3
+        v = dd.blocks[slot][2]
+        v["raw"][:B], v["idx"][:B], v["tail"][:] = raw, nxt, (n_valid, 0)
+        v["cursor"][0] = 100 * (t + 1)
+        dd.fifo.append((slot, t + 1, adds, 0.5))
+        dd.collect()
+        assert rp._pending == orc.pending, "launch %d" % t
+        assert dd.next_tree_idx.tolist() == nxt and dd.consumed == 100 * (t + 1)
+        cur = nxt
+    assert some_invalid, "the scenario must contain filtered draws"
