@@ -180,10 +180,6 @@ struct dra_dqn_learner {
   int64_t* idx_tag_dev;             // [4][1024]
   unsigned long long* rd_seq_dev;   // ring-direct updates completed (bumped by each one's head kernel)
   uint64_t rd_issued;               // ring-direct updates issued (host)
-  int64_t* ui_stage;                // pinned [8][1024]: staging of dra_dqn_learner_upload_idx
-  hipEvent_t ui_ev[8];
-  bool ui_used[8];
-  int ui_k;
   float* sp_stage;                  // pinned [8][1025]: staging of dra_dqn_learner_upload_sampling_prob
   hipEvent_t sp_ev[8];
   bool sp_used[8];
@@ -435,8 +431,6 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
     if (!rc) rc |= (int)hipMemset(l->rd_seq_dev, 0, sizeof(unsigned long long));
   }
   rc |= (int)hipHostMalloc(&l->sp_stage, (size_t)8 * 1025 * sizeof(float), hipHostMallocDefault);
-  rc |= (int)hipHostMalloc(&l->ui_stage, (size_t)8 * 1024 * sizeof(int64_t), hipHostMallocDefault);
-  for (int k = 0; k < 8; ++k) rc |= (int)hipEventCreateWithFlags(&l->ui_ev[k], hipEventDisableTiming);
   for (int k = 0; k < 8; ++k) rc |= (int)hipEventCreateWithFlags(&l->sp_ev[k], hipEventDisableTiming);
   rc |= (int)hipMalloc(&l->coop_ctr, sizeof(unsigned long long));
   if (!rc) rc |= (int)hipMemset(l->coop_ctr, 0, sizeof(unsigned long long));
@@ -542,8 +536,6 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (l->per2_idx) (void)hipFree(l->per2_idx);
   if (l->rd_seq_dev) (void)hipFree(l->rd_seq_dev);
   if (l->sp_stage) (void)hipHostFree(l->sp_stage);
-  if (l->ui_stage) (void)hipHostFree(l->ui_stage);
-  for (int k = 0; k < 8; ++k) if (l->ui_ev[k]) (void)hipEventDestroy(l->ui_ev[k]);
   for (int k = 0; k < 8; ++k) if (l->sp_ev[k]) (void)hipEventDestroy(l->sp_ev[k]);
   if (l->coop_ctr) (void)hipFree(l->coop_ctr);
   if (l->coop_flag) (void)hipHostFree(l->coop_flag);
@@ -3192,22 +3184,6 @@ DRA_API int dra_dqn_learner_upload_sampling_prob(dra_dqn_learner* l, const doubl
   DRA_HIP(hipMemcpyAsync(l->samp_prob, dst, (size_t)(n + 1) * sizeof(float), hipMemcpyHostToDevice, dra_stream(stream)));
   DRA_HIP(hipEventRecord(l->sp_ev[k], dra_stream(stream)));
   l->sp_used[k] = true;
-  return DRA_OK;
-}
-
-// The minibatch indices of the next dra_dqn_learner_update / _update_async (host int64[batch]) to the learner's device index
-// buffer on `stream`, through the learner's own rotating pinned staging: the host-emulator agent step spent 35 us per update in
-// the equivalent torch pinned-tensor copy + event (tools/prof_host_async.py).
-DRA_API int dra_dqn_learner_upload_idx(dra_dqn_learner* l, const int64_t* idx_host, int n, void* stream) {
-  if (!l || !idx_host || n != l->c.batch || n > 1024) return DRA_EINVAL;
-  const int k = l->ui_k;
-  l->ui_k = (k + 1) % 8;
-  if (l->ui_used[k]) DRA_HIP(hipEventSynchronize(l->ui_ev[k]));
-  int64_t* dst = l->ui_stage + (size_t)k * 1024;
-  memcpy(dst, idx_host, (size_t)n * sizeof(int64_t));
-  DRA_HIP(hipMemcpyAsync(l->idx, dst, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, dra_stream(stream)));
-  DRA_HIP(hipEventRecord(l->ui_ev[k], dra_stream(stream)));
-  l->ui_used[k] = true;
   return DRA_OK;
 }
 

@@ -148,6 +148,9 @@ class DQNLearner:
         lib.dra_dqn_learner_set_update_cus(h, int(self.update_cus or n_cu))
         self.params = StepParams()
         self._idx_view = np.ctypeslib.as_array(self.params.idx)[:batch]
+        self._idx_pinned = [torch.empty(batch, dtype=torch.int64).pin_memory() for _ in range(8)]
+        self._idx_events = [None] * 8
+        self._k = 0
 
     def _partitioned_streams(self):
         """Update stream / actor stream on disjoint CU sets (DRA_VAR_CU_PARTITION).  On MI355X mask bit i is CU
@@ -206,8 +209,16 @@ class DQNLearner:
 
     def upload_indices(self, idx):
         """numpy int64[batch] -> the learner's device idx buffer (async, pinned staging)."""
-        idx = np.ascontiguousarray(idx, dtype=np.int64)
-        lib.dra_dqn_learner_upload_idx(self.h, idx.ctypes.data_as(ctypes.c_void_p), int(idx.shape[0]), self._sp())
+        k = self._k
+        self._k = (k + 1) % len(self._idx_pinned)
+        if self._idx_events[k] is not None:
+            self._idx_events[k].synchronize()
+        self._idx_pinned[k].numpy()[:] = idx
+        with torch.cuda.stream(self.stream):
+            self.idx.copy_(self._idx_pinned[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._idx_events[k] = ev
 
     def upload_sampling_prob(self, prob, beta):
         """PER: numpy sampling probabilities [batch] + the importance exponent -> the learner's device buffer (async,

@@ -487,9 +487,6 @@ int dra_dqn_learner_sync_loss(dra_dqn_learner* l);
  * _q_host_async = dra_dqn_learner_q_host on `stream_actor`, reading the copy the update BEFORE the most recent one wrote --
  * the forward for agent step t+1 overlaps update t and never races with its optimizer. */
 int dra_dqn_learner_update_async(dra_dqn_learner* l, int use_graph, int per, float beta, void* stream_update);
-/* minibatch indices (host int64[batch]) of the next _update / _update_async -> the learner's device index buffer, on `stream`
- * through the learner's own pinned staging (replay.py:92-103's indices, what tensor(idx) would upload) */
-int dra_dqn_learner_upload_idx(dra_dqn_learner* l, const int64_t* idx_host, int n, void* stream);
 int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* state_host, float* q_host, void* stream_actor,
                                  void* stream_update);
 /* True resume (optimizer + ring + RNG state; the reference's save() keeps weights only, BaseAgent.py:24-33):
