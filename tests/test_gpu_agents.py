@@ -307,7 +307,9 @@ def test_fused_learner_matches_oracle(dra, double_q, variant):
         np.testing.assert_allclose(learner.delta.cpu().numpy(), delta.detach().numpy(), rtol=1e-5, atol=1e-5 * scale)
         np.testing.assert_allclose(learner.loss.item(), loss.item(), rtol=1e-5)
         np.testing.assert_allclose(learner.norm.item(), norm64, rtol=1e-5)
-        np.testing.assert_allclose(learner.norm.item(), float(norm), rtol=5e-5)    # torch's fp32 summation of the same gradients
+        # (a cross-check, not the bar: torch's own fp32 summation of the same 1.7 M gradient elements is 3.3e-5 away from their
+        # fp64 sum -- torch_fp32_vs_fp64_sum in the recorded errors -- and its summation order depends on the host's threads)
+        np.testing.assert_allclose(learner.norm.item(), float(norm), rtol=1e-4)
         with torch.no_grad():
             for k, g in zip(names, grads):
                 newp, sq[k], ga[k] = N.rmsprop_step(p[k], g, sq[k], ga[k], 0.00025, 0.95, 0.01, True)
