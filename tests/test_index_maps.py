@@ -43,3 +43,78 @@ def test_xcd_order_is_a_bijection_that_keeps_groups_on_one_xcd():
         assert all(len(v) == 1 for v in xcds.values()), (n_groups, per_group, first)
         if n_groups >= 8:
             assert len(xcds) == (n_groups // 8) * 8
+
+
+def test_conv1_full_k_throughput_kernel_maps():
+    """conv_v2.hip conv1_fwd_u8_tp_kernel, transcribed: (i) the launcher's (samples per group, tile parts, groups) and the
+    kernel's (group, wave) -> tiles enumeration cover every (sample, position tile) exactly once for the batches the GPU
+    tests run and the regime boundaries; (ii) operand o = 4 j + q of a tile reads byte c * 7056 + (4 oh + kh) * 84 + 4 ow + kw
+    of the sample, with (c, kh, kw) running over all K = 256 taps exactly once, quarter q = (channel pair q & 1, tap half
+    q >> 1) in the latency shape's order (areg[q][j] = weight row (2 (q & 1) + h) * 64 + (q >> 1) * 32 + j); (iii) evaluated in
+    fp64 on a small batch, the four-chain sum equals F.conv2d."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    H, OH, P, TPS, IMG, HH = 84, 20, 400, 13, 4 * 84 * 84, 84 * 84
+
+    def plan(batch, per=512):
+        spg = 2 if batch >= 2 * per else 1
+        tp = 1 if (spg == 2 or batch >= per) else (2 if 2 * batch >= per else 4)
+        n_groups = ((batch + spg - 1) // spg) * tp
+        return spg, tp, n_groups
+
+    for batch in (384, 389, 511, 512, 1023, 1024, 1025, 128, 131, 255):
+        spg, tp, n_groups = plan(batch)
+        seen = np.zeros((batch, TPS), dtype=np.int64)
+        for g in range(n_groups):
+            b0 = (g // tp) * spg
+            ns = min(spg, batch - b0)
+            part = g - (g // tp) * tp
+            t_lo, t_hi = (part * TPS // tp, (part + 1) * TPS // tp) if tp > 1 else (0, ns * TPS)
+            assert tp == 1 or ns == 1
+            for wave in range(4):
+                for tile in range(t_lo + wave, t_hi, 4):
+                    s = tile // TPS
+                    seen[b0 + s, tile - s * TPS] += 1
+        assert (seen == 1).all(), batch
+
+    def boff(o):
+        j, q = o >> 2, o & 3
+        t = (q >> 1) * 32 + j
+        kh, kw = divmod(t, 8)
+        return (q & 1) * 2 * HH + kh * H + kw
+
+    taps = set()
+    for h in range(2):
+        for o in range(128):
+            j, q = o >> 2, o & 3
+            off = h * HH + boff(o)
+            c, rem = divmod(off, HH)
+            kh, kw = divmod(rem, H)
+            assert c == 2 * (q & 1) + h and kh * 8 + kw == (q >> 1) * 32 + j and kw < 8
+            taps.add((c, kh, kw))
+    assert len(taps) == 256
+
+    rs = np.random.RandomState(0)
+    x = rs.randint(0, 256, size=(2, 4, H, H)).astype(np.uint8)
+    w = rs.standard_normal((32, 4, 8, 8))
+    wt = w.transpose(1, 2, 3, 0).reshape(256, 32)             # KOC: row (c * 8 + kh) * 8 + kw
+    lut = np.arange(256) / 255.0
+    smem = x.reshape(2, IMG)
+    y = np.zeros((2, 32, P))
+    for s in range(2):
+        for tile in range(TPS):
+            for li in range(32):
+                p = min(tile * 32 + li, P - 1)
+                oh, ow = divmod(p, OH)
+                acc = np.zeros((4, 32))
+                for h in range(2):
+                    base = h * HH + oh * 4 * H + ow * 4
+                    for o in range(128):
+                        j, q = o >> 2, o & 3
+                        row = (2 * (q & 1) + h) * 64 + (q >> 1) * 32 + j
+                        acc[q] += wt[row] * lut[smem[s, base + boff(o)]]
+                if tile * 32 + li < P:
+                    y[s, :, tile * 32 + li] = (acc[0] + acc[1]) + (acc[2] + acc[3])
+    ref = F.conv2d(torch.from_numpy(x.astype(np.float64) / 255.0), torch.from_numpy(w), stride=4).numpy().reshape(2, 32, P)
+    np.testing.assert_allclose(y, ref, rtol=1e-12, atol=1e-12)
