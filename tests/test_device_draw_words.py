@@ -158,3 +158,44 @@ def test_collect_keeps_pending_idx_in_the_devices_order():
         assert dd.next_tree_idx.tolist() == nxt and dd.consumed == 100 * (t + 1)
         cur = nxt
     assert some_invalid, "the scenario must contain filtered draws"
+
+
+def test_delta_propagation_commutes_exactly_in_the_exact_regime():
+    """sumtree_per_chain2_kernel writes priorities as tree[ancestor] += (new - old) with f64 atomics in whatever order the
+    hardware performs them.  That equals the reference's sequential walk (sum_tree.py:46-60) BIT FOR BIT whenever every value
+    is a multiple of one quantum and the total stays below 2^53 quanta -- the kernel's `ordered == 0` condition
+    (capacity * max <= 2^(53 + ilogb(min) - 23) for f32 priorities) -- and this test replays both on the oracle's tree in a
+    shuffled order.  Outside the regime (a priority 2^40 times smaller than the largest) the orders do differ, which is why
+    the kernel falls back to the ordered walk there."""
+    from oracle.sumtree_oracle import SumTreeOracle
+    rs = np.random.RandomState(5)
+    cap = 1000
+    for spread, expect_exact in ((1.0, True), (2.0 ** -40, False)):
+        a, b = SumTreeOracle(cap), SumTreeOracle(cap)
+        for t in (a, b):
+            for _ in range(cap):
+                t.add(1.0)
+        differed = False
+        lo, hi = 1.0, 1.0
+        for _ in range(40):
+            leaves = rs.choice(cap, size=32, replace=False) + cap - 1
+            prio = np.sqrt(np.abs(rs.standard_normal(32)).astype(np.float32) + np.float32(0.01)).astype(np.float32)
+            prio[::7] *= np.float32(spread)
+            lo, hi = min(lo, float(prio.min())), max(hi, float(prio.max()))
+            for leaf, p in zip(leaves, prio):                        # the reference: one leaf after the other, leaf -> root
+                a.pending.add(int(leaf))
+                a.update(int(leaf), float(p))
+            ops_ = []                                                # the kernel: every (ancestor, delta) pair, any order
+            for leaf, p in zip(leaves, prio):
+                delta = float(p) - b.tree[leaf]
+                b.tree[leaf] = float(p)
+                node = int(leaf)
+                while node > 0:
+                    node = (node - 1) // 2
+                    ops_.append((node, delta))
+            for k in rs.permutation(len(ops_)):
+                b.tree[ops_[k][0]] += ops_[k][1]
+            differed = differed or not np.array_equal(a.tree, b.tree)
+        in_regime = cap * hi <= 2.0 ** (53 + int(np.floor(np.log2(lo))) - 23)
+        assert in_regime == expect_exact
+        assert differed != expect_exact
