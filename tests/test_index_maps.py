@@ -118,3 +118,30 @@ def test_conv1_full_k_throughput_kernel_maps():
                     y[s, :, tile * 32 + li] = (acc[0] + acc[1]) + (acc[2] + acc[3])
     ref = F.conv2d(torch.from_numpy(x.astype(np.float64) / 255.0), torch.from_numpy(w), stride=4).numpy().reshape(2, 32, P)
     np.testing.assert_allclose(y, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_conv2_wide_staging_equals_the_row_shaped_map():
+    """conv_v2.hip V2StageWide (128-bit staging of conv2's whole fp32 image): float4 number idx of the contiguous sample lands
+    as two 64-bit LDS writes -- elements 0 / 2 at dst, dst + 1 and elements 1 / 3 at dst + WPH, dst + WPH + 1 -- exactly where
+    the row-shaped staging puts the same pixels: img[c * CS + row * RW + lds_col(col)], lds_col(iw) = (iw % S) * WPH + iw / S.
+    conv3 (S = 1): lds_col is the identity and RW = H, CS = H * H: the LDS image is the memory image."""
+    C, H, S = 32, 20, 2
+    WPH = (H + S - 1) // S
+    RW = S * WPH
+    NR = H
+    CS = NR * RW
+    where = {}
+    for idx in range(C * H * H // 4):
+        e = 4 * idx
+        c, rem = divmod(e, H * H)
+        row, col = divmod(rem, H)
+        assert col % 4 == 0
+        dst = c * CS + row * RW + col // 2
+        assert dst % 2 == 0 and (dst + WPH) % 2 == 0          # 64-bit aligned writes
+        for k, a in ((0, dst), (2, dst + 1), (1, dst + WPH), (3, dst + WPH + 1)):
+            where[(c, row, col + k)] = a
+    assert len(where) == C * H * H and len(set(where.values())) == C * H * H
+    for (c, row, iw), a in where.items():
+        assert a == c * CS + row * RW + (iw % S) * WPH + iw // S
+    C3, H3 = 64, 9
+    assert (1 * ((H3 + 0) // 1)) == H3 and (C3 * H3 * H3) % 4 == 0      # RW == H, whole float4s: a straight copy
