@@ -1675,13 +1675,24 @@ class _DeterministicPolicyAgent(BaseAgent):
         close_obj(self.replay)
         close_obj(self.task)
 
+    def _flat_pair(self, target, src):
+        """Both networks' parameters re-homed (once) into one flat fp32 buffer each, same tensor order and offsets; the
+        modules and their torch optimizers keep seeing the same Parameter objects (views into the buffers)."""
+        pair = getattr(self, '_soft_flat', None)
+        if pair is None or pair[2] is not target or pair[3] is not src:
+            tf, sf = FlatParams(list(target.parameters())), FlatParams(list(src.parameters()))
+            if tf.offsets != sf.offsets or tf.numel != sf.numel:
+                raise DraError("soft_update: target and source networks differ in parameter layout")
+            for p in list(target.parameters()) + list(src.parameters()):
+                p.grad = None        # FlatParams' gradient views are not used here (torch optimizers own the gradients)
+            pair = self._soft_flat = (tf, sf, target, src)
+        return pair[0].flat, pair[1].flat
+
     def soft_update(self, target, src):
-        """target <- (1 - mix) * target + mix * src over every parameter: two multi-tensor launches."""
-        mix = self.config.target_network_mix
-        with torch.no_grad():
-            tp, sp = list(target.parameters()), [p.detach() for p in src.parameters()]
-            torch._foreach_mul_(tp, 1.0 - mix)
-            torch._foreach_add_(tp, sp, alpha=mix)
+        """target <- target * (1 - mix) + src * mix over every parameter (DDPG_agent.py:26-30): ONE launch of
+        `dra_soft_update` over the two networks' flat parameter buffers."""
+        t_flat, s_flat = self._flat_pair(target, src)
+        ops.soft_update(t_flat, s_flat, self.config.target_network_mix)
 
     def eval_step(self, state):
         norm = self.config.state_normalizer

@@ -1000,6 +1000,37 @@ DRA_API int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream) 
   return DRA_OK;
 }
 
+// Polyak averaging of a target network over the two networks' FLAT parameter buffers (DDPG_agent.py:26-30, TD3_agent.py:28-32):
+//   target[i] = target[i] * keep + src[i] * mix          keep = f32(1 - mix), both products rounded before the add --
+// the reference's `target_param * (1.0 - mix) + param * mix` (fp contraction is off for this library).  One launch, 16
+// bytes per lane; 8 B read + 4 B written per parameter: bandwidth-bound.
+__global__ void __launch_bounds__(256) soft_update_kernel(float* __restrict__ target, const float* __restrict__ src, int64_t n,
+                                                          float keep, float mix) {
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x, i = 4 * i4;
+  if (i + 4 <= n) {
+    float4 t = reinterpret_cast<float4*>(target)[i4];
+    const float4 s = reinterpret_cast<const float4*>(src)[i4];
+    t.x = t.x * keep + s.x * mix;
+    t.y = t.y * keep + s.y * mix;
+    t.z = t.z * keep + s.z * mix;
+    t.w = t.w * keep + s.w * mix;
+    reinterpret_cast<float4*>(target)[i4] = t;
+  } else {
+    for (int64_t j = i; j < n; ++j) target[j] = target[j] * keep + src[j] * mix;
+  }
+}
+
+DRA_API int dra_soft_update(float* target, const float* src, int64_t n, float keep, float mix, void* stream) {
+  if (!target || !src || n < 0) return DRA_EINVAL;
+  if ((((uintptr_t)target) | ((uintptr_t)src)) & 15) return DRA_EINVAL;
+  if (n == 0) return DRA_OK;
+  const int64_t blocks = ((n + 3) / 4 + 255) / 256;
+  if (blocks > 0x7fffffff) return DRA_EINVAL;
+  hipLaunchKernelGGL(soft_update_kernel, dim3((unsigned)blocks), dim3(256), 0, dra_stream(stream), target, src, n, keep, mix);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 #ifdef DRA_TRACE
 extern "C" int dra_trace_set_optim(void* p) { return dra_trace_set_local(p); }
 #endif

@@ -232,8 +232,16 @@ class NoisyLinear(nn.Module):
         return x.sign().mul(x.abs().sqrt())
 
     def reset_noise(self):
+        """network_utils.py:73-80.  The three normal vectors are drawn from torch's CPU generator, in the reference's
+        order and with its tensor sizes (the reference's buffers live on Config.DEVICE = CPU there), and uploaded: like
+        every other random stream of the hot path the noise is host-drawn, so a seeded run consumes the generator exactly
+        as the reference does.  The factorised products are formed on the device."""
         for e in (self.noise_in, self.noise_out_weight, self.noise_out_bias):       # this draw order
-            e.normal_(std=Config.NOISY_LAYER_STD)
+            e.copy_(torch.empty(e.shape, dtype=e.dtype).normal_(std=Config.NOISY_LAYER_STD))
+        self.refresh_epsilon()
+
+    def refresh_epsilon(self):
+        """weight_epsilon = f(noise_out_weight) f(noise_in)^T, bias_epsilon = f(noise_out_bias) from the current noise vectors."""
         f = self.transform_noise
         self.weight_epsilon.copy_(torch.outer(f(self.noise_out_weight), f(self.noise_in)))
         self.bias_epsilon.copy_(f(self.noise_out_bias))

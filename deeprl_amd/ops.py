@@ -764,3 +764,13 @@ def adam_step_counter(param, grad, exp_avg, exp_avg_sq, partials, n_partials, ma
 
 def copy_f32(dst, src):
     lib.dra_copy_f32(ptr(dst), ptr(src), src.numel(), stream_ptr())
+
+
+def soft_update(target_flat, src_flat, mix):
+    """target <- target * (1 - mix) + src * mix over two flat fp32 buffers of equal length (DDPG_agent.py:26-30): one
+    launch of `dra_soft_update`; both products are rounded to fp32 before the add, as in the reference's expression."""
+    _dev(target_flat), _dev(src_flat)
+    if target_flat.numel() != src_flat.numel() or target_flat.dtype != torch.float32 or src_flat.dtype != torch.float32:
+        raise DraError("soft_update: two float32 buffers of equal length")
+    keep = float(np.float32(1.0 - mix))
+    lib.dra_soft_update(ptr(target_flat), ptr(src_flat), target_flat.numel(), keep, float(mix), stream_ptr())

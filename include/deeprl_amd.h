@@ -358,6 +358,10 @@ int dra_adam_step_counter(float* param, const float* grad, float* exp_avg, float
                           const double* partials, int n_partials, float max_norm, float lr, float beta1, float beta2,
                           float eps, const int64_t* step_dev, float* out_norm, float* param_copy, void* stream);
 int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream); /* DQN_agent.py:136-138 */
+/* polyak averaging of the target network (DDPG_agent.py:26-30, TD3_agent.py:28-32) over the two networks' flat parameter
+ * buffers (16-byte aligned): target[i] = target[i] * keep + src[i] * mix with keep = f32(1 - mix); each product is rounded
+ * before the add, as the reference's `target_param * (1.0 - mix) + param * mix` is.  One launch. */
+int dra_soft_update(float* target, const float* src, int64_t n, float keep, float mix, void* stream);
 
 /* ---- device-resident synthetic vector environment (on-policy agents; A2C_agent.py:26-34, PPO_agent.py:33-47): the uint8
  * [n_env][history][84*84] observations of one rollout step from per-environment frame counters / episode ages / stream

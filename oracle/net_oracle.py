@@ -66,6 +66,50 @@ def quantile_head(p, phi, action_dim, num_quantiles):
     return F.linear(phi, p["fc_quantiles.weight"], p["fc_quantiles.bias"]).view(-1, action_dim, num_quantiles)
 
 
+def dueling_head(p, phi):
+    """deep_rl/network/network_heads.py:32-37: q = value + (advantage - mean_a advantage)."""
+    value = F.linear(phi, p["fc_value.weight"], p["fc_value.bias"])
+    adv = F.linear(phi, p["fc_advantage.weight"], p["fc_advantage.bias"])
+    return value.expand_as(adv) + (adv - adv.mean(1, keepdim=True).expand_as(adv))
+
+
+def transform_noise(x):
+    """deep_rl/network/network_utils.py:82-83: f(e) = sign(e) sqrt|e|."""
+    return x.sign().mul(x.abs().sqrt())
+
+
+def noisy_epsilon(noise_in, noise_out_weight, noise_out_bias):
+    """deep_rl/network/network_utils.py:78-80: (weight_epsilon, bias_epsilon) from the three drawn vectors."""
+    return transform_noise(noise_out_weight).ger(transform_noise(noise_in)), transform_noise(noise_out_bias)
+
+
+def noisy_linear(p, x, prefix, training=True):
+    """deep_rl/network/network_utils.py:54-62: W = mu + sigma * eps (training) or mu (evaluation)."""
+    if training:
+        w = p[prefix + "weight_mu"] + p[prefix + "weight_sigma"].mul(p[prefix + "weight_epsilon"])
+        b = p[prefix + "bias_mu"] + p[prefix + "bias_sigma"].mul(p[prefix + "bias_epsilon"])
+    else:
+        w, b = p[prefix + "weight_mu"], p[prefix + "bias_mu"]
+    return F.linear(x, w, b)
+
+
+def nature_conv_body_noisy(p, x, training=True, prefix="body."):
+    """deep_rl/network/network_bodies.py:27-33 with fc4 = NoisyLinear (noisy_linear=True, :21-24)."""
+    y = F.relu(F.conv2d(x, p[prefix + "conv1.weight"], p[prefix + "conv1.bias"], stride=4))
+    y = F.relu(F.conv2d(y, p[prefix + "conv2.weight"], p[prefix + "conv2.bias"], stride=2))
+    y = F.relu(F.conv2d(y, p[prefix + "conv3.weight"], p[prefix + "conv3.bias"], stride=1))
+    return F.relu(noisy_linear(p, y.reshape(y.size(0), -1), prefix + "fc4.", training))
+
+
+def rainbow_head(p, phi, action_dim, num_atoms, training=True):
+    """deep_rl/network/network_heads.py:78-86 with NoisyLinear heads: (prob, log_prob) [B,A,N] of
+    value + (advantage - mean_a advantage)."""
+    value = noisy_linear(p, phi, "fc_value.", training).view(-1, 1, num_atoms)
+    adv = noisy_linear(p, phi, "fc_advantage.", training).view(-1, action_dim, num_atoms)
+    q = value + (adv - adv.mean(1, keepdim=True))
+    return F.softmax(q, dim=-1), F.log_softmax(q, dim=-1)
+
+
 def clip_grad_norm(grads, max_norm):
     """torch.nn.utils.clip_grad_norm_ (call site DQN_agent.py:132): global L2 norm
     over all grads (per-tensor 2-norms, then the 2-norm of those, as torch does);

@@ -849,9 +849,123 @@ def gen_pixel_onpolicy():
     save("pixel_onpolicy", **out)
 
 
+# --------------------------------------------------------------------------- Dueling / Rainbow heads + NoisyLinear (f4; config 4's
+# rainbow_pixel network, examples.py:283-336)
+def gen_rainbow_dueling():
+    """DuelingNet / RainbowNet(NoisyLinear) of the reference (network_heads.py:24-37,57-86, network_utils.py:31-83) over
+    NatureConvBody: (i) module level -- outputs and parameter gradients of a fixed linear functional on a seeded uint8
+    batch, the noise vectors the reference's own reset_noise() draws from torch's CPU generator; (ii) agent level --
+    CategoricalDQNAgent with rainbow_pixel's settings (noisy layers, PrioritizedReplay, double Q, Adam 6.25e-4 / 1.5e-4,
+    clip 10) and DQNAgent over DuelingNet on the synthetic Atari stream: parameters after every update, replay
+    bookkeeping, priority tree, RNG positions."""
+    from golden.make_golden_cases import (DUELING_SHAPES, RAINBOW_SHAPES, NOISY_LAYERS, NOISE_BUFFERS, HEAD_AGENT_CASES,
+                                          head_inputs)
+    out = {}
+    ref.Config.NOISY_LAYER_STD = 0.5
+    x, wq, wl = head_inputs()
+    xn = ref.ImageNormalizer()(x)
+    # ---- module level: DuelingNet
+    net = ref.DuelingNet(4, ref.NatureConvBody())
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in fake_envs.numpy_params(DUELING_SHAPES, 31).items()})
+    q = net(xn)["q"]
+    (q * torch.from_numpy(wq)).sum().backward()
+    out["dueling_q"] = q.detach().numpy()
+    for n, prm in net.named_parameters():
+        out["dueling_grad_" + n] = digest(prm.grad.numpy())
+    # ---- module level: RainbowNet with noisy layers
+    torch.manual_seed(9)
+    net = ref.RainbowNet(4, 51, ref.NatureConvBody(noisy_linear=True), noisy_linear=True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in fake_envs.numpy_params(RAINBOW_SHAPES, 33).items()}, strict=False)
+    torch.manual_seed(11)
+    net.reset_noise()                         # the reference's own draws (fc_value, fc_advantage, body.fc4: network_heads.py:72-76)
+    sd = net.state_dict()
+    for layer in NOISY_LAYERS:
+        for b in NOISE_BUFFERS:
+            out["rainbow_%s.%s" % (layer, b)] = sd["%s.%s" % (layer, b)].numpy().copy()
+        out["rainbow_%s.weight_sigma0" % layer] = sd[layer + ".weight_sigma"].numpy().reshape(-1)[:1].copy()
+        out["rainbow_%s.bias_sigma0" % layer] = sd[layer + ".bias_sigma"].numpy().reshape(-1)[:1].copy()
+        out["rainbow_%s.weight_epsilon" % layer] = digest(sd[layer + ".weight_epsilon"].numpy())
+    net.train()
+    o = net(xn)
+    (o["log_prob"] * torch.from_numpy(wl)).sum().backward()
+    out["rainbow_prob"], out["rainbow_log_prob"] = o["prob"].detach().numpy(), o["log_prob"].detach().numpy()
+    for n, prm in net.named_parameters():
+        out["rainbow_grad_" + n] = digest(prm.grad.numpy())
+    net.eval()
+    with torch.no_grad():
+        out["rainbow_prob_eval"] = net(xn)["prob"].numpy()
+    # ---- agent level
+    restore = _quiet_logger()
+    try:
+        for tag, steps in HEAD_AGENT_CASES:
+            cfg = ref.Config()
+            rainbow = tag == "rainbow"
+            replay_cls = ref.PrioritizedReplay if rainbow else ref.UniformReplay
+            cfg.merge(dict(game="fake", n_step=1, replay_cls=replay_cls, async_replay=False, log_level=0, tag=tag,
+                           noisy_linear=rainbow))
+            cfg.task_fn = lambda: _RefPixelTask(seed=7, done_period=8)
+            cfg.eval_env = cfg.task_fn()
+            if rainbow:
+                cfg.optimizer_fn = lambda p: torch.optim.Adam(p, lr=0.000625, eps=1.5e-4)
+                cfg.categorical_v_max, cfg.categorical_v_min, cfg.categorical_n_atoms = 10, -10, 51
+                cfg.network_fn = lambda: ref.RainbowNet(cfg.action_dim, cfg.categorical_n_atoms,
+                                                        ref.NatureConvBody(noisy_linear=True), noisy_linear=True)
+                cls, shapes, seed = ref.CategoricalDQNAgent, RAINBOW_SHAPES, 35
+            else:
+                cfg.optimizer_fn = lambda p: torch.optim.RMSprop(p, lr=0.00025, alpha=0.95, eps=0.01, centered=True)
+                cfg.network_fn = lambda: ref.DuelingNet(cfg.action_dim, ref.NatureConvBody())
+                cls, shapes, seed = ref.DQNAgent, DUELING_SHAPES, 37
+            cfg.random_action_prob = ref.LinearSchedule(1.0, 0.05, 60)
+            cfg.batch_size, cfg.discount, cfg.history_length = 32, 0.99, 4
+            kw = dict(memory_size=500, batch_size=32, n_step=1, discount=0.99, history_length=4)
+            cfg.replay_fn = lambda: ref.ReplayWrapper(cfg.replay_cls, kw, cfg.async_replay)
+            cfg.replay_eps, cfg.replay_alpha = 0.01, 0.5
+            cfg.replay_beta = ref.LinearSchedule(0.4, 1.0, 1000)
+            cfg.state_normalizer, cfg.reward_normalizer = ref.ImageNormalizer(), ref.SignNormalizer()
+            cfg.target_network_update_freq, cfg.exploration_steps, cfg.sgd_update_frequency = 3, 40, 4
+            cfg.gradient_clip, cfg.double_q, cfg.async_actor, cfg.max_steps = (10 if rainbow else 5), rainbow, False, 1e5
+            ref.random_seed(3)
+            random.seed(3)
+            agent = cls(cfg)
+            p_np = {k: torch.from_numpy(v) for k, v in fake_envs.numpy_params(shapes, seed).items()}
+            agent.network.load_state_dict(p_np, strict=False)
+            agent.target_network.load_state_dict(agent.network.state_dict())
+            torch.manual_seed(5)               # from here on torch's CPU generator only feeds reset_noise()
+            traj_steps, traj, actions = [], [], []
+            prev = trajectory_digest(dict(agent.network.named_parameters()))
+            for t in range(steps):
+                agent.step()
+                cur = trajectory_digest(dict(agent.network.named_parameters()))
+                if not np.array_equal(cur, prev):
+                    traj_steps.append(t)
+                    traj.append(cur)
+                prev = cur
+            k = tag + "_"
+            rp = agent.replay.replay
+            n = rp.size()
+            out[k + "update_steps"] = np.asarray(traj_steps, dtype=np.int64)
+            out[k + "update_digests"] = np.stack(traj)
+            out[k + "total_steps"] = np.asarray(agent.total_steps)
+            out[k + "pos_size"] = np.asarray([rp.pos, n])
+            out[k + "replay_action"] = np.asarray(rp.action[:n]).reshape(-1).astype(np.int64)
+            out[k + "replay_reward"] = np.asarray(rp.reward[:n], dtype=np.float64).reshape(-1)
+            out[k + "replay_mask"] = np.asarray(rp.mask[:n]).reshape(-1).astype(np.int32)
+            if rainbow:
+                out[k + "tree"] = np.asarray(rp.tree.tree, dtype=np.float64)
+                out[k + "max_priority"] = np.asarray(float(rp.max_priority))
+                out[k + "torch_rng_tail"] = torch.randint(0, 1 << 30, (4,)).numpy()
+            for name, v in agent.network.named_parameters():
+                out[k + "final_" + name] = digest(v.detach().numpy())
+            out[k + "np_rng_tail"] = np.random.randint(0, 1 << 30, size=4)
+            out[k + "py_rng_tail"] = np.asarray([random.getrandbits(30) for _ in range(2)], dtype=np.int64)
+    finally:
+        restore()
+    save("rainbow_dueling", **out)
+
+
 GENERATORS = [gen_uniform, gen_prioritized, gen_sumtree, gen_dqn_loss, gen_c51_loss, gen_qr_loss,
               gen_dqn_nature_update, gen_optim, gen_a2c, gen_ppo, gen_ppo_loss, gen_dqn_agent_cartpole, gen_ddpg_td3, gen_option_critic,
-              gen_pixel_agents, gen_pixel_onpolicy]
+              gen_pixel_agents, gen_pixel_onpolicy, gen_rainbow_dueling]
 
 if __name__ == "__main__":
     only = sys.argv[1:]

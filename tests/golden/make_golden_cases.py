@@ -35,6 +35,32 @@ PIXEL_AGENT_CASES = [   # tag, agent, replay, n_step, done_period, agent steps
     ("qr_n3", "qr", "uniform", 3, 11, 22),
 ]
 
+# Dueling / Rainbow heads (network_heads.py:24-37,57-86; NoisyLinear network_utils.py:31-83): tensors the fixtures load from
+# tests/fake_envs.numpy_params (strict=False for the noisy layers: their sigmas keep the constructor's constants)
+_CONV = [("body.conv1.weight", (32, 4, 8, 8)), ("body.conv1.bias", (32,)), ("body.conv2.weight", (64, 32, 4, 4)),
+         ("body.conv2.bias", (64,)), ("body.conv3.weight", (64, 64, 3, 3)), ("body.conv3.bias", (64,))]
+DUELING_SHAPES = _CONV + [("body.fc4.weight", (512, 3136)), ("body.fc4.bias", (512,)), ("fc_value.weight", (1, 512)),
+                          ("fc_value.bias", (1,)), ("fc_advantage.weight", (4, 512)), ("fc_advantage.bias", (4,))]
+RAINBOW_SHAPES = _CONV + [("body.fc4.weight_mu", (512, 3136)), ("body.fc4.bias_mu", (512,)),
+                          ("fc_value.weight_mu", (51, 512)), ("fc_value.bias_mu", (51,)),
+                          ("fc_advantage.weight_mu", (4 * 51, 512)), ("fc_advantage.bias_mu", (4 * 51,))]
+NOISY_LAYERS = ("body.fc4", "fc_value", "fc_advantage")
+NOISE_BUFFERS = ("noise_in", "noise_out_weight", "noise_out_bias")
+
+
+def head_inputs():
+    """Seeded inputs of the module-level Dueling / Rainbow fixtures: uint8 batch [5,4,84,84] and the weights of the two
+    linear functionals whose gradients are compared."""
+    rs = np.random.RandomState(41)
+    x = rs.randint(0, 256, size=(5, 4, 84, 84)).astype(np.uint8)
+    return x, rs.standard_normal((5, 4)).astype(np.float32), rs.standard_normal((5, 4, 51)).astype(np.float32)
+
+
+HEAD_AGENT_CASES = [   # tag, agent steps: rainbow_pixel's agent (examples.py:283-336) and DQNAgent over DuelingNet
+    ("rainbow", 24),
+    ("dueling", 22),
+]
+
 
 def trajectory_digest(state_dict, stride=4099):
     """Every `stride`-th element of every tensor of a state dict (fp32, in state-dict order): small enough to keep per

@@ -212,6 +212,27 @@ def test_network_modules_have_the_reference_names_and_initial_values(ref):
             assert torch.equal(mine[k].cpu(), want[k]), k
 
 
+def test_noisy_layers_draw_their_noise_like_the_reference(ref):
+    """NoisyLinear.reset_noise / RainbowNet.reset_noise (network_utils.py:73-80, network_heads.py:72-76): same generator
+    words, same layer order, same factorised epsilon as the reference's modules, and the generator ends at the same place."""
+    import deeprl_amd as d
+    d.select_device(-1)
+    d.Config.NOISY_LAYER_STD = ref.Config.NOISY_LAYER_STD = 0.5
+    tails = []
+    dicts = []
+    for lib in (d, ref):
+        torch.manual_seed(2)
+        net = lib.RainbowNet(3, 5, lib.FCBody(4, (8,), noisy_linear=True), True)
+        for _ in range(3):
+            net.reset_noise()
+        dicts.append(net.state_dict())
+        tails.append(torch.rand(3))
+    assert list(dicts[0]) == list(dicts[1])
+    for k in dicts[1]:
+        assert torch.equal(dicts[0][k], dicts[1][k]), k
+    assert torch.equal(tails[0], tails[1])
+
+
 def test_random_processes_consume_np_random_like_the_reference(ref):
     import deeprl_amd as d
     for name in ("OrnsteinUhlenbeckProcess", "GaussianProcess"):

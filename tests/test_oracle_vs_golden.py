@@ -266,6 +266,48 @@ def test_dqn_nature_update(golden):
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
 
 
+def test_dueling_rainbow_heads(golden):
+    """oracle/net_oracle.py's DuelingNet / RainbowNet + NoisyLinear restatements against the reference's own modules
+    (tests/golden/rainbow_dueling.npz: outputs, gradient digests, and the noise the reference's reset_noise() drew)."""
+    import math
+    import fake_envs
+    from golden.make_golden_cases import DUELING_SHAPES, RAINBOW_SHAPES, NOISY_LAYERS, digest, head_inputs
+    g = golden("rainbow_dueling")
+    x, wq, wl = head_inputs()
+    xn = torch.from_numpy(NUM.image_normalize_sync(x))
+    # Dueling
+    p = {k: torch.from_numpy(v).requires_grad_() for k, v in fake_envs.numpy_params(DUELING_SHAPES, 31).items()}
+    q = N.dueling_head(p, N.nature_conv_body(p, xn))
+    np.testing.assert_allclose(q.detach().numpy(), g["dueling_q"], rtol=1e-5, atol=1e-6)
+    (q * torch.from_numpy(wq)).sum().backward()
+    for n, v in p.items():
+        np.testing.assert_allclose(digest(v.grad.numpy()), g["dueling_grad_" + n], rtol=1e-4, atol=1e-5, err_msg=n)
+    # Rainbow: mu from the seeded generator, sigma the constructor's constant, epsilon from the reference's noise vectors
+    p = {k: torch.from_numpy(v) for k, v in fake_envs.numpy_params(RAINBOW_SHAPES, 33).items()}
+    for layer in NOISY_LAYERS:
+        fan_in, fan_out = p[layer + ".weight_mu"].shape[1], p[layer + ".weight_mu"].shape[0]
+        p[layer + ".weight_sigma"] = torch.full((fan_out, fan_in), 0.4 / math.sqrt(fan_in))
+        p[layer + ".bias_sigma"] = torch.full((fan_out,), 0.4 / math.sqrt(fan_out))
+        assert p[layer + ".weight_sigma"][0, 0].item() == g["rainbow_%s.weight_sigma0" % layer][0]
+        assert p[layer + ".bias_sigma"][0].item() == g["rainbow_%s.bias_sigma0" % layer][0]
+        we, be = N.noisy_epsilon(*[torch.from_numpy(g["rainbow_%s.%s" % (layer, b)])
+                                     for b in ("noise_in", "noise_out_weight", "noise_out_bias")])
+        assert np.array_equal(digest(we.numpy()), g["rainbow_%s.weight_epsilon" % layer])
+        p[layer + ".weight_epsilon"], p[layer + ".bias_epsilon"] = we, be
+    leaves = [k for k in p if not k.endswith("epsilon")]
+    for k in leaves:
+        p[k].requires_grad_()
+    prob, log_prob = N.rainbow_head(p, N.nature_conv_body_noisy(p, xn), 4, 51)
+    np.testing.assert_allclose(prob.detach().numpy(), g["rainbow_prob"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(log_prob.detach().numpy(), g["rainbow_log_prob"], rtol=1e-5, atol=1e-6)
+    (log_prob * torch.from_numpy(wl)).sum().backward()
+    for k in leaves:
+        np.testing.assert_allclose(digest(p[k].grad.numpy()), g["rainbow_grad_" + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    with torch.no_grad():
+        prob_eval, _ = N.rainbow_head(p, N.nature_conv_body_noisy(p, xn, training=False), 4, 51, training=False)
+    np.testing.assert_allclose(prob_eval.numpy(), g["rainbow_prob_eval"], rtol=1e-5, atol=1e-7)
+
+
 def test_image_lut_matches_reference_numerics():
     lut = NUM.image_lut()
     assert lut.dtype == np.float32 and lut.shape == (256,)
