@@ -126,8 +126,8 @@ class AsyncDqnScheduleOracle:
         idx = draw_uniform_indices(self.rep.size(), self.rep.pos, self.batch, 4, 1)
         return idx, self.rep.gather(idx)
 
-    def _update_dist(self, batch):
-        """One update of a distributional head: per-sample loss vector, its mean, clipped gradients, Adam."""
+    def _update_dist(self, batch, weights=None):
+        """One update of a distributional head: per-sample loss vector, its (importance-weighted) mean, clipped gradients, Adam."""
         st, ac, rw, ns, mk = batch
         p, pt = self.p, self.pt
         x = torch.from_numpy(NUM.image_normalize_sync(st))
@@ -147,7 +147,7 @@ class AsyncDqnScheduleOracle:
             quant = N.quantile_head(p, phi, self.A, self.n_atoms)
             vec = L.qr_loss(quant, qn, a_t, r_t, m_t, self.gamma)
             out = quant.mean(-1)
-        loss = vec.mean()
+        loss = vec.mean() if weights is None else vec.mul(weights).mean()      # DQN_agent.py:126-128
         grads = torch.autograd.grad(loss, [p[k] for k in self.names])
         norm, grads = N.clip_grad_norm(list(grads), self.clip)
         self.opt_step += 1
@@ -160,9 +160,11 @@ class AsyncDqnScheduleOracle:
         self.losses.append(loss)
         return loss, vec.detach().numpy(), out.detach().numpy(), float(norm)
 
-    def update(self, batch):
+    def update(self, batch, weights=None):
+        """weights: importance weights of a prioritized minibatch (DQN_agent.py:124-127), applied to the per-sample loss
+        vector before the mean; the returned TD errors / loss vector are the PRE-weight ones (what the priorities use)."""
         if self.head != "vanilla":
-            return self._update_dist(batch)
+            return self._update_dist(batch, weights)
         st, ac, rw, ns, mk = batch
         p, pt = self.p, self.pt
         x = torch.from_numpy(NUM.image_normalize_sync(st))
@@ -174,7 +176,7 @@ class AsyncDqnScheduleOracle:
         q = N.vanilla_head(p, phi)
         delta = L.dqn_td_error(q, qn, torch.from_numpy(ac), torch.from_numpy(rw.astype(np.float32)),
                                torch.from_numpy(mk.astype(np.float32)), self.gamma, q_next_online=qno)
-        loss = L.dqn_reduce(delta)
+        loss = L.dqn_reduce(delta) if weights is None else delta.pow(2).mul(0.5).mul(weights).mean()
         grads = torch.autograd.grad(loss, [p[k] for k in self.names])
         norm, grads = N.clip_grad_norm(list(grads), self.clip)
         with torch.no_grad():
@@ -185,3 +187,132 @@ class AsyncDqnScheduleOracle:
         loss = float(loss.detach())
         self.losses.append(loss)
         return loss, delta.detach().numpy(), q.detach().numpy(), float(norm)
+
+
+class _SyntheticAtariOracle:
+    """The synthetic Atari emulator behind DummyVecEnv's auto-reset (the stand-in for envs.py:126-150 + a real game): frame
+    k = counter hash (synth_transitions), reset() = ONE new frame repeated `history` times, step() hashes (reward, done) from
+    the counter of the frame it then generates; after a terminal step the post-step frame is dropped and the stack restarts."""
+
+    def __init__(self, seed, done_period, history=4, n_actions=4):
+        self.seed, self.done_period, self.history, self.A = seed, done_period, history, n_actions
+        self.counter = 0
+        self.frames = None
+
+    def _frame(self):
+        f = synth_transitions(self.counter, 1, 7056, seed=self.seed, n_actions=self.A, done_period=self.done_period)[0][0]
+        self.counter += 1
+        return f.reshape(84, 84)
+
+    def reset(self):
+        self.frames = [self._frame()] * self.history
+        return np.stack(self.frames)
+
+    def step(self):
+        _, _, rew, msk = synth_transitions(self.counter, 1, 7056, seed=self.seed, n_actions=self.A, done_period=self.done_period)
+        self.frames = self.frames[1:] + [self._frame()]
+        done = msk[0] == 0
+        if done:
+            self.reset()
+        return np.stack(self.frames), float(rew[0]), bool(done)
+
+
+class AsyncPerAgentScheduleOracle(AsyncDqnScheduleOracle):
+    """The async pipeline WITH PrioritizedReplay, at agent level (DQN_agent.py:101-138 with replay.py:152-196 and
+    sum_tree.py; round 4 -- until then async + PER was pinned to the in-order path with epsilon = 1 only).  The schedule
+    csrc/learner.hip + replay.DeviceDraw fix, per agent step k (the actor runs one agent step ahead):
+
+        report       the 4 transitions actor(k) produced: ring slots, then tree.add(max_priority) each   (replay.py:160-162)
+        if total_steps > exploration_steps:
+            draw_k   stratified random.uniform descent, valid_index filter, random.choice padding     (replay.py:164-186)
+            batch_k  gathered BEFORE actor(k+1) overwrites the oldest slots
+        actor(k+1)   on theta_k (= after updates .. k-1): stale by one update, q-dependent actions when dice >= epsilon
+        if updating: theta_{k+1} = update(theta_k, batch_k) with importance weights (beta schedule, one inc per update);
+                     update_priorities(tree_idx_k, (|loss_vec| + eps)^alpha)  -- max_priority first, first writer wins
+        target sync  when total_steps / sgd_update_frequency % target_network_update_freq == 0         (DQN_agent.py:136-138)
+
+    i.e. tree order per update: priorities k -> adds of actor(k+1) -> draw k+1, exactly the in-order order; what differs from
+    the in-order run is WHICH parameters the actor saw.  The device computes priorities from ITS fp32 loss vector; a checker
+    that wants the tree bit for bit passes those back through `override_priorities` (and compares them with the oracle's own
+    at the loss tolerance)."""
+
+    def __init__(self, params, cap, batch, env_seed, done_period, actor_rs, epsilon_fn, beta_fn, exploration_steps,
+                 target_freq, sgd_update_frequency=4, replay_eps=0.01, replay_alpha=0.5, n_actions=4, **kw):
+        from .replay_oracle import PrioritizedReplayOracle
+        kw.setdefault("seed", env_seed)
+        AsyncDqnScheduleOracle.__init__(self, params, params, 8, batch, n_actions=n_actions, done_period=done_period, **kw)
+        self.cap = cap
+        self.rep = PrioritizedReplayOracle(cap, batch, 1, self.gamma, 4)
+        self.env = _SyntheticAtariOracle(env_seed, done_period, 4, n_actions)
+        self.obs = None
+        self.actor_rs, self.epsilon_fn, self.beta_fn = actor_rs, epsilon_fn, beta_fn
+        self.exploration_steps, self.target_freq, self.freq = exploration_steps, target_freq, sgd_update_frequency
+        self.replay_eps, self.replay_alpha = replay_eps, replay_alpha
+        self.total_steps = 0
+        self.ahead = None              # transitions of the actor launch not yet reported
+        self.actions, self.q_gaps, self.losses = [], [], []
+
+    def actor_step(self, theta, override_actions=None):
+        """4 transitions on `theta` (DQN_agent.py:24-45): held back until report()."""
+        out, held = [], []
+        for e in range(self.freq):
+            if self.obs is None:
+                self.obs = self.env.reset()
+            eps = self.epsilon_fn()
+            ra = int(self.actor_rs.randint(self.A, size=1)[0])
+            dice = float(self.actor_rs.rand(1)[0])
+            x = torch.from_numpy(NUM.image_normalize_sync(self.obs[None]))
+            with torch.no_grad():
+                q = self._action_values(theta, N.nature_conv_body(theta, x)).numpy()[0]
+            srt = np.sort(q)
+            rnd = dice < eps
+            action = ra if rnd else int(np.argmax(q))
+            if not rnd:
+                self.q_gaps.append(float(srt[-1] - srt[-2]))
+            stored = action if override_actions is None else int(override_actions[e])
+            nxt, reward, done = self.env.step()
+            held.append((self.obs[-1].copy(), np.int64(stored), float(np.sign(reward)), np.int32(0 if done else 1)))
+            self.obs = nxt
+            out.append((action, float(srt[-1] - srt[-2]), rnd))
+            self.actions.append(action)
+        self.ahead = held
+        return out
+
+    def report(self):
+        """The agent step's accounting of the transitions produced one call earlier: replay feed (ring + tree add)."""
+        for frame, action, reward, mask in self.ahead:
+            self.rep.feed_one(frame, action, reward, mask)
+            self.total_steps += 1
+        self.ahead = None
+        return self.total_steps > self.exploration_steps
+
+    def draw(self):
+        tree_idx, prob, data_idx = self.rep.draw()
+        return tree_idx, prob, data_idx, self.rep.gather(data_idx)
+
+    def weights(self, prob, beta):
+        """DQN_agent.py:124-126 in fp32: (p * B + 1e-6)^-beta / max."""
+        sp = torch.from_numpy(np.asarray(prob, dtype=np.float32))
+        w = sp.mul(sp.size(0)).add(1e-6).pow(-beta)
+        return w / w.max()
+
+    def priorities(self, loss_vec):
+        """DQN_agent.py:121: (|loss| + replay_eps)^replay_alpha on the PRE-weight per-sample loss, fp32."""
+        return torch.from_numpy(np.asarray(loss_vec, dtype=np.float32)).abs().add(self.replay_eps).pow(self.replay_alpha).numpy()
+
+    def learn(self, tree_idx, prob, batch, override_priorities=None):
+        """update + update_priorities; returns (loss, pre-weight loss vector, own priorities, weights)."""
+        w = self.weights(prob, self.beta_fn())
+        loss, vec, out, norm = self.update(batch, weights=w)
+        if self.head == "vanilla":
+            vec = 0.5 * np.square(vec.astype(np.float32))        # DQN_agent.py:99: the loss vector is 0.5 * delta^2
+        prio = self.priorities(vec)
+        use = prio if override_priorities is None else np.asarray(override_priorities, dtype=np.float32)
+        self.rep.update_priorities(zip(tree_idx.tolist(), [float(v) for v in use]))
+        return loss, vec, prio, w.numpy()
+
+    def maybe_sync_target(self):
+        if self.total_steps / self.freq % self.target_freq == 0:
+            self.pt = {k: v.detach().clone() for k, v in self.p.items()}
+            return True
+        return False

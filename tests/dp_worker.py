@@ -64,7 +64,22 @@ def main():
     if world > 1 and os.environ.get("DP_WORKER_RANK_SEEDS"):
         np.savez(out + ".rank%d.npz" % dd.rank(), **{k: v.detach().cpu().numpy() for k, v in agent.network.state_dict().items()})
     if dd.rank() == 0:
-        np.savez(out, total_steps=agent.total_steps, **{k: v.detach().cpu().numpy() for k, v in agent.network.state_dict().items()})
+        extra = {}
+        fused = getattr(agent, "_fused", None)
+        if kind == "ppo" and fused is not None and fused.kind == "adam":
+            # Adam's second-moment estimate per element (the test's error bound is stated in terms of it) + the step count
+            names = {id(p): n for n, p in agent.network.named_parameters()}
+            for p, o in zip(fused.flat.params, fused.flat.offsets):
+                v = fused.state2[o:o + p.numel()]
+                if p.dim() == 4 and not p.data.is_contiguous():          # KOC storage [(c,kh,kw)][oc] (optim.FlatParams)
+                    oc, c, kh, kw = p.shape
+                    v = v.view(c, kh, kw, oc).permute(3, 0, 1, 2)
+                else:
+                    v = v.view(p.shape)
+                extra["__adam_v." + names[id(p)]] = v.detach().cpu().numpy()
+            extra["__adam_steps"] = np.asarray(fused.steps)
+        np.savez(out, total_steps=agent.total_steps, **extra,
+                 **{k: v.detach().cpu().numpy() for k, v in agent.network.state_dict().items()})
     agent.close()
     if world > 1:
         import torch.distributed as dist

@@ -43,17 +43,30 @@ def test_two_ranks_equal_one_process(tmp_path, kind, port):
     two = _run(kind, str(tmp_path / "two.npz"), 2, port)
     assert int(one["total_steps"]) == int(two["total_steps"]) > 0      # both count GLOBAL environment steps
     moved = 0.0
+    from parity_log import record_parity
+    steps = int(one["__adam_steps"]) if "__adam_steps" in one else 0
     for k in one:
-        if k == "total_steps":
+        if k == "total_steps" or k.startswith("__adam"):
             continue
         # rtol 1e-5 / atol 2e-6 absolute on O(0.05) weights: the two runs differ only in how the batch sum is split.
-        # PPO's Adam (eps 1e-8) turns a gradient element of ANY size into a step of about lr = 2.5e-4, so an element whose
-        # gradient is itself summation noise moves by a noise-dependent amount: a few elements per tensor may differ by a
-        # fraction of lr after the run's 24 Adam steps (measured: 4 of 2048 in fc_action.weight, up to 1.6e-5).
         err = np.abs(two[k] - one[k])
-        bad = err > 2e-6 + 1e-5 * np.abs(one[k])
-        limit = 0.0 if kind == "a2c" else 0.005
-        assert bad.mean() <= limit and err.max() < 1e-4, "%s: %d of %d elements off, max %g" % (k, bad.sum(), bad.size, err.max())
+        allowed = 2e-6 + 1e-5 * np.abs(one[k])
+        if kind == "ppo":
+            # Adam (eps 1e-8, examples.py:534) normalises every gradient element by its own RMS: u = lr * m / (sqrt(v) + eps).
+            # A gradient element that differs by the contraction noise e_g between the two runs moves the update by
+            # lr * e_g / sqrt(v_i) to first order -- negligible where |g_i| >> e_g, a whole step of lr where the element IS
+            # noise.  With e_g = 1e-5 of the tensor's largest gradient RMS (the contraction bar of test_gpu_kernels.py),
+            # S Adam steps and a factor 4 for the second-order terms (v and the later gradients see the perturbation too):
+            #     |dp_i| <= 2e-6 + 1e-5 |p_i| + 4 S lr min(1, e_g / sqrt(v_i))
+            # v_i = the bias-corrected second-moment estimate the single-process run ends with (written by dp_worker.py).
+            v = one["__adam_v." + k] / (1.0 - 0.999 ** steps)
+            rms = np.sqrt(np.maximum(v, 0.0))
+            e_g = 1e-5 * float(rms.max())
+            allowed = allowed + 4.0 * steps * 2.5e-4 * np.minimum(1.0, e_g / np.maximum(rms, 1e-30))
+        ratio = float((err / allowed).max())
+        record_parity("data_parallel %s %s" % (kind, k), err_max=float(err.max()), err_over_allowed=ratio,
+                      frac_over_plain=float((err > 2e-6 + 1e-5 * np.abs(one[k])).mean()))
+        assert ratio <= 1.0, "%s: max error %.3g = %.2f of the per-element bound" % (k, err.max(), ratio)
         moved = max(moved, float(np.abs(one[k]).max()))
     assert moved > 0
 

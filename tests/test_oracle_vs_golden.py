@@ -308,6 +308,84 @@ def test_dueling_rainbow_heads(golden):
     np.testing.assert_allclose(prob_eval.numpy(), g["rainbow_prob_eval"], rtol=1e-5, atol=1e-7)
 
 
+class _LinearSchedule:
+    """deep_rl/utils/schedule.py:16-31 (restated here so the oracle test does not lean on the product's copy)."""
+
+    def __init__(self, start, end=None, steps=None):
+        if end is None:
+            end, steps = start, 1
+        self.inc = (end - start) / float(steps)
+        self.current, self.end = start, end
+        self.bound = min if end > start else max
+
+    def __call__(self, steps=1):
+        val = self.current
+        self.current = self.bound(self.current + self.inc * steps, self.end)
+        return val
+
+
+def test_per_agent_schedule_oracle_in_order_equals_reference_run(golden):
+    """oracle/async_schedule_oracle.py::AsyncPerAgentScheduleOracle (the prioritized-replay schedule oracle of round 4) driven
+    IN ORDER -- actor(k) on the current parameters, report, draw, learn, target sync -- must reproduce the run of the
+    reference's own CategoricalDQNAgent + PrioritizedReplay (tests/golden/pixel_agents.npz, case c51_per): every stored
+    transition, the priority tree, max_priority, the parameters after every update and the positions of numpy's and python's
+    generators.  That pins everything in the class except the one thing the async pipeline defines -- WHICH parameters the
+    actor sees (one update staler) -- which is a two-line difference in the driver (tests/test_gpu_agents.py)."""
+    import zlib
+    import fake_envs
+    from golden.make_golden_cases import PIXEL_AGENT_CASES, trajectory_digest
+    from oracle.async_schedule_oracle import AsyncPerAgentScheduleOracle
+    g = golden("pixel_agents")
+    tag, kind, rep, n_step, done_period, steps = [c for c in PIXEL_AGENT_CASES if c[0] == "c51_per"][0]
+    k = tag + "_"
+    np_state, py_state = np.random.get_state(), random.getstate()
+    try:
+        np.random.seed(3)
+        np.random.randint(int(1e6))         # random_seed(3), torch_utils.py:36-38: the torch seed is drawn from the numpy stream
+        random.seed(3)
+        shapes = fake_envs.NATURE_SHAPES + [("fc_categorical.weight", (4 * 51, 512)), ("fc_categorical.bias", (4 * 51,))]
+        p_np = fake_envs.numpy_params(shapes, 17)
+        sched = _LinearSchedule(1.0, 0.05, 60)
+        actor_steps = [0]
+
+        def epsilon():                      # DQN_agent.py:34-39
+            eps = 1 if actor_steps[0] < 40 else sched()
+            actor_steps[0] += 1
+            return eps
+
+        orc = AsyncPerAgentScheduleOracle(p_np, 500, 32, env_seed=7, done_period=done_period, actor_rs=np.random,
+                                          epsilon_fn=epsilon, beta_fn=_LinearSchedule(0.4, 1.0, 1000), exploration_steps=40,
+                                          target_freq=3, head="c51", clip=5.0, lr=0.00025, eps=0.01 / 32)
+        # state_dict order of the reference's CategoricalNet: fc_categorical first, then the body
+        order = ["fc_categorical.weight", "fc_categorical.bias"] + [n for n, _ in fake_envs.NATURE_SHAPES]
+        traj = []
+        for t in range(steps):
+            orc.actor_step(orc.p)                                    # in order: the CURRENT parameters
+            if orc.report():
+                tree_idx, prob, data_idx, batch = orc.draw()
+                orc.learn(tree_idx, prob, batch)
+                traj.append(trajectory_digest({n: orc.p[n] for n in order}))
+            orc.maybe_sync_target()
+        want_steps = list(g[k + "update_steps"])
+        assert len(traj) == len(want_steps) == steps - want_steps[0]
+        rp = orc.rep
+        n = rp.size()
+        assert orc.total_steps == int(g[k + "total_steps"]) and [rp.pos, n] == list(g[k + "pos_size"])
+        assert np.array_equal(rp.action[:n].reshape(-1), g[k + "replay_action"])
+        assert np.array_equal(rp.reward[:n], g[k + "replay_reward"]) and np.array_equal(rp.mask[:n], g[k + "replay_mask"])
+        crc = np.asarray([zlib.crc32(np.ascontiguousarray(f).tobytes()) for f in rp.state[:n]], dtype=np.int64)
+        assert np.array_equal(crc, g[k + "replay_frame_crc"])
+        assert np.array_equal(np.random.randint(0, 1 << 30, size=4), g[k + "np_rng_tail"])
+        assert np.array_equal([random.getrandbits(30) for _ in range(2)], g[k + "py_rng_tail"])
+        np.testing.assert_allclose(rp.tree.tree, g[k + "tree"], rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(float(rp.max_priority), float(g[k + "max_priority"]), rtol=2e-5)
+        for i, (a, b) in enumerate(zip(traj, g[k + "update_digests"])):      # the parameters after EVERY update
+            np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6, err_msg="update %d" % i)
+    finally:
+        np.random.set_state(np_state)
+        random.setstate(py_state)
+
+
 def test_image_lut_matches_reference_numerics():
     lut = NUM.image_lut()
     assert lut.dtype == np.float32 and lut.shape == (256,)
