@@ -94,16 +94,17 @@ def cpu_baseline(seconds=15.0, ring=20_000, worker=False):
               ("body.conv2.bias", (64,)), ("body.conv3.weight", (64, 64, 3, 3)), ("body.conv3.bias", (64,)),
               ("body.fc4.weight", (512, 3136)), ("body.fc4.bias", (512,)), ("fc_head.weight", (A, 512)),
               ("fc_head.bias", (A,))]
-    p = {k: torch.tensor((rs.standard_normal(s) / np.sqrt(max(1, int(np.prod(s[1:]))))).astype(np.float32), requires_grad=True)
+    p = {k: torch.nn.Parameter(torch.tensor((rs.standard_normal(s) / np.sqrt(max(1, int(np.prod(s[1:]))))).astype(np.float32)))
          for k, s in shapes}
     pt = {k: v.detach().clone() for k, v in p.items()}
     rep = UniformReplayOracle(ring, B, 1, 0.99, H)
     frames, act, rew, msk = synth_transitions(0, ring, F, seed=0)
     for t in range(ring):
         rep.feed_one(frames[t].reshape(84, 84), act[t], rew[t], msk[t])
-    names = list(p)
-    sq = {k: torch.zeros_like(v) for k, v in p.items()}
-    ga = {k: torch.zeros_like(v) for k, v in p.items()}
+    # clip + optimizer: torch's own clip_grad_norm_ / RMSprop, the library calls the reference makes (DQN_agent.py:130-134,
+    # examples.py:67-68) -- the oracle's per-tensor restatement of them (net_oracle.rmsprop_step, used by the parity
+    # tests) is 30 % slower than the library's fused loops and would understate the CPU path
+    opt = torch.optim.RMSprop(list(p.values()), lr=0.00025, alpha=0.95, eps=0.01, centered=True)
     np.random.seed(0)
 
     def one():
@@ -116,12 +117,10 @@ def cpu_baseline(seconds=15.0, ring=20_000, worker=False):
         delta = L.dqn_td_error(q, qn, torch.from_numpy(ac), torch.from_numpy(rw.astype(np.float32)),
                                torch.from_numpy(mk.astype(np.float32)), 0.99)
         loss = L.dqn_reduce(delta)
-        grads = torch.autograd.grad(loss, [p[k] for k in names])
-        _, grads = N.clip_grad_norm(list(grads), 5)
-        with torch.no_grad():
-            for k, g in zip(names, grads):
-                newp, sq[k], ga[k] = N.rmsprop_step(p[k], g, sq[k], ga[k], 0.00025, 0.95, 0.01, True)
-                p[k].copy_(newp)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(p.values()), 5)
+        opt.step()
 
     def timed(limit):
         for _ in range(3):
@@ -154,9 +153,23 @@ def cpu_baseline(seconds=15.0, ring=20_000, worker=False):
     best_nt = max(sweep, key=sweep.get) if sweep else 1
     n_all, dt_all = (sweep[best_nt], 1.0) if sweep else (n / dt, 1.0)
     torch.set_num_threads(threads_before)
+    # the port against the reference ITSELF, measured where both exist (the authoring container; tools/cpu_port_vs_reference.py):
+    # read from the committed file, so that the "port" number can be converted
+    pvr = None
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_port_vs_reference.json")))
+        pvr = {"port_over_reference": rec["port_over_reference"], "reference_updates_per_s": rec["reference_updates_per_s"],
+               "port_updates_per_s": rec["port_updates_per_s"], "cores_on_that_box": rec["cores_on_this_box"],
+               "source": "committed file profiles/r04_cpu_port_vs_reference.json (the reference's own modules under tests/ref_shim.py "
+                         "vs this loop, same inputs, 1 thread, authoring container)"}
+    except Exception:
+        pass
     return {"value": n / dt, "unit": "gradient-updates/sec", "cores": 1, "kind": "port",
-            "sample": "%d DQN updates (B=32, 84x84x4, %d-frame ring) in %.1f s, torch-CPU fp32 oracle, 1 thread "
-                      "(the reference's set_one_thread()); kind 'port': the reference tree is not on the GPU box" % (n, ring, dt),
+            "sample": "%d DQN updates (B=32, 84x84x4, %d-frame ring) in %.1f s, torch-CPU fp32 oracle + torch's own clip_grad_norm_ / "
+                      "RMSprop, 1 thread (the reference's set_one_thread()); kind 'port': the reference tree is not on the GPU box%s"
+                      % (n, ring, dt, "; where both exist the port runs at %.2fx the reference's own loop" % pvr["port_over_reference"]
+                         if pvr else ""),
+            "port_vs_reference": pvr,
             "multi_thread": {"value": n_all / dt_all, "cores": best_nt,
                              "sample": "ONE learner, best of torch.set_num_threads(8 / 16 / 32), 2 s each: %s updates/s"
                                        % {k: round(v, 1) for k, v in sweep.items()}},
@@ -534,10 +547,24 @@ def main():
             t_low = max(roof["avg_ms"] - roof["event_pair_empty_ms"], 1e-6)
             roof["frac_event_pair_corrected"] = roof["algorithmic_flops"] / (t_low * 1e-3) / 1e12 / 157.3
         mf = getattr(bench, "roofline_mfma", None)
-        if mf is not None:      # the longest MFMA-bound kernel, with the same committed-file cross references
+        if mf is not None:
+            # The longest launch of the update is the optimizer's (fold + norm + RMSprop), but its 40 MB working set lives in
+            # the 256 MiB Infinity Cache: its GB/s are a fabric / MALL number, not an HBM one.  The path's
+            # limiter is the MFMA-bound backward: `roofline` IS that kernel (conv2's dgrad + wgrad launch), the optimizer is
+            # kept as `roofline.longest_kernel`.
             mf["rocprofv3"] = rocprof_kernel(mf["kernel"], mf.get("algorithmic_flops"))
+            if mf["rocprofv3"] is not None:
+                mf["rocprofv3"]["source"] = roof["rocprofv3"]["source"] if roof.get("rocprofv3") else "committed file"
             mf["traffic"] = pmc_traffic(mf["kernel"])
-            roof["mfma_kernel"] = mf
+            mf["traffic_source"] = roof["traffic_source"]
+            mf["source"] = roof["source"]
+            if mf.get("avg_ms") and mf.get("event_pair_empty_ms"):
+                t_low = max(mf["avg_ms"] - mf["event_pair_empty_ms"], 1e-6)
+                mf["frac_event_pair_corrected"] = mf["algorithmic_flops"] / (t_low * 1e-3) / 1e12 / 157.3
+            roof["bound"] = "fabric/MALL"
+            roof["peak_note"] = "8000 GB/s is the HBM spec, quoted as a yardstick only: FETCH_SIZE counts Infinity-Cache hits"
+            mf["longest_kernel"] = roof
+            roof = mf
         # the update chain owns a CU partition while the device actor runs beside it (lever 5):
         # the kernel is timed on that stream, i.e. on this many of the device's CUs
         roof["stream_cus"] = bench.learner.update_cus or torch.cuda.get_device_properties(0).multi_processor_count

@@ -91,7 +91,7 @@ def _describe(rc):
     if rc == -12:
         return " (out of host memory)"
     if rc == -110:
-        return " (a device-side grid barrier timed out: the cooperative optimizer's workgroups were not co-resident)"
+        return " (a bounded device-side wait gave up -- late_step's arrival slots or the actor's in-launch hand-over: results invalid)"
     if rc == 100:
         return " (hipErrorNoDevice: deeprl_amd needs an MI355X; there is no CPU path)"
     if rc == 2:

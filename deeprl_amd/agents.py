@@ -591,6 +591,7 @@ class DQNAgent(BaseAgent):
         if self._learner is not None:     # parameters changed behind the learner: actor copies are stale
             torch.cuda.synchronize()
             self._learner.invalidate_actor_copy()
+        self._ahead = None                # (host-emulator async actor) transitions produced ahead acted on the old parameters
 
     # -- true resume (the reference's save() keeps weights + normaliser only, BaseAgent.py:24-33) ------
     def save_full(self, filename):
@@ -614,11 +615,18 @@ class DQNAgent(BaseAgent):
                 sched[name] = dict(current=sc.current, inc=sc.inc, end=sc.end)
         state = dict(learner=self._learner.resume_state(), pipe=self._pipe.state_dict(), total_steps=self.total_steps,
                      actor_total_steps=self.actor._total_steps, schedules=sched, learner_lr=self._learner_lr,
+                     shape=self._resume_shape(),
                      np_random=np.random.get_state(), py_random=pyrandom.getstate(), torch_cpu=torch.get_rng_state(),
                      torch_cuda=torch.cuda.get_rng_state(Config.DEVICE), agent=type(self).__name__)
         self._inner_replay().save_full(filename, ahead=2 * self._pipe.n_env)   # the actor is one agent step ahead of the cursor
         with open(filename + '.resume', 'wb') as f:
             pickle.dump(state, f)
+
+    def _resume_shape(self):
+        cfg = self.config
+        return dict(n_env=int(self._pipe.n_env), batch_size=int(cfg.batch_size), history_length=int(cfg.history_length),
+                    n_step=int(cfg.n_step), sgd_update_frequency=int(cfg.sgd_update_frequency), lr=float(self._learner_lr),
+                    async_actor=bool(self._pipe.async_actor), per=bool(self._pipe.per))
 
     def load_full(self, filename):
         """Into a freshly constructed agent of the same Config (same network / replay / pipeline shape), before its first step."""
@@ -630,6 +638,12 @@ class DQNAgent(BaseAgent):
             state = pickle.load(f)
         if state["agent"] != type(self).__name__:
             raise DraError("%s.resume was written by a %s" % (filename, state["agent"]))
+        # the Config fields that shape the pipeline state being restored (pending blocks, slots written ahead, minibatch
+        # buffers, the optimizer's step size): a resume under a different Config must not continue silently
+        mine, theirs = self._resume_shape(), state.get("shape")
+        if theirs is not None and theirs != mine:
+            diff = {k: (theirs.get(k), mine.get(k)) for k in set(mine) | set(theirs) if theirs.get(k) != mine.get(k)}
+            raise DraError("%s.resume was written under a different Config (checkpoint, this agent): %s" % (filename, diff))
         with open(filename + '.stats', 'rb') as f:
             self.config.state_normalizer.load_state_dict(pickle.load(f))
         self._inner_replay().load_full(filename)

@@ -145,13 +145,6 @@ int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, flo
                          int batch, double u8_coef, int variant, const dra_fold_seg* fold, float* grad, double* fold_partials,
                          int* n_fold_partials, double* reset_slots, int n_reset, const PerChain2Args* chain, void* stream);
 
-// conv_v2.hip (library-internal), DRA_VAR_ACTOR_MEGA: one env step of the ring actor as ONE launch (conv1 with the fused head /
-// environment step, conv2, conv3, fc4 handing over through three arrival counters `flags`, zero at launch)
-int dra_actor_env_step_mega(const void* frames, const int64_t* slot_field_dev, const int32_t* stack_age_field_dev,
-                            const unsigned* seq_dev, int n_entries, int64_t stride_bytes, int64_t capacity, const void* newest_frame,
-                            const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
-                            const float* w4, const float* b4, float* y1, float* y2_planes, float* y3_planes, float* h4,
-                            double u8_coef, const ActorFuse* f, unsigned* flags, int* timeout_flag, void* stream);
 // ... and its default form: conv1 (fused head / environment step) and conv2 keep their launches, conv3 + fc4 share one
 // (flags[2] = conv3's arrival counter)
 int dra_actor_c3fc4(const float* y2_planes, const float* w3, const float* b3, const float* w4, const float* b4, float* y3_planes,

@@ -8,7 +8,7 @@
 #define DRA_OK 0
 #define DRA_EINVAL (-22)
 #define DRA_ENOMEM (-12)
-#define DRA_ETIMEDOUT (-110)   // a device-side wait gave up (cooperative optimizer barrier): the results are invalid
+#define DRA_ETIMEDOUT (-110)   // a bounded device-side wait gave up (late_step arrival slots, actor hand-over): the results are invalid
 
 // Every export returns 0 or an error code; nothing throws or aborts across the C ABI.
 #define DRA_HIP(expr)                                  \

@@ -970,18 +970,14 @@ int dra_conv_b1_split(int layer, const float* x0, const float* x1, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// DRA_VAR_ACTOR_MEGA: one env step of the ring actor (head of step e-1 + environment step + conv1, conv2, conv3, fc4) as ONE
-// launch of 98 workgroups x 512 threads instead of four dependent launches (DQN_agent.py:24-45: forward -> epsilon-greedy
-// -> env.step -> next forward).  The actor chain is as long as the update chain (4 x ~29 us per agent step against
-// ~113 us, profiles/r03b_phase_async_193023.json) and every one of its launches is a handful of workgroups waiting
-// 1.5-2.7 us for operands after a ~2 us boundary.  Here the roles are laid out in dependency order along blockIdx --
-//   [0, 13) conv1 tiles (ActorFuse: head + action + the rows of the new observation they convolve)   [13] environment
-//   [14, 26) conv2 (two partial planes)   [26, 34) conv3 (two partial planes)   [34, 98) fc4, 8 rows per workgroup --
-// and hand their outputs over through MegaSync counters: a consumer's weights (6.4 MB for fc4) are in registers before
-// its producer has finished, what remains after an arrival is one agent-scope read of the activations.  Workgroups are
-// dispatched in blockIdx order, so every producer is resident before a workgroup that waits for it (98 workgroups on
-// the actor's 32 CUs: two per CU at 512 threads, the 34 producers first).  Same arithmetic, same order as the four
-// launches: bit-identical action values, actions and ring contents (tests/test_gpu_env_switches.py).
+// DRA_VAR_ACTOR_MEGA: conv3 + fc4 of one env step of the ring actor as ONE launch (DQN_agent.py:24-45: forward -> epsilon-greedy
+// -> env.step -> next forward).  The actor chain is as long as the update chain and every one of its launches is a handful of
+// workgroups waiting 1.5-2.7 us for operands after a ~2 us boundary.  conv3's 8 workgroups and fc4's 64 share a launch and hand
+// conv3's planes over through a MegaSync counter: fc4's 6.4 MB of weights are in registers before conv3 has finished, what
+// remains after the arrival is one agent-scope read of the activations.  Workgroups are dispatched in blockIdx order, so
+// the producers are resident before a workgroup that waits for them.  Same arithmetic, same order as separate launches:
+// bit-identical (tests/test_gpu_env_switches.py).  (Round 3 also measured ALL FOUR layers as one launch of 98 workgroups:
+// -1.6 % -- a hand-over through memory costs what a launch boundary does; removed in round 4, profiles/r03c_ab.jsonl.)
 struct ActorMegaArgs {
   ConvV2Args c1;
   ActorFuse f;
@@ -990,9 +986,8 @@ struct ActorMegaArgs {
   unsigned* flags;         // [3] arrivals of conv1 / conv2 / conv3 of THIS env step, zero at launch
   int* timeout_flag;
 };
-constexpr int kMegaC1 = V2Tile<VG1, 1>::TPG, kMegaC2 = VG2::TPS * (VG2::OC / 32) * 2, kMegaC3 = VG3::TPS * (VG3::OC / 32) * 2;
+constexpr int kMegaC3 = VG3::TPS * (VG3::OC / 32) * 2;
 constexpr int kMegaFc = 512 / 8;
-constexpr int kMegaBlocks = kMegaC1 + 1 + kMegaC2 + kMegaC3 + kMegaFc;
 
 // fc4 role of the actor's fused launches: h4[row] = relu(b4[row] + <W4[row], relu(x0 + x1)>), one wave per row, the row's
 // weights requested BEFORE the wait for conv3's two partial planes (same per-lane products and butterfly as
@@ -1042,37 +1037,9 @@ __device__ __forceinline__ void mega_fc4_role(const ActorMegaArgs& m, const int 
   }
 }
 
-__global__ void __launch_bounds__(512) actor_mega_kernel(const ActorMegaArgs m) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int b = blockIdx.x;
-  if (b <= kMegaC1) {
-    MegaSync ms;
-    ms.done = m.flags;
-    conv_fwd_v2_body<VG1, true, 1, 8, true, true>(m.c1, m.f, b, 0, 0, b == kMegaC1, ms);
-    return;
-  }
-  b -= kMegaC1 + 1;
-  if (b < kMegaC2) {
-    MegaSync ms;
-    ms.wait = m.flags; ms.wait_target = kMegaC1; ms.done = m.flags + 1; ms.timeout_flag = m.timeout_flag;
-    conv_b1_split_body<VG2, 1, 2, true>(m.y1, nullptr, m.w2, m.b2, m.y2p, DRA_ACT_NONE, b % VG2::TPS, b / VG2::TPS, ms);
-    return;
-  }
-  b -= kMegaC2;
-  if (b < kMegaC3) {
-    MegaSync ms;
-    ms.wait = m.flags + 1; ms.wait_target = kMegaC2; ms.done = m.flags + 2; ms.timeout_flag = m.timeout_flag;
-    conv_b1_split_body<VG3, 2, 2, true>(m.y2p, m.y2p + VG2::OC * VG2::P, m.w3, m.b3, m.y3p, DRA_ACT_NONE, b % VG3::TPS, b / VG3::TPS, ms);
-    return;
-  }
-  b -= kMegaC3;
-  mega_fc4_role(m, b, lds);
-}
-
-// conv3 + fc4 only (DRA_ACTOR_MEGA_MODE=1, the default): conv1 and conv2 keep their own launches -- a hand-over through memory
-// costs about what a launch boundary does (stores acknowledged, the arrival count, the poll: ~2.4 us against ~2 us), so
-// fusing them gains nothing (measured: all four layers in one launch -1.6 %, profiles/r03c_ab.jsonl); what pays is fc4's
-// 6.4 MB of weights arriving while conv3 computes.  grid = 8 conv3 workgroups + 64 fc4 workgroups.
+// conv1 and conv2 keep their own launches -- a hand-over through memory costs about what a launch boundary does (stores
+// acknowledged, the arrival count, the poll: ~2.4 us against ~2 us); what pays is fc4's 6.4 MB of weights arriving while
+// conv3 computes.  grid = 8 conv3 workgroups + 64 fc4 workgroups.
 __global__ void __launch_bounds__(512) actor_c3fc4_kernel(const ActorMegaArgs m) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int b = blockIdx.x;
@@ -1083,41 +1050,6 @@ __global__ void __launch_bounds__(512) actor_c3fc4_kernel(const ActorMegaArgs m)
     return;
   }
   mega_fc4_role(m, b - kMegaC3, lds);
-}
-
-// Library-internal (actor_env.h).  flags: 3 zeroed arrival counters owned by this env step (the agent step's tail kernel
-// zeroes them again); everything else as dra_conv1_fwd_actor_fused + dra_conv_b1_split x 2 + the fc4 GEMV.
-int dra_actor_env_step_mega(const void* frames, const int64_t* slot_field_dev, const int32_t* stack_age_field_dev,
-                            const unsigned* seq_dev, int n_entries, int64_t stride_bytes, int64_t capacity, const void* newest_frame,
-                            const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
-                            const float* w4, const float* b4, float* y1, float* y2_planes, float* y3_planes, float* h4,
-                            double u8_coef, const ActorFuse* f, unsigned* flags, int* timeout_flag, void* stream) {
-  if (!frames || !slot_field_dev || !seq_dev || n_entries < 1 || stride_bytes < 8 || capacity < VG1::C || !w1 || !b1 || !w2 ||
-      !b2 || !w3 || !b3 || !w4 || !b4 || !y1 || !y2_planes || !y3_planes || !h4 || !f || !flags || !timeout_flag)
-    return DRA_EINVAL;
-  if (f->mode != 1 && f->mode != 2) return DRA_EINVAL;
-  if (f->mode == 2 && (f->e < 1 || f->e >= kMaxEnvSteps || f->n_actions < 1 || f->n_actions > 64 || !f->h4 || !f->wh || !f->bh))
-    return DRA_EINVAL;
-  ActorMegaArgs m;
-  ConvV2Args& a = m.c1;
-  a.x[0] = frames; a.wt[0] = w1; a.bias[0] = b1; a.y[0] = y1;
-  a.batch = 1; a.act = DRA_ACT_RELU; a.coef = u8_coef; a.ring_slot = slot_field_dev; a.ring_cap = capacity;
-  a.stack_age = stack_age_field_dev; a.slot_seq = seq_dev; a.slot_entries = n_entries; a.slot_stride = stride_bytes;
-  a.newest_frame = f->mode == 1 ? reinterpret_cast<const uint8_t*>(newest_frame) : nullptr;
-  m.f = *f;
-  m.w2 = w2; m.b2 = b2; m.w3 = w3; m.b3 = b3; m.w4 = w4; m.b4 = b4;
-  m.y1 = y1; m.y2p = y2_planes; m.y3p = y3_planes; m.h4 = h4; m.flags = flags; m.timeout_flag = timeout_flag;
-  constexpr size_t img1 = (size_t)VG1::C * V2Tile<VG1, 1>::CS * sizeof(float);
-  constexpr size_t img2 = (size_t)(VG2::C / 2) * V2Tile<VG2, 1>::CS * sizeof(float);
-  constexpr size_t img3 = (size_t)(VG3::C / 2) * V2Tile<VG3, 1>::CS * sizeof(float);
-  constexpr size_t red = (size_t)8 * 16 * 64 * sizeof(float);
-  constexpr size_t xfc = (size_t)VG3::OC * VG3::P * sizeof(float);
-  constexpr size_t m1 = img1 > img2 ? img1 : img2, m2 = img3 > red ? img3 : red, m3 = m1 > m2 ? m1 : m2;
-  constexpr size_t bytes = m3 > xfc ? m3 : xfc;
-  static_assert(bytes <= 64 * 1024, "default dynamic LDS limit");
-  hipLaunchKernelGGL(actor_mega_kernel, dim3(kMegaBlocks), dim3(512), bytes, dra_stream(stream), m);
-  DRA_LAUNCH_CHECK();
-  return DRA_OK;
 }
 
 // Library-internal (actor_env.h): conv3 (from conv2's two partial planes, written by the previous launch) + the fc4 GEMV as

@@ -169,11 +169,8 @@ struct dra_dqn_learner {
   hipEvent_t actor_last = nullptr;  // GATHER_ON_UPDATE: recorded after the most recent actor launch (a staging-slot event)
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
-  // DRA_VAR_COOP_OPT: slab fold + gradient norm + optimiser as one launch behind a grid barrier (optim.hip clip_step_kernel).
-  // Used only when the launch's grid fits the workgroup slots of the update stream's CUs (dra_dqn_learner_set_update_cus).
-  unsigned long long* coop_ctr;     // device: the barrier's ever-growing ticket counter
-  int* coop_flag;                   // pinned host: set by a workgroup whose barrier wait timed out
-  int coop_limit;                   // co-resident workgroups assumed available (0: unknown -> two-launch form)
+  int* timeout_flag;                // pinned host: set by a workgroup whose bounded device-side wait gave up (late_step's arrival
+                                    // slots, the actor's in-launch hand-over): every later step / update returns DRA_ETIMEDOUT
   // DRA_VAR_IDX_PREFETCH (ring-direct pipeline): step-tagged copies of the minibatch indices -- pinned (written by the host
   // with the indices), device (an unordered async copy on the side stream), and the device count of completed updates
   int64_t* idx_tag_pin[4];
@@ -193,13 +190,11 @@ struct dra_dqn_learner {
   hipEvent_t ev_hq[2];
   int64_t hq_updates;               // async updates issued
   bool hq_seeded;                   // copy (hq_updates - 1) mod 2 holds valid parameters
-  // the prioritized draw inside the update chain (dra_dqn_learner_set_per_chain): the replay's tree, its {max, min} pair and one
-  // pinned io block per rotation slot; captured into the PER update's first graph behind the loss kernel
+  // the prioritized draw inside the update (dra_dqn_learner_set_per_chain2): the replay's tree, its {max, min} pair and one pinned
+  // io block per rotation slot; the whole draw on the device; the next update's minibatch indices arrive in
+  // per2_idx[slot] (device), the sampling probabilities in samp_prob, without the host in between
   dra_sumtree* per_tree;
   double* per_stat;
-  dra_per_chain_io* per_io[4];
-  // second form (dra_dqn_learner_set_per_chain2): the whole draw on the device; the next update's minibatch indices arrive in
-  // per2_idx[slot] (device), the sampling probabilities in samp_prob, without the host in between
   dra_per_chain2_io* per2_io[4];
   void* per2_dev;                   // sumtree.hip PerChain2Dev
   int64_t* per2_idx;                // [4][1024]
@@ -211,13 +206,11 @@ struct dra_dqn_learner {
   bool per2_ride;                   // ... and the chain kernel rides in conv3's backward launch (per2_args) instead of its own
   bool per2_split;                  // ... its second half in conv1's weight-gradient launch (late-fold backward only)
   PerChain2Args per2_args;
-  hipEvent_t ev_per_fork, ev_per_join;   // capture-time fork / join of the chain kernel's branch
   unsigned* aflags;                 // DRA_VAR_ACTOR_MEGA: [kMaxEnvSteps][4] arrival counters of the one-launch env steps (zeroed by
                                     // the agent step's tail kernel)
   bool late;
   int late_nprior;                  // partials written before the optimizer launch
   int late_nfold;                   // fold workgroups of the optimizer launch (their partial slots double as arrival flags)
-  bool coop;                        // decided once, before the first graph capture
   bool captured;                    // some graph has been captured (the decision above is baked into it)
 };
 
@@ -432,10 +425,8 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   }
   rc |= (int)hipHostMalloc(&l->sp_stage, (size_t)8 * 1025 * sizeof(float), hipHostMallocDefault);
   for (int k = 0; k < 8; ++k) rc |= (int)hipEventCreateWithFlags(&l->sp_ev[k], hipEventDisableTiming);
-  rc |= (int)hipMalloc(&l->coop_ctr, sizeof(unsigned long long));
-  if (!rc) rc |= (int)hipMemset(l->coop_ctr, 0, sizeof(unsigned long long));
-  rc |= (int)hipHostMalloc(&l->coop_flag, sizeof(int), hipHostMallocDefault);
-  if (!rc) *l->coop_flag = 0;
+  rc |= (int)hipHostMalloc(&l->timeout_flag, sizeof(int), hipHostMallocDefault);
+  if (!rc) *l->timeout_flag = 0;
   rc |= (int)hipMalloc(&l->prm_dev, sizeof(dra_dqn_step_params));
   rc |= (int)hipHostMalloc(&l->prm_stage, 8 * sizeof(dra_dqn_step_params), hipHostMallocDefault);
   rc |= (int)hipHostMalloc(&l->idx_stage, (size_t)8 * 1024 * sizeof(int64_t), hipHostMallocDefault);
@@ -458,8 +449,6 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   for (int k = 0; k < 4; ++k) rc |= (int)hipEventCreateWithFlags(&l->ev_join[k], hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_actor_done, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_loss, hipEventDisableTiming);
-  rc |= (int)hipEventCreateWithFlags(&l->ev_per_fork, hipEventDisableTiming);
-  rc |= (int)hipEventCreateWithFlags(&l->ev_per_join, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_gather_done, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_step_done, hipEventDisableTiming);
   for (int g = 0; g < 2; ++g) {
@@ -537,8 +526,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (l->rd_seq_dev) (void)hipFree(l->rd_seq_dev);
   if (l->sp_stage) (void)hipHostFree(l->sp_stage);
   for (int k = 0; k < 8; ++k) if (l->sp_ev[k]) (void)hipEventDestroy(l->sp_ev[k]);
-  if (l->coop_ctr) (void)hipFree(l->coop_ctr);
-  if (l->coop_flag) (void)hipHostFree(l->coop_flag);
+  if (l->timeout_flag) (void)hipHostFree(l->timeout_flag);
   if (l->qs_stage) (void)hipHostFree(l->qs_stage);
   if (l->q_stage) (void)hipHostFree(l->q_stage);
   if (l->g_q_ready) (void)hipGraphExecDestroy(l->g_q);
@@ -553,7 +541,6 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   for (int k = 0; k < 4; ++k) (void)hipEventDestroy(l->ev_join[k]);
   (void)hipEventDestroy(l->ev_actor_done); (void)hipEventDestroy(l->ev_gather_done); (void)hipEventDestroy(l->ev_step_done);
   (void)hipEventDestroy(l->ev_loss);
-  (void)hipEventDestroy(l->ev_per_fork); (void)hipEventDestroy(l->ev_per_join);
   delete l;
   return DRA_OK;
 }
@@ -964,42 +951,6 @@ static void conv_fold_segs(const dra_dqn_learner* l, dra_fold_seg segs[3]) {
   }
 }
 
-// The CUs the update stream may use (the host created it, possibly CU-masked).  With DRA_VAR_COOP_OPT this decides whether
-// fold + norm + optimiser run as ONE cooperative launch: its grid must fit the workgroup slots of those CUs (a grid
-// barrier needs every workgroup resident).  Call before the first update; later calls are refused (graphs bake the choice).
-DRA_API int dra_dqn_learner_set_update_cus(dra_dqn_learner* l, int n_cus) {
-  if (!l || n_cus < 1) return DRA_EINVAL;
-  if (l->captured) return DRA_EINVAL;
-  l->coop = false;
-  l->coop_limit = 0;
-  if (!(l->variant & DRA_VAR_COOP_OPT) || !(l->variant & DRA_VAR_ONESHOT_WGRAD)) return DRA_OK;
-  int per_cu = 0, blocks = 0;
-  int rc = dra_clip_step_coop_occupancy(l->c.optimizer, &per_cu);
-  if (rc) return rc;
-  dra_fold_seg segs[3];
-  conv_fold_segs(l, segs);
-  if (dra_clip_step_coop_blocks(l->c.n_params, segs, 3, &blocks) != DRA_OK) return DRA_OK;   // layout not supported: two launches
-  l->coop_limit = per_cu * n_cus;
-  l->coop = blocks <= l->coop_limit;
-  return DRA_OK;
-}
-
-// 1 = the cooperative optimizer launch is in use, 0 = the two-launch form
-DRA_API int dra_dqn_learner_coop_state(dra_dqn_learner* l, int* coop, int* blocks, int* resident_limit) {
-  if (!l) return DRA_EINVAL;
-  if (coop) *coop = l->coop ? 1 : 0;
-  if (resident_limit) *resident_limit = l->coop_limit;
-  if (blocks) {
-    *blocks = 0;
-    if (l->variant & DRA_VAR_ONESHOT_WGRAD) {
-      dra_fold_seg segs[3];
-      conv_fold_segs(l, segs);
-      (void)dra_clip_step_coop_blocks(l->c.n_params, segs, 3, blocks);
-    }
-  }
-  return DRA_OK;
-}
-
 static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = nullptr) {
   const dra_dqn_config& c = l->c;
   if (l->late) {
@@ -1008,16 +959,7 @@ static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = 
     const bool adam = c.optimizer == DRA_OPT_ADAM;
     const float hyper[4] = {c.lr, adam ? c.beta1 : c.alpha, c.eps, adam ? c.beta2 : 0.f};
     return dra_clip_step_late(l->p, l->g, l->s1, l->s2, c.n_params, &segs[0], l->partials, l->late_nprior,
-                              l->coop_flag, c.optimizer, c.gradient_clip, hyper, c.centered, l->opt_step, l->norm, p_copy,
-                              (void*)st);
-  }
-  if (l->coop) {
-    dra_fold_seg segs[3];
-    conv_fold_segs(l, segs);
-    const bool adam = c.optimizer == DRA_OPT_ADAM;
-    const float hyper[4] = {c.lr, adam ? c.beta1 : c.alpha, c.eps, adam ? c.beta2 : 0.f};
-    return dra_clip_step_coop(l->p, l->g, l->s1, l->s2, c.n_params, segs, 3, l->partials, l->coop_ctr, l->coop_flag,
-                              l->coop_limit, c.optimizer, c.gradient_clip, hyper, c.centered, l->opt_step, l->norm, p_copy,
+                              l->timeout_flag, c.optimizer, c.gradient_clip, hyper, c.centered, l->opt_step, l->norm, p_copy,
                               (void*)st);
   }
   if (c.optimizer == DRA_OPT_ADAM)
@@ -1292,10 +1234,6 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
                                           B, 1, c.u8_coef, DRA_ACT_RELU, var, s));
     }
     if (own) {
-      if (l->coop) {   // fold + norm happen inside the optimizer launch (launch_optimizer)
-        if (l->profiling) { DRA_HIP(hipEventRecord(l->ev[K_NORM], st)); DRA_HIP(hipEventRecord(l->ev[K_STEP], st)); }
-        return DRA_OK;
-      }
       dra_fold_seg segs[3];
       conv_fold_segs(l, segs);
       int np_out = 0;
@@ -1384,10 +1322,6 @@ static int capture_part(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int 
   hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (b != hipSuccess) { l->gb = 0; l->rd_slot = -1; return (int)b; }
   int rc = run_body(l, st, per, per ? -1.f : 0.f, 0, part);     // PER: the exponent is read from sampling_prob[B]
-  // the prioritized draw inside the chain: write-back of THIS update's priorities, the next step's adds and the next
-  // draw's descent as one kernel right behind the loss (inputs / outputs in the slot's pinned block)
-  if (rc == DRA_OK && per && part == 1 && l->per_tree && l->per_io[q & 3])
-    rc = dra_sumtree_per_chain(l->per_tree, l->per_io[q & 3], l->prio, l->per_stat, (void*)st);
   if (rc == DRA_OK && with_optimizer) rc = launch_optimizer(l, st, l->pa[q]);
   hipError_t e = hipStreamEndCapture(st, &graph);
   l->gb = 0;
@@ -1399,10 +1333,9 @@ static int capture_part(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int 
   return DRA_OK;
 }
 
-// The prioritized update with the draw on the device (dra_sumtree_per_chain2) as ONE graph: [forward + loss], then two
-// branches -- the chain kernel (priorities -> tree, adds, next draw: a single-workgroup latency chain of ~40 us) on the side
-// stream, and [backward + norm + optimizer] -- joined at the end.  Nothing in the backward pass touches what the chain
-// kernel reads or writes (prio / tree / sampling_prob / the NEXT slot's indices), and the next update starts behind the join.
+// The prioritized update with the draw on the device (dra_sumtree_per_chain2) as ONE graph: [forward + loss], the draw
+// (priorities -> tree, adds, next draw), [backward + norm + optimizer].  Nothing in the backward pass touches what the draw
+// reads or writes (prio / tree / sampling_prob / the NEXT slot's indices), which is what lets it ride inside backward launches.
 static int capture_per2(dra_dqn_learner* l, hipStream_t st, int q, bool rd, hipGraphExec_t* exec) {
   hipGraph_t graph;
   l->gb = q & 1;
@@ -1411,24 +1344,16 @@ static int capture_per2(dra_dqn_learner* l, hipStream_t st, int q, bool rd, hipG
   if (b != hipSuccess) { l->gb = 0; l->rd_slot = -1; return (int)b; }
   l->per2_active = true;
   int rc = run_body(l, st, 1, -1.f, 0, 1);
-  static int fork = -1;
-  // 1: the chain kernel as a parallel branch of the graph.  Measured (profiles/r03h): the branches do overlap, but the forked
-  // graph no longer overlaps with the ACTOR stream's graph (4.5 k vs 6.0 k updates/s) and its results differ -- in line it is
-  if (fork < 0) { const char* e = getenv("DRA_PER_FORK"); fork = e ? atoi(e) : 0; }
-  hipStream_t sd = fork ? l->side : st;
-  if (rc == DRA_OK && fork) {
-    rc = (int)hipEventRecord(l->ev_per_fork, st);
-    if (rc == DRA_OK) rc = (int)hipStreamWaitEvent(sd, l->ev_per_fork, 0);
-  }
-  // DRA_PER_RIDE: 2 (default) = the draw as riding roles of two backward launches -- priorities / commits / adds in conv3's,
-  // descent / filter / hand-over in conv1's weight gradient (late-fold backward) --, 1 = whole in conv3's (27 instead of 12 us
-  // for that launch: profiles/r03i_timeline_per_ride.txt), 0 = its own launch between the loss and the backward pass.
-  // Minibatches up to 256 (a role has the launch's 256 threads), one-pass backward kernels.
-  static int ride = -1;
-  if (ride < 0) { const char* e = getenv("DRA_PER_RIDE"); ride = e ? atoi(e) : 2; }
+  // The draw rides as roles of two backward launches -- priorities / commits / adds in conv3's, descent / filter / hand-over in
+  // conv1's weight gradient (late-fold backward; without it: whole in conv3's) -- for minibatches up to 256 (a role has the
+  // launch's 256 threads) and the one-pass backward kernels; otherwise it is a launch of its own between the loss and the
+  // backward pass.  (Measured and removed in round 4: the kernel as a parallel BRANCH of the graph -- the forked graph no
+  // longer overlapped with the actor stream's, 4.5 k vs 6.0 k updates/s -- and whole-in-conv3's as a choice: 27 instead of
+  // 12 us for that launch; DESIGN.md section 4, profiles/r03h_*, r03i_*.)
+  hipStream_t sd = st;
   const int both = DRA_VAR_ONESHOT_WGRAD | DRA_VAR_ONESHOT_DGRAD;
-  l->per2_ride = ride && !fork && l->c.batch <= 256 && (l->variant & both) == both;
-  l->per2_split = l->per2_ride && ride == 2 && l->late;
+  l->per2_ride = l->c.batch <= 256 && (l->variant & both) == both;
+  l->per2_split = l->per2_ride && l->late;
   if (rc == DRA_OK && l->per2_ride)
     rc = dra_sumtree_per_chain2_args(l->per_tree, l->per2_io[q & 3], l->delta, l->c.replay_eps, l->c.replay_alpha, l->prio,
                                      l->per_stat, l->per2_dev, l->per2_words, l->per2_idx + (size_t)((q + 1) & 3) * 1024,
@@ -1441,10 +1366,6 @@ static int capture_per2(dra_dqn_learner* l, hipStream_t st, int q, bool rd, hipG
   l->per2_active = false;
   l->per2_ride = l->per2_split = false;
   if (rc == DRA_OK) rc = launch_optimizer(l, st, l->pa[q]);
-  if (rc == DRA_OK && fork) {
-    rc = (int)hipEventRecord(l->ev_per_join, sd);
-    if (rc == DRA_OK) rc = (int)hipStreamWaitEvent(st, l->ev_per_join, 0);
-  }
   hipError_t e = hipStreamEndCapture(st, &graph);
   l->gb = 0;
   l->rd_slot = -1;
@@ -1485,21 +1406,7 @@ static int pipe_graph(dra_dqn_learner* l, hipStream_t st, int par, int per = 0) 
 
 static int rd_graph(dra_dqn_learner* l, hipStream_t st, int q, int per = 0) { return update_graph(l, st, q, true, per); }
 
-// PrioritizedReplay inside the update chain (sumtree.hip dra_sumtree_per_chain): tree = the replay's sum tree, stat_dev = its
-// {max_priority, min priority} pair, io[4] = pinned blocks, one per rotation slot of the pipelined update (slot of the next
-// update: dra_dqn_learner_next_slot).  Must be set before the first prioritized update is captured; tree == null switches
-// it off (later captures).  dra_dqn_learner_sync_loss blocks the HOST until the loss kernel (and the chain kernel behind it)
-// of the update issued last have run: the next draw is then in that update's io block.
-DRA_API int dra_dqn_learner_set_per_chain(dra_dqn_learner* l, dra_sumtree* tree, double* stat_dev, dra_per_chain_io* io0,
-                                          dra_per_chain_io* io1, dra_per_chain_io* io2, dra_per_chain_io* io3) {
-  if (!l || (tree && (!stat_dev || !io0 || !io1 || !io2 || !io3))) return DRA_EINVAL;
-  for (int k = 0; k < 4; ++k)
-    if (l->g_rd_per_ready[k] || l->g_pipe_per_ready[k]) return DRA_EINVAL;     // the graphs bake the choice
-  l->per_tree = tree; l->per_stat = stat_dev;
-  l->per_io[0] = io0; l->per_io[1] = io1; l->per_io[2] = io2; l->per_io[3] = io3;
-  return DRA_OK;
-}
-// Second form (sumtree.hip dra_sumtree_per_chain2): io0..3 = pinned dra_per_chain2_io blocks, rng_words = pinned ring of
+// PrioritizedReplay.sample() inside the update (sumtree.hip dra_sumtree_per_chain2): io0..3 = pinned dra_per_chain2_io blocks, rng_words = pinned ring of
 // DRA_PER_RNG_WORDS Mersenne-Twister outputs.  From then on every prioritized update of the ring-direct pipeline reads its
 // minibatch indices from device memory (slot step_no & 3) and its sampling probabilities / exponent from the learner's
 // sampling_prob buffer, both written by the PREVIOUS update's chain kernel -- or by _per_chain2_seed for the first one.
@@ -1596,7 +1503,7 @@ DRA_API int dra_dqn_learner_keep_minibatch(dra_dqn_learner* l, int keep) {
 // is a kernel argument that changes per update); the stream must not be the NULL stream.
 DRA_API int dra_dqn_learner_update(dra_dqn_learner* l, int use_graph, int per, float beta, void* stream) {
   if (!l) return DRA_EINVAL;
-  if (*l->coop_flag) return DRA_ETIMEDOUT;
+  if (*l->timeout_flag) return DRA_ETIMEDOUT;
   hipStream_t st = dra_stream(stream);
   l->profiling = false;
   l->pa_valid = false;
@@ -1666,6 +1573,11 @@ DRA_API int dra_dqn_learner_last_minibatch(dra_dqn_learner* l, void** state, voi
 DRA_API int dra_dqn_learner_invalidate_actor_copy(dra_dqn_learner* l) {
   if (!l) return DRA_EINVAL;
   l->pa_valid = false;
+  // the host-emulator async actor (dra_dqn_learner_q_host_async) never looks at pa_valid: it reads the copy update
+  // (hq_updates - 2) wrote.  Start its rotation over, so that the next call re-copies the online parameters as they are now
+  // (the caller has synchronised: DQNAgent.load).
+  l->hq_updates = 0;
+  l->hq_seeded = false;
   return DRA_OK;
 }
 
@@ -2175,7 +2087,7 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
 // (the actor's CU partition), so it neither waits for update t nor races with its optimizer.  Needs DRA_VAR_ACTOR_PARAMS.
 DRA_API int dra_dqn_learner_update_async(dra_dqn_learner* l, int use_graph, int per, float beta, void* stream_update) {
   if (!l || !l->pa[0] || !l->pa[1]) return DRA_EINVAL;
-  if (*l->coop_flag) return DRA_ETIMEDOUT;
+  if (*l->timeout_flag) return DRA_ETIMEDOUT;
   hipStream_t st = dra_stream(stream_update);
   l->profiling = false;
   l->pa_valid = false;
@@ -2232,7 +2144,7 @@ DRA_API int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* stat
       // conv2 with its reduction split over two workgroups per tile, conv3 + fc4 as one launch (the device actor's kernels)
       if (!rc) rc = dra_conv_b1_split(2, l->ay1, nullptr, P + o[P_W2], P + o[P_B2], l->ay2p, s);
       if (!rc) rc = dra_actor_c3fc4(l->ay2p, P + o[P_W3], P + o[P_B3], P + o[P_W4], P + o[P_B4], l->ay3p, l->ah4,
-                                    l->aflags + 4 * (kMaxEnvSteps - 1), l->coop_flag, s);
+                                    l->aflags + 4 * (kMaxEnvSteps - 1), l->timeout_flag, s);
       if (!rc) {
         hipLaunchKernelGGL(head_q_kernel, dim3(1), dim3(c.head_kind != DRA_HEAD_VANILLA ? 1024 : 256), 0, st, (const float*)l->ah4,
                            P + o[P_WH], P + o[P_BH], c.n_actions, l->aq, head_spec(l), l->aflags + 4 * (kMaxEnvSteps - 1), 4);
@@ -2370,36 +2282,21 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   f.pend_reward = l->pend_reward; f.pend_mask = l->pend_mask; f.seed = (uint64_t)c.env_seed;
   const bool dist = c.head_kind != DRA_HEAD_VANILLA;
   f.head_kind = c.head_kind; f.n_atoms = c.n_atoms; f.atoms = l->atoms; f.pre = l->alog;
-  // DRA_VAR_ACTOR_MEGA: conv1 (+ head / environment step), conv2, conv3 and fc4 of an env step as ONE launch (conv_v2.hip)
+  // DRA_VAR_ACTOR_MEGA: conv3 + fc4 of an env step as ONE launch with an in-kernel hand-over (conv_v2.hip actor_c3fc4_kernel)
   const bool mega = (l->variant & DRA_VAR_ACTOR_MEGA) && actor_ksplit() && l->aflags;
-  static int mega_mode = -1;   // DRA_ACTOR_MEGA_MODE: 1 (default) = [conv1] [conv2] [conv3 + fc4], 0 = all four layers in one launch
-  if (mega_mode < 0) { const char* ev = getenv("DRA_ACTOR_MEGA_MODE"); mega_mode = ev ? atoi(ev) : 1; }
   for (int e = 0; e < n_env; ++e) {
     const int64_t* slot_field = reinterpret_cast<const int64_t*>(l->aring_dev + offsetof(dra_dqn_step_params, slot)) + e;
     const int32_t* age_field = reinterpret_cast<const int32_t*>(l->aring_dev + offsetof(dra_dqn_step_params, stack_age)) + e;
     f.mode = e == 0 ? 1 : 2;
     f.e = e;
-    if (mega && mega_mode == 1) {
+    if (mega) {
       if ((rc = dra_conv1_fwd_actor_fused(frames, slot_field, age_field, l->aring_seq, kAringSlots, (int64_t)kAprmStride, c.ring_capacity,
                                           e == 0 ? l->pend_frame : nullptr, P + o[P_W1], P + o[P_B1], l->ay1, c.u8_coef,
                                           DRA_ACT_RELU, &f, s)))
         return rc;
       if ((rc = dra_conv_b1_split(2, l->ay1, nullptr, P + o[P_W2], P + o[P_B2], l->ay2p, s))) return rc;
       if ((rc = dra_actor_c3fc4(l->ay2p, P + o[P_W3], P + o[P_B3], P + o[P_W4], P + o[P_B4], l->ay3p, l->ah4, l->aflags + 4 * e,
-                                l->coop_flag, s)))
-        return rc;
-      if (dist) {
-        hipLaunchKernelGGL(actor_dist_gemv_kernel, dim3((l->n_out + 3) / 4), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH],
-                           P + o[P_BH], l->n_out, l->alog);
-        DRA_LAUNCH_CHECK();
-      }
-      continue;
-    }
-    if (mega) {
-      if ((rc = dra_actor_env_step_mega(frames, slot_field, age_field, l->aring_seq, kAringSlots, (int64_t)kAprmStride, c.ring_capacity,
-                                        e == 0 ? l->pend_frame : nullptr, P + o[P_W1], P + o[P_B1], P + o[P_W2], P + o[P_B2],
-                                        P + o[P_W3], P + o[P_B3], P + o[P_W4], P + o[P_B4], l->ay1, l->ay2p, l->ay3p, l->ah4,
-                                        c.u8_coef, &f, l->aflags + 4 * e, l->coop_flag, s)))
+                                l->timeout_flag, s)))
         return rc;
       if (dist) {
         hipLaunchKernelGGL(actor_dist_gemv_kernel, dim3((l->n_out + 3) / 4), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH],
@@ -3100,19 +2997,9 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
 DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, void* stream_update,
                                  void* stream_actor) {
   if (!l || !prm || prm->n_env < 0 || prm->n_env > kMaxEnvSteps) return DRA_EINVAL;
-  if (*l->coop_flag) return DRA_ETIMEDOUT;   // a grid barrier of the cooperative optimizer timed out: results are invalid
+  if (*l->timeout_flag) return DRA_ETIMEDOUT;   // a bounded device-side wait gave up: results are invalid
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = learner_step_impl(l, prm, do_update, stream_update, stream_actor);
-  // PER inside the chain: the host comes back for this update's loss (dra_dqn_learner_sync_loss) only after generating
-  // the next parameter blocks -- make sure everything issued above is on its way to the device by then
-  if (rc == DRA_OK && l->per_tree && l->step_per) {
-    static int flush = -1;
-    if (flush < 0) { const char* e = getenv("DRA_PER_FLUSH"); flush = e ? atoi(e) : 1; }
-    if (flush) {
-      (void)hipStreamQuery(dra_stream(stream_update));
-      if (stream_actor) (void)hipStreamQuery(dra_stream(stream_actor));
-    }
-  }
   l->host_call_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   l->host_calls++;
   return rc;
@@ -3124,7 +3011,7 @@ static int step_split_check(dra_dqn_learner* l, const dra_dqn_step_params* prm, 
   if (!l->step_per || l->step_beta >= 0.f) return DRA_EINVAL;
   const int need = DRA_VAR_PIPE_GATHER | DRA_VAR_ACTOR_PARAMS | DRA_VAR_GATHER_ON_UPDATE | DRA_VAR_RING_DIRECT | DRA_VAR_ACTOR_RING;
   if ((l->variant & need) != need) return DRA_EINVAL;
-  if (*l->coop_flag) return DRA_ETIMEDOUT;
+  if (*l->timeout_flag) return DRA_ETIMEDOUT;
   return DRA_OK;
 }
 DRA_API int dra_dqn_learner_step_update(dra_dqn_learner* l, const dra_dqn_step_params* prm, void* stream_update, void* stream_actor) {

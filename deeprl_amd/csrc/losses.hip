@@ -605,7 +605,9 @@ gumbel_sample_kernel(const float* __restrict__ logits, int n_local, int n_action
     int arg = 0;
     for (int a = 0; a < n_actions; ++a) {
       const uint64_t h = gs_mix64(base + (uint64_t)(lo + i) * 64ull + (uint64_t)a);
-      const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1), 24 bits
+      // 23 bits: k + 0.5 is exact in fp32 for every k < 2^23, so u lies STRICTLY inside (0, 1) (with 24 bits the largest k
+      // rounded up to 2^24 and u == 1 made -log(-log u) = +inf: that action won whatever the logits, 2^-24 per draw)
+      const float u = ((float)(h >> 41) + 0.5f) * (1.0f / 8388608.0f);
       const float v = logits[(int64_t)i * n_actions + a] - logf(-logf(u));
       if (v > best) { best = v; arg = a; }
     }

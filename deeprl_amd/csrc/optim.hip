@@ -65,12 +65,9 @@ DRA_API int dra_grad_sqnorm(float* grad, int64_t n, const float* slabs, int n_sl
   return DRA_OK;
 }
 
-// Fixed-order reduction of the partials by every workgroup; returns the clip coefficient.
-// COHERENT: the partials were published by the other workgroups of THIS launch (agent-scope stores before a grid barrier):
-// read them with agent-scope loads, past this XCD's L2.
-template <bool COHERENT>
-__device__ __forceinline__ float clip_coef_impl(const double* __restrict__ partials, int n_partials, float max_norm,
-                                                float* __restrict__ out_norm) {
+// Fixed-order reduction of the partials (written by an EARLIER launch) by every workgroup; returns the clip coefficient.
+__device__ __forceinline__ float clip_coef_from_partials(const double* __restrict__ partials, int n_partials, float max_norm,
+                                                         float* __restrict__ out_norm) {
   if (!partials) return 1.f;  // uniform: no clipping requested
   __shared__ double s_part[4];
   __shared__ float s_coef;
@@ -83,8 +80,7 @@ __device__ __forceinline__ float clip_coef_impl(const double* __restrict__ parti
 #pragma unroll
     for (int u = 0; u < NPT; ++u) {
       const int i = (int)threadIdx.x + 256 * u;
-      const double* src = partials + (i < n_partials ? i : n_partials - 1);
-      v[u] = COHERENT ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+      v[u] = partials[i < n_partials ? i : n_partials - 1];
     }
 #pragma unroll
     for (int u = 0; u < NPT; ++u) d += ((int)threadIdx.x + 256 * u < n_partials) ? v[u] : 0.0;
@@ -104,14 +100,6 @@ __device__ __forceinline__ float clip_coef_impl(const double* __restrict__ parti
   }
   __syncthreads();
   return s_coef;
-}
-
-__device__ __forceinline__ float clip_coef_from_partials(const double* __restrict__ partials, int n_partials,
-                                                         float max_norm, float* __restrict__ out_norm) {
-  return clip_coef_impl<false>(partials, n_partials, max_norm, out_norm);
-}
-__device__ __forceinline__ float clip_coef_coherent(const double* partials, int n_partials, float max_norm, float* out_norm) {
-  return clip_coef_impl<true>(partials, n_partials, max_norm, out_norm);
 }
 
 // torch.optim.RMSprop:  sq = a*sq + (1-a)*g*g ; centered: ga = a*ga + (1-a)*g,
@@ -136,15 +124,12 @@ __device__ __forceinline__ void rmsprop_elem(float& p, float g, float& s, float&
   p = p - lr * (gk / avg);
 }
 
-// ---- segmented fold + norm, and the same pass with the optimiser behind a grid barrier ----------------------------
-// The one-pass conv weight gradients write one slab per (sample, row chunk): 32-160 slabs per layer.  ONE work
-// decomposition serves two launches:
-//   MODE 0  fold + per-workgroup sums of squares -> partials (the optimiser is a second launch, dra_*_step);
-//   MODE 1/2  the same, then every workgroup publishes its partial, meets the others at a GRID BARRIER, reduces the
-//           partials in the fixed order and applies RMSprop / Adam to the elements it already holds in registers --
-//           one launch less on the update's dependent chain, the gradient is not re-read, and the loads of the
-//           parameters / optimiser state (issued before the barrier) overlap the fold.  Needs every workgroup
-//           co-resident: the launcher refuses grids larger than the caller's resident-workgroup limit.
+// ---- segmented fold + norm --------------------------------------------------------------------------------------------
+// The one-pass conv weight gradients write one slab per (sample, row chunk): 32-160 slabs per layer.  This launch folds
+// them and leaves per-workgroup sums of squares in `partials` (the optimiser is a second launch, dra_*_step).
+// (Round 2 also ran the optimiser behind a GRID BARRIER in this launch -- every workgroup keeping its elements in registers,
+// one ticket counter: bit-identical and 14 % slower, the 796 tickets serialise at ~30 ns each: DESIGN.md section 4,
+// profiles/r02zt_*.  Removed in round 4; the late-fold form below is what replaced the second launch.)
 // Workgroup kinds (block ranges [fold blocks of segment 0][segment 1]...[plain blocks]); a fold workgroup is 16 slab
 // groups x 16 float4 elements per unit, thread (g, el) sums slabs g, g+16, ... in increasing order, the 16 group
 // partials meet in LDS and are added in group order: deterministic, and ONE memory round trip per workgroup:
@@ -154,7 +139,7 @@ __device__ __forceinline__ void rmsprop_elem(float& p, float g, float& s, float&
 constexpr int kPlainNV = 4;
 constexpr int kWideL = 10;
 constexpr int kNarrowU = 4;
-constexpr unsigned long long kBarrierTicks = 5000000ull;   // 50 ms of s_memrealtime (100 MHz): a barrier that cannot
+constexpr unsigned long long kBarrierTicks = 5000000ull;   // 50 ms of s_memrealtime (100 MHz): a device-side wait that cannot
                                                            // complete reports through the timeout flag instead of hanging
 
 struct FoldPlan {
@@ -164,7 +149,7 @@ struct FoldPlan {
   int64_t stride4[DRA_MAX_FOLD_SEGS];
   int32_t n_slabs[DRA_MAX_FOLD_SEGS];
   int32_t first_block[DRA_MAX_FOLD_SEGS + 1];  // block range of each segment; [n_segs] = first plain block
-  int32_t n_segs, plain_blocks, plain_iters;   // plain_iters > 1 (MODE 0 only): a plain workgroup walks that many strides
+  int32_t n_segs, plain_blocks, plain_iters;   // plain_iters > 1: a plain workgroup walks that many strides
   int64_t plain_begin4, plain_count4;    // [plain_begin4, plain_begin4 + plain_count4): no slabs
 };
 
@@ -177,26 +162,13 @@ struct StepHyper {
 __device__ __forceinline__ float sq4(const float4& v) { return v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
 __device__ __forceinline__ void add4(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
-template <int MODE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
-clip_step_kernel(float* __restrict__ grad, const FoldPlan fp, double* __restrict__ partials, float* __restrict__ p,
-                 float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ p_copy, const StepHyper hp,
-                 float* __restrict__ out_norm, unsigned long long* __restrict__ barrier, int* __restrict__ timeout_flag) {
+fold_norm_kernel(float* __restrict__ grad, const FoldPlan fp, double* __restrict__ partials) {
   __shared__ float4 s_part[kNarrowU][16][17];
   __shared__ double s_red[4];
-  __shared__ float s_hyper[2];
   const int tid = threadIdx.x, bid = blockIdx.x;
-  constexpr bool STEP = MODE != 0;
   float acc = 0.f;
-  // what this thread holds across the barrier: up to kPlainNV float4 elements (global float4 index gi, -1 = none)
-  int64_t gi[kPlainNV];
-  float4 G[kPlainNV], P[kPlainNV], S[kPlainNV], A[kPlainNV];
-#pragma unroll
-  for (int v = 0; v < kPlainNV; ++v) gi[v] = -1;
   float4* __restrict__ g4 = reinterpret_cast<float4*>(grad);
-  [[maybe_unused]] const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
-  [[maybe_unused]] const float4* __restrict__ s14 = reinterpret_cast<const float4*>(s1);
-  [[maybe_unused]] const float4* __restrict__ s24 = reinterpret_cast<const float4*>((MODE == 1 && !hp.centered) ? s1 : s2);
   DRA_STAMP(TR_NORM, 0);
   if (bid < fp.first_block[fp.n_segs]) {
     int sg = 0;
@@ -211,10 +183,6 @@ clip_step_kernel(float* __restrict__ grad, const FoldPlan fp, double* __restrict
       // ---- narrow: units b*4 .. b*4+3; the owner of element (u, el) is thread 16 u + el
       const int64_t e0 = (int64_t)b * (16 * kNarrowU);
       const int64_t io = e0 + tid;                               // owner's element (tid < 64)
-      if (STEP && tid < 16 * kNarrowU) {
-        const int64_t ic = fp.begin4[sg] + (io < n4 ? io : n4 - 1);
-        P[0] = p4[ic]; S[0] = s14[ic]; A[0] = s24[ic];
-      }
       float4 t[kNarrowU][2];
       const bool v0 = g < ns, v1 = g + 16 < ns;
       const int64_t r0 = (int64_t)(v0 ? g : 0) * st4, r1 = (int64_t)(v1 ? g + 16 : 0) * st4;
@@ -242,18 +210,12 @@ clip_step_kernel(float* __restrict__ grad, const FoldPlan fp, double* __restrict
         if (io < n4) {
           g4[fp.begin4[sg] + io] = r;
           acc += sq4(r);
-          G[0] = r;
-          gi[0] = fp.begin4[sg] + io;
         }
       }
     } else {
       // ---- wide: unit b; the owner of element el is thread el
       const int64_t i = (int64_t)b * 16 + el;
       const int64_t ic = i < n4 ? i : n4 - 1;
-      if (STEP && tid < 16) {
-        const int64_t ig = fp.begin4[sg] + ic;
-        P[0] = p4[ig]; S[0] = s14[ig]; A[0] = s24[ig];
-      }
       float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int s0 = g; s0 < ns; s0 += 16 * kWideL) {
         float4 t[kWideL];
@@ -275,95 +237,32 @@ clip_step_kernel(float* __restrict__ grad, const FoldPlan fp, double* __restrict
         if (i < n4) {
           g4[fp.begin4[sg] + i] = r;
           acc += sq4(r);
-          G[0] = r;
-          gi[0] = fp.begin4[sg] + i;
         }
       }
     }
   } else {
-    // ---- plain: kPlainNV float4 per thread, every operand requested up front
+    // ---- plain: kPlainNV float4 per thread and stride, every operand of a stride requested up front
     const int b = bid - fp.first_block[fp.n_segs];
-    for (int it = 0; it < (STEP ? 1 : fp.plain_iters); ++it) {
+    for (int it = 0; it < fp.plain_iters; ++it) {
       const int64_t i0 = ((int64_t)it * fp.plain_blocks + b) * (256 * kPlainNV) + tid;
+      float4 G[kPlainNV];
 #pragma unroll
       for (int v = 0; v < kPlainNV; ++v) {
         const int64_t i = i0 + 256 * v;
-        const int64_t ic = fp.plain_begin4 + (i < fp.plain_count4 ? i : fp.plain_count4 - 1);
-        G[v] = g4[ic];
-        if (STEP) { P[v] = p4[ic]; S[v] = s14[ic]; A[v] = s24[ic]; }
+        G[v] = g4[fp.plain_begin4 + (i < fp.plain_count4 ? i : fp.plain_count4 - 1)];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int v = 0; v < kPlainNV; ++v) {
-        const int64_t i = i0 + 256 * v;
-        if (i < fp.plain_count4) {
-          acc += sq4(G[v]);
-          gi[v] = fp.plain_begin4 + i;
-        }
-      }
+      for (int v = 0; v < kPlainNV; ++v)
+        if (i0 + 256 * v < fp.plain_count4) acc += sq4(G[v]);
     }
   }
   DRA_STAMP(TR_NORM, 4);
-  double d = wave_sum((double)acc);
+  const double d = wave_sum((double)acc);
   if ((tid & 63) == 0) s_red[tid >> 6] = d;
-  if (MODE == 2 && tid == 64) {   // Adam's bias corrections from the device step count, exactly as dra_adam_hyper forms them
-    const double t = (double)*hp.step_dev;
-    const double bc1 = 1.0 - pow((double)hp.a, t), bc2 = 1.0 - pow((double)hp.b2, t);
-    s_hyper[0] = (float)((double)hp.lr / bc1);
-    s_hyper[1] = (float)(1.0 / sqrt(bc2));
-  }
   __syncthreads();
-  if (!STEP) {
-    if (tid == 0) partials[bid] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    DRA_STAMP(TR_NORM, 5);
-    DRA_STAMP_END(TR_NORM);
-    return;
-  }
-  // ---- grid barrier.  The partial is published with an agent-scope store (written through: the other XCDs' L2s are not
-  // coherent with this one), completed with s_waitcnt, and only then the ticket is taken; the counter only ever grows
-  // (generation = ticket / workgroups), so graph replays need no reset.  (Same publish / ticket pattern as
-  // actor_fc4_head_env_kernel in learner.hip.)
-  if (tid == 0) {
-    __hip_atomic_store(partials + bid, (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long nb = gridDim.x;
-    const unsigned long long ticket = __hip_atomic_fetch_add(barrier, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long target = (ticket / nb + 1ull) * nb;
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > kBarrierTicks) {
-        __hip_atomic_store(timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-    }
-  }
-  __syncthreads();
+  if (tid == 0) partials[bid] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
   DRA_STAMP(TR_NORM, 5);
-  const float coef = clip_coef_coherent(partials, (int)gridDim.x, hp.max_norm, out_norm);
-  [[maybe_unused]] const float oma = 1.f - hp.a, omb2 = 1.f - hp.b2;
-  [[maybe_unused]] const float step_size = s_hyper[0], inv_sqrt_bc2 = s_hyper[1];
-#pragma unroll
-  for (int v = 0; v < kPlainNV; ++v) {
-    if (gi[v] >= 0) {
-      float* pp = &P[v].x; const float* gg = &G[v].x; float* ss = &S[v].x; float* aa = &A[v].x;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (MODE == 1) {
-          rmsprop_elem(pp[k], gg[k], ss[k], aa[k], coef, hp.a, oma, hp.lr, hp.eps, hp.centered);
-        } else {
-          const float gk = gg[k] * coef;
-          ss[k] = ss[k] * hp.a + oma * gk;                       // exp_avg
-          aa[k] = aa[k] * hp.b2 + omb2 * gk * gk;                // exp_avg_sq
-          pp[k] = pp[k] - step_size * (ss[k] / (sqrtf(aa[k]) * inv_sqrt_bc2 + hp.eps));
-        }
-      }
-      reinterpret_cast<float4*>(p)[gi[v]] = P[v];
-      if (p_copy) reinterpret_cast<float4*>(p_copy)[gi[v]] = P[v];
-      reinterpret_cast<float4*>(s1)[gi[v]] = S[v];
-      if (MODE == 2 || hp.centered) reinterpret_cast<float4*>(s2)[gi[v]] = A[v];
-    }
-  }
   DRA_STAMP_END(TR_NORM);
 }
 
@@ -412,6 +311,15 @@ static int make_fold_plan(int64_t n, const dra_fold_seg* segs, int n_segs, FoldP
 // (grad[seg] = sum_s slabs[s*stride + i], fixed order) and everything after the last segment is read as
 // is; *n_partials doubles are written (<= dra_norm_partials_max()) -- pass that count to dra_*_step.
 
+// Workgroups (= partials written) of dra_grad_sqnorm_segs for this gradient layout: pure host arithmetic.
+DRA_API int dra_grad_sqnorm_segs_blocks(int64_t n, const dra_fold_seg* segs, int n_segs, int* blocks) {
+  if (!blocks) return DRA_EINVAL;
+  FoldPlan fp;
+  int rc = make_fold_plan(n, segs, n_segs, &fp, blocks);
+  if (rc) return rc;
+  return *blocks > dra_norm_partials_max() ? DRA_EINVAL : DRA_OK;
+}
+
 DRA_API int dra_grad_sqnorm_segs(float* grad, int64_t n, const dra_fold_seg* segs, int n_segs, double* partials,
                                  int* n_partials, void* stream) {
   if (!grad || !partials || !n_partials || (((uintptr_t)grad) & 15)) return DRA_EINVAL;
@@ -420,71 +328,11 @@ DRA_API int dra_grad_sqnorm_segs(float* grad, int64_t n, const dra_fold_seg* seg
   int rc = make_fold_plan(n, segs, n_segs, &fp, &blocks);
   if (rc) return rc;
   if (blocks > dra_norm_partials_max()) return DRA_EINVAL;
-  StepHyper hp;
-  memset(&hp, 0, sizeof(hp));
-  hipLaunchKernelGGL(clip_step_kernel<0>, dim3(blocks), dim3(256), 0, dra_stream(stream), grad, fp, partials, (float*)nullptr,
-                     (float*)nullptr, (float*)nullptr, (float*)nullptr, hp, (float*)nullptr, (unsigned long long*)nullptr,
-                     (int*)nullptr);
+  hipLaunchKernelGGL(fold_norm_kernel, dim3(blocks), dim3(256), 0, dra_stream(stream), grad, fp, partials);
   DRA_LAUNCH_CHECK();
   *n_partials = blocks;
   return DRA_OK;
 }
-
-// ---- cooperative form: fold + norm + optimiser as ONE launch (clip_step_kernel<1 / 2>) --------------------------------
-// Workgroups of the launch for this gradient layout (the same count dra_grad_sqnorm_segs writes partials for).
-DRA_API int dra_clip_step_coop_blocks(int64_t n, const dra_fold_seg* segs, int n_segs, int* blocks) {
-  if (!blocks) return DRA_EINVAL;
-  FoldPlan fp;
-  int rc = make_fold_plan(n, segs, n_segs, &fp, blocks);
-  if (rc) return rc;
-  if (fp.plain_iters != 1 || *blocks > dra_norm_partials_max()) return DRA_EINVAL;   // the barrier form holds every element in registers
-  return DRA_OK;
-}
-
-// Workgroups of the cooperative kernel one CU can hold at once (registers / LDS of the compiled kernel): the grid barrier
-// needs blocks <= n_cus_of_the_stream * this.  optimizer: DRA_OPT_RMSPROP / DRA_OPT_ADAM.
-DRA_API int dra_clip_step_coop_occupancy(int optimizer, int* blocks_per_cu) {
-  if (!blocks_per_cu) return DRA_EINVAL;
-  int nb = 0;
-  if (optimizer == DRA_OPT_ADAM) DRA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, clip_step_kernel<2>, 256, 0));
-  else DRA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, clip_step_kernel<1>, 256, 0));
-  *blocks_per_cu = nb;
-  return DRA_OK;
-}
-
-// barrier_ctr: one zero-initialised 64-bit counter in device memory per (stream, gradient layout) -- it only grows;
-// timeout_flag: int in PINNED HOST memory, zero-initialised: set to 1 by a workgroup whose barrier wait exceeded 50 ms
-// (the grid was not co-resident after all); results of that launch are then invalid and the caller must check the flag.
-// resident_limit: workgroups that can be co-resident on the CUs `stream` may use; a larger grid is refused (DRA_EINVAL)
-// and the caller uses the two-launch form.  hyper: {lr, alpha | beta1, eps, beta2}; step_dev: Adam's device step count.
-DRA_API int dra_clip_step_coop(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* segs,
-                               int n_segs, double* partials, unsigned long long* barrier_ctr, int* timeout_flag,
-                               int resident_limit, int optimizer, float max_norm, const float* hyper, int centered,
-                               const int64_t* step_dev, float* out_norm, float* param_copy, void* stream) {
-  if (!param || !grad || !state1 || !partials || !barrier_ctr || !timeout_flag || !hyper) return DRA_EINVAL;
-  if (optimizer != DRA_OPT_RMSPROP && optimizer != DRA_OPT_ADAM) return DRA_EINVAL;
-  if ((optimizer == DRA_OPT_ADAM && (!state2 || !step_dev)) || (optimizer == DRA_OPT_RMSPROP && centered && !state2)) return DRA_EINVAL;
-  if ((((uintptr_t)param) | ((uintptr_t)grad) | ((uintptr_t)state1) | ((uintptr_t)state2) | ((uintptr_t)param_copy)) & 15)
-    return DRA_EINVAL;
-  FoldPlan fp;
-  int blocks = 0;
-  int rc = make_fold_plan(n, segs, n_segs, &fp, &blocks);
-  if (rc) return rc;
-  if (fp.plain_iters != 1 || blocks > dra_norm_partials_max() || blocks > resident_limit) return DRA_EINVAL;
-  StepHyper hp;
-  memset(&hp, 0, sizeof(hp));
-  hp.max_norm = max_norm; hp.lr = hyper[0]; hp.a = hyper[1]; hp.eps = hyper[2]; hp.b2 = hyper[3];
-  hp.centered = centered; hp.step_dev = step_dev;
-  if (optimizer == DRA_OPT_ADAM)
-    hipLaunchKernelGGL(clip_step_kernel<2>, dim3(blocks), dim3(256), 0, dra_stream(stream), grad, fp, partials, param, state1,
-                       state2, param_copy, hp, out_norm, barrier_ctr, timeout_flag);
-  else
-    hipLaunchKernelGGL(clip_step_kernel<1>, dim3(blocks), dim3(256), 0, dra_stream(stream), grad, fp, partials, param, state1,
-                       state2, param_copy, hp, out_norm, barrier_ctr, timeout_flag);
-  DRA_LAUNCH_CHECK();
-  return DRA_OK;
-}
-
 
 // ---- late-fold form (DRA_VAR_LATE_FOLD): the optimizer launch with only the LAST layer's fold in front --------------------
 // The gradient-norm pass was a launch of its own on the update's dependent chain (5.8 us + a 1.8 us boundary,
@@ -502,7 +350,7 @@ DRA_API int dra_clip_step_coop(float* param, float* grad, float* state1, float* 
 // the earlier launches' partials (plain cached loads) first; thread t < fold_blocks then polls slot t until it is
 // non-negative, the partials are reduced in the fixed order and the step is applied.  Progress: the fold workgroups have
 // the lowest block indices, so they are resident before any waiting workgroup; a wait is bounded (50 ms) and reports
-// through the pinned timeout flag like the cooperative form.  The slots must hold -1 at launch (FoldRole::reset_slots in
+// through the pinned timeout flag.  The slots must hold -1 at launch (FoldRole::reset_slots in
 // the preceding launch).
 struct LatePlan {
   int64_t n;             // floats in the flat buffers (a tail of n % 4 floats is stepped by the last workgroup)
@@ -702,7 +550,7 @@ DRA_API int dra_clip_step_late_blocks(const dra_fold_seg* seg, int* fold_blocks)
 
 // seg: the ONE segment still in slabs (must start at element 0 of the flat gradient, n_slabs <= 256, at most 256 fold
 // workgroups); partials[0, n_prior) were written by earlier launches, partials[n_prior, n_prior + fold_blocks) must hold -1.0
-// at launch and receive this launch's published sums; timeout_flag: pinned host int.  hyper / optimizer as dra_clip_step_coop.
+// at launch and receive this launch's published sums; timeout_flag: pinned host int.  optimizer: DRA_OPT_RMSPROP (hyper = {lr, alpha, eps, -}) or DRA_OPT_ADAM ({lr, beta1, eps, beta2}, step count read from step_dev).
 DRA_API int dra_clip_step_late(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* seg,
                                double* partials, int n_prior, int* timeout_flag, int optimizer, float max_norm,
                                const float* hyper, int centered, const int64_t* step_dev, float* out_norm, float* param_copy,
@@ -743,25 +591,8 @@ DRA_API int dra_clip_step_late(float* param, float* grad, float* state1, float* 
   return DRA_OK;
 }
 
-// NT: the optimizer state (sq, ga) and the gradient are touched once per update -- stream them past the caches
-// (non-temporal) so that the update does not evict what the concurrently running actor re-reads from L2 / MALL
-// (its parameter copy: 4 forwards per agent step)
-typedef float f32x4_nt __attribute__((ext_vector_type(4)));
-template <bool NT>
-__device__ __forceinline__ float4 ld4(const float4* p) {
-  if (!NT) return *p;
-  const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-template <bool NT>
-__device__ __forceinline__ void st4(float4* p, const float4& v) {
-  if (!NT) { *p = v; return; }
-  f32x4_nt w;
-  w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
-  __builtin_nontemporal_store(w, reinterpret_cast<f32x4_nt*>(p));
-}
-
-template <bool NT>
+// (Round 2 measured non-temporal loads / stores of the gradient and the optimizer state here, meant to keep the actor's parameter
+// copy in L2 / MALL: RMSprop 8.8 -> 11.2 us, actor fc4 unchanged -- DESIGN.md section 4; the switch was removed in round 4.)
 __global__ void __launch_bounds__(256)
 rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, float* __restrict__ ga,
                     int64_t n, const double* __restrict__ partials, int n_partials, float max_norm, float lr,
@@ -778,9 +609,9 @@ rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* _
     const int64_t i = i0 + 256 * v;
     const int64_t ic = i < n4 ? i : n4 - 1;
     P[v] = reinterpret_cast<float4*>(p)[ic];
-    G[v] = ld4<NT>(reinterpret_cast<const float4*>(g) + ic);
-    S[v] = ld4<NT>(reinterpret_cast<const float4*>(sq) + ic);
-    A[v] = ld4<NT>(reinterpret_cast<const float4*>(centered ? ga : sq) + ic);
+    G[v] = reinterpret_cast<const float4*>(g)[ic];
+    S[v] = reinterpret_cast<const float4*>(sq)[ic];
+    A[v] = reinterpret_cast<const float4*>(centered ? ga : sq)[ic];
   }
   __builtin_amdgcn_sched_barrier(0);
   const float coef = clip_coef_from_partials(partials, n_partials, max_norm, out_norm);
@@ -794,8 +625,8 @@ rmsprop_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* _
       for (int k = 0; k < 4; ++k) rmsprop_elem(pp[k], gg[k], ss[k], aa[k], coef, alpha, oma, lr, eps, centered);
       reinterpret_cast<float4*>(p)[i] = P[v];
       if (p_copy) reinterpret_cast<float4*>(p_copy)[i] = P[v];
-      st4<NT>(reinterpret_cast<float4*>(sq) + i, S[v]);
-      if (centered) st4<NT>(reinterpret_cast<float4*>(ga) + i, A[v]);
+      reinterpret_cast<float4*>(sq)[i] = S[v];
+      if (centered) reinterpret_cast<float4*>(ga)[i] = A[v];
     }
   }
   // tail (n not a multiple of 4): the last few floats, by the first threads of workgroup 0
@@ -829,14 +660,8 @@ DRA_API int dra_rmsprop_step_copy(float* param, const float* grad, float* square
   if (n < 4) return DRA_EINVAL;
   if (partials && (n_partials < 1 || n_partials > dra_norm_partials_max())) return DRA_EINVAL;
   if (step_blocks(n) > 0x7fffffff) return DRA_EINVAL;
-  static int nt = -1;
-  if (nt < 0) { const char* e = getenv("DRA_NT_OPT"); nt = e ? atoi(e) : 0; }
-  if (nt & 1)
-    hipLaunchKernelGGL(rmsprop_step_kernel<true>, dim3((unsigned)step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad,
-                       square_avg, grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps, centered, out_norm, param_copy);
-  else
-    hipLaunchKernelGGL(rmsprop_step_kernel<false>, dim3((unsigned)step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad,
-                       square_avg, grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps, centered, out_norm, param_copy);
+  hipLaunchKernelGGL(rmsprop_step_kernel, dim3((unsigned)step_blocks(n)), dim3(256), 0, dra_stream(stream), param, grad,
+                     square_avg, grad_avg, n, partials, n_partials, max_norm, lr, alpha, eps, centered, out_norm, param_copy);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

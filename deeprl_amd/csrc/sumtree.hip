@@ -341,145 +341,13 @@ DRA_API int dra_sumtree_rebuild(dra_sumtree* t, void* stream) {
   return DRA_OK;
 }
 
-// ---- the prioritized draw inside the update chain (round 3) ----------------------------------------------------------
-// PrioritizedReplay in the two-stream pipeline cost 229 us per agent step against 117 us with uniform replay: the write-back of
-// update t, the adds of step t+1 and the descent of draw t+1 ran on their own stream, and both the cross-stream wait in front
-// of them (38 us inside the launch call that follows a wait on an event recorded between two graph launches) and the host's
-// wait for the descent sat on the loop update -> priorities -> next draw -> next update (tools/diag_per_host.py).
-// dra_sumtree_per_chain is ONE single-workgroup kernel that the learner captures INTO its update graph right behind the loss
-// kernel:   commit (sumtree_commit_kernel's arithmetic, incl. the ordered-walk fallback)  ->  n adds at max_priority
-// (sumtree_set_many_from_kernel)  ->  stratified descent of the NEXT draw (sumtree_sample_kernel),
-// every per-step input read from, and the draw's results written to, ONE pinned host block `io` (constant kernel arguments:
-// the launch replays from a graph).  The host fills io before issuing the update -- which leaves are written is decided by
-// pending_idx gating that needs no priority value -- and collects the next draw after the loss event: no stream of its
-// own, no cross-stream event, the backward pass runs underneath the host's bookkeeping.  Same order as the reference's
+// ---- PrioritizedReplay.sample() entirely on the device (include/deeprl_amd.h dra_per_chain2_io) ---------------------------
+// PrioritizedReplay in the two-stream pipeline cost 229 us per agent step against 117 us with uniform replay while the
+// write-back of update t, the adds of step t+1 and the descent of draw t+1 ran on their own stream with the host in between
+// (tools/diag_per_host.py).  Round 3's first form put those three steps into ONE kernel behind the loss with the host still
+// gating / collecting between two updates (5.5 -> 7.0 k updates/s was the second form's gain over it); it was removed in
+// round 4.  What remains: the whole draw on the device, same order as the reference's
 // update_priorities(t) -> feed(t+1) x n -> sample(t+1) (replay.py:164-196).
-__global__ void __launch_bounds__(1024)
-sumtree_per_chain_kernel(double* __restrict__ tree, int levels, int64_t capacity, int64_t n_nodes, dra_per_chain_io* __restrict__ io,
-                         const float* __restrict__ prio, double* __restrict__ stat) {
-  __shared__ double s_hi[16], s_lo[16];
-  __shared__ int s_ordered, s_n, s_add_n, s_batch, s_next_batch, s_force;
-  __shared__ int64_t s_write0;
-  const int tid = threadIdx.x;
-  if (tid == 0) {
-    s_n = io->n_commit; s_add_n = io->add_n; s_batch = io->batch; s_next_batch = io->next_batch; s_force = io->force_ordered;
-    s_write0 = io->add_write0;
-  }
-  __syncthreads();
-  const int n = s_n, batch = s_batch;
-  // ---- commit: {max, min} over every offered priority, then the gated leaves
-  double hi = -INFINITY, lo = INFINITY;
-  for (int b = tid; b < batch; b += blockDim.x) {
-    const double v = (double)prio[b];
-    hi = fmax(hi, v);
-    lo = fmin(lo, v);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    hi = fmax(hi, __shfl_xor(hi, off));
-    lo = fmin(lo, __shfl_xor(lo, off));
-  }
-  if ((tid & 63) == 0) { s_hi[tid >> 6] = hi; s_lo[tid >> 6] = lo; }
-  __syncthreads();
-  if (tid == 0) {
-    const int nw = (int)(blockDim.x >> 6);
-    for (int w = 1; w < nw; ++w) { hi = fmax(hi, s_hi[w]); lo = fmin(lo, s_lo[w]); }
-    if (batch > 0) {
-      hi = fmax(hi, stat[0]);
-      lo = fmin(lo, stat[1]);
-      stat[0] = hi;
-      stat[1] = lo;
-    } else {
-      hi = stat[0];
-      lo = stat[1];
-    }
-    int ordered = s_force;
-    if (!(lo > 0.0) || !(hi < INFINITY)) ordered = 1;
-    else if ((double)capacity * hi > ldexp(1.0, 53 + ilogb(lo) - 23)) ordered = 1;
-    s_ordered = ordered;
-  }
-  __syncthreads();
-  if (s_ordered) {
-    if (tid == 0) {
-      for (int k = 0; k < n; ++k) {
-        int64_t node = io->leaves[k];
-        const double p = (double)prio[io->pos[k]];
-        const double change = __dsub_rn(p, node_load(tree + node));
-        node_store(tree + node, p);
-        while (node > 0) {
-          node = (node - 1) >> 1;
-          node_store(tree + node, __dadd_rn(node_load(tree + node), change));
-        }
-      }
-    }
-    __threadfence_block();
-  } else {
-    int64_t node = -1;
-    if (tid < n) {
-      node = io->leaves[tid];
-      node_store(tree + node, (double)prio[io->pos[tid]]);
-    }
-    for (int lv = 0; lv < levels; ++lv) {
-      __syncthreads();
-      if (node > 0) {
-        const int64_t parent = (node - 1) >> 1;
-        const double s = __dadd_rn(node_load(tree + 2 * parent + 1), node_load(tree + 2 * parent + 2));
-        node_store(tree + parent, s);
-        node = parent;
-      }
-    }
-  }
-  __syncthreads();
-  // ---- adds of the next agent step's transitions at max_priority (stat[0], just updated)
-  {
-    int64_t node = -1;
-    if (tid < s_add_n) {
-      node = (s_write0 + tid) % capacity + capacity - 1;
-      node_store(tree + node, node_load(stat));
-    }
-    for (int lv = 0; lv < levels; ++lv) {
-      __syncthreads();
-      if (node > 0) {
-        const int64_t parent = (node - 1) >> 1;
-        const double s = __dadd_rn(node_load(tree + 2 * parent + 1), node_load(tree + 2 * parent + 2));
-        node_store(tree + parent, s);
-        node = parent;
-      }
-    }
-  }
-  __syncthreads();
-  // ---- stratified descent of the next draw (python random.uniform(a, b) = a + (b - a) * u; sum_tree.py:23-33)
-  const int nb = s_next_batch;
-  const double total = node_load(tree);
-  if (tid == 0) io->out_total = total;
-  if (tid < nb) {
-    const double seg = __ddiv_rn(total, (double)nb);
-    const double a = __dmul_rn(seg, (double)tid);
-    const double b = __dmul_rn(seg, (double)(tid + 1));
-    double s = __dadd_rn(a, __dmul_rn(__dsub_rn(b, a), io->u[tid]));
-    int64_t idx = 0;
-    while (true) {
-      const int64_t left = 2 * idx + 1;
-      if (left >= n_nodes) break;
-      const double lv = node_load(tree + left);
-      if (s <= lv) idx = left;
-      else { idx = left + 1; s = __dsub_rn(s, lv); }
-    }
-    io->out_idx[tid] = idx;
-    io->out_p[tid] = node_load(tree + idx);
-  }
-}
-
-DRA_API int dra_sumtree_per_chain(dra_sumtree* t, dra_per_chain_io* io_pinned, const float* prio_f32_dev, double* stat_dev,
-                                  void* stream) {
-  if (!t || !io_pinned || !prio_f32_dev || !stat_dev) return DRA_EINVAL;
-  hipLaunchKernelGGL(sumtree_per_chain_kernel, dim3(1), dim3(1024), 0, dra_stream(stream), t->tree, t->levels, t->capacity,
-                     t->n_nodes, io_pinned, prio_f32_dev, stat_dev);
-  DRA_LAUNCH_CHECK();
-  return DRA_OK;
-}
-
-// ---- second form: PrioritizedReplay.sample() entirely on the device (include/deeprl_amd.h dra_per_chain2_io) --------------
 // The body lives in per_chain2.h (it also rides in the update's conv3 backward launch as a role: fused.hip ChainRole).
 __global__ void __launch_bounds__(1024) sumtree_per_chain2_kernel(const PerChain2Args a) {
   __shared__ __attribute__((aligned(16))) char smem[per_chain2_lds_bytes<1024>()];

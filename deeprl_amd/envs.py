@@ -292,7 +292,10 @@ def _real_task_envs(name, num_envs, seed, episode_life):
     except ImportError:
         make_atari = wrap_deepmind = None
     envs = []
+    from .support import random_seed
     for i in range(num_envs):
+        random_seed(seed)        # the reference's thunk reseeds np.random / torch for EVERY environment it builds (envs.py:28):
+        #                          the global generators' state after Task(...) is part of what a seeded run reproduces
         if name.startswith("dm"):
             import dm_control2gym
             _, domain, task = name.split('-')

@@ -142,10 +142,6 @@ class DQNLearner:
         else:
             self.stream = torch.cuda.Stream()                        # graphs cannot capture on the NULL stream
             self.actor_stream = torch.cuda.Stream()
-        # VAR_COOP_OPT: the cooperative optimizer launch needs its whole grid resident on the update stream's CUs -- the C
-        # side decides from their number (once, before the first update)
-        n_cu = torch.cuda.get_device_properties(Config.DEVICE).multi_processor_count
-        lib.dra_dqn_learner_set_update_cus(h, int(self.update_cus or n_cu))
         self.params = StepParams()
         self._idx_view = np.ctypeslib.as_array(self.params.idx)[:batch]
         self._idx_pinned = [torch.empty(batch, dtype=torch.int64).pin_memory() for _ in range(8)]
@@ -288,12 +284,6 @@ class DQNLearner:
         new priorities in self.prio."""
         lib.dra_dqn_learner_set_per(self.h, int(bool(per)), float(beta))
 
-    def set_per_chain(self, tree, stat, blocks):
-        """PrioritizedReplay inside the update chain: `tree` (ops.SumTree), `stat` (its device {max, min} pair) and four
-        pinned dra_per_chain_io blocks; before the first prioritized update."""
-        lib.dra_dqn_learner_set_per_chain(self.h, tree.h, ctypes.c_void_p(stat.data_ptr()),
-                                          *[ctypes.c_void_p(ctypes.addressof(b)) for b in blocks])
-
     def set_per_chain2(self, tree, stat, blocks, rng_words):
         """PrioritizedReplay.sample() on the device (dra_sumtree_per_chain2): four pinned dra_per_chain2_io blocks and the
         pinned ring of Mersenne-Twister words; before the first prioritized update."""
@@ -370,12 +360,6 @@ class DQNLearner:
     def synchronize(self):
         self.stream.synchronize()
         self.actor_stream.synchronize()
-
-    def coop_state(self):
-        """(cooperative optimizer launch in use, its grid, resident-workgroup limit it was compared with): VAR_COOP_OPT."""
-        c, b, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        lib.dra_dqn_learner_coop_state(self.h, ctypes.byref(c), ctypes.byref(b), ctypes.byref(r))
-        return bool(c.value), b.value, r.value
 
     def host_stats(self, reset=True):
         """Host-side accounting of dra_dqn_learner_step since the last reset: number of calls, mean microseconds inside the
@@ -568,17 +552,14 @@ class DeviceActorPipeline:
         # latency chains of ~20 dependent levels each; they depend on the previous UPDATE only, so they run on their own
         # stream underneath the actor's forward passes
         self.tree_stream = torch.cuda.Stream() if self.per else None
-        # PER + async: write-back, next step's adds and the next draw's descent run INSIDE the update graph behind the loss
-        # kernel (sumtree.hip dra_sumtree_per_chain): the host collects the next draw after the loss event instead of driving
-        # a tree stream (DRA_PER_CHAIN=0: the round-2 tree-stream form)
-        # DRA_PER_CHAIN=2 (default where the ring-direct pipeline runs): the kernel also filters / pads the draw and hands the
-        # minibatch to the next update in device memory (dra_sumtree_per_chain2, replay.DeviceDraw): no host wait at all
-        mode = int(os.environ.get("DRA_PER_CHAIN", "2")) if (self.per and async_actor) else 0
+        # PER + async (the ring-direct pipeline, minibatches up to 1024): the whole of sample() -- write-back, the next step's adds,
+        # descent, valid_index filter, padding -- runs INSIDE the update and hands the next minibatch over in device memory
+        # (dra_sumtree_per_chain2, replay.DeviceDraw): no host wait at all.  chain = 2 names that form (0: the round-2
+        # tree-stream form, the fallback for other kernel variants / larger minibatches; round 3's intermediate form 1 -- the
+        # host between two updates -- was removed in round 4)
         need2 = (ops.VAR_PIPE_GATHER | ops.VAR_ACTOR_PARAMS | ops.VAR_GATHER_ON_UPDATE | ops.VAR_RING_DIRECT | ops.VAR_ACTOR_RING)
-        if mode == 2 and ((learner.variant & need2) != need2 or replay.batch_size > 1024):
-            mode = 1
+        mode = 2 if (self.per and async_actor and (learner.variant & need2) == need2 and replay.batch_size <= 1024) else 0
         self.chain = mode
-        self._chain_io = self._chain_prev = None
         self._dd = None                       # replay.DeviceDraw (mode 2)
         self.A, self.n_env, self.epsilon_fn, self.async_actor = int(n_actions), int(n_env), epsilon_fn, bool(async_actor)
         self.rs = np.random.RandomState(actor_seed) if async_actor else np.random
@@ -602,10 +583,6 @@ class DeviceActorPipeline:
             dd = self._dd
             dd.release()                       # python `random` is the reference's again; the newest draw is the next update's
             chain_prev = (dd.next_tree_idx.tolist(), dd.next_p.tolist(), dd.next_total, dd.next_beta)
-        elif self._chain_prev is not None:       # the next draw, produced by the last update's chain kernel
-            self.L.sync_loss()
-            b, v = self.rp.batch_size, self._chain_prev.v
-            chain_prev = (v["out_idx"][:b].tolist(), v["out_p"][:b].tolist(), float(v["out_total"][0]))
         return dict(slot=self.slot, pending=[list(p) for p in self.pending], pushed=self.pushed, issued=self.issued,
                     primed=self.primed, rs=(self.rs.get_state() if self.async_actor else None), stream=self.stream.state_dict(),
                     chain_prev=chain_prev)
@@ -627,16 +604,6 @@ class DeviceActorPipeline:
                 self._dd = DeviceDraw(self.rp, self.L)
             idx, p, total, beta = st["chain_prev"]
             self._dd.start(idx, p, total, beta)
-        elif st.get("chain_prev") is not None:
-            if self._chain_io is None:
-                self._chain_io = self.rp.chain_blocks(4)
-                self.L.set_per_chain(self.rp.tree, self.rp._stat, [b for b, _ in self._chain_io])
-            io = self._chain_io[0][0]
-            idx, p, total = st["chain_prev"][:3]
-            io.v["out_idx"][:len(idx)] = idx
-            io.v["out_p"][:len(p)] = p
-            io.v["out_total"][0] = total
-            self._chain_prev = io
 
     def _block(self):
         """Host side of one agent step's transitions -> (StepParams head filled in learner.params, infos)."""
@@ -704,7 +671,7 @@ class DeviceActorPipeline:
         infos = self.pending.pop(0)                                  # produced by the actor launch issued last call
         if self.per:
             # (chain mode, once primed: the tree side of these adds ran inside the previous update's chain kernel)
-            primed = self._chain_prev is not None or (self._dd is not None and self._dd.active)
+            primed = self._dd is not None and self._dd.active
             rp.advance(self.n_env, stream=self.tree_stream, tree=not (self.chain and primed))
         else:
             rp.advance(self.n_env)
@@ -727,31 +694,6 @@ class DeviceActorPipeline:
             L.step_update()                                          # [fwd + loss][commit, adds, next draw][bwd + optimizer]
             L.step_actor(dd.issued_idx())                            # actor(t+1); hazard check on the minibatch just issued
             self.issued += 1
-            if self.pushed - self.issued < 16:
-                self._push(1)
-            return infos
-        if self.per and do_update and self.chain:
-            B = rp.batch_size
-            if self._chain_io is None:
-                self._chain_io = rp.chain_blocks(4)
-                L.set_per_chain(rp.tree, rp._stat, [b for b, _ in self._chain_io])
-            if self._chain_prev is None:
-                # the first prioritized update: a classic draw (tree stream); the tree is then handed to the update stream
-                tree_idx, prob, data_idx = rp.draw_end(rp.draw_begin(stream=self.tree_stream))
-                self.tree_stream.synchronize()
-            else:
-                L.sync_loss()                                       # loss + chain kernel of the previous update have run
-                tree_idx, prob, data_idx = rp.chain_collect(self._chain_prev, B)
-            leaves, pos = rp.commit_select(tree_idx)               # gating needs no priority value: decided before the update
-            io = self._chain_io[L.next_slot()][0]
-            rp.chain_fill(io, leaves, pos, batch=B, add_n=self.n_env, next_batch=B)
-            L.upload_sampling_prob(prob, self.beta_fn())
-            L.set_per(True, -1.0)
-            L.step(data_idx, True, True)                             # [fwd + loss][commit, adds, next descent][bwd + optimizer]
-            self._chain_prev = io
-            self.issued += 1
-            # the next parameter block, generated while this update's forward runs: ONE block per step (16 at a time is a
-            # ~1 ms burst every 16th step that nothing overlaps when the host waits for every update's loss)
             if self.pushed - self.issued < 16:
                 self._push(1)
             return infos
@@ -1017,6 +959,11 @@ class DQNLearnerBench:
 
     def report(self):
         ms = getattr(self, "kernel_ms", {})
-        coop, blocks, limit = self.learner.coop_state()
-        return {"kernel_ms": {k: round(v, 5) for k, v in ms.items()}, "update_kernel_ms_sum": round(sum(ms.values()), 5),
-                "coop_optimizer": {"in_use": coop, "workgroups": blocks, "resident_limit": limit}}
+        # an EAGER update with an event pair around every kernel group (dra_dqn_learner_profile): each entry includes the
+        # pair's own launch boundary, and the eager form gathers its minibatch (the timed ring-direct graphs do not launch
+        # `gather`); groups the learner's variant does not launch at all (a bare event pair) are dropped.  Not a
+        # decomposition of ms_per_step.
+        floor = 1.05 * getattr(self, "event_bracket_ms", 0.0)
+        shown = {k: round(v, 5) for k, v in ms.items() if v > floor}
+        return {"eager_profile_ms": shown, "eager_profile_note": "event-pair readings of ONE eager update, launch boundaries "
+                "included; `gather` runs only in this eager form (the timed graphs read the ring directly)"}

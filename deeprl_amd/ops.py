@@ -416,7 +416,6 @@ VAR_ACTOR_RING = 4096
 VAR_ACTOR_FUSED_CONV1 = 8192
 VAR_GATHER_ON_UPDATE = 16384
 VAR_RING_DIRECT = 32768
-VAR_COOP_OPT = 65536
 VAR_IDX_PREFETCH = 131072
 VAR_WGRAD_ACC = 262144
 VAR_LATE_FOLD = 524288
@@ -535,32 +534,6 @@ def _fold_seg_array(segs):
     return arr
 
 
-def clip_step_coop_blocks(n, segs):
-    """Workgroups of the cooperative fold + norm + optimiser launch for this gradient layout."""
-    b = ctypes.c_int(0)
-    lib.dra_clip_step_coop_blocks(int(n), _fold_seg_array(segs), len(segs), ctypes.byref(b))
-    return b.value
-
-
-def clip_step_coop_occupancy(optimizer):
-    """Workgroups of that kernel one CU holds at once (0 = RMSprop, 1 = Adam)."""
-    b = ctypes.c_int(0)
-    lib.dra_clip_step_coop_occupancy(int(optimizer), ctypes.byref(b))
-    return b.value
-
-
-def clip_step_coop(param, grad, state1, state2, segs, partials, barrier_ctr, timeout_flag, resident_limit, optimizer,
-                   max_norm, hyper, centered=True, step_dev=None, out_norm=None, param_copy=None):
-    """dra_clip_step_coop: slab fold + gradient norm + RMSprop (optimizer 0, hyper = (lr, alpha, eps)) or Adam (1: (lr, beta1,
-    eps, beta2), step count in the int64 device tensor step_dev) as ONE launch behind a grid barrier.  barrier_ctr: zeroed
-    int64 device tensor kept across calls; timeout_flag: zeroed int32 PINNED host tensor (becomes 1 when a barrier gave up)."""
-    hp = (ctypes.c_float * 4)(*([float(v) for v in hyper] + [0.0] * (4 - len(hyper))))
-    lib.dra_clip_step_coop(ptr(param), ptr(grad), ptr(state1), ptr(state2), param.numel(), _fold_seg_array(segs), len(segs),
-                           ptr(partials), ptr(barrier_ctr), ptr(timeout_flag), int(resident_limit), int(optimizer),
-                           float(max_norm if max_norm else 0.0), hp, int(bool(centered)), ptr(step_dev), ptr(out_norm),
-                           ptr(param_copy), stream_ptr())
-
-
 def conv_bwd_x(layer, dy, w, xact=None, act="relu"):
     """Gradient w.r.t. the layer's input; with `xact` (the layer-below's activated output) the
     activation derivative of that layer is folded in (gradient w.r.t. its PRE-activation)."""
@@ -674,14 +647,6 @@ def categorical_fwd(logits, action=None, uniform=None):
     action = _c(action, torch.int64)
     lib.dra_categorical_fwd(ptr(logits), b, a, ptr(action), None, None, ptr(lp), ptr(ent), stream_ptr())
     return action, lp, ent
-
-
-class PerChainIO(ctypes.Structure):
-    """include/deeprl_amd.h dra_per_chain_io (pinned host block of one dra_sumtree_per_chain launch)."""
-    _fields_ = [("n_commit", ctypes.c_int32), ("add_n", ctypes.c_int32), ("batch", ctypes.c_int32), ("next_batch", ctypes.c_int32),
-                ("force_ordered", ctypes.c_int32), ("reserved", ctypes.c_int32), ("add_write0", ctypes.c_int64),
-                ("leaves", ctypes.c_int64 * 1024), ("pos", ctypes.c_int32 * 1024), ("u", ctypes.c_double * 1024),
-                ("out_idx", ctypes.c_int64 * 1024), ("out_p", ctypes.c_double * 1024), ("out_total", ctypes.c_double)]
 
 
 class PerChain2IO(ctypes.Structure):

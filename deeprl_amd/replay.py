@@ -294,6 +294,9 @@ class UniformReplay(Storage):
                 self.device_ring(meta["state_shape"], np.uint8 if "uint8" in sd else (np.float64 if "64" in sd else np.float32),
                                  np.int64 if "int" in meta["action_dtype"] else np.float64)
             frames, actions, rewards, masks = self._ring.arrays()
+            if "frame_bytes" not in meta:
+                raise DraError("%s.replay records %d transitions but no device ring (it was written before the first feed "
+                               "reached the HBM ring): nothing to restore them from" % (prefix, meta["size"]))
             n, fb, per = meta.get("slots", meta["size"]), meta["frame_bytes"], meta.get("slots_per_shard", 1)
             for k in range(meta["shards"]):
                 part = torch.from_numpy(np.fromfile("%s.frames.%d" % (prefix, k), dtype=np.uint8))
@@ -516,65 +519,6 @@ class PrioritizedReplay(UniformReplay):
                 self.tree.update(self._leaf_up.upload(np.asarray(leaves, dtype=np.int64)),
                                  self._prio_up.upload(np.asarray(prios, dtype=np.float64)),
                                  ordered=self.ordered_updates or not self._exact_parallel())
-
-    # -- the prioritized draw inside the update chain (csrc/sumtree.hip dra_sumtree_per_chain; learner.DeviceActorPipeline) --
-    def chain_blocks(self, n=4):
-        """n pinned dra_per_chain_io blocks (one per rotation slot of the pipelined update) -> list of (ctypes struct, pinned
-        tensor); also moves {max_priority, min priority} to the device pair the chain kernel maintains."""
-        import ctypes
-        self._lazy_tree()
-        if not self._stat_on_device:
-            self._stat.copy_(torch.tensor([float(self._max_priority), float(self._min_priority)], dtype=torch.float64))
-            self._stat_on_device = True
-        out = []
-        C = ops.PerChainIO
-        for _ in range(n):
-            t = torch.zeros(ctypes.sizeof(C), dtype=torch.uint8).pin_memory()
-            io = C.from_address(t.data_ptr())
-            raw = t.numpy()
-
-            def view(field, dtype, count):
-                off = getattr(C, field).offset
-                return raw[off:off + count * np.dtype(dtype).itemsize].view(dtype)
-            # numpy views of the block's arrays (ctypes array slicing costs ~10 us per 32 elements; the host is on this loop)
-            io.v = dict(head=view("n_commit", np.int32, 6), write0=view("add_write0", np.int64, 1), leaves=view("leaves", np.int64, 1024),
-                        pos=view("pos", np.int32, 1024), u=view("u", np.float64, 1024), out_idx=view("out_idx", np.int64, 1024),
-                        out_p=view("out_p", np.float64, 1024), out_total=view("out_total", np.float64, 1))
-            out.append((io, t))
-        return out
-
-    def commit_select(self, tree_idx):
-        """update_priorities' gating (sum_tree.py:54-60) without the priorities: which sampled leaves are written -- pending
-        ones, first occurrence wins -- and their positions in the minibatch."""
-        leaves, pos = [], []
-        pend = self._pending
-        for j, idx in enumerate(tree_idx.tolist()):
-            if idx in pend:
-                pend.remove(idx)
-                leaves.append(idx)
-                pos.append(j)
-        return leaves, pos
-
-    def chain_fill(self, io, leaves, pos, batch, add_n, next_batch):
-        """Inputs of one dra_sumtree_per_chain launch: this update's gated leaves, the NEXT agent step's add_n adds (host
-        side of those adds happens here: a leaf that is overwritten is no longer pending, the write cursor moves on --
-        _add_leaf / advance), and the next draw's uniforms from python `random` (replay.py:169-172)."""
-        n = len(leaves)
-        v = io.v
-        v["head"][:5] = (n, int(add_n), int(batch), int(next_batch), int(bool(self.ordered_updates)))
-        v["write0"][0] = int(self._write)
-        if n:
-            v["leaves"][:n] = leaves
-            v["pos"][:n] = pos
-        for i in range(int(add_n)):
-            self._pending.discard((self._write + i) % self.memory_size + self.memory_size - 1)
-        self._write = (self._write + int(add_n)) % self.memory_size
-        v["u"][:next_batch] = [random.random() for _ in range(next_batch)]
-
-    def chain_collect(self, io, batch_size):
-        """draw_end() on the draw a chain kernel left in its pinned block."""
-        v = io.v
-        return self._finish_draw(v["out_idx"][:batch_size].copy(), v["out_p"][:batch_size].copy(), float(v["out_total"][0]), batch_size)
 
     def commit_device(self, tree_idx, prio_f32, stream=None):
         """update_priorities(zip(tree_idx, prio)) with the priorities still on the device (f32 tensor, one per sampled

@@ -77,27 +77,12 @@ int dra_sumtree_set_many_from(dra_sumtree* tree, int64_t write0, int n, const do
  * would not be exact in fp64 (capacity * max / ulp_f32(min) > 2^53), or when force_ordered != 0. */
 int dra_sumtree_commit_f32(dra_sumtree* tree, const int64_t* leaf_idx_dev, const int32_t* pos_dev, int n,
                            const float* prio_f32_dev, int batch, double* stat_dev, int force_ordered, void* stream);
-/* The prioritized draw inside the update chain (round 3): ONE single-workgroup kernel = write-back of the update that just
- * computed prio_f32_dev (as dra_sumtree_commit_f32, incl. its ordered-walk fallback) -> add_n adds at the write cursor at
- * max_priority (as dra_sumtree_set_many_from) -> stratified descent of the NEXT draw (as dra_sumtree_sample).  Every
- * per-step input is read from, and the next draw written to, one PINNED HOST block, so the launch has constant arguments and
- * is captured into the learner's update graph right behind its loss kernel (dra_dqn_learner_set_per_chain): no tree
- * stream, no cross-stream event; the host collects the draw after the loss event. */
 #define DRA_PER_CHAIN_MAX 1024
-typedef struct dra_per_chain_io {
-  int32_t n_commit, add_n, batch, next_batch, force_ordered, reserved;   /* inputs */
-  int64_t add_write0;
-  int64_t leaves[DRA_PER_CHAIN_MAX];    /* gated leaves of this update (first n_commit) */
-  int32_t pos[DRA_PER_CHAIN_MAX];       /* their positions in the minibatch */
-  double u[DRA_PER_CHAIN_MAX];          /* uniforms of the next draw (first next_batch) */
-  int64_t out_idx[DRA_PER_CHAIN_MAX];   /* outputs: leaves, priorities and the tree total of the next draw */
-  double out_p[DRA_PER_CHAIN_MAX];
-  double out_total;
-} dra_per_chain_io;
-int dra_sumtree_per_chain(dra_sumtree* tree, dra_per_chain_io* io_pinned, const float* prio_f32_dev, double* stat_dev,
-                          void* stream);
-/* Second form (round 3, DRA_PER_CHAIN=2): the whole of PrioritizedReplay.sample() runs on the device, so the HOST is no
- * longer between an update's priorities and the next update.  On top of dra_sumtree_per_chain the kernel
+/* The whole of PrioritizedReplay.sample() on the device (round 3), so that the HOST is not between an update's priorities and
+ * the next update: ONE kernel body = write-back of the update that just produced its loss vector (as dra_sumtree_commit_f32,
+ * incl. its ordered-walk fallback) -> add_n adds at the write cursor at max_priority (as dra_sumtree_set_many_from) ->
+ * stratified descent of the NEXT draw (as dra_sumtree_sample).  Every per-step input is read from one PINNED HOST block, so
+ * the launch has constant arguments and is captured into the learner's update graph.  The kernel
  *   - gates the commit itself (sum_tree.py:54-60: first occurrence of a leaf in the minibatch wins; every sampled leaf is
  *     pending by construction, the sampled leaves are kept in `dev` from one launch to the next),
  *   - draws its uniforms from python's `random` stream: `rng_words` is a pinned ring of DRA_PER_RNG_WORDS raw Mersenne-Twister
@@ -265,9 +250,8 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
                                     * (forward of every net, weight gradient) reads the uint8 frames of the sampled
                                     * transitions straight from the replay ring and the head kernel their action / n-step
                                     * reward / mask: one launch, 1.8 MB of writes and 1.8 MB of re-reads less per update */
-#define DRA_VAR_COOP_OPT 65536    /* learner (with ONESHOT_WGRAD): slab fold + gradient norm + optimiser as ONE launch behind a
-                                    * grid barrier (dra_clip_step_coop) when the grid fits the update stream's CUs
-                                    * (dra_dqn_learner_set_update_cus); otherwise the two-launch form */
+/* (bit 65536 was DRA_VAR_COOP_OPT, the one-launch fold + norm + optimiser behind a grid barrier: measured 14 % slower than the
+ * two launches, removed in round 4; the bit is ignored) */
 #define DRA_VAR_IDX_PREFETCH 131072 /* learner (with RING_DIRECT): a step-tagged copy of the minibatch indices goes to the device by
                                     * an unordered async copy when the step is enqueued; conv1 takes an element from there when
                                     * its tag is this update's (no PCIe read in front of its frame loads), else from pinned memory */
@@ -314,18 +298,7 @@ typedef struct dra_fold_seg {
 int dra_norm_partials_max(void);
 int dra_grad_sqnorm_segs(float* grad, int64_t n, const dra_fold_seg* segs, int n_segs, double* partials,
                          int* n_partials, void* stream);
-/* the same fold + norm with the optimiser behind a GRID BARRIER (one launch instead of two: clip_grad_norm_ +
- * optimizer.step(), DQN_agent.py:130-134): every workgroup keeps its elements in registers, publishes its partial, waits
- * for the others and applies RMSprop (optimizer 0: hyper = {lr, alpha, eps, -}) or Adam (1: {lr, beta1, eps, beta2}, step
- * count read from step_dev).  All workgroups must be co-resident: _coop_blocks gives the grid, _coop_occupancy the
- * workgroups one CU holds; a grid above resident_limit is refused.  barrier_ctr: zeroed uint64 in device memory (only
- * grows); timeout_flag: zeroed int in pinned host memory, set to 1 if a barrier wait exceeded 50 ms. */
-int dra_clip_step_coop_blocks(int64_t n, const dra_fold_seg* segs, int n_segs, int* blocks);
-int dra_clip_step_coop_occupancy(int optimizer, int* blocks_per_cu);
-int dra_clip_step_coop(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* segs,
-                       int n_segs, double* partials, unsigned long long* barrier_ctr, int* timeout_flag,
-                       int resident_limit, int optimizer, float max_norm, const float* hyper, int centered,
-                       const int64_t* step_dev, float* out_norm, float* param_copy, void* stream);
+int dra_grad_sqnorm_segs_blocks(int64_t n, const dra_fold_seg* segs, int n_segs, int* blocks); /* its workgroups = partials (host only) */
 /* the late-fold form (DRA_VAR_LATE_FOLD): every tensor's sum of squares was left in partials[0, n_prior) by the kernels
  * that produced its gradient, except ONE segment (starting at element 0, n_slabs <= 256: conv1, whose weight gradient is the
  * last kernel of the backward) that is still in slabs.  The launch's first dra_clip_step_late_blocks() (<= 256) workgroups
@@ -431,13 +404,6 @@ int dra_dqn_learner_set_per(dra_dqn_learner* learner, int per, float beta);
 /* PER: sampling probabilities (host f64[batch], converted to f32) + importance exponent -> the learner's sampling_prob
  * buffer on `stream`, through the learner's own pinned staging (DQN_agent.py:120-127's tensor(sampling_prob)) */
 int dra_dqn_learner_upload_sampling_prob(dra_dqn_learner* learner, const double* prob_host, int n, float beta, void* stream);
-/* DRA_VAR_COOP_OPT: n_cus = compute units the update stream may use (its CU mask, or the whole device).  Decides, once and
- * before the first update, whether slab fold + gradient norm + optimiser run as ONE cooperative launch
- * (dra_clip_step_coop: needs its whole grid resident on those CUs) or as two launches.  _coop_state reports the decision,
- * the grid and the resident-workgroup limit it was compared with.  A barrier that times out anyway makes every later
- * dra_dqn_learner_step / _update return -110. */
-int dra_dqn_learner_set_update_cus(dra_dqn_learner* learner, int n_cus);
-int dra_dqn_learner_coop_state(dra_dqn_learner* learner, int* coop, int* blocks, int* resident_limit);
 /* DRA_VAR_RING_DIRECT: also gather the minibatch into the learner's buffers (dra_dqn_learner_last_minibatch) -- for
  * checkers; the update itself keeps reading the ring */
 int dra_dqn_learner_keep_minibatch(dra_dqn_learner* learner, int keep);
@@ -464,12 +430,6 @@ int dra_dqn_learner_act(dra_dqn_learner* learner, const dra_dqn_step_params* prm
  * observation, q_host = float[n_actions] out.  Pinned staging both ways, batch-1 forward of the online parameters
  * as one captured graph; synchronises `stream` (like the reference's to_np(q)). */
 int dra_dqn_learner_q_host(dra_dqn_learner* learner, const uint8_t* state_host, float* q_host, void* stream);
-/* PrioritizedReplay inside the update chain (dra_sumtree_per_chain captured behind the loss kernel of the pipelined
- * prioritized update): set once before the first prioritized update (tree NULL = off); io0..3 = pinned blocks of the four
- * rotation slots; _next_slot = the slot the next update uses; _sync_loss blocks the host until the loss + chain kernels of the
- * update issued last have run (its io block then holds the next draw). */
-int dra_dqn_learner_set_per_chain(dra_dqn_learner* l, dra_sumtree* tree, double* stat_dev, dra_per_chain_io* io0,
-                                  dra_per_chain_io* io1, dra_per_chain_io* io2, dra_per_chain_io* io3);
 /* PrioritizedReplay.sample() on the device (dra_sumtree_per_chain2; needs the ring-direct pipeline): _set_per_chain2 once
  * before the first prioritized update; _per_chain2_seed hands the NEXT update's minibatch over from the host (first update,
  * resume); _per_chain2_wait spins until rotation slot `slot`'s block shows launch number >= seq (DRA_ETIMEDOUT after

@@ -86,8 +86,7 @@ def test_vectorised_index_draw_consumes_the_reference_stream():
 
 
 def test_clip_step_plan_host_arithmetic():
-    """dra_clip_step_coop_blocks (pure host code: the work decomposition shared by dra_grad_sqnorm_segs and the cooperative
-    clip + optimizer launch): one fold workgroup per 64 float4 for segments of <= 32 slabs, per 16 float4 above, one plain
+    """dra_grad_sqnorm_segs_blocks (pure host code: the work decomposition of the fold + norm launch): one fold workgroup per 64 float4 for segments of <= 32 slabs, per 16 float4 above, one plain
     workgroup per 1024 float4 -- 796 for the DQN learner's gradient (conv segments of 160 / 32 / 32 slabs, fc4 + head plain);
     malformed layouts are refused."""
     from deeprl_amd import ops
@@ -102,7 +101,7 @@ def test_clip_step_plan_host_arithmetic():
 
     def blocks(n, segs):
         b = ctypes.c_int(0)
-        rc = lib.dra_clip_step_coop_blocks.raw(int(n), ops._fold_seg_array(segs), len(segs), ctypes.byref(b))
+        rc = lib.dra_grad_sqnorm_segs_blocks.raw(int(n), ops._fold_seg_array(segs), len(segs), ctypes.byref(b))
         return rc, b.value
 
     counts, nsl = [8224, 32832, 36928], [160, 32, 32]
@@ -118,4 +117,5 @@ def test_clip_step_plan_host_arithmetic():
     assert blocks(off + tail + 1, segs)[0] == -22                                   # n not a multiple of 4
     assert blocks(off + tail, [(4, 8220, _T(0x10000), 8224, 160)])[0] == -22        # segments must start at 0, contiguously
     assert blocks(off + tail, [(0, 8224, _T(0x10004), 8224, 160)])[0] == -22        # misaligned slab pointer
-    assert blocks(64 * 1024 * 1024, [])[0] == -22                                   # would need more than one pass per workgroup
+    rc, b = blocks(64 * 1024 * 1024, [])                                            # more float4s than 4096 workgroups hold at once:
+    assert rc == 0 and b <= 4096                                                    # plain workgroups walk several strides

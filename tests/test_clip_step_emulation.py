@@ -1,6 +1,6 @@
-"""CPU transcription of clip_step_kernel's work decomposition (tools/emulate_oneshot.py emu_clip_step: block ranges, the
+"""CPU transcription of fold_norm_kernel's work decomposition (csrc/optim.hip) (tools/emulate_oneshot.py emu_clip_step: block ranges, the
 narrow / wide fold workgroups, the owner threads, the plain workgroups) against a plain numpy fold: every float4 of the
-gradient is owned by exactly ONE (workgroup, thread) -- what the cooperative form's optimizer phase relies on --, slab
+gradient is owned by exactly ONE (workgroup, thread), slab
 segments are folded in the documented order (slabs g, g+16, ... per group, then the 16 groups in order), elements outside
 the segments are untouched, and the partials add up to the squared norm.  Shapes the GPU tests do not sweep: segment sizes
 that are not multiples of the workgroup's element count, fewer than 16 slabs, 33-160 slabs, more than 160 (two passes)."""

@@ -176,3 +176,54 @@ def test_real_env_wrapper_stack_mirrors_make_env():
     t.env = Rec()
     t.step(np.array([[3.0, -2.0]]))
     assert np.array_equal(seen['a'], np.array([[1.0, -1.0]]))
+
+
+def test_real_env_construction_reseeds_like_the_reference_thunk(monkeypatch):
+    """make_env's thunk starts with random_seed(seed) (deep_rl/component/envs.py:28) -- np.random and torch are
+    reseeded for EVERY environment built, so the global generators' state after Task(...) is that of a fresh
+    random_seed(seed), whatever was drawn before.  Checked with a stand-in `gym` (the image has none)."""
+    import sys
+    import types
+    import numpy as np
+    import torch
+    from deeprl_amd import envs as E
+    from deeprl_amd.support import random_seed
+
+    class Space:
+        shape, low, high = (3,), np.zeros(3), np.ones(3)
+
+    class Emu:
+        observation_space, action_space = Space(), E.Discrete(2)
+
+        def __init__(self):
+            self.unwrapped, self.seeded = self, None
+            np.random.rand(5)                   # a constructor that consumes the global stream (as emulators do)
+
+        def seed(self, s):
+            self.seeded = s
+
+        def reset(self):
+            return np.zeros(3)
+
+        def step(self, a):
+            return np.zeros(3), 0.0, False, {}
+
+    gym = types.ModuleType("gym")
+    gym.__file__ = "/nonexistent/gym/__init__.py"
+    gym.make = lambda name: Emu()
+    gym.envs = types.SimpleNamespace()
+    monkeypatch.setitem(sys.modules, "gym", gym)
+    np.random.seed(123)
+    np.random.rand(7)
+    built = E._real_task_envs("Fake-v0", 3, 11, True)
+    assert built is not None and len(built) == 3
+    got_np, got_torch = np.random.get_state(), torch.get_rng_state()
+    random_seed(11)
+    np.random.rand(5)                           # the last environment's constructor ran after the last reseed
+    want_np, want_torch = np.random.get_state(), torch.get_rng_state()
+    assert got_np[0] == want_np[0] and np.array_equal(got_np[1], want_np[1]) and got_np[2:] == want_np[2:]
+    assert torch.equal(got_torch, want_torch)
+    e = built[2]
+    while hasattr(e, "env"):
+        e = e.env
+    assert e.seeded == 11 + 2

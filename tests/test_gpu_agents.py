@@ -239,7 +239,6 @@ def _rel(a, b, floor):
 
 
 @pytest.mark.parametrize("double_q,variant", [(False, 0), (False, 1), (False, 7), (False, 127), (True, 127), (True, 511),
-                                              (False, 511 + 65536), (True, 511 + 65536),   # + COOP_OPT: one-launch clip + optimizer
                                               (False, 511 + 262144), (True, 511 + 262144),   # + WGRAD_ACC: 8 / 8 / 40 slabs
                                               (False, 511 + 524288), (False, 511 + 262144 + 524288),   # + LATE_FOLD: no norm launch
                                               (True, 511 + 262144 + 524288)])
@@ -268,8 +267,6 @@ def test_fused_learner_matches_oracle(dra, double_q, variant):
     tgt.load_state_dict({k: torch.from_numpy(v) for k, v in t_np.items()})
     learner = DQNLearner(net, tgt, ring, b, a, 0.99, 5.0, 0.00025, 0.95, 0.01, centered=True, double_q=double_q,
                          variant=variant)
-    if variant & d.ops.VAR_COOP_OPT:
-        assert learner.coop_state()[0], "the cooperative optimizer launch must fit the update stream's CUs: %s" % (learner.coop_state(),)
     p = {k: torch.tensor(v, requires_grad=True) for k, v in p_np.items()}
     pt = {k: torch.tensor(v) for k, v in t_np.items()}
     names = list(p.keys())
@@ -389,8 +386,8 @@ def test_fused_step_sync_equals_act_then_update(dra, variant):
 _ASYNC_RESULTS = {}
 
 
-@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559, 4607, 12799, 29183, 61951, 61951 + 65536, 61951 + 131072,
-                                     61951 + 65536 + 131072, 61951 + 1048576, 61951 + 131072 + 1048576])   # + ACTOR_MEGA
+@pytest.mark.parametrize("variant", [0, 127, 255, 1023, 2047, 2559, 4607, 12799, 29183, 61951, 61951 + 131072,
+                                     61951 + 1048576, 61951 + 131072 + 1048576])   # + ACTOR_MEGA
 def test_fused_step_async_pipeline(dra, variant):
     """async_actor=True pipeline (actor one agent step ahead on its own stream, double-buffered actor
     parameters when variant has DRA_VAR_ACTOR_PARAMS): the transitions it feeds are the documented counter-hash
@@ -430,12 +427,10 @@ def test_fused_step_async_pipeline(dra, variant):
     # ... and the gather on the update stream (DRA_VAR_GATHER_ON_UPDATE = 16384; ring capacity 4000 with 32 samples per
     # step: the host-decided 'minibatch touches the slots the next actor graph overwrites' wait fires here)
     # ... and the ring-direct update (DRA_VAR_RING_DIRECT = 32768: conv1 and the head read the replay ring, no gather)
-    # ... and the cooperative one-launch clip + optimizer (DRA_VAR_COOP_OPT = 65536: same decomposition and reduction order
-    # as the two launches) and the prefetched minibatch indices (DRA_VAR_IDX_PREFETCH = 131072: same indices, another route)
+    # ... and the prefetched minibatch indices (DRA_VAR_IDX_PREFETCH = 131072: same indices, another route)
     # ... and the actor's env step as ONE launch (DRA_VAR_ACTOR_MEGA = 1048576: the four launches' arithmetic in the same order,
     # outputs handed over through arrival counters inside the launch)
-    for other in (255, 1023, 2047, 2559, 4607, 12799, 29183, 61951, 61951 + 65536, 61951 + 131072, 61951 + 65536 + 131072,
-                  61951 + 1048576, 61951 + 131072 + 1048576):
+    for other in (255, 1023, 2047, 2559, 4607, 12799, 29183, 61951, 61951 + 131072, 61951 + 1048576, 61951 + 131072 + 1048576):
         if 127 in _ASYNC_RESULTS and other in _ASYNC_RESULTS:
             assert np.array_equal(_ASYNC_RESULTS[127][0], _ASYNC_RESULTS[other][0])
             assert np.array_equal(_ASYNC_RESULTS[127][2], _ASYNC_RESULTS[other][2])
@@ -444,7 +439,7 @@ def test_fused_step_async_pipeline(dra, variant):
 @pytest.mark.parametrize("variant,init,cap", [(-1, "bench", 4000), (-1, "normal", 4000), (4607, "normal", 4000), (12799, "normal", 4000),
                                               (29183, "normal", 4000), (-1, "normal", 160), (12799, "normal", 160),
                                               (61951, "normal", 4000), (61951, "normal", 160), (61951, "bench", 4000),
-                                              (258559, "normal", 4000), (258559, "normal", 160), (258559, "bench", 4000),
+                                              (193023, "normal", 4000), (193023, "normal", 160), (193023, "bench", 4000),
                                               # round 3: + WGRAD_ACC (262144), + LATE_FOLD (524288) on the round-2 default 193023
                                               (455167, "normal", 4000), (979455, "normal", 4000), (979455, "normal", 160),
                                               (979455, "bench", 4000),
@@ -811,8 +806,7 @@ def test_onpolicy_device_env_equals_host_emulators(dra, monkeypatch, kind):
         assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
 
 
-@pytest.mark.parametrize("kind,per,chain", [("dqn", True, 2), ("c51", True, 2), ("dqn", True, 1), ("c51", True, 1), ("dqn", True, 0),
-                                            ("dqn", False, 2), ("c51", False, 2)])
+@pytest.mark.parametrize("kind,per,chain", [("dqn", True, 2), ("c51", True, 2), ("dqn", True, 0), ("dqn", False, 2), ("c51", False, 2)])
 def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch, kind, per, chain):
     """PrioritizedReplay inside the two-stream pipeline (config.async_actor=True: actor transitions of step t+1 on their own
     stream under update t; the prioritized draw of step t after the device-side write-back of update t-1; ring-direct update
@@ -827,8 +821,7 @@ def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch
     import deeprl_amd.agents as agents_mod
     monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
     # chain: where the prioritized draw runs in async mode -- 2 = entirely inside the update (device-side filter / padding,
-    # replay.DeviceDraw; the default), 1 = inside the update with the host between two updates, 0 = tree stream
-    monkeypatch.setenv("DRA_PER_CHAIN", str(chain))
+    # replay.DeviceDraw; the default), 0 = the tree-stream form other kernel variants / minibatches above 1024 fall back to
     outs = []
     for async_actor in (True, False):
         cfg = d.Config()
@@ -859,7 +852,8 @@ def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch
         agent = cls(cfg)
         assert agent._pipe is not None and agent._pipe.async_actor == async_actor and agent._pipe.per == per
         if per and async_actor:
-            assert agent._pipe.chain == chain
+            assert agent._pipe.chain == 2
+            agent._pipe.chain = chain           # (0: force the fallback form before the first step)
         agent._pipe.rs = np.random.RandomState(77)          # the actor's randint / rand stream, identical in both modes
         np.random.seed(5)                                   # uniform index draws (the async constructor drew its actor seed)
         p_np = fake_envs.numpy_params(fake_envs.NATURE_SHAPES + head, 17)
@@ -880,15 +874,6 @@ def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch
             # Same point for the in-order run:
             rp.advance(4)
             rp.draw()
-            torch.cuda.synchronize()
-        elif per and not async_actor and outs and outs[0]["chain"]:
-            # the async run ran the prioritized draw INSIDE its update chain (dra_sumtree_per_chain): its last update already
-            # performed the next agent step's four adds and the next draw (32 uniforms from python `random`).  Bring the
-            # in-order run to the same point before comparing tree / generator positions.
-            for _ in range(4):
-                rp._add_leaf()
-            for _ in range(32):
-                random.random()
             torch.cuda.synchronize()
         # the async actor is one agent step ahead: compare the transitions both runs have REPORTED (ring slots of the first
         # n_steps * 4 transitions; with a 300-slot ring that is the whole ring minus the 4 newest slots of the async run)

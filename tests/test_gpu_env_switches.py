@@ -60,27 +60,11 @@ def test_fc4_k_split_is_another_association_of_the_same_sums(tmp_path):
 @pytest.mark.parametrize("kind", ["dqn", "c51"])
 def test_actor_mega_is_bit_identical(tmp_path, kind):
     """DRA_VAR_ACTOR_MEGA (round 3): conv3 + fc4 of the actor's env step as ONE launch handing conv3's planes over through an
-    arrival counter (DRA_ACTOR_MEGA_MODE=1, the default), or all four layers in one launch (=0), against the four separate
-    launches (the bit cleared in DRA_TUNING): the same products in the same order -- same stored actions, bit-identical
-    parameters after 60 agent steps of the async pipeline."""
+    arrival counter, against the four separate launches (the bit cleared in DRA_TUNING): the same products in the same order --
+    same stored actions, bit-identical parameters after 60 agent steps of the async pipeline."""
     default = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 262144 | 524288 | 1048576
     a = _run(kind, {"DRA_TUNING": str(default)}, tmp_path, "mega1")
     b = _run(kind, {"DRA_TUNING": str(default & ~1048576)}, tmp_path, "nomega")
-    c = _run(kind, {"DRA_TUNING": str(default), "DRA_ACTOR_MEGA_MODE": "0"}, tmp_path, "mega0")
-    assert sorted(a) == sorted(b) == sorted(c)
+    assert sorted(a) == sorted(b)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
-        assert np.array_equal(a[k], c[k]), k
-
-
-@pytest.mark.parametrize("kind", ["dqn_per", "c51_per"])
-def test_per_device_draw_placement_is_bit_identical(tmp_path, kind):
-    """DRA_PER_RIDE: the device-side prioritized draw (dra_sumtree_per_chain2) as its own launch between loss and backward
-    (0), as one role of conv3's backward launch (1), or in two halves riding in conv3's backward and conv1's weight-gradient
-    launches (2, the default) -- the same kernel body on 1024 or 256 threads: same stored actions, priority tree, python
-    `random` state and parameters after 60 agent steps on a 300-slot ring (most draws filtered and padded)."""
-    runs = [_run(kind, {"DRA_PER_RIDE": v}, tmp_path, "ride" + v) for v in ("2", "1", "0")]
-    assert sorted(runs[0]) == sorted(runs[1]) == sorted(runs[2]) and "tree" in runs[0]
-    for k in runs[0]:
-        assert np.array_equal(runs[0][k], runs[1][k]), k
-        assert np.array_equal(runs[0][k], runs[2][k]), k

@@ -827,68 +827,6 @@ def test_grad_sqnorm_segs_many_slabs(dev):
     np.testing.assert_allclose(partials[:n_part].sum().item(), (got.astype(np.float64) ** 2).sum(), rtol=1e-6)
 
 
-@pytest.mark.parametrize("optimizer,centered,clip", [(0, True, 5.0), (0, False, 0.05), (0, True, 0.0), (1, True, 0.05), (1, True, 5.0)])
-def test_clip_step_coop_equals_two_launches(dev, optimizer, centered, clip):
-    """dra_clip_step_coop (slab fold + gradient norm + optimiser as ONE launch behind a grid barrier) against the two-launch
-    form it replaces in the fused learner (dra_grad_sqnorm_segs, then dra_rmsprop_step_copy / dra_adam_step_counter): the
-    DQN learner's gradient layout (conv segments with 160 / 32 / 32 slabs, fc4 + head plain), three consecutive steps --
-    parameters, both optimiser states, the parameter mirror, the folded gradient and the reported norm must be
-    BIT-IDENTICAL (same work decomposition, same fixed-order reductions), and the timeout flag must stay clear."""
-    import ctypes
-    from deeprl_amd import ops
-    from deeprl_amd._lib import lib, ptr
-    rs = np.random.RandomState(17 + optimizer)
-    counts, nsl = [8224, 32832, 36928], [160, 32, 32]
-    tail = 3136 * 512 + 512 + 4 * 512 + 4
-    n = sum(counts) + tail
-    p0 = rs.standard_normal(n).astype(np.float32) * 0.05
-    step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-    partials = [torch.zeros(ops.norm_partials_max(), dtype=torch.float64, device=dev) for _ in range(2)]
-    ctr = torch.zeros(1, dtype=torch.int64, device=dev)
-    flag = torch.zeros(1, dtype=torch.int32).pin_memory()
-    st = [dict(p=f32(p0.copy(), dev), g=torch.zeros(n, dtype=torch.float32, device=dev), s1=torch.zeros(n, dtype=torch.float32, device=dev),
-               s2=torch.zeros(n, dtype=torch.float32, device=dev), copy=torch.zeros(n, dtype=torch.float32, device=dev),
-               norm=torch.zeros(1, dtype=torch.float32, device=dev)) for _ in range(2)]
-    blocks = None
-    for it in range(3):
-        scale = [1.0, 30.0, 1e-3][it]                      # clipped and unclipped steps
-        slabs = [f32((rs.standard_normal((ns, cnt)) * scale / ns).astype(np.float32).reshape(-1), dev) for cnt, ns in zip(counts, nsl)]
-        gt = f32((rs.standard_normal(tail) * scale * 1e-2).astype(np.float32), dev)
-        step_dev += 1
-        segs, off = [], 0
-        for cnt, ns, t in zip(counts, nsl, slabs):
-            segs.append((off, cnt, t, cnt, ns))
-            off += cnt
-        for k in range(2):
-            st[k]["g"][off:] = gt
-            st[k]["g"][:off] = float("nan")                 # the fold must overwrite every element of the slab segments
-        # two launches
-        a = st[0]
-        npart = ops.grad_sqnorm_segs(a["g"], segs, partials[0])
-        if optimizer == 0:
-            lib.dra_rmsprop_step_copy(ptr(a["p"]), ptr(a["g"]), ptr(a["s1"]), ptr(a["s2"]), n, ptr(partials[0]), npart, clip, 0.00025,
-                                      0.95, 0.01, int(centered), ptr(a["norm"]), ptr(a["copy"]), ops.stream_ptr())
-        else:
-            ops.adam_step_counter(a["p"], a["g"], a["s1"], a["s2"], partials[0], npart, clip, 0.00025, 0.9, 0.999, 0.01 / 32, step_dev,
-                                  out_norm=a["norm"], param_copy=a["copy"])
-        # one cooperative launch
-        b_ = st[1]
-        blocks = ops.clip_step_coop_blocks(n, segs)
-        assert blocks == npart
-        hyper = (0.00025, 0.95, 0.01) if optimizer == 0 else (0.00025, 0.9, 0.01 / 32, 0.999)
-        ops.clip_step_coop(b_["p"], b_["g"], b_["s1"], b_["s2"], segs, partials[1], ctr, flag, 1 << 20, optimizer, clip, hyper,
-                           centered=centered, step_dev=step_dev, out_norm=b_["norm"], param_copy=b_["copy"])
-        torch.cuda.synchronize()
-        assert int(flag[0]) == 0, "grid barrier timed out"
-        for key in ("g", "p", "s1", "s2", "copy", "norm"):
-            if key == "s2" and optimizer == 0 and not centered:
-                continue
-            assert torch.equal(st[0][key], st[1][key]), (key, it)
-        assert torch.equal(st[1]["p"], st[1]["copy"])
-        assert torch.isfinite(st[1]["p"]).all() and not torch.equal(st[1]["p"], f32(p0, dev))
-    assert int(ctr[0]) == 3 * blocks                       # the barrier counter only grows: one ticket per workgroup and launch
-    per_cu = ops.clip_step_coop_occupancy(optimizer)
-    assert per_cu >= 3, "the cooperative kernel must keep >= 3 workgroups per CU resident (registers / LDS)"
 
 
 @pytest.mark.parametrize("b,a", [(1, 2), (16, 4), (80, 18), (1024, 6), (300, 64)])

@@ -23,11 +23,11 @@ def _c_layout(tmp_path, struct, fields):
 
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
-@pytest.mark.parametrize("which", ["dra_per_chain2_io", "dra_per_chain_io", "dra_dqn_step_params", "dra_fold_seg"])
+@pytest.mark.parametrize("which", ["dra_per_chain2_io", "dra_dqn_step_params", "dra_fold_seg"])
 def test_ctypes_mirror_matches_the_header(tmp_path, which):
     from deeprl_amd import ops
     from deeprl_amd.learner import StepParams
-    mirror = {"dra_per_chain2_io": ops.PerChain2IO, "dra_per_chain_io": ops.PerChainIO, "dra_dqn_step_params": StepParams,
+    mirror = {"dra_per_chain2_io": ops.PerChain2IO, "dra_dqn_step_params": StepParams,
               "dra_fold_seg": ops.FoldSeg}[which]
     names = [f[0] for f in mirror._fields_]
     got = _c_layout(tmp_path, which, names)

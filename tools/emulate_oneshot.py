@@ -490,9 +490,8 @@ if __name__ == "__main__":
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# clip_step_kernel (optim.hip): slab fold + sums of squares, transcribed workgroup by workgroup / thread by thread.
-# Returns (folded gradient, partials[blocks], owners[float4 index] = how many (block, thread) pairs hold that element
-# across the barrier -- the cooperative form applies the optimizer to exactly those).
+# fold_norm_kernel (optim.hip): slab fold + sums of squares, transcribed workgroup by workgroup / thread by thread.
+# Returns (folded gradient, partials[blocks], owners[float4 index] = how many (block, thread) pairs own that element).
 def emu_clip_step(grad, segs, plain_iters_cap=2048):
     """grad: f32 [n]; segs: list of (begin, count, slabs [ns, stride], stride, ns) with begin / count multiples of 4."""
     n = grad.size

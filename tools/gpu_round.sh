@@ -3,8 +3,8 @@
 # the same command, the two --pmc traffic passes (FETCH_SIZE / WRITE_SIZE, separate runs, kernel-trace only) for the default
 # kernels and with the accumulating conv2 weight gradient, SQ counters at batch 32, phase traces (update / actor chains, the
 # prioritized-draw kernel, the large-batch conv forward), the PER timeline + A/B, agent benches.
-# Everything under gpurun_out/<tag>/ (copy what should be judged into profiles/).   usage: gpurun -- 'bash tools/gpu_round.sh r03x'
-TAG=${1:-r03x}
+# Everything under gpurun_out/<tag>/ (copy what should be judged into profiles/).   usage: gpurun -- 'bash tools/gpu_round.sh r04x'
+TAG=${1:-r04x}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -12,7 +12,7 @@ R=$GRAFT_REPO_ROOT
 PV=${PMC_VARIANT:-787199}     # in-order learner: 255 + WGRAD_ACC + LATE_FOLD
 nproc > $OUT/nproc.txt
 rm -f gpurun_out/parity_errors.jsonl
-echo "== GPU tests"; timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; grep -E "passed|failed" $OUT/pytest_gpu.log | tail -2; tail -5 $OUT/pytest_gpu.log > $OUT/pytest_gpu_tail.txt
+echo "== GPU tests"; timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; grep -E "^FAILED|^ERROR" $OUT/pytest_gpu.log | head -40; grep -E "passed|failed" $OUT/pytest_gpu.log | tail -2; tail -5 $OUT/pytest_gpu.log > $OUT/pytest_gpu_tail.txt
 python tools/parity_summary.py gpurun_out/parity_errors.jsonl > $OUT/parity_errors.json 2>/dev/null; head -c 600 $OUT/parity_errors.json; echo
 echo "== bench" ; timeout 500 python bench.py > $OUT/bench.json 2> $OUT/bench.err; head -c 400 $OUT/bench.json; echo
 echo "== bench (driver command)" ; timeout 500 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err; head -c 300 $OUT/bench_driver_cmd.json; echo
@@ -32,12 +32,10 @@ echo "== SQ counters at batch 32"; PMC_VARIANT=$PV bash tools/pmc_sq_learner.sh 
 export DEEPRL_AMD_LIB=$R/deeprl_amd/lib/libdeeprl_amd_trace.so
 echo "== phase traces"; timeout 200 python tools/phase_trace.py > $OUT/phase_async.json 2> $OUT/phase.err; python tools/phase_summary.py $OUT/phase_async.json | grep -E "chain|env step"
 timeout 200 python tools/phase_trace.py --sync > $OUT/phase_sync.json 2>> $OUT/phase.err; python tools/phase_summary.py $OUT/phase_sync.json | grep -E "chain|env step"
-echo "== device-side prioritized draw: phases of the chain kernel"; timeout 120 python tools/diag_chain2.py dqn_pixel_per_device > $OUT/chain2_phases.txt 2>> $OUT/phase.err; tail -11 $OUT/chain2_phases.txt
 echo "== NatureConv forward at batch 1024: phases"; timeout 120 python tools/phase_conv_big.py 1024 > $OUT/phase_conv_big_b1024.json 2>> $OUT/phase.err
 unset DEEPRL_AMD_LIB
 echo "== NatureConv forward at batch 256 / 512 / 1024"; for b in 256 512 1024; do timeout 120 python tools/conv_big_ab.py $b 2>/dev/null; done > $OUT/conv_big.jsonl; DRA_CONV2_MODE=0 timeout 120 python tools/conv_big_ab.py 1024 2>/dev/null >> $OUT/conv_big.jsonl; cat $OUT/conv_big.jsonl
 echo "== prioritized agent step: kernel timeline"; (cd /tmp && timeout 200 rocprofv3 --kernel-trace -d $R/$OUT/prof_per -- python $R/tools/bench_agents.py --seconds 2 --cases dqn_pixel_per_device > $R/$OUT/prof_per.log 2>&1); python tools/prof_timeline.py $OUT/prof_per 3000 1 > $OUT/timeline_per.txt 2>&1; rm -rf $OUT/prof_per; grep -c . $OUT/timeline_per.txt
-echo "== PER same-box A/B"; bash tools/gpu_ab_agents.sh $TAG dqn_pixel_per_device,c51_pixel_per_device,dqn_pixel_uniform_device,c51_pixel_uniform_device DRA_PER_CHAIN=2 DRA_PER_CHAIN=1 2>&1 | tail -20
 echo "== agents bench"; timeout 400 python tools/bench_agents.py > $OUT/bench_agents.jsonl 2> $OUT/bench_agents.err; cat $OUT/bench_agents.jsonl | cut -c1-300
 echo "== launch contract: 2 ranks on this box (gloo barrier, replicas share the GPU)"; timeout 300 python bench.py --gpus 2 --steps 200 --warmup 20 --no-cpu-baseline --no-parity-check > $OUT/bench_2rank_one_box.json 2> $OUT/bench_2rank_one_box.err; head -c 300 $OUT/bench_2rank_one_box.json; echo
 echo "== done"
