@@ -418,12 +418,24 @@ def on_policy_main(args):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # what the collective itself saw, and every rank's own rate (its shard's environment steps over ITS wall time): a SCALE
+    # record then explains itself -- ranks RCCL spanned vs WORLD_SIZE, stragglers, whether the fc4 segment overlapped
+    rccl = agent.dp.comm.info() if getattr(agent.dp, "comm", None) is not None else None
+    mine = {"rank": rank, "seconds": dt, "env_steps_per_s": k * agent.config.rollout_length * per_gpu / dt,
+            "rccl_ranks": rccl[0] if rccl else None, "rccl_rank": rccl[1] if rccl else None,
+            "early_fc4_exchanges": int(getattr(agent.dp, "early_exchanges", 0)), "device": torch.cuda.current_device()}
+    per_rank = [mine]
     if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
         print(json.dumps({
+            "n_ranks": {"world_size": world, "rccl": rccl[0] if rccl else None,
+                        "backend": dist.get_backend() if world > 1 else "none", "devices_visible": n_dev},
+            "per_rank": per_rank,
             "metric": "env-steps/sec", "value": k * steps_per_call / dt, "unit": "env-steps/s", "n_gpus": world, "steps": k,
             "warmup": n_warm, "ms_per_step": 1e3 * dt / k, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -432,7 +444,8 @@ def on_policy_main(args):
                                        args.workload, per_gpu, agent.config.rollout_length,
                                        "device-resident synthetic environments" if getattr(agent.task, "on_device", False)
                                        else "host-side synthetic emulators"),
-                       "parallelism": "dp%d" % world, "collective": "dra_allreduce_grads (RCCL)" if agent.dp.comm else
+                       "parallelism": "dp%d" % world, "collective": "dra_allreduce_grads (RCCL), [fc4 + heads] segment first on a "
+                       "communication stream, joined before the clip + optimizer launch" if agent.dp.comm else
                        ("torch.distributed " + (dist.get_backend() if world > 1 else "none"))},
             "updates_per_sec": k * (1 if args.workload == "a2c_pixel" else 16) / dt}), flush=True)
     agent.close()

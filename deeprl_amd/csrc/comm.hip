@@ -6,9 +6,11 @@
 // gradient buffer (6.75 MB for the Atari actor-critic) over xGMI, scaled by 1/ranks, after which the fused
 // clip + optimizer kernels (optim.hip) run identically on every rank (A2C_agent.py:55-64, PPO_agent.py:77-99).
 //
-// xGMI is point to point (7 links per GPU), so at 6.75 MB RCCL's ring is latency- rather than bandwidth-bound; the
-// whole gradient goes out as ONE ncclAllReduce on the caller's stream (no bucketing: the buffer is already flat and
-// the backward that fills it is ~20 launches), and the 1/ranks scale is folded into the same stream right behind it.
+// xGMI is point to point (7 links per GPU), so at 6.75 MB RCCL's ring is latency- rather than bandwidth-bound; no bucketing
+// (the buffer is already flat).  Round 4: the host issues the exchange in TWO calls -- [fc4 + heads] (6.4 MB, complete as soon
+// as fc4's backward has run) on a communication stream while the convolutions are still being differentiated, then the
+// 0.3 MB of convolution gradients -- and joins before the clip + optimizer launch (deeprl_amd/dist.py DataParallel.plan_split);
+// the 1/ranks scale is folded into the same stream right behind each call.
 //
 // One process per GPU; the unique id travels from rank 0 to the others by whatever out-of-band channel the host has
 // (deeprl_amd/dist.py uses torch.distributed's store).
@@ -45,6 +47,17 @@ DRA_API int dra_comm_init_rank(dra_comm** out, int n_ranks, int rank, const void
   if (ncclCommInitRank(&c->comm, n_ranks, id, rank) != ncclSuccess) { delete c; return DRA_EINVAL; }
   c->n_ranks = n_ranks; c->rank = rank;
   *out = c;
+  return DRA_OK;
+}
+
+// What RCCL itself reports for this communicator (ncclCommCount / ncclCommUserRank): bench.py prints it next to the launcher's
+// WORLD_SIZE so that a scaling record says how many ranks the collective really spanned.
+DRA_API int dra_comm_info(dra_comm* c, int* n_ranks, int* rank) {
+  if (!c) return DRA_EINVAL;
+  int n = 0, r = -1;
+  if (ncclCommCount(c->comm, &n) != ncclSuccess || ncclCommUserRank(c->comm, &r) != ncclSuccess) return DRA_EINVAL;
+  if (n_ranks) *n_ranks = n;
+  if (rank) *rank = r;
   return DRA_OK;
 }
 

@@ -102,10 +102,18 @@ class RcclComm:
         self.h = ctypes.c_void_p()
         lib.dra_comm_init_rank(ctypes.byref(self.h), self.world, self.rank, buf)
 
-    def allreduce_grads(self, flat, scale):
+    def allreduce_grads(self, flat, scale, stream=None):
+        """flat <- (sum over ranks of flat) * scale on `stream` (default: the current stream).  `flat` may be a contiguous
+        16-byte aligned SEGMENT of the gradient buffer (the early fc4 exchange of DataParallel)."""
         from ._lib import stream_ptr
-        self.lib.dra_allreduce_grads(ctypes.c_void_p(flat.data_ptr()), flat.numel(), float(scale), self.h, stream_ptr())
+        self.lib.dra_allreduce_grads(ctypes.c_void_p(flat.data_ptr()), flat.numel(), float(scale), self.h, stream_ptr(stream))
         return flat
+
+    def info(self):
+        """(ranks, this rank) as RCCL itself reports them."""
+        n, r = ctypes.c_int(0), ctypes.c_int(-1)
+        self.lib.dra_comm_info(self.h, ctypes.byref(n), ctypes.byref(r))
+        return n.value, r.value
 
     def close(self):
         if self.h:
@@ -172,6 +180,10 @@ class DataParallel:
         config.env_shard = (self.lo, self.hi)
         self._gen = None
         self.step_dev = None          # device int64: sampler calls so far (the noise stream's position)
+        self._split = None            # plan_split(): float offset where the early (fc4 + heads) segment of the gradient starts
+        self._comm_stream = None
+        self._early, self._weight, self._hooks = None, 1.0, []
+        self.early_exchanges = 0      # tail segments that went out before sum_grads() was called
 
     @property
     def is_main(self):
@@ -215,16 +227,98 @@ class DataParallel:
         self._gen.manual_seed(self.noise_seed * 1000003 + int(step))
         return torch.rand(n_global, k, generator=self._gen, device=device)[self.lo:self.hi]
 
+    # -- the gradient exchange, split so that most of it overlaps the backward pass -----------------
+    # The flat gradient of the Atari actor-critic is [conv1 conv2 conv3 | fc4 heads]: 0.3 MB of convolution gradients in front of
+    # 6.4 MB that is COMPLETE as soon as fc4's backward has run -- before conv3 / conv2 / conv1 are differentiated.  plan_split()
+    # marks that boundary and counts the gradient accumulations of the tail's parameters; when the last of them has fired the
+    # tail segment goes out on a communication stream (RCCL; gloo: an asynchronous collective) while the convolutions'
+    # backward still runs, and sum_grads() then only exchanges the small head segment and joins.  Element for element the two
+    # segment sums are the one-call sum (with two ranks bit for bit: one addition per element either way;
+    # tests/test_dist_gloo.py); every rank receives identical values whatever the split.
+    def plan_split(self, flat_params, tail_params):
+        """flat_params: optim.FlatParams of the network; tail_params: the parameters whose gradients complete first
+        (fc4 + heads) -- they must form the END of the flat buffer.  Without a plan sum_grads() is the single exchange."""
+        self._split = None
+        self._hooks = getattr(self, "_hooks", [])
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if not self.active or not tail_params:
+            return
+        offs = sorted(flat_params.offset_of(p) for p in tail_params)
+        rest = [o for p, o in zip(flat_params.params, flat_params.offsets) if all(p is not q for q in tail_params)]
+        if rest and max(rest) > offs[0]:
+            return                       # the tail is not contiguous at the end of the buffer: keep the single exchange
+        self._split = int(offs[0])
+        self._tail_n, self._tail_seen, self._early, self._weight = len(tail_params), 0, None, 1.0
+        self._flat_grad = flat_params.grad
+
+        def fired(_p):
+            self._tail_seen += 1
+            if self._tail_seen == self._tail_n:
+                self._begin_tail()
+        for p in tail_params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(fired))
+
+    def set_weight(self, weight):
+        """The factor sum_grads() will be called with, announced BEFORE the backward pass (the early segment needs it)."""
+        self._weight = float(weight)
+
+    def _begin_tail(self):
+        """Every tail gradient has been accumulated: exchange flat[split:] now, asynchronously."""
+        flat, lo = self._flat_grad, self._split
+        seg = flat[lo:]
+        if flat.is_cuda:
+            if self.comm is None or torch.cuda.is_current_stream_capturing():
+                return                   # shared-GPU test box (gloo over host memory) / graph capture: exchanged at the tail
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream()
+                self._ev_ready, self._ev_done = torch.cuda.Event(), torch.cuda.Event()
+            self._ev_ready.record()                                   # the backward launches that wrote the tail segment
+            self._comm_stream.wait_event(self._ev_ready)
+            self.comm.allreduce_grads(seg, self._weight, stream=self._comm_stream)
+            self._early = "rccl"
+        else:
+            if self._weight != 1.0:
+                seg.mul_(self._weight)
+            self._early = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
+        self.early_exchanges += 1
+
     def sum_grads(self, flat, weight=1.0):
+        """flat <- sum over ranks of weight * flat (one exchange per optimizer step; in two segments when plan_split() is in
+        effect, the large one possibly already under way)."""
+        split = getattr(self, "_split", None)
+        if split is not None:
+            self._tail_seen = 0
         if not self.active:
             if weight != 1.0:
                 flat.mul_(weight)
             return flat
+        early, self._early = getattr(self, "_early", None), None
+        if early is not None and float(weight) != self._weight:
+            raise RuntimeError("DataParallel: the early segment went out with weight %r, sum_grads got %r" % (self._weight, weight))
+        if split is None or flat is not self._flat_grad:
+            segs = [flat]
+        else:
+            segs = [flat[:split]] if early is not None else [flat[split:], flat[:split]]     # fc4's 6.4 MB first
         if self.comm is not None and flat.is_cuda:
-            return self.comm.allreduce_grads(flat, weight)
-        if weight != 1.0:
-            flat.mul_(weight)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if early == "rccl":         # the head segment follows on the communication stream; the step waits for both
+                self._ev_ready.record()
+                self._comm_stream.wait_event(self._ev_ready)
+                for sg in segs:
+                    self.comm.allreduce_grads(sg, weight, stream=self._comm_stream)
+                self._ev_done.record(self._comm_stream)
+                torch.cuda.current_stream().wait_event(self._ev_done)
+            else:
+                for sg in segs:
+                    self.comm.allreduce_grads(sg, weight)
+            return flat
+        for sg in segs:
+            if weight != 1.0:
+                sg.mul_(weight)
+            dist.all_reduce(sg, op=dist.ReduceOp.SUM)
+        if early is not None:
+            early.wait()
         return flat
 
     def sum_scalars(self, values):

@@ -497,6 +497,7 @@ typedef struct dra_comm dra_comm;
 int dra_comm_unique_id(void* id_bytes);
 int dra_comm_init_rank(dra_comm** out, int n_ranks, int rank, const void* id_bytes);
 int dra_comm_destroy(dra_comm* comm);
+int dra_comm_info(dra_comm* comm, int* n_ranks, int* rank); /* as RCCL reports them (ncclCommCount / ncclCommUserRank) */
 /* flat_grad <- (sum over ranks) * scale, in place, asynchronous on stream (scale = 1/n_ranks: gradient of the global mean) */
 int dra_allreduce_grads(float* flat_grad, int64_t count, float scale, dra_comm* comm, void* stream);
 /* a few fp64 scalars summed over ranks (PPO's global advantage statistics, PPO_agent.py:66) */

@@ -176,7 +176,9 @@ class AsyncDqnScheduleOracle:
         q = N.vanilla_head(p, phi)
         delta = L.dqn_td_error(q, qn, torch.from_numpy(ac), torch.from_numpy(rw.astype(np.float32)),
                                torch.from_numpy(mk.astype(np.float32)), self.gamma, q_next_online=qno)
-        loss = L.dqn_reduce(delta) if weights is None else delta.pow(2).mul(0.5).mul(weights).mean()
+        # PER: the importance weights multiply the TD-error VECTOR compute_loss returns (DQN_agent.py:98-99,126), and
+        # reduce_loss squares afterwards (:78-79): mean(0.5 * (delta * w)^2)
+        loss = L.dqn_reduce(delta) if weights is None else L.dqn_reduce(delta.mul(weights))
         grads = torch.autograd.grad(loss, [p[k] for k in self.names])
         norm, grads = N.clip_grad_norm(list(grads), self.clip)
         with torch.no_grad():
@@ -301,11 +303,10 @@ class AsyncPerAgentScheduleOracle(AsyncDqnScheduleOracle):
         return torch.from_numpy(np.asarray(loss_vec, dtype=np.float32)).abs().add(self.replay_eps).pow(self.replay_alpha).numpy()
 
     def learn(self, tree_idx, prob, batch, override_priorities=None):
-        """update + update_priorities; returns (loss, pre-weight loss vector, own priorities, weights)."""
+        """update + update_priorities; returns (loss, the pre-weight vector compute_loss returns -- TD errors for the vanilla
+        head, KL per sample for C51 --, own priorities, weights)."""
         w = self.weights(prob, self.beta_fn())
-        loss, vec, out, norm = self.update(batch, weights=w)
-        if self.head == "vanilla":
-            vec = 0.5 * np.square(vec.astype(np.float32))        # DQN_agent.py:99: the loss vector is 0.5 * delta^2
+        loss, vec, out, norm = self.update(batch, weights=w)     # vec: TD errors (DQN_agent.py:98-99) / KL (CategoricalDQN :85-86)
         prio = self.priorities(vec)
         use = prio if override_priorities is None else np.asarray(override_priorities, dtype=np.float32)
         self.rep.update_priorities(zip(tree_idx.tolist(), [float(v) for v in use]))

@@ -33,6 +33,7 @@ PIXEL_AGENT_CASES = [   # tag, agent, replay, n_step, done_period, agent steps
     ("dqn_b32", "dqn", "uniform", 1, 9, 24),
     ("c51_per", "c51", "per", 1, 7, 24),
     ("qr_n3", "qr", "uniform", 3, 11, 22),
+    ("dqn_per", "dqn", "per", 1, 8, 24),        # round 4: the vanilla head's prioritized branch (DQN_agent.py:120-127)
 ]
 
 # Dueling / Rainbow heads (network_heads.py:24-37,57-86; NoisyLinear network_utils.py:31-83): tensors the fixtures load from

@@ -324,10 +324,11 @@ class _LinearSchedule:
         return val
 
 
-def test_per_agent_schedule_oracle_in_order_equals_reference_run(golden):
+@pytest.mark.parametrize("tag", ["c51_per", "dqn_per"])
+def test_per_agent_schedule_oracle_in_order_equals_reference_run(golden, tag):
     """oracle/async_schedule_oracle.py::AsyncPerAgentScheduleOracle (the prioritized-replay schedule oracle of round 4) driven
     IN ORDER -- actor(k) on the current parameters, report, draw, learn, target sync -- must reproduce the run of the
-    reference's own CategoricalDQNAgent + PrioritizedReplay (tests/golden/pixel_agents.npz, case c51_per): every stored
+    reference's own CategoricalDQNAgent / DQNAgent + PrioritizedReplay (tests/golden/pixel_agents.npz, cases c51_per, dqn_per): every stored
     transition, the priority tree, max_priority, the parameters after every update and the positions of numpy's and python's
     generators.  That pins everything in the class except the one thing the async pipeline defines -- WHICH parameters the
     actor sees (one update staler) -- which is a two-line difference in the driver (tests/test_gpu_agents.py)."""
@@ -336,15 +337,17 @@ def test_per_agent_schedule_oracle_in_order_equals_reference_run(golden):
     from golden.make_golden_cases import PIXEL_AGENT_CASES, trajectory_digest
     from oracle.async_schedule_oracle import AsyncPerAgentScheduleOracle
     g = golden("pixel_agents")
-    tag, kind, rep, n_step, done_period, steps = [c for c in PIXEL_AGENT_CASES if c[0] == "c51_per"][0]
+    tag, kind, rep, n_step, done_period, steps = [c for c in PIXEL_AGENT_CASES if c[0] == tag][0]
     k = tag + "_"
     np_state, py_state = np.random.get_state(), random.getstate()
     try:
         np.random.seed(3)
         np.random.randint(int(1e6))         # random_seed(3), torch_utils.py:36-38: the torch seed is drawn from the numpy stream
         random.seed(3)
-        shapes = fake_envs.NATURE_SHAPES + [("fc_categorical.weight", (4 * 51, 512)), ("fc_categorical.bias", (4 * 51,))]
+        hname, n_head = ("fc_categorical", 4 * 51) if kind == "c51" else ("fc_head", 4)
+        shapes = fake_envs.NATURE_SHAPES + [(hname + ".weight", (n_head, 512)), (hname + ".bias", (n_head,))]
         p_np = fake_envs.numpy_params(shapes, 17)
+        okw = dict(head="c51", clip=5.0, lr=0.00025, eps=0.01 / 32) if kind == "c51" else dict(head="vanilla", clip=5.0)
         sched = _LinearSchedule(1.0, 0.05, 60)
         actor_steps = [0]
 
@@ -355,9 +358,9 @@ def test_per_agent_schedule_oracle_in_order_equals_reference_run(golden):
 
         orc = AsyncPerAgentScheduleOracle(p_np, 500, 32, env_seed=7, done_period=done_period, actor_rs=np.random,
                                           epsilon_fn=epsilon, beta_fn=_LinearSchedule(0.4, 1.0, 1000), exploration_steps=40,
-                                          target_freq=3, head="c51", clip=5.0, lr=0.00025, eps=0.01 / 32)
-        # state_dict order of the reference's CategoricalNet: fc_categorical first, then the body
-        order = ["fc_categorical.weight", "fc_categorical.bias"] + [n for n, _ in fake_envs.NATURE_SHAPES]
+                                          target_freq=3, **okw)
+        # state_dict order of the reference's CategoricalNet / VanillaNet: the head first, then the body
+        order = [hname + ".weight", hname + ".bias"] + [n for n, _ in fake_envs.NATURE_SHAPES]
         traj = []
         for t in range(steps):
             orc.actor_step(orc.p)                                    # in order: the CURRENT parameters
