@@ -9,7 +9,7 @@
 //                          K-chunked implicit GEMM;
 //   DRA_VAR_ONESHOT_WGRAD  one-pass conv weight gradients (ConvWgradOne): one slab per (sample, row
 //                          chunk) -- dra_conv_wgrad_slabs() slabs instead of `ksplit`.
-#include "oneshot.h"
+#include "oneshot_lin.h"
 #include "actor_env.h"
 #include "per_chain2.h"
 #include <stdlib.h>
@@ -49,6 +49,16 @@ using WG1f = ConvWgradOne<G1, 4, 4, 88, 0, false>;
 using WG2 = ConvWgradOne<G2, 9, 4, 24, 4, false>;
 using WG3 = ConvWgradOne<G3, 7, 3, 10, 1, false>;
 using WG3b = ConvWgradOne<G3, 7, 6, 10, 1, false>;   // 6 k-tiles per workgroup: 96 instead of 192 workgroups
+// round 4 (oneshot_lin.h): the same contractions with straight-copy staging -- operands stay in LDS as they lie in memory
+using WG2l = ConvWgradLin<G2, 4>;
+using WG3l = ConvWgradLin<G3, 3>;
+// DRA_BWD_LIN (A/B switch of the round; bit 0 = input gradients of conv2 / conv3, bit 1 = conv2's weight gradient, bit 2 = conv3's
+// weight gradient as ConvWgradLin with one slab per sample instead of the unit-accumulating ConvWgradAcc)
+static int bwd_lin() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_BWD_LIN"); v = e ? atoi(e) : 3; }
+  return v;
+}
 // DRA_VAR_WGRAD_ACC: four (sample, chunk) units per workgroup, one slab per unit group (8 / 8 / 40 slabs at batch 32):
 // conv1 one k-tile per workgroup (320 workgroups x 40 MFMAs per wave), conv2 two k-tiles x one oc-tile (128 x 90),
 // conv3 two k-tiles x one oc-tile (144 x 56)
@@ -64,6 +74,7 @@ static int wgrad_acc_layers() {
   return v;
 }
 static bool wgrad_acc(int variant, int layer) {
+  if (layer == 3 && (bwd_lin() & 4)) return false;
   return (variant & DRA_VAR_WGRAD_ACC) && ((wgrad_acc_layers() >> (layer - 1)) & 1);
 }
 
@@ -94,14 +105,9 @@ static W make_wgrad_one(const float* dy, const void* x, float* dw, float* db, in
   return r;
 }
 
-// tiles per workgroup of the one-pass input gradient: conv2 (4 stride phases x 4 tiles per sample) pairs tiles
-// (DRA_DGRAD_PT=1 in the environment keeps one tile per workgroup: A/B switch)
+// tiles per workgroup of the one-pass input gradient: conv2 (4 stride phases x 4 tiles per sample) pairs tiles -- 256 instead of
+// 512 workgroups, one round together with the weight-gradient role (1 and 4 tiles per workgroup measured slower in round 2)
 template <class G> struct DgradTiles { static constexpr int PT = (G::S == 2) ? 2 : 1; };
-static int dgrad_pt_choice() {   // tiles per conv2 input-gradient workgroup: 1, 2 or 4 (all four tiles of a phase)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_DGRAD_PT"); v = e ? atoi(e) : 2; if (v != 1 && v != 2 && v != 4) v = 2; }
-  return v;
-}
 static int wg3_wide() {            // conv3 weight gradient: 6 k-tiles per workgroup (DRA_WG3_MTG=6) instead of 3
   static int v = -1;
   if (v < 0) { const char* e = getenv("DRA_WG3_MTG"); v = (e && atoi(e) == 6) ? 1 : 0; }
@@ -148,13 +154,10 @@ static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, con
   if (n3 > 0 && !(od && ow)) return DRA_EINVAL;   // a riding role exists for the one-pass pair only
   if (od && ow) {
     auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
-    if (DgradTiles<G>::PT > 1 && dgrad_pt_choice() == 1) {
-      auto rd1 = make_dgrad_one<G, 1>(dy, wt, xact, dx, batch, act);
-      return launch_multi(rd1, rd1.blocks(), rw, rw.blocks(), none, n3, st);
-    }
-    if (DgradTiles<G>::PT > 1 && dgrad_pt_choice() == 4) {
-      auto rd4 = make_dgrad_one<G, 4>(dy, wt, xact, dx, batch, act);
-      return launch_multi(rd4, rd4.blocks(), rw, rw.blocks(), none, n3, st);
+    if (bwd_lin() & 1) {
+      ConvDgradLin<G, DgradTiles<G>::PT> rl;
+      rl.dy = dy; rl.wt = wt; rl.xact = xact; rl.dx = dx; rl.B = batch; rl.act = act; rl.xcd = dra_xcd_order_enabled();
+      return launch_multi(rl, rl.blocks(), rw, rw.blocks(), none, n3, st);
     }
     auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
     return launch_multi(rd, rd.blocks(), rw, rw.blocks(), none, n3, st);
@@ -208,9 +211,11 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
       return dra_conv_bwd_w_koc(1, dy, x, dw, db, slab_stride, ksplit, batch, x_is_u8, u8_coef, stream);
     case 2:
       if (wgrad_acc(variant, 2)) return conv_bwd_fused_t<G2, WA2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+      if (bwd_lin() & 2) return conv_bwd_fused_t<G2, WG2l>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
       return conv_bwd_fused_t<G2, WG2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
     case 3:
       if (wgrad_acc(variant, 3)) return conv_bwd_fused_t<G3, WA3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+      if (bwd_lin() & 4) return conv_bwd_fused_t<G3, WG3l>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
       if (wg3_wide()) return conv_bwd_fused_t<G3, WG3b>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
       return conv_bwd_fused_t<G3, WG3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
   }
@@ -235,6 +240,7 @@ static int conv3_bwd_chain_t(const float* dy, const void* x, const float* wt, co
   ChainRole<PART> r;
   r.a = *chain;
   if (wgrad_acc(variant, 3)) return conv_bwd_fused_t<G3, WA3, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
+  if (bwd_lin() & 4) return conv_bwd_fused_t<G3, WG3l, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
   if (wg3_wide()) return conv_bwd_fused_t<G3, WG3b, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
   return conv_bwd_fused_t<G3, WG3, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
 }
@@ -293,10 +299,12 @@ int dra_conv_bwd_fused_fold(int layer, const float* dy, const void* x, const flo
   const bool acc = wgrad_acc(variant, layer);
   if (layer == 2) {
     if (acc) return conv_bwd_fused_t<G2, WA2, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
+    if (bwd_lin() & 2) return conv_bwd_fused_t<G2, WG2l, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
     return conv_bwd_fused_t<G2, WG2, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
   }
   if (layer == 3) {
     if (acc) return conv_bwd_fused_t<G3, WA3, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
+    if (bwd_lin() & 4) return conv_bwd_fused_t<G3, WG3l, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
     return conv_bwd_fused_t<G3, WG3, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
   }
   return DRA_EINVAL;

@@ -1,0 +1,286 @@
+// Round 4: the one-pass backward roles of conv2 / conv3 with STRAIGHT-COPY staging.
+//
+// oneshot.h's ConvDgradOne / ConvWgradOne scatter every staged element into a padded (dgrad) or transposed (wgrad) LDS image:
+// a constant division or two, a multiply-add and a ds_write_b32 per element -- 730 VALU instructions per wave around 64-90
+// MFMAs in conv2's backward launch (rocprofv3 SQ_INSTS_VALU / SQ_INSTS_MFMA = 10.1, profiles/r04a_sq_learner_b32.json), and
+// a zero fill + an extra barrier in front of it.  Here the operands stay in LDS exactly as they lie in memory -- the
+// workgroup's loads are float4, its LDS writes ds_write_b128 of the same float4, no index arithmetic at all -- and the
+// geometry moves into the per-lane BASE ADDRESS of the MFMA operand reads, computed once per workgroup:
+//   * input gradient: the gradient image dY[b] is [OC][P] as in memory.  A lane (position, tap) whose shifted read falls outside
+//     the image does not read a zero PADDING cell any more; its base address points into a small block of zeros instead, so the
+//     loop body stays `ds_read_b32 v, base + immediate` with no select;
+//   * weight gradient: the reduction index is the output position p in memory order, two consecutive positions per MFMA
+//     (k-slices h = 0 / 1).  P is odd (81, 49), so ONE MFMA of a tile carries a pad slot instead of one per output row
+//     (41 instead of 45 MFMAs per tile for conv2, 25 instead of 28 for conv3).  dY stays [oc][P]: lane = oc reads have the odd
+//     stride P -> conflict-free; the input image stays [c][H][H]: lane = tap reads are conflict-free for conv2's 4x4 taps.
+// Same products in the same order as the padded / transposed forms (a pad slot contributes fma(a, 0, acc) = acc): results are
+// bit-identical with oneshot.h's roles, which remain for conv1 and for the unit-accumulating weight gradient.
+#pragma once
+#include "oneshot.h"
+
+// ------------------------------------------------------------------------------------------------
+// Input gradient, KOC weights, one pass (see ConvDgradOne for the stride-phase decomposition and the slot maps).
+template <class G, int PT = 1>
+struct ConvDgradLin {
+  static constexpr int S = G::S, KP = (G::KH + S - 1) / S, NPH = S * S, HP = (G::H + S - 1) / S, PP = HP * HP;
+  static constexpr int OH = G::OH, P = G::P;
+  static constexpr int TPP = (PP + 31) / 32, TGP = (TPP + PT - 1) / PT;   // tiles / tile groups per phase
+  static constexpr int OCW = G::OC / 4, OCH = OCW / 2, NT = KP * KP, NJ = NT * OCH;
+  static constexpr int MT = G::C / 32;
+  static constexpr int NSRC = G::OC * P;                                 // one sample's gradient image, as in memory
+  static constexpr int ZERO = ((OCH - 1) * P + 1 + 3) & ~3;              // zeros read by (lane, tap) pairs outside the image
+  static constexpr int IMG = NSRC + ZERO;
+  static constexpr int RED = PT * 4096;
+  static constexpr int LDS_FLOATS = IMG > RED ? IMG : RED;
+  static_assert(G::KH % S == 0, "every stride phase has KP x KP taps");
+  static_assert(G::OC % 32 == 0 && OCH % 4 == 0 && G::C % 32 == 0, "float4 weight runs per half-wave");
+  static_assert(NSRC % 4 == 0, "float4 staging");
+  const float* dy;    // [B][OC][OH][OH] pre-activation gradient of this layer's output
+  const float* wt;    // [(c,kh,kw)][OC]
+  const float* xact;  // [B][C][H][H] this layer's input (post-activation) or null
+  float* dx;          // [B][C][H][H]
+  int B, act;
+  int xcd = 0;        // != 0: all workgroups of a sample on one XCD (xcd_order)
+  __host__ int blocks() const { return B * NPH * TGP * MT; }
+  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int bid = xcd ? xcd_order(bid_, first, B, NPH * TGP * MT) : bid_;
+    const int mt = bid % MT;
+    int r = bid / MT;
+    const int grp = r % TGP;
+    r /= TGP;
+    const int phi = r % NPH, bi = r / NPH;
+    const int ph = phi / S, pw = phi - ph * S;
+    const int c0 = mt * 32, p0 = grp * PT * 32;
+    const int np = min(32 * PT, PP - p0);
+    [[maybe_unused]] constexpr int TRR = (G::C == 32) ? TR_CONV2_B : TR_CONV3_B;
+    DRA_STAMP(TRR, 0);
+    // ---- weights: lane li <-> input channel c0 + li
+    float4 areg[NT][OCH / 4];
+    {
+      const float* wl = wt + (int64_t)(c0 + li) * G::KK * G::OC + wave * OCW + h * OCH;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int kh = (t / KP) * S + ph, kw = (t % KP) * S + pw;
+#pragma unroll
+        for (int v = 0; v < OCH / 4; ++v)
+          areg[t][v] = *reinterpret_cast<const float4*>(wl + (kh * G::KH + kw) * G::OC + 4 * v);
+      }
+    }
+    // ---- dY[bi] ([OC][P], contiguous, 16-byte aligned) -> registers as float4
+    constexpr int NV = NSRC / 4, RV = (NV + 255) / 256;
+    float4 rawv[RV];
+    const float4* dyb4 = reinterpret_cast<const float4*>(dy + (int64_t)bi * NSRC);
+#pragma unroll
+    for (int q = 0; q < RV; ++q) rawv[q] = dyb4[min(tid + 256 * q, NV - 1)];
+    // ---- epilogue side input (activation-derivative source), loaded with everything else; per (tile, tap) operand bases
+    int pix[PT];
+    bool inside[PT];
+    float aux[PT][4];
+    int boff[PT][NT];      // LDS float offset of this lane's B operand of tap t, slot jj = 0 (slot jj adds jj * P)
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int pj = min(32 * t + li, np - 1);
+      const int ih2 = (p0 + pj) / HP, iw2 = (p0 + pj) - ih2 * HP;
+      const int ih = ih2 * S + ph, iw = iw2 * S + pw;
+      inside[t] = ih < G::H && iw < G::H;
+      pix[t] = min(ih, G::H - 1) * G::H + min(iw, G::H - 1);
+      const float* src = xact ? xact : dx;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + mfma_row(wave * 4 + q, h);
+        aux[t][q] = src[((int64_t)bi * G::C + c) * G::HW + pix[t]];
+      }
+#pragma unroll
+      for (int tp = 0; tp < NT; ++tp) {
+        const int rr = ih2 - tp / KP, cc = iw2 - tp % KP;
+        const bool ok = rr >= 0 && rr < OH && cc >= 0 && cc < OH;
+        boff[t][tp] = ok ? (wave * OCW + h * OCH) * P + rr * OH + cc : NSRC;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float4* lds4 = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < ZERO / 4; i += 256) lds4[NSRC / 4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < RV; ++q) {
+      const int f = tid + 256 * q;
+      if (f < NV) lds4[f] = rawv[q];
+    }
+    DRA_STAMP(TRR, 1);
+    __syncthreads();
+    DRA_STAMP(TRR, 2);
+    // ---- MFMA: same slot <-> (oc, tap) map and the same order as ConvDgradOne
+    f32x16 acc[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) acc[t] = zero16();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int jj = 0; jj < OCH; ++jj) {
+        const float4 av = areg[t][jj / 4];
+        const float a = (jj % 4 == 0) ? av.x : ((jj % 4 == 1) ? av.y : ((jj % 4 == 2) ? av.z : av.w));
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+          const float b = lds[boff[pt][t] + jj * P];
+          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[pt], 0, 0, 0);
+        }
+      }
+    }
+    DRA_STAMP(TRR, 3);
+    __syncthreads();
+    DRA_STAMP(TRR, 4);
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      float s[4];
+      reduce4(lds + t * 4096, acc[t], wave, lane, s);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + mfma_row(wave * 4 + q, h);
+        if (32 * t + li < np && inside[t])
+          dx[((int64_t)bi * G::C + c) * G::HW + pix[t]] = xact ? s[q] * act_grad(aux[t][q], act) : s[q];
+      }
+    }
+    DRA_STAMP(TRR, 5);
+    DRA_STAMP_END(TRR);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient, KOC layout, one pass, ONE SAMPLE per workgroup (conv2 / conv3: a chunk is the whole sample):
+//   dWt[k][oc] = sum_p Xcol[k][p] * dY[oc][p],  k = (c,kh,kw);   db[oc] = sum_p dY[oc][p]      slab index = sample
+// Workgroup = (sample b, group of MTG 32-row k tiles); M = k (lane li = tap), N = oc (lane li = output channel), reduction over
+// the sample's P output positions in memory order, two per MFMA.  The channels the group's taps touch are one contiguous run
+// of the input (copied as it lies, from a 16-byte aligned start: `shift` floats of the previous channel come along), the
+// gradient is the sample's whole [OC][P] block.
+template <class G, int MTG>
+struct ConvWgradLin {
+  static constexpr int S = G::S, OH = G::OH, P = G::P, H = G::H, HW = G::HW;
+  static constexpr int NJ = (P + 1) / 2;                       // MFMAs per tile; the last one carries the pad slot when P is odd
+  static constexpr bool ODD = (P & 1) != 0;
+  static constexpr int MTILES = G::K / 32, NGRP = MTILES / MTG, NTL = G::OC / 32, TILES = MTG * NTL;
+  static constexpr int TPW = (TILES + 3) / 4;
+  static constexpr int NCHMAX = ((MTG * 32) % G::KK == 0) ? (MTG * 32) / G::KK : (MTG * 32 + G::KK - 2) / G::KK + 1;
+  static constexpr int NCH = NCHMAX < G::C ? NCHMAX : G::C;
+  static constexpr int IMGF = (NCH * HW + 3 + 3) & ~3;          // + up to 3 floats of alignment shift, whole float4s
+  static constexpr int NSRC = G::OC * P;
+  static constexpr int LDS_FLOATS = IMGF + NSRC + 4;            // + one zero float4: the pad slot's B operand
+  static_assert(G::K % 32 == 0 && MTILES % MTG == 0, "tiling");
+  static_assert(NSRC % 4 == 0 && (G::C * HW) % 4 == 0, "float4 staging; a sample starts on a float4");
+  const float* dy;   // [B][OC][OH][OH]
+  const void* x;     // [B][C][H][H] f32
+  float* dw;         // slab 0 of dWt [K][OC]
+  float* db;         // slab 0 of db [OC]
+  int64_t slab_stride;
+  int B;
+  double coef;       // (unused: f32 inputs only; kept so that the role is built like ConvWgradOne)
+  const int64_t* sample_idx = nullptr;   // (unused)
+  int xcd = 0;        // != 0: all workgroups of a sample on one XCD (xcd_order)
+  __host__ int blocks() const { return B * NGRP; }
+  __host__ static int n_slabs(int batch) { return batch; }
+  // LDS float offset of output position p's top-left input pixel inside a channel: (oh * S) * H + ow * S
+  static constexpr int pos_off(int p) { return (p / OH) * S * H + (p % OH) * S; }
+  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int bid = xcd ? xcd_order(bid_, first, B, NGRP) : bid_;
+    const int grp = bid % NGRP, bi = bid / NGRP;
+    const int k0 = grp * MTG * 32;
+    const int c_lo = k0 / G::KK;
+    const int c_hi = min((k0 + MTG * 32 - 1) / G::KK, G::C - 1);
+    const int nch = c_hi - c_lo + 1;                       // <= NCH
+    float* img = lds;
+    float* dyl = lds + IMGF;
+    [[maybe_unused]] constexpr int TRR = (G::C == 32) ? TR_CONV2_B : TR_CONV3_B;
+    DRA_STAMP(TRR, 0);
+    // ---- every load of the workgroup: the sample's gradient block, then the input channels [c_lo, c_hi] as they lie
+    constexpr int NVD = NSRC / 4, RD = (NVD + 255) / 256;
+    float4 draw[RD];
+    const float4* dyb4 = reinterpret_cast<const float4*>(dy + (int64_t)bi * NSRC);
+#pragma unroll
+    for (int q = 0; q < RD; ++q) draw[q] = dyb4[min(tid + 256 * q, NVD - 1)];
+    const int64_t xstart = ((int64_t)bi * G::C + c_lo) * HW;          // first float of the run
+    const int shift = (int)(xstart & 3);                               // floats between the aligned start and the run
+    const int nvi = (nch * HW + shift + 3) >> 2;                        // float4s that cover it
+    const int64_t xlast4 = ((int64_t)B * G::C * HW >> 2) - 1;            // last float4 of the tensor
+    const float4* x4 = reinterpret_cast<const float4*>(x) + (xstart >> 2);
+    constexpr int RI = (IMGF / 4 + 255) / 256;
+    float4 iraw[RI];
+#pragma unroll
+    for (int q = 0; q < RI; ++q) {
+      const int64_t f = min((int64_t)(tid + 256 * q), (int64_t)nvi - 1);
+      iraw[q] = x4[min(f, xlast4 - (xstart >> 2))];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float4* img4 = reinterpret_cast<float4*>(img);
+    float4* dyl4 = reinterpret_cast<float4*>(dyl);
+#pragma unroll
+    for (int q = 0; q < RI; ++q) {
+      const int f = tid + 256 * q;
+      if (f < nvi) img4[f] = iraw[q];
+    }
+#pragma unroll
+    for (int q = 0; q < RD; ++q) {
+      const int f = tid + 256 * q;
+      if (f < NVD) dyl4[f] = draw[q];
+    }
+    if (tid == 0) dyl4[NVD] = make_float4(0.f, 0.f, 0.f, 0.f);
+    DRA_STAMP(TRR, 1);
+    __syncthreads();
+    DRA_STAMP(TRR, 2);
+    // ---- MFMA: wave w owns tiles w, w+4, ...; tile t = (mt, nt), mt = t / NTL
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = zero16();
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < TILES) {
+        const int mt = tile / NTL, nt = tile - mt * NTL;
+        const int k = k0 + mt * 32 + li;
+        const int c = k / G::KK, kr = k - c * G::KK, kh = kr / G::KH, kw = kr - kh * G::KH;
+        const float* abase = img + shift + (c - c_lo) * HW + kh * H + kw;
+        // slice h = 1 of MFMA j reads position 2j + 1: the next column of the same output row, or -- when 2j + 1 starts a row --
+        // the first column of the next one
+        const float* ap_same = abase + h * S;
+        const float* ap_wrap = abase + h * (S * H - (OH - 1) * S);
+        const float* bp = dyl + (nt * 32 + li) * P + h;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const bool last_odd = ODD && j == NJ - 1;
+          const bool wrap = ((2 * j + 1) % OH) == 0;
+          float a, b;
+          if (last_odd) {            // positions (P - 1, pad): both slices read a finite A, slice 1 a zero B
+            a = abase[pos_off(2 * j)];
+            b = h ? dyl[NSRC] : bp[2 * j - h];
+          } else {
+            a = wrap ? ap_wrap[pos_off(2 * j)] : ap_same[pos_off(2 * j)];
+            b = bp[2 * j];
+          }
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    DRA_STAMP(TRR, 3);
+    // ---- slab stores (rows = k, 32 lanes along oc: 128-byte rows)
+    float* dws = dw + (int64_t)bi * slab_stride;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < TILES) {
+        const int mt = tile / NTL, nt = tile - mt * NTL;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int k = k0 + mt * 32 + mfma_row(rr, h);
+          dws[(int64_t)k * G::OC + nt * 32 + li] = acc[t][rr];
+        }
+      }
+    }
+    if (grp == 0 && tid < G::OC) {  // bias gradient of this sample: fixed-order row sum
+      float sb = 0.f;
+#pragma unroll 8
+      for (int pos = 0; pos < P; ++pos) sb += dyl[tid * P + pos];
+      db[(int64_t)bi * slab_stride + tid] = sb;
+    }
+    DRA_STAMP(TRR, 5);
+    DRA_STAMP_END(TRR);
+  }
+};

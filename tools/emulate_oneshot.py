@@ -162,6 +162,139 @@ def emu_conv_wgrad(G, ROWS, MTG, RW, CSPAD, dy, x, B):
     return dw, db
 
 
+def emu_conv_dgrad_lin(G, PT, dy, wt, xact, B):
+    """oneshot_lin.h ConvDgradLin<G, PT>::run for every block: the gradient image stays [OC][P] in "LDS", out-of-image
+    (lane, tap) pairs read a block of zeros behind it.  -> dx, and the flat LDS addresses every operand read used."""
+    S, KH, OC, C, H, OH, P = G.S, G.KH, G.OC, G.C, G.H, G.OH, G.P
+    KP = (KH + S - 1) // S
+    NPH, HP = S * S, (H + S - 1) // S
+    PP = HP * HP
+    TPP = (PP + 31) // 32
+    TGP = (TPP + PT - 1) // PT
+    OCW, OCH, NT, MT = OC // 4, OC // 8, KP * KP, C // 32
+    NSRC = OC * P
+    ZERO = ((OCH - 1) * P + 1 + 3) & ~3
+    dx = np.full((B, C, H, H), np.nan, dtype=np.float64)
+    wtf = wt.reshape(-1)
+    li = np.arange(32)
+    for bid in range(B * NPH * TGP * MT):
+        mt = bid % MT
+        r = bid // MT
+        grp = r % TGP
+        r //= TGP
+        phi, bi = r % NPH, r // NPH
+        ph, pw = phi // S, phi % S
+        c0, p0 = mt * 32, grp * PT * 32
+        np_ = min(32 * PT, PP - p0)
+        lds = np.full(NSRC + ZERO, np.nan)
+        lds[:NSRC] = dy[bi].reshape(-1)             # straight copy, float4 by float4
+        lds[NSRC:] = 0.0
+        for t in range(PT):
+            if 32 * t >= np_:
+                continue
+            pj = np.minimum(32 * t + li, np_ - 1)
+            ih2, iw2 = (p0 + pj) // HP, (p0 + pj) % HP
+            acc = np.zeros((32, 32))
+            for wave in range(4):
+                for tp in range(NT):
+                    kh2, kw2 = tp // KP, tp % KP
+                    kh, kw = kh2 * S + ph, kw2 * S + pw
+                    rr, cc = ih2 - kh2, iw2 - kw2
+                    ok = (rr >= 0) & (rr < OH) & (cc >= 0) & (cc < OH)
+                    for jj in range(OCH):
+                        a = np.zeros((2, 32))
+                        b = np.zeros((2, 32))
+                        for h in range(2):
+                            oc = wave * OCW + h * OCH + jj
+                            a[h] = wtf[((c0 + li) * G.KK + kh * KH + kw) * OC + oc]
+                            boff = np.where(ok, (wave * OCW + h * OCH) * P + rr * OH + cc, NSRC)
+                            addr = boff + jj * P
+                            assert (addr >= 0).all() and (addr < NSRC + ZERO).all()
+                            b[h] = lds[addr]
+                        mfma_acc(acc, a, b)
+            ih, iw = ih2 * S + ph, iw2 * S + pw
+            for l in range(32):
+                if 32 * t + l < np_ and ih[l] < H and iw[l] < H:
+                    for m in range(32):
+                        c = c0 + m
+                        dx[bi, c, ih[l], iw[l]] = acc[m][l] * (1.0 if xact[bi, c, ih[l], iw[l]] > 0 else 0.0)
+    return dx
+
+
+def emu_conv_wgrad_lin(G, MTG, dy, x, B):
+    """oneshot_lin.h ConvWgradLin<G, MTG>::run for every block: the input channels of a k-tile group and the sample's gradient
+    block stay in "LDS" as they lie in memory (the image from a 16-byte aligned start: `shift`); the reduction runs over the
+    output positions in memory order, two per MFMA.  -> (dw slabs [B][K][OC], db slabs [B][OC])."""
+    S, KH, OC, C, H, OH, P, HW = G.S, G.KH, G.OC, G.C, G.H, G.OH, G.P, G.HW
+    NJ = (P + 1) // 2
+    ODD = P & 1
+    MTILES = G.K // 32
+    NGRP, NTL = MTILES // MTG, OC // 32
+    TILES = MTG * NTL
+    NCHMAX = (MTG * 32) // G.KK if (MTG * 32) % G.KK == 0 else (MTG * 32 + G.KK - 2) // G.KK + 1
+    NCH = min(NCHMAX, C)
+    IMGF = (NCH * HW + 3 + 3) & ~3
+    NSRC = OC * P
+    xf = x.reshape(-1)
+    n_x4 = x.size // 4
+    dw = np.full((B, G.K, OC), np.nan)
+    db = np.full((B, OC), np.nan)
+    li = np.arange(32)
+
+    def pos_off(p):
+        return (p // OH) * S * H + (p % OH) * S
+    for bid in range(B * NGRP):
+        grp, bi = bid % NGRP, bid // NGRP
+        k0 = grp * MTG * 32
+        c_lo = k0 // G.KK
+        c_hi = min((k0 + MTG * 32 - 1) // G.KK, C - 1)
+        nch = c_hi - c_lo + 1
+        assert nch <= NCH
+        xstart = (bi * C + c_lo) * HW
+        shift = xstart & 3
+        nvi = (nch * HW + shift + 3) >> 2
+        assert nvi * 4 <= IMGF
+        img = np.full(IMGF, np.nan)
+        for f in range(nvi):
+            g4 = min((xstart >> 2) + f, n_x4 - 1)
+            img[4 * f:4 * f + 4] = xf[4 * g4:4 * g4 + 4]
+        dyl = np.full(NSRC + 4, np.nan)
+        dyl[:NSRC] = dy[bi].reshape(-1)
+        dyl[NSRC:] = 0.0
+        for wave in range(4):
+            for t in range((TILES + 3) // 4):
+                tile = wave + 4 * t
+                if tile >= TILES:
+                    continue
+                mt, nt = tile // NTL, tile % NTL
+                k = k0 + mt * 32 + li
+                c, kr = k // G.KK, k % G.KK
+                kh, kw = kr // KH, kr % KH
+                abase = shift + (c - c_lo) * HW + kh * H + kw
+                acc = np.zeros((32, 32))
+                for j in range(NJ):
+                    last_odd = ODD and j == NJ - 1
+                    wrap = ((2 * j + 1) % OH) == 0
+                    a = np.zeros((2, 32))
+                    b = np.zeros((2, 32))
+                    for h in range(2):
+                        if last_odd:
+                            aaddr = abase + pos_off(2 * j)
+                            b[h] = dyl[NSRC] if h else dyl[(nt * 32 + li) * P + 2 * j]
+                        else:
+                            aaddr = abase + h * ((S * H - (OH - 1) * S) if wrap else S) + pos_off(2 * j)
+                            b[h] = dyl[(nt * 32 + li) * P + h + 2 * j]
+                        assert (aaddr >= 0).all() and (aaddr < 4 * nvi).all()
+                        a[h] = img[aaddr]
+                    mfma_acc(acc, a, b)
+                assert not np.isnan(acc).any()
+                dw[bi, k0 + mt * 32:k0 + mt * 32 + 32, nt * 32:nt * 32 + 32] = acc
+        if grp == 0:
+            for oc in range(OC):
+                db[bi, oc] = sum(dyl[oc * P + pos] for pos in range(P))
+    return dw, db
+
+
 def emu_conv_wgrad_acc(G, ROWS, MTG, NTG, RW, CSPAD, dy, x, B):
     """ConvWgradAcc<G, ROWS, MTG, NTG, RW, CSPAD>::run for every block: wave w stages unit 4*ug + w with the kernel's own
     float4 / dword walk of the SOURCE (clamped loads, carries across output channels), runs every tile of the workgroup,
@@ -441,6 +574,12 @@ def main():
             check(name + " dgrad one-pass", got, want_dx)
         dw, db = emu_conv_wgrad(G, *wg, dy.numpy(), x.numpy(), B)
         want_dw = w.grad.permute(1, 2, 3, 0).reshape(G.K, G.OC).numpy()
+        if name != "conv1":       # round 4 (oneshot_lin.h): straight-copy staging, geometry in the operand base addresses
+            pt_lin = 2 if name == "conv2" else 1
+            check(name + " dgrad lin", emu_conv_dgrad_lin(G, pt_lin, dy.numpy(), wt, x.numpy(), B), want_dx)
+            dwl, dbl = emu_conv_wgrad_lin(G, 4 if name == "conv2" else 3, dy.numpy(), x.numpy(), B)
+            check(name + " wgrad lin", dwl.sum(0), want_dw)
+            check(name + " bias  lin", dbl.sum(0), dy.sum((0, 2, 3)).numpy())
         check(name + " wgrad one-pass", dw.sum(0), want_dw)
         check(name + " bias  one-pass", db.sum(0), dy.sum((0, 2, 3)).numpy())
         # DRA_VAR_WGRAD_ACC instantiations (fused.hip WA1 / WA2 / WA3), and a batch that is not a multiple of the 4 units
