@@ -357,17 +357,30 @@ int dra_fc_bwd_fused_sq(const float* dq, const float* h4, const float* dh4, cons
     return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
   constexpr int O = 512;
+  LinDgradOne<O> rd;
+  rd.dy = dh4; rd.w = w4; rd.xact = x3; rd.dx = dx3; rd.B = batch; rd.I = in_features; rd.act = act;
+  rd.tiles_n = (in_features + 31) / 32;
+  HeadWgradRole rh;
+  rh.dq = dq; rh.h4 = h4; rh.dwh = dwh; rh.dbh = dbh; rh.B = batch; rh.A = n_actions;
+  static int lin = -1;      // DRA_FC_WGRAD_ONE (A/B switch of the round): 1 = register-only weight gradient (oneshot_lin.h)
+  if (lin < 0) { const char* e = getenv("DRA_FC_WGRAD_ONE"); lin = e ? atoi(e) : 1; }
+  if (lin && batch <= 32) {
+    constexpr int NI = 8;
+    LinWgradOne<NI> rl;
+    rl.dy = dh4; rl.x = x3; rl.dw = dw4; rl.db = db4; rl.partials = sq_partials; rl.B = batch; rl.O = O; rl.I = in_features;
+    rl.tiles_o = O / 32; rl.groups_i = (rd.tiles_n + NI - 1) / NI;
+    const int nw = rl.blocks();
+    rh.partials = sq_partials + nw;
+    *n_sq_partials = nw + 2 * n_actions;
+    return launch_multi(rd, rd.tiles_n * ((batch + 31) / 32), rl, nw, rh, 2 * n_actions, st);
+  }
   LinWgradSq<64, 64, 32> pw;
   pw.M = O; pw.N = in_features + 1; pw.K = batch; pw.I = in_features; pw.dy = dh4; pw.x = x3; pw.dw = dw4; pw.db = db4;
   pw.partials = sq_partials;
   auto rw = make_igemm_role(pw, 1);
   const int nw = igemm_blocks(rw, 1);
-  HeadWgradRole rh;
-  rh.dq = dq; rh.h4 = h4; rh.dwh = dwh; rh.dbh = dbh; rh.B = batch; rh.A = n_actions; rh.partials = sq_partials + nw;
+  rh.partials = sq_partials + nw;
   *n_sq_partials = nw + 2 * n_actions;
-  LinDgradOne<O> rd;
-  rd.dy = dh4; rd.w = w4; rd.xact = x3; rd.dx = dx3; rd.B = batch; rd.I = in_features; rd.act = act;
-  rd.tiles_n = (in_features + 31) / 32;
   return launch_multi(rd, rd.tiles_n * ((batch + 31) / 32), rw, nw, rh, 2 * n_actions, st);
 }
 
@@ -388,6 +401,13 @@ DRA_API int dra_fc_bwd_fused(const float* dq, const float* h4, const float* dh4,
     LinDgradOne<O> rd;
     rd.dy = dh4; rd.w = w4; rd.xact = x3; rd.dx = dx3; rd.B = batch; rd.I = in_features; rd.act = act;
     rd.tiles_n = (in_features + 31) / 32;
+    if (batch <= 32) {     // register-only weight gradient (oneshot_lin.h), as in the learner's launch
+      constexpr int NI = 8;
+      LinWgradOne<NI> rl;
+      rl.dy = dh4; rl.x = x3; rl.dw = dw4; rl.db = db4; rl.partials = nullptr; rl.B = batch; rl.O = O; rl.I = in_features;
+      rl.tiles_o = O / 32; rl.groups_i = (rd.tiles_n + NI - 1) / NI;
+      return launch_multi(rd, rd.tiles_n * ((batch + 31) / 32), rl, rl.blocks(), rh, 2 * n_actions, st);
+    }
     return launch_multi(rd, rd.tiles_n * ((batch + 31) / 32), rw, igemm_blocks(rw, 1), rh, 2 * n_actions, st);
   }
   LinDgrad<32, 32, 64> pd;

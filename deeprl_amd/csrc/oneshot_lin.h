@@ -18,6 +18,10 @@
 #pragma once
 #include "oneshot.h"
 
+// 16-byte staging registers as a NATIVE vector: an array of HIP's float4 (a struct) copied whole was left in scratch memory by
+// the compiler (112-176 bytes of private segment per lane, scratch_load_dwordx4 in front of every LDS write)
+typedef float lin_f4 __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------------------------------------
 // Input gradient, KOC weights, one pass (see ConvDgradOne for the stride-phase decomposition and the slot maps).
 template <class G, int PT = 1>
@@ -69,8 +73,8 @@ struct ConvDgradLin {
     }
     // ---- dY[bi] ([OC][P], contiguous, 16-byte aligned) -> registers as float4
     constexpr int NV = NSRC / 4, RV = (NV + 255) / 256;
-    float4 rawv[RV];
-    const float4* dyb4 = reinterpret_cast<const float4*>(dy + (int64_t)bi * NSRC);
+    lin_f4 rawv[RV];
+    const lin_f4* dyb4 = reinterpret_cast<const lin_f4*>(dy + (int64_t)bi * NSRC);
 #pragma unroll
     for (int q = 0; q < RV; ++q) rawv[q] = dyb4[min(tid + 256 * q, NV - 1)];
     // ---- epilogue side input (activation-derivative source), loaded with everything else; per (tile, tap) operand bases
@@ -99,13 +103,11 @@ struct ConvDgradLin {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    float4* lds4 = reinterpret_cast<float4*>(lds);
-    for (int i = tid; i < ZERO / 4; i += 256) lds4[NSRC / 4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    lin_f4* lds4 = reinterpret_cast<lin_f4*>(lds);
+    for (int i = tid; i < ZERO / 4; i += 256) lds4[NSRC / 4 + i] = lin_f4{0.f, 0.f, 0.f, 0.f};
+    // (unconditional: a lane past the end re-writes the LAST float4 with the same value it loaded from the clamped index)
 #pragma unroll
-    for (int q = 0; q < RV; ++q) {
-      const int f = tid + 256 * q;
-      if (f < NV) lds4[f] = rawv[q];
-    }
+    for (int q = 0; q < RV; ++q) lds4[min(tid + 256 * q, NV - 1)] = rawv[q];
     DRA_STAMP(TRR, 1);
     __syncthreads();
     DRA_STAMP(TRR, 2);
@@ -193,36 +195,31 @@ struct ConvWgradLin {
     DRA_STAMP(TRR, 0);
     // ---- every load of the workgroup: the sample's gradient block, then the input channels [c_lo, c_hi] as they lie
     constexpr int NVD = NSRC / 4, RD = (NVD + 255) / 256;
-    float4 draw[RD];
-    const float4* dyb4 = reinterpret_cast<const float4*>(dy + (int64_t)bi * NSRC);
+    lin_f4 draw[RD];
+    const lin_f4* dyb4 = reinterpret_cast<const lin_f4*>(dy + (int64_t)bi * NSRC);
 #pragma unroll
     for (int q = 0; q < RD; ++q) draw[q] = dyb4[min(tid + 256 * q, NVD - 1)];
     const int64_t xstart = ((int64_t)bi * G::C + c_lo) * HW;          // first float of the run
     const int shift = (int)(xstart & 3);                               // floats between the aligned start and the run
     const int nvi = (nch * HW + shift + 3) >> 2;                        // float4s that cover it
     const int64_t xlast4 = ((int64_t)B * G::C * HW >> 2) - 1;            // last float4 of the tensor
-    const float4* x4 = reinterpret_cast<const float4*>(x) + (xstart >> 2);
+    const lin_f4* x4 = reinterpret_cast<const lin_f4*>(x) + (xstart >> 2);
     constexpr int RI = (IMGF / 4 + 255) / 256;
-    float4 iraw[RI];
+    lin_f4 iraw[RI];
 #pragma unroll
     for (int q = 0; q < RI; ++q) {
       const int64_t f = min((int64_t)(tid + 256 * q), (int64_t)nvi - 1);
       iraw[q] = x4[min(f, xlast4 - (xstart >> 2))];
     }
     __builtin_amdgcn_sched_barrier(0);
-    float4* img4 = reinterpret_cast<float4*>(img);
-    float4* dyl4 = reinterpret_cast<float4*>(dyl);
+    lin_f4* img4 = reinterpret_cast<lin_f4*>(img);
+    lin_f4* dyl4 = reinterpret_cast<lin_f4*>(dyl);
+    // (unconditional stores: lanes past the end re-write the last float4 with the value they loaded from the clamped index)
 #pragma unroll
-    for (int q = 0; q < RI; ++q) {
-      const int f = tid + 256 * q;
-      if (f < nvi) img4[f] = iraw[q];
-    }
+    for (int q = 0; q < RI; ++q) img4[min(tid + 256 * q, nvi - 1)] = iraw[q];
 #pragma unroll
-    for (int q = 0; q < RD; ++q) {
-      const int f = tid + 256 * q;
-      if (f < NVD) dyl4[f] = draw[q];
-    }
-    if (tid == 0) dyl4[NVD] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < RD; ++q) dyl4[min(tid + 256 * q, NVD - 1)] = draw[q];
+    if (tid == 0) dyl4[NVD] = lin_f4{0.f, 0.f, 0.f, 0.f};
     DRA_STAMP(TRR, 1);
     __syncthreads();
     DRA_STAMP(TRR, 2);
@@ -282,5 +279,87 @@ struct ConvWgradLin {
     }
     DRA_STAMP(TRR, 5);
     DRA_STAMP_END(TRR);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Linear weight gradient for a minibatch of at most 32 rows, NO LDS at all (fc4 of the DQN update: O = 512, I = 3136):
+//   dW[o][i] = sum_b dy[b][o] * x[b][i],   db[o] = sum_b dy[b][o]
+// The reduction index is the batch row: 16 MFMAs (32x32x2, slices h = rows 2j / 2j + 1) per 32 x 32 output tile, and both
+// operands have their MFMA lane axis contiguous in memory -- lane li <-> output o for dy[b][o0 + li], lane li <-> input i for
+// x[b][i0 + li] -- so they go straight from 128-byte coalesced global loads to registers.  The K-chunked implicit GEMM this
+// replaces (IgemmRole<LinWgradSq<64, 64, 32>>: 400 workgroups staging 64 x 32 tiles through LDS with ~20 VALU instructions
+// per MFMA) was the longest role of the fc backward launch (10.3 us for a contraction that WRITES 6.4 MB and reads 0.5 MB).
+// Workgroup = (32 outputs, NI x 32 inputs): wave w owns input tiles w, w + 4, ... of the group; every wave holds the same 16
+// dy registers.  With `partials` the workgroup leaves the sum of squares of what it stored (late-fold optimizer).
+template <int NI>
+struct LinWgradOne {
+  static constexpr int LDS_FLOATS = 8;
+  static constexpr int TPW = (NI + 3) / 4;
+  const float* dy;   // [B][O]
+  const float* x;    // [B][I]
+  float* dw;         // [O][I]
+  float* db;         // [O] or null
+  double* partials;  // [blocks()] or null
+  int B, O, I, tiles_o, groups_i;
+  __host__ int blocks() const { return tiles_o * groups_i; }
+  __device__ __forceinline__ void run(int bid, float* __restrict__ lds, int = 0) const {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int gi = bid % groups_i, to = bid / groups_i;
+    const int o0 = to * 32;
+    DRA_STAMP(TR_FC_B, 0);
+    // A: dy[2j + h][o0 + li]; rows >= B contribute zeros
+    float areg[16];
+    const int oc = min(o0 + li, O - 1);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) areg[j] = dy[(int64_t)min(2 * j + h, B - 1) * O + oc];
+    float breg[TPW][16];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int i0 = (gi * NI + wave + 4 * t) * 32;
+      const int ic = min(i0 + li, I - 1);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) breg[t][j] = x[(int64_t)min(2 * j + h, B - 1) * I + ic];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (2 * j + h >= B) areg[j] = 0.f;
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int it = wave + 4 * t;
+      const int i0 = (gi * NI + it) * 32;
+      if (it < NI && i0 < I) {
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[j], breg[t][j], acc, 0, 0, 0);
+        const int i = i0 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + mfma_row(r, h);
+          if (o < O && i < I) {
+            dw[(int64_t)o * I + i] = acc[r];
+            sq += acc[r] * acc[r];
+          }
+        }
+      }
+    }
+    DRA_STAMP(TR_FC_B, 3);
+    // bias gradient: the sequential sum over the batch rows, by the first input group's wave 0
+    if (db && gi == 0 && wave == 0 && h == 0 && o0 + li < O) {
+      float sb = 0.f;
+      for (int b = 0; b < B; ++b) sb += dy[(int64_t)b * O + o0 + li];
+      db[o0 + li] = sb;
+      sq += sb * sb;
+    }
+    if (partials) {   // (uniform) fixed-order workgroup sum: lanes by butterfly, waves (w0 + w1) + (w2 + w3)
+      const double d = wave_sum((double)sq);
+      double* dl = reinterpret_cast<double*>(lds);
+      if (lane == 0) dl[wave] = d;
+      __syncthreads();
+      if (tid == 0) partials[bid] = (dl[0] + dl[1]) + (dl[2] + dl[3]);
+    }
+    DRA_STAMP(TR_FC_B, 5);
   }
 };

@@ -438,6 +438,43 @@ def emu_lin_dgrad(O, dy, w, xact, B, I):
     return dx
 
 
+def emu_lin_wgrad_one(NI, dy, x, B, O, I):
+    """oneshot_lin.h LinWgradOne<NI>::run for every block: both operands straight from memory to registers (lane <-> o / i),
+    the reduction over the batch rows two per MFMA.  -> (dw [O][I], db [O])."""
+    tiles_i = (I + 31) // 32
+    tiles_o, groups_i = O // 32, (tiles_i + NI - 1) // NI
+    dw = np.full((O, I), np.nan)
+    db = np.full(O, np.nan)
+    li = np.arange(32)
+    for bid in range(tiles_o * groups_i):
+        gi, to = bid % groups_i, bid // groups_i
+        o0 = to * 32
+        for wave in range(4):
+            for t in range((NI + 3) // 4):
+                it = wave + 4 * t
+                i0 = (gi * NI + it) * 32
+                if not (it < NI and i0 < I):
+                    continue
+                acc = np.zeros((32, 32))
+                for j in range(16):
+                    a = np.zeros((2, 32))
+                    b = np.zeros((2, 32))
+                    for h in range(2):
+                        row = 2 * j + h
+                        a[h] = dy[min(row, B - 1), np.minimum(o0 + li, O - 1)] if row < B else 0.0
+                        b[h] = x[min(row, B - 1), np.minimum(i0 + li, I - 1)]
+                    mfma_acc(acc, a, b)
+                for m in range(32):
+                    for n in range(32):
+                        if o0 + m < O and i0 + n < I:
+                            dw[o0 + m, i0 + n] = acc[m][n]
+        if gi == 0:
+            for m in range(32):
+                if o0 + m < O:
+                    db[o0 + m] = sum(dy[b, o0 + m] for b in range(B))
+    return dw, db
+
+
 def emu_lin_fwd_slabs(I, KS, x, w, B, O):
     KPS = I // KS
     KW, NJ, LD = KPS // 4, KPS // 8, KPS + 1
@@ -603,6 +640,11 @@ def main():
     dyl, wl = rs.randn(B, O), rs.randn(O, I)
     xa = rs.randn(B, I)
     check("linear dgrad one-pass", emu_lin_dgrad(O, dyl, wl, xa, B, I), (dyl @ wl) * (xa > 0))
+    for B, I, O in ((32, 200, 64), (5, 96, 32), (1, 40, 64)):      # fc4's weight gradient at batch <= 32, ragged input tiles
+        dyl, xl = rs.randn(B, O), rs.randn(B, I)
+        dwl, dbl = emu_lin_wgrad_one(8, dyl, xl, B, O, I)
+        check("linear wgrad register-only B=%d" % B, dwl, dyl.T @ xl)
+        check("linear bias  register-only B=%d" % B, dbl, dyl.sum(0))
     B, I, O, KS = 3, 64, 40, 2
     xl, wl = rs.randn(B, I), rs.randn(O, I)
     check("linear fwd slabs one-pass", emu_lin_fwd_slabs(I, KS, xl, wl, B, O).sum(0), xl @ wl.T)
