@@ -349,6 +349,22 @@ int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, flo
 // dq [B][A], h4 [B][512] (post-ReLU), dh4 [B][512] (gradient w.r.t. fc4's pre-activation), x3 [B][I].
 // sq_partials (optional, DRA_VAR_LATE_FOLD; one-pass input gradient only): the workgroups that write dW4 / db4 and dWh / dbh
 // leave their sums of squares in sq_partials[0, *n_sq_partials): fc4's tiles first, then the head's 2 * n_actions
+// fc4's weight gradient of the learner's launch: the register-only role for minibatches up to 32 (oneshot_lin.h), else the
+// K-chunked implicit GEMM.  DRA_FC_WGRAD_ONE=0 (A/B switch of the round) keeps the implicit GEMM.
+static bool fc_wgrad_one(int batch) {
+  static int lin = -1;
+  if (lin < 0) { const char* e = getenv("DRA_FC_WGRAD_ONE"); lin = e ? atoi(e) : 1; }
+  return lin && batch <= 32;
+}
+constexpr int kFcWgradNI = 8;    // 32-wide input tiles per workgroup of LinWgradOne
+// partials dra_fc_bwd_fused_sq writes for this problem (library-internal, actor_env.h): the learner lays the later launches'
+// partials and the optimizer's arrival slots out behind them
+int dra_fc_bwd_fused_sq_partials(int batch, int n_actions, int in_features) {
+  const int tiles_i = (in_features + 31) / 32;
+  const int nw = fc_wgrad_one(batch) ? (512 / 32) * ((tiles_i + kFcWgradNI - 1) / kFcWgradNI) : (512 / 64) * ((in_features + 1 + 63) / 64);
+  return nw + 2 * n_actions;
+}
+
 int dra_fc_bwd_fused_sq(const float* dq, const float* h4, const float* dh4, const float* x3, const float* w4, float* dwh,
                         float* dbh, float* dw4, float* db4, float* dx3, int batch, int n_actions, int in_features, int act,
                         int variant, double* sq_partials, int* n_sq_partials, void* stream) {
@@ -362,10 +378,8 @@ int dra_fc_bwd_fused_sq(const float* dq, const float* h4, const float* dh4, cons
   rd.tiles_n = (in_features + 31) / 32;
   HeadWgradRole rh;
   rh.dq = dq; rh.h4 = h4; rh.dwh = dwh; rh.dbh = dbh; rh.B = batch; rh.A = n_actions;
-  static int lin = -1;      // DRA_FC_WGRAD_ONE (A/B switch of the round): 1 = register-only weight gradient (oneshot_lin.h)
-  if (lin < 0) { const char* e = getenv("DRA_FC_WGRAD_ONE"); lin = e ? atoi(e) : 1; }
-  if (lin && batch <= 32) {
-    constexpr int NI = 8;
+  if (fc_wgrad_one(batch)) {
+    constexpr int NI = kFcWgradNI;
     LinWgradOne<NI> rl;
     rl.dy = dh4; rl.x = x3; rl.dw = dw4; rl.db = db4; rl.partials = sq_partials; rl.B = batch; rl.O = O; rl.I = in_features;
     rl.tiles_o = O / 32; rl.groups_i = (rd.tiles_n + NI - 1) / NI;
@@ -401,8 +415,8 @@ DRA_API int dra_fc_bwd_fused(const float* dq, const float* h4, const float* dh4,
     LinDgradOne<O> rd;
     rd.dy = dh4; rd.w = w4; rd.xact = x3; rd.dx = dx3; rd.B = batch; rd.I = in_features; rd.act = act;
     rd.tiles_n = (in_features + 31) / 32;
-    if (batch <= 32) {     // register-only weight gradient (oneshot_lin.h), as in the learner's launch
-      constexpr int NI = 8;
+    if (fc_wgrad_one(batch)) {     // register-only weight gradient (oneshot_lin.h), as in the learner's launch
+      constexpr int NI = kFcWgradNI;
       LinWgradOne<NI> rl;
       rl.dy = dh4; rl.x = x3; rl.dw = dw4; rl.db = db4; rl.partials = nullptr; rl.B = batch; rl.O = O; rl.I = in_features;
       rl.tiles_o = O / 32; rl.groups_i = (rd.tiles_n + NI - 1) / NI;

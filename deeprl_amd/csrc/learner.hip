@@ -369,13 +369,13 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   l->n_partials = 2 * dra_norm_partials();
   if ((l->variant & DRA_VAR_LATE_FOLD) && (l->variant & DRA_VAR_ONESHOT_WGRAD) && (l->variant & DRA_VAR_ONESHOT_DGRAD) &&
       (l->variant & DRA_VAR_FUSED_BWD) && !rc && cfg->offset[P_W1] == 0 && l->lnslabs[1] <= 32 && l->lnslabs[2] <= 32) {
-    // partials: fc4 tiles (64 x 64 over [512][3137]) + head workgroups + one per 256 folded floats of conv3 / conv2 + conv1's
+    // partials: fc4's weight-gradient workgroups + head workgroups + one per 256 folded floats of conv3 / conv2 + conv1's
     // fold workgroups in the optimizer launch
     dra_fold_seg s0;
     memset(&s0, 0, sizeof(s0));
     s0.begin = 0; s0.count = l->lstride[0]; s0.slabs = l->lslabs[0]; s0.slab_stride = l->lstride[0]; s0.n_slabs = l->lnslabs[0];
     if (dra_clip_step_late_blocks(&s0, &l->late_nfold) == DRA_OK) {
-      const int64_t np = 8 * 50 + 2 * NO + (l->lstride[2] / 4 + 63) / 64 + (l->lstride[1] / 4 + 63) / 64 + l->late_nfold;
+      const int64_t np = dra_fc_bwd_fused_sq_partials(cfg->batch, NO, 3136) + (l->lstride[2] / 4 + 63) / 64 + (l->lstride[1] / 4 + 63) / 64 + l->late_nfold;
       l->late = np <= dra_norm_partials_max();
     }
   }
@@ -1192,7 +1192,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       dra_fold_seg segs[3];
       conv_fold_segs(l, segs);
       int nfc = 0, n3 = 0, n2 = 0;
-      const int nfc_expect = 8 * 50 + 2 * NO, n3_expect = (int)((l->lstride[2] / 4 + 63) / 64), n2_expect = (int)((l->lstride[1] / 4 + 63) / 64);
+      const int nfc_expect = dra_fc_bwd_fused_sq_partials(B, NO, 3136), n3_expect = (int)((l->lstride[2] / 4 + 63) / 64), n2_expect = (int)((l->lstride[1] / 4 + 63) / 64);
       STEP(K_FC4_BX, dra_fc_bwd_fused_sq(l->dq, l->h4, l->dh4, l->y3[0], P + o[P_W4], G + o[P_WH], G + o[P_BH], G + o[P_W4],
                                          G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, l->partials, &nfc, s));
       if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV3_BW], st));
