@@ -129,6 +129,9 @@ int dra_conv1_wgrad_ringbatch(const float* dy, const void* frames, const int64_t
 // the sums of squares of what they store, (b) a FoldRole riding along that folds the PREVIOUS launch's weight-gradient
 // slabs (`fold`, at most 32) into the flat gradient `grad` and leaves its workgroups' sums of squares; reset_slots[0, n_reset)
 // (optional) are set to -1.0 by the fold's first workgroup: the arrival slots of the late-fold optimizer launch
+// conv_v2.hip: conv3's forward with extra workgroups that prefetch fc4's forward weights into the L2 that will read them
+int dra_conv3_fwd_koc_pf(int nz, const void* const* x, const float* const* wt, const float* const* bias, float* const* y, int batch,
+                         int act, const float* const* pf_w, int pf_nz, void* stream);
 int dra_fc_bwd_fused_sq_partials(int batch, int n_actions, int in_features);   // partials the call below writes
 int dra_fc_bwd_fused_sq(const float* dq, const float* h4, const float* dh4, const float* x3, const float* w4, float* dwh,
                         float* dbh, float* dw4, float* db4, float* dx3, int batch, int n_actions, int in_features, int act,

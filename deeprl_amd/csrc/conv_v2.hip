@@ -90,6 +90,13 @@ struct ConvV2Args {
   // minibatch is written or re-read
   const int64_t* sample_idx = nullptr;
   int64_t idx_bias[DRA_MAX_Z] = {};
+  // optional (round 4): extra z-slices of the launch whose workgroups only PREFETCH the next launch's weights into the L2 of
+  // the XCD that will read them -- fc4's forward (LinFwdSlabsOne<3136, 14, 2>, two nets: 224 workgroups streaming 57 KB of
+  // weights each at the ~25 GB/s a CU gets from the fabric, 3.2 us of its 7.5).  Prefetch workgroup p runs on XCD p mod 8
+  // (the z-slices in front of it hold a multiple of 8 workgroups), exactly where fc4's workgroup p will run, and issues the
+  // same 14 float4 loads per lane; nothing is stored.  pf_nz = nets of that launch (0 = off).
+  const float* pf_w[DRA_MAX_Z] = {};
+  int pf_nz = 0, pf_first = 0;
   // optional: sample_idx may live in pinned HOST memory (one PCIe read per workgroup, ~1 us inside the operand phase); the
   // first workgroup of every sample leaves a copy here (device memory) for the later kernels of the same update
   int64_t* sample_idx_copy = nullptr;
@@ -509,16 +516,40 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
   DRA_STAMP_END(TRR);
 }
 
+// The weight slice fc4's forward workgroup with PHYSICAL index p (= blockIdx.x of the launch that follows: oneshot.h
+// LinFwdSlabsOne<3136, 14, 2>::run with xcd_order) will stream: 64 rows x 224 floats of net z's [512][3136] weight matrix.
+__device__ __forceinline__ void fc4_weight_prefetch(const ConvV2Args& a, const int p) {
+  constexpr int I = 3136, KS = 14, KPS = I / KS, V = KPS / 4, TILES_N = 512 / 64, ROWS = 64;
+  const int n_groups = KS * a.pf_nz;                  // (net, K slice) groups of TILES_N workgroups, one row tile (batch <= 32)
+  if (p >= TILES_N * n_groups) return;
+  const int bid = xcd_order(p, 0, n_groups, TILES_N);
+  const int bn = bid % TILES_N, r = bid / TILES_N, sl = r % KS, z = r / KS;
+  const float* __restrict__ wz = a.pf_w[z] + (int64_t)bn * ROWS * I + sl * KPS;
+  constexpr int NVW = ROWS * V, RW = (NVW + 255) / 256;
+  float4 t[RW];
+#pragma unroll
+  for (int q = 0; q < RW; ++q) {
+    const int e = min((int)threadIdx.x + 256 * q, NVW - 1), row = e / V, c4 = e - row * V;
+    t[q] = *reinterpret_cast<const float4*>(wz + (int64_t)row * I + 4 * c4);
+  }
+#pragma unroll
+  for (int q = 0; q < RW; ++q) asm volatile("" : : "v"(t[q].x), "v"(t[q].y), "v"(t[q].z), "v"(t[q].w));
+}
+
 template <class G, bool U8, int PT, int NW = 4>
 __global__ void __launch_bounds__(64 * NW) conv_fwd_v2_kernel(const ConvV2Args a) {
   ActorFuse none;
   none.mode = 0;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.pf_nz > 0 && (int)blockIdx.z >= a.pf_first) {
+    fc4_weight_prefetch(a, (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * ((int)blockIdx.z - a.pf_first)));
+    return;
+  }
   if (a.xcd_order) {
     // natural order: x = sample * TPG + tile group (fastest), y = output-channel tile, z = net; the sharing group is one
     // (net, sample): TPG * gridDim.y workgroups staging rows of the same input images
     constexpr int TPG = V2Tile<G, PT>::TPG;
-    const int ny = gridDim.y, per = TPG * ny, groups = (int)gridDim.z * a.batch;
+    const int ny = gridDim.y, per = TPG * ny, groups = (a.pf_nz > 0 ? a.pf_first : (int)gridDim.z) * a.batch;
     const int lin = bx + (int)gridDim.x * (by + ny * bz);
     const int v = xcd_order(lin, 0, groups, per);
     const int g = v / per, w = v - g * per;
@@ -1086,7 +1117,14 @@ static int launch_conv_v2_pt(const ConvV2Args& a, int nz, hipStream_t st) {
   }
   ConvV2Args ax = a;
   ax.xcd_order = dra_xcd_order_enabled();
-  hipLaunchKernelGGL((conv_fwd_v2_kernel<G, U8, PT, NW>), dim3(T::TPG * a.batch, G::OC / 32, nz), dim3(64 * NW), bytes, st, ax);
+  int gz = nz;
+  if (ax.pf_nz > 0) {
+    const int per_z = T::TPG * a.batch * (G::OC / 32);
+    // prefetch workgroup p must run on XCD p mod 8: the slices in front of it hold a multiple of 8 workgroups, 256 threads each
+    if (NW != 4 || !ax.xcd_order || (per_z * nz) % 8 != 0) ax.pf_nz = 0;
+    else { ax.pf_first = nz; gz = nz + (8 * 14 * ax.pf_nz + per_z - 1) / per_z; }
+  }
+  hipLaunchKernelGGL((conv_fwd_v2_kernel<G, U8, PT, NW>), dim3(T::TPG * a.batch, G::OC / 32, gz), dim3(64 * NW), bytes, st, ax);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -1366,6 +1404,27 @@ DRA_API int dra_conv_fwd_koc(int layer, int nz, const void* const* x, const floa
     case 3: return x_is_u8 ? DRA_EINVAL : launch_conv_v2<VG3, false, 2>(a, nz, st);
   }
   return DRA_EINVAL;
+}
+
+// conv3's forward of the update with fc4's weights prefetched for the launch that follows (library-internal, actor_env.h):
+// pf_w[z] = the [512][3136] weight matrix net z of dra_linear_fwd_slabs_one(nz = pf_nz, ksplit = 14) will read.
+int dra_conv3_fwd_koc_pf(int nz, const void* const* x, const float* const* wt, const float* const* bias, float* const* y, int batch,
+                         int act, const float* const* pf_w, int pf_nz, void* stream) {
+  if (nz < 1 || nz > DRA_MAX_Z || batch < 1 || batch > 32 || !x || !wt || !bias || !y || !pf_w || pf_nz < 1 || pf_nz > DRA_MAX_Z)
+    return DRA_EINVAL;
+  ConvV2Args a;
+  for (int z = 0; z < nz; ++z) {
+    if (!x[z] || !wt[z] || !bias[z] || !y[z]) return DRA_EINVAL;
+    a.x[z] = x[z]; a.wt[z] = wt[z]; a.bias[z] = bias[z]; a.y[z] = y[z];
+  }
+  for (int z = 0; z < pf_nz; ++z) {
+    if (!pf_w[z]) return DRA_EINVAL;
+    a.pf_w[z] = pf_w[z];
+  }
+  a.pf_nz = pf_nz;
+  a.batch = batch; a.act = act; a.coef = 1.0; a.ring_slot = nullptr; a.ring_cap = 0; a.stack_age = nullptr;
+  a.slot_seq = nullptr; a.slot_entries = 0; a.slot_stride = 0; a.newest_frame = nullptr;
+  return launch_conv_v2<VG3, false, 2>(a, nz, dra_stream(stream));
 }
 
 // conv1 of the UPDATE straight from the replay ring (library-internal, actor_env.h): net z of sample b convolves the 4 ring

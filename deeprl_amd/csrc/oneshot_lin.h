@@ -346,12 +346,22 @@ struct LinWgradOne {
       }
     }
     DRA_STAMP(TR_FC_B, 3);
-    // bias gradient: the sequential sum over the batch rows, by the first input group's wave 0
-    if (db && gi == 0 && wave == 0 && h == 0 && o0 + li < O) {
+    // bias gradient: the sequential sum over the batch rows, by the first input group's wave 0 -- from the rows the wave already
+    // holds (half h has rows 2j + h: the other half's value comes through a cross-half shuffle; a loop of 32 dependent loads
+    // here was a 14 us critical path of its own)
+    if (db && gi == 0 && wave == 0) {
       float sb = 0.f;
-      for (int b = 0; b < B; ++b) sb += dy[(int64_t)b * O + o0 + li];
-      db[o0 + li] = sb;
-      sq += sb * sb;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float other = __shfl_xor(areg[j], 32, 64);          // (rows >= B are zero in both halves)
+        const float even = h ? other : areg[j], odd = h ? areg[j] : other;
+        sb += even;
+        sb += odd;
+      }
+      if (h == 0 && o0 + li < O) {
+        db[o0 + li] = sb;
+        sq += sb * sb;
+      }
     }
     if (partials) {   // (uniform) fixed-order workgroup sum: lanes by butterfly, waves (w0 + w1) + (w2 + w3)
       const double d = wave_sum((double)sq);

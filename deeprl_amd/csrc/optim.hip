@@ -359,7 +359,6 @@ struct LatePlan {
   const float4* slabs;
   int64_t stride4;
   int32_t n_slabs, fold_blocks, n_prior;   // n_prior: partials already written by earlier launches ([0, n_prior))
-  int32_t chunks;        // 256 * kLateNV float4 runs per plain workgroup (1 or 2): see late_step_kernel
 };
 constexpr int kLateMaxFoldBlocks = 256;    // one polling thread per fold workgroup
 constexpr int kLateNV = 3;                 // float4 per thread of a plain workgroup: with the fold workgroups the grid stays
@@ -471,7 +470,7 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
     const double d = wave_sum((double)acc);
     if (tid == 0) __hip_atomic_store(partials + lp.n_prior + bid, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    const int64_t i0 = lp.fold_count4 + ((int64_t)(bid - lp.fold_blocks) * lp.chunks) * (256 * kStepNV) + tid;
+    const int64_t i0 = lp.fold_count4 + (int64_t)(bid - lp.fold_blocks) * (256 * kStepNV) + tid;
 #pragma unroll
     for (int v = 0; v < kStepNV; ++v) {
       const int64_t i = i0 + 256 * v;
@@ -494,24 +493,9 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
   const float coef = late_clip_coef(pre, partials, lp.n_prior, lp.fold_blocks, hp.max_norm, out_norm, timeout_flag);
   [[maybe_unused]] const float oma = 1.f - hp.a, omb2 = 1.f - hp.b2;
   [[maybe_unused]] const float step_size = s_hyper[0], inv_sqrt_bc2 = s_hyper[1];
-  // Second run of a plain workgroup (lp.chunks == 2): its loads are issued NOW, behind the wait for the clip coefficient, so
-  // that they travel while the first run is stepped and stored.  With one run per workgroup every workgroup of the launch
-  // loaded (27 MB), waited, and stored (27 MB) in lockstep -- reads and writes never overlapped (phase stamps: 4.2 us until the
-  // loads land, 6.2 us of wait + step + stores, profiles/r04a_phase_async.json).
-  int64_t gi2[kStepNV];
-  float4 G2[kStepNV], P2[kStepNV], S2[kStepNV], A2[kStepNV];
-  const bool second = lp.chunks == 2 && bid >= lp.fold_blocks;
-  if (second) {
-    const int64_t j0 = lp.fold_count4 + ((int64_t)(bid - lp.fold_blocks) * 2 + 1) * (256 * kStepNV) + tid;
-#pragma unroll
-    for (int v = 0; v < kStepNV; ++v) {
-      const int64_t i = j0 + 256 * v;
-      const int64_t ic = i < lp.n4 ? i : lp.n4 - 1;
-      P2[v] = p4[ic]; G2[v] = g4[ic]; S2[v] = s14[ic]; A2[v] = s24[ic];
-      gi2[v] = i < lp.n4 ? i : -1;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  // (Round 4 measured a SECOND run per plain workgroup whose loads were issued here, behind the wait for the coefficient, to
+  // overlap reads with the first run's stores: 16.4 -> 17.6 us.  The loads of the single run already travel under the wait for
+  // conv1's fold, which is what bounds the first half of this launch; profiles/r04d_ab_env.jsonl.)
   auto step_run = [&](float4* Pv, const float4* Gv, float4* Sv, float4* Av, const int64_t* giv) {
 #pragma unroll
     for (int v = 0; v < kStepNV; ++v) {
@@ -536,7 +520,6 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
     }
   };
   step_run(P, G, S, A, gi);
-  if (second) step_run(P2, G2, S2, A2, gi2);
   // tail (n not a multiple of 4): the last few floats, by the first threads of the last workgroup
   const int64_t tl = (lp.n4 << 2) + tid;
   if (bid == (int)gridDim.x - 1 && tl < lp.n) {
@@ -594,11 +577,7 @@ DRA_API int dra_clip_step_late(float* param, float* grad, float* state1, float* 
   lp.stride4 = seg->slab_stride >> 2; lp.n_slabs = seg->n_slabs; lp.n_prior = n_prior;
   lp.fold_blocks = fold_blocks;
   if (lp.n_prior + lp.fold_blocks > dra_norm_partials_max()) return DRA_EINVAL;
-  static int chunks = -1;      // DRA_LATE_CHUNKS (A/B switch of the round): runs per plain workgroup
-  if (chunks < 0) { const char* e = getenv("DRA_LATE_CHUNKS"); chunks = (e && atoi(e) == 1) ? 1 : 2; }
-  lp.chunks = chunks;
-  const int64_t per = (int64_t)256 * kLateNV * lp.chunks;
-  const int64_t plain = (lp.n4 - lp.fold_count4 + per - 1) / per;
+  const int64_t plain = (lp.n4 - lp.fold_count4 + 256 * kLateNV - 1) / (256 * kLateNV);
   const int64_t blocks = lp.fold_blocks + plain;
   if (blocks > 0x7fffffff) return DRA_EINVAL;
   StepHyper hp;
