@@ -56,7 +56,7 @@ using WG3l = ConvWgradLin<G3, 3>;
 // weight gradient as ConvWgradLin with one slab per sample instead of the unit-accumulating ConvWgradAcc)
 static int bwd_lin() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_BWD_LIN"); v = e ? atoi(e) : 3; }
+  if (v < 0) { const char* e = getenv("DRA_BWD_LIN"); v = e ? atoi(e) : 7; }
   return v;
 }
 // DRA_VAR_WGRAD_ACC: four (sample, chunk) units per workgroup, one slab per unit group (8 / 8 / 40 slabs at batch 32):

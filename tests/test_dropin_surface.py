@@ -227,3 +227,31 @@ def test_real_env_construction_reseeds_like_the_reference_thunk(monkeypatch):
     while hasattr(e, "env"):
         e = e.env
     assert e.seeded == 11 + 2
+
+
+def test_block_hashed_emulator_equals_the_per_step_definition():
+    """SyntheticAtari hashes its frames and (reward, done) pairs 256 counters at a time (so that a host-environment run measures
+    the pipeline and not numpy's per-call overhead); every observation, reward and `done` must equal the per-step definition
+    (synthetic_frame / synthetic_reward_done: the bytes the device environment writes), across block boundaries and the
+    resets DummyVecEnv performs."""
+    import numpy as np
+    from deeprl_amd.envs import DummyVecEnv, SyntheticAtari, synthetic_frame, synthetic_reward_done
+    seed, period = 5, 37
+    env = DummyVecEnv([SyntheticAtari(seed=seed, done_period=period)])
+    obs = env.reset()
+    counter, stack = 1, [0, 0, 0, 0]                 # frame counters of the observation's four frames
+    n_done = 0
+    for t in range(3 * SyntheticAtari.BLOCK + 11):
+        o = np.asarray(obs[0])
+        for j in range(4):
+            assert np.array_equal(o[j].reshape(-1), synthetic_frame(stack[j], seed)), (t, j)
+        obs, rew, done, info = env.step([t % 4])
+        want_r, want_d = synthetic_reward_done(counter, seed, period)
+        assert rew[0] == want_r and bool(done[0]) == want_d, t
+        stack = stack[1:] + [counter]
+        counter += 1
+        if want_d:                                   # auto-reset (envs.py:136-137): a fresh stack of the next frame
+            stack = [counter] * 4
+            counter += 1
+            n_done += 1
+    assert n_done >= 5

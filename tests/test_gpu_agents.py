@@ -900,8 +900,9 @@ def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch
         assert np.array_equal(a["params"][k], b["params"][k]), k
 
 
-@pytest.mark.parametrize("kind,cap", [("dqn", 160), ("dqn", 4000), ("c51", 160), ("c51", 4000)])
-def test_async_per_pipeline_matches_schedule_oracle(dra, monkeypatch, kind, cap):
+@pytest.mark.parametrize("kind,cap,mode", [("dqn", 160, "async"), ("dqn", 4000, "async"), ("c51", 160, "async"),
+                                           ("c51", 4000, "async"), ("dqn", 160, "inorder"), ("c51", 4000, "inorder")])
+def test_per_pipeline_matches_schedule_oracle(dra, monkeypatch, kind, cap, mode):
     """PrioritizedReplay INSIDE the async two-stream pipeline against an oracle of its schedule (verdict r3 #2/#3: until
     round 4 this combination was pinned to the in-order path with epsilon = 1 only -- stale actor parameters x q-dependent
     actions x the device-side draw one launch late were pinned to nothing).  `agent.step()` of DQNAgent / CategoricalDQNAgent
@@ -915,7 +916,12 @@ def test_async_per_pipeline_matches_schedule_oracle(dra, monkeypatch, kind, cap)
       * the priority tree after the update's commits and the next agent step's adds is compared BIT FOR BIT, every step;
       * parameters at rtol 1e-5 / atol 2e-6 (Adam: 5e-6); every stored action (a mismatch only at an fp32 near-tie).
     At the end: the whole ring (frames, actions, rewards, masks), max_priority and python's generator position.  160 slots:
-    the ring wraps 1.5 times and most minibatches touch the slots the concurrently running actor launch overwrites."""
+    the ring wraps 1.5 times and most minibatches touch the slots the concurrently running actor launch overwrites.
+    mode "inorder": config.async_actor = False -- the actor acts on the CURRENT parameters, the draw is the host-side one
+    (tree descent on the tree stream, validity / padding on the host: PipelinedDqn.step's in-order branch), importance weights
+    inside the in-order update, device-side write-back; same oracle driven in order, same per-update checks.  This is the
+    GPU-side pin of DQN + PrioritizedReplay in order: an unsynchronised run against the reference's own run is not strict
+    for it (tests/test_gpu_pixel_agents.py, GPU_CASES)."""
     import copy
     d = dra
     import deeprl_amd.agents as agents_mod
@@ -945,12 +951,14 @@ def test_async_per_pipeline_matches_schedule_oracle(dra, monkeypatch, kind, cap)
     cfg.replay_fn = lambda: d.ReplayWrapper(cfg.replay_cls, kw, cfg.async_replay)
     cfg.state_normalizer, cfg.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
     cfg.target_network_update_freq, cfg.exploration_steps, cfg.sgd_update_frequency = tfreq, explore, freq
-    cfg.gradient_clip, cfg.double_q, cfg.async_actor, cfg.max_steps = 5, False, True, 1e5
+    inorder = mode == "inorder"
+    cfg.gradient_clip, cfg.double_q, cfg.async_actor, cfg.max_steps = 5, False, not inorder, 1e5
     py_state = random.getstate()
     d.random_seed(3)
     random.seed(3)
     agent = cls(cfg)
-    assert agent._pipe is not None and agent._pipe.async_actor and agent._pipe.per and agent._pipe.chain == 2
+    assert agent._pipe is not None and agent._pipe.async_actor != inorder and agent._pipe.per
+    assert inorder or agent._pipe.chain == 2
     agent._pipe.rs = np.random.RandomState(77)
     p_np = fake_envs.numpy_params(fake_envs.NATURE_SHAPES + head, 17)
     agent.network.load_state_dict({k: torch.from_numpy(v) for k, v in p_np.items()})
@@ -959,6 +967,16 @@ def test_async_per_pipeline_matches_schedule_oracle(dra, monkeypatch, kind, cap)
     L, rp = agent._learner, agent.replay.replay
     w = d.ops._wrap_device_pointer
     rec = []
+    host_draws = []
+    if inorder:
+        draw_end = rp.draw_end
+
+        def recording_draw_end(pending):
+            out = draw_end(pending)
+            host_draws.append((np.asarray(out[0]).copy(), np.asarray(out[1], dtype=np.float64).copy()))
+            return out
+
+        rp.draw_end = recording_draw_end
 
     def slots_actions(first_transition):
         _, actions, _, _ = rp._ring.pointers()
@@ -970,16 +988,23 @@ def test_async_per_pipeline_matches_schedule_oracle(dra, monkeypatch, kind, cap)
         agent.step()
         L.synchronize()
         torch.cuda.synchronize()
-        if t == 0:
-            gpu_actions[0] = slots_actions(0)
-        gpu_actions[t + 1] = slots_actions(freq * (t + 1))          # the actor launch this call issued (one step ahead)
+        if inorder:
+            gpu_actions[t] = slots_actions(freq * t)
+        else:
+            if t == 0:
+                gpu_actions[0] = slots_actions(0)
+            gpu_actions[t + 1] = slots_actions(freq * (t + 1))      # the actor launch this call issued (one step ahead)
         r = dict(updated=agent.total_steps > explore)
         if r["updated"]:
-            dd = agent._pipe._dd
             r.update(vec=L.delta.cpu().numpy().copy(), prio=L.prio.cpu().numpy().copy(), state=L.export_state(),
-                     tree=rp.tree.as_tensor().cpu().numpy().copy(), tree_idx=np.asarray(dd.next_tree_idx).copy(),
-                     prob=np.asarray(dd.next_p, dtype=np.float64) / dd.next_total)
+                     tree=rp.tree.as_tensor().cpu().numpy().copy())
+            if inorder:
+                r.update(tree_idx=host_draws[-1][0], prob=host_draws[-1][1])
+            else:
+                dd = agent._pipe._dd
+                r.update(tree_idx=np.asarray(dd.next_tree_idx).copy(), prob=np.asarray(dd.next_p, dtype=np.float64) / dd.next_total)
         rec.append(r)
+    assert len(host_draws) == (steps - explore // freq if inorder else 0)
     agent.sync_host()
     L.synchronize()
     torch.cuda.synchronize()
@@ -1014,18 +1039,22 @@ def test_async_per_pipeline_matches_schedule_oracle(dra, monkeypatch, kind, cap)
                 assert (not rnd) and gap < 1e-5, "actor(%d) env step %d: action %d vs %d, top-2 gap %g" % (k, e, act, got, gap)
                 near_ties += 1
 
-    check_actions(orc.actor_step(orc._snapshot(), override_actions=gpu_actions[0]), 0)
+    if not inorder:
+        check_actions(orc.actor_step(orc._snapshot(), override_actions=gpu_actions[0]), 0)
     atol_p = 2e-6 if kind == "dqn" else 5e-6
     for t in range(steps):
         r = rec[t]
+        if inorder:                                                   # DQN_agent.py:84-127 as written: act, feed, sample, learn
+            check_actions(orc.actor_step(orc._snapshot(), override_actions=gpu_actions[t]), t)
         upd = orc.report()
         assert upd == r["updated"]
         if upd:
             tree_idx, prob, data_idx, batch = orc.draw()
             assert np.array_equal(tree_idx, r["tree_idx"]), "update %d: minibatch leaves" % t
             np.testing.assert_allclose(prob, r["prob"], rtol=1e-12, atol=0, err_msg="update %d: sampling probabilities" % t)
-        theta = orc._snapshot()                                   # what actor(t+1) acts on: one update staler than in order
-        check_actions(orc.actor_step(theta, override_actions=gpu_actions[t + 1]), t + 1)
+        if not inorder:
+            theta = orc._snapshot()                               # what actor(t+1) acts on: one update staler than in order
+            check_actions(orc.actor_step(theta, override_actions=gpu_actions[t + 1]), t + 1)
         if upd:
             loss, vec, prio, wts = orc.learn(tree_idx, prob, batch, override_priorities=r["prio"])
             ambiguous = orc.relu_margin < 5e-7
@@ -1035,7 +1064,7 @@ def test_async_per_pipeline_matches_schedule_oracle(dra, monkeypatch, kind, cap)
             gvec = r["vec"]                                     # TD errors (DQN) / KL per sample (C51): what compute_loss returns
             scale = max(1e-3, float(np.abs(vec).max())) if kind == "c51" else max(1.0, float(np.abs(vec).max()))
             perr = max(float(np.abs(r["state"]["params"][nm].numpy() - orc.p[nm].detach().numpy()).max()) for nm in orc.names)
-            _record_parity("per_schedule_oracle[%s-%d] step %d%s" % (kind, cap, t, " (ambiguous ReLU gate)" if ambiguous else ""),
+            _record_parity("per_schedule_oracle[%s-%d-%s] step %d%s" % (kind, cap, mode, t, " (ambiguous ReLU gate)" if ambiguous else ""),
                            loss_vec=_rel(gvec, vec, scale), prio=float(np.abs(r["prio"] - prio).max() / np.abs(prio).max()),
                            params_abs=perr, relu_margin=orc.relu_margin)
             msg = "step %d: relu margin %.1e, max param err %.1e" % (t, orc.relu_margin, perr)
@@ -1052,18 +1081,19 @@ def test_async_per_pipeline_matches_schedule_oracle(dra, monkeypatch, kind, cap)
             # the tree after this update's commits AND the adds of the transitions actor(t+1) just produced (the device
             # performs them inside the same update: per_chain2.h), bit for bit
             ahead = copy.deepcopy(orc.rep)
-            for fr, ac, rw, mk in orc.ahead:
+            for fr, ac, rw, mk in (orc.ahead or []):              # (in order: nothing is ahead)
                 ahead.feed_one(fr, ac, rw, mk)
             assert np.array_equal(ahead.tree.tree, r["tree"]), "step %d: priority tree differs in %d nodes" % (
                 t, int((ahead.tree.tree != r["tree"]).sum()))
         orc.maybe_sync_target()
     assert near_ties <= 1 and n_upd == steps - explore // freq
     assert strict >= n_upd // 2, "too few unambiguous steps to mean anything"
-    # ---- end state: the device ran one more actor step, the next step's adds and the next draw
-    orc.report()
-    orc.draw()
+    # ---- end state (async: the device ran one more actor step, the next step's adds and the next draw)
+    if not inorder:
+        orc.report()
+        orc.draw()
     o = orc.rep
-    assert end["total"] == freq * steps == orc.total_steps - freq
+    assert end["total"] == freq * steps == orc.total_steps - (0 if inorder else freq)
     assert end["pos"] == (freq * steps) % cap and end["size"] == min(cap, freq * steps)
     assert np.array_equal(end["act"][:o.size()], o.action[:o.size()].reshape(-1))
     assert np.array_equal(end["rew"][:o.size()], o.reward[:o.size()]) and np.array_equal(end["msk"][:o.size()], o.mask[:o.size()])
