@@ -118,8 +118,10 @@ struct dra_dqn_learner {
   bool pa_valid;
   float* ah4;                       // actor fc4 output (v2)
   // q(state) for a HOST environment (dra_dqn_learner_q_host): pinned staging + one captured graph
-  uint8_t* qs_stage;                // pinned [4 x 7056]
-  float* q_stage;                   // pinned [64]
+  uint8_t* qs_stage;                // pinned, device-mapped, coherent [4 x 7056]: the host actor's observation, read by conv1 in place
+  float* q_stage;                   // pinned, device-mapped, coherent [64 q values | sequence word]: written by head_q_kernel itself
+  unsigned* q_seq_dev;              // device: forwards completed (head_q_kernel publishes it behind the q values)
+  unsigned q_seq_host;              // host: forwards issued
   hipGraphExec_t g_q;
   bool g_q_ready;
   // actor v3: parameter blocks are read by the graph's first kernel straight from a pinned ring (no copy
@@ -181,6 +183,10 @@ struct dra_dqn_learner {
   hipEvent_t sp_ev[8];
   bool sp_used[8];
   int sp_k;
+  int64_t* ui_stage;                // pinned [8][1024]: staging of dra_dqn_learner_upload_indices
+  hipEvent_t ui_ev[8];
+  bool ui_used[8];
+  int ui_k;
   // DRA_VAR_LATE_FOLD: no gradient-norm launch (optim.hip late_step_kernel): sums of squares from the producing kernels,
   // conv3 / conv2 folds riding in the next backward launch, conv1's fold in front of the optimizer launch
   // host-environment async actor (dra_dqn_learner_update_async / _q_host_async): update t mirrors its parameters into copy
@@ -425,6 +431,8 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   }
   rc |= (int)hipHostMalloc(&l->sp_stage, (size_t)8 * 1025 * sizeof(float), hipHostMallocDefault);
   for (int k = 0; k < 8; ++k) rc |= (int)hipEventCreateWithFlags(&l->sp_ev[k], hipEventDisableTiming);
+  rc |= (int)hipHostMalloc(&l->ui_stage, (size_t)8 * 1024 * sizeof(int64_t), hipHostMallocDefault);
+  for (int k = 0; k < 8; ++k) rc |= (int)hipEventCreateWithFlags(&l->ui_ev[k], hipEventDisableTiming);
   rc |= (int)hipHostMalloc(&l->timeout_flag, sizeof(int), hipHostMallocDefault);
   if (!rc) *l->timeout_flag = 0;
   rc |= (int)hipMalloc(&l->prm_dev, sizeof(dra_dqn_step_params));
@@ -434,8 +442,15 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
     rc |= (int)hipHostMalloc(&l->idx_pin[k], (size_t)1024 * sizeof(int64_t), hipHostMallocDefault);
     rc |= (int)hipEventCreateWithFlags(&l->ev_upd[k], hipEventDisableTiming);
   }
-  rc |= (int)hipHostMalloc(&l->qs_stage, (size_t)4 * 7056, hipHostMallocDefault);
-  rc |= (int)hipHostMalloc(&l->q_stage, 64 * sizeof(float), hipHostMallocDefault);
+  // (coherent = fine-grained: the device reads the observation over the fabric uncached, the host sees the kernel's stores
+  // while the stream is still busy)
+  rc |= (int)hipHostMalloc(&l->qs_stage, (size_t)4 * 7056, hipHostMallocMapped | hipHostMallocCoherent);
+  rc |= (int)hipHostMalloc(&l->q_stage, 80 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent);
+  rc |= (int)hipMalloc(&l->q_seq_dev, sizeof(unsigned));
+  if (!rc) {
+    memset(l->q_stage, 0, 80 * sizeof(float));
+    rc |= (int)hipMemset(l->q_seq_dev, 0, sizeof(unsigned));
+  }
   if (rc) { delete l; return rc; }
   // slab gaps (alignment padding between tensors) are never written: keep them zero
   rc |= (int)hipMemset(l->slabs, 0, (size_t)cfg->ksplit * l->slab_stride * sizeof(float));
@@ -526,9 +541,12 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (l->rd_seq_dev) (void)hipFree(l->rd_seq_dev);
   if (l->sp_stage) (void)hipHostFree(l->sp_stage);
   for (int k = 0; k < 8; ++k) if (l->sp_ev[k]) (void)hipEventDestroy(l->sp_ev[k]);
+  if (l->ui_stage) (void)hipHostFree(l->ui_stage);
+  for (int k = 0; k < 8; ++k) if (l->ui_ev[k]) (void)hipEventDestroy(l->ui_ev[k]);
   if (l->timeout_flag) (void)hipHostFree(l->timeout_flag);
   if (l->qs_stage) (void)hipHostFree(l->qs_stage);
   if (l->q_stage) (void)hipHostFree(l->q_stage);
+  if (l->q_seq_dev) (void)hipFree(l->q_seq_dev);
   if (l->g_q_ready) (void)hipGraphExecDestroy(l->g_q);
   for (int k = 0; k < 2; ++k) {
     if (l->g_qa_ready[k]) (void)hipGraphExecDestroy(l->g_qa[k]);
@@ -2014,10 +2032,14 @@ static int stage_actor_params(dra_dqn_learner* l, const dra_dqn_step_params* prm
   return DRA_OK;
 }
 
-// q[a] of the head at batch 1 (one wave per action for VanillaNet; dist_head_q for the distributional heads)
+// q[a] of the head at batch 1 (one wave per action for VanillaNet; dist_head_q for the distributional heads).
+// mail != null (an environment on the HOST: dra_dqn_learner_q_host / _q_host_async): the q values are ALSO stored into the
+// host-mapped block mail[0..A) and then, behind a system-scope release, the number of forwards completed so far into mail[64]
+// -- the host polls that word instead of waiting for a device-to-host copy and an event (two engine hand-overs, ~15 us).
 __global__ void __launch_bounds__(1024)
 head_q_kernel(const float* __restrict__ h4, const float* __restrict__ wh, const float* __restrict__ bh, int A,
-              float* __restrict__ q_out, const HeadSpec hs, unsigned* __restrict__ flags_reset, int n_flags) {
+              float* __restrict__ q_out, const HeadSpec hs, unsigned* __restrict__ flags_reset, int n_flags,
+              float* __restrict__ mail, unsigned* __restrict__ seq_dev) {
   __shared__ float s_out[kMaxHeadOut];
   __shared__ float s_q[64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2026,16 +2048,59 @@ head_q_kernel(const float* __restrict__ h4, const float* __restrict__ wh, const 
     for (int i = threadIdx.x; i < n_flags; i += blockDim.x) __hip_atomic_store(flags_reset + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (hs.kind != DRA_HEAD_VANILLA) {
     dist_head_q(h4, wh, bh, A, hs, s_out, s_q);
-    if (threadIdx.x < A) q_out[threadIdx.x] = s_q[threadIdx.x];
-    return;
-  }
-  for (int a = wave; a < A; a += (int)(blockDim.x >> 6)) {
-    float part = 0.f;
+  } else {
+    for (int a = wave; a < A; a += (int)(blockDim.x >> 6)) {
+      float part = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) part += h4[lane + 64 * i] * wh[a * 512 + lane + 64 * i];
-    part = wave_sum(part);
-    if (lane == 0) q_out[a] = part + bh[a];
+      for (int i = 0; i < 8; ++i) part += h4[lane + 64 * i] * wh[a * 512 + lane + 64 * i];
+      part = wave_sum(part);
+      if (lane == 0) s_q[a] = part + bh[a];
+    }
+    __syncthreads();
   }
+  if (threadIdx.x < A) {            // (A <= 64: wave 0)
+    const float q = s_q[threadIdx.x];
+    q_out[threadIdx.x] = q;
+    if (mail) __hip_atomic_store(mail + threadIdx.x, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (mail && wave == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: the q stores of this wave have left
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const unsigned n = *seq_dev + 1u;
+      *seq_dev = n;
+      __hip_atomic_store(reinterpret_cast<unsigned*>(mail) + 64, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// DRA_QHOST_MAIL=0: the earlier form (H2D copy, graph, D2H copy, event poll) -- A/B switch of the round
+static bool q_host_mail() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("DRA_QHOST_MAIL"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+
+// Host side of the mailbox: wait for forward number `want` (spin on the mapped word: the host IS the critical path of a
+// host-environment actor, four dependent round trips per agent step), then copy the q values out.
+static int q_mail_wait(dra_dqn_learner* l, unsigned want, float* q_host) {
+  volatile unsigned* word = reinterpret_cast<volatile unsigned*>(l->q_stage) + 64;
+  struct timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (uint64_t spin = 1;; ++spin) {
+    if (*word == want) break;
+    if ((spin & 0xffff) == 0) {
+      struct timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 10.0) return DRA_ETIMEDOUT;
+      const hipError_t e = hipGetLastError();           // a failed launch would never publish
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  const volatile float* q = l->q_stage;
+  for (int a = 0; a < l->c.n_actions; ++a) q_host[a] = q[a];
+  return DRA_OK;
 }
 
 // DQNActor._transition's forward (DQN_agent.py:29-33) for an environment that lives on the HOST: the caller's
@@ -2046,8 +2111,9 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
   if (!l || !state_host || !q_host) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
   const dra_dqn_config& c = l->c;
+  const bool mail = q_host_mail();
   memcpy(l->qs_stage, state_host, (size_t)4 * 7056);
-  DRA_HIP(hipMemcpyAsync(l->act_state, l->qs_stage, (size_t)4 * 7056, hipMemcpyHostToDevice, st));
+  if (!mail) DRA_HIP(hipMemcpyAsync(l->act_state, l->qs_stage, (size_t)4 * 7056, hipMemcpyHostToDevice, st));
   if (!l->g_q_ready) {
     const int64_t* o = c.offset;
     const float* P = l->p;
@@ -2056,7 +2122,8 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
     DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int rc = DRA_OK;
     {
-      const void* x1[1] = {l->act_state}; const float* w1[1] = {P + o[P_W1]}; const float* b1[1] = {P + o[P_B1]};
+      const void* x1[1] = {mail ? (const void*)l->qs_stage : (const void*)l->act_state};
+      const float* w1[1] = {P + o[P_W1]}; const float* b1[1] = {P + o[P_B1]};
       float* y1[1] = {l->ay1};
       rc = dra_conv_fwd_koc(1, 1, x1, w1, b1, y1, 1, 1, c.u8_coef, DRA_ACT_RELU, s);
       const void* x2[1] = {l->ay1}; const float* w2[1] = {P + o[P_W2]}; const float* b2[1] = {P + o[P_B2]};
@@ -2069,7 +2136,8 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
         hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
                            l->ah4, 3136);
         hipLaunchKernelGGL(head_q_kernel, dim3(1), dim3(c.head_kind != DRA_HEAD_VANILLA ? 1024 : 256), 0, st, (const float*)l->ah4,
-                           P + o[P_WH], P + o[P_BH], c.n_actions, l->aq, head_spec(l), (unsigned*)nullptr, 0);
+                           P + o[P_WH], P + o[P_BH], c.n_actions, l->aq, head_spec(l), (unsigned*)nullptr, 0,
+                           mail ? l->q_stage : (float*)nullptr, l->q_seq_dev);
       }
     }
     hipError_t e = hipStreamEndCapture(st, &graph);
@@ -2080,6 +2148,7 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
     l->g_q_ready = true;
   }
   DRA_HIP(hipGraphLaunch(l->g_q, st));
+  if (mail) return q_mail_wait(l, ++l->q_seq_host, q_host);
   DRA_HIP(hipMemcpyAsync(l->q_stage, l->aq, (size_t)c.n_actions * sizeof(float), hipMemcpyDeviceToHost, st));
   DRA_HIP(hipStreamSynchronize(st));
   memcpy(q_host, l->q_stage, (size_t)c.n_actions * sizeof(float));
@@ -2133,8 +2202,9 @@ DRA_API int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* stat
       DRA_HIP(hipStreamWaitEvent(st, l->ev_hq[0], 0));
     }
   }
+  const bool mail = q_host_mail();
   memcpy(l->qs_stage, state_host, (size_t)4 * 7056);
-  DRA_HIP(hipMemcpyAsync(l->act_state, l->qs_stage, (size_t)4 * 7056, hipMemcpyHostToDevice, st));
+  if (!mail) DRA_HIP(hipMemcpyAsync(l->act_state, l->qs_stage, (size_t)4 * 7056, hipMemcpyHostToDevice, st));
   if (!l->g_qa_ready[k]) {
     const int64_t* o = c.offset;
     const float* P = l->pa[k];
@@ -2143,7 +2213,8 @@ DRA_API int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* stat
     DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int rc = DRA_OK;
     {
-      const void* x1[1] = {l->act_state}; const float* w1[1] = {P + o[P_W1]}; const float* b1[1] = {P + o[P_B1]};
+      const void* x1[1] = {mail ? (const void*)l->qs_stage : (const void*)l->act_state};
+      const float* w1[1] = {P + o[P_W1]}; const float* b1[1] = {P + o[P_B1]};
       float* y1[1] = {l->ay1};
       rc = dra_conv_fwd_koc(1, 1, x1, w1, b1, y1, 1, 1, c.u8_coef, DRA_ACT_RELU, s);
       // conv2 with its reduction split over two workgroups per tile, conv3 + fc4 as one launch (the device actor's kernels)
@@ -2152,7 +2223,8 @@ DRA_API int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* stat
                                     l->aflags + 4 * (kMaxEnvSteps - 1), l->timeout_flag, s);
       if (!rc) {
         hipLaunchKernelGGL(head_q_kernel, dim3(1), dim3(c.head_kind != DRA_HEAD_VANILLA ? 1024 : 256), 0, st, (const float*)l->ah4,
-                           P + o[P_WH], P + o[P_BH], c.n_actions, l->aq, head_spec(l), l->aflags + 4 * (kMaxEnvSteps - 1), 4);
+                           P + o[P_WH], P + o[P_BH], c.n_actions, l->aq, head_spec(l), l->aflags + 4 * (kMaxEnvSteps - 1), 4,
+                           mail ? l->q_stage : (float*)nullptr, l->q_seq_dev);
       }
     }
     hipError_t e = hipStreamEndCapture(st, &graph);
@@ -2163,6 +2235,7 @@ DRA_API int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* stat
     l->g_qa_ready[k] = true;
   }
   DRA_HIP(hipGraphLaunch(l->g_qa[k], st));
+  if (mail) return q_mail_wait(l, ++l->q_seq_host, q_host);
   DRA_HIP(hipMemcpyAsync(l->q_stage, l->aq, (size_t)c.n_actions * sizeof(float), hipMemcpyDeviceToHost, st));
   // the host IS the critical path here (4 dependent round trips per agent step): poll the completion instead of a blocking
   // synchronise (no wake-up latency); the wait is ~40 us
@@ -3076,6 +3149,22 @@ DRA_API int dra_dqn_learner_upload_sampling_prob(dra_dqn_learner* l, const doubl
   DRA_HIP(hipMemcpyAsync(l->samp_prob, dst, (size_t)(n + 1) * sizeof(float), hipMemcpyHostToDevice, dra_stream(stream)));
   DRA_HIP(hipEventRecord(l->sp_ev[k], dra_stream(stream)));
   l->sp_used[k] = true;
+  return DRA_OK;
+}
+
+// Minibatch indices (host int64[batch]) -> the learner's idx buffer on `stream`, through the learner's own pinned staging
+// (eight rotating slots).  What tensor(idx) + copy_ did from python, without torch's stream / device context managers and
+// per-call Event objects on the host's critical path (~30 us per agent step of a host-environment run).
+DRA_API int dra_dqn_learner_upload_indices(dra_dqn_learner* l, const int64_t* idx_host, int n, void* stream) {
+  if (!l || !idx_host || n != l->c.batch) return DRA_EINVAL;
+  const int k = l->ui_k;
+  l->ui_k = (k + 1) % 8;
+  if (l->ui_used[k]) DRA_HIP(hipEventSynchronize(l->ui_ev[k]));
+  int64_t* dst = l->ui_stage + (size_t)k * 1024;
+  memcpy(dst, idx_host, (size_t)n * sizeof(int64_t));
+  DRA_HIP(hipMemcpyAsync(l->idx, dst, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, dra_stream(stream)));
+  DRA_HIP(hipEventRecord(l->ui_ev[k], dra_stream(stream)));
+  l->ui_used[k] = true;
   return DRA_OK;
 }
 

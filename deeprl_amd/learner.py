@@ -144,8 +144,6 @@ class DQNLearner:
             self.actor_stream = torch.cuda.Stream()
         self.params = StepParams()
         self._idx_view = np.ctypeslib.as_array(self.params.idx)[:batch]
-        self._idx_pinned = [torch.empty(batch, dtype=torch.int64).pin_memory() for _ in range(8)]
-        self._idx_events = [None] * 8
         self._k = 0
 
     def _partitioned_streams(self):
@@ -204,17 +202,9 @@ class DQNLearner:
         return self.delta.pow(2).mul(0.5).mean()
 
     def upload_indices(self, idx):
-        """numpy int64[batch] -> the learner's device idx buffer (async, pinned staging)."""
-        k = self._k
-        self._k = (k + 1) % len(self._idx_pinned)
-        if self._idx_events[k] is not None:
-            self._idx_events[k].synchronize()
-        self._idx_pinned[k].numpy()[:] = idx
-        with torch.cuda.stream(self.stream):
-            self.idx.copy_(self._idx_pinned[k], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        self._idx_events[k] = ev
+        """numpy int64[batch] -> the learner's device idx buffer (async, the learner's pinned staging)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        lib.dra_dqn_learner_upload_indices(self.h, idx.ctypes.data_as(ctypes.c_void_p), int(idx.shape[0]), self._sp())
 
     def upload_sampling_prob(self, prob, beta):
         """PER: numpy sampling probabilities [batch] + the importance exponent -> the learner's device buffer (async,

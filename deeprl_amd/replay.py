@@ -153,6 +153,14 @@ class UniformReplay(Storage):
             raise DraError("deeprl_amd replay lives in HBM: call select_device(gpu_id >= 0) first (no CPU path)")
         return dev
 
+    def _on_device(self):
+        """torch.cuda.device(ring's device) only when it is not already current (the context manager costs ~5 us, a host-environment
+        agent step feeds four times, a prioritized one enters it four more times)."""
+        dev = self._device()
+        if dev.index is None or torch.cuda.current_device() == dev.index:
+            return contextlib.nullcontext()
+        return torch.cuda.device(dev)
+
     def _lazy_ring(self, state, action):
         if self._ring is not None:
             return
@@ -191,7 +199,7 @@ class UniformReplay(Storage):
         reward = rewards[0]
         mask = masks[0]
         slot = self.pos
-        with torch.cuda.device(self._device()):
+        with self._on_device():
             if isinstance(state, torch.Tensor):
                 a_t = action if isinstance(action, torch.Tensor) else None
                 self._ring.put_device(slot, state, actions=a_t, action_val=0 if a_t is not None else int(action),
@@ -233,7 +241,7 @@ class UniformReplay(Storage):
     def gather(self, idx, want_f32=False, out=None):
         """Device gather of validated indices (numpy int64 or device tensor) -> dict of device tensors
         (`out`: a dict returned by an earlier call, refilled in place -- static buffers of a captured update)."""
-        with torch.cuda.device(self._device()):
+        with self._on_device():
             if not isinstance(idx, torch.Tensor):
                 idx = self._idx_up.upload(idx)
             return self._ring.gather(idx, self._state_shape, self._state_dtype, self._action_dtype, want_f32=want_f32,
@@ -423,14 +431,6 @@ class PrioritizedReplay(UniformReplay):
         with self._on_device():
             self.tree.set_many_from(self._write, n, self._stat, stream=stream)   # one launch for the whole agent step's adds
         self._write = (self._write + n) % self.memory_size
-
-    def _on_device(self):
-        """torch.cuda.device(ring's device) only when it is not already current (the context manager costs ~5 us, and a
-        prioritized agent step enters it four times)."""
-        dev = self._device()
-        if dev.index is None or torch.cuda.current_device() == dev.index:
-            return contextlib.nullcontext()
-        return torch.cuda.device(dev)
 
     def draw_begin(self, batch_size=None, stream=None):
         """First half of draw(): B uniforms from python `random` (replay.py:169-172) and the tree descent enqueued on

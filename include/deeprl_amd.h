@@ -404,6 +404,9 @@ int dra_dqn_learner_set_per(dra_dqn_learner* learner, int per, float beta);
 /* PER: sampling probabilities (host f64[batch], converted to f32) + importance exponent -> the learner's sampling_prob
  * buffer on `stream`, through the learner's own pinned staging (DQN_agent.py:120-127's tensor(sampling_prob)) */
 int dra_dqn_learner_upload_sampling_prob(dra_dqn_learner* learner, const double* prob_host, int n, float beta, void* stream);
+/* minibatch indices (host int64[batch], replay.py:92-103's sampled_indices) -> the learner's idx buffer on `stream`, through
+ * the learner's own pinned staging (n must equal the learner's batch) */
+int dra_dqn_learner_upload_indices(dra_dqn_learner* learner, const int64_t* idx_host, int n, void* stream);
 /* DRA_VAR_RING_DIRECT: also gather the minibatch into the learner's buffers (dra_dqn_learner_last_minibatch) -- for
  * checkers; the update itself keeps reading the ring */
 int dra_dqn_learner_keep_minibatch(dra_dqn_learner* learner, int keep);

@@ -720,7 +720,10 @@ def test_conv_bwd_fused_vs_autograd(dev, layer, batch, variant):
     kk = c * k * k
     stride = dw_s.stride(0)
     n_slabs = dw_s.shape[0]
-    if variant & 262144 and (int(os.environ.get("DRA_WGRAD_ACC_LAYERS", "4")) >> (layer - 1)) & 1:
+    acc_layers = int(os.environ.get("DRA_WGRAD_ACC_LAYERS", "4"))
+    if int(os.environ.get("DRA_BWD_LIN", "7")) & 4:
+        acc_layers &= 3                 # conv3: one slab per sample on the linear operand maps (ConvWgradLin) takes precedence
+    if variant & 262144 and (acc_layers >> (layer - 1)) & 1:
         # one slab per group of four units (unit = sample x row chunk; conv1 has 5 chunks per sample); the library applies the
         # accumulating kernel to the layers of DRA_WGRAD_ACC_LAYERS (default: conv3 only)
         assert n_slabs == (batch * (5 if layer == 1 else 1) + 3) // 4
