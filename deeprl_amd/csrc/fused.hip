@@ -5,9 +5,9 @@
 // A layer's weight gradient and input gradient are independent given the incoming gradient, so they
 // share ONE launch (multi_kernel): one dependent-launch cost instead of two or three, and the two
 // half-empty grids fill the chip together.  `variant` selects the kernels behind each role:
-//   DRA_VAR_ONESHOT_DGRAD  one-pass input gradients (ConvDgradOne / LinDgradOne) instead of the
+//   DRA_VAR_ONESHOT_DGRAD  one-pass input gradients (ConvDgradLin / LinDgradOne) instead of the
 //                          K-chunked implicit GEMM;
-//   DRA_VAR_ONESHOT_WGRAD  one-pass conv weight gradients (ConvWgradOne): one slab per (sample, row
+//   DRA_VAR_ONESHOT_WGRAD  one-pass conv weight gradients (ConvWgradOne / ConvWgradLin): one slab per (sample, row
 //                          chunk) -- dra_conv_wgrad_slabs() slabs instead of `ksplit`.
 #include "oneshot_lin.h"
 #include "actor_env.h"
@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
-static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 262144 | 524288 | 1048576;
+static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 524288 | 1048576;
 // every bit up to DRA_VAR_CU_PARTITION plus ACTOR_RING, ACTOR_FUSED_CONV1, GATHER_ON_UPDATE and RING_DIRECT measured faster
 // on MI355X in same-box A/Bs (profiles/r01b_ab_variants.jsonl, r01d_*, r01f_*, r02y_ab_*, r02zf_ab_*); ACTOR_V3 (512),
 // ACTOR_FUSED_HEAD (1024) and GATHER_IN_GRAPH (2048) measured neutral or slower and stay opt-in; IDX_PREFETCH (131072): conv1_fwd
@@ -23,8 +23,8 @@ static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 262144 | 5242
 // counter costs 24 us on this part (profiles/r02zt_*) -- and stays opt-in as a kept negative result.
 // Round 3 (same-box A/Bs, profiles/r03*_ab*.jsonl): LATE_FOLD (524288: no gradient-norm launch) and ACTOR_MEGA (1048576: conv3 + fc4
 // of the actor's env step as one launch) together +0.5 %, 14 -> 12 launches on the update + actor chains per env step pair;
-// WGRAD_ACC (262144) on conv3 only by default (DRA_WGRAD_ACC_LAYERS = 4): neutral there and 3.5 MB less slab traffic; on conv2 it
-// costs 0.9 us (-1.2 % updates/s) for 6 MB less traffic, on conv1 2 us -- both stay opt-in (DRA_WGRAD_ACC_LAYERS = 6 / 7)
+// WGRAD_ACC (262144: four samples accumulated per workgroup, a quarter of the slabs) was neutral on conv3 and slower on conv1 /
+// conv2; against round 4's linear-map roles it lost on every layer and was removed (the bit is accepted and ignored).
 
 DRA_API int dra_set_tuning(int mask) {
   if (mask < 0) return DRA_EINVAL;
@@ -43,56 +43,24 @@ DRA_API int dra_get_tuning(int* mask) {
   return DRA_OK;
 }
 
-// conv1: 4 output rows per chunk, all 8 k tiles per workgroup; conv2 / conv3: whole sample per chunk
+// conv1: 4 output rows per chunk, all 8 k tiles per workgroup (uint8 frames, also straight from the replay ring)
 using WG1u = ConvWgradOne<G1, 4, 4, 88, 0, true>;
 using WG1f = ConvWgradOne<G1, 4, 4, 88, 0, false>;
-using WG2 = ConvWgradOne<G2, 9, 4, 24, 4, false>;
-using WG3 = ConvWgradOne<G3, 7, 3, 10, 1, false>;
-using WG3b = ConvWgradOne<G3, 7, 6, 10, 1, false>;   // 6 k-tiles per workgroup: 96 instead of 192 workgroups
-// round 4 (oneshot_lin.h): the same contractions with straight-copy staging -- operands stay in LDS as they lie in memory
+// conv2 / conv3 (round 4, oneshot_lin.h): one workgroup = one sample x a group of k tiles, operands staged into LDS as they
+// lie in memory.  (The round-2 forms with transposing staging -- ConvWgradOne<G2 / G3>, ConvDgradOne -- and round 3's
+// ConvWgradAcc, which accumulated four samples per workgroup to write a quarter of the slabs, were removed in round 4: same
+// box, 8633 -> 8922 updates/s for the linear maps, and every layer slower with the accumulating form than without
+// (conv1 -4 %, conv1 + conv2 -11 %; profiles/r04e_ab_env.jsonl, r04g_ab_env.jsonl).  DRA_VAR_WGRAD_ACC is accepted and ignored.)
 using WG2l = ConvWgradLin<G2, 4>;
 using WG3l = ConvWgradLin<G3, 3>;
-// DRA_BWD_LIN (A/B switch of the round; bit 0 = input gradients of conv2 / conv3, bit 1 = conv2's weight gradient, bit 2 = conv3's
-// weight gradient as ConvWgradLin with one slab per sample instead of the unit-accumulating ConvWgradAcc)
-static int bwd_lin() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_BWD_LIN"); v = e ? atoi(e) : 7; }
-  return v;
-}
-// DRA_VAR_WGRAD_ACC: four (sample, chunk) units per workgroup, one slab per unit group (8 / 8 / 40 slabs at batch 32):
-// conv1 one k-tile per workgroup (320 workgroups x 40 MFMAs per wave), conv2 two k-tiles x one oc-tile (128 x 90),
-// conv3 two k-tiles x one oc-tile (144 x 56)
-using WA1u = ConvWgradAcc<G1, 4, 1, 1, 88, 0, true>;
-using WA1f = ConvWgradAcc<G1, 4, 1, 1, 88, 0, false>;
-using WA2 = ConvWgradAcc<G2, 9, 2, 1, 24, 4, false>;
-using WA3 = ConvWgradAcc<G3, 7, 2, 1, 10, 1, false>;
-
-// layers DRA_VAR_WGRAD_ACC applies to (bit 0 = conv1 ... bit 2 = conv3; DRA_WGRAD_ACC_LAYERS in the environment, read once)
-static int wgrad_acc_layers() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_WGRAD_ACC_LAYERS"); v = e ? (atoi(e) & 7) : 4; }
-  return v;
-}
-static bool wgrad_acc(int variant, int layer) {
-  if (layer == 3 && (bwd_lin() & 4)) return false;
-  return (variant & DRA_VAR_WGRAD_ACC) && ((wgrad_acc_layers() >> (layer - 1)) & 1);
-}
 
 DRA_API int dra_conv_wgrad_slabs(int layer, int batch, int ksplit, int variant, int* n_slabs) {
   if (!n_slabs || batch < 1 || ksplit < 1 || layer < 1 || layer > 3) return DRA_EINVAL;
   if (!(variant & DRA_VAR_ONESHOT_WGRAD)) { *n_slabs = ksplit; return DRA_OK; }
-  if (wgrad_acc(variant, layer)) {
-    switch (layer) {
-      case 1: *n_slabs = WA1u::n_slabs(batch); return DRA_OK;
-      case 2: *n_slabs = WA2::n_slabs(batch); return DRA_OK;
-      case 3: *n_slabs = WA3::n_slabs(batch); return DRA_OK;
-    }
-    return DRA_EINVAL;
-  }
   switch (layer) {
     case 1: *n_slabs = WG1u::n_slabs(batch); return DRA_OK;
-    case 2: *n_slabs = WG2::n_slabs(batch); return DRA_OK;
-    case 3: *n_slabs = WG3::n_slabs(batch); return DRA_OK;   // (WG3b: same slab count, slabs are per (sample, chunk))
+    case 2: *n_slabs = WG2l::n_slabs(batch); return DRA_OK;
+    case 3: *n_slabs = WG3l::n_slabs(batch); return DRA_OK;
   }
   return DRA_EINVAL;
 }
@@ -108,15 +76,9 @@ static W make_wgrad_one(const float* dy, const void* x, float* dw, float* db, in
 // tiles per workgroup of the one-pass input gradient: conv2 (4 stride phases x 4 tiles per sample) pairs tiles -- 256 instead of
 // 512 workgroups, one round together with the weight-gradient role (1 and 4 tiles per workgroup measured slower in round 2)
 template <class G> struct DgradTiles { static constexpr int PT = (G::S == 2) ? 2 : 1; };
-static int wg3_wide() {            // conv3 weight gradient: 6 k-tiles per workgroup (DRA_WG3_MTG=6) instead of 3
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_WG3_MTG"); v = (e && atoi(e) == 6) ? 1 : 0; }
-  return v;
-}
-
 template <class G, int PT = DgradTiles<G>::PT>
-static ConvDgradOne<G, PT> make_dgrad_one(const float* dy, const float* wt, const float* xact, float* dx, int batch, int act) {
-  ConvDgradOne<G, PT> r;
+static ConvDgradLin<G, PT> make_dgrad_one(const float* dy, const float* wt, const float* xact, float* dx, int batch, int act) {
+  ConvDgradLin<G, PT> r;
   r.dy = dy; r.wt = wt; r.xact = xact; r.dx = dx; r.B = batch; r.act = act;
   r.xcd = dra_xcd_order_enabled();
   return r;
@@ -154,11 +116,6 @@ static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, con
   if (n3 > 0 && !(od && ow)) return DRA_EINVAL;   // a riding role exists for the one-pass pair only
   if (od && ow) {
     auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
-    if (bwd_lin() & 1) {
-      ConvDgradLin<G, DgradTiles<G>::PT> rl;
-      rl.dy = dy; rl.wt = wt; rl.xact = xact; rl.dx = dx; rl.B = batch; rl.act = act; rl.xcd = dra_xcd_order_enabled();
-      return launch_multi(rl, rl.blocks(), rw, rw.blocks(), none, n3, st);
-    }
     auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
     return launch_multi(rd, rd.blocks(), rw, rw.blocks(), none, n3, st);
   }
@@ -192,14 +149,6 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
   NoRole none;
   switch (layer) {
     case 1:
-      if ((variant & DRA_VAR_ONESHOT_WGRAD) && wgrad_acc(variant, 1)) {
-        if (x_is_u8) {
-          auto rw = make_wgrad_one<WA1u>(dy, x, dw, db, slab_stride, batch, u8_coef);
-          return launch_multi(rw, rw.blocks(), none, 0, none, 0, st);
-        }
-        auto rw = make_wgrad_one<WA1f>(dy, x, dw, db, slab_stride, batch, 1.0);
-        return launch_multi(rw, rw.blocks(), none, 0, none, 0, st);
-      }
       if (variant & DRA_VAR_ONESHOT_WGRAD) {
         if (x_is_u8) {
           auto rw = make_wgrad_one<WG1u>(dy, x, dw, db, slab_stride, batch, u8_coef);
@@ -210,14 +159,9 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
       }
       return dra_conv_bwd_w_koc(1, dy, x, dw, db, slab_stride, ksplit, batch, x_is_u8, u8_coef, stream);
     case 2:
-      if (wgrad_acc(variant, 2)) return conv_bwd_fused_t<G2, WA2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
-      if (bwd_lin() & 2) return conv_bwd_fused_t<G2, WG2l>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
-      return conv_bwd_fused_t<G2, WG2>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+      return conv_bwd_fused_t<G2, WG2l>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
     case 3:
-      if (wgrad_acc(variant, 3)) return conv_bwd_fused_t<G3, WA3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
-      if (bwd_lin() & 4) return conv_bwd_fused_t<G3, WG3l>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
-      if (wg3_wide()) return conv_bwd_fused_t<G3, WG3b>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
-      return conv_bwd_fused_t<G3, WG3>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+      return conv_bwd_fused_t<G3, WG3l>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
   }
   return DRA_EINVAL;
 }
@@ -239,10 +183,7 @@ static int conv3_bwd_chain_t(const float* dy, const void* x, const float* wt, co
                              int64_t slab_stride, float* dx, int batch, int act, int variant, const PerChain2Args* chain, hipStream_t st) {
   ChainRole<PART> r;
   r.a = *chain;
-  if (wgrad_acc(variant, 3)) return conv_bwd_fused_t<G3, WA3, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
-  if (bwd_lin() & 4) return conv_bwd_fused_t<G3, WG3l, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
-  if (wg3_wide()) return conv_bwd_fused_t<G3, WG3b, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
-  return conv_bwd_fused_t<G3, WG3, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
+  return conv_bwd_fused_t<G3, WG3l, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
 }
 int dra_conv3_bwd_fused_chain(const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
                               int64_t slab_stride, float* dx, int batch, int act, int variant, const PerChain2Args* chain,
@@ -260,11 +201,6 @@ int dra_conv1_wgrad_ringbatch(const float* dy, const void* frames, const int64_t
                               int64_t slab_stride, int batch, double u8_coef, int variant, void* stream) {
   if (!dy || !frames || !idx || !dw_slabs || !db_slabs || batch < 1 || !(variant & DRA_VAR_ONESHOT_WGRAD)) return DRA_EINVAL;
   NoRole none;
-  if (wgrad_acc(variant, 1)) {
-    auto ra = make_wgrad_one<WA1u>(dy, frames, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
-    ra.sample_idx = idx;
-    return launch_multi(ra, ra.blocks(), none, 0, none, 0, dra_stream(stream));
-  }
   auto rw = make_wgrad_one<WG1u>(dy, frames, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
   rw.sample_idx = idx;
   return launch_multi(rw, rw.blocks(), none, 0, none, 0, dra_stream(stream));
@@ -296,17 +232,10 @@ int dra_conv_bwd_fused_fold(int layer, const float* dy, const void* x, const flo
   hipStream_t st = dra_stream(stream);
   const FoldRole f = make_fold_role(fold, grad, fold_partials, reset_slots, n_reset);
   *n_fold_partials = f.blocks();
-  const bool acc = wgrad_acc(variant, layer);
-  if (layer == 2) {
-    if (acc) return conv_bwd_fused_t<G2, WA2, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
-    if (bwd_lin() & 2) return conv_bwd_fused_t<G2, WG2l, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
-    return conv_bwd_fused_t<G2, WG2, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
-  }
-  if (layer == 3) {
-    if (acc) return conv_bwd_fused_t<G3, WA3, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
-    if (bwd_lin() & 4) return conv_bwd_fused_t<G3, WG3l, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
-    return conv_bwd_fused_t<G3, WG3, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
-  }
+  if (layer == 2)
+    return conv_bwd_fused_t<G2, WG2l, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
+  if (layer == 3)
+    return conv_bwd_fused_t<G3, WG3l, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
   return DRA_EINVAL;
 }
 
@@ -324,21 +253,11 @@ int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, flo
     if (chain->nb > 256) return DRA_EINVAL;
     ChainRole<2> cr;
     cr.a = *chain;
-    if (wgrad_acc(variant, 1)) {
-      auto ra = make_wgrad_one<WA1u>(dy, x, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
-      ra.sample_idx = idx;
-      return launch_multi(ra, ra.blocks(), f, f.blocks(), cr, 1, dra_stream(stream));
-    }
     auto rw = make_wgrad_one<WG1u>(dy, x, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
     rw.sample_idx = idx;
     return launch_multi(rw, rw.blocks(), f, f.blocks(), cr, 1, dra_stream(stream));
   }
   NoRole none;
-  if (wgrad_acc(variant, 1)) {
-    auto ra = make_wgrad_one<WA1u>(dy, x, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
-    ra.sample_idx = idx;
-    return launch_multi(ra, ra.blocks(), f, f.blocks(), none, 0, dra_stream(stream));
-  }
   auto rw = make_wgrad_one<WG1u>(dy, x, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
   rw.sample_idx = idx;
   return launch_multi(rw, rw.blocks(), f, f.blocks(), none, 0, dra_stream(stream));
@@ -350,12 +269,8 @@ int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, flo
 // sq_partials (optional, DRA_VAR_LATE_FOLD; one-pass input gradient only): the workgroups that write dW4 / db4 and dWh / dbh
 // leave their sums of squares in sq_partials[0, *n_sq_partials): fc4's tiles first, then the head's 2 * n_actions
 // fc4's weight gradient of the learner's launch: the register-only role for minibatches up to 32 (oneshot_lin.h), else the
-// K-chunked implicit GEMM.  DRA_FC_WGRAD_ONE=0 (A/B switch of the round) keeps the implicit GEMM.
-static bool fc_wgrad_one(int batch) {
-  static int lin = -1;
-  if (lin < 0) { const char* e = getenv("DRA_FC_WGRAD_ONE"); lin = e ? atoi(e) : 1; }
-  return lin && batch <= 32;
-}
+// K-chunked implicit GEMM (same box: fc_bwd 13.1 -> 11.2 us, +1.6 % updates/s; profiles/r04e_ab_env.jsonl).
+static bool fc_wgrad_one(int batch) { return batch <= 32; }
 constexpr int kFcWgradNI = 8;    // 32-wide input tiles per workgroup of LinWgradOne
 // partials dra_fc_bwd_fused_sq writes for this problem (library-internal, actor_env.h): the learner lays the later launches'
 // partials and the optimizer's arrival slots out behind them

@@ -1140,9 +1140,9 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   const float* x4[3] = {l->y3[0], l->y3[1], l->y3[2]};
   const float* w4[3] = {P + o[P_W4], T + o[P_W4], P + o[P_W4]};
   const int ks4 = fc4_ks(l);
-  static int pf_fc4 = -1;     // DRA_PF_FC4 (A/B switch of the round): fc4's forward weights prefetched under conv3's forward
-  if (pf_fc4 < 0) { const char* e = getenv("DRA_PF_FC4"); pf_fc4 = e ? atoi(e) : 1; }
-  if (pf_fc4 && (l->variant & DRA_VAR_ONESHOT_FWD) && ks4 == kFc4SplitMid && nz == 2 && B <= 32)
+  // fc4's forward weights are prefetched into the L2 of the XCD that will stream them, by spare workgroups of conv3's forward
+  // launch (conv_v2.hip fc4_weight_prefetch; same box: fc4_fwd 10.9 -> 9.95 us, conv3_fwd +1.0 us, +0.5-0.8 % updates/s)
+  if ((l->variant & DRA_VAR_ONESHOT_FWD) && ks4 == kFc4SplitMid && nz == 2 && B <= 32)
     STEP(K_CONV3_F, dra_conv3_fwd_koc_pf(nz, x3, w3, b3, l->y3, B, DRA_ACT_RELU, w4, nz, s));
   else
   STEP(K_CONV3_F, dra_conv_fwd_koc(3, nz, x3, w3, b3, l->y3, B, 0, 1.0, DRA_ACT_RELU, s));

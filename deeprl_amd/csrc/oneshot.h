@@ -373,159 +373,6 @@ struct LinFwdSlabsOne {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Convolution input gradient with KOC weights, one pass (layers 2 and 3 of NatureConvBody).
-// Stride-phase decomposition as in ConvDgradKoc: phase (ph, pw) covers input pixels ih = ih2*S + ph,
-// iw = iw2*S + pw and only taps kh = kh2*S + ph, kw = kw2*S + pw reach them, so each phase is a dense
-// KPxKP correlation over the zero-padded output gradient:
-//   dXpre[b][c][ih][iw] = act'(X[b][c][ih][iw]) * sum_(oc,kh2,kw2) dYpad[b][oc][ih2-kh2+PAD][iw2-kw2+PAD] * Wt[(c,kh,kw)][oc]
-// Workgroup = (sample, phase, 32 positions of the phase, 32 input channels).  dY[b] goes to LDS once,
-// zero-padded ([OC][DH][RW]); MFMA lane li of the B operand is a position, so every B read is
-// `base(position) + immediate(oc, tap)`.  The A operand (weights, lane li = input channel c) is read
-// straight from the KOC tensor: slot (jj, h) of wave w <-> oc = 16w + 8h + jj, i.e. two float4 per tap.
-// PT = consecutive 32-position tiles of one (sample, phase) per workgroup: the staged gradient image and the
-// register-resident weights are shared by PT independent accumulation chains.  conv2 at batch 32 uses PT = 2:
-// 256 instead of 512 workgroups, so that together with the 128 weight-gradient workgroups of the same launch the
-// grid fits the chip's workgroup slots in ONE round (two workgroups per CU at these register counts).
-template <class G, int PT = 1>
-struct ConvDgradOne {
-  static constexpr int S = G::S, KP = (G::KH + S - 1) / S, NPH = S * S, HP = (G::H + S - 1) / S, PP = HP * HP;
-  static constexpr int PAD = KP - 1, DH = G::OH + 2 * PAD, RW = DH, CS = DH * RW;
-  static constexpr int TPP = (PP + 31) / 32, TGP = (TPP + PT - 1) / PT;   // tiles / tile groups per phase
-  static constexpr int OCW = G::OC / 4, OCH = OCW / 2, NT = KP * KP, NJ = NT * OCH;
-  static constexpr int MT = G::C / 32;
-  static constexpr int NCELL = G::OC * CS;
-  static constexpr int RED = PT * 4096;
-  static constexpr int LDS_FLOATS = NCELL > RED ? NCELL : RED;
-  static_assert(G::KH % S == 0, "every stride phase has KP x KP taps");
-  static_assert(HP + PAD == DH, "padded gradient covers every shifted read");
-  static_assert(G::OC % 32 == 0 && OCH % 4 == 0 && G::C % 32 == 0, "float4 weight runs per half-wave");
-  const float* dy;    // [B][OC][OH][OH] pre-activation gradient of this layer's output
-  const float* wt;    // [(c,kh,kw)][OC]
-  const float* xact;  // [B][C][H][H] this layer's input (post-activation) or null
-  float* dx;          // [B][C][H][H]
-  int B, act;
-  int xcd = 0;        // != 0: all workgroups of a sample on one XCD (xcd_order)
-  __host__ int blocks() const { return B * NPH * TGP * MT; }
-  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
-    const int bid = xcd ? xcd_order(bid_, first, B, NPH * TGP * MT) : bid_;
-    const int mt = bid % MT;
-    int r = bid / MT;
-    const int grp = r % TGP;
-    r /= TGP;
-    const int phi = r % NPH, bi = r / NPH;
-    const int ph = phi / S, pw = phi - ph * S;
-    const int c0 = mt * 32, p0 = grp * PT * 32;
-    const int np = min(32 * PT, PP - p0);
-    [[maybe_unused]] constexpr int TRR = (G::C == 32) ? TR_CONV2_B : TR_CONV3_B;
-    DRA_STAMP(TRR, 0);
-    // ---- weights: lane li <-> input channel c0 + li
-    float4 areg[NT][OCH / 4];
-    {
-      const float* wl = wt + (int64_t)(c0 + li) * G::KK * G::OC + wave * OCW + h * OCH;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int kh = (t / KP) * S + ph, kw = (t % KP) * S + pw;
-#pragma unroll
-        for (int v = 0; v < OCH / 4; ++v)
-          areg[t][v] = *reinterpret_cast<const float4*>(wl + (kh * G::KH + kw) * G::OC + 4 * v);
-      }
-    }
-    // ---- dY[bi] ([OC][OH][OH], contiguous, 16-byte aligned) -> registers as float4: NV loads per workgroup instead of
-    // one dword per padded LDS cell (conv2: 6 float4 per lane instead of 31 dwords, and one constant division per
-    // float4 instead of two per cell: SQ counters showed 1300 VALU instructions per wave for 72 MFMAs, profiles/r02a_*)
-    constexpr int NSRC = G::OC * G::P, NV = NSRC / 4, RV = (NV + 255) / 256;
-    static_assert(NSRC % 4 == 0 && NCELL % 4 == 0, "float4 staging");
-    float4 rawv[RV];
-    const float4* dyb4 = reinterpret_cast<const float4*>(dy + (int64_t)bi * NSRC);
-#pragma unroll
-    for (int q = 0; q < RV; ++q) rawv[q] = dyb4[min(tid + 256 * q, NV - 1)];
-    // ---- epilogue side input (activation-derivative source), loaded with everything else
-    int ih2[PT], iw2[PT], pix[PT];
-    bool inside[PT];
-    float aux[PT][4];
-#pragma unroll
-    for (int t = 0; t < PT; ++t) {
-      const int pj = min(32 * t + li, np - 1);
-      ih2[t] = (p0 + pj) / HP;
-      iw2[t] = (p0 + pj) - ih2[t] * HP;
-      const int ih = ih2[t] * S + ph, iw = iw2[t] * S + pw;
-      inside[t] = ih < G::H && iw < G::H;
-      pix[t] = min(ih, G::H - 1) * G::H + min(iw, G::H - 1);
-      const float* src = xact ? xact : dx;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = c0 + mfma_row(wave * 4 + q, h);
-        aux[t][q] = src[((int64_t)bi * G::C + c) * G::HW + pix[t]];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // zero the padded image while the loads are in flight, then drop the interior in (cell of source element (oc, oh, ow)
-    // is oc*CS + (oh+PAD)*RW + ow+PAD; a float4 may straddle two output channels)
-    for (int i = tid; i < NCELL / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < RV; ++q) {
-      const int f = tid + 256 * q;
-      float4 v4 = rawv[q];
-      asm volatile("" : "+v"(v4.x), "+v"(v4.y), "+v"(v4.z), "+v"(v4.w));  // keep the loads unconditional and batched
-      if (f < NV) {
-        const int j0 = 4 * f, oc0 = j0 / G::P, pos0 = j0 - oc0 * G::P;
-        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int p = pos0 + i, oc = oc0;
-          if (p >= G::P) { p -= G::P; ++oc; }
-          const int oh = p / G::OH, ow = p - oh * G::OH;
-          lds[oc * CS + (oh + PAD) * RW + ow + PAD] = vv[i];
-        }
-      }
-    }
-    DRA_STAMP(TRR, 1);
-    __syncthreads();
-    DRA_STAMP(TRR, 2);
-    // ---- MFMA: B operand of lane li = padded gradient at (ih2 - kh2 + PAD, iw2 - kw2 + PAD)
-    f32x16 acc[PT];
-    const float* bptr[PT];
-#pragma unroll
-    for (int t = 0; t < PT; ++t) {
-      acc[t] = zero16();
-      bptr[t] = lds + (wave * OCW + h * OCH) * CS + ih2[t] * RW + iw2[t];
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int kh2 = t / KP, kw2 = t % KP;
-#pragma unroll
-      for (int jj = 0; jj < OCH; ++jj) {
-        const float4 av = areg[t][jj / 4];
-        const float a = (jj % 4 == 0) ? av.x : ((jj % 4 == 1) ? av.y : ((jj % 4 == 2) ? av.z : av.w));
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-          const float b = bptr[pt][jj * CS + (PAD - kh2) * RW + (PAD - kw2)];
-          acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[pt], 0, 0, 0);
-        }
-      }
-    }
-    DRA_STAMP(TRR, 3);
-    __syncthreads();
-    DRA_STAMP(TRR, 4);
-#pragma unroll
-    for (int t = 0; t < PT; ++t) {
-      float s[4];
-      reduce4(lds + t * 4096, acc[t], wave, lane, s);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = c0 + mfma_row(wave * 4 + q, h);
-        if (32 * t + li < np && inside[t])
-          dx[((int64_t)bi * G::C + c) * G::HW + pix[t]] = xact ? s[q] * act_grad(aux[t][q], act) : s[q];
-      }
-    }
-    DRA_STAMP(TRR, 5);
-    DRA_STAMP_END(TRR);
-  }
-};
-
-// ------------------------------------------------------------------------------------------------
 // Convolution weight gradient in the KOC layout, one pass:
 //   dWt[k][oc] = sum_(b,p) Xcol[k][(b,p)] * dY[b][oc][p],  k = (c,kh,kw);   db[oc] = sum_(b,p) dY[b][oc][p]
 // Workgroup = (sample b, chunk of ROWS output rows, group of MTG 32-row k tiles): M = k (lane li = tap),
@@ -746,226 +593,3 @@ struct ConvWgradOne {
   }
 };
 
-// ------------------------------------------------------------------------------------------------
-// Convolution weight gradient, KOC layout, FOUR (sample, row chunk) units accumulated per workgroup (round 3).
-//
-// ConvWgradOne writes one slab per (sample, chunk): 32 / 32 / 160 slabs per layer at batch 32, 14 MB written by the
-// backward and re-read by the fold -- 21 MB of traffic for 4.2 MB of algorithmic bytes in conv2's launch
-// (profiles/r02zzz_pmc_traffic.json).  Here wave w of a workgroup owns unit 4*ug + w: it stages ITS unit's input rows and
-// output gradients into its own quarter of LDS (same layouts as ConvWgradOne: image [channel][row][RW], gradient
-// transposed [oh][ow][oc + 1]) and runs the SAME MFMA sequence over ALL tiles of the workgroup; the four waves'
-// accumulators are then added through LDS in the fixed order (u0 + u1) + (u2 + u3) and ONE slab per unit group is
-// stored: 8 / 8 / 40 slabs.  To keep the MFMA chain per wave (and the workgroup count) where it was, a workgroup owns
-// a quarter of the tiles ConvWgradOne's did: MTG k-tiles x NTG 32-wide output-channel tiles, and only those channels'
-// gradients are staged.  Workgroup = (unit group, k-tile group, oc-tile group).
-template <class G, int ROWS, int MTG, int NTG, int RW_, int CSPAD, bool U8>
-struct ConvWgradAcc {
-  static constexpr int SB = 4;                                  // units per workgroup = waves
-  static constexpr int S = G::S, OH = G::OH, OWP = (OH + 1) & ~1, NPAIR = OWP / 2, NJ = ROWS * NPAIR;
-  static constexpr int NCHUNK = OH / ROWS;
-  static constexpr int MTILES = G::K / 32, NGRP = MTILES / MTG, NTL = G::OC / 32, NNG = NTL / NTG, TILES = MTG * NTG;
-  static constexpr int NR = (ROWS - 1) * S + G::KH;
-  static constexpr int RW = RW_, CS = NR * RW + CSPAD;
-  // channels MTG*32 consecutive k (starting at a multiple of 32) can touch
-  static constexpr int NCHMAX = ((MTG * 32) % G::KK == 0) ? (MTG * 32) / G::KK
-                              : ((G::KK % (MTG * 32) == 0) ? 1 : (MTG * 32 + G::KK - 2) / G::KK + 1);
-  static constexpr int NCH = NCHMAX < G::C ? NCHMAX : G::C;
-  static constexpr int IMG = NCH * CS + RW;
-  static constexpr int OCW = 32 * NTG, LDB = OCW + 1, NPOS = ROWS * OWP, DYF = NPOS * LDB;
-  static constexpr int UNIT = (IMG + DYF + 3) & ~3;
-  static constexpr int REDF = TILES * 4096 + SB * OCW;
-  static constexpr int LDS_FLOATS = SB * UNIT > REDF ? SB * UNIT : REDF;
-  static_assert(G::K % 32 == 0 && MTILES % MTG == 0 && NTL % NTG == 0 && OH % ROWS == 0, "tiling");
-  static_assert(RW >= (OWP - 1) * S + G::KH, "LDS row holds the pad column's taps");
-  static_assert(OCW <= 64, "bias partials: one lane per staged output channel");
-  const float* dy;   // [B][OC][OH][OH]
-  const void* x;     // [B][C][H][H] f32 or u8
-  float* dw;         // slab 0 of dWt [K][OC]
-  float* db;         // slab 0 of db [OC]
-  int64_t slab_stride;
-  int B;
-  double coef;
-  const int64_t* sample_idx = nullptr;   // (U8) ring-direct minibatch, as in ConvWgradOne
-  int xcd = 0;        // != 0: all workgroups of a unit group on one XCD (xcd_order)
-  __host__ static int n_slabs(int batch) { return (batch * NCHUNK + SB - 1) / SB; }
-  __host__ int blocks() const { return n_slabs(B) * NGRP * NNG; }
-  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
-    const int bid = xcd ? xcd_order(bid_, first, (B * NCHUNK + SB - 1) / SB, NGRP * NNG) : bid_;
-    const int ng = bid % NNG;
-    int r = bid / NNG;
-    const int grp = r % NGRP, ug = r / NGRP;
-    const int n_units = B * NCHUNK;
-    const int unit = ug * SB + wave;
-    const bool valid = unit < n_units;
-    const int uc = valid ? unit : n_units - 1;              // clamped: every address below is mapped
-    const int bi = uc / NCHUNK, chunk = uc - bi * NCHUNK;
-    const int k0 = grp * MTG * 32, oc0 = ng * OCW;
-    const int c_lo = k0 / G::KK;
-    const int c_hi = min((k0 + MTG * 32 - 1) / G::KK, G::C - 1);
-    const int nch = c_hi - c_lo + 1;                        // <= NCH
-    const int ir0 = chunk * ROWS * S;
-    float* img = lds + wave * UNIT;
-    float* dyl = img + IMG;
-    [[maybe_unused]] constexpr int TRR = (G::C == 4) ? TR_CONV1_B : ((G::C == 32) ? TR_CONV2_B : TR_CONV3_B);
-    DRA_STAMP(TRR, 0);
-    // ---- this wave's loads: its unit's gradients of channels [oc0, oc0 + OCW), then its input rows
-    constexpr bool WHOLE = (ROWS == OH);
-    constexpr int RUN = ROWS * OH;
-    static_assert(WHOLE ? (OCW * G::P) % 4 == 0 : RUN % 4 == 0, "float4 dY staging");
-    constexpr int NVD = WHOLE ? (OCW * G::P) / 4 : OCW * (RUN / 4), RD = (NVD + 63) / 64;
-    float4 draw[RD];
-    const float* dyb = dy + ((int64_t)bi * G::OC + oc0) * G::P + chunk * ROWS * OH;
-#pragma unroll
-    for (int q = 0; q < RD; ++q) {
-      const int f = min(lane + 64 * q, NVD - 1);
-      if constexpr (WHOLE) {
-        draw[q] = reinterpret_cast<const float4*>(dyb)[f];
-      } else {
-        const int oc = f / (RUN / 4), v = f - oc * (RUN / 4);
-        draw[q] = *reinterpret_cast<const float4*>(dyb + oc * G::P + 4 * v);
-      }
-    }
-    constexpr int WPR = G::H / 4;                                    // (U8) u32 words per image row
-    constexpr int RUNI = NR * G::H;
-    constexpr bool V4 = !U8 && (RUNI % 4 == 0) && (G::HW % 4 == 0) && (G::H % 4 == 0);
-    constexpr int VPC = U8 ? NR * WPR : (V4 ? RUNI / 4 : RUNI);      // loads per channel
-    constexpr int NVI = NCH * VPC, RI = (NVI + 63) / 64;
-    unsigned iraw_u[U8 ? RI : 1];
-    float4 iraw4[V4 ? RI : 1];
-    float iraw1[(!U8 && !V4) ? RI : 1];
-    if constexpr (U8) {
-      const int64_t first = sample_idx ? sample_idx[bi] - (G::C - 1) : (int64_t)bi * G::C;
-      const uint8_t* xb = reinterpret_cast<const uint8_t*>(x) + (first + c_lo) * G::HW;
-#pragma unroll
-      for (int q = 0; q < RI; ++q) {
-        const int e = min(lane + 64 * q, nch * VPC - 1);
-        const int cl = e / VPC, rem = e - cl * VPC, rr = rem / WPR, wd = rem - rr * WPR;
-        iraw_u[q] = *reinterpret_cast<const unsigned*>(xb + ((int64_t)cl * G::H + ir0 + rr) * G::H + 4 * wd);
-      }
-    } else {
-      const float* xf = reinterpret_cast<const float*>(x) + ((int64_t)bi * G::C + c_lo) * G::HW + (int64_t)ir0 * G::H;
-#pragma unroll
-      for (int q = 0; q < RI; ++q) {
-        const int f = min(lane + 64 * q, nch * VPC - 1);
-        const int cl = f / VPC, v = f - cl * VPC;
-        if constexpr (V4) iraw4[q] = *reinterpret_cast<const float4*>(xf + (int64_t)cl * G::HW + 4 * v);
-        else iraw1[q] = xf[(int64_t)cl * G::HW + v];
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // zero this wave's quarter (image padding, pad columns of the transposed gradient) while the loads are in flight
-    for (int i = lane; i < UNIT / 4; i += 64) reinterpret_cast<float4*>(img)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < RI; ++q) {
-      const int e = lane + 64 * q;
-      if constexpr (U8) {
-        unsigned v = iraw_u[q];
-        asm volatile("" : "+v"(v));
-        if (e < nch * VPC) {
-          const int cl = e / VPC, rem = e - cl * VPC, rr = rem / WPR, wd = rem - rr * WPR;
-          float* d = img + cl * CS + rr * RW + 4 * wd;
-#pragma unroll
-          for (int b = 0; b < 4; ++b) d[b] = (float)((double)((v >> (8 * b)) & 0xffu) * coef);
-        }
-      } else if constexpr (V4) {
-        float4 v4 = iraw4[q];
-        asm volatile("" : "+v"(v4.x), "+v"(v4.y), "+v"(v4.z), "+v"(v4.w));
-        if (e < nch * VPC) {
-          const int cl = e / VPC, v = e - cl * VPC;
-          const int r0 = 4 * v, rr = r0 / G::H, cc = r0 - rr * G::H;   // H % 4 == 0: a float4 never leaves its image row
-          float* d = img + cl * CS + rr * RW + cc;
-          d[0] = v4.x; d[1] = v4.y; d[2] = v4.z; d[3] = v4.w;
-        }
-      } else {
-        float v1 = iraw1[q];
-        asm volatile("" : "+v"(v1));
-        if (e < nch * VPC) {
-          const int cl = e / VPC, v = e - cl * VPC;
-          const int rr = v / G::H, cc = v - rr * G::H;
-          img[cl * CS + rr * RW + cc] = v1;
-        }
-      }
-    }
-    // transposed gradient: element (ocl, ohl, ow) -> dyl[(ohl*OWP + ow)*LDB + ocl]
-#pragma unroll
-    for (int q = 0; q < RD; ++q) {
-      const int f = lane + 64 * q;
-      float4 v4 = draw[q];
-      asm volatile("" : "+v"(v4.x), "+v"(v4.y), "+v"(v4.z), "+v"(v4.w));
-      if (f < NVD) {
-        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-        int oc0l, pos0;
-        if constexpr (WHOLE) { oc0l = (4 * f) / G::P; pos0 = 4 * f - oc0l * G::P; }
-        else { oc0l = f / (RUN / 4); pos0 = 4 * (f - oc0l * (RUN / 4)); }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int p = pos0 + i, oc = oc0l;
-          if (WHOLE && p >= G::P) { p -= G::P; ++oc; }
-          const int ohl = p / OH, ow = p - ohl * OH;
-          dyl[(ohl * OWP + ow) * LDB + oc] = vv[i];
-        }
-      }
-    }
-    DRA_STAMP(TRR, 1);
-    __syncthreads();
-    DRA_STAMP(TRR, 2);
-    // ---- MFMA: every wave runs all TILES tiles on its own unit
-    f32x16 acc[TILES];
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) acc[t] = zero16();
-    if (valid) {
-#pragma unroll
-      for (int t = 0; t < TILES; ++t) {
-        const int mt = t / NTG, nt = t - mt * NTG;
-        const int k = k0 + mt * 32 + li;
-        const int c = k / G::KK, kr = k - c * G::KK, kh = kr / G::KH, kw = kr - kh * G::KH;
-        const float* ap = img + (c - c_lo) * CS + kh * RW + kw + h * S;
-        const float* bp = dyl + h * LDB + nt * 32 + li;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int ohl = j / NPAIR, jw = j - ohl * NPAIR;
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[ohl * S * RW + 2 * jw * S], bp[(ohl * OWP + 2 * jw) * LDB],
-                                                       acc[t], 0, 0, 0);
-        }
-      }
-    }
-    // bias gradient of this unit (k-group 0 only): fixed-order column sums of the staged gradient
-    float sb = 0.f;
-    if (grp == 0 && valid && lane < OCW) {
-#pragma unroll 8
-      for (int pos = 0; pos < NPOS; ++pos) sb += dyl[pos * LDB + lane];
-    }
-    DRA_STAMP(TRR, 3);
-    __syncthreads();   // every wave is done reading its operands: LDS becomes the reduction scratch
-    DRA_STAMP(TRR, 4);
-    float* red = lds;
-#pragma unroll
-    for (int t = 0; t < TILES; ++t)
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) red[t * 4096 + (wave * 16 + rr) * 64 + lane] = acc[t][rr];
-    if (grp == 0 && lane < OCW) red[TILES * 4096 + wave * OCW + lane] = sb;
-    __syncthreads();
-    float* dws = dw + (int64_t)ug * slab_stride;
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-      const int mt = t / NTG, nt = t - mt * NTG;
-      const float* rt = red + t * 4096;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int rr = wave * 4 + q;
-        const float s = (rt[(0 * 16 + rr) * 64 + lane] + rt[(1 * 16 + rr) * 64 + lane]) +
-                        (rt[(2 * 16 + rr) * 64 + lane] + rt[(3 * 16 + rr) * 64 + lane]);
-        const int k = k0 + mt * 32 + mfma_row(rr, h);
-        dws[(int64_t)k * G::OC + oc0 + nt * 32 + li] = s;
-      }
-    }
-    if (grp == 0 && tid < OCW) {
-      const float* rb = red + TILES * 4096;
-      db[(int64_t)ug * slab_stride + oc0 + tid] = (rb[tid] + rb[OCW + tid]) + (rb[2 * OCW + tid] + rb[3 * OCW + tid]);
-    }
-    DRA_STAMP(TRR, 5);
-    DRA_STAMP_END(TRR);
-  }
-};

@@ -1,20 +1,21 @@
-// Round 4: the one-pass backward roles of conv2 / conv3 with STRAIGHT-COPY staging.
+// The one-pass backward roles of conv2 / conv3: operands staged into LDS exactly as they lie in memory (round 4).
 //
-// oneshot.h's ConvDgradOne / ConvWgradOne scatter every staged element into a padded (dgrad) or transposed (wgrad) LDS image:
-// a constant division or two, a multiply-add and a ds_write_b32 per element -- 730 VALU instructions per wave around 64-90
-// MFMAs in conv2's backward launch (rocprofv3 SQ_INSTS_VALU / SQ_INSTS_MFMA = 10.1, profiles/r04a_sq_learner_b32.json), and
-// a zero fill + an extra barrier in front of it.  Here the operands stay in LDS exactly as they lie in memory -- the
-// workgroup's loads are float4, its LDS writes ds_write_b128 of the same float4, no index arithmetic at all -- and the
-// geometry moves into the per-lane BASE ADDRESS of the MFMA operand reads, computed once per workgroup:
+// The round-2 forms of these roles (ConvDgradOne, ConvWgradOne<G2 / G3>; removed) scattered every staged element into a padded
+// (input gradient) or transposed (weight gradient) LDS image: a constant division or two, a multiply-add and a ds_write_b32 per
+// element -- 730 VALU instructions per wave around 64-90 MFMAs in conv2's backward launch (rocprofv3 SQ_INSTS_VALU /
+// SQ_INSTS_MFMA = 10.1, profiles/r04a_sq_learner_b32.json), and a zero fill + an extra barrier in front of it.  Here the
+// workgroup's loads are float4, its LDS writes ds_write_b128 of the same float4, no index arithmetic at all, and the geometry
+// moves into the per-lane BASE ADDRESS of the MFMA operand reads, computed once per workgroup:
 //   * input gradient: the gradient image dY[b] is [OC][P] as in memory.  A lane (position, tap) whose shifted read falls outside
-//     the image does not read a zero PADDING cell any more; its base address points into a small block of zeros instead, so the
-//     loop body stays `ds_read_b32 v, base + immediate` with no select;
+//     the image does not read a zero PADDING cell; its base address points into a small block of zeros instead, so the loop
+//     body stays `ds_read_b32 v, base + immediate` with no select;
 //   * weight gradient: the reduction index is the output position p in memory order, two consecutive positions per MFMA
 //     (k-slices h = 0 / 1).  P is odd (81, 49), so ONE MFMA of a tile carries a pad slot instead of one per output row
 //     (41 instead of 45 MFMAs per tile for conv2, 25 instead of 28 for conv3).  dY stays [oc][P]: lane = oc reads have the odd
 //     stride P -> conflict-free; the input image stays [c][H][H]: lane = tap reads are conflict-free for conv2's 4x4 taps.
-// Same products in the same order as the padded / transposed forms (a pad slot contributes fma(a, 0, acc) = acc): results are
-// bit-identical with oneshot.h's roles, which remain for conv1 and for the unit-accumulating weight gradient.
+// Same products in the same order as the padded / transposed forms (a pad slot contributes fma(a, 0, acc) = acc): the results
+// were bit-identical with them on the device (profiles/r04d_ab_env.jsonl: same parameter sums), and tools/emulate_oneshot.py
+// replays both index maps on the CPU.  conv1 keeps oneshot.h's ConvWgradOne (uint8 frames, read straight from the replay ring).
 #pragma once
 #include "oneshot.h"
 
@@ -23,7 +24,16 @@
 typedef float lin_f4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
-// Input gradient, KOC weights, one pass (see ConvDgradOne for the stride-phase decomposition and the slot maps).
+// Convolution input gradient with KOC weights, one pass (layers 2 and 3 of NatureConvBody).
+// Stride-phase decomposition as in ConvDgradKoc: phase (ph, pw) covers input pixels ih = ih2*S + ph, iw = iw2*S + pw and only
+// taps kh = kh2*S + ph, kw = kw2*S + pw reach them, so each phase is a dense KPxKP correlation over the output gradient:
+//   dXpre[b][c][ih][iw] = act'(X[b][c][ih][iw]) * sum_(oc,kh2,kw2) dY[b][oc][ih2-kh2][iw2-kw2] * Wt[(c,kh,kw)][oc]   (0 outside)
+// Workgroup = (sample, phase, PT x 32 positions of the phase, 32 input channels).  MFMA lane li of the B operand is a
+// position: every B read is `base(position, tap) + immediate(oc)`.  The A operand (weights, lane li = input channel c) is read
+// straight from the KOC tensor: slot (jj, h) of wave w <-> oc = 16w + 8h + jj, i.e. two float4 per tap.
+// PT = consecutive 32-position tiles of one (sample, phase) per workgroup: the staged gradient image and the register-resident
+// weights are shared by PT independent accumulation chains.  conv2 at batch 32 uses PT = 2: 256 instead of 512 workgroups, so
+// that together with the weight-gradient workgroups of the same launch the grid fits the chip's workgroup slots in ONE round.
 template <class G, int PT = 1>
 struct ConvDgradLin {
   static constexpr int S = G::S, KP = (G::KH + S - 1) / S, NPH = S * S, HP = (G::H + S - 1) / S, PP = HP * HP;
@@ -111,7 +121,7 @@ struct ConvDgradLin {
     DRA_STAMP(TRR, 1);
     __syncthreads();
     DRA_STAMP(TRR, 2);
-    // ---- MFMA: same slot <-> (oc, tap) map and the same order as ConvDgradOne
+    // ---- MFMA: slot <-> (oc, tap) map as described above, taps outermost
     f32x16 acc[PT];
 #pragma unroll
     for (int t = 0; t < PT; ++t) acc[t] = zero16();

@@ -127,9 +127,12 @@ class _ConvFn(torch.autograd.Function):
 
 
 import os as _os
-# one slab per (sample, row chunk) + the segmented fold up to the on-policy minibatch sizes: a2c_pixel (batch 80) 106.6k -> 114.9k,
-# ppo_pixel (batch 256) 56.6k -> 65.2k env-steps/s against the fixed split-K weight gradient (profiles/r02zw_onpolicy_*.jsonl)
-_ONESHOT_WGRAD_MAX_BATCH = int(_os.environ.get("DRA_ONESHOT_WGRAD_MAX_BATCH", "256"))
+# one slab per (sample, row chunk) + the segmented fold at the on-policy minibatch sizes: a2c_pixel (batch 80) 106.6k -> 114.9k,
+# ppo_pixel (batch 256) 56.6k -> 65.2k env-steps/s against the fixed split-K weight gradient (profiles/r02zw_onpolicy_*.jsonl).
+# Round 4 measured the backward launches at batch 512 / 1024 both ways (profiles/r04f_conv_big.jsonl vs r04g_conv_big_oneshot.jsonl):
+# conv1 286 / 568 us -> 57 / 109 us, conv2 175 / 362 -> 88 / 159 us, conv3 124 / 240 -> 68 / 128 us (35-44 % of the fp32-MFMA peak
+# instead of 7-20 %); the slabs are 168 MB at batch 1024 (conv1), which is where the limit stays.
+_ONESHOT_WGRAD_MAX_BATCH = int(_os.environ.get("DRA_ONESHOT_WGRAD_MAX_BATCH", "1024"))
 
 
 class _ConvKocFn(torch.autograd.Function):

@@ -417,7 +417,6 @@ VAR_ACTOR_FUSED_CONV1 = 8192
 VAR_GATHER_ON_UPDATE = 16384
 VAR_RING_DIRECT = 32768
 VAR_IDX_PREFETCH = 131072
-VAR_WGRAD_ACC = 262144
 VAR_LATE_FOLD = 524288
 VAR_ACTOR_MEGA = 1048576
 VAR_ALL = 2097151

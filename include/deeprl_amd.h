@@ -255,9 +255,8 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
 #define DRA_VAR_IDX_PREFETCH 131072 /* learner (with RING_DIRECT): a step-tagged copy of the minibatch indices goes to the device by
                                     * an unordered async copy when the step is enqueued; conv1 takes an element from there when
                                     * its tag is this update's (no PCIe read in front of its frame loads), else from pinned memory */
-#define DRA_VAR_WGRAD_ACC 262144  /* with ONESHOT_WGRAD: four (sample, row chunk) units accumulated per workgroup (one per
-                                   * wave, added through LDS in a fixed order): 8 / 8 / 40 slabs per layer at batch 32 instead
-                                   * of 32 / 32 / 160 -- the backward's slab traffic drops from 14 MB to 3.5 MB */
+/* (bit 262144 was DRA_VAR_WGRAD_ACC, a conv weight gradient that accumulated four samples per workgroup to write a quarter of
+ * the slabs: slower than one slab per sample on every layer once the staging was cheap, removed in round 4; the bit is ignored) */
 #define DRA_VAR_LATE_FOLD 524288  /* learner (with ONESHOT_WGRAD + FUSED_BWD): no gradient-norm launch -- sums of squares come
                                    * from the kernels that write each gradient, conv3 / conv2 slabs are folded by spare
                                    * workgroups of the NEXT layer's backward launch, conv1's by the first workgroups of the

@@ -239,9 +239,8 @@ def _rel(a, b, floor):
 
 
 @pytest.mark.parametrize("double_q,variant", [(False, 0), (False, 1), (False, 7), (False, 127), (True, 127), (True, 511),
-                                              (False, 511 + 262144), (True, 511 + 262144),   # + WGRAD_ACC: 8 / 8 / 40 slabs
-                                              (False, 511 + 524288), (False, 511 + 262144 + 524288),   # + LATE_FOLD: no norm launch
-                                              (True, 511 + 262144 + 524288)])
+                                              (False, 511 + 524288), (True, 511 + 524288),   # + LATE_FOLD: no norm launch
+                                              (True, 511 + 262144 + 524288)])                  # (bit 262144: ignored since round 4)
 def test_fused_learner_matches_oracle(dra, double_q, variant):
     """The captured-graph DQN learner (one C-ABI call per update, zero host round trips) against
     the CPU oracle's full update on identical ring contents, indices and weights: 4 consecutive
@@ -440,12 +439,11 @@ def test_fused_step_async_pipeline(dra, variant):
                                               (29183, "normal", 4000), (-1, "normal", 160), (12799, "normal", 160),
                                               (61951, "normal", 4000), (61951, "normal", 160), (61951, "bench", 4000),
                                               (193023, "normal", 4000), (193023, "normal", 160), (193023, "bench", 4000),
-                                              # round 3: + WGRAD_ACC (262144), + LATE_FOLD (524288) on the round-2 default 193023
-                                              (455167, "normal", 4000), (979455, "normal", 4000), (979455, "normal", 160),
-                                              (979455, "bench", 4000),
-                                              # + ACTOR_MEGA (1048576): one launch per env step of the actor
+                                              # round 3: + LATE_FOLD (524288) on the round-2 default 193023
+                                              (717311, "normal", 4000), (717311, "normal", 160), (717311, "bench", 4000),
+                                              # + ACTOR_MEGA (1048576): conv3 + fc4 of the actor's env step as one launch
                                               (1241599, "normal", 4000), (1241599, "normal", 160), (1241599, "bench", 4000),
-                                              (1765887, "normal", 4000), (1765887, "bench", 4000), (2028031, "normal", 4000)])
+                                              (1765887, "normal", 4000), (1765887, "normal", 160), (1765887, "bench", 4000)])
 def test_async_pipeline_matches_schedule_oracle(dra, variant, init, cap):
     """THE BENCHMARKED CONFIGURATION against the oracle: DQNLearnerBench(async_actor=True) with the default kernel
     variant (bench.py's: CU partition, pipelined gather, actor parameter ring, fused actor conv1) for 14 agent steps vs

@@ -62,7 +62,7 @@ def test_actor_mega_is_bit_identical(tmp_path, kind):
     """DRA_VAR_ACTOR_MEGA (round 3): conv3 + fc4 of the actor's env step as ONE launch handing conv3's planes over through an
     arrival counter, against the four separate launches (the bit cleared in DRA_TUNING): the same products in the same order --
     same stored actions, bit-identical parameters after 60 agent steps of the async pipeline."""
-    default = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 262144 | 524288 | 1048576
+    default = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 524288 | 1048576
     a = _run(kind, {"DRA_TUNING": str(default)}, tmp_path, "mega1")
     b = _run(kind, {"DRA_TUNING": str(default & ~1048576)}, tmp_path, "nomega")
     assert sorted(a) == sorted(b)

@@ -635,6 +635,40 @@ def test_conv_koc_fwd_bwd_vs_oracle(dev, layer, batch):
 
 
 @pytest.mark.parametrize("layer", [1, 2, 3])
+@pytest.mark.parametrize("batch", [80, 256, 600])
+def test_conv_autograd_function_at_rollout_batches(dev, layer, batch):
+    """nets._ConvKocFn -- what NatureConvBody's layers run under autograd in the generic agents (A2C batch 80, PPO minibatch 256,
+    and a batch above the former one-slab-per-sample limit of 256) -- forward, weight / bias gradient (one slab per (sample, row
+    chunk), folded by the segmented norm kernel) and input gradient against F.conv2d in float64 at 1e-5 of each tensor's scale."""
+    import torch.nn.functional as F
+    from deeprl_amd import nets, ops
+    c, h, oc, k, s = CONV[layer]
+    rs = np.random.RandomState(7 * layer + batch)
+    w = (rs.standard_normal((oc, c, k, k)) / np.sqrt(c * k * k)).astype(np.float32)
+    b = (rs.standard_normal(oc) * 0.1).astype(np.float32)
+    w_dev = ops.to_koc(f32(w, dev)).view(c, k, k, oc).permute(3, 0, 1, 2).requires_grad_(True)   # [OC,C,KH,KW] view of KOC storage
+    b_dev = f32(b, dev).requires_grad_(True)
+    if layer == 1:
+        x_u8 = rs.randint(0, 256, size=(batch, c, h, h)).astype(np.uint8)
+        x = NUM.image_normalize_sync(x_u8)
+        x_dev, coef = cu(x_u8, dev), 1.0 / 255
+    else:
+        x = np.maximum(rs.standard_normal((batch, c, h, h)), 0).astype(np.float32)
+        x_dev, coef = f32(x, dev).requires_grad_(True), None
+    y = nets._ConvKocFn.apply(x_dev, w_dev, b_dev, layer, coef)
+    xt, wt, bt = t64(x), t64(w), t64(b)
+    pre = F.conv2d(xt, wt, bt, stride=s)
+    _scale_close(y.detach().cpu().numpy(), F.relu(pre).detach().numpy())
+    dy = rs.standard_normal(tuple(pre.shape)).astype(np.float32)
+    y.backward(f32(dy, dev))
+    pre.backward(t64(dy * (y.detach().cpu().numpy() > 0), False))          # through the device's ReLU gate
+    _scale_close(w_dev.grad.cpu().numpy(), wt.grad.numpy())
+    _scale_close(b_dev.grad.cpu().numpy(), bt.grad.numpy())
+    if layer > 1:
+        _scale_close(x_dev.grad.cpu().numpy(), xt.grad.numpy())
+
+
+@pytest.mark.parametrize("layer", [1, 2, 3])
 def test_conv_koc_fwd_throughput_shape(dev, layer):
     """conv_v2.hip picks the multi-tile (throughput) workgroup shape from batch 128 up: same arithmetic per
     output position as the one-tile (latency) shape, so the two agree to the bit on a shared prefix of the
@@ -688,11 +722,10 @@ def test_conv1_full_k_throughput_kernel(dev, batch):
 # ---------------------------------------------------------------- fused launches + one-pass kernels (fused.hip)
 @pytest.mark.parametrize("layer", [1, 2, 3])
 @pytest.mark.parametrize("batch", [32, 1, 5])
-@pytest.mark.parametrize("variant", [1, 3, 9, 11, 9 + 262144, 11 + 262144])
+@pytest.mark.parametrize("variant", [1, 3, 9, 11])
 def test_conv_bwd_fused_vs_autograd(dev, layer, batch, variant):
     """dra_conv_bwd_fused: weight/bias gradient slabs and the masked input gradient of one layer in ONE launch,
-    for the K-chunked (1), one-pass dgrad (3), one-pass wgrad (9) and all-one-pass (11) variants, and the one-pass weight
-    gradient that accumulates four (sample, chunk) units per workgroup (+ 262144 = DRA_VAR_WGRAD_ACC), against
+    for the K-chunked (1), one-pass dgrad (3), one-pass wgrad (9) and all-one-pass (11) variants, against
     F.conv2d autograd; the slab fold goes through dra_grad_sqnorm_segs."""
     import torch.nn.functional as F
     from deeprl_amd import ops
@@ -720,13 +753,8 @@ def test_conv_bwd_fused_vs_autograd(dev, layer, batch, variant):
     kk = c * k * k
     stride = dw_s.stride(0)
     n_slabs = dw_s.shape[0]
-    acc_layers = int(os.environ.get("DRA_WGRAD_ACC_LAYERS", "4"))
-    if int(os.environ.get("DRA_BWD_LIN", "7")) & 4:
-        acc_layers &= 3                 # conv3: one slab per sample on the linear operand maps (ConvWgradLin) takes precedence
-    if variant & 262144 and (acc_layers >> (layer - 1)) & 1:
-        # one slab per group of four units (unit = sample x row chunk; conv1 has 5 chunks per sample); the library applies the
-        # accumulating kernel to the layers of DRA_WGRAD_ACC_LAYERS (default: conv3 only)
-        assert n_slabs == (batch * (5 if layer == 1 else 1) + 3) // 4
+    if variant & 8:     # one-pass weight gradient: one slab per (sample, row chunk); conv1 has 5 chunks of 4 output rows
+        assert n_slabs == batch * (5 if layer == 1 else 1)
     seg = oc * kk + oc
     grad = torch.zeros(seg + 1000, dtype=torch.float32, device=dev)
     tail = rs.standard_normal(1000).astype(np.float32)

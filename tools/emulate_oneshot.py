@@ -38,62 +38,6 @@ G2 = Geom(32, 20, 64, 4, 2)
 G3 = Geom(64, 9, 64, 3, 1)
 
 
-def emu_conv_dgrad(G, dy, wt, xact, B):
-    """ConvDgradOne<G>::run for every block.  dy [B][OC][OH][OH], wt [K][OC], xact [B][C][H][H] -> dx."""
-    S, KH, OC, C, H, OH = G.S, G.KH, G.OC, G.C, G.H, G.OH
-    KP = (KH + S - 1) // S
-    NPH, HP = S * S, (H + S - 1) // S
-    PP, PAD = HP * HP, KP - 1
-    DH = OH + 2 * PAD
-    RW, CS = DH, DH * DH
-    TPP = (PP + 31) // 32
-    OCW, OCH, NT, MT = OC // 4, OC // 8, KP * KP, C // 32
-    NCELL = OC * CS
-    dx = np.full((B, C, H, H), np.nan, dtype=np.float64)
-    dyf, wtf = dy.reshape(-1), wt.reshape(-1)
-    for bid in range(B * NPH * TPP * MT):
-        mt = bid % MT
-        r = bid // MT
-        tile = r % TPP
-        r //= TPP
-        phi, bi = r % NPH, r // NPH
-        ph, pw = phi // S, phi % S
-        c0, p0 = mt * 32, tile * 32
-        np_ = min(32, PP - p0)
-        lds = np.zeros(NCELL)
-        for e in range(NCELL):
-            oc, rem = divmod(e, CS)
-            rr, cc = divmod(rem, RW)
-            inside = PAD <= rr < PAD + OH and PAD <= cc < PAD + OH
-            oh, ow = min(max(rr - PAD, 0), OH - 1), min(max(cc - PAD, 0), OH - 1)
-            v = dyf[bi * OC * G.P + (oc * OH + oh) * OH + ow]
-            lds[e] = v if inside else 0.0
-        acc = np.zeros((32, 32))
-        li = np.arange(32)
-        pj = np.minimum(li, np_ - 1)
-        ih2, iw2 = (p0 + pj) // HP, (p0 + pj) % HP
-        for wave in range(4):
-            for t in range(NT):
-                kh2, kw2 = t // KP, t % KP
-                kh, kw = kh2 * S + ph, kw2 * S + pw
-                for jj in range(OCH):
-                    a = np.zeros((2, 32))
-                    b = np.zeros((2, 32))
-                    for h in range(2):
-                        oc = wave * OCW + h * OCH + jj
-                        a[h] = wtf[((c0 + li) * G.KK + kh * KH + kw) * OC + oc]
-                        b[h] = lds[oc * CS + ih2 * RW + iw2 + (PAD - kh2) * RW + (PAD - kw2)]
-                    mfma_acc(acc, a, b)
-        ih, iw = ih2 * S + ph, iw2 * S + pw
-        for l in range(32):
-            if l < np_ and ih[l] < H and iw[l] < H:
-                for m in range(32):
-                    c = c0 + m
-                    v = acc[m][l]
-                    dx[bi, c, ih[l], iw[l]] = v * (1.0 if xact[bi, c, ih[l], iw[l]] > 0 else 0.0)
-    return dx
-
-
 def emu_conv_wgrad(G, ROWS, MTG, RW, CSPAD, dy, x, B):
     """ConvWgradOne<G, ROWS, MTG, RW, CSPAD>::run for every block -> (dw slabs [n_slabs][K][OC], db slabs)."""
     S, KH, OC, C, H, OH = G.S, G.KH, G.OC, G.C, G.H, G.OH
@@ -295,118 +239,6 @@ def emu_conv_wgrad_lin(G, MTG, dy, x, B):
     return dw, db
 
 
-def emu_conv_wgrad_acc(G, ROWS, MTG, NTG, RW, CSPAD, dy, x, B):
-    """ConvWgradAcc<G, ROWS, MTG, NTG, RW, CSPAD>::run for every block: wave w stages unit 4*ug + w with the kernel's own
-    float4 / dword walk of the SOURCE (clamped loads, carries across output channels), runs every tile of the workgroup,
-    the four waves are added (u0 + u1) + (u2 + u3) -> (dw slabs [n_slabs][K][OC], db slabs [n_slabs][OC])."""
-    S, KH, OC, C, H, OH = G.S, G.KH, G.OC, G.C, G.H, G.OH
-    SB = 4
-    OWP = (OH + 1) & ~1
-    NPAIR = OWP // 2
-    NJ, NCHUNK = ROWS * NPAIR, OH // ROWS
-    MTILES = G.K // 32
-    NGRP, NTL = MTILES // MTG, OC // 32
-    NNG, TILES = NTL // NTG, MTG * NTG
-    NR = (ROWS - 1) * S + KH
-    CS = NR * RW + CSPAD
-    if (MTG * 32) % G.KK == 0:
-        NCHMAX = (MTG * 32) // G.KK
-    elif G.KK % (MTG * 32) == 0:
-        NCHMAX = 1
-    else:
-        NCHMAX = (MTG * 32 + G.KK - 2) // G.KK + 1
-    NCH = min(NCHMAX, C)
-    IMG = NCH * CS + RW
-    OCW = 32 * NTG
-    LDB, NPOS = OCW + 1, ROWS * OWP
-    DYF = NPOS * LDB
-    UNIT = (IMG + DYF + 3) & ~3
-    n_units = B * NCHUNK
-    n_slabs = (n_units + SB - 1) // SB
-    WHOLE = ROWS == OH
-    RUN = ROWS * OH
-    NVD = (OCW * G.P) // 4 if WHOLE else OCW * (RUN // 4)
-    RUNI = NR * H
-    V4 = RUNI % 4 == 0 and G.HW % 4 == 0 and H % 4 == 0
-    VPC = RUNI // 4 if V4 else RUNI
-    assert RW >= (OWP - 1) * S + KH
-    assert (OCW * G.P) % 4 == 0 if WHOLE else RUN % 4 == 0
-    dw = np.full((n_slabs, G.K, OC), np.nan)
-    db = np.full((n_slabs, OC), np.nan)
-    dyflat, xflat = dy.reshape(-1), x.reshape(-1)
-    li = np.arange(32)
-    for bid in range(n_slabs * NGRP * NNG):
-        ng = bid % NNG
-        r = bid // NNG
-        grp, ug = r % NGRP, r // NGRP
-        k0, oc0 = grp * MTG * 32, ng * OCW
-        c_lo = k0 // G.KK
-        c_hi = min((k0 + MTG * 32 - 1) // G.KK, C - 1)
-        nch = c_hi - c_lo + 1
-        assert nch <= NCH
-        accs, sbs = [], []
-        for wave in range(SB):
-            unit = ug * SB + wave
-            valid = unit < n_units
-            uc = unit if valid else n_units - 1
-            bi, chunk = uc // NCHUNK, uc % NCHUNK
-            ir0 = chunk * ROWS * S
-            lds = np.zeros(UNIT)            # the zero fill
-            img, dyl = lds[:IMG], lds[IMG:]
-            xbase = (bi * C + c_lo) * G.HW + ir0 * H
-            for e in range(nch * VPC):      # e = lane + 64 q
-                cl, v = e // VPC, e % VPC
-                if V4:
-                    r0 = 4 * v
-                    rr, cc = r0 // H, r0 % H
-                    for i in range(4):
-                        img[cl * CS + rr * RW + cc + i] = xflat[xbase + cl * G.HW + 4 * v + i]
-                else:
-                    rr, cc = v // H, v % H
-                    img[cl * CS + rr * RW + cc] = xflat[xbase + cl * G.HW + v]
-            dybase = (bi * OC + oc0) * G.P + chunk * ROWS * OH
-            for f in range(NVD):
-                if WHOLE:
-                    oc0l, pos0 = (4 * f) // G.P, (4 * f) % G.P
-                    src = dybase + 4 * f
-                else:
-                    oc0l, pos0 = f // (RUN // 4), 4 * (f % (RUN // 4))
-                    src = dybase + oc0l * G.P + pos0
-                for i in range(4):
-                    p, oc = pos0 + i, oc0l
-                    if WHOLE and p >= G.P:
-                        p -= G.P
-                        oc += 1
-                    ohl, ow = p // OH, p % OH
-                    dyl[(ohl * OWP + ow) * LDB + oc] = dyflat[src + i]
-            acc = np.zeros((TILES, 32, 32))
-            if valid:
-                for t in range(TILES):
-                    mt, nt = t // NTG, t % NTG
-                    k = k0 + mt * 32 + li
-                    c, kr = k // G.KK, k % G.KK
-                    kh, kw = kr // KH, kr % KH
-                    for j in range(NJ):
-                        ohl, jw = j // NPAIR, j % NPAIR
-                        a = np.zeros((2, 32))
-                        b = np.zeros((2, 32))
-                        for h in range(2):
-                            ai = (c - c_lo) * CS + kh * RW + kw + h * S + ohl * S * RW + 2 * jw * S
-                            assert (ai < IMG).all()
-                            a[h] = img[ai]
-                            b[h] = dyl[h * LDB + nt * 32 + li + (ohl * OWP + 2 * jw) * LDB]
-                        mfma_acc(acc[t], a, b)
-            accs.append(acc)
-            sbs.append(np.array([sum(dyl[pos * LDB + o] for pos in range(NPOS)) for o in range(OCW)]) if valid else np.zeros(OCW))
-        tot = (accs[0] + accs[1]) + (accs[2] + accs[3])
-        for t in range(TILES):
-            mt, nt = t // NTG, t % NTG
-            dw[ug, k0 + mt * 32:k0 + mt * 32 + 32, oc0 + nt * 32:oc0 + nt * 32 + 32] = tot[t]
-        if grp == 0:
-            db[ug, oc0:oc0 + OCW] = (sbs[0] + sbs[1]) + (sbs[2] + sbs[3])
-    return dw, db
-
-
 def emu_lin_dgrad(O, dy, w, xact, B, I):
     """LinDgradOne<O>: dx[b][i] = relu'(xact) * sum_o dy[b][o] w[o][i]."""
     KW, NJ, LDA = O // 4, O // 8, O + 1
@@ -605,37 +437,18 @@ def main():
         dy = torch.randn_like(y)
         y.backward(dy)
         wt = w.detach().permute(1, 2, 3, 0).reshape(G.K, G.OC).numpy()
-        if name != "conv1":
-            want_dx = xr.grad.numpy() * (x.numpy() > 0)
-            got = emu_conv_dgrad(G, dy.numpy(), wt, x.numpy(), B)
-            check(name + " dgrad one-pass", got, want_dx)
-        dw, db = emu_conv_wgrad(G, *wg, dy.numpy(), x.numpy(), B)
         want_dw = w.grad.permute(1, 2, 3, 0).reshape(G.K, G.OC).numpy()
-        if name != "conv1":       # round 4 (oneshot_lin.h): straight-copy staging, geometry in the operand base addresses
+        if name != "conv1":       # oneshot_lin.h: operands in LDS as they lie in memory, geometry in the operand base addresses
+            want_dx = xr.grad.numpy() * (x.numpy() > 0)
             pt_lin = 2 if name == "conv2" else 1
             check(name + " dgrad lin", emu_conv_dgrad_lin(G, pt_lin, dy.numpy(), wt, x.numpy(), B), want_dx)
             dwl, dbl = emu_conv_wgrad_lin(G, 4 if name == "conv2" else 3, dy.numpy(), x.numpy(), B)
             check(name + " wgrad lin", dwl.sum(0), want_dw)
             check(name + " bias  lin", dbl.sum(0), dy.sum((0, 2, 3)).numpy())
-        check(name + " wgrad one-pass", dw.sum(0), want_dw)
-        check(name + " bias  one-pass", db.sum(0), dy.sum((0, 2, 3)).numpy())
-        # DRA_VAR_WGRAD_ACC instantiations (fused.hip WA1 / WA2 / WA3), and a batch that is not a multiple of the 4 units
-        # per workgroup for the whole-sample layers (padding units contribute nothing)
-        wa = {"conv1": (4, 1, 1, 88, 0), "conv2": (9, 2, 1, 24, 4), "conv3": (7, 2, 1, 10, 1)}[name]
-        dwa, dba = emu_conv_wgrad_acc(G, *wa, dy.numpy(), x.numpy(), B)
-        check(name + " wgrad acc", dwa.sum(0), want_dw)
-        check(name + " bias  acc", dba.sum(0), dy.sum((0, 2, 3)).numpy())
-        if name != "conv1":
-            B5 = 5
-            x5 = torch.randn(B5, G.C, G.H, G.H, dtype=torch.float64)
-            w5 = w.detach().clone().requires_grad_(True)
-            y5 = F.conv2d(x5, w5, stride=G.S)
-            dy5 = torch.randn_like(y5)
-            y5.backward(dy5)
-            dwa, dba = emu_conv_wgrad_acc(G, *wa, dy5.numpy(), x5.numpy(), B5)
-            assert dwa.shape[0] == 2
-            check(name + " wgrad acc B=5", dwa.sum(0), w5.grad.permute(1, 2, 3, 0).reshape(G.K, G.OC).numpy())
-            check(name + " bias  acc B=5", dba.sum(0), dy5.sum((0, 2, 3)).numpy())
+        else:                     # oneshot.h ConvWgradOne: conv1 (transposing staging, 4-row chunks)
+            dw, db = emu_conv_wgrad(G, *wg, dy.numpy(), x.numpy(), B)
+            check(name + " wgrad one-pass", dw.sum(0), want_dw)
+            check(name + " bias  one-pass", db.sum(0), dy.sum((0, 2, 3)).numpy())
     B, I, O = 5, 96, 64
     dyl, wl = rs.randn(B, O), rs.randn(O, I)
     xa = rs.randn(B, I)
