@@ -1447,6 +1447,8 @@ int dra_conv1_fwd_koc_ringbatch(const void* frames, const int64_t* idx, int64_t*
   a.sample_seq = update_seq;
   a.batch = batch; a.act = act; a.coef = u8_coef; a.ring_slot = nullptr; a.ring_cap = 0; a.stack_age = nullptr;
   a.slot_seq = nullptr; a.slot_entries = 0; a.slot_stride = 0; a.newest_frame = nullptr;
+  // (two 32-position tiles per workgroup -- 448 workgroups in one round instead of 832 in 1.3 -- measured 0.5 us slower,
+  // profiles/r04m_ab_conv1_fwd_pt.jsonl)
   return launch_conv_v2_pt<VG1, true, 1>(a, nz, dra_stream(stream));
 }
 

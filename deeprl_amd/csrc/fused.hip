@@ -51,8 +51,8 @@ using WG1f = ConvWgradOne<G1, 4, 4, 88, 0, false>;
 // ConvWgradAcc, which accumulated four samples per workgroup to write a quarter of the slabs, were removed in round 4: same
 // box, 8633 -> 8922 updates/s for the linear maps, and every layer slower with the accumulating form than without
 // (conv1 -4 %, conv1 + conv2 -11 %; profiles/r04e_ab_env.jsonl, r04g_ab_env.jsonl).  DRA_VAR_WGRAD_ACC is accepted and ignored.)
-using WG2l = ConvWgradLin<G2, 4>;
-using WG3l = ConvWgradLin<G3, 3>;
+using WG2l = ConvWgradLin<G2, 4>;     // 128 workgroups x 82 MFMAs per wave (2 k-tiles per workgroup: 256 x 41 measured 0.8 us slower)
+using WG3l = ConvWgradLin<G3, 2>;     // 288 x 25 (3 k-tiles: 192 x 50 / 25, 0.8 us slower); profiles/r04j_ab_wgrad_tiles_role_order.jsonl
 
 DRA_API int dra_conv_wgrad_slabs(int layer, int batch, int ksplit, int variant, int* n_slabs) {
   if (!n_slabs || batch < 1 || ksplit < 1 || layer < 1 || layer > 3) return DRA_EINVAL;
@@ -117,6 +117,7 @@ static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, con
   if (od && ow) {
     auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
     auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
+    // (the weight-gradient workgroups, the longer ones, FIRST in the launch: no difference, profiles/r04j_ab_wgrad_tiles_role_order.jsonl)
     return launch_multi(rd, rd.blocks(), rw, rw.blocks(), none, n3, st);
   }
   if constexpr (!std::is_same<R3, NoRole>::value) return DRA_EINVAL;

@@ -442,7 +442,7 @@ def main():
             want_dx = xr.grad.numpy() * (x.numpy() > 0)
             pt_lin = 2 if name == "conv2" else 1
             check(name + " dgrad lin", emu_conv_dgrad_lin(G, pt_lin, dy.numpy(), wt, x.numpy(), B), want_dx)
-            dwl, dbl = emu_conv_wgrad_lin(G, 4 if name == "conv2" else 3, dy.numpy(), x.numpy(), B)
+            dwl, dbl = emu_conv_wgrad_lin(G, 4 if name == "conv2" else 2, dy.numpy(), x.numpy(), B)
             check(name + " wgrad lin", dwl.sum(0), want_dw)
             check(name + " bias  lin", dbl.sum(0), dy.sum((0, 2, 3)).numpy())
         else:                     # oneshot.h ConvWgradOne: conv1 (transposing staging, 4-row chunks)

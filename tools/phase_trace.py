@@ -34,7 +34,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sync", action="store_true", help="in-order mode on the whole chip (default: async pipelined)")
     ap.add_argument("--variant", type=int, default=-1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=8000)     # (about a second: a cold device runs the first tens of milliseconds at a lower clock)
     ap.add_argument("--ring", type=int, default=200_000)
     args = ap.parse_args()
     if "trace" not in os.path.basename(LIBRARY):
