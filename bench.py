@@ -332,7 +332,7 @@ def pmc_traffic(kernel_group):
     tools/pmc_workload.py, calibrated on the gather launch whose byte count is known); null when the
     kernel was not profiled.  Counters cannot be collected inside this process."""
     import glob
-    # (newest round's table for the DEFAULT kernels: rNN_pmc_traffic.json, from round 3 on rNN_pmc_traffic_layers4.json)
+    # (newest round's table for the DEFAULT kernels: rNN_pmc_traffic.json; round 3's was rNN_pmc_traffic_layers4.json)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")) +
                    glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_layers4.json")), key=os.path.basename)
     if not files:
@@ -353,14 +353,17 @@ def rocprof_kernel(kernel_group, flops):
     fraction that gives.  A profiler cannot run inside this process; the live number above is the conservative one."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats.txt")))
-    pat = {"conv2_bwd_x": "ConvDgradOne<ConvGeom<32, 20, 64, 4, 2>", "conv3_bwd_x": "ConvDgradOne<ConvGeom<64, 9, 64, 3, 1>",
+    # (kernel names as rocprofv3 prints them; the one-pass input-gradient role was ConvDgradOne until round 3)
+    pats = {"conv2_bwd_x": ("ConvDgradLin<ConvGeom<32, 20, 64, 4, 2>", "ConvDgradOne<ConvGeom<32, 20, 64, 4, 2>"),
+            "conv3_bwd_x": ("ConvDgradLin<ConvGeom<64, 9, 64, 3, 1>", "ConvDgradOne<ConvGeom<64, 9, 64, 3, 1>")}
+    pat = {"conv2_bwd_x": None, "conv3_bwd_x": None,
            "conv1_fwd": "conv_fwd_v2_kernel<V2Geom<4, 84, 32, 8, 4>, true, 1, 4>", "rmsprop_step": "late_step_kernel",
            "grad_norm": "clip_step_kernel<0>"}.get(kernel_group)
-    if not files or not pat:
+    if not files or (not pat and kernel_group not in pats):
         return None
     try:
         for line in open(files[-1]):
-            if pat in line:
+            if (pat and pat in line) or any(q in line for q in pats.get(kernel_group, ())):
                 cols = line.split()                      # ... calls avg_us min_us max_us share
                 calls, avg_us = int(cols[-5]), float(cols[-4])
                 out = {"avg_ms": avg_us * 1e-3, "calls": calls, "file": os.path.relpath(files[-1], ROOT)}

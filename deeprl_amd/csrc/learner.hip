@@ -2074,13 +2074,6 @@ head_q_kernel(const float* __restrict__ h4, const float* __restrict__ wh, const 
   }
 }
 
-// DRA_QHOST_MAIL=0: the earlier form (H2D copy, graph, D2H copy, event poll) -- A/B switch of the round
-static bool q_host_mail() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_QHOST_MAIL"); v = e ? atoi(e) : 1; }
-  return v != 0;
-}
-
 // Host side of the mailbox: wait for forward number `want` (spin on the mapped word: the host IS the critical path of a
 // host-environment actor, four dependent round trips per agent step), then copy the q values out.
 static int q_mail_wait(dra_dqn_learner* l, unsigned want, float* q_host) {
@@ -2104,16 +2097,16 @@ static int q_mail_wait(dra_dqn_learner* l, unsigned want, float* q_host) {
 }
 
 // DQNActor._transition's forward (DQN_agent.py:29-33) for an environment that lives on the HOST: the caller's
-// uint8 [4][84][84] observation goes through pinned staging to the device, the batch-1 forward of the ONLINE
-// parameters runs as one captured graph (5 kernels), and q[0..A) comes back.  Synchronises `stream` (the
-// reference's to_np(q) does too): the action must reach the host emulator before it can step.
+// uint8 [4][84][84] observation is copied into mapped host memory that conv1 reads in place, the batch-1 forward of the
+// ONLINE parameters runs as one captured graph (5 kernels) whose last kernel stores q[0..A) and a completion word into
+// mapped host memory; the call returns when the word arrives (the reference's to_np(q) waits too: the action must reach the
+// host emulator before it can step).  Round 3's form -- H2D copy, graph, D2H copy, event poll -- was 58 us per call against
+// 34 us (profiles/r04g_prof_host_async_before.txt, r04h_prof_host_async.txt; the agent: 2.5 k -> 3.3 k updates/s).
 DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host, float* q_host, void* stream) {
   if (!l || !state_host || !q_host) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
   const dra_dqn_config& c = l->c;
-  const bool mail = q_host_mail();
-  memcpy(l->qs_stage, state_host, (size_t)4 * 7056);
-  if (!mail) DRA_HIP(hipMemcpyAsync(l->act_state, l->qs_stage, (size_t)4 * 7056, hipMemcpyHostToDevice, st));
+  memcpy(l->qs_stage, state_host, (size_t)4 * 7056);         // (mapped, coherent: conv1 reads it in place)
   if (!l->g_q_ready) {
     const int64_t* o = c.offset;
     const float* P = l->p;
@@ -2122,7 +2115,7 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
     DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int rc = DRA_OK;
     {
-      const void* x1[1] = {mail ? (const void*)l->qs_stage : (const void*)l->act_state};
+      const void* x1[1] = {l->qs_stage};
       const float* w1[1] = {P + o[P_W1]}; const float* b1[1] = {P + o[P_B1]};
       float* y1[1] = {l->ay1};
       rc = dra_conv_fwd_koc(1, 1, x1, w1, b1, y1, 1, 1, c.u8_coef, DRA_ACT_RELU, s);
@@ -2137,7 +2130,7 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
                            l->ah4, 3136);
         hipLaunchKernelGGL(head_q_kernel, dim3(1), dim3(c.head_kind != DRA_HEAD_VANILLA ? 1024 : 256), 0, st, (const float*)l->ah4,
                            P + o[P_WH], P + o[P_BH], c.n_actions, l->aq, head_spec(l), (unsigned*)nullptr, 0,
-                           mail ? l->q_stage : (float*)nullptr, l->q_seq_dev);
+                           l->q_stage, l->q_seq_dev);
       }
     }
     hipError_t e = hipStreamEndCapture(st, &graph);
@@ -2148,11 +2141,7 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
     l->g_q_ready = true;
   }
   DRA_HIP(hipGraphLaunch(l->g_q, st));
-  if (mail) return q_mail_wait(l, ++l->q_seq_host, q_host);
-  DRA_HIP(hipMemcpyAsync(l->q_stage, l->aq, (size_t)c.n_actions * sizeof(float), hipMemcpyDeviceToHost, st));
-  DRA_HIP(hipStreamSynchronize(st));
-  memcpy(q_host, l->q_stage, (size_t)c.n_actions * sizeof(float));
-  return DRA_OK;
+  return q_mail_wait(l, ++l->q_seq_host, q_host);
 }
 
 // ---- async actor over a HOST environment (BaseAgent.py:142-162 with a real emulator: the actor's forward for agent step
@@ -2202,9 +2191,7 @@ DRA_API int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* stat
       DRA_HIP(hipStreamWaitEvent(st, l->ev_hq[0], 0));
     }
   }
-  const bool mail = q_host_mail();
-  memcpy(l->qs_stage, state_host, (size_t)4 * 7056);
-  if (!mail) DRA_HIP(hipMemcpyAsync(l->act_state, l->qs_stage, (size_t)4 * 7056, hipMemcpyHostToDevice, st));
+  memcpy(l->qs_stage, state_host, (size_t)4 * 7056);         // (mapped, coherent: conv1 reads it in place)
   if (!l->g_qa_ready[k]) {
     const int64_t* o = c.offset;
     const float* P = l->pa[k];
@@ -2213,7 +2200,7 @@ DRA_API int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* stat
     DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int rc = DRA_OK;
     {
-      const void* x1[1] = {mail ? (const void*)l->qs_stage : (const void*)l->act_state};
+      const void* x1[1] = {l->qs_stage};
       const float* w1[1] = {P + o[P_W1]}; const float* b1[1] = {P + o[P_B1]};
       float* y1[1] = {l->ay1};
       rc = dra_conv_fwd_koc(1, 1, x1, w1, b1, y1, 1, 1, c.u8_coef, DRA_ACT_RELU, s);
@@ -2224,7 +2211,7 @@ DRA_API int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* stat
       if (!rc) {
         hipLaunchKernelGGL(head_q_kernel, dim3(1), dim3(c.head_kind != DRA_HEAD_VANILLA ? 1024 : 256), 0, st, (const float*)l->ah4,
                            P + o[P_WH], P + o[P_BH], c.n_actions, l->aq, head_spec(l), l->aflags + 4 * (kMaxEnvSteps - 1), 4,
-                           mail ? l->q_stage : (float*)nullptr, l->q_seq_dev);
+                           l->q_stage, l->q_seq_dev);
       }
     }
     hipError_t e = hipStreamEndCapture(st, &graph);
@@ -2235,18 +2222,7 @@ DRA_API int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* stat
     l->g_qa_ready[k] = true;
   }
   DRA_HIP(hipGraphLaunch(l->g_qa[k], st));
-  if (mail) return q_mail_wait(l, ++l->q_seq_host, q_host);
-  DRA_HIP(hipMemcpyAsync(l->q_stage, l->aq, (size_t)c.n_actions * sizeof(float), hipMemcpyDeviceToHost, st));
-  // the host IS the critical path here (4 dependent round trips per agent step): poll the completion instead of a blocking
-  // synchronise (no wake-up latency); the wait is ~40 us
-  DRA_HIP(hipEventRecord(l->ev_join[3], st));
-  for (;;) {
-    const hipError_t qe = hipEventQuery(l->ev_join[3]);
-    if (qe == hipSuccess) break;
-    if (qe != hipErrorNotReady) return (int)qe;
-  }
-  memcpy(q_host, l->q_stage, (size_t)c.n_actions * sizeof(float));
-  return DRA_OK;
+  return q_mail_wait(l, ++l->q_seq_host, q_host);
 }
 
 // ---- actor parameter ring (DRA_VAR_ACTOR_RING).  entry(seq) = ring + (seq mod kAringSlots) * kAprmStride holds the

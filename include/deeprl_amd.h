@@ -429,8 +429,9 @@ int dra_dqn_learner_invalidate_actor_copy(dra_dqn_learner* learner);
 /* DQNActor._transition on device for prm->n_env transitions (graph replay when use_graph). */
 int dra_dqn_learner_act(dra_dqn_learner* learner, const dra_dqn_step_params* prm, int use_graph, void* stream);
 /* DQNActor._transition's forward (DQN_agent.py:29-33) for a HOST environment: state_host = uint8 [4][84][84]
- * observation, q_host = float[n_actions] out.  Pinned staging both ways, batch-1 forward of the online parameters
- * as one captured graph; synchronises `stream` (like the reference's to_np(q)). */
+ * observation, q_host = float[n_actions] out.  The observation is read in place from the learner's mapped host staging, the
+ * batch-1 forward of the online parameters is one captured graph whose last kernel publishes q and a completion word to
+ * mapped host memory; returns when that word arrives (like the reference's to_np(q)); DRA_ETIMEDOUT after 10 s. */
 int dra_dqn_learner_q_host(dra_dqn_learner* learner, const uint8_t* state_host, float* q_host, void* stream);
 /* PrioritizedReplay.sample() on the device (dra_sumtree_per_chain2; needs the ring-direct pipeline): _set_per_chain2 once
  * before the first prioritized update; _per_chain2_seed hands the NEXT update's minibatch over from the host (first update,

@@ -26,7 +26,7 @@ GROUPS = [  # learner kernel group -> substring(s) of the rocprof kernel name
     ("conv3_bwd", ["ConvGeom<64, 9, 64, 3, 1>"]),
     ("conv2_bwd", ["ConvGeom<32, 20, 64, 4, 2>"]),
     ("conv1_bwd_w", ["ConvGeom<4, 84, 32, 8, 4>"]),
-    ("grad_norm", ["grad_sqnorm_kernel", "grad_fold_norm_kernel", "clip_step_kernel"]),
+    ("grad_norm", ["grad_sqnorm_kernel", "grad_fold_norm_kernel", "fold_norm_kernel", "clip_step_kernel"]),
     ("rmsprop_step", ["rmsprop_step_kernel", "late_step_kernel"]),
     ("actor_fc4", ["actor_fc4_kernel", "actor_fc4_planes", "actor_c3fc4_kernel"]),
 ]
