@@ -356,7 +356,9 @@ def rocprof_kernel(kernel_group, flops):
     # (kernel names as rocprofv3 prints them; the one-pass input-gradient role was ConvDgradOne until round 3)
     pats = {"conv2_bwd_x": ("ConvDgradLin<ConvGeom<32, 20, 64, 4, 2>", "ConvDgradOne<ConvGeom<32, 20, 64, 4, 2>"),
             "conv3_bwd_x": ("ConvDgradLin<ConvGeom<64, 9, 64, 3, 1>", "ConvDgradOne<ConvGeom<64, 9, 64, 3, 1>")}
-    pat = {"conv2_bwd_x": None, "conv3_bwd_x": None,
+    pat = {"conv2_bwd_x": None, "conv3_bwd_x": None, "conv2_fwd": "conv_fwd_v2_kernel<V2Geom<32, 20, 64, 4, 2>, false, 1, 4>",
+           "conv3_fwd": "conv_fwd_v2_kernel<V2Geom<64, 9, 64, 3, 1>, false, 1, 4>", "fc4_fwd": "LinFwdSlabsOne<3136",
+           "fc4_bwd_x": "multi_kernel<LinDgradOne<512>", "conv1_bwd_w": "multi_kernel<ConvWgradOne<ConvGeom<4, 84, 32, 8, 4>",
            "conv1_fwd": "conv_fwd_v2_kernel<V2Geom<4, 84, 32, 8, 4>, true, 1, 4>", "rmsprop_step": "late_step_kernel",
            "grad_norm": "clip_step_kernel<0>"}.get(kernel_group)
     if not files or (not pat and kernel_group not in pats):

@@ -940,11 +940,16 @@ class DQNLearnerBench:
 
         dom = max(ms, key=ms.get)
         out = entry(dom)
-        # the longest MFMA-bound kernel next to it (round 3: with the gradient norm folded into the optimizer launch that
-        # launch -- bandwidth-bound -- became the longest one of the update; the convolutions' MFMA rate is still the
-        # other number that matters)
-        dom_mfma = max((k for k in ms if k in flops), key=ms.get, default=None)
-        self.roofline_mfma = entry(dom_mfma) if dom_mfma is not None and dom_mfma != dom else None
+        # The MFMA-bound kernel reported next to it is conv2's backward launch (input + weight gradient: the largest MFMA
+        # launch of the backward pass, the one VERDICT r2 / r3 price the path by) -- by name, not "whichever MFMA kernel read
+        # longest in this run": the four convolution launches are within a microsecond of each other and the pick flipped
+        # between runs.  Every MFMA kernel's live reading is in `mfma_kernels`, longest first.
+        mfma = "conv2_bwd_x" if "conv2_bwd_x" in ms and "conv2_bwd_x" in flops else max((k for k in ms if k in flops), key=ms.get, default=None)
+        self.roofline_mfma = entry(mfma) if mfma is not None and mfma != dom else None
+        if self.roofline_mfma is not None:
+            self.roofline_mfma["mfma_kernels"] = [
+                {"kernel": k, "avg_ms": ms[k], "algorithmic_flops": flops[k], "frac": flops[k] / (ms[k] * 1e-3) / 1e12 / 157.3}
+                for k in sorted((k for k in ms if k in flops), key=ms.get, reverse=True)]
         return out
 
     def report(self):
