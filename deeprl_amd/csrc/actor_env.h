@@ -135,7 +135,9 @@ int dra_conv3_fwd_koc_pf(int nz, const void* const* x, const float* const* wt, c
 int dra_fc_bwd_fused_sq_partials(int batch, int n_actions, int in_features);   // partials the call below writes
 int dra_fc_bwd_fused_sq(const float* dq, const float* h4, const float* dh4, const float* x3, const float* w4, float* dwh,
                         float* dbh, float* dw4, float* db4, float* dx3, int batch, int n_actions, int in_features, int act,
-                        int variant, double* sq_partials, int* n_sq_partials, void* stream);
+                        int variant, double* sq_partials, int* n_sq_partials, const int64_t* head_action, int head_group,
+                        void* stream);   // head_action / head_group (optional): the head's gradient is zero outside the
+                                         // taken action's `head_group` outputs (distributional heads): those samples are skipped
 int dra_conv_bwd_fused_fold(int layer, const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
                             int64_t slab_stride, float* dx, int batch, int act, int variant, const dra_fold_seg* fold,
                             float* grad, double* fold_partials, int* n_fold_partials, double* reset_slots, int n_reset,

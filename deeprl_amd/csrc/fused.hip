@@ -283,7 +283,8 @@ int dra_fc_bwd_fused_sq_partials(int batch, int n_actions, int in_features) {
 
 int dra_fc_bwd_fused_sq(const float* dq, const float* h4, const float* dh4, const float* x3, const float* w4, float* dwh,
                         float* dbh, float* dw4, float* db4, float* dx3, int batch, int n_actions, int in_features, int act,
-                        int variant, double* sq_partials, int* n_sq_partials, void* stream) {
+                        int variant, double* sq_partials, int* n_sq_partials, const int64_t* head_action, int head_group,
+                        void* stream) {
   if (!dq || !h4 || !dh4 || !x3 || !w4 || !dwh || !dbh || !dw4 || !db4 || !dx3 || batch < 1 || n_actions < 1 ||
       in_features < 1 || !sq_partials || !n_sq_partials || !(variant & DRA_VAR_ONESHOT_DGRAD))
     return DRA_EINVAL;
@@ -294,6 +295,7 @@ int dra_fc_bwd_fused_sq(const float* dq, const float* h4, const float* dh4, cons
   rd.tiles_n = (in_features + 31) / 32;
   HeadWgradRole rh;
   rh.dq = dq; rh.h4 = h4; rh.dwh = dwh; rh.dbh = dbh; rh.B = batch; rh.A = n_actions;
+  if (head_action && head_group > 1 && n_actions % head_group == 0) { rh.action = head_action; rh.group = head_group; }
   if (fc_wgrad_one(batch)) {
     constexpr int NI = kFcWgradNI;
     LinWgradOne<NI> rl;

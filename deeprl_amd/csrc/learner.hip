@@ -746,6 +746,37 @@ __device__ __forceinline__ void dist_head_q(const float* __restrict__ h4, const 
   __syncthreads();
 }
 
+// Input gradient of a distributional head (CategoricalNet / QuantileNet over 512 features) at the update's batch:
+//   dh4[b][i] = relu'(h4[b][i]) * sum_n dq[b][a_b * N + n] * Wh[a_b * N + n][i]
+// The loss differentiates the taken action's N outputs only (dq is zero elsewhere: the loss kernels write the zeros), so the
+// [B, A*N] x [A*N, 512] contraction the K-chunked GEMM performed (17 us for C51, 24 us for QR-DQN at 4 actions) is a GATHERED
+// matrix-vector product per sample.  Workgroup = (sample, 128-column block): threads (r, c) = (t >> 7, t & 127) walk the rows
+// n = r, r + 2, ... of the sample's block as coalesced 512-byte row segments, eight in flight; the two row classes meet in
+// LDS as (even rows) + (odd rows).  One multiply and one add per term (no contraction).
+__global__ void __launch_bounds__(256)
+dist_head_dgrad_kernel(const float* __restrict__ dq, const float* __restrict__ wh, const float* __restrict__ h4,
+                       const int64_t* __restrict__ action, int N, int NO, float* __restrict__ dh4) {
+  __shared__ float s_part[128];
+  const int b = blockIdx.x, t = threadIdx.x, r = t >> 7, col = blockIdx.y * 128 + (t & 127);
+  const int64_t base = action[b] * (int64_t)N;
+  const float* __restrict__ d = dq + (int64_t)b * NO + base;
+  const float* __restrict__ w = wh + base * 512 + col;
+  const float x = h4[(int64_t)b * 512 + col];
+  float acc = 0.f;
+  int n = r;
+  for (; n + 14 < N; n += 16) {
+    float dv[8], wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { dv[u] = d[n + 2 * u]; wv[u] = w[(int64_t)(n + 2 * u) * 512]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += dv[u] * wv[u];
+  }
+  for (; n < N; n += 2) acc += d[n] * w[(int64_t)n * 512];
+  if (r == 1) s_part[t & 127] = acc;
+  __syncthreads();
+  if (r == 0) dh4[(int64_t)b * 512 + col] = x > 0.f ? acc + s_part[t] : 0.f;     // (ReLU: h4 is the post-activation value)
+}
+
 // h4[z][b][:] = relu(b4_z + sum_s fc4_slab[z][s][b][:]) for every net of the update (z = 0 online(states), 1 target(next),
 // 2 online(next)): the split-K reduction head_fused_kernel performs for the VanillaNet head, on its own for the
 // distributional heads (their outputs are a [B,512] x [512, A*N] contraction -> linear kernel).  grid (B, nz).
@@ -1081,7 +1112,10 @@ static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta
                      l->delta, l->loss, l->dq, s);
     if (rc) return rc;
   }
-  return dra_linear_bwd_x(l->dq, P + o[P_WH], l->h4, l->dh4, B, 512, NO, DRA_ACT_RELU, s);
+  hipLaunchKernelGGL(dist_head_dgrad_kernel, dim3(B, 4), dim3(256), 0, st, (const float*)l->dq, P + o[P_WH], (const float*)l->h4,
+                     (const int64_t*)l->action_[l->gb], N, NO, l->dh4);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
 }
 
 // forward + loss + backward + gradient norm (everything between the gather and the optimizer).
@@ -1217,7 +1251,8 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       int nfc = 0, n3 = 0, n2 = 0;
       const int nfc_expect = dra_fc_bwd_fused_sq_partials(B, NO, 3136), n3_expect = (int)((l->lstride[2] / 4 + 63) / 64), n2_expect = (int)((l->lstride[1] / 4 + 63) / 64);
       STEP(K_FC4_BX, dra_fc_bwd_fused_sq(l->dq, l->h4, l->dh4, l->y3[0], P + o[P_W4], G + o[P_WH], G + o[P_BH], G + o[P_W4],
-                                         G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, l->partials, &nfc, s));
+                                         G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, l->partials, &nfc,
+                                         c.head_kind != DRA_HEAD_VANILLA ? l->action_[l->gb] : nullptr, c.n_atoms, s));
       if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV3_BW], st));
       if (l->per2_active && l->per2_ride)
         STEP(K_CONV3_BX, dra_conv3_bwd_fused_chain(l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], l->dy2, B,

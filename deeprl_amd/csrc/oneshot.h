@@ -110,10 +110,45 @@ struct HeadWgradRole {
   float* dbh;        // [A]
   int B, A;
   double* partials = nullptr;   // optional [2 * A]: sum of squares of what each workgroup stored (DRA_VAR_LATE_FOLD)
+  // Distributional heads (A = n_actions * group outputs): the loss differentiates the TAKEN action's atoms / quantiles only
+  // (CategoricalDQN_agent.py:78-82, QuantileRegressionDQN_agent.py:62-66), dq is exactly zero elsewhere (the loss kernels write
+  // the zeros), so output row a gets terms from the samples whose action is a / group only.  action != null: the other samples
+  // are skipped -- each skipped term is +0 * h4, so the result is the dense sum's bit for bit -- a quarter of the reads at 4 actions.
+  const int64_t* action = nullptr;
+  int group = 0;
   __device__ __forceinline__ void run(int bid, float* lds, int = 0) const {
     const int a = bid >> 1, k = (bid & 1) * 256 + threadIdx.x;
     float acc = 0.f, accb = 0.f;
     int b = 0;
+    if (action) {
+      // the matching samples of 64 at a time as a wave-uniform bit mask; up to eight of them per round, their loads in flight
+      // together (a scalar loop with a branch per sample was SLOWER than the dense sum: one memory latency per match)
+      const int64_t mine = a / group;
+      const int lane = threadIdx.x & 63;
+      for (; b < B; b += 64) {
+        const int bl = b + lane;
+        unsigned long long mask = __ballot(bl < B && action[bl < B ? bl : B - 1] == mine);
+        while (mask) {
+          int idx[8];
+          float d[8], h[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            idx[i] = mask ? b + __ffsll((long long)mask) - 1 : -1;
+            mask &= mask - 1ull;                  // (0 stays 0)
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int bi = idx[i] < 0 ? 0 : idx[i];
+            d[i] = dq[(int64_t)bi * A + a];
+            h[i] = h4[(int64_t)bi * 512 + k];
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (idx[i] >= 0) { acc += d[i] * h[i]; accb += d[i]; }
+        }
+      }
+      b = B;
+    }
     for (; b + 8 <= B; b += 8) {
       float d[8], h[8];
 #pragma unroll
