@@ -1090,6 +1090,31 @@ def _dp_plan_exchange(dp, network, fused):
     dp.plan_split(fused.flat, [p for p, o in zip(fused.flat.params, fused.flat.offsets) if o >= start])
 
 
+def _device_state_fn(agent):
+    """How a device-resident rollout hands observations to the network.  ImageNormalizer over NatureConvBody (a2c_pixel /
+    ppo_pixel, examples.py:361-381, 525-550): conv1's kernels take the uint8 frames themselves and normalise while staging --
+    f32(f64(v) * coef), the normaliser's own table values, bit for bit (tests/test_gpu_kernels.py: u8 and f32 inputs agree to the
+    bit) -- so the normaliser's launch per rollout step disappears and the rollout is stored, gathered and re-read as uint8 (a
+    quarter of the bytes).  Anything else goes through config.state_normalizer as the reference does."""
+    from .nets import Conv2d, NatureConvBody
+    from .normalizers import RescaleNormalizer
+    cfg = agent.config
+    norm = cfg.state_normalizer
+    body = getattr(agent.network, 'phi_body', None)
+    conv1 = getattr(body, 'conv1', None)
+    if (Config.DEVICE.type == 'cuda' and isinstance(norm, RescaleNormalizer) and type(body) is NatureConvBody
+            and isinstance(conv1, Conv2d) and conv1.weight.permute(1, 2, 3, 0).is_contiguous()
+            and getattr(cfg, 'device_u8_states', True)):
+        conv1.u8_coef = float(norm.coef)
+
+        def passthrough(x):
+            if isinstance(x, torch.Tensor) and x.dtype == torch.uint8 and x.is_cuda:
+                return x
+            return norm(x)
+        return passthrough
+    return norm
+
+
 class A2CAgent(BaseAgent):
     """A2C_agent.py:12-64."""
 
@@ -1114,6 +1139,7 @@ class A2CAgent(BaseAgent):
         self.grad_hook = None  # optional extra hook on the flat gradient before the optimiser step
         self._rollout_step = 0
         self._dev_graph = _OnPolicyGraph(self)
+        self._dev_state = _device_state_fn(self)
         _install_sampler(self)
 
     def close(self):
@@ -1141,13 +1167,13 @@ class A2CAgent(BaseAgent):
         states, actions, values = [], [], []
         with torch.no_grad():
             for t in range(config.rollout_length):
-                state_t = config.state_normalizer(self.task.states(plan, t))
+                state_t = self._dev_state(self.task.states(plan, t))
                 prediction = self.network(state_t)
                 self._rollout_step += 1
                 states.append(state_t)
                 actions.append(prediction['action'])
                 values.append(prediction['v'])
-            values.append(self.network(config.state_normalizer(self.task.states(plan, config.rollout_length)))['v'])
+            values.append(self.network(self._dev_state(self.task.states(plan, config.rollout_length)))['v'])
         return self._learn(states, actions, values, [plan.reward[t] for t in range(config.rollout_length)],
                            [plan.mask[t] for t in range(config.rollout_length)], apply=apply)
 
@@ -1298,6 +1324,7 @@ class PPOAgent(BaseAgent):
             self.states = self.task.reset()
             self.states = config.state_normalizer(self.states)
         self._dev_graph = _OnPolicyGraph(self, optimizer_inside=False)
+        self._dev_state = _device_state_fn(self)
         if config.shared_repr:
             self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda step: 1 - step / config.max_steps)
         self.grad_hook = None
@@ -1337,12 +1364,12 @@ class PPOAgent(BaseAgent):
         storage = Storage(config.rollout_length)
         with torch.no_grad():
             for t in range(config.rollout_length):
-                state_t = config.state_normalizer(self.task.states(plan, t))
+                state_t = self._dev_state(self.task.states(plan, t))
                 prediction = self.network(state_t)
                 self._rollout_step += 1
                 storage.feed(prediction)
                 storage.feed({'reward': plan.reward[t], 'mask': plan.mask[t], 'state': state_t})
-            prediction = self.network(config.state_normalizer(self.task.states(plan, config.rollout_length)))
+            prediction = self.network(self._dev_state(self.task.states(plan, config.rollout_length)))
             self._rollout_step += 1
         storage.feed(prediction)
         storage.placeholder()

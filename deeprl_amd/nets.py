@@ -194,7 +194,9 @@ class Conv2d(nn.Conv2d):
             raise NotImplementedError("deeprl_amd has HIP kernels for the NatureConvBody convolutions only; got "
                                       "weight %s stride %s input %s" % (tuple(self.weight.shape), self.stride,
                                                                         tuple(x.shape)))
-        u8_coef = getattr(x, "dra_u8_coef", None) if x.dtype == torch.uint8 else None
+        # uint8 frames: the normaliser's coefficient travels on the tensor (RescaleNormalizer) or on the layer (device-resident
+        # rollouts hand conv1 the raw frames: agents._device_state_fn)
+        u8_coef = (getattr(x, "dra_u8_coef", None) or getattr(self, "u8_coef", None)) if x.dtype == torch.uint8 else None
         if x.dtype == torch.uint8 and u8_coef is None:
             raise TypeError("uint8 input to a convolution needs a normaliser (RescaleNormalizer marks it)")
         if self.weight.permute(1, 2, 3, 0).is_contiguous():     # KOC storage (FlatParams): one-round-trip kernels
