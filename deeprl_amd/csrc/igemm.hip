@@ -184,71 +184,71 @@ linear_gemv_kernel(LinPtrs q, int B, int K, int O, int act) {
 
 // Wide layers at rollout batch sizes (fc4 of NatureConvBody, 3136 -> 512, for the 8 / 16 environments of one A2C / PPO rollout
 // step): the K-chunked GEMM + its split-K finish were 13.2 + 5.4 us per rollout step (profiles/r02zw_kernel_stats_ppo_pixel_8.txt)
-// for 6.4 MB of weights and 26 MFLOP.  Same shape as the device actor's fc4 GEMV: one wave per output row, the row in registers
-// as R float4 per lane (all requested up front), the input rows staged in LDS eight at a time (100 KB at K = 3136) and shared
-// by the workgroup's four rows; every load of the workgroup (its weight rows, its eight input rows) is requested before the
-// first LDS write (a first version staged the input with a load -> store loop: six dependent round trips, slower than the
-// GEMM it replaced).  grid (ceil(O / 4), nz, ceil(B / 8)).  K % 4 == 0.
+// for 6.4 MB of weights and 26 MFLOP.  Round 2's form -- one wave per output row, eight input rows staged in 100 KB of LDS and
+// shared by a workgroup's four rows -- kept one workgroup per CU on 128 CUs, every workgroup re-reading all the input rows:
+// 11.6 us = 0.55 TB/s (profiles/r04o_kernel_stats_ppo_pixel_8.txt); removed in round 4 for the form below (ppo_pixel +1.8 %,
+// a2c_pixel +0.3 %, profiles/r04u_ab_gemv_rows.txt).
+// The input rows are read straight from L2 (they are 100-200 KB in all).  A workgroup of EIGHT waves owns two output rows, each row's reduction split over four waves (K quarters); a lane keeps its
+// R float4 of the weight row in registers and, per round, the matching float4 of up to eight input rows -- all requested before
+// the first is used; per sample: products, a wave sum, the four quarter sums met in LDS as (q0 + q1) + (q2 + q3).  No barrier
+// before the last step, 256 workgroups for 512 outputs.  Per-sample arithmetic does not depend on the batch.
+// grid (ceil(O / 2), nz, ceil(B / 32)).  K % 4 == 0, K <= 4096 * ... R * 64 * 4 * 4.
 template <int R>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))   // registers, not occupancy (100 KB of LDS: one workgroup per CU)
-linear_gemv_wide_kernel(LinPtrs q, int B, int K, int O, int act) {
-  extern __shared__ __attribute__((aligned(16))) float s_x[];   // [<= 8 rows][K]
-  float4* __restrict__ s_x4 = reinterpret_cast<float4*>(s_x);
-  const int z = blockIdx.y, b0 = blockIdx.z * 8;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int o = blockIdx.x * 4 + wave;
-  const int nv = K >> 2;
-  const int nb = min(8, B - b0);
-  const int n4 = nb * nv;
+__global__ void __launch_bounds__(512)
+linear_gemv_rows_kernel(LinPtrs q, int B, int K, int O, int act) {
+  __shared__ float s_part[32][8];
+  const int z = blockIdx.y, b0 = blockIdx.z * 32;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = wave >> 2, quarter = wave & 3;
+  const int o = blockIdx.x * 2 + row;
+  const int nv = K >> 2, nvq = (nv + 3) >> 2;            // float4 per row / per quarter
+  const int v0 = quarter * nvq, v1 = min(nv, v0 + nvq);
+  const int nb = min(32, B - b0);
   const float4* __restrict__ w4 = reinterpret_cast<const float4*>(q.w[z] + (int64_t)min(o, O - 1) * K);
-  const float4* __restrict__ src = reinterpret_cast<const float4*>(q.x[z] + (int64_t)b0 * K);
-  // 8 rows x nv float4 over 256 threads: nv / 32 <= 2 R per thread (two arrays of R: one array of 2 R float4 is left in
-  // scratch memory by the compiler's alloca promotion limit)
-  float4 wv[R], xa[R], xb[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) wv[i] = w4[min(lane + 64 * i, nv - 1)];
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(q.x[z] + (int64_t)b0 * K);
+  float4 wv[R];
+  int vi[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    xa[i] = src[min((int)threadIdx.x + 256 * i, n4 - 1)];
-    xb[i] = src[min((int)threadIdx.x + 256 * (R + i), n4 - 1)];
+    const int v = v0 + lane + 64 * i;
+    vi[i] = v < v1 ? v : -1;
+    wv[i] = w4[v < v1 ? v : (v1 > v0 ? v1 - 1 : 0)];
   }
-  const float bias = q.bias[z] ? q.bias[z][min(o, O - 1)] : 0.f;
-  __builtin_amdgcn_sched_barrier(0);
+  for (int bb = 0; bb < nb; bb += 8) {
+    float4 xv[8][R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) {   // (clamped like the loads: a surplus thread rewrites the last element with the value it holds)
-    const int e = (int)threadIdx.x + 256 * i;
-    float4 va = xa[i], vb = xb[i];
-    asm volatile("" : "+v"(va.x), "+v"(va.y), "+v"(va.z), "+v"(va.w));   // (member access: the arrays stay in registers)
-    asm volatile("" : "+v"(vb.x), "+v"(vb.y), "+v"(vb.z), "+v"(vb.w));
-    s_x4[min(e, n4 - 1)] = va;
-    s_x4[min(e + 256 * R, n4 - 1)] = vb;
+    for (int u = 0; u < 8; ++u) {
+      const int b = min(bb + u, nb - 1);
+#pragma unroll
+      for (int i = 0; i < R; ++i) xv[u][i] = x4[(int64_t)b * nv + (vi[i] >= 0 ? vi[i] : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const float4 a = wv[i], xx = xv[u][i];
+        if (vi[i] >= 0) acc += (a.x * xx.x + a.y * xx.y) + (a.z * xx.z + a.w * xx.w);
+      }
+      acc = wave_sum(acc);
+      if (lane == 0 && bb + u < nb) s_part[bb + u][wave] = acc;
+    }
   }
   __syncthreads();
-  if (o >= O) return;
-  float* __restrict__ out = q.y[z];
-  for (int b = 0; b < nb; ++b) {
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const float4 a = wv[i];
-      const float4 xv = s_x4[b * nv + min(lane + 64 * i, nv - 1)];
-      if (lane + 64 * i < nv) acc += (a.x * xv.x + a.y * xv.y) + (a.z * xv.z + a.w * xv.w);
+  // thread t < 2 * nb: (row, sample)
+  const int t = threadIdx.x;
+  if (t < 2 * nb) {
+    const int r = t / nb, b = t - r * nb, oo = blockIdx.x * 2 + r;
+    if (oo < O) {
+      const float v = (s_part[b][4 * r] + s_part[b][4 * r + 1]) + (s_part[b][4 * r + 2] + s_part[b][4 * r + 3]);
+      const float bias = q.bias[z] ? q.bias[z][oo] : 0.f;
+      q.y[z][(int64_t)(b0 + b) * O + oo] = act_apply(v + bias, act);
     }
-    acc = wave_sum(acc);
-    if (lane == 0) out[(int64_t)(b0 + b) * O + o] = act_apply(acc + bias, act);
   }
 }
 
 template <int R>
-static int launch_gemv_wide(const LinPtrs& q, int nz, int batch, int in_features, int out_features, int act, hipStream_t st) {
-  const size_t lds = (size_t)(batch < 8 ? batch : 8) * in_features * sizeof(float);
-  static bool attr_set = false;
-  if (lds > 64 * 1024 && !attr_set) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_gemv_wide_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(linear_gemv_wide_kernel<R>, dim3((out_features + 3) / 4, nz, (batch + 7) / 8), dim3(256), lds, st, q, batch,
+static int launch_gemv_rows(const LinPtrs& q, int nz, int batch, int in_features, int out_features, int act, hipStream_t st) {
+  hipLaunchKernelGGL(linear_gemv_rows_kernel<R>, dim3((out_features + 1) / 2, nz, (batch + 31) / 32), dim3(512), 0, st, q, batch,
                      in_features, out_features, act);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
@@ -291,11 +291,9 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
       aligned = aligned && !((((uintptr_t)x[z]) | ((uintptr_t)w[z])) & 15);
     }
     if (aligned) {
-      const int r = ((in_features >> 2) + 63) / 64;
-      if (r <= 4) return launch_gemv_wide<4>(q, nz, batch, in_features, out_features, act, st);
-      if (r <= 8) return launch_gemv_wide<8>(q, nz, batch, in_features, out_features, act, st);
-      if (r <= 13) return launch_gemv_wide<13>(q, nz, batch, in_features, out_features, act, st);
-      return launch_gemv_wide<16>(q, nz, batch, in_features, out_features, act, st);
+      const int rq = ((((in_features >> 2) + 3) >> 2) + 63) / 64;     // float4 per lane of a K quarter
+      if (rq <= 2) return launch_gemv_rows<2>(q, nz, batch, in_features, out_features, act, st);
+      return launch_gemv_rows<4>(q, nz, batch, in_features, out_features, act, st);
     }
   }
   LinFwd<32, 32, 64> p;
