@@ -828,10 +828,25 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
                   const float* __restrict__ reward, const float* __restrict__ mask, float gamma_n, int double_q,
                   float* __restrict__ h4_out, float* __restrict__ q_on, float* __restrict__ q_tg, float* __restrict__ q_on2,
                   float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dh4, int64_t* __restrict__ opt_step,
-                  const RingScalars rs, const float* __restrict__ per_w) {
+                  const RingScalars rs, const float* __restrict__ per_w, const float* __restrict__ pf_w4) {
   __shared__ float s_h[3][512];
   __shared__ float s_q[3][64];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= B) {
+    // Spare workgroups of this 32-workgroup launch prefetch what the NEXT launch's input-gradient role will stream: workgroup
+    // B + p pulls W4[0:512][32p : 32p + 32] (512 row segments of 128 B) -- the operand of LinDgradOne workgroup p, which runs on
+    // the same XCD (workgroups are dealt round-robin over the 8 XCDs and B is a multiple of 8) -- into that XCD's L2.
+    const int pcol = (b - B) * 32;
+    float4 v[16];
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) {
+      const int e = tid + 256 * qq, row = e >> 3, c4 = e & 7;
+      v[qq] = *reinterpret_cast<const float4*>(pf_w4 + (int64_t)row * 3136 + pcol + 4 * c4);
+    }
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) asm volatile("" :: "v"(v[qq].x), "v"(v[qq].y), "v"(v[qq].z), "v"(v[qq].w));
+    return;
+  }
   DRA_STAMP(TR_HEAD, 0);
   // everything this workgroup reads is requested up front: the head weights of the (net, action) pairs this wave owns, the
   // transition scalars, and then the split-K partials -- ONE exposed memory latency instead of three (phase trace r02a:
@@ -1197,24 +1212,29 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   } else {
     // weights known before the update (device-side prioritized draw): the fused head applies them, no batch-wide reduction
     const float* per_w = (per && l->per2_active) ? l->weights : nullptr;
+    // fc4's input-gradient weights prefetched by spare workgroups of the head launch (see head_fused_kernel; same box: the fc
+    // backward launch 11.5 -> 10.8 us, 9 163 -> 9 183 updates/s, profiles/r04v_ab_pf_fc4_bwd.jsonl)
+    const bool pf = (l->variant & DRA_VAR_ONESHOT_DGRAD) && B % 8 == 0 && B <= 32 && dra_xcd_order_enabled();
+    const float* pf_w4 = pf ? P + o[P_W4] : nullptr;
+    const int hb = B + (pf ? 3136 / 32 : 0);
     if (ks4 == kFc4SplitWide)
-      hipLaunchKernelGGL(head_fused_kernel<kFc4SplitWide>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
+      hipLaunchKernelGGL(head_fused_kernel<kFc4SplitWide>, dim3(hb), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                          P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
                          (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
                          c.double_q,
-                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs, per_w);
+                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs, per_w, pf_w4);
     else if (ks4 == kFc4SplitMid)
-      hipLaunchKernelGGL(head_fused_kernel<kFc4SplitMid>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
+      hipLaunchKernelGGL(head_fused_kernel<kFc4SplitMid>, dim3(hb), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                          P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
                          (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
                          c.double_q,
-                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs, per_w);
+                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs, per_w, pf_w4);
     else
-      hipLaunchKernelGGL(head_fused_kernel<kFc4Split>, dim3(B), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
+      hipLaunchKernelGGL(head_fused_kernel<kFc4Split>, dim3(hb), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                          P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
                          (const int64_t*)l->action_[l->gb], (const float*)l->reward_[l->gb], (const float*)l->mask_[l->gb], c.gamma_n,
                          c.double_q,
-                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs, per_w);
+                         l->h4, l->q[0], l->q[1], l->q[2], l->delta, l->dq, l->dh4, l->opt_step, rs, per_w, pf_w4);
     DRA_LAUNCH_CHECK();
     if (per && !per_w) {  // PER needs the batch-wide max of the importance weights: separate kernel recomputes dq, then dh4
       int rc = dra_td_loss(l->q[0], l->q[1], c.double_q ? l->q[2] : nullptr, l->action_[l->gb], 1, l->reward_[l->gb],
