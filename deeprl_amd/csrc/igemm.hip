@@ -141,11 +141,14 @@ linear_finish_kernel(LinPtrs q, const float* __restrict__ slabs, int ksplit, int
 // workgroup stages up to 32 input rows in LDS once (<= 64 KB) and each of its 4 waves owns one output: the weight row
 // sits in registers (<= 8 floats per lane, coalesced 2 KB reads), one wave-level dot product per input row.
 // grid (ceil(O / 4), nz, ceil(B / 32)).  Summation order per output: lane-strided partial sums, then the wave butterfly.
+// O1: output count of net z = 1 (two heads of different width on the same features in ONE launch: dra_linear_fwd_pair); every
+// other z has O outputs.
 template <int KV>   // float per lane: ceil(K / 64)
 __global__ void __launch_bounds__(256)
-linear_gemv_kernel(LinPtrs q, int B, int K, int O, int act) {
+linear_gemv_kernel(LinPtrs q, int B, int K, int O_, int act, int O1) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];   // [rows][K]
   const int z = blockIdx.y, b0 = blockIdx.z * 32, nb = min(32, B - b0);
+  const int O = (z == 1) ? O1 : O_;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int o = blockIdx.x * 4 + wave;
   const float* __restrict__ wrow = q.w[z] + (int64_t)min(o, O - 1) * K;
@@ -260,6 +263,29 @@ static int gemv_enabled() {
   return v;
 }
 
+// Two linear heads of different width on the SAME input (CategoricalActorCriticNet's fc_action / fc_critic on phi,
+// network_heads.py:241-243) in one launch of the small-layer kernel: y0 = x W0^T + b0 [B, O0], y1 = x W1^T + b1 [B, O1].
+// Per-output arithmetic is the single-layer kernel's.  in_features <= 512, batch <= 128.
+DRA_API int dra_linear_fwd_pair(const float* x, const float* w0, const float* b0, float* y0, int out0, const float* w1,
+                                const float* b1, float* y1, int out1, int batch, int in_features, int act, void* stream) {
+  if (!x || !w0 || !w1 || !y0 || !y1 || batch < 1 || batch > 128 || in_features < 1 || in_features > 512 || out0 < 1 || out1 < 1)
+    return DRA_EINVAL;
+  hipStream_t st = dra_stream(stream);
+  LinPtrs q;
+  q.x[0] = x; q.w[0] = w0; q.bias[0] = b0; q.y[0] = y0;
+  q.x[1] = x; q.w[1] = w1; q.bias[1] = b1; q.y[1] = y1;
+  const int omax = out0 > out1 ? out0 : out1;
+  const dim3 grid((omax + 3) / 4, 2, (batch + 31) / 32);
+  const size_t lds = (size_t)(batch < 32 ? batch : 32) * in_features * sizeof(float);
+  const int kv = (in_features + 63) / 64;
+  if (kv <= 1) hipLaunchKernelGGL(linear_gemv_kernel<1>, grid, dim3(256), lds, st, q, batch, in_features, out0, act, out1);
+  else if (kv <= 2) hipLaunchKernelGGL(linear_gemv_kernel<2>, grid, dim3(256), lds, st, q, batch, in_features, out0, act, out1);
+  else if (kv <= 4) hipLaunchKernelGGL(linear_gemv_kernel<4>, grid, dim3(256), lds, st, q, batch, in_features, out0, act, out1);
+  else hipLaunchKernelGGL(linear_gemv_kernel<8>, grid, dim3(256), lds, st, q, batch, in_features, out0, act, out1);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w, const float* const* bias,
                            float* const* y, int batch, int in_features, int out_features, int act, float* workspace,
                            int64_t workspace_floats, void* stream) {
@@ -275,10 +301,10 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
     const dim3 grid((out_features + 3) / 4, nz, (batch + 31) / 32);
     const size_t lds = (size_t)(batch < 32 ? batch : 32) * in_features * sizeof(float);
     const int kv = (in_features + 63) / 64;
-    if (kv <= 1) hipLaunchKernelGGL(linear_gemv_kernel<1>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
-    else if (kv <= 2) hipLaunchKernelGGL(linear_gemv_kernel<2>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
-    else if (kv <= 4) hipLaunchKernelGGL(linear_gemv_kernel<4>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
-    else hipLaunchKernelGGL(linear_gemv_kernel<8>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
+    if (kv <= 1) hipLaunchKernelGGL(linear_gemv_kernel<1>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act, out_features);
+    else if (kv <= 2) hipLaunchKernelGGL(linear_gemv_kernel<2>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act, out_features);
+    else if (kv <= 4) hipLaunchKernelGGL(linear_gemv_kernel<4>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act, out_features);
+    else hipLaunchKernelGGL(linear_gemv_kernel<8>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act, out_features);
     DRA_LAUNCH_CHECK();
     return DRA_OK;
   }

@@ -539,8 +539,15 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         phi = self.phi_body(obs)
         phi_a = self.actor_body(phi)
         phi_v = self.critic_body(phi)
-        logits = self.fc_action(phi_a)
-        v = self.fc_critic(phi_v)
+        if (phi_a is phi_v and phi_a.is_cuda and not torch.is_grad_enabled() and phi_a.dim() == 2 and phi_a.shape[0] <= 128
+                and phi_a.shape[1] <= 512 and type(self.fc_action) is Linear and type(self.fc_critic) is Linear
+                and self.fc_action.fused_act is None and self.fc_critic.fused_act is None):
+            # a rollout step: both heads read the same features -- one launch, the same per-output arithmetic
+            logits, v = ops.linear_fwd_pair(phi_a, self.fc_action.weight, self.fc_action.bias, self.fc_critic.weight,
+                                            self.fc_critic.bias)
+        else:
+            logits = self.fc_action(phi_a)
+            v = self.fc_critic(phi_v)
         # `sampler` (set by a data-parallel agent, dist.py): draws that do not depend on how the environments are spread
         # over ranks; default = one uniform per sample from torch's global generator, inverse CDF inside the fused kernel
         # (the reference's dist.sample() is torch.multinomial on ITS generator: the action stream of a GPU run is not the

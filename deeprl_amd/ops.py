@@ -564,6 +564,19 @@ def _workspace(device, floats):
     return t
 
 
+def linear_fwd_pair(x, w0, b0, w1, b1, act=None):
+    """(x W0^T + b0, x W1^T + b1) in one launch (two heads on the same features; in_features <= 512, batch <= 128)."""
+    x, w0, w1 = _c(x, _f32), _c(w0, _f32), _c(w1, _f32)
+    b0 = None if b0 is None else _c(b0, _f32)
+    b1 = None if b1 is None else _c(b1, _f32)
+    batch, fin = x.shape
+    y0 = torch.empty((batch, w0.shape[0]), dtype=_f32, device=x.device)
+    y1 = torch.empty((batch, w1.shape[0]), dtype=_f32, device=x.device)
+    lib.dra_linear_fwd_pair(ptr(x), ptr(w0), ptr(b0), ptr(y0), int(w0.shape[0]), ptr(w1), ptr(b1), ptr(y1), int(w1.shape[0]),
+                            batch, fin, ACT[act], stream_ptr())
+    return y0, y1
+
+
 def linear_fwd(xs, ws, bs, act=None):
     nz = len(xs)
     xs = [_c(x, _f32) for x in xs]
