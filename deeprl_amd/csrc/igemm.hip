@@ -176,12 +176,29 @@ linear_gemv_kernel(LinPtrs q, int B, int K, int O_, int act, int O1) {
   __syncthreads();
   if (o >= O) return;
   float* __restrict__ out = q.y[z];
-  for (int b = 0; b < nb; ++b) {
-    float part = 0.f;
+  // eight input rows per round: their wave butterflies are independent chains of six cross-lane moves each (~100 cycles apiece),
+  // interleaved by offset -- one row at a time the kernel spent ~0.45 us per input row waiting for them (rocprofv3: 7.2 us at 8
+  // rows, 15.5 us at 16, profiles/r04o_kernel_stats_ppo_pixel_8.txt, r04z_kernel_stats_a2c_pixel_16.txt).  Same sums, same order.
+  for (int bb = 0; bb < nb; bb += 8) {
+    float part[8];
 #pragma unroll
-    for (int i = 0; i < KV; ++i) part += (lane + 64 * i < K) ? s_x[b * K + lane + 64 * i] * w[i] : 0.f;
-    part = wave_sum(part);
-    if (lane == 0) out[(int64_t)(b0 + b) * O + o] = act_apply(part + bias, act);
+    for (int u = 0; u < 8; ++u) {
+      const int b = min(bb + u, nb - 1);
+      float p = 0.f;
+#pragma unroll
+      for (int i = 0; i < KV; ++i) p += (lane + 64 * i < K) ? s_x[b * K + lane + 64 * i] * w[i] : 0.f;
+      part[u] = p;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) part[u] += __shfl_xor(part[u], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (bb + u < nb) out[(int64_t)(b0 + bb + u) * O + o] = act_apply(part[u] + bias, act);
+    }
   }
 }
 
@@ -224,16 +241,26 @@ linear_gemv_rows_kernel(LinPtrs q, int B, int K, int O, int act) {
 #pragma unroll
       for (int i = 0; i < R; ++i) xv[u][i] = x4[(int64_t)b * nv + (vi[i] >= 0 ? vi[i] : 0)];
     }
+    float acc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      float acc = 0.f;
+      float a_ = 0.f;
 #pragma unroll
       for (int i = 0; i < R; ++i) {
         const float4 a = wv[i], xx = xv[u][i];
-        if (vi[i] >= 0) acc += (a.x * xx.x + a.y * xx.y) + (a.z * xx.z + a.w * xx.w);
+        if (vi[i] >= 0) a_ += (a.x * xx.x + a.y * xx.y) + (a.z * xx.z + a.w * xx.w);
       }
-      acc = wave_sum(acc);
-      if (lane == 0 && bb + u < nb) s_part[bb + u][wave] = acc;
+      acc[u] = a_;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {      // eight independent butterflies, interleaved by offset
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += __shfl_xor(acc[u], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (bb + u < nb) s_part[bb + u][wave] = acc[u];
     }
   }
   __syncthreads();
