@@ -141,14 +141,11 @@ linear_finish_kernel(LinPtrs q, const float* __restrict__ slabs, int ksplit, int
 // workgroup stages up to 32 input rows in LDS once (<= 64 KB) and each of its 4 waves owns one output: the weight row
 // sits in registers (<= 8 floats per lane, coalesced 2 KB reads), one wave-level dot product per input row.
 // grid (ceil(O / 4), nz, ceil(B / 32)).  Summation order per output: lane-strided partial sums, then the wave butterfly.
-// O1: output count of net z = 1 (two heads of different width on the same features in ONE launch: dra_linear_fwd_pair); every
-// other z has O outputs.
 template <int KV>   // float per lane: ceil(K / 64)
 __global__ void __launch_bounds__(256)
-linear_gemv_kernel(LinPtrs q, int B, int K, int O_, int act, int O1) {
+linear_gemv_kernel(LinPtrs q, int B, int K, int O, int act) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];   // [rows][K]
   const int z = blockIdx.y, b0 = blockIdx.z * 32, nb = min(32, B - b0);
-  const int O = (z == 1) ? O1 : O_;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int o = blockIdx.x * 4 + wave;
   const float* __restrict__ wrow = q.w[z] + (int64_t)min(o, O - 1) * K;
@@ -291,24 +288,68 @@ static int gemv_enabled() {
 }
 
 // Two linear heads of different width on the SAME input (CategoricalActorCriticNet's fc_action / fc_critic on phi,
-// network_heads.py:241-243) in one launch of the small-layer kernel: y0 = x W0^T + b0 [B, O0], y1 = x W1^T + b1 [B, O1].
-// Per-output arithmetic is the single-layer kernel's.  in_features <= 512, batch <= 128.
+// network_heads.py:241-243) in one launch: y0 = x W0^T + b0 [B, O0], y1 = x W1^T + b1 [B, O1].  in_features <= 512, batch <= 128.
+// A rollout step's heads are a few thousand multiply-adds: everything is latency.  One WAVE per input row: its 512 features sit in
+// 8 registers per lane (k = lane + 64 i, the small-layer kernel's own assignment), the weight rows of up to eight outputs are
+// requested together with them -- one memory round trip, no LDS, no barrier -- then the eight dot products and their wave
+// butterflies run interleaved.  Per-output arithmetic (lane-strided partial sums in i order, then the butterfly) is exactly
+// linear_gemv_kernel's: the update's forward through the two Linear modules reproduces these values bit for bit.
+// (The staging form took 12.7 us for 16 rows x 5 outputs, 15 % of an A2C agent step: profiles/r04ab_kernel_stats_a2c_pixel_16.txt.)
+__global__ void __launch_bounds__(256)
+linear_heads_rows_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ b0,
+                         float* __restrict__ y0, int O0, const float* __restrict__ w1, const float* __restrict__ b1,
+                         float* __restrict__ y1, int O1, int B, int K, int act) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  float xv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xv[i] = (lane + 64 * i < K) ? x[(int64_t)b * K + lane + 64 * i] : 0.f;
+  const int OT = O0 + O1;
+  for (int oc = 0; oc < OT; oc += 8) {
+    float wv[8][8], bias[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int o = min(oc + u, OT - 1);
+      const float* __restrict__ row = o < O0 ? w0 + (int64_t)o * K : w1 + (int64_t)(o - O0) * K;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wv[u][i] = (lane + 64 * i < K) ? row[lane + 64 * i] : 0.f;
+      const float* __restrict__ bp = o < O0 ? b0 : b1;
+      bias[u] = bp ? bp[o < O0 ? o : o - O0] : 0.f;
+    }
+    float part[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float p = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p += (lane + 64 * i < K) ? xv[i] * wv[u][i] : 0.f;
+      part[u] = p;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) part[u] += __shfl_xor(part[u], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = oc + u;
+        if (o < OT) {
+          const float v = act_apply(part[u] + bias[u], act);
+          if (o < O0) y0[(int64_t)b * O0 + o] = v;
+          else y1[(int64_t)b * O1 + (o - O0)] = v;
+        }
+      }
+    }
+  }
+}
+
 DRA_API int dra_linear_fwd_pair(const float* x, const float* w0, const float* b0, float* y0, int out0, const float* w1,
                                 const float* b1, float* y1, int out1, int batch, int in_features, int act, void* stream) {
   if (!x || !w0 || !w1 || !y0 || !y1 || batch < 1 || batch > 128 || in_features < 1 || in_features > 512 || out0 < 1 || out1 < 1)
     return DRA_EINVAL;
-  hipStream_t st = dra_stream(stream);
-  LinPtrs q;
-  q.x[0] = x; q.w[0] = w0; q.bias[0] = b0; q.y[0] = y0;
-  q.x[1] = x; q.w[1] = w1; q.bias[1] = b1; q.y[1] = y1;
-  const int omax = out0 > out1 ? out0 : out1;
-  const dim3 grid((omax + 3) / 4, 2, (batch + 31) / 32);
-  const size_t lds = (size_t)(batch < 32 ? batch : 32) * in_features * sizeof(float);
-  const int kv = (in_features + 63) / 64;
-  if (kv <= 1) hipLaunchKernelGGL(linear_gemv_kernel<1>, grid, dim3(256), lds, st, q, batch, in_features, out0, act, out1);
-  else if (kv <= 2) hipLaunchKernelGGL(linear_gemv_kernel<2>, grid, dim3(256), lds, st, q, batch, in_features, out0, act, out1);
-  else if (kv <= 4) hipLaunchKernelGGL(linear_gemv_kernel<4>, grid, dim3(256), lds, st, q, batch, in_features, out0, act, out1);
-  else hipLaunchKernelGGL(linear_gemv_kernel<8>, grid, dim3(256), lds, st, q, batch, in_features, out0, act, out1);
+  hipLaunchKernelGGL(linear_heads_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), x, w0, b0, y0, out0, w1, b1,
+                     y1, out1, batch, in_features, act);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -328,10 +369,10 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
     const dim3 grid((out_features + 3) / 4, nz, (batch + 31) / 32);
     const size_t lds = (size_t)(batch < 32 ? batch : 32) * in_features * sizeof(float);
     const int kv = (in_features + 63) / 64;
-    if (kv <= 1) hipLaunchKernelGGL(linear_gemv_kernel<1>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act, out_features);
-    else if (kv <= 2) hipLaunchKernelGGL(linear_gemv_kernel<2>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act, out_features);
-    else if (kv <= 4) hipLaunchKernelGGL(linear_gemv_kernel<4>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act, out_features);
-    else hipLaunchKernelGGL(linear_gemv_kernel<8>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act, out_features);
+    if (kv <= 1) hipLaunchKernelGGL(linear_gemv_kernel<1>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
+    else if (kv <= 2) hipLaunchKernelGGL(linear_gemv_kernel<2>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
+    else if (kv <= 4) hipLaunchKernelGGL(linear_gemv_kernel<4>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
+    else hipLaunchKernelGGL(linear_gemv_kernel<8>, grid, dim3(256), lds, st, q, batch, in_features, out_features, act);
     DRA_LAUNCH_CHECK();
     return DRA_OK;
   }

@@ -893,6 +893,23 @@ def test_categorical_policy_kernels_vs_torch(dev, b, a):
     np.testing.assert_allclose(lp_s.cpu().numpy(), np.log(p[np.arange(b), got]), rtol=1e-5, atol=3e-6)
 
 
+@pytest.mark.parametrize("b,k,o0,o1", [(16, 512, 4, 1), (8, 512, 18, 1), (1, 512, 6, 1), (33, 64, 3, 2), (128, 400, 9, 9), (5, 17, 1, 1)])
+def test_linear_fwd_pair_equals_two_layers(dev, b, k, o0, o1):
+    """dra_linear_fwd_pair (both heads of the actor-critic nets on the shared features in one launch, used in rollout steps)
+    == dra_linear_fwd of each head on its own (what the update's forward runs through the two Linear modules): bit for bit."""
+    from deeprl_amd import ops
+    rs = np.random.RandomState(b + 3 * k + 5 * o0 + 7 * o1)
+    x = f32(rs.standard_normal((b, k)).astype(np.float32), dev)
+    w0, w1 = f32(rs.standard_normal((o0, k)).astype(np.float32), dev), f32(rs.standard_normal((o1, k)).astype(np.float32), dev)
+    b0, b1 = f32(rs.standard_normal(o0).astype(np.float32), dev), f32(rs.standard_normal(o1).astype(np.float32), dev)
+    y0, y1 = ops.linear_fwd_pair(x, w0, b0, w1, b1)
+    r0 = ops.linear_fwd([x], [w0], [b0])[0]
+    r1 = ops.linear_fwd([x], [w1], [b1])[0]
+    assert torch.equal(y0, r0) and torch.equal(y1, r1)
+    ref = (x.double().cpu() @ w0.double().cpu().T + b0.double().cpu()).numpy()
+    _scale_close(y0.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("b,k,o,act", [(16, 512, 4, None), (16, 512, 1, None), (80, 512, 18, None), (1, 17, 64, "tanh"),
                                       (64, 64, 64, "relu"), (33, 400, 300, "relu"), (128, 512, 204, None), (5, 3, 2, None),
                                       (8, 3136, 512, "relu"), (16, 3136, 512, "relu"), (5, 1024, 37, None), (9, 4096, 16, "tanh"),
