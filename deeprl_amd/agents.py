@@ -1205,7 +1205,11 @@ class A2CAgent(BaseAgent):
                                                 prediction['v'].detach(), adv.reshape(-1, 1), ret.reshape(-1, 1),
                                                 config.entropy_weight, config.value_loss_weight)
         self._fused.zero_grad()
-        torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']], [g_lp, g_ent, g_v])
+        # (one batched forward: every parameter is used once -> the layers write their gradients in place, nets.direct_param_grads;
+        # data parallel keeps autograd's accumulation: its post-accumulate hooks start the early gradient exchange)
+        from .nets import direct_param_grads
+        with direct_param_grads(not self.dp.active):
+            torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']], [g_lp, g_ent, g_v])
         return self._learn_apply(out4) if apply else out4
 
     def step(self):
@@ -1490,8 +1494,10 @@ class PPOAgent(BaseAgent):
             self._fused.zero_grad()
             dp.set_weight(weight)       # (the fc4 segment of the exchange goes out from inside the backward pass: dist.py)
             if prediction is not None:
-                torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']],
-                                        [g_lp, g_ent, g_v])
+                from .nets import direct_param_grads
+                with direct_param_grads(not dp.active):       # (one forward per minibatch: see A2CAgent._learn)
+                    torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']],
+                                            [g_lp, g_ent, g_v])
             dp.sum_grads(self._fused.flat.grad, weight)
             if self.grad_hook is not None:
                 self.grad_hook(self._fused.flat.grad)

@@ -11,6 +11,8 @@ altogether for the DQN family.
 """
 import math
 
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -38,6 +40,31 @@ def layer_init(layer, w_scale=1.0):
 
 
 # ----------------------------------------------------------------------------------------------------
+# Parameter gradients written IN PLACE.  autograd hands a parameter's gradient to AccumulateGrad, which ADDS it to the existing
+# .grad -- one elementwise launch per parameter (12 per update of the actor-critic pixel nets: 9 % of an A2C agent step's kernel
+# time, profiles/r04ab_kernel_stats_a2c_pixel_16.txt), and for fc4 a 6.4 MB read-modify-write of a buffer that was just zeroed.
+# Inside `with direct_param_grads():` the layer Functions below write their weight / bias gradients straight into the
+# parameters' .grad (the views of the optimizer's flat gradient buffer) and return None for them.  That is an OVERWRITE: only
+# for a backward pass in which every such parameter is used ONCE (A2C's batched update, a PPO minibatch) -- 0 + g == g, so the
+# result is what the accumulation gives.
+_DIRECT = [False]
+
+
+@contextlib.contextmanager
+def direct_param_grads(enable=True):
+    prev = _DIRECT[0]
+    _DIRECT[0] = bool(enable)
+    try:
+        yield
+    finally:
+        _DIRECT[0] = prev
+
+
+def _grad_slot(p):
+    g = None if p is None else p.grad
+    return g if (g is not None and g.dtype == torch.float32 and g.is_cuda and g.shape == p.shape) else None
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, act):
@@ -45,6 +72,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, y)
         ctx.act = act
         ctx.has_bias = b is not None
+        ctx.params = (w, b)             # (the Parameter objects themselves: their .grad is where a direct write goes)
         return y
 
     @staticmethod
@@ -52,7 +80,12 @@ class _LinearFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         dy = dy.contiguous()
         dpre = ops.act_bwd(dy, y, ctx.act) if ctx.act else dy
-        dw, db = ops.linear_bwd_w(dpre, x, want_bias=ctx.has_bias)
+        gw, gb = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if _DIRECT[0] else (None, None)
+        if gw is not None and gw.is_contiguous() and (not ctx.has_bias or (gb is not None and gb.is_contiguous())):
+            ops.linear_bwd_w(dpre, x, dw=gw, db=gb if ctx.has_bias else None, want_bias=ctx.has_bias)
+            dw = db = None
+        else:
+            dw, db = ops.linear_bwd_w(dpre, x, want_bias=ctx.has_bias)
         dx = ops.linear_bwd_x(dpre, w) if ctx.needs_input_grad[0] else None
         return dx, dw, db, None
 
@@ -147,6 +180,7 @@ class _ConvKocFn(torch.autograd.Function):
         y = ops.conv_fwd_koc(layer, [x], [wt], [b], act="relu", u8_coef=u8_coef)[0]
         ctx.save_for_backward(x, w, y)
         ctx.layer, ctx.u8_coef = layer, u8_coef
+        ctx.params = (w, b)
         return y
 
     @staticmethod
@@ -161,7 +195,12 @@ class _ConvKocFn(torch.autograd.Function):
             (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD)
         dx, slabs, n_slabs, stride = ops.conv_bwd_fused_koc(layer, dpre, x, w.permute(1, 2, 3, 0), ksplit=_ConvKocFn.KSPLIT,
                                                             u8_coef=ctx.u8_coef, variant=variant)
-        flat = torch.empty(stride, dtype=torch.float32, device=w.device)
+        # direct_param_grads(): FlatParams lays [weight (KOC) | bias] out back to back, which is a slab's own layout -- the fold
+        # writes the layer's gradient segment of the optimizer's flat buffer itself
+        gw, gb = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if _DIRECT[0] else (None, None)
+        direct = (gw is not None and gb is not None and stride == n_w + oc and gw.permute(1, 2, 3, 0).is_contiguous()
+                  and gb.is_contiguous() and gb.data_ptr() == gw.data_ptr() + 4 * n_w and gw.data_ptr() % 16 == 0)
+        flat = torch.as_strided(gw, (stride,), (1,)) if direct else torch.empty(stride, dtype=torch.float32, device=w.device)
         if n_slabs > 32 and stride % 4 == 0:
             # one slab per (sample, row chunk): hundreds of slabs -- the segmented fold keeps 160 of them in flight per element
             # (dra_grad_sqnorm's per-element serial walk is for the <= 64 slabs of the fixed split-K kernels)
@@ -170,6 +209,8 @@ class _ConvKocFn(torch.autograd.Function):
         else:
             partials = torch.empty(ops.norm_partials(), dtype=torch.float64, device=w.device)
             ops.grad_sqnorm(flat, partials, slabs=slabs, n_slabs=n_slabs, slab_stride=stride)  # fixed-order slab fold
+        if direct:
+            return (dx if ctx.needs_input_grad[0] and layer > 1 else None), None, None, None, None
         dw = flat[:n_w].view(c, kh, kw, oc).permute(3, 0, 1, 2)
         db = flat[n_w:n_w + oc]
         return (dx if ctx.needs_input_grad[0] and layer > 1 else None), dw, db, None, None

@@ -804,6 +804,50 @@ def test_onpolicy_device_env_equals_host_emulators(dra, monkeypatch, kind):
         assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
 
 
+@pytest.mark.parametrize("kind", ["a2c", "ppo"])
+def test_in_place_parameter_gradients_equal_autograd_accumulation(dra, monkeypatch, kind):
+    """nets.direct_param_grads (round 4): inside an A2C update / a PPO minibatch the layer Functions write their weight and bias
+    gradients straight into the optimizer's flat gradient buffer and return None for them, instead of twelve AccumulateGrad adds
+    onto the zeroed buffer.  0 + g == g: the agents end on bit-identical parameters with the mechanism switched off."""
+    d = dra
+    import contextlib
+    import deeprl_amd.agents as agents_mod
+    import deeprl_amd.nets as nets_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    outs = []
+    for direct in (True, False):
+        if not direct:
+            monkeypatch.setattr(nets_mod, "direct_param_grads", lambda enable=True: contextlib.nullcontext())
+        cfg = d.Config()
+        cfg.merge(dict(game="synthetic-atari", num_workers=4, log_level=0, tag="dg%d" % direct, device_env=True))
+        cfg.task_fn = lambda: d.Task(cfg.game, num_envs=cfg.num_workers, seed=31, synthetic_done_period=9)
+        cfg.eval_env = d.Task(cfg.game, seed=3)
+        cfg.network_fn = lambda: d.CategoricalActorCriticNet(cfg.state_dim, cfg.action_dim, d.NatureConvBody())
+        cfg.state_normalizer, cfg.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
+        cfg.discount, cfg.use_gae, cfg.entropy_weight = 0.99, True, 0.01
+        if kind == "a2c":
+            cfg.optimizer_fn = lambda p: torch.optim.RMSprop(p, lr=1e-4, alpha=0.99, eps=1e-5)
+            cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 1.0, 5, 5
+            cls, n = d.A2CAgent, 5
+        else:
+            cfg.optimizer_fn = lambda p: torch.optim.Adam(p, lr=2.5e-4)
+            cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 0.95, 16, 0.5
+            cfg.optimization_epochs, cfg.mini_batch_size, cfg.ppo_ratio_clip, cfg.shared_repr = 2, 16, 0.1, True
+            cfg.max_steps, cfg.log_interval, cfg.target_kl = 1e6, 10 ** 9, 0.01
+            cls, n = d.PPOAgent, 4
+        d.random_seed(21)
+        torch.manual_seed(22)
+        agent = cls(cfg)
+        for _ in range(n):
+            agent.step()
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()})
+        agent.close()
+    for k in outs[0]:
+        assert np.isfinite(outs[0][k]).all()
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
 @pytest.mark.parametrize("kind,per,chain", [("dqn", True, 2), ("c51", True, 2), ("dqn", True, 0), ("dqn", False, 2), ("c51", False, 2)])
 def test_per_async_pipeline_equals_in_order_with_random_actions(dra, monkeypatch, kind, per, chain):
     """PrioritizedReplay inside the two-stream pipeline (config.async_actor=True: actor transitions of step t+1 on their own
