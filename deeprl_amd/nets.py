@@ -60,6 +60,20 @@ def direct_param_grads(enable=True):
         _DIRECT[0] = prev
 
 
+# ReLU masks applied by the PRODUCER of a gradient.  A fused-ReLU layer's backward starts with dpre = dy * (y > 0) -- a launch of
+# its own in front of every conv layer's backward.  The layer ABOVE knows the same mask (its input x IS that y) and its
+# input-gradient kernel has an epilogue for it (xact): it hands down dx * (x > 0) and leaves the tensor's address here; the layer
+# below skips its own mask when the gradient it receives is that very tensor (anything autograd copied or accumulated in between
+# has another address and is masked as before).  (y > 0) in {0, 1}: the values are the same either way.
+_MASKED = [0]
+
+
+def _already_masked(dy):
+    hit = _MASKED[0] != 0 and dy.data_ptr() == _MASKED[0]
+    _MASKED[0] = 0
+    return hit
+
+
 def _grad_slot(p):
     g = None if p is None else p.grad
     return g if (g is not None and g.dtype == torch.float32 and g.is_cuda and g.shape == p.shape) else None
@@ -67,10 +81,11 @@ def _grad_slot(p):
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, act):
+    def forward(ctx, x, w, b, act, x_relu=False):
         y = ops.linear_fwd([x], [w], [b], act=act)[0]
         ctx.save_for_backward(x, w, y)
         ctx.act = act
+        ctx.x_relu = bool(x_relu)       # x is the output of a fused-ReLU layer (NatureConvBody: conv3 -> fc4)
         ctx.has_bias = b is not None
         ctx.params = (w, b)             # (the Parameter objects themselves: their .grad is where a direct write goes)
         return y
@@ -86,8 +101,14 @@ class _LinearFn(torch.autograd.Function):
             dw = db = None
         else:
             dw, db = ops.linear_bwd_w(dpre, x, want_bias=ctx.has_bias)
-        dx = ops.linear_bwd_x(dpre, w) if ctx.needs_input_grad[0] else None
-        return dx, dw, db, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.x_relu:
+                dx = ops.linear_bwd_x(dpre, w, xact=x, act="relu")
+                _MASKED[0] = dx.data_ptr()
+            else:
+                dx = ops.linear_bwd_x(dpre, w)
+        return dx, dw, db, None, None
 
 
 class _CategoricalFn(torch.autograd.Function):
@@ -124,10 +145,10 @@ def categorical_policy(logits, action=None, sampler=None):
     return action, lp.unsqueeze(-1), ent.unsqueeze(-1)
 
 
-def linear(x, w, b, act=None):
+def linear(x, w, b, act=None, x_relu=False):
     x = x.float() if x.dtype != torch.float32 else x
     lead = x.shape[:-1]
-    y = _LinearFn.apply(x.reshape(-1, x.shape[-1]).contiguous(), w, b, act)
+    y = _LinearFn.apply(x.reshape(-1, x.shape[-1]).contiguous(), w, b, act, x_relu)
     return y.reshape(lead + (w.shape[0],))
 
 
@@ -175,26 +196,32 @@ class _ConvKocFn(torch.autograd.Function):
     KSPLIT = 16
 
     @staticmethod
-    def forward(ctx, x, w, b, layer, u8_coef):
+    def forward(ctx, x, w, b, layer, u8_coef, x_relu=False):
         wt = w.permute(1, 2, 3, 0)                      # the contiguous KOC storage
         y = ops.conv_fwd_koc(layer, [x], [wt], [b], act="relu", u8_coef=u8_coef)[0]
         ctx.save_for_backward(x, w, y)
         ctx.layer, ctx.u8_coef = layer, u8_coef
         ctx.params = (w, b)
+        ctx.x_relu = bool(x_relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         layer = ctx.layer
-        dpre = ops.act_bwd(dy.contiguous(), y, "relu")
+        dy = dy.contiguous()
+        dpre = dy if _already_masked(dy) else ops.act_bwd(dy, y, "relu")
         oc, c, kh, kw = w.shape
         n_w = w.numel()
         # per-(sample, row chunk) slabs pay off at DQN batch sizes; large batches use the fixed split-K weight gradient
         variant = (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD | ops.VAR_ONESHOT_WGRAD) if x.shape[0] <= _ONESHOT_WGRAD_MAX_BATCH else \
             (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD)
+        # layers 2 / 3: the input is the layer below's fused-ReLU output (NatureConvBody) -- the input-gradient epilogue masks
+        mask_below = layer > 1 and ctx.needs_input_grad[0] and getattr(ctx, "x_relu", False)
         dx, slabs, n_slabs, stride = ops.conv_bwd_fused_koc(layer, dpre, x, w.permute(1, 2, 3, 0), ksplit=_ConvKocFn.KSPLIT,
-                                                            u8_coef=ctx.u8_coef, variant=variant)
+                                                            u8_coef=ctx.u8_coef, variant=variant, xact=x if mask_below else None)
+        if mask_below:
+            _MASKED[0] = dx.data_ptr()
         # direct_param_grads(): FlatParams lays [weight (KOC) | bias] out back to back, which is a slab's own layout -- the fold
         # writes the layer's gradient segment of the optimizer's flat buffer itself
         gw, gb = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if _DIRECT[0] else (None, None)
@@ -210,19 +237,20 @@ class _ConvKocFn(torch.autograd.Function):
             partials = torch.empty(ops.norm_partials(), dtype=torch.float64, device=w.device)
             ops.grad_sqnorm(flat, partials, slabs=slabs, n_slabs=n_slabs, slab_stride=stride)  # fixed-order slab fold
         if direct:
-            return (dx if ctx.needs_input_grad[0] and layer > 1 else None), None, None, None, None
+            return (dx if ctx.needs_input_grad[0] and layer > 1 else None), None, None, None, None, None
         dw = flat[:n_w].view(c, kh, kw, oc).permute(3, 0, 1, 2)
         db = flat[n_w:n_w + oc]
-        return (dx if ctx.needs_input_grad[0] and layer > 1 else None), dw, db, None, None
+        return (dx if ctx.needs_input_grad[0] and layer > 1 else None), dw, db, None, None, None
 
 
 class Linear(nn.Linear):
     """nn.Linear whose forward / backward are the HIP contractions; `fused_act` folds the body's
     gate into the GEMM epilogue."""
     fused_act = None
+    input_is_relu = False       # set by a body whose previous layer ends in a fused ReLU (see _MASKED)
 
     def forward(self, x):
-        return linear(x, self.weight, self.bias, self.fused_act)
+        return linear(x, self.weight, self.bias, self.fused_act, self.input_is_relu)
 
 
 class Conv2d(nn.Conv2d):
@@ -241,7 +269,7 @@ class Conv2d(nn.Conv2d):
         if x.dtype == torch.uint8 and u8_coef is None:
             raise TypeError("uint8 input to a convolution needs a normaliser (RescaleNormalizer marks it)")
         if self.weight.permute(1, 2, 3, 0).is_contiguous():     # KOC storage (FlatParams): one-round-trip kernels
-            return _ConvKocFn.apply(x.contiguous(), self.weight, self.bias, layer, u8_coef)
+            return _ConvKocFn.apply(x.contiguous(), self.weight, self.bias, layer, u8_coef, getattr(self, "input_is_relu", False))
         return _ConvFn.apply(x.contiguous(), self.weight, self.bias, layer, u8_coef)
 
 
@@ -314,6 +342,10 @@ class NatureConvBody(nn.Module):
         else:
             self.fc4 = layer_init(Linear(7 * 7 * 64, self.feature_dim))
         self.fc4.fused_act = "relu"
+        # conv2 / conv3 / fc4 read the fused-ReLU output of the layer below: their input-gradient kernels apply its mask (see _MASKED)
+        self.conv2.input_is_relu = self.conv3.input_is_relu = True
+        if not noisy_linear:
+            self.fc4.input_is_relu = True
         self.noisy_linear = noisy_linear
 
     def reset_noise(self):

@@ -458,7 +458,7 @@ def conv_bwd_fused(layer, dy, x, wt=None, xact=None, ksplit=16, u8_coef=None, ac
     return v[:, :oc * kk], v[:, oc * kk:oc * kk + oc], dx, slabs
 
 
-def conv_bwd_fused_koc(layer, dy, x, wt, ksplit=16, u8_coef=None, variant=0):
+def conv_bwd_fused_koc(layer, dy, x, wt, ksplit=16, u8_coef=None, variant=0, xact=None):
     """Production form of conv_bwd_fused (generic autograd path): dy = gradient w.r.t. this layer's pre-activation,
     wt = KOC weights.  One launch -> (dx or None, slab buffer [n_slabs * stride], n_slabs, stride); slab s holds
     dWt [K*OC] then db [OC]; the caller folds them (grad_sqnorm)."""
@@ -472,8 +472,8 @@ def conv_bwd_fused_koc(layer, dy, x, wt, ksplit=16, u8_coef=None, variant=0):
     if stride != oc * kk + oc:
         slabs.view(n_slabs, stride)[:, oc * kk + oc:].zero_()      # alignment gap is folded too: keep it finite
     dx = torch.empty((batch, c, h, h), dtype=_f32, device=x.device) if layer > 1 else None
-    lib.dra_conv_bwd_fused(layer, ptr(_c(dy, _f32)), ptr(_c(x)), ptr(_c(wt, _f32)), None, ptr(slabs),
-                           ctypes.c_void_p(slabs.data_ptr() + 4 * oc * kk), stride, ksplit, ptr(dx), batch, int(is_u8),
+    lib.dra_conv_bwd_fused(layer, ptr(_c(dy, _f32)), ptr(_c(x)), ptr(_c(wt, _f32)), ptr(None if xact is None else _c(xact, _f32)),
+                           ptr(slabs), ctypes.c_void_p(slabs.data_ptr() + 4 * oc * kk), stride, ksplit, ptr(dx), batch, int(is_u8),
                            float(u8_coef if is_u8 else 1.0), ACT["relu"], int(variant), stream_ptr())
     return dx, slabs, n_slabs, stride
 
