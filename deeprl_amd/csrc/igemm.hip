@@ -288,7 +288,7 @@ static int gemv_enabled() {
 }
 
 // Two linear heads of different width on the SAME input (CategoricalActorCriticNet's fc_action / fc_critic on phi,
-// network_heads.py:241-243) in one launch: y0 = x W0^T + b0 [B, O0], y1 = x W1^T + b1 [B, O1].  in_features <= 512, batch <= 128.
+// network_heads.py:241-243) in one launch: y0 = x W0^T + b0 [B, O0], y1 = x W1^T + b1 [B, O1].  in_features <= 512.
 // A rollout step's heads are a few thousand multiply-adds: everything is latency.  One WAVE per input row: its 512 features sit in
 // 8 registers per lane (k = lane + 64 i, the small-layer kernel's own assignment), the weight rows of up to eight outputs are
 // requested together with them -- one memory round trip, no LDS, no barrier -- then the eight dot products and their wave
@@ -346,7 +346,7 @@ linear_heads_rows_kernel(const float* __restrict__ x, const float* __restrict__ 
 
 DRA_API int dra_linear_fwd_pair(const float* x, const float* w0, const float* b0, float* y0, int out0, const float* w1,
                                 const float* b1, float* y1, int out1, int batch, int in_features, int act, void* stream) {
-  if (!x || !w0 || !w1 || !y0 || !y1 || batch < 1 || batch > 128 || in_features < 1 || in_features > 512 || out0 < 1 || out1 < 1)
+  if (!x || !w0 || !w1 || !y0 || !y1 || batch < 1 || batch > 65536 || in_features < 1 || in_features > 512 || out0 < 1 || out1 < 1)
     return DRA_EINVAL;
   hipLaunchKernelGGL(linear_heads_rows_kernel, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), x, w0, b0, y0, out0, w1, b1,
                      y1, out1, batch, in_features, act);

@@ -111,6 +111,39 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+class _LinearPairFn(torch.autograd.Function):
+    """Two heads on the same features (fc_action / fc_critic of the actor-critic nets on phi): forward as ONE launch
+    (ops.linear_fwd_pair: one wave per input row, bit-identical with two _LinearFn), backward = the two layers' own kernels,
+    d phi = d phi_a + d phi_c as autograd's accumulation forms it."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1):
+        y0, y1 = ops.linear_fwd_pair(x, w0, b0, w1, b1)
+        ctx.save_for_backward(x, w0, w1)
+        ctx.params = (w0, b0, w1, b1)
+        return y0, y1
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        x, w0, w1 = ctx.saved_tensors
+        outs, dx = [], None
+        for g, w, pw, pb in ((g0, w0, ctx.params[0], ctx.params[1]), (g1, w1, ctx.params[2], ctx.params[3])):
+            if g is None:
+                outs += [None, None]
+                continue
+            g = g.contiguous()
+            gw, gb = (_grad_slot(pw), _grad_slot(pb)) if _DIRECT[0] else (None, None)
+            if gw is not None and gw.is_contiguous() and gb is not None and gb.is_contiguous():
+                ops.linear_bwd_w(g, x, dw=gw, db=gb, want_bias=True)
+                outs += [None, None]
+            else:
+                outs += list(ops.linear_bwd_w(g, x, want_bias=True))
+            if ctx.needs_input_grad[0]:
+                d = ops.linear_bwd_x(g, w)
+                dx = d if dx is None else dx + d
+        return (dx,) + tuple(outs)
+
+
 class _CategoricalFn(torch.autograd.Function):
     """Categorical(logits) -> (log_pi_a, entropy) for given actions as one kernel each way (losses.hip K12)."""
 
@@ -612,12 +645,16 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         phi = self.phi_body(obs)
         phi_a = self.actor_body(phi)
         phi_v = self.critic_body(phi)
-        if (phi_a is phi_v and phi_a.is_cuda and not torch.is_grad_enabled() and phi_a.dim() == 2 and phi_a.shape[0] <= 128
-                and phi_a.shape[1] <= 512 and type(self.fc_action) is Linear and type(self.fc_critic) is Linear
-                and self.fc_action.fused_act is None and self.fc_critic.fused_act is None):
-            # a rollout step: both heads read the same features -- one launch, the same per-output arithmetic
-            logits, v = ops.linear_fwd_pair(phi_a, self.fc_action.weight, self.fc_action.bias, self.fc_critic.weight,
-                                            self.fc_critic.bias)
+        if (phi_a is phi_v and phi_a.is_cuda and phi_a.dim() == 2 and phi_a.shape[1] <= 512 and phi_a.dtype == torch.float32
+                and type(self.fc_action) is Linear and type(self.fc_critic) is Linear and self.fc_action.bias is not None
+                and self.fc_critic.bias is not None and self.fc_action.fused_act is None and self.fc_critic.fused_act is None):
+            # both heads read the same features: one launch, the same per-output arithmetic (rollout steps and updates alike)
+            if torch.is_grad_enabled() and (phi_a.requires_grad or self.fc_action.weight.requires_grad):
+                logits, v = _LinearPairFn.apply(phi_a.contiguous(), self.fc_action.weight, self.fc_action.bias,
+                                                self.fc_critic.weight, self.fc_critic.bias)
+            else:
+                logits, v = ops.linear_fwd_pair(phi_a, self.fc_action.weight, self.fc_action.bias, self.fc_critic.weight,
+                                                self.fc_critic.bias)
         else:
             logits = self.fc_action(phi_a)
             v = self.fc_critic(phi_v)

@@ -565,7 +565,7 @@ def _workspace(device, floats):
 
 
 def linear_fwd_pair(x, w0, b0, w1, b1, act=None):
-    """(x W0^T + b0, x W1^T + b1) in one launch (two heads on the same features; in_features <= 512, batch <= 128)."""
+    """(x W0^T + b0, x W1^T + b1) in one launch (two heads on the same features; in_features <= 512)."""
     x, w0, w1 = _c(x, _f32), _c(w0, _f32), _c(w1, _f32)
     b0 = None if b0 is None else _c(b0, _f32)
     b1 = None if b1 is None else _c(b1, _f32)

@@ -207,7 +207,7 @@ int dra_linear_fwd(int nz, const float* const* x, const float* const* w, const f
                    int batch, int in_features, int out_features, int act, float* workspace, int64_t workspace_floats,
                    void* stream);
 /* two heads of different width on the same features in one launch (network_heads.py:241-243: fc_action / fc_critic of the
- * actor-critic nets on phi); in_features <= 512, batch <= 128; same per-output arithmetic as dra_linear_fwd */
+ * actor-critic nets on phi), one wave per input row; in_features <= 512; same per-output arithmetic as dra_linear_fwd */
 int dra_linear_fwd_pair(const float* x, const float* w0, const float* b0, float* y0, int out0, const float* w1, const float* b1,
                         float* y1, int out1, int batch, int in_features, int act, void* stream);
 /* raw split-K partial sums [nz][ksplit][batch][out] (no bias / activation): the consumer reduces them. */
