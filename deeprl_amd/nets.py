@@ -126,18 +126,21 @@ class _LinearPairFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g0, g1):
         x, w0, w1 = ctx.saved_tensors
+        if g0 is not None and g1 is not None:
+            # both gradients present (the usual case): ONE launch for d phi and both layers' weight / bias gradients
+            slots = [_grad_slot(p) if _DIRECT[0] else None for p in ctx.params]
+            direct = all(g is not None and g.is_contiguous() for g in slots)
+            dx, dw0, db0, dw1, db1 = ops.linear_bwd_pair(g0.contiguous(), g1.contiguous(), x, w0, w1,
+                                                         *((slots[0], slots[1], slots[2], slots[3]) if direct else ()),
+                                                         want_dx=bool(ctx.needs_input_grad[0]))
+            return (dx, None, None, None, None) if direct else (dx, dw0, db0, dw1, db1)
         outs, dx = [], None
         for g, w, pw, pb in ((g0, w0, ctx.params[0], ctx.params[1]), (g1, w1, ctx.params[2], ctx.params[3])):
             if g is None:
                 outs += [None, None]
                 continue
             g = g.contiguous()
-            gw, gb = (_grad_slot(pw), _grad_slot(pb)) if _DIRECT[0] else (None, None)
-            if gw is not None and gw.is_contiguous() and gb is not None and gb.is_contiguous():
-                ops.linear_bwd_w(g, x, dw=gw, db=gb, want_bias=True)
-                outs += [None, None]
-            else:
-                outs += list(ops.linear_bwd_w(g, x, want_bias=True))
+            outs += list(ops.linear_bwd_w(g, x, want_bias=True))
             if ctx.needs_input_grad[0]:
                 d = ops.linear_bwd_x(g, w)
                 dx = d if dx is None else dx + d

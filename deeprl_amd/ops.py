@@ -577,6 +577,22 @@ def linear_fwd_pair(x, w0, b0, w1, b1, act=None):
     return y0, y1
 
 
+def linear_bwd_pair(g0, g1, x, w0, w1, dw0=None, db0=None, dw1=None, db1=None, want_dx=True):
+    """Backward of linear_fwd_pair in one launch -> (dx or None, dw0, db0, dw1, db1); dw / db may be given (written in place)."""
+    g0, g1, x, w0, w1 = [_c(t, _f32) for t in (g0, g1, x, w0, w1)]
+    batch, fin = x.shape
+    o0, o1 = w0.shape[0], w1.shape[0]
+    dev = x.device
+    dw0 = torch.empty((o0, fin), dtype=_f32, device=dev) if dw0 is None else dw0
+    db0 = torch.empty(o0, dtype=_f32, device=dev) if db0 is None else db0
+    dw1 = torch.empty((o1, fin), dtype=_f32, device=dev) if dw1 is None else dw1
+    db1 = torch.empty(o1, dtype=_f32, device=dev) if db1 is None else db1
+    dx = torch.empty((batch, fin), dtype=_f32, device=dev) if want_dx else None
+    lib.dra_linear_bwd_pair(ptr(g0), ptr(g1), ptr(x), ptr(w0), ptr(w1), ptr(dx), ptr(dw0), ptr(db0), ptr(dw1), ptr(db1), batch, fin,
+                            o0, o1, stream_ptr())
+    return dx, dw0, db0, dw1, db1
+
+
 def linear_fwd(xs, ws, bs, act=None):
     nz = len(xs)
     xs = [_c(x, _f32) for x in xs]

@@ -210,6 +210,9 @@ int dra_linear_fwd(int nz, const float* const* x, const float* const* w, const f
  * actor-critic nets on phi), one wave per input row; in_features <= 512; same per-output arithmetic as dra_linear_fwd */
 int dra_linear_fwd_pair(const float* x, const float* w0, const float* b0, float* y0, int out0, const float* w1, const float* b1,
                         float* y1, int out1, int batch, int in_features, int act, void* stream);
+/* backward of that pair in one launch: dx [B, K] (optional) = g0 W0 + g1 W1, dW_h = g_h^T x, db_h = column sums of g_h */
+int dra_linear_bwd_pair(const float* g0, const float* g1, const float* x, const float* w0, const float* w1, float* dx, float* dw0,
+                        float* db0, float* dw1, float* db1, int batch, int in_features, int out0, int out1, void* stream);
 /* raw split-K partial sums [nz][ksplit][batch][out] (no bias / activation): the consumer reduces them. */
 int dra_linear_fwd_slabs(int nz, const float* const* x, const float* const* w, int batch, int in_features,
                          int out_features, int ksplit, float* slabs, void* stream);

@@ -910,6 +910,23 @@ def test_linear_fwd_pair_equals_two_layers(dev, b, k, o0, o1):
     _scale_close(y0.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("b,k,o0,o1", [(80, 512, 4, 1), (256, 512, 18, 1), (1, 512, 6, 1), (33, 64, 3, 2), (5, 17, 1, 1)])
+def test_linear_bwd_pair_vs_fp64(dev, b, k, o0, o1):
+    """dra_linear_bwd_pair (input gradient and both layers' weight / bias gradients of the paired heads in one launch) against
+    float64: d x = g0 W0 + g1 W1, dW_h = g_h^T x, db_h = column sums, each at 1e-5 of its scale."""
+    from deeprl_amd import ops
+    rs = np.random.RandomState(11 * b + k + o0 + o1)
+    x, g0, g1 = [rs.standard_normal(sh).astype(np.float32) for sh in ((b, k), (b, o0), (b, o1))]
+    w0, w1 = rs.standard_normal((o0, k)).astype(np.float32), rs.standard_normal((o1, k)).astype(np.float32)
+    dx, dw0, db0, dw1, db1 = ops.linear_bwd_pair(f32(g0, dev), f32(g1, dev), f32(x, dev), f32(w0, dev), f32(w1, dev))
+    X, G0, G1, W0, W1 = [a.astype(np.float64) for a in (x, g0, g1, w0, w1)]
+    _scale_close(dx.cpu().numpy(), G0 @ W0 + G1 @ W1)
+    _scale_close(dw0.cpu().numpy(), G0.T @ X)
+    _scale_close(dw1.cpu().numpy(), G1.T @ X)
+    _scale_close(db0.cpu().numpy(), G0.sum(0))
+    _scale_close(db1.cpu().numpy(), G1.sum(0))
+
+
 @pytest.mark.parametrize("b,k,o,act", [(16, 512, 4, None), (16, 512, 1, None), (80, 512, 18, None), (1, 17, 64, "tanh"),
                                       (64, 64, 64, "relu"), (33, 400, 300, "relu"), (128, 512, 204, None), (5, 3, 2, None),
                                       (8, 3136, 512, "relu"), (16, 3136, 512, "relu"), (5, 1024, 37, None), (9, 4096, 16, "tanh"),
