@@ -65,12 +65,16 @@ def direct_param_grads(enable=True):
 # input-gradient kernel has an epilogue for it (xact): it hands down dx * (x > 0) and leaves the tensor's address here; the layer
 # below skips its own mask when the gradient it receives is that very tensor (anything autograd copied or accumulated in between
 # has another address and is masked as before).  (y > 0) in {0, 1}: the values are the same either way.
-_MASKED = [0]
+_MASKED = [0, 0]       # (address, element count) of the gradient the layer above has already masked
+
+
+def _mark_masked(dx):
+    _MASKED[0], _MASKED[1] = dx.data_ptr(), dx.numel()
 
 
 def _already_masked(dy):
-    hit = _MASKED[0] != 0 and dy.data_ptr() == _MASKED[0]
-    _MASKED[0] = 0
+    hit = _MASKED[0] != 0 and dy.data_ptr() == _MASKED[0] and dy.numel() == _MASKED[1]
+    _MASKED[0] = _MASKED[1] = 0          # consumed (or not ours): a mark never outlives the next layer's backward
     return hit
 
 
@@ -105,7 +109,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ctx.x_relu:
                 dx = ops.linear_bwd_x(dpre, w, xact=x, act="relu")
-                _MASKED[0] = dx.data_ptr()
+                _mark_masked(dx)
             else:
                 dx = ops.linear_bwd_x(dpre, w)
         return dx, dw, db, None, None
@@ -201,7 +205,8 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        dpre = ops.act_bwd(dy.contiguous(), y, "relu")
+        dy = dy.contiguous()
+        dpre = dy if _already_masked(dy) else ops.act_bwd(dy, y, "relu")
         n_w, n_b = w.numel(), w.shape[0]
         dw_s, db_s = ops.conv_bwd_w(ctx.layer, dpre, x, ksplit=_ConvFn.KSPLIT, u8_coef=ctx.u8_coef)
         stride = dw_s.stride(0)
@@ -257,7 +262,7 @@ class _ConvKocFn(torch.autograd.Function):
         dx, slabs, n_slabs, stride = ops.conv_bwd_fused_koc(layer, dpre, x, w.permute(1, 2, 3, 0), ksplit=_ConvKocFn.KSPLIT,
                                                             u8_coef=ctx.u8_coef, variant=variant, xact=x if mask_below else None)
         if mask_below:
-            _MASKED[0] = dx.data_ptr()
+            _mark_masked(dx)
         # direct_param_grads(): FlatParams lays [weight (KOC) | bias] out back to back, which is a slab's own layout -- the fold
         # writes the layer's gradient segment of the optimizer's flat buffer itself
         gw, gb = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if _DIRECT[0] else (None, None)
