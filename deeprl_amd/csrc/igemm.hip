@@ -281,6 +281,9 @@ static int launch_gemv_rows(const LinPtrs& q, int nz, int batch, int in_features
   return DRA_OK;
 }
 
+extern "C" int dra_linear_fwd_slabs_one(int nz, const float* const* x, const float* const* w, int batch, int in_features,
+                                        int out_features, int ksplit, float* slabs, void* stream);   // fused.hip
+
 static int gemv_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("DRA_LINEAR_GEMV"); v = e ? atoi(e) : 1; }
@@ -455,6 +458,27 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
       const int rq = ((((in_features >> 2) + 3) >> 2) + 63) / 64;     // float4 per lane of a K quarter
       if (rq <= 2) return launch_gemv_rows<2>(q, nz, batch, in_features, out_features, act, st);
       return launch_gemv_rows<4>(q, nz, batch, in_features, out_features, act, st);
+    }
+  }
+  if (in_features == 3136 && batch > 32 && batch <= 4096 && workspace &&
+      (int64_t)nz * 14 * batch * out_features <= workspace_floats && gemv_enabled()) {
+    // fc4 of NatureConvBody at update batch sizes (A2C 80, a PPO minibatch of 256): the learner's one-pass K-slice kernel (both
+    // operands through LDS once, 14 slices: 336 / 896 workgroups) + the slab finish, instead of the K-chunked GEMM (13.9 + 5.1 us
+    // at batch 80, 30.8 + 5 us at 256: profiles/r04ag_kernel_stats_a2c_pixel_16.txt, r04o_kernel_stats_ppo_pixel_8.txt)
+    bool aligned = true;
+    LinPtrs q;
+    for (int z = 0; z < nz; ++z) {
+      if (!x[z] || !w[z] || !y[z]) return DRA_EINVAL;
+      q.x[z] = x[z]; q.w[z] = w[z]; q.bias[z] = bias ? bias[z] : nullptr; q.y[z] = y[z];
+      aligned = aligned && !((((uintptr_t)x[z]) | ((uintptr_t)w[z])) & 15);
+    }
+    if (aligned) {
+      int rc = dra_linear_fwd_slabs_one(nz, x, w, batch, in_features, out_features, 14, workspace, stream);
+      if (rc != DRA_OK) return rc;
+      hipLaunchKernelGGL(linear_finish_kernel, dim3((batch * out_features + 255) / 256, nz), dim3(256), 0, st, q,
+                         (const float*)workspace, 14, batch, out_features, act);
+      DRA_LAUNCH_CHECK();
+      return DRA_OK;
     }
   }
   LinFwd<32, 32, 64> p;

@@ -930,7 +930,7 @@ def test_linear_bwd_pair_vs_fp64(dev, b, k, o0, o1):
 @pytest.mark.parametrize("b,k,o,act", [(16, 512, 4, None), (16, 512, 1, None), (80, 512, 18, None), (1, 17, 64, "tanh"),
                                       (64, 64, 64, "relu"), (33, 400, 300, "relu"), (128, 512, 204, None), (5, 3, 2, None),
                                       (8, 3136, 512, "relu"), (16, 3136, 512, "relu"), (5, 1024, 37, None), (9, 4096, 16, "tanh"),
-                                      (32, 2052, 6, None)])
+                                      (32, 2052, 6, None), (80, 3136, 512, "relu"), (256, 3136, 512, "relu"), (33, 3136, 7, None)])
 def test_linear_small_layers_vs_torch(dev, b, k, o, act):
     """The one-pass forwards behind dra_linear_fwd -- in_features <= 512, batch <= 128 (heads and FCBody layers), and the wide
     GEMV for 512 < in_features <= 4096 at batch <= 32 (fc4 of NatureConvBody at rollout batch sizes) -- against F.linear in
