@@ -758,7 +758,8 @@ dist_head_dgrad_kernel(const float* __restrict__ dq, const float* __restrict__ w
                        const int64_t* __restrict__ action, int N, int NO, float* __restrict__ dh4) {
   __shared__ float s_part[128];
   const int b = blockIdx.x, t = threadIdx.x, r = t >> 7, col = blockIdx.y * 128 + (t & 127);
-  const int64_t base = action[b] * (int64_t)N;
+  const int64_t act_b = action[b];
+  const int64_t base = (act_b < 0 ? 0 : (act_b >= NO / N ? NO / N - 1 : act_b)) * (int64_t)N;   // (clamped like head_fused_kernel's read)
   const float* __restrict__ d = dq + (int64_t)b * NO + base;
   const float* __restrict__ w = wh + base * 512 + col;
   const float x = h4[(int64_t)b * 512 + col];
