@@ -145,3 +145,105 @@ def test_conv2_wide_staging_equals_the_row_shaped_map():
         assert a == c * CS + row * RW + (iw % S) * WPH + iw // S
     C3, H3 = 64, 9
     assert (1 * ((H3 + 0) // 1)) == H3 and (C3 * H3 * H3) % 4 == 0      # RW == H, whole float4s: a straight copy
+
+
+def test_round4_small_kernel_maps():
+    """Transcriptions of the round-4 latency kernels' work decompositions (the kernels themselves run in the GPU suite):
+    (i) linear_gemv_rows_kernel (igemm.hip): 8 waves = 2 output rows x 4 K quarters, lane l of quarter q holds float4
+        v0 + l + 64 i -- every float4 of every row is covered exactly once for the K the GPU tests use, and the
+        (q0 + q1) + (q2 + q3) combination of the quarter sums is the dot product;
+    (ii) linear_heads_rows_kernel: one wave per input row, k = lane + 64 i, outputs in chunks of eight, head 0 first;
+    (iii) dist_head_dgrad_kernel (learner.hip): workgroup (sample, 128-column block), threads (r, c): rows n = r, r + 2, ... in
+        chunks of eight + a tail, the two row classes added as (even) + (odd): every row of the action's block exactly once;
+    (iv) HeadWgradRole with the action array (oneshot.h): the matching samples found 64 at a time as a bit mask, taken eight per
+        round in ascending order -- the dense sum over the batch with the other samples' (zero) terms left out;
+    (v) linear_pair_bwd_kernel: workgroups [0, B) = input rows, [B, B + 2 (O0 + O1)) = (output row, half of K)."""
+    import numpy as np
+    rs = np.random.RandomState(4)
+    # (i)
+    for K in (3136, 1024, 2052, 4096, 516):
+        nv = K // 4
+        nvq = (nv + 3) // 4
+        R = 2 if ((nvq + 63) // 64) <= 2 else 4
+        assert R * 64 >= nvq
+        seen = np.zeros(nv, dtype=np.int64)
+        x, w = rs.standard_normal(K), rs.standard_normal(K)
+        parts = []
+        for q in range(4):
+            v0, v1 = q * nvq, min(nv, q * nvq + nvq)
+            lane_sums = np.zeros(64)
+            for lane in range(64):
+                for i in range(R):
+                    v = v0 + lane + 64 * i
+                    if v < v1:
+                        seen[v] += 1
+                        lane_sums[lane] += float(np.dot(w[4 * v:4 * v + 4], x[4 * v:4 * v + 4]))
+            parts.append(lane_sums.sum())
+        assert (seen == 1).all(), K
+        np.testing.assert_allclose((parts[0] + parts[1]) + (parts[2] + parts[3]), float(np.dot(w, x)), rtol=1e-12)
+    # (ii)
+    for K, O0, O1 in ((512, 4, 1), (512, 18, 1), (64, 3, 2), (17, 1, 1), (400, 9, 9)):
+        x = rs.standard_normal(K)
+        w = rs.standard_normal((O0 + O1, K))
+        got = np.full(O0 + O1, np.nan)
+        order = []
+        for oc in range(0, O0 + O1, 8):
+            for u in range(8):
+                o = oc + u
+                if o >= O0 + O1:
+                    continue
+                lane_sums = [sum(x[l + 64 * i] * w[o][l + 64 * i] for i in range(8) if l + 64 * i < K) for l in range(64)]
+                got[o] = sum(lane_sums)
+                order.append(o)
+        assert order == list(range(O0 + O1))
+        np.testing.assert_allclose(got, w @ x, rtol=1e-10, atol=1e-12)
+    # (iii)
+    for N in (51, 200, 8, 1, 17):
+        d, w = rs.standard_normal(N), rs.standard_normal((N, 4))
+        acc, rows = [np.zeros(4), np.zeros(4)], [[], []]
+        for r in (0, 1):
+            n = r
+            while n + 14 < N:
+                for u in range(8):
+                    rows[r].append(n + 2 * u)
+                    acc[r] += d[n + 2 * u] * w[n + 2 * u]
+                n += 16
+            while n < N:
+                rows[r].append(n)
+                acc[r] += d[n] * w[n]
+                n += 2
+        assert sorted(rows[0] + rows[1]) == list(range(N)) and all(v % 2 == 0 for v in rows[0]) and all(v % 2 for v in rows[1])
+        np.testing.assert_allclose(acc[0] + acc[1], d @ w, rtol=1e-10, atol=1e-12)
+    # (iv)
+    for B, A, group in ((32, 204, 51), (100, 800, 200), (7, 12, 3), (1024, 8, 4)):
+        n_act = A // group
+        action = rs.randint(0, n_act, size=B)
+        dq = np.zeros((B, A))
+        for b in range(B):
+            dq[b, action[b] * group:(action[b] + 1) * group] = rs.standard_normal(group)
+        h4 = rs.standard_normal(B)
+        for a in (0, A // 2, A - 1):
+            mine = a // group
+            acc, taken = 0.0, []
+            for b0 in range(0, B, 64):
+                mask = [b0 + l for l in range(64) if b0 + l < B and action[b0 + l] == mine]
+                while mask:
+                    chunk, mask = mask[:8], mask[8:]
+                    for b in chunk:
+                        taken.append(b)
+                        acc += dq[b, a] * h4[b]
+            assert taken == [b for b in range(B) if action[b] == mine]
+            np.testing.assert_allclose(acc, float(dq[:, a] @ h4), rtol=1e-10, atol=1e-12)
+    # (v)
+    for B, O0, O1 in ((80, 4, 1), (1, 18, 1), (33, 3, 2)):
+        jobs = []
+        for bid in range(B + 2 * (O0 + O1)):
+            if bid < B:
+                jobs.append(("dx", bid))
+            else:
+                r = bid - B
+                row, half = r >> 1, r & 1
+                jobs.append(("dw0", row, half) if row < O0 else ("dw1", row - O0, half))
+        assert [j for j in jobs if j[0] == "dx"] == [("dx", b) for b in range(B)]
+        assert sorted(j for j in jobs if j[0] == "dw0") == [("dw0", o, h) for o in range(O0) for h in (0, 1)]
+        assert sorted(j for j in jobs if j[0] == "dw1") == [("dw1", o, h) for o in range(O1) for h in (0, 1)]
