@@ -1,0 +1,53 @@
+"""The bench line's contract, checked on the newest committed `python bench.py` output (profiles/r*_bench.json) and on
+bench.py's own helpers that read committed profiler summaries -- no GPU needed.  The driver parses this line; a field that
+goes missing here goes missing there."""
+import glob
+import importlib.util
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _newest(pattern):
+    def key(p):
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(p))
+        return (int(m.group(1)), len(m.group(2)), m.group(2))
+    files = [p for p in glob.glob(os.path.join(ROOT, "profiles", pattern)) if re.match(r"r\d+[a-z]*_bench\.json$", os.path.basename(p))]
+    assert files, pattern
+    return max(files, key=key)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    path = _newest("r*_bench.json")
+    b = json.load(open(path))
+    for k, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                   ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str)):
+        assert isinstance(b[k], typ), (path, k)
+    assert "vs_baseline" in b and b["vs_baseline"] is None            # BASELINE.md holds no published number for this metric
+    assert b["metric"] == "gradient-updates/sec" and b["scaling"] == "weak" and b["dtype"] == "f32" and b["data"] == "synthetic"
+    assert isinstance(b["config"]["workload"], str) and "model" not in b["config"]
+    assert abs(b["value"] - b["n_gpus"] * 1e3 / b["ms_per_step"]) / b["value"] < 1e-6
+    r = b["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["kernel"] == "conv2_bwd_x" and r["peak"] == 157.3                    # the MFMA limiter, by name (round 4)
+    assert [m["kernel"] for m in r["mfma_kernels"]] and all(0 < m["frac"] < 1 for m in r["mfma_kernels"])
+    assert r["longest_kernel"]["bound"] == "fabric/MALL"
+    c = b["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str) and c["unit"]
+    assert 0.5 < c["port_vs_reference"]["port_over_reference"] < 2.0
+    assert b["parity_check"]["ok"] is True
+
+
+def test_bench_reads_the_newest_committed_profiler_summaries():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    k = mod.rocprof_kernel("conv2_bwd_x", 339738624)
+    assert k is not None and 5e-3 < k["avg_ms"] < 3e-2 and 0.05 < k["frac"] < 0.6 and k["file"].startswith("profiles/")
+    assert mod.rocprof_kernel("rmsprop_step", 0)["avg_ms"] > 5e-3
+    t = mod.pmc_traffic("conv2_bwd_x")
+    assert t is not None and 4e6 < t < 4e7
