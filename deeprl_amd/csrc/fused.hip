@@ -348,6 +348,19 @@ DRA_API int dra_fc_bwd_fused(const float* dq, const float* h4, const float* dh4,
   return launch_multi(rd, igemm_blocks(rd, 1), rw, igemm_blocks(rw, 1), rh, 2 * n_actions, st);
 }
 
+// Input gradient of a 512-output linear layer on its own (fc4 of NatureConvBody in the autograd path: dx = act'(xact) * dy W,
+// dy [B][512], W [512][I]) through the learner's one-pass role instead of the K-chunked implicit GEMM (24.9 us at a PPO
+// minibatch of 256, profiles/r04ap_kernel_stats_ppo_pixel_8.txt).  Library-internal (igemm.hip dra_linear_bwd_x).
+extern "C" int dra_linear_bwd_x_one512(const float* dy, const float* w, const float* xact, float* dx, int batch, int in_features,
+                                       int act, void* stream) {
+  if (!dy || !w || !dx || batch < 1 || in_features < 1) return DRA_EINVAL;
+  LinDgradOne<512> rd;
+  rd.dy = dy; rd.w = w; rd.xact = xact; rd.dx = dx; rd.B = batch; rd.I = in_features; rd.act = act;
+  rd.tiles_n = (in_features + 31) / 32;
+  NoRole none;
+  return launch_multi(rd, rd.tiles_n * ((batch + 31) / 32), none, 0, none, 0, dra_stream(stream));
+}
+
 // fc4 forward partial sums in one pass per K split (in_features = 3136, ksplit = 8): same contract as
 // dra_linear_fwd_slabs.
 DRA_API int dra_linear_fwd_slabs_one(int nz, const float* const* x, const float* const* w, int batch, int in_features,

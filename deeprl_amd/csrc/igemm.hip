@@ -284,6 +284,9 @@ static int launch_gemv_rows(const LinPtrs& q, int nz, int batch, int in_features
 extern "C" int dra_linear_fwd_slabs_one(int nz, const float* const* x, const float* const* w, int batch, int in_features,
                                         int out_features, int ksplit, float* slabs, void* stream);   // fused.hip
 
+extern "C" int dra_linear_bwd_x_one512(const float* dy, const float* w, const float* xact, float* dx, int batch, int in_features,
+                                       int act, void* stream);   // fused.hip
+
 static int gemv_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("DRA_LINEAR_GEMV"); v = e ? atoi(e) : 1; }
@@ -551,6 +554,8 @@ DRA_API int dra_linear_bwd_w(const float* dy, const float* x, float* dw, float* 
 DRA_API int dra_linear_bwd_x(const float* dy, const float* w, const float* xact, float* dx, int batch, int in_features,
                              int out_features, int act, void* stream) {
   if (!dy || !w || !dx || batch < 1 || in_features < 1 || out_features < 1) return DRA_EINVAL;
+  if (out_features == 512 && in_features >= 1024 && gemv_enabled())     // fc4-shaped: the one-pass role (fused.hip)
+    return dra_linear_bwd_x_one512(dy, w, xact, dx, batch, in_features, act, stream);
   LinDgrad<32, 32, 64> p;
   p.M = batch; p.N = in_features; p.K = out_features; p.dy = dy; p.w = w; p.xact = xact; p.dx = dx; p.act = act;
   return launch_igemm(p, 1, 1, dra_stream(stream));

@@ -549,7 +549,8 @@ def test_conv_fwd_bwd_vs_oracle(dev, layer, batch):
 
 @pytest.mark.parametrize("batch,fin,fout,act", [(32, 3136, 512, "relu"), (32, 512, 4, None), (32, 512, 204, None),
                                                 (10, 4, 64, "relu"), (64, 17, 64, "tanh"), (1, 3136, 512, "relu"),
-                                                (256, 64, 1, None), (32, 512, 800, None)])
+                                                (256, 64, 1, None), (32, 512, 800, None), (256, 3136, 512, "relu"),
+                                                (80, 3136, 512, "relu"), (5, 1024, 512, None)])
 def test_linear_fwd_bwd_vs_oracle(dev, batch, fin, fout, act):
     import torch.nn.functional as F
     from deeprl_amd import ops
