@@ -10,7 +10,7 @@
 // (the buffer is already flat).  Round 4: the host issues the exchange in TWO calls -- [fc4 + heads] (6.4 MB, complete as soon
 // as fc4's backward has run) on a communication stream while the convolutions are still being differentiated, then the
 // 0.3 MB of convolution gradients -- and joins before the clip + optimizer launch (deeprl_amd/dist.py DataParallel.plan_split);
-// the 1/ranks scale is folded into the same stream right behind each call.
+// the per-rank scale runs on the same stream right in front of each call.
 //
 // One process per GPU; the unique id travels from rank 0 to the others by whatever out-of-band channel the host has
 // (deeprl_amd/dist.py uses torch.distributed's store).
@@ -79,21 +79,23 @@ __global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ x, int64
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= s;
 }
 
-// flat_grad[0, count) <- (sum over ranks of flat_grad) * scale, in place, asynchronous on `stream`.
-// scale = 1 / n_ranks gives the gradient of the mean loss over the GLOBAL rollout when every rank's loss is the mean over
-// an equally sized shard.
+// flat_grad[0, count) <- sum over ranks of (scale_r * flat_grad_r), in place, asynchronous on `stream`: every rank scales ITS
+// gradient by ITS `scale` first and the scaled buffers are summed.  scale = 1 / n_ranks on every rank gives the gradient of the
+// mean loss over the GLOBAL rollout when the shards are equally sized (A2C); PPO's shuffled minibatches give each rank
+// scale_r = rows_r / rows of the global minibatch, which differs per rank -- scaling after the sum (the round-4 order) handed
+// every rank a different gradient (dist.py:281).  Same order as the gloo path (mul_ then all_reduce).
 DRA_API int dra_allreduce_grads(float* flat_grad, int64_t count, float scale, dra_comm* c, void* stream) {
   if (!flat_grad || count < 1 || !c || (((uintptr_t)flat_grad) & 15)) return DRA_EINVAL;
   hipStream_t st = dra_stream(stream);
-  if (c->n_ranks > 1) {
-    if (ncclAllReduce(flat_grad, flat_grad, (size_t)count, ncclFloat, ncclSum, c->comm, st) != ncclSuccess) return DRA_EINVAL;
-  }
   if (scale != 1.f) {
     int64_t blocks = ((count >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)blocks), dim3(256), 0, st, flat_grad, count, scale);
     DRA_LAUNCH_CHECK();
+  }
+  if (c->n_ranks > 1) {
+    if (ncclAllReduce(flat_grad, flat_grad, (size_t)count, ncclFloat, ncclSum, c->comm, st) != ncclSuccess) return DRA_EINVAL;
   }
   return DRA_OK;
 }

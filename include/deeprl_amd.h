@@ -508,7 +508,9 @@ int dra_comm_unique_id(void* id_bytes);
 int dra_comm_init_rank(dra_comm** out, int n_ranks, int rank, const void* id_bytes);
 int dra_comm_destroy(dra_comm* comm);
 int dra_comm_info(dra_comm* comm, int* n_ranks, int* rank); /* as RCCL reports them (ncclCommCount / ncclCommUserRank) */
-/* flat_grad <- (sum over ranks) * scale, in place, asynchronous on stream (scale = 1/n_ranks: gradient of the global mean) */
+/* flat_grad <- sum over ranks of (this rank's scale * this rank's flat_grad), in place, asynchronous on stream: the scale is
+ * applied BEFORE the sum, so ranks may pass different scales (PPO: rows here / rows of the global minibatch); 1/n_ranks on
+ * every rank gives the gradient of the global mean over equal shards */
 int dra_allreduce_grads(float* flat_grad, int64_t count, float scale, dra_comm* comm, void* stream);
 /* a few fp64 scalars summed over ranks (PPO's global advantage statistics, PPO_agent.py:66) */
 int dra_allreduce_f64(double* values, int count, dra_comm* comm, void* stream);

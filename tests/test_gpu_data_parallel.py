@@ -103,7 +103,7 @@ def test_rccl_two_ranks_equal_gloo_two_ranks(tmp_path, kind, port):
 
 
 def test_rccl_comm_of_size_one():
-    """csrc/comm.hip through its C ABI: unique id, init_rank, dra_allreduce_grads (sum over 1 rank, then the scale),
+    """csrc/comm.hip through its C ABI: unique id, init_rank, dra_allreduce_grads (this rank's scale, then the sum over 1 rank),
     dra_allreduce_f64, destroy."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
