@@ -986,7 +986,17 @@ def _install_sampler(agent):
         return
     from .envs import Discrete
     if not isinstance(agent.task.action_space, Discrete):
-        raise NotImplementedError("data-parallel sampling is implemented for categorical policies (BASELINE config 5)")
+        from .nets import GaussianActorCriticNet
+        if not isinstance(net, GaussianActorCriticNet):
+            raise NotImplementedError("rank-invariant sampling is implemented for categorical and Gaussian policies")
+        from . import ppo_mlp
+
+        def gauss(mean, scale):     # mean + scale * hashed normal of (noise seed, sampler step, GLOBAL environment, dimension)
+            if dp.step_dev is None:
+                dp.step_dev = torch.zeros(1, dtype=torch.int64, device=mean.device)
+            return ppo_mlp.gauss_sample(mean, scale, dp.noise_seed, dp.step_dev, dp.global_workers, dp.lo)
+        net.sampler = gauss
+        return
     # one kernel per sample; the noise stream's position is a device counter the kernel advances: graph-capturable
     net.sampler = lambda logits: dp.sample(logits.detach())
 
@@ -1320,22 +1330,31 @@ class PPOAgent(BaseAgent):
         if config.shared_repr:
             _dp_plan_exchange(self.dp, self.network, self._fused)
         self.total_steps = 0
-        from .device_env import DeviceAtariVec
+        from .device_env import DeviceAtariVec, DeviceContinuousVec
+        from .ppo_mlp import MlpPPO
+        self.grad_hook = None
+        self._mlp = MlpPPO(self)        # csrc/ppo_mlp.hip: two small tanh MLPs + two Adam optimisers as persistent kernels
         if DeviceAtariVec.eligible(self.task, config):      # synthetic Atari emulators: the environments live on the device
             self.task = DeviceAtariVec(self.task)
             self.states = None
         else:
             self.states = self.task.reset()
             self.states = config.state_normalizer(self.states)
+            if DeviceContinuousVec.eligible(self.task, config) and self._mlp.usable():
+                # synthetic continuous-control environments (BASELINE configs[2]): observations, counters and the observation
+                # statistics move to the device; rollouts are one launch each (_step_device_mlp)
+                self.task = DeviceContinuousVec(self.task, self.states, config.state_normalizer)
+                self.states = None
         self._dev_graph = _OnPolicyGraph(self, optimizer_inside=False)
         self._dev_state = _device_state_fn(self)
         if config.shared_repr:
             self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda step: 1 - step / config.max_steps)
-        self.grad_hook = None
         self._graphed = _GraphedPPO(self)
         self._rollout_graph = dict(calls=0, graph=None, failed=False, k=0)
         self._rollout_step = 0
         _install_sampler(self)
+        # action noise of the device rollout: the rank-invariant stream when one is configured, else a seed of its own
+        self._noise_seed = self.dp.noise_seed if self.dp.invariant_sampling else int(getattr(config, 'dp_noise_seed', None) or 0)
 
     def close(self):
         close_obj(self.task)
@@ -1390,8 +1409,51 @@ class PPOAgent(BaseAgent):
             ops.adv_normalize_(entries.advantage)
         return entries
 
+    def _step_device_mlp(self):
+        """step() over device_env.DeviceContinuousVec: PPO_agent.py:32-49 is ONE launch (dra_ppo_mlp_rollout: per step the
+        normalised observation, both forwards, action = mean + softplus(std) * noise, log-probability, environment step,
+        running observation statistics), then the return scan, the advantage normalisation and optimize()."""
+        import ctypes
+        from collections import namedtuple
+        from ._lib import lib, stream_ptr
+        from .ppo_mlp import RolloutIO
+        config, task, dp = self.config, self.task, self.dp
+        t_len, n = int(config.rollout_length), task.num_envs
+        b = task.buffers(t_len)
+        events = task.shadow(t_len)
+        if dp.step_dev is None:
+            dp.step_dev = torch.zeros(1, dtype=torch.int64, device=Config.DEVICE)
+        cfg, actor, critic = self._mlp.structs()
+        self._mlp.sync_counts()
+        io = RolloutIO()
+        io.env_state, io.env_counter, io.env_seed = task.env_state.data_ptr(), task.env_counter.data_ptr(), task.env_seed.data_ptr()
+        io.rms, io.cur_state, io.sampler_step = task.rms.data_ptr(), task.cur_state.data_ptr(), dp.step_dev.data_ptr()
+        io.out_state, io.out_action, io.out_log_pi_a = b['state'].data_ptr(), b['action'].data_ptr(), b['log_pi_a'].data_ptr()
+        io.out_v, io.out_reward, io.out_mask = b['v'].data_ptr(), b['reward'].data_ptr(), b['mask'].data_ptr()
+        io.env0, io.n_global, io.noise_seed, io.horizon = dp.lo, dp.global_workers, self._noise_seed, task.horizon
+        io.reward_coef, io.rms_epsilon, io.rms_clip = float(config.reward_normalizer.coef), task.rms_epsilon, task.rms_clip
+        io.rms_update = 1 if (task.rms_kind == 'meanstd' and not config.state_normalizer.read_only) else 0
+        io.t_len, io.n_env = t_len, n
+        lib.dra_ppo_mlp_rollout(ctypes.byref(cfg), ctypes.byref(actor), ctypes.byref(critic), ctypes.byref(io), stream_ptr())
+        self._rollout_step += t_len + 1
+        for t, i, ret in events:        # BaseAgent.record_online_return at the step the episode ended
+            at = self.total_steps + t * dp.global_workers + i
+            self.logger.add_scalar('episodic_return_train', ret, at)
+            self.logger.info('steps %d, episodic_return_train %s' % (at, ret))
+        self.total_steps += t_len * dp.global_workers
+        adv, ret = ops.gae(b['reward'], b['mask'], b['v'], config.discount, config.gae_tau, config.use_gae)
+        entry_cls = namedtuple('Entry', ['state', 'action', 'log_pi_a', 'ret', 'advantage'])
+        rows = t_len * n
+        entries = entry_cls(b['state'].view(rows, -1), b['action'].view(rows, -1), b['log_pi_a'].view(rows, 1),
+                            ret.view(rows, 1), adv.view(rows, 1))
+        ops.adv_normalize_(entries.advantage)
+        self.optimize(entries)
+
     def step(self):
         if getattr(self.task, 'on_device', False):
+            from .device_env import DeviceContinuousVec
+            if isinstance(self.task, DeviceContinuousVec):
+                return self._step_device_mlp()
             return self._step_device()
         config = self.config
         storage = Storage(config.rollout_length)
@@ -1523,6 +1585,9 @@ class PPOAgent(BaseAgent):
         """PPO_agent.py:71-99: epochs of shuffled minibatches over the (detached) rollout entries."""
         config = self.config
         dp = self.dp
+        if self._mlp.usable() and self._mlp.optimize(entries):      # all epochs x minibatches in one launch (csrc/ppo_mlp.hip)
+            return
+        self._mlp.sync_counts()
         if dp.invariant_sampling:        # G ranks, or one process asked to behave exactly like G ranks would
             return self._optimize_data_parallel(entries)
         if self._graphed.usable() and self._graphed.optimize(entries):

@@ -1,0 +1,991 @@
+// ppo_mlp: BASELINE configs[2] -- PPO over GaussianActorCriticNet with two small tanh MLPs (examples.py:497-523: HalfCheetah
+// shapes 17 -> 64 -> 64 -> {6, 1}, 16 workers, rollout 2048, 10 epochs x 512 minibatches of 64, two Adam optimisers) -- as
+// persistent kernels.  Replaces, per rollout, 2049 host round trips of PPO_agent.py:32-49 and the 5120 x (forward + loss +
+// backward + 2 optimizer steps) launch chains of PPO_agent.py:71-99 with four launches:
+//
+//   ppo_mlp_rollout_kernel   one workgroup walks the whole rollout: observation statistics (fp64 RunningMeanStd), both forwards,
+//                            action = mean + softplus(std) * noise, log-probability, environment step (csrc/cont_env.h)
+//   (dra_gae, dra_adv_normalize: scan.hip / losses.hip, unchanged)
+//   ppo_pack_kernel          the rows of every minibatch of every epoch gathered once (PPO_agent.py:72-76)
+//   ppo_mlp_update_kernel    TWO workgroups -- the actor's and the critic's networks never meet when phi_body is the identity
+//                            (network_heads.py:181-183) -- each keeping its weights and Adam moments in registers (one MFMA
+//                            operand layout serves the forward AND receives the weight gradient, see below) from the first
+//                            minibatch to the last; the approx-KL gate (PPO_agent.py:88) is evaluated on the device.
+//
+// The work is a chain of 5120 dependent 64-row updates of an 5.7 k-parameter network: latency-bound by construction (SURVEY.md
+// 8d), nothing to spread over 256 CUs.  What can be removed is everything between the dependent steps: launches, HBM round
+// trips of weights / activations / optimizer state, host decisions.  Contractions run on v_mfma_f32_16x16x4_f32 (exact fp32).
+//
+// Operand layout (lane l of a wave: c16 = l & 15, g = l >> 4).  For D = A x B the instruction takes A[i = c16][k = g],
+// B[k = g][j = c16] and returns D[i = 4g + reg][j = c16].  The K index of a step may be ANY 4 values as long as A and B agree,
+// so a hidden layer y[row][n] = sum_k x[row][k] W[n][k] walks k as 16 tk + 4 g + r (step (tk, r)): a lane's B operands
+// W[16 nt + c16][16 tk + 4 g + r] are then exactly the elements the weight-gradient contraction dW^T[k][n] = sum_row x[row][k]
+// dz[row][n] leaves in that lane's accumulators (D row 4 g + r of tile tk, column c16).  Wave nt therefore OWNS units
+// [16 nt, 16 nt + 16): it alone reads those weights in the forward, receives their gradient and applies Adam in registers;
+// only the transposed use (dh = dz W) needs a copy in LDS.
+#include "common.h"
+#include "cont_env.h"
+#include <math.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int kRows = 64;              // rows a workgroup holds at once: 4 M tiles
+constexpr int kMaxS = 64, kMaxA = 16;
+constexpr int kLdX = kMaxS + 4;        // allocation stride of the observation tile (the used stride is 16 KT1 + 4)
+constexpr int kLd3 = 20;               // stride of the [rows][16] head-side arrays
+constexpr int kAuxLp = 16, kAuxAdv = 17, kAuxRet = 18;
+constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
+constexpr float kEntConst = 1.4189385332046727f;   // 0.5 + 0.5 log(2 pi)   (torch.distributions.Normal.entropy)
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the transcendental unit (v_exp_f32 / v_rcp_f32, 1 ulp each): absolute error < 2e-7 on
+// the whole line, saturating to +-1 exactly.  36 evaluations per lane and minibatch: the library routine would cost more
+// than the layer's MFMAs.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
+}
+// F.softplus (beta 1, threshold 20) and its derivative as autograd forms it (z / (z + 1), z = exp(x))
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float softplus_grad(float x) {
+  if (x > 20.f) return 1.f;
+  const float z = expf(x);
+  return z / (z + 1.f);
+}
+// batch row of contraction step s for lane group g in the weight-gradient contractions: a bijection (s < 4 MT, g < 4) -> rows
+// whose four rows per step lie 4 apart, so the 4 x 16-float reads of one ds_read_b32 fall on 4 distinct bank groups
+__device__ __forceinline__ int row_of(int s, int g) { return ((s >> 2) << 4) + (g << 2) + (s & 3); }
+
+__device__ __forceinline__ float group16_sum(float v) {   // over the 16 lanes that share g
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+__device__ __forceinline__ float over_g_sum(float v) {    // over the 4 lanes that share c16
+  v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+struct AdamScalars { float step_size, inv_sqrt_bc2, beta1, beta2, omb1, omb2, eps; };
+__device__ __forceinline__ void adam_elem(float& p, float gk, float& m, float& v, const AdamScalars& a) {
+  // optim.hip adam_step_kernel's element formula (torch.optim.Adam, no amsgrad / weight decay)
+  m = m * a.beta1 + a.omb1 * gk;
+  v = v * a.beta2 + a.omb2 * gk * gk;
+  p = p - a.step_size * (m / (sqrtf(v) * a.inv_sqrt_bc2 + a.eps));
+}
+
+constexpr size_t update_lds_floats(int H) {
+  return (size_t)kRows * (kLdX + kLd3) + 3 * (size_t)kRows * (H + 4) + (size_t)H * (H + 4) + 16 * (size_t)(H + 4) +
+         (size_t)kRows * kLd3 + 16 + 16 + 64 + 64;
+}
+
+// debug dump layout (floats, per role; the critic's region starts at kDbgRole)
+constexpr int kDbgRole = 32768, kDbgH1 = 0, kDbgH2 = 4096, kDbgHead = 8192, kDbgLp = 9216, kDbgGl = 9280, kDbgScal = 9344,
+              kDbgDz3 = 10240, kDbgDz2 = 11264, kDbgDz1 = 15360, kDbgW1 = 19456, kDbgW2 = 23552, kDbgW3 = 27648,
+              kDbgB1 = 28672, kDbgB2 = 28736, kDbgB3 = 28800, kDbgStd = 28816;
+static_assert(2 * kDbgRole <= DRA_PPO_MLP_DBG_FLOATS, "debug buffer");
+
+// ------------------------------------------------------------------------------------------------ update
+template <int H, bool ACTOR, bool DUMP>
+__device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, const dra_ppo_mlp_net& net, const float* __restrict__ packed,
+                                const int n, const int epochs, float* __restrict__ out3, int64_t* __restrict__ out_counts,
+                                float* __restrict__ dbg_all, float* lds) {
+  constexpr int NT = H / 16, LD = H + 4;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c16 = l & 15, g = l >> 4;
+  const int S = cfg.state_dim, AP = cfg.action_dim, A = ACTOR ? cfg.action_dim : 1, MB = cfg.mini_batch;
+  const int KT1 = (S + 15) >> 4, LDX = 16 * KT1 + 4;
+  const int MT = (MB + 15) >> 4;      // M tiles that can hold rows (the contractions over rows stop there)
+  const int per_epoch = (n + MB - 1) / MB, total = per_epoch * epochs;
+  const bool own = w < NT;
+  const int ncol = 16 * w + c16;
+  float* dbg = (DUMP && dbg_all) ? dbg_all + (ACTOR ? 0 : kDbgRole) : nullptr;
+
+  float* sX = lds;                    // [kRows][LDX] | sAux [kRows][kLd3]: the minibatch image, laid out as ppo_pack_kernel writes it
+  float* sAux = sX + kRows * LDX;
+  float* sH1 = lds + kRows * (kLdX + kLd3);
+  float* sH2 = sH1 + kRows * LD;      // h2, later dz1
+  float* sDZ2 = sH2 + kRows * LD;
+  float* sW2 = sDZ2 + kRows * LD;
+  float* sW3 = sW2 + H * LD;
+  float* sDZ3 = sW3 + 16 * LD;
+  float* sB3 = sDZ3 + kRows * kLd3;
+  float* sStd = sB3 + 16;
+  float* sRed = sStd + 16;            // [4 waves][4]
+  float* sPart = sRed + 64;           // [4 waves][16]
+  for (int i = tid; i < (int)update_lds_floats(H); i += 256) lds[i] = 0.f;
+  __syncthreads();
+
+  // ---- masters: parameters + Adam moments of this lane's share, in the forward's B-operand layout
+  float w1p[4][4], w1m[4][4], w1v[4][4];
+  float w2p[NT][4], w2m[NT][4], w2v[NT][4];
+  float w3p[4], w3m[4], w3v[4];
+  float b1p = 0.f, b1m = 0.f, b1v = 0.f, b2p = 0.f, b2m = 0.f, b2v = 0.f, b3p = 0.f, b3m = 0.f, b3v = 0.f;
+  float sdp = 0.f, sdm = 0.f, sdv = 0.f;
+#pragma unroll
+  for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * tk + 4 * g + r;
+      const bool ok = own && k < S;
+      const int idx = net.off_w1 + ncol * S + k;
+      w1p[tk][r] = ok ? net.param[idx] : 0.f;
+      w1m[tk][r] = ok ? net.exp_avg[idx] : 0.f;
+      w1v[tk][r] = ok ? net.exp_avg_sq[idx] : 0.f;
+    }
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = net.off_w2 + ncol * H + 16 * tk + 4 * g + r;
+      w2p[tk][r] = own ? net.param[idx] : 0.f;
+      w2m[tk][r] = own ? net.exp_avg[idx] : 0.f;
+      w2v[tk][r] = own ? net.exp_avg_sq[idx] : 0.f;
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool ok = own && c16 < A;
+    const int idx = net.off_w3 + c16 * H + 16 * w + 4 * g + r;
+    w3p[r] = ok ? net.param[idx] : 0.f;
+    w3m[r] = ok ? net.exp_avg[idx] : 0.f;
+    w3v[r] = ok ? net.exp_avg_sq[idx] : 0.f;
+  }
+  if (own) {
+    b1p = net.param[net.off_b1 + ncol]; b1m = net.exp_avg[net.off_b1 + ncol]; b1v = net.exp_avg_sq[net.off_b1 + ncol];
+    b2p = net.param[net.off_b2 + ncol]; b2m = net.exp_avg[net.off_b2 + ncol]; b2v = net.exp_avg_sq[net.off_b2 + ncol];
+  }
+  if (w == 0 && c16 < A) {
+    b3p = net.param[net.off_b3 + c16]; b3m = net.exp_avg[net.off_b3 + c16]; b3v = net.exp_avg_sq[net.off_b3 + c16];
+    if (ACTOR) { sdp = net.param[net.off_std + c16]; sdm = net.exp_avg[net.off_std + c16]; sdv = net.exp_avg_sq[net.off_std + c16]; }
+  }
+  auto publish = [&]() {     // the LDS copies the transposed contractions and the head read
+    if (own) {
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk) {
+        f32x4 v = {w2p[tk][0], w2p[tk][1], w2p[tk][2], w2p[tk][3]};
+        *reinterpret_cast<f32x4*>(&sW2[ncol * LD + 16 * tk + 4 * g]) = v;
+      }
+      f32x4 v3 = {w3p[0], w3p[1], w3p[2], w3p[3]};
+      *reinterpret_cast<f32x4*>(&sW3[c16 * LD + 16 * w + 4 * g]) = v3;
+    }
+    if (w == 0 && g == 0) { sB3[c16] = b3p; sStd[c16] = sdp; }
+  };
+  publish();
+
+  // ---- Adam's bias corrections: beta^t as a running product from pow(beta, t0) (within 1e-12 of pow(beta, t))
+  int64_t steps = *net.step_dev;
+  const int64_t steps0 = steps;
+  double pw1 = pow((double)net.beta1, (double)steps), pw2 = pow((double)net.beta2, (double)steps);
+  AdamScalars ad;
+  ad.beta1 = net.beta1; ad.beta2 = net.beta2; ad.omb1 = 1.f - net.beta1; ad.omb2 = 1.f - net.beta2; ad.eps = net.eps;
+
+  // ---- minibatch images (ppo_pack_kernel: [kRows][LDX] observations, zero padded | [kRows][kLd3] action, log_pi_a, advantage,
+  // ret): prefetched one minibatch ahead into registers, committed to LDS -- same linear layout -- at the end of the iteration
+  constexpr int NJ = (kRows * (kLdX + kLd3) / 4 + 255) / 256;
+  f32x4 pf[NJ];
+  const int img4 = kRows * (LDX + kLd3) / 4;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) pf[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto issue = [&](int q) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(packed) + (int64_t)q * img4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (tid + 256 * j < img4) pf[j] = src[tid + 256 * j];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (tid + 256 * j < img4) reinterpret_cast<f32x4*>(sX)[tid + 256 * j] = pf[j];
+  };
+  if (total > 0) { issue(0); commit(); }
+  __syncthreads();
+
+  int64_t applied = 0;
+  for (int q = 0; q < total; ++q) {
+    const int kq = q % per_epoch;
+    const int rows = min(MB, n - kq * MB);
+    const float inv_m = 1.f / (float)rows;
+    const bool dump = DUMP && dbg && q == 0;
+    if (q + 1 < total) issue(q + 1);
+
+    // ---- F1: h1 = tanh(x W1^T + b1)
+    if (own) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk)
+        if (tk < KT1) {
+          f32x4 av[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            av[mt] = *reinterpret_cast<const f32x4*>(&sX[(16 * mt + c16) * LDX + 16 * tk + 4 * g]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+              acc[mt] = MFMA16(av[mt][r], w1p[tk][r], acc[mt]);
+        }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + 4 * g + r;
+            const float h = fast_tanh(acc[mt][r] + b1p);
+            sH1[row * LD + ncol] = h;
+            if (dump) dbg[kDbgH1 + row * 64 + ncol] = h;
+          }
+    }
+    __syncthreads();
+    // ---- F2: h2 = tanh(h1 W2^T + b2)
+    if (own) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk) {
+        f32x4 av[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          av[mt] = *reinterpret_cast<const f32x4*>(&sH1[(16 * mt + c16) * LD + 16 * tk + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            acc[mt] = MFMA16(av[mt][r], w2p[tk][r], acc[mt]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + 4 * g + r;
+            const float h = fast_tanh(acc[mt][r] + b2p);
+            sH2[row * LD + ncol] = h;
+            if (dump) dbg[kDbgH2 + row * 64 + ncol] = h;
+          }
+    }
+    __syncthreads();
+    // ---- F3 + loss: wave mt takes rows [16 mt, 16 mt + 16); lane (c16 = head output, g, reg) <-> row 16 mt + 4 g + reg
+    float sd = 1.f, log_sd = 0.f, std_raw = 0.f;
+    if (ACTOR) { std_raw = sStd[c16]; sd = softplus_f(std_raw); log_sd = logf(sd); }
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(&sH2[(16 * w + c16) * LD + 16 * tk + 4 * g]);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(&sW3[c16 * LD + 16 * tk + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = MFMA16(av[r], bv[r], acc);
+      }
+      const float b3 = sB3[c16];
+      const bool col_ok = c16 < A;
+      float s0 = 0.f, s1 = 0.f, gsd = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * w + 4 * g + r;
+        const bool row_ok = row < rows;
+        float dz = 0.f;
+        if (ACTOR) {
+          const float var = sd * sd;
+          const float mean = fast_tanh(acc[r] + b3);
+          const float diff = sAux[row * kLd3 + c16] - mean;
+          const float lpe = col_ok ? (-(diff * diff) / (2.f * var) - log_sd - kLogSqrt2Pi) : 0.f;
+          const float lp = group16_sum(lpe);
+          const float lp_old = sAux[row * kLd3 + kAuxLp], adv = sAux[row * kLd3 + kAuxAdv];
+          // losses.hip ppo_loss_kernel's arithmetic (PPO_agent.py:78-86), row by row
+          const float ratio = expf(lp - lp_old);
+          const float obj = ratio * adv;
+          const float rc = fminf(fmaxf(ratio, 1.f - cfg.ratio_clip), 1.f + cfg.ratio_clip);
+          const float objc = rc * adv;
+          const bool inside = (ratio >= 1.f - cfg.ratio_clip) && (ratio <= 1.f + cfg.ratio_clip);
+          const float gate = inside ? 1.f : (obj < objc ? 1.f : (obj == objc ? 0.5f : 0.f));
+          const float g_lp = row_ok ? -gate * obj * inv_m : 0.f;
+          if (row_ok && c16 == 0) { s0 += fminf(obj, objc); s1 += lp_old - lp; }
+          if (col_ok) {
+            dz = (g_lp * (diff / var)) * (1.f - mean * mean);
+            gsd += g_lp * ((diff * diff) / (var * sd) - 1.f / sd);
+          }
+          if (dump) {
+            dbg[kDbgHead + row * 16 + c16] = mean;
+            if (c16 == 0) { dbg[kDbgLp + row] = lp; dbg[kDbgGl + row] = g_lp; }
+          }
+        } else {
+          const float v = acc[r] + b3;
+          const float dv = sAux[row * kLd3 + kAuxRet] - v;
+          if (row_ok && c16 == 0) { s0 += dv * dv; dz = -dv * inv_m; }
+          if (dump) {
+            dbg[kDbgHead + row * 16 + c16] = v;
+            if (c16 == 0) { dbg[kDbgLp + row] = v; dbg[kDbgGl + row] = dz; }
+          }
+        }
+        sDZ3[row * kLd3 + c16] = dz;
+        if (dump) dbg[kDbgDz3 + row * 16 + c16] = dz;
+      }
+      s0 = over_g_sum(s0); s1 = over_g_sum(s1); gsd = over_g_sum(gsd);
+      if (l == 0) { sRed[4 * w] = s0; sRed[4 * w + 1] = s1; }
+      if (g == 0) sPart[16 * w + c16] = gsd;
+    }
+    __syncthreads();
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+{ t0 += sRed[4 * mt]; t1 += sRed[4 * mt + 1]; }
+    bool open = true;
+    float ent = 0.f;
+    if (ACTOR) {
+      const float kl = t1 * inv_m;
+      open = (double)kl <= cfg.kl_limit;
+      const float ent_e = c16 < A ? kEntConst + log_sd : 0.f;
+      ent = group16_sum(ent_e);
+      if (tid == 0 && (q == total - 1 || dump)) {
+        const float pl = -t0 * inv_m - cfg.entropy_weight * ent;
+        if (q == total - 1) { out3[0] = pl; out3[2] = kl; }
+        if (dump) { dbg[kDbgScal] = pl; dbg[kDbgScal + 2] = kl; dbg[kDbgScal + 3] = open ? 1.f : 0.f; dbg[kDbgScal + 4] = ent; }
+      }
+    } else if (tid == 0 && (q == total - 1 || dump)) {
+      const float vl = 0.5f * (t0 * inv_m);
+      if (q == total - 1) out3[1] = vl;
+      if (dump) dbg[kDbgScal + 1] = vl;
+    }
+
+    if (open) {
+      float gw3[4] = {0.f, 0.f, 0.f, 0.f}, gb3 = 0.f, gstd = 0.f;
+      // ---- B3: dz2 = (dz3 W3) (1 - h2^2);  dW3^T tile tk = w;  db3, dstd
+      if (own) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+          if (4 * s2 < A) {
+            const float b = sW3[(4 * s2 + g) * LD + ncol];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+              acc[mt] = MFMA16(sDZ3[(16 * mt + c16) * kLd3 + 4 * s2 + g], b, acc[mt]);
+          }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * mt + 4 * g + r;
+              const float h2 = sH2[row * LD + ncol];
+              const float dz = acc[mt][r] * (1.f - h2 * h2);
+              sDZ2[row * LD + ncol] = dz;
+              if (dump) dbg[kDbgDz2 + row * 64 + ncol] = dz;
+            }
+        f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
+        float bsum = 0.f;
+        for (int s = 0; s < 4 * MT; ++s) {
+          const int rr = row_of(s, g);
+          const float b = sDZ3[rr * kLd3 + c16];
+          bsum += b;
+          a3 = MFMA16(sH2[rr * LD + ncol], b, a3);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gw3[r] = a3[r];
+        gb3 = over_g_sum(bsum);
+        if (ACTOR && w == 0) {
+          float t = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            t += sPart[16 * mt + c16];
+          // d(-entropy_weight * mean(entropy)) / d scale = -entropy_weight / scale
+          gstd = (t - cfg.entropy_weight / sd) * softplus_grad(std_raw);
+        }
+        if (dump) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dbg[kDbgW3 + c16 * 64 + 16 * w + 4 * g + r] = gw3[r];
+          if (w == 0 && g == 0) { dbg[kDbgB3 + c16] = gb3; dbg[kDbgStd + c16] = gstd; }
+        }
+      }
+      __syncthreads();
+      // ---- B2: dW2^T tiles (this wave's units x all inputs);  dz1 = (dz2 W2) (1 - h1^2) into sH2
+      float gw2[NT][4], gb2 = 0.f;
+      if (own) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk) acc[tk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float bsum = 0.f;
+        for (int s = 0; s < 4 * MT; ++s) {
+          const int rr = row_of(s, g);
+          const float b = sDZ2[rr * LD + ncol];
+          bsum += b;
+#pragma unroll
+          for (int tk = 0; tk < NT; ++tk) acc[tk] = MFMA16(sH1[rr * LD + 16 * tk + c16], b, acc[tk]);
+        }
+        gb2 = over_g_sum(bsum);
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gw2[tk][r] = acc[tk][r];
+        f32x4 accd[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) accd[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) {
+          f32x4 av[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            av[mt] = *reinterpret_cast<const f32x4*>(&sDZ2[(16 * mt + c16) * LD + 16 * tn + 4 * g]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float b = sW2[(16 * tn + 4 * g + r) * LD + ncol];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+              accd[mt] = MFMA16(av[mt][r], b, accd[mt]);
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * mt + 4 * g + r;
+              const float h1 = sH1[row * LD + ncol];
+              const float dz = accd[mt][r] * (1.f - h1 * h1);
+              sH2[row * LD + ncol] = dz;
+              if (dump) dbg[kDbgDz1 + row * 64 + ncol] = dz;
+            }
+        if (dump) {
+#pragma unroll
+          for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dbg[kDbgW2 + ncol * 64 + 16 * tk + 4 * g + r] = gw2[tk][r];
+          if (g == 0) dbg[kDbgB2 + ncol] = gb2;
+        }
+      }
+      __syncthreads();
+      // ---- B1: dW1^T tiles;  then Adam on every master of this lane
+      if (own) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk) acc[tk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float bsum = 0.f;
+        for (int s = 0; s < 4 * MT; ++s) {
+          const int rr = row_of(s, g);
+          const float b = sH2[rr * LD + ncol];
+          bsum += b;
+#pragma unroll
+          for (int tk = 0; tk < 4; ++tk)
+            if (tk < KT1) acc[tk] = MFMA16(sX[rr * LDX + 16 * tk + c16], b, acc[tk]);
+        }
+        const float gb1 = over_g_sum(bsum);
+        if (dump) {
+#pragma unroll
+          for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (16 * tk + 4 * g + r < S) dbg[kDbgW1 + ncol * 64 + 16 * tk + 4 * g + r] = acc[tk][r];
+          if (g == 0) dbg[kDbgB1 + ncol] = gb1;
+        }
+        pw1 *= (double)net.beta1;
+        pw2 *= (double)net.beta2;
+        ad.step_size = (float)((double)net.lr / (1.0 - pw1));
+        ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pw2));
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+          if (tk < KT1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) adam_elem(w1p[tk][r], acc[tk][r], w1m[tk][r], w1v[tk][r], ad);
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) adam_elem(w2p[tk][r], gw2[tk][r], w2m[tk][r], w2v[tk][r], ad);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) adam_elem(w3p[r], gw3[r], w3m[r], w3v[r], ad);
+        adam_elem(b1p, gb1, b1m, b1v, ad);
+        adam_elem(b2p, gb2, b2m, b2v, ad);
+        if (w == 0 && c16 < A) {
+          adam_elem(b3p, gb3, b3m, b3v, ad);
+          if (ACTOR) adam_elem(sdp, gstd, sdm, sdv, ad);
+        }
+      }
+      ++steps;
+      ++applied;
+    }
+    __syncthreads();          // every read of sX / sAux / sW2 / sW3 of this minibatch has been issued and returned
+    if (open) publish();
+    if (q + 1 < total) commit();
+    __syncthreads();
+  }
+
+  // ---- write the resident state back
+  if (own) {
+#pragma unroll
+    for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * tk + 4 * g + r;
+        if (k < S) {
+          const int idx = net.off_w1 + ncol * S + k;
+          net.param[idx] = w1p[tk][r]; net.exp_avg[idx] = w1m[tk][r]; net.exp_avg_sq[idx] = w1v[tk][r];
+        }
+      }
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = net.off_w2 + ncol * H + 16 * tk + 4 * g + r;
+        net.param[idx] = w2p[tk][r]; net.exp_avg[idx] = w2m[tk][r]; net.exp_avg_sq[idx] = w2v[tk][r];
+      }
+    if (c16 < A)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = net.off_w3 + c16 * H + 16 * w + 4 * g + r;
+        net.param[idx] = w3p[r]; net.exp_avg[idx] = w3m[r]; net.exp_avg_sq[idx] = w3v[r];
+      }
+    if (g == 0) {
+      net.param[net.off_b1 + ncol] = b1p; net.exp_avg[net.off_b1 + ncol] = b1m; net.exp_avg_sq[net.off_b1 + ncol] = b1v;
+      net.param[net.off_b2 + ncol] = b2p; net.exp_avg[net.off_b2 + ncol] = b2m; net.exp_avg_sq[net.off_b2 + ncol] = b2v;
+      if (w == 0 && c16 < A) {
+        net.param[net.off_b3 + c16] = b3p; net.exp_avg[net.off_b3 + c16] = b3m; net.exp_avg_sq[net.off_b3 + c16] = b3v;
+        if (ACTOR) { net.param[net.off_std + c16] = sdp; net.exp_avg[net.off_std + c16] = sdm; net.exp_avg_sq[net.off_std + c16] = sdv; }
+      }
+    }
+  }
+  if (tid == 0) {
+    *net.step_dev = steps0 + applied;
+    if (out_counts) out_counts[ACTOR ? 0 : 1] = applied;
+  }
+}
+
+template <int H, bool DUMP>
+__global__ void __launch_bounds__(256)
+ppo_mlp_update_kernel(dra_ppo_mlp_cfg cfg, dra_ppo_mlp_net actor, dra_ppo_mlp_net critic, const float* __restrict__ packed, int n,
+                      int epochs, float* __restrict__ out3, int64_t* __restrict__ out_counts, float* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (blockIdx.x == 0) ppo_update_role<H, true, DUMP>(cfg, actor, packed, n, epochs, out3, out_counts, dbg, lds);
+  else ppo_update_role<H, false, DUMP>(cfg, critic, packed, n, epochs, out3, out_counts, dbg, lds);
+}
+
+// ------------------------------------------------------------------------------------------------ pack
+// PPO_agent.py:72-76: minibatch k of epoch e holds rows perm[e][k MB .. k MB + MB) of the rollout.  One LDS image per minibatch:
+// [kRows][LDX] observations (columns >= S and rows past the minibatch zero) then [kRows][kLd3] = action [A] | 0 .. | log_pi_a,
+// advantage, ret at columns 16, 17, 18.
+__global__ void __launch_bounds__(256)
+ppo_pack_kernel(const float* __restrict__ state, const float* __restrict__ action, const float* __restrict__ lp,
+                const float* __restrict__ adv, const float* __restrict__ ret, const int64_t* __restrict__ perm, int n, int epochs,
+                int mb, int S, int A, float* __restrict__ out) {
+  const int LDX = 16 * ((S + 15) >> 4) + 4, img = kRows * (LDX + kLd3), per_epoch = (n + mb - 1) / mb;
+  const int64_t total = (int64_t)epochs * per_epoch * img, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t q = i / img;
+    const int o = (int)(i - q * img);
+    const int e = (int)(q / per_epoch), k = (int)(q - (int64_t)e * per_epoch);
+    const int rows = min(mb, n - k * mb);
+    float v = 0.f;
+    if (o < kRows * LDX) {
+      const int row = o / LDX, c = o - row * LDX;
+      if (row < rows && c < S) v = state[perm[(int64_t)e * n + k * mb + row] * S + c];
+    } else {
+      const int o2 = o - kRows * LDX;
+      const int row = o2 / kLd3, c = o2 - row * kLd3;
+      if (row < rows) {
+        const int64_t src = perm[(int64_t)e * n + k * mb + row];
+        if (c < A) v = action[src * A + c];
+        else if (c == kAuxLp) v = lp[src];
+        else if (c == kAuxAdv) v = adv[src];
+        else if (c == kAuxRet) v = ret[src];
+      }
+    }
+    out[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ stand-alone pieces
+__global__ void __launch_bounds__(256)
+rms_normalize_kernel(const double* __restrict__ x, int n, int d, double* __restrict__ mean, double* __restrict__ var,
+                     double* __restrict__ count, int update, double epsilon, double clip, float* __restrict__ out_f32,
+                     double* __restrict__ out_f64) {
+  extern __shared__ __attribute__((aligned(16))) double s_stat[];   // mean [d], var [d]
+  const double cnt = *count;
+  for (int j = threadIdx.x; j < d; j += blockDim.x) {
+    double m = mean[j], v = var[j];
+    if (update) rms_fold(x + j, d, n, m, v, cnt);
+    s_stat[j] = m;
+    s_stat[d + j] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n * d; i += blockDim.x) {
+    const int j = i % d;
+    const double m = s_stat[j], v = s_stat[d + j];
+    double z = (x[i] - m) / sqrt(v + epsilon);
+    z = z < -clip ? -clip : (z > clip ? clip : z);
+    if (out_f64) out_f64[i] = z;
+    if (out_f32) out_f32[i] = (float)z;
+  }
+  if (update) {
+    for (int j = threadIdx.x; j < d; j += blockDim.x) { mean[j] = s_stat[j]; var[j] = s_stat[d + j]; }
+    __syncthreads();     // every thread has read *count
+    if (threadIdx.x == 0) *count = cnt + (double)n;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gauss_sample_kernel(const float* __restrict__ mean, const float* __restrict__ scale, int n, int a_dim, uint64_t noise_seed,
+                    int64_t* __restrict__ step_dev, int64_t n_global, int64_t env0, float* __restrict__ out) {
+  const int64_t t = *step_dev;
+  for (int i = threadIdx.x; i < n * a_dim; i += blockDim.x) {
+    const int r = i / a_dim, d = i - r * a_dim;
+    out[i] = gauss_noise(noise_seed, t, n_global, env0 + r, d) * scale[d] + mean[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *step_dev = t + 1;
+}
+
+__global__ void __launch_bounds__(256)
+cont_env_step_kernel(double* __restrict__ state, int64_t* __restrict__ counter, const int64_t* __restrict__ seed,
+                     const float* __restrict__ action, int n, int S, int A, int64_t horizon, double* __restrict__ out_reward,
+                     int32_t* __restrict__ out_done) {
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int64_t c = counter[i] + 1;
+    const uint64_t sd = (uint64_t)seed[i];
+    const double mean_a = cenv_mean_action(action + (int64_t)i * A, A);
+    const bool done = cenv_done(sd, c, horizon);
+    for (int j = threadIdx.x; j < S; j += blockDim.x)
+      state[(int64_t)i * S + j] = cenv_next_state(sd, c, j, state[(int64_t)i * S + j], mean_a, done);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      counter[i] = c;
+      out_reward[i] = cenv_reward(sd, c);
+      out_done[i] = done ? 1 : 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ rollout
+constexpr size_t rollout_lds_floats(int H) {
+  // sX | per role: sH1, sH2 (kRows x LD) | sW3 [2][16][LD] | sAct [kRows][kLd3] | fp64: state [kRows][kMaxS], mean, var [kMaxS],
+  // mean_a [kRows], count | counters i64 [kRows] | done i32 [kRows]
+  return (size_t)kRows * kLdX + 4 * (size_t)kRows * (H + 4) + 32 * (size_t)(H + 4) + (size_t)kRows * kLd3 +
+         2 * ((size_t)kRows * kMaxS + 2 * kMaxS + kRows + 2) + 2 * kRows + kRows + 64;
+}
+
+template <int H>
+__global__ void __launch_bounds__(512)
+ppo_mlp_rollout_kernel(dra_ppo_mlp_cfg cfg, dra_ppo_mlp_net actor, dra_ppo_mlp_net critic, dra_ppo_mlp_rollout_io io) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NT = H / 16, LD = H + 4;
+  const int tid = threadIdx.x, wv = tid >> 6, role = wv >> 2, w = wv & 3, l = tid & 63, c16 = l & 15, g = l >> 4;
+  const dra_ppo_mlp_net& net = role == 0 ? actor : critic;
+  const int S = cfg.state_dim, AD = cfg.action_dim, A = role == 0 ? AD : 1;
+  const int N = io.n_env, T = io.t_len;
+  const int KT1 = (S + 15) >> 4, LDX = 16 * KT1 + 4;
+  const int MT = (N + 15) >> 4;
+  const bool own = w < NT;
+  const int ncol = 16 * w + c16;
+
+  float* sX = lds;
+  float* sH1 = sX + kRows * kLdX + role * (2 * kRows * LD);
+  float* sH2 = sH1 + kRows * LD;
+  float* sW3 = sX + kRows * kLdX + 4 * kRows * LD + role * (16 * LD);
+  float* sAct = sX + kRows * kLdX + 4 * kRows * LD + 32 * LD;
+  double* sState = reinterpret_cast<double*>(sAct + kRows * kLd3);
+  double* sMean = sState + kRows * kMaxS;
+  double* sVar = sMean + kMaxS;
+  double* sMeanA = sVar + kMaxS;
+  double* sCount = sMeanA + kRows;         // [2]
+  int64_t* sCtr = reinterpret_cast<int64_t*>(sCount + 2);
+  int32_t* sDone = reinterpret_cast<int32_t*>(sCtr + kRows);
+  for (int i = tid; i < (int)rollout_lds_floats(H); i += 512) lds[i] = 0.f;
+  __syncthreads();
+
+  // weights as forward B operands (constant over the rollout)
+  float w1[4][4], w2[NT][4];
+#pragma unroll
+  for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * tk + 4 * g + r;
+      w1[tk][r] = (own && k < S) ? net.param[net.off_w1 + ncol * S + k] : 0.f;
+    }
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w2[tk][r] = own ? net.param[net.off_w2 + ncol * H + 16 * tk + 4 * g + r] : 0.f;
+  const float b1 = own ? net.param[net.off_b1 + ncol] : 0.f, b2 = own ? net.param[net.off_b2 + ncol] : 0.f;
+  if (own && c16 < A)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sW3[c16 * LD + 16 * w + 4 * g + r] = net.param[net.off_w3 + c16 * H + 16 * w + 4 * g + r];
+  const float b3 = c16 < A ? net.param[net.off_b3 + c16] : 0.f;
+  float sd = 1.f, log_sd = 0.f;
+  if (role == 0 && c16 < A) { sd = softplus_f(net.param[net.off_std + c16]); log_sd = logf(sd); }
+  // environment + normaliser state
+  for (int i = tid; i < N * S; i += 512) {
+    const int e = i / S, j = i - e * S;
+    sState[e * kMaxS + j] = io.env_state[i];
+    sX[e * LDX + j] = io.cur_state[i];
+  }
+  for (int i = tid; i < S; i += 512) { sMean[i] = io.rms[i]; sVar[i] = io.rms[S + i]; }
+  for (int i = tid; i < N; i += 512) sCtr[i] = io.env_counter[i];
+  if (tid == 0) sCount[0] = io.rms[2 * S];
+  const int64_t t_noise0 = *io.sampler_step;
+  __syncthreads();
+
+  for (int t = 0; t <= T; ++t) {
+    if (t < T)
+      for (int i = tid; i < N * S; i += 512) {
+        const int e = i / S, j = i - e * S;
+        io.out_state[(int64_t)t * N * S + i] = sX[e * LDX + j];
+      }
+    // F1
+    if (own) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk)
+        if (tk < KT1) {
+          f32x4 av[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            if (mt < MT) av[mt] = *reinterpret_cast<const f32x4*>(&sX[(16 * mt + c16) * LDX + 16 * tk + 4 * g]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+              if (mt < MT) acc[mt] = MFMA16(av[mt][r], w1[tk][r], acc[mt]);
+        }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        if (mt < MT)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sH1[(16 * mt + 4 * g + r) * LD + ncol] = fast_tanh(acc[mt][r] + b1);
+    }
+    __syncthreads();
+    if (own) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk) {
+        f32x4 av[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          if (mt < MT) av[mt] = *reinterpret_cast<const f32x4*>(&sH1[(16 * mt + c16) * LD + 16 * tk + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+            if (mt < MT) acc[mt] = MFMA16(av[mt][r], w2[tk][r], acc[mt]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        if (mt < MT)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sH2[(16 * mt + 4 * g + r) * LD + ncol] = fast_tanh(acc[mt][r] + b2);
+    }
+    __syncthreads();
+    // head: wave mt of each role takes environments [16 mt, 16 mt + 16)
+    if (w < MT) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(&sH2[(16 * w + c16) * LD + 16 * tk + 4 * g]);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(&sW3[c16 * LD + 16 * tk + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = MFMA16(av[r], bv[r], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = 16 * w + 4 * g + r;
+        if (role == 0) {
+          if (t < T) {
+            const float mean = fast_tanh(acc[r] + b3);
+            float lpe = 0.f;
+            if (c16 < A && e < N) {
+              // network_heads.py:205-208: action = mean + scale * noise;  log_prob sums the per-dimension Normal log densities
+              const float act = gauss_noise(io.noise_seed, t_noise0 + t, io.n_global, io.env0 + e, c16) * sd + mean;
+              const float diff = act - mean;
+              lpe = -(diff * diff) / (2.f * (sd * sd)) - log_sd - kLogSqrt2Pi;
+              io.out_action[((int64_t)t * N + e) * AD + c16] = act;
+              sAct[e * kLd3 + c16] = act;
+            }
+            const float lp = group16_sum(lpe);
+            if (c16 == 0 && e < N) io.out_log_pi_a[(int64_t)t * N + e] = lp;
+          }
+        } else if (c16 == 0 && e < N) {
+          io.out_v[(int64_t)t * N + e] = acc[r] + b3;
+        }
+      }
+    }
+    if (t == T) break;
+    __syncthreads();
+    // environment step: per environment scalars first ...
+    for (int e = tid; e < N; e += 512) {
+      const int64_t c = sCtr[e] + 1;
+      const uint64_t sdv = (uint64_t)io.env_seed[e];
+      sCtr[e] = c;
+      sMeanA[e] = cenv_mean_action(sAct + e * kLd3, AD);
+      const bool done = cenv_done(sdv, c, io.horizon);
+      sDone[e] = done ? 1 : 0;
+      io.out_reward[(int64_t)t * N + e] = (float)(cenv_reward(sdv, c) * io.reward_coef);
+      io.out_mask[(int64_t)t * N + e] = done ? 0.f : 1.f;
+    }
+    __syncthreads();
+    // ... then every observation component
+    for (int i = tid; i < N * S; i += 512) {
+      const int e = i / S, j = i - e * S;
+      sState[e * kMaxS + j] = cenv_next_state((uint64_t)io.env_seed[e], sCtr[e], j, sState[e * kMaxS + j], sMeanA[e], sDone[e] != 0);
+    }
+    __syncthreads();
+    // running statistics (one thread per feature), then the normalised observation of step t + 1
+    if (io.rms_update) {
+      for (int j = tid; j < S; j += 512) {
+        double m = sMean[j], v = sVar[j];
+        rms_fold(sState + j, kMaxS, N, m, v, sCount[0]);
+        sMean[j] = m;
+        sVar[j] = v;
+      }
+      __syncthreads();
+      if (tid == 0) sCount[0] = sCount[0] + (double)N;
+    }
+    __syncthreads();
+    for (int i = tid; i < N * S; i += 512) {
+      const int e = i / S, j = i - e * S;
+      sX[e * LDX + j] = rms_apply(sState[e * kMaxS + j], sMean[j], sVar[j], io.rms_epsilon, io.rms_clip);
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int i = tid; i < N * S; i += 512) {
+    const int e = i / S, j = i - e * S;
+    io.env_state[i] = sState[e * kMaxS + j];
+    io.cur_state[i] = sX[e * LDX + j];
+  }
+  for (int i = tid; i < S; i += 512) { io.rms[i] = sMean[i]; io.rms[S + i] = sVar[i]; }
+  for (int i = tid; i < N; i += 512) io.env_counter[i] = sCtr[i];
+  if (tid == 0) {
+    io.rms[2 * S] = sCount[0];
+    *io.sampler_step = t_noise0 + T + 1;
+  }
+}
+
+int check_net(const dra_ppo_mlp_net* n, bool actor) {
+  if (!n || !n->param || !n->exp_avg || !n->exp_avg_sq || !n->step_dev) return DRA_EINVAL;
+  if (n->off_w1 < 0 || n->off_b1 < 0 || n->off_w2 < 0 || n->off_b2 < 0 || n->off_w3 < 0 || n->off_b3 < 0) return DRA_EINVAL;
+  if (actor && n->off_std < 0) return DRA_EINVAL;
+  if (!(n->eps > 0.f) || !(n->beta1 >= 0.f && n->beta1 < 1.f) || !(n->beta2 >= 0.f && n->beta2 < 1.f)) return DRA_EINVAL;
+  return DRA_OK;
+}
+
+}  // namespace
+
+DRA_API int dra_ppo_mlp_supported(int state_dim, int action_dim, int hidden1, int hidden2, int mini_batch) {
+  if (state_dim < 1 || state_dim > kMaxS || action_dim < 1 || action_dim > kMaxA) return DRA_EINVAL;
+  if (hidden1 != hidden2 || (hidden1 != 16 && hidden1 != 32 && hidden1 != 64)) return DRA_EINVAL;
+  if (mini_batch < 1 || mini_batch > kRows) return DRA_EINVAL;
+  return DRA_OK;
+}
+
+DRA_API int dra_ppo_mlp_packed_floats(int n, int epochs, int mini_batch, int s_dim, int64_t* floats) {
+  if (!floats || n < 1 || epochs < 1 || mini_batch < 1 || mini_batch > kRows || s_dim < 1 || s_dim > kMaxS) return DRA_EINVAL;
+  const int LDX = 16 * ((s_dim + 15) >> 4) + 4;
+  *floats = (int64_t)epochs * ((n + mini_batch - 1) / mini_batch) * kRows * (LDX + kLd3);
+  return DRA_OK;
+}
+
+DRA_API int dra_ppo_mlp_pack(const float* state, const float* action, const float* log_pi_a, const float* advantage, const float* ret,
+                             const int64_t* perm, int n, int epochs, int mini_batch, int s_dim, int a_dim, float* out_packed,
+                             void* stream) {
+  if (!state || !action || !log_pi_a || !advantage || !ret || !perm || !out_packed) return DRA_EINVAL;
+  int64_t floats = 0;
+  if (dra_ppo_mlp_packed_floats(n, epochs, mini_batch, s_dim, &floats) || a_dim < 1 || a_dim > kMaxA) return DRA_EINVAL;
+  int64_t blocks = (floats + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(ppo_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, dra_stream(stream), state, action, log_pi_a, advantage,
+                     ret, perm, n, epochs, mini_batch, s_dim, a_dim, out_packed);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+template <int H, bool DUMP>
+static int launch_update(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic, const float* packed,
+                         int n, int epochs, float* out3, int64_t* out_counts, float* dbg, void* stream) {
+  const size_t bytes = update_lds_floats(H) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_update_kernel<H, DUMP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((ppo_mlp_update_kernel<H, DUMP>), dim3(2), dim3(256), bytes, dra_stream(stream), *cfg, *actor, *critic, packed, n,
+                     epochs, out3, out_counts, dbg);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+DRA_API int dra_ppo_mlp_update(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
+                               const float* packed, int n, int epochs, float* out3, int64_t* out_counts, float* dbg, void* stream) {
+  if (!cfg || !packed || !out3 || n < 1 || epochs < 1) return DRA_EINVAL;
+  if (dra_ppo_mlp_supported(cfg->state_dim, cfg->action_dim, cfg->hidden, cfg->hidden, cfg->mini_batch)) return DRA_EINVAL;
+  if (check_net(actor, true) || check_net(critic, false)) return DRA_EINVAL;
+  // the dump build is a separate instantiation: its stores would otherwise cost the product kernel registers
+#define DRA_PPO_UPD(HH) (dbg ? launch_update<HH, true>(cfg, actor, critic, packed, n, epochs, out3, out_counts, dbg, stream) \
+                             : launch_update<HH, false>(cfg, actor, critic, packed, n, epochs, out3, out_counts, dbg, stream))
+  switch (cfg->hidden) {
+    case 16: return DRA_PPO_UPD(16);
+    case 32: return DRA_PPO_UPD(32);
+    default: return DRA_PPO_UPD(64);
+  }
+#undef DRA_PPO_UPD
+}
+
+template <int H>
+static int launch_rollout(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
+                          const dra_ppo_mlp_rollout_io* io, void* stream) {
+  const size_t bytes = rollout_lds_floats(H) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_rollout_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(ppo_mlp_rollout_kernel<H>, dim3(1), dim3(512), bytes, dra_stream(stream), *cfg, *actor, *critic, *io);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+DRA_API int dra_ppo_mlp_rollout(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
+                                const dra_ppo_mlp_rollout_io* io, void* stream) {
+  if (!cfg || !io) return DRA_EINVAL;
+  if (dra_ppo_mlp_supported(cfg->state_dim, cfg->action_dim, cfg->hidden, cfg->hidden, 1)) return DRA_EINVAL;
+  if (check_net(actor, true) || check_net(critic, false)) return DRA_EINVAL;
+  if (io->n_env < 1 || io->n_env > kRows || io->t_len < 1 || io->horizon < 1 || io->n_global < io->n_env || io->env0 < 0) return DRA_EINVAL;
+  if (!io->env_state || !io->env_counter || !io->env_seed || !io->rms || !io->cur_state || !io->sampler_step || !io->out_state ||
+      !io->out_action || !io->out_log_pi_a || !io->out_v || !io->out_reward || !io->out_mask)
+    return DRA_EINVAL;
+  switch (cfg->hidden) {
+    case 16: return launch_rollout<16>(cfg, actor, critic, io, stream);
+    case 32: return launch_rollout<32>(cfg, actor, critic, io, stream);
+    default: return launch_rollout<64>(cfg, actor, critic, io, stream);
+  }
+}
+
+DRA_API int dra_rms_normalize(const double* x, int n, int d, double* mean, double* var, double* count, int update, double epsilon,
+                              double clip, float* out_f32, double* out_f64, void* stream) {
+  if (!x || !mean || !var || !count || n < 1 || d < 1 || d > 4096) return DRA_EINVAL;
+  hipLaunchKernelGGL(rms_normalize_kernel, dim3(1), dim3(256), 2 * (size_t)d * sizeof(double), dra_stream(stream), x, n, d, mean, var,
+                     count, update, epsilon, clip, out_f32, out_f64);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+DRA_API int dra_gauss_sample(const float* mean, const float* scale, int n, int a_dim, uint64_t noise_seed, int64_t* step_dev,
+                             int64_t n_global, int64_t env0, float* out_action, void* stream) {
+  if (!mean || !scale || !step_dev || !out_action || n < 1 || a_dim < 1 || a_dim > 32 || n_global < n || env0 < 0) return DRA_EINVAL;
+  hipLaunchKernelGGL(gauss_sample_kernel, dim3(1), dim3(256), 0, dra_stream(stream), mean, scale, n, a_dim, noise_seed, step_dev,
+                     n_global, env0, out_action);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+DRA_API int dra_cont_env_step(double* state, int64_t* counter, const int64_t* seed, const float* action, int n, int s_dim, int a_dim,
+                              int64_t horizon, double* out_reward, int32_t* out_done, void* stream) {
+  if (!state || !counter || !seed || !action || !out_reward || !out_done || n < 1 || s_dim < 1 || s_dim > 64 || a_dim < 1 ||
+      horizon < 1)
+    return DRA_EINVAL;
+  hipLaunchKernelGGL(cont_env_step_kernel, dim3((unsigned)(n < 1024 ? n : 1024)), dim3(64), 0, dra_stream(stream), state, counter, seed,
+                     action, n, s_dim, a_dim, horizon, out_reward, out_done);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}

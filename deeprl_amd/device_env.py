@@ -148,3 +148,106 @@ class DeviceAtariVec:
 
     def close(self):
         return
+
+
+class DeviceContinuousVec:
+    """The SyntheticContinuous environments of a Task, resident on the device (BASELINE configs[2]: PPO, 16 HalfCheetah-shaped
+    workers): raw fp64 observations, step counters and the observation normaliser's running statistics live in HBM and one
+    launch (dra_ppo_mlp_rollout) walks a whole rollout -- normalise, both forwards, sample, environment step -- without a host
+    round trip.  Rewards and terminals are hashes of (seed, counter) alone, so the host keeps a shadow of them (vectorised,
+    one pass per rollout) for the episodic-return log lines; observations depend on the actions and exist only on the device.
+    Same arithmetic as envs.SyntheticContinuous + normalizers.MeanStdNormalizer stepped from python (csrc/cont_env.h;
+    tests/test_gpu_ppo_mlp.py compares the two paths)."""
+    on_device = True
+
+    def __init__(self, task, agent_states, normalizer):
+        """task: the envs.Task whose (already reset) environments move to the device; agent_states: the normalised observations
+        the agent holds (what config.state_normalizer(task.reset()) returned); normalizer: config.state_normalizer."""
+        from .normalizers import MeanStdNormalizer
+        envs = task.env.envs
+        dev = Config.DEVICE
+        self.task = task
+        self.name, self.state_dim, self.action_dim = task.name, task.state_dim, task.action_dim
+        self.observation_space, self.action_space = task.observation_space, task.action_space
+        self.num_envs, self.horizon = len(envs), int(envs[0].horizon)
+        self.seeds_host = np.asarray([e.seed for e in envs], dtype=np.int64)
+        self.counters_host = np.asarray([e.c for e in envs], dtype=np.int64)
+        self.ret_host = np.asarray([e.ret for e in envs], dtype=np.float64)
+        self.env_state = torch.from_numpy(np.stack([e.s for e in envs]).astype(np.float64)).to(dev)
+        self.env_counter = torch.from_numpy(self.counters_host.copy()).to(dev)
+        self.env_seed = torch.from_numpy(self.seeds_host.copy()).to(dev)
+        self.cur_state = torch.from_numpy(np.ascontiguousarray(np.asarray(agent_states, dtype=np.float32))).to(dev)
+        s = self.state_dim
+        rms = np.zeros(2 * s + 1, dtype=np.float64)
+        self.normalizer = normalizer
+        if isinstance(normalizer, MeanStdNormalizer):
+            rms[:s], rms[s:2 * s], rms[2 * s] = normalizer.rms.mean.reshape(-1), normalizer.rms.var.reshape(-1), normalizer.rms.count
+            self.rms_epsilon, self.rms_clip, self.rms_kind = float(normalizer.epsilon), float(normalizer.clip), 'meanstd'
+        else:       # RescaleNormalizer(1.0): (x - 0) / sqrt(1 + 0) = x exactly, no clipping, no statistics
+            rms[s:2 * s] = 1.0
+            self.rms_epsilon, self.rms_clip, self.rms_kind = 0.0, float('inf'), 'identity'
+        self.rms = torch.from_numpy(rms).to(dev)
+        if self.rms_kind == 'meanstd':
+            normalizer.attach_device(self.rms, s)
+        for e in envs:
+            e.s = "device"          # the host objects are retired: stepping them too would fork the streams
+        self._bufs = {}
+
+    @staticmethod
+    def eligible(task, config):
+        from .envs import DummyVecEnv, SyntheticContinuous, Task
+        from .normalizers import MeanStdNormalizer, RescaleNormalizer
+        if Config.DEVICE.type != 'cuda' or getattr(config, 'device_env', True) is False or type(task) is not Task:
+            return False
+        env = getattr(task, 'env', None)
+        if type(env) is not DummyVecEnv or not env.envs or len(env.envs) > 64:
+            return False
+        e0 = env.envs[0]
+        if not all(type(e) is SyntheticContinuous and e.horizon == e0.horizon and e.state_dim == e0.state_dim and
+                   e.action_dim == e0.action_dim for e in env.envs):
+            return False
+        sn, rn = config.state_normalizer, config.reward_normalizer
+        state_ok = type(sn) is MeanStdNormalizer or (type(sn) is RescaleNormalizer and sn.coef == 1.0)
+        return state_ok and type(rn) is RescaleNormalizer
+
+    def buffers(self, t_len):
+        if t_len not in self._bufs:
+            n, s, a, dev = self.num_envs, self.state_dim, self.action_dim, Config.DEVICE
+            f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+            self._bufs[t_len] = dict(state=f(t_len, n, s), action=f(t_len, n, a), log_pi_a=f(t_len, n, 1), v=f(t_len + 1, n, 1),
+                                     reward=f(t_len, n, 1), mask=f(t_len, n, 1))
+        return self._bufs[t_len]
+
+    def shadow(self, t_len):
+        """Advances the host shadow by t_len steps of every environment -> list of (t, env, episodic_return) for the episodes
+        that end inside the rollout (envs.SyntheticContinuous.step's reward / done / return arithmetic, vectorised)."""
+        from .envs import _GOLD, _mix64
+        n = self.num_envs
+        c = (self.counters_host[None, :] + np.arange(1, t_len + 1, dtype=np.int64)[:, None]).astype(np.uint64)     # [T, N]
+        with np.errstate(over="ignore"):
+            sd = self.seeds_host.astype(np.uint64)[None, :] * np.uint64(8)
+            base_r = (sd + np.uint64(2)) * _GOLD + c * np.uint64(64)
+            u = [(_mix64(base_r + np.uint64(j)) >> np.uint64(11)).astype(np.float64) * 1.1102230246251565e-16 for j in range(4)]
+            done = (_mix64((sd + np.uint64(3)) * _GOLD + c * np.uint64(64)) % np.uint64(self.horizon)) == 0
+        reward = (((u[0] + u[1]) + (u[2] + u[3])) - 2.0) * 1.7320508075688772
+        events = []
+        for i in range(n):
+            ends = np.nonzero(done[:, i])[0]
+            start, carry = 0, self.ret_host[i]
+            for t in ends:
+                carry = float(np.cumsum(np.concatenate([[carry], reward[start:t + 1, i]]))[-1])
+                events.append((int(t), i, carry))
+                start, carry = int(t) + 1, 0.0
+            self.ret_host[i] = float(np.cumsum(np.concatenate([[carry], reward[start:, i]]))[-1])
+        self.counters_host += t_len
+        events.sort()
+        return events
+
+    def reset(self):
+        return None
+
+    def step(self, actions):
+        raise RuntimeError("DeviceContinuousVec is driven through PPOAgent's device rollout; its environments are not steppable")
+
+    def close(self):
+        return

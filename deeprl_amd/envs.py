@@ -160,6 +160,49 @@ class SyntheticVector:
         return self.s.copy(), reward, done, info
 
 
+class SyntheticContinuous:
+    """Continuous-control stand-in (HalfCheetah shapes by default: 17 observations, 6 actions in [-1, 1]) whose every
+    quantity is a hash of (seed, stream, step counter, component) -- the host statement of csrc/cont_env.h, bit for bit, so
+    that the same environments can live on the device (device_env.DeviceContinuousVec) and a device rollout can be compared
+    with this class stepped from python:
+        step(a):  c += 1;  m = (((a0 + a1) + a2) + ...) / A  (fp64);  s = (s + 0.01 m) + (-0.02 + 0.04 U(0, c, j))
+                  reward = (((U(1,c,0) + U(1,c,1)) + (U(1,c,2) + U(1,c,3))) - 2) * sqrt(3);  done = hash(2, c) mod horizon == 0
+        reset():  s_j = -0.05 + 0.1 U(3, c, j)
+    The observation drifts with the mean action, so a rollout keeps the data dependence a real simulator has."""
+
+    def __init__(self, seed=0, state_dim=17, action_dim=6, horizon=1000):
+        self.seed, self.state_dim, self.action_dim, self.horizon = int(seed), int(state_dim), int(action_dim), int(horizon)
+        self.c = 0
+        self.s = None
+        self.ret = 0.0
+        self._j = np.arange(self.state_dim, dtype=np.uint64)
+
+    def _hash(self, stream, j):
+        with np.errstate(over="ignore"):
+            base = (np.uint64(self.seed) * np.uint64(8) + np.uint64(stream + 1)) * _GOLD + np.uint64(self.c) * np.uint64(64)
+            return _mix64(base + j)
+
+    def _u(self, stream, j):
+        return (self._hash(stream, j) >> np.uint64(11)).astype(np.float64) * 1.1102230246251565e-16
+
+    def reset(self):
+        self.s = -0.05 + 0.1 * self._u(3, self._j)
+        self.ret = 0.0
+        return self.s.copy()
+
+    def step(self, action):
+        a = np.clip(np.asarray(action, dtype=np.float32).reshape(-1), np.float32(-1.0), np.float32(1.0)).astype(np.float64)
+        self.c += 1
+        mean_a = float(np.cumsum(a)[-1]) / float(a.size)         # left-to-right sum (np.mean's pairwise order is numpy's business)
+        self.s = (self.s + 0.01 * mean_a) + (-0.02 + 0.04 * self._u(0, self._j))
+        u = self._u(1, np.arange(4, dtype=np.uint64))
+        reward = float((((u[0] + u[1]) + (u[2] + u[3])) - 2.0) * 1.7320508075688772)
+        done = bool(int(self._hash(2, np.uint64(0))) % self.horizon == 0)
+        self.ret += reward
+        info = {'episodic_return': self.ret if done else None}
+        return self.s.copy(), reward, done, info
+
+
 class DummyVecEnv:
     """envs.py:126-150: serial vector env with auto-reset on done."""
 
@@ -370,7 +413,7 @@ class Task:
             self.observation_space = Box(0, 255, (4, 84, 84))
             self.action_space = Discrete(4)
         elif continuous:
-            envs = [SyntheticVector(seed + i, 17, 6, continuous=True, horizon=synthetic_done_period or 1000) for i in range(num_envs)]
+            envs = [SyntheticContinuous(seed + i, 17, 6, horizon=synthetic_done_period or 1000) for i in range(num_envs)]
             self.observation_space = Box(-np.inf, np.inf, (17,))
             self.action_space = Box(-1.0, 1.0, (6,))
         else:

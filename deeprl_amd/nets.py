@@ -629,7 +629,11 @@ class GaussianActorCriticNet(nn.Module, BaseNet):
             # dist.sample() is torch.normal(mean, scale): standard normals, times scale, plus mean.  Written out
             # because torch.normal checks `scale >= 0` on the HOST, which a captured rollout graph cannot do.
             with torch.no_grad():
-                action = torch.randn_like(mean).mul_(scale).add_(mean)
+                sampler = getattr(self, "sampler", None)
+                if sampler is not None:     # counter-hash normals (ppo_mlp.gauss_sample): the stream the device rollout draws
+                    action = sampler(mean.detach(), scale.detach())
+                else:
+                    action = torch.randn_like(mean).mul_(scale).add_(mean)
         log_prob = dist.log_prob(action).sum(-1).unsqueeze(-1)
         entropy = dist.entropy().sum(-1).unsqueeze(-1)
         return {'action': action, 'log_pi_a': log_prob, 'entropy': entropy, 'mean': mean, 'v': v}

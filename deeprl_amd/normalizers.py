@@ -57,7 +57,10 @@ class MeanStdNormalizer(BaseNormalizer):
         self.clip, self.epsilon, self.rms = clip, epsilon, None
 
     def __call__(self, x):
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float64:
+            return self._call_device(x)
         x = np.asarray(x)
+        self.sync_from_device()
         if self.rms is None:                       # statistics are per feature, shared by the environments
             self.rms = RunningMeanStd(shape=(1,) + x.shape[1:])
         if not self.read_only:
@@ -65,11 +68,47 @@ class MeanStdNormalizer(BaseNormalizer):
         z = (x - self.rms.mean) / np.sqrt(self.rms.var + self.epsilon)
         return np.clip(z, -self.clip, self.clip)
 
+    def attach_device(self, rms_dev, dim):
+        """The statistics moved to the device (device_env.DeviceContinuousVec: f64 [mean (dim) | var (dim) | count]); the host
+        copy is refreshed from there whenever it is asked for."""
+        self._dev, self._dim = rms_dev, int(dim)
+
+    def sync_from_device(self):
+        dev = getattr(self, '_dev', None)
+        if dev is not None:
+            h, d = dev.cpu().numpy(), self._dim
+            shape = self.rms.mean.shape
+            self.rms.mean, self.rms.var, self.rms.count = h[:d].reshape(shape).copy(), h[d:2 * d].reshape(shape).copy(), float(h[2 * d])
+
+    def _call_device(self, x):
+        """A float64 DEVICE batch [n, d]: one kernel (dra_rms_normalize) updates the statistics -- kept on the device from the
+        first such call on -- and returns the float32 tensor tensor() would have uploaded.  Same operation order as the host
+        arithmetic above, bit for bit (tests/test_gpu_ppo_mlp.py)."""
+        from . import ppo_mlp
+        d = x.shape[1]
+        if getattr(self, '_dev', None) is None:
+            if self.rms is None:
+                self.rms = RunningMeanStd(shape=(1, d))
+            h = np.concatenate([np.asarray(self.rms.mean, dtype=np.float64).reshape(-1),
+                                np.asarray(self.rms.var, dtype=np.float64).reshape(-1), [float(self.rms.count)]])
+            self.attach_device(torch.from_numpy(h).to(x.device), d)
+        dev = self._dev
+        out, _ = ppo_mlp.rms_normalize(x, dev[:d], dev[d:2 * d], dev[2 * d:], update=not self.read_only, epsilon=self.epsilon,
+                                       clip=self.clip)
+        return out
+
     def state_dict(self):
+        self.sync_from_device()
         return dict(mean=self.rms.mean, var=self.rms.var)
 
     def load_state_dict(self, saved):
         self.rms.mean, self.rms.var = saved['mean'], saved['var']
+        dev = getattr(self, '_dev', None)
+        if dev is not None:
+            import torch
+            d = self._dim
+            dev[:d].copy_(torch.from_numpy(np.asarray(self.rms.mean, dtype=np.float64).reshape(-1)))
+            dev[d:2 * d].copy_(torch.from_numpy(np.asarray(self.rms.var, dtype=np.float64).reshape(-1)))
 
 
 class RescaleNormalizer(BaseNormalizer):

@@ -515,6 +515,78 @@ int dra_allreduce_grads(float* flat_grad, int64_t count, float scale, dra_comm* 
 /* a few fp64 scalars summed over ranks (PPO's global advantage statistics, PPO_agent.py:66) */
 int dra_allreduce_f64(double* values, int count, dra_comm* comm, void* stream);
 
+/* ---- ppo_mlp: BASELINE configs[2] (PPO on HalfCheetah shapes, examples.py:497-523) end to end on the device.
+ * GaussianActorCriticNet (network_heads.py:173-214) with two separate tanh FCBody(state_dim, (H, H)) networks, H in
+ * {16, 32, 64}, state_dim <= 64, action_dim <= 16, separate Adam optimisers (examples.py:508-509), mini_batch_size <= 64. */
+/* deep_rl/utils/normalizer.py:28-51 (MeanStdNormalizer over baselines' RunningMeanStd, restated in
+ * deeprl_amd/normalizers.py): x f64 [n][d] (device); mean / var f64 [d], count f64 [1] (device, updated when update != 0:
+ * batch moments over axis 0, Chan merge, the host class's operation order); outputs clip((x - mean) / sqrt(var + epsilon),
+ * +-clip) as f32 and / or f64 (either may be NULL). */
+int dra_rms_normalize(const double* x, int n, int d, double* mean, double* var, double* count, int update, double epsilon,
+                      double clip, float* out_f32, double* out_f64, void* stream);
+/* network_heads.py:205-206 (dist.sample() = mean + scale * standard normal) with counter-hash normals: row r of mean [n][a_dim]
+ * is GLOBAL environment env0 + r of n_global; *step_dev (device int64) is the sampler's position, advanced by one per call. */
+int dra_gauss_sample(const float* mean, const float* scale, int n, int a_dim, uint64_t noise_seed, int64_t* step_dev,
+                     int64_t n_global, int64_t env0, float* out_action, void* stream);
+/* one step of n synthetic continuous environments (deeprl_amd/envs.py SyntheticContinuous, csrc/cont_env.h), auto reset on
+ * done (envs.py:126-150): state f64 [n][s_dim] and counter i64 [n] are updated in place; action f32 [n][a_dim] is clipped to
+ * [-1, 1] (envs.py:186-189); out_reward f64 [n], out_done i32 [n]. */
+int dra_cont_env_step(double* state, int64_t* counter, const int64_t* seed, const float* action, int n, int s_dim, int a_dim,
+                      int64_t horizon, double* out_reward, int32_t* out_done, void* stream);
+typedef struct dra_ppo_mlp_net {     /* one of the two networks with its Adam optimiser (optim.FusedOptimizer's buffers) */
+  float* param;                      /* flat parameters (device) */
+  float* exp_avg;                    /* Adam first / second moments, same layout */
+  float* exp_avg_sq;
+  int64_t* step_dev;                 /* device: optimizer steps taken so far; advanced by every step the kernel applies */
+  int32_t off_w1, off_b1, off_w2, off_b2, off_w3, off_b3, off_std, reserved;  /* float offsets; off_std < 0: no std (critic) */
+  float lr, beta1, beta2, eps;
+} dra_ppo_mlp_net;
+typedef struct dra_ppo_mlp_cfg {
+  int32_t state_dim, action_dim, hidden, mini_batch;
+  float ratio_clip, entropy_weight;
+  double kl_limit;                   /* the actor steps while approx_kl <= kl_limit = 1.5 * target_kl (PPO_agent.py:88) */
+} dra_ppo_mlp_cfg;
+int dra_ppo_mlp_supported(int state_dim, int action_dim, int hidden1, int hidden2, int mini_batch);   /* 0 = yes */
+/* PPO_agent.py:72-76: the rows of every minibatch of every epoch, gathered once.  state [n][S], action [n][A], log_pi_a /
+ * advantage / ret [n] (f32 device), perm i64 [epochs][n] (the np.random permutations, device) -> out_packed: one image per
+ * minibatch (epochs x ceil(n / mini_batch) of them, *floats in total) in the layout the update kernel keeps in LDS:
+ * 64 x (16 ceil(S / 16) + 4) observations, zero padded, then 64 x 20 = action | log_pi_a, advantage, ret at columns 16..18. */
+int dra_ppo_mlp_packed_floats(int n, int epochs, int mini_batch, int s_dim, int64_t* floats);
+int dra_ppo_mlp_pack(const float* state, const float* action, const float* log_pi_a, const float* advantage, const float* ret,
+                     const int64_t* perm, int n, int epochs, int mini_batch, int s_dim, int a_dim, float* out_packed, void* stream);
+/* PPO_agent.py:71-99 for shared_repr = False: epochs x ceil(n / mini_batch) minibatch updates in ONE launch of two persistent
+ * workgroups (actor: forward, clipped-ratio loss, approx-KL gate, backward, Adam; critic: forward, value loss, backward, Adam),
+ * weights and Adam moments resident in registers / LDS from the first minibatch to the last.  out3 (device f32 [3]) = policy
+ * loss, value loss, approx_kl of the LAST minibatch; out_counts (device i64 [2]) = actor / critic steps applied by this launch.
+ * dbg: NULL, or device f32 [DRA_PPO_MLP_DBG_FLOATS] receiving the first minibatch's intermediates (tests). */
+#define DRA_PPO_MLP_DBG_FLOATS 65536
+int dra_ppo_mlp_update(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
+                       const float* packed, int n, int epochs, float* out3, int64_t* out_counts, float* dbg, void* stream);
+/* PPO_agent.py:32-49 over device-resident synthetic environments: t_len x [store normalised observation, no-grad forward of
+ * both networks, action = mean + softplus(std) * noise, log-probability, environment step, reward / mask, running
+ * observation statistics + normalisation] and the bootstrap forward, in ONE launch of one persistent workgroup. */
+typedef struct dra_ppo_mlp_rollout_io {
+  double* env_state;        /* [n_env][S] raw observations (in/out) */
+  int64_t* env_counter;     /* [n_env] (in/out) */
+  const int64_t* env_seed;  /* [n_env] */
+  double* rms;              /* mean [S], var [S], count [1] (in/out; not updated when rms_update == 0) */
+  float* cur_state;         /* [n_env][S] normalised observation the rollout starts from (in) / the next one starts from (out) */
+  int64_t* sampler_step;    /* device int64: position of the action-noise stream (advanced by t_len + 1) */
+  float* out_state;         /* [t_len][n_env][S] */
+  float* out_action;        /* [t_len][n_env][A] */
+  float* out_log_pi_a;      /* [t_len][n_env] */
+  float* out_v;             /* [t_len + 1][n_env] */
+  float* out_reward;        /* [t_len][n_env]  f32(reward * reward_coef) */
+  float* out_mask;          /* [t_len][n_env]  1 - done */
+  int64_t env0, n_global;   /* first GLOBAL environment index of this rank / global environment count (noise stream) */
+  uint64_t noise_seed;
+  int64_t horizon;
+  double reward_coef, rms_epsilon, rms_clip;
+  int32_t rms_update, t_len, n_env, reserved;
+} dra_ppo_mlp_rollout_io;
+int dra_ppo_mlp_rollout(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
+                        const dra_ppo_mlp_rollout_io* io, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -721,7 +721,7 @@ def test_graphed_ppo_optimisation_is_bit_identical(dra, monkeypatch, kind):
         c = d.Config()
         pixel = kind == "pixel"
         c.merge(dict(game="BreakoutNoFrameskip-v4" if pixel else "HalfCheetah-v2", log_level=0, tag="ppo%d" % graph,
-                     graph_update=graph, skip=False))
+                     graph_update=graph, skip=False, fused_ppo_mlp=False))      # (the generic minibatch loop is under test)
         c.num_workers = 2
         c.task_fn = lambda: d.Task(c.game, num_envs=c.num_workers, seed=3)
         c.eval_env = d.Task(c.game, seed=4)

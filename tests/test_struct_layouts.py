@@ -23,12 +23,14 @@ def _c_layout(tmp_path, struct, fields):
 
 
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
-@pytest.mark.parametrize("which", ["dra_per_chain2_io", "dra_dqn_step_params", "dra_fold_seg"])
+@pytest.mark.parametrize("which", ["dra_per_chain2_io", "dra_dqn_step_params", "dra_fold_seg", "dra_ppo_mlp_net", "dra_ppo_mlp_cfg",
+                                   "dra_ppo_mlp_rollout_io"])
 def test_ctypes_mirror_matches_the_header(tmp_path, which):
     from deeprl_amd import ops
     from deeprl_amd.learner import StepParams
-    mirror = {"dra_per_chain2_io": ops.PerChain2IO, "dra_dqn_step_params": StepParams,
-              "dra_fold_seg": ops.FoldSeg}[which]
+    from deeprl_amd import ppo_mlp
+    mirror = {"dra_per_chain2_io": ops.PerChain2IO, "dra_dqn_step_params": StepParams, "dra_fold_seg": ops.FoldSeg,
+              "dra_ppo_mlp_net": ppo_mlp.Net, "dra_ppo_mlp_cfg": ppo_mlp.Cfg, "dra_ppo_mlp_rollout_io": ppo_mlp.RolloutIO}[which]
     names = [f[0] for f in mirror._fields_]
     got = _c_layout(tmp_path, which, names)
     assert got[0] == ctypes.sizeof(mirror)

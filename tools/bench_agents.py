@@ -93,9 +93,9 @@ def a2c_pixel(workers=16, device=True):
     return d.A2CAgent(c), dict(env_per_step=5 * workers, updates_per_step=1)
 
 
-def ppo_continuous(workers=1):
+def ppo_continuous(workers=1, device=True, fused=True):
     c = d.Config()
-    c.merge(dict(game="HalfCheetah-v2", log_level=0, tag="bench"))
+    c.merge(dict(game="synthetic-continuous-HalfCheetah", log_level=0, tag="bench", device_env=device, fused_ppo_mlp=fused))
     c.num_workers = workers
     c.task_fn = lambda: d.Task(c.game, num_envs=c.num_workers, seed=1)
     c.eval_env = d.Task(c.game, seed=2)
@@ -148,7 +148,9 @@ CASES = {
     "ppo_pixel_8": lambda: ppo_pixel(8),
     "ppo_pixel_8_host": lambda: ppo_pixel(8, device=False),
     "ppo_continuous_1": lambda: ppo_continuous(1),
-    "ppo_continuous_16": lambda: ppo_continuous(16),
+    "ppo_continuous_16": lambda: ppo_continuous(16),                                  # device environments + persistent kernels
+    "ppo_continuous_16_host": lambda: ppo_continuous(16, device=False),               # host environments, persistent update kernel
+    "ppo_continuous_16_generic": lambda: ppo_continuous(16, device=False, fused=False),   # round-4 path
 }
 
 
