@@ -47,6 +47,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
   const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return 1.f - 2.f * __builtin_amdgcn_rcpf(t + 1.f);
 }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 // F.softplus (beta 1, threshold 20) and its derivative as autograd forms it (z / (z + 1), z = exp(x))
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float softplus_grad(float x) {
@@ -58,8 +60,15 @@ __device__ __forceinline__ float softplus_grad(float x) {
 // whose four rows per step lie 4 apart, so the 4 x 16-float reads of one ds_read_b32 fall on 4 distinct bank groups
 __device__ __forceinline__ int row_of(int s, int g) { return ((s >> 2) << 4) + (g << 2) + (s & 3); }
 
-__device__ __forceinline__ float group16_sum(float v) {   // over the 16 lanes that share g
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {     // lane permutation inside a row of 16 lanes, on the VALU (no LDS crossbar)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float group16_sum(float v) {   // over the 16 lanes that share g; every lane receives the sum
+  v += dpp_mov<0xB1>(v);     // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror: quad 0 <-> quad 1, quad 2 <-> quad 3
+  v += dpp_mov<0x140>(v);    // row_mirror: lower half <-> upper half
   return v;
 }
 __device__ __forceinline__ float over_g_sum(float v) {    // over the 4 lanes that share c16
@@ -69,15 +78,17 @@ __device__ __forceinline__ float over_g_sum(float v) {    // over the 4 lanes th
 
 struct AdamScalars { float step_size, inv_sqrt_bc2, beta1, beta2, omb1, omb2, eps; };
 __device__ __forceinline__ void adam_elem(float& p, float gk, float& m, float& v, const AdamScalars& a) {
-  // optim.hip adam_step_kernel's element formula (torch.optim.Adam, no amsgrad / weight decay)
+  // optim.hip adam_step_kernel's element formula (torch.optim.Adam, no amsgrad / weight decay), with the square root and the
+  // division on the transcendental unit (v_sqrt_f32 / v_rcp_f32, 1 ulp each: a relative 2e-7 on a step of lr x O(1)) -- the
+  // IEEE sequences cost ~20 instructions per parameter, 37 parameters per lane and minibatch (profiles/r05c_prof_ppo_mlp.json)
   m = m * a.beta1 + a.omb1 * gk;
   v = v * a.beta2 + a.omb2 * gk * gk;
-  p = p - a.step_size * (m / (sqrtf(v) * a.inv_sqrt_bc2 + a.eps));
+  p = p - (a.step_size * m) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * a.inv_sqrt_bc2 + a.eps);
 }
 
 constexpr size_t update_lds_floats(int H) {
-  return (size_t)kRows * (kLdX + kLd3) + 3 * (size_t)kRows * (H + 4) + (size_t)H * (H + 4) + 16 * (size_t)(H + 4) +
-         (size_t)kRows * kLd3 + 16 + 16 + 64 + 64;
+  return 2 * (size_t)kRows * (kLdX + kLd3) + 3 * (size_t)kRows * (H + 4) + (size_t)H * (H + 4) + 16 * (size_t)(H + 4) +
+         (size_t)kRows * kLd3 + 16 + 16 + 32 + 256;
 }
 
 // debug dump layout (floats, per role; the critic's region starts at kDbgRole)
@@ -87,23 +98,49 @@ constexpr int kDbgRole = 32768, kDbgH1 = 0, kDbgH2 = 4096, kDbgHead = 8192, kDbg
 static_assert(2 * kDbgRole <= DRA_PPO_MLP_DBG_FLOATS, "debug buffer");
 
 // ------------------------------------------------------------------------------------------------ update
-template <int H, bool ACTOR, bool DUMP>
+// One workgroup = one network.  Per minibatch (phases separated by workgroup barriers; "own": wave w < H / 16 owns hidden units
+// [16 w, 16 w + 16) of both hidden layers -- their weights, the Adam moments and the matching slice of the head's weights):
+//   F1   h1 = tanh(x W1^T + b1)                       tile by tile, a tile's tanh / LDS stores under the next tile's MFMAs
+//   F2   h2 = tanh(h1 W2^T + b2)
+//   F3   head + loss: wave mt takes rows [16 mt, 16 mt + 16); policy mean / value, log-probability, clipped-ratio terms, dz3
+//   gate approx-KL against the limit (PPO_agent.py:88); the next minibatch's image is committed to the OTHER LDS buffer
+//   B3   dz2 = (dz3 W3)(1 - h2^2);  dW3^T, db3, dstd
+//   B2   dW2^T with Adam(W3, b3, std) in the MFMA shadow; dz1 = (dz2 W2)(1 - h1^2) with Adam(W2, b2) in the MFMA shadow
+//   B1   dW1^T; Adam(W1, b1)
+// The time of a minibatch is the sum of dependent latencies, not of work: what matters is how little sits between the MFMAs
+// (profiles/r05*_prof_ppo_mlp.json: cycles per phase).
+template <int H, bool ACTOR, int MODE, int KTC>
 __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, const dra_ppo_mlp_net& net, const float* __restrict__ packed,
-                                const int n, const int epochs, float* __restrict__ out3, int64_t* __restrict__ out_counts,
-                                float* __restrict__ dbg_all, float* lds) {
+                                                const int n, const int epochs, float* __restrict__ out3,
+                                                int64_t* __restrict__ out_counts, float* __restrict__ dbg_all, float* lds) {
   constexpr int NT = H / 16, LD = H + 4;
+  constexpr int KTM = KTC ? KTC : 4;            // KTC: ceil(state_dim / 16) at compile time (0: any, read from the configuration)
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c16 = l & 15, g = l >> 4;
-  const int S = cfg.state_dim, AP = cfg.action_dim, A = ACTOR ? cfg.action_dim : 1, MB = cfg.mini_batch;
-  const int KT1 = (S + 15) >> 4, LDX = 16 * KT1 + 4;
+  const int S = cfg.state_dim, A = ACTOR ? cfg.action_dim : 1, MB = cfg.mini_batch;
+  const int KT1 = KTC ? KTC : (S + 15) >> 4;
+  const int LDX = 16 * KT1 + 4;
   const int MT = (MB + 15) >> 4;      // M tiles that can hold rows (the contractions over rows stop there)
   const int per_epoch = (n + MB - 1) / MB, total = per_epoch * epochs;
   const bool own = w < NT;
   const int ncol = 16 * w + c16;
+  constexpr bool DUMP = MODE == 1, PROF = MODE == 2;   // 1: dump of minibatch 0 (tests); 2: cycle counts per phase (tools)
   float* dbg = (DUMP && dbg_all) ? dbg_all + (ACTOR ? 0 : kDbgRole) : nullptr;
+  long long prof[16], prof_last = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) prof[i] = 0;
+  auto stamp = [&](int k) {
+    if (PROF && tid == 0) {
+      const long long t = clock64();
+      prof[k] += t - prof_last;
+      prof_last = t;
+    }
+  };
 
-  float* sX = lds;                    // [kRows][LDX] | sAux [kRows][kLd3]: the minibatch image, laid out as ppo_pack_kernel writes it
-  float* sAux = sX + kRows * LDX;
-  float* sH1 = lds + kRows * (kLdX + kLd3);
+  // LDS: two minibatch images ([kRows][LDX] observations | [kRows][kLd3] action, log_pi_a, advantage, ret -- the layout
+  // ppo_pack_kernel writes), then activations / gradients / the transposed-use weight copies
+  const int img = kRows * (LDX + kLd3);
+  float* sImg = lds;
+  float* sH1 = lds + 2 * kRows * (kLdX + kLd3);
   float* sH2 = sH1 + kRows * LD;      // h2, later dz1
   float* sDZ2 = sH2 + kRows * LD;
   float* sW2 = sDZ2 + kRows * LD;
@@ -111,19 +148,19 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
   float* sDZ3 = sW3 + 16 * LD;
   float* sB3 = sDZ3 + kRows * kLd3;
   float* sStd = sB3 + 16;
-  float* sRed = sStd + 16;            // [4 waves][4]
-  float* sPart = sRed + 64;           // [4 waves][16]
+  float* sRed = sStd + 16;            // [4 waves][4 g][2]
+  float* sPart = sRed + 32;           // [4 waves][4 g][16]
   for (int i = tid; i < (int)update_lds_floats(H); i += 256) lds[i] = 0.f;
   __syncthreads();
 
   // ---- masters: parameters + Adam moments of this lane's share, in the forward's B-operand layout
-  float w1p[4][4], w1m[4][4], w1v[4][4];
+  float w1p[KTM][4], w1m[KTM][4], w1v[KTM][4];
   float w2p[NT][4], w2m[NT][4], w2v[NT][4];
   float w3p[4], w3m[4], w3v[4];
   float b1p = 0.f, b1m = 0.f, b1v = 0.f, b2p = 0.f, b2m = 0.f, b2v = 0.f, b3p = 0.f, b3m = 0.f, b3v = 0.f;
   float sdp = 0.f, sdm = 0.f, sdv = 0.f;
 #pragma unroll
-  for (int tk = 0; tk < 4; ++tk)
+  for (int tk = 0; tk < KTM; ++tk)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = 16 * tk + 4 * g + r;
@@ -158,32 +195,37 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
     b3p = net.param[net.off_b3 + c16]; b3m = net.exp_avg[net.off_b3 + c16]; b3v = net.exp_avg_sq[net.off_b3 + c16];
     if (ACTOR) { sdp = net.param[net.off_std + c16]; sdm = net.exp_avg[net.off_std + c16]; sdv = net.exp_avg_sq[net.off_std + c16]; }
   }
-  auto publish = [&]() {     // the LDS copies the transposed contractions and the head read
+  // the LDS copies the transposed contractions (dh = dz W) and the head read
+  auto publish_w2 = [&]() {
     if (own) {
 #pragma unroll
       for (int tk = 0; tk < NT; ++tk) {
         f32x4 v = {w2p[tk][0], w2p[tk][1], w2p[tk][2], w2p[tk][3]};
         *reinterpret_cast<f32x4*>(&sW2[ncol * LD + 16 * tk + 4 * g]) = v;
       }
+    }
+  };
+  auto publish_head = [&]() {
+    if (own) {
       f32x4 v3 = {w3p[0], w3p[1], w3p[2], w3p[3]};
       *reinterpret_cast<f32x4*>(&sW3[c16 * LD + 16 * w + 4 * g]) = v3;
     }
     if (w == 0 && g == 0) { sB3[c16] = b3p; sStd[c16] = sdp; }
   };
-  publish();
+  publish_w2();
+  publish_head();
 
   // ---- Adam's bias corrections: beta^t as a running product from pow(beta, t0) (within 1e-12 of pow(beta, t))
-  int64_t steps = *net.step_dev;
-  const int64_t steps0 = steps;
-  double pw1 = pow((double)net.beta1, (double)steps), pw2 = pow((double)net.beta2, (double)steps);
+  const int64_t steps0 = *net.step_dev;
+  double pw1 = pow((double)net.beta1, (double)steps0), pw2 = pow((double)net.beta2, (double)steps0);
   AdamScalars ad;
   ad.beta1 = net.beta1; ad.beta2 = net.beta2; ad.omb1 = 1.f - net.beta1; ad.omb2 = 1.f - net.beta2; ad.eps = net.eps;
+  ad.step_size = 0.f; ad.inv_sqrt_bc2 = 0.f;
 
-  // ---- minibatch images (ppo_pack_kernel: [kRows][LDX] observations, zero padded | [kRows][kLd3] action, log_pi_a, advantage,
-  // ret): prefetched one minibatch ahead into registers, committed to LDS -- same linear layout -- at the end of the iteration
-  constexpr int NJ = (kRows * (kLdX + kLd3) / 4 + 255) / 256;
+  // ---- minibatch images: prefetched one minibatch ahead into registers, committed to the other LDS buffer after the gate
+  constexpr int NJ = (kRows * ((KTC ? 16 * KTC + 4 : kLdX) + kLd3) / 4 + 255) / 256;
   f32x4 pf[NJ];
-  const int img4 = kRows * (LDX + kLd3) / 4;
+  const int img4 = img / 4;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) pf[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto issue = [&](int q) {
@@ -192,91 +234,114 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
     for (int j = 0; j < NJ; ++j)
       if (tid + 256 * j < img4) pf[j] = src[tid + 256 * j];
   };
-  auto commit = [&]() {
+  auto commit = [&](int buf) {
+    f32x4* dst = reinterpret_cast<f32x4*>(sImg + buf * kRows * (kLdX + kLd3));
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      if (tid + 256 * j < img4) reinterpret_cast<f32x4*>(sX)[tid + 256 * j] = pf[j];
+      if (tid + 256 * j < img4) dst[tid + 256 * j] = pf[j];
   };
-  if (total > 0) { issue(0); commit(); }
+  if (total > 0) { issue(0); commit(0); }
   __syncthreads();
 
   int64_t applied = 0;
+  float sd = 1.f, log_sd = 0.f, std_raw = 0.f, inv_sd = 1.f, inv_var = 1.f;
+  bool std_dirty = true;
   for (int q = 0; q < total; ++q) {
     const int kq = q % per_epoch;
     const int rows = min(MB, n - kq * MB);
     const float inv_m = 1.f / (float)rows;
     const bool dump = DUMP && dbg && q == 0;
+    const float* sX = sImg + (q & 1) * kRows * (kLdX + kLd3);
+    const float* sAux = sX + kRows * LDX;
+    if (PROF && tid == 0 && q == 0) prof_last = clock64();
     if (q + 1 < total) issue(q + 1);
+    stamp(0);
 
-    // ---- F1: h1 = tanh(x W1^T + b1)
+    // ---- F1: h1 = tanh(x W1^T + b1).  Tile mt's MFMAs (two accumulator chains) carry tile mt - 1's tanh + stores in their shadow.
     if (own) {
-      f32x4 acc[4];
+      f32x4 prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt <= 4; ++mt) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        if (mt < 4) {
 #pragma unroll
-      for (int tk = 0; tk < 4; ++tk)
-        if (tk < KT1) {
-          f32x4 av[4];
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-            av[mt] = *reinterpret_cast<const f32x4*>(&sX[(16 * mt + c16) * LDX + 16 * tk + 4 * g]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-              acc[mt] = MFMA16(av[mt][r], w1p[tk][r], acc[mt]);
+          for (int tk = 0; tk < KTM; ++tk)
+            if (tk < KT1) {
+              const f32x4 av = *reinterpret_cast<const f32x4*>(&sX[(16 * mt + c16) * LDX + 16 * tk + 4 * g]);
+              // (a step whose four k = 16 tk + 4 g + r all lie past the observation is all zeros)
+              if (16 * tk + 0 < S) a0 = MFMA16(av[0], w1p[tk][0], a0);
+              if (16 * tk + 1 < S) a1 = MFMA16(av[1], w1p[tk][1], a1);
+              if (16 * tk + 2 < S) a0 = MFMA16(av[2], w1p[tk][2], a0);
+              if (16 * tk + 3 < S) a1 = MFMA16(av[3], w1p[tk][3], a1);
+            }
         }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+        if (mt > 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * mt + 4 * g + r;
-            const float h = fast_tanh(acc[mt][r] + b1p);
+            const int row = 16 * (mt - 1) + 4 * g + r;
+            const float h = fast_tanh(prev[r] + b1p);
             sH1[row * LD + ncol] = h;
             if (dump) dbg[kDbgH1 + row * 64 + ncol] = h;
           }
+        }
+        prev = a0 + a1;
+      }
     }
+    stamp(1);
     __syncthreads();
+    stamp(2);
     // ---- F2: h2 = tanh(h1 W2^T + b2)
     if (own) {
-      f32x4 acc[4];
+      f32x4 prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt <= 4; ++mt) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+        if (mt < 4) {
 #pragma unroll
-      for (int tk = 0; tk < NT; ++tk) {
-        f32x4 av[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          av[mt] = *reinterpret_cast<const f32x4*>(&sH1[(16 * mt + c16) * LD + 16 * tk + 4 * g]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-            acc[mt] = MFMA16(av[mt][r], w2p[tk][r], acc[mt]);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+          for (int tk = 0; tk < NT; ++tk) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&sH1[(16 * mt + c16) * LD + 16 * tk + 4 * g]);
+            a0 = MFMA16(av[0], w2p[tk][0], a0);
+            a1 = MFMA16(av[1], w2p[tk][1], a1);
+            a0 = MFMA16(av[2], w2p[tk][2], a0);
+            a1 = MFMA16(av[3], w2p[tk][3], a1);
+          }
+        }
+        if (mt > 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * mt + 4 * g + r;
-            const float h = fast_tanh(acc[mt][r] + b2p);
+            const int row = 16 * (mt - 1) + 4 * g + r;
+            const float h = fast_tanh(prev[r] + b2p);
             sH2[row * LD + ncol] = h;
             if (dump) dbg[kDbgH2 + row * 64 + ncol] = h;
           }
+        }
+        prev = a0 + a1;
+      }
     }
+    stamp(3);
     __syncthreads();
-    // ---- F3 + loss: wave mt takes rows [16 mt, 16 mt + 16); lane (c16 = head output, g, reg) <-> row 16 mt + 4 g + reg
-    float sd = 1.f, log_sd = 0.f, std_raw = 0.f;
-    if (ACTOR) { std_raw = sStd[c16]; sd = softplus_f(std_raw); log_sd = logf(sd); }
+    stamp(4);
+    // ---- F3 + loss: lane (c16 = head output, g, reg) <-> row 16 w + 4 g + reg
+    if (ACTOR && std_dirty) {      // scale = softplus(std) and what the row loop needs of it, once per actor step
+      std_raw = sStd[c16];
+      sd = std_raw > 20.f ? std_raw : fast_log(1.f + fast_exp(std_raw));
+      log_sd = fast_log(sd);
+      inv_sd = __builtin_amdgcn_rcpf(sd);
+      inv_var = inv_sd * inv_sd;
+      std_dirty = false;
+    }
     {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};     // two chains: a dependent MFMA waits 40 cycles
 #pragma unroll
       for (int tk = 0; tk < NT; ++tk) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(&sH2[(16 * w + c16) * LD + 16 * tk + 4 * g]);
         const f32x4 bv = *reinterpret_cast<const f32x4*>(&sW3[c16 * LD + 16 * tk + 4 * g]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = MFMA16(av[r], bv[r], acc);
+        acc = MFMA16(av[0], bv[0], acc);
+        acc_b = MFMA16(av[1], bv[1], acc_b);
+        acc = MFMA16(av[2], bv[2], acc);
+        acc_b = MFMA16(av[3], bv[3], acc_b);
       }
+      acc += acc_b;
       const float b3 = sB3[c16];
       const bool col_ok = c16 < A;
       float s0 = 0.f, s1 = 0.f, gsd = 0.f;
@@ -286,24 +351,23 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
         const bool row_ok = row < rows;
         float dz = 0.f;
         if (ACTOR) {
-          const float var = sd * sd;
           const float mean = fast_tanh(acc[r] + b3);
           const float diff = sAux[row * kLd3 + c16] - mean;
-          const float lpe = col_ok ? (-(diff * diff) / (2.f * var) - log_sd - kLogSqrt2Pi) : 0.f;
+          const float lpe = col_ok ? (-(diff * diff) * (0.5f * inv_var) - log_sd - kLogSqrt2Pi) : 0.f;
           const float lp = group16_sum(lpe);
           const float lp_old = sAux[row * kLd3 + kAuxLp], adv = sAux[row * kLd3 + kAuxAdv];
           // losses.hip ppo_loss_kernel's arithmetic (PPO_agent.py:78-86), row by row
-          const float ratio = expf(lp - lp_old);
+          const float ratio = fast_exp(lp - lp_old);
           const float obj = ratio * adv;
           const float rc = fminf(fmaxf(ratio, 1.f - cfg.ratio_clip), 1.f + cfg.ratio_clip);
           const float objc = rc * adv;
           const bool inside = (ratio >= 1.f - cfg.ratio_clip) && (ratio <= 1.f + cfg.ratio_clip);
           const float gate = inside ? 1.f : (obj < objc ? 1.f : (obj == objc ? 0.5f : 0.f));
           const float g_lp = row_ok ? -gate * obj * inv_m : 0.f;
-          if (row_ok && c16 == 0) { s0 += fminf(obj, objc); s1 += lp_old - lp; }
+          if (row_ok) { s0 += fminf(obj, objc); s1 += lp_old - lp; }
           if (col_ok) {
-            dz = (g_lp * (diff / var)) * (1.f - mean * mean);
-            gsd += g_lp * ((diff * diff) / (var * sd) - 1.f / sd);
+            dz = (g_lp * (diff * inv_var)) * (1.f - mean * mean);
+            gsd += g_lp * ((diff * diff) * (inv_var * inv_sd) - inv_sd);
           }
           if (dump) {
             dbg[kDbgHead + row * 16 + c16] = mean;
@@ -321,23 +385,25 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
         sDZ3[row * kLd3 + c16] = dz;
         if (dump) dbg[kDbgDz3 + row * 16 + c16] = dz;
       }
-      s0 = over_g_sum(s0); s1 = over_g_sum(s1); gsd = over_g_sum(gsd);
-      if (l == 0) { sRed[4 * w] = s0; sRed[4 * w + 1] = s1; }
-      if (g == 0) sPart[16 * w + c16] = gsd;
+      // per (wave, lane group) partial sums: reduced after the barrier by whoever needs them, in a fixed order
+      if (c16 == 0) { sRed[2 * (4 * w + g)] = s0; sRed[2 * (4 * w + g) + 1] = s1; }
+      if (ACTOR) sPart[16 * (4 * w + g) + c16] = gsd;
     }
+    stamp(5);
     __syncthreads();
     float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-{ t0 += sRed[4 * mt]; t1 += sRed[4 * mt + 1]; }
+    for (int i = 0; i < 16; ++i) { t0 += sRed[2 * i]; t1 += sRed[2 * i + 1]; }
     bool open = true;
-    float ent = 0.f;
     if (ACTOR) {
       const float kl = t1 * inv_m;
       open = (double)kl <= cfg.kl_limit;
-      const float ent_e = c16 < A ? kEntConst + log_sd : 0.f;
-      ent = group16_sum(ent_e);
       if (tid == 0 && (q == total - 1 || dump)) {
+        float ent = 0.f;
+        for (int a = 0; a < A; ++a) {
+          const float x = sStd[a];
+          ent += kEntConst + fast_log(x > 20.f ? x : fast_log(1.f + fast_exp(x)));
+        }
         const float pl = -t0 * inv_m - cfg.entropy_weight * ent;
         if (q == total - 1) { out3[0] = pl; out3[2] = kl; }
         if (dump) { dbg[kDbgScal] = pl; dbg[kDbgScal + 2] = kl; dbg[kDbgScal + 3] = open ? 1.f : 0.f; dbg[kDbgScal + 4] = ent; }
@@ -347,11 +413,17 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
       if (q == total - 1) out3[1] = vl;
       if (dump) dbg[kDbgScal + 1] = vl;
     }
+    if (q + 1 < total) commit((q + 1) & 1);      // (that buffer's last readers finished before the previous iteration's last barrier)
+    stamp(6);
 
     if (open) {
       float gw3[4] = {0.f, 0.f, 0.f, 0.f}, gb3 = 0.f, gstd = 0.f;
       // ---- B3: dz2 = (dz3 W3) (1 - h2^2);  dW3^T tile tk = w;  db3, dstd
       if (own) {
+        pw1 *= (double)net.beta1;
+        pw2 *= (double)net.beta2;
+        ad.step_size = (float)((double)net.lr / (1.0 - pw1));
+        ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pw2));
         f32x4 acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -363,34 +435,43 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
             for (int mt = 0; mt < 4; ++mt)
               acc[mt] = MFMA16(sDZ3[(16 * mt + c16) * kLd3 + 4 * s2 + g], b, acc[mt]);
           }
+        // dW3^T (two chains over the rows) with the dz2 epilogue of the four dh2 tiles in its shadow
+        f32x4 a3 = {0.f, 0.f, 0.f, 0.f}, a3b = {0.f, 0.f, 0.f, 0.f};
+        float bsum = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-  #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+        for (int s = 0; s < 16; s += 2) {
+          if (s < 4 * MT) {
+            const int r0 = row_of(s, g), r1 = row_of(s + 1, g);
+            const float b0 = sDZ3[r0 * kLd3 + c16], b1 = sDZ3[r1 * kLd3 + c16];
+            bsum += b0;
+            bsum += b1;
+            a3 = MFMA16(sH2[r0 * LD + ncol], b0, a3);
+            a3b = MFMA16(sH2[r1 * LD + ncol], b1, a3b);
+          }
+          {
+            const int mt = s >> 2, rp = s & 3;      // two of the sixteen dz2 values per step
+#pragma unroll
+            for (int r = rp; r < rp + 2; ++r) {
               const int row = 16 * mt + 4 * g + r;
               const float h2 = sH2[row * LD + ncol];
               const float dz = acc[mt][r] * (1.f - h2 * h2);
               sDZ2[row * LD + ncol] = dz;
               if (dump) dbg[kDbgDz2 + row * 64 + ncol] = dz;
             }
-        f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
-        float bsum = 0.f;
-        for (int s = 0; s < 4 * MT; ++s) {
-          const int rr = row_of(s, g);
-          const float b = sDZ3[rr * kLd3 + c16];
-          bsum += b;
-          a3 = MFMA16(sH2[rr * LD + ncol], b, a3);
+          }
         }
+        a3 += a3b;
 #pragma unroll
         for (int r = 0; r < 4; ++r) gw3[r] = a3[r];
         gb3 = over_g_sum(bsum);
         if (ACTOR && w == 0) {
           float t = 0.f;
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-            t += sPart[16 * mt + c16];
-          // d(-entropy_weight * mean(entropy)) / d scale = -entropy_weight / scale
-          gstd = (t - cfg.entropy_weight / sd) * softplus_grad(std_raw);
+          for (int i = 0; i < 16; ++i) t += sPart[16 * i + c16];
+          // d(-entropy_weight * mean(entropy)) / d scale = -entropy_weight / scale;  d softplus = z / (z + 1), z = exp(std)
+          const float z = fast_exp(std_raw);
+          const float sg = std_raw > 20.f ? 1.f : z * __builtin_amdgcn_rcpf(z + 1.f);
+          gstd = (t - cfg.entropy_weight * inv_sd) * sg;
         }
         if (dump) {
 #pragma unroll
@@ -398,120 +479,127 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
           if (w == 0 && g == 0) { dbg[kDbgB3 + c16] = gb3; dbg[kDbgStd + c16] = gstd; }
         }
       }
+      stamp(7);
       __syncthreads();
-      // ---- B2: dW2^T tiles (this wave's units x all inputs);  dz1 = (dz2 W2) (1 - h1^2) into sH2
-      float gw2[NT][4], gb2 = 0.f;
+      stamp(8);
+      // ---- B2: dW2^T tiles (this wave's units x all inputs) with Adam(W3, b3, std) in the MFMA shadow;
+      //          dz1 = (dz2 W2) (1 - h1^2) into sH2 with Adam(W2, b2) in the MFMA shadow
       if (own) {
         f32x4 acc[NT];
 #pragma unroll
         for (int tk = 0; tk < NT; ++tk) acc[tk] = f32x4{0.f, 0.f, 0.f, 0.f};
         float bsum = 0.f;
-        for (int s = 0; s < 4 * MT; ++s) {
-          const int rr = row_of(s, g);
-          const float b = sDZ2[rr * LD + ncol];
-          bsum += b;
 #pragma unroll
-          for (int tk = 0; tk < NT; ++tk) acc[tk] = MFMA16(sH1[rr * LD + 16 * tk + c16], b, acc[tk]);
-        }
-        gb2 = over_g_sum(bsum);
+        for (int s = 0; s < 16; ++s) {
+          if (s < 4 * MT) {
+            const int rr = row_of(s, g);
+            const float b = sDZ2[rr * LD + ncol];
+            bsum += b;
 #pragma unroll
-        for (int tk = 0; tk < NT; ++tk)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) gw2[tk][r] = acc[tk][r];
-        f32x4 accd[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) accd[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tn = 0; tn < NT; ++tn) {
-          f32x4 av[4];
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-            av[mt] = *reinterpret_cast<const f32x4*>(&sDZ2[(16 * mt + c16) * LD + 16 * tn + 4 * g]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float b = sW2[(16 * tn + 4 * g + r) * LD + ncol];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-              accd[mt] = MFMA16(av[mt][r], b, accd[mt]);
+            for (int tk = 0; tk < NT; ++tk) acc[tk] = MFMA16(sH1[rr * LD + 16 * tk + c16], b, acc[tk]);
+          }
+          if (s < 4) adam_elem(w3p[s], gw3[s], w3m[s], w3v[s], ad);
+          if (s == 4 && w == 0 && c16 < A) {
+            adam_elem(b3p, gb3, b3m, b3v, ad);
+            if (ACTOR) adam_elem(sdp, gstd, sdm, sdv, ad);
           }
         }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-  #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = 16 * mt + 4 * g + r;
-              const float h1 = sH1[row * LD + ncol];
-              const float dz = accd[mt][r] * (1.f - h1 * h1);
-              sH2[row * LD + ncol] = dz;
-              if (dump) dbg[kDbgDz1 + row * 64 + ncol] = dz;
-            }
+        const float gb2 = over_g_sum(bsum);
+        publish_head();           // (sW3 / sB3 / sStd were last read before the B3 | B2 barrier)
         if (dump) {
 #pragma unroll
           for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dbg[kDbgW2 + ncol * 64 + 16 * tk + 4 * g + r] = gw2[tk][r];
+            for (int r = 0; r < 4; ++r) dbg[kDbgW2 + ncol * 64 + 16 * tk + 4 * g + r] = acc[tk][r];
           if (g == 0) dbg[kDbgB2 + ncol] = gb2;
         }
-      }
-      __syncthreads();
-      // ---- B1: dW1^T tiles;  then Adam on every master of this lane
-      if (own) {
-        f32x4 acc[4];
+        // dh1 tile by tile: the previous tile's epilogue and one W2 Adam element per k step ride in the MFMA shadow
+        f32x4 prev = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tk = 0; tk < 4; ++tk) acc[tk] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float bsum = 0.f;
-        for (int s = 0; s < 4 * MT; ++s) {
-          const int rr = row_of(s, g);
-          const float b = sH2[rr * LD + ncol];
-          bsum += b;
+        for (int mt = 0; mt <= 4; ++mt) {
+          f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+          if (mt < 4) {
 #pragma unroll
-          for (int tk = 0; tk < 4; ++tk)
-            if (tk < KT1) acc[tk] = MFMA16(sX[rr * LDX + 16 * tk + c16], b, acc[tk]);
+            for (int tn = 0; tn < NT; ++tn) {
+              const f32x4 av = *reinterpret_cast<const f32x4*>(&sDZ2[(16 * mt + c16) * LD + 16 * tn + 4 * g]);
+              a0 = MFMA16(av[0], sW2[(16 * tn + 4 * g + 0) * LD + ncol], a0);
+              a1 = MFMA16(av[1], sW2[(16 * tn + 4 * g + 1) * LD + ncol], a1);
+              a0 = MFMA16(av[2], sW2[(16 * tn + 4 * g + 2) * LD + ncol], a0);
+              a1 = MFMA16(av[3], sW2[(16 * tn + 4 * g + 3) * LD + ncol], a1);
+              // Adam on the master registers (the forward's operands); the transposed reads above go to the LDS copy, which
+              // keeps the OLD weights until publish_w2() in B1
+              adam_elem(w2p[tn][mt], acc[tn][mt], w2m[tn][mt], w2v[tn][mt], ad);
+            }
+          }
+          if (mt > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = 16 * (mt - 1) + 4 * g + r;
+              const float h1 = sH1[row * LD + ncol];
+              const float dz = prev[r] * (1.f - h1 * h1);
+              sH2[row * LD + ncol] = dz;
+              if (dump) dbg[kDbgDz1 + row * 64 + ncol] = dz;
+            }
+          }
+          prev = a0 + a1;
         }
+        adam_elem(b2p, gb2, b2m, b2v, ad);
+      }
+      stamp(9);
+      __syncthreads();
+      stamp(10);
+      // ---- B1: dW1^T tiles;  Adam(W1, b1)
+      if (own) {
+        publish_w2();             // (sW2 was last read before the B2 | B1 barrier)
+        f32x4 acc[KTM];
+#pragma unroll
+        for (int tk = 0; tk < KTM; ++tk) acc[tk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float bsum = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+          if (s < 4 * MT) {
+            const int rr = row_of(s, g);
+            const float b = sH2[rr * LD + ncol];
+            bsum += b;
+#pragma unroll
+            for (int tk = 0; tk < KTM; ++tk)
+              if (tk < KT1) acc[tk] = MFMA16(sX[rr * LDX + 16 * tk + c16], b, acc[tk]);
+          }
         const float gb1 = over_g_sum(bsum);
         if (dump) {
 #pragma unroll
-          for (int tk = 0; tk < 4; ++tk)
+          for (int tk = 0; tk < KTM; ++tk)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (16 * tk + 4 * g + r < S) dbg[kDbgW1 + ncol * 64 + 16 * tk + 4 * g + r] = acc[tk][r];
           if (g == 0) dbg[kDbgB1 + ncol] = gb1;
         }
-        pw1 *= (double)net.beta1;
-        pw2 *= (double)net.beta2;
-        ad.step_size = (float)((double)net.lr / (1.0 - pw1));
-        ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pw2));
+        stamp(11);
 #pragma unroll
-        for (int tk = 0; tk < 4; ++tk)
+        for (int tk = 0; tk < KTM; ++tk)
           if (tk < KT1)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) adam_elem(w1p[tk][r], acc[tk][r], w1m[tk][r], w1v[tk][r], ad);
-#pragma unroll
-        for (int tk = 0; tk < NT; ++tk)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) adam_elem(w2p[tk][r], gw2[tk][r], w2m[tk][r], w2v[tk][r], ad);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) adam_elem(w3p[r], gw3[r], w3m[r], w3v[r], ad);
+            for (int r = 0; r < 4; ++r)
+              if (16 * tk + r < S) adam_elem(w1p[tk][r], acc[tk][r], w1m[tk][r], w1v[tk][r], ad);
         adam_elem(b1p, gb1, b1m, b1v, ad);
-        adam_elem(b2p, gb2, b2m, b2v, ad);
-        if (w == 0 && c16 < A) {
-          adam_elem(b3p, gb3, b3m, b3v, ad);
-          if (ACTOR) adam_elem(sdp, gstd, sdm, sdv, ad);
-        }
       }
-      ++steps;
       ++applied;
+      std_dirty = true;
     }
-    __syncthreads();          // every read of sX / sAux / sW2 / sW3 of this minibatch has been issued and returned
-    if (open) publish();
-    if (q + 1 < total) commit();
-    __syncthreads();
+    stamp(12);
+    __syncthreads();          // the next image, the published weights and every read of this minibatch's buffers are complete
+    stamp(13);
+  }
+  if (PROF && tid == 0 && dbg_all) {
+    long long* out = reinterpret_cast<long long*>(dbg_all) + (ACTOR ? 0 : 16);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i] = prof[i];
   }
 
   // ---- write the resident state back
   if (own) {
 #pragma unroll
-    for (int tk = 0; tk < 4; ++tk)
+    for (int tk = 0; tk < KTM; ++tk)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k = 16 * tk + 4 * g + r;
@@ -548,13 +636,13 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
   }
 }
 
-template <int H, bool DUMP>
+template <int H, int MODE, int KTC>
 __global__ void __launch_bounds__(256)
 ppo_mlp_update_kernel(dra_ppo_mlp_cfg cfg, dra_ppo_mlp_net actor, dra_ppo_mlp_net critic, const float* __restrict__ packed, int n,
                       int epochs, float* __restrict__ out3, int64_t* __restrict__ out_counts, float* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if (blockIdx.x == 0) ppo_update_role<H, true, DUMP>(cfg, actor, packed, n, epochs, out3, out_counts, dbg, lds);
-  else ppo_update_role<H, false, DUMP>(cfg, critic, packed, n, epochs, out3, out_counts, dbg, lds);
+  if (blockIdx.x == 0) ppo_update_role<H, true, MODE, KTC>(cfg, actor, packed, n, epochs, out3, out_counts, dbg, lds);
+  else ppo_update_role<H, false, MODE, KTC>(cfg, critic, packed, n, epochs, out3, out_counts, dbg, lds);
 }
 
 // ------------------------------------------------------------------------------------------------ pack
@@ -898,18 +986,18 @@ DRA_API int dra_ppo_mlp_pack(const float* state, const float* action, const floa
   return DRA_OK;
 }
 
-template <int H, bool DUMP>
+template <int H, int MODE, int KTC>
 static int launch_update(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic, const float* packed,
                          int n, int epochs, float* out3, int64_t* out_counts, float* dbg, void* stream) {
   const size_t bytes = update_lds_floats(H) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_update_kernel<H, DUMP>),
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_update_kernel<H, MODE, KTC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL((ppo_mlp_update_kernel<H, DUMP>), dim3(2), dim3(256), bytes, dra_stream(stream), *cfg, *actor, *critic, packed, n,
-                     epochs, out3, out_counts, dbg);
+  hipLaunchKernelGGL((ppo_mlp_update_kernel<H, MODE, KTC>), dim3(2), dim3(256), bytes, dra_stream(stream), *cfg, *actor, *critic, packed,
+                     n, epochs, out3, out_counts, dbg);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -919,15 +1007,29 @@ DRA_API int dra_ppo_mlp_update(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net
   if (!cfg || !packed || !out3 || n < 1 || epochs < 1) return DRA_EINVAL;
   if (dra_ppo_mlp_supported(cfg->state_dim, cfg->action_dim, cfg->hidden, cfg->hidden, cfg->mini_batch)) return DRA_EINVAL;
   if (check_net(actor, true) || check_net(critic, false)) return DRA_EINVAL;
-  // the dump build is a separate instantiation: its stores would otherwise cost the product kernel registers
-#define DRA_PPO_UPD(HH) (dbg ? launch_update<HH, true>(cfg, actor, critic, packed, n, epochs, out3, out_counts, dbg, stream) \
-                             : launch_update<HH, false>(cfg, actor, critic, packed, n, epochs, out3, out_counts, dbg, stream))
+  // the dump build is a separate instantiation (its stores would otherwise cost the product kernel registers); hidden = 64 with
+  // 17..32 observations (the HalfCheetah / Walker / Hopper family of examples.py:497-523) has ceil(state_dim / 16) = 2 compiled in
+#define DRA_PPO_UPD(HH, KK) (dbg ? launch_update<HH, 1, 0>(cfg, actor, critic, packed, n, epochs, out3, out_counts, dbg, stream) \
+                                 : launch_update<HH, 0, KK>(cfg, actor, critic, packed, n, epochs, out3, out_counts, dbg, stream))
   switch (cfg->hidden) {
-    case 16: return DRA_PPO_UPD(16);
-    case 32: return DRA_PPO_UPD(32);
-    default: return DRA_PPO_UPD(64);
+    case 16: return DRA_PPO_UPD(16, 0);
+    case 32: return DRA_PPO_UPD(32, 0);
+    default: return (cfg->state_dim > 16 && cfg->state_dim <= 32) ? DRA_PPO_UPD(64, 2) : DRA_PPO_UPD(64, 0);
   }
 #undef DRA_PPO_UPD
+}
+
+// measurement aid (tools/prof_ppo_mlp.py): the same launch with thread 0 of each workgroup accumulating shader-clock cycles per
+// phase of the minibatch loop; cycles (device int64 [2][16]): actor row, critic row.
+DRA_API int dra_ppo_mlp_update_profile(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
+                                       const float* packed, int n, int epochs, float* out3, int64_t* out_counts, int64_t* cycles,
+                                       void* stream) {
+  if (!cfg || !packed || !out3 || !cycles || n < 1 || epochs < 1 || cfg->hidden != 64) return DRA_EINVAL;
+  if (dra_ppo_mlp_supported(cfg->state_dim, cfg->action_dim, cfg->hidden, cfg->hidden, cfg->mini_batch)) return DRA_EINVAL;
+  if (check_net(actor, true) || check_net(critic, false)) return DRA_EINVAL;
+  if (cfg->state_dim > 16 && cfg->state_dim <= 32)
+    return launch_update<64, 2, 2>(cfg, actor, critic, packed, n, epochs, out3, out_counts, reinterpret_cast<float*>(cycles), stream);
+  return launch_update<64, 2, 0>(cfg, actor, critic, packed, n, epochs, out3, out_counts, reinterpret_cast<float*>(cycles), stream);
 }
 
 template <int H>

@@ -562,6 +562,11 @@ int dra_ppo_mlp_pack(const float* state, const float* action, const float* log_p
 #define DRA_PPO_MLP_DBG_FLOATS 65536
 int dra_ppo_mlp_update(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
                        const float* packed, int n, int epochs, float* out3, int64_t* out_counts, float* dbg, void* stream);
+/* measurement aid: the same launch (hidden = 64) with shader-clock cycles per phase of the minibatch loop accumulated by thread 0
+ * of each workgroup into cycles (device i64 [2][16]: actor row, critic row); tools/prof_ppo_mlp.py names the phases. */
+int dra_ppo_mlp_update_profile(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
+                               const float* packed, int n, int epochs, float* out3, int64_t* out_counts, int64_t* cycles,
+                               void* stream);
 /* PPO_agent.py:32-49 over device-resident synthetic environments: t_len x [store normalised observation, no-grad forward of
  * both networks, action = mean + softplus(std) * noise, log-probability, environment step, reward / mask, running
  * observation statistics + normalisation] and the bootstrap forward, in ONE launch of one persistent workgroup. */
