@@ -86,10 +86,12 @@ __device__ __forceinline__ void adam_elem(float& p, float gk, float& m, float& v
   p = p - (a.step_size * m) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) * a.inv_sqrt_bc2 + a.eps);
 }
 
-constexpr size_t update_lds_floats(int H) {
-  return 2 * (size_t)kRows * (kLdX + kLd3) + 3 * (size_t)kRows * (H + 4) + (size_t)H * (H + 4) + 16 * (size_t)(H + 4) +
-         (size_t)kRows * kLd3 + 16 + 16 + 32 + 256;
+constexpr size_t update_lds_floats(int H, int S) {
+  // 2 images | h1, h2 [row][unit] | h1T, h2T, dz2T [unit][row] | W2T | W3 | dz3 | dz3T | b3, std, reduction slots
+  return 2 * (size_t)kRows * (16 * ((S + 15) / 16) + 4 + kLd3) + 2 * (size_t)kRows * (H + 4) + 3 * (size_t)H * (kRows + 4) +
+         (size_t)H * (H + 4) + 16 * (size_t)(H + 4) + (size_t)kRows * kLd3 + 16 * (size_t)(kRows + 4) + 16 + 16 + 32 + 256;
 }
+constexpr size_t kLdsFloatsMax = 160 * 1024 / 4;
 
 // debug dump layout (floats, per role; the critic's region starts at kDbgRole)
 constexpr int kDbgRole = 32768, kDbgH1 = 0, kDbgH2 = 4096, kDbgHead = 8192, kDbgLp = 9216, kDbgGl = 9280, kDbgScal = 9344,
@@ -137,20 +139,25 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
   };
 
   // LDS: two minibatch images ([kRows][LDX] observations | [kRows][kLd3] action, log_pi_a, advantage, ret -- the layout
-  // ppo_pack_kernel writes), then activations / gradients / the transposed-use weight copies
+  // ppo_pack_kernel writes), then activations / gradients row-major AND transposed (every MFMA operand is then one 16-byte read:
+  // contractions over units read [row][unit], contractions over rows read [unit][row]) and the transposed-use weight copies
+  constexpr int LDT = kRows + 4;
   const int img = kRows * (LDX + kLd3);
   float* sImg = lds;
-  float* sH1 = lds + 2 * kRows * (kLdX + kLd3);
-  float* sH2 = sH1 + kRows * LD;      // h2, later dz1
-  float* sDZ2 = sH2 + kRows * LD;
-  float* sW2 = sDZ2 + kRows * LD;
-  float* sW3 = sW2 + H * LD;
-  float* sDZ3 = sW3 + 16 * LD;
-  float* sB3 = sDZ3 + kRows * kLd3;
+  float* sH1 = lds + 2 * img;         // h1 [row][unit]
+  float* sH1T = sH1 + kRows * LD;     // h1 [unit][row]
+  float* sH2 = sH1T + H * LDT;        // h2 [row][unit], overwritten in place by dz2
+  float* sH2T = sH2 + kRows * LD;     // h2 [unit][row], later dz1 [unit][row]
+  float* sDZ2T = sH2T + H * LDT;      // dz2 [unit][row]
+  float* sW2T = sDZ2T + H * LDT;      // W2 [in][out]
+  float* sW3 = sW2T + H * LD;         // W3 [out (16)][in]
+  float* sDZ3 = sW3 + 16 * LD;        // dz3 [row][out]
+  float* sDZ3T = sDZ3 + kRows * kLd3; // dz3 [out][row]
+  float* sB3 = sDZ3T + 16 * LDT;
   float* sStd = sB3 + 16;
   float* sRed = sStd + 16;            // [4 waves][4 g][2]
   float* sPart = sRed + 32;           // [4 waves][4 g][16]
-  for (int i = tid; i < (int)update_lds_floats(H); i += 256) lds[i] = 0.f;
+  for (int i = tid; i < (int)update_lds_floats(H, S); i += 256) lds[i] = 0.f;
   __syncthreads();
 
   // ---- masters: parameters + Adam moments of this lane's share, in the forward's B-operand layout
@@ -196,13 +203,12 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
     if (ACTOR) { sdp = net.param[net.off_std + c16]; sdm = net.exp_avg[net.off_std + c16]; sdv = net.exp_avg_sq[net.off_std + c16]; }
   }
   // the LDS copies the transposed contractions (dh = dz W) and the head read
-  auto publish_w2 = [&]() {
+  auto publish_w2 = [&]() {      // W2 [in][out]: what dh1 = dz2 W2 reads (lane: out = 16 tn + 4 g + r contiguous, in = its unit)
     if (own) {
 #pragma unroll
-      for (int tk = 0; tk < NT; ++tk) {
-        f32x4 v = {w2p[tk][0], w2p[tk][1], w2p[tk][2], w2p[tk][3]};
-        *reinterpret_cast<f32x4*>(&sW2[ncol * LD + 16 * tk + 4 * g]) = v;
-      }
+      for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sW2T[(16 * tk + 4 * g + r) * LD + ncol] = w2p[tk][r];
     }
   };
   auto publish_head = [&]() {
@@ -235,7 +241,7 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
       if (tid + 256 * j < img4) pf[j] = src[tid + 256 * j];
   };
   auto commit = [&](int buf) {
-    f32x4* dst = reinterpret_cast<f32x4*>(sImg + buf * kRows * (kLdX + kLd3));
+    f32x4* dst = reinterpret_cast<f32x4*>(sImg + buf * img);
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
       if (tid + 256 * j < img4) dst[tid + 256 * j] = pf[j];
@@ -251,40 +257,55 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
     const int rows = min(MB, n - kq * MB);
     const float inv_m = 1.f / (float)rows;
     const bool dump = DUMP && dbg && q == 0;
-    const float* sX = sImg + (q & 1) * kRows * (kLdX + kLd3);
+    const float* sX = sImg + (q & 1) * img;
     const float* sAux = sX + kRows * LDX;
     if (PROF && tid == 0 && q == 0) prof_last = clock64();
     if (q + 1 < total) issue(q + 1);
     stamp(0);
 
-    // ---- F1: h1 = tanh(x W1^T + b1).  Tile mt's MFMAs (two accumulator chains) carry tile mt - 1's tanh + stores in their shadow.
+    // ---- F1: h1 = tanh(x W1^T + b1).  Tile by tile: the next tile's operands are requested before this tile's MFMAs (two
+    // accumulator chains), the previous tile's tanh + stores ride in their shadow.
     if (own) {
-      f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+      f32x4 avc[KTM], avn[KTM], prev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < KTM; ++tk) {
+        avc[tk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tk < KT1) avc[tk] = *reinterpret_cast<const f32x4*>(&sX[c16 * LDX + 16 * tk + 4 * g]);
+      }
 #pragma unroll
       for (int mt = 0; mt <= 4; ++mt) {
+        if (mt < 3) {
+#pragma unroll
+          for (int tk = 0; tk < KTM; ++tk)
+            if (tk < KT1) avn[tk] = *reinterpret_cast<const f32x4*>(&sX[(16 * (mt + 1) + c16) * LDX + 16 * tk + 4 * g]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
         if (mt < 4) {
 #pragma unroll
           for (int tk = 0; tk < KTM; ++tk)
             if (tk < KT1) {
-              const f32x4 av = *reinterpret_cast<const f32x4*>(&sX[(16 * mt + c16) * LDX + 16 * tk + 4 * g]);
               // (a step whose four k = 16 tk + 4 g + r all lie past the observation is all zeros)
-              if (16 * tk + 0 < S) a0 = MFMA16(av[0], w1p[tk][0], a0);
-              if (16 * tk + 1 < S) a1 = MFMA16(av[1], w1p[tk][1], a1);
-              if (16 * tk + 2 < S) a0 = MFMA16(av[2], w1p[tk][2], a0);
-              if (16 * tk + 3 < S) a1 = MFMA16(av[3], w1p[tk][3], a1);
+              if (16 * tk + 0 < S) a0 = MFMA16(avc[tk][0], w1p[tk][0], a0);
+              if (16 * tk + 1 < S) a1 = MFMA16(avc[tk][1], w1p[tk][1], a1);
+              if (16 * tk + 2 < S) a0 = MFMA16(avc[tk][2], w1p[tk][2], a0);
+              if (16 * tk + 3 < S) a1 = MFMA16(avc[tk][3], w1p[tk][3], a1);
             }
         }
         if (mt > 0) {
+          f32x4 h;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * (mt - 1) + 4 * g + r;
-            const float h = fast_tanh(prev[r] + b1p);
-            sH1[row * LD + ncol] = h;
-            if (dump) dbg[kDbgH1 + row * 64 + ncol] = h;
+            h[r] = fast_tanh(prev[r] + b1p);
+            sH1[row * LD + ncol] = h[r];
+            if (dump) dbg[kDbgH1 + row * 64 + ncol] = h[r];
           }
+          *reinterpret_cast<f32x4*>(&sH1T[ncol * LDT + 16 * (mt - 1) + 4 * g]) = h;
         }
         prev = a0 + a1;
+#pragma unroll
+        for (int tk = 0; tk < KTM; ++tk) avc[tk] = avn[tk];
       }
     }
     stamp(1);
@@ -292,59 +313,85 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
     stamp(2);
     // ---- F2: h2 = tanh(h1 W2^T + b2)
     if (own) {
-      f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+      f32x4 avc[NT], avn[NT], prev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk) avc[tk] = *reinterpret_cast<const f32x4*>(&sH1[c16 * LD + 16 * tk + 4 * g]);
 #pragma unroll
       for (int mt = 0; mt <= 4; ++mt) {
+        if (mt < 3) {
+#pragma unroll
+          for (int tk = 0; tk < NT; ++tk)
+            avn[tk] = *reinterpret_cast<const f32x4*>(&sH1[(16 * (mt + 1) + c16) * LD + 16 * tk + 4 * g]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
         if (mt < 4) {
 #pragma unroll
           for (int tk = 0; tk < NT; ++tk) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(&sH1[(16 * mt + c16) * LD + 16 * tk + 4 * g]);
-            a0 = MFMA16(av[0], w2p[tk][0], a0);
-            a1 = MFMA16(av[1], w2p[tk][1], a1);
-            a0 = MFMA16(av[2], w2p[tk][2], a0);
-            a1 = MFMA16(av[3], w2p[tk][3], a1);
+            a0 = MFMA16(avc[tk][0], w2p[tk][0], a0);
+            a1 = MFMA16(avc[tk][1], w2p[tk][1], a1);
+            a0 = MFMA16(avc[tk][2], w2p[tk][2], a0);
+            a1 = MFMA16(avc[tk][3], w2p[tk][3], a1);
           }
         }
         if (mt > 0) {
+          f32x4 h;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * (mt - 1) + 4 * g + r;
-            const float h = fast_tanh(prev[r] + b2p);
-            sH2[row * LD + ncol] = h;
-            if (dump) dbg[kDbgH2 + row * 64 + ncol] = h;
+            h[r] = fast_tanh(prev[r] + b2p);
+            sH2[row * LD + ncol] = h[r];
+            if (dump) dbg[kDbgH2 + row * 64 + ncol] = h[r];
           }
+          *reinterpret_cast<f32x4*>(&sH2T[ncol * LDT + 16 * (mt - 1) + 4 * g]) = h;
         }
         prev = a0 + a1;
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk) avc[tk] = avn[tk];
       }
     }
     stamp(3);
     __syncthreads();
     stamp(4);
     // ---- F3 + loss: lane (c16 = head output, g, reg) <-> row 16 w + 4 g + reg
-    if (ACTOR && std_dirty) {      // scale = softplus(std) and what the row loop needs of it, once per actor step
-      std_raw = sStd[c16];
-      sd = std_raw > 20.f ? std_raw : fast_log(1.f + fast_exp(std_raw));
-      log_sd = fast_log(sd);
-      inv_sd = __builtin_amdgcn_rcpf(sd);
-      inv_var = inv_sd * inv_sd;
-      std_dirty = false;
-    }
     {
+      f32x4 av[NT], bv[NT];
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk) {
+        av[tk] = *reinterpret_cast<const f32x4*>(&sH2[(16 * w + c16) * LD + 16 * tk + 4 * g]);
+        bv[tk] = *reinterpret_cast<const f32x4*>(&sW3[c16 * LD + 16 * tk + 4 * g]);
+      }
+      f32x4 aux;      // this lane's four rows of the image: its own action column, and the row scalars
+      float lp_old[4], adv4[4], ret4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * w + 4 * g + r;
+        aux[r] = sAux[row * kLd3 + c16];
+        if (ACTOR) { lp_old[r] = sAux[row * kLd3 + kAuxLp]; adv4[r] = sAux[row * kLd3 + kAuxAdv]; }
+        else ret4[r] = sAux[row * kLd3 + kAuxRet];
+      }
+      const float b3 = sB3[c16];
+      if (ACTOR && std_dirty) {      // scale = softplus(std) and what the row loop needs of it, once per actor step
+        std_raw = sStd[c16];
+        sd = std_raw > 20.f ? std_raw : fast_log(1.f + fast_exp(std_raw));
+        log_sd = fast_log(sd);
+        inv_sd = __builtin_amdgcn_rcpf(sd);
+        inv_var = inv_sd * inv_sd;
+        std_dirty = false;
+      }
+      __builtin_amdgcn_sched_barrier(0);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};     // two chains: a dependent MFMA waits 40 cycles
 #pragma unroll
       for (int tk = 0; tk < NT; ++tk) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(&sH2[(16 * w + c16) * LD + 16 * tk + 4 * g]);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(&sW3[c16 * LD + 16 * tk + 4 * g]);
-        acc = MFMA16(av[0], bv[0], acc);
-        acc_b = MFMA16(av[1], bv[1], acc_b);
-        acc = MFMA16(av[2], bv[2], acc);
-        acc_b = MFMA16(av[3], bv[3], acc_b);
+        acc = MFMA16(av[tk][0], bv[tk][0], acc);
+        acc_b = MFMA16(av[tk][1], bv[tk][1], acc_b);
+        acc = MFMA16(av[tk][2], bv[tk][2], acc);
+        acc_b = MFMA16(av[tk][3], bv[tk][3], acc_b);
       }
       acc += acc_b;
-      const float b3 = sB3[c16];
       const bool col_ok = c16 < A;
       float s0 = 0.f, s1 = 0.f, gsd = 0.f;
+      f32x4 dzv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * w + 4 * g + r;
@@ -352,19 +399,18 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
         float dz = 0.f;
         if (ACTOR) {
           const float mean = fast_tanh(acc[r] + b3);
-          const float diff = sAux[row * kLd3 + c16] - mean;
+          const float diff = aux[r] - mean;
           const float lpe = col_ok ? (-(diff * diff) * (0.5f * inv_var) - log_sd - kLogSqrt2Pi) : 0.f;
           const float lp = group16_sum(lpe);
-          const float lp_old = sAux[row * kLd3 + kAuxLp], adv = sAux[row * kLd3 + kAuxAdv];
           // losses.hip ppo_loss_kernel's arithmetic (PPO_agent.py:78-86), row by row
-          const float ratio = fast_exp(lp - lp_old);
-          const float obj = ratio * adv;
+          const float ratio = fast_exp(lp - lp_old[r]);
+          const float obj = ratio * adv4[r];
           const float rc = fminf(fmaxf(ratio, 1.f - cfg.ratio_clip), 1.f + cfg.ratio_clip);
-          const float objc = rc * adv;
+          const float objc = rc * adv4[r];
           const bool inside = (ratio >= 1.f - cfg.ratio_clip) && (ratio <= 1.f + cfg.ratio_clip);
           const float gate = inside ? 1.f : (obj < objc ? 1.f : (obj == objc ? 0.5f : 0.f));
           const float g_lp = row_ok ? -gate * obj * inv_m : 0.f;
-          if (row_ok) { s0 += fminf(obj, objc); s1 += lp_old - lp; }
+          if (row_ok) { s0 += fminf(obj, objc); s1 += lp_old[r] - lp; }
           if (col_ok) {
             dz = (g_lp * (diff * inv_var)) * (1.f - mean * mean);
             gsd += g_lp * ((diff * diff) * (inv_var * inv_sd) - inv_sd);
@@ -375,16 +421,18 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
           }
         } else {
           const float v = acc[r] + b3;
-          const float dv = sAux[row * kLd3 + kAuxRet] - v;
+          const float dv = ret4[r] - v;
           if (row_ok && c16 == 0) { s0 += dv * dv; dz = -dv * inv_m; }
           if (dump) {
             dbg[kDbgHead + row * 16 + c16] = v;
             if (c16 == 0) { dbg[kDbgLp + row] = v; dbg[kDbgGl + row] = dz; }
           }
         }
+        dzv[r] = dz;
         sDZ3[row * kLd3 + c16] = dz;
         if (dump) dbg[kDbgDz3 + row * 16 + c16] = dz;
       }
+      *reinterpret_cast<f32x4*>(&sDZ3T[c16 * LDT + 16 * w + 4 * g]) = dzv;
       // per (wave, lane group) partial sums: reduced after the barrier by whoever needs them, in a fixed order
       if (c16 == 0) { sRed[2 * (4 * w + g)] = s0; sRed[2 * (4 * w + g) + 1] = s1; }
       if (ACTOR) sPart[16 * (4 * w + g) + c16] = gsd;
@@ -420,44 +468,62 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
       float gw3[4] = {0.f, 0.f, 0.f, 0.f}, gb3 = 0.f, gstd = 0.f;
       // ---- B3: dz2 = (dz3 W3) (1 - h2^2);  dW3^T tile tk = w;  db3, dstd
       if (own) {
+        // operands: dh2 = dz3 W3 contracts the (<= 16) head outputs in steps of four; dW3^T contracts the rows: both operands of
+        // that one come [unit][row] / [out][row] (and h2 [unit][row] is also what the dz2 epilogue multiplies by)
+        float b3w[4];
+        float a3d[4][4];
+        f32x4 hT[4], dT[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          b3w[s2] = 0.f;
+          if (4 * s2 < A) {
+            b3w[s2] = sW3[(4 * s2 + g) * LD + ncol];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a3d[s2][mt] = sDZ3[(16 * mt + c16) * kLd3 + 4 * s2 + g];
+          }
+        }
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+          hT[sg] = *reinterpret_cast<const f32x4*>(&sH2T[ncol * LDT + 16 * sg + 4 * g]);
+          dT[sg] = *reinterpret_cast<const f32x4*>(&sDZ3T[c16 * LDT + 16 * sg + 4 * g]);
+        }
         pw1 *= (double)net.beta1;
         pw2 *= (double)net.beta2;
         ad.step_size = (float)((double)net.lr / (1.0 - pw1));
         ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pw2));
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[4];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2)
           if (4 * s2 < A) {
-            const float b = sW3[(4 * s2 + g) * LD + ncol];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-              acc[mt] = MFMA16(sDZ3[(16 * mt + c16) * kLd3 + 4 * s2 + g], b, acc[mt]);
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = MFMA16(a3d[s2][mt], b3w[s2], acc[mt]);
           }
         // dW3^T (two chains over the rows) with the dz2 epilogue of the four dh2 tiles in its shadow
         f32x4 a3 = {0.f, 0.f, 0.f, 0.f}, a3b = {0.f, 0.f, 0.f, 0.f};
         float bsum = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; s += 2) {
-          if (s < 4 * MT) {
-            const int r0 = row_of(s, g), r1 = row_of(s + 1, g);
-            const float b0 = sDZ3[r0 * kLd3 + c16], b1 = sDZ3[r1 * kLd3 + c16];
-            bsum += b0;
-            bsum += b1;
-            a3 = MFMA16(sH2[r0 * LD + ncol], b0, a3);
-            a3b = MFMA16(sH2[r1 * LD + ncol], b1, a3b);
+        for (int sg = 0; sg < 4; ++sg) {
+          if (sg < MT) {
+            bsum += (dT[sg][0] + dT[sg][1]) + (dT[sg][2] + dT[sg][3]);
+            a3 = MFMA16(hT[sg][0], dT[sg][0], a3);
+            a3b = MFMA16(hT[sg][1], dT[sg][1], a3b);
+            a3 = MFMA16(hT[sg][2], dT[sg][2], a3);
+            a3b = MFMA16(hT[sg][3], dT[sg][3], a3b);
           }
           {
-            const int mt = s >> 2, rp = s & 3;      // two of the sixteen dz2 values per step
+            const int mt = sg;
+            f32x4 dz;
 #pragma unroll
-            for (int r = rp; r < rp + 2; ++r) {
+            for (int r = 0; r < 4; ++r) {
               const int row = 16 * mt + 4 * g + r;
-              const float h2 = sH2[row * LD + ncol];
-              const float dz = acc[mt][r] * (1.f - h2 * h2);
-              sDZ2[row * LD + ncol] = dz;
-              if (dump) dbg[kDbgDz2 + row * 64 + ncol] = dz;
+              dz[r] = acc[mt][r] * (1.f - hT[mt][r] * hT[mt][r]);
+              sH2[row * LD + ncol] = dz[r];       // in place: this lane read h2 [row][its unit] from the transposed copy
+              if (dump) dbg[kDbgDz2 + row * 64 + ncol] = dz[r];
             }
+            *reinterpret_cast<f32x4*>(&sDZ2T[ncol * LDT + 16 * mt + 4 * g]) = dz;
           }
         }
         a3 += a3b;
@@ -483,26 +549,41 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
       __syncthreads();
       stamp(8);
       // ---- B2: dW2^T tiles (this wave's units x all inputs) with Adam(W3, b3, std) in the MFMA shadow;
-      //          dz1 = (dz2 W2) (1 - h1^2) into sH2 with Adam(W2, b2) in the MFMA shadow
+      //          dz1 = (dz2 W2) (1 - h1^2), kept [unit][row], with Adam(W2, b2) in the MFMA shadow
       if (own) {
+        f32x4 bw[4], awc[NT], awn[NT], bd[NT];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) bw[sg] = *reinterpret_cast<const f32x4*>(&sDZ2T[ncol * LDT + 16 * sg + 4 * g]);
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk) awc[tk] = *reinterpret_cast<const f32x4*>(&sH1T[(16 * tk + c16) * LDT + 4 * g]);
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) bd[tn] = *reinterpret_cast<const f32x4*>(&sW2T[ncol * LD + 16 * tn + 4 * g]);
         f32x4 acc[NT];
 #pragma unroll
         for (int tk = 0; tk < NT; ++tk) acc[tk] = f32x4{0.f, 0.f, 0.f, 0.f};
         float bsum = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          if (s < 4 * MT) {
-            const int rr = row_of(s, g);
-            const float b = sDZ2[rr * LD + ncol];
-            bsum += b;
+        for (int sg = 0; sg < 4; ++sg) {
+          if (sg < 3) {
 #pragma unroll
-            for (int tk = 0; tk < NT; ++tk) acc[tk] = MFMA16(sH1[rr * LD + 16 * tk + c16], b, acc[tk]);
+            for (int tk = 0; tk < NT; ++tk)
+              awn[tk] = *reinterpret_cast<const f32x4*>(&sH1T[(16 * tk + c16) * LDT + 16 * (sg + 1) + 4 * g]);
           }
-          if (s < 4) adam_elem(w3p[s], gw3[s], w3m[s], w3v[s], ad);
-          if (s == 4 && w == 0 && c16 < A) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (sg < MT) {
+            bsum += (bw[sg][0] + bw[sg][1]) + (bw[sg][2] + bw[sg][3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int tk = 0; tk < NT; ++tk) acc[tk] = MFMA16(awc[tk][j], bw[sg][j], acc[tk]);
+          }
+          adam_elem(w3p[sg], gw3[sg], w3m[sg], w3v[sg], ad);
+          if (sg == 3 && w == 0 && c16 < A) {
             adam_elem(b3p, gb3, b3m, b3v, ad);
             if (ACTOR) adam_elem(sdp, gstd, sdm, sdv, ad);
           }
+#pragma unroll
+          for (int tk = 0; tk < NT; ++tk) awc[tk] = awn[tk];
         }
         const float gb2 = over_g_sum(bsum);
         publish_head();           // (sW3 / sB3 / sStd were last read before the B3 | B2 barrier)
@@ -513,35 +594,48 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
             for (int r = 0; r < 4; ++r) dbg[kDbgW2 + ncol * 64 + 16 * tk + 4 * g + r] = acc[tk][r];
           if (g == 0) dbg[kDbgB2 + ncol] = gb2;
         }
-        // dh1 tile by tile: the previous tile's epilogue and one W2 Adam element per k step ride in the MFMA shadow
-        f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+        // dh1 tile by tile: the next tile's operands requested first, the previous tile's epilogue and one W2 Adam element per
+        // k step in the MFMA shadow
+        f32x4 adc[NT], adn[NT], h1c, h1n, prev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tn = 0; tn < NT; ++tn) adc[tn] = *reinterpret_cast<const f32x4*>(&sH2[c16 * LD + 16 * tn + 4 * g]);
+        h1c = *reinterpret_cast<const f32x4*>(&sH1T[ncol * LDT + 4 * g]);
+        h1n = h1c;
 #pragma unroll
         for (int mt = 0; mt <= 4; ++mt) {
+          if (mt < 3) {
+#pragma unroll
+            for (int tn = 0; tn < NT; ++tn)
+              adn[tn] = *reinterpret_cast<const f32x4*>(&sH2[(16 * (mt + 1) + c16) * LD + 16 * tn + 4 * g]);
+          }
+          if (mt >= 1 && mt < 4) h1n = *reinterpret_cast<const f32x4*>(&sH1T[ncol * LDT + 16 * mt + 4 * g]);
+          __builtin_amdgcn_sched_barrier(0);
           f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
           if (mt < 4) {
 #pragma unroll
             for (int tn = 0; tn < NT; ++tn) {
-              const f32x4 av = *reinterpret_cast<const f32x4*>(&sDZ2[(16 * mt + c16) * LD + 16 * tn + 4 * g]);
-              a0 = MFMA16(av[0], sW2[(16 * tn + 4 * g + 0) * LD + ncol], a0);
-              a1 = MFMA16(av[1], sW2[(16 * tn + 4 * g + 1) * LD + ncol], a1);
-              a0 = MFMA16(av[2], sW2[(16 * tn + 4 * g + 2) * LD + ncol], a0);
-              a1 = MFMA16(av[3], sW2[(16 * tn + 4 * g + 3) * LD + ncol], a1);
-              // Adam on the master registers (the forward's operands); the transposed reads above go to the LDS copy, which
-              // keeps the OLD weights until publish_w2() in B1
+              a0 = MFMA16(adc[tn][0], bd[tn][0], a0);
+              a1 = MFMA16(adc[tn][1], bd[tn][1], a1);
+              a0 = MFMA16(adc[tn][2], bd[tn][2], a0);
+              a1 = MFMA16(adc[tn][3], bd[tn][3], a1);
+              // Adam on the master registers (the forward's operands); the transposed reads went to the LDS copy, which keeps the
+              // OLD weights until publish_w2() in B1
               adam_elem(w2p[tn][mt], acc[tn][mt], w2m[tn][mt], w2v[tn][mt], ad);
             }
           }
           if (mt > 0) {
+            f32x4 dz;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int row = 16 * (mt - 1) + 4 * g + r;
-              const float h1 = sH1[row * LD + ncol];
-              const float dz = prev[r] * (1.f - h1 * h1);
-              sH2[row * LD + ncol] = dz;
-              if (dump) dbg[kDbgDz1 + row * 64 + ncol] = dz;
+              dz[r] = prev[r] * (1.f - h1c[r] * h1c[r]);
+              if (dump) dbg[kDbgDz1 + (16 * (mt - 1) + 4 * g + r) * 64 + ncol] = dz[r];
             }
+            *reinterpret_cast<f32x4*>(&sH2T[ncol * LDT + 16 * (mt - 1) + 4 * g]) = dz;
           }
           prev = a0 + a1;
+          if (mt >= 1) h1c = h1n;
+#pragma unroll
+          for (int tn = 0; tn < NT; ++tn) adc[tn] = adn[tn];
         }
         adam_elem(b2p, gb2, b2m, b2v, ad);
       }
@@ -550,21 +644,45 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
       stamp(10);
       // ---- B1: dW1^T tiles;  Adam(W1, b1)
       if (own) {
-        publish_w2();             // (sW2 was last read before the B2 | B1 barrier)
+        publish_w2();             // (the LDS copy was last read before the B2 | B1 barrier)
+        f32x4 bx[4];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) bx[sg] = *reinterpret_cast<const f32x4*>(&sH2T[ncol * LDT + 16 * sg + 4 * g]);
+        float axc[4][KTM], axn[4][KTM];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int tk = 0; tk < KTM; ++tk) {
+            axc[j][tk] = 0.f;
+            if (tk < KT1) axc[j][tk] = sX[(4 * g + j) * LDX + 16 * tk + c16];
+          }
         f32x4 acc[KTM];
 #pragma unroll
         for (int tk = 0; tk < KTM; ++tk) acc[tk] = f32x4{0.f, 0.f, 0.f, 0.f};
         float bsum = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-          if (s < 4 * MT) {
-            const int rr = row_of(s, g);
-            const float b = sH2[rr * LD + ncol];
-            bsum += b;
+        for (int sg = 0; sg < 4; ++sg) {
+          if (sg < 3) {
 #pragma unroll
-            for (int tk = 0; tk < KTM; ++tk)
-              if (tk < KT1) acc[tk] = MFMA16(sX[rr * LDX + 16 * tk + c16], b, acc[tk]);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int tk = 0; tk < KTM; ++tk)
+                if (tk < KT1) axn[j][tk] = sX[(16 * (sg + 1) + 4 * g + j) * LDX + 16 * tk + c16];
           }
+          __builtin_amdgcn_sched_barrier(0);
+          if (sg < MT) {
+            bsum += (bx[sg][0] + bx[sg][1]) + (bx[sg][2] + bx[sg][3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int tk = 0; tk < KTM; ++tk)
+                if (tk < KT1) acc[tk] = MFMA16(axc[j][tk], bx[sg][j], acc[tk]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tk = 0; tk < KTM; ++tk) axc[j][tk] = axn[j][tk];
+        }
         const float gb1 = over_g_sum(bsum);
         if (dump) {
 #pragma unroll
@@ -962,6 +1080,7 @@ DRA_API int dra_ppo_mlp_supported(int state_dim, int action_dim, int hidden1, in
   if (state_dim < 1 || state_dim > kMaxS || action_dim < 1 || action_dim > kMaxA) return DRA_EINVAL;
   if (hidden1 != hidden2 || (hidden1 != 16 && hidden1 != 32 && hidden1 != 64)) return DRA_EINVAL;
   if (mini_batch < 1 || mini_batch > kRows) return DRA_EINVAL;
+  if (update_lds_floats(hidden1, state_dim) > kLdsFloatsMax) return DRA_EINVAL;      // (hidden 64: up to 48 observations)
   return DRA_OK;
 }
 
@@ -989,12 +1108,12 @@ DRA_API int dra_ppo_mlp_pack(const float* state, const float* action, const floa
 template <int H, int MODE, int KTC>
 static int launch_update(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic, const float* packed,
                          int n, int epochs, float* out3, int64_t* out_counts, float* dbg, void* stream) {
-  const size_t bytes = update_lds_floats(H) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  const size_t bytes = update_lds_floats(H, cfg->state_dim) * sizeof(float);
+  static size_t attr_bytes = 0;
+  if (bytes > attr_bytes) {
     DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_update_kernel<H, MODE, KTC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    attr_set = true;
+    attr_bytes = bytes;
   }
   hipLaunchKernelGGL((ppo_mlp_update_kernel<H, MODE, KTC>), dim3(2), dim3(256), bytes, dra_stream(stream), *cfg, *actor, *critic, packed,
                      n, epochs, out3, out_counts, dbg);

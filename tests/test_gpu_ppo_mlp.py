@@ -186,7 +186,7 @@ _DBG = dict(role=32768, h1=0, h2=4096, head=8192, lp=9216, gl=9280, scal=9344, d
             w3=27648, b1=28672, b2=28736, b3=28800, std=28816)
 
 
-@pytest.mark.parametrize("s_dim,a_dim,hidden,mb", [(17, 6, 64, 64), (5, 2, 16, 32), (33, 16, 32, 48), (64, 1, 64, 20)])
+@pytest.mark.parametrize("s_dim,a_dim,hidden,mb", [(17, 6, 64, 64), (5, 2, 16, 32), (33, 16, 32, 48), (48, 1, 64, 20)])
 def test_update_kernel_first_minibatch_intermediates(dra, s_dim, a_dim, hidden, mb):
     """The debug instantiation's dump of minibatch 0 -- hidden activations, policy mean / value, log-probabilities, loss
     scalars, the loss gradient per row and EVERY parameter gradient of both networks -- against autograd on the reference's
