@@ -111,15 +111,16 @@ static_assert(2 * kDbgRole <= DRA_PPO_MLP_DBG_FLOATS, "debug buffer");
 //   B1   dW1^T; Adam(W1, b1)
 // The time of a minibatch is the sum of dependent latencies, not of work: what matters is how little sits between the MFMAs
 // (profiles/r05*_prof_ppo_mlp.json: cycles per phase).
-template <int H, bool ACTOR, int MODE, int KTC>
+template <int H, bool ACTOR, int MODE, int SC>
 __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, const dra_ppo_mlp_net& net, const float* __restrict__ packed,
                                                 const int n, const int epochs, float* __restrict__ out3,
                                                 int64_t* __restrict__ out_counts, float* __restrict__ dbg_all, float* lds) {
   constexpr int NT = H / 16, LD = H + 4;
-  constexpr int KTM = KTC ? KTC : 4;            // KTC: ceil(state_dim / 16) at compile time (0: any, read from the configuration)
+  constexpr int KTC = (SC + 15) / 16;           // SC: state_dim at compile time (0: any, read from the configuration)
+  constexpr int KTM = SC ? KTC : 4;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c16 = l & 15, g = l >> 4;
-  const int S = cfg.state_dim, A = ACTOR ? cfg.action_dim : 1, MB = cfg.mini_batch;
-  const int KT1 = KTC ? KTC : (S + 15) >> 4;
+  const int S = SC ? SC : cfg.state_dim, A = ACTOR ? cfg.action_dim : 1, MB = cfg.mini_batch;
+  const int KT1 = SC ? KTC : (S + 15) >> 4;
   const int LDX = 16 * KT1 + 4;
   const int MT = (MB + 15) >> 4;      // M tiles that can hold rows (the contractions over rows stop there)
   const int per_epoch = (n + MB - 1) / MB, total = per_epoch * epochs;
@@ -229,7 +230,7 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
   ad.step_size = 0.f; ad.inv_sqrt_bc2 = 0.f;
 
   // ---- minibatch images: prefetched one minibatch ahead into registers, committed to the other LDS buffer after the gate
-  constexpr int NJ = (kRows * ((KTC ? 16 * KTC + 4 : kLdX) + kLd3) / 4 + 255) / 256;
+  constexpr int NJ = (kRows * ((SC ? 16 * KTC + 4 : kLdX) + kLd3) / 4 + 255) / 256;
   f32x4 pf[NJ];
   const int img4 = img / 4;
 #pragma unroll
@@ -285,11 +286,12 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
 #pragma unroll
           for (int tk = 0; tk < KTM; ++tk)
             if (tk < KT1) {
-              // (a step whose four k = 16 tk + 4 g + r all lie past the observation is all zeros)
-              if (16 * tk + 0 < S) a0 = MFMA16(avc[tk][0], w1p[tk][0], a0);
-              if (16 * tk + 1 < S) a1 = MFMA16(avc[tk][1], w1p[tk][1], a1);
-              if (16 * tk + 2 < S) a0 = MFMA16(avc[tk][2], w1p[tk][2], a0);
-              if (16 * tk + 3 < S) a1 = MFMA16(avc[tk][3], w1p[tk][3], a1);
+              // (a step whose four k = 16 tk + 4 g + r all lie past the observation is all zeros: skipped when the observation
+              // size is a compile-time constant -- a run-time test per MFMA costs more than the MFMA)
+              if (!SC || 16 * tk + 0 < SC) a0 = MFMA16(avc[tk][0], w1p[tk][0], a0);
+              if (!SC || 16 * tk + 1 < SC) a1 = MFMA16(avc[tk][1], w1p[tk][1], a1);
+              if (!SC || 16 * tk + 2 < SC) a0 = MFMA16(avc[tk][2], w1p[tk][2], a0);
+              if (!SC || 16 * tk + 3 < SC) a1 = MFMA16(avc[tk][3], w1p[tk][3], a1);
             }
         }
         if (mt > 0) {
@@ -698,7 +700,7 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
           if (tk < KT1)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (16 * tk + r < S) adam_elem(w1p[tk][r], acc[tk][r], w1m[tk][r], w1v[tk][r], ad);
+              if (!SC || 16 * tk + r < SC) adam_elem(w1p[tk][r], acc[tk][r], w1m[tk][r], w1v[tk][r], ad);
         adam_elem(b1p, gb1, b1m, b1v, ad);
       }
       ++applied;
@@ -754,13 +756,13 @@ __device__ __forceinline__ void ppo_update_role(const dra_ppo_mlp_cfg& cfg, cons
   }
 }
 
-template <int H, int MODE, int KTC>
+template <int H, int MODE, int SC>
 __global__ void __launch_bounds__(256)
 ppo_mlp_update_kernel(dra_ppo_mlp_cfg cfg, dra_ppo_mlp_net actor, dra_ppo_mlp_net critic, const float* __restrict__ packed, int n,
                       int epochs, float* __restrict__ out3, int64_t* __restrict__ out_counts, float* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  if (blockIdx.x == 0) ppo_update_role<H, true, MODE, KTC>(cfg, actor, packed, n, epochs, out3, out_counts, dbg, lds);
-  else ppo_update_role<H, false, MODE, KTC>(cfg, critic, packed, n, epochs, out3, out_counts, dbg, lds);
+  if (blockIdx.x == 0) ppo_update_role<H, true, MODE, SC>(cfg, actor, packed, n, epochs, out3, out_counts, dbg, lds);
+  else ppo_update_role<H, false, MODE, SC>(cfg, critic, packed, n, epochs, out3, out_counts, dbg, lds);
 }
 
 // ------------------------------------------------------------------------------------------------ pack
@@ -859,41 +861,103 @@ cont_env_step_kernel(double* __restrict__ state, int64_t* __restrict__ counter, 
 }
 
 // ------------------------------------------------------------------------------------------------ rollout
+// One workgroup walks the rollout: 8 waves, waves 0-3 the actor's network, 4-7 the critic's (each owning 16 hidden units as in
+// the update kernel).  What does NOT depend on the actions is taken off the sequential chain first, in parallel over the whole
+// rollout: rewards and terminals (hashes of the step counters: written straight to out_reward / out_mask) and the action noise
+// (Box-Muller: parked in out_action, which step t overwrites with the action).  Per step, between workgroup barriers:
+//   F1 | F2 | heads (action = mean + scale * noise, log-probability, value) | environment: every observation component |
+//   running statistics: one lane per feature, rows in order (normalizer.py:39-41's arithmetic) | normalised observation t + 1
 constexpr size_t rollout_lds_floats(int H) {
-  // sX | per role: sH1, sH2 (kRows x LD) | sW3 [2][16][LD] | sAct [kRows][kLd3] | fp64: state [kRows][kMaxS], mean, var [kMaxS],
-  // mean_a [kRows], count | counters i64 [kRows] | done i32 [kRows]
-  return (size_t)kRows * kLdX + 4 * (size_t)kRows * (H + 4) + 32 * (size_t)(H + 4) + (size_t)kRows * kLd3 +
-         2 * ((size_t)kRows * kMaxS + 2 * kMaxS + kRows + 2) + 2 * kRows + kRows + 64;
+  // sX | sH1, sH2 (kRows x LD) | sW3 [16][LD] | sAct [kRows][kLd3] | fp64: state [kRows][kMaxS], mean, var, den [kMaxS], count [2]
+  return (size_t)kRows * kLdX + 2 * (size_t)kRows * (H + 4) + 16 * (size_t)(H + 4) + (size_t)kRows * kLd3 +
+         2 * ((size_t)kRows * kMaxS + 3 * kMaxS + 2) + 64;
 }
 
-template <int H>
+// the batch x[0..N) of one feature folded into (mean, var, count): rms_fold's arithmetic with the rows fetched eight at a time
+// (independent LDS reads) and added in order
+__device__ __forceinline__ void rms_fold_lds(const double* x, int stride, int N, double& mean, double& var, double count) {
+  double sum = 0.0;
+  for (int i0 = 0; i0 < N; i0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (i0 + k < N) ? x[(i0 + k) * stride] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + k < N) sum += v[k];
+  }
+  const double b_mean = sum / (double)N;
+  double sq = 0.0;
+  for (int i0 = 0; i0 < N; i0 += 8) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (i0 + k < N) ? x[(i0 + k) * stride] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + k < N) {
+        const double d = v[k] - b_mean;
+        sq += d * d;
+      }
+  }
+  const double b_var = sq / (double)N;
+  const double n = count, b_count = (double)N, total = count + b_count;
+  const double delta = b_mean - mean;
+  const double m2 = var * n + b_var * b_count + delta * delta * n * b_count / total;
+  mean = mean + delta * b_count / total;
+  var = m2 / total;
+}
+
+template <int H, bool PROF>
 __global__ void __launch_bounds__(512)
-ppo_mlp_rollout_kernel(dra_ppo_mlp_cfg cfg, dra_ppo_mlp_net actor, dra_ppo_mlp_net critic, dra_ppo_mlp_rollout_io io) {
+ppo_mlp_rollout_kernel(dra_ppo_mlp_cfg cfg, dra_ppo_mlp_net actor, dra_ppo_mlp_rollout_io io, long long* __restrict__ cycles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_last = 0;
+  auto stamp = [&](int k) {
+    if (PROF && threadIdx.x == 0) {
+      const long long t = clock64();
+      prof[k] += t - prof_last;
+      prof_last = t;
+    }
+  };
   constexpr int NT = H / 16, LD = H + 4;
-  const int tid = threadIdx.x, wv = tid >> 6, role = wv >> 2, w = wv & 3, l = tid & 63, c16 = l & 15, g = l >> 4;
-  const dra_ppo_mlp_net& net = role == 0 ? actor : critic;
-  const int S = cfg.state_dim, AD = cfg.action_dim, A = role == 0 ? AD : 1;
+  // waves 0-3 carry the policy network (each owning 16 hidden units, as in the update kernel); all 8 waves share the
+  // environment / statistics phases.  The value network is NOT on the sequential chain (nothing in the loop reads v_t): it
+  // runs afterwards over all (t_len + 1) x n_env observations at once (ppo_mlp_value_kernel).
+  const int tid = threadIdx.x, wv = tid >> 6, w = wv & 3, l = tid & 63, c16 = l & 15, g = l >> 4;
+  const dra_ppo_mlp_net& net = actor;
+  const int S = cfg.state_dim, A = cfg.action_dim;
   const int N = io.n_env, T = io.t_len;
   const int KT1 = (S + 15) >> 4, LDX = 16 * KT1 + 4;
   const int MT = (N + 15) >> 4;
-  const bool own = w < NT;
+  const bool own = wv < NT;
+  const bool head = wv < MT;
   const int ncol = 16 * w + c16;
 
   float* sX = lds;
-  float* sH1 = sX + kRows * kLdX + role * (2 * kRows * LD);
+  float* sH1 = sX + kRows * kLdX;
   float* sH2 = sH1 + kRows * LD;
-  float* sW3 = sX + kRows * kLdX + 4 * kRows * LD + role * (16 * LD);
-  float* sAct = sX + kRows * kLdX + 4 * kRows * LD + 32 * LD;
+  float* sW3 = sH2 + kRows * LD;
+  float* sAct = sW3 + 16 * LD;
   double* sState = reinterpret_cast<double*>(sAct + kRows * kLd3);
   double* sMean = sState + kRows * kMaxS;
   double* sVar = sMean + kMaxS;
-  double* sMeanA = sVar + kMaxS;
-  double* sCount = sMeanA + kRows;         // [2]
-  int64_t* sCtr = reinterpret_cast<int64_t*>(sCount + 2);
-  int32_t* sDone = reinterpret_cast<int32_t*>(sCtr + kRows);
+  double* sDen = sVar + kMaxS;
+  double* sCount = sDen + kMaxS;           // [2]
   for (int i = tid; i < (int)rollout_lds_floats(H); i += 512) lds[i] = 0.f;
   __syncthreads();
+
+  // ---- off the chain, over the whole rollout: rewards / terminals and the action noise
+  for (int i = tid; i < T * N; i += 512) {
+    const int t = i / N, e = i - t * N;
+    const int64_t c = io.env_counter[e] + t + 1;
+    const uint64_t sdv = (uint64_t)io.env_seed[e];
+    io.out_reward[i] = (float)(cenv_reward(sdv, c) * io.reward_coef);
+    io.out_mask[i] = cenv_done(sdv, c, io.horizon) ? 0.f : 1.f;
+  }
+  const int64_t t_noise0 = *io.sampler_step;
+  for (int i = tid; i < T * N * A; i += 512) {
+    const int t = i / (N * A), r = i - t * (N * A), e = r / A, d = r - e * A;
+    io.out_action[i] = gauss_noise(io.noise_seed, t_noise0 + t, io.n_global, io.env0 + e, d);
+  }
 
   // weights as forward B operands (constant over the rollout)
   float w1[4][4], w2[NT][4];
@@ -913,145 +977,192 @@ ppo_mlp_rollout_kernel(dra_ppo_mlp_cfg cfg, dra_ppo_mlp_net actor, dra_ppo_mlp_n
 #pragma unroll
     for (int r = 0; r < 4; ++r) sW3[c16 * LD + 16 * w + 4 * g + r] = net.param[net.off_w3 + c16 * H + 16 * w + 4 * g + r];
   const float b3 = c16 < A ? net.param[net.off_b3 + c16] : 0.f;
-  float sd = 1.f, log_sd = 0.f;
-  if (role == 0 && c16 < A) { sd = softplus_f(net.param[net.off_std + c16]); log_sd = logf(sd); }
+  float sd = 1.f, log_sd = 0.f, inv_2var = 0.5f;
+  if (c16 < A) {
+    sd = softplus_f(net.param[net.off_std + c16]);
+    log_sd = logf(sd);
+    inv_2var = 1.f / (2.f * (sd * sd));
+  }
   // environment + normaliser state
   for (int i = tid; i < N * S; i += 512) {
     const int e = i / S, j = i - e * S;
     sState[e * kMaxS + j] = io.env_state[i];
     sX[e * LDX + j] = io.cur_state[i];
   }
-  for (int i = tid; i < S; i += 512) { sMean[i] = io.rms[i]; sVar[i] = io.rms[S + i]; }
-  for (int i = tid; i < N; i += 512) sCtr[i] = io.env_counter[i];
+  for (int i = tid; i < S; i += 512) {
+    const double m = io.rms[i], v = io.rms[S + i];
+    sMean[i] = m;
+    sVar[i] = v;
+    sDen[i] = sqrt(v + io.rms_epsilon);
+  }
   if (tid == 0) sCount[0] = io.rms[2 * S];
-  const int64_t t_noise0 = *io.sampler_step;
+  // the (up to two) observation components this thread steps: environment, component, LDS slots, hashing constants
+  int pe[2], pj[2];
+  bool pok[2];
+  uint64_t pseed[2];
+  int64_t pc0[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = tid + 512 * k;
+    pok[k] = i < N * S;
+    pe[k] = pok[k] ? i / S : 0;
+    pj[k] = pok[k] ? i - pe[k] * S : 0;
+    pseed[k] = (uint64_t)io.env_seed[pe[k]];
+    pc0[k] = io.env_counter[pe[k]];
+  }
+  __threadfence();
   __syncthreads();
 
+  if (PROF && tid == 0) prof_last = clock64();
   for (int t = 0; t <= T; ++t) {
-    if (t < T)
-      for (int i = tid; i < N * S; i += 512) {
-        const int e = i / S, j = i - e * S;
-        io.out_state[(int64_t)t * N * S + i] = sX[e * LDX + j];
-      }
-    // F1
-    if (own) {
-      f32x4 acc[4];
+    // what this step will need from global memory, requested now: the terminal flags of the environment step and the noise
+    float mask_e[2] = {1.f, 1.f};
+    float eps4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < 2; ++k)
+        if (pok[k]) mask_e[k] = io.out_mask[t * N + pe[k]];
+      if (head && c16 < A)
 #pragma unroll
-      for (int tk = 0; tk < 4; ++tk)
-        if (tk < KT1) {
-          f32x4 av[4];
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-            if (mt < MT) av[mt] = *reinterpret_cast<const f32x4*>(&sX[(16 * mt + c16) * LDX + 16 * tk + 4 * g]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-              if (mt < MT) acc[mt] = MFMA16(av[mt][r], w1[tk][r], acc[mt]);
+        for (int r = 0; r < 4; ++r) {
+          const int e = 16 * wv + 4 * g + r;
+          if (e < N) eps4[r] = io.out_action[(t * N + e) * A + c16];
         }
 #pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (pok[k]) io.out_state[t * N * S + tid + 512 * k] = sX[pe[k] * LDX + pj[k]];
+      for (int i = tid + 1024; i < N * S; i += 512) io.out_state[t * N * S + i] = sX[(i / S) * LDX + i % S];
+    }
+    // F1
+    if (own && t < T) {
+      f32x4 av[4][4];
+#pragma unroll
       for (int mt = 0; mt < 4; ++mt)
         if (mt < MT)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sH1[(16 * mt + 4 * g + r) * LD + ncol] = fast_tanh(acc[mt][r] + b1);
+          for (int tk = 0; tk < 4; ++tk)
+            if (tk < KT1) av[mt][tk] = *reinterpret_cast<const f32x4*>(&sX[(16 * mt + c16) * LDX + 16 * tk + 4 * g]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        if (mt < MT) {
+          f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tk = 0; tk < 4; ++tk)
+            if (tk < KT1) {
+              a0 = MFMA16(av[mt][tk][0], w1[tk][0], a0);
+              a1 = MFMA16(av[mt][tk][1], w1[tk][1], a1);
+              a0 = MFMA16(av[mt][tk][2], w1[tk][2], a0);
+              a1 = MFMA16(av[mt][tk][3], w1[tk][3], a1);
+            }
+          a0 += a1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sH1[(16 * mt + 4 * g + r) * LD + ncol] = fast_tanh(a0[r] + b1);
+        }
     }
+    stamp(0);
+    if (t == T) break;       // (the bootstrap observation's value comes from the value kernel; the sampler still counts it)
     __syncthreads();
     if (own) {
-      f32x4 acc[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int tk = 0; tk < NT; ++tk) {
-        f32x4 av[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          if (mt < MT) av[mt] = *reinterpret_cast<const f32x4*>(&sH1[(16 * mt + c16) * LD + 16 * tk + 4 * g]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
-            if (mt < MT) acc[mt] = MFMA16(av[mt][r], w2[tk][r], acc[mt]);
-      }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
-        if (mt < MT)
+        if (mt < MT) {
+          f32x4 av[NT];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sH2[(16 * mt + 4 * g + r) * LD + ncol] = fast_tanh(acc[mt][r] + b2);
+          for (int tk = 0; tk < NT; ++tk) av[tk] = *reinterpret_cast<const f32x4*>(&sH1[(16 * mt + c16) * LD + 16 * tk + 4 * g]);
+          f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tk = 0; tk < NT; ++tk) {
+            a0 = MFMA16(av[tk][0], w2[tk][0], a0);
+            a1 = MFMA16(av[tk][1], w2[tk][1], a1);
+            a0 = MFMA16(av[tk][2], w2[tk][2], a0);
+            a1 = MFMA16(av[tk][3], w2[tk][3], a1);
+          }
+          a0 += a1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sH2[(16 * mt + 4 * g + r) * LD + ncol] = fast_tanh(a0[r] + b2);
+        }
     }
+    stamp(1);
     __syncthreads();
-    // head: wave mt of each role takes environments [16 mt, 16 mt + 16)
-    if (w < MT) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // head: wave mt takes environments [16 mt, 16 mt + 16)
+    if (head) {
+      f32x4 av[NT], bv[NT];
 #pragma unroll
       for (int tk = 0; tk < NT; ++tk) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(&sH2[(16 * w + c16) * LD + 16 * tk + 4 * g]);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(&sW3[c16 * LD + 16 * tk + 4 * g]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = MFMA16(av[r], bv[r], acc);
+        av[tk] = *reinterpret_cast<const f32x4*>(&sH2[(16 * wv + c16) * LD + 16 * tk + 4 * g]);
+        bv[tk] = *reinterpret_cast<const f32x4*>(&sW3[c16 * LD + 16 * tk + 4 * g]);
       }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk) {
+        acc = MFMA16(av[tk][0], bv[tk][0], acc);
+        acc_b = MFMA16(av[tk][1], bv[tk][1], acc_b);
+        acc = MFMA16(av[tk][2], bv[tk][2], acc);
+        acc_b = MFMA16(av[tk][3], bv[tk][3], acc_b);
+      }
+      acc += acc_b;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int e = 16 * w + 4 * g + r;
-        if (role == 0) {
-          if (t < T) {
-            const float mean = fast_tanh(acc[r] + b3);
-            float lpe = 0.f;
-            if (c16 < A && e < N) {
-              // network_heads.py:205-208: action = mean + scale * noise;  log_prob sums the per-dimension Normal log densities
-              const float act = gauss_noise(io.noise_seed, t_noise0 + t, io.n_global, io.env0 + e, c16) * sd + mean;
-              const float diff = act - mean;
-              lpe = -(diff * diff) / (2.f * (sd * sd)) - log_sd - kLogSqrt2Pi;
-              io.out_action[((int64_t)t * N + e) * AD + c16] = act;
-              sAct[e * kLd3 + c16] = act;
-            }
-            const float lp = group16_sum(lpe);
-            if (c16 == 0 && e < N) io.out_log_pi_a[(int64_t)t * N + e] = lp;
-          }
-        } else if (c16 == 0 && e < N) {
-          io.out_v[(int64_t)t * N + e] = acc[r] + b3;
+        const int e = 16 * wv + 4 * g + r;
+        const float mean = fast_tanh(acc[r] + b3);
+        float lpe = 0.f;
+        if (c16 < A && e < N) {
+          // network_heads.py:205-208: action = mean + scale * noise;  log_prob sums the per-dimension Normal log densities
+          const float act = eps4[r] * sd + mean;
+          const float diff = act - mean;
+          lpe = -(diff * diff) * inv_2var - log_sd - kLogSqrt2Pi;
+          io.out_action[(t * N + e) * A + c16] = act;
+          sAct[e * kLd3 + c16] = act;
         }
+        const float lp = group16_sum(lpe);
+        if (c16 == 0 && e < N) io.out_log_pi_a[t * N + e] = lp;
       }
     }
-    if (t == T) break;
+    stamp(2);
     __syncthreads();
-    // environment step: per environment scalars first ...
-    for (int e = tid; e < N; e += 512) {
-      const int64_t c = sCtr[e] + 1;
-      const uint64_t sdv = (uint64_t)io.env_seed[e];
-      sCtr[e] = c;
-      sMeanA[e] = cenv_mean_action(sAct + e * kLd3, AD);
-      const bool done = cenv_done(sdv, c, io.horizon);
-      sDone[e] = done ? 1 : 0;
-      io.out_reward[(int64_t)t * N + e] = (float)(cenv_reward(sdv, c) * io.reward_coef);
-      io.out_mask[(int64_t)t * N + e] = done ? 0.f : 1.f;
-    }
-    __syncthreads();
-    // ... then every observation component
-    for (int i = tid; i < N * S; i += 512) {
+    // environment step, one thread per observation component (the mean action of its environment recomputed by each)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (pok[k])
+        sState[pe[k] * kMaxS + pj[k]] = cenv_next_state(pseed[k], pc0[k] + t + 1, pj[k], sState[pe[k] * kMaxS + pj[k]],
+                                                        cenv_mean_action(sAct + pe[k] * kLd3, A), mask_e[k] == 0.f);
+    for (int i = tid + 1024; i < N * S; i += 512) {     // (more than 1024 components: 64 environments x > 16 observations)
       const int e = i / S, j = i - e * S;
-      sState[e * kMaxS + j] = cenv_next_state((uint64_t)io.env_seed[e], sCtr[e], j, sState[e * kMaxS + j], sMeanA[e], sDone[e] != 0);
+      sState[e * kMaxS + j] = cenv_next_state((uint64_t)io.env_seed[e], io.env_counter[e] + t + 1, j, sState[e * kMaxS + j],
+                                              cenv_mean_action(sAct + e * kLd3, A), io.out_mask[t * N + e] == 0.f);
     }
+    stamp(3);
     __syncthreads();
-    // running statistics (one thread per feature), then the normalised observation of step t + 1
-    if (io.rms_update) {
-      for (int j = tid; j < S; j += 512) {
-        double m = sMean[j], v = sVar[j];
-        rms_fold(sState + j, kMaxS, N, m, v, sCount[0]);
-        sMean[j] = m;
-        sVar[j] = v;
+    // running statistics: one lane per feature (the rows in order), and the divisor of the normalisation
+    if (io.rms_update && tid < S) {
+      double m = sMean[tid], v = sVar[tid];
+      rms_fold_lds(sState + tid, kMaxS, N, m, v, sCount[0]);
+      sMean[tid] = m;
+      sVar[tid] = v;
+      sDen[tid] = sqrt(v + io.rms_epsilon);
+    }
+    stamp(4);
+    __syncthreads();
+    if (io.rms_update && tid == 0) sCount[0] = sCount[0] + (double)N;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (pok[k]) {
+        double z = (sState[pe[k] * kMaxS + pj[k]] - sMean[pj[k]]) / sDen[pj[k]];
+        z = z < -io.rms_clip ? -io.rms_clip : (z > io.rms_clip ? io.rms_clip : z);
+        sX[pe[k] * LDX + pj[k]] = (float)z;
       }
-      __syncthreads();
-      if (tid == 0) sCount[0] = sCount[0] + (double)N;
-    }
-    __syncthreads();
-    for (int i = tid; i < N * S; i += 512) {
+    for (int i = tid + 1024; i < N * S; i += 512) {
       const int e = i / S, j = i - e * S;
-      sX[e * LDX + j] = rms_apply(sState[e * kMaxS + j], sMean[j], sVar[j], io.rms_epsilon, io.rms_clip);
+      double z = (sState[e * kMaxS + j] - sMean[j]) / sDen[j];
+      z = z < -io.rms_clip ? -io.rms_clip : (z > io.rms_clip ? io.rms_clip : z);
+      sX[e * LDX + j] = (float)z;
     }
+    stamp(5);
     __syncthreads();
+    stamp(6);
   }
+  if (PROF && tid == 0 && cycles)
+    for (int i = 0; i < 8; ++i) cycles[i] = prof[i];
   __syncthreads();
   for (int i = tid; i < N * S; i += 512) {
     const int e = i / S, j = i - e * S;
@@ -1059,10 +1170,107 @@ ppo_mlp_rollout_kernel(dra_ppo_mlp_cfg cfg, dra_ppo_mlp_net actor, dra_ppo_mlp_n
     io.cur_state[i] = sX[e * LDX + j];
   }
   for (int i = tid; i < S; i += 512) { io.rms[i] = sMean[i]; io.rms[S + i] = sVar[i]; }
-  for (int i = tid; i < N; i += 512) io.env_counter[i] = sCtr[i];
+  __syncthreads();        // (every thread has read the counters the steps were derived from)
+  for (int i = tid; i < N; i += 512) io.env_counter[i] = io.env_counter[i] + T;
   if (tid == 0) {
     io.rms[2 * S] = sCount[0];
     *io.sampler_step = t_noise0 + T + 1;
+  }
+}
+
+// v = critic(observation) for all (t_len + 1) x n_env observations of a rollout at once (PPO_agent.py:35,47: the value of every
+// stored observation and of the bootstrap observation): rows [0, rows_a) come from out_state, the rest from cur_state.  One
+// workgroup per 64 rows, the update kernel's forward.
+template <int H>
+__global__ void __launch_bounds__(256)
+ppo_mlp_value_kernel(dra_ppo_mlp_cfg cfg, dra_ppo_mlp_net net, const float* __restrict__ rows_a_ptr, int rows_a,
+                     const float* __restrict__ rows_b_ptr, int rows_b, float* __restrict__ out_v) {
+  __shared__ __attribute__((aligned(16))) float sX[kRows * kLdX];
+  __shared__ __attribute__((aligned(16))) float sHa[kRows * (H + 4)];
+  __shared__ __attribute__((aligned(16))) float sHb[kRows * (H + 4)];
+  constexpr int NT = H / 16, LD = H + 4;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, c16 = l & 15, g = l >> 4;
+  const int S = cfg.state_dim, KT1 = (S + 15) >> 4, LDX = 16 * KT1 + 4;
+  const int row0 = blockIdx.x * kRows, total = rows_a + rows_b;
+  const bool own = w < NT;
+  const int ncol = 16 * w + c16;
+  for (int i = tid; i < kRows * LDX; i += 256) {
+    const int r = i / LDX, c = i - r * LDX, row = row0 + r;
+    float v = 0.f;
+    if (c < S && row < total) v = row < rows_a ? rows_a_ptr[(int64_t)row * S + c] : rows_b_ptr[(int64_t)(row - rows_a) * S + c];
+    sX[i] = v;
+  }
+  float w1[4][4], w2[NT][4], w3[NT][4];
+#pragma unroll
+  for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * tk + 4 * g + r;
+      w1[tk][r] = (own && k < S) ? net.param[net.off_w1 + ncol * S + k] : 0.f;
+    }
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      w2[tk][r] = own ? net.param[net.off_w2 + ncol * H + 16 * tk + 4 * g + r] : 0.f;
+      w3[tk][r] = c16 == 0 ? net.param[net.off_w3 + 16 * tk + 4 * g + r] : 0.f;     // head output 0 of 16
+    }
+  const float b1 = own ? net.param[net.off_b1 + ncol] : 0.f, b2 = own ? net.param[net.off_b2 + ncol] : 0.f;
+  const float b3 = net.param[net.off_b3];
+  __syncthreads();
+  if (own) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk)
+        if (tk < KT1) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(&sX[(16 * mt + c16) * LDX + 16 * tk + 4 * g]);
+          a0 = MFMA16(av[0], w1[tk][0], a0);
+          a1 = MFMA16(av[1], w1[tk][1], a1);
+          a0 = MFMA16(av[2], w1[tk][2], a0);
+          a1 = MFMA16(av[3], w1[tk][3], a1);
+        }
+      a0 += a1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sHa[(16 * mt + 4 * g + r) * LD + ncol] = fast_tanh(a0[r] + b1);
+    }
+  }
+  __syncthreads();
+  if (own) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tk = 0; tk < NT; ++tk) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(&sHa[(16 * mt + c16) * LD + 16 * tk + 4 * g]);
+        a0 = MFMA16(av[0], w2[tk][0], a0);
+        a1 = MFMA16(av[1], w2[tk][1], a1);
+        a0 = MFMA16(av[2], w2[tk][2], a0);
+        a1 = MFMA16(av[3], w2[tk][3], a1);
+      }
+      a0 += a1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sHb[(16 * mt + 4 * g + r) * LD + ncol] = fast_tanh(a0[r] + b2);
+    }
+  }
+  __syncthreads();
+  {
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&sHb[(16 * w + c16) * LD + 16 * tk + 4 * g]);
+      a0 = MFMA16(av[0], w3[tk][0], a0);
+      a1 = MFMA16(av[1], w3[tk][1], a1);
+      a0 = MFMA16(av[2], w3[tk][2], a0);
+      a1 = MFMA16(av[3], w3[tk][3], a1);
+    }
+    a0 += a1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 16 * w + 4 * g + r;
+      if (c16 == 0 && row < total) out_v[row] = a0[r] + b3;
+    }
   }
 }
 
@@ -1105,17 +1313,17 @@ DRA_API int dra_ppo_mlp_pack(const float* state, const float* action, const floa
   return DRA_OK;
 }
 
-template <int H, int MODE, int KTC>
+template <int H, int MODE, int SC>
 static int launch_update(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic, const float* packed,
                          int n, int epochs, float* out3, int64_t* out_counts, float* dbg, void* stream) {
   const size_t bytes = update_lds_floats(H, cfg->state_dim) * sizeof(float);
   static size_t attr_bytes = 0;
   if (bytes > attr_bytes) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_update_kernel<H, MODE, KTC>),
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_update_kernel<H, MODE, SC>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     attr_bytes = bytes;
   }
-  hipLaunchKernelGGL((ppo_mlp_update_kernel<H, MODE, KTC>), dim3(2), dim3(256), bytes, dra_stream(stream), *cfg, *actor, *critic, packed,
+  hipLaunchKernelGGL((ppo_mlp_update_kernel<H, MODE, SC>), dim3(2), dim3(256), bytes, dra_stream(stream), *cfg, *actor, *critic, packed,
                      n, epochs, out3, out_counts, dbg);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
@@ -1127,13 +1335,13 @@ DRA_API int dra_ppo_mlp_update(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net
   if (dra_ppo_mlp_supported(cfg->state_dim, cfg->action_dim, cfg->hidden, cfg->hidden, cfg->mini_batch)) return DRA_EINVAL;
   if (check_net(actor, true) || check_net(critic, false)) return DRA_EINVAL;
   // the dump build is a separate instantiation (its stores would otherwise cost the product kernel registers); hidden = 64 with
-  // 17..32 observations (the HalfCheetah / Walker / Hopper family of examples.py:497-523) has ceil(state_dim / 16) = 2 compiled in
-#define DRA_PPO_UPD(HH, KK) (dbg ? launch_update<HH, 1, 0>(cfg, actor, critic, packed, n, epochs, out3, out_counts, dbg, stream) \
-                                 : launch_update<HH, 0, KK>(cfg, actor, critic, packed, n, epochs, out3, out_counts, dbg, stream))
+  // 17 observations (HalfCheetah / Walker2d: examples.py:497-523) or 11 (Hopper / Reacher) has the observation size compiled in
+#define DRA_PPO_UPD(HH, SS) (dbg ? launch_update<HH, 1, 0>(cfg, actor, critic, packed, n, epochs, out3, out_counts, dbg, stream) \
+                                 : launch_update<HH, 0, SS>(cfg, actor, critic, packed, n, epochs, out3, out_counts, dbg, stream))
   switch (cfg->hidden) {
     case 16: return DRA_PPO_UPD(16, 0);
     case 32: return DRA_PPO_UPD(32, 0);
-    default: return (cfg->state_dim > 16 && cfg->state_dim <= 32) ? DRA_PPO_UPD(64, 2) : DRA_PPO_UPD(64, 0);
+    default: return cfg->state_dim == 17 ? DRA_PPO_UPD(64, 17) : (cfg->state_dim == 11 ? DRA_PPO_UPD(64, 11) : DRA_PPO_UPD(64, 0));
   }
 #undef DRA_PPO_UPD
 }
@@ -1146,40 +1354,60 @@ DRA_API int dra_ppo_mlp_update_profile(const dra_ppo_mlp_cfg* cfg, const dra_ppo
   if (!cfg || !packed || !out3 || !cycles || n < 1 || epochs < 1 || cfg->hidden != 64) return DRA_EINVAL;
   if (dra_ppo_mlp_supported(cfg->state_dim, cfg->action_dim, cfg->hidden, cfg->hidden, cfg->mini_batch)) return DRA_EINVAL;
   if (check_net(actor, true) || check_net(critic, false)) return DRA_EINVAL;
-  if (cfg->state_dim > 16 && cfg->state_dim <= 32)
-    return launch_update<64, 2, 2>(cfg, actor, critic, packed, n, epochs, out3, out_counts, reinterpret_cast<float*>(cycles), stream);
+  if (cfg->state_dim == 17)
+    return launch_update<64, 2, 17>(cfg, actor, critic, packed, n, epochs, out3, out_counts, reinterpret_cast<float*>(cycles), stream);
   return launch_update<64, 2, 0>(cfg, actor, critic, packed, n, epochs, out3, out_counts, reinterpret_cast<float*>(cycles), stream);
 }
 
-template <int H>
+template <int H, bool PROF>
 static int launch_rollout(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
-                          const dra_ppo_mlp_rollout_io* io, void* stream) {
+                          const dra_ppo_mlp_rollout_io* io, int64_t* cycles, void* stream) {
   const size_t bytes = rollout_lds_floats(H) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_rollout_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)bytes));
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_rollout_kernel<H, PROF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     attr_set = true;
   }
-  hipLaunchKernelGGL(ppo_mlp_rollout_kernel<H>, dim3(1), dim3(512), bytes, dra_stream(stream), *cfg, *actor, *critic, *io);
+  hipLaunchKernelGGL((ppo_mlp_rollout_kernel<H, PROF>), dim3(1), dim3(512), bytes, dra_stream(stream), *cfg, *actor, *io,
+                     reinterpret_cast<long long*>(cycles));
   DRA_LAUNCH_CHECK();
+  // the values of the t_len x n_env stored observations and of the bootstrap observation (the one the rollout left in cur_state)
+  const int rows_a = io->t_len * io->n_env, rows_b = io->n_env;
+  hipLaunchKernelGGL(ppo_mlp_value_kernel<H>, dim3((unsigned)((rows_a + rows_b + kRows - 1) / kRows)), dim3(256), 0, dra_stream(stream),
+                     *cfg, *critic, (const float*)io->out_state, rows_a, (const float*)io->cur_state, rows_b, io->out_v);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+static int rollout_checked(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
+                           const dra_ppo_mlp_rollout_io* io) {
+  if (!cfg || !io) return DRA_EINVAL;
+  if (dra_ppo_mlp_supported(cfg->state_dim, cfg->action_dim, cfg->hidden, cfg->hidden, 1)) return DRA_EINVAL;
+  if (check_net(actor, true) || check_net(critic, false)) return DRA_EINVAL;
+  if (io->n_env < 1 || io->n_env > kRows || io->t_len < 1 || io->horizon < 1 || io->n_global < io->n_env || io->env0 < 0) return DRA_EINVAL;
+  if ((int64_t)(io->t_len + 1) * io->n_env * (cfg->state_dim > cfg->action_dim ? cfg->state_dim : cfg->action_dim) > 0x7fffffff) return DRA_EINVAL;
+  if (!io->env_state || !io->env_counter || !io->env_seed || !io->rms || !io->cur_state || !io->sampler_step || !io->out_state ||
+      !io->out_action || !io->out_log_pi_a || !io->out_v || !io->out_reward || !io->out_mask)
+    return DRA_EINVAL;
   return DRA_OK;
 }
 
 DRA_API int dra_ppo_mlp_rollout(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
                                 const dra_ppo_mlp_rollout_io* io, void* stream) {
-  if (!cfg || !io) return DRA_EINVAL;
-  if (dra_ppo_mlp_supported(cfg->state_dim, cfg->action_dim, cfg->hidden, cfg->hidden, 1)) return DRA_EINVAL;
-  if (check_net(actor, true) || check_net(critic, false)) return DRA_EINVAL;
-  if (io->n_env < 1 || io->n_env > kRows || io->t_len < 1 || io->horizon < 1 || io->n_global < io->n_env || io->env0 < 0) return DRA_EINVAL;
-  if (!io->env_state || !io->env_counter || !io->env_seed || !io->rms || !io->cur_state || !io->sampler_step || !io->out_state ||
-      !io->out_action || !io->out_log_pi_a || !io->out_v || !io->out_reward || !io->out_mask)
-    return DRA_EINVAL;
+  if (rollout_checked(cfg, actor, critic, io)) return DRA_EINVAL;
   switch (cfg->hidden) {
-    case 16: return launch_rollout<16>(cfg, actor, critic, io, stream);
-    case 32: return launch_rollout<32>(cfg, actor, critic, io, stream);
-    default: return launch_rollout<64>(cfg, actor, critic, io, stream);
+    case 16: return launch_rollout<16, false>(cfg, actor, critic, io, nullptr, stream);
+    case 32: return launch_rollout<32, false>(cfg, actor, critic, io, nullptr, stream);
+    default: return launch_rollout<64, false>(cfg, actor, critic, io, nullptr, stream);
   }
+}
+
+// measurement aid: the same launch (hidden = 64) with thread 0's shader-clock cycles per phase of the step loop in cycles [8]
+DRA_API int dra_ppo_mlp_rollout_profile(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
+                                        const dra_ppo_mlp_rollout_io* io, int64_t* cycles, void* stream) {
+  if (rollout_checked(cfg, actor, critic, io) || !cycles || cfg->hidden != 64) return DRA_EINVAL;
+  return launch_rollout<64, true>(cfg, actor, critic, io, cycles, stream);
 }
 
 DRA_API int dra_rms_normalize(const double* x, int n, int d, double* mean, double* var, double* count, int update, double epsilon,

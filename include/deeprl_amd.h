@@ -591,6 +591,10 @@ typedef struct dra_ppo_mlp_rollout_io {
 } dra_ppo_mlp_rollout_io;
 int dra_ppo_mlp_rollout(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
                         const dra_ppo_mlp_rollout_io* io, void* stream);
+/* measurement aid: the same launch (hidden = 64) with thread 0's shader-clock cycles per phase of the step loop (cycles: device
+ * i64 [8]: F1, F2, heads, environment, statistics, normalisation, trailing barrier) */
+int dra_ppo_mlp_rollout_profile(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
+                                const dra_ppo_mlp_rollout_io* io, int64_t* cycles, void* stream);
 
 #ifdef __cplusplus
 }

@@ -73,7 +73,54 @@ def main():
         res[role + "_cycles_per_minibatch"] = {"%02d %s" % (i, p): round(float(v), 1) for i, (p, v) in enumerate(zip(PHASES, row))}
         res[role + "_cycles_total"] = round(float(row.sum()), 1)
     res["clock_MHz_implied"] = round(c[0].sum() / res["profile_us_per_minibatch"], 1)
+    res["rollout"] = rollout_profile(d, T, O, fa, pa, fc, pc, cfg, steps)
     print(json.dumps(res, indent=1))
+
+
+ROLLOUT_PHASES = ["F1 (+ step-top loads / stores)", "barrier + F2", "barrier + heads", "barrier + environment",
+                  "barrier + statistics", "barrier + normalisation", "barrier"]
+
+
+def rollout_profile(d, T, O, fa, pa, fc, pc, cfg, steps, n=16, t_len=2048):
+    """cycles per phase of the rollout kernel's step loop at BASELINE configs[2] shapes (16 environments, 2048 steps)"""
+    dev = d.Config.DEVICE
+    s_dim, a_dim = cfg.state_dim, cfg.action_dim
+    na, nc = T._net_struct(fa, pa, steps[0:1], True), T._net_struct(fc, pc, steps[1:2], False)
+    f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    o = dict(state=f(t_len, n, s_dim), action=f(t_len, n, a_dim), log_pi_a=f(t_len, n), v=f(t_len + 1, n), reward=f(t_len, n),
+             mask=f(t_len, n))
+    env_state = torch.zeros(n, s_dim, dtype=torch.float64, device=dev)
+    env_counter = torch.zeros(n, dtype=torch.int64, device=dev)
+    env_seed = torch.arange(n, dtype=torch.int64, device=dev)
+    rms = torch.cat([torch.zeros(s_dim), torch.ones(s_dim), torch.tensor([1e-4])]).double().to(dev)
+    cur_state = torch.zeros(n, s_dim, dtype=torch.float32, device=dev)
+    sampler = torch.zeros(1, dtype=torch.int64, device=dev)
+    cycles = torch.zeros(8, dtype=torch.int64, device=dev)
+    io = ppo_mlp.RolloutIO()
+    io.env_state, io.env_counter, io.env_seed, io.rms = env_state.data_ptr(), env_counter.data_ptr(), env_seed.data_ptr(), rms.data_ptr()
+    io.cur_state, io.sampler_step = cur_state.data_ptr(), sampler.data_ptr()
+    io.out_state, io.out_action, io.out_log_pi_a = o['state'].data_ptr(), o['action'].data_ptr(), o['log_pi_a'].data_ptr()
+    io.out_v, io.out_reward, io.out_mask = o['v'].data_ptr(), o['reward'].data_ptr(), o['mask'].data_ptr()
+    io.env0, io.n_global, io.noise_seed, io.horizon = 0, n, 1, 1000
+    io.reward_coef, io.rms_epsilon, io.rms_clip, io.rms_update, io.t_len, io.n_env = 1.0, 1e-8, 10.0, 1, t_len, n
+    out = {}
+    for name, call in (("product", lambda: lib.dra_ppo_mlp_rollout(ctypes.byref(cfg), ctypes.byref(na), ctypes.byref(nc),
+                                                                   ctypes.byref(io), stream_ptr())),
+                       ("profile", lambda: lib.dra_ppo_mlp_rollout_profile(ctypes.byref(cfg), ctypes.byref(na), ctypes.byref(nc),
+                                                                           ctypes.byref(io), ptr(cycles), stream_ptr()))):
+        call()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        call()
+        ev1.record()
+        torch.cuda.synchronize()
+        out[name + "_ms"] = ev0.elapsed_time(ev1)
+        out[name + "_us_per_step"] = out[name + "_ms"] * 1e3 / t_len
+    c = cycles.cpu().numpy().astype(np.float64) / t_len
+    out["cycles_per_step"] = {"%d %s" % (i, p): round(float(v), 1) for i, (p, v) in enumerate(zip(ROLLOUT_PHASES, c))}
+    out["cycles_per_step_total"] = round(float(c[:7].sum()), 1)
+    return out
 
 
 if __name__ == "__main__":
