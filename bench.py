@@ -62,9 +62,10 @@ def parse():
     ap.add_argument("--cpu-replica-worker", type=float, default=0.0,
                     help="internal: run the single-thread CPU oracle loop for this many seconds and print its count")
     ap.add_argument("--master-port", type=int, default=29517, help="rendezvous port when bench.py launches the ranks itself")
-    ap.add_argument("--workload", default="dqn_pixel", choices=["dqn_pixel", "a2c_pixel", "ppo_pixel"],
+    ap.add_argument("--workload", default="dqn_pixel", choices=["dqn_pixel", "a2c_pixel", "ppo_pixel", "ppo_continuous"],
                     help="dqn_pixel = BASELINE configs[1] (the headline); a2c_pixel / ppo_pixel = configs[4]: the on-policy agents, "
-                         "environments sharded over the ranks, one gradient all-reduce per optimizer step (SURVEY.md 8e)")
+                         "environments sharded over the ranks, one gradient all-reduce per optimizer step (SURVEY.md 8e); "
+                         "ppo_continuous = configs[2]: PPO on HalfCheetah shapes, 16 workers per GPU (replicas over the ranks)")
     return ap.parse_args()
 
 
@@ -250,6 +251,68 @@ def agent_api(seconds=2.0):
     return out
 
 
+def _continuous_agent(d, zoo, workers, **over):
+    """examples.py::ppo_continuous (497-523) on HalfCheetah shapes with `workers` vectorised environments (BASELINE configs[2]
+    names 16; the reference's literal task_fn builds one)."""
+    over.setdefault("save_interval", 0)
+    c = zoo.config("ppo_continuous", game="synthetic-continuous-HalfCheetah", overrides=dict(num_workers=workers, **over))
+    c.task_fn = lambda: d.Task(c.game, num_envs=c.num_workers, seed=1)
+    return d.PPOAgent(c)
+
+
+def other_config_lines(seconds=3.0):
+    """BASELINE configs[2..4] through the drop-in surface (zoo = the reference's examples.py entries, stepped as run_steps does),
+    a few seconds each, so that the driver's own record carries them: DQN + PrioritizedReplay is in agent_api above; here
+    C51, C51 + PER, QR-DQN (configs[3]), A2C / PPO on pixels (configs[4], one GPU's share of the environments) and PPO on
+    HalfCheetah shapes with 16 workers (configs[2]).  Never `value`."""
+    import deeprl_amd as d
+    import deeprl_amd.agents as agents_mod
+    from deeprl_amd import zoo
+
+    class _Quiet:
+        def info(self, *a, **k):
+            pass
+        add_scalar = add_histogram = info
+
+    agents_mod.get_logger = lambda *a, **k: _Quiet()
+    dqn = dict(exploration_steps=200, save_interval=0)
+    cases = [
+        ("categorical_dqn_pixel", lambda: zoo.agent("categorical_dqn_pixel", game="synthetic-atari", overrides=dict(dqn)), 300, 4, 1),
+        ("categorical_dqn_pixel_prioritized_replay",
+         lambda: zoo.agent("categorical_dqn_pixel", game="synthetic-atari", replay_cls=d.PrioritizedReplay, overrides=dict(dqn)), 300, 4, 1),
+        ("quantile_regression_dqn_pixel",
+         lambda: zoo.agent("quantile_regression_dqn_pixel", game="synthetic-atari", overrides=dict(dqn)), 300, 4, 1),
+        ("a2c_pixel_16", lambda: zoo.agent("a2c_pixel", game="synthetic-atari", overrides=dict(num_workers=16, save_interval=0)), 6, 80, 1),
+        ("ppo_pixel_8", lambda: zoo.agent("ppo_pixel", game="synthetic-atari", overrides=dict(num_workers=8, save_interval=0)), 4, 1024, 16),
+        ("ppo_continuous_16", lambda: _continuous_agent(d, zoo, 16), 3, 2048 * 16, 5120),
+    ]
+    out = {}
+    for name, build, warm, env_per_step, upd_per_step in cases:
+        try:
+            d.random_seed(1)
+            agent = build()
+            for _ in range(warm):
+                agent.step()
+            torch.cuda.synchronize()
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds or n < 2:
+                agent.step()
+                n += 1
+            learner = getattr(agent, "_learner", None)
+            if learner is not None:
+                learner.synchronize()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[name] = {"env_steps_per_s": n * env_per_step / dt, "updates_per_s": n * upd_per_step / dt, "agent_steps": n,
+                         "seconds": dt}
+            agent.close()
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+    out["note"] = ("Agent.step() of the zoo entries (= examples.py functions) on synthetic environments; updates_per_s counts "
+                   "optimizer steps (PPO: minibatch updates; ppo_continuous: the critic's 5120 per rollout)")
+    return out
+
+
 def parity_check(bench, n_steps=6, gate_margin=5e-7):
     """n_steps more agent steps of the configuration that was just timed (same learner, same pipeline, same graphs), replayed
     through the CPU oracle and CHAINED: the oracle starts from the learner's parameters / RMSprop state before the first of
@@ -257,9 +320,10 @@ def parity_check(bench, n_steps=6, gate_margin=5e-7):
     the learner's gather produced.  Bar per step: loss 1e-5 relative, every parameter within atol 2e-6 + rtol 1e-5 (weights
     are O(0.05)) of the oracle's.  A step in which some ReLU input of the differentiated forward lies within fp32 summation
     noise of zero (|pre-activation| < gate_margin: two correct fp32 implementations may gate it differently, which changes
-    that unit's whole backward contribution; about one batch-32 update in three with zero-initialised biases) is reported
-    but not judged, and the oracle re-adopts the learner's state after it, which starts a new chain.  Reports the worst
-    errors over the judged steps, the longest chain, and every step."""
+    that unit's whole backward contribution) is still JUDGED when it is within tolerance (it almost always is); only a step
+    that is outside the tolerance AND has such an input is excused -- reported, not judged -- and the oracle re-adopts the
+    learner's state after it, which starts a new chain.  Reports the worst errors over the judged steps, the longest chain,
+    and every step."""
     from oracle import loss_oracle as L, net_oracle as N, numerics_oracle as NUM
     lr = bench.learner
     torch.set_num_threads(min(8, os.cpu_count() or 1))
@@ -301,10 +365,20 @@ def parity_check(bench, n_steps=6, gate_margin=5e-7):
         rel_loss = abs(gpu_loss - loss_f) / max(abs(loss_f), 1e-12)
         ok = ok and rel_loss <= 1e-5
         ambiguous = bool(margin < gate_margin)
+        # every step within tolerance is JUDGED (and counts); a step outside it is excused -- reported, not counted -- only when
+        # some ReLU input of the differentiated forward lay within fp32 summation noise of zero, i.e. when a gate flip between
+        # two correct fp32 implementations explains it; anything else is a failure
+        excused = (not ok) and ambiguous
         steps.append({"rel_loss_err": rel_loss, "max_abs_param_err": step_abs, "min_relu_input_abs": margin,
-                      "gate_ambiguous": ambiguous, "within_tolerance": bool(ok), "chained_from_step": it - chain})
-        if ambiguous or not ok:
-            if not ambiguous:
+                      "gate_ambiguous": ambiguous, "within_tolerance": bool(ok), "excused": bool(excused),
+                      "chained_from_step": it - chain})
+        if ok:
+            judged += 1
+            chain += 1
+            best_chain = max(best_chain, chain)
+            worst_loss, worst_param = max(worst_loss, rel_loss), max(worst_param, step_abs)
+        else:
+            if not excused:
                 all_ok = False
                 judged += 1
                 worst_loss, worst_param = max(worst_loss, rel_loss), max(worst_param, step_abs)
@@ -312,16 +386,12 @@ def parity_check(bench, n_steps=6, gate_margin=5e-7):
             p = {k: v.clone() for k, v in now["params"].items()}
             sq = {k: v.clone() for k, v in now["square_avg"].items()}
             ga = {k: v.clone() for k, v in now["grad_avg"].items()}
-        else:
-            judged += 1
-            chain += 1
-            best_chain = max(best_chain, chain)
-            worst_loss, worst_param = max(worst_loss, rel_loss), max(worst_param, step_abs)
     lr.keep_minibatch(False)
     return {"ok": bool(all_ok and judged > 0), "steps_checked": n_steps, "steps_judged": judged, "longest_chain": best_chain,
             "worst_rel_loss_err": worst_loss, "worst_abs_param_err": worst_param, "steps": steps,
-            "tolerance": "per step: loss 1e-5 rel; params atol 2e-6 + rtol 1e-5 against the oracle's CHAINED state; steps with a "
-                         "ReLU input within %g of zero are reported, not judged, and restart the chain" % gate_margin,
+            "tolerance": "per step: loss 1e-5 rel; params atol 2e-6 + rtol 1e-5 against the oracle's CHAINED state; every step "
+                         "within tolerance is judged; a step OUTSIDE it is excused (reported, not judged, chain restarted) only if a "
+                         "ReLU input lay within %g of zero" % gate_margin,
             "what": "%d more agent steps of the timed configuration (same learner, pipeline and graphs) replayed through the CPU "
                     "oracle on the minibatches its gather produced; outside the timed region" % n_steps}
 
@@ -401,6 +471,8 @@ def on_policy_main(args):
         add_scalar = add_histogram = info
 
     agents_mod.get_logger = lambda *a, **k: Quiet()
+    if args.workload == "ppo_continuous":
+        return ppo_continuous_main(args, d, zoo, rank, world)
     per_gpu = 16 if args.workload == "a2c_pixel" else 8
     torch.manual_seed(0)
     np.random.seed(0)
@@ -453,6 +525,105 @@ def on_policy_main(args):
                        "communication stream, joined before the clip + optimizer launch" if agent.dp.comm else
                        ("torch.distributed " + (dist.get_backend() if world > 1 else "none"))},
             "updates_per_sec": k * (1 if args.workload == "a2c_pixel" else 16) / dt}), flush=True)
+    agent.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def ppo_cpu_baseline(seconds=10.0):
+    """The CPU oracle of the same update (oracle.ppo_mlp_oracle.ppo_update: the reference's PPO_agent.py:71-99 loop on
+    torch-CPU fp32 autograd + torch.optim.Adam, one thread as the reference's set_one_thread()) on a bounded sample:
+    minibatch updates of 64 rows over 2048 x 16 rollout rows until `seconds` have passed."""
+    from oracle import ppo_mlp_oracle as O
+    torch.set_num_threads(1)
+    rs = np.random.RandomState(0)
+    s_dim, a_dim, n = 17, 6, 2048 * 16
+    actor, critic = O.init_params(s_dim, a_dim, 64, seed=1)
+    state = torch.from_numpy(rs.randn(n, s_dim).astype(np.float32))
+    with torch.no_grad():
+        pred = O.gaussian_forward(actor, critic, state, noise=torch.from_numpy(rs.randn(n, a_dim).astype(np.float32)))
+    entries = [state, pred['action'], pred['log_pi_a'], pred['v'] + torch.from_numpy(rs.randn(n, 1).astype(np.float32)),
+               torch.from_numpy(rs.randn(n, 1).astype(np.float32))]
+    done, t0, state_opt = 0, time.perf_counter(), None
+    while time.perf_counter() - t0 < seconds:
+        rows = rs.permutation(n)[:64 * 64]          # 64 minibatches per call
+        sub = [e[rows] for e in entries]
+        a_opt, c_opt, _, _ = O.ppo_update(actor, critic, sub, [np.arange(len(rows))], 64, 0.2, 0.0, 0.01, opt_state=state_opt)
+        state_opt = (a_opt.state_dict(), c_opt.state_dict())
+        done += 64
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "updates/s", "cores": 1, "kind": "port",
+            "sample": "%d minibatch updates (64 rows, both networks, Adam) of the CPU oracle in %.1f s, one thread" % (done, dt)}
+
+
+def ppo_continuous_main(args, d, zoo, rank, world):
+    """BASELINE configs[2]: PPO, GaussianActorCriticNet over two 17 -> 64 -> 64 tanh MLPs, 16 vectorised HalfCheetah-shaped
+    workers per GPU, rollout 2048, 10 epochs x 512 minibatches of 64 (examples.py:497-523).  A step = one agent.step() = one
+    rollout + its optimisation phase: three persistent launches (rollout, value, update) + scan / normalise / pack.  N > 1:
+    independent replicas (the persistent update kernel keeps its weights on one CU; sharding 16 environments would put a
+    collective between 64-row minibatches 10 us apart): value = sum over ranks."""
+    import torch.distributed as dist
+    torch.manual_seed(rank)
+    np.random.seed(rank)
+    agent = _continuous_agent(d, zoo, 16, data_parallel=False)
+    per_step = agent.config.rollout_length * 16
+    n_warm = max(3, args.warmup if args.warmup <= 20 else args.warmup // 20)
+    for _ in range(n_warm):
+        agent.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    k = max(1, args.steps if args.steps <= 100 else args.steps // 20)
+    t0 = time.perf_counter()
+    for _ in range(k):
+        agent.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        agent._mlp.sync_counts()
+        n_mb = agent.config.optimization_epochs * (per_step // agent.config.mini_batch_size)
+        # the dominant kernel, timed live with HIP events on its stream: the persistent update launch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        times = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            ev0.record()
+            agent.step()
+            ev1.record()
+            torch.cuda.synchronize()
+            times.append(ev0.elapsed_time(ev1))
+        # algorithmic flops of one minibatch update (both networks, forward + input / weight gradients), 64 rows
+        mac_a = 17 * 64 + 64 * 64 + 64 * 6
+        mac_c = 17 * 64 + 64 * 64 + 64 * 1
+        flops_mb = 2 * 64 * ((mac_a + mac_c) + (2 * (mac_a + mac_c) - 2 * 17 * 64))
+        ms_step = float(np.median(times))
+        ach = n_mb * flops_mb / (ms_step * 1e-3) / 1e12
+        out = {"metric": "env-steps/sec", "value": world * k * per_step / dt, "unit": "env-steps/s", "n_gpus": world, "steps": k,
+               "warmup": n_warm, "ms_per_step": 1e3 * dt / k, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "PPO HalfCheetah shapes (17 obs, 6 actions), 16 vectorised workers per GPU, rollout 2048, "
+                                      "10 epochs x 512 minibatches of 64, two Adam optimisers (BASELINE configs[2]); device-resident "
+                                      "synthetic environments" + ("" if getattr(agent.task, "on_device", False) else " NOT ACTIVE"),
+                          "parallelism": "replicas x%d" % world},
+               "updates_per_sec": world * k * n_mb / dt,
+               "roofline": {"kernel": "whole agent step (rollout + value + scan + pack + ppo_mlp_update_kernel)", "bound": "mfma",
+                            "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                            "avg_ms": ms_step, "algorithmic_flops": n_mb * flops_mb,
+                            "note": "a chain of 5120 dependent 64-row updates on TWO workgroups (one network each): latency-bound by "
+                                    "construction (SURVEY.md 8d) -- the fraction of the chip's MFMA peak says how little of the "
+                                    "chip a sequential 5.7 k-parameter update can use, not how well the kernel is scheduled; "
+                                    "profiles/r05*_prof_ppo_mlp.json has cycles per phase"},
+               "fused_update_launches": agent._mlp.launches}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = ppo_cpu_baseline()
+        print(json.dumps(out), flush=True)
     agent.close()
     if world > 1:
         dist.barrier()
@@ -583,6 +754,16 @@ def main():
             roof["peak_note"] = "8000 GB/s is the HBM spec, quoted as a yardstick only: FETCH_SIZE counts Infinity-Cache hits"
             mf["longest_kernel"] = roof
             roof = mf
+        # `frac` / `achieved` of the headline kernel: the rocprofv3 duration of the same command's committed summary when there is
+        # one (the kernel alone), else the live event pair; the live pair (kernel + launch boundary + record: conservative) is
+        # always kept as frac_hip_events / achieved_hip_events
+        roof["frac_hip_events"], roof["achieved_hip_events"] = roof.get("frac"), roof.get("achieved")
+        rp = roof.get("rocprofv3")
+        if rp and rp.get("frac"):
+            roof["frac"], roof["achieved"] = rp["frac"], rp["achieved"]
+            roof["frac_source"] = "rocprofv3 avg duration of this kernel in %s (builder box); frac_hip_events is this run's live, conservative reading" % rp.get("file")
+        else:
+            roof["frac_source"] = "hip_events of this run (no committed rocprofv3 summary found)"
         # the update chain owns a CU partition while the device actor runs beside it (lever 5):
         # the kernel is timed on that stream, i.e. on this many of the device's CUs
         roof["stream_cus"] = bench.learner.update_cus or torch.cuda.get_device_properties(0).multi_processor_count
@@ -612,6 +793,10 @@ def main():
             out["parity_check"] = parity
         if world == 1 and not args.no_cpu_baseline:
             out["agent_api"] = agent_api()
+            try:
+                out["agent_api"]["other_configs"] = other_config_lines()
+            except Exception as e:      # extra lines must never take the headline down
+                out["agent_api"]["other_configs"] = {"error": repr(e)}
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if distributed:
