@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--cpu-replica-worker", type=float, default=0.0,
                     help="internal: run the single-thread CPU oracle loop for this many seconds and print its count")
     ap.add_argument("--master-port", type=int, default=29517, help="rendezvous port when bench.py launches the ranks itself")
+    ap.add_argument("--comm-check", action="store_true",
+                    help="multi-GPU self-diagnosis instead of a benchmark: device count vs --gpus, what RCCL reports for the "
+                         "communicator (ranks, algorithm / protocol lines of NCCL_DEBUG=INFO), and the 6.75 MB gradient all-reduce "
+                         "timed alone (us, GB/s)")
     ap.add_argument("--workload", default="dqn_pixel", choices=["dqn_pixel", "a2c_pixel", "ppo_pixel", "ppo_continuous"],
                     help="dqn_pixel = BASELINE configs[1] (the headline); a2c_pixel / ppo_pixel = configs[4]: the on-policy agents, "
                          "environments sharded over the ranks, one gradient all-reduce per optimizer step (SURVEY.md 8e); "
@@ -521,8 +525,10 @@ def on_policy_main(args):
                                        args.workload, per_gpu, agent.config.rollout_length,
                                        "device-resident synthetic environments" if getattr(agent.task, "on_device", False)
                                        else "host-side synthetic emulators"),
-                       "parallelism": "dp%d" % world, "collective": "dra_allreduce_grads (RCCL), [fc4 + heads] segment first on a "
-                       "communication stream, joined before the clip + optimizer launch" if agent.dp.comm else
+                       "parallelism": "dp%d" % world, "collective": ("dra_allreduce_grads (RCCL): each rank's gradient scaled by ITS weight, then "
+                       "summed; PPO (eager backward): the [fc4 + heads] segment goes out first on a communication stream and is joined "
+                       "before the clip + optimizer launch; A2C (captured rollout graph): one exchange at the graph's tail -- "
+                       "early_fc4_exchanges in per_rank counts the early segments that really went out") if agent.dp.comm else
                        ("torch.distributed " + (dist.get_backend() if world > 1 else "none"))},
             "updates_per_sec": k * (1 if args.workload == "a2c_pixel" else 16) / dt}), flush=True)
     agent.close()
@@ -630,13 +636,109 @@ def ppo_continuous_main(args, d, zoo, rank, world):
         dist.destroy_process_group()
 
 
+def comm_check(args):
+    """`bench.py --gpus N --comm-check`: one SCALE run's worth of self-diagnosis for the data-parallel path.
+    Every rank: is there a GPU for it, what does RCCL say about the communicator, how long does the all-reduce of the actor-critic
+    net's flat fp32 gradient (1 686 693 floats = 6.75 MB, examples.py:361-381 / 525-550 with 4 actions) take on its own.
+    Rank 0 prints ONE JSON line.  Algorithm / protocol: RCCL only reports its choice through NCCL_DEBUG=INFO, so the ranks run
+    with NCCL_DEBUG=INFO, NCCL_DEBUG_SUBSYS=INIT,COLL,TUNING into per-rank files and rank 0 returns the lines that name them."""
+    import glob
+    import tempfile
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    n_dev = torch.cuda.device_count()
+    log_dir = os.environ.get("DRA_COMM_CHECK_DIR") or tempfile.mkdtemp(prefix="dra_rccl_")
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,COLL,TUNING")
+    os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(log_dir, "rccl_rank%d_%%p.log" % rank))
+    out = {"comm_check": True, "n_gpus_requested": args.gpus, "world_size": world, "devices_visible": n_dev,
+           "enough_devices": n_dev >= world}
+    if n_dev < 1:
+        out["error"] = "no GPU visible"
+        print(json.dumps(out), flush=True)
+        return 3
+    import deeprl_amd as d
+    import deeprl_amd.dist as dd
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        torch.cuda.set_device(local_rank % n_dev)
+        dd.init("nccl" if world <= n_dev else "gloo")
+    d.select_device(local_rank % n_dev)
+    n = 1_686_693
+    grad = torch.randn(n + (-n) % 4, dtype=torch.float32, device=d.Config.DEVICE)
+    comm = dd.RcclComm() if (world == 1 or world <= n_dev) else None
+    rec = {"rank": rank, "device": torch.cuda.current_device()}
+    if comm is not None:
+        info = comm.info()
+        rec.update(rccl_ranks=info[0], rccl_rank=info[1])
+        for _ in range(10):
+            comm.allreduce_grads(grad, 1.0 / world)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        e0.record()
+        for _ in range(reps):
+            comm.allreduce_grads(grad, 1.0 / world)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / reps
+        nbytes = 4 * n
+        rec.update(allreduce_us=us, alg_GBps=nbytes / us / 1e3,
+                   bus_GBps=(2.0 * (world - 1) / world) * nbytes / us / 1e3 if world > 1 else 0.0)
+        comm.close()
+    else:
+        rec["note"] = "more ranks than GPUs: the ranks share devices over gloo, RCCL is not exercised"
+    recs = [rec]
+    if world > 1:
+        recs = [None] * world
+        dist.all_gather_object(recs, rec)
+    if rank == 0:
+        lines = []
+        for f in sorted(glob.glob(os.path.join(log_dir, "rccl_rank*.log")))[:2]:
+            try:
+                for ln in open(f, errors="replace"):
+                    low = ln.lower()
+                    if any(k in low for k in ("algo", "proto", "ring", "tree", "xgmi", "channel", "nranks", "rccl version", "nccl version")):
+                        lines.append(ln.strip()[:240])
+            except Exception:
+                pass
+        out["per_rank"] = recs
+        slow = max((r.get("allreduce_us") or 0.0) for r in recs)
+        out["allreduce_us_max_over_ranks"] = slow
+        if world > 1 and slow > 0:
+            bus = (2.0 * (world - 1) / world) * 4 * n / slow / 1e3
+            links = min(world - 1, 7)
+            out["bus_GBps"] = bus
+            out["per_link_GBps_if_spread_over_%d_links" % links] = bus / links
+            out["xgmi_link_peak_GBps"] = 153.0
+            out["reading"] = ("a ring keeps ONE link per direction busy per step: if bus_GBps is near one link's 153 GB/s the ring is "
+                              "link-bound and a direct reduce-scatter + all-gather over all %d links (SURVEY.md 5) would pay; if it is "
+                              "far below, the 6.75 MB exchange is latency-bound and overlap (dist.DataParallel.plan_split) matters more" % links)
+        out["rccl_debug_lines"] = lines[:60]
+        out["rccl_debug_dir"] = log_dir
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse()
     if args.cpu_replica_worker > 0:
         print(json.dumps(cpu_baseline(args.cpu_replica_worker, min(args.ring, 20_000), worker=True)), flush=True)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.comm_check and torch.cuda.device_count() < args.gpus:
+            print(json.dumps({"comm_check": True, "n_gpus_requested": args.gpus, "devices_visible": torch.cuda.device_count(),
+                              "enough_devices": False, "error": "fewer GPUs than --gpus: nothing launched"}), flush=True)
+            sys.exit(3)
         sys.exit(spawn_ranks(args))
+    if args.comm_check:
+        sys.exit(comm_check(args))
     if args.workload != "dqn_pixel":
         return on_policy_main(args)
     rank = int(os.environ.get("RANK", 0))

@@ -1323,7 +1323,12 @@ class PPOAgent(BaseAgent):
             self.critic_opt = config.critic_opt_fn(self.network.critic_params)
             actor_ids = {id(p) for p in self.network.actor_params}
             if any(id(p) in actor_ids for p in self.network.critic_params):
-                raise NotImplementedError("PPO with a shared phi_body and separate optimisers: use shared_repr=True")
+                # (the reference cannot run this configuration either: PPO_agent.py:89-96 calls policy_loss.backward() and then
+                # value_loss.backward() on ONE forward -- with a parameterised phi_body the first call frees the shared part of the
+                # graph and steps its weights in place, and the second raises inside autograd; tests/test_nets_host_logic.py)
+                raise NotImplementedError("PPO with a parameterised phi_body shared by separate actor / critic optimisers: the "
+                                          "reference's own update (PPO_agent.py:89-96) raises inside autograd for it; use "
+                                          "shared_repr=True (one optimiser, examples.py:525-550)")
             self._fused_actor = FusedOptimizer.adopt(self.actor_opt)
             self._fused_critic = FusedOptimizer.adopt(self.critic_opt)
         _dp_sync_start(self.dp, self.network, *([self._fused] if config.shared_repr else [self._fused_actor, self._fused_critic]))

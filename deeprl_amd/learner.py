@@ -588,11 +588,22 @@ class DeviceActorPipeline:
         if self.async_actor:
             self.rs.set_state(st["rs"])
         self.stream.load_state_dict(st["stream"])
-        if st.get("chain_prev") is not None and self.chain == 2:
+        if st.get("chain_prev") is not None:
+            # a saved draw has already consumed python's `random`: dropping it would silently fork the resumed run
+            if self.chain != 2:
+                raise DraError("the checkpoint holds a pending device-side prioritized draw (chain_prev) but this pipeline "
+                               "draws on the host: resume with the same async_actor / replay configuration it was saved with")
             from .replay import DeviceDraw
             if self._dd is None:
                 self._dd = DeviceDraw(self.rp, self.L)
-            idx, p, total, beta = st["chain_prev"]
+            prev = tuple(st["chain_prev"])
+            if len(prev) == 3:          # written by the retired chain mode 1 (no importance exponent): take the schedule's current value
+                prev = prev + (None,)
+            if len(prev) != 4:
+                raise DraError("unrecognised chain_prev record of %d fields in the checkpoint" % len(prev))
+            idx, p, total, beta = prev
+            if beta is None:
+                beta = float(self.rp.config_beta()) if hasattr(self.rp, "config_beta") else 0.4
             self._dd.start(idx, p, total, beta)
 
     def _block(self):

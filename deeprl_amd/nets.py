@@ -48,16 +48,35 @@ def layer_init(layer, w_scale=1.0):
 # for a backward pass in which every such parameter is used ONCE (A2C's batched update, a PPO minibatch) -- 0 + g == g, so the
 # result is what the accumulation gives.
 _DIRECT = [False]
+_WRITTEN = set()        # ids of the parameters whose .grad the current backward pass has already overwritten
 
 
 @contextlib.contextmanager
 def direct_param_grads(enable=True):
+    """Inside the context the layer Functions write each parameter's gradient straight into its .grad the FIRST time the
+    backward pass reaches it; a parameter reached again (a module applied twice in one forward: weight sharing, siamese or
+    recurrent bodies) gets its further contributions through autograd's own accumulation, on top of the direct write -- the sum
+    is what plain accumulation gives (a second overwrite would silently drop the first contribution)."""
     prev = _DIRECT[0]
     _DIRECT[0] = bool(enable)
+    if enable:
+        _WRITTEN.clear()
     try:
         yield
     finally:
         _DIRECT[0] = prev
+        _WRITTEN.clear()
+
+
+def _claim_direct(params):
+    """True when direct writes are on and NONE of `params` has been written in this backward pass; claims them."""
+    if not _DIRECT[0]:
+        return False
+    ids = [id(p) for p in params if p is not None]
+    if any(i in _WRITTEN for i in ids):
+        return False
+    _WRITTEN.update(ids)
+    return True
 
 
 # ReLU masks applied by the PRODUCER of a gradient.  A fused-ReLU layer's backward starts with dpre = dy * (y > 0) -- a launch of
@@ -65,16 +84,23 @@ def direct_param_grads(enable=True):
 # input-gradient kernel has an epilogue for it (xact): it hands down dx * (x > 0) and leaves the tensor's address here; the layer
 # below skips its own mask when the gradient it receives is that very tensor (anything autograd copied or accumulated in between
 # has another address and is masked as before).  (y > 0) in {0, 1}: the values are the same either way.
-_MASKED = [0, 0]       # (address, element count) of the gradient the layer above has already masked
+_MASKED = [0, 0, None]       # (address, element count, weak reference) of the gradient the layer above has already masked
 
 
 def _mark_masked(dx):
-    _MASKED[0], _MASKED[1] = dx.data_ptr(), dx.numel()
+    import weakref
+    _MASKED[0], _MASKED[1], _MASKED[2] = dx.data_ptr(), dx.numel(), weakref.ref(dx)
 
 
 def _already_masked(dy):
-    hit = _MASKED[0] != 0 and dy.data_ptr() == _MASKED[0] and dy.numel() == _MASKED[1]
+    """The mark names a tensor OBJECT that is still alive (a freed tensor's address may be handed to an unrelated gradient by
+    the caching allocator: a stale mark must not match it) with the address / size this gradient has (autograd may hand the
+    consumer a view or the same storage through another Python object)."""
+    ref = _MASKED[2]
+    alive = ref is not None and ref() is not None
+    hit = alive and _MASKED[0] != 0 and dy.data_ptr() == _MASKED[0] and dy.numel() == _MASKED[1]
     _MASKED[0] = _MASKED[1] = 0          # consumed (or not ours): a mark never outlives the next layer's backward
+    _MASKED[2] = None
     return hit
 
 
@@ -99,7 +125,7 @@ class _LinearFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         dy = dy.contiguous()
         dpre = ops.act_bwd(dy, y, ctx.act) if ctx.act else dy
-        gw, gb = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if _DIRECT[0] else (None, None)
+        gw, gb = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if _claim_direct(ctx.params) else (None, None)
         if gw is not None and gw.is_contiguous() and (not ctx.has_bias or (gb is not None and gb.is_contiguous())):
             ops.linear_bwd_w(dpre, x, dw=gw, db=gb if ctx.has_bias else None, want_bias=ctx.has_bias)
             dw = db = None
@@ -132,7 +158,8 @@ class _LinearPairFn(torch.autograd.Function):
         x, w0, w1 = ctx.saved_tensors
         if g0 is not None and g1 is not None:
             # both gradients present (the usual case): ONE launch for d phi and both layers' weight / bias gradients
-            slots = [_grad_slot(p) if _DIRECT[0] else None for p in ctx.params]
+            direct = _claim_direct(ctx.params)
+            slots = [_grad_slot(p) if direct else None for p in ctx.params]
             direct = all(g is not None and g.is_contiguous() for g in slots)
             dx, dw0, db0, dw1, db1 = ops.linear_bwd_pair(g0.contiguous(), g1.contiguous(), x, w0, w1,
                                                          *((slots[0], slots[1], slots[2], slots[3]) if direct else ()),
@@ -265,7 +292,7 @@ class _ConvKocFn(torch.autograd.Function):
             _mark_masked(dx)
         # direct_param_grads(): FlatParams lays [weight (KOC) | bias] out back to back, which is a slab's own layout -- the fold
         # writes the layer's gradient segment of the optimizer's flat buffer itself
-        gw, gb = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if _DIRECT[0] else (None, None)
+        gw, gb = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if _claim_direct(ctx.params) else (None, None)
         direct = (gw is not None and gb is not None and stride == n_w + oc and gw.permute(1, 2, 3, 0).is_contiguous()
                   and gb.is_contiguous() and gb.data_ptr() == gw.data_ptr() + 4 * n_w and gw.data_ptr() % 16 == 0)
         flat = torch.as_strided(gw, (stride,), (1,)) if direct else torch.empty(stride, dtype=torch.float32, device=w.device)
@@ -657,7 +684,8 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         phi = self.phi_body(obs)
         phi_a = self.actor_body(phi)
         phi_v = self.critic_body(phi)
-        if (phi_a is phi_v and phi_a.is_cuda and phi_a.dim() == 2 and phi_a.shape[1] <= 512 and phi_a.dtype == torch.float32
+        if (phi_a is phi_v and phi_a.is_cuda and phi_a.dim() == 2 and phi_a.shape[1] <= 512 and phi_a.shape[0] <= 65536
+                and phi_a.dtype == torch.float32
                 and type(self.fc_action) is Linear and type(self.fc_critic) is Linear and self.fc_action.bias is not None
                 and self.fc_critic.bias is not None and self.fc_action.fused_act is None and self.fc_critic.fused_act is None):
             # both heads read the same features: one launch, the same per-output arithmetic (rollout steps and updates alike)

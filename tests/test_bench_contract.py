@@ -51,3 +51,34 @@ def test_bench_reads_the_newest_committed_profiler_summaries():
     assert mod.rocprof_kernel("rmsprop_step", 0)["avg_ms"] > 5e-3
     t = mod.pmc_traffic("conv2_bwd_x")
     assert t is not None and 4e6 < t < 4e7
+
+
+def test_newest_bench_line_round5_fields():
+    """Round 5 additions to the driver's record: every passing parity step is judged, the headline fraction names its source and
+    keeps the live event-pair reading beside it, and the other BASELINE configs' agent lines travel with the headline."""
+    b = json.load(open(_newest("r*_bench.json")))
+    pc = b["parity_check"]
+    assert pc["steps_judged"] == sum(1 for s in pc["steps"] if s["within_tolerance"] or not s.get("excused", False))
+    assert pc["steps_judged"] == pc["steps_checked"] or any(s.get("excused") for s in pc["steps"])
+    r = b["roofline"]
+    assert "frac_source" in r and r["frac_hip_events"] > 0 and r["frac"] >= r["frac_hip_events"] * 0.9
+    other = b["agent_api"]["other_configs"]
+    for name in ("categorical_dqn_pixel", "categorical_dqn_pixel_prioritized_replay", "quantile_regression_dqn_pixel", "a2c_pixel_16",
+                 "ppo_pixel_8", "ppo_continuous_16"):
+        assert other[name]["env_steps_per_s"] > 0 and other[name]["updates_per_s"] > 0, name
+    # BASELINE configs[2] on the device (VERDICT r4 item 1: >= 150 k env-steps/s and >= 50 k minibatch updates/s)
+    assert other["ppo_continuous_16"]["env_steps_per_s"] >= 150e3 and other["ppo_continuous_16"]["updates_per_s"] >= 50e3
+
+
+def test_comm_check_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N --comm-check` on a box with fewer GPUs prints one JSON line saying so and exits 3 (nothing launched)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("box has two GPUs: the check would run")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm-check"], capture_output=True, text=True,
+                       timeout=300)
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 3 and rec["comm_check"] and rec["enough_devices"] is False and rec["n_gpus_requested"] == 2

@@ -118,3 +118,19 @@ def test_rccl_comm_of_size_one():
     torch.cuda.synchronize()
     assert np.array_equal(g.cpu().numpy(), want)
     comm.close()
+
+
+def test_comm_check_on_one_rank():
+    """`bench.py --comm-check`: on the one-GPU box the self-diagnosis runs over a communicator of size 1
+    and reports what a SCALE run would read first -- devices, RCCL's own rank count, the 6.75 MB exchange timed alone."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--comm-check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["comm_check"] and rec["enough_devices"] and rec["world_size"] == 1
+    one = rec["per_rank"][0]
+    assert one["rccl_ranks"] == 1 and one["rccl_rank"] == 0 and 0.0 < one["allreduce_us"] < 1e4

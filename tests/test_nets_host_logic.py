@@ -49,3 +49,63 @@ def test_nature_conv_body_marks_the_layers_that_read_a_fused_relu():
     assert body.conv2.input_is_relu and body.conv3.input_is_relu and body.fc4.input_is_relu
     noisy = nets.NatureConvBody(noisy_linear=True)
     assert not getattr(noisy.fc4, "input_is_relu", False)
+
+
+def test_direct_param_grads_claims_each_parameter_once():
+    """nets.direct_param_grads: the first backward use of a parameter may overwrite its .grad, a second use inside the same
+    backward pass (weight sharing) must go through autograd's accumulation; the record is cleared per pass."""
+    import torch
+    from deeprl_amd import nets
+    p, q = torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2))
+    assert not nets._claim_direct((p, None))            # outside the context: never direct
+    with nets.direct_param_grads():
+        assert nets._claim_direct((p, None))
+        assert not nets._claim_direct((p, q))           # p already written: the pair falls back, q is not claimed by it
+        assert nets._claim_direct((q,))
+        with nets.direct_param_grads(False):
+            assert not nets._claim_direct((torch.nn.Parameter(torch.zeros(1)),))
+    with nets.direct_param_grads():
+        assert nets._claim_direct((p, q))               # a new pass starts clean
+    assert not nets._WRITTEN
+
+
+def test_masked_gradient_mark_needs_a_live_tensor():
+    """The 'already ReLU-masked' hand-off matches a gradient by address AND by the marked tensor still being alive: a stale
+    mark (its tensor freed, the address recycled) must not make an unrelated gradient skip its mask."""
+    import torch
+    from deeprl_amd import nets
+    a = torch.zeros(8)
+    nets._mark_masked(a)
+    assert nets._already_masked(a)
+    assert not nets._already_masked(a)                  # consumed
+    b = torch.zeros(8)
+    nets._mark_masked(b)
+    addr, numel = b.data_ptr(), b.numel()
+    del b
+    class Fake:                                         # an unrelated gradient that happens to get the same address / size
+        def data_ptr(self): return addr
+        def numel(self): return numel
+    assert not nets._already_masked(Fake())
+
+
+def test_shared_body_with_two_optimisers_cannot_run_in_the_reference_either():
+    """PPOAgent refuses a parameterised phi_body shared by separate actor / critic optimisers (agents.py).  So does the
+    reference, implicitly: PPO_agent.py:89-96 backpropagates policy_loss and then value_loss through ONE forward; with a shared
+    parameterised body the first backward frees the shared graph (and actor_opt.step() rewrites its weights in place), so the
+    second raises inside autograd.  Reproduced here with plain torch modules of the same structure."""
+    import pytest
+    import torch
+    import torch.nn as nn
+    torch.manual_seed(0)
+    phi = nn.Sequential(nn.Linear(4, 8), nn.Tanh(), nn.Linear(8, 8), nn.Tanh())
+    fa, fc = nn.Linear(8, 2), nn.Linear(8, 1)
+    actor_opt = torch.optim.Adam(list(fa.parameters()) + list(phi.parameters()), 3e-4)
+    critic_opt = torch.optim.Adam(list(fc.parameters()) + list(phi.parameters()), 1e-3)
+    h = phi(torch.randn(16, 4))
+    policy_loss, value_loss = fa(h).pow(2).mean(), fc(h).pow(2).mean()
+    actor_opt.zero_grad()
+    policy_loss.backward()
+    actor_opt.step()
+    critic_opt.zero_grad()
+    with pytest.raises(RuntimeError):
+        value_loss.backward()
