@@ -54,13 +54,23 @@ using WG1f = ConvWgradOne<G1, 4, 4, 88, 0, false>;
 using WG2l = ConvWgradLin<G2, 4>;     // 128 workgroups x 82 MFMAs per wave (2 k-tiles per workgroup: 256 x 41 measured 0.8 us slower)
 using WG3l = ConvWgradLin<G3, 2>;     // 288 x 25 (3 k-tiles: 192 x 50 / 25, 0.8 us slower); profiles/r04j_ab_wgrad_tiles_role_order.jsonl
 
+// rollout batch sizes (A2C 80 stays below; PPO minibatches 256 ...): the persistent forms, one slab per batch share
+using WG2p = ConvWgradPers<G2, 8, 128, 1>;   // 2 k groups x 128 shares = 256 workgroups; 164 MFMAs per wave and sample
+using WG3p = ConvWgradPers<G3, 6, 85, 2>;    // 3 k groups x 85 shares = 255 workgroups (one per CU: 288 left 32 CUs with two); 2 x 75 MFMAs per wave and iteration
+// from which batch on: conv3 from 128 (its persistent role shares the launch with the input gradient); conv2 from 768 (two launches:
+// at 256 / 512 the one-sample form, one launch, is as fast or faster: 46 vs 49 us, 86 vs 89 us)
+template <class G> struct PersistFrom { static constexpr int batch = 768; static constexpr bool one_launch = false; };
+template <> struct PersistFrom<G3> { static constexpr int batch = 128; static constexpr bool one_launch = true; };
+
 DRA_API int dra_conv_wgrad_slabs(int layer, int batch, int ksplit, int variant, int* n_slabs) {
   if (!n_slabs || batch < 1 || ksplit < 1 || layer < 1 || layer > 3) return DRA_EINVAL;
   if (!(variant & DRA_VAR_ONESHOT_WGRAD)) { *n_slabs = ksplit; return DRA_OK; }
+  const bool pers2 = batch >= PersistFrom<G2>::batch && (variant & DRA_VAR_ONESHOT_DGRAD);
+  const bool pers3 = batch >= PersistFrom<G3>::batch && (variant & DRA_VAR_ONESHOT_DGRAD);
   switch (layer) {
     case 1: *n_slabs = WG1u::n_slabs(batch); return DRA_OK;
-    case 2: *n_slabs = WG2l::n_slabs(batch); return DRA_OK;
-    case 3: *n_slabs = WG3l::n_slabs(batch); return DRA_OK;
+    case 2: *n_slabs = pers2 ? WG2p::n_slabs(batch) : WG2l::n_slabs(batch); return DRA_OK;
+    case 3: *n_slabs = pers3 ? WG3p::n_slabs(batch) : WG3l::n_slabs(batch); return DRA_OK;
   }
   return DRA_EINVAL;
 }
@@ -108,15 +118,35 @@ template <class R>
 static int igemm_blocks(const R& r, int nz) { return r.tiles * r.ksplit * nz; }
 
 // layers 2 / 3: weight gradient + input gradient in one launch
-template <class G, class WOne, class R3 = NoRole>
+template <class G, class WOne, class WPers = WOne, class R3 = NoRole>
 static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
                             int64_t slab_stride, int ksplit, float* dx, int batch, int act, int variant, hipStream_t st,
                             const R3& none = R3(), int n3 = 0) {
   const bool ow = variant & DRA_VAR_ONESHOT_WGRAD, od = variant & DRA_VAR_ONESHOT_DGRAD;
   if (n3 > 0 && !(od && ow)) return DRA_EINVAL;   // a riding role exists for the one-pass pair only
   if (od && ow) {
+    if constexpr (!std::is_same<WPers, WOne>::value) {
+      if (batch >= PersistFrom<G>::batch && n3 == 0) {
+        WPers rp;
+        rp.dy = dy; rp.x = x; rp.dw = dw; rp.db = db; rp.slab_stride = slab_stride; rp.B = batch;
+        auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
+        const bool only_d = variant & DRA_VAR_MEASURE_DGRAD_ONLY, only_w = variant & DRA_VAR_MEASURE_WGRAD_ONLY;
+        if (!PersistFrom<G>::one_launch || only_d || only_w) {
+          // two launches: the persistent role's LDS image would cost the input-gradient workgroups their occupancy (conv2)
+          int rc = DRA_OK;
+          if (!only_d) rc = launch_multi(rp, rp.blocks(), none, 0, none, 0, st);
+          if (rc == DRA_OK && !only_w) rc = launch_multi(rd, rd.blocks(), none, 0, none, 0, st);
+          return rc;
+        }
+        // one launch, the persistent weight-gradient workgroups (its longest) FIRST in the grid (conv3)
+        return launch_multi(rp, rp.blocks(), rd, rd.blocks(), none, 0, st);
+      }
+    }
     auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
     auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
+    if (variant & (DRA_VAR_MEASURE_DGRAD_ONLY | DRA_VAR_MEASURE_WGRAD_ONLY))
+      return launch_multi(rd, (variant & DRA_VAR_MEASURE_WGRAD_ONLY) ? 0 : rd.blocks(), rw,
+                          (variant & DRA_VAR_MEASURE_DGRAD_ONLY) ? 0 : rw.blocks(), none, n3, st);
     // (the weight-gradient workgroups, the longer ones, FIRST in the launch: no difference, profiles/r04j_ab_wgrad_tiles_role_order.jsonl)
     return launch_multi(rd, rd.blocks(), rw, rw.blocks(), none, n3, st);
   }
@@ -160,9 +190,9 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
       }
       return dra_conv_bwd_w_koc(1, dy, x, dw, db, slab_stride, ksplit, batch, x_is_u8, u8_coef, stream);
     case 2:
-      return conv_bwd_fused_t<G2, WG2l>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+      return conv_bwd_fused_t<G2, WG2l, WG2p>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
     case 3:
-      return conv_bwd_fused_t<G3, WG3l>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
+      return conv_bwd_fused_t<G3, WG3l, WG3p>(dy, x, wt, xact, dw, db, slab_stride, ksplit, dx, batch, act, variant, st);
   }
   return DRA_EINVAL;
 }
@@ -184,7 +214,7 @@ static int conv3_bwd_chain_t(const float* dy, const void* x, const float* wt, co
                              int64_t slab_stride, float* dx, int batch, int act, int variant, const PerChain2Args* chain, hipStream_t st) {
   ChainRole<PART> r;
   r.a = *chain;
-  return conv_bwd_fused_t<G3, WG3l, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
+  return conv_bwd_fused_t<G3, WG3l, WG3l, ChainRole<PART>>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, r, 1);
 }
 int dra_conv3_bwd_fused_chain(const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
                               int64_t slab_stride, float* dx, int batch, int act, int variant, const PerChain2Args* chain,
@@ -234,9 +264,9 @@ int dra_conv_bwd_fused_fold(int layer, const float* dy, const void* x, const flo
   const FoldRole f = make_fold_role(fold, grad, fold_partials, reset_slots, n_reset);
   *n_fold_partials = f.blocks();
   if (layer == 2)
-    return conv_bwd_fused_t<G2, WG2l, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
+    return conv_bwd_fused_t<G2, WG2l, WG2l, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
   if (layer == 3)
-    return conv_bwd_fused_t<G3, WG3l, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
+    return conv_bwd_fused_t<G3, WG3l, WG3l, FoldRole>(dy, x, wt, xact, dw, db, slab_stride, 1, dx, batch, act, variant, st, f, f.blocks());
   return DRA_EINVAL;
 }
 

@@ -383,3 +383,162 @@ struct LinWgradOne {
     DRA_STAMP(TR_FC_B, 5);
   }
 };
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of conv2 / conv3 at ROLLOUT batch sizes (PPO minibatches 256, 512, 1024): the same contraction as
+// ConvWgradLin -- same staging (operands copied into LDS as they lie in memory), same MFMA loop -- but PERSISTENT over the batch:
+// a workgroup = (group of MTG k tiles, share of the batch) keeps its output tiles in its accumulators and walks its samples SPI
+// at a time, the next SPI samples' loads in flight (registers) while the current ones are contracted.  One slab per batch SHARE
+// instead of one per sample: at batch 1024 conv2 wrote 134 MB of slabs that the fold read straight back (3.3-4.6x the
+// algorithmic traffic, profiles/r04w_pmc_traffic.json).  Sizing rules measured in round 5 (profiles/r05k_conv_big_roles.jsonl):
+// an iteration needs >= ~8 k cycles of MFMA per wave or the next samples' loads (2-3 us under load) are not back in time
+// (conv3 with 75 MFMAs per sample and SPI 1: 0.28 of peak; conv2 with 164: 0.60); the grid is ONE workgroup per CU (288
+// workgroups on 256 CUs left 32 CUs with two: conv3 0.37 -> 0.51 at 255); and a launch's LDS / VGPR footprint is the maximum
+// over its roles: conv2's 46 KB next to the input-gradient role cost that role its occupancy (fused 205 us, the two launches one
+// after the other 155 us at batch 1024), conv3's 20 KB does not (fused 112 us, separate 122 us).
+// (A persistent input-gradient role -- weights staged once per workgroup, 16 x 16 x 4 MFMAs, no cross-wave fold -- was built and
+// measured in the same round: 96.6 us against ConvDgradLin's 98.4 us for conv2 at batch 1024, 134 us against 75 us for conv3;
+// one wave per SIMD cannot hide its own operand reads behind its own MFMAs (tools/ubench/mfma_coissue.hip), and the one-sample
+// workgroups of ConvDgradLin overlap each other instead.  Not kept.)
+// Bias gradient: the workgroups of k group 0 sum their samples' rows with all four waves (a quarter of the positions each) and
+// fold them once at the end.  The DQN update (batch 32) keeps ConvWgradLin: with one sample per workgroup there is nothing to
+// walk (and the accumulating form lost there, profiles/r04e_ab_env.jsonl).
+template <class G, int MTG, int SHARES, int SPI>
+struct ConvWgradPers {
+  using L = ConvWgradLin<G, MTG>;
+  static constexpr int S = G::S, OH = G::OH, P = G::P, H = G::H, HW = G::HW;
+  static constexpr int NJ = L::NJ, NGRP = L::NGRP, NTL = L::NTL, TILES = L::TILES, TPW = L::TPW, IMGF = L::IMGF, NSRC = L::NSRC;
+  static constexpr bool ODD = L::ODD;
+  static constexpr int BUF = (IMGF + NSRC + 4 + 3) & ~3;       // one staged sample: input channels | gradient block | zero float4
+  static constexpr int RED = 4 * G::OC;                       // bias partials of the four waves
+  static constexpr int LDS_FLOATS = SPI * BUF + RED;
+  const float* dy;   // [B][OC][OH][OH]
+  const void* x;     // [B][C][H][H] f32
+  float* dw;         // slab 0 of dWt [K][OC]
+  float* db;         // slab 0 of db [OC]
+  int64_t slab_stride;
+  int B;
+  __host__ __device__ static int spw(int batch) { return (batch + SHARES - 1) / SHARES; }        // samples per workgroup
+  __host__ static int n_slabs(int batch) { return (batch + spw(batch) - 1) / spw(batch); }
+  __host__ int blocks() const { return n_slabs(B) * NGRP; }
+  static constexpr int pos_off(int p) { return (p / OH) * S * H + (p % OH) * S; }
+  __device__ __forceinline__ void run(int bid, float* __restrict__ lds, int = 0) const {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
+    const int per = spw(B);
+    const int grp = bid % NGRP, share = bid / NGRP;
+    const int b0 = share * per, b1 = min(B, b0 + per);
+    const int k0 = grp * MTG * 32;
+    const int c_lo = k0 / G::KK;
+    const int c_hi = min((k0 + MTG * 32 - 1) / G::KK, G::C - 1);
+    const int nch = c_hi - c_lo + 1;
+    constexpr int NVD = NSRC / 4, RD = (NVD + 255) / 256;
+    constexpr int RI = (IMGF / 4 + 255) / 256;
+    const int64_t xlast4 = ((int64_t)B * G::C * HW >> 2) - 1;
+    lin_f4 draw[SPI][RD], iraw[SPI][RI];
+    int shift_nxt[SPI], nvi_nxt[SPI], shift[SPI];
+    auto fetch = [&](int bi0) {         // every load of up to SPI samples, into registers (samples past the share: clamped, unused)
+#pragma unroll
+      for (int u = 0; u < SPI; ++u) {
+        const int bi = min(bi0 + u, b1 - 1);
+        const lin_f4* dyb4 = reinterpret_cast<const lin_f4*>(dy + (int64_t)bi * NSRC);
+#pragma unroll
+        for (int q = 0; q < RD; ++q) draw[u][q] = dyb4[min(tid + 256 * q, NVD - 1)];
+        const int64_t xstart = ((int64_t)bi * G::C + c_lo) * HW;
+        shift_nxt[u] = (int)(xstart & 3);
+        nvi_nxt[u] = (nch * HW + shift_nxt[u] + 3) >> 2;
+        const lin_f4* x4 = reinterpret_cast<const lin_f4*>(x) + (xstart >> 2);
+#pragma unroll
+        for (int q = 0; q < RI; ++q) {
+          const int64_t f = min((int64_t)(tid + 256 * q), (int64_t)nvi_nxt[u] - 1);
+          iraw[u][q] = x4[min(f, xlast4 - (xstart >> 2))];
+        }
+      }
+    };
+    auto stage = [&]() {                // registers -> LDS images (unconditional stores, clamped indices: see ConvWgradLin)
+#pragma unroll
+      for (int u = 0; u < SPI; ++u) {
+        lin_f4* img4 = reinterpret_cast<lin_f4*>(lds + u * BUF);
+        lin_f4* dyl4 = reinterpret_cast<lin_f4*>(lds + u * BUF + IMGF);
+#pragma unroll
+        for (int q = 0; q < RI; ++q) img4[min(tid + 256 * q, nvi_nxt[u] - 1)] = iraw[u][q];
+#pragma unroll
+        for (int q = 0; q < RD; ++q) dyl4[min(tid + 256 * q, NVD - 1)] = draw[u][q];
+        if (tid == 0) dyl4[NVD] = lin_f4{0.f, 0.f, 0.f, 0.f};
+        shift[u] = shift_nxt[u];
+      }
+    };
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = zero16();
+    float sb = 0.f;                     // bias partial of (oc = tid & (OC - 1), positions = wave, wave + 4, ...)
+    fetch(b0);
+    stage();
+    __syncthreads();
+    for (int bi = b0; bi < b1; bi += SPI) {
+      if (bi + SPI < b1) fetch(bi + SPI);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < SPI; ++u) {
+        if (bi + u < b1) {
+          const float* img = lds + u * BUF;
+          const float* dyl = img + IMGF;
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) {
+            const int tile = wave + 4 * t;
+            if (tile < TILES) {
+              const int mt = tile / NTL, nt = tile - mt * NTL;
+              const int k = k0 + mt * 32 + li;
+              const int c = k / G::KK, kr = k - c * G::KK, kh = kr / G::KH, kw = kr - kh * G::KH;
+              const float* abase = img + shift[u] + (c - c_lo) * HW + kh * H + kw;
+              const float* ap_same = abase + h * S;
+              const float* ap_wrap = abase + h * (S * H - (OH - 1) * S);
+              const float* bp = dyl + (nt * 32 + li) * P + h;
+#pragma unroll
+              for (int j = 0; j < NJ; ++j) {
+                const bool last_odd = ODD && j == NJ - 1;
+                const bool wrap = ((2 * j + 1) % OH) == 0;
+                float a, b;
+                if (last_odd) {
+                  a = abase[pos_off(2 * j)];
+                  b = h ? dyl[NSRC] : bp[2 * j - h];
+                } else {
+                  a = wrap ? ap_wrap[pos_off(2 * j)] : ap_same[pos_off(2 * j)];
+                  b = bp[2 * j];
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+              }
+            }
+          }
+          if (grp == 0) {
+            const int oc = tid & (G::OC - 1);
+            for (int pos = wave; pos < P; pos += 4) sb += dyl[oc * P + pos];
+          }
+        }
+      }
+      __syncthreads();                  // every wave has read the images
+      if (bi + SPI < b1) stage();
+      __syncthreads();
+    }
+    // ---- one slab per batch share (rows = k, 32 lanes along oc: 128-byte rows)
+    float* dws = dw + (int64_t)share * slab_stride;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < TILES) {
+        const int mt = tile / NTL, nt = tile - mt * NTL;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int k = k0 + mt * 32 + mfma_row(rr, h);
+          dws[(int64_t)k * G::OC + nt * 32 + li] = acc[t][rr];
+        }
+      }
+    }
+    if (grp == 0) {
+      static_assert(G::OC == 64, "one bias partial per (wave, output channel)");
+      float* red = lds + SPI * BUF;
+      red[wave * G::OC + (tid & (G::OC - 1))] = sb;
+      __syncthreads();
+      if (tid < G::OC) db[(int64_t)share * slab_stride + tid] = (red[tid] + red[G::OC + tid]) + (red[2 * G::OC + tid] + red[3 * G::OC + tid]);
+    }
+  }
+};

@@ -272,6 +272,9 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
                                    * previous step, environment step, conv1, conv2, conv3, fc4 -- is ONE launch whose workgroups
                                    * hand their outputs over through arrival counters (4 launches per agent step + the tail
                                    * kernel instead of 17): weights are prefetched before a layer's input exists */
+#define DRA_VAR_MEASURE_DGRAD_ONLY 2097152 /* measurement aid (tools/conv_big_bwd.py): dra_conv_bwd_fused launches ONLY the
+                                          * input-gradient role -- the weight-gradient slabs are NOT written */
+#define DRA_VAR_MEASURE_WGRAD_ONLY 4194304 /* ... ONLY the weight-gradient role -- dx is NOT written */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */

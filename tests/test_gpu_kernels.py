@@ -636,7 +636,7 @@ def test_conv_koc_fwd_bwd_vs_oracle(dev, layer, batch):
 
 
 @pytest.mark.parametrize("layer", [1, 2, 3])
-@pytest.mark.parametrize("batch", [80, 256, 600])
+@pytest.mark.parametrize("batch", [80, 131, 256, 600, 1024])
 def test_conv_autograd_function_at_rollout_batches(dev, layer, batch):
     """nets._ConvKocFn -- what NatureConvBody's layers run under autograd in the generic agents (A2C batch 80, PPO minibatch 256,
     and a batch above the former one-slab-per-sample limit of 256) -- forward, weight / bias gradient (one slab per (sample, row

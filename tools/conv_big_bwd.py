@@ -40,6 +40,12 @@ def main():
                  "bwd": lambda: ops.conv_bwd_fused_koc(layer, dy, x, wt.view(c, kh, kh, oc), ksplit=16, u8_coef=coef, variant=variant)}
         fl_pass = 2.0 * B * oh * oh * oc * c * kh * kh
         flops = {"fwd": fl_pass, "bwd": fl_pass * (1 if layer == 1 else 2)}       # conv1 has no input gradient
+        if layer > 1:       # each role of the backward launch alone (DRA_VAR_MEASURE_*: the other role's outputs are not written)
+            calls["bwd_x_only"] = lambda: ops.conv_bwd_fused_koc(layer, dy, x, wt.view(c, kh, kh, oc), ksplit=16, u8_coef=coef,
+                                                                 variant=variant | 2097152)
+            calls["bwd_w_only"] = lambda: ops.conv_bwd_fused_koc(layer, dy, x, wt.view(c, kh, kh, oc), ksplit=16, u8_coef=coef,
+                                                                 variant=variant | 4194304)
+            flops["bwd_x_only"] = flops["bwd_w_only"] = fl_pass
         for name, call in calls.items():
             for _ in range(5):
                 call()
