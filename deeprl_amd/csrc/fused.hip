@@ -46,6 +46,14 @@ DRA_API int dra_get_tuning(int* mask) {
 // conv1: 4 output rows per chunk, all 8 k tiles per workgroup (uint8 frames, also straight from the replay ring)
 using WG1u = ConvWgradOne<G1, 4, 4, 88, 0, true>;
 using WG1f = ConvWgradOne<G1, 4, 4, 88, 0, false>;
+// rollout batch sizes, persistent over the batch (profiles/r05m_conv_big_roles.jsonl): below 512 samples 10 output rows per chunk,
+// 2 k groups x 256 shares (0.41 of peak at 256); from 512 on all 8 k tiles per workgroup, 5 rows per chunk -- the gradient chunk
+// is staged once for all of K -- x 512 shares (0.54 at 1024)
+using WG1up = ConvWgradOne<G1, 10, 4, 88, 0, true, 256>;
+using WG1fp = ConvWgradOne<G1, 10, 4, 88, 0, false, 256>;
+using WG1uq = ConvWgradOne<G1, 5, 8, 88, 0, true, 512>;
+using WG1fq = ConvWgradOne<G1, 5, 8, 88, 0, false, 512>;
+constexpr int kPersistConv1Batch = 128;
 // conv2 / conv3 (round 4, oneshot_lin.h): one workgroup = one sample x a group of k tiles, operands staged into LDS as they
 // lie in memory.  (The round-2 forms with transposing staging -- ConvWgradOne<G2 / G3>, ConvDgradOne -- and round 3's
 // ConvWgradAcc, which accumulated four samples per workgroup to write a quarter of the slabs, were removed in round 4: same
@@ -68,7 +76,7 @@ DRA_API int dra_conv_wgrad_slabs(int layer, int batch, int ksplit, int variant, 
   const bool pers2 = batch >= PersistFrom<G2>::batch && (variant & DRA_VAR_ONESHOT_DGRAD);
   const bool pers3 = batch >= PersistFrom<G3>::batch && (variant & DRA_VAR_ONESHOT_DGRAD);
   switch (layer) {
-    case 1: *n_slabs = WG1u::n_slabs(batch); return DRA_OK;
+    case 1: *n_slabs = batch >= 512 ? WG1uq::n_slabs(batch) : (batch >= kPersistConv1Batch ? WG1up::n_slabs(batch) : WG1u::n_slabs(batch)); return DRA_OK;
     case 2: *n_slabs = pers2 ? WG2p::n_slabs(batch) : WG2l::n_slabs(batch); return DRA_OK;
     case 3: *n_slabs = pers3 ? WG3p::n_slabs(batch) : WG3l::n_slabs(batch); return DRA_OK;
   }
@@ -129,17 +137,29 @@ static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, con
       if (batch >= PersistFrom<G>::batch && n3 == 0) {
         WPers rp;
         rp.dy = dy; rp.x = x; rp.dw = dw; rp.db = db; rp.slab_stride = slab_stride; rp.B = batch;
-        auto rd = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
+        // (input gradient at these sizes: all position tiles of a sample's phase in one workgroup -- the gradient image staged
+        // once instead of once per tile)
         const bool only_d = variant & DRA_VAR_MEASURE_DGRAD_ONLY, only_w = variant & DRA_VAR_MEASURE_WGRAD_ONLY;
+        if (G::S == 1 && batch < 512) {      // conv3 below 512: one position tile per workgroup keeps the grid large enough
+          auto rd1 = make_dgrad_one<G>(dy, wt, xact, dx, batch, act);
+          if (only_d || only_w) {
+            int rc = DRA_OK;
+            if (!only_d) rc = launch_multi(rp, rp.blocks(), none, 0, none, 0, st);
+            if (rc == DRA_OK && !only_w) rc = launch_multi_tp(rd1, rd1.blocks(), none, 0, none, 0, st);
+            return rc;
+          }
+          return launch_multi_tp(rp, rp.blocks(), rd1, rd1.blocks(), none, 0, st);
+        }
+        auto rd = make_dgrad_one<G, (G::S == 2) ? 2 : 3>(dy, wt, xact, dx, batch, act);
         if (!PersistFrom<G>::one_launch || only_d || only_w) {
           // two launches: the persistent role's LDS image would cost the input-gradient workgroups their occupancy (conv2)
           int rc = DRA_OK;
           if (!only_d) rc = launch_multi(rp, rp.blocks(), none, 0, none, 0, st);
-          if (rc == DRA_OK && !only_w) rc = launch_multi(rd, rd.blocks(), none, 0, none, 0, st);
+          if (rc == DRA_OK && !only_w) rc = launch_multi_tp(rd, rd.blocks(), none, 0, none, 0, st);
           return rc;
         }
         // one launch, the persistent weight-gradient workgroups (its longest) FIRST in the grid (conv3)
-        return launch_multi(rp, rp.blocks(), rd, rd.blocks(), none, 0, st);
+        return launch_multi_tp(rp, rp.blocks(), rd, rd.blocks(), none, 0, st);
       }
     }
     auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
@@ -148,6 +168,7 @@ static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, con
       return launch_multi(rd, (variant & DRA_VAR_MEASURE_WGRAD_ONLY) ? 0 : rd.blocks(), rw,
                           (variant & DRA_VAR_MEASURE_DGRAD_ONLY) ? 0 : rw.blocks(), none, n3, st);
     // (the weight-gradient workgroups, the longer ones, FIRST in the launch: no difference, profiles/r04j_ab_wgrad_tiles_role_order.jsonl)
+    if (batch >= 128 && n3 == 0) return launch_multi_tp(rd, rd.blocks(), rw, rw.blocks(), none, 0, st);     // three waves per SIMD
     return launch_multi(rd, rd.blocks(), rw, rw.blocks(), none, n3, st);
   }
   if constexpr (!std::is_same<R3, NoRole>::value) return DRA_EINVAL;
@@ -181,6 +202,22 @@ DRA_API int dra_conv_bwd_fused(int layer, const float* dy, const void* x, const 
   switch (layer) {
     case 1:
       if (variant & DRA_VAR_ONESHOT_WGRAD) {
+        if (batch >= 512) {
+          if (x_is_u8) {
+            auto rw = make_wgrad_one<WG1uq>(dy, x, dw, db, slab_stride, batch, u8_coef);
+            return launch_multi_tp(rw, rw.blocks(), none, 0, none, 0, st);
+          }
+          auto rw = make_wgrad_one<WG1fq>(dy, x, dw, db, slab_stride, batch, 1.0);
+          return launch_multi_tp(rw, rw.blocks(), none, 0, none, 0, st);
+        }
+        if (batch >= kPersistConv1Batch) {
+          if (x_is_u8) {
+            auto rw = make_wgrad_one<WG1up>(dy, x, dw, db, slab_stride, batch, u8_coef);
+            return launch_multi_tp(rw, rw.blocks(), none, 0, none, 0, st);
+          }
+          auto rw = make_wgrad_one<WG1fp>(dy, x, dw, db, slab_stride, batch, 1.0);
+          return launch_multi_tp(rw, rw.blocks(), none, 0, none, 0, st);
+        }
         if (x_is_u8) {
           auto rw = make_wgrad_one<WG1u>(dy, x, dw, db, slab_stride, batch, u8_coef);
           return launch_multi(rw, rw.blocks(), none, 0, none, 0, st);

@@ -81,6 +81,35 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   else r3.run(b - n1 - n2, dyn_lds, n1 + n2);
 }
 
+// the same launch for throughput-sized grids (rollout batch sizes: thousands of one-sample workgroups): three waves per SIMD
+// instead of two, so that one workgroup's loads / staging / epilogue hide behind two others' MFMAs
+template <class R1, class R2, class R3>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) multi_kernel_tp(const R1 r1, const R2 r2, const R3 r3, const int n1, const int n2) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  const int b = blockIdx.x;
+  if (b < n1) r1.run(b, dyn_lds, 0);
+  else if (b < n1 + n2) r2.run(b - n1, dyn_lds, n1);
+  else r3.run(b - n1 - n2, dyn_lds, n1 + n2);
+}
+
+template <class R1, class R2, class R3>
+static int launch_multi_tp(const R1& r1, int n1, const R2& r2, int n2, const R3& r3, int n3, hipStream_t st) {
+  constexpr int f12 = R1::LDS_FLOATS > R2::LDS_FLOATS ? R1::LDS_FLOATS : R2::LDS_FLOATS;
+  constexpr int fl = f12 > R3::LDS_FLOATS ? f12 : R3::LDS_FLOATS;
+  constexpr size_t bytes = (size_t)fl * sizeof(float);
+  static_assert(bytes <= 160 * 1024, "LDS per workgroup");
+  if (n1 < 0 || n2 < 0 || n3 < 0 || n1 + n2 + n3 < 1) return DRA_EINVAL;
+  static bool attr_set = false;
+  if (bytes > 64 * 1024 && !attr_set) {
+    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&multi_kernel_tp<R1, R2, R3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((multi_kernel_tp<R1, R2, R3>), dim3(n1 + n2 + n3), dim3(256), bytes, st, r1, r2, r3, n1, n2);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 template <class R1, class R2, class R3>
 static int launch_multi(const R1& r1, int n1, const R2& r2, int n2, const R3& r3, int n3, hipStream_t st) {
   constexpr int f12 = R1::LDS_FLOATS > R2::LDS_FLOATS ? R1::LDS_FLOATS : R2::LDS_FLOATS;
@@ -417,7 +446,10 @@ struct LinFwdSlabsOne {
 // lane = oc read.  The two k-slices of an MFMA are the even / odd output columns of the same row, so
 // both operand addresses are `lane base + immediate`.  Every (sample, chunk) writes its own slab:
 // slab index = b * (OH/ROWS) + chunk; the fold happens in the gradient-norm pass (dra_grad_sqnorm_segs).
-template <class G, int ROWS, int MTG, int RW_, int CSPAD, bool U8>
+// SHARES > 0 (rollout batch sizes, round 5): PERSISTENT over the batch -- a workgroup = (k group, share of the batch) walks its
+// samples' chunks with its output tiles resident in the accumulators and writes ONE slab per share (conv1 at batch 1024: 5120
+// slabs of 33 KB, 168 MB written and folded back, became SHARES slabs).
+template <class G, int ROWS, int MTG, int RW_, int CSPAD, bool U8, int SHARES = 0>
 struct ConvWgradOne {
   static constexpr int S = G::S, OH = G::OH, OWP = (OH + 1) & ~1, NPAIR = OWP / 2, NJ = ROWS * NPAIR;
   static constexpr int NCHUNK = OH / ROWS;
@@ -444,23 +476,32 @@ struct ConvWgradOne {
   // (conv1's weight gradient straight from the replay ring); null = image bi of a plain [B][C][H][H] batch
   const int64_t* sample_idx = nullptr;
   int xcd = 0;        // != 0: all workgroups of a sample on one XCD (xcd_order)
-  __host__ int blocks() const { return B * NCHUNK * NGRP; }
-  __host__ static int n_slabs(int batch) { return batch * NCHUNK; }
+  __host__ __device__ static int spw(int batch) { return SHARES ? (batch + SHARES - 1) / SHARES : 1; }   // samples per workgroup
+  __host__ int blocks() const { return SHARES ? ((B + spw(B) - 1) / spw(B)) * NGRP : B * NCHUNK * NGRP; }
+  __host__ static int n_slabs(int batch) { return SHARES ? (batch + spw(batch) - 1) / spw(batch) : batch * NCHUNK; }
   __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
-    const int bid = xcd ? xcd_order(bid_, first, B, NCHUNK * NGRP) : bid_;
+    const int bid = (xcd && !SHARES) ? xcd_order(bid_, first, B, NCHUNK * NGRP) : bid_;
     const int grp = bid % NGRP;
-    int r = bid / NGRP;
-    const int chunk = r % NCHUNK, bi = r / NCHUNK;
+    const int r = bid / NGRP;
+    // the (sample, chunk) pairs this workgroup contracts: one (r) in the one-slab-per-chunk form, a share's in the persistent form
+    const int it0 = SHARES ? r * spw(B) * NCHUNK : r;
+    const int it1 = SHARES ? min(B, (r + 1) * spw(B)) * NCHUNK : r + 1;
     const int k0 = grp * MTG * 32;
     const int c_lo = k0 / G::KK;
     const int c_hi = min((k0 + MTG * 32 - 1) / G::KK, G::C - 1);
     const int nch = c_hi - c_lo + 1;                       // <= NCH
-    const int ir0 = chunk * ROWS * S;                      // first input row
     float* img = lds;
     float* dyl = lds + IMG;
     [[maybe_unused]] constexpr int TRR = (G::C == 4) ? TR_CONV1_B : ((G::C == 32) ? TR_CONV2_B : TR_CONV3_B);
     DRA_STAMP(TRR, 0);
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = zero16();
+    float sb_acc = 0.f;
+    for (int it = it0; it < it1; ++it) {
+    const int chunk = it % NCHUNK, bi = it / NCHUNK;
+    const int ir0 = chunk * ROWS * S;                      // first input row
     // ---- issue all loads: dY chunk, then the image rows.  Loads walk the SOURCE as float4 (a few per lane, one constant
     // division each) instead of one dword per padded LDS cell with two or three divisions (SQ counters: ~1300 VALU
     // instructions per wave around 90 MFMAs, profiles/r02a_sq_learner_b32.json); padding is zero-filled up front.
@@ -581,9 +622,6 @@ struct ConvWgradOne {
     __syncthreads();
     DRA_STAMP(TRR, 2);
     // ---- MFMA: wave w owns tiles w, w+4, ...; tile t = (mt, nt), mt = t / NTL
-    f32x16 acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = zero16();
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const int tile = wave + 4 * t;
@@ -601,9 +639,17 @@ struct ConvWgradOne {
         }
       }
     }
+    if (grp == 0 && tid < G::OC) {  // bias gradient of this (sample, chunk): fixed-order column sum
+      float sb = 0.f;
+#pragma unroll 8
+      for (int pos = 0; pos < NPOS; ++pos) sb += dyl[pos * LDB + tid];
+      sb_acc += sb;
+    }
+    if (it + 1 < it1) __syncthreads();       // (persistent form) every wave has read this chunk's images
+    }
     DRA_STAMP(TRR, 3);
     // ---- slab stores (rows = k, 32 lanes along oc: 128-byte rows)
-    const int64_t slab = (int64_t)bi * NCHUNK + chunk;
+    const int64_t slab = SHARES ? (int64_t)r : (int64_t)it0;
     float* dws = dw + slab * slab_stride;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -617,12 +663,7 @@ struct ConvWgradOne {
         }
       }
     }
-    if (grp == 0 && tid < G::OC) {  // bias gradient of this (sample, chunk): fixed-order column sum
-      float sb = 0.f;
-#pragma unroll 8
-      for (int pos = 0; pos < NPOS; ++pos) sb += dyl[pos * LDB + tid];
-      db[slab * slab_stride + tid] = sb;
-    }
+    if (grp == 0 && tid < G::OC) db[slab * slab_stride + tid] = sb_acc;
     DRA_STAMP(TRR, 5);
     DRA_STAMP_END(TRR);
   }
