@@ -130,7 +130,8 @@ def test_comm_check_on_one_rank():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--comm-check"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-800:]
-    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    # (RCCL's own NCCL_DEBUG=INFO banner shares the stream and is flushed at exit: take the JSON line, not the last line)
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"comm_check"')][-1])
     assert rec["comm_check"] and rec["enough_devices"] and rec["world_size"] == 1
     one = rec["per_rank"][0]
     assert one["rccl_ranks"] == 1 and one["rccl_rank"] == 0 and 0.0 < one["allreduce_us"] < 1e4
