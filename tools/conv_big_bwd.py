@@ -6,7 +6,7 @@ gradient in ONE launch; the one-pass slab kernels up to DRA_ONESHOT_WGRAD_MAX_BA
 gradient above).  tools/conv_big_counters.sh runs this under rocprofv3 (kernel durations) and under a PMC pass
 (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE: counter-derived MFMA utilisation next to the FLOP-derived one).
 
-    python tools/conv_big_bwd.py <batch> [reps]
+    python tools/conv_big_bwd.py <batch> [reps] [roles]      (roles: also the input- / weight-gradient role of conv2 / conv3 alone)
 """
 import json
 import os
@@ -24,6 +24,7 @@ def main():
     dev = d.Config.DEVICE
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    roles = len(sys.argv) > 3 and sys.argv[3] == "roles"     # also time each role of the backward launch alone
     GEOM = {1: (4, 84, 32, 8, 4), 2: (32, 20, 64, 4, 2), 3: (64, 9, 64, 3, 1)}
     out = {}
     for layer, (c, h, oc, kh, s) in GEOM.items():
@@ -40,7 +41,7 @@ def main():
                  "bwd": lambda: ops.conv_bwd_fused_koc(layer, dy, x, wt.view(c, kh, kh, oc), ksplit=16, u8_coef=coef, variant=variant)}
         fl_pass = 2.0 * B * oh * oh * oc * c * kh * kh
         flops = {"fwd": fl_pass, "bwd": fl_pass * (1 if layer == 1 else 2)}       # conv1 has no input gradient
-        if layer > 1:       # each role of the backward launch alone (DRA_VAR_MEASURE_*: the other role's outputs are not written)
+        if layer > 1 and roles:       # each role of the backward launch alone (DRA_VAR_MEASURE_*: the other role's outputs are not written)
             calls["bwd_x_only"] = lambda: ops.conv_bwd_fused_koc(layer, dy, x, wt.view(c, kh, kh, oc), ksplit=16, u8_coef=coef,
                                                                  variant=variant | 2097152)
             calls["bwd_w_only"] = lambda: ops.conv_bwd_fused_koc(layer, dy, x, wt.view(c, kh, kh, oc), ksplit=16, u8_coef=coef,
