@@ -976,6 +976,17 @@ def _rollout_scan(storage, config, bootstrap_v):
     return adv, ret
 
 
+def _begin_rollout(agent, n_env):
+    """Announces a rollout of rollout_length + 1 no-grad forwards over n_env environments to a categorical actor-critic
+    (nets.RolloutSlots: one uniform draw for the whole rollout, results written into persistent rows) -> the slots, or None
+    (another network family, or a rank-invariant sampler is installed)."""
+    slots = getattr(agent.network, 'rollout_slots', None)
+    if slots is None or getattr(agent.network, 'sampler', None) is not None or Config.DEVICE.type != 'cuda':
+        return None
+    slots.begin(int(agent.config.rollout_length) + 1, int(n_env))
+    return slots
+
+
 def _install_sampler(agent):
     """Data-parallel agents (and config.dp_invariant_sampling) sample actions from per-step noise that is the same
     however the environments are spread over ranks (dist.DataParallel.uniforms); everything else keeps the reference's
@@ -1174,18 +1185,29 @@ class A2CAgent(BaseAgent):
 
     def _rollout_compute(self, plan, apply=True):
         config = self.config
+        t_len = config.rollout_length
+        slots = _begin_rollout(self, self.task.num_envs)
+        frames = self.task.states_all(plan)        # every observation of the planned rollout, one launch
         states, actions, values = [], [], []
         with torch.no_grad():
-            for t in range(config.rollout_length):
-                state_t = self._dev_state(self.task.states(plan, t))
+            for t in range(t_len):
+                state_t = self._dev_state(frames[t])
                 prediction = self.network(state_t)
                 self._rollout_step += 1
                 states.append(state_t)
                 actions.append(prediction['action'])
                 values.append(prediction['v'])
-            values.append(self.network(self._dev_state(self.task.states(plan, config.rollout_length)))['v'])
-        return self._learn(states, actions, values, [plan.reward[t] for t in range(config.rollout_length)],
-                           [plan.mask[t] for t in range(config.rollout_length)], apply=apply)
+            values.append(self.network(self._dev_state(frames[t_len]))['v'])
+        if slots is not None:
+            slots.end()
+            if (values[-1].data_ptr() == slots.v[t_len].data_ptr() and states[-1].data_ptr() == frames[t_len - 1].data_ptr()):
+                # the forwards wrote into the slots' rows and read the frames in place: the rollout IS these buffers (no stack / cat)
+                n = self.task.num_envs
+                return self._learn_stacked(frames[:t_len].reshape((t_len * n,) + tuple(frames.shape[2:])),
+                                           slots.action[:t_len].reshape(-1), slots.v[:t_len + 1].unsqueeze(-1), plan.reward,
+                                           plan.mask, apply=apply)
+        return self._learn(states, actions, values, [plan.reward[t] for t in range(t_len)],
+                           [plan.mask[t] for t in range(t_len)], apply=apply)
 
     def _learn_apply(self, out4=None):
         """The part of an update behind the backward pass: gradient exchange (data parallel: the loss is the mean over this
@@ -1203,22 +1225,29 @@ class A2CAgent(BaseAgent):
         stored observations with the stored actions gives the same log-probabilities, entropies and values and ONE
         backward the same gradient (up to fp32 summation order) -- T-fold fewer backward launches and no gradient
         accumulation passes (rocprofv3, profiles/r02z9_*: 490 launches per A2C step, 86 of them `grad += ...`)."""
-        config = self.config
-        t_len = config.rollout_length
-        value = torch.stack(values).contiguous()
-        adv, ret = ops.gae(torch.stack(rewards).contiguous(), torch.stack(masks).contiguous(), value, config.discount,
-                           config.gae_tau, config.use_gae)
         # (stored actions: [N] per step for Categorical policies, [N, action_dim] for Gaussian ones -- a2c_continuous,
         # examples.py:384-404 -- so the environment axis is concatenated and the action axis kept)
-        prediction = self.network(torch.cat(states, dim=0), torch.cat(actions, dim=0))
+        return self._learn_stacked(torch.cat(states, dim=0), torch.cat(actions, dim=0), torch.stack(values).contiguous(),
+                                   torch.stack(rewards).contiguous(), torch.stack(masks).contiguous(), apply=apply)
+
+    def _learn_stacked(self, states, actions, value, reward, mask, apply=True):
+        """_learn on a rollout that is already laid out: states [T * N, ...], actions [T * N(, A)], value [T + 1, N, 1],
+        reward / mask [T, N, 1]."""
+        config = self.config
+        adv, ret = ops.gae(reward, mask, value, config.discount, config.gae_tau, config.use_gae)
+        prediction = self.network(states, actions)
         out4, (g_lp, g_ent, g_v) = ops.a2c_loss(prediction['log_pi_a'].detach(), prediction['entropy'].detach(),
                                                 prediction['v'].detach(), adv.reshape(-1, 1), ret.reshape(-1, 1),
                                                 config.entropy_weight, config.value_loss_weight)
-        self._fused.zero_grad()
+        self._fused.zero_grad(direct=not self.dp.active)
         # (one batched forward: every parameter is used once -> the layers write their gradients in place, nets.direct_param_grads;
         # data parallel keeps autograd's accumulation: its post-accumulate hooks start the early gradient exchange)
         from .nets import direct_param_grads
-        with direct_param_grads(not self.dp.active):
+        # (the optimizer step follows with nothing reading the gradient in between -> the conv layers' slab folds ride in its
+        # norm launch; config.defer_conv_folds = False restores one fold launch per layer)
+        defer = self._fused if (apply and not self.dp.active and self.grad_hook is None
+                                and getattr(config, 'defer_conv_folds', True)) else None
+        with direct_param_grads(not self.dp.active, defer_folds_to=defer, covers=[self._fused]):
             torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']], [g_lp, g_ent, g_v])
         return self._learn_apply(out4) if apply else out4
 
@@ -1228,6 +1257,7 @@ class A2CAgent(BaseAgent):
         config = self.config
         states = self.states
         seen, actions, values, rewards_l, masks_l = [], [], [], [], []
+        slots = _begin_rollout(self, len(states))       # the same single draw per rollout as the device path
         for _ in range(config.rollout_length):
             with torch.no_grad():
                 state_t = tensor(config.state_normalizer(states))
@@ -1246,6 +1276,8 @@ class A2CAgent(BaseAgent):
         self.states = states
         with torch.no_grad():
             values.append(self.network(config.state_normalizer(states))['v'])
+        if slots is not None:
+            slots.end()
         self.last_loss = self._learn(seen, actions, values, rewards_l, masks_l)
 
 
@@ -1389,22 +1421,39 @@ class PPOAgent(BaseAgent):
 
     def _rollout_compute(self, plan, normalise=True):
         config = self.config
-        storage = Storage(config.rollout_length)
+        t_len = config.rollout_length
+        slots = _begin_rollout(self, self.task.num_envs)
+        frames = self.task.states_all(plan)        # every observation of the planned rollout, one launch
+        storage = Storage(t_len)
         with torch.no_grad():
-            for t in range(config.rollout_length):
-                state_t = self._dev_state(self.task.states(plan, t))
+            for t in range(t_len):
+                state_t = self._dev_state(frames[t])
                 prediction = self.network(state_t)
                 self._rollout_step += 1
                 storage.feed(prediction)
                 storage.feed({'reward': plan.reward[t], 'mask': plan.mask[t], 'state': state_t})
-            prediction = self.network(self._dev_state(self.task.states(plan, config.rollout_length)))
+            prediction = self.network(self._dev_state(frames[t_len]))
             self._rollout_step += 1
-        storage.feed(prediction)
-        storage.placeholder()
-        _rollout_scan(storage, config, prediction['v'])
-        entries = storage.extract(['state', 'action', 'log_pi_a', 'ret', 'advantage'])
-        entry_cls = entries.__class__
-        entries = entry_cls(*[x.detach() for x in entries])
+        if slots is not None:
+            slots.end()
+        if (slots is not None and prediction['v'].data_ptr() == slots.v[t_len].data_ptr()
+                and state_t.data_ptr() == frames[t_len - 1].data_ptr()):
+            # the forwards wrote into the slots' rows and read the frames in place: the rollout IS these buffers (Storage's
+            # per-key torch.cat launches and the reward / mask / value stacks of the scan disappear)
+            from collections import namedtuple
+            rows = t_len * self.task.num_envs
+            adv, ret = ops.gae(plan.reward, plan.mask, slots.v[:t_len + 1].unsqueeze(-1), config.discount, config.gae_tau,
+                               config.use_gae)
+            entry_cls = namedtuple('Entry', ['state', 'action', 'log_pi_a', 'ret', 'advantage'])
+            entries = entry_cls(frames[:t_len].reshape((rows,) + tuple(frames.shape[2:])), slots.action[:t_len].reshape(rows),
+                                slots.log_pi_a[:t_len].reshape(rows, 1), ret.reshape(rows, 1), adv.reshape(rows, 1))
+        else:
+            storage.feed(prediction)
+            storage.placeholder()
+            _rollout_scan(storage, config, prediction['v'])
+            entries = storage.extract(['state', 'action', 'log_pi_a', 'ret', 'advantage'])
+            entry_cls = entries.__class__
+            entries = entry_cls(*[x.detach() for x in entries])
         if not normalise:
             return entries
         if self.dp.active:
@@ -1463,6 +1512,7 @@ class PPOAgent(BaseAgent):
         config = self.config
         storage = Storage(config.rollout_length)
         states = self.states
+        slots = _begin_rollout(self, len(states))       # the same single draw per rollout as the device path
         for _ in range(config.rollout_length):
             prediction, state_t = self._act(states)
             self._rollout_step += 1
@@ -1478,6 +1528,8 @@ class PPOAgent(BaseAgent):
         self.states = states
         prediction, _ = self._act(states)
         self._rollout_step += 1
+        if slots is not None:
+            slots.end()
         storage.feed(prediction)
         storage.placeholder()
         _rollout_scan(storage, config, prediction['v'])
@@ -1516,6 +1568,13 @@ class PPOAgent(BaseAgent):
                         g['events'] = [None] * 4
                         torch.distributions.Distribution.set_default_validate_args(False)
                         graph = torch.cuda.CUDAGraph()
+                        # (a categorical net reads its uniforms from the rollout's one draw: the captured forward reads a static
+                        # row that every replay fills from that draw first)
+                        slots = getattr(self.network, 'rollout_slots', None)
+                        g['u'] = None
+                        if slots is not None and getattr(self.network, 'sampler', None) is None:
+                            g['u'] = torch.zeros(x.shape[0], dtype=torch.float32, device=Config.DEVICE)
+                            slots.pin(g['u'])
                         torch.cuda.synchronize()
                         with _capture(graph):
                             with torch.no_grad():
@@ -1526,6 +1585,8 @@ class PPOAgent(BaseAgent):
                         g['failed'] = True
                     finally:
                         torch.distributions.Distribution.set_default_validate_args(validate)
+                        if getattr(self.network, 'rollout_slots', None) is not None:
+                            self.network.rollout_slots.pin(None)
                 if not g['failed']:
                     k = g['k']
                     g['k'] = (k + 1) % 4
@@ -1536,6 +1597,12 @@ class PPOAgent(BaseAgent):
                     ev = torch.cuda.Event()
                     ev.record()
                     g['events'][k] = ev
+                    if g['u'] is not None:
+                        u = self.network.rollout_slots.next_uniform()
+                        if u is not None and u.numel() == g['u'].numel():
+                            g['u'].copy_(u)
+                        else:
+                            g['u'].uniform_()
                     g['graph'].replay()
                     return {key: v.clone() for key, v in g['out'].items()}, g['in'].clone()
         with torch.no_grad():
@@ -1558,11 +1625,13 @@ class PPOAgent(BaseAgent):
         else:       # this rank holds no row of the global minibatch: it still takes part in the exchange
             prediction, out3, g_lp, g_ent, g_v = None, torch.zeros(3, device=Config.DEVICE), None, None, None
         if config.shared_repr:
-            self._fused.zero_grad()
+            self._fused.zero_grad(direct=not dp.active and prediction is not None)
             dp.set_weight(weight)       # (the fc4 segment of the exchange goes out from inside the backward pass: dist.py)
             if prediction is not None:
                 from .nets import direct_param_grads
-                with direct_param_grads(not dp.active):       # (one forward per minibatch: see A2CAgent._learn)
+                defer = self._fused if (not dp.active and self.grad_hook is None
+                                        and getattr(config, 'defer_conv_folds', True)) else None
+                with direct_param_grads(not dp.active, defer_folds_to=defer, covers=[self._fused]):     # (one forward per minibatch: see A2CAgent._learn)
                     torch.autograd.backward([prediction['log_pi_a'], prediction['entropy'], prediction['v']],
                                             [g_lp, g_ent, g_v])
             dp.sum_grads(self._fused.flat.grad, weight)
@@ -1665,7 +1734,7 @@ class _GraphedPPO:
     def _capture(self, entry_cls):
         a = self.agent
         cfg = a.config
-        rows = lambda: entry_cls(*[x[self.idx] for x in self.static])
+        rows = lambda: entry_cls(*ops.gather_rows(list(self.static), self.idx))     # all five fields, one launch
         opts = [a._fused] if cfg.shared_repr else [a._fused_actor, a._fused_critic]
         for o in opts:
             o.enable_graph_mode()
@@ -1747,7 +1816,7 @@ class _GraphedPPO:
                     else:
                         out3 = self._eager_split(entry_cls(*[x[bi] for x in self.static]))
                     continue
-                self.idx.copy_(self._up.upload(np.asarray(batch_indices, dtype=np.int64)), non_blocking=True)
+                self._up.upload_into(self.idx, np.asarray(batch_indices, dtype=np.int64))
                 if cfg.shared_repr:
                     a._fused.prepare_step()
                     self.graphs['all'].replay()

@@ -47,6 +47,53 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Categorical(logits = x[0..A)) of one sample (network_heads.py:249-254): log-softmax, entropy, and -- when no action is given --
+// the inverse-CDF draw from one uniform (first a with cumsum(p)[a] > u; the last action absorbs rounding).  ONE statement shared
+// by categorical_fwd_kernel (losses.hip) and the fused rollout head (igemm.hip: policy_heads_sample_kernel), so that both give
+// the same bits for the same logits.
+__device__ __forceinline__ void categorical_row(const float* x, int A, bool given, int64_t action_in, float ub, int64_t* act_out,
+                                                float* log_pi_a, float* entropy) {
+  float m = x[0];
+  for (int a = 1; a < A; ++a) m = fmaxf(m, x[a]);
+  float se = 0.f;
+  for (int a = 0; a < A; ++a) se += expf(x[a] - m);
+  const float lse = m + logf(se);
+  int64_t act = given ? action_in : (int64_t)(A - 1);
+  float ent = 0.f, cum = 0.f;
+  bool found = given;
+  for (int a = 0; a < A; ++a) {
+    const float lp = x[a] - lse, p = expf(lp);
+    ent -= p * lp;
+    cum += p;
+    if (!found && cum > ub) { act = a; found = true; }
+  }
+  if (act < 0) act = 0;
+  if (act >= A) act = A - 1;
+  *act_out = act;
+  *log_pi_a = x[act] - lse;
+  *entropy = ent;
+}
+
+// Backward of the same: dlogits[a] = g_lp (1[a == action] - p[a]) - g_ent p[a] (logp[a] + entropy).  categorical_row_stats gives
+// the row's log-sum-exp and entropy (the sums in ascending a, as the forward forms them); categorical_dlogit one component.
+// Shared by categorical_bwd_kernel (losses.hip) and the fused head backward (igemm.hip: policy_heads_bwd_kernel).
+__device__ __forceinline__ void categorical_row_stats(const float* x, int A, float* lse_out, float* ent_out) {
+  float m = x[0];
+  for (int a = 1; a < A; ++a) m = fmaxf(m, x[a]);
+  float se = 0.f;
+  for (int a = 0; a < A; ++a) se += expf(x[a] - m);
+  const float lse = m + logf(se);
+  float ent = 0.f;
+  for (int a = 0; a < A; ++a) { const float lp = x[a] - lse; ent -= expf(lp) * lp; }
+  *lse_out = lse;
+  *ent_out = ent;
+}
+__device__ __forceinline__ float categorical_dlogit(float xa, float lse, float ent, bool is_action, float gl, float ge) {
+  const float lp = xa - lse, p = expf(lp);
+  return gl * ((is_action ? 1.f : 0.f) - p) - ge * p * (lp + ent);
+}
+
+// ------------------------------------------------------------------------------------------------
 // XCD-aware workgroup order.  MI355X dispatches the workgroups of a launch round-robin over its 8 XCDs (blockIdx mod 8;
 // wgs_per_xcd in every phase trace under profiles/) and every XCD has its own L2: with the natural (sample-major) block
 // order the 8-13 workgroups that share one sample's operands land on 8 different XCDs and every L2 fetches that sample

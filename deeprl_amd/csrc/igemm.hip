@@ -301,13 +301,11 @@ static int gemv_enabled() {
 // butterflies run interleaved.  Per-output arithmetic (lane-strided partial sums in i order, then the butterfly) is exactly
 // linear_gemv_kernel's: the update's forward through the two Linear modules reproduces these values bit for bit.
 // (The staging form took 12.7 us for 16 rows x 5 outputs, 15 % of an A2C agent step: profiles/r04ab_kernel_stats_a2c_pixel_16.txt.)
-__global__ void __launch_bounds__(256)
-linear_heads_rows_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ b0,
-                         float* __restrict__ y0, int O0, const float* __restrict__ w1, const float* __restrict__ b1,
-                         float* __restrict__ y1, int O1, int B, int K, int act) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + wave;
-  if (b >= B) return;
+// heads_row_outputs: the wave's work for input row b; sink(o, value) runs on lane 0 for every output o of [0, O0 + O1).
+template <class Sink>
+__device__ __forceinline__ void heads_row_outputs(const float* __restrict__ x, const float* __restrict__ w0,
+                                                  const float* __restrict__ b0, int O0, const float* __restrict__ w1,
+                                                  const float* __restrict__ b1, int O1, int b, int K, int act, int lane, Sink sink) {
   float xv[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) xv[i] = (lane + 64 * i < K) ? x[(int64_t)b * K + lane + 64 * i] : 0.f;
@@ -340,14 +338,182 @@ linear_heads_rows_kernel(const float* __restrict__ x, const float* __restrict__ 
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int o = oc + u;
-        if (o < OT) {
-          const float v = act_apply(part[u] + bias[u], act);
-          if (o < O0) y0[(int64_t)b * O0 + o] = v;
-          else y1[(int64_t)b * O1 + (o - O0)] = v;
-        }
+        if (o < OT) sink(o, act_apply(part[u] + bias[u], act));
       }
     }
   }
+}
+
+__global__ void __launch_bounds__(256)
+linear_heads_rows_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ b0,
+                         float* __restrict__ y0, int O0, const float* __restrict__ w1, const float* __restrict__ b1,
+                         float* __restrict__ y1, int O1, int B, int K, int act) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  heads_row_outputs(x, w0, b0, O0, w1, b1, O1, b, K, act, lane, [&](int o, float v) {
+    if (o < O0) y0[(int64_t)b * O0 + o] = v;
+    else y1[(int64_t)b * O1 + (o - O0)] = v;
+  });
+}
+
+// A rollout step's whole policy head (network_heads.py:240-255 under no_grad, action = None) in ONE launch: the two heads above,
+// then Categorical(logits) of the row -- inverse-CDF sample from uniform[b], log_pi_a, entropy (common.h categorical_row: the
+// statement categorical_fwd_kernel runs) -- on the lane that holds the row's outputs.  Three launches of ~4.5 us each (heads,
+// torch.rand, categorical_fwd) in a rollout step of eight before (profiles/r05q_kernel_stats_a2c_pixel_16.txt); the uniforms now
+// come from one draw per rollout (nets.RolloutSlots).  Bit-identical with the separate launches for the same uniforms.
+__global__ void __launch_bounds__(256)
+policy_heads_sample_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ b0, int A,
+                           const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ uniform,
+                           const int64_t* __restrict__ action_in, int B, int K, int64_t* __restrict__ out_action,
+                           float* __restrict__ out_lp, float* __restrict__ out_ent, float* __restrict__ out_v,
+                           float* __restrict__ out_logits) {
+  __shared__ float s_out[4][68];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  float* so = s_out[wave];
+  heads_row_outputs(x, w0, b0, A, w1, b1, 1, b, K, /*act=*/0, lane, [&](int o, float v) { so[o] = v; });
+  if (lane == 0) {      // (the same lane wrote so[]: program order, no barrier)
+    int64_t act;
+    float lp, ent;
+    categorical_row(so, A, action_in != nullptr, action_in ? action_in[b] : 0, uniform ? uniform[b] : 0.f, &act, &lp, &ent);
+    if (out_action) out_action[b] = act;
+    out_lp[b] = lp;
+    out_ent[b] = ent;
+    out_v[b] = so[A];
+    if (out_logits)
+      for (int a = 0; a < A; ++a) out_logits[(int64_t)b * A + a] = so[a];
+  }
+}
+
+DRA_API int dra_policy_heads_sample(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                                    const float* uniform, int batch, int in_features, int n_actions, int64_t* out_action,
+                                    float* out_log_pi_a, float* out_entropy, float* out_v, float* out_logits, void* stream) {
+  if (!x || !w0 || !w1 || !uniform || !out_action || !out_log_pi_a || !out_entropy || !out_v || batch < 1 || batch > 65536 ||
+      in_features < 1 || in_features > 512 || n_actions < 1 || n_actions > 64)
+    return DRA_EINVAL;
+  hipLaunchKernelGGL(policy_heads_sample_kernel, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), x, w0, b0, n_actions, w1,
+                     b1, uniform, (const int64_t*)nullptr, batch, in_features, out_action, out_log_pi_a, out_entropy, out_v,
+                     out_logits);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// The same launch for GIVEN actions (the update's forward, network_heads.py:249-254 with action != None): log_pi_a / entropy of
+// the stored actions, v, and the logits the backward needs.
+DRA_API int dra_policy_heads_given(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                                   const int64_t* action, int batch, int in_features, int n_actions, float* out_log_pi_a,
+                                   float* out_entropy, float* out_v, float* out_logits, void* stream) {
+  if (!x || !w0 || !w1 || !action || !out_log_pi_a || !out_entropy || !out_v || !out_logits || batch < 1 || batch > 65536 ||
+      in_features < 1 || in_features > 512 || n_actions < 1 || n_actions > 64)
+    return DRA_EINVAL;
+  hipLaunchKernelGGL(policy_heads_sample_kernel, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), x, w0, b0, n_actions, w1,
+                     b1, (const float*)nullptr, action, batch, in_features, (int64_t*)nullptr, out_log_pi_a, out_entropy, out_v,
+                     out_logits);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// Backward of that head in ONE launch: categorical_bwd_kernel (dlogits from g_log_pi_a / g_entropy), linear_pair_bwd_kernel
+// (d phi, both layers' weight / bias gradients) and -- when phi is the output of a fused ReLU -- act_bwd_kernel's mask were three
+// launches of ~5-12 us on the update's dependent chain (profiles/r05r_kernel_stats_*).  Same sums in the same order:
+//   workgroups [0, B): input row b.  Lanes a < A of wave 0 form dlogits[b][a] (each walks the row's A logits itself: the
+//     forward's ascending sums), then thread t owns k = t, t + 256:  dx[b][k] = sum_a dlogits[a] W0[a][k] + g_v[b] W1[0][k],
+//     times [x[b][k] > 0] with relu_mask
+//   workgroups [B, B + 2 (A + 1)): (output row, half of K).  The row's gradient column over all samples is formed in LDS first
+//     (thread t: samples t, t + 256, ...), then dW[o][k] = sum_b g[b][o] x[b][k], db[o] = sum_b g[b][o] in ascending b.
+constexpr int kHeadsBwdMaxBatch = 8192;    // the gradient column in LDS (32 KB)
+__global__ void __launch_bounds__(256)
+policy_heads_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ action, const float* __restrict__ g_lp,
+                        const float* __restrict__ g_ent, const float* __restrict__ g_v, const float* __restrict__ x,
+                        const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ dx,
+                        float* __restrict__ dw0, float* __restrict__ db0, float* __restrict__ dw1, float* __restrict__ db1,
+                        int B, int K, int A, int relu_mask) {
+  extern __shared__ float s_g[];      // dx workgroups: [A]; weight-gradient workgroups: [B]
+  const int t = threadIdx.x;
+  if ((int)blockIdx.x < B) {
+    if (!dx) return;
+    const int b = blockIdx.x;
+    if (t < A) {
+      const float* xr = logits + (int64_t)b * A;
+      float lse, ent;
+      categorical_row_stats(xr, A, &lse, &ent);
+      s_g[t] = categorical_dlogit(xr[t], lse, ent, (int64_t)t == action[b], g_lp ? g_lp[b] : 0.f, g_ent ? g_ent[b] : 0.f);
+    }
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f;
+    const int k0 = t, k1 = t + 256;
+    for (int o = 0; o < A; ++o) {
+      const float g = s_g[o];
+      if (k0 < K) a0 += g * w0[(int64_t)o * K + k0];
+      if (k1 < K) a1 += g * w0[(int64_t)o * K + k1];
+    }
+    float c0 = 0.f, c1 = 0.f;
+    {
+      const float g = g_v ? g_v[b] : 0.f;
+      if (k0 < K) c0 += g * w1[k0];
+      if (k1 < K) c1 += g * w1[k1];
+    }
+    if (k0 < K) { const float v = a0 + c0; dx[(int64_t)b * K + k0] = (!relu_mask || x[(int64_t)b * K + k0] > 0.f) ? v : 0.f; }
+    if (k1 < K) { const float v = a1 + c1; dx[(int64_t)b * K + k1] = (!relu_mask || x[(int64_t)b * K + k1] > 0.f) ? v : 0.f; }
+    return;
+  }
+  const int r = blockIdx.x - B, row = r >> 1, k = (r & 1) * 256 + t;
+  const bool first = row < A;
+  const int o = first ? row : 0;
+  for (int b = t; b < B; b += 256) {
+    float g;
+    if (first) {
+      const float* xr = logits + (int64_t)b * A;
+      float lse, ent;
+      categorical_row_stats(xr, A, &lse, &ent);
+      g = categorical_dlogit(xr[o], lse, ent, (int64_t)o == action[b], g_lp ? g_lp[b] : 0.f, g_ent ? g_ent[b] : 0.f);
+    } else {
+      g = g_v ? g_v[b] : 0.f;
+    }
+    s_g[b] = g;
+  }
+  __syncthreads();
+  float acc = 0.f, accb = 0.f;
+  int b = 0;
+  for (; b + 32 <= B; b += 32) {        // linear_pair_bwd_kernel's rounds: 32 samples' loads in flight, ascending b
+    float h[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) h[i] = k < K ? x[(int64_t)(b + i) * K + k] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { const float d = s_g[b + i]; acc += d * h[i]; accb += d; }
+  }
+  for (; b + 8 <= B; b += 8) {
+    float h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = k < K ? x[(int64_t)(b + i) * K + k] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float d = s_g[b + i]; acc += d * h[i]; accb += d; }
+  }
+  for (; b < B; ++b) {
+    const float d = s_g[b];
+    acc += d * (k < K ? x[(int64_t)b * K + k] : 0.f);
+    accb += d;
+  }
+  float* __restrict__ dw = first ? dw0 : dw1;
+  float* __restrict__ db = first ? db0 : db1;
+  if (k < K) dw[(int64_t)o * K + k] = acc;
+  if (k == 0) db[o] = accb;
+}
+
+DRA_API int dra_policy_heads_bwd(const float* logits, const int64_t* action, const float* g_log_pi_a, const float* g_entropy,
+                                 const float* g_v, const float* x, const float* w0, const float* w1, float* dx, float* dw0,
+                                 float* db0, float* dw1, float* db1, int batch, int in_features, int n_actions, int relu_mask,
+                                 void* stream) {
+  if (!logits || !action || !x || !w0 || !w1 || !dw0 || !db0 || !dw1 || !db1 || batch < 1 || batch > kHeadsBwdMaxBatch ||
+      in_features < 1 || in_features > 512 || n_actions < 1 || n_actions > 64)
+    return DRA_EINVAL;
+  const size_t lds = sizeof(float) * (size_t)(batch > 64 ? batch : 64);
+  hipLaunchKernelGGL(policy_heads_bwd_kernel, dim3(batch + 2 * (n_actions + 1)), dim3(256), lds, dra_stream(stream), logits, action,
+                     g_log_pi_a, g_entropy, g_v, x, w0, w1, dx, dw0, db0, dw1, db1, batch, in_features, n_actions, relu_mask);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
 }
 
 DRA_API int dra_linear_fwd_pair(const float* x, const float* w0, const float* b0, float* y0, int out0, const float* w1,

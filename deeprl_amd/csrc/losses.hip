@@ -471,26 +471,11 @@ categorical_fwd_kernel(const float* __restrict__ logits, int B, int A, const int
                        float* __restrict__ entropy) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const float* x = logits + (int64_t)b * A;
-  float m = x[0];
-  for (int a = 1; a < A; ++a) m = fmaxf(m, x[a]);
-  float se = 0.f;
-  for (int a = 0; a < A; ++a) se += expf(x[a] - m);
-  const float lse = m + logf(se);
-  int64_t act = action_in ? action_in[b] : (int64_t)(A - 1);
-  float ent = 0.f, cum = 0.f;
-  bool found = action_in != nullptr;
-  const float ub = u ? u[b] : 0.f;
-  for (int a = 0; a < A; ++a) {
-    const float lp = x[a] - lse, p = expf(lp);
-    ent -= p * lp;
-    cum += p;
-    if (!found && cum > ub) { act = a; found = true; }
-  }
-  if (act < 0) act = 0;
-  if (act >= A) act = A - 1;
+  int64_t act;
+  float lp, ent;
+  categorical_row(logits + (int64_t)b * A, A, action_in != nullptr, action_in ? action_in[b] : 0, u ? u[b] : 0.f, &act, &lp, &ent);
   if (action_out) action_out[b] = act;
-  log_pi_a[b] = x[act] - lse;
+  log_pi_a[b] = lp;
   entropy[b] = ent;
 }
 
@@ -500,19 +485,11 @@ categorical_bwd_kernel(const float* __restrict__ logits, int B, int A, const int
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float* x = logits + (int64_t)b * A;
-  float m = x[0];
-  for (int a = 1; a < A; ++a) m = fmaxf(m, x[a]);
-  float se = 0.f;
-  for (int a = 0; a < A; ++a) se += expf(x[a] - m);
-  const float lse = m + logf(se);
-  float ent = 0.f;
-  for (int a = 0; a < A; ++a) { const float lp = x[a] - lse; ent -= expf(lp) * lp; }
+  float lse, ent;
+  categorical_row_stats(x, A, &lse, &ent);
   const float gl = g_lp ? g_lp[b] : 0.f, ge = g_ent ? g_ent[b] : 0.f;
   const int64_t act = action[b];
-  for (int a = 0; a < A; ++a) {
-    const float lp = x[a] - lse, p = expf(lp);
-    dlogits[(int64_t)b * A + a] = gl * ((a == act ? 1.f : 0.f) - p) - ge * p * (lp + ent);
-  }
+  for (int a = 0; a < A; ++a) dlogits[(int64_t)b * A + a] = categorical_dlogit(x[a], lse, ent, a == act, gl, ge);
 }
 
 DRA_API int dra_categorical_fwd(const float* logits, int batch, int n_actions, const int64_t* action_in, const float* uniform,

@@ -340,6 +340,64 @@ u8_lut_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t n
   for (int64_t t = (n16 << 4) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) out[t] = s_lut[in[t]];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Minibatch rows of an on-policy rollout (PPO_agent.py:77-80: `entry = entries[batch_indices]` over state / action / log_pi_a /
+// ret / advantage): up to DRA_GATHER_MAX_FIELDS row-major arrays gathered by ONE index vector in ONE launch -- ATen's x[idx]
+// is a launch per field (four index kernels + one vectorised gather, 24 us of a 330 us ppo_pixel minibatch,
+// profiles/r05s_kernel_stats_ppo_pixel_8.txt).  Workgroup (r, c): chunk c of row idx[r] of every field that has one
+// (16-byte vectors when the row size and both pointers allow, else bytes); grid (n_rows, max chunks), a chunk = 4 KB.
+struct GatherFields {
+  const uint8_t* src[DRA_GATHER_MAX_FIELDS];
+  uint8_t* dst[DRA_GATHER_MAX_FIELDS];
+  int64_t row_bytes[DRA_GATHER_MAX_FIELDS];
+  int32_t vec16[DRA_GATHER_MAX_FIELDS];
+  int32_t n_fields;
+};
+constexpr int kGatherChunk = 4096;
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const GatherFields f, const int64_t* __restrict__ idx, int64_t n_src_rows) {
+  const int r = blockIdx.x;
+  const int64_t c0 = (int64_t)blockIdx.y * kGatherChunk;
+  int64_t i = idx[r];
+  if (i < 0) i += n_src_rows;                     // (torch indexing semantics for negative indices)
+  for (int q = 0; q < f.n_fields; ++q) {
+    const int64_t rb = f.row_bytes[q];
+    if (c0 >= rb) continue;
+    const int64_t n = min((int64_t)kGatherChunk, rb - c0);
+    const uint8_t* s_ = f.src[q] + i * rb + c0;
+    uint8_t* d_ = f.dst[q] + (int64_t)r * rb + c0;
+    if (f.vec16[q]) {
+      const u32x4* s4 = reinterpret_cast<const u32x4*>(s_);
+      u32x4* d4 = reinterpret_cast<u32x4*>(d_);
+      const int t = threadIdx.x;                  // a chunk is exactly 256 vectors
+      if (16 * (int64_t)t < n) d4[t] = s4[t];
+    } else {
+      for (int64_t t = threadIdx.x; t < n; t += 256) d_[t] = s_[t];
+    }
+  }
+}
+
+DRA_API int dra_gather_rows(int n_fields, const void* const* src, void* const* dst, const int64_t* row_bytes, const int64_t* idx_dev,
+                            int n_rows, int64_t n_src_rows, void* stream) {
+  if (n_fields < 1 || n_fields > DRA_GATHER_MAX_FIELDS || !src || !dst || !row_bytes || !idx_dev || n_rows < 1 || n_src_rows < 1)
+    return DRA_EINVAL;
+  GatherFields f;
+  memset(&f, 0, sizeof(f));
+  int64_t max_rb = 0;
+  for (int q = 0; q < n_fields; ++q) {
+    if (!src[q] || !dst[q] || row_bytes[q] < 1) return DRA_EINVAL;
+    f.src[q] = (const uint8_t*)src[q]; f.dst[q] = (uint8_t*)dst[q]; f.row_bytes[q] = row_bytes[q];
+    f.vec16[q] = ((row_bytes[q] & 15) == 0 && ((((uintptr_t)src[q]) | ((uintptr_t)dst[q])) & 15) == 0) ? 1 : 0;
+    if (row_bytes[q] > max_rb) max_rb = row_bytes[q];
+  }
+  f.n_fields = n_fields;
+  const int64_t chunks = (max_rb + kGatherChunk - 1) / kGatherChunk;
+  if (chunks > 65535) return DRA_EINVAL;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(n_rows, (unsigned)chunks), dim3(256), 0, dra_stream(stream), f, idx_dev, n_src_rows);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 DRA_API int dra_u8_to_f32_lut(const void* in_u8, float* out, int64_t n, const float* lut256_dev, void* stream) {
   if (!in_u8 || !out || !lut256_dev || n < 0) return DRA_EINVAL;
   if (n == 0) return DRA_OK;

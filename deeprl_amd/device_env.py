@@ -143,6 +143,20 @@ class DeviceAtariVec:
                              ctypes.c_void_p(out.data_ptr()), stream_ptr())
         return out
 
+    def states_all(self, plan):
+        """uint8 [t_len + 1, N, history, 84, 84]: the observations of every step of the planned rollout (row t_len: the
+        bootstrap observation) from ONE launch -- the environment is a pure function of the planned counters, so nothing orders
+        observation t + 1 behind action t; states(plan, t) row by row costs a launch per rollout step."""
+        rows = (plan.t_len + 1) * self.num_envs
+        key = ('seeds', plan.t_len)
+        if key not in self._bufs:
+            self._bufs[key] = self.seeds.repeat(plan.t_len + 1).contiguous()
+        out = torch.empty((plan.t_len + 1, self.num_envs, self.history, 84, 84), dtype=torch.uint8, device=Config.DEVICE)
+        lib.dra_synth_stacks(ctypes.c_void_p(plan.counters.data_ptr()), ctypes.c_void_p(plan.ages.data_ptr()),
+                             ctypes.c_void_p(self._bufs[key].data_ptr()), rows, self.history, ctypes.c_void_p(out.data_ptr()),
+                             stream_ptr())
+        return out
+
     def step(self, actions):
         raise RuntimeError("DeviceAtariVec is driven through plan() / states(); its environments are not steppable one by one")
 

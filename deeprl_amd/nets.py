@@ -51,20 +51,36 @@ _DIRECT = [False]
 _WRITTEN = set()        # ids of the parameters whose .grad the current backward pass has already overwritten
 
 
+_SHARED = [False]       # the current backward pass reached some parameter a second time
+_DEFER = [None]         # the optimizer (optim.FusedOptimizer) that will fold the conv layers' slabs in its own norm launch
+
+
 @contextlib.contextmanager
-def direct_param_grads(enable=True):
+def direct_param_grads(enable=True, defer_folds_to=None, covers=()):
     """Inside the context the layer Functions write each parameter's gradient straight into its .grad the FIRST time the
     backward pass reaches it; a parameter reached again (a module applied twice in one forward: weight sharing, siamese or
     recurrent bodies) gets its further contributions through autograd's own accumulation, on top of the direct write -- the sum
-    is what plain accumulation gives (a second overwrite would silently drop the first contribution)."""
-    prev = _DIRECT[0]
+    is what plain accumulation gives (a second overwrite would silently drop the first contribution).
+    defer_folds_to (a FusedOptimizer whose step() follows this backward with nothing reading the gradient in between): a conv
+    layer whose gradient segment lives in that optimizer's flat buffer leaves its per-(sample, chunk) slabs unfolded and
+    registers them (FusedOptimizer.defer_fold); the optimizer folds every registered layer inside the launch that forms the
+    gradient norm -- one launch instead of one per layer plus the norm's (profiles/r05r_kernel_stats_*: fold_norm_kernel x 3 +
+    grad_sqnorm_kernel per update)."""
+    prev, prev_defer = _DIRECT[0], _DEFER[0]
     _DIRECT[0] = bool(enable)
+    _DEFER[0] = defer_folds_to if enable else None
     if enable:
         _WRITTEN.clear()
+        _SHARED[0] = False
     try:
         yield
     finally:
+        # `covers`: did this backward overwrite EVERY parameter of these optimizers, each exactly once?  Then the zero fill in
+        # front of the next such backward is dead work (FusedOptimizer.zero_grad(direct=True) skips it)
+        for opt in (covers if enable else ()):
+            opt.all_direct = (not _SHARED[0]) and all(id(p) in _WRITTEN for p in opt.flat.params)
         _DIRECT[0] = prev
+        _DEFER[0] = prev_defer
         _WRITTEN.clear()
 
 
@@ -74,6 +90,7 @@ def _claim_direct(params):
         return False
     ids = [id(p) for p in params if p is not None]
     if any(i in _WRITTEN for i in ids):
+        _SHARED[0] = True       # a parameter reached twice: its further contributions ACCUMULATE (the buffer must start at zero)
         return False
     _WRITTEN.update(ids)
     return True
@@ -124,12 +141,14 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         dy = dy.contiguous()
-        dpre = ops.act_bwd(dy, y, ctx.act) if ctx.act else dy
+        # (a consumer that knows this layer ends in a fused ReLU hands the gradient of the pre-activation over: _PolicyHeadFn)
+        dpre = dy if (ctx.act == "relu" and _already_masked(dy)) else (ops.act_bwd(dy, y, ctx.act) if ctx.act else dy)
         gw, gb = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if _claim_direct(ctx.params) else (None, None)
         if gw is not None and gw.is_contiguous() and (not ctx.has_bias or (gb is not None and gb.is_contiguous())):
             ops.linear_bwd_w(dpre, x, dw=gw, db=gb if ctx.has_bias else None, want_bias=ctx.has_bias)
             dw = db = None
         else:
+            _SHARED[0] = True       # (claimed or not, these gradients reach .grad through autograd's accumulation)
             dw, db = ops.linear_bwd_w(dpre, x, want_bias=ctx.has_bias)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -161,11 +180,13 @@ class _LinearPairFn(torch.autograd.Function):
             direct = _claim_direct(ctx.params)
             slots = [_grad_slot(p) if direct else None for p in ctx.params]
             direct = all(g is not None and g.is_contiguous() for g in slots)
+            _SHARED[0] = _SHARED[0] or not direct
             dx, dw0, db0, dw1, db1 = ops.linear_bwd_pair(g0.contiguous(), g1.contiguous(), x, w0, w1,
                                                          *((slots[0], slots[1], slots[2], slots[3]) if direct else ()),
                                                          want_dx=bool(ctx.needs_input_grad[0]))
             return (dx, None, None, None, None) if direct else (dx, dw0, db0, dw1, db1)
         outs, dx = [], None
+        _SHARED[0] = True
         for g, w, pw, pb in ((g0, w0, ctx.params[0], ctx.params[1]), (g1, w1, ctx.params[2], ctx.params[3])):
             if g is None:
                 outs += [None, None]
@@ -176,6 +197,36 @@ class _LinearPairFn(torch.autograd.Function):
                 d = ops.linear_bwd_x(g, w)
                 dx = d if dx is None else dx + d
         return (dx,) + tuple(outs)
+
+
+class _PolicyHeadFn(torch.autograd.Function):
+    """The whole policy head of the update's forward -- fc_action / fc_critic on the shared features, Categorical(logits) of the
+    stored actions -> (log_pi_a, entropy, v) [B] -- as ONE launch each way (ops.policy_heads_given / policy_heads_bwd; before: heads,
+    categorical forward | categorical backward, paired-heads backward, the ReLU mask of the layer below).  x_relu: the features
+    are a fused-ReLU output, the input gradient comes back as the gradient of its pre-activation (marked, _already_masked)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, action, x_relu):
+        lp, ent, v, logits = ops.policy_heads_given(x, w0, b0, w1, b1, action)
+        ctx.save_for_backward(x, w0, w1, logits, action)
+        ctx.params = (w0, b0, w1, b1)
+        ctx.x_relu = bool(x_relu)
+        return lp, ent, v
+
+    @staticmethod
+    def backward(ctx, g_lp, g_ent, g_v):
+        x, w0, w1, logits, action = ctx.saved_tensors
+        direct = _claim_direct(ctx.params)
+        slots = [_grad_slot(p) if direct else None for p in ctx.params]
+        direct = all(g is not None and g.is_contiguous() for g in slots)
+        _SHARED[0] = _SHARED[0] or not direct
+        want_dx = bool(ctx.needs_input_grad[0])
+        dx, dw0, db0, dw1, db1 = ops.policy_heads_bwd(logits, action, g_lp, g_ent, g_v, x, w0, w1,
+                                                      *((slots[0], slots[1], slots[2], slots[3]) if direct else ()),
+                                                      want_dx=want_dx, relu_mask=ctx.x_relu and want_dx)
+        if ctx.x_relu and dx is not None:
+            _mark_masked(dx)
+        return (dx, None, None, None, None, None, None) if direct else (dx, dw0, db0, dw1, db1, None, None)
 
 
 class _CategoricalFn(torch.autograd.Function):
@@ -193,16 +244,66 @@ class _CategoricalFn(torch.autograd.Function):
         return ops.categorical_bwd(logits, action, g_lp, g_ent), None
 
 
-def categorical_policy(logits, action=None, sampler=None):
+class RolloutSlots:
+    """Where a categorical actor-critic's no-grad forwards of ONE rollout get their uniforms and put their results.  The
+    reference draws inside every forward (network_heads.py:251 dist.sample()); here the agent announces a rollout of `rows`
+    forwards over `n` environments (begin: ONE uniform_() on torch's global device generator for all of them) and forward number i
+    reads row i and writes action / log_pi_a / entropy / v into row i of persistent [rows, n] buffers -- the agent reads the
+    rollout back as views, without the per-key torch.stack / torch.cat launches, and the sampling launch per step disappears
+    into the head kernel (ops.policy_heads_sample).  Forwards outside an announced rollout (evaluation episodes, another batch
+    size, more forwards than announced) draw torch.rand(B) as before.  `pin(u)`: every forward reads the given static [n] buffer
+    and allocates its outputs (a forward captured in a hipGraph of its own: PPOAgent._act copies next_uniform() into it)."""
+
+    def __init__(self):
+        self.rows, self.n, self.i = 0, 0, 0
+        self.pinned = None
+        self.uniform = self.action = self.log_pi_a = self.entropy = self.v = None
+
+    def begin(self, rows, n):
+        if (rows, n) != (self.rows, self.n):
+            dev = Config.DEVICE
+            self.uniform = torch.empty((rows, n), dtype=torch.float32, device=dev)
+            self.action = torch.zeros((rows, n), dtype=torch.int64, device=dev)
+            self.log_pi_a, self.entropy, self.v = (torch.zeros((rows, n), dtype=torch.float32, device=dev) for _ in range(3))
+            self.rows, self.n = rows, n
+        self.uniform.uniform_()
+        self.i = 0
+
+    def end(self):
+        self.i = self.rows          # later forwards draw for themselves
+
+    def next_uniform(self):
+        """Row i of the announced draw (None outside a rollout); advances."""
+        if self.i >= self.rows:
+            return None
+        self.i += 1
+        return self.uniform[self.i - 1]
+
+    def take(self, b):
+        """-> (uniform [b] or None, (action, log_pi_a, entropy, v) rows to write into or None) for a forward over b samples."""
+        if self.pinned is not None and self.pinned.numel() == b:
+            return self.pinned, None
+        if self.i >= self.rows or b != self.n:
+            return None, None
+        i = self.i
+        self.i += 1
+        return self.uniform[i], (self.action[i], self.log_pi_a[i], self.entropy[i], self.v[i])
+
+    def pin(self, u):
+        self.pinned = u
+
+
+def categorical_policy(logits, action=None, sampler=None, uniform=None):
     """network_heads.py:249-254: (action, log_pi_a [B,1], entropy [B,1]) of Categorical(logits=logits).  action None: drawn
-    by `sampler(logits)` when given, else by inverse CDF from one torch.rand(B) on torch's global device generator."""
+    by `sampler(logits)` when given, else by inverse CDF from `uniform` [B] (a row of the rollout's one draw: RolloutSlots) or
+    one torch.rand(B) on torch's global device generator."""
     logits = logits.float().contiguous()
     if action is None:
         if sampler is not None:
             action = sampler(logits)
         else:
             with torch.no_grad():
-                u = torch.rand(logits.shape[0], dtype=torch.float32, device=logits.device)
+                u = uniform if uniform is not None else torch.rand(logits.shape[0], dtype=torch.float32, device=logits.device)
                 action, lp, ent = ops.categorical_fwd(logits.detach(), uniform=u)
             if not (torch.is_grad_enabled() and logits.requires_grad):
                 # a rollout step (no_grad): the sampling launch already produced log_pi_a / entropy of its own draw
@@ -216,7 +317,10 @@ def linear(x, w, b, act=None, x_relu=False):
     x = x.float() if x.dtype != torch.float32 else x
     lead = x.shape[:-1]
     y = _LinearFn.apply(x.reshape(-1, x.shape[-1]).contiguous(), w, b, act, x_relu)
-    return y.reshape(lead + (w.shape[0],))
+    y = y.reshape(lead + (w.shape[0],))
+    if act == "relu":
+        y.dra_fused_relu = True     # (a consumer may hand the gradient of the pre-activation back: _PolicyHeadFn, _already_masked)
+    return y
 
 
 class _ConvFn(torch.autograd.Function):
@@ -295,6 +399,9 @@ class _ConvKocFn(torch.autograd.Function):
         gw, gb = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if _claim_direct(ctx.params) else (None, None)
         direct = (gw is not None and gb is not None and stride == n_w + oc and gw.permute(1, 2, 3, 0).is_contiguous()
                   and gb.is_contiguous() and gb.data_ptr() == gw.data_ptr() + 4 * n_w and gw.data_ptr() % 16 == 0)
+        _SHARED[0] = _SHARED[0] or not direct
+        if direct and _DEFER[0] is not None and _DEFER[0].defer_fold(gw, stride, slabs, n_slabs):
+            return (dx if ctx.needs_input_grad[0] and layer > 1 else None), None, None, None, None, None
         flat = torch.as_strided(gw, (stride,), (1,)) if direct else torch.empty(stride, dtype=torch.float32, device=w.device)
         if n_slabs > 32 and stride % 4 == 0:
             # one slab per (sample, row chunk): hundreds of slabs -- the segmented fold keeps 160 of them in flight per element
@@ -677,6 +784,7 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         self.actor_params = list(self.actor_body.parameters()) + list(self.fc_action.parameters())
         self.critic_params = list(self.critic_body.parameters()) + list(self.fc_critic.parameters())
         self.phi_params = list(self.phi_body.parameters())
+        self.rollout_slots = RolloutSlots()
         self.to(Config.DEVICE)
 
     def forward(self, obs, action=None):
@@ -684,12 +792,38 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         phi = self.phi_body(obs)
         phi_a = self.actor_body(phi)
         phi_v = self.critic_body(phi)
-        if (phi_a is phi_v and phi_a.is_cuda and phi_a.dim() == 2 and phi_a.shape[1] <= 512 and phi_a.shape[0] <= 65536
+        sampler = getattr(self, "sampler", None)
+        # `sampler` (set by a data-parallel agent, dist.py): draws that do not depend on how the environments are spread
+        # over ranks; default = one uniform per sample from torch's global generator (one draw per announced rollout,
+        # RolloutSlots, else one per forward), inverse CDF inside the fused kernel (the reference's dist.sample() is
+        # torch.multinomial on ITS generator: the action stream of a GPU run is not the reference's CPU stream either way)
+        uniform = rows = None
+        if action is None and sampler is None and phi_a.is_cuda and phi_a.dim() == 2:
+            uniform, rows = self.rollout_slots.take(phi_a.shape[0])
+        pair = (phi_a is phi_v and phi_a.is_cuda and phi_a.dim() == 2 and phi_a.shape[1] <= 512 and phi_a.shape[0] <= 65536
                 and phi_a.dtype == torch.float32
                 and type(self.fc_action) is Linear and type(self.fc_critic) is Linear and self.fc_action.bias is not None
-                and self.fc_critic.bias is not None and self.fc_action.fused_act is None and self.fc_critic.fused_act is None):
+                and self.fc_critic.bias is not None and self.fc_action.fused_act is None and self.fc_critic.fused_act is None)
+        with_grad = torch.is_grad_enabled() and (phi_a.requires_grad or self.fc_action.weight.requires_grad)
+        if (pair and action is None and sampler is None and not with_grad and self.fc_action.weight.shape[0] <= 64
+                and self.fc_critic.weight.shape[0] == 1):
+            # a rollout step: both heads, the sample, its log-probability and the entropy in ONE launch
+            if uniform is None:
+                uniform = torch.rand(phi_a.shape[0], dtype=torch.float32, device=phi_a.device)
+            a, lp, ent, v = ops.policy_heads_sample(phi_a.detach(), self.fc_action.weight.detach(), self.fc_action.bias.detach(),
+                                                    self.fc_critic.weight.detach(), self.fc_critic.bias.detach(), uniform, rows)
+            return {'action': a, 'log_pi_a': lp.unsqueeze(-1), 'entropy': ent.unsqueeze(-1), 'v': v.unsqueeze(-1)}
+        if (pair and isinstance(action, torch.Tensor) and action.is_cuda and self.fc_action.weight.shape[0] <= 64
+                and self.fc_critic.weight.shape[0] == 1 and phi_a.shape[0] <= ops.HEADS_BWD_MAX_BATCH and action.dim() == 1
+                and action.shape[0] == phi_a.shape[0]):
+            # the update's forward: both heads + log-probability / entropy of the stored actions in one launch each way
+            x_relu = bool(getattr(phi_a, 'dra_fused_relu', False))      # (the body ends in a Linear with a fused ReLU)
+            lp, ent, v = _PolicyHeadFn.apply(phi_a.contiguous(), self.fc_action.weight, self.fc_action.bias, self.fc_critic.weight,
+                                             self.fc_critic.bias, action.long().contiguous(), x_relu)
+            return {'action': action, 'log_pi_a': lp.unsqueeze(-1), 'entropy': ent.unsqueeze(-1), 'v': v.unsqueeze(-1)}
+        if pair:
             # both heads read the same features: one launch, the same per-output arithmetic (rollout steps and updates alike)
-            if torch.is_grad_enabled() and (phi_a.requires_grad or self.fc_action.weight.requires_grad):
+            if with_grad:
                 logits, v = _LinearPairFn.apply(phi_a.contiguous(), self.fc_action.weight, self.fc_action.bias,
                                                 self.fc_critic.weight, self.fc_critic.bias)
             else:
@@ -698,16 +832,12 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         else:
             logits = self.fc_action(phi_a)
             v = self.fc_critic(phi_v)
-        # `sampler` (set by a data-parallel agent, dist.py): draws that do not depend on how the environments are spread
-        # over ranks; default = one uniform per sample from torch's global generator, inverse CDF inside the fused kernel
-        # (the reference's dist.sample() is torch.multinomial on ITS generator: the action stream of a GPU run is not the
-        # reference's CPU stream either way)
         if logits.is_cuda and logits.shape[-1] <= 64:
-            action, log_prob, entropy = categorical_policy(logits, action, getattr(self, "sampler", None))
+            action, log_prob, entropy = categorical_policy(logits, action, sampler, uniform)
             return {'action': action, 'log_pi_a': log_prob, 'entropy': entropy, 'v': v}
         dist = torch.distributions.Categorical(logits=logits)
         if action is None:
-            action = self.sampler(logits) if getattr(self, "sampler", None) is not None else dist.sample()
+            action = sampler(logits) if sampler is not None else dist.sample()
         log_prob = dist.log_prob(action).unsqueeze(-1)
         entropy = dist.entropy().unsqueeze(-1)
         return {'action': action, 'log_pi_a': log_prob, 'entropy': entropy, 'v': v}

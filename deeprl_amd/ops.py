@@ -522,6 +522,9 @@ def grad_sqnorm_segs(grad, segs, partials):
     return n.value
 
 
+MAX_FOLD_SEGS = 4      # DRA_MAX_FOLD_SEGS (include/deeprl_amd.h)
+
+
 def norm_partials_max():
     return lib.dra_norm_partials_max.raw()
 
@@ -575,6 +578,89 @@ def linear_fwd_pair(x, w0, b0, w1, b1, act=None):
     lib.dra_linear_fwd_pair(ptr(x), ptr(w0), ptr(b0), ptr(y0), int(w0.shape[0]), ptr(w1), ptr(b1), ptr(y1), int(w1.shape[0]),
                             batch, fin, ACT[act], stream_ptr())
     return y0, y1
+
+
+def gather_rows(tensors, idx):
+    """[t[idx] for t in tensors] (row gathers along dim 0 of contiguous device tensors that share their row count) in ONE launch."""
+    idx = _c(idx, torch.int64)
+    n = int(idx.numel())
+    k = len(tensors)
+    if not 1 <= k <= 8:
+        raise ValueError("gather_rows: 1..8 tensors")
+    rows = int(tensors[0].shape[0])
+    srcs, outs = [], []
+    for t in tensors:
+        t = _c(t)
+        if t.dim() < 1 or int(t.shape[0]) != rows:
+            raise ValueError("gather_rows: tensors must share dim 0")
+        srcs.append(t)
+        outs.append(torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device))
+    src_arr = (ctypes.c_void_p * k)(*[t.data_ptr() for t in srcs])
+    dst_arr = (ctypes.c_void_p * k)(*[t.data_ptr() for t in outs])
+    rb = (ctypes.c_int64 * k)(*[(t.numel() // rows) * t.element_size() for t in srcs])
+    lib.dra_gather_rows(k, src_arr, dst_arr, rb, ptr(idx), n, rows, stream_ptr())
+    return outs
+
+
+def policy_heads_sample(x, w0, b0, w1, b1, uniform, out=None):
+    """A rollout step's policy head in one launch: (action i64 [B], log_pi_a [B], entropy [B], v [B]) of
+    Categorical(logits = x W0^T + b0) sampled by inverse CDF from uniform [B], v = x w1^T + b1 -- linear_fwd_pair +
+    categorical_fwd, bit for bit.  out: four preallocated tensors of those shapes (rows of a rollout's buffers)."""
+    x, w0, w1, uniform = _c(x, _f32), _c(w0, _f32), _c(w1, _f32), _c(uniform, _f32)
+    b0 = None if b0 is None else _c(b0, _f32)
+    b1 = None if b1 is None else _c(b1, _f32)
+    batch, fin = x.shape
+    if w1.shape[0] != 1 or uniform.numel() != batch:
+        raise ValueError("policy_heads_sample: one value output and one uniform per row")
+    if out is None:
+        out = (torch.empty(batch, dtype=torch.int64, device=x.device), torch.empty(batch, dtype=_f32, device=x.device),
+               torch.empty(batch, dtype=_f32, device=x.device), torch.empty(batch, dtype=_f32, device=x.device))
+    a, lp, ent, v = out
+    for t_, dt in ((a, torch.int64), (lp, _f32), (ent, _f32), (v, _f32)):
+        if t_.dtype != dt or t_.numel() != batch or not t_.is_contiguous():
+            raise ValueError("policy_heads_sample: output rows must be contiguous [B] tensors (i64, f32, f32, f32)")
+    lib.dra_policy_heads_sample(ptr(x), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(uniform), batch, fin, int(w0.shape[0]), ptr(a),
+                                ptr(lp), ptr(ent), ptr(v), None, stream_ptr())
+    return a, lp, ent, v
+
+
+def policy_heads_given(x, w0, b0, w1, b1, action):
+    """The update's forward through the policy head in one launch -> (log_pi_a [B], entropy [B], v [B], logits [B, A]) for the
+    given actions (linear_fwd_pair + categorical_fwd(action=...), bit for bit)."""
+    x, w0, w1, action = _c(x, _f32), _c(w0, _f32), _c(w1, _f32), _c(action, torch.int64)
+    b0 = None if b0 is None else _c(b0, _f32)
+    b1 = None if b1 is None else _c(b1, _f32)
+    batch, fin = x.shape
+    a = int(w0.shape[0])
+    if w1.shape[0] != 1 or action.numel() != batch:
+        raise ValueError("policy_heads_given: one value output and one action per row")
+    lp, ent, v = (torch.empty(batch, dtype=_f32, device=x.device) for _ in range(3))
+    logits = torch.empty((batch, a), dtype=_f32, device=x.device)
+    lib.dra_policy_heads_given(ptr(x), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(action), batch, fin, a, ptr(lp), ptr(ent), ptr(v),
+                               ptr(logits), stream_ptr())
+    return lp, ent, v, logits
+
+
+HEADS_BWD_MAX_BATCH = 8192
+
+
+def policy_heads_bwd(logits, action, g_lp, g_ent, g_v, x, w0, w1, dw0=None, db0=None, dw1=None, db1=None, want_dx=True,
+                     relu_mask=False):
+    """Backward of policy_heads_given in one launch -> (dx or None, dw0, db0, dw1, db1); g_* [B] or None (= zero); dw / db may
+    be given (written in place); relu_mask: x is a fused-ReLU output, dx is the gradient of its PRE-activation."""
+    logits, action, x, w0, w1 = _c(logits, _f32), _c(action, torch.int64), _c(x, _f32), _c(w0, _f32), _c(w1, _f32)
+    g_lp, g_ent, g_v = [None if g is None else _c(g, _f32) for g in (g_lp, g_ent, g_v)]
+    batch, fin = x.shape
+    a = int(w0.shape[0])
+    dev = x.device
+    dw0 = torch.empty((a, fin), dtype=_f32, device=dev) if dw0 is None else dw0
+    db0 = torch.empty(a, dtype=_f32, device=dev) if db0 is None else db0
+    dw1 = torch.empty((1, fin), dtype=_f32, device=dev) if dw1 is None else dw1
+    db1 = torch.empty(1, dtype=_f32, device=dev) if db1 is None else db1
+    dx = torch.empty((batch, fin), dtype=_f32, device=dev) if want_dx else None
+    lib.dra_policy_heads_bwd(ptr(logits), ptr(action), ptr(g_lp), ptr(g_ent), ptr(g_v), ptr(x), ptr(w0), ptr(w1), ptr(dx), ptr(dw0),
+                             ptr(db0), ptr(dw1), ptr(db1), batch, fin, a, 1 if relu_mask else 0, stream_ptr())
+    return dx, dw0, db0, dw1, db1
 
 
 def linear_bwd_pair(g0, g1, x, w0, w1, dw0=None, db0=None, dw1=None, db1=None, want_dx=True):

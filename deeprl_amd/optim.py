@@ -94,6 +94,37 @@ class FusedOptimizer:
         self.graph_mode = False
         self._hyper_dev = None
         self._hyper_up = None
+        # conv layers whose slab folds wait for step() (nets.direct_param_grads(defer_folds_to=self)): (offset, floats, slabs,
+        # slab stride, slab count) per layer
+        self._pending_folds = []
+        self._partials_segs = None
+
+    def defer_fold(self, grad_view, floats, slabs, n_slabs):
+        """A conv layer's backward hands its unfolded weight-gradient slabs over: step() folds them into
+        flat.grad[offset : offset + floats] inside the launch that forms the gradient norm.  False: not this optimizer's
+        buffer / not aligned -- the layer folds as before."""
+        off = (grad_view.data_ptr() - self.flat.grad.data_ptr()) // 4
+        if (grad_view.data_ptr() - self.flat.grad.data_ptr()) % 16 or off < 0 or off + floats > self.flat.numel or floats % 4 \
+                or n_slabs < 1 or slabs.data_ptr() % 16:
+            return False
+        self._pending_folds.append((int(off), int(floats), slabs, int(floats), int(n_slabs)))
+        return True
+
+    def _fold_pending(self, want_norm):
+        """Folds the registered layers.  -> (partials, count) covering the WHOLE gradient when one launch could do everything
+        (segments contiguous from offset 0: the NatureConvBody layers of a FlatParams buffer), else None (folded, no norm)."""
+        segs = sorted(self._pending_folds, key=lambda t: t[0])
+        self._pending_folds = []
+        f = self.flat
+        contiguous = segs[0][0] == 0 and all(segs[i][0] == segs[i - 1][0] + segs[i - 1][1] for i in range(1, len(segs)))
+        if self._partials_segs is None:
+            self._partials_segs = torch.zeros(ops.norm_partials_max(), dtype=torch.float64, device=f.flat.device)
+        if contiguous and len(segs) <= ops.MAX_FOLD_SEGS and f.numel % 4 == 0:
+            n = ops.grad_sqnorm_segs(f.grad, segs, self._partials_segs)
+            return self._partials_segs, n
+        for off, cnt, slabs, stride, ns in segs:
+            ops.grad_sqnorm_segs(f.grad[off:off + cnt], [(0, cnt, slabs, stride, ns)], self._partials_segs)
+        return None
 
     @classmethod
     def adopt(cls, torch_optimizer, flat=None):
@@ -115,7 +146,13 @@ class FusedOptimizer:
             raise DraError("no HIP kernel for optimizer %s" % type(torch_optimizer).__name__)
         return cls(flat, kind, g, torch_optimizer)
 
-    def zero_grad(self):
+    def zero_grad(self, direct=False):
+        """direct: the backward pass that follows runs under nets.direct_param_grads(True, covers=[self]) -- when the previous such
+        pass overwrote every parameter's gradient (all_direct) the fill is skipped (6.75 MB per update of the pixel nets; the
+        alignment gaps between parameters are zero from construction and never written)."""
+        self._pending_folds = []
+        if direct and getattr(self, 'all_direct', False):
+            return
         self.flat.zero_grad()
 
     def enable_graph_mode(self):
@@ -141,29 +178,33 @@ class FusedOptimizer:
             b1, b2 = self.hyper['betas']
             hp = (ctypes.c_float * 2)()
             lib.dra_adam_hyper(float(self.hyper['lr']), float(b1), float(b2), int(self.steps), hp)
-            self._hyper_dev.copy_(self._hyper_up.upload([hp[0], hp[1]]), non_blocking=True)
+            self._hyper_up.upload_into(self._hyper_dev, [hp[0], hp[1]])
 
     def step(self, max_norm=None):
         """max_norm None / 0 = no clipping (then the norm pass is skipped)."""
         f, h = self.flat, self.hyper
         clip = bool(max_norm)
-        if clip:
-            ops.grad_sqnorm(f.grad, self.partials)
-        partials = self.partials if clip else None
+        folded = self._fold_pending(clip) if self._pending_folds else None
+        if folded is not None:      # the deferred folds' launch formed every partial sum of squares as well
+            partials, n_partials = (folded if clip else (None, self.n_partials))
+        else:
+            if clip:
+                ops.grad_sqnorm(f.grad, self.partials)
+            partials, n_partials = (self.partials if clip else None), self.n_partials
         if self.graph_mode:   # steps / Adam scalars were advanced by prepare_step()
             if self.kind == 'rmsprop':
-                ops.rmsprop_step(f.flat, f.grad, self.state1, self.state2, partials, self.n_partials, max_norm or 0.0,
+                ops.rmsprop_step(f.flat, f.grad, self.state1, self.state2, partials, n_partials, max_norm or 0.0,
                                  h['lr'], h['alpha'], h['eps'], h['centered'], self.norm if clip else None)
             else:
                 b1, b2 = h['betas']
-                ops.adam_step_dev(f.flat, f.grad, self.state1, self.state2, partials, self.n_partials, max_norm or 0.0,
+                ops.adam_step_dev(f.flat, f.grad, self.state1, self.state2, partials, n_partials, max_norm or 0.0,
                                   b1, b2, h['eps'], self._hyper_dev, self.norm if clip else None)
             return
         self.steps += 1
         if self.kind == 'rmsprop':
-            ops.rmsprop_step(f.flat, f.grad, self.state1, self.state2, partials, self.n_partials, max_norm or 0.0,
+            ops.rmsprop_step(f.flat, f.grad, self.state1, self.state2, partials, n_partials, max_norm or 0.0,
                              h['lr'], h['alpha'], h['eps'], h['centered'], self.norm if clip else None)
         else:
             b1, b2 = h['betas']
-            ops.adam_step(f.flat, f.grad, self.state1, self.state2, partials, self.n_partials, max_norm or 0.0, h['lr'],
+            ops.adam_step(f.flat, f.grad, self.state1, self.state2, partials, n_partials, max_norm or 0.0, h['lr'],
                           b1, b2, h['eps'], self.steps, self.norm if clip else None)

@@ -89,6 +89,24 @@ class _PinnedUploader:
             self.events[k].record(stream)
         self.unguarded = []
 
+    def upload_into(self, dst, array):
+        """dst[:len(array)] <- array through the next staging slot: ONE host-to-device copy on the current stream (upload()
+        followed by dst.copy_() is two: the staging tensor's own device copy, then a device-to-device one)."""
+        k = self.k
+        self.k = (k + 1) % len(self.bufs)
+        if k in self.unguarded:
+            torch.cuda.current_stream().synchronize()
+            self.unguarded.remove(k)
+        elif self.used[k]:
+            self.events[k].synchronize()
+        n = len(array)
+        self.views[k][:n] = array
+        dst[:n].copy_(self.bufs[k][:n], non_blocking=True)
+        if self.events[k] is None:
+            self.events[k] = torch.cuda.Event()
+        self.events[k].record()
+        self.used[k] = True
+
     def upload(self, array, device_copy=True, stream=None):
         k = self.k
         self.k = (k + 1) % len(self.bufs)

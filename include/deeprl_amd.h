@@ -210,6 +210,22 @@ int dra_linear_fwd(int nz, const float* const* x, const float* const* w, const f
  * actor-critic nets on phi), one wave per input row; in_features <= 512; same per-output arithmetic as dra_linear_fwd */
 int dra_linear_fwd_pair(const float* x, const float* w0, const float* b0, float* y0, int out0, const float* w1, const float* b1,
                         float* y1, int out1, int batch, int in_features, int act, void* stream);
+/* a rollout step's policy head (network_heads.py:240-255 under no_grad, action = None) in one launch: logits = x W0^T + b0
+ * [batch, n_actions <= 64], v = x w1^T + b1 [batch], then Categorical(logits): action by inverse CDF from uniform[b], log_pi_a,
+ * entropy -- dra_linear_fwd_pair + dra_categorical_fwd, bit for bit; out_logits may be NULL */
+int dra_policy_heads_sample(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                            const float* uniform, int batch, int in_features, int n_actions, int64_t* out_action,
+                            float* out_log_pi_a, float* out_entropy, float* out_v, float* out_logits, void* stream);
+/* the same head for GIVEN actions (the update's forward): log_pi_a / entropy of action[b], v, and the logits [batch, n_actions] */
+int dra_policy_heads_given(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                           const int64_t* action, int batch, int in_features, int n_actions, float* out_log_pi_a,
+                           float* out_entropy, float* out_v, float* out_logits, void* stream);
+/* its backward in one launch (dra_categorical_bwd + dra_linear_bwd_pair [+ dra_act_bwd], same sums in the same order): from the
+ * gradients of log_pi_a / entropy / v [batch] (any may be NULL = zero) -> dx [batch, in_features] (optional; relu_mask != 0:
+ * times [x > 0], x being a fused-ReLU output), dW0 [n_actions, in_features], db0, dW1 [1, in_features], db1; batch <= 8192 */
+int dra_policy_heads_bwd(const float* logits, const int64_t* action, const float* g_log_pi_a, const float* g_entropy,
+                         const float* g_v, const float* x, const float* w0, const float* w1, float* dx, float* dw0, float* db0,
+                         float* dw1, float* db1, int batch, int in_features, int n_actions, int relu_mask, void* stream);
 /* backward of that pair in one launch: dx [B, K] (optional) = g0 W0 + g1 W1, dW_h = g_h^T x, db_h = column sums of g_h */
 int dra_linear_bwd_pair(const float* g0, const float* g1, const float* x, const float* w0, const float* w1, float* dx, float* dw0,
                         float* db0, float* dw1, float* db1, int batch, int in_features, int out0, int out1, void* stream);
@@ -344,6 +360,13 @@ int dra_copy_f32(float* dst, const float* src, int64_t n, void* stream); /* DQN_
  * buffers (16-byte aligned): target[i] = target[i] * keep + src[i] * mix with keep = f32(1 - mix); each product is rounded
  * before the add, as the reference's `target_param * (1.0 - mix) + param * mix` is.  One launch. */
 int dra_soft_update(float* target, const float* src, int64_t n, float keep, float mix, void* stream);
+
+/* ---- minibatch rows of an on-policy rollout (PPO_agent.py:77-80: entries[batch_indices] over state / action / log_pi_a / ret /
+ * advantage): dst[q][r] = src[q][idx[r]] for n_fields <= DRA_GATHER_MAX_FIELDS row-major device arrays of row_bytes[q] bytes per
+ * row, one launch for all of them; idx_dev int64 [n_rows] (negative = from the end, as torch indexes), n_src_rows rows per source */
+#define DRA_GATHER_MAX_FIELDS 8
+int dra_gather_rows(int n_fields, const void* const* src, void* const* dst, const int64_t* row_bytes, const int64_t* idx_dev,
+                    int n_rows, int64_t n_src_rows, void* stream);
 
 /* ---- device-resident synthetic vector environment (on-policy agents; A2C_agent.py:26-34, PPO_agent.py:33-47): the uint8
  * [n_env][history][84*84] observations of one rollout step from per-environment frame counters / episode ages / stream

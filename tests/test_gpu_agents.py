@@ -817,9 +817,11 @@ def test_in_place_parameter_gradients_equal_autograd_accumulation(dra, monkeypat
     outs = []
     for direct in (True, False):
         if not direct:
-            monkeypatch.setattr(nets_mod, "direct_param_grads", lambda enable=True: contextlib.nullcontext())
+            monkeypatch.setattr(nets_mod, "direct_param_grads", lambda enable=True, **kw: contextlib.nullcontext())
         cfg = d.Config()
-        cfg.merge(dict(game="synthetic-atari", num_workers=4, log_level=0, tag="dg%d" % direct, device_env=True))
+        # (defer_conv_folds off: the deferred form sums the norm's partials in another grouping -- compared on its own below)
+        cfg.merge(dict(game="synthetic-atari", num_workers=4, log_level=0, tag="dg%d" % direct, device_env=True,
+                       defer_conv_folds=False))
         cfg.task_fn = lambda: d.Task(cfg.game, num_envs=cfg.num_workers, seed=31, synthetic_done_period=9)
         cfg.eval_env = d.Task(cfg.game, seed=3)
         cfg.network_fn = lambda: d.CategoricalActorCriticNet(cfg.state_dim, cfg.action_dim, d.NatureConvBody())
@@ -846,6 +848,50 @@ def test_in_place_parameter_gradients_equal_autograd_accumulation(dra, monkeypat
     for k in outs[0]:
         assert np.isfinite(outs[0][k]).all()
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("kind", ["a2c", "ppo"])
+def test_deferred_conv_folds_give_the_same_update(dra, monkeypatch, kind):
+    """config.defer_conv_folds (round 5, default on): the conv layers leave their weight-gradient slabs unfolded and the
+    optimizer's norm launch folds all three (dra_grad_sqnorm_segs over [conv1 | conv2 | conv3 | rest]) -- the folded gradients are
+    the same bits, the norm's partial sums are grouped differently (fp64), so the clip coefficient may differ in its last bit:
+    parameters after several agent steps agree to 1e-6 of their scale, and the captured graph holds one fold launch."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    outs = []
+    for defer in (True, False):
+        cfg = d.Config()
+        cfg.merge(dict(game="synthetic-atari", num_workers=4, log_level=0, tag="df%d" % defer, device_env=True,
+                       defer_conv_folds=defer))
+        cfg.task_fn = lambda: d.Task(cfg.game, num_envs=cfg.num_workers, seed=31, synthetic_done_period=9)
+        cfg.eval_env = d.Task(cfg.game, seed=3)
+        cfg.network_fn = lambda: d.CategoricalActorCriticNet(cfg.state_dim, cfg.action_dim, d.NatureConvBody())
+        cfg.state_normalizer, cfg.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
+        cfg.discount, cfg.use_gae, cfg.entropy_weight = 0.99, True, 0.01
+        if kind == "a2c":
+            cfg.optimizer_fn = lambda p: torch.optim.RMSprop(p, lr=1e-4, alpha=0.99, eps=1e-5)
+            cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 1.0, 5, 5
+            cls, n = d.A2CAgent, 5
+        else:
+            cfg.optimizer_fn = lambda p: torch.optim.Adam(p, lr=2.5e-4)
+            cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 0.95, 16, 0.5
+            cfg.optimization_epochs, cfg.mini_batch_size, cfg.ppo_ratio_clip, cfg.shared_repr = 2, 16, 0.1, True
+            cfg.max_steps, cfg.log_interval, cfg.target_kl = 1e6, 10 ** 9, 0.01
+            cls, n = d.PPOAgent, 4
+        d.random_seed(21)
+        torch.manual_seed(22)
+        agent = cls(cfg)
+        for _ in range(n):
+            agent.step()
+        torch.cuda.synchronize()
+        assert not agent._fused._pending_folds
+        outs.append({k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()})
+        agent.close()
+    for k in outs[0]:
+        scale = max(1e-3, float(np.abs(outs[1][k]).max()))
+        assert np.isfinite(outs[0][k]).all()
+        assert float(np.abs(outs[0][k] - outs[1][k]).max()) <= 2e-6 * scale + 1e-7, k
 
 
 @pytest.mark.parametrize("kind,per,chain", [("dqn", True, 2), ("c51", True, 2), ("dqn", True, 0), ("dqn", False, 2), ("c51", False, 2)])

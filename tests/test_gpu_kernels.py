@@ -911,6 +911,85 @@ def test_linear_fwd_pair_equals_two_layers(dev, b, k, o0, o1):
     _scale_close(y0.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("b,k,a", [(16, 512, 4), (8, 512, 18), (1, 512, 6), (33, 64, 3), (128, 400, 64), (5, 17, 1), (1024, 512, 9)])
+def test_policy_heads_sample_equals_heads_then_categorical(dev, b, k, a):
+    """dra_policy_heads_sample (a rollout step's two heads + Categorical sample / log-probability / entropy in ONE launch)
+    == dra_linear_fwd_pair followed by dra_categorical_fwd on the same uniforms: every output bit for bit, into caller-owned
+    rows as well as freshly allocated ones; and the sampled action is the inverse-CDF action of the float64 softmax."""
+    from deeprl_amd import ops
+    rs = np.random.RandomState(b + 3 * k + 5 * a)
+    x = f32(rs.standard_normal((b, k)).astype(np.float32), dev)
+    w0, w1 = f32(0.2 * rs.standard_normal((a, k)).astype(np.float32), dev), f32(rs.standard_normal((1, k)).astype(np.float32), dev)
+    b0, b1 = f32(rs.standard_normal(a).astype(np.float32), dev), f32(rs.standard_normal(1).astype(np.float32), dev)
+    u = f32(rs.uniform(size=b).astype(np.float32), dev)
+    logits, v = ops.linear_fwd_pair(x, w0, b0, w1, b1)
+    act, lp, ent = ops.categorical_fwd(logits, uniform=u)
+    got = ops.policy_heads_sample(x, w0, b0, w1, b1, u)
+    rows = (torch.full((3, b), -1, dtype=torch.int64, device=dev), torch.zeros((3, b), device=dev), torch.zeros((3, b), device=dev),
+            torch.zeros((3, b), device=dev))
+    got2 = ops.policy_heads_sample(x, w0, b0, w1, b1, u, tuple(r[1] for r in rows))
+    for g in (got, got2):
+        assert torch.equal(g[0], act.reshape(-1).long()) and torch.equal(g[1], lp.reshape(-1))
+        assert torch.equal(g[2], ent.reshape(-1)) and torch.equal(g[3], v.reshape(-1))
+    assert all(torch.equal(r[1], g) for r, g in zip(rows, got)) and int(rows[0][0].max()) == -1 and float(rows[3][2].abs().max()) == 0
+    p = torch.softmax(logits.double(), dim=1).cpu().numpy()
+    cum = np.cumsum(p, axis=1)
+    a_np, u_np = got[0].cpu().numpy(), u.cpu().numpy()
+    for i in range(b):
+        lo = cum[i, a_np[i] - 1] if a_np[i] > 0 else 0.0
+        assert lo - 1e-6 <= u_np[i] <= cum[i, a_np[i]] + 1e-6 or a_np[i] == a - 1
+
+
+@pytest.mark.parametrize("b,k,a,relu", [(80, 512, 4, True), (256, 512, 18, True), (1, 512, 6, False), (33, 64, 3, True), (5, 17, 1, False),
+                                        (1000, 512, 9, True)])
+def test_policy_heads_given_and_backward_equal_the_separate_launches(dev, b, k, a, relu):
+    """dra_policy_heads_given == dra_linear_fwd_pair + dra_categorical_fwd(action) and dra_policy_heads_bwd == dra_categorical_bwd +
+    dra_linear_bwd_pair (+ dra_act_bwd's ReLU mask on the input gradient): every output bit for bit -- the fused launches keep
+    the separate kernels' sums in their order -- also with missing gradients (None = zero) and caller-owned gradient buffers."""
+    from deeprl_amd import ops
+    rs = np.random.RandomState(7 * b + k + a)
+    x = f32(np.maximum(rs.standard_normal((b, k)), 0).astype(np.float32), dev)         # a ReLU output: about half zeros
+    w0, w1 = f32(0.2 * rs.standard_normal((a, k)).astype(np.float32), dev), f32(rs.standard_normal((1, k)).astype(np.float32), dev)
+    b0, b1 = f32(rs.standard_normal(a).astype(np.float32), dev), f32(rs.standard_normal(1).astype(np.float32), dev)
+    act = torch.from_numpy(rs.randint(0, a, size=b)).to(dev)
+    logits, v = ops.linear_fwd_pair(x, w0, b0, w1, b1)
+    _, lp, ent = ops.categorical_fwd(logits, action=act)
+    lp2, ent2, v2, logits2 = ops.policy_heads_given(x, w0, b0, w1, b1, act)
+    assert torch.equal(lp2, lp.reshape(-1)) and torch.equal(ent2, ent.reshape(-1)) and torch.equal(v2, v.reshape(-1))
+    assert torch.equal(logits2, logits)
+    g_lp, g_ent, g_v = [f32(rs.standard_normal(b).astype(np.float32), dev) for _ in range(3)]
+    for use in ((True, True, True), (True, True, False), (False, False, True)):
+        gl, ge, gv = [g if u else None for g, u in zip((g_lp, g_ent, g_v), use)]
+        zero = torch.zeros(b, device=dev)
+        dlogits = ops.categorical_bwd(logits, act, gl if gl is not None else zero, ge if ge is not None else zero)
+        rdx, rdw0, rdb0, rdw1, rdb1 = ops.linear_bwd_pair(dlogits, (gv if gv is not None else zero).reshape(b, 1), x, w0, w1)
+        if relu:
+            rdx = ops.act_bwd(rdx, x, "relu")
+        own = (torch.full((a, k), 7.0, device=dev), torch.full((a,), 7.0, device=dev), torch.full((1, k), 7.0, device=dev),
+               torch.full((1,), 7.0, device=dev))
+        dx, dw0, db0, dw1, db1 = ops.policy_heads_bwd(logits2, act, gl, ge, gv, x, w0, w1, *own, relu_mask=relu)
+        assert dw0 is own[0] and db1 is own[3]
+        assert torch.equal(dx, rdx), float((dx - rdx).abs().max())
+        assert torch.equal(dw0, rdw0) and torch.equal(db0, rdb0) and torch.equal(dw1, rdw1) and torch.equal(db1, rdb1)
+    assert ops.policy_heads_bwd(logits2, act, g_lp, g_ent, g_v, x, w0, w1, want_dx=False)[0] is None
+
+
+@pytest.mark.parametrize("rows,n", [(1024, 256), (80, 16), (7, 7), (2048, 1)])
+def test_gather_rows_equals_indexing(dev, rows, n):
+    """dra_gather_rows (the five fields of a PPO minibatch -- uint8 frame stacks, int64 actions, three float columns -- by one
+    index vector in one launch) == x[idx] field by field, bit for bit; odd row sizes and negative indices included."""
+    from deeprl_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(rows + n)
+    fields = [torch.randint(0, 256, (rows, 4, 84, 84), dtype=torch.uint8, generator=g), torch.randint(0, 18, (rows,), generator=g),
+              torch.randn((rows, 1), generator=g), torch.randn((rows, 1), generator=g), torch.randn((rows, 3, 5), generator=g),
+              torch.randint(0, 256, (rows, 13), dtype=torch.uint8, generator=g)]
+    fields = [f.to(dev) for f in fields]
+    idx = torch.randint(-rows, rows, (n,), generator=g).to(dev)
+    got = ops.gather_rows(fields, idx)
+    for f, o in zip(fields, got):
+        assert o.dtype == f.dtype and torch.equal(o, f[idx])
+
+
 @pytest.mark.parametrize("b,k,o0,o1", [(80, 512, 4, 1), (256, 512, 18, 1), (1, 512, 6, 1), (33, 64, 3, 2), (5, 17, 1, 1)])
 def test_linear_bwd_pair_vs_fp64(dev, b, k, o0, o1):
     """dra_linear_bwd_pair (input gradient and both layers' weight / bias gradients of the paired heads in one launch) against

@@ -109,3 +109,35 @@ def test_shared_body_with_two_optimisers_cannot_run_in_the_reference_either():
     critic_opt.zero_grad()
     with pytest.raises(RuntimeError):
         value_loss.backward()
+
+
+def test_rollout_slots_hand_out_the_announced_rows_then_fall_back():
+    """nets.RolloutSlots: begin(rows, n) draws ONE [rows, n] block from torch's generator; forward i of the rollout gets row i
+    and the rows to write into; any other batch size, a forward beyond the announced ones, or one after end() gets (None, None)
+    -- the caller draws torch.rand(B) itself; pin(u) overrides with a static row (a forward captured in its own graph)."""
+    import torch
+    from deeprl_amd.nets import RolloutSlots
+    s = RolloutSlots()
+    assert s.take(4) == (None, None) and s.next_uniform() is None
+    torch.manual_seed(3)
+    s.begin(3, 4)
+    torch.manual_seed(3)
+    ref = torch.empty(3, 4).uniform_()
+    assert torch.equal(s.uniform, ref)
+    u0, rows0 = s.take(4)
+    assert torch.equal(u0, ref[0]) and rows0[0].data_ptr() == s.action[0].data_ptr() and rows0[3].data_ptr() == s.v[0].data_ptr()
+    assert s.take(5) == (None, None)                      # another batch size does not consume a row
+    assert torch.equal(s.next_uniform(), ref[1])
+    u2, rows2 = s.take(4)
+    assert torch.equal(u2, ref[2]) and rows2[1].data_ptr() == s.log_pi_a[2].data_ptr()
+    assert s.take(4) == (None, None) and s.next_uniform() is None
+    buf = s.uniform.data_ptr()
+    s.begin(3, 4)                                          # same shape: same buffers (a captured graph keeps reading them)
+    assert s.uniform.data_ptr() == buf and s.i == 0
+    pinned = torch.zeros(4)
+    s.pin(pinned)
+    u, rows = s.take(4)
+    assert u is pinned and rows is None and s.i == 0
+    s.pin(None)
+    s.end()
+    assert s.take(4) == (None, None)
