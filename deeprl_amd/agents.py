@@ -987,6 +987,81 @@ def _begin_rollout(agent, n_env):
     return slots
 
 
+class _PixelRollout:
+    """The no-grad forwards of one A2C / PPO rollout over CategoricalActorCriticNet(NatureConvBody) and device-resident synthetic
+    Atari environments as FOUR launches per step instead of five (csrc/conv_v2.hip: rollout_conv1_heads_kernel): [conv1 of step t
+    | policy head of step t - 1], conv2, conv3, fc4 -- every launch of such a step is a few dozen workgroups at its latency floor,
+    so the step costs what its launches cost.  The head of step t - 1 can share conv1's launch because the planned observations
+    do not depend on the actions (DeviceAtariVec.states_all).  Same device functions as the module path: the rollout's actions,
+    log-probabilities, entropies and values are bit-identical (tests/test_gpu_agents.py).  a2c_pixel 209 k -> 224 k, ppo_pixel
+    109 k -> 118 k env-steps/s (profiles/r05x_bench_agents_c3fc4_ab.jsonl; conv3 + fc4 as one launch was measured too and lost)."""
+
+    def __init__(self, agent):
+        self.agent = agent
+        self.bufs = None
+
+    def eligible(self):
+        from .device_env import DeviceAtariVec
+        from .nets import CategoricalActorCriticNet, Conv2d, DummyBody, Linear, NatureConvBody
+        a = self.agent
+        net, cfg = a.network, a.config
+        if getattr(cfg, 'fused_rollout', True) is False or Config.DEVICE.type != 'cuda' or not isinstance(a.task, DeviceAtariVec):
+            return False
+        if type(net) is not CategoricalActorCriticNet or getattr(net, 'sampler', None) is not None:
+            return False
+        body = net.phi_body
+        if type(body) is not NatureConvBody or type(net.actor_body) is not DummyBody or type(net.critic_body) is not DummyBody:
+            return False
+        convs = [body.conv1, body.conv2, body.conv3]
+        if not all(type(c) is Conv2d and c.bias is not None and c.weight.permute(1, 2, 3, 0).is_contiguous() for c in convs):
+            return False
+        if getattr(body.conv1, 'u8_coef', None) is None or a.task.history != 4:
+            return False
+        heads = [body.fc4, net.fc_action, net.fc_critic]
+        if not all(type(m) is Linear and m.bias is not None and m.weight.is_contiguous() for m in heads):
+            return False
+        return (body.fc4.fused_act == "relu" and tuple(body.fc4.weight.shape) == (512, 3136) and net.fc_action.fused_act is None
+                and net.fc_critic.fused_act is None and net.fc_action.weight.shape[0] <= 64 and net.fc_critic.weight.shape[0] == 1
+                and a.task.num_envs <= 32)
+
+    def run(self, frames, slots):
+        """frames: uint8 [T + 1, N, 4, 84, 84]; fills rows 0..T of `slots` (action, log_pi_a, entropy, v) from slots.uniform."""
+        import ctypes
+        from ._lib import lib, stream_ptr
+        a = self.agent
+        net = a.network
+        body = net.phi_body
+        rows, n = int(frames.shape[0]), int(frames.shape[1])
+        dev = frames.device
+        if self.bufs is None or self.bufs['n'] != n or self.bufs['rows'] < rows:
+            f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            self.bufs = dict(n=n, rows=rows, y1=f(n, 32, 20, 20), y2=f(n, 64, 9, 9), y3=f(n, 64, 7, 7), phi=f(n, 512))
+        b = self.bufs
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+        arr = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+        st = stream_ptr()
+        w1, w2, w3 = body.conv1.weight, body.conv2.weight, body.conv3.weight       # [(c, kh, kw)][oc] storage (FlatParams)
+        wa, ba, wv, bv = net.fc_action.weight, net.fc_action.bias, net.fc_critic.weight, net.fc_critic.bias
+        n_act = int(wa.shape[0])
+        coef = float(body.conv1.u8_coef)
+        x2, wt2, b2, y2 = arr(b['y1']), arr(w2), arr(body.conv2.bias), arr(b['y2'])
+        wt3, b3, y3, w4, b4, phi = arr(w3), arr(body.conv3.bias), arr(b['y3']), arr(body.fc4.weight), arr(body.fc4.bias), arr(b['phi'])
+        for t in range(rows):
+            prev = t > 0
+            lib.dra_rollout_conv1_heads(p(frames[t]), p(w1), p(body.conv1.bias), p(b['y1']), n, coef,
+                                        p(b['phi']) if prev else None, p(wa), p(ba), p(wv), p(bv),
+                                        p(slots.uniform[t - 1]) if prev else None, n_act,
+                                        p(slots.action[t - 1]) if prev else None, p(slots.log_pi_a[t - 1]) if prev else None,
+                                        p(slots.entropy[t - 1]) if prev else None, p(slots.v[t - 1]) if prev else None, st)
+            lib.dra_conv_fwd_koc(2, 1, x2, wt2, b2, y2, n, 0, 1.0, ops.ACT["relu"], st)
+            lib.dra_conv_fwd_koc(3, 1, y2, wt3, b3, y3, n, 0, 1.0, ops.ACT["relu"], st)
+            lib.dra_linear_fwd(1, y3, w4, b4, phi, n, 3136, 512, ops.ACT["relu"], None, 0, st)
+        t = rows - 1
+        lib.dra_policy_heads_sample(p(b['phi']), p(wa), p(ba), p(wv), p(bv), p(slots.uniform[t]), n, 512, n_act, p(slots.action[t]),
+                                    p(slots.log_pi_a[t]), p(slots.entropy[t]), p(slots.v[t]), None, st)
+        slots.end()
+
+
 def _install_sampler(agent):
     """Data-parallel agents (and config.dp_invariant_sampling) sample actions from per-step noise that is the same
     however the environments are spread over ranks (dist.DataParallel.uniforms); everything else keeps the reference's
@@ -1162,6 +1237,7 @@ class A2CAgent(BaseAgent):
         self._dev_graph = _OnPolicyGraph(self)
         self._dev_state = _device_state_fn(self)
         _install_sampler(self)
+        self._pixel_rollout = _PixelRollout(self)
 
     def close(self):
         close_obj(self.task)
@@ -1188,6 +1264,13 @@ class A2CAgent(BaseAgent):
         t_len = config.rollout_length
         slots = _begin_rollout(self, self.task.num_envs)
         frames = self.task.states_all(plan)        # every observation of the planned rollout, one launch
+        if slots is not None and self._pixel_rollout.eligible():
+            self._pixel_rollout.run(frames, slots)     # three launches per rollout step (csrc/conv_v2.hip)
+            self._rollout_step += t_len + 1
+            n = self.task.num_envs
+            return self._learn_stacked(frames[:t_len].reshape((t_len * n,) + tuple(frames.shape[2:])),
+                                       slots.action[:t_len].reshape(-1), slots.v[:t_len + 1].unsqueeze(-1), plan.reward,
+                                       plan.mask, apply=apply)
         states, actions, values = [], [], []
         with torch.no_grad():
             for t in range(t_len):
@@ -1390,6 +1473,7 @@ class PPOAgent(BaseAgent):
         self._rollout_graph = dict(calls=0, graph=None, failed=False, k=0)
         self._rollout_step = 0
         _install_sampler(self)
+        self._pixel_rollout = _PixelRollout(self)
         # action noise of the device rollout: the rank-invariant stream when one is configured, else a seed of its own
         self._noise_seed = self.dp.noise_seed if self.dp.invariant_sampling else int(getattr(config, 'dp_noise_seed', None) or 0)
 
@@ -1425,19 +1509,24 @@ class PPOAgent(BaseAgent):
         slots = _begin_rollout(self, self.task.num_envs)
         frames = self.task.states_all(plan)        # every observation of the planned rollout, one launch
         storage = Storage(t_len)
-        with torch.no_grad():
-            for t in range(t_len):
-                state_t = self._dev_state(frames[t])
-                prediction = self.network(state_t)
+        fused = slots is not None and self._pixel_rollout.eligible()
+        if fused:
+            self._pixel_rollout.run(frames, slots)     # three launches per rollout step (csrc/conv_v2.hip)
+            self._rollout_step += t_len + 1
+        else:
+            with torch.no_grad():
+                for t in range(t_len):
+                    state_t = self._dev_state(frames[t])
+                    prediction = self.network(state_t)
+                    self._rollout_step += 1
+                    storage.feed(prediction)
+                    storage.feed({'reward': plan.reward[t], 'mask': plan.mask[t], 'state': state_t})
+                prediction = self.network(self._dev_state(frames[t_len]))
                 self._rollout_step += 1
-                storage.feed(prediction)
-                storage.feed({'reward': plan.reward[t], 'mask': plan.mask[t], 'state': state_t})
-            prediction = self.network(self._dev_state(frames[t_len]))
-            self._rollout_step += 1
-        if slots is not None:
-            slots.end()
-        if (slots is not None and prediction['v'].data_ptr() == slots.v[t_len].data_ptr()
-                and state_t.data_ptr() == frames[t_len - 1].data_ptr()):
+            if slots is not None:
+                slots.end()
+        if fused or (slots is not None and prediction['v'].data_ptr() == slots.v[t_len].data_ptr()
+                     and state_t.data_ptr() == frames[t_len - 1].data_ptr()):
             # the forwards wrote into the slots' rows and read the frames in place: the rollout IS these buffers (Storage's
             # per-key torch.cat launches and the reward / mask / value stacks of the scan disappear)
             from collections import namedtuple

@@ -19,6 +19,7 @@
 // Numerics: fp32 MFMA (exact fmaf chains), summation order differs from igemm.hip / the CPU
 // oracle only in the order of the four K-quarters.
 #include "actor_env.h"
+#include "rollout_roles.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -1512,6 +1513,65 @@ int dra_conv1_fwd_actor_fused(const void* frames, const int64_t* slot_field_dev,
   a.newest_frame = f->mode == 1 ? reinterpret_cast<const uint8_t*>(newest_frame) : nullptr;
   if (conv_b1_waves() == 8) return launch_conv1_actor_fused<8>(a, *f, dra_stream(stream));
   return launch_conv1_actor_fused<4>(a, *f, dra_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// An A2C / PPO rollout step over NatureConvBody at 8-32 environments as FOUR launches instead of five (agents._PixelRollout;
+// every launch of such a step is a few dozen workgroups at its latency floor, 5.6-6.6 us each: profiles/r05t_kernel_stats_*):
+//   [conv1 of step t | policy head of step t-1]   the synthetic environments' observations do not depend on the actions (they
+//       are generated for the whole rollout up front), so step t's conv1 has nothing to wait for in step t-1's head: the head's
+//       ceil(B / 4) workgroups ride in front of conv1's 13 B (the DQN actor's conv1_actor_fused_kernel does the same): 5.7 us
+//       against 5.6 + 6.0 + a boundary
+//   conv2, conv3, fc4                              the plain launches
+// Same device functions as the separate launches (conv_fwd_v2_body, rollout_roles.h): bit-identical results.
+// (Measured and removed: [conv3 | fc4] as one launch -- fc4's 256 workgroups fetching their 6.4 MB of weights while conv3 runs,
+// then waiting on an arrival counter -- took 13.9 us against 6.6 + 6.3 + a 0.7 us boundary: the write-through of conv3's planes,
+// the arrival count, the poll and the cold read of the hand-over cost more than the boundary they replace; with an acquire
+// fence per wave in front of the reads 27 us.  a2c_pixel 215 k against 224 k env-steps/s, ppo_pixel 115 k against 118 k:
+// profiles/r05x_bench_agents_c3fc4_ab.jsonl.)
+__global__ void __launch_bounds__(256)
+rollout_conv1_heads_kernel(const ConvV2Args a, const PolicyHeadArgs h, const int head_wgs) {
+  __shared__ float s_out[4][68];
+  if ((int)blockIdx.x < head_wgs) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + wave;
+    if (b < h.B) policy_head_row(h, b, lane, s_out[wave]);
+    return;
+  }
+  ActorFuse none;
+  none.mode = 0;
+  conv_fwd_v2_body<VG1, true, 1, 4, false>(a, none, (int)blockIdx.x - head_wgs, 0, 0, false);
+}
+
+DRA_API int dra_rollout_conv1_heads(const void* frames_u8, const float* wt1, const float* b1, float* y1, int batch, double u8_coef,
+                                    const float* phi_prev, const float* w_a, const float* b_a, const float* w_v, const float* b_v,
+                                    const float* uniform, int n_actions, int64_t* out_action, float* out_log_pi_a,
+                                    float* out_entropy, float* out_v, void* stream) {
+  if (!frames_u8 || !wt1 || !b1 || !y1 || batch < 1 || batch > 4096) return DRA_EINVAL;
+  if (phi_prev && (!w_a || !w_v || !uniform || !out_action || !out_log_pi_a || !out_entropy || !out_v || n_actions < 1 ||
+                   n_actions > 64))
+    return DRA_EINVAL;
+  using T = V2Tile<VG1, 1>;
+  ConvV2Args a;
+  a.x[0] = frames_u8; a.wt[0] = wt1; a.bias[0] = b1; a.y[0] = y1;
+  a.batch = batch; a.act = DRA_ACT_RELU; a.coef = u8_coef; a.ring_slot = nullptr; a.ring_cap = 0; a.stack_age = nullptr;
+  a.slot_seq = nullptr; a.slot_entries = 0; a.slot_stride = 0; a.newest_frame = nullptr;
+  PolicyHeadArgs h;
+  memset(&h, 0, sizeof(h));
+  int head_wgs = 0;
+  if (phi_prev) {
+    h.x = phi_prev; h.w0 = w_a; h.b0 = b_a; h.w1 = w_v; h.b1 = b_v; h.uniform = uniform; h.action_in = nullptr;
+    h.out_action = out_action; h.out_lp = out_log_pi_a; h.out_ent = out_entropy; h.out_v = out_v; h.out_logits = nullptr;
+    h.B = batch; h.K = 512; h.A = n_actions;
+    head_wgs = (batch + 3) / 4;
+  }
+  constexpr size_t img = (size_t)VG1::C * T::CS * sizeof(float);
+  constexpr size_t red = (size_t)4 * 16 * 64 * sizeof(float);
+  constexpr size_t bytes = img > red ? img : red;
+  static_assert(bytes <= 64 * 1024, "conv1's latency shape fits the default dynamic LDS limit");
+  hipLaunchKernelGGL(rollout_conv1_heads_kernel, dim3(head_wgs + T::TPG * batch), dim3(256), bytes, dra_stream(stream), a, h, head_wgs);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
 }
 
 // Layout conversion [OC][K] <-> [K][OC] for one layer's weight tensor (tests, generic path, and

@@ -1,5 +1,6 @@
 // K2/K3 exports: NatureConvBody / FCBody / head contractions (templates in igemm.h).
 #include "igemm.h"
+#include "rollout_roles.h"
 #include <stdlib.h>
 
 template <class G, int BM, int BN, int BK, bool U8>
@@ -210,73 +211,19 @@ linear_gemv_kernel(LinPtrs q, int B, int K, int O, int act) {
 // the first is used; per sample: products, a wave sum, the four quarter sums met in LDS as (q0 + q1) + (q2 + q3).  No barrier
 // before the last step, 256 workgroups for 512 outputs.  Per-sample arithmetic does not depend on the batch.
 // grid (ceil(O / 2), nz, ceil(B / 32)).  K % 4 == 0, K <= 4096 * ... R * 64 * 4 * 4.
-template <int R>
+template <int R, int RB, int WPR>
 __global__ void __launch_bounds__(512)
-linear_gemv_rows_kernel(LinPtrs q, int B, int K, int O, int act) {
+linear_gemv_rows_kernel(LinPtrs q, int B, int K, int O, int act) {     // body: rollout_roles.h gemv_rows_body
   __shared__ float s_part[32][8];
-  const int z = blockIdx.y, b0 = blockIdx.z * 32;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = wave >> 2, quarter = wave & 3;
-  const int o = blockIdx.x * 2 + row;
-  const int nv = K >> 2, nvq = (nv + 3) >> 2;            // float4 per row / per quarter
-  const int v0 = quarter * nvq, v1 = min(nv, v0 + nvq);
-  const int nb = min(32, B - b0);
-  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(q.w[z] + (int64_t)min(o, O - 1) * K);
-  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(q.x[z] + (int64_t)b0 * K);
-  float4 wv[R];
-  int vi[R];
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int v = v0 + lane + 64 * i;
-    vi[i] = v < v1 ? v : -1;
-    wv[i] = w4[v < v1 ? v : (v1 > v0 ? v1 - 1 : 0)];
-  }
-  for (int bb = 0; bb < nb; bb += 8) {
-    float4 xv[8][R];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int b = min(bb + u, nb - 1);
-#pragma unroll
-      for (int i = 0; i < R; ++i) xv[u][i] = x4[(int64_t)b * nv + (vi[i] >= 0 ? vi[i] : 0)];
-    }
-    float acc[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      float a_ = 0.f;
-#pragma unroll
-      for (int i = 0; i < R; ++i) {
-        const float4 a = wv[i], xx = xv[u][i];
-        if (vi[i] >= 0) a_ += (a.x * xx.x + a.y * xx.y) + (a.z * xx.z + a.w * xx.w);
-      }
-      acc[u] = a_;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {      // eight independent butterflies, interleaved by offset
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += __shfl_xor(acc[u], off, 64);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (bb + u < nb) s_part[bb + u][wave] = acc[u];
-    }
-  }
-  __syncthreads();
-  // thread t < 2 * nb: (row, sample)
-  const int t = threadIdx.x;
-  if (t < 2 * nb) {
-    const int r = t / nb, b = t - r * nb, oo = blockIdx.x * 2 + r;
-    if (oo < O) {
-      const float v = (s_part[b][4 * r] + s_part[b][4 * r + 1]) + (s_part[b][4 * r + 2] + s_part[b][4 * r + 3]);
-      const float bias = q.bias[z] ? q.bias[z][oo] : 0.f;
-      q.y[z][(int64_t)(b0 + b) * O + oo] = act_apply(v + bias, act);
-    }
-  }
+  const int z = blockIdx.y;
+  gemv_rows_body<R, RB, WPR>(q.x[z], q.w[z], q.bias[z], q.y[z], blockIdx.x, blockIdx.z * 32, B, K, O, act, s_part);
 }
 
-template <int R>
+template <int R, int RB, int WPR>
 static int launch_gemv_rows(const LinPtrs& q, int nz, int batch, int in_features, int out_features, int act, hipStream_t st) {
-  hipLaunchKernelGGL(linear_gemv_rows_kernel<R>, dim3((out_features + 1) / 2, nz, (batch + 31) / 32), dim3(512), 0, st, q, batch,
-                     in_features, out_features, act);
+  constexpr int RPW = 8 / WPR;
+  hipLaunchKernelGGL((linear_gemv_rows_kernel<R, RB, WPR>), dim3((out_features + RPW - 1) / RPW, nz, (batch + 31) / 32), dim3(512), 0, st,
+                     q, batch, in_features, out_features, act);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -301,49 +248,6 @@ static int gemv_enabled() {
 // butterflies run interleaved.  Per-output arithmetic (lane-strided partial sums in i order, then the butterfly) is exactly
 // linear_gemv_kernel's: the update's forward through the two Linear modules reproduces these values bit for bit.
 // (The staging form took 12.7 us for 16 rows x 5 outputs, 15 % of an A2C agent step: profiles/r04ab_kernel_stats_a2c_pixel_16.txt.)
-// heads_row_outputs: the wave's work for input row b; sink(o, value) runs on lane 0 for every output o of [0, O0 + O1).
-template <class Sink>
-__device__ __forceinline__ void heads_row_outputs(const float* __restrict__ x, const float* __restrict__ w0,
-                                                  const float* __restrict__ b0, int O0, const float* __restrict__ w1,
-                                                  const float* __restrict__ b1, int O1, int b, int K, int act, int lane, Sink sink) {
-  float xv[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) xv[i] = (lane + 64 * i < K) ? x[(int64_t)b * K + lane + 64 * i] : 0.f;
-  const int OT = O0 + O1;
-  for (int oc = 0; oc < OT; oc += 8) {
-    float wv[8][8], bias[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int o = min(oc + u, OT - 1);
-      const float* __restrict__ row = o < O0 ? w0 + (int64_t)o * K : w1 + (int64_t)(o - O0) * K;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) wv[u][i] = (lane + 64 * i < K) ? row[lane + 64 * i] : 0.f;
-      const float* __restrict__ bp = o < O0 ? b0 : b1;
-      bias[u] = bp ? bp[o < O0 ? o : o - O0] : 0.f;
-    }
-    float part[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      float p = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) p += (lane + 64 * i < K) ? xv[i] * wv[u][i] : 0.f;
-      part[u] = p;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) part[u] += __shfl_xor(part[u], off, 64);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int o = oc + u;
-        if (o < OT) sink(o, act_apply(part[u] + bias[u], act));
-      }
-    }
-  }
-}
-
 __global__ void __launch_bounds__(256)
 linear_heads_rows_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ b0,
                          float* __restrict__ y0, int O0, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -363,28 +267,21 @@ linear_heads_rows_kernel(const float* __restrict__ x, const float* __restrict__ 
 // torch.rand, categorical_fwd) in a rollout step of eight before (profiles/r05q_kernel_stats_a2c_pixel_16.txt); the uniforms now
 // come from one draw per rollout (nets.RolloutSlots).  Bit-identical with the separate launches for the same uniforms.
 __global__ void __launch_bounds__(256)
-policy_heads_sample_kernel(const float* __restrict__ x, const float* __restrict__ w0, const float* __restrict__ b0, int A,
-                           const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ uniform,
-                           const int64_t* __restrict__ action_in, int B, int K, int64_t* __restrict__ out_action,
-                           float* __restrict__ out_lp, float* __restrict__ out_ent, float* __restrict__ out_v,
-                           float* __restrict__ out_logits) {
+policy_heads_sample_kernel(const PolicyHeadArgs h) {       // body: rollout_roles.h policy_head_row
   __shared__ float s_out[4][68];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + wave;
-  if (b >= B) return;
-  float* so = s_out[wave];
-  heads_row_outputs(x, w0, b0, A, w1, b1, 1, b, K, /*act=*/0, lane, [&](int o, float v) { so[o] = v; });
-  if (lane == 0) {      // (the same lane wrote so[]: program order, no barrier)
-    int64_t act;
-    float lp, ent;
-    categorical_row(so, A, action_in != nullptr, action_in ? action_in[b] : 0, uniform ? uniform[b] : 0.f, &act, &lp, &ent);
-    if (out_action) out_action[b] = act;
-    out_lp[b] = lp;
-    out_ent[b] = ent;
-    out_v[b] = so[A];
-    if (out_logits)
-      for (int a = 0; a < A; ++a) out_logits[(int64_t)b * A + a] = so[a];
-  }
+  if (b >= h.B) return;
+  policy_head_row(h, b, lane, s_out[wave]);
+}
+
+static PolicyHeadArgs head_args(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
+                                const float* uniform, const int64_t* action_in, int batch, int in_features, int n_actions,
+                                int64_t* out_action, float* out_lp, float* out_ent, float* out_v, float* out_logits) {
+  PolicyHeadArgs h;
+  h.x = x; h.w0 = w0; h.b0 = b0; h.w1 = w1; h.b1 = b1; h.uniform = uniform; h.action_in = action_in; h.out_action = out_action;
+  h.out_lp = out_lp; h.out_ent = out_ent; h.out_v = out_v; h.out_logits = out_logits; h.B = batch; h.K = in_features; h.A = n_actions;
+  return h;
 }
 
 DRA_API int dra_policy_heads_sample(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
@@ -393,9 +290,9 @@ DRA_API int dra_policy_heads_sample(const float* x, const float* w0, const float
   if (!x || !w0 || !w1 || !uniform || !out_action || !out_log_pi_a || !out_entropy || !out_v || batch < 1 || batch > 65536 ||
       in_features < 1 || in_features > 512 || n_actions < 1 || n_actions > 64)
     return DRA_EINVAL;
-  hipLaunchKernelGGL(policy_heads_sample_kernel, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), x, w0, b0, n_actions, w1,
-                     b1, uniform, (const int64_t*)nullptr, batch, in_features, out_action, out_log_pi_a, out_entropy, out_v,
-                     out_logits);
+  hipLaunchKernelGGL(policy_heads_sample_kernel, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream),
+                     head_args(x, w0, b0, w1, b1, uniform, nullptr, batch, in_features, n_actions, out_action, out_log_pi_a,
+                               out_entropy, out_v, out_logits));
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -408,9 +305,9 @@ DRA_API int dra_policy_heads_given(const float* x, const float* w0, const float*
   if (!x || !w0 || !w1 || !action || !out_log_pi_a || !out_entropy || !out_v || !out_logits || batch < 1 || batch > 65536 ||
       in_features < 1 || in_features > 512 || n_actions < 1 || n_actions > 64)
     return DRA_EINVAL;
-  hipLaunchKernelGGL(policy_heads_sample_kernel, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), x, w0, b0, n_actions, w1,
-                     b1, (const float*)nullptr, action, batch, in_features, (int64_t*)nullptr, out_log_pi_a, out_entropy, out_v,
-                     out_logits);
+  hipLaunchKernelGGL(policy_heads_sample_kernel, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream),
+                     head_args(x, w0, b0, w1, b1, nullptr, action, batch, in_features, n_actions, nullptr, out_log_pi_a, out_entropy,
+                               out_v, out_logits));
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -634,8 +531,11 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
     }
     if (aligned) {
       const int rq = ((((in_features >> 2) + 3) >> 2) + 63) / 64;     // float4 per lane of a K quarter
-      if (rq <= 2) return launch_gemv_rows<2>(q, nz, batch, in_features, out_features, act, st);
-      return launch_gemv_rows<4>(q, nz, batch, in_features, out_features, act, st);
+      // (sixteen samples per round with a row's K in eighths -- gemv_rows_body<2, 16, 8>, one round for A2C's 16 environments
+      // instead of two -- measured SLOWER: a2c_pixel 215 k against 224 k env-steps/s, profiles/r05y_bench_agents_gemv16.jsonl; and
+      // its summation tree differs from the eight-sample form the fused DQN learner's actor reproduces.  Not dispatched.)
+      if (rq <= 2) return launch_gemv_rows<2, 8, 4>(q, nz, batch, in_features, out_features, act, st);
+      return launch_gemv_rows<4, 8, 4>(q, nz, batch, in_features, out_features, act, st);
     }
   }
   if (in_features == 3136 && batch > 32 && batch <= 4096 && workspace &&

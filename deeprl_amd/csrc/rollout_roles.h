@@ -1,0 +1,158 @@
+// Device-side pieces shared by the stand-alone kernels of igemm.hip and the fused rollout launches of conv_v2.hip (an A2C / PPO
+// rollout step over NatureConvBody as four launches: [conv1 | policy head of the previous step], conv2, conv3, fc4).
+// One statement of each piece, so that a fused launch and the separate kernels give the same bits.
+#pragma once
+#include "common.h"
+
+__device__ __forceinline__ float rr_act(float v, int act) {      // DRA_ACT_*: igemm.h act_apply / conv_v2.hip v2_act
+  if (act == DRA_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == DRA_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+// Two linear heads on the same features: the wave's work for input row b (in_features K <= 512: 8 registers per lane, k = lane +
+// 64 i); the weight rows of up to eight outputs are requested together with them -- one memory round trip, no LDS, no barrier --
+// then the eight dot products and their wave butterflies run interleaved.  sink(o, value) runs on lane 0 for every output o of
+// [0, O0 + O1).  Per-output arithmetic (lane-strided partial sums in i order, then the butterfly) is linear_gemv_kernel's.
+template <class Sink>
+__device__ __forceinline__ void heads_row_outputs(const float* __restrict__ x, const float* __restrict__ w0,
+                                                  const float* __restrict__ b0, int O0, const float* __restrict__ w1,
+                                                  const float* __restrict__ b1, int O1, int b, int K, int act, int lane, Sink sink) {
+  float xv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) xv[i] = (lane + 64 * i < K) ? x[(int64_t)b * K + lane + 64 * i] : 0.f;
+  const int OT = O0 + O1;
+  for (int oc = 0; oc < OT; oc += 8) {
+    float wv[8][8], bias[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int o = min(oc + u, OT - 1);
+      const float* __restrict__ row = o < O0 ? w0 + (int64_t)o * K : w1 + (int64_t)(o - O0) * K;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wv[u][i] = (lane + 64 * i < K) ? row[lane + 64 * i] : 0.f;
+      const float* __restrict__ bp = o < O0 ? b0 : b1;
+      bias[u] = bp ? bp[o < O0 ? o : o - O0] : 0.f;
+    }
+    float part[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float p = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p += (lane + 64 * i < K) ? xv[i] * wv[u][i] : 0.f;
+      part[u] = p;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) part[u] += __shfl_xor(part[u], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = oc + u;
+        if (o < OT) sink(o, rr_act(part[u] + bias[u], act));
+      }
+    }
+  }
+}
+
+// A categorical actor-critic's whole policy head for input row b (network_heads.py:240-255): logits = x W0^T + b0 [A <= 64],
+// v = x w1^T + b1, then Categorical(logits) of the row on the lane that holds the outputs -- inverse-CDF sample from uniform[b]
+// (action_in == nullptr) or the given action, log_pi_a, entropy (common.h categorical_row).  so: >= A + 1 floats of LDS owned by
+// the calling wave.
+struct PolicyHeadArgs {
+  const float *x, *w0, *b0, *w1, *b1, *uniform;
+  const int64_t* action_in;
+  int64_t* out_action;
+  float *out_lp, *out_ent, *out_v, *out_logits;
+  int B, K, A;
+};
+__device__ __forceinline__ void policy_head_row(const PolicyHeadArgs& h, int b, int lane, float* so) {
+  heads_row_outputs(h.x, h.w0, h.b0, h.A, h.w1, h.b1, 1, b, h.K, /*act=*/0, lane, [&](int o, float v) { so[o] = v; });
+  if (lane == 0) {      // (the same lane wrote so[]: program order, no barrier)
+    int64_t act;
+    float lp, ent;
+    categorical_row(so, h.A, h.action_in != nullptr, h.action_in ? h.action_in[b] : 0, h.uniform ? h.uniform[b] : 0.f, &act, &lp,
+                    &ent);
+    if (h.out_action) h.out_action[b] = act;
+    h.out_lp[b] = lp;
+    h.out_ent[b] = ent;
+    h.out_v[b] = so[h.A];
+    if (h.out_logits)
+      for (int a = 0; a < h.A; ++a) h.out_logits[(int64_t)b * h.A + a] = so[a];
+  }
+}
+
+// A wide linear layer at rollout batch sizes (fc4 of NatureConvBody, 3136 -> 512, for the 8 / 16 environments of one rollout
+// step): a workgroup of EIGHT waves owns 8 / WPR output rows (o2 = index of the group), each row's reduction split over WPR waves
+// (K parts); a lane keeps its R float4 of the weight row in registers and, per round, the matching float4 of up to RB input
+// rows -- all requested before the first is used; per sample: products, a wave sum, the WPR part sums met in LDS as a fixed
+// pairwise tree.  Per-sample arithmetic depends on (R, WPR) only.  K % 4 == 0, K <= 4 * 64 * WPR * R.
+//   <4, 8, 4>: two rows per workgroup, eight samples per round (<= 8 samples: one round; 16 samples were two dependent rounds,
+//              9.4 us against 6.3: profiles/r05t_kernel_stats_a2c_pixel_16.txt)
+//   <2, 16, 8>: one row per workgroup, sixteen samples per round (the same 128 registers of inputs in flight)
+// s_part: [32][8] floats of LDS.
+template <int R, int RB, int WPR>
+__device__ __forceinline__ void gemv_rows_body(const float* __restrict__ x, const float* __restrict__ w,
+                                               const float* __restrict__ bias, float* __restrict__ y, int o2, int b0, int B, int K,
+                                               int O, int act, float (*s_part)[8]) {
+  static_assert(WPR == 4 || WPR == 8, "a row's K parts: 4 or 8 waves");
+  constexpr int RPW = 8 / WPR;                             // output rows per workgroup
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row = wave / WPR, part = wave % WPR;
+  const int o = o2 * RPW + row;
+  const int nv = K >> 2, nvq = (nv + WPR - 1) / WPR;       // float4 per row / per part
+  const int v0 = part * nvq, v1 = min(nv, v0 + nvq);
+  const int nb = min(32, B - b0);
+  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w + (int64_t)min(o, O - 1) * K);
+  const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + (int64_t)b0 * K);
+  float4 wv[R];
+  int vi[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int v = v0 + lane + 64 * i;
+    vi[i] = v < v1 ? v : -1;
+    wv[i] = w4[v < v1 ? v : (v1 > v0 ? v1 - 1 : 0)];
+  }
+  for (int bb = 0; bb < nb; bb += RB) {
+    float4 xv[RB][R];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int b = min(bb + u, nb - 1);
+#pragma unroll
+      for (int i = 0; i < R; ++i) xv[u][i] = x4[(int64_t)b * nv + (vi[i] >= 0 ? vi[i] : 0)];
+    }
+    float acc[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      float a_ = 0.f;
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const float4 a = wv[i], xx = xv[u][i];
+        if (vi[i] >= 0) a_ += (a.x * xx.x + a.y * xx.y) + (a.z * xx.z + a.w * xx.w);
+      }
+      acc[u] = a_;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {      // RB independent butterflies, interleaved by offset
+#pragma unroll
+      for (int u = 0; u < RB; ++u) acc[u] += __shfl_xor(acc[u], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < RB; ++u)
+        if (bb + u < nb) s_part[bb + u][wave] = acc[u];
+    }
+  }
+  __syncthreads();
+  // thread t < RPW * nb: (row, sample)
+  const int t = threadIdx.x;
+  if (t < RPW * nb) {
+    const int r = t / nb, b = t - r * nb, oo = o2 * RPW + r;
+    if (oo < O) {
+      const float* sp = &s_part[b][WPR * r];
+      float v = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+      if constexpr (WPR == 8) v = v + ((sp[4] + sp[5]) + (sp[6] + sp[7]));
+      y[(int64_t)(b0 + b) * O + oo] = rr_act(v + (bias ? bias[oo] : 0.f), act);
+    }
+  }
+}

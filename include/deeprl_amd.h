@@ -374,6 +374,17 @@ int dra_gather_rows(int n_fields, const void* const* src, void* const* dst, cons
 int dra_synth_stacks(const int64_t* counter_dev, const int32_t* age_dev, const int64_t* seed_dev, int n_env, int history,
                      void* out_u8, void* stream);
 
+/* ---- an A2C / PPO rollout step over NatureConvBody at 8-32 device-resident environments as four launches (agents._PixelRollout;
+ * A2C_agent.py:26-34 / PPO_agent.py:33-47 under no_grad): [conv1 of step t | the policy head of step t-1], conv2, conv3
+ * (dra_conv_fwd_koc), fc4 (dra_linear_fwd).  Same arithmetic as the separate launches, bit for bit. */
+/* conv1 (+ ReLU) of uint8 frames [batch][4][84][84] -> y1 [batch][32][20][20]; and, when phi_prev != NULL, dra_policy_heads_sample of
+ * the previous step's features phi_prev [batch][512] (workgroups of their own in the same launch: the observations do not depend on
+ * the previous step's actions) */
+int dra_rollout_conv1_heads(const void* frames_u8, const float* wt1, const float* b1, float* y1, int batch, double u8_coef,
+                            const float* phi_prev, const float* w_a, const float* b_a, const float* w_v, const float* b_v,
+                            const float* uniform, int n_actions, int64_t* out_action, float* out_log_pi_a, float* out_entropy,
+                            float* out_v, void* stream);
+
 /* ---- fused DQN learner + device-resident actor: DQN_agent.py:24-45 (actor step), :114-138 (update) for
  * VanillaNet(NatureConvBody).  All five flat buffers are caller-owned f32[n_params] with the tensor order
  * conv1.w, conv1.b, conv2.w, conv2.b, conv3.w, conv3.b, fc4.w, fc4.b, head.w, head.b at `offset[]` (16-byte

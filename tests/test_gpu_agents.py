@@ -850,6 +850,52 @@ def test_in_place_parameter_gradients_equal_autograd_accumulation(dra, monkeypat
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+@pytest.mark.parametrize("kind,workers", [("a2c", 16), ("ppo", 8), ("a2c", 5)])
+def test_fused_rollout_launches_equal_the_module_path(dra, monkeypatch, kind, workers):
+    """agents._PixelRollout (round 5): a rollout step as [conv1 | head of the previous step], conv2, conv3, fc4 -- the same device
+    functions as the five separate launches of network.forward, the head one step behind in conv1's launch: the agents end on
+    the SAME parameters bit for bit and draw the same actions."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    outs = []
+    for fused in (True, False):
+        cfg = d.Config()
+        cfg.merge(dict(game="synthetic-atari", log_level=0, tag="fr%d" % fused, device_env=True, fused_rollout=fused))
+        cfg.num_workers = workers
+        cfg.task_fn = lambda: d.Task(cfg.game, num_envs=cfg.num_workers, seed=11, synthetic_done_period=13)
+        cfg.eval_env = d.Task(cfg.game, seed=12)
+        cfg.network_fn = lambda: d.CategoricalActorCriticNet(cfg.state_dim, cfg.action_dim, d.NatureConvBody())
+        cfg.state_normalizer, cfg.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
+        cfg.discount, cfg.use_gae, cfg.entropy_weight = 0.99, True, 0.01
+        if kind == "a2c":
+            cfg.optimizer_fn = lambda p: torch.optim.RMSprop(p, lr=1e-3, alpha=0.99, eps=1e-5)
+            cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 1.0, 5, 5
+            cls, n = d.A2CAgent, 12
+        else:
+            cfg.optimizer_fn = lambda p: torch.optim.Adam(p, lr=1e-3)
+            cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 0.95, 32, 0.5
+            cfg.optimization_epochs, cfg.mini_batch_size, cfg.ppo_ratio_clip, cfg.shared_repr = 2, 64, 0.1, True
+            cfg.max_steps, cfg.log_interval, cfg.target_kl = 1e6, 10 ** 9, 0.01
+            cls, n = d.PPOAgent, 5
+        d.random_seed(21)
+        torch.manual_seed(22)
+        agent = cls(cfg)
+        assert agent._pixel_rollout.eligible() == fused
+        acts = []
+        for _ in range(n):
+            agent.step()
+            acts.append(agent.network.rollout_slots.action.clone())
+        torch.cuda.synchronize()
+        outs.append(({k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()},
+                     torch.stack(acts).cpu().numpy(), agent.network.rollout_slots.log_pi_a.cpu().numpy().copy()))
+        agent.close()
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert len(np.unique(outs[0][1])) > 1
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+
+
 @pytest.mark.parametrize("kind", ["a2c", "ppo"])
 def test_deferred_conv_folds_give_the_same_update(dra, monkeypatch, kind):
     """config.defer_conv_folds (round 5, default on): the conv layers leave their weight-gradient slabs unfolded and the

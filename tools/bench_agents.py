@@ -78,9 +78,9 @@ def dqn_family(kind, replay_cls, ring=200_000, fused=True, device=False, async_a
     return agent_cls(c), dict(env_per_step=4, updates_per_step=1)
 
 
-def a2c_pixel(workers=16, device=True):
+def a2c_pixel(workers=16, device=True, **switches):
     c = d.Config()
-    c.merge(dict(game="BreakoutNoFrameskip-v4", log_level=0, tag="bench", device_env=device))
+    c.merge(dict(game="BreakoutNoFrameskip-v4", log_level=0, tag="bench", device_env=device, **switches))
     c.num_workers = workers
     c.task_fn = lambda: d.Task(c.game, num_envs=c.num_workers, seed=1)
     c.eval_env = d.Task(c.game, seed=2)
@@ -111,9 +111,9 @@ def ppo_continuous(workers=1, device=True, fused=True):
     return d.PPOAgent(c), dict(env_per_step=2048 * workers, updates_per_step=n_mb)
 
 
-def ppo_pixel(workers=8, device=True):
+def ppo_pixel(workers=8, device=True, **switches):
     c = d.Config()
-    c.merge(dict(game="BreakoutNoFrameskip-v4", log_level=0, tag="bench", skip=False, device_env=device))
+    c.merge(dict(game="BreakoutNoFrameskip-v4", log_level=0, tag="bench", skip=False, device_env=device, **switches))
     c.num_workers = workers
     c.task_fn = lambda: d.Task(c.game, num_envs=c.num_workers, seed=1)
     c.eval_env = d.Task(c.game, seed=2)
@@ -146,6 +146,8 @@ CASES = {
     "a2c_pixel_16": lambda: a2c_pixel(16),                      # device-resident environments (the default)
     "a2c_pixel_16_host": lambda: a2c_pixel(16, device=False),   # host emulators
     "ppo_pixel_8": lambda: ppo_pixel(8),
+    "a2c_pixel_16_modules": lambda: a2c_pixel(16, fused_rollout=False),         # rollout through network.forward (5 launches / step)
+    "ppo_pixel_8_modules": lambda: ppo_pixel(8, fused_rollout=False),
     "ppo_pixel_8_host": lambda: ppo_pixel(8, device=False),
     "ppo_continuous_1": lambda: ppo_continuous(1),
     "ppo_continuous_16": lambda: ppo_continuous(16),                                  # device environments + persistent kernels
