@@ -428,6 +428,24 @@ extern "C" int dra_linear_bwd_x_one512(const float* dy, const float* w, const fl
   return launch_multi(rd, rd.tiles_n * ((batch + 31) / 32), none, 0, none, 0, dra_stream(stream));
 }
 
+// Both gradients of such a layer in ONE launch: the input gradient's one-pass role and the weight / bias gradient's implicit GEMM
+// (igemm.hip dra_linear_bwd_w's own problem) read the same dy and do not depend on each other -- back to back they were 9.9 + 10.1
+// us of an A2C update and 17.5 + 20 us of a PPO minibatch, each launch filling the chip partly
+// (profiles/r05z2_kernel_stats_a2c_pixel_16.txt).  Same roles, same arithmetic.
+DRA_API int dra_linear_bwd_xw_one512(const float* dy, const float* w, const float* x, int x_is_relu_output, float* dx, float* dw,
+                                     float* db, int batch, int in_features, void* stream) {
+  if (!dy || !w || !x || !dx || !dw || batch < 1 || in_features < 1024) return DRA_EINVAL;
+  LinDgradOne<512> rd;
+  rd.dy = dy; rd.w = w; rd.xact = x_is_relu_output ? x : nullptr; rd.dx = dx; rd.B = batch; rd.I = in_features;
+  rd.act = x_is_relu_output ? ACT_RELU : ACT_NONE;
+  rd.tiles_n = (in_features + 31) / 32;
+  LinWgrad<64, 64, 32> p;
+  p.M = 512; p.N = in_features + 1; p.K = batch; p.I = in_features; p.dy = dy; p.x = x; p.dw = dw; p.db = db;
+  auto rw = make_igemm_role(p, 1);
+  NoRole none;
+  return launch_multi(rd, rd.tiles_n * ((batch + 31) / 32), rw, rw.tiles, none, 0, dra_stream(stream));
+}
+
 // fc4 forward partial sums in one pass per K split (in_features = 3136, ksplit = 8): same contract as
 // dra_linear_fwd_slabs.
 DRA_API int dra_linear_fwd_slabs_one(int nz, const float* const* x, const float* const* w, int batch, int in_features,

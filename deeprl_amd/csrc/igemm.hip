@@ -219,11 +219,10 @@ linear_gemv_rows_kernel(LinPtrs q, int B, int K, int O, int act) {     // body: 
   gemv_rows_body<R, RB, WPR>(q.x[z], q.w[z], q.bias[z], q.y[z], blockIdx.x, blockIdx.z * 32, B, K, O, act, s_part);
 }
 
-template <int R, int RB, int WPR>
+template <int R>
 static int launch_gemv_rows(const LinPtrs& q, int nz, int batch, int in_features, int out_features, int act, hipStream_t st) {
-  constexpr int RPW = 8 / WPR;
-  hipLaunchKernelGGL((linear_gemv_rows_kernel<R, RB, WPR>), dim3((out_features + RPW - 1) / RPW, nz, (batch + 31) / 32), dim3(512), 0, st,
-                     q, batch, in_features, out_features, act);
+  hipLaunchKernelGGL((linear_gemv_rows_kernel<R, 8, 4>), dim3((out_features + 1) / 2, nz, (batch + 31) / 32), dim3(512), 0, st, q, batch,
+                     in_features, out_features, act);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -534,8 +533,8 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
       // (sixteen samples per round with a row's K in eighths -- gemv_rows_body<2, 16, 8>, one round for A2C's 16 environments
       // instead of two -- measured SLOWER: a2c_pixel 215 k against 224 k env-steps/s, profiles/r05y_bench_agents_gemv16.jsonl; and
       // its summation tree differs from the eight-sample form the fused DQN learner's actor reproduces.  Not dispatched.)
-      if (rq <= 2) return launch_gemv_rows<2, 8, 4>(q, nz, batch, in_features, out_features, act, st);
-      return launch_gemv_rows<4, 8, 4>(q, nz, batch, in_features, out_features, act, st);
+      if (rq <= 2) return launch_gemv_rows<2>(q, nz, batch, in_features, out_features, act, st);
+      return launch_gemv_rows<4>(q, nz, batch, in_features, out_features, act, st);
     }
   }
   if (in_features == 3136 && batch > 32 && batch <= 4096 && workspace &&

@@ -156,3 +156,11 @@ __device__ __forceinline__ void gemv_rows_body(const float* __restrict__ x, cons
     }
   }
 }
+
+// (Measured and removed, round 5 -- the eight-wave form above stayed the fastest at 8 AND 16 samples:
+//   gemv_rows_body<2, 16, 8>  sixteen samples per round, K in eighths             a2c_pixel 215 k against 224-226 k env-steps/s
+//   eight-sample groups on separate workgroups (two per output pair at 16)      221 k
+//   two output rows per wave, four waves per workgroup (half the input reads)   222 k; ppo_pixel 116.1 k against 117.6 k
+//  profiles/r05y_bench_agents_gemv16.jsonl, r05z3_bench_agents_gemv_split.jsonl, r05z4_bench_agents_gemv_pair.jsonl (second pair
+//  of lines: the eight-wave form in the same call): the launch is a latency chain -- weights, inputs,
+//  butterflies, LDS exchange -- that eight waves per workgroup hide best, not a traffic problem.)

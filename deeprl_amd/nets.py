@@ -144,7 +144,15 @@ class _LinearFn(torch.autograd.Function):
         # (a consumer that knows this layer ends in a fused ReLU hands the gradient of the pre-activation over: _PolicyHeadFn)
         dpre = dy if (ctx.act == "relu" and _already_masked(dy)) else (ops.act_bwd(dy, y, ctx.act) if ctx.act else dy)
         gw, gb = (_grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])) if _claim_direct(ctx.params) else (None, None)
-        if gw is not None and gw.is_contiguous() and (not ctx.has_bias or (gb is not None and gb.is_contiguous())):
+        direct = gw is not None and gw.is_contiguous() and (not ctx.has_bias or (gb is not None and gb.is_contiguous()))
+        if (direct and ctx.needs_input_grad[0] and w.shape[0] == 512 and w.shape[1] >= 1024 and w.is_contiguous()
+                and x.is_contiguous()):
+            # fc4-shaped: both gradients in one launch (the two problems share dy and nothing else)
+            dx, _, _ = ops.linear_bwd_xw_512(dpre, x, w, ctx.x_relu, dw=gw, db=gb if ctx.has_bias else None, want_bias=ctx.has_bias)
+            if ctx.x_relu:
+                _mark_masked(dx)
+            return dx, None, None, None, None
+        if direct:
             ops.linear_bwd_w(dpre, x, dw=gw, db=gb if ctx.has_bias else None, want_bias=ctx.has_bias)
             dw = db = None
         else:

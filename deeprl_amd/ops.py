@@ -706,6 +706,20 @@ def linear_bwd_w(dy, x, dw=None, db=None, want_bias=True):
     return dw, db
 
 
+def linear_bwd_xw_512(dy, x, w, x_relu, dw=None, db=None, want_bias=True):
+    """Input gradient and weight / bias gradient of a 512-output layer with in_features >= 1024 in ONE launch -> (dx, dw, db):
+    linear_bwd_x(dy, w, xact=x if x_relu, act='relu') and linear_bwd_w(dy, x), same arithmetic."""
+    dy, x, w = _c(dy, _f32), _c(x, _f32), _c(w, _f32)
+    batch, fin = x.shape
+    if dw is None:
+        dw = torch.empty((512, fin), dtype=_f32, device=x.device)
+    if db is None and want_bias:
+        db = torch.empty(512, dtype=_f32, device=x.device)
+    dx = torch.empty((batch, fin), dtype=_f32, device=x.device)
+    lib.dra_linear_bwd_xw_one512(ptr(dy), ptr(w), ptr(x), 1 if x_relu else 0, ptr(dx), ptr(dw), ptr(db), batch, fin, stream_ptr())
+    return dx, dw, db
+
+
 def linear_bwd_x(dy, w, xact=None, act=None, dx=None):
     dy, w = _c(dy, _f32), _c(w, _f32)
     batch, fout = dy.shape

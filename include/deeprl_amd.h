@@ -229,6 +229,10 @@ int dra_policy_heads_bwd(const float* logits, const int64_t* action, const float
 /* backward of that pair in one launch: dx [B, K] (optional) = g0 W0 + g1 W1, dW_h = g_h^T x, db_h = column sums of g_h */
 int dra_linear_bwd_pair(const float* g0, const float* g1, const float* x, const float* w0, const float* w1, float* dx, float* dw0,
                         float* db0, float* dw1, float* db1, int batch, int in_features, int out0, int out1, void* stream);
+/* both gradients of a 512-output linear layer (fc4 of NatureConvBody) in one launch: dx [batch, in_features] = dy W (times
+ * [x > 0] when x is a fused-ReLU output), dW [512, in_features] = dy^T x, db [512] (optional) = column sums of dy; in_features >= 1024 */
+int dra_linear_bwd_xw_one512(const float* dy, const float* w, const float* x, int x_is_relu_output, float* dx, float* dw, float* db,
+                             int batch, int in_features, void* stream);
 /* raw split-K partial sums [nz][ksplit][batch][out] (no bias / activation): the consumer reduces them. */
 int dra_linear_fwd_slabs(int nz, const float* const* x, const float* const* w, int batch, int in_features,
                          int out_features, int ksplit, float* slabs, void* stream);

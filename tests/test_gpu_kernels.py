@@ -974,6 +974,21 @@ def test_policy_heads_given_and_backward_equal_the_separate_launches(dev, b, k, 
     assert ops.policy_heads_bwd(logits2, act, g_lp, g_ent, g_v, x, w0, w1, want_dx=False)[0] is None
 
 
+@pytest.mark.parametrize("b,relu", [(80, True), (256, True), (33, False), (1, True)])
+def test_linear_bwd_xw_512_equals_the_two_launches(dev, b, relu):
+    """dra_linear_bwd_xw_one512 (fc4's input gradient and weight / bias gradient as two roles of one launch) == dra_linear_bwd_x +
+    dra_linear_bwd_w, bit for bit."""
+    from deeprl_amd import ops
+    rs = np.random.RandomState(b)
+    x = f32(np.maximum(rs.standard_normal((b, 3136)), 0).astype(np.float32), dev)
+    w = f32(0.05 * rs.standard_normal((512, 3136)).astype(np.float32), dev)
+    dy = f32(rs.standard_normal((b, 512)).astype(np.float32), dev)
+    rdx = ops.linear_bwd_x(dy, w, xact=x if relu else None, act="relu" if relu else None)
+    rdw, rdb = ops.linear_bwd_w(dy, x)
+    dx, dw, db = ops.linear_bwd_xw_512(dy, x, w, relu)
+    assert torch.equal(dx, rdx) and torch.equal(dw, rdw) and torch.equal(db, rdb)
+
+
 @pytest.mark.parametrize("rows,n", [(1024, 256), (80, 16), (7, 7), (2048, 1)])
 def test_gather_rows_equals_indexing(dev, rows, n):
     """dra_gather_rows (the five fields of a PPO minibatch -- uint8 frame stacks, int64 actions, three float columns -- by one
