@@ -1238,6 +1238,7 @@ class A2CAgent(BaseAgent):
         self._dev_state = _device_state_fn(self)
         _install_sampler(self)
         self._pixel_rollout = _PixelRollout(self)
+        self.network.fuse_fc4_head = bool(getattr(config, 'fuse_fc4_head', True))
 
     def close(self):
         close_obj(self.task)
@@ -1474,6 +1475,7 @@ class PPOAgent(BaseAgent):
         self._rollout_step = 0
         _install_sampler(self)
         self._pixel_rollout = _PixelRollout(self)
+        self.network.fuse_fc4_head = bool(getattr(config, 'fuse_fc4_head', True))
         # action noise of the device rollout: the rank-invariant stream when one is configured, else a seed of its own
         self._noise_seed = self.dp.noise_seed if self.dp.invariant_sampling else int(getattr(config, 'dp_noise_seed', None) or 0)
 

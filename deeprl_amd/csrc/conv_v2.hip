@@ -1563,6 +1563,7 @@ DRA_API int dra_rollout_conv1_heads(const void* frames_u8, const float* wt1, con
     h.x = phi_prev; h.w0 = w_a; h.b0 = b_a; h.w1 = w_v; h.b1 = b_v; h.uniform = uniform; h.action_in = nullptr;
     h.out_action = out_action; h.out_lp = out_log_pi_a; h.out_ent = out_entropy; h.out_v = out_v; h.out_logits = nullptr;
     h.B = batch; h.K = 512; h.A = n_actions;
+    h.slabs = nullptr; h.fold_bias = nullptr; h.out_x = nullptr;
     head_wgs = (batch + 3) / 4;
   }
   constexpr size_t img = (size_t)VG1::C * T::CS * sizeof(float);

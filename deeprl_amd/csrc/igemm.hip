@@ -265,13 +265,14 @@ linear_heads_rows_kernel(const float* __restrict__ x, const float* __restrict__ 
 // statement categorical_fwd_kernel runs) -- on the lane that holds the row's outputs.  Three launches of ~4.5 us each (heads,
 // torch.rand, categorical_fwd) in a rollout step of eight before (profiles/r05q_kernel_stats_a2c_pixel_16.txt); the uniforms now
 // come from one draw per rollout (nets.RolloutSlots).  Bit-identical with the separate launches for the same uniforms.
+template <int KS>
 __global__ void __launch_bounds__(256)
 policy_heads_sample_kernel(const PolicyHeadArgs h) {       // body: rollout_roles.h policy_head_row
   __shared__ float s_out[4][68];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + wave;
   if (b >= h.B) return;
-  policy_head_row(h, b, lane, s_out[wave]);
+  policy_head_row<KS>(h, b, lane, s_out[wave]);
 }
 
 static PolicyHeadArgs head_args(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
@@ -280,6 +281,7 @@ static PolicyHeadArgs head_args(const float* x, const float* w0, const float* b0
   PolicyHeadArgs h;
   h.x = x; h.w0 = w0; h.b0 = b0; h.w1 = w1; h.b1 = b1; h.uniform = uniform; h.action_in = action_in; h.out_action = out_action;
   h.out_lp = out_lp; h.out_ent = out_ent; h.out_v = out_v; h.out_logits = out_logits; h.B = batch; h.K = in_features; h.A = n_actions;
+  h.slabs = nullptr; h.fold_bias = nullptr; h.out_x = nullptr;
   return h;
 }
 
@@ -289,7 +291,7 @@ DRA_API int dra_policy_heads_sample(const float* x, const float* w0, const float
   if (!x || !w0 || !w1 || !uniform || !out_action || !out_log_pi_a || !out_entropy || !out_v || batch < 1 || batch > 65536 ||
       in_features < 1 || in_features > 512 || n_actions < 1 || n_actions > 64)
     return DRA_EINVAL;
-  hipLaunchKernelGGL(policy_heads_sample_kernel, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream),
+  hipLaunchKernelGGL(policy_heads_sample_kernel<0>, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream),
                      head_args(x, w0, b0, w1, b1, uniform, nullptr, batch, in_features, n_actions, out_action, out_log_pi_a,
                                out_entropy, out_v, out_logits));
   DRA_LAUNCH_CHECK();
@@ -304,9 +306,26 @@ DRA_API int dra_policy_heads_given(const float* x, const float* w0, const float*
   if (!x || !w0 || !w1 || !action || !out_log_pi_a || !out_entropy || !out_v || !out_logits || batch < 1 || batch > 65536 ||
       in_features < 1 || in_features > 512 || n_actions < 1 || n_actions > 64)
     return DRA_EINVAL;
-  hipLaunchKernelGGL(policy_heads_sample_kernel, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream),
+  hipLaunchKernelGGL(policy_heads_sample_kernel<0>, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream),
                      head_args(x, w0, b0, w1, b1, nullptr, action, batch, in_features, n_actions, nullptr, out_log_pi_a, out_entropy,
                                out_v, out_logits));
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// ... and with fc4's finish in front (the update's forward of CategoricalActorCriticNet(NatureConvBody)): the features are folded
+// from the 14 K-slice partial sums of dra_linear_fwd_slabs_one inside the head launch (+ bias, ReLU; written to out_phi for the
+// backward pass) -- linear_finish_kernel was a launch of 5.6 us for 0.16 MB (profiles/r05z2_kernel_stats_a2c_pixel_16.txt).
+DRA_API int dra_policy_heads_given_fold14(const float* slabs, const float* fold_bias, const float* w0, const float* b0, const float* w1,
+                                          const float* b1, const int64_t* action, int batch, int n_actions, float* out_log_pi_a,
+                                          float* out_entropy, float* out_v, float* out_logits, float* out_phi, void* stream) {
+  if (!slabs || !fold_bias || !w0 || !w1 || !action || !out_log_pi_a || !out_entropy || !out_v || !out_logits || !out_phi ||
+      batch < 1 || batch > 65536 || n_actions < 1 || n_actions > 64)
+    return DRA_EINVAL;
+  PolicyHeadArgs h = head_args(nullptr, w0, b0, w1, b1, nullptr, action, batch, 512, n_actions, nullptr, out_log_pi_a, out_entropy,
+                               out_v, out_logits);
+  h.slabs = slabs; h.fold_bias = fold_bias; h.out_x = out_phi;
+  hipLaunchKernelGGL(policy_heads_sample_kernel<14>, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), h);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

@@ -14,13 +14,14 @@ __device__ __forceinline__ float rr_act(float v, int act) {      // DRA_ACT_*: i
 // 64 i); the weight rows of up to eight outputs are requested together with them -- one memory round trip, no LDS, no barrier --
 // then the eight dot products and their wave butterflies run interleaved.  sink(o, value) runs on lane 0 for every output o of
 // [0, O0 + O1).  Per-output arithmetic (lane-strided partial sums in i order, then the butterfly) is linear_gemv_kernel's.
-template <class Sink>
-__device__ __forceinline__ void heads_row_outputs(const float* __restrict__ x, const float* __restrict__ w0,
-                                                  const float* __restrict__ b0, int O0, const float* __restrict__ w1,
-                                                  const float* __restrict__ b1, int O1, int b, int K, int act, int lane, Sink sink) {
+// load_x(k): feature k of the row (a plain row of x, or -- the update's fc4 handing its K-slice partial sums over -- their fold).
+template <class XLoad, class Sink>
+__device__ __forceinline__ void heads_row_outputs_from(XLoad load_x, const float* __restrict__ w0, const float* __restrict__ b0, int O0,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1, int O1, int K,
+                                                       int act, int lane, Sink sink) {
   float xv[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) xv[i] = (lane + 64 * i < K) ? x[(int64_t)b * K + lane + 64 * i] : 0.f;
+  for (int i = 0; i < 8; ++i) xv[i] = (lane + 64 * i < K) ? load_x(lane + 64 * i) : 0.f;
   const int OT = O0 + O1;
   for (int oc = 0; oc < OT; oc += 8) {
     float wv[8][8], bias[8];
@@ -56,19 +57,48 @@ __device__ __forceinline__ void heads_row_outputs(const float* __restrict__ x, c
   }
 }
 
+template <class Sink>
+__device__ __forceinline__ void heads_row_outputs(const float* __restrict__ x, const float* __restrict__ w0,
+                                                  const float* __restrict__ b0, int O0, const float* __restrict__ w1,
+                                                  const float* __restrict__ b1, int O1, int b, int K, int act, int lane, Sink sink) {
+  heads_row_outputs_from([&](int k) { return x[(int64_t)b * K + k]; }, w0, b0, O0, w1, b1, O1, K, act, lane, sink);
+}
+
 // A categorical actor-critic's whole policy head for input row b (network_heads.py:240-255): logits = x W0^T + b0 [A <= 64],
 // v = x w1^T + b1, then Categorical(logits) of the row on the lane that holds the outputs -- inverse-CDF sample from uniform[b]
 // (action_in == nullptr) or the given action, log_pi_a, entropy (common.h categorical_row).  so: >= A + 1 floats of LDS owned by
 // the calling wave.
+// KS > 0 (template argument of policy_head_row): the features are the fold of KS K-slice partial sums slabs[s][b][k] of the layer
+// below (fc4's one-pass forward) + fold_bias[k], through a ReLU -- linear_finish_kernel's sum, slab 0 first -- and are written to
+// out_x [B][K] for the backward pass; KS == 0: x [B][K] as is.
 struct PolicyHeadArgs {
   const float *x, *w0, *b0, *w1, *b1, *uniform;
   const int64_t* action_in;
   int64_t* out_action;
   float *out_lp, *out_ent, *out_v, *out_logits;
   int B, K, A;
+  const float *slabs, *fold_bias;
+  float* out_x;
 };
+template <int KS = 0>
 __device__ __forceinline__ void policy_head_row(const PolicyHeadArgs& h, int b, int lane, float* so) {
-  heads_row_outputs(h.x, h.w0, h.b0, h.A, h.w1, h.b1, 1, b, h.K, /*act=*/0, lane, [&](int o, float v) { so[o] = v; });
+  auto sink = [&](int o, float v) { so[o] = v; };
+  if constexpr (KS > 0) {
+    heads_row_outputs_from([&](int k) {
+      const float* sl = h.slabs + (int64_t)b * h.K + k;
+      float part[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) part[s] = sl[(int64_t)s * h.B * h.K];
+      float v = part[0];
+#pragma unroll
+      for (int s = 1; s < KS; ++s) v += part[s];
+      v = rr_act(v + h.fold_bias[k], DRA_ACT_RELU);
+      h.out_x[(int64_t)b * h.K + k] = v;
+      return v;
+    }, h.w0, h.b0, h.A, h.w1, h.b1, 1, h.K, /*act=*/0, lane, sink);
+  } else {
+    heads_row_outputs(h.x, h.w0, h.b0, h.A, h.w1, h.b1, 1, b, h.K, /*act=*/0, lane, sink);
+  }
   if (lane == 0) {      // (the same lane wrote so[]: program order, no barrier)
     int64_t act;
     float lp, ent;

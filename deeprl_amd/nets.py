@@ -237,6 +237,39 @@ class _PolicyHeadFn(torch.autograd.Function):
         return (dx, None, None, None, None, None, None) if direct else (dx, dw0, db0, dw1, db1, None, None)
 
 
+class _Fc4PolicyHeadFn(torch.autograd.Function):
+    """NatureConvBody's fc4 (+ ReLU) and the policy head of the update's forward as one autograd node: forward = fc4's one-pass
+    K-slice launch + the head launch that folds the slices (ops.fc4_policy_heads_given: no finish launch), backward = the head's
+    one launch (ReLU mask included) + fc4's one launch (input and weight gradients as two roles).  Same arithmetic as
+    _LinearFn followed by _PolicyHeadFn."""
+
+    @staticmethod
+    def forward(ctx, y3, w4, b4, w0, b0, w1, b1, action):
+        lp, ent, v, logits, phi = ops.fc4_policy_heads_given(y3, w4, b4, w0, b0, w1, b1, action)
+        ctx.save_for_backward(y3, w4, phi, w0, w1, logits, action)
+        ctx.params = (w4, b4, w0, b0, w1, b1)
+        return lp, ent, v
+
+    @staticmethod
+    def backward(ctx, g_lp, g_ent, g_v):
+        y3, w4, phi, w0, w1, logits, action = ctx.saved_tensors
+        p4, pb4, p0, pb0, p1, pb1 = ctx.params
+        direct_h = _claim_direct((p0, pb0, p1, pb1))
+        hs = [_grad_slot(p) if direct_h else None for p in (p0, pb0, p1, pb1)]
+        direct_h = all(g is not None and g.is_contiguous() for g in hs)
+        dphi, dw0, db0, dw1, db1 = ops.policy_heads_bwd(logits, action, g_lp, g_ent, g_v, phi, w0, w1,
+                                                        *((hs[0], hs[1], hs[2], hs[3]) if direct_h else ()), relu_mask=True)
+        direct_4 = _claim_direct((p4, pb4))
+        g4 = [_grad_slot(p) if direct_4 else None for p in (p4, pb4)]
+        direct_4 = all(g is not None and g.is_contiguous() for g in g4)
+        _SHARED[0] = _SHARED[0] or not (direct_h and direct_4)
+        dy3, dw4, db4 = ops.linear_bwd_xw_512(dphi, y3, w4, True, *((g4[0], g4[1]) if direct_4 else ()))
+        _mark_masked(dy3)
+        if not ctx.needs_input_grad[0]:
+            dy3 = None
+        return (dy3,) + ((None, None) if direct_4 else (dw4, db4)) + ((None,) * 4 if direct_h else (dw0, db0, dw1, db1)) + (None,)
+
+
 class _CategoricalFn(torch.autograd.Function):
     """Categorical(logits) -> (log_pi_a, entropy) for given actions as one kernel each way (losses.hip K12)."""
 
@@ -795,8 +828,33 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         self.rollout_slots = RolloutSlots()
         self.to(Config.DEVICE)
 
+    def _fc4_head_fused(self, obs, action):
+        """The update's forward over NatureConvBody with fc4 and the policy head as one autograd node (_Fc4PolicyHeadFn), or None
+        when the network / batch is not that case."""
+        body = self.phi_body
+        if not (type(body) is NatureConvBody and type(self.actor_body) is DummyBody and type(self.critic_body) is DummyBody
+                and isinstance(action, torch.Tensor) and action.is_cuda and action.dim() == 1 and obs.is_cuda and obs.dim() == 4
+                and 32 < obs.shape[0] <= 4096 and action.shape[0] == obs.shape[0]
+                and type(body.fc4) is Linear and body.fc4.fused_act == "relu" and tuple(body.fc4.weight.shape) == (512, 3136)
+                and body.fc4.bias is not None and body.fc4.weight.is_contiguous()
+                and type(self.fc_action) is Linear and type(self.fc_critic) is Linear and self.fc_action.bias is not None
+                and self.fc_critic.bias is not None and self.fc_action.fused_act is None and self.fc_critic.fused_act is None
+                and self.fc_action.weight.shape[0] <= 64 and self.fc_critic.weight.shape[0] == 1
+                and getattr(self, 'fuse_fc4_head', True)):
+            return None
+        y = body.conv3(body.conv2(body.conv1(obs)))
+        if not (y.dtype == torch.float32 and y.is_contiguous()):
+            return None
+        lp, ent, v = _Fc4PolicyHeadFn.apply(y.view(y.size(0), -1), body.fc4.weight, body.fc4.bias, self.fc_action.weight,
+                                            self.fc_action.bias, self.fc_critic.weight, self.fc_critic.bias, action.long().contiguous())
+        return {'action': action, 'log_pi_a': lp.unsqueeze(-1), 'entropy': ent.unsqueeze(-1), 'v': v.unsqueeze(-1)}
+
     def forward(self, obs, action=None):
         obs = tensor(obs)
+        if action is not None:
+            out = self._fc4_head_fused(obs, action)
+            if out is not None:
+                return out
         phi = self.phi_body(obs)
         phi_a = self.actor_body(phi)
         phi_v = self.critic_body(phi)

@@ -220,6 +220,11 @@ int dra_policy_heads_sample(const float* x, const float* w0, const float* b0, co
 int dra_policy_heads_given(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
                            const int64_t* action, int batch, int in_features, int n_actions, float* out_log_pi_a,
                            float* out_entropy, float* out_v, float* out_logits, void* stream);
+/* ... with the finish of the 512-feature layer below in front: features = relu(fold_bias + sum of the 14 K-slice partial sums
+ * slabs [14][batch][512] of dra_linear_fwd_slabs_one, slab 0 first), written to out_phi [batch][512] */
+int dra_policy_heads_given_fold14(const float* slabs, const float* fold_bias, const float* w0, const float* b0, const float* w1,
+                                  const float* b1, const int64_t* action, int batch, int n_actions, float* out_log_pi_a,
+                                  float* out_entropy, float* out_v, float* out_logits, float* out_phi, void* stream);
 /* its backward in one launch (dra_categorical_bwd + dra_linear_bwd_pair [+ dra_act_bwd], same sums in the same order): from the
  * gradients of log_pi_a / entropy / v [batch] (any may be NULL = zero) -> dx [batch, in_features] (optional; relu_mask != 0:
  * times [x > 0], x being a fused-ReLU output), dW0 [n_actions, in_features], db0, dW1 [1, in_features], db1; batch <= 8192 */

@@ -897,6 +897,48 @@ def test_fused_rollout_launches_equal_the_module_path(dra, monkeypatch, kind, wo
 
 
 @pytest.mark.parametrize("kind", ["a2c", "ppo"])
+def test_fc4_and_policy_head_as_one_autograd_node(dra, monkeypatch, kind):
+    """nets._Fc4PolicyHeadFn (round 5): in the update's forward fc4's K-slice partial sums are folded inside the policy-head launch
+    (no finish launch) and fc4's two gradients share a launch -- the same sums in the same order as Linear + _PolicyHeadFn: the
+    agents end on bit-identical parameters with network.fuse_fc4_head switched off."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    outs = []
+    for fuse in (True, False):
+        cfg = d.Config()
+        cfg.merge(dict(game="synthetic-atari", log_level=0, tag="fh%d" % fuse, device_env=True, fuse_fc4_head=fuse))
+        cfg.num_workers = 16 if kind == "a2c" else 8
+        cfg.task_fn = lambda: d.Task(cfg.game, num_envs=cfg.num_workers, seed=11, synthetic_done_period=13)
+        cfg.eval_env = d.Task(cfg.game, seed=12)
+        cfg.network_fn = lambda: d.CategoricalActorCriticNet(cfg.state_dim, cfg.action_dim, d.NatureConvBody())
+        cfg.state_normalizer, cfg.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
+        cfg.discount, cfg.use_gae, cfg.entropy_weight = 0.99, True, 0.01
+        if kind == "a2c":
+            cfg.optimizer_fn = lambda p: torch.optim.RMSprop(p, lr=1e-3, alpha=0.99, eps=1e-5)
+            cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 1.0, 5, 5          # update batch 80
+            cls, n = d.A2CAgent, 6
+        else:
+            cfg.optimizer_fn = lambda p: torch.optim.Adam(p, lr=1e-3)
+            cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 0.95, 32, 0.5
+            cfg.optimization_epochs, cfg.mini_batch_size, cfg.ppo_ratio_clip, cfg.shared_repr = 2, 64, 0.1, True
+            cfg.max_steps, cfg.log_interval, cfg.target_kl = 1e6, 10 ** 9, 0.01
+            cls, n = d.PPOAgent, 4
+        d.random_seed(21)
+        torch.manual_seed(22)
+        agent = cls(cfg)
+        assert agent.network.fuse_fc4_head == fuse
+        for _ in range(n):
+            agent.step()
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()})
+        agent.close()
+    for k in outs[0]:
+        assert np.isfinite(outs[0][k]).all()
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("kind", ["a2c", "ppo"])
 def test_deferred_conv_folds_give_the_same_update(dra, monkeypatch, kind):
     """config.defer_conv_folds (round 5, default on): the conv layers leave their weight-gradient slabs unfolded and the
     optimizer's norm launch folds all three (dra_grad_sqnorm_segs over [conv1 | conv2 | conv3 | rest]) -- the folded gradients are

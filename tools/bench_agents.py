@@ -146,6 +146,8 @@ CASES = {
     "a2c_pixel_16": lambda: a2c_pixel(16),                      # device-resident environments (the default)
     "a2c_pixel_16_host": lambda: a2c_pixel(16, device=False),   # host emulators
     "ppo_pixel_8": lambda: ppo_pixel(8),
+    "a2c_pixel_16_nofc4head": lambda: a2c_pixel(16, fuse_fc4_head=False),      # fc4 finish / policy head as separate autograd nodes
+    "ppo_pixel_8_nofc4head": lambda: ppo_pixel(8, fuse_fc4_head=False),
     "a2c_pixel_16_modules": lambda: a2c_pixel(16, fused_rollout=False),         # rollout through network.forward (5 launches / step)
     "ppo_pixel_8_modules": lambda: ppo_pixel(8, fused_rollout=False),
     "ppo_pixel_8_host": lambda: ppo_pixel(8, device=False),
