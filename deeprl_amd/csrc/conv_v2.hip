@@ -1154,15 +1154,11 @@ static int launch_conv_v2_persist(const ConvV2Args& a, int nz, hipStream_t st) {
   static int resident = -1;
   if (resident < 0) {
     int per_cu = 0, dev = 0, n_cu = 0;
-    const char* e = getenv("DRA_CONV_PERSIST_WGS");
-    if (e) resident = atoi(e);
-    else {
-      DRA_HIP(hipGetDevice(&dev));
-      DRA_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-      DRA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT, NW, SEQ, WPE>),
-                                                           64 * NW, bytes));
-      resident = (per_cu > 0 ? per_cu : 1) * n_cu;
-    }
+    DRA_HIP(hipGetDevice(&dev));
+    DRA_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    DRA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_fwd_v2_persist_kernel<G, U8, PT, NW, SEQ, WPE>),
+                                                         64 * NW, bytes));
+    resident = (per_cu > 0 ? per_cu : 1) * n_cu;
   }
   const int lanes = (G::OC / 32) * nz;
   const int per = resident / lanes > 0 ? resident / lanes : 1;
@@ -1342,44 +1338,24 @@ static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
     g_conv_pt_threshold = e ? atoi(e) : 128;
   }
   if (PTBIG > 1 && g_conv_pt_threshold > 0 && a.batch >= g_conv_pt_threshold && !a.ring_slot) {
+    // The throughput shapes: persistent pipelined workgroups.  One measured winner per layer is left (the A/B switches
+    // DRA_CONV_PERSIST, DRA_CONV1_TP, DRA_CONV1_SEQ, DRA_CONV2_MODE, DRA_CONV3_SEQ of rounds 3-4 are retired; the records are in
+    // DESIGN_HISTORY.md section 4 and profiles/r03*_conv_big*, r04*_conv_big*):
     if constexpr (U8 || G::H <= 32) {
-      static int persist = -1;
-      if (persist < 0) { const char* e = getenv("DRA_CONV_PERSIST"); persist = e ? atoi(e) : 1; }
-      if (persist) {
-        if constexpr (U8 && G::C == 4) {
-          // conv1 on uint8 frames: its own throughput kernel (all of K in registers).  DRA_CONV1_TP=0: the K-split form below
-          static int tp1 = -1;
-          if (tp1 < 0) { const char* e = getenv("DRA_CONV1_TP"); tp1 = e ? atoi(e) : 1; }
-          // (from 384 samples per net on: below, the K-split form's smaller work units fill the chip better -- batch 256: 26.5 against
-          // 27.2 us; batch 512: 48.0 against 44.2; 1024: 91 against 81; 2048: 149 us = 57 % of the fp32-MFMA peak)
-          if (tp1 && a.batch >= 384 && !a.sample_idx && !a.newest_frame) return launch_conv1_u8_tp(a, nz, st);
-        }
-        if constexpr (G::C == 4) {
-          // conv1: 64 MFMAs per wave and group against ~2.6 us of staging / exchange: with the one-tile exchange (49 KB of LDS)
-          // three workgroups share a CU.  DRA_CONV1_SEQ=0: the round-2 form (two)
-          static int seq1 = -1;
-          if (seq1 < 0) { const char* e = getenv("DRA_CONV1_SEQ"); seq1 = e ? atoi(e) : 1; }
-          if (seq1) return launch_conv_v2_persist<G, U8, PTBIG, 4, true, 3>(a, nz, st);
-        }
-        if constexpr (!U8 && G::C == 64) {
-          // conv3: the same one-tile exchange (37 KB of LDS; DRA_CONV3_SEQ=1: three workgroups per CU, 2: two) measured no
-          // different from the plain form (55.1 / 54.3 / 54.5 % at batch 1024): off
-          static int seq3 = -1;
-          if (seq3 < 0) { const char* e = getenv("DRA_CONV3_SEQ"); seq3 = e ? atoi(e) : 0; }
-          if (seq3 == 1) return launch_conv_v2_persist<G, U8, PTBIG, 4, true, 3>(a, nz, st);
-          if (seq3) return launch_conv_v2_persist<G, U8, PTBIG, 4, true>(a, nz, st);
-        }
-        if constexpr (!U8 && G::C == 32) {
-          // conv2 (51 KB fp32 image per sample).  DRA_CONV2_MODE: 2 (default) = one tile's partial sums at a time, two
-          // workgroups per CU; 1 = eight waves, one workgroup per CU (a different summation tree: not bit-identical with
-          // the latency shape); 0 = the round-2 form (four waves, one workgroup per CU)
-          static int mode = -1;
-          if (mode < 0) { const char* e = getenv("DRA_CONV2_MODE"); mode = e ? atoi(e) : 2; }
-          if (mode == 2) return launch_conv_v2_persist<G, U8, PTBIG, 4, true>(a, nz, st);
-          if (mode == 1) return launch_conv_v2_persist<G, U8, PTBIG, 8>(a, nz, st);
-        }
-        return launch_conv_v2_persist<G, U8, PTBIG>(a, nz, st);
+      if constexpr (U8 && G::C == 4) {
+        // conv1 on uint8 frames from 384 samples per net on: its own throughput kernel (all of K in registers); below, the K-split
+        // form's smaller work units fill the chip better -- batch 256: 26.5 against 27.2 us; 512: 48.0 against 44.2; 1024: 91
+        // against 81; 2048: 149 us = 57 % of the fp32-MFMA peak
+        if (a.batch >= 384 && !a.sample_idx && !a.newest_frame) return launch_conv1_u8_tp(a, nz, st);
       }
+      // conv1: 64 MFMAs per wave and group against ~2.6 us of staging / exchange -- the one-tile partial-sum exchange (49 KB of
+      // LDS), three workgroups per CU
+      if constexpr (G::C == 4) return launch_conv_v2_persist<G, U8, PTBIG, 4, true, 3>(a, nz, st);
+      // conv2 (51 KB fp32 image per sample): one tile's partial sums at a time, two workgroups per CU (an eight-wave form and
+      // the round-2 four-wave form lost)
+      if constexpr (!U8 && G::C == 32) return launch_conv_v2_persist<G, U8, PTBIG, 4, true>(a, nz, st);
+      // conv3: the plain persistent form (the one-tile exchange measured no different: 55.1 / 54.3 / 54.5 % at batch 1024)
+      return launch_conv_v2_persist<G, U8, PTBIG>(a, nz, st);
     }
     return launch_conv_v2_pt<G, U8, PTBIG>(a, nz, st);
   }

@@ -2711,20 +2711,13 @@ DRA_API int dra_dqn_learner_trace_read(dra_dqn_learner* l, float* out_ms, int ma
 // The gather sits between the actor graph that wrote this step's transitions and the one that overwrites the
 // oldest ring slots, in stream order -- no event on either chain's critical path: the waits below (minibatch
 // buffer free again, optimizer of step t-1 done) refer to work issued a whole step earlier.
-static int debug_nosync() {   // TIMING EXPERIMENTS ONLY (results are then wrong): bit 0 drops the update stream's wait for the
-  static int v = -1;          // gather, bit 1 the minibatch-free event, bit 2 the actor stream's waits
-  if (v < 0) { const char* e = getenv("DRA_DEBUG_NOSYNC"); v = e ? atoi(e) : 0; }
-  return v;
-}
-
 static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, hipStream_t su,
                           hipStream_t sa, int k) {
   const int B = l->c.batch;
   const int par = (int)(l->step_no & 1);
-  const int dbg = debug_nosync();
   int rc;
   if (do_update) {
-    if (l->mb_used[par] && !(dbg & 4)) DRA_HIP(hipStreamWaitEvent(sa, l->ev_mb_free[par], 0));
+    if (l->mb_used[par]) DRA_HIP(hipStreamWaitEvent(sa, l->ev_mb_free[par], 0));
     const int64_t* pinned = (l->variant & DRA_VAR_PINNED_IDX) ? l->idx_stage + (size_t)k * 1024 : nullptr;
     if (!pinned)
       DRA_HIP(hipMemcpyAsync(l->idx, l->idx_stage + (size_t)k * 1024, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, sa));
@@ -2739,7 +2732,7 @@ static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, in
   bool seeded = false;
   if (prm->n_env > 0) {
     if (l->pa_valid && l->pa_cur != (par ^ 1)) l->pa_valid = false;   // copies out of phase with the step parity
-    if (!(dbg & 4) && l->last_done) DRA_HIP(hipStreamWaitEvent(sa, l->last_done, 0));   // the optimizer that produced the copy read below
+    if (l->last_done) DRA_HIP(hipStreamWaitEvent(sa, l->last_done, 0));   // the optimizer that produced the copy read below
     if (!l->pa_valid) {
       l->pa_cur = par ^ 1;
       DRA_HIP(hipMemcpyAsync(l->pa[l->pa_cur], l->p, (size_t)l->c.n_params * sizeof(float), hipMemcpyDeviceToDevice, sa));
@@ -2756,7 +2749,7 @@ static int step_pipelined(dra_dqn_learner* l, const dra_dqn_step_params* prm, in
   DRA_HIP(hipEventRecord(l->stage_ev[k], sa));  // staging slot k: parameter block copy and the gather's pinned index reads
   if (prm->n_env > 0) l->actor_last = l->stage_ev[k];
   if (do_update) {
-    if (!(dbg & 1)) DRA_HIP(hipStreamWaitEvent(su, l->ev_mb_ready[par], 0));
+    DRA_HIP(hipStreamWaitEvent(su, l->ev_mb_ready[par], 0));
     if (seeded) DRA_HIP(hipStreamWaitEvent(su, l->ev_join[0], 0));    // the seed copy read the parameters this step overwrites
     TRACE(3, su);
     if ((rc = pipe_graph(l, su, par))) return rc;
