@@ -990,7 +990,7 @@ def _begin_rollout(agent, n_env):
 class _PixelRollout:
     """The no-grad forwards of one A2C / PPO rollout over CategoricalActorCriticNet(NatureConvBody) and device-resident synthetic
     Atari environments as FOUR launches per step instead of five (csrc/conv_v2.hip: rollout_conv1_heads_kernel): [conv1 of step t
-    | policy head of step t - 1], conv2, conv3, fc4 -- every launch of such a step is a few dozen workgroups at its latency floor,
+    | fc4's finish + policy head of step t - 1], conv2, conv3, fc4's 28 K-slice partial sums -- every launch of such a step is a few dozen workgroups at its latency floor,
     so the step costs what its launches cost.  The head of step t - 1 can share conv1's launch because the planned observations
     do not depend on the actions (DeviceAtariVec.states_all).  Same device functions as the module path: the rollout's actions,
     log-probabilities, entropies and values are bit-identical (tests/test_gpu_agents.py).  a2c_pixel 209 k -> 224 k, ppo_pixel
@@ -1007,7 +1007,7 @@ class _PixelRollout:
         net, cfg = a.network, a.config
         if getattr(cfg, 'fused_rollout', True) is False or Config.DEVICE.type != 'cuda' or not isinstance(a.task, DeviceAtariVec):
             return False
-        if type(net) is not CategoricalActorCriticNet or getattr(net, 'sampler', None) is not None:
+        if type(net) is not CategoricalActorCriticNet or getattr(net, 'sampler', None) is not None or not getattr(net, 'rollout_fc4_slices', True):
             return False
         body = net.phi_body
         if type(body) is not NatureConvBody or type(net.actor_body) is not DummyBody or type(net.critic_body) is not DummyBody:
@@ -1035,7 +1035,7 @@ class _PixelRollout:
         dev = frames.device
         if self.bufs is None or self.bufs['n'] != n or self.bufs['rows'] < rows:
             f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-            self.bufs = dict(n=n, rows=rows, y1=f(n, 32, 20, 20), y2=f(n, 64, 9, 9), y3=f(n, 64, 7, 7), phi=f(n, 512))
+            self.bufs = dict(n=n, rows=rows, y1=f(n, 32, 20, 20), y2=f(n, 64, 9, 9), y3=f(n, 64, 7, 7), slabs=f(28, n, 512))
         b = self.bufs
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         arr = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
@@ -1045,20 +1045,22 @@ class _PixelRollout:
         n_act = int(wa.shape[0])
         coef = float(body.conv1.u8_coef)
         x2, wt2, b2, y2 = arr(b['y1']), arr(w2), arr(body.conv2.bias), arr(b['y2'])
-        wt3, b3, y3, w4, b4, phi = arr(w3), arr(body.conv3.bias), arr(b['y3']), arr(body.fc4.weight), arr(body.fc4.bias), arr(b['phi'])
+        wt3, b3, y3, w4 = arr(w3), arr(body.conv3.bias), arr(b['y3']), arr(body.fc4.weight)
+        b4, slabs = body.fc4.bias, b['slabs']
         for t in range(rows):
             prev = t > 0
+            # fc4 of step t - 1 left its 28 K-slice partial sums: the head that rides in this launch folds them (bias, ReLU) first
             lib.dra_rollout_conv1_heads(p(frames[t]), p(w1), p(body.conv1.bias), p(b['y1']), n, coef,
-                                        p(b['phi']) if prev else None, p(wa), p(ba), p(wv), p(bv),
+                                        p(slabs) if prev else None, p(b4) if prev else None, p(wa), p(ba), p(wv), p(bv),
                                         p(slots.uniform[t - 1]) if prev else None, n_act,
                                         p(slots.action[t - 1]) if prev else None, p(slots.log_pi_a[t - 1]) if prev else None,
                                         p(slots.entropy[t - 1]) if prev else None, p(slots.v[t - 1]) if prev else None, st)
             lib.dra_conv_fwd_koc(2, 1, x2, wt2, b2, y2, n, 0, 1.0, ops.ACT["relu"], st)
             lib.dra_conv_fwd_koc(3, 1, y2, wt3, b3, y3, n, 0, 1.0, ops.ACT["relu"], st)
-            lib.dra_linear_fwd(1, y3, w4, b4, phi, n, 3136, 512, ops.ACT["relu"], None, 0, st)
+            lib.dra_linear_fwd_slabs_one(1, y3, w4, n, 3136, 512, 28, p(slabs), st)
         t = rows - 1
-        lib.dra_policy_heads_sample(p(b['phi']), p(wa), p(ba), p(wv), p(bv), p(slots.uniform[t]), n, 512, n_act, p(slots.action[t]),
-                                    p(slots.log_pi_a[t]), p(slots.entropy[t]), p(slots.v[t]), None, st)
+        lib.dra_policy_heads_sample_fold28(p(slabs), p(b4), p(wa), p(ba), p(wv), p(bv), p(slots.uniform[t]), n, n_act,
+                                           p(slots.action[t]), p(slots.log_pi_a[t]), p(slots.entropy[t]), p(slots.v[t]), st)
         slots.end()
 
 
@@ -1239,6 +1241,7 @@ class A2CAgent(BaseAgent):
         _install_sampler(self)
         self._pixel_rollout = _PixelRollout(self)
         self.network.fuse_fc4_head = bool(getattr(config, 'fuse_fc4_head', True))
+        self.network.rollout_fc4_slices = bool(getattr(config, 'rollout_fc4_slices', True))
 
     def close(self):
         close_obj(self.task)
@@ -1476,6 +1479,7 @@ class PPOAgent(BaseAgent):
         _install_sampler(self)
         self._pixel_rollout = _PixelRollout(self)
         self.network.fuse_fc4_head = bool(getattr(config, 'fuse_fc4_head', True))
+        self.network.rollout_fc4_slices = bool(getattr(config, 'rollout_fc4_slices', True))
         # action noise of the device rollout: the rank-invariant stream when one is configured, else a seed of its own
         self._noise_seed = self.dp.noise_seed if self.dp.invariant_sampling else int(getattr(config, 'dp_noise_seed', None) or 0)
 

@@ -1508,7 +1508,12 @@ int dra_conv1_fwd_actor_fused(const void* frames, const int64_t* slot_field_dev,
 __global__ void __launch_bounds__(256)
 rollout_conv1_heads_kernel(const ConvV2Args a, const PolicyHeadArgs h, const int head_wgs) {
   __shared__ float s_out[4][68];
+  __shared__ float s_phi[512];
   if ((int)blockIdx.x < head_wgs) {
+    if (h.slabs) {        // one row per workgroup, its features folded from fc4's 28 K-slice partial sums first
+      policy_head_row_fold_wg<28>(h, (int)blockIdx.x, s_phi, s_out[0]);
+      return;
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + wave;
     if (b < h.B) policy_head_row(h, b, lane, s_out[wave]);
@@ -1520,9 +1525,9 @@ rollout_conv1_heads_kernel(const ConvV2Args a, const PolicyHeadArgs h, const int
 }
 
 DRA_API int dra_rollout_conv1_heads(const void* frames_u8, const float* wt1, const float* b1, float* y1, int batch, double u8_coef,
-                                    const float* phi_prev, const float* w_a, const float* b_a, const float* w_v, const float* b_v,
-                                    const float* uniform, int n_actions, int64_t* out_action, float* out_log_pi_a,
-                                    float* out_entropy, float* out_v, void* stream) {
+                                    const float* phi_prev, const float* fold_bias, const float* w_a, const float* b_a,
+                                    const float* w_v, const float* b_v, const float* uniform, int n_actions, int64_t* out_action,
+                                    float* out_log_pi_a, float* out_entropy, float* out_v, void* stream) {
   if (!frames_u8 || !wt1 || !b1 || !y1 || batch < 1 || batch > 4096) return DRA_EINVAL;
   if (phi_prev && (!w_a || !w_v || !uniform || !out_action || !out_log_pi_a || !out_entropy || !out_v || n_actions < 1 ||
                    n_actions > 64))
@@ -1541,6 +1546,10 @@ DRA_API int dra_rollout_conv1_heads(const void* frames_u8, const float* wt1, con
     h.B = batch; h.K = 512; h.A = n_actions;
     h.slabs = nullptr; h.fold_bias = nullptr; h.out_x = nullptr;
     head_wgs = (batch + 3) / 4;
+    if (fold_bias) {      // phi_prev is [28][batch][512]: the K-slice partial sums of dra_linear_fwd_slabs_one(ksplit = 28)
+      h.x = nullptr; h.slabs = phi_prev; h.fold_bias = fold_bias;
+      head_wgs = batch;
+    }
   }
   constexpr size_t img = (size_t)VG1::C * T::CS * sizeof(float);
   constexpr size_t red = (size_t)4 * 16 * 64 * sizeof(float);

@@ -330,6 +330,30 @@ DRA_API int dra_policy_heads_given_fold14(const float* slabs, const float* fold_
   return DRA_OK;
 }
 
+// A rollout step's fc4 finish + policy head (rollout_roles.h policy_head_row_fold_wg): one workgroup per row, the features
+// folded from the 28 K-slice partial sums of dra_linear_fwd_slabs_one(ksplit = 28).  K = 512.
+__global__ void __launch_bounds__(256)
+policy_heads_fold28_kernel(const PolicyHeadArgs h) {
+  __shared__ float s_phi[512];
+  __shared__ float s_out[68];
+  policy_head_row_fold_wg<28>(h, blockIdx.x, s_phi, s_out);
+}
+
+DRA_API int dra_policy_heads_sample_fold28(const float* slabs, const float* fold_bias, const float* w0, const float* b0,
+                                           const float* w1, const float* b1, const float* uniform, int batch, int n_actions,
+                                           int64_t* out_action, float* out_log_pi_a, float* out_entropy, float* out_v,
+                                           void* stream) {
+  if (!slabs || !fold_bias || !w0 || !w1 || !uniform || !out_action || !out_log_pi_a || !out_entropy || !out_v || batch < 1 ||
+      batch > 65536 || n_actions < 1 || n_actions > 64)
+    return DRA_EINVAL;
+  PolicyHeadArgs h = head_args(nullptr, w0, b0, w1, b1, uniform, nullptr, batch, 512, n_actions, out_action, out_log_pi_a, out_entropy,
+                               out_v, nullptr);
+  h.slabs = slabs; h.fold_bias = fold_bias;
+  hipLaunchKernelGGL(policy_heads_fold28_kernel, dim3(batch), dim3(256), 0, dra_stream(stream), h);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
 // Backward of that head in ONE launch: categorical_bwd_kernel (dlogits from g_log_pi_a / g_entropy), linear_pair_bwd_kernel
 // (d phi, both layers' weight / bias gradients) and -- when phi is the output of a fused ReLU -- act_bwd_kernel's mask were three
 // launches of ~5-12 us on the update's dependent chain (profiles/r05r_kernel_stats_*).  Same sums in the same order:

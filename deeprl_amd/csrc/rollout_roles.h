@@ -113,6 +113,50 @@ __device__ __forceinline__ void policy_head_row(const PolicyHeadArgs& h, int b, 
   }
 }
 
+// The same head for ONE row per WORKGROUP of four waves, the row's features folded from KS K-slice partial sums first (fc4 of a
+// rollout step through the one-pass K-slice kernel with 28 slices: 4.3 us at 8-32 samples against the eight-wave GEMV's 5.6 / 8.1 /
+// 13.2 us, tools/fc4_small_probe.py -- its finish happens here, and in a rollout this head rides in the NEXT step's conv1 launch,
+// where the fold's loads cost nothing on the chain): thread t folds features t and t + 256 (2 KS loads in flight, slab 0 first, +
+// bias, ReLU: linear_finish_kernel's sum) into LDS, then wave 0 runs the head on them.  s_phi: 512 floats, so: >= A + 1 floats.
+template <int KS>
+__device__ __forceinline__ void policy_head_row_fold_wg(const PolicyHeadArgs& h, int b, float* s_phi, float* so) {
+  const int t = threadIdx.x;
+  float part[2][KS];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float* sl = h.slabs + (int64_t)b * h.K + t + 256 * j;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) part[j][s] = sl[(int64_t)s * h.B * h.K];
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = t + 256 * j;
+    float v = part[j][0];
+#pragma unroll
+    for (int s = 1; s < KS; ++s) v += part[j][s];
+    v = rr_act(v + h.fold_bias[k], DRA_ACT_RELU);
+    s_phi[k] = v;
+    if (h.out_x) h.out_x[(int64_t)b * h.K + k] = v;
+  }
+  __syncthreads();
+  if (t >= 64) return;
+  const int lane = t;
+  heads_row_outputs_from([&](int k) { return s_phi[k]; }, h.w0, h.b0, h.A, h.w1, h.b1, 1, h.K, /*act=*/0, lane,
+                         [&](int o, float v) { so[o] = v; });
+  if (lane == 0) {
+    int64_t act;
+    float lp, ent;
+    categorical_row(so, h.A, h.action_in != nullptr, h.action_in ? h.action_in[b] : 0, h.uniform ? h.uniform[b] : 0.f, &act, &lp,
+                    &ent);
+    if (h.out_action) h.out_action[b] = act;
+    h.out_lp[b] = lp;
+    h.out_ent[b] = ent;
+    h.out_v[b] = so[h.A];
+    if (h.out_logits)
+      for (int a = 0; a < h.A; ++a) h.out_logits[(int64_t)b * h.A + a] = so[a];
+  }
+}
+
 // A wide linear layer at rollout batch sizes (fc4 of NatureConvBody, 3136 -> 512, for the 8 / 16 environments of one rollout
 // step): a workgroup of EIGHT waves owns 8 / WPR output rows (o2 = index of the group), each row's reduction split over WPR waves
 // (K parts); a lane keeps its R float4 of the weight row in registers and, per round, the matching float4 of up to RB input

@@ -832,15 +832,9 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         """The update's forward over NatureConvBody with fc4 and the policy head as one autograd node (_Fc4PolicyHeadFn), or None
         when the network / batch is not that case."""
         body = self.phi_body
-        if not (type(body) is NatureConvBody and type(self.actor_body) is DummyBody and type(self.critic_body) is DummyBody
-                and isinstance(action, torch.Tensor) and action.is_cuda and action.dim() == 1 and obs.is_cuda and obs.dim() == 4
-                and 32 < obs.shape[0] <= 4096 and action.shape[0] == obs.shape[0]
-                and type(body.fc4) is Linear and body.fc4.fused_act == "relu" and tuple(body.fc4.weight.shape) == (512, 3136)
-                and body.fc4.bias is not None and body.fc4.weight.is_contiguous()
-                and type(self.fc_action) is Linear and type(self.fc_critic) is Linear and self.fc_action.bias is not None
-                and self.fc_critic.bias is not None and self.fc_action.fused_act is None and self.fc_critic.fused_act is None
-                and self.fc_action.weight.shape[0] <= 64 and self.fc_critic.weight.shape[0] == 1
-                and getattr(self, 'fuse_fc4_head', True)):
+        if not (isinstance(action, torch.Tensor) and action.is_cuda and action.dim() == 1 and obs.is_cuda and obs.dim() == 4
+                and 32 < obs.shape[0] <= 4096 and action.shape[0] == obs.shape[0] and getattr(self, 'fuse_fc4_head', True)
+                and self._nature_heads_ok()):
             return None
         y = body.conv3(body.conv2(body.conv1(obs)))
         if not (y.dtype == torch.float32 and y.is_contiguous()):
@@ -849,10 +843,44 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
                                             self.fc_action.bias, self.fc_critic.weight, self.fc_critic.bias, action.long().contiguous())
         return {'action': action, 'log_pi_a': lp.unsqueeze(-1), 'entropy': ent.unsqueeze(-1), 'v': v.unsqueeze(-1)}
 
+    def _nature_heads_ok(self):
+        """phi_body is NatureConvBody (fc4 3136 -> 512 with the fused ReLU), the actor / critic bodies are identities and the two
+        heads are plain Linear layers (<= 64 actions, one value): the shapes the fused head launches are written for."""
+        body = self.phi_body
+        return (type(body) is NatureConvBody and type(self.actor_body) is DummyBody and type(self.critic_body) is DummyBody
+                and type(body.fc4) is Linear and body.fc4.fused_act == "relu" and tuple(body.fc4.weight.shape) == (512, 3136)
+                and body.fc4.bias is not None and body.fc4.weight.is_contiguous()
+                and type(self.fc_action) is Linear and type(self.fc_critic) is Linear and self.fc_action.bias is not None
+                and self.fc_critic.bias is not None and self.fc_action.fused_act is None and self.fc_critic.fused_act is None
+                and self.fc_action.weight.shape[0] <= 64 and self.fc_critic.weight.shape[0] == 1)
+
+    def _rollout_fc4_head(self, obs):
+        """A rollout step's forward (no gradient, action sampled) over NatureConvBody at <= 32 rows with fc4 through the one-pass
+        K-slice kernel and its finish inside the head launch (ops.fc4_policy_heads_sample), or None when this is not that case."""
+        if not (obs.is_cuda and obs.dim() == 4 and obs.shape[0] <= 32 and getattr(self, "sampler", None) is None
+                and not (torch.is_grad_enabled() and self.fc_action.weight.requires_grad) and getattr(self, 'rollout_fc4_slices', True)
+                and self._nature_heads_ok()):
+            return None
+        body = self.phi_body
+        y = body.conv3(body.conv2(body.conv1(obs)))
+        if not (y.dtype == torch.float32 and y.is_contiguous()):
+            return None
+        uniform, rows = self.rollout_slots.take(y.shape[0])
+        if uniform is None:
+            uniform = torch.rand(y.shape[0], dtype=torch.float32, device=y.device)
+        a, lp, ent, v = ops.fc4_policy_heads_sample(y.view(y.size(0), -1).detach(), body.fc4.weight.detach(), body.fc4.bias.detach(),
+                                                    self.fc_action.weight.detach(), self.fc_action.bias.detach(),
+                                                    self.fc_critic.weight.detach(), self.fc_critic.bias.detach(), uniform, rows)
+        return {'action': a, 'log_pi_a': lp.unsqueeze(-1), 'entropy': ent.unsqueeze(-1), 'v': v.unsqueeze(-1)}
+
     def forward(self, obs, action=None):
         obs = tensor(obs)
         if action is not None:
             out = self._fc4_head_fused(obs, action)
+            if out is not None:
+                return out
+        else:
+            out = self._rollout_fc4_head(obs)
             if out is not None:
                 return out
         phi = self.phi_body(obs)

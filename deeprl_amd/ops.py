@@ -661,6 +661,26 @@ def fc4_policy_heads_given(y3, w4, b4, w0, b0, w1, b1, action):
     return lp, ent, v, logits, phi
 
 
+def fc4_policy_heads_sample(y3, w4, b4, w0, b0, w1, b1, uniform, out=None):
+    """fc4 (3136 -> 512, + ReLU) and the sampling policy head of a rollout step (<= 32 rows) as TWO launches: the one-pass K-slice
+    forward with 28 slices and the head launch that folds them -> (action i64 [B], log_pi_a, entropy, v [B]).  (The eight-wave GEMV
+    + policy_heads_sample are two as well, 5.6 / 8.1 / 13.2 + 6 us at 8 / 16 / 32 rows against 4.3 + 5: tools/fc4_small_probe.py.)"""
+    y3, w4, b4, w0, w1, uniform = _c(y3, _f32), _c(w4, _f32), _c(b4, _f32), _c(w0, _f32), _c(w1, _f32), _c(uniform, _f32)
+    b0 = None if b0 is None else _c(b0, _f32)
+    b1 = None if b1 is None else _c(b1, _f32)
+    batch = int(y3.shape[0])
+    dev = y3.device
+    slabs = torch.empty((28, batch, 512), dtype=_f32, device=dev)
+    lib.dra_linear_fwd_slabs_one(1, ptr_array([y3]), ptr_array([w4]), batch, 3136, 512, 28, ptr(slabs), stream_ptr())
+    if out is None:
+        out = (torch.empty(batch, dtype=torch.int64, device=dev), torch.empty(batch, dtype=_f32, device=dev),
+               torch.empty(batch, dtype=_f32, device=dev), torch.empty(batch, dtype=_f32, device=dev))
+    a, lp, ent, v = out
+    lib.dra_policy_heads_sample_fold28(ptr(slabs), ptr(b4), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(uniform), batch, int(w0.shape[0]),
+                                       ptr(a), ptr(lp), ptr(ent), ptr(v), stream_ptr())
+    return a, lp, ent, v
+
+
 HEADS_BWD_MAX_BATCH = 8192
 
 

@@ -225,6 +225,11 @@ int dra_policy_heads_given(const float* x, const float* w0, const float* b0, con
 int dra_policy_heads_given_fold14(const float* slabs, const float* fold_bias, const float* w0, const float* b0, const float* w1,
                                   const float* b1, const int64_t* action, int batch, int n_actions, float* out_log_pi_a,
                                   float* out_entropy, float* out_v, float* out_logits, float* out_phi, void* stream);
+/* a rollout step's head with the finish of fc4's 28-slice one-pass forward in front: features = relu(fold_bias + sum of slabs
+ * [28][batch][512], slab 0 first); one workgroup per row; then as dra_policy_heads_sample */
+int dra_policy_heads_sample_fold28(const float* slabs, const float* fold_bias, const float* w0, const float* b0, const float* w1,
+                                   const float* b1, const float* uniform, int batch, int n_actions, int64_t* out_action,
+                                   float* out_log_pi_a, float* out_entropy, float* out_v, void* stream);
 /* its backward in one launch (dra_categorical_bwd + dra_linear_bwd_pair [+ dra_act_bwd], same sums in the same order): from the
  * gradients of log_pi_a / entropy / v [batch] (any may be NULL = zero) -> dx [batch, in_features] (optional; relu_mask != 0:
  * times [x > 0], x being a fused-ReLU output), dW0 [n_actions, in_features], db0, dW1 [1, in_features], db1; batch <= 8192 */
@@ -386,13 +391,15 @@ int dra_synth_stacks(const int64_t* counter_dev, const int32_t* age_dev, const i
 /* ---- an A2C / PPO rollout step over NatureConvBody at 8-32 device-resident environments as four launches (agents._PixelRollout;
  * A2C_agent.py:26-34 / PPO_agent.py:33-47 under no_grad): [conv1 of step t | the policy head of step t-1], conv2, conv3
  * (dra_conv_fwd_koc), fc4 (dra_linear_fwd).  Same arithmetic as the separate launches, bit for bit. */
-/* conv1 (+ ReLU) of uint8 frames [batch][4][84][84] -> y1 [batch][32][20][20]; and, when phi_prev != NULL, dra_policy_heads_sample of
- * the previous step's features phi_prev [batch][512] (workgroups of their own in the same launch: the observations do not depend on
- * the previous step's actions) */
+/* conv1 (+ ReLU) of uint8 frames [batch][4][84][84] -> y1 [batch][32][20][20]; and, when phi_prev != NULL, the policy head of the
+ * previous step (workgroups of their own in the same launch: the observations do not depend on the previous step's actions):
+ * fold_bias == NULL: dra_policy_heads_sample of the features phi_prev [batch][512]; fold_bias != NULL: phi_prev is the
+ * [28][batch][512] K-slice partial sums of fc4 (dra_linear_fwd_slabs_one, ksplit 28) and the head folds them first
+ * (dra_policy_heads_sample_fold28) */
 int dra_rollout_conv1_heads(const void* frames_u8, const float* wt1, const float* b1, float* y1, int batch, double u8_coef,
-                            const float* phi_prev, const float* w_a, const float* b_a, const float* w_v, const float* b_v,
-                            const float* uniform, int n_actions, int64_t* out_action, float* out_log_pi_a, float* out_entropy,
-                            float* out_v, void* stream);
+                            const float* phi_prev, const float* fold_bias, const float* w_a, const float* b_a, const float* w_v,
+                            const float* b_v, const float* uniform, int n_actions, int64_t* out_action, float* out_log_pi_a,
+                            float* out_entropy, float* out_v, void* stream);
 
 /* ---- fused DQN learner + device-resident actor: DQN_agent.py:24-45 (actor step), :114-138 (update) for
  * VanillaNet(NatureConvBody).  All five flat buffers are caller-owned f32[n_params] with the tensor order

@@ -938,6 +938,44 @@ def test_fc4_and_policy_head_as_one_autograd_node(dra, monkeypatch, kind):
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+def test_rollout_fc4_through_k_slices_samples_the_same_policy(dra, monkeypatch):
+    """config.rollout_fc4_slices (round 5, default on): a rollout step's fc4 runs as the one-pass 28-slice kernel with its finish
+    inside the head launch instead of the eight-wave GEMV -- another fp32 summation order for the 3136-term dot products, so the
+    rollout's log-probabilities and values agree at 1e-5 (not bit for bit) and the same uniforms pick the same actions except
+    where one lands within that distance of a CDF boundary (none in this run's first rollouts)."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    outs = []
+    for slices in (True, False):
+        cfg = d.Config()
+        cfg.merge(dict(game="synthetic-atari", log_level=0, tag="rs%d" % slices, device_env=True, rollout_fc4_slices=slices))
+        cfg.num_workers = 16
+        cfg.task_fn = lambda: d.Task(cfg.game, num_envs=cfg.num_workers, seed=11, synthetic_done_period=13)
+        cfg.eval_env = d.Task(cfg.game, seed=12)
+        cfg.network_fn = lambda: d.CategoricalActorCriticNet(cfg.state_dim, cfg.action_dim, d.NatureConvBody())
+        cfg.state_normalizer, cfg.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
+        cfg.discount, cfg.use_gae, cfg.entropy_weight = 0.99, True, 0.01
+        cfg.optimizer_fn = lambda p: torch.optim.RMSprop(p, lr=1e-4, alpha=0.99, eps=1e-5)
+        cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 1.0, 5, 5
+        d.random_seed(21)
+        torch.manual_seed(22)
+        agent = d.A2CAgent(cfg)
+        assert agent._pixel_rollout.eligible() == slices
+        agent.step()
+        torch.cuda.synchronize()
+        sl = agent.network.rollout_slots
+        outs.append((sl.action.cpu().numpy().copy(), sl.log_pi_a.cpu().numpy().copy(), sl.v.cpu().numpy().copy(),
+                     {k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()}))
+        agent.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-5)
+    for k in outs[0][3]:
+        scale = max(1e-3, float(np.abs(outs[1][3][k]).max()))
+        assert float(np.abs(outs[0][3][k] - outs[1][3][k]).max()) <= 1e-4 * scale, k
+
+
 @pytest.mark.parametrize("kind", ["a2c", "ppo"])
 def test_deferred_conv_folds_give_the_same_update(dra, monkeypatch, kind):
     """config.defer_conv_folds (round 5, default on): the conv layers leave their weight-gradient slabs unfolded and the

@@ -989,6 +989,31 @@ def test_linear_bwd_xw_512_equals_the_two_launches(dev, b, relu):
     assert torch.equal(dx, rdx) and torch.equal(dw, rdw) and torch.equal(db, rdb)
 
 
+@pytest.mark.parametrize("b,a", [(8, 4), (16, 18), (1, 6), (32, 9), (5, 64)])
+def test_fc4_policy_heads_sample_folds_the_28_slices_like_the_finish_kernel(dev, b, a):
+    """ops.fc4_policy_heads_sample (a rollout step's fc4 through the one-pass 28-slice kernel, its finish inside the head launch):
+    the head's outputs equal dra_policy_heads_sample on phi = relu(b4 + slab 0 + slab 1 + ... + slab 27) formed in that order in
+    fp32 -- bit for bit -- and phi agrees with the float64 product at 1e-5 of its scale."""
+    from deeprl_amd import ops
+    from deeprl_amd._lib import lib, stream_ptr
+    rs = np.random.RandomState(b + 7 * a)
+    y3 = f32(np.maximum(rs.standard_normal((b, 3136)), 0).astype(np.float32), dev)
+    w4, b4 = f32(0.03 * rs.standard_normal((512, 3136)).astype(np.float32), dev), f32(rs.standard_normal(512).astype(np.float32), dev)
+    w0, w1 = f32(0.2 * rs.standard_normal((a, 512)).astype(np.float32), dev), f32(rs.standard_normal((1, 512)).astype(np.float32), dev)
+    b0, b1 = f32(rs.standard_normal(a).astype(np.float32), dev), f32(rs.standard_normal(1).astype(np.float32), dev)
+    u = f32(rs.uniform(size=b).astype(np.float32), dev)
+    got = ops.fc4_policy_heads_sample(y3, w4, b4, w0, b0, w1, b1, u)
+    slabs = ops.linear_fwd_slabs([y3], [w4], ksplit=28, one_pass=True)[0]
+    phi = slabs[0].clone()
+    for s in range(1, 28):
+        phi = phi + slabs[s]
+    phi = torch.relu(phi + b4)
+    ref = ops.policy_heads_sample(phi, w0, b0, w1, b1, u)
+    for g, r in zip(got, ref):
+        assert torch.equal(g, r)
+    _scale_close(phi.cpu().numpy(), np.maximum(y3.double().cpu().numpy() @ w4.double().cpu().numpy().T + b4.double().cpu().numpy(), 0))
+
+
 @pytest.mark.parametrize("rows,n", [(1024, 256), (80, 16), (7, 7), (2048, 1)])
 def test_gather_rows_equals_indexing(dev, rows, n):
     """dra_gather_rows (the five fields of a PPO minibatch -- uint8 frame stacks, int64 actions, three float columns -- by one

@@ -148,6 +148,8 @@ CASES = {
     "ppo_pixel_8": lambda: ppo_pixel(8),
     "a2c_pixel_16_nofc4head": lambda: a2c_pixel(16, fuse_fc4_head=False),      # fc4 finish / policy head as separate autograd nodes
     "ppo_pixel_8_nofc4head": lambda: ppo_pixel(8, fuse_fc4_head=False),
+    "a2c_pixel_16_gemv": lambda: a2c_pixel(16, rollout_fc4_slices=False),       # rollout fc4 as the eight-wave GEMV (module path)
+    "ppo_pixel_8_gemv": lambda: ppo_pixel(8, rollout_fc4_slices=False),
     "a2c_pixel_16_modules": lambda: a2c_pixel(16, fused_rollout=False),         # rollout through network.forward (5 launches / step)
     "ppo_pixel_8_modules": lambda: ppo_pixel(8, fused_rollout=False),
     "ppo_pixel_8_host": lambda: ppo_pixel(8, device=False),
