@@ -314,18 +314,20 @@ DRA_API int dra_policy_heads_given(const float* x, const float* w0, const float*
 }
 
 // ... and with fc4's finish in front (the update's forward of CategoricalActorCriticNet(NatureConvBody)): the features are folded
-// from the 14 K-slice partial sums of dra_linear_fwd_slabs_one inside the head launch (+ bias, ReLU; written to out_phi for the
-// backward pass) -- linear_finish_kernel was a launch of 5.6 us for 0.16 MB (profiles/r05z2_kernel_stats_a2c_pixel_16.txt).
-DRA_API int dra_policy_heads_given_fold14(const float* slabs, const float* fold_bias, const float* w0, const float* b0, const float* w1,
-                                          const float* b1, const int64_t* action, int batch, int n_actions, float* out_log_pi_a,
-                                          float* out_entropy, float* out_v, float* out_logits, float* out_phi, void* stream) {
-  if (!slabs || !fold_bias || !w0 || !w1 || !action || !out_log_pi_a || !out_entropy || !out_v || !out_logits || !out_phi ||
-      batch < 1 || batch > 65536 || n_actions < 1 || n_actions > 64)
+// from the 8 / 14 K-slice partial sums of dra_linear_fwd_slabs_one inside the head launch (+ bias, ReLU; written to out_phi for
+// the backward pass; 8 slices: 8.9 / 17.3 us at 80 / 256 rows against 10.9 / 21.2 with 14, tools/fc4_small_probe.py) -- linear_finish_kernel was a launch of 5.6 us for 0.16 MB (profiles/r05z2_kernel_stats_a2c_pixel_16.txt).
+DRA_API int dra_policy_heads_given_fold(const float* slabs, int n_slabs, const float* fold_bias, const float* w0, const float* b0,
+                                        const float* w1, const float* b1, const int64_t* action, int batch, int n_actions,
+                                        float* out_log_pi_a, float* out_entropy, float* out_v, float* out_logits, float* out_phi,
+                                        void* stream) {
+  if (!slabs || (n_slabs != 8 && n_slabs != 14) || !fold_bias || !w0 || !w1 || !action || !out_log_pi_a || !out_entropy || !out_v ||
+      !out_logits || !out_phi || batch < 1 || batch > 65536 || n_actions < 1 || n_actions > 64)
     return DRA_EINVAL;
   PolicyHeadArgs h = head_args(nullptr, w0, b0, w1, b1, nullptr, action, batch, 512, n_actions, nullptr, out_log_pi_a, out_entropy,
                                out_v, out_logits);
   h.slabs = slabs; h.fold_bias = fold_bias; h.out_x = out_phi;
-  hipLaunchKernelGGL(policy_heads_sample_kernel<14>, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), h);
+  if (n_slabs == 8) hipLaunchKernelGGL(policy_heads_sample_kernel<8>, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), h);
+  else hipLaunchKernelGGL(policy_heads_sample_kernel<14>, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), h);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -581,9 +583,9 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
     }
   }
   if (in_features == 3136 && batch > 32 && batch <= 4096 && workspace &&
-      (int64_t)nz * 14 * batch * out_features <= workspace_floats && gemv_enabled()) {
+      (int64_t)nz * 8 * batch * out_features <= workspace_floats && gemv_enabled()) {
     // fc4 of NatureConvBody at update batch sizes (A2C 80, a PPO minibatch of 256): the learner's one-pass K-slice kernel (both
-    // operands through LDS once, 14 slices: 336 / 896 workgroups) + the slab finish, instead of the K-chunked GEMM (13.9 + 5.1 us
+    // operands through LDS once, K slices) + the slab finish, instead of the K-chunked GEMM (13.9 + 5.1 us
     // at batch 80, 30.8 + 5 us at 256: profiles/r04ag_kernel_stats_a2c_pixel_16.txt, r04o_kernel_stats_ppo_pixel_8.txt)
     bool aligned = true;
     LinPtrs q;
@@ -593,10 +595,12 @@ DRA_API int dra_linear_fwd(int nz, const float* const* x, const float* const* w,
       aligned = aligned && !((((uintptr_t)x[z]) | ((uintptr_t)w[z])) & 15);
     }
     if (aligned) {
-      int rc = dra_linear_fwd_slabs_one(nz, x, w, batch, in_features, out_features, 14, workspace, stream);
+      // (8 slices from round 5 on: 8.9 / 17.3 us at 80 / 256 rows against 10.9 / 21.2 with 14, tools/fc4_small_probe.py -- the same
+      // count nets._Fc4PolicyHeadFn folds inside its head launch, so both forms give the same bits)
+      int rc = dra_linear_fwd_slabs_one(nz, x, w, batch, in_features, out_features, 8, workspace, stream);
       if (rc != DRA_OK) return rc;
       hipLaunchKernelGGL(linear_finish_kernel, dim3((batch * out_features + 255) / 256, nz), dim3(256), 0, st, q,
-                         (const float*)workspace, 14, batch, out_features, act);
+                         (const float*)workspace, 8, batch, out_features, act);
       DRA_LAUNCH_CHECK();
       return DRA_OK;
     }

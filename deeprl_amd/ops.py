@@ -642,7 +642,7 @@ def policy_heads_given(x, w0, b0, w1, b1, action):
 
 
 def fc4_policy_heads_given(y3, w4, b4, w0, b0, w1, b1, action):
-    """fc4 (3136 -> 512, + ReLU) and the policy head for given actions as TWO launches: the one-pass K-slice forward (14 slabs) and
+    """fc4 (3136 -> 512, + ReLU) and the policy head for given actions as TWO launches: the one-pass K-slice forward (8 slabs) and
     the head launch that folds them -> (log_pi_a [B], entropy [B], v [B], logits [B, A], phi [B, 512]); linear_fwd + its finish +
     policy_heads_given were three, same arithmetic."""
     y3, w4, b4, w0, w1, action = _c(y3, _f32), _c(w4, _f32), _c(b4, _f32), _c(w0, _f32), _c(w1, _f32), _c(action, torch.int64)
@@ -651,12 +651,12 @@ def fc4_policy_heads_given(y3, w4, b4, w0, b0, w1, b1, action):
     batch = int(y3.shape[0])
     a = int(w0.shape[0])
     dev = y3.device
-    slabs = torch.empty((14, batch, 512), dtype=_f32, device=dev)
-    lib.dra_linear_fwd_slabs_one(1, ptr_array([y3]), ptr_array([w4]), batch, 3136, 512, 14, ptr(slabs), stream_ptr())
+    slabs = torch.empty((8, batch, 512), dtype=_f32, device=dev)      # (8 slices: the fastest at 80 / 256 rows, tools/fc4_small_probe.py)
+    lib.dra_linear_fwd_slabs_one(1, ptr_array([y3]), ptr_array([w4]), batch, 3136, 512, 8, ptr(slabs), stream_ptr())
     lp, ent, v = (torch.empty(batch, dtype=_f32, device=dev) for _ in range(3))
     logits = torch.empty((batch, a), dtype=_f32, device=dev)
     phi = torch.empty((batch, 512), dtype=_f32, device=dev)
-    lib.dra_policy_heads_given_fold14(ptr(slabs), ptr(b4), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(action), batch, a, ptr(lp),
+    lib.dra_policy_heads_given_fold(ptr(slabs), 8, ptr(b4), ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(action), batch, a, ptr(lp),
                                       ptr(ent), ptr(v), ptr(logits), ptr(phi), stream_ptr())
     return lp, ent, v, logits, phi
 

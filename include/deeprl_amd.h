@@ -220,11 +220,11 @@ int dra_policy_heads_sample(const float* x, const float* w0, const float* b0, co
 int dra_policy_heads_given(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
                            const int64_t* action, int batch, int in_features, int n_actions, float* out_log_pi_a,
                            float* out_entropy, float* out_v, float* out_logits, void* stream);
-/* ... with the finish of the 512-feature layer below in front: features = relu(fold_bias + sum of the 14 K-slice partial sums
- * slabs [14][batch][512] of dra_linear_fwd_slabs_one, slab 0 first), written to out_phi [batch][512] */
-int dra_policy_heads_given_fold14(const float* slabs, const float* fold_bias, const float* w0, const float* b0, const float* w1,
-                                  const float* b1, const int64_t* action, int batch, int n_actions, float* out_log_pi_a,
-                                  float* out_entropy, float* out_v, float* out_logits, float* out_phi, void* stream);
+/* ... with the finish of the 512-feature layer below in front: features = relu(fold_bias + sum of the n_slabs (8 or 14) K-slice
+ * partial sums slabs [n_slabs][batch][512] of dra_linear_fwd_slabs_one, slab 0 first), written to out_phi [batch][512] */
+int dra_policy_heads_given_fold(const float* slabs, int n_slabs, const float* fold_bias, const float* w0, const float* b0,
+                                const float* w1, const float* b1, const int64_t* action, int batch, int n_actions,
+                                float* out_log_pi_a, float* out_entropy, float* out_v, float* out_logits, float* out_phi, void* stream);
 /* a rollout step's head with the finish of fc4's 28-slice one-pass forward in front: features = relu(fold_bias + sum of slabs
  * [28][batch][512], slab 0 first); one workgroup per row; then as dra_policy_heads_sample */
 int dra_policy_heads_sample_fold28(const float* slabs, const float* fold_bias, const float* w0, const float* b0, const float* w1,

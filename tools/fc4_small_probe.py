@@ -43,11 +43,11 @@ def timed(fn, reps=32, iters=20):
     return best
 
 
-for b in (8, 16, 32):
+for b in (8, 16, 32, 80, 256):
     x = torch.randn(b, 3136, device=dev)
     out = {"batch": b}
     y = torch.empty(b, 512, device=dev)
-    out["gemv_rows_us"] = timed(lambda: ops.linear_fwd([x], [w], [bias], act="relu"))
+    out["linear_fwd_us"] = timed(lambda: ops.linear_fwd([x], [w], [bias], act="relu"))      # <= 32: eight-wave GEMV; above: 14 slices + finish
     for ks in (8, 14, 28):
         slabs = torch.empty(1, ks, b, 512, device=dev)
         xa, wa = ops.ptr_array([x]), ops.ptr_array([w])
