@@ -163,6 +163,33 @@ class FusedOptimizer:
             self._hyper_up = _PinnedUploader(torch.float32, 2, dev)
             self.graph_mode = True
 
+    def enable_block_mode(self, k):
+        """Graph mode for k consecutive steps inside ONE captured graph: step j of the block reads its Adam scalars from row j of
+        a [k, 2] device block that prepare_steps(k) fills with one copy."""
+        self.enable_graph_mode()
+        if getattr(self, '_hyper_block', None) is None or self._hyper_block.shape[0] != k:
+            dev = self.flat.flat.device
+            self._hyper_block = torch.zeros((k, 2), dtype=torch.float32, device=dev)
+            from .replay import _PinnedUploader
+            self._hyper_block_up = _PinnedUploader(torch.float32, 2 * k, dev)
+        return self._hyper_block
+
+    def prepare_steps(self, k):
+        """prepare_step() for the next k steps at once (same host arithmetic per step: dra_adam_hyper), one upload."""
+        vals = []
+        if self.kind == 'adam':
+            import ctypes
+            from ._lib import lib
+            b1, b2 = self.hyper['betas']
+            hp = (ctypes.c_float * 2)()
+            for _ in range(k):
+                self.steps += 1
+                lib.dra_adam_hyper(float(self.hyper['lr']), float(b1), float(b2), int(self.steps), hp)
+                vals += [hp[0], hp[1]]
+            self._hyper_block_up.upload_into(self._hyper_block.view(-1), vals)
+        else:
+            self.steps += k
+
     def hyper_signature(self):
         """Hyper-parameters that are baked into a captured update (a change invalidates the graph)."""
         h = self.hyper
