@@ -275,6 +275,15 @@ policy_heads_sample_kernel(const PolicyHeadArgs h) {       // body: rollout_role
   policy_head_row<KS>(h, b, lane, s_out[wave]);
 }
 
+// one workgroup per row, the row's features folded from KS K-slice partial sums first (rollout_roles.h policy_head_row_fold_wg)
+template <int KS>
+__global__ void __launch_bounds__(256)
+policy_heads_foldwg_kernel(const PolicyHeadArgs h) {
+  __shared__ float s_phi[512];
+  __shared__ float s_out[68];
+  policy_head_row_fold_wg<KS>(h, blockIdx.x, s_phi, s_out);
+}
+
 static PolicyHeadArgs head_args(const float* x, const float* w0, const float* b0, const float* w1, const float* b1,
                                 const float* uniform, const int64_t* action_in, int batch, int in_features, int n_actions,
                                 int64_t* out_action, float* out_lp, float* out_ent, float* out_v, float* out_logits) {
@@ -326,20 +335,16 @@ DRA_API int dra_policy_heads_given_fold(const float* slabs, int n_slabs, const f
   PolicyHeadArgs h = head_args(nullptr, w0, b0, w1, b1, nullptr, action, batch, 512, n_actions, nullptr, out_log_pi_a, out_entropy,
                                out_v, out_logits);
   h.slabs = slabs; h.fold_bias = fold_bias; h.out_x = out_phi;
-  if (n_slabs == 8) hipLaunchKernelGGL(policy_heads_sample_kernel<8>, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), h);
-  else hipLaunchKernelGGL(policy_heads_sample_kernel<14>, dim3((batch + 3) / 4), dim3(256), 0, dra_stream(stream), h);
+  // one workgroup per row (the fold spread over four waves): the wave-per-row form took 10.2 us at 256 rows -- 64 workgroups for
+  // 4 MB of slabs (profiles/r05fb_kernel_stats_ppo_pixel_8.txt); same sums in the same order
+  if (n_slabs == 8) hipLaunchKernelGGL(policy_heads_foldwg_kernel<8>, dim3(batch), dim3(256), 0, dra_stream(stream), h);
+  else hipLaunchKernelGGL(policy_heads_foldwg_kernel<14>, dim3(batch), dim3(256), 0, dra_stream(stream), h);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
 
 // A rollout step's fc4 finish + policy head (rollout_roles.h policy_head_row_fold_wg): one workgroup per row, the features
 // folded from the 28 K-slice partial sums of dra_linear_fwd_slabs_one(ksplit = 28).  K = 512.
-__global__ void __launch_bounds__(256)
-policy_heads_fold28_kernel(const PolicyHeadArgs h) {
-  __shared__ float s_phi[512];
-  __shared__ float s_out[68];
-  policy_head_row_fold_wg<28>(h, blockIdx.x, s_phi, s_out);
-}
 
 DRA_API int dra_policy_heads_sample_fold28(const float* slabs, const float* fold_bias, const float* w0, const float* b0,
                                            const float* w1, const float* b1, const float* uniform, int batch, int n_actions,
@@ -351,7 +356,7 @@ DRA_API int dra_policy_heads_sample_fold28(const float* slabs, const float* fold
   PolicyHeadArgs h = head_args(nullptr, w0, b0, w1, b1, uniform, nullptr, batch, 512, n_actions, out_action, out_log_pi_a, out_entropy,
                                out_v, nullptr);
   h.slabs = slabs; h.fold_bias = fold_bias;
-  hipLaunchKernelGGL(policy_heads_fold28_kernel, dim3(batch), dim3(256), 0, dra_stream(stream), h);
+  hipLaunchKernelGGL(policy_heads_foldwg_kernel<28>, dim3(batch), dim3(256), 0, dra_stream(stream), h);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
