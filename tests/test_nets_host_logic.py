@@ -141,3 +141,60 @@ def test_rollout_slots_hand_out_the_announced_rows_then_fall_back():
     s.pin(None)
     s.end()
     assert s.take(4) == (None, None)
+
+
+def test_deferred_folds_are_grouped_into_one_norm_launch_when_they_tile_the_buffer_from_zero(monkeypatch):
+    """optim.FusedOptimizer.defer_fold / step (host logic, kernels mocked): conv layers whose gradient segments tile the flat
+    buffer from offset 0 are folded by ONE dra_grad_sqnorm_segs call whose partial sums the step then reads; segments that do
+    not (a gap, or not starting at 0) are folded one by one and the plain norm pass runs; a view that is not this optimizer's
+    buffer / not 16-byte aligned is refused (the layer folds itself); zero_grad() forgets registered slabs."""
+    import torch
+    from deeprl_amd import ops, optim
+    calls = []
+    monkeypatch.setattr(ops, "grad_sqnorm_segs", lambda grad, segs, partials: calls.append(("segs", grad.numel(), [s[:2] + s[3:] for s in segs])) or 7)
+    monkeypatch.setattr(ops, "grad_sqnorm", lambda grad, partials, **kw: calls.append(("norm", grad.numel())))
+    monkeypatch.setattr(ops, "rmsprop_step", lambda *a, **k: calls.append(("step", a[5])))
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (32, 64, 16, 40)]
+    opt = optim.FusedOptimizer.adopt(torch.optim.RMSprop(params, lr=1e-3))
+    g = opt.flat.grad
+    slabs = torch.zeros(4 * 64)
+    assert opt.defer_fold(g[0:32], 32, slabs, 4) and opt.defer_fold(g[96:112], 16, slabs, 2) and opt.defer_fold(g[32:96], 64, slabs, 3)
+    assert not opt.defer_fold(torch.zeros(32), 32, slabs, 4)            # another buffer
+    assert not opt.defer_fold(g[2:34], 32, slabs, 4)                    # not 16-byte aligned
+    opt.step(5.0)
+    assert calls == [("segs", 152, [(0, 32, 32, 4), (32, 64, 64, 3), (96, 16, 16, 2)]), ("step", 7)] and not opt._pending_folds
+    calls.clear()
+    assert opt.defer_fold(g[32:96], 64, slabs, 3) and opt.defer_fold(g[96:112], 16, slabs, 2)      # does not start at 0
+    opt.step(5.0)
+    assert [c[0] for c in calls] == ["segs", "segs", "norm", "step"] and calls[0][1] == 64 and calls[-1][1] == opt.n_partials
+    calls.clear()
+    assert opt.defer_fold(g[0:32], 32, slabs, 4)
+    opt.zero_grad()
+    opt.step(None)
+    assert calls == [("step", opt.n_partials)]
+
+
+def test_zero_grad_is_skipped_only_after_a_backward_that_overwrote_every_gradient():
+    """nets.direct_param_grads(covers=[opt]) + FusedOptimizer.zero_grad(direct=True): the fill is dead work when the previous
+    direct backward claimed every parameter exactly once; a parameter reached twice (accumulation) or never brings it back."""
+    import torch
+    from deeprl_amd import nets, optim
+    params = [torch.nn.Parameter(torch.zeros(8)) for _ in range(3)]
+    opt = optim.FusedOptimizer.adopt(torch.optim.RMSprop(params, lr=1e-3))
+    fills = []
+    opt.flat.zero_grad = lambda: fills.append(1)
+    opt.zero_grad(direct=True)
+    assert fills == [1]                                   # nothing known yet
+    with nets.direct_param_grads(True, covers=[opt]):
+        assert nets._claim_direct(params[:2]) and nets._claim_direct(params[2:])
+    opt.zero_grad(direct=True)
+    assert fills == [1] and opt.all_direct                # every gradient will be overwritten again
+    opt.zero_grad()                                       # a caller that does not promise a direct backward still gets its fill
+    assert fills == [1, 1]
+    with nets.direct_param_grads(True, covers=[opt]):
+        assert nets._claim_direct(params[:2]) and not nets._claim_direct(params[1:])      # params[1] reached twice
+    opt.zero_grad(direct=True)
+    assert fills == [1, 1, 1] and not opt.all_direct
+    with nets.direct_param_grads(True, covers=[opt]):
+        assert nets._claim_direct(params[:2])                                                # params[2] never written
+    assert not opt.all_direct
