@@ -1330,6 +1330,7 @@ static int launch_conv1_u8_tp(const ConvV2Args& a, int nz, hipStream_t st) {
 
 // Tile shape by problem size: one tile per workgroup (latency shape) until the launch has several workgroups
 // per CU slot anyway, then PTBIG tiles per workgroup (throughput shape).  DRA_CONV_PT=1 forces the latency shape.
+constexpr int kConvNw8MaxBatch = 16;
 static int g_conv_pt_threshold = -1;
 template <class G, bool U8, int PTBIG>
 static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
@@ -1359,7 +1360,10 @@ static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
     }
     return launch_conv_v2_pt<G, U8, PTBIG>(a, nz, st);
   }
-  if (a.batch == 1 && conv_b1_waves() == 8) return launch_conv_v2_pt<G, U8, 1, 8>(a, nz, st);
+  // the eight-wave latency shape (K split eight ways: half the MFMA chain per wave) up to kConvNw8MaxBatch samples: the batch-1
+  // actor's launches since round 3, and from round 5 the 8 / 16-environment rollout steps of the actor-critic agents (a2c_pixel
+  // 245.3 k -> 249.0 k, ppo_pixel 134.1 k -> 135.6 k env-steps/s, same-call A/B: profiles/r05g8_bench_agents_nw8.txt)
+  if (a.batch <= kConvNw8MaxBatch && !a.pf_nz && !a.sample_idx && conv_b1_waves() == 8) return launch_conv_v2_pt<G, U8, 1, 8>(a, nz, st);
   return launch_conv_v2_pt<G, U8, 1>(a, nz, st);
 }
 
@@ -1505,11 +1509,13 @@ int dra_conv1_fwd_actor_fused(const void* frames, const int64_t* slot_field_dev,
 // the arrival count, the poll and the cold read of the hand-over cost more than the boundary they replace; with an acquire
 // fence per wave in front of the reads 27 us.  a2c_pixel 215 k against 224 k env-steps/s, ppo_pixel 115 k against 118 k:
 // profiles/r05x_bench_agents_c3fc4_ab.jsonl.)
-__global__ void __launch_bounds__(256)
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
 rollout_conv1_heads_kernel(const ConvV2Args a, const PolicyHeadArgs h, const int head_wgs) {
   __shared__ float s_out[4][68];
   __shared__ float s_phi[512];
   if ((int)blockIdx.x < head_wgs) {
+    if (threadIdx.x >= 256) return;      // the head's workgroups are four waves (an exited wave does not hold a barrier up)
     if (h.slabs) {        // one row per workgroup, its features folded from fc4's 28 K-slice partial sums first
       policy_head_row_fold_wg<28>(h, (int)blockIdx.x, s_phi, s_out[0]);
       return;
@@ -1521,7 +1527,7 @@ rollout_conv1_heads_kernel(const ConvV2Args a, const PolicyHeadArgs h, const int
   }
   ActorFuse none;
   none.mode = 0;
-  conv_fwd_v2_body<VG1, true, 1, 4, false>(a, none, (int)blockIdx.x - head_wgs, 0, 0, false);
+  conv_fwd_v2_body<VG1, true, 1, NW, false>(a, none, (int)blockIdx.x - head_wgs, 0, 0, false);
 }
 
 DRA_API int dra_rollout_conv1_heads(const void* frames_u8, const float* wt1, const float* b1, float* y1, int batch, double u8_coef,
@@ -1552,10 +1558,14 @@ DRA_API int dra_rollout_conv1_heads(const void* frames_u8, const float* wt1, con
     }
   }
   constexpr size_t img = (size_t)VG1::C * T::CS * sizeof(float);
-  constexpr size_t red = (size_t)4 * 16 * 64 * sizeof(float);
-  constexpr size_t bytes = img > red ? img : red;
-  static_assert(bytes <= 64 * 1024, "conv1's latency shape fits the default dynamic LDS limit");
-  hipLaunchKernelGGL(rollout_conv1_heads_kernel, dim3(head_wgs + T::TPG * batch), dim3(256), bytes, dra_stream(stream), a, h, head_wgs);
+  constexpr size_t red8 = (size_t)8 * 16 * 64 * sizeof(float), red4 = (size_t)4 * 16 * 64 * sizeof(float);
+  constexpr size_t bytes8 = img > red8 ? img : red8, bytes4 = img > red4 ? img : red4;
+  static_assert(bytes8 <= 64 * 1024, "conv1's latency shapes fit the default dynamic LDS limit");
+  // the same wave count dra_conv_fwd_koc picks for this batch (launch_conv_v2): bit-identical with the plain launch
+  if (batch <= kConvNw8MaxBatch && conv_b1_waves() == 8)
+    hipLaunchKernelGGL(rollout_conv1_heads_kernel<8>, dim3(head_wgs + T::TPG * batch), dim3(512), bytes8, dra_stream(stream), a, h, head_wgs);
+  else
+    hipLaunchKernelGGL(rollout_conv1_heads_kernel<4>, dim3(head_wgs + T::TPG * batch), dim3(256), bytes4, dra_stream(stream), a, h, head_wgs);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

@@ -700,7 +700,7 @@ def test_conv_koc_fwd_throughput_shape(dev, layer):
 def test_conv1_full_k_throughput_kernel(dev, batch):
     """conv1's own throughput kernel (conv_v2.hip conv1_fwd_u8_tp_kernel, uint8 batches >= 384): all of K in a wave's
     registers, the latency shape's four K quarters as four accumulation chains folded (q0 + q1) + (q2 + q3) -- bit-identical
-    with the latency shape on a shared prefix, and F.conv2d within the contraction tolerance.  389: one sample per workgroup
+    with the four-wave latency shape (17 ... 127 samples) on a shared prefix / suffix, and F.conv2d within the contraction tolerance.  389: one sample per workgroup
     iteration, an odd batch; 1025: two samples per iteration, a second iteration, a last group of one sample."""
     import torch.nn.functional as F
     from deeprl_amd import ops
@@ -712,8 +712,9 @@ def test_conv1_full_k_throughput_kernel(dev, batch):
     x_u8 = rs.randint(0, 256, size=(batch, c, h, h)).astype(np.uint8)
     big = ops.conv_fwd_koc(1, [cu(x_u8, dev)], [wt], [f32(b, dev)], u8_coef=1.0 / 255)[0]
     small = ops.conv_fwd_koc(1, [cu(x_u8[:33], dev)], [wt], [f32(b, dev)], u8_coef=1.0 / 255)[0]
-    tail = ops.conv_fwd_koc(1, [cu(x_u8[-7:], dev)], [wt], [f32(b, dev)], u8_coef=1.0 / 255)[0]
-    assert torch.equal(big[:33], small) and torch.equal(big[-7:], tail)
+    # (19 samples: batches of <= 16 run the EIGHT-wave latency shape from round 5 on -- another summation tree)
+    tail = ops.conv_fwd_koc(1, [cu(x_u8[-19:], dev)], [wt], [f32(b, dev)], u8_coef=1.0 / 255)[0]
+    assert torch.equal(big[:33], small) and torch.equal(big[-19:], tail)
     keep = np.r_[0:40, batch - 40:batch]
     x = NUM.image_normalize_sync(x_u8[keep])
     ref = F.relu(F.conv2d(t64(x, False), t64(w, False), t64(b, False), stride=s)).numpy()
