@@ -230,15 +230,18 @@ ring_gather_kernel(const uint8_t* __restrict__ frames, const uint8_t* __restrict
                    const int64_t* __restrict__ idx, int64_t frame_bytes, int64_t action_bytes, int H, int n,
                    double discount, uint8_t* __restrict__ out_state, uint8_t* __restrict__ out_next,
                    uint8_t* __restrict__ out_action, double* __restrict__ out_reward, int32_t* __restrict__ out_mask,
-                   float* __restrict__ out_reward_f32, float* __restrict__ out_mask_f32) {
+                   float* __restrict__ out_reward_f32, float* __restrict__ out_mask_f32, const int block) {
   const int span = H + n;
   const int b = blockIdx.x / span;
   const int j = blockIdx.x - b * span;
   DRA_STAMP(TR_GATHER, 0);
   const int64_t i = idx[b];
   const uint8_t* src = frames + (i - H + 1 + j) * frame_bytes;
-  uint8_t* d0 = (j < H && out_state) ? out_state + ((int64_t)b * H + j) * frame_bytes : nullptr;
-  uint8_t* d1 = (j >= n && out_next) ? out_next + ((int64_t)b * H + (j - n)) * frame_bytes : nullptr;
+  // block != 0: out_state is ONE [B][H + n][frame] block, every frame of the run written once (state = frames [0, H), next_state
+  // = frames [n, H + n) of the same sample: two views); else the two [B][H][frame] tensors, the H - n shared frames written twice
+  uint8_t* d0 = block ? out_state + ((int64_t)b * span + j) * frame_bytes
+                      : ((j < H && out_state) ? out_state + ((int64_t)b * H + j) * frame_bytes : nullptr);
+  uint8_t* d1 = (!block && j >= n && out_next) ? out_next + ((int64_t)b * H + (j - n)) * frame_bytes : nullptr;
   if (VEC16) {
     // two 16-byte loads per lane in flight before the first store (a 7056-byte frame is 441 vectors: one pass
     // of this loop); STREAM (many-minibatch launches whose output does not fit the caches) also streams the stores
@@ -291,27 +294,42 @@ ring_gather_kernel(const uint8_t* __restrict__ frames, const uint8_t* __restrict
 // (A workgroup-per-SAMPLE shape -- one workgroup walking the whole 5-frame run, 3 loads per lane in flight -- was measured
 // for many-minibatch launches and LOST to the workgroup-per-frame shape below: 4.90 vs 5.81 TB/s at 1024 minibatches on the
 // same box, profiles/r02w_kernel_microbench_gather_ab.json; fewer, longer workgroups leave fewer loads in flight per CU.)
-DRA_API int dra_ring_gather(dra_ring* r, const int64_t* idx_dev, int batch, void* out_state, void* out_next_state,
-                            void* out_action, double* out_reward, int32_t* out_mask, float* out_reward_f32,
-                            float* out_mask_f32, void* stream) {
-  if (!r || !idx_dev || batch <= 0) return DRA_EINVAL;
+static int ring_gather_launch(dra_ring* r, const int64_t* idx_dev, int batch, void* out_state, void* out_next_state, void* out_action,
+                              double* out_reward, int32_t* out_mask, float* out_reward_f32, float* out_mask_f32, int block,
+                              void* stream) {
+  if (!r || !idx_dev || batch <= 0 || (block && !out_state)) return DRA_EINVAL;
   const int span = r->history + r->n_step;
   const bool vec = (r->frame_bytes % 16 == 0) && aligned16(r->frames) && (!out_state || aligned16(out_state)) &&
                    (!out_next_state || aligned16(out_next_state));
-  dim3 grid((unsigned)batch * span), block(256);
+  dim3 grid((unsigned)batch * span), blk(256);
   // an output larger than the 256 MB Infinity Cache cannot stay on die anyway: stream it past the caches
-  const bool stream_out = (int64_t)batch * 2 * r->history * r->frame_bytes >= ((int64_t)256 << 20);
+  const bool stream_out = (int64_t)batch * (block ? span : 2 * r->history) * r->frame_bytes >= ((int64_t)256 << 20);
 #define DRA_GATHER_LAUNCH(V, S)                                                                                        \
-  hipLaunchKernelGGL((ring_gather_kernel<V, S>), grid, block, 0, dra_stream(stream), r->frames, r->actions, r->rewards, \
+  hipLaunchKernelGGL((ring_gather_kernel<V, S>), grid, blk, 0, dra_stream(stream), r->frames, r->actions, r->rewards,   \
                      r->masks, idx_dev, r->frame_bytes, r->action_bytes, r->history, r->n_step, r->discount,          \
                      (uint8_t*)out_state, (uint8_t*)out_next_state, (uint8_t*)out_action, out_reward, out_mask,       \
-                     out_reward_f32, out_mask_f32)
+                     out_reward_f32, out_mask_f32, block)
   if (vec && stream_out) DRA_GATHER_LAUNCH(true, true);
   else if (vec) DRA_GATHER_LAUNCH(true, false);
   else DRA_GATHER_LAUNCH(false, false);
 #undef DRA_GATHER_LAUNCH
   DRA_LAUNCH_CHECK();
   return DRA_OK;
+}
+
+DRA_API int dra_ring_gather(dra_ring* r, const int64_t* idx_dev, int batch, void* out_state, void* out_next_state,
+                            void* out_action, double* out_reward, int32_t* out_mask, float* out_reward_f32,
+                            float* out_mask_f32, void* stream) {
+  return ring_gather_launch(r, idx_dev, batch, out_state, out_next_state, out_action, out_reward, out_mask, out_reward_f32,
+                            out_mask_f32, 0, stream);
+}
+
+// state / next_state as two views of ONE [batch][history + n_step][frame] block (replay.py:112-140 stacks the same frames twice:
+// the history - n_step shared frames of a sample are written once here -- 1.13 instead of 1.81 MB per DQN minibatch)
+DRA_API int dra_ring_gather_block(dra_ring* r, const int64_t* idx_dev, int batch, void* out_block, void* out_action,
+                                  double* out_reward, int32_t* out_mask, float* out_reward_f32, float* out_mask_f32, void* stream) {
+  return ring_gather_launch(r, idx_dev, batch, out_block, nullptr, out_action, out_reward, out_mask, out_reward_f32, out_mask_f32, 1,
+                            stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -338,6 +356,44 @@ u8_lut_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t n
     }
   }
   for (int64_t t = (n16 << 4) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) out[t] = s_lut[in[t]];
+}
+
+// The same table for rows that are contiguous inside but in_row_stride bytes apart (the state / next_state views of
+// dra_ring_gather_block): out is dense [n_rows][row_elems].  row_elems % 16 == 0, 16-byte aligned rows.
+__global__ void __launch_bounds__(256)
+u8_lut_rows_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t n_rows, int64_t row_elems, int64_t in_row_stride,
+                   const float* __restrict__ lut) {
+  __shared__ float s_lut[256];
+  s_lut[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const int64_t v_per_row = row_elems >> 4, total = n_rows * v_per_row;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float4* out4 = reinterpret_cast<float4*>(out);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t row = t / v_per_row, c = t - row * v_per_row;
+    const uint4 v = *reinterpret_cast<const uint4*>(in + row * in_row_stride + (c << 4));
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 o;
+      o.x = s_lut[w[q] & 0xff]; o.y = s_lut[(w[q] >> 8) & 0xff];
+      o.z = s_lut[(w[q] >> 16) & 0xff]; o.w = s_lut[w[q] >> 24];
+      out4[t * 4 + q] = o;
+    }
+  }
+}
+
+DRA_API int dra_u8_to_f32_lut_rows(const void* in_u8, float* out, int64_t n_rows, int64_t row_elems, int64_t in_row_stride,
+                                   const float* lut256_dev, void* stream) {
+  if (!in_u8 || !out || !lut256_dev || n_rows < 1 || row_elems < 16 || (row_elems & 15) || in_row_stride < row_elems ||
+      (in_row_stride & 15) || ((((uintptr_t)in_u8) | ((uintptr_t)out)) & 15))
+    return DRA_EINVAL;
+  int64_t b = (n_rows * (row_elems >> 4) + 255) / 256;
+  if (b > 4096) b = 4096;
+  hipLaunchKernelGGL(u8_lut_rows_kernel, dim3((unsigned)b), dim3(256), 0, dra_stream(stream), (const uint8_t*)in_u8, out, n_rows,
+                     row_elems, in_row_stride, lut256_dev);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -77,11 +77,31 @@ class Ring:
         lib.dra_ring_fill_synthetic(self.h, int(slot0), int(count), int(counter0), int(seed), int(n_actions),
                                     int(done_period), stream_ptr())
 
-    def gather(self, idx, state_shape, state_dtype, action_dtype=torch.int64, want_f32=False, out=None):
-        """idx: int64 device tensor [B].  Returns dict of device tensors shaped like the reference's sample()."""
+    def gather(self, idx, state_shape, state_dtype, action_dtype=torch.int64, want_f32=False, out=None, block=True):
+        """idx: int64 device tensor [B].  Returns dict of device tensors shaped like the reference's sample().  block (and no
+        caller-owned `out`): state / next_state are two VIEWS of one [B, history + n_step, ...] block in which every frame of a
+        sample's run is written once (dra_ring_gather_block) -- same values, non-contiguous along the batch axis."""
         idx = _c(idx, torch.int64)
         b = idx.numel()
         dev = idx.device
+        if out is not None and out.get("block") is not None:        # a dict this method returned in block form: refill in place
+            lib.dra_ring_gather_block(self.h, ptr(idx), b, ptr(out["block"]), ptr(out["action"]), ptr(out["reward"]), ptr(out["mask"]),
+                                      ptr(out.get("reward_f32")), ptr(out.get("mask_f32")), stream_ptr())
+            return out
+        if out is None and block:
+            h, n = self.history, self.n_step
+            blk = torch.empty((b, h + n) + tuple(state_shape), dtype=state_dtype, device=dev)
+            esize = torch.empty(0, dtype=action_dtype).element_size()
+            ashape = (b,) if self.action_bytes == esize else (b, self.action_bytes // esize)
+            out = dict(block=blk, state=blk[:, :h] if h > 1 else blk[:, 0], next_state=blk[:, n:] if h > 1 else blk[:, n],
+                       action=torch.empty(ashape, dtype=action_dtype, device=dev),
+                       reward=torch.empty(b, dtype=torch.float64, device=dev), mask=torch.empty(b, dtype=torch.int32, device=dev))
+            if want_f32:
+                out["reward_f32"] = torch.empty(b, dtype=_f32, device=dev)
+                out["mask_f32"] = torch.empty(b, dtype=_f32, device=dev)
+            lib.dra_ring_gather_block(self.h, ptr(idx), b, ptr(blk), ptr(out["action"]), ptr(out["reward"]), ptr(out["mask"]),
+                                      ptr(out.get("reward_f32")), ptr(out.get("mask_f32")), stream_ptr())
+            return out
         if out is None:
             stack = (b, self.history) + tuple(state_shape) if self.history > 1 else (b,) + tuple(state_shape)
             esize = torch.empty(0, dtype=action_dtype).element_size()
@@ -106,8 +126,18 @@ class Ring:
 
 
 def u8_to_f32(x_u8, lut):
-    x = _c(x_u8, torch.uint8)
-    out = torch.empty(x.shape, dtype=_f32, device=x.device)
+    _dev(x_u8)
+    if x_u8.dtype != torch.uint8:
+        raise DraError("expected dtype %s, got %s" % (torch.uint8, x_u8.dtype))
+    out = torch.empty(x_u8.shape, dtype=_f32, device=x_u8.device)
+    if (not x_u8.is_contiguous() and x_u8.dim() >= 2 and x_u8.shape[0] > 0 and x_u8[0].is_contiguous()
+            and x_u8[0].numel() % 16 == 0 and x_u8.stride(0) % 16 == 0 and x_u8.stride(0) >= x_u8[0].numel()
+            and x_u8.data_ptr() % 16 == 0):
+        # rows that are contiguous inside and a fixed distance apart (the state / next_state views of Ring.gather): read in place
+        lib.dra_u8_to_f32_lut_rows(ptr(x_u8), ptr(out), int(x_u8.shape[0]), int(x_u8[0].numel()), int(x_u8.stride(0)),
+                                   ptr(_c(lut, _f32)), stream_ptr())
+        return out
+    x = x_u8 if x_u8.is_contiguous() else x_u8.contiguous()
     lib.dra_u8_to_f32_lut(ptr(x), ptr(out), x.numel(), ptr(_c(lut, _f32)), stream_ptr())
     return out
 

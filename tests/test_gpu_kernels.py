@@ -229,6 +229,37 @@ def test_ring_vs_oracle_atari_shapes(dev):
     ring.close()
 
 
+@pytest.mark.parametrize("h,n", [(4, 1), (4, 3), (1, 1), (2, 5)])
+def test_gather_block_views_equal_the_two_tensor_form(dev, h, n):
+    """dra_ring_gather_block (replay.py:112-140 with state / next_state as two VIEWS of one [B, history + n_step, ...] block:
+    every frame of a sample's run written once) == dra_ring_gather's two stacked tensors, bit for bit, for history / n-step
+    combinations incl. history 1 and n_step > history; refilling the returned dict in place keeps the block form; the uint8 ->
+    f32 table kernel reads the views in place (dra_u8_to_f32_lut_rows) and gives what it gives on contiguous copies."""
+    from deeprl_amd import ops
+    from deeprl_amd.normalizers import ImageNormalizer
+    cap, fb = 3000, 84 * 84
+    ring = ops.Ring(cap, fb, 8, h, n, 0.99)
+    ring.fill_synthetic(0, cap, 0, 9, n_actions=6, done_period=37)
+    rs = np.random.RandomState(h * 10 + n)
+    idx = cu(rs.randint(h + 5, cap - n - 5, size=96).astype(np.int64), dev)
+    shape = (84, 84)
+    a = ring.gather(idx, shape, torch.uint8, torch.int64, want_f32=True)
+    b = ring.gather(idx, shape, torch.uint8, torch.int64, want_f32=True, block=False)
+    assert a["block"].shape[1] == h + n and not (h > 1 and a["state"].is_contiguous()) and b["state"].is_contiguous()
+    for k in ("state", "next_state", "action", "reward", "mask", "reward_f32", "mask_f32"):
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+    idx2 = cu(rs.randint(h + 5, cap - n - 5, size=96).astype(np.int64), dev)
+    ptr0 = a["state"].data_ptr()
+    a2 = ring.gather(idx2, shape, torch.uint8, torch.int64, want_f32=True, out=a)
+    b2 = ring.gather(idx2, shape, torch.uint8, torch.int64, want_f32=True, block=False)
+    assert a2 is a and a["state"].data_ptr() == ptr0
+    assert torch.equal(a["state"], b2["state"]) and torch.equal(a["next_state"], b2["next_state"]) and torch.equal(a["reward"], b2["reward"])
+    norm = ImageNormalizer()
+    for k in ("state", "next_state"):
+        assert torch.equal(norm(a[k]), norm(b2[k]))
+    ring.close()
+
+
 def test_image_lut_bit_exact(dev):
     from deeprl_amd.normalizers import ImageNormalizer
     rs = np.random.RandomState(0)
