@@ -42,13 +42,16 @@ def main():
     for k in (1, 64, 1024):
         b = 32 * k
         idx = torch.from_numpy(rs.randint(3, cap - 2, size=b).astype(np.int64)).to(dev)
-        bufs = ring.gather(idx, (84, 84), torch.uint8, torch.int64, want_f32=True)
-        t = timeit(lambda: ring.gather(idx, (84, 84), torch.uint8, torch.int64, want_f32=True, out=bufs), n=10 if k > 64 else 50)
-        rd, wr = b * 5 * 7056, 2 * b * 4 * 7056
-        out["gather_k%d" % k] = {"minibatches": k, "seconds": t, "read_GBps": rd / t / 1e9, "read_plus_write_GBps": (rd + wr) / t / 1e9,
-                                 "frac_hbm_read_8TBps": rd / t / 8e12, "frac_hbm_total_8TBps": (rd + wr) / t / 8e12,
-                                 "frac_hbm_total_6.3TBps": (rd + wr) / t / 6.3e12}
-        del bufs
+        # both output forms: two stacked tensors (the reference's layout: 2 x 4 frames written per sample) and, from round 5 on what
+        # sample() returns, one [B, 5, 84, 84] block with state / next_state as views (5 frames written per sample)
+        for form, blockf, frames_written in (("", False, 8), ("_block", True, 5)):
+            bufs = ring.gather(idx, (84, 84), torch.uint8, torch.int64, want_f32=True, block=blockf)
+            t = timeit(lambda: ring.gather(idx, (84, 84), torch.uint8, torch.int64, want_f32=True, out=bufs), n=10 if k > 64 else 50)
+            rd, wr = b * 5 * 7056, b * frames_written * 7056
+            out["gather%s_k%d" % (form, k)] = {"minibatches": k, "seconds": t, "read_GBps": rd / t / 1e9,
+                                             "read_plus_write_GBps": (rd + wr) / t / 1e9, "frac_hbm_read_8TBps": rd / t / 8e12,
+                                             "frac_hbm_total_8TBps": (rd + wr) / t / 8e12, "frac_hbm_total_6.3TBps": (rd + wr) / t / 6.3e12}
+            del bufs
     ring.close()
     # clip + centered RMSprop over the DQN parameter count
     n = 1_686_180
