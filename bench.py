@@ -85,6 +85,25 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def pin_this_rank():
+    """One rank per GPU: pin this process to cores of its GPU's NUMA node, disjoint from the node's other ranks
+    (deeprl_amd.dist.pin_rank; SURVEY.md 8e: eight Python drivers must not share cores).  Returns the mapping for the line."""
+    from deeprl_amd.dist import pin_rank
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", 1)))
+    return pin_rank(local_rank, local_world)
+
+
+def gather_affinity(mine, world):
+    """Every rank's placement on rank 0 (all ranks must call)."""
+    if world <= 1:
+        return [mine]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return out
+
+
 def cpu_baseline(seconds=15.0, ring=20_000, worker=False):
     """The CPU oracle of the same update (port of the reference path): numpy ring gather ->
     f64*(1/255)->f32 -> target fwd, online fwd, TD loss, backward, clip, centered RMSprop on
@@ -400,6 +419,39 @@ def parity_check(bench, n_steps=6, gate_margin=5e-7):
                     "oracle on the minibatches its gather produced; outside the timed region" % n_steps}
 
 
+def replay_gather_line(bench, minibatches=1024, reps=10):
+    """The replay ring's minibatch gather (what UniformReplay.sample() / PrioritizedReplay.sample() launch on the generic
+    paths; the timed update reads the ring from conv1 and does not gather), live on the bench's own ring: `minibatches` x 32
+    samples per launch, block form (5 frames of 7056 B read and 5 written per sample).  north_star's target is quoted on the
+    READ roofline; one byte is written per byte read, so read + write is the kernel's position and the read share is half."""
+    import deeprl_amd as d
+    ring, cap = bench.ring, bench.capacity
+    rs = np.random.RandomState(7)
+    b = 32 * minibatches
+    idx = torch.from_numpy(rs.randint(3, min(cap, bench.size) - 2, size=b).astype(np.int64)).to(d.Config.DEVICE)
+    out = ring.gather(idx, (84, 84), torch.uint8, torch.int64, want_f32=True, block=True)
+    for _ in range(3):
+        ring.gather(idx, (84, 84), torch.uint8, torch.int64, want_f32=True, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ring.gather(idx, (84, 84), torch.uint8, torch.int64, want_f32=True, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / reps
+    rd = wr = b * 5 * 7056
+    del out
+    return {"kernel": "ring_gather_kernel (block form)", "minibatches_per_launch": minibatches, "samples": b,
+            "algorithmic_bytes": {"read": rd, "written": wr}, "us_per_launch": t * 1e6,
+            "read_GBps": rd / t / 1e9, "read_plus_write_GBps": (rd + wr) / t / 1e9,
+            "frac_read_of_8TBps": rd / t / 8e12, "frac_read_plus_write_of_8TBps": (rd + wr) / t / 8e12,
+            "target": "north_star: replay gather >= 70 % of the HBM-read roofline", "target_met": bool(rd / t / 8e12 >= 0.7),
+            "note": "every byte read is written once, so the read stream can use at most half of the fabric: the literal read "
+                    "fraction is reported, the kernel's roofline position is read + write; the timed update does not launch "
+                    "this kernel (conv1 reads the ring in place)"}
+
+
 def pmc_traffic(kernel_group):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (profiles/rNN_pmc_traffic.json, made by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of
@@ -468,6 +520,7 @@ def on_policy_main(args):
         torch.cuda.set_device(local_rank % n_dev)
         dd.init("nccl" if world <= n_dev else "gloo")
     d.select_device(local_rank % n_dev)
+    affinity = pin_this_rank()
 
     class Quiet:
         def info(self, *a, **k):
@@ -502,7 +555,7 @@ def on_policy_main(args):
     # what the collective itself saw, and every rank's own rate (its shard's environment steps over ITS wall time): a SCALE
     # record then explains itself -- ranks RCCL spanned vs WORLD_SIZE, stragglers, whether the fc4 segment overlapped
     rccl = agent.dp.comm.info() if getattr(agent.dp, "comm", None) is not None else None
-    mine = {"rank": rank, "seconds": dt, "env_steps_per_s": k * agent.config.rollout_length * per_gpu / dt,
+    mine = {"rank": rank, "seconds": dt, "env_steps_per_s": k * agent.config.rollout_length * per_gpu / dt, "cpu_affinity": affinity,
             "rccl_ranks": rccl[0] if rccl else None, "rccl_rank": rccl[1] if rccl else None,
             "early_fc4_exchanges": int(getattr(agent.dp, "early_exchanges", 0)), "device": torch.cuda.current_device()}
     per_rank = [mine]
@@ -668,7 +721,7 @@ def comm_check(args):
     n = 1_686_693
     grad = torch.randn(n + (-n) % 4, dtype=torch.float32, device=d.Config.DEVICE)
     comm = dd.RcclComm() if (world == 1 or world <= n_dev) else None
-    rec = {"rank": rank, "device": torch.cuda.current_device()}
+    rec = {"rank": rank, "device": torch.cuda.current_device(), "cpu_affinity": pin_this_rank()}
     if comm is not None:
         info = comm.info()
         rec.update(rccl_ranks=info[0], rccl_rank=info[1])
@@ -767,6 +820,7 @@ def main():
     import deeprl_amd as d
     from deeprl_amd.learner import DQNLearnerBench
     d.select_device(local_rank)
+    affinity = gather_affinity(pin_this_rank(), world)
     torch.manual_seed(1234 + rank)
     np.random.seed(rank)
     bench = DQNLearnerBench(ring_capacity=args.ring, batch=B, seed=rank, actor=not args.no_actor,
@@ -856,20 +910,33 @@ def main():
             roof["peak_note"] = "8000 GB/s is the HBM spec, quoted as a yardstick only: FETCH_SIZE counts Infinity-Cache hits"
             mf["longest_kernel"] = roof
             roof = mf
-        # `frac` / `achieved` of the headline kernel: the rocprofv3 duration of the same command's committed summary when there is
-        # one (the kernel alone), else the live event pair; the live pair (kernel + launch boundary + record: conservative) is
-        # always kept as frac_hip_events / achieved_hip_events
+        # `frac` / `achieved` of the headline kernel are THIS RUN's: the kernel replayed alone, 64 dependent launches in one
+        # captured graph between two events, minus the per-launch period of an empty kernel in the same form (the in-graph
+        # launch boundary) = the kernel's own duration, the quantity rocprofv3 reports (ADVICE r5 / VERDICT r5 item 3).  The live
+        # event pair around one eager launch (kernel + boundary + record: conservative) stays as frac_hip_events; the committed
+        # rocprofv3 summary of the same command on a builder box only under its own key.
         roof["frac_hip_events"], roof["achieved_hip_events"] = roof.get("frac"), roof.get("achieved")
         rp = roof.get("rocprofv3")
         if rp and rp.get("frac"):
-            roof["frac"], roof["achieved"] = rp["frac"], rp["achieved"]
-            roof["frac_source"] = "rocprofv3 avg duration of this kernel in %s (builder box); frac_hip_events is this run's live, conservative reading" % rp.get("file")
+            roof["frac_rocprofv3_committed"] = rp["frac"]
+        gr = roof.get("graph_replay")
+        if gr and gr.get("frac"):
+            roof["frac"], roof["achieved"], roof["avg_ms"] = gr["frac"], gr["achieved"], gr["kernel_us"] * 1e-3
+            roof["frac_source"] = ("this run: graph replay of the kernel alone (64 dependent launches between two events) minus the "
+                                   "same replay of an empty kernel; frac_with_boundary / frac_hip_events are the conservative "
+                                   "live readings, frac_rocprofv3_committed the builder-box profile")
         else:
-            roof["frac_source"] = "hip_events of this run (no committed rocprofv3 summary found)"
+            roof["frac_source"] = "hip_events of this run (event pair around one eager launch, launch boundary included)"
+        if roof.get("traffic") and roof.get("algorithmic_bytes_hbm"):
+            roof["traffic_ratio"] = roof["traffic"] / roof["algorithmic_bytes_hbm"]
         # the update chain owns a CU partition while the device actor runs beside it (lever 5):
         # the kernel is timed on that stream, i.e. on this many of the device's CUs
         roof["stream_cus"] = bench.learner.update_cus or torch.cuda.get_device_properties(0).multi_processor_count
         extra = bench.report()
+        try:
+            extra["replay_gather"] = replay_gather_line(bench)
+        except Exception as e:      # an extra line must never take the headline down
+            extra["replay_gather"] = {"error": repr(e)}
         if not args.no_actor:
             extra["host_us_per_step"] = bench.host_profile(100)
         ups = world * args.steps / dt
@@ -888,6 +955,7 @@ def main():
         }
         out.update(extra)
         out["host"] = host      # per step: time in the enqueueing C call, of which blocked on the GPU; whole python loop
+        out["per_rank_cpu_affinity"] = affinity
         if long_run is not None:
             out["short_run"] = True
             out["long_run"] = long_run

@@ -26,6 +26,13 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// conv_fwd_v2_body: image rows requested before the weight operands (see there).  DRA_EXP_IMAGE_FIRST=0 builds the
+// round 2-5 order for A/B runs (tools/README.md: `make exp EXPFLAGS=...`).
+#ifndef DRA_EXP_IMAGE_FIRST
+#define DRA_EXP_IMAGE_FIRST 1
+#endif
+constexpr bool kImageFirst = DRA_EXP_IMAGE_FIRST != 0;
+
 template <int C_, int H_, int OC_, int KH_, int S_>
 struct V2Geom {
   static constexpr int C = C_, H = H_, OC = OC_, KH = KH_, S = S_;
@@ -275,23 +282,28 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
   const int cp0 = (G::CP >= NW) ? wave * KS::CPW : (wave % G::CP);
   const int t0 = (G::CP >= NW) ? 0 : (wave / G::CP) * KS::TW;
   float areg[KS::NJ];
-  {
+  // bias of the 4 output rows this wave finalises: requested with the operands (a load in the epilogue exposes a
+  // second memory latency per workgroup: 0.5-0.7 us of the 1.2-2.0 us epilogue in the phase traces, profiles/r02a_*)
+  constexpr int RPW = 16 / NW;                                 // accumulator registers a wave finalises
+  float bias_r[RPW];
+  // Order of the requests (round 6): a wave's loads return in the order they were issued, and only the IMAGE gates the
+  // barrier in front of the MFMA loop -- MFMA j needs weight register j alone.  Image rows first, weights behind them:
+  // the MFMA loop starts when the image is staged and walks down vmcnt while the rest of its 16 KB of weights per wave
+  // is still arriving (weights first: the barrier waited for all of them).  Same values, same order of operations.
+  auto request_weights = [&]() {
     const float* wbase = wt + ((int64_t)(2 * cp0 + h) * G::KK + t0) * G::OC + oc0 + li;
 #pragma unroll
     for (int j = 0; j < KS::NJ; ++j) {
       const int cpl = j / KS::TW, t = j - cpl * KS::TW;
       areg[j] = wbase[(2 * cpl * G::KK + t) * G::OC];
     }
-  }
-  // bias of the 4 output rows this wave finalises: requested with the operands (a load in the epilogue exposes a
-  // second memory latency per workgroup: 0.5-0.7 us of the 1.2-2.0 us epilogue in the phase traces, profiles/r02a_*)
-  constexpr int RPW = 16 / NW;                                 // accumulator registers a wave finalises
-  float bias_r[RPW];
 #pragma unroll
-  for (int q = 0; q < RPW; ++q) {
-    const int r = wave * RPW + q;
-    bias_r[q] = a.bias[z][oc0 + (r & 3) + 8 * (r >> 2) + 4 * h];
-  }
+    for (int q = 0; q < RPW; ++q) {
+      const int r = wave * RPW + q;
+      bias_r[q] = a.bias[z][oc0 + (r & 3) + 8 * (r >> 2) + 4 * h];
+    }
+  };
+  if (!kImageFirst) request_weights();
   // Staging maps lanes to (row, column) so that no per-element division is needed: LR lanes walk one image
   // row (the surplus lanes of a row idle), 64 / LR rows per pass; row offsets are compile-time immediates and
   // the de-interleaved LDS column is a per-lane constant.  (The flat "element e of the block" mapping this
@@ -360,6 +372,7 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
 #pragma unroll
       for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = src[min(2 * RPARTS * q + rsub, nrows - 1) * WPR];
     }
+    if (kImageFirst) { __builtin_amdgcn_sched_barrier(0); request_weights(); __builtin_amdgcn_sched_barrier(0); }
     if (tid < 256) s_lut[tid] = (float)((double)tid * a.coef);
     __syncthreads();
     if constexpr (FUSE) {
@@ -414,6 +427,7 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
         raw[ci * LPT + q] = src[min(e, ne - 1)];
       }
     }
+    if (kImageFirst) { __builtin_amdgcn_sched_barrier(0); request_weights(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
       const int c = wave + NW * ci;
@@ -445,6 +459,7 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
 #pragma unroll
       for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = src[min(RP * q + rsub, nrows - 1) * G::H];
     }
+    if (kImageFirst) { __builtin_amdgcn_sched_barrier(0); request_weights(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
       const int c = wave + NW * ci;

@@ -171,6 +171,7 @@ struct dra_dqn_learner {
   hipEvent_t actor_last = nullptr;  // GATHER_ON_UPDATE: recorded after the most recent actor launch (a staging-slot event)
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
+  int only_kernel = -1;             // >= 0: run_body issues this kernel group alone (dra_dqn_learner_kernel_replay)
   int* timeout_flag;                // pinned host: set by a workgroup whose bounded device-side wait gave up (late_step's arrival
                                     // slots, the actor's in-launch hand-over): every later step / update returns DRA_ETIMEDOUT
   // DRA_VAR_IDX_PREFETCH (ring-direct pipeline): step-tagged copies of the minibatch indices -- pinned (written by the host
@@ -993,6 +994,7 @@ head_wgrad_kernel(const float* __restrict__ dq, const float* __restrict__ h4, in
 
 #define STEP(kid, expr)                                                        \
   do {                                                                         \
+    if (l->only_kernel >= 0 && l->only_kernel != (kid)) break;                 \
     if (l->profiling) DRA_HIP(hipEventRecord(l->ev[kid], st));                 \
     int _rc = (expr);                                                          \
     if (_rc != DRA_OK) return _rc;                                             \
@@ -1207,7 +1209,9 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     rs.out_action = l->action_[l->gb]; rs.out_reward = l->reward_[l->gb]; rs.out_mask = l->mask_[l->gb];
     if (l->variant & DRA_VAR_IDX_PREFETCH) rs.seq = l->rd_seq_dev;
   }
-  if (c.head_kind != DRA_HEAD_VANILLA) {
+  if (l->only_kernel >= 0 && l->only_kernel != K_HEAD) {
+    // (single-kernel replay of another group: no head launch)
+  } else if (c.head_kind != DRA_HEAD_VANILLA) {
     int rc = run_dist_head(l, st, per, beta, rs);
     if (rc) return rc;
   } else {
@@ -1269,8 +1273,9 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       // conv1's launch]; conv1's own slabs are folded by the first workgroups of the optimizer launch
       dra_fold_seg segs[3];
       conv_fold_segs(l, segs);
-      int nfc = 0, n3 = 0, n2 = 0;
       const int nfc_expect = dra_fc_bwd_fused_sq_partials(B, NO, 3136), n3_expect = (int)((l->lstride[2] / 4 + 63) / 64), n2_expect = (int)((l->lstride[1] / 4 + 63) / 64);
+      // (single-kernel replay: the skipped launches leave their partial counts at the expected values)
+      int nfc = l->only_kernel >= 0 ? nfc_expect : 0, n3 = l->only_kernel >= 0 ? n3_expect : 0, n2 = l->only_kernel >= 0 ? n2_expect : 0;
       STEP(K_FC4_BX, dra_fc_bwd_fused_sq(l->dq, l->h4, l->dh4, l->y3[0], P + o[P_W4], G + o[P_WH], G + o[P_BH], G + o[P_W4],
                                          G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, l->partials, &nfc,
                                          c.head_kind != DRA_HEAD_VANILLA ? l->action_[l->gb] : nullptr, c.n_atoms, s));
@@ -1628,6 +1633,62 @@ DRA_API int dra_dqn_learner_profile(dra_dqn_learner* l, float* out_ms, int n_out
     DRA_HIP(hipEventElapsedTime(&ms, l->ev[0], l->ev[1]));
     out_ms[K_COUNT] = ms;
   }
+  return DRA_OK;
+}
+
+__global__ void __launch_bounds__(256) empty_probe_kernel(const int* p) { if (p == reinterpret_cast<const int*>(1)) __builtin_trap(); }
+
+// Measurement aid: kernel group `kernel` of the update ALONE, `reps` dependent launches captured into one graph and replayed
+// between two events on `stream` -- out_us[0] = microseconds per launch (kernel + one in-graph dependent-launch boundary);
+// out_us[1] = the same for an EMPTY kernel (the boundary alone); the kernel's own duration is their difference, which is what
+// rocprofv3's per-kernel duration measures.  The kernel runs on the workspaces the last update left (same shapes, same
+// grids as the timed graphs; results are overwritten by the next update).  Groups that change state a replay must not change
+// (the optimizer) and groups the variant does not launch are refused.  Synchronises.
+DRA_API int dra_dqn_learner_kernel_replay(dra_dqn_learner* l, int kernel, int reps, float* out_us, void* stream) {
+  if (!l || !out_us || reps < 1 || reps > 4096) return DRA_EINVAL;
+  if (kernel <= K_GATHER || kernel >= K_NORM) return DRA_EINVAL;
+  if (!(l->variant & (DRA_VAR_FUSED_BWD | DRA_VAR_ONESHOT_WGRAD)) || !l->late) return DRA_EINVAL;   // (the default chain's groups)
+  if (kernel == K_HEAD_BW || kernel == K_FC4_BW || kernel == K_CONV3_BW || kernel == K_CONV2_BW) return DRA_EINVAL;  // ride in *_BX
+  hipStream_t st = dra_stream(stream);
+  DRA_HIP(hipStreamSynchronize(st));
+  float us[2] = {0.f, 0.f};
+  for (int pass = 0; pass < 2; ++pass) {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    const bool rd = l->variant & DRA_VAR_RING_DIRECT;
+    l->gb = 0;
+    l->rd_slot = rd ? 0 : -1;
+    l->only_kernel = kernel;
+    hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    int rc = b == hipSuccess ? DRA_OK : (int)b;
+    for (int r = 0; r < reps && rc == DRA_OK && b == hipSuccess; ++r) {
+      if (pass == 0) rc = run_body(l, st, 0, 0.f, 0);
+      else hipLaunchKernelGGL(empty_probe_kernel, dim3(224), dim3(256), 0, st, (const int*)nullptr);
+    }
+    l->only_kernel = -1;
+    l->rd_slot = -1;
+    hipError_t e = b == hipSuccess ? hipStreamEndCapture(st, &graph) : b;
+    if (rc != DRA_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    DRA_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    DRA_HIP(hipGraphLaunch(exec, st));                   // warm: code objects / TLB / clocks
+    DRA_HIP(hipStreamSynchronize(st));
+    float best = 0.f;
+    for (int t = 0; t < 3; ++t) {                        // the fastest of three replays (a host hiccup only ever adds time)
+      DRA_HIP(hipEventRecord(l->ev[0], st));
+      DRA_HIP(hipGraphLaunch(exec, st));
+      DRA_HIP(hipEventRecord(l->ev[1], st));
+      DRA_HIP(hipEventSynchronize(l->ev[1]));
+      float ms = 0.f;
+      DRA_HIP(hipEventElapsedTime(&ms, l->ev[0], l->ev[1]));
+      if (t == 0 || ms < best) best = ms;
+    }
+    us[pass] = best * 1e3f / (float)reps;
+    (void)hipGraphExecDestroy(exec);
+  }
+  out_us[0] = us[0];
+  out_us[1] = us[1];
   return DRA_OK;
 }
 

@@ -37,6 +37,102 @@ def world():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+# ---- host-side placement of the ranks of one node -------------------------------------------------------------------------
+# Every rank is a Python driver that enqueues ~65-100 us of host work per agent step (bench.py `host`); eight of them wandering
+# over the cores of both sockets is the contention SURVEY.md 8(e) names as the risk for ">= 6x at 8 GPUs" (the reference runs one
+# docker job per GPU and leaves placement to the kernel, docker_batch.sh:2-8).  Each rank pins itself to cores of the NUMA node
+# its GPU hangs off, disjoint from the other ranks of the node.
+
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-", 1)
+            cpus.extend(range(int(lo), int(hi) + 1))
+        else:
+            cpus.append(int(part))
+    return sorted(set(cpus))
+
+
+def plan_affinity(allowed, node_cpus_of_rank, local_rank):
+    """Pure placement rule.  allowed: cpus this process may run on; node_cpus_of_rank[r]: cpus local to the GPU of local rank r
+    (None = unknown).  Ranks whose GPUs share a node split that node's allowed cpus into contiguous, disjoint shares in rank
+    order; a rank with no topology information gets the share of an even split of `allowed`; with fewer cpus than ranks the
+    ranks share round-robin.  Returns the sorted cpu list of `local_rank` (never empty)."""
+    allowed = sorted(set(int(c) for c in allowed))
+    if not allowed:
+        raise ValueError("plan_affinity: no cpu allowed")
+    n = len(node_cpus_of_rank)
+    keys = []
+    for r in range(n):
+        local = node_cpus_of_rank[r]
+        pool = sorted(set(local) & set(allowed)) if local else []
+        keys.append(tuple(pool) if pool else None)
+    mine = keys[local_rank]
+    pool = list(mine) if mine is not None else allowed
+    group = [r for r in range(n) if keys[r] == mine]          # the ranks that draw from the same pool, in rank order
+    pos, g = group.index(local_rank), len(group)
+    if len(pool) < g:
+        return [pool[pos % len(pool)]]
+    lo, hi = (pos * len(pool)) // g, ((pos + 1) * len(pool)) // g
+    return pool[lo:hi]
+
+
+def gpu_local_cpus(device_index, sysfs="/sys"):
+    """cpus of the NUMA node GPU `device_index` is attached to, from the PCI device's local_cpulist; None when unknown."""
+    import os
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        dom, bus, dev = int(getattr(pr, "pci_domain_id", 0)), int(pr.pci_bus_id), int(pr.pci_device_id)
+    except Exception:
+        return None
+    for fn in (0, 1):
+        path = os.path.join(sysfs, "bus", "pci", "devices", "%04x:%02x:%02x.%d" % (dom, bus, dev, fn), "local_cpulist")
+        try:
+            cpus = _parse_cpulist(open(path).read())
+            if cpus:
+                return cpus
+        except OSError:
+            continue
+    return None
+
+
+def pin_rank(local_rank, local_world, devices=None):
+    """Pins the calling process (os.sched_setaffinity) per plan_affinity; devices[r] = GPU index of local rank r (default
+    r mod the visible GPUs).  Returns the mapping for the bench line; DRA_NO_PIN=1 or any failure leaves the process
+    where it is and says so."""
+    import os
+    info = {"local_rank": int(local_rank), "local_world": int(local_world), "pinned": False}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if devices is None:
+            devices = [(r % n_dev) if n_dev else None for r in range(local_world)]
+        node = [gpu_local_cpus(dv) if dv is not None else None for dv in devices]
+        cpus = plan_affinity(allowed, node, local_rank)
+        info.update(device=devices[local_rank], gpu_node_known=node[local_rank] is not None, cpus=cpus, allowed=len(allowed))
+        if os.environ.get("DRA_NO_PIN") == "1" or local_world <= 1:
+            info["note"] = "not pinned (single rank or DRA_NO_PIN=1)"
+            return info
+        # every thread the process already has (the HIP runtime's helpers exist as soon as a device was queried); threads
+        # created later inherit the caller's mask
+        tids = [int(t) for t in os.listdir("/proc/self/task")] if os.path.isdir("/proc/self/task") else [0]
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, cpus)
+            except OSError:
+                pass
+        os.sched_setaffinity(0, cpus)
+        info["pinned"] = True
+        info["threads_pinned"] = len(tids)
+    except Exception as e:      # placement is an optimisation: never fail a run over it
+        info["error"] = repr(e)
+    return info
+
+
 def rank():
     return dist.get_rank() if dist.is_initialized() else 0
 

@@ -347,6 +347,20 @@ class DQNLearner:
         res["_event_bracket"] = float(out[n])      # two event records with nothing in between (the bracket's own cost)
         return res
 
+    def kernel_replay(self, name, reps=64):
+        """Kernel group `name` of the update alone: `reps` dependent launches in one captured graph between two events.
+        Returns (us per launch incl. one in-graph boundary, us per launch of an EMPTY kernel in the same form); the
+        difference is the kernel's own duration (what rocprofv3 reports), measured live."""
+        n = lib.dra_dqn_learner_kernel_count.raw()
+        for k in range(n):
+            buf = ctypes.create_string_buffer(32)
+            lib.dra_dqn_learner_kernel_name(k, buf, 32)
+            if buf.value.decode() == name:
+                out = (ctypes.c_float * 2)()
+                lib.dra_dqn_learner_kernel_replay(self.h, k, int(reps), out, self._sp())
+                return float(out[0]), float(out[1])
+        raise DraError("kernel_replay: no kernel group named %r" % (name,))
+
     def synchronize(self):
         self.stream.synchronize()
         self.actor_stream.synchronize()
@@ -938,12 +952,20 @@ class DQNLearnerBench:
             step_bytes += 4 * n1 * (32 * 4 * 8 * 8 + 32)
         bytes_ = {"gather": b * (5 * 7056) + 2 * b * 4 * 7056, "rmsprop_step": step_bytes}
 
+        # algorithmic HBM bytes of the MFMA launches (every distinct operand read once, every result written once, fp32):
+        # what the PMC traffic of the same launch is compared with (`traffic_ratio`)
+        w1, w2, w3 = 32 * 4 * 64 + 32, 64 * 32 * 16 + 64, 64 * 64 * 9 + 64
+        y1, y2, y3 = b * 32 * 400, b * 64 * 81, b * 64 * 49
+        alg_hbm = {"conv1_fwd": 2 * b * 4 * 7056 + 4 * (2 * w1 + 2 * y1), "conv2_fwd": 4 * (2 * y1 + 2 * w2 + 2 * y2),
+                   "conv3_fwd": 4 * (2 * y2 + 2 * w3 + 2 * y3), "conv3_bwd_x": 4 * (y3 + y2 + w3 + y2 + w3),
+                   "conv2_bwd_x": 4 * (y2 + y1 + w2 + y1 + w2), "conv1_bwd_w": b * 4 * 7056 + 4 * (y1 + w1)}
+
         def entry(k):
             if k in flops:
                 ach = flops[k] / (ms[k] * 1e-3) / 1e12
                 return {"kernel": k, "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s",
                         "frac": ach / 157.3, "traffic": None, "avg_ms": ms[k], "algorithmic_flops": flops[k],
-                        "event_pair_empty_ms": self.event_bracket_ms}
+                        "algorithmic_bytes_hbm": alg_hbm.get(k), "event_pair_empty_ms": self.event_bracket_ms}
             byt = bytes_.get(k, 0)
             ach = byt / (ms[k] * 1e-3) / 1e9
             return {"kernel": k, "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
@@ -958,6 +980,18 @@ class DQNLearnerBench:
         mfma = "conv2_bwd_x" if "conv2_bwd_x" in ms and "conv2_bwd_x" in flops else max((k for k in ms if k in flops), key=ms.get, default=None)
         self.roofline_mfma = entry(mfma) if mfma is not None and mfma != dom else None
         if self.roofline_mfma is not None:
+            # the same kernel replayed ALONE, 64 dependent launches in one captured graph between two events (no event pair per
+            # launch): per-launch period, the period of an empty kernel in the same form (the in-graph launch boundary), and
+            # their difference = the kernel's own duration, live in this run
+            try:
+                per_us, empty_us = L.kernel_replay(mfma, 64)
+                own_us = max(per_us - empty_us, 1e-3)
+                self.roofline_mfma["graph_replay"] = {
+                    "launches": 64, "us_per_launch": per_us, "empty_kernel_us_per_launch": empty_us, "kernel_us": own_us,
+                    "achieved": flops[mfma] / (own_us * 1e-6) / 1e12, "frac": flops[mfma] / (own_us * 1e-6) / 1e12 / 157.3,
+                    "frac_with_boundary": flops[mfma] / (per_us * 1e-6) / 1e12 / 157.3}
+            except DraError as e:
+                self.roofline_mfma["graph_replay"] = {"error": str(e)}
             self.roofline_mfma["mfma_kernels"] = [
                 {"kernel": k, "avg_ms": ms[k], "algorithmic_flops": flops[k], "frac": flops[k] / (ms[k] * 1e-3) / 1e12 / 157.3}
                 for k in sorted((k for k in ms if k in flops), key=ms.get, reverse=True)]

@@ -485,6 +485,11 @@ int dra_dqn_learner_wait_loss(dra_dqn_learner* learner, void* stream);
  * (dra_dqn_learner_kernel_count groups, names from _kernel_name).  With n_out > count, out_ms[count] = the same event pair
  * with NOTHING in between (the bracket's own cost, to be subtracted).  Synchronises. */
 int dra_dqn_learner_profile(dra_dqn_learner* learner, float* out_ms, int n_out, void* stream);
+/* measurement aid: kernel group `kernel` (index as in _kernel_name) of the update ALONE, `reps` dependent launches in ONE
+ * captured graph between two events: out_us[0] = microseconds per launch (kernel + one in-graph launch boundary), out_us[1] =
+ * the same for an empty kernel (the boundary alone).  Their difference is the kernel's own duration -- the quantity rocprofv3
+ * reports -- measured live.  Runs on the workspaces of the last update; refuses the optimizer group.  Synchronises. */
+int dra_dqn_learner_kernel_replay(dra_dqn_learner* learner, int kernel, int reps, float* out_us, void* stream);
 /* the minibatch the most recently issued update consumed (device pointers into the learner's buffers: u8 states /
  * next states [B][4][84][84], int64 actions [B], f32 rewards / masks [B]); for checkers, after a synchronise */
 int dra_dqn_learner_last_minibatch(dra_dqn_learner* learner, void** state, void** next_state, void** action, void** reward,
