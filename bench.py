@@ -181,11 +181,13 @@ def cpu_baseline(seconds=15.0, ring=20_000, worker=False):
     # read from the committed file, so that the "port" number can be converted
     pvr = None
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_port_vs_reference.json")))
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_port_vs_reference.json")))[-1]
+        rec = json.load(open(newest))
         pvr = {"port_over_reference": rec["port_over_reference"], "reference_updates_per_s": rec["reference_updates_per_s"],
                "port_updates_per_s": rec["port_updates_per_s"], "cores_on_that_box": rec["cores_on_this_box"],
-               "source": "committed file profiles/r04_cpu_port_vs_reference.json (the reference's own modules under tests/ref_shim.py "
-                         "vs this loop, same inputs, 1 thread, authoring container)"}
+               "source": "committed file profiles/%s (the reference's own modules under tests/ref_shim.py "
+                         "vs this loop, same inputs, 1 thread, authoring container)" % os.path.basename(newest)}
     except Exception:
         pass
     return {"value": n / dt, "unit": "gradient-updates/sec", "cores": 1, "kind": "port",

@@ -22,6 +22,7 @@ Differences that are the point of the rewrite (results unchanged):
     `config.fused_learner = False` keeps the generic autograd path.
 """
 import pickle
+import os
 
 import contextlib
 import gc
@@ -1481,11 +1482,26 @@ class PPOAgent(BaseAgent):
         self.network.fuse_fc4_head = bool(getattr(config, 'fuse_fc4_head', True))
         self.network.rollout_fc4_slices = bool(getattr(config, 'rollout_fc4_slices', True))
         # action noise of the device rollout: the rank-invariant stream when one is configured, else a seed of its own
-        self._noise_seed = self.dp.noise_seed if self.dp.invariant_sampling else int(getattr(config, 'dp_noise_seed', None) or 0)
+        self._noise_seed = self.dp.noise_seed
 
     def close(self):
         close_obj(self.task)
         self.dp.close()
+
+    def save(self, filename):
+        """The reference's two files (BaseAgent.py:24-27) plus `<filename>.sampler`: seed and position of the counter-hash action
+        noise of the device rollout, without which a restored agent would replay the noise of its first rollouts."""
+        BaseAgent.save(self, filename)
+        if self.dp.is_main:
+            with open(filename + '.sampler', 'wb') as f:
+                pickle.dump(self.dp.sampler_state(), f)
+
+    def load(self, filename):
+        BaseAgent.load(self, filename)
+        if os.path.isfile(filename + '.sampler'):      # (checkpoints of the reference itself have no such file)
+            with open(filename + '.sampler', 'rb') as f:
+                self.dp.load_sampler_state(pickle.load(f), Config.DEVICE)
+            self._noise_seed = self.dp.noise_seed
 
     def _step_device(self):
         """step() over device-resident environments (see A2CAgent._step_device): the rollout -- T x [observations, image

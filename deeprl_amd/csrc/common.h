@@ -27,6 +27,23 @@
 
 static inline hipStream_t dra_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: remember, per device ordinal, the largest
+// size already granted (a process that launches on a second GPU after a first -- select_device -- must set it there too;
+// ADVICE r5).  One object per kernel instantiation (a function-local static at the launch site).
+struct DraLdsAttr {
+  size_t granted[32] = {};
+};
+static inline int dra_grant_lds(DraLdsAttr& a, const void* kernel, size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+  if (bytes > a.granted[dev]) {
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    a.granted[dev] = bytes;
+  }
+  return DRA_OK;
+}
+
 constexpr int kWave = 64;  // CDNA4 wavefront
 
 // 64-lane butterfly reductions (wave64: offsets up to 32).

@@ -99,12 +99,9 @@ static int launch_multi_tp(const R1& r1, int n1, const R2& r2, int n2, const R3&
   constexpr size_t bytes = (size_t)fl * sizeof(float);
   static_assert(bytes <= 160 * 1024, "LDS per workgroup");
   if (n1 < 0 || n2 < 0 || n3 < 0 || n1 + n2 + n3 < 1) return DRA_EINVAL;
-  static bool attr_set = false;
-  if (bytes > 64 * 1024 && !attr_set) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&multi_kernel_tp<R1, R2, R3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    attr_set = true;
-  }
+  static DraLdsAttr lds_attr;     // one per instantiation, per device
+  if (bytes > 64 * 1024)
+    if (int rc = dra_grant_lds(lds_attr, reinterpret_cast<const void*>(&multi_kernel_tp<R1, R2, R3>), bytes)) return rc;
   hipLaunchKernelGGL((multi_kernel_tp<R1, R2, R3>), dim3(n1 + n2 + n3), dim3(256), bytes, st, r1, r2, r3, n1, n2);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
@@ -117,12 +114,9 @@ static int launch_multi(const R1& r1, int n1, const R2& r2, int n2, const R3& r3
   constexpr size_t bytes = (size_t)fl * sizeof(float);
   static_assert(bytes <= 160 * 1024, "LDS per workgroup");
   if (n1 < 0 || n2 < 0 || n3 < 0 || n1 + n2 + n3 < 1) return DRA_EINVAL;
-  static bool attr_set = false;  // one flag per instantiation
-  if (bytes > 64 * 1024 && !attr_set) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&multi_kernel<R1, R2, R3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    attr_set = true;
-  }
+  static DraLdsAttr lds_attr;     // one per instantiation, per device
+  if (bytes > 64 * 1024)
+    if (int rc = dra_grant_lds(lds_attr, reinterpret_cast<const void*>(&multi_kernel<R1, R2, R3>), bytes)) return rc;
   hipLaunchKernelGGL((multi_kernel<R1, R2, R3>), dim3(n1 + n2 + n3), dim3(256), bytes, st, r1, r2, r3, n1, n2);
   DRA_LAUNCH_CHECK();
   return DRA_OK;

@@ -1317,12 +1317,8 @@ template <int H, int MODE, int SC>
 static int launch_update(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic, const float* packed,
                          int n, int epochs, float* out3, int64_t* out_counts, float* dbg, void* stream) {
   const size_t bytes = update_lds_floats(H, cfg->state_dim) * sizeof(float);
-  static size_t attr_bytes = 0;
-  if (bytes > attr_bytes) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_update_kernel<H, MODE, SC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    attr_bytes = bytes;
-  }
+  static DraLdsAttr lds_attr;
+  if (int rc = dra_grant_lds(lds_attr, reinterpret_cast<const void*>(&ppo_mlp_update_kernel<H, MODE, SC>), bytes)) return rc;
   hipLaunchKernelGGL((ppo_mlp_update_kernel<H, MODE, SC>), dim3(2), dim3(256), bytes, dra_stream(stream), *cfg, *actor, *critic, packed,
                      n, epochs, out3, out_counts, dbg);
   DRA_LAUNCH_CHECK();
@@ -1363,12 +1359,8 @@ template <int H, bool PROF>
 static int launch_rollout(const dra_ppo_mlp_cfg* cfg, const dra_ppo_mlp_net* actor, const dra_ppo_mlp_net* critic,
                           const dra_ppo_mlp_rollout_io* io, int64_t* cycles, void* stream) {
   const size_t bytes = rollout_lds_floats(H) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    DRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_mlp_rollout_kernel<H, PROF>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    attr_set = true;
-  }
+  static DraLdsAttr lds_attr;
+  if (int rc = dra_grant_lds(lds_attr, reinterpret_cast<const void*>(&ppo_mlp_rollout_kernel<H, PROF>), bytes)) return rc;
   hipLaunchKernelGGL((ppo_mlp_rollout_kernel<H, PROF>), dim3(1), dim3(512), bytes, dra_stream(stream), *cfg, *actor, *io,
                      reinterpret_cast<long long*>(cycles));
   DRA_LAUNCH_CHECK();

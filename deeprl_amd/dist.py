@@ -270,7 +270,12 @@ class DataParallel:
                 noise_seed = int(seed.item())
             if _distinct_gpus():
                 self.comm = RcclComm()
-        self.noise_seed = int(noise_seed or 0)
+        if noise_seed is None:
+            # no configured seed: follow the run's torch seed (random_seed() / torch.manual_seed, misc.py:43-46), as the
+            # reference's dist.sample() does -- read without consuming any generator, so every other stream stays where the
+            # reference has it.  (Round 5 used 0 here: every run, whatever its seed, explored with the same noise.)
+            noise_seed = int(torch.initial_seed()) & 0x3fffffff
+        self.noise_seed = int(noise_seed)
         if self.invariant_sampling:         # permutations and action noise come from streams every rank can reproduce
             self.rs = np.random.RandomState(self.noise_seed + 12345)
         config.env_shard = (self.lo, self.hi)
@@ -280,6 +285,19 @@ class DataParallel:
         self._comm_stream = None
         self._early, self._weight, self._hooks = None, 1.0, []
         self.early_exchanges = 0      # tail segments that went out before sum_grads() was called
+
+    def sampler_state(self):
+        """(noise seed, sampler calls so far): the position of the counter-hash noise streams, for checkpoints."""
+        step = 0 if self.step_dev is None else int(self.step_dev.item())
+        return {"noise_seed": int(self.noise_seed), "step": step}
+
+    def load_sampler_state(self, state, device=None):
+        self.noise_seed = int(state["noise_seed"])
+        if self.invariant_sampling:
+            self.rs = np.random.RandomState(self.noise_seed + 12345)
+        if self.step_dev is None:
+            self.step_dev = torch.zeros(1, dtype=torch.int64, device=device if device is not None else "cpu")
+        self.step_dev.fill_(int(state["step"]))
 
     @property
     def is_main(self):

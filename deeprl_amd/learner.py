@@ -611,14 +611,15 @@ class DeviceActorPipeline:
             if self._dd is None:
                 self._dd = DeviceDraw(self.rp, self.L)
             prev = tuple(st["chain_prev"])
-            if len(prev) == 3:          # written by the retired chain mode 1 (no importance exponent): take the schedule's current value
-                prev = prev + (None,)
+            if len(prev) == 3:
+                # written by the retired chain mode 1: no importance exponent in the record, and guessing one (the schedule's
+                # start value, say) would silently change the first resumed update's weights once beta has annealed
+                raise DraError("the checkpoint's pending prioritized draw (chain_prev) has no importance exponent: it was written "
+                               "by a round-3 build; save it again with this version (load it there, step once, save_full)")
             if len(prev) != 4:
                 raise DraError("unrecognised chain_prev record of %d fields in the checkpoint" % len(prev))
             idx, p, total, beta = prev
-            if beta is None:
-                beta = float(self.rp.config_beta()) if hasattr(self.rp, "config_beta") else 0.4
-            self._dd.start(idx, p, total, beta)
+            self._dd.start(idx, p, total, float(beta))
 
     def _block(self):
         """Host side of one agent step's transitions -> (StepParams head filled in learner.params, infos)."""

@@ -65,8 +65,19 @@ class MeanStdNormalizer(BaseNormalizer):
             self.rms = RunningMeanStd(shape=(1,) + x.shape[1:])
         if not self.read_only:
             self.rms.update(x)
+            self._push_to_device()                 # (statistics attached to the device: the device copy is the one that lives on)
         z = (x - self.rms.mean) / np.sqrt(self.rms.var + self.epsilon)
         return np.clip(z, -self.clip, self.clip)
+
+    def _push_to_device(self):
+        """A host-side update while the statistics live on the device: write mean / var / count back, so that the next
+        device rollout (or sync_from_device) continues from them instead of discarding the update."""
+        dev = getattr(self, '_dev', None)
+        if dev is not None:
+            d = self._dim
+            h = np.concatenate([np.asarray(self.rms.mean, dtype=np.float64).reshape(-1),
+                                np.asarray(self.rms.var, dtype=np.float64).reshape(-1), [float(self.rms.count)]])
+            dev[:2 * d + 1].copy_(torch.from_numpy(h))
 
     def attach_device(self, rms_dev, dim):
         """The statistics moved to the device (device_env.DeviceContinuousVec: f64 [mean (dim) | var (dim) | count]); the host

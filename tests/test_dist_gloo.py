@@ -235,3 +235,29 @@ def test_pin_rank_is_a_noop_for_one_rank():
     before = sorted(os.sched_getaffinity(0))
     info = pin_rank(0, 1)
     assert info["pinned"] is False and sorted(os.sched_getaffinity(0)) == before
+
+
+def test_default_noise_seed_follows_the_torch_seed_and_round_trips():
+    """without config.dp_noise_seed the counter-hash action noise is seeded from the run's torch seed (as the
+    reference's dist.sample() is), not from a constant; seed + position survive a checkpoint (DataParallel.sampler_state)."""
+    from deeprl_amd import dist as ddist
+
+    class Cfg:
+        num_workers = 4
+    state = np.random.get_state()[1].copy()
+    torch.manual_seed(123)
+    a = ddist.DataParallel(Cfg())
+    torch.manual_seed(124)
+    b = ddist.DataParallel(Cfg())
+    assert a.noise_seed == 123 and b.noise_seed == 124                 # small seeds pass through the mask unchanged
+    assert np.array_equal(np.random.get_state()[1], state)            # no numpy draw was consumed (reference stream position)
+
+    class Fixed:
+        num_workers = 4
+        dp_noise_seed = 0
+    assert ddist.DataParallel(Fixed()).noise_seed == 0                 # an explicit 0 stays 0
+    a.step_dev = torch.tensor([17], dtype=torch.int64)
+    st = a.sampler_state()
+    assert st == {"noise_seed": 123, "step": 17}
+    b.load_sampler_state(st)
+    assert b.noise_seed == 123 and int(b.step_dev.item()) == 17

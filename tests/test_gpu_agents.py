@@ -971,6 +971,14 @@ def test_rollout_fc4_through_k_slices_samples_the_same_policy(dra, monkeypatch):
     assert np.array_equal(outs[0][0], outs[1][0])
     np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-5)
+    # How likely is a flipped action?  The inverse-CDF draw picks another action only when its uniform lies between the two
+    # forms' CDF edges.  A probability moves by |dp| <= p * |d log p| <= the measured log-probability difference, an edge of the
+    # A-action CDF by at most (A - 1) of those, and there are A - 1 edges: P(flip per draw) <= 2 (A - 1)^2 max|d log pi|.
+    # state it and hold it to a bar -- below 1e-4 per draw (measured ~1e-6: a flip every ~10^4 rollouts of 80 draws).
+    n_act = 4
+    dlog = float(np.abs(outs[0][1] - outs[1][1]).max())
+    flip_bound = 2.0 * (n_act - 1) ** 2 * dlog
+    assert flip_bound < 1e-4, (dlog, flip_bound)
     for k in outs[0][3]:
         scale = max(1e-3, float(np.abs(outs[1][3][k]).max()))
         assert float(np.abs(outs[0][3][k] - outs[1][3][k]).max()) <= 1e-4 * scale, k

@@ -7,6 +7,7 @@ import ctypes
 import numpy as np
 import pytest
 import torch
+from parity_log import record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -270,15 +271,26 @@ def test_update_kernel_matches_oracle(dra, s_dim, a_dim, hidden, mb, n, epochs, 
         w = want.detach().numpy()
         assert np.max(np.abs(got - w)) <= 1e-5 * max(np.abs(w).max(), 1e-2), ("critic", name, np.max(np.abs(got - w)))
     # Adam moments (exp_avg / exp_avg_sq) of every parameter
+    worst_m = worst_v = 0.0
     for fused, ps, opt, params in ((k['fa'], k['psa'], aopt, a0), (k['fc'], k['psc'], copt, c0)):
         for p_dev, p_cpu in zip(ps, params.values()):
             st = opt.state[p_cpu]
             m = fused.flat.view(fused.state1, p_dev).cpu().numpy()
             v = fused.flat.view(fused.state2, p_dev).cpu().numpy()
             wm, wv = st['exp_avg'].numpy(), st['exp_avg_sq'].numpy()
-            assert np.max(np.abs(m - wm)) <= 2e-5 * max(np.abs(wm).max(), 1e-6)
-            assert np.max(np.abs(v - wv)) <= 2e-5 * max(np.abs(wv).max(), 1e-10)
-    np.testing.assert_allclose(k['out3'], np.asarray(out3, dtype=np.float32), rtol=2e-5, atol=2e-6)
+            worst_m = max(worst_m, float(np.max(np.abs(m - wm)) / max(np.abs(wm).max(), 1e-6)))
+            worst_v = max(worst_v, float(np.max(np.abs(v - wv)) / max(np.abs(wv).max(), 1e-10)))
+    want3 = np.asarray(out3, dtype=np.float64)
+    worst_s = float(np.max(np.abs(np.asarray(k['out3'], dtype=np.float64) - want3) / np.maximum(np.abs(want3), 0.1)))
+    # the measured maxima are written next to the other parity errors (profiles/rNN_parity_errors.json)
+    record_parity("ppo_mlp update kernel vs oracle [%d,%d,%d,%d,%d]" % (s_dim, a_dim, hidden, mb, n), adam_exp_avg=worst_m,
+                  adam_exp_avg_sq=worst_v, loss_scalars=worst_s)
+    # measured on MI355X (round 6, profiles/r06*_parity_errors.json): exp_avg 0.7-2.3e-6, loss scalars 0.8-2.4e-6,
+    # exp_avg_sq 1.3-1.6e-5 -- the second moment is QUADRATIC in the gradient, so a gradient inside north_star's 1e-5
+    # (test_update_kernel_first_minibatch_matches_autograd holds every parameter gradient to that) is worth 2e-5 there
+    assert worst_m <= 1e-5, worst_m
+    assert worst_v <= 2e-5, worst_v
+    assert worst_s <= 1e-5, (worst_s, k['out3'], out3)
 
 
 # ------------------------------------------------------------------------------------------ the agent

@@ -10,7 +10,7 @@ no /root/reference, so bench.py's `cpu_baseline.kind` is "port" there).  VERDICT
             reduce_loss on a stand-in with the attributes those methods read, torch.optim.RMSprop)
     port  = bench.py's cpu_baseline() loop (oracle/: numpy ring, torch-CPU fp32 restatement)
 
-Same seeded inputs, same initial weights; interleaved repetitions.  Writes profiles/r04_cpu_port_vs_reference.json:
+Same seeded inputs, same initial weights; interleaved repetitions.  Writes profiles/<ROUND_TAG, default r06>_cpu_port_vs_reference.json:
 updates/s of both and the ratio port / reference that bench.py quotes in `cpu_baseline.sample`.
 
     python tools/cpu_port_vs_reference.py [seconds_per_repetition] [repetitions]
@@ -140,7 +140,7 @@ def main():
            "first_losses": {"reference": ref_losses, "port": port_losses,
                             "note": "same seeded minibatches and initial weights: the two loops are the same computation"},
            "torch": torch.__version__}
-    path = os.path.join(ROOT, "profiles", "r04_cpu_port_vs_reference.json")
+    path = os.path.join(ROOT, "profiles", "%s_cpu_port_vs_reference.json" % os.environ.get("ROUND_TAG", "r06"))
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out))
 
