@@ -86,10 +86,6 @@ struct ActorFuse {
   int mode;                    // 0 = plain conv1, 1 = commit pending (env step 0), 2 = head(e-1) + env step -> e
   int e, n_actions, done_period;
   const float* h4;             // [512] fc4 output of env step e-1
-  // round 6 (dra_actor_c3fc4_fly): fc4's pre-activation arrives as 16 K-slice partial sums [16][512]; the head folds them,
-  // h4[j] = relu(b4[j] + fixed tree over the slices) (actor_fold_h4 below).  null = h4 above is finished
-  const float* h4_parts;
-  const float* b4;
   const float* wh;             // [A][512]
   const float* bh;             // [A]
   const uint8_t* aring;        // device parameter ring
@@ -104,17 +100,6 @@ struct ActorFuse {
   const float* atoms;
   const float* pre;
 };
-
-// fc4 output j of the actor from its 16 K-slice partial sums (dra_actor_c3fc4_fly): ONE summation order for every consumer
-__device__ __forceinline__ float actor_fold_h4(const float* __restrict__ parts, const float* __restrict__ b4, int j) {
-  float t[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) t[k] = parts[k * 512 + j];
-  const float s = (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
-                  (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
-  const float v = s + b4[j];
-  return v > 0.f ? v : 0.f;
-}
 
 // conv_v2.hip (library-internal)
 int dra_conv1_fwd_actor_fused(const void* frames, const int64_t* slot_field_dev, const int32_t* stack_age_field_dev, const unsigned* seq_dev, int n_entries,
@@ -168,6 +153,5 @@ int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, flo
 
 // ... and its default form: conv1 (fused head / environment step) and conv2 keep their launches, conv3 + fc4 share one
 // (flags[2] = conv3's arrival counter)
-int dra_actor_c3fc4_fly(const float* y2_planes, const float* w3, const float* b3, const float* w4, float* parts, void* stream);
 int dra_actor_c3fc4(const float* y2_planes, const float* w3, const float* b3, const float* w4, const float* b4, float* y3_planes,
                     float* h4, unsigned* flags, int* timeout_flag, void* stream);

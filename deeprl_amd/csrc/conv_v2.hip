@@ -154,19 +154,6 @@ __device__ __forceinline__ void fused_head_q(const ActorFuse& f, int wave, int l
     }
     return;
   }
-  if (f.h4_parts) {   // fc4 arrives as 16 K-slice partial sums: fold once per workgroup, then the same per-lane products
-    __shared__ float s_h4[512];
-    for (int j = threadIdx.x; j < 512; j += 64 * NW) s_h4[j] = actor_fold_h4(f.h4_parts, f.b4, j);
-    __syncthreads();
-    for (int a = wave; a < f.n_actions; a += NW) {
-      float part = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) part += s_h4[lane + 64 * i] * f.wh[a * 512 + lane + 64 * i];
-      part = wave_sum(part);
-      if (lane == 0) s_q[a] = part + f.bh[a];
-    }
-    return;
-  }
   for (int a = wave; a < f.n_actions; a += NW) {
     float part = 0.f;
 #pragma unroll
@@ -1131,120 +1118,12 @@ int dra_actor_c3fc4(const float* y2_planes, const float* w3, const float* b3, co
   return DRA_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Round 6: conv3 + fc4 of the actor's env step WITHOUT a hand-over.  The one-launch form above pays an in-kernel hand-over
-// (conv3's 8 workgroups publish, fc4's 64 poll: stores acknowledged + arrival count + poll + a cold read ~ 2.4 us of its 9 us)
-// because every fc4 workgroup needs all of conv3's output.  Here fc4 is split along K instead: workgroup (kq, rq) owns the 196
-// fc4 inputs that are conv3's output channels 4 kq .. 4 kq + 3 and 128 of fc4's 512 rows -- and COMPUTES those four 7 x 7
-// planes itself from conv2's planes (4 x 49 x 576 multiply-adds on the vector ALU: 0.3 us, repeated by the four row quarters),
-// while its 100 KB slice of fc4's weights (the launch's 6.4 MB, the long pole on the actor's 32 CUs) is already in flight.
-// Nothing crosses workgroups inside the launch.  Output: 16 K-slice partial sums of fc4's pre-activation,
-// parts[kq][row] = <W4[row][196 kq .. 196 kq + 195], relu(conv3)[...]>; the CONSUMER (the head riding in the next env step's
-// conv1 launch, or the agent step's tail kernel) folds them: h4[row] = relu(b4[row] + fixed tree over kq) -- what worked for
-// the rollout's fc4 in round 5 (K slices, finish in the consumer's staging).  A different fp32 summation order than the
-// MFMA conv3 / one-row-per-wave GEMV: action values agree at 1e-6 of their scale, not bit for bit.
-constexpr int kFlyKQ = 16, kFlyRQ = 4, kFlyOC = VG3::OC / kFlyKQ, kFlyCols = kFlyOC * VG3::P, kFlyRows = 512 / kFlyRQ;
-static_assert(kFlyCols == 196 && kFlyCols % 4 == 0 && kFlyCols / 4 <= 64, "one float4 per lane covers a K slice");
-constexpr int kFlyKG = 8;                      // channel groups of the on-the-fly conv3 = the 8 waves (8 channels each)
-
-__global__ void __launch_bounds__(512, 4) actor_c3fc4_fly_kernel(const float* __restrict__ y2p, const float* __restrict__ w3,
-                                                                 const float* __restrict__ b3, const float* __restrict__ w4,
-                                                                 float* __restrict__ parts) {
-  using G = VG3;
-  constexpr int I = G::OC * G::P, XN = G::C * G::H * G::H;       // 3136 fc4 inputs; 5184 floats per conv2 plane
-  __shared__ __attribute__((aligned(16))) float s_x[XN];             // relu(plane 0 + plane 1) of conv2: [64][9][9]
-  __shared__ __attribute__((aligned(16))) float s_p[kFlyKG * G::P * kFlyOC];
-  __shared__ __attribute__((aligned(16))) float s_y[kFlyCols];       // relu(conv3)[4][49] = fc4 inputs 196 kq ..
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // (provably wave-uniform: conv3's weights go through SGPRs)
-  const int kq = blockIdx.x % kFlyKQ, rq = blockIdx.x / kFlyKQ;
-  DRA_STAMP(TR_A_CONV1 + 2, 0);
-  // Requests in the order they are needed (a wave's loads return in issue order): conv2's two partial planes (plane 0 carries
-  // the bias) gate the on-the-fly conv3; fc4's weights -- 16 rows per wave, one float4 per lane and row (lanes >= 49 re-read
-  // the last one) -- go out behind them and arrive while conv3 is computed
-  constexpr int XQ = (XN + 511) / 512;
-  float xa[XQ], xb[XQ];
-#pragma unroll
-  for (int q = 0; q < XQ; ++q) {
-    const int i = min(tid + 512 * q, XN - 1);
-    xa[q] = y2p[i];
-    xb[q] = y2p[XN + i];
-  }
-  const float bias = b3[kFlyOC * kq + (tid & 3)];
-  __builtin_amdgcn_sched_barrier(0);
-  constexpr int RPWV = kFlyRows / 8;
-  float4 wv[RPWV];
-  {
-    const float* wb = w4 + ((int64_t)(rq * kFlyRows + wave * RPWV)) * I + kq * kFlyCols + 4 * min(lane, kFlyCols / 4 - 1);
-#pragma unroll
-    for (int i = 0; i < RPWV; ++i) wv[i] = *reinterpret_cast<const float4*>(wb + (int64_t)i * I);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // (every load above is unconditional on a clamped index and pinned here: left alone, the compiler sinks the tail loads
-  // into the bounds checks below -- more exposed memory round trips)
-#pragma unroll
-  for (int q = 0; q < XQ; ++q) asm volatile("" : "+v"(xa[q]), "+v"(xb[q]));
-#pragma unroll
-  for (int q = 0; q < XQ; ++q) {
-    const int i = tid + 512 * q;
-    if (i < XN) s_x[i] = fmaxf(xa[q] + xb[q], 0.f);
-  }
-  __syncthreads();
-  DRA_STAMP(TR_A_CONV1 + 2, 2);
-  // conv3 on the fly: wave g accumulates channels 8 g .. 8 g + 7, lane p one of the 49 positions, for the 4 output channels;
-  // the weights W3[(c, kh, kw)][4 kq .. 4 kq + 3] are the same for every lane of the wave: scalar loads, SGPR operands
-  {
-    const int p = min(lane, G::P - 1);
-    const int oh = p / G::OH, ow = p - oh * G::OH;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    constexpr int CG = G::C / kFlyKG;
-    const float* __restrict__ wg = w3 + (int64_t)(wave * CG) * G::KK * G::OC + kFlyOC * kq;
-    const float* xg = s_x + (wave * CG) * (G::H * G::H) + oh * G::H + ow;
-#pragma unroll 2
-    for (int cc = 0; cc < CG; ++cc) {
-#pragma unroll
-      for (int kh = 0; kh < G::KH; ++kh)
-#pragma unroll
-        for (int kw = 0; kw < G::KH; ++kw) {
-          const float x = xg[cc * (G::H * G::H) + kh * G::H + kw];
-          const float4 w = *reinterpret_cast<const float4*>(wg + (int64_t)(cc * G::KK + kh * G::KH + kw) * G::OC);
-          a0 += x * w.x; a1 += x * w.y; a2 += x * w.z; a3 += x * w.w;
-        }
-    }
-    if (lane < G::P) *reinterpret_cast<float4*>(s_p + 4 * (wave * G::P + lane)) = make_float4(a0, a1, a2, a3);
-  }
-  __syncthreads();
-  if (tid < kFlyCols) {   // thread = (position p, channel ol): the 8 channel groups as a fixed balanced tree, + bias, ReLU
-    const int ol = tid & 3, p = tid >> 2;
-    float t[kFlyKG];
-#pragma unroll
-    for (int g = 0; g < kFlyKG; ++g) t[g] = s_p[4 * (g * G::P + p) + ol];
-    const float v = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7])) + bias;
-    s_y[ol * G::P + p] = fmaxf(v, 0.f);
-  }
-  __syncthreads();
-  DRA_STAMP(TR_A_CONV1 + 2, 3);
-  const float4 xv = *reinterpret_cast<const float4*>(s_y + 4 * min(lane, kFlyCols / 4 - 1));
-  float* out = parts + (int64_t)kq * 512 + rq * kFlyRows + wave * RPWV;
-#pragma unroll
-  for (int i = 0; i < RPWV; ++i) {
-    float4 a = wv[i];
-    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
-    float d = (lane < kFlyCols / 4) ? (a.x * xv.x + a.y * xv.y) + (a.z * xv.z + a.w * xv.w) : 0.f;
-    d = wave_sum(d);
-    if (lane == 0) out[i] = d;
-  }
-  DRA_STAMP(TR_A_CONV1 + 2, 5);
-  DRA_STAMP_END(TR_A_CONV1 + 2);
-}
-
-// Library-internal (actor_env.h): the launch above; parts = [16][512] floats.
-int dra_actor_c3fc4_fly(const float* y2_planes, const float* w3, const float* b3, const float* w4, float* parts, void* stream) {
-  if (!y2_planes || !w3 || !b3 || !w4 || !parts) return DRA_EINVAL;
-  hipLaunchKernelGGL(actor_c3fc4_fly_kernel, dim3(kFlyKQ * kFlyRQ), dim3(512), 0, dra_stream(stream), y2_planes, w3, b3, w4, parts);
-  DRA_LAUNCH_CHECK();
-  return DRA_OK;
-}
+// (Round 6 measured a hand-over-free form of this launch -- fc4 split along K into 16 slices x 4 row quarters, every workgroup
+// computing its four conv3 planes itself on the vector ALU and the head folding the 16 partial sums -- in four layouts of the
+// on-the-fly conv3: 13.8 / 16.6 / 13.2 us per launch against 9.0-9.6 for this one, 8 137 vs 9 190 updates/s
+// (profiles/r06e_ab_actor_fly.jsonl, r06f-h_actor_fly_kernel_stats_*).  The reason is not the conv3 arithmetic: fc4's 6.4 MB of
+// weights stream at ~30 GB/s per CU on the actor's 32 CUs (6.6 us), which the form above hides completely behind conv3's
+// workgroups; any form that makes the weight requests wait behind conv3's inputs puts that stream back on the path.  Removed.)
 
 template <class G, bool U8, int PT, int NW = 4>
 static int launch_conv_v2_pt(const ConvV2Args& a, int nz, hipStream_t st) {

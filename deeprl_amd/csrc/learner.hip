@@ -45,12 +45,6 @@ constexpr int kFc4SplitMid = 14;  // ... DRA_FC4_KS=14: 224 workgroups of 224-wi
                                   // update partition (a CU's share of HBM is ~32 GB/s: 128 workgroups leave 96 CUs idle)
 static int fc4_ks(const struct dra_dqn_learner* l);
 constexpr int kAprmSlots = 16;
-// round 6: the ring actor's conv3 + fc4 as the hand-over-free K-slice launch (conv_v2.hip actor_c3fc4_fly_kernel).
-// DRA_EXP_ACTOR_FLY=0 builds the round 3-5 form (one launch with an in-kernel hand-over) for A/B runs.
-#ifndef DRA_EXP_ACTOR_FLY
-#define DRA_EXP_ACTOR_FLY 1
-#endif
-constexpr bool kActorFly = DRA_EXP_ACTOR_FLY != 0;
 
 struct dra_dqn_learner {
   dra_dqn_config c;
@@ -123,7 +117,6 @@ struct dra_dqn_learner {
   int pa_cur;                       // pa[pa_cur] holds the newest completed parameters
   bool pa_valid;
   float* ah4;                       // actor fc4 output (v2)
-  float* ah4p;                      // ... as 16 K-slice partial sums [16][512] (dra_actor_c3fc4_fly; folded by the head)
   // q(state) for a HOST environment (dra_dqn_learner_q_host): pinned staging + one captured graph
   uint8_t* qs_stage;                // pinned, device-mapped, coherent [4 x 7056]: the host actor's observation, read by conv1 in place
   float* q_stage;                   // pinned, device-mapped, coherent [64 q values | sequence word]: written by head_q_kernel itself
@@ -395,7 +388,6 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
     }
   }
   rc |= alloc_f(&l->ah4, 512);
-  rc |= alloc_f(&l->ah4p, 16 * 512);
   rc |= (int)hipMalloc(&l->aflags, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
   if (!rc) rc |= (int)hipMemset(l->aflags, 0, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
   if (l->variant & DRA_VAR_ACTOR_PARAMS) { rc |= alloc_f(&l->pa[0], cfg->n_params); rc |= alloc_f(&l->pa[1], cfg->n_params); }
@@ -510,7 +502,6 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   for (auto& ga : l->g_actor) if (ga.ready) (void)hipGraphExecDestroy(ga.exec);
   for (int k = 0; k < 4; ++k) if (l->pa[k]) (void)hipFree(l->pa[k]);
   if (l->ah4) (void)hipFree(l->ah4);
-  if (l->ah4p) (void)hipFree(l->ah4p);
   if (l->aflags) (void)hipFree(l->aflags);
   if (l->aring_dev) {
     (void)hipFree(l->aring_dev); (void)hipHostFree(l->aring_stage); (void)hipFree(l->aring_seq);
@@ -2385,17 +2376,10 @@ actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restric
                            uint8_t* __restrict__ ring_actions, float* __restrict__ q_out, uint8_t* __restrict__ frames,
                            double* __restrict__ rewards, int32_t* __restrict__ masks, uint8_t* __restrict__ pend_frame,
                            double* __restrict__ pend_reward, int32_t* __restrict__ pend_mask, uint64_t seed,
-                           int done_period, const HeadSpec hs, unsigned* __restrict__ flags_reset, int n_flags,
-                           const float* __restrict__ h4_parts = nullptr, const float* __restrict__ b4 = nullptr) {
+                           int done_period, const HeadSpec hs, unsigned* __restrict__ flags_reset, int n_flags) {
   __shared__ float s_q[64];
   __shared__ float s_out[kMaxHeadOut];
-  __shared__ float s_h4[512];
   DRA_STAMP(TR_A_HEAD, 0);
-  if (h4_parts) {   // fc4 as 16 K-slice partial sums (dra_actor_c3fc4_fly): the same fold as the fused head's
-    for (int j = threadIdx.x; j < 512; j += blockDim.x) s_h4[j] = actor_fold_h4(h4_parts, b4, j);
-    __syncthreads();
-    h4 = s_h4;
-  }
   // DRA_VAR_ACTOR_MEGA: the arrival counters of this agent step's one-launch env steps are done with; zero them for the next
   if (flags_reset)
     for (int i = threadIdx.x; i < n_flags; i += blockDim.x) __hip_atomic_store(flags_reset + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2472,9 +2456,6 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   f.head_kind = c.head_kind; f.n_atoms = c.n_atoms; f.atoms = l->atoms; f.pre = l->alog;
   // DRA_VAR_ACTOR_MEGA: conv3 + fc4 of an env step as ONE launch with an in-kernel hand-over (conv_v2.hip actor_c3fc4_kernel)
   const bool mega = (l->variant & DRA_VAR_ACTOR_MEGA) && actor_ksplit() && l->aflags;
-  // round 6: conv3 + fc4 without the in-launch hand-over (conv_v2.hip actor_c3fc4_fly_kernel), the fold in the head
-  const bool fly = mega && !dist && kActorFly;
-  if (fly) { f.h4_parts = l->ah4p; f.b4 = P + o[P_B4]; }
   for (int e = 0; e < n_env; ++e) {
     const int64_t* slot_field = reinterpret_cast<const int64_t*>(l->aring_dev + offsetof(dra_dqn_step_params, slot)) + e;
     const int32_t* age_field = reinterpret_cast<const int32_t*>(l->aring_dev + offsetof(dra_dqn_step_params, stack_age)) + e;
@@ -2486,10 +2467,6 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
                                           DRA_ACT_RELU, &f, s)))
         return rc;
       if ((rc = dra_conv_b1_split(2, l->ay1, nullptr, P + o[P_W2], P + o[P_B2], l->ay2p, s))) return rc;
-      if (fly) {
-        if ((rc = dra_actor_c3fc4_fly(l->ay2p, P + o[P_W3], P + o[P_B3], P + o[P_W4], l->ah4p, s))) return rc;
-        continue;
-      }
       if ((rc = dra_actor_c3fc4(l->ay2p, P + o[P_W3], P + o[P_B3], P + o[P_W4], P + o[P_B4], l->ay3p, l->ah4, l->aflags + 4 * e,
                                 l->timeout_flag, s)))
         return rc;
@@ -2547,8 +2524,7 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   hipLaunchKernelGGL(actor_head_env_ring_kernel, dim3(1), dim3(1024), 0, st, (const uint8_t*)l->aring_dev, l->aring_seq,
                      n_env - 1, 1, 0, (const float*)l->ah4, P + o[P_WH], P + o[P_BH], c.n_actions, (uint8_t*)actions, l->aq,
                      (uint8_t*)frames, (double*)rewards, (int32_t*)masks, l->pend_frame, l->pend_reward, l->pend_mask,
-                     (uint64_t)c.env_seed, (int)c.env_done_period, hs_tail, mega ? l->aflags : (unsigned*)nullptr, kMaxEnvSteps * 4,
-                     fly ? (const float*)l->ah4p : (const float*)nullptr, P + o[P_B4]);
+                     (uint64_t)c.env_seed, (int)c.env_done_period, hs_tail, mega ? l->aflags : (unsigned*)nullptr, kMaxEnvSteps * 4);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
