@@ -912,21 +912,28 @@ def main():
             roof["peak_note"] = "8000 GB/s is the HBM spec, quoted as a yardstick only: FETCH_SIZE counts Infinity-Cache hits"
             mf["longest_kernel"] = roof
             roof = mf
-        # `frac` / `achieved` of the headline kernel are THIS RUN's: the kernel replayed alone, 64 dependent launches in one
-        # captured graph between two events, minus the per-launch period of an empty kernel in the same form (the in-graph
-        # launch boundary) = the kernel's own duration, the quantity rocprofv3 reports (ADVICE r5 / VERDICT r5 item 3).  The live
-        # event pair around one eager launch (kernel + boundary + record: conservative) stays as frac_hip_events; the committed
-        # rocprofv3 summary of the same command on a builder box only under its own key.
+        # `frac` / `achieved` of the headline kernel are THIS RUN's (ADVICE r5 / VERDICT r5 item 3): the kernel replayed alone, 64
+        # dependent launches in one captured graph between two events -- microseconds per launch INCLUDING one in-graph launch
+        # boundary.  That is the conservative live reading and it lands within a few per cent of the rocprofv3 duration of the same
+        # kernel inside the running pipeline (r06: 9.8-9.9 us per launch against 10.3-10.5 us): alone and replayed, the kernel's
+        # operands are L2-warm, which about cancels the boundary.  Beside it: the same replay minus an EMPTY kernel's per-launch
+        # period (`frac_kernel_alone_warm`: the kernel's own duration with warm caches, an upper bound of the in-pipeline
+        # fraction), the event pair around one eager launch (`frac_hip_events`, kernel + boundary + record), and the committed
+        # builder-box rocprofv3 figure under its own key only.
         roof["frac_hip_events"], roof["achieved_hip_events"] = roof.get("frac"), roof.get("achieved")
         rp = roof.get("rocprofv3")
         if rp and rp.get("frac"):
             roof["frac_rocprofv3_committed"] = rp["frac"]
         gr = roof.get("graph_replay")
-        if gr and gr.get("frac"):
-            roof["frac"], roof["achieved"], roof["avg_ms"] = gr["frac"], gr["achieved"], gr["kernel_us"] * 1e-3
-            roof["frac_source"] = ("this run: graph replay of the kernel alone (64 dependent launches between two events) minus the "
-                                   "same replay of an empty kernel; frac_with_boundary / frac_hip_events are the conservative "
-                                   "live readings, frac_rocprofv3_committed the builder-box profile")
+        if gr and gr.get("frac_with_boundary"):
+            roof["frac"] = gr["frac_with_boundary"]
+            roof["achieved"] = gr["frac_with_boundary"] * 157.3
+            roof["avg_ms"] = gr["us_per_launch"] * 1e-3
+            roof["frac_kernel_alone_warm"] = gr["frac"]
+            roof["frac_source"] = ("this run: graph replay of the kernel alone, 64 dependent launches between two events, per-launch "
+                                   "period incl. one in-graph boundary (conservative); frac_kernel_alone_warm = the same minus an "
+                                   "empty kernel's period; frac_hip_events = event pair around one eager launch; "
+                                   "frac_rocprofv3_committed = builder-box profile")
         else:
             roof["frac_source"] = "hip_events of this run (event pair around one eager launch, launch boundary included)"
         if roof.get("traffic") and roof.get("algorithmic_bytes_hbm"):
