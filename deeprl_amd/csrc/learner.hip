@@ -275,12 +275,6 @@ DRA_API int dra_stream_destroy(void* stream) {
 
 constexpr int kMaxHeadOut = 4096;   // n_actions * n_atoms the batch-1 actor head keeps in LDS
 
-static int dist_actor_fused() {   // DRA_ACTOR_DIST_FUSED=0: distributional heads on the six-launch env step (own head kernel)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_ACTOR_DIST_FUSED"); v = e ? atoi(e) : 1; }
-  return v;
-}
-
 static int alloc_f(float** p, int64_t n) { return (int)hipMalloc(p, (size_t)n * sizeof(float)); }
 
 DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const dra_dqn_config* cfg, float* params,
@@ -359,8 +353,8 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
     // parameter ring); the launches that fold the VanillaNet head into a neighbouring kernel do not apply
     l->variant |= DRA_VAR_ACTOR_V2;
     l->variant &= ~(DRA_VAR_ACTOR_V3 | DRA_VAR_ACTOR_FUSED_HEAD | DRA_VAR_GATHER_IN_GRAPH);
-    if (!dist_actor_fused()) l->variant &= ~DRA_VAR_ACTOR_FUSED_CONV1;   // (the ring actor's fused conv1 launch reduces the
-                                                                        // head outputs of actor_dist_gemv_kernel to action values)
+    // (the ring actor's fused conv1 launch reduces the head outputs of actor_dist_gemv_kernel to action values; the six-launch
+    // env step with its own head kernel was the A/B partner until round 6: DRA_ACTOR_DIST_FUSED, retired)
   }
   if (l->variant & DRA_VAR_ONESHOT_WGRAD) {
     // layer L's segment of the flat gradient is [offset(W_L), offset(b_L) + OC): weight then bias, contiguous
@@ -1037,42 +1031,6 @@ static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = 
                                c.lr, c.alpha, c.eps, c.centered, l->norm, p_copy, (void*)st);
 }
 
-// Head contraction of the distributional heads at the update's batch: out[z][b][o] = bh_z[o] + <h4[z][b], Wh_z[o]>,
-// [B,512] x [512, A*N] per net (6.7 MFLOP for C51, 26 for QR at 200 quantiles).  Too small for the K-chunked implicit
-// GEMM to pay (16 us: 8 dependent 64-wide chunks on 14 workgroups): a workgroup stages 32 samples of h4 in LDS once (64 KB)
-// and each of its 4 waves owns one output row -- the 2 KB weight row sits in registers (8 floats per lane), 32 wave-level
-// dot products against the LDS rows.  grid (ceil(A*N / 4), nets, ceil(B / 32)).
-__global__ void __launch_bounds__(256)
-head_fwd_gemv_kernel(const float* __restrict__ h4, int B, int NO, const float* __restrict__ wh_on, const float* __restrict__ wh_tg,
-                     const float* __restrict__ bh_on, const float* __restrict__ bh_tg, float* __restrict__ out0,
-                     float* __restrict__ out1, float* __restrict__ out2) {
-  __shared__ __attribute__((aligned(16))) float s_h[32 * 512];
-  const int z = blockIdx.y, b0 = blockIdx.z * 32, nb = min(32, B - b0);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int o = blockIdx.x * 4 + wave;
-  const float* __restrict__ wh = (z == 1) ? wh_tg : wh_on;
-  float w[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) w[i] = wh[(int64_t)min(o, NO - 1) * 512 + lane + 64 * i];
-  const float bias = ((z == 1) ? bh_tg : bh_on)[min(o, NO - 1)];
-  const float4* __restrict__ src = reinterpret_cast<const float4*>(h4 + ((int64_t)z * B + b0) * 512);
-  float4 v[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) v[q] = src[min((int)threadIdx.x + 256 * q, nb * 128 - 1)];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) reinterpret_cast<float4*>(s_h)[threadIdx.x + 256 * q] = v[q];
-  __syncthreads();
-  if (o >= NO) return;
-  float* __restrict__ out = (z == 0) ? out0 : (z == 1 ? out1 : out2);
-  for (int b = 0; b < nb; ++b) {
-    float part = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) part += s_h[b * 512 + lane + 64 * i] * w[i];
-    part = wave_sum(part);
-    if (lane == 0) out[(int64_t)(b0 + b) * NO + o] = part + bias;
-  }
-}
-
 // Head + loss + head input-gradient for the distributional heads (everything head_fused_kernel does for VanillaNet):
 //   h4[z] <- fc4 partial sums ; out[z] = h4[z] Wh_z^T + bh_z (q[z], [B][A*N]) ; fused loss kernel -> per-sample loss
 //   vector (delta) and d(reduced loss)/d out (dq) ; dh4 = (dq Wh) * relu'(h4[0]).
@@ -1094,23 +1052,14 @@ static int run_dist_head(dra_dqn_learner* l, hipStream_t st, int per, float beta
     hipLaunchKernelGGL(fc4_reduce_kernel<kFc4Split>, dim3(B, nz), dim3(256), 0, st, (const float*)l->fc4_slabs, B, P + o[P_B4],
                        T + o[P_B4], l->h4, l->opt_step, rs);
   DRA_LAUNCH_CHECK();
-  static int gemv = -1;   // DRA_HEAD_GEMV: 2 = one-pass MFMA contraction (default), 1 = wave-per-output GEMV, 0 = K-chunked GEMM
-  if (gemv < 0) { const char* e = getenv("DRA_HEAD_GEMV"); gemv = e ? atoi(e) : 2; }
+  // the head contraction as the one-pass MFMA kernel (fused.hip dra_head_fwd_one); the wave-per-output GEMV and the K-chunked
+  // GEMM it replaced were A/B partners behind DRA_HEAD_GEMV until round 6
   int rc = DRA_OK;
-  if (gemv == 2) {
+  {
     const float* hx[3] = {l->h4, l->h4 + (int64_t)B * 512, l->h4 + (int64_t)2 * B * 512};
     const float* hw[3] = {P + o[P_WH], T + o[P_WH], P + o[P_WH]};
     const float* hb[3] = {P + o[P_BH], T + o[P_BH], P + o[P_BH]};
     if ((rc = dra_head_fwd_one(nz, hx, hw, hb, l->q, B, NO, s))) return rc;
-  } else if (gemv) {
-    hipLaunchKernelGGL(head_fwd_gemv_kernel, dim3((NO + 3) / 4, nz, (B + 31) / 32), dim3(256), 0, st, (const float*)l->h4, B, NO,
-                       P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH], l->q[0], l->q[1], l->q[2]);
-    DRA_LAUNCH_CHECK();
-  } else {
-    const float* hx[3] = {l->h4, l->h4 + (int64_t)B * 512, l->h4 + (int64_t)2 * B * 512};
-    const float* hw[3] = {P + o[P_WH], T + o[P_WH], P + o[P_WH]};
-    const float* hb[3] = {P + o[P_BH], T + o[P_BH], P + o[P_BH]};
-    if ((rc = dra_linear_fwd(nz, hx, hw, hb, l->q, B, 512, NO, DRA_ACT_NONE, l->lin_ws, l->lin_ws_floats, s))) return rc;
   }
   if (c.head_kind == DRA_HEAD_CATEGORICAL) {
     const float* weights = nullptr;
@@ -1208,7 +1157,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     rs.idx = l->idx; rs.actions = (const uint8_t*)ring_actions; rs.rewards = (const double*)ring_rewards;
     rs.masks = (const int32_t*)ring_masks; rs.n_step = ring_n; rs.discount = ring_discount;
     rs.out_action = l->action_[l->gb]; rs.out_reward = l->reward_[l->gb]; rs.out_mask = l->mask_[l->gb];
-    if (l->variant & DRA_VAR_IDX_PREFETCH) rs.seq = l->rd_seq_dev;
+    if ((l->variant & DRA_VAR_IDX_PREFETCH) && l->only_kernel < 0) rs.seq = l->rd_seq_dev;   // (a replay is not an update)
   }
   if (l->only_kernel >= 0 && l->only_kernel != K_HEAD) {
     // (single-kernel replay of another group: no head launch)
@@ -1874,47 +1823,8 @@ actor_fc4_kernel(const float* __restrict__ x, const float* __restrict__ w, const
   DRA_STAMP_END(TR_A_FC4);
 }
 
-// actor_fc4_kernel whose input is conv3's two partial planes (dra_conv_b1_split; plane 0 carries the bias): x = relu(x0 + x1),
-// formed while the operands are loaded
-__global__ void __launch_bounds__(256)
-actor_fc4_planes_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ h4, int in_features) {
-  constexpr int R = 13;  // float4 per lane: 3136 / 4 / 64 = 12.25
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wave;
-  const int nv = in_features >> 2;
-  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w + (int64_t)row * in_features);
-  const float4* __restrict__ a4 = reinterpret_cast<const float4*>(x0);
-  const float4* __restrict__ c4 = reinterpret_cast<const float4*>(x1);
-  DRA_STAMP(TR_A_FC4, 0);
-  float4 wv[R], av[R], cv[R];
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    const int i = min(lane + 64 * q, nv - 1);
-    wv[q] = w4[i];
-    av[q] = a4[i];
-    cv[q] = c4[i];
-  }
-  float acc = 0.f;
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    float4 a = wv[q];
-    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));  // loads stay unconditional and batched
-    float4 b;
-    b.x = fmaxf(av[q].x + cv[q].x, 0.f); b.y = fmaxf(av[q].y + cv[q].y, 0.f);
-    b.z = fmaxf(av[q].z + cv[q].z, 0.f); b.w = fmaxf(av[q].w + cv[q].w, 0.f);
-    if (lane + 64 * q < nv) acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) {
-    const float v = acc + bias[row];
-    h4[row] = v > 0.f ? v : 0.f;
-  }
-  DRA_STAMP(TR_A_FC4, 5);
-  DRA_STAMP_END(TR_A_FC4);
-}
-
-// The same GEMV with x = relu(x0 + x1) formed ONCE per workgroup and staged in LDS (12.5 KB) instead of both planes in every
-// lane's registers: 13 float4 of weights + a few transient registers per lane, so that a CU keeps >= 4 of these workgroups
+// actor_fc4_kernel whose input is conv3's two partial planes (dra_conv_b1_split; plane 0 carries the bias), x = relu(x0 + x1)
+// formed ONCE per workgroup and staged in LDS (12.5 KB) instead of both planes in every lane's registers: 13 float4 of weights + a few transient registers per lane, so that a CU keeps >= 4 of these workgroups
 // resident -- the 128 workgroups are ONE round on the actor's 32 CUs (the register-resident form ran 64 + 32 + 32: phase
 // trace profiles/r02zj_phase_async_acu32.json, 7.7 us per env step for 3.3 us workgroups).  Same products, same order.
 __global__ void __launch_bounds__(256)
@@ -2487,15 +2397,9 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
       if ((rc = dra_conv_b1_split(2, l->ay1, nullptr, P + o[P_W2], P + o[P_B2], l->ay2p, s))) return rc;
       if ((rc = dra_conv_b1_split(3, l->ay2p, l->ay2p + 64 * 81, P + o[P_W3], P + o[P_B3], l->ay3p, s))) return rc;
       // the input staged through LDS: one round of workgroups on the actor's CUs, same-box A/B 8 575 / 8 559 vs 8 409 / 8 242
-      // updates/s (profiles/r02zt_ab.json); DRA_ACTOR_FC4_LDS=0 = the register-resident form
-      static int fc4_lds = -1;
-      if (fc4_lds < 0) { const char* e = getenv("DRA_ACTOR_FC4_LDS"); fc4_lds = e ? atoi(e) : 1; }
-      if (fc4_lds)
-        hipLaunchKernelGGL(actor_fc4_planes_lds_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3p,
-                           (const float*)(l->ay3p + 64 * 49), P + o[P_W4], P + o[P_B4], l->ah4, 3136);
-      else
-        hipLaunchKernelGGL(actor_fc4_planes_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3p, (const float*)(l->ay3p + 64 * 49),
-                           P + o[P_W4], P + o[P_B4], l->ah4, 3136);
+      // updates/s against the register-resident form (profiles/r02zt_ab.json; that form and its switch were retired in round 6)
+      hipLaunchKernelGGL(actor_fc4_planes_lds_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3p,
+                         (const float*)(l->ay3p + 64 * 49), P + o[P_W4], P + o[P_B4], l->ah4, 3136);
       DRA_LAUNCH_CHECK();
       if (dist) {   // the head's A*N outputs of this env step (consumed by the next launch: fused conv1 of e+1, or the tail kernel)
         hipLaunchKernelGGL(actor_dist_gemv_kernel, dim3((l->n_out + 3) / 4), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH],
@@ -2529,12 +2433,6 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   return DRA_OK;
 }
 
-static int actor_dist_gemv() {   // DRA_ACTOR_DIST_GEMV=0: the distributional head's outputs inside the one-workgroup head kernel
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_ACTOR_DIST_GEMV"); v = e ? atoi(e) : 1; }
-  return v;
-}
-
 static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
   if (l->variant & DRA_VAR_ACTOR_FUSED_CONV1) return run_actor_steps_ring_fused(l, n_env, P, st);
   const dra_dqn_config& c = l->c;
@@ -2559,7 +2457,7 @@ static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, h
     hipLaunchKernelGGL(actor_fc4_kernel, dim3(128), dim3(256), 0, st, (const float*)l->ay3, P + o[P_W4], P + o[P_B4],
                        l->ah4, 3136);
     HeadSpec hs = head_spec(l);
-    if (c.head_kind != DRA_HEAD_VANILLA && actor_dist_gemv()) {
+    if (c.head_kind != DRA_HEAD_VANILLA) {
       hipLaunchKernelGGL(actor_dist_gemv_kernel, dim3((l->n_out + 3) / 4), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH],
                          P + o[P_BH], l->n_out, l->alog);
       hs.pre = l->alog;

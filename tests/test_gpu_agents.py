@@ -1406,3 +1406,37 @@ def test_async_pipeline_dist_heads_match_schedule_oracle(dra, head, cap):
     np.random.set_state(rng_state)
     L.close()
     bench.ring.close()
+
+
+def test_kernel_replay_measures_without_side_effects(dra):
+    """dra_dqn_learner_kernel_replay (round 6: bench.py's live roofline reading) replays ONE kernel group of the update alone, 64
+    dependent launches in a captured graph.  It must (i) return a per-launch time above the empty kernel's, (ii) refuse the
+    groups a replay must not run (the optimizer, groups that ride in another group's launch), and (iii) leave the learner exactly
+    where it was: two benches on the same seeds, one of them replaying every replayable group between its steps, end on the
+    same parameters bit for bit."""
+    d = dra
+    from deeprl_amd._lib import DraError
+    from deeprl_amd.learner import DQNLearnerBench
+    outs = []
+    for replay in (False, True):
+        np.random.seed(3)
+        torch.manual_seed(4)
+        b = DQNLearnerBench(ring_capacity=4096, batch=32, seed=5, actor=True, async_actor=True)
+        for _ in range(12):
+            b.step()
+        if replay:
+            for name in ("conv1_fwd", "conv2_fwd", "conv3_fwd", "fc4_fwd", "head_loss", "fc4_bwd_x", "conv3_bwd_x", "conv2_bwd_x",
+                         "conv1_bwd_w"):
+                b.learner.synchronize()
+                per, empty = b.learner.kernel_replay(name, 16)
+                assert 0.5 < empty < per < 200.0, (name, per, empty)
+            for name in ("rmsprop_step", "grad_norm", "conv2_bwd_w", "gather"):
+                with pytest.raises(DraError):
+                    b.learner.kernel_replay(name, 4)
+        for _ in range(6):
+            b.step()
+        b.learner.synchronize()
+        outs.append(b.learner.flat.flat.detach().cpu().numpy().copy())
+        b.learner.close()
+        b.ring.close()
+    assert np.array_equal(outs[0], outs[1])

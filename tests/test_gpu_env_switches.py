@@ -24,20 +24,8 @@ def _run(kind, env, tmp_path, tag):
     return dict(np.load(out))
 
 
-@pytest.mark.parametrize("kind,switch", [("c51", "DRA_ACTOR_DIST_GEMV"), ("qr", "DRA_ACTOR_DIST_GEMV"), ("dqn", "DRA_ACTOR_FC4_LDS"),
-                                         ("c51", "DRA_ACTOR_DIST_FUSED"), ("qr", "DRA_ACTOR_DIST_FUSED")])
-def test_actor_kernel_switch_is_bit_identical(tmp_path, kind, switch):
-    """DRA_ACTOR_DIST_GEMV (the distributional head's A*N outputs by a many-workgroup GEMV in front of the head kernel, or inside
-    it), DRA_ACTOR_FC4_LDS (the actor's fc4 input staged through LDS, or register-resident) and DRA_ACTOR_DIST_FUSED (the
-    distributional actor on the fused conv1 launch -- five launches per env step -- or with its own head kernel, six): same
-    products in the same order -- 60 mostly-greedy agent steps of the device-resident async pipeline must store the same actions and end on
-    bit-identical parameters with the switch on and off."""
-    a = _run(kind, {switch: "1"}, tmp_path, "on")
-    b = _run(kind, {switch: "0"}, tmp_path, "off")
-    assert sorted(a) == sorted(b)
-    for k in a:
-        assert np.array_equal(a[k], b[k]), k
-    assert len(set(a["act"][:200].tolist())) > 1, "the probe must take more than one distinct action"
+# (DRA_ACTOR_DIST_GEMV, DRA_ACTOR_DIST_FUSED, DRA_ACTOR_FC4_LDS and DRA_HEAD_GEMV were checked here -- switch on == switch off, bit for
+# bit, 60 agent steps -- until round 6 retired them: the measured winner of each is the only form left in the library.)
 
 
 def test_fc4_k_split_is_another_association_of_the_same_sums(tmp_path):
