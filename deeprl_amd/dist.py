@@ -57,28 +57,47 @@ def _parse_cpulist(text):
     return sorted(set(cpus))
 
 
-def plan_affinity(allowed, node_cpus_of_rank, local_rank):
+def plan_affinity(allowed, node_cpus_of_rank, local_rank, core_of=None):
     """Pure placement rule.  allowed: cpus this process may run on; node_cpus_of_rank[r]: cpus local to the GPU of local rank r
     (None = unknown).  Ranks whose GPUs share a node split that node's allowed cpus into contiguous, disjoint shares in rank
     order; a rank with no topology information gets the share of an even split of `allowed`; with fewer cpus than ranks the
-    ranks share round-robin.  Returns the sorted cpu list of `local_rank` (never empty)."""
+    ranks share round-robin.  core_of (optional): cpu -> id of its physical core; the shares are then cut from the list ordered
+    by core, so that the hardware threads of one core go to the SAME rank (a node's cpulist is "64-127,192-255" on the MI355X
+    hosts: 192 is the sibling of 64 -- splitting the list in halves would put two ranks on every core).  Returns the sorted cpu
+    list of `local_rank` (never empty)."""
     allowed = sorted(set(int(c) for c in allowed))
+    order = (lambda c: (core_of.get(c, c), c)) if core_of else (lambda c: c)
     if not allowed:
         raise ValueError("plan_affinity: no cpu allowed")
     n = len(node_cpus_of_rank)
     keys = []
     for r in range(n):
         local = node_cpus_of_rank[r]
-        pool = sorted(set(local) & set(allowed)) if local else []
+        pool = sorted(set(local) & set(allowed), key=order) if local else []
         keys.append(tuple(pool) if pool else None)
     mine = keys[local_rank]
-    pool = list(mine) if mine is not None else allowed
+    pool = list(mine) if mine is not None else sorted(allowed, key=order)
     group = [r for r in range(n) if keys[r] == mine]          # the ranks that draw from the same pool, in rank order
     pos, g = group.index(local_rank), len(group)
     if len(pool) < g:
         return [pool[pos % len(pool)]]
     lo, hi = (pos * len(pool)) // g, ((pos + 1) * len(pool)) // g
-    return pool[lo:hi]
+    return sorted(pool[lo:hi])
+
+
+def cpu_cores(cpus, sysfs="/sys"):
+    """cpu -> smallest cpu number among its hardware-thread siblings (an id of the physical core); cpus without topology files
+    map to themselves."""
+    import os
+    out = {}
+    for c in cpus:
+        try:
+            sib = _parse_cpulist(open(os.path.join(sysfs, "devices", "system", "cpu", "cpu%d" % c, "topology",
+                                                   "thread_siblings_list")).read())
+            out[c] = min(sib) if sib else c
+        except (OSError, ValueError):
+            out[c] = c
+    return out
 
 
 def gpu_local_cpus(device_index, sysfs="/sys"):
@@ -112,7 +131,7 @@ def pin_rank(local_rank, local_world, devices=None):
         if devices is None:
             devices = [(r % n_dev) if n_dev else None for r in range(local_world)]
         node = [gpu_local_cpus(dv) if dv is not None else None for dv in devices]
-        cpus = plan_affinity(allowed, node, local_rank)
+        cpus = plan_affinity(allowed, node, local_rank, cpu_cores(allowed))
         info.update(device=devices[local_rank], gpu_node_known=node[local_rank] is not None, cpus=cpus, allowed=len(allowed))
         if os.environ.get("DRA_NO_PIN") == "1" or local_world <= 1:
             info["note"] = "not pinned (single rank or DRA_NO_PIN=1)"

@@ -226,6 +226,10 @@ def test_plan_affinity_rules():
     # no topology: even split of what is allowed; more ranks than cpus: round-robin, one cpu each
     assert [plan_affinity(range(8), [None] * 4, r) for r in range(4)] == [[0, 1], [2, 3], [4, 5], [6, 7]]
     assert [plan_affinity(range(2), [None] * 4, r) for r in range(4)] == [[0], [1], [0], [1]]
+    # hardware threads: the node's list is "0-3,8-11" with cpu 8 the sibling of cpu 0 ...: whole cores per rank
+    core_of = {c: c % 8 for c in range(16)}
+    smt = [plan_affinity(range(16), [[0, 1, 2, 3, 8, 9, 10, 11]] * 2, r, core_of) for r in range(2)]
+    assert smt == [[0, 1, 8, 9], [2, 3, 10, 11]]
     # a GPU whose node has no allowed cpu falls back to the even split among the ranks in the same situation
     assert plan_affinity(range(4), [[100, 101], [100, 101]], 1) == [2, 3]
 
