@@ -101,6 +101,17 @@ struct ActorFuse {
   const float* pre;
 };
 
+// optim.hip (library-internal; DRA_VAR_DEFER_FC4, common.h DraFc4Rider): dra_clip_step_late with floats [skip_begin, + skip_count)
+// left for the riders: the launch writes the clip coefficient to *defer_coef, raises *defer_pending, clears *defer_valid
+int dra_clip_step_late_defer(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* seg,
+                             double* partials, int n_prior, int* timeout_flag, float max_norm, const float* hyper, int centered,
+                             float* out_norm, float* param_copy, int64_t skip_begin, int64_t skip_count, float* defer_coef,
+                             int* defer_pending, int* defer_valid, void* stream);
+// conv_v2.hip (library-internal): what the NEXT batched conv forward launch issued from this thread carries beside its own work
+// (consumed by that launch, then cleared): rider workgroups [first, first + count) of the deferred fc4 segment as extra
+// z-slices, and / or the words the first workgroup sets once the riders' launches are over (pending <- 0, valid <- 1)
+void dra_conv_attach_rider(const DraFc4Rider* rider, int first, int count, int* done_pending, int* done_valid);
+
 // conv_v2.hip (library-internal)
 int dra_conv1_fwd_actor_fused(const void* frames, const int64_t* slot_field_dev, const int32_t* stack_age_field_dev, const unsigned* seq_dev, int n_entries,
                               int64_t stride_bytes, int64_t capacity, const void* newest_frame, const float* wt,
@@ -153,5 +164,9 @@ int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, flo
 
 // ... and its default form: conv1 (fused head / environment step) and conv2 keep their launches, conv3 + fc4 share one
 // (flags[2] = conv3's arrival counter)
+// (w4_valid, optional: a device word the fc4 role waits to become non-zero before it requests w4 -- DRA_VAR_DEFER_FC4: the copy's
+// fc4 segment is completed by riders of the update that runs beside this actor graph)
+int dra_actor_c3fc4_valid(const float* y2_planes, const float* w3, const float* b3, const float* w4, const float* b4, float* y3_planes,
+                          float* h4, unsigned* flags, int* timeout_flag, const int* w4_valid, void* stream);
 int dra_actor_c3fc4(const float* y2_planes, const float* w3, const float* b3, const float* w4, const float* b4, float* y3_planes,
                     float* h4, unsigned* flags, int* timeout_flag, void* stream);

@@ -27,6 +27,93 @@
 
 static inline hipStream_t dra_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- one RMSprop element (torch.optim.RMSprop, centered or not; g already the raw gradient, coef the clip coefficient) -- the
+// ONE statement of the arithmetic for optim.hip's step kernels and for the riders below
+__device__ __forceinline__ void rmsprop_elem(float& p, float g, float& s, float& a, float coef, float alpha, float oma,
+                                             float lr, float eps, int centered) {
+  const float gk = g * coef;
+  s = s * alpha + oma * gk * gk;
+  float avg;
+  if (centered) {
+    a = a * alpha + oma * gk;
+    avg = sqrtf(s - a * a) + eps;
+  } else {
+    avg = sqrtf(s) + eps;
+  }
+  p = p - lr * (gk / avg);
+}
+
+// ---- DRA_VAR_DEFER_FC4 (round 6): the fc4 segment of the DQN learner's optimizer step, deferred ------------------------------
+// fc4's weights are 95 % of the parameters: 51 of the 54 MB the optimizer launch moves, on the update's critical path for ~8 of
+// its ~15 us.  Nothing reads them before fc4's forward of the NEXT update (the fourth launch of its graph, ~31 us in) -- and
+// the actor reads its copy of them ~16 us after that graph starts.  So the optimizer launch steps everything BUT that segment,
+// leaves the clip coefficient in device memory and raises `pending`; the segment is stepped by RIDER workgroups -- extra
+// z-slices of the next update's conv1 / conv2 forward launches (conv_v2.hip), memory-bound work beside latency-bound work --
+// with the arithmetic above, hence the same bits.  The launch after the riders' lowers `pending` and marks the actor copy the
+// riders completed as valid (the actor's fc4 waits for that word before it requests the weights).  Anything that reads the
+// parameters outside the pipelined graphs flushes first (learner.hip flush_fc4): the same rider code as a launch of its own.
+struct DraFc4Rider {
+  float *p, *g, *s1, *s2, *p_copy;    // flat buffers (p_copy: the actor copy the deferred step also has to reach; may be null)
+  int64_t begin4, count4;             // the segment, in float4 units
+  const float* coef;                  // clip coefficient left by the optimizer launch
+  const int* pending;                 // != 0: the segment has not been stepped yet
+  float lr, alpha, eps;
+  int centered;
+};
+// (DRA_EXP_RIDER_NT=1: gradient / optimizer-state / copy traffic of the riders as non-temporal accesses -- an A/B build)
+#ifndef DRA_EXP_RIDER_NT
+#define DRA_EXP_RIDER_NT 0
+#endif
+constexpr int kRiderNV = 3;           // float4 per thread of a rider workgroup (256 threads)
+__host__ __device__ inline int fc4_rider_blocks(int64_t count4) { return (int)((count4 + 256 * kRiderNV - 1) / (256 * kRiderNV)); }
+
+// rider workgroup `rb` of `nrb` (nrb * 256 * kRiderNV >= count4)
+__device__ __forceinline__ void fc4_rider_run(const DraFc4Rider& r, int rb) {
+  if (*r.pending == 0) return;
+  const int64_t i0 = (int64_t)rb * (256 * kRiderNV) + threadIdx.x;
+  float4 P[kRiderNV], G[kRiderNV], S[kRiderNV], A[kRiderNV];
+  const float4* p4 = reinterpret_cast<const float4*>(r.p) + r.begin4;
+  const float4* g4 = reinterpret_cast<const float4*>(r.g) + r.begin4;
+  const float4* s4 = reinterpret_cast<const float4*>(r.s1) + r.begin4;
+  const float4* a4 = reinterpret_cast<const float4*>(r.centered ? r.s2 : r.s1) + r.begin4;
+#pragma unroll
+  for (int v = 0; v < kRiderNV; ++v) {
+    const int64_t i = i0 + 256 * v, ic = i < r.count4 ? i : r.count4 - 1;
+#if DRA_EXP_RIDER_NT
+    P[v] = p4[ic];
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    const nt_f4 gq = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(g4 + ic));
+    const nt_f4 sq = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(s4 + ic));
+    const nt_f4 aq = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(a4 + ic));
+    G[v] = make_float4(gq.x, gq.y, gq.z, gq.w); S[v] = make_float4(sq.x, sq.y, sq.z, sq.w); A[v] = make_float4(aq.x, aq.y, aq.z, aq.w);
+#else
+    P[v] = p4[ic]; G[v] = g4[ic]; S[v] = s4[ic]; A[v] = a4[ic];
+#endif
+  }
+  const float coef = *r.coef, oma = 1.f - r.alpha;
+#pragma unroll
+  for (int v = 0; v < kRiderNV; ++v) {
+    const int64_t i = i0 + 256 * v;
+    if (i < r.count4) {
+      float* pp = &P[v].x; const float* gg = &G[v].x; float* ss = &S[v].x; float* aa = &A[v].x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rmsprop_elem(pp[k], gg[k], ss[k], aa[k], coef, r.alpha, oma, r.lr, r.eps, r.centered);
+      reinterpret_cast<float4*>(r.p)[r.begin4 + i] = P[v];
+#if DRA_EXP_RIDER_NT
+      typedef float nt_f4 __attribute__((ext_vector_type(4)));
+      const nt_f4 pq = {P[v].x, P[v].y, P[v].z, P[v].w}, sq = {S[v].x, S[v].y, S[v].z, S[v].w}, aq = {A[v].x, A[v].y, A[v].z, A[v].w};
+      if (r.p_copy) __builtin_nontemporal_store(pq, reinterpret_cast<nt_f4*>(r.p_copy) + r.begin4 + i);
+      __builtin_nontemporal_store(sq, reinterpret_cast<nt_f4*>(r.s1) + r.begin4 + i);
+      if (r.centered) __builtin_nontemporal_store(aq, reinterpret_cast<nt_f4*>(r.s2) + r.begin4 + i);
+#else
+      if (r.p_copy) reinterpret_cast<float4*>(r.p_copy)[r.begin4 + i] = P[v];
+      reinterpret_cast<float4*>(r.s1)[r.begin4 + i] = S[v];
+      if (r.centered) reinterpret_cast<float4*>(r.s2)[r.begin4 + i] = A[v];
+#endif
+    }
+  }
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: remember, per device ordinal, the largest
 // size already granted (a process that launches on a second GPU after a first -- select_device -- must set it there too;
 // ADVICE r5).  One object per kernel instantiation (a function-local static at the launch site).

@@ -116,7 +116,25 @@ struct ConvV2Args {
   const unsigned long long* sample_seq = nullptr;
   // != 0: XCD-aware block order (common.h xcd_order): every workgroup of one (net, sample) runs on one XCD
   int xcd_order = 0;
+  // DRA_VAR_DEFER_FC4 (common.h DraFc4Rider; dra_conv_attach_rider): the FIRST rider_z z-slices of the launch are RIDERS -- workgroup k
+  // of them steps rider block rider_first + k (< rider_end) of the deferred fc4 segment; nz_real = the nets of the launch itself.
+  // rider_done_*: the launch's first workgroup lowers `pending` / marks the completed actor copy valid (the launch AFTER the riders')
+  DraFc4Rider rider = {};
+  int rider_z = 0, rider_first = 0, rider_end = 0, nz_real = 0;
+  int* rider_done_pending = nullptr;
+  int* rider_done_valid = nullptr;
 };
+
+// the attachment the next batched forward launch consumes (dra_conv_attach_rider)
+static thread_local struct { DraFc4Rider rider; int first, count; int* done_pending; int* done_valid; bool armed; } g_rider_next;
+void dra_conv_attach_rider(const DraFc4Rider* rider, int first, int count, int* done_pending, int* done_valid) {
+  g_rider_next.armed = (rider && count > 0) || done_pending || done_valid;
+  if (rider) g_rider_next.rider = *rider;
+  g_rider_next.first = first;
+  g_rider_next.count = rider ? count : 0;
+  g_rider_next.done_pending = done_pending;
+  g_rider_next.done_valid = done_valid;
+}
 
 __device__ __forceinline__ float v2_act(float v, int act) {
   if (act == DRA_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -557,6 +575,22 @@ __global__ void __launch_bounds__(64 * NW) conv_fwd_v2_kernel(const ConvV2Args a
   ActorFuse none;
   none.mode = 0;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.rider_z > 0) {
+    // riders: the deferred fc4 segment of the previous update's optimizer step, the FIRST rider_z z-slices of the launch -- they are
+    // dispatched first and stream while the launch's own workgroups sit in their latency phases
+    if ((int)blockIdx.z < a.rider_z) {
+      if constexpr (NW == 4) {
+        const int k = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z);
+        if (a.rider_first + k < a.rider_end) fc4_rider_run(a.rider, a.rider_first + k);
+      }
+      return;
+    }
+    bz -= a.rider_z;
+  }
+  if (a.rider_done_pending && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    __hip_atomic_store(a.rider_done_pending, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.rider_done_valid) __hip_atomic_store(a.rider_done_valid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (a.pf_nz > 0 && (int)blockIdx.z >= a.pf_first) {
     fc4_weight_prefetch(a, (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * ((int)blockIdx.z - a.pf_first)));
     return;
@@ -565,8 +599,8 @@ __global__ void __launch_bounds__(64 * NW) conv_fwd_v2_kernel(const ConvV2Args a
     // natural order: x = sample * TPG + tile group (fastest), y = output-channel tile, z = net; the sharing group is one
     // (net, sample): TPG * gridDim.y workgroups staging rows of the same input images
     constexpr int TPG = V2Tile<G, PT>::TPG;
-    const int ny = gridDim.y, per = TPG * ny, groups = (a.pf_nz > 0 ? a.pf_first : (int)gridDim.z) * a.batch;
-    const int lin = bx + (int)gridDim.x * (by + ny * bz);
+    const int ny = gridDim.y, per = TPG * ny, groups = (a.pf_nz > 0 ? a.pf_first : (a.nz_real > 0 ? a.nz_real : (int)gridDim.z)) * a.batch;
+    const int lin = bx + (int)gridDim.x * (by + ny * bz);       // (bz: the slice among the launch's OWN z-slices)
     const int v = xcd_order(lin, 0, groups, per);
     const int g = v / per, w = v - g * per;
     bz = g / a.batch;
@@ -1032,9 +1066,18 @@ struct ActorMegaArgs {
   float *y1, *y2p, *y3p, *h4;
   unsigned* flags;         // [3] arrivals of conv1 / conv2 / conv3 of THIS env step, zero at launch
   int* timeout_flag;
+  const int* w4_valid;     // optional (DRA_VAR_DEFER_FC4): non-zero once w4 (a parameter copy's fc4 segment) is complete
 };
 constexpr int kMegaC3 = VG3::TPS * (VG3::OC / 32) * 2;
-constexpr int kMegaFc = 512 / 8;
+// fc4 rows per wave of the fused launch: 1 (64 workgroups of 8 rows).  Round 6 measured 2 (32 workgroups of 16 rows, so that the
+// agent-scope read of conv3's planes after the arrival happens half as often per CU): 9.39 against 8.97 us per launch, same
+// rate, same bits (profiles/r06p_*) -- 26 instead of 13 float4 of weights per lane in flight did not stream faster and the
+// 128-register cap cost conv3's role.  DRA_EXP_MEGA_ROWS=2 builds it.
+#ifndef DRA_EXP_MEGA_ROWS
+#define DRA_EXP_MEGA_ROWS 1
+#endif
+constexpr int kMegaRows = DRA_EXP_MEGA_ROWS;
+constexpr int kMegaFc = 512 / (8 * kMegaRows);
 
 // fc4 role of the actor's fused launches: h4[row] = relu(b4[row] + <W4[row], relu(x0 + x1)>), one wave per row, the row's
 // weights requested BEFORE the wait for conv3's two partial planes (same per-lane products and butterfly as
@@ -1042,12 +1085,29 @@ constexpr int kMegaFc = 512 / 8;
 __device__ __forceinline__ void mega_fc4_role(const ActorMegaArgs& m, const int b, float* __restrict__ lds) {
   constexpr int I = VG3::OC * VG3::P, NV = I / 4, R = (NV + 63) / 64;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = b * 8 + wave;
-  const float4* __restrict__ w4 = reinterpret_cast<const float4*>(m.w4 + (int64_t)row * I);
-  float4 wv[R];
+  const int row0 = (b * 8 + wave) * kMegaRows;
+  if (m.w4_valid) {   // the copy's fc4 segment is completed by riders of the update running beside this graph: normally long done
+    if (threadIdx.x == 0) {
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(m.w4_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t0 > kMegaWaitTicks) {
+          if (m.timeout_flag) __hip_atomic_store(m.timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float4 wv[kMegaRows][R];
+  float bias[kMegaRows];
 #pragma unroll
-  for (int q = 0; q < R; ++q) wv[q] = w4[min(lane + 64 * q, NV - 1)];
-  const float bias = m.b4[row];
+  for (int rr = 0; rr < kMegaRows; ++rr) {
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(m.w4 + (int64_t)(row0 + rr) * I);
+#pragma unroll
+    for (int q = 0; q < R; ++q) wv[rr][q] = w4[min(lane + 64 * q, NV - 1)];
+    bias[rr] = m.b4[row0 + rr];
+  }
   __builtin_amdgcn_sched_barrier(0);
   MegaSync ms;
   ms.wait = m.flags + 2; ms.wait_target = kMegaC3; ms.timeout_flag = m.timeout_flag;
@@ -1069,25 +1129,28 @@ __device__ __forceinline__ void mega_fc4_role(const ActorMegaArgs& m, const int 
   }
   __syncthreads();
   const float4* sx = reinterpret_cast<const float4*>(lds);
-  float acc = 0.f;
 #pragma unroll
-  for (int q = 0; q < R; ++q) {
-    float4 a = wv[q];
-    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
-    const float4 x = sx[min(lane + 64 * q, NV - 1)];
-    if (lane + 64 * q < NV) acc += (a.x * x.x + a.y * x.y) + (a.z * x.z + a.w * x.w);
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) {
-    const float v = acc + bias;
-    m.h4[row] = v > 0.f ? v : 0.f;
+  for (int rr = 0; rr < kMegaRows; ++rr) {
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      float4 a = wv[rr][q];
+      asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
+      const float4 x = sx[min(lane + 64 * q, NV - 1)];
+      if (lane + 64 * q < NV) acc += (a.x * x.x + a.y * x.y) + (a.z * x.z + a.w * x.w);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float v = acc + bias[rr];
+      m.h4[row0 + rr] = v > 0.f ? v : 0.f;
+    }
   }
 }
 
 // conv1 and conv2 keep their own launches -- a hand-over through memory costs about what a launch boundary does (stores
 // acknowledged, the arrival count, the poll: ~2.4 us against ~2 us); what pays is fc4's 6.4 MB of weights arriving while
 // conv3 computes.  grid = 8 conv3 workgroups + 64 fc4 workgroups.
-__global__ void __launch_bounds__(512) actor_c3fc4_kernel(const ActorMegaArgs m) {
+__global__ void __launch_bounds__(512, kMegaRows == 2 ? 4 : 1) actor_c3fc4_kernel(const ActorMegaArgs m) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int b = blockIdx.x;
   if (b < kMegaC3) {
@@ -1103,9 +1166,15 @@ __global__ void __launch_bounds__(512) actor_c3fc4_kernel(const ActorMegaArgs m)
 // one launch; flags[2] = conv3's arrival counter, zero at launch.
 int dra_actor_c3fc4(const float* y2_planes, const float* w3, const float* b3, const float* w4, const float* b4, float* y3_planes,
                     float* h4, unsigned* flags, int* timeout_flag, void* stream) {
+  return dra_actor_c3fc4_valid(y2_planes, w3, b3, w4, b4, y3_planes, h4, flags, timeout_flag, nullptr, stream);
+}
+
+int dra_actor_c3fc4_valid(const float* y2_planes, const float* w3, const float* b3, const float* w4, const float* b4, float* y3_planes,
+                          float* h4, unsigned* flags, int* timeout_flag, const int* w4_valid, void* stream) {
   if (!y2_planes || !w3 || !b3 || !w4 || !b4 || !y3_planes || !h4 || !flags || !timeout_flag) return DRA_EINVAL;
   ActorMegaArgs m;
   memset(&m, 0, sizeof(m));
+  m.w4_valid = w4_valid;
   m.w3 = w3; m.b3 = b3; m.w4 = w4; m.b4 = b4;
   m.y2p = const_cast<float*>(y2_planes); m.y3p = y3_planes; m.h4 = h4; m.flags = flags; m.timeout_flag = timeout_flag;
   constexpr size_t img3 = (size_t)(VG3::C / 2) * V2Tile<VG3, 1>::CS * sizeof(float);
@@ -1143,6 +1212,22 @@ static int launch_conv_v2_pt(const ConvV2Args& a, int nz, hipStream_t st) {
     // prefetch workgroup p must run on XCD p mod 8: the slices in front of it hold a multiple of 8 workgroups, 256 threads each
     if (NW != 4 || !ax.xcd_order || (per_z * nz) % 8 != 0) ax.pf_nz = 0;
     else { ax.pf_first = nz; gz = nz + (8 * 14 * ax.pf_nz + per_z - 1) / per_z; }
+  }
+  if (g_rider_next.armed) {   // (dra_conv_attach_rider: riders behind the launch's own slices, and / or the done words)
+    g_rider_next.armed = false;
+    ax.rider_done_pending = g_rider_next.done_pending;
+    ax.rider_done_valid = g_rider_next.done_valid;
+    if (g_rider_next.count > 0) {
+      if (NW != 4) return DRA_EINVAL;           // a rider workgroup is 256 threads
+      const int per_z = T::TPG * a.batch * (G::OC / 32);
+      ax.rider = g_rider_next.rider;
+      ax.rider_first = g_rider_next.first;
+      ax.rider_end = g_rider_next.first + g_rider_next.count;
+      if (ax.pf_nz > 0) return DRA_EINVAL;      // (the prefetch slices count from the launch's own: not combined)
+      ax.nz_real = nz;
+      ax.rider_z = (g_rider_next.count + per_z - 1) / per_z;
+      gz += ax.rider_z;
+    }
   }
   hipLaunchKernelGGL((conv_fwd_v2_kernel<G, U8, PT, NW>), dim3(T::TPG * a.batch, G::OC / 32, gz), dim3(64 * NW), bytes, st, ax);
   DRA_LAUNCH_CHECK();
@@ -1355,6 +1440,7 @@ static int launch_conv_v2(const ConvV2Args& a, int nz, hipStream_t st) {
     g_conv_pt_threshold = e ? atoi(e) : 128;
   }
   if (PTBIG > 1 && g_conv_pt_threshold > 0 && a.batch >= g_conv_pt_threshold && !a.ring_slot) {
+    if (g_rider_next.armed) { g_rider_next.armed = false; return DRA_EINVAL; }   // riders ride in the latency shape only
     // The throughput shapes: persistent pipelined workgroups.  One measured winner per layer is left (the A/B switches
     // DRA_CONV_PERSIST, DRA_CONV1_TP, DRA_CONV1_SEQ, DRA_CONV2_MODE, DRA_CONV3_SEQ of rounds 3-4 are retired; the records are in
     // DESIGN_HISTORY.md section 4 and profiles/r03*_conv_big*, r04*_conv_big*):

@@ -172,6 +172,15 @@ struct dra_dqn_learner {
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
   int only_kernel;                  // >= 0: run_body issues this kernel group alone (dra_dqn_learner_kernel_replay); -1 otherwise
+  // DRA_VAR_DEFER_FC4 (common.h DraFc4Rider): the ring-direct pipelined graphs leave fc4's segment of the optimizer step to rider
+  // workgroups in the NEXT graph's conv1 / conv2 forward launches
+  bool defer;                       // active for this learner (decided at creation)
+  float* defer_dev;                 // device words: [0] clip coefficient (float), [1] pending (int), [2 + q] parameter copy q valid (int)
+  bool defer_host;                  // an issued optimizer launch left the segment pending and no rider graph / flush has been issued since
+  int defer_q;                      // ... and the rotation slot (actor copy) it belongs to
+  int rider_q;                      // >= 0 while run_body captures a graph whose forward launches carry the riders for copy rider_q
+  int64_t defer_begin, defer_count; // the segment (floats)
+  hipEvent_t ev_flush;              // recorded behind a flush (becomes last_done)
   int* timeout_flag;                // pinned host: set by a workgroup whose bounded device-side wait gave up (late_step's arrival
                                     // slots, the actor's in-launch hand-over): every later step / update returns DRA_ETIMEDOUT
   // DRA_VAR_IDX_PREFETCH (ring-direct pipeline): step-tagged copies of the minibatch indices -- pinned (written by the host
@@ -382,6 +391,22 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
     }
   }
   rc |= alloc_f(&l->ah4, 512);
+  l->rider_q = -1;
+  l->defer_begin = cfg->offset[P_W4];
+  l->defer_count = cfg->offset[P_B4] - cfg->offset[P_W4];
+  {
+    const int need = DRA_VAR_DEFER_FC4 | DRA_VAR_RING_DIRECT | DRA_VAR_GATHER_ON_UPDATE | DRA_VAR_ACTOR_PARAMS | DRA_VAR_ACTOR_RING |
+                     DRA_VAR_ACTOR_FUSED_CONV1 | DRA_VAR_ACTOR_MEGA | DRA_VAR_ONESHOT_FWD;
+    l->defer = (l->variant & need) == need && l->late && cfg->head_kind == DRA_HEAD_VANILLA && cfg->optimizer == DRA_OPT_RMSPROP &&
+               !cfg->double_q && cfg->batch > 16 && cfg->batch < 128 &&            // (the forwards' four-wave latency shape)
+               (l->defer_begin & 3) == 0 && (l->defer_count & 3) == 0 && l->defer_count == (int64_t)512 * 3136 &&
+               l->defer_begin >= l->lstride[0];
+  }
+  rc |= (int)hipMalloc(&l->defer_dev, 8 * sizeof(float));
+  if (!rc) {
+    const int init[8] = {0, 0, 1, 1, 1, 1, 0, 0};      // coefficient 0.0f, nothing pending, every copy valid
+    rc |= (int)hipMemcpy(l->defer_dev, init, sizeof(init), hipMemcpyHostToDevice);
+  }
   rc |= (int)hipMalloc(&l->aflags, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
   if (!rc) rc |= (int)hipMemset(l->aflags, 0, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
   if (l->variant & DRA_VAR_ACTOR_PARAMS) { rc |= alloc_f(&l->pa[0], cfg->n_params); rc |= alloc_f(&l->pa[1], cfg->n_params); }
@@ -462,6 +487,7 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= (int)hipEventCreateWithFlags(&l->ev_loss, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_gather_done, hipEventDisableTiming);
   rc |= (int)hipEventCreateWithFlags(&l->ev_step_done, hipEventDisableTiming);
+  rc |= (int)hipEventCreateWithFlags(&l->ev_flush, hipEventDisableTiming);
   for (int g = 0; g < 2; ++g) {
     rc |= (int)hipEventCreateWithFlags(&l->ev_mb_ready[g], hipEventDisableTiming);
     rc |= (int)hipEventCreateWithFlags(&l->ev_mb_free[g], hipEventDisableTiming);
@@ -496,6 +522,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   for (auto& ga : l->g_actor) if (ga.ready) (void)hipGraphExecDestroy(ga.exec);
   for (int k = 0; k < 4; ++k) if (l->pa[k]) (void)hipFree(l->pa[k]);
   if (l->ah4) (void)hipFree(l->ah4);
+  if (l->defer_dev) (void)hipFree(l->defer_dev);
   if (l->aflags) (void)hipFree(l->aflags);
   if (l->aring_dev) {
     (void)hipFree(l->aring_dev); (void)hipHostFree(l->aring_stage); (void)hipFree(l->aring_seq);
@@ -553,7 +580,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   (void)hipStreamDestroy(l->side);
   (void)hipEventDestroy(l->ev_fork);
   for (int k = 0; k < 4; ++k) (void)hipEventDestroy(l->ev_join[k]);
-  (void)hipEventDestroy(l->ev_actor_done); (void)hipEventDestroy(l->ev_gather_done); (void)hipEventDestroy(l->ev_step_done);
+  (void)hipEventDestroy(l->ev_actor_done); (void)hipEventDestroy(l->ev_gather_done); (void)hipEventDestroy(l->ev_step_done); (void)hipEventDestroy(l->ev_flush);
   (void)hipEventDestroy(l->ev_loss);
   delete l;
   return DRA_OK;
@@ -574,6 +601,7 @@ DRA_API int dra_dqn_learner_resume_buffer_count(void) { return (int)(sizeof(kRes
 
 DRA_API int dra_dqn_learner_resume_buffer(dra_dqn_learner* l, int index, void** ptr, int64_t* bytes, char* name, int name_len) {
   if (!l || !ptr || !bytes || index < 0 || index >= (int)(sizeof(kResumeNames) / sizeof(kResumeNames[0]))) return DRA_EINVAL;
+  if (l->defer_host) return DRA_EINVAL;   // (DRA_VAR_DEFER_FC4: dra_dqn_learner_flush + a synchronise first -- a pending fc4 segment is not a state to save)
   void* p = nullptr;
   int64_t n = 0;
   const int64_t pbytes = (int64_t)l->c.n_params * (int64_t)sizeof(float);
@@ -596,6 +624,7 @@ DRA_API int dra_dqn_learner_resume_buffer(dra_dqn_learner* l, int index, void** 
 
 DRA_API int dra_dqn_learner_resume_counters(dra_dqn_learner* l, int64_t* io, int n, int restore) {
   if (!l || !io || n < 16) return DRA_EINVAL;
+  if (l->defer_host) return DRA_EINVAL;   // (DRA_VAR_DEFER_FC4: dra_dqn_learner_flush + a synchronise first -- a pending fc4 segment is not a state to save)
   if (!restore) {
     memset(io, 0, (size_t)n * sizeof(int64_t));
     io[0] = l->step_no; io[1] = l->pa_cur; io[2] = l->pa_valid ? 1 : 0; io[3] = (int64_t)l->aring_pushed;
@@ -1013,13 +1042,26 @@ static void conv_fold_segs(const dra_dqn_learner* l, dra_fold_seg segs[3]) {
   }
 }
 
-static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = nullptr) {
+// share of the rider blocks in conv1's forward launch (the rest rides in conv2's): conv1 is the longer launch
+#ifndef DRA_EXP_RIDER_CONV1_PCT
+#define DRA_EXP_RIDER_CONV1_PCT 57
+#endif
+constexpr int kRiderConv1Pct = DRA_EXP_RIDER_CONV1_PCT;
+static int* defer_pending_word(const dra_dqn_learner* l) { return reinterpret_cast<int*>(l->defer_dev) + 1; }
+static int* defer_valid_word(const dra_dqn_learner* l, int q) { return reinterpret_cast<int*>(l->defer_dev) + 2 + (q & 3); }
+
+// defer_q >= 0 (DRA_VAR_DEFER_FC4): fc4's segment is left to the riders of the next graph; the launch marks copy defer_q incomplete
+static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = nullptr, int defer_q = -1) {
   const dra_dqn_config& c = l->c;
   if (l->late) {
     dra_fold_seg segs[3];
     conv_fold_segs(l, segs);
     const bool adam = c.optimizer == DRA_OPT_ADAM;
     const float hyper[4] = {c.lr, adam ? c.beta1 : c.alpha, c.eps, adam ? c.beta2 : 0.f};
+    if (defer_q >= 0)
+      return dra_clip_step_late_defer(l->p, l->g, l->s1, l->s2, c.n_params, &segs[0], l->partials, l->late_nprior, l->timeout_flag,
+                                      c.gradient_clip, hyper, c.centered, l->norm, p_copy, l->defer_begin, l->defer_count,
+                                      l->defer_dev, defer_pending_word(l), defer_valid_word(l, defer_q), (void*)st);
     return dra_clip_step_late(l->p, l->g, l->s1, l->s2, c.n_params, &segs[0], l->partials, l->late_nprior,
                               l->timeout_flag, c.optimizer, c.gradient_clip, hyper, c.centered, l->opt_step, l->norm, p_copy,
                               (void*)st);
@@ -1029,6 +1071,43 @@ static int launch_optimizer(dra_dqn_learner* l, hipStream_t st, float* p_copy = 
                                  c.beta1, c.beta2, c.eps, l->opt_step, l->norm, p_copy, (void*)st);
   return dra_rmsprop_step_copy(l->p, l->g, l->s1, l->s2, c.n_params, l->partials, l->n_partials, c.gradient_clip,
                                c.lr, c.alpha, c.eps, c.centered, l->norm, p_copy, (void*)st);
+}
+
+static DraFc4Rider fc4_rider(const dra_dqn_learner* l, float* p_copy) {
+  DraFc4Rider r;
+  memset(&r, 0, sizeof(r));
+  r.p = l->p; r.g = l->g; r.s1 = l->s1; r.s2 = l->s2; r.p_copy = p_copy;
+  r.begin4 = l->defer_begin >> 2; r.count4 = l->defer_count >> 2;
+  r.coef = l->defer_dev; r.pending = defer_pending_word(l);
+  r.lr = l->c.lr; r.alpha = l->c.alpha; r.eps = l->c.eps; r.centered = l->c.centered;
+  return r;
+}
+
+__global__ void __launch_bounds__(256) fc4_flush_kernel(const DraFc4Rider r) { fc4_rider_run(r, (int)blockIdx.x); }
+__global__ void fc4_flush_done_kernel(int* pending, int* valid) {
+  __hip_atomic_store(pending, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(valid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The deferred fc4 segment stepped NOW, on `st` (ordered behind the optimizer launch that left it: `st` waits for last_done):
+// in front of everything that reads the parameters, the optimizer state or an actor copy outside the pipelined ring-direct graphs.
+static int flush_fc4(dra_dqn_learner* l, hipStream_t st) {
+  if (!l->defer_host) return DRA_OK;
+  if (l->last_done) DRA_HIP(hipStreamWaitEvent(st, l->last_done, 0));
+  const DraFc4Rider r = fc4_rider(l, l->pa[l->defer_q & 3]);
+  hipLaunchKernelGGL(fc4_flush_kernel, dim3(fc4_rider_blocks(r.count4)), dim3(256), 0, st, r);
+  DRA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(fc4_flush_done_kernel, dim3(1), dim3(1), 0, st, defer_pending_word(l), defer_valid_word(l, l->defer_q));
+  DRA_LAUNCH_CHECK();
+  DRA_HIP(hipEventRecord(l->ev_flush, st));     // whoever waits for "the last optimizer step" now waits for this
+  l->last_done = l->ev_flush;
+  l->defer_host = false;
+  return DRA_OK;
+}
+
+DRA_API int dra_dqn_learner_flush(dra_dqn_learner* l, void* stream) {
+  if (!l) return DRA_EINVAL;
+  return flush_fc4(l, dra_stream(stream));
 }
 
 // Head + loss + head input-gradient for the distributional heads (everything head_fused_kernel does for VanillaNet):
@@ -1126,6 +1205,11 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     // (PER drawn on the device: the previous update's chain kernel left them in device memory)
     const bool dev_idx = per && l->per2_dev;
     const bool pf = (l->variant & DRA_VAR_IDX_PREFETCH) && !dev_idx;
+    if (l->rider_q >= 0 && l->only_kernel < 0) {   // first half of the deferred fc4 segment rides here (common.h DraFc4Rider)
+      const DraFc4Rider r = fc4_rider(l, l->pa[l->rider_q]);
+      const int nb = fc4_rider_blocks(r.count4);
+      dra_conv_attach_rider(&r, 0, (nb * kRiderConv1Pct) / 100, nullptr, nullptr);
+    }
     STEP(K_CONV1_F, dra_conv1_fwd_koc_ringbatch(ring_frames, dev_idx ? l->per2_idx + (size_t)l->rd_slot * 1024 : l->idx_pin[l->rd_slot], l->idx,
                                                 pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr,
                                                 off, nz, w1, b1, l->y1, B, c.u8_coef, DRA_ACT_RELU, s));
@@ -1135,6 +1219,11 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   const void* x2[3] = {l->y1[0], l->y1[1], l->y1[2]};
   const float* w2[3] = {P + o[P_W2], T + o[P_W2], P + o[P_W2]};
   const float* b2[3] = {P + o[P_B2], T + o[P_B2], P + o[P_B2]};
+  if (rd && l->rider_q >= 0 && l->only_kernel < 0) {   // ... the second half here
+    const DraFc4Rider r = fc4_rider(l, l->pa[l->rider_q]);
+    const int nb = fc4_rider_blocks(r.count4);
+    dra_conv_attach_rider(&r, (nb * kRiderConv1Pct) / 100, nb - (nb * kRiderConv1Pct) / 100, nullptr, nullptr);
+  }
   STEP(K_CONV2_F, dra_conv_fwd_koc(2, nz, x2, w2, b2, l->y2, B, 0, 1.0, DRA_ACT_RELU, s));
   const void* x3[3] = {l->y2[0], l->y2[1], l->y2[2]};
   const float* w3[3] = {P + o[P_W3], T + o[P_W3], P + o[P_W3]};
@@ -1144,6 +1233,9 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   const int ks4 = fc4_ks(l);
   // fc4's forward weights are prefetched into the L2 of the XCD that will stream them, by spare workgroups of conv3's forward
   // launch (conv_v2.hip fc4_weight_prefetch; same box: fc4_fwd 10.9 -> 9.95 us, conv3_fwd +1.0 us, +0.5-0.8 % updates/s)
+  // ... and the launch after the riders' lowers `pending` and marks the actor copy they completed valid
+  if (rd && l->rider_q >= 0 && l->only_kernel < 0)
+    dra_conv_attach_rider(nullptr, 0, 0, defer_pending_word(l), defer_valid_word(l, l->rider_q));
   if ((l->variant & DRA_VAR_ONESHOT_FWD) && ks4 == kFc4SplitMid && nz == 2 && B <= 32)
     STEP(K_CONV3_F, dra_conv3_fwd_koc_pf(nz, x3, w3, b3, l->y3, B, DRA_ACT_RELU, w4, nz, s));
   else
@@ -1355,8 +1447,13 @@ static int capture_part(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int 
   l->rd_slot = rd ? q : -1;
   hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
   if (b != hipSuccess) { l->gb = 0; l->rd_slot = -1; return (int)b; }
+  // DRA_VAR_DEFER_FC4: this graph's forwards carry the riders that finish update q - 1's optimizer step (its copy: slot q + 3),
+  // and its own optimizer launch leaves fc4's segment to the next graph
+  const bool defer = rd && l->defer && !per && part == 0 && with_optimizer;
+  l->rider_q = defer ? ((q + 3) & 3) : -1;
   int rc = run_body(l, st, per, per ? -1.f : 0.f, 0, part);     // PER: the exponent is read from sampling_prob[B]
-  if (rc == DRA_OK && with_optimizer) rc = launch_optimizer(l, st, l->pa[q]);
+  l->rider_q = -1;
+  if (rc == DRA_OK && with_optimizer) rc = launch_optimizer(l, st, l->pa[q], defer ? q : -1);
   hipError_t e = hipStreamEndCapture(st, &graph);
   l->gb = 0;
   l->rd_slot = -1;
@@ -1426,7 +1523,15 @@ static int update_graph(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int 
     }
     *ready = true;
   }
+  // DRA_VAR_DEFER_FC4: a pending fc4 segment is completed by THIS graph's riders only if it is the previous rotation slot's and
+  // this is a riding graph; anything else steps it first
+  const bool riding = rd && l->defer && !per;
+  if (l->defer_host && !(riding && l->defer_q == ((q + 3) & 3))) {
+    int rcf = flush_fc4(l, st);
+    if (rcf) return rcf;
+  }
   DRA_HIP(hipGraphLaunch(*exec, st));
+  if (riding) { l->defer_host = true; l->defer_q = q; }
   if (per && !(l->per2_dev && l->per_tree)) {
     DRA_HIP(hipEventRecord(l->ev_loss, st));
     DRA_HIP(hipGraphLaunch(*exec_b, st));
@@ -1538,6 +1643,7 @@ DRA_API int dra_dqn_learner_keep_minibatch(dra_dqn_learner* l, int keep) {
 DRA_API int dra_dqn_learner_update(dra_dqn_learner* l, int use_graph, int per, float beta, void* stream) {
   if (!l) return DRA_EINVAL;
   if (*l->timeout_flag) return DRA_ETIMEDOUT;
+  if (int rcf = flush_fc4(l, dra_stream(stream))) return rcf;   // (DRA_VAR_DEFER_FC4: nothing outside the riding graphs sees a half-stepped fc4)
   hipStream_t st = dra_stream(stream);
   l->profiling = false;
   l->pa_valid = false;
@@ -1555,6 +1661,7 @@ DRA_API int dra_dqn_learner_update(dra_dqn_learner* l, int use_graph, int per, f
 // per-group milliseconds of THIS update.  Synchronises: measurement aid, not the hot path.
 DRA_API int dra_dqn_learner_profile(dra_dqn_learner* l, float* out_ms, int n_out, void* stream) {
   if (!l || !out_ms || n_out < K_COUNT) return DRA_EINVAL;
+  if (int rcf = flush_fc4(l, dra_stream(stream))) return rcf;   // (DRA_VAR_DEFER_FC4: nothing outside the riding graphs sees a half-stepped fc4)
   hipStream_t st = dra_stream(stream);
   l->profiling = true;
   l->pa_valid = false;   // the parameters change behind the async actor's copies
@@ -1596,6 +1703,7 @@ __global__ void __launch_bounds__(256) empty_probe_kernel(const int* p) { if (p 
 // (the optimizer) and groups the variant does not launch are refused.  Synchronises.
 DRA_API int dra_dqn_learner_kernel_replay(dra_dqn_learner* l, int kernel, int reps, float* out_us, void* stream) {
   if (!l || !out_us || reps < 1 || reps > 4096) return DRA_EINVAL;
+  if (int rcf = flush_fc4(l, dra_stream(stream))) return rcf;   // (DRA_VAR_DEFER_FC4: nothing outside the riding graphs sees a half-stepped fc4)
   if (kernel <= K_GATHER || kernel >= K_NORM) return DRA_EINVAL;
   if (!(l->variant & (DRA_VAR_FUSED_BWD | DRA_VAR_ONESHOT_WGRAD)) || !l->late) return DRA_EINVAL;   // (the default chain's groups)
   if (kernel == K_HEAD_BW || kernel == K_FC4_BW || kernel == K_CONV3_BW || kernel == K_CONV2_BW) return DRA_EINVAL;  // ride in *_BX
@@ -1682,6 +1790,7 @@ DRA_API int dra_dqn_learner_kernel_count(void) { return K_COUNT; }
 
 DRA_API int dra_dqn_learner_sync_target(dra_dqn_learner* l, void* stream) {
   if (!l) return DRA_EINVAL;
+  if (int rcf = flush_fc4(l, dra_stream(stream))) return rcf;   // (DRA_VAR_DEFER_FC4: nothing outside the riding graphs sees a half-stepped fc4)
   return dra_copy_f32(l->pt, l->p, l->c.n_params, stream);
 }
 
@@ -2132,6 +2241,7 @@ static int q_mail_wait(dra_dqn_learner* l, unsigned want, float* q_host) {
 // 34 us (profiles/r04g_prof_host_async_before.txt, r04h_prof_host_async.txt; the agent: 2.5 k -> 3.3 k updates/s).
 DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host, float* q_host, void* stream) {
   if (!l || !state_host || !q_host) return DRA_EINVAL;
+  if (int rcf = flush_fc4(l, dra_stream(stream))) return rcf;   // (DRA_VAR_DEFER_FC4: nothing outside the riding graphs sees a half-stepped fc4)
   hipStream_t st = dra_stream(stream);
   const dra_dqn_config& c = l->c;
   memcpy(l->qs_stage, state_host, (size_t)4 * 7056);         // (mapped, coherent: conv1 reads it in place)
@@ -2179,6 +2289,7 @@ DRA_API int dra_dqn_learner_q_host(dra_dqn_learner* l, const uint8_t* state_host
 DRA_API int dra_dqn_learner_update_async(dra_dqn_learner* l, int use_graph, int per, float beta, void* stream_update) {
   if (!l || !l->pa[0] || !l->pa[1]) return DRA_EINVAL;
   if (*l->timeout_flag) return DRA_ETIMEDOUT;
+  if (int rcf = flush_fc4(l, dra_stream(stream_update))) return rcf;   // (DRA_VAR_DEFER_FC4: nothing outside the riding graphs sees a half-stepped fc4)
   hipStream_t st = dra_stream(stream_update);
   l->profiling = false;
   l->pa_valid = false;
@@ -2199,6 +2310,7 @@ DRA_API int dra_dqn_learner_update_async(dra_dqn_learner* l, int use_graph, int 
 DRA_API int dra_dqn_learner_q_host_async(dra_dqn_learner* l, const uint8_t* state_host, float* q_host, void* stream_actor,
                                          void* stream_update) {
   if (!l || !state_host || !q_host || !l->pa[0] || !l->pa[1]) return DRA_EINVAL;
+  if (int rcf = flush_fc4(l, dra_stream(stream_update))) return rcf;   // (DRA_VAR_DEFER_FC4: nothing outside the riding graphs sees a half-stepped fc4)
   hipStream_t st = dra_stream(stream_actor);
   const dra_dqn_config& c = l->c;
   // copy the newest COMPLETED-BY-ORDER update wrote: update (hq_updates - 2) while update (hq_updates - 1) may still run
@@ -2377,8 +2489,13 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
                                           DRA_ACT_RELU, &f, s)))
         return rc;
       if ((rc = dra_conv_b1_split(2, l->ay1, nullptr, P + o[P_W2], P + o[P_B2], l->ay2p, s))) return rc;
-      if ((rc = dra_actor_c3fc4(l->ay2p, P + o[P_W3], P + o[P_B3], P + o[P_W4], P + o[P_B4], l->ay3p, l->ah4, l->aflags + 4 * e,
-                                l->timeout_flag, s)))
+      // (DRA_VAR_DEFER_FC4: the first env step's fc4 waits for the word that says copy P's fc4 segment is complete)
+      const int* w4_valid = nullptr;
+      if (e == 0 && l->defer)
+        for (int k = 0; k < 4; ++k)
+          if (P == l->pa[k] && l->pa[k]) w4_valid = defer_valid_word(l, k);
+      if ((rc = dra_actor_c3fc4_valid(l->ay2p, P + o[P_W3], P + o[P_B3], P + o[P_W4], P + o[P_B4], l->ay3p, l->ah4, l->aflags + 4 * e,
+                                      l->timeout_flag, w4_valid, s)))
         return rc;
       if (dist) {
         hipLaunchKernelGGL(actor_dist_gemv_kernel, dim3((l->n_out + 3) / 4), dim3(256), 0, st, (const float*)l->ah4, P + o[P_WH],
@@ -2794,6 +2911,14 @@ static int step_pipelined3(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
   const int q = (int)(l->step_no & 3), qr = (q + 3) & 3;
   const int par = q & 1;           // minibatch buffers alternate
   int rc;
+  // DRA_VAR_DEFER_FC4: a pending fc4 segment stays pending only if this call issues the riding graph that completes it (a plain
+  // ring-direct update, the actor copies in phase with the rotation); every other call steps it first -- before `opt_prev` is
+  // read: the actor launch below then waits for the flush
+  if (l->defer_host && phase != 2) {
+    const bool riding = do_update && phase == 0 && l->defer && !l->step_per && (l->variant & DRA_VAR_RING_DIRECT) &&
+                        l->defer_q == qr && (prm->n_env <= 0 || (l->pa_valid && l->pa_cur == qr));
+    if (!riding && (rc = flush_fc4(l, su))) return rc;
+  }
   hipEvent_t opt_prev = phase == 2 ? l->split_opt_prev : l->last_done;   // optimizer of step t-1: produced the copy the actor graph below reads
   // the block the actor graph issued by THIS call consumes: with the parameter ring that is the next un-issued ring entry
   // (pushed up to 16 agent steps ahead; `prm` then only carries n_env and the minibatch indices)
@@ -3031,6 +3156,7 @@ static int stage_acquire(dra_dqn_learner* l, int* k_out) {
 // Actor only: runs prm->n_env environment transitions on `stream` (graph replay).
 DRA_API int dra_dqn_learner_act(dra_dqn_learner* l, const dra_dqn_step_params* prm, int use_graph, void* stream) {
   if (!l || !prm || prm->n_env < 1 || prm->n_env > kMaxEnvSteps) return DRA_EINVAL;
+  if (int rcf = flush_fc4(l, dra_stream(stream))) return rcf;   // (DRA_VAR_DEFER_FC4: nothing outside the riding graphs sees a half-stepped fc4)
   hipStream_t st = dra_stream(stream);
   int k;
   int rc = stage_acquire(l, &k);
@@ -3169,6 +3295,11 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
   const int B = l->c.batch;
   l->profiling = false;
   int k, rc;
+  {   // DRA_VAR_DEFER_FC4: only step_pipelined3 may leave a segment pending across calls (it decides for itself)
+    const bool p3 = stream_actor && (l->variant & DRA_VAR_PIPE_GATHER) && (l->variant & DRA_VAR_ACTOR_PARAMS) &&
+                    (l->variant & DRA_VAR_GATHER_ON_UPDATE) && !((l->variant & DRA_VAR_GATHER_IN_GRAPH) && !(l->variant & DRA_VAR_ACTOR_V3));
+    if (!p3 && (rc = flush_fc4(l, su))) return rc;
+  }
   if ((rc = stage_acquire(l, &k))) return rc;
   memcpy(&l->prm_stage[k], prm, kPrmHeadBytes);
   memcpy(l->idx_stage + (size_t)k * 1024, prm->idx, (size_t)B * sizeof(int64_t));

@@ -110,19 +110,7 @@ __device__ __forceinline__ float clip_coef_from_partials(const double* __restric
 // ran as 1280 + 367 on 160 CUs (phase trace, profiles/r02a_phase_async.json: span 11.0 us for 6.0 us workgroups).
 constexpr int kStepNV = 2;
 
-__device__ __forceinline__ void rmsprop_elem(float& p, float g, float& s, float& a, float coef, float alpha, float oma,
-                                             float lr, float eps, int centered) {
-  const float gk = g * coef;
-  s = s * alpha + oma * gk * gk;
-  float avg;
-  if (centered) {
-    a = a * alpha + oma * gk;
-    avg = sqrtf(s - a * a) + eps;
-  } else {
-    avg = sqrtf(s) + eps;
-  }
-  p = p - lr * (gk / avg);
-}
+// (rmsprop_elem: common.h -- shared with the deferred fc4 segment's riders)
 
 // ---- segmented fold + norm --------------------------------------------------------------------------------------------
 // The one-pass conv weight gradients write one slab per (sample, row chunk): 32-160 slabs per layer.  This launch folds
@@ -359,6 +347,12 @@ struct LatePlan {
   const float4* slabs;
   int64_t stride4;
   int32_t n_slabs, fold_blocks, n_prior;   // n_prior: partials already written by earlier launches ([0, n_prior))
+  // DRA_VAR_DEFER_FC4 (common.h DraFc4Rider): float4s [skip_begin4, skip_begin4 + skip_count4) are NOT stepped by this launch;
+  // it leaves the clip coefficient in *defer_coef, raises *defer_pending and clears *defer_valid instead (all null = off)
+  int64_t skip_begin4, skip_count4;
+  float* defer_coef;
+  int* defer_pending;
+  int* defer_valid;
 };
 constexpr int kLateMaxFoldBlocks = 256;    // one polling thread per fold workgroup
 constexpr int kLateNV = 3;                 // float4 per thread of a plain workgroup: with the fold workgroups the grid stays
@@ -473,7 +467,8 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
     const int64_t i0 = lp.fold_count4 + (int64_t)(bid - lp.fold_blocks) * (256 * kStepNV) + tid;
 #pragma unroll
     for (int v = 0; v < kStepNV; ++v) {
-      const int64_t i = i0 + 256 * v;
+      int64_t i = i0 + 256 * v;
+      if (i >= lp.skip_begin4) i += lp.skip_count4;       // (the deferred segment: skip_count4 = 0 when nothing is deferred)
       const int64_t ic = i < lp.n4 ? i : lp.n4 - 1;
       P[v] = p4[ic]; G[v] = g4[ic]; S[v] = s14[ic]; A[v] = s24[ic];
       if (i < lp.n4) gi[v] = i;
@@ -491,6 +486,11 @@ late_step_kernel(float* __restrict__ grad, const LatePlan lp, double* __restrict
   for (int u = 0; u < NPT; ++u) pre += (tid + 256 * u < lp.n_prior) ? pv[u] : 0.0;
   DRA_STAMP(TR_STEP, 2);
   const float coef = late_clip_coef(pre, partials, lp.n_prior, lp.fold_blocks, hp.max_norm, out_norm, timeout_flag);
+  if (lp.defer_coef && bid == 0 && tid == 0) {   // hand the deferred segment over: coefficient, pending, the copy it will complete
+    *lp.defer_coef = coef;
+    __hip_atomic_store(lp.defer_pending, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(lp.defer_valid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   [[maybe_unused]] const float oma = 1.f - hp.a, omb2 = 1.f - hp.b2;
   [[maybe_unused]] const float step_size = s_hyper[0], inv_sqrt_bc2 = s_hyper[1];
   // (Round 4 measured a SECOND run per plain workgroup whose loads were issued here, behind the wait for the coefficient, to
@@ -557,9 +557,10 @@ DRA_API int dra_clip_step_late_blocks(const dra_fold_seg* seg, int* fold_blocks)
 // seg: the ONE segment still in slabs (must start at element 0 of the flat gradient, n_slabs <= 256, at most 256 fold
 // workgroups); partials[0, n_prior) were written by earlier launches, partials[n_prior, n_prior + fold_blocks) must hold -1.0
 // at launch and receive this launch's published sums; timeout_flag: pinned host int.  optimizer: DRA_OPT_RMSPROP (hyper = {lr, alpha, eps, -}) or DRA_OPT_ADAM ({lr, beta1, eps, beta2}, step count read from step_dev).
-DRA_API int dra_clip_step_late(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* seg,
+static int clip_step_late_impl(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* seg,
                                double* partials, int n_prior, int* timeout_flag, int optimizer, float max_norm,
                                const float* hyper, int centered, const int64_t* step_dev, float* out_norm, float* param_copy,
+                               int64_t skip_begin, int64_t skip_count, float* defer_coef, int* defer_pending, int* defer_valid,
                                void* stream) {
   if (!param || !grad || !state1 || !seg || !partials || !timeout_flag || !hyper) return DRA_EINVAL;
   if (optimizer != DRA_OPT_RMSPROP && optimizer != DRA_OPT_ADAM) return DRA_EINVAL;
@@ -577,7 +578,15 @@ DRA_API int dra_clip_step_late(float* param, float* grad, float* state1, float* 
   lp.stride4 = seg->slab_stride >> 2; lp.n_slabs = seg->n_slabs; lp.n_prior = n_prior;
   lp.fold_blocks = fold_blocks;
   if (lp.n_prior + lp.fold_blocks > dra_norm_partials_max()) return DRA_EINVAL;
-  const int64_t plain = (lp.n4 - lp.fold_count4 + 256 * kLateNV - 1) / (256 * kLateNV);
+  lp.skip_begin4 = lp.n4; lp.skip_count4 = 0;        // (nothing skipped: no index reaches n4)
+  if (skip_count > 0) {
+    if ((skip_begin & 3) || (skip_count & 3) || skip_begin < seg->count || skip_begin + skip_count > (n & ~(int64_t)3) || !defer_coef ||
+        !defer_pending || !defer_valid || optimizer != DRA_OPT_RMSPROP)
+      return DRA_EINVAL;
+    lp.skip_begin4 = skip_begin >> 2; lp.skip_count4 = skip_count >> 2;
+    lp.defer_coef = defer_coef; lp.defer_pending = defer_pending; lp.defer_valid = defer_valid;
+  }
+  const int64_t plain = (lp.n4 - lp.fold_count4 - lp.skip_count4 + 256 * kLateNV - 1) / (256 * kLateNV);
   const int64_t blocks = lp.fold_blocks + plain;
   if (blocks > 0x7fffffff) return DRA_EINVAL;
   StepHyper hp;
@@ -595,6 +604,25 @@ DRA_API int dra_clip_step_late(float* param, float* grad, float* state1, float* 
 #undef DRA_LATE_LAUNCH
   DRA_LAUNCH_CHECK();
   return DRA_OK;
+}
+
+DRA_API int dra_clip_step_late(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* seg,
+                               double* partials, int n_prior, int* timeout_flag, int optimizer, float max_norm,
+                               const float* hyper, int centered, const int64_t* step_dev, float* out_norm, float* param_copy,
+                               void* stream) {
+  return clip_step_late_impl(param, grad, state1, state2, n, seg, partials, n_prior, timeout_flag, optimizer, max_norm, hyper,
+                             centered, step_dev, out_norm, param_copy, 0, 0, nullptr, nullptr, nullptr, stream);
+}
+
+// Library-internal (common.h DraFc4Rider): the same launch with floats [skip_begin, skip_begin + skip_count) left for the riders
+// (RMSprop only; both multiples of 4, behind the folded segment).
+int dra_clip_step_late_defer(float* param, float* grad, float* state1, float* state2, int64_t n, const dra_fold_seg* seg,
+                             double* partials, int n_prior, int* timeout_flag, float max_norm, const float* hyper, int centered,
+                             float* out_norm, float* param_copy, int64_t skip_begin, int64_t skip_count, float* defer_coef,
+                             int* defer_pending, int* defer_valid, void* stream) {
+  return clip_step_late_impl(param, grad, state1, state2, n, seg, partials, n_prior, timeout_flag, DRA_OPT_RMSPROP, max_norm, hyper,
+                             centered, nullptr, out_norm, param_copy, skip_begin, skip_count, defer_coef, defer_pending, defer_valid,
+                             stream);
 }
 
 // (Round 2 measured non-temporal loads / stores of the gradient and the optimizer state here, meant to keep the actor's parameter

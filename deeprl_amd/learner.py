@@ -362,6 +362,9 @@ class DQNLearner:
         raise DraError("kernel_replay: no kernel group named %r" % (name,))
 
     def synchronize(self):
+        # (DRA_VAR_DEFER_FC4: a pending fc4 segment of the last optimizer step is completed first -- after this call the
+        # parameters, the optimizer state and the actor copies are what optimizer.step() of DQN_agent.py:133 left)
+        lib.dra_dqn_learner_flush(self.h, self._sp())
         self.stream.synchronize()
         self.actor_stream.synchronize()
 

@@ -449,7 +449,8 @@ VAR_RING_DIRECT = 32768
 VAR_IDX_PREFETCH = 131072
 VAR_LATE_FOLD = 524288
 VAR_ACTOR_MEGA = 1048576
-VAR_ALL = 2097151
+VAR_DEFER_FC4 = 8388608       # fc4's segment of the optimizer step rides in the next update's forward launches
+VAR_ALL = 2097151 | 8388608
 
 
 def set_tuning(mask):

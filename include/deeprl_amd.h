@@ -313,6 +313,12 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
 #define DRA_VAR_MEASURE_DGRAD_ONLY 2097152 /* measurement aid (tools/conv_big_bwd.py): dra_conv_bwd_fused launches ONLY the
                                           * input-gradient role -- the weight-gradient slabs are NOT written */
 #define DRA_VAR_MEASURE_WGRAD_ONLY 4194304 /* ... ONLY the weight-gradient role -- dx is NOT written */
+#define DRA_VAR_DEFER_FC4 8388608 /* learner (RING_DIRECT + LATE_FOLD + ACTOR_MEGA, VanillaNet + RMSprop): the optimizer launch of the
+                                   * pipelined graphs steps everything but fc4's weights (95 % of the parameters, 51 of its 54 MB);
+                                   * that segment is stepped by rider workgroups in the NEXT update's conv1 / conv2 forward
+                                   * launches -- nothing reads it before that graph's fc4 forward, the actor's copy of it is guarded
+                                   * by a device word -- with the same arithmetic (same bits).  dra_dqn_learner_flush steps a
+                                   * pending segment at once; every entry that reads parameters outside those graphs does so itself */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
@@ -485,6 +491,10 @@ int dra_dqn_learner_wait_loss(dra_dqn_learner* learner, void* stream);
  * (dra_dqn_learner_kernel_count groups, names from _kernel_name).  With n_out > count, out_ms[count] = the same event pair
  * with NOTHING in between (the bracket's own cost, to be subtracted).  Synchronises. */
 int dra_dqn_learner_profile(dra_dqn_learner* learner, float* out_ms, int n_out, void* stream);
+/* DRA_VAR_DEFER_FC4: step a pending fc4 segment of the optimizer step now, on `stream` (ordered behind the update that left it).
+ * Call before reading parameters / optimizer state / actor copies from outside the library (a synchronise alone does not
+ * complete the step); a no-op when nothing is pending.  DQN_agent.py:133 (optimizer.step() is ONE call in the reference). */
+int dra_dqn_learner_flush(dra_dqn_learner* learner, void* stream);
 /* measurement aid: kernel group `kernel` (index as in _kernel_name) of the update ALONE, `reps` dependent launches in ONE
  * captured graph between two events: out_us[0] = microseconds per launch (kernel + one in-graph launch boundary), out_us[1] =
  * the same for an empty kernel (the boundary alone).  Their difference is the kernel's own duration -- the quantity rocprofv3

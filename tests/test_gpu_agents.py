@@ -1440,3 +1440,42 @@ def test_kernel_replay_measures_without_side_effects(dra):
         b.learner.close()
         b.ring.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_deferred_fc4_step_is_bit_identical(dra):
+    """DRA_VAR_DEFER_FC4 (round 6): the pipelined graphs' optimizer launch leaves fc4's weights (95 % of the parameters) to rider
+    workgroups in the NEXT update's conv1 / conv2 forward launches; the actor's copy of them is guarded by a device word, and
+    everything that reads parameters outside those graphs flushes first.  Same arithmetic, hence the same bits: the benchmarked
+    pipeline with the bit set and cleared ends on identical parameters, optimizer state, ring contents and target network --
+    also when one of the runs is interrupted by synchronise() (a flush), a target sync and kernel replays in the middle."""
+    d = dra
+    from deeprl_amd import ops
+    from deeprl_amd.learner import DQNLearnerBench
+    default = ops.get_tuning()
+    assert default & ops.VAR_DEFER_FC4, "the library default carries DRA_VAR_DEFER_FC4"
+    outs = []
+    for variant, interrupt in ((default & ~ops.VAR_DEFER_FC4, False), (default, False), (default, True)):
+        np.random.seed(11)
+        torch.manual_seed(12)
+        b = DQNLearnerBench(ring_capacity=4096, batch=32, seed=13, actor=True, async_actor=True, variant=variant)
+        L = b.learner
+        for t in range(30):
+            b.step()
+            if t == 14:
+                L.sync_target()                       # DQN_agent.py:136-138 in the middle of the pipeline
+            if interrupt and t in (7, 8, 21):
+                L.synchronize()                       # a flush between two riding graphs
+            if interrupt and t == 19:
+                L.kernel_replay("conv2_bwd_x", 4)
+        L.synchronize()
+        frames = d.ops._wrap_device_pointer(b.ring.pointers()[0], 200 * 7056, torch.uint8).cpu().numpy().copy()
+        acts = d.ops._wrap_device_pointer(b.ring.pointers()[1], 200, torch.int64).cpu().numpy().copy()
+        outs.append(dict(p=L.flat.flat.detach().cpu().numpy().copy(), s1=L.state1.detach().cpu().numpy().copy(),
+                         s2=L.state2.detach().cpu().numpy().copy(), pt=L.target_flat.flat.detach().cpu().numpy().copy(),
+                         frames=frames, acts=acts))
+        L.close()
+        b.ring.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), ("defer on vs off", k)
+        assert np.array_equal(outs[1][k], outs[2][k]), ("interrupted vs not", k)
+    assert float(np.abs(outs[0]["p"]).max()) > 0
