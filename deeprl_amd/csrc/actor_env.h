@@ -170,3 +170,38 @@ int dra_actor_c3fc4_valid(const float* y2_planes, const float* w3, const float* 
                           float* h4, unsigned* flags, int* timeout_flag, const int* w4_valid, void* stream);
 int dra_actor_c3fc4(const float* y2_planes, const float* w3, const float* b3, const float* w4, const float* b4, float* y3_planes,
                     float* h4, unsigned* flags, int* timeout_flag, void* stream);
+
+// conv_v2.hip (library-internal), DRA_VAR_ACTOR_PERSIST: every env step of an agent step of the ring actor as ONE launch
+// (actor_persist.h; VanillaNet head; 64 co-resident workgroups of 512 threads: needs >= 32 CUs on the stream)
+typedef unsigned long long ll_t;
+
+struct ActorPersistArgs {
+  const float *w1, *b1, *w2, *b2, *w3, *b3, *w4, *b4, *wh, *bh;
+  uint8_t* frames; uint8_t* actions; double* rewards; int32_t* masks;     // replay ring arrays
+  int64_t ring_cap;
+  const uint8_t* aring; unsigned* seq;                                     // device parameter-block ring + step counter
+  uint8_t* pend_frame; double* pend_reward; int32_t* pend_mask;
+  float* q_out;                // [A] action values of the last head evaluated
+  float* h4_plain;             // [512] plain copy of the last env step's features (observers)
+  ll_t *y1, *y2p, *y3p, *h4;   // {value, tag} words: [32 * 400], [2 * 64 * 81], [2 * 64 * 49], [2][512]
+  int* abort_word;             // device: set by the first wait that gives up, read by the others
+  uint64_t seed;
+  double coef;
+  int done_period, n_actions, n_env;
+  int* timeout_flag;           // pinned host
+  const int* w4_valid;         // optional (DRA_VAR_DEFER_FC4)
+};
+
+constexpr size_t kPersistY1 = 32 * 400, kPersistY2 = 2 * 64 * 81, kPersistY3 = 2 * 64 * 49, kPersistH4 = 2 * 512;
+constexpr size_t kPersistLLWords = kPersistY1 + kPersistY2 + kPersistY3 + kPersistH4;
+constexpr int kPersistWgs = 32;                 // one per CU of the actor's partition
+int dra_actor_persist(const ActorPersistArgs* a, void* stream);
+
+// conv_v2.hip (library-internal), DRA_VAR_FWD_CHAIN: conv1 (ring-direct) + conv2 + conv3 of the update's forward pass as one launch;
+// done_counters = 2 * DRA_MAX_Z * 32 unsigned (never reset), *epoch = chains completed (bumped by a later launch of the update)
+constexpr int kFwdChainCounters = 2 * DRA_MAX_Z * 32;
+int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* idx_tagged,
+                       const unsigned long long* update_seq, const int64_t* newest_off, int nz, const float* const* w1,
+                       const float* const* b1, float* const* y1, const float* const* w2, const float* const* b2, float* const* y2,
+                       const float* const* w3, const float* const* b3, float* const* y3, int batch, double u8_coef,
+                       unsigned* done_counters, const unsigned* epoch, int* timeout_flag, void* stream);

@@ -224,6 +224,9 @@ struct MegaSync {
   const unsigned* wait = nullptr;  // the counter this role waits on (consumers), null = nothing to wait for
   unsigned wait_target = 0;
   int* timeout_flag = nullptr;     // pinned host int
+  // optional: counters that are never reset -- the wait is for (*epoch + 1) * wait_target arrivals, `epoch` = launches of this
+  // kind completed so far (a LATER launch of the same step bumps it: the update's head kernel for the forward chain)
+  const unsigned* epoch = nullptr;
 };
 constexpr unsigned long long kMegaWaitTicks = 5000000ull;   // 50 ms of s_memrealtime (100 MHz)
 
@@ -237,7 +240,8 @@ __device__ __forceinline__ void mega_wait(const MegaSync& ms) {
   if (!ms.wait) return;
   if (threadIdx.x == 0) {
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(ms.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ms.wait_target) {
+    const unsigned target = ms.epoch ? (*ms.epoch + 1u) * ms.wait_target : ms.wait_target;
+    while (__hip_atomic_load(ms.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if (wall_clock64() - t0 > kMegaWaitTicks) {
         if (ms.timeout_flag) __hip_atomic_store(ms.timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -259,7 +263,9 @@ template <bool COH> __device__ __forceinline__ void mega_st(float* p, float v) {
 // (bx, by, bz) = the workgroup's position in the conv grid (blockIdx of a plain launch; a role offset inside the actor's
 // one-launch env step), env_wg = this workgroup is the fused launch's environment workgroup; COH = outputs are handed to
 // other workgroups of the SAME launch (agent-scope stores + mega_publish)
-template <class G, bool U8, int PT, int NW, bool FUSE, bool COH = false>
+// CIN = the input planes come from other workgroups of the SAME launch (the update's forward chain): weights first, then the wait
+// for the producers of this workgroup's sample, then agent-scope loads
+template <class G, bool U8, int PT, int NW, bool FUSE, bool COH = false, bool CIN = false>
 __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const ActorFuse& f, const int bx, const int by, const int bz,
                                                  const bool env_wg, const MegaSync ms = MegaSync()) {
   using T = V2Tile<G, PT>;
@@ -308,20 +314,32 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
   // barrier in front of the MFMA loop -- MFMA j needs weight register j alone.  Image rows first, weights behind them:
   // the MFMA loop starts when the image is staged and walks down vmcnt while the rest of its 16 KB of weights per wave
   // is still arriving (weights first: the barrier waited for all of them).  Same values, same order of operations.
-  auto request_weights = [&]() {
+  // (CIN: the first half of the weights is requested in front of the wait, the second half once the staged rows have left their
+  // registers -- it arrives behind the first half's MFMAs; all of them at once with the 48 row registers of conv2 exceed the 128
+  // registers four chain workgroups per CU leave a wave)
+  constexpr int NJ0 = CIN ? KS::NJ / 2 : KS::NJ;
+  auto request_weights_range = [&](auto lo, auto hi) {
     const float* wbase = wt + ((int64_t)(2 * cp0 + h) * G::KK + t0) * G::OC + oc0 + li;
 #pragma unroll
-    for (int j = 0; j < KS::NJ; ++j) {
+    for (int j = decltype(lo)::value; j < decltype(hi)::value; ++j) {
       const int cpl = j / KS::TW, t = j - cpl * KS::TW;
       areg[j] = wbase[(2 * cpl * G::KK + t) * G::OC];
     }
+  };
+  auto request_weights = [&]() {
+    request_weights_range(std::integral_constant<int, 0>{}, std::integral_constant<int, NJ0>{});
 #pragma unroll
     for (int q = 0; q < RPW; ++q) {
       const int r = wave * RPW + q;
       bias_r[q] = a.bias[z][oc0 + (r & 3) + 8 * (r >> 2) + 4 * h];
     }
   };
-  if (!kImageFirst) request_weights();
+  static_assert(!CIN || (!U8 && G::H <= 32), "chained input: the fp32 row-shaped staging");
+  if (!kImageFirst || CIN) request_weights();
+  if constexpr (CIN) {
+    __builtin_amdgcn_sched_barrier(0);   // the weight / bias loads above are in flight while this workgroup waits
+    mega_wait(ms);
+  }
   // Staging maps lanes to (row, column) so that no per-element division is needed: LR lanes walk one image
   // row (the surplus lanes of a row idle), 64 / LR rows per pass; row offsets are compile-time immediates and
   // the de-interleaved LDS column is a per-lane constant.  (The flat "element e of the block" mapping this
@@ -475,9 +493,9 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
       const int c = wave + NW * ci;
       const float* src = xf + ((int64_t)(bi * G::C + min(c, G::C - 1)) * G::H + ir0) * G::H + iwc;
 #pragma unroll
-      for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = src[min(RP * q + rsub, nrows - 1) * G::H];
+      for (int q = 0; q < LPT; ++q) raw[ci * LPT + q] = mega_ld<CIN>(src + min(RP * q + rsub, nrows - 1) * G::H);
     }
-    if (kImageFirst) { __builtin_amdgcn_sched_barrier(0); request_weights(); __builtin_amdgcn_sched_barrier(0); }
+    if (kImageFirst && !CIN) { __builtin_amdgcn_sched_barrier(0); request_weights(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int ci = 0; ci < CPT; ++ci) {
       const int c = wave + NW * ci;
@@ -488,6 +506,11 @@ __device__ __forceinline__ void conv_fwd_v2_body(const ConvV2Args& a, const Acto
         asm volatile("" : "+v"(v));
         if (iw < G::H && RP * q + rsub < nrows && c < G::C) dst[RP * q * G::RW] = v;
       }
+    }
+    if constexpr (CIN) {
+      __builtin_amdgcn_sched_barrier(0);
+      request_weights_range(std::integral_constant<int, NJ0>{}, std::integral_constant<int, KS::NJ>{});
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   DRA_STAMP(TRR, 1);   // loads consumed, LDS writes issued
@@ -1187,6 +1210,15 @@ int dra_actor_c3fc4_valid(const float* y2_planes, const float* w3, const float* 
   return DRA_OK;
 }
 
+// ---- DRA_VAR_ACTOR_PERSIST: the whole agent step of the ring actor as one launch ({value, tag} hand-overs), actor_persist.h
+#include "actor_persist.h"
+int dra_actor_persist(const ActorPersistArgs* a, void* stream) {
+  if (!a || !a->w1 || !a->w4 || !a->wh || !a->frames || !a->aring || !a->seq || !a->y1 || !a->y2p || !a->y3p || !a->h4 || !a->abort_word ||
+      !a->timeout_flag || !a->pend_frame)
+    return DRA_EINVAL;
+  return launch_actor_persist(*a, dra_stream(stream));
+}
+
 // (Round 6 measured a hand-over-free form of this launch -- fc4 split along K into 16 slices x 4 row quarters, every workgroup
 // computing its four conv3 planes itself on the vector ALU and the head folding the 16 partial sums -- in four layouts of the
 // on-the-fly conv3: 13.8 / 16.6 / 13.2 us per launch against 9.0-9.6 for this one, 8 137 vs 9 190 updates/s
@@ -1425,6 +1457,105 @@ static int launch_conv1_u8_tp(const ConvV2Args& a, int nz, hipStream_t st) {
   const int nwg = n_groups < per ? n_groups : per;
   const size_t lds_bytes = spg == 2 ? (size_t)2 * IMG : (size_t)(IMG > G::K * G::OC * 4 ? IMG : G::K * G::OC * 4);
   hipLaunchKernelGGL(conv1_fwd_u8_tp_kernel, dim3(nwg, 1, nz), dim3(256), lds_bytes, st, a, n_groups, spg, tp);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DRA_VAR_FWD_CHAIN (round 6): conv1 -> conv2 -> conv3 of the UPDATE's forward pass (both nets, batch <= 32, ring-direct conv1)
+// as ONE launch.  The three launches were 10.8 + 8.8 + 9.1 us of kernel span with 2.4 + 3.2 us between them, each made of
+// workgroups that first wait 2-3.8 us for their operands (profiles/r06m_phase_async.json); a workgroup of layer L+1 needs only
+// the planes of ITS sample.  Here the 832 + 384 + 256 workgroups are one grid in dependency order (a workgroup waits only for
+// workgroups dispatched before it), every (net, sample) has an arrival counter per layer: a producer stores agent-scope,
+// completes its stores and counts itself; a consumer requests its weights FIRST, then polls its sample's counter (bounded), then
+// reads the planes with agent-scope loads.  The counters are never reset: a wait is for (epoch + 1) x (workgroups per sample)
+// arrivals, `epoch` = chains completed, bumped by the update's head kernel (learner.hip).  Same arithmetic in the same order as
+// the three launches: bit-identical activations (tests/test_gpu_agents.py::test_forward_chain_is_bit_identical).
+struct FwdChainArgs {
+  ConvV2Args c1, c2, c3;
+  unsigned* done1;           // [nz * batch] arrivals of conv1's workgroups per (net, sample)
+  unsigned* done2;           // ... of conv2's
+  const unsigned* epoch;
+  int* timeout_flag;
+  int n1, n2, n3;            // workgroups per role
+};
+
+__global__ void __launch_bounds__(256, 4) conv_fwd_chain_kernel(const FwdChainArgs a) {
+  ActorFuse none;
+  none.mode = 0;
+  int b = blockIdx.x;
+  const int batch = a.c1.batch;
+  if (b < a.n1) {
+    constexpr int TPG = V2Tile<VG1, 1>::TPG, per = TPG * (VG1::OC / 32);
+    const int v = a.c1.xcd_order ? xcd_order(b, 0, a.n1 / per, per) : b;
+    const int g = v / per, w = v - g * per;
+    const int bz = g / batch, bi = g - bz * batch;
+    MegaSync ms;
+    ms.done = a.done1 + g;
+    conv_fwd_v2_body<VG1, true, 1, 4, false, true, false>(a.c1, none, bi * TPG + w, 0, bz, false, ms);
+    return;
+  }
+  b -= a.n1;
+  if (b < a.n2) {
+    constexpr int TPG = V2Tile<VG2, 1>::TPG, ny = VG2::OC / 32, per = TPG * ny;
+    const int v = a.c2.xcd_order ? xcd_order(b, a.n1, a.n2 / per, per) : b;
+    const int g = v / per, w = v - g * per;
+    const int bz = g / batch, bi = g - bz * batch, grp = w / ny, by = w - grp * ny;
+    MegaSync ms;
+    ms.wait = a.done1 + g; ms.wait_target = V2Tile<VG1, 1>::TPG * (VG1::OC / 32); ms.epoch = a.epoch; ms.timeout_flag = a.timeout_flag;
+    ms.done = a.done2 + g;
+    conv_fwd_v2_body<VG2, false, 1, 4, false, true, true>(a.c2, none, bi * TPG + grp, by, bz, false, ms);
+    return;
+  }
+  b -= a.n2;
+  {
+    constexpr int TPG = V2Tile<VG3, 1>::TPG, ny = VG3::OC / 32, per = TPG * ny;
+    const int v = a.c3.xcd_order ? xcd_order(b, a.n1 + a.n2, a.n3 / per, per) : b;
+    const int g = v / per, w = v - g * per;
+    const int bz = g / batch, bi = g - bz * batch, grp = w / ny, by = w - grp * ny;
+    MegaSync ms;
+    ms.wait = a.done2 + g; ms.wait_target = V2Tile<VG2, 1>::TPG * (VG2::OC / 32); ms.epoch = a.epoch; ms.timeout_flag = a.timeout_flag;
+    conv_fwd_v2_body<VG3, false, 1, 4, false, false, true>(a.c3, none, bi * TPG + grp, by, bz, false, ms);
+  }
+}
+
+// Library-internal (actor_env.h): conv1 (ring-direct, as dra_conv1_fwd_koc_ringbatch) + conv2 + conv3 (as dra_conv_fwd_koc) of nz nets.
+int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* idx_tagged,
+                       const unsigned long long* update_seq, const int64_t* newest_off, int nz, const float* const* w1,
+                       const float* const* b1, float* const* y1, const float* const* w2, const float* const* b2, float* const* y2,
+                       const float* const* w3, const float* const* b3, float* const* y3, int batch, double u8_coef,
+                       unsigned* done_counters, const unsigned* epoch, int* timeout_flag, void* stream) {
+  if (!frames || !idx || !newest_off || nz < 1 || nz > DRA_MAX_Z || batch < 1 || batch > 32 || !w1 || !b1 || !y1 || !w2 || !b2 || !y2 ||
+      !w3 || !b3 || !y3 || !done_counters || !epoch || !timeout_flag)
+    return DRA_EINVAL;
+  if ((idx_tagged != nullptr) != (update_seq != nullptr)) return DRA_EINVAL;
+  if (g_rider_next.armed) { g_rider_next.armed = false; return DRA_EINVAL; }   // (the chain carries no riders)
+  FwdChainArgs a;
+  for (int z = 0; z < nz; ++z) {
+    if (!w1[z] || !b1[z] || !y1[z] || !w2[z] || !b2[z] || !y2[z] || !w3[z] || !b3[z] || !y3[z]) return DRA_EINVAL;
+    a.c1.x[z] = frames; a.c1.wt[z] = w1[z]; a.c1.bias[z] = b1[z]; a.c1.y[z] = y1[z];
+    a.c1.idx_bias[z] = newest_off[z] - (VG1::C - 1);
+    a.c2.x[z] = y1[z]; a.c2.wt[z] = w2[z]; a.c2.bias[z] = b2[z]; a.c2.y[z] = y2[z];
+    a.c3.x[z] = y2[z]; a.c3.wt[z] = w3[z]; a.c3.bias[z] = b3[z]; a.c3.y[z] = y3[z];
+  }
+  a.c1.sample_idx = idx; a.c1.sample_idx_copy = idx_copy; a.c1.sample_idx_tagged = idx_tagged; a.c1.sample_seq = update_seq;
+  ConvV2Args* cs[3] = {&a.c1, &a.c2, &a.c3};
+  for (ConvV2Args* c : cs) {
+    c->batch = batch; c->act = DRA_ACT_RELU; c->coef = 1.0; c->ring_slot = nullptr; c->ring_cap = 0; c->stack_age = nullptr;
+    c->slot_seq = nullptr; c->slot_entries = 0; c->slot_stride = 0; c->newest_frame = nullptr;
+    c->xcd_order = dra_xcd_order_enabled();
+  }
+  a.c1.coef = u8_coef;
+  a.done1 = done_counters; a.done2 = done_counters + DRA_MAX_Z * 32; a.epoch = epoch; a.timeout_flag = timeout_flag;
+  a.n1 = nz * batch * V2Tile<VG1, 1>::TPG * (VG1::OC / 32);
+  a.n2 = nz * batch * V2Tile<VG2, 1>::TPG * (VG2::OC / 32);
+  a.n3 = nz * batch * V2Tile<VG3, 1>::TPG * (VG3::OC / 32);
+  constexpr size_t i1 = (size_t)VG1::C * V2Tile<VG1, 1>::CS, i2 = (size_t)VG2::C * V2Tile<VG2, 1>::CS, i3 = (size_t)VG3::C * V2Tile<VG3, 1>::CS;
+  constexpr size_t red = (size_t)4 * 16 * 64;
+  constexpr size_t m12 = i1 > i2 ? i1 : i2, m3 = i3 > red ? i3 : red;
+  constexpr size_t bytes = (m12 > m3 ? m12 : m3) * sizeof(float);
+  static_assert(bytes <= 40 * 1024, "four chain workgroups per CU");
+  hipLaunchKernelGGL(conv_fwd_chain_kernel, dim3(a.n1 + a.n2 + a.n3), dim3(256), bytes, dra_stream(stream), a);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

@@ -222,6 +222,10 @@ struct dra_dqn_learner {
   bool per2_ride;                   // ... and the chain kernel rides in conv3's backward launch (per2_args) instead of its own
   bool per2_split;                  // ... its second half in conv1's weight-gradient launch (late-fold backward only)
   PerChain2Args per2_args;
+  unsigned* fchain_dev;             // DRA_VAR_FWD_CHAIN: [kFwdChainCounters] arrival counters (never reset) + [1] chains completed
+  bool fchain;                      // the update's conv forwards run as one chained launch
+  unsigned long long* all_dev;      // DRA_VAR_ACTOR_PERSIST: {value, tag} hand-over arrays (y1 | y2p | y3p | h4[2]) + the abort word
+  int actor_cus;                    // CUs of the stream the actor launches run on (0 = unknown: the whole device)
   unsigned* aflags;                 // DRA_VAR_ACTOR_MEGA: [kMaxEnvSteps][4] arrival counters of the one-launch env steps (zeroed by
                                     // the agent step's tail kernel)
   bool late;
@@ -402,12 +406,23 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
                (l->defer_begin & 3) == 0 && (l->defer_count & 3) == 0 && l->defer_count == (int64_t)512 * 3136 &&
                l->defer_begin >= l->lstride[0];
   }
+  // DRA_VAR_FWD_CHAIN: VanillaNet, ring-direct, two nets, the four-wave latency shape; the chain carries no riders (DEFER_FC4 off)
+  l->fchain = (l->variant & DRA_VAR_FWD_CHAIN) && (l->variant & DRA_VAR_RING_DIRECT) && cfg->head_kind == DRA_HEAD_VANILLA &&
+              !cfg->double_q && cfg->batch > 16 && cfg->batch <= 32;
+  if (l->fchain) l->defer = false;
   rc |= (int)hipMalloc(&l->defer_dev, 8 * sizeof(float));
   if (!rc) {
     const int init[8] = {0, 0, 1, 1, 1, 1, 0, 0};      // coefficient 0.0f, nothing pending, every copy valid
     rc |= (int)hipMemcpy(l->defer_dev, init, sizeof(init), hipMemcpyHostToDevice);
   }
   rc |= (int)hipMalloc(&l->aflags, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
+  rc |= (int)hipMalloc(&l->fchain_dev, (size_t)(kFwdChainCounters + 1) * sizeof(unsigned));
+  if (!rc) rc |= (int)hipMemset(l->fchain_dev, 0, (size_t)(kFwdChainCounters + 1) * sizeof(unsigned));
+  {
+    const size_t words = kPersistLLWords + 1;
+    rc |= (int)hipMalloc(&l->all_dev, words * sizeof(unsigned long long));
+    if (!rc) rc |= (int)hipMemset(l->all_dev, 0, words * sizeof(unsigned long long));   // tag 0 is never used
+  }
   if (!rc) rc |= (int)hipMemset(l->aflags, 0, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
   if (l->variant & DRA_VAR_ACTOR_PARAMS) { rc |= alloc_f(&l->pa[0], cfg->n_params); rc |= alloc_f(&l->pa[1], cfg->n_params); }
   if ((l->variant & DRA_VAR_ACTOR_PARAMS) && (l->variant & DRA_VAR_GATHER_ON_UPDATE)) {
@@ -524,6 +539,8 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (l->ah4) (void)hipFree(l->ah4);
   if (l->defer_dev) (void)hipFree(l->defer_dev);
   if (l->aflags) (void)hipFree(l->aflags);
+  if (l->all_dev) (void)hipFree(l->all_dev);
+  if (l->fchain_dev) (void)hipFree(l->fchain_dev);
   if (l->aring_dev) {
     (void)hipFree(l->aring_dev); (void)hipHostFree(l->aring_stage); (void)hipFree(l->aring_seq);
     (void)hipFree(l->pend_frame); (void)hipFree(l->pend_reward); (void)hipFree(l->pend_mask);
@@ -680,6 +697,8 @@ struct RingScalars {
   // DRA_VAR_IDX_PREFETCH: workgroup 0 counts this update as done (conv1 of the next update compares the tags of its
   // prefetched indices with the count: ConvV2Args::sample_idx_tagged)
   unsigned long long* seq;
+  // DRA_VAR_FWD_CHAIN: workgroup 0 counts the forward chain of this update as done (conv_v2.hip FwdChainArgs::epoch)
+  unsigned* chain_epoch;
 };
 
 // action / n-step reward / mask of sampled transition b straight from the replay ring, folded as ring_gather_kernel does
@@ -989,6 +1008,7 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
   }
   if (opt_step && b == 0 && tid == 0) *opt_step += 1;   // one optimizer step per update (Adam's t)
   if (rs.seq && b == 0 && tid == 0) *rs.seq += 1ull;
+  if (rs.chain_epoch && b == 0 && tid == 0) *rs.chain_epoch += 1u;
   DRA_STAMP(TR_HEAD, 5);
   DRA_STAMP_END(TR_HEAD);
 }
@@ -1198,6 +1218,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   const void* x1[3] = {l->state_[l->gb], l->next_state_[l->gb], l->next_state_[l->gb]};
   const float* w1[3] = {P + o[P_W1], T + o[P_W1], P + o[P_W1]};
   const float* b1[3] = {P + o[P_B1], T + o[P_B1], P + o[P_B1]};
+  bool chain = false;   // DRA_VAR_FWD_CHAIN: conv1 + conv2 + conv3 as one launch (conv_v2.hip conv_fwd_chain_kernel)
   if (rd) {
     const int64_t off[3] = {0, ring_n, ring_n};
     // (the indices sit in pinned host memory: conv1's workgroups pay the one PCIe read and leave a device copy in l->idx
@@ -1210,6 +1231,18 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       const int nb = fc4_rider_blocks(r.count4);
       dra_conv_attach_rider(&r, 0, (nb * kRiderConv1Pct) / 100, nullptr, nullptr);
     }
+    chain = l->fchain && !l->profiling && l->only_kernel < 0 && nz == 2;
+    if (chain) {
+      const float* w2c[3] = {P + o[P_W2], T + o[P_W2], P + o[P_W2]};
+      const float* b2c[3] = {P + o[P_B2], T + o[P_B2], P + o[P_B2]};
+      const float* w3c[3] = {P + o[P_W3], T + o[P_W3], P + o[P_W3]};
+      const float* b3c[3] = {P + o[P_B3], T + o[P_B3], P + o[P_B3]};
+      int rcc = dra_conv_fwd_chain(ring_frames, dev_idx ? l->per2_idx + (size_t)l->rd_slot * 1024 : l->idx_pin[l->rd_slot], l->idx,
+                                   pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr, off, nz,
+                                   w1, b1, l->y1, w2c, b2c, l->y2, w3c, b3c, l->y3, B, c.u8_coef, l->fchain_dev,
+                                   l->fchain_dev + kFwdChainCounters, l->timeout_flag, s);
+      if (rcc) return rcc;
+    } else
     STEP(K_CONV1_F, dra_conv1_fwd_koc_ringbatch(ring_frames, dev_idx ? l->per2_idx + (size_t)l->rd_slot * 1024 : l->idx_pin[l->rd_slot], l->idx,
                                                 pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr,
                                                 off, nz, w1, b1, l->y1, B, c.u8_coef, DRA_ACT_RELU, s));
@@ -1224,6 +1257,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     const int nb = fc4_rider_blocks(r.count4);
     dra_conv_attach_rider(&r, (nb * kRiderConv1Pct) / 100, nb - (nb * kRiderConv1Pct) / 100, nullptr, nullptr);
   }
+  if (!chain)
   STEP(K_CONV2_F, dra_conv_fwd_koc(2, nz, x2, w2, b2, l->y2, B, 0, 1.0, DRA_ACT_RELU, s));
   const void* x3[3] = {l->y2[0], l->y2[1], l->y2[2]};
   const float* w3[3] = {P + o[P_W3], T + o[P_W3], P + o[P_W3]};
@@ -1236,7 +1270,9 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   // ... and the launch after the riders' lowers `pending` and marks the actor copy they completed valid
   if (rd && l->rider_q >= 0 && l->only_kernel < 0)
     dra_conv_attach_rider(nullptr, 0, 0, defer_pending_word(l), defer_valid_word(l, l->rider_q));
-  if ((l->variant & DRA_VAR_ONESHOT_FWD) && ks4 == kFc4SplitMid && nz == 2 && B <= 32)
+  if (chain) {
+    // (conv3 ran inside the chained launch)
+  } else if ((l->variant & DRA_VAR_ONESHOT_FWD) && ks4 == kFc4SplitMid && nz == 2 && B <= 32)
     STEP(K_CONV3_F, dra_conv3_fwd_koc_pf(nz, x3, w3, b3, l->y3, B, DRA_ACT_RELU, w4, nz, s));
   else
   STEP(K_CONV3_F, dra_conv_fwd_koc(3, nz, x3, w3, b3, l->y3, B, 0, 1.0, DRA_ACT_RELU, s));
@@ -1250,6 +1286,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     rs.masks = (const int32_t*)ring_masks; rs.n_step = ring_n; rs.discount = ring_discount;
     rs.out_action = l->action_[l->gb]; rs.out_reward = l->reward_[l->gb]; rs.out_mask = l->mask_[l->gb];
     if ((l->variant & DRA_VAR_IDX_PREFETCH) && l->only_kernel < 0) rs.seq = l->rd_seq_dev;   // (a replay is not an update)
+    if (chain) rs.chain_epoch = l->fchain_dev + kFwdChainCounters;
   }
   if (l->only_kernel >= 0 && l->only_kernel != K_HEAD) {
     // (single-kernel replay of another group: no head launch)
@@ -2478,6 +2515,28 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   f.head_kind = c.head_kind; f.n_atoms = c.n_atoms; f.atoms = l->atoms; f.pre = l->alog;
   // DRA_VAR_ACTOR_MEGA: conv3 + fc4 of an env step as ONE launch with an in-kernel hand-over (conv_v2.hip actor_c3fc4_kernel)
   const bool mega = (l->variant & DRA_VAR_ACTOR_MEGA) && actor_ksplit() && l->aflags;
+  // DRA_VAR_ACTOR_PERSIST: the whole agent step as ONE launch (conv_v2.hip actor_persist.h).  Needs its 32 workgroups co-resident
+  // (one per CU: a stream restricted to fewer CUs keeps the multi-launch form), the VanillaNet head and consecutive ring slots
+  // (the host's feed order: replay.py:70-80; checked when the blocks are pushed)
+  if (mega && (l->variant & DRA_VAR_ACTOR_PERSIST) && !dist && l->all_dev && n_env <= kMaxEnvSteps &&
+      (l->actor_cus == 0 || l->actor_cus >= kPersistWgs)) {
+    ActorPersistArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.w1 = P + o[P_W1]; pa.b1 = P + o[P_B1]; pa.w2 = P + o[P_W2]; pa.b2 = P + o[P_B2]; pa.w3 = P + o[P_W3]; pa.b3 = P + o[P_B3];
+    pa.w4 = P + o[P_W4]; pa.b4 = P + o[P_B4]; pa.wh = P + o[P_WH]; pa.bh = P + o[P_BH];
+    pa.frames = (uint8_t*)frames; pa.actions = (uint8_t*)actions; pa.rewards = (double*)rewards; pa.masks = (int32_t*)masks;
+    pa.ring_cap = c.ring_capacity; pa.aring = l->aring_dev; pa.seq = l->aring_seq;
+    pa.pend_frame = l->pend_frame; pa.pend_reward = l->pend_reward; pa.pend_mask = l->pend_mask;
+    pa.q_out = l->aq; pa.h4_plain = l->ah4;
+    pa.y1 = l->all_dev; pa.y2p = pa.y1 + kPersistY1; pa.y3p = pa.y2p + kPersistY2; pa.h4 = pa.y3p + kPersistY3;
+    pa.abort_word = reinterpret_cast<int*>(l->all_dev + kPersistLLWords);
+    pa.seed = (uint64_t)c.env_seed; pa.coef = c.u8_coef; pa.done_period = (int)c.env_done_period; pa.n_actions = c.n_actions;
+    pa.n_env = n_env; pa.timeout_flag = l->timeout_flag;
+    if (l->defer)
+      for (int k = 0; k < 4; ++k)
+        if (P == l->pa[k] && l->pa[k]) pa.w4_valid = defer_valid_word(l, k);
+    return dra_actor_persist(&pa, s);
+  }
   for (int e = 0; e < n_env; ++e) {
     const int64_t* slot_field = reinterpret_cast<const int64_t*>(l->aring_dev + offsetof(dra_dqn_step_params, slot)) + e;
     const int32_t* age_field = reinterpret_cast<const int32_t*>(l->aring_dev + offsetof(dra_dqn_step_params, stack_age)) + e;
@@ -2589,6 +2648,13 @@ static int run_actor_steps_ring(dra_dqn_learner* l, int n_env, const float* P, h
   return DRA_OK;
 }
 
+DRA_API int dra_dqn_learner_set_actor_cus(dra_dqn_learner* l, int n_cus) {
+  if (!l || n_cus < 0) return DRA_EINVAL;
+  if (l->captured || l->step_no != 0 || l->aring_issued != 0) return DRA_EINVAL;   // the actor graphs bake the choice in
+  l->actor_cus = n_cus;
+  return DRA_OK;
+}
+
 // Uploads `n` parameter blocks (agent steps pushed, pushed+1, ...) into the device ring on `stream` (the actor
 // stream: in order with the actor graphs).  At most kAringSlots / 2 blocks may be pending (pushed - issued).
 DRA_API int dra_dqn_learner_actor_ring_push(dra_dqn_learner* l, const dra_dqn_step_params* blocks, int n, void* stream) {
@@ -2599,6 +2665,11 @@ DRA_API int dra_dqn_learner_actor_ring_push(dra_dqn_learner* l, const dra_dqn_st
     if (blocks[i].n_env < 1 || blocks[i].n_env > kMaxEnvSteps) return DRA_EINVAL;
     for (int e = 0; e < blocks[i].n_env; ++e)
       if (blocks[i].counter[e] < 0) return DRA_EINVAL;   // the ring actor owns the (device-resident) environment
+    // (DRA_VAR_ACTOR_PERSIST keeps the frame stack in LDS across env steps: observation e is the frame of slot[e], the one
+    // before it slot[e] - 1 -- the feed order of replay.py:70-80)
+    if (l->variant & DRA_VAR_ACTOR_PERSIST)
+      for (int e = 1; e < blocks[i].n_env; ++e)
+        if (blocks[i].slot[e] != (blocks[i].slot[e - 1] + 1) % l->c.ring_capacity) return DRA_EINVAL;
     const size_t k = (size_t)((l->aring_pushed + i) % kAringSlots);
     memcpy(l->aring_stage + k * kAprmStride, &blocks[i], kPrmHeadBytes);
   }

@@ -142,6 +142,9 @@ class DQNLearner:
         else:
             self.stream = torch.cuda.Stream()                        # graphs cannot capture on the NULL stream
             self.actor_stream = torch.cuda.Stream()
+        if self.actor_cus:
+            # (DRA_VAR_ACTOR_PERSIST: the one-launch agent step needs 32 co-resident workgroups, one per CU of the actor's stream)
+            lib.dra_dqn_learner_set_actor_cus(self.h, int(self.actor_cus))
         self.params = StepParams()
         self._idx_view = np.ctypeslib.as_array(self.params.idx)[:batch]
         self._k = 0

@@ -450,7 +450,9 @@ VAR_IDX_PREFETCH = 131072
 VAR_LATE_FOLD = 524288
 VAR_ACTOR_MEGA = 1048576
 VAR_DEFER_FC4 = 8388608       # fc4's segment of the optimizer step rides in the next update's forward launches
-VAR_ALL = 2097151 | 8388608
+VAR_ACTOR_PERSIST = 16777216  # the whole agent step of the device actor as one launch ({value, tag} hand-overs)
+VAR_FWD_CHAIN = 33554432      # conv1 + conv2 + conv3 of the update's forward as one chained launch
+VAR_ALL = 2097151 | 8388608 | 16777216 | 33554432
 
 
 def set_tuning(mask):

@@ -319,6 +319,18 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
                                    * launches -- nothing reads it before that graph's fc4 forward, the actor's copy of it is guarded
                                    * by a device word -- with the same arithmetic (same bits).  dra_dqn_learner_flush steps a
                                    * pending segment at once; every entry that reads parameters outside those graphs does so itself */
+#define DRA_VAR_ACTOR_PERSIST 16777216 /* learner (with ACTOR_RING + ACTOR_FUSED_CONV1 + ACTOR_MEGA, VanillaNet): ALL env steps of an agent
+                                    * step of the device actor as ONE launch of 32 co-resident workgroups -- activations cross
+                                    * workgroups as 8-byte {value, tag} words (no launch boundary, no arrival counter), fc4's and the
+                                    * convolutions' weights stay in registers / LDS for the whole agent step, conv1's workgroups keep
+                                    * their rows of the frame stack in LDS.  Same arithmetic as the multi-launch env step: bit-identical
+                                    * actions, action values and ring contents.  Needs >= 32 CUs on the actor's stream
+                                    * (dra_dqn_learner_set_actor_cus), else the multi-launch form runs.  DQN_agent.py:24-45 */
+#define DRA_VAR_FWD_CHAIN 33554432 /* learner (RING_DIRECT, VanillaNet, two nets, batch 17..32): conv1 + conv2 + conv3 of the update's
+                                    * forward pass as ONE launch in dependency order -- a workgroup of layer L + 1 waits (arrival
+                                    * counter per (net, sample), weights requested first) for the workgroups of ITS sample in layer L
+                                    * instead of for the whole layer and a launch boundary.  Same arithmetic: bit-identical.  Carries
+                                    * no riders: DRA_VAR_DEFER_FC4 is off with it.  DQN_agent.py:81-99, network_bodies.py:10-33 */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
@@ -491,6 +503,10 @@ int dra_dqn_learner_wait_loss(dra_dqn_learner* learner, void* stream);
  * (dra_dqn_learner_kernel_count groups, names from _kernel_name).  With n_out > count, out_ms[count] = the same event pair
  * with NOTHING in between (the bracket's own cost, to be subtracted).  Synchronises. */
 int dra_dqn_learner_profile(dra_dqn_learner* learner, float* out_ms, int n_out, void* stream);
+/* how many compute units the stream the actor launches are issued on may use (a CU-masked stream: DRA_VAR_CU_PARTITION; 0 = the
+ * whole device, the default).  DRA_VAR_ACTOR_PERSIST's launch needs 32 co-resident workgroups of one per CU: with fewer CUs the
+ * learner keeps the multi-launch env step.  Call before the first step (the choice is baked into the captured actor graphs). */
+int dra_dqn_learner_set_actor_cus(dra_dqn_learner* learner, int n_cus);
 /* DRA_VAR_DEFER_FC4: step a pending fc4 segment of the optimizer step now, on `stream` (ordered behind the update that left it).
  * Call before reading parameters / optimizer state / actor copies from outside the library (a synchronise alone does not
  * complete the step); a no-op when nothing is pending.  DQN_agent.py:133 (optimizer.step() is ONE call in the reference). */

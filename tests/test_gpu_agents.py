@@ -1479,3 +1479,84 @@ def test_deferred_fc4_step_is_bit_identical(dra):
         assert np.array_equal(outs[0][k], outs[1][k]), ("defer on vs off", k)
         assert np.array_equal(outs[1][k], outs[2][k]), ("interrupted vs not", k)
     assert float(np.abs(outs[0]["p"]).max()) > 0
+
+
+def test_persistent_actor_is_bit_identical(dra):
+    """DRA_VAR_ACTOR_PERSIST (round 6): the whole agent step of the device actor -- n_env x [forward, epsilon-greedy, env.step]
+    (DQN_agent.py:24-45) -- as ONE launch of 32 co-resident workgroups whose activations cross workgroups as {value, tag} words.
+    Same arithmetic in the same order as the multi-launch env step, hence the same bits: the benchmarked pipeline with the bit
+    set and cleared ends on identical parameters, optimizer state, target network, ring contents (frames and ACTIONS) and action
+    values of the last step -- also across synchronise() calls and a target sync in the middle, and with DRA_VAR_DEFER_FC4's
+    guarded fc4 segment on either side."""
+    d = dra
+    from deeprl_amd import ops
+    from deeprl_amd.learner import DQNLearnerBench
+    default = ops.get_tuning()
+    outs = []
+    for variant, interrupt in ((default & ~ops.VAR_ACTOR_PERSIST, False), (default | ops.VAR_ACTOR_PERSIST, False),
+                               (default | ops.VAR_ACTOR_PERSIST, True),
+                               ((default | ops.VAR_ACTOR_PERSIST) & ~ops.VAR_DEFER_FC4, False)):
+        np.random.seed(21)
+        torch.manual_seed(22)
+        b = DQNLearnerBench(ring_capacity=4096, batch=32, seed=23, actor=True, async_actor=True, variant=variant)
+        L = b.learner
+        for t in range(40):
+            b.step()
+            if t == 17:
+                L.sync_target()
+            if interrupt and t in (5, 6, 29):
+                L.synchronize()
+        L.synchronize()
+        frames = d.ops._wrap_device_pointer(b.ring.pointers()[0], 260 * 7056, torch.uint8).cpu().numpy().copy()
+        acts = d.ops._wrap_device_pointer(b.ring.pointers()[1], 260, torch.int64).cpu().numpy().copy()
+        outs.append(dict(p=L.flat.flat.detach().cpu().numpy().copy(), s1=L.state1.detach().cpu().numpy().copy(),
+                         s2=L.state2.detach().cpu().numpy().copy(), pt=L.target_flat.flat.detach().cpu().numpy().copy(),
+                         frames=frames, acts=acts, q=L.actor_q.cpu().numpy().copy()))
+        L.close()
+        b.ring.close()
+    for k in outs[0]:
+        for i in (1, 2, 3):
+            assert np.array_equal(outs[0][k], outs[i][k]), ("persistent vs multi-launch actor", i, k)
+    assert float(np.abs(outs[0]["q"]).max()) > 0
+    assert len(set(outs[0]["acts"][:160].tolist())) > 1
+
+
+def test_forward_chain_is_bit_identical(dra):
+    """DRA_VAR_FWD_CHAIN (round 6): conv1 + conv2 + conv3 of the update's forward pass (DQN_agent.py:81-99 through
+    network_bodies.py:10-33, both nets) as ONE launch whose workgroups wait for the workgroups of THEIR sample in the layer below
+    (arrival counters that are never reset, targets relative to the number of chains completed).  Same arithmetic in the same
+    order, hence the same bits: the benchmarked pipeline with the bit set and cleared ends on identical parameters, optimizer
+    state, target network and ring contents -- also across synchronise() calls, a target sync, kernel replays (which run the
+    three launches on their own) and an eager profile in the middle."""
+    d = dra
+    from deeprl_amd import ops
+    from deeprl_amd.learner import DQNLearnerBench
+    default = ops.get_tuning()
+    outs = []
+    for variant, interrupt in ((default & ~ops.VAR_FWD_CHAIN, False), (default | ops.VAR_FWD_CHAIN, False),
+                               (default | ops.VAR_FWD_CHAIN, True)):
+        np.random.seed(31)
+        torch.manual_seed(32)
+        b = DQNLearnerBench(ring_capacity=4096, batch=32, seed=33, actor=True, async_actor=True, variant=variant)
+        L = b.learner
+        for t in range(40):
+            b.step()
+            if t == 17:
+                L.sync_target()
+            if interrupt and t in (5, 6, 29):
+                L.synchronize()
+            if interrupt and t == 11:
+                L.kernel_replay("conv2_fwd", 4)
+                L.kernel_replay("conv2_bwd_x", 4)
+        L.synchronize()
+        frames = d.ops._wrap_device_pointer(b.ring.pointers()[0], 260 * 7056, torch.uint8).cpu().numpy().copy()
+        acts = d.ops._wrap_device_pointer(b.ring.pointers()[1], 260, torch.int64).cpu().numpy().copy()
+        outs.append(dict(p=L.flat.flat.detach().cpu().numpy().copy(), s1=L.state1.detach().cpu().numpy().copy(),
+                         s2=L.state2.detach().cpu().numpy().copy(), pt=L.target_flat.flat.detach().cpu().numpy().copy(),
+                         frames=frames, acts=acts))
+        L.close()
+        b.ring.close()
+    for k in outs[0]:
+        for i in (1, 2):
+            assert np.array_equal(outs[0][k], outs[i][k]), ("chained vs separate forward launches", i, k)
+    assert float(np.abs(outs[0]["p"]).max()) > 0
