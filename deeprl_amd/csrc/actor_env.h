@@ -198,10 +198,13 @@ constexpr int kPersistWgs = 32;                 // one per CU of the actor's par
 int dra_actor_persist(const ActorPersistArgs* a, void* stream);
 
 // conv_v2.hip (library-internal), DRA_VAR_FWD_CHAIN: conv1 (ring-direct) + conv2 + conv3 of the update's forward pass as one launch;
-// done_counters = 2 * DRA_MAX_Z * 32 unsigned (never reset), *epoch = chains completed (bumped by a later launch of the update)
-constexpr int kFwdChainCounters = 2 * DRA_MAX_Z * 32;
+// done_counters = kFwdChainCounters unsigned (never reset), *epoch = chains completed (bumped by a later launch of the update);
+// rider (optional, DRA_VAR_DEFER_FC4): the deferred fc4 segment as trailing workgroups of the launch, rider_count a zeroed device word
+constexpr int kChainPad = 32;                  // unsigned per counter: one 128-byte line each
+constexpr int kFwdChainCounters = 2 * DRA_MAX_Z * 32 * kChainPad;
 int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* idx_tagged,
                        const unsigned long long* update_seq, const int64_t* newest_off, int nz, const float* const* w1,
                        const float* const* b1, float* const* y1, const float* const* w2, const float* const* b2, float* const* y2,
                        const float* const* w3, const float* const* b3, float* const* y3, int batch, double u8_coef,
-                       unsigned* done_counters, const unsigned* epoch, int* timeout_flag, void* stream);
+                       unsigned* done_counters, const unsigned* epoch, int* timeout_flag, const DraFc4Rider* rider,
+                       unsigned* rider_count, int* rider_pending, int* rider_valid, void* stream);

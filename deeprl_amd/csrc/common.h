@@ -67,7 +67,10 @@ struct DraFc4Rider {
 constexpr int kRiderNV = 3;           // float4 per thread of a rider workgroup (256 threads)
 __host__ __device__ inline int fc4_rider_blocks(int64_t count4) { return (int)((count4 + 256 * kRiderNV - 1) / (256 * kRiderNV)); }
 
-// rider workgroup `rb` of `nrb` (nrb * 256 * kRiderNV >= count4)
+// rider workgroup `rb` of `nrb` (nrb * 256 * kRiderNV >= count4).  COPY_WT: the actor copy is written THROUGH (agent-scope stores) --
+// for riders whose completion is announced from inside their own launch (the forward chain: no launch boundary writes the L2 back
+// before the actor, on another XCD, is told that the copy is complete)
+template <bool COPY_WT = false>
 __device__ __forceinline__ void fc4_rider_run(const DraFc4Rider& r, int rb) {
   if (*r.pending == 0) return;
   const int64_t i0 = (int64_t)rb * (256 * kRiderNV) + threadIdx.x;
@@ -106,7 +109,15 @@ __device__ __forceinline__ void fc4_rider_run(const DraFc4Rider& r, int rb) {
       __builtin_nontemporal_store(sq, reinterpret_cast<nt_f4*>(r.s1) + r.begin4 + i);
       if (r.centered) __builtin_nontemporal_store(aq, reinterpret_cast<nt_f4*>(r.s2) + r.begin4 + i);
 #else
-      if (r.p_copy) reinterpret_cast<float4*>(r.p_copy)[r.begin4 + i] = P[v];
+      if (r.p_copy) {
+        if constexpr (COPY_WT) {
+          float* pc = r.p_copy + 4 * (r.begin4 + i);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) __hip_atomic_store(pc + k, pp[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          reinterpret_cast<float4*>(r.p_copy)[r.begin4 + i] = P[v];
+        }
+      }
       reinterpret_cast<float4*>(r.s1)[r.begin4 + i] = S[v];
       if (r.centered) reinterpret_cast<float4*>(r.s2)[r.begin4 + i] = A[v];
 #endif

@@ -1473,11 +1473,20 @@ static int launch_conv1_u8_tp(const ConvV2Args& a, int nz, hipStream_t st) {
 // the three launches: bit-identical activations (tests/test_gpu_agents.py::test_forward_chain_is_bit_identical).
 struct FwdChainArgs {
   ConvV2Args c1, c2, c3;
-  unsigned* done1;           // [nz * batch] arrivals of conv1's workgroups per (net, sample)
+  unsigned* done1;           // [nz * batch] x kChainPad: arrivals of conv1's workgroups per (net, sample), one 128-byte line each
+                             // (64 counters in two lines polled by 384 workgroups: the chain measured 43 us against 35)
   unsigned* done2;           // ... of conv2's
   const unsigned* epoch;
   int* timeout_flag;
   int n1, n2, n3;            // workgroups per role
+  // DRA_VAR_DEFER_FC4: the LAST n_riders workgroups of the grid step the deferred fc4 segment of the previous update (they are
+  // dispatched as conv1's workgroups leave, beside the 640 of conv2 / conv3, which are in front of them for the slots); the actor
+  // copy is written through, every rider counts itself, the last one lowers `pending` and marks the copy valid
+  DraFc4Rider rider;
+  int n_riders;
+  unsigned* rider_count;
+  int* rider_pending;
+  int* rider_valid;
 };
 
 __global__ void __launch_bounds__(256, 4) conv_fwd_chain_kernel(const FwdChainArgs a) {
@@ -1491,7 +1500,7 @@ __global__ void __launch_bounds__(256, 4) conv_fwd_chain_kernel(const FwdChainAr
     const int g = v / per, w = v - g * per;
     const int bz = g / batch, bi = g - bz * batch;
     MegaSync ms;
-    ms.done = a.done1 + g;
+    ms.done = a.done1 + g * kChainPad;
     conv_fwd_v2_body<VG1, true, 1, 4, false, true, false>(a.c1, none, bi * TPG + w, 0, bz, false, ms);
     return;
   }
@@ -1502,19 +1511,33 @@ __global__ void __launch_bounds__(256, 4) conv_fwd_chain_kernel(const FwdChainAr
     const int g = v / per, w = v - g * per;
     const int bz = g / batch, bi = g - bz * batch, grp = w / ny, by = w - grp * ny;
     MegaSync ms;
-    ms.wait = a.done1 + g; ms.wait_target = V2Tile<VG1, 1>::TPG * (VG1::OC / 32); ms.epoch = a.epoch; ms.timeout_flag = a.timeout_flag;
-    ms.done = a.done2 + g;
+    ms.wait = a.done1 + g * kChainPad; ms.wait_target = V2Tile<VG1, 1>::TPG * (VG1::OC / 32); ms.epoch = a.epoch; ms.timeout_flag = a.timeout_flag;
+    ms.done = a.done2 + g * kChainPad;
     conv_fwd_v2_body<VG2, false, 1, 4, false, true, true>(a.c2, none, bi * TPG + grp, by, bz, false, ms);
     return;
   }
   b -= a.n2;
+  if (b >= a.n3) {
+    fc4_rider_run<true>(a.rider, b - a.n3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned old = __hip_atomic_fetch_add(a.rider_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == (unsigned)a.n_riders - 1u) {
+        __hip_atomic_store(a.rider_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.rider_pending, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.rider_valid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
   {
     constexpr int TPG = V2Tile<VG3, 1>::TPG, ny = VG3::OC / 32, per = TPG * ny;
     const int v = a.c3.xcd_order ? xcd_order(b, a.n1 + a.n2, a.n3 / per, per) : b;
     const int g = v / per, w = v - g * per;
     const int bz = g / batch, bi = g - bz * batch, grp = w / ny, by = w - grp * ny;
     MegaSync ms;
-    ms.wait = a.done2 + g; ms.wait_target = V2Tile<VG2, 1>::TPG * (VG2::OC / 32); ms.epoch = a.epoch; ms.timeout_flag = a.timeout_flag;
+    ms.wait = a.done2 + g * kChainPad; ms.wait_target = V2Tile<VG2, 1>::TPG * (VG2::OC / 32); ms.epoch = a.epoch; ms.timeout_flag = a.timeout_flag;
     conv_fwd_v2_body<VG3, false, 1, 4, false, false, true>(a.c3, none, bi * TPG + grp, by, bz, false, ms);
   }
 }
@@ -1524,12 +1547,13 @@ int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy
                        const unsigned long long* update_seq, const int64_t* newest_off, int nz, const float* const* w1,
                        const float* const* b1, float* const* y1, const float* const* w2, const float* const* b2, float* const* y2,
                        const float* const* w3, const float* const* b3, float* const* y3, int batch, double u8_coef,
-                       unsigned* done_counters, const unsigned* epoch, int* timeout_flag, void* stream) {
+                       unsigned* done_counters, const unsigned* epoch, int* timeout_flag, const DraFc4Rider* rider,
+                       unsigned* rider_count, int* rider_pending, int* rider_valid, void* stream) {
   if (!frames || !idx || !newest_off || nz < 1 || nz > DRA_MAX_Z || batch < 1 || batch > 32 || !w1 || !b1 || !y1 || !w2 || !b2 || !y2 ||
       !w3 || !b3 || !y3 || !done_counters || !epoch || !timeout_flag)
     return DRA_EINVAL;
   if ((idx_tagged != nullptr) != (update_seq != nullptr)) return DRA_EINVAL;
-  if (g_rider_next.armed) { g_rider_next.armed = false; return DRA_EINVAL; }   // (the chain carries no riders)
+  if (g_rider_next.armed) { g_rider_next.armed = false; return DRA_EINVAL; }   // (the chain's riders come through `rider`)
   FwdChainArgs a;
   for (int z = 0; z < nz; ++z) {
     if (!w1[z] || !b1[z] || !y1[z] || !w2[z] || !b2[z] || !y2[z] || !w3[z] || !b3[z] || !y3[z]) return DRA_EINVAL;
@@ -1546,16 +1570,22 @@ int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy
     c->xcd_order = dra_xcd_order_enabled();
   }
   a.c1.coef = u8_coef;
-  a.done1 = done_counters; a.done2 = done_counters + DRA_MAX_Z * 32; a.epoch = epoch; a.timeout_flag = timeout_flag;
+  a.done1 = done_counters; a.done2 = done_counters + DRA_MAX_Z * 32 * kChainPad; a.epoch = epoch; a.timeout_flag = timeout_flag;
   a.n1 = nz * batch * V2Tile<VG1, 1>::TPG * (VG1::OC / 32);
   a.n2 = nz * batch * V2Tile<VG2, 1>::TPG * (VG2::OC / 32);
   a.n3 = nz * batch * V2Tile<VG3, 1>::TPG * (VG3::OC / 32);
+  a.n_riders = 0;
+  if (rider) {
+    if (!rider_count || !rider_pending || !rider_valid) return DRA_EINVAL;
+    a.rider = *rider; a.n_riders = fc4_rider_blocks(rider->count4);
+    a.rider_count = rider_count; a.rider_pending = rider_pending; a.rider_valid = rider_valid;
+  }
   constexpr size_t i1 = (size_t)VG1::C * V2Tile<VG1, 1>::CS, i2 = (size_t)VG2::C * V2Tile<VG2, 1>::CS, i3 = (size_t)VG3::C * V2Tile<VG3, 1>::CS;
   constexpr size_t red = (size_t)4 * 16 * 64;
   constexpr size_t m12 = i1 > i2 ? i1 : i2, m3 = i3 > red ? i3 : red;
   constexpr size_t bytes = (m12 > m3 ? m12 : m3) * sizeof(float);
   static_assert(bytes <= 40 * 1024, "four chain workgroups per CU");
-  hipLaunchKernelGGL(conv_fwd_chain_kernel, dim3(a.n1 + a.n2 + a.n3), dim3(256), bytes, dra_stream(stream), a);
+  hipLaunchKernelGGL(conv_fwd_chain_kernel, dim3(a.n1 + a.n2 + a.n3 + a.n_riders), dim3(256), bytes, dra_stream(stream), a);
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }

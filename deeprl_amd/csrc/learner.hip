@@ -406,18 +406,17 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
                (l->defer_begin & 3) == 0 && (l->defer_count & 3) == 0 && l->defer_count == (int64_t)512 * 3136 &&
                l->defer_begin >= l->lstride[0];
   }
-  // DRA_VAR_FWD_CHAIN: VanillaNet, ring-direct, two nets, the four-wave latency shape; the chain carries no riders (DEFER_FC4 off)
+  // DRA_VAR_FWD_CHAIN: VanillaNet, ring-direct, two nets, the four-wave latency shape
   l->fchain = (l->variant & DRA_VAR_FWD_CHAIN) && (l->variant & DRA_VAR_RING_DIRECT) && cfg->head_kind == DRA_HEAD_VANILLA &&
               !cfg->double_q && cfg->batch > 16 && cfg->batch <= 32;
-  if (l->fchain) l->defer = false;
   rc |= (int)hipMalloc(&l->defer_dev, 8 * sizeof(float));
   if (!rc) {
     const int init[8] = {0, 0, 1, 1, 1, 1, 0, 0};      // coefficient 0.0f, nothing pending, every copy valid
     rc |= (int)hipMemcpy(l->defer_dev, init, sizeof(init), hipMemcpyHostToDevice);
   }
   rc |= (int)hipMalloc(&l->aflags, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
-  rc |= (int)hipMalloc(&l->fchain_dev, (size_t)(kFwdChainCounters + 1) * sizeof(unsigned));
-  if (!rc) rc |= (int)hipMemset(l->fchain_dev, 0, (size_t)(kFwdChainCounters + 1) * sizeof(unsigned));
+  rc |= (int)hipMalloc(&l->fchain_dev, (size_t)(kFwdChainCounters + 2) * sizeof(unsigned));
+  if (!rc) rc |= (int)hipMemset(l->fchain_dev, 0, (size_t)(kFwdChainCounters + 2) * sizeof(unsigned));
   {
     const size_t words = kPersistLLWords + 1;
     rc |= (int)hipMalloc(&l->all_dev, words * sizeof(unsigned long long));
@@ -1226,21 +1225,26 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     // (PER drawn on the device: the previous update's chain kernel left them in device memory)
     const bool dev_idx = per && l->per2_dev;
     const bool pf = (l->variant & DRA_VAR_IDX_PREFETCH) && !dev_idx;
-    if (l->rider_q >= 0 && l->only_kernel < 0) {   // first half of the deferred fc4 segment rides here (common.h DraFc4Rider)
+    chain = l->fchain && !l->profiling && l->only_kernel < 0 && nz == 2;
+    if (!chain && l->rider_q >= 0 && l->only_kernel < 0) {   // first half of the deferred fc4 segment rides here (common.h DraFc4Rider)
       const DraFc4Rider r = fc4_rider(l, l->pa[l->rider_q]);
       const int nb = fc4_rider_blocks(r.count4);
       dra_conv_attach_rider(&r, 0, (nb * kRiderConv1Pct) / 100, nullptr, nullptr);
     }
-    chain = l->fchain && !l->profiling && l->only_kernel < 0 && nz == 2;
     if (chain) {
       const float* w2c[3] = {P + o[P_W2], T + o[P_W2], P + o[P_W2]};
       const float* b2c[3] = {P + o[P_B2], T + o[P_B2], P + o[P_B2]};
       const float* w3c[3] = {P + o[P_W3], T + o[P_W3], P + o[P_W3]};
       const float* b3c[3] = {P + o[P_B3], T + o[P_B3], P + o[P_B3]};
+      const bool riding = l->rider_q >= 0;      // the deferred fc4 segment as trailing workgroups of the chained launch
+      DraFc4Rider rdr;
+      if (riding) rdr = fc4_rider(l, l->pa[l->rider_q]);
       int rcc = dra_conv_fwd_chain(ring_frames, dev_idx ? l->per2_idx + (size_t)l->rd_slot * 1024 : l->idx_pin[l->rd_slot], l->idx,
                                    pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr, off, nz,
                                    w1, b1, l->y1, w2c, b2c, l->y2, w3c, b3c, l->y3, B, c.u8_coef, l->fchain_dev,
-                                   l->fchain_dev + kFwdChainCounters, l->timeout_flag, s);
+                                   l->fchain_dev + kFwdChainCounters, l->timeout_flag, riding ? &rdr : nullptr,
+                                   l->fchain_dev + kFwdChainCounters + 1, defer_pending_word(l),
+                                   defer_valid_word(l, l->rider_q >= 0 ? l->rider_q : 0), s);
       if (rcc) return rcc;
     } else
     STEP(K_CONV1_F, dra_conv1_fwd_koc_ringbatch(ring_frames, dev_idx ? l->per2_idx + (size_t)l->rd_slot * 1024 : l->idx_pin[l->rd_slot], l->idx,
@@ -1252,7 +1256,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   const void* x2[3] = {l->y1[0], l->y1[1], l->y1[2]};
   const float* w2[3] = {P + o[P_W2], T + o[P_W2], P + o[P_W2]};
   const float* b2[3] = {P + o[P_B2], T + o[P_B2], P + o[P_B2]};
-  if (rd && l->rider_q >= 0 && l->only_kernel < 0) {   // ... the second half here
+  if (!chain && rd && l->rider_q >= 0 && l->only_kernel < 0) {   // ... the second half here
     const DraFc4Rider r = fc4_rider(l, l->pa[l->rider_q]);
     const int nb = fc4_rider_blocks(r.count4);
     dra_conv_attach_rider(&r, (nb * kRiderConv1Pct) / 100, nb - (nb * kRiderConv1Pct) / 100, nullptr, nullptr);
@@ -1268,7 +1272,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   // fc4's forward weights are prefetched into the L2 of the XCD that will stream them, by spare workgroups of conv3's forward
   // launch (conv_v2.hip fc4_weight_prefetch; same box: fc4_fwd 10.9 -> 9.95 us, conv3_fwd +1.0 us, +0.5-0.8 % updates/s)
   // ... and the launch after the riders' lowers `pending` and marks the actor copy they completed valid
-  if (rd && l->rider_q >= 0 && l->only_kernel < 0)
+  if (!chain && rd && l->rider_q >= 0 && l->only_kernel < 0)
     dra_conv_attach_rider(nullptr, 0, 0, defer_pending_word(l), defer_valid_word(l, l->rider_q));
   if (chain) {
     // (conv3 ran inside the chained launch)
