@@ -208,3 +208,13 @@ int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy
                        const float* const* w3, const float* const* b3, float* const* y3, int batch, double u8_coef,
                        unsigned* done_counters, const unsigned* epoch, int* timeout_flag, const DraFc4Rider* rider,
                        unsigned* rider_count, int* rider_pending, int* rider_valid, void* stream);
+
+// fused.hip (library-internal), DRA_VAR_BWD_CHAIN: conv3's, conv2's and conv1's backward launches (one-pass roles, late fold) of a
+// minibatch of at most 32 as ONE launch in dependency order; counters = dra_bwd_chain_counters() zeroed unsigned, never reset
+int dra_bwd_chain_counters(void);
+int dra_conv_bwd_chain(const float* dy3, const float* y2, const float* wt3, float* dw3, float* db3, int64_t stride3, float* dy2,
+                       const float* y1, const float* wt2, float* dw2, float* db2, int64_t stride2, float* dy1, const void* frames,
+                       const int64_t* idx, float* dw1, float* db1, int64_t stride1, int batch, double u8_coef, int act,
+                       const dra_fold_seg* fold3, const dra_fold_seg* fold2, float* grad, double* partials3, int* n_partials3,
+                       double* partials2, int* n_partials2, double* reset_slots, int n_reset, unsigned* counters,
+                       const unsigned* epoch, int* timeout_flag, void* stream);

@@ -161,6 +161,91 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- cross-workgroup hand-over inside ONE launch (the actor's conv3 + fc4 launch, the update's chained launches) ----------------
+struct MegaSync {
+  unsigned* done = nullptr;        // this role's arrival counter (producers), null = nothing to publish
+  const unsigned* wait = nullptr;  // the counter this role waits on (consumers), null = nothing to wait for
+  unsigned wait_target = 0;
+  int* timeout_flag = nullptr;     // pinned host int
+  // optional: counters that are never reset -- the wait is for (*epoch + 1) * wait_target arrivals, `epoch` = launches of this
+  // kind completed so far (a LATER launch of the same step bumps it: the update's head kernel for the forward chain)
+  const unsigned* epoch = nullptr;
+  unsigned epoch_bias = 1;         // (0: the bump has already happened when the waiting launch runs -- the backward chain)
+  int slow = 0;                    // != 0: poll every ~0.4 us (hundreds of waiting workgroups on ONE counter: the slab folds)
+};
+constexpr unsigned long long kMegaWaitTicks = 5000000ull;   // 50 ms of s_memrealtime (100 MHz)
+
+__device__ __forceinline__ void mega_publish(const MegaSync& ms) {
+  if (!ms.done) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ms.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mega_wait(const MegaSync& ms) {
+  if (!ms.wait) return;
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = wall_clock64();
+    const unsigned target = ms.epoch ? (*ms.epoch + ms.epoch_bias) * ms.wait_target : ms.wait_target;
+    while (__hip_atomic_load(ms.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (ms.slow) __builtin_amdgcn_s_sleep(16);
+      else __builtin_amdgcn_s_sleep(1);
+      if (wall_clock64() - t0 > kMegaWaitTicks) {
+        if (ms.timeout_flag) __hip_atomic_store(ms.timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+template <bool COH> __device__ __forceinline__ float mega_ld(const float* p) {
+  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool COH> __device__ __forceinline__ void mega_st(float* p, float v) {
+  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+
+// 64- / 128-bit agent-scope loads for float4-shaped staging (two 8-byte relaxed atomic loads: the compiler tracks them)
+typedef float dra_f4 __attribute__((ext_vector_type(4)));
+template <bool COH> __device__ __forceinline__ dra_f4 mega_ld4(const dra_f4* p) {
+  if constexpr (COH) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    dra_f4 v;
+    v.x = __uint_as_float((unsigned)a); v.y = __uint_as_float((unsigned)(a >> 32));
+    v.z = __uint_as_float((unsigned)b); v.w = __uint_as_float((unsigned)(b >> 32));
+    return v;
+  } else {
+    return *p;
+  }
+}
+
+// What a ROLE of a chained launch (oneshot.h / oneshot_lin.h roles under fused.hip's bwd_chain_kernel) needs to know about its
+// place in the chain: the counters its workgroups wait on / count themselves on, one 128-byte line per sample (stride in
+// unsigned; 0 = ONE counter for the whole role: the slab folds wait for every weight-gradient workgroup of a layer).
+constexpr int kChainLine = 32;    // unsigned per counter line
+struct ChainHook {
+  const unsigned* wait = nullptr;
+  unsigned wait_target = 0;       // arrivals per launch on one counter
+  int wait_stride = 0;
+  unsigned* done = nullptr;
+  int done_stride = 0;
+  const unsigned* epoch = nullptr;
+  unsigned epoch_bias = 0;
+  int slow = 0;
+  int* timeout_flag = nullptr;
+  __device__ __forceinline__ MegaSync sync(int sample) const {
+    MegaSync ms;
+    if (wait) { ms.wait = wait + (int64_t)sample * wait_stride; ms.wait_target = wait_target; }
+    if (done) ms.done = done + (int64_t)sample * done_stride;
+    ms.epoch = epoch; ms.epoch_bias = epoch_bias; ms.timeout_flag = timeout_flag; ms.slow = slow;
+    return ms;
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Categorical(logits = x[0..A)) of one sample (network_heads.py:249-254): log-softmax, entropy, and -- when no action is given --
 // the inverse-CDF draw from one uniform (first a with cumsum(p)[a] > u; the last action absorbs rounding).  ONE statement shared

@@ -219,46 +219,7 @@ __device__ __forceinline__ void fused_env_workgroup(const ActorFuse& f, float* _
 // then the pinned timeout flag is set and the wait gives up -- results of that launch are invalid and the host reports
 // DRA_ETIMEDOUT), and the activations are read with agent-scope loads.  Few arrivals per counter (13 / 12 / 8): the
 // ~30 ns an agent-scope atomic costs on this part does not add up (the 796-ticket grid barrier of round 2 did).
-struct MegaSync {
-  unsigned* done = nullptr;        // this role's arrival counter (producers), null = nothing to publish
-  const unsigned* wait = nullptr;  // the counter this role waits on (consumers), null = nothing to wait for
-  unsigned wait_target = 0;
-  int* timeout_flag = nullptr;     // pinned host int
-  // optional: counters that are never reset -- the wait is for (*epoch + 1) * wait_target arrivals, `epoch` = launches of this
-  // kind completed so far (a LATER launch of the same step bumps it: the update's head kernel for the forward chain)
-  const unsigned* epoch = nullptr;
-};
-constexpr unsigned long long kMegaWaitTicks = 5000000ull;   // 50 ms of s_memrealtime (100 MHz)
-
-__device__ __forceinline__ void mega_publish(const MegaSync& ms) {
-  if (!ms.done) return;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(ms.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void mega_wait(const MegaSync& ms) {
-  if (!ms.wait) return;
-  if (threadIdx.x == 0) {
-    const unsigned long long t0 = wall_clock64();
-    const unsigned target = ms.epoch ? (*ms.epoch + 1u) * ms.wait_target : ms.wait_target;
-    while (__hip_atomic_load(ms.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (wall_clock64() - t0 > kMegaWaitTicks) {
-        if (ms.timeout_flag) __hip_atomic_store(ms.timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-    }
-  }
-  __syncthreads();
-}
-template <bool COH> __device__ __forceinline__ float mega_ld(const float* p) {
-  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else return *p;
-}
-template <bool COH> __device__ __forceinline__ void mega_st(float* p, float v) {
-  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
+// (MegaSync, mega_publish / mega_wait / mega_ld / mega_st live in common.h: the update's chained launches use them too)
 
 // (bx, by, bz) = the workgroup's position in the conv grid (blockIdx of a plain launch; a role offset inside the actor's
 // one-launch env step), env_wg = this workgroup is the fused launch's environment workgroup; COH = outputs are handed to
@@ -1483,7 +1444,7 @@ struct FwdChainArgs {
   // dispatched as conv1's workgroups leave, beside the 640 of conv2 / conv3, which are in front of them for the slots); the actor
   // copy is written through, every rider counts itself, the last one lowers `pending` and marks the copy valid
   DraFc4Rider rider;
-  int n_riders;
+  int n_riders, rider_after;
   unsigned* rider_count;
   int* rider_pending;
   int* rider_valid;
@@ -1494,31 +1455,9 @@ __global__ void __launch_bounds__(256, 4) conv_fwd_chain_kernel(const FwdChainAr
   none.mode = 0;
   int b = blockIdx.x;
   const int batch = a.c1.batch;
-  if (b < a.n1) {
-    constexpr int TPG = V2Tile<VG1, 1>::TPG, per = TPG * (VG1::OC / 32);
-    const int v = a.c1.xcd_order ? xcd_order(b, 0, a.n1 / per, per) : b;
-    const int g = v / per, w = v - g * per;
-    const int bz = g / batch, bi = g - bz * batch;
-    MegaSync ms;
-    ms.done = a.done1 + g * kChainPad;
-    conv_fwd_v2_body<VG1, true, 1, 4, false, true, false>(a.c1, none, bi * TPG + w, 0, bz, false, ms);
-    return;
-  }
-  b -= a.n1;
-  if (b < a.n2) {
-    constexpr int TPG = V2Tile<VG2, 1>::TPG, ny = VG2::OC / 32, per = TPG * ny;
-    const int v = a.c2.xcd_order ? xcd_order(b, a.n1, a.n2 / per, per) : b;
-    const int g = v / per, w = v - g * per;
-    const int bz = g / batch, bi = g - bz * batch, grp = w / ny, by = w - grp * ny;
-    MegaSync ms;
-    ms.wait = a.done1 + g * kChainPad; ms.wait_target = V2Tile<VG1, 1>::TPG * (VG1::OC / 32); ms.epoch = a.epoch; ms.timeout_flag = a.timeout_flag;
-    ms.done = a.done2 + g * kChainPad;
-    conv_fwd_v2_body<VG2, false, 1, 4, false, true, true>(a.c2, none, bi * TPG + grp, by, bz, false, ms);
-    return;
-  }
-  b -= a.n2;
-  if (b >= a.n3) {
-    fc4_rider_run<true>(a.rider, b - a.n3);
+  // the riders sit behind `rider_after` convolution workgroups of the grid
+  if (b >= a.rider_after && b < a.rider_after + a.n_riders) {
+    fc4_rider_run<true>(a.rider, b - a.rider_after);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1531,9 +1470,36 @@ __global__ void __launch_bounds__(256, 4) conv_fwd_chain_kernel(const FwdChainAr
     }
     return;
   }
+  if (b >= a.rider_after) b -= a.n_riders;
+  // (first = index of a role's first workgroup in the GRID: the XCD a workgroup runs on is blockIdx mod 8)
+  const int f2 = a.n1 + (a.n1 >= a.rider_after ? a.n_riders : 0), f3 = a.n1 + a.n2 + (a.n1 + a.n2 >= a.rider_after ? a.n_riders : 0);
+  const int f1 = 0 >= a.rider_after ? a.n_riders : 0;
+  if (b < a.n1) {
+    constexpr int TPG = V2Tile<VG1, 1>::TPG, per = TPG * (VG1::OC / 32);
+    const int v = a.c1.xcd_order ? xcd_order(b, f1, a.n1 / per, per) : b;
+    const int g = v / per, w = v - g * per;
+    const int bz = g / batch, bi = g - bz * batch;
+    MegaSync ms;
+    ms.done = a.done1 + g * kChainPad;
+    conv_fwd_v2_body<VG1, true, 1, 4, false, true, false>(a.c1, none, bi * TPG + w, 0, bz, false, ms);
+    return;
+  }
+  b -= a.n1;
+  if (b < a.n2) {
+    constexpr int TPG = V2Tile<VG2, 1>::TPG, ny = VG2::OC / 32, per = TPG * ny;
+    const int v = a.c2.xcd_order ? xcd_order(b, f2, a.n2 / per, per) : b;
+    const int g = v / per, w = v - g * per;
+    const int bz = g / batch, bi = g - bz * batch, grp = w / ny, by = w - grp * ny;
+    MegaSync ms;
+    ms.wait = a.done1 + g * kChainPad; ms.wait_target = V2Tile<VG1, 1>::TPG * (VG1::OC / 32); ms.epoch = a.epoch; ms.timeout_flag = a.timeout_flag;
+    ms.done = a.done2 + g * kChainPad;
+    conv_fwd_v2_body<VG2, false, 1, 4, false, true, true>(a.c2, none, bi * TPG + grp, by, bz, false, ms);
+    return;
+  }
+  b -= a.n2;
   {
     constexpr int TPG = V2Tile<VG3, 1>::TPG, ny = VG3::OC / 32, per = TPG * ny;
-    const int v = a.c3.xcd_order ? xcd_order(b, a.n1 + a.n2, a.n3 / per, per) : b;
+    const int v = a.c3.xcd_order ? xcd_order(b, f3, a.n3 / per, per) : b;
     const int g = v / per, w = v - g * per;
     const int bz = g / batch, bi = g - bz * batch, grp = w / ny, by = w - grp * ny;
     MegaSync ms;
@@ -1574,12 +1540,16 @@ int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy
   a.n1 = nz * batch * V2Tile<VG1, 1>::TPG * (VG1::OC / 32);
   a.n2 = nz * batch * V2Tile<VG2, 1>::TPG * (VG2::OC / 32);
   a.n3 = nz * batch * V2Tile<VG3, 1>::TPG * (VG3::OC / 32);
-  a.n_riders = 0;
+  a.n_riders = 0; a.rider_after = 0;
   if (rider) {
     if (!rider_count || !rider_pending || !rider_valid) return DRA_EINVAL;
     a.rider = *rider; a.n_riders = fc4_rider_blocks(rider->count4);
     a.rider_count = rider_count; a.rider_pending = rider_pending; a.rider_valid = rider_valid;
   }
+  // the riders are the LAST workgroups of the grid: dispatched as conv1's workgroups leave, behind conv2's and conv3's for the slots
+  // (behind conv2 they measured 8 376, behind conv1 7 557, in front of everything 9 347 against 9 750 updates/s at the end:
+  // riders in front of waiting workgroups hold the slots those need -- profiles/r06ze_ab_rider_position.jsonl)
+  a.rider_after = a.n1 + a.n2 + a.n3;
   constexpr size_t i1 = (size_t)VG1::C * V2Tile<VG1, 1>::CS, i2 = (size_t)VG2::C * V2Tile<VG2, 1>::CS, i3 = (size_t)VG3::C * V2Tile<VG3, 1>::CS;
   constexpr size_t red = (size_t)4 * 16 * 64;
   constexpr size_t m12 = i1 > i2 ? i1 : i2, m3 = i3 > red ? i3 : red;

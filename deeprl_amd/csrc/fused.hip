@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
-static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 524288 | 1048576 | 8388608 | 16777216 | 33554432;
+static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 524288 | 1048576 | 8388608 | 16777216 | 33554432 | 67108864;
 // every bit up to DRA_VAR_CU_PARTITION plus ACTOR_RING, ACTOR_FUSED_CONV1, GATHER_ON_UPDATE and RING_DIRECT measured faster
 // on MI355X in same-box A/Bs (profiles/r01b_ab_variants.jsonl, r01d_*, r01f_*, r02y_ab_*, r02zf_ab_*); ACTOR_V3 (512),
 // ACTOR_FUSED_HEAD (1024) and GATHER_IN_GRAPH (2048) measured neutral or slower and stay opt-in; IDX_PREFETCH (131072): conv1_fwd
@@ -329,6 +329,93 @@ int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, flo
   auto rw = make_wgrad_one<WG1u>(dy, x, dw_slabs, db_slabs, slab_stride, batch, u8_coef);
   rw.sample_idx = idx;
   return launch_multi(rw, rw.blocks(), f, f.blocks(), none, 0, dra_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// DRA_VAR_BWD_CHAIN (round 6): the three conv backward launches of the DQN update (batch <= 32, one-pass roles, late fold) as ONE
+// launch in dependency order:
+//   [conv3 dgrad | conv3 wgrad] [conv2 dgrad | conv2 wgrad] [conv1 wgrad] [fold of conv3's slabs] [fold of conv2's slabs]
+// A workgroup of layer L - 1 waits (its weights / forward activations requested first) for the input-gradient workgroups of ITS
+// sample in layer L; the folds wait for every weight-gradient workgroup of their layer (one counter, polled slowly: they are the
+// last in dispatch order and off the path).  Producers store agent-scope, complete their stores and count themselves; consumers
+// read with agent-scope loads.  Counters are never reset (targets = chains completed x arrivals per chain; the update's head
+// kernel has bumped the count when this launch runs).  Same arithmetic as the three launches: bit-identical gradients
+// (tests/test_gpu_agents.py::test_backward_chain_is_bit_identical).  DQN_agent.py:129-134's loss.backward() through
+// network_bodies.py:10-33.
+struct BwdChainN { int d3, w3, d2, w2, w1, f3, f2; };
+using BD3 = ConvDgradLin<G3, 1>;
+using BD2 = ConvDgradLin<G2, 2>;
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+bwd_chain_kernel(const BD3 d3, const WG3l w3, const BD2 d2, const WG2l w2, const WG1u w1, const FoldRole f3, const FoldRole f2,
+                 const BwdChainN n) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  int b = blockIdx.x, first = 0;
+  if (b < n.d3) { d3.run_<false, true>(b, dyn_lds, first); return; }
+  b -= n.d3; first += n.d3;
+  if (b < n.w3) { w3.run_<false, true>(b, dyn_lds, first); return; }
+  b -= n.w3; first += n.w3;
+  if (b < n.d2) { d2.run_<true, true>(b, dyn_lds, first); return; }
+  b -= n.d2; first += n.d2;
+  if (b < n.w2) { w2.run_<true, true>(b, dyn_lds, first); return; }
+  b -= n.w2; first += n.w2;
+  if (b < n.w1) { w1.run_<true>(b, dyn_lds, first); return; }
+  b -= n.w1;
+  if (b < n.f3) { f3.run_<true>(b, dyn_lds); return; }
+  b -= n.f3;
+  f2.run_<true>(b, dyn_lds);
+}
+
+constexpr int kBwdChainCounters = (2 * 32 + 2) * kChainLine;
+int dra_bwd_chain_counters(void) { return kBwdChainCounters; }
+
+// Library-internal (actor_env.h).  counters: kBwdChainCounters zeroed unsigned (never reset); *epoch = updates whose head kernel
+// has run (so: chains launched, this one included).  The fold arguments are those of dra_conv_bwd_fused_fold (layer 2: conv3's
+// segment) and dra_conv1_wgrad_fold (conv2's segment + the optimizer's arrival slots).
+int dra_conv_bwd_chain(const float* dy3, const float* y2, const float* wt3, float* dw3, float* db3, int64_t stride3, float* dy2,
+                       const float* y1, const float* wt2, float* dw2, float* db2, int64_t stride2, float* dy1, const void* frames,
+                       const int64_t* idx, float* dw1, float* db1, int64_t stride1, int batch, double u8_coef, int act,
+                       const dra_fold_seg* fold3, const dra_fold_seg* fold2, float* grad, double* partials3, int* n_partials3,
+                       double* partials2, int* n_partials2, double* reset_slots, int n_reset, unsigned* counters,
+                       const unsigned* epoch, int* timeout_flag, void* stream) {
+  if (!dy3 || !y2 || !wt3 || !dw3 || !db3 || !dy2 || !y1 || !wt2 || !dw2 || !db2 || !dy1 || !frames || !dw1 || !db1 || batch < 1 ||
+      batch > 32 || !n_partials3 || !n_partials2 || !fold_ok(fold3, grad, partials3) || !fold_ok(fold2, grad, partials2) || !counters ||
+      !epoch || !timeout_flag)
+    return DRA_EINVAL;
+  BD3 d3 = make_dgrad_one<G3, 1>(dy3, wt3, y2, dy2, batch, act);
+  WG3l w3 = make_wgrad_one<WG3l>(dy3, y2, dw3, db3, stride3, batch, 1.0);
+  BD2 d2 = make_dgrad_one<G2, 2>(dy2, wt2, y1, dy1, batch, act);
+  WG2l w2 = make_wgrad_one<WG2l>(dy2, y1, dw2, db2, stride2, batch, 1.0);
+  WG1u w1 = make_wgrad_one<WG1u>(dy1, frames, dw1, db1, stride1, batch, u8_coef);
+  w1.sample_idx = idx;
+  FoldRole f3 = make_fold_role(fold3, grad, partials3, nullptr, 0);
+  FoldRole f2 = make_fold_role(fold2, grad, partials2, reset_slots, n_reset);
+  BwdChainN n;
+  n.d3 = d3.blocks(); n.w3 = w3.blocks(); n.d2 = d2.blocks(); n.w2 = w2.blocks(); n.w1 = w1.blocks(); n.f3 = f3.blocks(); n.f2 = f2.blocks();
+  *n_partials3 = n.f3; *n_partials2 = n.f2;
+  unsigned* cA = counters;                       // conv3's input-gradient workgroups, per sample
+  unsigned* cB = counters + 32 * kChainLine;     // conv2's
+  unsigned* cW3 = counters + 64 * kChainLine;    // conv3's weight-gradient workgroups, all samples
+  unsigned* cW2 = counters + 65 * kChainLine;
+  ChainHook base;
+  base.epoch = epoch; base.epoch_bias = 0; base.timeout_flag = timeout_flag;
+  d3.hook = base; d3.hook.done = cA; d3.hook.done_stride = kChainLine;
+  w3.hook = base; w3.hook.done = cW3;
+  d2.hook = base; d2.hook.wait = cA; d2.hook.wait_stride = kChainLine; d2.hook.wait_target = BD3::WGS_PER_SAMPLE;
+  d2.hook.done = cB; d2.hook.done_stride = kChainLine;
+  w2.hook = base; w2.hook.wait = cA; w2.hook.wait_stride = kChainLine; w2.hook.wait_target = BD3::WGS_PER_SAMPLE; w2.hook.done = cW2;
+  w1.hook = base; w1.hook.wait = cB; w1.hook.wait_stride = kChainLine; w1.hook.wait_target = BD2::WGS_PER_SAMPLE;
+  f3.hook = base; f3.hook.wait = cW3; f3.hook.wait_target = (unsigned)n.w3; f3.hook.slow = 1;
+  f2.hook = base; f2.hook.wait = cW2; f2.hook.wait_target = (unsigned)n.w2; f2.hook.slow = 1;
+  constexpr int fa = BD3::LDS_FLOATS > WG3l::LDS_FLOATS ? BD3::LDS_FLOATS : WG3l::LDS_FLOATS;
+  constexpr int fb = BD2::LDS_FLOATS > WG2l::LDS_FLOATS ? BD2::LDS_FLOATS : WG2l::LDS_FLOATS;
+  constexpr int fc = WG1u::LDS_FLOATS > FoldRole::LDS_FLOATS ? WG1u::LDS_FLOATS : FoldRole::LDS_FLOATS;
+  constexpr int fab = fa > fb ? fa : fb, fl = fab > fc ? fab : fc;
+  constexpr size_t bytes = (size_t)fl * sizeof(float);
+  static_assert(bytes <= 64 * 1024, "LDS per workgroup of the chained backward launch");
+  hipLaunchKernelGGL(bwd_chain_kernel, dim3(n.d3 + n.w3 + n.d2 + n.w2 + n.w1 + n.f3 + n.f2), dim3(256), bytes, dra_stream(stream),
+                     d3, w3, d2, w2, w1, f3, f2, n);
+  DRA_LAUNCH_CHECK();
+  return DRA_OK;
 }
 
 // Backward of head + fc4 in one launch (VanillaNet over NatureConvBody, hidden = 512):

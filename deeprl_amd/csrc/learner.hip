@@ -224,6 +224,8 @@ struct dra_dqn_learner {
   PerChain2Args per2_args;
   unsigned* fchain_dev;             // DRA_VAR_FWD_CHAIN: [kFwdChainCounters] arrival counters (never reset) + [1] chains completed
   bool fchain;                      // the update's conv forwards run as one chained launch
+  unsigned* bchain_dev;             // DRA_VAR_BWD_CHAIN: arrival counters of the chained backward launch (never reset)
+  bool bchain;                      // the update's conv backward launches run as one chained launch
   unsigned long long* all_dev;      // DRA_VAR_ACTOR_PERSIST: {value, tag} hand-over arrays (y1 | y2p | y3p | h4[2]) + the abort word
   int actor_cus;                    // CUs of the stream the actor launches run on (0 = unknown: the whole device)
   unsigned* aflags;                 // DRA_VAR_ACTOR_MEGA: [kMaxEnvSteps][4] arrival counters of the one-launch env steps (zeroed by
@@ -409,6 +411,11 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   // DRA_VAR_FWD_CHAIN: VanillaNet, ring-direct, two nets, the four-wave latency shape
   l->fchain = (l->variant & DRA_VAR_FWD_CHAIN) && (l->variant & DRA_VAR_RING_DIRECT) && cfg->head_kind == DRA_HEAD_VANILLA &&
               !cfg->double_q && cfg->batch > 16 && cfg->batch <= 32;
+  // DRA_VAR_BWD_CHAIN: the one-pass backward roles with the late fold, VanillaNet, ring-direct, batch 17..32
+  l->bchain = (l->variant & DRA_VAR_BWD_CHAIN) && (l->variant & DRA_VAR_RING_DIRECT) && l->late && cfg->head_kind == DRA_HEAD_VANILLA &&
+              !cfg->double_q && cfg->batch > 16 && cfg->batch <= 32;
+  rc |= (int)hipMalloc(&l->bchain_dev, (size_t)dra_bwd_chain_counters() * sizeof(unsigned));
+  if (!rc) rc |= (int)hipMemset(l->bchain_dev, 0, (size_t)dra_bwd_chain_counters() * sizeof(unsigned));
   rc |= (int)hipMalloc(&l->defer_dev, 8 * sizeof(float));
   if (!rc) {
     const int init[8] = {0, 0, 1, 1, 1, 1, 0, 0};      // coefficient 0.0f, nothing pending, every copy valid
@@ -540,6 +547,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (l->aflags) (void)hipFree(l->aflags);
   if (l->all_dev) (void)hipFree(l->all_dev);
   if (l->fchain_dev) (void)hipFree(l->fchain_dev);
+  if (l->bchain_dev) (void)hipFree(l->bchain_dev);
   if (l->aring_dev) {
     (void)hipFree(l->aring_dev); (void)hipHostFree(l->aring_stage); (void)hipFree(l->aring_seq);
     (void)hipFree(l->pend_frame); (void)hipFree(l->pend_reward); (void)hipFree(l->pend_mask);
@@ -1202,6 +1210,8 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   // DRA_VAR_RING_DIRECT (l->rd_slot >= 0): the uint8 frames come straight from the replay ring, sample b of net z = the 4
   // slots ending at idx[b] (+ n_step for the next-state nets); no gathered copy exists
   const bool rd = l->rd_slot >= 0;
+  // DRA_VAR_BWD_CHAIN: conv3 / conv2 / conv1 backward as one chained launch (fused.hip bwd_chain_kernel)
+  const bool bchain = l->bchain && rd && !l->profiling && l->only_kernel < 0 && part == 0 && !per && !(l->per2_active && l->per2_ride);
   void *ring_frames = nullptr, *ring_actions = nullptr, *ring_rewards = nullptr, *ring_masks = nullptr;
   int ring_h = 4, ring_n = 1;
   double ring_discount = 1.0;
@@ -1290,7 +1300,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     rs.masks = (const int32_t*)ring_masks; rs.n_step = ring_n; rs.discount = ring_discount;
     rs.out_action = l->action_[l->gb]; rs.out_reward = l->reward_[l->gb]; rs.out_mask = l->mask_[l->gb];
     if ((l->variant & DRA_VAR_IDX_PREFETCH) && l->only_kernel < 0) rs.seq = l->rd_seq_dev;   // (a replay is not an update)
-    if (chain) rs.chain_epoch = l->fchain_dev + kFwdChainCounters;
+    if (chain || bchain) rs.chain_epoch = l->fchain_dev + kFwdChainCounters;
   }
   if (l->only_kernel >= 0 && l->only_kernel != K_HEAD) {
     // (single-kernel replay of another group: no head launch)
@@ -1363,6 +1373,17 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
                                          G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, l->partials, &nfc,
                                          c.head_kind != DRA_HEAD_VANILLA ? l->action_[l->gb] : nullptr, c.n_atoms, s));
       if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV3_BW], st));
+      if (bchain) {
+        int rcb = dra_conv_bwd_chain(l->dy3, l->y2[0], P + o[P_W3], dw[2], dbs[2], stride[2], l->dy2, l->y1[0], P + o[P_W2], dw[1],
+                                     dbs[1], stride[1], l->dy1, ring_frames, l->idx, dw[0], dbs[0], stride[0], B, c.u8_coef,
+                                     DRA_ACT_RELU, &segs[2], &segs[1], G, l->partials + nfc, &n3, l->partials + nfc + n3_expect, &n2,
+                                     l->partials + nfc_expect + n3_expect + n2_expect, l->late_nfold, l->bchain_dev,
+                                     l->fchain_dev + kFwdChainCounters, l->timeout_flag, s);
+        if (rcb) return rcb;
+        if (nfc != nfc_expect || n3 != n3_expect || n2 != n2_expect) return DRA_EINVAL;
+        l->late_nprior = nfc + n3 + n2;
+        return DRA_OK;
+      }
       if (l->per2_active && l->per2_ride)
         STEP(K_CONV3_BX, dra_conv3_bwd_fused_chain(l->dy3, l->y2[0], P + o[P_W3], l->y2[0], dw[2], dbs[2], stride[2], l->dy2, B,
                                                    DRA_ACT_RELU, var, &l->per2_args, l->per2_split ? 1 : 0, s));

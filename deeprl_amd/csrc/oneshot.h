@@ -214,7 +214,10 @@ struct FoldRole {
   double* reset_slots = nullptr;
   int n_reset = 0;
   __host__ int blocks() const { return (int)((count4 + EPB - 1) / EPB); }
-  __device__ __forceinline__ void run(int bid, float* lds, int = 0) const {
+  ChainHook hook;     // DRA_VAR_BWD_CHAIN (run_<CIN>: the slabs come from the weight-gradient workgroups of the SAME launch)
+  __device__ __forceinline__ void run(int bid, float* lds, int = 0) const { run_<false>(bid, lds); }
+  template <bool CIN>
+  __device__ __forceinline__ void run_(int bid, float* lds, int = 0) const {
     const int tid = threadIdx.x, g = tid >> 6, el = tid & 63;
     if (reset_slots && bid == 0)
       for (int i = tid; i < n_reset; i += 256) __hip_atomic_store(reset_slots + i, -1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -222,10 +225,12 @@ struct FoldRole {
     const int64_t ic = i < count4 ? i : count4 - 1;
     const float4* __restrict__ sl = reinterpret_cast<const float4*>(slabs) + ic;
     float4 t[SPT];
+    if constexpr (CIN) mega_wait(hook.sync(0));
 #pragma unroll
     for (int u = 0; u < SPT; ++u) {
       const int s = g + NG * u;
-      t[u] = sl[(int64_t)(s < n_slabs ? s : 0) * stride4];
+      const dra_f4 v4 = mega_ld4<CIN>(reinterpret_cast<const dra_f4*>(sl + (int64_t)(s < n_slabs ? s : 0) * stride4));
+      t[u] = make_float4(v4.x, v4.y, v4.z, v4.w);
     }
     __builtin_amdgcn_sched_barrier(0);
     float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -473,7 +478,11 @@ struct ConvWgradOne {
   __host__ __device__ static int spw(int batch) { return SHARES ? (batch + SHARES - 1) / SHARES : 1; }   // samples per workgroup
   __host__ int blocks() const { return SHARES ? ((B + spw(B) - 1) / spw(B)) * NGRP : B * NCHUNK * NGRP; }
   __host__ static int n_slabs(int batch) { return SHARES ? (batch + spw(batch) - 1) / spw(batch) : batch * NCHUNK; }
-  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
+  ChainHook hook;     // DRA_VAR_BWD_CHAIN (run_<CIN>: dy from workgroups of the same launch; uint8 input, one sample per workgroup)
+  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const { run_<false>(bid_, lds, first); }
+  template <bool CIN>
+  __device__ __forceinline__ void run_(int bid_, float* __restrict__ lds, int first = 0) const {
+    static_assert(!CIN || (U8 && SHARES == 0), "chained input: conv1's one-slab-per-chunk role");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int bid = (xcd && !SHARES) ? xcd_order(bid_, first, B, NCHUNK * NGRP) : bid_;
     const int grp = bid % NGRP;
@@ -507,16 +516,22 @@ struct ConvWgradOne {
     constexpr int NVD = WHOLE ? (G::OC * G::P) / 4 : G::OC * (RUN / 4), RD = (NVD + 255) / 256;
     float4 draw[RD];
     const float* dyb = dy + (int64_t)bi * G::OC * G::P + chunk * ROWS * OH;
+    auto request_dy = [&](auto coh) {
 #pragma unroll
-    for (int q = 0; q < RD; ++q) {
-      const int f = min(tid + 256 * q, NVD - 1);
-      if constexpr (WHOLE) {
-        draw[q] = reinterpret_cast<const float4*>(dyb)[f];
-      } else {
-        const int oc = f / (RUN / 4), v = f - oc * (RUN / 4);
-        draw[q] = *reinterpret_cast<const float4*>(dyb + oc * G::P + 4 * v);
+      for (int q = 0; q < RD; ++q) {
+        const int f = min(tid + 256 * q, NVD - 1);
+        const float* src;
+        if constexpr (WHOLE) {
+          src = dyb + 4 * f;
+        } else {
+          const int oc = f / (RUN / 4), v = f - oc * (RUN / 4);
+          src = dyb + oc * G::P + 4 * v;
+        }
+        const dra_f4 v4 = mega_ld4<decltype(coh)::value>(reinterpret_cast<const dra_f4*>(src));
+        draw[q] = make_float4(v4.x, v4.y, v4.z, v4.w);
       }
-    }
+    };
+    if constexpr (!CIN) request_dy(std::false_type{});
     if constexpr (U8) {
       constexpr int WPR = G::H / 4;                         // u32 words per 84-byte row
       constexpr int NW = NCH * NR * WPR, RI = (NW + 255) / 256;
@@ -530,6 +545,10 @@ struct ConvWgradOne {
         iraw[q] = *reinterpret_cast<const unsigned*>(xb + ((int64_t)min(cl, nch - 1) * G::H + ir0 + rr) * G::H + 4 * wd);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (CIN) {      // (the frame rows above are in flight while this workgroup waits for its sample's gradient)
+        mega_wait(hook.sync(bi));
+        request_dy(std::true_type{});
+      }
       for (int i = tid; i < DYF; i += 256) dyl[i] = 0.f;        // pad columns of the transposed gradient
 #pragma unroll
       for (int q = 0; q < RI; ++q) {

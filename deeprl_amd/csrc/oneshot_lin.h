@@ -55,8 +55,14 @@ struct ConvDgradLin {
   float* dx;          // [B][C][H][H]
   int B, act;
   int xcd = 0;        // != 0: all workgroups of a sample on one XCD (xcd_order)
+  ChainHook hook;     // DRA_VAR_BWD_CHAIN: this role's place in the chained backward launch (run_<CIN, COUT>)
+  static constexpr int WGS_PER_SAMPLE = NPH * TGP * MT;
   __host__ int blocks() const { return B * NPH * TGP * MT; }
-  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
+  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const { run_<false, false>(bid_, lds, first); }
+  // CIN: dy comes from workgroups of the SAME launch (wait for this sample's producers, agent-scope loads; the weights and the
+  // activation-derivative source are requested in front of the wait); COUT: dx goes to workgroups of the same launch
+  template <bool CIN, bool COUT>
+  __device__ __forceinline__ void run_(int bid_, float* __restrict__ lds, int first = 0) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int bid = xcd ? xcd_order(bid_, first, B, NPH * TGP * MT) : bid_;
     const int mt = bid % MT;
@@ -85,8 +91,10 @@ struct ConvDgradLin {
     constexpr int NV = NSRC / 4, RV = (NV + 255) / 256;
     lin_f4 rawv[RV];
     const lin_f4* dyb4 = reinterpret_cast<const lin_f4*>(dy + (int64_t)bi * NSRC);
+    if constexpr (!CIN) {
 #pragma unroll
-    for (int q = 0; q < RV; ++q) rawv[q] = dyb4[min(tid + 256 * q, NV - 1)];
+      for (int q = 0; q < RV; ++q) rawv[q] = dyb4[min(tid + 256 * q, NV - 1)];
+    }
     // ---- epilogue side input (activation-derivative source), loaded with everything else; per (tile, tap) operand bases
     int pix[PT];
     bool inside[PT];
@@ -113,6 +121,12 @@ struct ConvDgradLin {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    [[maybe_unused]] const MegaSync ms = hook.sync(bi);
+    if constexpr (CIN) {
+      mega_wait(ms);
+#pragma unroll
+      for (int q = 0; q < RV; ++q) rawv[q] = mega_ld4<true>(dyb4 + min(tid + 256 * q, NV - 1));
+    }
     lin_f4* lds4 = reinterpret_cast<lin_f4*>(lds);
     for (int i = tid; i < ZERO / 4; i += 256) lds4[NSRC / 4 + i] = lin_f4{0.f, 0.f, 0.f, 0.f};
     // (unconditional: a lane past the end re-writes the LAST float4 with the same value it loaded from the clamped index)
@@ -149,10 +163,11 @@ struct ConvDgradLin {
       for (int q = 0; q < 4; ++q) {
         const int c = c0 + mfma_row(wave * 4 + q, h);
         if (32 * t + li < np && inside[t])
-          dx[((int64_t)bi * G::C + c) * G::HW + pix[t]] = xact ? s[q] * act_grad(aux[t][q], act) : s[q];
+          mega_st<COUT>(&dx[((int64_t)bi * G::C + c) * G::HW + pix[t]], xact ? s[q] * act_grad(aux[t][q], act) : s[q]);
       }
     }
     DRA_STAMP(TRR, 5);
+    if constexpr (COUT) mega_publish(ms);
     DRA_STAMP_END(TRR);
   }
 };
@@ -187,11 +202,14 @@ struct ConvWgradLin {
   double coef;       // (unused: f32 inputs only; kept so that the role is built like ConvWgradOne)
   const int64_t* sample_idx = nullptr;   // (unused)
   int xcd = 0;        // != 0: all workgroups of a sample on one XCD (xcd_order)
+  ChainHook hook;     // DRA_VAR_BWD_CHAIN (run_<CIN, COUT>: dy from / slabs to workgroups of the same launch)
   __host__ int blocks() const { return B * NGRP; }
   __host__ static int n_slabs(int batch) { return batch; }
   // LDS float offset of output position p's top-left input pixel inside a channel: (oh * S) * H + ow * S
   static constexpr int pos_off(int p) { return (p / OH) * S * H + (p % OH) * S; }
-  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const {
+  __device__ __forceinline__ void run(int bid_, float* __restrict__ lds, int first = 0) const { run_<false, false>(bid_, lds, first); }
+  template <bool CIN, bool COUT>
+  __device__ __forceinline__ void run_(int bid_, float* __restrict__ lds, int first = 0) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int bid = xcd ? xcd_order(bid_, first, B, NGRP) : bid_;
     const int grp = bid % NGRP, bi = bid / NGRP;
@@ -207,8 +225,10 @@ struct ConvWgradLin {
     constexpr int NVD = NSRC / 4, RD = (NVD + 255) / 256;
     lin_f4 draw[RD];
     const lin_f4* dyb4 = reinterpret_cast<const lin_f4*>(dy + (int64_t)bi * NSRC);
+    if constexpr (!CIN) {
 #pragma unroll
-    for (int q = 0; q < RD; ++q) draw[q] = dyb4[min(tid + 256 * q, NVD - 1)];
+      for (int q = 0; q < RD; ++q) draw[q] = dyb4[min(tid + 256 * q, NVD - 1)];
+    }
     const int64_t xstart = ((int64_t)bi * G::C + c_lo) * HW;          // first float of the run
     const int shift = (int)(xstart & 3);                               // floats between the aligned start and the run
     const int nvi = (nch * HW + shift + 3) >> 2;                        // float4s that cover it
@@ -222,6 +242,12 @@ struct ConvWgradLin {
       iraw[q] = x4[min(f, xlast4 - (xstart >> 2))];
     }
     __builtin_amdgcn_sched_barrier(0);
+    [[maybe_unused]] const MegaSync ms = hook.sync(bi);
+    if constexpr (CIN) {      // (the input channels above are in flight while this workgroup waits for its sample's gradient)
+      mega_wait(ms);
+#pragma unroll
+      for (int q = 0; q < RD; ++q) draw[q] = mega_ld4<true>(dyb4 + min(tid + 256 * q, NVD - 1));
+    }
     lin_f4* img4 = reinterpret_cast<lin_f4*>(img);
     lin_f4* dyl4 = reinterpret_cast<lin_f4*>(dyl);
     // (unconditional stores: lanes past the end re-write the last float4 with the value they loaded from the clamped index)
@@ -277,7 +303,7 @@ struct ConvWgradLin {
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
           const int k = k0 + mt * 32 + mfma_row(rr, h);
-          dws[(int64_t)k * G::OC + nt * 32 + li] = acc[t][rr];
+          mega_st<COUT>(&dws[(int64_t)k * G::OC + nt * 32 + li], acc[t][rr]);
         }
       }
     }
@@ -285,9 +311,10 @@ struct ConvWgradLin {
       float sb = 0.f;
 #pragma unroll 8
       for (int pos = 0; pos < P; ++pos) sb += dyl[tid * P + pos];
-      db[(int64_t)bi * slab_stride + tid] = sb;
+      mega_st<COUT>(&db[(int64_t)bi * slab_stride + tid], sb);
     }
     DRA_STAMP(TRR, 5);
+    if constexpr (COUT) mega_publish(ms);
     DRA_STAMP_END(TRR);
   }
 };

@@ -331,6 +331,10 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
                                     * counter per (net, sample), weights requested first) for the workgroups of ITS sample in layer L
                                     * instead of for the whole layer and a launch boundary.  Same arithmetic: bit-identical.  Carries
                                     * no riders: DRA_VAR_DEFER_FC4 is off with it.  DQN_agent.py:81-99, network_bodies.py:10-33 */
+#define DRA_VAR_BWD_CHAIN 67108864 /* learner (as FWD_CHAIN, with LATE_FOLD): conv3's, conv2's and conv1's backward launches as ONE launch
+                                    * in dependency order -- a workgroup of layer L - 1 waits for the input-gradient workgroups of ITS
+                                    * sample in layer L, the slab folds for the weight-gradient workgroups of their layer.  Same
+                                    * arithmetic: bit-identical gradients.  DQN_agent.py:129-134 */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */

@@ -1560,3 +1560,44 @@ def test_forward_chain_is_bit_identical(dra):
         for i in (1, 2):
             assert np.array_equal(outs[0][k], outs[i][k]), ("chained vs separate forward launches", i, k)
     assert float(np.abs(outs[0]["p"]).max()) > 0
+
+
+def test_backward_chain_is_bit_identical(dra):
+    """DRA_VAR_BWD_CHAIN (round 6): conv1 + conv2 + conv3 of the update's forward pass (DQN_agent.py:81-99 through
+    network_bodies.py:10-33, both nets) as ONE launch whose workgroups wait for the workgroups of THEIR sample in the layer below
+    (arrival counters that are never reset, targets relative to the number of chains completed).  Same arithmetic in the same
+    order, hence the same bits: the benchmarked pipeline with the bit set and cleared ends on identical parameters, optimizer
+    state, target network and ring contents -- also across synchronise() calls, a target sync, kernel replays (which run the
+    three launches on their own) and an eager profile in the middle."""
+    d = dra
+    from deeprl_amd import ops
+    from deeprl_amd.learner import DQNLearnerBench
+    default = ops.get_tuning()
+    outs = []
+    for variant, interrupt in ((default & ~ops.VAR_BWD_CHAIN, False), (default | ops.VAR_BWD_CHAIN, False),
+                               (default | ops.VAR_BWD_CHAIN, True)):
+        np.random.seed(41)
+        torch.manual_seed(42)
+        b = DQNLearnerBench(ring_capacity=4096, batch=32, seed=43, actor=True, async_actor=True, variant=variant)
+        L = b.learner
+        for t in range(40):
+            b.step()
+            if t == 17:
+                L.sync_target()
+            if interrupt and t in (5, 6, 29):
+                L.synchronize()
+            if interrupt and t == 11:
+                L.kernel_replay("conv2_fwd", 4)
+                L.kernel_replay("conv2_bwd_x", 4)
+        L.synchronize()
+        frames = d.ops._wrap_device_pointer(b.ring.pointers()[0], 260 * 7056, torch.uint8).cpu().numpy().copy()
+        acts = d.ops._wrap_device_pointer(b.ring.pointers()[1], 260, torch.int64).cpu().numpy().copy()
+        outs.append(dict(p=L.flat.flat.detach().cpu().numpy().copy(), s1=L.state1.detach().cpu().numpy().copy(),
+                         s2=L.state2.detach().cpu().numpy().copy(), pt=L.target_flat.flat.detach().cpu().numpy().copy(),
+                         frames=frames, acts=acts))
+        L.close()
+        b.ring.close()
+    for k in outs[0]:
+        for i in (1, 2):
+            assert np.array_equal(outs[0][k], outs[i][k]), ("chained vs separate backward launches", i, k)
+    assert float(np.abs(outs[0]["p"]).max()) > 0
