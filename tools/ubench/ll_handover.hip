@@ -109,6 +109,62 @@ __global__ void __launch_bounds__(NT) ll_kernel(const Args a) {
   }
 }
 
+
+// Same-XCD forms: only workgroups with blockIdx % 8 == 0 take part (the dispatcher deals workgroups round-robin over the 8 XCDs),
+// so both groups share ONE L2.  LOCAL = 0: the agent-scope counter protocol above, unchanged (what the update's chained launches
+// use today); LOCAL = 1: plain stores, completed (s_waitcnt), a workgroup-scope atomic (executed in this XCD's L2), and
+// non-temporal loads for the poll and the data (lines that are not kept in the CU's L1: every poll is served by the L2).
+template <int MAXQ, int LOCAL>
+__global__ void __launch_bounds__(NT) flag_xcd_kernel(const Args a) {
+  if (blockIdx.x & 7) return;
+  const int wg = blockIdx.x >> 3;
+  const int grp = wg / a.p, w = wg - grp * a.p, tid = threadIdx.x;
+  const int share = a.n / a.p;
+  float v[MAXQ];
+  for (int s = 0; s < a.stages; ++s) {
+    if ((s & 1) != grp) continue;
+    float sum = 0.f;
+    if (s > 0) {
+      if (tid == 0) {
+        long spins = 0;
+        for (;;) {
+          unsigned c;
+          if (LOCAL) c = __builtin_nontemporal_load(a.counters + (s - 1));
+          else c = __hip_atomic_load(a.counters + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (c >= (unsigned)a.p) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > 2000000) { *a.fail = 3 + LOCAL; break; }
+        }
+      }
+      __syncthreads();
+      const float* src = a.plain[(s - 1) & 1];
+#pragma unroll
+      for (int q = 0; q < MAXQ; ++q) {
+        const int i = tid + NT * q;
+        const float* pp = src + (i < a.n ? i : a.n - 1);
+        v[q] = LOCAL ? __builtin_nontemporal_load(pp) : __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int q = 0; q < MAXQ; ++q) sum += v[q];
+    }
+    __shared__ float s_first;
+    if (tid == 0) s_first = s > 0 ? v[0] : 0.f;
+    __syncthreads();
+    const float out = s_first + 1.f + (sum != sum ? 1.f : 0.f);
+    float* dst = a.plain[s & 1];
+    for (int i = tid; i < share; i += NT) {
+      if (LOCAL) dst[w * share + i] = out;
+      else __hip_atomic_store(dst + w * share + i, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      if (LOCAL) __hip_atomic_fetch_add(a.counters + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __hip_atomic_fetch_add(a.counters + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const int mask_bits = argc > 1 ? atoi(argv[1]) : 0;   // > 0: run on a stream restricted to the first `mask_bits` CUs
   hipStream_t st;
@@ -161,6 +217,33 @@ int main(int argc, char** argv) {
       printf("%s{\"n_values\": %d, \"workgroups_per_group\": %d, \"flag_us_per_stage\": %.3f, \"ll_us_per_stage\": %.3f, \"final_flag\": %.0f, \"final_ll\": %.0f}",
              first ? "" : ", ", a.n, a.p, us[0], us[1], got[0], got[1]);
       first = false;
+    }
+  printf("], \"same_xcd\": [");
+  first = true;
+  for (int ni = 0; ni < 3; ++ni)
+    for (int pi = 0; pi < 2; ++pi) {
+      a.n = ns[ni]; a.p = ps[pi] / 2;      // 4 / 8 workgroups per group, all on XCD 0
+      double us[2] = {0, 0};
+      float got[2] = {0, 0};
+      for (int form = 0; form < 2; ++form) {
+        double best = 1e30;
+        for (int rep = 0; rep < 5; ++rep) {
+          CK(hipMemsetAsync(a.counters, 0, S * sizeof(unsigned), st));
+          CK(hipEventRecord(e0, st));
+          if (form == 0) hipLaunchKernelGGL((flag_xcd_kernel<12, 0>), dim3(16 * a.p), dim3(NT), 0, st, a);
+          else hipLaunchKernelGGL((flag_xcd_kernel<12, 1>), dim3(16 * a.p), dim3(NT), 0, st, a);
+          CK(hipEventRecord(e1, st));
+          CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          if (ms * 1e3 / S < best) best = ms * 1e3 / S;
+        }
+        us[form] = best;
+        CK(hipMemcpy(&got[form], a.plain[(S - 1) & 1], sizeof(float), hipMemcpyDeviceToHost));
+      }
+      printf("%s{\"n_values\": %d, \"workgroups_per_group\": %d, \"agent_scope_us_per_stage\": %.3f, \"local_us_per_stage\": %.3f, \"final_agent\": %.0f, \"final_local\": %.0f}",
+             first ? "" : ", ", a.n, a.p, us[0], us[1], got[0], got[1]);
+      first = false;
+      fflush(stdout);
     }
   printf("], \"fail\": %d}\n", *fail);
   return 0;
