@@ -190,6 +190,13 @@ struct ActorPersistArgs {
   int done_period, n_actions, n_env;
   int* timeout_flag;           // pinned host
   const int* w4_valid;         // optional (DRA_VAR_DEFER_FC4)
+  // DRA_VAR_FLAG_SYNC (all optional): instead of a stream wait on the update stream's event, every workgroup waits until
+  // *fs_count (device: update launches STARTED, conv_fwd_chain_kernel) has reached fs_need[agent step mod kAringSlots] (pinned
+  // host ring, written by the host before it issues this launch; 0 = nothing to wait for) BEFORE it reads anything the update
+  // stream produced; the environment workgroup publishes the agent steps completed to *fs_done_host (pinned host) at its end
+  const unsigned long long* fs_count;
+  const unsigned long long* fs_need;
+  unsigned long long* fs_done_host;
 };
 
 constexpr size_t kPersistY1 = 32 * 400, kPersistY2 = 2 * 64 * 81, kPersistY3 = 2 * 64 * 49, kPersistH4 = 2 * 512;
@@ -202,6 +209,7 @@ int dra_actor_persist(const ActorPersistArgs* a, void* stream);
 // rider (optional, DRA_VAR_DEFER_FC4): the deferred fc4 segment as trailing workgroups of the launch, rider_count a zeroed device word
 constexpr int kChainPad = 32;                  // unsigned per counter: one 128-byte line each
 constexpr int kFwdChainCounters = 2 * DRA_MAX_Z * 32 * kChainPad;
+void dra_conv_chain_attach_announce(unsigned long long* count);   // the next dra_conv_fwd_chain launch counts itself in *count
 int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* idx_tagged,
                        const unsigned long long* update_seq, const int64_t* newest_off, int nz, const float* const* w1,
                        const float* const* b1, float* const* y1, const float* const* w2, const float* const* b2, float* const* y2,

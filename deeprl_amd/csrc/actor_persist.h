@@ -127,6 +127,24 @@ __device__ __forceinline__ void actor_persist_body(const ActorPersistArgs& a, fl
   }
   const dra_dqn_step_params* prm = reinterpret_cast<const dra_dqn_step_params*>(s_prm);
 
+  // ---- DRA_VAR_FLAG_SYNC: the parameter copy read below is complete once the update stream has STARTED launch number `need`
+  // (everything it ran before that launch -- the optimizer that wrote the copy -- is then complete and written back); the host left
+  // `need` for this agent step in its pinned ring before issuing this launch.  One poller per workgroup, an agent-scope acquire
+  // behind it (nothing of the copy can be in this CU's caches from before: the launch boundary invalidated them and nobody here
+  // has read the copy since -- the fence is the formal half of that)
+  if (a.fs_count) {
+    if (tid == 0) {
+      const unsigned long long need = __hip_atomic_load(a.fs_need + (sq % kAringSlots), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      ck.start();
+      while (__hip_atomic_load(a.fs_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(8);
+        if (ck.expired()) break;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
+
   // ---- role geometry + operands
   PersistConv<16> c1;
   PersistConv<16> c2;
@@ -317,7 +335,12 @@ __device__ __forceinline__ void actor_persist_body(const ActorPersistArgs& a, fl
               *a.pend_mask = synth_mask(a.seed, nxt->rcounter[0], a.done_period);
             }
           }
-          if (tid == 0) *a.seq = sq + 1u;
+          if (tid == 0) {
+            *a.seq = sq + 1u;
+            // (DRA_VAR_FLAG_SYNC: every workgroup has read its share of the parameter copy long before the last head; the host
+            // uses this count only to decide when a copy / a staging entry may be REUSED, never to read what this launch wrote)
+            if (a.fs_done_host) __hip_atomic_store(a.fs_done_host, (unsigned long long)sq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
         }
       }
     }

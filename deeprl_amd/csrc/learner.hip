@@ -230,6 +230,23 @@ struct dra_dqn_learner {
   int actor_cus;                    // CUs of the stream the actor launches run on (0 = unknown: the whole device)
   unsigned* aflags;                 // DRA_VAR_ACTOR_MEGA: [kMaxEnvSteps][4] arrival counters of the one-launch env steps (zeroed by
                                     // the agent step's tail kernel)
+  // DRA_VAR_FLAG_SYNC (step_lane): the steady-state pipelined step without events.  fs = the learner can run it (decided at
+  // creation), fs_on = the streams currently carry lane work that no event covers (every other entry point leaves the lane first)
+  bool fs, fs_on;
+  unsigned long long* fs_count;     // device (own 256 bytes): ring-direct update graphs STARTED (conv_fwd_chain_kernel's first workgroup)
+  uint64_t fs_issued;               // host: ... issued (every launch of a graph captured with the announce, + fs_bump launches)
+  unsigned long long* fs_host;      // pinned: [0] agent steps completed by the persistent actor, [8 + i] `need` of agent step i mod kAringSlots
+  bool fs_graph[4];                 // g_rd[q] was captured with the announce
+  bool fs_agraph[4];                // g_aring[k] holds the persistent actor launch (the one that polls fs_count)
+  bool fs_persist_taken;            // set by run_actor_steps_ring_fused when it issues the persistent launch
+  bool fs_capturing;                // run_body is capturing such a graph
+  uint64_t fs_need_next;            // `need` of the next actor launch issue_actor_ring issues (0 = none; consumed there)
+  uint64_t fs_reader[4];            // agent-step count (aring_issued + 1) of the last actor launch that reads copy q (0: none pending)
+  struct { uint64_t done_at; int n; int64_t slots[8]; } fs_arec[4];   // the last four lane actor launches: complete once fs_host[0] >= done_at
+  int fs_arec_n;
+  hipStream_t fs_su, fs_sa;         // the streams the lane runs on (while fs_on)
+  int64_t fs_stat[4];               // lane steps, lane entries, hazard bumps, host waits for the actor stream (dra_dqn_learner_lane_stats)
+  hipEvent_t ev_fs;                 // recorded on the actor stream when the lane is left (actor_last of the event paths)
   bool late;
   int late_nprior;                  // partials written before the optimizer launch
   int late_nfold;                   // fold workgroups of the optimizer launch (their partial slots double as arrival flags)
@@ -238,6 +255,7 @@ struct dra_dqn_learner {
 
 struct HeadSpec;
 static HeadSpec head_spec(const dra_dqn_learner* l);
+static int fs_leave_any(dra_dqn_learner* l);   // DRA_VAR_FLAG_SYNC: leave the event-free lane (both streams drained) -- defined with step_lane
 
 // K slices of the update's fc4 forward (one-pass kernel only).  Default: 14 for two nets (224 workgroups: one per CU of the
 // update partition; fc4_fwd 10.4 -> 8.2 us, +1.8 % updates/s same box, profiles/r02zu_*), 8 with the third net of double-Q
@@ -421,6 +439,19 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
     const int init[8] = {0, 0, 1, 1, 1, 1, 0, 0};      // coefficient 0.0f, nothing pending, every copy valid
     rc |= (int)hipMemcpy(l->defer_dev, init, sizeof(init), hipMemcpyHostToDevice);
   }
+  // DRA_VAR_FLAG_SYNC: the forward chain announces, the persistent actor polls and publishes, the step is ring-direct with the
+  // parameter-block ring and four rotating copies
+  {
+    const int need = DRA_VAR_FLAG_SYNC | DRA_VAR_RING_DIRECT | DRA_VAR_GATHER_ON_UPDATE | DRA_VAR_PIPE_GATHER | DRA_VAR_ACTOR_PARAMS |
+                     DRA_VAR_ACTOR_RING | DRA_VAR_ACTOR_FUSED_CONV1 | DRA_VAR_ACTOR_MEGA | DRA_VAR_ACTOR_PERSIST;
+    l->fs = (l->variant & need) == need && l->fchain && cfg->head_kind == DRA_HEAD_VANILLA &&
+            !(l->variant & (DRA_VAR_GATHER_IN_GRAPH | DRA_VAR_ACTOR_V3));
+  }
+  rc |= (int)hipMalloc(&l->fs_count, 256);
+  if (!rc) rc |= (int)hipMemset(l->fs_count, 0, 256);
+  rc |= (int)hipHostMalloc(&l->fs_host, (size_t)(8 + kAringSlots) * sizeof(unsigned long long), hipHostMallocDefault);
+  if (!rc) memset(l->fs_host, 0, (size_t)(8 + kAringSlots) * sizeof(unsigned long long));
+  rc |= (int)hipEventCreateWithFlags(&l->ev_fs, hipEventDisableTiming);
   rc |= (int)hipMalloc(&l->aflags, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
   rc |= (int)hipMalloc(&l->fchain_dev, (size_t)(kFwdChainCounters + 2) * sizeof(unsigned));
   if (!rc) rc |= (int)hipMemset(l->fchain_dev, 0, (size_t)(kFwdChainCounters + 2) * sizeof(unsigned));
@@ -548,6 +579,9 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (l->all_dev) (void)hipFree(l->all_dev);
   if (l->fchain_dev) (void)hipFree(l->fchain_dev);
   if (l->bchain_dev) (void)hipFree(l->bchain_dev);
+  if (l->fs_count) (void)hipFree(l->fs_count);
+  if (l->fs_host) (void)hipHostFree(l->fs_host);
+  if (l->ev_fs) (void)hipEventDestroy(l->ev_fs);
   if (l->aring_dev) {
     (void)hipFree(l->aring_dev); (void)hipHostFree(l->aring_stage); (void)hipFree(l->aring_seq);
     (void)hipFree(l->pend_frame); (void)hipFree(l->pend_reward); (void)hipFree(l->pend_mask);
@@ -625,6 +659,7 @@ DRA_API int dra_dqn_learner_resume_buffer_count(void) { return (int)(sizeof(kRes
 
 DRA_API int dra_dqn_learner_resume_buffer(dra_dqn_learner* l, int index, void** ptr, int64_t* bytes, char* name, int name_len) {
   if (!l || !ptr || !bytes || index < 0 || index >= (int)(sizeof(kResumeNames) / sizeof(kResumeNames[0]))) return DRA_EINVAL;
+  if (int rcl = fs_leave_any(l)) return rcl;
   if (l->defer_host) return DRA_EINVAL;   // (DRA_VAR_DEFER_FC4: dra_dqn_learner_flush + a synchronise first -- a pending fc4 segment is not a state to save)
   void* p = nullptr;
   int64_t n = 0;
@@ -648,6 +683,7 @@ DRA_API int dra_dqn_learner_resume_buffer(dra_dqn_learner* l, int index, void** 
 
 DRA_API int dra_dqn_learner_resume_counters(dra_dqn_learner* l, int64_t* io, int n, int restore) {
   if (!l || !io || n < 16) return DRA_EINVAL;
+  if (int rcl = fs_leave_any(l)) return rcl;
   if (l->defer_host) return DRA_EINVAL;   // (DRA_VAR_DEFER_FC4: dra_dqn_learner_flush + a synchronise first -- a pending fc4 segment is not a state to save)
   if (!restore) {
     memset(io, 0, (size_t)n * sizeof(int64_t));
@@ -1119,6 +1155,7 @@ __global__ void fc4_flush_done_kernel(int* pending, int* valid) {
 // The deferred fc4 segment stepped NOW, on `st` (ordered behind the optimizer launch that left it: `st` waits for last_done):
 // in front of everything that reads the parameters, the optimizer state or an actor copy outside the pipelined ring-direct graphs.
 static int flush_fc4(dra_dqn_learner* l, hipStream_t st) {
+  if (int rcl = fs_leave_any(l)) return rcl;     // (DRA_VAR_FLAG_SYNC: the event paths never meet un-recorded lane work)
   if (!l->defer_host) return DRA_OK;
   if (l->last_done) DRA_HIP(hipStreamWaitEvent(st, l->last_done, 0));
   const DraFc4Rider r = fc4_rider(l, l->pa[l->defer_q & 3]);
@@ -1249,6 +1286,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       const bool riding = l->rider_q >= 0;      // the deferred fc4 segment as trailing workgroups of the chained launch
       DraFc4Rider rdr;
       if (riding) rdr = fc4_rider(l, l->pa[l->rider_q]);
+      if (l->fs_capturing) dra_conv_chain_attach_announce(l->fs_count);
       int rcc = dra_conv_fwd_chain(ring_frames, dev_idx ? l->per2_idx + (size_t)l->rd_slot * 1024 : l->idx_pin[l->rd_slot], l->idx,
                                    pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr, off, nz,
                                    w1, b1, l->y1, w2c, b2c, l->y2, w3c, b3c, l->y3, B, c.u8_coef, l->fchain_dev,
@@ -1513,7 +1551,10 @@ static int capture_part(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int 
   // and its own optimizer launch leaves fc4's segment to the next graph
   const bool defer = rd && l->defer && !per && part == 0 && with_optimizer;
   l->rider_q = defer ? ((q + 3) & 3) : -1;
+  // DRA_VAR_FLAG_SYNC: the plain ring-direct graph's first launch counts itself in fs_count (update_graph counts the replays)
+  l->fs_capturing = l->fs && rd && !per && part == 0 && with_optimizer;
   int rc = run_body(l, st, per, per ? -1.f : 0.f, 0, part);     // PER: the exponent is read from sampling_prob[B]
+  if (l->fs_capturing) { l->fs_graph[q & 3] = rc == DRA_OK; l->fs_capturing = false; }
   l->rider_q = -1;
   if (rc == DRA_OK && with_optimizer) rc = launch_optimizer(l, st, l->pa[q], defer ? q : -1);
   hipError_t e = hipStreamEndCapture(st, &graph);
@@ -1593,6 +1634,7 @@ static int update_graph(dra_dqn_learner* l, hipStream_t st, int q, bool rd, int 
     if (rcf) return rcf;
   }
   DRA_HIP(hipGraphLaunch(*exec, st));
+  if (rd && !per && l->fs_graph[q & 3]) l->fs_issued++;     // (its first launch bumps fs_count when it starts)
   if (riding) { l->defer_host = true; l->defer_q = q; }
   if (per && !(l->per2_dev && l->per_tree)) {
     DRA_HIP(hipEventRecord(l->ev_loss, st));
@@ -2557,6 +2599,7 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
     pa.abort_word = reinterpret_cast<int*>(l->all_dev + kPersistLLWords);
     pa.seed = (uint64_t)c.env_seed; pa.coef = c.u8_coef; pa.done_period = (int)c.env_done_period; pa.n_actions = c.n_actions;
     pa.n_env = n_env; pa.timeout_flag = l->timeout_flag;
+    if (l->fs) { pa.fs_count = l->fs_count; pa.fs_need = l->fs_host + 8; pa.fs_done_host = l->fs_host; l->fs_persist_taken = true; }
     if (l->defer)
       for (int k = 0; k < 4; ++k)
         if (P == l->pa[k] && l->pa[k]) pa.w4_valid = defer_valid_word(l, k);
@@ -2721,6 +2764,11 @@ static int issue_actor_ring(dra_dqn_learner* l, int n_env, const float* P, int p
     DRA_LAUNCH_CHECK();
     l->aring_primed = true;
   }
+  // DRA_VAR_FLAG_SYNC: what this agent step's launch waits for on the device (0: nothing -- the caller ordered the streams)
+  if (l->fs_host) {
+    __atomic_store_n(&l->fs_host[8 + (size_t)(l->aring_issued % kAringSlots)], (unsigned long long)l->fs_need_next, __ATOMIC_RELEASE);
+    l->fs_need_next = 0;
+  }
   int rc;
   if (!use_graph) {
     rc = run_actor_steps_ring(l, n_env, P, st);
@@ -2732,7 +2780,9 @@ static int issue_actor_ring(dra_dqn_learner* l, int n_env, const float* P, int p
     if (!l->g_aring_ready[par]) {
       hipGraph_t graph;
       DRA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      l->fs_persist_taken = false;
       rc = run_actor_steps_ring(l, n_env, P, st);
+      l->fs_agraph[par] = l->fs_persist_taken && rc == DRA_OK;
       hipError_t e = hipStreamEndCapture(st, &graph);
       if (rc != DRA_OK) return rc;
       if (e != hipSuccess) return (int)e;
@@ -3232,6 +3282,147 @@ static int step_pipelined2(dra_dqn_learner* l, const dra_dqn_step_params* prm, i
   return DRA_OK;
 }
 
+// ---- DRA_VAR_FLAG_SYNC: the steady-state pipelined step without events ------------------------------------------------------------
+// tools/ubench/graph_gap.hip (profiles/r06zi_graph_gap.jsonl): with the update as one graph per step, the event record behind it
+// costs 4.9 us of the update stream's time and the actor stream's wait on that event another 9.4 us -- per step, on the chain that
+// bounds the rate.  In the lane neither stream records or waits for anything:
+//   * update t's first launch counts itself in fs_count when it STARTS -- which says that everything the update stream ran before
+//     it, update t-1's optimizer included, is complete and written back (a launch boundary);
+//   * the actor launch issued with update t reads the copy update t-1 wrote: its workgroups poll fs_count >= `need` (the host leaves
+//     the number of update t in a pinned ring indexed by the agent step) instead of the stream waiting for an event;
+//   * the host never runs more than three calls ahead: before it issues update t it polls the pinned count of agent steps the
+//     actor has completed until the launch issued with update t-3 is done -- that launch read the copy update t's optimizer
+//     overwrites, and it started only after update t-4 was complete, which frees the pinned index buffer of rotation slot q;
+//   * the two rare slot hazards (DQN_agent.py:101-127 fed and sampled in one step) keep their meaning: a minibatch that reads slots
+//     an unfinished actor launch writes makes the HOST wait for the actor stream; an actor launch that overwrites slots this
+//     call's minibatch reads waits for one more count, which a one-thread launch behind the update graph provides.
+// Every other entry point of the learner leaves the lane first (fs_leave: both streams drained, the event paths' bookkeeping reset
+// to "nothing pending"), so the event paths never meet un-recorded work.
+__global__ void fs_bump_kernel(unsigned long long* count) { __hip_atomic_fetch_add(count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+static int fs_leave(dra_dqn_learner* l, hipStream_t su, hipStream_t sa);
+static int fs_leave_any(dra_dqn_learner* l) { return l->fs_on ? fs_leave(l, l->fs_su, l->fs_sa) : DRA_OK; }
+static int fs_leave(dra_dqn_learner* l, hipStream_t su, hipStream_t sa) {
+  if (!l->fs_on) return DRA_OK;
+  l->fs_on = false;
+  DRA_HIP(hipStreamSynchronize(su));     // (every count an actor launch polls for comes from work already issued on `su`)
+  DRA_HIP(hipStreamSynchronize(sa));
+  l->last_done = nullptr;
+  for (int q = 0; q < 4; ++q) { l->pa_reader[q] = nullptr; l->upd_used[q] = false; l->fs_reader[q] = 0; }
+  for (int k = 0; k < 8; ++k) l->stage_used[k] = false;
+  l->arec_count = 0;
+  l->fs_arec_n = 0;
+  DRA_HIP(hipEventRecord(l->ev_fs, sa));
+  l->actor_last = l->ev_fs;
+  return DRA_OK;
+}
+
+static inline uint64_t fs_actor_done(const dra_dqn_learner* l) { return __atomic_load_n(&l->fs_host[0], __ATOMIC_ACQUIRE); }
+
+// the 32-bit device count against a 64-bit host target (the device counter wraps, the distance never exceeds a few steps)
+static inline bool fs_reached(uint64_t done32, uint64_t target) { return (uint32_t)((uint32_t)done32 - (uint32_t)target) < 0x80000000u; }
+
+static int fs_wait_actor(dra_dqn_learner* l, uint64_t target) {
+  if (fs_reached(fs_actor_done(l), target)) return DRA_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    for (int i = 0; i < 64; ++i) {
+      if (fs_reached(fs_actor_done(l), target)) {
+        l->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return DRA_OK;
+      }
+      __builtin_ia32_pause();
+    }
+    if (*l->timeout_flag) return DRA_ETIMEDOUT;
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) return DRA_ETIMEDOUT;
+  }
+}
+
+// can THIS call run in the lane?  (everything that would make step_pipelined3 do more than [update graph, actor graph])
+static bool fs_eligible(const dra_dqn_learner* l, const dra_dqn_step_params* prm, int do_update, void* stream_actor) {
+  if (!l->fs || !stream_actor || !do_update || prm->n_env < 1 || l->step_per || l->keep_minibatch || l->tr_ev) return false;
+  const int q = (int)(l->step_no & 3), qr = (q + 3) & 3;
+  if (!l->pa_valid || l->pa_cur != qr) return false;                       // (a seed copy: event path)
+  if (!l->g_rd_ready[q] || !l->fs_graph[q]) return false;                  // (the first four updates capture on the event path)
+  if (!l->g_aring_ready[qr] || !l->fs_agraph[qr] || l->g_aring_nenv[qr] != prm->n_env) return false;
+  if (!l->aring_primed || l->aring_issued >= l->aring_pushed) return false;
+  if (l->defer ? (l->defer_host && l->defer_q != qr) : l->defer_host) return false;   // (a pending fc4 segment this graph's riders do not finish)
+  return true;
+}
+
+static int step_lane(dra_dqn_learner* l, const dra_dqn_step_params* prm, hipStream_t su, hipStream_t sa) {
+  const int B = l->c.batch;
+  const int q = (int)(l->step_no & 3), cur = (q + 3) & 3;
+  int rc;
+  if (!l->fs_on) {
+    // entering: whatever the event paths left on the streams completes first, then the counts agree by construction
+    DRA_HIP(hipStreamSynchronize(su));
+    DRA_HIP(hipStreamSynchronize(sa));
+    __atomic_store_n(&l->fs_host[0], (unsigned long long)(uint32_t)l->aring_issued, __ATOMIC_RELEASE);   // (non-persistent launches do not publish)
+    for (int i = 0; i < 4; ++i) l->fs_reader[i] = 0;
+    l->fs_arec_n = 0;
+    l->fs_on = true;
+    l->fs_stat[1]++;
+  }
+  const dra_dqn_step_params* ablk =
+      reinterpret_cast<const dra_dqn_step_params*>(l->aring_stage + (size_t)(l->aring_issued % kAringSlots) * kAprmStride);
+  // the copy update t overwrites (and, transitively, index buffer q): its last reader must be done
+  if (l->fs_reader[q]) {
+    if ((rc = fs_wait_actor(l, l->fs_reader[q]))) return rc;
+    l->fs_reader[q] = 0;
+  }
+  // minibatch reads slots an unfinished actor launch writes: the host waits for the actor stream (a real completion: the ring
+  // writes must be visible to the update's first launch)
+  for (int i = l->fs_arec_n - 1; i >= 0; --i) {
+    const auto& r = l->fs_arec[i];
+    if (fs_reached(fs_actor_done(l), r.done_at)) continue;
+    if (gather_reads_slots(l, prm->idx, r.slots, r.n)) {
+      const auto t0 = std::chrono::steady_clock::now();
+      DRA_HIP(hipStreamSynchronize(sa));
+      l->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      l->fs_stat[3]++;
+      break;
+    }
+  }
+  const bool hazard = gather_reads_slots(l, prm->idx, ablk->slot, prm->n_env);
+  memcpy(l->idx_pin[q], prm->idx, (size_t)B * sizeof(int64_t));
+  if (l->variant & DRA_VAR_IDX_PREFETCH) {
+    const uint64_t tag = ((l->rd_issued + 1ull) & 0xffffffull) << 40;
+    volatile int64_t* dst = l->idx_tag_pin[q];
+    for (int b = 0; b < B; ++b) dst[b] = (int64_t)((uint64_t)prm->idx[b] | tag);
+    DRA_HIP(hipMemcpyAsync(l->idx_tag_dev + (size_t)q * 1024, l->idx_tag_pin[q], (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, l->side));
+  }
+  l->rd_issued++;
+  l->last_gb = q & 1;
+  if ((rc = rd_graph(l, su, q, 0))) return rc;           // [update t] -- counts itself in fs_count at its start
+  if (!l->fs_on) return DRA_EINVAL;                       // (rd_graph never flushes here: fs_eligible checked the pending segment)
+  if (hazard) {                                           // the actor launch below must not start before update t has read the ring
+    hipLaunchKernelGGL(fs_bump_kernel, dim3(1), dim3(1), 0, su, l->fs_count);
+    DRA_LAUNCH_CHECK();
+    l->fs_issued++;
+    l->fs_stat[2]++;
+  }
+  l->fs_need_next = l->fs_issued;
+  if ((rc = issue_actor_ring(l, prm->n_env, l->pa[cur], cur, sa, true))) return rc;   // [actor t+1] -- polls fs_count >= need
+  l->actor_pending = true;
+  const uint64_t done_at = l->aring_issued;               // (issue_actor_ring advanced it: agent steps completed once this launch is)
+  l->fs_reader[cur] = done_at;
+  if (l->fs_arec_n == 4) { for (int i = 1; i < 4; ++i) l->fs_arec[i - 1] = l->fs_arec[i]; l->fs_arec_n = 3; }
+  auto& r = l->fs_arec[l->fs_arec_n++];
+  r.done_at = done_at; r.n = prm->n_env;
+  for (int e = 0; e < prm->n_env && e < 8; ++e) r.slots[e] = ablk->slot[e];
+  l->pa_cur = q;                                          // the graph's optimizer writes copy q
+  l->step_no++;
+  l->fs_stat[0]++;
+  return DRA_OK;
+}
+
+DRA_API int dra_dqn_learner_lane_stats(dra_dqn_learner* l, int64_t* out) {
+  if (!l || !out) return DRA_EINVAL;
+  for (int i = 0; i < 4; ++i) out[i] = l->fs_stat[i];
+  return DRA_OK;
+}
+
 // pinned staging slot k is free again once the copies issued from it have completed
 static int stage_acquire(dra_dqn_learner* l, int* k_out) {
   const int k = l->stage_k;
@@ -3294,6 +3485,7 @@ DRA_API int dra_dqn_learner_step(dra_dqn_learner* l, const dra_dqn_step_params* 
 static int step_split_check(dra_dqn_learner* l, const dra_dqn_step_params* prm, void* su, void* sa) {
   if (!l || !prm || !su || !sa || prm->n_env < 1 || prm->n_env > kMaxEnvSteps || !l->per2_dev) return DRA_EINVAL;
   if (!l->step_per || l->step_beta >= 0.f) return DRA_EINVAL;
+  if (int rcl = fs_leave_any(l)) return rcl;
   const int need = DRA_VAR_PIPE_GATHER | DRA_VAR_ACTOR_PARAMS | DRA_VAR_GATHER_ON_UPDATE | DRA_VAR_RING_DIRECT | DRA_VAR_ACTOR_RING;
   if ((l->variant & need) != need) return DRA_EINVAL;
   if (*l->timeout_flag) return DRA_ETIMEDOUT;
@@ -3391,6 +3583,12 @@ static int learner_step_impl(dra_dqn_learner* l, const dra_dqn_step_params* prm,
   const int B = l->c.batch;
   l->profiling = false;
   int k, rc;
+  if (fs_eligible(l, prm, do_update, stream_actor)) {
+    if (l->fs_on && (su != l->fs_su || sa != l->fs_sa)) { if ((rc = fs_leave_any(l))) return rc; }
+    l->fs_su = su; l->fs_sa = sa;
+    return step_lane(l, prm, su, sa);
+  }
+  if ((rc = fs_leave_any(l))) return rc;
   {   // DRA_VAR_DEFER_FC4: only step_pipelined3 may leave a segment pending across calls (it decides for itself)
     const bool p3 = stream_actor && (l->variant & DRA_VAR_PIPE_GATHER) && (l->variant & DRA_VAR_ACTOR_PARAMS) &&
                     (l->variant & DRA_VAR_GATHER_ON_UPDATE) && !((l->variant & DRA_VAR_GATHER_IN_GRAPH) && !(l->variant & DRA_VAR_ACTOR_V3));

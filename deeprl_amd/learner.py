@@ -380,6 +380,12 @@ class DQNLearner:
         n = max(1.0, out[0])
         return {"calls": int(out[0]), "call_us": 1e6 * out[1] / n, "blocked_on_gpu_us": 1e6 * out[2] / n}
 
+    def lane_stats(self):
+        """DRA_VAR_FLAG_SYNC: {'steps', 'entries', 'hazard_bumps', 'host_waits'} of the event-free lane since creation."""
+        out = (ctypes.c_int64 * 4)()
+        lib.dra_dqn_learner_lane_stats(self.h, out)
+        return {"steps": int(out[0]), "entries": int(out[1]), "hazard_bumps": int(out[2]), "host_waits": int(out[3])}
+
     def invalidate_actor_copy(self):
         """The parameters were changed from outside (checkpoint load): the async actor's copies are reseeded on the next step."""
         lib.dra_dqn_learner_invalidate_actor_copy(self.h)

@@ -335,6 +335,14 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
                                     * in dependency order -- a workgroup of layer L - 1 waits for the input-gradient workgroups of ITS
                                     * sample in layer L, the slab folds for the weight-gradient workgroups of their layer.  Same
                                     * arithmetic: bit-identical gradients.  DQN_agent.py:129-134 */
+#define DRA_VAR_FLAG_SYNC 134217728 /* learner (RING_DIRECT + ACTOR_RING + ACTOR_PERSIST + FWD_CHAIN, plain uniform replay): the steady-state
+                                    * pipelined step records no event and waits for none.  The update graph's first launch counts
+                                    * itself in a device word when it STARTS (= the previous update is complete and written back);
+                                    * the actor launch polls that word for the number the host left for it in a pinned ring; the
+                                    * host paces itself (three calls ahead) on a pinned count the actor launch publishes.  An event
+                                    * record behind a graph replay costs 4.9 us of the update stream, the other stream's wait on it
+                                    * 9.4 us more (tools/ubench/graph_gap.hip).  Every other entry point drains both streams first.
+                                    * Same launches on the same data: bit-identical.  DQN_agent.py:101-138, BaseAgent.py:108-182 */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
@@ -580,6 +588,11 @@ int dra_dqn_learner_step(dra_dqn_learner* learner, const dra_dqn_step_params* pr
 /* host-side accounting of dra_dqn_learner_step since the last reset: out[0] calls, out[1] seconds in the call,
  * out[2] seconds of that blocked on a pinned staging slot (GPU back-pressure). */
 int dra_dqn_learner_host_stats(dra_dqn_learner* learner, double* out, int reset);
+
+/* DRA_VAR_FLAG_SYNC accounting since creation: out[0] steps issued in the event-free lane, out[1] times the lane was entered,
+ * out[2] steps whose actor launch waited for one more count (it overwrites slots the step's own minibatch reads), out[3] steps
+ * whose update made the host wait for the actor stream (the minibatch reads slots an unfinished actor launch writes). */
+int dra_dqn_learner_lane_stats(dra_dqn_learner* learner, int64_t* out);
 
 /* HIP stream restricted to the compute units whose bit is set in cu_mask (n_words x 32 bits): the async agent step
  * gives the actor chain and the update chain disjoint CU partitions (DRA_VAR_CU_PARTITION, host side). */

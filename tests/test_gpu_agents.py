@@ -1562,6 +1562,55 @@ def test_forward_chain_is_bit_identical(dra):
     assert float(np.abs(outs[0]["p"]).max()) > 0
 
 
+def test_flag_sync_lane_is_bit_identical(dra):
+    """DRA_VAR_FLAG_SYNC (round 6): the steady-state pipelined step (DQN_agent.py:101-138 under BaseAgent.py:108-182's async actor)
+    records no event and waits for none -- the update graph's first launch counts itself in a device word, the actor launch
+    polls that word for the number the host left in a pinned ring, the host paces itself on a pinned count the actor publishes.
+    The same launches on the same data, hence the same bits: with the bit set and cleared the benchmarked pipeline ends on
+    identical parameters, optimizer state, target network, ring contents (frames AND actions) and last action values -- on a
+    4096-slot ring, where about every fifth step meets one of the two slot hazards (the minibatch reads slots the actor launch
+    beside it writes, or an unfinished one wrote), and across the things that LEAVE the lane: synchronise(), a target sync,
+    kernel replays, an actor-only call pattern change."""
+    d = dra
+    from deeprl_amd import ops
+    from deeprl_amd.learner import DQNLearnerBench
+    default = ops.get_tuning()
+    assert default & ops.VAR_FLAG_SYNC, "the library default carries DRA_VAR_FLAG_SYNC"
+    outs, stats = [], []
+    for variant, interrupt in ((default & ~ops.VAR_FLAG_SYNC, False), (default, False), (default, True),
+                               (default & ~ops.VAR_DEFER_FC4, False)):
+        np.random.seed(41)
+        torch.manual_seed(42)
+        b = DQNLearnerBench(ring_capacity=4096, batch=32, seed=43, actor=True, async_actor=True, variant=variant)
+        L = b.learner
+        for t in range(120):
+            b.step()
+            if t == 57:
+                L.sync_target()
+            if interrupt and t in (9, 10, 33, 90):
+                L.synchronize()
+            if interrupt and t == 21:
+                L.kernel_replay("conv2_bwd_x", 4)
+        L.synchronize()
+        stats.append(L.lane_stats())
+        frames = d.ops._wrap_device_pointer(b.ring.pointers()[0], 600 * 7056, torch.uint8).cpu().numpy().copy()
+        acts = d.ops._wrap_device_pointer(b.ring.pointers()[1], 600, torch.int64).cpu().numpy().copy()
+        outs.append(dict(p=L.flat.flat.detach().cpu().numpy().copy(), s1=L.state1.detach().cpu().numpy().copy(),
+                         s2=L.state2.detach().cpu().numpy().copy(), pt=L.target_flat.flat.detach().cpu().numpy().copy(),
+                         frames=frames, acts=acts, q=L.actor_q.cpu().numpy().copy()))
+        L.close()
+        b.ring.close()
+    for k in outs[0]:
+        for i in (1, 2, 3):
+            assert np.array_equal(outs[0][k], outs[i][k]), ("lane vs event path", i, k)
+    assert float(np.abs(outs[0]["p"]).max()) > 0
+    assert stats[0]["steps"] == 0
+    assert stats[1]["steps"] >= 100 and stats[1]["entries"] == 2, stats[1]       # (entered once, left for the target sync, entered again)
+    assert stats[1]["hazard_bumps"] + stats[1]["host_waits"] >= 5, stats[1]      # (the small ring did produce hazards)
+    assert stats[2]["steps"] >= 80 and stats[2]["entries"] >= 5, stats[2]
+    assert stats[3]["steps"] >= 100, stats[3]
+
+
 def test_backward_chain_is_bit_identical(dra):
     """DRA_VAR_BWD_CHAIN (round 6): conv1 + conv2 + conv3 of the update's forward pass (DQN_agent.py:81-99 through
     network_bodies.py:10-33, both nets) as ONE launch whose workgroups wait for the workgroups of THEIR sample in the layer below
