@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
-static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 524288 | 1048576 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728;
+static int g_tuning = 511 | 4096 | 8192 | 16384 | 32768 | 131072 | 524288 | 1048576 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456;
 // every bit up to DRA_VAR_CU_PARTITION plus ACTOR_RING, ACTOR_FUSED_CONV1, GATHER_ON_UPDATE and RING_DIRECT measured faster
 // on MI355X in same-box A/Bs (profiles/r01b_ab_variants.jsonl, r01d_*, r01f_*, r02y_ab_*, r02zf_ab_*); ACTOR_V3 (512),
 // ACTOR_FUSED_HEAD (1024) and GATHER_IN_GRAPH (2048) measured neutral or slower and stay opt-in; IDX_PREFETCH (131072): conv1_fwd

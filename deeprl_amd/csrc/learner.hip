@@ -3350,6 +3350,27 @@ static bool fs_eligible(const dra_dqn_learner* l, const dra_dqn_step_params* prm
   return true;
 }
 
+// DRA_VAR_LANE_EAGER: update t as its six plain launches instead of one graph replay -- exactly what capture_part records for the
+// plain ring-direct graph of rotation slot q (riders for copy q - 1, announce, optimizer into copy q, fc4's segment deferred), with
+// update_graph's bookkeeping.  A graph replay costs 6 us before its first kernel, a plain dependent launch 1.3 us
+// (profiles/r06zi_graph_gap.jsonl); the host pays ~4 us per launch instead, which it has (it paces itself three calls ahead).
+static int rd_eager(dra_dqn_learner* l, hipStream_t st, int q) {
+  l->gb = q & 1;
+  l->rd_slot = q;
+  l->rider_q = l->defer ? ((q + 3) & 3) : -1;
+  l->fs_capturing = true;
+  int rc = run_body(l, st, 0, 0.f, 0, 0);
+  l->fs_capturing = false;
+  l->rider_q = -1;
+  if (rc == DRA_OK) rc = launch_optimizer(l, st, l->pa[q], l->defer ? q : -1);
+  l->gb = 0;
+  l->rd_slot = -1;
+  if (rc != DRA_OK) return rc;
+  l->fs_issued++;
+  if (l->defer) { l->defer_host = true; l->defer_q = q; }
+  return DRA_OK;
+}
+
 static int step_lane(dra_dqn_learner* l, const dra_dqn_step_params* prm, hipStream_t su, hipStream_t sa) {
   const int B = l->c.batch;
   const int q = (int)(l->step_no & 3), cur = (q + 3) & 3;
@@ -3394,7 +3415,7 @@ static int step_lane(dra_dqn_learner* l, const dra_dqn_step_params* prm, hipStre
   }
   l->rd_issued++;
   l->last_gb = q & 1;
-  if ((rc = rd_graph(l, su, q, 0))) return rc;           // [update t] -- counts itself in fs_count at its start
+  if ((rc = (l->variant & DRA_VAR_LANE_EAGER) ? rd_eager(l, su, q) : rd_graph(l, su, q, 0))) return rc;   // [update t] -- counts itself in fs_count at its start
   if (!l->fs_on) return DRA_EINVAL;                       // (rd_graph never flushes here: fs_eligible checked the pending segment)
   if (hazard) {                                           // the actor launch below must not start before update t has read the ring
     hipLaunchKernelGGL(fs_bump_kernel, dim3(1), dim3(1), 0, su, l->fs_count);

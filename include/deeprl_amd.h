@@ -343,6 +343,9 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
                                     * record behind a graph replay costs 4.9 us of the update stream, the other stream's wait on it
                                     * 9.4 us more (tools/ubench/graph_gap.hip).  Every other entry point drains both streams first.
                                     * Same launches on the same data: bit-identical.  DQN_agent.py:101-138, BaseAgent.py:108-182 */
+#define DRA_VAR_LANE_EAGER 268435456 /* learner (with FLAG_SYNC): in the event-free lane the update is issued as its six plain launches
+                                    * instead of one graph replay (a replay costs 6 us before its first kernel, a plain dependent
+                                    * launch 1.3 us; the host pays the launches instead).  Same launches: bit-identical */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */

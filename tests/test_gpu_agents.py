@@ -1578,7 +1578,7 @@ def test_flag_sync_lane_is_bit_identical(dra):
     assert default & ops.VAR_FLAG_SYNC, "the library default carries DRA_VAR_FLAG_SYNC"
     outs, stats = [], []
     for variant, interrupt in ((default & ~ops.VAR_FLAG_SYNC, False), (default, False), (default, True),
-                               (default & ~ops.VAR_DEFER_FC4, False)):
+                               (default & ~ops.VAR_DEFER_FC4, False), (default ^ ops.VAR_LANE_EAGER, True)):
         np.random.seed(41)
         torch.manual_seed(42)
         b = DQNLearnerBench(ring_capacity=4096, batch=32, seed=43, actor=True, async_actor=True, variant=variant)
@@ -1601,7 +1601,7 @@ def test_flag_sync_lane_is_bit_identical(dra):
         L.close()
         b.ring.close()
     for k in outs[0]:
-        for i in (1, 2, 3):
+        for i in (1, 2, 3, 4):
             assert np.array_equal(outs[0][k], outs[i][k]), ("lane vs event path", i, k)
     assert float(np.abs(outs[0]["p"]).max()) > 0
     assert stats[0]["steps"] == 0
@@ -1609,6 +1609,7 @@ def test_flag_sync_lane_is_bit_identical(dra):
     assert stats[1]["hazard_bumps"] + stats[1]["host_waits"] >= 5, stats[1]      # (the small ring did produce hazards)
     assert stats[2]["steps"] >= 80 and stats[2]["entries"] >= 5, stats[2]
     assert stats[3]["steps"] >= 100, stats[3]
+    assert stats[4]["steps"] >= 80, stats[4]              # (the update as plain launches / as a graph replay: the other form)
 
 
 def test_backward_chain_is_bit_identical(dra):
