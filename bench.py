@@ -838,6 +838,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     bench.learner.host_stats(reset=True)
+    lane0 = bench.learner.lane_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         bench.step()
@@ -849,6 +850,13 @@ def main():
     dt = time.perf_counter() - t0
     host = bench.learner.host_stats(reset=True)
     host["python_loop_us_per_step"] = 1e6 * t_host / args.steps
+    lane1 = bench.learner.lane_stats()
+    n_lane = lane1["steps"] - lane0["steps"]
+    # DRA_VAR_FLAG_SYNC: how many of the timed steps ran in the event-free lane, and the C call's parts there (host microseconds)
+    host["lane"] = {"steps": n_lane, "hazard_bumps": lane1["hazard_bumps"] - lane0["hazard_bumps"],
+                    "host_waits": lane1["host_waits"] - lane0["host_waits"],
+                    "c_call_parts_us": {k: (lane1["host_us_per_step"][k] * lane1["steps"] - lane0["host_us_per_step"][k] * lane0["steps"])
+                                        / max(1, n_lane) for k in lane1["host_us_per_step"]}}
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

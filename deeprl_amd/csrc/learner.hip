@@ -245,7 +245,8 @@ struct dra_dqn_learner {
   struct { uint64_t done_at; int n; int64_t slots[8]; } fs_arec[4];   // the last four lane actor launches: complete once fs_host[0] >= done_at
   int fs_arec_n;
   hipStream_t fs_su, fs_sa;         // the streams the lane runs on (while fs_on)
-  int64_t fs_stat[4];               // lane steps, lane entries, hazard bumps, host waits for the actor stream (dra_dqn_learner_lane_stats)
+  int64_t fs_stat[12];              // lane steps, lane entries, hazard bumps, host waits for the actor stream; [4..8] host nanoseconds in the
+                                    // lane call: pacing wait, index staging (+ tag copy), update launches, actor launch, whole call
   hipEvent_t ev_fs;                 // recorded on the actor stream when the lane is left (actor_last of the event paths)
   bool late;
   int late_nprior;                  // partials written before the optimizer launch
@@ -3387,6 +3388,9 @@ static int step_lane(dra_dqn_learner* l, const dra_dqn_step_params* prm, hipStre
   }
   const dra_dqn_step_params* ablk =
       reinterpret_cast<const dra_dqn_step_params*>(l->aring_stage + (size_t)(l->aring_issued % kAringSlots) * kAprmStride);
+  using clk = std::chrono::steady_clock;
+  auto ns = [](clk::time_point a, clk::time_point b) { return (int64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
+  const auto tp0 = clk::now();
   // the copy update t overwrites (and, transitively, index buffer q): its last reader must be done
   if (l->fs_reader[q]) {
     if ((rc = fs_wait_actor(l, l->fs_reader[q]))) return rc;
@@ -3406,6 +3410,7 @@ static int step_lane(dra_dqn_learner* l, const dra_dqn_step_params* prm, hipStre
     }
   }
   const bool hazard = gather_reads_slots(l, prm->idx, ablk->slot, prm->n_env);
+  const auto tp1 = clk::now();
   memcpy(l->idx_pin[q], prm->idx, (size_t)B * sizeof(int64_t));
   if (l->variant & DRA_VAR_IDX_PREFETCH) {
     const uint64_t tag = ((l->rd_issued + 1ull) & 0xffffffull) << 40;
@@ -3415,6 +3420,7 @@ static int step_lane(dra_dqn_learner* l, const dra_dqn_step_params* prm, hipStre
   }
   l->rd_issued++;
   l->last_gb = q & 1;
+  const auto tp2 = clk::now();
   if ((rc = (l->variant & DRA_VAR_LANE_EAGER) ? rd_eager(l, su, q) : rd_graph(l, su, q, 0))) return rc;   // [update t] -- counts itself in fs_count at its start
   if (!l->fs_on) return DRA_EINVAL;                       // (rd_graph never flushes here: fs_eligible checked the pending segment)
   if (hazard) {                                           // the actor launch below must not start before update t has read the ring
@@ -3424,7 +3430,10 @@ static int step_lane(dra_dqn_learner* l, const dra_dqn_step_params* prm, hipStre
     l->fs_stat[2]++;
   }
   l->fs_need_next = l->fs_issued;
+  const auto tp3 = clk::now();
   if ((rc = issue_actor_ring(l, prm->n_env, l->pa[cur], cur, sa, true))) return rc;   // [actor t+1] -- polls fs_count >= need
+  const auto tp4 = clk::now();
+  l->fs_stat[4] += ns(tp0, tp1); l->fs_stat[5] += ns(tp1, tp2); l->fs_stat[6] += ns(tp2, tp3); l->fs_stat[7] += ns(tp3, tp4);
   l->actor_pending = true;
   const uint64_t done_at = l->aring_issued;               // (issue_actor_ring advanced it: agent steps completed once this launch is)
   l->fs_reader[cur] = done_at;
@@ -3435,12 +3444,13 @@ static int step_lane(dra_dqn_learner* l, const dra_dqn_step_params* prm, hipStre
   l->pa_cur = q;                                          // the graph's optimizer writes copy q
   l->step_no++;
   l->fs_stat[0]++;
+  l->fs_stat[8] += ns(tp0, clk::now());
   return DRA_OK;
 }
 
 DRA_API int dra_dqn_learner_lane_stats(dra_dqn_learner* l, int64_t* out) {
   if (!l || !out) return DRA_EINVAL;
-  for (int i = 0; i < 4; ++i) out[i] = l->fs_stat[i];
+  for (int i = 0; i < 12; ++i) out[i] = l->fs_stat[i];
   return DRA_OK;
 }
 

@@ -382,9 +382,13 @@ class DQNLearner:
 
     def lane_stats(self):
         """DRA_VAR_FLAG_SYNC: {'steps', 'entries', 'hazard_bumps', 'host_waits'} of the event-free lane since creation."""
-        out = (ctypes.c_int64 * 4)()
+        out = (ctypes.c_int64 * 12)()
         lib.dra_dqn_learner_lane_stats(self.h, out)
-        return {"steps": int(out[0]), "entries": int(out[1]), "hazard_bumps": int(out[2]), "host_waits": int(out[3])}
+        n = max(1, int(out[0]))
+        return {"steps": int(out[0]), "entries": int(out[1]), "hazard_bumps": int(out[2]), "host_waits": int(out[3]),
+                "host_us_per_step": {"pacing_wait": out[4] / n / 1e3, "index_staging": out[5] / n / 1e3,
+                                     "update_launches": out[6] / n / 1e3, "actor_launch": out[7] / n / 1e3,
+                                     "whole_call": out[8] / n / 1e3}}
 
     def invalidate_actor_copy(self):
         """The parameters were changed from outside (checkpoint load): the async actor's copies are reseeded on the next step."""

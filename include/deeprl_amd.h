@@ -592,9 +592,11 @@ int dra_dqn_learner_step(dra_dqn_learner* learner, const dra_dqn_step_params* pr
  * out[2] seconds of that blocked on a pinned staging slot (GPU back-pressure). */
 int dra_dqn_learner_host_stats(dra_dqn_learner* learner, double* out, int reset);
 
-/* DRA_VAR_FLAG_SYNC accounting since creation: out[0] steps issued in the event-free lane, out[1] times the lane was entered,
+/* DRA_VAR_FLAG_SYNC accounting since creation, out[12]: out[0] steps issued in the event-free lane, out[1] times the lane was entered,
  * out[2] steps whose actor launch waited for one more count (it overwrites slots the step's own minibatch reads), out[3] steps
- * whose update made the host wait for the actor stream (the minibatch reads slots an unfinished actor launch writes). */
+ * whose update made the host wait for the actor stream (the minibatch reads slots an unfinished actor launch writes);
+ * out[4..8] host nanoseconds inside those calls: pacing wait + hazard checks, index staging (+ the tagged copy command), the update's
+ * launches, the actor launch, the whole call; out[9..11] reserved (0). */
 int dra_dqn_learner_lane_stats(dra_dqn_learner* learner, int64_t* out);
 
 /* HIP stream restricted to the compute units whose bit is set in cu_mask (n_words x 32 bits): the async agent step
