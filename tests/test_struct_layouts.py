@@ -35,3 +35,85 @@ def test_ctypes_mirror_matches_the_header(tmp_path, which):
     got = _c_layout(tmp_path, which, names)
     assert got[0] == ctypes.sizeof(mirror)
     assert got[1:] == [getattr(mirror, n).offset for n in names]
+
+
+def test_step_params_numpy_view_has_the_ctypes_layout():
+    from deeprl_amd.learner import _STEP_PARAMS_DTYPE, StepParams
+    assert _STEP_PARAMS_DTYPE.itemsize == ctypes.sizeof(StepParams)
+    head = [f[0] for f in StepParams._fields_ if f[0] not in ("reserved", "idx")]
+    assert list(_STEP_PARAMS_DTYPE.names) == head
+    for n in head:
+        assert _STEP_PARAMS_DTYPE.fields[n][1] == getattr(StepParams, n).offset
+        assert _STEP_PARAMS_DTYPE.fields[n][0].itemsize == getattr(StepParams, n).size
+
+
+@pytest.mark.parametrize("n_actions", [1, 2, 4, 16, 6])
+def test_actor_randomness_block_is_the_scalar_stream(n_actions):
+    """DQNLearnerBench._push_blocks draws the actor's epsilon-greedy randomness for 64 env steps in one call: the values and the
+    generator state afterwards must be the scalar calls' (randint(n, size=1), rand(1) per env step: torch_utils.py:51-58)."""
+    import numpy as np
+    from deeprl_amd.learner import actor_randomness_block
+    a, b = np.random.RandomState(977), np.random.RandomState(977)
+    got = actor_randomness_block(b, n_actions, 64)
+    if n_actions & (n_actions - 1):
+        assert got is None                    # no vectorised form: the caller keeps the scalar draws
+        return
+    ra = np.empty(64, dtype=np.int64)
+    dice = np.empty(64, dtype=np.float64)
+    for i in range(64):
+        ra[i] = a.randint(n_actions, size=1)[0]
+        dice[i] = a.rand(1)[0]
+    assert np.array_equal(got[0], ra) and np.array_equal(got[1], dice)
+    assert a.randint(1 << 30) == b.randint(1 << 30)
+
+
+def test_push_blocks_array_form_equals_the_per_field_form(monkeypatch):
+    """The array-filled upload of 16 agent steps is byte for byte the one the per-field loop builds (no GPU: the C entry point
+    is replaced by a recorder)."""
+    import numpy as np
+    from deeprl_amd import learner as lm
+
+    class _Rec:
+        def __init__(self):
+            self.calls = []
+
+        def dra_dqn_learner_actor_ring_push(self, h, blocks, n, stream):
+            raw = ctypes.string_at(ctypes.addressof(blocks.contents) if hasattr(blocks, "contents") else ctypes.addressof(blocks),
+                                   n * ctypes.sizeof(lm.StepParams))
+            head = lm.StepParams.idx.offset
+            self.calls.append(b"".join(raw[i * ctypes.sizeof(lm.StepParams):i * ctypes.sizeof(lm.StepParams) + head] for i in range(n)))
+            return 0
+
+    class _L:
+        h = None
+        actor_stream = None
+        set_env_steps = lm.DQNLearner.set_env_steps
+
+        def __init__(self):
+            self.params = lm.StepParams()
+
+        def _sp(self, s=None):
+            return None
+
+    def make(vectorised):
+        b = lm.DQNLearnerBench.__new__(lm.DQNLearnerBench)
+        b.learner, b.n_actions, b.capacity, b.epsilon = _L(), 4, 1000, 0.01
+        b.pos, b.size, b.counter = 990, 995, 123456
+        b.actor_rs = np.random.RandomState(3)
+        b._ring_pushed = 0
+        if not vectorised:
+            monkeypatch.setattr(lm, "actor_randomness_block", lambda *a: None)
+        return b
+
+    rec = _Rec()
+    monkeypatch.setattr(lm, "lib", rec)
+    fast = make(True)
+    fast._push_blocks(16)
+    fast._push_blocks(16)
+    slow = make(False)
+    slow._push_blocks(16)
+    slow._push_blocks(16)
+    assert rec.calls[0] == rec.calls[2] and rec.calls[1] == rec.calls[3]
+    assert (fast.pos, fast.size, fast.counter, fast._ring_pushed) == (slow.pos, slow.size, slow.counter, slow._ring_pushed)
+    assert bytes(fast.learner.params)[:lm.StepParams.idx.offset] == bytes(slow.learner.params)[:lm.StepParams.idx.offset]
+    assert fast.actor_rs.randint(1 << 30) == slow.actor_rs.randint(1 << 30)
