@@ -172,6 +172,7 @@ struct dra_dqn_learner {
   hipEvent_t ev[K_COUNT + 1];
   bool profiling;
   int only_kernel;                  // >= 0: run_body issues this kernel group alone (dra_dqn_learner_kernel_replay); -1 otherwise
+  int only_chain;                   // 1 / 2: run_body issues the chained forward / backward launch alone (dra_dqn_learner_chain_replay)
   // DRA_VAR_DEFER_FC4 (common.h DraFc4Rider): the ring-direct pipelined graphs leave fc4's segment of the optimizer step to rider
   // workgroups in the NEXT graph's conv1 / conv2 forward launches
   bool defer;                       // active for this learner (decided at creation)
@@ -1260,7 +1261,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     if (rc0) return rc0;
     if (ring_h != 4) return DRA_EINVAL;
   }
-  if (part != 2) {
+  if (part != 2 && l->only_chain != 2) {
   // z = 0: online(states)   z = 1: target(next_states)   z = 2: online(next_states) [double-Q]
   const void* x1[3] = {l->state_[l->gb], l->next_state_[l->gb], l->next_state_[l->gb]};
   const float* w1[3] = {P + o[P_W1], T + o[P_W1], P + o[P_W1]};
@@ -1295,6 +1296,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
                                    l->fchain_dev + kFwdChainCounters + 1, defer_pending_word(l),
                                    defer_valid_word(l, l->rider_q >= 0 ? l->rider_q : 0), s);
       if (rcc) return rcc;
+      if (l->only_chain == 1) return DRA_OK;
     } else
     STEP(K_CONV1_F, dra_conv1_fwd_koc_ringbatch(ring_frames, dev_idx ? l->per2_idx + (size_t)l->rd_slot * 1024 : l->idx_pin[l->rd_slot], l->idx,
                                                 pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr,
@@ -1407,7 +1409,8 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       conv_fold_segs(l, segs);
       const int nfc_expect = dra_fc_bwd_fused_sq_partials(B, NO, 3136), n3_expect = (int)((l->lstride[2] / 4 + 63) / 64), n2_expect = (int)((l->lstride[1] / 4 + 63) / 64);
       // (single-kernel replay: the skipped launches leave their partial counts at the expected values)
-      int nfc = l->only_kernel >= 0 ? nfc_expect : 0, n3 = l->only_kernel >= 0 ? n3_expect : 0, n2 = l->only_kernel >= 0 ? n2_expect : 0;
+      int nfc = (l->only_kernel >= 0 || l->only_chain == 2) ? nfc_expect : 0, n3 = l->only_kernel >= 0 ? n3_expect : 0, n2 = l->only_kernel >= 0 ? n2_expect : 0;
+      if (l->only_chain != 2)
       STEP(K_FC4_BX, dra_fc_bwd_fused_sq(l->dq, l->h4, l->dh4, l->y3[0], P + o[P_W4], G + o[P_WH], G + o[P_BH], G + o[P_W4],
                                          G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, l->partials, &nfc,
                                          c.head_kind != DRA_HEAD_VANILLA ? l->action_[l->gb] : nullptr, c.n_atoms, s));
@@ -1853,6 +1856,71 @@ DRA_API int dra_dqn_learner_kernel_replay(dra_dqn_learner* l, int kernel, int re
   out_us[0] = us[0];
   out_us[1] = us[1];
   return DRA_OK;
+}
+
+__global__ void chain_epoch_bump_kernel(unsigned* epoch) { *epoch += 1u; }
+
+// Measurement aid: the chained forward (which = 0: conv1 + conv2 + conv3 of both nets, conv_fwd_chain_kernel) or backward
+// (which = 1: conv3 / conv2 / conv1 backward + the two slab folds, bwd_chain_kernel) launch of the update ALONE -- the launches the
+// timed pipeline runs under DRA_VAR_FWD_CHAIN / DRA_VAR_BWD_CHAIN, which dra_dqn_learner_kernel_replay's per-layer groups are not.
+// `reps` x [chain launch, a one-thread launch that advances the chains' epoch word as the update's head kernel does] in one
+// captured graph between two events: out_us[0] = microseconds per repetition, out_us[1] = the same with an EMPTY kernel in the
+// chain launch's place; their difference is the chained kernel's own duration beyond an empty launch (what rocprofv3 reports
+// for it, minus the deferred fc4 segment's riders: a replay must not step parameters, the pending segment is flushed first).
+// Same workspaces, indices and grids as the last update.  Synchronises.
+DRA_API int dra_dqn_learner_chain_replay(dra_dqn_learner* l, int which, int reps, float* out_us, void* stream) {
+  if (!l || !out_us || reps < 1 || reps > 4096 || which < 0 || which > 1) return DRA_EINVAL;
+  if (!(l->variant & DRA_VAR_RING_DIRECT) || !l->late || (which == 0 ? !l->fchain : !l->bchain) || l->c.double_q) return DRA_EINVAL;
+  if (int rcl = fs_leave_any(l)) return rcl;
+  hipStream_t st = dra_stream(stream);
+  if (int rcf = flush_fc4(l, st)) return rcf;
+  DRA_HIP(hipStreamSynchronize(st));
+  unsigned* epoch = l->fchain_dev + kFwdChainCounters;
+  float us[2] = {0.f, 0.f};
+  for (int pass = 0; pass < 2; ++pass) {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    l->gb = 0;
+    l->rd_slot = 0;
+    l->only_chain = which + 1;
+    hipError_t b = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    int rc = b == hipSuccess ? DRA_OK : (int)b;
+    for (int r = 0; r < reps && rc == DRA_OK && b == hipSuccess; ++r) {
+      // (the forward chain waits for (epoch + 1) x arrivals: the bump follows it; the backward chain for epoch x arrivals, its
+      // own update's head included: the bump precedes it)
+      if (which == 1) hipLaunchKernelGGL(chain_epoch_bump_kernel, dim3(1), dim3(1), 0, st, epoch);
+      if (pass == 0) rc = run_body(l, st, 0, 0.f, 0);
+      else hipLaunchKernelGGL(empty_probe_kernel, dim3(224), dim3(256), 0, st, (const int*)nullptr);
+      if (which == 0) hipLaunchKernelGGL(chain_epoch_bump_kernel, dim3(1), dim3(1), 0, st, epoch);
+    }
+    l->only_chain = 0;
+    l->rd_slot = -1;
+    hipError_t e = b == hipSuccess ? hipStreamEndCapture(st, &graph) : b;
+    if (rc != DRA_OK) return rc;
+    if (e != hipSuccess) return (int)e;
+    DRA_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    float best = 0.f;
+    for (int t = 0; t < 4; ++t) {                        // one warm replay, then the fastest of three
+      DRA_HIP(hipEventRecord(l->ev[0], st));
+      DRA_HIP(hipGraphLaunch(exec, st));
+      DRA_HIP(hipEventRecord(l->ev[1], st));
+      DRA_HIP(hipEventSynchronize(l->ev[1]));
+      float ms = 0.f;
+      DRA_HIP(hipEventElapsedTime(&ms, l->ev[0], l->ev[1]));
+      if (t == 1 || (t > 1 && ms < best)) best = ms;
+    }
+    // the replays advanced the epoch word for ONE chain's counters (the empty pass for none): both chains are brought level
+    // again -- every arrival counter holds epoch x (arrivals per epoch) between updates, so all zero is a level state
+    DRA_HIP(hipMemsetAsync(l->fchain_dev, 0, (size_t)(kFwdChainCounters + 1) * sizeof(unsigned), st));
+    DRA_HIP(hipMemsetAsync(l->bchain_dev, 0, (size_t)dra_bwd_chain_counters() * sizeof(unsigned), st));
+    DRA_HIP(hipStreamSynchronize(st));
+    us[pass] = best * 1e3f / (float)reps;
+    (void)hipGraphExecDestroy(exec);
+  }
+  out_us[0] = us[0];
+  out_us[1] = us[1];
+  return *l->timeout_flag ? DRA_ETIMEDOUT : DRA_OK;   // (a chain workgroup's bounded wait gave up: the reading is void)
 }
 
 // The minibatch the most recently issued update consumed (device pointers into the learner's own buffers: uint8

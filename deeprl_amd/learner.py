@@ -364,6 +364,14 @@ class DQNLearner:
                 return float(out[0]), float(out[1])
         raise DraError("kernel_replay: no kernel group named %r" % (name,))
 
+    def chain_replay(self, which, reps=64):
+        """The chained forward (which="fwd") or backward ("bwd") launch of the update alone, `reps` times in one captured graph
+        (each followed / preceded by the one-thread epoch launch).  Returns (us per repetition, us per repetition with an empty
+        kernel in the chain launch's place); the difference is the chained kernel's own duration, live."""
+        out = (ctypes.c_float * 2)()
+        lib.dra_dqn_learner_chain_replay(self.h, {"fwd": 0, "bwd": 1}[which], int(reps), out, self._sp())
+        return float(out[0]), float(out[1])
+
     def synchronize(self):
         # (DRA_VAR_DEFER_FC4: a pending fc4 segment of the last optimizer step is completed first -- after this call the
         # parameters, the optimizer state and the actor copies are what optimizer.step() of DQN_agent.py:133 left)
@@ -1056,6 +1064,37 @@ class DQNLearnerBench:
                     "frac_with_boundary": flops[mfma] / (per_us * 1e-6) / 1e12 / 157.3}
             except DraError as e:
                 self.roofline_mfma["graph_replay"] = {"error": str(e)}
+            # DRA_VAR_FWD_CHAIN / DRA_VAR_BWD_CHAIN: the timed pipeline runs conv1 + conv2 + conv3 forward (both nets) and the three
+            # conv backward layers as ONE launch each; the per-layer groups above are what the eager profile launches, not what is
+            # timed.  The headline MFMA kernel is then the chained forward launch (the longest kernel of the update stream),
+            # replayed alone the same way; the chained backward beside it.
+            chains = {}
+            if (variant & ops.VAR_FWD_CHAIN) and (variant & ops.VAR_BWD_CHAIN):
+                spec = {"fwd": ("conv_fwd_chain", ("conv1_fwd", "conv2_fwd", "conv3_fwd"),
+                                alg_hbm["conv1_fwd"] + 4 * (2 * w2 + 2 * y2) + 4 * (2 * w3 + 2 * y3)),
+                        "bwd": ("conv_bwd_chain", ("conv3_bwd_x", "conv2_bwd_x", "conv1_bwd_w"),
+                                4 * (y3 + y2 + 2 * w3) + 4 * (y1 + 2 * w2) + b * 4 * 7056 + 4 * w1)}
+                for which, (name, parts, alg) in spec.items():
+                    try:
+                        per_us, empty_us = L.chain_replay(which, 64)
+                    except DraError as e:
+                        chains[name] = {"error": str(e)}
+                        continue
+                    fl = sum(flops[k] for k in parts)
+                    own_us = max(per_us - empty_us, 1e-3)
+                    with_boundary_us = own_us + 0.5 * empty_us      # (the empty pass is two launches per repetition)
+                    chains[name] = {"kernel": name, "bound": "mfma", "peak": 157.3, "unit": "TFLOP/s", "layers": list(parts),
+                                    "algorithmic_flops": fl, "algorithmic_bytes_hbm": alg, "traffic": None,
+                                    "avg_ms": with_boundary_us * 1e-3, "achieved": fl / (with_boundary_us * 1e-6) / 1e12,
+                                    "frac": fl / (with_boundary_us * 1e-6) / 1e12 / 157.3,
+                                    "event_pair_empty_ms": self.event_bracket_ms,
+                                    "graph_replay": {"launches": 64, "us_per_launch": with_boundary_us,
+                                                     "us_per_repetition_with_epoch_launch": per_us,
+                                                     "empty_kernel_us_per_repetition": empty_us, "kernel_us": own_us,
+                                                     "achieved": fl / (own_us * 1e-6) / 1e12,
+                                                     "frac": fl / (own_us * 1e-6) / 1e12 / 157.3,
+                                                     "frac_with_boundary": fl / (with_boundary_us * 1e-6) / 1e12 / 157.3}}
+            self.roofline_chains = chains
             self.roofline_mfma["mfma_kernels"] = [
                 {"kernel": k, "avg_ms": ms[k], "algorithmic_flops": flops[k], "frac": flops[k] / (ms[k] * 1e-3) / 1e12 / 157.3}
                 for k in sorted((k for k in ms if k in flops), key=ms.get, reverse=True)]

@@ -531,6 +531,14 @@ int dra_dqn_learner_flush(dra_dqn_learner* learner, void* stream);
  * the same for an empty kernel (the boundary alone).  Their difference is the kernel's own duration -- the quantity rocprofv3
  * reports -- measured live.  Runs on the workspaces of the last update; refuses the optimizer group.  Synchronises. */
 int dra_dqn_learner_kernel_replay(dra_dqn_learner* learner, int kernel, int reps, float* out_us, void* stream);
+/* measurement aid: the chained launches the timed pipeline runs under DRA_VAR_FWD_CHAIN / DRA_VAR_BWD_CHAIN, ALONE -- which = 0:
+ * conv1 + conv2 + conv3 forward of both nets (network_bodies.py:10-33, online(states) and target(next_states) of
+ * DQN_agent.py:114-127); which = 1: conv3 / conv2 / conv1 backward + the two slab folds (DQN_agent.py:131).  `reps` x [the launch,
+ * a one-thread launch advancing the chains' epoch word as the update's head kernel does] in ONE captured graph between two
+ * events: out_us[0] = microseconds per repetition, out_us[1] = the same with an empty kernel in the launch's place; the
+ * difference is the chained kernel's own duration (rocprofv3's figure for it, less the deferred fc4 optimizer segment's riders:
+ * a replay never steps parameters, a pending segment is flushed first).  Runs on the workspaces of the last update.  Synchronises. */
+int dra_dqn_learner_chain_replay(dra_dqn_learner* learner, int which, int reps, float* out_us, void* stream);
 /* the minibatch the most recently issued update consumed (device pointers into the learner's buffers: u8 states /
  * next states [B][4][84][84], int64 actions [B], f32 rewards / masks [B]); for checkers, after a synchronise */
 int dra_dqn_learner_last_minibatch(dra_dqn_learner* learner, void** state, void** next_state, void** action, void** reward,

@@ -1433,6 +1433,11 @@ def test_kernel_replay_measures_without_side_effects(dra):
             for name in ("rmsprop_step", "grad_norm", "conv2_bwd_w", "gather"):
                 with pytest.raises(DraError):
                     b.learner.kernel_replay(name, 4)
+            # the chained launches the timed pipeline actually runs (DRA_VAR_FWD_CHAIN / DRA_VAR_BWD_CHAIN): dra_dqn_learner_chain_replay
+            for which in ("fwd", "bwd", "fwd"):
+                b.learner.synchronize()
+                per, empty = b.learner.chain_replay(which, 16)
+                assert 1.0 < empty < per < 400.0, (which, per, empty)
         for _ in range(6):
             b.step()
         b.learner.synchronize()

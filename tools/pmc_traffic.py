@@ -23,12 +23,15 @@ GROUPS = [  # learner kernel group -> substring(s) of the rocprof kernel name
     ("head_loss", ["head_fused_kernel"]),
     ("fc4_bwd", ["LinDgradOne<", "igemm_kernel<LinDgrad<", "multi_kernel<IgemmRole<LinDgrad<"]),
     ("fc4_bwd_w", ["igemm_kernel<LinWgrad<"]),
-    ("conv3_bwd", ["ConvGeom<64, 9, 64, 3, 1>"]),
-    ("conv2_bwd", ["ConvGeom<32, 20, 64, 4, 2>"]),
-    ("conv1_bwd_w", ["ConvGeom<4, 84, 32, 8, 4>"]),
+    ("conv3_bwd", ["multi_kernel<ConvDgradLin<ConvGeom<64, 9, 64, 3, 1>", "multi_kernel<ConvDgradOne<ConvGeom<64, 9, 64, 3, 1>"]),
+    ("conv2_bwd", ["multi_kernel<ConvDgradLin<ConvGeom<32, 20, 64, 4, 2>", "multi_kernel<ConvDgradOne<ConvGeom<32, 20, 64, 4, 2>"]),
+    ("conv1_bwd_w", ["multi_kernel<ConvWgradOne<ConvGeom<4, 84, 32, 8, 4>"]),
+    ("conv_fwd_chain", ["conv_fwd_chain_kernel"]),     # DRA_VAR_FWD_CHAIN: conv1 + conv2 + conv3 forward of both nets (+ the fc4 riders)
+    ("conv_bwd_chain", ["bwd_chain_kernel"]),          # DRA_VAR_BWD_CHAIN: conv3 / conv2 / conv1 backward + the two slab folds
     ("grad_norm", ["grad_sqnorm_kernel", "grad_fold_norm_kernel", "fold_norm_kernel", "clip_step_kernel"]),
     ("rmsprop_step", ["rmsprop_step_kernel", "late_step_kernel"]),
     ("actor_fc4", ["actor_fc4_kernel", "actor_fc4_planes", "actor_c3fc4_kernel"]),
+    ("actor_persist", ["actor_persist_kernel"]),
 ]
 
 

@@ -24,10 +24,14 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--ring", type=int, default=400_000)
     ap.add_argument("--no-calibration", action="store_true", help="skip the 1024-minibatch gather launches")
+    ap.add_argument("--async-actor", action="store_true",
+                    help="the benchmarked two-stream pipeline (the chained launches run only there).  Counter collection serialises "
+                         "kernels: pass a --variant without DRA_VAR_FLAG_SYNC / DRA_VAR_ACTOR_PERSIST, whose launches wait for each other "
+                         "ACROSS streams on device words")
     args = ap.parse_args()
     d.select_device(0)
     dev = d.Config.DEVICE
-    bench = DQNLearnerBench(ring_capacity=args.ring, batch=32, seed=0, actor=True, async_actor=False, variant=args.variant)
+    bench = DQNLearnerBench(ring_capacity=args.ring, batch=32, seed=0, actor=True, async_actor=args.async_actor, variant=args.variant)
     if not args.no_calibration:
         rs = np.random.RandomState(0)
         idx = torch.from_numpy(rs.randint(3, args.ring - 2, size=32 * 1024).astype(np.int64)).to(dev)
