@@ -569,8 +569,16 @@ class DQNAgent(BaseAgent):
                 self.total_steps += 1
             return self.total_steps > cfg.exploration_steps
 
+        pipe = self._pipe
+        if pipe.async_actor and not pipe.per:
+            # the uniform two-stream pipeline names its stream in every call (learner._sp): no torch stream context -- entering and
+            # leaving one is ~15 us of host time per agent step, a sixth of the device-side step
+            pipe.step(account)
+            if self.total_steps / cfg.sgd_update_frequency % cfg.target_network_update_freq == 0:
+                self.sync_target()
+            return
         with torch.cuda.stream(self._learner.stream):
-            self._pipe.step(account)
+            pipe.step(account)
             if self.total_steps / cfg.sgd_update_frequency % cfg.target_network_update_freq == 0:
                 self.sync_target()
 

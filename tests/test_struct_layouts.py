@@ -117,3 +117,61 @@ def test_push_blocks_array_form_equals_the_per_field_form(monkeypatch):
     assert (fast.pos, fast.size, fast.counter, fast._ring_pushed) == (slow.pos, slow.size, slow.counter, slow._ring_pushed)
     assert bytes(fast.learner.params)[:lm.StepParams.idx.offset] == bytes(slow.learner.params)[:lm.StepParams.idx.offset]
     assert fast.actor_rs.randint(1 << 30) == slow.actor_rs.randint(1 << 30)
+
+
+def test_device_actor_pipeline_push_array_form_equals_the_per_field_form(monkeypatch):
+    """DeviceActorPipeline._push (the agents' async device pipeline): the array-filled upload of 16 agent steps -- episode
+    shadow, epsilon schedule, the actor's own random stream -- is byte for byte the per-field one, and reports the same
+    (reward, done, info) per transition."""
+    import numpy as np
+    from deeprl_amd import learner as lm
+    from deeprl_amd.support import LinearSchedule
+    head = lm.StepParams.idx.offset
+    size = ctypes.sizeof(lm.StepParams)
+
+    class _Rec:
+        def __init__(self):
+            self.calls = []
+
+        def dra_dqn_learner_actor_ring_push(self, h, blocks, n, stream):
+            addr = ctypes.addressof(blocks.contents) if hasattr(blocks, "contents") else ctypes.addressof(blocks)
+            raw = ctypes.string_at(addr, n * size)
+            self.calls.append(b"".join(raw[i * size:i * size + head] for i in range(n)))
+            return 0
+
+    class _L:
+        h = None
+        actor_stream = None
+        set_env_steps = lm.DQNLearner.set_env_steps
+
+        def __init__(self):
+            self.params = lm.StepParams()
+
+        def _sp(self, s=None):
+            return None
+
+    def make():
+        p = lm.DeviceActorPipeline.__new__(lm.DeviceActorPipeline)
+        p.L, p.A, p.n_env, p.capacity, p.slot = _L(), 4, 4, 5000, 4990
+        p.stream = lm.SyntheticEpisodeStream(seed=7, counter0=100, done_period=37)
+        p.epsilon_fn = LinearSchedule(1.0, 0.01, 500)
+        p.rs = np.random.RandomState(1977)
+        p.async_actor, p.pending, p.pushed = True, [], 0
+        return p
+
+    rec = _Rec()
+    monkeypatch.setattr(lm, "lib", rec)
+    fast = make()
+    fast._push()
+    fast._push(16)
+    monkeypatch.setattr(lm, "actor_randomness_block", lambda *a: None)
+    slow = make()
+    slow._push()
+    slow._push(16)
+    assert rec.calls[0] == rec.calls[2] and rec.calls[1] == rec.calls[3]
+    assert fast.pending == slow.pending and len(fast.pending) == 32
+    assert any(done for step in fast.pending for (_, done, _) in step)          # (episode boundaries inside the blocks)
+    assert (fast.slot, fast.pushed) == (slow.slot, slow.pushed)
+    assert bytes(fast.L.params)[:head] == bytes(slow.L.params)[:head]
+    assert fast.rs.randint(1 << 30) == slow.rs.randint(1 << 30)
+    assert fast.epsilon_fn() == slow.epsilon_fn() and fast.stream.state_dict() == slow.stream.state_dict()

@@ -23,6 +23,11 @@ find $OUT/prof -name "*.db" -size +20M -delete
 echo "== pmc passes"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -- python $R/tools/pmc_workload.py --steps 40 --variant $PV > $R/$OUT/pmc_fetch.log 2>&1); tail -1 $OUT/pmc_fetch.log
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write -- python $R/tools/pmc_workload.py --steps 40 --variant $PV > $R/$OUT/pmc_write.log 2>&1); tail -1 $OUT/pmc_write.log
+# the chained launches run only in the two-stream pipeline: a second pair of passes there, WITHOUT the variants whose launches wait
+# for each other across streams on device words (counter collection serialises kernels): default - FLAG_SYNC - LANE_EAGER - ACTOR_PERSIST
+PV2=${PMC_VARIANT_ASYNC:-110817791}
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch/async -- python $R/tools/pmc_workload.py --steps 40 --variant $PV2 --async-actor --no-calibration > $R/$OUT/pmc_fetch_async.log 2>&1); tail -1 $OUT/pmc_fetch_async.log
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write/async -- python $R/tools/pmc_workload.py --steps 40 --variant $PV2 --async-actor --no-calibration > $R/$OUT/pmc_write_async.log 2>&1); tail -1 $OUT/pmc_write_async.log
 python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err; head -c 1200 $OUT/pmc_traffic.json; tail -2 $OUT/pmc_traffic.err
 find $OUT/pmc_fetch $OUT/pmc_write -name "*.db" -size +20M -delete
 find $OUT/pmc_fetch $OUT/pmc_write -name "*kernel_trace*" -size +20M -delete
