@@ -249,6 +249,28 @@ struct dra_dqn_learner {
   int64_t fs_stat[12];              // lane steps, lane entries, hazard bumps, host waits for the actor stream; [4..8] host nanoseconds in the
                                     // lane call: pacing wait, index staging (+ tag copy), update launches, actor launch, whole call
   hipEvent_t ev_fs;                 // recorded on the actor stream when the lane is left (actor_last of the event paths)
+  // DRA_VAR_TARGET_AHEAD (step_lane + rd_eager): target(next_states) of update t + 1 -- conv1 + conv2 + conv3 + fc4's split-K partial
+  // sums, which depend on the target parameters and the ring only -- runs on its own stream UNDER update t (gated on update t's
+  // start), the update's forward chain carries the online net alone and its head kernel reads the target's partial sums from a
+  // stash.  ah = the learner can (decided at creation + dra_dqn_learner_set_ahead_stream); everything per parity of the update
+  // number: ahead(t + 1) works on set (t + 1) & 1 while update t may still read / fall back on set t & 1.
+  bool ah;
+  hipStream_t ah_stream;            // (not owned: a stream on the update's CU partition)
+  float *ah_y1[2], *ah_y2[2], *ah_y3[2];   // the target net's activations (nothing reads them after fc4)
+  float* ah_slabs[2];               // [ks][B][512]: what the head kernel folds for z = 1
+  unsigned* ah_chain[2];            // arrival counters + epoch word of the target chain's launches (never reset: each use adds one epoch)
+  int64_t* ah_idx_pin[8];           // pinned: the indices ahead(t + 1) reads (rotation of 8: the host runs up to three calls ahead of
+                                    // the device, an ahead sequence is only known complete at its update's head kernel)
+  int64_t* ah_idx_copy;             // device scratch (conv1 leaves a copy of what it read)
+  unsigned long long* ah_done;      // device: number (+ 1) of the newest update whose ahead launches are complete
+  int64_t ah_next_idx[1024];        // host: dra_dqn_learner_stage_next_indices
+  bool ah_next_set;
+  int64_t ah_idx[1024];             // host: the indices the stash in flight was computed for ...
+  uint64_t ah_for_step;             // ... and the update (step_no) it belongs to
+  bool ah_valid;
+  int ah_mode;                      // run_body: 0 = both nets in the update's chain, 1 = z = 1 from the stash, 2 = z = 1 by the target
+                                    // chain on the update stream first (no stash for this update)
+  int64_t ah_stat[4];               // updates served from the stash, computed in line, ahead launches skipped for a slot hazard, index mismatches
   bool late;
   int late_nprior;                  // partials written before the optimizer launch
   int late_nfold;                   // fold workgroups of the optimizer launch (their partial slots double as arrival flags)
@@ -457,6 +479,21 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   rc |= (int)hipMalloc(&l->aflags, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
   rc |= (int)hipMalloc(&l->fchain_dev, (size_t)(kFwdChainCounters + 2) * sizeof(unsigned));
   if (!rc) rc |= (int)hipMemset(l->fchain_dev, 0, (size_t)(kFwdChainCounters + 2) * sizeof(unsigned));
+  // DRA_VAR_TARGET_AHEAD: workspaces (the stream comes later: dra_dqn_learner_set_ahead_stream)
+  l->ah = false;
+  if ((l->variant & DRA_VAR_TARGET_AHEAD) && l->fs && (l->variant & DRA_VAR_LANE_EAGER) && l->bchain && !cfg->double_q && B <= 32 &&
+      (l->variant & DRA_VAR_ONESHOT_FWD)) {
+    for (int k = 0; k < 2; ++k) {
+      rc |= alloc_f(&l->ah_y1[k], (int64_t)B * 32 * 400); rc |= alloc_f(&l->ah_y2[k], (int64_t)B * 64 * 81);
+      rc |= alloc_f(&l->ah_y3[k], (int64_t)B * 64 * 49); rc |= alloc_f(&l->ah_slabs[k], (int64_t)kFc4SplitWide * B * 512);
+      rc |= (int)hipMalloc(&l->ah_chain[k], (size_t)(kFwdChainCounters + 2) * sizeof(unsigned));
+      if (!rc) rc |= (int)hipMemset(l->ah_chain[k], 0, (size_t)(kFwdChainCounters + 2) * sizeof(unsigned));
+    }
+    for (int k = 0; k < 8; ++k) rc |= (int)hipHostMalloc(&l->ah_idx_pin[k], 1024 * sizeof(int64_t), hipHostMallocDefault);
+    rc |= (int)hipMalloc(&l->ah_idx_copy, 1024 * sizeof(int64_t));
+    rc |= (int)hipMalloc(&l->ah_done, 256);
+    if (!rc) rc |= (int)hipMemset(l->ah_done, 0, 256);
+  }
   {
     const size_t words = kPersistLLWords + 1;
     rc |= (int)hipMalloc(&l->all_dev, words * sizeof(unsigned long long));
@@ -580,6 +617,13 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (l->aflags) (void)hipFree(l->aflags);
   if (l->all_dev) (void)hipFree(l->all_dev);
   if (l->fchain_dev) (void)hipFree(l->fchain_dev);
+  for (int k = 0; k < 2; ++k) {
+    void* ab[] = {l->ah_y1[k], l->ah_y2[k], l->ah_y3[k], l->ah_slabs[k], l->ah_chain[k]};
+    for (void* b : ab) if (b) (void)hipFree(b);
+  }
+  for (int k = 0; k < 8; ++k) if (l->ah_idx_pin[k]) (void)hipHostFree(l->ah_idx_pin[k]);
+  if (l->ah_idx_copy) (void)hipFree(l->ah_idx_copy);
+  if (l->ah_done) (void)hipFree(l->ah_done);
   if (l->bchain_dev) (void)hipFree(l->bchain_dev);
   if (l->fs_count) (void)hipFree(l->fs_count);
   if (l->fs_host) (void)hipHostFree(l->fs_host);
@@ -744,6 +788,12 @@ struct RingScalars {
   unsigned long long* seq;
   // DRA_VAR_FWD_CHAIN: workgroup 0 counts the forward chain of this update as done (conv_v2.hip FwdChainArgs::epoch)
   unsigned* chain_epoch;
+  // DRA_VAR_TARGET_AHEAD: the target net's split-K partial sums [KS][B][512] come from this stash (written by launches on another
+  // stream: complete once *z1_done >= z1_want; read with agent-scope loads) instead of slabs' z = 1 block.  Null: both from `slabs`.
+  const float* z1_slabs;
+  const unsigned long long* z1_done;
+  unsigned long long z1_want;
+  int* z1_timeout;
 };
 
 // action / n-step reward / mask of sampled transition b straight from the replay ring, folded as ring_gather_kernel does
@@ -967,15 +1017,35 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
   float dwh[2];                                             // wh_on[ab][k] for this thread's two k (dL/dh4 below)
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) dwh[rep] = wh_on[(int)min(max(ab, (int64_t)0), (int64_t)(A - 1)) * 512 + tid + 256 * rep];
+  if (rs.z1_slabs) {
+    // (expected to hold already: the target's launches were issued one update ago and started when the previous update did)
+    if (tid == 0) {
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(rs.z1_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < rs.z1_want) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > kMegaWaitTicks) {
+          if (rs.z1_timeout) __hip_atomic_store(rs.z1_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+      }
+    }
+    __syncthreads();
+  }
   for (int z = 0; z < nz; ++z) {
     const float* bias = (z == 1) ? b4_tg : b4_on;
+    const bool stash = z == 1 && rs.z1_slabs;
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
       const int k = tid + 256 * rep;
-      const float* s = slabs + ((int64_t)z * KS * B + b) * 512 + k;
+      const float* s = stash ? rs.z1_slabs + (int64_t)b * 512 + k : slabs + ((int64_t)z * KS * B + b) * 512 + k;
       float part[KS];
+      if (stash) {
 #pragma unroll
-      for (int i = 0; i < KS; ++i) part[i] = s[(int64_t)i * B * 512];  // all split-K partials in flight at once
+        for (int i = 0; i < KS; ++i) part[i] = mega_ld<true>(s + (int64_t)i * B * 512);
+      } else {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) part[i] = s[(int64_t)i * B * 512];  // all split-K partials in flight at once
+      }
       float v = part[0];
 #pragma unroll
       for (int i = 1; i < KS; ++i) v += part[i];
@@ -1176,6 +1246,61 @@ DRA_API int dra_dqn_learner_flush(dra_dqn_learner* l, void* stream) {
   return flush_fc4(l, dra_stream(stream));
 }
 
+__global__ void chain_epoch_bump_kernel(unsigned* epoch) { *epoch += 1u; }
+__global__ void ah_done_kernel(unsigned long long* done, unsigned long long value) {
+  __hip_atomic_store(done, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// first launch of an ahead sequence: holds its stream until the update stream has STARTED launch number `need` (fs_count, counted by
+// the forward chain's first workgroup) -- the previous update is then complete: nothing reads this parity's stash, scratch or
+// counters any more
+__global__ void ah_gate_kernel(const unsigned long long* count, unsigned long long need, int* timeout_flag) {
+  const unsigned long long t0 = wall_clock64();
+  while (__hip_atomic_load(count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+    __builtin_amdgcn_s_sleep(32);
+    if (wall_clock64() - t0 > 4 * kMegaWaitTicks) {
+      __hip_atomic_store(timeout_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+}
+
+// DRA_VAR_TARGET_AHEAD: target(next_states) of ONE minibatch on `st` with parity set `par` -- conv1 + conv2 + conv3 as the chained
+// launch over the target net alone (own counters; the one-thread launch behind it advances their epoch), and with_fc4: fc4's split-K
+// partial sums into the stash + the completion word.  Same kernels, same per-sample arithmetic as net z = 1 of the update's own
+// chain and fc4 launch: the stash holds the same bits.  DQN_agent.py:85-88 (q_next = target_network(next_states).detach()).
+static int ah_target_launches(dra_dqn_learner* l, hipStream_t st, int par, const int64_t* idx_pinned, bool with_fc4,
+                              unsigned long long done_value) {
+  const dra_dqn_config& c = l->c;
+  void *ring_frames = nullptr, *ra = nullptr, *rr = nullptr, *rm = nullptr;
+  int ring_h = 4, ring_n = 1;
+  int rc = dra_ring_pointers(l->ring, &ring_frames, &ra, &rr, &rm);
+  if (!rc) rc = dra_ring_shape(l->ring, &ring_h, &ring_n);
+  if (rc) return rc;
+  if (ring_h != 4) return DRA_EINVAL;
+  const float* T = l->pt;
+  const int64_t* o = c.offset;
+  const int64_t off[1] = {ring_n};
+  const float* w1[1] = {T + o[P_W1]}; const float* b1[1] = {T + o[P_B1]};
+  const float* w2[1] = {T + o[P_W2]}; const float* b2[1] = {T + o[P_B2]};
+  const float* w3[1] = {T + o[P_W3]}; const float* b3[1] = {T + o[P_B3]};
+  float* y1[1] = {l->ah_y1[par]}; float* y2[1] = {l->ah_y2[par]}; float* y3[1] = {l->ah_y3[par]};
+  unsigned* cnt = l->ah_chain[par];
+  rc = dra_conv_fwd_chain(ring_frames, idx_pinned, l->ah_idx_copy, nullptr, nullptr, off, 1, w1, b1, y1, w2, b2, y2, w3, b3, y3,
+                          c.batch, c.u8_coef, cnt, cnt + kFwdChainCounters, l->timeout_flag, nullptr, nullptr, nullptr, nullptr, (void*)st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(chain_epoch_bump_kernel, dim3(1), dim3(1), 0, st, cnt + kFwdChainCounters);
+  DRA_LAUNCH_CHECK();
+  if (with_fc4) {
+    const float* x4[1] = {l->ah_y3[par]};
+    const float* w4[1] = {T + o[P_W4]};
+    rc = dra_linear_fwd_slabs_one(1, x4, w4, c.batch, 3136, 512, fc4_ks(l), l->ah_slabs[par], (void*)st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ah_done_kernel, dim3(1), dim3(1), 0, st, l->ah_done, done_value);
+    DRA_LAUNCH_CHECK();
+  }
+  return DRA_OK;
+}
+
 // Head + loss + head input-gradient for the distributional heads (everything head_fused_kernel does for VanillaNet):
 //   h4[z] <- fc4 partial sums ; out[z] = h4[z] Wh_z^T + bh_z (q[z], [B][A*N]) ; fused loss kernel -> per-sample loss
 //   vector (delta) and d(reduced loss)/d out (dq) ; dh4 = (dq Wh) * relu'(h4[0]).
@@ -1289,14 +1414,19 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       DraFc4Rider rdr;
       if (riding) rdr = fc4_rider(l, l->pa[l->rider_q]);
       if (l->fs_capturing) dra_conv_chain_attach_announce(l->fs_count);
+      // DRA_VAR_TARGET_AHEAD (rd_eager): the update's chain carries the online net alone
       int rcc = dra_conv_fwd_chain(ring_frames, dev_idx ? l->per2_idx + (size_t)l->rd_slot * 1024 : l->idx_pin[l->rd_slot], l->idx,
-                                   pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr, off, nz,
+                                   pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr, off,
+                                   l->ah_mode ? 1 : nz,
                                    w1, b1, l->y1, w2c, b2c, l->y2, w3c, b3c, l->y3, B, c.u8_coef, l->fchain_dev,
                                    l->fchain_dev + kFwdChainCounters, l->timeout_flag, riding ? &rdr : nullptr,
                                    l->fchain_dev + kFwdChainCounters + 1, defer_pending_word(l),
                                    defer_valid_word(l, l->rider_q >= 0 ? l->rider_q : 0), s);
       if (rcc) return rcc;
       if (l->only_chain == 1) return DRA_OK;
+      // ... and with no stash for this update the target net follows in line (its own chained launch; fc4 below takes both)
+      if (l->ah_mode == 2)
+        if (int rct = ah_target_launches(l, st, (int)(l->step_no & 1), l->idx_pin[l->rd_slot], false, 0)) return rct;
     } else
     STEP(K_CONV1_F, dra_conv1_fwd_koc_ringbatch(ring_frames, dev_idx ? l->per2_idx + (size_t)l->rd_slot * 1024 : l->idx_pin[l->rd_slot], l->idx,
                                                 pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr,
@@ -1331,7 +1461,8 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     STEP(K_CONV3_F, dra_conv3_fwd_koc_pf(nz, x3, w3, b3, l->y3, B, DRA_ACT_RELU, w4, nz, s));
   else
   STEP(K_CONV3_F, dra_conv_fwd_koc(3, nz, x3, w3, b3, l->y3, B, 0, 1.0, DRA_ACT_RELU, s));
-  if (l->variant & DRA_VAR_ONESHOT_FWD) STEP(K_FC4_F, dra_linear_fwd_slabs_one(nz, x4, w4, B, 3136, 512, ks4, l->fc4_slabs, s));
+  if (chain && l->ah_mode == 2) x4[1] = l->ah_y3[l->step_no & 1];      // (the in-line target chain's planes)
+  if (l->variant & DRA_VAR_ONESHOT_FWD) STEP(K_FC4_F, dra_linear_fwd_slabs_one((chain && l->ah_mode == 1) ? 1 : nz, x4, w4, B, 3136, 512, ks4, l->fc4_slabs, s));
   else STEP(K_FC4_F, dra_linear_fwd_slabs(nz, x4, w4, B, 3136, 512, kFc4Split, l->fc4_slabs, s));
   if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_HEAD], st));
   RingScalars rs;
@@ -1342,6 +1473,9 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
     rs.out_action = l->action_[l->gb]; rs.out_reward = l->reward_[l->gb]; rs.out_mask = l->mask_[l->gb];
     if ((l->variant & DRA_VAR_IDX_PREFETCH) && l->only_kernel < 0) rs.seq = l->rd_seq_dev;   // (a replay is not an update)
     if (chain || bchain) rs.chain_epoch = l->fchain_dev + kFwdChainCounters;
+    if (chain && l->ah_mode == 1) {     // the target net's partial sums: ahead(this update) left them in the stash
+      rs.z1_slabs = l->ah_slabs[l->step_no & 1]; rs.z1_done = l->ah_done; rs.z1_want = l->step_no + 1ull; rs.z1_timeout = l->timeout_flag;
+    }
   }
   if (l->only_kernel >= 0 && l->only_kernel != K_HEAD) {
     // (single-kernel replay of another group: no head launch)
@@ -1857,8 +1991,6 @@ DRA_API int dra_dqn_learner_kernel_replay(dra_dqn_learner* l, int kernel, int re
   out_us[1] = us[1];
   return DRA_OK;
 }
-
-__global__ void chain_epoch_bump_kernel(unsigned* epoch) { *epoch += 1u; }
 
 // Measurement aid: the chained forward (which = 0: conv1 + conv2 + conv3 of both nets, conv_fwd_chain_kernel) or backward
 // (which = 1: conv3 / conv2 / conv1 backward + the two slab folds, bwd_chain_kernel) launch of the update ALONE -- the launches the
@@ -3376,6 +3508,18 @@ static int fs_leave(dra_dqn_learner* l, hipStream_t su, hipStream_t sa) {
   l->fs_on = false;
   DRA_HIP(hipStreamSynchronize(su));     // (every count an actor launch polls for comes from work already issued on `su`)
   DRA_HIP(hipStreamSynchronize(sa));
+  if (l->ah && l->ah_stream) {
+    // DRA_VAR_TARGET_AHEAD: an ahead sequence still in flight completes (its gate's count was issued on `su`); a stash nobody
+    // consumed is dropped (the next lane step computes its target in line).  The lane's chains carried the online net alone: the
+    // update's chain counters are brought level for the event paths' two-net launches (every counter holds epoch x arrivals
+    // between updates: all zero is a level state)
+    DRA_HIP(hipStreamSynchronize(l->ah_stream));
+    l->ah_valid = false;
+    l->ah_next_set = false;
+    DRA_HIP(hipMemsetAsync(l->fchain_dev, 0, (size_t)(kFwdChainCounters + 1) * sizeof(unsigned), su));
+    DRA_HIP(hipMemsetAsync(l->bchain_dev, 0, (size_t)dra_bwd_chain_counters() * sizeof(unsigned), su));
+    DRA_HIP(hipStreamSynchronize(su));
+  }
   l->last_done = nullptr;
   for (int q = 0; q < 4; ++q) { l->pa_reader[q] = nullptr; l->upd_used[q] = false; l->fs_reader[q] = 0; }
   for (int k = 0; k < 8; ++k) l->stage_used[k] = false;
@@ -3489,7 +3633,26 @@ static int step_lane(dra_dqn_learner* l, const dra_dqn_step_params* prm, hipStre
   l->rd_issued++;
   l->last_gb = q & 1;
   const auto tp2 = clk::now();
-  if ((rc = (l->variant & DRA_VAR_LANE_EAGER) ? rd_eager(l, su, q) : rd_graph(l, su, q, 0))) return rc;   // [update t] -- counts itself in fs_count at its start
+  // DRA_VAR_TARGET_AHEAD: is the target side of THIS update in the stash (issued one call ago for exactly these indices)?
+  l->ah_mode = 0;
+  if (l->ah && l->ah_stream) {
+    if (l->ah_valid && l->ah_for_step == l->step_no && memcmp(l->ah_idx, prm->idx, (size_t)B * sizeof(int64_t)) == 0) {
+      l->ah_mode = 1;
+      l->ah_stat[0]++;
+    } else {
+      if (l->ah_valid) {                                   // a stash for other indices / another update: its launches finish before
+        DRA_HIP(hipStreamSynchronize(l->ah_stream));       // this update's in-line target chain touches the same parity set
+        l->ah_stat[3]++;
+      }
+      l->ah_mode = 2;
+      l->ah_stat[1]++;
+    }
+    l->ah_valid = false;
+  }
+  rc = (l->variant & DRA_VAR_LANE_EAGER) ? rd_eager(l, su, q) : rd_graph(l, su, q, 0);   // [update t] -- counts itself in fs_count at its start
+  l->ah_mode = 0;
+  if (rc) return rc;
+  const uint64_t ah_need = l->fs_issued;                  // (the count update t's first workgroup raises fs_count to)
   if (!l->fs_on) return DRA_EINVAL;                       // (rd_graph never flushes here: fs_eligible checked the pending segment)
   if (hazard) {                                           // the actor launch below must not start before update t has read the ring
     hipLaunchKernelGGL(fs_bump_kernel, dim3(1), dim3(1), 0, su, l->fs_count);
@@ -3510,9 +3673,72 @@ static int step_lane(dra_dqn_learner* l, const dra_dqn_step_params* prm, hipStre
   r.done_at = done_at; r.n = prm->n_env;
   for (int e = 0; e < prm->n_env && e < 8; ++e) r.slots[e] = ablk->slot[e];
   l->pa_cur = q;                                          // the graph's optimizer writes copy q
+  // DRA_VAR_TARGET_AHEAD: [target(next_states) of update t + 1] on its own stream, gated on update t's start.  Skipped (the next
+  // update then computes its target in line) when one of its frames is a slot an unfinished actor launch writes -- the launch just
+  // issued included -- or the NEXT actor launch will overwrite (that launch starts with update t + 1, the ahead sequence is only
+  // known to be complete at that update's head kernel).
+  if (l->ah && l->ah_stream && l->ah_next_set) {
+    l->ah_next_set = false;
+    bool ok = l->aring_issued < l->aring_pushed;          // (the next launch's block must be known)
+    for (int i = 0; ok && i < l->fs_arec_n; ++i) {
+      const auto& ar = l->fs_arec[i];
+      if (!fs_reached(fs_actor_done(l), ar.done_at) && gather_reads_slots(l, l->ah_next_idx, ar.slots, ar.n)) ok = false;
+    }
+    if (ok) {
+      const dra_dqn_step_params* nblk =
+          reinterpret_cast<const dra_dqn_step_params*>(l->aring_stage + (size_t)(l->aring_issued % kAringSlots) * kAprmStride);
+      if (gather_reads_slots(l, l->ah_next_idx, nblk->slot, nblk->n_env)) ok = false;
+    }
+    if (ok) {
+      const uint64_t nxt = l->step_no + 1;
+      int64_t* pin = l->ah_idx_pin[nxt & 7];
+      memcpy(pin, l->ah_next_idx, (size_t)B * sizeof(int64_t));
+      // (gated on the update's START.  Gating on its head kernel instead -- the sequence then runs beside the small launches and the
+      // backward chain -- and confining the ahead stream to 64 / 112 CUs measured no better: profiles/r06zx_ab_ahead_placement.jsonl)
+      hipLaunchKernelGGL(ah_gate_kernel, dim3(1), dim3(1), 0, l->ah_stream, (const unsigned long long*)l->fs_count,
+                         (unsigned long long)ah_need, l->timeout_flag);
+      DRA_LAUNCH_CHECK();
+      if ((rc = ah_target_launches(l, l->ah_stream, (int)(nxt & 1), pin, true, nxt + 1ull))) return rc;
+      memcpy(l->ah_idx, l->ah_next_idx, (size_t)B * sizeof(int64_t));
+      l->ah_for_step = nxt;
+      l->ah_valid = true;
+    } else {
+      l->ah_stat[2]++;
+    }
+  }
   l->step_no++;
   l->fs_stat[0]++;
   l->fs_stat[8] += ns(tp0, clk::now());
+  return DRA_OK;
+}
+
+// DRA_VAR_TARGET_AHEAD: the stream the ahead sequences run on (a stream on the update's CU partition; not owned).  Null switches
+// the variant off again.  Leaves the lane.
+DRA_API int dra_dqn_learner_set_ahead_stream(dra_dqn_learner* l, void* stream) {
+  if (!l) return DRA_EINVAL;
+  if (int rcl = fs_leave_any(l)) return rcl;
+  if (!stream || !l->ah_done) { l->ah = false; l->ah_stream = nullptr; return DRA_OK; }   // (no workspaces: this learner's configuration
+                                                                                              // cannot run the variant -- dra_dqn_learner_ahead_stats says so)
+  l->ah_stream = dra_stream(stream);
+  l->ah = true;
+  return DRA_OK;
+}
+
+// DRA_VAR_TARGET_AHEAD: the minibatch indices of the NEXT update (the call after the coming dra_dqn_learner_step), known one call
+// early.  The coming call issues that update's target(next_states) under its own update; the next call uses it if it is handed
+// exactly these indices, and computes the target in line otherwise.  n = the learner's batch.
+DRA_API int dra_dqn_learner_stage_next_indices(dra_dqn_learner* l, const int64_t* idx_next, int n) {
+  if (!l || !idx_next || n != l->c.batch || n > 1024) return DRA_EINVAL;
+  if (!l->ah) return DRA_OK;          // (nothing to do: every update computes both nets)
+  memcpy(l->ah_next_idx, idx_next, (size_t)n * sizeof(int64_t));
+  l->ah_next_set = true;
+  return DRA_OK;
+}
+
+DRA_API int dra_dqn_learner_ahead_stats(dra_dqn_learner* l, int64_t* out) {
+  if (!l || !out) return DRA_EINVAL;
+  for (int i = 0; i < 4; ++i) out[i] = l->ah_stat[i];
+  out[4] = l->ah ? 1 : 0;
   return DRA_OK;
 }
 

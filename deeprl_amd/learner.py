@@ -146,6 +146,13 @@ class DQNLearner:
         if self.actor_cus:
             # (DRA_VAR_ACTOR_PERSIST: the one-launch agent step needs 32 co-resident workgroups, one per CU of the actor's stream)
             lib.dra_dqn_learner_set_actor_cus(self.h, int(self.actor_cus))
+        # DRA_VAR_TARGET_AHEAD: the target net's forward of the NEXT update runs on a third stream (the update's CU partition)
+        self.ahead_stream = None
+        if self.variant & ops.VAR_TARGET_AHEAD:
+            self.ahead_stream = self._ahead_stream()
+            lib.dra_dqn_learner_set_ahead_stream(self.h, self._sp(self.ahead_stream))
+            if not self.ahead_stats()["active"]:
+                self.ahead_stream = None
         self.params = StepParams()
         self._idx_view = np.ctypeslib.as_array(self.params.idx)[:batch]
         self._k = 0
@@ -180,6 +187,34 @@ class DQNLearner:
                 out.append(torch.cuda.ExternalStream(h.value, device=Config.DEVICE))
         _PARTITIONED_STREAMS[key] = out
         return out
+
+    def _ahead_stream(self):
+        """A second stream on the update stream's CU set (or a plain one without DRA_VAR_CU_PARTITION)."""
+        if not self.update_cus:
+            return torch.cuda.Stream()
+        key = (Config.DEVICE.index, self.actor_cus, "ahead")
+        if key not in _PARTITIONED_STREAMS:
+            n_cu = self.update_cus + self.actor_cus
+            words = (n_cu + 31) // 32
+            mask = (ctypes.c_uint32 * words)()
+            for b in range(self.actor_cus, n_cu):
+                mask[b // 32] |= 1 << (b % 32)
+            h = ctypes.c_void_p()
+            with torch.cuda.device(Config.DEVICE):
+                lib.dra_stream_create_masked(ctypes.byref(h), mask, words)
+            _PARTITIONED_STREAMS[key] = torch.cuda.ExternalStream(h.value, device=Config.DEVICE)
+        return _PARTITIONED_STREAMS[key]
+
+    def stage_next_indices(self, idx_next):
+        """DRA_VAR_TARGET_AHEAD: the minibatch indices of the update AFTER the coming step() (numpy int64 [batch])."""
+        a = np.ascontiguousarray(idx_next, dtype=np.int64)
+        lib.dra_dqn_learner_stage_next_indices(self.h, a.ctypes.data_as(ctypes.c_void_p), int(a.size))
+
+    def ahead_stats(self):
+        out = (ctypes.c_int64 * 8)()
+        lib.dra_dqn_learner_ahead_stats(self.h, out)
+        return {"from_stash": int(out[0]), "in_line": int(out[1]), "skipped_slot_hazard": int(out[2]),
+                "index_mismatch": int(out[3]), "active": bool(out[4])}
 
     def close(self):
         if self.h:
@@ -862,6 +897,7 @@ class DQNLearnerBench:
         self.actor_rs = np.random.RandomState(seed + 977) if async_actor else None
         self._ring_pushed = self._ring_issued = 0
         self._fed_steps = 0
+        self._idx_next = None
         self._pos0, self._size0 = self.pos, self.size
 
     def _queue_env_steps(self, n=4):
@@ -900,9 +936,15 @@ class DQNLearnerBench:
                 L.actor_stream.synchronize()
                 self._primed = True
             self._fed_steps += 1                                   # transitions of this step are in the ring
-            n = 4 * self._fed_steps
-            pos, size = (self._pos0 + n) % self.capacity, min(self._size0 + n, self.capacity)
-            idx = draw_uniform_indices(size, pos, self.batch, self.history, self.n_step)
+            if L.ahead_stream is not None:
+                # DRA_VAR_TARGET_AHEAD: this step's minibatch was drawn one call ago (the same draws in the same order: nothing
+                # else consumes np.random here -- the async actor has its own RandomState), the next one is drawn now and handed
+                # over with this call, which issues its target(next_states) under this step's update
+                idx = self._idx_next if self._idx_next is not None else self._draw_at(self._fed_steps)
+                self._idx_next = self._draw_at(self._fed_steps + 1)
+                L.stage_next_indices(self._idx_next)
+            else:
+                idx = self._draw_at(self._fed_steps)
             if self._ring_pushed - self._ring_issued < 8:
                 self._push_blocks()
             L.params.n_env = 4
@@ -926,6 +968,12 @@ class DQNLearnerBench:
         self.updates += 1
         if self.updates % 10000 == 0:
             L.sync_target()
+
+    def _draw_at(self, fed_steps):
+        """The uniform minibatch of the agent step after `fed_steps` x 4 transitions (replay.py:92-110 on the ring's cursor then)."""
+        n = 4 * fed_steps
+        pos, size = (self._pos0 + n) % self.capacity, min(self._size0 + n, self.capacity)
+        return draw_uniform_indices(size, pos, self.batch, self.history, self.n_step)
 
     def _push_blocks(self, n=16):
         """Generates the parameter blocks of the next n agent steps (slots / counters / actor randomness) and

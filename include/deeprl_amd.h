@@ -346,6 +346,13 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
 #define DRA_VAR_LANE_EAGER 268435456 /* learner (with FLAG_SYNC): in the event-free lane the update is issued as its six plain launches
                                     * instead of one graph replay (a replay costs 6 us before its first kernel, a plain dependent
                                     * launch 1.3 us; the host pays the launches instead).  Same launches: bit-identical */
+#define DRA_VAR_TARGET_AHEAD 536870912 /* learner (with FLAG_SYNC + LANE_EAGER + BWD_CHAIN, an ahead stream set): target(next_states) of
+                                    * update t + 1 (DQN_agent.py:85-88: conv1-3 + fc4 of the target net, which depend on the target
+                                    * parameters and the replay ring only) is issued one call early on its own stream and runs UNDER
+                                    * update t; the update's forward chain then carries the online net alone and its head kernel folds
+                                    * the target's fc4 partial sums from a stash.  Needs the next minibatch's indices one call early
+                                    * (dra_dqn_learner_stage_next_indices); an update without a stash computes its target in line.
+                                    * Same kernels on the same data: bit-identical.  DQN_agent.py:114-127 */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */
@@ -600,6 +607,17 @@ int dra_dqn_learner_step(dra_dqn_learner* learner, const dra_dqn_step_params* pr
  * out[2] seconds of that blocked on a pinned staging slot (GPU back-pressure). */
 int dra_dqn_learner_host_stats(dra_dqn_learner* learner, double* out, int reset);
 
+/* DRA_VAR_TARGET_AHEAD: the stream the ahead sequences run on (on the update's CU partition; not owned by the learner; null
+ * = switch the variant off).  The learner must have been created with the variant bit (workspaces).  Leaves the lane. */
+int dra_dqn_learner_set_ahead_stream(dra_dqn_learner* learner, void* stream);
+/* DRA_VAR_TARGET_AHEAD: the indices UniformReplay.sample (replay.py:92-110) will return for the update AFTER the coming
+ * dra_dqn_learner_step call (n = batch).  The coming call issues target_network(next_states) of that minibatch
+ * (DQN_agent.py:85-88) under its own update; the call after it uses the result if prm->idx equals these indices and
+ * computes the target in line otherwise.  A no-op without the variant. */
+int dra_dqn_learner_stage_next_indices(dra_dqn_learner* learner, const int64_t* idx_next, int n);
+/* out[5]: updates whose target came from the stash, updates that computed it in line, ahead sequences skipped for a ring-slot
+ * hazard, stashes dropped for an index mismatch, 1 if the variant is active. */
+int dra_dqn_learner_ahead_stats(dra_dqn_learner* learner, int64_t* out);
 /* DRA_VAR_FLAG_SYNC accounting since creation, out[12]: out[0] steps issued in the event-free lane, out[1] times the lane was entered,
  * out[2] steps whose actor launch waited for one more count (it overwrites slots the step's own minibatch reads), out[3] steps
  * whose update made the host wait for the actor stream (the minibatch reads slots an unfinished actor launch writes);

@@ -1486,6 +1486,54 @@ def test_deferred_fc4_step_is_bit_identical(dra):
     assert float(np.abs(outs[0]["p"]).max()) > 0
 
 
+def test_target_ahead_is_bit_identical(dra):
+    """DRA_VAR_TARGET_AHEAD (round 6): target_network(next_states) of update t + 1 (DQN_agent.py:85-88) -- conv1-3 + fc4 of the target
+    net, which depend on the target parameters and the ring alone -- is issued one call early on its own stream and runs under
+    update t; the update's forward chain carries the online net alone and the head kernel folds the target's partial sums from a
+    stash.  Same kernels on the same data: the benchmarked pipeline with the bit set and cleared ends on identical parameters,
+    optimizer state, target network, ring contents and actions -- on a 4096-slot ring, where minibatches regularly read slots the
+    actor launches around them write (those updates compute their target in line), across synchronise() calls, a target sync and
+    kernel / chain replays in the middle (each leaves the lane and drops the stash in flight)."""
+    d = dra
+    from deeprl_amd import ops
+    from deeprl_amd.learner import DQNLearnerBench
+    default = ops.get_tuning()
+    outs, stats = [], []
+    for variant, interrupt in ((default & ~ops.VAR_TARGET_AHEAD, False), (default | ops.VAR_TARGET_AHEAD, False),
+                               (default | ops.VAR_TARGET_AHEAD, True)):
+        np.random.seed(31)
+        torch.manual_seed(32)
+        b = DQNLearnerBench(ring_capacity=4096, batch=32, seed=33, actor=True, async_actor=True, variant=variant)
+        L = b.learner
+        for t in range(400):
+            b.step()
+            if t == 170:
+                L.sync_target()
+            if interrupt and t in (50, 51, 290):
+                L.synchronize()
+            if interrupt and t == 120:
+                L.kernel_replay("conv2_bwd_x", 4)
+            if interrupt and t == 230:
+                L.chain_replay("fwd", 4)
+        L.synchronize()
+        stats.append(L.ahead_stats())
+        frames = d.ops._wrap_device_pointer(b.ring.pointers()[0], 4096 * 7056, torch.uint8).cpu().numpy().copy()
+        acts = d.ops._wrap_device_pointer(b.ring.pointers()[1], 4096, torch.int64).cpu().numpy().copy()
+        outs.append(dict(p=L.flat.flat.detach().cpu().numpy().copy(), s1=L.state1.detach().cpu().numpy().copy(),
+                         s2=L.state2.detach().cpu().numpy().copy(), pt=L.target_flat.flat.detach().cpu().numpy().copy(),
+                         frames=frames, acts=acts, q=L.actor_q.cpu().numpy().copy()))
+        L.close()
+        b.ring.close()
+    assert not stats[0]["active"] and stats[1]["active"] and stats[2]["active"]
+    assert stats[1]["from_stash"] > 250, stats          # (the lane's steady state is served from the stash ...)
+    assert stats[1]["skipped_slot_hazard"] > 0, stats   # (... except where the 4096-slot ring's hazards forbid it)
+    assert stats[1]["index_mismatch"] == 0, stats
+    for k in outs[0]:
+        for i in (1, 2):
+            assert np.array_equal(outs[0][k], outs[i][k]), ("target ahead vs in the update's chain", i, k)
+    assert float(np.abs(outs[0]["q"]).max()) > 0
+
+
 def test_persistent_actor_is_bit_identical(dra):
     """DRA_VAR_ACTOR_PERSIST (round 6): the whole agent step of the device actor -- n_env x [forward, epsilon-greedy, env.step]
     (DQN_agent.py:24-45) -- as ONE launch of 32 co-resident workgroups whose activations cross workgroups as {value, tag} words.

@@ -16,26 +16,27 @@ def main():
     d.select_device(0)
     d.random_seed(0)
     agent, meta = ba.CASES[case]()
-    for _ in range(400):
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+    for _ in range(max(8, n // 8)):
         agent.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(3000):
+    for _ in range(n):
         agent.step()
     th = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"case": case, "us_per_step": 1e6 * dt / 3000, "host_loop_us_per_step": 1e6 * th / 3000,
-                      "updates_per_s": 3000 * meta["updates_per_step"] / dt}))
+    print(json.dumps({"case": case, "us_per_step": 1e6 * dt / n, "host_loop_us_per_step": 1e6 * th / n,
+                      "updates_per_s": n * meta["updates_per_step"] / dt, "env_steps_per_s": n * meta["env_per_step"] / dt}))
     pr = cProfile.Profile()
     pr.enable()
-    for _ in range(3000):
+    for _ in range(n):
         agent.step()
     pr.disable()
     torch.cuda.synchronize()
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(22)
-    print(s.getvalue()[:5000])
+    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30)
+    print(s.getvalue()[:7000])
 
 
 if __name__ == "__main__":
