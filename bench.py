@@ -937,8 +937,15 @@ def main():
                 if ch["rocprofv3"] is not None:
                     ch["rocprofv3"]["source"] = "committed file %s (rocprofv3 --kernel-trace --stats of this command on a builder box)" % ch["rocprofv3"].get("file")
                 ch["traffic"] = pmc_traffic(name)
-                if ch.get("traffic") and ch.get("algorithmic_bytes_hbm"):
-                    ch["traffic_ratio"] = ch["traffic"] / ch["algorithmic_bytes_hbm"]
+                alg = ch.get("algorithmic_bytes_hbm")
+                if name == "conv_fwd_chain" and (bench.learner.variant & 8388608):
+                    # DRA_VAR_DEFER_FC4: in the pipeline (where the counters were collected) the launch also steps fc4's weights of
+                    # the previous update -- parameter, gradient and two state buffers read; parameter, two state buffers and the
+                    # actor's copy written: 8 x 4 B per weight
+                    ch["algorithmic_bytes_riders"] = 8 * 4 * 512 * 3136
+                    alg = (alg or 0) + ch["algorithmic_bytes_riders"]
+                if ch.get("traffic") and alg:
+                    ch["traffic_ratio"] = ch["traffic"] / alg
             fc["traffic_source"] = roof.get("traffic_source")
             fc["source"] = "graph replay of the chained launch alone (this run)"
             fc["in_pipeline_note"] = ("in the timed pipeline the same launch also carries the deferred fc4 optimizer segment "
@@ -972,7 +979,7 @@ def main():
                                    "frac_rocprofv3_committed = builder-box profile")
         else:
             roof["frac_source"] = "hip_events of this run (event pair around one eager launch, launch boundary included)"
-        if roof.get("traffic") and roof.get("algorithmic_bytes_hbm"):
+        if roof.get("traffic") and roof.get("algorithmic_bytes_hbm") and "traffic_ratio" not in roof:
             roof["traffic_ratio"] = roof["traffic"] / roof["algorithmic_bytes_hbm"]
         # the update chain owns a CU partition while the device actor runs beside it (lever 5):
         # the kernel is timed on that stream, i.e. on this many of the device's CUs

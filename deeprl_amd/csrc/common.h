@@ -310,12 +310,8 @@ __device__ __forceinline__ int xcd_order(int bid, int first, int n_groups, int p
   const int xcd = (bid + first) & (kXcds - 1), j = bid >> 3;      // j < gpx * per_group
   return (xcd * gpx + j / per_group) * per_group + (j % per_group);
 }
-// DRA_XCD_ORDER=0 keeps the natural order (A/B switch, read once per process)
-static inline int dra_xcd_order_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_XCD_ORDER"); v = e ? atoi(e) : 1; }
-  return v;
-}
+// (the DRA_XCD_ORDER=0 A/B switch of round 4 is retired: the XCD-aware order is the only one)
+static constexpr int dra_xcd_order_enabled() { return 1; }
 
 // ------------------------------------------------------------------------------------------------
 // Phase trace (measurement aid, compiled only into libdeeprl_amd_trace.so: `make trace`, -DDRA_TRACE).

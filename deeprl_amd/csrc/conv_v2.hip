@@ -1227,12 +1227,9 @@ static int launch_conv_v2_pt(const ConvV2Args& a, int nz, hipStream_t st) {
   return DRA_OK;
 }
 
-// batch-1 launches (the actor's forward) use 8 waves per workgroup unless DRA_CONV_B1_WAVES=4
-static int conv_b1_waves() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_CONV_B1_WAVES"); v = (e && atoi(e) == 4) ? 4 : 8; }
-  return v;
-}
+// batch-1 launches (the actor's forward) use 8 waves per workgroup (the DRA_CONV_B1_WAVES=4 A/B switch of round 3 is retired: the
+// four-wave form lost on every layer, DESIGN_HISTORY.md section 4)
+static constexpr int conv_b1_waves() { return 8; }
 
 template <class G, bool U8, int PT, int NW = 4, bool SEQ = false, int WPE = 1>
 static int launch_conv_v2_persist(const ConvV2Args& a, int nz, hipStream_t st) {

@@ -233,11 +233,7 @@ extern "C" int dra_linear_fwd_slabs_one(int nz, const float* const* x, const flo
 extern "C" int dra_linear_bwd_x_one512(const float* dy, const float* w, const float* xact, float* dx, int batch, int in_features,
                                        int act, void* stream);   // fused.hip
 
-static int gemv_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_LINEAR_GEMV"); v = e ? atoi(e) : 1; }
-  return v;
-}
+static constexpr int gemv_enabled() { return 1; }   // (the DRA_LINEAR_GEMV=0 A/B switch is retired: small-batch linears are GEMVs)
 
 // Two linear heads of different width on the SAME input (CategoricalActorCriticNet's fc_action / fc_critic on phi,
 // network_heads.py:241-243) in one launch: y0 = x W0^T + b0 [B, O0], y1 = x W1^T + b1 [B, O1].  in_features <= 512.

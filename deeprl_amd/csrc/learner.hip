@@ -2760,11 +2760,8 @@ actor_head_env_ring_kernel(const uint8_t* __restrict__ ring, unsigned* __restric
 // step 0's launch commits the pending observation instead; the head of the LAST env step keeps its own kernel (it also
 // produces the next agent step's first observation and advances the step counter).  Same arithmetic, same order:
 // bit-identical action values, actions and ring contents.
-static int actor_ksplit() {   // DRA_ACTOR_KSPLIT=0: conv2 / conv3 of the ring actor as single-workgroup-per-tile launches
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("DRA_ACTOR_KSPLIT"); v = e ? atoi(e) : 1; }
-  return v;
-}
+static constexpr int actor_ksplit() { return 1; }   // (conv2 / conv3 of the ring actor split along K over two workgroups; the
+                                                    // DRA_ACTOR_KSPLIT=0 A/B switch of round 2 is retired)
 
 static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float* P, hipStream_t st) {
   const dra_dqn_config& c = l->c;
@@ -2782,7 +2779,7 @@ static int run_actor_steps_ring_fused(dra_dqn_learner* l, int n_env, const float
   const bool dist = c.head_kind != DRA_HEAD_VANILLA;
   f.head_kind = c.head_kind; f.n_atoms = c.n_atoms; f.atoms = l->atoms; f.pre = l->alog;
   // DRA_VAR_ACTOR_MEGA: conv3 + fc4 of an env step as ONE launch with an in-kernel hand-over (conv_v2.hip actor_c3fc4_kernel)
-  const bool mega = (l->variant & DRA_VAR_ACTOR_MEGA) && actor_ksplit() && l->aflags;
+  const bool mega = (l->variant & DRA_VAR_ACTOR_MEGA) && l->aflags;   // (the K-split batch-1 convolutions: always since round 6)
   // DRA_VAR_ACTOR_PERSIST: the whole agent step as ONE launch (conv_v2.hip actor_persist.h).  Needs its 32 workgroups co-resident
   // (one per CU: a stream restricted to fewer CUs keeps the multi-launch form), the VanillaNet head and consecutive ring slots
   // (the host's feed order: replay.py:70-80; checked when the blocks are pushed)
