@@ -220,9 +220,20 @@ int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy
 // fused.hip (library-internal), DRA_VAR_BWD_CHAIN: conv3's, conv2's and conv1's backward launches (one-pass roles, late fold) of a
 // minibatch of at most 32 as ONE launch in dependency order; counters = dra_bwd_chain_counters() zeroed unsigned, never reset
 int dra_bwd_chain_counters(void);
+// DRA_VAR_BWD_CHAIN_FC: fc4's + the head's backward (the arguments of dra_fc_bwd_fused_sq: input gradient | fc4 weight gradient |
+// head weight gradient) as the LEADING roles of the same launch; conv3's roles wait for the input-gradient workgroups (one counter)
+struct DraBwdChainFc {
+  const float *dq, *h4, *dh4, *x3, *w4;
+  float *dwh, *dbh, *dw4, *db4;
+  int n_actions, in_features;
+  double* sq_partials;
+  int* n_sq_partials;
+  const int64_t* head_action;
+  int head_group;
+};
 int dra_conv_bwd_chain(const float* dy3, const float* y2, const float* wt3, float* dw3, float* db3, int64_t stride3, float* dy2,
                        const float* y1, const float* wt2, float* dw2, float* db2, int64_t stride2, float* dy1, const void* frames,
                        const int64_t* idx, float* dw1, float* db1, int64_t stride1, int batch, double u8_coef, int act,
                        const dra_fold_seg* fold3, const dra_fold_seg* fold2, float* grad, double* partials3, int* n_partials3,
                        double* partials2, int* n_partials2, double* reset_slots, int n_reset, unsigned* counters,
-                       const unsigned* epoch, int* timeout_flag, void* stream);
+                       const unsigned* epoch, int* timeout_flag, const DraBwdChainFc* fc, void* stream);

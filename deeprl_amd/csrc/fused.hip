@@ -342,17 +342,33 @@ int dra_conv1_wgrad_fold(const float* dy, const void* x, const int64_t* idx, flo
 // kernel has bumped the count when this launch runs).  Same arithmetic as the three launches: bit-identical gradients
 // (tests/test_gpu_agents.py::test_backward_chain_is_bit_identical).  DQN_agent.py:129-134's loss.backward() through
 // network_bodies.py:10-33.
-struct BwdChainN { int d3, w3, d2, w2, w1, f3, f2; };
+// (fc4's weight gradient of the learner's launch: the register-only role for minibatches up to 32 -- see dra_fc_bwd_fused_sq)
+static bool fc_wgrad_one(int batch) { return batch <= 32; }
+constexpr int kFcWgradNI = 8;    // 32-wide input tiles per workgroup of LinWgradOne
+struct BwdChainN { int fd, fw, fh, d3, w3, d2, w2, w1, f3, f2; };
 using BD3 = ConvDgradLin<G3, 1>;
 using BD2 = ConvDgradLin<G2, 2>;
+using FCD = LinDgradOne<512>;
+using FCW = LinWgradOne<8>;
+// FC (DRA_VAR_BWD_CHAIN_FC): fc4's input gradient, fc4's weight gradient and the head's weight gradient lead the launch; conv3's roles
+// then take dy3 from the input-gradient workgroups of the same launch (one arrival counter: a column tile of dy3 covers every sample)
+template <bool FC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
-bwd_chain_kernel(const BD3 d3, const WG3l w3, const BD2 d2, const WG2l w2, const WG1u w1, const FoldRole f3, const FoldRole f2,
-                 const BwdChainN n) {
+bwd_chain_kernel(const FCD fd, const FCW fw, const HeadWgradRole fh, const BD3 d3, const WG3l w3, const BD2 d2, const WG2l w2,
+                 const WG1u w1, const FoldRole f3, const FoldRole f2, const BwdChainN n) {
   extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
   int b = blockIdx.x, first = 0;
-  if (b < n.d3) { d3.run_<false, true>(b, dyn_lds, first); return; }
+  if constexpr (FC) {
+    if (b < n.fd) { fd.run_<true>(b, dyn_lds); return; }
+    b -= n.fd; first += n.fd;
+    if (b < n.fw) { fw.run(b, dyn_lds, first); return; }
+    b -= n.fw; first += n.fw;
+    if (b < n.fh) { fh.run(b, dyn_lds, first); return; }
+    b -= n.fh; first += n.fh;
+  }
+  if (b < n.d3) { d3.run_<FC, true>(b, dyn_lds, first); return; }
   b -= n.d3; first += n.d3;
-  if (b < n.w3) { w3.run_<false, true>(b, dyn_lds, first); return; }
+  if (b < n.w3) { w3.run_<FC, true>(b, dyn_lds, first); return; }
   b -= n.w3; first += n.w3;
   if (b < n.d2) { d2.run_<true, true>(b, dyn_lds, first); return; }
   b -= n.d2; first += n.d2;
@@ -365,7 +381,7 @@ bwd_chain_kernel(const BD3 d3, const WG3l w3, const BD2 d2, const WG2l w2, const
   f2.run_<true>(b, dyn_lds);
 }
 
-constexpr int kBwdChainCounters = (2 * 32 + 2) * kChainLine;
+constexpr int kBwdChainCounters = (2 * 32 + 3) * kChainLine;
 int dra_bwd_chain_counters(void) { return kBwdChainCounters; }
 
 // Library-internal (actor_env.h).  counters: kBwdChainCounters zeroed unsigned (never reset); *epoch = updates whose head kernel
@@ -376,7 +392,7 @@ int dra_conv_bwd_chain(const float* dy3, const float* y2, const float* wt3, floa
                        const int64_t* idx, float* dw1, float* db1, int64_t stride1, int batch, double u8_coef, int act,
                        const dra_fold_seg* fold3, const dra_fold_seg* fold2, float* grad, double* partials3, int* n_partials3,
                        double* partials2, int* n_partials2, double* reset_slots, int n_reset, unsigned* counters,
-                       const unsigned* epoch, int* timeout_flag, void* stream) {
+                       const unsigned* epoch, int* timeout_flag, const DraBwdChainFc* fc, void* stream) {
   if (!dy3 || !y2 || !wt3 || !dw3 || !db3 || !dy2 || !y1 || !wt2 || !dw2 || !db2 || !dy1 || !frames || !dw1 || !db1 || batch < 1 ||
       batch > 32 || !n_partials3 || !n_partials2 || !fold_ok(fold3, grad, partials3) || !fold_ok(fold2, grad, partials2) || !counters ||
       !epoch || !timeout_flag)
@@ -390,16 +406,43 @@ int dra_conv_bwd_chain(const float* dy3, const float* y2, const float* wt3, floa
   FoldRole f3 = make_fold_role(fold3, grad, partials3, nullptr, 0);
   FoldRole f2 = make_fold_role(fold2, grad, partials2, reset_slots, n_reset);
   BwdChainN n;
+  n.fd = n.fw = n.fh = 0;
   n.d3 = d3.blocks(); n.w3 = w3.blocks(); n.d2 = d2.blocks(); n.w2 = w2.blocks(); n.w1 = w1.blocks(); n.f3 = f3.blocks(); n.f2 = f2.blocks();
   *n_partials3 = n.f3; *n_partials2 = n.f2;
   unsigned* cA = counters;                       // conv3's input-gradient workgroups, per sample
   unsigned* cB = counters + 32 * kChainLine;     // conv2's
   unsigned* cW3 = counters + 64 * kChainLine;    // conv3's weight-gradient workgroups, all samples
   unsigned* cW2 = counters + 65 * kChainLine;
+  unsigned* cF = counters + 66 * kChainLine;     // fc4's input-gradient workgroups (DRA_VAR_BWD_CHAIN_FC)
   ChainHook base;
   base.epoch = epoch; base.epoch_bias = 0; base.timeout_flag = timeout_flag;
+  FCD fd = {};
+  FCW fw = {};
+  HeadWgradRole fh;
+  fh.dq = nullptr; fh.h4 = nullptr; fh.dwh = nullptr; fh.dbh = nullptr; fh.B = 0; fh.A = 0;
+  if (fc) {
+    if (!fc->dq || !fc->h4 || !fc->dh4 || !fc->x3 || !fc->w4 || !fc->dwh || !fc->dbh || !fc->dw4 || !fc->db4 || fc->n_actions < 1 ||
+        fc->in_features != G3::OC * G3::P || !fc->sq_partials || !fc->n_sq_partials || !fc_wgrad_one(batch))
+      return DRA_EINVAL;
+    // (the roles of dra_fc_bwd_fused_sq, argument for argument; the input gradient IS dy3)
+    fd.dy = fc->dh4; fd.w = fc->w4; fd.xact = fc->x3; fd.dx = const_cast<float*>(dy3); fd.B = batch; fd.I = fc->in_features; fd.act = act;
+    fd.tiles_n = (fc->in_features + 31) / 32;
+    fd.hook = base; fd.hook.done = cF;
+    fw.dy = fc->dh4; fw.x = fc->x3; fw.dw = fc->dw4; fw.db = fc->db4; fw.partials = fc->sq_partials; fw.B = batch; fw.O = 512;
+    fw.I = fc->in_features; fw.tiles_o = 512 / 32; fw.groups_i = (fd.tiles_n + kFcWgradNI - 1) / kFcWgradNI;
+    fh.dq = fc->dq; fh.h4 = fc->h4; fh.dwh = fc->dwh; fh.dbh = fc->dbh; fh.B = batch; fh.A = fc->n_actions;
+    if (fc->head_action && fc->head_group > 1 && fc->n_actions % fc->head_group == 0) { fh.action = fc->head_action; fh.group = fc->head_group; }
+    n.fd = fd.tiles_n * ((batch + 31) / 32); n.fw = fw.blocks(); n.fh = 2 * fc->n_actions;
+    fh.partials = fc->sq_partials + n.fw;
+    *fc->n_sq_partials = n.fw + 2 * fc->n_actions;
+  }
   d3.hook = base; d3.hook.done = cA; d3.hook.done_stride = kChainLine;
   w3.hook = base; w3.hook.done = cW3;
+  if (fc) {
+    // (480 workgroups on ONE counter: polled slowly, like the folds' -- tight polls on the line starve the producers' adds)
+    d3.hook.wait = cF; d3.hook.wait_stride = 0; d3.hook.wait_target = (unsigned)n.fd; d3.hook.slow = 1;
+    w3.hook.wait = cF; w3.hook.wait_stride = 0; w3.hook.wait_target = (unsigned)n.fd; w3.hook.slow = 1;
+  }
   d2.hook = base; d2.hook.wait = cA; d2.hook.wait_stride = kChainLine; d2.hook.wait_target = BD3::WGS_PER_SAMPLE;
   d2.hook.done = cB; d2.hook.done_stride = kChainLine;
   w2.hook = base; w2.hook.wait = cA; w2.hook.wait_stride = kChainLine; w2.hook.wait_target = BD3::WGS_PER_SAMPLE; w2.hook.done = cW2;
@@ -408,12 +451,22 @@ int dra_conv_bwd_chain(const float* dy3, const float* y2, const float* wt3, floa
   f2.hook = base; f2.hook.wait = cW2; f2.hook.wait_target = (unsigned)n.w2; f2.hook.slow = 1;
   constexpr int fa = BD3::LDS_FLOATS > WG3l::LDS_FLOATS ? BD3::LDS_FLOATS : WG3l::LDS_FLOATS;
   constexpr int fb = BD2::LDS_FLOATS > WG2l::LDS_FLOATS ? BD2::LDS_FLOATS : WG2l::LDS_FLOATS;
-  constexpr int fc = WG1u::LDS_FLOATS > FoldRole::LDS_FLOATS ? WG1u::LDS_FLOATS : FoldRole::LDS_FLOATS;
-  constexpr int fab = fa > fb ? fa : fb, fl = fab > fc ? fab : fc;
+  constexpr int fcl = WG1u::LDS_FLOATS > FoldRole::LDS_FLOATS ? WG1u::LDS_FLOATS : FoldRole::LDS_FLOATS;
+  constexpr int fab = fa > fb ? fa : fb, fl = fab > fcl ? fab : fcl;
   constexpr size_t bytes = (size_t)fl * sizeof(float);
   static_assert(bytes <= 64 * 1024, "LDS per workgroup of the chained backward launch");
-  hipLaunchKernelGGL(bwd_chain_kernel, dim3(n.d3 + n.w3 + n.d2 + n.w2 + n.w1 + n.f3 + n.f2), dim3(256), bytes, dra_stream(stream),
-                     d3, w3, d2, w2, w1, f3, f2, n);
+  const int grid = n.fd + n.fw + n.fh + n.d3 + n.w3 + n.d2 + n.w2 + n.w1 + n.f3 + n.f2;
+  if (fc) {
+    // fc4's input gradient stages dh4 as [32][513] floats: 65.7 KB -- still two workgroups per CU
+    constexpr size_t bytes_fc = (size_t)(FCD::LDS_FLOATS > fl ? FCD::LDS_FLOATS : fl) * sizeof(float);
+    static_assert(bytes_fc <= 80 * 1024, "two workgroups of the chained backward launch per CU");
+    static DraLdsAttr lds_attr;
+    if (bytes_fc > 64 * 1024)
+      if (int rc = dra_grant_lds(lds_attr, reinterpret_cast<const void*>(&bwd_chain_kernel<true>), bytes_fc)) return rc;
+    hipLaunchKernelGGL(bwd_chain_kernel<true>, dim3(grid), dim3(256), bytes_fc, dra_stream(stream), fd, fw, fh, d3, w3, d2, w2, w1, f3, f2, n);
+  } else {
+    hipLaunchKernelGGL(bwd_chain_kernel<false>, dim3(grid), dim3(256), bytes, dra_stream(stream), fd, fw, fh, d3, w3, d2, w2, w1, f3, f2, n);
+  }
   DRA_LAUNCH_CHECK();
   return DRA_OK;
 }
@@ -425,8 +478,6 @@ int dra_conv_bwd_chain(const float* dy3, const float* y2, const float* wt3, floa
 // leave their sums of squares in sq_partials[0, *n_sq_partials): fc4's tiles first, then the head's 2 * n_actions
 // fc4's weight gradient of the learner's launch: the register-only role for minibatches up to 32 (oneshot_lin.h), else the
 // K-chunked implicit GEMM (same box: fc_bwd 13.1 -> 11.2 us, +1.6 % updates/s; profiles/r04e_ab_env.jsonl).
-static bool fc_wgrad_one(int batch) { return batch <= 32; }
-constexpr int kFcWgradNI = 8;    // 32-wide input tiles per workgroup of LinWgradOne
 // partials dra_fc_bwd_fused_sq writes for this problem (library-internal, actor_env.h): the learner lays the later launches'
 // partials and the optimizer's arrival slots out behind them
 int dra_fc_bwd_fused_sq_partials(int batch, int n_actions, int in_features) {

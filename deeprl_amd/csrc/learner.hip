@@ -1543,18 +1543,27 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       conv_fold_segs(l, segs);
       const int nfc_expect = dra_fc_bwd_fused_sq_partials(B, NO, 3136), n3_expect = (int)((l->lstride[2] / 4 + 63) / 64), n2_expect = (int)((l->lstride[1] / 4 + 63) / 64);
       // (single-kernel replay: the skipped launches leave their partial counts at the expected values)
-      int nfc = (l->only_kernel >= 0 || l->only_chain == 2) ? nfc_expect : 0, n3 = l->only_kernel >= 0 ? n3_expect : 0, n2 = l->only_kernel >= 0 ? n2_expect : 0;
-      if (l->only_chain != 2)
+      const bool fc_in_chain = bchain && (l->variant & DRA_VAR_BWD_CHAIN_FC) && B <= 32;
+      int nfc = (l->only_kernel >= 0 || (l->only_chain == 2 && !fc_in_chain)) ? nfc_expect : 0, n3 = l->only_kernel >= 0 ? n3_expect : 0, n2 = l->only_kernel >= 0 ? n2_expect : 0;
+      if (l->only_chain != 2 && !fc_in_chain)
       STEP(K_FC4_BX, dra_fc_bwd_fused_sq(l->dq, l->h4, l->dh4, l->y3[0], P + o[P_W4], G + o[P_WH], G + o[P_BH], G + o[P_W4],
                                          G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, l->partials, &nfc,
                                          c.head_kind != DRA_HEAD_VANILLA ? l->action_[l->gb] : nullptr, c.n_atoms, s));
       if (l->profiling) DRA_HIP(hipEventRecord(l->ev[K_CONV3_BW], st));
       if (bchain) {
+        DraBwdChainFc fcb;
+        if (fc_in_chain) {      // DRA_VAR_BWD_CHAIN_FC: the arguments of the dra_fc_bwd_fused_sq launch skipped above
+          fcb.dq = l->dq; fcb.h4 = l->h4; fcb.dh4 = l->dh4; fcb.x3 = l->y3[0]; fcb.w4 = P + o[P_W4]; fcb.dwh = G + o[P_WH];
+          fcb.dbh = G + o[P_BH]; fcb.dw4 = G + o[P_W4]; fcb.db4 = G + o[P_B4]; fcb.n_actions = NO; fcb.in_features = 3136;
+          fcb.sq_partials = l->partials; fcb.n_sq_partials = &nfc;
+          fcb.head_action = c.head_kind != DRA_HEAD_VANILLA ? l->action_[l->gb] : nullptr; fcb.head_group = c.n_atoms;
+        }
         int rcb = dra_conv_bwd_chain(l->dy3, l->y2[0], P + o[P_W3], dw[2], dbs[2], stride[2], l->dy2, l->y1[0], P + o[P_W2], dw[1],
                                      dbs[1], stride[1], l->dy1, ring_frames, l->idx, dw[0], dbs[0], stride[0], B, c.u8_coef,
-                                     DRA_ACT_RELU, &segs[2], &segs[1], G, l->partials + nfc, &n3, l->partials + nfc + n3_expect, &n2,
+                                     DRA_ACT_RELU, &segs[2], &segs[1], G, l->partials + nfc_expect, &n3,
+                                     l->partials + nfc_expect + n3_expect, &n2,
                                      l->partials + nfc_expect + n3_expect + n2_expect, l->late_nfold, l->bchain_dev,
-                                     l->fchain_dev + kFwdChainCounters, l->timeout_flag, s);
+                                     l->fchain_dev + kFwdChainCounters, l->timeout_flag, fc_in_chain ? &fcb : nullptr, s);
         if (rcb) return rcb;
         if (nfc != nfc_expect || n3 != n3_expect || n2 != n2_expect) return DRA_EINVAL;
         l->late_nprior = nfc + n3 + n2;

@@ -273,7 +273,10 @@ struct LinDgradOne {
   const float* xact;  // [B][I] or null
   float* dx;          // [B][I]
   int B, I, act, tiles_n;
-  __device__ __forceinline__ void run(int bid, float* __restrict__ lds, int = 0) const {
+  ChainHook hook;     // DRA_VAR_BWD_CHAIN_FC (run_<true>: dx goes to workgroups of the SAME launch -- conv3's backward roles)
+  __device__ __forceinline__ void run(int bid, float* __restrict__ lds, int = 0) const { run_<false>(bid, lds); }
+  template <bool COUT>
+  __device__ __forceinline__ void run_(int bid, float* __restrict__ lds) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int bm = bid / tiles_n, bn = bid - bm * tiles_n;
     const int m0 = bm * 32, n0 = bn * 32;
@@ -322,9 +325,10 @@ struct LinDgradOne {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int m = m0 + mfma_row(wave * 4 + q, h);
-      if (m < B && n0 + li < I) dx[(int64_t)m * I + n0 + li] = xact ? s[q] * act_grad(aux[q], act) : s[q];
+      if (m < B && n0 + li < I) mega_st<COUT>(&dx[(int64_t)m * I + n0 + li], xact ? s[q] * act_grad(aux[q], act) : s[q]);
     }
     DRA_STAMP(TR_FC_B, 5);
+    if constexpr (COUT) mega_publish(hook.sync(0));     // (one counter for the whole role: a column tile covers every sample)
     DRA_STAMP_END(TR_FC_B);
   }
 };

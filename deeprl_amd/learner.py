@@ -1138,6 +1138,9 @@ class DQNLearnerBench:
                                 alg_hbm["conv1_fwd"] + 4 * (2 * w2 + 2 * y2) + 4 * (2 * w3 + 2 * y3)),
                         "bwd": ("conv_bwd_chain", ("conv3_bwd_x", "conv2_bwd_x", "conv1_bwd_w"),
                                 4 * (y3 + y2 + 2 * w3) + 4 * (y1 + 2 * w2) + b * 4 * 7056 + 4 * w1)}
+                if variant & ops.VAR_BWD_CHAIN_FC:      # fc4's + the head's backward lead the chained backward launch
+                    w4 = 512 * 3136
+                    spec["bwd"] = ("conv_bwd_chain", ("fc4_bwd_x",) + spec["bwd"][1], spec["bwd"][2] + 4 * (2 * w4 + b * 512 + 2 * y3))
                 for which, (name, parts, alg) in spec.items():
                     try:
                         per_us, empty_us = L.chain_replay(which, 64)

@@ -353,6 +353,13 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
                                     * the target's fc4 partial sums from a stash.  Needs the next minibatch's indices one call early
                                     * (dra_dqn_learner_stage_next_indices); an update without a stash computes its target in line.
                                     * Same kernels on the same data: bit-identical.  DQN_agent.py:114-127 */
+#define DRA_VAR_BWD_CHAIN_FC 1073741824 /* learner (with BWD_CHAIN): fc4's and the head's backward (input gradient, fc4 weight gradient,
+                                    * head weight gradient) lead the chained backward launch; conv3's roles wait for the
+                                    * input-gradient workgroups instead of for a launch boundary.  Same arithmetic: bit-identical
+                                    * gradients.  OPT-IN, measured SLOWER on MI355X (92.4 -> 97.5 us per step): a launch's register
+                                    * and LDS footprint is the maximum over its roles -- fc4's input gradient (152 + 32 registers,
+                                    * 65.7 KB of LDS) takes the whole launch from three workgroups per CU to two.
+                                    * DQN_agent.py:129-134 */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */

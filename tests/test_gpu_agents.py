@@ -1677,8 +1677,12 @@ def test_backward_chain_is_bit_identical(dra):
     from deeprl_amd.learner import DQNLearnerBench
     default = ops.get_tuning()
     outs = []
-    for variant, interrupt in ((default & ~ops.VAR_BWD_CHAIN, False), (default | ops.VAR_BWD_CHAIN, False),
-                               (default | ops.VAR_BWD_CHAIN, True)):
+    # (DRA_VAR_BWD_CHAIN_FC: fc4's + the head's backward as the leading roles of the same launch -- cleared and set, the latter
+    # also with the chained launch replayed alone in the middle)
+    fcbit = ops.VAR_BWD_CHAIN_FC
+    for variant, interrupt in (((default & ~ops.VAR_BWD_CHAIN) & ~fcbit, False), ((default | ops.VAR_BWD_CHAIN) & ~fcbit, False),
+                               ((default | ops.VAR_BWD_CHAIN) & ~fcbit, True), (default | ops.VAR_BWD_CHAIN | fcbit, False),
+                               (default | ops.VAR_BWD_CHAIN | fcbit, True)):
         np.random.seed(41)
         torch.manual_seed(42)
         b = DQNLearnerBench(ring_capacity=4096, batch=32, seed=43, actor=True, async_actor=True, variant=variant)
@@ -1692,6 +1696,8 @@ def test_backward_chain_is_bit_identical(dra):
             if interrupt and t == 11:
                 L.kernel_replay("conv2_fwd", 4)
                 L.kernel_replay("conv2_bwd_x", 4)
+            if interrupt and t == 23:
+                L.chain_replay("bwd", 4)
         L.synchronize()
         frames = d.ops._wrap_device_pointer(b.ring.pointers()[0], 260 * 7056, torch.uint8).cpu().numpy().copy()
         acts = d.ops._wrap_device_pointer(b.ring.pointers()[1], 260, torch.int64).cpu().numpy().copy()
@@ -1701,6 +1707,6 @@ def test_backward_chain_is_bit_identical(dra):
         L.close()
         b.ring.close()
     for k in outs[0]:
-        for i in (1, 2):
+        for i in (1, 2, 3, 4):
             assert np.array_equal(outs[0][k], outs[i][k]), ("chained vs separate backward launches", i, k)
     assert float(np.abs(outs[0]["p"]).max()) > 0
