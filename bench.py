@@ -826,8 +826,17 @@ def main():
     affinity = gather_affinity(pin_this_rank(), world)
     torch.manual_seed(1234 + rank)
     np.random.seed(rank)
+    variant = args.variant
+    shared_device = distributed and world > torch.cuda.device_count()
+    if shared_device and variant < 0:
+        # several ranks on ONE GPU (the launch contract exercised on a 1-GPU box): DRA_VAR_ACTOR_PERSIST's launch needs its 32
+        # workgroups co-resident on the actor partition -- two processes' launches on the same CUs can each hold a part of it and
+        # wait for the rest until their bounded waits give up.  A process that shares its GPU runs the multi-launch actor and
+        # the event path (one rank per GPU, the deployment the variants are for, is unaffected)
+        from deeprl_amd import ops as _ops
+        variant = _ops.get_tuning() & ~(_ops.VAR_ACTOR_PERSIST | _ops.VAR_FLAG_SYNC | _ops.VAR_LANE_EAGER)
     bench = DQNLearnerBench(ring_capacity=args.ring, batch=B, seed=rank, actor=not args.no_actor,
-                            async_actor=not args.sync_actor, variant=args.variant)
+                            async_actor=not args.sync_actor, variant=variant)
     # Setup before the contract's W warm-up steps when W is tiny (the driver's W = 5 is 0.6 ms): the four rotation slots'
     # graphs are captured on first use, the 1M-frame ring's pages are touched for the first time and the clocks ramp.  These
     # steps are untimed like the warm-up, reported as `setup_steps`; the K timed steps are exactly K steps either way.
