@@ -210,6 +210,7 @@ int dra_actor_persist(const ActorPersistArgs* a, void* stream);
 constexpr int kChainPad = 32;                  // unsigned per counter: one 128-byte line each
 constexpr int kFwdChainCounters = 2 * DRA_MAX_Z * 32 * kChainPad;
 void dra_conv_chain_attach_announce(unsigned long long* count);   // the next dra_conv_fwd_chain launch counts itself in *count
+void dra_conv_chain_attach_zero(unsigned* word);   // DRA_VAR_HEAD_CHAIN: the next dra_conv_fwd_chain launch zeroes *word when it starts
 int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* idx_tagged,
                        const unsigned long long* update_seq, const int64_t* newest_off, int nz, const float* const* w1,
                        const float* const* b1, float* const* y1, const float* const* w2, const float* const* b2, float* const* y2,

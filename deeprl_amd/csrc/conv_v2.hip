@@ -1449,6 +1449,9 @@ struct FwdChainArgs {
   // stream ran before this launch -- the previous update's optimizer -- is complete and visible, which is what the actor launch
   // on the other stream polls for instead of waiting for an event (learner.hip step_lane)
   unsigned long long* announce;
+  // DRA_VAR_HEAD_CHAIN: a word the first workgroup sets to zero -- the arrival counter of the head -> fc4-backward hand-over of the
+  // PREVIOUS update's launch (complete when this launch starts; the next such launch of this update counts from zero again)
+  unsigned* zero_word;
 };
 
 __global__ void __launch_bounds__(256, 4) conv_fwd_chain_kernel(const FwdChainArgs a) {
@@ -1457,6 +1460,7 @@ __global__ void __launch_bounds__(256, 4) conv_fwd_chain_kernel(const FwdChainAr
   int b = blockIdx.x;
   const int batch = a.c1.batch;
   if (a.announce && b == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(a.announce, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.zero_word && b == 0 && threadIdx.x == 0) __hip_atomic_store(a.zero_word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // the riders sit behind `rider_after` convolution workgroups of the grid
   if (b >= a.rider_after && b < a.rider_after + a.n_riders) {
     fc4_rider_run<true>(a.rider, b - a.rider_after);
@@ -1513,6 +1517,8 @@ __global__ void __launch_bounds__(256, 4) conv_fwd_chain_kernel(const FwdChainAr
 // Library-internal (actor_env.h): the NEXT dra_conv_fwd_chain launch counts itself in *count when it starts (DRA_VAR_FLAG_SYNC)
 static unsigned long long* g_chain_announce = nullptr;
 void dra_conv_chain_attach_announce(unsigned long long* count) { g_chain_announce = count; }
+static unsigned* g_chain_zero = nullptr;
+void dra_conv_chain_attach_zero(unsigned* word) { g_chain_zero = word; }   // (the NEXT dra_conv_fwd_chain launch zeroes *word when it starts)
 
 // Library-internal (actor_env.h): conv1 (ring-direct, as dra_conv1_fwd_koc_ringbatch) + conv2 + conv3 (as dra_conv_fwd_koc) of nz nets.
 int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy, const int64_t* idx_tagged,
@@ -1529,6 +1535,8 @@ int dra_conv_fwd_chain(const void* frames, const int64_t* idx, int64_t* idx_copy
   FwdChainArgs a;
   a.announce = g_chain_announce;
   g_chain_announce = nullptr;
+  a.zero_word = g_chain_zero;
+  g_chain_zero = nullptr;
   for (int z = 0; z < nz; ++z) {
     if (!w1[z] || !b1[z] || !y1[z] || !w2[z] || !b2[z] || !y2[z] || !w3[z] || !b3[z] || !y3[z]) return DRA_EINVAL;
     a.c1.x[z] = frames; a.c1.wt[z] = w1[z]; a.c1.bias[z] = b1[z]; a.c1.y[z] = y1[z];

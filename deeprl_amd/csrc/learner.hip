@@ -19,6 +19,7 @@
 //     around optimizer.step() / the actor's forward (DQN_agent.py:30,133) become HIP events: the
 //     optimizer kernel is the only section exclusive with the actor's weight reads, and the
 //     actor's ring writes wait for the update's gather.
+#include "oneshot_lin.h"     // (LinDgradOne / LinWgradOne / HeadWgradRole: DRA_VAR_HEAD_CHAIN launches them next to the head role)
 #include "actor_env.h"
 #include "per_chain2.h"
 #include <new>
@@ -173,6 +174,7 @@ struct dra_dqn_learner {
   bool profiling;
   int only_kernel;                  // >= 0: run_body issues this kernel group alone (dra_dqn_learner_kernel_replay); -1 otherwise
   int only_chain;                   // 1 / 2: run_body issues the chained forward / backward launch alone (dra_dqn_learner_chain_replay)
+  unsigned* hchain_dev;             // DRA_VAR_HEAD_CHAIN: arrivals of the head role's workgroups (zeroed by the next update's forward chain)
   // DRA_VAR_DEFER_FC4 (common.h DraFc4Rider): the ring-direct pipelined graphs leave fc4's segment of the optimizer step to rider
   // workgroups in the NEXT graph's conv1 / conv2 forward launches
   bool defer;                       // active for this learner (decided at creation)
@@ -477,6 +479,8 @@ DRA_API int dra_dqn_learner_create(dra_dqn_learner** out, dra_ring* ring, const 
   if (!rc) memset(l->fs_host, 0, (size_t)(8 + kAringSlots) * sizeof(unsigned long long));
   rc |= (int)hipEventCreateWithFlags(&l->ev_fs, hipEventDisableTiming);
   rc |= (int)hipMalloc(&l->aflags, (size_t)kMaxEnvSteps * 4 * sizeof(unsigned));
+  rc |= (int)hipMalloc(&l->hchain_dev, 256);
+  if (!rc) rc |= (int)hipMemset(l->hchain_dev, 0, 256);
   rc |= (int)hipMalloc(&l->fchain_dev, (size_t)(kFwdChainCounters + 2) * sizeof(unsigned));
   if (!rc) rc |= (int)hipMemset(l->fchain_dev, 0, (size_t)(kFwdChainCounters + 2) * sizeof(unsigned));
   // DRA_VAR_TARGET_AHEAD: workspaces (the stream comes later: dra_dqn_learner_set_ahead_stream)
@@ -617,6 +621,7 @@ DRA_API int dra_dqn_learner_destroy(dra_dqn_learner* l) {
   if (l->aflags) (void)hipFree(l->aflags);
   if (l->all_dev) (void)hipFree(l->all_dev);
   if (l->fchain_dev) (void)hipFree(l->fchain_dev);
+  if (l->hchain_dev) (void)hipFree(l->hchain_dev);
   for (int k = 0; k < 2; ++k) {
     void* ab[] = {l->ah_y1[k], l->ah_y2[k], l->ah_y3[k], l->ah_slabs[k], l->ah_chain[k]};
     for (void* b : ab) if (b) (void)hipFree(b);
@@ -960,33 +965,17 @@ fc4_reduce_kernel(const float* __restrict__ slabs, int B, const float* __restric
 //   dh4[b][k]   = dq[b][a_b] * Wh_0[a_b][k] * (h4[0][b][k] > 0)     (gradient w.r.t. fc4's pre-activation)
 // Per-sample work only: the batch-mean loss is recovered from `delta` on demand, and the PER
 // variant (needs max over the batch) keeps the separate td_loss kernel.
-template <int KS>
-__global__ void __launch_bounds__(256)
-head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const float* __restrict__ b4_on,
+// (the body: one workgroup = one sample b.  COUT (DRA_VAR_HEAD_CHAIN): h4 / dq / dh4 go to workgroups of the SAME launch -- fc4's and
+// the head's backward roles -- agent-scope stores, then the workgroup counts itself on `done`)
+template <int KS, bool COUT>
+__device__ __forceinline__ void head_fused_body(const float* __restrict__ slabs, int nz, int B, int A, const float* __restrict__ b4_on,
                   const float* __restrict__ b4_tg, const float* __restrict__ wh_on, const float* __restrict__ wh_tg,
                   const float* __restrict__ bh_on, const float* __restrict__ bh_tg, const int64_t* __restrict__ action,
                   const float* __restrict__ reward, const float* __restrict__ mask, float gamma_n, int double_q,
                   float* __restrict__ h4_out, float* __restrict__ q_on, float* __restrict__ q_tg, float* __restrict__ q_on2,
                   float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dh4, int64_t* __restrict__ opt_step,
-                  const RingScalars rs, const float* __restrict__ per_w, const float* __restrict__ pf_w4) {
-  __shared__ float s_h[3][512];
-  __shared__ float s_q[3][64];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (b >= B) {
-    // Spare workgroups of this 32-workgroup launch prefetch what the NEXT launch's input-gradient role will stream: workgroup
-    // B + p pulls W4[0:512][32p : 32p + 32] (512 row segments of 128 B) -- the operand of LinDgradOne workgroup p, which runs on
-    // the same XCD (workgroups are dealt round-robin over the 8 XCDs and B is a multiple of 8) -- into that XCD's L2.
-    const int pcol = (b - B) * 32;
-    float4 v[16];
-#pragma unroll
-    for (int qq = 0; qq < 16; ++qq) {
-      const int e = tid + 256 * qq, row = e >> 3, c4 = e & 7;
-      v[qq] = *reinterpret_cast<const float4*>(pf_w4 + (int64_t)row * 3136 + pcol + 4 * c4);
-    }
-#pragma unroll
-    for (int qq = 0; qq < 16; ++qq) asm volatile("" :: "v"(v[qq].x), "v"(v[qq].y), "v"(v[qq].z), "v"(v[qq].w));
-    return;
-  }
+                  const RingScalars rs, const float* __restrict__ per_w, const int b, float (*s_h)[512], float (*s_q)[64], unsigned* done) {
+  const int tid = threadIdx.x;
   DRA_STAMP(TR_HEAD, 0);
   // everything this workgroup reads is requested up front: the head weights of the (net, action) pairs this wave owns, the
   // transition scalars, and then the split-K partials -- ONE exposed memory latency instead of three (phase trace r02a:
@@ -1052,7 +1041,7 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
       v += bias[k];
       v = v > 0.f ? v : 0.f;
       s_h[z][k] = v;
-      if (z == 0) h4_out[(int64_t)b * 512 + k] = v;
+      if (z == 0) mega_st<COUT>(&h4_out[(int64_t)b * 512 + k], v);
     }
   }
   __syncthreads();
@@ -1114,18 +1103,86 @@ head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const f
     q_on[(int64_t)b * A + tid] = s_q[0][tid];
     q_tg[(int64_t)b * A + tid] = s_q[1][tid];
     if (nz > 2) q_on2[(int64_t)b * A + tid] = s_q[2][tid];
-    dq[(int64_t)b * A + tid] = (tid == ab) ? dqa : 0.f;
+    mega_st<COUT>(&dq[(int64_t)b * A + tid], (tid == ab) ? dqa : 0.f);
   }
 #pragma unroll
   for (int rep = 0; rep < 2; ++rep) {
     const int k = tid + 256 * rep;
-    dh4[(int64_t)b * 512 + k] = s_h[0][k] > 0.f ? dqa * dwh[rep] : 0.f;
+    mega_st<COUT>(&dh4[(int64_t)b * 512 + k], s_h[0][k] > 0.f ? dqa * dwh[rep] : 0.f);
   }
   if (opt_step && b == 0 && tid == 0) *opt_step += 1;   // one optimizer step per update (Adam's t)
   if (rs.seq && b == 0 && tid == 0) *rs.seq += 1ull;
   if (rs.chain_epoch && b == 0 && tid == 0) *rs.chain_epoch += 1u;
   DRA_STAMP(TR_HEAD, 5);
   DRA_STAMP_END(TR_HEAD);
+  if constexpr (COUT) {
+    MegaSync ms;
+    ms.done = done;
+    mega_publish(ms);
+  }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256)
+head_fused_kernel(const float* __restrict__ slabs, int nz, int B, int A, const float* __restrict__ b4_on,
+                  const float* __restrict__ b4_tg, const float* __restrict__ wh_on, const float* __restrict__ wh_tg,
+                  const float* __restrict__ bh_on, const float* __restrict__ bh_tg, const int64_t* __restrict__ action,
+                  const float* __restrict__ reward, const float* __restrict__ mask, float gamma_n, int double_q,
+                  float* __restrict__ h4_out, float* __restrict__ q_on, float* __restrict__ q_tg, float* __restrict__ q_on2,
+                  float* __restrict__ delta, float* __restrict__ dq, float* __restrict__ dh4, int64_t* __restrict__ opt_step,
+                  const RingScalars rs, const float* __restrict__ per_w, const float* __restrict__ pf_w4) {
+  __shared__ float s_h[3][512];
+  __shared__ float s_q[3][64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= B) {
+    // Spare workgroups of this 32-workgroup launch prefetch what the NEXT launch's input-gradient role will stream: workgroup
+    // B + p pulls W4[0:512][32p : 32p + 32] (512 row segments of 128 B) -- the operand of LinDgradOne workgroup p, which runs on
+    // the same XCD (workgroups are dealt round-robin over the 8 XCDs and B is a multiple of 8) -- into that XCD's L2.
+    const int pcol = (b - B) * 32;
+    float4 v[16];
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) {
+      const int e = tid + 256 * qq, row = e >> 3, c4 = e & 7;
+      v[qq] = *reinterpret_cast<const float4*>(pf_w4 + (int64_t)row * 3136 + pcol + 4 * c4);
+    }
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) asm volatile("" :: "v"(v[qq].x), "v"(v[qq].y), "v"(v[qq].z), "v"(v[qq].w));
+    return;
+  }
+  head_fused_body<KS, false>(slabs, nz, B, A, b4_on, b4_tg, wh_on, wh_tg, bh_on, bh_tg, action, reward, mask, gamma_n, double_q, h4_out, q_on, q_tg, q_on2, delta, dq, dh4, opt_step, rs, per_w, b, s_h, s_q, nullptr);
+}
+
+// DRA_VAR_HEAD_CHAIN: the head launch and fc4's / the head's backward launch as ONE launch in dependency order --
+//   [head role: B workgroups] [fc4 input gradient] [fc4 weight gradient] [head weight gradient]
+// the backward roles request what does not depend on the head (fc4's weights, conv3's activations) FIRST, wait on one arrival
+// counter for the B head workgroups, then read dh4 / dq / h4 with agent-scope loads.  The counter is zeroed by the first
+// workgroup of the NEXT update's forward chain.  Same arithmetic in the same order as the two launches: bit-identical.
+// DQN_agent.py:85-99 (loss) + the first two nodes of loss.backward() (DQN_agent.py:131).
+struct HeadArgs {
+  const float* slabs; int nz, B, A;
+  const float *b4_on, *b4_tg, *wh_on, *wh_tg, *bh_on, *bh_tg;
+  const int64_t* action; const float *reward, *mask; float gamma_n; int double_q;
+  float *h4_out, *q_on, *q_tg, *q_on2, *delta, *dq, *dh4; int64_t* opt_step;
+  RingScalars rs; const float* per_w; unsigned* done;
+};
+template <int KS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+head_fc_bwd_kernel(const HeadArgs ha, const LinDgradOne<512> rd, const LinWgradOne<8> rl, const HeadWgradRole rh, const int nd, const int nw) {
+  extern __shared__ __attribute__((aligned(16))) float dyn_lds[];
+  int b = blockIdx.x;
+  if (b < ha.B) {
+    float (*s_h)[512] = reinterpret_cast<float (*)[512]>(dyn_lds);
+    float (*s_q)[64] = reinterpret_cast<float (*)[64]>(dyn_lds + 3 * 512);
+    head_fused_body<KS, true>(ha.slabs, ha.nz, ha.B, ha.A, ha.b4_on, ha.b4_tg, ha.wh_on, ha.wh_tg, ha.bh_on, ha.bh_tg, ha.action, ha.reward,
+                              ha.mask, ha.gamma_n, ha.double_q, ha.h4_out, ha.q_on, ha.q_tg, ha.q_on2, ha.delta, ha.dq, ha.dh4, ha.opt_step,
+                              ha.rs, ha.per_w, b, s_h, s_q, ha.done);
+    return;
+  }
+  b -= ha.B;
+  if (b < nd) { rd.run_<false, true>(b, dyn_lds); return; }
+  b -= nd;
+  if (b < nw) { rl.run_<true>(b, dyn_lds); return; }
+  rh.run_<true>(b - nw, dyn_lds);
 }
 
 // dWh[a][k] = sum_b dq[b][a] * h4[b][k] ;  dbh[a] = sum_b dq[b][a]      (grid = A, 512 threads)
@@ -1376,6 +1433,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   const bool rd = l->rd_slot >= 0;
   // DRA_VAR_BWD_CHAIN: conv3 / conv2 / conv1 backward as one chained launch (fused.hip bwd_chain_kernel)
   const bool bchain = l->bchain && rd && !l->profiling && l->only_kernel < 0 && part == 0 && !per && !(l->per2_active && l->per2_ride);
+  bool head_chain = false;   // DRA_VAR_HEAD_CHAIN: the head launch below also carried fc4's / the head's backward roles
   void *ring_frames = nullptr, *ring_actions = nullptr, *ring_rewards = nullptr, *ring_masks = nullptr;
   int ring_h = 4, ring_n = 1;
   double ring_discount = 1.0;
@@ -1414,6 +1472,7 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       DraFc4Rider rdr;
       if (riding) rdr = fc4_rider(l, l->pa[l->rider_q]);
       if (l->fs_capturing) dra_conv_chain_attach_announce(l->fs_count);
+      if ((l->variant & DRA_VAR_HEAD_CHAIN) && l->hchain_dev) dra_conv_chain_attach_zero(l->hchain_dev);
       // DRA_VAR_TARGET_AHEAD (rd_eager): the update's chain carries the online net alone
       int rcc = dra_conv_fwd_chain(ring_frames, dev_idx ? l->per2_idx + (size_t)l->rd_slot * 1024 : l->idx_pin[l->rd_slot], l->idx,
                                    pf ? l->idx_tag_dev + (size_t)l->rd_slot * 1024 : nullptr, pf ? l->rd_seq_dev : nullptr, off,
@@ -1485,11 +1544,42 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
   } else {
     // weights known before the update (device-side prioritized draw): the fused head applies them, no batch-wide reduction
     const float* per_w = (per && l->per2_active) ? l->weights : nullptr;
+    head_chain = (l->variant & DRA_VAR_HEAD_CHAIN) && chain && !per && ks4 == kFc4SplitMid && B <= 32 && nz == 2 && l->late && part == 0 &&
+                 !(l->variant & DRA_VAR_BWD_CHAIN_FC) && (l->variant & DRA_VAR_ONESHOT_DGRAD) && l->hchain_dev && !l->profiling;
     // fc4's input-gradient weights prefetched by spare workgroups of the head launch (see head_fused_kernel; same box: the fc
     // backward launch 11.5 -> 10.8 us, 9 163 -> 9 183 updates/s, profiles/r04v_ab_pf_fc4_bwd.jsonl)
     const bool pf = (l->variant & DRA_VAR_ONESHOT_DGRAD) && B % 8 == 0 && B <= 32 && dra_xcd_order_enabled();
     const float* pf_w4 = pf ? P + o[P_W4] : nullptr;
     const int hb = B + (pf ? 3136 / 32 : 0);
+    if (head_chain) {
+      HeadArgs ha;
+      ha.slabs = l->fc4_slabs; ha.nz = nz; ha.B = B; ha.A = A; ha.b4_on = P + o[P_B4]; ha.b4_tg = T + o[P_B4]; ha.wh_on = P + o[P_WH];
+      ha.wh_tg = T + o[P_WH]; ha.bh_on = P + o[P_BH]; ha.bh_tg = T + o[P_BH]; ha.action = (const int64_t*)l->action_[l->gb];
+      ha.reward = (const float*)l->reward_[l->gb]; ha.mask = (const float*)l->mask_[l->gb]; ha.gamma_n = c.gamma_n; ha.double_q = c.double_q;
+      ha.h4_out = l->h4; ha.q_on = l->q[0]; ha.q_tg = l->q[1]; ha.q_on2 = l->q[2]; ha.delta = l->delta; ha.dq = l->dq; ha.dh4 = l->dh4;
+      ha.opt_step = l->opt_step; ha.rs = rs; ha.per_w = nullptr; ha.done = l->hchain_dev;
+      ChainHook hk;
+      hk.wait = l->hchain_dev; hk.wait_target = (unsigned)B; hk.timeout_flag = l->timeout_flag;
+      // (the roles of dra_fc_bwd_fused_sq, argument for argument)
+      LinDgradOne<512> rd = {};
+      rd.dy = l->dh4; rd.w = P + o[P_W4]; rd.xact = l->y3[0]; rd.dx = l->dy3; rd.B = B; rd.I = 3136; rd.act = DRA_ACT_RELU; rd.tiles_n = 3136 / 32;
+      rd.hook = hk;
+      LinWgradOne<8> rl = {};
+      float* Gh = l->g;
+      rl.dy = l->dh4; rl.x = l->y3[0]; rl.dw = Gh + o[P_W4]; rl.db = Gh + o[P_B4]; rl.partials = l->partials; rl.B = B; rl.O = 512; rl.I = 3136;
+      rl.tiles_o = 512 / 32; rl.groups_i = (rd.tiles_n + 8 - 1) / 8;
+      rl.hook = hk;
+      HeadWgradRole rh;
+      rh.dq = l->dq; rh.h4 = l->h4; rh.dwh = Gh + o[P_WH]; rh.dbh = Gh + o[P_BH]; rh.B = B; rh.A = A;
+      const int nd = rd.tiles_n, nw = rl.blocks();
+      rh.partials = l->partials + nw;
+      rh.hook = hk;
+      if (nw + 2 * A != dra_fc_bwd_fused_sq_partials(B, A, 3136)) return DRA_EINVAL;
+      constexpr size_t hbytes = (size_t)LinDgradOne<512>::LDS_FLOATS * sizeof(float);
+      static DraLdsAttr lds_attr;
+      if (int rcl = dra_grant_lds(lds_attr, reinterpret_cast<const void*>(&head_fc_bwd_kernel<kFc4SplitMid>), hbytes)) return rcl;
+      hipLaunchKernelGGL(head_fc_bwd_kernel<kFc4SplitMid>, dim3(B + nd + nw + 2 * A), dim3(256), hbytes, st, ha, rd, rl, rh, nd, nw);
+    } else
     if (ks4 == kFc4SplitWide)
       hipLaunchKernelGGL(head_fused_kernel<kFc4SplitWide>, dim3(hb), dim3(256), 0, st, (const float*)l->fc4_slabs, nz, B, A,
                          P + o[P_B4], T + o[P_B4], P + o[P_WH], T + o[P_WH], P + o[P_BH], T + o[P_BH],
@@ -1543,9 +1633,9 @@ static int run_body(dra_dqn_learner* l, hipStream_t st, int per, float beta, int
       conv_fold_segs(l, segs);
       const int nfc_expect = dra_fc_bwd_fused_sq_partials(B, NO, 3136), n3_expect = (int)((l->lstride[2] / 4 + 63) / 64), n2_expect = (int)((l->lstride[1] / 4 + 63) / 64);
       // (single-kernel replay: the skipped launches leave their partial counts at the expected values)
-      const bool fc_in_chain = bchain && (l->variant & DRA_VAR_BWD_CHAIN_FC) && B <= 32;
-      int nfc = (l->only_kernel >= 0 || (l->only_chain == 2 && !fc_in_chain)) ? nfc_expect : 0, n3 = l->only_kernel >= 0 ? n3_expect : 0, n2 = l->only_kernel >= 0 ? n2_expect : 0;
-      if (l->only_chain != 2 && !fc_in_chain)
+      const bool fc_in_chain = bchain && (l->variant & DRA_VAR_BWD_CHAIN_FC) && B <= 32 && !head_chain;
+      int nfc = (l->only_kernel >= 0 || (l->only_chain == 2 && !fc_in_chain) || head_chain) ? nfc_expect : 0, n3 = l->only_kernel >= 0 ? n3_expect : 0, n2 = l->only_kernel >= 0 ? n2_expect : 0;
+      if (l->only_chain != 2 && !fc_in_chain && !head_chain)
       STEP(K_FC4_BX, dra_fc_bwd_fused_sq(l->dq, l->h4, l->dh4, l->y3[0], P + o[P_W4], G + o[P_WH], G + o[P_BH], G + o[P_W4],
                                          G + o[P_B4], l->dy3, B, NO, 3136, DRA_ACT_RELU, var, l->partials, &nfc,
                                          c.head_kind != DRA_HEAD_VANILLA ? l->action_[l->gb] : nullptr, c.n_atoms, s));

@@ -139,11 +139,15 @@ struct HeadWgradRole {
   // are skipped -- each skipped term is +0 * h4, so the result is the dense sum's bit for bit -- a quarter of the reads at 4 actions.
   const int64_t* action = nullptr;
   int group = 0;
-  __device__ __forceinline__ void run(int bid, float* lds, int = 0) const {
+  ChainHook hook;     // DRA_VAR_HEAD_CHAIN (run_<true>: dq / h4 come from the head role of the SAME launch)
+  __device__ __forceinline__ void run(int bid, float* lds, int = 0) const { run_<false>(bid, lds); }
+  template <bool CIN>
+  __device__ __forceinline__ void run_(int bid, float* lds) const {
     const int a = bid >> 1, k = (bid & 1) * 256 + threadIdx.x;
     float acc = 0.f, accb = 0.f;
     int b = 0;
-    if (action) {
+    if constexpr (CIN) mega_wait(hook.sync(0));
+    if (!CIN && action) {
       // the matching samples of 64 at a time as a wave-uniform bit mask; up to eight of them per round, their loads in flight
       // together (a scalar loop with a branch per sample was SLOWER than the dense sum: one memory latency per match)
       const int64_t mine = a / group;
@@ -175,13 +179,13 @@ struct HeadWgradRole {
     for (; b + 8 <= B; b += 8) {
       float d[8], h[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { d[i] = dq[(int64_t)(b + i) * A + a]; h[i] = h4[(int64_t)(b + i) * 512 + k]; }
+      for (int i = 0; i < 8; ++i) { d[i] = mega_ld<CIN>(dq + (int64_t)(b + i) * A + a); h[i] = mega_ld<CIN>(h4 + (int64_t)(b + i) * 512 + k); }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { acc += d[i] * h[i]; accb += d[i]; }
     }
     for (; b < B; ++b) {
-      const float d = dq[(int64_t)b * A + a];
-      acc += d * h4[(int64_t)b * 512 + k];
+      const float d = mega_ld<CIN>(dq + (int64_t)b * A + a);
+      acc += d * mega_ld<CIN>(h4 + (int64_t)b * 512 + k);
       accb += d;
     }
     dwh[a * 512 + k] = acc;
@@ -275,7 +279,9 @@ struct LinDgradOne {
   int B, I, act, tiles_n;
   ChainHook hook;     // DRA_VAR_BWD_CHAIN_FC (run_<true>: dx goes to workgroups of the SAME launch -- conv3's backward roles)
   __device__ __forceinline__ void run(int bid, float* __restrict__ lds, int = 0) const { run_<false>(bid, lds); }
-  template <bool COUT>
+  // CIN (DRA_VAR_HEAD_CHAIN): dy comes from the head role of the SAME launch -- the weights and the activation-derivative source
+  // are requested first, then the wait, then agent-scope loads of dy
+  template <bool COUT, bool CIN = false>
   __device__ __forceinline__ void run_(int bid, float* __restrict__ lds) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int bm = bid / tiles_n, bn = bid - bm * tiles_n;
@@ -290,10 +296,12 @@ struct LinDgradOne {
       for (int j = 0; j < NJ; ++j) breg[j] = wp[(int64_t)j * I];
     }
     float araw[RA];
+    if constexpr (!CIN) {
 #pragma unroll
-    for (int q = 0; q < RA; ++q) {
-      const int e = tid + 256 * q, row = e / O, col = e - row * O;
-      araw[q] = dy[(int64_t)min(m0 + row, B - 1) * O + col];
+      for (int q = 0; q < RA; ++q) {
+        const int e = tid + 256 * q, row = e / O, col = e - row * O;
+        araw[q] = dy[(int64_t)min(m0 + row, B - 1) * O + col];
+      }
     }
     float aux[4];
     {
@@ -305,6 +313,14 @@ struct LinDgradOne {
       }
     }
     __builtin_amdgcn_sched_barrier(0);  // every load above is issued before the first LDS write below
+    if constexpr (CIN) {
+      mega_wait(hook.sync(0));
+#pragma unroll
+      for (int q = 0; q < RA; ++q) {
+        const int e = tid + 256 * q, row = e / O, col = e - row * O;
+        araw[q] = mega_ld<true>(dy + (int64_t)min(m0 + row, B - 1) * O + col);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < RA; ++q) {
       const int e = tid + 256 * q, row = e / O, col = e - row * O;

@@ -339,8 +339,11 @@ struct LinWgradOne {
   float* db;         // [O] or null
   double* partials;  // [blocks()] or null
   int B, O, I, tiles_o, groups_i;
+  ChainHook hook;     // DRA_VAR_HEAD_CHAIN (run_<true>: dy comes from the head role of the SAME launch; x is requested before the wait)
   __host__ int blocks() const { return tiles_o * groups_i; }
-  __device__ __forceinline__ void run(int bid, float* __restrict__ lds, int = 0) const {
+  __device__ __forceinline__ void run(int bid, float* __restrict__ lds, int = 0) const { run_<false>(bid, lds); }
+  template <bool CIN>
+  __device__ __forceinline__ void run_(int bid, float* __restrict__ lds) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, h = lane >> 5;
     const int gi = bid % groups_i, to = bid / groups_i;
     const int o0 = to * 32;
@@ -348,8 +351,10 @@ struct LinWgradOne {
     // A: dy[2j + h][o0 + li]; rows >= B contribute zeros
     float areg[16];
     const int oc = min(o0 + li, O - 1);
+    if constexpr (!CIN) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) areg[j] = dy[(int64_t)min(2 * j + h, B - 1) * O + oc];
+      for (int j = 0; j < 16; ++j) areg[j] = dy[(int64_t)min(2 * j + h, B - 1) * O + oc];
+    }
     float breg[TPW][16];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -359,6 +364,11 @@ struct LinWgradOne {
       for (int j = 0; j < 16; ++j) breg[t][j] = x[(int64_t)min(2 * j + h, B - 1) * I + ic];
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (CIN) {
+      mega_wait(hook.sync(0));
+#pragma unroll
+      for (int j = 0; j < 16; ++j) areg[j] = mega_ld<true>(dy + (int64_t)min(2 * j + h, B - 1) * O + oc);
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j)
       if (2 * j + h >= B) areg[j] = 0.f;

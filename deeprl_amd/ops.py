@@ -457,7 +457,8 @@ VAR_FLAG_SYNC = 134217728     # the steady-state pipelined step without events (
 VAR_LANE_EAGER = 268435456    # ... and the update as plain launches instead of a graph replay
 VAR_TARGET_AHEAD = 536870912  # target(next_states) of update t + 1 issued one call early, under update t (needs the next indices)
 VAR_BWD_CHAIN_FC = 1073741824 # fc4's + the head's backward as leading roles of the chained backward launch
-VAR_ALL = 2097151 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456 | 536870912 | 1073741824
+VAR_HEAD_CHAIN = 65536        # head launch + fc4's / the head's backward launch as one launch in dependency order
+VAR_ALL = 2097151 | 8388608 | 16777216 | 33554432 | 67108864 | 134217728 | 268435456 | 536870912 | 1073741824 | 65536
 
 
 def set_tuning(mask):

@@ -360,6 +360,10 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
                                     * and LDS footprint is the maximum over its roles -- fc4's input gradient (152 + 32 registers,
                                     * 65.7 KB of LDS) takes the whole launch from three workgroups per CU to two.
                                     * DQN_agent.py:129-134 */
+#define DRA_VAR_HEAD_CHAIN 65536 /* learner (with FWD_CHAIN, VanillaNet head, uniform replay, batch <= 32): the head launch (fc4 fold, head,
+                                    * TD error, dq, dh4) and fc4's + the head's backward launch as ONE launch in dependency order: the
+                                    * backward roles request fc4's weights / conv3's activations first, then wait for the head role's
+                                    * workgroups on one arrival counter.  Same arithmetic: bit-identical.  DQN_agent.py:85-99,131 */
 #define DRA_VAR_CU_PARTITION 256 /* host: actor stream and update stream own disjoint CU sets (dra_stream_create_masked) */
 #define DRA_VAR_PIPE_GATHER 128  /* learner, async: gather on the actor stream into a double-buffered minibatch,
                                     body + optimizer as one graph -- no cross-stream wait on either chain */

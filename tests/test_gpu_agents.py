@@ -1534,6 +1534,50 @@ def test_target_ahead_is_bit_identical(dra):
     assert float(np.abs(outs[0]["q"]).max()) > 0
 
 
+def test_head_chain_is_bit_identical(dra):
+    """DRA_VAR_HEAD_CHAIN (round 6): the head launch (fc4 fold, head, TD error, dq, dh4: DQN_agent.py:85-99) and fc4's + the head's
+    backward launch as ONE launch in dependency order -- the backward roles request fc4's weights and conv3's activations first,
+    then wait on one arrival counter (zeroed by the next update's forward chain) for the head role's workgroups.  Same arithmetic
+    in the same order: the benchmarked pipeline with the bit set and cleared ends on identical parameters, optimizer state, target
+    network and ring contents -- across synchronise() calls, a target sync, kernel replays (which run the two launches on their own)
+    and chain replays in the middle."""
+    d = dra
+    from deeprl_amd import ops
+    from deeprl_amd.learner import DQNLearnerBench
+    default = ops.get_tuning()
+    outs = []
+    for variant, interrupt in ((default & ~ops.VAR_HEAD_CHAIN, False), (default | ops.VAR_HEAD_CHAIN, False),
+                               (default | ops.VAR_HEAD_CHAIN, True)):
+        np.random.seed(51)
+        torch.manual_seed(52)
+        b = DQNLearnerBench(ring_capacity=4096, batch=32, seed=53, actor=True, async_actor=True, variant=variant)
+        L = b.learner
+        for t in range(60):
+            b.step()
+            if t == 27:
+                L.sync_target()
+            if interrupt and t in (5, 6, 39):
+                L.synchronize()
+            if interrupt and t == 11:
+                L.kernel_replay("head_loss", 4)
+                L.kernel_replay("fc4_bwd_x", 4)
+            if interrupt and t == 33:
+                L.chain_replay("bwd", 4)
+                L.chain_replay("fwd", 4)
+        L.synchronize()
+        frames = d.ops._wrap_device_pointer(b.ring.pointers()[0], 300 * 7056, torch.uint8).cpu().numpy().copy()
+        acts = d.ops._wrap_device_pointer(b.ring.pointers()[1], 300, torch.int64).cpu().numpy().copy()
+        outs.append(dict(p=L.flat.flat.detach().cpu().numpy().copy(), s1=L.state1.detach().cpu().numpy().copy(),
+                         s2=L.state2.detach().cpu().numpy().copy(), pt=L.target_flat.flat.detach().cpu().numpy().copy(),
+                         frames=frames, acts=acts, q=L.q.detach().cpu().numpy().copy(), delta=L.delta.detach().cpu().numpy().copy()))
+        L.close()
+        b.ring.close()
+    for k in outs[0]:
+        for i in (1, 2):
+            assert np.array_equal(outs[0][k], outs[i][k]), ("head + fc4 backward as one launch vs two", i, k)
+    assert float(np.abs(outs[0]["p"]).max()) > 0 and float(np.abs(outs[0]["delta"]).max()) > 0
+
+
 def test_persistent_actor_is_bit_identical(dra):
     """DRA_VAR_ACTOR_PERSIST (round 6): the whole agent step of the device actor -- n_env x [forward, epsilon-greedy, env.step]
     (DQN_agent.py:24-45) -- as ONE launch of 32 co-resident workgroups whose activations cross workgroups as {value, tag} words.
