@@ -10,6 +10,7 @@
 //   DRA_VAR_ONESHOT_WGRAD  one-pass conv weight gradients (ConvWgradOne / ConvWgradLin): one slab per (sample, row
 //                          chunk) -- dra_conv_wgrad_slabs() slabs instead of `ksplit`.
 #include "oneshot_lin.h"
+#include "dgrad_scatter.h"
 #include "actor_env.h"
 #include "per_chain2.h"
 #include <stdlib.h>
@@ -67,6 +68,11 @@ using WG2p = ConvWgradPers<G2, 8, 128, 1>;   // 2 k groups x 128 shares = 256 wo
 using WG3p = ConvWgradPers<G3, 6, 85, 2>;    // 3 k groups x 85 shares = 255 workgroups (one per CU: 288 left 32 CUs with two); 2 x 75 MFMAs per wave and iteration
 // from which batch on: conv3 from 128 (its persistent role shares the launch with the input gradient); conv2 from 768 (two launches:
 // at 256 / 512 the one-sample form, one launch, is as fast or faster: 46 vs 49 us, 86 vs 89 us)
+// DRA_VAR_DGRAD_SCATTER: samples per workgroup of the scatter-form input gradient (conv3: 2 x 49 positions = 7 tiles of 16, a
+// 41.5 KB image; conv2: 81 positions = 6 tiles, 51.3 KB)
+constexpr int kScatterFromBatch = 256;      // (at 128 samples the gather form's 512 / 1024 small workgroups win: 22.6 vs 24.5 / 25.8 vs 31.3 us, profiles/r06zzk)
+template <class G> struct ScatSamples { static constexpr int NS = 1; };
+template <> struct ScatSamples<G3> { static constexpr int NS = 2; };
 template <class G> struct PersistFrom { static constexpr int batch = 768; static constexpr bool one_launch = false; };
 template <> struct PersistFrom<G3> { static constexpr int batch = 128; static constexpr bool one_launch = true; };
 
@@ -125,6 +131,34 @@ static IgemmRole<ConvDgradKoc<G, 32, 32, 64>> make_dgrad_igemm(const float* dy, 
 template <class R>
 static int igemm_blocks(const R& r, int nz) { return r.tiles * r.ksplit * nz; }
 
+// DRA_VAR_DGRAD_SCATTER: weight gradient (persistent form from PersistFrom<G>::batch on, else one sample per workgroup) + the
+// scatter-form input gradient with NS samples per workgroup; one launch with DRA_VAR_FUSED_BWD, else two
+template <class G, class WOne, class WPers, int NS>
+static int conv_bwd_scatter_t(const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
+                              int64_t slab_stride, float* dx, int batch, int act, int variant, hipStream_t st) {
+  NoRole none;
+  using RS = ConvDgradScat<G, NS>;
+  RS rs;
+  rs.dy = dy; rs.wt = wt; rs.xact = xact; rs.dx = dx; rs.B = batch; rs.act = act;
+  const bool only_d = variant & DRA_VAR_MEASURE_DGRAD_ONLY, only_w = variant & DRA_VAR_MEASURE_WGRAD_ONLY;
+  if (batch >= PersistFrom<G>::batch) {
+    WPers rp;
+    rp.dy = dy; rp.x = x; rp.dw = dw; rp.db = db; rp.slab_stride = slab_stride; rp.B = batch;
+    if (only_d) return launch_multi(rs, rs.blocks(), none, 0, none, 0, st);
+    if (only_w) return launch_multi(rp, rp.blocks(), none, 0, none, 0, st);
+    // (conv2: the two roles together need more than 256 registers -- one wave per SIMD -- so they stay two launches)
+    if ((variant & DRA_VAR_FUSED_BWD) && PersistFrom<G>::one_launch) return launch_multi(rp, rp.blocks(), rs, rs.blocks(), none, 0, st);
+    if (int rc = launch_multi(rp, rp.blocks(), none, 0, none, 0, st)) return rc;
+    return launch_multi(rs, rs.blocks(), none, 0, none, 0, st);
+  }
+  auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
+  if (only_d) return launch_multi(rs, rs.blocks(), none, 0, none, 0, st);
+  if (only_w) return launch_multi_tp(rw, rw.blocks(), none, 0, none, 0, st);
+  if (variant & DRA_VAR_FUSED_BWD) return launch_multi(rs, rs.blocks(), rw, rw.blocks(), none, 0, st);
+  if (int rc = launch_multi_tp(rw, rw.blocks(), none, 0, none, 0, st)) return rc;
+  return launch_multi(rs, rs.blocks(), none, 0, none, 0, st);
+}
+
 // layers 2 / 3: weight gradient + input gradient in one launch
 template <class G, class WOne, class WPers = WOne, class R3 = NoRole>
 static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, const float* xact, float* dw, float* db,
@@ -134,6 +168,14 @@ static int conv_bwd_fused_t(const float* dy, const void* x, const float* wt, con
   if (n3 > 0 && !(od && ow)) return DRA_EINVAL;   // a riding role exists for the one-pass pair only
   if (od && ow) {
     if constexpr (!std::is_same<WPers, WOne>::value) {
+      // DRA_VAR_DGRAD_SCATTER (round 6, dgrad_scatter.h): the input gradient contracted over the output positions
+      if ((variant & DRA_VAR_DGRAD_SCATTER) && batch >= kScatterFromBatch && n3 == 0) {
+        // (conv3 below 512 samples: one sample per workgroup -- 64 / 49 padding, but twice the workgroups)
+        if constexpr (ScatSamples<G>::NS > 1) {
+          if (batch < 512) return conv_bwd_scatter_t<G, WOne, WPers, 1>(dy, x, wt, xact, dw, db, slab_stride, dx, batch, act, variant, st);
+        }
+        return conv_bwd_scatter_t<G, WOne, WPers, ScatSamples<G>::NS>(dy, x, wt, xact, dw, db, slab_stride, dx, batch, act, variant, st);
+      }
       if (batch >= PersistFrom<G>::batch && n3 == 0) {
         WPers rp;
         rp.dy = dy; rp.x = x; rp.dw = dw; rp.db = db; rp.slab_stride = slab_stride; rp.B = batch;

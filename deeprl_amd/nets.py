@@ -427,7 +427,9 @@ class _ConvKocFn(torch.autograd.Function):
         oc, c, kh, kw = w.shape
         n_w = w.numel()
         # per-(sample, row chunk) slabs pay off at DQN batch sizes; large batches use the fixed split-K weight gradient
-        variant = (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD | ops.VAR_ONESHOT_WGRAD) if x.shape[0] <= _ONESHOT_WGRAD_MAX_BATCH else \
+        # (VAR_DGRAD_SCATTER acts from 256 samples on: conv2 / conv3 input gradient contracted over the output positions --
+        # 46.8 -> 42.8 / 38.7 -> 30.5 us per layer at PPO's minibatch of 256, profiles/r06zzk_ab_dgrad_scatter.jsonl)
+        variant = (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD | ops.VAR_ONESHOT_WGRAD | ops.VAR_DGRAD_SCATTER) if x.shape[0] <= _ONESHOT_WGRAD_MAX_BATCH else \
             (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD)
         # layers 2 / 3: the input is the layer below's fused-ReLU output (NatureConvBody) -- the input-gradient epilogue masks
         mask_below = layer > 1 and ctx.needs_input_grad[0] and getattr(ctx, "x_relu", False)

@@ -447,6 +447,7 @@ VAR_ACTOR_FUSED_CONV1 = 8192
 VAR_GATHER_ON_UPDATE = 16384
 VAR_RING_DIRECT = 32768
 VAR_IDX_PREFETCH = 131072
+VAR_DGRAD_SCATTER = 262144    # conv2 / conv3 input gradient at batch >= 256 in scatter (col2im) form
 VAR_LATE_FOLD = 524288
 VAR_ACTOR_MEGA = 1048576
 VAR_DEFER_FC4 = 8388608       # fc4's segment of the optimizer step rides in the next update's forward launches

@@ -300,8 +300,12 @@ int dra_atari_preprocess(const uint8_t* raw, int n_env, int height, int width, i
 #define DRA_VAR_IDX_PREFETCH 131072 /* learner (with RING_DIRECT): a step-tagged copy of the minibatch indices goes to the device by
                                     * an unordered async copy when the step is enqueued; conv1 takes an element from there when
                                     * its tag is this update's (no PCIe read in front of its frame loads), else from pinned memory */
-/* (bit 262144 was DRA_VAR_WGRAD_ACC, a conv weight gradient that accumulated four samples per workgroup to write a quarter of
- * the slabs: slower than one slab per sample on every layer once the staging was cheap, removed in round 4; the bit is ignored) */
+#define DRA_VAR_DGRAD_SCATTER 262144 /* dra_conv_bwd_fused, layers 2 / 3, batch >= 256 (with ONESHOT_DGRAD + ONESHOT_WGRAD): the
+                                    * input gradient in scatter form -- the contraction runs over the OUTPUT positions (no padded
+                                    * (pixel, tap) columns: conv3 1.96x -> 1.14x, conv2 1.58x -> 1.19x issued MFMAs), col2im
+                                    * by in-order read-add-write into an LDS image of dX; deterministic (csrc/dgrad_scatter.h).  Below 256 samples
+                                    * the bit is ignored.  (Until round 4 this bit was DRA_VAR_WGRAD_ACC, a removed experiment.)
+                                    * network_bodies.py:10-33 */
 #define DRA_VAR_LATE_FOLD 524288  /* learner (with ONESHOT_WGRAD + FUSED_BWD): no gradient-norm launch -- sums of squares come
                                    * from the kernels that write each gradient, conv3 / conv2 slabs are folded by spare
                                    * workgroups of the NEXT layer's backward launch, conv1's by the first workgroups of the

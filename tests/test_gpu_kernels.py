@@ -700,6 +700,41 @@ def test_conv_autograd_function_at_rollout_batches(dev, layer, batch):
         _scale_close(x_dev.grad.cpu().numpy(), xt.grad.numpy())
 
 
+@pytest.mark.parametrize("layer", [2, 3])
+@pytest.mark.parametrize("batch", [256, 259, 511, 600, 1024])
+def test_conv_input_gradient_scatter_form(dev, layer, batch):
+    """DRA_VAR_DGRAD_SCATTER (csrc/dgrad_scatter.h, round 6): conv2 / conv3 input gradient contracted over the OUTPUT positions
+    (v_mfma_f32_16x16x4_f32 per tap, col2im by in-order read-add-write into an LDS image of dX) -- against F.conv2d's input
+    gradient in float64 at 1e-5 of the tensor's scale, with and without the activation mask; bit-identical on a second run (no
+    atomics: every dX element is summed in a fixed order); the weight-gradient slabs of the same call are the gather variant's
+    bit for bit (same role); one launch and two.  Batches: the first one the form applies to (PPO's minibatch), an odd one, one either
+    side of conv3's samples-per-workgroup switch at 512 (600: even; 1024; 511: odd, one sample per workgroup).  network_bodies.py:10-33."""
+    import torch.nn.functional as F
+    from deeprl_amd import ops
+    c, h, oc, k, s = CONV[layer]
+    rs = np.random.RandomState(31 * layer + batch)
+    w = (rs.standard_normal((oc, c, k, k)) / np.sqrt(c * k * k)).astype(np.float32)
+    x = np.maximum(rs.standard_normal((batch, c, h, h)), 0).astype(np.float32)
+    oh = (h - k) // s + 1
+    dy = rs.standard_normal((batch, oc, oh, oh)).astype(np.float32)
+    xt = t64(x)
+    F.conv2d(xt, t64(w, False), None, stride=s).backward(t64(dy, False))
+    ref = xt.grad.numpy()
+    wt_dev, x_dev, dy_dev = ops.to_koc(f32(w, dev)), f32(x, dev), f32(dy, dev)
+    base = ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD | ops.VAR_ONESHOT_WGRAD
+    dw_g, db_g, dx_g, _ = ops.conv_bwd_fused(layer, dy_dev, x_dev, wt=wt_dev, xact=x_dev, ksplit=16, variant=base)
+    for var in (base | ops.VAR_DGRAD_SCATTER, (base | ops.VAR_DGRAD_SCATTER) & ~ops.VAR_FUSED_BWD):
+        dw_s, db_s, dx_s, _ = ops.conv_bwd_fused(layer, dy_dev, x_dev, wt=wt_dev, xact=x_dev, ksplit=16, variant=var)
+        assert not torch.isnan(dx_s).any()          # every element is written
+        _scale_close(dx_s.cpu().numpy(), ref * (x > 0))
+        assert torch.equal(dw_s, dw_g) and torch.equal(db_s, db_g)
+        again = ops.conv_bwd_fused(layer, dy_dev, x_dev, wt=wt_dev, xact=x_dev, ksplit=16, variant=var)[2]
+        assert torch.equal(again, dx_s)
+    plain = ops.conv_bwd_fused(layer, dy_dev, x_dev, wt=wt_dev, xact=None, ksplit=16, variant=base | ops.VAR_DGRAD_SCATTER)[2]
+    _scale_close(plain.cpu().numpy(), ref)
+    _scale_close(dx_g.cpu().numpy(), ref * (x > 0))
+
+
 @pytest.mark.parametrize("layer", [1, 2, 3])
 def test_conv_koc_fwd_throughput_shape(dev, layer):
     """conv_v2.hip picks the multi-tile (throughput) workgroup shape from batch 128 up: same arithmetic per
