@@ -36,7 +36,10 @@ def main():
         dy = torch.randn(B, oc, oh, oh, device=dev)
         coef = 1.0 / 255 if layer == 1 else None
         one = B <= nets._ONESHOT_WGRAD_MAX_BATCH
-        variant = (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD | (ops.VAR_ONESHOT_WGRAD if one else 0))
+        # (the variant nets._ConvKocFn.backward passes: from round 6 on with the scatter-form input gradient, which acts from 256 samples;
+        # DRA_CONV_BIG_GATHER=1 measures the gather form instead)
+        scatter = 0 if os.environ.get("DRA_CONV_BIG_GATHER") else ops.VAR_DGRAD_SCATTER
+        variant = (ops.VAR_FUSED_BWD | ops.VAR_ONESHOT_DGRAD | ((ops.VAR_ONESHOT_WGRAD | scatter) if one else 0))
         calls = {"fwd": lambda: ops.conv_fwd_koc(layer, [x], [wt], [bb], u8_coef=coef),
                  "bwd": lambda: ops.conv_bwd_fused_koc(layer, dy, x, wt.view(c, kh, kh, oc), ksplit=16, u8_coef=coef, variant=variant)}
         fl_pass = 2.0 * B * oh * oh * oc * c * kh * kh
@@ -62,7 +65,7 @@ def main():
                 best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
             out["conv%d_%s" % (layer, name)] = {"us": round(best, 1), "flops": flops[name],
                                                 "frac_of_157.3_TFLOPs": round(flops[name] / best / 1e6 / 157.3, 3)}
-    print(json.dumps({"batch": B, "oneshot_wgrad": B <= nets._ONESHOT_WGRAD_MAX_BATCH, "timing": "HIP events, best of 3 x %d calls" % reps,
+    print(json.dumps({"batch": B, "oneshot_wgrad": B <= nets._ONESHOT_WGRAD_MAX_BATCH, "dgrad_scatter": not os.environ.get("DRA_CONV_BIG_GATHER"), "timing": "HIP events, best of 3 x %d calls" % reps,
                       "kernels": out}))
 
 

@@ -25,7 +25,7 @@ def main():
     for f in glob.glob(sys.argv[3] + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             pmc.setdefault(r["Kernel_Name"], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    out = {"batch": ev["batch"], "oneshot_wgrad": ev["oneshot_wgrad"], "kernels": {}}
+    out = {"batch": ev["batch"], "oneshot_wgrad": ev["oneshot_wgrad"], "dgrad_scatter": ev.get("dgrad_scatter", False), "kernels": {}}
     for key, e in ev["kernels"].items():
         layer, kind = int(key[4]), key.split("_")[1]
         pats = GEOM[layer].split("|")
@@ -53,7 +53,9 @@ def main():
                 mf = sum(sum(pmc.get(r[0], {}).get("SQ_INSTS_MFMA", [0])) / max(1, len(pmc.get(r[0], {}).get("SQ_INSTS_MFMA", [1]))) for r in ks)
                 if mf:
                     rec["valu_per_mfma"] = round(valu / mf, 2)
-                    rec["issued_mfma_flop_frac"] = round(mf * 4096 * 2 / 2 / max(e["flops"], 1), 3)   # 32x32x2 MFMA = 4096 FLOP
+                # issued MFMA FLOP / algorithmic FLOP: the fp32 MFMAs run 64 FLOP per busy cycle whatever their shape (32x32x2: 4096 in
+                # 64 cycles, 16x16x4: 2048 in 32 -- the scatter-form input gradient of round 6 uses the latter)
+                rec["issued_mfma_flop_frac"] = round(busy * 64 / max(e["flops"], 1), 3)
         out["kernels"][key] = rec
     print(json.dumps(out))
 
