@@ -37,7 +37,9 @@
 typedef float scat_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) float scat_lds_float;
 
-template <class G, int NS>
+// LOOP: the workgroup takes several groups of NS samples (`cap` workgroups in all) with its weights fetched once -- for a launch the
+// role has to itself; the registers the loop keeps alive across the epilogue (~30) would cost the shared launches their second wave.
+template <class G, int NS, bool LOOP = false>
 struct ConvDgradScat {
   static constexpr int S = G::S, OH = G::OH, P = G::P, H = G::H, HW = G::HW, OC = G::OC, C = G::C, KH = G::KH;
   static constexpr int NCB = C / 16;           // 16-channel blocks
@@ -63,11 +65,15 @@ struct ConvDgradScat {
   const float* xact;  // [B][C][H][H] this layer's input (post-activation) or null
   float* dx;          // [B][C][H][H]
   int B, act;
-  __host__ int blocks() const { return (B + NS - 1) / NS; }
+  int cap = 0;        // > 0: at most `cap` workgroups, each looping over groups of NS samples (weights fetched once per workgroup);
+                      // set when the role has a launch to itself (two workgroups per CU fit: 512)
+  __host__ int groups() const { return (B + NS - 1) / NS; }
+  __host__ int blocks() const { return LOOP && cap > 0 && groups() > cap ? cap : groups(); }
   __device__ __forceinline__ void run(int bid, float* __restrict__ lds, int = 0) const {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kq = lane >> 4;
     const int cb = wave % NCB, ps = wave / NCB;
-    const int b0 = bid * NS, ns = min(NS, B - b0), nq = ns * P;
+    const int n_groups = (B + NS - 1) / NS, n_wg = LOOP && cap > 0 && n_groups > cap ? cap : n_groups;
+    int b0 = bid * NS, ns = min(NS, B - b0), nq = ns * P;
     [[maybe_unused]] constexpr int TRR = (G::C == 32) ? TR_CONV2_B : TR_CONV3_B;
     DRA_STAMP(TRR, 0);
     // ---- weights: A row m <-> channel 16 cb + (m >> 2) + 4 (m & 3), so that output register r of lane group kq is channel
@@ -85,8 +91,8 @@ struct ConvDgradScat {
         wraw[khi][i] = *reinterpret_cast<const scat_f4*>(wt + ((int64_t)(16 * cb + ci) * G::KK + (ps + NPS * khi) * KH) * OC + 4 * col);
       }
     const float* dyb = dy + (int64_t)b0 * OC * P;
-    int boff, aoff;
-    bool ok;
+    int boff = 0, aoff = 0;
+    bool ok = false;
     auto place = [&](int tile) {     // this lane's output position of `tile`: gradient offset, image offset
       int q = tile * 16 + n;
       ok = q < nq;
@@ -120,7 +126,16 @@ struct ConvDgradScat {
           }
       }
     }
-    __syncthreads();       // (the image overlaps every wave's staging region)
+    int grp = bid;
+    do {
+    if (LOOP && grp != bid) {      // (a later group of this workgroup: the first one's operands were requested in front of the weights)
+      b0 = grp * NS; ns = min(NS, B - b0); nq = ns * P;
+      dyb = dy + (int64_t)b0 * OC * P;
+      place(0);
+#pragma unroll
+      for (int j = 0; j < KST; ++j) bnext[j] = dyb[boff + (16 * (j >> 2) + (j & 3)) * P];
+    }
+    __syncthreads();       // (the image overlaps every wave's staging region; later groups: the epilogue has read the image)
     // ---- the image starts at zero
     {
       scat_f4* l4 = reinterpret_cast<scat_f4*>(lds);
@@ -234,6 +249,7 @@ struct ConvDgradScat {
         dx4[e4] = v;
       }
     }
+    } while (LOOP && (grp += n_wg) < n_groups);      // (groups of this workgroup)
     DRA_STAMP_END(TRR);
   }
 };

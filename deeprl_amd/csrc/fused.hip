@@ -140,23 +140,26 @@ static int conv_bwd_scatter_t(const float* dy, const void* x, const float* wt, c
   using RS = ConvDgradScat<G, NS>;
   RS rs;
   rs.dy = dy; rs.wt = wt; rs.xact = xact; rs.dx = dx; rs.B = batch; rs.act = act;
+  ConvDgradScat<G, NS, true> alone;      // a launch to itself: two workgroups per CU, each looping over its groups with the weights in registers
+  alone.dy = dy; alone.wt = wt; alone.xact = xact; alone.dx = dx; alone.B = batch; alone.act = act;
+  alone.cap = 512;
   const bool only_d = variant & DRA_VAR_MEASURE_DGRAD_ONLY, only_w = variant & DRA_VAR_MEASURE_WGRAD_ONLY;
   if (batch >= PersistFrom<G>::batch) {
     WPers rp;
     rp.dy = dy; rp.x = x; rp.dw = dw; rp.db = db; rp.slab_stride = slab_stride; rp.B = batch;
-    if (only_d) return launch_multi(rs, rs.blocks(), none, 0, none, 0, st);
+    if (only_d) return launch_multi(alone, alone.blocks(), none, 0, none, 0, st);
     if (only_w) return launch_multi(rp, rp.blocks(), none, 0, none, 0, st);
     // (conv2: the two roles together need more than 256 registers -- one wave per SIMD -- so they stay two launches)
     if ((variant & DRA_VAR_FUSED_BWD) && PersistFrom<G>::one_launch) return launch_multi(rp, rp.blocks(), rs, rs.blocks(), none, 0, st);
     if (int rc = launch_multi(rp, rp.blocks(), none, 0, none, 0, st)) return rc;
-    return launch_multi(rs, rs.blocks(), none, 0, none, 0, st);
+    return launch_multi(alone, alone.blocks(), none, 0, none, 0, st);
   }
   auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
-  if (only_d) return launch_multi(rs, rs.blocks(), none, 0, none, 0, st);
+  if (only_d) return launch_multi(alone, alone.blocks(), none, 0, none, 0, st);
   if (only_w) return launch_multi_tp(rw, rw.blocks(), none, 0, none, 0, st);
   if (variant & DRA_VAR_FUSED_BWD) return launch_multi(rs, rs.blocks(), rw, rw.blocks(), none, 0, st);
   if (int rc = launch_multi_tp(rw, rw.blocks(), none, 0, none, 0, st)) return rc;
-  return launch_multi(rs, rs.blocks(), none, 0, none, 0, st);
+  return launch_multi(alone, alone.blocks(), none, 0, none, 0, st);
 }
 
 // layers 2 / 3: weight gradient + input gradient in one launch

@@ -701,14 +701,15 @@ def test_conv_autograd_function_at_rollout_batches(dev, layer, batch):
 
 
 @pytest.mark.parametrize("layer", [2, 3])
-@pytest.mark.parametrize("batch", [256, 259, 511, 600, 1024])
+@pytest.mark.parametrize("batch", [256, 259, 511, 513, 600, 1024])
 def test_conv_input_gradient_scatter_form(dev, layer, batch):
     """DRA_VAR_DGRAD_SCATTER (csrc/dgrad_scatter.h, round 6): conv2 / conv3 input gradient contracted over the OUTPUT positions
     (v_mfma_f32_16x16x4_f32 per tap, col2im by in-order read-add-write into an LDS image of dX) -- against F.conv2d's input
     gradient in float64 at 1e-5 of the tensor's scale, with and without the activation mask; bit-identical on a second run (no
     atomics: every dX element is summed in a fixed order); the weight-gradient slabs of the same call are the gather variant's
     bit for bit (same role); one launch and two.  Batches: the first one the form applies to (PPO's minibatch), an odd one, one either
-    side of conv3's samples-per-workgroup switch at 512 (600: even; 1024; 511: odd, one sample per workgroup).  network_bodies.py:10-33."""
+    side of conv3's samples-per-workgroup switch at 512 (511: one sample per workgroup; 513: two, the last workgroup with one;
+    600; 1024).  network_bodies.py:10-33."""
     import torch.nn.functional as F
     from deeprl_amd import ops
     c, h, oc, k, s = CONV[layer]
