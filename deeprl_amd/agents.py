@@ -1044,7 +1044,13 @@ class _PixelRollout:
         dev = frames.device
         if self.bufs is None or self.bufs['n'] != n or self.bufs['rows'] < rows:
             f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-            self.bufs = dict(n=n, rows=rows, y1=f(n, 32, 20, 20), y2=f(n, 64, 9, 9), y3=f(n, 64, 7, 7), slabs=f(28, n, 512))
+            # (the activations of every step are kept: A2C's update backpropagates through them, as the reference does through the
+            # rollout's own forward graph -- config.reuse_rollout_activations)
+            self.bufs = dict(n=n, rows=rows, y1=f(rows, n, 32, 20, 20), y2=f(rows, n, 64, 9, 9), y3=f(rows, n, 64, 7, 7), slabs=f(28, n, 512))
+            one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+            # (per-step pointer arguments built once: the rollout loop of PPO's 129 steps is host-side eager code)
+            self.bufs['args'] = [(ctypes.c_void_p(self.bufs['y1'][t].data_ptr()), one(self.bufs['y1'][t]), one(self.bufs['y2'][t]),
+                                  one(self.bufs['y3'][t])) for t in range(rows)]
         b = self.bufs
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         arr = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
@@ -1053,13 +1059,14 @@ class _PixelRollout:
         wa, ba, wv, bv = net.fc_action.weight, net.fc_action.bias, net.fc_critic.weight, net.fc_critic.bias
         n_act = int(wa.shape[0])
         coef = float(body.conv1.u8_coef)
-        x2, wt2, b2, y2 = arr(b['y1']), arr(w2), arr(body.conv2.bias), arr(b['y2'])
-        wt3, b3, y3, w4 = arr(w3), arr(body.conv3.bias), arr(b['y3']), arr(body.fc4.weight)
+        wt2, b2 = arr(w2), arr(body.conv2.bias)
+        wt3, b3, w4 = arr(w3), arr(body.conv3.bias), arr(body.fc4.weight)
         b4, slabs = body.fc4.bias, b['slabs']
         for t in range(rows):
             prev = t > 0
+            y1p, x2, y2, y3 = b['args'][t]
             # fc4 of step t - 1 left its 28 K-slice partial sums: the head that rides in this launch folds them (bias, ReLU) first
-            lib.dra_rollout_conv1_heads(p(frames[t]), p(w1), p(body.conv1.bias), p(b['y1']), n, coef,
+            lib.dra_rollout_conv1_heads(p(frames[t]), p(w1), p(body.conv1.bias), y1p, n, coef,
                                         p(slabs) if prev else None, p(b4) if prev else None, p(wa), p(ba), p(wv), p(bv),
                                         p(slots.uniform[t - 1]) if prev else None, n_act,
                                         p(slots.action[t - 1]) if prev else None, p(slots.log_pi_a[t - 1]) if prev else None,
@@ -1281,6 +1288,15 @@ class A2CAgent(BaseAgent):
             self._pixel_rollout.run(frames, slots)     # three launches per rollout step (csrc/conv_v2.hip)
             self._rollout_step += t_len + 1
             n = self.task.num_envs
+            if getattr(config, 'reuse_rollout_activations', True):
+                # A2C_agent.py:29-64 backpropagates through the rollout's own forwards; so does this update: the conv layers of its
+                # one batched forward take the rollout's stored outputs (same inputs, same parameters) instead of recomputing them
+                # -- 31 us of a 315 us agent step at 16 x 5.  (The recomputed forward runs the four-wave kernel shape, the rollout
+                # the eight-wave one: the two differ in fp32 summation order, parameters agree to ~1e-6 per update, not bit for bit.)
+                acts, body = self._pixel_rollout.bufs, self.network.phi_body
+                for conv, key in ((body.conv1, 'y1'), (body.conv2, 'y2'), (body.conv3, 'y3')):
+                    y = acts[key][:t_len]
+                    conv._y_pre = y.reshape((t_len * n,) + tuple(y.shape[2:]))
             return self._learn_stacked(frames[:t_len].reshape((t_len * n,) + tuple(frames.shape[2:])),
                                        slots.action[:t_len].reshape(-1), slots.v[:t_len + 1].unsqueeze(-1), plan.reward,
                                        plan.mask, apply=apply)

@@ -409,9 +409,12 @@ class _ConvKocFn(torch.autograd.Function):
     KSPLIT = 16
 
     @staticmethod
-    def forward(ctx, x, w, b, layer, u8_coef, x_relu=False):
+    def forward(ctx, x, w, b, layer, u8_coef, x_relu=False, y_pre=None):
         wt = w.permute(1, 2, 3, 0)                      # the contiguous KOC storage
-        y = ops.conv_fwd_koc(layer, [x], [wt], [b], act="relu", u8_coef=u8_coef)[0]
+        # y_pre: this layer's output for exactly this input and these parameters, computed earlier under no_grad (the A2C rollout's
+        # forwards: the reference keeps the rollout's own forward graph, A2C_agent.py:29-64) -- no launch, the node only records
+        # what its backward needs
+        y = y_pre.view_as(y_pre) if y_pre is not None else ops.conv_fwd_koc(layer, [x], [wt], [b], act="relu", u8_coef=u8_coef)[0]
         ctx.save_for_backward(x, w, y)
         ctx.layer, ctx.u8_coef = layer, u8_coef
         ctx.params = (w, b)
@@ -444,7 +447,7 @@ class _ConvKocFn(torch.autograd.Function):
                   and gb.is_contiguous() and gb.data_ptr() == gw.data_ptr() + 4 * n_w and gw.data_ptr() % 16 == 0)
         _SHARED[0] = _SHARED[0] or not direct
         if direct and _DEFER[0] is not None and _DEFER[0].defer_fold(gw, stride, slabs, n_slabs):
-            return (dx if ctx.needs_input_grad[0] and layer > 1 else None), None, None, None, None, None
+            return (dx if ctx.needs_input_grad[0] and layer > 1 else None), None, None, None, None, None, None
         flat = torch.as_strided(gw, (stride,), (1,)) if direct else torch.empty(stride, dtype=torch.float32, device=w.device)
         if n_slabs > 32 and stride % 4 == 0:
             # one slab per (sample, row chunk): hundreds of slabs -- the segmented fold keeps 160 of them in flight per element
@@ -455,10 +458,10 @@ class _ConvKocFn(torch.autograd.Function):
             partials = torch.empty(ops.norm_partials(), dtype=torch.float64, device=w.device)
             ops.grad_sqnorm(flat, partials, slabs=slabs, n_slabs=n_slabs, slab_stride=stride)  # fixed-order slab fold
         if direct:
-            return (dx if ctx.needs_input_grad[0] and layer > 1 else None), None, None, None, None, None
+            return (dx if ctx.needs_input_grad[0] and layer > 1 else None), None, None, None, None, None, None
         dw = flat[:n_w].view(c, kh, kw, oc).permute(3, 0, 1, 2)
         db = flat[n_w:n_w + oc]
-        return (dx if ctx.needs_input_grad[0] and layer > 1 else None), dw, db, None, None, None
+        return (dx if ctx.needs_input_grad[0] and layer > 1 else None), dw, db, None, None, None, None
 
 
 class Linear(nn.Linear):
@@ -487,7 +490,11 @@ class Conv2d(nn.Conv2d):
         if x.dtype == torch.uint8 and u8_coef is None:
             raise TypeError("uint8 input to a convolution needs a normaliser (RescaleNormalizer marks it)")
         if self.weight.permute(1, 2, 3, 0).is_contiguous():     # KOC storage (FlatParams): one-round-trip kernels
-            return _ConvKocFn.apply(x.contiguous(), self.weight, self.bias, layer, u8_coef, getattr(self, "input_is_relu", False))
+            # (_y_pre: set by A2CAgent for ONE call -- the rollout's stored output of this layer for this batch, see _ConvKocFn.forward)
+            y_pre = self.__dict__.pop("_y_pre", None)
+            if y_pre is not None and (not torch.is_grad_enabled() or y_pre.shape[0] != x.shape[0]):
+                y_pre = None
+            return _ConvKocFn.apply(x.contiguous(), self.weight, self.bias, layer, u8_coef, getattr(self, "input_is_relu", False), y_pre)
         return _ConvFn.apply(x.contiguous(), self.weight, self.bias, layer, u8_coef)
 
 

@@ -769,7 +769,8 @@ def test_onpolicy_device_env_equals_host_emulators(dra, monkeypatch, kind):
     outs = []
     for device_env in (True, False):
         cfg = d.Config()
-        cfg.merge(dict(game="synthetic-atari", log_level=0, tag="dv%d" % device_env, device_env=device_env))
+        # (reuse_rollout_activations off: bit-identity with the host-emulator agent needs the update to recompute conv1-3 as that one does)
+        cfg.merge(dict(game="synthetic-atari", log_level=0, tag="dv%d" % device_env, device_env=device_env, reuse_rollout_activations=False))
         cfg.num_workers = 4
         cfg.task_fn = lambda: d.Task(cfg.game, num_envs=cfg.num_workers, seed=11, synthetic_done_period=13)
         cfg.eval_env = d.Task(cfg.game, seed=12)
@@ -861,7 +862,10 @@ def test_fused_rollout_launches_equal_the_module_path(dra, monkeypatch, kind, wo
     outs = []
     for fused in (True, False):
         cfg = d.Config()
-        cfg.merge(dict(game="synthetic-atari", log_level=0, tag="fr%d" % fused, device_env=True, fused_rollout=fused))
+        # (reuse_rollout_activations off: with it A2C's update takes the conv outputs of the rollout's eight-wave kernels instead of
+        # recomputing them with the four-wave shape -- another fp32 summation order; test_a2c_update_through_the_rollout_activations)
+        cfg.merge(dict(game="synthetic-atari", log_level=0, tag="fr%d" % fused, device_env=True, fused_rollout=fused,
+                       reuse_rollout_activations=False))
         cfg.num_workers = workers
         cfg.task_fn = lambda: d.Task(cfg.game, num_envs=cfg.num_workers, seed=11, synthetic_done_period=13)
         cfg.eval_env = d.Task(cfg.game, seed=12)
@@ -894,6 +898,70 @@ def test_fused_rollout_launches_equal_the_module_path(dra, monkeypatch, kind, wo
     assert len(np.unique(outs[0][1])) > 1
     for k in outs[0][0]:
         assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+
+
+@pytest.mark.parametrize("workers", [16, 5])
+def test_a2c_update_through_the_rollout_activations(dra, monkeypatch, workers):
+    """config.reuse_rollout_activations (round 6, default): A2C's update backpropagates through the conv outputs the ROLLOUT computed
+    (A2C_agent.py:29-64 keeps the rollout's own forward graph) instead of recomputing conv1-3 over the 80 stored observations.
+    Same inputs and parameters, but the rollout runs the eight-wave kernel shape and the recomputed forward the four-wave one
+    (another fp32 summation tree): from the same start the first update's flat GRADIENT agrees to 1e-5 of its largest magnitude,
+    the parameters after it to 1e-4 of each tensor's largest magnitude (RMSprop's first step divides by ~0.1 |g| + eps: an element
+    with |g| near eps turns a 1e-9 gradient difference into a 1e-7 step difference -- measured 1.4e-5 of scale on fc_action.weight),
+    and the rollout's actions / log-probabilities / stored activations are bit-identical (the rollout's kernels are the same)."""
+    d = dra
+    import deeprl_amd.agents as agents_mod
+    from deeprl_amd import ops
+    monkeypatch.setattr(agents_mod, "get_logger", lambda *a, **k: _Quiet())
+    outs = []
+    for reuse in (True, False):
+        cfg = d.Config()
+        cfg.merge(dict(game="synthetic-atari", log_level=0, tag="ra%d" % reuse, device_env=True, reuse_rollout_activations=reuse))
+        cfg.num_workers = workers
+        cfg.task_fn = lambda: d.Task(cfg.game, num_envs=cfg.num_workers, seed=11, synthetic_done_period=13)
+        cfg.eval_env = d.Task(cfg.game, seed=12)
+        cfg.network_fn = lambda: d.CategoricalActorCriticNet(cfg.state_dim, cfg.action_dim, d.NatureConvBody())
+        cfg.state_normalizer, cfg.reward_normalizer = d.ImageNormalizer(), d.SignNormalizer()
+        cfg.discount, cfg.use_gae, cfg.entropy_weight = 0.99, True, 0.01
+        cfg.optimizer_fn = lambda p: torch.optim.RMSprop(p, lr=1e-3, alpha=0.99, eps=1e-5)
+        cfg.gae_tau, cfg.rollout_length, cfg.gradient_clip = 1.0, 5, 5
+        d.random_seed(21)
+        torch.manual_seed(22)
+        agent = d.A2CAgent(cfg)
+        assert agent._pixel_rollout.eligible()
+        start = {k: v.detach().clone() for k, v in agent.network.state_dict().items()}
+        grads = []
+        agent.grad_hook = lambda g: grads.append(g.detach().clone())
+        agent.step()
+        torch.cuda.synchronize()
+        agent.grad_hook = None
+        bufs = agent._pixel_rollout.bufs
+        if reuse:       # the stored activations against a recomputed batched forward with the STARTING parameters
+            body = agent.network.phi_body
+            for conv in (body.conv1, body.conv2, body.conv3):
+                assert "_y_pre" not in conv.__dict__          # consumed by the update's forward
+        outs.append(({k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()},
+                     agent.network.rollout_slots.action.cpu().numpy().copy(), agent.network.rollout_slots.log_pi_a.cpu().numpy().copy(),
+                     {k: bufs[k].detach().cpu().numpy().copy() for k in ("y1", "y2", "y3")},
+                     {k: v.cpu().numpy() for k, v in start.items()}, grads[0].cpu().numpy().astype(np.float64)))
+        # a few more steps through the captured graph: finite, and the hand-over is consumed every time
+        for _ in range(4):
+            agent.step()
+        torch.cuda.synchronize()
+        assert all(np.isfinite(v.detach().cpu().numpy()).all() for v in agent.network.state_dict().values())
+        agent.close()
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    for k in ("y1", "y2", "y3"):        # the rollout's kernels are the same in both runs
+        assert np.array_equal(outs[0][3][k], outs[1][3][k]), k
+    moved = 0.0
+    for k in outs[0][0]:
+        a, b, s0 = outs[0][0][k].astype(np.float64), outs[1][0][k].astype(np.float64), outs[0][4][k].astype(np.float64)
+        scale = max(np.abs(b).max(), 1e-3)
+        assert np.abs(a - b).max() <= 1e-4 * scale, (k, np.abs(a - b).max() / scale)
+        moved = max(moved, np.abs(b - s0).max())
+    assert moved > 1e-4          # the update did something
+    ga, gb = outs[0][5], outs[1][5]
+    assert np.abs(gb).max() > 0 and np.abs(ga - gb).max() <= 1e-5 * np.abs(gb).max(), np.abs(ga - gb).max() / np.abs(gb).max()
 
 
 @pytest.mark.parametrize("kind", ["a2c", "ppo"])

@@ -145,6 +145,7 @@ CASES = {
     "qr_dqn_pixel_uniform_device": lambda: dqn_family("qr", d.UniformReplay, device=True),
     "a2c_pixel_16": lambda: a2c_pixel(16),                      # device-resident environments (the default)
     "a2c_pixel_16_host": lambda: a2c_pixel(16, device=False),   # host emulators
+    "a2c_pixel_16_recompute": lambda: a2c_pixel(16, reuse_rollout_activations=False),   # the update recomputes conv1-3 (rounds 2-5)
     "ppo_pixel_8": lambda: ppo_pixel(8),
     "a2c_pixel_16_nofc4head": lambda: a2c_pixel(16, fuse_fc4_head=False),      # fc4 finish / policy head as separate autograd nodes
     "ppo_pixel_8_nofc4head": lambda: ppo_pixel(8, fuse_fc4_head=False),
