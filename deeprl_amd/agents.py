@@ -1046,11 +1046,12 @@ class _PixelRollout:
             f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
             # (the activations of every step are kept: A2C's update backpropagates through them, as the reference does through the
             # rollout's own forward graph -- config.reuse_rollout_activations)
-            self.bufs = dict(n=n, rows=rows, y1=f(rows, n, 32, 20, 20), y2=f(rows, n, 64, 9, 9), y3=f(rows, n, 64, 7, 7), slabs=f(28, n, 512))
+            self.bufs = dict(n=n, rows=rows, y1=f(rows, n, 32, 20, 20), y2=f(rows, n, 64, 9, 9), y3=f(rows, n, 64, 7, 7), slabs=f(28, n, 512),
+                             phi=f(rows, n, 512))
             one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
             # (per-step pointer arguments built once: the rollout loop of PPO's 129 steps is host-side eager code)
             self.bufs['args'] = [(ctypes.c_void_p(self.bufs['y1'][t].data_ptr()), one(self.bufs['y1'][t]), one(self.bufs['y2'][t]),
-                                  one(self.bufs['y3'][t])) for t in range(rows)]
+                                  one(self.bufs['y3'][t]), ctypes.c_void_p(self.bufs['phi'][t].data_ptr())) for t in range(rows)]
         b = self.bufs
         p = lambda t: ctypes.c_void_p(t.data_ptr())
         arr = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
@@ -1064,13 +1065,15 @@ class _PixelRollout:
         b4, slabs = body.fc4.bias, b['slabs']
         for t in range(rows):
             prev = t > 0
-            y1p, x2, y2, y3 = b['args'][t]
+            y1p, x2, y2, y3, _ = b['args'][t]
             # fc4 of step t - 1 left its 28 K-slice partial sums: the head that rides in this launch folds them (bias, ReLU) first
-            lib.dra_rollout_conv1_heads(p(frames[t]), p(w1), p(body.conv1.bias), y1p, n, coef,
-                                        p(slabs) if prev else None, p(b4) if prev else None, p(wa), p(ba), p(wv), p(bv),
-                                        p(slots.uniform[t - 1]) if prev else None, n_act,
-                                        p(slots.action[t - 1]) if prev else None, p(slots.log_pi_a[t - 1]) if prev else None,
-                                        p(slots.entropy[t - 1]) if prev else None, p(slots.v[t - 1]) if prev else None, st)
+            # (and leaves the folded features of step t - 1 in phi[t - 1]: fc4's forward output, for A2C's update)
+            lib.dra_rollout_conv1_heads_phi(p(frames[t]), p(w1), p(body.conv1.bias), y1p, n, coef,
+                                            p(slabs) if prev else None, p(b4) if prev else None, p(wa), p(ba), p(wv), p(bv),
+                                            p(slots.uniform[t - 1]) if prev else None, n_act,
+                                            p(slots.action[t - 1]) if prev else None, p(slots.log_pi_a[t - 1]) if prev else None,
+                                            p(slots.entropy[t - 1]) if prev else None, p(slots.v[t - 1]) if prev else None,
+                                            b['args'][t - 1][4] if prev else None, st)
             lib.dra_conv_fwd_koc(2, 1, x2, wt2, b2, y2, n, 0, 1.0, ops.ACT["relu"], st)
             lib.dra_conv_fwd_koc(3, 1, y2, wt3, b3, y3, n, 0, 1.0, ops.ACT["relu"], st)
             lib.dra_linear_fwd_slabs_one(1, y3, w4, n, 3136, 512, 28, p(slabs), st)
@@ -1297,6 +1300,9 @@ class A2CAgent(BaseAgent):
                 for conv, key in ((body.conv1, 'y1'), (body.conv2, 'y2'), (body.conv3, 'y3')):
                     y = acts[key][:t_len]
                     conv._y_pre = y.reshape((t_len * n,) + tuple(y.shape[2:]))
+                # (and fc4's output: the folded features the rollout's head launches left -- the update's fc4 + head node runs the
+                # head launch alone)
+                self.network._phi_pre = acts['phi'][:t_len].reshape(t_len * n, 512)
             return self._learn_stacked(frames[:t_len].reshape((t_len * n,) + tuple(frames.shape[2:])),
                                        slots.action[:t_len].reshape(-1), slots.v[:t_len + 1].unsqueeze(-1), plan.reward,
                                        plan.mask, apply=apply)

@@ -1783,6 +1783,18 @@ DRA_API int dra_rollout_conv1_heads(const void* frames_u8, const float* wt1, con
                                     const float* phi_prev, const float* fold_bias, const float* w_a, const float* b_a,
                                     const float* w_v, const float* b_v, const float* uniform, int n_actions, int64_t* out_action,
                                     float* out_log_pi_a, float* out_entropy, float* out_v, void* stream) {
+  return dra_rollout_conv1_heads_phi(frames_u8, wt1, b1, y1, batch, u8_coef, phi_prev, fold_bias, w_a, b_a, w_v, b_v, uniform, n_actions,
+                                     out_action, out_log_pi_a, out_entropy, out_v, nullptr, stream);
+}
+
+// The same launch; out_phi != NULL (with fold_bias: phi_prev = fc4's 28 K-slice partial sums): the head's workgroups also leave the
+// folded features relu(sum of slices + bias) [batch][512] of the PREVIOUS step there -- what A2C's update needs of fc4's forward
+// when it backpropagates through the rollout's own activations (agents._PixelRollout, config.reuse_rollout_activations).
+DRA_API int dra_rollout_conv1_heads_phi(const void* frames_u8, const float* wt1, const float* b1, float* y1, int batch, double u8_coef,
+                                        const float* phi_prev, const float* fold_bias, const float* w_a, const float* b_a,
+                                        const float* w_v, const float* b_v, const float* uniform, int n_actions, int64_t* out_action,
+                                        float* out_log_pi_a, float* out_entropy, float* out_v, float* out_phi, void* stream) {
+  if (out_phi && !(phi_prev && fold_bias)) return DRA_EINVAL;
   if (!frames_u8 || !wt1 || !b1 || !y1 || batch < 1 || batch > 4096) return DRA_EINVAL;
   if (phi_prev && (!w_a || !w_v || !uniform || !out_action || !out_log_pi_a || !out_entropy || !out_v || n_actions < 1 ||
                    n_actions > 64))
@@ -1802,7 +1814,7 @@ DRA_API int dra_rollout_conv1_heads(const void* frames_u8, const float* wt1, con
     h.slabs = nullptr; h.fold_bias = nullptr; h.out_x = nullptr;
     head_wgs = (batch + 3) / 4;
     if (fold_bias) {      // phi_prev is [28][batch][512]: the K-slice partial sums of dra_linear_fwd_slabs_one(ksplit = 28)
-      h.x = nullptr; h.slabs = phi_prev; h.fold_bias = fold_bias;
+      h.x = nullptr; h.slabs = phi_prev; h.fold_bias = fold_bias; h.out_x = out_phi;
       head_wgs = batch;
     }
   }

@@ -244,8 +244,12 @@ class _Fc4PolicyHeadFn(torch.autograd.Function):
     _LinearFn followed by _PolicyHeadFn."""
 
     @staticmethod
-    def forward(ctx, y3, w4, b4, w0, b0, w1, b1, action):
-        lp, ent, v, logits, phi = ops.fc4_policy_heads_given(y3, w4, b4, w0, b0, w1, b1, action)
+    def forward(ctx, y3, w4, b4, w0, b0, w1, b1, action, phi_pre=None):
+        if phi_pre is not None:     # fc4's output for exactly these inputs and parameters, computed by the rollout (see _ConvKocFn.forward)
+            phi = phi_pre.view_as(phi_pre)
+            lp, ent, v, logits = ops.policy_heads_given(phi, w0, b0, w1, b1, action)
+        else:
+            lp, ent, v, logits, phi = ops.fc4_policy_heads_given(y3, w4, b4, w0, b0, w1, b1, action)
         ctx.save_for_backward(y3, w4, phi, w0, w1, logits, action)
         ctx.params = (w4, b4, w0, b0, w1, b1)
         return lp, ent, v
@@ -267,7 +271,7 @@ class _Fc4PolicyHeadFn(torch.autograd.Function):
         _mark_masked(dy3)
         if not ctx.needs_input_grad[0]:
             dy3 = None
-        return (dy3,) + ((None, None) if direct_4 else (dw4, db4)) + ((None,) * 4 if direct_h else (dw0, db0, dw1, db1)) + (None,)
+        return (dy3,) + ((None, None) if direct_4 else (dw4, db4)) + ((None,) * 4 if direct_h else (dw0, db0, dw1, db1)) + (None, None)
 
 
 class _CategoricalFn(torch.autograd.Function):
@@ -837,7 +841,7 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         self.rollout_slots = RolloutSlots()
         self.to(Config.DEVICE)
 
-    def _fc4_head_fused(self, obs, action):
+    def _fc4_head_fused(self, obs, action, phi_pre=None):
         """The update's forward over NatureConvBody with fc4 and the policy head as one autograd node (_Fc4PolicyHeadFn), or None
         when the network / batch is not that case."""
         body = self.phi_body
@@ -848,8 +852,11 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
         y = body.conv3(body.conv2(body.conv1(obs)))
         if not (y.dtype == torch.float32 and y.is_contiguous()):
             return None
+        if phi_pre is not None and (not torch.is_grad_enabled() or phi_pre.shape[0] != y.shape[0]):
+            phi_pre = None
         lp, ent, v = _Fc4PolicyHeadFn.apply(y.view(y.size(0), -1), body.fc4.weight, body.fc4.bias, self.fc_action.weight,
-                                            self.fc_action.bias, self.fc_critic.weight, self.fc_critic.bias, action.long().contiguous())
+                                            self.fc_action.bias, self.fc_critic.weight, self.fc_critic.bias, action.long().contiguous(),
+                                            phi_pre)
         return {'action': action, 'log_pi_a': lp.unsqueeze(-1), 'entropy': ent.unsqueeze(-1), 'v': v.unsqueeze(-1)}
 
     def _nature_heads_ok(self):
@@ -884,8 +891,10 @@ class CategoricalActorCriticNet(nn.Module, BaseNet):
 
     def forward(self, obs, action=None):
         obs = tensor(obs)
+        # (_phi_pre: set by A2CAgent for ONE call -- the rollout's fc4 output for this batch; only the fused fc4 + head node takes it)
+        phi_pre = self.__dict__.pop("_phi_pre", None)
         if action is not None:
-            out = self._fc4_head_fused(obs, action)
+            out = self._fc4_head_fused(obs, action, phi_pre)
             if out is not None:
                 return out
         else:

@@ -463,6 +463,13 @@ int dra_rollout_conv1_heads(const void* frames_u8, const float* wt1, const float
                             const float* phi_prev, const float* fold_bias, const float* w_a, const float* b_a, const float* w_v,
                             const float* b_v, const float* uniform, int n_actions, int64_t* out_action, float* out_log_pi_a,
                             float* out_entropy, float* out_v, void* stream);
+/* the same launch; out_phi != NULL (needs fold_bias): the head's workgroups also store the previous step's folded features
+ * relu(sum of the 28 slices + bias) [batch][512] -- fc4's forward output, kept for an A2C update that backpropagates through the
+ * rollout's own activations (A2C_agent.py:29-64) */
+int dra_rollout_conv1_heads_phi(const void* frames_u8, const float* wt1, const float* b1, float* y1, int batch, double u8_coef,
+                                const float* phi_prev, const float* fold_bias, const float* w_a, const float* b_a, const float* w_v,
+                                const float* b_v, const float* uniform, int n_actions, int64_t* out_action, float* out_log_pi_a,
+                                float* out_entropy, float* out_v, float* out_phi, void* stream);
 
 /* ---- fused DQN learner + device-resident actor: DQN_agent.py:24-45 (actor step), :114-138 (update) for
  * VanillaNet(NatureConvBody).  All five flat buffers are caller-owned f32[n_params] with the tensor order

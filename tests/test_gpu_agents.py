@@ -940,9 +940,10 @@ def test_a2c_update_through_the_rollout_activations(dra, monkeypatch, workers):
             body = agent.network.phi_body
             for conv in (body.conv1, body.conv2, body.conv3):
                 assert "_y_pre" not in conv.__dict__          # consumed by the update's forward
+            assert "_phi_pre" not in agent.network.__dict__    # (fc4's output too: the rollout's head launches leave it)
         outs.append(({k: v.detach().cpu().numpy().copy() for k, v in agent.network.state_dict().items()},
                      agent.network.rollout_slots.action.cpu().numpy().copy(), agent.network.rollout_slots.log_pi_a.cpu().numpy().copy(),
-                     {k: bufs[k].detach().cpu().numpy().copy() for k in ("y1", "y2", "y3")},
+                     {k: bufs[k].detach().cpu().numpy().copy() for k in ("y1", "y2", "y3", "phi")},
                      {k: v.cpu().numpy() for k, v in start.items()}, grads[0].cpu().numpy().astype(np.float64)))
         # a few more steps through the captured graph: finite, and the hand-over is consumed every time
         for _ in range(4):
@@ -951,8 +952,9 @@ def test_a2c_update_through_the_rollout_activations(dra, monkeypatch, workers):
         assert all(np.isfinite(v.detach().cpu().numpy()).all() for v in agent.network.state_dict().values())
         agent.close()
     assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
-    for k in ("y1", "y2", "y3"):        # the rollout's kernels are the same in both runs
-        assert np.array_equal(outs[0][3][k], outs[1][3][k]), k
+    for k in ("y1", "y2", "y3", "phi"):        # the rollout's kernels are the same in both runs
+        assert np.array_equal(outs[0][3][k][:5], outs[1][3][k][:5]), k
+    assert np.abs(outs[0][3]["phi"][:5]).max() > 0
     moved = 0.0
     for k in outs[0][0]:
         a, b, s0 = outs[0][0][k].astype(np.float64), outs[1][0][k].astype(np.float64), outs[0][4][k].astype(np.float64)
@@ -975,7 +977,10 @@ def test_fc4_and_policy_head_as_one_autograd_node(dra, monkeypatch, kind):
     outs = []
     for fuse in (True, False):
         cfg = d.Config()
-        cfg.merge(dict(game="synthetic-atari", log_level=0, tag="fh%d" % fuse, device_env=True, fuse_fc4_head=fuse))
+        # (reuse_rollout_activations off: with it the fused node takes fc4's output from the rollout's 28-slice fold, the unfused
+        # path recomputes it)
+        cfg.merge(dict(game="synthetic-atari", log_level=0, tag="fh%d" % fuse, device_env=True, fuse_fc4_head=fuse,
+                       reuse_rollout_activations=False))
         cfg.num_workers = 16 if kind == "a2c" else 8
         cfg.task_fn = lambda: d.Task(cfg.game, num_envs=cfg.num_workers, seed=11, synthetic_done_period=13)
         cfg.eval_env = d.Task(cfg.game, seed=12)
