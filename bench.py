@@ -489,7 +489,7 @@ def rocprof_kernel(kernel_group, flops):
            "conv3_fwd": "conv_fwd_v2_kernel<V2Geom<64, 9, 64, 3, 1>, false, 1, 4>", "fc4_fwd": "LinFwdSlabsOne<3136",
            "fc4_bwd_x": "multi_kernel<LinDgradOne<512>", "conv1_bwd_w": "multi_kernel<ConvWgradOne<ConvGeom<4, 84, 32, 8, 4>",
            "conv1_fwd": "conv_fwd_v2_kernel<V2Geom<4, 84, 32, 8, 4>, true, 1, 4>", "rmsprop_step": "late_step_kernel",
-           "grad_norm": "clip_step_kernel<0>", "conv_fwd_chain": "conv_fwd_chain_kernel(", "conv_bwd_chain": "bwd_chain_kernel("}.get(kernel_group)
+           "grad_norm": "clip_step_kernel<0>", "conv_fwd_chain": "conv_fwd_chain_kernel(", "conv_bwd_chain": "bwd_chain_kernel"}.get(kernel_group)     # (`bwd_chain_kernel<false>(` since DRA_VAR_BWD_CHAIN_FC made it a template)
     if not files or (not pat and kernel_group not in pats):
         return None
     try:
