@@ -21,9 +21,9 @@
 // 29, profiles/r06zzg_ab_dgrad_scatter.jsonl.)  The image has the layout of dX itself; the epilogue applies the activation
 // derivative and copies it out in float4s.
 //
-// Measured (profiles/r06zzk_*): input gradient alone 0.46 of the fp32-MFMA peak at batch 1024 (conv3; gather form 0.33), whole
-// backward launch 0.46-0.50 (0.41-0.45); a workgroup's life at one per CU = 3.7 us until its 147 KB of weights have arrived (all
-// CUs fetch at once: ~10 TB/s chip-wide), 3.1 us per tile (1.9 us of MFMA issue), 2-4 us epilogue.
+// Measured (profiles/r06zzl_*, r06zzn_conv_big.jsonl): input gradient alone 0.50 of the fp32-MFMA peak at batch 1024 (conv3; gather form
+// 0.33), whole backward launch 0.49-0.52 by rocprofv3 (0.43-0.44); a workgroup's life at one per CU = 3.7 us until its 147 KB of
+// weights have arrived (all CUs fetch at once: ~10 TB/s chip-wide), 2.9 us per tile (1.9 us of MFMA issue), 2-4 us epilogue.
 //
 // Arithmetic: per dX element the taps' partial sums (each an fp32 MFMA chain over the 64 output channels) are added in tap
 // order -- a different association than the gather form's one chain over (tap, oc), same products; the contraction tests compare
@@ -31,7 +31,7 @@
 #pragma once
 #include "oneshot_lin.h"
 #ifndef DRA_SCAT_PIPE
-#define DRA_SCAT_PIPE 1     // explicit MFMA / LDS interleave of the tile body (sched_group_barrier); 0 = the compiler's own order
+#define DRA_SCAT_PIPE 1     // explicit MFMA / LDS interleave of the tile body (sched_barrier between 8-MFMA chunks); 0 = the compiler's own order
 #endif
 
 typedef float scat_f4 __attribute__((ext_vector_type(4)));
