@@ -247,3 +247,100 @@ def test_round4_small_kernel_maps():
         assert [j for j in jobs if j[0] == "dx"] == [("dx", b) for b in range(B)]
         assert sorted(j for j in jobs if j[0] == "dw0") == [("dw0", o, h) for o in range(O0) for h in (0, 1)]
         assert sorted(j for j in jobs if j[0] == "dw1") == [("dw1", o, h) for o in range(O1) for h in (0, 1)]
+
+
+def test_scatter_input_gradient_maps():
+    """csrc/dgrad_scatter.h (round 6), transcribed lane by lane for conv3 (NS = 1, 2) and conv2 (NS = 1): the weight / gradient
+    operand maps (A row m <-> channel 16 cb + (m >> 2) + 4 (m & 3); step j = 4 v + e of lane group kq <-> oc = 16 v + 4 kq + e),
+    the image address of every (lane, output register, tap), and the dump area of lanes past the last position.  Checked:
+      * the determinism argument -- within ONE tap's read-add-write the 64 lanes x 4 registers of a wave touch distinct LDS words,
+        and two different waves of a workgroup never touch the same word at all;
+      * dump addresses stay inside [IMG, LDS_FLOATS) and never alias an image word;
+      * MFMA semantics over these maps + the col2im reproduce F.conv2d's input gradient in float64 (incl. a last workgroup with
+        fewer samples and a last tile with idle lanes)."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+
+    def geom(c, h, oc, kh, s):
+        oh = (h - kh) // s + 1
+        return dict(C=c, H=h, OC=oc, KH=kh, S=s, OH=oh, P=oh * oh, HW=h * h)
+
+    for (c, h, oc, kh, s), ns, batch in (((64, 9, 64, 3, 1), 2, 3), ((64, 9, 64, 3, 1), 1, 2), ((32, 20, 64, 4, 2), 1, 2)):
+        g = geom(c, h, oc, kh, s)
+        C, H, OC, KH, S, OH, P, HW = (g[k] for k in ("C", "H", "OC", "KH", "S", "OH", "P", "HW"))
+        NCB, KST = C // 16, OC // 4
+        NPS = 4 // NCB
+        KHN = KH // NPS
+        NTAP = KHN * KH
+        HWP = HW if HW & 1 else HW + 1
+        IMG = ns * C * HWP
+        ROWF = KH * OC
+        WREG = 16 * (ROWF + 4)
+        DUMP = 64 + 12 * HWP + (KH - 1) * (H + 1) + 4
+        LDS_FLOATS = (max(IMG + DUMP, 4 * WREG) + 3) & ~3
+        assert LDS_FLOATS * 4 <= 160 * 1024
+        rs = np.random.RandomState(c + ns)
+        w = rs.standard_normal((oc, c, kh, kh))
+        dy = rs.standard_normal((batch, oc, OH, OH))
+        wt = np.ascontiguousarray(w.transpose(1, 2, 3, 0)).reshape(c * kh * kh, oc)       # [(c,kh,kw)][oc]
+        xt = torch.zeros((batch, c, h, h), dtype=torch.float64, requires_grad=True)
+        F.conv2d(xt, torch.from_numpy(w), None, stride=s).backward(torch.from_numpy(dy))
+        want = xt.grad.numpy()
+        got = np.zeros_like(want)
+        n_groups = (batch + ns - 1) // ns
+        for grp in range(n_groups):
+            b0 = grp * ns
+            nsmp = min(ns, batch - b0)
+            nq = nsmp * P
+            lds = np.zeros(LDS_FLOATS)
+            owner = np.full(LDS_FLOATS, -1)          # which wave touched an image word
+            for wave in range(4):
+                cb, ps = wave % NCB, wave // NCB
+                lanes = np.arange(64)
+                n, kq = lanes & 15, lanes >> 4
+                # A operand: a[t][j] of lane (n, kq)
+                ch_a = 16 * cb + (n >> 2) + 4 * (n & 3)
+                tiles = (nq + 15) // 16
+                for tile in range(tiles):
+                    q = tile * 16 + n
+                    ok = q < nq
+                    qc = np.minimum(q, nq - 1)
+                    smp, p = qc // P, qc % P
+                    ohh, oww = p // OH, p % OH
+                    ao = np.where(ok, (smp * C + 16 * cb + kq) * HWP + (ohh * S + ps) * H + oww * S, IMG + lanes)
+                    for t in range(NTAP):
+                        kh_, kw_ = ps + NPS * (t // KH), t % KH
+                        # the 16 x 16 x 4 MFMA chain of this tap: D[row][col] = sum_k A[row][k] B[k][col]; lane (col = n, 4 kq + r rows)
+                        acc = np.zeros((64, 4))
+                        for j in range(KST):
+                            ocs = 16 * (j >> 2) + 4 * np.arange(4) + (j & 3)          # oc of lane group kq = 0..3 in step j
+                            A = np.zeros((16, 4))                                       # [row m][k = kq]
+                            for m in range(16):
+                                chm = 16 * cb + (m >> 2) + 4 * (m & 3)
+                                A[m] = wt[(chm * KH + kh_) * KH + kw_, ocs]
+                            B = np.zeros((4, 16))                                       # [k = kq][col n]
+                            for col in range(16):
+                                lane0 = col                                             # lanes (col, kq) share position col
+                                if tile * 16 + col < nq:
+                                    B[:, col] = dy[b0 + smp[lane0], ocs, ohh[lane0], oww[lane0]]
+                            D = A @ B
+                            for r in range(4):
+                                acc[:, r] += D[4 * kq + r, n]
+                        off = NPS * (t // KH) * H + (t % KH)
+                        addr = ao[:, None] + 4 * np.arange(4)[None, :] * HWP + off      # [lane][r]
+                        assert len(np.unique(addr)) == 256, "one tap's read-add-write: 64 lanes x 4 registers, distinct words"
+                        img = addr[ok]
+                        assert img.size == 0 or (img.min() >= 0 and img.max() < IMG)
+                        dump = addr[~ok]
+                        assert dump.size == 0 or (dump.min() >= IMG and dump.max() < LDS_FLOATS)
+                        assert np.all((owner[img] == -1) | (owner[img] == wave)), "two waves never share an image word"
+                        owner[img] = wave
+                        lds[addr] += acc
+                        # output register r of lane group kq is channel 16 cb + kq + 4 r = the channel of A row 4 kq + r
+                        assert np.array_equal(ch_a[(4 * kq[:, None] + np.arange(4)[None, :])], 16 * cb + kq[:, None] + 4 * np.arange(4)[None, :])
+            for si in range(nsmp):
+                for ch in range(C):
+                    base = (si * C + ch) * HWP
+                    got[b0 + si, ch] = lds[base:base + HW].reshape(H, H)
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-10)
