@@ -157,6 +157,9 @@ static int conv_bwd_scatter_t(const float* dy, const void* x, const float* wt, c
   auto rw = make_wgrad_one<WOne>(dy, x, dw, db, slab_stride, batch, 1.0);
   if (only_d) return launch_multi(alone, alone.blocks(), none, 0, none, 0, st);
   if (only_w) return launch_multi_tp(rw, rw.blocks(), none, 0, none, 0, st);
+#if defined(DRA_EXP_SCAT_WGRAD_FIRST) && DRA_EXP_SCAT_WGRAD_FIRST
+  if (variant & DRA_VAR_FUSED_BWD) return launch_multi(rw, rw.blocks(), rs, rs.blocks(), none, 0, st);     // (A/B build: weight gradient first)
+#endif
   if (variant & DRA_VAR_FUSED_BWD) return launch_multi(rs, rs.blocks(), rw, rw.blocks(), none, 0, st);
   if (int rc = launch_multi_tp(rw, rw.blocks(), none, 0, none, 0, st)) return rc;
   return launch_multi(alone, alone.blocks(), none, 0, none, 0, st);
