@@ -48,7 +48,11 @@ struct ConvDgradScat {
   static constexpr int KST = OC / 4;           // MFMA steps per tap; in step j = 4 v + e lane group kq multiplies oc = 16 v + 4 kq + e:
                                                // a weight float4 load (fixed v) reads 64 contiguous bytes per channel
   static constexpr int TG = (NTAP % 3 == 0) ? 3 : ((NTAP % 4 == 0) ? 4 : 1);   // taps whose accumulation chains interleave
-  static constexpr int HWP = (HW & 1) ? HW : HW + 1;                            // channel stride of the LDS image: odd (bank spread)
+#ifndef DRA_SCAT_HWPAD
+#define DRA_SCAT_HWPAD 4    // even HW: channel stride HW + 4 (float4 rows for the epilogue; HW + 1 spreads the read-add-write's banks
+                            // better -- 2-way instead of 4-way conflicts -- but forces scalar LDS reads + an index division there)
+#endif
+  static constexpr int HWP = (HW & 1) ? HW : HW + DRA_SCAT_HWPAD;              // channel stride of the LDS image
   static constexpr int IMG = NS * C * HWP;
   static constexpr int ROWF = KH * OC, ROW4 = ROWF / 4;        // one contiguous (channel, kh) weight row: floats, float4s
   static constexpr int RPT = 16 * ROW4 / 64;                   // float4s per lane of one kh row of a wave's 16 channels
@@ -243,7 +247,8 @@ struct ConvDgradScat {
         else {
           const int e = 4 * e4, ch = e / HW, pix = e - ch * HW;
           const float* src = lds + ch * HWP + pix;
-          v = scat_f4{src[0], src[1], src[2], src[3]};
+          if constexpr (HWP % 4 == 0) v = *reinterpret_cast<const scat_f4*>(src);
+          else v = scat_f4{src[0], src[1], src[2], src[3]};
         }
         if (xact) v = scat_f4{v.x * act_grad(y[i].x, act), v.y * act_grad(y[i].y, act), v.z * act_grad(y[i].z, act), v.w * act_grad(y[i].w, act)};
         dx4[e4] = v;

@@ -273,7 +273,7 @@ def test_scatter_input_gradient_maps():
         NPS = 4 // NCB
         KHN = KH // NPS
         NTAP = KHN * KH
-        HWP = HW if HW & 1 else HW + 1
+        HWP = HW if HW & 1 else HW + 4          # (DRA_SCAT_HWPAD: float4 rows for the epilogue)
         IMG = ns * C * HWP
         ROWF = KH * OC
         WREG = 16 * (ROWF + 4)
