@@ -70,7 +70,7 @@ struct ConvDgradScat {
   float* dx;          // [B][C][H][H]
   int B, act;
   int cap = 0;        // > 0: at most `cap` workgroups, each looping over groups of NS samples (weights fetched once per workgroup);
-                      // set when the role has a launch to itself (two workgroups per CU fit: 512)
+                      // set when the role has a launch to itself (two workgroups per CU fit: 2 x the CU count)
   __host__ int groups() const { return (B + NS - 1) / NS; }
   __host__ int blocks() const { return LOOP && cap > 0 && groups() > cap ? cap : groups(); }
   __device__ __forceinline__ void run(int bid, float* __restrict__ lds, int = 0) const {

@@ -131,6 +131,17 @@ static IgemmRole<ConvDgradKoc<G, 32, 32, 64>> make_dgrad_igemm(const float* dy, 
 template <class R>
 static int igemm_blocks(const R& r, int nz) { return r.tiles * r.ksplit * nz; }
 
+// compute units of the current device (asked once per process: one GPU per process; MI355X's 256 assumed if the question fails)
+static int scatter_cu_count() {
+  static int n_cu = 0;
+  if (n_cu <= 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    n_cu = n;
+  }
+  return n_cu;
+}
+
 // DRA_VAR_DGRAD_SCATTER: weight gradient (persistent form from PersistFrom<G>::batch on, else one sample per workgroup) + the
 // scatter-form input gradient with NS samples per workgroup; one launch with DRA_VAR_FUSED_BWD, else two
 template <class G, class WOne, class WPers, int NS>
@@ -140,9 +151,9 @@ static int conv_bwd_scatter_t(const float* dy, const void* x, const float* wt, c
   using RS = ConvDgradScat<G, NS>;
   RS rs;
   rs.dy = dy; rs.wt = wt; rs.xact = xact; rs.dx = dx; rs.B = batch; rs.act = act;
-  ConvDgradScat<G, NS, true> alone;      // a launch to itself: two workgroups per CU, each looping over its groups with the weights in registers
+  ConvDgradScat<G, NS, true> alone;      // a launch to itself: two workgroups per CU (its register footprint), each looping over its groups with the weights kept
   alone.dy = dy; alone.wt = wt; alone.xact = xact; alone.dx = dx; alone.B = batch; alone.act = act;
-  alone.cap = 512;
+  alone.cap = 2 * scatter_cu_count();
   const bool only_d = variant & DRA_VAR_MEASURE_DGRAD_ONLY, only_w = variant & DRA_VAR_MEASURE_WGRAD_ONLY;
   if (batch >= PersistFrom<G>::batch) {
     WPers rp;
